@@ -1,0 +1,182 @@
+"""Deterministic synthetic tied-state triphone sets + utterances.
+
+The generator follows the random-draw ORDER of the survey's scratch generator, so the known
+answers recorded there (e.g. `-6.124135e+01` for the first utterance of the 1k x 8 set, seed 1)
+apply to the files written here.  It writes the files the reference tools read (text MMF, HTK
+parameter files, label files, SCP, hmmlist, config, dict) and returns the same content as flat
+numpy arrays in the packed layout of include/htk_amd.h, so one call feeds both the reference
+(oracle/_ref) and the HIP path.
+
+Nothing here is on the product path: it is workload/test tooling.
+"""
+from __future__ import annotations
+
+import os
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+LZERO = -1.0e10
+PK_MFCC_E_D_A = 6 | 0o100 | 0o400 | 0o1000  # HParm.h parameter-kind bits: MFCC + _E + _D + _A
+
+# transition matrix of the synthetic sets; linear probabilities as in an MMF
+TRANSP_5 = np.array(
+    [[0, 1, 0, 0, 0],
+     [0, 0.6, 0.4, 0, 0],
+     [0, 0, 0.6, 0.4, 0],
+     [0, 0, 0, 0.7, 0.3],
+     [0, 0, 0, 0, 0]], dtype=np.float32)
+
+
+@dataclass
+class SynthSet:
+    D: int
+    NS: int          # tied states
+    M: int           # mixtures per state
+    NP: int          # physical models
+    means: np.ndarray   # [NS, M, D] f32
+    var: np.ndarray     # [NS, M, D] f32
+    w: np.ndarray       # [NS, M] f32 (linear)
+    st: np.ndarray      # [NP, 3] tied-state index of emitting states 2..4
+    seqs: list = field(default_factory=list)    # per utterance: int array of model indices
+    feats: list = field(default_factory=list)   # per utterance: [T, D] f32
+    outdir: str | None = None
+
+    # ---- packed layout (include/htk_amd.h: htkamd_model_desc) ----
+    def packed(self) -> dict:
+        G = self.NS * self.M
+        tp = TRANSP_5.astype(np.float64)
+        with np.errstate(divide="ignore"):
+            logt = np.where(tp > 0, np.log(tp), LZERO).astype(np.float32)  # HModel.c:2003 GetTransMat
+        return dict(
+            vecSize=self.D,
+            numStates=self.NS,
+            numComp=G,
+            numGauss=G,
+            stateCompOff=(np.arange(self.NS + 1) * self.M).astype(np.int32),
+            compWeight=self.w.reshape(G).astype(np.float32),
+            compGauss=np.arange(G, dtype=np.int32),
+            mean=np.ascontiguousarray(self.means.reshape(G, self.D)),
+            var=np.ascontiguousarray(self.var.reshape(G, self.D)),
+            gconst=None,                      # no <GCONST> in the file: library applies FixDiagGConst
+            numTrans=1,
+            transN=np.array([5], np.int32),
+            transOff=np.array([0, 25], np.int32),
+            transP=logt.reshape(-1),
+            numPhys=self.NP,
+            hmmTrans=np.zeros(self.NP, np.int32),
+            hmmStateOff=(np.arange(self.NP + 1) * 3).astype(np.int32),
+            hmmState=self.st.reshape(-1).astype(np.int32),
+        )
+
+
+def _vec(v) -> str:
+    return " " + " ".join("%e" % x for x in v)
+
+
+def write_mmf(path: str, s: SynthSet, kind: str = "MFCC_E_D_A") -> None:
+    D, M = s.D, s.M
+    with open(path, "w") as f:
+        f.write("~o\n<STREAMINFO> 1 %d\n<VECSIZE> %d<NULLD><%s><DIAGC>\n" % (D, D, kind))
+        f.write('~t "T1"\n<TRANSP> 5\n 0 1 0 0 0\n 0 0.6 0.4 0 0\n 0 0 0.6 0.4 0\n 0 0 0 0.7 0.3\n 0 0 0 0 0\n')
+        for i in range(s.NS):
+            f.write('~s "S%d"\n' % i)
+            if M > 1:
+                f.write("<NUMMIXES> %d\n" % M)
+            for m in range(M):
+                if M > 1:
+                    f.write("<MIXTURE> %d %e\n" % (m + 1, s.w[i, m]))
+                f.write("<MEAN> %d\n%s\n<VARIANCE> %d\n%s\n" % (D, _vec(s.means[i, m]), D, _vec(s.var[i, m])))
+        for p in range(s.NP):
+            f.write('~h "p%d"\n<BEGINHMM>\n<NUMSTATES> 5\n' % p)
+            for j in range(3):
+                f.write('<STATE> %d\n~s "S%d"\n' % (j + 2, s.st[p, j]))
+            f.write('~t "T1"\n<ENDHMM>\n')
+
+
+def write_htk_param(path: str, X: np.ndarray, samp_period: int = 100000, kind: int = PK_MFCC_E_D_A) -> None:
+    """HTK parameter file: 12-byte big-endian header + BE float32 rows (HTKBook speechio.tex:835-950)."""
+    T, D = X.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack(">iihh", T, samp_period, D * 4, kind))
+        f.write(np.ascontiguousarray(X, dtype=">f4").tobytes())
+
+
+def read_htk_param(path: str):
+    with open(path, "rb") as f:
+        n, period, size, kind = struct.unpack(">iihh", f.read(12))
+        X = np.frombuffer(f.read(n * size), dtype=">f4").reshape(n, size // 4).astype(np.float32)
+    return X, period, kind
+
+
+def round_to_mmf_precision(a: np.ndarray) -> np.ndarray:
+    """The text MMF carries '%e' (7 significant digits); the reference therefore sees
+    float(strtod('%e' % x)), not x.  Apply the same round trip so the packed arrays equal
+    what LoadHMMSet produces bit for bit."""
+    flat = a.reshape(-1)
+    out = np.array([float("%e" % x) for x in flat], dtype=np.float64).astype(np.float32)
+    return out.reshape(a.shape)
+
+
+def generate(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39,
+             outdir: str | None = None, write_data: bool = True) -> SynthSet:
+    """SURVEY.md Appendix F generator (same draw order).  If outdir is given the reference-format
+    files are written there: hmm0/MMF, hmmlist, data/u%05d.mfc, lab/u%05d.lab, train.scp, config, dict."""
+    rng = np.random.default_rng(seed)
+    means = rng.normal(0, 3, size=(NS, M, D)).astype(np.float32)
+    var = rng.uniform(0.5, 2.0, size=(NS, M, D)).astype(np.float32)
+    w = rng.dirichlet(np.ones(M) * 5, size=NS).astype(np.float32)
+    st = rng.integers(0, NS, size=(NP, 3))
+    flat = st.reshape(-1)
+    k = min(NS, flat.size)
+    flat[:k] = rng.permutation(NS)[:k]          # every tied state used at least once
+    st = flat.reshape(NP, 3)
+
+    # what the reference will actually hold after reading the text MMF
+    s = SynthSet(D=D, NS=NS, M=M, NP=NP,
+                 means=round_to_mmf_precision(means), var=round_to_mmf_precision(var),
+                 w=round_to_mmf_precision(w), st=st.astype(np.int32), outdir=outdir)
+    if outdir:
+        for d in ("data", "lab", "hmm0", "hmm1"):
+            os.makedirs(os.path.join(outdir, d), exist_ok=True)
+        raw = SynthSet(D=D, NS=NS, M=M, NP=NP, means=means, var=var, w=w, st=st)
+        write_mmf(os.path.join(outdir, "hmm0", "MMF"), raw)
+        with open(os.path.join(outdir, "hmmlist"), "w") as f:
+            for p in range(NP):
+                f.write("p%d\n" % p)
+        with open(os.path.join(outdir, "dict"), "w") as f:
+            for p in range(NP):
+                f.write("p%d p%d\n" % (p, p))
+        with open(os.path.join(outdir, "config"), "w") as f:
+            f.write("TARGETKIND = MFCC_E_D_A\nBINARYACCFORMAT = T\n")
+        scp = open(os.path.join(outdir, "train.scp"), "w")
+
+    for u in range(NU):
+        Q = max(1, T // 12)
+        seq = rng.integers(0, NP, size=Q)
+        fr = []
+        per = T // Q
+        for q, p in enumerate(seq):
+            n = per if q < Q - 1 else T - per * (Q - 1)
+            for j in range(3):
+                nj = n // 3 if j < 2 else n - 2 * (n // 3)
+                si = st[p, j]
+                ms = rng.integers(0, M, size=nj)
+                # frames are sampled from the UNROUNDED parameters, exactly as the survey generator did
+                fr.append(means[si, ms] + rng.normal(0, 1, size=(nj, D)).astype(np.float32) * np.sqrt(var[si, ms]))
+        X = np.concatenate(fr).astype(np.float32)
+        assert X.shape[0] == T
+        s.seqs.append(seq.astype(np.int32))
+        s.feats.append(X)
+        if outdir:
+            fn = "%s/data/u%05d.mfc" % (outdir, u)
+            if write_data:
+                write_htk_param(fn, X)
+                with open("%s/lab/u%05d.lab" % (outdir, u), "w") as f:
+                    for p in seq:
+                        f.write("p%d\n" % p)
+            scp.write(fn + "\n")
+    if outdir:
+        scp.close()
+    return s

@@ -1,0 +1,130 @@
+/* htk_oracle.h -- CPU restatement of the reference HTK hot path (TEST INFRASTRUCTURE).
+ *
+ * This is the parity ORACLE: plain C that follows the reference's arithmetic (types, operation
+ * order, thresholds) for the HERest / HVite hot path, each function citing the reference
+ * file:line it restates.  It is pinned against the reference itself (oracle/_ref built from
+ * /root/reference by oracle/Makefile; see tests/test_oracle_vs_ref.py and tests/golden/).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (htk_amd/, include/) never links, imports or calls it.
+ *
+ * Indexing: model arrays are 0-based; HMM states keep the reference's numbering 1..N
+ * (1 = entry, N = exit) so that formulas read like the reference.
+ */
+#ifndef HTK_ORACLE_H
+#define HTK_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_LZERO   (-1.0E10)    /* HMath.h:42 */
+#define ORC_LSMALL  (-0.5E10)    /* HMath.h:43 */
+#define ORC_MINEARG (-708.3)     /* HMath.h:44 */
+#define ORC_MINLARG 2.45E-308    /* HMath.h:45 */
+#define ORC_TPI     6.28318530717959   /* HMath.h:41 (truncated literal, as in the reference) */
+#define ORC_PI      3.14159265358979   /* HMath.h:40 */
+#define ORC_MINMIX  1.0E-5       /* HModel.h:52 */
+#define ORC_LMINMIX (-11.5129254649702) /* HModel.h:53 */
+#define ORC_NOPRUNE 1.0E20       /* HFB.h:31 */
+
+/* update flags, HTrain.h / HModel.h UPDSet bits actually used on the path */
+#define ORC_UPMEANS 1
+#define ORC_UPVARS  2
+#define ORC_UPTRANS 4
+#define ORC_UPMIXES 8
+
+typedef struct {
+   int D;                     /* vecSize */
+   int S;                     /* tied states (StateInfo with sIdx)        */
+   int C;                     /* mixture components = sum_s nMix(s)       */
+   int G;                     /* distinct Gaussians (MixPDF with mIdx)    */
+   int nT;                    /* transition matrices                       */
+   int H;                     /* physical HMMs                             */
+   const int   *stateCompOff; /* [S+1] components of state s               */
+   const float *compLogWt;    /* [C] MixLogWeight() value (HModel.c:5288)  */
+   const int   *compGauss;    /* [C] Gaussian index of component           */
+   const float *mean;         /* [G*D]                                     */
+   const float *ivar;         /* [G*D] after ConvDiagC (HUtil.c:413)       */
+   const float *gconst;       /* [G]   DIAGC gConst (HModel.c:5641)        */
+   const int   *transN;       /* [nT] states per matrix                    */
+   const int   *transOff;     /* [nT+1] offset of matrix t in transP       */
+   const float *transP;       /* log probs row-major N*N, LZERO = none     */
+   const int   *hmmTrans;     /* [H]                                       */
+   const int   *hmmStateOff;  /* [H+1]                                     */
+   const int   *hmmState;     /* tied-state index of emitting states 2..N-1*/
+} orc_model;
+
+typedef struct {              /* float accumulators exactly as HTrain.h:211-232 */
+   float *mu;                 /* [G*D] MuAcc.mu   */
+   float *muOcc;              /* [G]   MuAcc.occ  */
+   float *va;                 /* [G*D] VaAcc.cov.var */
+   float *vaOcc;              /* [G]   VaAcc.occ  */
+   float *wt;                 /* [C]   WtAcc.c    */
+   float *wtOcc;              /* [S]   WtAcc.occ  */
+   float *tr;                 /* [transOff[nT]] TrAcc.tran */
+   float *trOcc;              /* [sum_t N_t] TrAcc.occ, matrix t at sum_{k<t} N_k */
+   int   *nEgs;               /* [H] hmm->hook example counter (HFB.c:1768-1772) */
+} orc_accs;
+
+typedef struct {
+   double pruneInit, pruneInc, pruneLim;   /* HFB.c:76-83 pruneSetting */
+   float  minFrwdP;
+   int    uFlags;
+} orc_fbcfg;
+
+typedef struct {              /* optional dumps; any pointer may be NULL */
+   double *beta;              /* [T*Q*maxN] NaN where the reference holds NULL */
+   double *alpha;             /* [T*Q*maxN] alphat column after step t          */
+   float  *outp;              /* [T*Q*maxN] state output prob, NaN if not evaluated */
+   int    *qLo, *qHi;         /* [T] final beta beam                            */
+   int    *aLo, *aHi;         /* [T] alpha beam                                  */
+   float  *occ;               /* [T*Q*maxN] occt                                 */
+   long long nEval;           /* number of (t, chain state) output-prob evaluations (Setotprob) */
+} orc_fbdump;
+
+/* ---- log arithmetic (HMath.c:1576) ---- */
+double orc_ladd(double x, double y);
+
+/* ---- model preparation ---- */
+void  orc_fix_diag_gconst(int D, const float *var, float *gconst_out);      /* HModel.c:5641 */
+void  orc_conv_diagc(int n, const float *var, float *ivar_out);              /* HUtil.c:413   */
+float orc_mix_log_weight(float w);                                           /* HModel.c:5288 */
+int   orc_min_dur(int N, const float *transP);                               /* HFB.c:106     */
+
+/* ---- GMM scoring ---- */
+float orc_idoutp(const float *x, int D, const float *mean, const float *ivar, float gconst); /* HModel.c:5420 */
+/* ShStrP (HFB.c:898) == cSOutP (HRec.c:438) arithmetic: returns state log-lik, fills mixp[0..M-1]
+   (LZERO for skipped components) when mixp != NULL */
+float orc_state_outp(const orc_model *m, int s, const float *x, float *mixp);
+/* SOutP arithmetic (HModel.c:5503): double accumulation, one float rounding */
+float orc_soutp(const orc_model *m, int s, const float *x);
+/* dense block: out[t*ns + k] = orc_state_outp(states[k], X[t]) */
+void  orc_score_block(const orc_model *m, const float *X, int T, const int *states, int ns, float *out);
+
+/* ---- forward-backward for one utterance (FBFile, HFB.c:1923) ---- */
+/* returns 1 on success (stats accumulated, *pr set), 0 if the utterance is skipped (-7324),
+   <0 on the reference's fatal errors (-7332 tee-model placement, -7390 alpha prune failure) */
+int orc_fb_utt(const orc_model *m, const orc_fbcfg *cfg, const float *X, int T,
+               const int *labs, int Q, orc_accs *acc, double *pr, orc_fbdump *dump);
+
+/* ---- model update (HERest.c:1262 MLUpdateModels) on packed arrays, in place ---- */
+typedef struct {
+   int   minEgs;              /* HERest.c:96 default 3 */
+   float minVar;              /* -v, HERest.c:95 default 0.0 */
+   float mixWeightFloor;      /* -w f  => f*MINMIX, HERest.c:425 */
+   int   uFlags;
+} orc_updcfg;
+typedef struct {
+   int nFloorVar, nFloorVarMix;  /* HERest.c:791-792 */
+   int nSkippedHmm;              /* models with < minEgs examples */
+} orc_updstats;
+void orc_update(const orc_model *m, const orc_accs *acc, const orc_updcfg *cfg,
+                float *mean /*[G*D] in/out*/, float *var /*[G*D] DIAGC in/out*/,
+                float *gconst /*[G] in/out*/, float *compWeight /*[C] linear in/out*/,
+                float *transP /*in/out (log)*/, orc_updstats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""ctypes binding of the CPU oracle (oracle/htk_oracle.c) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(BUILD, "libhtk_oracle.so")
+SRCS = ["htk_oracle.c", "orc_viterbi.c", "orc_mfcc.c"]
+
+LZERO = -1.0e10
+LSMALL = -0.5e10
+UPMEANS, UPVARS, UPTRANS, UPMIXES = 1, 2, 4, 8
+UPALL = 15
+NOPRUNE = 1.0e20
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
+    deps = srcs + [os.path.join(HERE, "htk_oracle.h")]
+    if (not force) and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return LIB
+    os.makedirs(BUILD, exist_ok=True)
+    # no FMA contraction, no fast-math: the reference is SSE2 scalar float
+    cmd = ["gcc", "-O2", "-std=gnu99", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB] + srcs + ["-lm"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_ladd.restype = C.c_double
+        _lib.orc_ladd.argtypes = [C.c_double, C.c_double]
+        _lib.orc_mix_log_weight.restype = C.c_float
+        _lib.orc_mix_log_weight.argtypes = [C.c_float]
+        _lib.orc_idoutp.restype = C.c_float
+        _lib.orc_state_outp.restype = C.c_float
+        _lib.orc_soutp.restype = C.c_float
+        _lib.orc_min_dur.restype = C.c_int
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CModel(C.Structure):
+    _fields_ = [("D", C.c_int), ("S", C.c_int), ("C", C.c_int), ("G", C.c_int), ("nT", C.c_int), ("H", C.c_int),
+                ("stateCompOff", C.c_void_p), ("compLogWt", C.c_void_p), ("compGauss", C.c_void_p),
+                ("mean", C.c_void_p), ("ivar", C.c_void_p), ("gconst", C.c_void_p),
+                ("transN", C.c_void_p), ("transOff", C.c_void_p), ("transP", C.c_void_p),
+                ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p)]
+
+
+class CAccs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs")]
+
+
+class CFbCfg(C.Structure):
+    _fields_ = [("pruneInit", C.c_double), ("pruneInc", C.c_double), ("pruneLim", C.c_double),
+                ("minFrwdP", C.c_float), ("uFlags", C.c_int)]
+
+
+class CFbDump(C.Structure):
+    _fields_ = [("beta", C.c_void_p), ("alpha", C.c_void_p), ("outp", C.c_void_p),
+                ("qLo", C.c_void_p), ("qHi", C.c_void_p), ("aLo", C.c_void_p), ("aHi", C.c_void_p),
+                ("occ", C.c_void_p), ("nEval", C.c_longlong)]
+
+
+class CUpdCfg(C.Structure):
+    _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int)]
+
+
+class CUpdStats(C.Structure):
+    _fields_ = [("nFloorVar", C.c_int), ("nFloorVarMix", C.c_int), ("nSkippedHmm", C.c_int)]
+
+
+class Model:
+    """Packed model (same field names as include/htk_amd.h) prepared the way HERest/HVite prepare an HMMSet:
+    FixDiagGConst if no gconst (HModel.c:206-208), ConvDiagC (HUtil.c:413), ConvLogWt (HUtil.c:474)."""
+
+    def __init__(self, pk: dict):
+        L = lib()
+        self.pk = pk
+        self.D = int(pk["vecSize"]); self.S = int(pk["numStates"]); self.C = int(pk["numComp"])
+        self.G = int(pk["numGauss"]); self.nT = int(pk["numTrans"]); self.H = int(pk["numPhys"])
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self.stateCompOff = i32(pk["stateCompOff"]); self.compWeight = f32(pk["compWeight"]).copy()
+        self.compGauss = i32(pk["compGauss"]); self.mean = f32(pk["mean"]).reshape(self.G, self.D).copy()
+        self.var = f32(pk["var"]).reshape(self.G, self.D).copy()
+        self.transN = i32(pk["transN"]); self.transOff = i32(pk["transOff"]); self.transP = f32(pk["transP"]).copy()
+        self.hmmTrans = i32(pk["hmmTrans"]); self.hmmStateOff = i32(pk["hmmStateOff"]); self.hmmState = i32(pk["hmmState"])
+        if pk.get("gconst") is None:
+            self.gconst = np.empty(self.G, np.float32)
+            for g in range(self.G):
+                L.orc_fix_diag_gconst(C.c_int(self.D), _p(self.var[g]), C.c_void_p(self.gconst.ctypes.data + 4 * g))
+        else:
+            self.gconst = f32(pk["gconst"]).copy()
+        self.refresh()
+
+    def refresh(self):
+        """Recompute the derived arrays (ivar, log weights) after the parameters changed."""
+        L = lib()
+        self.ivar = np.empty_like(self.var)
+        L.orc_conv_diagc(C.c_int(self.G * self.D), _p(self.var), _p(self.ivar))
+        self.compLogWt = np.array([L.orc_mix_log_weight(C.c_float(w)) for w in self.compWeight], np.float32)
+        self.c = CModel(self.D, self.S, self.C, self.G, self.nT, self.H,
+                        _p(self.stateCompOff), _p(self.compLogWt), _p(self.compGauss),
+                        _p(self.mean), _p(self.ivar), _p(self.gconst),
+                        _p(self.transN), _p(self.transOff), _p(self.transP),
+                        _p(self.hmmTrans), _p(self.hmmStateOff), _p(self.hmmState))
+
+    @property
+    def maxN(self):
+        return int(self.transN.max())
+
+    def state_outp(self, s: int, x: np.ndarray, want_mix=False):
+        x = np.ascontiguousarray(x, np.float32)
+        M = int(self.stateCompOff[s + 1] - self.stateCompOff[s])
+        mix = np.empty(M, np.float32) if want_mix else None
+        v = lib().orc_state_outp(C.byref(self.c), C.c_int(s), _p(x), _p(mix))
+        return (v, mix) if want_mix else v
+
+    def soutp(self, s: int, x: np.ndarray):
+        x = np.ascontiguousarray(x, np.float32)
+        return lib().orc_soutp(C.byref(self.c), C.c_int(s), _p(x))
+
+    def score_block(self, X: np.ndarray, states: np.ndarray) -> np.ndarray:
+        X = np.ascontiguousarray(X, np.float32); states = np.ascontiguousarray(states, np.int32)
+        out = np.empty((X.shape[0], len(states)), np.float32)
+        lib().orc_score_block(C.byref(self.c), _p(X), C.c_int(X.shape[0]), _p(states), C.c_int(len(states)), _p(out))
+        return out
+
+
+class Accs:
+    def __init__(self, m: Model):
+        self.m = m
+        self.mu = np.zeros((m.G, m.D), np.float32); self.muOcc = np.zeros(m.G, np.float32)
+        self.va = np.zeros((m.G, m.D), np.float32); self.vaOcc = np.zeros(m.G, np.float32)
+        self.wt = np.zeros(m.C, np.float32); self.wtOcc = np.zeros(m.S, np.float32)
+        self.tr = np.zeros(int(m.transOff[-1]), np.float32); self.trOcc = np.zeros(int(m.transN.sum()), np.float32)
+        self.nEgs = np.zeros(m.H, np.int32)
+        self.c = CAccs(*[_p(getattr(self, n)) for n in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs")])
+
+
+def fb_cfg(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, uFlags=UPALL):
+    return CFbCfg(pruneInit, pruneInc, pruneLim, minFrwdP, uFlags)
+
+
+def fb_utt(m: Model, cfg: CFbCfg, X: np.ndarray, labs: np.ndarray, acc: Accs, dump: bool = False):
+    """FBFile (HFB.c:1923) for one utterance.  Returns (rc, pr, dumpdict|None)."""
+    X = np.ascontiguousarray(X, np.float32); labs = np.ascontiguousarray(labs, np.int32)
+    T, Q = X.shape[0], len(labs)
+    pr = C.c_double(0.0)
+    d = None; cd = None
+    if dump:
+        maxN = m.maxN
+        d = dict(beta=np.empty((T, Q, maxN)), alpha=np.empty((T, Q, maxN)),
+                 outp=np.empty((T, Q, maxN), np.float32), occ=np.empty((T, Q, maxN), np.float32),
+                 qLo=np.zeros(T, np.int32), qHi=np.zeros(T, np.int32), aLo=np.zeros(T, np.int32), aHi=np.zeros(T, np.int32))
+        cd = CFbDump(_p(d["beta"]), _p(d["alpha"]), _p(d["outp"]), _p(d["qLo"]), _p(d["qHi"]),
+                     _p(d["aLo"]), _p(d["aHi"]), _p(d["occ"]), 0)
+    rc = lib().orc_fb_utt(C.byref(m.c), C.byref(cfg), _p(X), C.c_int(T), _p(labs), C.c_int(Q),
+                          C.byref(acc.c), C.byref(pr), C.byref(cd) if cd is not None else None)
+    if d is not None:
+        d["nEval"] = cd.nEval
+    return rc, pr.value, d
+
+
+def update(m: Model, acc: Accs, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL):
+    """MLUpdateModels (HERest.c:1262) in place on m.mean / m.var / m.gconst / m.compWeight / m.transP."""
+    cfg = CUpdCfg(minEgs, minVar, mixWeightFloor, uFlags)
+    st = CUpdStats()
+    lib().orc_update(C.byref(m.c), C.byref(acc.c), C.byref(cfg), _p(m.mean), _p(m.var), _p(m.gconst),
+                     _p(m.compWeight), _p(m.transP), C.byref(st))
+    m.refresh()
+    return dict(nFloorVar=st.nFloorVar, nFloorVarMix=st.nFloorVarMix, nSkippedHmm=st.nSkippedHmm)
