@@ -1,0 +1,63 @@
+"""Build libhtk_amd.so (HIP kernels for gfx950 + host C) in-tree.
+
+    python -m htk_amd.build          # or __graft_entry__.build()
+
+hipcc cross-compiles gfx950 without a GPU.  Host C is compiled by gcc as C, kernels and launchers by
+hipcc; everything is linked into ONE shared object next to this file so that it travels with the tree.
+FMA contraction is off everywhere: the exact-order kernels must round like the reference's SSE2 code.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libhtk_amd.so")
+HIP_SRCS = ["csrc/model.hip", "csrc/gmm_exact.hip", "csrc/fb_kernels.hip", "csrc/fb.hip"]
+C_SRCS = ["host/prep.c"]
+HEADERS = ["csrc/internal.h", "csrc/kernels.h", "csrc/hipcheck.h", "../include/htk_amd.h"]
+ARCH = "gfx950"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in HIP_SRCS + C_SRCS:
+        p = os.path.join(HERE, src)
+        if not os.path.exists(p):
+            continue
+        o = os.path.join(OBJ, os.path.basename(src) + ".o")
+        objs.append(o)
+        if force or _newer(o, [p] + hdrs):
+            if src.endswith(".hip"):
+                cmd = ["hipcc", "--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+                       "-Wall", "-Wno-unused-function", "-c", p, "-o", o]
+            else:
+                cmd = ["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-Wall", "-c", p, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("build failed: " + " ".join(cmd))
+    if force or procs or _newer(LIB, objs):
+        cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

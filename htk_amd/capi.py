@@ -1,0 +1,273 @@
+"""ctypes binding of libhtk_amd.so (the C ABI of include/htk_amd.h) plus thin Python holders.
+
+This is the host-side mirror used by the tests, bench.py and the Python drivers.  It contains no
+numerics: every score, trellis and statistic comes from the HIP kernels behind the C ABI, and the
+import fails loudly when the shared object is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "libhtk_amd.so")
+
+LZERO = -1.0e10
+LSMALL = -0.5e10
+NOPRUNE = 1.0e20
+UPMEANS, UPVARS, UPTRANS, UPMIXES = 1, 2, 4, 8
+UPALL = 15
+UTT_OK, UTT_SKIPPED, UTT_ETEE, UTT_EALPHA = 1, 0, -7332, -7390
+
+
+class HtkAmdError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("vecSize", C.c_int), ("numStates", C.c_int), ("numComp", C.c_int), ("numGauss", C.c_int),
+                ("numTrans", C.c_int), ("numPhys", C.c_int),
+                ("stateCompOff", C.c_void_p), ("compWeight", C.c_void_p), ("compGauss", C.c_void_p),
+                ("mean", C.c_void_p), ("var", C.c_void_p), ("gconst", C.c_void_p),
+                ("transN", C.c_void_p), ("transOff", C.c_void_p), ("transP", C.c_void_p),
+                ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p)]
+
+
+class AccsLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs",
+                                         "totalPr", "totalT", "nUttDone", "nUttSkipped", "nEval", "total")]
+
+
+class FbConfig(C.Structure):
+    _fields_ = [("pruneInit", C.c_double), ("pruneInc", C.c_double), ("pruneLim", C.c_double),
+                ("minFrwdP", C.c_float), ("uFlags", C.c_int)]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("nUtt", C.c_int), ("dX", C.c_void_p), ("frameOff", C.c_void_p), ("labOff", C.c_void_p), ("labs", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the native library.  There is deliberately no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise HtkAmdError("%s is missing: run `python -m htk_amd.build` (hipcc --offload-arch=gfx950)" % LIBPATH)
+        L = C.CDLL(LIBPATH)
+        L.htkamd_last_error.restype = C.c_char_p
+        L.htkamd_fb_frame_states.restype = C.c_longlong
+        L.htkamd_fb_frame_states.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise HtkAmdError("%s failed (%d): %s" % (what, rc, lib().htkamd_last_error().decode()))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DevArray:
+    """A device buffer owned through the C ABI (hipMalloc)."""
+
+    def __init__(self, host: np.ndarray | None = None, nbytes: int | None = None):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(host.nbytes if host is not None else nbytes)
+        check(lib().htkamd_dev_malloc(C.byref(self.ptr), C.c_size_t(self.nbytes)), "dev_malloc")
+        if host is not None:
+            h = np.ascontiguousarray(host)
+            check(lib().htkamd_memcpy_h2d(self.ptr, _p(h), C.c_size_t(h.nbytes), None), "memcpy_h2d")
+
+    def to_host(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().htkamd_memcpy_d2h(_p(out), self.ptr, C.c_size_t(out.nbytes), None), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().htkamd_dev_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Model:
+    """htkamd_model holder.  `pk` is the packed layout dict (htk_amd.synth.SynthSet.packed() / the MMF loader)."""
+
+    def __init__(self, pk: dict):
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        self.pk = pk
+        self._keep = dict(stateCompOff=i32(pk["stateCompOff"]), compWeight=f32(pk["compWeight"]), compGauss=i32(pk["compGauss"]),
+                          mean=f32(pk["mean"]), var=f32(pk["var"]), gconst=f32(pk.get("gconst")),
+                          transN=i32(pk["transN"]), transOff=i32(pk["transOff"]), transP=f32(pk["transP"]),
+                          hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]))
+        k = self._keep
+        d = ModelDesc(int(pk["vecSize"]), int(pk["numStates"]), int(pk["numComp"]), int(pk["numGauss"]),
+                      int(pk["numTrans"]), int(pk["numPhys"]),
+                      _p(k["stateCompOff"]), _p(k["compWeight"]), _p(k["compGauss"]), _p(k["mean"]), _p(k["var"]), _p(k["gconst"]),
+                      _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]))
+        self.h = C.c_void_p()
+        check(lib().htkamd_model_create(C.byref(d), C.byref(self.h)), "model_create")
+        self.D, self.S, self.C, self.G = d.vecSize, d.numStates, d.numComp, d.numGauss
+        self.nT, self.H = d.numTrans, d.numPhys
+        self.maxN = int(np.max(k["transN"]))
+
+    def set_params(self, mean=None, var=None, gconst=None, compWeight=None, transP=None):
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        args = [f32(mean), f32(var), f32(gconst), f32(compWeight), f32(transP)]
+        check(lib().htkamd_model_set_params(self.h, *[_p(a) for a in args]), "model_set_params")
+
+    def get_prepared(self):
+        ivar = np.empty((self.G, self.D), np.float32); gc = np.empty(self.G, np.float32)
+        lw = np.empty(self.C, np.float32); md = np.empty(self.nT, np.int32)
+        check(lib().htkamd_model_get_prepared(self.h, _p(ivar), _p(gc), _p(lw), _p(md)), "model_get_prepared")
+        return dict(ivar=ivar, gconst=gc, compLogWt=lw, minDur=md)
+
+    def outp_block(self, X: np.ndarray, states: np.ndarray) -> np.ndarray:
+        """Scores [T, ns] of the listed tied states (HIP kernel K1), returned frame-major for convenience."""
+        X = np.ascontiguousarray(X, np.float32); states = np.ascontiguousarray(states, np.int32)
+        T, ns = X.shape[0], len(states)
+        if T == 0 or ns == 0:
+            return np.empty((T, ns), np.float32)
+        dX, dS = DevArray(X), DevArray(states)
+        dO = DevArray(nbytes=4 * T * ns)
+        check(lib().htkamd_outp_block(self.h, dX.ptr, C.c_int(T), dS.ptr, C.c_int(ns), dO.ptr, C.c_int(T), None), "outp_block")
+        out = dO.to_host(np.float32, (ns, T))
+        return np.ascontiguousarray(out.T)
+
+    def close(self):
+        if self.h:
+            lib().htkamd_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Accs:
+    def __init__(self, model: Model):
+        self.model = model
+        self.h = C.c_void_p()
+        check(lib().htkamd_accs_create(model.h, C.byref(self.h)), "accs_create")
+        self.lay = AccsLayout()
+        check(lib().htkamd_accs_get_layout(self.h, C.byref(self.lay)), "accs_get_layout")
+
+    def zero(self, stream=None):
+        check(lib().htkamd_accs_zero(self.h, stream), "accs_zero")
+
+    def device_vector(self):
+        p = C.c_void_p(); n = C.c_size_t()
+        check(lib().htkamd_accs_device_vector(self.h, C.byref(p), C.byref(n)), "accs_device_vector")
+        return p.value, n.value
+
+    def download(self) -> dict:
+        v = np.empty(self.lay.total, np.float64)
+        check(lib().htkamd_accs_download(self.h, _p(v), None), "accs_download")
+        return self.split(v)
+
+    def upload_add(self, vec: np.ndarray):
+        vec = np.ascontiguousarray(vec, np.float64)
+        assert vec.size == self.lay.total
+        check(lib().htkamd_accs_upload_add(self.h, _p(vec), None), "accs_upload_add")
+
+    def split(self, v: np.ndarray) -> dict:
+        m, L = self.model, self.lay
+        GD = m.G * m.D
+        return dict(vec=v, mu=v[L.mu:L.mu + GD].reshape(m.G, m.D), muOcc=v[L.muOcc:L.muOcc + m.G],
+                    va=v[L.va:L.va + GD].reshape(m.G, m.D), vaOcc=v[L.vaOcc:L.vaOcc + m.G],
+                    wt=v[L.wt:L.wt + m.C], wtOcc=v[L.wtOcc:L.wtOcc + m.S], tr=v[L.tr:L.trOcc], trOcc=v[L.trOcc:L.nEgs],
+                    nEgs=v[L.nEgs:L.nEgs + m.H], totalPr=v[L.totalPr], totalT=v[L.totalT], nUttDone=v[L.nUttDone],
+                    nUttSkipped=v[L.nUttSkipped], nEval=v[L.nEval])
+
+    def close(self):
+        if self.h:
+            lib().htkamd_accs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, uFlags=UPALL):
+    return FbConfig(pruneInit, pruneInc, pruneLim, minFrwdP, uFlags)
+
+
+class ForwardBackward:
+    """htkamd_fb holder: FBFile (HFB.c:1923) over a batch of utterances."""
+
+    def __init__(self, model: Model, debug: bool = False):
+        self.model = model
+        self.h = C.c_void_p()
+        check(lib().htkamd_fb_create(model.h, C.byref(self.h)), "fb_create")
+        if debug:
+            check(lib().htkamd_fb_set_debug(self.h, 1), "fb_set_debug")
+        self.nUtt = 0
+        self._keep = None
+
+    def prepare(self, dX_ptr: int, frameOff: np.ndarray, labOff: np.ndarray, labs: np.ndarray, stream=None):
+        frameOff = np.ascontiguousarray(frameOff, np.int32); labOff = np.ascontiguousarray(labOff, np.int32)
+        labs = np.ascontiguousarray(labs, np.int32)
+        self.nUtt = len(frameOff) - 1
+        self._keep = (frameOff, labOff, labs)
+        b = BatchDesc(self.nUtt, C.c_void_p(dX_ptr), _p(frameOff), _p(labOff), _p(labs))
+        check(lib().htkamd_fb_prepare(self.h, C.byref(b), stream), "fb_prepare")
+
+    def execute(self, cfg: FbConfig, accs: Accs, stream=None):
+        check(lib().htkamd_fb_execute(self.h, C.byref(cfg), accs.h, stream), "fb_execute")
+
+    def results(self, stream=None):
+        pr = np.empty(self.nUtt, np.float64); st = np.empty(self.nUtt, np.int32)
+        check(lib().htkamd_fb_results(self.h, _p(pr), _p(st), stream), "fb_results")
+        return pr, st
+
+    def frame_states(self) -> int:
+        return int(lib().htkamd_fb_frame_states(self.h))
+
+    def kernel_times(self):
+        t = (C.c_double * 4)()
+        check(lib().htkamd_fb_kernel_times(self.h, t), "fb_kernel_times")
+        return list(t)
+
+    def trellis(self, u: int, want_alpha: bool = True):
+        T = C.c_int(); Q = C.c_int(); mN = C.c_int()
+        check(lib().htkamd_fb_get_trellis(self.h, C.c_int(u), None, None, None, None, None, None, None,
+                                          C.byref(T), C.byref(Q), C.byref(mN), None), "fb_get_trellis")
+        T, Q, mN = T.value, Q.value, mN.value
+        d = dict(beta=np.empty((T, Q, mN)), alpha=np.empty((T, Q, mN)) if want_alpha else None,
+                 outp=np.empty((T, Q, mN), np.float32), qLo=np.zeros(T, np.int32), qHi=np.zeros(T, np.int32),
+                 aLo=np.zeros(T, np.int32), aHi=np.zeros(T, np.int32))
+        check(lib().htkamd_fb_get_trellis(self.h, C.c_int(u), _p(d["beta"]), _p(d["alpha"]), _p(d["outp"]),
+                                          _p(d["qLo"]), _p(d["qHi"]), _p(d["aLo"]), _p(d["aHi"]), None, None, None, None),
+              "fb_get_trellis")
+        return d
+
+    def close(self):
+        if self.h:
+            lib().htkamd_fb_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,355 @@
+// fb.hip -- host side of the batched forward-backward (FBFile replacement): chain tables,
+// workspace, launches of K1..K4, result collection.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+
+struct DevBuf {
+   void *p = nullptr;
+   size_t cap = 0;
+   int reserve(size_t bytes)
+   {
+      if (bytes <= cap) return HTKAMD_OK;
+      if (p) (void)hipFree(p);
+      p = nullptr; cap = 0;
+      size_t want = bytes + bytes / 8;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) { htkamd_set_error("fb: hipMalloc(%zu bytes): %s", want, hipGetErrorString(e)); return HTKAMD_ENOMEM; }
+      cap = want;
+      return HTKAMD_OK;
+   }
+   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct htkamd_fb {
+   htkamd_model *m;
+   int nUtt;
+   int debug;
+   // host tables of the prepared batch
+   std::vector<UttDesc> utt;
+   std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
+   std::vector<short> cQ, cI, taperLo, taperHi;
+   std::vector<ScoreTask> tasks;
+   std::vector<size_t> gamOff;
+   size_t outpTotal, betaTotal, gamTotal;
+   int totalFrames, nCellsMax, QMax, blockDim;
+   long long frameStates;
+   const float *dX;
+   // device
+   DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
+   DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
+   DevBuf d_transOff, d_trOccOff;
+   hipEvent_t ev[5];
+   bool evValid, timed;
+};
+
+extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
+{
+   if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
+   if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
+   htkamd_fb *fb = new htkamd_fb();
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->evValid = false; fb->timed = false;
+   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr;
+   for (int i = 0; i < 5; i++) {
+      hipError_t e = hipEventCreate(&fb->ev[i]);
+      if (e != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate: %s", hipGetErrorString(e)); delete fb; return HTKAMD_EHIP; }
+   }
+   fb->evValid = true;
+   int rc;
+   if ((rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { delete fb; return rc; }
+   HIPCHECK(hipMemcpy(fb->d_transOff.p, m->h_transOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice));
+   HIPCHECK(hipMemcpy(fb->d_trOccOff.p, m->h_trOccOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice));
+   *out = fb;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
+{
+   if (!fb) return;
+   DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
+                    &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
+                    &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
+                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff};
+   for (DevBuf *b : all) b->release();
+   if (fb->evValid) for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]);
+   delete fb;
+}
+
+extern "C" int htkamd_fb_set_debug(htkamd_fb *fb, int on)
+{
+   if (!fb) { htkamd_set_error("fb_set_debug: NULL"); return HTKAMD_EINVAL; }
+   fb->debug = on;
+   return HTKAMD_OK;
+}
+
+template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
+{
+   int rc = b.reserve(sizeof(T) * (v.size() ? v.size() : 1));
+   if (rc) return rc;
+   if (!v.empty()) HIPCHECK(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s));
+   return HTKAMD_OK;
+}
+
+// CreateInsts (HFB.c:508-574) + SetBeamTaper (HFB.c:1116-1145) for every utterance of the batch,
+// and the flat tables the kernels index.
+extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void *stream)
+{
+   if (!fb || !b || b->nUtt < 0 || (b->nUtt > 0 && (!b->dX || !b->frameOff || !b->labOff || !b->labs))) {
+      htkamd_set_error("fb_prepare: bad argument"); return HTKAMD_EINVAL;
+   }
+   const htkamd_model *m = fb->m;
+   hipStream_t s = (hipStream_t)stream;
+   const int U = b->nUtt;
+   fb->nUtt = U; fb->dX = b->dX;
+   fb->utt.assign(U, UttDesc());
+   fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
+   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear();
+   fb->totalFrames = U ? b->frameOff[U] : 0;
+   fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
+   fb->gamOff.assign(U + 1, 0);
+   fb->nCellsMax = 1; fb->QMax = 1;
+   fb->frameStates = 0;
+   size_t outp = 0, beta = 0, gam = 0;
+   for (int u = 0; u < U; u++) {
+      UttDesc &d = fb->utt[u];
+      const int T = b->frameOff[u + 1] - b->frameOff[u], Q = b->labOff[u + 1] - b->labOff[u];
+      const int *labs = b->labs + b->labOff[u];
+      d.T = T; d.Q = Q; d.frame0 = b->frameOff[u];
+      d.q0 = (int)fb->mN.size(); d.cell0 = (int)fb->cQ.size(); d.slot0 = (int)fb->slotState.size();
+      d.status = HTKAMD_UTT_OK; d.nEval = 0;
+      d.outp0 = outp; d.beta0 = beta; d.gam0 = gam;
+      fb->gamOff[u] = gam;
+      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nCells = d.nSlots = 0; continue; }
+      int nCells = 0, nSlots = 0, qt = 0, prevDm = 1;
+      for (int q = 1; q <= Q; q++) {
+         const int h = labs[q - 1];
+         if (h < 0 || h >= m->H) { htkamd_set_error("fb_prepare: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
+         const int ti = m->h_hmmTrans[h], N = m->h_transN[ti], dm = m->h_minDur[ti];
+         fb->mN.push_back(N); fb->mTp.push_back(m->h_transOff[ti]); fb->mCell0.push_back(nCells); fb->mSlot0.push_back(nSlots);
+         fb->mDms.push_back(dm); fb->mHmm.push_back(h); fb->mTrans.push_back(ti);
+         for (int i = 1; i <= N; i++) { fb->cQ.push_back((short)q); fb->cI.push_back((short)i); }
+         for (int j = 2; j < N; j++) fb->slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]);
+         nCells += N; nSlots += N - 2; qt += dm;
+         if (q > 1 && dm == 0 && prevDm == 0) d.status = HTKAMD_UTT_ETEE;      // successive tee models (HFB.c:557)
+         prevDm = dm;
+      }
+      if (fb->mDms[d.q0] == 0 || fb->mDms[d.q0 + Q - 1] == 0) d.status = HTKAMD_UTT_ETEE;   // HFB.c:564
+      if (d.status == HTKAMD_UTT_OK && qt > T) d.status = HTKAMD_UTT_SKIPPED;                 // HFB.c:1339
+      d.nCells = nCells; d.nSlots = nSlots;
+      if (Q > 32000 || nCells > 1024) {
+         htkamd_set_error("fb_prepare: utterance %d has %d model states; the device path handles up to 1024 per utterance", u, nCells);
+         return HTKAMD_EINVAL;
+      }
+      if (nCells > fb->nCellsMax) fb->nCellsMax = nCells;
+      if (Q > fb->QMax) fb->QMax = Q;
+      outp += (size_t)T * nSlots; beta += (size_t)T * nCells; gam += (size_t)T * nSlots;
+      if (d.status != HTKAMD_UTT_OK) continue;
+      // SetBeamTaper
+      short *lo = fb->taperLo.data() + d.frame0 - 1, *hi = fb->taperHi.data() + d.frame0 - 1;
+      const int *dms = fb->mDms.data() + d.q0 - 1;                         // 1-based q
+      {
+         int q = 1, dq = dms[q], i = 0;
+         for (int t = 1; t <= T; t++) {
+            while (i == dq) { i = 0; if (q < Q) { q++; dq = dms[q]; } else dq = -1; }
+            hi[t] = (short)q; i++;
+         }
+         q = Q; dq = dms[q]; i = 0;
+         for (int t = T; t >= 1; t--) {
+            while (i == dq) { i = 0; if (q > 1) { q--; dq = dms[q]; } else dq = -1; }
+            lo[t] = (short)q; i++;
+         }
+      }
+      // output-probability evaluations of the un-pruned pass (Setotprob ranges, HFB.c:1177,1215 + 1014)
+      {
+         const long long before = fb->frameStates;
+         int qHiN = Q, qLoN = lo[T];
+         const int *msl = fb->mSlot0.data() + d.q0 - 1;
+         auto slotsIn = [&](int a, int z) { return (z < Q ? msl[z + 1] : nSlots) - msl[a]; };
+         fb->frameStates += slotsIn(qLoN > 1 ? qLoN - 1 : 1, Q);
+         for (int t = T - 1; t >= 1; t--) {
+            const int startq = qHiN;
+            int endq = (qLoN == 1) ? 1 : ((lo[t] >= qLoN) ? lo[t] : qLoN - 1);
+            while (endq > 1 && dms[endq - 1] == 0) endq--;
+            fb->frameStates += slotsIn(endq > 1 ? endq - 1 : 1, startq);
+            qHiN = (hi[t] < startq) ? hi[t] : startq; qLoN = endq;
+         }
+         d.nEval = (int)(fb->frameStates - before);
+      }
+      // scoring tasks: tiles of frames x chunks of chain states
+      for (int t0 = 0; t0 < T; t0 += SCORE_TILE_FRAMES)
+         for (int k0 = 0; k0 < nSlots; k0 += SCORE_TASK_SLOTS) {
+            ScoreTask tk;
+            tk.frame0 = d.frame0 + t0;
+            tk.nFrames = (T - t0 < SCORE_TILE_FRAMES) ? T - t0 : SCORE_TILE_FRAMES;
+            tk.slot0 = d.slot0 + k0;
+            tk.nSlots = (nSlots - k0 < SCORE_TASK_SLOTS) ? nSlots - k0 : SCORE_TASK_SLOTS;
+            tk.outSlot0 = k0; tk.ldo = T;
+            tk.outBase = d.outp0 + (size_t)t0;
+            fb->tasks.push_back(tk);
+         }
+   }
+   fb->gamOff[U] = gam;
+   fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
+   fb->blockDim = ((fb->nCellsMax + 63) / 64) * 64;
+   if (fb->blockDim < 64) fb->blockDim = 64;
+
+   int rc;
+   if ((rc = upload(fb->d_utt, fb->utt, s)) || (rc = upload(fb->d_mN, fb->mN, s)) || (rc = upload(fb->d_mTp, fb->mTp, s)) ||
+       (rc = upload(fb->d_mCell0, fb->mCell0, s)) || (rc = upload(fb->d_mSlot0, fb->mSlot0, s)) || (rc = upload(fb->d_mDms, fb->mDms, s)) ||
+       (rc = upload(fb->d_mHmm, fb->mHmm, s)) || (rc = upload(fb->d_mTrans, fb->mTrans, s)) || (rc = upload(fb->d_slotState, fb->slotState, s)) ||
+       (rc = upload(fb->d_cQ, fb->cQ, s)) || (rc = upload(fb->d_cI, fb->cI, s)) || (rc = upload(fb->d_taperLo, fb->taperLo, s)) ||
+       (rc = upload(fb->d_taperHi, fb->taperHi, s)) || (rc = upload(fb->d_tasks, fb->tasks, s)) || (rc = upload(fb->d_gamOff, fb->gamOff, s)))
+      return rc;
+   const size_t nf = fb->totalFrames ? fb->totalFrames : 1;
+   if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
+       (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
+       (rc = fb->d_outp.reserve(sizeof(float) * (outp ? outp : 1))) || (rc = fb->d_beta.reserve(sizeof(double) * (beta ? beta : 1))) ||
+       (rc = fb->d_gam.reserve(sizeof(double) * (gam ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
+       (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))))
+      return rc;
+   if (fb->debug && (rc = fb->d_alpha.reserve(sizeof(double) * (beta ? beta : 1)))) return rc;
+   // the source vectors must outlive the async copies
+   HIPCHECK(hipStreamSynchronize(s));
+   return HTKAMD_OK;
+}
+
+extern "C" long long htkamd_fb_frame_states(const htkamd_fb *fb) { return fb ? fb->frameStates : 0; }
+
+extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream)
+{
+   if (!fb || !cfg || !accs) { htkamd_set_error("fb_execute: NULL argument"); return HTKAMD_EINVAL; }
+   if (accs->m != fb->m) { htkamd_set_error("fb_execute: accumulators belong to a different model"); return HTKAMD_EINVAL; }
+   if (fb->nUtt == 0) return HTKAMD_OK;
+   const htkamd_model *m = fb->m;
+   hipStream_t s = (hipStream_t)stream;
+
+   ScoreArgs sa;
+   sa.tasks = (const ScoreTask *)fb->d_tasks.p; sa.nTasks = (int)fb->tasks.size(); sa.X = fb->dX;
+   sa.slotState = (const int *)fb->d_slotState.p; sa.out = (float *)fb->d_outp.p;
+   sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
+   sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
+
+   FbArgs fa;
+   memset(&fa, 0, sizeof(fa));
+   fa.utt = (const UttDesc *)fb->d_utt.p; fa.nUtt = fb->nUtt;
+   fa.mN = (const int *)fb->d_mN.p; fa.mTp = (const int *)fb->d_mTp.p; fa.mCell0 = (const int *)fb->d_mCell0.p;
+   fa.mSlot0 = (const int *)fb->d_mSlot0.p; fa.mDms = (const int *)fb->d_mDms.p; fa.mHmm = (const int *)fb->d_mHmm.p;
+   fa.mTrans = (const int *)fb->d_mTrans.p;
+   fa.cQ = (const short *)fb->d_cQ.p; fa.cI = (const short *)fb->d_cI.p; fa.slotState = (const int *)fb->d_slotState.p;
+   fa.taperLo = (const short *)fb->d_taperLo.p; fa.taperHi = (const short *)fb->d_taperHi.p;
+   fa.qLo = (short *)fb->d_qLo.p; fa.qHi = (short *)fb->d_qHi.p; fa.aLo = (short *)fb->d_aLo.p; fa.aHi = (short *)fb->d_aHi.p;
+   fa.X = fb->dX; fa.transP = m->d_transP; fa.outp = (float *)fb->d_outp.p;
+   fa.beta = (double *)fb->d_beta.p; fa.gam = (double *)fb->d_gam.p; fa.alphaDbg = fb->debug ? (double *)fb->d_alpha.p : nullptr;
+   fa.pr = (double *)fb->d_pr.p; fa.status = (int *)fb->d_status.p;
+   fa.stateCompOff = m->d_stateCompOff; fa.compGauss = m->d_compGauss;
+   fa.transOff = (const int *)fb->d_transOff.p; fa.trOccOff = (const int *)fb->d_trOccOff.p;
+   fa.compLogWt = m->d_compLogWt; fa.gparam = m->d_gparam; fa.mean = m->d_mean;
+   fa.PS = m->PS; fa.D = m->D; fa.maxN = m->maxN; fa.maxM = m->maxM;
+   fa.nCellsMax = fb->blockDim; fa.QMax = fb->QMax;
+   fa.acc = accs->d_vec; fa.lay = accs->lay;
+   fa.pruneInit = cfg->pruneInit; fa.pruneInc = cfg->pruneInc; fa.pruneLim = cfg->pruneLim;
+   fa.minLogExp = m->minLogExp; fa.minFrwdP = cfg->minFrwdP; fa.uFlags = cfg->uFlags;
+   fa.gamTotal = fb->gamTotal; fa.gamOffByUtt = (const size_t *)fb->d_gamOff.p;
+
+   const size_t nc = fa.nCellsMax, qm = fa.QMax + 3, mn = m->maxN;
+   auto r8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+   const size_t ldsBeta = 2 * r8(nc * 8) + r8(qm * 8) + r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32);
+   const size_t ldsAlpha = 2 * r8(nc * 8) + r8(3 * nc * 8) + r8(qm * 8) + r8(nc * (mn + 1) * 8) + 2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32);
+   if (ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
+
+   int rc;
+   HIPCHECK(hipEventRecord(fb->ev[0], s));
+   if ((rc = htkamd_launch_score_exact(m, sa, s))) return rc;
+   HIPCHECK(hipEventRecord(fb->ev[1], s));
+   if ((rc = htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;
+   HIPCHECK(hipEventRecord(fb->ev[2], s));
+   if ((rc = htkamd_launch_alpha(fa, fb->blockDim, ldsAlpha, s))) return rc;
+   HIPCHECK(hipEventRecord(fb->ev[3], s));
+   if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES))
+      if ((rc = htkamd_launch_mixstats(fa, s))) return rc;
+   HIPCHECK(hipEventRecord(fb->ev[4], s));
+   fb->timed = true;
+   // the metric's unit count rides along in the accumulator vector so that it is all-reduced with it
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *stream)
+{
+   if (!fb) { htkamd_set_error("fb_results: NULL"); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   if (fb->nUtt == 0) return HTKAMD_OK;
+   if (pr) HIPCHECK(hipMemcpyAsync(pr, fb->d_pr.p, sizeof(double) * fb->nUtt, hipMemcpyDeviceToHost, s));
+   if (status) HIPCHECK(hipMemcpyAsync(status, fb->d_status.p, sizeof(int) * fb->nUtt, hipMemcpyDeviceToHost, s));
+   HIPCHECK(hipStreamSynchronize(s));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_fb_kernel_times(htkamd_fb *fb, double out[4])
+{
+   if (!fb || !out) { htkamd_set_error("fb_kernel_times: NULL"); return HTKAMD_EINVAL; }
+   if (!fb->timed) { htkamd_set_error("fb_kernel_times: nothing executed yet"); return HTKAMD_EINVAL; }
+   HIPCHECK(hipEventSynchronize(fb->ev[4]));
+   for (int i = 0; i < 4; i++) {
+      float ms = 0.f;
+      HIPCHECK(hipEventElapsedTime(&ms, fb->ev[i], fb->ev[i + 1]));
+      out[i] = (double)ms * 1e-3;
+   }
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double *alpha, float *outp,
+                                     int *qLo, int *qHi, int *aLo, int *aHi, int *pT, int *pQ, int *pMaxN, void *stream)
+{
+   if (!fb || u < 0 || u >= fb->nUtt) { htkamd_set_error("fb_get_trellis: bad utterance index"); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   HIPCHECK(hipStreamSynchronize(s));
+   const UttDesc &d = fb->utt[u];
+   const int T = d.T, Q = d.Q, nC = d.nCells, nS = d.nSlots, maxN = fb->m->maxN;
+   if (pT) *pT = T; if (pQ) *pQ = Q; if (pMaxN) *pMaxN = maxN;
+   if (T <= 0 || Q <= 0) return HTKAMD_OK;
+   std::vector<short> lo(T), hi(T), alo(T), ahi(T);
+   HIPCHECK(hipMemcpy(lo.data(), (short *)fb->d_qLo.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(hi.data(), (short *)fb->d_qHi.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(alo.data(), (short *)fb->d_aLo.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(ahi.data(), (short *)fb->d_aHi.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
+   for (int t = 0; t < T; t++) {
+      if (qLo) qLo[t] = lo[t]; if (qHi) qHi[t] = hi[t]; if (aLo) aLo[t] = alo[t]; if (aHi) aHi[t] = ahi[t];
+   }
+   const int *mN = fb->mN.data() + d.q0, *mC = fb->mCell0.data() + d.q0, *mS = fb->mSlot0.data() + d.q0;
+   const size_t n = (size_t)T * Q * maxN;
+   if (beta) {
+      std::vector<double> b((size_t)T * nC);
+      HIPCHECK(hipMemcpy(b.data(), (double *)fb->d_beta.p + d.beta0, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < n; k++) beta[k] = NAN;
+      for (int t = 0; t < T; t++)
+         for (int q = lo[t]; q <= hi[t]; q++)
+            for (int i = 0; i < mN[q - 1]; i++)
+               beta[((size_t)t * Q + (q - 1)) * maxN + i] = b[(size_t)t * nC + mC[q - 1] + i];
+   }
+   if (alpha) {
+      if (!fb->debug) { htkamd_set_error("fb_get_trellis: alpha is only kept in debug mode (htkamd_fb_set_debug before prepare)"); return HTKAMD_EINVAL; }
+      std::vector<double> al((size_t)T * nC);
+      HIPCHECK(hipMemcpy(al.data(), (double *)fb->d_alpha.p + d.beta0, sizeof(double) * al.size(), hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < n; k++) alpha[k] = NAN;
+      for (int t = 0; t < T; t++)
+         for (int q = 1; q <= Q; q++)
+            for (int i = 0; i < mN[q - 1]; i++)
+               alpha[((size_t)t * Q + (q - 1)) * maxN + i] = al[(size_t)t * nC + mC[q - 1] + i];
+   }
+   if (outp) {
+      std::vector<float> o((size_t)T * nS);
+      HIPCHECK(hipMemcpy(o.data(), (float *)fb->d_outp.p + d.outp0, sizeof(float) * o.size(), hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < n; k++) outp[k] = NAN;
+      for (int t = 0; t < T; t++)
+         for (int q = 1; q <= Q; q++)
+            for (int j = 2; j < mN[q - 1]; j++)
+               outp[((size_t)t * Q + (q - 1)) * maxN + (j - 1)] = o[(size_t)(mS[q - 1] + j - 2) * T + t];
+   }
+   return HTKAMD_OK;
+}

@@ -1,0 +1,624 @@
+// fb_kernels.hip -- K2 (beta pass), K3 (alpha pass + occupation / transition statistics) and
+// K4 (mixture statistics) of the embedded Baum-Welch step.
+//
+// Reference semantics restated here (all of HFB.c, S==1, PLAINHS/SHAREDHS, no xforms):
+//   SetBeta 1149-1296, StepAlpha 686-784, InitAlpha 616-651, MaxModelProb 655-682,
+//   SetOcct 399-418, UpTranParms 1371-1423, UpMixParms 1426-1744, StepBack retry loop 1321-1366.
+//
+// MI355X mapping.  The recursions are sequential in time and only as wide as the utterance's
+// model chain (Q models x N states, ~200 cells), so ONE WORKGROUP OWNS ONE UTTERANCE and one
+// thread owns one (model,state) cell; thousands of utterances are resident at once (1 block each),
+// which is where the parallelism comes from.  The alpha/beta columns of the current and previous
+// frame live in LDS (doubles, like the reference's DVectors); the transition row/column of each
+// cell is staged in LDS once; the full beta trellis goes to HBM as [t][cell] so a column is one
+// coalesced 8-byte-per-lane store/load.  Transition and occupation counts are summed over time in
+// thread-private LDS slots and flushed with one fp64 atomic per (cell,entry) at the end of the
+// utterance (HW global_atomic_add_f64), so a transition matrix shared by every model is not hit
+// once per frame.  Mixture-level statistics are not computed inside the sequential loop: K3 writes
+// log-occupancy seeds densely ([t][slot], LZERO when below the MINFORPROB prune) and K4 scans them
+// with whole waves, recomputing the per-component likelihoods only for the ~2% of (frame,state)
+// pairs that survive the prune.
+#include <hip/hip_runtime.h>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+
+__device__ __forceinline__ double ladd(double x, double y, double minLogExp)
+{
+   if (x < y) { double t = x; x = y; y = t; }
+   double diff = y - x;
+   if (diff < minLogExp) return (x < LSMALL) ? LZERO : x;
+   return x + log(1.0 + exp(diff));
+}
+
+struct CellMeta {
+   int q, i, N, mc0, ms0;      // model (1-based), state (1..N), states in model, cell of state 1, slot of state 2
+};
+
+struct LdsCarve {
+   char *p;
+   __device__ explicit LdsCarve(void *base) : p((char *)base) {}
+   template <typename T> __device__ T *take(size_t n)
+   {
+      T *r = (T *)p;
+      p += ((n * sizeof(T) + 7) & ~(size_t)7);
+      return r;
+   }
+};
+
+// ------------------------------------------------------------------------------------ K2: beta
+__global__ void k_beta(FbArgs a)
+{
+   const int nCellsMax = a.nCellsMax, QMax = a.QMax;
+   extern __shared__ double smem[];
+   const int u = blockIdx.x, tid = threadIdx.x;
+   const UttDesc ud = a.utt[u];
+   if (ud.status != HTKAMD_UTT_OK) {
+      if (tid == 0) { a.status[u] = ud.status; a.pr[u] = LZERO; }
+      return;
+   }
+   const int T = ud.T, Q = ud.Q, nC = ud.nCells, maxN = a.maxN;
+   LdsCarve lds(smem);
+   double *colA = lds.take<double>(nCellsMax);
+   double *colB = lds.take<double>(nCellsMax);
+   double *maxP = lds.take<double>(QMax + 3);
+   float *trow = lds.take<float>((size_t)nCellsMax * maxN);
+   float *mA1N = lds.take<float>(QMax + 3);
+   int *mC0 = lds.take<int>(QMax + 3);
+   int *mNq = lds.take<int>(QMax + 3);
+   int *mDm = lds.take<int>(QMax + 3);
+   int *sh = lds.take<int>(8);
+
+   CellMeta cm = {0, 0, 0, 0, 0};
+   const bool live = tid < nC;
+   if (live) {
+      cm.q = a.cQ[ud.cell0 + tid]; cm.i = a.cI[ud.cell0 + tid];
+      const int mi = ud.q0 + cm.q - 1;
+      cm.N = a.mN[mi]; cm.mc0 = a.mCell0[mi]; cm.ms0 = a.mSlot0[mi];
+      const float *tp = a.transP + a.mTp[mi];
+      for (int j = 1; j <= cm.N; j++) trow[tid * maxN + (j - 1)] = tp[(cm.i - 1) * cm.N + (j - 1)];
+   }
+   for (int q = tid + 1; q <= Q; q += blockDim.x) {
+      const int mi = ud.q0 + q - 1, N = a.mN[mi];
+      mC0[q] = a.mCell0[mi]; mNq[q] = N; mDm[q] = a.mDms[mi];
+      mA1N[q] = a.transP[a.mTp[mi] + (N - 1)];          // a_1N: the tee transition
+   }
+   if (tid == 0) { mC0[Q + 1] = 0; mNq[Q + 1] = 0; mDm[Q + 1] = 1; mA1N[Q + 1] = (float)LZERO; mA1N[0] = (float)LZERO; mDm[0] = 1; }
+   __syncthreads();
+
+   const short *tLo = a.taperLo + ud.frame0 - 1, *tHi = a.taperHi + ud.frame0 - 1;   // 1-based t
+   short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;
+   const float *outp = a.outp + ud.outp0;
+   double *gbeta = a.beta + ud.beta0;
+   const double mle = a.minLogExp;
+   const bool pruning = a.pruneInit < HTKAMD_NOPRUNE;
+
+   double thresh = a.pruneInit, pr = LZERO;
+   int ok = 0;
+   for (;;) {                                            // StepBack retry loop (HFB.c:1332-1361)
+      double *colC = colA, *colN = colB;
+      int fail = 0;
+      // ---- t = T (HFB.c:1175-1198)
+      int endq = tLo[T];
+      if (tid == 0) {
+         double e = 0.0;
+         for (int q = Q; q >= endq; q--) {
+            e = (q == Q) ? 0.0 : e + (double)mA1N[q + 1];
+            colC[mC0[q] + mNq[q] - 1] = e;
+         }
+      }
+      __syncthreads();
+      if (live && cm.q >= endq && cm.i > 1 && cm.i < cm.N)
+         colC[tid] = (double)trow[tid * maxN + cm.N - 1] + colC[cm.mc0 + cm.N - 1];
+      __syncthreads();
+      if (live && cm.q >= endq && cm.i == 1) {
+         double x = LZERO;
+         for (int j = 2; j < cm.N; j++) {
+            double aa = trow[tid * maxN + j - 1], y = colC[cm.mc0 + j - 1];
+            if (aa > LSMALL && y > LSMALL)
+               x = ladd(x, aa + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (T - 1)] + y, mle);
+         }
+         colC[tid] = x;
+      }
+      __syncthreads();
+      if (live && cm.q >= endq) gbeta[(size_t)(T - 1) * nC + tid] = colC[tid];
+      if (tid == 0) { gLo[T] = (short)endq; gHi[T] = (short)Q; }
+      int qHiN = Q, qLoN = endq, lastEnd = endq;
+
+      // ---- t = T-1 .. 1 (HFB.c:1205-1277)
+      for (int t = T - 1; t >= 1; t--) {
+         const int startq = qHiN;
+         endq = (qLoN == 1) ? 1 : ((tLo[t] >= qLoN) ? tLo[t] : qLoN - 1);
+         while (endq > 1 && mDm[endq - 1] == 0) endq--;
+         { double *tmp = colC; colC = colN; colN = tmp; }
+         const bool inRange = live && cm.q >= endq && cm.q <= startq;
+         if (inRange && cm.i > 1) {
+            const int q = cm.q;
+            const bool p1 = (q < Q) && (q + 1 >= qLoN) && (q + 1 <= qHiN);
+            double ex = p1 ? colN[mC0[q + 1]] : LZERO;
+            if (q < startq) {
+               const float a1N = mA1N[q + 1];
+               if (a1N > (float)LSMALL) {                // next model is a tee model: same-frame exit of q+1
+                  const bool p2 = (q + 1 < Q) && (q + 2 >= qLoN) && (q + 2 <= qHiN);
+                  double ex1 = p2 ? colN[mC0[q + 2]] : LZERO;
+                  ex = ladd(ex, ex1 + (double)a1N, mle);
+               }
+            }
+            if (cm.i == cm.N)
+               colC[tid] = ex;
+            else {
+               double x = (double)trow[tid * maxN + cm.N - 1] + ex;
+               if (q >= qLoN && q <= qHiN)
+                  for (int j = 2; j < cm.N; j++) {
+                     double aa = trow[tid * maxN + j - 1], y = colN[cm.mc0 + j - 1];
+                     if (aa > LSMALL && y > LSMALL)
+                        x = ladd(x, aa + (double)outp[(size_t)(cm.ms0 + j - 2) * T + t] + y, mle);   // b_j(t+1)
+                  }
+               colC[tid] = x;
+            }
+         }
+         __syncthreads();
+         if (inRange && cm.i == 1) {
+            double x = LZERO, lMax = LZERO;
+            for (int j = 2; j < cm.N; j++) {
+               double aa = trow[tid * maxN + j - 1], y = colC[cm.mc0 + j - 1];
+               if (y > lMax) lMax = y;
+               if (aa > LSMALL && y > LSMALL)
+                  x = ladd(x, aa + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (t - 1)] + y, mle);      // b_j(t)
+            }
+            colC[tid] = x;
+            maxP[cm.q] = lMax;
+         }
+         __syncthreads();
+         int newHi, newLo;
+         if (!pruning) {                                 // only the taper acts (HFB.c:1259-1264)
+            newHi = (tHi[t] < startq) ? tHi[t] : startq;
+            newLo = endq;
+         } else {
+            if (tid < 64) {                              // beam pruning (HFB.c:1254-1272)
+               double g = LZERO;
+               for (int q = endq + tid; q <= startq; q += 64) g = fmax(g, maxP[q]);
+               for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
+               if (tid == 0) {
+                  int s = startq, e = endq, f = 0;
+                  while (s >= 1 && g - maxP[s] > thresh) --s;
+                  while (s >= 1 && tHi[t] < s) --s;
+                  if (s < 1) f = 1;
+                  else
+                     while (g - maxP[e] > thresh) { ++e; if (e > s) { f = 1; break; } }
+                  sh[0] = s; sh[1] = e; sh[2] = f;
+               }
+            }
+            __syncthreads();
+            newHi = sh[0]; newLo = sh[1];
+            if (sh[2]) fail = 1;
+            __syncthreads();
+         }
+         if (fail) break;
+         if (inRange) gbeta[(size_t)(t - 1) * nC + tid] = colC[tid];
+         if (tid == 0) { gLo[t] = (short)newLo; gHi[t] = (short)newHi; }
+         qHiN = newHi; qLoN = newLo; lastEnd = endq;
+      }
+      if (!fail) {
+         pr = colC[mC0[lastEnd]];                        // utt->pr = bqt[1] of the last model processed
+         if (pr > LSMALL) { ok = 1; break; }
+      }
+      __syncthreads();
+      thresh += a.pruneInc;
+      if (thresh > a.pruneLim || a.pruneInc == 0.0) break;
+   }
+   if (tid == 0) {
+      a.pr[u] = ok ? pr : LZERO;
+      a.status[u] = ok ? HTKAMD_UTT_OK : HTKAMD_UTT_SKIPPED;
+   }
+}
+
+// ------------------------------------------------------------------------------------ K3: alpha + stats
+__global__ void k_alpha(FbArgs a)
+{
+   const int nCellsMax = a.nCellsMax, QMax = a.QMax;
+   extern __shared__ double smem[];
+   const int u = blockIdx.x, tid = threadIdx.x;
+   const UttDesc ud = a.utt[u];
+   if (a.status[u] != HTKAMD_UTT_OK) {                   // skipped in the beta pass (or pre-check)
+      if (tid == 0) atomicAdd(a.acc + a.lay.nUttSkipped, 1.0);
+      return;
+   }
+   const int T = ud.T, Q = ud.Q, nC = ud.nCells, maxN = a.maxN;
+   LdsCarve lds(smem);
+   double *acol0 = lds.take<double>(nCellsMax);
+   double *acol1 = lds.take<double>(nCellsMax);
+   double *bcol = lds.take<double>((size_t)3 * nCellsMax);
+   double *mmp = lds.take<double>(QMax + 3);
+   double *tacc = lds.take<double>((size_t)nCellsMax * (maxN + 1));
+   float *trow = lds.take<float>((size_t)nCellsMax * maxN);
+   float *tcol = lds.take<float>((size_t)nCellsMax * maxN);
+   float *mA1N = lds.take<float>(QMax + 3);
+   int *mC0 = lds.take<int>(QMax + 3);
+   int *mNq = lds.take<int>(QMax + 3);
+   int *mDm = lds.take<int>(QMax + 3);
+   int *sh = lds.take<int>(8);
+
+   CellMeta cm = {0, 0, 0, 0, 0};
+   const bool live = tid < nC;
+   int cM = 0, cHmm = 0, cTrans = 0;
+   if (live) {
+      cm.q = a.cQ[ud.cell0 + tid]; cm.i = a.cI[ud.cell0 + tid];
+      const int mi = ud.q0 + cm.q - 1;
+      cm.N = a.mN[mi]; cm.mc0 = a.mCell0[mi]; cm.ms0 = a.mSlot0[mi];
+      cHmm = a.mHmm[mi]; cTrans = a.mTrans[mi];
+      const float *tp = a.transP + a.mTp[mi];
+      for (int j = 1; j <= cm.N; j++) {
+         trow[tid * maxN + (j - 1)] = tp[(cm.i - 1) * cm.N + (j - 1)];
+         tcol[tid * maxN + (j - 1)] = tp[(j - 1) * cm.N + (cm.i - 1)];
+      }
+      for (int j = 0; j <= maxN; j++) tacc[tid * (maxN + 1) + j] = 0.0;
+      if (cm.i > 1 && cm.i < cm.N) {
+         const int s = a.slotState[ud.slot0 + cm.ms0 + cm.i - 2];
+         cM = a.stateCompOff[s + 1] - a.stateCompOff[s];
+      }
+   }
+   for (int q = tid + 1; q <= Q; q += blockDim.x) {
+      const int mi = ud.q0 + q - 1, N = a.mN[mi];
+      mC0[q] = a.mCell0[mi]; mNq[q] = N; mDm[q] = a.mDms[mi];
+      mA1N[q] = a.transP[a.mTp[mi] + (N - 1)];
+   }
+   if (tid == 0) { mC0[Q + 1] = 0; mNq[Q + 1] = 0; mDm[Q + 1] = 1; mA1N[Q + 1] = (float)LZERO; mA1N[0] = (float)LZERO; mDm[0] = 1; mC0[0] = 0; mNq[0] = 0; }
+
+   const short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;    // final beta beam, 1-based t
+   short *gaLo = a.aLo + ud.frame0 - 1, *gaHi = a.aHi + ud.frame0 - 1;
+   const float *outp = a.outp + ud.outp0;
+   const double *gbeta = a.beta + ud.beta0;
+   double *gam = a.gam + ud.gam0;
+   const double mle = a.minLogExp, pr = a.pr[u];
+   const double minF = (double)a.minFrwdP;
+   const bool wantMix = (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) != 0;
+   const bool wantTrans = (a.uFlags & HTKAMD_UPTRANS) != 0;
+   const int nSlots = ud.nSlots;
+
+   // beta columns 1 and 2 into the ring (column t lives in slot t % 3)
+   if (live) {
+      { const int q = cm.q; if (q >= gLo[1] && q <= gHi[1]) bcol[(size_t)(1 % 3) * nCellsMax + tid] = gbeta[tid]; }
+      if (T >= 2) { const int q = cm.q; if (q >= gLo[2] && q <= gHi[2]) bcol[(size_t)(2 % 3) * nCellsMax + tid] = gbeta[(size_t)nC + tid]; }
+   }
+   double *aC = acol0, *aP = acol1;
+   int sq = 1, eq = gHi[1];
+   double occAcc = 0.0;
+   int err = 0;
+
+   // ---- t = 1: InitAlpha (HFB.c:616-651)
+   if (tid == 0) {
+      double a1 = 0.0;
+      for (int q = 1; q <= eq; q++) {
+         a1 = (q == 1) ? 0.0 : a1 + (double)mA1N[q - 1];
+         aC[mC0[q]] = a1;
+      }
+   }
+   __syncthreads();
+   if (live && cm.i > 1 && cm.i < cm.N) {
+      double v = LZERO;
+      if (cm.q <= eq) {
+         const double aa = tcol[tid * maxN + 0];
+         if (aa > LSMALL) v = aC[cm.mc0] + aa + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + 0];
+      }
+      aC[tid] = v;
+   }
+   if (live && cm.q > eq && cm.i == 1) aC[tid] = LZERO;
+   __syncthreads();
+   if (live && cm.i == cm.N) {
+      double x = LZERO;
+      if (cm.q <= eq)
+         for (int i = 2; i < cm.N; i++) {
+            const double aa = tcol[tid * maxN + i - 1];
+            if (aa > LSMALL) x = ladd(x, aC[cm.mc0 + i - 1] + aa, mle);
+         }
+      aC[tid] = x;
+   }
+   __syncthreads();
+
+   for (int t = 1; t <= T; t++) {
+      if (t > 1) {
+         // ---- alpha beam (HFB.c:699-722): MaxModelProb of every model against column t-1
+         const double *bP = bcol + (size_t)((t - 1) % 3) * nCellsMax;
+         if (live && t + 1 <= T) {                       // stage beta(t+1)
+            const int q = cm.q;
+            if (q >= gLo[t + 1] && q <= gHi[t + 1]) bcol[(size_t)((t + 1) % 3) * nCellsMax + tid] = gbeta[(size_t)t * nC + tid];
+         }
+         const int pLo = gLo[t - 1], pHi = gHi[t - 1];
+         if (live && cm.i == 1) {
+            const int q = cm.q;
+            double m = LZERO;
+            if (q > 1 && q - 1 >= pLo && q - 1 <= pHi) {
+               const int c1 = mC0[q - 1] + mNq[q - 1] - 1;
+               m = aC[c1] + bP[c1];
+            }
+            if (q >= pLo && q <= pHi)
+               for (int i = 1; i < cm.N; i++) {
+                  const double x = aC[cm.mc0 + i - 1] + bP[cm.mc0 + i - 1];
+                  if (x > m) m = x;
+               }
+            mmp[q] = m;
+         }
+         __syncthreads();
+         if (tid == 0) {
+            int s = pLo, e, f = 0;
+            const int cLo = gLo[t], cHi = gHi[t];
+            while (pr - mmp[s] > minF) { ++s; if (s > cHi) { f = 1; break; } }
+            if (!f) {
+               if (s < cLo) s = cLo;
+               e = (pHi < Q) ? pHi + 1 : pHi;
+               for (;;) {
+                  double m = mmp[e];
+                  // tee predecessors above the start point (MaxModelProb's qx loop, HFB.c:667-672)
+                  for (int qx = e - 1; qx > s && mA1N[qx] > (float)LSMALL; qx--) {
+                     const int qx1 = qx - 1;
+                     if (qx1 >= 1 && qx1 >= pLo && qx1 <= pHi) {
+                        const int c1 = mC0[qx1] + mNq[qx1] - 1;
+                        const double x = aC[c1] + bP[c1];
+                        if (x > m) m = x;
+                     }
+                  }
+                  if (!(pr - m > minF)) break;
+                  --e;
+                  if (e < s) { f = 1; break; }
+               }
+               if (!f) {
+                  while (e < Q && mDm[e] == 0) e++;
+                  if (e > cHi) e = cHi;
+               }
+               sh[0] = s; sh[1] = e;
+            }
+            sh[2] = f;
+         }
+         __syncthreads();
+         if (sh[2]) { err = 1; break; }
+         sq = sh[0]; eq = sh[1];
+         { double *tmp = aC; aC = aP; aP = tmp; }
+         // ---- alpha column t (HFB.c:729-771)
+         if (live) {
+            const int q = cm.q;
+            if (q < sq || q > eq) {
+               if (cm.i < cm.N) aC[tid] = LZERO;
+            } else if (cm.i < cm.N) {
+               double a1;
+               if (q == 1) a1 = LZERO;
+               else {
+                  a1 = aP[mC0[q - 1] + mNq[q - 1] - 1];
+                  const float t1N = mA1N[q - 1];
+                  if (q > sq && t1N > (float)LSMALL) {   // previous model is a tee model
+                     const double a1p = (q - 1 == 1) ? LZERO : aP[mC0[q - 2] + mNq[q - 2] - 1];
+                     a1 = ladd(a1, a1p + (double)t1N, mle);
+                  }
+               }
+               if (cm.i == 1) aC[tid] = a1;
+               else {
+                  double aa = tcol[tid * maxN + 0];
+                  double x = (aa > LSMALL) ? aa + a1 : LZERO;
+                  for (int i = 2; i < cm.N; i++) {
+                     aa = tcol[tid * maxN + i - 1];
+                     const double y = aP[cm.mc0 + i - 1];
+                     if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa, mle);
+                  }
+                  aC[tid] = x + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + (t - 1)];
+               }
+            }
+         }
+         __syncthreads();
+         if (live && cm.i == cm.N) {
+            double x = LZERO;
+            if (cm.q >= sq && cm.q <= eq)
+               for (int i = 2; i < cm.N; i++) {
+                  const double aa = tcol[tid * maxN + i - 1], y = aC[cm.mc0 + i - 1];
+                  if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa, mle);
+               }
+            aC[tid] = x;
+         }
+         __syncthreads();
+      }
+      if (tid == 0) { gaLo[t] = (short)sq; gaHi[t] = (short)eq; }
+      if (a.alphaDbg && live) a.alphaDbg[ud.beta0 + (size_t)(t - 1) * nC + tid] = aC[tid];
+
+      // ---- statistics for column t (HFB.c:1790-1806)
+      if (live) {
+         const int q = cm.q, i = cm.i, N = cm.N;
+         const double *bT = bcol + (size_t)(t % 3) * nCellsMax;
+         const double *bT1 = bcol + (size_t)((t + 1) % 3) * nCellsMax;
+         const bool inBeam = q >= sq && q <= eq;
+         double seed = LZERO;
+         if (inBeam) {
+            const bool bqt1ok = (t < T) && q >= gLo[t + 1] && q <= gHi[t + 1];
+            const bool bq1tok = (q < Q) && (q + 1) >= gLo[t] && (q + 1) <= gHi[t];
+            const double ai = aC[tid], bi = bT[tid];
+            // SetOcct (HFB.c:399-418)
+            double x = ai + bi;
+            const float a1N = trow[tid * maxN + N - 1];
+            if (i == 1 && bq1tok && a1N > (float)LSMALL) x = ladd(x, ai + bT[mC0[q + 1]] + (double)a1N, mle);
+            x -= pr;
+            const float occ = (x > MINEARG) ? (float)exp(x) : 0.0f;
+            if (i < N) occAcc += (double)occ;
+            if (wantTrans && i < N) {                    // UpTranParms (HFB.c:1390-1410), row i
+               double *ta = tacc + tid * (maxN + 1);
+               if (i == 1) {
+                  for (int j = 2; j < N; j++) {
+                     x = ai + (double)trow[tid * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (t - 1)] + bT[cm.mc0 + j - 1] - pr;
+                     if (x > MINEARG) ta[j] += exp(x);
+                  }
+                  if (a1N > (float)LSMALL && bq1tok) {
+                     x = ai + (double)a1N + bT[mC0[q + 1]] - pr;
+                     if (x > MINEARG) ta[N] += exp(x);
+                  }
+               } else {
+                  if (bqt1ok)
+                     for (int j = 2; j < N; j++) {
+                        x = ai + (double)trow[tid * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + t] + bT1[cm.mc0 + j - 1] - pr;
+                        if (x > MINEARG) ta[j] += exp(x);
+                     }
+                  x = ai + (double)trow[tid * maxN + N - 1] + bT[cm.mc0 + N - 1] - pr;
+                  if (x > MINEARG) ta[N] += exp(x);
+               }
+            }
+            if (wantMix && i > 1 && i < N) {             // UpMixParms seed (HFB.c:1479-1489,1573-1606)
+               if (cM == 1 || a.maxM == 1) {
+                  x = ai + bi - pr;
+                  if (-x < minF) seed = x;
+               } else {
+                  double initx = (double)tcol[tid * maxN + 0] + aC[cm.mc0];
+                  if (t > 1)
+                     for (int i2 = 2; i2 < N; i2++) {
+                        const double aa = tcol[tid * maxN + i2 - 1];
+                        if (aa > LSMALL) initx = ladd(initx, aP[cm.mc0 + i2 - 1] + aa, mle);
+                     }
+                  initx += bi - pr;
+                  // every component's x = initx + logw + prob is <= initx + b_j(t) (+ float rounding)
+                  const double ub = initx + (double)outp[(size_t)(cm.ms0 + i - 2) * T + (t - 1)];
+                  if (ub > -minF - 0.01) seed = initx;
+               }
+            }
+         }
+         if (i > 1 && i < N) gam[(size_t)(t - 1) * nSlots + cm.ms0 + i - 2] = seed;
+      }
+   }
+
+   if (err) {
+      if (tid == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
+      return;
+   }
+   // ---- flush the per-cell sums
+   if (live && wantTrans && cm.i < cm.N) {
+      const double *ta = tacc + tid * (maxN + 1);
+      double *tr = a.acc + a.lay.tr + a.transOff[cTrans] + (size_t)(cm.i - 1) * cm.N;
+      for (int j = 2; j <= cm.N; j++)
+         if (ta[j] != 0.0) atomicAdd(tr + (j - 1), ta[j]);
+      if (occAcc != 0.0) atomicAdd(a.acc + a.lay.trOcc + a.trOccOff[cTrans] + (cm.i - 1), occAcc);
+   }
+   if (live && cm.i == 1) atomicAdd(a.acc + a.lay.nEgs + cHmm, 1.0);
+   if (tid == 0) {
+      atomicAdd(a.acc + a.lay.totalPr, pr);
+      atomicAdd(a.acc + a.lay.totalT, (double)T);
+      atomicAdd(a.acc + a.lay.nUttDone, 1.0);
+      atomicAdd(a.acc + a.lay.nEval, (double)ud.nEval);
+   }
+}
+
+// ------------------------------------------------------------------------------------ K4: mixture statistics
+__global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
+{
+   const int lane = threadIdx.x & 63;
+   const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+   const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const int D = a.D;
+   const double minF = (double)a.minFrwdP;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   for (size_t base = waveId * 64; base < a.gamTotal; base += nWaves * 64) {
+      const size_t idx = base + lane;
+      const double v = (idx < a.gamTotal) ? a.gam[idx] : LZERO;
+      unsigned long long hits = __ballot(v > LSMALL);
+      while (hits) {
+         const int src = __ffsll((long long)hits) - 1;
+         hits &= hits - 1;
+         const size_t hidx = base + src;
+         const double seed = __shfl(v, src);
+         // utterance of this entry: last u with gamOffByUtt[u] <= hidx
+         int lo = 0, hi = a.nUtt - 1;
+         while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.gamOffByUtt[mid] <= hidx) lo = mid; else hi = mid - 1;
+         }
+         const int u = lo;
+         if (a.status[u] != HTKAMD_UTT_OK) continue;
+         const UttDesc ud = a.utt[u];
+         const size_t rel = hidx - ud.gam0;
+         const int t0 = (int)(rel / ud.nSlots), slot = (int)(rel % ud.nSlots);
+         const int s = a.slotState[ud.slot0 + slot];
+         const int c0 = a.stateCompOff[s], M = a.stateCompOff[s + 1] - c0;
+         const float *xrow = a.X + (size_t)(ud.frame0 + t0) * D;
+         // per-component posterior (lane = component): x = initx + logw + prob (HFB.c:1581-1606)
+         for (int mb = 0; mb < M; mb += 64) {
+            const int m = mb + lane;
+            bool pass = false;
+            double Lr = 0.0;
+            if (m < M) {
+               if (M == 1 || a.maxM == 1) { pass = true; Lr = exp(seed); }
+               else {
+                  const float wt = a.compLogWt[c0 + m];
+                  if (wt > (float)LMINMIX) {
+                     const float *P = a.gparam + (size_t)a.compGauss[c0 + m] * a.PS;
+                     float sum = P[0];
+                     for (int i = 0; i < D; i++) {
+                        const float xmm = xrow[i] - P[1 + 2 * i];
+                        sum += xmm * xmm * P[2 + 2 * i];
+                     }
+                     const float prob = -0.5f * sum;
+                     const double x = (seed + (double)wt) + (double)prob;
+                     if (-x < minF) { pass = true; Lr = exp(x); }
+                  }
+               }
+            }
+            double sumLr = pass ? Lr : 0.0;
+            for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
+            if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
+            unsigned long long pm = __ballot(pass);
+            while (pm) {
+               const int ml = __ffsll((long long)pm) - 1;
+               pm &= pm - 1;
+               const double L = __shfl(Lr, ml);
+               const int c = c0 + mb + ml, g = a.compGauss[c];
+               if (lane == 0) {
+                  if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, L);
+                  if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, L);
+                  if (upWt) atomicAdd(a.acc + a.lay.wt + c, L);
+               }
+               const float *mean = a.mean + (size_t)g * D;
+               for (int k = lane; k < D; k += 64) {
+                  const float z = xrow[k] - mean[k];
+                  if (upMu && upVa) {                    // HFB.c:1673-1678
+                     const float zl = (float)((double)z * L);
+                     atomicAdd(a.acc + a.lay.mu + (size_t)g * D + k, (double)zl);
+                     atomicAdd(a.acc + a.lay.va + (size_t)g * D + k, (double)(z * zl));
+                  } else if (upMu) {                     // HFB.c:1697-1698
+                     atomicAdd(a.acc + a.lay.mu + (size_t)g * D + k, (double)z * L);
+                  } else if (upVa) {                     // HFB.c:1706-1709
+                     atomicAdd(a.acc + a.lay.va + (size_t)g * D + k, (double)(z * z) * L);
+                  }
+               }
+            }
+         }
+      }
+   }
+}
+
+static int set_lds_limit(const void *fn, size_t lds)
+{
+   if (lds > 64 * 1024)      // dynamic LDS beyond 64 KiB must be allowed explicitly (160 KiB per CU on gfx950)
+      HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+   return HTKAMD_OK;
+}
+
+int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s)
+{
+   int rc = set_lds_limit((const void *)k_beta, lds);
+   if (rc) return rc;
+   hipLaunchKernelGGL(k_beta, dim3(a.nUtt), dim3(blockDim), lds, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s)
+{
+   int rc = set_lds_limit((const void *)k_alpha, lds);
+   if (rc) return rc;
+   hipLaunchKernelGGL(k_alpha, dim3(a.nUtt), dim3(blockDim), lds, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s)
+{
+   if (a.gamTotal == 0) return HTKAMD_OK;
+   size_t waves = (a.gamTotal + 63) / 64;
+   size_t blocks = (waves + 3) / 4;
+   if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
+   hipLaunchKernelGGL(k_mixstats, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}

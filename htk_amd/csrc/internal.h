@@ -1,0 +1,55 @@
+/* internal.h -- shared declarations of the htk_amd native library (not part of the C ABI). */
+#ifndef HTKAMD_INTERNAL_H
+#define HTKAMD_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/htk_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HTK constants (HMath.h:42-45, HModel.h:52-53) */
+#define LZERO    (-1.0E10)
+#define LSMALL   (-0.5E10)
+#define MINEARG  (-708.3)
+#define MINLARG  2.45E-308
+#define HTK_TPI  6.28318530717959
+#define MINMIX   1.0E-5
+#define LMINMIX  (-11.5129254649702)
+
+void htkamd_set_error(const char *fmt, ...);
+
+/* ---- host-side preparation (htk_amd/host/prep.c) ---- */
+void   htkamd_host_fix_diag_gconst(int D, const float *var, float *gconst);   /* HModel.c:5641 */
+void   htkamd_host_conv_diagc(size_t n, const float *var, float *ivar);        /* HUtil.c:413  */
+float  htkamd_host_mix_log_weight(float w);                                    /* HModel.c:5288 */
+int    htkamd_host_min_dur(int N, const float *tp);                            /* HFB.c:106    */
+double htkamd_host_min_log_exp(void);                                          /* HMath.c:1680 */
+
+/* ---- packed model ---- */
+struct htkamd_model {
+   int D, S, C, G, nT, H, maxN, maxM;
+   int PS;                     /* floats per Gaussian in gparam: 2*D+1 rounded up to a multiple of 4 */
+   /* host copies */
+   int   *h_stateCompOff, *h_compGauss, *h_transN, *h_transOff, *h_hmmTrans, *h_hmmStateOff, *h_hmmState, *h_minDur;
+   int   *h_trOccOff;          /* [nT+1] prefix sum of transN */
+   float *h_mean, *h_var, *h_ivar, *h_gconst, *h_compWeight, *h_compLogWt, *h_transP;
+   /* device copies */
+   float *d_gparam;            /* [G*PS]: gconst, then (mean[i], ivar[i]) pairs */
+   float *d_mean, *d_ivar, *d_gconst, *d_compLogWt, *d_transP;
+   int   *d_stateCompOff, *d_compGauss, *d_transN, *d_transOff;
+   double minLogExp;
+};
+
+struct htkamd_accs {
+   struct htkamd_model *m;
+   htkamd_accs_layout lay;
+   double *d_vec;
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif

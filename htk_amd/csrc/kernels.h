@@ -1,0 +1,83 @@
+// kernels.h -- device-side argument blocks shared by the launchers (internal).
+#ifndef HTKAMD_KERNELS_H
+#define HTKAMD_KERNELS_H
+#include <hip/hip_runtime.h>
+#include "internal.h"
+
+#define SCORE_TILE_FRAMES 128   /* 64 lanes x 2 frames per lane */
+#define SCORE_TASK_SLOTS  32    /* tied states scored per task */
+
+struct ScoreTask {
+   int frame0;        // first row of the tile in X
+   int nFrames;       // valid frames in the tile (<= SCORE_TILE_FRAMES)
+   int slot0;         // first entry in slotState
+   int nSlots;        // states to score
+   int outSlot0;      // row of the first state in the output block
+   int ldo;           // leading dimension (frames) of the output block
+   size_t outBase;    // element offset of (row 0, first frame of this tile) in out
+};
+
+struct ScoreArgs {
+   const ScoreTask *tasks;
+   int nTasks;
+   const float *X;
+   const int *slotState;
+   float *out;
+   const int *stateCompOff, *compGauss;
+   const float *compLogWt, *gparam;
+   int PS, D;
+   double minLogExp;
+};
+
+int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream);
+
+// ---- forward-backward ----
+struct UttDesc {
+   int T, Q, nCells, nSlots;
+   int frame0;        // first row in X and in the per-frame beam arrays
+   int q0;            // first entry in the per-model tables
+   int cell0;         // first entry in the per-cell tables
+   int slot0;         // first entry in slotState
+   int status;        // host pre-check (CreateInsts): HTKAMD_UTT_*
+   int nEval;         // output-probability evaluations of the un-pruned pass (metric unit)
+   size_t outp0;      // floats : outp[outp0 + slot*T + (t-1)]
+   size_t beta0;      // doubles: beta[beta0 + (t-1)*nCells + cell]
+   size_t gam0;       // doubles: gam [gam0  + (t-1)*nSlots + slot]
+};
+
+struct FbArgs {
+   const UttDesc *utt;
+   int nUtt;
+   // per-model tables (index q0 + q - 1)
+   const int *mN, *mTp, *mCell0, *mSlot0, *mDms, *mHmm, *mTrans;
+   // per-cell tables (index cell0 + c)
+   const short *cQ, *cI;
+   const int *slotState;
+   // per-frame (index frame0 + t - 1)
+   const short *taperLo, *taperHi;
+   short *qLo, *qHi, *aLo, *aHi;
+   const float *X;
+   const float *transP;
+   float *outp;
+   double *beta, *gam, *alphaDbg;    // alphaDbg: NULL unless debugging, layout as beta
+   double *pr;                       // [nUtt]
+   int *status;                      // [nUtt]
+   // model tables for the statistics kernel
+   const int *stateCompOff, *compGauss, *transOff, *trOccOff;
+   const float *compLogWt, *gparam, *mean;
+   int PS, D, maxN, maxM;
+   int nCellsMax, QMax;              // maxima over the batch (LDS carve)
+   double *acc;                      // accumulator vector
+   htkamd_accs_layout lay;
+   double pruneInit, pruneInc, pruneLim, minLogExp;
+   float minFrwdP;
+   int uFlags;
+   size_t gamTotal;                  // doubles in gam for this batch
+   const size_t *gamOffByUtt;        // [nUtt+1] = utt[u].gam0 (for the flat-index -> utterance search)
+};
+
+int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
+int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
+int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s);
+
+#endif

@@ -1,0 +1,295 @@
+// model.hip -- packed HMM set on the device, accumulator vector, error plumbing.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include "internal.h"
+#include "hipcheck.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void htkamd_set_error(const char *fmt, ...)
+{
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(g_err, sizeof(g_err), fmt, ap);
+   va_end(ap);
+}
+
+extern "C" const char *htkamd_last_error(void) { return g_err; }
+extern "C" int htkamd_version(void) { return 100; }
+
+extern "C" int htkamd_device_count(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+extern "C" int htkamd_set_device(int ordinal)
+{
+   HIPCHECK(hipSetDevice(ordinal));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_dev_malloc(void **dptr, size_t bytes)
+{
+   if (!dptr) { htkamd_set_error("dev_malloc: NULL"); return HTKAMD_EINVAL; }
+   hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+   if (e != hipSuccess) { htkamd_set_error("dev_malloc(%zu): %s", bytes, hipGetErrorString(e)); return (e == hipErrorOutOfMemory) ? HTKAMD_ENOMEM : HTKAMD_EHIP; }
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_dev_free(void *dptr)
+{
+   if (dptr) HIPCHECK(hipFree(dptr));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_memcpy_h2d(void *dDst, const void *hSrc, size_t bytes, void *stream)
+{
+   if (bytes == 0) return HTKAMD_OK;
+   HIPCHECK(hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_memcpy_d2h(void *hDst, const void *dSrc, size_t bytes, void *stream)
+{
+   if (bytes == 0) return HTKAMD_OK;
+   HIPCHECK(hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_stream_sync(void *stream)
+{
+   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+template <typename T> static T *dupHost(const T *src, size_t n)
+{
+   T *p = (T *)malloc(sizeof(T) * (n ? n : 1));
+   if (src && n) memcpy(p, src, sizeof(T) * n);
+   return p;
+}
+
+template <typename T> static int toDevice(T **dst, const T *src, size_t n)
+{
+   if (*dst == nullptr) HIPCHECK(hipMalloc((void **)dst, sizeof(T) * (n ? n : 1)));
+   if (n) HIPCHECK(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+   return HTKAMD_OK;
+}
+
+// (Re)derive ivar / log weights / min durations / the interleaved scoring table and push them.
+static int model_refresh(htkamd_model *m)
+{
+   const int D = m->D, PS = m->PS;
+   htkamd_host_conv_diagc((size_t)m->G * D, m->h_var, m->h_ivar);
+   for (int c = 0; c < m->C; c++) m->h_compLogWt[c] = htkamd_host_mix_log_weight(m->h_compWeight[c]);
+   for (int t = 0; t < m->nT; t++) m->h_minDur[t] = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+   float *gp = (float *)calloc((size_t)m->G * PS, sizeof(float));
+   for (int g = 0; g < m->G; g++) {
+      float *p = gp + (size_t)g * PS;
+      p[0] = m->h_gconst[g];
+      for (int i = 0; i < D; i++) {
+         p[1 + 2 * i] = m->h_mean[(size_t)g * D + i];
+         p[2 + 2 * i] = m->h_ivar[(size_t)g * D + i];
+      }
+   }
+   int rc = toDevice(&m->d_gparam, gp, (size_t)m->G * PS);
+   free(gp);
+   if (rc) return rc;
+   if ((rc = toDevice(&m->d_mean, m->h_mean, (size_t)m->G * D))) return rc;
+   if ((rc = toDevice(&m->d_ivar, m->h_ivar, (size_t)m->G * D))) return rc;
+   if ((rc = toDevice(&m->d_gconst, m->h_gconst, (size_t)m->G))) return rc;
+   if ((rc = toDevice(&m->d_compLogWt, m->h_compLogWt, (size_t)m->C))) return rc;
+   if ((rc = toDevice(&m->d_transP, m->h_transP, (size_t)m->h_transOff[m->nT]))) return rc;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **out)
+{
+   if (!d || !out) { htkamd_set_error("model_create: NULL argument"); return HTKAMD_EINVAL; }
+   if (htkamd_device_count() <= 0) { htkamd_set_error("model_create: no HIP device"); return HTKAMD_ENODEV; }
+   if (d->vecSize <= 0 || d->numStates <= 0 || d->numComp <= 0 || d->numGauss <= 0 || d->numTrans <= 0 || d->numPhys <= 0) {
+      htkamd_set_error("model_create: empty model"); return HTKAMD_EINVAL;
+   }
+   htkamd_model *m = (htkamd_model *)calloc(1, sizeof(htkamd_model));
+   m->D = d->vecSize; m->S = d->numStates; m->C = d->numComp; m->G = d->numGauss; m->nT = d->numTrans; m->H = d->numPhys;
+   m->PS = ((2 * m->D + 1) + 3) & ~3;
+   m->minLogExp = htkamd_host_min_log_exp();
+   m->h_stateCompOff = dupHost(d->stateCompOff, (size_t)m->S + 1);
+   m->h_compGauss = dupHost(d->compGauss, (size_t)m->C);
+   m->h_compWeight = dupHost(d->compWeight, (size_t)m->C);
+   m->h_compLogWt = dupHost((const float *)nullptr, (size_t)m->C);
+   m->h_mean = dupHost(d->mean, (size_t)m->G * m->D);
+   m->h_var = dupHost(d->var, (size_t)m->G * m->D);
+   m->h_ivar = dupHost((const float *)nullptr, (size_t)m->G * m->D);
+   m->h_transN = dupHost(d->transN, (size_t)m->nT);
+   m->h_transOff = dupHost(d->transOff, (size_t)m->nT + 1);
+   m->h_transP = dupHost(d->transP, (size_t)d->transOff[m->nT]);
+   m->h_hmmTrans = dupHost(d->hmmTrans, (size_t)m->H);
+   m->h_hmmStateOff = dupHost(d->hmmStateOff, (size_t)m->H + 1);
+   m->h_hmmState = dupHost(d->hmmState, (size_t)d->hmmStateOff[m->H]);
+   m->h_minDur = dupHost((const int *)nullptr, (size_t)m->nT);
+   m->h_trOccOff = dupHost((const int *)nullptr, (size_t)m->nT + 1);
+   m->h_gconst = dupHost(d->gconst, (size_t)m->G);
+   if (!d->gconst)                                   // CheckMix: gConst fixed at load (HModel.c:206-208)
+      for (int g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst(m->D, m->h_var + (size_t)g * m->D, m->h_gconst + g);
+   m->maxN = 0; m->maxM = 1; m->h_trOccOff[0] = 0;
+   for (int t = 0; t < m->nT; t++) {
+      if (m->h_transN[t] > m->maxN) m->maxN = m->h_transN[t];
+      m->h_trOccOff[t + 1] = m->h_trOccOff[t] + m->h_transN[t];
+      if (m->h_transOff[t + 1] - m->h_transOff[t] != m->h_transN[t] * m->h_transN[t]) {
+         htkamd_set_error("model_create: transOff inconsistent with transN at matrix %d", t);
+         htkamd_model_destroy(m); return HTKAMD_EINVAL;
+      }
+   }
+   for (int s = 0; s < m->S; s++) {
+      int M = m->h_stateCompOff[s + 1] - m->h_stateCompOff[s];
+      if (M < 1) { htkamd_set_error("model_create: state %d has no mixture component", s); htkamd_model_destroy(m); return HTKAMD_EINVAL; }
+      if (M > m->maxM) m->maxM = M;
+   }
+   for (int h = 0; h < m->H; h++) {
+      int N = m->h_transN[m->h_hmmTrans[h]];
+      if (m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h] != N - 2) {
+         htkamd_set_error("model_create: HMM %d has %d emitting states but its transP has %d states", h,
+                          m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h], N);
+         htkamd_model_destroy(m); return HTKAMD_EINVAL;
+      }
+   }
+   int rc;
+   if ((rc = toDevice(&m->d_stateCompOff, m->h_stateCompOff, (size_t)m->S + 1)) ||
+       (rc = toDevice(&m->d_compGauss, m->h_compGauss, (size_t)m->C)) ||
+       (rc = toDevice(&m->d_transN, m->h_transN, (size_t)m->nT)) ||
+       (rc = toDevice(&m->d_transOff, m->h_transOff, (size_t)m->nT + 1)) ||
+       (rc = model_refresh(m))) {
+      htkamd_model_destroy(m); return rc;
+   }
+   *out = m;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_model_destroy(htkamd_model *m)
+{
+   if (!m) return;
+   free(m->h_stateCompOff); free(m->h_compGauss); free(m->h_transN); free(m->h_transOff); free(m->h_hmmTrans);
+   free(m->h_hmmStateOff); free(m->h_hmmState); free(m->h_minDur); free(m->h_trOccOff);
+   free(m->h_mean); free(m->h_var); free(m->h_ivar); free(m->h_gconst); free(m->h_compWeight); free(m->h_compLogWt); free(m->h_transP);
+   (void)hipFree(m->d_gparam); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
+   (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
+   (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff);
+   free(m);
+}
+
+extern "C" int htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,
+                                       const float *compWeight, const float *transP)
+{
+   if (!m) { htkamd_set_error("model_set_params: NULL model"); return HTKAMD_EINVAL; }
+   if (mean) memcpy(m->h_mean, mean, sizeof(float) * (size_t)m->G * m->D);
+   if (var) memcpy(m->h_var, var, sizeof(float) * (size_t)m->G * m->D);
+   if (gconst) memcpy(m->h_gconst, gconst, sizeof(float) * (size_t)m->G);
+   else if (var)
+      for (int g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst(m->D, m->h_var + (size_t)g * m->D, m->h_gconst + g);
+   if (compWeight) memcpy(m->h_compWeight, compWeight, sizeof(float) * (size_t)m->C);
+   if (transP) memcpy(m->h_transP, transP, sizeof(float) * (size_t)m->h_transOff[m->nT]);
+   return model_refresh(m);
+}
+
+extern "C" int htkamd_model_get_prepared(htkamd_model *m, float *ivar, float *gconst, float *compLogWt, int *minDur)
+{
+   if (!m) { htkamd_set_error("model_get_prepared: NULL model"); return HTKAMD_EINVAL; }
+   // read back from the DEVICE copies so that tests see what the kernels see
+   if (ivar) HIPCHECK(hipMemcpy(ivar, m->d_ivar, sizeof(float) * (size_t)m->G * m->D, hipMemcpyDeviceToHost));
+   if (gconst) HIPCHECK(hipMemcpy(gconst, m->d_gconst, sizeof(float) * (size_t)m->G, hipMemcpyDeviceToHost));
+   if (compLogWt) HIPCHECK(hipMemcpy(compLogWt, m->d_compLogWt, sizeof(float) * (size_t)m->C, hipMemcpyDeviceToHost));
+   if (minDur) memcpy(minDur, m->h_minDur, sizeof(int) * (size_t)m->nT);
+   return HTKAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------ accumulators
+
+extern "C" int htkamd_accs_create(htkamd_model *m, htkamd_accs **out)
+{
+   if (!m || !out) { htkamd_set_error("accs_create: NULL argument"); return HTKAMD_EINVAL; }
+   htkamd_accs *a = (htkamd_accs *)calloc(1, sizeof(htkamd_accs));
+   a->m = m;
+   size_t o = 0, GD = (size_t)m->G * m->D;
+   a->lay.mu = o; o += GD;
+   a->lay.muOcc = o; o += m->G;
+   a->lay.va = o; o += GD;
+   a->lay.vaOcc = o; o += m->G;
+   a->lay.wt = o; o += m->C;
+   a->lay.wtOcc = o; o += m->S;
+   a->lay.tr = o; o += m->h_transOff[m->nT];
+   a->lay.trOcc = o; o += m->h_trOccOff[m->nT];
+   a->lay.nEgs = o; o += m->H;
+   a->lay.totalPr = o++; a->lay.totalT = o++; a->lay.nUttDone = o++; a->lay.nUttSkipped = o++; a->lay.nEval = o++;
+   a->lay.total = o;
+   hipError_t e = hipMalloc((void **)&a->d_vec, sizeof(double) * o);
+   if (e != hipSuccess) { htkamd_set_error("accs_create: hipMalloc(%zu doubles): %s", o, hipGetErrorString(e)); free(a); return HTKAMD_ENOMEM; }
+   e = hipMemset(a->d_vec, 0, sizeof(double) * o);
+   if (e != hipSuccess) { htkamd_set_error("accs_create: hipMemset: %s", hipGetErrorString(e)); (void)hipFree(a->d_vec); free(a); return HTKAMD_EHIP; }
+   *out = a;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_accs_destroy(htkamd_accs *a)
+{
+   if (!a) return;
+   (void)hipFree(a->d_vec);
+   free(a);
+}
+
+extern "C" int htkamd_accs_zero(htkamd_accs *a, void *stream)
+{
+   if (!a) { htkamd_set_error("accs_zero: NULL"); return HTKAMD_EINVAL; }
+   HIPCHECK(hipMemsetAsync(a->d_vec, 0, sizeof(double) * a->lay.total, (hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_accs_get_layout(const htkamd_accs *a, htkamd_accs_layout *out)
+{
+   if (!a || !out) { htkamd_set_error("accs_get_layout: NULL"); return HTKAMD_EINVAL; }
+   *out = a->lay;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_accs_device_vector(htkamd_accs *a, double **dVec, size_t *n)
+{
+   if (!a || !dVec || !n) { htkamd_set_error("accs_device_vector: NULL"); return HTKAMD_EINVAL; }
+   *dVec = a->d_vec; *n = a->lay.total;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_accs_download(htkamd_accs *a, double *hostVec, void *stream)
+{
+   if (!a || !hostVec) { htkamd_set_error("accs_download: NULL"); return HTKAMD_EINVAL; }
+   HIPCHECK(hipMemcpyAsync(hostVec, a->d_vec, sizeof(double) * a->lay.total, hipMemcpyDeviceToHost, (hipStream_t)stream));
+   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+__global__ void k_vec_add(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+   for (; i < n; i += st) dst[i] += src[i];
+}
+
+extern "C" int htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream)
+{
+   if (!a || !hostVec) { htkamd_set_error("accs_upload_add: NULL"); return HTKAMD_EINVAL; }
+   double *tmp = nullptr;
+   HIPCHECK(hipMalloc((void **)&tmp, sizeof(double) * a->lay.total));
+   hipStream_t s = (hipStream_t)stream;
+   HIPCHECK(hipMemcpyAsync(tmp, hostVec, sizeof(double) * a->lay.total, hipMemcpyHostToDevice, s));
+   hipLaunchKernelGGL(k_vec_add, dim3(1024), dim3(256), 0, s, a->d_vec, tmp, a->lay.total);
+   HIPCHECK(hipGetLastError());
+   HIPCHECK(hipStreamSynchronize(s));
+   HIPCHECK(hipFree(tmp));
+   return HTKAMD_OK;
+}

@@ -1,0 +1,194 @@
+/* htk_amd.h -- C ABI of the MI355X-native HTK acoustic-scoring / Baum-Welch / Viterbi core.
+ *
+ * This is the drop-in boundary for the HERest / HVite hot path of HTK 3.4.1:
+ * plain C, plain pointers and sizes, no C++ or torch types.  An HTKLib build binds these entry
+ * points from the places cited on each declaration (INTEGRATION.md shows the shim a maintainer
+ * adds to HModel.c / HFB.c / HRec.c / HParm.c).  Everything numeric runs in hand-written HIP
+ * kernels for gfx950; there is no CPU fallback -- every call fails with HTKAMD_ENODEV when no
+ * device is present.
+ *
+ * Conventions
+ *  - "host" pointers are ordinary memory, "device" pointers are HBM addresses (hipMalloc or any
+ *    allocator that yields device memory, e.g. a torch CUDA tensor's data_ptr()).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - All functions return 0 on success or a negative HTKAMD_E* code; htkamd_last_error() gives
+ *    the message of the most recent failure on the calling thread.
+ *  - Indices are 0-based; HMM state numbers inside a model keep HTK's 1..N (1 entry, N exit).
+ */
+#ifndef HTK_AMD_H
+#define HTK_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTKAMD_OK        0
+#define HTKAMD_EINVAL   (-1)   /* bad argument */
+#define HTKAMD_ENODEV   (-2)   /* no HIP device / kernel image not loadable */
+#define HTKAMD_ENOMEM   (-3)
+#define HTKAMD_EHIP     (-4)   /* HIP runtime error, see htkamd_last_error() */
+#define HTKAMD_EMODEL   (-5)   /* model violates a restriction of this path (streams>1, non-diagonal cov...) */
+
+/* HTK's log-arithmetic constants (HMath.h:42-45, HModel.h:52-53, HFB.h:31) */
+#define HTKAMD_LZERO    (-1.0E10)
+#define HTKAMD_LSMALL   (-0.5E10)
+#define HTKAMD_NOPRUNE  1.0E20
+
+/* UPDSet bits used by HERest (HModel.h UPDSet; HERest.c:97 default "tmvw") */
+#define HTKAMD_UPMEANS  1
+#define HTKAMD_UPVARS   2
+#define HTKAMD_UPTRANS  4
+#define HTKAMD_UPMIXES  8
+
+int         htkamd_version(void);
+const char *htkamd_last_error(void);
+int         htkamd_device_count(void);
+int         htkamd_set_device(int ordinal);
+
+/* Device-memory plumbing for hosts that do not bring their own allocator (the C drivers, the tests). */
+int htkamd_dev_malloc(void **dptr, size_t bytes);
+int htkamd_dev_free(void *dptr);
+int htkamd_memcpy_h2d(void *dDst, const void *hSrc, size_t bytes, void *stream);   /* synchronous on return */
+int htkamd_memcpy_d2h(void *hDst, const void *dSrc, size_t bytes, void *stream);   /* synchronous on return */
+int htkamd_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Packed HMM set.  Flat restatement of HMMSet / HMMDef / StateInfo / StreamElem / MixPDF
+ * (HModel.h:85-152,297-340) for one stream, diagonal covariances, PLAINHS/SHAREDHS:
+ *   tied states   <-> StateInfo with sIdx 1..S   (SetIndexes, HModel.c:3942)
+ *   components    <-> MixtureElem {weight, mpdf}
+ *   Gaussians     <-> MixPDF with mIdx 1..G      (several components may share one: ~m macros)
+ *   transP        <-> SMatrix with tIdx, LOG probabilities, LZERO for "no transition"
+ * Parameters are given as they stand after LoadHMMSet (DIAGC variances, linear weights);
+ * the library applies FixDiagGConst (HModel.c:5641) when gconst==NULL, ConvDiagC (HUtil.c:413)
+ * and ConvLogWt (HUtil.c:474) itself, exactly once, as HERest.c:592-645 / HVite.c:503 do.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+   int vecSize;               /* D  (hset->vecSize)                                  */
+   int numStates;             /* S  tied states                                       */
+   int numComp;               /* C  = sum over states of nMix                         */
+   int numGauss;              /* G  distinct MixPDFs                                  */
+   int numTrans;              /* nT distinct transition matrices                      */
+   int numPhys;               /* H  physical HMMs                                     */
+   const int   *stateCompOff; /* [S+1] components of state s: stateCompOff[s]..[s+1)  */
+   const float *compWeight;   /* [C] linear mixture weights (MixtureElem.weight)      */
+   const int   *compGauss;    /* [C] Gaussian index of each component                 */
+   const float *mean;         /* [G*D] MixPDF.mean                                    */
+   const float *var;          /* [G*D] MixPDF.cov.var, DIAGC (variances)              */
+   const float *gconst;       /* [G] MixPDF.gConst or NULL to have it computed        */
+   const int   *transN;       /* [nT] numStates N of each matrix (entry+exit included)*/
+   const int   *transOff;     /* [nT+1] offset of matrix t inside transP              */
+   const float *transP;       /* row-major N*N log probs per matrix                   */
+   const int   *hmmTrans;     /* [H] tIdx of each physical HMM                        */
+   const int   *hmmStateOff;  /* [H+1]                                                */
+   const int   *hmmState;     /* tied-state index of the emitting states 2..N-1       */
+} htkamd_model_desc;
+
+typedef struct htkamd_model htkamd_model;
+
+int  htkamd_model_create(const htkamd_model_desc *desc, htkamd_model **out);
+void htkamd_model_destroy(htkamd_model *m);
+/* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */
+int  htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,
+                             const float *compWeight, const float *transP);
+/* Read back the prepared device-side values (test/debug aid): each may be NULL. */
+int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gconst /*[G]*/,
+                               float *compLogWt /*[C]*/, int *minDur /*[nT]*/);
+
+/* ------------------------------------------------------------------------------------------
+ * GMM scoring: replaces the state output-probability calls
+ *     LogFloat OutP(Observation*,HLink,int)  HModel.h:560 / POutP :561 / SOutP :567 /
+ *     MOutP, IDOutP :577-578, and the per-tool caching wrappers ShStrP (HFB.c:898) and
+ *     cSOutP/cPOutP (HRec.c:438,512)
+ * with one batched call: scores of `ns` tied states for T frames.
+ *   dX      device [T*D] row-major feature matrix (Observation.fv[1][1..D] per frame)
+ *   dStates device [ns] tied-state indices
+ *   dOut    device [ns*ldo]: dOut[k*ldo + t] = log b_{states[k]}(x_t),  ldo >= T
+ * Arithmetic = ShStrP/cSOutP: float Mahalanobis sum in dimension order, mixture log-sum with the
+ * double-precision LAdd (HMath.c:1576) re-rounded to float after every component: results are
+ * bit-identical to the reference.
+ * ------------------------------------------------------------------------------------------ */
+int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
+                      float *dOut, int ldo, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Baum-Welch accumulators: MuAcc / VaAcc / WtAcc / TrAcc of HTrain.h:211-232 plus the
+ * per-model example counters (hmm->hook, HFB.c:1768-1772) and HERest's totals
+ * (totalPr, totalT: HERest.c:779-780), kept on the device as ONE flat vector of doubles so
+ * that the parallel-mode merge (HERest -p N dump + -p 0 load: HTrain.c:1453,1625) is a single
+ * sum all-reduce over that vector.
+ * Vector layout (offsets via htkamd_accs_layout):
+ *   mu[G*D] muOcc[G] va[G*D] vaOcc[G] wt[C] wtOcc[S] tr[transOff[nT]] trOcc[sum N] nEgs[H]
+ *   totalPr totalT nUttDone nUttSkipped nEval
+ * ------------------------------------------------------------------------------------------ */
+typedef struct htkamd_accs htkamd_accs;
+typedef struct {
+   size_t mu, muOcc, va, vaOcc, wt, wtOcc, tr, trOcc, nEgs, totalPr, totalT, nUttDone, nUttSkipped, nEval;
+   size_t total;              /* number of doubles */
+} htkamd_accs_layout;
+
+int  htkamd_accs_create(htkamd_model *m, htkamd_accs **out);
+void htkamd_accs_destroy(htkamd_accs *a);
+int  htkamd_accs_zero(htkamd_accs *a, void *stream);                          /* ZeroAccs HTrain.c */
+int  htkamd_accs_get_layout(const htkamd_accs *a, htkamd_accs_layout *out);
+int  htkamd_accs_device_vector(htkamd_accs *a, double **dVec, size_t *n);      /* for the all-reduce */
+int  htkamd_accs_download(htkamd_accs *a, double *hostVec /*[layout.total]*/, void *stream);
+int  htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream); /* LoadAccs: adds */
+
+/* ------------------------------------------------------------------------------------------
+ * Forward-backward over a batch of utterances: replaces, per utterance,
+ *     Boolean FBFile(FBInfo*, UttInfo*, char *datafn)          HFB.h:143 / HFB.c:1923
+ * i.e. StepBack (SetBeamTaper, Setotprob, SetBeta with the beta beam and its retry loop) and
+ * StepForward (StepAlpha with the alpha beam, SetOcct, UpMixParms, UpTranParms).
+ * The label sequence of an utterance is the list of physical-HMM indices CreateInsts
+ * (HFB.c:508) derives from the transcription.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+   double pruneInit, pruneInc, pruneLim;   /* HERest -t f [i l]; HTKAMD_NOPRUNE = off (HERest.c:121-123) */
+   float  minFrwdP;                        /* HFB MINFORPROB / HERest -c, default 10.0 (HFB.c:83)        */
+   int    uFlags;                          /* HTKAMD_UP* bits                                            */
+} htkamd_fb_config;
+
+typedef struct {
+   int          nUtt;
+   const float *dX;          /* device [frameOff[nUtt]*D] all utterances' frames, row-major  */
+   const int   *frameOff;    /* host [nUtt+1]                                               */
+   const int   *labOff;      /* host [nUtt+1]                                               */
+   const int   *labs;        /* host [labOff[nUtt]] physical HMM index of each label        */
+} htkamd_batch_desc;
+
+/* per-utterance status values */
+#define HTKAMD_UTT_OK        1
+#define HTKAMD_UTT_SKIPPED   0        /* HError -7324: no path / qt > T (HFB.c:1339-1356)   */
+#define HTKAMD_UTT_ETEE     (-7332)   /* tee-model placement (HFB.c:557,564)                */
+#define HTKAMD_UTT_EALPHA   (-7390)   /* alpha prune failed (HFB.c:706,718)                 */
+
+typedef struct htkamd_fb htkamd_fb;
+
+int  htkamd_fb_create(htkamd_model *m, htkamd_fb **out);
+void htkamd_fb_destroy(htkamd_fb *fb);
+/* Keep every alpha column (test aid, T*cells doubles more per utterance); call before prepare. */
+int  htkamd_fb_set_debug(htkamd_fb *fb, int on);
+/* Host part of CreateInsts/SetBeamTaper for the whole batch + upload of the chain tables. */
+int  htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *batch, void *stream);
+/* Device part: scores, beta pass, alpha pass + statistics into `accs`. Asynchronous on `stream`. */
+int  htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream);
+/* Waits for the stream and copies per-utterance log-probabilities (utt->pr) and status. */
+int  htkamd_fb_results(htkamd_fb *fb, double *pr /*[nUtt]*/, int *status /*[nUtt]*/, void *stream);
+/* Number of (frame, chain-state) output-probability evaluations the reference would perform
+   for the prepared batch without pruning (Setotprob visits) -- the unit of the throughput metric. */
+long long htkamd_fb_frame_states(const htkamd_fb *fb);
+/* Debug/test access to one utterance's trellis after execute (device -> host copies):
+   beta/alpha [T*Q*maxN] (NaN where the reference holds no vector), outp [T*Q*maxN], beams [T]. */
+int  htkamd_fb_get_trellis(htkamd_fb *fb, int utt, double *beta, double *alpha, float *outp,
+                           int *qLo, int *qHi, int *aLo, int *aHi, int *T, int *Q, int *maxN, void *stream);
+/* Seconds spent in the kernels of the last execute, measured with HIP events on `stream`:
+   out[0]=scoring out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics. Synchronises. */
+int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

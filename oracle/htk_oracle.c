@@ -737,6 +737,25 @@ void orc_update(const orc_model *m, const orc_accs *acc, const orc_updcfg *cfg,
       int M = m->stateCompOff[i + 1] - m->stateCompOff[i];
       if (M > maxM) maxM = M;
    }
+   if (cfg->singleProcess) {
+      /* HERest.c:1336-1339: the set is INVDIAGC with log weights at this point; ForceDiagC (HUtil.c:441)
+         inverts the inverse variances again and ConvExpWt (HUtil.c:488) exponentiates the float log weights,
+         so parameters that are NOT re-estimated come back through a float round trip. */
+      size_t n = (size_t)m->G * D, z;
+      for (z = 0; z < n; z++) {
+         float v = var[z], iv;
+         if (v > 1E+30) v = 1E+30;
+         if (v < 1E-30) v = 1E-30;
+         iv = 1 / v;
+         if (iv > 1E+30) iv = 1E+30;
+         if (iv < 1E-30) iv = 1E-30;
+         var[z] = 1 / iv;
+      }
+      for (c = 0; c < m->C; c++) {
+         float lw = orc_mix_log_weight(compWeight[c]);
+         compWeight[c] = exp(lw);
+      }
+   }
    for (h = 0; h < m->H; h++) {
       int n = acc->nEgs[h], ti = m->hmmTrans[h], N = m->transN[ti];
       if (n < cfg->minEgs) st->nSkippedHmm++;

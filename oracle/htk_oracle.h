@@ -114,6 +114,7 @@ typedef struct {
    float minVar;              /* -v, HERest.c:95 default 0.0 */
    float mixWeightFloor;      /* -w f  => f*MINMIX, HERest.c:425 */
    int   uFlags;
+   int   singleProcess;       /* parMode == -1: ForceDiagC + ConvExpWt round trips first (HERest.c:1336-1339) */
 } orc_updcfg;
 typedef struct {
    int nFloorVar, nFloorVarMix;  /* HERest.c:791-792 */

@@ -82,7 +82,8 @@ class CFbDump(C.Structure):
 
 
 class CUpdCfg(C.Structure):
-    _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int)]
+    _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int),
+                ("singleProcess", C.c_int)]
 
 
 class CUpdStats(C.Structure):
@@ -182,9 +183,9 @@ def fb_utt(m: Model, cfg: CFbCfg, X: np.ndarray, labs: np.ndarray, acc: Accs, du
     return rc, pr.value, d
 
 
-def update(m: Model, acc: Accs, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL):
+def update(m: Model, acc: Accs, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False):
     """MLUpdateModels (HERest.c:1262) in place on m.mean / m.var / m.gconst / m.compWeight / m.transP."""
-    cfg = CUpdCfg(minEgs, minVar, mixWeightFloor, uFlags)
+    cfg = CUpdCfg(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess))
     st = CUpdStats()
     lib().orc_update(C.byref(m.c), C.byref(acc.c), C.byref(cfg), _p(m.mean), _p(m.var), _p(m.gconst),
                      _p(m.compWeight), _p(m.transP), C.byref(st))
