@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- HERest hot path (GMM scoring -> forward-backward -> statistics -> accumulator all-reduce)
+on the configuration BASELINE.json's metric is quoted on: 5k tied states x 16 mixtures, 39-dim features,
+500-frame synthetic utterances; config[2] sharded 8-way = 1250 utterances per GPU (weak scaling: every rank
+processes its own 1250-utterance shard, the accumulator vector is summed with RCCL once per pass).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A step = one embedded Baum-Welch pass over the rank's shard with the features already resident in HBM:
+CreateInsts/beam taper on the host, K1 scoring, K2 beta, K3 alpha + occupation/transition statistics,
+K4 mixture statistics, all-reduce(sum) of the fp64 accumulator vector, per-utterance results read back.
+PyTorch is used for device memory, the stream, the barrier and torch.distributed (backend nccl = RCCL);
+everything numeric is the HIP library behind include/htk_amd.h.
+
+One JSON line is printed by rank 0 (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
+FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
+
+
+def cpu_baseline(s, pk, budget_s: float):
+    """Oracle (CPU restatement of the reference, oracle/htk_oracle.c) timed on one host core over a bounded
+    sample of the same workload.  Reported, never the thing measured as `value`."""
+    from oracle import pyoracle as po
+    om = po.Model(pk)
+    acc = po.Accs(om)
+    cfg = po.fb_cfg()
+    n, nev, t0 = 0, 0, time.perf_counter()
+    lib = po.lib()
+    import ctypes as C
+    while n < len(s.feats):
+        rc, pr, _ = po.fb_utt(om, cfg, s.feats[n], s.seqs[n], acc)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return n, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--states", type=int, default=5000)
+    ap.add_argument("--mix", type=int, default=16)
+    ap.add_argument("--phones", type=int, default=6000)
+    ap.add_argument("--utts", type=int, default=1250, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from htk_amd import synth, capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world), file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    capi.check(capi.lib().htkamd_set_device(local_rank), "set_device")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    D = 39
+    # same model on every rank (model_seed), a different 1250-utterance shard per rank (seed)
+    s = synth.generate_fast(args.states, args.mix, args.phones, args.utts, args.frames, seed=1000 + rank, model_seed=3)
+    pk = s.packed()
+    model = capi.Model(pk)
+    accs = capi.Accs(model)
+    fb = capi.ForwardBackward(model)
+    cfg = capi.fb_config()                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
+
+    X = np.concatenate(s.feats)
+    frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in s.feats])]).astype(np.int32)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)
+    labs = np.concatenate(s.seqs).astype(np.int32)
+    dX = torch.from_numpy(X).cuda()                      # features resident in HBM before the timed region
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    vec_ptr, vec_n = accs.device_vector()
+    # a torch view of the accumulator vector for the collective (no copy)
+    acc_t = None
+    if world > 1:
+        class _Wrap:
+            pass
+        w = _Wrap()
+        w.__cuda_array_interface__ = {"shape": (vec_n,), "typestr": "<f8", "data": (vec_ptr, False), "version": 2}
+        acc_t = torch.as_tensor(w, device=torch.device("cuda", local_rank))
+
+    def step():
+        accs.zero(sptr)
+        fb.prepare(dX.data_ptr(), frameOff, labOff, labs, sptr)
+        fb.execute(cfg, accs, sptr)
+        if world > 1:
+            dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)
+        return fb.results(sptr)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ktimes = np.zeros(4)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pr, st = step()
+        ktimes += np.array(fb.kernel_times())
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ktimes /= max(args.steps, 1)
+
+    a = accs.download()
+    n_ok_local = int((st == capi.UTT_OK).sum())
+    units_local = fb.frame_states()                      # (frame, chain state) evaluations of this rank's shard
+    units_total = float(a["nEval"]) if world > 1 else float(units_local)
+    utts_total = float(a["nUttDone"])
+    value = units_total * args.steps / dt
+
+    if rank == 0:
+        flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
+        k1 = float(ktimes[0])
+        achieved = units_local * flop_unit / k1 / 1e12 if k1 > 0 else 0.0
+        out = {
+            "metric": "herest_gmm_frame_state_loglik_per_sec",
+            "value": value,
+            "unit": "frame-state log-lik/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "HERest pass, %d tied states x %d mix, D=39, %d x %d-frame utterances per GPU "
+                                   "(BASELINE config[2]: 10k utterances sharded 8-way)" % (args.states, args.mix, args.utts, args.frames),
+                       "states": args.states, "mix": args.mix, "utts_per_gpu": args.utts, "frames": args.frames,
+                       "parallelism": "utterance shards, 1 all-reduce of %d fp64 accumulators per pass" % vec_n},
+            "herest_utterances_per_sec": utts_total * args.steps / dt,
+            "utterances_ok": utts_total,
+            "avg_logprob_per_frame": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
+            "kernel_ms": {"score": ktimes[0] * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
+            "roofline": {"bound": "mfma", "kernel": "k_score_exact<39,2>", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_unit": flop_unit, "units_per_launch": units_local},
+        }
+        if args.cpu_seconds > 0:
+            n, cdt = cpu_baseline(s, pk, args.cpu_seconds)
+            per_utt = units_local / max(len(s.feats), 1)
+            out["cpu_baseline"] = {"value": n * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",
+                                   "utterances_per_sec": n / cdt,
+                                   "sample": "%d utterances of the same shard through oracle/htk_oracle.c (scalar C restatement of "
+                                             "HFB/HModel, bit-exact vs the reference), %.1f s on one host core" % (n, cdt)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,3 +180,41 @@ def generate(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39,
     if outdir:
         scp.close()
     return s
+
+
+def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39, model_seed: int | None = None) -> SynthSet:
+    """Vectorised variant for large workloads (bench.py): same model distribution and utterance structure as
+    generate() (Q = T//12 models per utterance, equal thirds per state, frames drawn from the aligned state's
+    GMM) but bulk random draws, no files and no MMF-precision round trip.  `model_seed` fixes the model
+    independently of the utterance seed so that every rank of a sharded run holds the same HMM set."""
+    mrng = np.random.default_rng(seed if model_seed is None else model_seed)
+    means = mrng.normal(0, 3, size=(NS, M, D)).astype(np.float32)
+    var = mrng.uniform(0.5, 2.0, size=(NS, M, D)).astype(np.float32)
+    w = mrng.dirichlet(np.ones(M) * 5, size=NS).astype(np.float32)
+    st = mrng.integers(0, NS, size=(NP, 3))
+    flat = st.reshape(-1)
+    k = min(NS, flat.size)
+    flat[:k] = mrng.permutation(NS)[:k]
+    st = flat.reshape(NP, 3).astype(np.int32)
+    s = SynthSet(D=D, NS=NS, M=M, NP=NP, means=means, var=var, w=w, st=st)
+    rng = np.random.default_rng([seed, 1])
+    Q = max(1, T // 12)
+    per = T // Q
+    # frame -> (model position, state) map shared by all utterances
+    qpos, spos = [], []
+    for q in range(Q):
+        n = per if q < Q - 1 else T - per * (Q - 1)
+        for j in range(3):
+            nj = n // 3 if j < 2 else n - 2 * (n // 3)
+            qpos += [q] * nj
+            spos += [j] * nj
+    qpos = np.array(qpos); spos = np.array(spos)
+    seqs = rng.integers(0, NP, size=(NU, Q))
+    sd = np.sqrt(var)
+    for u in range(NU):
+        states = st[seqs[u][qpos], spos]                      # [T]
+        ms = rng.integers(0, M, size=T)
+        X = means[states, ms] + rng.standard_normal((T, D), dtype=np.float32) * sd[states, ms]
+        s.seqs.append(seqs[u].astype(np.int32))
+        s.feats.append(X.astype(np.float32))
+    return s
