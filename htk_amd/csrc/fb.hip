@@ -44,7 +44,7 @@ struct htkamd_fb {
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
-   DevBuf d_transOff, d_trOccOff;
+   DevBuf d_transOff, d_trOccOff, d_counter;
    hipEvent_t ev[5];
    bool evValid, timed;
 };
@@ -62,7 +62,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    }
    fb->evValid = true;
    int rc;
-   if ((rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { delete fb; return rc; }
+   if ((rc = fb->d_counter.reserve(64)) || (rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { delete fb; return rc; }
    HIPCHECK(hipMemcpy(fb->d_transOff.p, m->h_transOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice));
    HIPCHECK(hipMemcpy(fb->d_trOccOff.p, m->h_trOccOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice));
    *out = fb;
@@ -75,7 +75,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff};
+                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter};
    for (DevBuf *b : all) b->release();
    if (fb->evValid) for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]);
    delete fb;
@@ -116,6 +116,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    fb->nCellsMax = 1; fb->QMax = 1;
    fb->frameStates = 0;
    size_t outp = 0, beta = 0, gam = 0;
+   std::vector<int> evLo, evHi, slotModel;
    for (int u = 0; u < U; u++) {
       UttDesc &d = fb->utt[u];
       const int T = b->frameOff[u + 1] - b->frameOff[u], Q = b->labOff[u + 1] - b->labOff[u];
@@ -165,34 +166,54 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
             lo[t] = (short)q; i++;
          }
       }
-      // output-probability evaluations of the un-pruned pass (Setotprob ranges, HFB.c:1177,1215 + 1014)
+      // Setotprob ranges of the un-pruned pass (HFB.c:1177,1215 + 1014): models evLo[t]..evHi[t] are scored at t.
+      // They bound what any pass can touch (pruning only narrows them) and give the metric's unit count.
+      evLo.assign(T + 2, 0); evHi.assign(T + 2, 0);
       {
          const long long before = fb->frameStates;
          int qHiN = Q, qLoN = lo[T];
          const int *msl = fb->mSlot0.data() + d.q0 - 1;
          auto slotsIn = [&](int a, int z) { return (z < Q ? msl[z + 1] : nSlots) - msl[a]; };
-         fb->frameStates += slotsIn(qLoN > 1 ? qLoN - 1 : 1, Q);
+         evLo[T] = qLoN > 1 ? qLoN - 1 : 1; evHi[T] = Q;
+         fb->frameStates += slotsIn(evLo[T], Q);
          for (int t = T - 1; t >= 1; t--) {
             const int startq = qHiN;
             int endq = (qLoN == 1) ? 1 : ((lo[t] >= qLoN) ? lo[t] : qLoN - 1);
             while (endq > 1 && dms[endq - 1] == 0) endq--;
-            fb->frameStates += slotsIn(endq > 1 ? endq - 1 : 1, startq);
+            evLo[t] = endq > 1 ? endq - 1 : 1; evHi[t] = startq;
+            fb->frameStates += slotsIn(evLo[t], startq);
             qHiN = (hi[t] < startq) ? hi[t] : startq; qLoN = endq;
          }
          d.nEval = (int)(fb->frameStates - before);
       }
-      // scoring tasks: tiles of frames x chunks of chain states
-      for (int t0 = 0; t0 < T; t0 += SCORE_TILE_FRAMES)
-         for (int k0 = 0; k0 < nSlots; k0 += SCORE_TASK_SLOTS) {
-            ScoreTask tk;
-            tk.frame0 = d.frame0 + t0;
-            tk.nFrames = (T - t0 < SCORE_TILE_FRAMES) ? T - t0 : SCORE_TILE_FRAMES;
-            tk.slot0 = d.slot0 + k0;
-            tk.nSlots = (nSlots - k0 < SCORE_TASK_SLOTS) ? nSlots - k0 : SCORE_TASK_SLOTS;
-            tk.outSlot0 = k0; tk.ldo = T;
-            tk.outBase = d.outp0 + (size_t)t0;
-            fb->tasks.push_back(tk);
+      // scoring tasks: chunks of chain states x tiles of the frames in which the chunk can be in the beam
+      {
+         const short *cq = fb->cQ.data() + d.cell0;
+         (void)cq;
+         // model of every slot
+         slotModel.resize(nSlots);
+         for (int q = 1; q <= Q; q++) {
+            const int s0 = fb->mSlot0[d.q0 + q - 1], n = fb->mN[d.q0 + q - 1] - 2;
+            for (int j = 0; j < n; j++) slotModel[s0 + j] = q;
          }
+         for (int k0 = 0; k0 < nSlots; k0 += SCORE_TASK_SLOTS) {
+            const int k1 = (k0 + SCORE_TASK_SLOTS < nSlots) ? k0 + SCORE_TASK_SLOTS : nSlots;
+            const int qa = slotModel[k0], qb = slotModel[k1 - 1];
+            int tmin = 1, tmax = T;
+            while (tmin <= T && evHi[tmin] < qa) tmin++;
+            while (tmax >= 1 && evLo[tmax] > qb) tmax--;
+            for (int t0 = tmin - 1; t0 < tmax; t0 += SCORE_TILE_FRAMES) {
+               ScoreTask tk;
+               tk.frame0 = d.frame0 + t0;
+               tk.nFrames = (tmax - t0 < SCORE_TILE_FRAMES) ? tmax - t0 : SCORE_TILE_FRAMES;
+               tk.slot0 = d.slot0 + k0;
+               tk.nSlots = k1 - k0;
+               tk.outSlot0 = k0; tk.ldo = T;
+               tk.outBase = d.outp0 + (size_t)t0;
+               fb->tasks.push_back(tk);
+            }
+         }
+      }
    }
    fb->gamOff[U] = gam;
    fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
@@ -234,6 +255,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.slotState = (const int *)fb->d_slotState.p; sa.out = (float *)fb->d_outp.p;
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
+   sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
 
    FbArgs fa;
    memset(&fa, 0, sizeof(fa));

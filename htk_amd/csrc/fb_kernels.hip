@@ -543,10 +543,10 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
                   const float wt = a.compLogWt[c0 + m];
                   if (wt > (float)LMINMIX) {
                      const float *P = a.gparam + (size_t)a.compGauss[c0 + m] * a.PS;
-                     float sum = P[0];
+                     float sum = P[2 * D];
                      for (int i = 0; i < D; i++) {
-                        const float xmm = xrow[i] - P[1 + 2 * i];
-                        sum += xmm * xmm * P[2 + 2 * i];
+                        const float xmm = xrow[i] - P[2 * i];
+                        sum += xmm * xmm * P[2 * i + 1];
                      }
                      const float prob = -0.5f * sum;
                      const double x = (seed + (double)wt) + (double)prob;

@@ -5,99 +5,101 @@
 //     sum = gConst; for i: xmm = x[i]-mean[i]; sum += xmm*xmm*ivar[i];   (float, in order, no FMA)
 //     mixp = -0.5*sum;  x = LAdd(x, wt+mixp)   (float add; LAdd in double, HMath.c:1576; stored to float)
 //
-// MI355X mapping.  Lanes are FRAMES, the Gaussian is wave-uniform: one wave owns a tile of
-// 64*FPL frames of one utterance, keeps those feature vectors in VGPRs (D*FPL registers) and
-// walks over the tied states of its task.  Because the state/component/Gaussian indices are
-// wave-uniform, the parameter table (gconst, then interleaved mean/ivar pairs, 16-byte aligned
-// rows) is fetched with scalar loads (s_load_dwordx8/x16 through the scalar cache) and used as
-// SGPR operands of v_sub/v_mul/v_mul/v_add: no LDS, no VGPR traffic for parameters, and every
-// byte of the feature matrix is read from HBM once per task (coalesced 64*D*4-byte tile).
-// Output is state-major (out[slot*ldo + t]) so that the 64 lanes store 256 contiguous bytes.
+// MI355X mapping.  Lanes are FRAMES, the Gaussian is wave-uniform.  One wave owns a tile of 128 frames
+// of one utterance and keeps those feature vectors in VGPRs as float2 {frame lane, frame lane+64}, so
+// the inner loop is four PACKED FP32 instructions per dimension and Gaussian (v_pk_add, v_pk_mul,
+// v_pk_mul, v_pk_add -- gfx950 reaches its FP32 vector rate only with packed instructions; measured
+// 75.8 vs 38.5 Tlane-op/s, tools/ubench/valu_rate.hip) with every rounding the reference performs.
+// The state/component/Gaussian indices are wave-uniform, so the parameter row ((mean,ivar) pairs,
+// 8-byte aligned, then gConst) is fetched with scalar loads through the constant address space and
+// feeds the packed instructions as an SGPR pair: no LDS, no VGPRs and no vector-memory traffic for
+// parameters.  The mixture log-sum uses the LDS-resident LAdd table (ladd.h).  Tasks (frame tile x
+// chunk of chain states, clipped to the utterance's beam) are pulled from a global counter by
+// persistent waves, so ragged utterances balance across the 256 CUs.  Output is state-major
+// (out[slot*ldo + t]): 64 lanes store 256 contiguous bytes.
 //
-// Algorithmic work: M*(4*D+8) flop per (frame,state); VALU bound.
+// Algorithmic work: M*(4*D+8) flop per (frame,state); VALU (packed FP32) bound.
 #include <hip/hip_runtime.h>
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
+#include "ladd.h"
 
-__device__ __forceinline__ double dev_ladd(double x, double y, double minLogExp)
-{
-   if (x < y) { double t = x; x = y; y = t; }
-   double diff = y - x;
-   if (diff < minLogExp) return (x < LSMALL) ? LZERO : x;
-   return x + log(1.0 + exp(diff));
-}
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float cfloat;    // constant address space -> s_load
+typedef const __attribute__((address_space(4))) int cint;
 
-template <int D, int FPL>
+template <int D>
 __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
 {
+   __shared__ double tab[LADD_TAB_DOUBLES];
+   ladd_table_to_lds(tab, a.laddTab);
+   __syncthreads();
    const int lane = threadIdx.x & 63;
-   const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-   if (task >= a.nTasks) return;
-   const ScoreTask tk = a.tasks[task];
+   const double mle = a.minLogExp;
+   cint *slotState = (cint *)a.slotState;
+   cint *stateCompOff = (cint *)a.stateCompOff;
+   cint *compGauss = (cint *)a.compGauss;
+   cfloat *compLogWt = (cfloat *)a.compLogWt;
 
-   float x[FPL][D];
-#pragma unroll
-   for (int f = 0; f < FPL; f++) {
-      int t = lane + 64 * f;
-      if (t > tk.nFrames - 1) t = tk.nFrames - 1;
-      const float *row = a.X + (size_t)(tk.frame0 + t) * D;
-#pragma unroll
-      for (int i = 0; i < D; i++) x[f][i] = row[i];
-   }
+   for (;;) {
+      int task = 0;
+      if (lane == 0) task = atomicAdd(a.taskCounter, 1);
+      task = __builtin_amdgcn_readfirstlane(task);
+      if (task >= a.nTasks) break;
+      const ScoreTask tk = a.tasks[task];
 
-   for (int k = 0; k < tk.nSlots; k++) {
-      const int s = a.slotState[tk.slot0 + k];
-      const int c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
-      float acc[FPL];
-      if (c1 - c0 == 1) {                       // single Gaussian: no weight, no LAdd (HFB.c:917-928)
-         const float *P = a.gparam + (size_t)a.compGauss[c0] * a.PS;
-         float sum[FPL];
+      v2f x[D];
+      {
+         int t0 = lane, t1 = lane + 64;
+         if (t0 > tk.nFrames - 1) t0 = tk.nFrames - 1;
+         if (t1 > tk.nFrames - 1) t1 = tk.nFrames - 1;
+         const float *r0 = a.X + (size_t)(tk.frame0 + t0) * D;
+         const float *r1 = a.X + (size_t)(tk.frame0 + t1) * D;
 #pragma unroll
-         for (int f = 0; f < FPL; f++) sum[f] = P[0];
-#pragma unroll
-         for (int i = 0; i < D; i++) {
-            const float mu = P[1 + 2 * i], iv = P[2 + 2 * i];
-#pragma unroll
-            for (int f = 0; f < FPL; f++) {
-               float xmm = x[f][i] - mu;
-               sum[f] += xmm * xmm * iv;
-            }
-         }
-#pragma unroll
-         for (int f = 0; f < FPL; f++) acc[f] = -0.5f * sum[f];
-      } else {
-#pragma unroll
-         for (int f = 0; f < FPL; f++) acc[f] = (float)LZERO;
-         for (int c = c0; c < c1; c++) {
-            const float wt = a.compLogWt[c];
-            if (wt > (float)LMINMIX) {          // wave-uniform branch
-               const float *P = a.gparam + (size_t)a.compGauss[c] * a.PS;
-               float sum[FPL];
-#pragma unroll
-               for (int f = 0; f < FPL; f++) sum[f] = P[0];
-#pragma unroll
-               for (int i = 0; i < D; i++) {
-                  const float mu = P[1 + 2 * i], iv = P[2 + 2 * i];
-#pragma unroll
-                  for (int f = 0; f < FPL; f++) {
-                     float xmm = x[f][i] - mu;
-                     sum[f] += xmm * xmm * iv;
-                  }
-               }
-#pragma unroll
-               for (int f = 0; f < FPL; f++) {
-                  float mixp = -0.5f * sum[f];
-                  float y = wt + mixp;
-                  acc[f] = (float)dev_ladd((double)acc[f], (double)y, a.minLogExp);
-               }
-            }
-         }
+         for (int i = 0; i < D; i++) { x[i].x = r0[i]; x[i].y = r1[i]; }
       }
+
+      for (int k = 0; k < tk.nSlots; k++) {
+         const int s = slotState[tk.slot0 + k];
+         const int c0 = stateCompOff[s], c1 = stateCompOff[s + 1];
+         float acc0, acc1;
+         if (c1 - c0 == 1) {                    // single Gaussian: no weight, no LAdd (HFB.c:917-928)
+            cfloat *P = (cfloat *)(a.gparam + (size_t)compGauss[c0] * a.PS);
+            v2f sum = {P[2 * D], P[2 * D]};
 #pragma unroll
-      for (int f = 0; f < FPL; f++) {
-         int t = lane + 64 * f;
-         if (t < tk.nFrames) a.out[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + t] = acc[f];
+            for (int i = 0; i < D; i++) {
+               const float mu = P[2 * i], iv = P[2 * i + 1];
+               v2f xm = x[i] - mu;
+               xm = xm * xm;
+               xm = xm * iv;
+               sum = sum + xm;
+            }
+            acc0 = -0.5f * sum.x; acc1 = -0.5f * sum.y;
+         } else {
+            acc0 = (float)LZERO; acc1 = (float)LZERO;
+            for (int c = c0; c < c1; c++) {
+               const float wt = compLogWt[c];
+               if (wt > (float)LMINMIX) {       // wave-uniform branch
+                  cfloat *P = (cfloat *)(a.gparam + (size_t)compGauss[c] * a.PS);
+                  v2f sum = {P[2 * D], P[2 * D]};
+#pragma unroll
+                  for (int i = 0; i < D; i++) {
+                     const float mu = P[2 * i], iv = P[2 * i + 1];
+                     v2f xm = x[i] - mu;
+                     xm = xm * xm;
+                     xm = xm * iv;
+                     sum = sum + xm;
+                  }
+                  const v2f y = wt + (-0.5f * sum);
+                  acc0 = (float)ladd_tab((double)acc0, (double)y.x, mle, tab);
+                  acc1 = (float)ladd_tab((double)acc1, (double)y.y, mle, tab);
+               }
+            }
+         }
+         float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo;
+         if (lane < tk.nFrames) o[lane] = acc0;
+         if (lane + 64 < tk.nFrames) o[lane + 64] = acc1;
       }
    }
 }
@@ -105,37 +107,44 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
 // Any vector size: features are re-read from global memory per dimension (L1-resident rows).
 __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
 {
+   __shared__ double tab[LADD_TAB_DOUBLES];
+   ladd_table_to_lds(tab, a.laddTab);
+   __syncthreads();
    const int lane = threadIdx.x & 63;
-   const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-   if (task >= a.nTasks) return;
-   const ScoreTask tk = a.tasks[task];
    const int D = a.D;
-   for (int f = 0; f < 2; f++) {
-      int t = lane + 64 * f;
-      const bool live = t < tk.nFrames;
-      if (!live) t = tk.nFrames - 1;
-      const float *row = a.X + (size_t)(tk.frame0 + t) * D;
-      for (int k = 0; k < tk.nSlots; k++) {
-         const int s = a.slotState[tk.slot0 + k];
-         const int c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
-         float acc = (float)LZERO;
-         for (int c = c0; c < c1; c++) {
-            const float wt = a.compLogWt[c];
-            if (c1 - c0 > 1 && !(wt > (float)LMINMIX)) continue;
-            const float *P = a.gparam + (size_t)a.compGauss[c] * a.PS;
-            float sum = P[0];
-            for (int i = 0; i < D; i++) {
-               float xmm = row[i] - P[1 + 2 * i];
-               sum += xmm * xmm * P[2 + 2 * i];
+   for (;;) {
+      int task = 0;
+      if (lane == 0) task = atomicAdd(a.taskCounter, 1);
+      task = __builtin_amdgcn_readfirstlane(task);
+      if (task >= a.nTasks) break;
+      const ScoreTask tk = a.tasks[task];
+      for (int f = 0; f < 2; f++) {
+         int t = lane + 64 * f;
+         const bool live = t < tk.nFrames;
+         if (!live) t = tk.nFrames - 1;
+         const float *row = a.X + (size_t)(tk.frame0 + t) * D;
+         for (int k = 0; k < tk.nSlots; k++) {
+            const int s = a.slotState[tk.slot0 + k];
+            const int c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+            float acc = (float)LZERO;
+            for (int c = c0; c < c1; c++) {
+               const float wt = a.compLogWt[c];
+               if (c1 - c0 > 1 && !(wt > (float)LMINMIX)) continue;
+               const float *P = a.gparam + (size_t)a.compGauss[c] * a.PS;
+               float sum = P[2 * D];
+               for (int i = 0; i < D; i++) {
+                  float xmm = row[i] - P[2 * i];
+                  sum += xmm * xmm * P[2 * i + 1];
+               }
+               float mixp = -0.5f * sum;
+               if (c1 - c0 == 1) acc = mixp;
+               else {
+                  float y = wt + mixp;
+                  acc = (float)ladd_tab((double)acc, (double)y, a.minLogExp, tab);
+               }
             }
-            float mixp = -0.5f * sum;
-            if (c1 - c0 == 1) acc = mixp;
-            else {
-               float y = wt + mixp;
-               acc = (float)dev_ladd((double)acc, (double)y, a.minLogExp);
-            }
+            if (live) a.out[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + t] = acc;
          }
-         if (live) a.out[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + t] = acc;
       }
    }
 }
@@ -143,11 +152,14 @@ __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
 int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
-   dim3 grid((a.nTasks + 3) / 4), block(256);
+   HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
+   int blocks = (a.nTasks + 3) / 4;
+   if (blocks > 256 * 5) blocks = 256 * 5;      // persistent: up to 5 four-wave blocks per CU (VGPR-limited)
+   dim3 grid(blocks), block(256);
    switch (m->D) {
-   case 39: hipLaunchKernelGGL((k_score_exact<39, 2>), grid, block, 0, stream, a); break;
-   case 26: hipLaunchKernelGGL((k_score_exact<26, 2>), grid, block, 0, stream, a); break;
-   case 13: hipLaunchKernelGGL((k_score_exact<13, 2>), grid, block, 0, stream, a); break;
+   case 39: hipLaunchKernelGGL((k_score_exact<39>), grid, block, 0, stream, a); break;
+   case 26: hipLaunchKernelGGL((k_score_exact<26>), grid, block, 0, stream, a); break;
+   case 13: hipLaunchKernelGGL((k_score_exact<13>), grid, block, 0, stream, a); break;
    default: hipLaunchKernelGGL(k_score_exact_anyD, grid, block, 0, stream, a); break;
    }
    HIPCHECK(hipGetLastError());
@@ -180,13 +192,14 @@ extern "C" int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const 
          tk.ldo = ldo;
          tk.outBase = (size_t)ti * FR;
       }
-   ScoreTask *d = nullptr;
-   HIPCHECK(hipMalloc((void **)&d, sizeof(ScoreTask) * (size_t)nTasks));
+   char *d = nullptr;                            // task table followed by the queue head
+   HIPCHECK(hipMalloc((void **)&d, sizeof(ScoreTask) * (size_t)nTasks + sizeof(int)));
    HIPCHECK(hipMemcpyAsync(d, h, sizeof(ScoreTask) * (size_t)nTasks, hipMemcpyHostToDevice, s));
    ScoreArgs a;
-   a.tasks = d; a.nTasks = nTasks; a.X = dX; a.slotState = dStates; a.out = dOut;
+   a.tasks = (const ScoreTask *)d; a.nTasks = nTasks; a.X = dX; a.slotState = dStates; a.out = dOut;
    a.stateCompOff = m->d_stateCompOff; a.compGauss = m->d_compGauss; a.compLogWt = m->d_compLogWt;
    a.gparam = m->d_gparam; a.PS = m->PS; a.D = m->D; a.minLogExp = m->minLogExp;
+   a.laddTab = m->d_laddTab; a.taskCounter = (int *)(d + sizeof(ScoreTask) * (size_t)nTasks);
    int rc = htkamd_launch_score_exact(m, a, s);
    hipError_t e = hipStreamSynchronize(s);      // the task table is freed below
    free(h);

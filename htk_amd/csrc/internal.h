@@ -28,6 +28,13 @@ float  htkamd_host_mix_log_weight(float w);                                    /
 int    htkamd_host_min_dur(int N, const float *tp);                            /* HFB.c:106    */
 double htkamd_host_min_log_exp(void);                                          /* HMath.c:1680 */
 
+/* device LAdd table: 8 intervals per unit of d over [minLogExp, 0] = [-23.03, 0], degree-8 Taylor rows */
+#define LADD_INV_H 8
+#define LADD_DEG   8
+#define LADD_NK    186          /* ceil(23.0259 * 8) + 1 */
+int    htkamd_host_ladd_table_size(void);
+void   htkamd_host_build_ladd_table(double *tab);
+
 /* ---- packed model ---- */
 struct htkamd_model {
    int D, S, C, G, nT, H, maxN, maxM;
@@ -37,7 +44,8 @@ struct htkamd_model {
    int   *h_trOccOff;          /* [nT+1] prefix sum of transN */
    float *h_mean, *h_var, *h_ivar, *h_gconst, *h_compWeight, *h_compLogWt, *h_transP;
    /* device copies */
-   float *d_gparam;            /* [G*PS]: gconst, then (mean[i], ivar[i]) pairs */
+   float *d_gparam;            /* [G*PS]: (mean[i], ivar[i]) pairs, 8-byte aligned, then gconst at [2*D] */
+   double *d_laddTab;          /* [LADD_NK*(LADD_DEG+1)] */
    float *d_mean, *d_ivar, *d_gconst, *d_compLogWt, *d_transP;
    int   *d_stateCompOff, *d_compGauss, *d_transN, *d_transOff;
    double minLogExp;

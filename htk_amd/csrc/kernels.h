@@ -5,7 +5,7 @@
 #include "internal.h"
 
 #define SCORE_TILE_FRAMES 128   /* 64 lanes x 2 frames per lane */
-#define SCORE_TASK_SLOTS  32    /* tied states scored per task */
+#define SCORE_TASK_SLOTS  16    /* chain states scored per task */
 
 struct ScoreTask {
    int frame0;        // first row of the tile in X
@@ -27,6 +27,8 @@ struct ScoreArgs {
    const float *compLogWt, *gparam;
    int PS, D;
    double minLogExp;
+   const double *laddTab;
+   int *taskCounter;          // dynamic task queue head (zeroed before the launch)
 };
 
 int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream);

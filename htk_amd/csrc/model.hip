@@ -94,11 +94,11 @@ static int model_refresh(htkamd_model *m)
    float *gp = (float *)calloc((size_t)m->G * PS, sizeof(float));
    for (int g = 0; g < m->G; g++) {
       float *p = gp + (size_t)g * PS;
-      p[0] = m->h_gconst[g];
       for (int i = 0; i < D; i++) {
-         p[1 + 2 * i] = m->h_mean[(size_t)g * D + i];
-         p[2 + 2 * i] = m->h_ivar[(size_t)g * D + i];
+         p[2 * i] = m->h_mean[(size_t)g * D + i];
+         p[2 * i + 1] = m->h_ivar[(size_t)g * D + i];
       }
+      p[2 * D] = m->h_gconst[g];
    }
    int rc = toDevice(&m->d_gparam, gp, (size_t)m->G * PS);
    free(gp);
@@ -170,6 +170,14 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
        (rc = model_refresh(m))) {
       htkamd_model_destroy(m); return rc;
    }
+   {
+      const int n = htkamd_host_ladd_table_size();
+      double *tab = (double *)malloc(sizeof(double) * (size_t)n);
+      htkamd_host_build_ladd_table(tab);
+      rc = toDevice(&m->d_laddTab, tab, (size_t)n);
+      free(tab);
+      if (rc) { htkamd_model_destroy(m); return rc; }
+   }
    *out = m;
    return HTKAMD_OK;
 }
@@ -180,7 +188,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    free(m->h_stateCompOff); free(m->h_compGauss); free(m->h_transN); free(m->h_transOff); free(m->h_hmmTrans);
    free(m->h_hmmStateOff); free(m->h_hmmState); free(m->h_minDur); free(m->h_trOccOff);
    free(m->h_mean); free(m->h_var); free(m->h_ivar); free(m->h_gconst); free(m->h_compWeight); free(m->h_compLogWt); free(m->h_transP);
-   (void)hipFree(m->d_gparam); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
+   (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
    (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff);
    free(m);

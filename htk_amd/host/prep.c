@@ -84,3 +84,51 @@ int htkamd_host_min_dur(int N, const float *tp)
    free(rank); free(byRank); free(md);
    return res;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * Table for the device LAdd.  LAdd(x,y) = x + log(1 + exp(y-x)) (HMath.c:1576-1590) is evaluated
+ * on the device as x + f(d), d = y-x in [minLogExp, 0], f(d) = log1p(exp(d)), with f taken from a
+ * piecewise Taylor polynomial: interval k = (int)(-d*LADD_INV_H) has centre c_k = -(k+0.5)/LADD_INV_H
+ * and f(c_k + r) = sum_n tab[k][n] r^n, |r| <= 1/(2*LADD_INV_H).  With 8 intervals per unit and
+ * degree 8 the truncation error is below 1e-16, i.e. at the rounding level of the glibc
+ * exp()/log() pair the reference calls, so float-rounded results agree except when the double
+ * result sits within ~1e-16 of a float rounding boundary.
+ * Derivatives: f' = s, s = 1/(1+exp(-d));  f^(n+1) = (d/ds f^(n)) * s(1-s), polynomials in s.
+ * ------------------------------------------------------------------------------------------ */
+int htkamd_host_ladd_table_size(void) { return LADD_NK * (LADD_DEG + 1); }
+
+void htkamd_host_build_ladd_table(double *tab)
+{
+   /* polynomials P_n(s) with f^(n)(d) = P_n(s(d)), n = 1..LADD_DEG */
+   long double P[LADD_DEG + 1][LADD_DEG + 2];
+   int n, i, k;
+   for (n = 0; n <= LADD_DEG; n++)
+      for (i = 0; i <= LADD_DEG + 1; i++) P[n][i] = 0.0L;
+   P[1][1] = 1.0L;                                           /* f' = s */
+   for (n = 1; n < LADD_DEG; n++) {
+      /* P_{n+1} = P_n'(s) * (s - s^2) */
+      long double dP[LADD_DEG + 2];
+      for (i = 0; i <= LADD_DEG; i++) dP[i] = (i + 1) * P[n][i + 1];
+      dP[LADD_DEG + 1] = 0.0L;
+      for (i = 0; i <= LADD_DEG + 1; i++) {
+         long double v = 0.0L;
+         if (i >= 1) v += dP[i - 1];
+         if (i >= 2) v -= dP[i - 2];
+         P[n + 1][i] = v;
+      }
+   }
+   for (k = 0; k < LADD_NK; k++) {
+      long double c = -((long double)k + 0.5L) / (long double)LADD_INV_H;
+      long double s = 1.0L / (1.0L + expl(-c));
+      long double fact = 1.0L;
+      double *row = tab + (size_t)k * (LADD_DEG + 1);
+      row[0] = (double)log1pl(expl(c));
+      for (n = 1; n <= LADD_DEG; n++) {
+         long double v = 0.0L, sp = 1.0L;
+         fact *= n;
+         for (i = 0; i <= LADD_DEG + 1; i++) { v += P[n][i] * sp; sp *= s; }
+         row[n] = (double)(v / fact);
+      }
+   }
+}
