@@ -34,7 +34,7 @@ struct htkamd_fb {
    // host tables of the prepared batch
    std::vector<UttDesc> utt;
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
-   std::vector<short> cQ, cI, taperLo, taperHi;
+   std::vector<short> cQ, cI, taperLo, taperHi, thrCell;
    std::vector<ScoreTask> tasks;
    std::vector<size_t> gamOff;
    size_t outpTotal, betaTotal, gamTotal;
@@ -44,7 +44,7 @@ struct htkamd_fb {
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
-   DevBuf d_transOff, d_trOccOff, d_counter;
+   DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell;
    hipEvent_t ev[5];
    bool evValid, timed;
 };
@@ -75,7 +75,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter};
+                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell};
    for (DevBuf *b : all) b->release();
    if (fb->evValid) for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]);
    delete fb;
@@ -109,7 +109,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    fb->nUtt = U; fb->dX = b->dX;
    fb->utt.assign(U, UttDesc());
    fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
-   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear();
+   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->thrCell.clear();
+   int nThrMax = 64;
    fb->totalFrames = U ? b->frameOff[U] : 0;
    fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
    fb->gamOff.assign(U + 1, 0);
@@ -126,7 +127,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       d.status = HTKAMD_UTT_OK; d.nEval = 0;
       d.outp0 = outp; d.beta0 = beta; d.gam0 = gam;
       fb->gamOff[u] = gam;
-      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nCells = d.nSlots = 0; continue; }
+      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nCells = d.nSlots = 0; d.thr0 = (int)fb->thrCell.size(); d.nThr = 0; continue; }
       int nCells = 0, nSlots = 0, qt = 0, prevDm = 1;
       for (int q = 1; q <= Q; q++) {
          const int h = labs[q - 1];
@@ -143,7 +144,21 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       if (fb->mDms[d.q0] == 0 || fb->mDms[d.q0 + Q - 1] == 0) d.status = HTKAMD_UTT_ETEE;   // HFB.c:564
       if (d.status == HTKAMD_UTT_OK && qt > T) d.status = HTKAMD_UTT_SKIPPED;                 // HFB.c:1339
       d.nCells = nCells; d.nSlots = nSlots;
-      if (Q > 32000 || nCells > 1024) {
+      {  // thread map: entry cells | emitting cells | exit cells, each group padded to a multiple of 64
+         d.thr0 = (int)fb->thrCell.size();
+         for (int role = 0; role < 3; role++) {
+            for (int q = 1; q <= Q; q++) {
+               const int c0 = fb->mCell0[d.q0 + q - 1], N = fb->mN[d.q0 + q - 1];
+               if (role == 0) fb->thrCell.push_back((short)c0);
+               else if (role == 2) fb->thrCell.push_back((short)(c0 + N - 1));
+               else for (int i = 2; i < N; i++) fb->thrCell.push_back((short)(c0 + i - 1));
+            }
+            while ((fb->thrCell.size() - d.thr0) % 64) fb->thrCell.push_back((short)-1);
+         }
+         d.nThr = (int)fb->thrCell.size() - d.thr0;
+         if (d.nThr > nThrMax) nThrMax = d.nThr;
+      }
+      if (Q > 32000 || d.nThr > 1024) {
          htkamd_set_error("fb_prepare: utterance %d has %d model states; the device path handles up to 1024 per utterance", u, nCells);
          return HTKAMD_EINVAL;
       }
@@ -217,14 +232,13 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    }
    fb->gamOff[U] = gam;
    fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
-   fb->blockDim = ((fb->nCellsMax + 63) / 64) * 64;
-   if (fb->blockDim < 64) fb->blockDim = 64;
+   fb->blockDim = nThrMax;
 
    int rc;
    if ((rc = upload(fb->d_utt, fb->utt, s)) || (rc = upload(fb->d_mN, fb->mN, s)) || (rc = upload(fb->d_mTp, fb->mTp, s)) ||
        (rc = upload(fb->d_mCell0, fb->mCell0, s)) || (rc = upload(fb->d_mSlot0, fb->mSlot0, s)) || (rc = upload(fb->d_mDms, fb->mDms, s)) ||
        (rc = upload(fb->d_mHmm, fb->mHmm, s)) || (rc = upload(fb->d_mTrans, fb->mTrans, s)) || (rc = upload(fb->d_slotState, fb->slotState, s)) ||
-       (rc = upload(fb->d_cQ, fb->cQ, s)) || (rc = upload(fb->d_cI, fb->cI, s)) || (rc = upload(fb->d_taperLo, fb->taperLo, s)) ||
+       (rc = upload(fb->d_cQ, fb->cQ, s)) || (rc = upload(fb->d_thrCell, fb->thrCell, s)) || (rc = upload(fb->d_cI, fb->cI, s)) || (rc = upload(fb->d_taperLo, fb->taperLo, s)) ||
        (rc = upload(fb->d_taperHi, fb->taperHi, s)) || (rc = upload(fb->d_tasks, fb->tasks, s)) || (rc = upload(fb->d_gamOff, fb->gamOff, s)))
       return rc;
    const size_t nf = fb->totalFrames ? fb->totalFrames : 1;
@@ -263,7 +277,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.mN = (const int *)fb->d_mN.p; fa.mTp = (const int *)fb->d_mTp.p; fa.mCell0 = (const int *)fb->d_mCell0.p;
    fa.mSlot0 = (const int *)fb->d_mSlot0.p; fa.mDms = (const int *)fb->d_mDms.p; fa.mHmm = (const int *)fb->d_mHmm.p;
    fa.mTrans = (const int *)fb->d_mTrans.p;
-   fa.cQ = (const short *)fb->d_cQ.p; fa.cI = (const short *)fb->d_cI.p; fa.slotState = (const int *)fb->d_slotState.p;
+   fa.thrCell = (const short *)fb->d_thrCell.p; fa.cQ = (const short *)fb->d_cQ.p; fa.cI = (const short *)fb->d_cI.p; fa.slotState = (const int *)fb->d_slotState.p;
    fa.taperLo = (const short *)fb->d_taperLo.p; fa.taperHi = (const short *)fb->d_taperHi.p;
    fa.qLo = (short *)fb->d_qLo.p; fa.qHi = (short *)fb->d_qHi.p; fa.aLo = (short *)fb->d_aLo.p; fa.aHi = (short *)fb->d_aHi.p;
    fa.X = fb->dX; fa.transP = m->d_transP; fa.outp = (float *)fb->d_outp.p;
@@ -271,9 +285,9 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.pr = (double *)fb->d_pr.p; fa.status = (int *)fb->d_status.p;
    fa.stateCompOff = m->d_stateCompOff; fa.compGauss = m->d_compGauss;
    fa.transOff = (const int *)fb->d_transOff.p; fa.trOccOff = (const int *)fb->d_trOccOff.p;
-   fa.compLogWt = m->d_compLogWt; fa.gparam = m->d_gparam; fa.mean = m->d_mean;
+   fa.compLogWt = m->d_compLogWt; fa.gparam = m->d_gparam; fa.mean = m->d_mean; fa.laddTab = m->d_laddTab;
    fa.PS = m->PS; fa.D = m->D; fa.maxN = m->maxN; fa.maxM = m->maxM;
-   fa.nCellsMax = fb->blockDim; fa.QMax = fb->QMax;
+   fa.nCellsMax = fb->nCellsMax; fa.QMax = fb->QMax;
    fa.acc = accs->d_vec; fa.lay = accs->lay;
    fa.pruneInit = cfg->pruneInit; fa.pruneInc = cfg->pruneInc; fa.pruneLim = cfg->pruneLim;
    fa.minLogExp = m->minLogExp; fa.minFrwdP = cfg->minFrwdP; fa.uFlags = cfg->uFlags;
@@ -281,8 +295,9 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
 
    const size_t nc = fa.nCellsMax, qm = fa.QMax + 3, mn = m->maxN;
    auto r8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
-   const size_t ldsBeta = 2 * r8(nc * 8) + r8(qm * 8) + r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32);
-   const size_t ldsAlpha = 2 * r8(nc * 8) + r8(3 * nc * 8) + r8(qm * 8) + r8(nc * (mn + 1) * 8) + 2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32);
+   const size_t ldsTab = r8((size_t)LADD_NK * (LADD_DEG + 1) * 8);
+   const size_t ldsBeta = 2 * r8(nc * 8) + r8(qm * 8) + r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32) + ldsTab;
+   const size_t ldsAlpha = 2 * r8(nc * 8) + r8(3 * nc * 8) + r8(qm * 8) + r8(nc * (mn + 1) * 8) + 2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32) + ldsTab;
    if (ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
 
    int rc;

@@ -22,14 +22,15 @@
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
+#include "ladd.h"
 
-__device__ __forceinline__ double ladd(double x, double y, double minLogExp)
-{
-   if (x < y) { double t = x; x = y; y = t; }
-   double diff = y - x;
-   if (diff < minLogExp) return (x < LSMALL) ? LZERO : x;
-   return x + log(1.0 + exp(diff));
-}
+// every LAdd of the recursions goes through the LDS table (ladd.h); `ltab` is the block's copy
+#define ladd(x, y, mle) ladd_tab((x), (y), (mle), ltab)
+
+// SetOcct/UpTranParms add exp(x) whenever x > MINEARG (-708.3).  exp(-100) = 3.7e-44 is below the smallest float
+// increment the reference's float counters can register next to any real count, so the exponential is only
+// evaluated above this floor (saves ~30 fp64 instructions per skipped term in the sequential loop).
+#define EXPFLOOR (-100.0)
 
 struct CellMeta {
    int q, i, N, mc0, ms0;      // model (1-based), state (1..N), states in model, cell of state 1, slot of state 2
@@ -68,15 +69,20 @@ __global__ void k_beta(FbArgs a)
    int *mNq = lds.take<int>(QMax + 3);
    int *mDm = lds.take<int>(QMax + 3);
    int *sh = lds.take<int>(8);
+   double *ltab = lds.take<double>(LADD_TAB_DOUBLES);
+   ladd_table_to_lds(ltab, a.laddTab);
 
    CellMeta cm = {0, 0, 0, 0, 0};
-   const bool live = tid < nC;
+   // threads are grouped by role (entry | emitting | exit cells, each padded to whole waves) so that a wave
+   // executes one role's code path; c is this thread's cell in the q-major cell order used by the LDS columns
+   const int c = (tid < ud.nThr) ? (int)a.thrCell[ud.thr0 + tid] : -1;
+   const bool live = c >= 0;
    if (live) {
-      cm.q = a.cQ[ud.cell0 + tid]; cm.i = a.cI[ud.cell0 + tid];
+      cm.q = a.cQ[ud.cell0 + c]; cm.i = a.cI[ud.cell0 + c];
       const int mi = ud.q0 + cm.q - 1;
       cm.N = a.mN[mi]; cm.mc0 = a.mCell0[mi]; cm.ms0 = a.mSlot0[mi];
       const float *tp = a.transP + a.mTp[mi];
-      for (int j = 1; j <= cm.N; j++) trow[tid * maxN + (j - 1)] = tp[(cm.i - 1) * cm.N + (j - 1)];
+      for (int j = 1; j <= cm.N; j++) trow[c * maxN + (j - 1)] = tp[(cm.i - 1) * cm.N + (j - 1)];
    }
    for (int q = tid + 1; q <= Q; q += blockDim.x) {
       const int mi = ud.q0 + q - 1, N = a.mN[mi];
@@ -109,19 +115,19 @@ __global__ void k_beta(FbArgs a)
       }
       __syncthreads();
       if (live && cm.q >= endq && cm.i > 1 && cm.i < cm.N)
-         colC[tid] = (double)trow[tid * maxN + cm.N - 1] + colC[cm.mc0 + cm.N - 1];
+         colC[c] = (double)trow[c * maxN + cm.N - 1] + colC[cm.mc0 + cm.N - 1];
       __syncthreads();
       if (live && cm.q >= endq && cm.i == 1) {
          double x = LZERO;
          for (int j = 2; j < cm.N; j++) {
-            double aa = trow[tid * maxN + j - 1], y = colC[cm.mc0 + j - 1];
+            double aa = trow[c * maxN + j - 1], y = colC[cm.mc0 + j - 1];
             if (aa > LSMALL && y > LSMALL)
                x = ladd(x, aa + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (T - 1)] + y, mle);
          }
-         colC[tid] = x;
+         colC[c] = x;
       }
       __syncthreads();
-      if (live && cm.q >= endq) gbeta[(size_t)(T - 1) * nC + tid] = colC[tid];
+      if (live && cm.q >= endq) gbeta[(size_t)(T - 1) * nC + c] = colC[c];
       if (tid == 0) { gLo[T] = (short)endq; gHi[T] = (short)Q; }
       int qHiN = Q, qLoN = endq, lastEnd = endq;
 
@@ -145,28 +151,28 @@ __global__ void k_beta(FbArgs a)
                }
             }
             if (cm.i == cm.N)
-               colC[tid] = ex;
+               colC[c] = ex;
             else {
-               double x = (double)trow[tid * maxN + cm.N - 1] + ex;
+               double x = (double)trow[c * maxN + cm.N - 1] + ex;
                if (q >= qLoN && q <= qHiN)
                   for (int j = 2; j < cm.N; j++) {
-                     double aa = trow[tid * maxN + j - 1], y = colN[cm.mc0 + j - 1];
+                     double aa = trow[c * maxN + j - 1], y = colN[cm.mc0 + j - 1];
                      if (aa > LSMALL && y > LSMALL)
                         x = ladd(x, aa + (double)outp[(size_t)(cm.ms0 + j - 2) * T + t] + y, mle);   // b_j(t+1)
                   }
-               colC[tid] = x;
+               colC[c] = x;
             }
          }
          __syncthreads();
          if (inRange && cm.i == 1) {
             double x = LZERO, lMax = LZERO;
             for (int j = 2; j < cm.N; j++) {
-               double aa = trow[tid * maxN + j - 1], y = colC[cm.mc0 + j - 1];
+               double aa = trow[c * maxN + j - 1], y = colC[cm.mc0 + j - 1];
                if (y > lMax) lMax = y;
                if (aa > LSMALL && y > LSMALL)
                   x = ladd(x, aa + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (t - 1)] + y, mle);      // b_j(t)
             }
-            colC[tid] = x;
+            colC[c] = x;
             maxP[cm.q] = lMax;
          }
          __syncthreads();
@@ -195,7 +201,7 @@ __global__ void k_beta(FbArgs a)
             __syncthreads();
          }
          if (fail) break;
-         if (inRange) gbeta[(size_t)(t - 1) * nC + tid] = colC[tid];
+         if (inRange) gbeta[(size_t)(t - 1) * nC + c] = colC[c];
          if (tid == 0) { gLo[t] = (short)newLo; gHi[t] = (short)newHi; }
          qHiN = newHi; qLoN = newLo; lastEnd = endq;
       }
@@ -238,21 +244,24 @@ __global__ void k_alpha(FbArgs a)
    int *mNq = lds.take<int>(QMax + 3);
    int *mDm = lds.take<int>(QMax + 3);
    int *sh = lds.take<int>(8);
+   double *ltab = lds.take<double>(LADD_TAB_DOUBLES);
+   ladd_table_to_lds(ltab, a.laddTab);
 
    CellMeta cm = {0, 0, 0, 0, 0};
-   const bool live = tid < nC;
+   const int c = (tid < ud.nThr) ? (int)a.thrCell[ud.thr0 + tid] : -1;     // role-grouped threads, see k_beta
+   const bool live = c >= 0;
    int cM = 0, cHmm = 0, cTrans = 0;
    if (live) {
-      cm.q = a.cQ[ud.cell0 + tid]; cm.i = a.cI[ud.cell0 + tid];
+      cm.q = a.cQ[ud.cell0 + c]; cm.i = a.cI[ud.cell0 + c];
       const int mi = ud.q0 + cm.q - 1;
       cm.N = a.mN[mi]; cm.mc0 = a.mCell0[mi]; cm.ms0 = a.mSlot0[mi];
       cHmm = a.mHmm[mi]; cTrans = a.mTrans[mi];
       const float *tp = a.transP + a.mTp[mi];
       for (int j = 1; j <= cm.N; j++) {
-         trow[tid * maxN + (j - 1)] = tp[(cm.i - 1) * cm.N + (j - 1)];
-         tcol[tid * maxN + (j - 1)] = tp[(j - 1) * cm.N + (cm.i - 1)];
+         trow[c * maxN + (j - 1)] = tp[(cm.i - 1) * cm.N + (j - 1)];
+         tcol[c * maxN + (j - 1)] = tp[(j - 1) * cm.N + (cm.i - 1)];
       }
-      for (int j = 0; j <= maxN; j++) tacc[tid * (maxN + 1) + j] = 0.0;
+      for (int j = 0; j <= maxN; j++) tacc[c * (maxN + 1) + j] = 0.0;
       if (cm.i > 1 && cm.i < cm.N) {
          const int s = a.slotState[ud.slot0 + cm.ms0 + cm.i - 2];
          cM = a.stateCompOff[s + 1] - a.stateCompOff[s];
@@ -278,12 +287,13 @@ __global__ void k_alpha(FbArgs a)
 
    // beta columns 1 and 2 into the ring (column t lives in slot t % 3)
    if (live) {
-      { const int q = cm.q; if (q >= gLo[1] && q <= gHi[1]) bcol[(size_t)(1 % 3) * nCellsMax + tid] = gbeta[tid]; }
-      if (T >= 2) { const int q = cm.q; if (q >= gLo[2] && q <= gHi[2]) bcol[(size_t)(2 % 3) * nCellsMax + tid] = gbeta[(size_t)nC + tid]; }
+      { const int q = cm.q; if (q >= gLo[1] && q <= gHi[1]) bcol[(size_t)(1 % 3) * nCellsMax + c] = gbeta[c]; }
+      if (T >= 2) { const int q = cm.q; if (q >= gLo[2] && q <= gHi[2]) bcol[(size_t)(2 % 3) * nCellsMax + c] = gbeta[(size_t)nC + c]; }
    }
    double *aC = acol0, *aP = acol1;
    int sq = 1, eq = gHi[1];
    double occAcc = 0.0;
+   double xpre = LZERO;          // log sum_i alpha_i(t-1) a_ij (+ entry term) of this emitting cell, before b_j(t)
    int err = 0;
 
    // ---- t = 1: InitAlpha (HFB.c:616-651)
@@ -298,21 +308,22 @@ __global__ void k_alpha(FbArgs a)
    if (live && cm.i > 1 && cm.i < cm.N) {
       double v = LZERO;
       if (cm.q <= eq) {
-         const double aa = tcol[tid * maxN + 0];
-         if (aa > LSMALL) v = aC[cm.mc0] + aa + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + 0];
+         const double aa = tcol[c * maxN + 0];
+         xpre = aC[cm.mc0] + aa;
+         if (aa > LSMALL) v = xpre + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + 0];
       }
-      aC[tid] = v;
+      aC[c] = v;
    }
-   if (live && cm.q > eq && cm.i == 1) aC[tid] = LZERO;
+   if (live && cm.q > eq && cm.i == 1) aC[c] = LZERO;
    __syncthreads();
    if (live && cm.i == cm.N) {
       double x = LZERO;
       if (cm.q <= eq)
          for (int i = 2; i < cm.N; i++) {
-            const double aa = tcol[tid * maxN + i - 1];
+            const double aa = tcol[c * maxN + i - 1];
             if (aa > LSMALL) x = ladd(x, aC[cm.mc0 + i - 1] + aa, mle);
          }
-      aC[tid] = x;
+      aC[c] = x;
    }
    __syncthreads();
 
@@ -322,7 +333,7 @@ __global__ void k_alpha(FbArgs a)
          const double *bP = bcol + (size_t)((t - 1) % 3) * nCellsMax;
          if (live && t + 1 <= T) {                       // stage beta(t+1)
             const int q = cm.q;
-            if (q >= gLo[t + 1] && q <= gHi[t + 1]) bcol[(size_t)((t + 1) % 3) * nCellsMax + tid] = gbeta[(size_t)t * nC + tid];
+            if (q >= gLo[t + 1] && q <= gHi[t + 1]) bcol[(size_t)((t + 1) % 3) * nCellsMax + c] = gbeta[(size_t)t * nC + c];
          }
          const int pLo = gLo[t - 1], pHi = gHi[t - 1];
          if (live && cm.i == 1) {
@@ -378,7 +389,7 @@ __global__ void k_alpha(FbArgs a)
          if (live) {
             const int q = cm.q;
             if (q < sq || q > eq) {
-               if (cm.i < cm.N) aC[tid] = LZERO;
+               if (cm.i < cm.N) aC[c] = LZERO;
             } else if (cm.i < cm.N) {
                double a1;
                if (q == 1) a1 = LZERO;
@@ -390,16 +401,17 @@ __global__ void k_alpha(FbArgs a)
                      a1 = ladd(a1, a1p + (double)t1N, mle);
                   }
                }
-               if (cm.i == 1) aC[tid] = a1;
+               if (cm.i == 1) aC[c] = a1;
                else {
-                  double aa = tcol[tid * maxN + 0];
+                  double aa = tcol[c * maxN + 0];
                   double x = (aa > LSMALL) ? aa + a1 : LZERO;
                   for (int i = 2; i < cm.N; i++) {
-                     aa = tcol[tid * maxN + i - 1];
+                     aa = tcol[c * maxN + i - 1];
                      const double y = aP[cm.mc0 + i - 1];
                      if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa, mle);
                   }
-                  aC[tid] = x + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + (t - 1)];
+                  xpre = x;
+                  aC[c] = x + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + (t - 1)];
                }
             }
          }
@@ -408,15 +420,15 @@ __global__ void k_alpha(FbArgs a)
             double x = LZERO;
             if (cm.q >= sq && cm.q <= eq)
                for (int i = 2; i < cm.N; i++) {
-                  const double aa = tcol[tid * maxN + i - 1], y = aC[cm.mc0 + i - 1];
+                  const double aa = tcol[c * maxN + i - 1], y = aC[cm.mc0 + i - 1];
                   if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa, mle);
                }
-            aC[tid] = x;
+            aC[c] = x;
          }
          __syncthreads();
       }
       if (tid == 0) { gaLo[t] = (short)sq; gaHi[t] = (short)eq; }
-      if (a.alphaDbg && live) a.alphaDbg[ud.beta0 + (size_t)(t - 1) * nC + tid] = aC[tid];
+      if (a.alphaDbg && live) a.alphaDbg[ud.beta0 + (size_t)(t - 1) * nC + c] = aC[c];
 
       // ---- statistics for column t (HFB.c:1790-1806)
       if (live) {
@@ -428,33 +440,33 @@ __global__ void k_alpha(FbArgs a)
          if (inBeam) {
             const bool bqt1ok = (t < T) && q >= gLo[t + 1] && q <= gHi[t + 1];
             const bool bq1tok = (q < Q) && (q + 1) >= gLo[t] && (q + 1) <= gHi[t];
-            const double ai = aC[tid], bi = bT[tid];
+            const double ai = aC[c], bi = bT[c];
             // SetOcct (HFB.c:399-418)
             double x = ai + bi;
-            const float a1N = trow[tid * maxN + N - 1];
+            const float a1N = trow[c * maxN + N - 1];
             if (i == 1 && bq1tok && a1N > (float)LSMALL) x = ladd(x, ai + bT[mC0[q + 1]] + (double)a1N, mle);
             x -= pr;
-            const float occ = (x > MINEARG) ? (float)exp(x) : 0.0f;
+            const float occ = (x > EXPFLOOR) ? (float)exp(x) : 0.0f;
             if (i < N) occAcc += (double)occ;
             if (wantTrans && i < N) {                    // UpTranParms (HFB.c:1390-1410), row i
-               double *ta = tacc + tid * (maxN + 1);
+               double *ta = tacc + c * (maxN + 1);
                if (i == 1) {
                   for (int j = 2; j < N; j++) {
-                     x = ai + (double)trow[tid * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (t - 1)] + bT[cm.mc0 + j - 1] - pr;
-                     if (x > MINEARG) ta[j] += exp(x);
+                     x = ai + (double)trow[c * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (t - 1)] + bT[cm.mc0 + j - 1] - pr;
+                     if (x > EXPFLOOR) ta[j] += exp(x);
                   }
                   if (a1N > (float)LSMALL && bq1tok) {
                      x = ai + (double)a1N + bT[mC0[q + 1]] - pr;
-                     if (x > MINEARG) ta[N] += exp(x);
+                     if (x > EXPFLOOR) ta[N] += exp(x);
                   }
                } else {
                   if (bqt1ok)
                      for (int j = 2; j < N; j++) {
-                        x = ai + (double)trow[tid * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + t] + bT1[cm.mc0 + j - 1] - pr;
-                        if (x > MINEARG) ta[j] += exp(x);
+                        x = ai + (double)trow[c * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + t] + bT1[cm.mc0 + j - 1] - pr;
+                        if (x > EXPFLOOR) ta[j] += exp(x);
                      }
-                  x = ai + (double)trow[tid * maxN + N - 1] + bT[cm.mc0 + N - 1] - pr;
-                  if (x > MINEARG) ta[N] += exp(x);
+                  x = ai + (double)trow[c * maxN + N - 1] + bT[cm.mc0 + N - 1] - pr;
+                  if (x > EXPFLOOR) ta[N] += exp(x);
                }
             }
             if (wantMix && i > 1 && i < N) {             // UpMixParms seed (HFB.c:1479-1489,1573-1606)
@@ -462,12 +474,10 @@ __global__ void k_alpha(FbArgs a)
                   x = ai + bi - pr;
                   if (-x < minF) seed = x;
                } else {
-                  double initx = (double)tcol[tid * maxN + 0] + aC[cm.mc0];
-                  if (t > 1)
-                     for (int i2 = 2; i2 < N; i2++) {
-                        const double aa = tcol[tid * maxN + i2 - 1];
-                        if (aa > LSMALL) initx = ladd(initx, aP[cm.mc0 + i2 - 1] + aa, mle);
-                     }
+                  // initx = log(a_1j alpha_1(t) + sum_i alpha_i(t-1) a_ij) + beta_j - pr (HFB.c:1481-1488).  The sum is
+                  // the one the alpha recursion formed before adding b_j(t) (same operands, same order); the two
+                  // only differ by how log-zero terms are skipped, which cannot lift a sum above LSMALL.
+                  double initx = xpre;
                   initx += bi - pr;
                   // every component's x = initx + logw + prob is <= initx + b_j(t) (+ float rounding)
                   const double ub = initx + (double)outp[(size_t)(cm.ms0 + i - 2) * T + (t - 1)];
@@ -485,7 +495,7 @@ __global__ void k_alpha(FbArgs a)
    }
    // ---- flush the per-cell sums
    if (live && wantTrans && cm.i < cm.N) {
-      const double *ta = tacc + tid * (maxN + 1);
+      const double *ta = tacc + c * (maxN + 1);
       double *tr = a.acc + a.lay.tr + a.transOff[cTrans] + (size_t)(cm.i - 1) * cm.N;
       for (int j = 2; j <= cm.N; j++)
          if (ta[j] != 0.0) atomicAdd(tr + (j - 1), ta[j]);

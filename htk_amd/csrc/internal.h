@@ -28,10 +28,10 @@ float  htkamd_host_mix_log_weight(float w);                                    /
 int    htkamd_host_min_dur(int N, const float *tp);                            /* HFB.c:106    */
 double htkamd_host_min_log_exp(void);                                          /* HMath.c:1680 */
 
-/* device LAdd table: 8 intervals per unit of d over [minLogExp, 0] = [-23.03, 0], degree-8 Taylor rows */
-#define LADD_INV_H 8
-#define LADD_DEG   8
-#define LADD_NK    186          /* ceil(23.0259 * 8) + 1 */
+/* device LAdd table: 4 intervals per unit of d over [minLogExp, 0] = [-23.03, 0], degree-10 Taylor rows (8 KB) */
+#define LADD_INV_H 4
+#define LADD_DEG   10
+#define LADD_NK    93           /* floor(23.0259 * 4) + 1 */
 int    htkamd_host_ladd_table_size(void);
 void   htkamd_host_build_ladd_table(double *tab);
 

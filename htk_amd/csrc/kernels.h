@@ -42,6 +42,7 @@ struct UttDesc {
    int slot0;         // first entry in slotState
    int status;        // host pre-check (CreateInsts): HTKAMD_UTT_*
    int nEval;         // output-probability evaluations of the un-pruned pass (metric unit)
+   int thr0, nThr;    // this utterance's slice of thrCell; threads in use
    size_t outp0;      // floats : outp[outp0 + slot*T + (t-1)]
    size_t beta0;      // doubles: beta[beta0 + (t-1)*nCells + cell]
    size_t gam0;       // doubles: gam [gam0  + (t-1)*nSlots + slot]
@@ -54,6 +55,7 @@ struct FbArgs {
    const int *mN, *mTp, *mCell0, *mSlot0, *mDms, *mHmm, *mTrans;
    // per-cell tables (index cell0 + c)
    const short *cQ, *cI;
+   const short *thrCell;             // [thr0 + thread] -> cell (or -1): threads grouped by role, padded to waves
    const int *slotState;
    // per-frame (index frame0 + t - 1)
    const short *taperLo, *taperHi;
@@ -67,6 +69,7 @@ struct FbArgs {
    // model tables for the statistics kernel
    const int *stateCompOff, *compGauss, *transOff, *trOccOff;
    const float *compLogWt, *gparam, *mean;
+   const double *laddTab;
    int PS, D, maxN, maxM;
    int nCellsMax, QMax;              // maxima over the batch (LDS carve)
    double *acc;                      // accumulator vector

@@ -90,8 +90,8 @@ int htkamd_host_min_dur(int N, const float *tp)
  * Table for the device LAdd.  LAdd(x,y) = x + log(1 + exp(y-x)) (HMath.c:1576-1590) is evaluated
  * on the device as x + f(d), d = y-x in [minLogExp, 0], f(d) = log1p(exp(d)), with f taken from a
  * piecewise Taylor polynomial: interval k = (int)(-d*LADD_INV_H) has centre c_k = -(k+0.5)/LADD_INV_H
- * and f(c_k + r) = sum_n tab[k][n] r^n, |r| <= 1/(2*LADD_INV_H).  With 8 intervals per unit and
- * degree 8 the truncation error is below 1e-16, i.e. at the rounding level of the glibc
+ * and f(c_k + r) = sum_n tab[k][n] r^n, |r| <= 1/(2*LADD_INV_H).  With 4 intervals per unit and
+ * degree 10 the truncation error is below 1e-17, i.e. at the rounding level of the glibc
  * exp()/log() pair the reference calls, so float-rounded results agree except when the double
  * result sits within ~1e-16 of a float rounding boundary.
  * Derivatives: f' = s, s = 1/(1+exp(-d));  f^(n+1) = (d/ds f^(n)) * s(1-s), polynomials in s.
