@@ -38,7 +38,7 @@ struct htkamd_fb {
    std::vector<ScoreTask> tasks;
    std::vector<size_t> gamOff;
    size_t outpTotal, betaTotal, gamTotal;
-   int totalFrames, nCellsMax, QMax, blockDim;
+   int totalFrames, nCellsMax, QMax, TMax, blockDim;
    long long frameStates;
    const float *dX;
    // device
@@ -114,7 +114,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    fb->totalFrames = U ? b->frameOff[U] : 0;
    fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
    fb->gamOff.assign(U + 1, 0);
-   fb->nCellsMax = 1; fb->QMax = 1;
+   fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1;
    fb->frameStates = 0;
    size_t outp = 0, beta = 0, gam = 0;
    std::vector<int> evLo, evHi, slotModel;
@@ -164,6 +164,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       }
       if (nCells > fb->nCellsMax) fb->nCellsMax = nCells;
       if (Q > fb->QMax) fb->QMax = Q;
+      if (T > fb->TMax) fb->TMax = T;
       outp += (size_t)T * nSlots; beta += (size_t)T * nCells; gam += (size_t)T * nSlots;
       if (d.status != HTKAMD_UTT_OK) continue;
       // SetBeamTaper
@@ -287,7 +288,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.transOff = (const int *)fb->d_transOff.p; fa.trOccOff = (const int *)fb->d_trOccOff.p;
    fa.compLogWt = m->d_compLogWt; fa.gparam = m->d_gparam; fa.mean = m->d_mean; fa.laddTab = m->d_laddTab;
    fa.PS = m->PS; fa.D = m->D; fa.maxN = m->maxN; fa.maxM = m->maxM;
-   fa.nCellsMax = fb->nCellsMax; fa.QMax = fb->QMax;
+   fa.nCellsMax = fb->nCellsMax; fa.QMax = fb->QMax; fa.TMax = fb->TMax;
    fa.acc = accs->d_vec; fa.lay = accs->lay;
    fa.pruneInit = cfg->pruneInit; fa.pruneInc = cfg->pruneInc; fa.pruneLim = cfg->pruneLim;
    fa.minLogExp = m->minLogExp; fa.minFrwdP = cfg->minFrwdP; fa.uFlags = cfg->uFlags;
@@ -297,7 +298,9 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    auto r8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
    const size_t ldsTab = r8((size_t)LADD_NK * (LADD_DEG + 1) * 8);
    const size_t ldsBeta = 2 * r8(nc * 8) + r8(qm * 8) + r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32) + ldsTab;
-   const size_t ldsAlpha = 2 * r8(nc * 8) + r8(3 * nc * 8) + r8(qm * 8) + r8(nc * (mn + 1) * 8) + 2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + r8(32) + ldsTab;
+   const size_t tm = (size_t)fb->TMax + 3;
+   const size_t ldsAlpha = 2 * r8(nc * 8) + r8(3 * nc * 8) + r8(qm * 8) + r8(nc * (mn + 1) * 8) + ldsTab + r8(3 * nc * 4) +
+                           2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + 2 * r8(tm * 2);
    if (ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
 
    int rc;

@@ -234,17 +234,19 @@ __global__ void k_alpha(FbArgs a)
    LdsCarve lds(smem);
    double *acol0 = lds.take<double>(nCellsMax);
    double *acol1 = lds.take<double>(nCellsMax);
-   double *bcol = lds.take<double>((size_t)3 * nCellsMax);
+   double *bcol = lds.take<double>((size_t)3 * nCellsMax);     // beta columns t-1, t, t+1 (slot = t % 3)
    double *mmp = lds.take<double>(QMax + 3);
    double *tacc = lds.take<double>((size_t)nCellsMax * (maxN + 1));
+   double *ltab = lds.take<double>(LADD_TAB_DOUBLES);
+   float *ocol = lds.take<float>((size_t)3 * nCellsMax);       // output probs of columns t-1, t, t+1
    float *trow = lds.take<float>((size_t)nCellsMax * maxN);
    float *tcol = lds.take<float>((size_t)nCellsMax * maxN);
    float *mA1N = lds.take<float>(QMax + 3);
    int *mC0 = lds.take<int>(QMax + 3);
    int *mNq = lds.take<int>(QMax + 3);
    int *mDm = lds.take<int>(QMax + 3);
-   int *sh = lds.take<int>(8);
-   double *ltab = lds.take<double>(LADD_TAB_DOUBLES);
+   short *bLo = lds.take<short>(a.TMax + 3);                   // final beta beam of every frame (1-based t)
+   short *bHi = lds.take<short>(a.TMax + 3);
    ladd_table_to_lds(ltab, a.laddTab);
 
    CellMeta cm = {0, 0, 0, 0, 0};
@@ -273,10 +275,13 @@ __global__ void k_alpha(FbArgs a)
       mA1N[q] = a.transP[a.mTp[mi] + (N - 1)];
    }
    if (tid == 0) { mC0[Q + 1] = 0; mNq[Q + 1] = 0; mDm[Q + 1] = 1; mA1N[Q + 1] = (float)LZERO; mA1N[0] = (float)LZERO; mDm[0] = 1; mC0[0] = 0; mNq[0] = 0; }
+   {
+      const short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;
+      for (int t = tid + 1; t <= T; t += blockDim.x) { bLo[t] = gLo[t]; bHi[t] = gHi[t]; }
+      if (tid == 0) { bLo[0] = 1; bHi[0] = 0; bLo[T + 1] = 1; bHi[T + 1] = 0; }
+   }
 
-   const short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;    // final beta beam, 1-based t
    short *gaLo = a.aLo + ud.frame0 - 1, *gaHi = a.aHi + ud.frame0 - 1;
-   const float *outp = a.outp + ud.outp0;
    const double *gbeta = a.beta + ud.beta0;
    double *gam = a.gam + ud.gam0;
    const double mle = a.minLogExp, pr = a.pr[u];
@@ -284,17 +289,26 @@ __global__ void k_alpha(FbArgs a)
    const bool wantMix = (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) != 0;
    const bool wantTrans = (a.uFlags & HTKAMD_UPTRANS) != 0;
    const int nSlots = ud.nSlots;
+   const bool emitting = live && cm.i > 1 && cm.i < cm.N;
+   // this cell's row of the state-major output-probability block (only meaningful for emitting cells)
+   const float *orow = a.outp + ud.outp0 + (size_t)(emitting ? cm.ms0 + cm.i - 2 : 0) * T;
 
-   // beta columns 1 and 2 into the ring (column t lives in slot t % 3)
+   // Columns 1 and 2 of beta / output probabilities go into the rings now; from then on column t+2 is
+   // requested from HBM at the top of step t and parked in LDS at its end, so no step waits on memory.
    if (live) {
-      { const int q = cm.q; if (q >= gLo[1] && q <= gHi[1]) bcol[(size_t)(1 % 3) * nCellsMax + c] = gbeta[c]; }
-      if (T >= 2) { const int q = cm.q; if (q >= gLo[2] && q <= gHi[2]) bcol[(size_t)(2 % 3) * nCellsMax + c] = gbeta[(size_t)nC + c]; }
+      bcol[(size_t)1 * nCellsMax + c] = gbeta[c];
+      if (emitting) ocol[(size_t)1 * nCellsMax + c] = orow[0];
+      if (T >= 2) {
+         bcol[(size_t)2 * nCellsMax + c] = gbeta[(size_t)nC + c];
+         if (emitting) ocol[(size_t)2 * nCellsMax + c] = orow[1];
+      }
    }
    double *aC = acol0, *aP = acol1;
-   int sq = 1, eq = gHi[1];
    double occAcc = 0.0;
    double xpre = LZERO;          // log sum_i alpha_i(t-1) a_ij (+ entry term) of this emitting cell, before b_j(t)
    int err = 0;
+   __syncthreads();
+   int sq = 1, eq = bHi[1];
 
    // ---- t = 1: InitAlpha (HFB.c:616-651)
    if (tid == 0) {
@@ -305,12 +319,12 @@ __global__ void k_alpha(FbArgs a)
       }
    }
    __syncthreads();
-   if (live && cm.i > 1 && cm.i < cm.N) {
+   if (emitting) {
       double v = LZERO;
       if (cm.q <= eq) {
          const double aa = tcol[c * maxN + 0];
          xpre = aC[cm.mc0] + aa;
-         if (aa > LSMALL) v = xpre + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + 0];
+         if (aa > LSMALL) v = xpre + (double)ocol[(size_t)1 * nCellsMax + c];
       }
       aC[c] = v;
    }
@@ -328,62 +342,45 @@ __global__ void k_alpha(FbArgs a)
    __syncthreads();
 
    for (int t = 1; t <= T; t++) {
+      // request column t+2 (consumed at the end of this step)
+      double bNext = 0.0; float oNext = 0.0f;
+      const bool haveNext = live && (t + 2 <= T);
+      if (haveNext) {
+         bNext = gbeta[(size_t)(t + 1) * nC + c];
+         if (emitting) oNext = orow[t + 1];
+      }
       if (t > 1) {
-         // ---- alpha beam (HFB.c:699-722): MaxModelProb of every model against column t-1
+         // ---- alpha beam (HFB.c:699-722).  mmp[q] = MaxModelProb(q, t-1, minq=q) was left in LDS by step t-1;
+         // every thread walks the two short loops itself (uniform LDS reads) instead of waiting for one thread.
          const double *bP = bcol + (size_t)((t - 1) % 3) * nCellsMax;
-         if (live && t + 1 <= T) {                       // stage beta(t+1)
-            const int q = cm.q;
-            if (q >= gLo[t + 1] && q <= gHi[t + 1]) bcol[(size_t)((t + 1) % 3) * nCellsMax + c] = gbeta[(size_t)t * nC + c];
-         }
-         const int pLo = gLo[t - 1], pHi = gHi[t - 1];
-         if (live && cm.i == 1) {
-            const int q = cm.q;
-            double m = LZERO;
-            if (q > 1 && q - 1 >= pLo && q - 1 <= pHi) {
-               const int c1 = mC0[q - 1] + mNq[q - 1] - 1;
-               m = aC[c1] + bP[c1];
-            }
-            if (q >= pLo && q <= pHi)
-               for (int i = 1; i < cm.N; i++) {
-                  const double x = aC[cm.mc0 + i - 1] + bP[cm.mc0 + i - 1];
-                  if (x > m) m = x;
-               }
-            mmp[q] = m;
-         }
-         __syncthreads();
-         if (tid == 0) {
-            int s = pLo, e, f = 0;
-            const int cLo = gLo[t], cHi = gHi[t];
-            while (pr - mmp[s] > minF) { ++s; if (s > cHi) { f = 1; break; } }
-            if (!f) {
-               if (s < cLo) s = cLo;
-               e = (pHi < Q) ? pHi + 1 : pHi;
-               for (;;) {
-                  double m = mmp[e];
-                  // tee predecessors above the start point (MaxModelProb's qx loop, HFB.c:667-672)
-                  for (int qx = e - 1; qx > s && mA1N[qx] > (float)LSMALL; qx--) {
-                     const int qx1 = qx - 1;
-                     if (qx1 >= 1 && qx1 >= pLo && qx1 <= pHi) {
-                        const int c1 = mC0[qx1] + mNq[qx1] - 1;
-                        const double x = aC[c1] + bP[c1];
-                        if (x > m) m = x;
-                     }
+         const int pLo = bLo[t - 1], pHi = bHi[t - 1], cLo = bLo[t], cHi = bHi[t];
+         int s = pLo, e = 0, f = 0;
+         while (pr - mmp[s] > minF) { ++s; if (s > cHi) { f = 1; break; } }
+         if (!f) {
+            if (s < cLo) s = cLo;
+            e = (pHi < Q) ? pHi + 1 : pHi;
+            for (;;) {
+               double m = mmp[e];
+               // tee predecessors above the start point (MaxModelProb's qx loop, HFB.c:667-672)
+               for (int qx = e - 1; qx > s && mA1N[qx] > (float)LSMALL; qx--) {
+                  const int qx1 = qx - 1;
+                  if (qx1 >= 1 && qx1 >= pLo && qx1 <= pHi) {
+                     const int c1 = mC0[qx1] + mNq[qx1] - 1;
+                     const double x = aC[c1] + bP[c1];
+                     if (x > m) m = x;
                   }
-                  if (!(pr - m > minF)) break;
-                  --e;
-                  if (e < s) { f = 1; break; }
                }
-               if (!f) {
-                  while (e < Q && mDm[e] == 0) e++;
-                  if (e > cHi) e = cHi;
-               }
-               sh[0] = s; sh[1] = e;
+               if (!(pr - m > minF)) break;
+               --e;
+               if (e < s) { f = 1; break; }
             }
-            sh[2] = f;
+            if (!f) {
+               while (e < Q && mDm[e] == 0) e++;
+               if (e > cHi) e = cHi;
+            }
          }
-         __syncthreads();
-         if (sh[2]) { err = 1; break; }
-         sq = sh[0]; eq = sh[1];
+         if (f) { err = 1; break; }                      // uniform: every thread computed the same f
+         sq = s; eq = e;
          { double *tmp = aC; aC = aP; aP = tmp; }
          // ---- alpha column t (HFB.c:729-771)
          if (live) {
@@ -411,7 +408,7 @@ __global__ void k_alpha(FbArgs a)
                      if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa, mle);
                   }
                   xpre = x;
-                  aC[c] = x + (double)outp[(size_t)(cm.ms0 + cm.i - 2) * T + (t - 1)];
+                  aC[c] = x + (double)ocol[(size_t)(t % 3) * nCellsMax + c];
                }
             }
          }
@@ -425,21 +422,42 @@ __global__ void k_alpha(FbArgs a)
                }
             aC[c] = x;
          }
-         __syncthreads();
       }
+      // park column t+2 (its ring slot held column t-1, last read by the beam walk above)
+      if (haveNext) {
+         bcol[(size_t)((t + 2) % 3) * nCellsMax + c] = bNext;
+         if (emitting) ocol[(size_t)((t + 2) % 3) * nCellsMax + c] = oNext;
+      }
+      __syncthreads();
       if (tid == 0) { gaLo[t] = (short)sq; gaHi[t] = (short)eq; }
       if (a.alphaDbg && live) a.alphaDbg[ud.beta0 + (size_t)(t - 1) * nC + c] = aC[c];
 
-      // ---- statistics for column t (HFB.c:1790-1806)
+      // ---- statistics for column t (HFB.c:1790-1806) and MaxModelProb of column t for the next beam walk
       if (live) {
          const int q = cm.q, i = cm.i, N = cm.N;
          const double *bT = bcol + (size_t)(t % 3) * nCellsMax;
          const double *bT1 = bcol + (size_t)((t + 1) % 3) * nCellsMax;
+         const float *oT = ocol + (size_t)(t % 3) * nCellsMax;
+         const float *oT1 = ocol + (size_t)((t + 1) % 3) * nCellsMax;
+         const int cLo = bLo[t], cHi = bHi[t];
+         if (i == 1) {                                   // HFB.c:655-682 with minq == q
+            double m = LZERO;
+            if (q > 1 && q - 1 >= cLo && q - 1 <= cHi) {
+               const int c1 = mC0[q - 1] + mNq[q - 1] - 1;
+               m = aC[c1] + bT[c1];
+            }
+            if (q >= cLo && q <= cHi)
+               for (int i2 = 1; i2 < N; i2++) {
+                  const double x = aC[cm.mc0 + i2 - 1] + bT[cm.mc0 + i2 - 1];
+                  if (x > m) m = x;
+               }
+            mmp[q] = m;
+         }
          const bool inBeam = q >= sq && q <= eq;
          double seed = LZERO;
          if (inBeam) {
-            const bool bqt1ok = (t < T) && q >= gLo[t + 1] && q <= gHi[t + 1];
-            const bool bq1tok = (q < Q) && (q + 1) >= gLo[t] && (q + 1) <= gHi[t];
+            const bool bqt1ok = (t < T) && q >= bLo[t + 1] && q <= bHi[t + 1];
+            const bool bq1tok = (q < Q) && (q + 1) >= cLo && (q + 1) <= cHi;
             const double ai = aC[c], bi = bT[c];
             // SetOcct (HFB.c:399-418)
             double x = ai + bi;
@@ -452,7 +470,7 @@ __global__ void k_alpha(FbArgs a)
                double *ta = tacc + c * (maxN + 1);
                if (i == 1) {
                   for (int j = 2; j < N; j++) {
-                     x = ai + (double)trow[c * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + (t - 1)] + bT[cm.mc0 + j - 1] - pr;
+                     x = ai + (double)trow[c * maxN + j - 1] + (double)oT[cm.mc0 + j - 1] + bT[cm.mc0 + j - 1] - pr;
                      if (x > EXPFLOOR) ta[j] += exp(x);
                   }
                   if (a1N > (float)LSMALL && bq1tok) {
@@ -462,7 +480,7 @@ __global__ void k_alpha(FbArgs a)
                } else {
                   if (bqt1ok)
                      for (int j = 2; j < N; j++) {
-                        x = ai + (double)trow[c * maxN + j - 1] + (double)outp[(size_t)(cm.ms0 + j - 2) * T + t] + bT1[cm.mc0 + j - 1] - pr;
+                        x = ai + (double)trow[c * maxN + j - 1] + (double)oT1[cm.mc0 + j - 1] + bT1[cm.mc0 + j - 1] - pr;
                         if (x > EXPFLOOR) ta[j] += exp(x);
                      }
                   x = ai + (double)trow[c * maxN + N - 1] + bT[cm.mc0 + N - 1] - pr;
@@ -480,13 +498,14 @@ __global__ void k_alpha(FbArgs a)
                   double initx = xpre;
                   initx += bi - pr;
                   // every component's x = initx + logw + prob is <= initx + b_j(t) (+ float rounding)
-                  const double ub = initx + (double)outp[(size_t)(cm.ms0 + i - 2) * T + (t - 1)];
+                  const double ub = initx + (double)oT[c];
                   if (ub > -minF - 0.01) seed = initx;
                }
             }
          }
          if (i > 1 && i < N) gam[(size_t)(t - 1) * nSlots + cm.ms0 + i - 2] = seed;
       }
+      __syncthreads();
    }
 
    if (err) {

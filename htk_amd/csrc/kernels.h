@@ -71,7 +71,7 @@ struct FbArgs {
    const float *compLogWt, *gparam, *mean;
    const double *laddTab;
    int PS, D, maxN, maxM;
-   int nCellsMax, QMax;              // maxima over the batch (LDS carve)
+   int nCellsMax, QMax, TMax;        // maxima over the batch (LDS carve)
    double *acc;                      // accumulator vector
    htkamd_accs_layout lay;
    double pruneInit, pruneInc, pruneLim, minLogExp;
