@@ -215,12 +215,12 @@ def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, 
 class ForwardBackward:
     """htkamd_fb holder: FBFile (HFB.c:1923) over a batch of utterances."""
 
-    def __init__(self, model: Model, debug: bool = False):
+    def __init__(self, model: Model, debug: bool = False, force_general: bool = False):
         self.model = model
         self.h = C.c_void_p()
         check(lib().htkamd_fb_create(model.h, C.byref(self.h)), "fb_create")
-        if debug:
-            check(lib().htkamd_fb_set_debug(self.h, 1), "fb_set_debug")
+        if debug or force_general:
+            check(lib().htkamd_fb_set_debug(self.h, (1 if debug else 0) | (2 if force_general else 0)), "fb_set_debug")
         self.nUtt = 0
         self._keep = None
 

@@ -31,6 +31,7 @@ struct htkamd_fb {
    htkamd_model *m;
    int nUtt;
    int debug;
+   int forceGeneral;            // test aid: use the workgroup-per-utterance kernels even when the wave path applies
    // host tables of the prepared batch
    std::vector<UttDesc> utt;
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
@@ -54,7 +55,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->evValid = false; fb->timed = false;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr;
    for (int i = 0; i < 5; i++) {
       hipError_t e = hipEventCreate(&fb->ev[i]);
@@ -84,7 +85,8 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
 extern "C" int htkamd_fb_set_debug(htkamd_fb *fb, int on)
 {
    if (!fb) { htkamd_set_error("fb_set_debug: NULL"); return HTKAMD_EINVAL; }
-   fb->debug = on;
+   fb->debug = on & 1;
+   fb->forceGeneral = (on & 2) ? 1 : 0;
    return HTKAMD_OK;
 }
 
@@ -307,9 +309,10 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    HIPCHECK(hipEventRecord(fb->ev[0], s));
    if ((rc = htkamd_launch_score_exact(m, sa, s))) return rc;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
-   if ((rc = htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;
+   const bool wavePath = (m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
+   if ((rc = wavePath ? htkamd_launch_beta_w(fa, s) : htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;
    HIPCHECK(hipEventRecord(fb->ev[2], s));
-   if ((rc = htkamd_launch_alpha(fa, fb->blockDim, ldsAlpha, s))) return rc;
+   if ((rc = wavePath ? htkamd_launch_alpha_w(fa, s) : htkamd_launch_alpha(fa, fb->blockDim, ldsAlpha, s))) return rc;
    HIPCHECK(hipEventRecord(fb->ev[3], s));
    if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES))
       if ((rc = htkamd_launch_mixstats(fa, s))) return rc;

@@ -169,7 +169,8 @@ typedef struct htkamd_fb htkamd_fb;
 
 int  htkamd_fb_create(htkamd_model *m, htkamd_fb **out);
 void htkamd_fb_destroy(htkamd_fb *fb);
-/* Keep every alpha column (test aid, T*cells doubles more per utterance); call before prepare. */
+/* Test aid; call before prepare.  bit 0: keep every alpha column (T*cells doubles more per utterance);
+   bit 1: force the general workgroup-per-utterance kernels even where the wave-per-utterance path applies. */
 int  htkamd_fb_set_debug(htkamd_fb *fb, int on);
 /* Host part of CreateInsts/SetBeamTaper for the whole batch + upload of the chain tables. */
 int  htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *batch, void *stream);

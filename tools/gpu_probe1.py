@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from htk_amd import synth, capi
 from oracle import pyoracle as po
 
-def main(NS=60, M=4, NP=40, NU=6, T=150, seed=5):
+def main(NS=60, M=4, NP=40, NU=6, T=150, seed=5, general=False):
     s = synth.generate(NS, M, NP, NU, T, seed)
     pk = s.packed()
     om = po.Model(pk)
@@ -24,7 +24,8 @@ def main(NS=60, M=4, NP=40, NU=6, T=150, seed=5):
     labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)
     labs = np.concatenate(s.seqs).astype(np.int32)
     dX = capi.DevArray(X)
-    fb = capi.ForwardBackward(gm, debug=True)
+    fb = capi.ForwardBackward(gm, debug=True, force_general=general)
+    print('=== path:', 'general (workgroup per utterance)' if general else 'wave per utterance')
     acc = capi.Accs(gm)
     fb.prepare(dX.ptr.value, frameOff, labOff, labs)
     cfg = capi.fb_config()
@@ -60,4 +61,5 @@ def main(NS=60, M=4, NP=40, NU=6, T=150, seed=5):
 
 if __name__ == "__main__":
     main()
+    main(general=True)
     if len(sys.argv) > 1: main(1000, 8, 2000, 8, 500, 1)
