@@ -530,32 +530,48 @@ __global__ void k_alpha(FbArgs a)
 }
 
 // ------------------------------------------------------------------------------------ K4: mixture statistics
+// DT > 0: vector size known at compile time (all parameter loads of a component are issued together);
+// DT == 0: any size.
+template <int DT>
 __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
 {
    const int lane = threadIdx.x & 63;
    const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
    const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-   const int D = a.D;
+   const int D = DT > 0 ? DT : a.D;
    const double minF = (double)a.minFrwdP;
+   // the last utterance looked up: consecutive hits almost always fall into the same one
+   int cu = -1; size_t cuLo = 1, cuHi = 0; UttDesc ud; int cuOk = 0;
    const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
-   for (size_t base = waveId * 64; base < a.gamTotal; base += nWaves * 64) {
-      const size_t idx = base + lane;
-      const double v = (idx < a.gamTotal) ? a.gam[idx] : LZERO;
+   // dense scan of the seed array: 8 x 64 seeds per wave and iteration (8 independent 512-byte loads in flight)
+   for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
+    double vv[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+       const size_t idx = base0 + (size_t)r * 64 + lane;
+       vv[r] = (idx < a.gamTotal) ? a.gam[idx] : LZERO;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const size_t base = base0 + (size_t)r * 64;
+      const double v = vv[r];
       unsigned long long hits = __ballot(v > LSMALL);
       while (hits) {
          const int src = __ffsll((long long)hits) - 1;
          hits &= hits - 1;
          const size_t hidx = base + src;
          const double seed = __shfl(v, src);
-         // utterance of this entry: last u with gamOffByUtt[u] <= hidx
-         int lo = 0, hi = a.nUtt - 1;
-         while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (a.gamOffByUtt[mid] <= hidx) lo = mid; else hi = mid - 1;
+         if (hidx < cuLo || hidx >= cuHi) {              // utterance of this entry: last u with gamOffByUtt[u] <= hidx
+            int lo = 0, hi = a.nUtt - 1;
+            while (lo < hi) {
+               const int mid = (lo + hi + 1) >> 1;
+               if (a.gamOffByUtt[mid] <= hidx) lo = mid; else hi = mid - 1;
+            }
+            cu = lo; cuLo = a.gamOffByUtt[cu]; cuHi = a.gamOffByUtt[cu + 1];
+            ud = a.utt[cu];
+            cuOk = a.status[cu] == HTKAMD_UTT_OK;
          }
-         const int u = lo;
-         if (a.status[u] != HTKAMD_UTT_OK) continue;
-         const UttDesc ud = a.utt[u];
+         if (!cuOk) continue;
          const size_t rel = hidx - ud.gam0;
          const int t0 = (int)(rel / ud.nSlots), slot = (int)(rel % ud.nSlots);
          const int s = a.slotState[ud.slot0 + slot];
@@ -573,9 +589,22 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
                   if (wt > (float)LMINMIX) {
                      const float *P = a.gparam + (size_t)a.compGauss[c0 + m] * a.PS;
                      float sum = P[2 * D];
-                     for (int i = 0; i < D; i++) {
-                        const float xmm = xrow[i] - P[2 * i];
-                        sum += xmm * xmm * P[2 * i + 1];
+                     if (DT > 0) {
+                        const float2 *P2 = (const float2 *)P;         // (mean, ivar) pairs, 8-byte aligned rows
+                        float2 pv[DT > 0 ? DT : 1];
+                        float xv[DT > 0 ? DT : 1];
+#pragma unroll
+                        for (int i = 0; i < DT; i++) { pv[i] = P2[i]; xv[i] = xrow[i]; }
+#pragma unroll
+                        for (int i = 0; i < DT; i++) {
+                           const float xmm = xv[i] - pv[i].x;
+                           sum += xmm * xmm * pv[i].y;
+                        }
+                     } else {
+                        for (int i = 0; i < D; i++) {
+                           const float xmm = xrow[i] - P[2 * i];
+                           sum += xmm * xmm * P[2 * i + 1];
+                        }
                      }
                      const float prob = -0.5f * sum;
                      const double x = (seed + (double)wt) + (double)prob;
@@ -613,6 +642,7 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
             }
          }
       }
+    }
    }
 }
 
@@ -644,10 +674,15 @@ int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s
 int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s)
 {
    if (a.gamTotal == 0) return HTKAMD_OK;
-   size_t waves = (a.gamTotal + 63) / 64;
+   size_t waves = (a.gamTotal + 511) / 512;
    size_t blocks = (waves + 3) / 4;
    if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
-   hipLaunchKernelGGL(k_mixstats, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   switch (a.D) {
+   case 39: hipLaunchKernelGGL(k_mixstats<39>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+   case 26: hipLaunchKernelGGL(k_mixstats<26>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+   case 13: hipLaunchKernelGGL(k_mixstats<13>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+   default: hipLaunchKernelGGL(k_mixstats<0>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+   }
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }

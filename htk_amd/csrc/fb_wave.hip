@@ -25,6 +25,7 @@
 #define EXPFLOOR (-100.0)     // see fb_kernels.hip
 
 #define ladd(x, y) ladd_tab((x), (y), mle, ltab)
+#define EXPT(x) exp_tab((x), etab)
 
 __device__ __forceinline__ double shfl_d(double v, int srcLane) { return __shfl(v, srcLane); }
 __device__ __forceinline__ int lowest_set(unsigned long long m) { return __ffsll((long long)m) - 1; }       // -1 if none
@@ -247,7 +248,9 @@ template <int MAXN>
 __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
 {
    __shared__ double ltab[LADD_TAB_DOUBLES];
+   __shared__ double etab[EXP_TAB_N];
    ladd_table_to_lds(ltab, a.laddTab);
+   exp_table_to_lds(etab);
    __syncthreads();
    const int lane = threadIdx.x & 63;
    const int u = blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
                double x = ai + bi;
                if (i == 1 && bq1tok && a1N > (float)LSMALL) x = ladd(x, ai + bEntryNext + (double)a1N);
                x -= pr;
-               const float occ = (x > EXPFLOOR) ? (float)exp(x) : 0.0f;
+               const float occ = (x > EXPFLOOR) ? (float)EXPT(x) : 0.0f;
                occAcc[i] += (double)occ;
                if (wantTrans) {                          // UpTranParms (HFB.c:1390-1410), row i
                   if (i == 1) {
@@ -474,12 +477,12 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
                      for (int j = 2; j < MAXN; j++)
                         if (j < N) {
                            x = ai + (double)m.tp[0][j - 1] + (double)oT[j] + bT[j] - pr;
-                           if (x > EXPFLOOR) ta[1][j] += exp(x);
+                           if (x > EXPFLOOR) ta[1][j] += EXPT(x);
                         }
                      if (a1N > (float)LSMALL && bq1tok) {
                         x = ai + (double)a1N + bEntryNext - pr;
                         if (x > EXPFLOOR) {
-                           const double e = exp(x);
+                           const double e = EXPT(x);
 #pragma unroll
                            for (int j = 2; j <= MAXN; j++) if (j == N) ta[1][j] += e;
                         }
@@ -490,12 +493,12 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
                         for (int j = 2; j < MAXN; j++)
                            if (j < N) {
                               x = ai + (double)m.tp[i - 1][j - 1] + (double)oT1[j] + bT1[j] - pr;
-                              if (x > EXPFLOOR) ta[i][j] += exp(x);
+                              if (x > EXPFLOOR) ta[i][j] += EXPT(x);
                            }
                      }
                      x = ai + (double)m.aN[i - 1] + bN - pr;
                      if (x > EXPFLOOR) {
-                        const double e = exp(x);
+                        const double e = EXPT(x);
 #pragma unroll
                         for (int j = 2; j <= MAXN; j++) if (j == N) ta[i][j] += e;
                      }

@@ -33,4 +33,53 @@ __device__ __forceinline__ double ladd_tab(double x, double y, const double minL
    return x + f;
 }
 
+
+// Branch-free form: always evaluates the table row (with d clamped into the table) and selects at the end.
+// In the latency-bound recursions this lets the scheduler interleave independent LAdd chains.
+__device__ __forceinline__ double ladd_tab_bl(const double x, const double y, const double minLogExp, const double *tab)
+{
+   const double hi = fmax(x, y), lo = fmin(x, y);
+   const double d = lo - hi;
+   const bool skip = d < minLogExp;
+   const double dc = skip ? minLogExp : d;
+   const int k = (int)(-dc * (double)LADD_INV_H);
+   const double r = dc + ((double)k + 0.5) * (1.0 / (double)LADD_INV_H);
+   const double *row = tab + k * LADD_ROW;
+   double f = row[LADD_DEG];
+#pragma unroll
+   for (int j = LADD_DEG - 1; j >= 0; j--) f = fma(f, r, row[j]);
+   const double res = hi + f;
+   const double keep = (hi < LSMALL) ? LZERO : hi;
+   return skip ? keep : res;
+}
+
+// exp(x) for x in [EXP_TAB_MIN, ~0] from a table of exp(-k/8) and a degree-8 Taylor polynomial of the remainder
+// (|r| <= 1/8: relative error < 1e-13).  Used for occupation / transition counts, which only have to be good
+// to the reference's float accumulators; returns 0 below EXP_TAB_MIN (exp(-100) = 3.7e-44).
+#define EXP_TAB_MIN (-100.0)
+#define EXP_TAB_N 801
+__device__ __forceinline__ void exp_table_to_lds(double *lds)
+{
+   for (int i = threadIdx.x; i < EXP_TAB_N; i += blockDim.x) lds[i] = exp(-(double)i * 0.125);
+}
+__device__ __forceinline__ double exp_tab(const double x, const double *etab)
+{
+   const bool live = x > EXP_TAB_MIN;
+   const double xc = live ? fmin(x, 0.125) : 0.0;
+   int k = (int)(-xc * 8.0);
+   if (k < 0) k = 0;
+   const double r = xc + (double)k * 0.125;          // in (-1/8, 1/8]
+   double p = 1.0 / 40320.0;
+   p = fma(p, r, 1.0 / 5040.0);
+   p = fma(p, r, 1.0 / 720.0);
+   p = fma(p, r, 1.0 / 120.0);
+   p = fma(p, r, 1.0 / 24.0);
+   p = fma(p, r, 1.0 / 6.0);
+   p = fma(p, r, 0.5);
+   p = fma(p, r, 1.0);
+   p = fma(p, r, 1.0);
+   const double v = etab[k] * p;
+   return live ? v : 0.0;
+}
+
 #endif
