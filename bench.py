@@ -67,7 +67,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from htk_amd import synth, capi
+    from htk_amd import synth, capi, herest
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,20 +104,14 @@ def main():
     sptr = stream.cuda_stream
     vec_ptr, vec_n = accs.device_vector()
     # a torch view of the accumulator vector for the collective (no copy)
-    acc_t = None
-    if world > 1:
-        class _Wrap:
-            pass
-        w = _Wrap()
-        w.__cuda_array_interface__ = {"shape": (vec_n,), "typestr": "<f8", "data": (vec_ptr, False), "version": 2}
-        acc_t = torch.as_tensor(w, device=torch.device("cuda", local_rank))
+    acc_t = herest.device_vector_as_tensor(accs, local_rank) if world > 1 else None
 
     def step():
         accs.zero(sptr)
         fb.prepare(dX.data_ptr(), frameOff, labOff, labs, sptr)
         fb.execute(cfg, accs, sptr)
         if world > 1:
-            dist.all_reduce(acc_t, op=dist.ReduceOp.SUM)
+            herest.all_reduce_accumulators(acc_t)      # the pass's one exchange: RCCL sum over xGMI
         return fb.results(sptr)
 
     def sync_all():

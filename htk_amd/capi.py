@@ -45,6 +45,15 @@ class FbConfig(C.Structure):
                 ("minFrwdP", C.c_float), ("uFlags", C.c_int)]
 
 
+class UpdateConfig(C.Structure):
+    _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int),
+                ("singleProcess", C.c_int)]
+
+
+class UpdateStats(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nFloorVar", "nFloorVarMix", "nSkippedHmm", "nNoTransOut", "nNoMixUse", "nNoVarUse")]
+
+
 class BatchDesc(C.Structure):
     _fields_ = [("nUtt", C.c_int), ("dX", C.c_void_p), ("frameOff", C.c_void_p), ("labOff", C.c_void_p), ("labs", C.c_void_p)]
 
@@ -136,6 +145,23 @@ class Model:
         lw = np.empty(self.C, np.float32); md = np.empty(self.nT, np.int32)
         check(lib().htkamd_model_get_prepared(self.h, _p(ivar), _p(gc), _p(lw), _p(md)), "model_get_prepared")
         return dict(ivar=ivar, gconst=gc, compLogWt=lw, minDur=md)
+
+    def update(self, accs: "Accs", vec: np.ndarray, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False):
+        """UpdateModels (HERest.c:1326) from a host copy of the (summed) accumulator vector."""
+        vec = np.ascontiguousarray(vec, np.float64)
+        cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess))
+        st = UpdateStats()
+        check(lib().htkamd_model_update(self.h, accs.h, _p(vec), C.byref(cfg), C.byref(st)), "model_update")
+        return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
+
+    def get_params(self) -> dict:
+        k = self._keep
+        out = dict(mean=np.empty((self.G, self.D), np.float32), var=np.empty((self.G, self.D), np.float32),
+                   gconst=np.empty(self.G, np.float32), compWeight=np.empty(self.C, np.float32),
+                   transP=np.empty(len(k["transP"]), np.float32))
+        check(lib().htkamd_model_get_params(self.h, _p(out["mean"]), _p(out["var"]), _p(out["gconst"]),
+                                            _p(out["compWeight"]), _p(out["transP"])), "model_get_params")
+        return out
 
     def outp_block(self, X: np.ndarray, states: np.ndarray) -> np.ndarray:
         """Scores [T, ns] of the listed tied states (HIP kernel K1), returned frame-major for convenience."""

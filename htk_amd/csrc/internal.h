@@ -51,6 +51,9 @@ struct htkamd_model {
    double minLogExp;
 };
 
+int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, const double *acc,
+                         const htkamd_update_config *cfg, htkamd_update_stats *st);   /* host/update.c */
+
 struct htkamd_accs {
    struct htkamd_model *m;
    htkamd_accs_layout lay;

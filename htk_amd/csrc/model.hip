@@ -219,6 +219,27 @@ extern "C" int htkamd_model_get_prepared(htkamd_model *m, float *ivar, float *gc
    return HTKAMD_OK;
 }
 
+extern "C" int htkamd_model_update(htkamd_model *m, const htkamd_accs *accs, const double *hostVec,
+                                   const htkamd_update_config *cfg, htkamd_update_stats *stats)
+{
+   if (!m || !accs || !hostVec || !cfg || !stats) { htkamd_set_error("model_update: NULL argument"); return HTKAMD_EINVAL; }
+   if (accs->m != m) { htkamd_set_error("model_update: accumulators belong to a different model"); return HTKAMD_EINVAL; }
+   int rc = htkamd_update_models(m, &accs->lay, hostVec, cfg, stats);
+   if (rc) return rc;
+   return model_refresh(m);
+}
+
+extern "C" int htkamd_model_get_params(htkamd_model *m, float *mean, float *var, float *gconst, float *compWeight, float *transP)
+{
+   if (!m) { htkamd_set_error("model_get_params: NULL model"); return HTKAMD_EINVAL; }
+   if (mean) memcpy(mean, m->h_mean, sizeof(float) * (size_t)m->G * m->D);
+   if (var) memcpy(var, m->h_var, sizeof(float) * (size_t)m->G * m->D);
+   if (gconst) memcpy(gconst, m->h_gconst, sizeof(float) * (size_t)m->G);
+   if (compWeight) memcpy(compWeight, m->h_compWeight, sizeof(float) * (size_t)m->C);
+   if (transP) memcpy(transP, m->h_transP, sizeof(float) * (size_t)m->h_transOff[m->nT]);
+   return HTKAMD_OK;
+}
+
 // ------------------------------------------------------------------------------------ accumulators
 
 extern "C" int htkamd_accs_create(htkamd_model *m, htkamd_accs **out)

@@ -1,0 +1,144 @@
+/* update.c -- host-side (C) model update after a Baum-Welch pass: MLUpdateModels of HERest.
+ *
+ * The update is a few milliseconds of scalar work over the whole HMM set and stays on the host, as in the
+ * reference.  Input is the fp64 accumulator vector the device produced (htkamd_accs layout); each entry is
+ * rounded to float ONCE and from there the arithmetic follows the reference's float expressions:
+ *   UpdateTrans   HERest.c:795-816    a_ij = tran/occ -> log
+ *   UpdateWeights HERest.c:897-971    c_m/occ, > MINMIX else 0, FloorMixes HERest.c:819-840
+ *   UpdateVars    HERest.c:1045-1122  va/occ - (mu/occ)^2, floored; BEFORE the means
+ *   UpdateMeans   HERest.c:974-1012   mean += mu/occ
+ *   FixGConsts    HModel.c:5688-5714
+ *   MLUpdateModels HERest.c:1262-1321 models with fewer than minEgs examples are left alone; a shared
+ *                 structure (tied state, Gaussian, transP) is updated by the first model that qualifies.
+ * singleProcess mirrors parMode == -1 (HERest.c:1336-1339): the set went through ConvDiagC/ConvLogWt before
+ * the pass, so parameters that are not re-estimated come back through ForceDiagC/ConvExpWt float round trips.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../csrc/internal.h"
+
+int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, const double *acc,
+                         const htkamd_update_config *cfg, htkamd_update_stats *st)
+{
+   const int D = m->D;
+   int h, i, j, k, c, maxM = m->maxM;
+   unsigned char *doneT, *doneS, *doneMu, *doneVa;
+   float *mean = m->h_mean, *var = m->h_var, *gconst = m->h_gconst, *wgt = m->h_compWeight, *transP = m->h_transP;
+   if (!m || !lay || !acc || !cfg || !st) { htkamd_set_error("update_models: NULL argument"); return HTKAMD_EINVAL; }
+   memset(st, 0, sizeof(*st));
+   doneT = (unsigned char *)calloc((size_t)m->nT, 1);
+   doneS = (unsigned char *)calloc((size_t)m->S, 1);
+   doneMu = (unsigned char *)calloc((size_t)m->G, 1);
+   doneVa = (unsigned char *)calloc((size_t)m->G, 1);
+#define ACCF(off, idx) ((float)acc[(off) + (size_t)(idx)])
+   if (cfg->singleProcess) {
+      size_t n = (size_t)m->G * D, z;
+      for (z = 0; z < n; z++) {
+         float v = var[z], iv;
+         if (v > 1E+30) v = 1E+30;
+         if (v < 1E-30) v = 1E-30;
+         iv = 1 / v;
+         if (iv > 1E+30) iv = 1E+30;
+         if (iv < 1E-30) iv = 1E-30;
+         var[z] = 1 / iv;
+      }
+      for (c = 0; c < m->C; c++) wgt[c] = exp(htkamd_host_mix_log_weight(wgt[c]));
+   }
+   for (h = 0; h < m->H; h++) {
+      const int n = (int)llround(acc[lay->nEgs + h]), ti = m->h_hmmTrans[h], N = m->h_transN[ti];
+      const int *hs = m->h_hmmState + m->h_hmmStateOff[h];
+      if (n < cfg->minEgs) st->nSkippedHmm++;
+      if (!(n >= cfg->minEgs && n > 0)) continue;
+      if ((cfg->uFlags & HTKAMD_UPTRANS) && !doneT[ti]) {
+         float *tp = transP + m->h_transOff[ti];
+         for (i = 1; i < N; i++) {
+            const float occi = ACCF(lay->trOcc, m->h_trOccOff[ti] + i - 1);
+            if (occi > 0.0)
+               for (j = 2; j <= N; j++) {
+                  const float x = ACCF(lay->tr, m->h_transOff[ti] + (i - 1) * N + (j - 1)) / occi;
+                  tp[(i - 1) * N + (j - 1)] = (x > MINLARG) ? log(x) : LZERO;
+               }
+            else st->nNoTransOut++;
+         }
+         doneT[ti] = 1;
+      }
+      if (maxM > 1 && (cfg->uFlags & HTKAMD_UPMIXES))
+         for (j = 0; j < N - 2; j++) {
+            const int s = hs[j], c0 = m->h_stateCompOff[s], M = m->h_stateCompOff[s + 1] - c0;
+            const float occi = ACCF(lay->wtOcc, s);
+            if (doneS[s]) continue;
+            if (occi > 0) {
+               for (k = 0; k < M; k++) {
+                  float x = ACCF(lay->wt, c0 + k) / occi;
+                  if (x > 1.0) x = 1.0;
+                  wgt[c0 + k] = (x > MINMIX) ? x : 0.0;
+               }
+               if (cfg->mixWeightFloor > 0.0) {
+                  float sum = 0.0, fsum = 0.0, scale;
+                  const float floor = cfg->mixWeightFloor;
+                  for (k = 0; k < M; k++) {
+                     if (wgt[c0 + k] > floor) sum += wgt[c0 + k];
+                     else { fsum += floor; wgt[c0 + k] = floor; }
+                  }
+                  if (fsum != 0.0 && sum != 0.0) {
+                     scale = (1.0 - fsum) / sum;
+                     for (k = 0; k < M; k++)
+                        if (wgt[c0 + k] > floor) wgt[c0 + k] *= scale;
+                  }
+               }
+            } else st->nNoMixUse++;
+            doneS[s] = 1;
+         }
+      if (cfg->uFlags & HTKAMD_UPVARS)
+         for (j = 0; j < N - 2; j++) {
+            const int s = hs[j];
+            for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
+               if (wgt[c] > MINMIX) {
+                  const int g = m->h_compGauss[c];
+                  if (!doneVa[g]) {
+                     const float occim = ACCF(lay->vaOcc, g);
+                     int mixFloored = 0;
+                     if (occim > 0.0) {
+                        const float muOcc = ACCF(lay->muOcc, g);
+                        const int shared = ((cfg->uFlags & HTKAMD_UPMEANS) == 0 || doneMu[g] || muOcc <= 0.0);
+                        for (k = 0; k < D; k++) {
+                           const float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)g * D + k) / muOcc;
+                           float x = ACCF(lay->va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
+                           if (x < cfg->minVar) { x = cfg->minVar; st->nFloorVar++; mixFloored = 1; }
+                           var[(size_t)g * D + k] = x;
+                        }
+                     } else st->nNoVarUse++;
+                     if (mixFloored) st->nFloorVarMix++;
+                     doneVa[g] = 1;
+                  }
+               }
+         }
+      if (cfg->uFlags & HTKAMD_UPMEANS)
+         for (j = 0; j < N - 2; j++) {
+            const int s = hs[j];
+            for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
+               if (wgt[c] > MINMIX) {
+                  const int g = m->h_compGauss[c];
+                  if (!doneMu[g]) {
+                     const float occim = ACCF(lay->muOcc, g);
+                     if (occim > 0.0)
+                        for (k = 0; k < D; k++) mean[(size_t)g * D + k] += ACCF(lay->mu, (size_t)g * D + k) / occim;
+                     doneMu[g] = 1;
+                  }
+               }
+         }
+      if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))
+         for (j = 0; j < N - 2; j++) {
+            const int s = hs[j];
+            for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
+               if (wgt[c] > MINMIX) {
+                  const int g = m->h_compGauss[c];
+                  htkamd_host_fix_diag_gconst(D, var + (size_t)g * D, gconst + g);
+               }
+         }
+   }
+#undef ACCF
+   free(doneT); free(doneS); free(doneMu); free(doneVa);
+   return HTKAMD_OK;
+}

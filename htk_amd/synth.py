@@ -218,3 +218,109 @@ def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int =
         s.seqs.append(seqs[u].astype(np.int32))
         s.feats.append(X.astype(np.float32))
     return s
+
+
+# --------------------------------------------------------------------------------------------
+# Arbitrary packed model -> text MMF, and a small set with mixed topologies (tee model, 3/4/5-state
+# models, 1..3 mixture components) for the parity tests of the general code paths.
+# --------------------------------------------------------------------------------------------
+
+def write_mmf_packed(path: str, pk: dict, hmm_names: list, kind: str = "USER") -> None:
+    """Text MMF with ~t "T<i>", ~s "S<i>" and ~h macros for any packed model (no shared Gaussians)."""
+    D = int(pk["vecSize"])
+    with open(path, "w") as f:
+        f.write("~o\n<STREAMINFO> 1 %d\n<VECSIZE> %d<NULLD><%s><DIAGC>\n" % (D, D, kind))
+        for t in range(int(pk["numTrans"])):
+            N = int(pk["transN"][t])
+            tp = np.asarray(pk["transP"][pk["transOff"][t]:pk["transOff"][t + 1]], np.float64).reshape(N, N)
+            lin = np.where(tp > -0.5e10, np.exp(tp), 0.0)
+            f.write('~t "T%d"\n<TRANSP> %d\n' % (t, N))
+            for i in range(N):
+                f.write(" " + " ".join("%e" % v for v in lin[i]) + "\n")
+        for s in range(int(pk["numStates"])):
+            c0, c1 = int(pk["stateCompOff"][s]), int(pk["stateCompOff"][s + 1])
+            f.write('~s "S%d"\n' % s)
+            if c1 - c0 > 1:
+                f.write("<NUMMIXES> %d\n" % (c1 - c0))
+            for c in range(c0, c1):
+                g = int(pk["compGauss"][c])
+                if c1 - c0 > 1:
+                    f.write("<MIXTURE> %d %e\n" % (c - c0 + 1, pk["compWeight"][c]))
+                f.write("<MEAN> %d\n%s\n<VARIANCE> %d\n%s\n" % (D, _vec(pk["mean"][g]), D, _vec(pk["var"][g])))
+        for h, name in enumerate(hmm_names):
+            t = int(pk["hmmTrans"][h]); N = int(pk["transN"][t])
+            f.write('~h "%s"\n<BEGINHMM>\n<NUMSTATES> %d\n' % (name, N))
+            for j in range(N - 2):
+                f.write('<STATE> %d\n~s "S%d"\n' % (j + 2, pk["hmmState"][pk["hmmStateOff"][h] + j]))
+            f.write('~t "T%d"\n<ENDHMM>\n' % t)
+
+
+TOPO_NAMES = ["a", "b", "sp", "c", "d", "e"]
+
+
+def make_topo_set(seed: int = 21, D: int = 13, NU: int = 5, outdir: str | None = None):
+    """Packed model with: two 5-state models, a 3-state TEE model "sp" (a_13 > 0), a 4-state model with a skip, a plain
+    3-state model and a second 5-state model sharing a tied state; states with 1, 2 and 3 mixture components.
+    Returns (pk, names, seqs, feats).  Parameters are rounded to the MMF's '%e' precision so that the packed arrays
+    equal what the reference loads from the file written to `outdir`."""
+    rng = np.random.default_rng(seed)
+    lin = [np.array([[0, 1, 0, 0, 0], [0, .6, .4, 0, 0], [0, 0, .5, .5, 0], [0, 0, 0, .7, .3], [0, 0, 0, 0, 0]]),
+           np.array([[0, .7, .3], [0, .6, .4], [0, 0, 0]]),                                   # tee
+           np.array([[0, 1, 0, 0], [0, .5, .3, .2], [0, 0, .6, .4], [0, 0, 0, 0]]),          # skip 2 -> 4
+           np.array([[0, 1, 0], [0, .8, .2], [0, 0, 0]])]
+    transN = np.array([m.shape[0] for m in lin], np.int32)
+    transOff = np.concatenate([[0], np.cumsum(transN ** 2)]).astype(np.int32)
+    with np.errstate(divide="ignore"):
+        # GetTransMat (HModel.c:2003): the file value is read into a float, the log is taken in double
+        transP = np.concatenate([np.where(m.reshape(-1) > 0,
+                                          np.log(np.array([float("%e" % v) for v in m.reshape(-1)], np.float32).astype(np.float64)), LZERO)
+                                 for m in lin]).astype(np.float32)
+    nmix = [1, 2, 3, 2, 1, 3, 2, 2, 1, 3, 2]                    # 11 tied states
+    S = len(nmix); G = sum(nmix)
+    stateCompOff = np.concatenate([[0], np.cumsum(nmix)]).astype(np.int32)
+    mean = round_to_mmf_precision(rng.normal(0, 2.0, size=(G, D)).astype(np.float32))
+    var = round_to_mmf_precision(rng.uniform(0.5, 2.0, size=(G, D)).astype(np.float32))
+    w = np.concatenate([rng.dirichlet(np.ones(m) * 4) for m in nmix]).astype(np.float32)
+    w = round_to_mmf_precision(w)
+    #            a(T0)      b(T0)      sp(T1) c(T2)   d(T3)  e(T0, shares state 1 with a)
+    hmmTrans = np.array([0, 0, 1, 2, 3, 0], np.int32)
+    hmmStates = [[0, 1, 2], [3, 4, 5], [6], [7, 8], [9], [10, 1, 4]]
+    hmmStateOff = np.concatenate([[0], np.cumsum([len(x) for x in hmmStates])]).astype(np.int32)
+    pk = dict(vecSize=D, numStates=S, numComp=G, numGauss=G, stateCompOff=stateCompOff, compWeight=w,
+              compGauss=np.arange(G, dtype=np.int32), mean=mean, var=var, gconst=None,
+              numTrans=len(lin), transN=transN, transOff=transOff, transP=transP, numPhys=len(hmmStates),
+              hmmTrans=hmmTrans, hmmStateOff=hmmStateOff, hmmState=np.concatenate(hmmStates).astype(np.int32))
+    seqs, feats = [], []
+    for u in range(NU):
+        L = int(rng.integers(4, 9))
+        seq = []
+        for k in range(L):
+            h = int(rng.choice([0, 1, 3, 4, 5]))
+            seq.append(h)
+            if k < L - 1 and rng.random() < 0.5:
+                seq.append(2)                              # tee model, never first/last, never twice in a row
+        fr = []
+        for h in seq:
+            for s in hmmStates[h]:
+                n = int(rng.integers(0 if h == 2 else 2, 5))   # the tee model may be skipped entirely
+                for _ in range(n):
+                    c = int(rng.integers(stateCompOff[s], stateCompOff[s + 1]))
+                    fr.append(mean[c] + rng.normal(0, 1, D) * np.sqrt(var[c]))
+        X = np.array(fr, np.float32)
+        seqs.append(np.array(seq, np.int32)); feats.append(X)
+    if outdir:
+        for d in ("data", "lab", "hmm0", "hmm1"):
+            os.makedirs(os.path.join(outdir, d), exist_ok=True)
+        write_mmf_packed(os.path.join(outdir, "hmm0", "MMF"), pk, TOPO_NAMES)
+        with open(os.path.join(outdir, "hmmlist"), "w") as f:
+            f.write("\n".join(TOPO_NAMES) + "\n")
+        with open(os.path.join(outdir, "config"), "w") as f:
+            f.write("BINARYACCFORMAT = T\n")
+        with open(os.path.join(outdir, "train.scp"), "w") as scp:
+            for u in range(NU):
+                fn = "%s/data/u%05d.mfc" % (outdir, u)
+                write_htk_param(fn, feats[u], kind=9)      # USER
+                with open("%s/lab/u%05d.lab" % (outdir, u), "w") as f:
+                    f.write("\n".join(TOPO_NAMES[h] for h in seqs[u]) + "\n")
+                scp.write(fn + "\n")
+    return pk, list(TOPO_NAMES), seqs, feats

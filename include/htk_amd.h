@@ -138,6 +138,29 @@ int  htkamd_accs_download(htkamd_accs *a, double *hostVec /*[layout.total]*/, vo
 int  htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream); /* LoadAccs: adds */
 
 /* ------------------------------------------------------------------------------------------
+ * Model update after a pass: UpdateModels (HERest.c:1326) -> MLUpdateModels (HERest.c:1262) with
+ * UpdateTrans :795, UpdateWeights :897 (+FloorMixes :819), UpdateVars :1045, UpdateMeans :974 and
+ * FixGConsts (HModel.c:5688).  Runs on the host (milliseconds, as in the reference) from a host copy of
+ * the summed accumulator vector, then refreshes the device tables.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+   int   minEgs;            /* HERest -m, default 3 (HERest.c:96)                                  */
+   float minVar;            /* HERest -v, default 0.0 (HERest.c:95)                                */
+   float mixWeightFloor;    /* HERest -w f gives f*MINMIX (HERest.c:425), default 0.0              */
+   int   uFlags;            /* HTKAMD_UP* bits                                                     */
+   int   singleProcess;     /* 1 = parMode -1: ForceDiagC/ConvExpWt round trips (HERest.c:1336-1339) */
+} htkamd_update_config;
+typedef struct {
+   int nFloorVar, nFloorVarMix;      /* "Total %d floored variance elements in %d different mixes"  */
+   int nSkippedHmm;                  /* models copied because they had < minEgs examples (-2331)     */
+   int nNoTransOut, nNoMixUse, nNoVarUse;   /* warnings -2326 / -2330                                */
+} htkamd_update_stats;
+int htkamd_model_update(htkamd_model *m, const htkamd_accs *accs, const double *hostVec,
+                        const htkamd_update_config *cfg, htkamd_update_stats *stats);
+/* Current parameters (DIAGC variances, linear weights, log transitions); any pointer may be NULL. */
+int htkamd_model_get_params(htkamd_model *m, float *mean, float *var, float *gconst, float *compWeight, float *transP);
+
+/* ------------------------------------------------------------------------------------------
  * Forward-backward over a batch of utterances: replaces, per utterance,
  *     Boolean FBFile(FBInfo*, UttInfo*, char *datafn)          HFB.h:143 / HFB.c:1923
  * i.e. StepBack (SetBeamTaper, Setotprob, SetBeta with the beta beam and its retry loop) and

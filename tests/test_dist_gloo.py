@@ -1,0 +1,86 @@
+"""The multi-rank path on CPU: two processes (gloo), utterance shards, one all-reduce of the accumulator vector,
+identical update on every rank -- the same code bench.py / the drivers use with backend nccl (= RCCL) on the GPUs.
+Per-rank statistics come from the oracle here (there is no GPU in this container); what is under test is the
+sharding, the vector layout, the collective and that the merged result equals the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from htk_amd import herest, synth
+    from oracle import pyoracle as po
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = synth.generate(30, 3, 20, 9, 90, 55)
+    pk = s.packed()
+    m = po.Model(pk)
+    lay = herest.layout_from_packed(pk)
+    mine = herest.shard_indices(len(s.feats), rank, world)
+    acc = po.Accs(m); cfg = po.fb_cfg()
+    tot_pr, tot_t, done = 0.0, 0, 0
+    for u in mine:
+        rc, pr, _ = po.fb_utt(m, cfg, s.feats[u], s.seqs[u], acc)
+        if rc == 1:
+            tot_pr += pr; tot_t += s.feats[u].shape[0]; done += 1
+    vec = herest.pack_vector(lay, acc, tot_pr, tot_t, done)
+    t = torch.from_numpy(vec)
+    herest.all_reduce_accumulators(t)                      # dist.all_reduce(SUM) on the flat fp64 vector
+    q.put((rank, t.numpy().copy(), list(mine)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_equals_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, v0, s0), (r1, v1, s1) = res
+    assert np.array_equal(v0, v1)                           # every rank holds the same sum
+    assert sorted(s0 + s1) == list(range(9)) and not set(s0) & set(s1)
+    # single process reference
+    sys.path.insert(0, ROOT)
+    from htk_amd import herest, synth
+    from oracle import pyoracle as po
+    s = synth.generate(30, 3, 20, 9, 90, 55)
+    pk = s.packed(); m = po.Model(pk); acc = po.Accs(m); cfg = po.fb_cfg()
+    tot_pr, tot_t = 0.0, 0
+    for u in range(9):
+        rc, pr, _ = po.fb_utt(m, cfg, s.feats[u], s.seqs[u], acc)
+        tot_pr += pr; tot_t += s.feats[u].shape[0]
+    lay = herest.layout_from_packed(pk)
+    ref = herest.pack_vector(lay, acc, tot_pr, tot_t, 9)
+    # float accumulators summed in a different order: the reference's own -p N merge differs at this level too
+    assert np.allclose(v0, ref, rtol=2e-5, atol=1e-5)
+    assert v0[lay["nUttDone"]] == 9 and v0[lay["totalT"]] == tot_t
+    assert np.array_equal(v0[lay["nEgs"]:lay["nEgs"] + 20], acc.nEgs.astype(np.float64))
+
+
+def test_shards_are_balanced_and_disjoint():
+    sys.path.insert(0, ROOT)
+    from htk_amd import herest
+    for n, w in ((10000, 8), (7, 8), (9, 2), (0, 4)):
+        parts = [herest.shard_indices(n, r, w) for r in range(w)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

@@ -1,0 +1,257 @@
+"""Parity of the HIP path (through the C ABI) against the reference's golden vectors and the oracle.
+Runs on the MI355X box:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from util import acc_close, batch_arrays, load_case, mmf_fmt
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["fb_small", "fb_small_prune", "fb_topo", "fb_topo_prune"]
+
+
+def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15):
+    model = native.Model(pk)
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = native.DevArray(X)
+    fb = native.ForwardBackward(model, debug=debug, force_general=general)
+    acc = native.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+    fb.execute(native.fb_config(uFlags=uFlags, **(prune or {})), acc)
+    pr, st = fb.results()
+    return model, fb, acc, pr, st
+
+
+# ----------------------------------------------------------------------------------------- scoring (K1)
+@pytest.mark.parametrize("name", ["fb_small", "fb_topo"])
+def test_outp_block_bit_exact(native, oracle, name):
+    """IDOutP + ShStrP/cSOutP arithmetic: every float identical to the oracle (which is bit-exact vs the reference)."""
+    case = load_case(name)
+    gm, om = native.Model(case["pk"]), oracle.Model(case["pk"])
+    X = np.concatenate([u["feat"] for u in case["utts"]])
+    states = np.arange(case["pk"]["numStates"], dtype=np.int32)
+    got, ref = gm.outp_block(X, states), om.score_block(X, states)
+    assert np.array_equal(got, ref)
+    prep = gm.get_prepared()
+    assert np.array_equal(prep["ivar"], om.ivar) and np.array_equal(prep["gconst"], om.gconst)
+    assert np.array_equal(prep["compLogWt"], om.compLogWt)
+
+
+@pytest.mark.parametrize("D,M", [(20, 3), (26, 2), (39, 16), (7, 1)])
+def test_outp_block_other_sizes(native, oracle, D, M):
+    """D = 26/39 use the register-resident kernels, D = 20/7 the any-D kernel; M = 1 skips the LAdd; ragged T."""
+    from htk_amd import synth
+    s = synth.generate(25, M, 10, 1, 333, 40 + D, D=D)
+    pk = s.packed()
+    gm, om = native.Model(pk), oracle.Model(pk)
+    X = s.feats[0]
+    states = np.array([3, 3, 0, 24, 7, 11], np.int32)          # repeats and arbitrary order are allowed
+    assert np.array_equal(gm.outp_block(X, states), om.score_block(X, states))
+    assert gm.outp_block(X[:0], states).shape == (0, 6)
+    assert np.array_equal(gm.outp_block(X[:1], states), om.score_block(X[:1], states))
+
+
+def test_outp_large_block_statistics(native, oracle):
+    """BASELINE config-2 shape (1k states x 8 mix, 2 x 500 frames x all states = 1M scores): bit-exact on a sample of rows,
+    and every score finite and negative."""
+    from htk_amd import synth
+    s = synth.generate(1000, 8, 2000, 2, 500, 1)
+    pk = s.packed()
+    gm, om = native.Model(pk), oracle.Model(pk)
+    X = np.concatenate(s.feats)
+    states = np.arange(1000, dtype=np.int32)
+    got = gm.outp_block(X, states)
+    assert np.isfinite(got).all() and (got < 0).all()
+    rows = np.arange(0, 1000, 37)
+    assert np.array_equal(got[rows], om.score_block(X[rows], states))
+
+
+# ----------------------------------------------------------------------------------------- forward-backward
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("name", CASES)
+def test_forward_backward_vs_reference(native, name, general):
+    case = load_case(name)
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], general=general)
+    for u, ut in enumerate(case["utts"]):
+        assert st[u] == ut["ok"] == 1
+        assert abs(pr[u] - float(ut["pr"])) <= 1e-10 * abs(float(ut["pr"]))       # alpha/beta bar is 1e-4 relative
+        g = fb.trellis(u)
+        for k in ("qLo", "qHi", "aLo", "aHi"):
+            assert np.array_equal(g[k], ut[k]), k
+        if "beta" in ut:
+            for k in ("beta", "alpha"):
+                ref, got = ut[k], g[k]
+                if k == "beta":
+                    assert np.array_equal(np.isnan(ref), np.isnan(got))
+                ok = ~np.isnan(ref) & (ref > -1e9)
+                assert np.allclose(got[ok], ref[ok], rtol=1e-10, atol=0), k
+                zero = ~np.isnan(ref) & (ref <= -1e9)                              # log-zero stays log-zero
+                assert (got[zero] < -0.5e10).all()
+            ok = ~np.isnan(ut["outp"])
+            assert np.array_equal(g["outp"][ok], ut["outp"][ok])                   # output probabilities: bit-exact
+    a = acc.download()
+    ref = case["acc"]
+    assert np.array_equal(a["nEgs"], ref["nEgs"])
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+        acc_close(a[k], ref[k], "%s/%s" % (name, k))
+    assert a["nUttDone"] == len(case["utts"]) and a["nUttSkipped"] == 0
+    assert abs(a["totalPr"] - float(ref["totalPr"])) <= 1e-5 * abs(float(ref["totalPr"]))   # HERest keeps it as float
+    assert a["totalT"] == int(ref["totalT"])
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("prune", [dict(pruneInit=0.5, pruneInc=2.0, pruneLim=12.0), dict(pruneInit=0.01, pruneInc=0.0, pruneLim=0.01)],
+                         ids=["retry", "overprune"])
+def test_pruning_retry_and_skip(native, oracle, prune, general):
+    """StepBack's retry loop (HFB.c:1332-1361) and the skip of over-pruned utterances, against the oracle."""
+    from htk_amd import synth
+    po = oracle
+    s = synth.generate(30, 3, 20, 6, 90, 103)
+    pk = s.packed()
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    model, fb, acc, pr, st = run_fb(native, pk, utts, prune, general=general)
+    om = po.Model(pk); oacc = po.Accs(om); cfg = po.fb_cfg(**prune)
+    nskip = 0
+    for u in range(6):
+        rc, opr, d = po.fb_utt(om, cfg, s.feats[u], s.seqs[u], oacc, dump=True)
+        assert st[u] == rc
+        if rc == 1:
+            assert abs(pr[u] - opr) <= 1e-10 * abs(opr)
+            g = fb.trellis(u)
+            for k in ("qLo", "qHi", "aLo", "aHi"):
+                assert np.array_equal(g[k], d[k]), k
+        else:
+            nskip += 1
+    a = acc.download()
+    assert a["nUttSkipped"] == nskip and a["nUttDone"] == 6 - nskip
+    acc_close(a["muOcc"], oacc.muOcc, "muOcc"); acc_close(a["tr"], oacc.tr, "tr")
+
+
+def test_ragged_batch_skips_and_empty(native, oracle):
+    """Utterances of different lengths in one batch; one too short for its transcription (qt > T, HFB.c:1339);
+    an empty batch is a no-op."""
+    from htk_amd import synth
+    po = oracle
+    s = synth.generate(30, 2, 20, 5, 96, 9)
+    pk = s.packed()
+    lens = [96, 40, 5, 77, 24]                                 # Q = 8 models x minDur 3 = 24 frames minimum
+    utts = [dict(seq=q, feat=x[:n]) for q, x, n in zip(s.seqs, s.feats, lens)]
+    model, fb, acc, pr, st = run_fb(native, pk, utts)
+    om = po.Model(pk); oacc = po.Accs(om); cfg = po.fb_cfg()
+    for u, ut in enumerate(utts):
+        rc, opr, _ = po.fb_utt(om, cfg, ut["feat"], ut["seq"], oacc)
+        assert st[u] == rc
+        if rc == 1:
+            assert abs(pr[u] - opr) <= 1e-10 * abs(opr)
+    assert list(st) == [1, 1, 0, 1, 1]
+    a = acc.download()
+    acc_close(a["mu"], oacc.mu, "mu"); acc_close(a["va"], oacc.va, "va"); acc_close(a["wt"], oacc.wt, "wt")
+    assert np.array_equal(a["nEgs"], oacc.nEgs)
+    # empty batch
+    fb2 = native.ForwardBackward(model)
+    dX = native.DevArray(np.zeros((1, 39), np.float32))
+    fb2.prepare(dX.ptr.value, np.array([0], np.int32), np.array([0], np.int32), np.zeros(0, np.int32))
+    acc2 = native.Accs(model)
+    fb2.execute(native.fb_config(), acc2)
+    assert acc2.download()["nUttDone"] == 0
+
+
+def test_update_flags_subset(native, oracle):
+    """-u m / -u v / -u t style passes only touch the requested accumulators (HFB.c:1663-1721)."""
+    from htk_amd import capi
+    case = load_case("fb_small")
+    om = oracle.Model(case["pk"])
+    for flags in (capi.UPMEANS, capi.UPVARS, capi.UPTRANS, capi.UPMIXES | capi.UPMEANS):
+        model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], uFlags=flags)
+        oacc = oracle.Accs(om); cfg = oracle.fb_cfg(uFlags=flags)
+        for ut in case["utts"]:
+            oracle.fb_utt(om, cfg, ut["feat"], ut["seq"], oacc)
+        a = acc.download()
+        for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+            acc_close(a[k], getattr(oacc, k), "flags=%d %s" % (flags, k))
+
+
+# ----------------------------------------------------------------------------------------- update (host C)
+@pytest.mark.parametrize("name", ["fb_small", "fb_topo"])
+def test_model_update_vs_reference_mmf(native, name):
+    """Accumulate on the GPU, update with htk_amd/host/update.c, compare with the MMF the reference's HERest -m 1 wrote.
+    Means within 1e-4*max(|ref|, sigma), variances/weights/gconst within 1e-4 relative."""
+    case = load_case(name)
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], debug=False)
+    a = acc.download()
+    stats = model.update(acc, a["vec"], minEgs=1, singleProcess=True)
+    p = model.get_params()
+    upd = case["upd"]
+    ref_mean = np.asarray(upd["mean"], np.float64); ref_var = np.asarray(upd["var"], np.float64)
+    ok = ~np.isnan(ref_mean)
+    sigma = np.sqrt(np.where(ok, np.abs(ref_var), 1.0))
+    assert (np.abs(p["mean"] - ref_mean)[ok] <= 1e-4 * np.maximum(np.abs(ref_mean), sigma)[ok] + 1e-6).all()
+    assert np.allclose(p["var"][ok], ref_var[ok], rtol=2e-4, atol=1e-6)
+    w = np.asarray(upd["compWeight"], np.float64)
+    assert np.allclose(p["compWeight"], w, rtol=1e-4, atol=2e-6)
+    gc = np.asarray(upd["gconst"], np.float64); okg = ~np.isnan(gc)
+    assert np.allclose(p["gconst"][okg], gc[okg], rtol=1e-5, atol=1e-4)
+    lin = np.where(p["transP"] > -0.5e10, np.exp(p["transP"].astype(np.float64)), 0.0)
+    assert np.allclose(lin, np.asarray(upd["transLin"], np.float64), rtol=1e-4, atol=1e-6)
+    assert "floored variance" not in case["log"] or stats["nFloorVar"] >= 0
+
+
+def test_em_iterations_increase_likelihood(native):
+    """Three Baum-Welch iterations through prepare/execute/update: the total log-likelihood must not decrease."""
+    from htk_amd import synth
+    s = synth.generate(20, 2, 12, 24, 72, 77)
+    pk = s.packed()
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    model = native.Model(pk); dX = native.DevArray(X)
+    fb = native.ForwardBackward(model); acc = native.Accs(model)
+    tot = []
+    for it in range(3):
+        acc.zero()
+        fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+        fb.execute(native.fb_config(), acc)
+        pr, st = fb.results()
+        assert (st == 1).all()
+        tot.append(pr.sum())
+        a = acc.download()
+        model.update(acc, a["vec"], minEgs=1, minVar=0.01)
+    assert tot[1] >= tot[0] - 1e-6 and tot[2] >= tot[1] - 1e-6
+
+
+# ----------------------------------------------------------------------------------------- full-size properties
+def test_config2_properties(native):
+    """1k states x 8 mix, 64 x 500-frame utterances (BASELINE config 2): size-independent invariants.
+    sum_j gamma_j(t) = 1 per frame -> total occupancy = frames; weight counts = occupancy; transitions out of the
+    entry state = one per model instance; first utterances match the reference's printed per-frame log probabilities."""
+    from htk_amd import synth
+    import os, util
+    s = synth.generate(1000, 8, 2000, 64, 500, 1)
+    pk = s.packed()
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    model, fb, acc, pr, st = run_fb(native, pk, utts, debug=False)
+    assert (st == 1).all()
+    known = np.load(os.path.join(util.GOLDEN, "c2_known.npz"))["per_frame"]
+    for u in range(3):
+        assert float("%e" % (pr[u] / 500)) == float("%e" % known[u])
+    a = acc.download()
+    frames = 64 * 500
+    assert abs(a["muOcc"].sum() - frames) < 1e-3 * frames          # components below the MINFORPROB prune are dropped
+    assert abs(a["wt"].sum() - a["muOcc"].sum()) < 1e-6 * frames
+    assert abs(a["wtOcc"].sum() - a["muOcc"].sum()) < 1e-6 * frames
+    assert a["nEgs"].sum() == 64 * 41 and a["totalT"] == frames
+    tr = a["tr"].reshape(5, 5)
+    assert abs(tr[0, 1] - 64 * 41) < 1e-6 * 64 * 41               # every model instance is entered exactly once
+    assert abs(tr[1:4, 4].sum() - 64 * 41) < 1e-6 * 64 * 41       # ... and left exactly once
+    assert abs(a["trOcc"][1:4].sum() - frames) < 1e-6 * frames    # emitting-state occupancy sums to the frame count
+    assert "%.6e" % (a["totalPr"] / a["totalT"]) == "-6.108214e+01"  # HERest: "average log prob per frame" 
+    assert a["nEval"] == fb.frame_states() == 64 * 47220
+
+
+def test_accumulator_merge_is_load_accs(native):
+    """upload_add == LoadAccs (HTrain.c:1625): adding a dumped vector to a zeroed set reproduces it; adding twice doubles."""
+    case = load_case("fb_small")
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], debug=False)
+    v = acc.download()["vec"].copy()
+    acc2 = native.Accs(model)
+    acc2.upload_add(v); acc2.upload_add(v)
+    assert np.array_equal(acc2.download()["vec"], 2 * v)

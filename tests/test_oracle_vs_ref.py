@@ -1,0 +1,69 @@
+"""Live cross-check of the oracle against the reference build (oracle/_ref) on fresh seeds.  Runs only where the
+reference was built (this container); the committed golden vectors cover the same ground elsewhere."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from util import REFDIR, eq_nan
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "ref_fbdump")),
+                                reason="oracle/_ref not built (needs /root/reference)")
+
+
+def run_ref(d, tflag=""):
+    from oracle import refio
+    scp = open(os.path.join(d, "train.scp")).read().split()
+    r = subprocess.run("%s/ref_fbdump -C config %s -H hmm0/MMF -L lab -p 1 -M hmm1 hmmlist dump.bin %s"
+                       % (REFDIR, tflag, " ".join(scp)), shell=True, cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return refio.read_fbdump(os.path.join(d, "dump.bin"))
+
+
+@pytest.mark.parametrize("seed,tflag,prune", [
+    (101, "", {}),
+    (102, "-t 40.0", dict(pruneInit=40.0, pruneInc=0.0, pruneLim=40.0)),
+    (103, "-t 0.5 2.0 12.0", dict(pruneInit=0.5, pruneInc=2.0, pruneLim=12.0)),     # forces retries of the beta pass
+    (104, "-t 0.01", dict(pruneInit=0.01, pruneInc=0.0, pruneLim=0.01)),             # over-pruning: utterances skipped
+])
+def test_random_set(oracle, seed, tflag, prune):
+    from htk_amd import synth
+    from oracle import refio
+    po = oracle
+    with tempfile.TemporaryDirectory() as d:
+        s = synth.generate(30, 3, 20, 5, 90, seed, outdir=d)
+        ref = run_ref(d, tflag)
+        pk = s.packed()
+        m = po.Model(pk); acc = po.Accs(m); cfg = po.fb_cfg(**prune)
+        for u in range(5):
+            rc, pr, dd = po.fb_utt(m, cfg, s.feats[u], s.seqs[u], acc, dump=True)
+            r = ref[u]
+            assert rc == r["ok"]
+            if not rc:
+                continue
+            assert pr == r["pr"]
+            for k in ("qLo", "qHi", "aLo", "aHi"):
+                assert np.array_equal(dd[k], r[k])
+            b = dd["beta"].copy(); b[np.isnan(r["beta"])] = np.nan
+            assert eq_nan(b, r["beta"]) and eq_nan(dd["alpha"], r["alpha"]) and eq_nan(dd["occ"], r["occ"])
+        ra = refio.read_acc(os.path.join(d, "hmm1", "HER1.acc"), pk, ["p%d" % i for i in range(20)])
+        for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs"):
+            assert np.array_equal(np.asarray(getattr(acc, k)).reshape(-1), ra[k].reshape(-1)), k
+
+
+def test_too_short_utterance_is_skipped(oracle):
+    """qt > T: 'Unable to traverse' (HFB.c:1339-1344) -> FBFile returns FALSE, nothing accumulated."""
+    from htk_amd import synth
+    po = oracle
+    with tempfile.TemporaryDirectory() as d:
+        s = synth.generate(30, 2, 20, 2, 36, 7, outdir=d)          # Q = 3 models, min 9 frames
+        # truncate the second utterance to 5 frames
+        X = s.feats[1][:5]
+        synth.write_htk_param(os.path.join(d, "data", "u00001.mfc"), X)
+        ref = run_ref(d)
+        assert ref[0]["ok"] == 1 and ref[1]["ok"] == 0
+        m = po.Model(s.packed()); acc = po.Accs(m)
+        rc, _, _ = po.fb_utt(m, po.fb_cfg(), X, s.seqs[1], acc)
+        assert rc == 0 and acc.nEgs.sum() == 0
