@@ -125,6 +125,13 @@ void orc_update(const orc_model *m, const orc_accs *acc, const orc_updcfg *cfg,
                 float *gconst /*[G] in/out*/, float *compWeight /*[C] linear in/out*/,
                 float *transP /*in/out (log)*/, orc_updstats *st);
 
+/* ---- Viterbi forced alignment of a chain of physical models (HRec token passing, 1-best; orc_viterbi.c) ----
+   Returns the number of state segments (time order) or -1 when no token survives.  Frames are 0-based,
+   [segStart, segEnd).  segScore = like(next Align record) - like(this one) (LatFromPaths HRec.c:1512). */
+int orc_viterbi_align(const orc_model *m, const float *X, int T, const int *labs, int Q, float genBeam,
+                      int maxSeg, int *segQ, int *segState, int *segStart, int *segEnd, double *segScore,
+                      int *modStart, int *modEnd, double *modScore, double *totalLike);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,3 +191,35 @@ def update(m: Model, acc: Accs, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags
                      _p(m.compWeight), _p(m.transP), C.byref(st))
     m.refresh()
     return dict(nFloorVar=st.nFloorVar, nFloorVarMix=st.nFloorVarMix, nSkippedHmm=st.nSkippedHmm)
+
+
+def viterbi_align(m: Model, X: np.ndarray, labs: np.ndarray, genBeam: float = 1.0e10):
+    """HVite -a -f -m on a chain of physical models (HRec.c token passing).  Returns dict or None if no token survived."""
+    X = np.ascontiguousarray(X, np.float32); labs = np.ascontiguousarray(labs, np.int32)
+    T, Q = X.shape[0], len(labs)
+    maxSeg = int(sum(m.transN[m.hmmTrans[h]] - 2 for h in labs))
+    sq = np.zeros(maxSeg, np.int32); ss = np.zeros(maxSeg, np.int32); s0 = np.zeros(maxSeg, np.int32); s1 = np.zeros(maxSeg, np.int32)
+    sc = np.zeros(maxSeg, np.float64)
+    m0 = np.zeros(Q, np.int32); m1 = np.zeros(Q, np.int32); msc = np.zeros(Q, np.float64)
+    tot = C.c_double(0.0)
+    n = lib().orc_viterbi_align(C.byref(m.c), _p(X), C.c_int(T), _p(labs), C.c_int(Q), C.c_float(genBeam), C.c_int(maxSeg),
+                                _p(sq), _p(ss), _p(s0), _p(s1), _p(sc), _p(m0), _p(m1), _p(msc), C.byref(tot))
+    if n < 0:
+        return None
+    return dict(n=n, q=sq[:n], state=ss[:n], start=s0[:n], end=s1[:n], score=sc[:n], modStart=m0, modEnd=m1, modScore=msc,
+                total=tot.value)
+
+
+def format_rec(res: dict, labs, names, frame_dur: int = 100000):
+    """The label lines HVite -a -f -m writes (start end s<j> score [model modelscore [word]]), HRec.c:2300-2335."""
+    lines = []
+    lastq = -1
+    for k in range(res["n"]):
+        q = int(res["q"][k])
+        s = "%d %d s%d %f" % (res["start"][k] * frame_dur, res["end"][k] * frame_dur, res["state"][k], np.float32(res["score"][k]))
+        if q != lastq:
+            nm = names[labs[q - 1]]
+            s += " %s %f %s" % (nm, np.float32(res["modScore"][q - 1]), nm)
+            lastq = q
+        lines.append(s)
+    return lines
