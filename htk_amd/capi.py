@@ -297,3 +297,71 @@ class ForwardBackward:
             self.close()
         except Exception:
             pass
+
+
+class Viterbi:
+    """htkamd_viterbi holder: HVite -a forced alignment of a batch (HRec token passing on the label chain)."""
+
+    def __init__(self, model: Model):
+        self.model = model
+        self.h = C.c_void_p()
+        check(lib().htkamd_viterbi_create(model.h, C.byref(self.h)), "viterbi_create")
+        self._keep = None
+
+    def align(self, dX_ptr: int, frameOff, labOff, labs, genBeam: float = 1.0e10, stream=None):
+        frameOff = np.ascontiguousarray(frameOff, np.int32); labOff = np.ascontiguousarray(labOff, np.int32)
+        labs = np.ascontiguousarray(labs, np.int32)
+        self._keep = (frameOff, labOff, labs)
+        nUtt = len(frameOff) - 1
+        b = BatchDesc(nUtt, C.c_void_p(dX_ptr), _p(frameOff), _p(labOff), _p(labs))
+        check(lib().htkamd_viterbi_align(self.h, C.byref(b), C.c_float(genBeam), stream), "viterbi_align")
+        ns = C.c_size_t(); nm = C.c_size_t()
+        check(lib().htkamd_viterbi_sizes(self.h, C.byref(ns), C.byref(nm)), "viterbi_sizes")
+        r = dict(segStart=np.empty(ns.value, np.int32), segEnd=np.empty(ns.value, np.int32), segScore=np.empty(ns.value, np.float64),
+                 modStart=np.empty(nm.value, np.int32), modEnd=np.empty(nm.value, np.int32), modScore=np.empty(nm.value, np.float64),
+                 total=np.empty(nUtt, np.float64), status=np.empty(nUtt, np.int32))
+        check(lib().htkamd_viterbi_results(self.h, _p(r["segStart"]), _p(r["segEnd"]), _p(r["segScore"]), _p(r["modStart"]),
+                                           _p(r["modEnd"]), _p(r["modScore"]), _p(r["total"]), _p(r["status"]), stream), "viterbi_results")
+        # split per utterance
+        m = self.model
+        k = m._keep
+        out = []
+        so = mo = 0
+        for u in range(nUtt):
+            ql = labs[labOff[u]:labOff[u + 1]]
+            nst = [int(k["transN"][k["hmmTrans"][h]]) - 2 for h in ql]
+            n = sum(nst)
+            out.append(dict(labs=ql, nStates=nst, segStart=r["segStart"][so:so + n], segEnd=r["segEnd"][so:so + n],
+                            segScore=r["segScore"][so:so + n], modStart=r["modStart"][mo:mo + len(ql)],
+                            modEnd=r["modEnd"][mo:mo + len(ql)], modScore=r["modScore"][mo:mo + len(ql)],
+                            total=r["total"][u], status=int(r["status"][u])))
+            so += n; mo += len(ql)
+        return out
+
+    def close(self):
+        if self.h:
+            lib().htkamd_viterbi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_rec(utt: dict, names, frame_dur: int = 100000):
+    """Label lines as HVite -a -f -m writes them: start end s<j> score [model modelscore word] (HRec.c:2300-2335)."""
+    lines = []
+    k = 0
+    for q, (h, ns) in enumerate(zip(utt["labs"], utt["nStates"])):
+        first = True
+        for j in range(ns):
+            if utt["segStart"][k] >= 0:
+                s = "%d %d s%d %f" % (utt["segStart"][k] * frame_dur, utt["segEnd"][k] * frame_dur, j + 2, np.float32(utt["segScore"][k]))
+                if first:
+                    s += " %s %f %s" % (names[h], np.float32(utt["modScore"][q]), names[h])
+                    first = False
+                lines.append(s)
+            k += 1
+    return lines

@@ -1,0 +1,470 @@
+// viterbi.hip -- K5: Viterbi forced alignment (HVite -a) of a batch of utterances, one wavefront per utterance.
+//
+// Reference semantics (HRec.c, 1-best, alignment network = linear chain of the transcription's models, see
+// oracle/orc_viterbi.c for the restatement this kernel is tested against):
+//   StepHMM1 642-787   best predecessor over [seIndex[j][0], seIndex[j][1]], first maximum wins; token likes are
+//                      double sums of float log transition / output probabilities; genThresh state pruning
+//   ProcessObservation 1935-2030  genThresh = float(genMax - genBeam) floored at LSMALL, one frame stale in pass 1;
+//                      pass 2 detaches instances below it, StepHMM2 (790) passes tee models, SetEntryState (1303)
+//   LatFromPaths 1512-1660 / TranscriptionFromLattice 2176  state and model segments with scores
+//
+// MI355X mapping: as in fb_wave.hip, lane q owns model q (tokens, transition matrix, seIndex in registers); the
+// exit -> entry hand-over to the next model is a wave shuffle, the per-frame maximum a wave reduction, the tee
+// chain a loop over the set bits of a ballot.  Output probabilities come from K1 (bit-exact scores), so the token
+// likes -- the same additions in the same order as the reference -- are bit-identical and so are the alignments.
+// Per frame each lane writes its states' back-pointers (1 byte) and pre-output likes (8 bytes) as a contiguous run.
+// A second tiny kernel walks the back-pointers (one lane per utterance) and emits the segments.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+
+#define VWPB 4
+#define VMAXN 5
+
+struct VitUtt {
+   int T, Q, nSlots, frame0, q0, slot0, status, pad;
+   size_t outp0;      // floats : outp[outp0 + slot*T + (t-1)]
+   size_t tr0;        // per-(t,slot) trellis index base: (t-1)*nSlots + slot
+   size_t mt0;        // per-(t,model) trellis index base: t*Q + (q-1), t = 0..T
+   size_t seg0;       // per-slot output base
+   size_t mod0;       // per-model output base
+};
+
+struct VitArgs {
+   const VitUtt *utt; int nUtt;
+   const int *mN, *mTp, *mSlot0;
+   const float *transP, *outp;
+   signed char *bp; double *pre;           // [sum T*nSlots]
+   double *exl, *entAt; signed char *exbp; // [sum (T+1)*Q]
+   int *segStart, *segEnd; double *segScore;   // [sum nSlots]
+   int *modStart, *modEnd; double *modScore;   // [sum Q]
+   double *total; int *status;             // [nUtt]
+   float genBeam;
+};
+
+template <int MAXN>
+__global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
+{
+   const int lane = threadIdx.x & 63;
+   const int u = blockIdx.x * VWPB + (threadIdx.x >> 6);
+   if (u >= a.nUtt) return;
+   const VitUtt ud = a.utt[u];
+   if (ud.status != HTKAMD_UTT_OK) { if (lane == 0) { a.status[u] = ud.status; a.total[u] = LZERO; } return; }
+   const int T = ud.T, Q = ud.Q, nSlots = ud.nSlots;
+   const int q = lane + 1;
+   const bool valid = q <= Q;
+   int N = 0, ms0 = 0;
+   float tp[MAXN][MAXN];
+   int seLo[MAXN + 1], seHi[MAXN + 1];
+#pragma unroll
+   for (int i = 0; i < MAXN; i++)
+#pragma unroll
+      for (int j = 0; j < MAXN; j++) tp[i][j] = (float)LZERO;
+#pragma unroll
+   for (int j = 0; j <= MAXN; j++) { seLo[j] = 1; seHi[j] = 1; }
+   if (valid) {
+      const int mi = ud.q0 + q - 1;
+      N = a.mN[mi]; ms0 = a.mSlot0[mi];
+      const float *g = a.transP + a.mTp[mi];
+#pragma unroll
+      for (int i = 0; i < MAXN; i++)
+#pragma unroll
+         for (int j = 0; j < MAXN; j++)
+            if (i < N && j < N) tp[i][j] = g[i * N + j];
+      // CreateSEIndex (HRec.c:1403-1431)
+#pragma unroll
+      for (int j = 2; j <= MAXN; j++)
+         if (j <= N) {
+            int mn = N, mx = 1;
+#pragma unroll
+            for (int i = MAXN - 1; i >= 1; i--)
+               if (i < N && i >= ((j == N) ? 2 : 1) && tp[i - 1][j - 1] > (float)LSMALL) mn = i;
+#pragma unroll
+            for (int i = 2; i < MAXN; i++)
+               if (i < N && tp[i - 1][j - 1] > (float)LSMALL) mx = i;
+            if (mn > mx) { mn = (j == N) ? 2 : 1; mx = N - 1; }
+            seLo[j] = mn; seHi[j] = mx;
+         }
+   }
+   float aN[MAXN];                                      // aN[i] = log a_iN
+   int loN = 2, hiN = 1;
+#pragma unroll
+   for (int i = 0; i < MAXN; i++) aN[i] = (float)LZERO;
+#pragma unroll
+   for (int j = 2; j <= MAXN; j++)
+      if (j == N) {
+         loN = seLo[j]; hiN = seHi[j];
+#pragma unroll
+         for (int i = 1; i < MAXN; i++) if (i < N) aN[i] = tp[i - 1][j - 1];
+      }
+   const float a1N = aN[1 % MAXN];
+   const bool tee = valid && a1N > (float)LSMALL;
+   const unsigned long long teeMask = __ballot(tee);
+
+   const float *orow = a.outp + ud.outp0 + (size_t)ms0 * T;
+   signed char *gbp = a.bp + ud.tr0 + ms0;
+   double *gpre = a.pre + ud.tr0 + ms0;
+   double *gexl = a.exl + ud.mt0 + (q - 1), *gent = a.entAt + ud.mt0 + (q - 1);
+   signed char *gexbp = a.exbp + ud.mt0 + (q - 1);
+
+   double like[MAXN + 1];                                // like[i], i = 1 (entry) .. N-1
+#pragma unroll
+   for (int i = 0; i <= MAXN; i++) like[i] = LZERO;
+   double exitL = LZERO, instMax = LZERO;
+   bool active = false;
+   float genThresh = (float)LSMALL;
+   float ob[MAXN], obN[MAXN];
+#pragma unroll
+   for (int j = 0; j < MAXN; j++) { ob[j] = 0.f; obN[j] = 0.f; }
+   if (valid && T >= 1) {
+#pragma unroll
+      for (int j = 2; j < MAXN; j++) if (j < N) obN[j] = orow[(size_t)(j - 2) * T];
+   }
+   double finalLike = LZERO;
+
+   for (int t = 0; t <= T; t++) {
+      double genMax = LZERO;
+      int exArg = 0;
+      if (t >= 1) {
+#pragma unroll
+         for (int j = 0; j < MAXN; j++) ob[j] = obN[j];
+         if (valid && t + 1 <= T) {
+#pragma unroll
+            for (int j = 2; j < MAXN; j++) if (j < N) obN[j] = orow[(size_t)(j - 2) * T + t];
+         }
+         // ---- pass 1: StepHMM1
+         if (valid && active) {
+            double nw[MAXN + 1];
+            double mx = LZERO;
+#pragma unroll
+            for (int j = 2; j < MAXN; j++) {
+               nw[j] = LZERO;
+               if (j < N) {
+                  int arg = seLo[j];
+                  double best = LZERO;
+#pragma unroll
+                  for (int i = 1; i < MAXN; i++) if (i == arg) best = like[i] + (double)tp[i - 1][j - 1];
+#pragma unroll
+                  for (int i = 2; i < MAXN; i++)
+                     if (i > seLo[j] && i <= seHi[j]) {
+                        const double c = like[i] + (double)tp[i - 1][j - 1];
+                        if (c > best) { best = c; arg = i; }
+                     }
+                  gpre[(size_t)(t - 1) * nSlots + j - 2] = best;
+                  gbp[(size_t)(t - 1) * nSlots + j - 2] = (signed char)arg;
+                  if (best > genThresh) {
+                     nw[j] = best + (double)ob[j];
+                     if (nw[j] > mx) mx = nw[j];
+                  }
+               }
+            }
+            like[1] = LZERO;
+#pragma unroll
+            for (int j = 2; j < MAXN; j++) if (j < N) like[j] = nw[j];
+            instMax = mx;
+            genMax = mx;
+            {  // exit state: best of like_i + a_iN over seIndex[N], first maximum wins (HRec.c:738-760)
+               double best = LZERO;
+               exArg = 0;
+#pragma unroll
+               for (int i = 1; i < MAXN; i++)
+                  if (i < N && i >= loN && i <= hiN) {
+                     const double c = like[i] + (double)aN[i];
+                     if (exArg == 0 || c > best) { best = c; exArg = i; }
+                  }
+               if (best > LSMALL) exitL = best; else { exitL = LZERO; exArg = 0; }
+            }
+         } else { exitL = LZERO; }
+         for (int o = 32; o > 0; o >>= 1) genMax = fmax(genMax, __shfl_xor(genMax, o));
+         genThresh = (float)(genMax - (double)a.genBeam);
+         if (genThresh < (float)LSMALL) genThresh = (float)LSMALL;
+      }
+      // ---- pass 2: exit -> entry of the next model, in chain order
+      // A: candidates from the predecessor's pass-1 exit (valid wherever the predecessor is not a tee model)
+      const bool selfAlive = valid && active && !(instMax < (double)genThresh);     // not detached on its own account
+      double exOut = (selfAlive && exitL > (double)genThresh) ? exitL : LZERO;
+      double cand = __shfl_up(exOut, 1);
+      if (q == 1) cand = (t == 0) ? 0.0 : LZERO;
+      bool gotEntry = false;
+      if (valid && cand > (double)genThresh) {
+         if (!active) { active = true; instMax = LZERO; exitL = LZERO;
+#pragma unroll
+            for (int i = 0; i <= MAXN; i++) like[i] = LZERO; }
+         if (cand > like[1]) like[1] = cand;
+         if (like[1] > instMax) instMax = like[1];
+         gotEntry = true;
+      }
+      // B: tee models in ascending order: entry -> exit within the frame (StepHMM2), then onward
+      unsigned long long tm = teeMask;
+      while (tm) {
+         const int tl = __ffsll((long long)tm) - 1;                   // lane of the tee model
+         tm &= tm - 1;
+         // the tee lane refreshes its entry from its predecessor's CURRENT exit (the predecessor may be a tee lane done earlier)
+         const bool pAlive = valid && active && !(instMax < (double)genThresh);
+         const double pOut = (pAlive && exitL > (double)genThresh) ? exitL : LZERO;
+         const double c2 = (tl == 0) ? ((t == 0) ? 0.0 : LZERO) : __shfl(pOut, tl - 1);
+         if (lane == tl) {
+            if (c2 > (double)genThresh) {
+               if (!active) { active = true; instMax = LZERO; exitL = LZERO;
+#pragma unroll
+                  for (int i = 0; i <= MAXN; i++) like[i] = LZERO; }
+               if (c2 > like[1]) like[1] = c2;
+               if (like[1] > instMax) instMax = like[1];
+               gotEntry = true;
+            }
+            if (active && !(instMax < (double)genThresh)) {
+               const double c = like[1] + (double)a1N;
+               if (c > exitL) { exitL = c; exArg = 1; }
+            }
+         }
+         // the model after the tee model sees the updated exit
+         const bool tAlive = valid && active && !(instMax < (double)genThresh);
+         const double tOut = (tAlive && exitL > (double)genThresh) ? exitL : LZERO;
+         const double c3 = __shfl(tOut, tl);
+         if (lane == tl + 1 && valid && !((teeMask >> lane) & 1ull) && c3 > (double)genThresh) {
+            if (!active) { active = true; instMax = LZERO; exitL = LZERO;
+#pragma unroll
+               for (int i = 0; i <= MAXN; i++) like[i] = LZERO; }
+            if (c3 > like[1]) like[1] = c3;
+            if (like[1] > instMax) instMax = like[1];
+            gotEntry = true;
+         }
+      }
+      // detach (HRec.c:2008-2011): nothing alive and nothing arrived
+      if (valid && active && instMax < (double)genThresh) {
+         active = false; exitL = LZERO; exArg = 0;
+#pragma unroll
+         for (int i = 0; i <= MAXN; i++) like[i] = LZERO;
+      }
+      if (valid) {
+         gent[(size_t)t * Q] = active ? like[1] : LZERO;
+         gexl[(size_t)t * Q] = active ? exitL : LZERO;
+         gexbp[(size_t)t * Q] = (signed char)exArg;
+      }
+      if (t == T) {
+         const bool lastAlive = valid && active;
+         const double fo = (lastAlive && exitL > (double)genThresh && exitL > LSMALL) ? exitL : LZERO;
+         finalLike = __shfl(fo, Q - 1);
+      }
+      (void)gotEntry;
+   }
+   if (lane == 0) {
+      a.total[u] = finalLike;
+      a.status[u] = (finalLike > LSMALL) ? HTKAMD_UTT_OK : HTKAMD_UTT_SKIPPED;
+   }
+}
+
+// one lane per utterance: walk the back-pointers (LatFromPaths / TranscriptionFromLattice restated on the trellis)
+__global__ void k_viterbi_trace(VitArgs a)
+{
+   const int u = blockIdx.x * blockDim.x + threadIdx.x;
+   if (u >= a.nUtt) return;
+   const VitUtt ud = a.utt[u];
+   const int T = ud.T, Q = ud.Q, nSlots = ud.nSlots;
+   for (int k = 0; k < nSlots; k++) { a.segStart[ud.seg0 + k] = -1; a.segEnd[ud.seg0 + k] = -1; a.segScore[ud.seg0 + k] = 0.0; }
+   for (int q = 0; q < Q; q++) { a.modStart[ud.mod0 + q] = -1; a.modEnd[ud.mod0 + q] = -1; a.modScore[ud.mod0 + q] = 0.0; }
+   if (a.status[u] != HTKAMD_UTT_OK) return;
+   const signed char *bp = a.bp + ud.tr0, *exbp = a.exbp + ud.mt0;
+   const double *pre = a.pre + ud.tr0, *exl = a.exl + ud.mt0, *ent = a.entAt + ud.mt0;
+   int tcur = T, q = Q;
+   while (q >= 1) {
+      const int slot0 = a.mSlot0[ud.q0 + q - 1];
+      int st = exbp[(size_t)tcur * Q + q - 1];
+      const double exitLike = exl[(size_t)tcur * Q + q - 1];
+      double nextLike = exitLike;
+      int segEndT = tcur;
+      if (st == 1) {                                      // tee pass-through: the model takes no frame
+         a.modStart[ud.mod0 + q - 1] = tcur; a.modEnd[ud.mod0 + q - 1] = tcur;
+         a.modScore[ud.mod0 + q - 1] = exitLike - ent[(size_t)tcur * Q + q - 1];
+         q--;
+         continue;
+      }
+      a.modEnd[ud.mod0 + q - 1] = tcur;
+      for (;;) {
+         const size_t ix = (size_t)(tcur - 1) * nSlots + slot0 + st - 2;
+         const int p = bp[ix];
+         if (p != st) {
+            a.segStart[ud.seg0 + slot0 + st - 2] = tcur - 1;
+            a.segEnd[ud.seg0 + slot0 + st - 2] = segEndT;
+            a.segScore[ud.seg0 + slot0 + st - 2] = nextLike - pre[ix];
+            nextLike = pre[ix];
+            segEndT = tcur - 1;
+            if (p == 1) {
+               a.modStart[ud.mod0 + q - 1] = tcur - 1;
+               a.modScore[ud.mod0 + q - 1] = exitLike - ent[(size_t)(tcur - 1) * Q + q - 1];
+               tcur--; q--;
+               break;
+            }
+            st = p;
+         }
+         tcur--;
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct VBuf {
+   void *p = nullptr; size_t cap = 0;
+   int reserve(size_t bytes)
+   {
+      if (bytes <= cap) return HTKAMD_OK;
+      if (p) (void)hipFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = bytes + bytes / 8 + 64;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) { htkamd_set_error("viterbi: hipMalloc(%zu): %s", want, hipGetErrorString(e)); return HTKAMD_ENOMEM; }
+      cap = want;
+      return HTKAMD_OK;
+   }
+   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct htkamd_viterbi {
+   htkamd_model *m;
+   int nUtt;
+   std::vector<VitUtt> utt;
+   std::vector<int> mN, mTp, mSlot0, slotState;
+   std::vector<ScoreTask> tasks;
+   size_t segTotal, modTotal;
+   VBuf d_utt, d_mN, d_mTp, d_mSlot0, d_slotState, d_tasks, d_counter, d_outp, d_bp, d_pre, d_exl, d_ent, d_exbp;
+   VBuf d_segStart, d_segEnd, d_segScore, d_modStart, d_modEnd, d_modScore, d_total, d_status;
+};
+
+extern "C" int htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out)
+{
+   if (!m || !out) { htkamd_set_error("viterbi_create: NULL argument"); return HTKAMD_EINVAL; }
+   if (m->maxN > VMAXN) { htkamd_set_error("viterbi_create: models with %d states; this path handles up to %d", m->maxN, VMAXN); return HTKAMD_EMODEL; }
+   htkamd_viterbi *v = new htkamd_viterbi();
+   v->m = m; v->nUtt = 0; v->segTotal = v->modTotal = 0;
+   *out = v;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_viterbi_destroy(htkamd_viterbi *v)
+{
+   if (!v) return;
+   VBuf *all[] = {&v->d_utt, &v->d_mN, &v->d_mTp, &v->d_mSlot0, &v->d_slotState, &v->d_tasks, &v->d_counter, &v->d_outp, &v->d_bp,
+                  &v->d_pre, &v->d_exl, &v->d_ent, &v->d_exbp, &v->d_segStart, &v->d_segEnd, &v->d_segScore, &v->d_modStart,
+                  &v->d_modEnd, &v->d_modScore, &v->d_total, &v->d_status};
+   for (VBuf *b : all) b->release();
+   delete v;
+}
+
+template <typename T> static int vupload(VBuf &b, const std::vector<T> &v, hipStream_t s)
+{
+   int rc = b.reserve(sizeof(T) * (v.size() ? v.size() : 1));
+   if (rc) return rc;
+   if (!v.empty()) HIPCHECK(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *b, float genBeam, void *stream)
+{
+   if (!v || !b || b->nUtt < 0 || (b->nUtt > 0 && (!b->dX || !b->frameOff || !b->labOff || !b->labs))) {
+      htkamd_set_error("viterbi_align: bad argument"); return HTKAMD_EINVAL;
+   }
+   const htkamd_model *m = v->m;
+   hipStream_t s = (hipStream_t)stream;
+   const int U = b->nUtt;
+   v->nUtt = U;
+   v->utt.assign(U, VitUtt());
+   v->mN.clear(); v->mTp.clear(); v->mSlot0.clear(); v->slotState.clear(); v->tasks.clear();
+   size_t outp = 0, tr = 0, mt = 0, seg = 0, mod = 0;
+   for (int u = 0; u < U; u++) {
+      VitUtt &d = v->utt[u];
+      const int T = b->frameOff[u + 1] - b->frameOff[u], Q = b->labOff[u + 1] - b->labOff[u];
+      const int *labs = b->labs + b->labOff[u];
+      d.T = T; d.Q = Q; d.frame0 = b->frameOff[u]; d.q0 = (int)v->mN.size(); d.slot0 = (int)v->slotState.size();
+      d.status = HTKAMD_UTT_OK; d.pad = 0; d.outp0 = outp; d.tr0 = tr; d.mt0 = mt; d.seg0 = seg; d.mod0 = mod;
+      int nSlots = 0;
+      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nSlots = 0; continue; }
+      if (Q > 64) { htkamd_set_error("viterbi_align: utterance %d has %d models; this path handles up to 64", u, Q); return HTKAMD_EINVAL; }
+      for (int q = 1; q <= Q; q++) {
+         const int h = labs[q - 1];
+         if (h < 0 || h >= m->H) { htkamd_set_error("viterbi_align: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
+         const int ti = m->h_hmmTrans[h], N = m->h_transN[ti];
+         v->mN.push_back(N); v->mTp.push_back(m->h_transOff[ti]); v->mSlot0.push_back(nSlots);
+         for (int j = 2; j < N; j++) v->slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]);
+         nSlots += N - 2;
+      }
+      d.nSlots = nSlots;
+      for (int t0 = 0; t0 < T; t0 += SCORE_TILE_FRAMES)
+         for (int k0 = 0; k0 < nSlots; k0 += SCORE_TASK_SLOTS) {
+            ScoreTask tk;
+            tk.frame0 = d.frame0 + t0; tk.nFrames = (T - t0 < SCORE_TILE_FRAMES) ? T - t0 : SCORE_TILE_FRAMES;
+            tk.slot0 = d.slot0 + k0; tk.nSlots = (nSlots - k0 < SCORE_TASK_SLOTS) ? nSlots - k0 : SCORE_TASK_SLOTS;
+            tk.outSlot0 = k0; tk.ldo = T; tk.outBase = d.outp0 + (size_t)t0;
+            v->tasks.push_back(tk);
+         }
+      outp += (size_t)T * nSlots; tr += (size_t)T * nSlots; mt += (size_t)(T + 1) * Q; seg += nSlots; mod += Q;
+   }
+   v->segTotal = seg; v->modTotal = mod;
+   int rc;
+   if ((rc = vupload(v->d_utt, v->utt, s)) || (rc = vupload(v->d_mN, v->mN, s)) || (rc = vupload(v->d_mTp, v->mTp, s)) ||
+       (rc = vupload(v->d_mSlot0, v->mSlot0, s)) || (rc = vupload(v->d_slotState, v->slotState, s)) || (rc = vupload(v->d_tasks, v->tasks, s)))
+      return rc;
+   auto nz = [](size_t x) { return x ? x : (size_t)1; };
+   if ((rc = v->d_counter.reserve(64)) || (rc = v->d_outp.reserve(4 * nz(outp))) || (rc = v->d_bp.reserve(nz(tr))) ||
+       (rc = v->d_pre.reserve(8 * nz(tr))) || (rc = v->d_exl.reserve(8 * nz(mt))) || (rc = v->d_ent.reserve(8 * nz(mt))) ||
+       (rc = v->d_exbp.reserve(nz(mt))) || (rc = v->d_segStart.reserve(4 * nz(seg))) || (rc = v->d_segEnd.reserve(4 * nz(seg))) ||
+       (rc = v->d_segScore.reserve(8 * nz(seg))) || (rc = v->d_modStart.reserve(4 * nz(mod))) || (rc = v->d_modEnd.reserve(4 * nz(mod))) ||
+       (rc = v->d_modScore.reserve(8 * nz(mod))) || (rc = v->d_total.reserve(8 * nz(U))) || (rc = v->d_status.reserve(4 * nz(U))))
+      return rc;
+   if (U == 0) return HTKAMD_OK;
+
+   ScoreArgs sa;
+   sa.tasks = (const ScoreTask *)v->d_tasks.p; sa.nTasks = (int)v->tasks.size(); sa.X = b->dX;
+   sa.slotState = (const int *)v->d_slotState.p; sa.out = (float *)v->d_outp.p;
+   sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
+   sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
+   sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)v->d_counter.p;
+   if ((rc = htkamd_launch_score_exact(m, sa, s))) return rc;
+
+   VitArgs va;
+   va.utt = (const VitUtt *)v->d_utt.p; va.nUtt = U;
+   va.mN = (const int *)v->d_mN.p; va.mTp = (const int *)v->d_mTp.p; va.mSlot0 = (const int *)v->d_mSlot0.p;
+   va.transP = m->d_transP; va.outp = (const float *)v->d_outp.p;
+   va.bp = (signed char *)v->d_bp.p; va.pre = (double *)v->d_pre.p;
+   va.exl = (double *)v->d_exl.p; va.entAt = (double *)v->d_ent.p; va.exbp = (signed char *)v->d_exbp.p;
+   va.segStart = (int *)v->d_segStart.p; va.segEnd = (int *)v->d_segEnd.p; va.segScore = (double *)v->d_segScore.p;
+   va.modStart = (int *)v->d_modStart.p; va.modEnd = (int *)v->d_modEnd.p; va.modScore = (double *)v->d_modScore.p;
+   va.total = (double *)v->d_total.p; va.status = (int *)v->d_status.p;
+   va.genBeam = genBeam;
+   hipLaunchKernelGGL((k_viterbi_w<VMAXN>), dim3((U + VWPB - 1) / VWPB), dim3(64 * VWPB), 0, s, va);
+   HIPCHECK(hipGetLastError());
+   hipLaunchKernelGGL(k_viterbi_trace, dim3((U + 63) / 64), dim3(64), 0, s, va);
+   HIPCHECK(hipGetLastError());
+   // the host tables must outlive the async uploads
+   HIPCHECK(hipStreamSynchronize(s));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_viterbi_sizes(const htkamd_viterbi *v, size_t *nSeg, size_t *nMod)
+{
+   if (!v) { htkamd_set_error("viterbi_sizes: NULL"); return HTKAMD_EINVAL; }
+   if (nSeg) *nSeg = v->segTotal;
+   if (nMod) *nMod = v->modTotal;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_viterbi_results(htkamd_viterbi *v, int *segStart, int *segEnd, double *segScore,
+                                      int *modStart, int *modEnd, double *modScore, double *total, int *status, void *stream)
+{
+   if (!v) { htkamd_set_error("viterbi_results: NULL"); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   HIPCHECK(hipStreamSynchronize(s));
+   if (v->nUtt == 0) return HTKAMD_OK;
+   if (segStart) HIPCHECK(hipMemcpy(segStart, v->d_segStart.p, 4 * v->segTotal, hipMemcpyDeviceToHost));
+   if (segEnd) HIPCHECK(hipMemcpy(segEnd, v->d_segEnd.p, 4 * v->segTotal, hipMemcpyDeviceToHost));
+   if (segScore) HIPCHECK(hipMemcpy(segScore, v->d_segScore.p, 8 * v->segTotal, hipMemcpyDeviceToHost));
+   if (modStart) HIPCHECK(hipMemcpy(modStart, v->d_modStart.p, 4 * v->modTotal, hipMemcpyDeviceToHost));
+   if (modEnd) HIPCHECK(hipMemcpy(modEnd, v->d_modEnd.p, 4 * v->modTotal, hipMemcpyDeviceToHost));
+   if (modScore) HIPCHECK(hipMemcpy(modScore, v->d_modScore.p, 8 * v->modTotal, hipMemcpyDeviceToHost));
+   if (total) HIPCHECK(hipMemcpy(total, v->d_total.p, 8 * (size_t)v->nUtt, hipMemcpyDeviceToHost));
+   if (status) HIPCHECK(hipMemcpy(status, v->d_status.p, 4 * (size_t)v->nUtt, hipMemcpyDeviceToHost));
+   return HTKAMD_OK;
+}

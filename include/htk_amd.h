@@ -212,6 +212,30 @@ int  htkamd_fb_get_trellis(htkamd_fb *fb, int utt, double *beta, double *alpha, 
    out[0]=scoring out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics. Synchronises. */
 int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
 
+/* ------------------------------------------------------------------------------------------
+ * Viterbi forced alignment of a batch (HVite -a): replaces, per utterance, the frame loop of
+ * HVite.c:640-710 ProcessFile on the alignment network of DoAlignment (HVite.c:830):
+ *     StartRecognition / ProcessObservation / CompleteRecognition      HRec.h:170-190
+ *     TranscriptionFromLattice (HRec.c:2176) for the state (-f) and model (-m) level labels
+ * The network is the linear chain of the transcription's physical models (LatticeFromLabels +
+ * ExpandWordNet with one pronunciation per word).  genBeam is HVite's -t value (1e10 = off).
+ * Results are per chain state (one segment per emitting state, start = -1 if the state was skipped):
+ * frames [segStart, segEnd) 0-based and segScore = acoustic score of the segment, and per model
+ * [modStart, modEnd), modScore -- the numbers HVite prints as "start end s<j> score model score".
+ * Token likelihoods are the same double additions in the same order as HRec's, on bit-exact output
+ * probabilities, so segmentations are bit-identical to the reference's.
+ * Restrictions of this path: <= 64 models per utterance, <= 5 states per model; general word
+ * networks (HVite recognition mode) are not covered.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct htkamd_viterbi htkamd_viterbi;
+int  htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out);
+void htkamd_viterbi_destroy(htkamd_viterbi *v);
+int  htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *batch, float genBeam, void *stream);
+int  htkamd_viterbi_sizes(const htkamd_viterbi *v, size_t *nSeg /* sum of chain states */, size_t *nMod /* sum of models */);
+int  htkamd_viterbi_results(htkamd_viterbi *v, int *segStart, int *segEnd, double *segScore,
+                            int *modStart, int *modEnd, double *modScore,
+                            double *total /*[nUtt]*/, int *status /*[nUtt]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,27 @@ def main():
         snames = ["S%d" % i for i in range(int(pk["numStates"]))]
         pack_case("fb_topo", pk, names, snames, seqs, feats, d, herest_extra="-m 1", keep_trellis=5)
         pack_case("fb_topo_prune", pk, names, snames, seqs, feats, d, tflag="-t 20.0 10.0 100.0", herest_extra="-m 1", keep_trellis=5)
+    # HVite -a -f -m alignments (.rec label files): plain set, with a beam, mixed topologies (tee model left out of the
+    # labels: the reference's LatFromPaths aborts on a skipped tee model under PHNALG, HRec.c:1625)
+    rec = {}
+    with tempfile.TemporaryDirectory() as d:
+        s = synth.generate(60, 4, 40, 4, 120, 5, outdir=d)
+        for tag, tflag in (("small", ""), ("small_t40", "-t 40.0")):
+            os.makedirs(os.path.join(d, "ali_" + tag))
+            run("%s/HVite -C config -a -f -m %s -H hmm0/MMF -L lab -X lab -l ali_%s -y rec -S train.scp dict hmmlist" % (REF, tflag, tag), d)
+            for u in range(4):
+                rec["%s_%d" % (tag, u)] = np.array(open(os.path.join(d, "ali_" + tag, "u%05d.rec" % u)).read())
+    with tempfile.TemporaryDirectory() as d:
+        pk, names, seqs, feats = synth.make_topo_set(outdir=d)
+        os.makedirs(os.path.join(d, "lab2")); os.makedirs(os.path.join(d, "ali"))
+        for u, q in enumerate(seqs):
+            open(os.path.join(d, "lab2", "u%05d.lab" % u), "w").write("\n".join(names[h] for h in q if h != 2) + "\n")
+        open(os.path.join(d, "dict"), "w").write("".join("%s %s\n" % (n, n) for n in sorted(names)))
+        run("%s/HVite -C config -a -f -m -H hmm0/MMF -L lab2 -X lab -l ali -y rec -S train.scp dict hmmlist" % REF, d)
+        for u in range(len(seqs)):
+            rec["topo_%d" % u] = np.array(open(os.path.join(d, "ali", "u%05d.rec" % u)).read())
+    np.savez_compressed(os.path.join(OUT, "hvite_rec.npz"), **rec)
+    print("hvite_rec", len(rec), "files")
     # known answers recorded in SURVEY.md Appendix F for the 1k x 8 set (seed 1): per-frame log prob of the first 3 utterances
     with tempfile.TemporaryDirectory() as d:
         s = synth.generate(1000, 8, 2000, 3, 500, 1, outdir=d)

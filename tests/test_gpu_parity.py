@@ -255,3 +255,84 @@ def test_accumulator_merge_is_load_accs(native):
     acc2 = native.Accs(model)
     acc2.upload_add(v); acc2.upload_add(v)
     assert np.array_equal(acc2.download()["vec"], 2 * v)
+
+
+# ----------------------------------------------------------------------------------------- Viterbi alignment (K5)
+def _align(native, pk, seqs, feats, beam=1.0e10):
+    model = native.Model(pk)
+    utts = [dict(seq=q, feat=x) for q, x in zip(seqs, feats)]
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = native.DevArray(X)
+    v = native.Viterbi(model)
+    return v.align(dX.ptr.value, frameOff, labOff, labs, genBeam=beam)
+
+
+def _check_vs_oracle(oracle, om, got, seqs, feats, beam):
+    for u, g in enumerate(got):
+        r = oracle.viterbi_align(om, feats[u], seqs[u], genBeam=beam)
+        if r is None:
+            assert g["status"] == 0
+            continue
+        assert g["status"] == 1 and g["total"] == r["total"]            # token likes: bit-identical doubles
+        visited = g["segStart"] >= 0
+        assert visited.sum() == r["n"]
+        assert np.array_equal(g["segStart"][visited], r["start"]) and np.array_equal(g["segEnd"][visited], r["end"])
+        assert np.array_equal(g["segScore"][visited], r["score"])
+        assert np.array_equal(g["modStart"], r["modStart"]) and np.array_equal(g["modEnd"], r["modEnd"])
+        assert np.array_equal(g["modScore"], r["modScore"])
+
+
+@pytest.mark.parametrize("beam", [1.0e10, 40.0, 15.0])
+def test_viterbi_alignment_bit_identical(native, oracle, beam):
+    """State alignments must be bit-identical to the reference's (north star): compared with the committed HVite
+    label files line by line and with the oracle's segment table (also under pruning beams)."""
+    import os
+    import util
+    from htk_amd import synth
+    s = synth.generate(60, 4, 40, 4, 120, 5)
+    pk = s.packed()
+    got = _align(native, pk, s.seqs, s.feats, beam)
+    _check_vs_oracle(oracle, oracle.Model(pk), got, s.seqs, s.feats, beam)
+    z = np.load(os.path.join(util.GOLDEN, "hvite_rec.npz"))
+    names = ["p%d" % i for i in range(40)]
+    tag = {1.0e10: "small", 40.0: "small_t40"}.get(beam)
+    if tag:
+        for u in range(4):
+            want = [l for l in str(z["%s_%d" % (tag, u)]).split("\n") if l.strip()]
+            assert native.format_rec(got[u], names) == want
+
+
+def test_viterbi_mixed_topologies_and_tee(native, oracle):
+    """3/4/5-state models with a skip transition vs the reference's label files; with the tee model in the chain
+    (which the reference's label writer cannot emit) vs the oracle's token passing."""
+    import os
+    import util
+    from htk_amd import synth
+    pk, names, seqs, feats = synth.make_topo_set()
+    z = np.load(os.path.join(util.GOLDEN, "hvite_rec.npz"))
+    noTee = [np.array([h for h in q if h != 2], np.int32) for q in seqs]
+    got = _align(native, pk, noTee, feats)
+    for u in range(len(seqs)):
+        want = [l for l in str(z["topo_%d" % u]).split("\n") if l.strip()]
+        assert native.format_rec(got[u], names) == want
+    got = _align(native, pk, seqs, feats)
+    _check_vs_oracle(oracle, oracle.Model(pk), got, seqs, feats, 1.0e10)
+
+
+def test_viterbi_config2_size(native, oracle):
+    """1k x 8, 500-frame utterances: first lines of the alignment the survey recorded from the reference, the
+    per-utterance score HVite prints, and segment bookkeeping (contiguous cover of all frames)."""
+    from htk_amd import synth
+    s = synth.generate(1000, 8, 2000, 8, 500, 1)
+    got = _align(native, s.packed(), s.seqs, s.feats)
+    names = ["p%d" % i for i in range(2000)]
+    lines = native.format_rec(got[0], names)
+    assert lines[0] == "0 400000 s2 -228.724319 p63 -742.978210 p63"
+    assert lines[1] == "400000 800000 s3 -255.099365" and lines[2] == "800000 1200000 s4 -259.154510"
+    assert lines[3] == "1200000 1600000 s2 -249.230179 p447 -742.860291 p447"
+    assert "%.4f" % (got[6]["total"] / 500) == "-61.1013"                   # "[500 frames] -61.1013" for u00006
+    for g in got:
+        assert g["status"] == 1
+        assert g["segStart"][0] == 0 and g["segEnd"][-1] == 500
+        assert np.array_equal(g["segStart"][1:], g["segEnd"][:-1])
+        assert abs(g["segScore"].sum() - g["total"]) < 1e-6 * abs(g["total"])

@@ -88,3 +88,29 @@ def test_state_outp_variants_differ_only_in_rounding(oracle):
     a = np.array([[m.state_outp(s, X[t]) for s in range(20)] for t in range(40)])
     b = np.array([[m.soutp(s, X[t]) for s in range(20)] for t in range(40)])
     assert np.allclose(a, b, rtol=3e-7)
+
+
+def _rec_lines(z, key):
+    return [l for l in str(z[key]).split("\n") if l.strip()]
+
+
+def test_viterbi_alignment_identical_to_hvite(oracle):
+    """Label files of the reference's `HVite -a -f -m` (tests/golden/hvite_rec.npz) reproduced line for line:
+    times, state/model labels and the 6-decimal scores (HRec.c token passing restated in oracle/orc_viterbi.c)."""
+    import os
+    import util
+    from htk_amd import synth
+    po = oracle
+    z = np.load(os.path.join(util.GOLDEN, "hvite_rec.npz"))
+    s = synth.generate(60, 4, 40, 4, 120, 5)
+    m = po.Model(s.packed()); names = ["p%d" % i for i in range(40)]
+    for tag, beam in (("small", 1.0e10), ("small_t40", 40.0)):
+        for u in range(4):
+            r = po.viterbi_align(m, s.feats[u], s.seqs[u], genBeam=beam)
+            assert po.format_rec(r, s.seqs[u], names) == _rec_lines(z, "%s_%d" % (tag, u))
+    pk, names, seqs, feats = synth.make_topo_set()
+    m = po.Model(pk)
+    for u in range(len(seqs)):
+        q = np.array([h for h in seqs[u] if h != 2], np.int32)
+        r = po.viterbi_align(m, feats[u], q)
+        assert po.format_rec(r, q, names) == _rec_lines(z, "topo_%d" % u)
