@@ -125,6 +125,23 @@ void orc_update(const orc_model *m, const orc_accs *acc, const orc_updcfg *cfg,
                 float *gconst /*[G] in/out*/, float *compWeight /*[C] linear in/out*/,
                 float *transP /*in/out (log)*/, orc_updstats *st);
 
+/* ---- waveform -> MFCC front end (orc_mfcc.c): HWave.c:1575,1663,1683; HParm.c:2214 ConvertFrame, :1618 AddQualifiers;
+        HSigP.c PreEmphasise :134, Ham :122, FFT :311, Realft :362, InitFBank :471, Wave2FBank :558, FBank2MFCC :607,
+        FBank2C0 :647, WeightCepstrum :773, Regress :827, FZeroMean :803, NormaliseLogEnergy :911 ---- */
+typedef struct {
+   double sampPeriod;          /* SOURCERATE, 100 ns units (625 = 16 kHz) */
+   double winDur, frPeriod;    /* WINDOWSIZE, TARGETRATE, 100 ns units     */
+   int    numChans, numCeps, cepLifter;            /* NUMCHANS NUMCEPS CEPLIFTER */
+   float  preEmph;                                 /* PREEMCOEF */
+   int    useHam, usePower, zMeanSource, rawEnergy, eNormalise;   /* USEHAMMING USEPOWER ZMEANSOURCE RAWENERGY ENORMALISE */
+   float  loFreq, hiFreq, cepScale, silFloor, eScale;             /* LOFREQ HIFREQ (<0 = off) CEPSCALE SILFLOOR ESCALE */
+   int    hasC0, hasE, hasD, hasA, hasZ;           /* _0 _E _D _A _Z of TARGETKIND = MFCC... */
+   int    delWin, accWin;                          /* DELTAWINDOW ACCWINDOW */
+} orc_mfcc_cfg;
+int orc_mfcc_frames(int nSamples, const orc_mfcc_cfg *c, int *frSize, int *frRate);
+int orc_mfcc_cols(const orc_mfcc_cfg *c);
+int orc_mfcc(const short *wav, int nSamples, const orc_mfcc_cfg *c, float *out);
+
 /* ---- Viterbi forced alignment of a chain of physical models (HRec token passing, 1-best; orc_viterbi.c) ----
    Returns the number of state segments (time order) or -1 when no token survives.  Frames are 0-based,
    [segStart, segEnd).  segScore = like(next Align record) - like(this one) (LatFromPaths HRec.c:1512). */

@@ -223,3 +223,33 @@ def format_rec(res: dict, labs, names, frame_dur: int = 100000):
             lastq = q
         lines.append(s)
     return lines
+
+
+class CMfccCfg(C.Structure):
+    _fields_ = [("sampPeriod", C.c_double), ("winDur", C.c_double), ("frPeriod", C.c_double),
+                ("numChans", C.c_int), ("numCeps", C.c_int), ("cepLifter", C.c_int), ("preEmph", C.c_float),
+                ("useHam", C.c_int), ("usePower", C.c_int), ("zMeanSource", C.c_int), ("rawEnergy", C.c_int), ("eNormalise", C.c_int),
+                ("loFreq", C.c_float), ("hiFreq", C.c_float), ("cepScale", C.c_float), ("silFloor", C.c_float), ("eScale", C.c_float),
+                ("hasC0", C.c_int), ("hasE", C.c_int), ("hasD", C.c_int), ("hasA", C.c_int), ("hasZ", C.c_int),
+                ("delWin", C.c_int), ("accWin", C.c_int)]
+
+
+def mfcc_cfg(kind="MFCC_0_D_A", sampPeriod=625.0, winDur=250000.0, frPeriod=100000.0, numChans=26, numCeps=12, cepLifter=22,
+             preEmph=0.97, useHam=True, usePower=False, zMeanSource=False, rawEnergy=True, eNormalise=True,
+             loFreq=-1.0, hiFreq=-1.0, cepScale=1.0, silFloor=50.0, eScale=0.1, delWin=2, accWin=2):
+    """HParm defaults (HParm.c:337-367) for the MFCC path; `kind` is the TARGETKIND string."""
+    q = kind.upper().split("_")
+    assert q[0] == "MFCC"
+    return CMfccCfg(sampPeriod, winDur, frPeriod, numChans, numCeps, cepLifter, preEmph, int(useHam), int(usePower), int(zMeanSource),
+                    int(rawEnergy), int(eNormalise), loFreq, hiFreq, cepScale, silFloor, eScale,
+                    int("0" in q[1:]), int("E" in q[1:]), int("D" in q[1:]), int("A" in q[1:]), int("Z" in q[1:]), delWin, accWin)
+
+
+def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
+    wav = np.ascontiguousarray(wav, np.int16)
+    T = lib().orc_mfcc_frames(C.c_int(len(wav)), C.byref(cfg), None, None)
+    cols = lib().orc_mfcc_cols(C.byref(cfg))
+    out = np.zeros((max(T, 0), cols), np.float32)
+    if T > 0:
+        lib().orc_mfcc(_p(wav), C.c_int(len(wav)), C.byref(cfg), _p(out))
+    return out
