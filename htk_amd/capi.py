@@ -365,3 +365,63 @@ def format_rec(utt: dict, names, frame_dur: int = 100000):
                 lines.append(s)
             k += 1
     return lines
+
+
+class MfccConfig(C.Structure):
+    _fields_ = [("sampPeriod", C.c_double), ("winDur", C.c_double), ("frPeriod", C.c_double),
+                ("numChans", C.c_int), ("numCeps", C.c_int), ("cepLifter", C.c_int), ("preEmph", C.c_float),
+                ("useHam", C.c_int), ("usePower", C.c_int), ("zMeanSource", C.c_int), ("rawEnergy", C.c_int), ("eNormalise", C.c_int),
+                ("loFreq", C.c_float), ("hiFreq", C.c_float), ("cepScale", C.c_float), ("silFloor", C.c_float), ("eScale", C.c_float),
+                ("hasC0", C.c_int), ("hasE", C.c_int), ("hasD", C.c_int), ("hasA", C.c_int), ("hasZ", C.c_int),
+                ("delWin", C.c_int), ("accWin", C.c_int)]
+
+
+def mfcc_config(kind="MFCC_0_D_A", sampPeriod=625.0, winDur=250000.0, frPeriod=100000.0, numChans=26, numCeps=12, cepLifter=22,
+                preEmph=0.97, useHam=True, usePower=False, zMeanSource=False, rawEnergy=True, eNormalise=True,
+                loFreq=-1.0, hiFreq=-1.0, cepScale=1.0, silFloor=50.0, eScale=0.1, delWin=2, accWin=2):
+    """HParm configuration variables with their defaults (HParm.c:337-367); `kind` is TARGETKIND."""
+    q = kind.upper().split("_")
+    if q[0] != "MFCC":
+        raise HtkAmdError("only MFCC target kinds are on this path")
+    return MfccConfig(sampPeriod, winDur, frPeriod, numChans, numCeps, cepLifter, preEmph, int(useHam), int(usePower), int(zMeanSource),
+                      int(rawEnergy), int(eNormalise), loFreq, hiFreq, cepScale, silFloor, eScale,
+                      int("0" in q[1:]), int("E" in q[1:]), int("D" in q[1:]), int("A" in q[1:]), int("Z" in q[1:]), delWin, accWin)
+
+
+class Mfcc:
+    """htkamd_mfcc holder: waveform -> MFCC feature matrix on the device (HParm/HSigP front end)."""
+
+    def __init__(self, cfg: MfccConfig):
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        check(lib().htkamd_mfcc_create(C.byref(cfg), C.byref(self.h)), "mfcc_create")
+        self.cols = lib().htkamd_mfcc_num_cols(C.byref(cfg))
+
+    def compute(self, waves, stream=None):
+        """waves: list of int16 arrays.  Returns (DevArray features [sumT, cols], frameOff)."""
+        waves = [np.ascontiguousarray(w, np.int16) for w in waves]
+        sampOff = np.concatenate([[0], np.cumsum([len(w) for w in waves])]).astype(np.int32)
+        allw = np.concatenate(waves) if waves else np.zeros(0, np.int16)
+        frames = [lib().htkamd_mfcc_num_frames(C.byref(self.cfg), C.c_int(len(w))) for w in waves]
+        total = int(sum(frames))
+        dW = DevArray(allw if len(allw) else np.zeros(1, np.int16))
+        dO = DevArray(nbytes=4 * max(total, 1) * self.cols)
+        frameOff = np.zeros(len(waves) + 1, np.int32)
+        check(lib().htkamd_mfcc_compute(self.h, dW.ptr, _p(sampOff), C.c_int(len(waves)), _p(frameOff), dO.ptr, stream), "mfcc_compute")
+        assert frameOff[-1] == total
+        return dO, frameOff
+
+    def compute_host(self, waves):
+        dO, frameOff = self.compute(waves)
+        return dO.to_host(np.float32, (int(frameOff[-1]), self.cols)), frameOff
+
+    def close(self):
+        if self.h:
+            lib().htkamd_mfcc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

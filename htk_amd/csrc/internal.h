@@ -35,6 +35,22 @@ double htkamd_host_min_log_exp(void);                                          /
 int    htkamd_host_ladd_table_size(void);
 void   htkamd_host_build_ladd_table(double *tab);
 
+/* ---- MFCC front-end tables (htk_amd/host/fbank.c) ---- */
+struct htkamd_mfcc_tables {
+   int frSize, frRate, fftN, klo, khi;
+   float mfnorm;
+   float *ham;                 /* [frSize+1] 1-based */
+   float *cepWin;              /* [numCeps+1] */
+   float *loWt;                /* [fftN/2+2] 1-based */
+   int *binA0, *binA1, *binB0, *binB1;   /* [numChans+2] k ranges feeding each bin (one allocation at binA0) */
+   double *dct;                /* [(numCeps+1)*(numChans+1)] cos(x_j*(k-0.5)) */
+   double *tw;                 /* FFT twiddles (wr,wi), stages concatenated: fftN/2 pairs */
+   double *rtw;                /* Realft (yr,yi) for i = 2..fftN/4 at [2i],[2i+1] */
+   short *brev;                /* [fftN/2] bit-reversed complex index */
+};
+int  htkamd_mfcc_tables_build(const htkamd_mfcc_config *c, struct htkamd_mfcc_tables *t);
+void htkamd_mfcc_tables_free(struct htkamd_mfcc_tables *t);
+
 /* ---- packed model ---- */
 struct htkamd_model {
    int D, S, C, G, nT, H, maxN, maxM;

@@ -1,0 +1,345 @@
+// mfcc.hip -- K6: waveform -> MFCC(+_0/_E)(+_D)(+_A)(+_Z) on the device (HSigP/HParm front end).
+//
+// The reference converts one frame at a time with float data, double-precision twiddle recurrences and libm
+// calls (HParm.c:2214 ConvertFrame; HSigP.c).  Everything libm-dependent that does not depend on the signal
+// (Hamming window, mel weights, lifter, DCT cosines, FFT twiddle recurrences) is tabulated on the host exactly as
+// the reference computes it (host/fbank.c); the kernels then perform the reference's multiply/add sequences in
+// the reference's order, so the output equals HCopy's up to the device's double log()/sqrt() rounding.
+//
+// MI355X mapping: frames are independent, so one wavefront owns one frame (thousands of frames in flight).  The
+// 512-point real FFT is a 256-point complex radix-2 DIT in LDS (2 butterflies per lane and stage, double
+// arithmetic, float storage -- as the reference); mel bins and cepstra are sequential float sums in the
+// reference, so a lane owns a bin / a cepstral coefficient and walks its k range in order.  Frame energies and
+// the source mean are 400-term sequential float sums: a lane per FRAME does those in a separate tiny kernel.
+// Deltas/accelerations are one thread per output element; energy normalisation and _Z are per-utterance passes.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "internal.h"
+#include "hipcheck.h"
+
+struct MfccArgs {
+   const short *wav;
+   const long long *frameSamp;   // [F] first sample of each frame
+   int nFrames;
+   int frSize, fftN, klo, khi, numChans, numCeps, nCols, nStat;
+   float preEmph, cepScale, mfnorm;
+   int useHam, usePower, zMean, hasC0, hasE, rawEnergy;
+   const float *ham, *cepWin, *loWt;
+   const int *binA0, *binA1, *binB0, *binB1;
+   const double *dct, *tw, *rtw;
+   const short *brev;
+   float *frameMean;             // [F] (ZMEANSOURCE)
+   float *out;
+};
+
+// lane per frame: source mean (ZeroMeanFrame HParm.c:2132) and log energy (HParm.c:2234-2238 / HSigP.c:571-575)
+__global__ void k_mfcc_energy(MfccArgs a)
+{
+   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+   if (f >= a.nFrames) return;
+   const short *w = a.wav + a.frameSamp[f];
+   float off = 0.0f;
+   if (a.zMean) {
+      float sum = 0.0f;
+      for (int i = 0; i < a.frSize; i++) sum += (float)w[i];
+      off = sum / a.frSize;
+      a.frameMean[f] = off;
+   }
+   if (!a.hasE) return;
+   float te = 0.0f;
+   if (a.rawEnergy) {
+      for (int i = 0; i < a.frSize; i++) { const float s = (float)w[i] - off; te += s * s; }
+   } else {                                              // energy of the pre-emphasised, windowed frame
+      float prev = 0.0f;
+      for (int i = 0; i < a.frSize; i++) {
+         const float cur = (float)w[i] - off;
+         float s;
+         if (a.preEmph > 0.0f) s = (i == 0) ? (float)((double)cur * (1.0 - (double)a.preEmph)) : cur - prev * a.preEmph;
+         else s = cur;
+         if (a.useHam) s *= a.ham[i + 1];
+         te += (s * s);
+         prev = cur;
+      }
+   }
+   a.out[(size_t)f * a.nCols + a.nStat - 1] = (te < MINLARG) ? (float)LZERO : (float)log((double)te);
+}
+
+// one wavefront per frame
+__global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
+{
+   extern __shared__ float lds[];
+   const int lane = threadIdx.x, f = blockIdx.x;
+   const int fftN = a.fftN, nn = fftN / 2;
+   float *xs = lds;                       // [fftN] interleaved (re,im), 0-based
+   float *ek = lds + fftN;                // [nn + 1] spectral magnitudes, 1-based k
+   float *fb = ek + nn + 2;               // [numChans + 1]
+   const short *w = a.wav + a.frameSamp[f];
+   const float off = a.zMean ? a.frameMean[f] : 0.0f;
+
+   // ---- load, pre-emphasise (HSigP.c:134), window (HSigP.c:122), zero-pad, bit-reverse the complex index
+   for (int c = lane; c < nn; c += 64) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+         const int i = 2 * c + h;
+         float s = 0.0f;
+         if (i < a.frSize) {
+            const float cur = (float)w[i] - off;
+            if (a.preEmph > 0.0f) {
+               if (i == 0) s = (float)((double)cur * (1.0 - (double)a.preEmph));
+               else { const float prev = (float)w[i - 1] - off; s = cur - prev * a.preEmph; }
+            } else s = cur;
+            if (a.useHam) s *= a.ham[i + 1];
+         }
+         v[h] = s;
+      }
+      const int r = a.brev[c];
+      xs[2 * r] = v[0]; xs[2 * r + 1] = v[1];
+   }
+   __syncthreads();
+   // ---- complex FFT, radix-2 DIT (HSigP.c:332-349): stage with half-size h, twiddles tabulated
+   {
+      int twOff = 0;
+      for (int h = 1; h < nn; h *= 2) {
+         for (int b = lane; b < nn / 2; b += 64) {
+            const int grp = b / h, pos = b % h;
+            const int ia = grp * 2 * h + pos, ib = ia + h;
+            const double wr = a.tw[2 * (twOff + pos)], wi = a.tw[2 * (twOff + pos) + 1];
+            const float sjr = xs[2 * ib], sji = xs[2 * ib + 1], sir = xs[2 * ia], sii = xs[2 * ia + 1];
+            const double xre = wr * (double)sjr - wi * (double)sji;
+            const double xri = wr * (double)sji + wi * (double)sjr;
+            xs[2 * ib] = (float)((double)sir - xre); xs[2 * ib + 1] = (float)((double)sii - xri);
+            xs[2 * ia] = (float)((double)sir + xre); xs[2 * ia + 1] = (float)((double)sii + xri);
+         }
+         twOff += h;
+         __syncthreads();
+      }
+   }
+   // ---- Realft post-pass (HSigP.c:371-390), 1-based indices of the reference mapped to xs[idx-1]
+   {
+      const int n = nn, n2 = n / 2;
+      for (int i = 2 + lane; i <= n2; i += 64) {
+         const int i1 = i + i - 1, i2 = i1 + 1, i3 = n + n + 3 - i2, i4 = i3 + 1;
+         const double wrs = a.rtw[2 * i], wis = a.rtw[2 * i + 1];
+         const float s1 = xs[i1 - 1], s2 = xs[i2 - 1], s3 = xs[i3 - 1], s4 = xs[i4 - 1];
+         const double xr1 = ((double)(s1 + s3)) / 2.0, xi1 = ((double)(s2 - s4)) / 2.0;
+         const double xr2 = ((double)(s2 + s4)) / 2.0, xi2 = ((double)(s3 - s1)) / 2.0;
+         xs[i1 - 1] = (float)(xr1 + wrs * xr2 - wis * xi2);
+         xs[i2 - 1] = (float)(xi1 + wrs * xi2 + wis * xr2);
+         xs[i3 - 1] = (float)(xr1 - wrs * xr2 + wis * xi2);
+         xs[i4 - 1] = (float)(-xi1 + wrs * xi2 + wis * xr2);
+      }
+      __syncthreads();
+      if (lane == 0) { const float xr1 = xs[0]; xs[0] = xr1 + xs[1]; xs[1] = 0.0f; }
+      __syncthreads();
+   }
+   // ---- magnitudes (HSigP.c:585-590)
+   for (int k = a.klo + lane; k <= a.khi; k += 64) {
+      const float t1 = xs[2 * k - 2], t2 = xs[2 * k - 1];
+      const float p = t1 * t1 + t2 * t2;
+      ek[k] = a.usePower ? p : (float)sqrt((double)p);
+   }
+   __syncthreads();
+   // ---- mel bins (HSigP.c:591-594) in the reference's accumulation order, then log with floor 1.0 (:598-603)
+   for (int b = 1 + lane; b <= a.numChans; b += 64) {
+      float acc = 0.0f;
+      for (int k = a.binA0[b]; k <= a.binA1[b]; k++) { const float e = ek[k]; const float t1 = a.loWt[k] * e; acc += e - t1; }
+      for (int k = a.binB0[b]; k <= a.binB1[b]; k++) { const float t1 = a.loWt[k] * ek[k]; acc += t1; }
+      if (acc < 1.0f) acc = 1.0f;
+      fb[b] = (float)log((double)acc);
+   }
+   __syncthreads();
+   // ---- DCT (HSigP.c:607-621), lifter (:773), CEPSCALE; C0 (:647)
+   float *row = a.out + (size_t)f * a.nCols;
+   for (int j = 1 + lane; j <= a.numCeps; j += 64) {
+      float c = 0.0f;
+      const double *ct = a.dct + (size_t)j * (a.numChans + 1);
+      for (int k = 1; k <= a.numChans; k++) c = (float)((double)c + (double)fb[k] * ct[k]);
+      c *= a.mfnorm;
+      c *= a.cepWin[j];
+      row[j - 1] = c * a.cepScale;
+   }
+   if (a.hasC0 && lane == 63) {
+      float sum = 0.0f;
+      for (int k = 1; k <= a.numChans; k++) sum += fb[k];
+      row[a.numCeps] = (sum * a.mfnorm) * a.cepScale;
+   }
+}
+
+// NormaliseLogEnergy (HSigP.c:911-932): one block per utterance
+__global__ void k_mfcc_enorm(float *out, const int *frameOff, int nCols, int col, float silFloor, float eScale)
+{
+   __shared__ float red[256];
+   const int u = blockIdx.x, f0 = frameOff[u], f1 = frameOff[u + 1];
+   if (f1 <= f0) return;
+   float mx = out[(size_t)f0 * nCols + col];
+   for (int f = f0 + threadIdx.x; f < f1; f += blockDim.x) mx = fmaxf(mx, out[(size_t)f * nCols + col]);
+   red[threadIdx.x] = mx;
+   __syncthreads();
+   for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+      __syncthreads();
+   }
+   mx = red[0];
+   const float mn = (float)((double)mx - ((double)silFloor * log(10.0)) / 10.0);
+   for (int f = f0 + threadIdx.x; f < f1; f += blockDim.x) {
+      float p = out[(size_t)f * nCols + col];
+      if (p < mn) p = mn;
+      out[(size_t)f * nCols + col] = (float)(1.0 - (double)((mx - p) * eScale));
+   }
+}
+
+// Regress (HSigP.c:827-856) on a whole table: out[t][ti+k] = sum_tau tau*(c[min(t+tau,last)] - c[max(t-tau,first)]) / (2 sum tau^2)
+__global__ void k_mfcc_delta(float *out, const int *frameUtt, const int *frameOff, int nFrames, int nCols, int si, int ti, int d, int win)
+{
+   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= (size_t)nFrames * d) return;
+   const int f = (int)(g / d), k = (int)(g % d);
+   const int u = frameUtt[f], f0 = frameOff[u], f1 = frameOff[u + 1] - 1;
+   float sigmaT2 = 0.0f;
+   for (int t = 1; t <= win; t++) sigmaT2 += t * t;
+   sigmaT2 *= 2.0;
+   float sum = 0.0f;
+   for (int t = 1; t <= win; t++) {
+      const int fb = (f - t < f0) ? f0 : f - t, ff = (f + t > f1) ? f1 : f + t;
+      sum += t * (out[(size_t)ff * nCols + si + k] - out[(size_t)fb * nCols + si + k]);
+   }
+   out[(size_t)f * nCols + ti + k] = sum / sigmaT2;
+}
+
+// FZeroMean (HSigP.c:803-823): one thread per (utterance, column), double sum in frame order
+__global__ void k_mfcc_zmean(float *out, const int *frameOff, int nUtt, int nCols, int d)
+{
+   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= nUtt * d) return;
+   const int u = g / d, k = g % d, f0 = frameOff[u], f1 = frameOff[u + 1];
+   if (f1 <= f0) return;
+   double sum = 0.0;
+   for (int f = f0; f < f1; f++) sum += (double)out[(size_t)f * nCols + k];
+   const float mean = (float)(sum / (double)(f1 - f0));
+   for (int f = f0; f < f1; f++) out[(size_t)f * nCols + k] -= mean;
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct htkamd_mfcc {
+   htkamd_mfcc_config cfg;
+   htkamd_mfcc_tables tab;
+   float *d_ham, *d_cepWin, *d_loWt, *d_frameMean;
+   int *d_bins, *d_frameOff, *d_frameUtt;
+   double *d_dct, *d_tw, *d_rtw;
+   short *d_brev;
+   long long *d_frameSamp;
+   size_t capFrames, capUtt;
+};
+
+template <typename T> static int up(T **d, const T *h, size_t n)
+{
+   HIPCHECK(hipMalloc((void **)d, sizeof(T) * (n ? n : 1)));
+   if (n) HIPCHECK(hipMemcpy(*d, h, sizeof(T) * n, hipMemcpyHostToDevice));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_mfcc_create(const htkamd_mfcc_config *cfg, htkamd_mfcc **out)
+{
+   if (!cfg || !out) { htkamd_set_error("mfcc_create: NULL argument"); return HTKAMD_EINVAL; }
+   if (htkamd_device_count() <= 0) { htkamd_set_error("mfcc_create: no HIP device"); return HTKAMD_ENODEV; }
+   htkamd_mfcc *f = (htkamd_mfcc *)calloc(1, sizeof(htkamd_mfcc));
+   f->cfg = *cfg;
+   int rc = htkamd_mfcc_tables_build(cfg, &f->tab);
+   if (rc) { free(f); return rc; }
+   const htkamd_mfcc_tables &t = f->tab;
+   const int nn = t.fftN / 2;
+   if ((rc = up(&f->d_ham, t.ham, (size_t)t.frSize + 1)) || (rc = up(&f->d_cepWin, t.cepWin, (size_t)cfg->numCeps + 1)) ||
+       (rc = up(&f->d_loWt, t.loWt, (size_t)nn + 2)) || (rc = up(&f->d_bins, t.binA0, (size_t)4 * (cfg->numChans + 2))) ||
+       (rc = up(&f->d_dct, t.dct, (size_t)(cfg->numCeps + 1) * (cfg->numChans + 1))) || (rc = up(&f->d_tw, t.tw, (size_t)2 * nn)) ||
+       (rc = up(&f->d_rtw, t.rtw, (size_t)2 * (nn / 2 + 2))) || (rc = up(&f->d_brev, t.brev, (size_t)nn))) {
+      htkamd_mfcc_destroy(f); return rc;
+   }
+   *out = f;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_mfcc_destroy(htkamd_mfcc *f)
+{
+   if (!f) return;
+   (void)hipFree(f->d_ham); (void)hipFree(f->d_cepWin); (void)hipFree(f->d_loWt); (void)hipFree(f->d_bins); (void)hipFree(f->d_dct);
+   (void)hipFree(f->d_tw); (void)hipFree(f->d_rtw); (void)hipFree(f->d_brev); (void)hipFree(f->d_frameSamp); (void)hipFree(f->d_frameMean);
+   (void)hipFree(f->d_frameOff); (void)hipFree(f->d_frameUtt);
+   htkamd_mfcc_tables_free(&f->tab);
+   free(f);
+}
+
+extern "C" int htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int *sampOff, int nUtt, int *frameOff, float *dOut, void *stream)
+{
+   if (!f || !sampOff || !frameOff || nUtt < 0 || (nUtt > 0 && (!dWav || !dOut))) { htkamd_set_error("mfcc_compute: bad argument"); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   const htkamd_mfcc_config &c = f->cfg;
+   const htkamd_mfcc_tables &t = f->tab;
+   const int nCols = htkamd_mfcc_num_cols(&c), nStat = c.numCeps + (c.hasC0 ? 1 : 0) + (c.hasE ? 1 : 0);
+   std::vector<long long> frameSamp;
+   std::vector<int> frameUtt;
+   frameOff[0] = 0;
+   for (int u = 0; u < nUtt; u++) {
+      const int T = htkamd_mfcc_num_frames(&c, sampOff[u + 1] - sampOff[u]);
+      for (int k = 0; k < T; k++) { frameSamp.push_back((long long)sampOff[u] + (long long)k * t.frRate); frameUtt.push_back(u); }
+      frameOff[u + 1] = frameOff[u] + T;
+   }
+   const int F = (int)frameSamp.size();
+   if (F == 0) return HTKAMD_OK;
+   if ((size_t)F > f->capFrames) {
+      (void)hipFree(f->d_frameSamp); (void)hipFree(f->d_frameMean); (void)hipFree(f->d_frameUtt);
+      f->d_frameSamp = nullptr; f->d_frameMean = nullptr; f->d_frameUtt = nullptr;
+      const size_t cap = (size_t)F + F / 8;
+      HIPCHECK(hipMalloc((void **)&f->d_frameSamp, sizeof(long long) * cap));
+      HIPCHECK(hipMalloc((void **)&f->d_frameMean, sizeof(float) * cap));
+      HIPCHECK(hipMalloc((void **)&f->d_frameUtt, sizeof(int) * cap));
+      f->capFrames = cap;
+   }
+   if ((size_t)nUtt + 1 > f->capUtt) {
+      (void)hipFree(f->d_frameOff); f->d_frameOff = nullptr;
+      HIPCHECK(hipMalloc((void **)&f->d_frameOff, sizeof(int) * ((size_t)nUtt + 1)));
+      f->capUtt = (size_t)nUtt + 1;
+   }
+   HIPCHECK(hipMemcpyAsync(f->d_frameSamp, frameSamp.data(), sizeof(long long) * F, hipMemcpyHostToDevice, s));
+   HIPCHECK(hipMemcpyAsync(f->d_frameUtt, frameUtt.data(), sizeof(int) * F, hipMemcpyHostToDevice, s));
+   HIPCHECK(hipMemcpyAsync(f->d_frameOff, frameOff, sizeof(int) * ((size_t)nUtt + 1), hipMemcpyHostToDevice, s));
+
+   MfccArgs a;
+   a.wav = dWav; a.frameSamp = f->d_frameSamp; a.nFrames = F;
+   a.frSize = t.frSize; a.fftN = t.fftN; a.klo = t.klo; a.khi = t.khi; a.numChans = c.numChans; a.numCeps = c.numCeps;
+   a.nCols = nCols; a.nStat = nStat; a.preEmph = c.preEmph; a.cepScale = c.cepScale; a.mfnorm = t.mfnorm;
+   a.useHam = c.useHam; a.usePower = c.usePower; a.zMean = c.zMeanSource; a.hasC0 = c.hasC0; a.hasE = c.hasE; a.rawEnergy = c.rawEnergy;
+   a.ham = f->d_ham; a.cepWin = f->d_cepWin; a.loWt = f->d_loWt;
+   a.binA0 = f->d_bins; a.binA1 = f->d_bins + (c.numChans + 2); a.binB0 = a.binA1 + (c.numChans + 2); a.binB1 = a.binB0 + (c.numChans + 2);
+   a.dct = f->d_dct; a.tw = f->d_tw; a.rtw = f->d_rtw; a.brev = f->d_brev; a.frameMean = f->d_frameMean; a.out = dOut;
+
+   if (c.hasE || c.zMeanSource) {
+      hipLaunchKernelGGL(k_mfcc_energy, dim3((F + 63) / 64), dim3(64), 0, s, a);
+      HIPCHECK(hipGetLastError());
+   }
+   const size_t lds = sizeof(float) * ((size_t)t.fftN + t.fftN / 2 + 2 + c.numChans + 2);
+   hipLaunchKernelGGL(k_mfcc_frames, dim3(F), dim3(64), lds, s, a);
+   HIPCHECK(hipGetLastError());
+   if (c.hasE && c.eNormalise) {
+      hipLaunchKernelGGL(k_mfcc_enorm, dim3(nUtt), dim3(256), 0, s, dOut, f->d_frameOff, nCols, nStat - 1, c.silFloor, c.eScale);
+      HIPCHECK(hipGetLastError());
+   }
+   if (c.hasD) {
+      const size_t n = (size_t)F * nStat;
+      hipLaunchKernelGGL(k_mfcc_delta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dOut, f->d_frameUtt, f->d_frameOff, F, nCols, 0, nStat, nStat, c.delWin);
+      HIPCHECK(hipGetLastError());
+      if (c.hasA) {
+         hipLaunchKernelGGL(k_mfcc_delta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dOut, f->d_frameUtt, f->d_frameOff, F, nCols, nStat, 2 * nStat, nStat, c.accWin);
+         HIPCHECK(hipGetLastError());
+      }
+   }
+   if (c.hasZ) {
+      const int d = c.numCeps + (c.hasC0 ? 1 : 0);
+      hipLaunchKernelGGL(k_mfcc_zmean, dim3((nUtt * d + 63) / 64), dim3(64), 0, s, dOut, f->d_frameOff, nUtt, nCols, d);
+      HIPCHECK(hipGetLastError());
+   }
+   HIPCHECK(hipStreamSynchronize(s));           // frameSamp / frameUtt are host temporaries
+   return HTKAMD_OK;
+}

@@ -236,6 +236,37 @@ int  htkamd_viterbi_results(htkamd_viterbi *v, int *segStart, int *segEnd, doubl
                             int *modStart, int *modEnd, double *modScore,
                             double *total /*[nUtt]*/, int *status /*[nUtt]*/, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Waveform -> MFCC(+_0/_E)(+_D)(+_A)(+_Z) on the device: replaces what OpenBuffer (HParm.h, HParm.c:4357)
+ * does for a waveform source with maxObs == 0 (whole file converted into a table):
+ *   GetWave HWave.c:1683 frame slicing; ConvertFrame HParm.c:2214 = PreEmphasise HSigP.c:134, Ham :122,
+ *   Wave2FBank :558 (Realft :362 / FFT :311, mel binning, log), FBank2MFCC :607, FBank2C0 :647,
+ *   WeightCepstrum :773, raw log energy; NormaliseLogEnergy :911; AddQualifiers HParm.c:1618 =
+ *   AddRegression HSigP.c:860 for deltas/accelerations, FZeroMean :803 for _Z.
+ * Configuration names follow the HParm config variables (HParm.c:258-367).
+ * Output rows have the reference's column order: c1..cN [c0] [E] [deltas] [accs]; the output buffer is a
+ * feature matrix that htkamd_outp_block / htkamd_fb_* / htkamd_viterbi_* take as dX.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+   double sampPeriod;          /* SOURCERATE (100 ns units; 625 = 16 kHz)                 */
+   double winDur, frPeriod;    /* WINDOWSIZE, TARGETRATE (100 ns units)                    */
+   int    numChans, numCeps, cepLifter;                        /* NUMCHANS NUMCEPS CEPLIFTER */
+   float  preEmph;                                             /* PREEMCOEF                 */
+   int    useHam, usePower, zMeanSource, rawEnergy, eNormalise;/* USEHAMMING USEPOWER ZMEANSOURCE RAWENERGY ENORMALISE */
+   float  loFreq, hiFreq, cepScale, silFloor, eScale;          /* LOFREQ HIFREQ (<0 off) CEPSCALE SILFLOOR ESCALE */
+   int    hasC0, hasE, hasD, hasA, hasZ;                       /* qualifiers of TARGETKIND   */
+   int    delWin, accWin;                                      /* DELTAWINDOW ACCWINDOW      */
+} htkamd_mfcc_config;
+
+typedef struct htkamd_mfcc htkamd_mfcc;
+int  htkamd_mfcc_create(const htkamd_mfcc_config *cfg, htkamd_mfcc **out);
+void htkamd_mfcc_destroy(htkamd_mfcc *f);
+int  htkamd_mfcc_num_frames(const htkamd_mfcc_config *cfg, int nSamples);     /* FramesInWave HWave.c:1663 */
+int  htkamd_mfcc_num_cols(const htkamd_mfcc_config *cfg);
+/* dWav: device int16 samples of nUtt waveforms back to back; sampOff host [nUtt+1]; frameOff host OUT [nUtt+1];
+   dOut: device float [frameOff[nUtt] * cols].  Asynchronous on `stream` except for the table upload of the first call. */
+int  htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int *sampOff, int nUtt, int *frameOff, float *dOut, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

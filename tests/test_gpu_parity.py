@@ -336,3 +336,57 @@ def test_viterbi_config2_size(native, oracle):
         assert g["segStart"][0] == 0 and g["segEnd"][-1] == 500
         assert np.array_equal(g["segStart"][1:], g["segEnd"][:-1])
         assert abs(g["segScore"].sum() - g["total"]) < 1e-6 * abs(g["total"])
+
+
+# ----------------------------------------------------------------------------------------- MFCC front end (K6)
+def _test_wave(n=48000, seed=7):
+    rng = np.random.default_rng(seed); t = np.arange(n) / 16000
+    return (3000 * np.sin(2 * np.pi * 440 * t) * np.sin(2 * np.pi * 3 * t) + rng.normal(0, 800, n)).clip(-32768, 32767).astype("<i2")
+
+
+@pytest.mark.parametrize("kind,kw", [("MFCC_0_D_A", {}), ("MFCC_E_D_A", {}), ("MFCC_E_D_A_Z", {}), ("MFCC_0", {}),
+                                     ("MFCC_E_D", dict(rawEnergy=False, zMeanSource=True)),
+                                     ("MFCC_0_D_A", dict(loFreq=300.0, hiFreq=3400.0, numChans=20, numCeps=10, usePower=True))])
+def test_mfcc_matches_reference_front_end(native, oracle, kind, kw):
+    """WAV -> MFCC on the device vs the oracle (bit-equal to the reference's HCopy, tests/test_oracle_golden.py).
+    Tolerance class: 1e-4 relative with an absolute floor of 1e-3; observed: bit-equal except where the
+    device's double log() rounds differently."""
+    waves = [_test_wave(48000, 7), _test_wave(12345, 8), _test_wave(400, 9), _test_wave(399, 10)]     # ragged, 1 frame, 0 frames
+    got, frameOff = native.Mfcc(native.mfcc_config(kind, **kw)).compute_host(waves)
+    ocfg = oracle.mfcc_cfg(kind, **kw)
+    refs = [oracle.mfcc(w, ocfg) for w in waves]
+    assert list(frameOff) == list(np.concatenate([[0], np.cumsum([r.shape[0] for r in refs])]))
+    assert refs[2].shape[0] == 1 and refs[3].shape[0] == 0
+    ref = np.concatenate(refs)
+    assert got.shape == ref.shape
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-3)
+    assert (got == ref).mean() > 0.999
+
+
+def test_mfcc_known_answer_config5(native):
+    """3 s synthetic WAV, MFCC_0_D_A: 298 frames, first-frame statics and C0 as HCopy/HList print them."""
+    got, frameOff = native.Mfcc(native.mfcc_config("MFCC_0_D_A")).compute_host([_test_wave()])
+    assert got.shape == (298, 39)
+    want = [-20.591204, -2.0929291, -4.9431148, -4.984157, -9.7785, -11.552636, -8.135165, -4.291196, 0.3099544, 4.2238774, 3.6917002, 8.413123]
+    assert np.allclose(got[0, :12], want, rtol=1e-6) and abs(got[0, 12] - 75.76163) < 1e-4
+    assert np.allclose(got[0, 13:18], [-0.199, -0.417, -0.302, -0.200, -0.803], atol=1e-3)
+
+
+def test_wav_to_scores_on_device(native, oracle):
+    """BASELINE config 5: raw 16 kHz waveform -> on-device MFCC_0_D_A -> GMM scoring, no host round trip of the features."""
+    import ctypes as C
+    from htk_amd import synth
+    s = synth.generate(25, 4, 10, 0, 10, 3)
+    pk = s.packed()
+    gm, om = native.Model(pk), oracle.Model(pk)
+    mf = native.Mfcc(native.mfcc_config("MFCC_0_D_A"))
+    dX, frameOff = mf.compute([_test_wave()])
+    T = int(frameOff[-1])
+    states = np.arange(25, dtype=np.int32)
+    dS = native.DevArray(states); dO = native.DevArray(nbytes=4 * T * 25)
+    native.check(native.lib().htkamd_outp_block(gm.h, dX.ptr, C.c_int(T), dS.ptr, C.c_int(25), dO.ptr, C.c_int(T), None), "outp_block")
+    got = dO.to_host(np.float32, (25, T)).T
+    X = dX.to_host(np.float32, (T, 39))
+    assert np.array_equal(got, om.score_block(X, states))                 # scoring of the device features: bit-exact
+    ref = om.score_block(oracle.mfcc(_test_wave(), oracle.mfcc_cfg("MFCC_0_D_A")), states)
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-2)

@@ -67,3 +67,24 @@ def test_too_short_utterance_is_skipped(oracle):
         m = po.Model(s.packed()); acc = po.Accs(m)
         rc, _, _ = po.fb_utt(m, po.fb_cfg(), X, s.seqs[1], acc)
         assert rc == 0 and acc.nEgs.sum() == 0
+
+
+@pytest.mark.parametrize("kind", ["MFCC_0_D_A", "MFCC_E_D_A", "MFCC_E_D_A_Z", "MFCC_0"])
+def test_mfcc_oracle_equals_hcopy(oracle, kind):
+    """oracle/orc_mfcc.c vs the reference's HCopy on the SURVEY config-5 waveform: every float identical."""
+    import wave
+    from htk_amd import synth
+    rng = np.random.default_rng(7); n = 48000; t = np.arange(n) / 16000
+    x = (3000 * np.sin(2 * np.pi * 440 * t) * np.sin(2 * np.pi * 3 * t) + rng.normal(0, 800, n)).clip(-32768, 32767).astype("<i2")
+    with tempfile.TemporaryDirectory() as d:
+        w = wave.open(os.path.join(d, "t.wav"), "wb"); w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(x.tobytes()); w.close()
+        open(os.path.join(d, "mfcc.conf"), "w").write(
+            "SOURCEFORMAT = WAV\nSOURCERATE = 625\nWINDOWSIZE = 250000.0\nTARGETRATE = 100000.0\nNUMCHANS = 26\nNUMCEPS = 12\n"
+            "CEPLIFTER = 22\nPREEMCOEF = 0.97\nUSEHAMMING = T\nTARGETKIND = %s\n" % kind)
+        r = subprocess.run("%s/HCopy -C mfcc.conf t.wav t.mfc" % REFDIR, shell=True, cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        ref, period, k = synth.read_htk_param(os.path.join(d, "t.mfc"))
+    mine = oracle.mfcc(x, oracle.mfcc_cfg(kind))
+    assert period == 100000 and ref.shape == (298, mine.shape[1])
+    assert np.array_equal(ref, mine)
