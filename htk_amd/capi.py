@@ -425,3 +425,47 @@ class Mfcc:
             self.close()
         except Exception:
             pass
+
+
+def _desc_from_packed(pk: dict):
+    """(ModelDesc, keepalive) from a packed dict -- for the pure-host entry points that take a description."""
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    k = dict(stateCompOff=i32(pk["stateCompOff"]), compWeight=f32(pk["compWeight"]), compGauss=i32(pk["compGauss"]),
+             mean=f32(pk["mean"]), var=f32(pk["var"]), gconst=f32(pk.get("gconst")),
+             transN=i32(pk["transN"]), transOff=i32(pk["transOff"]), transP=f32(pk["transP"]),
+             hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]))
+    d = ModelDesc(int(pk["vecSize"]), int(pk["numStates"]), int(pk["numComp"]), int(pk["numGauss"]), int(pk["numTrans"]), int(pk["numPhys"]),
+                  _p(k["stateCompOff"]), _p(k["compWeight"]), _p(k["compGauss"]), _p(k["mean"]), _p(k["var"]), _p(k["gconst"]),
+                  _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]))
+    return d, k
+
+
+def _names_array(names):
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    return arr
+
+
+def accs_layout(pk: dict) -> AccsLayout:
+    d, keep = _desc_from_packed(pk)
+    lay = AccsLayout()
+    check(lib().htkamd_accs_layout_from_desc(C.byref(d), C.byref(lay)), "accs_layout_from_desc")
+    return lay
+
+
+def hmm_scan_order(names) -> np.ndarray:
+    order = np.zeros(len(names), np.int32)
+    check(lib().htkamd_hmm_scan_order(_names_array(names), C.c_int(len(names)), _p(order)), "hmm_scan_order")
+    return order
+
+
+def accs_dump_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UPALL):
+    d, keep = _desc_from_packed(pk)
+    vec = np.ascontiguousarray(vec, np.float64)
+    check(lib().htkamd_accs_dump_file(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), path.encode()), "accs_dump_file")
+
+
+def accs_load_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UPALL):
+    d, keep = _desc_from_packed(pk)
+    assert vec.dtype == np.float64 and vec.flags.c_contiguous
+    check(lib().htkamd_accs_load_file(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), path.encode()), "accs_load_file")

@@ -1,0 +1,182 @@
+/* accio.c -- host-side (C) reading and writing of HERest accumulator files (HERN.acc), so that the
+ * reference's parallel mode and this library can exchange statistics:
+ *     HERest -p N  ->  DumpAccs (HTrain.c:1453-1505) + float totalPr, int totalT (HERest.c:546-548)
+ *     HERest -p 0  ->  LoadAccs (HTrain.c:1625-1687): ADDS each file to the accumulators
+ * File layout (binary, big-endian, HShell.c:1638): per physical HMM in HMM-scan order -- quoted name + newline,
+ * int32 example count, for every not-yet-seen state WtAcc {c[M], occ} followed by, per not-yet-seen Gaussian,
+ * MuAcc {mu[D], occ} and VaAcc {var[D], occ}; for a not-yet-seen transition matrix TrAcc {tran[N][N], occ[N]};
+ * int32 marker 123456.  The scan order is the order of the 'h' macros in the set's hash table (HUtil.c:265-295
+ * GoNextHMM over mtab; HModel.c:3314 Hash, :3384 head insertion): ascending hash bucket, later definitions first.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../csrc/internal.h"
+
+#define MACHASHSIZE 250007                      /* HModel.h:50 */
+
+static unsigned mac_hash(const char *name)      /* HModel.c:3314-3321 */
+{
+   unsigned hashval;
+   for (hashval = 0; *name != '\0'; name++) hashval = *name + 31 * hashval;
+   return hashval % MACHASHSIZE;
+}
+
+typedef struct { unsigned h; int idx; } scan_ent;
+static int scan_cmp(const void *a, const void *b)
+{
+   const scan_ent *x = (const scan_ent *)a, *y = (const scan_ent *)b;
+   if (x->h != y->h) return (x->h < y->h) ? -1 : 1;
+   return (x->idx > y->idx) ? -1 : (x->idx < y->idx);       /* head insertion: later definitions come first */
+}
+
+/* order[k] = index of the k-th physical HMM in the reference's scan (names in definition order) */
+int htkamd_hmm_scan_order(const char *const *names, int H, int *order)
+{
+   scan_ent *e;
+   int i;
+   if (!names || !order || H < 0) { htkamd_set_error("hmm_scan_order: bad argument"); return HTKAMD_EINVAL; }
+   e = (scan_ent *)malloc(sizeof(scan_ent) * (size_t)(H ? H : 1));
+   for (i = 0; i < H; i++) { e[i].h = mac_hash(names[i]); e[i].idx = i; }
+   qsort(e, (size_t)H, sizeof(scan_ent), scan_cmp);
+   for (i = 0; i < H; i++) order[i] = e[i].idx;
+   free(e);
+   return HTKAMD_OK;
+}
+
+int htkamd_accs_layout_from_desc(const htkamd_model_desc *d, htkamd_accs_layout *lay)
+{
+   size_t o = 0, GD;
+   int t, sumN = 0;
+   if (!d || !lay) { htkamd_set_error("accs_layout_from_desc: NULL"); return HTKAMD_EINVAL; }
+   GD = (size_t)d->numGauss * d->vecSize;
+   for (t = 0; t < d->numTrans; t++) sumN += d->transN[t];
+   lay->mu = o; o += GD;
+   lay->muOcc = o; o += d->numGauss;
+   lay->va = o; o += GD;
+   lay->vaOcc = o; o += d->numGauss;
+   lay->wt = o; o += d->numComp;
+   lay->wtOcc = o; o += d->numStates;
+   lay->tr = o; o += d->transOff[d->numTrans];
+   lay->trOcc = o; o += sumN;
+   lay->nEgs = o; o += d->numPhys;
+   lay->totalPr = o++; lay->totalT = o++; lay->nUttDone = o++; lay->nUttSkipped = o++; lay->nEval = o++;
+   lay->total = o;
+   return HTKAMD_OK;
+}
+
+static void put_be32(FILE *f, const void *p)
+{
+   const unsigned char *b = (const unsigned char *)p;
+   unsigned char o[4] = {b[3], b[2], b[1], b[0]};
+   fwrite(o, 1, 4, f);
+}
+static void put_f(FILE *f, double v) { float x = (float)v; put_be32(f, &x); }
+static void put_i(FILE *f, int v) { put_be32(f, &v); }
+static int get_be32(FILE *f, void *p)
+{
+   unsigned char b[4], *o = (unsigned char *)p;
+   if (fread(b, 1, 4, f) != 4) return 0;
+   o[0] = b[3]; o[1] = b[2]; o[2] = b[1]; o[3] = b[0];
+   return 1;
+}
+
+/* walks the file structure once; `wr` != 0 writes vec -> file, else adds file -> vec */
+static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_accs_layout *lay, double *vec,
+                    const char *const *names, int uFlags, const char *path)
+{
+   const int D = d->vecSize;
+   unsigned char *seenS = (unsigned char *)calloc((size_t)d->numStates, 1);
+   unsigned char *seenG = (unsigned char *)calloc((size_t)d->numGauss, 1);
+   unsigned char *seenT = (unsigned char *)calloc((size_t)d->numTrans, 1);
+   int *order = (int *)malloc(sizeof(int) * (size_t)(d->numPhys ? d->numPhys : 1));
+   int *occOff = (int *)calloc((size_t)d->numTrans + 1, sizeof(int));
+   int k, j, c, i, rc = HTKAMD_OK, t;
+   float x;
+   for (t = 0; t < d->numTrans; t++) occOff[t + 1] = occOff[t] + d->transN[t];
+   htkamd_hmm_scan_order(names, d->numPhys, order);
+#define IO(off)  do { if (wr) put_f(f, vec[off]); else { if (!get_be32(f, &x)) { rc = HTKAMD_EINVAL; goto bad; } vec[off] += (double)x; } } while (0)
+   for (k = 0; k < d->numPhys; k++) {
+      const int h = order[k], ti = d->hmmTrans[h], N = d->transN[ti];
+      if (wr) {
+         const char *p;
+         fputc('"', f);
+         for (p = names[h]; *p; p++) { if (*p == '"' || *p == '\\') fputc('\\', f); fputc(*p, f); }
+         fputc('"', f); fputc('\n', f);
+         put_i(f, (int)(vec[lay->nEgs + h] + 0.5));
+      } else {
+         char buf[512]; int n = 0, ch, negs;
+         if (fgetc(f) != '"') { rc = HTKAMD_EINVAL; goto bad; }
+         while ((ch = fgetc(f)) != EOF && ch != '"' && n < 510) { if (ch == '\\') ch = fgetc(f); buf[n++] = (char)ch; }
+         buf[n] = 0;
+         if (ch != '"' || fgetc(f) != '\n' || strcmp(buf, names[h]) != 0) {      /* CheckPName HTrain.c:1600 */
+            htkamd_set_error("accs_load_file: %s: expected HMM \"%s\", found \"%s\"", path, names[h], buf);
+            rc = HTKAMD_EINVAL; goto bad2;
+         }
+         if (!get_be32(f, &negs)) { rc = HTKAMD_EINVAL; goto bad; }
+         vec[lay->nEgs + h] += negs;
+      }
+      for (j = 0; j < N - 2; j++) {
+         const int s = d->hmmState[d->hmmStateOff[h] + j];
+         if (seenS[s]) continue;
+         seenS[s] = 1;
+         for (c = d->stateCompOff[s]; c < d->stateCompOff[s + 1]; c++) IO(lay->wt + c);
+         IO(lay->wtOcc + s);
+         for (c = d->stateCompOff[s]; c < d->stateCompOff[s + 1]; c++) {
+            const int g = d->compGauss[c];
+            if (seenG[g]) continue;
+            seenG[g] = 1;
+            if (uFlags & HTKAMD_UPMEANS) { for (i = 0; i < D; i++) IO(lay->mu + (size_t)g * D + i); IO(lay->muOcc + g); }
+            if (uFlags & HTKAMD_UPVARS) { for (i = 0; i < D; i++) IO(lay->va + (size_t)g * D + i); IO(lay->vaOcc + g); }
+         }
+      }
+      if (!seenT[ti]) {
+         seenT[ti] = 1;
+         for (i = 0; i < N * N; i++) IO(lay->tr + d->transOff[ti] + i);
+         for (i = 0; i < N; i++) IO(lay->trOcc + occOff[ti] + i);
+      }
+      if (wr) put_i(f, 123456);
+      else { int mark; if (!get_be32(f, &mark) || mark != 123456) { htkamd_set_error("accs_load_file: %s: marker missing after \"%s\"", path, names[h]); rc = HTKAMD_EINVAL; goto bad2; } }
+   }
+   if (wr) { put_f(f, vec[lay->totalPr]); put_i(f, (int)(vec[lay->totalT] + 0.5)); }
+   else { int tt; if (!get_be32(f, &x) || !get_be32(f, &tt)) { rc = HTKAMD_EINVAL; goto bad; } vec[lay->totalPr] += (double)x; vec[lay->totalT] += tt; }
+   goto done;
+bad:
+   htkamd_set_error("accs_load_file: %s: truncated or malformed", path);
+bad2:
+done:
+#undef IO
+   free(seenS); free(seenG); free(seenT); free(order); free(occOff);
+   return rc;
+}
+
+/* DumpAccs + HERest's trailer: write the host vector as HER<n>.acc */
+int htkamd_accs_dump_file(const htkamd_model_desc *d, const double *vec, const char *const *names, int uFlags, const char *path)
+{
+   htkamd_accs_layout lay;
+   FILE *f;
+   int rc;
+   if (!d || !vec || !names || !path) { htkamd_set_error("accs_dump_file: NULL argument"); return HTKAMD_EINVAL; }
+   htkamd_accs_layout_from_desc(d, &lay);
+   f = fopen(path, "wb");
+   if (!f) { htkamd_set_error("accs_dump_file: cannot open %s", path); return HTKAMD_EINVAL; }
+   rc = acc_walk(f, 1, d, &lay, (double *)vec, names, uFlags, path);
+   fclose(f);
+   return rc;
+}
+
+/* LoadAccs + trailer: ADD the file to the host vector */
+int htkamd_accs_load_file(const htkamd_model_desc *d, double *vec, const char *const *names, int uFlags, const char *path)
+{
+   htkamd_accs_layout lay;
+   FILE *f;
+   int rc;
+   if (!d || !vec || !names || !path) { htkamd_set_error("accs_load_file: NULL argument"); return HTKAMD_EINVAL; }
+   htkamd_accs_layout_from_desc(d, &lay);
+   f = fopen(path, "rb");
+   if (!f) { htkamd_set_error("accs_load_file: cannot open %s", path); return HTKAMD_EINVAL; }
+   rc = acc_walk(f, 0, d, &lay, vec, names, uFlags, path);
+   if (rc == HTKAMD_OK && fgetc(f) != EOF) { htkamd_set_error("accs_load_file: %s: trailing bytes", path); rc = HTKAMD_EINVAL; }
+   fclose(f);
+   return rc;
+}

@@ -137,6 +137,15 @@ int  htkamd_accs_device_vector(htkamd_accs *a, double **dVec, size_t *n);      /
 int  htkamd_accs_download(htkamd_accs *a, double *hostVec /*[layout.total]*/, void *stream);
 int  htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream); /* LoadAccs: adds */
 
+/* Accumulator files (HERN.acc) for exchanging statistics with the reference's parallel mode: DumpAccs
+ * (HTrain.c:1453) + trailer (HERest.c:546-548) and LoadAccs (HTrain.c:1625; adds).  Pure host functions on the
+ * flat vector; `names[h]` is the physical HMM name in definition order (the HMM list).  Files follow the
+ * reference's HMM-scan order, so `HERest -p 0` reads what is written here and vice versa. */
+int htkamd_accs_layout_from_desc(const htkamd_model_desc *d, htkamd_accs_layout *out);
+int htkamd_hmm_scan_order(const char *const *names, int H, int *order);
+int htkamd_accs_dump_file(const htkamd_model_desc *d, const double *hostVec, const char *const *names, int uFlags, const char *path);
+int htkamd_accs_load_file(const htkamd_model_desc *d, double *hostVec, const char *const *names, int uFlags, const char *path);
+
 /* ------------------------------------------------------------------------------------------
  * Model update after a pass: UpdateModels (HERest.c:1326) -> MLUpdateModels (HERest.c:1262) with
  * UpdateTrans :795, UpdateWeights :897 (+FloorMixes :819), UpdateVars :1045, UpdateMeans :974 and

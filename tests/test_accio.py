@@ -1,0 +1,86 @@
+"""HERN.acc files (host C, htk_amd/host/accio.c) against the reference: the loader reads what the reference's DumpAccs wrote
+(golden HER1.acc content, re-encoded through our writer), scan order equals the reference's, and -- live, where the reference
+is built -- `HERest -p 0` accepts a file written here and produces the same model as from its own dump."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from util import REFDIR, load_case
+
+
+def _vec_from_case(native, case):
+    lay = native.accs_layout(case["pk"])
+    v = np.zeros(lay.total, np.float64)
+    a = case["acc"]
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs"):
+        x = np.asarray(a[k], np.float64).reshape(-1)
+        off = getattr(lay, k)
+        v[off:off + x.size] = x
+    v[lay.totalPr] = float(a["totalPr"]); v[lay.totalT] = int(a["totalT"])
+    return lay, v
+
+
+def test_layout_matches_python_mirror(native):
+    from htk_amd import herest
+    case = load_case("fb_topo")
+    lay = native.accs_layout(case["pk"])
+    py = herest.layout_from_packed(case["pk"])
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs", "totalPr", "totalT", "nUttDone", "nUttSkipped", "nEval", "total"):
+        assert getattr(lay, k) == py[k], k
+
+
+@pytest.mark.parametrize("name,names", [("fb_small", ["p%d" % i for i in range(40)]), ("fb_topo", ["a", "b", "sp", "c", "d", "e"])])
+def test_dump_then_load_round_trip(native, name, names):
+    case = load_case(name)
+    lay, v = _vec_from_case(native, case)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "HER1.acc")
+        native.accs_dump_file(case["pk"], v, names, path)
+        w = np.zeros_like(v)
+        native.accs_load_file(case["pk"], w, names, path)
+        native.accs_load_file(case["pk"], w, names, path)            # LoadAccs adds
+        assert np.array_equal(w[:lay.nUttDone], 2 * v[:lay.nUttDone])
+        # the independent Python parser of the reference's format reads our file too, in the same HMM order
+        from oracle import refio
+        r = refio.read_acc(path, case["pk"], names)
+        assert np.array_equal(r["mu"].reshape(-1), np.asarray(case["acc"]["mu"]).reshape(-1))
+        assert np.array_equal(r["tr"], case["acc"]["tr"]) and np.array_equal(r["nEgs"], case["acc"]["nEgs"])
+        assert list(r["order"]) == list(native.hmm_scan_order(names))
+        with pytest.raises(native.HtkAmdError):
+            native.accs_load_file(case["pk"], w, names[::-1], path)   # CheckPName: wrong model set
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "HERest")), reason="oracle/_ref not built")
+def test_reference_herest_p0_accepts_our_file(native, oracle):
+    """Write oracle statistics with OUR writer, let the reference's `HERest -p 0` load + update, and compare with the
+    reference updating from its own dump: identical MMFs.  Also our loader reads the reference's dump bit for bit."""
+    from htk_amd import herest, synth
+    from oracle import refio
+    with tempfile.TemporaryDirectory() as d:
+        s = synth.generate(30, 3, 20, 6, 90, 77, outdir=d)
+        names = ["p%d" % i for i in range(20)]
+        pk = s.packed()
+        scp = open(os.path.join(d, "train.scp")).read().split()
+        r = subprocess.run("%s/HERest -C config -H hmm0/MMF -M hmm1 -L lab -p 1 hmmlist %s" % (REFDIR, " ".join(scp)),
+                           shell=True, cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        ref_acc = os.path.join(d, "hmm1", "HER1.acc")
+        lay = native.accs_layout(pk)
+        v = np.zeros(lay.total, np.float64)
+        native.accs_load_file(pk, v, names, ref_acc)
+        ra = refio.read_acc(ref_acc, pk, names)
+        assert np.array_equal(v[lay.mu:lay.muOcc], ra["mu"].reshape(-1).astype(np.float64))
+        assert np.array_equal(v[lay.nEgs:lay.nEgs + 20], ra["nEgs"].astype(np.float64))
+        assert list(ra["order"]) == list(native.hmm_scan_order(names))
+        # our file -> reference reducer
+        os.makedirs(os.path.join(d, "ours")); os.makedirs(os.path.join(d, "outA")); os.makedirs(os.path.join(d, "outB"))
+        native.accs_dump_file(pk, v, names, os.path.join(d, "ours", "HER1.acc"))
+        assert open(os.path.join(d, "ours", "HER1.acc"), "rb").read() == open(ref_acc, "rb").read()
+        for src, out in ((ref_acc, "outA"), (os.path.join(d, "ours", "HER1.acc"), "outB")):
+            r = subprocess.run("%s/HERest -C config -H hmm0/MMF -M %s -m 1 -p 0 hmmlist %s" % (REFDIR, out, src),
+                               shell=True, cwd=d, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+        assert open(os.path.join(d, "outA", "MMF")).read() == open(os.path.join(d, "outB", "MMF")).read()
