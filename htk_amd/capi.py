@@ -469,3 +469,19 @@ def accs_load_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UP
     d, keep = _desc_from_packed(pk)
     assert vec.dtype == np.float64 and vec.flags.c_contiguous
     check(lib().htkamd_accs_load_file(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), path.encode()), "accs_load_file")
+
+
+def parm_read(path: str):
+    """HTK parameter file -> (float32 [T, cols], sampPeriod, kind) through the host C reader (handles _C and _K)."""
+    data = C.c_void_p(); T = C.c_int(); cols = C.c_int(); per = C.c_int(); kind = C.c_int()
+    check(lib().htkamd_parm_read(path.encode(), C.byref(data), C.byref(T), C.byref(cols), C.byref(per), C.byref(kind)), "parm_read")
+    n = T.value * cols.value
+    arr = np.ctypeslib.as_array((C.c_float * max(n, 1)).from_address(data.value))[:n].copy().reshape(T.value, cols.value)
+    lib().htkamd_free(data)
+    return arr, per.value, kind.value
+
+
+def parm_write(path: str, X: np.ndarray, sampPeriod: int, kind: int, withCrc: bool = False):
+    X = np.ascontiguousarray(X, np.float32)
+    check(lib().htkamd_parm_write(path.encode(), _p(X), C.c_int(X.shape[0]), C.c_int(X.shape[1]), C.c_int(sampPeriod), C.c_int(kind),
+                                  C.c_int(int(withCrc))), "parm_write")

@@ -1,0 +1,97 @@
+/* parmfile.c -- host-side (C) HTK parameter files (HTKBook speechio.tex:835-950):
+ *   12-byte big-endian header {int32 nSamples, int32 sampPeriod (100 ns), int16 sampSize (bytes), int16 parmKind}
+ *   (ReadHTKHeader HWave.c:1408), rows of big-endian float32, or with _C (02000) int16 rows preceded by the float
+ *   vectors A and B (4 "samples"), value = (short + B)/A (GetParm HParm.c:3488-3492); with _K (010000) a trailing
+ *   16-bit checksum over all 16-bit words after the header, crc = (crc*65536 + word) % 36897 (UpdateCRCC HParm.c:3357).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../csrc/internal.h"
+
+#define HASCOMPX 02000
+#define HASCRCC  010000
+
+static unsigned be16(const unsigned char *p) { return ((unsigned)p[0] << 8) | p[1]; }
+static unsigned be32(const unsigned char *p) { return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3]; }
+static float be_float(const unsigned char *p) { unsigned u = be32(p); float f; memcpy(&f, &u, 4); return f; }
+
+void htkamd_free(void *p) { free(p); }
+
+int htkamd_parm_read(const char *path, float **data, int *nFrames, int *nCols, int *sampPeriod, int *kind)
+{
+   FILE *f;
+   unsigned char hdr[12], *buf = NULL;
+   long n, fileBytes;
+   int nSamples, sampSize, pk, cols, i, j, rc = HTKAMD_OK;
+   size_t bodyBytes;
+   float *out = NULL;
+   if (!path || !data || !nFrames || !nCols) { htkamd_set_error("parm_read: NULL argument"); return HTKAMD_EINVAL; }
+   f = fopen(path, "rb");
+   if (!f) { htkamd_set_error("parm_read: cannot open %s", path); return HTKAMD_EINVAL; }
+   if (fread(hdr, 1, 12, f) != 12) { fclose(f); htkamd_set_error("parm_read: %s: no HTK header", path); return HTKAMD_EINVAL; }
+   nSamples = (int)be32(hdr); sampSize = (int)(short)be16(hdr + 8); pk = (int)be16(hdr + 10);
+   if (sampPeriod) *sampPeriod = (int)be32(hdr + 4);
+   fseek(f, 0, SEEK_END); fileBytes = ftell(f); fseek(f, 12, SEEK_SET);
+   if (nSamples < 0 || sampSize <= 0) { fclose(f); htkamd_set_error("parm_read: %s: bad header", path); return HTKAMD_EINVAL; }
+   bodyBytes = (size_t)nSamples * sampSize;
+   if ((long)(12 + bodyBytes + ((pk & HASCRCC) ? 2 : 0)) > fileBytes) { fclose(f); htkamd_set_error("parm_read: %s: file shorter than its header says", path); return HTKAMD_EINVAL; }
+   buf = (unsigned char *)malloc(bodyBytes + 2);
+   n = (long)fread(buf, 1, bodyBytes + ((pk & HASCRCC) ? 2 : 0), f);
+   fclose(f);
+   if ((size_t)n != bodyBytes + ((pk & HASCRCC) ? 2 : 0)) { free(buf); htkamd_set_error("parm_read: %s: short read", path); return HTKAMD_EINVAL; }
+   if (pk & HASCRCC) {
+      unsigned crc = 0;
+      size_t w;
+      for (w = 0; w + 1 < bodyBytes + 1; w += 2) crc = (crc * 65536u + be16(buf + w)) % 36897u;
+      if (crc != be16(buf + bodyBytes)) { free(buf); htkamd_set_error("parm_read: %s: CRC check failed", path); return HTKAMD_EINVAL; }
+   }
+   if (pk & HASCOMPX) {
+      cols = sampSize / 2;
+      if (nSamples < 4) { free(buf); htkamd_set_error("parm_read: %s: compressed file without A/B vectors", path); return HTKAMD_EINVAL; }
+      nSamples -= 4;
+      out = (float *)malloc(sizeof(float) * (size_t)(nSamples ? nSamples : 1) * cols);
+      for (i = 0; i < nSamples; i++)
+         for (j = 0; j < cols; j++) {
+            const float A = be_float(buf + 4 * j), B = be_float(buf + 4 * (cols + j));
+            const short s = (short)be16(buf + 8 * cols + ((size_t)i * cols + j) * 2);
+            out[(size_t)i * cols + j] = ((float)s + B) / A;
+         }
+   } else {
+      cols = sampSize / 4;
+      out = (float *)malloc(sizeof(float) * (size_t)(nSamples ? nSamples : 1) * cols);
+      for (i = 0; i < nSamples * cols; i++) out[i] = be_float(buf + 4 * (size_t)i);
+   }
+   free(buf);
+   *data = out; *nFrames = nSamples; *nCols = cols;
+   if (kind) *kind = pk & ~(HASCOMPX | HASCRCC);
+   return rc;
+}
+
+int htkamd_parm_write(const char *path, const float *data, int nFrames, int nCols, int sampPeriod, int kind, int withCrc)
+{
+   FILE *f;
+   unsigned char hdr[12], *buf;
+   unsigned crc = 0;
+   size_t i, n = (size_t)nFrames * nCols;
+   int pk = (kind & ~(HASCOMPX | HASCRCC)) | (withCrc ? HASCRCC : 0), sz = nCols * 4;
+   if (!path || (!data && n) || nFrames < 0 || nCols <= 0) { htkamd_set_error("parm_write: bad argument"); return HTKAMD_EINVAL; }
+   f = fopen(path, "wb");
+   if (!f) { htkamd_set_error("parm_write: cannot open %s", path); return HTKAMD_EINVAL; }
+   hdr[0] = (unsigned char)(nFrames >> 24); hdr[1] = (unsigned char)(nFrames >> 16); hdr[2] = (unsigned char)(nFrames >> 8); hdr[3] = (unsigned char)nFrames;
+   hdr[4] = (unsigned char)(sampPeriod >> 24); hdr[5] = (unsigned char)(sampPeriod >> 16); hdr[6] = (unsigned char)(sampPeriod >> 8); hdr[7] = (unsigned char)sampPeriod;
+   hdr[8] = (unsigned char)(sz >> 8); hdr[9] = (unsigned char)sz; hdr[10] = (unsigned char)(pk >> 8); hdr[11] = (unsigned char)pk;
+   fwrite(hdr, 1, 12, f);
+   buf = (unsigned char *)malloc(4 * (n ? n : 1));
+   for (i = 0; i < n; i++) {
+      unsigned u; memcpy(&u, data + i, 4);
+      buf[4 * i] = (unsigned char)(u >> 24); buf[4 * i + 1] = (unsigned char)(u >> 16); buf[4 * i + 2] = (unsigned char)(u >> 8); buf[4 * i + 3] = (unsigned char)u;
+      crc = (crc * 65536u + (u >> 16)) % 36897u;
+      crc = (crc * 65536u + (u & 0xffffu)) % 36897u;
+   }
+   fwrite(buf, 1, 4 * n, f);
+   if (withCrc) { unsigned char c[2] = {(unsigned char)(crc >> 8), (unsigned char)crc}; fwrite(c, 1, 2, f); }
+   free(buf);
+   fclose(f);
+   return HTKAMD_OK;
+}

@@ -137,6 +137,13 @@ int  htkamd_accs_device_vector(htkamd_accs *a, double **dVec, size_t *n);      /
 int  htkamd_accs_download(htkamd_accs *a, double *hostVec /*[layout.total]*/, void *stream);
 int  htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream); /* LoadAccs: adds */
 
+/* HTK parameter files: header + big-endian float rows, _C compression and _K checksum on input
+ * (ReadHTKHeader HWave.c:1408, OpenParmChannel HParm.c:3561, GetParm :3464, UpdateCRCC :3357).  *data is malloc'd
+ * (release with htkamd_free); *kind comes back without the _C/_K bits. */
+int  htkamd_parm_read(const char *path, float **data, int *nFrames, int *nCols, int *sampPeriod, int *kind);
+int  htkamd_parm_write(const char *path, const float *data, int nFrames, int nCols, int sampPeriod, int kind, int withCrc);
+void htkamd_free(void *p);
+
 /* Accumulator files (HERN.acc) for exchanging statistics with the reference's parallel mode: DumpAccs
  * (HTrain.c:1453) + trailer (HERest.c:546-548) and LoadAccs (HTrain.c:1625; adds).  Pure host functions on the
  * flat vector; `names[h]` is the physical HMM name in definition order (the HMM list).  Files follow the
