@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
                      sum = sum + xm;
                   }
                   const v2f y = wt + (-0.5f * sum);
-                  acc0 = (float)ladd_tab((double)acc0, (double)y.x, mle, tab);
-                  acc1 = (float)ladd_tab((double)acc1, (double)y.y, mle, tab);
+                  acc0 = ladd_tab_f(acc0, y.x, mle, tab);
+                  acc1 = ladd_tab_f(acc1, y.y, mle, tab);
                }
             }
          }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
                if (c1 - c0 == 1) acc = mixp;
                else {
                   float y = wt + mixp;
-                  acc = (float)ladd_tab((double)acc, (double)y, a.minLogExp, tab);
+                  acc = ladd_tab_f(acc, y, a.minLogExp, tab);
                }
             }
             if (live) a.out[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + t] = acc;

@@ -82,4 +82,25 @@ __device__ __forceinline__ double exp_tab(const double x, const double *etab)
    return live ? v : 0.0;
 }
 
+
+// LAdd whose result is rounded to FLOAT right away (the mixture sum of ShStrP/cSOutP keeps LogFloat x).
+// x and y are doubles holding float values.  Besides the reference's own cut-off (diff < minLogExp) there is an exact
+// shortcut: for hi <= -16 and diff < -16 the increment log(1+exp(diff)) < 1.2e-7 is below a quarter of the float
+// spacing at hi (>= 2^-19 for |hi| >= 16, and >= 2^-20 on the side towards zero at a binade edge), so
+// float(hi + increment) == hi and the table row need not be evaluated.
+__device__ __forceinline__ float ladd_tab_f(const float xf, const float yf, const double minLogExp, const double *tab)
+{
+   const float hi = fmaxf(xf, yf), lo = fminf(xf, yf);
+   const double d = (double)lo - (double)hi;
+   if (d < minLogExp) return (hi < (float)LSMALL) ? (float)LZERO : hi;
+   if (d < -16.0 && hi <= -16.0f) return hi;
+   const int k = (int)(-d * (double)LADD_INV_H);
+   const double r = d + ((double)k + 0.5) * (1.0 / (double)LADD_INV_H);
+   const double *row = tab + k * LADD_ROW;
+   double f = row[LADD_DEG];
+#pragma unroll
+   for (int j = LADD_DEG - 1; j >= 0; j--) f = fma(f, r, row[j]);
+   return (float)((double)hi + f);
+}
+
 #endif
