@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--phones", type=int, default=6000)
     ap.add_argument("--utts", type=int, default=1250, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--score", choices=["exact", "mfma"], default="mfma",
+                    help="scoring arithmetic: exact = bit-identical to the reference (packed FP32 VALU); mfma = fp32 matrix-core GEMM, 1e-4 tolerance class")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -93,7 +95,7 @@ def main():
     model = capi.Model(pk)
     accs = capi.Accs(model)
     fb = capi.ForwardBackward(model)
-    cfg = capi.fb_config()                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
+    cfg = capi.fb_config(scoreMode=1 if args.score == "mfma" else 0)                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
 
     X = np.concatenate(s.feats)
     frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in s.feats])]).astype(np.int32)
@@ -167,7 +169,8 @@ def main():
             "utterances_ok": utts_total,
             "avg_logprob_per_frame": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
             "kernel_ms": {"score": ktimes[0] * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
-            "roofline": {"bound": "mfma", "kernel": "k_score_exact<39,2>", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+            "score_mode": args.score,
+            "roofline": {"bound": "mfma", "kernel": "k_score_mfma<20>" if args.score == "mfma" else "k_score_exact<39>", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
                          "flop_per_unit": flop_unit, "units_per_launch": units_local},
         }

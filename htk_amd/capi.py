@@ -42,7 +42,7 @@ class AccsLayout(C.Structure):
 
 class FbConfig(C.Structure):
     _fields_ = [("pruneInit", C.c_double), ("pruneInc", C.c_double), ("pruneLim", C.c_double),
-                ("minFrwdP", C.c_float), ("uFlags", C.c_int)]
+                ("minFrwdP", C.c_float), ("uFlags", C.c_int), ("scoreMode", C.c_int)]
 
 
 class UpdateConfig(C.Structure):
@@ -163,7 +163,7 @@ class Model:
                                             _p(out["compWeight"]), _p(out["transP"])), "model_get_params")
         return out
 
-    def outp_block(self, X: np.ndarray, states: np.ndarray) -> np.ndarray:
+    def outp_block(self, X: np.ndarray, states: np.ndarray, mode: int = 0) -> np.ndarray:
         """Scores [T, ns] of the listed tied states (HIP kernel K1), returned frame-major for convenience."""
         X = np.ascontiguousarray(X, np.float32); states = np.ascontiguousarray(states, np.int32)
         T, ns = X.shape[0], len(states)
@@ -171,7 +171,7 @@ class Model:
             return np.empty((T, ns), np.float32)
         dX, dS = DevArray(X), DevArray(states)
         dO = DevArray(nbytes=4 * T * ns)
-        check(lib().htkamd_outp_block(self.h, dX.ptr, C.c_int(T), dS.ptr, C.c_int(ns), dO.ptr, C.c_int(T), None), "outp_block")
+        check(lib().htkamd_outp_block_mode(self.h, dX.ptr, C.c_int(T), dS.ptr, C.c_int(ns), dO.ptr, C.c_int(T), C.c_int(mode), None), "outp_block")
         out = dO.to_host(np.float32, (ns, T))
         return np.ascontiguousarray(out.T)
 
@@ -234,8 +234,8 @@ class Accs:
             pass
 
 
-def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, uFlags=UPALL):
-    return FbConfig(pruneInit, pruneInc, pruneLim, minFrwdP, uFlags)
+def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, uFlags=UPALL, scoreMode=0):
+    return FbConfig(pruneInit, pruneInc, pruneLim, minFrwdP, uFlags, scoreMode)
 
 
 class ForwardBackward:

@@ -273,6 +273,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
+   sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff;
+   if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
 
    FbArgs fa;
    memset(&fa, 0, sizeof(fa));
@@ -307,7 +309,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
 
    int rc;
    HIPCHECK(hipEventRecord(fb->ev[0], s));
-   if ((rc = htkamd_launch_score_exact(m, sa, s))) return rc;
+   if ((rc = (cfg->scoreMode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, sa, s) : htkamd_launch_score_exact(m, sa, s))) return rc;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
    const bool wavePath = (m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
    if ((rc = wavePath ? htkamd_launch_beta_w(fa, s) : htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;

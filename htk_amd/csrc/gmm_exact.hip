@@ -167,8 +167,22 @@ int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStre
 }
 
 // ------------------------------------------------------------------------------------ C ABI
+static int outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns, float *dOut, int ldo, int mode, void *stream);
+
 extern "C" int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                                  float *dOut, int ldo, void *stream)
+{
+   return outp_block(m, dX, T, dStates, ns, dOut, ldo, HTKAMD_SCORE_EXACT, stream);
+}
+
+extern "C" int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
+                                      float *dOut, int ldo, int scoreMode, void *stream)
+{
+   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
+   return outp_block(m, dX, T, dStates, ns, dOut, ldo, scoreMode, stream);
+}
+
+static int outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns, float *dOut, int ldo, int mode, void *stream)
 {
    if (!m || !dX || !dStates || !dOut || T < 0 || ns < 0 || ldo < T) {
       htkamd_set_error("outp_block: bad argument (T=%d ns=%d ldo=%d)", T, ns, ldo);
@@ -200,7 +214,8 @@ extern "C" int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const 
    a.stateCompOff = m->d_stateCompOff; a.compGauss = m->d_compGauss; a.compLogWt = m->d_compLogWt;
    a.gparam = m->d_gparam; a.PS = m->PS; a.D = m->D; a.minLogExp = m->minLogExp;
    a.laddTab = m->d_laddTab; a.taskCounter = (int *)(d + sizeof(ScoreTask) * (size_t)nTasks);
-   int rc = htkamd_launch_score_exact(m, a, s);
+   a.mfmaTab = m->d_mfmaTab; a.stateTileOff = m->d_stateTileOff;
+   int rc = (mode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, a, s) : htkamd_launch_score_exact(m, a, s);
    hipError_t e = hipStreamSynchronize(s);      // the task table is freed below
    free(h);
    (void)hipFree(d);

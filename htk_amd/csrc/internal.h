@@ -64,6 +64,10 @@ struct htkamd_model {
    double *d_laddTab;          /* [LADD_NK*(LADD_DEG+1)] */
    float *d_mean, *d_ivar, *d_gconst, *d_compLogWt, *d_transP;
    int   *d_stateCompOff, *d_compGauss, *d_transN, *d_transOff;
+   /* MFMA scoring path (gmm_mfma.hip): A-operand fragments [tile][mfmaNS+4][64], 16 components per tile */
+   float *d_mfmaTab;           /* NULL when D has no MFMA kernel */
+   int   *d_stateTileOff;      /* [S+1] */
+   int    mfmaNS, nTiles;
    double minLogExp;
 };
 

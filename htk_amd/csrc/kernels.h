@@ -29,9 +29,12 @@ struct ScoreArgs {
    double minLogExp;
    const double *laddTab;
    int *taskCounter;          // dynamic task queue head (zeroed before the launch)
+   const float *mfmaTab;      // MFMA path only
+   const int *stateTileOff;
 };
 
 int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream);
+int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream);
 
 // ---- forward-backward ----
 struct UttDesc {

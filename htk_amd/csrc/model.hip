@@ -84,6 +84,59 @@ template <typename T> static int toDevice(T **dst, const T *src, size_t n)
    return HTKAMD_OK;
 }
 
+// A-operand fragment table of the MFMA scoring kernel (layout: gmm_mfma.hip).  Column j of tile t of state s is
+// component stateCompOff[s] + 16*(t - stateTileOff[s]) + j; K index 4*step + kq carries dimension 2*step + (kq>>1),
+// as the x^2 coefficient -0.5*ivar for even kq and the x coefficient mean*ivar for odd kq; rows mfmaNS..mfmaNS+3 are
+// the accumulator start (log weight - 0.5*(gConst + sum mean^2*ivar)) in the C-operand layout.  Unused components
+// start at -1e30 (drop out of the sum).
+static int mfma_refresh(htkamd_model *m)
+{
+   const int D = m->D;
+   if (!(D == 39 || D == 26 || D == 13)) return HTKAMD_OK;
+   const int NS = (D + 1) / 2;
+   if (!m->d_stateTileOff) {
+      int *off = (int *)malloc(sizeof(int) * ((size_t)m->S + 1));
+      off[0] = 0;
+      for (int s = 0; s < m->S; s++) off[s + 1] = off[s] + (m->h_stateCompOff[s + 1] - m->h_stateCompOff[s] + 15) / 16;
+      m->nTiles = off[m->S]; m->mfmaNS = NS;
+      int rc = toDevice(&m->d_stateTileOff, off, (size_t)m->S + 1);
+      free(off);
+      if (rc) return rc;
+   }
+   const size_t stride = (size_t)(NS + 4) * 64;
+   float *tab = (float *)calloc((size_t)m->nTiles * stride, sizeof(float));
+   size_t t = 0;
+   for (int s = 0; s < m->S; s++) {
+      const int c0 = m->h_stateCompOff[s], c1 = m->h_stateCompOff[s + 1];
+      for (int cb = c0; cb < c1; cb += 16, t++) {
+         float *T = tab + t * stride;
+         for (int col = 0; col < 16; col++) {
+            const int c = cb + col;
+            const bool live = c < c1 && (c1 - c0 == 1 || m->h_compLogWt[c] > (float)LMINMIX);
+            // accumulator start of row `col`: lane (kq = col/4, any column) register col%4, i.e. table row NS + col%4
+            float *ciRow = T + (size_t)(NS + (col & 3)) * 64 + (col >> 2) * 16;
+            if (!live) { for (int j = 0; j < 16; j++) ciRow[j] = -1.0e30f; continue; }
+            const int g = m->h_compGauss[c];
+            const float *mu = m->h_mean + (size_t)g * D, *iv = m->h_ivar + (size_t)g * D;
+            double k0 = m->h_gconst[g];
+            for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+            const float ci = (float)((c1 - c0 == 1 ? 0.0 : (double)m->h_compLogWt[c]) - 0.5 * k0);
+            for (int j = 0; j < 16; j++) ciRow[j] = ci;
+            for (int st = 0; st < NS; st++)
+               for (int kq = 0; kq < 4; kq++) {
+                  const int dim = 2 * st + (kq >> 1);
+                  float v = 0.0f;
+                  if (dim < D) v = (kq & 1) ? (float)((double)mu[dim] * iv[dim]) : -0.5f * iv[dim];
+                  T[(size_t)st * 64 + kq * 16 + col] = v;
+               }
+         }
+      }
+   }
+   int rc = toDevice(&m->d_mfmaTab, tab, (size_t)m->nTiles * stride);
+   free(tab);
+   return rc;
+}
+
 // (Re)derive ivar / log weights / min durations / the interleaved scoring table and push them.
 static int model_refresh(htkamd_model *m)
 {
@@ -108,7 +161,7 @@ static int model_refresh(htkamd_model *m)
    if ((rc = toDevice(&m->d_gconst, m->h_gconst, (size_t)m->G))) return rc;
    if ((rc = toDevice(&m->d_compLogWt, m->h_compLogWt, (size_t)m->C))) return rc;
    if ((rc = toDevice(&m->d_transP, m->h_transP, (size_t)m->h_transOff[m->nT]))) return rc;
-   return HTKAMD_OK;
+   return mfma_refresh(m);
 }
 
 extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **out)
@@ -190,7 +243,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    free(m->h_mean); free(m->h_var); free(m->h_ivar); free(m->h_gconst); free(m->h_compWeight); free(m->h_compLogWt); free(m->h_transP);
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
-   (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff);
+   (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff); (void)hipFree(m->d_mfmaTab); (void)hipFree(m->d_stateTileOff);
    free(m);
 }
 

