@@ -146,6 +146,16 @@ def main():
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
+        kname = "k_score_mfma<20>" if args.score == "mfma" else "k_score_exact<39>"
+        traffic = None                                       # HBM-side bytes per launch from the committed PMC pass, same workload only
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+            w = tj["workload"]
+            if (w["states"], w["mix"], w["utts_per_gpu"], w["frames"]) == (args.states, args.mix, args.utts, args.frames):
+                k = tj["kernels"][kname]
+                traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            traffic = None
         k1 = float(ktimes[0])
         achieved = units_local * flop_unit / k1 / 1e12 if k1 > 0 else 0.0
         out = {
@@ -170,8 +180,8 @@ def main():
             "avg_logprob_per_frame": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
             "kernel_ms": {"score": ktimes[0] * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
             "score_mode": args.score,
-            "roofline": {"bound": "mfma", "kernel": "k_score_mfma<20>" if args.score == "mfma" else "k_score_exact<39>", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_unit": flop_unit, "units_per_launch": units_local},
         }
         if args.cpu_seconds > 0:
