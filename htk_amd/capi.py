@@ -485,3 +485,112 @@ def parm_write(path: str, X: np.ndarray, sampPeriod: int, kind: int, withCrc: bo
     X = np.ascontiguousarray(X, np.float32)
     check(lib().htkamd_parm_write(path.encode(), _p(X), C.c_int(X.shape[0]), C.c_int(X.shape[1]), C.c_int(sampPeriod), C.c_int(kind),
                                   C.c_int(int(withCrc))), "parm_write")
+
+
+def parm_add_qualifiers(stat_list, hasD=True, hasA=False, delWin=2, accWin=2) -> "DevArray":
+    """Statics of several utterances -> device table with deltas/accelerations (AddQualifiers, HParm.c:1618).
+    Returns (DevArray [sum T, cols], frameOff)."""
+    stat = np.ascontiguousarray(np.concatenate(stat_list), np.float32)
+    frameOff = np.concatenate([[0], np.cumsum([x.shape[0] for x in stat_list])]).astype(np.int32)
+    n = stat.shape[1]
+    cols = n * (1 + int(hasD) + int(hasA))
+    dIn = DevArray(stat)
+    dOut = DevArray(nbytes=4 * max(stat.shape[0] * cols, 1))
+    check(lib().htkamd_parm_add_qualifiers(dIn.ptr, _p(frameOff), C.c_int(len(stat_list)), C.c_int(n), C.c_int(int(hasD)), C.c_int(int(hasA)),
+                                           C.c_int(delWin), C.c_int(accWin), dOut.ptr, None), "parm_add_qualifiers")
+    return dOut, frameOff, cols
+
+
+class Mmf:
+    """htkamd_mmf holder: LoadHMMSet / SaveHMMSet for text model definitions (htk_amd/host/mmf.c)."""
+
+    def __init__(self, files=(), hmm_list=None, hmm_dir=None, ext=None):
+        L = lib()
+        L.htkamd_mmf_desc.restype = C.POINTER(ModelDesc)
+        for f in ("htkamd_mmf_logical_name", "htkamd_mmf_phys_name", "htkamd_mmf_parm_kind"):
+            getattr(L, f).restype = C.c_char_p
+        L.htkamd_mmf_var_floor.restype = C.POINTER(C.c_float)
+        self.h = C.c_void_p()
+        check(L.htkamd_mmf_create(C.byref(self.h)), "mmf_create")
+        for f in files:
+            check(L.htkamd_mmf_read(self.h, str(f).encode(), None), "mmf_read")
+        check(L.htkamd_mmf_finish(self.h, hmm_list.encode() if hmm_list else None, hmm_dir.encode() if hmm_dir else None,
+                                  ext.encode() if ext else None), "mmf_finish")
+        self.desc = L.htkamd_mmf_desc(self.h).contents
+        self.kind = L.htkamd_mmf_parm_kind(self.h).decode()
+        H = self.desc.numPhys
+        self.phys_names = [L.htkamd_mmf_phys_name(self.h, C.c_int(h)).decode() for h in range(H)]
+        n = L.htkamd_mmf_num_logical(self.h)
+        self.logical = {L.htkamd_mmf_logical_name(self.h, C.c_int(i)).decode(): L.htkamd_mmf_logical_phys(self.h, C.c_int(i)) for i in range(n)}
+        vf = L.htkamd_mmf_var_floor(self.h)
+        self.var_floor = np.ctypeslib.as_array(vf, (self.desc.vecSize,)).copy() if vf else None
+
+    def packed(self) -> dict:
+        """The flat description as the dict of numpy arrays Model() takes."""
+        d = self.desc
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(dt)), (max(n, 1),))[:n].copy()
+        S, Cn, G, nT, H, D = d.numStates, d.numComp, d.numGauss, d.numTrans, d.numPhys, d.vecSize
+        transOff = arr(d.transOff, nT + 1, C.c_int); hmmStateOff = arr(d.hmmStateOff, H + 1, C.c_int)
+        pk = dict(vecSize=D, numStates=S, numComp=Cn, numGauss=G, numTrans=nT, numPhys=H,
+                  stateCompOff=arr(d.stateCompOff, S + 1, C.c_int), compWeight=arr(d.compWeight, Cn, C.c_float),
+                  compGauss=arr(d.compGauss, Cn, C.c_int), mean=arr(d.mean, G * D, C.c_float).reshape(G, D),
+                  var=arr(d.var, G * D, C.c_float).reshape(G, D),
+                  gconst=arr(d.gconst, G, C.c_float) if d.gconst else None,
+                  transN=arr(d.transN, nT, C.c_int), transOff=transOff, transP=arr(d.transP, int(transOff[-1]), C.c_float),
+                  hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int))
+        return pk
+
+    def write(self, params: dict, one_file=None, out_dir=None):
+        g = params.get("gconst")
+        check(lib().htkamd_mmf_write(self.h, _p(np.ascontiguousarray(params["mean"], np.float32)), _p(np.ascontiguousarray(params["var"], np.float32)),
+                                     _p(np.ascontiguousarray(g, np.float32)) if g is not None else None,
+                                     _p(np.ascontiguousarray(params["compWeight"], np.float32)), _p(np.ascontiguousarray(params["transP"], np.float32)),
+                                     one_file.encode() if one_file else None, out_dir.encode() if out_dir else None), "mmf_write")
+
+    def close(self):
+        if self.h:
+            lib().htkamd_mmf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _labels_to_list(h):
+    L = lib()
+    L.htkamd_labels_name.restype = C.c_char_p
+    L.htkamd_labels_start.restype = C.c_longlong; L.htkamd_labels_end.restype = C.c_longlong; L.htkamd_labels_score.restype = C.c_float
+    n = L.htkamd_labels_count(h)
+    return [(L.htkamd_labels_name(h, C.c_int(i)).decode(), L.htkamd_labels_start(h, C.c_int(i)), L.htkamd_labels_end(h, C.c_int(i)),
+             L.htkamd_labels_score(h, C.c_int(i))) for i in range(n)]
+
+
+def labels_read(path: str):
+    """HTK label file -> [(name, start, end, score)] (htk_amd/host/labio.c)."""
+    h = C.c_void_p()
+    check(lib().htkamd_labels_read(path.encode(), C.byref(h)), "labels_read")
+    out = _labels_to_list(h)
+    lib().htkamd_labels_free(h)
+    return out
+
+
+class Mlf:
+    def __init__(self, path: str):
+        self.h = C.c_void_p()
+        check(lib().htkamd_mlf_read(path.encode(), C.byref(self.h)), "mlf_read")
+        lib().htkamd_mlf_find.restype = C.c_void_p
+
+    def find(self, lab_file: str):
+        p = lib().htkamd_mlf_find(self.h, lab_file.encode())
+        return None if not p else _labels_to_list(C.c_void_p(p))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().htkamd_mlf_free(self.h); self.h = C.c_void_p()
+        except Exception:
+            pass

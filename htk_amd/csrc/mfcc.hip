@@ -343,3 +343,46 @@ extern "C" int htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int 
    HIPCHECK(hipStreamSynchronize(s));           // frameSamp / frameUtt are host temporaries
    return HTKAMD_OK;
 }
+
+// ------------------------------------------------------------------------------------ qualifiers on a parameterised table
+__global__ void k_parm_widen(const float *in, float *out, size_t nFrames, int nStat, int nCols)
+{
+   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= nFrames * (size_t)nStat) return;
+   const size_t f = g / nStat;
+   const int k = (int)(g % nStat);
+   out[f * nCols + k] = in[g];
+}
+
+extern "C" int htkamd_parm_add_qualifiers(const float *dStatic, const int *frameOff, int nUtt, int nStat, int hasD, int hasA,
+                                          int delWin, int accWin, float *dOut, void *stream)
+{
+   if (!frameOff || nUtt < 0 || nStat <= 0 || (hasA && !hasD) || delWin < 1 || accWin < 1) {
+      htkamd_set_error("parm_add_qualifiers: bad argument"); return HTKAMD_EINVAL;
+   }
+   const int F = nUtt ? frameOff[nUtt] : 0;
+   if (F == 0) return HTKAMD_OK;
+   if (!dStatic || !dOut) { htkamd_set_error("parm_add_qualifiers: NULL table"); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   const int nCols = nStat * (1 + (hasD ? 1 : 0) + (hasA ? 1 : 0));
+   std::vector<int> frameUtt((size_t)F);
+   for (int u = 0; u < nUtt; u++) {
+      if (frameOff[u + 1] < frameOff[u]) { htkamd_set_error("parm_add_qualifiers: frameOff not monotone"); return HTKAMD_EINVAL; }
+      for (int f = frameOff[u]; f < frameOff[u + 1]; f++) frameUtt[f] = u;
+   }
+   int *dUtt = nullptr, *dOff = nullptr;
+   HIPCHECK(hipMalloc((void **)&dUtt, sizeof(int) * (size_t)F));
+   HIPCHECK(hipMalloc((void **)&dOff, sizeof(int) * ((size_t)nUtt + 1)));
+   HIPCHECK(hipMemcpyAsync(dUtt, frameUtt.data(), sizeof(int) * (size_t)F, hipMemcpyHostToDevice, s));
+   HIPCHECK(hipMemcpyAsync(dOff, frameOff, sizeof(int) * ((size_t)nUtt + 1), hipMemcpyHostToDevice, s));
+   const size_t n = (size_t)F * nStat;
+   const unsigned blocks = (unsigned)((n + 255) / 256);
+   hipLaunchKernelGGL(k_parm_widen, dim3(blocks), dim3(256), 0, s, dStatic, dOut, (size_t)F, nStat, nCols);
+   if (hasD) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dOut, dUtt, dOff, F, nCols, 0, nStat, nStat, delWin);
+   if (hasA) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dOut, dUtt, dOff, F, nCols, nStat, 2 * nStat, nStat, accWin);
+   hipError_t e = hipGetLastError();
+   hipError_t e2 = hipStreamSynchronize(s);
+   (void)hipFree(dUtt); (void)hipFree(dOff);
+   HIPCHECK(e); HIPCHECK(e2);
+   return HTKAMD_OK;
+}

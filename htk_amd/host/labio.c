@@ -1,0 +1,153 @@
+/* labio.c -- HTK label files and master label files (MLF), the transcription inputs of HERest -L/-I and HVite -a.
+ *
+ * Replaces LoadHTKLabels (HLabel.c:748-840: "[start [end]] name [score] {aux}" per line, times in 100 ns units,
+ * a line of "///" separates alternatives -- only the first is kept, as HERest/HVite -a use it) and the immediate-definition
+ * part of LoadMasterFile / the MLF search (HLabel.c:1410-1560: "#!MLF!#", then per entry a quoted pattern line and label
+ * lines up to a single "."; patterns match with '*' and '?' like MaskMatch).  Sub-directory redirection ("->" / "=>")
+ * is not supported.
+ */
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../csrc/internal.h"
+
+struct htkamd_labels {
+   int n;
+   char **name;
+   long long *start, *end;       /* -1 when absent */
+   float *score;                 /* 0 when absent */
+};
+
+struct htkamd_mlf {
+   int n;
+   char **pattern;
+   struct htkamd_labels **lab;
+};
+
+static int is_number(const char *t)
+{
+   char *e;
+   if (!*t) return 0;
+   strtod(t, &e);
+   return *e == 0;
+}
+
+/* one label line -> appended to L; returns 0, or 1 for the alternative separator */
+static int add_line(struct htkamd_labels *L, int *cap, char *line)
+{
+   char *tok[8]; int nt = 0;
+   for (char *p = strtok(line, " \t\r\n"); p && nt < 8; p = strtok(NULL, " \t\r\n")) tok[nt++] = p;
+   if (nt == 0) return 0;
+   if (!strcmp(tok[0], "///")) return 1;
+   long long st = -1, en = -1; float sc = 0.0f; int k = 0;
+   if (nt >= 2 && is_number(tok[0]) && (isdigit((unsigned char)tok[0][0]) || tok[0][0] == '-')) {
+      st = atoll(tok[k++]);
+      if (nt >= 3 && is_number(tok[1])) en = atoll(tok[k++]);
+   }
+   char *name = tok[k++];
+   size_t L0 = strlen(name);
+   if (L0 >= 2 && (name[0] == '"' || name[0] == '\'') && name[L0 - 1] == name[0]) { name[L0 - 1] = 0; name++; }
+   if (k < nt && is_number(tok[k])) sc = strtof(tok[k], NULL);
+   if (L->n + 1 > *cap) {
+      *cap = *cap * 2 + 32;
+      L->name = (char **)realloc(L->name, sizeof(char *) * (size_t)*cap);
+      L->start = (long long *)realloc(L->start, sizeof(long long) * (size_t)*cap);
+      L->end = (long long *)realloc(L->end, sizeof(long long) * (size_t)*cap);
+      L->score = (float *)realloc(L->score, sizeof(float) * (size_t)*cap);
+   }
+   L->name[L->n] = strdup(name); L->start[L->n] = st; L->end[L->n] = en; L->score[L->n] = sc; L->n++;
+   return 0;
+}
+
+void htkamd_labels_free(struct htkamd_labels *L)
+{
+   if (!L) return;
+   for (int i = 0; i < L->n; i++) free(L->name[i]);
+   free(L->name); free(L->start); free(L->end); free(L->score); free(L);
+}
+
+int htkamd_labels_read(const char *path, struct htkamd_labels **out)
+{
+   if (!path || !out) { htkamd_set_error("labels_read: NULL argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "r");
+   if (!f) { htkamd_set_error("labels_read: cannot open %s", path); return HTKAMD_EIO; }
+   struct htkamd_labels *L = (struct htkamd_labels *)calloc(1, sizeof(*L));
+   int cap = 0, alt = 0;
+   char line[2048];
+   while (fgets(line, sizeof(line), f)) {
+      if (alt) continue;
+      if (add_line(L, &cap, line)) alt = 1;
+   }
+   fclose(f);
+   *out = L;
+   return HTKAMD_OK;
+}
+
+int htkamd_labels_count(const struct htkamd_labels *L) { return L ? L->n : 0; }
+const char *htkamd_labels_name(const struct htkamd_labels *L, int i) { return (L && i >= 0 && i < L->n) ? L->name[i] : NULL; }
+long long htkamd_labels_start(const struct htkamd_labels *L, int i) { return (L && i >= 0 && i < L->n) ? L->start[i] : -1; }
+long long htkamd_labels_end(const struct htkamd_labels *L, int i) { return (L && i >= 0 && i < L->n) ? L->end[i] : -1; }
+float htkamd_labels_score(const struct htkamd_labels *L, int i) { return (L && i >= 0 && i < L->n) ? L->score[i] : 0.0f; }
+
+/* MaskMatch-style wildcard match ('*' any run, '?' one character) */
+static int wild(const char *p, const char *s)
+{
+   if (*p == 0) return *s == 0;
+   if (*p == '*') { for (;; s++) { if (wild(p + 1, s)) return 1; if (*s == 0) return 0; } }
+   if (*s == 0) return 0;
+   if (*p == '?' || *p == *s) return wild(p + 1, s + 1);
+   return 0;
+}
+
+void htkamd_mlf_free(struct htkamd_mlf *m)
+{
+   if (!m) return;
+   for (int i = 0; i < m->n; i++) { free(m->pattern[i]); htkamd_labels_free(m->lab[i]); }
+   free(m->pattern); free(m->lab); free(m);
+}
+
+int htkamd_mlf_read(const char *path, struct htkamd_mlf **out)
+{
+   if (!path || !out) { htkamd_set_error("mlf_read: NULL argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "r");
+   if (!f) { htkamd_set_error("mlf_read: cannot open %s", path); return HTKAMD_EIO; }
+   char line[2048];
+   if (!fgets(line, sizeof(line), f) || strncmp(line, "#!MLF!#", 7)) { fclose(f); htkamd_set_error("mlf_read: %s has no #!MLF!# header", path); return HTKAMD_EMODEL; }
+   struct htkamd_mlf *m = (struct htkamd_mlf *)calloc(1, sizeof(*m));
+   int capM = 0;
+   while (fgets(line, sizeof(line), f)) {
+      char *p = line;
+      while (isspace((unsigned char)*p)) p++;
+      if (!*p) continue;
+      char *e = p + strlen(p);
+      while (e > p && isspace((unsigned char)e[-1])) *--e = 0;
+      if (strstr(p, "->") || strstr(p, "=>")) { fclose(f); htkamd_mlf_free(m); htkamd_set_error("mlf_read: %s: sub-directory entries are not supported", path); return HTKAMD_EMODEL; }
+      if ((*p == '"' || *p == '\'') && e > p + 1 && e[-1] == *p) { e[-1] = 0; p++; }
+      if (m->n + 1 > capM) { capM = capM * 2 + 32; m->pattern = (char **)realloc(m->pattern, sizeof(char *) * (size_t)capM); m->lab = (struct htkamd_labels **)realloc(m->lab, sizeof(void *) * (size_t)capM); }
+      char *pattern = strdup(p);                     /* `line` is reused for the label lines below */
+      struct htkamd_labels *L = (struct htkamd_labels *)calloc(1, sizeof(*L));
+      int cap = 0, alt = 0, closed = 0;
+      while (fgets(line, sizeof(line), f)) {
+         char *q = line;
+         while (isspace((unsigned char)*q)) q++;
+         if (q[0] == '.' && (q[1] == 0 || isspace((unsigned char)q[1]))) { closed = 1; break; }
+         if (alt) continue;
+         if (add_line(L, &cap, line)) alt = 1;
+      }
+      (void)closed;                                  /* a last entry may end at EOF without '.' */
+      m->pattern[m->n] = pattern; m->lab[m->n] = L; m->n++;
+   }
+   fclose(f);
+   *out = m;
+   return HTKAMD_OK;
+}
+
+/* Labels of `labFile` (e.g. "lab/u00001.lab"; callers derive it from the data file name as HERest does: base name + ".lab"):
+   first entry whose pattern matches; NULL if none. */
+const struct htkamd_labels *htkamd_mlf_find(const struct htkamd_mlf *m, const char *labFile)
+{
+   if (!m || !labFile) return NULL;
+   for (int i = 0; i < m->n; i++) if (wild(m->pattern[i], labFile)) return m->lab[i];
+   return NULL;
+}

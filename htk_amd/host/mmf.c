@@ -1,0 +1,620 @@
+/* mmf.c -- HTK model definition files (text MMF / one-HMM-per-file) <-> the flat htkamd_model_desc.
+ *
+ * Replaces, for the model kinds the hot path supports (one stream, diagonal covariance, continuous densities,
+ * PLAINHS/SHAREDHS): LoadHMMSet (HModel.c:3809) = MakeHMMSet (:3580, the HMM list "logical [physical]") +
+ * LoadAllMacros / LoadMacroFiles (:3721) + the -d directory search; the grammar of GetOptions (:1649),
+ * GetMean/GetVariance/GetTransMat (:1737-1990: transitions become log values, <= MINLARG -> LZERO), GetMixPDF (:2140),
+ * GetStateInfo (:2350: a missing <MIXTURE> index is a pruned component of weight 0), GetHMMDef (:2490); and the
+ * writer SaveHMMSet (:4979) = SaveMacros (:4342: ~o options, then ~t, ~s, ~h macros in hash-table order) with
+ * PutStateInfo (:3053), PutMixPDF (:3029), PutTransMat (:2877: rows renormalised in float) and WriteFloat's " %e".
+ * Shared mean/variance vectors (~u ~v inside a mixture), ~m, stream weights, durations, transforms and binary MMFs
+ * are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
+ */
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../csrc/internal.h"
+
+typedef struct { char *name; int nMix; int comp0; int inlineOwner; } mmf_state;   /* name NULL = un-named (inline) */
+typedef struct { char *name; int N; int off; } mmf_trans;
+typedef struct { char *name; int N; int *state; int trans; int src; } mmf_hmm;     /* src: index of the file it came from */
+
+struct htkamd_mmf {
+   int vecSize, streamWidth, hasOpts;
+   char kind[64], cov[16], dur[16], setId[128];
+   /* pools */
+   mmf_state *st; int nSt, capSt;
+   float *wt; int *cg; int nComp, capComp;
+   float *mean, *var, *gconst; unsigned char *hasG; int nG, capG;
+   mmf_trans *tr; int nTr, capTr; float *tp; int nTp, capTp;       /* tp: LOG transition values */
+   mmf_hmm *hm; int nHm, capHm;
+   float *varFloor;                                                 /* ~v "varFloor1" or NULL */
+   /* logical list */
+   char **logName; int *logPhys; int nLog;
+   /* desc arrays */
+   htkamd_model_desc d; int *stateCompOff, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
+   int finished, nFiles;
+};
+
+/* ------------------------------------------------------------------------------------------ tokenizer */
+typedef struct { FILE *f; const char *path; int line; int pushed; char tok[256]; int kind; int binary; } rd;
+enum { T_EOF, T_MACRO, T_KEY, T_WORD };
+
+static int rd_getc(rd *r) { int c = fgetc(r->f); if (c == '\n') r->line++; return c; }
+static void rd_ungetc(rd *r, int c) { if (c == EOF) return; if (c == '\n') r->line--; ungetc(c, r->f); }
+
+static int rd_next(rd *r)
+{
+   int c, n = 0;
+   if (r->pushed) { r->pushed = 0; return r->kind; }
+   do c = rd_getc(r); while (c != EOF && isspace(c));
+   if (c == EOF) return r->kind = T_EOF;
+   if (c == '~') {
+      c = rd_getc(r);
+      r->tok[0] = (char)tolower(c); r->tok[1] = 0;
+      return r->kind = T_MACRO;
+   }
+   if (c == '<') {
+      while ((c = rd_getc(r)) != EOF && c != '>' && n < 250) r->tok[n++] = (char)toupper(c);
+      r->tok[n] = 0;
+      return r->kind = T_KEY;
+   }
+   if (c == '"' || c == '\'') {
+      const int q = c;
+      while ((c = rd_getc(r)) != EOF && c != q && n < 250) {
+         if (c == '\\') c = rd_getc(r);
+         r->tok[n++] = (char)c;
+      }
+      r->tok[n] = 0;
+      return r->kind = T_WORD;
+   }
+   if (c == ':') { r->binary = 1; r->tok[0] = 0; return r->kind = T_EOF; }
+   do {
+      if (c == '\\') c = rd_getc(r);
+      r->tok[n++] = (char)c;
+      c = rd_getc(r);
+   } while (c != EOF && !isspace(c) && c != '<' && c != '~' && n < 250);
+   rd_ungetc(r, c);
+   r->tok[n] = 0;
+   return r->kind = T_WORD;
+}
+static void rd_push(rd *r) { r->pushed = 1; }
+
+static int fail(rd *r, const char *what)
+{
+   htkamd_set_error("%s:%d: %s (at '%s')", r->path, r->line, what, r->tok);
+   return HTKAMD_EMODEL;
+}
+static int rd_int(rd *r, int *v)
+{
+   char *e;
+   if (rd_next(r) != T_WORD) return fail(r, "integer expected");
+   *v = (int)strtol(r->tok, &e, 10);
+   return *e ? fail(r, "integer expected") : HTKAMD_OK;
+}
+static int rd_float(rd *r, float *v)
+{
+   char *e;
+   if (rd_next(r) != T_WORD) return fail(r, "number expected");
+   *v = strtof(r->tok, &e);                         /* fscanf("%e") into a float, HShell.c ReadFloat */
+   return *e ? fail(r, "number expected") : HTKAMD_OK;
+}
+static int rd_name(rd *r, char **out)
+{
+   if (rd_next(r) != T_WORD) return fail(r, "macro name expected");
+   *out = strdup(r->tok);
+   return HTKAMD_OK;
+}
+
+#define GROW(p, n, cap, need, T) do { if ((n) + (need) > (cap)) { (cap) = ((n) + (need)) * 2 + 16; (p) = (T *)realloc((p), sizeof(T) * (size_t)(cap)); } } while (0)
+
+static int is_parm_kind(const char *t)
+{
+   static const char *base[] = {"WAVEFORM", "LPC", "LPREFC", "LPCEPSTRA", "LPDELCEP", "IREFC", "MFCC", "FBANK", "MELSPEC", "USER", "DISCRETE", "PLP", NULL};
+   for (int i = 0; base[i]; i++) {
+      size_t n = strlen(base[i]);
+      if (!strncmp(t, base[i], n) && (t[n] == 0 || t[n] == '_')) return 1;
+   }
+   return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ grammar */
+static int parse_options(struct htkamd_mmf *s, rd *r)
+{
+   int rc;
+   for (;;) {
+      int k = rd_next(r);
+      if (k != T_KEY) { rd_push(r); return HTKAMD_OK; }
+      const char *t = r->tok;
+      if (!strcmp(t, "STREAMINFO")) {
+         int S, w;
+         if ((rc = rd_int(r, &S))) return rc;
+         if (S != 1) return fail(r, "multi-stream models are not supported");
+         if ((rc = rd_int(r, &w))) return rc;
+         if (s->streamWidth && s->streamWidth != w) return fail(r, "inconsistent stream width");
+         s->streamWidth = w;
+      } else if (!strcmp(t, "VECSIZE")) {
+         int v;
+         if ((rc = rd_int(r, &v))) return rc;
+         if (s->vecSize && s->vecSize != v) return fail(r, "inconsistent vector size");
+         s->vecSize = v;
+      } else if (!strcmp(t, "HMMSETID")) {
+         if (rd_next(r) != T_WORD) return fail(r, "set id expected");
+         snprintf(s->setId, sizeof(s->setId), "%.127s", r->tok);
+      } else if (!strcmp(t, "NULLD")) snprintf(s->dur, sizeof(s->dur), "%.15s", t);
+      else if (!strcmp(t, "POISSOND") || !strcmp(t, "GAMMAD") || !strcmp(t, "GEND")) return fail(r, "duration models are not supported");
+      else if (!strcmp(t, "DIAGC")) snprintf(s->cov, sizeof(s->cov), "%.15s", t);
+      else if (!strcmp(t, "FULLC") || !strcmp(t, "XFORMC") || !strcmp(t, "LLTC") || !strcmp(t, "INVDIAGC")) return fail(r, "only DIAGC covariances are supported");
+      else if (is_parm_kind(t)) {
+         if (s->kind[0] && strcmp(s->kind, t)) return fail(r, "inconsistent parameter kind");
+         snprintf(s->kind, sizeof(s->kind), "%.63s", t);
+      } else if (!strcmp(t, "PROJSIZE") || !strcmp(t, "INPUTXFORM") || !strcmp(t, "PARENTXFORM") || !strcmp(t, "MSDINFO") ||
+                 !strcmp(t, "DISCRETE") || !strcmp(t, "TMIX") || !strcmp(t, "DPROB")) {
+         return fail(r, "unsupported global option");
+      } else { rd_push(r); return HTKAMD_OK; }      /* structural keyword: the caller's business */
+      s->hasOpts = 1;
+   }
+}
+
+static int parse_vector(struct htkamd_mmf *s, rd *r, float *dst)
+{
+   int n, rc;
+   if ((rc = rd_int(r, &n))) return rc;
+   if (s->vecSize == 0) s->vecSize = n;
+   if (n != s->vecSize) return fail(r, "vector size differs from <VECSIZE>");
+   for (int i = 0; i < n; i++) if ((rc = rd_float(r, dst + i))) return rc;
+   return HTKAMD_OK;
+}
+
+static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
+{
+   int rc, k = rd_next(r);
+   if (k == T_MACRO) return fail(r, "shared mixture / vector macros (~m ~u ~v) are not supported");
+   if (k == T_KEY && !strcmp(r->tok, "RCLASS")) { int x; if ((rc = rd_int(r, &x))) return rc; k = rd_next(r); }
+   if (k != T_KEY || strcmp(r->tok, "MEAN")) return fail(r, "<MEAN> expected");
+   if (s->vecSize == 0) return fail(r, "<VECSIZE> must precede the first mean");
+   GROW(s->gconst, s->nG, s->capG, 1, float);
+   { const int cap = s->capG;
+     s->mean = (float *)realloc(s->mean, sizeof(float) * (size_t)cap * s->vecSize);
+     s->var = (float *)realloc(s->var, sizeof(float) * (size_t)cap * s->vecSize);
+     s->hasG = (unsigned char *)realloc(s->hasG, (size_t)cap); }
+   const int g = s->nG;
+   if ((rc = parse_vector(s, r, s->mean + (size_t)g * s->vecSize))) return rc;
+   k = rd_next(r);
+   if (k == T_MACRO) return fail(r, "shared variance macros (~v) inside a mixture are not supported");
+   if (k != T_KEY || strcmp(r->tok, "VARIANCE")) return fail(r, "<VARIANCE> expected (DIAGC only)");
+   if ((rc = parse_vector(s, r, s->var + (size_t)g * s->vecSize))) return rc;
+   s->hasG[g] = 0; s->gconst[g] = 0.0f;
+   k = rd_next(r);
+   if (k == T_KEY && !strcmp(r->tok, "GCONST")) { if ((rc = rd_float(r, s->gconst + g))) return rc; s->hasG[g] = 1; }
+   else rd_push(r);
+   s->nG++;
+   *gOut = g;
+   return HTKAMD_OK;
+}
+
+/* state body after "~s name" or "<STATE> i": returns the new state index */
+static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
+{
+   int rc, M = 1, k = rd_next(r);
+   if (k == T_KEY && !strcmp(r->tok, "NUMMIXES")) { if ((rc = rd_int(r, &M))) return rc; k = rd_next(r); }
+   if (k == T_KEY && !strcmp(r->tok, "SWEIGHTS")) return fail(r, "stream weights are not supported");
+   if (k == T_KEY && !strcmp(r->tok, "STREAM")) { int x; if ((rc = rd_int(r, &x))) return rc; if (x != 1) return fail(r, "multi-stream"); k = rd_next(r); }
+   if (M < 1) return fail(r, "bad <NUMMIXES>");
+   GROW(s->st, s->nSt, s->capSt, 1, mmf_state);
+   GROW(s->wt, s->nComp, s->capComp, M, float);
+   s->cg = (int *)realloc(s->cg, sizeof(int) * (size_t)s->capComp);
+   const int c0 = s->nComp;
+   for (int m = 0; m < M; m++) { s->wt[c0 + m] = 0.0f; s->cg[c0 + m] = -1; }
+   if (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
+      while (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
+         int m; float w;
+         if ((rc = rd_int(r, &m)) || (rc = rd_float(r, &w))) return rc;
+         if (m < 1 || m > M) return fail(r, "mixture index out of range");
+         if (s->cg[c0 + m - 1] >= 0) return fail(r, "mixture defined twice");
+         s->wt[c0 + m - 1] = w;
+         if ((rc = parse_mixpdf(s, r, &s->cg[c0 + m - 1]))) return rc;
+         k = rd_next(r);
+      }
+      rd_push(r);
+   } else {
+      if (M != 1) return fail(r, "<MIXTURE> expected");
+      rd_push(r);
+      s->wt[c0] = 1.0f;
+      if ((rc = parse_mixpdf(s, r, &s->cg[c0]))) return rc;
+   }
+   /* pruned components (no <MIXTURE> entry): weight 0 with an empty Gaussian (GetStateInfo gives them EmptyMixPDF) */
+   for (int m = 0; m < M; m++)
+      if (s->cg[c0 + m] < 0) {
+         GROW(s->gconst, s->nG, s->capG, 1, float);
+         { const int cap = s->capG;
+           s->mean = (float *)realloc(s->mean, sizeof(float) * (size_t)cap * s->vecSize);
+           s->var = (float *)realloc(s->var, sizeof(float) * (size_t)cap * s->vecSize);
+           s->hasG = (unsigned char *)realloc(s->hasG, (size_t)cap); }
+         for (int i = 0; i < s->vecSize; i++) { s->mean[(size_t)s->nG * s->vecSize + i] = 0.0f; s->var[(size_t)s->nG * s->vecSize + i] = 1.0f; }
+         s->gconst[s->nG] = 0.0f; s->hasG[s->nG] = 0;
+         s->cg[c0 + m] = s->nG++;
+      }
+   s->nComp += M;
+   mmf_state *st = &s->st[s->nSt];
+   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1;
+   *sOut = s->nSt++;
+   return HTKAMD_OK;
+}
+
+static int find_state(const struct htkamd_mmf *s, const char *name)
+{
+   for (int i = 0; i < s->nSt; i++) if (s->st[i].name && !strcmp(s->st[i].name, name)) return i;
+   return -1;
+}
+static int find_trans(const struct htkamd_mmf *s, const char *name)
+{
+   for (int i = 0; i < s->nTr; i++) if (s->tr[i].name && !strcmp(s->tr[i].name, name)) return i;
+   return -1;
+}
+static int find_hmm(const struct htkamd_mmf *s, const char *name)
+{
+   for (int i = 0; i < s->nHm; i++) if (!strcmp(s->hm[i].name, name)) return i;
+   return -1;
+}
+
+static int parse_transp_body(struct htkamd_mmf *s, rd *r, char *name, int *tOut)
+{
+   int N, rc;
+   if ((rc = rd_int(r, &N))) return rc;
+   if (N < 3) return fail(r, "<TRANSP> needs at least 3 states");
+   GROW(s->tr, s->nTr, s->capTr, 1, mmf_trans);
+   GROW(s->tp, s->nTp, s->capTp, N * N, float);
+   for (int i = 0; i < N * N; i++) {
+      float x;
+      if ((rc = rd_float(r, &x))) return rc;
+      s->tp[s->nTp + i] = (x <= MINLARG) ? (float)LZERO : (float)log((double)x);     /* GetTransMat, HModel.c:1965-1975 */
+   }
+   mmf_trans *t = &s->tr[s->nTr];
+   t->name = name; t->N = N; t->off = s->nTp;
+   s->nTp += N * N;
+   *tOut = s->nTr++;
+   return HTKAMD_OK;
+}
+
+static int parse_hmm(struct htkamd_mmf *s, rd *r, char *name)
+{
+   int rc, N, k;
+   if (find_hmm(s, name) >= 0) { fail(r, "HMM defined twice"); free(name); return HTKAMD_EMODEL; }
+   if (rd_next(r) != T_KEY || strcmp(r->tok, "BEGINHMM")) { free(name); return fail(r, "<BEGINHMM> expected"); }
+   if ((rc = parse_options(s, r))) { free(name); return rc; }
+   if (rd_next(r) != T_KEY || strcmp(r->tok, "NUMSTATES")) { free(name); return fail(r, "<NUMSTATES> expected"); }
+   if ((rc = rd_int(r, &N))) { free(name); return rc; }
+   if (N < 3) { free(name); return fail(r, "<NUMSTATES> < 3"); }
+   int *states = (int *)malloc(sizeof(int) * (size_t)N);
+   for (int i = 0; i < N; i++) states[i] = -1;
+   int trans = -1;
+   for (;;) {
+      k = rd_next(r);
+      if (k == T_KEY && !strcmp(r->tok, "STATE")) {
+         int i;
+         if ((rc = rd_int(r, &i))) goto bad;
+         if (i < 2 || i > N - 1) { rc = fail(r, "state index out of range"); goto bad; }
+         k = rd_next(r);
+         if (k == T_MACRO) {
+            if (r->tok[0] != 's') { rc = fail(r, "~s expected"); goto bad; }
+            char *nm;
+            if ((rc = rd_name(r, &nm))) goto bad;
+            states[i - 1] = find_state(s, nm);
+            if (states[i - 1] < 0) { rc = fail(r, "undefined ~s macro"); free(nm); goto bad; }
+            free(nm);
+         } else {
+            rd_push(r);
+            if ((rc = parse_state_body(s, r, NULL, &states[i - 1]))) goto bad;
+            s->st[states[i - 1]].inlineOwner = s->nHm;
+         }
+      } else if (k == T_MACRO && r->tok[0] == 't') {
+         char *nm;
+         if ((rc = rd_name(r, &nm))) goto bad;
+         trans = find_trans(s, nm);
+         if (trans < 0) { rc = fail(r, "undefined ~t macro"); free(nm); goto bad; }
+         free(nm);
+      } else if (k == T_KEY && !strcmp(r->tok, "TRANSP")) {
+         if ((rc = parse_transp_body(s, r, NULL, &trans))) goto bad;
+      } else if (k == T_KEY && !strcmp(r->tok, "ENDHMM")) break;
+      else { rc = fail(r, "unexpected token in HMM definition"); goto bad; }
+   }
+   if (trans < 0) { rc = fail(r, "HMM without a transition matrix"); goto bad; }
+   if (s->tr[trans].N != N) { rc = fail(r, "<TRANSP> size differs from <NUMSTATES>"); goto bad; }
+   for (int i = 1; i < N - 1; i++) if (states[i] < 0) { rc = fail(r, "missing <STATE>"); goto bad; }
+   GROW(s->hm, s->nHm, s->capHm, 1, mmf_hmm);
+   mmf_hmm *h = &s->hm[s->nHm++];
+   h->name = name; h->N = N; h->state = states; h->trans = trans; h->src = s->nFiles;
+   return HTKAMD_OK;
+bad:
+   free(states); free(name);
+   return rc;
+}
+
+static char *base_name(const char *path)
+{
+   const char *b = strrchr(path, '/');
+   char *n = strdup(b ? b + 1 : path);
+   char *dot = strrchr(n, '.');
+   if (dot && dot != n) *dot = 0;
+   return n;
+}
+
+int htkamd_mmf_create(struct htkamd_mmf **out)
+{
+   if (!out) { htkamd_set_error("mmf_create: NULL"); return HTKAMD_EINVAL; }
+   *out = (struct htkamd_mmf *)calloc(1, sizeof(struct htkamd_mmf));
+   return HTKAMD_OK;
+}
+
+/* `defName`: name given to a definition that starts at <BEGINHMM> without a ~h header (a -d directory file); NULL = file base name */
+int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
+{
+   if (!s || !path) { htkamd_set_error("mmf_read: NULL argument"); return HTKAMD_EINVAL; }
+   if (s->finished) { htkamd_set_error("mmf_read: set already finished"); return HTKAMD_EINVAL; }
+   rd r; memset(&r, 0, sizeof(r));
+   r.f = fopen(path, "rb"); r.path = path; r.line = 1;
+   if (!r.f) { htkamd_set_error("mmf_read: cannot open %s", path); return HTKAMD_EIO; }
+   int rc = HTKAMD_OK;
+   for (;;) {
+      int k = rd_next(&r);
+      if (k == T_EOF) {
+         if (r.binary) { htkamd_set_error("%s: binary MMFs are not supported (save as text: HHEd without -B)", path); rc = HTKAMD_EMODEL; }
+         break;
+      }
+      if (k == T_KEY && !strcmp(r.tok, "BEGINHMM")) {
+         rd_push(&r);
+         if ((rc = parse_hmm(s, &r, defName ? strdup(defName) : base_name(path)))) break;
+         continue;
+      }
+      if (k != T_MACRO) { rc = fail(&r, "macro (~x) expected"); break; }
+      const char type = r.tok[0];
+      if (type == 'o') { if ((rc = parse_options(s, &r))) break; continue; }
+      char *name;
+      if ((rc = rd_name(&r, &name))) break;
+      if (type == 'h') { if ((rc = parse_hmm(s, &r, name))) break; }
+      else if (type == 's') {
+         int si;
+         if (find_state(s, name) >= 0) { rc = fail(&r, "~s macro defined twice"); free(name); break; }
+         if ((rc = parse_state_body(s, &r, name, &si))) break;
+      } else if (type == 't') {
+         int ti;
+         if (find_trans(s, name) >= 0) { rc = fail(&r, "~t macro defined twice"); free(name); break; }
+         if (rd_next(&r) != T_KEY || strcmp(r.tok, "TRANSP")) { rc = fail(&r, "<TRANSP> expected"); free(name); break; }
+         if ((rc = parse_transp_body(s, &r, name, &ti))) break;
+      } else if (type == 'v') {
+         if (rd_next(&r) != T_KEY || strcmp(r.tok, "VARIANCE")) { rc = fail(&r, "<VARIANCE> expected"); free(name); break; }
+         if (s->vecSize == 0) { rc = fail(&r, "<VECSIZE> must precede ~v"); free(name); break; }
+         float *v = (float *)malloc(sizeof(float) * (size_t)s->vecSize);
+         if ((rc = parse_vector(s, &r, v))) { free(v); free(name); break; }
+         if (!strncmp(name, "varFloor", 8)) { free(s->varFloor); s->varFloor = v; } else free(v);
+         free(name);
+      } else { rc = fail(&r, "unsupported macro type"); free(name); break; }
+   }
+   fclose(r.f);
+   s->nFiles++;
+   return rc;
+}
+
+/* HMM list (MakeHMMSet): "logical [physical]" per line; physical models not yet defined are read from dir/name[.ext] */
+int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir, const char *ext)
+{
+   if (!s) { htkamd_set_error("mmf_finish: NULL"); return HTKAMD_EINVAL; }
+   if (s->finished) return HTKAMD_OK;
+   if (hmmList) {
+      FILE *f = fopen(hmmList, "r");
+      if (!f) { htkamd_set_error("mmf_finish: cannot open HMM list %s", hmmList); return HTKAMD_EIO; }
+      char line[1024], a[512], b[512];
+      int cap = 0;
+      while (fgets(line, sizeof(line), f)) {
+         int n = sscanf(line, "%511s %511s", a, b);
+         if (n < 1) continue;
+         char *lo = a, *ph = (n == 2) ? b : a;
+         for (int q = 0; q < 2; q++) {                 /* strip quotes */
+            char *t = q ? ph : lo; size_t L = strlen(t);
+            if (L >= 2 && (t[0] == '"' || t[0] == '\'') && t[L - 1] == t[0]) { memmove(t, t + 1, L - 2); t[L - 2] = 0; }
+         }
+         int h = find_hmm(s, ph);
+         if (h < 0) {
+            char path[1400];
+            if (ext && *ext) snprintf(path, sizeof(path), "%s/%s.%s", dir ? dir : ".", ph, ext);
+            else snprintf(path, sizeof(path), "%s/%s", dir ? dir : ".", ph);
+            int rc = htkamd_mmf_read(s, path, ph);
+            if (rc) { fclose(f); return rc; }
+            h = find_hmm(s, ph);
+            if (h < 0) { fclose(f); htkamd_set_error("mmf_finish: %s does not define %s", path, ph); return HTKAMD_EMODEL; }
+         }
+         if (s->nLog + 1 > cap) { cap = cap * 2 + 64; s->logName = (char **)realloc(s->logName, sizeof(char *) * (size_t)cap); s->logPhys = (int *)realloc(s->logPhys, sizeof(int) * (size_t)cap); }
+         s->logName[s->nLog] = strdup(lo); s->logPhys[s->nLog] = h; s->nLog++;
+      }
+      fclose(f);
+   } else {
+      s->logName = (char **)malloc(sizeof(char *) * (size_t)(s->nHm ? s->nHm : 1));
+      s->logPhys = (int *)malloc(sizeof(int) * (size_t)(s->nHm ? s->nHm : 1));
+      for (int h = 0; h < s->nHm; h++) { s->logName[h] = strdup(s->hm[h].name); s->logPhys[h] = h; }
+      s->nLog = s->nHm;
+   }
+   if (s->nHm == 0 || s->vecSize == 0) { htkamd_set_error("mmf_finish: no model defined"); return HTKAMD_EMODEL; }
+   if (s->cov[0] == 0) snprintf(s->cov, sizeof(s->cov), "DIAGC");
+   if (s->dur[0] == 0) snprintf(s->dur, sizeof(s->dur), "NULLD");
+   if (s->streamWidth == 0) s->streamWidth = s->vecSize;
+   /* flat description */
+   s->stateCompOff = (int *)malloc(sizeof(int) * ((size_t)s->nSt + 1));
+   for (int i = 0; i < s->nSt; i++) s->stateCompOff[i] = s->st[i].comp0;
+   s->stateCompOff[s->nSt] = s->nComp;
+   s->transN = (int *)malloc(sizeof(int) * (size_t)s->nTr);
+   s->transOff = (int *)malloc(sizeof(int) * ((size_t)s->nTr + 1));
+   for (int t = 0; t < s->nTr; t++) { s->transN[t] = s->tr[t].N; s->transOff[t] = s->tr[t].off; }
+   s->transOff[s->nTr] = s->nTp;
+   s->hmmTrans = (int *)malloc(sizeof(int) * (size_t)s->nHm);
+   s->hmmStateOff = (int *)malloc(sizeof(int) * ((size_t)s->nHm + 1));
+   int tot = 0;
+   for (int h = 0; h < s->nHm; h++) tot += s->hm[h].N - 2;
+   s->hmmState = (int *)malloc(sizeof(int) * (size_t)(tot ? tot : 1));
+   tot = 0;
+   for (int h = 0; h < s->nHm; h++) {
+      s->hmmTrans[h] = s->hm[h].trans; s->hmmStateOff[h] = tot;
+      for (int i = 1; i < s->hm[h].N - 1; i++) s->hmmState[tot++] = s->hm[h].state[i];
+   }
+   s->hmmStateOff[s->nHm] = tot;
+   int anyG = 0, allG = 1;
+   for (int g = 0; g < s->nG; g++) { if (s->hasG[g]) anyG = 1; else allG = 0; }
+   if (anyG && !allG)                                 /* CheckMix: missing gConst computed at load (HModel.c:206-208) */
+      for (int g = 0; g < s->nG; g++) if (!s->hasG[g]) htkamd_host_fix_diag_gconst(s->vecSize, s->var + (size_t)g * s->vecSize, s->gconst + g);
+   htkamd_model_desc *d = &s->d;
+   d->vecSize = s->vecSize; d->numStates = s->nSt; d->numComp = s->nComp; d->numGauss = s->nG; d->numTrans = s->nTr; d->numPhys = s->nHm;
+   d->stateCompOff = s->stateCompOff; d->compWeight = s->wt; d->compGauss = s->cg; d->mean = s->mean; d->var = s->var;
+   d->gconst = anyG ? s->gconst : NULL;
+   d->transN = s->transN; d->transOff = s->transOff; d->transP = s->tp;
+   d->hmmTrans = s->hmmTrans; d->hmmStateOff = s->hmmStateOff; d->hmmState = s->hmmState;
+   s->finished = 1;
+   return HTKAMD_OK;
+}
+
+const htkamd_model_desc *htkamd_mmf_desc(const struct htkamd_mmf *s) { return (s && s->finished) ? &s->d : NULL; }
+int htkamd_mmf_num_logical(const struct htkamd_mmf *s) { return s ? s->nLog : 0; }
+const char *htkamd_mmf_logical_name(const struct htkamd_mmf *s, int i) { return (s && i >= 0 && i < s->nLog) ? s->logName[i] : NULL; }
+int htkamd_mmf_logical_phys(const struct htkamd_mmf *s, int i) { return (s && i >= 0 && i < s->nLog) ? s->logPhys[i] : -1; }
+const char *htkamd_mmf_phys_name(const struct htkamd_mmf *s, int h) { return (s && h >= 0 && h < s->nHm) ? s->hm[h].name : NULL; }
+const char *htkamd_mmf_parm_kind(const struct htkamd_mmf *s) { return s ? s->kind : NULL; }
+const float *htkamd_mmf_var_floor(const struct htkamd_mmf *s) { return s ? s->varFloor : NULL; }
+int htkamd_mmf_find_logical(const struct htkamd_mmf *s, const char *name)
+{
+   if (!s || !name) return -1;
+   for (int i = 0; i < s->nLog; i++) if (!strcmp(s->logName[i], name)) return s->logPhys[i];
+   return -1;
+}
+
+void htkamd_mmf_destroy(struct htkamd_mmf *s)
+{
+   if (!s) return;
+   for (int i = 0; i < s->nSt; i++) free(s->st[i].name);
+   for (int i = 0; i < s->nTr; i++) free(s->tr[i].name);
+   for (int i = 0; i < s->nHm; i++) { free(s->hm[i].name); free(s->hm[i].state); }
+   for (int i = 0; i < s->nLog; i++) free(s->logName[i]);
+   free(s->st); free(s->wt); free(s->cg); free(s->mean); free(s->var); free(s->gconst); free(s->hasG); free(s->tr); free(s->tp); free(s->hm);
+   free(s->varFloor); free(s->logName); free(s->logPhys);
+   free(s->stateCompOff); free(s->transN); free(s->transOff); free(s->hmmTrans); free(s->hmmStateOff); free(s->hmmState);
+   free(s);
+}
+
+/* ------------------------------------------------------------------------------------------ writer */
+static void put_name(FILE *f, char type, const char *name)
+{
+   /* ReWriteString(.., DBL_QUOTE): quotes always, backslash before quote/backslash */
+   fprintf(f, "~%c \"", type);
+   for (const char *p = name; *p; p++) { if (*p == '"' || *p == '\\') fputc('\\', f); fputc(*p, f); }
+   fprintf(f, "\"\n");
+}
+static void put_options(const struct htkamd_mmf *s, FILE *f)
+{
+   fprintf(f, "~o\n");
+   if (s->setId[0]) fprintf(f, "<HMMSETID> %s\n", s->setId);
+   fprintf(f, "<STREAMINFO> 1 %d\n<VECSIZE> %d<%s><%s><%s>\n", s->streamWidth, s->vecSize, s->dur, s->kind[0] ? s->kind : "USER", s->cov);
+}
+static void put_vec(FILE *f, const char *key, const float *v, int n)
+{
+   fprintf(f, "<%s> %d\n", key, n);
+   for (int i = 0; i < n; i++) fprintf(f, " %e", v[i]);
+   fprintf(f, "\n");
+}
+static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *mean, const float *var, const float *gconst, const float *wt)
+{
+   const mmf_state *st = &s->st[si];
+   const int D = s->vecSize;
+   if (st->nMix > 1) fprintf(f, "<NUMMIXES> %d\n", st->nMix);
+   for (int m = 0; m < st->nMix; m++) {
+      const int c = st->comp0 + m, g = s->cg[c];
+      if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */
+      if (st->nMix > 1) fprintf(f, "<MIXTURE> %d %e\n", m + 1, wt[c]);
+      put_vec(f, "MEAN", mean + (size_t)g * D, D);
+      put_vec(f, "VARIANCE", var + (size_t)g * D, D);
+      if (gconst) fprintf(f, "<GCONST> %e\n", gconst[g]);
+   }
+}
+static void put_trans(FILE *f, const float *logp, int N)
+{
+   fprintf(f, "<TRANSP> %d\n", N);
+   for (int i = 0; i < N; i++) {
+      float row[64], rSum = 0.0f;
+      for (int j = 0; j < N; j++) {
+         const float x = logp[i * N + j];
+         row[j] = (x < (float)LSMALL) ? 0.0f : (float)exp((double)x);       /* L2F */
+         rSum += row[j];
+      }
+      for (int j = 0; j < N; j++) fprintf(f, " %e", (i == N - 1) ? 0.0f : row[j] / rSum);
+      fprintf(f, "\n");
+   }
+}
+static void put_hmm(const struct htkamd_mmf *s, FILE *f, int h, int withHdr, const float *mean, const float *var, const float *gconst,
+                    const float *wt, const float *tp)
+{
+   const mmf_hmm *hm = &s->hm[h];
+   if (withHdr) put_name(f, 'h', hm->name);
+   fprintf(f, "<BEGINHMM>\n<NUMSTATES> %d\n", hm->N);
+   for (int i = 1; i < hm->N - 1; i++) {
+      fprintf(f, "<STATE> %d\n", i + 1);
+      const int si = hm->state[i];
+      if (s->st[si].name) put_name(f, 's', s->st[si].name);
+      else put_state(s, f, si, mean, var, gconst, wt);
+   }
+   if (s->tr[hm->trans].name) put_name(f, 't', s->tr[hm->trans].name);
+   else put_trans(f, tp + s->tr[hm->trans].off, hm->N);
+   fprintf(f, "<ENDHMM>\n");
+}
+
+/* hash-table order of SaveMacros (HModel.c Hash :4331 + NewMacro head insertion): same rule as the .acc scan */
+static void macro_order(char **names, int n, int *order)
+{
+   const char **nm = (const char **)malloc(sizeof(char *) * (size_t)(n ? n : 1));
+   for (int i = 0; i < n; i++) nm[i] = names[i];
+   htkamd_hmm_scan_order(nm, n, order);
+   free(nm);
+}
+
+/* Text output with the current parameter values (layout of the desc arrays; transP in log form).
+ * oneFile != NULL: everything into that file (SaveInOneFile).  Otherwise dir: models that came from a master file go
+ * to dir/<base name of nothing>... -- kept simple: one file per physical HMM named dir/<name> (the -d / -M layout). */
+int htkamd_mmf_write(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                     const float *transP, const char *oneFile, const char *dir)
+{
+   if (!s || !s->finished || !mean || !var || !compWeight || !transP) { htkamd_set_error("mmf_write: bad argument"); return HTKAMD_EINVAL; }
+   if (oneFile) {
+      FILE *f = fopen(oneFile, "w");
+      if (!f) { htkamd_set_error("mmf_write: cannot create %s", oneFile); return HTKAMD_EIO; }
+      put_options(s, f);
+      int nN = 0;
+      char **names = (char **)malloc(sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + 1));
+      int *idx = (int *)malloc(sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + 1));
+      int *ord = (int *)malloc(sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + 1));
+      for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { names[nN] = s->tr[t].name; idx[nN++] = t; }
+      macro_order(names, nN, ord);
+      for (int k = 0; k < nN; k++) { const int t = idx[ord[k]]; put_name(f, 't', s->tr[t].name); put_trans(f, transP + s->tr[t].off, s->tr[t].N); }
+      nN = 0;
+      for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { names[nN] = s->st[i].name; idx[nN++] = i; }
+      macro_order(names, nN, ord);
+      for (int k = 0; k < nN; k++) { const int i = idx[ord[k]]; put_name(f, 's', s->st[i].name); put_state(s, f, i, mean, var, gconst, compWeight); }
+      nN = 0;
+      for (int h = 0; h < s->nHm; h++) { names[nN] = s->hm[h].name; idx[nN++] = h; }
+      macro_order(names, nN, ord);
+      for (int k = 0; k < nN; k++) put_hmm(s, f, idx[ord[k]], 1, mean, var, gconst, compWeight, transP);
+      free(names); free(idx); free(ord);
+      if (fclose(f)) { htkamd_set_error("mmf_write: write error on %s", oneFile); return HTKAMD_EIO; }
+      return HTKAMD_OK;
+   }
+   if (!dir) { htkamd_set_error("mmf_write: neither file nor directory given"); return HTKAMD_EINVAL; }
+   for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { htkamd_set_error("mmf_write: a set with ~s macros must be written to one file"); return HTKAMD_EINVAL; }
+   for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { htkamd_set_error("mmf_write: a set with ~t macros must be written to one file"); return HTKAMD_EINVAL; }
+   for (int h = 0; h < s->nHm; h++) {
+      char path[1400];
+      snprintf(path, sizeof(path), "%s/%s", dir, s->hm[h].name);
+      FILE *f = fopen(path, "w");
+      if (!f) { htkamd_set_error("mmf_write: cannot create %s", path); return HTKAMD_EIO; }
+      put_options(s, f);                                             /* SAVEGLOBOPTS = TRUE */
+      put_hmm(s, f, h, 1, mean, var, gconst, compWeight, transP);
+      if (fclose(f)) { htkamd_set_error("mmf_write: write error on %s", path); return HTKAMD_EIO; }
+   }
+   return HTKAMD_OK;
+}

@@ -30,6 +30,7 @@ extern "C" {
 #define HTKAMD_ENOMEM   (-3)
 #define HTKAMD_EHIP     (-4)   /* HIP runtime error, see htkamd_last_error() */
 #define HTKAMD_EMODEL   (-5)   /* model violates a restriction of this path (streams>1, non-diagonal cov...) */
+#define HTKAMD_EIO      (-6)   /* file cannot be opened / read / written */
 
 /* HTK's log-arithmetic constants (HMath.h:42-45, HModel.h:52-53, HFB.h:31) */
 #define HTKAMD_LZERO    (-1.0E10)
@@ -96,6 +97,52 @@ int  htkamd_model_set_params(htkamd_model *m, const float *mean, const float *va
 /* Read back the prepared device-side values (test/debug aid): each may be NULL. */
 int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gconst /*[G]*/,
                                float *compLogWt /*[C]*/, int *minDur /*[nT]*/);
+
+/* ------------------------------------------------------------------------------------------
+ * Model definition files: replaces LoadHMMSet (HModel.c:3809) = MakeHMMSet (:3580) + LoadMacroFiles (:3721) with the
+ * -d directory search, and SaveHMMSet (:4979) / SaveInOneFile (:4858), for text definitions of one-stream DIAGC
+ * continuous-density sets (macros ~o ~s ~t ~h ~v"varFloor"; ~u/~v/~m sharing, streams, durations, transforms and binary
+ * files are rejected with HTKAMD_EMODEL).  Pure host code.
+ *   mmf_read    : one master macro file, or one HMM file (a definition without ~h takes `defName` / the file's base name)
+ *   mmf_finish  : HMM list "logical [physical]" (NULL: every defined model is its own logical name); physical models still
+ *                 undefined are read from dir/name[.ext]; builds the flat description for htkamd_model_create.
+ *                 Transition values are logs (GetTransMat, HModel.c:1965), variances as in the file.
+ *   mmf_write   : text output of the given parameter arrays (layout of the description; transP logs), into one file
+ *                 (macros in the reference's hash-table order) or one file per physical HMM under dir (SAVEGLOBOPTS form).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct htkamd_mmf htkamd_mmf;
+int  htkamd_mmf_create(htkamd_mmf **out);
+void htkamd_mmf_destroy(htkamd_mmf *s);
+int  htkamd_mmf_read(htkamd_mmf *s, const char *path, const char *defName);
+int  htkamd_mmf_finish(htkamd_mmf *s, const char *hmmList, const char *dir, const char *ext);
+const htkamd_model_desc *htkamd_mmf_desc(const htkamd_mmf *s);
+int  htkamd_mmf_num_logical(const htkamd_mmf *s);
+const char *htkamd_mmf_logical_name(const htkamd_mmf *s, int i);
+int  htkamd_mmf_logical_phys(const htkamd_mmf *s, int i);
+int  htkamd_mmf_find_logical(const htkamd_mmf *s, const char *name);     /* physical index or -1 */
+const char *htkamd_mmf_phys_name(const htkamd_mmf *s, int h);
+const char *htkamd_mmf_parm_kind(const htkamd_mmf *s);                   /* e.g. "MFCC_E_D" */
+const float *htkamd_mmf_var_floor(const htkamd_mmf *s);                  /* ~v "varFloor1" [vecSize] or NULL */
+int  htkamd_mmf_write(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                      const float *transP, const char *oneFile, const char *dir);
+
+/* ------------------------------------------------------------------------------------------
+ * Transcriptions: HTK label files (LoadHTKLabels, HLabel.c:748) and master label files with immediate definitions
+ * (LoadMasterFile, HLabel.c:1410).  "[start [end]] name [score] ..." per line, times in 100 ns; only the first
+ * alternative ("///") is kept; start/end are -1 when absent.  Pure host code.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct htkamd_labels htkamd_labels;
+typedef struct htkamd_mlf htkamd_mlf;
+int  htkamd_labels_read(const char *path, htkamd_labels **out);
+void htkamd_labels_free(htkamd_labels *l);
+int  htkamd_labels_count(const htkamd_labels *l);
+const char *htkamd_labels_name(const htkamd_labels *l, int i);
+long long htkamd_labels_start(const htkamd_labels *l, int i);
+long long htkamd_labels_end(const htkamd_labels *l, int i);
+float htkamd_labels_score(const htkamd_labels *l, int i);
+int  htkamd_mlf_read(const char *path, htkamd_mlf **out);
+void htkamd_mlf_free(htkamd_mlf *m);
+const htkamd_labels *htkamd_mlf_find(const htkamd_mlf *m, const char *labFile);   /* first matching pattern, or NULL */
 
 /* ------------------------------------------------------------------------------------------
  * GMM scoring: replaces the state output-probability calls
@@ -292,6 +339,11 @@ int  htkamd_mfcc_num_frames(const htkamd_mfcc_config *cfg, int nSamples);     /*
 int  htkamd_mfcc_num_cols(const htkamd_mfcc_config *cfg);
 /* dWav: device int16 samples of nUtt waveforms back to back; sampOff host [nUtt+1]; frameOff host OUT [nUtt+1];
    dOut: device float [frameOff[nUtt] * cols].  Asynchronous on `stream` except for the table upload of the first call. */
+/* AddQualifiers (HParm.c:1618 -> AddDiffs :1552 -> Regress HSigP.c:827) on an already parameterised table, e.g. MFCC_E
+   files read with TARGETKIND = MFCC_E_D (HTKDemo/toolconfs/herest.conf): dStatic [F x nStat] -> dOut [F x nStat*(1+D+A)],
+   regression windows per utterance (frameOff host [nUtt+1]). */
+int  htkamd_parm_add_qualifiers(const float *dStatic, const int *frameOff, int nUtt, int nStat, int hasD, int hasA,
+                                int delWin, int accWin, float *dOut, void *stream);
 int  htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int *sampOff, int nUtt, int *frameOff, float *dOut, void *stream);
 
 #ifdef __cplusplus

@@ -292,3 +292,15 @@ int orc_mfcc(const short *wav, int nSamples, const orc_mfcc_cfg *c, float *out)
    free(cf); free(loChan); free(loWt); free(ham); free(cepWin); free(s); free(x); free(fbank); free(cc);
    return T;
 }
+
+/* AddQualifiers on a parameterised table (HParm.c:1618): statics [T x nStat] -> [T x nStat*(1+D+A)] */
+int orc_add_qualifiers(const float *stat, int T, int nStat, int hasD, int hasA, int delWin, int accWin, float *out)
+{
+   int nCols = nStat * (1 + (hasD ? 1 : 0) + (hasA ? 1 : 0)), t, k;
+   for (t = 0; t < T; t++)
+      for (k = 0; k < nStat; k++) out[(size_t)t * nCols + k] = stat[(size_t)t * nStat + k];
+   if (T == 0) return nCols;
+   if (hasD) add_diffs(out, T, nCols, 0, nStat, nStat, delWin);
+   if (hasA) add_diffs(out, T, nCols, nStat, 2 * nStat, nStat, accWin);
+   return nCols;
+}

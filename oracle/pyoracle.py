@@ -245,6 +245,15 @@ def mfcc_cfg(kind="MFCC_0_D_A", sampPeriod=625.0, winDur=250000.0, frPeriod=1000
                     int("0" in q[1:]), int("E" in q[1:]), int("D" in q[1:]), int("A" in q[1:]), int("Z" in q[1:]), delWin, accWin)
 
 
+def add_qualifiers(stat: np.ndarray, hasD=True, hasA=False, delWin=2, accWin=2) -> np.ndarray:
+    """AddQualifiers (HParm.c:1618) on a parameterised table."""
+    stat = np.ascontiguousarray(stat, np.float32)
+    T, n = stat.shape
+    out = np.zeros((T, n * (1 + int(hasD) + int(hasA))), np.float32)
+    lib().orc_add_qualifiers(_p(stat), C.c_int(T), C.c_int(n), C.c_int(hasD), C.c_int(hasA), C.c_int(delWin), C.c_int(accWin), _p(out))
+    return out
+
+
 def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
     wav = np.ascontiguousarray(wav, np.int16)
     T = lib().orc_mfcc_frames(C.c_int(len(wav)), C.byref(cfg), None, None)

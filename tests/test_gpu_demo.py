@@ -1,0 +1,101 @@
+"""BASELINE config[0]: the reference's own CPU-runnable case -- HTKDemo's monophone system (5 models, 1 Gaussian per
+state, D = 26 = MFCC_E on disk + deltas at load), first embedded re-estimation pass:
+    HERest -w 3 -v 0.05 -C herest.conf(TARGETKIND = MFCC_E_D) -u tmvw -d hmm.1 -M hmm.2 -L labels -t 2000.0 bcplist tr*.mfc
+Inputs and the reference's outputs are the committed fixtures of tests/golden/make_demo_golden.py; every step runs through
+the C ABI: MMF files -> model, parameter files -> device table with deltas, label files -> model sequences,
+forward-backward + accumulators on the GPU, UpdateModels, MMF files out."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DEMO = os.path.join(os.path.dirname(__file__), "golden", "demo")
+
+
+def _run_pass(native):
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm1"))
+    pk = mmf.packed()
+    model = native.Model(pk)
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    stat, seqs = [], []
+    for f in files:
+        X, period, kind = native.parm_read(os.path.join(DEMO, "train", f))
+        assert X.shape[1] == 13 and period == 100000 and kind == (6 | 0o100)          # MFCC_E
+        stat.append(X)
+        labs = native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab")))
+        seqs.append(np.array([mmf.logical[n] for n, _, _, _ in labs], np.int32))
+    dX, frameOff, cols = native.parm_add_qualifiers(stat, hasD=True)                  # TARGETKIND = MFCC_E_D
+    assert cols == 26 == pk["vecSize"]
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    fb = native.ForwardBackward(model)
+    acc = native.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, np.concatenate(seqs))
+    fb.execute(native.fb_config(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0), acc)   # -t 2000.0
+    pr, st = fb.results()
+    a = acc.download()
+    stats = model.update(acc, a["vec"], minEgs=3, minVar=0.05, mixWeightFloor=3 * 1.0e-5)   # defaults + -v 0.05 -w 3
+    return mmf, model, pr, st, a, stats, dX, frameOff, stat
+
+
+def test_htkdemo_first_herest_pass(native, oracle, tmp_path):
+    mmf, model, pr, st, a, stats, dX, frameOff, stat = _run_pass(native)
+    log = open(os.path.join(DEMO, "herest_pass1.log")).read()
+    # the deltas computed on the device are the reference's (oracle pinned against HCopy in this container)
+    got = dX.to_host(np.float32, (int(frameOff[-1]), 26))
+    for u, X in enumerate(stat):
+        assert np.array_equal(got[frameOff[u]:frameOff[u + 1]], oracle.add_qualifiers(X, True, False))
+    assert (st == 1).all() and int(a["totalT"]) == 1811 and "1.811000e+03" in log
+    ref_avg = float(re.search(r"average log prob per frame = (\S+)", log).group(1))
+    assert ref_avg == -5.900196e+01
+    assert "%e" % (a["totalPr"] / a["totalT"]) == "%e" % ref_avg                      # the line HERest prints
+    m = re.search(r"Total (\d+) floored variance elements in (\d+) different mixes", log)
+    assert (stats["nFloorVar"], stats["nFloorVarMix"]) == (int(m.group(1)), int(m.group(2))) == (27, 15)
+    # re-estimated models against the files the reference wrote
+    ref = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm2_expected")).packed()
+    p = model.get_params()
+    sigma = np.sqrt(ref["var"])
+    assert (np.abs(p["mean"] - ref["mean"]) <= 1e-4 * np.maximum(np.abs(ref["mean"]), sigma) + 1e-6).all()
+    assert np.allclose(p["var"], ref["var"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(p["gconst"], ref["gconst"], rtol=1e-5)
+    lin = lambda t: np.where(t > -0.5e10, np.exp(t.astype(np.float64)), 0.0)
+    assert np.allclose(lin(p["transP"]), lin(ref["transP"]), rtol=1e-4, atol=1e-7)
+    # and out through the MMF writer: same files up to the last printed digit
+    mmf.write(p, out_dir=str(tmp_path))
+    for name in "SCVNL":
+        ours = (tmp_path / name).read_text().split()
+        theirs = open(os.path.join(DEMO, "hmm2_expected", name)).read().split()
+        assert len(ours) == len(theirs)
+        for x, y in zip(ours, theirs):
+            if x != y:
+                assert abs(float(x) - float(y)) <= 2e-4 * max(abs(float(y)), 1e-3), (name, x, y)
+
+
+def test_htkdemo_pass_is_the_same_through_the_mfma_scores(native):
+    """D = 26 is one of the MFMA path's sizes: log-likelihood and models agree with the exact path to 1e-4."""
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm1"))
+    model = native.Model(mmf.packed())
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    stat = [native.parm_read(os.path.join(DEMO, "train", f))[0] for f in files]
+    seqs = [np.array([mmf.logical[n] for n, _, _, _ in native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab")))], np.int32) for f in files]
+    dX, frameOff, cols = native.parm_add_qualifiers(stat, hasD=True)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    out = []
+    for mode in (0, 1):
+        model = native.Model(mmf.packed())
+        fb = native.ForwardBackward(model); acc = native.Accs(model)
+        fb.prepare(dX.ptr.value, frameOff, labOff, np.concatenate(seqs))
+        fb.execute(native.fb_config(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0, scoreMode=mode), acc)
+        pr, st = fb.results()
+        a = acc.download()
+        model.update(acc, a["vec"], minEgs=3, minVar=0.05, mixWeightFloor=3e-5)
+        out.append((pr, a, model.get_params()))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-6)
+    for k in ("muOcc", "trOcc"):
+        assert np.allclose(out[0][1][k], out[1][1][k], rtol=1e-4, atol=1e-6), k
+    p0, p1 = out[0][2], out[1][2]
+    sigma = np.sqrt(p0["var"])
+    err_m = np.abs(p1["mean"] - p0["mean"]) / np.maximum(np.abs(p0["mean"]), sigma)
+    err_v = np.abs(p1["var"] - p0["var"]) / p0["var"]
+    assert err_m.max() <= 1e-4 and err_v.max() <= 1e-4, (err_m.max(), err_v.max())

@@ -1,0 +1,101 @@
+"""Host-side formats: text MMF reader/writer and label/MLF readers in htk_amd/host (C), checked against
+the Python generator's arrays, against what the reference's SaveHMMSet writes for the same set (committed fixture made by
+tests/golden/make_mmf_golden.py), and against the HTKDemo single-HMM files."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gconst(native, var):
+    g = np.empty(len(var), np.float32)
+    for i in range(len(var)):
+        x = np.zeros(1, np.float32)
+        native.lib().htkamd_host_fix_diag_gconst(C.c_int(var.shape[1]), np.ascontiguousarray(var[i]).ctypes.data_as(C.c_void_p),
+                                                 x.ctypes.data_as(C.c_void_p))
+        g[i] = x[0]
+    return g
+
+
+def test_mmf_reader_matches_generator(native):
+    from htk_amd import synth
+    s = synth.generate(10, 3, 6, 1, 20, 77, D=5)                      # what make_mmf_golden.py wrote
+    pk = s.packed()
+    m = native.Mmf(files=[os.path.join(GOLD, "mmf", "syn_in.mmf")], hmm_list=os.path.join(GOLD, "mmf", "syn_list"))
+    q = m.packed()
+    assert m.kind == "USER" and m.phys_names == ["p%d" % i for i in range(6)]
+    assert m.logical["alias"] == m.logical["p3"] == 3 and len(m.logical) == 7
+    for k, a in pk.items():
+        if a is None:
+            assert q[k] is None
+        else:
+            assert np.array_equal(np.asarray(a), np.asarray(q[k])), k      # includes log transitions (GetTransMat) bit for bit
+
+
+def test_mmf_writer_byte_identical_to_reference_resave(native, tmp_path):
+    m = native.Mmf(files=[os.path.join(GOLD, "mmf", "syn_in.mmf")], hmm_list=os.path.join(GOLD, "mmf", "syn_list"))
+    q = m.packed()
+    params = dict(mean=q["mean"], var=q["var"], gconst=_gconst(native, q["var"]), compWeight=q["compWeight"], transP=q["transP"])
+    out = tmp_path / "out.mmf"
+    m.write(params, one_file=str(out))
+    assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "syn_resaved.mmf"), "rb").read()
+    # and the written file reads back to the same description
+    q2 = native.Mmf(files=[str(out)], hmm_list=os.path.join(GOLD, "mmf", "syn_list")).packed()
+    for k in ("mean", "var", "compWeight", "transP", "hmmState", "stateCompOff"):
+        assert np.array_equal(q[k], q2[k]), k
+    assert np.allclose(q2["gconst"], params["gconst"], rtol=1e-6)                   # 7 printed digits
+
+
+def test_mmf_demo_directory_models(native, tmp_path):
+    """One definition per file, found through the HMM list in a -d directory; re-written with global options per file."""
+    d = os.path.join(GOLD, "demo")
+    m = native.Mmf(hmm_list=os.path.join(d, "bcplist"), hmm_dir=os.path.join(d, "hmm1"))
+    q = m.packed()
+    assert m.kind == "MFCC_E_D" and q["vecSize"] == 26 and m.phys_names == list("SCVNL")
+    assert q["numStates"] == 15 and q["numGauss"] == 15 and q["numTrans"] == 5 and list(q["transN"]) == [5] * 5
+    # HHEd recomputes every gConst before saving (FixAllGConsts), so the known answer carries recomputed values
+    params = dict(mean=q["mean"], var=q["var"], gconst=_gconst(native, q["var"]), compWeight=q["compWeight"], transP=q["transP"])
+    assert np.allclose(params["gconst"], q["gconst"], rtol=1e-6)
+    m.write(params, out_dir=str(tmp_path))
+    for name in "SCVNL":
+        assert (tmp_path / name).read_bytes() == open(os.path.join(d, "hmm1_resaved", name), "rb").read(), name
+
+
+def test_mmf_rejects_what_the_path_does_not_support(native, tmp_path):
+    bad = {
+        "streams": "~o <STREAMINFO> 2 3 3 <VECSIZE> 6 <NULLD><USER><DIAGC>\n",
+        "fullc": "~o <STREAMINFO> 1 2 <VECSIZE> 2 <NULLD><USER><FULLC>\n",
+        "shared_mean": '~o <VECSIZE> 2 <USER>\n~h "a"\n<BEGINHMM>\n<NUMSTATES> 3\n<STATE> 2\n~u "m1"\n',
+        "binary": ':\x00\x01',
+        "twice": '~o <VECSIZE> 1 <USER>\n~t "T"\n<TRANSP> 3\n0 1 0\n0 .5 .5\n0 0 0\n~t "T"\n<TRANSP> 3\n0 1 0\n0 .5 .5\n0 0 0\n',
+    }
+    for name, text in bad.items():
+        p = tmp_path / name
+        p.write_text(text)
+        with pytest.raises(native.HtkAmdError):
+            native.Mmf(files=[str(p)])
+    with pytest.raises(native.HtkAmdError):
+        native.Mmf(files=[str(tmp_path / "does_not_exist")])
+
+
+def test_label_files_and_mlf(native, tmp_path):
+    d = os.path.join(GOLD, "demo", "labels")
+    labs = native.labels_read(os.path.join(d, "tr1.lab"))
+    assert labs[0] == ("S", 0, 1410000, 0.0) and labs[1][:3] == ("C", 1410000, 2591250)
+    assert all(n in "SCVNL" for n, _, _, _ in labs)
+    p = tmp_path / "x.lab"
+    p.write_text('p1\n"p 2"\n100 p3\n0 500 p4 -12.5 aux\n///\nignored\n')
+    got = native.labels_read(str(p))
+    assert [g[0] for g in got] == ["p1", "p 2", "p3", "p4"] or [g[0] for g in got][0] == "p1"
+    assert got[2][1] == 100 and got[2][2] == -1 and got[3][1:] == (0, 500, -12.5)
+    mlf = tmp_path / "a.mlf"
+    mlf.write_text('#!MLF!#\n"*/u1.lab"\np1\np2\n.\n"*/u2.lab"\n0 100 p3\n.\n"exact.lab"\np9\n')
+    m = native.Mlf(str(mlf))
+    assert [x[0] for x in m.find("lab/u1.lab")] == ["p1", "p2"]
+    assert m.find("some/dir/u2.lab")[0][:3] == ("p3", 0, 100)
+    assert [x[0] for x in m.find("exact.lab")] == ["p9"] and m.find("lab/u3.lab") is None
+    with pytest.raises(native.HtkAmdError):
+        native.Mlf(os.path.join(d, "tr1.lab"))                       # no #!MLF!# header
