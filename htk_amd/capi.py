@@ -594,3 +594,37 @@ class Mlf:
                 lib().htkamd_mlf_free(self.h); self.h = C.c_void_p()
         except Exception:
             pass
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("nNodes", C.c_int), ("nLinks", C.c_int), ("nProns", C.c_int), ("initial", C.c_int), ("final", C.c_int),
+                ("kind", C.c_void_p), ("model", C.c_void_p), ("pronProb", C.c_void_p),
+                ("linkOff", C.c_void_p), ("linkDest", C.c_void_p), ("linkLike", C.c_void_p)]
+
+
+class Net:
+    """htkamd_net holder: SLF word network + dictionary expanded over a model set (htk_amd/host/net.c)."""
+
+    def __init__(self, slf: str, dictionary: str, mmf: "Mmf"):
+        L = lib()
+        L.htkamd_net_get.restype = C.POINTER(NetDesc)
+        L.htkamd_net_out_sym.restype = C.c_char_p
+        self.h = C.c_void_p()
+        check(L.htkamd_net_build(slf.encode(), dictionary.encode(), mmf.h, C.byref(self.h)), "net_build")
+        self.desc = L.htkamd_net_get(self.h).contents
+        self.out_syms = [L.htkamd_net_out_sym(self.h, C.c_int(k)).decode() for k in range(self.desc.nProns)]
+
+    def arrays(self) -> dict:
+        d = self.desc
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(dt)), (max(n, 1),))[:n].copy()
+        return dict(kind=arr(d.kind, d.nNodes, C.c_int), model=arr(d.model, d.nNodes, C.c_int), pronProb=arr(d.pronProb, d.nNodes, C.c_float),
+                    linkOff=arr(d.linkOff, d.nNodes + 1, C.c_int), linkDest=arr(d.linkDest, d.nLinks, C.c_int),
+                    linkLike=arr(d.linkLike, d.nLinks, C.c_float), initial=d.initial, final=d.final)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().htkamd_net_destroy(self.h); self.h = C.c_void_p()
+        except Exception:
+            pass

@@ -311,6 +311,30 @@ int  htkamd_viterbi_results(htkamd_viterbi *v, int *segStart, int *segEnd, doubl
                             double *total /*[nUtt]*/, int *status /*[nUtt]*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Recognition network: word lattice (SLF) + dictionary -> model-level network, for context-independent sets.
+ * Replaces ReadLattice (HNet.c:631), ReadDict (HDict.c:224) and ExpandWordNet (HNet.c:3438, xc == 0 form): per lattice
+ * node and pronunciation a chain of HMM nodes ending in a WORD node, NULL nodes for !NULL words, lattice arcs as links
+ * carrying the LM log probability, node 0 = the network's initial null node, node 1 = its final null node
+ * (AddInitialFinal HNet.c:2180).  Pure host code.
+ * ------------------------------------------------------------------------------------------ */
+#define HTKAMD_NODE_HMM  0     /* model = physical HMM index */
+#define HTKAMD_NODE_WORD 1     /* model = pronunciation index (htkamd_net_out_sym), pronProb = log pron prob */
+#define HTKAMD_NODE_NULL 2
+typedef struct {
+   int nNodes, nLinks, nProns, initial, final;
+   const int   *kind, *model;
+   const float *pronProb;
+   const int   *linkOff;     /* [nNodes+1] links of node n: linkOff[n]..linkOff[n+1) */
+   const int   *linkDest;
+   const float *linkLike;    /* LM log probability of the link (NetLink.like) */
+} htkamd_net_desc;
+typedef struct htkamd_net htkamd_net;
+int  htkamd_net_build(const char *slfPath, const char *dictPath, const htkamd_mmf *hmms, htkamd_net **out);
+void htkamd_net_destroy(htkamd_net *n);
+const htkamd_net_desc *htkamd_net_get(const htkamd_net *n);
+const char *htkamd_net_out_sym(const htkamd_net *n, int pron);
+
+/* ------------------------------------------------------------------------------------------
  * Waveform -> MFCC(+_0/_E)(+_D)(+_A)(+_Z) on the device: replaces what OpenBuffer (HParm.h, HParm.c:4357)
  * does for a waveform source with maxObs == 0 (whole file converted into a table):
  *   GetWave HWave.c:1683 frame slicing; ConvertFrame HParm.c:2214 = PreEmphasise HSigP.c:134, Ham :122,

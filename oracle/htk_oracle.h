@@ -146,6 +146,13 @@ int orc_add_qualifiers(const float *stat, int T, int nStat, int hasD, int hasA, 
 /* ---- Viterbi forced alignment of a chain of physical models (HRec token passing, 1-best; orc_viterbi.c) ----
    Returns the number of state segments (time order) or -1 when no token survives.  Frames are 0-based,
    [segStart, segEnd).  segScore = like(next Align record) - like(this one) (LatFromPaths HRec.c:1512). */
+/* 1-best decoding over a flat recognition network (orc_decode.c): returns the number of words, -1 if no token reached
+   the final node, -3 if maxWords is too small, -4 if the zero-time nodes form a loop.  Frames are 0-based boundaries. */
+int orc_decode(const orc_model *m, const float *X, int T,
+               int nNodes, const int *kind, const int *model, const float *pronProb,
+               const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
+               float genBeam, float wordBeam, float lmScale, float wordPen, float prScale,
+               int maxWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *totalLike);
 int orc_viterbi_align(const orc_model *m, const float *X, int T, const int *labs, int Q, float genBeam,
                       int maxSeg, int *segQ, int *segState, int *segStart, int *segEnd, double *segScore,
                       int *modStart, int *modEnd, double *modScore, double *totalLike);
