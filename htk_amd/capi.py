@@ -628,3 +628,46 @@ class Net:
                 lib().htkamd_net_destroy(self.h); self.h = C.c_void_p()
         except Exception:
             pass
+
+
+class DecodeConfig(C.Structure):
+    _fields_ = [("genBeam", C.c_float), ("wordBeam", C.c_float), ("lmScale", C.c_float), ("wordPen", C.c_float), ("prScale", C.c_float)]
+
+
+class Decoder:
+    """htkamd_decoder holder: HVite -w (1-best word labels) for a batch of utterances on the device."""
+
+    def __init__(self, model: "Model", net: "Net", lmScale: float = 1.0):
+        self.h = C.c_void_p()
+        self.model, self.net, self.lmScale = model, net, float(lmScale)
+        check(lib().htkamd_decoder_create(model.h, C.byref(net.desc), C.c_float(lmScale), C.byref(self.h)), "decoder_create")
+
+    def run(self, feats, genBeam=1.0e10, wordBeam=1.0e10, lmScale=None, wordPen=0.0, prScale=1.0, maxWords=1024):
+        """feats: list of [T, D] arrays.  Returns per utterance (list of (pron, startFrame, endFrame, score) or None, total)."""
+        lmScale = self.lmScale if lmScale is None else float(lmScale)
+        if lmScale != self.lmScale:
+            raise HtkAmdError("Decoder.run: the LM scale is fixed at creation (LikeToWord look-ahead)")
+        nU = len(feats)
+        X = np.ascontiguousarray(np.concatenate(feats) if nU else np.zeros((0, self.model.D)), np.float32)
+        frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int32)
+        dX = DevArray(X) if X.size else DevArray(nbytes=4)
+        nW = np.zeros(max(nU, 1), np.int32); tot = np.zeros(max(nU, 1), np.float64)
+        wp = np.zeros(max(nU, 1) * maxWords, np.int32); ws = np.zeros_like(wp); we = np.zeros_like(wp); sc = np.zeros(max(nU, 1) * maxWords, np.float32)
+        cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale)
+        check(lib().htkamd_decoder_run(self.h, C.byref(cfg), dX.ptr, _p(frameOff), C.c_int(nU), C.c_int(maxWords), _p(nW), _p(wp), _p(ws), _p(we),
+                                       _p(sc), _p(tot), None), "decoder_run")
+        out = []
+        for u in range(nU):
+            if nW[u] < 0:
+                out.append((None, float(tot[u])))
+            else:
+                o = u * maxWords
+                out.append(([(int(wp[o + i]), int(ws[o + i]), int(we[o + i]), float(sc[o + i])) for i in range(nW[u])], float(tot[u])))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().htkamd_decoder_destroy(self.h); self.h = C.c_void_p()
+        except Exception:
+            pass

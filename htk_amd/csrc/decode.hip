@@ -1,0 +1,576 @@
+// decode.hip -- K7: 1-best Viterbi decoding over a recognition network (HVite -w), one workgroup per utterance.
+//
+// Reference semantics (HRec.c with nToks = 1, no alignment records; oracle/orc_decode.c is the restatement this kernel
+// is tested against):
+//   StartRecognition :1884 / ProcessObservation :1935-2030 -- pass 1 StepHMM1 (:642) on every model instance with the
+//   PREVIOUS frame's genThresh, beam tops genMaxTok / wordMaxTok (exit + LikeToWord :1172); thresholds as floats floored at
+//   LSMALL; pass 2: instances under genThresh are detached, StepInst2 (:1360) = StepWord2 (:1046: word penalty, pron prob,
+//   Path record) / StepHMM2 (:790, tee models), wordThresh on word tokens, tokens above genThresh go down every link with
+//   like += lm*scale into SetEntryState (:1303, strict >).  CompleteRecognition :2054 + LatFromPaths :1512 +
+//   TranscriptionFromLattice :2176 give the word labels and their LArcTotLike scores.
+//
+// MI355X mapping.  Output probabilities are NOT evaluated inside the token loop: K1 (exact mode) scores every tied state the
+// network uses for all frames first -- the dense, compute-bound form of the problem -- so the sequential part only reads
+// floats.  The token loop is latency-bound (500 dependent frames), so each utterance gets one 1024-thread workgroup and
+// the machine is filled with utterances.  The reference PUSHES tokens along links in list order; here every node PULLS:
+//   phase A   thread per model node: entry token = best over predecessors' exit tokens (reverse CSR), then StepHMM1 on
+//             registers; block-wide max for the two beam tops; thread 0 publishes the thresholds.
+//   phase L   the zero-time nodes (word ends, null nodes, tee models) level by level in topological order, thread per node
+//             pulling from its predecessors; nodes with a large fan-in (the loop/back-off null nodes: thousands of word
+//             ends) are reduced by the whole workgroup.  One barrier per level.
+// Detaching an instance only changes which tokens are visible later, so it is folded into the next frame's phase A
+// (instance max of the previous frame against the threshold of the previous frame).  Word-end Path records go to a dense
+// [frame][word node] table (no allocation, no garbage collection); the final token's chain is walked by one thread.
+// Tokens are (double like, float lm, int path), kept as separate arrays in global memory (L2-resident per utterance).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+
+#define DEC_THREADS 1024
+#define DEC_MAXN 8              /* states per model incl. entry/exit */
+#define DEC_WIDE 96             /* fan-in from which a node is reduced by the whole workgroup */
+
+struct DecNet {
+   int nNodes, nHmm, nLevels, nWordNodes, initial, final, nTok;
+   const int *kind, *model;            // [nNodes]
+   const float *pronProb;              // [nNodes]
+   const int *predOff, *predSrc;       // reverse CSR
+   const float *predLike;
+   const int *tok0;                    // [nNodes] first token (state 1) of the node
+   const int *hmmNodes;                // [nHmm] model nodes (tee or not)
+   const int *nodeN, *nodeTp, *nodeSt; // [nNodes] HMM: numStates, offset of transP, offset into hmmState
+   const unsigned char *nodeTee;       // [nNodes]
+   const float *wdlk;                  // [nNodes]
+   const int *wordIdx;                 // [nNodes] dense index of WORD nodes (path table column) or -1
+   const int *wordNode;                // [nWordNodes] inverse of wordIdx
+   const int *levelOff, *levelNodes;   // zero-time nodes by level: narrow ones first, then wide ones
+   const int *levelWide;               // [nLevels] index in levelNodes where the wide nodes of the level start
+   const float *transP;
+   const int *hmmState;
+   const int *stateSlot;               // [S] row of the tied state in the score block, -1 if unused
+};
+
+struct DecUtt {
+   int T, frame0, status, pad;
+   size_t score0;      // floats: score[score0 + slot*T + (t-1)]
+   size_t tok0;        // token arrays base
+   size_t node0;       // exit-token / instance-max arrays base
+   size_t path0;       // path table base: (t*nWordNodes + w)
+   size_t out0;        // word output base
+};
+
+struct DecArgs {
+   DecNet net;
+   const DecUtt *utt; int nUtt;
+   const float *score;
+   double *tokLike; float *tokLm; int *tokPath;
+   double *exLike; float *exLm; int *exPath; double *imax;
+   int *pathPrev; double *pathLike; float *pathLm;
+   float genBeam, wordBeam, lmScale, wordPen, prScale;
+   int maxWords;
+   int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore; double *total;
+};
+
+struct Tok { double like; float lm; int path; };
+
+__device__ __forceinline__ Tok null_tok() { Tok t; t.like = LZERO; t.lm = 0.0f; t.path = -1; return t; }
+
+// entry token of node n: best over predecessors (SetEntryState over StepInst2's sends), first maximum wins
+__device__ __forceinline__ Tok pull_range(const DecArgs &a, const DecUtt &ud, int k0, int k1, int kstep, float gT, float wT, int *argk)
+{
+   Tok best = null_tok();
+   int arg = 0x7fffffff;
+   for (int k = k0; k < k1; k += kstep) {
+      const int p = a.net.predSrc[k];
+      const double el = a.exLike[ud.node0 + p];
+      if (!(el > gT)) continue;
+      if (a.net.kind[p] != HTKAMD_NODE_HMM && el < wT) continue;       // word-end beam on word/null tokens
+      const float lm = a.net.predLike[k];
+      const double c = el + lm * a.lmScale;
+      if (!(c > gT)) continue;
+      if (c > best.like) { best.like = c; best.lm = a.exLm[ud.node0 + p] + lm; best.path = a.exPath[ud.node0 + p]; arg = k; }
+   }
+   *argk = arg;
+   return best;
+}
+
+__device__ __forceinline__ double block_max(double v, double *red)
+{
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = (w > v) ? w : v; }
+   const int wv = threadIdx.x >> 6;
+   __syncthreads();
+   if ((threadIdx.x & 63) == 0) red[wv] = v;
+   __syncthreads();
+   double r = red[0];
+   for (int i = 1; i < DEC_THREADS / 64; i++) r = (red[i] > r) ? red[i] : r;
+   return r;
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
+{
+   __shared__ double red[DEC_THREADS / 64];
+   __shared__ double red2[DEC_THREADS / 64];
+   __shared__ int redk[DEC_THREADS / 64];
+   __shared__ float thr[2];
+   const int u = blockIdx.x, tid = threadIdx.x;
+   if (u >= a.nUtt) return;
+   const DecUtt ud = a.utt[u];
+   const DecNet &N = a.net;
+   const int T = ud.T;
+   double *tokLike = a.tokLike + ud.tok0; float *tokLm = a.tokLm + ud.tok0; int *tokPath = a.tokPath + ud.tok0;
+   double *exLike = a.exLike + ud.node0; float *exLm = a.exLm + ud.node0; int *exPath = a.exPath + ud.node0; double *imax = a.imax + ud.node0;
+
+   for (int i = tid; i < N.nTok; i += DEC_THREADS) { tokLike[i] = LZERO; tokLm[i] = 0.0f; tokPath[i] = -1; }
+   for (int i = tid; i < N.nNodes; i += DEC_THREADS) { exLike[i] = LZERO; exLm[i] = 0.0f; exPath[i] = -1; imax[i] = LZERO; }
+   if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; }
+   __syncthreads();
+
+   for (int t = 0; t <= T; t++) {
+      if (t >= 1) {
+         const float gT = thr[0];                         // threshold of the previous frame
+         double myGen = LZERO, myWord = LZERO;
+         for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
+            const int n = N.hmmNodes[hk];
+            const int NS = N.nodeN[n], t0 = N.tok0[n];
+            const float *tp = N.transP + N.nodeTp[n];
+            Tok s[DEC_MAXN];
+            const bool detached = imax[n] < gT;           // DetachInst of the previous frame's pass 2
+            bool live = false;
+#pragma unroll
+            for (int i = 1; i < DEC_MAXN; i++) {
+               s[i] = null_tok();
+               // the entry token (i == 1) was pulled at the end of the previous frame's level phase
+               if (i < NS && (i == 1 || !detached)) { s[i].like = tokLike[t0 + i - 1]; s[i].lm = tokLm[t0 + i - 1]; s[i].path = tokPath[t0 + i - 1]; }
+            }
+#pragma unroll
+            for (int i = 1; i < DEC_MAXN; i++) if (i < NS && s[i].like > LSMALL) live = true;
+            Tok ex = null_tok();
+            double mx = LZERO;
+            if (live) {
+               Tok nw[DEC_MAXN];
+#pragma unroll
+               for (int j = 2; j < DEC_MAXN; j++) {
+                  nw[j] = null_tok();
+                  if (j < NS) {
+                     // CreateSEIndex (HRec.c:1403): predecessor range with a transition, first maximum wins
+                     int lo = 1, hi = NS - 1;
+                     while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
+                     while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
+                     if (lo > hi) { lo = 1; hi = NS - 1; }
+                     Tok best = s[lo]; best.like += tp[(lo - 1) * NS + (j - 1)];
+                     for (int i = lo + 1; i <= hi; i++) {
+                        const double c = s[i].like + tp[(i - 1) * NS + (j - 1)];
+                        if (c > best.like) { best = s[i]; best.like = c; }
+                     }
+                     if (best.like > gT) {
+                        const int st = N.hmmState[N.nodeSt[n] + (j - 2)];
+                        best.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
+                        nw[j] = best;
+                        if (best.like > mx) mx = best.like;
+                     }
+                  }
+               }
+               {
+                  int lo = 2, hi = NS - 1;
+                  while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
+                  while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
+                  if (lo > hi) { lo = 2; hi = NS - 1; }
+                  Tok best = nw[lo]; best.like += tp[(lo - 1) * NS + (NS - 1)];
+                  for (int i = lo + 1; i <= hi; i++) {
+                     const double c = nw[i].like + tp[(i - 1) * NS + (NS - 1)];
+                     if (c > best.like) { best = nw[i]; best.like = c; }
+                  }
+                  if (best.like > LSMALL) {
+                     ex = best;
+                     const double w = best.like + N.wdlk[n];
+                     if (w > myWord) myWord = w;
+                  }
+               }
+               tokLike[t0] = LZERO; tokLm[t0] = 0.0f; tokPath[t0] = -1;       // entry consumed
+#pragma unroll
+               for (int j = 2; j < DEC_MAXN; j++)
+                  if (j < NS) { tokLike[t0 + j - 1] = nw[j].like; tokLm[t0 + j - 1] = nw[j].lm; tokPath[t0 + j - 1] = nw[j].path; }
+               if (mx > myGen) myGen = mx;
+            } else if (detached) {
+               for (int i = 1; i < NS; i++) { tokLike[t0 + i - 1] = LZERO; tokLm[t0 + i - 1] = 0.0f; tokPath[t0 + i - 1] = -1; }
+            }
+            exLike[n] = ex.like; exLm[n] = ex.lm; exPath[n] = ex.path; imax[n] = mx;
+         }
+         const double genMax = block_max(myGen, red);
+         const double wordMax = block_max(myWord, red2);
+         if (tid == 0) {
+            float w = (float)(wordMax - a.wordBeam); if (w < (float)LSMALL) w = (float)LSMALL;
+            float g = (float)(genMax - a.genBeam); if (g < (float)LSMALL) g = (float)LSMALL;
+            thr[0] = g; thr[1] = w;
+         }
+         __syncthreads();
+      }
+      // ---- zero-time nodes, level by level (at t = 0: StartRecognition's propagation of the initial token)
+      const float gT = thr[0], wT = thr[1];
+      for (int L = 0; L < N.nLevels; L++) {
+         const int l0 = N.levelOff[L], lw = N.levelWide[L], l1 = N.levelOff[L + 1];
+         for (int k = l0 + tid; k < lw; k += DEC_THREADS) {
+            const int n = N.levelNodes[k];
+            int ak;
+            Tok st = pull_range(a, ud, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; }
+            Tok ex = null_tok();
+            if (N.kind[n] == HTKAMD_NODE_HMM) {            // tee model: StepHMM2
+               const int NS = N.nodeN[n], t0 = N.tok0[n];
+               tokLike[t0] = st.like; tokLm[t0] = st.lm; tokPath[t0] = st.path;
+               ex.like = exLike[n]; ex.lm = exLm[n]; ex.path = exPath[n];
+               const double m2 = (st.like > imax[n]) ? st.like : imax[n];
+               if (t >= 1 && m2 < gT) ex = null_tok();
+               else if (st.like > LSMALL) {
+                  const double c = st.like + N.transP[N.nodeTp[n] + (NS - 1)];
+                  if (c > ex.like) { ex = st; ex.like = c; }
+               }
+            } else if (st.like > LSMALL) {
+               ex = st;
+               if (N.kind[n] == HTKAMD_NODE_WORD) {        // StepWord2
+                  ex.like += a.wordPen;
+                  ex.like += N.pronProb[n] * a.prScale;
+                  const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
+                  a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = ex.like; a.pathLm[ud.path0 + pid] = ex.lm;
+                  ex.path = (int)pid; ex.lm = 0.0f;
+               }
+            }
+            exLike[n] = ex.like; exLm[n] = ex.lm; exPath[n] = ex.path;
+         }
+         for (int k = lw; k < l1; k++) {                  // wide fan-in: the whole workgroup reduces one node
+            const int n = N.levelNodes[k];
+            int ak;
+            Tok st = pull_range(a, ud, N.predOff[n] + tid, N.predOff[n + 1], DEC_THREADS, gT, wT, &ak);
+            // argmax over the workgroup: larger like, then smaller predecessor position
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+               const double ol = __shfl_xor(st.like, o); const int ok = __shfl_xor(ak, o);
+               const float olm = __shfl_xor(st.lm, o); const int op = __shfl_xor(st.path, o);
+               if (ol > st.like || (ol == st.like && ok < ak)) { st.like = ol; st.lm = olm; st.path = op; ak = ok; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { red[tid >> 6] = st.like; redk[tid >> 6] = ak; red2[tid >> 6] = __hiloint2double(__float_as_int(st.lm), st.path); }
+            __syncthreads();
+            if (tid == 0) {
+               int bw = 0;
+               for (int i = 1; i < DEC_THREADS / 64; i++) if (red[i] > red[bw] || (red[i] == red[bw] && redk[i] < redk[bw])) bw = i;
+               Tok b; b.like = red[bw]; b.lm = __int_as_float(__double2hiint(red2[bw])); b.path = __double2loint(red2[bw]);
+               if (redk[bw] == 0x7fffffff) b = null_tok();
+               if (t == 0 && n == N.initial) { b.like = 0.0; b.lm = 0.0f; b.path = -1; }
+               Tok ex = null_tok();
+               if (b.like > LSMALL) {
+                  ex = b;
+                  if (N.kind[n] == HTKAMD_NODE_WORD) {
+                     ex.like += a.wordPen;
+                     ex.like += N.pronProb[n] * a.prScale;
+                     const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
+                     a.pathPrev[ud.path0 + pid] = b.path; a.pathLike[ud.path0 + pid] = ex.like; a.pathLm[ud.path0 + pid] = ex.lm;
+                     ex.path = (int)pid; ex.lm = 0.0f;
+                  }
+               }
+               exLike[n] = ex.like; exLm[n] = ex.lm; exPath[n] = ex.path;
+            }
+         }
+         __syncthreads();
+      }
+      // ---- entry tokens of the emitting models for the next frame (SetEntryState from this frame's exits)
+      if (t < T) {
+         for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
+            const int n = N.hmmNodes[hk];
+            if (N.nodeTee[n]) continue;
+            int ak;
+            const Tok e = pull_range(a, ud, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            const int t0 = N.tok0[n];
+            tokLike[t0] = e.like; tokLm[t0] = e.lm; tokPath[t0] = e.path;
+         }
+         __syncthreads();
+      }
+   }
+
+   // ---- CompleteRecognition + LatFromPaths + TranscriptionFromLattice for the 1-best chain
+   if (tid == 0) {
+      const int fp = exPath[N.final];
+      int nW = 0;
+      a.total[u] = LZERO;
+      if (fp >= 0) {
+         a.total[u] = exLike[N.final];
+         for (int p = fp; p >= 0; p = a.pathPrev[ud.path0 + p]) nW++;
+         if (nW > a.maxWords) nW = -3;
+         else {
+            int w = nW;
+            for (int p = fp; p >= 0;) {
+               const int prev = a.pathPrev[ud.path0 + p];
+               const int widx = p % N.nWordNodes, frame = p / N.nWordNodes;
+               const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
+               const double wp = a.wordPen;
+               const float plm = a.pathLm[ud.path0 + p];
+               float aclike = (float)(a.pathLike[ud.path0 + p] - prlk - plm * a.lmScale - wp);
+               const int node = N.wordNode[widx];
+               const float pr = N.pronProb[node];
+               aclike -= pr * a.prScale;
+               const float sc = (float)((double)((aclike * 1.0f + plm * a.lmScale) + pr * a.prScale) + (double)a.wordPen);
+               w--;
+               a.wordPron[ud.out0 + w] = N.model[node];
+               a.wordEnd[ud.out0 + w] = frame;
+               a.wordStart[ud.out0 + w] = (prev >= 0) ? prev / N.nWordNodes : 0;
+               a.wordScore[ud.out0 + w] = sc;
+               p = prev;
+            }
+         }
+      } else nW = -1;
+      a.nWords[u] = nW;
+   }
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct htkamd_decoder {
+   htkamd_model *m;
+   DecNet net;                         // device pointers
+   std::vector<void *> owned;
+   std::vector<int> usedStates;        // tied states of the network in slot order
+   int *d_usedStates;
+   int maxWidthNodes;
+};
+
+template <typename T> static int upv(htkamd_decoder *d, const std::vector<T> &v, const T **out)
+{
+   T *p = nullptr;
+   HIPCHECK(hipMalloc((void **)&p, sizeof(T) * (v.size() ? v.size() : 1)));
+   if (!v.empty()) HIPCHECK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+   d->owned.push_back(p);
+   *out = p;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_decoder_destroy(htkamd_decoder *d)
+{
+   if (!d) return;
+   for (void *p : d->owned) (void)hipFree(p);
+   delete d;
+}
+
+static float like_to_word(const htkamd_net_desc *nd, const htkamd_model *m, const std::vector<unsigned char> &tee, int n, float scale)
+{
+   float best = (float)LZERO;
+   for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) {
+      const int dst = nd->linkDest[k];
+      const bool zt = nd->kind[dst] != HTKAMD_NODE_HMM || tee[dst];
+      if (!zt) continue;
+      float like = nd->linkLike[k] * scale;
+      if (like <= best) continue;
+      if (nd->kind[dst] != HTKAMD_NODE_HMM) { if (like > best) best = like; }
+      else {
+         const int ti = m->h_hmmTrans[nd->model[dst]], NS = m->h_transN[ti];
+         like += m->h_transP[m->h_transOff[ti] + (NS - 1)];
+         like += like_to_word(nd, m, tee, dst, scale);
+         if (like > best) best = like;
+      }
+   }
+   return best;
+}
+
+extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd, float lmScale, htkamd_decoder **out)
+{
+   if (!m || !nd || !out) { htkamd_set_error("decoder_create: NULL argument"); return HTKAMD_EINVAL; }
+   const int nN = nd->nNodes;
+   std::vector<int> kind(nd->kind, nd->kind + nN), model(nd->model, nd->model + nN), tok0(nN), nodeN(nN, 2), nodeTp(nN, 0), nodeSt(nN, 0), wordIdx(nN, -1), hmmNodes;
+   std::vector<float> pron(nd->pronProb, nd->pronProb + nN), wdlk(nN, (float)LZERO);
+   std::vector<unsigned char> tee(nN, 0);
+   std::vector<int> stateSlot(m->S, -1), wordNode;
+   htkamd_decoder *d = new htkamd_decoder();
+   d->m = m; d->d_usedStates = nullptr;
+   int nTok = 0, nW = 0;
+   for (int n = 0; n < nN; n++) {
+      tok0[n] = nTok;
+      if (kind[n] == HTKAMD_NODE_HMM) {
+         const int h = model[n];
+         if (h < 0 || h >= m->H) { htkamd_set_error("decoder_create: node %d names model %d of %d", n, h, m->H); delete d; return HTKAMD_EINVAL; }
+         const int ti = m->h_hmmTrans[h], NS = m->h_transN[ti];
+         if (NS > DEC_MAXN) { htkamd_set_error("decoder_create: model with %d states (max %d)", NS, DEC_MAXN); delete d; return HTKAMD_EMODEL; }
+         nodeN[n] = NS; nodeTp[n] = m->h_transOff[ti]; nodeSt[n] = m->h_hmmStateOff[h];
+         tee[n] = m->h_transP[m->h_transOff[ti] + (NS - 1)] > (float)LSMALL;
+         nTok += NS - 1;
+         hmmNodes.push_back(n);
+         for (int j = 0; j < NS - 2; j++) {
+            const int s = m->h_hmmState[m->h_hmmStateOff[h] + j];
+            if (stateSlot[s] < 0) { stateSlot[s] = (int)d->usedStates.size(); d->usedStates.push_back(s); }
+         }
+      } else {
+         nTok += 1;
+         if (kind[n] == HTKAMD_NODE_WORD) { wordIdx[n] = nW++; wordNode.push_back(n); }
+      }
+   }
+   // reverse CSR in source-node order
+   std::vector<int> predOff(nN + 1, 0), predSrc(nd->nLinks);
+   std::vector<float> predLike(nd->nLinks);
+   for (int k = 0; k < nd->nLinks; k++) predOff[nd->linkDest[k] + 1]++;
+   for (int n = 0; n < nN; n++) predOff[n + 1] += predOff[n];
+   {
+      std::vector<int> fill(predOff.begin(), predOff.end() - 1);
+      for (int n = 0; n < nN; n++)
+         for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) { const int at = fill[nd->linkDest[k]]++; predSrc[at] = n; predLike[at] = nd->linkLike[k]; }
+   }
+   // levels of the zero-time sub-graph
+   auto zt = [&](int n) { return kind[n] != HTKAMD_NODE_HMM || tee[n]; };
+   std::vector<int> level(nN, -1), indeg(nN, 0), queue;
+   for (int n = 0; n < nN; n++) if (zt(n)) for (int k = predOff[n]; k < predOff[n + 1]; k++) if (zt(predSrc[k])) indeg[n]++;
+   for (int n = 0; n < nN; n++) if (zt(n) && indeg[n] == 0) { level[n] = 0; queue.push_back(n); }
+   int nLevels = 0;
+   for (size_t qi = 0; qi < queue.size(); qi++) {
+      const int n = queue[qi];
+      if (level[n] + 1 > nLevels) nLevels = level[n] + 1;
+      for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) {
+         const int dst = nd->linkDest[k];
+         if (!zt(dst)) continue;
+         if (level[n] + 1 > level[dst]) level[dst] = level[n] + 1;
+         if (--indeg[dst] == 0) queue.push_back(dst);
+      }
+   }
+   { int nz = 0; for (int n = 0; n < nN; n++) if (zt(n)) nz++;
+     if ((int)queue.size() != nz) { htkamd_set_error("decoder_create: the network has a loop of word/null/tee nodes"); delete d; return HTKAMD_EMODEL; } }
+   std::vector<int> levelOff(nLevels + 1, 0), levelWide(nLevels, 0), levelNodes;
+   for (int L = 0; L < nLevels; L++) {
+      levelOff[L] = (int)levelNodes.size();
+      for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] < DEC_WIDE) levelNodes.push_back(n);
+      levelWide[L] = (int)levelNodes.size();
+      for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] >= DEC_WIDE) {
+         if (kind[n] == HTKAMD_NODE_HMM) { htkamd_set_error("decoder_create: tee model with %d predecessors", predOff[n + 1] - predOff[n]); delete d; return HTKAMD_EMODEL; }
+         levelNodes.push_back(n);
+      }
+   }
+   levelOff[nLevels] = (int)levelNodes.size();
+   for (int n = 0; n < nN; n++) {
+      bool wd0 = false;
+      if (kind[n] == HTKAMD_NODE_HMM) for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) if (kind[nd->linkDest[k]] != HTKAMD_NODE_HMM) wd0 = true;
+      if (wd0) wdlk[n] = like_to_word(nd, m, tee, n, lmScale);
+   }
+   DecNet &N = d->net;
+   memset(&N, 0, sizeof(N));
+   N.nNodes = nN; N.nHmm = (int)hmmNodes.size(); N.nLevels = nLevels; N.nWordNodes = nW > 0 ? nW : 1; N.initial = nd->initial; N.final = nd->final; N.nTok = nTok;
+   int rc;
+   if ((rc = upv(d, kind, &N.kind)) || (rc = upv(d, model, &N.model)) || (rc = upv(d, pron, &N.pronProb)) || (rc = upv(d, predOff, &N.predOff)) ||
+       (rc = upv(d, predSrc, &N.predSrc)) || (rc = upv(d, predLike, &N.predLike)) || (rc = upv(d, tok0, &N.tok0)) || (rc = upv(d, hmmNodes, &N.hmmNodes)) ||
+       (rc = upv(d, nodeN, &N.nodeN)) || (rc = upv(d, nodeTp, &N.nodeTp)) || (rc = upv(d, nodeSt, &N.nodeSt)) || (rc = upv(d, tee, &N.nodeTee)) ||
+       (rc = upv(d, wdlk, &N.wdlk)) || (rc = upv(d, wordIdx, &N.wordIdx)) || (rc = upv(d, levelOff, &N.levelOff)) || (rc = upv(d, levelNodes, &N.levelNodes)) ||
+       (rc = upv(d, levelWide, &N.levelWide)) || (rc = upv(d, stateSlot, &N.stateSlot)) || (rc = upv(d, wordNode, &N.wordNode))) { htkamd_decoder_destroy(d); return rc; }
+   {
+      std::vector<int> hs(m->h_hmmState, m->h_hmmState + m->h_hmmStateOff[m->H]);
+      if ((rc = upv(d, hs, &N.hmmState))) { htkamd_decoder_destroy(d); return rc; }
+      const int *us = nullptr;
+      if ((rc = upv(d, d->usedStates, &us))) { htkamd_decoder_destroy(d); return rc; }
+      d->d_usedStates = (int *)us;
+   }
+   N.transP = m->d_transP;
+   *out = d;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
+                                  int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *total, void *stream)
+{
+   if (!d || !cfg || !frameOff || nUtt < 0 || maxWords < 1 || !nWords || !wordPron || !wordStart || !wordEnd || !wordScore || !total) {
+      htkamd_set_error("decoder_run: bad argument"); return HTKAMD_EINVAL;
+   }
+   if (nUtt == 0) return HTKAMD_OK;
+   hipStream_t s = (hipStream_t)stream;
+   htkamd_model *m = d->m;
+   const DecNet &N = d->net;
+   const int ns = (int)d->usedStates.size();
+   const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
+   // chunk the batch so that the per-utterance work space (scores, tokens, path table) stays under ~24 GB
+   int u0 = 0;
+   while (u0 < nUtt) {
+      size_t bytes = 0; int u1 = u0;
+      while (u1 < nUtt) {
+         const size_t T = (size_t)(frameOff[u1 + 1] - frameOff[u1]);
+         const size_t b = (size_t)ns * T * 4 + (size_t)N.nTok * 16 + (size_t)N.nNodes * 24 + (T + 1) * (size_t)N.nWordNodes * 16;
+         if (u1 > u0 && bytes + b > ((size_t)24 << 30)) break;
+         bytes += b; u1++;
+      }
+      const int nu = u1 - u0;
+      std::vector<DecUtt> utt(nu);
+      std::vector<ScoreTask> tasks;
+      size_t score = 0, tok = 0, node = 0, path = 0;
+      for (int k = 0; k < nu; k++) {
+         DecUtt &ud = utt[k];
+         ud.T = frameOff[u0 + k + 1] - frameOff[u0 + k]; ud.frame0 = frameOff[u0 + k]; ud.status = HTKAMD_UTT_OK; ud.pad = 0;
+         ud.score0 = score; ud.tok0 = tok; ud.node0 = node; ud.path0 = path; ud.out0 = (size_t)k * maxWords;
+         for (int ti = 0; ti * FR < ud.T; ti++)
+            for (int ch = 0; ch * SL < ns; ch++) {
+               ScoreTask tk;
+               tk.frame0 = ud.frame0 + ti * FR; tk.nFrames = std::min(FR, ud.T - ti * FR);
+               tk.slot0 = ch * SL; tk.nSlots = std::min(SL, ns - ch * SL); tk.outSlot0 = ch * SL; tk.ldo = ud.T;
+               tk.outBase = ud.score0 + (size_t)ti * FR;
+               tasks.push_back(tk);
+            }
+         score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += (size_t)(ud.T + 1) * N.nWordNodes;
+      }
+      void *dScore = nullptr, *dTokLike = nullptr, *dTokLm = nullptr, *dTokPath = nullptr, *dExLike = nullptr, *dExLm = nullptr, *dExPath = nullptr, *dImax = nullptr;
+      void *dPPrev = nullptr, *dPLike = nullptr, *dPLm = nullptr, *dUtt = nullptr, *dTasks = nullptr, *dOutI = nullptr, *dOutF = nullptr, *dTot = nullptr;
+      int rc = HTKAMD_OK;
+      auto A = [&](void **p, size_t n) { if (rc) return; hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) { htkamd_set_error("decoder_run: hipMalloc(%zu): %s", n, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; } };
+      A(&dScore, score * 4); A(&dTokLike, tok * 8); A(&dTokLm, tok * 4); A(&dTokPath, tok * 4);
+      A(&dExLike, node * 8); A(&dExLm, node * 4); A(&dExPath, node * 4); A(&dImax, node * 8);
+      A(&dPPrev, path * 4); A(&dPLike, path * 8); A(&dPLm, path * 4);
+      A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
+      A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * (size_t)nu * maxWords); A(&dTot, sizeof(double) * nu);
+      std::vector<int> hI; std::vector<float> hF; std::vector<double> hT;
+      if (!rc) {
+         hipError_t e;
+         if ((e = hipMemcpyAsync(dUtt, utt.data(), sizeof(DecUtt) * nu, hipMemcpyHostToDevice, s)) != hipSuccess ||
+             (e = hipMemcpyAsync(dTasks, tasks.data(), sizeof(ScoreTask) * tasks.size(), hipMemcpyHostToDevice, s)) != hipSuccess) {
+            htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP;
+         }
+      }
+      if (!rc) {
+         ScoreArgs sa;
+         sa.tasks = (const ScoreTask *)dTasks; sa.nTasks = (int)tasks.size(); sa.X = dX; sa.slotState = d->d_usedStates; sa.out = (float *)dScore;
+         sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
+         sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
+         sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)((char *)dTasks + sizeof(ScoreTask) * tasks.size());
+         sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff;
+         rc = htkamd_launch_score_exact(m, sa, s);           // exact scores: the decoded path must be the reference's
+      }
+      if (!rc) {
+         DecArgs a;
+         a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
+         a.tokLike = (double *)dTokLike; a.tokLm = (float *)dTokLm; a.tokPath = (int *)dTokPath;
+         a.exLike = (double *)dExLike; a.exLm = (float *)dExLm; a.exPath = (int *)dExPath; a.imax = (double *)dImax;
+         a.pathPrev = (int *)dPPrev; a.pathLike = (double *)dPLike; a.pathLm = (float *)dPLm;
+         a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
+         a.maxWords = maxWords;
+         int *oi = (int *)dOutI;
+         a.nWords = oi; a.wordPron = oi + nu; a.wordStart = a.wordPron + (size_t)nu * maxWords; a.wordEnd = a.wordStart + (size_t)nu * maxWords;
+         a.wordScore = (float *)dOutF; a.total = (double *)dTot;
+         hipLaunchKernelGGL(k_decode, dim3(nu), dim3(DEC_THREADS), 0, s, a);
+         hipError_t e = hipGetLastError();
+         if (e != hipSuccess) { htkamd_set_error("decoder_run: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+      }
+      if (!rc) {
+         hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords); hT.resize(nu);
+         hipError_t e;
+         if ((e = hipMemcpyAsync(hI.data(), dOutI, sizeof(int) * hI.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
+             (e = hipMemcpyAsync(hF.data(), dOutF, sizeof(float) * hF.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
+             (e = hipMemcpyAsync(hT.data(), dTot, sizeof(double) * nu, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+             (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+      } else (void)hipStreamSynchronize(s);
+      for (void *p : {dScore, dTokLike, dTokLm, dTokPath, dExLike, dExLm, dExPath, dImax, dPPrev, dPLike, dPLm, dUtt, dTasks, dOutI, dOutF, dTot}) (void)hipFree(p);
+      if (rc) return rc;
+      for (int k = 0; k < nu; k++) {
+         nWords[u0 + k] = hI[k]; total[u0 + k] = hT[k];
+         const size_t o = (size_t)(u0 + k) * maxWords, si = (size_t)k * maxWords;
+         for (int w = 0; w < maxWords; w++) {
+            wordPron[o + w] = hI[nu + si + w]; wordStart[o + w] = hI[nu + (size_t)nu * maxWords + si + w];
+            wordEnd[o + w] = hI[nu + (size_t)nu * maxWords * 2 + si + w]; wordScore[o + w] = hF[si + w];
+         }
+      }
+      u0 = u1;
+   }
+   return HTKAMD_OK;
+}

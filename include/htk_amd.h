@@ -335,6 +335,24 @@ const htkamd_net_desc *htkamd_net_get(const htkamd_net *n);
 const char *htkamd_net_out_sym(const htkamd_net *n, int pron);
 
 /* ------------------------------------------------------------------------------------------
+ * Network decoding of a batch (HVite -w net): replaces, per utterance, InitVRecInfo / StartRecognition /
+ * ProcessObservation / CompleteRecognition (HRec.h:150-190) with nToks = 1 and TranscriptionFromLattice (HRec.c:2176)
+ * for the word-level 1-best labels.  genBeam / wordBeam = HVite -t / -v (1e10 = off), lmScale -s, wordPen -p, prScale -r.
+ * LikeToWord look-ahead (HRec.c:1172) depends on the LM scale, hence lmScale at creation.
+ * Results per utterance u: nWords[u] (-1: no token reached the end of the network, -3: more than maxWords words), and for
+ * word w < nWords[u] at [u*maxWords + w]: pronunciation index (htkamd_net_out_sym), frames [start, end), score = LArcTotLike
+ * (acoustic + scaled LM + scaled pron prob + word penalty, HNet.h:257); total[u] = likelihood of the final token.
+ * Models of up to 8 states; tee models may not have more than 95 predecessors.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { float genBeam, wordBeam, lmScale, wordPen, prScale; } htkamd_decode_config;
+typedef struct htkamd_decoder htkamd_decoder;
+int  htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *net, float lmScale, htkamd_decoder **out);
+void htkamd_decoder_destroy(htkamd_decoder *d);
+int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
+                        int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *total,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Waveform -> MFCC(+_0/_E)(+_D)(+_A)(+_Z) on the device: replaces what OpenBuffer (HParm.h, HParm.c:4357)
  * does for a waveform source with maxObs == 0 (whole file converted into a table):
  *   GetWave HWave.c:1683 frame slicing; ConvertFrame HParm.c:2214 = PreEmphasise HSigP.c:134, Ham :122,

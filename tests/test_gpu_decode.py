@@ -1,0 +1,61 @@
+"""Network decoding on the device (K7, htkamd_decoder_*) against the reference's HVite label files (committed fixtures) and
+against the oracle: word sequences, frame boundaries and printed scores identical."""
+import numpy as np
+import pytest
+
+from decode_util import format_words, load_decode_case, parse_opts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["loop", "bigram", "tee"])
+def test_decoder_reproduces_hvite_label_files(native, oracle, case):
+    mmf, net, feats, expected = load_decode_case(native, case)
+    model = native.Model(mmf.packed())
+    om = oracle.Model(mmf.packed())
+    arrays = net.arrays()
+    for opts, per in expected.items():
+        p = parse_opts(opts)
+        dec = native.Decoder(model, net, lmScale=p["lmScale"])
+        res = dec.run(feats, **p)
+        for u, (words, total) in enumerate(res):
+            assert words is not None, (case, opts, u)
+            assert format_words(words, net.out_syms) == per["u%d" % u], (case, opts, u)
+            ow, ot = oracle.decode(om, feats[u], arrays, **p)
+            assert words == ow and total == ot                      # token likelihoods are the same doubles
+
+
+def test_decoder_larger_loop_matches_oracle(native, oracle, tmp_path):
+    """400 single-model words over 150 tied states x 4 mixtures (fan-in of the loop node > one wave), 6 ragged utterances, beam 120."""
+    from htk_amd import synth
+    s = synth.generate(150, 4, 400, 6, 90, 17, D=13)
+    d = tmp_path
+    synth.write_mmf(str(d / "MMF"), s, kind="USER")
+    names = ["p%d" % i for i in range(400)]
+    (d / "hmmlist").write_text("\n".join(names) + "\n")
+    (d / "dict").write_text("".join("%s %s\n" % (n, n) for n in names))
+    V = len(names)
+    with open(d / "net.slf", "w") as f:                             # the shape HBuild gives a word loop
+        f.write("VERSION=1.0\nN=%d L=%d\n" % (V + 4, 2 * V + 3))
+        f.write("I=0 W=!NULL\nI=1 W=!NULL\n")
+        for i, n in enumerate(names):
+            f.write("I=%d W=%s\n" % (2 + i, n))
+        f.write("I=%d W=!NULL\nI=%d W=!NULL\n" % (V + 2, V + 3))
+        j = 0
+        f.write("J=%d S=0 E=1 l=0.00\n" % j); j += 1
+        f.write("J=%d S=%d E=1 l=0.00\n" % (j, V + 2)); j += 1
+        for i in range(V):
+            f.write("J=%d S=1 E=%d l=%.2f\n" % (j, 2 + i, np.log(1.0 / V))); j += 1
+            f.write("J=%d S=%d E=%d l=0.00\n" % (j, 2 + i, V + 2)); j += 1
+        f.write("J=%d S=%d E=%d l=0.00\n" % (j, V + 2, V + 3))
+    mmf = native.Mmf(files=[str(d / "MMF")], hmm_list=str(d / "hmmlist"))
+    net = native.Net(str(d / "net.slf"), str(d / "dict"), mmf)
+    feats = [f[: 90 - 7 * u] for u, f in enumerate(s.feats)]
+    model = native.Model(mmf.packed()); om = oracle.Model(mmf.packed())
+    res = native.Decoder(model, net).run(feats, genBeam=120.0)
+    for u, (words, total) in enumerate(res):
+        ow, ot = oracle.decode(om, feats[u], net.arrays(), genBeam=120.0)
+        assert words == ow and total == ot and len(words) >= 3
+    # an impossible utterance (shorter than any path through the network) reports "no token survived"
+    short = native.Decoder(model, net).run([s.feats[0][:2]], genBeam=120.0)
+    assert short[0][0] is None
