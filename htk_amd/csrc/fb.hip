@@ -6,6 +6,11 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <thread>
+#include <chrono>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
@@ -13,8 +18,11 @@
 struct DevBuf {
    void *p = nullptr;
    size_t cap = 0;
+   bool view = false;            // p points into another allocation (the batch-table arena)
+   void set_view(void *q) { if (p && !view) (void)hipFree(p); p = q; cap = 0; view = true; }
    int reserve(size_t bytes)
    {
+      if (view) { p = nullptr; view = false; cap = 0; }
       if (bytes <= cap) return HTKAMD_OK;
       if (p) (void)hipFree(p);
       p = nullptr; cap = 0;
@@ -24,7 +32,75 @@ struct DevBuf {
       cap = want;
       return HTKAMD_OK;
    }
-   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+   void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
+};
+
+// Small persistent worker pool for the host-side batch preparation (thread creation costs more than a share's work).
+struct PrepPool {
+   std::vector<std::thread> th;
+   std::mutex mu;
+   std::condition_variable cvGo, cvDone;
+   std::function<void(int)> job;
+   int generation = 0, pending = 0, nJobs = 0;
+   bool quit = false;
+   void start(int n)
+   {
+      for (int k = 0; k < n; k++)
+         th.emplace_back([this, k]() {
+            int seen = 0;
+            for (;;) {
+               std::function<void(int)> f;
+               {
+                  std::unique_lock<std::mutex> lk(mu);
+                  cvGo.wait(lk, [&] { return quit || generation != seen; });
+                  if (quit) return;
+                  seen = generation;
+                  if (k + 1 >= nJobs) { if (--pending == 0) cvDone.notify_one(); continue; }
+                  f = job;
+               }
+               f(k + 1);                                   // share 0 runs on the calling thread
+               std::unique_lock<std::mutex> lk(mu);
+               if (--pending == 0) cvDone.notify_one();
+            }
+         });
+   }
+   // runs f(0..n-1); f(0) on the caller
+   void run(int n, const std::function<void(int)> &f)
+   {
+      if (n <= 1 || th.empty()) { for (int k = 0; k < n; k++) f(k); return; }
+      {
+         std::unique_lock<std::mutex> lk(mu);
+         job = f; nJobs = n; pending = (int)th.size(); generation++;
+      }
+      cvGo.notify_all();
+      f(0);
+      std::unique_lock<std::mutex> lk(mu);
+      cvDone.wait(lk, [&] { return pending == 0; });
+   }
+   ~PrepPool()
+   {
+      { std::unique_lock<std::mutex> lk(mu); quit = true; }
+      cvGo.notify_all();
+      for (auto &t : th) t.join();
+   }
+};
+
+// One worker's share of a batch: the tables of a contiguous range of utterances with offsets relative to the share.
+struct PrepChunk {
+   std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
+   std::vector<short> cQ, cI, thrCell;
+   std::vector<ScoreTask> tasks;
+   std::vector<int> evLo, evHi, slotModel;
+   size_t outp = 0, beta = 0, gam = 0;
+   long long frameStates = 0;
+   int nCellsMax = 1, QMax = 1, TMax = 1, nThrMax = 64, rc = HTKAMD_OK;
+   char err[256] = "";
+   void reset()                                          // keeps the vectors' capacity from batch to batch
+   {
+      mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear();
+      cQ.clear(); cI.clear(); thrCell.clear(); tasks.clear();
+      outp = beta = gam = 0; frameStates = 0; nCellsMax = QMax = TMax = 1; nThrMax = 64; rc = HTKAMD_OK; err[0] = 0;
+   }
 };
 
 struct htkamd_fb {
@@ -45,9 +121,11 @@ struct htkamd_fb {
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
-   DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell;
-   hipEvent_t ev[5];
-   bool evValid, timed;
+   DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena;
+   PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
+   void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
+   hipEvent_t ev[5], evCopy;
+   bool evValid, timed, copyPending;
 };
 
 extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
@@ -55,12 +133,13 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false;
-   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false;
+   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) {
       hipError_t e = hipEventCreate(&fb->ev[i]);
       if (e != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate: %s", hipGetErrorString(e)); delete fb; return HTKAMD_EHIP; }
    }
+   if (hipEventCreateWithFlags(&fb->evCopy, hipEventDisableTiming) != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate failed"); delete fb; return HTKAMD_EHIP; }
    fb->evValid = true;
    int rc;
    if ((rc = fb->d_counter.reserve(64)) || (rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { delete fb; return rc; }
@@ -76,9 +155,11 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell};
+                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena};
    for (DevBuf *b : all) b->release();
-   if (fb->evValid) for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]);
+   if (fb->h_arena) (void)hipHostFree(fb->h_arena);
+   delete fb->pool; delete fb->chunks;
+   if (fb->evValid) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]); (void)hipEventDestroy(fb->evCopy); }
    delete fb;
 }
 
@@ -98,80 +179,62 @@ template <typename T> static int upload(DevBuf &b, const std::vector<T> &v, hipS
    return HTKAMD_OK;
 }
 
-// CreateInsts (HFB.c:508-574) + SetBeamTaper (HFB.c:1116-1145) for every utterance of the batch,
-// and the flat tables the kernels index.
-extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void *stream)
+// CreateInsts (HFB.c:508-574) + SetBeamTaper (HFB.c:1116-1145) + the scoring tasks of utterance u, appended to chunk C.
+static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, PrepChunk &C)
 {
-   if (!fb || !b || b->nUtt < 0 || (b->nUtt > 0 && (!b->dX || !b->frameOff || !b->labOff || !b->labs))) {
-      htkamd_set_error("fb_prepare: bad argument"); return HTKAMD_EINVAL;
-   }
    const htkamd_model *m = fb->m;
-   hipStream_t s = (hipStream_t)stream;
-   const int U = b->nUtt;
-   fb->nUtt = U; fb->dX = b->dX;
-   fb->utt.assign(U, UttDesc());
-   fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
-   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->thrCell.clear();
-   int nThrMax = 64;
-   fb->totalFrames = U ? b->frameOff[U] : 0;
-   fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
-   fb->gamOff.assign(U + 1, 0);
-   fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1;
-   fb->frameStates = 0;
-   size_t outp = 0, beta = 0, gam = 0;
-   std::vector<int> evLo, evHi, slotModel;
-   for (int u = 0; u < U; u++) {
+   std::vector<int> &evLo = C.evLo, &evHi = C.evHi, &slotModel = C.slotModel;
       UttDesc &d = fb->utt[u];
       const int T = b->frameOff[u + 1] - b->frameOff[u], Q = b->labOff[u + 1] - b->labOff[u];
       const int *labs = b->labs + b->labOff[u];
       d.T = T; d.Q = Q; d.frame0 = b->frameOff[u];
-      d.q0 = (int)fb->mN.size(); d.cell0 = (int)fb->cQ.size(); d.slot0 = (int)fb->slotState.size();
+      d.q0 = (int)C.mN.size(); d.cell0 = (int)C.cQ.size(); d.slot0 = (int)C.slotState.size();
       d.status = HTKAMD_UTT_OK; d.nEval = 0;
-      d.outp0 = outp; d.beta0 = beta; d.gam0 = gam;
-      fb->gamOff[u] = gam;
-      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nCells = d.nSlots = 0; d.thr0 = (int)fb->thrCell.size(); d.nThr = 0; continue; }
+      d.outp0 = C.outp; d.beta0 = C.beta; d.gam0 = C.gam;
+      
+      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nCells = d.nSlots = 0; d.thr0 = (int)C.thrCell.size(); d.nThr = 0; return HTKAMD_OK; }
       int nCells = 0, nSlots = 0, qt = 0, prevDm = 1;
       for (int q = 1; q <= Q; q++) {
          const int h = labs[q - 1];
-         if (h < 0 || h >= m->H) { htkamd_set_error("fb_prepare: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
+         if (h < 0 || h >= m->H) { snprintf(C.err, sizeof(C.err), "fb_prepare: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
          const int ti = m->h_hmmTrans[h], N = m->h_transN[ti], dm = m->h_minDur[ti];
-         fb->mN.push_back(N); fb->mTp.push_back(m->h_transOff[ti]); fb->mCell0.push_back(nCells); fb->mSlot0.push_back(nSlots);
-         fb->mDms.push_back(dm); fb->mHmm.push_back(h); fb->mTrans.push_back(ti);
-         for (int i = 1; i <= N; i++) { fb->cQ.push_back((short)q); fb->cI.push_back((short)i); }
-         for (int j = 2; j < N; j++) fb->slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]);
+         C.mN.push_back(N); C.mTp.push_back(m->h_transOff[ti]); C.mCell0.push_back(nCells); C.mSlot0.push_back(nSlots);
+         C.mDms.push_back(dm); C.mHmm.push_back(h); C.mTrans.push_back(ti);
+         for (int i = 1; i <= N; i++) { C.cQ.push_back((short)q); C.cI.push_back((short)i); }
+         for (int j = 2; j < N; j++) C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]);
          nCells += N; nSlots += N - 2; qt += dm;
          if (q > 1 && dm == 0 && prevDm == 0) d.status = HTKAMD_UTT_ETEE;      // successive tee models (HFB.c:557)
          prevDm = dm;
       }
-      if (fb->mDms[d.q0] == 0 || fb->mDms[d.q0 + Q - 1] == 0) d.status = HTKAMD_UTT_ETEE;   // HFB.c:564
+      if (C.mDms[d.q0] == 0 || C.mDms[d.q0 + Q - 1] == 0) d.status = HTKAMD_UTT_ETEE;   // HFB.c:564
       if (d.status == HTKAMD_UTT_OK && qt > T) d.status = HTKAMD_UTT_SKIPPED;                 // HFB.c:1339
       d.nCells = nCells; d.nSlots = nSlots;
       {  // thread map: entry cells | emitting cells | exit cells, each group padded to a multiple of 64
-         d.thr0 = (int)fb->thrCell.size();
+         d.thr0 = (int)C.thrCell.size();
          for (int role = 0; role < 3; role++) {
             for (int q = 1; q <= Q; q++) {
-               const int c0 = fb->mCell0[d.q0 + q - 1], N = fb->mN[d.q0 + q - 1];
-               if (role == 0) fb->thrCell.push_back((short)c0);
-               else if (role == 2) fb->thrCell.push_back((short)(c0 + N - 1));
-               else for (int i = 2; i < N; i++) fb->thrCell.push_back((short)(c0 + i - 1));
+               const int c0 = C.mCell0[d.q0 + q - 1], N = C.mN[d.q0 + q - 1];
+               if (role == 0) C.thrCell.push_back((short)c0);
+               else if (role == 2) C.thrCell.push_back((short)(c0 + N - 1));
+               else for (int i = 2; i < N; i++) C.thrCell.push_back((short)(c0 + i - 1));
             }
-            while ((fb->thrCell.size() - d.thr0) % 64) fb->thrCell.push_back((short)-1);
+            while ((C.thrCell.size() - d.thr0) % 64) C.thrCell.push_back((short)-1);
          }
-         d.nThr = (int)fb->thrCell.size() - d.thr0;
-         if (d.nThr > nThrMax) nThrMax = d.nThr;
+         d.nThr = (int)C.thrCell.size() - d.thr0;
+         if (d.nThr > C.nThrMax) C.nThrMax = d.nThr;
       }
       if (Q > 32000 || d.nThr > 1024) {
-         htkamd_set_error("fb_prepare: utterance %d has %d model states; the device path handles up to 1024 per utterance", u, nCells);
+         snprintf(C.err, sizeof(C.err), "fb_prepare: utterance %d has %d model states; the device path handles up to 1024 per utterance", u, nCells);
          return HTKAMD_EINVAL;
       }
-      if (nCells > fb->nCellsMax) fb->nCellsMax = nCells;
-      if (Q > fb->QMax) fb->QMax = Q;
-      if (T > fb->TMax) fb->TMax = T;
-      outp += (size_t)T * nSlots; beta += (size_t)T * nCells; gam += (size_t)T * nSlots;
-      if (d.status != HTKAMD_UTT_OK) continue;
+      if (nCells > C.nCellsMax) C.nCellsMax = nCells;
+      if (Q > C.QMax) C.QMax = Q;
+      if (T > C.TMax) C.TMax = T;
+      C.outp += (size_t)T * nSlots; C.beta += (size_t)T * nCells; C.gam += (size_t)T * nSlots;
+      if (d.status != HTKAMD_UTT_OK) return HTKAMD_OK;
       // SetBeamTaper
       short *lo = fb->taperLo.data() + d.frame0 - 1, *hi = fb->taperHi.data() + d.frame0 - 1;
-      const int *dms = fb->mDms.data() + d.q0 - 1;                         // 1-based q
+      const int *dms = C.mDms.data() + d.q0 - 1;                         // 1-based q
       {
          int q = 1, dq = dms[q], i = 0;
          for (int t = 1; t <= T; t++) {
@@ -188,30 +251,30 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       // They bound what any pass can touch (pruning only narrows them) and give the metric's unit count.
       evLo.assign(T + 2, 0); evHi.assign(T + 2, 0);
       {
-         const long long before = fb->frameStates;
+         const long long before = C.frameStates;
          int qHiN = Q, qLoN = lo[T];
-         const int *msl = fb->mSlot0.data() + d.q0 - 1;
+         const int *msl = C.mSlot0.data() + d.q0 - 1;
          auto slotsIn = [&](int a, int z) { return (z < Q ? msl[z + 1] : nSlots) - msl[a]; };
          evLo[T] = qLoN > 1 ? qLoN - 1 : 1; evHi[T] = Q;
-         fb->frameStates += slotsIn(evLo[T], Q);
+         C.frameStates += slotsIn(evLo[T], Q);
          for (int t = T - 1; t >= 1; t--) {
             const int startq = qHiN;
             int endq = (qLoN == 1) ? 1 : ((lo[t] >= qLoN) ? lo[t] : qLoN - 1);
             while (endq > 1 && dms[endq - 1] == 0) endq--;
             evLo[t] = endq > 1 ? endq - 1 : 1; evHi[t] = startq;
-            fb->frameStates += slotsIn(evLo[t], startq);
+            C.frameStates += slotsIn(evLo[t], startq);
             qHiN = (hi[t] < startq) ? hi[t] : startq; qLoN = endq;
          }
-         d.nEval = (int)(fb->frameStates - before);
+         d.nEval = (int)(C.frameStates - before);
       }
       // scoring tasks: chunks of chain states x tiles of the frames in which the chunk can be in the beam
       {
-         const short *cq = fb->cQ.data() + d.cell0;
+         const short *cq = C.cQ.data() + d.cell0;
          (void)cq;
          // model of every slot
          slotModel.resize(nSlots);
          for (int q = 1; q <= Q; q++) {
-            const int s0 = fb->mSlot0[d.q0 + q - 1], n = fb->mN[d.q0 + q - 1] - 2;
+            const int s0 = C.mSlot0[d.q0 + q - 1], n = C.mN[d.q0 + q - 1] - 2;
             for (int j = 0; j < n; j++) slotModel[s0 + j] = q;
          }
          for (int k0 = 0; k0 < nSlots; k0 += SCORE_TASK_SLOTS) {
@@ -228,22 +291,119 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
                tk.nSlots = k1 - k0;
                tk.outSlot0 = k0; tk.ldo = T;
                tk.outBase = d.outp0 + (size_t)t0;
-               fb->tasks.push_back(tk);
+               C.tasks.push_back(tk);
             }
          }
       }
+   return HTKAMD_OK;
+}
+
+// CreateInsts (HFB.c:508-574) + SetBeamTaper (HFB.c:1116-1145) for every utterance of the batch,
+// and the flat tables the kernels index.  The utterances are independent: host threads take contiguous shares and the
+// shares are concatenated with their offsets rebased (the reference does this work inside its per-file loop).
+extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void *stream)
+{
+   if (!fb || !b || b->nUtt < 0 || (b->nUtt > 0 && (!b->dX || !b->frameOff || !b->labOff || !b->labs))) {
+      htkamd_set_error("fb_prepare: bad argument"); return HTKAMD_EINVAL;
+   }
+   hipStream_t s = (hipStream_t)stream;
+   const int U = b->nUtt;
+   static const bool timing = getenv("HTKAMD_PREP_TIMING") != nullptr;
+   auto tp0 = std::chrono::steady_clock::now();
+   auto lap = [&](const char *what) { if (!timing) return; auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "  prepare %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
+   fb->nUtt = U; fb->dX = b->dX;
+   fb->utt.assign(U, UttDesc());
+   fb->totalFrames = U ? b->frameOff[U] : 0;
+   fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
+   fb->gamOff.assign(U + 1, 0);
+   if (!fb->pool) {
+      int hw = (int)std::thread::hardware_concurrency();
+      if (hw > 16) hw = 16;
+      if (hw < 1) hw = 1;
+      fb->pool = new PrepPool();
+      fb->pool->start(hw - 1);
+      fb->chunks = new std::vector<PrepChunk>(hw);
+   }
+   int nW = (int)fb->chunks->size();
+   if (nW > U / 32) nW = U / 32;
+   if (nW < 1) nW = 1;
+   std::vector<PrepChunk> &chunks = *fb->chunks;
+   fb->pool->run(nW, [&](int k) {
+      PrepChunk &C = chunks[k];
+      C.reset();
+      const int u0 = (int)((long long)U * k / nW), u1 = (int)((long long)U * (k + 1) / nW);
+      for (int u = u0; u < u1; u++)
+         if ((C.rc = prep_utterance(fb, b, u, C))) return;
+   });
+   lap("workers");
+   for (int k = 0; k < nW; k++) if (chunks[k].rc) { htkamd_set_error("%s", chunks[k].err); return chunks[k].rc; }
+   // concatenate the shares, rebasing their offsets
+   fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
+   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->thrCell.clear();
+   fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1; fb->frameStates = 0;
+   int nThrMax = 64;
+   size_t outp = 0, beta = 0, gam = 0;
+   for (int k = 0; k < nW; k++) {
+      PrepChunk &C = chunks[k];
+      const int u0 = (int)((long long)U * k / nW), u1 = (int)((long long)U * (k + 1) / nW);
+      const int bQ = (int)fb->mN.size(), bCell = (int)fb->cQ.size(), bSlot = (int)fb->slotState.size(), bThr = (int)fb->thrCell.size();
+      for (int u = u0; u < u1; u++) {
+         UttDesc &d = fb->utt[u];
+         d.q0 += bQ; d.cell0 += bCell; d.slot0 += bSlot; d.thr0 += bThr; d.outp0 += outp; d.beta0 += beta; d.gam0 += gam;
+         fb->gamOff[u] = d.gam0;
+      }
+      for (ScoreTask &tk : C.tasks) { tk.slot0 += bSlot; tk.outBase += outp; }
+      auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
+      app(fb->mN, C.mN); app(fb->mTp, C.mTp); app(fb->mCell0, C.mCell0); app(fb->mSlot0, C.mSlot0); app(fb->mDms, C.mDms); app(fb->mHmm, C.mHmm);
+      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks);
+      outp += C.outp; beta += C.beta; gam += C.gam;
+      fb->frameStates += C.frameStates;
+      if (C.nCellsMax > fb->nCellsMax) fb->nCellsMax = C.nCellsMax;
+      if (C.QMax > fb->QMax) fb->QMax = C.QMax;
+      if (C.TMax > fb->TMax) fb->TMax = C.TMax;
+      if (C.nThrMax > nThrMax) nThrMax = C.nThrMax;
    }
    fb->gamOff[U] = gam;
    fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
    fb->blockDim = nThrMax;
 
+   lap("merge");
    int rc;
-   if ((rc = upload(fb->d_utt, fb->utt, s)) || (rc = upload(fb->d_mN, fb->mN, s)) || (rc = upload(fb->d_mTp, fb->mTp, s)) ||
-       (rc = upload(fb->d_mCell0, fb->mCell0, s)) || (rc = upload(fb->d_mSlot0, fb->mSlot0, s)) || (rc = upload(fb->d_mDms, fb->mDms, s)) ||
-       (rc = upload(fb->d_mHmm, fb->mHmm, s)) || (rc = upload(fb->d_mTrans, fb->mTrans, s)) || (rc = upload(fb->d_slotState, fb->slotState, s)) ||
-       (rc = upload(fb->d_cQ, fb->cQ, s)) || (rc = upload(fb->d_thrCell, fb->thrCell, s)) || (rc = upload(fb->d_cI, fb->cI, s)) || (rc = upload(fb->d_taperLo, fb->taperLo, s)) ||
-       (rc = upload(fb->d_taperHi, fb->taperHi, s)) || (rc = upload(fb->d_tasks, fb->tasks, s)) || (rc = upload(fb->d_gamOff, fb->gamOff, s)))
-      return rc;
+   {
+      // all tables through one pinned staging buffer and ONE host-to-device copy
+      struct Part { DevBuf *dst; const void *src; size_t bytes, off; };
+      Part parts[] = {
+         {&fb->d_utt, fb->utt.data(), sizeof(UttDesc) * fb->utt.size(), 0}, {&fb->d_mN, fb->mN.data(), sizeof(int) * fb->mN.size(), 0},
+         {&fb->d_mTp, fb->mTp.data(), sizeof(int) * fb->mTp.size(), 0}, {&fb->d_mCell0, fb->mCell0.data(), sizeof(int) * fb->mCell0.size(), 0},
+         {&fb->d_mSlot0, fb->mSlot0.data(), sizeof(int) * fb->mSlot0.size(), 0}, {&fb->d_mDms, fb->mDms.data(), sizeof(int) * fb->mDms.size(), 0},
+         {&fb->d_mHmm, fb->mHmm.data(), sizeof(int) * fb->mHmm.size(), 0}, {&fb->d_mTrans, fb->mTrans.data(), sizeof(int) * fb->mTrans.size(), 0},
+         {&fb->d_slotState, fb->slotState.data(), sizeof(int) * fb->slotState.size(), 0}, {&fb->d_cQ, fb->cQ.data(), sizeof(short) * fb->cQ.size(), 0},
+         {&fb->d_thrCell, fb->thrCell.data(), sizeof(short) * fb->thrCell.size(), 0}, {&fb->d_cI, fb->cI.data(), sizeof(short) * fb->cI.size(), 0},
+         {&fb->d_taperLo, fb->taperLo.data(), sizeof(short) * fb->taperLo.size(), 0}, {&fb->d_taperHi, fb->taperHi.data(), sizeof(short) * fb->taperHi.size(), 0},
+         {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0}};
+      size_t total = 0;
+      for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
+      if (total == 0) total = 256;
+      if (total > fb->h_arenaCap) {
+         if (fb->h_arena) (void)hipHostFree(fb->h_arena);
+         fb->h_arena = nullptr; fb->h_arenaCap = 0;
+         const size_t want = total + total / 4;
+         HIPCHECK(hipHostMalloc(&fb->h_arena, want, hipHostMallocDefault));
+         fb->h_arenaCap = want;
+      }
+      if (fb->copyPending) { HIPCHECK(hipEventSynchronize(fb->evCopy)); fb->copyPending = false; }   // previous batch still in flight
+      for (Part &q : parts) q.dst->release();
+      if ((rc = fb->d_arena.reserve(total))) return rc;
+      for (Part &q : parts) {
+         if (q.bytes) memcpy((char *)fb->h_arena + q.off, q.src, q.bytes);
+         q.dst->set_view((char *)fb->d_arena.p + q.off);
+      }
+      HIPCHECK(hipMemcpyAsync(fb->d_arena.p, fb->h_arena, total, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipEventRecord(fb->evCopy, s));
+      fb->copyPending = true;
+   }
+   lap("stage+copy");
    const size_t nf = fb->totalFrames ? fb->totalFrames : 1;
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
@@ -252,8 +412,9 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
        (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))))
       return rc;
    if (fb->debug && (rc = fb->d_alpha.reserve(sizeof(double) * (beta ? beta : 1)))) return rc;
-   // the source vectors must outlive the async copies
-   HIPCHECK(hipStreamSynchronize(s));
+   lap("reserve");
+   // no synchronisation here: the copy is stream-ordered before the kernels of execute, and the staging buffer is
+   // guarded by evCopy against being refilled while the copy is still in flight
    return HTKAMD_OK;
 }
 
