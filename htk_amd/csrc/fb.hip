@@ -114,6 +114,7 @@ struct htkamd_fb {
    std::vector<short> cQ, cI, taperLo, taperHi, thrCell;
    std::vector<ScoreTask> tasks;
    std::vector<size_t> gamOff;
+   std::vector<int> gamChunkUtt;
    size_t outpTotal, betaTotal, gamTotal;
    int totalFrames, nCellsMax, QMax, TMax, blockDim;
    long long frameStates;
@@ -121,7 +122,7 @@ struct htkamd_fb {
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
-   DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena;
+   DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
    hipEvent_t ev[5], evCopy;
@@ -155,7 +156,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena};
+                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -365,6 +366,15 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       if (C.nThrMax > nThrMax) nThrMax = C.nThrMax;
    }
    fb->gamOff[U] = gam;
+   {  // utterance of every 512th seed (k_mixstats' scan chunks)
+      const size_t nChunk = (gam + 511) / 512;
+      fb->gamChunkUtt.assign(nChunk ? nChunk : 1, 0);
+      int u = 0;
+      for (size_t c = 0; c < nChunk; c++) {
+         while (u + 1 < U && fb->gamOff[u + 1] <= c * 512) u++;
+         fb->gamChunkUtt[c] = u;
+      }
+   }
    fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
    fb->blockDim = nThrMax;
 
@@ -381,7 +391,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_slotState, fb->slotState.data(), sizeof(int) * fb->slotState.size(), 0}, {&fb->d_cQ, fb->cQ.data(), sizeof(short) * fb->cQ.size(), 0},
          {&fb->d_thrCell, fb->thrCell.data(), sizeof(short) * fb->thrCell.size(), 0}, {&fb->d_cI, fb->cI.data(), sizeof(short) * fb->cI.size(), 0},
          {&fb->d_taperLo, fb->taperLo.data(), sizeof(short) * fb->taperLo.size(), 0}, {&fb->d_taperHi, fb->taperHi.data(), sizeof(short) * fb->taperHi.size(), 0},
-         {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0}};
+         {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
+         {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -457,7 +468,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.acc = accs->d_vec; fa.lay = accs->lay;
    fa.pruneInit = cfg->pruneInit; fa.pruneInc = cfg->pruneInc; fa.pruneLim = cfg->pruneLim;
    fa.minLogExp = m->minLogExp; fa.minFrwdP = cfg->minFrwdP; fa.uFlags = cfg->uFlags;
-   fa.gamTotal = fb->gamTotal; fa.gamOffByUtt = (const size_t *)fb->d_gamOff.p;
+   fa.gamTotal = fb->gamTotal; fa.gamOffByUtt = (const size_t *)fb->d_gamOff.p; fa.gamChunkUtt = (const int *)fb->d_gamChunkUtt.p;
 
    const size_t nc = fa.nCellsMax, qm = fa.QMax + 3, mn = m->maxN;
    auto r8 = [](size_t x) { return (x + 7) & ~(size_t)7; };

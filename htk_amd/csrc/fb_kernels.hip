@@ -19,6 +19,7 @@
 // with whole waves, recomputing the per-component likelihoods only for the ~2% of (frame,state)
 // pairs that survive the prune.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
@@ -532,16 +533,19 @@ __global__ void k_alpha(FbArgs a)
 // ------------------------------------------------------------------------------------ K4: mixture statistics
 // DT > 0: vector size known at compile time (all parameter loads of a component are issued together);
 // DT == 0: any size.
-template <int DT>
+template <int DT, int GS>
 __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
 {
+   // GS lanes per hit (GS >= max mixture count, a power of two): 64/GS hits are worked on side by side, lane%GS = component
+   constexpr int HPS = 64 / GS;
+   __shared__ unsigned short hitIdx[4][512];
+   __shared__ double hitSeed[4][512];
    const int lane = threadIdx.x & 63;
+   const int grp = lane / GS, sub = lane % GS;
    const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
    const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
    const int D = DT > 0 ? DT : a.D;
    const double minF = (double)a.minFrwdP;
-   // the last utterance looked up: consecutive hits almost always fall into the same one
-   int cu = -1; size_t cuLo = 1, cuHi = 0; UttDesc ud; int cuOk = 0;
    const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
    // dense scan of the seed array: 8 x 64 seeds per wave and iteration (8 independent 512-byte loads in flight)
    for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
@@ -551,43 +555,55 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
        const size_t idx = base0 + (size_t)r * 64 + lane;
        vv[r] = (idx < a.gamTotal) ? a.gam[idx] : LZERO;
     }
+    const int cu = a.gamChunkUtt[base0 >> 9];            // utterance of the chunk's first seed (host table)
+    // hits are sparse (a few per 512 seeds): collect them in a wave-private LDS list first, so that the lane groups
+    // always have HPS hits to work on side by side
+    volatile unsigned short *hIdx = hitIdx[threadIdx.x >> 6];
+    volatile double *hSeed = hitSeed[threadIdx.x >> 6];
+    int count = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const size_t base = base0 + (size_t)r * 64;
-      const double v = vv[r];
-      unsigned long long hits = __ballot(v > LSMALL);
-      while (hits) {
-         const int src = __ffsll((long long)hits) - 1;
-         hits &= hits - 1;
-         const size_t hidx = base + src;
-         const double seed = __shfl(v, src);
-         if (hidx < cuLo || hidx >= cuHi) {              // utterance of this entry: last u with gamOffByUtt[u] <= hidx
-            int lo = 0, hi = a.nUtt - 1;
-            while (lo < hi) {
-               const int mid = (lo + hi + 1) >> 1;
-               if (a.gamOffByUtt[mid] <= hidx) lo = mid; else hi = mid - 1;
-            }
-            cu = lo; cuLo = a.gamOffByUtt[cu]; cuHi = a.gamOffByUtt[cu + 1];
-            ud = a.utt[cu];
-            cuOk = a.status[cu] == HTKAMD_UTT_OK;
-         }
-         if (!cuOk) continue;
+       const double v = vv[r];
+       const unsigned long long hm = __ballot(v > LSMALL);
+       if (v > LSMALL) {
+          const int pos = count + __popcll(hm & ((1ull << lane) - 1));
+          hIdx[pos] = (unsigned short)(r * 64 + lane); hSeed[pos] = v;
+       }
+       count += __popcll(hm);
+    }
+    {
+      for (int i0 = 0; i0 < count; i0 += HPS) {
+         const int src = (i0 + grp < count) ? i0 + grp : -1;
+         const bool have = src >= 0;
+         const size_t hidx = base0 + (have ? hIdx[src] : 0);
+         const double seed = have ? hSeed[src] : LZERO;
+         // utterance of this entry: advance from the chunk's first utterance (seeds are laid out utterance by utterance)
+         int u = cu;
+         while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
+         const UttDesc ud = a.utt[u];
+         const bool ok = have && a.status[u] == HTKAMD_UTT_OK;
          const size_t rel = hidx - ud.gam0;
-         const int t0 = (int)(rel / ud.nSlots), slot = (int)(rel % ud.nSlots);
-         const int s = a.slotState[ud.slot0 + slot];
-         const int c0 = a.stateCompOff[s], M = a.stateCompOff[s + 1] - c0;
-         const float *xrow = a.X + (size_t)(ud.frame0 + t0) * D;
-         // per-component posterior (lane = component): x = initx + logw + prob (HFB.c:1581-1606)
-         for (int mb = 0; mb < M; mb += 64) {
-            const int m = mb + lane;
+         const int nSl = ud.nSlots > 0 ? ud.nSlots : 1;
+         const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
+         const int s = ok ? a.slotState[ud.slot0 + slot] : 0;
+         const int c0 = a.stateCompOff[s], M = ok ? a.stateCompOff[s + 1] - c0 : 0;
+         const float *xrow = a.X + (size_t)(ud.frame0 + (ok ? t0 : 0)) * D;
+         // per-component posterior (lane%GS = component): x = initx + logw + prob (HFB.c:1581-1606)
+         int Mmax = M;
+#pragma unroll
+         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(Mmax, o); Mmax = w > Mmax ? w : Mmax; }
+         for (int mb = 0; mb < Mmax; mb += GS) {
+            const int m = mb + sub;
             bool pass = false;
             double Lr = 0.0;
+            int g = 0;
             if (m < M) {
+               g = a.compGauss[c0 + m];
                if (M == 1 || a.maxM == 1) { pass = true; Lr = exp(seed); }
                else {
                   const float wt = a.compLogWt[c0 + m];
                   if (wt > (float)LMINMIX) {
-                     const float *P = a.gparam + (size_t)a.compGauss[c0 + m] * a.PS;
+                     const float *P = a.gparam + (size_t)g * a.PS;
                      float sum = P[2 * D];
                      if (DT > 0) {
                         const float2 *P2 = (const float2 *)P;         // (mean, ivar) pairs, 8-byte aligned rows
@@ -613,30 +629,34 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
                }
             }
             double sumLr = pass ? Lr : 0.0;
-            for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
-            if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
+#pragma unroll
+            for (int o = GS / 2; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);      // within the hit's lane group
+            if (sub == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
+            if (pass) {
+               if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+               if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+               if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+            }
+            // first-order statistics of every surviving (hit, component): the whole wave, lane = dimension
             unsigned long long pm = __ballot(pass);
             while (pm) {
                const int ml = __ffsll((long long)pm) - 1;
                pm &= pm - 1;
                const double L = __shfl(Lr, ml);
-               const int c = c0 + mb + ml, g = a.compGauss[c];
-               if (lane == 0) {
-                  if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, L);
-                  if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, L);
-                  if (upWt) atomicAdd(a.acc + a.lay.wt + c, L);
-               }
-               const float *mean = a.mean + (size_t)g * D;
+               const int gg = __shfl(g, ml);
+               const unsigned long long xp = (unsigned long long)xrow;
+               const float *xr = (const float *)(((unsigned long long)__shfl((int)(xp >> 32), ml) << 32) | (unsigned int)__shfl((int)(xp & 0xffffffffu), ml));
+               const float *mean = a.mean + (size_t)gg * D;
                for (int k = lane; k < D; k += 64) {
-                  const float z = xrow[k] - mean[k];
+                  const float z = xr[k] - mean[k];
                   if (upMu && upVa) {                    // HFB.c:1673-1678
                      const float zl = (float)((double)z * L);
-                     atomicAdd(a.acc + a.lay.mu + (size_t)g * D + k, (double)zl);
-                     atomicAdd(a.acc + a.lay.va + (size_t)g * D + k, (double)(z * zl));
+                     atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+                     atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
                   } else if (upMu) {                     // HFB.c:1697-1698
-                     atomicAdd(a.acc + a.lay.mu + (size_t)g * D + k, (double)z * L);
+                     atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
                   } else if (upVa) {                     // HFB.c:1706-1709
-                     atomicAdd(a.acc + a.lay.va + (size_t)g * D + k, (double)(z * z) * L);
+                     atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
                   }
                }
             }
@@ -671,18 +691,25 @@ int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s
    return HTKAMD_OK;
 }
 
-int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s)
+int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s)
 {
-   if (a.gamTotal == 0) return HTKAMD_OK;
-   size_t waves = (a.gamTotal + 511) / 512;
+   if (a_in.gamTotal == 0) return HTKAMD_OK;
+   size_t waves = (a_in.gamTotal + 511) / 512;
    size_t blocks = (waves + 3) / 4;
    if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
-   switch (a.D) {
-   case 39: hipLaunchKernelGGL(k_mixstats<39>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-   case 26: hipLaunchKernelGGL(k_mixstats<26>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-   case 13: hipLaunchKernelGGL(k_mixstats<13>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-   default: hipLaunchKernelGGL(k_mixstats<0>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+   const dim3 grid((unsigned)blocks), block(256);
+   const FbArgs &a = a_in;
+#define MIXSTATS_LAUNCH(GS) \
+   switch (a.D) { \
+   case 39: hipLaunchKernelGGL((k_mixstats<39, GS>), grid, block, 0, s, a); break; \
+   case 26: hipLaunchKernelGGL((k_mixstats<26, GS>), grid, block, 0, s, a); break; \
+   case 13: hipLaunchKernelGGL((k_mixstats<13, GS>), grid, block, 0, s, a); break; \
+   default: hipLaunchKernelGGL((k_mixstats<0, GS>), grid, block, 0, s, a); break; \
    }
+   if (a.maxM <= 16) { MIXSTATS_LAUNCH(16) }
+   else if (a.maxM <= 32) { MIXSTATS_LAUNCH(32) }
+   else { MIXSTATS_LAUNCH(64) }
+#undef MIXSTATS_LAUNCH
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }

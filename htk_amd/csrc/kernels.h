@@ -82,6 +82,7 @@ struct FbArgs {
    int uFlags;
    size_t gamTotal;                  // doubles in gam for this batch
    const size_t *gamOffByUtt;        // [nUtt+1] = utt[u].gam0 (for the flat-index -> utterance search)
+   const int *gamChunkUtt;           // [ceil(gamTotal/512)] utterance holding seed 512*c
 };
 
 int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
