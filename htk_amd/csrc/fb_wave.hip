@@ -537,9 +537,31 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
       if (lane == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
       return;
    }
-   // ---- flush the per-model sums
-   if (valid) {
-      if (wantTrans) {
+   // ---- flush the per-model sums.  Models of an utterance usually share their transition matrix (always, in a
+   // tied-transition system): then the counts are first summed over the lanes, so that an utterance issues ONE atomic
+   // per matrix entry -- same-address f64 atomics serialise in L2, and 41 lanes x 1250 utterances on 15 addresses
+   // used to cost more than the whole recursion.
+   if (wantTrans) {
+      const int t0 = __shfl(cTrans, 0);
+      const bool uniform = __all(!valid || cTrans == t0);
+      if (uniform) {
+         const int N0 = __shfl(N, 0);
+         double *tr = a.acc + a.lay.tr + a.transOff[t0];
+#pragma unroll
+         for (int i = 1; i < MAXN; i++) {
+#pragma unroll
+            for (int j = 2; j <= MAXN; j++) {
+               double v = (valid && i < N && j <= N) ? ta[i][j] : 0.0;
+#pragma unroll
+               for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+               if (lane == 0 && i < N0 && j <= N0 && v != 0.0) atomicAdd(tr + (size_t)(i - 1) * N0 + (j - 1), v);
+            }
+            double v = (valid && i < N) ? occAcc[i] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && i < N0 && v != 0.0) atomicAdd(a.acc + a.lay.trOcc + a.trOccOff[t0] + (i - 1), v);
+         }
+      } else if (valid) {
          double *tr = a.acc + a.lay.tr + a.transOff[cTrans];
 #pragma unroll
          for (int i = 1; i < MAXN; i++)
@@ -550,8 +572,8 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
                if (occAcc[i] != 0.0) atomicAdd(a.acc + a.lay.trOcc + a.trOccOff[cTrans] + (i - 1), occAcc[i]);
             }
       }
-      atomicAdd(a.acc + a.lay.nEgs + cHmm, 1.0);
    }
+   if (valid) atomicAdd(a.acc + a.lay.nEgs + cHmm, 1.0);
    if (lane == 0) {
       atomicAdd(a.acc + a.lay.totalPr, pr);
       atomicAdd(a.acc + a.lay.totalT, (double)T);
