@@ -126,6 +126,7 @@ struct htkamd_fb {
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
    hipEvent_t ev[5], evCopy;
+   hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending;
 };
 
@@ -141,6 +142,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
       if (e != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate: %s", hipGetErrorString(e)); delete fb; return HTKAMD_EHIP; }
    }
    if (hipEventCreateWithFlags(&fb->evCopy, hipEventDisableTiming) != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate failed"); delete fb; return HTKAMD_EHIP; }
+   if (hipStreamCreateWithFlags(&fb->resStream, hipStreamNonBlocking) != hipSuccess) { htkamd_set_error("fb_create: hipStreamCreate failed"); delete fb; return HTKAMD_EHIP; }
    fb->evValid = true;
    int rc;
    if ((rc = fb->d_counter.reserve(64)) || (rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { delete fb; return rc; }
@@ -160,7 +162,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
-   if (fb->evValid) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]); (void)hipEventDestroy(fb->evCopy); }
+   if (fb->evValid) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]); (void)hipEventDestroy(fb->evCopy); (void)hipStreamDestroy(fb->resStream); }
    delete fb;
 }
 
@@ -501,6 +503,14 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    if (!fb) { htkamd_set_error("fb_results: NULL"); return HTKAMD_EINVAL; }
    hipStream_t s = (hipStream_t)stream;
    if (fb->nUtt == 0) return HTKAMD_OK;
+   if (fb->timed) {
+      // wait for THIS batch's last kernel only (work queued on the stream afterwards, e.g. the next batch, keeps running)
+      HIPCHECK(hipEventSynchronize(fb->ev[4]));
+      if (pr) HIPCHECK(hipMemcpyAsync(pr, fb->d_pr.p, sizeof(double) * fb->nUtt, hipMemcpyDeviceToHost, fb->resStream));
+      if (status) HIPCHECK(hipMemcpyAsync(status, fb->d_status.p, sizeof(int) * fb->nUtt, hipMemcpyDeviceToHost, fb->resStream));
+      HIPCHECK(hipStreamSynchronize(fb->resStream));
+      return HTKAMD_OK;
+   }
    if (pr) HIPCHECK(hipMemcpyAsync(pr, fb->d_pr.p, sizeof(double) * fb->nUtt, hipMemcpyDeviceToHost, s));
    if (status) HIPCHECK(hipMemcpyAsync(status, fb->d_status.p, sizeof(int) * fb->nUtt, hipMemcpyDeviceToHost, s));
    HIPCHECK(hipStreamSynchronize(s));
