@@ -59,3 +59,38 @@ def test_decoder_larger_loop_matches_oracle(native, oracle, tmp_path):
     # an impossible utterance (shorter than any path through the network) reports "no token survived"
     short = native.Decoder(model, net).run([s.feats[0][:2]], genBeam=120.0)
     assert short[0][0] is None
+
+
+def test_decoder_config3_size_matches_reference(native, tmp_path):
+    """BASELINE config[3] at full size: 5000 tied states x 16 mixtures, 6000-word loop, 500-frame utterances, -t 250.
+    The expected label lines were written by the reference's HVite for the same (seeded) set:
+    tests/golden/decode/config3/expected.json; the set itself is regenerated here from its seed."""
+    import json
+    import os
+    from htk_amd import synth
+    exp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "decode", "config3", "expected.json")))["-t 250.0"]
+    s = synth.generate(5000, 16, 6000, 2, 500, 3)
+    V = 6000
+    names = ["p%d" % i for i in range(V)]
+    d = tmp_path
+    synth.write_mmf(str(d / "MMF"), s)
+    (d / "hmmlist").write_text("\n".join(names) + "\n")
+    (d / "dict").write_text("".join("%s %s\n" % (n, n) for n in names))
+    with open(d / "net.slf", "w") as f:                             # HBuild's word loop: l = log(1/V) printed with two decimals
+        f.write("VERSION=1.0\nN=%d L=%d\nI=0 W=!NULL\nI=1 W=!NULL\n" % (V + 4, 2 * V + 3))
+        for i, n in enumerate(names):
+            f.write("I=%d W=%s\n" % (2 + i, n))
+        f.write("I=%d W=!NULL\nI=%d W=!NULL\n" % (V + 2, V + 3))
+        j = 0
+        f.write("J=%d S=0 E=1 l=0.00\n" % j); j += 1
+        f.write("J=%d S=%d E=1 l=0.00\n" % (j, V + 2)); j += 1
+        for i in range(V):
+            f.write("J=%d S=1 E=%d l=%.2f\n" % (j, 2 + i, np.log(1.0 / V))); j += 1
+            f.write("J=%d S=%d E=%d l=0.00\n" % (j, 2 + i, V + 2)); j += 1
+        f.write("J=%d S=%d E=%d l=0.00\n" % (j, V + 2, V + 3))
+    mmf = native.Mmf(files=[str(d / "MMF")], hmm_list=str(d / "hmmlist"))
+    net = native.Net(str(d / "net.slf"), str(d / "dict"), mmf)
+    model = native.Model(mmf.packed())
+    res = native.Decoder(model, net).run(s.feats, genBeam=250.0)
+    for u, (words, total) in enumerate(res):
+        assert format_words(words, net.out_syms) == exp["u%05d" % u], u
