@@ -94,3 +94,32 @@ def test_decoder_config3_size_matches_reference(native, tmp_path):
     res = native.Decoder(model, net).run(s.feats, genBeam=250.0)
     for u, (words, total) in enumerate(res):
         assert format_words(words, net.out_syms) == exp["u%05d" % u], u
+
+
+def test_decoder_edge_cases(native, oracle):
+    """Empty batch, an utterance with no frames, a word budget that is too small, and a beam so tight that the path dies:
+    the statuses follow CompleteRecognition (no token in the final node -> nothing to output)."""
+    mmf, net, feats, expected = load_decode_case(native, "bigram")
+    model = native.Model(mmf.packed())
+    dec = native.Decoder(model, net)
+    assert dec.run([]) == []
+    res = dec.run([feats[0], feats[0][:0], feats[1]], genBeam=250.0)
+    assert res[0][0] is not None and res[2][0] is not None and res[1][0] is None
+    om = oracle.Model(mmf.packed())
+    assert res[0][0] == oracle.decode(om, feats[0], net.arrays(), genBeam=250.0)[0]       # neighbours of the empty one unaffected
+    with pytest.raises(native.HtkAmdError):
+        dec.run([feats[0]], lmScale=3.0)                             # LM scale is part of the decoder (LikeToWord look-ahead)
+    lib = native.lib()
+    import ctypes as C
+    X = np.ascontiguousarray(feats[0], np.float32)
+    dX = native.DevArray(X)
+    frameOff = np.array([0, X.shape[0]], np.int32)
+    nW = np.zeros(1, np.int32); tot = np.zeros(1, np.float64)
+    wp = np.zeros(2, np.int32); ws = np.zeros(2, np.int32); we = np.zeros(2, np.int32); sc = np.zeros(2, np.float32)
+    cfg = native.DecodeConfig(250.0, 1.0e10, 1.0, 0.0, 1.0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    native.check(lib.htkamd_decoder_run(dec.h, C.byref(cfg), dX.ptr, p(frameOff), C.c_int(1), C.c_int(2), p(nW), p(wp), p(ws), p(we), p(sc), p(tot), None), "run")
+    assert nW[0] == -3 and tot[0] > -1e9                              # five words do not fit into maxWords = 2
+    tight = dec.run([feats[0]], genBeam=0.5)
+    ow, _ = oracle.decode(om, feats[0], net.arrays(), genBeam=0.5)
+    assert tight[0][0] == ow                                          # whatever the reference semantics give (None or a path)
