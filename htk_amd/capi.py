@@ -541,9 +541,10 @@ class Mmf:
                   hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int))
         return pk
 
-    def write(self, params: dict, one_file=None, out_dir=None):
+    def write(self, params: dict, one_file=None, out_dir=None, binary=False):
         g = params.get("gconst")
-        check(lib().htkamd_mmf_write(self.h, _p(np.ascontiguousarray(params["mean"], np.float32)), _p(np.ascontiguousarray(params["var"], np.float32)),
+        fn = lib().htkamd_mmf_write_binary if binary else lib().htkamd_mmf_write
+        check(fn(self.h, _p(np.ascontiguousarray(params["mean"], np.float32)), _p(np.ascontiguousarray(params["var"], np.float32)),
                                      _p(np.ascontiguousarray(g, np.float32)) if g is not None else None,
                                      _p(np.ascontiguousarray(params["compWeight"], np.float32)), _p(np.ascontiguousarray(params["transP"], np.float32)),
                                      one_file.encode() if one_file else None, out_dir.encode() if out_dir else None), "mmf_write")

@@ -7,7 +7,8 @@
  * GetStateInfo (:2350: a missing <MIXTURE> index is a pruned component of weight 0), GetHMMDef (:2490); and the
  * writer SaveHMMSet (:4979) = SaveMacros (:4342: ~o options, then ~t, ~s, ~h macros in hash-table order) with
  * PutStateInfo (:3053), PutMixPDF (:3029), PutTransMat (:2877: rows renormalised in float) and WriteFloat's " %e".
- * Shared mean/variance vectors (~u ~v inside a mixture), ~m, stream weights, durations, transforms and binary MMFs
+ * Binary definitions (':' + code byte keywords, big-endian numbers: PutSymbol :2581, Token.binForm :505) are read and
+ * written as well.  Shared mean/variance vectors (~u ~v inside a mixture), ~m, stream weights, durations and transforms
  * are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
  */
 #include <ctype.h>
@@ -39,7 +40,7 @@ struct htkamd_mmf {
 };
 
 /* ------------------------------------------------------------------------------------------ tokenizer */
-typedef struct { FILE *f; const char *path; int line; int pushed; char tok[256]; int kind; int binary; } rd;
+typedef struct { FILE *f; const char *path; int line; int pushed; char tok[256]; int kind; int bin; } rd;   /* bin: the last keyword was a binary symbol, so its numbers are binary too (Token.binForm, HModel.c:505,570) */
 enum { T_EOF, T_MACRO, T_KEY, T_WORD };
 
 static int rd_getc(rd *r) { int c = fgetc(r->f); if (c == '\n') r->line++; return c; }
@@ -59,6 +60,7 @@ static int rd_next(rd *r)
    if (c == '<') {
       while ((c = rd_getc(r)) != EOF && c != '>' && n < 250) r->tok[n++] = (char)toupper(c);
       r->tok[n] = 0;
+      r->bin = 0;
       return r->kind = T_KEY;
    }
    if (c == '"' || c == '\'') {
@@ -70,7 +72,18 @@ static int rd_next(rd *r)
       r->tok[n] = 0;
       return r->kind = T_WORD;
    }
-   if (c == ':') { r->binary = 1; r->tok[0] = 0; return r->kind = T_EOF; }
+   if (c == ':') {                                   /* binary symbol: ':' + code byte (PutSymbol HModel.c:2581, enum Symbol :394) */
+      static const char *const code[32] = {"BEGINHMM", "USE", "ENDHMM", "NUMMIXES", "NUMSTATES", "STREAMINFO", "VECSIZE", "NULLD", "POISSOND", "GAMMAD",
+         "RELD", "GEND", "DIAGC", "FULLC", "XFORMC", "STATE", "TMIX", "MIXTURE", "STREAM", "SWEIGHTS", "MEAN", "VARIANCE", "INVCOVAR", "XFORM", "GCONST",
+         "DURATION", "INVDIAGC", "TRANSP", "DPROB", "LLTC", "LLTCOVAR", "PROJSIZE"};
+      c = rd_getc(r);
+      if (c >= 0 && c < 32) snprintf(r->tok, sizeof(r->tok), "%s", code[c]);
+      else if (c == 110) snprintf(r->tok, sizeof(r->tok), "RCLASS");
+      else if (c == 119) snprintf(r->tok, sizeof(r->tok), "HMMSETID");
+      else snprintf(r->tok, sizeof(r->tok), "?BINARY%d", c);
+      r->bin = 1;
+      return r->kind = T_KEY;
+   }
    do {
       if (c == '\\') c = rd_getc(r);
       r->tok[n++] = (char)c;
@@ -90,6 +103,12 @@ static int fail(rd *r, const char *what)
 static int rd_int(rd *r, int *v)
 {
    char *e;
+   if (r->bin && !r->pushed) {                       /* ReadShort, big-endian (HShell.c:1545) */
+      const int hi = fgetc(r->f), lo = fgetc(r->f);
+      if (lo == EOF) return fail(r, "unexpected end of binary data");
+      *v = (short)((hi << 8) | lo);
+      return HTKAMD_OK;
+   }
    if (rd_next(r) != T_WORD) return fail(r, "integer expected");
    *v = (int)strtol(r->tok, &e, 10);
    return *e ? fail(r, "integer expected") : HTKAMD_OK;
@@ -97,6 +116,13 @@ static int rd_int(rd *r, int *v)
 static int rd_float(rd *r, float *v)
 {
    char *e;
+   if (r->bin && !r->pushed) {                       /* ReadFloat, big-endian IEEE (HShell.c:1600) */
+      unsigned char b[4];
+      if (fread(b, 1, 4, r->f) != 4) return fail(r, "unexpected end of binary data");
+      const unsigned int u = ((unsigned int)b[0] << 24) | ((unsigned int)b[1] << 16) | ((unsigned int)b[2] << 8) | b[3];
+      memcpy(v, &u, 4);
+      return HTKAMD_OK;
+   }
    if (rd_next(r) != T_WORD) return fail(r, "number expected");
    *v = strtof(r->tok, &e);                         /* fscanf("%e") into a float, HShell.c ReadFloat */
    return *e ? fail(r, "number expected") : HTKAMD_OK;
@@ -360,10 +386,7 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
    int rc = HTKAMD_OK;
    for (;;) {
       int k = rd_next(&r);
-      if (k == T_EOF) {
-         if (r.binary) { htkamd_set_error("%s: binary MMFs are not supported (save as text: HHEd without -B)", path); rc = HTKAMD_EMODEL; }
-         break;
-      }
+      if (k == T_EOF) break;
       if (k == T_KEY && !strcmp(r.tok, "BEGINHMM")) {
          rd_push(&r);
          if ((rc = parse_hmm(s, &r, defName ? strdup(defName) : base_name(path)))) break;
@@ -501,42 +524,56 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
 }
 
 /* ------------------------------------------------------------------------------------------ writer */
+static int g_bin;                                  /* writer mode: text or binary (SaveHMMSet's `binary`), set by htkamd_mmf_write* */
+static void put_sym(FILE *f, const char *name, int code) { if (g_bin) { fputc(':', f); fputc(code, f); } else fprintf(f, "<%s>", name); }
+static void put_short(FILE *f, int v) { if (g_bin) { fputc((v >> 8) & 255, f); fputc(v & 255, f); } else fprintf(f, " %d", v); }
+static void put_float(FILE *f, float v)
+{
+   if (g_bin) { unsigned int u; memcpy(&u, &v, 4); fputc(u >> 24, f); fputc((u >> 16) & 255, f); fputc((u >> 8) & 255, f); fputc(u & 255, f); }
+   else fprintf(f, " %e", v);
+}
+static void put_nl(FILE *f) { if (!g_bin) fputc('\n', f); }
 static void put_name(FILE *f, char type, const char *name)
 {
    /* ReWriteString(.., DBL_QUOTE): quotes always, backslash before quote/backslash */
    fprintf(f, "~%c \"", type);
    for (const char *p = name; *p; p++) { if (*p == '"' || *p == '\\') fputc('\\', f); fputc(*p, f); }
-   fprintf(f, "\"\n");
+   fprintf(f, "\"");
+   put_nl(f);
 }
 static void put_options(const struct htkamd_mmf *s, FILE *f)
 {
    fprintf(f, "~o\n");
-   if (s->setId[0]) fprintf(f, "<HMMSETID> %s\n", s->setId);
-   fprintf(f, "<STREAMINFO> 1 %d\n<VECSIZE> %d<%s><%s><%s>\n", s->streamWidth, s->vecSize, s->dur, s->kind[0] ? s->kind : "USER", s->cov);
+   if (s->setId[0]) { put_sym(f, "HMMSETID", 119); fprintf(f, " %s\n", s->setId); }
+   put_sym(f, "STREAMINFO", 5); put_short(f, 1); put_short(f, s->streamWidth); put_nl(f);
+   put_sym(f, "VECSIZE", 6); put_short(f, s->vecSize);
+   put_sym(f, s->dur, 7);                                            /* NULLD */
+   fprintf(f, "<%s><%s>", s->kind[0] ? s->kind : "USER", s->cov);      /* parameter and covariance kinds are text even in binary files */
+   put_nl(f);
 }
-static void put_vec(FILE *f, const char *key, const float *v, int n)
+static void put_vec(FILE *f, const char *key, int code, const float *v, int n)
 {
-   fprintf(f, "<%s> %d\n", key, n);
-   for (int i = 0; i < n; i++) fprintf(f, " %e", v[i]);
-   fprintf(f, "\n");
+   put_sym(f, key, code); put_short(f, n); put_nl(f);
+   for (int i = 0; i < n; i++) put_float(f, v[i]);
+   put_nl(f);
 }
 static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *mean, const float *var, const float *gconst, const float *wt)
 {
    const mmf_state *st = &s->st[si];
    const int D = s->vecSize;
-   if (st->nMix > 1) fprintf(f, "<NUMMIXES> %d\n", st->nMix);
+   if (st->nMix > 1) { put_sym(f, "NUMMIXES", 3); put_short(f, st->nMix); put_nl(f); }
    for (int m = 0; m < st->nMix; m++) {
       const int c = st->comp0 + m, g = s->cg[c];
       if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */
-      if (st->nMix > 1) fprintf(f, "<MIXTURE> %d %e\n", m + 1, wt[c]);
-      put_vec(f, "MEAN", mean + (size_t)g * D, D);
-      put_vec(f, "VARIANCE", var + (size_t)g * D, D);
-      if (gconst) fprintf(f, "<GCONST> %e\n", gconst[g]);
+      if (st->nMix > 1) { put_sym(f, "MIXTURE", 17); put_short(f, m + 1); put_float(f, wt[c]); put_nl(f); }
+      put_vec(f, "MEAN", 20, mean + (size_t)g * D, D);
+      put_vec(f, "VARIANCE", 21, var + (size_t)g * D, D);
+      if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
    }
 }
 static void put_trans(FILE *f, const float *logp, int N)
 {
-   fprintf(f, "<TRANSP> %d\n", N);
+   put_sym(f, "TRANSP", 27); put_short(f, N); put_nl(f);
    for (int i = 0; i < N; i++) {
       float row[64], rSum = 0.0f;
       for (int j = 0; j < N; j++) {
@@ -544,8 +581,8 @@ static void put_trans(FILE *f, const float *logp, int N)
          row[j] = (x < (float)LSMALL) ? 0.0f : (float)exp((double)x);       /* L2F */
          rSum += row[j];
       }
-      for (int j = 0; j < N; j++) fprintf(f, " %e", (i == N - 1) ? 0.0f : row[j] / rSum);
-      fprintf(f, "\n");
+      for (int j = 0; j < N; j++) put_float(f, (i == N - 1) ? 0.0f : row[j] / rSum);
+      put_nl(f);
    }
 }
 static void put_hmm(const struct htkamd_mmf *s, FILE *f, int h, int withHdr, const float *mean, const float *var, const float *gconst,
@@ -553,16 +590,17 @@ static void put_hmm(const struct htkamd_mmf *s, FILE *f, int h, int withHdr, con
 {
    const mmf_hmm *hm = &s->hm[h];
    if (withHdr) put_name(f, 'h', hm->name);
-   fprintf(f, "<BEGINHMM>\n<NUMSTATES> %d\n", hm->N);
+   put_sym(f, "BEGINHMM", 0); put_nl(f);
+   put_sym(f, "NUMSTATES", 4); put_short(f, hm->N); put_nl(f);
    for (int i = 1; i < hm->N - 1; i++) {
-      fprintf(f, "<STATE> %d\n", i + 1);
+      put_sym(f, "STATE", 15); put_short(f, i + 1); put_nl(f);
       const int si = hm->state[i];
       if (s->st[si].name) put_name(f, 's', s->st[si].name);
       else put_state(s, f, si, mean, var, gconst, wt);
    }
    if (s->tr[hm->trans].name) put_name(f, 't', s->tr[hm->trans].name);
    else put_trans(f, tp + s->tr[hm->trans].off, hm->N);
-   fprintf(f, "<ENDHMM>\n");
+   put_sym(f, "ENDHMM", 2); put_nl(f);
 }
 
 /* hash-table order of SaveMacros (HModel.c Hash :4331 + NewMacro head insertion): same rule as the .acc scan */
@@ -577,12 +615,35 @@ static void macro_order(char **names, int n, int *order)
 /* Text output with the current parameter values (layout of the desc arrays; transP in log form).
  * oneFile != NULL: everything into that file (SaveInOneFile).  Otherwise dir: models that came from a master file go
  * to dir/<base name of nothing>... -- kept simple: one file per physical HMM named dir/<name> (the -d / -M layout). */
+int htkamd_mmf_write_binary(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                            const float *transP, const char *oneFile, const char *dir);
+static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                     const float *transP, const char *oneFile, const char *dir);
+
 int htkamd_mmf_write(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                     const float *transP, const char *oneFile, const char *dir)
+{
+   g_bin = 0;
+   return mmf_write(s, mean, var, gconst, compWeight, transP, oneFile, dir);
+}
+
+/* The same in HTK's binary form (SaveHMMSet with binary = TRUE, e.g. HERest -B): ':' + code byte for the keywords,
+   big-endian shorts and floats, no line structure. */
+int htkamd_mmf_write_binary(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                            const float *transP, const char *oneFile, const char *dir)
+{
+   g_bin = 1;
+   const int rc = mmf_write(s, mean, var, gconst, compWeight, transP, oneFile, dir);
+   g_bin = 0;
+   return rc;
+}
+
+static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
                      const float *transP, const char *oneFile, const char *dir)
 {
    if (!s || !s->finished || !mean || !var || !compWeight || !transP) { htkamd_set_error("mmf_write: bad argument"); return HTKAMD_EINVAL; }
    if (oneFile) {
-      FILE *f = fopen(oneFile, "w");
+      FILE *f = fopen(oneFile, "wb");
       if (!f) { htkamd_set_error("mmf_write: cannot create %s", oneFile); return HTKAMD_EIO; }
       put_options(s, f);
       int nN = 0;

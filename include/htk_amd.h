@@ -101,8 +101,8 @@ int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gc
 /* ------------------------------------------------------------------------------------------
  * Model definition files: replaces LoadHMMSet (HModel.c:3809) = MakeHMMSet (:3580) + LoadMacroFiles (:3721) with the
  * -d directory search, and SaveHMMSet (:4979) / SaveInOneFile (:4858), for text definitions of one-stream DIAGC
- * continuous-density sets (macros ~o ~s ~t ~h ~v"varFloor"; ~u/~v/~m sharing, streams, durations, transforms and binary
- * files are rejected with HTKAMD_EMODEL).  Pure host code.
+ * continuous-density sets, text or binary (macros ~o ~s ~t ~h ~v"varFloor"; ~u/~v/~m sharing, streams, durations and
+ * transforms are rejected with HTKAMD_EMODEL).  Pure host code.
  *   mmf_read    : one master macro file, or one HMM file (a definition without ~h takes `defName` / the file's base name)
  *   mmf_finish  : HMM list "logical [physical]" (NULL: every defined model is its own logical name); physical models still
  *                 undefined are read from dir/name[.ext]; builds the flat description for htkamd_model_create.
@@ -125,6 +125,9 @@ const char *htkamd_mmf_parm_kind(const htkamd_mmf *s);                   /* e.g.
 const float *htkamd_mmf_var_floor(const htkamd_mmf *s);                  /* ~v "varFloor1" [vecSize] or NULL */
 int  htkamd_mmf_write(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
                       const float *transP, const char *oneFile, const char *dir);
+/* the same in HTK's binary form (SaveHMMSet with binary = TRUE, HERest/HHEd -B); htkamd_mmf_read takes either form */
+int  htkamd_mmf_write_binary(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                             const float *transP, const char *oneFile, const char *dir);
 
 /* ------------------------------------------------------------------------------------------
  * Transcriptions: HTK label files (LoadHTKLabels, HLabel.c:748) and master label files with immediate definitions

@@ -1,5 +1,5 @@
 """Fixture for the MMF reader/writer: a small synthetic set with ~s/~t macros, written by htk_amd.synth, and the same set
-as the reference re-saves it (HHEd with an empty edit script: LoadHMMSet + SaveHMMSet, text).  Needs oracle/_ref.
+as the reference re-saves it (HHEd with an empty edit script: LoadHMMSet + SaveHMMSet), in text and (-B) in binary form.  Needs oracle/_ref.
     python tests/golden/make_mmf_golden.py"""
 import os
 import subprocess
@@ -22,6 +22,7 @@ def main():
         f.write("alias p3\n")                       # a logical name sharing a physical model
     open(os.path.join(OUT, "empty.hed"), "w").close()
     subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "HHEd"), "-H", "syn_in.mmf", "-w", "syn_resaved.mmf", "empty.hed", "syn_list"], cwd=OUT)
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "HHEd"), "-B", "-H", "syn_in.mmf", "-w", "syn_resaved_bin.mmf", "empty.hed", "syn_list"], cwd=OUT)
     os.remove(os.path.join(OUT, "empty.hed"))
     print(os.listdir(OUT))
 

@@ -99,3 +99,22 @@ def test_label_files_and_mlf(native, tmp_path):
     assert [x[0] for x in m.find("exact.lab")] == ["p9"] and m.find("lab/u3.lab") is None
     with pytest.raises(native.HtkAmdError):
         native.Mlf(os.path.join(d, "tr1.lab"))                       # no #!MLF!# header
+
+
+def test_mmf_binary_form(native, tmp_path):
+    """HTK's binary model files (HHEd/HERest -B): read to the same description as the text form of the same set, and
+    written byte-identically to what the reference wrote."""
+    lst = os.path.join(GOLD, "mmf", "syn_list")
+    mb = native.Mmf(files=[os.path.join(GOLD, "mmf", "syn_resaved_bin.mmf")], hmm_list=lst)
+    mt = native.Mmf(files=[os.path.join(GOLD, "mmf", "syn_resaved.mmf")], hmm_list=lst)
+    qb, qt = mb.packed(), mt.packed()
+    assert mb.kind == mt.kind and mb.phys_names == mt.phys_names and mb.logical == mt.logical
+    for k in ("stateCompOff", "compGauss", "hmmState", "hmmTrans", "transN"):
+        assert np.array_equal(qb[k], qt[k]), k
+    for k in ("mean", "var", "gconst", "compWeight"):
+        assert np.allclose(qb[k], qt[k], rtol=1e-6), k              # the text form carries 7 digits, the binary one all bits
+    lin = lambda t: np.where(t > -0.5e10, np.exp(t.astype(np.float64)), 0.0)
+    assert np.allclose(lin(qb["transP"]), lin(qt["transP"]), rtol=1e-6, atol=1e-9)
+    out = tmp_path / "out.bin"
+    mb.write(dict(mean=qb["mean"], var=qb["var"], gconst=qb["gconst"], compWeight=qb["compWeight"], transP=qb["transP"]), one_file=str(out), binary=True)
+    assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "syn_resaved_bin.mmf"), "rb").read()
