@@ -105,25 +105,39 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
     vec_ptr, vec_n = accs.device_vector()
-    # a torch view of the accumulator vector for the collective (no copy)
-    acc_t = herest.device_vector_as_tensor(accs, local_rank) if world > 1 else None
-
-    # Two batch contexts alternate so that the host-side preparation of a pass (CreateInsts/SetBeamTaper on a worker pool,
-    # 0.7 ms) and its launches overlap the previous pass still running on the device -- what a training loop over many
-    # batches does.  Every pass does all of its work: zero, prepare, score, beta, alpha, statistics, all-reduce; its
-    # per-utterance results are collected one pass later.
+    # Two batch contexts AND two accumulator vectors alternate: the host-side preparation of a pass (CreateInsts /
+    # SetBeamTaper on a worker pool, 0.7 ms) and its launches overlap the previous pass still running on the device, and the
+    # previous pass's all-reduce (52 MB of fp64 over xGMI, on a side stream) overlaps this pass's kernels -- what a training
+    # loop over many batches does.  Every pass does all of its work: zero, prepare, score, beta, alpha, statistics,
+    # all-reduce; its per-utterance results are collected one pass later.  The same stream/event choreography runs at
+    # N = 1 (without the collective), so the single-GPU run exercises it.
     fbs = [fb, capi.ForwardBackward(model)]
+    accs2 = [accs, capi.Accs(model)]
+    acc_ts = [herest.device_vector_as_tensor(a, local_rank) for a in accs2]
+    comm = torch.cuda.Stream()
+    ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # pass finished accumulating into accs2[k] (main stream)
+    ev_red = [torch.cuda.Event(), torch.cuda.Event()]    # all-reduce of accs2[k] finished (side stream)
+    red_pending = [False, False]
 
     def launch(i):
-        f = fbs[i & 1]
-        accs.zero(sptr)
+        k = i & 1
+        f = fbs[k]
+        if red_pending[k]:
+            stream.wait_event(ev_red[k])                 # accs2[k] is still being summed from two passes ago
+        accs2[k].zero(sptr)
         f.prepare(dX.data_ptr(), frameOff, labOff, labs, sptr)
-        f.execute(cfg, accs, sptr)
-        if world > 1:
-            herest.all_reduce_accumulators(acc_t)      # the pass's one exchange: RCCL sum over xGMI
+        f.execute(cfg, accs2[k], sptr)
+        ev_done[k].record(stream)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_done[k])
+            if world > 1:
+                herest.all_reduce_accumulators(acc_ts[k])   # the pass's one exchange: RCCL sum over xGMI
+            ev_red[k].record(comm)
+        red_pending[k] = True
         return f
 
     def sync_all():
+        torch.cuda.synchronize()                         # both streams
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -150,7 +164,7 @@ def main():
         dt = float(tmax.item())
     ktimes /= max(args.steps, 1)
 
-    a = accs.download()
+    a = accs2[(args.steps - 1) & 1].download() if args.steps > 0 else accs.download()
     n_ok_local = int((st == capi.UTT_OK).sum())
     units_local = fb.frame_states()                      # (frame, chain state) evaluations of this rank's shard
     units_total = float(a["nEval"]) if world > 1 else float(units_local)
