@@ -45,7 +45,7 @@ __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
 
 template <int NS>
-__global__ __launch_bounds__(256) void k_score_mfma(ScoreArgs a)
+__global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
 {
    constexpr int TW = (NS + 4) * 64;                  // floats per fragment tile
    constexpr int PT = (TW + 255) / 256;               // floats staged per thread
@@ -170,7 +170,7 @@ int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStrea
    if (!m->d_mfmaTab) { htkamd_set_error("score_mfma: vector size %d not supported by the MFMA path (13, 26, 39)", m->D); return HTKAMD_EMODEL; }
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
    int blocks = a.nTasks;
-   if (blocks > 256 * 3) blocks = 256 * 3;      // persistent blocks (3 per CU at ~136 VGPRs), one task (128 frames x 16 states) at a time
+   if (blocks > 256 * 4) blocks = 256 * 4;      // persistent blocks (4 per CU at <= 128 VGPRs), one task (128 frames x 16 states) at a time
    dim3 grid(blocks), block(256);
    switch (m->mfmaNS) {
    case 20: hipLaunchKernelGGL((k_score_mfma<20>), grid, block, 0, stream, a); break;
