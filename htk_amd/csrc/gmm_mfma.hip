@@ -4,6 +4,7 @@
 // expanded form
 //     log( w_m N(x; mu_m, var_m) ) = cinit_m + sum_i ( -0.5*ivar_mi * x_i^2  +  mu_mi*ivar_mi * x_i )
 //     cinit_m = log w_m - 0.5*( gConst_m + sum_i mu_mi^2 * ivar_mi )
+// (all coefficients pre-multiplied by log2(e) on the host, so that the mixture sum runs on v_exp_f32 / v_log_f32 directly)
 // so that frames x Gaussians is a GEMM  [x^2 | x] (T x 2D)  *  W (2D x M)  accumulated on top of cinit, followed by
 // a float log-sum-exp over the M columns of a state.  This is the TOLERANCE path (HERest: alpha/beta and the
 // re-estimated parameters to 1e-4 relative, tests/test_gpu_parity.py); scores differ from the reference's float
@@ -39,6 +40,8 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) int cint;
 
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#define LOG2(x) __builtin_amdgcn_logf(x)
 #define MFMA_COL_TILES 2          /* 16-frame column tiles per wave: 4 waves x 32 frames = one 128-frame task */
 
 __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
@@ -129,16 +132,17 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
 #pragma unroll
             for (int ft = 0; ft < MFMA_COL_TILES; ft++) {
                const f4 y = Cx[ft];
+               // the table is scaled by log2(e): y is a base-2 logarithm, so v_exp_f32 / v_log_f32 apply without a multiply
                float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
                mx = fmaxf(mx, xor16(mx));
                mx = fmaxf(mx, xor32(mx));
-               float sm = (__expf(y[0] - mx) + __expf(y[1] - mx)) + (__expf(y[2] - mx) + __expf(y[3] - mx));
+               float sm = (EXP2(y[0] - mx) + EXP2(y[1] - mx)) + (EXP2(y[2] - mx) + EXP2(y[3] - mx));
                sm += xor16(sm);
                sm += xor32(sm);
                if (first) { rM[ft] = mx; rS[ft] = sm; }
                else {
                   const float M2 = fmaxf(rM[ft], mx);
-                  rS[ft] = rS[ft] * __expf(rM[ft] - M2) + sm * __expf(mx - M2);
+                  rS[ft] = rS[ft] * EXP2(rM[ft] - M2) + sm * EXP2(mx - M2);
                   rM[ft] = M2;
                }
             }
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
          }
          tile = nextFirst;
          // lanes 0..31 (kq = column tile) store frames fw + lane: 128 contiguous bytes
-         const float r0 = rM[0] + __logf(rS[0]), r1 = rM[1] + __logf(rS[1]);
+         const float r0 = (rM[0] + LOG2(rS[0])) * 0.69314718055994531f, r1 = (rM[1] + LOG2(rS[1])) * 0.69314718055994531f;
          const float res = (kq == 1) ? r1 : r0;
          float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + fw;
          if (active && lane < 32 && fw + lane < tk.nFrames) o[lane] = res;

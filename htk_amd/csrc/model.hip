@@ -120,13 +120,14 @@ static int mfma_refresh(htkamd_model *m)
             const float *mu = m->h_mean + (size_t)g * D, *iv = m->h_ivar + (size_t)g * D;
             double k0 = m->h_gconst[g];
             for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
-            const float ci = (float)((c1 - c0 == 1 ? 0.0 : (double)m->h_compLogWt[c]) - 0.5 * k0);
+            const double L2E = 1.4426950408889634;           // table in base-2 logarithms (gmm_mfma.hip)
+            const float ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)m->h_compLogWt[c]) - 0.5 * k0) * L2E);
             for (int j = 0; j < 16; j++) ciRow[j] = ci;
             for (int st = 0; st < NS; st++)
                for (int kq = 0; kq < 4; kq++) {
                   const int dim = 2 * st + (kq >> 1);
                   float v = 0.0f;
-                  if (dim < D) v = (kq & 1) ? (float)((double)mu[dim] * iv[dim]) : -0.5f * iv[dim];
+                  if (dim < D) v = (kq & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
                   T[(size_t)st * 64 + kq * 16 + col] = v;
                }
          }
