@@ -21,7 +21,7 @@
 //       even kq and x for odd kq: ceil(D/2) registers per column tile, loaded once per task (2*20 VGPRs at D=39).
 //   C[row = 4*(lane>>4)+r][col = lane&15] : a lane ends with 4 components of one frame; accumulators start at cinit
 //       (table rows NS..NS+3), so the GEMM result IS log(w N).
-// The mixture log-sum-exp is then 4 values in-lane + two cross-lane exchanges (lanes ^16, ^32) for max and for sum.
+// The mixture log-sum-exp is then 4 values in-lane + two row swaps (v_permlane16_swap / v_permlane32_swap) for max and for sum.
 // Lanes 0..31 store frames fw..fw+31 of the state's output row (128 contiguous bytes).  A short last piece leaves
 // whole waves without frames; they skip the arithmetic and only take part in the staging.
 // States with more than 16 components take several tiles, merged with a running (max, sum).
@@ -44,8 +44,23 @@ typedef const __attribute__((address_space(4))) int cint;
 #define LOG2(x) __builtin_amdgcn_logf(x)
 #define MFMA_COL_TILES 2          /* 16-frame column tiles per wave: 4 waves x 32 frames = one 128-frame task */
 
-__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16); }
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
+// Combining a value across the four 16-lane rows of the wave with gfx950's row-swap instructions (VALU, no LDS round trip):
+// v_permlane16_swap(v, v) leaves {rows 0,0,2,2} and {rows 1,1,3,3}; v_permlane32_swap(v, v) {lower, lower} and {upper, upper}:
+// op(first, second) is op(lane, lane ^ 16) resp. op(lane, lane ^ 32) in every lane.
+__device__ __forceinline__ float rows_max(float v)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 template <int NS>
 __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
@@ -134,11 +149,9 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
                const f4 y = Cx[ft];
                // the table is scaled by log2(e): y is a base-2 logarithm, so v_exp_f32 / v_log_f32 apply without a multiply
                float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
-               mx = fmaxf(mx, xor16(mx));
-               mx = fmaxf(mx, xor32(mx));
+               mx = rows_max(mx);
                float sm = (EXP2(y[0] - mx) + EXP2(y[1] - mx)) + (EXP2(y[2] - mx) + EXP2(y[3] - mx));
-               sm += xor16(sm);
-               sm += xor32(sm);
+               sm = rows_sum(sm);
                if (first) { rM[ft] = mx; rS[ft] = sm; }
                else {
                   const float M2 = fmaxf(rM[ft], mx);
