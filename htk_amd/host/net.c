@@ -9,7 +9,8 @@
  * probability (ProcessCrossWordLinks :2559); an extra null node precedes all initial lattice nodes and another follows
  * all final ones (AddInitialFinal :2180).  Node kinds: HMM (emits, unless its model is a tee model: a_1N > LSMALL),
  * WORD (word end of a real pronunciation: adds the word penalty and pron prob, starts a path record), NULL (passes tokens).
- * Sub-lattices, tags, N-gram back-off via external LM files and context-dependent expansion are out of this row's scope.
+ * When the dictionary is written in phones that are not all model names, pronunciations are expanded word-internally into
+ * context-dependent models (resolve_models below).  Sub-lattices, tags and cross-word context expansion are out of this row's scope.
  */
 #include <ctype.h>
 #include <math.h>
@@ -18,7 +19,7 @@
 #include <string.h>
 #include "../csrc/internal.h"
 
-typedef struct { char *word, *outSym; float prob; int nPhones; int *phone; } dpron;   /* phone = physical model index */
+typedef struct { char *word, *outSym; float prob; int nPhones; int *phone; char **phoneName; } dpron;   /* phone = physical model index (filled by resolve_models) */
 
 struct htkamd_net {
    htkamd_net_desc d;
@@ -43,6 +44,80 @@ static char *rd_word(char **pp)
    }
    buf[n] = 0; *pp = p;
    return strdup(buf);
+}
+
+
+/* ---- phones -> models.  ExpandWordNet (HNet.c:3438) first asks whether every phone of the WHOLE dictionary is a model name
+ * (ClosedDict :1876): then pronunciations are chains of exactly those models.  Otherwise the model set defines contexts
+ * (DefineContexts :1892) and, cross-word expansion being off by default (ALLOWXWRDEXP = F), pronunciations are expanded
+ * WORD-INTERNALLY: phone j gets the model FindModel (:2052) picks for (left context, phone, right context), where the
+ * contexts come from the neighbouring phones inside the word (FindLContext/FindRContext :1850-1873), context-free phones
+ * (models that never appear as anybody's context, e.g. sp/sil) count as word boundaries (CFWORDBOUNDARY = T), and
+ * context-independent phones (only ever defined bare) keep their own name. */
+static void tri_strip(const char *name, char *out, size_t n)
+{
+   const char *b = strchr(name, '-'); b = b ? b + 1 : name;
+   snprintf(out, n, "%s", b);
+   char *e = strchr(out, '+'); if (e) *e = 0;
+}
+typedef struct { char **v; int n, cap; } strset;
+static int set_has(const strset *s, const char *x) { for (int i = 0; i < s->n; i++) if (!strcmp(s->v[i], x)) return 1; return 0; }
+static void set_add(strset *s, const char *x)
+{
+   if (set_has(s, x)) return;
+   if (s->n + 1 > s->cap) { s->cap = s->cap * 2 + 64; s->v = (char **)realloc(s->v, sizeof(char *) * (size_t)s->cap); }
+   s->v[s->n++] = strdup(x);
+}
+static void set_free(strset *s) { for (int i = 0; i < s->n; i++) free(s->v[i]); free(s->v); }
+
+static int resolve_models(dpron *pr, int nPr, const struct htkamd_mmf *hmms, const char *dictPath)
+{
+   int closed = 1;
+   for (int k = 0; k < nPr && closed; k++)
+      for (int q = 0; q < pr[k].nPhones; q++)
+         if (htkamd_mmf_find_logical(hmms, pr[k].phoneName[q]) < 0) { closed = 0; break; }
+   if (closed) {
+      for (int k = 0; k < nPr; k++)
+         for (int q = 0; q < pr[k].nPhones; q++) pr[k].phone[q] = htkamd_mmf_find_logical(hmms, pr[k].phoneName[q]);
+      return HTKAMD_OK;
+   }
+   /* DefineContexts */
+   strset cxs = {0}, dep = {0};                      /* contexts seen; base names that have a context-dependent model */
+   int sLeft = 0, sRight = 0;
+   const int nLog = htkamd_mmf_num_logical(hmms);
+   char buf[512], base[512];
+   for (int i = 0; i < nLog; i++) {
+      const char *nm = htkamd_mmf_logical_name(hmms, i);
+      const char *mi = strchr(nm, '-'), *pl = strchr(nm, '+');
+      if (mi) { snprintf(buf, sizeof(buf), "%.*s", (int)(mi - nm), nm); set_add(&cxs, buf); sLeft = 1; }
+      if (pl) { set_add(&cxs, pl + 1); sRight = 1; }
+      if (mi || pl) { tri_strip(nm, base, sizeof(base)); set_add(&dep, base); }
+   }
+   int rc = HTKAMD_OK;
+   for (int k = 0; k < nPr && !rc; k++) {
+      dpron *d = &pr[k];
+      for (int q = 0; q < d->nPhones && !rc; q++) {
+         /* contexts: previous / next phone inside the word; a phone that is nobody's context is a word boundary (0) */
+         const char *lc = NULL, *rcx = NULL;
+         if (q > 0) { tri_strip(d->phoneName[q - 1], base, sizeof(base)); if (set_has(&cxs, base)) lc = d->phoneName[q - 1]; }
+         if (q + 1 < d->nPhones) { tri_strip(d->phoneName[q + 1], base, sizeof(base)); if (set_has(&cxs, base)) rcx = d->phoneName[q + 1]; }
+         char lcs[256] = "", rcs[256] = "";
+         if (lc) tri_strip(lc, lcs, sizeof(lcs));
+         if (rcx) tri_strip(rcx, rcs, sizeof(rcs));
+         const char *nm = d->phoneName[q];
+         const int ci = !set_has(&dep, nm);                   /* IsHCIContextInd: only the bare model exists */
+         if ((!lc && !rcx) || ci) snprintf(buf, sizeof(buf), "%s", nm);
+         else if ((!lc || !sLeft) && rcx) snprintf(buf, sizeof(buf), "%s+%s", nm, rcs);
+         else if ((!rcx || !sRight) && lc) snprintf(buf, sizeof(buf), "%s-%s", lcs, nm);
+         else snprintf(buf, sizeof(buf), "%s-%s+%s", lcs, nm, rcs);
+         int h = htkamd_mmf_find_logical(hmms, buf);
+         if (h < 0) h = htkamd_mmf_find_logical(hmms, nm);      /* "then try the name itself" */
+         if (h < 0) { htkamd_set_error("%s: word %s: no model %s (nor %s) in the model set", dictPath, d->word, buf, nm); rc = HTKAMD_EMODEL; }
+         d->phone[q] = h;
+      }
+   }
+   set_free(&cxs); set_free(&dep);
+   return rc;
 }
 
 static int read_dict(const char *path, const struct htkamd_mmf *hmms, dpron **out, int *nOut)
@@ -77,17 +152,14 @@ static int read_dict(const char *path, const struct htkamd_mmf *hmms, dpron **ou
                d->prob = (float)log(v); free(t); continue;
             }
          }
-         const int h = htkamd_mmf_find_logical(hmms, t);
-         if (h < 0) { fclose(f); htkamd_set_error("%s:%d: no model for phone %s", path, lineNo, t); free(t); return HTKAMD_EMODEL; }
-         free(t);
-         if (d->nPhones + 1 > capP) { capP = capP * 2 + 8; d->phone = (int *)realloc(d->phone, sizeof(int) * (size_t)capP); }
-         d->phone[d->nPhones++] = h;
+         if (d->nPhones + 1 > capP) { capP = capP * 2 + 8; d->phone = (int *)realloc(d->phone, sizeof(int) * (size_t)capP); d->phoneName = (char **)realloc(d->phoneName, sizeof(char *) * (size_t)capP); }
+         d->phoneName[d->nPhones] = t; d->phone[d->nPhones] = -1; d->nPhones++;
       }
       n++;
    }
    fclose(f);
    *out = pr; *nOut = n;
-   return HTKAMD_OK;
+   return resolve_models(pr, n, hmms, path);
 }
 
 typedef struct { char *word; int var; } lnode;
@@ -170,7 +242,10 @@ void htkamd_net_destroy(struct htkamd_net *n)
    free(n->kind); free(n->model); free(n->linkOff); free(n->linkDest); free(n->wordOf); free(n->pronProb); free(n->linkLike);
    for (int i = 0; i < n->nWordNames; i++) free(n->wordName[i]);
    free(n->wordName);
-   for (int i = 0; i < n->nPron; i++) { free(n->pron[i].word); free(n->pron[i].outSym); free(n->pron[i].phone); }
+   for (int i = 0; i < n->nPron; i++) {
+      for (int q = 0; q < n->pron[i].nPhones; q++) free(n->pron[i].phoneName[q]);
+      free(n->pron[i].phoneName); free(n->pron[i].word); free(n->pron[i].outSym); free(n->pron[i].phone);
+   }
    free(n->pron);
    free(n);
 }

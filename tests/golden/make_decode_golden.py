@@ -6,6 +6,8 @@ Cases (all files land in tests/golden/decode/<case>/, a few hundred kB in total)
   bigram multi-phone words, two pronunciations with probabilities, an output symbol, a word without output symbol,
          a hand-written back-off bigram lattice (per-word successor arcs + back-off null node)        3 option sets
   tee    mixed-topology models incl. a tee model `sp` at the end of some pronunciations, word loop    HVite -t 250 / -t 40
+  wint   a monophone dictionary over a model set of word-internal triphones/biphones (logical names tied to 12 physical
+         models), so that ExpandWordNet's context expansion is exercised                              2 option sets
 Each case: MMF (text), hmmlist, dict, net.slf, feats.npz (the utterances' feature matrices), expected.json =
 {option string: {utterance: [label lines of the .rec file]}} exactly as HVite wrote them."""
 import json
@@ -148,7 +150,38 @@ def main():
                 ph.append(idx[p])
         feats.append(sample(pk2, ph, rng, frames_per_state=3))
     run_hvite(d, feats, ["-t 250.0", "-t 40.0"], 9, "")
-    for c in ("loop", "bigram", "tee"):
+    # ---------------------------------------------------------------- wint: word-internal triphones
+    d = os.path.join(OUT, "wint"); os.makedirs(d, exist_ok=True)
+    synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
+    phones = ["a", "b", "c", "d"]
+    logical = []
+    k = 0
+    for p_ in phones:
+        for l_ in [None] + phones:
+            for r_ in [None] + phones:
+                if l_ is None and r_ is None:
+                    continue                                                    # bare monophones: only "b" below
+                name = ("%s-" % l_ if l_ else "") + p_ + ("+%s" % r_ if r_ else "")
+                logical.append((name, "p%d" % (k % 10))); k += 1
+    logical += [("b", "p3"), ("sil", "p10"), ("sp", "p11")]
+    with open(os.path.join(d, "hmmlist"), "w") as f:
+        for n in names:
+            f.write(n + "\n")                                                   # the physical models themselves
+        for lg, ph in logical:
+            f.write("%s %s\n" % (lg, ph))
+    open(os.path.join(d, "dict"), "w").write("SIL sil\nW1 a b sp\nW2 c d a sp\nW3 b sp\nW4 d c b a sp\n")
+    open(os.path.join(d, "wlist"), "w").write("SIL\nW1\nW2\nW3\nW4\n")
+    subprocess.check_call([os.path.join(REF, "HBuild"), "wlist", "net.slf"], cwd=d)
+    os.remove(os.path.join(d, "wlist"))
+    lmap = dict(logical)
+    wseq = {"SIL": ["sil"], "W1": ["a+b", "a-b", "sp"], "W2": ["c+d", "c-d+a", "d-a", "sp"], "W3": ["b", "sp"], "W4": ["d+c", "d-c+b", "c-b+a", "b-a", "sp"]}
+    feats = []
+    for u in range(4):
+        seq = ["SIL"] + [list(wseq)[1 + k] for k in rng.integers(0, 4, size=4)] + ["SIL"]
+        ph = [int(lmap[m][1:]) for w in seq for m in wseq[w]]
+        feats.append(sample(pk, ph, rng, frames_per_state=3))
+    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -p -20.0 -s 3.0"], 9, "")
+    for c in ("loop", "bigram", "tee", "wint"):
         e = json.load(open(os.path.join(OUT, c, "expected.json")))
         print(c, {k: sum(len(v) for v in per.values()) for k, per in e.items()})
 

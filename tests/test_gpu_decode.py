@@ -8,7 +8,7 @@ from decode_util import format_words, load_decode_case, parse_opts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["loop", "bigram", "tee"])
+@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint"])
 def test_decoder_reproduces_hvite_label_files(native, oracle, case):
     mmf, net, feats, expected = load_decode_case(native, case)
     model = native.Model(mmf.packed())
