@@ -22,6 +22,11 @@ UPALL = 15
 UTT_OK, UTT_SKIPPED, UTT_ETEE, UTT_EALPHA = 1, 0, -7332, -7390
 
 
+def _stream(s):
+    """A raw hipStream_t given as a Python int (torch: stream.cuda_stream) must travel as a pointer, not as a C int."""
+    return None if s is None else (s if isinstance(s, C.c_void_p) else C.c_void_p(int(s)))
+
+
 class HtkAmdError(RuntimeError):
     pass
 
@@ -196,7 +201,7 @@ class Accs:
         check(lib().htkamd_accs_get_layout(self.h, C.byref(self.lay)), "accs_get_layout")
 
     def zero(self, stream=None):
-        check(lib().htkamd_accs_zero(self.h, stream), "accs_zero")
+        check(lib().htkamd_accs_zero(self.h, _stream(stream)), "accs_zero")
 
     def device_vector(self):
         p = C.c_void_p(); n = C.c_size_t()
@@ -256,14 +261,14 @@ class ForwardBackward:
         self.nUtt = len(frameOff) - 1
         self._keep = (frameOff, labOff, labs)
         b = BatchDesc(self.nUtt, C.c_void_p(dX_ptr), _p(frameOff), _p(labOff), _p(labs))
-        check(lib().htkamd_fb_prepare(self.h, C.byref(b), stream), "fb_prepare")
+        check(lib().htkamd_fb_prepare(self.h, C.byref(b), _stream(stream)), "fb_prepare")
 
     def execute(self, cfg: FbConfig, accs: Accs, stream=None):
-        check(lib().htkamd_fb_execute(self.h, C.byref(cfg), accs.h, stream), "fb_execute")
+        check(lib().htkamd_fb_execute(self.h, C.byref(cfg), accs.h, _stream(stream)), "fb_execute")
 
     def results(self, stream=None):
         pr = np.empty(self.nUtt, np.float64); st = np.empty(self.nUtt, np.int32)
-        check(lib().htkamd_fb_results(self.h, _p(pr), _p(st), stream), "fb_results")
+        check(lib().htkamd_fb_results(self.h, _p(pr), _p(st), _stream(stream)), "fb_results")
         return pr, st
 
     def frame_states(self) -> int:
@@ -314,14 +319,14 @@ class Viterbi:
         self._keep = (frameOff, labOff, labs)
         nUtt = len(frameOff) - 1
         b = BatchDesc(nUtt, C.c_void_p(dX_ptr), _p(frameOff), _p(labOff), _p(labs))
-        check(lib().htkamd_viterbi_align(self.h, C.byref(b), C.c_float(genBeam), stream), "viterbi_align")
+        check(lib().htkamd_viterbi_align(self.h, C.byref(b), C.c_float(genBeam), _stream(stream)), "viterbi_align")
         ns = C.c_size_t(); nm = C.c_size_t()
         check(lib().htkamd_viterbi_sizes(self.h, C.byref(ns), C.byref(nm)), "viterbi_sizes")
         r = dict(segStart=np.empty(ns.value, np.int32), segEnd=np.empty(ns.value, np.int32), segScore=np.empty(ns.value, np.float64),
                  modStart=np.empty(nm.value, np.int32), modEnd=np.empty(nm.value, np.int32), modScore=np.empty(nm.value, np.float64),
                  total=np.empty(nUtt, np.float64), status=np.empty(nUtt, np.int32))
         check(lib().htkamd_viterbi_results(self.h, _p(r["segStart"]), _p(r["segEnd"]), _p(r["segScore"]), _p(r["modStart"]),
-                                           _p(r["modEnd"]), _p(r["modScore"]), _p(r["total"]), _p(r["status"]), stream), "viterbi_results")
+                                           _p(r["modEnd"]), _p(r["modScore"]), _p(r["total"]), _p(r["status"]), _stream(stream)), "viterbi_results")
         # split per utterance
         m = self.model
         k = m._keep
@@ -407,7 +412,7 @@ class Mfcc:
         dW = DevArray(allw if len(allw) else np.zeros(1, np.int16))
         dO = DevArray(nbytes=4 * max(total, 1) * self.cols)
         frameOff = np.zeros(len(waves) + 1, np.int32)
-        check(lib().htkamd_mfcc_compute(self.h, dW.ptr, _p(sampOff), C.c_int(len(waves)), _p(frameOff), dO.ptr, stream), "mfcc_compute")
+        check(lib().htkamd_mfcc_compute(self.h, dW.ptr, _p(sampOff), C.c_int(len(waves)), _p(frameOff), dO.ptr, _stream(stream)), "mfcc_compute")
         assert frameOff[-1] == total
         return dO, frameOff
 
