@@ -230,7 +230,7 @@ def main():
             ach = units_local * flop_unit / float(ktimes_solo[0]) / 1e12
             out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha_stats": ktimes_solo[2] * 1e3, "mix_stats": ktimes_solo[3] * 1e3}
             out["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:               # the CPU leg runs at N = 1 only
             n, cdt = cpu_baseline(s, pk, args.cpu_seconds)
             per_utt = units_local / max(len(s.feats), 1)
             out["cpu_baseline"] = {"value": n * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",
