@@ -1,0 +1,158 @@
+"""Randomised parity sweep of the HIP path against the oracle (run on the GPU box; not part of the test-suite because of its
+run time): forward-backward (pr, beams, accumulators) with random topologies / pruning / ragged batches, forced alignment
+with random beams, network decoding over random word networks.   python tools/fuzz_parity.py [iterations] [seed]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from htk_amd import capi, synth  # noqa: E402
+import pyoracle  # noqa: E402
+from util import batch_arrays  # noqa: E402
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3))) if a.size else 0.0
+
+
+def fuzz_fb(rng, it):
+    if rng.random() < 0.5:
+        pk, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=int(rng.choice([13, 26, 39])), NU=int(rng.integers(2, 7)))
+    else:
+        s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 6)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
+                           int(rng.integers(30, 140)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 20, 39])))
+        pk, seqs, feats = s.packed(), s.seqs, s.feats
+    feats = [f[: max(3, len(f) - int(rng.integers(0, 10)))] for f in feats]          # ragged
+    prune = {}
+    r = rng.random()
+    if r < 0.35:
+        prune = dict(pruneInit=float(rng.uniform(20, 200)), pruneInc=0.0, pruneLim=0.0)
+        prune["pruneLim"] = prune["pruneInit"]
+    elif r < 0.6:
+        prune = dict(pruneInit=float(rng.uniform(1, 30)), pruneInc=float(rng.uniform(5, 40)), pruneLim=float(rng.uniform(60, 300)))
+    general = bool(rng.random() < 0.3)
+    mode = int(rng.random() < 0.3 and pk["vecSize"] in (13, 26, 39))
+    model = capi.Model(pk); om = pyoracle.Model(pk)
+    utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(seqs, feats)]
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = capi.DevArray(X)
+    fb = capi.ForwardBackward(model, debug=False, force_general=general)
+    acc = capi.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+    fb.execute(capi.fb_config(scoreMode=mode, **prune), acc)
+    pr, st = fb.results()
+    a = acc.download()
+    oacc = pyoracle.Accs(om)
+    ocfg = pyoracle.fb_cfg(**prune)
+    bad = []
+    for u, ut in enumerate(utts):
+        rc, opr, _ = pyoracle.fb_utt(om, ocfg, ut["feat"], ut["seq"], oacc)
+        ok_o = rc == 1
+        if (st[u] == 1) != ok_o:
+            bad.append("status u%d gpu %d oracle rc %d" % (u, st[u], rc))
+        elif ok_o and abs(pr[u] - opr) > (1e-6 if mode else 1e-10) * abs(opr):
+            bad.append("pr u%d %r vs %r" % (u, pr[u], opr))
+    tol = 2e-4 if mode else 1e-4
+    for k in ("muOcc", "wtOcc", "trOcc", "tr", "wt"):
+        e = rel(a[k], getattr(oacc, k))
+        if e > tol:
+            bad.append("%s rel %.3g" % (k, e))
+    if bad:
+        print("FB  it %d general=%s mode=%d prune=%s: %s" % (it, general, mode, prune, "; ".join(bad)))
+    return not bad
+
+
+def fuzz_align(rng, it):
+    s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 5)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
+                       int(rng.integers(40, 150)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 39])))
+    pk = s.packed()
+    beam = float(rng.choice([1.0e10, rng.uniform(5, 80)]))
+    model = capi.Model(pk); om = pyoracle.Model(pk)
+    utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(s.seqs, s.feats)]
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = capi.DevArray(X)                              # must outlive the call
+    got = capi.Viterbi(model).align(dX.ptr.value, frameOff, labOff, labs, genBeam=beam)
+    ok = True
+    for u, g in enumerate(got):
+        r = pyoracle.viterbi_align(om, s.feats[u], utts[u]["seq"], genBeam=beam)
+        if r is None:
+            ok &= g["status"] == 0
+            continue
+        v = g["segStart"] >= 0
+        good = bool(g["status"] == 1 and g["total"] == r["total"] and int(v.sum()) == int(r["n"]) and
+                    np.array_equal(g["segStart"][v], r["start"][: r["n"]]) and np.array_equal(g["segScore"][v], r["score"][: r["n"]]))
+        if not good:
+            print("   u%d status %d total %r vs %r, n %d vs %d" % (u, g["status"], g["total"], r["total"], int(v.sum()), int(r["n"])))
+        ok &= good
+    if not ok:
+        print("ALIGN it %d beam %g mismatch" % (it, beam))
+    return ok
+
+
+def fuzz_decode(rng, it, tmp):
+    NP = int(rng.integers(6, 30))
+    s = synth.generate(int(rng.integers(20, 60)), int(rng.integers(1, 4)), NP, int(rng.integers(2, 5)), int(rng.integers(40, 120)), int(rng.integers(1, 10**6)), D=13)
+    d = os.path.join(tmp, "d%d" % it); os.makedirs(d, exist_ok=True)
+    synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
+    names = ["p%d" % i for i in range(NP)]
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    V = int(rng.integers(3, 12))
+    words = []
+    with open(os.path.join(d, "dict"), "w") as f:
+        for w in range(V):
+            for v in range(int(rng.integers(1, 3))):
+                ph = [names[int(k)] for k in rng.integers(0, NP, size=int(rng.integers(1, 4)))]
+                pp = "" if rng.random() < 0.5 else "%.2f " % rng.uniform(0.1, 1.0)
+                f.write("W%d %s%s\n" % (w, pp, " ".join(ph)))
+            words.append("W%d" % w)
+    arcs = []
+    for w in range(V):
+        arcs.append((0, 1 + w, float(np.log(1.0 / V))))
+        for k in rng.choice(V, size=min(V, 3), replace=False):
+            arcs.append((1 + w, 1 + int(k), float(np.log(rng.uniform(0.05, 0.5)))))
+        arcs.append((1 + w, V + 1, float(np.log(0.1))))
+    with open(os.path.join(d, "net.slf"), "w") as f:
+        f.write("VERSION=1.0\nN=%d L=%d\nI=0 W=!NULL\n" % (V + 2, len(arcs)))
+        for w in range(V):
+            f.write("I=%d W=%s\n" % (1 + w, words[w]))
+        f.write("I=%d W=!NULL\n" % (V + 1))
+        for j, (a_, b_, l) in enumerate(arcs):
+            f.write("J=%d S=%d E=%d l=%.4f\n" % (j, a_, b_, l))
+    mmf = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
+    net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
+    p = dict(genBeam=float(rng.choice([1.0e10, rng.uniform(20, 200)])), wordBeam=float(rng.choice([1.0e10, rng.uniform(10, 100)])),
+             lmScale=float(rng.choice([1.0, rng.uniform(0.5, 8)])), wordPen=float(rng.choice([0.0, rng.uniform(-20, 10)])), prScale=float(rng.choice([1.0, rng.uniform(0.5, 3)])))
+    model = capi.Model(mmf.packed()); om = pyoracle.Model(mmf.packed())
+    res = capi.Decoder(model, net, lmScale=p["lmScale"]).run(s.feats, **p)
+    ok = True
+    for u, (words_g, total) in enumerate(res):
+        ow, ot = pyoracle.decode(om, s.feats[u], net.arrays(), **p)
+        if words_g != ow or (ow is not None and total != ot):
+            ok = False
+            print("DECODE it %d u%d params %s\n  gpu    %s\n  oracle %s" % (it, u, p, words_g, ow))
+    return ok
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    tmp = tempfile.mkdtemp()
+    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0])
+    for it in range(n):
+        for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp))):
+            try:
+                ok = fn()
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                print("%s it %d raised %r" % (name, it, e))
+            res[name][0] += 1; res[name][1] += int(ok)
+    print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})
+    sys.exit(0 if all(v[0] == v[1] for v in res.values()) else 1)
+
+
+if __name__ == "__main__":
+    main()
