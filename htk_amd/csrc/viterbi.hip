@@ -258,6 +258,136 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
    }
 }
 
+// ------------------------------------------------------------------------------------ general form
+// Chains of more than 64 models or models of more than VMAXN states: one workgroup per utterance, thread = model for
+// pass 1 (tokens in LDS), thread 0 walks the exit -> entry chain of pass 2 (it is sequential in the reference too:
+// instance-list order).  Same arithmetic, same trellis layout as k_viterbi_w, so k_viterbi_trace serves both.
+#define VG_THREADS 256
+#define VG_MAXN 16
+__global__ __launch_bounds__(VG_THREADS) void k_viterbi_g(VitArgs a)
+{
+   extern __shared__ double vsm[];
+   __shared__ double red[VG_THREADS / 64];
+   __shared__ float gthr;
+   const int u = blockIdx.x, tid = threadIdx.x;
+   if (u >= a.nUtt) return;
+   const VitUtt ud = a.utt[u];
+   if (ud.status != HTKAMD_UTT_OK) { if (tid == 0) { a.status[u] = ud.status; a.total[u] = LZERO; } return; }
+   const int T = ud.T, Q = ud.Q, nSlots = ud.nSlots;
+   int maxN = 0;
+   for (int q = 0; q < Q; q++) { const int n = a.mN[ud.q0 + q]; if (n > maxN) maxN = n; }
+   const int LS = maxN + 1;
+   double *like = vsm;                                   // like[(q-1)*LS + i], i = 1..N-1
+   double *exitL = like + (size_t)Q * LS, *instMax = exitL + Q;
+   signed char *exArgS = (signed char *)(instMax + Q), *active = exArgS + Q;
+   for (int k = tid; k < Q * LS; k += VG_THREADS) like[k] = LZERO;
+   for (int k = tid; k < Q; k += VG_THREADS) { exitL[k] = LZERO; instMax[k] = LZERO; exArgS[k] = 0; active[k] = 0; }
+   if (tid == 0) gthr = (float)LSMALL;
+   __syncthreads();
+   signed char *gbp = a.bp + ud.tr0; double *gpre = a.pre + ud.tr0;
+   double *gexl = a.exl + ud.mt0, *gent = a.entAt + ud.mt0; signed char *gexbp = a.exbp + ud.mt0;
+   double finalLike = LZERO;
+
+   for (int t = 0; t <= T; t++) {
+      if (t >= 1) {
+         const float genThresh = gthr;                    // previous frame's threshold
+         double myMax = LZERO;
+         for (int q = tid; q < Q; q += VG_THREADS) {
+            if (!active[q]) { exitL[q] = LZERO; exArgS[q] = 0; continue; }
+            const int N = a.mN[ud.q0 + q], ms0 = a.mSlot0[ud.q0 + q];
+            const float *tp = a.transP + a.mTp[ud.q0 + q];
+            double *lk = like + (size_t)q * LS;
+            double nw[VG_MAXN];
+            double mx = LZERO;
+            for (int j = 2; j < N; j++) {
+               int lo = 1, hi = N - 1;                    // CreateSEIndex (HRec.c:1403)
+               while (lo < N && !(tp[(lo - 1) * N + (j - 1)] > (float)LSMALL)) lo++;
+               while (hi > 1 && !(tp[(hi - 1) * N + (j - 1)] > (float)LSMALL)) hi--;
+               if (lo > hi) { lo = 1; hi = N - 1; }
+               int arg = lo;
+               double best = lk[lo] + (double)tp[(lo - 1) * N + (j - 1)];
+               for (int i = lo + 1; i <= hi; i++) {
+                  const double c = lk[i] + (double)tp[(i - 1) * N + (j - 1)];
+                  if (c > best) { best = c; arg = i; }
+               }
+               gpre[(size_t)(t - 1) * nSlots + ms0 + j - 2] = best;
+               gbp[(size_t)(t - 1) * nSlots + ms0 + j - 2] = (signed char)arg;
+               nw[j] = LZERO;
+               if (best > genThresh) {
+                  nw[j] = best + (double)a.outp[ud.outp0 + (size_t)(ms0 + j - 2) * T + (t - 1)];
+                  if (nw[j] > mx) mx = nw[j];
+               }
+            }
+            lk[1] = LZERO;
+            for (int j = 2; j < N; j++) lk[j] = nw[j];
+            instMax[q] = mx;
+            if (mx > myMax) myMax = mx;
+            int lo = 2, hi = N - 1;
+            while (lo < N && !(tp[(lo - 1) * N + (N - 1)] > (float)LSMALL)) lo++;
+            while (hi > 1 && !(tp[(hi - 1) * N + (N - 1)] > (float)LSMALL)) hi--;
+            if (lo > hi) { lo = 2; hi = N - 1; }
+            int arg = lo;
+            double best = lk[lo] + (double)tp[(lo - 1) * N + (N - 1)];
+            for (int i = lo + 1; i <= hi; i++) {
+               const double c = lk[i] + (double)tp[(i - 1) * N + (N - 1)];
+               if (c > best) { best = c; arg = i; }
+            }
+            if (best > LSMALL) { exitL[q] = best; exArgS[q] = (signed char)arg; } else { exitL[q] = LZERO; exArgS[q] = 0; }
+         }
+         for (int o = 32; o > 0; o >>= 1) myMax = fmax(myMax, __shfl_xor(myMax, o));
+         __syncthreads();
+         if ((tid & 63) == 0) red[tid >> 6] = myMax;
+         __syncthreads();
+         if (tid == 0) {
+            double g = red[0];
+            for (int k = 1; k < VG_THREADS / 64; k++) g = fmax(g, red[k]);
+            float th = (float)(g - (double)a.genBeam);
+            if (th < (float)LSMALL) th = (float)LSMALL;
+            gthr = th;
+         }
+         __syncthreads();
+      }
+      if (tid == 0) {                                     // pass 2 in chain order (HRec.c:2007-2016)
+         const float genThresh = gthr;
+         double carry = (t == 0) ? 0.0 : LZERO;
+         bool haveCarry = (t == 0);
+         for (int q = 0; q < Q; q++) {
+            const int N = a.mN[ud.q0 + q];
+            const float *tp = a.transP + a.mTp[ud.q0 + q];
+            double *lk = like + (size_t)q * LS;
+            if (haveCarry && carry > genThresh) {          // SetEntryState
+               if (!active[q]) { active[q] = 1; instMax[q] = LZERO; exitL[q] = LZERO; exArgS[q] = 0; for (int i = 1; i < N; i++) lk[i] = LZERO; }
+               if (carry > lk[1]) lk[1] = carry;
+               if (lk[1] > instMax[q]) instMax[q] = lk[1];
+            }
+            haveCarry = false; carry = LZERO;
+            if (active[q]) {
+               if (instMax[q] < genThresh) {              // DetachInst
+                  active[q] = 0; exitL[q] = LZERO; exArgS[q] = 0;
+                  for (int i = 1; i < N; i++) lk[i] = LZERO;
+               } else {
+                  const float a1N = tp[N - 1];
+                  if (a1N > (float)LSMALL) {              // StepHMM2
+                     const double c = lk[1] + (double)a1N;
+                     if (c > exitL[q]) { exitL[q] = c; exArgS[q] = 1; }
+                  }
+                  if (exitL[q] > genThresh) { carry = exitL[q]; haveCarry = true; }
+               }
+            }
+            gent[(size_t)t * Q + q] = active[q] ? lk[1] : LZERO;
+            gexl[(size_t)t * Q + q] = active[q] ? exitL[q] : LZERO;
+            gexbp[(size_t)t * Q + q] = exArgS[q];
+         }
+         if (t == T) finalLike = (haveCarry && carry > LSMALL) ? carry : LZERO;
+      }
+      __syncthreads();
+   }
+   if (tid == 0) {
+      a.total[u] = finalLike;
+      a.status[u] = (finalLike > LSMALL) ? HTKAMD_UTT_OK : HTKAMD_UTT_SKIPPED;
+   }
+}
+
 // one lane per utterance: walk the back-pointers (LatFromPaths / TranscriptionFromLattice restated on the trellis)
 __global__ void k_viterbi_trace(VitArgs a)
 {
@@ -337,7 +467,7 @@ struct htkamd_viterbi {
 extern "C" int htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out)
 {
    if (!m || !out) { htkamd_set_error("viterbi_create: NULL argument"); return HTKAMD_EINVAL; }
-   if (m->maxN > VMAXN) { htkamd_set_error("viterbi_create: models with %d states; this path handles up to %d", m->maxN, VMAXN); return HTKAMD_EMODEL; }
+   if (m->maxN > VG_MAXN) { htkamd_set_error("viterbi_create: models with %d states; this path handles up to %d", m->maxN, VG_MAXN); return HTKAMD_EMODEL; }
    htkamd_viterbi *v = new htkamd_viterbi();
    v->m = m; v->nUtt = 0; v->segTotal = v->modTotal = 0;
    *out = v;
@@ -374,6 +504,8 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
    v->utt.assign(U, VitUtt());
    v->mN.clear(); v->mTp.clear(); v->mSlot0.clear(); v->slotState.clear(); v->tasks.clear();
    size_t outp = 0, tr = 0, mt = 0, seg = 0, mod = 0;
+   bool general = m->maxN > VMAXN;                       // long chains or big models: k_viterbi_g
+   int maxQ = 1;
    for (int u = 0; u < U; u++) {
       VitUtt &d = v->utt[u];
       const int T = b->frameOff[u + 1] - b->frameOff[u], Q = b->labOff[u + 1] - b->labOff[u];
@@ -382,7 +514,9 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
       d.status = HTKAMD_UTT_OK; d.pad = 0; d.outp0 = outp; d.tr0 = tr; d.mt0 = mt; d.seg0 = seg; d.mod0 = mod;
       int nSlots = 0;
       if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nSlots = 0; continue; }
-      if (Q > 64) { htkamd_set_error("viterbi_align: utterance %d has %d models; this path handles up to 64", u, Q); return HTKAMD_EINVAL; }
+      if (Q > 4000) { htkamd_set_error("viterbi_align: utterance %d has %d models (max 4000)", u, Q); return HTKAMD_EINVAL; }
+      if (Q > 64) general = true;
+      if (Q > maxQ) maxQ = Q;
       for (int q = 1; q <= Q; q++) {
          const int h = labs[q - 1];
          if (h < 0 || h >= m->H) { htkamd_set_error("viterbi_align: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
@@ -434,7 +568,13 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
    va.modStart = (int *)v->d_modStart.p; va.modEnd = (int *)v->d_modEnd.p; va.modScore = (double *)v->d_modScore.p;
    va.total = (double *)v->d_total.p; va.status = (int *)v->d_status.p;
    va.genBeam = genBeam;
-   hipLaunchKernelGGL((k_viterbi_w<VMAXN>), dim3((U + VWPB - 1) / VWPB), dim3(64 * VWPB), 0, s, va);
+   if (!general) hipLaunchKernelGGL((k_viterbi_w<VMAXN>), dim3((U + VWPB - 1) / VWPB), dim3(64 * VWPB), 0, s, va);
+   else {
+      const size_t lds = sizeof(double) * ((size_t)maxQ * (m->maxN + 1) + 2 * (size_t)maxQ) + 2 * (size_t)maxQ + 64;
+      if (lds > 150 * 1024) { htkamd_set_error("viterbi_align: %d models of up to %d states need %zu bytes of LDS", maxQ, m->maxN, lds); return HTKAMD_EMODEL; }
+      if (lds > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void *)k_viterbi_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_viterbi_g, dim3(U), dim3(VG_THREADS), lds, s, va);
+   }
    HIPCHECK(hipGetLastError());
    hipLaunchKernelGGL(k_viterbi_trace, dim3((U + 63) / 64), dim3(64), 0, s, va);
    HIPCHECK(hipGetLastError());

@@ -458,3 +458,26 @@ def test_wav_to_scores_on_device(native, oracle):
     assert np.array_equal(got, om.score_block(X, states))                 # scoring of the device features: bit-exact
     ref = om.score_block(oracle.mfcc(_test_wave(), oracle.mfcc_cfg("MFCC_0_D_A")), states)
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-2)
+
+
+def test_viterbi_long_chains_general_kernel(native, oracle):
+    """Transcriptions of more than 64 models (one wavefront cannot hold them) go through the workgroup-per-utterance
+    kernel: same tokens, same segments as the oracle; short and long utterances mixed in one batch, with and without a beam."""
+    from htk_amd import synth
+    s = synth.generate(60, 3, 40, 3, 700, 23, D=13)
+    pk = s.packed()
+    rng = np.random.default_rng(4)
+    seqs = [np.asarray(rng.integers(0, 40, size=n), np.int32) for n in (90, 30, 150)]
+    feats = []
+    for q in seqs:                                                  # 4 frames per state of the chain
+        fr = []
+        for h in q:
+            for st in pk["hmmState"][pk["hmmStateOff"][h]:pk["hmmStateOff"][h + 1]]:
+                c = pk["stateCompOff"][st]
+                fr.append(pk["mean"][pk["compGauss"][c]] + rng.normal(size=(4, 13)) * np.sqrt(pk["var"][pk["compGauss"][c]]))
+        feats.append(np.concatenate(fr).astype(np.float32))
+    om = oracle.Model(pk)
+    for beam in (1.0e10, 60.0):
+        got = _align(native, pk, seqs, feats, beam=beam)
+        _check_vs_oracle(oracle, om, got, seqs, feats, beam)
+        assert all(g["status"] == 1 for g in got)
