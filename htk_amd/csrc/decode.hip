@@ -36,11 +36,12 @@
 #define DEC_WIDE 96             /* fan-in from which a node is reduced by the whole workgroup */
 
 struct DecNet {
-   int nNodes, nHmm, nLevels, nWordNodes, initial, final, nTok;
+   int nNodes, nHmm, nLevels, nWordNodes, initial, final, nTok, nTpFloats;
    const int *kind, *model;            // [nNodes]
    const float *pronProb;              // [nNodes]
-   const int *predOff, *predSrc;       // reverse CSR
+   const int *predOff, *predSrc;       // reverse CSR; bit 31 of predSrc: the predecessor is a word/null node
    const float *predLike;
+   const int4 *nodeInfo;               // [nNodes] {kind | N << 4 | tee << 12, first token, offset of transP, offset into hmmState}
    const int *tok0;                    // [nNodes] first token (state 1) of the node
    const int *hmmNodes;                // [nHmm] model nodes (tee or not)
    const int *nodeN, *nodeTp, *nodeSt; // [nNodes] HMM: numStates, offset of transP, offset into hmmState
@@ -64,36 +65,36 @@ struct DecUtt {
    size_t out0;        // word output base
 };
 
+struct __attribute__((aligned(16))) Tok { double like; float lm; int path; };   // one 16-byte load/store per token
+
 struct DecArgs {
    DecNet net;
    const DecUtt *utt; int nUtt;
    const float *score;
-   double *tokLike; float *tokLm; int *tokPath;
-   double *exLike; float *exLm; int *exPath; double *imax;
+   Tok *tok;                           // [sum nTok]   state tokens
+   Tok *ex; double *imax;              // [sum nNodes] exit tokens, instance maxima
    int *pathPrev; double *pathLike; float *pathLm;
    float genBeam, wordBeam, lmScale, wordPen, prScale;
    int maxWords;
    int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore; double *total;
 };
 
-struct Tok { double like; float lm; int path; };
-
 __device__ __forceinline__ Tok null_tok() { Tok t; t.like = LZERO; t.lm = 0.0f; t.path = -1; return t; }
 
 // entry token of node n: best over predecessors (SetEntryState over StepInst2's sends), first maximum wins
-__device__ __forceinline__ Tok pull_range(const DecArgs &a, const DecUtt &ud, int k0, int k1, int kstep, float gT, float wT, int *argk)
+__device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k0, int k1, int kstep, float gT, float wT, int *argk)
 {
    Tok best = null_tok();
    int arg = 0x7fffffff;
    for (int k = k0; k < k1; k += kstep) {
-      const int p = a.net.predSrc[k];
-      const double el = a.exLike[ud.node0 + p];
-      if (!(el > gT)) continue;
-      if (a.net.kind[p] != HTKAMD_NODE_HMM && el < wT) continue;       // word-end beam on word/null tokens
+      const int ps = a.net.predSrc[k];
       const float lm = a.net.predLike[k];
-      const double c = el + lm * a.lmScale;
+      const Tok e = ex[ps & 0x7fffffff];
+      if (!(e.like > gT)) continue;
+      if (ps < 0 && e.like < wT) continue;                            // word-end beam on word/null tokens
+      const double c = e.like + lm * a.lmScale;
       if (!(c > gT)) continue;
-      if (c > best.like) { best.like = c; best.lm = a.exLm[ud.node0 + p] + lm; best.path = a.exPath[ud.node0 + p]; arg = k; }
+      if (c > best.like) { best.like = c; best.lm = e.lm + lm; best.path = e.path; arg = k; }
    }
    *argk = arg;
    return best;
@@ -112,22 +113,28 @@ __device__ __forceinline__ double block_max(double v, double *red)
    return r;
 }
 
+#define DEC_LDS_TP 4096            /* floats of transition matrices cached in LDS (all of them, else global memory) */
+
 __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
 {
    __shared__ double red[DEC_THREADS / 64];
    __shared__ double red2[DEC_THREADS / 64];
    __shared__ int redk[DEC_THREADS / 64];
    __shared__ float thr[2];
+   __shared__ float ltp[DEC_LDS_TP];
    const int u = blockIdx.x, tid = threadIdx.x;
    if (u >= a.nUtt) return;
    const DecUtt ud = a.utt[u];
    const DecNet &N = a.net;
    const int T = ud.T;
-   double *tokLike = a.tokLike + ud.tok0; float *tokLm = a.tokLm + ud.tok0; int *tokPath = a.tokPath + ud.tok0;
-   double *exLike = a.exLike + ud.node0; float *exLm = a.exLm + ud.node0; int *exPath = a.exPath + ud.node0; double *imax = a.imax + ud.node0;
+   Tok *tok = a.tok + ud.tok0, *ex = a.ex + ud.node0;
+   double *imax = a.imax + ud.node0;
+   const bool tpInLds = N.nTpFloats <= DEC_LDS_TP;
+   if (tpInLds) for (int i = tid; i < N.nTpFloats; i += DEC_THREADS) ltp[i] = N.transP[i];
+   const float *tpBase = tpInLds ? ltp : N.transP;
 
-   for (int i = tid; i < N.nTok; i += DEC_THREADS) { tokLike[i] = LZERO; tokLm[i] = 0.0f; tokPath[i] = -1; }
-   for (int i = tid; i < N.nNodes; i += DEC_THREADS) { exLike[i] = LZERO; exLm[i] = 0.0f; exPath[i] = -1; imax[i] = LZERO; }
+   for (int i = tid; i < N.nTok; i += DEC_THREADS) tok[i] = null_tok();
+   for (int i = tid; i < N.nNodes; i += DEC_THREADS) { ex[i] = null_tok(); imax[i] = LZERO; }
    if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; }
    __syncthreads();
 
@@ -137,8 +144,9 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
          double myGen = LZERO, myWord = LZERO;
          for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
             const int n = N.hmmNodes[hk];
-            const int NS = N.nodeN[n], t0 = N.tok0[n];
-            const float *tp = N.transP + N.nodeTp[n];
+            const int4 ni = N.nodeInfo[n];
+            const int NS = (ni.x >> 4) & 255, t0 = ni.y;
+            const float *tp = tpBase + ni.z;
             Tok s[DEC_MAXN];
             const bool detached = imax[n] < gT;           // DetachInst of the previous frame's pass 2
             bool live = false;
@@ -146,11 +154,11 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             for (int i = 1; i < DEC_MAXN; i++) {
                s[i] = null_tok();
                // the entry token (i == 1) was pulled at the end of the previous frame's level phase
-               if (i < NS && (i == 1 || !detached)) { s[i].like = tokLike[t0 + i - 1]; s[i].lm = tokLm[t0 + i - 1]; s[i].path = tokPath[t0 + i - 1]; }
+               if (i < NS && (i == 1 || !detached)) s[i] = tok[t0 + i - 1];
             }
 #pragma unroll
             for (int i = 1; i < DEC_MAXN; i++) if (i < NS && s[i].like > LSMALL) live = true;
-            Tok ex = null_tok();
+            Tok exT = null_tok();
             double mx = LZERO;
             if (live) {
                Tok nw[DEC_MAXN];
@@ -163,13 +171,16 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                      while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
                      while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
                      if (lo > hi) { lo = 1; hi = NS - 1; }
-                     Tok best = s[lo]; best.like += tp[(lo - 1) * NS + (j - 1)];
-                     for (int i = lo + 1; i <= hi; i++) {
-                        const double c = s[i].like + tp[(i - 1) * NS + (j - 1)];
-                        if (c > best.like) { best = s[i]; best.like = c; }
-                     }
+                     Tok best = s[1]; double bl = LZERO;
+#pragma unroll
+                     for (int i = 1; i < DEC_MAXN; i++)
+                        if (i >= lo && i <= hi) {
+                           const double c = s[i].like + tp[(i - 1) * NS + (j - 1)];
+                           if (i == lo || c > bl) { best = s[i]; bl = c; }
+                        }
+                     best.like = bl;
                      if (best.like > gT) {
-                        const int st = N.hmmState[N.nodeSt[n] + (j - 2)];
+                        const int st = N.hmmState[ni.w + (j - 2)];
                         best.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
                         nw[j] = best;
                         if (best.like > mx) mx = best.like;
@@ -181,26 +192,28 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                   while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
                   while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
                   if (lo > hi) { lo = 2; hi = NS - 1; }
-                  Tok best = nw[lo]; best.like += tp[(lo - 1) * NS + (NS - 1)];
-                  for (int i = lo + 1; i <= hi; i++) {
-                     const double c = nw[i].like + tp[(i - 1) * NS + (NS - 1)];
-                     if (c > best.like) { best = nw[i]; best.like = c; }
-                  }
+                  Tok best = nw[2]; double bl = LZERO;
+#pragma unroll
+                  for (int i = 2; i < DEC_MAXN; i++)
+                     if (i >= lo && i <= hi) {
+                        const double c = nw[i].like + tp[(i - 1) * NS + (NS - 1)];
+                        if (i == lo || c > bl) { best = nw[i]; bl = c; }
+                     }
+                  best.like = bl;
                   if (best.like > LSMALL) {
-                     ex = best;
+                     exT = best;
                      const double w = best.like + N.wdlk[n];
                      if (w > myWord) myWord = w;
                   }
                }
-               tokLike[t0] = LZERO; tokLm[t0] = 0.0f; tokPath[t0] = -1;       // entry consumed
+               tok[t0] = null_tok();                        // entry consumed
 #pragma unroll
-               for (int j = 2; j < DEC_MAXN; j++)
-                  if (j < NS) { tokLike[t0 + j - 1] = nw[j].like; tokLm[t0 + j - 1] = nw[j].lm; tokPath[t0 + j - 1] = nw[j].path; }
+               for (int j = 2; j < DEC_MAXN; j++) if (j < NS) tok[t0 + j - 1] = nw[j];
                if (mx > myGen) myGen = mx;
             } else if (detached) {
-               for (int i = 1; i < NS; i++) { tokLike[t0 + i - 1] = LZERO; tokLm[t0 + i - 1] = 0.0f; tokPath[t0 + i - 1] = -1; }
+               for (int i = 1; i < NS; i++) tok[t0 + i - 1] = null_tok();
             }
-            exLike[n] = ex.like; exLm[n] = ex.lm; exPath[n] = ex.path; imax[n] = mx;
+            ex[n] = exT; imax[n] = mx;
          }
          const double genMax = block_max(myGen, red);
          const double wordMax = block_max(myWord, red2);
@@ -217,36 +230,38 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
          const int l0 = N.levelOff[L], lw = N.levelWide[L], l1 = N.levelOff[L + 1];
          for (int k = l0 + tid; k < lw; k += DEC_THREADS) {
             const int n = N.levelNodes[k];
+            const int4 ni = N.nodeInfo[n];
+            const int kind = ni.x & 15;
             int ak;
-            Tok st = pull_range(a, ud, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            Tok st = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
             if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; }
-            Tok ex = null_tok();
-            if (N.kind[n] == HTKAMD_NODE_HMM) {            // tee model: StepHMM2
-               const int NS = N.nodeN[n], t0 = N.tok0[n];
-               tokLike[t0] = st.like; tokLm[t0] = st.lm; tokPath[t0] = st.path;
-               ex.like = exLike[n]; ex.lm = exLm[n]; ex.path = exPath[n];
+            Tok e = null_tok();
+            if (kind == HTKAMD_NODE_HMM) {                 // tee model: StepHMM2
+               const int NS = (ni.x >> 4) & 255;
+               tok[ni.y] = st;
+               e = ex[n];
                const double m2 = (st.like > imax[n]) ? st.like : imax[n];
-               if (t >= 1 && m2 < gT) ex = null_tok();
+               if (t >= 1 && m2 < gT) e = null_tok();
                else if (st.like > LSMALL) {
-                  const double c = st.like + N.transP[N.nodeTp[n] + (NS - 1)];
-                  if (c > ex.like) { ex = st; ex.like = c; }
+                  const double c = st.like + tpBase[ni.z + (NS - 1)];
+                  if (c > e.like) { e = st; e.like = c; }
                }
             } else if (st.like > LSMALL) {
-               ex = st;
-               if (N.kind[n] == HTKAMD_NODE_WORD) {        // StepWord2
-                  ex.like += a.wordPen;
-                  ex.like += N.pronProb[n] * a.prScale;
+               e = st;
+               if (kind == HTKAMD_NODE_WORD) {             // StepWord2
+                  e.like += a.wordPen;
+                  e.like += N.pronProb[n] * a.prScale;
                   const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
-                  a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = ex.like; a.pathLm[ud.path0 + pid] = ex.lm;
-                  ex.path = (int)pid; ex.lm = 0.0f;
+                  a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
+                  e.path = (int)pid; e.lm = 0.0f;
                }
             }
-            exLike[n] = ex.like; exLm[n] = ex.lm; exPath[n] = ex.path;
+            ex[n] = e;
          }
          for (int k = lw; k < l1; k++) {                  // wide fan-in: the whole workgroup reduces one node
             const int n = N.levelNodes[k];
             int ak;
-            Tok st = pull_range(a, ud, N.predOff[n] + tid, N.predOff[n + 1], DEC_THREADS, gT, wT, &ak);
+            Tok st = pull_range(a, ex, N.predOff[n] + tid, N.predOff[n + 1], DEC_THREADS, gT, wT, &ak);
             // argmax over the workgroup: larger like, then smaller predecessor position
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -263,18 +278,18 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                Tok b; b.like = red[bw]; b.lm = __int_as_float(__double2hiint(red2[bw])); b.path = __double2loint(red2[bw]);
                if (redk[bw] == 0x7fffffff) b = null_tok();
                if (t == 0 && n == N.initial) { b.like = 0.0; b.lm = 0.0f; b.path = -1; }
-               Tok ex = null_tok();
+               Tok e = null_tok();
                if (b.like > LSMALL) {
-                  ex = b;
+                  e = b;
                   if (N.kind[n] == HTKAMD_NODE_WORD) {
-                     ex.like += a.wordPen;
-                     ex.like += N.pronProb[n] * a.prScale;
+                     e.like += a.wordPen;
+                     e.like += N.pronProb[n] * a.prScale;
                      const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
-                     a.pathPrev[ud.path0 + pid] = b.path; a.pathLike[ud.path0 + pid] = ex.like; a.pathLm[ud.path0 + pid] = ex.lm;
-                     ex.path = (int)pid; ex.lm = 0.0f;
+                     a.pathPrev[ud.path0 + pid] = b.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
+                     e.path = (int)pid; e.lm = 0.0f;
                   }
                }
-               exLike[n] = ex.like; exLm[n] = ex.lm; exPath[n] = ex.path;
+               ex[n] = e;
             }
          }
          __syncthreads();
@@ -283,11 +298,10 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
       if (t < T) {
          for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
             const int n = N.hmmNodes[hk];
-            if (N.nodeTee[n]) continue;
+            const int4 ni = N.nodeInfo[n];
+            if ((ni.x >> 12) & 1) continue;                // tee models got theirs in the level phase
             int ak;
-            const Tok e = pull_range(a, ud, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
-            const int t0 = N.tok0[n];
-            tokLike[t0] = e.like; tokLm[t0] = e.lm; tokPath[t0] = e.path;
+            tok[ni.y] = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
          }
          __syncthreads();
       }
@@ -295,11 +309,12 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
 
    // ---- CompleteRecognition + LatFromPaths + TranscriptionFromLattice for the 1-best chain
    if (tid == 0) {
-      const int fp = exPath[N.final];
+      const Tok fin = ex[N.final];
+      const int fp = fin.path;
       int nW = 0;
       a.total[u] = LZERO;
       if (fp >= 0) {
-         a.total[u] = exLike[N.final];
+         a.total[u] = fin.like;
          for (int p = fp; p >= 0; p = a.pathPrev[ud.path0 + p]) nW++;
          if (nW > a.maxWords) nW = -3;
          else {
@@ -414,12 +429,16 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
    {
       std::vector<int> fill(predOff.begin(), predOff.end() - 1);
       for (int n = 0; n < nN; n++)
-         for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) { const int at = fill[nd->linkDest[k]]++; predSrc[at] = n; predLike[at] = nd->linkLike[k]; }
+         for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) {
+            const int at = fill[nd->linkDest[k]]++;
+            predSrc[at] = n | (kind[n] != HTKAMD_NODE_HMM ? (int)0x80000000 : 0);      // bit 31: word/null predecessor (word-end beam applies)
+            predLike[at] = nd->linkLike[k];
+         }
    }
    // levels of the zero-time sub-graph
    auto zt = [&](int n) { return kind[n] != HTKAMD_NODE_HMM || tee[n]; };
    std::vector<int> level(nN, -1), indeg(nN, 0), queue;
-   for (int n = 0; n < nN; n++) if (zt(n)) for (int k = predOff[n]; k < predOff[n + 1]; k++) if (zt(predSrc[k])) indeg[n]++;
+   for (int n = 0; n < nN; n++) if (zt(n)) for (int k = predOff[n]; k < predOff[n + 1]; k++) if (zt(predSrc[k] & 0x7fffffff)) indeg[n]++;
    for (int n = 0; n < nN; n++) if (zt(n) && indeg[n] == 0) { level[n] = 0; queue.push_back(n); }
    int nLevels = 0;
    for (size_t qi = 0; qi < queue.size(); qi++) {
@@ -450,15 +469,18 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       if (kind[n] == HTKAMD_NODE_HMM) for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) if (kind[nd->linkDest[k]] != HTKAMD_NODE_HMM) wd0 = true;
       if (wd0) wdlk[n] = like_to_word(nd, m, tee, n, lmScale);
    }
+   std::vector<int4> nodeInfo(nN);
+   for (int n = 0; n < nN; n++) nodeInfo[n] = make_int4(kind[n] | (nodeN[n] << 4) | ((int)tee[n] << 12), tok0[n], nodeTp[n], nodeSt[n]);
    DecNet &N = d->net;
    memset(&N, 0, sizeof(N));
-   N.nNodes = nN; N.nHmm = (int)hmmNodes.size(); N.nLevels = nLevels; N.nWordNodes = nW > 0 ? nW : 1; N.initial = nd->initial; N.final = nd->final; N.nTok = nTok;
+   N.nNodes = nN; N.nHmm = (int)hmmNodes.size(); N.nLevels = nLevels; N.nWordNodes = nW > 0 ? nW : 1; N.initial = nd->initial; N.final = nd->final; N.nTok = nTok; N.nTpFloats = m->h_transOff[m->nT];
    int rc;
    if ((rc = upv(d, kind, &N.kind)) || (rc = upv(d, model, &N.model)) || (rc = upv(d, pron, &N.pronProb)) || (rc = upv(d, predOff, &N.predOff)) ||
        (rc = upv(d, predSrc, &N.predSrc)) || (rc = upv(d, predLike, &N.predLike)) || (rc = upv(d, tok0, &N.tok0)) || (rc = upv(d, hmmNodes, &N.hmmNodes)) ||
        (rc = upv(d, nodeN, &N.nodeN)) || (rc = upv(d, nodeTp, &N.nodeTp)) || (rc = upv(d, nodeSt, &N.nodeSt)) || (rc = upv(d, tee, &N.nodeTee)) ||
        (rc = upv(d, wdlk, &N.wdlk)) || (rc = upv(d, wordIdx, &N.wordIdx)) || (rc = upv(d, levelOff, &N.levelOff)) || (rc = upv(d, levelNodes, &N.levelNodes)) ||
-       (rc = upv(d, levelWide, &N.levelWide)) || (rc = upv(d, stateSlot, &N.stateSlot)) || (rc = upv(d, wordNode, &N.wordNode))) { htkamd_decoder_destroy(d); return rc; }
+       (rc = upv(d, levelWide, &N.levelWide)) || (rc = upv(d, stateSlot, &N.stateSlot)) || (rc = upv(d, wordNode, &N.wordNode)) ||
+       (rc = upv(d, nodeInfo, &N.nodeInfo))) { htkamd_decoder_destroy(d); return rc; }
    {
       std::vector<int> hs(m->h_hmmState, m->h_hmmState + m->h_hmmStateOff[m->H]);
       if ((rc = upv(d, hs, &N.hmmState))) { htkamd_decoder_destroy(d); return rc; }
@@ -511,12 +533,11 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
             }
          score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += (size_t)(ud.T + 1) * N.nWordNodes;
       }
-      void *dScore = nullptr, *dTokLike = nullptr, *dTokLm = nullptr, *dTokPath = nullptr, *dExLike = nullptr, *dExLm = nullptr, *dExPath = nullptr, *dImax = nullptr;
+      void *dScore = nullptr, *dTok = nullptr, *dEx = nullptr, *dImax = nullptr;
       void *dPPrev = nullptr, *dPLike = nullptr, *dPLm = nullptr, *dUtt = nullptr, *dTasks = nullptr, *dOutI = nullptr, *dOutF = nullptr, *dTot = nullptr;
       int rc = HTKAMD_OK;
       auto A = [&](void **p, size_t n) { if (rc) return; hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) { htkamd_set_error("decoder_run: hipMalloc(%zu): %s", n, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; } };
-      A(&dScore, score * 4); A(&dTokLike, tok * 8); A(&dTokLm, tok * 4); A(&dTokPath, tok * 4);
-      A(&dExLike, node * 8); A(&dExLm, node * 4); A(&dExPath, node * 4); A(&dImax, node * 8);
+      A(&dScore, score * 4); A(&dTok, tok * sizeof(Tok)); A(&dEx, node * sizeof(Tok)); A(&dImax, node * 8);
       A(&dPPrev, path * 4); A(&dPLike, path * 8); A(&dPLm, path * 4);
       A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
       A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * (size_t)nu * maxWords); A(&dTot, sizeof(double) * nu);
@@ -540,8 +561,7 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
       if (!rc) {
          DecArgs a;
          a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
-         a.tokLike = (double *)dTokLike; a.tokLm = (float *)dTokLm; a.tokPath = (int *)dTokPath;
-         a.exLike = (double *)dExLike; a.exLm = (float *)dExLm; a.exPath = (int *)dExPath; a.imax = (double *)dImax;
+         a.tok = (Tok *)dTok; a.ex = (Tok *)dEx; a.imax = (double *)dImax;
          a.pathPrev = (int *)dPPrev; a.pathLike = (double *)dPLike; a.pathLm = (float *)dPLm;
          a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
          a.maxWords = maxWords;
@@ -560,7 +580,7 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
              (e = hipMemcpyAsync(hT.data(), dTot, sizeof(double) * nu, hipMemcpyDeviceToHost, s)) != hipSuccess ||
              (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       } else (void)hipStreamSynchronize(s);
-      for (void *p : {dScore, dTokLike, dTokLm, dTokPath, dExLike, dExLm, dExPath, dImax, dPPrev, dPLike, dPLm, dUtt, dTasks, dOutI, dOutF, dTot}) (void)hipFree(p);
+      for (void *p : {dScore, dTok, dEx, dImax, dPPrev, dPLike, dPLm, dUtt, dTasks, dOutI, dOutF, dTot}) (void)hipFree(p);
       if (rc) return rc;
       for (int k = 0; k < nu; k++) {
          nWords[u0 + k] = hI[k]; total[u0 + k] = hT[k];
