@@ -619,6 +619,13 @@ class Net:
         check(L.htkamd_net_build(slf.encode(), dictionary.encode(), mmf.h, C.byref(self.h)), "net_build")
         self.desc = L.htkamd_net_get(self.h).contents
         self.out_syms = [L.htkamd_net_out_sym(self.h, C.c_int(k)).decode() for k in range(self.desc.nProns)]
+        L.htkamd_net_word_name.restype = C.c_char_p
+        self.word_names = [L.htkamd_net_word_name(self.h, C.c_int(k)).decode() for k in range(self.desc.nProns)]
+        self.pron_models = []
+        buf = (C.c_int * 256)()
+        for k in range(self.desc.nProns):
+            n = L.htkamd_net_pron_models(self.h, C.c_int(k), buf, C.c_int(256))
+            self.pron_models.append([int(buf[i]) for i in range(min(n, 256))])
 
     def arrays(self) -> dict:
         d = self.desc
@@ -659,9 +666,11 @@ class Decoder:
         dX = DevArray(X) if X.size else DevArray(nbytes=4)
         nW = np.zeros(max(nU, 1), np.int32); tot = np.zeros(max(nU, 1), np.float64)
         wp = np.zeros(max(nU, 1) * maxWords, np.int32); ws = np.zeros_like(wp); we = np.zeros_like(wp); sc = np.zeros(max(nU, 1) * maxWords, np.float32)
+        lm = np.zeros_like(sc)
         cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale)
         check(lib().htkamd_decoder_run(self.h, C.byref(cfg), dX.ptr, _p(frameOff), C.c_int(nU), C.c_int(maxWords), _p(nW), _p(wp), _p(ws), _p(we),
-                                       _p(sc), _p(tot), None), "decoder_run")
+                                       _p(sc), _p(lm), _p(tot), None), "decoder_run")
+        self.last_lm = [[float(lm[u * maxWords + i]) for i in range(max(int(nW[u]), 0))] for u in range(nU)]
         out = []
         for u in range(nU):
             if nW[u] < 0:

@@ -76,7 +76,7 @@ struct DecArgs {
    int *pathPrev; double *pathLike; float *pathLm;
    float genBeam, wordBeam, lmScale, wordPen, prScale;
    int maxWords;
-   int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore; double *total;
+   int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm; double *total;
 };
 
 __device__ __forceinline__ Tok null_tok() { Tok t; t.like = LZERO; t.lm = 0.0f; t.path = -1; return t; }
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                a.wordEnd[ud.out0 + w] = frame;
                a.wordStart[ud.out0 + w] = (prev >= 0) ? prev / N.nWordNodes : 0;
                a.wordScore[ud.out0 + w] = sc;
+               a.wordLm[ud.out0 + w] = plm;
                p = prev;
             }
          }
@@ -494,7 +495,8 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
 }
 
 extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
-                                  int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *total, void *stream)
+                                  int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
+                                  double *total, void *stream)
 {
    if (!d || !cfg || !frameOff || nUtt < 0 || maxWords < 1 || !nWords || !wordPron || !wordStart || !wordEnd || !wordScore || !total) {
       htkamd_set_error("decoder_run: bad argument"); return HTKAMD_EINVAL;
@@ -540,7 +542,7 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
       A(&dScore, score * 4); A(&dTok, tok * sizeof(Tok)); A(&dEx, node * sizeof(Tok)); A(&dImax, node * 8);
       A(&dPPrev, path * 4); A(&dPLike, path * 8); A(&dPLm, path * 4);
       A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
-      A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * (size_t)nu * maxWords); A(&dTot, sizeof(double) * nu);
+      A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * (size_t)nu * maxWords * 2); A(&dTot, sizeof(double) * nu);
       std::vector<int> hI; std::vector<float> hF; std::vector<double> hT;
       if (!rc) {
          hipError_t e;
@@ -567,13 +569,13 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
          a.maxWords = maxWords;
          int *oi = (int *)dOutI;
          a.nWords = oi; a.wordPron = oi + nu; a.wordStart = a.wordPron + (size_t)nu * maxWords; a.wordEnd = a.wordStart + (size_t)nu * maxWords;
-         a.wordScore = (float *)dOutF; a.total = (double *)dTot;
+         a.wordScore = (float *)dOutF; a.wordLm = (float *)dOutF + (size_t)nu * maxWords; a.total = (double *)dTot;
          hipLaunchKernelGGL(k_decode, dim3(nu), dim3(DEC_THREADS), 0, s, a);
          hipError_t e = hipGetLastError();
          if (e != hipSuccess) { htkamd_set_error("decoder_run: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       }
       if (!rc) {
-         hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords); hT.resize(nu);
+         hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords * 2); hT.resize(nu);
          hipError_t e;
          if ((e = hipMemcpyAsync(hI.data(), dOutI, sizeof(int) * hI.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
              (e = hipMemcpyAsync(hF.data(), dOutF, sizeof(float) * hF.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
@@ -588,6 +590,7 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
          for (int w = 0; w < maxWords; w++) {
             wordPron[o + w] = hI[nu + si + w]; wordStart[o + w] = hI[nu + (size_t)nu * maxWords + si + w];
             wordEnd[o + w] = hI[nu + (size_t)nu * maxWords * 2 + si + w]; wordScore[o + w] = hF[si + w];
+            if (wordLm) wordLm[o + w] = hF[(size_t)nu * maxWords + si + w];
          }
       }
       u0 = u1;

@@ -359,3 +359,14 @@ done:
 const htkamd_net_desc *htkamd_net_get(const struct htkamd_net *n) { return n ? &n->d : NULL; }
 /* output symbol of pronunciation k (the `model` field of a WORD node); "" = word produces no label */
 const char *htkamd_net_out_sym(const struct htkamd_net *n, int k) { return (n && k >= 0 && k < n->nWordNames) ? n->wordName[k] : NULL; }
+
+/* physical models of pronunciation k (after context expansion), in order; returns their number (may exceed `max`) */
+int htkamd_net_pron_models(const struct htkamd_net *n, int k, int *models, int max)
+{
+   if (!n || k < 0 || k >= n->nPron) return -1;
+   for (int q = 0; q < n->pron[k].nPhones && q < max; q++) models[q] = n->pron[k].phone[q];
+   return n->pron[k].nPhones;
+}
+
+/* the dictionary word a pronunciation belongs to (HVite -m/-f label the first model of a word with the word's NAME) */
+const char *htkamd_net_word_name(const struct htkamd_net *n, int k) { return (n && k >= 0 && k < n->nPron) ? n->pron[k].word : NULL; }

@@ -336,6 +336,9 @@ int  htkamd_net_build(const char *slfPath, const char *dictPath, const htkamd_mm
 void htkamd_net_destroy(htkamd_net *n);
 const htkamd_net_desc *htkamd_net_get(const htkamd_net *n);
 const char *htkamd_net_out_sym(const htkamd_net *n, int pron);
+/* physical models of pronunciation `pron` after context expansion; returns their number (which may exceed max) */
+int  htkamd_net_pron_models(const htkamd_net *n, int pron, int *models, int max);
+const char *htkamd_net_word_name(const htkamd_net *n, int pron);
 
 /* ------------------------------------------------------------------------------------------
  * Network decoding of a batch (HVite -w net): replaces, per utterance, InitVRecInfo / StartRecognition /
@@ -344,7 +347,11 @@ const char *htkamd_net_out_sym(const htkamd_net *n, int pron);
  * LikeToWord look-ahead (HRec.c:1172) depends on the LM scale, hence lmScale at creation.
  * Results per utterance u: nWords[u] (-1: no token reached the end of the network, -3: more than maxWords words), and for
  * word w < nWords[u] at [u*maxWords + w]: pronunciation index (htkamd_net_out_sym), frames [start, end), score = LArcTotLike
- * (acoustic + scaled LM + scaled pron prob + word penalty, HNet.h:257); total[u] = likelihood of the final token.
+ * (acoustic + scaled LM + scaled pron prob + word penalty, HNet.h:257), wordLm (may be NULL) = the arc's LM log probability
+ * (LArc.lmlike: what HVite -m/-f print, scaled and with the word penalty, as the word's auxiliary score); total[u] = likelihood
+ * of the final token.  Model-level labels of the recognised words (HVite -m with -w) = htkamd_viterbi_align on the chain of
+ * htkamd_net_pron_models of the recognised pronunciations: for a fixed word sequence the LM terms are constants, so the best
+ * alignment of that chain is the decoder's path.
  * Models of up to 8 states; tee models may not have more than 95 predecessors.
  * ------------------------------------------------------------------------------------------ */
 typedef struct { float genBeam, wordBeam, lmScale, wordPen, prScale; } htkamd_decode_config;
@@ -352,8 +359,8 @@ typedef struct htkamd_decoder htkamd_decoder;
 int  htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *net, float lmScale, htkamd_decoder **out);
 void htkamd_decoder_destroy(htkamd_decoder *d);
 int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
-                        int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *total,
-                        void *stream);
+                        int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
+                        double *total, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Waveform -> MFCC(+_0/_E)(+_D)(+_A)(+_Z) on the device: replaces what OpenBuffer (HParm.h, HParm.c:4357)

@@ -19,7 +19,7 @@ def load_decode_case(native, name):
 
 def parse_opts(opts: str) -> dict:
     """HVite switches -> decoder parameters (HVite.c:81-95 defaults: -s 1.0 -p 0.0 -r 1.0, beams off)."""
-    t = opts.split()
+    t = [x for x in opts.split() if x != "-m"]
     p = dict(genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0)
     key = {"-t": "genBeam", "-v": "wordBeam", "-s": "lmScale", "-p": "wordPen", "-r": "prScale"}
     for i in range(0, len(t), 2):
@@ -31,3 +31,19 @@ def format_words(words, out_syms, frame_dur=100000):
     """The lines of the .rec file: start end outsym score (%f of the float); words without output symbol are dropped
     (TranscriptionFromLattice HRec.c:2342-2356)."""
     return ["%d %d %s %f" % (s * frame_dur, e * frame_dur, out_syms[w], np.float32(sc)) for w, s, e, sc in words if out_syms[w] != ""]
+
+
+def format_model_labels(words, lms, align, pron_models, phys_names, out_syms, lmScale, wordPen, frame_dur=100000):
+    """The lines HVite -m writes for a recognised utterance (TranscriptionFromLattice HRec.c:2289-2337): one per model,
+    `start end model score`, the first model of a word followed by the word's output symbol and its LM score
+    LArcTotLMLike = lmlike*lmscale + wdpenalty (HNet.h:252).  `align` = forced alignment of the recognised model chain."""
+    lines, q = [], 0
+    for (w, s, e, sc), lm in zip(words, lms):
+        for k, m in enumerate(pron_models[w]):
+            ln = "%d %d %s %f" % (align["modStart"][q] * frame_dur, align["modEnd"][q] * frame_dur, phys_names[m], np.float32(align["modScore"][q]))
+            if k == 0:
+                aux = np.float32(np.float64(np.float32(np.float32(lm) * np.float32(lmScale))) + np.float64(np.float32(wordPen)))
+                ln += " %s %f" % (out_syms[w], aux)
+            lines.append(ln)
+            q += 1
+    return lines

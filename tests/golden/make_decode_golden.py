@@ -88,7 +88,7 @@ def main():
     open(os.path.join(d, "wlist"), "w").write("\n".join(sorted(names)) + "\n")
     subprocess.check_call([os.path.join(REF, "HBuild"), "wlist", "net.slf"], cwd=d)
     os.remove(os.path.join(d, "wlist"))
-    run_hvite(d, s.feats, ["-t 250.0", "-t 25.0"], 9, "")
+    run_hvite(d, s.feats, ["-t 250.0", "-t 25.0", "-m -t 250.0"], 9, "")
     # ---------------------------------------------------------------- bigram
     d = os.path.join(OUT, "bigram"); os.makedirs(d, exist_ok=True)
     synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
@@ -126,7 +126,7 @@ def main():
             alt = prons[w]
             ph += alt[int(rng.integers(0, len(alt)))]
         feats.append(sample(pk, ph, rng))
-    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -s 5.0 -p -10.0", "-t 60.0 -v 30.0 -s 2.0 -p 3.0 -r 2.0"], 9, "")
+    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -s 5.0 -p -10.0", "-t 60.0 -v 30.0 -s 2.0 -p 3.0 -r 2.0", "-m -t 250.0 -s 5.0 -p -10.0"], 9, "")
     # ---------------------------------------------------------------- tee
     d = os.path.join(OUT, "tee"); os.makedirs(d, exist_ok=True)
     pk2, tnames, _, _ = synth.make_topo_set(seed=33, D=13, NU=1)
@@ -180,7 +180,7 @@ def main():
         seq = ["SIL"] + [list(wseq)[1 + k] for k in rng.integers(0, 4, size=4)] + ["SIL"]
         ph = [int(lmap[m][1:]) for w in seq for m in wseq[w]]
         feats.append(sample(pk, ph, rng, frames_per_state=3))
-    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -p -20.0 -s 3.0"], 9, "")
+    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -p -20.0 -s 3.0", "-m -t 250.0"], 9, "")
     for c in ("loop", "bigram", "tee", "wint"):
         e = json.load(open(os.path.join(OUT, c, "expected.json")))
         print(c, {k: sum(len(v) for v in per.values()) for k, per in e.items()})

@@ -15,6 +15,8 @@ def test_decoder_reproduces_hvite_label_files(native, oracle, case):
     om = oracle.Model(mmf.packed())
     arrays = net.arrays()
     for opts, per in expected.items():
+        if "-m" in opts.split():
+            continue                                                 # model-level output: its own test below
         p = parse_opts(opts)
         dec = native.Decoder(model, net, lmScale=p["lmScale"])
         res = dec.run(feats, **p)
@@ -118,8 +120,34 @@ def test_decoder_edge_cases(native, oracle):
     wp = np.zeros(2, np.int32); ws = np.zeros(2, np.int32); we = np.zeros(2, np.int32); sc = np.zeros(2, np.float32)
     cfg = native.DecodeConfig(250.0, 1.0e10, 1.0, 0.0, 1.0)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    native.check(lib.htkamd_decoder_run(dec.h, C.byref(cfg), dX.ptr, p(frameOff), C.c_int(1), C.c_int(2), p(nW), p(wp), p(ws), p(we), p(sc), p(tot), None), "run")
+    native.check(lib.htkamd_decoder_run(dec.h, C.byref(cfg), dX.ptr, p(frameOff), C.c_int(1), C.c_int(2), p(nW), p(wp), p(ws), p(we), p(sc), None, p(tot), None), "run")
     assert nW[0] == -3 and tot[0] > -1e9                              # five words do not fit into maxWords = 2
     tight = dec.run([feats[0]], genBeam=0.5)
     ow, _ = oracle.decode(om, feats[0], net.arrays(), genBeam=0.5)
     assert tight[0][0] == ow                                          # whatever the reference semantics give (None or a path)
+
+
+@pytest.mark.parametrize("case", ["loop", "bigram", "wint"])
+def test_model_level_labels_of_recognition(native, case):
+    """HVite -m with -w: model-level labels of the recognised words = decoder (words, LM scores) + forced alignment of the
+    recognised pronunciations' model chain; compared line by line with the reference's output."""
+    from decode_util import format_model_labels
+    from util import batch_arrays
+    mmf, net, feats, expected = load_decode_case(native, case)
+    model = native.Model(mmf.packed())
+    n = 0
+    for opts, per in expected.items():
+        if "-m" not in opts.split():
+            continue
+        p = parse_opts(opts)
+        dec = native.Decoder(model, net, lmScale=p["lmScale"])
+        res = dec.run(feats, **p)
+        chains = [np.array([m for w in words for m in net.pron_models[w[0]]], np.int32) for words, _ in res]
+        X, frameOff, labOff, labs = batch_arrays([dict(seq=c, feat=f) for c, f in zip(chains, feats)])
+        dX = native.DevArray(X)
+        al = native.Viterbi(model).align(dX.ptr.value, frameOff, labOff, labs, genBeam=p["genBeam"])
+        for u, (words, total) in enumerate(res):
+            got = format_model_labels(words, dec.last_lm[u], al[u], net.pron_models, mmf.phys_names, net.word_names, p["lmScale"], p["wordPen"])
+            assert got == per["u%d" % u], (case, opts, u)
+            n += len(got)
+    assert n > 10
