@@ -558,7 +558,9 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
          sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
          sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)((char *)dTasks + sizeof(ScoreTask) * tasks.size());
          sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff;
-         rc = htkamd_launch_score_exact(m, sa, s);           // exact scores: the decoded path must be the reference's
+         if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
+         else rc = (cfg->scoreMode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, sa, s)      // tolerance class, ~2.5x faster
+                                                         : htkamd_launch_score_exact(m, sa, s);    // the decoded path is the reference's
       }
       if (!rc) {
          DecArgs a;

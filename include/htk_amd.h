@@ -354,7 +354,11 @@ const char *htkamd_net_word_name(const htkamd_net *n, int pron);
  * alignment of that chain is the decoder's path.
  * Models of up to 8 states; tee models may not have more than 95 predecessors.
  * ------------------------------------------------------------------------------------------ */
-typedef struct { float genBeam, wordBeam, lmScale, wordPen, prScale; } htkamd_decode_config;
+typedef struct {
+   float genBeam, wordBeam, lmScale, wordPen, prScale;
+   int   scoreMode;   /* HTKAMD_SCORE_EXACT (0): scores, token likelihoods and therefore paths are the reference's bit for bit;
+                         HTKAMD_SCORE_MFMA: matrix-core scores (1e-4 class) -- same words unless two paths tie within that */
+} htkamd_decode_config;
 typedef struct htkamd_decoder htkamd_decoder;
 int  htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *net, float lmScale, htkamd_decoder **out);
 void htkamd_decoder_destroy(htkamd_decoder *d);

@@ -118,7 +118,7 @@ def test_decoder_edge_cases(native, oracle):
     frameOff = np.array([0, X.shape[0]], np.int32)
     nW = np.zeros(1, np.int32); tot = np.zeros(1, np.float64)
     wp = np.zeros(2, np.int32); ws = np.zeros(2, np.int32); we = np.zeros(2, np.int32); sc = np.zeros(2, np.float32)
-    cfg = native.DecodeConfig(250.0, 1.0e10, 1.0, 0.0, 1.0)
+    cfg = native.DecodeConfig(250.0, 1.0e10, 1.0, 0.0, 1.0, 0)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     native.check(lib.htkamd_decoder_run(dec.h, C.byref(cfg), dX.ptr, p(frameOff), C.c_int(1), C.c_int(2), p(nW), p(wp), p(ws), p(we), p(sc), None, p(tot), None), "run")
     assert nW[0] == -3 and tot[0] > -1e9                              # five words do not fit into maxWords = 2
@@ -151,3 +151,17 @@ def test_model_level_labels_of_recognition(native, case):
             assert got == per["u%d" % u], (case, opts, u)
             n += len(got)
     assert n > 10
+
+
+def test_decoder_with_matrix_core_scores(native):
+    """scoreMode = MFMA in the decoder: same words and boundaries as the exact mode on the golden cases, scores within 1e-2
+    (sums of ~100 frame scores each good to ~1e-4)."""
+    for case in ("loop", "bigram"):
+        mmf, net, feats, expected = load_decode_case(native, case)
+        model = native.Model(mmf.packed())
+        dec = native.Decoder(model, net)
+        ex = dec.run(feats, genBeam=250.0)
+        mf = dec.run(feats, genBeam=250.0, scoreMode=1)
+        for (we, te), (wm, tm) in zip(ex, mf):
+            assert [w[:3] for w in we] == [w[:3] for w in wm]
+            assert np.allclose([w[3] for w in we], [w[3] for w in wm], atol=1e-2) and abs(te - tm) < 5e-2

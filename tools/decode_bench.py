@@ -44,7 +44,7 @@ def main():
     dec = capi.Decoder(model, net)
     for rep in range(2):
         t0 = time.time()
-        res = dec.run(s.feats, genBeam=250.0)
+        res = dec.run(s.feats, genBeam=250.0, scoreMode=int(os.environ.get("DEC_SCORE_MODE", "0")))
         dt = time.time() - t0
         ok = sum(1 for w, _ in res if w is not None)
         # word accuracy against the generating sequence (sanity: the models are well separated)
