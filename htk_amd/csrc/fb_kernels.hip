@@ -513,13 +513,34 @@ __global__ void k_alpha(FbArgs a)
       if (tid == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
       return;
    }
-   // ---- flush the per-cell sums
-   if (live && wantTrans && cm.i < cm.N) {
-      const double *ta = tacc + c * (maxN + 1);
-      double *tr = a.acc + a.lay.tr + a.transOff[cTrans] + (size_t)(cm.i - 1) * cm.N;
-      for (int j = 2; j <= cm.N; j++)
-         if (ta[j] != 0.0) atomicAdd(tr + (j - 1), ta[j]);
-      if (occAcc != 0.0) atomicAdd(a.acc + a.lay.trOcc + a.trOccOff[cTrans] + (cm.i - 1), occAcc);
+   // ---- flush the per-cell sums.  When every model of the utterance uses the same transition matrix (the usual case), the
+   // cells are first summed per (row, column) in LDS: same-address f64 atomics serialise in L2 (see fb_wave.hip).
+   if (wantTrans) {
+      __shared__ int tShared, tMixed;
+      if (tid == 0) { tShared = a.mTrans[ud.q0]; tMixed = 0; }
+      __syncthreads();
+      if (live && cTrans != tShared) tMixed = 1;
+      if (live) tacc[c * (maxN + 1)] = (cm.i < cm.N) ? occAcc : 0.0;       // column 0 of a cell's row is free: its occupation count
+      __syncthreads();
+      if (!tMixed) {
+         const int N0 = a.mN[ud.q0], t0 = tShared;
+         for (int idx = tid; idx < maxN * (maxN + 1); idx += blockDim.x) {
+            const int i = idx / (maxN + 1) + 1, j = idx % (maxN + 1);
+            if (i >= N0 || j == 1 || j > N0) continue;
+            double v = 0.0;
+            for (int cc = 0; cc < ud.nCells; cc++)
+               if (a.cI[ud.cell0 + cc] == i) v += tacc[cc * (maxN + 1) + j];
+            if (v == 0.0) continue;
+            if (j == 0) atomicAdd(a.acc + a.lay.trOcc + a.trOccOff[t0] + (i - 1), v);
+            else atomicAdd(a.acc + a.lay.tr + a.transOff[t0] + (size_t)(i - 1) * N0 + (j - 1), v);
+         }
+      } else if (live && cm.i < cm.N) {
+         const double *ta = tacc + c * (maxN + 1);
+         double *tr = a.acc + a.lay.tr + a.transOff[cTrans] + (size_t)(cm.i - 1) * cm.N;
+         for (int j = 2; j <= cm.N; j++)
+            if (ta[j] != 0.0) atomicAdd(tr + (j - 1), ta[j]);
+         if (occAcc != 0.0) atomicAdd(a.acc + a.lay.trOcc + a.trOccOff[cTrans] + (cm.i - 1), occAcc);
+      }
    }
    if (live && cm.i == 1) atomicAdd(a.acc + a.lay.nEgs + cHmm, 1.0);
    if (tid == 0) {
