@@ -99,3 +99,31 @@ def test_htkdemo_pass_is_the_same_through_the_mfma_scores(native):
     err_m = np.abs(p1["mean"] - p0["mean"]) / np.maximum(np.abs(p0["mean"]), sigma)
     err_v = np.abs(p1["var"] - p0["var"]) / p0["var"]
     assert err_m.max() <= 1e-4 and err_v.max() <= 1e-4, (err_m.max(), err_v.max())
+
+
+def test_examples_on_fixture_files(native, tmp_path):
+    """The two example drivers (HERest-pass and HVite data flows over HTK files) run on the committed fixtures and print /
+    write what the reference's tools did."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "examples"))
+    import herest_pass, hvite_decode
+    from htk_amd import synth
+    a, stats = herest_pass.main(["--hmmlist", os.path.join(DEMO, "bcplist"), "--hmmdir", os.path.join(DEMO, "hmm1"), "--labdir", os.path.join(DEMO, "labels"),
+                                 "--target-kind", "MFCC_E_D", "--prune", "2000", "--minvar", "0.05", "--mixfloor", "3", "--outdir", str(tmp_path / "hmm2"),
+                                 "--data"] + sorted(glob.glob(os.path.join(DEMO, "train", "*.mfc"))))
+    assert "%e" % (a["totalPr"] / a["totalT"]) == "-5.900196e+01" and (stats["nFloorVar"], stats["nFloorVarMix"]) == (27, 15)
+    assert sorted(os.listdir(tmp_path / "hmm2")) == sorted("SCVNL")
+    d = os.path.join(os.path.dirname(__file__), "golden", "decode", "bigram")
+    z = np.load(os.path.join(d, "feats.npz"))
+    files = []
+    for u in range(len(z.files)):
+        fn = str(tmp_path / ("u%d.mfc" % u)); synth.write_htk_param(fn, z["u%d" % u], kind=9); files.append(fn)
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    hvite_decode.main(["--mmf", os.path.join(d, "MMF"), "--hmmlist", os.path.join(d, "hmmlist"), "--dict", os.path.join(d, "dict"), "--net", os.path.join(d, "net.slf"),
+                       "--beam", "250", "--lmscale", "5", "--wordpen", "-10", "--models", "--out", str(tmp_path / "rec.mlf")] + files)
+    got = open(tmp_path / "rec.mlf").read().split("\n")
+    want = exp["-m -t 250.0 -s 5.0 -p -10.0"]
+    lines = [l for l in got[1:] if l and not l.startswith('"') and l != "."]
+    assert lines == [l for u in range(len(files)) for l in want["u%d" % u]]
