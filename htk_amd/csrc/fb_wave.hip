@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
       if (lane == 0) { gLo[T] = (short)endq; gHi[T] = (short)Q; }
       int qHiN = Q, qLoN = endq, lastEnd = endq;
       int nxtLo = (T >= 2) ? tLo[T - 1] : 1, nxtHi = (T >= 2) ? tHi[T - 1] : 1;
+      bool stPrev = false, stIn = false; int tPrev = 0, loPrev = 1, hiPrev = 1;
 
       // ---- t = T-1 .. 1 (HFB.c:1205-1277)
       for (int t = T - 1; t >= 1; t--) {
@@ -156,6 +157,16 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
          // rotate: previous column, output probabilities
 #pragma unroll
          for (int i = 0; i <= MAXN; i++) bP[i] = bC[i];
+         // the column finished in the previous iteration goes out NOW: vmcnt counts stores on gfx9, so a store issued at the end
+         // of a frame would make the next frame's first wait (for its prefetched inputs) also wait for the write acknowledgement
+         if (stPrev) {
+            if (stIn) {
+#pragma unroll
+               for (int i = 1; i <= MAXN; i++) if (i <= N) gbeta[(size_t)(tPrev - 1) * nC + m.mc0 + i - 1] = bP[i];
+            }
+            if (lane == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
+            stPrev = false;
+         }
 #pragma unroll
          for (int j = 0; j < MAXN; j++) { ob1[j] = obT[j]; obT[j] = obP[j]; }
          if (valid && t >= 2) {
@@ -223,12 +234,15 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
             }
          }
          if (fail) break;
-         if (inRange) {
-#pragma unroll
-            for (int i = 1; i <= MAXN; i++) if (i <= N) gbeta[(size_t)(t - 1) * nC + m.mc0 + i - 1] = bC[i];
-         }
-         if (lane == 0) { gLo[t] = (short)newLo; gHi[t] = (short)newHi; }
+         stPrev = true; stIn = inRange; tPrev = t; loPrev = newLo; hiPrev = newHi;
          qHiN = newHi; qLoN = newLo; lastEnd = endq;
+      }
+      if (!fail && stPrev) {                             // the last column (t = 1)
+         if (stIn) {
+#pragma unroll
+            for (int i = 1; i <= MAXN; i++) if (i <= N) gbeta[(size_t)(tPrev - 1) * nC + m.mc0 + i - 1] = bC[i];
+         }
+         if (lane == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
       }
       if (!fail) {
          pr = shfl_d(bC[1], lastEnd - 1);                // utt->pr = bqt[1] of the last model processed
