@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
 int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
-   if (!m->d_mfmaTab) { htkamd_set_error("score_mfma: vector size %d not supported by the MFMA path (13, 26, 39)", m->D); return HTKAMD_EMODEL; }
+   if (!m->d_mfmaTab) { htkamd_set_error("score_mfma: vector size %d not supported by the MFMA path (up to 40)", m->D); return HTKAMD_EMODEL; }
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
    int blocks = a.nTasks;
    if (blocks > 256 * 4) blocks = 256 * 4;      // persistent blocks (4 per CU at <= 128 VGPRs), one task (128 frames x 16 states) at a time

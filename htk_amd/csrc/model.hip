@@ -92,8 +92,10 @@ template <typename T> static int toDevice(T **dst, const T *src, size_t n)
 static int mfma_refresh(htkamd_model *m)
 {
    const int D = m->D;
-   if (!(D == 39 || D == 26 || D == 13)) return HTKAMD_OK;
-   const int NS = (D + 1) / 2;
+   if (D > 40) return HTKAMD_OK;                      // no MFMA kernel: the exact path serves such sets
+   // K steps of 4 = 2 dimensions each; kernels exist for 7, 13 and 20 steps, smaller sizes are zero-padded up to the next
+   const int need = (D + 1) / 2;
+   const int NS = need <= 7 ? 7 : (need <= 13 ? 13 : 20);
    if (!m->d_stateTileOff) {
       int *off = (int *)malloc(sizeof(int) * ((size_t)m->S + 1));
       off[0] = 0;

@@ -166,7 +166,7 @@ int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dState
  *   HTKAMD_SCORE_EXACT  as above (packed-FP32 vector path).
  *   HTKAMD_SCORE_MFMA   Mahalanobis contraction as an fp32 GEMM on the matrix cores ([x^2|x] times per-Gaussian
  *                       coefficients) and a float log-sum-exp over the mixture: within ~1e-4 absolute of the
- *                       reference's float sum (vector sizes 13, 26, 39; HTKAMD_EMODEL otherwise).  For HERest-style
+ *                       reference's float sum (vector sizes up to 40; HTKAMD_EMODEL beyond).  For HERest-style
  *                       accumulation, where the bar is 1e-4 relative on the re-estimated parameters. */
 #define HTKAMD_SCORE_EXACT 0
 #define HTKAMD_SCORE_MFMA  1

@@ -67,7 +67,7 @@ def test_outp_large_block_statistics(native, oracle):
 
 
 # ----------------------------------------------------------------------------------------- scoring on the matrix cores (K1m)
-@pytest.mark.parametrize("D,M", [(39, 16), (39, 20), (39, 5), (26, 2), (13, 1), (13, 33)])
+@pytest.mark.parametrize("D,M", [(39, 16), (39, 20), (39, 5), (26, 2), (13, 1), (13, 33), (36, 8), (20, 3), (7, 2), (40, 4)])
 def test_outp_block_mfma_tolerance(native, oracle, D, M):
     """HTKAMD_SCORE_MFMA: expanded-form fp32 GEMM + float log-sum-exp.  Tolerance class: |score - reference| <= 1e-3
     absolute (scores are O(100); the reference's own float rounding is ~1e-4), typical error far smaller.
@@ -91,7 +91,7 @@ def test_outp_block_mfma_tolerance(native, oracle, D, M):
 
 def test_outp_block_mfma_rejects_other_sizes(native):
     from htk_amd import synth
-    s = synth.generate(5, 2, 4, 1, 20, 5, D=20)
+    s = synth.generate(5, 2, 4, 1, 20, 5, D=45)
     gm = native.Model(s.packed())
     with pytest.raises(native.HtkAmdError):
         gm.outp_block(s.feats[0], np.arange(5, dtype=np.int32), mode=1)
