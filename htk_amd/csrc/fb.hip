@@ -125,9 +125,9 @@ struct htkamd_fb {
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
-   hipEvent_t ev[5], evCopy;
+   hipEvent_t ev[5], evK[2], evCopy;          // ev: stream intervals; evK: the scoring dispatch's own start/stop
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
-   bool evValid, timed, copyPending;
+   bool evValid, timed, copyPending, scored;
 };
 
 extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
@@ -135,12 +135,13 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) {
       hipError_t e = hipEventCreate(&fb->ev[i]);
       if (e != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate: %s", hipGetErrorString(e)); delete fb; return HTKAMD_EHIP; }
    }
+   if (hipEventCreate(&fb->evK[0]) != hipSuccess || hipEventCreate(&fb->evK[1]) != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate failed"); delete fb; return HTKAMD_EHIP; }
    if (hipEventCreateWithFlags(&fb->evCopy, hipEventDisableTiming) != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate failed"); delete fb; return HTKAMD_EHIP; }
    if (hipStreamCreateWithFlags(&fb->resStream, hipStreamNonBlocking) != hipSuccess) { htkamd_set_error("fb_create: hipStreamCreate failed"); delete fb; return HTKAMD_EHIP; }
    fb->evValid = true;
@@ -162,7 +163,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
-   if (fb->evValid) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]); (void)hipEventDestroy(fb->evCopy); (void)hipStreamDestroy(fb->resStream); }
+   if (fb->evValid) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]); (void)hipEventDestroy(fb->evCopy); (void)hipEventDestroy(fb->evK[0]); (void)hipEventDestroy(fb->evK[1]); (void)hipStreamDestroy(fb->resStream); }
    delete fb;
 }
 
@@ -483,7 +484,9 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
 
    int rc;
    HIPCHECK(hipEventRecord(fb->ev[0], s));
-   if ((rc = (cfg->scoreMode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, sa, s) : htkamd_launch_score_exact(m, sa, s))) return rc;
+   if ((rc = (cfg->scoreMode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, sa, s, fb->evK[0], fb->evK[1])
+                                                   : htkamd_launch_score_exact(m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
+   fb->scored = sa.nTasks > 0;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
    const bool wavePath = (m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
    if ((rc = wavePath ? htkamd_launch_beta_w(fa, s) : htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;
@@ -524,7 +527,9 @@ extern "C" int htkamd_fb_kernel_times(htkamd_fb *fb, double out[4])
    HIPCHECK(hipEventSynchronize(fb->ev[4]));
    for (int i = 0; i < 4; i++) {
       float ms = 0.f;
-      HIPCHECK(hipEventElapsedTime(&ms, fb->ev[i], fb->ev[i + 1]));
+      // scoring: the dispatch's own start -> stop; the others: interval between stream events around the launch
+      if (i == 0 && fb->scored) HIPCHECK(hipEventElapsedTime(&ms, fb->evK[0], fb->evK[1]));
+      else HIPCHECK(hipEventElapsedTime(&ms, fb->ev[i], fb->ev[i + 1]));
       out[i] = (double)ms * 1e-3;
    }
    return HTKAMD_OK;

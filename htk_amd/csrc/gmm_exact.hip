@@ -20,6 +20,7 @@
 //
 // Algorithmic work: M*(4*D+8) flop per (frame,state); VALU (packed FP32) bound.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
    }
 }
 
-int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream)
+int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
@@ -157,10 +158,10 @@ int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStre
    if (blocks > 256 * 5) blocks = 256 * 5;      // persistent: up to 5 four-wave blocks per CU (VGPR-limited)
    dim3 grid(blocks), block(256);
    switch (m->D) {
-   case 39: hipLaunchKernelGGL((k_score_exact<39>), grid, block, 0, stream, a); break;
-   case 26: hipLaunchKernelGGL((k_score_exact<26>), grid, block, 0, stream, a); break;
-   case 13: hipLaunchKernelGGL((k_score_exact<13>), grid, block, 0, stream, a); break;
-   default: hipLaunchKernelGGL(k_score_exact_anyD, grid, block, 0, stream, a); break;
+   case 39: hipExtLaunchKernelGGL((k_score_exact<39>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 26: hipExtLaunchKernelGGL((k_score_exact<26>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 13: hipExtLaunchKernelGGL((k_score_exact<13>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   default: hipExtLaunchKernelGGL(k_score_exact_anyD, grid, block, 0, stream, evStart, evStop, 0, a); break;
    }
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;

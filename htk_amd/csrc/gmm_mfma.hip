@@ -33,6 +33,7 @@
 // Roofline: 2*16*(4*NS) flop per (frame, tile) on MFMA = 2560 flop at D=39 against the algorithmic
 // M*(4*D+8) = 2624; peak 157.3 TFLOP/s (fp32 matrix).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
    }
 }
 
-int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream)
+int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
    if (!m->d_mfmaTab) { htkamd_set_error("score_mfma: vector size %d not supported by the MFMA path (up to 40)", m->D); return HTKAMD_EMODEL; }
@@ -190,9 +191,9 @@ int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStrea
    if (blocks > 256 * 4) blocks = 256 * 4;      // persistent blocks (4 per CU at <= 128 VGPRs), one task (128 frames x 16 states) at a time
    dim3 grid(blocks), block(256);
    switch (m->mfmaNS) {
-   case 20: hipLaunchKernelGGL((k_score_mfma<20>), grid, block, 0, stream, a); break;
-   case 13: hipLaunchKernelGGL((k_score_mfma<13>), grid, block, 0, stream, a); break;
-   case 7: hipLaunchKernelGGL((k_score_mfma<7>), grid, block, 0, stream, a); break;
+   case 20: hipExtLaunchKernelGGL((k_score_mfma<20>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 13: hipExtLaunchKernelGGL((k_score_mfma<13>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 7: hipExtLaunchKernelGGL((k_score_mfma<7>), grid, block, 0, stream, evStart, evStop, 0, a); break;
    default: htkamd_set_error("score_mfma: no kernel for %d K-steps", m->mfmaNS); return HTKAMD_EMODEL;
    }
    HIPCHECK(hipGetLastError());

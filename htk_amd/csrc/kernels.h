@@ -33,8 +33,10 @@ struct ScoreArgs {
    const int *stateTileOff;
 };
 
-int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream);
-int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream);
+// evStart/evStop (may be NULL): updated with the dispatch's own start and stop time (hipExtLaunchKernel), i.e. without the time
+// the kernel waits for the machine when another stream is using it
+int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
+int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 
 // ---- forward-backward ----
 struct UttDesc {

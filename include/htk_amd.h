@@ -286,7 +286,8 @@ long long htkamd_fb_frame_states(const htkamd_fb *fb);
 int  htkamd_fb_get_trellis(htkamd_fb *fb, int utt, double *beta, double *alpha, float *outp,
                            int *qLo, int *qHi, int *aLo, int *aHi, int *T, int *Q, int *maxN, void *stream);
 /* Seconds spent in the kernels of the last execute, measured with HIP events on `stream`:
-   out[0]=scoring out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics. Synchronises. */
+   out[0]=scoring (the dispatch's own start -> stop, hipExtLaunchKernel: what a kernel trace reports even when other streams share
+   the device) out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics (intervals between stream events). Synchronises. */
 int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
 
 /* ------------------------------------------------------------------------------------------
