@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--score", choices=["exact", "mfma"], default="mfma",
                     help="scoring arithmetic: exact = bit-identical to the reference (packed FP32 VALU); mfma = fp32 matrix-core GEMM, 1e-4 tolerance class")
-    ap.add_argument("--two-streams", type=int, default=1, help="run the two alternating batch contexts on two streams (1) or one (0)")
+    ap.add_argument("--two-streams", type=int, default=1, help="run the alternating batch contexts on their own streams (1) or on one stream (0)")
+    ap.add_argument("--contexts", type=int, default=2, help="batch contexts in flight (each with its own work space and accumulator vector)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -155,19 +156,20 @@ def main():
     # loop over many batches does.  Every pass does all of its work: zero, prepare, score, beta, alpha, statistics,
     # all-reduce; its per-utterance results are collected one pass later.  The same stream/event choreography runs at
     # N = 1 (without the collective), so the single-GPU run exercises it.
-    fbs = [fb, capi.ForwardBackward(model)]
-    accs2 = [accs, capi.Accs(model)]
+    NC = max(2, args.contexts)
+    fbs = [fb] + [capi.ForwardBackward(model) for _ in range(NC - 1)]
+    accs2 = [accs] + [capi.Accs(model) for _ in range(NC - 1)]
     acc_ts = [herest.device_vector_as_tensor(a, local_rank) for a in accs2]
     comm = torch.cuda.Stream()
     # ... and the two contexts run on two streams, so that the latency-bound recursions of one pass (1250 wavefronts, most
     # of the machine idle) share the GPU with the compute-bound scoring of the next
-    lanes = [torch.cuda.Stream(), torch.cuda.Stream()] if args.two_streams else [stream, stream]
-    ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # pass finished accumulating into accs2[k] (main stream)
-    ev_red = [torch.cuda.Event(), torch.cuda.Event()]    # all-reduce of accs2[k] finished (side stream)
-    red_pending = [False, False]
+    lanes = [torch.cuda.Stream() for _ in range(NC)] if args.two_streams else [stream] * NC
+    ev_done = [torch.cuda.Event() for _ in range(NC)]    # pass finished accumulating into accs2[k] (its stream)
+    ev_red = [torch.cuda.Event() for _ in range(NC)]     # all-reduce of accs2[k] finished (side stream)
+    red_pending = [False] * NC
 
     def launch(i):
-        k = i & 1
+        k = i % NC
         f = fbs[k]
         st_k = lanes[k]; sp = st_k.cuda_stream
         if red_pending[k]:
@@ -195,15 +197,16 @@ def main():
     ktimes = np.zeros(4)
     sync_all()
     t0 = time.perf_counter()
-    prev = None
+    inflight = []
     for i in range(args.steps):
-        cur = launch(i)
-        if prev is not None:
-            pr, st = prev.results(sptr)                # waits for the previous pass only
-            ktimes += np.array(prev.kernel_times())
-        prev = cur
-    pr, st = prev.results(sptr)
-    ktimes += np.array(prev.kernel_times())
+        inflight.append(launch(i))
+        if len(inflight) >= NC:                          # collect the oldest pass before its context is reused
+            old = inflight.pop(0)
+            pr, st = old.results(sptr)                   # waits for that pass only
+            ktimes += np.array(old.kernel_times())
+    for old in inflight:
+        pr, st = old.results(sptr)
+        ktimes += np.array(old.kernel_times())
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -212,7 +215,7 @@ def main():
         dt = float(tmax.item())
     ktimes /= max(args.steps, 1)
 
-    a = accs2[(args.steps - 1) & 1].download() if args.steps > 0 else accs.download()
+    a = accs2[(args.steps - 1) % NC].download() if args.steps > 0 else accs.download()
     # one more pass ALONE on the device (outside the timed region): the kernels' durations without a neighbour stream
     ktimes_solo = None
     if args.two_streams:
@@ -262,7 +265,7 @@ def main():
             "avg_logprob_per_frame": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
             "kernel_ms": {"score": ktimes[0] * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
             "score_mode": args.score,
-            "streams": 2 if args.two_streams else 1,
+            "streams": NC if args.two_streams else 1, "contexts": NC,
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_unit": flop_unit, "units_per_launch": units_local},
