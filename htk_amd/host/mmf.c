@@ -8,8 +8,8 @@
  * writer SaveHMMSet (:4979) = SaveMacros (:4342: ~o options, then ~t, ~s, ~h macros in hash-table order) with
  * PutStateInfo (:3053), PutMixPDF (:3029), PutTransMat (:2877: rows renormalised in float) and WriteFloat's " %e".
  * Binary definitions (':' + code byte keywords, big-endian numbers: PutSymbol :2581, Token.binForm :505) are read and
- * written as well.  Shared mean/variance vectors (~u ~v inside a mixture), ~m, stream weights, durations and transforms
- * are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
+ * written as well, shared mixture pdfs (~m) are kept shared (one Gaussian, several components).  Shared mean/variance vectors
+ * (~u ~v inside a mixture), stream weights, durations and transforms are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
  */
 #include <ctype.h>
 #include <math.h>
@@ -29,6 +29,7 @@ struct htkamd_mmf {
    mmf_state *st; int nSt, capSt;
    float *wt; int *cg; int nComp, capComp;
    float *mean, *var, *gconst; unsigned char *hasG; int nG, capG;
+   char **gName; int capGN;                                         /* ~m macro name of Gaussian g or NULL */
    mmf_trans *tr; int nTr, capTr; float *tp; int nTp, capTp;       /* tp: LOG transition values */
    mmf_hmm *hm; int nHm, capHm;
    float *varFloor;                                                 /* ~v "varFloor1" or NULL */
@@ -194,10 +195,35 @@ static int parse_vector(struct htkamd_mmf *s, rd *r, float *dst)
    return HTKAMD_OK;
 }
 
+static void gname_set(struct htkamd_mmf *s, int g, char *name)
+{
+   if (g + 1 > s->capGN) {
+      const int nc = (g + 1) * 2 + 16;
+      s->gName = (char **)realloc(s->gName, sizeof(char *) * (size_t)nc);
+      for (int i = s->capGN; i < nc; i++) s->gName[i] = NULL;
+      s->capGN = nc;
+   }
+   s->gName[g] = name;
+}
+static int find_gauss(const struct htkamd_mmf *s, const char *name)
+{
+   for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g] && !strcmp(s->gName[g], name)) return g;
+   return -1;
+}
+
 static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
 {
    int rc, k = rd_next(r);
-   if (k == T_MACRO) return fail(r, "shared mixture / vector macros (~m ~u ~v) are not supported");
+   if (k == T_MACRO && r->tok[0] == 'm') {               /* reference to a shared mixture pdf */
+      char *nm;
+      if ((rc = rd_name(r, &nm))) return rc;
+      const int g = find_gauss(s, nm);
+      if (g < 0) { rc = fail(r, "undefined ~m macro"); free(nm); return rc; }
+      free(nm);
+      *gOut = g;
+      return HTKAMD_OK;
+   }
+   if (k == T_MACRO) return fail(r, "shared vector macros (~u ~v) inside a mixture are not supported");
    if (k == T_KEY && !strcmp(r->tok, "RCLASS")) { int x; if ((rc = rd_int(r, &x))) return rc; k = rd_next(r); }
    if (k != T_KEY || strcmp(r->tok, "MEAN")) return fail(r, "<MEAN> expected");
    if (s->vecSize == 0) return fail(r, "<VECSIZE> must precede the first mean");
@@ -407,6 +433,11 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
          if (find_trans(s, name) >= 0) { rc = fail(&r, "~t macro defined twice"); free(name); break; }
          if (rd_next(&r) != T_KEY || strcmp(r.tok, "TRANSP")) { rc = fail(&r, "<TRANSP> expected"); free(name); break; }
          if ((rc = parse_transp_body(s, &r, name, &ti))) break;
+      } else if (type == 'm') {
+         int g;
+         if (find_gauss(s, name) >= 0) { rc = fail(&r, "~m macro defined twice"); free(name); break; }
+         if ((rc = parse_mixpdf(s, &r, &g))) { free(name); break; }
+         gname_set(s, g, name);
       } else if (type == 'v') {
          if (rd_next(&r) != T_KEY || strcmp(r.tok, "VARIANCE")) { rc = fail(&r, "<VARIANCE> expected"); free(name); break; }
          if (s->vecSize == 0) { rc = fail(&r, "<VECSIZE> must precede ~v"); free(name); break; }
@@ -517,6 +548,8 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
    for (int i = 0; i < s->nTr; i++) free(s->tr[i].name);
    for (int i = 0; i < s->nHm; i++) { free(s->hm[i].name); free(s->hm[i].state); }
    for (int i = 0; i < s->nLog; i++) free(s->logName[i]);
+   for (int g = 0; g < s->capGN; g++) free(s->gName[g]);
+   free(s->gName);
    free(s->st); free(s->wt); free(s->cg); free(s->mean); free(s->var); free(s->gconst); free(s->hasG); free(s->tr); free(s->tp); free(s->hm);
    free(s->varFloor); free(s->logName); free(s->logPhys);
    free(s->stateCompOff); free(s->transN); free(s->transOff); free(s->hmmTrans); free(s->hmmStateOff); free(s->hmmState);
@@ -566,6 +599,7 @@ static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *
       const int c = st->comp0 + m, g = s->cg[c];
       if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */
       if (st->nMix > 1) { put_sym(f, "MIXTURE", 17); put_short(f, m + 1); put_float(f, wt[c]); put_nl(f); }
+      if (g < s->capGN && s->gName[g]) { put_name(f, 'm', s->gName[g]); continue; }     /* PutMixPDF: macro reference */
       put_vec(f, "MEAN", 20, mean + (size_t)g * D, D);
       put_vec(f, "VARIANCE", 21, var + (size_t)g * D, D);
       if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
@@ -653,6 +687,19 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
       for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { names[nN] = s->tr[t].name; idx[nN++] = t; }
       macro_order(names, nN, ord);
       for (int k = 0; k < nN; k++) { const int t = idx[ord[k]]; put_name(f, 't', s->tr[t].name); put_trans(f, transP + s->tr[t].off, s->tr[t].N); }
+      nN = 0;                                                  /* ~m macros come after the atomic ones, before the states */
+      names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
+      ord = (int *)realloc(ord, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
+      for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g]) { names[nN] = s->gName[g]; idx[nN++] = g; }
+      macro_order(names, nN, ord);
+      for (int k = 0; k < nN; k++) {
+         const int g = idx[ord[k]];
+         put_name(f, 'm', s->gName[g]);
+         put_vec(f, "MEAN", 20, mean + (size_t)g * s->vecSize, s->vecSize);
+         put_vec(f, "VARIANCE", 21, var + (size_t)g * s->vecSize, s->vecSize);
+         if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
+      }
       nN = 0;
       for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { names[nN] = s->st[i].name; idx[nN++] = i; }
       macro_order(names, nN, ord);
@@ -668,6 +715,7 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
    if (!dir) { htkamd_set_error("mmf_write: neither file nor directory given"); return HTKAMD_EINVAL; }
    for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { htkamd_set_error("mmf_write: a set with ~s macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { htkamd_set_error("mmf_write: a set with ~t macros must be written to one file"); return HTKAMD_EINVAL; }
+   for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g]) { htkamd_set_error("mmf_write: a set with ~m macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int h = 0; h < s->nHm; h++) {
       char path[1400];
       snprintf(path, sizeof(path), "%s/%s", dir, s->hm[h].name);

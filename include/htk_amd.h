@@ -101,7 +101,7 @@ int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gc
 /* ------------------------------------------------------------------------------------------
  * Model definition files: replaces LoadHMMSet (HModel.c:3809) = MakeHMMSet (:3580) + LoadMacroFiles (:3721) with the
  * -d directory search, and SaveHMMSet (:4979) / SaveInOneFile (:4858), for text definitions of one-stream DIAGC
- * continuous-density sets, text or binary (macros ~o ~s ~t ~h ~v"varFloor"; ~u/~v/~m sharing, streams, durations and
+ * continuous-density sets, text or binary (macros ~o ~s ~t ~m ~h ~v"varFloor"; ~u/~v sharing inside a pdf, streams, durations and
  * transforms are rejected with HTKAMD_EMODEL).  Pure host code.
  *   mmf_read    : one master macro file, or one HMM file (a definition without ~h takes `defName` / the file's base name)
  *   mmf_finish  : HMM list "logical [physical]" (NULL: every defined model is its own logical name); physical models still

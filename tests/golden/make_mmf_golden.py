@@ -23,6 +23,11 @@ def main():
     open(os.path.join(OUT, "empty.hed"), "w").close()
     subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "HHEd"), "-H", "syn_in.mmf", "-w", "syn_resaved.mmf", "empty.hed", "syn_list"], cwd=OUT)
     subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "HHEd"), "-B", "-H", "syn_in.mmf", "-w", "syn_resaved_bin.mmf", "empty.hed", "syn_list"], cwd=OUT)
+    # shared mixture pdfs: the reference's HHEd ties some components into ~m macros
+    with open(os.path.join(OUT, "tie.hed"), "w") as f:
+        f.write("TI mA {(p0,p1,p2).state[2].mix[1]}\nTI mB {(p3,p4).state[3-4].mix[2]}\n")
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "HHEd"), "-H", "syn_in.mmf", "-w", "syn_tied.mmf", "tie.hed", "syn_list"], cwd=OUT)
+    os.remove(os.path.join(OUT, "tie.hed"))
     os.remove(os.path.join(OUT, "empty.hed"))
     print(os.listdir(OUT))
 

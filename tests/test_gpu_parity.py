@@ -481,3 +481,23 @@ def test_viterbi_long_chains_general_kernel(native, oracle):
         got = _align(native, pk, seqs, feats, beam=beam)
         _check_vs_oracle(oracle, om, got, seqs, feats, beam)
         assert all(g["status"] == 1 for g in got)
+
+
+def test_tied_mixture_components_accumulate_jointly(native, oracle):
+    """A model set with shared mixture pdfs (~m macros, read from the reference's HHEd output): statistics of a shared Gaussian
+    are the sum over the components that use it, as in the reference (one MuAcc/VaAcc per MixPDF); HIP path vs oracle."""
+    import os
+    from htk_amd import synth
+    gold = os.path.join(os.path.dirname(__file__), "golden", "mmf")
+    m = native.Mmf(files=[os.path.join(gold, "syn_tied.mmf")], hmm_list=os.path.join(gold, "syn_list"))
+    pk = m.packed()
+    s = synth.generate(10, 3, 6, 4, 60, 77, D=5)                    # the set the fixture was made from: use its utterances
+    utts = [dict(seq=np.asarray(q, np.int32), feat=f) for q, f in zip(s.seqs, s.feats)]
+    model, fb, acc, pr, st = run_fb(native, pk, utts, debug=False)
+    om = oracle.Model(pk); oacc = oracle.Accs(om)
+    for u, ut in enumerate(utts):
+        rc, opr, _ = oracle.fb_utt(om, oracle.fb_cfg(), ut["feat"], ut["seq"], oacc)
+        assert rc == 1 and st[u] == 1 and abs(pr[u] - opr) <= 1e-10 * abs(opr)
+    a = acc.download()
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+        acc_close(a[k], getattr(oacc, k), k)

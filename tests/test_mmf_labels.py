@@ -118,3 +118,19 @@ def test_mmf_binary_form(native, tmp_path):
     out = tmp_path / "out.bin"
     mb.write(dict(mean=qb["mean"], var=qb["var"], gconst=qb["gconst"], compWeight=qb["compWeight"], transP=qb["transP"]), one_file=str(out), binary=True)
     assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "syn_resaved_bin.mmf"), "rb").read()
+
+
+def test_mmf_shared_mixture_macros(native, tmp_path):
+    """~m macros (HHEd TI on mixture components): the shared pdf is ONE Gaussian referenced by several components, and the
+    set is written back exactly as the reference wrote it."""
+    lst = os.path.join(GOLD, "mmf", "syn_list")
+    m = native.Mmf(files=[os.path.join(GOLD, "mmf", "syn_tied.mmf")], hmm_list=lst)
+    q = m.packed()
+    assert q["numComp"] == 30 and q["numGauss"] < 30
+    counts = np.bincount(q["compGauss"], minlength=q["numGauss"])
+    assert counts.max() >= 2 and (counts >= 1).all()                 # some Gaussians are shared, none is orphaned
+    out = tmp_path / "tied.mmf"
+    m.write(dict(mean=q["mean"], var=q["var"], gconst=q["gconst"], compWeight=q["compWeight"], transP=q["transP"]), one_file=str(out))
+    assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "syn_tied.mmf"), "rb").read()
+    with pytest.raises(native.HtkAmdError):
+        m.write(dict(mean=q["mean"], var=q["var"], gconst=q["gconst"], compWeight=q["compWeight"], transP=q["transP"]), out_dir=str(tmp_path))
