@@ -122,6 +122,8 @@ struct htkamd_fb {
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
+   DevBuf d_betaW;                          // wave path's beta block [frame][5][64]
+   bool lastWave;                           // the last execute ran the wave-per-utterance kernels (beta is in d_betaW)
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
@@ -135,7 +137,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) {
       hipError_t e = hipEventCreate(&fb->ev[i]);
@@ -159,7 +161,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -421,7 +423,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    const size_t nf = fb->totalFrames ? fb->totalFrames : 1;
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
-       (rc = fb->d_outp.reserve(sizeof(float) * (outp ? outp : 1))) || (rc = fb->d_beta.reserve(sizeof(double) * (beta ? beta : 1))) ||
+       (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * (beta ? beta : 1))) ||
        (rc = fb->d_gam.reserve(sizeof(double) * (gam ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
        (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))))
       return rc;
@@ -489,6 +491,11 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fb->scored = sa.nTasks > 0;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
    const bool wavePath = (m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
+   fb->lastWave = wavePath;
+   if (wavePath) {
+      if ((rc = fb->d_betaW.reserve(sizeof(double) * 5 * 64 * ((size_t)fb->totalFrames + 1)))) return rc;
+      fa.betaW = (double *)fb->d_betaW.p;
+   }
    if ((rc = wavePath ? htkamd_launch_beta_w(fa, s) : htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;
    HIPCHECK(hipEventRecord(fb->ev[2], s));
    if ((rc = wavePath ? htkamd_launch_alpha_w(fa, s) : htkamd_launch_alpha(fa, fb->blockDim, ldsAlpha, s))) return rc;
@@ -557,6 +564,14 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
    const size_t n = (size_t)T * Q * maxN;
    if (beta) {
       std::vector<double> b((size_t)T * nC);
+      if (fb->lastWave) {                                // the wave path's block [frame][state][lane] -> cells
+         std::vector<double> bs((size_t)T * 5 * 64);
+         HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + (size_t)d.frame0 * 5 * 64, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));
+         for (int t = 0; t < T; t++)
+            for (int q = 1; q <= Q; q++)
+               for (int i = 0; i < mN[q - 1]; i++)
+                  b[(size_t)t * nC + mC[q - 1] + i] = bs[((size_t)t * 5 + i) * 64 + (q - 1)];
+      } else
       HIPCHECK(hipMemcpy(b.data(), (double *)fb->d_beta.p + d.beta0, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
       for (size_t k = 0; k < n; k++) beta[k] = NAN;
       for (int t = 0; t < T; t++)

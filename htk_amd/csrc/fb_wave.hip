@@ -70,11 +70,46 @@ __device__ __forceinline__ void load_model(ModelRegs<MAXN> &m, const FbArgs &a, 
    }
 }
 
+
+// Output-probability rows are time-contiguous per state (outp[slot][t]), so a lane fetches FOUR frames of one of its states with a
+// single 16-byte load.  A block is requested one block (4 frames) before it is needed, waits in registers, and is written to a
+// wave-private LDS slot when the recursion reaches it; each frame then reads its scores from LDS.  No register is copied between
+// request and use, so no step waits for a load younger than four frames (a per-frame 4-byte gather with one frame of look-ahead
+// left the wave waiting on HBM latency every step).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int NE> struct ObsStage {
+   float *lds;                 // this wave's [2][NE][64][4] floats
+   f4u R[NE];                  // block in flight
+   const float *row[NE];       // the lane's score rows (NULL: no such state)
+   int lane;
+   __device__ __forceinline__ void load(int blk)
+   {
+#pragma unroll
+      for (int j = 0; j < NE; j++) if (row[j]) R[j] = *(const f4u *)(row[j] + 4 * blk);
+   }
+   __device__ __forceinline__ void park(int blk)
+   {
+#pragma unroll
+      for (int j = 0; j < NE; j++) *(f4u *)(lds + ((((blk & 1) * NE + j) * 64 + lane) << 2)) = R[j];
+   }
+   // scores of frame index f (0-based) into ob[2..]: the frame's block must have been parked
+   __device__ __forceinline__ void get(int f, float *ob) const
+   {
+#pragma unroll
+      for (int j = 0; j < NE; j++) if (row[j]) ob[j + 2] = lds[(((((f >> 2) & 1) * NE + j) * 64 + lane) << 2) + (f & 3)];
+   }
+};
+
+// beta of the wave path: betaW[((frame0 + t-1)*MAXN + i-1)*64 + lane] -- one state of all models of a frame is one contiguous run,
+// so the wave's store (beta pass) and load (alpha pass) of a state are coalesced
+#define BETA_W(t, i) (gbeta[((size_t)((t) - 1) * MAXN + ((i) - 1)) * 64])
+
 // ------------------------------------------------------------------------------------ K2w: beta
 template <int MAXN>
 __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
 {
    __shared__ double ltab[LADD_TAB_DOUBLES];
+   __shared__ float stage[WPB][2 * (MAXN - 2) * 64 * 4];
    ladd_table_to_lds(ltab, a.laddTab);
    __syncthreads();
    const int lane = threadIdx.x & 63;
@@ -99,8 +134,14 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
 
    const short *tLo = a.taperLo + ud.frame0 - 1, *tHi = a.taperHi + ud.frame0 - 1;   // 1-based t
    short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;
-   const float *orow = a.outp + ud.outp0 + (size_t)m.ms0 * T;                          // rows of this model's emitting states
-   double *gbeta = a.beta + ud.beta0;
+   ObsStage<MAXN - 2> st;
+   st.lds = stage[threadIdx.x >> 6]; st.lane = lane;
+#pragma unroll
+   for (int j = 0; j < MAXN - 2; j++) {
+      st.row[j] = (valid && j + 2 < N) ? a.outp + ud.outp0 + (size_t)(m.ms0 + j) * T : nullptr;   // rows of this model's emitting states
+      st.R[j] = (f4u)(0.f);
+   }
+   double *gbeta = a.betaW + (size_t)ud.frame0 * MAXN * 64 + lane;
    const double mle = a.minLogExp;
    const bool pruning = a.pruneInit < HTKAMD_NOPRUNE;
 
@@ -116,10 +157,15 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
       for (int j = 0; j < MAXN; j++) { obT[j] = 0.f; ob1[j] = 0.f; obP[j] = 0.f; }
       // ---- t = T (HFB.c:1175-1198)
       int endq = tLo[T];
-      if (valid) {
-#pragma unroll
-         for (int j = 2; j < MAXN; j++)
-            if (j < N) { obT[j] = orow[(size_t)(j - 2) * T + (T - 1)]; if (T >= 2) obP[j] = orow[(size_t)(j - 2) * T + (T - 2)]; }
+      {  // scores: the last block straight into LDS, the one before it in flight
+         const int bl = (T - 1) >> 2;
+         st.load(bl); st.park(bl);
+         if (bl >= 1) st.load(bl - 1);
+         st.get(T - 1, obT);
+         if (T >= 2) {
+            if (((T - 2) & 3) == 3) { st.park((T - 2) >> 2); if (((T - 2) >> 2) >= 1) st.load(((T - 2) >> 2) - 1); }
+            st.get(T - 2, obP);
+         }
       }
       {
          // exit chain: e(Q) = 0, e(q) = e(q+1) + a_1N(q+1)
@@ -142,7 +188,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
                }
             bC[1] = x;
 #pragma unroll
-            for (int i = 1; i <= MAXN; i++) if (i <= N) gbeta[(size_t)(T - 1) * nC + m.mc0 + i - 1] = bC[i];
+            for (int i = 1; i <= MAXN; i++) if (i <= N) BETA_W(T, i) = bC[i];
          }
       }
       if (lane == 0) { gLo[T] = (short)endq; gHi[T] = (short)Q; }
@@ -154,26 +200,25 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
       for (int t = T - 1; t >= 1; t--) {
          const int taperLoT = nxtLo, taperHiT = nxtHi;
          if (t >= 2) { nxtLo = tLo[t - 1]; nxtHi = tHi[t - 1]; }
+         // a new block of scores is parked when the recursion reaches it, and the next one requested; this is the only place the
+         // wave waits for memory: the block's loads are four frames old, and the stores below are issued after it
+         if (t >= 2 && ((t - 2) & 3) == 3) { st.park((t - 2) >> 2); if (((t - 2) >> 2) >= 1) st.load(((t - 2) >> 2) - 1); }
          // rotate: previous column, output probabilities
 #pragma unroll
          for (int i = 0; i <= MAXN; i++) bP[i] = bC[i];
-         // the column finished in the previous iteration goes out NOW: vmcnt counts stores on gfx9, so a store issued at the end
-         // of a frame would make the next frame's first wait (for its prefetched inputs) also wait for the write acknowledgement
+         // the column finished in the previous iteration goes out now (vmcnt counts stores on gfx9: a store issued at the end of a
+         // frame would be waited for at the top of the next one)
          if (stPrev) {
             if (stIn) {
 #pragma unroll
-               for (int i = 1; i <= MAXN; i++) if (i <= N) gbeta[(size_t)(tPrev - 1) * nC + m.mc0 + i - 1] = bP[i];
+               for (int i = 1; i <= MAXN; i++) if (i <= N) BETA_W(tPrev, i) = bP[i];
             }
             if (lane == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
             stPrev = false;
          }
 #pragma unroll
          for (int j = 0; j < MAXN; j++) { ob1[j] = obT[j]; obT[j] = obP[j]; }
-         if (valid && t >= 2) {
-#pragma unroll
-            for (int j = 2; j < MAXN; j++)
-               if (j < N) obP[j] = orow[(size_t)(j - 2) * T + (t - 2)];
-         }
+         if (t >= 2) st.get(t - 2, obP);
          const int startq = qHiN;
          endq = (qLoN == 1) ? 1 : ((taperLoT >= qLoN) ? taperLoT : qLoN - 1);
          while (endq > 1 && ((teeMask >> (endq - 2)) & 1ull)) endq--;
@@ -240,7 +285,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
       if (!fail && stPrev) {                             // the last column (t = 1)
          if (stIn) {
 #pragma unroll
-            for (int i = 1; i <= MAXN; i++) if (i <= N) gbeta[(size_t)(tPrev - 1) * nC + m.mc0 + i - 1] = bC[i];
+            for (int i = 1; i <= MAXN; i++) if (i <= N) BETA_W(tPrev, i) = bC[i];
          }
          if (lane == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
       }
@@ -299,7 +344,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
    const short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;    // final beta beam, 1-based t
    short *gaLo = a.aLo + ud.frame0 - 1, *gaHi = a.aHi + ud.frame0 - 1;
    const float *orow = a.outp + ud.outp0 + (size_t)m.ms0 * T;
-   const double *gbeta = a.beta + ud.beta0 + m.mc0;
+   const double *gbeta = a.betaW + (size_t)ud.frame0 * MAXN * 64 + lane;
    double *gam = a.gam + ud.gam0 + m.ms0;
    const double mle = a.minLogExp, pr = a.pr[u];
    const double minF = (double)a.minFrwdP;
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
    if (valid) {
 #pragma unroll
       for (int i = 1; i <= MAXN; i++)
-         if (i <= N) { bT[i] = gbeta[i - 1]; if (T >= 2) bT1[i] = gbeta[(size_t)nC + i - 1]; }
+         if (i <= N) { bT[i] = BETA_W(1, i); if (T >= 2) bT1[i] = BETA_W(2, i); }
 #pragma unroll
       for (int j = 2; j < MAXN; j++)
          if (j < N) { oT[j] = orow[(size_t)(j - 2) * T]; if (T >= 2) oT1[j] = orow[(size_t)(j - 2) * T + 1]; }
@@ -368,7 +413,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
          lo3 = gLo[t + 2]; hi3 = gHi[t + 2];
          if (valid) {
 #pragma unroll
-            for (int i = 1; i <= MAXN; i++) if (i <= N) bT2[i] = gbeta[(size_t)(t + 1) * nC + i - 1];
+            for (int i = 1; i <= MAXN; i++) if (i <= N) bT2[i] = BETA_W(t + 2, i);
 #pragma unroll
             for (int j = 2; j < MAXN; j++) if (j < N) oT2[j] = orow[(size_t)(j - 2) * T + (t + 1)];
          }

@@ -69,6 +69,7 @@ struct FbArgs {
    const float *transP;
    float *outp;
    double *beta, *gam, *alphaDbg;    // alphaDbg: NULL unless debugging, layout as beta
+   double *betaW;                    // wave path: beta as [(frame0 + t-1)][state 0..4][64 lanes] (coalesced per state)
    double *pr;                       // [nUtt]
    int *status;                      // [nUtt]
    // model tables for the statistics kernel
