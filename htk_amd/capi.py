@@ -506,6 +506,32 @@ def parm_add_qualifiers(stat_list, hasD=True, hasA=False, delWin=2, accWin=2) ->
     return dOut, frameOff, cols
 
 
+class ParmQuals(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nStat", "nZeroMean", "hasD", "hasA", "hasT", "delWin", "accWin", "thirdWin", "nullECol")]
+
+
+def parm_quals_from_kind(kind: str, nStat: int, delWin=2, accWin=2, thirdWin=2) -> ParmQuals:
+    """Qualifier step for tables of base kind + _0/_E statics (`nStat` columns) read with TARGETKIND = `kind`, e.g. "MFCC_E_D_A_N"."""
+    q = kind.upper().split("_")[1:]
+    nE = int("E" in q) + int("0" in q)
+    base = nStat - nE
+    nZ = (base + int("0" in q and "N" not in q)) if "Z" in q else 0            # HParm.c:1712-1715
+    null = base if ("N" in q and nE) else -1                                   # the column after the base coefficients
+    return ParmQuals(nStat, nZ, int("D" in q), int("A" in q), int("T" in q), delWin, accWin, thirdWin, null)
+
+
+def parm_qualify(stat_list, quals: ParmQuals):
+    """htkamd_parm_qualify on the statics of several utterances. Returns (DevArray [sum T, cols], frameOff, cols)."""
+    stat = np.ascontiguousarray(np.concatenate(stat_list), np.float32)
+    frameOff = np.concatenate([[0], np.cumsum([x.shape[0] for x in stat_list])]).astype(np.int32)
+    assert stat.shape[1] == quals.nStat
+    cols = lib().htkamd_parm_quals_cols(C.byref(quals))
+    dIn = DevArray(stat)
+    dOut = DevArray(nbytes=4 * max(stat.shape[0] * cols, 1))
+    check(lib().htkamd_parm_qualify(dIn.ptr, _p(frameOff), C.c_int(len(stat_list)), C.byref(quals), dOut.ptr, None), "parm_qualify")
+    return dOut, frameOff, cols
+
+
 class Mmf:
     """htkamd_mmf holder: LoadHMMSet / SaveHMMSet for text model definitions (htk_amd/host/mmf.c)."""
 

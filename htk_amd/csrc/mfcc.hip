@@ -354,35 +354,73 @@ __global__ void k_parm_widen(const float *in, float *out, size_t nFrames, int nS
    out[f * nCols + k] = in[g];
 }
 
-extern "C" int htkamd_parm_add_qualifiers(const float *dStatic, const int *frameOff, int nUtt, int nStat, int hasD, int hasA,
-                                          int delWin, int accWin, float *dOut, void *stream)
+// _N: the row without its absolute energy / C0 column (ExtractObservation HParm.c:2882-2893)
+__global__ void k_parm_drop_col(const float *in, float *out, size_t nFrames, int nFull, int col)
 {
-   if (!frameOff || nUtt < 0 || nStat <= 0 || (hasA && !hasD) || delWin < 1 || accWin < 1) {
-      htkamd_set_error("parm_add_qualifiers: bad argument"); return HTKAMD_EINVAL;
+   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   const int nCols = nFull - 1;
+   if (g >= nFrames * (size_t)nCols) return;
+   const size_t f = g / nCols;
+   const int k = (int)(g % nCols);
+   out[g] = in[f * nFull + (k < col ? k : k + 1)];
+}
+
+extern "C" int htkamd_parm_quals_cols(const htkamd_parm_quals *q)
+{
+   if (!q || q->nStat <= 0) return 0;
+   return q->nStat * (1 + (q->hasD ? 1 : 0) + (q->hasA ? 1 : 0) + (q->hasT ? 1 : 0)) - (q->nullECol >= 0 ? 1 : 0);
+}
+
+extern "C" int htkamd_parm_qualify(const float *dStatic, const int *frameOff, int nUtt, const htkamd_parm_quals *q, float *dOut, void *stream)
+{
+   if (!q || !frameOff || nUtt < 0 || q->nStat <= 0 || (q->hasA && !q->hasD) || (q->hasT && !q->hasA) ||
+       (q->hasD && q->delWin < 1) || (q->hasA && q->accWin < 1) || (q->hasT && q->thirdWin < 1) ||
+       q->nZeroMean < 0 || q->nZeroMean > q->nStat || q->nullECol >= q->nStat || (q->nullECol >= 0 && !q->hasD)) {
+      htkamd_set_error("parm_qualify: bad argument"); return HTKAMD_EINVAL;       /* _N needs _D: ValidConversion HParm.c:1420 */
    }
    const int F = nUtt ? frameOff[nUtt] : 0;
    if (F == 0) return HTKAMD_OK;
-   if (!dStatic || !dOut) { htkamd_set_error("parm_add_qualifiers: NULL table"); return HTKAMD_EINVAL; }
+   if (!dStatic || !dOut) { htkamd_set_error("parm_qualify: NULL table"); return HTKAMD_EINVAL; }
    hipStream_t s = (hipStream_t)stream;
-   const int nCols = nStat * (1 + (hasD ? 1 : 0) + (hasA ? 1 : 0));
+   const int nStat = q->nStat;
+   const int nFull = nStat * (1 + (q->hasD ? 1 : 0) + (q->hasA ? 1 : 0) + (q->hasT ? 1 : 0));
    std::vector<int> frameUtt((size_t)F);
    for (int u = 0; u < nUtt; u++) {
-      if (frameOff[u + 1] < frameOff[u]) { htkamd_set_error("parm_add_qualifiers: frameOff not monotone"); return HTKAMD_EINVAL; }
+      if (frameOff[u + 1] < frameOff[u]) { htkamd_set_error("parm_qualify: frameOff not monotone"); return HTKAMD_EINVAL; }
       for (int f = frameOff[u]; f < frameOff[u + 1]; f++) frameUtt[f] = u;
    }
    int *dUtt = nullptr, *dOff = nullptr;
+   float *dFull = dOut;
    HIPCHECK(hipMalloc((void **)&dUtt, sizeof(int) * (size_t)F));
    HIPCHECK(hipMalloc((void **)&dOff, sizeof(int) * ((size_t)nUtt + 1)));
+   if (q->nullECol >= 0) HIPCHECK(hipMalloc((void **)&dFull, sizeof(float) * (size_t)F * nFull));
    HIPCHECK(hipMemcpyAsync(dUtt, frameUtt.data(), sizeof(int) * (size_t)F, hipMemcpyHostToDevice, s));
    HIPCHECK(hipMemcpyAsync(dOff, frameOff, sizeof(int) * ((size_t)nUtt + 1), hipMemcpyHostToDevice, s));
    const size_t n = (size_t)F * nStat;
    const unsigned blocks = (unsigned)((n + 255) / 256);
-   hipLaunchKernelGGL(k_parm_widen, dim3(blocks), dim3(256), 0, s, dStatic, dOut, (size_t)F, nStat, nCols);
-   if (hasD) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dOut, dUtt, dOff, F, nCols, 0, nStat, nStat, delWin);
-   if (hasA) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dOut, dUtt, dOff, F, nCols, nStat, 2 * nStat, nStat, accWin);
+   hipLaunchKernelGGL(k_parm_widen, dim3(blocks), dim3(256), 0, s, dStatic, dFull, (size_t)F, nStat, nFull);
+   if (q->hasD) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, 0, nStat, nStat, q->delWin);
+   if (q->hasA) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, nStat, 2 * nStat, nStat, q->accWin);
+   if (q->hasT) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, 2 * nStat, 3 * nStat, nStat, q->thirdWin);
+   if (q->nZeroMean > 0)
+      hipLaunchKernelGGL(k_mfcc_zmean, dim3((nUtt * q->nZeroMean + 63) / 64), dim3(64), 0, s, dFull, dOff, nUtt, nFull, q->nZeroMean);
+   if (q->nullECol >= 0) {
+      const size_t m = (size_t)F * (nFull - 1);
+      hipLaunchKernelGGL(k_parm_drop_col, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, dFull, dOut, (size_t)F, nFull, q->nullECol);
+   }
    hipError_t e = hipGetLastError();
    hipError_t e2 = hipStreamSynchronize(s);
    (void)hipFree(dUtt); (void)hipFree(dOff);
+   if (dFull != dOut) (void)hipFree(dFull);
    HIPCHECK(e); HIPCHECK(e2);
    return HTKAMD_OK;
+}
+
+extern "C" int htkamd_parm_add_qualifiers(const float *dStatic, const int *frameOff, int nUtt, int nStat, int hasD, int hasA,
+                                          int delWin, int accWin, float *dOut, void *stream)
+{
+   if (nStat <= 0 || (hasA && !hasD) || delWin < 1 || accWin < 1) { htkamd_set_error("parm_add_qualifiers: bad argument"); return HTKAMD_EINVAL; }
+   htkamd_parm_quals q;
+   q.nStat = nStat; q.nZeroMean = 0; q.hasD = hasD; q.hasA = hasA; q.hasT = 0; q.delWin = delWin; q.accWin = accWin; q.thirdWin = 2; q.nullECol = -1;
+   return htkamd_parm_qualify(dStatic, frameOff, nUtt, &q, dOut, stream);
 }

@@ -401,6 +401,19 @@ int  htkamd_mfcc_num_cols(const htkamd_mfcc_config *cfg);
    regression windows per utterance (frameOff host [nUtt+1]). */
 int  htkamd_parm_add_qualifiers(const float *dStatic, const int *frameOff, int nUtt, int nStat, int hasD, int hasA,
                                 int delWin, int accWin, float *dOut, void *stream);
+/* The whole qualifier step of AddQualifiers for a table: _D _A _T (third differentials = regression of the accelerations over
+   THIRDWINDOW, HParm.c:1675-1681), then _Z (FZeroMean over the first nZeroMean columns per utterance, HParm.c:1700-1726: the base
+   coefficients, plus C0 when the kind has _0 and not _N), and _N (the row is handed out without its absolute energy / C0 column
+   `nullECol`, ExtractObservation HParm.c:2882-2893; needs _D).  dOut: [F x htkamd_parm_quals_cols(q)]. */
+typedef struct {
+   int nStat;                       /* static columns incl. C0 / energy                        */
+   int nZeroMean;                   /* _Z: leading columns to zero-mean (0 = no _Z)            */
+   int hasD, hasA, hasT;            /* _D _A _T                                                */
+   int delWin, accWin, thirdWin;    /* DELTAWINDOW ACCWINDOW THIRDWINDOW                       */
+   int nullECol;                    /* _N: column left out of every row (-1 = none)            */
+} htkamd_parm_quals;
+int  htkamd_parm_quals_cols(const htkamd_parm_quals *q);
+int  htkamd_parm_qualify(const float *dStatic, const int *frameOff, int nUtt, const htkamd_parm_quals *q, float *dOut, void *stream);
 int  htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int *sampOff, int nUtt, int *frameOff, float *dOut, void *stream);
 
 #ifdef __cplusplus

@@ -142,6 +142,8 @@ int orc_mfcc_frames(int nSamples, const orc_mfcc_cfg *c, int *frSize, int *frRat
 int orc_mfcc_cols(const orc_mfcc_cfg *c);
 int orc_mfcc(const short *wav, int nSamples, const orc_mfcc_cfg *c, float *out);
 int orc_add_qualifiers(const float *stat, int T, int nStat, int hasD, int hasA, int delWin, int accWin, float *out);
+int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
+                     int delWin, int accWin, int thirdWin, int nullECol, float *out);
 
 /* ---- Viterbi forced alignment of a chain of physical models (HRec token passing, 1-best; orc_viterbi.c) ----
    Returns the number of state segments (time order) or -1 when no token survives.  Frames are 0-based,

@@ -304,3 +304,35 @@ int orc_add_qualifiers(const float *stat, int T, int nStat, int hasD, int hasA, 
    if (hasA) add_diffs(out, T, nCols, nStat, 2 * nStat, nStat, accWin);
    return nCols;
 }
+
+/* The remaining qualifiers of AddQualifiers on a table: third differentials (HParm.c:1675-1681, regression of the
+   accelerations over THIRDWINDOW), _Z after the differentials (HParm.c:1700-1726: FZeroMean over the first nZeroMean
+   columns), and _N (the absolute energy / C0 column nullECol is left out when the row is handed out as an observation,
+   ExtractObservation HParm.c:2882-2893).  out holds nStat*(1+D+A+T) - (nullECol >= 0) columns; returns that number. */
+int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
+                     int delWin, int accWin, int thirdWin, int nullECol, float *out)
+{
+   int nFull = nStat * (1 + (hasD ? 1 : 0) + (hasA ? 1 : 0) + (hasT ? 1 : 0)), nCols = nFull - (nullECol >= 0 ? 1 : 0), t, k, i, j;
+   float *full = (nullECol >= 0) ? (float *)malloc(sizeof(float) * (size_t)(T ? T : 1) * nFull) : out;
+   for (t = 0; t < T; t++)
+      for (k = 0; k < nStat; k++) full[(size_t)t * nFull + k] = stat[(size_t)t * nStat + k];
+   if (T > 0) {
+      if (hasD) add_diffs(full, T, nFull, 0, nStat, nStat, delWin);
+      if (hasA) add_diffs(full, T, nFull, nStat, 2 * nStat, nStat, accWin);
+      if (hasT) add_diffs(full, T, nFull, 2 * nStat, 3 * nStat, nStat, thirdWin);
+      for (i = 0; i < nZeroMean; i++) {                                              /* FZeroMean HSigP.c:803 */
+         double sum = 0.0; float mean, *fp = full + i;
+         for (j = 0; j < T; j++) { sum += *fp; fp += nFull; }
+         mean = sum / (double)T;
+         fp = full + i;
+         for (j = 0; j < T; j++) { *fp -= mean; fp += nFull; }
+      }
+   }
+   if (nullECol >= 0) {
+      for (t = 0; t < T; t++)
+         for (k = 0, j = 0; k < nFull; k++)
+            if (k != nullECol) out[(size_t)t * nCols + j++] = full[(size_t)t * nFull + k];
+      free(full);
+   }
+   return nCols;
+}

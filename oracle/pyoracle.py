@@ -254,6 +254,18 @@ def add_qualifiers(stat: np.ndarray, hasD=True, hasA=False, delWin=2, accWin=2) 
     return out
 
 
+def parm_qualify(stat: np.ndarray, nZeroMean=0, hasD=True, hasA=False, hasT=False, delWin=2, accWin=2, thirdWin=2, nullECol=-1) -> np.ndarray:
+    """AddQualifiers incl. third differentials and _Z on a table, then the _N column drop of ExtractObservation."""
+    stat = np.ascontiguousarray(stat, np.float32)
+    T, n = stat.shape
+    cols = n * (1 + int(hasD) + int(hasA) + int(hasT)) - int(nullECol >= 0)
+    out = np.zeros((T, cols), np.float32)
+    got = lib().orc_parm_qualify(_p(stat), C.c_int(T), C.c_int(n), C.c_int(nZeroMean), C.c_int(hasD), C.c_int(hasA), C.c_int(hasT),
+                                 C.c_int(delWin), C.c_int(accWin), C.c_int(thirdWin), C.c_int(nullECol), _p(out))
+    assert got == cols
+    return out
+
+
 def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
     wav = np.ascontiguousarray(wav, np.int16)
     T = lib().orc_mfcc_frames(C.c_int(len(wav)), C.byref(cfg), None, None)
