@@ -52,7 +52,7 @@ class FbConfig(C.Structure):
 
 class UpdateConfig(C.Structure):
     _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int),
-                ("singleProcess", C.c_int)]
+                ("singleProcess", C.c_int), ("varFloor", C.POINTER(C.c_float))]
 
 
 class UpdateStats(C.Structure):
@@ -151,10 +151,15 @@ class Model:
         check(lib().htkamd_model_get_prepared(self.h, _p(ivar), _p(gc), _p(lw), _p(md)), "model_get_prepared")
         return dict(ivar=ivar, gconst=gc, compLogWt=lw, minDur=md)
 
-    def update(self, accs: "Accs", vec: np.ndarray, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False):
-        """UpdateModels (HERest.c:1326) from a host copy of the (summed) accumulator vector."""
+    def update(self, accs: "Accs", vec: np.ndarray, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False, varFloor=None):
+        """UpdateModels (HERest.c:1326) from a host copy of the (summed) accumulator vector.  varFloor: the ~v "varFloor1" vector."""
         vec = np.ascontiguousarray(vec, np.float64)
-        cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess))
+        vf = None
+        if varFloor is not None:
+            vf = np.ascontiguousarray(varFloor, np.float32)
+            assert vf.shape == (self.D,)
+        cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess),
+                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None)
         st = UpdateStats()
         check(lib().htkamd_model_update(self.h, accs.h, _p(vec), C.byref(cfg), C.byref(st)), "model_update")
         return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
@@ -504,6 +509,18 @@ def parm_add_qualifiers(stat_list, hasD=True, hasA=False, delWin=2, accWin=2) ->
     check(lib().htkamd_parm_add_qualifiers(dIn.ptr, _p(frameOff), C.c_int(len(stat_list)), C.c_int(n), C.c_int(int(hasD)), C.c_int(int(hasA)),
                                            C.c_int(delWin), C.c_int(accWin), dOut.ptr, None), "parm_add_qualifiers")
     return dOut, frameOff, cols
+
+
+def compv(dX_ptr, nFrames: int, D: int, minVar: float = 0.0):
+    """htkamd_compv: HCompV's global mean and variance of a device table [nFrames x D]."""
+    mean = np.zeros(D, np.float32); var = np.zeros(D, np.float32)
+    check(lib().htkamd_compv(dX_ptr, C.c_longlong(nFrames), C.c_int(D), C.c_float(minVar), _p(mean), _p(var), None), "compv")
+    return mean, var
+
+
+def write_vfloors(path: str, var: np.ndarray, scale: float):
+    var = np.ascontiguousarray(var, np.float32)
+    check(lib().htkamd_mmf_write_vfloors(path.encode(), _p(var), C.c_int(len(var)), C.c_float(scale)), "mmf_write_vfloors")
 
 
 class ParmQuals(C.Structure):

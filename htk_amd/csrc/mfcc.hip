@@ -424,3 +424,42 @@ extern "C" int htkamd_parm_add_qualifiers(const float *dStatic, const int *frame
    q.nStat = nStat; q.nZeroMean = 0; q.hasD = hasD; q.hasA = hasA; q.hasT = 0; q.delWin = delWin; q.accWin = accWin; q.thirdWin = 2; q.nullECol = -1;
    return htkamd_parm_qualify(dStatic, frameOff, nUtt, &q, dOut, stream);
 }
+
+// ------------------------------------------------------------------------------------ HCompV: global mean and variance
+// One block per slab of frames, thread = dimension (strided), fp64 partial sums, one atomic per (block, dimension).
+__global__ void k_compv(const float *X, long long nFrames, int D, double *acc)
+{
+   const long long per = (nFrames + gridDim.x - 1) / gridDim.x;
+   const long long f0 = (long long)blockIdx.x * per, f1 = (f0 + per < nFrames) ? f0 + per : nFrames;
+   for (int k = threadIdx.x; k < D; k += blockDim.x) {
+      double s = 0.0, q = 0.0;
+      for (long long f = f0; f < f1; f++) { const double v = (double)X[(size_t)f * D + k]; s += v; q += v * v; }
+      if (f1 > f0) { atomicAdd(acc + k, s); atomicAdd(acc + D + k, q); }
+   }
+}
+
+extern "C" int htkamd_compv(const float *dX, long long nFrames, int D, float minVar, float *mean, float *var, void *stream)
+{
+   if (!dX || !mean || !var || D <= 0) { htkamd_set_error("compv: bad argument"); return HTKAMD_EINVAL; }
+   if (nFrames < 2) { htkamd_set_error("compv: only %lld frames (HCompV error 2021)", nFrames); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   double *dAcc = nullptr;
+   HIPCHECK(hipMalloc((void **)&dAcc, sizeof(double) * 2 * (size_t)D));
+   HIPCHECK(hipMemsetAsync(dAcc, 0, sizeof(double) * 2 * (size_t)D, s));
+   long long blocks = (nFrames + 255) / 256;
+   if (blocks > 4096) blocks = 4096;
+   hipLaunchKernelGGL(k_compv, dim3((unsigned)blocks), dim3(64), 0, s, dX, nFrames, D, dAcc);
+   std::vector<double> h(2 * (size_t)D);
+   hipError_t e = hipGetLastError();
+   hipError_t e2 = hipMemcpyAsync(h.data(), dAcc, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s);
+   hipError_t e3 = hipStreamSynchronize(s);
+   (void)hipFree(dAcc);
+   HIPCHECK(e); HIPCHECK(e2); HIPCHECK(e3);
+   const double n = (double)nFrames;
+   for (int k = 0; k < D; k++) {
+      const double m = h[k] / n, v = h[D + k] / n - m * m;
+      mean[k] = (float)m;
+      var[k] = ((float)v > minVar) ? (float)v : minVar;
+   }
+   return HTKAMD_OK;
+}

@@ -727,3 +727,16 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
    }
    return HTKAMD_OK;
 }
+
+/* HCompV's variance floor macro file (PutVFloor, HCompV.c:359-389): one stream. */
+int htkamd_mmf_write_vfloors(const char *path, const float *var, int D, float scale)
+{
+   if (!path || !var || D <= 0) { htkamd_set_error("mmf_write_vfloors: bad argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "w");
+   if (!f) { htkamd_set_error("mmf_write_vfloors: cannot create %s", path); return HTKAMD_EIO; }
+   fprintf(f, "~v varFloor1\n<Variance> %d\n", D);
+   for (int i = 0; i < D; i++) { float v = var[i]; v *= scale; fprintf(f, " %e", v); }
+   fputc('\n', f);
+   fclose(f);
+   return HTKAMD_OK;
+}

@@ -105,7 +105,8 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                         for (k = 0; k < D; k++) {
                            const float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)g * D + k) / muOcc;
                            float x = ACCF(lay->va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
-                           if (x < cfg->minVar) { x = cfg->minVar; st->nFloorVar++; mixFloored = 1; }
+                           const float fl = cfg->varFloor ? cfg->varFloor[k] : cfg->minVar;
+                           if (x < fl) { x = fl; st->nFloorVar++; mixFloored = 1; }
                            var[(size_t)g * D + k] = x;
                         }
                      } else st->nNoVarUse++;

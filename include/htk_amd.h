@@ -112,6 +112,8 @@ int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gc
  * ------------------------------------------------------------------------------------------ */
 typedef struct htkamd_mmf htkamd_mmf;
 int  htkamd_mmf_create(htkamd_mmf **out);
+/* HCompV's PutVFloor (HCompV.c:359-389): "~v varFloor1 <Variance> D" with scale*var, written like WriteVector(" %e"). */
+int  htkamd_mmf_write_vfloors(const char *path, const float *var, int D, float scale);
 void htkamd_mmf_destroy(htkamd_mmf *s);
 int  htkamd_mmf_read(htkamd_mmf *s, const char *path, const char *defName);
 int  htkamd_mmf_finish(htkamd_mmf *s, const char *hmmList, const char *dir, const char *ext);
@@ -225,6 +227,8 @@ typedef struct {
    float mixWeightFloor;    /* HERest -w f gives f*MINMIX (HERest.c:425), default 0.0              */
    int   uFlags;            /* HTKAMD_UP* bits                                                     */
    int   singleProcess;     /* 1 = parMode -1: ForceDiagC/ConvExpWt round trips (HERest.c:1336-1339) */
+   const float *varFloor;   /* [vecSize] per-component floor = the ~v "varFloor1" macro (SetVFloor HModel.c:3512: when the
+                               macro exists it replaces minVar); NULL = minVar everywhere                */
 } htkamd_update_config;
 typedef struct {
    int nFloorVar, nFloorVarMix;      /* "Total %d floored variance elements in %d different mixes"  */
@@ -414,6 +418,12 @@ typedef struct {
 } htkamd_parm_quals;
 int  htkamd_parm_quals_cols(const htkamd_parm_quals *q);
 int  htkamd_parm_qualify(const float *dStatic, const int *frameOff, int nUtt, const htkamd_parm_quals *q, float *dOut, void *stream);
+/* HCompV's global statistics over a device table of frames: replaces AccVar / CalcCovs (HTKTools/HCompV.c:392-411, :261-291) --
+   mean and diagonal variance of all frames, variance floored at minVar (HCompV -v, default 0).  The reference sums in float in
+   file order; this sums in fp64 (order-free), so the results agree to the reference's own rounding (~1e-6 relative at a few
+   thousand frames, growing with the frame count on the reference's side).  Flat start = every Gaussian's mean/variance set to
+   these (HCompV -m), the variance floor macro = f * var (HCompV -f f, htkamd_mmf_write_vfloors). */
+int  htkamd_compv(const float *dX, long long nFrames, int D, float minVar, float *mean /*[D]*/, float *var /*[D]*/, void *stream);
 int  htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int *sampOff, int nUtt, int *frameOff, float *dOut, void *stream);
 
 #ifdef __cplusplus

@@ -336,3 +336,25 @@ int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int has
    }
    return nCols;
 }
+
+/* HCompV's global statistics (HTKTools/HCompV.c): AccVar :392-411 adds every observation, in file order, into FLOAT
+   accumulators (sum and sum of squares per component); CalcCovs :261-291 divides by the float frame count and floors the
+   variance at minVar (default 0.0).  X: all frames [T x D] in the order the files were given. */
+void orc_compv(const float *X, long T, int D, float minVar, float *mean, float *var)
+{
+   long t; int k;
+   float *sum = (float *)calloc((size_t)D, sizeof(float)), *sq = (float *)calloc((size_t)D, sizeof(float));
+   float n = (float)T;
+   for (t = 0; t < T; t++)
+      for (k = 0; k < D; k++) {
+         float val = X[(size_t)t * D + k];
+         sum[k] += val;
+         sq[k] += val * val;
+      }
+   for (k = 0; k < D; k++) mean[k] = sum[k] / n;
+   for (k = 0; k < D; k++) {
+      float meanx = mean[k], varxy = sq[k] / n - meanx * meanx;
+      var[k] = (varxy > minVar) ? varxy : minVar;
+   }
+   free(sum); free(sq);
+}

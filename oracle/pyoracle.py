@@ -254,6 +254,15 @@ def add_qualifiers(stat: np.ndarray, hasD=True, hasA=False, delWin=2, accWin=2) 
     return out
 
 
+def compv(X: np.ndarray, minVar=0.0):
+    """HCompV's global mean / variance (float accumulators in frame order)."""
+    X = np.ascontiguousarray(X, np.float32)
+    T, D = X.shape
+    mean = np.zeros(D, np.float32); var = np.zeros(D, np.float32)
+    lib().orc_compv(_p(X), C.c_long(T), C.c_int(D), C.c_float(minVar), _p(mean), _p(var))
+    return mean, var
+
+
 def parm_qualify(stat: np.ndarray, nZeroMean=0, hasD=True, hasA=False, hasT=False, delWin=2, accWin=2, thirdWin=2, nullECol=-1) -> np.ndarray:
     """AddQualifiers incl. third differentials and _Z on a table, then the _N column drop of ExtractObservation."""
     stat = np.ascontiguousarray(stat, np.float32)
