@@ -654,12 +654,18 @@ class NetDesc(C.Structure):
 class Net:
     """htkamd_net holder: SLF word network + dictionary expanded over a model set (htk_amd/host/net.c)."""
 
-    def __init__(self, slf: str, dictionary: str, mmf: "Mmf"):
+    def __init__(self, slf: str | None, dictionary: str, mmf: "Mmf", words=None, boundary: str | None = None):
+        """slf: word lattice file; or slf=None and words=[...]: the alignment network of HVite -a for that transcription."""
         L = lib()
         L.htkamd_net_get.restype = C.POINTER(NetDesc)
         L.htkamd_net_out_sym.restype = C.c_char_p
         self.h = C.c_void_p()
-        check(L.htkamd_net_build(slf.encode(), dictionary.encode(), mmf.h, C.byref(self.h)), "net_build")
+        if slf is not None:
+            check(L.htkamd_net_build(slf.encode(), dictionary.encode(), mmf.h, C.byref(self.h)), "net_build")
+        else:
+            arr = (C.c_char_p * len(words))(*[w.encode() for w in words])
+            check(L.htkamd_net_build_words(arr, C.c_int(len(words)), boundary.encode() if boundary else None, dictionary.encode(),
+                                           mmf.h, C.byref(self.h)), "net_build_words")
         self.desc = L.htkamd_net_get(self.h).contents
         self.out_syms = [L.htkamd_net_out_sym(self.h, C.c_int(k)).decode() for k in range(self.desc.nProns)]
         L.htkamd_net_word_name.restype = C.c_char_p

@@ -252,6 +252,8 @@ void htkamd_net_destroy(struct htkamd_net *n)
 
 typedef struct { int from, to; float like; } tlink;
 
+static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, struct htkamd_net **out);
+
 int htkamd_net_build(const char *slfPath, const char *dictPath, const struct htkamd_mmf *hmms, struct htkamd_net **out)
 {
    if (!slfPath || !dictPath || !hmms || !out) { htkamd_set_error("net_build: NULL argument"); return HTKAMD_EINVAL; }
@@ -261,6 +263,33 @@ int htkamd_net_build(const char *slfPath, const char *dictPath, const struct htk
    if ((rc = read_dict(dictPath, hmms, &pr, &nPr))) return rc;
    lnode *ln = NULL; larc *la = NULL; int NN = 0, NA = 0;
    if ((rc = read_slf(slfPath, &ln, &NN, &la, &NA))) return rc;
+   return expand_lattice(ln, NN, la, NA, pr, nPr, slfPath, dictPath, out);
+}
+
+/* The alignment network of HVite -a (DoAlignment HVite.c:830): LatticeFromLabels (HNet.c:1516) makes the word-level transcription a
+   linear lattice -- one node per label, `boundary` (HVite -b) added at both ends when given, arcs without LM score -- which is then
+   expanded like any other lattice (all pronunciations of a word in parallel). */
+int htkamd_net_build_words(const char *const *words, int nWords, const char *boundary, const char *dictPath,
+                           const struct htkamd_mmf *hmms, struct htkamd_net **out)
+{
+   if (!words || nWords <= 0 || !dictPath || !hmms || !out) { htkamd_set_error("net_build_words: bad argument"); return HTKAMD_EINVAL; }
+   if (!htkamd_mmf_desc(hmms)) { htkamd_set_error("net_build_words: model set not finished"); return HTKAMD_EINVAL; }
+   dpron *pr = NULL; int nPr = 0, rc;
+   if ((rc = read_dict(dictPath, hmms, &pr, &nPr))) return rc;
+   const int NN = nWords + (boundary ? 2 : 0), NA = NN - 1;
+   lnode *ln = (lnode *)calloc((size_t)NN, sizeof(lnode));
+   larc *la = (larc *)calloc((size_t)(NA ? NA : 1), sizeof(larc));
+   for (int i = 0; i < NN; i++) {
+      const char *w = (boundary && (i == 0 || i == NN - 1)) ? boundary : words[i - (boundary ? 1 : 0)];
+      ln[i].word = strdup(w ? w : "!NULL");
+      if (i > 0) { la[i - 1].s = i - 1; la[i - 1].e = i; la[i - 1].l = 0.0f; }
+   }
+   return expand_lattice(ln, NN, la, NA, pr, nPr, "(transcription)", dictPath, out);
+}
+
+static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, struct htkamd_net **out)
+{
+   int rc;
 
    struct htkamd_net *net = (struct htkamd_net *)calloc(1, sizeof(*net));
    net->pron = pr; net->nPron = nPr;

@@ -338,6 +338,11 @@ typedef struct {
 } htkamd_net_desc;
 typedef struct htkamd_net htkamd_net;
 int  htkamd_net_build(const char *slfPath, const char *dictPath, const htkamd_mmf *hmms, htkamd_net **out);
+/* Alignment network of HVite -a from a word-level transcription: LatticeFromLabels (HNet.c:1516: one node per label, the boundary
+   word of HVite -b at both ends when non-NULL) + the same expansion; decoding it with htkamd_decoder_* is HVite -a (DoAlignment
+   HVite.c:830), word- or model-level (-m) labels. */
+int  htkamd_net_build_words(const char *const *words, int nWords, const char *boundary, const char *dictPath,
+                            const htkamd_mmf *hmms, htkamd_net **out);
 void htkamd_net_destroy(htkamd_net *n);
 const htkamd_net_desc *htkamd_net_get(const htkamd_net *n);
 const char *htkamd_net_out_sym(const htkamd_net *n, int pron);

@@ -19,7 +19,10 @@ def load_decode_case(native, name):
 
 def parse_opts(opts: str) -> dict:
     """HVite switches -> decoder parameters (HVite.c:81-95 defaults: -s 1.0 -p 0.0 -r 1.0, beams off)."""
-    t = [x for x in opts.split() if x != "-m"]
+    t = opts.split()
+    if "-b" in t:                                                # -b word: alignment only (boundary word), not a decoder parameter
+        del t[t.index("-b"):t.index("-b") + 2]
+    t = [x for x in t if x != "-m"]
     p = dict(genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0)
     key = {"-t": "genBeam", "-v": "wordBeam", "-s": "lmScale", "-p": "wordPen", "-r": "prScale"}
     for i in range(0, len(t), 2):
@@ -43,7 +46,9 @@ def format_model_labels(words, lms, align, pron_models, phys_names, out_syms, lm
             ln = "%d %d %s %f" % (align["modStart"][q] * frame_dur, align["modEnd"][q] * frame_dur, phys_names[m], np.float32(align["modScore"][q]))
             if k == 0:
                 aux = np.float32(np.float64(np.float32(np.float32(lm) * np.float32(lmScale))) + np.float64(np.float32(wordPen)))
-                ln += " %s %f" % (out_syms[w], aux)
+                ln += " %s" % out_syms[w]
+                if aux != 0.0:                                       # an auxiliary score of 0.0 is not written (HLabel.c SaveHTKLabels)
+                    ln += " %f" % aux
             lines.append(ln)
             q += 1
     return lines

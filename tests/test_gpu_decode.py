@@ -1,5 +1,7 @@
 """Network decoding on the device (K7, htkamd_decoder_*) against the reference's HVite label files (committed fixtures) and
 against the oracle: word sequences, frame boundaries and printed scores identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -165,3 +167,43 @@ def test_decoder_with_matrix_core_scores(native):
         for (we, te), (wm, tm) in zip(ex, mf):
             assert [w[:3] for w in we] == [w[:3] for w in wm]
             assert np.allclose([w[3] for w in we], [w[3] for w in wm], atol=1e-2) and abs(te - tm) < 5e-2
+
+
+def test_word_level_forced_alignment_with_pronunciation_variants(native):
+    """HVite -a from word-level transcriptions (DoAlignment HVite.c:830): the transcription becomes a linear lattice
+    (LatticeFromLabels, with the -b boundary word when given), every pronunciation of a word is a parallel branch, token passing
+    picks the variant; word-level and model-level (-m) label files against the reference's (make_align_golden.py)."""
+    import json
+    from decode_util import GOLD, format_model_labels, format_words, parse_opts
+    from util import batch_arrays
+    src, d = os.path.join(GOLD, "bigram"), os.path.join(GOLD, "align")
+    mmf = native.Mmf(files=[os.path.join(src, "MMF")], hmm_list=os.path.join(src, "hmmlist"))
+    model = native.Model(mmf.packed())
+    z = np.load(os.path.join(d, "feats.npz"))
+    feats = [z["u%d" % u] for u in range(len(z.files))]
+    trans = json.load(open(os.path.join(d, "words.json")))
+    expected = json.load(open(os.path.join(d, "expected.json")))
+    n = variants = 0
+    for opts, per in expected.items():
+        p = parse_opts(opts)
+        t = opts.split()
+        bnd = t[t.index("-b") + 1] if "-b" in t else None
+        for u, (X, words) in enumerate(zip(feats, trans)):
+            net = native.Net(None, os.path.join(src, "dict"), mmf, words=words, boundary=bnd)
+            dec = native.Decoder(model, net, lmScale=p["lmScale"])
+            (got_words, total), = dec.run([X], **p)
+            assert [net.word_names[w[0]] for w in got_words] == ([bnd] if bnd else []) + words + ([bnd] if bnd else [])
+            variants += sum(1 for w in got_words if net.pron_models[w[0]] == [0, 2])            # AB's second pronunciation
+            if "-m" in t:
+                chain = np.array([m for w in got_words for m in net.pron_models[w[0]]], np.int32)
+                Xb, frameOff, labOff, labs = batch_arrays([dict(seq=chain, feat=X)])
+                dX = native.DevArray(Xb)
+                al = native.Viterbi(model).align(dX.ptr.value, frameOff, labOff, labs, genBeam=p["genBeam"])
+                got = format_model_labels(got_words, dec.last_lm[0], al[0], net.pron_models, mmf.phys_names, net.word_names, p["lmScale"], p["wordPen"])
+            else:
+                got = format_words(got_words, net.out_syms)
+            assert got == per["u%d" % u], (opts, u)
+            n += len(got)
+    assert n > 50 and variants > 0
+    with pytest.raises(native.HtkAmdError):
+        native.Net(None, os.path.join(src, "dict"), mmf, words=["AB", "NOSUCHWORD"])
