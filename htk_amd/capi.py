@@ -491,6 +491,18 @@ def parm_read(path: str):
     return arr, per.value, kind.value
 
 
+WAVE_HTK, WAVE_WAV = 1, 2
+
+
+def wave_read(path: str, fmt: int = WAVE_WAV):
+    """Waveform file -> (int16 samples, sampPeriod in 100 ns units) through the host C reader."""
+    data = C.c_void_p(); n = C.c_long(); per = C.c_double()
+    check(lib().htkamd_wave_read(path.encode(), C.c_int(fmt), C.byref(data), C.byref(n), C.byref(per)), "wave_read")
+    arr = np.ctypeslib.as_array((C.c_short * max(n.value, 1)).from_address(data.value))[:n.value].copy()
+    lib().htkamd_free(data)
+    return arr, per.value
+
+
 def parm_write(path: str, X: np.ndarray, sampPeriod: int, kind: int, withCrc: bool = False):
     X = np.ascontiguousarray(X, np.float32)
     check(lib().htkamd_parm_write(path.encode(), _p(X), C.c_int(X.shape[0]), C.c_int(X.shape[1]), C.c_int(sampPeriod), C.c_int(kind),

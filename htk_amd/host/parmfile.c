@@ -95,3 +95,65 @@ int htkamd_parm_write(const char *path, const float *data, int nFrames, int nCol
    fclose(f);
    return HTKAMD_OK;
 }
+
+/* ---- waveform files: the sources of the MFCC front end (SOURCEFORMAT = WAV | HTK) ------------------------------------
+ * WAV : RIFF/WAVE little-endian, chunks walked until "data" as GetWAVHeaderInfo does (HWave.c:1052-1131); 16-bit PCM mono only
+ *       (the reference also converts 8-bit, mu/a-law and stereo: rejected here), sampPeriod = 1e7 / rate in 100 ns units.
+ * HTK : 12-byte big-endian header {nSamples, sampPeriod, sampSize = 2, kind = WAVEFORM (0)} + big-endian shorts
+ *       (GetHTKHeaderInfo HWave.c:1408 ff.).
+ * *samples is malloc'd (release with htkamd_free). */
+static unsigned le32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((unsigned)p[3] << 24); }
+static unsigned le16(const unsigned char *p) { return p[0] | (p[1] << 8); }
+
+int htkamd_wave_read(const char *path, int format, short **samples, long *nSamples, double *sampPeriod)
+{
+   if (!path || !samples || !nSamples) { htkamd_set_error("wave_read: NULL argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "rb");
+   if (!f) { htkamd_set_error("wave_read: cannot open %s", path); return HTKAMD_EIO; }
+   unsigned char h[16];
+   short *out = NULL; long n = 0; double per = 0.0;
+   if (format == HTKAMD_WAVE_HTK) {
+      if (fread(h, 1, 12, f) != 12) { fclose(f); htkamd_set_error("wave_read: %s: short header", path); return HTKAMD_EINVAL; }
+      const long ns = (long)((h[0] << 24) | (h[1] << 16) | (h[2] << 8) | h[3]);
+      const long sp = (long)((h[4] << 24) | (h[5] << 16) | (h[6] << 8) | h[7]);
+      const int size = (h[8] << 8) | h[9], kind = (h[10] << 8) | h[11];
+      if ((kind & 077) != 0 || size != 2 || ns < 0) { fclose(f); htkamd_set_error("wave_read: %s is not an HTK WAVEFORM file (kind %o, sample size %d)", path, kind, size); return HTKAMD_EINVAL; }
+      out = (short *)malloc(sizeof(short) * (size_t)(ns ? ns : 1));
+      unsigned char *raw = (unsigned char *)malloc((size_t)(ns ? ns : 1) * 2);
+      if (fread(raw, 2, (size_t)ns, f) != (size_t)ns) { free(raw); free(out); fclose(f); htkamd_set_error("wave_read: %s: file shorter than its header says", path); return HTKAMD_EINVAL; }
+      for (long i = 0; i < ns; i++) out[i] = (short)((raw[2 * i] << 8) | raw[2 * i + 1]);
+      free(raw); n = ns; per = (double)sp;
+   } else if (format == HTKAMD_WAVE_WAV) {
+      if (fread(h, 1, 12, f) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) { fclose(f); htkamd_set_error("wave_read: %s is not a RIFF/WAVE file", path); return HTKAMD_EINVAL; }
+      int gotFmt = 0;
+      for (;;) {
+         if (fread(h, 1, 8, f) != 8) { fclose(f); htkamd_set_error("wave_read: %s: no data chunk", path); return HTKAMD_EINVAL; }
+         unsigned len = le32(h + 4);
+         if (!memcmp(h, "data", 4)) {
+            if (!gotFmt) { fclose(f); htkamd_set_error("wave_read: %s: data chunk before fmt chunk", path); return HTKAMD_EINVAL; }
+            n = (long)(len / 2);
+            out = (short *)malloc(sizeof(short) * (size_t)(n ? n : 1));
+            unsigned char *raw = (unsigned char *)malloc((size_t)(n ? n : 1) * 2);
+            if (fread(raw, 2, (size_t)n, f) != (size_t)n) { free(raw); free(out); fclose(f); htkamd_set_error("wave_read: %s: data chunk shorter than its length field", path); return HTKAMD_EINVAL; }
+            for (long i = 0; i < n; i++) out[i] = (short)le16(raw + 2 * i);
+            free(raw);
+            break;
+         }
+         if (!memcmp(h, "fmt ", 4)) {
+            unsigned char fm[16];
+            if (len < 16 || fread(fm, 1, 16, f) != 16) { fclose(f); htkamd_set_error("wave_read: %s: bad fmt chunk", path); return HTKAMD_EINVAL; }
+            const unsigned type = le16(fm), chans = le16(fm + 2), rate = le32(fm + 4), bits = le16(fm + 14);
+            if (type != 1 || chans != 1 || bits != 16 || rate == 0) {
+               fclose(f); htkamd_set_error("wave_read: %s: only 16-bit mono PCM is supported (format %u, %u channels, %u bits)", path, type, chans, bits); return HTKAMD_EINVAL;
+            }
+            per = (double)(1.0E7f / (float)rate);                   /* w->sampPeriod = 1.0E7 / (float)lng (HWave.c:1107) */
+            gotFmt = 1; len -= 16;
+         }
+         if (len && fseek(f, (long)len, SEEK_CUR)) { fclose(f); htkamd_set_error("wave_read: %s: truncated chunk", path); return HTKAMD_EINVAL; }
+      }
+   } else { fclose(f); htkamd_set_error("wave_read: unknown format %d", format); return HTKAMD_EINVAL; }
+   fclose(f);
+   *samples = out; *nSamples = n;
+   if (sampPeriod) *sampPeriod = per;
+   return HTKAMD_OK;
+}

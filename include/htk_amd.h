@@ -205,6 +205,11 @@ int  htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream)
 int  htkamd_parm_read(const char *path, float **data, int *nFrames, int *nCols, int *sampPeriod, int *kind);
 int  htkamd_parm_write(const char *path, const float *data, int nFrames, int nCols, int sampPeriod, int kind, int withCrc);
 void htkamd_free(void *p);
+/* Waveform files, the sources of the MFCC front end: SOURCEFORMAT = WAV (RIFF 16-bit mono PCM, GetWAVHeaderInfo HWave.c:1052) or
+ * HTK (big-endian WAVEFORM file).  *samples is malloc'd (htkamd_free); *sampPeriod in 100 ns units (625 at 16 kHz). */
+#define HTKAMD_WAVE_HTK 1
+#define HTKAMD_WAVE_WAV 2
+int  htkamd_wave_read(const char *path, int format, short **samples, long *nSamples, double *sampPeriod);
 
 /* Accumulator files (HERN.acc) for exchanging statistics with the reference's parallel mode: DumpAccs
  * (HTrain.c:1453) + trailer (HERest.c:546-548) and LoadAccs (HTrain.c:1625; adds).  Pure host functions on the
