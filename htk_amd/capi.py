@@ -481,6 +481,13 @@ def accs_load_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UP
     check(lib().htkamd_accs_load_file(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), path.encode()), "accs_load_file")
 
 
+def stats_write_file(pk: dict, vec: np.ndarray, names, path: str):
+    """HERest -s: state occupation statistics file (htkamd_stats_write_file)."""
+    d, keep = _desc_from_packed(pk)
+    vec = np.ascontiguousarray(vec, np.float64)
+    check(lib().htkamd_stats_write_file(C.byref(d), _p(vec), _names_array(names), path.encode()), "stats_write_file")
+
+
 def parm_read(path: str):
     """HTK parameter file -> (float32 [T, cols], sampPeriod, kind) through the host C reader (handles _C and _K)."""
     data = C.c_void_p(); T = C.c_int(); cols = C.c_int(); per = C.c_int(); kind = C.c_int()

@@ -180,3 +180,31 @@ int htkamd_accs_load_file(const htkamd_model_desc *d, double *vec, const char *c
    fclose(f);
    return rc;
 }
+
+/* HERest -s: the state occupation statistics file HHEd's clustering commands read (StatReport / PrintStats, HERest.c:708-747):
+   one line per physical HMM in HMM-scan order, "%4d %14s %4d " index, quoted name (ReWriteString with double quotes), number of
+   training examples, then " %10f" with the occupation count of every emitting state (the state's WtAcc occ, a float). */
+int htkamd_stats_write_file(const htkamd_model_desc *d, const double *vec, const char *const *names, const char *path)
+{
+   if (!d || !vec || !names || !path) { htkamd_set_error("stats_write_file: NULL argument"); return HTKAMD_EINVAL; }
+   htkamd_accs_layout lay;
+   int rc = htkamd_accs_layout_from_desc(d, &lay);
+   if (rc) return rc;
+   FILE *f = fopen(path, "w");
+   if (!f) { htkamd_set_error("stats_write_file: cannot create %s", path); return HTKAMD_EIO; }
+   int *order = (int *)malloc(sizeof(int) * (size_t)(d->numPhys ? d->numPhys : 1));
+   htkamd_hmm_scan_order(names, d->numPhys, order);
+   for (int k = 0; k < d->numPhys; k++) {
+      const int h = order[k], N = d->transN[d->hmmTrans[h]];
+      char buf[1024]; int n = 0;
+      buf[n++] = '"';
+      for (const char *p = names[h]; *p && n < 1000; p++) { if (*p == '"' || *p == '\\') buf[n++] = '\\'; buf[n++] = *p; }
+      buf[n++] = '"'; buf[n] = 0;
+      fprintf(f, "%4d %14s %4d ", k + 1, buf, (int)(vec[lay.nEgs + h] + 0.5));
+      for (int j = 0; j < N - 2; j++) fprintf(f, " %10f", (float)vec[lay.wtOcc + d->hmmState[d->hmmStateOff[h] + j]]);
+      fprintf(f, "\n");
+   }
+   free(order);
+   fclose(f);
+   return HTKAMD_OK;
+}

@@ -219,6 +219,9 @@ int htkamd_accs_layout_from_desc(const htkamd_model_desc *d, htkamd_accs_layout 
 int htkamd_hmm_scan_order(const char *const *names, int H, int *order);
 int htkamd_accs_dump_file(const htkamd_model_desc *d, const double *hostVec, const char *const *names, int uFlags, const char *path);
 int htkamd_accs_load_file(const htkamd_model_desc *d, double *hostVec, const char *const *names, int uFlags, const char *path);
+/* HERest -s file: per physical HMM (scan order) its index, quoted name, example count and the occupation of each emitting
+ * state -- StatReport / PrintStats (HERest.c:708-747), the input of HHEd's RO / TB / TC commands. */
+int htkamd_stats_write_file(const htkamd_model_desc *d, const double *hostVec, const char *const *names, const char *path);
 
 /* ------------------------------------------------------------------------------------------
  * Model update after a pass: UpdateModels (HERest.c:1326) -> MLUpdateModels (HERest.c:1262) with

@@ -36,7 +36,7 @@ if __name__ == "__main__":
                 f.write(proto.replace('~h "S"', '~h "%s"' % n))
         os.makedirs(os.path.join(d, "hmm1"))
         log = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "HERest"), "-C", cfg, "-H", os.path.join(OUT, "flat_hmm0.mmf"), "-M", os.path.join(d, "hmm1"),
-                              "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", "-T", "1", os.path.join(DEMO, "bcplist")] +
+                              "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", "-T", "1", "-s", os.path.join(OUT, "flat_stats"), os.path.join(DEMO, "bcplist")] +
                              sorted(glob.glob(os.path.join(DEMO, "train", "tr*.mfc"))), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
         shutil.copy(os.path.join(d, "hmm1", "flat_hmm0.mmf"), os.path.join(OUT, "flat_hmm1_expected.mmf"))
         keep = [l for l in log.splitlines() if "average log prob" in l or "floored variance" in l]

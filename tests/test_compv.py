@@ -95,6 +95,17 @@ def test_flat_start_pass_matches_reference(native, oracle):
     log = open(os.path.join(GOLD, "compv", "flat_herest.log")).read()
     ref_avg = float(re.search(r"average log prob per frame = (\S+)", log).group(1))
     assert (st == 1).all() and "%e" % (a["totalPr"] / a["totalT"]) == "%e" % ref_avg
+    # HERest -s: the occupation statistics file (index, name, examples, occupation of each emitting state)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        native.stats_write_file(pk, a["vec"], mmf.phys_names, os.path.join(d, "stats"))
+        ours = [l.split() for l in open(os.path.join(d, "stats"))]
+        raw = open(os.path.join(d, "stats")).read()
+    theirs = [l.split() for l in open(os.path.join(GOLD, "compv", "flat_stats"))]
+    assert len(ours) == len(theirs) == 5 and raw.startswith('   1 ')
+    for o, t in zip(ours, theirs):
+        assert o[:3] == t[:3] and len(o) == len(t) == 6
+        assert np.allclose([float(x) for x in o[3:]], [float(x) for x in t[3:]], rtol=1e-4)
     model.update(acc, a["vec"], minEgs=3, varFloor=mmf.var_floor)
     rmmf = native.Mmf(files=[os.path.join(GOLD, "compv", "flat_hmm1_expected.mmf")], hmm_list=os.path.join(demo, "bcplist"))
     ref = rmmf.packed()
