@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HIP path against the oracle (run on the GPU box; not part of the test-suite because of its
 run time): forward-backward (pr, beams, accumulators) with random topologies / pruning / ragged batches, forced alignment
-with random beams, network decoding over random word networks.   python tools/fuzz_parity.py [iterations] [seed]"""
+with random beams, network decoding over random word networks.   python tests/fuzz_parity.py [iterations] [seed]"""
 import os
 import sys
 import tempfile
@@ -8,7 +8,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.join(os.path.dirname(__file__), "..")
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from htk_amd import capi, synth  # noqa: E402
 import pyoracle  # noqa: E402
 from util import batch_arrays  # noqa: E402

@@ -1,6 +1,6 @@
 """Throughput of the device front end at BASELINE config[4]: 16 kHz mono PCM, 25 ms / 10 ms, 26 channels, 12 cepstra,
 MFCC_0_D_A, 3-second utterances (298 frames).  Waveforms resident on the device; time = htkamd_mfcc_compute only.
-Next to it: the oracle (C restatement of HSigP/HParm, bit-equal to HCopy) on one host core.
+(The CPU side of the comparison -- the reference's HCopy on one core -- is measured separately; tools never touch oracle/.)
 Run on the GPU box: python tools/mfcc_bench.py [nUtt]"""
 import ctypes as C
 import os
@@ -10,7 +10,6 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
 from htk_amd import capi  # noqa: E402
 
 
@@ -37,16 +36,6 @@ def main():
         dt = time.perf_counter() - t0
         print("GPU run %d: %d utterances, %d frames in %.2f ms = %.2f M frames/s, %.2f GB/s of PCM, %.0f x real time"
               % (rep, nU, frames, dt * 1e3, frames / dt / 1e6, allw.nbytes / dt / 1e9, nU * 3.0 / dt))
-    try:
-        import pyoracle
-        ocfg = pyoracle.mfcc_cfg("MFCC_0_D_A")
-        t0 = time.perf_counter(); k = 0
-        while time.perf_counter() - t0 < 5.0:
-            pyoracle.mfcc(waves[k % 8], ocfg); k += 1
-        dt = time.perf_counter() - t0
-        print("CPU oracle (1 core): %d utterances in %.1f s = %.3f M frames/s, %.0f x real time" % (k, dt, k * 298 / dt / 1e6, k * 3.0 / dt))
-    except Exception as e:  # the oracle is optional here
-        print("oracle leg skipped:", e)
 
 
 if __name__ == "__main__":
