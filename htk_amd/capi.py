@@ -543,17 +543,18 @@ def write_vfloors(path: str, var: np.ndarray, scale: float):
 
 
 class ParmQuals(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nStat", "nZeroMean", "hasD", "hasA", "hasT", "delWin", "accWin", "thirdWin", "nullECol")]
+    _fields_ = [(n, C.c_int) for n in ("nStat", "nZeroMean", "hasD", "hasA", "hasT", "delWin", "accWin", "thirdWin", "nullECol",
+                                       "v1Compat", "simpleDiffs")]
 
 
-def parm_quals_from_kind(kind: str, nStat: int, delWin=2, accWin=2, thirdWin=2) -> ParmQuals:
+def parm_quals_from_kind(kind: str, nStat: int, delWin=2, accWin=2, thirdWin=2, v1Compat=False, simpleDiffs=False) -> ParmQuals:
     """Qualifier step for tables of base kind + _0/_E statics (`nStat` columns) read with TARGETKIND = `kind`, e.g. "MFCC_E_D_A_N"."""
     q = kind.upper().split("_")[1:]
     nE = int("E" in q) + int("0" in q)
     base = nStat - nE
     nZ = (base + int("0" in q and "N" not in q)) if "Z" in q else 0            # HParm.c:1712-1715
     null = base if ("N" in q and nE) else -1                                   # the column after the base coefficients
-    return ParmQuals(nStat, nZ, int("D" in q), int("A" in q), int("T" in q), delWin, accWin, thirdWin, null)
+    return ParmQuals(nStat, nZ, int("D" in q), int("A" in q), int("T" in q), delWin, accWin, thirdWin, null, int(v1Compat), int(simpleDiffs))
 
 
 def parm_qualify(stat_list, quals: ParmQuals):

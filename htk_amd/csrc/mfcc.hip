@@ -192,12 +192,23 @@ __global__ void k_mfcc_enorm(float *out, const int *frameOff, int nCols, int col
 }
 
 // Regress (HSigP.c:827-856) on a whole table: out[t][ti+k] = sum_tau tau*(c[min(t+tau,last)] - c[max(t-tau,first)]) / (2 sum tau^2)
-__global__ void k_mfcc_delta(float *out, const int *frameUtt, const int *frameOff, int nFrames, int nCols, int si, int ti, int d, int win)
+// mode bit 0: SIMPLEDIFFS = (c[t+w] - c[t-w]) / 2w (HSigP.c:848); bit 1: V1COMPAT = the first / last w rows of a table longer than 2w
+// rows are forward / backward differences (AddHeadRegress / AddTailRegress with delwin 0, HSigP.c:866-908)
+__global__ void k_mfcc_delta(float *out, const int *frameUtt, const int *frameOff, int nFrames, int nCols, int si, int ti, int d, int win, int mode = 0)
 {
    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= (size_t)nFrames * d) return;
    const int f = (int)(g / d), k = (int)(g % d);
    const int u = frameUtt[f], f0 = frameOff[u], f1 = frameOff[u + 1] - 1;
+   if ((mode & 2) && (f1 - f0 + 1) - 2 * win > 0) {
+      if (f - f0 < win) { out[(size_t)f * nCols + ti + k] = out[(size_t)(f + 1) * nCols + si + k] - out[(size_t)f * nCols + si + k]; return; }
+      if (f1 - f < win) { out[(size_t)f * nCols + ti + k] = out[(size_t)f * nCols + si + k] - out[(size_t)(f - 1) * nCols + si + k]; return; }
+   }
+   if (mode & 1) {
+      const int fb = (f - win < f0) ? f0 : f - win, ff = (f + win > f1) ? f1 : f + win;
+      out[(size_t)f * nCols + ti + k] = (out[(size_t)ff * nCols + si + k] - out[(size_t)fb * nCols + si + k]) / (2 * win);
+      return;
+   }
    float sigmaT2 = 0.0f;
    for (int t = 1; t <= win; t++) sigmaT2 += t * t;
    sigmaT2 *= 2.0;
@@ -399,9 +410,10 @@ extern "C" int htkamd_parm_qualify(const float *dStatic, const int *frameOff, in
    const size_t n = (size_t)F * nStat;
    const unsigned blocks = (unsigned)((n + 255) / 256);
    hipLaunchKernelGGL(k_parm_widen, dim3(blocks), dim3(256), 0, s, dStatic, dFull, (size_t)F, nStat, nFull);
-   if (q->hasD) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, 0, nStat, nStat, q->delWin);
-   if (q->hasA) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, nStat, 2 * nStat, nStat, q->accWin);
-   if (q->hasT) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, 2 * nStat, 3 * nStat, nStat, q->thirdWin);
+   const int mode = (q->simpleDiffs ? 1 : 0) | (q->v1Compat ? 2 : 0);
+   if (q->hasD) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, 0, nStat, nStat, q->delWin, mode);
+   if (q->hasA) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, nStat, 2 * nStat, nStat, q->accWin, mode);
+   if (q->hasT) hipLaunchKernelGGL(k_mfcc_delta, dim3(blocks), dim3(256), 0, s, dFull, dUtt, dOff, F, nFull, 2 * nStat, 3 * nStat, nStat, q->thirdWin, mode);
    if (q->nZeroMean > 0)
       hipLaunchKernelGGL(k_mfcc_zmean, dim3((nUtt * q->nZeroMean + 63) / 64), dim3(64), 0, s, dFull, dOff, nUtt, nFull, q->nZeroMean);
    if (q->nullECol >= 0) {
@@ -421,7 +433,7 @@ extern "C" int htkamd_parm_add_qualifiers(const float *dStatic, const int *frame
 {
    if (nStat <= 0 || (hasA && !hasD) || delWin < 1 || accWin < 1) { htkamd_set_error("parm_add_qualifiers: bad argument"); return HTKAMD_EINVAL; }
    htkamd_parm_quals q;
-   q.nStat = nStat; q.nZeroMean = 0; q.hasD = hasD; q.hasA = hasA; q.hasT = 0; q.delWin = delWin; q.accWin = accWin; q.thirdWin = 2; q.nullECol = -1;
+   q.nStat = nStat; q.nZeroMean = 0; q.hasD = hasD; q.hasA = hasA; q.hasT = 0; q.delWin = delWin; q.accWin = accWin; q.thirdWin = 2; q.nullECol = -1; q.v1Compat = 0; q.simpleDiffs = 0;
    return htkamd_parm_qualify(dStatic, frameOff, nUtt, &q, dOut, stream);
 }
 

@@ -428,6 +428,7 @@ typedef struct {
    int hasD, hasA, hasT;            /* _D _A _T                                                */
    int delWin, accWin, thirdWin;    /* DELTAWINDOW ACCWINDOW THIRDWINDOW                       */
    int nullECol;                    /* _N: column left out of every row (-1 = none)            */
+   int v1Compat, simpleDiffs;       /* V1COMPAT (edge rows = plain differences), SIMPLEDIFFS    */
 } htkamd_parm_quals;
 int  htkamd_parm_quals_cols(const htkamd_parm_quals *q);
 int  htkamd_parm_qualify(const float *dStatic, const int *frameOff, int nUtt, const htkamd_parm_quals *q, float *dOut, void *stream);

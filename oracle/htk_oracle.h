@@ -142,6 +142,8 @@ int orc_mfcc_frames(int nSamples, const orc_mfcc_cfg *c, int *frSize, int *frRat
 int orc_mfcc_cols(const orc_mfcc_cfg *c);
 int orc_mfcc(const short *wav, int nSamples, const orc_mfcc_cfg *c, float *out);
 int orc_add_qualifiers(const float *stat, int T, int nStat, int hasD, int hasA, int delWin, int accWin, float *out);
+int orc_parm_qualify2(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
+                      int delWin, int accWin, int thirdWin, int nullECol, int v1Compat, int simpleDiffs, float *out);
 void orc_compv(const float *X, long T, int D, float minVar, float *mean, float *var);
 int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
                      int delWin, int accWin, int thirdWin, int nullECol, float *out);

@@ -305,21 +305,71 @@ int orc_add_qualifiers(const float *stat, int T, int nStat, int hasD, int hasA, 
    return nCols;
 }
 
+/* AddDiffs with the two variants of the difference computation (HParm.c:1552-1598): SIMPLEDIFFS = (c[t+w] - c[t-w]) / 2w with
+   the same edge replication (Regress, HSigP.c:846-849), V1COMPAT = the first / last w rows are plain forward / backward
+   differences (AddHeadRegress / AddTailRegress with delwin 0, HSigP.c:866-908); tables shorter than 2w+1 rows take the one-call
+   regression in either case (HParm.c:1566-1573). */
+static void regress_simple(float *data, int vSize, int n, int step, int offset, int delwin, int head, int tail)
+{
+   float *fp = data, *fp1, *fp2, *back, *forw;
+   int i, t, j;
+   for (i = 1; i <= n; i++) {
+      fp1 = fp; fp2 = fp + offset;
+      for (j = 1; j <= vSize; j++) {
+         back = forw = fp1;
+         for (t = 1; t <= delwin; t++) {
+            if (head + i - t > 0) back -= step;
+            if (tail + n - i + 1 - t > 0) forw += step;
+         }
+         *fp2 = (*forw - *back) / (2 * delwin);
+         ++fp1; ++fp2;
+      }
+      fp += step;
+   }
+}
+
+static void add_diffs_mode(float *data, int nRows, int nCols, int si, int ti, int d, int winSize, int v1Compat, int simpleDiffs)
+{
+   float *p = data + si;
+   int offset = ti - si, head = winSize, tail = winSize, n = nRows - (head + tail), i, j;
+   if (!v1Compat && !simpleDiffs) { add_diffs(data, nRows, nCols, si, ti, d, winSize); return; }
+#define REG(pp, nn, hh, tt) do { if (simpleDiffs) regress_simple(pp, d, nn, nCols, offset, winSize, hh, tt); else regress(pp, d, nn, nCols, offset, winSize, hh, tt); } while (0)
+   if (n <= 0) { REG(p, nRows, 0, 0); return; }
+   if (v1Compat) {
+      for (i = 0; i < head; i++) for (j = 0; j < d; j++) p[i * nCols + j + offset] = p[(i + 1) * nCols + j] - p[i * nCols + j];
+   } else REG(p, head, 0, winSize);
+   p += head * nCols;
+   REG(p, n, winSize, winSize);
+   p += n * nCols;
+   if (v1Compat) {
+      for (i = 0; i < tail; i++) for (j = 0; j < d; j++) p[i * nCols + j + offset] = p[i * nCols + j] - p[(i - 1) * nCols + j];
+   } else REG(p, tail, winSize, 0);
+#undef REG
+}
+
 /* The remaining qualifiers of AddQualifiers on a table: third differentials (HParm.c:1675-1681, regression of the
    accelerations over THIRDWINDOW), _Z after the differentials (HParm.c:1700-1726: FZeroMean over the first nZeroMean
    columns), and _N (the absolute energy / C0 column nullECol is left out when the row is handed out as an observation,
    ExtractObservation HParm.c:2882-2893).  out holds nStat*(1+D+A+T) - (nullECol >= 0) columns; returns that number. */
+int orc_parm_qualify2(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
+                      int delWin, int accWin, int thirdWin, int nullECol, int v1Compat, int simpleDiffs, float *out);
 int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
                      int delWin, int accWin, int thirdWin, int nullECol, float *out)
+{
+   return orc_parm_qualify2(stat, T, nStat, nZeroMean, hasD, hasA, hasT, delWin, accWin, thirdWin, nullECol, 0, 0, out);
+}
+
+int orc_parm_qualify2(const float *stat, int T, int nStat, int nZeroMean, int hasD, int hasA, int hasT,
+                      int delWin, int accWin, int thirdWin, int nullECol, int v1Compat, int simpleDiffs, float *out)
 {
    int nFull = nStat * (1 + (hasD ? 1 : 0) + (hasA ? 1 : 0) + (hasT ? 1 : 0)), nCols = nFull - (nullECol >= 0 ? 1 : 0), t, k, i, j;
    float *full = (nullECol >= 0) ? (float *)malloc(sizeof(float) * (size_t)(T ? T : 1) * nFull) : out;
    for (t = 0; t < T; t++)
       for (k = 0; k < nStat; k++) full[(size_t)t * nFull + k] = stat[(size_t)t * nStat + k];
    if (T > 0) {
-      if (hasD) add_diffs(full, T, nFull, 0, nStat, nStat, delWin);
-      if (hasA) add_diffs(full, T, nFull, nStat, 2 * nStat, nStat, accWin);
-      if (hasT) add_diffs(full, T, nFull, 2 * nStat, 3 * nStat, nStat, thirdWin);
+      if (hasD) add_diffs_mode(full, T, nFull, 0, nStat, nStat, delWin, v1Compat, simpleDiffs);
+      if (hasA) add_diffs_mode(full, T, nFull, nStat, 2 * nStat, nStat, accWin, v1Compat, simpleDiffs);
+      if (hasT) add_diffs_mode(full, T, nFull, 2 * nStat, 3 * nStat, nStat, thirdWin, v1Compat, simpleDiffs);
       for (i = 0; i < nZeroMean; i++) {                                              /* FZeroMean HSigP.c:803 */
          double sum = 0.0; float mean, *fp = full + i;
          for (j = 0; j < T; j++) { sum += *fp; fp += nFull; }

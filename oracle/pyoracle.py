@@ -263,14 +263,15 @@ def compv(X: np.ndarray, minVar=0.0):
     return mean, var
 
 
-def parm_qualify(stat: np.ndarray, nZeroMean=0, hasD=True, hasA=False, hasT=False, delWin=2, accWin=2, thirdWin=2, nullECol=-1) -> np.ndarray:
+def parm_qualify(stat: np.ndarray, nZeroMean=0, hasD=True, hasA=False, hasT=False, delWin=2, accWin=2, thirdWin=2, nullECol=-1,
+                 v1Compat=False, simpleDiffs=False) -> np.ndarray:
     """AddQualifiers incl. third differentials and _Z on a table, then the _N column drop of ExtractObservation."""
     stat = np.ascontiguousarray(stat, np.float32)
     T, n = stat.shape
     cols = n * (1 + int(hasD) + int(hasA) + int(hasT)) - int(nullECol >= 0)
     out = np.zeros((T, cols), np.float32)
-    got = lib().orc_parm_qualify(_p(stat), C.c_int(T), C.c_int(n), C.c_int(nZeroMean), C.c_int(hasD), C.c_int(hasA), C.c_int(hasT),
-                                 C.c_int(delWin), C.c_int(accWin), C.c_int(thirdWin), C.c_int(nullECol), _p(out))
+    got = lib().orc_parm_qualify2(_p(stat), C.c_int(T), C.c_int(n), C.c_int(nZeroMean), C.c_int(hasD), C.c_int(hasA), C.c_int(hasT),
+                                  C.c_int(delWin), C.c_int(accWin), C.c_int(thirdWin), C.c_int(nullECol), C.c_int(v1Compat), C.c_int(simpleDiffs), _p(out))
     assert got == cols
     return out
 

@@ -22,6 +22,10 @@ if __name__ == "__main__":
             cfg = os.path.join(d, "cfg")
             open(cfg, "w").write("TARGETKIND = %s\nTHIRDWINDOW = 3\n" % kind)
             subprocess.check_call([os.path.join(REF, "HCopy"), "-C", cfg, SRC, os.path.join(OUT, "tr1_%s.mfc" % kind)])
+        for tag, extra in (("V1", "V1COMPAT = T\n"), ("SD", "SIMPLEDIFFS = T\n")):      # the two variants of the difference computation
+            cfg = os.path.join(d, "cfg" + tag)
+            open(cfg, "w").write("TARGETKIND = MFCC_E_D_A\nDELTAWINDOW = 3\n" + extra)
+            subprocess.check_call([os.path.join(REF, "HCopy"), "-C", cfg, SRC, os.path.join(OUT, "tr1_MFCC_E_D_A_%s.mfc" % tag)])
         cfg = os.path.join(d, "cfgN")
         open(cfg, "w").write("TARGETKIND = MFCC_E_D_A_N\n")
         txt = subprocess.check_output([os.path.join(REF, "HList"), "-C", cfg, "-o", "-h", "-e", "39", SRC]).decode()

@@ -24,7 +24,9 @@ def stat():
 
 CASES = [("MFCC_E_D_A_T", dict(hasD=True, hasA=True, hasT=True, thirdWin=3)),
          ("MFCC_E_D_A_T_Z", dict(hasD=True, hasA=True, hasT=True, thirdWin=3, nZeroMean=12)),
-         ("MFCC_E_D_Z", dict(hasD=True, nZeroMean=12))]
+         ("MFCC_E_D_Z", dict(hasD=True, nZeroMean=12)),
+         ("MFCC_E_D_A_V1", dict(hasD=True, hasA=True, delWin=3, v1Compat=True)),           # V1COMPAT = T, DELTAWINDOW = 3
+         ("MFCC_E_D_A_SD", dict(hasD=True, hasA=True, delWin=3, simpleDiffs=True))]        # SIMPLEDIFFS = T
 
 
 @pytest.mark.parametrize("kind,kw", CASES)
@@ -87,12 +89,30 @@ def test_device_qualify_bit_exact(native, oracle, stat, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw", [("V1", dict(v1Compat=True)), ("SD", dict(simpleDiffs=True)), ("V1SD", dict(v1Compat=True, simpleDiffs=True))])
+def test_device_difference_variants(native, oracle, stat, tag, kw):
+    """V1COMPAT / SIMPLEDIFFS on the device == oracle bit for bit (ragged batch incl. tables shorter than 2w+1 rows), and == the
+    file HCopy wrote where there is one."""
+    from htk_amd import capi
+    utts = [stat, stat[5:12], stat[40:41], stat[100:106], stat[7:14]]
+    q = capi.parm_quals_from_kind("MFCC_E_D_A", 13, delWin=3, **kw)
+    d, frameOff, cols = capi.parm_qualify(utts, q)
+    got = d.to_host(np.float32, (int(frameOff[-1]), cols))
+    for u, x in enumerate(utts):
+        ref = oracle.parm_qualify(x, hasD=True, hasA=True, delWin=3, **kw)
+        assert np.array_equal(got[frameOff[u]:frameOff[u + 1]], ref), (tag, u)
+    if tag in ("V1", "SD"):
+        ref, _, _ = _read(os.path.join(GOLD, "quals", "tr1_MFCC_E_D_A_%s.mfc" % tag))
+        assert np.array_equal(got[:stat.shape[0]], ref)
+
+
+@pytest.mark.gpu
 def test_device_qualify_rejects(native):
     from htk_amd import capi
     x = [np.zeros((4, 13), np.float32)]
-    for bad in (capi.ParmQuals(13, 0, 0, 1, 0, 2, 2, 2, -1),      # _A without _D
-                capi.ParmQuals(13, 0, 1, 0, 1, 2, 2, 2, -1),      # _T without _A
-                capi.ParmQuals(13, 0, 0, 0, 0, 2, 2, 2, 12),      # _N without _D
-                capi.ParmQuals(13, 14, 1, 0, 0, 2, 2, 2, -1)):    # more zero-mean columns than statics
+    for bad in (capi.ParmQuals(13, 0, 0, 1, 0, 2, 2, 2, -1, 0, 0),      # _A without _D
+                capi.ParmQuals(13, 0, 1, 0, 1, 2, 2, 2, -1, 0, 0),      # _T without _A
+                capi.ParmQuals(13, 0, 0, 0, 0, 2, 2, 2, 12, 0, 0),      # _N without _D
+                capi.ParmQuals(13, 14, 1, 0, 0, 2, 2, 2, -1, 0, 0)):    # more zero-mean columns than statics
         with pytest.raises(capi.HtkAmdError):
             capi.parm_qualify(x, bad)
