@@ -52,7 +52,7 @@ class FbConfig(C.Structure):
 
 class UpdateConfig(C.Structure):
     _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int),
-                ("singleProcess", C.c_int), ("varFloor", C.POINTER(C.c_float))]
+                ("singleProcess", C.c_int), ("varFloor", C.POINTER(C.c_float)), ("rowNormalise", C.c_int)]
 
 
 class UpdateStats(C.Structure):
@@ -151,7 +151,8 @@ class Model:
         check(lib().htkamd_model_get_prepared(self.h, _p(ivar), _p(gc), _p(lw), _p(md)), "model_get_prepared")
         return dict(ivar=ivar, gconst=gc, compLogWt=lw, minDur=md)
 
-    def update(self, accs: "Accs", vec: np.ndarray, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False, varFloor=None):
+    def update(self, accs: "Accs", vec: np.ndarray, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False, varFloor=None,
+               rowNormalise=False):
         """UpdateModels (HERest.c:1326) from a host copy of the (summed) accumulator vector.  varFloor: the ~v "varFloor1" vector."""
         vec = np.ascontiguousarray(vec, np.float64)
         vf = None
@@ -159,7 +160,7 @@ class Model:
             vf = np.ascontiguousarray(varFloor, np.float32)
             assert vf.shape == (self.D,)
         cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess),
-                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None)
+                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise))
         st = UpdateStats()
         check(lib().htkamd_model_update(self.h, accs.h, _p(vec), C.byref(cfg), C.byref(st)), "model_update")
         return {n: getattr(st, n) for n, _ in UpdateStats._fields_}

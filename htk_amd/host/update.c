@@ -54,7 +54,14 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
          float *tp = transP + m->h_transOff[ti];
          for (i = 1; i < N; i++) {
             const float occi = ACCF(lay->trOcc, m->h_trOccOff[ti] + i - 1);
-            if (occi > 0.0)
+            if (occi > 0.0 && cfg->rowNormalise) {       /* HRest's RestTransP (HRest.c:1015-1039): the row is renormalised by its sum */
+               float sum = 0.0, row[N + 1];
+               for (j = 2; j <= N; j++) { row[j - 1] = ACCF(lay->tr, m->h_transOff[ti] + (i - 1) * N + (j - 1)) / occi; sum += row[j - 1]; }
+               for (j = 2; j <= N; j++) {
+                  const float x = row[j - 1] / sum;
+                  tp[(i - 1) * N + (j - 1)] = (x < MINLARG) ? LZERO : log(x);
+               }
+            } else if (occi > 0.0)
                for (j = 2; j <= N; j++) {
                   const float x = ACCF(lay->tr, m->h_transOff[ti] + (i - 1) * N + (j - 1)) / occi;
                   tp[(i - 1) * N + (j - 1)] = (x > MINLARG) ? log(x) : LZERO;

@@ -237,6 +237,8 @@ typedef struct {
    int   singleProcess;     /* 1 = parMode -1: ForceDiagC/ConvExpWt round trips (HERest.c:1336-1339) */
    const float *varFloor;   /* [vecSize] per-component floor = the ~v "varFloor1" macro (SetVFloor HModel.c:3512: when the
                                macro exists it replaces minVar); NULL = minVar everywhere                */
+   int   rowNormalise;      /* 1 = transition rows renormalised by their sum, as the isolated-unit trainer does
+                               (RestTransP HRest.c:1015); 0 = HERest's UpdateTrans                       */
 } htkamd_update_config;
 typedef struct {
    int nFloorVar, nFloorVarMix;      /* "Total %d floored variance elements in %d different mixes"  */

@@ -127,3 +127,44 @@ def test_examples_on_fixture_files(native, tmp_path):
     want = exp["-m -t 250.0 -s 5.0 -p -10.0"]
     lines = [l for l in got[1:] if l and not l.startswith('"') and l != "."]
     assert lines == [l for u in range(len(files)) for l in want["u%d" % u]]
+
+
+@pytest.mark.parametrize("name", list("SCVNL"))
+def test_hrest_isolated_unit_reestimation(native, oracle, name):
+    """The demo's HRest step (HRest -u tmvw -w 3 -v 0.05 -i 10 -l X hmm.0/X -> hmm.1/X) through the library: the tokens of one
+    model as single-model utterances, forward-backward + update iterated like ReEstimateModel.  Per-iteration average log
+    probability against the reference's trace, final model against the file it wrote."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from examples.hrest_model import hrest
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm0"))
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    tables, labels = [], []
+    for f in files:
+        X, _, _ = native.parm_read(os.path.join(DEMO, "train", f))
+        tables.append(oracle.parm_qualify(X, hasD=True))                             # TARGETKIND = MFCC_E_D over the whole file
+        labels.append(native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab"))))
+    ref_lines = [l for l in open(os.path.join(DEMO, "hinit_hrest.log")) if l.startswith("HRest %s: Ave LogProb" % name)]
+    ref = [(float(re.search(r"= +(-?[\d.]+) using", l).group(1)), int(re.search(r"using (\d+) examples", l).group(1))) for l in ref_lines]
+    # the stopping rule |change| < 1e-4 is applied to a float near -600 (spacing 6e-5) whose last bits depend on HRest's own
+    # output-probability rounding: our own stop may come a pass or two earlier or later ...
+    _, own = hrest(native, mmf, name, tables, labels, max_iter=10, min_var=0.05, mix_weight_floor=3 * 1.0e-5)
+    assert abs(len(own) - len(ref)) <= 3, (own, ref)
+    # ... so the numbers are compared pass by pass over the reference's number of passes
+    model, hist = hrest(native, mmf, name, tables, labels, max_iter=len(ref), epsilon=0.0, min_var=0.05, mix_weight_floor=3 * 1.0e-5)
+    assert len(hist) == len(ref), (hist, ref)
+    for (p, n), (rp, rn) in zip(hist, ref):
+        assert n == rn and abs(p - rp) <= 1e-6 * abs(rp), (name, p, rp)
+    # final parameters of this model against hmm.1 (the other four models are untouched: no tokens of theirs in the batch)
+    rmmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm1"))
+    rq, pk, p = rmmf.packed(), mmf.packed(), model.get_params()
+    h, rh = mmf.logical[name], rmmf.logical[name]
+    for s, rs in zip(pk["hmmState"][pk["hmmStateOff"][h]:pk["hmmStateOff"][h + 1]], rq["hmmState"][rq["hmmStateOff"][rh]:rq["hmmStateOff"][rh + 1]]):
+        g, rg = int(pk["compGauss"][pk["stateCompOff"][s]]), int(rq["compGauss"][rq["stateCompOff"][rs]])
+        sigma = np.sqrt(rq["var"][rg])
+        assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-4 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-6).all()
+        assert np.allclose(p["var"][g], rq["var"][rg], rtol=1e-4, atol=1e-7)
+    t, rt = int(pk["hmmTrans"][h]), int(rq["hmmTrans"][rh])
+    N = int(pk["transN"][t])
+    lin = lambda v: np.where(v > -0.5e10, np.exp(v.astype(np.float64)), 0.0)
+    assert np.allclose(lin(p["transP"][pk["transOff"][t]:pk["transOff"][t] + N * N]), lin(rq["transP"][rq["transOff"][rt]:rq["transOff"][rt] + N * N]), rtol=1e-4, atol=1e-7)
