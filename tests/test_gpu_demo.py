@@ -168,3 +168,95 @@ def test_hrest_isolated_unit_reestimation(native, oracle, name):
     N = int(pk["transN"][t])
     lin = lambda v: np.where(v > -0.5e10, np.exp(v.astype(np.float64)), 0.0)
     assert np.allclose(lin(p["transP"][pk["transOff"][t]:pk["transOff"][t] + N * N]), lin(rq["transP"][rq["transOff"][rt]:rq["transOff"][rt] + N * N]), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", list("SCVNL"))
+def test_hinit_viterbi_training(native, oracle, name):
+    """The demo's HInit step (HInit -i 10 -l X -o X proto/X -> hmm.0/X): uniform segmentation, then Viterbi alignment on the
+    device (the batch alignment kernel, one single-model utterance per token) and re-estimation from the aligned frames, pass
+    by pass against the reference's trace ("Iteration k: Average LogP") and the model it wrote."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from examples.hinit_model import hinit
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "proto"))
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    tables, labels = [], []
+    for f in files:
+        X, _, _ = native.parm_read(os.path.join(DEMO, "train", f))
+        tables.append(oracle.parm_qualify(X, hasD=True))
+        labels.append(native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab"))))
+    pk, model, hist, converged = hinit(native, mmf, name, tables, labels, max_iter=10)
+    lines = [l for l in open(os.path.join(DEMO, "hinit_hrest.log")) if l.startswith("HInit %s:" % name)]
+    ref = [float(re.search(r"Average LogP = *(-?[\d.]+)", l).group(1)) for l in lines if "Average LogP" in l]
+    assert len(hist) == len(ref), (hist, ref)
+    for p, rp in zip(hist, ref):
+        assert abs(p - rp) <= 1e-6 * abs(rp), (name, hist, ref)
+    assert converged == any("converged" in l for l in lines)
+    rmmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm0"))
+    rq, p = rmmf.packed(), model.get_params()
+    q0 = mmf.packed()
+    h, rh = mmf.logical[name], rmmf.logical[name]
+    for s, rs in zip(q0["hmmState"][q0["hmmStateOff"][h]:q0["hmmStateOff"][h + 1]], rq["hmmState"][rq["hmmStateOff"][rh]:rq["hmmStateOff"][rh + 1]]):
+        g, rg = int(q0["compGauss"][q0["stateCompOff"][s]]), int(rq["compGauss"][rq["stateCompOff"][rs]])
+        sigma = np.sqrt(rq["var"][rg])
+        assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-4 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-6).all()
+        assert np.allclose(p["var"][g], rq["var"][rg], rtol=1e-4, atol=1e-7)
+    t, rt = int(q0["hmmTrans"][h]), int(rq["hmmTrans"][rh])
+    N = int(q0["transN"][t])
+    lin = lambda v: np.where(v > -0.5e10, np.exp(v.astype(np.float64)), 0.0)
+    assert np.allclose(lin(p["transP"][q0["transOff"][t]:q0["transOff"][t] + N * N]), lin(rq["transP"][rq["transOff"][rt]:rq["transOff"][rt] + N * N]), rtol=1e-4, atol=1e-7)
+
+
+def test_htkdemo_training_chain_from_prototypes(native, oracle, tmp_path):
+    """The whole training side of HTKDemo's monPlainM1S1 on the device, each stage fed by the previous one's OUTPUT FILES:
+    prototypes -> HInit (Viterbi training per model) -> HRest (Baum-Welch per model) -> one embedded HERest pass; the result
+    against the models the reference's own chain wrote (hmm2_expected).  The stages' own parity is tested above at 1e-4; the
+    chain's differences add up, so the bar here is 1e-3."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from examples.hinit_model import hinit
+    from examples.hrest_model import hrest
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    stat = [native.parm_read(os.path.join(DEMO, "train", f))[0] for f in files]
+    tables = [oracle.parm_qualify(X, hasD=True) for X in stat]
+    labels = [native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab"))) for f in files]
+    d0, d1 = tmp_path / "hmm0", tmp_path / "hmm1"
+    d0.mkdir(); d1.mkdir()
+    for src, dst, step in ((os.path.join(DEMO, "proto"), d0, "hinit"), (str(d0), d1, "hrest")):
+        for name in "SCVNL":
+            mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=src)
+            if step == "hinit":
+                pk, model, hist, _ = hinit(native, mmf, name, tables, labels, max_iter=10)
+            else:
+                model, hist = hrest(native, mmf, name, tables, labels, max_iter=10, min_var=0.05, mix_weight_floor=3 * 1.0e-5)
+            one = native.Mmf(files=[os.path.join(src, name)])                    # the model's own file, rewritten with the new values
+            q, p = one.packed(), model.get_params()
+            full = mmf.packed()
+            h = mmf.logical[name]
+            st = full["hmmState"][full["hmmStateOff"][h]:full["hmmStateOff"][h + 1]]
+            g = [int(full["compGauss"][full["stateCompOff"][s]]) for s in st]
+            t = int(full["hmmTrans"][h]); N = int(full["transN"][t]); o = int(full["transOff"][t])
+            one.write(dict(mean=p["mean"][g], var=p["var"][g], gconst=p["gconst"][g], compWeight=q["compWeight"],
+                           transP=p["transP"][o:o + N * N]), out_dir=str(dst))
+    # embedded pass from the files just written
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=str(d1))
+    model = native.Model(mmf.packed())
+    seqs = [np.array([mmf.logical[n] for n, _, _, _ in labs], np.int32) for labs in labels]
+    dX, frameOff, cols = native.parm_add_qualifiers(stat, hasD=True)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    fb = native.ForwardBackward(model); acc = native.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, np.concatenate(seqs))
+    fb.execute(native.fb_config(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0), acc)
+    pr, st = fb.results()
+    a = acc.download()
+    assert abs(a["totalPr"] / a["totalT"] - (-5.900196e+01)) < 2e-3             # the reference's first-pass figure
+    model.update(acc, a["vec"], minEgs=3, minVar=0.05, mixWeightFloor=3 * 1.0e-5)
+    rmmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm2_expected"))
+    rq, pk, p = rmmf.packed(), mmf.packed(), model.get_params()
+    for name in "SCVNL":
+        h, rh = mmf.logical[name], rmmf.logical[name]
+        for s, rs in zip(pk["hmmState"][pk["hmmStateOff"][h]:pk["hmmStateOff"][h + 1]], rq["hmmState"][rq["hmmStateOff"][rh]:rq["hmmStateOff"][rh + 1]]):
+            g, rg = int(pk["compGauss"][pk["stateCompOff"][s]]), int(rq["compGauss"][rq["stateCompOff"][rs]])
+            sigma = np.sqrt(rq["var"][rg])
+            assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-3 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-5).all(), name
+            assert np.allclose(p["var"][g], rq["var"][rg], rtol=2e-3, atol=1e-6), name
