@@ -260,3 +260,30 @@ def test_htkdemo_training_chain_from_prototypes(native, oracle, tmp_path):
             sigma = np.sqrt(rq["var"][rg])
             assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-3 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-5).all(), name
             assert np.allclose(p["var"][g], rq["var"][rg], rtol=2e-3, atol=1e-6), name
+
+
+def test_htkdemo_recognition_matches_reference_label_files(native):
+    """The demo's test step on the device: HVite -w monLattice -t 300.0 -p 5.0 -s 0.0 bcpvocab bcplist over the three test files
+    and the seven training files with the demo's final models; every line of every .rec file the reference wrote (HResults on
+    them gives the known answer of HTKDemo/results/monPlainM1S1.res: %Corr=63.91, Acc=59.40 on the test set)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from decode_util import format_words
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm_final"))
+    model = native.Model(mmf.packed())
+    net = native.Net(os.path.join(DEMO, "monLattice"), os.path.join(DEMO, "bcpvocab"), mmf)
+    dec = native.Decoder(model, net, lmScale=0.0)
+    expected = json.load(open(os.path.join(DEMO, "hvite_expected.json")))
+    n = 0
+    for part in ("test", "train"):
+        names = sorted(expected[part])
+        stat = [native.parm_read(os.path.join(DEMO, part, u + ".mfc"))[0] for u in names]
+        dX, frameOff, cols = native.parm_add_qualifiers(stat, hasD=True)
+        feats = dX.to_host(np.float32, (int(frameOff[-1]), cols))
+        res = dec.run([feats[frameOff[u]:frameOff[u + 1]] for u in range(len(names))], genBeam=300.0, lmScale=0.0, wordPen=5.0)
+        for u, (words, total) in zip(names, res):
+            got = format_words(words, net.out_syms)
+            assert got == expected[part][u], (part, u)
+            n += len(got)
+    assert n == sum(len(v) for per in expected.values() for v in per.values()) == 292
