@@ -610,6 +610,14 @@ class Mmf:
                   hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int))
         return pk
 
+    def mixup(self, target: int, states=None):
+        """HHEd's MU command on the loaded set: `target` > 0 components per state (or -target more if negative) for the states
+        whose indices are in `states` (None = all).  packed() / write() reflect the new set afterwards."""
+        sel = None
+        if states is not None:
+            sel = np.zeros(self.desc.numStates, np.uint8); sel[list(states)] = 1
+        check(lib().htkamd_mmf_mixup(self.h, C.c_int(target), _p(sel) if sel is not None else None), "mmf_mixup")
+
     def write(self, params: dict, one_file=None, out_dir=None, binary=False):
         g = params.get("gconst")
         fn = lib().htkamd_mmf_write_binary if binary else lib().htkamd_mmf_write

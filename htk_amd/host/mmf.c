@@ -740,3 +740,128 @@ int htkamd_mmf_write_vfloors(const char *path, const float *var, int D, float sc
    fclose(f);
    return HTKAMD_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ mixture splitting (HHEd MU)
+ * MixUpCommand (HHEd.c:4020-4090) on the loaded set: every selected state goes to `target` components (target > 0) or gains
+ * -target components (target < 0).  As in the reference: the gConst mean / deviation over the set guard against splitting
+ * outliers (SetGCStats :2080, HeaviestMix :2112: score = weight - number of splits, minus 5000 once when gConst < mean - 4 sd);
+ * the heaviest component is replaced by a clone with mean + 0.2 sd and half the weight, a second clone with mean - 0.2 sd goes
+ * to the end of the state's list (SplitMix :1318, UpMix :2149); defunct components (weight <= MINMIX) are refilled first
+ * (FixDefunctMix :2177).  Afterwards the flat description (htkamd_mmf_desc) has the new sizes. */
+static int mix_new_gauss(struct htkamd_mmf *s, int from)
+{
+   const int D = s->vecSize;
+   if (s->nG + 1 > s->capG) {
+      s->capG = s->capG * 2 + 64;
+      s->gconst = (float *)realloc(s->gconst, sizeof(float) * (size_t)s->capG);
+      s->mean = (float *)realloc(s->mean, sizeof(float) * (size_t)s->capG * D);
+      s->var = (float *)realloc(s->var, sizeof(float) * (size_t)s->capG * D);
+      s->hasG = (unsigned char *)realloc(s->hasG, (size_t)s->capG);
+   }
+   const int g = s->nG++;
+   memcpy(s->mean + (size_t)g * D, s->mean + (size_t)from * D, sizeof(float) * (size_t)D);
+   memcpy(s->var + (size_t)g * D, s->var + (size_t)from * D, sizeof(float) * (size_t)D);
+   s->gconst[g] = s->gconst[from]; s->hasG[g] = 1;
+   return g;
+}
+
+typedef struct { float w; int g; int hook; } mix_elem;
+
+static int mix_heaviest(struct htkamd_mmf *s, mix_elem *me, int M, float meanGC, float stdGC)
+{
+   const float gThresh = meanGC - 4.0 * stdGC;
+   int maxm = 0;
+   float max = me[0].w - me[0].hook;
+   if (me[0].hook < 5000 && s->gconst[me[0].g] < gThresh) { max -= 5000.0; me[0].hook = 5000; }
+   for (int m = 1; m < M; m++) {
+      float w = me[m].w - me[m].hook;
+      if (me[m].hook < 5000 && s->gconst[me[m].g] < gThresh) { w -= 5000.0; me[m].hook = 5000; }
+      if (w > max) { max = w; maxm = m; }
+   }
+   return maxm;
+}
+
+/* SplitMix: me[m] -> two clones; the first takes its place, the second is returned in *second */
+static void mix_split(struct htkamd_mmf *s, mix_elem *me, int m, mix_elem *second, const int *use)
+{
+   const int D = s->vecSize, g0 = me[m].g;
+   const int shared = (g0 < s->capGN && s->gName[g0]) || use[g0] > 1;       /* a pdf somebody else uses is left alone (CloneMixPDF) */
+   const int g1 = shared ? mix_new_gauss(s, g0) : g0;
+   const int g2 = mix_new_gauss(s, g0);
+   const int split = me[m].hook + 1;
+   const float pertDepth = 0.2;
+   for (int k = 0; k < D; k++) {
+      const float x = sqrt(s->var[(size_t)g0 * D + k]) * pertDepth;
+      const float base = s->mean[(size_t)g0 * D + k];
+      s->mean[(size_t)g1 * D + k] = base + x;
+      s->mean[(size_t)g2 * D + k] = base - x;
+   }
+   const float w = me[m].w / 2.0;
+   me[m].w = w; me[m].g = g1; me[m].hook = split;
+   second->w = w; second->g = g2; second->hook = split;
+}
+
+int htkamd_mmf_mixup(struct htkamd_mmf *s, int target, const unsigned char *stateSel)
+{
+   if (!s || !s->finished || target == 0) { htkamd_set_error("mmf_mixup: bad argument (set not finished, or target 0)"); return HTKAMD_EINVAL; }
+   const int D = s->vecSize;
+   for (int g = 0; g < s->nG; g++) { htkamd_host_fix_diag_gconst(D, s->var + (size_t)g * D, s->gconst + g); s->hasG[g] = 1; }   /* FixAllGConsts */
+   double sum = 0.0, sumsq = 0.0; int count = 0;
+   for (int i = 0; i < s->nSt; i++)
+      for (int c = s->st[i].comp0; c < s->st[i].comp0 + s->st[i].nMix; c++) { const float x = s->gconst[s->cg[c]]; sum += x; sumsq += x * x; count++; }
+   if (!count) { htkamd_set_error("mmf_mixup: empty model set"); return HTKAMD_EMODEL; }
+   const float meanGC = sum / count, stdGC = sqrt(sumsq / count - meanGC * meanGC);
+   int *use = (int *)calloc((size_t)s->nG + 1, sizeof(int));
+   for (int c = 0; c < s->nComp; c++) use[s->cg[c]]++;
+   const int nG0 = s->nG;
+   float *nwt = NULL; int *ncg = NULL; int nc = 0, capc = 0;
+   for (int i = 0; i < s->nSt; i++) {
+      const int M = s->st[i].nMix, c0 = s->st[i].comp0;
+      int m = M;
+      if (!stateSel || stateSel[i]) m = (target < 0) ? M - target : target;
+      if (m < M) m = M;                                         /* MU never removes components */
+      mix_elem *me = (mix_elem *)malloc(sizeof(mix_elem) * (size_t)m);
+      for (int k = 0; k < M; k++) { me[k].w = s->wt[c0 + k]; me[k].g = s->cg[c0 + k]; me[k].hook = 0; }
+      int cnt = M;
+      if (m > M || (stateSel ? stateSel[i] : 1)) {
+         int defunct = 0;
+         for (int k = 0; k < M; k++) if (me[k].w <= MINMIX) defunct++;
+         if (m > M - defunct) {                                 /* FixDefunctMix: refill dead components first */
+            int n2fix = m - M + defunct;
+            if (n2fix > defunct) n2fix = defunct;
+            for (int f = 0; f < n2fix; f++) {
+               int l = 0;
+               while (l < M && me[l].w > MINMIX) l++;
+               const int hv = mix_heaviest(s, me, M, meanGC, stdGC);
+               mix_elem second;
+               mix_split(s, me, hv, &second, use);
+               me[l] = second;
+            }
+         }
+         while (cnt < m) {                                      /* UpMix */
+            const int hv = mix_heaviest(s, me, cnt, meanGC, stdGC);
+            mix_split(s, me, hv, &me[cnt], use);
+            cnt++;
+         }
+      }
+      if (nc + cnt > capc) { capc = (nc + cnt) * 2 + 64; nwt = (float *)realloc(nwt, sizeof(float) * (size_t)capc); ncg = (int *)realloc(ncg, sizeof(int) * (size_t)capc); }
+      for (int k = 0; k < cnt; k++) { nwt[nc + k] = me[k].w; ncg[nc + k] = me[k].g; }
+      s->st[i].comp0 = nc; s->st[i].nMix = cnt; nc += cnt;
+      free(me);
+   }
+   (void)nG0;
+   free(use);
+   free(s->wt); free(s->cg);
+   s->wt = nwt; s->cg = ncg; s->nComp = nc; s->capComp = capc;
+   if (s->nG > s->capGN) {                                      /* names: the clones are un-named */
+      s->gName = (char **)realloc(s->gName, sizeof(char *) * (size_t)s->nG);
+      for (int g = s->capGN; g < s->nG; g++) s->gName[g] = NULL;
+      s->capGN = s->nG;
+   }
+   for (int i = 0; i < s->nSt; i++) s->stateCompOff[i] = s->st[i].comp0;
+   s->stateCompOff[s->nSt] = s->nComp;
+   htkamd_model_desc *d = &s->d;
+   d->numComp = s->nComp; d->numGauss = s->nG;
+   d->compWeight = s->wt; d->compGauss = s->cg; d->mean = s->mean; d->var = s->var; d->gconst = s->gconst;
+   return HTKAMD_OK;
+}

@@ -112,6 +112,10 @@ int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gc
  * ------------------------------------------------------------------------------------------ */
 typedef struct htkamd_mmf htkamd_mmf;
 int  htkamd_mmf_create(htkamd_mmf **out);
+/* Mixture splitting as HHEd's MU command does it (MixUpCommand HHEd.c:4020, UpMix :2149, SplitMix :1318, HeaviestMix :2112): every
+   state with stateSel[state] != 0 (NULL = all) goes to `target` components, or gains -target if target < 0; afterwards
+   htkamd_mmf_desc / htkamd_mmf_write reflect the new set.  The step between single-Gaussian and mixture systems in a recipe. */
+int  htkamd_mmf_mixup(htkamd_mmf *s, int target, const unsigned char *stateSel);
 /* HCompV's PutVFloor (HCompV.c:359-389): "~v varFloor1 <Variance> D" with scale*var, written like WriteVector(" %e"). */
 int  htkamd_mmf_write_vfloors(const char *path, const float *var, int D, float scale);
 void htkamd_mmf_destroy(htkamd_mmf *s);

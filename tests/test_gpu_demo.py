@@ -287,3 +287,45 @@ def test_htkdemo_recognition_matches_reference_label_files(native):
             assert got == expected[part][u], (part, u)
             n += len(got)
     assert n == sum(len(v) for per in expected.values() for v in per.values()) == 292
+
+
+def test_herest_pass_on_mixture_system_from_mixup(native, tmp_path):
+    """Single-Gaussian demo models split to 3 (5 for one state) components with htkamd_mmf_mixup (= HHEd MU, byte-identical files:
+    tests/test_mmf_labels.py), then one embedded pass: log-likelihood, floored variances and re-estimated mixture parameters
+    against the reference's HERest run from the reference HHEd's output (tests/golden/demo/hmm_mixup, make_mixup_golden.py)."""
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm_final"))
+    mmf.mixup(3)
+    q1 = mmf.packed()
+    h = mmf.logical["S"]
+    mmf.mixup(-2, states=[int(q1["hmmState"][q1["hmmStateOff"][h]])])
+    pk = mmf.packed()
+    model = native.Model(pk)
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    stat = [native.parm_read(os.path.join(DEMO, "train", f))[0] for f in files]
+    seqs = [np.array([mmf.logical[n] for n, _, _, _ in native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab")))], np.int32) for f in files]
+    dX, frameOff, cols = native.parm_add_qualifiers(stat, hasD=True)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in seqs])]).astype(np.int32)
+    fb = native.ForwardBackward(model); acc = native.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, np.concatenate(seqs))
+    fb.execute(native.fb_config(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0), acc)
+    pr, st = fb.results()
+    a = acc.download()
+    log = open(os.path.join(DEMO, "hmm_mixup", "herest.log")).read()
+    ref_avg = float(re.search(r"average log prob per frame = (\S+)", log).group(1))
+    assert (st == 1).all() and "%e" % (a["totalPr"] / a["totalT"]) == "%e" % ref_avg
+    stats = model.update(acc, a["vec"], minEgs=3, minVar=0.05, mixWeightFloor=3 * 1.0e-5)
+    mm = re.search(r"Total (\d+) floored variance elements in (\d+) different mixes", log)
+    assert (stats["nFloorVar"], stats["nFloorVarMix"]) == (int(mm.group(1)), int(mm.group(2)))
+    rmmf = native.Mmf(files=[os.path.join(DEMO, "hmm_mixup", "after_herest")], hmm_list=os.path.join(DEMO, "bcplist"))
+    rq, p = rmmf.packed(), model.get_params()
+    for name in "SCVNL":
+        hh, rh = mmf.logical[name], rmmf.logical[name]
+        for s, rs in zip(pk["hmmState"][pk["hmmStateOff"][hh]:pk["hmmStateOff"][hh + 1]], rq["hmmState"][rq["hmmStateOff"][rh]:rq["hmmStateOff"][rh + 1]]):
+            c0, c1, r0, r1 = int(pk["stateCompOff"][s]), int(pk["stateCompOff"][s + 1]), int(rq["stateCompOff"][rs]), int(rq["stateCompOff"][rs + 1])
+            assert c1 - c0 == r1 - r0
+            assert np.allclose(p["compWeight"][c0:c1], rq["compWeight"][r0:r1], rtol=1e-4, atol=2e-6), name
+            for c, rc in zip(range(c0, c1), range(r0, r1)):
+                g, rg = int(pk["compGauss"][c]), int(rq["compGauss"][rc])
+                sigma = np.sqrt(rq["var"][rg])
+                assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-4 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-6).all(), name
+                assert np.allclose(p["var"][g], rq["var"][rg], rtol=2e-4, atol=1e-6), name

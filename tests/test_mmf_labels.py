@@ -134,3 +134,27 @@ def test_mmf_shared_mixture_macros(native, tmp_path):
     assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "syn_tied.mmf"), "rb").read()
     with pytest.raises(native.HtkAmdError):
         m.write(dict(mean=q["mean"], var=q["var"], gconst=q["gconst"], compWeight=q["compWeight"], transP=q["transP"]), out_dir=str(tmp_path))
+
+
+def test_mixture_splitting_matches_hhed(native, tmp_path):
+    """HHEd's MU (MixUpCommand: heaviest component split into mean +- 0.2 sd clones with half the weight each) on HTKDemo's final
+    models: MU 3 on every state, then MU +2 on S.state[2]; the file written afterwards equals the reference HHEd's byte for byte."""
+    demo = os.path.join(GOLD, "demo")
+    m = native.Mmf(hmm_list=os.path.join(demo, "bcplist"), hmm_dir=os.path.join(demo, "hmm_final"))
+    q0 = m.packed()
+    assert q0["numComp"] == 15
+    m.mixup(3)
+    q1 = m.packed()
+    assert q1["numComp"] == 45 and q1["numGauss"] == 45 and (np.diff(q1["stateCompOff"]) == 3).all()
+    assert np.allclose(np.add.reduceat(q1["compWeight"], q1["stateCompOff"][:-1]), 1.0, atol=1e-6)
+    h = m.logical["S"]
+    s2 = int(q1["hmmState"][q1["hmmStateOff"][h]])                  # S.state[2]
+    m.mixup(-2, states=[s2])
+    q = m.packed()
+    assert q["numComp"] == 47 and int(q["stateCompOff"][s2 + 1] - q["stateCompOff"][s2]) == 5
+    out = tmp_path / "newMacros"                                    # HHEd saves an edited set loaded from a directory as one file
+    m.write(dict(mean=q["mean"], var=q["var"], gconst=q["gconst"], compWeight=q["compWeight"], transP=q["transP"]), one_file=str(out))
+    assert out.read_bytes() == open(os.path.join(demo, "hmm_mixup", "newMacros"), "rb").read()
+    # the split set loads again (structure is consistent)
+    m2 = native.Mmf(files=[str(out)], hmm_list=os.path.join(demo, "bcplist"))
+    assert m2.packed()["numComp"] == 47
