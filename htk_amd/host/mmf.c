@@ -782,10 +782,10 @@ static int mix_heaviest(struct htkamd_mmf *s, mix_elem *me, int M, float meanGC,
 }
 
 /* SplitMix: me[m] -> two clones; the first takes its place, the second is returned in *second */
-static void mix_split(struct htkamd_mmf *s, mix_elem *me, int m, mix_elem *second, const int *use)
+static void mix_split(struct htkamd_mmf *s, mix_elem *me, int m, mix_elem *second, const int *use, int nUse)
 {
    const int D = s->vecSize, g0 = me[m].g;
-   const int shared = (g0 < s->capGN && s->gName[g0]) || use[g0] > 1;       /* a pdf somebody else uses is left alone (CloneMixPDF) */
+   const int shared = (g0 < s->capGN && s->gName[g0]) || (g0 < nUse && use[g0] > 1);   /* a pdf somebody else uses is left alone (CloneMixPDF); clones made here are private */
    const int g1 = shared ? mix_new_gauss(s, g0) : g0;
    const int g2 = mix_new_gauss(s, g0);
    const int split = me[m].hook + 1;
@@ -834,13 +834,13 @@ int htkamd_mmf_mixup(struct htkamd_mmf *s, int target, const unsigned char *stat
                while (l < M && me[l].w > MINMIX) l++;
                const int hv = mix_heaviest(s, me, M, meanGC, stdGC);
                mix_elem second;
-               mix_split(s, me, hv, &second, use);
+               mix_split(s, me, hv, &second, use, nG0);
                me[l] = second;
             }
          }
          while (cnt < m) {                                      /* UpMix */
             const int hv = mix_heaviest(s, me, cnt, meanGC, stdGC);
-            mix_split(s, me, hv, &me[cnt], use);
+            mix_split(s, me, hv, &me[cnt], use, nG0);
             cnt++;
          }
       }
@@ -849,7 +849,6 @@ int htkamd_mmf_mixup(struct htkamd_mmf *s, int target, const unsigned char *stat
       s->st[i].comp0 = nc; s->st[i].nMix = cnt; nc += cnt;
       free(me);
    }
-   (void)nG0;
    free(use);
    free(s->wt); free(s->cg);
    s->wt = nwt; s->cg = ncg; s->nComp = nc; s->capComp = capc;

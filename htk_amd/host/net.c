@@ -85,7 +85,7 @@ static int resolve_models(dpron *pr, int nPr, const struct htkamd_mmf *hmms, con
    strset cxs = {0}, dep = {0};                      /* contexts seen; base names that have a context-dependent model */
    int sLeft = 0, sRight = 0;
    const int nLog = htkamd_mmf_num_logical(hmms);
-   char buf[512], base[512];
+   char buf[1600], base[512];
    for (int i = 0; i < nLog; i++) {
       const char *nm = htkamd_mmf_logical_name(hmms, i);
       const char *mi = strchr(nm, '-'), *pl = strchr(nm, '+');
