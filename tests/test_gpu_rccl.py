@@ -11,16 +11,29 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_one_rank_rccl_all_reduce_on_accumulator_vector(native):
+def test_one_rank_rccl_all_reduce_on_accumulator_vector():
+    """Runs in a process of its own with torch imported first, as bench.py does: the HIP runtime torch ships and the one the
+    library links must be initialised in that order for torch to see the device."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def _main():
     import torch
     import torch.distributed as dist
-    from htk_amd import herest, synth
+    torch.cuda.set_device(0)
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    import sys
+    sys.path.insert(0, sys_path); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from htk_amd import capi as native, herest, synth
+    from util import batch_arrays
     s = synth.generate(12, 2, 6, 3, 60, 5)
     pk = s.packed()
     model = native.Model(pk)
     acc = native.Accs(model)
     utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
-    from util import batch_arrays
     X, frameOff, labOff, labs = batch_arrays(utts)
     dX = native.DevArray(X)
     fb = native.ForwardBackward(model)
@@ -44,3 +57,8 @@ def test_one_rank_rccl_all_reduce_on_accumulator_vector(native):
         assert np.array_equal(t.cpu().numpy(), before)
     finally:
         dist.destroy_process_group()
+    print("RCCL_OK")
+
+
+if __name__ == "__main__":
+    _main()
