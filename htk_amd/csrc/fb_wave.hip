@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
       if (lane == 0) { a.status[u] = ud.status; a.pr[u] = LZERO; }
       return;
    }
-   const int T = ud.T, Q = ud.Q, nC = ud.nCells;
+   const int T = ud.T, Q = ud.Q;
    const int q = lane + 1;
    const bool valid = q <= Q;
    ModelRegs<MAXN> m;
