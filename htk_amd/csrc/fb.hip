@@ -420,10 +420,12 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       fb->copyPending = true;
    }
    lap("stage+copy");
+   // the wave-per-utterance kernels keep beta in their own state-major block (d_betaW, reserved in execute)
+   const bool wavePathPrep = (fb->m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
    const size_t nf = fb->totalFrames ? fb->totalFrames : 1;
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
-       (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * (beta ? beta : 1))) ||
+       (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * ((beta && !wavePathPrep) ? beta : 1))) ||
        (rc = fb->d_gam.reserve(sizeof(double) * (gam ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
        (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))))
       return rc;
