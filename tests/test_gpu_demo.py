@@ -329,3 +329,29 @@ def test_herest_pass_on_mixture_system_from_mixup(native, tmp_path):
                 sigma = np.sqrt(rq["var"][rg])
                 assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-4 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-6).all(), name
                 assert np.allclose(p["var"][g], rq["var"][rg], rtol=2e-4, atol=1e-6), name
+
+
+def test_c_driver_runs_the_demo_pass(tmp_path):
+    """examples/herest_pass.c -- a host written against include/htk_amd.h alone, compiled with gcc -- runs HTKDemo's first embedded
+    pass from the model / parameter / label FILES and prints the reference's summary lines; its output models equal the
+    reference's to the printed digits' tolerance."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = tmp_path / "herest_pass"
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "herest_pass.c"), "-o", str(exe),
+                           "-L" + os.path.join(root, "htk_amd"), "-lhtk_amd", "-Wl,-rpath," + os.path.abspath(os.path.join(root, "htk_amd"))])
+    out = tmp_path / "hmm2"; out.mkdir()
+    files = sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    r = subprocess.run([str(exe), os.path.join(DEMO, "bcplist"), os.path.join(DEMO, "hmm1"), os.path.join(DEMO, "labels"), str(out), "2000.0", "0.05", "3"] + files,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    log = open(os.path.join(DEMO, "herest_pass1.log")).read()
+    assert "average log prob per frame = -5.900196e+01" in r.stdout and "-5.900196e+01" in log
+    assert "Total 27 floored variance elements in 15 different mixes" in r.stdout
+    for name in "SCVNL":
+        ours = (out / name).read_text().split()
+        theirs = open(os.path.join(DEMO, "hmm2_expected", name)).read().split()
+        assert len(ours) == len(theirs)
+        for x, y in zip(ours, theirs):
+            if x != y:
+                assert abs(float(x) - float(y)) <= 2e-4 * max(abs(float(y)), 1e-3), (name, x, y)
