@@ -656,6 +656,20 @@ def labels_read(path: str):
     return out
 
 
+def scp_read(path: str):
+    """Script file -> [(logical, physical, start, end)] (start/end -1 = whole file); extended file names are split."""
+    L = lib()
+    for f in ("htkamd_scp_logical", "htkamd_scp_physical"):
+        getattr(L, f).restype = C.c_char_p
+    L.htkamd_scp_start.restype = C.c_long; L.htkamd_scp_end.restype = C.c_long
+    h = C.c_void_p()
+    check(L.htkamd_scp_read(path.encode(), C.byref(h)), "scp_read")
+    out = [(L.htkamd_scp_logical(h, i).decode(), L.htkamd_scp_physical(h, i).decode(), int(L.htkamd_scp_start(h, i)), int(L.htkamd_scp_end(h, i)))
+           for i in range(L.htkamd_scp_count(h))]
+    L.htkamd_scp_free(h)
+    return out
+
+
 class Mlf:
     def __init__(self, path: str):
         self.h = C.c_void_p()

@@ -151,3 +151,69 @@ const struct htkamd_labels *htkamd_mlf_find(const struct htkamd_mlf *m, const ch
    for (int i = 0; i < m->n; i++) if (wild(m->pattern[i], labFile)) return m->lab[i];
    return NULL;
 }
+
+/* ---- script files (-S): the list of data files of a tool run ------------------------------------------------------------
+ * ScriptWord (HShell.c:661-688): words separated by white space, or enclosed in single / double quotes (no escapes);
+ * RegisterExtFileName (HShell.c:86-140): a word may be an extended file name  logical=physical[start,end]  (either part optional):
+ * the data are read from `physical`, frames start..end inclusive, and the file is known (label lookup) as `logical`. */
+struct htkamd_scp {
+   int n;
+   char **logical, **physical;
+   long *start, *end;            /* -1 = whole file */
+};
+
+void htkamd_scp_free(struct htkamd_scp *s)
+{
+   if (!s) return;
+   for (int i = 0; i < s->n; i++) { free(s->logical[i]); free(s->physical[i]); }
+   free(s->logical); free(s->physical); free(s->start); free(s->end); free(s);
+}
+
+int htkamd_scp_read(const char *path, struct htkamd_scp **out)
+{
+   if (!path || !out) { htkamd_set_error("scp_read: NULL argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "r");
+   if (!f) { htkamd_set_error("scp_read: cannot open script file %s", path); return HTKAMD_EIO; }
+   struct htkamd_scp *s = (struct htkamd_scp *)calloc(1, sizeof(*s));
+   int cap = 0, ch;
+   char buf[4096];
+   for (;;) {
+      int i = 0;
+      do ch = fgetc(f); while (ch != EOF && isspace(ch));
+      if (ch == EOF) break;
+      if (ch == '\'' || ch == '"') {
+         const int q = ch;
+         while ((ch = fgetc(f)) != q && ch != EOF) if (i < (int)sizeof(buf) - 1) buf[i++] = (char)ch;
+         if (ch == EOF) { fclose(f); htkamd_scp_free(s); htkamd_set_error("scp_read: %s: closing quote missing", path); return HTKAMD_EINVAL; }
+      } else {
+         do { if (i < (int)sizeof(buf) - 1) buf[i++] = (char)ch; ch = fgetc(f); } while (ch != EOF && !isspace(ch));
+      }
+      buf[i] = 0;
+      if (s->n + 1 > cap) {
+         cap = cap * 2 + 64;
+         s->logical = (char **)realloc(s->logical, sizeof(char *) * (size_t)cap); s->physical = (char **)realloc(s->physical, sizeof(char *) * (size_t)cap);
+         s->start = (long *)realloc(s->start, sizeof(long) * (size_t)cap); s->end = (long *)realloc(s->end, sizeof(long) * (size_t)cap);
+      }
+      long st = -1, en = -1;
+      char *eq = strchr(buf, '='), *lb = strchr(buf, '[');
+      if (lb) {
+         char *co = strchr(buf, ','), *rb = strchr(buf, ']');
+         if (!co || !rb) { fclose(f); htkamd_scp_free(s); htkamd_set_error("scp_read: %s: bad index spec in %s", path, buf); return HTKAMD_EINVAL; }
+         *rb = 0; en = atol(co + 1);
+         *co = 0; st = atol(lb + 1);
+         *lb = 0;
+      }
+      if (eq) { *eq = 0; s->physical[s->n] = strdup(eq + 1); s->logical[s->n] = strdup(buf); }
+      else { s->physical[s->n] = strdup(buf); s->logical[s->n] = strdup(buf); }
+      s->start[s->n] = st; s->end[s->n] = en; s->n++;
+   }
+   fclose(f);
+   *out = s;
+   return HTKAMD_OK;
+}
+
+int htkamd_scp_count(const struct htkamd_scp *s) { return s ? s->n : 0; }
+const char *htkamd_scp_logical(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->logical[i] : NULL; }
+const char *htkamd_scp_physical(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->physical[i] : NULL; }
+long htkamd_scp_start(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->start[i] : -1; }
+long htkamd_scp_end(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->end[i] : -1; }

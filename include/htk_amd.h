@@ -135,6 +135,17 @@ int  htkamd_mmf_write(const htkamd_mmf *s, const float *mean, const float *var, 
 int  htkamd_mmf_write_binary(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
                              const float *transP, const char *oneFile, const char *dir);
 
+/* Script files (-S scp): white-space separated or quoted words (ScriptWord HShell.c:661), each a data file name or an extended
+ * file name logical=physical[start,end] (RegisterExtFileName HShell.c:86: frames start..end of `physical`, known as `logical`). */
+typedef struct htkamd_scp htkamd_scp;
+int  htkamd_scp_read(const char *path, htkamd_scp **out);
+void htkamd_scp_free(htkamd_scp *s);
+int  htkamd_scp_count(const htkamd_scp *s);
+const char *htkamd_scp_logical(const htkamd_scp *s, int i);
+const char *htkamd_scp_physical(const htkamd_scp *s, int i);
+long htkamd_scp_start(const htkamd_scp *s, int i);      /* -1 = whole file */
+long htkamd_scp_end(const htkamd_scp *s, int i);
+
 /* ------------------------------------------------------------------------------------------
  * Transcriptions: HTK label files (LoadHTKLabels, HLabel.c:748) and master label files with immediate definitions
  * (LoadMasterFile, HLabel.c:1410).  "[start [end]] name [score] ..." per line, times in 100 ns; only the first

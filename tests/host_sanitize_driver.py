@@ -48,6 +48,9 @@ def main():
     open(mlf, "w").write('#!MLF!#\n"*/a.lab"\n0 100 x\n100 200 y 1.5\n///\n0 1 z\n.\n"*/b?.lab"\nw\n')
     ml = capi.Mlf(mlf)
     assert ml.find("dir/a.lab") is not None and ml.find("q/b1.lab") is not None and ml.find("nothing") is None
+    scp = os.path.join(tmp, "x.scp")
+    open(scp, "w").write('a.mfc "b c.mfc" u=p.mfc[3,9]\n')
+    assert len(capi.scp_read(scp)) == 3
     # networks: SLF + dictionary, word-internal contexts, alignment networks
     for case in ("loop", "bigram", "tee", "wint"):
         d = os.path.join(GOLD, "decode", case)

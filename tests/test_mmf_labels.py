@@ -158,3 +158,20 @@ def test_mixture_splitting_matches_hhed(native, tmp_path):
     # the split set loads again (structure is consistent)
     m2 = native.Mmf(files=[str(out)], hmm_list=os.path.join(demo, "bcplist"))
     assert m2.packed()["numComp"] == 47
+
+
+def test_script_files_and_extended_file_names(native, tmp_path):
+    """-S script files: words by white space or quotes (ScriptWord HShell.c:661), extended names logical=physical[s,e]
+    (RegisterExtFileName HShell.c:86)."""
+    p = tmp_path / "train.scp"
+    p.write_text('data/a.mfc\n  "dir with space/b.mfc"   c.mfc\n\'q d.mfc\'\nutt1=big.mfc[100,250]\nseg.mfc[7,9]\nalias=phys.mfc\n')
+    got = native.scp_read(str(p))
+    assert got == [("data/a.mfc", "data/a.mfc", -1, -1), ("dir with space/b.mfc", "dir with space/b.mfc", -1, -1), ("c.mfc", "c.mfc", -1, -1),
+                   ("q d.mfc", "q d.mfc", -1, -1), ("utt1", "big.mfc", 100, 250), ("seg.mfc", "seg.mfc", 7, 9), ("alias", "phys.mfc", -1, -1)]
+    (tmp_path / "bad.scp").write_text('"unterminated\n')
+    (tmp_path / "bad2.scp").write_text('x.mfc[5\n')
+    for bad in ("bad.scp", "bad2.scp", "missing.scp"):
+        with pytest.raises(native.HtkAmdError):
+            native.scp_read(str(tmp_path / bad))
+    (tmp_path / "empty.scp").write_text("\n  \n")
+    assert native.scp_read(str(tmp_path / "empty.scp")) == []
