@@ -54,13 +54,14 @@ def test_bad_arguments_are_rejected(native):
 
 
 def test_header_is_plain_c_and_the_c_driver_links(tmp_path):
-    """include/htk_amd.h compiles as C (gnu11, -Wall -Wextra -pedantic clean) and examples/herest_pass.c -- a host that uses nothing
-    but that header -- links against the library (the GPU tests run it)."""
+    """include/htk_amd.h compiles as C (gnu11, -Wall -Wextra -pedantic clean) and the C hosts under examples/ -- which use nothing
+    but that header -- link against the library (the GPU tests run it)."""
     import subprocess
     root = os.path.join(os.path.dirname(__file__), "..")
     src = tmp_path / "hdr.c"
     src.write_text('#include "htk_amd.h"\nint main(void) { return htkamd_device_count() < -1; }\n')
     lib = os.path.join(root, "htk_amd")
-    for args in (["-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", str(src)], [os.path.join(root, "examples", "herest_pass.c"), "-Wall", "-Werror"]):
+    for args in (["-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", str(src)], [os.path.join(root, "examples", "herest_pass.c"), "-Wall", "-Werror"],
+                 [os.path.join(root, "examples", "hvite_decode.c"), "-Wall", "-Werror"]):
         subprocess.check_call(["gcc", "-O1", "-I" + os.path.join(root, "include")] + args + ["-o", str(tmp_path / "a.out"), "-L" + lib, "-lhtk_amd",
                                                                                            "-Wl,-rpath," + os.path.abspath(lib)])

@@ -355,3 +355,21 @@ def test_c_driver_runs_the_demo_pass(tmp_path):
         for x, y in zip(ours, theirs):
             if x != y:
                 assert abs(float(x) - float(y)) <= 2e-4 * max(abs(float(y)), 1e-3), (name, x, y)
+
+
+def test_c_driver_recognises_the_demo_test_set(tmp_path):
+    """examples/hvite_decode.c (C ABI only, gcc): the .rec files it writes for HTKDemo's test files are the reference HVite's."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = tmp_path / "hvite_decode"
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "hvite_decode.c"), "-o", str(exe),
+                           "-L" + os.path.join(root, "htk_amd"), "-lhtk_amd", "-Wl,-rpath," + os.path.abspath(os.path.join(root, "htk_amd"))])
+    out = tmp_path / "rec"; out.mkdir()
+    expected = json.load(open(os.path.join(DEMO, "hvite_expected.json")))["test"]
+    files = [os.path.join(DEMO, "test", u + ".mfc") for u in sorted(expected)]
+    r = subprocess.run([str(exe), os.path.join(DEMO, "bcplist"), os.path.join(DEMO, "hmm_final"), os.path.join(DEMO, "monLattice"), os.path.join(DEMO, "bcpvocab"),
+                        str(out), "300.0", "0.0", "5.0"] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for u in expected:
+        assert (out / (u + ".rec")).read_text().splitlines() == expected[u], u
