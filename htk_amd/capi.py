@@ -656,6 +656,49 @@ def labels_read(path: str):
     return out
 
 
+OUT_FLAGS = dict(S=1, W=2, T=4, N=8, X=16, C=32, M=64)       # the letters of HVite -o
+
+
+class Trans:
+    """htkamd_trans holder: a transcription being written (labels with up to two auxiliary labels), HVite's -o formatting."""
+
+    def __init__(self, max_aux: int = 0):
+        self.h = C.c_void_p()
+        check(lib().htkamd_trans_create(C.c_int(max_aux), C.byref(self.h)), "trans_create")
+
+    def add(self, start, end, name, score=0.0, aux1=None, aux1_score=0.0, aux2=None, aux2_score=0.0):
+        check(lib().htkamd_trans_add(self.h, C.c_double(start), C.c_double(end), name.encode(), C.c_float(score),
+                                     aux1.encode() if aux1 is not None else None, C.c_float(aux1_score),
+                                     aux2.encode() if aux2 is not None else None, C.c_float(aux2_score)), "trans_add")
+
+    def format(self, frame_dur=100000.0, states=False, models=False, flags=""):
+        bits = sum(OUT_FLAGS[c] for c in flags)
+        check(lib().htkamd_trans_format(self.h, C.c_double(frame_dur), C.c_int(states), C.c_int(models), C.c_int(bits)), "trans_format")
+
+    def write(self, path: str):
+        check(lib().htkamd_trans_write(self.h, path.encode()), "trans_write")
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().htkamd_trans_free(self.h); self.h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class MlfOut:
+    def __init__(self, path: str):
+        self.h = C.c_void_p()
+        check(lib().htkamd_mlf_out_open(path.encode(), C.byref(self.h)), "mlf_out_open")
+
+    def add(self, lab_file: str, trans: Trans):
+        check(lib().htkamd_mlf_out_add(self.h, lab_file.encode(), trans.h), "mlf_out_add")
+
+    def close(self):
+        if self.h:
+            lib().htkamd_mlf_out_close(self.h); self.h = C.c_void_p()
+
+
 def scp_read(path: str):
     """Script file -> [(logical, physical, start, end)] (start/end -1 = whole file); extended file names are split."""
     L = lib()

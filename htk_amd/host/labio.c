@@ -217,3 +217,159 @@ const char *htkamd_scp_logical(const struct htkamd_scp *s, int i) { return (s &&
 const char *htkamd_scp_physical(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->physical[i] : NULL; }
 long htkamd_scp_start(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->start[i] : -1; }
 long htkamd_scp_end(const struct htkamd_scp *s, int i) { return (s && i >= 0 && i < s->n) ? s->end[i] : -1; }
+
+/* ---- label output: a transcription being built, FormatTranscription and SaveHTKLabels ---------------------------------------
+ * One label list (one level) with up to two auxiliary labels per entry, as TranscriptionFromLattice builds it for HVite
+ * (HRec.c:2176-2360: word level = no auxiliary labels; -m = [word]; -f -m = [model, word]); htkamd_trans_format applies HVite's
+ * -o flags the way FormatTranscription does (HRec.c:2368-2472); htkamd_trans_write prints like SaveHTKLabels (HLabel.c:1481-1525:
+ * times "%.0f" in 100 ns units when present, a score column only if ANY label of the list has a non-zero score in it). */
+#include <math.h>
+
+typedef struct { double start, end; char *name; float score; char *aux[2]; float auxScore[2]; } trans_lab;
+struct htkamd_trans { int n, cap, maxAux; trans_lab *lab; };
+
+int htkamd_trans_create(int maxAux, struct htkamd_trans **out)
+{
+   if (!out || maxAux < 0 || maxAux > 2) { htkamd_set_error("trans_create: bad argument"); return HTKAMD_EINVAL; }
+   struct htkamd_trans *t = (struct htkamd_trans *)calloc(1, sizeof(*t));
+   t->maxAux = maxAux;
+   *out = t;
+   return HTKAMD_OK;
+}
+
+void htkamd_trans_free(struct htkamd_trans *t)
+{
+   if (!t) return;
+   for (int i = 0; i < t->n; i++) { free(t->lab[i].name); free(t->lab[i].aux[0]); free(t->lab[i].aux[1]); }
+   free(t->lab); free(t);
+}
+
+/* start / end in 100 ns units (-1 = absent); aux1 / aux2 may be NULL */
+int htkamd_trans_add(struct htkamd_trans *t, double start, double end, const char *name, float score,
+                     const char *aux1, float aux1Score, const char *aux2, float aux2Score)
+{
+   if (!t || !name) { htkamd_set_error("trans_add: NULL argument"); return HTKAMD_EINVAL; }
+   if (t->n + 1 > t->cap) { t->cap = t->cap * 2 + 32; t->lab = (trans_lab *)realloc(t->lab, sizeof(trans_lab) * (size_t)t->cap); }
+   trans_lab *l = &t->lab[t->n++];
+   l->start = start; l->end = end; l->name = strdup(name); l->score = score;
+   l->aux[0] = (aux1 && t->maxAux >= 1) ? strdup(aux1) : NULL; l->auxScore[0] = aux1Score;
+   l->aux[1] = (aux2 && t->maxAux >= 2) ? strdup(aux2) : NULL; l->auxScore[1] = aux2Score;
+   return HTKAMD_OK;
+}
+
+static void tri_strip_inplace(char *s)                       /* TriStrip (HLabel/HUtil): a-b+c -> b */
+{
+   char *p = strchr(s, '-');
+   if (p) memmove(s, p + 1, strlen(p + 1) + 1);
+   if ((p = strrchr(s, '+')) != NULL) *p = 0;
+}
+
+/* flags: the letters of HVite -o / HTKAMD_OUT_* bits.  frameDur in 100 ns units; states / models = the -f / -m switches. */
+int htkamd_trans_format(struct htkamd_trans *t, double frameDur, int states, int models, int flags)
+{
+   if (!t || frameDur <= 0) { htkamd_set_error("trans_format: bad argument"); return HTKAMD_EINVAL; }
+   if (flags & HTKAMD_OUT_NOSCORES)
+      for (int i = 0; i < t->n; i++) { t->lab[i].score = 0.0f; t->lab[i].auxScore[0] = t->lab[i].auxScore[1] = 0.0f; }
+   if (flags & HTKAMD_OUT_TRISTRIP)
+      for (int i = 0; i < t->n; i++) {
+         trans_lab *l = &t->lab[i];
+         if (states && !models) {                             /* "model[state]" names: keep the tail */
+            char tail[64] = "", *p = strrchr(l->name, '[');
+            if (p) { snprintf(tail, sizeof(tail), "%s", p); *p = 0; }
+            tri_strip_inplace(l->name);
+            char *nn = (char *)malloc(strlen(l->name) + strlen(tail) + 1);
+            strcpy(nn, l->name); strcat(nn, tail); free(l->name); l->name = nn;
+         } else if (!states && models) tri_strip_inplace(l->name);
+         else if (states && models && l->aux[0]) tri_strip_inplace(l->aux[0]);
+      }
+   if (flags & HTKAMD_OUT_NORMSCORES)
+      for (int i = 0; i < t->n; i++) {
+         trans_lab *l = &t->lab[i];
+         int frames = (int)floor((l->end - l->start) / frameDur + 0.4);
+         l->score = frames == 0 ? 0.0f : l->score / frames;
+         if (states && models && t->maxAux > 0 && l->aux[0]) {          /* the model spans the labels up to the next model label */
+            double end = l->end;
+            for (int k = i + 1; k < t->n && !t->lab[k].aux[0]; k++) end = t->lab[k].end;
+            frames = (int)floor((end - l->start) / frameDur + 0.4);
+            l->auxScore[0] = frames == 0 ? 0.0f : l->auxScore[0] / frames;
+         }
+      }
+   if (flags & HTKAMD_OUT_NOTIMES)
+      for (int i = 0; i < t->n; i++) t->lab[i].start = t->lab[i].end = -1.0;
+   if (flags & HTKAMD_OUT_CENTRE)
+      for (int i = 0; i < t->n; i++) { t->lab[i].start += frameDur / 2; t->lab[i].end -= frameDur / 2; }
+   if ((flags & HTKAMD_OUT_NOWORDS) && t->maxAux > 0)
+      for (int i = 0; i < t->n; i++) { free(t->lab[i].aux[t->maxAux - 1]); t->lab[i].aux[t->maxAux - 1] = NULL; }
+   if ((flags & HTKAMD_OUT_NOMODELS) && models && states && t->maxAux == 2)
+      for (int i = 0; i < t->n; i++) {
+         trans_lab *l = &t->lab[i];
+         free(l->aux[0]); l->aux[0] = l->aux[1]; l->auxScore[0] = l->auxScore[1]; l->aux[1] = NULL;
+      }
+   return HTKAMD_OK;
+}
+
+static void write_name(FILE *f, const char *s)               /* WriteString with q = 0 (HShell.c:1268): quote only names that start with one */
+{
+   int q = 0;
+   if (s[0] == '"') q = '\''; else if (s[0] == '\'') q = '"';
+   if (q) fputc(q, f);
+   for (const unsigned char *p = (const unsigned char *)s; *p; p++) {
+      if (*p == '\\' || (q && *p == q)) { fputc('\\', f); fputc(*p, f); }
+      else if (*p >= 32 && *p < 127) fputc(*p, f);
+      else fprintf(f, "\\%c%c%c", ((*p / 64) % 8) + '0', ((*p / 8) % 8) + '0', (*p % 8) + '0');
+   }
+   if (q) fputc(q, f);
+}
+
+static void trans_print(FILE *f, const struct htkamd_trans *t)
+{
+   int has[3] = {0, 0, 0};
+   for (int i = 0; i < t->n; i++) {
+      if (t->lab[i].score != 0.0f) has[0] = 1;
+      for (int j = 0; j < t->maxAux; j++) if (t->lab[i].auxScore[j] != 0.0f) has[j + 1] = 1;
+   }
+   for (int i = 0; i < t->n; i++) {
+      const trans_lab *l = &t->lab[i];
+      if (l->start >= 0.0) {
+         fprintf(f, "%.0f ", l->start);
+         if (l->end >= 0.0) fprintf(f, "%.0f ", l->end);
+      }
+      write_name(f, l->name);
+      if (has[0]) fprintf(f, " %f", l->score);
+      for (int j = 0; j < t->maxAux; j++)
+         if (l->aux[j]) { fputc(' ', f); write_name(f, l->aux[j]); if (has[j + 1]) fprintf(f, " %f", l->auxScore[j]); }
+      fprintf(f, "\n");
+   }
+}
+
+int htkamd_trans_write(const struct htkamd_trans *t, const char *path)
+{
+   if (!t || !path) { htkamd_set_error("trans_write: NULL argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "w");
+   if (!f) { htkamd_set_error("trans_write: cannot create %s", path); return HTKAMD_EIO; }
+   trans_print(f, t);
+   fclose(f);
+   return HTKAMD_OK;
+}
+
+/* master label file output (HVite -i): "#!MLF!#", then per transcription its quoted name, the labels and "." */
+struct htkamd_mlf_out { FILE *f; };
+int htkamd_mlf_out_open(const char *path, struct htkamd_mlf_out **out)
+{
+   if (!path || !out) { htkamd_set_error("mlf_out_open: NULL argument"); return HTKAMD_EINVAL; }
+   FILE *f = fopen(path, "w");
+   if (!f) { htkamd_set_error("mlf_out_open: cannot create %s", path); return HTKAMD_EIO; }
+   fprintf(f, "#!MLF!#\n");
+   struct htkamd_mlf_out *o = (struct htkamd_mlf_out *)calloc(1, sizeof(*o));
+   o->f = f; *out = o;
+   return HTKAMD_OK;
+}
+int htkamd_mlf_out_add(struct htkamd_mlf_out *o, const char *labFile, const struct htkamd_trans *t)
+{
+   if (!o || !labFile || !t) { htkamd_set_error("mlf_out_add: NULL argument"); return HTKAMD_EINVAL; }
+   fprintf(o->f, "\"%s\"\n", labFile);
+   trans_print(o->f, t);
+   fprintf(o->f, ".\n");
+   return HTKAMD_OK;
+}
+void htkamd_mlf_out_close(struct htkamd_mlf_out *o) { if (o) { fclose(o->f); free(o); } }

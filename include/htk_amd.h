@@ -146,6 +146,29 @@ const char *htkamd_scp_physical(const htkamd_scp *s, int i);
 long htkamd_scp_start(const htkamd_scp *s, int i);      /* -1 = whole file */
 long htkamd_scp_end(const htkamd_scp *s, int i);
 
+/* Label OUTPUT: a transcription (one label list, up to two auxiliary labels per entry, as TranscriptionFromLattice HRec.c:2176
+ * builds them: word level none; HVite -m [word]; -f -m [model, word]), HVite's -o formatting (FormatTranscription HRec.c:2368)
+ * and the writers (SaveHTKLabels HLabel.c:1481: a score column appears only if some label of the list has a non-zero score in it;
+ * master label files as HVite -i writes them).  Times in 100 ns units, -1 = absent. */
+#define HTKAMD_OUT_NOSCORES   1      /* -o S */
+#define HTKAMD_OUT_NOWORDS    2      /* -o W */
+#define HTKAMD_OUT_NOTIMES    4      /* -o T */
+#define HTKAMD_OUT_NORMSCORES 8      /* -o N : scores per frame */
+#define HTKAMD_OUT_TRISTRIP   16     /* -o X : a-b+c -> b */
+#define HTKAMD_OUT_CENTRE     32     /* -o C */
+#define HTKAMD_OUT_NOMODELS   64     /* -o M */
+typedef struct htkamd_trans htkamd_trans;
+typedef struct htkamd_mlf_out htkamd_mlf_out;
+int  htkamd_trans_create(int maxAux, htkamd_trans **out);
+void htkamd_trans_free(htkamd_trans *t);
+int  htkamd_trans_add(htkamd_trans *t, double start, double end, const char *name, float score,
+                      const char *aux1, float aux1Score, const char *aux2, float aux2Score);
+int  htkamd_trans_format(htkamd_trans *t, double frameDur, int states, int models, int flags);
+int  htkamd_trans_write(const htkamd_trans *t, const char *path);
+int  htkamd_mlf_out_open(const char *path, htkamd_mlf_out **out);
+int  htkamd_mlf_out_add(htkamd_mlf_out *o, const char *labFile, const htkamd_trans *t);
+void htkamd_mlf_out_close(htkamd_mlf_out *o);
+
 /* ------------------------------------------------------------------------------------------
  * Transcriptions: HTK label files (LoadHTKLabels, HLabel.c:748) and master label files with immediate definitions
  * (LoadMasterFile, HLabel.c:1410).  "[start [end]] name [score] ..." per line, times in 100 ns; only the first

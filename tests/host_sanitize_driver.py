@@ -48,6 +48,16 @@ def main():
     open(mlf, "w").write('#!MLF!#\n"*/a.lab"\n0 100 x\n100 200 y 1.5\n///\n0 1 z\n.\n"*/b?.lab"\nw\n')
     ml = capi.Mlf(mlf)
     assert ml.find("dir/a.lab") is not None and ml.find("q/b1.lab") is not None and ml.find("nothing") is None
+    t = capi.Trans(2)
+    t.add(0, 300000, "a-b+c[2]", -10.0, aux1="a-b+c", aux1_score=-30.0, aux2="WORD", aux2_score=-2.5)
+    t.add(300000, 700000, "a-b+c[3]", -20.0)
+    t.add(700000, 900000, "'quoted", 0.0, aux1="x-y", aux1_score=0.0)
+    t.format(100000.0, states=True, models=True, flags="NXC")
+    t.write(os.path.join(tmp, "t.lab"))
+    o = capi.MlfOut(os.path.join(tmp, "o.mlf")); o.add("*/t.rec", t); o.close()
+    capi.Mlf(os.path.join(tmp, "o.mlf"))
+    t2 = capi.Trans(2); t2.add(0, 100, "s[2]", 1.0, aux1="m", aux1_score=2.0, aux2="w", aux2_score=3.0); t2.format(100000.0, True, True, "SWTM")
+    t2.write(os.path.join(tmp, "t2.lab"))
     scp = os.path.join(tmp, "x.scp")
     open(scp, "w").write('a.mfc "b c.mfc" u=p.mfc[3,9]\n')
     assert len(capi.scp_read(scp)) == 3

@@ -175,3 +175,24 @@ def test_script_files_and_extended_file_names(native, tmp_path):
             native.scp_read(str(tmp_path / bad))
     (tmp_path / "empty.scp").write_text("\n  \n")
     assert native.scp_read(str(tmp_path / "empty.scp")) == []
+
+
+def test_label_writer_columns_and_flags(native, tmp_path):
+    """SaveHTKLabels: a score column is written only if some label of the list has a non-zero score in it (then for every label);
+    times as "%.0f"; names that start with a quote are quoted; -o flags of FormatTranscription."""
+    t = native.Trans(1)
+    t.add(0, 1300000, "p1", -22.5, aux1="W1", aux1_score=0.0)
+    t.add(1300000, 2600000, "p2", 0.0)
+    t.add(2600000, 3000000, '"odd', -1.0, aux1="W2", aux1_score=0.0)
+    t.write(str(tmp_path / "a.lab"))
+    assert (tmp_path / "a.lab").read_text() == "0 1300000 p1 -22.500000 W1\n1300000 2600000 p2 0.000000\n2600000 3000000 \'\"odd\' -1.000000 W2\n"
+    t.format(100000.0, models=True, flags="NT")
+    t.write(str(tmp_path / "b.lab"))
+    assert (tmp_path / "b.lab").read_text().splitlines()[0] == "p1 %f W1" % np.float32(np.float32(-22.5) / 13)
+    t.format(100000.0, models=True, flags="SW")
+    t.write(str(tmp_path / "c.lab"))
+    assert (tmp_path / "c.lab").read_text() == "p1\np2\n\'\"odd\'\n"
+    o = native.MlfOut(str(tmp_path / "o.mlf")); o.add("*/x.rec", t); o.close()
+    assert (tmp_path / "o.mlf").read_text() == '#!MLF!#\n"*/x.rec"\np1\np2\n\'"odd\'\n.\n'
+    back = native.Mlf(str(tmp_path / "o.mlf")).find("dir/x.rec")
+    assert [l[0] for l in back] == ["p1", "p2", '"odd']
