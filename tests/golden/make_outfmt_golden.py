@@ -15,7 +15,8 @@ from htk_amd import synth  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
 OUT = os.path.join(HERE, "decode", "outfmt")
-CASES = {"loop": ["-o N", "-o S", "-o ST", "-o C", "-m -o W", "-m -o N", "-m"], "wint": ["-m -o X", "-m -o SWX", "-o TS"]}
+CASES = {"loop": ["-o N", "-o S", "-o ST", "-o C", "-m -o W", "-m -o N", "-m", "-f -m", "-f", "-f -m -o N", "-f -m -o M", "-f -m -o WS"],
+         "wint": ["-m -o X", "-m -o SWX", "-o TS", "-f -m -o X"]}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

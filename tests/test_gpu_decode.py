@@ -210,8 +210,8 @@ def test_word_level_forced_alignment_with_pronunciation_variants(native):
 
 
 def test_output_formatting_matches_hvite_mlf(native, tmp_path):
-    """HVite's -o flags (FormatTranscription), -m auxiliary labels and the master label file it writes with -i, through the C label
-    writer (htkamd_trans_* / htkamd_mlf_out_*): whole MLFs equal to the reference's, byte for byte."""
+    """HVite's -o flags (FormatTranscription), the -m / -f auxiliary labels and the master label file it writes with -i, through
+    the C label writer (htkamd_trans_* / htkamd_mlf_out_*): whole MLFs equal to the reference's, byte for byte."""
     from decode_util import GOLD
     from util import batch_arrays
     gold = os.path.join(GOLD, "outfmt")
@@ -219,34 +219,54 @@ def test_output_formatting_matches_hvite_mlf(native, tmp_path):
     for fn in sorted(os.listdir(gold)):
         case, optstr = fn[:-4].split("__")
         opts = optstr.replace("_", " ").split()
-        models = "-m" in opts
+        models, states = "-m" in opts, "-f" in opts
         flags = opts[opts.index("-o") + 1] if "-o" in opts else ""
         mmf, net, feats, _ = load_decode_case(native, case)
         model = native.Model(mmf.packed())
         dec = native.Decoder(model, net, lmScale=1.0)
         res = dec.run(feats, genBeam=250.0)
         al = None
-        if models:
+        if models or states:
             chains = [np.array([m for w in words for m in net.pron_models[w[0]]], np.int32) for words, _ in res]
             X, frameOff, labOff, labs = batch_arrays([dict(seq=c, feat=f) for c, f in zip(chains, feats)])
             dX = native.DevArray(X)
             al = native.Viterbi(model).align(dX.ptr.value, frameOff, labOff, labs, genBeam=250.0)
         out = native.MlfOut(str(tmp_path / fn))
         for u, (words, total) in enumerate(res):
-            t = native.Trans(1 if models else 0)
-            q = 0
+            t = native.Trans((1 if models else 0) + (1 if states else 0) if (models or states) else 0)
+            q = k0 = 0                                            # model index / first state slot of that model in the alignment
             for (w, s, e, sc), lm in zip(words, dec.last_lm[u]):
-                if models:
-                    for k, m in enumerate(net.pron_models[w]):
-                        aux = np.float32(np.float64(np.float32(np.float32(lm) * np.float32(1.0))) + np.float64(np.float32(0.0)))
-                        t.add(al[u]["modStart"][q] * 100000.0, al[u]["modEnd"][q] * 100000.0, mmf.phys_names[m], float(np.float32(al[u]["modScore"][q])),
-                              aux1=net.word_names[w] if k == 0 else None, aux1_score=float(aux) if k == 0 else 0.0)
-                        q += 1
-                elif net.out_syms[w] != "":
-                    t.add(s * 100000.0, e * 100000.0, net.out_syms[w], float(np.float32(sc)))
-            t.format(100000.0, states=False, models=models, flags=flags)
+                aux = float(np.float32(np.float64(np.float32(np.float32(lm) * np.float32(1.0))) + np.float64(np.float32(0.0))))
+                if not (models or states):
+                    if net.out_syms[w] != "":
+                        t.add(s * 100000.0, e * 100000.0, net.out_syms[w], float(np.float32(sc)))
+                    continue
+                for k, m in enumerate(net.pron_models[w]):
+                    word = net.word_names[w] if k == 0 else None
+                    name = mmf.phys_names[m]
+                    if not states:
+                        t.add(al[u]["modStart"][q] * 100000.0, al[u]["modEnd"][q] * 100000.0, name, float(np.float32(al[u]["modScore"][q])),
+                              aux1=word, aux1_score=aux if word else 0.0)
+                    else:
+                        first = True
+                        for j in range(al[u]["nStates"][q]):
+                            st, en = int(al[u]["segStart"][k0 + j]), int(al[u]["segEnd"][k0 + j])
+                            if st < 0:
+                                continue
+                            ssc = float(np.float32(al[u]["segScore"][k0 + j]))
+                            if models:
+                                t.add(st * 100000.0, en * 100000.0, "s%d" % (j + 2), ssc, aux1=name if first else None,
+                                      aux1_score=float(np.float32(al[u]["modScore"][q])) if first else 0.0,
+                                      aux2=word if first else None, aux2_score=aux if (first and word) else 0.0)
+                            else:
+                                t.add(st * 100000.0, en * 100000.0, "%s[%d]" % (name, j + 2), ssc, aux1=word if first else None,
+                                      aux1_score=aux if (first and word) else 0.0)
+                            first = False
+                    k0 += al[u]["nStates"][q]
+                    q += 1
+            t.format(100000.0, states=states, models=models, flags=flags)
             out.add("*/u%d.rec" % u, t)
         out.close()
         assert (tmp_path / fn).read_text() == open(os.path.join(gold, fn)).read(), fn
         n += 1
-    assert n == 10
+    assert n == 16
