@@ -272,9 +272,10 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
             int s = highest_set(keep & lane_range(0, startq - 1)) + 1;          // model numbers are lane+1
             if (s >= 1 && taperHiT < s) s = taperHiT;
             if (s < 1) { fail = 1; newHi = newLo = 1; }
-            else {
-               const int e = lowest_set(keep & lane_range(endq - 1, 63)) + 1;
-               if (e < 1 || e > s) { fail = 1; newHi = newLo = 1; }
+            else if ((keep >> (endq - 1)) & 1ull) { newHi = s; newLo = endq; }   // the bottom model survives: no test against s (the
+            else {                                                                 // taper may have pulled s below it, HFB.c:1259-1272)
+               const int e = lowest_set(keep & lane_range(endq, s - 1)) + 1;       // raise endq till thresh reached; passing s fails
+               if (e < 1) { fail = 1; newHi = newLo = 1; }
                else { newHi = s; newLo = e; }
             }
          }

@@ -56,13 +56,17 @@ def fuzz_fb(rng, it):
             bad.append("status u%d gpu %d oracle rc %d" % (u, st[u], rc))
         elif ok_o and abs(pr[u] - opr) > (1e-6 if mode else 1e-10) * abs(opr):
             bad.append("pr u%d %r vs %r" % (u, pr[u], opr))
-    tol = 2e-4 if mode else 1e-4
+    tol = 5e-4 if mode else 1e-4          # MFMA scores: posteriors near the MINFORPROB cut move by a few 1e-4 of small occupancies
     for k in ("muOcc", "wtOcc", "trOcc", "tr", "wt"):
         e = rel(a[k], getattr(oacc, k))
         if e > tol:
             bad.append("%s rel %.3g" % (k, e))
     if bad:
         print("FB  it %d general=%s mode=%d prune=%s: %s" % (it, general, mode, prune, "; ".join(bad)))
+        import pickle
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)             # keep the case for a closer look
+        pickle.dump(dict(pk=pk, utts=utts, prune=prune, general=general, mode=mode, bad=bad),
+                    open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_fb_%d.pkl" % it), "wb"))
     return not bad
 
 

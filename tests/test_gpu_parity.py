@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the reference's golden vectors and the oracle.
 Runs on the MI355X box:  python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 
@@ -501,3 +503,31 @@ def test_tied_mixture_components_accumulate_jointly(native, oracle):
     a = acc.download()
     for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
         acc_close(a[k], getattr(oacc, k), k)
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+def test_beta_beam_bottom_model_above_tapered_top(native, oracle, general):
+    """A case the randomised sweep found (tests/fuzz_parity.py): tight pruning with retries on a chain with tee models, where the
+    taper pulls the top of the beta beam BELOW its bottom model at t = 1.  The reference keeps that beam (qLo > qHi: its test
+    against the top only runs while the bottom is being raised, HFB.c:1259-1272) and then fails in the alpha pass (error 7390);
+    both kernel families must follow it -- same status, pr and beams as the oracle -- instead of retrying with a wider beam."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz", "alpha_prune_case.npz"))
+    pk = {k[3:]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("pk_")}
+    if pk["gconst"].size == 0:
+        pk["gconst"] = None
+    for k in ("vecSize", "numStates", "numComp", "numGauss", "numTrans", "numPhys"):
+        pk[k] = int(pk[k])
+    prune = dict(pruneInit=float(z["prune"][0]), pruneInc=float(z["prune"][1]), pruneLim=float(z["prune"][2]))
+    utts = [dict(seq=z["seq"], feat=z["feat"])]
+    model, fb, acc, pr, st = run_fb(native, pk, utts, prune, general=general)
+    om = oracle.Model(pk); oacc = oracle.Accs(om)
+    rc, opr, d = oracle.fb_utt(om, oracle.fb_cfg(**prune), z["feat"], z["seq"], oacc, dump=True)
+    assert rc == -7390 and st[0] == rc
+    g = fb.trellis(0, want_alpha=False)
+    assert np.array_equal(g["qLo"], d["qLo"]) and np.array_equal(g["qHi"], d["qHi"]) and g["qLo"][0] > g["qHi"][0]
+    a = acc.download()
+    assert a["nUttSkipped"] == 1 and a["nUttDone"] == 0 and not a["muOcc"].any()
+    # without pruning the utterance is fine on every path
+    model, fb, acc, pr, st = run_fb(native, pk, utts, general=general)
+    rc, opr, _ = oracle.fb_utt(om, oracle.fb_cfg(), z["feat"], z["seq"], oracle.Accs(om))
+    assert rc == 1 and st[0] == 1 and abs(pr[0] - opr) <= 1e-10 * abs(opr)
