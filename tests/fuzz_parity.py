@@ -23,8 +23,9 @@ def fuzz_fb(rng, it):
     if rng.random() < 0.5:
         pk, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=int(rng.choice([13, 26, 39])), NU=int(rng.integers(2, 7)))
     else:
-        s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 6)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
-                           int(rng.integers(30, 140)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 20, 39])))
+        big = rng.random() < 0.08                                   # now and then: long chains (up to 64 models, and beyond: general kernels)
+        s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 13)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
+                           int(rng.integers(600, 1000)) if big else int(rng.integers(30, 140)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 20, 39])))
         pk, seqs, feats = s.packed(), s.seqs, s.feats
     feats = [f[: max(3, len(f) - int(rng.integers(0, 10)))] for f in feats]          # ragged
     prune = {}
@@ -43,11 +44,16 @@ def fuzz_fb(rng, it):
     fb = capi.ForwardBackward(model, debug=False, force_general=general)
     acc = capi.Accs(model)
     fb.prepare(dX.ptr.value, frameOff, labOff, labs)
-    fb.execute(capi.fb_config(scoreMode=mode, **prune), acc)
+    extra = {}
+    if rng.random() < 0.3:
+        extra["minFrwdP"] = float(rng.choice([3.0, 5.0, 20.0, 40.0]))
+    if rng.random() < 0.3:
+        extra["uFlags"] = int(rng.integers(1, 16))
+    fb.execute(capi.fb_config(scoreMode=mode, **prune, **extra), acc)
     pr, st = fb.results()
     a = acc.download()
     oacc = pyoracle.Accs(om)
-    ocfg = pyoracle.fb_cfg(**prune)
+    ocfg = pyoracle.fb_cfg(**prune, **extra)
     bad = []
     for u, ut in enumerate(utts):
         rc, opr, _ = pyoracle.fb_utt(om, ocfg, ut["feat"], ut["seq"], oacc)
@@ -62,18 +68,23 @@ def fuzz_fb(rng, it):
         if e > tol:
             bad.append("%s rel %.3g" % (k, e))
     if bad:
-        print("FB  it %d general=%s mode=%d prune=%s: %s" % (it, general, mode, prune, "; ".join(bad)))
+        print("FB  it %d general=%s mode=%d prune=%s extra=%s: %s" % (it, general, mode, prune, extra, "; ".join(bad)))
         import pickle
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)             # keep the case for a closer look
-        pickle.dump(dict(pk=pk, utts=utts, prune=prune, general=general, mode=mode, bad=bad),
+        pickle.dump(dict(pk=pk, utts=utts, prune=prune, extra=extra, general=general, mode=mode, bad=bad),
                     open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_fb_%d.pkl" % it), "wb"))
     return not bad
 
 
 def fuzz_align(rng, it):
-    s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 5)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
-                       int(rng.integers(40, 150)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 39])))
-    pk = s.packed()
+    if rng.random() < 0.3:                                          # mixed topologies incl. a tee model
+        from types import SimpleNamespace
+        pk, _, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=int(rng.choice([13, 39])), NU=int(rng.integers(2, 6)))
+        s = SimpleNamespace(seqs=seqs, feats=feats)
+    else:
+        s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 5)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
+                           int(rng.integers(900, 1100)) if rng.random() < 0.05 else int(rng.integers(40, 150)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 39])))
+        pk = s.packed()
     beam = float(rng.choice([1.0e10, rng.uniform(5, 80)]))
     model = capi.Model(pk); om = pyoracle.Model(pk)
     utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(s.seqs, s.feats)]
