@@ -109,18 +109,30 @@ def fuzz_align(rng, it):
 
 
 def fuzz_decode(rng, it, tmp):
-    NP = int(rng.integers(6, 30))
-    s = synth.generate(int(rng.integers(20, 60)), int(rng.integers(1, 4)), NP, int(rng.integers(2, 5)), int(rng.integers(40, 120)), int(rng.integers(1, 10**6)), D=13)
     d = os.path.join(tmp, "d%d" % it); os.makedirs(d, exist_ok=True)
-    synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
-    names = ["p%d" % i for i in range(NP)]
+    tee = None
+    if rng.random() < 0.3:                                          # mixed topologies with the tee model "sp" closing some pronunciations
+        from types import SimpleNamespace
+        pkt, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=13, NU=int(rng.integers(2, 5)))
+        s = SimpleNamespace(seqs=seqs, feats=feats)
+        synth.write_mmf_packed(os.path.join(d, "MMF"), pkt, names)
+        NP = len(names); tee = names.index("sp")
+    else:
+        NP = int(rng.integers(6, 30))
+        s = synth.generate(int(rng.integers(20, 60)), int(rng.integers(1, 4)), NP, int(rng.integers(2, 5)), int(rng.integers(40, 120)), int(rng.integers(1, 10**6)), D=13)
+        synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
+        names = ["p%d" % i for i in range(NP)]
     open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
     V = int(rng.integers(3, 12))
     words = []
     with open(os.path.join(d, "dict"), "w") as f:
         for w in range(V):
             for v in range(int(rng.integers(1, 3))):
-                ph = [names[int(k)] for k in rng.integers(0, NP, size=int(rng.integers(1, 4)))]
+                if tee is None:
+                    ph = [names[int(k)] for k in rng.integers(0, NP, size=int(rng.integers(1, 4)))]
+                else:                                                 # real models, optionally closed by the tee model (never two tee models in a row)
+                    real = [k for k in range(NP) if k != tee]
+                    ph = [names[int(rng.choice(real))] for _ in range(int(rng.integers(1, 4)))] + (["sp"] if rng.random() < 0.6 else [])
                 pp = "" if rng.random() < 0.5 else "%.2f " % rng.uniform(0.1, 1.0)
                 f.write("W%d %s%s\n" % (w, pp, " ".join(ph)))
             words.append("W%d" % w)
