@@ -371,6 +371,15 @@ extern "C" void htkamd_decoder_destroy(htkamd_decoder *d)
    delete d;
 }
 
+// IsWd0Link (HNet.c:1663): the link leads to a word node, directly or through tee models
+static bool is_wd0_link(const htkamd_net_desc *nd, const std::vector<unsigned char> &tee, int dst)
+{
+   if (nd->kind[dst] != HTKAMD_NODE_HMM) return true;
+   if (!tee[dst]) return false;
+   for (int k = nd->linkOff[dst]; k < nd->linkOff[dst + 1]; k++) if (is_wd0_link(nd, tee, nd->linkDest[k])) return true;
+   return false;
+}
+
 static float like_to_word(const htkamd_net_desc *nd, const htkamd_model *m, const std::vector<unsigned char> &tee, int n, float scale)
 {
    float best = (float)LZERO;
@@ -467,7 +476,7 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
    levelOff[nLevels] = (int)levelNodes.size();
    for (int n = 0; n < nN; n++) {
       bool wd0 = false;
-      if (kind[n] == HTKAMD_NODE_HMM) for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) if (kind[nd->linkDest[k]] != HTKAMD_NODE_HMM) wd0 = true;
+      if (kind[n] == HTKAMD_NODE_HMM) for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) if (is_wd0_link(nd, tee, nd->linkDest[k])) wd0 = true;   // n_wd0 (HNet.c:3626-3631)
       if (wd0) wdlk[n] = like_to_word(nd, m, tee, n, lmScale);
    }
    std::vector<int4> nodeInfo(nN);

@@ -149,7 +149,11 @@ static int read_dict(const char *path, const struct htkamd_mmf *hmms, dpron **ou
             char *e; double v = strtod(t, &e);
             if (*e == 0 && (isdigit((unsigned char)t[0]) || t[0] == '.')) {
                if (v <= 0.0 || v > 1.0) { fclose(f); htkamd_set_error("%s:%d: pronunciation probability out of range", path, lineNo); return HTKAMD_EMODEL; }
-               d->prob = (float)log(v); free(t); continue;
+               /* the reference keeps the probability as a FLOAT before taking the log (ReadDictWord's `float v`, NewPron HDict.c:144-150),
+                  and treats anything below MINPRONPROB = 1e-6 as log-zero */
+               const float vf = (float)v;
+               d->prob = (vf >= 1.0E-6f) ? (float)log((double)vf) : (float)LZERO;
+               free(t); continue;
             }
          }
          if (d->nPhones + 1 > capP) { capP = capP * 2 + 8; d->phone = (int *)realloc(d->phone, sizeof(int) * (size_t)capP); d->phoneName = (char **)realloc(d->phoneName, sizeof(char *) * (size_t)capP); }

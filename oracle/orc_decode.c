@@ -65,6 +65,15 @@ static float like_to_word(const dnet *d, int n, float scale)
    return best;
 }
 
+/* IsWd0Link (HNet.c:1663): the link leads to a word node, directly or through tee models */
+static int is_wd0_link(const dnet *d, int dst)
+{
+   if (d->kind[dst] != KIND_HMM) return 1;
+   if (!d->tee[dst]) return 0;
+   for (int k = d->linkOff[dst]; k < d->linkOff[dst + 1]; k++) if (is_wd0_link(d, d->linkDest[k])) return 1;
+   return 0;
+}
+
 int orc_decode(const orc_model *m, const float *X, int T,
                int nNodes, const int *kind, const int *model, const float *pronProb,
                const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
@@ -114,7 +123,7 @@ int orc_decode(const orc_model *m, const float *X, int T,
    for (n = 0; n < nNodes; n++) {
       int wd0 = 0;
       if (kind[n] == KIND_HMM)
-         for (int k = linkOff[n]; k < linkOff[n + 1]; k++) if (kind[linkDest[k]] != KIND_HMM) wd0 = 1;   /* IsWd0Link */
+         for (int k = linkOff[n]; k < linkOff[n + 1]; k++) if (is_wd0_link(&d, linkDest[k])) wd0 = 1;   /* n_wd0 (HNet.c:3626-3631) */
       d.wdlk[n] = wd0 ? like_to_word(&d, n, lmScale) : (float)ORC_LZERO;
    }
 

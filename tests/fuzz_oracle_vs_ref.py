@@ -1,0 +1,185 @@
+"""Randomised check of the ORACLE against the reference's own binaries (CPU only; needs oracle/_ref, i.e. this container):
+   decode : random model sets / dictionaries (pronunciation variants, probabilities, tee model) / lattices / switches ->
+            the reference's HVite label files vs oracle.decode
+   fb     : random sets, utterances and pruning -> the reference HERest's per-utterance "Utterance prob per frame" trace and the
+            utterances it skips vs oracle.fb_utt
+The GPU sweep (tests/fuzz_parity.py) compares the HIP path with the oracle; this one keeps the oracle honest.
+    python tests/fuzz_oracle_vs_ref.py [iterations] [seed]"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from htk_amd import capi, synth  # noqa: E402   (host-side readers only: no GPU is touched)
+import pyoracle  # noqa: E402
+from decode_util import format_words  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def fuzz_decode(rng, it, tmp):
+    d = os.path.join(tmp, "d%d" % it); os.makedirs(d, exist_ok=True)
+    tee = None
+    if rng.random() < 0.4:
+        pk, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=13, NU=int(rng.integers(2, 4)))
+        s = SimpleNamespace(seqs=seqs, feats=feats)
+        synth.write_mmf_packed(os.path.join(d, "MMF"), pk, names)
+        NP = len(names); tee = names.index("sp")
+    else:
+        NP = int(rng.integers(6, 20))
+        s = synth.generate(int(rng.integers(20, 50)), int(rng.integers(1, 4)), NP, int(rng.integers(2, 4)), int(rng.integers(40, 100)), int(rng.integers(1, 10**6)), D=13)
+        synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
+        names = ["p%d" % i for i in range(NP)]
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    V = int(rng.integers(3, 10))
+    words = ["W%d" % w for w in range(V)]
+    with open(os.path.join(d, "dict"), "w") as f:
+        for w in range(V):
+            for v in range(int(rng.integers(1, 3))):
+                if tee is None:
+                    ph = [names[int(k)] for k in rng.integers(0, NP, size=int(rng.integers(1, 4)))]
+                else:
+                    real = [k for k in range(NP) if k != tee]
+                    ph = [names[int(rng.choice(real))] for _ in range(int(rng.integers(1, 4)))] + (["sp"] if rng.random() < 0.6 else [])
+                out = "" if rng.random() < 0.7 else ("[] " if rng.random() < 0.3 else "[o%d] " % w)
+                pp = "" if rng.random() < 0.5 else "%.2f " % rng.uniform(0.1, 1.0)
+                f.write("W%d %s%s%s\n" % (w, out, pp, " ".join(ph)))
+    arcs = []
+    for w in range(V):
+        arcs.append((0, 1 + w, float(np.log(1.0 / V))))
+        for k in rng.choice(V, size=min(V, 3), replace=False):
+            arcs.append((1 + w, 1 + int(k), float(np.log(rng.uniform(0.05, 0.5)))))
+        arcs.append((1 + w, V + 1, float(np.log(0.1))))
+    with open(os.path.join(d, "net.slf"), "w") as f:
+        f.write("VERSION=1.0\nN=%d L=%d\nI=0 W=!NULL\n" % (V + 2, len(arcs)))
+        for w in range(V):
+            f.write("I=%d W=%s\n" % (1 + w, words[w]))
+        f.write("I=%d W=!NULL\n" % (V + 1))
+        for j, (a_, b_, l) in enumerate(arcs):
+            f.write("J=%d S=%d E=%d l=%.4f\n" % (j, a_, b_, l))
+    p = dict(genBeam=float(rng.choice([1.0e10, round(rng.uniform(20, 200), 2)])), wordBeam=float(rng.choice([1.0e10, round(rng.uniform(10, 100), 2)])),
+             lmScale=float(rng.choice([1.0, round(rng.uniform(0.5, 8), 2)])), wordPen=float(rng.choice([0.0, round(rng.uniform(-20, 10), 2)])),
+             prScale=float(rng.choice([1.0, round(rng.uniform(0.5, 3), 2)])))
+    scp = []
+    for u, X in enumerate(s.feats):
+        fn = os.path.join(d, "u%d.mfc" % u)
+        synth.write_htk_param(fn, X, kind=9)
+        scp.append(fn)
+    open(os.path.join(d, "scp"), "w").write("\n".join(scp) + "\n")
+    open(os.path.join(d, "config"), "w").write("")
+    opts = []
+    if p["genBeam"] < 1e9: opts += ["-t", "%.2f" % p["genBeam"]]
+    if p["wordBeam"] < 1e9: opts += ["-v", "%.2f" % p["wordBeam"]]
+    opts += ["-s", "%.2f" % p["lmScale"], "-p", "%.2f" % p["wordPen"], "-r", "%.2f" % p["prScale"]]
+    mlf = os.path.join(d, "out.mlf")
+    r = subprocess.run([os.path.join(REF, "HVite"), "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-S", os.path.join(d, "scp"), "-i", mlf,
+                        "-w", os.path.join(d, "net.slf")] + opts + [os.path.join(d, "dict"), os.path.join(d, "hmmlist")], capture_output=True, text=True)
+    ref = {}
+    if os.path.exists(mlf):
+        cur = None
+        for line in open(mlf).read().splitlines()[1:]:
+            if line.startswith('"'):
+                cur = os.path.basename(line.strip('"')).replace(".rec", ""); ref[cur] = []
+            elif line == ".":
+                cur = None
+            elif cur is not None:
+                ref[cur].append(line)
+    mmf = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
+    net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
+    om = pyoracle.Model(mmf.packed())
+    ok = True
+    for u, X in enumerate(s.feats):
+        ow, ot = pyoracle.decode(om, X, net.arrays(), **p)
+        got = None if ow is None else format_words(ow, net.out_syms)
+        want = ref.get("u%d" % u)
+        if got != want and not (got is None and want is None):
+            # "No tokens survived" utterances: the reference writes no entry
+            ok = False
+            print("DECODE it %d u%d params %s rc %d\n  oracle %s\n  HVite  %s" % (it, u, p, r.returncode, got, want))
+    if not ok and os.environ.get("FUZZ_KEEP"):
+        import json, shutil
+        json.dump(p, open(os.path.join(d, "params.json"), "w"))
+        shutil.copytree(d, os.path.join(os.environ["FUZZ_KEEP"], "decode_%d" % it), dirs_exist_ok=True)
+    return ok
+
+
+def fuzz_fb(rng, it, tmp):
+    d = os.path.join(tmp, "f%d" % it); os.makedirs(os.path.join(d, "out"), exist_ok=True)
+    if rng.random() < 0.5:
+        pk, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=13, NU=int(rng.integers(2, 5)))
+    else:
+        s = synth.generate(int(rng.integers(20, 50)), int(rng.integers(1, 5)), int(rng.integers(8, 25)), int(rng.integers(2, 5)),
+                           int(rng.integers(30, 120)), int(rng.integers(1, 10**6)), D=13)
+        pk, seqs, feats = s.packed(), s.seqs, s.feats
+        names = ["p%d" % i for i in range(pk["numPhys"])]
+    feats = [f[: max(3, len(f) - int(rng.integers(0, 10)))] for f in feats]
+    synth.write_mmf_packed(os.path.join(d, "MMF"), pk, names)
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    scp = []
+    for u, (X, q) in enumerate(zip(feats, seqs)):
+        fn = os.path.join(d, "u%d.mfc" % u)
+        synth.write_htk_param(fn, X, kind=9); scp.append(fn)
+        open(os.path.join(d, "u%d.lab" % u), "w").write("\n".join(names[int(h)] for h in q) + "\n")
+    open(os.path.join(d, "config"), "w").write("")
+    prune, opts = {}, []
+    r_ = rng.random()
+    if r_ < 0.35:
+        t = round(float(rng.uniform(20, 200)), 2)
+        prune = dict(pruneInit=t, pruneInc=0.0, pruneLim=t); opts = ["-t", "%.2f" % t]
+    elif r_ < 0.6:
+        a, b, c = round(float(rng.uniform(1, 30)), 2), round(float(rng.uniform(5, 40)), 2), round(float(rng.uniform(60, 300)), 2)
+        prune = dict(pruneInit=a, pruneInc=b, pruneLim=c); opts = ["-t", "%.2f" % a, "%.2f" % b, "%.2f" % c]
+    r = subprocess.run([os.path.join(REF, "HERest"), "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-M", os.path.join(d, "out"), "-L", d, "-T", "1", "-m", "0"] +
+                       opts + [os.path.join(d, "hmmlist")] + scp, capture_output=True, text=True)
+    # per file: the LAST "Utterance prob per frame" after its "Processing Data" line, or a skip
+    per, cur = {}, None
+    for line in r.stdout.splitlines():
+        m = re.search(r"Processing Data: (\S+?)\.mfc", line)
+        if m:
+            cur = os.path.basename(m.group(1)); per[cur] = None
+        m = re.search(r"Utterance prob per frame = (\S+)", line)
+        if m and cur:
+            per[cur] = m.group(1)
+    crashed = r.returncode != 0
+    om = pyoracle.Model(pk); oacc = pyoracle.Accs(om); cfg = pyoracle.fb_cfg(**prune)
+    ok = True
+    for u, (X, q) in enumerate(zip(feats, seqs)):
+        rc, opr, _ = pyoracle.fb_utt(om, cfg, X, np.asarray(q, np.int32), oacc)
+        want = per.get("u%d" % u)
+        if rc in (1, -7390):                                   # -7390: the beta pass succeeded (prob printed), the alpha pass aborts the reference
+            got = "%e" % (opr / X.shape[0])
+            if want != got and not (crashed and want is None):
+                ok = False
+                print("FB it %d u%d prune %s: oracle rc %d %s, HERest %s (exit %d)" % (it, u, prune, rc, got, want, r.returncode))
+        elif want is not None and not crashed:
+            ok = False
+            print("FB it %d u%d prune %s: oracle rc %d, HERest printed %s" % (it, u, prune, rc, want))
+        if rc == -7390 and not crashed:
+            ok = False
+            print("FB it %d u%d: oracle says alpha failure, HERest finished normally" % (it, u))
+    return ok
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
+    if not os.path.exists(os.path.join(REF, "HVite")):
+        sys.exit("needs oracle/_ref (make -C oracle)")
+    res = dict(decode=[0, 0], fb=[0, 0])
+    with tempfile.TemporaryDirectory() as tmp:
+        for it in range(n):
+            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb)):
+                ok = fn(rng, it, tmp)
+                res[name][0] += 1; res[name][1] += int(ok)
+    print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})
+    sys.exit(0 if all(v[0] == v[1] for v in res.values()) else 1)
+
+
+if __name__ == "__main__":
+    main()
