@@ -23,6 +23,9 @@ def test_decoder_reproduces_hvite_label_files(native, oracle, case):
         dec = native.Decoder(model, net, lmScale=p["lmScale"])
         res = dec.run(feats, **p)
         for u, (words, total) in enumerate(res):
+            if "u%d" % u not in per:                                 # "No tokens survived": HVite writes no entry for the file
+                assert words is None and oracle.decode(om, feats[u], arrays, **p)[0] is None, (case, opts, u)
+                continue
             assert words is not None, (case, opts, u)
             assert format_words(words, net.out_syms) == per["u%d" % u], (case, opts, u)
             ow, ot = oracle.decode(om, feats[u], arrays, **p)

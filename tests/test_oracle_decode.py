@@ -21,6 +21,9 @@ def test_oracle_decode_reproduces_hvite(native, oracle, case):
             continue
         for u, X in enumerate(feats):
             words, total = oracle.decode(om, X, arrays, **parse_opts(opts))
+            if "u%d" % u not in per:                                 # "No tokens survived": HVite writes no entry for the file
+                assert words is None, (case, opts, u)
+                continue
             assert words is not None
             assert format_words(words, net.out_syms) == per["u%d" % u], (case, opts, u)
             n += len(words)

@@ -88,3 +88,15 @@ def test_mfcc_oracle_equals_hcopy(oracle, kind):
     mine = oracle.mfcc(x, oracle.mfcc_cfg(kind))
     assert period == 100000 and ref.shape == (298, mine.shape[1])
     assert np.array_equal(ref, mine)
+
+
+def test_randomised_sweep_against_the_reference_binaries():
+    """A short run of tests/fuzz_oracle_vs_ref.py: random model sets, dictionaries (pronunciation variants, probabilities, tee
+    model), lattices, switches and pruning -- the reference's HVite label files and HERest traces vs the oracle."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "HVite")):
+        pytest.skip("reference binaries not built (oracle/_ref)")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_oracle_vs_ref.py"), "12", "2024"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
