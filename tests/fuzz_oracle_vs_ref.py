@@ -3,6 +3,8 @@
             the reference's HVite label files vs oracle.decode
    fb     : random sets, utterances and pruning -> the reference HERest's per-utterance "Utterance prob per frame" trace and the
             utterances it skips vs oracle.fb_utt
+   align  : HVite -a -f -m label files (state and model level, tee models, beams) vs oracle.viterbi_align
+   update : the models a HERest pass writes (random -v / -w / -m) vs oracle F-B + oracle MLUpdateModels
 The GPU sweep (tests/fuzz_parity.py) compares the HIP path with the oracle; this one keeps the oracle honest.
     python tests/fuzz_oracle_vs_ref.py [iterations] [seed]"""
 import os
@@ -166,15 +168,103 @@ def fuzz_fb(rng, it, tmp):
     return ok
 
 
+def fuzz_align(rng, it, tmp):
+    """HVite -a -f -m (phone-level transcriptions, DoAlignment): state/model label lines vs oracle.viterbi_align."""
+    d = os.path.join(tmp, "a%d" % it); os.makedirs(d, exist_ok=True)
+    if rng.random() < 0.5:
+        pk, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=13, NU=int(rng.integers(2, 5)))
+        # a tee model as a WORD of its own is fatal in the reference when it is skipped ("LatFromPaths: Align have dur<=0"):
+        # the transcriptions keep the other five topologies (single-state, skip, tied state)
+        tee = names.index("sp")
+        seqs = [[h for h in q if h != tee] for q in seqs]
+    else:
+        s = synth.generate(int(rng.integers(20, 50)), int(rng.integers(1, 4)), int(rng.integers(8, 25)), int(rng.integers(2, 5)),
+                           int(rng.integers(40, 120)), int(rng.integers(1, 10**6)), D=13)
+        pk, seqs, feats = s.packed(), s.seqs, s.feats
+        names = ["p%d" % i for i in range(pk["numPhys"])]
+    synth.write_mmf_packed(os.path.join(d, "MMF"), pk, names)
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    open(os.path.join(d, "dict"), "w").write("".join("%s %s\n" % (n, n) for n in sorted(names)))
+    scp = []
+    for u, (X, q) in enumerate(zip(feats, seqs)):
+        fn = os.path.join(d, "u%d.mfc" % u)
+        synth.write_htk_param(fn, X, kind=9); scp.append(fn)
+        open(os.path.join(d, "u%d.lab" % u), "w").write("\n".join(names[int(h)] for h in q) + "\n")
+    open(os.path.join(d, "config"), "w").write("")
+    beam = float(rng.choice([1.0e10, round(float(rng.uniform(5, 80)), 2)]))
+    opts = ["-t", "%.2f" % beam] if beam < 1e9 else []
+    mlf = os.path.join(d, "out.mlf")
+    subprocess.run([os.path.join(REF, "HVite"), "-a", "-f", "-m", "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-L", d, "-i", mlf] + opts +
+                   [os.path.join(d, "dict"), os.path.join(d, "hmmlist")] + scp, capture_output=True, text=True)
+    ref, cur = {}, None
+    if os.path.exists(mlf):
+        for line in open(mlf).read().splitlines()[1:]:
+            if line.startswith('"'):
+                cur = os.path.basename(line.strip('"')).replace(".rec", ""); ref[cur] = []
+            elif line == ".":
+                cur = None
+            elif cur is not None:
+                ref[cur].append(line)
+    om = pyoracle.Model(pk)
+    ok = True
+    for u, (X, q) in enumerate(zip(feats, seqs)):
+        r = pyoracle.viterbi_align(om, X, np.asarray(q, np.int32), genBeam=beam)
+        got = None if r is None else pyoracle.format_rec(r, np.asarray(q, np.int32), names)
+        want = ref.get("u%d" % u)
+        if got != want:
+            ok = False
+            print("ALIGN it %d u%d beam %g\n  oracle %s\n  HVite  %s" % (it, u, beam, None if got is None else got[:4], None if want is None else want[:4]))
+    return ok
+
+
+def fuzz_update(rng, it, tmp):
+    """One HERest pass end to end: the models the reference writes vs oracle F-B + oracle MLUpdateModels (to the 7 printed digits)."""
+    d = os.path.join(tmp, "p%d" % it); os.makedirs(os.path.join(d, "out"), exist_ok=True)
+    s = synth.generate(int(rng.integers(10, 30)), int(rng.integers(1, 4)), int(rng.integers(5, 12)), int(rng.integers(6, 14)),
+                       int(rng.integers(60, 140)), int(rng.integers(1, 10**6)), D=13)
+    pk = s.packed()
+    names = ["p%d" % i for i in range(pk["numPhys"])]
+    synth.write_mmf_packed(os.path.join(d, "MMF"), pk, names)
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    scp = []
+    for u, (X, q) in enumerate(zip(s.feats, s.seqs)):
+        fn = os.path.join(d, "u%d.mfc" % u)
+        synth.write_htk_param(fn, X, kind=9); scp.append(fn)
+        open(os.path.join(d, "u%d.lab" % u), "w").write("\n".join(names[int(h)] for h in q) + "\n")
+    open(os.path.join(d, "config"), "w").write("")
+    minVar = float(rng.choice([0.0, 0.05, 0.5])); wf = float(rng.choice([0.0, 2.0, 5.0])); minEgs = int(rng.choice([1, 3]))
+    r = subprocess.run([os.path.join(REF, "HERest"), "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-M", os.path.join(d, "out"), "-L", d,
+                        "-v", "%g" % minVar, "-w", "%g" % wf, "-m", "%d" % minEgs, os.path.join(d, "hmmlist")] + scp, capture_output=True, text=True)
+    if r.returncode != 0:
+        print("UPDATE it %d: HERest failed: %s" % (it, r.stdout[-300:])); return False
+    pkr = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist")).packed()    # what the reference loaded (7 digits)
+    om = pyoracle.Model(pkr); oacc = pyoracle.Accs(om)
+    for X, q in zip(s.feats, s.seqs):
+        pyoracle.fb_utt(om, pyoracle.fb_cfg(), X, np.asarray(q, np.int32), oacc)
+    pyoracle.update(om, oacc, minEgs=minEgs, minVar=minVar, mixWeightFloor=wf * 1.0e-5, singleProcess=True)
+    ref = capi.Mmf(files=[os.path.join(d, "out", "MMF")], hmm_list=os.path.join(d, "hmmlist")).packed()
+    ok = True
+    for k, tol in (("mean", 2e-6), ("var", 2e-6), ("compWeight", 2e-6)):
+        a, b = np.asarray(getattr(om, k), np.float64).reshape(-1), np.asarray(ref[k], np.float64).reshape(-1)
+        e = np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3))
+        if e > tol:
+            ok = False; print("UPDATE it %d: %s differs by %.3g (minVar %g w %g m %d)" % (it, k, e, minVar, wf, minEgs))
+    lin = lambda v: np.where(np.asarray(v) > -0.5e10, np.exp(np.asarray(v, np.float64)), 0.0)
+    e = np.max(np.abs(lin(om.transP) - lin(ref["transP"])))
+    if e > 2e-6:
+        ok = False; print("UPDATE it %d: transP differs by %.3g" % (it, e))
+    return ok
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
     if not os.path.exists(os.path.join(REF, "HVite")):
         sys.exit("needs oracle/_ref (make -C oracle)")
-    res = dict(decode=[0, 0], fb=[0, 0])
+    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0])
     with tempfile.TemporaryDirectory() as tmp:
         for it in range(n):
-            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb)):
+            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update)):
                 ok = fn(rng, it, tmp)
                 res[name][0] += 1; res[name][1] += int(ok)
     print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})
