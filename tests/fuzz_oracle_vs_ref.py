@@ -38,13 +38,31 @@ def fuzz_decode(rng, it, tmp):
         s = synth.generate(int(rng.integers(20, 50)), int(rng.integers(1, 4)), NP, int(rng.integers(2, 4)), int(rng.integers(40, 100)), int(rng.integers(1, 10**6)), D=13)
         synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")
         names = ["p%d" % i for i in range(NP)]
-    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    wint = tee is None and rng.random() < 0.35                 # word-internal context expansion over a triphone-style logical list
+    phones4, ctx = ["a", "b", "c", "d"], None
+    if wint:
+        ctx = phones4 + (["sp"] if rng.random() < 0.5 else [])   # sp may or may not be somebody's context
+        with open(os.path.join(d, "hmmlist"), "w") as f:
+            f.write("\n".join(names) + "\n")
+            for x in phones4:
+                for l_ in [None] + ctx:
+                    for r_ in [None] + ctx:
+                        if l_ is None and r_ is None and rng.random() < 0.5:
+                            continue                               # the bare model is there only sometimes
+                        f.write("%s%s%s %s\n" % ("%s-" % l_ if l_ else "", x, "+%s" % r_ if r_ else "", names[int(rng.integers(0, NP))]))
+            f.write("sil %s\nsp %s\n" % (names[int(rng.integers(0, NP))], names[int(rng.integers(0, NP))]))
+    else:
+        open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
     V = int(rng.integers(3, 10))
     words = ["W%d" % w for w in range(V)]
     with open(os.path.join(d, "dict"), "w") as f:
         for w in range(V):
             for v in range(int(rng.integers(1, 3))):
-                if tee is None:
+                if wint:
+                    ph = [phones4[int(k)] for k in rng.integers(0, 4, size=int(rng.integers(2, 5)))] + (["sp"] if rng.random() < 0.6 else [])
+                    if w == 0:
+                        ph = ["sil"]
+                elif tee is None:
                     ph = [names[int(k)] for k in rng.integers(0, NP, size=int(rng.integers(1, 4)))]
                 else:
                     real = [k for k in range(NP) if k != tee]
