@@ -33,17 +33,29 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
    doneVa = (unsigned char *)calloc((size_t)m->G, 1);
 #define ACCF(off, idx) ((float)acc[(off) + (size_t)(idx)])
    if (cfg->singleProcess) {
-      size_t n = (size_t)m->G * D, z;
-      for (z = 0; z < n; z++) {
-         float v = var[z], iv;
-         if (v > 1E+30) v = 1E+30;
-         if (v < 1E-30) v = 1E-30;
-         iv = 1 / v;
-         if (iv > 1E+30) iv = 1E+30;
-         if (iv < 1E-30) iv = 1E-30;
-         var[z] = 1 / iv;
+      /* the conversions walk the set with an HMM scan: a state macro that no model uses keeps its values */
+      unsigned char *usedS = (unsigned char *)calloc((size_t)m->S, 1), *usedG = (unsigned char *)calloc((size_t)m->G, 1);
+      size_t z;
+      int g, s0;
+      for (h = 0; h < m->H; h++)
+         for (j = m->h_hmmStateOff[h]; j < m->h_hmmStateOff[h + 1]; j++) usedS[m->h_hmmState[j]] = 1;
+      for (s0 = 0; s0 < m->S; s0++)
+         if (usedS[s0]) for (c = m->h_stateCompOff[s0]; c < m->h_stateCompOff[s0 + 1]; c++) usedG[m->h_compGauss[c]] = 1;
+      for (g = 0; g < m->G; g++) {
+         if (!usedG[g]) continue;
+         for (z = (size_t)g * D; z < (size_t)(g + 1) * D; z++) {
+            float v = var[z], iv;
+            if (v > 1E+30) v = 1E+30;
+            if (v < 1E-30) v = 1E-30;
+            iv = 1 / v;
+            if (iv > 1E+30) iv = 1E+30;
+            if (iv < 1E-30) iv = 1E-30;
+            var[z] = 1 / iv;
+         }
       }
-      for (c = 0; c < m->C; c++) wgt[c] = exp(htkamd_host_mix_log_weight(wgt[c]));
+      for (s0 = 0; s0 < m->S; s0++)
+         if (usedS[s0]) for (c = m->h_stateCompOff[s0]; c < m->h_stateCompOff[s0 + 1]; c++) wgt[c] = exp(htkamd_host_mix_log_weight(wgt[c]));
+      free(usedS); free(usedG);
    }
    for (h = 0; h < m->H; h++) {
       const int n = (int)llround(acc[lay->nEgs + h]), ti = m->h_hmmTrans[h], N = m->h_transN[ti];

@@ -741,20 +741,35 @@ void orc_update(const orc_model *m, const orc_accs *acc, const orc_updcfg *cfg,
       /* HERest.c:1336-1339: the set is INVDIAGC with log weights at this point; ForceDiagC (HUtil.c:441)
          inverts the inverse variances again and ConvExpWt (HUtil.c:488) exponentiates the float log weights,
          so parameters that are NOT re-estimated come back through a float round trip. */
-      size_t n = (size_t)m->G * D, z;
-      for (z = 0; z < n; z++) {
-         float v = var[z], iv;
-         if (v > 1E+30) v = 1E+30;
-         if (v < 1E-30) v = 1E-30;
-         iv = 1 / v;
-         if (iv > 1E+30) iv = 1E+30;
-         if (iv < 1E-30) iv = 1E-30;
-         var[z] = 1 / iv;
+      /* ConvDiagC / ForceDiagC / ConvLogWt / ConvExpWt walk the set with an HMM scan: a state macro that no model uses is not
+         visited and keeps its values (and, in a file written afterwards, has no <GCONST>) */
+      unsigned char *usedS = (unsigned char *)calloc((size_t)m->S, 1), *usedG = (unsigned char *)calloc((size_t)m->G, 1);
+      size_t z;
+      int g;
+      for (h = 0; h < m->H; h++)
+         for (j = m->hmmStateOff[h]; j < m->hmmStateOff[h + 1]; j++) usedS[m->hmmState[j]] = 1;
+      for (i = 0; i < m->S; i++)
+         if (usedS[i]) for (c = m->stateCompOff[i]; c < m->stateCompOff[i + 1]; c++) usedG[m->compGauss[c]] = 1;
+      for (g = 0; g < m->G; g++) {
+         if (!usedG[g]) continue;
+         for (z = (size_t)g * D; z < (size_t)(g + 1) * D; z++) {
+            float v = var[z], iv;
+            if (v > 1E+30) v = 1E+30;
+            if (v < 1E-30) v = 1E-30;
+            iv = 1 / v;
+            if (iv > 1E+30) iv = 1E+30;
+            if (iv < 1E-30) iv = 1E-30;
+            var[z] = 1 / iv;
+         }
       }
-      for (c = 0; c < m->C; c++) {
-         float lw = orc_mix_log_weight(compWeight[c]);
-         compWeight[c] = exp(lw);
+      for (i = 0; i < m->S; i++) {
+         if (!usedS[i]) continue;
+         for (c = m->stateCompOff[i]; c < m->stateCompOff[i + 1]; c++) {
+            float lw = orc_mix_log_weight(compWeight[c]);
+            compWeight[c] = exp(lw);
+         }
       }
+      free(usedS); free(usedG);
    }
    for (h = 0; h < m->H; h++) {
       int n = acc->nEgs[h], ti = m->hmmTrans[h], N = m->transN[ti];
