@@ -5,6 +5,7 @@
             utterances it skips vs oracle.fb_utt
    align  : HVite -a -f -m label files (state and model level, tee models, beams) vs oracle.viterbi_align
    update : the models a HERest pass writes (random -v / -w / -m) vs oracle F-B + oracle MLUpdateModels
+   mfcc   : the file HCopy codes from a WAV under a random front-end configuration vs oracle.mfcc, every float
 The GPU sweep (tests/fuzz_parity.py) compares the HIP path with the oracle; this one keeps the oracle honest.
     python tests/fuzz_oracle_vs_ref.py [iterations] [seed]"""
 import os
@@ -286,15 +287,66 @@ def fuzz_update(rng, it, tmp):
     return ok
 
 
+def mfcc_case(rng):
+    """A random front-end configuration: (HCopy config text, keyword arguments of mfcc_cfg, TARGETKIND)."""
+    base = str(rng.choice(["0", "E"]))
+    quals = [base] + (["D"] + (["A"] if rng.random() < 0.6 else []) if rng.random() < 0.7 else []) + (["Z"] if rng.random() < 0.3 else [])
+    kind = "MFCC_" + "_".join(quals)
+    rate = int(rng.choice([8000, 16000]))
+    kw = dict(sampPeriod=1.0e7 / rate, winDur=float(rng.choice([200000.0, 250000.0, 320000.0])), frPeriod=float(rng.choice([100000.0, 80000.0, 125000.0])),
+              numChans=int(rng.choice([20, 24, 26, 40])), numCeps=int(rng.choice([8, 12, 13])), cepLifter=int(rng.choice([0, 22, 30])),
+              preEmph=float(rng.choice([0.0, 0.95, 0.97])), useHam=bool(rng.random() < 0.8), usePower=bool(rng.random() < 0.3),
+              zMeanSource=bool(rng.random() < 0.3), rawEnergy=bool(rng.random() < 0.6), eNormalise=bool(rng.random() < 0.6),
+              delWin=int(rng.choice([1, 2, 3])), accWin=int(rng.choice([1, 2])))
+    if rng.random() < 0.3:
+        kw["loFreq"], kw["hiFreq"] = float(rng.choice([64.0, 125.0, 300.0])), float(rng.choice([3400.0, 3800.0]))
+    if rng.random() < 0.2:
+        kw["silFloor"], kw["eScale"] = 40.0, 0.2
+    T = lambda b: "T" if b else "F"
+    cfg = ("SOURCEFORMAT = WAV\nTARGETKIND = %s\nWINDOWSIZE = %.1f\nTARGETRATE = %.1f\nNUMCHANS = %d\nNUMCEPS = %d\nCEPLIFTER = %d\nPREEMCOEF = %g\n"
+           "USEHAMMING = %s\nUSEPOWER = %s\nZMEANSOURCE = %s\nRAWENERGY = %s\nENORMALISE = %s\nDELTAWINDOW = %d\nACCWINDOW = %d\n"
+           % (kind, kw["winDur"], kw["frPeriod"], kw["numChans"], kw["numCeps"], kw["cepLifter"], kw["preEmph"], T(kw["useHam"]), T(kw["usePower"]),
+              T(kw["zMeanSource"]), T(kw["rawEnergy"]), T(kw["eNormalise"]), kw["delWin"], kw["accWin"]))
+    if "loFreq" in kw:
+        cfg += "LOFREQ = %g\nHIFREQ = %g\n" % (kw["loFreq"], kw["hiFreq"])
+    if "silFloor" in kw:
+        cfg += "SILFLOOR = %g\nESCALE = %g\n" % (kw["silFloor"], kw["eScale"])
+    return kind, kw, cfg, rate
+
+
+def fuzz_mfcc(rng, it, tmp):
+    """Waveform -> MFCC: the file the reference's HCopy codes from a WAV vs oracle.mfcc, every float."""
+    import wave
+    d = os.path.join(tmp, "m%d" % it); os.makedirs(d, exist_ok=True)
+    kind, kw, cfg, rate = mfcc_case(rng)
+    n = int(rng.integers(rate // 10, rate))
+    t = np.arange(n) / rate
+    x = (float(rng.uniform(500, 6000)) * np.sin(2 * np.pi * float(rng.uniform(100, 1500)) * t) * np.sin(2 * np.pi * 3 * t) + rng.normal(0, float(rng.uniform(50, 1500)), n))
+    x = x.clip(-32768, 32767).astype("<i2")
+    with wave.open(os.path.join(d, "x.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(rate); w.writeframes(x.tobytes())
+    open(os.path.join(d, "cfg"), "w").write(cfg)
+    r = subprocess.run([os.path.join(REF, "HCopy"), "-C", os.path.join(d, "cfg"), os.path.join(d, "x.wav"), os.path.join(d, "x.mfc")], capture_output=True, text=True)
+    if r.returncode != 0:
+        print("MFCC it %d: HCopy failed on %s: %s" % (it, cfg.replace("\n", " "), (r.stdout + r.stderr)[-300:])); return False
+    ref, _, _ = capi.parm_read(os.path.join(d, "x.mfc"))
+    got = pyoracle.mfcc(x, pyoracle.mfcc_cfg(kind, **kw))
+    if got.shape != ref.shape or not np.array_equal(got, ref):
+        bad = "shape %s vs %s" % (got.shape, ref.shape) if got.shape != ref.shape else "%d of %d values differ, max %.3g" % ((got != ref).sum(), got.size, np.abs(got - ref).max())
+        print("MFCC it %d: %s: %s" % (it, cfg.replace("\n", " "), bad))
+        return False
+    return True
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
     if not os.path.exists(os.path.join(REF, "HVite")):
         sys.exit("needs oracle/_ref (make -C oracle)")
-    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0])
+    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0], mfcc=[0, 0])
     with tempfile.TemporaryDirectory() as tmp:
         for it in range(n):
-            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update)):
+            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("mfcc", fuzz_mfcc)):
                 ok = fn(rng, it, tmp)
                 res[name][0] += 1; res[name][1] += int(ok)
     print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})

@@ -164,13 +164,38 @@ def fuzz_decode(rng, it, tmp):
     return ok
 
 
+def fuzz_mfcc(rng, it):
+    """Random front-end configurations (the sweep of fuzz_oracle_vs_ref.py pins the oracle to HCopy on the same family):
+    device MFCC of a ragged batch vs the oracle -- bit-equal but for the odd value where the device's double log() rounds the
+    other way (tolerance class of SURVEY App. A: 1e-4 relative, 1e-3 absolute floor)."""
+    from fuzz_oracle_vs_ref import mfcc_case
+    kind, kw, _, rate = mfcc_case(rng)
+    waves = []
+    for _ in range(int(rng.integers(1, 5))):
+        n = int(rng.integers(rate // 20, rate))
+        t = np.arange(n) / rate
+        x = float(rng.uniform(500, 6000)) * np.sin(2 * np.pi * float(rng.uniform(100, 1500)) * t) * np.sin(2 * np.pi * 3 * t) + rng.normal(0, float(rng.uniform(50, 1500)), n)
+        waves.append(x.clip(-32768, 32767).astype("<i2"))
+    got, frameOff = capi.Mfcc(capi.mfcc_config(kind, **kw)).compute_host(waves)
+    ocfg = pyoracle.mfcc_cfg(kind, **kw)
+    refs = [pyoracle.mfcc(w, ocfg) for w in waves]
+    ref = np.concatenate(refs) if refs else np.zeros((0, got.shape[1]), np.float32)
+    ok = list(frameOff) == list(np.concatenate([[0], np.cumsum([r.shape[0] for r in refs])])) and got.shape == ref.shape
+    ok = ok and bool(np.allclose(got, ref, rtol=1e-4, atol=1e-3)) and (ref.size == 0 or (got == ref).mean() > 0.995)
+    if not ok:
+        print("MFCC it %d %s %s: shapes %s %s, equal fraction %.5f, max abs %.3g" % (it, kind, kw, got.shape, ref.shape, (got == ref).mean() if got.shape == ref.shape and ref.size else -1,
+                                                                                   np.abs(got - ref).max() if got.shape == ref.shape and ref.size else -1))
+    return ok
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     tmp = tempfile.mkdtemp()
-    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0])
+    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0])
     for it in range(n):
-        for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp))):
+        for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp)),
+                         ("mfcc", lambda: fuzz_mfcc(rng, it))):
             try:
                 ok = fn()
             except Exception as e:  # noqa: BLE001
