@@ -5,6 +5,7 @@
             utterances it skips vs oracle.fb_utt
    align  : HVite -a -f -m label files (state and model level, tee models, beams) vs oracle.viterbi_align
    update : the models a HERest pass writes (random -v / -w / -m) vs oracle F-B + oracle MLUpdateModels
+   quals  : the qualifier step on parameter files (_D _A _T _Z, windows, V1COMPAT, SIMPLEDIFFS, very short files) vs oracle.parm_qualify
    mfcc   : the file HCopy codes from a WAV under a random front-end configuration vs oracle.mfcc, every float
 The GPU sweep (tests/fuzz_parity.py) compares the HIP path with the oracle; this one keeps the oracle honest.
     python tests/fuzz_oracle_vs_ref.py [iterations] [seed]"""
@@ -338,15 +339,48 @@ def fuzz_mfcc(rng, it, tmp):
     return True
 
 
+def quals_case(rng):
+    """Random qualifier step on a 13-column MFCC_E table: (TARGETKIND, oracle keyword arguments, HCopy config text)."""
+    q = ["D"] + (["A"] + (["T"] if rng.random() < 0.5 else []) if rng.random() < 0.7 else [])
+    z = rng.random() < 0.4
+    kind = "MFCC_E_" + "_".join(q) + ("_Z" if z else "")
+    kw = dict(hasD=True, hasA="A" in q, hasT="T" in q, delWin=int(rng.integers(1, 5)), accWin=int(rng.integers(1, 4)), thirdWin=int(rng.integers(1, 4)),
+              nZeroMean=12 if z else 0, v1Compat=bool(rng.random() < 0.25), simpleDiffs=bool(rng.random() < 0.25))
+    cfg = "TARGETKIND = %s\nDELTAWINDOW = %d\nACCWINDOW = %d\nTHIRDWINDOW = %d\nV1COMPAT = %s\nSIMPLEDIFFS = %s\n" % (
+        kind, kw["delWin"], kw["accWin"], kw["thirdWin"], "T" if kw["v1Compat"] else "F", "T" if kw["simpleDiffs"] else "F")
+    return kind, kw, cfg
+
+
+def fuzz_quals(rng, it, tmp):
+    """The qualifier step at load time (_D _A _T _Z, windows, V1COMPAT, SIMPLEDIFFS): the file HCopy writes from an MFCC_E file vs
+    oracle.parm_qualify, every float; short tables (fewer rows than the windows need) included."""
+    d = os.path.join(tmp, "q%d" % it); os.makedirs(d, exist_ok=True)
+    kind, kw, cfg = quals_case(rng)
+    T = int(rng.choice([1, 2, 3, 4, 5, 7, 9, int(rng.integers(10, 120))]))
+    X = rng.normal(0, 3, size=(T, 13)).astype(np.float32)
+    synth.write_htk_param(os.path.join(d, "x.mfc"), X, kind=6 | 0o100)          # MFCC_E
+    open(os.path.join(d, "cfg"), "w").write(cfg)
+    r = subprocess.run([os.path.join(REF, "HCopy"), "-C", os.path.join(d, "cfg"), os.path.join(d, "x.mfc"), os.path.join(d, "y.mfc")], capture_output=True, text=True)
+    if r.returncode != 0:
+        print("QUALS it %d: HCopy failed (%s, T=%d): %s" % (it, cfg.replace("\n", " "), T, (r.stdout + r.stderr)[-200:])); return False
+    ref, _, _ = capi.parm_read(os.path.join(d, "y.mfc"))
+    got = pyoracle.parm_qualify(X, **kw)
+    if got.shape != ref.shape or not np.array_equal(got, ref):
+        print("QUALS it %d: %s T=%d: %s" % (it, cfg.replace("\n", " "), T, "shape %s vs %s" % (got.shape, ref.shape) if got.shape != ref.shape else
+                                              "%d of %d values differ" % ((got != ref).sum(), got.size)))
+        return False
+    return True
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
     if not os.path.exists(os.path.join(REF, "HVite")):
         sys.exit("needs oracle/_ref (make -C oracle)")
-    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0], mfcc=[0, 0])
+    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0], mfcc=[0, 0], quals=[0, 0])
     with tempfile.TemporaryDirectory() as tmp:
         for it in range(n):
-            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("mfcc", fuzz_mfcc)):
+            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("mfcc", fuzz_mfcc), ("quals", fuzz_quals)):
                 ok = fn(rng, it, tmp)
                 res[name][0] += 1; res[name][1] += int(ok)
     print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})

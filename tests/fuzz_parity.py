@@ -188,14 +188,33 @@ def fuzz_mfcc(rng, it):
     return ok
 
 
+def fuzz_quals(rng, it):
+    """Random qualifier steps (the family fuzz_oracle_vs_ref.py pins against HCopy, plus _N) on ragged batches with very short
+    tables: htkamd_parm_qualify == oracle, bit for bit."""
+    from fuzz_oracle_vs_ref import quals_case
+    kind, kw, _ = quals_case(rng)
+    null = 12 if rng.random() < 0.3 else -1
+    utts = [rng.normal(0, 3, size=(int(rng.choice([1, 2, 3, 4, 5, 7, 9, int(rng.integers(10, 200))])), 13)).astype(np.float32) for _ in range(int(rng.integers(1, 6)))]
+    q = capi.ParmQuals(13, kw["nZeroMean"], 1, int(kw["hasA"]), int(kw["hasT"]), kw["delWin"], kw["accWin"], kw["thirdWin"], null, int(kw["v1Compat"]), int(kw["simpleDiffs"]))
+    d, frameOff, cols = capi.parm_qualify(utts, q)
+    got = d.to_host(np.float32, (int(frameOff[-1]), cols))
+    ok = True
+    for u, x in enumerate(utts):
+        ref = pyoracle.parm_qualify(x, nullECol=null, **kw)
+        if not np.array_equal(got[frameOff[u]:frameOff[u + 1]], ref):
+            ok = False
+            print("QUALS it %d %s %s null %d: utterance %d (T=%d) differs" % (it, kind, kw, null, u, x.shape[0]))
+    return ok
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     tmp = tempfile.mkdtemp()
-    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0])
+    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0], quals=[0, 0])
     for it in range(n):
         for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp)),
-                         ("mfcc", lambda: fuzz_mfcc(rng, it))):
+                         ("mfcc", lambda: fuzz_mfcc(rng, it)), ("quals", lambda: fuzz_quals(rng, it))):
             try:
                 ok = fn()
             except Exception as e:  # noqa: BLE001
