@@ -5,6 +5,7 @@
             utterances it skips vs oracle.fb_utt
    align  : HVite -a -f -m label files (state and model level, tee models, beams) vs oracle.viterbi_align
    update : the models a HERest pass writes (random -v / -w / -m) vs oracle F-B + oracle MLUpdateModels
+   mmf    : our MMF writer (text, binary) through the reference's HHEd and back; HHEd's binary through our reader
    quals  : the qualifier step on parameter files (_D _A _T _Z, windows, V1COMPAT, SIMPLEDIFFS, very short files) vs oracle.parm_qualify
    mfcc   : the file HCopy codes from a WAV under a random front-end configuration vs oracle.mfcc, every float
 The GPU sweep (tests/fuzz_parity.py) compares the HIP path with the oracle; this one keeps the oracle honest.
@@ -372,15 +373,81 @@ def fuzz_quals(rng, it, tmp):
     return True
 
 
+def fuzz_mmf(rng, it, tmp):
+    """Model files: what htkamd_mmf_write (text and binary) produces is read by the reference's HHEd and saved again -- the text
+    must come back byte for byte, the binary must load to the same numbers -- and what HHEd saves in binary is read back by
+    htkamd_mmf_read to the same arrays.  Random sets: tied states, 1-6 mixtures, mixed topologies with a tee model, defunct
+    mixture components (weight 0: left out of the file, HModel.c:3094)."""
+    import ctypes as C
+    d = os.path.join(tmp, "h%d" % it); os.makedirs(d, exist_ok=True)
+    if rng.random() < 0.4:
+        pk, names, _, _ = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=int(rng.choice([5, 13])), NU=1)
+    else:
+        NPm = int(rng.integers(3, 15))                               # every state macro in use: HHEd purges unused macros when it saves
+        s = synth.generate(int(rng.integers(3, 3 * NPm + 1)), int(rng.integers(1, 7)), NPm, 1, 10, int(rng.integers(1, 10**6)), D=int(rng.choice([3, 13, 26])))
+        pk = s.packed(); names = ["p%d" % i for i in range(pk["numPhys"])]
+        if len(set(int(x) for x in pk["hmmState"])) < pk["numStates"]:
+            return True                                               # (the generator left a state unused: not a case for this check)
+    synth.write_mmf_packed(os.path.join(d, "src.mmf"), pk, names)
+    lst = os.path.join(d, "hmmlist"); open(lst, "w").write("\n".join(names) + "\n")
+    m = capi.Mmf(files=[os.path.join(d, "src.mmf")], hmm_list=lst)
+    q = m.packed()
+    w = q["compWeight"].copy()
+    if rng.random() < 0.4:                                          # a defunct component in a state with several
+        cand = [i for i in range(q["numStates"]) if q["stateCompOff"][i + 1] - q["stateCompOff"][i] >= 2]
+        if cand:
+            st = int(rng.choice(cand)); c0, c1 = int(q["stateCompOff"][st]), int(q["stateCompOff"][st + 1])
+            w[c0 + int(rng.integers(0, c1 - c0))] = 0.0
+            w[c0:c1] /= w[c0:c1].sum()
+    def gconsts(var):                                                # HHEd fixes every gConst before it saves (FixAllGConsts)
+        g_ = np.empty(len(var), np.float32)
+        for i in range(len(var)):
+            x = np.zeros(1, np.float32)
+            capi.lib().htkamd_host_fix_diag_gconst(C.c_int(var.shape[1]), np.ascontiguousarray(var[i]).ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+            g_[i] = x[0]
+        return g_
+    g = gconsts(q["var"])
+    par = dict(mean=q["mean"], var=q["var"], gconst=g, compWeight=w, transP=q["transP"])
+    m.write(par, one_file=os.path.join(d, "ours.mmf"))
+    # the binary file from what the TEXT file holds (7 digits), which is all HHEd gets to see
+    m2 = capi.Mmf(files=[os.path.join(d, "ours.mmf")], hmm_list=lst)
+    q2 = m2.packed()
+    m2.write(dict(mean=q2["mean"], var=q2["var"], gconst=gconsts(q2["var"]), compWeight=q2["compWeight"], transP=q2["transP"]), one_file=os.path.join(d, "ours.bin"), binary=True)
+    open(os.path.join(d, "e.hed"), "w").close()
+    ok = True
+    for src, out, extra in (("ours.mmf", "ref_from_text.mmf", []), ("ours.bin", "ref_from_bin.mmf", []), ("ours.mmf", "ref.bin", ["-B"])):
+        r = subprocess.run([os.path.join(REF, "HHEd")] + extra + ["-H", os.path.join(d, src), "-w", os.path.join(d, out), os.path.join(d, "e.hed"), lst], capture_output=True, text=True)
+        if r.returncode != 0:
+            print("MMF it %d: HHEd failed on %s: %s" % (it, src, (r.stdout + r.stderr)[-300:])); return False
+    ours = open(os.path.join(d, "ours.mmf"), "rb").read()
+    for out in ("ref_from_text.mmf", "ref_from_bin.mmf"):
+        if open(os.path.join(d, out), "rb").read() != ours:
+            ok = False; print("MMF it %d: %s differs from the file we wrote" % (it, out))
+    if open(os.path.join(d, "ref.bin"), "rb").read() != open(os.path.join(d, "ours.bin"), "rb").read():
+        ok = False; print("MMF it %d: binary file differs from HHEd -B" % it)
+    a, b = capi.Mmf(files=[os.path.join(d, "ref.bin")], hmm_list=lst).packed(), capi.Mmf(files=[os.path.join(d, "ours.mmf")], hmm_list=lst).packed()
+    for k in ("mean", "var", "compWeight", "transP", "compGauss", "stateCompOff", "hmmState", "hmmTrans"):
+        if k in ("mean", "var", "compWeight", "transP"):
+            same = np.allclose(a[k], b[k], rtol=2e-7, atol=1e-30) if k != "transP" else np.allclose(np.exp(np.maximum(a[k], -80)), np.exp(np.maximum(b[k], -80)), rtol=1e-6, atol=1e-30)
+        else:
+            same = np.array_equal(a[k], b[k])
+        if not same:
+            ok = False; print("MMF it %d: %s differs between HHEd's binary and our text" % (it, k))
+    if not ok and os.environ.get("FUZZ_KEEP"):
+        import shutil
+        shutil.copytree(d, os.path.join(os.environ["FUZZ_KEEP"], "mmf_%d" % it), dirs_exist_ok=True)
+    return ok
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
     if not os.path.exists(os.path.join(REF, "HVite")):
         sys.exit("needs oracle/_ref (make -C oracle)")
-    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0], mfcc=[0, 0], quals=[0, 0])
+    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0], mfcc=[0, 0], quals=[0, 0], mmf=[0, 0])
     with tempfile.TemporaryDirectory() as tmp:
         for it in range(n):
-            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("mfcc", fuzz_mfcc), ("quals", fuzz_quals)):
+            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("mfcc", fuzz_mfcc), ("quals", fuzz_quals), ("mmf", fuzz_mmf)):
                 ok = fn(rng, it, tmp)
                 res[name][0] += 1; res[name][1] += int(ok)
     print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})
