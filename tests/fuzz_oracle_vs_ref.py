@@ -5,6 +5,8 @@
             utterances it skips vs oracle.fb_utt
    align  : HVite -a -f -m label files (state and model level, tee models, beams) vs oracle.viterbi_align
    update : the models a HERest pass writes (random -v / -w / -m) vs oracle F-B + oracle MLUpdateModels
+   acc    : the HER1.acc a `HERest -p 1` pass dumps (random pruning / update flags) vs the oracle's accumulators written by OUR
+            writer: the two files byte for byte
    mmf    : our MMF writer (text, binary) through the reference's HHEd and back; HHEd's binary through our reader
    quals  : the qualifier step on parameter files (_D _A _T _Z, windows, V1COMPAT, SIMPLEDIFFS, very short files) vs oracle.parm_qualify
    mfcc   : the file HCopy codes from a WAV under a random front-end configuration vs oracle.mfcc, every float
@@ -289,6 +291,63 @@ def fuzz_update(rng, it, tmp):
     return ok
 
 
+def fuzz_acc(rng, it, tmp):
+    """HERest -p 1 (accumulate and dump, HERest.c:600-640 + HTrain.c DumpAccs) vs oracle accumulators through htkamd_accs_dump_file."""
+    d = os.path.join(tmp, "a%d" % it); os.makedirs(os.path.join(d, "out"), exist_ok=True)
+    s = synth.generate(int(rng.integers(6, 20)), int(rng.integers(1, 4)), int(rng.integers(4, 10)), int(rng.integers(5, 12)),
+                       int(rng.integers(50, 120)), int(rng.integers(1, 10**6)), D=int(rng.choice([5, 13])))
+    pk0 = s.packed()
+    names = ["p%d" % i for i in range(pk0["numPhys"])]
+    synth.write_mmf_packed(os.path.join(d, "MMF"), pk0, names)
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    scp = []
+    for u, (X, q) in enumerate(zip(s.feats, s.seqs)):
+        fn = os.path.join(d, "u%d.mfc" % u)
+        synth.write_htk_param(fn, X, kind=9); scp.append(fn)
+        open(os.path.join(d, "u%d.lab" % u), "w").write("\n".join(names[int(h)] for h in q) + "\n")
+    open(os.path.join(d, "config"), "w").write("")
+    flagsel = str(rng.choice(["tmvw", "mv", "tw", "m", "tmv"]))
+    uFlags = sum({"m": capi.UPMEANS, "v": capi.UPVARS, "t": capi.UPTRANS, "w": capi.UPMIXES}[ch] for ch in flagsel)
+    prune = float(rng.choice([0.0, 60.0, 150.0]))
+    args = ["-u", flagsel] + (["-t", "%g" % prune] if prune > 0 else [])
+    r = subprocess.run([os.path.join(REF, "HERest"), "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-M", os.path.join(d, "out"), "-L", d,
+                        "-p", "1"] + args + [os.path.join(d, "hmmlist")] + scp, capture_output=True, text=True)
+    ref_acc = os.path.join(d, "out", "HER1.acc")
+    if r.returncode != 0 or not os.path.exists(ref_acc):
+        print("ACC it %d: HERest failed: %s" % (it, r.stdout[-300:])); return False
+    pk = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist")).packed()
+    om = pyoracle.Model(pk); oacc = pyoracle.Accs(om)
+    cfg = pyoracle.fb_cfg(uFlags=uFlags) if prune == 0 else pyoracle.fb_cfg(pruneInit=prune, pruneLim=prune, uFlags=uFlags)
+    totalPr, totalT = 0.0, 0
+    for X, q in zip(s.feats, s.seqs):
+        rc, pr, _ = pyoracle.fb_utt(om, cfg, X, np.asarray(q, np.int32), oacc)
+        if rc == 1:                                            # TRUE: the utterance was accumulated
+            totalPr += pr; totalT += X.shape[0]
+    lay = capi.accs_layout(pk)
+    v = np.zeros(lay.total, np.float64)
+    v[lay.totalPr], v[lay.totalT] = totalPr, totalT
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs"):
+        x = np.asarray(getattr(oacc, k), np.float64).reshape(-1)
+        off = getattr(lay, k); v[off:off + x.size] = x
+    ours = os.path.join(d, "ours.acc")
+    capi.accs_dump_file(pk, v, names, ours, uFlags)
+    a, b = open(ours, "rb").read(), open(ref_acc, "rb").read()
+    ok = a == b
+    if not ok:
+        w = np.zeros_like(v)
+        try:
+            capi.accs_load_file(pk, w, names, ref_acc, uFlags)
+            bad = [(k, float(np.max(np.abs(w[getattr(lay, k):getattr(lay, k) + np.asarray(getattr(oacc, k)).size] - np.asarray(getattr(oacc, k), np.float64).reshape(-1)))))
+                   for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs")]
+        except Exception as e:  # noqa: BLE001
+            bad = str(e)
+        print("ACC it %d: files differ (%d vs %d bytes, -u %s -t %g): %s" % (it, len(a), len(b), flagsel, prune, bad))
+        if os.environ.get("FUZZ_KEEP"):
+            import shutil
+            shutil.copytree(d, os.path.join(os.environ["FUZZ_KEEP"], "acc_%d" % it), dirs_exist_ok=True)
+    return ok
+
+
 def mfcc_case(rng):
     """A random front-end configuration: (HCopy config text, keyword arguments of mfcc_cfg, TARGETKIND)."""
     base = str(rng.choice(["0", "E"]))
@@ -444,10 +503,14 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
     if not os.path.exists(os.path.join(REF, "HVite")):
         sys.exit("needs oracle/_ref (make -C oracle)")
-    res = dict(decode=[0, 0], fb=[0, 0], align=[0, 0], update=[0, 0], mfcc=[0, 0], quals=[0, 0], mmf=[0, 0])
+    kinds = (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("acc", fuzz_acc), ("mfcc", fuzz_mfcc),
+             ("quals", fuzz_quals), ("mmf", fuzz_mmf))
+    if os.environ.get("FUZZ_KINDS"):                      # e.g. FUZZ_KINDS=acc,mmf
+        kinds = tuple(k for k in kinds if k[0] in os.environ["FUZZ_KINDS"].split(","))
+    res = {k[0]: [0, 0] for k in kinds}
     with tempfile.TemporaryDirectory() as tmp:
         for it in range(n):
-            for name, fn in (("decode", fuzz_decode), ("fb", fuzz_fb), ("align", fuzz_align), ("update", fuzz_update), ("mfcc", fuzz_mfcc), ("quals", fuzz_quals), ("mmf", fuzz_mmf)):
+            for name, fn in kinds:
                 ok = fn(rng, it, tmp)
                 res[name][0] += 1; res[name][1] += int(ok)
     print("passed/total:", {k: "%d/%d" % (v[1], v[0]) for k, v in res.items()})
