@@ -122,8 +122,12 @@ struct htkamd_fb {
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
-   DevBuf d_betaW;                          // wave path's beta block [frame][5][64]
-   bool lastWave;                           // the last execute ran the wave-per-utterance kernels (beta is in d_betaW)
+   DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
+   DevBuf d_uttList;                        // utterance numbers grouped by class: W = 1 | 2 | 4 | 8 | general
+   std::vector<int> uttList;
+   int clsOff[6];                           // class c occupies uttList[clsOff[c] .. clsOff[c+1])
+   size_t betaWTotal;
+   bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
@@ -137,7 +141,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; for (int c = 0; c < 6; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) {
       hipError_t e = hipEventCreate(&fb->ev[i]);
@@ -161,7 +165,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -227,14 +231,20 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
             while ((C.thrCell.size() - d.thr0) % 64) C.thrCell.push_back((short)-1);
          }
          d.nThr = (int)C.thrCell.size() - d.thr0;
+      }
+      // chains of up to 512 models of up to 5 states run on 1..8 wavefronts (fb_wave.hip); the others on the general kernels: one
+      // thread per model state, everything of a frame in LDS
+      const bool waveOk = fb->m->maxN <= 5 && !fb->forceGeneral && Q <= 512;
+      if (!waveOk) {
+         if (Q > 32000 || d.nThr > 1024) {
+            snprintf(C.err, sizeof(C.err), "fb_prepare: utterance %d has %d models / %d model states; the device path handles chains of up to 512 models of "
+                     "up to 5 states, or up to 1024 model states per utterance", u, Q, nCells);
+            return HTKAMD_EINVAL;
+         }
          if (d.nThr > C.nThrMax) C.nThrMax = d.nThr;
+         if (nCells > C.nCellsMax) C.nCellsMax = nCells;
+         if (Q > C.QMax) C.QMax = Q;
       }
-      if (Q > 32000 || d.nThr > 1024) {
-         snprintf(C.err, sizeof(C.err), "fb_prepare: utterance %d has %d model states; the device path handles up to 1024 per utterance", u, nCells);
-         return HTKAMD_EINVAL;
-      }
-      if (nCells > C.nCellsMax) C.nCellsMax = nCells;
-      if (Q > C.QMax) C.QMax = Q;
       if (T > C.TMax) C.TMax = T;
       C.outp += (size_t)T * nSlots; C.beta += (size_t)T * nCells; C.gam += (size_t)T * nSlots;
       if (d.status != HTKAMD_UTT_OK) return HTKAMD_OK;
@@ -382,6 +392,22 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    }
    fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
    fb->blockDim = nThrMax;
+   {  // classes: chains of <= 64 / 128 / 256 models of <= 5 states go to the wave kernels with 1 / 2 / 4 wavefronts, the rest to
+      // the general workgroup-per-utterance kernels
+      std::vector<int> cls[5];
+      size_t bw = 0;
+      for (int u = 0; u < U; u++) {
+         UttDesc &d = fb->utt[u];
+         const int W = (fb->m->maxN <= 5 && !fb->forceGeneral) ? (d.Q <= 64 ? 1 : d.Q <= 128 ? 2 : d.Q <= 256 ? 4 : d.Q <= 512 ? 8 : 0) : 0;
+         d.W = W; d.pad = 0; d.betaW0 = bw;
+         bw += (size_t)d.T * 5 * 64 * W;
+         cls[W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4].push_back(u);
+      }
+      fb->betaWTotal = bw;
+      fb->uttList.clear(); fb->clsOff[0] = 0;
+      for (int c = 0; c < 5; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
+      if (fb->uttList.empty()) fb->uttList.push_back(0);
+   }
 
    lap("merge");
    int rc;
@@ -397,7 +423,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_thrCell, fb->thrCell.data(), sizeof(short) * fb->thrCell.size(), 0}, {&fb->d_cI, fb->cI.data(), sizeof(short) * fb->cI.size(), 0},
          {&fb->d_taperLo, fb->taperLo.data(), sizeof(short) * fb->taperLo.size(), 0}, {&fb->d_taperHi, fb->taperHi.data(), sizeof(short) * fb->taperHi.size(), 0},
          {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
-         {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0}};
+         {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0},
+         {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -421,7 +448,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    }
    lap("stage+copy");
    // the wave-per-utterance kernels keep beta in their own state-major block (d_betaW, reserved in execute)
-   const bool wavePathPrep = (fb->m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
+   const bool wavePathPrep = fb->clsOff[5] == fb->clsOff[4];          // no utterance needs the general kernels
    const size_t nf = fb->totalFrames ? fb->totalFrames : 1;
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
@@ -484,7 +511,6 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    const size_t tm = (size_t)fb->TMax + 3;
    const size_t ldsAlpha = 2 * r8(nc * 8) + r8(3 * nc * 8) + r8(qm * 8) + r8(nc * (mn + 1) * 8) + ldsTab + r8(3 * nc * 4) +
                            2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + 2 * r8(tm * 2);
-   if (ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
 
    int rc;
    HIPCHECK(hipEventRecord(fb->ev[0], s));
@@ -492,16 +518,23 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
                                                    : htkamd_launch_score_exact(m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
    fb->scored = sa.nTasks > 0;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
-   const bool wavePath = (m->maxN <= 5) && (fb->QMax <= 64) && !fb->forceGeneral;
-   fb->lastWave = wavePath;
-   if (wavePath) {
-      if ((rc = fb->d_betaW.reserve(sizeof(double) * 5 * 64 * ((size_t)fb->totalFrames + 1)))) return rc;
-      fa.betaW = (double *)fb->d_betaW.p;
+   const int nGeneral = fb->clsOff[5] - fb->clsOff[4];
+   fb->lastWave = nGeneral == 0;
+   if (nGeneral > 0 && ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
+   if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 5 * 64)))) return rc;
+   fa.betaW = (double *)fb->d_betaW.p;
+   static const int clsW[4] = {1, 2, 4, 8};
+   // the longest chains first: their recursions are the critical path of the pass
+   for (int pass = 0; pass < 2; pass++) {
+      FbArgs fc = fa;
+      fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[4]; fc.nList = nGeneral;
+      if (nGeneral > 0 && (rc = pass == 0 ? htkamd_launch_beta(fc, fb->blockDim, ldsBeta, s) : htkamd_launch_alpha(fc, fb->blockDim, ldsAlpha, s))) return rc;
+      for (int c = 3; c >= 0; c--) {
+         fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[c]; fc.nList = fb->clsOff[c + 1] - fb->clsOff[c];
+         if ((rc = pass == 0 ? htkamd_launch_beta_w(fc, clsW[c], s) : htkamd_launch_alpha_w(fc, clsW[c], s))) return rc;
+      }
+      HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }
-   if ((rc = wavePath ? htkamd_launch_beta_w(fa, s) : htkamd_launch_beta(fa, fb->blockDim, ldsBeta, s))) return rc;
-   HIPCHECK(hipEventRecord(fb->ev[2], s));
-   if ((rc = wavePath ? htkamd_launch_alpha_w(fa, s) : htkamd_launch_alpha(fa, fb->blockDim, ldsAlpha, s))) return rc;
-   HIPCHECK(hipEventRecord(fb->ev[3], s));
    if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES))
       if ((rc = htkamd_launch_mixstats(fa, s))) return rc;
    HIPCHECK(hipEventRecord(fb->ev[4], s));
@@ -566,13 +599,14 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
    const size_t n = (size_t)T * Q * maxN;
    if (beta) {
       std::vector<double> b((size_t)T * nC);
-      if (fb->lastWave) {                                // the wave path's block [frame][state][lane] -> cells
-         std::vector<double> bs((size_t)T * 5 * 64);
-         HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + (size_t)d.frame0 * 5 * 64, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));
+      if (d.W > 0) {                                     // the wave path's block [frame][state][lane] -> cells
+         const size_t run = (size_t)64 * d.W;
+         std::vector<double> bs((size_t)T * 5 * run);
+         HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + d.betaW0, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));
          for (int t = 0; t < T; t++)
             for (int q = 1; q <= Q; q++)
                for (int i = 0; i < mN[q - 1]; i++)
-                  b[(size_t)t * nC + mC[q - 1] + i] = bs[((size_t)t * 5 + i) * 64 + (q - 1)];
+                  b[(size_t)t * nC + mC[q - 1] + i] = bs[((size_t)t * 5 + i) * run + (q - 1)];
       } else
       HIPCHECK(hipMemcpy(b.data(), (double *)fb->d_beta.p + d.beta0, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
       for (size_t k = 0; k < n; k++) beta[k] = NAN;

@@ -53,7 +53,7 @@ __global__ void k_beta(FbArgs a)
 {
    const int nCellsMax = a.nCellsMax, QMax = a.QMax;
    extern __shared__ double smem[];
-   const int u = blockIdx.x, tid = threadIdx.x;
+   const int u = a.uttList[blockIdx.x], tid = threadIdx.x;
    const UttDesc ud = a.utt[u];
    if (ud.status != HTKAMD_UTT_OK) {
       if (tid == 0) { a.status[u] = ud.status; a.pr[u] = LZERO; }
@@ -225,7 +225,7 @@ __global__ void k_alpha(FbArgs a)
 {
    const int nCellsMax = a.nCellsMax, QMax = a.QMax;
    extern __shared__ double smem[];
-   const int u = blockIdx.x, tid = threadIdx.x;
+   const int u = a.uttList[blockIdx.x], tid = threadIdx.x;
    const UttDesc ud = a.utt[u];
    if (a.status[u] != HTKAMD_UTT_OK) {                   // skipped in the beta pass (or pre-check)
       if (tid == 0) atomicAdd(a.acc + a.lay.nUttSkipped, 1.0);
@@ -698,7 +698,7 @@ int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s)
 {
    int rc = set_lds_limit((const void *)k_beta, lds);
    if (rc) return rc;
-   hipLaunchKernelGGL(k_beta, dim3(a.nUtt), dim3(blockDim), lds, s, a);
+   hipLaunchKernelGGL(k_beta, dim3(a.nList), dim3(blockDim), lds, s, a);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }
@@ -707,7 +707,7 @@ int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s
 {
    int rc = set_lds_limit((const void *)k_alpha, lds);
    if (rc) return rc;
-   hipLaunchKernelGGL(k_alpha, dim3(a.nUtt), dim3(blockDim), lds, s, a);
+   hipLaunchKernelGGL(k_alpha, dim3(a.nList), dim3(blockDim), lds, s, a);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }

@@ -1,8 +1,12 @@
 // fb_wave.hip -- K2w / K3w: beta and alpha passes with ONE WAVEFRONT PER UTTERANCE.
 //
 // Same reference semantics as fb_kernels.hip (SetBeta, StepAlpha, InitAlpha, MaxModelProb, SetOcct,
-// UpTranParms, UpMixParms seeds -- HFB.c, S==1) for utterances whose chain has at most 64 models of at most
-// MAXN states.  This is the fast path; fb_kernels.hip (one workgroup per utterance) stays as the general one.
+// UpTranParms, UpMixParms seeds -- HFB.c, S==1) for utterances whose chain has at most 64*W models (W = 1, 2, 4 or 8
+// wavefronts per utterance) of at most MAXN states.  This is the fast path; fb_kernels.hip (one workgroup per
+// utterance, cells in LDS) stays as the general one.  With W > 1 the wavefronts of an utterance exchange the few
+// values that cross a 64-model boundary (entry/exit values of the neighbouring models, beam ballots, the column
+// maximum) through LDS with one workgroup barrier per exchange (Grp<W> below); W = 1 compiles to plain wave
+// shuffles and ballots with no barrier at all.
 //
 // MI355X mapping.  The recursions are a T-step dependent chain with only ~Q-way parallelism per step, so what
 // limits them is the latency of one step, not throughput.  Here lane q of a 64-wide wavefront owns model q of
@@ -21,23 +25,127 @@
 #include "kernels.h"
 #include "ladd.h"
 
-#define WPB 4                 // wavefronts (utterances) per workgroup
+#define UPB(W) ((W) == 1 ? 4 : 1)   // utterances per workgroup: four single-wave utterances, or one multi-wave utterance
 #define EXPFLOOR (-100.0)     // see fb_kernels.hip
 
 #define ladd(x, y) ladd_tab((x), (y), mle, ltab)
 #define EXPT(x) exp_tab((x), etab)
 
-__device__ __forceinline__ double shfl_d(double v, int srcLane) { return __shfl(v, srcLane); }
 __device__ __forceinline__ int lowest_set(unsigned long long m) { return __ffsll((long long)m) - 1; }       // -1 if none
 __device__ __forceinline__ int highest_set(unsigned long long m) { return m ? 63 - __clzll((long long)m) : -1; }
 // lanes [lo..hi] (0-based, inclusive) as a mask
 __device__ __forceinline__ unsigned long long lane_range(int lo, int hi)
 {
-   if (hi < lo) return 0ull;
+   if (hi < lo || hi < 0 || lo > 63) return 0ull;
    const unsigned long long upTo = (hi >= 63) ? ~0ull : ((1ull << (hi + 1)) - 1);
    const unsigned long long below = (lo <= 0) ? 0ull : ((1ull << lo) - 1);
    return upTo & ~below;
 }
+
+// ---- the W wavefronts of one utterance as one group of 64*W "lanes" (group lane gl = 64*wave + lane holds model gl+1)
+template <int W> struct MaskW {                 // one bit per group lane
+   unsigned long long w[W];
+   __device__ __forceinline__ bool bit(int i) const { return W == 1 ? ((w[0] >> i) & 1ull) != 0 : ((w[(i >> 6) & (W - 1)] >> (i & 63)) & 1ull) != 0; }
+   __device__ __forceinline__ int highest() const
+   {
+#pragma unroll
+      for (int k = W - 1; k >= 0; k--) if (w[k]) return 64 * k + highest_set(w[k]);
+      return -1;
+   }
+   __device__ __forceinline__ int lowest() const
+   {
+#pragma unroll
+      for (int k = 0; k < W; k++) if (w[k]) return 64 * k + lowest_set(w[k]);
+      return -1;
+   }
+   __device__ __forceinline__ MaskW operator&(const MaskW &o) const { MaskW r; for (int k = 0; k < W; k++) r.w[k] = w[k] & o.w[k]; return r; }
+   __device__ __forceinline__ MaskW operator~() const { MaskW r; for (int k = 0; k < W; k++) r.w[k] = ~w[k]; return r; }
+   static __device__ __forceinline__ MaskW range(int lo, int hi)          // group lanes [lo..hi], 0-based inclusive
+   {
+      MaskW r;
+#pragma unroll
+      for (int k = 0; k < W; k++) r.w[k] = lane_range(lo - 64 * k, hi - 64 * k);
+      return r;
+   }
+};
+
+template <int W> struct Grp {
+   unsigned long long *x;      // LDS exchange slots [2][W][4]
+   float *a1;                  // LDS: a_1N of every model of the chain, [64*W]
+   int wave, lane, ph;
+   __device__ __forceinline__ unsigned long long *slot(int w) const { return x + ((ph * W + w) << 2); }
+   // value of group lane gl+d (d = 1 or 2); the last lanes of the last wave keep their own
+   __device__ __forceinline__ void down2(double v, double &r1, double &r2)
+   {
+      r1 = __shfl_down(v, 1); r2 = __shfl_down(v, 2);
+      if constexpr (W > 1) {
+         if (lane < 2) slot(wave)[lane] = (unsigned long long)__double_as_longlong(v);
+         __syncthreads();
+         if (wave + 1 < W) {
+            const unsigned long long *n = slot(wave + 1);
+            if (lane == 63) { r1 = __longlong_as_double((long long)n[0]); r2 = __longlong_as_double((long long)n[1]); }
+            if (lane == 62) r2 = __longlong_as_double((long long)n[0]);
+         }
+         ph ^= 1;
+      }
+   }
+   __device__ __forceinline__ void up2(double v, double &r1, double &r2)
+   {
+      r1 = __shfl_up(v, 1); r2 = __shfl_up(v, 2);
+      if constexpr (W > 1) {
+         if (lane >= 62) slot(wave)[lane - 62] = (unsigned long long)__double_as_longlong(v);
+         __syncthreads();
+         if (wave > 0) {
+            const unsigned long long *n = slot(wave - 1);
+            if (lane == 0) { r1 = __longlong_as_double((long long)n[1]); r2 = __longlong_as_double((long long)n[0]); }
+            if (lane == 1) r2 = __longlong_as_double((long long)n[1]);
+         }
+         ph ^= 1;
+      }
+   }
+   __device__ __forceinline__ double down1(double v) { double r1, r2; down2(v, r1, r2); return r1; }
+   __device__ __forceinline__ double up1(double v) { double r1, r2; up2(v, r1, r2); return r1; }
+   __device__ __forceinline__ double upBy2(double v) { double r1, r2; up2(v, r1, r2); return r2; }
+   __device__ __forceinline__ MaskW<W> ballot(bool p)
+   {
+      MaskW<W> r;
+      const unsigned long long b = __ballot(p);
+      if constexpr (W == 1) r.w[0] = b;
+      else {
+         if (lane == 0) slot(wave)[0] = b;
+         __syncthreads();
+#pragma unroll
+         for (int k = 0; k < W; k++) r.w[k] = slot(k)[0];
+         ph ^= 1;
+      }
+      return r;
+   }
+   __device__ __forceinline__ double maxall(double g)
+   {
+      for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
+      if constexpr (W > 1) {
+         if (lane == 0) slot(wave)[0] = (unsigned long long)__double_as_longlong(g);
+         __syncthreads();
+#pragma unroll
+         for (int k = 0; k < W; k++) g = fmax(g, __longlong_as_double((long long)slot(k)[0]));
+         ph ^= 1;
+      }
+      return g;
+   }
+   __device__ __forceinline__ double bcast(double v, int gl)              // value of group lane gl
+   {
+      if constexpr (W == 1) return __shfl(v, gl);
+      else {
+         if (wave == (gl >> 6) && lane == (gl & 63)) slot(0)[0] = (unsigned long long)__double_as_longlong(v);
+         __syncthreads();
+         const double r = __longlong_as_double((long long)slot(0)[0]);
+         ph ^= 1;
+         return r;
+      }
+   }
+   // a_1N of model gl+1: a wave shuffle of the lane's own value when there is one wave, the LDS copy otherwise
+   __device__ __forceinline__ float a1N_at(float mine, int gl) const { if constexpr (W == 1) return __shfl(mine, gl); else return a1[gl]; }
+};
 
 template <int MAXN> struct ModelRegs {
    int N, mc0, ms0;
@@ -100,48 +208,54 @@ template <int NE> struct ObsStage {
    }
 };
 
-// beta of the wave path: betaW[((frame0 + t-1)*MAXN + i-1)*64 + lane] -- one state of all models of a frame is one contiguous run,
+// beta of the wave path: betaW[betaW0 + ((t-1)*MAXN + i-1)*64*W + group lane] -- one state of all models of a frame is one contiguous run,
 // so the wave's store (beta pass) and load (alpha pass) of a state are coalesced
-#define BETA_W(t, i) (gbeta[((size_t)((t) - 1) * MAXN + ((i) - 1)) * 64])
+#define BETA_W(t, i) (gbeta[((size_t)((t) - 1) * MAXN + ((i) - 1)) * (64 * W)])
 
 // ------------------------------------------------------------------------------------ K2w: beta
-template <int MAXN>
-__global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
+template <int MAXN, int W>
+__global__ __launch_bounds__(64 * W * UPB(W)) void k_beta_w(FbArgs a)
 {
    __shared__ double ltab[LADD_TAB_DOUBLES];
-   __shared__ float stage[WPB][2 * (MAXN - 2) * 64 * 4];
+   __shared__ float stage[W * UPB(W)][2 * (MAXN - 2) * 64 * 4];
+   __shared__ unsigned long long gx[2 * W * 4];
+   __shared__ float ga1[64 * W];
    ladd_table_to_lds(ltab, a.laddTab);
    __syncthreads();
-   const int lane = threadIdx.x & 63;
-   const int u = blockIdx.x * WPB + (threadIdx.x >> 6);
-   if (u >= a.nUtt) return;
+   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;           // wave in block
+   const int li = blockIdx.x * UPB(W) + wib / W;                        // the block's utterance(s): all waves of a group leave together
+   if (li >= a.nList) return;
+   const int u = a.uttList[li];
+   Grp<W> g; g.x = gx; g.a1 = ga1; g.wave = wib % W; g.lane = lane; g.ph = 0;
+   const int gl = 64 * g.wave + lane;
    const UttDesc ud = a.utt[u];
    if (ud.status != HTKAMD_UTT_OK) {
-      if (lane == 0) { a.status[u] = ud.status; a.pr[u] = LZERO; }
+      if (gl == 0) { a.status[u] = ud.status; a.pr[u] = LZERO; }
       return;
    }
    const int T = ud.T, Q = ud.Q;
-   const int q = lane + 1;
+   const int q = gl + 1;
    const bool valid = q <= Q;
    ModelRegs<MAXN> m;
    load_model<MAXN>(m, a, ud, q, valid);
    const int N = m.N;
    const float a1N = m.aN[0];
+   if constexpr (W > 1) ga1[gl] = a1N;                   // read after the barrier of the first exchange below
    // neighbours' constants
-   const float a1N_n1 = __shfl_down(a1N, 1);                  // a_1N of model q+1 (LZERO-ish garbage beyond Q is masked below)
+   const float a1N_n1 = (float)g.down1((double)a1N);     // a_1N of model q+1 (LZERO-ish garbage beyond Q is masked below)
    const int dm = valid ? a.mDms[ud.q0 + q - 1] : 1;
-   const unsigned long long teeMask = __ballot(valid && dm == 0);        // bit (q-1) set when model q is a tee model
+   const MaskW<W> teeMask = g.ballot(valid && dm == 0);  // bit (q-1) set when model q is a tee model
 
    const short *tLo = a.taperLo + ud.frame0 - 1, *tHi = a.taperHi + ud.frame0 - 1;   // 1-based t
    short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;
    ObsStage<MAXN - 2> st;
-   st.lds = stage[threadIdx.x >> 6]; st.lane = lane;
+   st.lds = stage[wib]; st.lane = lane;
 #pragma unroll
    for (int j = 0; j < MAXN - 2; j++) {
       st.row[j] = (valid && j + 2 < N) ? a.outp + ud.outp0 + (size_t)(m.ms0 + j) * T : nullptr;   // rows of this model's emitting states
       st.R[j] = (f4u)(0.f);
    }
-   double *gbeta = a.betaW + (size_t)ud.frame0 * MAXN * 64 + lane;
+   double *gbeta = a.betaW + ud.betaW0 + gl;
    const double mle = a.minLogExp;
    const bool pruning = a.pruneInit < HTKAMD_NOPRUNE;
 
@@ -171,7 +285,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
          // exit chain: e(Q) = 0, e(q) = e(q+1) + a_1N(q+1)
          double e = 0.0, mine = 0.0;
          for (int k = Q; k >= endq; k--) {
-            if (k < Q) e = e + (double)__shfl(a1N, k);   // lane k holds model k+1
+            if (k < Q) e = e + (double)g.a1N_at(a1N, k);   // lane k holds model k+1
             if (q == k) mine = e;
          }
          if (valid && q >= endq) {
@@ -191,7 +305,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
             for (int i = 1; i <= MAXN; i++) if (i <= N) BETA_W(T, i) = bC[i];
          }
       }
-      if (lane == 0) { gLo[T] = (short)endq; gHi[T] = (short)Q; }
+      if (gl == 0) { gLo[T] = (short)endq; gHi[T] = (short)Q; }
       int qHiN = Q, qLoN = endq, lastEnd = endq;
       int nxtLo = (T >= 2) ? tLo[T - 1] : 1, nxtHi = (T >= 2) ? tHi[T - 1] : 1;
       bool stPrev = false, stIn = false; int tPrev = 0, loPrev = 1, hiPrev = 1;
@@ -213,7 +327,7 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
 #pragma unroll
                for (int i = 1; i <= MAXN; i++) if (i <= N) BETA_W(tPrev, i) = bP[i];
             }
-            if (lane == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
+            if (gl == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
             stPrev = false;
          }
 #pragma unroll
@@ -221,9 +335,10 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
          if (t >= 2) st.get(t - 2, obP);
          const int startq = qHiN;
          endq = (qLoN == 1) ? 1 : ((taperLoT >= qLoN) ? taperLoT : qLoN - 1);
-         while (endq > 1 && ((teeMask >> (endq - 2)) & 1ull)) endq--;
+         while (endq > 1 && teeMask.bit(endq - 2)) endq--;
          // neighbours' entry values of column t+1 (shuffles are executed by every lane)
-         const double e1 = __shfl_down(bP[1], 1), e2 = __shfl_down(bP[1], 2);
+         double e1, e2;
+         g.down2(bP[1], e1, e2);
          const bool inRange = valid && q >= endq && q <= startq;
          double lMax = LZERO;
          if (inRange) {
@@ -266,15 +381,14 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
             newHi = (taperHiT < startq) ? taperHiT : startq;
             newLo = endq;
          } else {                                        // beam pruning (HFB.c:1254-1272) on the lane mask
-            double g = inRange ? lMax : LZERO;
-            for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
-            const unsigned long long keep = __ballot(inRange && !(g - lMax > thresh));
-            int s = highest_set(keep & lane_range(0, startq - 1)) + 1;          // model numbers are lane+1
+            const double gmax = g.maxall(inRange ? lMax : LZERO);
+            const MaskW<W> keep = g.ballot(inRange && !(gmax - lMax > thresh));
+            int s = (keep & MaskW<W>::range(0, startq - 1)).highest() + 1;       // model numbers are lane+1
             if (s >= 1 && taperHiT < s) s = taperHiT;
             if (s < 1) { fail = 1; newHi = newLo = 1; }
-            else if ((keep >> (endq - 1)) & 1ull) { newHi = s; newLo = endq; }   // the bottom model survives: no test against s (the
+            else if (keep.bit(endq - 1)) { newHi = s; newLo = endq; }             // the bottom model survives: no test against s (the
             else {                                                                 // taper may have pulled s below it, HFB.c:1259-1272)
-               const int e = lowest_set(keep & lane_range(endq, s - 1)) + 1;       // raise endq till thresh reached; passing s fails
+               const int e = (keep & MaskW<W>::range(endq, s - 1)).lowest() + 1;   // raise endq till thresh reached; passing s fails
                if (e < 1) { fail = 1; newHi = newLo = 1; }
                else { newHi = s; newLo = e; }
             }
@@ -288,48 +402,54 @@ __global__ __launch_bounds__(64 * WPB) void k_beta_w(FbArgs a)
 #pragma unroll
             for (int i = 1; i <= MAXN; i++) if (i <= N) BETA_W(tPrev, i) = bC[i];
          }
-         if (lane == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
+         if (gl == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
       }
       if (!fail) {
-         pr = shfl_d(bC[1], lastEnd - 1);                // utt->pr = bqt[1] of the last model processed
+         pr = g.bcast(bC[1], lastEnd - 1);               // utt->pr = bqt[1] of the last model processed
          if (pr > LSMALL) { ok = 1; break; }
       }
       thresh += a.pruneInc;
       if (thresh > a.pruneLim || a.pruneInc == 0.0) break;
    }
-   if (lane == 0) {
+   if (gl == 0) {
       a.pr[u] = ok ? pr : LZERO;
       a.status[u] = ok ? HTKAMD_UTT_OK : HTKAMD_UTT_SKIPPED;
    }
 }
 
 // ------------------------------------------------------------------------------------ K3w: alpha + stats
-template <int MAXN>
-__global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
+template <int MAXN, int W>
+__global__ __launch_bounds__(64 * W * UPB(W)) void k_alpha_w(FbArgs a)
 {
    __shared__ double ltab[LADD_TAB_DOUBLES];
    __shared__ double etab[EXP_TAB_N];
+   __shared__ unsigned long long gx[2 * W * 4];
+   __shared__ float ga1[64 * W];
    ladd_table_to_lds(ltab, a.laddTab);
    exp_table_to_lds(etab);
    __syncthreads();
-   const int lane = threadIdx.x & 63;
-   const int u = blockIdx.x * WPB + (threadIdx.x >> 6);
-   if (u >= a.nUtt) return;
+   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+   const int li = blockIdx.x * UPB(W) + wib / W;
+   if (li >= a.nList) return;
+   const int u = a.uttList[li];
+   Grp<W> g; g.x = gx; g.a1 = ga1; g.wave = wib % W; g.lane = lane; g.ph = 0;
+   const int gl = 64 * g.wave + lane;
    const UttDesc ud = a.utt[u];
    if (a.status[u] != HTKAMD_UTT_OK) {                   // skipped in the beta pass (or pre-check)
-      if (lane == 0) atomicAdd(a.acc + a.lay.nUttSkipped, 1.0);
+      if (gl == 0) atomicAdd(a.acc + a.lay.nUttSkipped, 1.0);
       return;
    }
    const int T = ud.T, Q = ud.Q, nC = ud.nCells, nSlots = ud.nSlots;
-   const int q = lane + 1;
+   const int q = gl + 1;
    const bool valid = q <= Q;
    ModelRegs<MAXN> m;
    load_model<MAXN>(m, a, ud, q, valid);
    const int N = m.N;
    const float a1N = m.aN[0];
-   const float a1N_p1 = __shfl_up(a1N, 1);               // a_1N of model q-1
+   if constexpr (W > 1) ga1[gl] = a1N;
+   const float a1N_p1 = (float)g.up1((double)a1N);       // a_1N of model q-1
    const int dm = valid ? a.mDms[ud.q0 + q - 1] : 1;
-   const unsigned long long teeMask = __ballot(valid && dm == 0);
+   const MaskW<W> teeMask = g.ballot(valid && dm == 0);
    const int cHmm = valid ? a.mHmm[ud.q0 + q - 1] : 0, cTrans = valid ? a.mTrans[ud.q0 + q - 1] : 0;
    int cM[MAXN];                                          // mixture count of emitting state j
 #pragma unroll
@@ -345,7 +465,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
    const short *gLo = a.qLo + ud.frame0 - 1, *gHi = a.qHi + ud.frame0 - 1;    // final beta beam, 1-based t
    short *gaLo = a.aLo + ud.frame0 - 1, *gaHi = a.aHi + ud.frame0 - 1;
    const float *orow = a.outp + ud.outp0 + (size_t)m.ms0 * T;
-   const double *gbeta = a.betaW + (size_t)ud.frame0 * MAXN * 64 + lane;
+   const double *gbeta = a.betaW + ud.betaW0 + gl;
    double *gam = a.gam + ud.gam0 + m.ms0;
    const double mle = a.minLogExp, pr = a.pr[u];
    const double minF = (double)a.minFrwdP;
@@ -384,7 +504,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
    {
       double a1 = 0.0, mine = 0.0;
       for (int k = 1; k <= eq; k++) {
-         if (k > 1) a1 = a1 + (double)__shfl(a1N, k - 2);              // lane k-2 holds model k-1
+         if (k > 1) a1 = a1 + (double)g.a1N_at(a1N, k - 2);            // lane k-2 holds model k-1
          if (q == k) mine = a1;
       }
       if (valid && q <= eq) {
@@ -422,8 +542,8 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
       if (t > 1) {
          // ---- alpha beam (HFB.c:699-722) from MaxModelProb of column t-1, as lane masks
          // lo0/hi0 = beta beam of t-1, lo1/hi1 = beta beam of t
-         const unsigned long long pruneA = __ballot(valid && (pr - mmpA > minF));
-         int s = lowest_set(~pruneA & lane_range(lo0 - 1, 63)) + 1;     // first model >= qLo[t-1] that is kept
+         const MaskW<W> pruneA = g.ballot(valid && (pr - mmpA > minF));
+         int s = (~pruneA & MaskW<W>::range(lo0 - 1, 64 * W - 1)).lowest() + 1;     // first model >= qLo[t-1] that is kept
          // lanes beyond Q are "kept" (valid==false -> bit clear in pruneA), which mirrors running past the chain
          if (s < 1 || s > hi1) { err = 1; break; }
          if (s < lo1) s = lo1;
@@ -431,13 +551,13 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
          // MaxModelProb(e, t-1, minq = s): tee predecessors above the start point add alpha_N + beta_N of the model
          // before them (HFB.c:667-672).  exitSum of model q-2 arrives by shuffle.
          // exitSumLast = alpha_N(t-1) + beta_N(t-1) of this model (LZERO outside the beta beam), kept from step t-1
-         const double ex2 = __shfl_up(exitSumLast, 2);
+         const double ex2 = g.upBy2(exitSumLast);
          double mB = mmpA;
          if (valid && q >= 3 && (q - 1) > s && a1N_p1 > (float)LSMALL && ex2 > mB) mB = ex2;
-         const unsigned long long pruneB = __ballot(valid && (pr - mB > minF));
-         e = highest_set(~pruneB & lane_range(0, e - 1) & lane_range(0, Q - 1)) + 1;
+         const MaskW<W> pruneB = g.ballot(valid && (pr - mB > minF));
+         e = (~pruneB & MaskW<W>::range(0, e - 1) & MaskW<W>::range(0, Q - 1)).highest() + 1;
          if (e < 1 || e < s) { err = 1; break; }
-         while (e < Q && ((teeMask >> (e - 1)) & 1ull)) e++;
+         while (e < Q && teeMask.bit(e - 1)) e++;
          if (e > hi1) e = hi1;
          sq = s; eq = e;
          // ---- alpha column t (HFB.c:729-771)
@@ -446,7 +566,8 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
          double exP = LZERO;                             // alpha_N(t-1) of this model
 #pragma unroll
          for (int i = 1; i <= MAXN; i++) if (i == N) exP = aP[i];
-         const double exP1 = __shfl_up(exP, 1), exP2 = __shfl_up(exP, 2);
+         double exP1, exP2;
+         g.up2(exP, exP1, exP2);
          if (valid) {
             if (q < sq || q > eq) {
 #pragma unroll
@@ -489,21 +610,21 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
             }
          }
       }
-      if (lane == 0) { gaLo[t] = (short)sq; gaHi[t] = (short)eq; }
+      if (gl == 0) { gaLo[t] = (short)sq; gaHi[t] = (short)eq; }
       if (a.alphaDbg && valid) {
 #pragma unroll
          for (int i = 1; i <= MAXN; i++) if (i <= N) a.alphaDbg[ud.beta0 + (size_t)(t - 1) * nC + m.mc0 + i - 1] = aC[i];
       }
 
       // ---- statistics for column t (HFB.c:1790-1806) and MaxModelProb of column t
-      const double bEntryNext = __shfl_down(bT[1], 1);   // beta_1(q+1, t)
+      const double bEntryNext = g.down1(bT[1]);          // beta_1(q+1, t)
       double exitSumT = LZERO;                           // alpha_N(t) + beta_N(t) if this model is in the beta beam of t
       const bool inB = valid && q >= lo1 && q <= hi1;
       if (inB) {
 #pragma unroll
          for (int i = 1; i <= MAXN; i++) if (i == N) exitSumT = aC[i] + bT[i];
       }
-      const double exitSumPrev = __shfl_up(exitSumT, 1);
+      const double exitSumPrev = g.up1(exitSumT);
       {
          double mm = (q > 1) ? exitSumPrev : LZERO;      // HFB.c:662-666
          if (inB) {
@@ -594,13 +715,13 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
    }
 
    if (err) {
-      if (lane == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
+      if (gl == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
       return;
    }
    // ---- flush the per-model sums.  Models of an utterance usually share their transition matrix (always, in a
    // tied-transition system): then the counts are first summed over the lanes, so that an utterance issues ONE atomic
    // per matrix entry -- same-address f64 atomics serialise in L2, and 41 lanes x 1250 utterances on 15 addresses
-   // used to cost more than the whole recursion.
+   // used to cost more than the whole recursion.  (Each wavefront of a multi-wave utterance flushes its own 64 models.)
    if (wantTrans) {
       const int t0 = __shfl(cTrans, 0);
       const bool uniform = __all(!valid || cTrans == t0);
@@ -634,7 +755,7 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
       }
    }
    if (valid) atomicAdd(a.acc + a.lay.nEgs + cHmm, 1.0);
-   if (lane == 0) {
+   if (gl == 0) {
       atomicAdd(a.acc + a.lay.totalPr, pr);
       atomicAdd(a.acc + a.lay.totalT, (double)T);
       atomicAdd(a.acc + a.lay.nUttDone, 1.0);
@@ -642,16 +763,25 @@ __global__ __launch_bounds__(64 * WPB) void k_alpha_w(FbArgs a)
    }
 }
 
-int htkamd_launch_beta_w(const FbArgs &a, hipStream_t s)
+// a.uttList / a.nList: the utterances of one class (W wavefronts each)
+int htkamd_launch_beta_w(const FbArgs &a, int W, hipStream_t s)
 {
-   hipLaunchKernelGGL((k_beta_w<5>), dim3((a.nUtt + WPB - 1) / WPB), dim3(64 * WPB), 0, s, a);
+   if (a.nList <= 0) return HTKAMD_OK;
+   if (W == 1) hipLaunchKernelGGL((k_beta_w<5, 1>), dim3((a.nList + 3) / 4), dim3(256), 0, s, a);
+   else if (W == 2) hipLaunchKernelGGL((k_beta_w<5, 2>), dim3(a.nList), dim3(128), 0, s, a);
+   else if (W == 4) hipLaunchKernelGGL((k_beta_w<5, 4>), dim3(a.nList), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL((k_beta_w<5, 8>), dim3(a.nList), dim3(512), 0, s, a);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }
 
-int htkamd_launch_alpha_w(const FbArgs &a, hipStream_t s)
+int htkamd_launch_alpha_w(const FbArgs &a, int W, hipStream_t s)
 {
-   hipLaunchKernelGGL((k_alpha_w<5>), dim3((a.nUtt + WPB - 1) / WPB), dim3(64 * WPB), 0, s, a);
+   if (a.nList <= 0) return HTKAMD_OK;
+   if (W == 1) hipLaunchKernelGGL((k_alpha_w<5, 1>), dim3((a.nList + 3) / 4), dim3(256), 0, s, a);
+   else if (W == 2) hipLaunchKernelGGL((k_alpha_w<5, 2>), dim3(a.nList), dim3(128), 0, s, a);
+   else if (W == 4) hipLaunchKernelGGL((k_alpha_w<5, 4>), dim3(a.nList), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL((k_alpha_w<5, 8>), dim3(a.nList), dim3(512), 0, s, a);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }

@@ -51,11 +51,15 @@ struct UttDesc {
    size_t outp0;      // floats : outp[outp0 + slot*T + (t-1)]
    size_t beta0;      // doubles: beta[beta0 + (t-1)*nCells + cell]
    size_t gam0;       // doubles: gam [gam0  + (t-1)*nSlots + slot]
+   size_t betaW0;     // doubles: wave path's beta block of this utterance, betaW[betaW0 + ((t-1)*5 + i-1)*64*W + model-1]
+   int W, pad;        // wavefronts working on the utterance (1, 2, 4 or 8: chain of <= 64*W models); 0 = general kernels
 };
 
 struct FbArgs {
    const UttDesc *utt;
    int nUtt;
+   const int *uttList;               // the utterances this launch works on (one class: same W), and their number
+   int nList;
    // per-model tables (index q0 + q - 1)
    const int *mN, *mTp, *mCell0, *mSlot0, *mDms, *mHmm, *mTrans;
    // per-cell tables (index cell0 + c)
@@ -69,7 +73,7 @@ struct FbArgs {
    const float *transP;
    float *outp;
    double *beta, *gam, *alphaDbg;    // alphaDbg: NULL unless debugging, layout as beta
-   double *betaW;                    // wave path: beta as [(frame0 + t-1)][state 0..4][64 lanes] (coalesced per state)
+   double *betaW;                    // wave path: beta per utterance as [t-1][state 0..4][64*W lanes] from UttDesc::betaW0 (coalesced per state)
    double *pr;                       // [nUtt]
    int *status;                      // [nUtt]
    // model tables for the statistics kernel
@@ -92,7 +96,7 @@ int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s)
 int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
-int htkamd_launch_beta_w(const FbArgs &a, hipStream_t s);
-int htkamd_launch_alpha_w(const FbArgs &a, hipStream_t s);
+int htkamd_launch_beta_w(const FbArgs &a, int W, hipStream_t s);
+int htkamd_launch_alpha_w(const FbArgs &a, int W, hipStream_t s);
 
 #endif

@@ -28,6 +28,16 @@ def fuzz_fb(rng, it):
                            int(rng.integers(600, 1000)) if big else int(rng.integers(30, 140)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 20, 39])))
         pk, seqs, feats = s.packed(), s.seqs, s.feats
     feats = [f[: max(3, len(f) - int(rng.integers(0, 10)))] for f in feats]          # ragged
+    if rng.random() < 0.25:                                         # long chains: 2 / 4 / 8 wavefronts per utterance
+        nq, nx = [], []
+        for _ in range(int(rng.integers(2, 6))):
+            tgt = int(rng.choice([rng.integers(55, 75), rng.integers(120, 136), rng.integers(65, 260), rng.integers(250, 290), rng.integers(300, 440)]))
+            q, x = [], []
+            while sum(len(a) for a in q) < tgt:
+                k = int(rng.integers(0, len(seqs)))
+                q.append(np.asarray(seqs[k], np.int32)); x.append(feats[k])
+            nq.append(np.concatenate(q)); nx.append(np.concatenate(x))
+        seqs, feats = nq, nx
     prune = {}
     r = rng.random()
     if r < 0.35:
@@ -35,7 +45,7 @@ def fuzz_fb(rng, it):
         prune["pruneLim"] = prune["pruneInit"]
     elif r < 0.6:
         prune = dict(pruneInit=float(rng.uniform(1, 30)), pruneInc=float(rng.uniform(5, 40)), pruneLim=float(rng.uniform(60, 300)))
-    general = bool(rng.random() < 0.3)
+    general = bool(rng.random() < 0.3) and max(len(q) for q in seqs) <= 150     # the general kernels hold up to 1024 model states per utterance
     mode = int(rng.random() < 0.3 and pk["vecSize"] in (13, 26, 39))
     model = capi.Model(pk); om = pyoracle.Model(pk)
     utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(seqs, feats)]
@@ -55,16 +65,19 @@ def fuzz_fb(rng, it):
     oacc = pyoracle.Accs(om)
     ocfg = pyoracle.fb_cfg(**prune, **extra)
     bad = []
+    aborted = False
     for u, ut in enumerate(utts):
         rc, opr, _ = pyoracle.fb_utt(om, ocfg, ut["feat"], ut["seq"], oacc)
         ok_o = rc == 1
+        aborted |= rc == -7390                                      # the reference's HERest stops here (fatal error in the alpha pass), having
+                                                                    # accumulated part of the utterance: there is no accumulator state to compare
         if (st[u] == 1) != ok_o:
             bad.append("status u%d gpu %d oracle rc %d" % (u, st[u], rc))
         elif ok_o and abs(pr[u] - opr) > (1e-6 if mode else 1e-10) * abs(opr):
             bad.append("pr u%d %r vs %r" % (u, pr[u], opr))
     tol = 5e-4 if mode else 1e-4          # MFMA scores: posteriors near the MINFORPROB cut move by a few 1e-4 of small occupancies
     for k in ("muOcc", "wtOcc", "trOcc", "tr", "wt"):
-        e = rel(a[k], getattr(oacc, k))
+        e = 0.0 if aborted else rel(a[k], getattr(oacc, k))
         if e > tol:
             bad.append("%s rel %.3g" % (k, e))
     if bad:

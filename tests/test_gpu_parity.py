@@ -531,3 +531,57 @@ def test_beta_beam_bottom_model_above_tapered_top(native, oracle, general):
     model, fb, acc, pr, st = run_fb(native, pk, utts, general=general)
     rc, opr, _ = oracle.fb_utt(om, oracle.fb_cfg(), z["feat"], z["seq"], oracle.Accs(om))
     assert rc == 1 and st[0] == 1 and abs(pr[0] - opr) <= 1e-10 * abs(opr)
+
+
+# ----------------------------------------------------------------------------------------- long chains: 2 / 4 wavefronts per utterance
+def _concat_chains(rng, seqs, feats, targets):
+    """Utterances with chains of about `targets` models: whole utterances of the pool strung together (labels and frames)."""
+    out = []
+    for tgt in targets:
+        q, x = [], []
+        while sum(len(a) for a in q) < tgt:
+            k = int(rng.integers(0, len(seqs)))
+            q.append(np.asarray(seqs[k], np.int32)); x.append(feats[k])
+        out.append(dict(seq=np.concatenate(q), feat=np.concatenate(x)))
+    return out
+
+
+@pytest.mark.parametrize("prune", [None, dict(pruneInit=150.0, pruneInc=0.0, pruneLim=150.0), dict(pruneInit=30.0, pruneInc=60.0, pruneLim=400.0)],
+                         ids=["noprune", "beam", "retry"])
+@pytest.mark.parametrize("topo", [False, True], ids=["3state", "topo"])
+def test_long_chains_every_kernel_class(native, oracle, prune, topo):
+    """Chains of 40 .. 500 models in ONE batch: <= 64 models run on one wavefront, <= 128 on two, <= 256 on four, <= 512 on eight
+    (values that cross a 64-model boundary go through LDS).  Same pr, beams, beta/alpha and accumulators as the oracle."""
+    from htk_amd import synth
+    rng = np.random.default_rng(11 + int(topo))
+    if topo:
+        pk, names, seqs, feats = synth.make_topo_set(seed=77, D=13, NU=8)
+    else:
+        s = synth.generate(30, 3, 20, 12, 60, 4242, D=13)
+        pk, seqs, feats = s.packed(), s.seqs, s.feats
+    utts = _concat_chains(rng, seqs, feats, [40, 64, 66, 120, 128, 131, 200, 255, 258, 300, 500])
+    Qs = [len(u["seq"]) for u in utts]
+    assert min(Qs) <= 64 and any(64 < q <= 128 for q in Qs) and any(128 < q <= 256 for q in Qs) and 256 < max(Qs) <= 512
+    model, fb, acc, pr, st = run_fb(native, pk, utts, prune)
+    om = oracle.Model(pk); oacc = oracle.Accs(om); cfg = oracle.fb_cfg(**(prune or {}))
+    ndone = 0
+    for u, ut in enumerate(utts):
+        rc, opr, d = oracle.fb_utt(om, cfg, ut["feat"], ut["seq"], oacc, dump=True)
+        assert st[u] == rc, (u, Qs[u], st[u], rc)
+        if rc != 1:
+            continue
+        ndone += 1
+        assert abs(pr[u] - opr) <= 1e-10 * abs(opr), (u, Qs[u])
+        g = fb.trellis(u)
+        for k in ("qLo", "qHi", "aLo", "aHi"):
+            assert np.array_equal(g[k], d[k]), (k, u, Qs[u])
+        for k in ("beta", "alpha"):
+            ref, got = d[k], g[k]
+            ok = ~np.isnan(got) & ~np.isnan(ref) & (ref > -1e9)
+            assert ok.any() and np.allclose(got[ok], ref[ok], rtol=1e-10, atol=0), (k, u, Qs[u])
+    assert ndone >= 5
+    a = acc.download()
+    assert a["nUttDone"] == ndone
+    for k in ("muOcc", "wtOcc", "trOcc", "tr", "wt", "mu", "va"):
+        acc_close(a[k], getattr(oacc, k), k)
+    assert np.array_equal(a["nEgs"], oacc.nEgs)
