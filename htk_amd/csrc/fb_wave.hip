@@ -69,6 +69,11 @@ template <int W> struct MaskW {                 // one bit per group lane
    }
 };
 
+// Barrier of the utterance's wavefronts for the LDS exchange only.  __syncthreads() would also wait for every outstanding global
+// load (s_waitcnt vmcnt(0)), i.e. for the beta column and scores requested two frames ahead at the top of each step, and put the
+// HBM latency back into every step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int W> struct Grp {
    unsigned long long *x;      // LDS exchange slots [2][W][4]
    float *a1;                  // LDS: a_1N of every model of the chain, [64*W]
@@ -80,7 +85,7 @@ template <int W> struct Grp {
       r1 = __shfl_down(v, 1); r2 = __shfl_down(v, 2);
       if constexpr (W > 1) {
          if (lane < 2) slot(wave)[lane] = (unsigned long long)__double_as_longlong(v);
-         __syncthreads();
+         lds_barrier();
          if (wave + 1 < W) {
             const unsigned long long *n = slot(wave + 1);
             if (lane == 63) { r1 = __longlong_as_double((long long)n[0]); r2 = __longlong_as_double((long long)n[1]); }
@@ -94,7 +99,7 @@ template <int W> struct Grp {
       r1 = __shfl_up(v, 1); r2 = __shfl_up(v, 2);
       if constexpr (W > 1) {
          if (lane >= 62) slot(wave)[lane - 62] = (unsigned long long)__double_as_longlong(v);
-         __syncthreads();
+         lds_barrier();
          if (wave > 0) {
             const unsigned long long *n = slot(wave - 1);
             if (lane == 0) { r1 = __longlong_as_double((long long)n[1]); r2 = __longlong_as_double((long long)n[0]); }
@@ -113,7 +118,7 @@ template <int W> struct Grp {
       if constexpr (W == 1) r.w[0] = b;
       else {
          if (lane == 0) slot(wave)[0] = b;
-         __syncthreads();
+         lds_barrier();
 #pragma unroll
          for (int k = 0; k < W; k++) r.w[k] = slot(k)[0];
          ph ^= 1;
@@ -125,7 +130,7 @@ template <int W> struct Grp {
       for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o));
       if constexpr (W > 1) {
          if (lane == 0) slot(wave)[0] = (unsigned long long)__double_as_longlong(g);
-         __syncthreads();
+         lds_barrier();
 #pragma unroll
          for (int k = 0; k < W; k++) g = fmax(g, __longlong_as_double((long long)slot(k)[0]));
          ph ^= 1;
@@ -137,7 +142,7 @@ template <int W> struct Grp {
       if constexpr (W == 1) return __shfl(v, gl);
       else {
          if (wave == (gl >> 6) && lane == (gl & 63)) slot(0)[0] = (unsigned long long)__double_as_longlong(v);
-         __syncthreads();
+         lds_barrier();
          const double r = __longlong_as_double((long long)slot(0)[0]);
          ph ^= 1;
          return r;

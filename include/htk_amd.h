@@ -324,7 +324,9 @@ void htkamd_fb_destroy(htkamd_fb *fb);
 /* Test aid; call before prepare.  bit 0: keep every alpha column (T*cells doubles more per utterance);
    bit 1: force the general workgroup-per-utterance kernels even where the wave-per-utterance path applies. */
 int  htkamd_fb_set_debug(htkamd_fb *fb, int on);
-/* Host part of CreateInsts/SetBeamTaper for the whole batch + upload of the chain tables. */
+/* Host part of CreateInsts/SetBeamTaper for the whole batch + upload of the chain tables.
+   Limits per utterance: chains of up to 512 models when no model has more than 5 states, otherwise up to
+   1024 model states; an utterance beyond them fails the call with HTKAMD_EINVAL (nothing is truncated). */
 int  htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *batch, void *stream);
 /* Device part: scores, beta pass, alpha pass + statistics into `accs`. Asynchronous on `stream`. */
 int  htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream);
@@ -354,8 +356,8 @@ int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
  * [modStart, modEnd), modScore -- the numbers HVite prints as "start end s<j> score model score".
  * Token likelihoods are the same double additions in the same order as HRec's, on bit-exact output
  * probabilities, so segmentations are bit-identical to the reference's.
- * Restrictions of this path: <= 64 models per utterance, <= 5 states per model; general word
- * networks (HVite recognition mode) are not covered.
+ * Chains of <= 64 models of <= 5 states run one wavefront per utterance; longer chains and larger
+ * models a workgroup per utterance (same results).  Word networks: htkamd_decode_* below.
  * ------------------------------------------------------------------------------------------ */
 typedef struct htkamd_viterbi htkamd_viterbi;
 int  htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out);
