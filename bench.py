@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--phones", type=int, default=6000)
     ap.add_argument("--utts", type=int, default=1250, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
     ap.add_argument("--score", choices=["exact", "mfma"], default="mfma",
                     help="scoring arithmetic: exact = bit-identical to the reference (packed FP32 VALU); mfma = fp32 matrix-core GEMM, 1e-4 tolerance class")
     ap.add_argument("--two-streams", type=int, default=1, help="run the alternating batch contexts on their own streams (1) or on one stream (0)")
@@ -142,6 +143,11 @@ def main():
     fb = capi.ForwardBackward(model)
     cfg = capi.fb_config(scoreMode=1 if args.score == "mfma" else 0)                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
 
+    if args.ragged:                                      # not the headline workload: utterance lengths spread over [frames/2, frames], chains
+        rr = np.random.default_rng(77 + rank)            # spread likewise (one model per 12 frames), in random order within the batch
+        for u in range(len(s.feats)):
+            T = int(rr.integers(args.frames // 2, args.frames + 1))
+            s.feats[u] = s.feats[u][:T]; s.seqs[u] = s.seqs[u][: max(1, T // 12)]
     X = np.concatenate(s.feats)
     frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in s.feats])]).astype(np.int32)
     labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)

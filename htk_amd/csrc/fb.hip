@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
 #include <vector>
 #include <thread>
 #include <chrono>
@@ -404,6 +405,10 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          cls[W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4].push_back(u);
       }
       fb->betaWTotal = bw;
+      // within a class the longest utterances are dispatched first (their recursions are the critical path when the batch is larger
+      // than the 2048 wavefront slots of the machine), and the four single-wave utterances of a workgroup have similar lengths
+      for (int c = 0; c < 5; c++)
+         std::stable_sort(cls[c].begin(), cls[c].end(), [&](int x, int y) { return fb->utt[x].T > fb->utt[y].T; });
       fb->uttList.clear(); fb->clsOff[0] = 0;
       for (int c = 0; c < 5; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
       if (fb->uttList.empty()) fb->uttList.push_back(0);
