@@ -21,8 +21,9 @@
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
+#include "wavegrp.h"
 
-#define VWPB 4
+#define UPB(W) ((W) == 1 ? 4 : 1)   // utterances per workgroup: four single-wave utterances, or one multi-wave utterance
 #define VMAXN 5
 
 struct VitUtt {
@@ -36,6 +37,7 @@ struct VitUtt {
 
 struct VitArgs {
    const VitUtt *utt; int nUtt;
+   const int *uttList; int nList;          // the utterances of this launch (one class: same number of wavefronts per utterance)
    const int *mN, *mTp, *mSlot0;
    const float *transP, *outp;
    signed char *bp; double *pre;           // [sum T*nSlots]
@@ -46,16 +48,20 @@ struct VitArgs {
    float genBeam;
 };
 
-template <int MAXN>
-__global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
+template <int MAXN, int W>
+__global__ __launch_bounds__(64 * W * UPB(W)) void k_viterbi_w(VitArgs a)
 {
-   const int lane = threadIdx.x & 63;
-   const int u = blockIdx.x * VWPB + (threadIdx.x >> 6);
-   if (u >= a.nUtt) return;
+   __shared__ unsigned long long gx[2 * W * 8];
+   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+   const int li = blockIdx.x * UPB(W) + wib / W;         // all wavefronts of an utterance leave together
+   if (li >= a.nList) return;
+   const int u = a.uttList[li];
+   Grp<W> g; g.x = gx; g.a1 = nullptr; g.wave = wib % W; g.lane = lane; g.ph = 0;
+   const int gl = 64 * g.wave + lane;                    // group lane: model gl+1 of the chain
    const VitUtt ud = a.utt[u];
-   if (ud.status != HTKAMD_UTT_OK) { if (lane == 0) { a.status[u] = ud.status; a.total[u] = LZERO; } return; }
+   if (ud.status != HTKAMD_UTT_OK) { if (gl == 0) { a.status[u] = ud.status; a.total[u] = LZERO; } return; }
    const int T = ud.T, Q = ud.Q, nSlots = ud.nSlots;
-   const int q = lane + 1;
+   const int q = gl + 1;
    const bool valid = q <= Q;
    int N = 0, ms0 = 0;
    float tp[MAXN][MAXN];
@@ -69,12 +75,12 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
    if (valid) {
       const int mi = ud.q0 + q - 1;
       N = a.mN[mi]; ms0 = a.mSlot0[mi];
-      const float *g = a.transP + a.mTp[mi];
+      const float *gt = a.transP + a.mTp[mi];
 #pragma unroll
       for (int i = 0; i < MAXN; i++)
 #pragma unroll
          for (int j = 0; j < MAXN; j++)
-            if (i < N && j < N) tp[i][j] = g[i * N + j];
+            if (i < N && j < N) tp[i][j] = gt[i * N + j];
       // CreateSEIndex (HRec.c:1403-1431)
 #pragma unroll
       for (int j = 2; j <= MAXN; j++)
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
       }
    const float a1N = aN[1 % MAXN];
    const bool tee = valid && a1N > (float)LSMALL;
-   const unsigned long long teeMask = __ballot(tee);
+   const MaskW<W> teeMask = g.ballot(tee);
 
    const float *orow = a.outp + ud.outp0 + (size_t)ms0 * T;
    signed char *gbp = a.bp + ud.tr0 + ms0;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
                if (best > LSMALL) exitL = best; else { exitL = LZERO; exArg = 0; }
             }
          } else { exitL = LZERO; }
-         for (int o = 32; o > 0; o >>= 1) genMax = fmax(genMax, __shfl_xor(genMax, o));
+         genMax = g.maxall(genMax);
          genThresh = (float)(genMax - (double)a.genBeam);
          if (genThresh < (float)LSMALL) genThresh = (float)LSMALL;
       }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
       // A: candidates from the predecessor's pass-1 exit (valid wherever the predecessor is not a tee model)
       const bool selfAlive = valid && active && !(instMax < (double)genThresh);     // not detached on its own account
       double exOut = (selfAlive && exitL > (double)genThresh) ? exitL : LZERO;
-      double cand = __shfl_up(exOut, 1);
+      double cand = g.up1(exOut);
       if (q == 1) cand = (t == 0) ? 0.0 : LZERO;
       bool gotEntry = false;
       if (valid && cand > (double)genThresh) {
@@ -199,15 +205,24 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
          gotEntry = true;
       }
       // B: tee models in ascending order: entry -> exit within the frame (StepHMM2), then onward
-      unsigned long long tm = teeMask;
+      // With several wavefronts each one works through the tee models of its own 64 lanes with wave shuffles; only a tee model in
+      // the first or last lane of a wavefront involves the neighbouring wavefront (one LDS exchange, all wavefronts take part), and
+      // the ascending order across wavefronts is kept by exactly those exchanges.
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+      unsigned long long tm = teeMask.w[k];
       while (tm) {
-         const int tl = __ffsll((long long)tm) - 1;                   // lane of the tee model
+         const int tlw = __ffsll((long long)tm) - 1, tl = 64 * k + tlw;   // lane / group lane of the tee model
          tm &= tm - 1;
+         const bool mine = (W == 1) || g.wave == k;
          // the tee lane refreshes its entry from its predecessor's CURRENT exit (the predecessor may be a tee lane done earlier)
          const bool pAlive = valid && active && !(instMax < (double)genThresh);
          const double pOut = (pAlive && exitL > (double)genThresh) ? exitL : LZERO;
-         const double c2 = (tl == 0) ? ((t == 0) ? 0.0 : LZERO) : __shfl(pOut, tl - 1);
-         if (lane == tl) {
+         double c2;
+         if (tl == 0) c2 = (t == 0) ? 0.0 : LZERO;
+         else if (W > 1 && tlw == 0) c2 = g.bcast(pOut, tl - 1);
+         else c2 = __shfl(pOut, (tlw - 1) & 63);
+         if (mine && lane == tlw) {
             if (c2 > (double)genThresh) {
                if (!active) { active = true; instMax = LZERO; exitL = LZERO;
 #pragma unroll
@@ -224,8 +239,10 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
          // the model after the tee model sees the updated exit
          const bool tAlive = valid && active && !(instMax < (double)genThresh);
          const double tOut = (tAlive && exitL > (double)genThresh) ? exitL : LZERO;
-         const double c3 = __shfl(tOut, tl);
-         if (lane == tl + 1 && valid && !((teeMask >> lane) & 1ull) && c3 > (double)genThresh) {
+         const bool crossOut = W > 1 && tlw == 63 && k + 1 < W;           // the next model lives in the next wavefront
+         const double c3 = crossOut ? g.bcast(tOut, tl) : __shfl(tOut, tlw);
+         const bool consumer = crossOut ? (g.wave == k + 1 && lane == 0) : (mine && lane == tlw + 1);
+         if (consumer && valid && !teeMask.bit(gl) && c3 > (double)genThresh) {
             if (!active) { active = true; instMax = LZERO; exitL = LZERO;
 #pragma unroll
                for (int i = 0; i <= MAXN; i++) like[i] = LZERO; }
@@ -233,6 +250,7 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
             if (like[1] > instMax) instMax = like[1];
             gotEntry = true;
          }
+      }
       }
       // detach (HRec.c:2008-2011): nothing alive and nothing arrived
       if (valid && active && instMax < (double)genThresh) {
@@ -248,11 +266,11 @@ __global__ __launch_bounds__(64 * VWPB) void k_viterbi_w(VitArgs a)
       if (t == T) {
          const bool lastAlive = valid && active;
          const double fo = (lastAlive && exitL > (double)genThresh && exitL > LSMALL) ? exitL : LZERO;
-         finalLike = __shfl(fo, Q - 1);
+         finalLike = g.bcast(fo, Q - 1);
       }
       (void)gotEntry;
    }
-   if (lane == 0) {
+   if (gl == 0) {
       a.total[u] = finalLike;
       a.status[u] = (finalLike > LSMALL) ? HTKAMD_UTT_OK : HTKAMD_UTT_SKIPPED;
    }
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(VG_THREADS) void k_viterbi_g(VitArgs a)
    extern __shared__ double vsm[];
    __shared__ double red[VG_THREADS / 64];
    __shared__ float gthr;
-   const int u = blockIdx.x, tid = threadIdx.x;
+   const int u = a.uttList[blockIdx.x], tid = threadIdx.x;
    if (u >= a.nUtt) return;
    const VitUtt ud = a.utt[u];
    if (ud.status != HTKAMD_UTT_OK) { if (tid == 0) { a.status[u] = ud.status; a.total[u] = LZERO; } return; }
@@ -460,6 +478,7 @@ struct htkamd_viterbi {
    std::vector<int> mN, mTp, mSlot0, slotState;
    std::vector<ScoreTask> tasks;
    size_t segTotal, modTotal;
+   VBuf d_uttList;
    VBuf d_utt, d_mN, d_mTp, d_mSlot0, d_slotState, d_tasks, d_counter, d_outp, d_bp, d_pre, d_exl, d_ent, d_exbp;
    VBuf d_segStart, d_segEnd, d_segScore, d_modStart, d_modEnd, d_modScore, d_total, d_status;
 };
@@ -477,7 +496,7 @@ extern "C" int htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out)
 extern "C" void htkamd_viterbi_destroy(htkamd_viterbi *v)
 {
    if (!v) return;
-   VBuf *all[] = {&v->d_utt, &v->d_mN, &v->d_mTp, &v->d_mSlot0, &v->d_slotState, &v->d_tasks, &v->d_counter, &v->d_outp, &v->d_bp,
+   VBuf *all[] = {&v->d_uttList, &v->d_utt, &v->d_mN, &v->d_mTp, &v->d_mSlot0, &v->d_slotState, &v->d_tasks, &v->d_counter, &v->d_outp, &v->d_bp,
                   &v->d_pre, &v->d_exl, &v->d_ent, &v->d_exbp, &v->d_segStart, &v->d_segEnd, &v->d_segScore, &v->d_modStart,
                   &v->d_modEnd, &v->d_modScore, &v->d_total, &v->d_status};
    for (VBuf *b : all) b->release();
@@ -504,7 +523,9 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
    v->utt.assign(U, VitUtt());
    v->mN.clear(); v->mTp.clear(); v->mSlot0.clear(); v->slotState.clear(); v->tasks.clear();
    size_t outp = 0, tr = 0, mt = 0, seg = 0, mod = 0;
-   bool general = m->maxN > VMAXN;                       // long chains or big models: k_viterbi_g
+   // chains of up to 64 / 128 / 256 / 512 models of up to VMAXN states: 1 / 2 / 4 / 8 wavefronts per utterance (k_viterbi_w);
+   // longer chains or bigger models: a workgroup per utterance (k_viterbi_g)
+   std::vector<int> cls[5];
    int maxQ = 1;
    for (int u = 0; u < U; u++) {
       VitUtt &d = v->utt[u];
@@ -513,10 +534,13 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
       d.T = T; d.Q = Q; d.frame0 = b->frameOff[u]; d.q0 = (int)v->mN.size(); d.slot0 = (int)v->slotState.size();
       d.status = HTKAMD_UTT_OK; d.pad = 0; d.outp0 = outp; d.tr0 = tr; d.mt0 = mt; d.seg0 = seg; d.mod0 = mod;
       int nSlots = 0;
-      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nSlots = 0; continue; }
+      if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nSlots = 0; cls[0].push_back(u); continue; }   // the kernel reports it
       if (Q > 4000) { htkamd_set_error("viterbi_align: utterance %d has %d models (max 4000)", u, Q); return HTKAMD_EINVAL; }
-      if (Q > 64) general = true;
-      if (Q > maxQ) maxQ = Q;
+      {
+         const int c = (m->maxN > VMAXN) ? 4 : (Q <= 64 ? 0 : Q <= 128 ? 1 : Q <= 256 ? 2 : Q <= 512 ? 3 : 4);
+         cls[c].push_back(u);
+         if (c == 4 && Q > maxQ) maxQ = Q;
+      }
       for (int q = 1; q <= Q; q++) {
          const int h = labs[q - 1];
          if (h < 0 || h >= m->H) { htkamd_set_error("viterbi_align: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
@@ -537,7 +561,12 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
       outp += (size_t)T * nSlots; tr += (size_t)T * nSlots; mt += (size_t)(T + 1) * Q; seg += nSlots; mod += Q;
    }
    v->segTotal = seg; v->modTotal = mod;
+   int clsOff[6] = {0, 0, 0, 0, 0, 0};
+   std::vector<int> uttList;
+   for (int c = 0; c < 5; c++) { uttList.insert(uttList.end(), cls[c].begin(), cls[c].end()); clsOff[c + 1] = (int)uttList.size(); }
+   if (uttList.empty()) uttList.push_back(0);
    int rc;
+   if ((rc = vupload(v->d_uttList, uttList, s))) return rc;
    if ((rc = vupload(v->d_utt, v->utt, s)) || (rc = vupload(v->d_mN, v->mN, s)) || (rc = vupload(v->d_mTp, v->mTp, s)) ||
        (rc = vupload(v->d_mSlot0, v->mSlot0, s)) || (rc = vupload(v->d_slotState, v->slotState, s)) || (rc = vupload(v->d_tasks, v->tasks, s)))
       return rc;
@@ -568,12 +597,21 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
    va.modStart = (int *)v->d_modStart.p; va.modEnd = (int *)v->d_modEnd.p; va.modScore = (double *)v->d_modScore.p;
    va.total = (double *)v->d_total.p; va.status = (int *)v->d_status.p;
    va.genBeam = genBeam;
-   if (!general) hipLaunchKernelGGL((k_viterbi_w<VMAXN>), dim3((U + VWPB - 1) / VWPB), dim3(64 * VWPB), 0, s, va);
-   else {
+   for (int c = 3; c >= 0; c--) {                        // the longest chains first
+      va.uttList = (const int *)v->d_uttList.p + clsOff[c]; va.nList = clsOff[c + 1] - clsOff[c];
+      if (va.nList <= 0) continue;
+      if (c == 0) hipLaunchKernelGGL((k_viterbi_w<VMAXN, 1>), dim3((va.nList + 3) / 4), dim3(256), 0, s, va);
+      else if (c == 1) hipLaunchKernelGGL((k_viterbi_w<VMAXN, 2>), dim3(va.nList), dim3(128), 0, s, va);
+      else if (c == 2) hipLaunchKernelGGL((k_viterbi_w<VMAXN, 4>), dim3(va.nList), dim3(256), 0, s, va);
+      else hipLaunchKernelGGL((k_viterbi_w<VMAXN, 8>), dim3(va.nList), dim3(512), 0, s, va);
+      HIPCHECK(hipGetLastError());
+   }
+   va.uttList = (const int *)v->d_uttList.p + clsOff[4]; va.nList = clsOff[5] - clsOff[4];
+   if (va.nList > 0) {
       const size_t lds = sizeof(double) * ((size_t)maxQ * (m->maxN + 1) + 2 * (size_t)maxQ) + 2 * (size_t)maxQ + 64;
       if (lds > 150 * 1024) { htkamd_set_error("viterbi_align: %d models of up to %d states need %zu bytes of LDS", maxQ, m->maxN, lds); return HTKAMD_EMODEL; }
       if (lds > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void *)k_viterbi_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_viterbi_g, dim3(U), dim3(VG_THREADS), lds, s, va);
+      hipLaunchKernelGGL(k_viterbi_g, dim3(va.nList), dim3(VG_THREADS), lds, s, va);
    }
    HIPCHECK(hipGetLastError());
    hipLaunchKernelGGL(k_viterbi_trace, dim3((U + 63) / 64), dim3(64), 0, s, va);

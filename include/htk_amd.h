@@ -356,7 +356,7 @@ int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
  * [modStart, modEnd), modScore -- the numbers HVite prints as "start end s<j> score model score".
  * Token likelihoods are the same double additions in the same order as HRec's, on bit-exact output
  * probabilities, so segmentations are bit-identical to the reference's.
- * Chains of <= 64 models of <= 5 states run one wavefront per utterance; longer chains and larger
+ * Chains of <= 512 models of <= 5 states run on 1..8 wavefronts per utterance; longer chains and larger
  * models a workgroup per utterance (same results).  Word networks: htkamd_decode_* below.
  * ------------------------------------------------------------------------------------------ */
 typedef struct htkamd_viterbi htkamd_viterbi;

@@ -98,6 +98,16 @@ def fuzz_align(rng, it):
         s = synth.generate(int(rng.integers(20, 80)), int(rng.integers(1, 5)), int(rng.integers(10, 40)), int(rng.integers(2, 6)),
                            int(rng.integers(900, 1100)) if rng.random() < 0.05 else int(rng.integers(40, 150)), int(rng.integers(1, 10**6)), D=int(rng.choice([13, 39])))
         pk = s.packed()
+    if rng.random() < 0.2:                                          # long chains: 2 / 4 / 8 wavefronts per utterance, workgroup kernel beyond 512 models
+        nq, nx = [], []
+        for _ in range(int(rng.integers(2, 5))):
+            tgt = int(rng.choice([rng.integers(55, 75), rng.integers(120, 136), rng.integers(65, 260), rng.integers(250, 560)]))
+            q, x = [], []
+            while sum(len(a) for a in q) < tgt:
+                k = int(rng.integers(0, len(s.seqs)))
+                q.append(np.asarray(s.seqs[k], np.int32)); x.append(s.feats[k])
+            nq.append(np.concatenate(q)); nx.append(np.concatenate(x))
+        s.seqs, s.feats = nq, nx
     beam = float(rng.choice([1.0e10, rng.uniform(5, 80)]))
     model = capi.Model(pk); om = pyoracle.Model(pk)
     utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(s.seqs, s.feats)]

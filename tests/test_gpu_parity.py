@@ -560,6 +560,13 @@ def test_long_chains_every_kernel_class(native, oracle, prune, topo):
         s = synth.generate(30, 3, 20, 12, 60, 4242, D=13)
         pk, seqs, feats = s.packed(), s.seqs, s.feats
     utts = _concat_chains(rng, seqs, feats, [40, 64, 66, 120, 128, 131, 200, 255, 258, 300, 500])
+    if topo:                                            # tee models on the wavefront boundaries of some chains (lanes 63|64, 127|128 ...)
+        tee = names.index("sp")
+        for ut in utts[2:]:
+            q = ut["seq"]
+            for pos in (63, 64, 127, 128, 191, 256):
+                if pos + 1 < len(q) and q[pos - 1] != tee and q[pos + 1] != tee and rng.random() < 0.7:
+                    q[pos] = tee
     Qs = [len(u["seq"]) for u in utts]
     assert min(Qs) <= 64 and any(64 < q <= 128 for q in Qs) and any(128 < q <= 256 for q in Qs) and 256 < max(Qs) <= 512
     model, fb, acc, pr, st = run_fb(native, pk, utts, prune)
@@ -585,3 +592,30 @@ def test_long_chains_every_kernel_class(native, oracle, prune, topo):
     for k in ("muOcc", "wtOcc", "trOcc", "tr", "wt", "mu", "va"):
         acc_close(a[k], getattr(oacc, k), k)
     assert np.array_equal(a["nEgs"], oacc.nEgs)
+
+
+@pytest.mark.parametrize("beam", [1.0e10, 60.0], ids=["nobeam", "beam60"])
+@pytest.mark.parametrize("topo", [False, True], ids=["3state", "topo"])
+def test_viterbi_long_chains_every_kernel_class(native, oracle, beam, topo):
+    """Alignment chains of 40 .. 600 models in one batch: 1 / 2 / 4 / 8 wavefronts per utterance, beyond 512 models the workgroup kernel.
+    The topology set puts tee models anywhere in the chain, also in the first and last lane of a wavefront (lanes 63|64, 127|128 ...),
+    where the entry/exit hand-over crosses wavefronts.  Tokens, segments and scores identical to the oracle's."""
+    from htk_amd import synth
+    rng = np.random.default_rng(5 + int(topo))
+    if topo:
+        pk, names, seqs, feats = synth.make_topo_set(seed=78, D=13, NU=8)
+        tee = names.index("sp")
+    else:
+        s = synth.generate(30, 3, 20, 12, 60, 4243, D=13)
+        pk, seqs, feats = s.packed(), s.seqs, s.feats
+    utts = _concat_chains(rng, seqs, feats, [40, 64, 66, 120, 128, 131, 200, 255, 258, 300, 500, 600])
+    if topo:                                            # force tee models onto the wavefront boundaries of some chains
+        for ut in utts[2:]:
+            q = ut["seq"]
+            for pos in (63, 64, 127, 128, 191, 256):
+                if pos + 1 < len(q) and q[pos - 1] != tee and q[pos + 1] != tee and rng.random() < 0.7:
+                    q[pos] = tee
+    sq, ft = [u["seq"] for u in utts], [u["feat"] for u in utts]
+    got = _align(native, pk, sq, ft, beam=beam)
+    _check_vs_oracle(oracle, oracle.Model(pk), got, sq, ft, beam)
+    assert sum(g["status"] == 1 for g in got) >= 6
