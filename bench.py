@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--utts", type=int, default=1250, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
-    ap.add_argument("--score", choices=["exact", "mfma"], default="mfma",
+    ap.add_argument("--score", choices=["exact", "mfma", "fast"], default="fast",
                     help="scoring arithmetic: exact = bit-identical to the reference (packed FP32 VALU); mfma = fp32 matrix-core GEMM, 1e-4 tolerance class")
     ap.add_argument("--two-streams", type=int, default=1, help="run the alternating batch contexts on their own streams (1) or on one stream (0)")
     ap.add_argument("--contexts", type=int, default=2, help="batch contexts in flight (each with its own work space and accumulator vector)")
@@ -141,7 +141,7 @@ def main():
     model = capi.Model(pk)
     accs = capi.Accs(model)
     fb = capi.ForwardBackward(model)
-    cfg = capi.fb_config(scoreMode=1 if args.score == "mfma" else 0)                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
+    cfg = capi.fb_config(scoreMode={"exact": 0, "mfma": 1, "fast": 3}[args.score])                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
 
     if args.ragged:                                      # not the headline workload: utterance lengths spread over [frames/2, frames], chains
         rr = np.random.default_rng(77 + rank)            # spread likewise (one model per 12 frames), in random order within the batch
@@ -237,7 +237,7 @@ def main():
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
-        kname = "k_score_mfma<20>" if args.score == "mfma" else "k_score_exact<39>"
+        kname = "k_score_mfma<20>" if args.score != "exact" else "k_score_exact<39>"
         traffic = None                                       # HBM-side bytes per launch from the committed PMC pass, same workload only
         try:
             tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))

@@ -431,24 +431,11 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
          if (kind[n] == HTKAMD_NODE_WORD) { wordIdx[n] = nW++; wordNode.push_back(n); }
       }
    }
-   // reverse CSR in source-node order
-   std::vector<int> predOff(nN + 1, 0), predSrc(nd->nLinks);
-   std::vector<float> predLike(nd->nLinks);
-   for (int k = 0; k < nd->nLinks; k++) predOff[nd->linkDest[k] + 1]++;
-   for (int n = 0; n < nN; n++) predOff[n + 1] += predOff[n];
-   {
-      std::vector<int> fill(predOff.begin(), predOff.end() - 1);
-      for (int n = 0; n < nN; n++)
-         for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) {
-            const int at = fill[nd->linkDest[k]]++;
-            predSrc[at] = n | (kind[n] != HTKAMD_NODE_HMM ? (int)0x80000000 : 0);      // bit 31: word/null predecessor (word-end beam applies)
-            predLike[at] = nd->linkLike[k];
-         }
-   }
-   // levels of the zero-time sub-graph
+   // Zero-time sub-graph (word ends, null nodes, tee models) in topological order: Kahn's algorithm seeded in node order, successors
+   // in link order.  This order is also the order of the zero-time senders of a frame (below).
    auto zt = [&](int n) { return kind[n] != HTKAMD_NODE_HMM || tee[n]; };
    std::vector<int> level(nN, -1), indeg(nN, 0), queue;
-   for (int n = 0; n < nN; n++) if (zt(n)) for (int k = predOff[n]; k < predOff[n + 1]; k++) if (zt(predSrc[k] & 0x7fffffff)) indeg[n]++;
+   for (int n = 0; n < nN; n++) if (zt(n)) for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) if (zt(nd->linkDest[k])) indeg[nd->linkDest[k]]++;
    for (int n = 0; n < nN; n++) if (zt(n) && indeg[n] == 0) { level[n] = 0; queue.push_back(n); }
    int nLevels = 0;
    for (size_t qi = 0; qi < queue.size(); qi++) {
@@ -463,6 +450,26 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
    }
    { int nz = 0; for (int n = 0; n < nN; n++) if (zt(n)) nz++;
      if ((int)queue.size() != nz) { htkamd_set_error("decoder_create: the network has a loop of word/null/tee nodes"); delete d; return HTKAMD_EMODEL; } }
+   // Reverse CSR.  A node keeps the FIRST of several equally likely tokens (SetEntryState HRec.c:1303, strict >), so the order of a
+   // node's predecessors is the order in which the senders are stepped within a frame: the emitting models' exit tokens go out first
+   // (node order), then the zero-time nodes in their propagation order (HRec keeps its instance list in that order, ReOrderList
+   // HRec.c:1152; oracle/orc_decode.c walks the same sequence); links of one sender stay in link order.
+   std::vector<int> predOff(nN + 1, 0), predSrc(nd->nLinks);
+   std::vector<float> predLike(nd->nLinks);
+   for (int k = 0; k < nd->nLinks; k++) predOff[nd->linkDest[k] + 1]++;
+   for (int n = 0; n < nN; n++) predOff[n + 1] += predOff[n];
+   {
+      std::vector<int> fill(predOff.begin(), predOff.end() - 1);
+      auto send = [&](int n) {
+         for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) {
+            const int at = fill[nd->linkDest[k]]++;
+            predSrc[at] = n | (kind[n] != HTKAMD_NODE_HMM ? (int)0x80000000 : 0);      // bit 31: word/null predecessor (word-end beam applies)
+            predLike[at] = nd->linkLike[k];
+         }
+      };
+      for (int n = 0; n < nN; n++) if (!zt(n)) send(n);
+      for (int n : queue) send(n);
+   }
    std::vector<int> levelOff(nLevels + 1, 0), levelWide(nLevels, 0), levelNodes;
    for (int L = 0; L < nLevels; L++) {
       levelOff[L] = (int)levelNodes.size();

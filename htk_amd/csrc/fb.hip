@@ -485,7 +485,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff;
-   if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
+   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
+   const bool mfmaScores = (cfg->scoreMode & HTKAMD_SCORE_MFMA) != 0, fastLadd = (cfg->scoreMode & HTKAMD_SCORE_FASTLADD) != 0;
 
    FbArgs fa;
    memset(&fa, 0, sizeof(fa));
@@ -519,7 +520,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
 
    int rc;
    HIPCHECK(hipEventRecord(fb->ev[0], s));
-   if ((rc = (cfg->scoreMode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, sa, s, fb->evK[0], fb->evK[1])
+   if ((rc = mfmaScores ? htkamd_launch_score_mfma(m, sa, s, fb->evK[0], fb->evK[1])
                                                    : htkamd_launch_score_exact(m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
    fb->scored = sa.nTasks > 0;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
@@ -536,7 +537,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       if (nGeneral > 0 && (rc = pass == 0 ? htkamd_launch_beta(fc, fb->blockDim, ldsBeta, s) : htkamd_launch_alpha(fc, fb->blockDim, ldsAlpha, s))) return rc;
       for (int c = 3; c >= 0; c--) {
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[c]; fc.nList = fb->clsOff[c + 1] - fb->clsOff[c];
-         if ((rc = pass == 0 ? htkamd_launch_beta_w(fc, clsW[c], s) : htkamd_launch_alpha_w(fc, clsW[c], s))) return rc;
+         if ((rc = pass == 0 ? htkamd_launch_beta_w(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_w(fc, clsW[c], fastLadd, s))) return rc;
       }
       HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }

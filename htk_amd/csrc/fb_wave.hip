@@ -29,8 +29,8 @@
 #define UPB(W) ((W) == 1 ? 4 : 1)   // utterances per workgroup: four single-wave utterances, or one multi-wave utterance
 #define EXPFLOOR (-100.0)     // see fb_kernels.hip
 
-#define ladd(x, y) ladd_tab((x), (y), mle, ltab)
-#define EXPT(x) exp_tab((x), etab)
+#define ladd(x, y) ladd_sel<FAST>((x), (y), mle, ltab)
+#define EXPT(x) exp_sel<FAST>((x), etab)
 
 template <int MAXN> struct ModelRegs {
    int N, mc0, ms0;
@@ -98,14 +98,14 @@ template <int NE> struct ObsStage {
 #define BETA_W(t, i) (gbeta[((size_t)((t) - 1) * MAXN + ((i) - 1)) * (64 * W)])
 
 // ------------------------------------------------------------------------------------ K2w: beta
-template <int MAXN, int W>
+template <int MAXN, int W, bool FAST>
 __global__ __launch_bounds__(64 * W * UPB(W)) void k_beta_w(FbArgs a)
 {
-   __shared__ double ltab[LADD_TAB_DOUBLES];
+   __shared__ double ltab[FAST ? 1 : LADD_TAB_DOUBLES];
    __shared__ float stage[W * UPB(W)][2 * (MAXN - 2) * 64 * 4];
    __shared__ unsigned long long gx[2 * W * 4];
    __shared__ float ga1[64 * W];
-   ladd_table_to_lds(ltab, a.laddTab);
+   if constexpr (!FAST) ladd_table_to_lds(ltab, a.laddTab);
    __syncthreads();
    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;           // wave in block
    const int li = blockIdx.x * UPB(W) + wib / W;                        // the block's utterance(s): all waves of a group leave together
@@ -303,15 +303,14 @@ __global__ __launch_bounds__(64 * W * UPB(W)) void k_beta_w(FbArgs a)
 }
 
 // ------------------------------------------------------------------------------------ K3w: alpha + stats
-template <int MAXN, int W>
+template <int MAXN, int W, bool FAST>
 __global__ __launch_bounds__(64 * W * UPB(W)) void k_alpha_w(FbArgs a)
 {
-   __shared__ double ltab[LADD_TAB_DOUBLES];
-   __shared__ double etab[EXP_TAB_N];
+   __shared__ double ltab[FAST ? 1 : LADD_TAB_DOUBLES];
+   __shared__ double etab[FAST ? 1 : EXP_TAB_N];
    __shared__ unsigned long long gx[2 * W * 4];
    __shared__ float ga1[64 * W];
-   ladd_table_to_lds(ltab, a.laddTab);
-   exp_table_to_lds(etab);
+   if constexpr (!FAST) { ladd_table_to_lds(ltab, a.laddTab); exp_table_to_lds(etab); }
    __syncthreads();
    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
    const int li = blockIdx.x * UPB(W) + wib / W;
@@ -649,24 +648,34 @@ __global__ __launch_bounds__(64 * W * UPB(W)) void k_alpha_w(FbArgs a)
 }
 
 // a.uttList / a.nList: the utterances of one class (W wavefronts each)
-int htkamd_launch_beta_w(const FbArgs &a, int W, hipStream_t s)
+template <bool FAST> static void launch_beta_w(const FbArgs &a, int W, hipStream_t s)
+{
+   if (W == 1) hipLaunchKernelGGL((k_beta_w<5, 1, FAST>), dim3((a.nList + 3) / 4), dim3(256), 0, s, a);
+   else if (W == 2) hipLaunchKernelGGL((k_beta_w<5, 2, FAST>), dim3(a.nList), dim3(128), 0, s, a);
+   else if (W == 4) hipLaunchKernelGGL((k_beta_w<5, 4, FAST>), dim3(a.nList), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL((k_beta_w<5, 8, FAST>), dim3(a.nList), dim3(512), 0, s, a);
+}
+template <bool FAST> static void launch_alpha_w(const FbArgs &a, int W, hipStream_t s)
+{
+   if (W == 1) hipLaunchKernelGGL((k_alpha_w<5, 1, FAST>), dim3((a.nList + 3) / 4), dim3(256), 0, s, a);
+   else if (W == 2) hipLaunchKernelGGL((k_alpha_w<5, 2, FAST>), dim3(a.nList), dim3(128), 0, s, a);
+   else if (W == 4) hipLaunchKernelGGL((k_alpha_w<5, 4, FAST>), dim3(a.nList), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL((k_alpha_w<5, 8, FAST>), dim3(a.nList), dim3(512), 0, s, a);
+}
+
+// fast: tolerance-class LAdd / exp (ladd.h); the exact forms otherwise
+int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
-   if (W == 1) hipLaunchKernelGGL((k_beta_w<5, 1>), dim3((a.nList + 3) / 4), dim3(256), 0, s, a);
-   else if (W == 2) hipLaunchKernelGGL((k_beta_w<5, 2>), dim3(a.nList), dim3(128), 0, s, a);
-   else if (W == 4) hipLaunchKernelGGL((k_beta_w<5, 4>), dim3(a.nList), dim3(256), 0, s, a);
-   else hipLaunchKernelGGL((k_beta_w<5, 8>), dim3(a.nList), dim3(512), 0, s, a);
+   if (fast) launch_beta_w<true>(a, W, s); else launch_beta_w<false>(a, W, s);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }
 
-int htkamd_launch_alpha_w(const FbArgs &a, int W, hipStream_t s)
+int htkamd_launch_alpha_w(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
-   if (W == 1) hipLaunchKernelGGL((k_alpha_w<5, 1>), dim3((a.nList + 3) / 4), dim3(256), 0, s, a);
-   else if (W == 2) hipLaunchKernelGGL((k_alpha_w<5, 2>), dim3(a.nList), dim3(128), 0, s, a);
-   else if (W == 4) hipLaunchKernelGGL((k_alpha_w<5, 4>), dim3(a.nList), dim3(256), 0, s, a);
-   else hipLaunchKernelGGL((k_alpha_w<5, 8>), dim3(a.nList), dim3(512), 0, s, a);
+   if (fast) launch_alpha_w<true>(a, W, s); else launch_alpha_w<false>(a, W, s);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }

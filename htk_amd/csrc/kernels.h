@@ -96,7 +96,7 @@ int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s)
 int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
-int htkamd_launch_beta_w(const FbArgs &a, int W, hipStream_t s);
-int htkamd_launch_alpha_w(const FbArgs &a, int W, hipStream_t s);
+int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s);
+int htkamd_launch_alpha_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 
 #endif

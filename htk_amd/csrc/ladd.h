@@ -103,4 +103,30 @@ __device__ __forceinline__ float ladd_tab_f(const float xf, const float yf, cons
    return (float)((double)hi + f);
 }
 
+// Tolerance-class forms for the HERest recursions (scoreMode bit HTKAMD_SCORE_FASTLADD): the increment log(1+exp(d)) and the
+// occupation exponentials on the hardware's fp32 transcendentals (v_exp_f32 / v_log_f32), the running values stay fp64.
+// Absolute error of the increment ~1e-7 (d <= 0: e in (0,1], 1+e rounded to float, v_log_f32 to ~1 ulp), against a bar of 1e-4
+// relative on alpha/beta and on the re-estimated parameters.  Branch-free: LZERO operands need no test (exp2(-1.4e10) = 0), and
+// the reference's cut-off d < minLogExp = -23.03 is where 1+e rounds to 1 anyway.
+__device__ __forceinline__ double ladd_fast(const double x, const double y)
+{
+   const double hi = fmax(x, y), lo = fmin(x, y);
+   const float d = (float)(lo - hi);
+   const float e = __builtin_amdgcn_exp2f(d * 1.44269504088896341f);
+   const float f = __builtin_amdgcn_logf(1.0f + e) * 0.69314718055994531f;
+   return hi + (double)f;
+}
+__device__ __forceinline__ double exp_fast(const double x)
+{
+   return (double)__builtin_amdgcn_exp2f((float)x * 1.44269504088896341f);
+}
+template <bool FAST> __device__ __forceinline__ double ladd_sel(const double x, const double y, const double mle, const double *tab)
+{
+   if constexpr (FAST) return ladd_fast(x, y); else return ladd_tab(x, y, mle, tab);
+}
+template <bool FAST> __device__ __forceinline__ double exp_sel(const double x, const double *etab)
+{
+   if constexpr (FAST) return exp_fast(x); else return exp_tab(x, etab);
+}
+
 #endif

@@ -256,7 +256,7 @@ void htkamd_net_destroy(struct htkamd_net *n)
 
 typedef struct { int from, to; float like; } tlink;
 
-static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, struct htkamd_net **out);
+static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, const htkamd_model_desc *md, struct htkamd_net **out);
 
 int htkamd_net_build(const char *slfPath, const char *dictPath, const struct htkamd_mmf *hmms, struct htkamd_net **out)
 {
@@ -267,7 +267,7 @@ int htkamd_net_build(const char *slfPath, const char *dictPath, const struct htk
    if ((rc = read_dict(dictPath, hmms, &pr, &nPr))) return rc;
    lnode *ln = NULL; larc *la = NULL; int NN = 0, NA = 0;
    if ((rc = read_slf(slfPath, &ln, &NN, &la, &NA))) return rc;
-   return expand_lattice(ln, NN, la, NA, pr, nPr, slfPath, dictPath, out);
+   return expand_lattice(ln, NN, la, NA, pr, nPr, slfPath, dictPath, md, out);
 }
 
 /* The alignment network of HVite -a (DoAlignment HVite.c:830): LatticeFromLabels (HNet.c:1516) makes the word-level transcription a
@@ -288,10 +288,10 @@ int htkamd_net_build_words(const char *const *words, int nWords, const char *bou
       ln[i].word = strdup(w ? w : "!NULL");
       if (i > 0) { la[i - 1].s = i - 1; la[i - 1].e = i; la[i - 1].l = 0.0f; }
    }
-   return expand_lattice(ln, NN, la, NA, pr, nPr, "(transcription)", dictPath, out);
+   return expand_lattice(ln, NN, la, NA, pr, nPr, "(transcription)", dictPath, htkamd_mmf_desc(hmms), out);
 }
 
-static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, struct htkamd_net **out)
+static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, const htkamd_model_desc *md, struct htkamd_net **out)
 {
    int rc;
 
@@ -314,11 +314,28 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
    for (int i = 0; i < NN; i++) {
       firstOf[i] = nInst; cntOf[i] = 0;
       const int isNull = !strcmp(ln[i].word, "!NULL");
-      int found = 0;
+      /* pronunciations of the word, in the order of the reference's PronHolder list: InitPronHolders (HNet.c:2293) drops a
+         pronunciation that repeats an earlier one (same phones, same probability: remDupPron) and PREPENDS each holder, so the list --
+         and with it the order of every link made per holder -- runs from the last pronunciation of the dictionary to the first */
+      int sel[256], nSel = 0, found = 0;
       for (int k = 0; k < nPr && !isNull; k++) {
          if (strcmp(pr[k].word, ln[i].word)) continue;
          found++;
          if (ln[i].var > 0 && found != ln[i].var) continue;     /* v= selects one pronunciation */
+         int dup = 0;
+         for (int z = 0; z < nSel && !dup; z++) {
+            const dpron *o = &pr[sel[z]];
+            if (o->nPhones != pr[k].nPhones || o->prob != pr[k].prob) continue;
+            int q = 0;
+            while (q < o->nPhones && !strcmp(o->phoneName[q], pr[k].phoneName[q])) q++;
+            dup = (q == o->nPhones);
+         }
+         if (dup) continue;
+         if (nSel >= 256) { htkamd_set_error("net_build: word %s has more than 256 pronunciations", ln[i].word); rc = HTKAMD_EMODEL; goto done; }
+         sel[nSel++] = k;
+      }
+      for (int z = nSel - 1; z >= 0; z--) {
+         const int k = sel[z];
          if (nInst + 1 > capI) { capI = capI * 2 + 1024; pStart = (int *)realloc(pStart, sizeof(int) * (size_t)capI); pEnd = (int *)realloc(pEnd, sizeof(int) * (size_t)capI); }
          if (pr[k].nPhones == 0) {                              /* phone-less pronunciation: word node only */
             NEWNODE(HTKAMD_NODE_WORD, k, pr[k].prob, k);
@@ -373,6 +390,24 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
       memcpy(fill, net->linkOff, sizeof(int) * (size_t)nN);
       for (int k = 0; k < nL; k++) { const int at = fill[tl[k].from]++; net->linkDest[at] = tl[k].to; net->linkLike[at] = tl[k].like; }
       free(fill);
+   }
+   /* "put all n_tr0 nodes first" (ExpandWordNet HNet.c:3632-3645): links to zero-time nodes (word ends, null nodes, tee models) move to
+      the front of a node's link array by the reference's own swaps -- HRec walks them first (ReOrderList HRec.c:1152) */
+   if (md) {
+      for (int n = 0; n < nN; n++) {
+         const int l0 = net->linkOff[n], nl = net->linkOff[n + 1] - l0;
+#define IS_TR0(x) (net->kind[x] != HTKAMD_NODE_HMM || md->transP[md->transOff[md->hmmTrans[net->model[x]]] + md->transN[md->hmmTrans[net->model[x]]] - 1] > (float)LSMALL)
+         for (int a = 0; a < nl; a++) {
+            if (IS_TR0(net->linkDest[l0 + a])) continue;
+            int b = a + 1;
+            while (b < nl && !IS_TR0(net->linkDest[l0 + b])) b++;
+            if (b >= nl) break;
+            const int td = net->linkDest[l0 + a]; const float tk = net->linkLike[l0 + a];
+            net->linkDest[l0 + a] = net->linkDest[l0 + b]; net->linkLike[l0 + a] = net->linkLike[l0 + b];
+            net->linkDest[l0 + b] = td; net->linkLike[l0 + b] = tk;
+         }
+#undef IS_TR0
+      }
    }
    net->wordName = (char **)malloc(sizeof(char *) * (size_t)(nPr ? nPr : 1));
    for (int k = 0; k < nPr; k++) net->wordName[k] = strdup(pr[k].outSym);

@@ -210,6 +210,12 @@ int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dState
  *                       accumulation, where the bar is 1e-4 relative on the re-estimated parameters. */
 #define HTKAMD_SCORE_EXACT 0
 #define HTKAMD_SCORE_MFMA  1
+/* Forward-backward only (htkamd_fb_config.scoreMode, may be or-ed with HTKAMD_SCORE_MFMA): the log-add of the alpha/beta
+ * recursions (LAdd HMath.c:1576) and the occupation exponentials on fp32 hardware transcendentals; running values stay double.
+ * Increment error ~1e-7 absolute: utterance log-probabilities ~1e-9 relative, occupancies / accumulators ~1e-5 relative --
+ * inside the 1e-4 bar of the HERest path.  Chains that need the general kernels (models of > 5 states) ignore the bit. */
+#define HTKAMD_SCORE_FASTLADD 2
+#define HTKAMD_SCORE_FAST  (HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)
 int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                            float *dOut, int ldo, int scoreMode, void *stream);
 
@@ -300,7 +306,7 @@ typedef struct {
    double pruneInit, pruneInc, pruneLim;   /* HERest -t f [i l]; HTKAMD_NOPRUNE = off (HERest.c:121-123) */
    float  minFrwdP;                        /* HFB MINFORPROB / HERest -c, default 10.0 (HFB.c:83)        */
    int    uFlags;                          /* HTKAMD_UP* bits                                            */
-   int    scoreMode;                       /* HTKAMD_SCORE_EXACT (0, default) or HTKAMD_SCORE_MFMA        */
+   int    scoreMode;                       /* HTKAMD_SCORE_EXACT (0, default), or HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD bits */
 } htkamd_fb_config;
 
 typedef struct {

@@ -179,6 +179,14 @@ def fuzz_decode(rng, it, tmp):
     model = capi.Model(mmf.packed()); om = pyoracle.Model(mmf.packed())
     res = capi.Decoder(model, net, lmScale=p["lmScale"]).run(s.feats, **p)
     ok = True
+    keep = os.environ.get("HTKAMD_FUZZ_KEEP_DECODE")                 # e.g. "1840": copy that case's files next to the logs
+    if keep and it in [int(k) for k in keep.split(",")]:
+        import json, shutil
+        dst = os.path.join(ROOT, "gpurun_out", "fuzz_decode_%d" % it)
+        shutil.copytree(d, dst, dirs_exist_ok=True)
+        np.savez(os.path.join(dst, "feats.npz"), **{"u%d" % u: x for u, x in enumerate(s.feats)})
+        json.dump(dict(params=p, gpu=[[list(map(float, w)) for w in (r[0] or [])] for r in res], total=[float(r[1]) for r in res]),
+                  open(os.path.join(dst, "case.json"), "w"))
     for u, (words_g, total) in enumerate(res):
         ow, ot = pyoracle.decode(om, s.feats[u], net.arrays(), **p)
         if words_g != ow or (ow is not None and total != ot):

@@ -8,6 +8,10 @@ Cases (all files land in tests/golden/decode/<case>/, a few hundred kB in total)
   tee    mixed-topology models incl. a tee model `sp` at the end of some pronunciations, word loop    HVite -t 250 / -t 40
   wint   a monophone dictionary over a model set of word-internal triphones/biphones (logical names tied to 12 physical
          models), so that ExpandWordNet's context expansion is exercised                              2 option sets
+  ties   a case the randomised GPU sweep recorded (python tests/fuzz_parity.py 1841 20261002 with HTKAMD_FUZZ_KEEP_DECODE=1840: the
+         generator's files are kept as they were written): homophones W0 = "a sp" (tee model skipped) and W2 = "a" with different
+         pronunciation probabilities make "... W2 W0 W2" and "... W0 W2 W2" EXACTLY equally likely (the same float terms summed in
+         another order); the reference keeps the token that arrives first in its instance-list order      -t 83.53 -v 33.40 -r 1.7962
 Each case: MMF (text), hmmlist, dict, net.slf, feats.npz (the utterances' feature matrices), expected.json =
 {option string: {utterance: [label lines of the .rec file]}} exactly as HVite wrote them (no entry = "No tokens survived").
 NOTE: HBuild numbers the nodes of a word loop in an order that varies from run to run; after re-running this script keep the
@@ -183,7 +187,12 @@ def main():
         ph = [int(lmap[m][1:]) for w in seq for m in wseq[w]]
         feats.append(sample(pk, ph, rng, frames_per_state=3))
     run_hvite(d, feats, ["-t 250.0", "-t 250.0 -p -20.0 -s 3.0", "-m -t 250.0"], 9, "")
-    for c in ("loop", "bigram", "tee", "wint"):
+    # ---------------------------------------------------------------- ties: inputs are committed (recorded from the sweep), expectations from HVite
+    d = os.path.join(OUT, "ties")
+    z = np.load(os.path.join(d, "feats.npz"))
+    feats = [z["u%d" % u] for u in range(len(z.files))]
+    run_hvite(d, feats, ["-t 83.5292734595038 -v 33.403143058686354 -r 1.7961669175753967", "-r 1.7961669175753967", "-t 83.5292734595038 -r 2.0"], 9, "")
+    for c in ("loop", "bigram", "tee", "wint", "ties"):
         e = json.load(open(os.path.join(OUT, c, "expected.json")))
         print(c, {k: sum(len(v) for v in per.values()) for k, per in e.items()})
 

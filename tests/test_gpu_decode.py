@@ -10,7 +10,7 @@ from decode_util import format_words, load_decode_case, parse_opts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint"])
+@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint", "ties"])
 def test_decoder_reproduces_hvite_label_files(native, oracle, case):
     mmf, net, feats, expected = load_decode_case(native, case)
     model = native.Model(mmf.packed())

@@ -101,13 +101,14 @@ def test_outp_block_mfma_rejects_other_sizes(native):
         gm.outp_block(s.feats[0], np.arange(5, dtype=np.int32), mode=7)
 
 
-@pytest.mark.parametrize("name", ["fb_small", "fb_topo"])
-def test_mfma_forward_backward_within_tolerance(native, name):
-    """HERest through the MFMA scores: utterance log-probabilities within 1e-6 relative, alpha/beta within 1e-4 relative,
-    and the parameters re-estimated from its accumulators within 1e-4 of the MMF the reference's HERest wrote
-    (BASELINE.json north_star tolerance)."""
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["mfma", "fastladd", "fast"])
+@pytest.mark.parametrize("name", ["fb_small", "fb_topo", "fb_small_prune", "fb_topo_prune"])
+def test_mfma_forward_backward_within_tolerance(native, name, mode):
+    """HERest through the tolerance-class kernels (matrix-core scores and / or the fp32-transcendental LAdd of the recursions):
+    utterance log-probabilities within 1e-6 relative, alpha/beta within 1e-4 relative, and the parameters re-estimated from
+    its accumulators within 1e-4 of the MMF the reference's HERest wrote (BASELINE.json north_star tolerance)."""
     case = load_case(name)
-    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], scoreMode=1)
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], scoreMode=mode)
     for u, ut in enumerate(case["utts"]):
         assert st[u] == 1
         assert abs(pr[u] - float(ut["pr"])) <= 1e-6 * abs(float(ut["pr"]))
@@ -315,6 +316,55 @@ def test_config2_properties(native):
     assert abs(a["trOcc"][1:4].sum() - frames) < 1e-6 * frames    # emitting-state occupancy sums to the frame count
     assert "%.6e" % (a["totalPr"] / a["totalT"]) == "-6.108214e+01"  # HERest: "average log prob per frame" 
     assert a["nEval"] == fb.frame_states() == 64 * 47220
+
+
+@pytest.mark.parametrize("mode", [0, 3], ids=["exact", "fast"])
+def test_config3_headline_size(native, oracle, mode):
+    """The configuration bench.py measures (BASELINE config[2] per GPU: 5k tied states x 16 mix, D = 39, 500-frame utterances of 41
+    models), 64 utterances, in the exact mode and in the mode the bench runs (matrix-core scores + fast LAdd): utterance
+    log-probabilities against the oracle on a sample (1e-10 exact / 1e-6 tolerance class), accumulators of the sampled
+    utterances' states through acc_close on a batch of just those utterances, and the size-independent invariants on all 64."""
+    from htk_amd import synth
+    s = synth.generate(5000, 16, 6000, 64, 500, 3)
+    pk = s.packed()
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    model, fb, acc, pr, st = run_fb(native, pk, utts, debug=False, scoreMode=mode)
+    assert (st == 1).all()
+    om = oracle.Model(pk)
+    cfg = oracle.fb_cfg()
+    sample = [0, 17, 63]
+    oacc = oracle.Accs(om)
+    tol = 1e-6 if mode else 1e-10
+    for u in sample:
+        rc, opr, _ = oracle.fb_utt(om, cfg, utts[u]["feat"], utts[u]["seq"], oacc)
+        assert rc == 1 and abs(pr[u] - opr) <= tol * abs(opr), (u, pr[u], opr)
+    a = acc.download()
+    frames = 64 * 500
+    assert abs(a["muOcc"].sum() - frames) < 1e-3 * frames
+    assert abs(a["wt"].sum() - a["muOcc"].sum()) < 1e-6 * frames and abs(a["wtOcc"].sum() - a["muOcc"].sum()) < 1e-6 * frames
+    assert a["nEgs"].sum() == 64 * 41 and a["totalT"] == frames
+    tr = a["tr"].reshape(5, 5)
+    assert abs(tr[0, 1] - 64 * 41) < 1e-5 * 64 * 41 and abs(tr[1:4, 4].sum() - 64 * 41) < 1e-5 * 64 * 41
+    assert abs(a["trOcc"][1:4].sum() - frames) < 1e-5 * frames
+    assert a["nEval"] == fb.frame_states() == 64 * 47220
+    assert abs(a["totalPr"] - pr.sum()) <= 1e-9 * abs(pr.sum())
+    # the sampled utterances alone: every accumulator against the oracle's
+    model2, fb2, acc2, pr2, st2 = run_fb(native, pk, [utts[u] for u in sample], debug=False, scoreMode=mode)
+    a2 = acc2.download()
+    assert np.array_equal(a2["nEgs"], oacc.nEgs)
+    rt = 5e-4 if mode else 1e-4
+    for k in ("muOcc", "vaOcc", "wt", "wtOcc", "tr", "trOcc") + (() if mode else ("mu", "va")):
+        acc_close(a2[k], getattr(oacc, k), "c3/%s" % k, rtol=rt)
+    if mode:
+        # first- and second-order sums are kept about the current mean (HFB.c:1671-1678): an entry near zero is a cancellation of
+        # terms of the size of its Gaussian's occupancy, which is therefore the scale a tolerance-class change of the posteriors
+        # moves it by (the exact mode above holds every entry to 1e-4 of its own value)
+        occ = np.maximum(np.asarray(oacc.muOcc, np.float64), 1e-3)[:, None]
+        for k in ("mu", "va"):
+            got = np.asarray(a2[k], np.float64).reshape(occ.shape[0], -1); ref = np.asarray(getattr(oacc, k), np.float64).reshape(occ.shape[0], -1)
+            assert (np.abs(got - ref) <= rt * np.maximum(np.abs(ref), occ)).all(), k
+    for k, u in enumerate(sample):
+        assert pr2[k] == pr[u]                              # a score does not depend on the batch it is in
 
 
 def test_accumulator_merge_is_load_accs(native):
