@@ -8,9 +8,10 @@ processes its own 1250-utterance shard, the accumulator vector is summed with RC
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A step = one embedded Baum-Welch pass over the rank's shard with the features already resident in HBM:
-CreateInsts/beam taper on the host, K1 scoring, K2 beta, K3 alpha + occupation/transition statistics,
-K4 mixture statistics, all-reduce(sum) of the fp64 accumulator vector, per-utterance results read back.
+A step = one EM ITERATION of embedded Baum-Welch over the rank's shard with the features already resident in HBM:
+ZeroAccs, CreateInsts/beam taper on the host, K1 scoring, K2 beta, K3 alpha + occupation/transition statistics,
+K4 mixture statistics, all-reduce(sum) of the fp64 accumulator vector, UpdateModels + table refresh on the device,
+per-utterance results read back.  Step k+1 runs on the model step k wrote: nothing overlaps between steps.
 PyTorch is used for device memory, the stream, the barrier and torch.distributed (backend nccl = RCCL);
 everything numeric is the HIP library behind include/htk_amd.h.
 
@@ -40,22 +41,22 @@ def cpu_baseline(s, pk, budget_s: float):
     om = po.Model(pk)
     acc = po.Accs(om)
     cfg = po.fb_cfg()
-    n, nev, t0 = 0, 0, time.perf_counter()
-    lib = po.lib()
-    import ctypes as C
+    n, t0, prs = 0, time.perf_counter(), []
     while n < len(s.feats):
         rc, pr, _ = po.fb_utt(om, cfg, s.feats[n], s.seqs[n], acc)
+        prs.append(pr)
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return n, dt
+    return n, dt, np.array(prs)
 
 
-def cpu_baseline_reference(s, pk, n_utt: int):
-    """The reference's own HERest (oracle/_ref/HERest, built from /root/reference by oracle/Makefile and shipped with the tree)
-    on one host core over the first utterances of the same shard.  Model loading (a 25 MB text MMF) is taken out by
-    differencing a run over n and a run over 2n utterances.  Returns (utterances, seconds) or None if the binary is absent."""
+def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
+    """The reference's own HERest (oracle/_ref/HERest, built from /root/reference by oracle/Makefile and shipped with the tree) as
+    `workers` parallel processes `HERest -p k` (its parallel mode: every process accumulates its own shard and dumps HERk.acc,
+    HERest.c:543-550), each over n_utt utterances of the same shard.  Model loading (a 25 MB text MMF per process) is taken out by
+    differencing a round over n and a round over 2n utterances per process.  Returns (utterances, seconds, workers) or None."""
     import subprocess
     import tempfile
     from htk_amd import synth
@@ -70,29 +71,47 @@ def cpu_baseline_reference(s, pk, n_utt: int):
         with open(os.path.join(d, "hmmlist"), "w") as f:
             f.write("\n".join(names) + "\n")
         os.makedirs(os.path.join(d, "out"))
-        n2 = min(2 * n_utt, len(s.feats))
-        for u in range(n2):
+        pool = min(len(s.feats), max(2 * n_utt, 240))              # files on disk; the workers read overlapping windows of them
+        for u in range(pool):
             synth.write_htk_param(os.path.join(d, "u%05d.mfc" % u), s.feats[u], kind=9)
             with open(os.path.join(d, "u%05d.lab" % u), "w") as f:
                 f.write("\n".join(names[int(h)] for h in s.seqs[u]) + "\n")
         open(os.path.join(d, "config"), "w").close()
         times = []
-        for n in (n2 // 2, n2):
-            with open(os.path.join(d, "scp"), "w") as f:
-                f.write("\n".join(os.path.join(d, "u%05d.mfc" % u) for u in range(n)) + "\n")
+        for n in (n_utt, 2 * n_utt):
+            procs = []
+            for k in range(workers):
+                scp = os.path.join(d, "scp%d" % k)
+                with open(scp, "w") as f:
+                    f.write("\n".join(os.path.join(d, "u%05d.mfc" % ((k * 7 + i) % pool)) for i in range(n)) + "\n")
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-S", os.path.join(d, "scp"), "-L", d,
-                                "-M", os.path.join(d, "out"), os.path.join(d, "hmmlist")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-            if r.returncode != 0:
+            for k in range(workers):
+                procs.append(subprocess.Popen([exe, "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-S", os.path.join(d, "scp%d" % k),
+                                               "-L", d, "-M", os.path.join(d, "out"), "-p", str(k + 1), os.path.join(d, "hmmlist")],
+                                              stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT))
+            if any(p.wait() != 0 for p in procs):
                 return None
             times.append(time.perf_counter() - t0)
         dt = times[1] - times[0]
-        return (n2 - n2 // 2, dt) if dt > 0 else None
+        return (workers * n_utt, dt, workers) if dt > 0 else None
     except OSError:
         return None
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
+
+
+def host_cores() -> int:
+    """Cores this process may use (the reference is run as that many -p workers, capped at the physical core count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import psutil
+        ph = psutil.cpu_count(logical=False)
+        if ph:
+            n = min(n, ph)
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
 
 
 def main():
@@ -108,8 +127,10 @@ def main():
     ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
     ap.add_argument("--score", choices=["exact", "mfma", "fast"], default="fast",
                     help="scoring arithmetic: exact = bit-identical to the reference (packed FP32 VALU); mfma = fp32 matrix-core GEMM, 1e-4 tolerance class")
-    ap.add_argument("--two-streams", type=int, default=1, help="run the alternating batch contexts on their own streams (1) or on one stream (0)")
-    ap.add_argument("--contexts", type=int, default=2, help="batch contexts in flight (each with its own work space and accumulator vector)")
+    ap.add_argument("--two-streams", type=int, default=1, help="run the chunks of an iteration on two alternating streams (1) or on one stream (0)")
+    ap.add_argument("--chunks", type=int, default=2, help="sub-batches an iteration's shard is cut into (alternating over two streams, one accumulator vector)")
+    ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the reference CPU baseline (0 = one per physical host core)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -140,7 +161,6 @@ def main():
     pk = s.packed()
     model = capi.Model(pk)
     accs = capi.Accs(model)
-    fb = capi.ForwardBackward(model)
     cfg = capi.fb_config(scoreMode={"exact": 0, "mfma": 1, "fast": 3}[args.score])                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
 
     if args.ragged:                                      # not the headline workload: utterance lengths spread over [frames/2, frames], chains
@@ -149,70 +169,85 @@ def main():
             T = int(rr.integers(args.frames // 2, args.frames + 1))
             s.feats[u] = s.feats[u][:T]; s.seqs[u] = s.seqs[u][: max(1, T // 12)]
     X = np.concatenate(s.feats)
-    frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in s.feats])]).astype(np.int32)
-    labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)
-    labs = np.concatenate(s.seqs).astype(np.int32)
     dX = torch.from_numpy(X).cuda()                      # features resident in HBM before the timed region
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
     vec_ptr, vec_n = accs.device_vector()
-    # Two batch contexts AND two accumulator vectors alternate: the host-side preparation of a pass (CreateInsts /
-    # SetBeamTaper on a worker pool, 0.7 ms) and its launches overlap the previous pass still running on the device, and the
-    # previous pass's all-reduce (52 MB of fp64 over xGMI, on a side stream) overlaps this pass's kernels -- what a training
-    # loop over many batches does.  Every pass does all of its work: zero, prepare, score, beta, alpha, statistics,
-    # all-reduce; its per-utterance results are collected one pass later.  The same stream/event choreography runs at
-    # N = 1 (without the collective), so the single-GPU run exercises it.
-    NC = max(2, args.contexts)
-    fbs = [fb] + [capi.ForwardBackward(model) for _ in range(NC - 1)]
-    accs2 = [accs] + [capi.Accs(model) for _ in range(NC - 1)]
-    acc_ts = [herest.device_vector_as_tensor(a, local_rank) for a in accs2]
-    comm = torch.cuda.Stream()
-    # ... and the two contexts run on two streams, so that the latency-bound recursions of one pass (1250 wavefronts, most
-    # of the machine idle) share the GPU with the compute-bound scoring of the next
-    lanes = [torch.cuda.Stream() for _ in range(NC)] if args.two_streams else [stream] * NC
-    ev_done = [torch.cuda.Event() for _ in range(NC)]    # pass finished accumulating into accs2[k] (its stream)
-    ev_red = [torch.cuda.Event() for _ in range(NC)]     # all-reduce of accs2[k] finished (side stream)
-    red_pending = [False] * NC
+    acc_t = herest.device_vector_as_tensor(accs, local_rank)
+    # A step is one EM ITERATION of HERest over the rank's shard, nothing left out and nothing carried over from the step before:
+    #   ZeroAccs -> [CreateInsts/SetBeamTaper on the host, K1 scoring, K2 beta, K3 alpha + occupation/transition counts, K4 mixture
+    #   statistics] -> all-reduce(sum) of the accumulator vector over the ranks -> UpdateModels + rebuild of every scoring table on the
+    #   device -> per-utterance results on the host.
+    # Iteration k+1 needs iteration k's model, so iterations cannot overlap.  WITHIN an iteration the shard is cut into `chunks`
+    # sub-batches that alternate over two streams and add into the one accumulator vector: the latency-bound recursions of one chunk
+    # share the machine with the compute-bound scoring of the next.
+    NCH = max(1, args.chunks)
+    U = len(s.feats)
+    cuts = [U * c // NCH for c in range(NCH + 1)]
+    frame_off_all = np.concatenate([[0], np.cumsum([f.shape[0] for f in s.feats])]).astype(np.int64)
+    chunks = []
+    for c in range(NCH):
+        u0, u1 = cuts[c], cuts[c + 1]
+        fo = (frame_off_all[u0:u1 + 1] - frame_off_all[u0]).astype(np.int32)
+        lo = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs[u0:u1]])]).astype(np.int32)
+        lb = np.concatenate(s.seqs[u0:u1]).astype(np.int32)
+        chunks.append(dict(fb=capi.ForwardBackward(model), frameOff=fo, labOff=lo, labs=lb, x_ptr=dX.data_ptr() + int(frame_off_all[u0]) * D * 4, n=u1 - u0))
+    lanes = [torch.cuda.Stream() for _ in range(min(2, NCH))] if (args.two_streams and NCH > 1) else [stream]
+    ev_chunk = [torch.cuda.Event() for _ in range(NCH)]
+    ev_zero = torch.cuda.Event()
+    upd = dict(minEgs=3, minVar=args.min_var)                                   # HERest -m 3 (default), -v
+    t_parts = np.zeros(4)                                                      # pass, all-reduce, update, results (host clock, rank-local)
 
-    def launch(i):
-        k = i % NC
-        f = fbs[k]
-        st_k = lanes[k]; sp = st_k.cuda_stream
-        if red_pending[k]:
-            st_k.wait_event(ev_red[k])                   # accs2[k] is still being summed from two passes ago
-        accs2[k].zero(sp)
-        f.prepare(dX.data_ptr(), frameOff, labOff, labs, sp)
-        f.execute(cfg, accs2[k], sp)
-        ev_done[k].record(st_k)
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev_done[k])
-            if world > 1:
-                herest.all_reduce_accumulators(acc_ts[k])   # the pass's one exchange: RCCL sum over xGMI
-            ev_red[k].record(comm)
-        red_pending[k] = True
-        return f
+    def em_iteration(timed: bool):
+        t = [time.perf_counter()]
+        accs.zero(sptr)
+        ev_zero.record(stream)
+        for c, ch in enumerate(chunks):
+            ln = lanes[c % len(lanes)]
+            ln.wait_event(ev_zero)
+            ch["fb"].prepare(ch["x_ptr"], ch["frameOff"], ch["labOff"], ch["labs"], ln.cuda_stream)
+            ch["fb"].execute(cfg, accs, ln.cuda_stream)
+            ev_chunk[c].record(ln)
+        for c in range(NCH):
+            stream.wait_event(ev_chunk[c])
+        if timed:
+            stream.synchronize(); t.append(time.perf_counter())
+        if world > 1:
+            herest.all_reduce_accumulators(acc_t)                              # the iteration's one exchange: RCCL sum over xGMI
+        if timed:
+            stream.synchronize(); t.append(time.perf_counter())
+        st_upd = model.update_device(accs, stream=sptr, **upd)                   # synchronises the stream
+        if timed:
+            t.append(time.perf_counter())
+        prs, sts = zip(*[ch["fb"].results(sptr) for ch in chunks])
+        if timed:
+            t.append(time.perf_counter())
+            t_parts[:] += np.diff(t)
+        return np.concatenate(prs), np.concatenate(sts), st_upd
 
     def sync_all():
-        torch.cuda.synchronize()                         # both streams
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the pass with the INITIAL model, outside the timed region: its log-probabilities are checked against the oracle below
+    accs.zero(sptr)
+    for ch in chunks:
+        ch["fb"].prepare(ch["x_ptr"], ch["frameOff"], ch["labOff"], ch["labs"], sptr); ch["fb"].execute(cfg, accs, sptr)
+    pr_init = np.concatenate([ch["fb"].results(sptr)[0] for ch in chunks])
+    a_init = accs.download()
+    units_local = sum(ch["fb"].frame_states() for ch in chunks)               # (frame, chain state) evaluations of this rank's shard
+
     for i in range(args.warmup):
-        launch(i).results(sptr)
+        em_iteration(False)
     ktimes = np.zeros(4)
     sync_all()
     t0 = time.perf_counter()
-    inflight = []
     for i in range(args.steps):
-        inflight.append(launch(i))
-        if len(inflight) >= NC:                          # collect the oldest pass before its context is reused
-            old = inflight.pop(0)
-            pr, st = old.results(sptr)                   # waits for that pass only
-            ktimes += np.array(old.kernel_times())
-    for old in inflight:
-        pr, st = old.results(sptr)
-        ktimes += np.array(old.kernel_times())
+        pr, st, st_upd = em_iteration(True)
+        for ch in chunks:
+            ktimes += np.array(ch["fb"].kernel_times())                         # per kernel: summed over the iteration's chunks
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -220,17 +255,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ktimes /= max(args.steps, 1)
+    t_parts /= max(args.steps, 1)
+    a = accs.download()                                                        # the last iteration's summed statistics
 
-    a = accs2[(args.steps - 1) % NC].download() if args.steps > 0 else accs.download()
-    # one more pass ALONE on the device (outside the timed region): the kernels' durations without a neighbour stream
-    ktimes_solo = None
-    if args.two_streams:
-        accs2[0].zero(sptr); fbs[0].prepare(dX.data_ptr(), frameOff, labOff, labs, sptr); fbs[0].execute(cfg, accs2[0], sptr)
-        fbs[0].results(sptr)
-        ktimes_solo = np.array(fbs[0].kernel_times())
-        torch.cuda.synchronize()
-    n_ok_local = int((st == capi.UTT_OK).sum())
-    units_local = fb.frame_states()                      # (frame, chain state) evaluations of this rank's shard
+    # one un-chunked pass ALONE (outside the timed region): the kernels' own durations, the latency of a single pass
+    fb1 = capi.ForwardBackward(model)
+    frameOff = frame_off_all.astype(np.int32)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)
+    labs = np.concatenate(s.seqs).astype(np.int32)
+    acc1 = capi.Accs(model)
+    lat = []
+    for rep in range(3):
+        torch.cuda.synchronize(); tl = time.perf_counter()
+        acc1.zero(sptr); fb1.prepare(dX.data_ptr(), frameOff, labOff, labs, sptr); fb1.execute(cfg, acc1, sptr); fb1.results(sptr)
+        lat.append(time.perf_counter() - tl)
+    ktimes_solo = np.array(fb1.kernel_times())
+    torch.cuda.synchronize()
     units_total = float(a["nEval"]) if world > 1 else float(units_local)
     utts_total = float(a["nUttDone"])
     value = units_total * args.steps / dt
@@ -240,13 +280,14 @@ def main():
         kname = "k_score_mfma<20>" if args.score != "exact" else "k_score_exact<39>"
         traffic = None                                       # HBM-side bytes per launch from the committed PMC pass, same workload only
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")))
             w = tj["workload"]
-            if (w["states"], w["mix"], w["utts_per_gpu"], w["frames"]) == (args.states, args.mix, args.utts, args.frames):
+            if (w["states"], w["mix"], w["utts_per_gpu"], w["frames"], w.get("chunks", 1)) == (args.states, args.mix, args.utts, args.frames, NCH):
                 k = tj["kernels"][kname]
                 traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
         except (OSError, KeyError, ValueError):
             traffic = None
+        # the scoring kernel's launches of one iteration (one per chunk): algorithmic flops of the iteration / summed dispatch time
         k1 = float(ktimes[0])
         achieved = units_local * flop_unit / k1 / 1e12 if k1 > 0 else 0.0
         out = {
@@ -262,39 +303,51 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "HERest pass, %d tied states x %d mix, D=39, %d x %d-frame utterances per GPU "
-                                   "(BASELINE config[2]: 10k utterances sharded 8-way)" % (args.states, args.mix, args.utts, args.frames),
-                       "states": args.states, "mix": args.mix, "utts_per_gpu": args.utts, "frames": args.frames,
-                       "parallelism": "utterance shards, 1 all-reduce of %d fp64 accumulators per pass" % vec_n},
+            "config": {"workload": "HERest EM iteration (pass + accumulator all-reduce + model update), %d tied states x %d mix, D=39, "
+                                   "%d x %d-frame utterances per GPU (BASELINE config[2]: 10k utterances sharded 8-way)" % (args.states, args.mix, args.utts, args.frames),
+                       "states": args.states, "mix": args.mix, "utts_per_gpu": args.utts, "frames": args.frames, "chunks": NCH,
+                       "update": "HERest -m 3 -v %g, on the device" % args.min_var,
+                       "parallelism": "utterance shards, 1 all-reduce of %d fp64 accumulators per iteration" % vec_n},
             "herest_utterances_per_sec": utts_total * args.steps / dt,
             "utterances_ok": utts_total,
-            "avg_logprob_per_frame": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
-            "kernel_ms": {"score": ktimes[0] * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
+            "em_iteration_ms": dt / args.steps * 1e3,
+            "em_iteration_parts_ms": {"pass": t_parts[0] * 1e3, "allreduce": t_parts[1] * 1e3, "update_and_refresh": t_parts[2] * 1e3, "results": t_parts[3] * 1e3},
+            "pass_latency_ms": float(np.median(lat)) * 1e3,
+            "avg_logprob_per_frame": float(a_init["totalPr"] / a_init["totalT"]) if a_init["totalT"] else None,
+            "avg_logprob_per_frame_last_iteration": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
+            "update_stats_last_iteration": st_upd,
+            "kernel_ms": {"score": k1 * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
             "score_mode": args.score,
-            "streams": NC if args.two_streams else 1, "contexts": NC,
+            "streams": len(lanes),
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "flop_per_unit": flop_unit, "units_per_launch": units_local},
+                         "flop_per_unit": flop_unit, "units_per_launch": units_local / NCH, "launches_per_step": NCH},
         }
-        if ktimes_solo is not None and ktimes_solo[0] > 0:
-            # `roofline` above follows the contract (events over the timed region, where the kernel shares the GPU with the
-            # other stream's recursions); this is the same kernel running alone
+        if ktimes_solo[0] > 0:
             ach = units_local * flop_unit / float(ktimes_solo[0]) / 1e12
             out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha_stats": ktimes_solo[2] * 1e3, "mix_stats": ktimes_solo[3] * 1e3}
             out["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}
         if args.cpu_seconds > 0 and world == 1:               # the CPU leg runs at N = 1 only
             per_utt = units_local / max(len(s.feats), 1)
-            n, cdt = cpu_baseline(s, pk, args.cpu_seconds)
+            n, cdt, opr = cpu_baseline(s, pk, args.cpu_seconds)
+            # the checker: the oracle's utterance log-probabilities for the same utterances under the same (initial) model
+            tol = 1e-10 if args.score == "exact" else 1e-6
+            worst = float(np.max(np.abs(pr_init[:n] - opr) / np.abs(opr))) if n else 0.0
+            assert worst <= tol, "bench: utterance log-probabilities differ from the oracle: max relative %.3g over %d utterances" % (worst, n)
+            out["oracle_check"] = {"utterances": n, "max_rel_diff_logprob": worst, "tolerance": tol,
+                                   "avg_logprob_per_frame_oracle": float(np.sum(opr) / sum(s.feats[u].shape[0] for u in range(n))),
+                                   "avg_logprob_per_frame_hip": float(np.sum(pr_init[:n]) / sum(s.feats[u].shape[0] for u in range(n)))}
             port = {"value": n * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",
                     "utterances_per_sec": n / cdt,
                     "sample": "%d utterances of the same shard through oracle/htk_oracle.c (scalar C restatement of "
                               "HFB/HModel, bit-exact vs the reference), %.1f s on one host core" % (n, cdt)}
-            ref = cpu_baseline_reference(s, pk, 60)
+            cores = host_cores() if args.cpu_workers <= 0 else args.cpu_workers
+            ref = cpu_baseline_reference(s, pk, 60, workers=cores)
             if ref is not None:
-                out["cpu_baseline"] = {"value": ref[0] * per_utt / ref[1], "unit": "frame-state log-lik/s", "cores": 1, "kind": "reference",
+                out["cpu_baseline"] = {"value": ref[0] * per_utt / ref[1], "unit": "frame-state log-lik/s", "cores": ref[2], "kind": "reference",
                                        "utterances_per_sec": ref[0] / ref[1],
-                                       "sample": "the reference's own HERest (oracle/_ref, one process, one core) over %d utterances of the same "
-                                                 "shard; model loading differenced out (run over 2n minus run over n utterances)" % (2 * ref[0])}
+                                       "sample": "the reference's own HERest (oracle/_ref) as %d parallel `-p k` processes, one per host core, %d utterances of the "
+                                                 "same shard each; model loading differenced out (round over 2n minus round over n utterances per process)" % (ref[2], 60)}
                 out["cpu_baseline_port"] = port
             else:
                 out["cpu_baseline"] = port

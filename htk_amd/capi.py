@@ -56,7 +56,7 @@ class UpdateConfig(C.Structure):
 
 
 class UpdateStats(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nFloorVar", "nFloorVarMix", "nSkippedHmm", "nNoTransOut", "nNoMixUse", "nNoVarUse")]
+    _fields_ = [(n, C.c_int) for n in ("nFloorVar", "nFloorVarMix", "nSkippedHmm", "nNoTransOut", "nNoMixUse", "nNoVarUse", "nWeightAboveOne")]
 
 
 class BatchDesc(C.Structure):
@@ -163,6 +163,19 @@ class Model:
                            vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise))
         st = UpdateStats()
         check(lib().htkamd_model_update(self.h, accs.h, _p(vec), C.byref(cfg), C.byref(st)), "model_update")
+        return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
+
+    def update_device(self, accs: "Accs", minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False, varFloor=None,
+                      rowNormalise=False, stream=None):
+        """The same update on the device, from the accumulator vector where it lies (htkamd_model_update_device)."""
+        vf = None
+        if varFloor is not None:
+            vf = np.ascontiguousarray(varFloor, np.float32)
+            assert vf.shape == (self.D,)
+        cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess),
+                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise))
+        st = UpdateStats()
+        check(lib().htkamd_model_update_device(self.h, accs.h, C.byref(cfg), C.byref(st), _stream(stream)), "model_update_device")
         return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
 
     def get_params(self) -> dict:

@@ -64,6 +64,11 @@ struct htkamd_model {
    double *d_laddTab;          /* [LADD_NK*(LADD_DEG+1)] */
    float *d_mean, *d_ivar, *d_gconst, *d_compLogWt, *d_transP;
    int   *d_stateCompOff, *d_compGauss, *d_transN, *d_transOff;
+   /* device-side update (update.hip): linear parameters and topology, uploaded on first use */
+   float *d_var, *d_compWeight;
+   int   *d_trOccOff, *d_hmmTrans, *d_hmmStateOff, *d_hmmState;
+   void  *d_updScratch; size_t updScratchCap;
+   int    hostStale;           /* the host copies of mean/var/gconst/weights are older than the device's (after htkamd_model_update_device) */
    /* MFMA scoring path (gmm_mfma.hip): A-operand fragments [tile][mfmaNS+4][64], 16 components per tile */
    float *d_mfmaTab;           /* NULL when D has no MFMA kernel */
    int   *d_stateTileOff;      /* [S+1] */
@@ -71,6 +76,8 @@ struct htkamd_model {
    double minLogExp;
 };
 
+int htkamd_model_device_tables(struct htkamd_model *m);      /* model.hip: uploads d_var etc. once */
+int htkamd_model_sync_host(struct htkamd_model *m);          /* model.hip: device -> host parameter copies when stale */
 int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, const double *acc,
                          const htkamd_update_config *cfg, htkamd_update_stats *st);   /* host/update.c */
 

@@ -141,11 +141,13 @@ static int mfma_refresh(htkamd_model *m)
 }
 
 // (Re)derive ivar / log weights / min durations / the interleaved scoring table and push them.
-static int model_refresh(htkamd_model *m)
+static int model_refresh(htkamd_model *m, bool derive = true)
 {
    const int D = m->D, PS = m->PS;
-   htkamd_host_conv_diagc((size_t)m->G * D, m->h_var, m->h_ivar);
-   for (int c = 0; c < m->C; c++) m->h_compLogWt[c] = htkamd_host_mix_log_weight(m->h_compWeight[c]);
+   if (derive) {
+      htkamd_host_conv_diagc((size_t)m->G * D, m->h_var, m->h_ivar);
+      for (int c = 0; c < m->C; c++) m->h_compLogWt[c] = htkamd_host_mix_log_weight(m->h_compWeight[c]);
+   }
    for (int t = 0; t < m->nT; t++) m->h_minDur[t] = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
    float *gp = (float *)calloc((size_t)m->G * PS, sizeof(float));
    for (int g = 0; g < m->G; g++) {
@@ -164,7 +166,34 @@ static int model_refresh(htkamd_model *m)
    if ((rc = toDevice(&m->d_gconst, m->h_gconst, (size_t)m->G))) return rc;
    if ((rc = toDevice(&m->d_compLogWt, m->h_compLogWt, (size_t)m->C))) return rc;
    if ((rc = toDevice(&m->d_transP, m->h_transP, (size_t)m->h_transOff[m->nT]))) return rc;
+   if (m->d_var && ((rc = toDevice(&m->d_var, m->h_var, (size_t)m->G * D)) || (rc = toDevice(&m->d_compWeight, m->h_compWeight, (size_t)m->C)))) return rc;
    return mfma_refresh(m);
+}
+
+// Linear parameters and the model topology on the device, for the device-side update (uploaded on its first call).
+int htkamd_model_device_tables(htkamd_model *m)
+{
+   if (m->d_var) return HTKAMD_OK;
+   int rc;
+   if ((rc = toDevice(&m->d_var, m->h_var, (size_t)m->G * m->D)) || (rc = toDevice(&m->d_compWeight, m->h_compWeight, (size_t)m->C)) ||
+       (rc = toDevice(&m->d_trOccOff, m->h_trOccOff, (size_t)m->nT + 1)) || (rc = toDevice(&m->d_hmmTrans, m->h_hmmTrans, (size_t)m->H)) ||
+       (rc = toDevice(&m->d_hmmStateOff, m->h_hmmStateOff, (size_t)m->H + 1)) ||
+       (rc = toDevice(&m->d_hmmState, m->h_hmmState, (size_t)m->h_hmmStateOff[m->H]))) return rc;
+   return HTKAMD_OK;
+}
+
+// After a device-side update the host copies are refreshed on demand (get_params, the host update, set_params).
+int htkamd_model_sync_host(htkamd_model *m)
+{
+   if (!m->hostStale) return HTKAMD_OK;
+   HIPCHECK(hipMemcpy(m->h_mean, m->d_mean, sizeof(float) * (size_t)m->G * m->D, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(m->h_var, m->d_var, sizeof(float) * (size_t)m->G * m->D, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(m->h_ivar, m->d_ivar, sizeof(float) * (size_t)m->G * m->D, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(m->h_gconst, m->d_gconst, sizeof(float) * (size_t)m->G, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(m->h_compWeight, m->d_compWeight, sizeof(float) * (size_t)m->C, hipMemcpyDeviceToHost));
+   HIPCHECK(hipMemcpy(m->h_compLogWt, m->d_compLogWt, sizeof(float) * (size_t)m->C, hipMemcpyDeviceToHost));
+   m->hostStale = 0;
+   return HTKAMD_OK;
 }
 
 extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **out)
@@ -247,6 +276,8 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
    (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff); (void)hipFree(m->d_mfmaTab); (void)hipFree(m->d_stateTileOff);
+   (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
+   (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    free(m);
 }
 
@@ -254,6 +285,7 @@ extern "C" int htkamd_model_set_params(htkamd_model *m, const float *mean, const
                                        const float *compWeight, const float *transP)
 {
    if (!m) { htkamd_set_error("model_set_params: NULL model"); return HTKAMD_EINVAL; }
+   { int rc0 = htkamd_model_sync_host(m); if (rc0) return rc0; }
    if (mean) memcpy(m->h_mean, mean, sizeof(float) * (size_t)m->G * m->D);
    if (var) memcpy(m->h_var, var, sizeof(float) * (size_t)m->G * m->D);
    if (gconst) memcpy(m->h_gconst, gconst, sizeof(float) * (size_t)m->G);
@@ -262,6 +294,18 @@ extern "C" int htkamd_model_set_params(htkamd_model *m, const float *mean, const
    if (compWeight) memcpy(m->h_compWeight, compWeight, sizeof(float) * (size_t)m->C);
    if (transP) memcpy(m->h_transP, transP, sizeof(float) * (size_t)m->h_transOff[m->nT]);
    return model_refresh(m);
+}
+
+// Prepared tables given by the caller (an HTKLib front-end that has already run ConvDiagC / ConvLogWt / FixGConsts on its HMMSet):
+// the kernels then read the caller's own floats, bit for bit, instead of values re-derived from variances and linear weights.
+extern "C" int htkamd_model_set_prepared(htkamd_model *m, const float *ivar, const float *gconst, const float *compLogWt)
+{
+   if (!m) { htkamd_set_error("model_set_prepared: NULL model"); return HTKAMD_EINVAL; }
+   { int rc0 = htkamd_model_sync_host(m); if (rc0) return rc0; }
+   if (ivar) memcpy(m->h_ivar, ivar, sizeof(float) * (size_t)m->G * m->D);
+   if (gconst) memcpy(m->h_gconst, gconst, sizeof(float) * (size_t)m->G);
+   if (compLogWt) memcpy(m->h_compLogWt, compLogWt, sizeof(float) * (size_t)m->C);
+   return model_refresh(m, false);
 }
 
 extern "C" int htkamd_model_get_prepared(htkamd_model *m, float *ivar, float *gconst, float *compLogWt, int *minDur)
@@ -280,14 +324,18 @@ extern "C" int htkamd_model_update(htkamd_model *m, const htkamd_accs *accs, con
 {
    if (!m || !accs || !hostVec || !cfg || !stats) { htkamd_set_error("model_update: NULL argument"); return HTKAMD_EINVAL; }
    if (accs->m != m) { htkamd_set_error("model_update: accumulators belong to a different model"); return HTKAMD_EINVAL; }
-   int rc = htkamd_update_models(m, &accs->lay, hostVec, cfg, stats);
+   int rc = htkamd_model_sync_host(m);
    if (rc) return rc;
-   return model_refresh(m);
+   rc = htkamd_update_models(m, &accs->lay, hostVec, cfg, stats);
+   if (rc && rc != HTKAMD_EMODEL) return rc;
+   const int rc2 = model_refresh(m);
+   return rc2 ? rc2 : rc;
 }
 
 extern "C" int htkamd_model_get_params(htkamd_model *m, float *mean, float *var, float *gconst, float *compWeight, float *transP)
 {
    if (!m) { htkamd_set_error("model_get_params: NULL model"); return HTKAMD_EINVAL; }
+   { int rc0 = htkamd_model_sync_host(m); if (rc0) return rc0; }
    if (mean) memcpy(mean, m->h_mean, sizeof(float) * (size_t)m->G * m->D);
    if (var) memcpy(var, m->h_var, sizeof(float) * (size_t)m->G * m->D);
    if (gconst) memcpy(gconst, m->h_gconst, sizeof(float) * (size_t)m->G);

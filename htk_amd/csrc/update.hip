@@ -1,0 +1,285 @@
+// update.hip -- UpdateModels on the device: re-estimation from the summed accumulator vector and the refresh of every table the
+// scoring / recursion kernels read, without the accumulators or the parameters crossing PCIe.
+//
+// Same arithmetic as htk_amd/host/update.c (= HERest.c MLUpdateModels :1262, UpdateTrans :795, UpdateWeights :897 + FloorMixes
+// :819, UpdateVars :1045, UpdateMeans :974, FixGConsts HModel.c:5688): every fp64 sum is rounded to float ONCE and the reference's
+// float expressions follow (no FMA contraction; correctly rounded float division).  The reference walks the models in scan order
+// and lets the first model that qualifies (>= minEgs examples) update a shared structure; since a structure is updated at most once,
+// that is "update exactly the structures some qualifying model reaches", which is order-free:
+//   k_upd_mark    thread = physical HMM: example count against minEgs; marks its transition matrix and its tied states
+//   k_upd_trans   thread = transition matrix (marked): a_ij = tr/occ -> log
+//   k_upd_state   thread = tied state: [single-process float round trip of the weights]; marked: c_m/occ, MINMIX cut, floor; then the
+//                 log weights the kernels use, and the state's Gaussians whose new weight exceeds MINMIX are marked
+//   k_upd_gauss   thread = Gaussian: [round trip of the variances]; marked: variances (before the means), means, gConst; then
+//                 1/variance and the interleaved (mean, 1/var) row of the exact scoring kernel
+//   k_upd_mfma    thread = (fragment tile, component column): the A-operand table of the matrix-core scoring kernel
+// 80 000 Gaussians x 39 dimensions: ~60 MB read, ~60 MB written, a fraction of a millisecond -- against 52 MB D2H, a single host
+// thread over 80 k Gaussians and ~80 MB H2D on the host path (which stays: htkamd_model_update).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include "internal.h"
+#include "hipcheck.h"
+
+struct UpdArgs {
+   int D, S, C, G, nT, H, PS, maxM;
+   const int *stateCompOff, *compGauss, *transN, *transOff, *trOccOff, *hmmTrans, *hmmStateOff, *hmmState;
+   float *mean, *var, *gconst, *compWeight, *transP;        // parameters (DIAGC variances, linear weights, log transitions)
+   float *ivar, *gparam, *compLogWt;                        // derived tables
+   const double *acc;
+   htkamd_accs_layout lay;
+   int minEgs, uFlags, singleProcess, rowNormalise, hasVarFloor;
+   float minVar, mixWeightFloor;
+   double logTpi;                                           // log(2 pi) as the host's libm gives it
+   const float *varFloor;
+   unsigned char *qualT, *qualS, *qualG, *anyS, *anyG;      // marked by a qualifying model / used by any model
+   int *stats;                                              // htkamd_update_stats fields in order + [6] weights above 1.001
+};
+
+#define ACCF(off, idx) ((float)a.acc[(off) + (size_t)(idx)])
+
+__global__ void k_upd_mark(UpdArgs a)
+{
+   const int h = blockIdx.x * blockDim.x + threadIdx.x;
+   if (h >= a.H) return;
+   const long long n = llround(a.acc[a.lay.nEgs + h]);
+   const int *hs = a.hmmState + a.hmmStateOff[h];
+   const int ns = a.hmmStateOff[h + 1] - a.hmmStateOff[h];
+   for (int j = 0; j < ns; j++) a.anyS[hs[j]] = 1;
+   if (n < a.minEgs) atomicAdd(a.stats + 2, 1);
+   if (!(n >= a.minEgs && n > 0)) return;
+   a.qualT[a.hmmTrans[h]] = 1;
+   for (int j = 0; j < ns; j++) a.qualS[hs[j]] = 1;
+}
+
+__global__ void k_upd_trans(UpdArgs a)
+{
+   const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+   if (ti >= a.nT || !a.qualT[ti] || !(a.uFlags & HTKAMD_UPTRANS)) return;
+   const int N = a.transN[ti];
+   float *tp = a.transP + a.transOff[ti];
+   for (int i = 1; i < N; i++) {
+      const float occi = ACCF(a.lay.trOcc, a.trOccOff[ti] + i - 1);
+      if (occi > 0.0f && a.rowNormalise) {                   // RestTransP (HRest.c:1015-1039)
+         float sum = 0.0f;
+         for (int j = 2; j <= N; j++) sum += ACCF(a.lay.tr, a.transOff[ti] + (i - 1) * N + (j - 1)) / occi;
+         for (int j = 2; j <= N; j++) {
+            const float x = (ACCF(a.lay.tr, a.transOff[ti] + (i - 1) * N + (j - 1)) / occi) / sum;
+            tp[(i - 1) * N + (j - 1)] = ((double)x < MINLARG) ? (float)LZERO : (float)log((double)x);
+         }
+      } else if (occi > 0.0f) {
+         for (int j = 2; j <= N; j++) {
+            const float x = ACCF(a.lay.tr, a.transOff[ti] + (i - 1) * N + (j - 1)) / occi;
+            tp[(i - 1) * N + (j - 1)] = ((double)x > MINLARG) ? (float)log((double)x) : (float)LZERO;
+         }
+      } else atomicAdd(a.stats + 3, 1);
+   }
+}
+
+__device__ __forceinline__ float mix_log_weight(float w) { return ((double)w < MINMIX) ? (float)LZERO : (float)log((double)w); }
+
+__global__ void k_upd_state(UpdArgs a)
+{
+   const int s = blockIdx.x * blockDim.x + threadIdx.x;
+   if (s >= a.S) return;
+   const int c0 = a.stateCompOff[s], M = a.stateCompOff[s + 1] - c0;
+   float *wgt = a.compWeight + c0;
+   if (a.singleProcess && a.anyS[s])                         // ConvLogWt before the pass, ConvExpWt after it (HERest.c:1336-1339)
+      for (int k = 0; k < M; k++) wgt[k] = (float)exp((double)mix_log_weight(wgt[k]));
+   if (a.qualS[s] && a.maxM > 1 && (a.uFlags & HTKAMD_UPMIXES)) {
+      const float occi = ACCF(a.lay.wtOcc, s);
+      if (occi > 0.0f) {
+         for (int k = 0; k < M; k++) {
+            float x = ACCF(a.lay.wt, c0 + k) / occi;
+            if ((double)x > 1.001) atomicAdd(a.stats + 6, 1);                 // HError 2393 in the reference
+            if (x > 1.0f) x = 1.0f;
+            wgt[k] = ((double)x > MINMIX) ? x : 0.0f;
+         }
+         if (a.mixWeightFloor > 0.0f) {                      // FloorMixes
+            float sum = 0.0f, fsum = 0.0f;
+            const float floor = a.mixWeightFloor;
+            for (int k = 0; k < M; k++) {
+               if (wgt[k] > floor) sum += wgt[k];
+               else { fsum += floor; wgt[k] = floor; }
+            }
+            if (fsum != 0.0f && sum != 0.0f) {
+               const float scale = (float)((1.0 - (double)fsum) / (double)sum);
+               for (int k = 0; k < M; k++) if (wgt[k] > floor) wgt[k] *= scale;
+            }
+         }
+      } else atomicAdd(a.stats + 4, 1);
+   }
+   for (int k = 0; k < M; k++) {
+      a.compLogWt[c0 + k] = mix_log_weight(wgt[k]);
+      const int g = a.compGauss[c0 + k];
+      if (a.anyS[s]) a.anyG[g] = 1;
+      if (a.qualS[s] && (double)wgt[k] > MINMIX) a.qualG[g] = 1;
+   }
+}
+
+__global__ void k_upd_gauss(UpdArgs a)
+{
+   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= a.G) return;
+   const int D = a.D;
+   float *var = a.var + (size_t)g * D, *mean = a.mean + (size_t)g * D;
+   if (a.singleProcess && a.anyG[g])                         // ConvDiagC before the pass, ForceDiagC after it
+      for (int k = 0; k < D; k++) {
+         float v = var[k], iv;
+         if (v > 1E+30f) v = 1E+30f;
+         if (v < 1E-30f) v = 1E-30f;
+         iv = 1 / v;
+         if (iv > 1E+30f) iv = 1E+30f;
+         if (iv < 1E-30f) iv = 1E-30f;
+         var[k] = 1 / iv;
+      }
+   if (a.qualG[g]) {
+      const float muOcc = ACCF(a.lay.muOcc, g);
+      if (a.uFlags & HTKAMD_UPVARS) {
+         const float occim = ACCF(a.lay.vaOcc, g);
+         if (occim > 0.0f) {
+            const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0f;
+            int floored = 0;
+            for (int k = 0; k < D; k++) {
+               const float muDiffk = shared ? 0.0f : ACCF(a.lay.mu, (size_t)g * D + k) / muOcc;
+               float x = ACCF(a.lay.va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
+               const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
+               if (x < fl) { x = fl; floored++; }
+               var[k] = x;
+            }
+            if (floored) { atomicAdd(a.stats + 0, floored); atomicAdd(a.stats + 1, 1); }
+         } else atomicAdd(a.stats + 5, 1);
+      }
+      if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f)
+         for (int k = 0; k < D; k++) mean[k] += ACCF(a.lay.mu, (size_t)g * D + k) / muOcc;
+      if (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS)) {      // FixDiagGConst
+         float sum = (float)((double)D * a.logTpi);
+         for (int k = 0; k < D; k++) {
+            const float z = ((double)var[k] <= MINLARG) ? (float)LZERO : (float)log((double)var[k]);
+            sum += z;
+         }
+         a.gconst[g] = sum;
+      }
+   }
+   // derived tables: ConvDiagC (HUtil.c:413) and the interleaved row of the exact scoring kernel
+   float *iv = a.ivar + (size_t)g * D, *gp = a.gparam + (size_t)g * a.PS;
+   for (int k = 0; k < D; k++) {
+      float v = var[k];
+      if (v > 1E+30f) v = 1E+30f;
+      if (v < 1E-30f) v = 1E-30f;
+      const float r = 1 / v;
+      iv[k] = r; gp[2 * k] = mean[k]; gp[2 * k + 1] = r;
+   }
+   gp[2 * D] = a.gconst[g];
+}
+
+// A-operand fragment table of gmm_mfma.hip; layout and arithmetic as mfma_refresh() in model.hip
+struct MfmaTabArgs {
+   int D, NS, S;
+   const int *stateCompOff, *stateTileOff, *compGauss;
+   const float *mean, *ivar, *gconst, *compLogWt;
+   float *tab;
+};
+
+__global__ void k_upd_mfma(MfmaTabArgs a, int nTiles)
+{
+   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+   if (idx >= nTiles * 16) return;
+   const int t = idx >> 4, col = idx & 15;
+   // state of tile t: binary search in stateTileOff
+   int lo = 0, hi = a.S - 1;
+   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.stateTileOff[mid] <= t) lo = mid; else hi = mid - 1; }
+   const int s = lo, c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+   const int c = c0 + 16 * (t - a.stateTileOff[s]) + col;
+   const int NS = a.NS, D = a.D;
+   float *T = a.tab + (size_t)t * (NS + 4) * 64;
+   float *ciRow = T + (size_t)(NS + (col & 3)) * 64 + (col >> 2) * 16;
+   const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
+   if (!live) {
+      for (int j = 0; j < 16; j++) ciRow[j] = -1.0e30f;
+      for (int st = 0; st < NS; st++) for (int kq = 0; kq < 4; kq++) T[(size_t)st * 64 + kq * 16 + col] = 0.0f;
+      return;
+   }
+   const int g = a.compGauss[c];
+   const float *mu = a.mean + (size_t)g * D, *iv = a.ivar + (size_t)g * D;
+   double k0 = a.gconst[g];
+   for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+   const double L2E = 1.4426950408889634;
+   const float ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+   for (int j = 0; j < 16; j++) ciRow[j] = ci;
+   for (int st = 0; st < NS; st++)
+      for (int kq = 0; kq < 4; kq++) {
+         const int dim = 2 * st + (kq >> 1);
+         float v = 0.0f;
+         if (dim < D) v = (kq & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+         T[(size_t)st * 64 + kq * 16 + col] = v;
+      }
+}
+
+int htkamd_model_refresh_mfma_device(htkamd_model *m, hipStream_t s)
+{
+   if (!m->d_mfmaTab) return HTKAMD_OK;
+   MfmaTabArgs t;
+   t.D = m->D; t.NS = m->mfmaNS; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss;
+   t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = m->d_mfmaTab;
+   const int n = m->nTiles * 16;
+   hipLaunchKernelGGL(k_upd_mfma, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, htkamd_update_stats *stats, void *stream)
+{
+   if (!m || !accs || !cfg) { htkamd_set_error("model_update_device: NULL argument"); return HTKAMD_EINVAL; }
+   if (accs->m != m) { htkamd_set_error("model_update_device: accumulators belong to a different model"); return HTKAMD_EINVAL; }
+   hipStream_t s = (hipStream_t)stream;
+   int rc;
+   if ((rc = htkamd_model_device_tables(m))) return rc;
+   const size_t nFlag = (size_t)m->nT + 2 * (size_t)m->S + 2 * (size_t)m->G;
+   const size_t need = ((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int) + sizeof(float) * (size_t)m->D;
+   if (need > m->updScratchCap) {
+      if (m->d_updScratch) (void)hipFree(m->d_updScratch);
+      m->d_updScratch = nullptr; m->updScratchCap = 0;
+      HIPCHECK(hipMalloc(&m->d_updScratch, need));
+      m->updScratchCap = need;
+   }
+   unsigned char *fl = (unsigned char *)m->d_updScratch;
+   HIPCHECK(hipMemsetAsync(fl, 0, ((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int), s));
+   UpdArgs a;
+   memset(&a, 0, sizeof(a));
+   a.D = m->D; a.S = m->S; a.C = m->C; a.G = m->G; a.nT = m->nT; a.H = m->H; a.PS = m->PS; a.maxM = m->maxM;
+   a.stateCompOff = m->d_stateCompOff; a.compGauss = m->d_compGauss; a.transN = m->d_transN; a.transOff = m->d_transOff;
+   a.trOccOff = m->d_trOccOff; a.hmmTrans = m->d_hmmTrans; a.hmmStateOff = m->d_hmmStateOff; a.hmmState = m->d_hmmState;
+   a.mean = m->d_mean; a.var = m->d_var; a.gconst = m->d_gconst; a.compWeight = m->d_compWeight; a.transP = m->d_transP;
+   a.ivar = m->d_ivar; a.gparam = m->d_gparam; a.compLogWt = m->d_compLogWt;
+   a.acc = accs->d_vec; a.lay = accs->lay;
+   a.minEgs = cfg->minEgs; a.uFlags = cfg->uFlags; a.singleProcess = cfg->singleProcess; a.rowNormalise = cfg->rowNormalise;
+   a.minVar = cfg->minVar; a.mixWeightFloor = cfg->mixWeightFloor; a.logTpi = log(HTK_TPI);
+   a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G;
+   a.stats = (int *)(fl + ((nFlag + 63) & ~(size_t)63));
+   float *dFloor = (float *)(a.stats + 16);
+   a.hasVarFloor = cfg->varFloor != nullptr; a.varFloor = dFloor;
+   if (cfg->varFloor) HIPCHECK(hipMemcpyAsync(dFloor, cfg->varFloor, sizeof(float) * (size_t)m->D, hipMemcpyHostToDevice, s));
+   const int B = 128;
+   hipLaunchKernelGGL(k_upd_mark, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
+   hipLaunchKernelGGL(k_upd_trans, dim3((m->nT + B - 1) / B), dim3(B), 0, s, a);
+   hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
+   hipLaunchKernelGGL(k_upd_gauss, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   if ((rc = htkamd_model_refresh_mfma_device(m, s))) return rc;
+   m->hostStale = 1;
+   // the transition matrices are small and the host needs them (minimum durations for CreateInsts, tee flags for the decoder)
+   const size_t nTp = (size_t)m->h_transOff[m->nT];
+   int hst[16];
+   HIPCHECK(hipMemcpyAsync(m->h_transP, m->d_transP, sizeof(float) * nTp, hipMemcpyDeviceToHost, s));
+   HIPCHECK(hipMemcpyAsync(hst, a.stats, sizeof(hst), hipMemcpyDeviceToHost, s));
+   HIPCHECK(hipStreamSynchronize(s));
+   for (int t = 0; t < m->nT; t++) m->h_minDur[t] = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+   if (stats) {
+      stats->nFloorVar = hst[0]; stats->nFloorVarMix = hst[1]; stats->nSkippedHmm = hst[2];
+      stats->nNoTransOut = hst[3]; stats->nNoMixUse = hst[4]; stats->nNoVarUse = hst[5]; stats->nWeightAboveOne = hst[6];
+   }
+   if (hst[6] > 0) { htkamd_set_error("model_update_device: %d mixture weights above 1.001 (HERest: HError 2393)", hst[6]); return HTKAMD_EMODEL; }
+   return HTKAMD_OK;
+}

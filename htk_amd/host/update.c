@@ -90,6 +90,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             if (occi > 0) {
                for (k = 0; k < M; k++) {
                   float x = ACCF(lay->wt, c0 + k) / occi;
+                  if (x > 1.001) st->nWeightAboveOne++;          /* fatal HError 2393 in the reference (HERest.c:926) */
                   if (x > 1.0) x = 1.0;
                   wgt[c0 + k] = (x > MINMIX) ? x : 0.0;
                }
@@ -160,5 +161,9 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
    }
 #undef ACCF
    free(doneT); free(doneS); free(doneMu); free(doneVa);
+   if (st->nWeightAboveOne > 0) {
+      htkamd_set_error("update_models: %d mixture weights above 1.001 (HERest: HError 2393): corrupt accumulators?", st->nWeightAboveOne);
+      return HTKAMD_EMODEL;
+   }
    return HTKAMD_OK;
 }

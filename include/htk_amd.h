@@ -94,6 +94,10 @@ void htkamd_model_destroy(htkamd_model *m);
 /* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */
 int  htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,
                              const float *compWeight, const float *transP);
+/* Prepared tables as an HTKLib front-end holds them after ConvDiagC (HUtil.c:413), FixGConsts (HModel.c:5688) and ConvLogWt (HUtil.c:474):
+   1/variance [G*D], gConst [G], log mixture weights [C] (LZERO below MINMIX).  The kernels then read exactly these floats (the
+   HTKLib shim, shim/htklib_hfb_shim.c, hands over the values of the HMMSet it was given).  Any pointer may be NULL = unchanged. */
+int  htkamd_model_set_prepared(htkamd_model *m, const float *ivar, const float *gconst, const float *compLogWt);
 /* Read back the prepared device-side values (test/debug aid): each may be NULL. */
 int  htkamd_model_get_prepared(htkamd_model *m, float *ivar /*[G*D]*/, float *gconst /*[G]*/,
                                float *compLogWt /*[C]*/, int *minDur /*[nT]*/);
@@ -288,9 +292,16 @@ typedef struct {
    int nFloorVar, nFloorVarMix;      /* "Total %d floored variance elements in %d different mixes"  */
    int nSkippedHmm;                  /* models copied because they had < minEgs examples (-2331)     */
    int nNoTransOut, nNoMixUse, nNoVarUse;   /* warnings -2326 / -2330                                */
+   int nWeightAboveOne;              /* re-estimated mixture weights above 1.001: fatal HError 2393 in UpdateWeights (HERest.c:926);
+                                        the update is carried out (weights clamped to 1) and the call returns HTKAMD_EMODEL */
 } htkamd_update_stats;
 int htkamd_model_update(htkamd_model *m, const htkamd_accs *accs, const double *hostVec,
                         const htkamd_update_config *cfg, htkamd_update_stats *stats);
+/* The same update on the device, straight from the accumulator vector where it lies (after the all-reduce): nothing but the
+   transition matrices (for the host's minimum-duration table) and the counters of `stats` crosses PCIe, and every table the kernels
+   read -- 1/variance, the interleaved scoring rows, log weights, the matrix-core fragment table -- is rebuilt in place.
+   Arithmetic as htkamd_model_update; `stats` may be NULL.  Synchronises `stream` before returning. */
+int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, htkamd_update_stats *stats, void *stream);
 /* Current parameters (DIAGC variances, linear weights, log transitions); any pointer may be NULL. */
 int htkamd_model_get_params(htkamd_model *m, float *mean, float *var, float *gconst, float *compWeight, float *transP);
 

@@ -267,6 +267,61 @@ def test_model_update_vs_reference_mmf(native, name):
     assert "floored variance" not in case["log"] or stats["nFloorVar"] >= 0
 
 
+@pytest.mark.parametrize("variant", ["plain", "single", "floors", "flags", "minegs"])
+@pytest.mark.parametrize("name", ["fb_small", "fb_topo", "c3"])
+def test_device_update_equals_host_update(native, name, variant):
+    """htkamd_model_update_device against htkamd_model_update (host C, itself pinned to the MMF the reference's HERest wrote) from the
+    SAME device accumulators: parameters equal to the last float bit but for the odd value where the device's double log()/exp()
+    rounds the other way (<= 1 ulp, a handful at most), the update counters equal, and every derived table the kernels read -- so the
+    scores of the next pass -- identical in both score modes."""
+    from htk_amd import synth, capi
+    if name == "c3":
+        s = synth.generate(5000, 16, 6000, 24, 500, 3)
+        pk, utts, prune = s.packed(), [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)], None
+    else:
+        case = load_case(name)
+        pk, utts, prune = case["pk"], case["utts"], case["prune"]
+    kw = dict(plain=dict(minEgs=1), single=dict(minEgs=1, singleProcess=True), floors=dict(minEgs=1, minVar=0.7, mixWeightFloor=2e-5 * 3),
+              flags=dict(minEgs=1, uFlags=capi.UPMEANS | capi.UPTRANS, singleProcess=True), minegs=dict(minEgs=3))[variant]
+    if variant == "floors":
+        kw["varFloor"] = np.linspace(0.4, 1.2, int(pk["vecSize"])).astype(np.float32)
+    mh, fb, acc, pr, st = run_fb(native, pk, utts, prune, debug=False)
+    md = native.Model(pk)
+    a = acc.download()
+    sh = mh.update(acc, a["vec"], **kw)
+    accd = native.Accs(md); accd.upload_add(a["vec"])
+    sd = md.update_device(accd, **kw)
+    assert sh == sd, (sh, sd)
+    ph, pd = mh.get_params(), md.get_params()
+    for k in ("mean", "var", "gconst", "compWeight", "transP"):
+        x, y = ph[k].reshape(-1), pd[k].reshape(-1)
+        ne = x != y
+        assert ne.sum() <= max(3, 1e-5 * x.size), (k, int(ne.sum()))
+        assert np.allclose(x[ne], y[ne], rtol=2.5e-7, atol=0), k
+    qh, qd = mh.get_prepared(), md.get_prepared()
+    assert np.array_equal(qh["minDur"], qd["minDur"])
+    if all((ph[k] == pd[k]).all() for k in ph):
+        for k in ("ivar", "gconst", "compLogWt"):
+            assert np.array_equal(qh[k], qd[k]), k
+        X = np.concatenate([u["feat"] for u in utts[:2]])[:300]
+        states = np.arange(min(int(pk["numStates"]), 64), dtype=np.int32)
+        for mode in (0, 1):
+            if mode == 1 and int(pk["vecSize"]) > 40:
+                continue
+            assert np.array_equal(mh.outp_block(X, states, mode=mode), md.outp_block(X, states, mode=mode)), mode
+    # a second pass runs on the refreshed tables
+    model2, fb2, acc2, pr2, st2 = None, None, None, None, None
+    X, frameOff, labOff, labs = batch_arrays(utts[:4])
+    dX = native.DevArray(X)
+    res = []
+    for m_ in (mh, md):
+        fbm = native.ForwardBackward(m_); am = native.Accs(m_)
+        fbm.prepare(dX.ptr.value, frameOff, labOff, labs)
+        fbm.execute(native.fb_config(**(prune or {})), am)
+        res.append(fbm.results()[0])
+    assert np.allclose(res[0], res[1], rtol=1e-9, atol=0)
+
+
 def test_em_iterations_increase_likelihood(native):
     """Three Baum-Welch iterations through prepare/execute/update: the total log-likelihood must not decrease."""
     from htk_amd import synth

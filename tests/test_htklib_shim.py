@@ -1,0 +1,83 @@
+"""The drop-in boundary as a LINKED program: the reference's unchanged HERest.c object + HTKLib without its HFB module + this
+repository's HFB (shim/htklib_hfb_shim.c) + libhtk_amd.so = oracle/_ref/HERest_amd (recipe: oracle/Makefile; built only where
+/root/reference exists, shipped to the GPU box with the other oracle/_ref products).
+CPU: the link resolved every symbol, the HFB entry points come from the shim, and without a device the run stops with the library's
+ENODEV message.  GPU: HTKDemo's first embedded re-estimation pass run by that program reproduces the reference's own run -- the
+log lines HERest prints and the models it writes."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "HERest_amd")
+DEMO = os.path.join(os.path.dirname(__file__), "golden", "demo")
+HFB_SYMBOLS = ["InitFB", "SetTraceFB", "InitialiseForBack", "UseAlignHMMSet", "InitUttInfo", "GetInputObs", "LoadLabs", "LoadData",
+               "InitUttObservations", "FBFile", "PrLog", "SetMinDurs", "FindStateOrder"]
+
+needs_exe = pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/HERest_amd not built (needs /root/reference: make -C oracle)")
+
+
+def _demo_cmd(out_dir, conf):
+    files = sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    return [EXE, "-T", "1", "-w", "3", "-v", "0.05", "-C", conf, "-u", "tmvw", "-d", os.path.join(DEMO, "hmm1"), "-M", out_dir,
+            "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + files
+
+
+@needs_exe
+def test_link_resolves_and_hfb_comes_from_the_shim():
+    nm = subprocess.run(["nm", EXE], capture_output=True, text=True, check=True).stdout
+    defined = {l.split()[-1] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] in "Tt"}
+    undefined = {l.split()[-1] for l in nm.splitlines() if len(l.split()) == 2 and l.split()[0] == "U"}
+    for s in HFB_SYMBOLS + ["__wrap_NewHMMScan", "NewHMMScan", "DumpAccs", "LoadAccs", "LoadHMMSet"]:
+        assert s in defined, s
+    # what stays undefined is resolved at load time: libc/libm and the C ABI of the HIP library
+    ours = sorted(u for u in undefined if u.startswith("htkamd_"))
+    assert "htkamd_fb_execute" in ours and "htkamd_model_create" in ours and "htkamd_accs_download" in ours
+    assert all("@" in u or u.startswith("htkamd_") or u.startswith("_") for u in undefined), sorted(undefined)[:20]
+    # the shim object itself imports only HTKLib's public API and ours
+    obj = os.path.join(ROOT, "oracle", "_ref", "obj", "htklib_hfb_shim.o")
+    und = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout.split()
+    assert "FBFile" not in und and "htkamd_fb_prepare" in und and "ReadAsTable" in und and "__real_NewHMMScan" in und
+    header = open(os.path.join(ROOT, "include", "htk_amd.h")).read()
+    for u in und:
+        if u.startswith("htkamd_"):
+            assert re.search(r"\b%s\s*\(" % u, header), u            # every entry point the shim binds is declared in include/htk_amd.h
+
+
+@needs_exe
+def test_without_a_device_the_front_end_stops_with_enodev(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    conf = tmp_path / "herest.conf"
+    conf.write_text("TARGETKIND = MFCC_E_D\n")
+    r = subprocess.run(_demo_cmd(str(tmp_path), str(conf)), capture_output=True, text=True)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "7399" in out and "no HIP device" in out and "HTKAMD_ENODEV" in out, out[-600:]
+    assert not (tmp_path / "S").exists()                               # nothing was re-estimated on the way
+
+
+@pytest.mark.gpu
+@needs_exe
+def test_reference_herest_front_end_runs_its_e_step_on_the_gpu(native, tmp_path):
+    conf = tmp_path / "herest.conf"
+    conf.write_text("TARGETKIND = MFCC_E_D\n")
+    r = subprocess.run(_demo_cmd(str(tmp_path), str(conf)), capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    ref_log = open(os.path.join(DEMO, "herest_pass1.log")).read()
+    for pat in (r"Pruning-On\[2000\.0\]", r"Total 27 floored variance elements in 15 different mixes",
+                r"average log prob per frame = -5\.900196e\+01", r"total frames seen\s+= 1\.811000e\+03"):
+        assert re.search(pat, ref_log) and re.search(pat, r.stdout), (pat, r.stdout[-800:])
+    assert r.stdout.count("Utterance prob per frame") == 7             # one FBFile per training file, served by the library
+    ref = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm2_expected")).packed()
+    got = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=str(tmp_path)).packed()
+    sigma = np.sqrt(ref["var"])
+    assert (np.abs(got["mean"] - ref["mean"]) <= 1e-4 * np.maximum(np.abs(ref["mean"]), sigma) + 1e-6).all()
+    assert np.allclose(got["var"], ref["var"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(got["gconst"], ref["gconst"], rtol=1e-5)
+    lin = lambda t: np.where(t > -0.5e10, np.exp(t.astype(np.float64)), 0.0)
+    assert np.allclose(lin(got["transP"]), lin(ref["transP"]), rtol=1e-4, atol=1e-7)
