@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--score", choices=["exact", "mfma", "fast"], default="fast",
                     help="scoring arithmetic: exact = bit-identical to the reference (packed FP32 VALU); mfma = fp32 matrix-core GEMM, 1e-4 tolerance class")
     ap.add_argument("--two-streams", type=int, default=1, help="run the chunks of an iteration on two alternating streams (1) or on one stream (0)")
-    ap.add_argument("--chunks", type=int, default=2, help="sub-batches an iteration's shard is cut into (alternating over two streams, one accumulator vector)")
+    ap.add_argument("--chunks", type=int, default=1, help="sub-batches an iteration's shard is cut into (alternating over two streams, one accumulator vector)")
     ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the reference CPU baseline (0 = one per physical host core)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -178,9 +178,11 @@ def main():
     #   ZeroAccs -> [CreateInsts/SetBeamTaper on the host, K1 scoring, K2 beta, K3 alpha + occupation/transition counts, K4 mixture
     #   statistics] -> all-reduce(sum) of the accumulator vector over the ranks -> UpdateModels + rebuild of every scoring table on the
     #   device -> per-utterance results on the host.
-    # Iteration k+1 needs iteration k's model, so iterations cannot overlap.  WITHIN an iteration the shard is cut into `chunks`
-    # sub-batches that alternate over two streams and add into the one accumulator vector: the latency-bound recursions of one chunk
-    # share the machine with the compute-bound scoring of the next.
+    # Iteration k+1 needs iteration k's model, so the device work of two iterations cannot overlap.  The one thing that does not depend
+    # on the model's parameters -- the host-side batch tables (CreateInsts / SetBeamTaper: transcriptions and minimum durations) -- is
+    # built for iteration k+1 while iteration k's kernels run, and rebuilt inside iteration k+1 should the update have changed a
+    # minimum duration (`batch_tables_rebuilt_in_iteration` counts those).  `--chunks C` cuts the shard into C sub-batches alternating
+    # over two streams into the one accumulator vector (measured: no gain with the state-per-lane recursions; default 1).
     NCH = max(1, args.chunks)
     U = len(s.feats)
     cuts = [U * c // NCH for c in range(NCH + 1)]
@@ -191,23 +193,39 @@ def main():
         fo = (frame_off_all[u0:u1 + 1] - frame_off_all[u0]).astype(np.int32)
         lo = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs[u0:u1]])]).astype(np.int32)
         lb = np.concatenate(s.seqs[u0:u1]).astype(np.int32)
-        chunks.append(dict(fb=capi.ForwardBackward(model), frameOff=fo, labOff=lo, labs=lb, x_ptr=dX.data_ptr() + int(frame_off_all[u0]) * D * 4, n=u1 - u0))
+        # two batch contexts per chunk: while iteration k's kernels run on one, the host builds iteration k+1's tables in the other
+        chunks.append(dict(fbs=[capi.ForwardBackward(model), capi.ForwardBackward(model)], ready=[False, False], frameOff=fo, labOff=lo, labs=lb,
+                           x_ptr=dX.data_ptr() + int(frame_off_all[u0]) * D * 4, n=u1 - u0))
     lanes = [torch.cuda.Stream() for _ in range(min(2, NCH))] if (args.two_streams and NCH > 1) else [stream]
     ev_chunk = [torch.cuda.Event() for _ in range(NCH)]
     ev_zero = torch.cuda.Event()
     upd = dict(minEgs=3, minVar=args.min_var)                                   # HERest -m 3 (default), -v
     t_parts = np.zeros(4)                                                      # pass, all-reduce, update, results (host clock, rank-local)
+    n_reprepared = [0]
+    it_no = [0]
+
+    def prep(ch, k, sp):
+        ch["fbs"][k].prepare(ch["x_ptr"], ch["frameOff"], ch["labOff"], ch["labs"], sp)
+        ch["ready"][k] = True
 
     def em_iteration(timed: bool):
+        k = it_no[0] & 1
+        it_no[0] += 1
         t = [time.perf_counter()]
         accs.zero(sptr)
         ev_zero.record(stream)
         for c, ch in enumerate(chunks):
             ln = lanes[c % len(lanes)]
             ln.wait_event(ev_zero)
-            ch["fb"].prepare(ch["x_ptr"], ch["frameOff"], ch["labOff"], ch["labs"], ln.cuda_stream)
-            ch["fb"].execute(cfg, accs, ln.cuda_stream)
+            # CreateInsts / SetBeamTaper depend on the transcriptions and the models' minimum durations only: the tables were built
+            # during the previous iteration (below) and are rebuilt here if its update changed a minimum duration
+            if not (ch["ready"][k] and ch["fbs"][k].prepared_current()):
+                prep(ch, k, ln.cuda_stream)
+                n_reprepared[0] += int(timed)
+            ch["fbs"][k].execute(cfg, accs, ln.cuda_stream)
             ev_chunk[c].record(ln)
+        for c, ch in enumerate(chunks):                                        # the kernels are running: next iteration's tables
+            prep(ch, k ^ 1, lanes[c % len(lanes)].cuda_stream)
         for c in range(NCH):
             stream.wait_event(ev_chunk[c])
         if timed:
@@ -219,11 +237,11 @@ def main():
         st_upd = model.update_device(accs, stream=sptr, **upd)                   # synchronises the stream
         if timed:
             t.append(time.perf_counter())
-        prs, sts = zip(*[ch["fb"].results(sptr) for ch in chunks])
+        prs, sts = zip(*[ch["fbs"][k].results(sptr) for ch in chunks])
         if timed:
             t.append(time.perf_counter())
             t_parts[:] += np.diff(t)
-        return np.concatenate(prs), np.concatenate(sts), st_upd
+        return np.concatenate(prs), np.concatenate(sts), st_upd, k
 
     def sync_all():
         torch.cuda.synchronize()
@@ -234,10 +252,10 @@ def main():
     # the pass with the INITIAL model, outside the timed region: its log-probabilities are checked against the oracle below
     accs.zero(sptr)
     for ch in chunks:
-        ch["fb"].prepare(ch["x_ptr"], ch["frameOff"], ch["labOff"], ch["labs"], sptr); ch["fb"].execute(cfg, accs, sptr)
-    pr_init = np.concatenate([ch["fb"].results(sptr)[0] for ch in chunks])
+        prep(ch, 0, sptr); ch["fbs"][0].execute(cfg, accs, sptr)
+    pr_init = np.concatenate([ch["fbs"][0].results(sptr)[0] for ch in chunks])
     a_init = accs.download()
-    units_local = sum(ch["fb"].frame_states() for ch in chunks)               # (frame, chain state) evaluations of this rank's shard
+    units_local = sum(ch["fbs"][0].frame_states() for ch in chunks)           # (frame, chain state) evaluations of this rank's shard
 
     for i in range(args.warmup):
         em_iteration(False)
@@ -245,9 +263,9 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        pr, st, st_upd = em_iteration(True)
+        pr, st, st_upd, kk = em_iteration(True)
         for ch in chunks:
-            ktimes += np.array(ch["fb"].kernel_times())                         # per kernel: summed over the iteration's chunks
+            ktimes += np.array(ch["fbs"][kk].kernel_times())                    # per kernel: summed over the iteration's chunks
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -311,6 +329,7 @@ def main():
             "herest_utterances_per_sec": utts_total * args.steps / dt,
             "utterances_ok": utts_total,
             "em_iteration_ms": dt / args.steps * 1e3,
+            "batch_tables_rebuilt_in_iteration": n_reprepared[0],
             "em_iteration_parts_ms": {"pass": t_parts[0] * 1e3, "allreduce": t_parts[1] * 1e3, "update_and_refresh": t_parts[2] * 1e3, "results": t_parts[3] * 1e3},
             "pass_latency_ms": float(np.median(lat)) * 1e3,
             "avg_logprob_per_frame": float(a_init["totalPr"] / a_init["totalT"]) if a_init["totalT"] else None,

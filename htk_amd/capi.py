@@ -265,12 +265,12 @@ def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, 
 class ForwardBackward:
     """htkamd_fb holder: FBFile (HFB.c:1923) over a batch of utterances."""
 
-    def __init__(self, model: Model, debug: bool = False, force_general: bool = False):
+    def __init__(self, model: Model, debug: bool = False, force_general: bool = False, no_state_path: bool = False):
         self.model = model
         self.h = C.c_void_p()
         check(lib().htkamd_fb_create(model.h, C.byref(self.h)), "fb_create")
-        if debug or force_general:
-            check(lib().htkamd_fb_set_debug(self.h, (1 if debug else 0) | (2 if force_general else 0)), "fb_set_debug")
+        if debug or force_general or no_state_path:
+            check(lib().htkamd_fb_set_debug(self.h, (1 if debug else 0) | (2 if force_general else 0) | (4 if no_state_path else 0)), "fb_set_debug")
         self.nUtt = 0
         self._keep = None
 
@@ -289,6 +289,9 @@ class ForwardBackward:
         pr = np.empty(self.nUtt, np.float64); st = np.empty(self.nUtt, np.int32)
         check(lib().htkamd_fb_results(self.h, _p(pr), _p(st), _stream(stream)), "fb_results")
         return pr, st
+
+    def prepared_current(self) -> bool:
+        return bool(lib().htkamd_fb_prepared_current(self.h))
 
     def frame_states(self) -> int:
         return int(lib().htkamd_fb_frame_states(self.h))

@@ -89,7 +89,7 @@ struct PrepPool {
 // One worker's share of a batch: the tables of a contiguous range of utterances with offsets relative to the share.
 struct PrepChunk {
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
-   std::vector<short> cQ, cI, thrCell;
+   std::vector<short> cQ, cI, thrCell, sQ;
    std::vector<ScoreTask> tasks;
    std::vector<int> evLo, evHi, slotModel;
    size_t outp = 0, beta = 0, gam = 0;
@@ -99,7 +99,7 @@ struct PrepChunk {
    void reset()                                          // keeps the vectors' capacity from batch to batch
    {
       mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear();
-      cQ.clear(); cI.clear(); thrCell.clear(); tasks.clear();
+      cQ.clear(); cI.clear(); thrCell.clear(); sQ.clear(); tasks.clear();
       outp = beta = gam = 0; frameStates = 0; nCellsMax = QMax = TMax = 1; nThrMax = 64; rc = HTKAMD_OK; err[0] = 0;
    }
 };
@@ -109,10 +109,12 @@ struct htkamd_fb {
    int nUtt;
    int debug;
    int forceGeneral;            // test aid: use the workgroup-per-utterance kernels even when the wave path applies
+   int noStatePath;             // test aid: keep utterances off the state-per-lane kernels (fb_state.hip)
+   int topoVersion;             // the model's topology version the batch tables were built against
    // host tables of the prepared batch
    std::vector<UttDesc> utt;
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
-   std::vector<short> cQ, cI, taperLo, taperHi, thrCell;
+   std::vector<short> cQ, cI, taperLo, taperHi, thrCell, sQ;
    std::vector<ScoreTask> tasks;
    std::vector<size_t> gamOff;
    std::vector<int> gamChunkUtt;
@@ -124,9 +126,9 @@ struct htkamd_fb {
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
-   DevBuf d_uttList;                        // utterance numbers grouped by class: W = 1 | 2 | 4 | 8 | general
+   DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
-   int clsOff[6];                           // class c occupies uttList[clsOff[c] .. clsOff[c+1])
+   int clsOff[10];                          // class c occupies uttList[clsOff[c] .. clsOff[c+1])
    size_t betaWTotal;
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
@@ -142,7 +144,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; for (int c = 0; c < 6; c++) fb->clsOff[c] = 0;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) {
       hipError_t e = hipEventCreate(&fb->ev[i]);
@@ -166,7 +168,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -179,6 +181,7 @@ extern "C" int htkamd_fb_set_debug(htkamd_fb *fb, int on)
    if (!fb) { htkamd_set_error("fb_set_debug: NULL"); return HTKAMD_EINVAL; }
    fb->debug = on & 1;
    fb->forceGeneral = (on & 2) ? 1 : 0;
+   fb->noStatePath = (on & 4) ? 1 : 0;
    return HTKAMD_OK;
 }
 
@@ -212,7 +215,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
          C.mN.push_back(N); C.mTp.push_back(m->h_transOff[ti]); C.mCell0.push_back(nCells); C.mSlot0.push_back(nSlots);
          C.mDms.push_back(dm); C.mHmm.push_back(h); C.mTrans.push_back(ti);
          for (int i = 1; i <= N; i++) { C.cQ.push_back((short)q); C.cI.push_back((short)i); }
-         for (int j = 2; j < N; j++) C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]);
+         for (int j = 2; j < N; j++) { C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]); C.sQ.push_back((short)q); }
          nCells += N; nSlots += N - 2; qt += dm;
          if (q > 1 && dm == 0 && prevDm == 0) d.status = HTKAMD_UTT_ETEE;      // successive tee models (HFB.c:557)
          prevDm = dm;
@@ -329,7 +332,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    auto tp0 = std::chrono::steady_clock::now();
    auto lap = [&](const char *what) { if (!timing) return; auto t = std::chrono::steady_clock::now();
       fprintf(stderr, "  prepare %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
-   fb->nUtt = U; fb->dX = b->dX;
+   fb->nUtt = U; fb->dX = b->dX; fb->topoVersion = fb->m->topoVersion;
    fb->utt.assign(U, UttDesc());
    fb->totalFrames = U ? b->frameOff[U] : 0;
    fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
@@ -357,7 +360,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    for (int k = 0; k < nW; k++) if (chunks[k].rc) { htkamd_set_error("%s", chunks[k].err); return chunks[k].rc; }
    // concatenate the shares, rebasing their offsets
    fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
-   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->thrCell.clear();
+   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->thrCell.clear(); fb->sQ.clear();
    fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1; fb->frameStates = 0;
    int nThrMax = 64;
    size_t outp = 0, beta = 0, gam = 0;
@@ -373,7 +376,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       for (ScoreTask &tk : C.tasks) { tk.slot0 += bSlot; tk.outBase += outp; }
       auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
       app(fb->mN, C.mN); app(fb->mTp, C.mTp); app(fb->mCell0, C.mCell0); app(fb->mSlot0, C.mSlot0); app(fb->mDms, C.mDms); app(fb->mHmm, C.mHmm);
-      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks);
+      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->sQ, C.sQ); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks);
       outp += C.outp; beta += C.beta; gam += C.gam;
       fb->frameStates += C.frameStates;
       if (C.nCellsMax > fb->nCellsMax) fb->nCellsMax = C.nCellsMax;
@@ -395,22 +398,30 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    fb->blockDim = nThrMax;
    {  // classes: chains of <= 64 / 128 / 256 models of <= 5 states go to the wave kernels with 1 / 2 / 4 wavefronts, the rest to
       // the general workgroup-per-utterance kernels
-      std::vector<int> cls[5];
+      std::vector<int> cls[9];
       size_t bw = 0;
       for (int u = 0; u < U; u++) {
          UttDesc &d = fb->utt[u];
-         const int W = (fb->m->maxN <= 5 && !fb->forceGeneral) ? (d.Q <= 64 ? 1 : d.Q <= 128 ? 2 : d.Q <= 256 ? 4 : d.Q <= 512 ? 8 : 0) : 0;
-         d.W = W; d.pad = 0; d.betaW0 = bw;
-         bw += (size_t)d.T * 5 * 64 * W;
-         cls[W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4].push_back(u);
+         // a lane per chain state (fb_state.hip) where the chain has no tee model and at most 512 emitting states; else a lane per model
+         // (fb_wave.hip, chains of up to 512 models); else the general workgroup-per-utterance kernels
+         bool noTee = d.status == HTKAMD_UTT_OK || d.status == HTKAMD_UTT_SKIPPED;
+         for (int q = 0; q < d.Q && noTee; q++) if (fb->mDms[d.q0 + q] == 0) noTee = false;
+         const bool small = fb->m->maxN <= 5 && !fb->forceGeneral;
+         int W = 0, kind = 0;
+         if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) { kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8; }
+         else if (small) W = d.Q <= 64 ? 1 : d.Q <= 128 ? 2 : d.Q <= 256 ? 4 : d.Q <= 512 ? 8 : 0;
+         d.W = W; d.pad = kind; d.betaW0 = bw;
+         bw += kind ? (size_t)d.T * 2 * 64 * W : (size_t)d.T * 5 * 64 * W;
+         const int wc = W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4;
+         cls[(kind && W) ? 5 + wc : wc].push_back(u);
       }
       fb->betaWTotal = bw;
       // within a class the longest utterances are dispatched first (their recursions are the critical path when the batch is larger
-      // than the 2048 wavefront slots of the machine), and the four single-wave utterances of a workgroup have similar lengths
-      for (int c = 0; c < 5; c++)
+      // than the wavefront slots of the machine)
+      for (int c = 0; c < 9; c++)
          std::stable_sort(cls[c].begin(), cls[c].end(), [&](int x, int y) { return fb->utt[x].T > fb->utt[y].T; });
       fb->uttList.clear(); fb->clsOff[0] = 0;
-      for (int c = 0; c < 5; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
+      for (int c = 0; c < 9; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
       if (fb->uttList.empty()) fb->uttList.push_back(0);
    }
 
@@ -429,7 +440,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_taperLo, fb->taperLo.data(), sizeof(short) * fb->taperLo.size(), 0}, {&fb->d_taperHi, fb->taperHi.data(), sizeof(short) * fb->taperHi.size(), 0},
          {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
          {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0},
-         {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}};
+         {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -470,6 +481,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
 
 extern "C" long long htkamd_fb_frame_states(const htkamd_fb *fb) { return fb ? fb->frameStates : 0; }
 
+extern "C" int htkamd_fb_prepared_current(const htkamd_fb *fb) { return fb && fb->topoVersion == fb->m->topoVersion; }
+
 extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream)
 {
    if (!fb || !cfg || !accs) { htkamd_set_error("fb_execute: NULL argument"); return HTKAMD_EINVAL; }
@@ -477,6 +490,10 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    if (fb->nUtt == 0) return HTKAMD_OK;
    const htkamd_model *m = fb->m;
    hipStream_t s = (hipStream_t)stream;
+   if (fb->topoVersion != m->topoVersion) {
+      htkamd_set_error("fb_execute: the model's minimum durations changed since htkamd_fb_prepare (a re-estimated transition reached or left zero): prepare the batch again");
+      return HTKAMD_EINVAL;
+   }
 
    ScoreArgs sa;
    sa.tasks = (const ScoreTask *)fb->d_tasks.p; sa.nTasks = (int)fb->tasks.size(); sa.X = fb->dX;
@@ -494,6 +511,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.mN = (const int *)fb->d_mN.p; fa.mTp = (const int *)fb->d_mTp.p; fa.mCell0 = (const int *)fb->d_mCell0.p;
    fa.mSlot0 = (const int *)fb->d_mSlot0.p; fa.mDms = (const int *)fb->d_mDms.p; fa.mHmm = (const int *)fb->d_mHmm.p;
    fa.mTrans = (const int *)fb->d_mTrans.p;
+   fa.sQ = (const short *)fb->d_sQ.p;
    fa.thrCell = (const short *)fb->d_thrCell.p; fa.cQ = (const short *)fb->d_cQ.p; fa.cI = (const short *)fb->d_cI.p; fa.slotState = (const int *)fb->d_slotState.p;
    fa.taperLo = (const short *)fb->d_taperLo.p; fa.taperHi = (const short *)fb->d_taperHi.p;
    fa.qLo = (short *)fb->d_qLo.p; fa.qHi = (short *)fb->d_qHi.p; fa.aLo = (short *)fb->d_aLo.p; fa.aHi = (short *)fb->d_aHi.p;
@@ -538,6 +556,10 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       for (int c = 3; c >= 0; c--) {
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[c]; fc.nList = fb->clsOff[c + 1] - fb->clsOff[c];
          if ((rc = pass == 0 ? htkamd_launch_beta_w(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_w(fc, clsW[c], fastLadd, s))) return rc;
+      }
+      for (int c = 3; c >= 0; c--) {
+         fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[5 + c]; fc.nList = fb->clsOff[6 + c] - fb->clsOff[5 + c];
+         if ((rc = pass == 0 ? htkamd_launch_beta_s(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_s(fc, clsW[c], fastLadd, s))) return rc;
       }
       HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }
@@ -605,7 +627,23 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
    const size_t n = (size_t)T * Q * maxN;
    if (beta) {
       std::vector<double> b((size_t)T * nC);
-      if (d.W > 0) {                                     // the wave path's block [frame][state][lane] -> cells
+      if (d.W > 0 && d.pad == 1) {                       // state-per-lane path: betaS[T][L] (emitting states) + betaE[T][L] (entry state at the
+         const size_t Lw = (size_t)64 * d.W;             // model's first lane); the exit state's value is the next model's entry value one frame on
+         std::vector<double> bs((size_t)T * 2 * Lw);
+         HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + d.betaW0, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));
+         const int *mSl = fb->mSlot0.data() + d.q0;
+         for (int t = 0; t < T; t++)
+            for (int q = 1; q <= Q; q++) {
+               const int Nq = mN[q - 1], l0 = mSl[q - 1];
+               double *cell = &b[(size_t)t * nC + mC[q - 1]];
+               cell[0] = bs[(size_t)T * Lw + (size_t)t * Lw + l0];
+               for (int i = 2; i < Nq; i++) cell[i - 1] = bs[(size_t)t * Lw + l0 + i - 2];
+               double bN = LZERO;
+               if (t == T - 1) bN = (q == Q) ? 0.0 : LZERO;
+               else if (q < Q && q + 1 >= lo[t + 1] && q + 1 <= hi[t + 1]) bN = bs[(size_t)T * Lw + (size_t)(t + 1) * Lw + mSl[q]];
+               cell[Nq - 1] = bN;
+            }
+      } else if (d.W > 0) {                              // the wave path's block [frame][state][lane] -> cells
          const size_t run = (size_t)64 * d.W;
          std::vector<double> bs((size_t)T * 5 * run);
          HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + d.betaW0, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));

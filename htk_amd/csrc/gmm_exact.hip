@@ -183,6 +183,27 @@ extern "C" int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, c
    return outp_block(m, dX, T, dStates, ns, dOut, ldo, scoreMode, stream);
 }
 
+// Task tables of outp_block calls live in a small ring of persistent (device, pinned host) buffer pairs owned by the model: no
+// allocation, no free and no synchronisation per call -- a caller that scores a buffer of frames per call (HVite's POutP through the
+// HTKLib shim, HDecode's block scorer) pays a launch, not an allocator round trip.  A slot is reused only after the event recorded
+// behind its kernel has completed, so up to OB_SLOTS calls may be in flight (on any streams).
+#define OB_SLOTS 4
+struct ObSlot { char *d, *h; size_t cap; hipEvent_t ev; bool hasEv, busy; };
+struct ObRing { ObSlot s[OB_SLOTS]; int next; };
+
+void htkamd_outp_ring_free(void *ring)
+{
+   ObRing *r = (ObRing *)ring;
+   if (!r) return;
+   for (int i = 0; i < OB_SLOTS; i++) {
+      if (r->s[i].busy) (void)hipEventSynchronize(r->s[i].ev);
+      if (r->s[i].d) (void)hipFree(r->s[i].d);
+      if (r->s[i].h) (void)hipHostFree(r->s[i].h);
+      if (r->s[i].hasEv) (void)hipEventDestroy(r->s[i].ev);
+   }
+   free(r);
+}
+
 static int outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns, float *dOut, int ldo, int mode, void *stream)
 {
    if (!m || !dX || !dStates || !dOut || T < 0 || ns < 0 || ldo < T) {
@@ -194,7 +215,23 @@ static int outp_block(htkamd_model *m, const float *dX, int T, const int *dState
    const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
    const int nTiles = (T + FR - 1) / FR, nChunks = (ns + SL - 1) / SL;
    const int nTasks = nTiles * nChunks;
-   ScoreTask *h = (ScoreTask *)malloc(sizeof(ScoreTask) * (size_t)nTasks);
+   if (!m->obRing) { m->obRing = calloc(1, sizeof(ObRing)); if (!m->obRing) { htkamd_set_error("outp_block: out of memory"); return HTKAMD_ENOMEM; } }
+   ObRing *ring = (ObRing *)m->obRing;
+   ObSlot &sl = ring->s[ring->next];
+   ring->next = (ring->next + 1) % OB_SLOTS;
+   if (!sl.hasEv) { HIPCHECK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming)); sl.hasEv = true; }
+   if (sl.busy) { HIPCHECK(hipEventSynchronize(sl.ev)); sl.busy = false; }        // the call that used this slot four calls ago
+   const size_t need = sizeof(ScoreTask) * (size_t)nTasks + sizeof(int);
+   if (need > sl.cap) {
+      if (sl.d) (void)hipFree(sl.d);
+      if (sl.h) (void)hipHostFree(sl.h);
+      sl.d = sl.h = nullptr; sl.cap = 0;
+      const size_t want = need + need / 2 + 4096;
+      HIPCHECK(hipMalloc((void **)&sl.d, want));
+      HIPCHECK(hipHostMalloc((void **)&sl.h, want, hipHostMallocDefault));
+      sl.cap = want;
+   }
+   ScoreTask *h = (ScoreTask *)sl.h;
    int n = 0;
    for (int ti = 0; ti < nTiles; ti++)
       for (int ch = 0; ch < nChunks; ch++) {
@@ -207,20 +244,15 @@ static int outp_block(htkamd_model *m, const float *dX, int T, const int *dState
          tk.ldo = ldo;
          tk.outBase = (size_t)ti * FR;
       }
-   char *d = nullptr;                            // task table followed by the queue head
-   HIPCHECK(hipMalloc((void **)&d, sizeof(ScoreTask) * (size_t)nTasks + sizeof(int)));
-   HIPCHECK(hipMemcpyAsync(d, h, sizeof(ScoreTask) * (size_t)nTasks, hipMemcpyHostToDevice, s));
+   HIPCHECK(hipMemcpyAsync(sl.d, sl.h, sizeof(ScoreTask) * (size_t)nTasks, hipMemcpyHostToDevice, s));
    ScoreArgs a;
-   a.tasks = (const ScoreTask *)d; a.nTasks = nTasks; a.X = dX; a.slotState = dStates; a.out = dOut;
+   a.tasks = (const ScoreTask *)sl.d; a.nTasks = nTasks; a.X = dX; a.slotState = dStates; a.out = dOut;
    a.stateCompOff = m->d_stateCompOff; a.compGauss = m->d_compGauss; a.compLogWt = m->d_compLogWt;
    a.gparam = m->d_gparam; a.PS = m->PS; a.D = m->D; a.minLogExp = m->minLogExp;
-   a.laddTab = m->d_laddTab; a.taskCounter = (int *)(d + sizeof(ScoreTask) * (size_t)nTasks);
+   a.laddTab = m->d_laddTab; a.taskCounter = (int *)(sl.d + sizeof(ScoreTask) * (size_t)nTasks);
    a.mfmaTab = m->d_mfmaTab; a.stateTileOff = m->d_stateTileOff;
-   int rc = (mode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, a, s) : htkamd_launch_score_exact(m, a, s);
-   hipError_t e = hipStreamSynchronize(s);      // the task table is freed below
-   free(h);
-   (void)hipFree(d);
-   if (rc) return rc;
-   HIPCHECK(e);
-   return HTKAMD_OK;
+   const int rc = (mode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, a, s) : htkamd_launch_score_exact(m, a, s);
+   HIPCHECK(hipEventRecord(sl.ev, s));
+   sl.busy = true;
+   return rc;
 }

@@ -68,6 +68,9 @@ struct htkamd_model {
    float *d_var, *d_compWeight;
    int   *d_trOccOff, *d_hmmTrans, *d_hmmStateOff, *d_hmmState;
    void  *d_updScratch; size_t updScratchCap;
+   int    topoVersion;         /* bumped whenever a minimum duration (hence tee-ness) of a transition matrix changes: batch tables
+                                  prepared before that (htkamd_fb_prepare) no longer describe the model */
+   void  *obRing;              /* task-table ring of htkamd_outp_block (gmm_exact.hip) */
    int    hostStale;           /* the host copies of mean/var/gconst/weights are older than the device's (after htkamd_model_update_device) */
    /* MFMA scoring path (gmm_mfma.hip): A-operand fragments [tile][mfmaNS+4][64], 16 components per tile */
    float *d_mfmaTab;           /* NULL when D has no MFMA kernel */
@@ -76,6 +79,7 @@ struct htkamd_model {
    double minLogExp;
 };
 
+void htkamd_outp_ring_free(void *ring);                      /* gmm_exact.hip */
 int htkamd_model_device_tables(struct htkamd_model *m);      /* model.hip: uploads d_var etc. once */
 int htkamd_model_sync_host(struct htkamd_model *m);          /* model.hip: device -> host parameter copies when stale */
 int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, const double *acc,

@@ -52,7 +52,9 @@ struct UttDesc {
    size_t beta0;      // doubles: beta[beta0 + (t-1)*nCells + cell]
    size_t gam0;       // doubles: gam [gam0  + (t-1)*nSlots + slot]
    size_t betaW0;     // doubles: wave path's beta block of this utterance, betaW[betaW0 + ((t-1)*5 + i-1)*64*W + model-1]
-   int W, pad;        // wavefronts working on the utterance (1, 2, 4 or 8: chain of <= 64*W models); 0 = general kernels
+   int W, pad;        // wavefronts working on the utterance (1, 2, 4 or 8); 0 = general kernels.  pad = 0: a lane per MODEL (fb_wave.hip,
+                      // chain of <= 64*W models); pad = 1: a lane per chain STATE (fb_state.hip, <= 64*W emitting states, no tee models),
+                      // beta block = betaS[T][64*W] then betaE[T][64*W]
 };
 
 struct FbArgs {
@@ -66,6 +68,7 @@ struct FbArgs {
    const short *cQ, *cI;
    const short *thrCell;             // [thr0 + thread] -> cell (or -1): threads grouped by role, padded to waves
    const int *slotState;
+   const short *sQ;                  // [slot0 + slot] -> model (1-based) of the chain state (state-per-lane kernels)
    // per-frame (index frame0 + t - 1)
    const short *taperLo, *taperHi;
    short *qLo, *qHi, *aLo, *aHi;
@@ -96,6 +99,9 @@ int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s)
 int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
+// state-per-lane fast path (fb_state.hip): chains of <= 512 emitting states, models of <= 5 states, no tee models
+int htkamd_launch_beta_s(const FbArgs &a, int W, bool fast, hipStream_t s);
+int htkamd_launch_alpha_s(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_alpha_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 

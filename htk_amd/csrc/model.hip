@@ -148,7 +148,10 @@ static int model_refresh(htkamd_model *m, bool derive = true)
       htkamd_host_conv_diagc((size_t)m->G * D, m->h_var, m->h_ivar);
       for (int c = 0; c < m->C; c++) m->h_compLogWt[c] = htkamd_host_mix_log_weight(m->h_compWeight[c]);
    }
-   for (int t = 0; t < m->nT; t++) m->h_minDur[t] = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+   for (int t = 0; t < m->nT; t++) {
+      const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+      if (md != m->h_minDur[t]) { m->h_minDur[t] = md; m->topoVersion++; }
+   }
    float *gp = (float *)calloc((size_t)m->G * PS, sizeof(float));
    for (int g = 0; g < m->G; g++) {
       float *p = gp + (size_t)g * PS;
@@ -221,6 +224,7 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
    m->h_hmmStateOff = dupHost(d->hmmStateOff, (size_t)m->H + 1);
    m->h_hmmState = dupHost(d->hmmState, (size_t)d->hmmStateOff[m->H]);
    m->h_minDur = dupHost((const int *)nullptr, (size_t)m->nT);
+   for (int t = 0; t < m->nT; t++) m->h_minDur[t] = -1;
    m->h_trOccOff = dupHost((const int *)nullptr, (size_t)m->nT + 1);
    m->h_gconst = dupHost(d->gconst, (size_t)m->G);
    if (!d->gconst)                                   // CheckMix: gConst fixed at load (HModel.c:206-208)
@@ -278,6 +282,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff); (void)hipFree(m->d_mfmaTab); (void)hipFree(m->d_stateTileOff);
    (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
+   htkamd_outp_ring_free(m->obRing);
    free(m);
 }
 

@@ -275,7 +275,10 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    HIPCHECK(hipMemcpyAsync(m->h_transP, m->d_transP, sizeof(float) * nTp, hipMemcpyDeviceToHost, s));
    HIPCHECK(hipMemcpyAsync(hst, a.stats, sizeof(hst), hipMemcpyDeviceToHost, s));
    HIPCHECK(hipStreamSynchronize(s));
-   for (int t = 0; t < m->nT; t++) m->h_minDur[t] = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+   for (int t = 0; t < m->nT; t++) {
+      const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+      if (md != m->h_minDur[t]) { m->h_minDur[t] = md; m->topoVersion++; }
+   }
    if (stats) {
       stats->nFloorVar = hst[0]; stats->nFloorVarMix = hst[1]; stats->nSkippedHmm = hst[2];
       stats->nNoTransOut = hst[3]; stats->nNoMixUse = hst[4]; stats->nNoVarUse = hst[5]; stats->nWeightAboveOne = hst[6];

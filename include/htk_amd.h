@@ -203,6 +203,8 @@ const htkamd_labels *htkamd_mlf_find(const htkamd_mlf *m, const char *labFile); 
  * Arithmetic = ShStrP/cSOutP: float Mahalanobis sum in dimension order, mixture log-sum with the
  * double-precision LAdd (HMath.c:1576) re-rounded to float after every component: results are
  * bit-identical to the reference.
+ * Asynchronous on `stream` (dOut is ready once the stream reaches this point); the call itself allocates and frees nothing after
+ * the first few calls.
  * ------------------------------------------------------------------------------------------ */
 int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                       float *dOut, int ldo, void *stream);
@@ -339,12 +341,18 @@ typedef struct htkamd_fb htkamd_fb;
 int  htkamd_fb_create(htkamd_model *m, htkamd_fb **out);
 void htkamd_fb_destroy(htkamd_fb *fb);
 /* Test aid; call before prepare.  bit 0: keep every alpha column (T*cells doubles more per utterance);
-   bit 1: force the general workgroup-per-utterance kernels even where the wave-per-utterance path applies. */
+   bit 1: force the general workgroup-per-utterance kernels even where the wave-per-utterance path applies;
+   bit 2: keep utterances off the lane-per-chain-state kernels (they then take the lane-per-model ones). */
 int  htkamd_fb_set_debug(htkamd_fb *fb, int on);
 /* Host part of CreateInsts/SetBeamTaper for the whole batch + upload of the chain tables.
    Limits per utterance: chains of up to 512 models when no model has more than 5 states, otherwise up to
    1024 model states; an utterance beyond them fails the call with HTKAMD_EINVAL (nothing is truncated). */
 int  htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *batch, void *stream);
+/* The batch tables depend on the transcriptions and on the models' minimum durations only, so a batch may be prepared ahead of the
+   pass that uses it (e.g. for the next EM iteration while this one's kernels run) and executed any number of times.  Returns 0 when
+   a model update has since changed a minimum duration (a transition reached or left zero): htkamd_fb_execute then refuses the batch
+   (HTKAMD_EINVAL) and it must be prepared again. */
+int  htkamd_fb_prepared_current(const htkamd_fb *fb);
 /* Device part: scores, beta pass, alpha pass + statistics into `accs`. Asynchronous on `stream`. */
 int  htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream);
 /* Waits for the stream and copies per-utterance log-probabilities (utt->pr) and status. */

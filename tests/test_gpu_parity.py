@@ -12,11 +12,16 @@ pytestmark = pytest.mark.gpu
 CASES = ["fb_small", "fb_small_prune", "fb_topo", "fb_topo_prune"]
 
 
-def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, scoreMode=0):
+PATHS = ["state", "wave", "general"]        # lane per chain state (fb_state.hip) | lane per model (fb_wave.hip) | workgroup per utterance
+
+
+def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, scoreMode=0, path=None):
     model = native.Model(pk)
     X, frameOff, labOff, labs = batch_arrays(utts)
     dX = native.DevArray(X)
-    fb = native.ForwardBackward(model, debug=debug, force_general=general)
+    if path is not None:
+        general = path == "general"
+    fb = native.ForwardBackward(model, debug=debug, force_general=general, no_state_path=(path == "wave"))
     acc = native.Accs(model)
     fb.prepare(dX.ptr.value, frameOff, labOff, labs)
     fb.execute(native.fb_config(uFlags=uFlags, scoreMode=scoreMode, **(prune or {})), acc)
@@ -138,11 +143,11 @@ def test_mfma_forward_backward_within_tolerance(native, name, mode):
 
 
 # ----------------------------------------------------------------------------------------- forward-backward
-@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", CASES)
-def test_forward_backward_vs_reference(native, name, general):
+def test_forward_backward_vs_reference(native, name, path):
     case = load_case(name)
-    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], general=general)
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], case["prune"], path=path)
     for u, ut in enumerate(case["utts"]):
         assert st[u] == ut["ok"] == 1
         assert abs(pr[u] - float(ut["pr"])) <= 1e-10 * abs(float(ut["pr"]))       # alpha/beta bar is 1e-4 relative
@@ -170,17 +175,17 @@ def test_forward_backward_vs_reference(native, name, general):
     assert a["totalT"] == int(ref["totalT"])
 
 
-@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("prune", [dict(pruneInit=0.5, pruneInc=2.0, pruneLim=12.0), dict(pruneInit=0.01, pruneInc=0.0, pruneLim=0.01)],
                          ids=["retry", "overprune"])
-def test_pruning_retry_and_skip(native, oracle, prune, general):
+def test_pruning_retry_and_skip(native, oracle, prune, path):
     """StepBack's retry loop (HFB.c:1332-1361) and the skip of over-pruned utterances, against the oracle."""
     from htk_amd import synth
     po = oracle
     s = synth.generate(30, 3, 20, 6, 90, 103)
     pk = s.packed()
     utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
-    model, fb, acc, pr, st = run_fb(native, pk, utts, prune, general=general)
+    model, fb, acc, pr, st = run_fb(native, pk, utts, prune, path=path)
     om = po.Model(pk); oacc = po.Accs(om); cfg = po.fb_cfg(**prune)
     nskip = 0
     for u in range(6):
