@@ -146,18 +146,19 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    htkamd_fb *fb = new htkamd_fb();
    fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
-   for (int i = 0; i < 5; i++) {
-      hipError_t e = hipEventCreate(&fb->ev[i]);
-      if (e != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate: %s", hipGetErrorString(e)); delete fb; return HTKAMD_EHIP; }
-   }
-   if (hipEventCreate(&fb->evK[0]) != hipSuccess || hipEventCreate(&fb->evK[1]) != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate failed"); delete fb; return HTKAMD_EHIP; }
-   if (hipEventCreateWithFlags(&fb->evCopy, hipEventDisableTiming) != hipSuccess) { htkamd_set_error("fb_create: hipEventCreate failed"); delete fb; return HTKAMD_EHIP; }
-   if (hipStreamCreateWithFlags(&fb->resStream, hipStreamNonBlocking) != hipSuccess) { htkamd_set_error("fb_create: hipStreamCreate failed"); delete fb; return HTKAMD_EHIP; }
-   fb->evValid = true;
+   for (int i = 0; i < 5; i++) fb->ev[i] = nullptr;
+   fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
+   fb->evValid = true;                                   // destroy releases whatever has been created (null handles are skipped)
+   auto fail = [&](const char *what, hipError_t e) { htkamd_set_error("fb_create: %s: %s", what, hipGetErrorString(e)); htkamd_fb_destroy(fb); return HTKAMD_EHIP; };
+   hipError_t e;
+   for (int i = 0; i < 5; i++) if ((e = hipEventCreate(&fb->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+   if ((e = hipEventCreate(&fb->evK[0])) != hipSuccess || (e = hipEventCreate(&fb->evK[1])) != hipSuccess) return fail("hipEventCreate", e);
+   if ((e = hipEventCreateWithFlags(&fb->evCopy, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+   if ((e = hipStreamCreateWithFlags(&fb->resStream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
    int rc;
-   if ((rc = fb->d_counter.reserve(64)) || (rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { delete fb; return rc; }
-   HIPCHECK(hipMemcpy(fb->d_transOff.p, m->h_transOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice));
-   HIPCHECK(hipMemcpy(fb->d_trOccOff.p, m->h_trOccOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice));
+   if ((rc = fb->d_counter.reserve(64)) || (rc = fb->d_transOff.reserve(sizeof(int) * (m->nT + 1))) || (rc = fb->d_trOccOff.reserve(sizeof(int) * (m->nT + 1)))) { htkamd_fb_destroy(fb); return rc; }
+   if ((e = hipMemcpy(fb->d_transOff.p, m->h_transOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice)) != hipSuccess ||
+       (e = hipMemcpy(fb->d_trOccOff.p, m->h_trOccOff, sizeof(int) * (m->nT + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
    *out = fb;
    return HTKAMD_OK;
 }
@@ -172,7 +173,13 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
-   if (fb->evValid) { for (int i = 0; i < 5; i++) (void)hipEventDestroy(fb->ev[i]); (void)hipEventDestroy(fb->evCopy); (void)hipEventDestroy(fb->evK[0]); (void)hipEventDestroy(fb->evK[1]); (void)hipStreamDestroy(fb->resStream); }
+   if (fb->evValid) {
+      for (int i = 0; i < 5; i++) if (fb->ev[i]) (void)hipEventDestroy(fb->ev[i]);
+      if (fb->evCopy) (void)hipEventDestroy(fb->evCopy);
+      if (fb->evK[0]) (void)hipEventDestroy(fb->evK[0]);
+      if (fb->evK[1]) (void)hipEventDestroy(fb->evK[1]);
+      if (fb->resStream) (void)hipStreamDestroy(fb->resStream);
+   }
    delete fb;
 }
 
@@ -328,6 +335,16 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    }
    hipStream_t s = (hipStream_t)stream;
    const int U = b->nUtt;
+   // check the batch description before any state of `fb` is touched: a failing call leaves the previous batch as it was
+   if (U > 0) {
+      if (b->frameOff[0] < 0 || b->labOff[0] < 0) { htkamd_set_error("fb_prepare: negative first offset"); return HTKAMD_EINVAL; }
+      for (int u = 0; u < U; u++)
+         if (b->frameOff[u + 1] < b->frameOff[u] || b->labOff[u + 1] < b->labOff[u]) {
+            htkamd_set_error("fb_prepare: frameOff / labOff must be non-decreasing (utterance %d)", u); return HTKAMD_EINVAL;
+         }
+   }
+   // from here on a failure invalidates the context: execute / results / get_trellis then see an empty batch, never a mixture of two
+   struct Invalidate { htkamd_fb *f; bool ok; ~Invalidate() { if (!ok) { f->nUtt = 0; f->timed = false; } } } guard{fb, false};
    static const bool timing = getenv("HTKAMD_PREP_TIMING") != nullptr;
    auto tp0 = std::chrono::steady_clock::now();
    auto lap = [&](const char *what) { if (!timing) return; auto t = std::chrono::steady_clock::now();
@@ -476,6 +493,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    lap("reserve");
    // no synchronisation here: the copy is stream-ordered before the kernels of execute, and the staging buffer is
    // guarded by evCopy against being refilled while the copy is still in flight
+   guard.ok = true;
    return HTKAMD_OK;
 }
 
@@ -501,9 +519,9 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
-   sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff;
-   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
-   const bool mfmaScores = (cfg->scoreMode & HTKAMD_SCORE_MFMA) != 0, fastLadd = (cfg->scoreMode & HTKAMD_SCORE_FASTLADD) != 0;
+   sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab;
+   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
+   const bool fastLadd = (cfg->scoreMode & HTKAMD_SCORE_FASTLADD) != 0;
 
    FbArgs fa;
    memset(&fa, 0, sizeof(fa));
@@ -538,8 +556,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
 
    int rc;
    HIPCHECK(hipEventRecord(fb->ev[0], s));
-   if ((rc = mfmaScores ? htkamd_launch_score_mfma(m, sa, s, fb->evK[0], fb->evK[1])
-                                                   : htkamd_launch_score_exact(m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
+   if ((rc = htkamd_launch_score(cfg->scoreMode, m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
    fb->scored = sa.nTasks > 0;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
    const int nGeneral = fb->clsOff[5] - fb->clsOff[4];

@@ -1,0 +1,305 @@
+// gmm_bf16.hip -- K1b: GMM state log-likelihoods on the BF16 matrix pipe with three-way operand splitting.
+//
+// Same quantity and the same expanded form as gmm_mfma.hip (K1m):
+//     log2( w_m N(x; mu_m, var_m) ) = cinit_m + sum_k a_mk z_k ,   z = (x_0^2, x_0, x_1^2, x_1, ...),
+//     a_m,2i = -0.5 ivar_mi log2(e),  a_m,2i+1 = mu_mi ivar_mi log2(e)
+// K1m contracts it with v_mfma_f32_16x16x4_f32, which runs at the FP32 VECTOR rate (64 FLOP/clk/SIMD) and shares the FP32 lanes with
+// every other vector instruction of the SIMD.  The BF16 pipe is 16 times faster per clock (v_mfma_f32_16x16x32_bf16: 16 cycles for a
+// 16x16x32 block) and leaves half of its cycles to vector issue, but a bf16 carries 8 significant bits.  So both operands are split,
+// exactly, into three bf16 pieces each,  a = a1 + a2 + a3,  z = z1 + z2 + z3  (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2):
+// |a - a1| <= 2^-9 |a|, |a - a1 - a2| <= 2^-18 |a|), and the product is summed over the six piece pairs that matter at fp32 accuracy:
+//     a z  =  a1 z1 + (a1 z2 + a2 z1) + (a2 z2 + a1 z3 + a3 z1)  +  O(2^-27 |a z|),
+// accumulated in fp32 by the matrix unit.  Six bf16 blocks of K = 32 against eight fp32 blocks of K = 4 for the same 32 terms:
+// 6 x 16 = 96 cycles instead of 8 x 32 = 256, and the mixture's log-sum-exp (v_exp_f32 / v_log_f32 / row swaps) issues beside them.
+// Tolerance class like K1m (|score - reference| <= 1e-3, typically 1e-5): the Viterbi path and the C ABI default stay on gmm_exact.hip.
+//
+// Layout.  K is cut into NC chunks of 32 (NC = ceil(2D/32): 3 at D = 39, dimensions beyond D are zero).  Lane l of a wave holds, per
+// chunk c, the 8 consecutive k = 32c + 8(l>>4) + j of its matrix row / column (cdna_hip_programming.md "A/B operand lane maps"):
+//   A (Gaussians = rows, l&15): host/device-built table, per tile of 16 components: [piece 3][chunk NC][lane 64][8 bf16], then the
+//       accumulator start cinit as [lane 64][4 f32] in the C layout (row = 4(l>>4) + r, col = l&15: rows only matter).
+//   B (frames = columns, l&15): built once per task from the feature rows: 4 consecutive dimensions per lane and chunk, squared and
+//       plain, split into the three pieces (3 x NC x 4 VGPRs per 16-frame column tile).
+// Task structure, LDS staging of the table (one copy per workgroup, a tile ahead), log-sum-exp and stores are K1m's.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) int cint;
+
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#define LOG2(x) __builtin_amdgcn_logf(x)
+#define B16_COL_TILES 2
+
+__device__ __forceinline__ float rows_max_b(float v)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum_b(float v)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// round-to-nearest-even bf16 of a finite float, as bits, and back
+__device__ __host__ __forceinline__ unsigned short bf16_bits(float x)
+{
+   unsigned int u;
+   memcpy(&u, &x, 4);
+   u += 0x7FFFu + ((u >> 16) & 1u);
+   return (unsigned short)(u >> 16);
+}
+__device__ __host__ __forceinline__ float bf16_val(unsigned short b)
+{
+   const unsigned int u = (unsigned int)b << 16;
+   float x;
+   memcpy(&x, &u, 4);
+   return x;
+}
+// x = p1 + p2 + p3 + O(2^-27 |x|), every piece a bf16 and every difference exact in fp32
+__device__ __host__ __forceinline__ void split3(float x, unsigned short &p1, unsigned short &p2, unsigned short &p3)
+{
+   p1 = bf16_bits(x);
+   const float r1 = x - bf16_val(p1);
+   p2 = bf16_bits(r1);
+   const float r2 = r1 - bf16_val(p2);
+   p3 = bf16_bits(r2);
+}
+
+template <int NC>
+__global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
+{
+   constexpr int TWB = 3 * NC * 64 * 16 + 64 * 16;     // bytes per fragment tile
+   constexpr int TW4 = TWB / 16;                       // 16-byte words per tile
+   constexpr int PT = (TW4 + 255) / 256;               // words staged per thread
+   __shared__ u4 wbuf[2][TW4];
+   __shared__ int taskSh;
+   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   const int col = lane & 15, kg = lane >> 4;
+   const int D = a.D;
+   cint *slotState = (cint *)a.slotState;
+   cint *stateTileOff = (cint *)a.stateTileOff;
+   const u4 *tab = (const u4 *)a.bf16Tab;
+
+   for (;;) {
+      if (tid == 0) taskSh = atomicAdd(a.taskCounter, 1);
+      __syncthreads();
+      const int task = __builtin_amdgcn_readfirstlane(taskSh);
+      if (task >= a.nTasks) break;
+      const ScoreTask tk = a.tasks[task];
+      const int fw = 32 * wv;                         // this wave's first frame in the tile
+      const bool active = fw < tk.nFrames;
+
+      int tile = stateTileOff[slotState[tk.slot0]];
+      {
+         const u4 *W = tab + (size_t)tile * TW4;
+#pragma unroll
+         for (int j = 0; j < PT; j++)
+            if (j * 256 + tid < TW4) wbuf[0][j * 256 + tid] = W[j * 256 + tid];
+      }
+
+      // B operand: this lane's frame (col) of each column tile, the 8 k of lane group kg in every chunk, in three bf16 pieces
+      bf8 zb[B16_COL_TILES][3][NC];
+      if (active)
+#pragma unroll
+      for (int ft = 0; ft < B16_COL_TILES; ft++) {
+         int f = fw + ft * 16 + col;
+         if (f > tk.nFrames - 1) f = tk.nFrames - 1;
+         const float *row = a.X + (size_t)(tk.frame0 + f) * D;
+#pragma unroll
+         for (int c = 0; c < NC; c++) {
+            const int d0 = 16 * c + 4 * kg;           // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
+            unsigned short p[3][8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+               int dim = d0 + i;
+               const bool pad = dim >= D;
+               if (pad) dim = D - 1;
+               float v = row[dim];
+               if (pad) v = 0.0f;
+               split3(v * v, p[0][2 * i], p[1][2 * i], p[2][2 * i]);
+               split3(v, p[0][2 * i + 1], p[1][2 * i + 1], p[2][2 * i + 1]);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+               u4 w;
+               w[0] = p[s][0] | ((unsigned int)p[s][1] << 16); w[1] = p[s][2] | ((unsigned int)p[s][3] << 16);
+               w[2] = p[s][4] | ((unsigned int)p[s][5] << 16); w[3] = p[s][6] | ((unsigned int)p[s][7] << 16);
+               zb[ft][s][c] = __builtin_bit_cast(bf8, w);
+            }
+         }
+      }
+      __syncthreads();
+
+      int buf = 0;
+      for (int k = 0; k < tk.nSlots; k++) {
+         const int st = slotState[tk.slot0 + k];
+         const int t1 = stateTileOff[st + 1];
+         const int nextFirst = (k + 1 < tk.nSlots) ? stateTileOff[slotState[tk.slot0 + k + 1]] : -1;
+         float rM[B16_COL_TILES], rS[B16_COL_TILES];
+         bool first = true;
+         for (;;) {
+            const int nextTile = (tile + 1 < t1) ? tile + 1 : nextFirst;
+            u4 stg[PT];
+            if (nextTile >= 0) {
+               const u4 *W = tab + (size_t)nextTile * TW4;
+#pragma unroll
+               for (int j = 0; j < PT; j++)
+                  if (j * 256 + tid < TW4) stg[j] = W[j * 256 + tid];
+            }
+            if (active) {
+               bf8 wa[3][NC];
+#pragma unroll
+               for (int s = 0; s < 3; s++)
+#pragma unroll
+                  for (int c = 0; c < NC; c++) wa[s][c] = __builtin_bit_cast(bf8, wbuf[buf][(s * NC + c) * 64 + lane]);
+               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][3 * NC * 64 + lane]);
+               f4 Cx[B16_COL_TILES];
+#pragma unroll
+               for (int ft = 0; ft < B16_COL_TILES; ft++) Cx[ft] = ci;
+               // smallest products first: (a2 z2, a1 z3, a3 z1), then (a1 z2, a2 z1), then a1 z1
+#pragma unroll
+               for (int c = 0; c < NC; c++)
+#pragma unroll
+                  for (int ft = 0; ft < B16_COL_TILES; ft++) {
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][c], zb[ft][1][c], Cx[ft], 0, 0, 0);
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][c], zb[ft][2][c], Cx[ft], 0, 0, 0);
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2][c], zb[ft][0][c], Cx[ft], 0, 0, 0);
+                  }
+#pragma unroll
+               for (int c = 0; c < NC; c++)
+#pragma unroll
+                  for (int ft = 0; ft < B16_COL_TILES; ft++) {
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][c], zb[ft][1][c], Cx[ft], 0, 0, 0);
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][c], zb[ft][0][c], Cx[ft], 0, 0, 0);
+                  }
+#pragma unroll
+               for (int c = 0; c < NC; c++)
+#pragma unroll
+                  for (int ft = 0; ft < B16_COL_TILES; ft++)
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][c], zb[ft][0][c], Cx[ft], 0, 0, 0);
+               // log-sum-exp over the tile's 16 rows: 4 in this lane, the rest in lanes ^16, ^32, ^48 (base-2 logs, as K1m)
+#pragma unroll
+               for (int ft = 0; ft < B16_COL_TILES; ft++) {
+                  const f4 y = Cx[ft];
+                  float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                  mx = rows_max_b(mx);
+                  float sm = (EXP2(y[0] - mx) + EXP2(y[1] - mx)) + (EXP2(y[2] - mx) + EXP2(y[3] - mx));
+                  sm = rows_sum_b(sm);
+                  if (first) { rM[ft] = mx; rS[ft] = sm; }
+                  else {
+                     const float M2 = fmaxf(rM[ft], mx);
+                     rS[ft] = rS[ft] * EXP2(rM[ft] - M2) + sm * EXP2(mx - M2);
+                     rM[ft] = M2;
+                  }
+               }
+               first = false;
+            }
+            if (nextTile >= 0) {
+#pragma unroll
+               for (int j = 0; j < PT; j++)
+                  if (j * 256 + tid < TW4) wbuf[buf ^ 1][j * 256 + tid] = stg[j];
+            }
+            __syncthreads();
+            buf ^= 1;
+            tile++;
+            if (tile >= t1) break;
+         }
+         tile = nextFirst;
+         const float r0 = (rM[0] + LOG2(rS[0])) * 0.69314718055994531f, r1 = (rM[1] + LOG2(rS[1])) * 0.69314718055994531f;
+         const float res = (kg == 1) ? r1 : r0;
+         float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + fw;
+         if (active && lane < 32 && fw + lane < tk.nFrames) o[lane] = res;
+      }
+   }
+}
+
+int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
+{
+   if (a.nTasks <= 0) return HTKAMD_OK;
+   if (!m->d_bf16Tab) { htkamd_set_error("score_bf16: vector size %d not supported by the matrix-core paths (up to 48)", m->D); return HTKAMD_EMODEL; }
+   HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
+   int blocks = a.nTasks;
+   if (blocks > 256 * 3) blocks = 256 * 3;      // persistent blocks, one task (128 frames x 16 states) at a time
+   dim3 grid(blocks), block(256);
+   switch (m->bf16NC) {
+   case 3: hipExtLaunchKernelGGL((k_score_bf16<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 2: hipExtLaunchKernelGGL((k_score_bf16<2>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 1: hipExtLaunchKernelGGL((k_score_bf16<1>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   default: htkamd_set_error("score_bf16: no kernel for %d K-chunks", m->bf16NC); return HTKAMD_EMODEL;
+   }
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------ the A-operand table, built on the device
+struct Bf16TabArgs {
+   int D, NC, S;
+   const int *stateCompOff, *stateTileOff, *compGauss;
+   const float *mean, *ivar, *gconst, *compLogWt;
+   unsigned short *tab;        // [tile][ 3*NC*64*8 bf16 | 64*4 f32 ]
+};
+
+__global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
+{
+   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+   if (idx >= nTiles * 16) return;
+   const int t = idx >> 4, rowc = idx & 15;            // component = matrix row
+   int lo = 0, hi = a.S - 1;
+   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.stateTileOff[mid] <= t) lo = mid; else hi = mid - 1; }
+   const int s = lo, c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
+   const int NC = a.NC, D = a.D;
+   const size_t tileShorts = (size_t)3 * NC * 64 * 8 + 64 * 8;      // the f32 part counted in shorts
+   unsigned short *T = a.tab + (size_t)t * tileShorts;
+   float *ciBase = (float *)(T + (size_t)3 * NC * 64 * 8);          // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
+   const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
+   const float *mu = nullptr, *iv = nullptr;
+   float ci = -1.0e30f;
+   const double L2E = 1.4426950408889634;
+   if (live) {
+      const int g = a.compGauss[c];
+      mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D;
+      double k0 = a.gconst[g];
+      for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+      ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+   }
+   for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
+   for (int ch = 0; ch < NC; ch++)
+      for (int kg = 0; kg < 4; kg++) {
+         const int laneA = kg * 16 + rowc;
+         for (int j = 0; j < 8; j++) {
+            const int k = 32 * ch + 8 * kg + j, dim = k >> 1;
+            float v = 0.0f;
+            if (live && dim < D) v = (k & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+            unsigned short p1, p2, p3;
+            split3(v, p1, p2, p3);
+            T[((size_t)(0 * NC + ch) * 64 + laneA) * 8 + j] = p1;
+            T[((size_t)(1 * NC + ch) * 64 + laneA) * 8 + j] = p2;
+            T[((size_t)(2 * NC + ch) * 64 + laneA) * 8 + j] = p3;
+         }
+      }
+}
+
+int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
+{
+   hipStream_t s = (hipStream_t)stream;
+   if (!m->d_bf16Tab) return HTKAMD_OK;
+   Bf16TabArgs t;
+   t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss;
+   t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_bf16Tab;
+   const int n = m->nTiles * 16;
+   hipLaunchKernelGGL(k_build_bf16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}

@@ -179,7 +179,7 @@ extern "C" int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const 
 extern "C" int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                                       float *dOut, int ldo, int scoreMode, void *stream)
 {
-   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
+   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA && scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
    return outp_block(m, dX, T, dStates, ns, dOut, ldo, scoreMode, stream);
 }
 
@@ -250,8 +250,8 @@ static int outp_block(htkamd_model *m, const float *dX, int T, const int *dState
    a.stateCompOff = m->d_stateCompOff; a.compGauss = m->d_compGauss; a.compLogWt = m->d_compLogWt;
    a.gparam = m->d_gparam; a.PS = m->PS; a.D = m->D; a.minLogExp = m->minLogExp;
    a.laddTab = m->d_laddTab; a.taskCounter = (int *)(sl.d + sizeof(ScoreTask) * (size_t)nTasks);
-   a.mfmaTab = m->d_mfmaTab; a.stateTileOff = m->d_stateTileOff;
-   const int rc = (mode == HTKAMD_SCORE_MFMA) ? htkamd_launch_score_mfma(m, a, s) : htkamd_launch_score_exact(m, a, s);
+   a.mfmaTab = m->d_mfmaTab; a.stateTileOff = m->d_stateTileOff; a.bf16Tab = m->d_bf16Tab;
+   const int rc = htkamd_launch_score(mode, m, a, s);
    HIPCHECK(hipEventRecord(sl.ev, s));
    sl.busy = true;
    return rc;

@@ -76,10 +76,13 @@ struct htkamd_model {
    float *d_mfmaTab;           /* NULL when D has no MFMA kernel */
    int   *d_stateTileOff;      /* [S+1] */
    int    mfmaNS, nTiles;
+   void  *d_bf16Tab;           /* bf16 x 3 scoring path (gmm_bf16.hip): A-operand pieces per tile; NULL when D > 48 */
+   int    bf16NC;              /* K chunks of 32 per piece: ceil(2D/32) */
    double minLogExp;
 };
 
 void htkamd_outp_ring_free(void *ring);                      /* gmm_exact.hip */
+int htkamd_model_refresh_bf16_device(struct htkamd_model *m, void *stream);   /* gmm_bf16.hip (stream: hipStream_t) */
 int htkamd_model_device_tables(struct htkamd_model *m);      /* model.hip: uploads d_var etc. once */
 int htkamd_model_sync_host(struct htkamd_model *m);          /* model.hip: device -> host parameter copies when stale */
 int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, const double *acc,

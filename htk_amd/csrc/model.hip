@@ -92,8 +92,8 @@ template <typename T> static int toDevice(T **dst, const T *src, size_t n)
 static int mfma_refresh(htkamd_model *m)
 {
    const int D = m->D;
-   if (D > 40) return HTKAMD_OK;                      // no MFMA kernel: the exact path serves such sets
-   // K steps of 4 = 2 dimensions each; kernels exist for 7, 13 and 20 steps, smaller sizes are zero-padded up to the next
+   if (D > 48) return HTKAMD_OK;                      // no matrix-core kernel: the exact path serves such sets
+   // fp32 path: K steps of 4 = 2 dimensions each; kernels exist for 7, 13 and 20 steps, smaller sizes are zero-padded up to the next
    const int need = (D + 1) / 2;
    const int NS = need <= 7 ? 7 : (need <= 13 ? 13 : 20);
    if (!m->d_stateTileOff) {
@@ -104,7 +104,15 @@ static int mfma_refresh(htkamd_model *m)
       int rc = toDevice(&m->d_stateTileOff, off, (size_t)m->S + 1);
       free(off);
       if (rc) return rc;
+      m->bf16NC = (2 * D + 31) / 32;
+      HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
    }
+   {  // bf16 x 3 path: its table is built on the device from the tables just uploaded
+      int rcb = htkamd_model_refresh_bf16_device(m, nullptr);
+      if (rcb) return rcb;
+      HIPCHECK(hipStreamSynchronize(nullptr));
+   }
+   if (D > 40) return HTKAMD_OK;
    const size_t stride = (size_t)(NS + 4) * 64;
    float *tab = (float *)calloc((size_t)m->nTiles * stride, sizeof(float));
    size_t t = 0;
@@ -280,6 +288,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
    (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff); (void)hipFree(m->d_mfmaTab); (void)hipFree(m->d_stateTileOff);
+   (void)hipFree(m->d_bf16Tab);
    (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
@@ -423,11 +432,11 @@ extern "C" int htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, voi
    if (!a || !hostVec) { htkamd_set_error("accs_upload_add: NULL"); return HTKAMD_EINVAL; }
    double *tmp = nullptr;
    HIPCHECK(hipMalloc((void **)&tmp, sizeof(double) * a->lay.total));
+   struct Free { double *p; ~Free() { (void)hipFree(p); } } freeTmp{tmp};      // released on every path
    hipStream_t s = (hipStream_t)stream;
    HIPCHECK(hipMemcpyAsync(tmp, hostVec, sizeof(double) * a->lay.total, hipMemcpyHostToDevice, s));
    hipLaunchKernelGGL(k_vec_add, dim3(1024), dim3(256), 0, s, a->d_vec, tmp, a->lay.total);
    HIPCHECK(hipGetLastError());
    HIPCHECK(hipStreamSynchronize(s));
-   HIPCHECK(hipFree(tmp));
    return HTKAMD_OK;
 }

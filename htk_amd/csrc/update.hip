@@ -267,7 +267,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
    hipLaunchKernelGGL(k_upd_gauss, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
    HIPCHECK(hipGetLastError());
-   if ((rc = htkamd_model_refresh_mfma_device(m, s))) return rc;
+   if ((rc = htkamd_model_refresh_mfma_device(m, s)) || (rc = htkamd_model_refresh_bf16_device(m, s))) return rc;
    m->hostStale = 1;
    // the transition matrices are small and the host needs them (minimum durations for CreateInsts, tee flags for the decoder)
    const size_t nTp = (size_t)m->h_transOff[m->nT];

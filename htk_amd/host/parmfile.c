@@ -34,9 +34,13 @@ int htkamd_parm_read(const char *path, float **data, int *nFrames, int *nCols, i
    if (sampPeriod) *sampPeriod = (int)be32(hdr + 4);
    fseek(f, 0, SEEK_END); fileBytes = ftell(f); fseek(f, 12, SEEK_SET);
    if (nSamples < 0 || sampSize <= 0) { fclose(f); htkamd_set_error("parm_read: %s: bad header", path); return HTKAMD_EINVAL; }
+   if (sampSize % ((pk & HASCOMPX) ? 2 : 4)) {          /* a row is whole shorts (compressed) or whole floats */
+      fclose(f); htkamd_set_error("parm_read: %s: sample size %d is not a multiple of %d", path, sampSize, (pk & HASCOMPX) ? 2 : 4); return HTKAMD_EINVAL;
+   }
    bodyBytes = (size_t)nSamples * sampSize;
    if ((long)(12 + bodyBytes + ((pk & HASCRCC) ? 2 : 0)) > fileBytes) { fclose(f); htkamd_set_error("parm_read: %s: file shorter than its header says", path); return HTKAMD_EINVAL; }
-   buf = (unsigned char *)malloc(bodyBytes + 2);
+   buf = (unsigned char *)malloc(bodyBytes + 2);          /* bounded by the file's own size (checked above) */
+   if (!buf) { fclose(f); htkamd_set_error("parm_read: %s: out of memory (%zu bytes)", path, bodyBytes); return HTKAMD_ENOMEM; }
    n = (long)fread(buf, 1, bodyBytes + ((pk & HASCRCC) ? 2 : 0), f);
    fclose(f);
    if ((size_t)n != bodyBytes + ((pk & HASCRCC) ? 2 : 0)) { free(buf); htkamd_set_error("parm_read: %s: short read", path); return HTKAMD_EINVAL; }
@@ -51,6 +55,7 @@ int htkamd_parm_read(const char *path, float **data, int *nFrames, int *nCols, i
       if (nSamples < 4) { free(buf); htkamd_set_error("parm_read: %s: compressed file without A/B vectors", path); return HTKAMD_EINVAL; }
       nSamples -= 4;
       out = (float *)malloc(sizeof(float) * (size_t)(nSamples ? nSamples : 1) * cols);
+      if (!out) { free(buf); htkamd_set_error("parm_read: %s: out of memory", path); return HTKAMD_ENOMEM; }
       for (i = 0; i < nSamples; i++)
          for (j = 0; j < cols; j++) {
             const float A = be_float(buf + 4 * j), B = be_float(buf + 4 * (cols + j));
@@ -60,7 +65,8 @@ int htkamd_parm_read(const char *path, float **data, int *nFrames, int *nCols, i
    } else {
       cols = sampSize / 4;
       out = (float *)malloc(sizeof(float) * (size_t)(nSamples ? nSamples : 1) * cols);
-      for (i = 0; i < nSamples * cols; i++) out[i] = be_float(buf + 4 * (size_t)i);
+      if (!out) { free(buf); htkamd_set_error("parm_read: %s: out of memory", path); return HTKAMD_ENOMEM; }
+      { size_t z, nz = (size_t)nSamples * (size_t)cols; for (z = 0; z < nz; z++) out[z] = be_float(buf + 4 * z); }
    }
    free(buf);
    *data = out; *nFrames = nSamples; *nCols = cols;
@@ -83,6 +89,7 @@ int htkamd_parm_write(const char *path, const float *data, int nFrames, int nCol
    hdr[8] = (unsigned char)(sz >> 8); hdr[9] = (unsigned char)sz; hdr[10] = (unsigned char)(pk >> 8); hdr[11] = (unsigned char)pk;
    fwrite(hdr, 1, 12, f);
    buf = (unsigned char *)malloc(4 * (n ? n : 1));
+   if (!buf) { fclose(f); htkamd_set_error("parm_write: out of memory"); return HTKAMD_ENOMEM; }
    for (i = 0; i < n; i++) {
       unsigned u; memcpy(&u, data + i, 4);
       buf[4 * i] = (unsigned char)(u >> 24); buf[4 * i + 1] = (unsigned char)(u >> 16); buf[4 * i + 2] = (unsigned char)(u >> 8); buf[4 * i + 3] = (unsigned char)u;
@@ -118,8 +125,13 @@ int htkamd_wave_read(const char *path, int format, short **samples, long *nSampl
       const long sp = (long)((h[4] << 24) | (h[5] << 16) | (h[6] << 8) | h[7]);
       const int size = (h[8] << 8) | h[9], kind = (h[10] << 8) | h[11];
       if ((kind & 077) != 0 || size != 2 || ns < 0) { fclose(f); htkamd_set_error("wave_read: %s is not an HTK WAVEFORM file (kind %o, sample size %d)", path, kind, size); return HTKAMD_EINVAL; }
+      {  /* the header's count is bounded by what the file holds before anything is allocated */
+         const long at = ftell(f); fseek(f, 0, SEEK_END); const long left = ftell(f) - at; fseek(f, at, SEEK_SET);
+         if (ns > left / 2) { fclose(f); htkamd_set_error("wave_read: %s: file shorter than its header says", path); return HTKAMD_EINVAL; }
+      }
       out = (short *)malloc(sizeof(short) * (size_t)(ns ? ns : 1));
       unsigned char *raw = (unsigned char *)malloc((size_t)(ns ? ns : 1) * 2);
+      if (!out || !raw) { free(raw); free(out); fclose(f); htkamd_set_error("wave_read: %s: out of memory", path); return HTKAMD_ENOMEM; }
       if (fread(raw, 2, (size_t)ns, f) != (size_t)ns) { free(raw); free(out); fclose(f); htkamd_set_error("wave_read: %s: file shorter than its header says", path); return HTKAMD_EINVAL; }
       for (long i = 0; i < ns; i++) out[i] = (short)((raw[2 * i] << 8) | raw[2 * i + 1]);
       free(raw); n = ns; per = (double)sp;
@@ -131,9 +143,14 @@ int htkamd_wave_read(const char *path, int format, short **samples, long *nSampl
          unsigned len = le32(h + 4);
          if (!memcmp(h, "data", 4)) {
             if (!gotFmt) { fclose(f); htkamd_set_error("wave_read: %s: data chunk before fmt chunk", path); return HTKAMD_EINVAL; }
+            {  /* a streamed WAV announces 0xFFFFFFFF (or 0): take what the file holds, as the reference's reader does for pipes */
+               const long at = ftell(f); fseek(f, 0, SEEK_END); const long left = ftell(f) - at; fseek(f, at, SEEK_SET);
+               if ((long)len > left || len == 0xFFFFFFFFu) len = (unsigned)left;
+            }
             n = (long)(len / 2);
             out = (short *)malloc(sizeof(short) * (size_t)(n ? n : 1));
             unsigned char *raw = (unsigned char *)malloc((size_t)(n ? n : 1) * 2);
+            if (!out || !raw) { free(raw); free(out); fclose(f); htkamd_set_error("wave_read: %s: out of memory", path); return HTKAMD_ENOMEM; }
             if (fread(raw, 2, (size_t)n, f) != (size_t)n) { free(raw); free(out); fclose(f); htkamd_set_error("wave_read: %s: data chunk shorter than its length field", path); return HTKAMD_EINVAL; }
             for (long i = 0; i < n; i++) out[i] = (short)le16(raw + 2 * i);
             free(raw);
@@ -149,6 +166,7 @@ int htkamd_wave_read(const char *path, int format, short **samples, long *nSampl
             per = (double)(1.0E7f / (float)rate);                   /* w->sampPeriod = 1.0E7 / (float)lng (HWave.c:1107) */
             gotFmt = 1; len -= 16;
          }
+         len += len & 1u;                                         /* RIFF chunks are padded to an even length */
          if (len && fseek(f, (long)len, SEEK_CUR)) { fclose(f); htkamd_set_error("wave_read: %s: truncated chunk", path); return HTKAMD_EINVAL; }
       }
    } else { fclose(f); htkamd_set_error("wave_read: unknown format %d", format); return HTKAMD_EINVAL; }

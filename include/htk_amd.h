@@ -221,7 +221,12 @@ int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dState
  * Increment error ~1e-7 absolute: utterance log-probabilities ~1e-9 relative, occupancies / accumulators ~1e-5 relative --
  * inside the 1e-4 bar of the HERest path.  Chains that need the general kernels (models of > 5 states) ignore the bit. */
 #define HTKAMD_SCORE_FASTLADD 2
+/* The same expanded form on the BF16 matrix pipe, both operands split exactly into three bf16 pieces and the six piece products that
+ * matter at fp32 accuracy summed in fp32 (gmm_bf16.hip): the tolerance class of HTKAMD_SCORE_MFMA at ~2.5x its speed (vector sizes up
+ * to 48; HTKAMD_EMODEL beyond).  Takes precedence over HTKAMD_SCORE_MFMA when both bits are set. */
+#define HTKAMD_SCORE_BF16  4
 #define HTKAMD_SCORE_FAST  (HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)
+#define HTKAMD_SCORE_FASTEST (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_FASTLADD)
 int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                            float *dOut, int ldo, int scoreMode, void *stream);
 

@@ -41,8 +41,6 @@
 
 #include "htk_amd.h"
 
-void SetIndexes(HMMSet *hset);          /* HModel.c:3942 -- exported by HModel.o, not declared in HModel.h */
-
 #define SHIM_T_TOP 0001
 
 static ConfParam *cParm[MAXGLOBS];
@@ -61,7 +59,7 @@ typedef struct {
    HLink *transOwner;                  /* [nT] a model that owns matrix t */
    int *stateCompOff, *compGauss, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
    /* pointer -> index tables (open addressing) */
-   void **hkey; int *hval; size_t hcap;
+   void **hkey; int *hval; size_t hcap, hn;
    htkamd_model *model;
    htkamd_accs *accs;
    htkamd_fb *fb;
@@ -80,14 +78,26 @@ static void amd_check(int rc, const char *what)
 
 static void map_put(ShimSet *z, void *key, int val)
 {
-   size_t h = ((size_t)key >> 4) * 0x9E3779B97F4A7C15ull % z->hcap;
+   size_t h;
+   if (2 * (z->hn + 1) > z->hcap) {                    /* grow: keep the table at most half full */
+      void **ok = z->hkey; int *ov = z->hval; const size_t oc = z->hcap;
+      size_t i;
+      z->hcap = oc ? 2 * oc : 1024; z->hn = 0;
+      z->hkey = (void **)calloc(z->hcap, sizeof(void *)); z->hval = (int *)calloc(z->hcap, sizeof(int));
+      for (i = 0; i < oc; i++) if (ok[i] != NULL) map_put(z, ok[i], ov[i]);
+      free(ok); free(ov);
+   }
+   h = ((size_t)key >> 4) * 0x9E3779B97F4A7C15ull % z->hcap;
    while (z->hkey[h] != NULL && z->hkey[h] != key) h = (h + 1) % z->hcap;
+   if (z->hkey[h] == NULL) z->hn++;
    z->hkey[h] = key; z->hval[h] = val;
 }
 
 static int map_get(const ShimSet *z, const void *key)
 {
-   size_t h = ((size_t)key >> 4) * 0x9E3779B97F4A7C15ull % z->hcap;
+   size_t h;
+   if (z->hcap == 0) return -1;
+   h = ((size_t)key >> 4) * 0x9E3779B97F4A7C15ull % z->hcap;
    while (z->hkey[h] != NULL) {
       if (z->hkey[h] == key) return z->hval[h];
       h = (h + 1) % z->hcap;
@@ -264,35 +274,50 @@ static void pack_set(ShimSet *z)
    int nTp = 0, nHs = 0;
 
    if (hset->xf != NULL) HError(7399, "FBFile: input transforms are not supported by the MI355X module");
-   SetIndexes(hset);                                    /* sIdx 1..S, mIdx 1..G, tIdx 1..nT (HModel.c:3942) */
-   z->D = hset->vecSize; z->S = hset->numStates; z->G = hset->numMix; z->nT = hset->numTransP; z->H = hset->numPhyHMM;
+   /* Own numbering of the shared structures (a pointer -> index table): physical models in scan order, tied states, Gaussians and
+      transition matrices in the order they are first met.  HModel's SetIndexes (HModel.c:3942) is NOT used for this: it borrows the
+      hook of every transition matrix and leaves it NULL -- the hook that carries the TrAcc the front-end's UpdateTrans reads. */
+   z->H = hset->numPhyHMM;
    z->hmmOf = (HLink *)calloc((size_t)z->H, sizeof(HLink));
-   z->steOf = (StreamElem **)calloc((size_t)z->S + 1, sizeof(StreamElem *));
-   z->mixOf = (MixPDF **)calloc((size_t)z->G + 1, sizeof(MixPDF *));
-   z->transOwner = (HLink *)calloc((size_t)z->nT + 1, sizeof(HLink));
-   z->hcap = (size_t)4 * (size_t)z->H + 64;
-   z->hkey = (void **)calloc(z->hcap, sizeof(void *)); z->hval = (int *)calloc(z->hcap, sizeof(int));
-   /* first walk: the physical models in scan order, their states and matrices */
-   h = 0;
-   NewHMMScan(hset, &hss);
-   do {
-      HLink hmm = hss.hmm;
-      z->hmmOf[h] = hmm; map_put(z, hmm, h);
-      if (z->transOwner[hmm->tIdx] == NULL) { z->transOwner[hmm->tIdx] = hmm; nTp += hmm->numStates * hmm->numStates; }
-      nHs += hmm->numStates - 2;
-      for (j = 2; j < hmm->numStates; j++) {
-         StateInfo *si = hmm->svec[j].info;
-         if (z->steOf[si->sIdx] == NULL) z->steOf[si->sIdx] = si->pdf + 1;
-      }
-      h++;
-   } while (GoNextHMM(&hss));
-   EndHMMScan(&hss);
+   {
+      int capS = 1024, capG = 4096, capT = 256;
+      z->steOf = (StreamElem **)calloc((size_t)capS + 1, sizeof(StreamElem *));
+      z->mixOf = (MixPDF **)calloc((size_t)capG + 1, sizeof(MixPDF *));
+      z->transOwner = (HLink *)calloc((size_t)capT + 1, sizeof(HLink));
+      z->S = z->G = z->nT = 0;
+      h = 0;
+      NewHMMScan(hset, &hss);
+      do {
+         HLink hmm = hss.hmm;
+         if (h >= z->H) HError(7399, "FBFile: more physical models scanned than the set declares (%d)", z->H);
+         z->hmmOf[h] = hmm; map_put(z, hmm, h);
+         if (map_get(z, hmm->transP) < 0) {
+            if (z->nT + 1 > capT) { capT *= 2; z->transOwner = (HLink *)realloc(z->transOwner, sizeof(HLink) * ((size_t)capT + 1)); }
+            map_put(z, hmm->transP, z->nT); z->transOwner[++z->nT] = hmm;
+            nTp += hmm->numStates * hmm->numStates;
+         }
+         nHs += hmm->numStates - 2;
+         for (j = 2; j < hmm->numStates; j++) {
+            StateInfo *si = hmm->svec[j].info;
+            StreamElem *ste = si->pdf + 1;
+            if (map_get(z, si) >= 0) continue;
+            if (z->S + 1 > capS) { capS *= 2; z->steOf = (StreamElem **)realloc(z->steOf, sizeof(StreamElem *) * ((size_t)capS + 1)); }
+            map_put(z, si, z->S); z->steOf[++z->S] = ste;
+            for (k = 1; k <= ste->nMix; k++) {
+               MixPDF *mp = ste->spdf.cpdf[k].mpdf;
+               if (map_get(z, mp) >= 0) continue;
+               if (z->G + 1 > capG) { capG *= 2; z->mixOf = (MixPDF **)realloc(z->mixOf, sizeof(MixPDF *) * ((size_t)capG + 1)); }
+               map_put(z, mp, z->G); z->mixOf[++z->G] = mp;
+            }
+         }
+         h++;
+      } while (GoNextHMM(&hss));
+      EndHMMScan(&hss);
+   }
+   z->D = hset->vecSize;
    if (h != z->H) HError(7399, "FBFile: %d physical models scanned, %d expected", h, z->H);
    z->stateCompOff = (int *)calloc((size_t)z->S + 1, sizeof(int));
-   for (s = 1; s <= z->S; s++) {
-      if (z->steOf[s] == NULL) HError(7399, "FBFile: tied state %d is not reachable from any model", s);
-      z->stateCompOff[s] = z->stateCompOff[s - 1] + z->steOf[s]->nMix;
-   }
+   for (s = 1; s <= z->S; s++) z->stateCompOff[s] = z->stateCompOff[s - 1] + z->steOf[s]->nMix;
    z->C = z->stateCompOff[z->S];
    z->compGauss = (int *)calloc((size_t)z->C, sizeof(int));
    weight = (float *)calloc((size_t)z->C, sizeof(float)); logwt = (float *)calloc((size_t)z->C, sizeof(float));
@@ -302,8 +327,7 @@ static void pack_set(ShimSet *z)
          MixPDF *mp = me->mpdf;
          c = z->stateCompOff[s - 1] + k - 1;
          if (mp->ckind != DIAGC && mp->ckind != INVDIAGC) HError(7399, "FBFile: only diagonal covariances are supported by the MI355X module");
-         z->compGauss[c] = mp->mIdx - 1;
-         if (z->mixOf[mp->mIdx] == NULL) z->mixOf[mp->mIdx] = mp;
+         z->compGauss[c] = map_get(z, mp);
          /* the front-end has already run ConvLogWt when the first file arrives (HERest.c:640): keep BOTH forms exact */
          if (hset->logWt) { logwt[c] = me->weight; weight[c] = (me->weight <= LMINMIX) ? 0.0f : (float)exp((double)me->weight); }
          else { weight[c] = me->weight; logwt[c] = (me->weight < MINMIX) ? (float)LZERO : (float)log((double)me->weight); }
@@ -312,7 +336,6 @@ static void pack_set(ShimSet *z)
    ivar = (float *)calloc((size_t)z->G * z->D, sizeof(float)); gconst = (float *)calloc((size_t)z->G, sizeof(float));
    for (g = 1; g <= z->G; g++) {
       MixPDF *mp = z->mixOf[g];
-      if (mp == NULL) HError(7399, "FBFile: Gaussian %d is not reachable from any state", g);
       for (k = 1; k <= z->D; k++) {
          const float v = mp->cov.var[k];
          mean[(size_t)(g - 1) * z->D + k - 1] = mp->mean[k];
@@ -334,9 +357,9 @@ static void pack_set(ShimSet *z)
    z->hmmState = (int *)calloc((size_t)nHs, sizeof(int));
    for (h = 0; h < z->H; h++) {
       HLink hmm = z->hmmOf[h];
-      z->hmmTrans[h] = hmm->tIdx - 1;
+      z->hmmTrans[h] = map_get(z, hmm->transP);
       z->hmmStateOff[h + 1] = z->hmmStateOff[h] + hmm->numStates - 2;
-      for (j = 2; j < hmm->numStates; j++) z->hmmState[z->hmmStateOff[h] + j - 2] = hmm->svec[j].info->sIdx - 1;
+      for (j = 2; j < hmm->numStates; j++) z->hmmState[z->hmmStateOff[h] + j - 2] = map_get(z, hmm->svec[j].info);
    }
    memset(&d, 0, sizeof(d));
    d.vecSize = z->D; d.numStates = z->S; d.numComp = z->C; d.numGauss = z->G; d.numTrans = z->nT; d.numPhys = z->H;
@@ -365,6 +388,10 @@ static void flush_to_hooks(ShimSet *z)
    v = (double *)malloc(sizeof(double) * lay.total);
    amd_check(htkamd_accs_download(z->accs, v, NULL), "htkamd_accs_download");
    amd_check(htkamd_accs_zero(z->accs, NULL), "htkamd_accs_zero");
+   if (getenv("HTKAMD_SHIM_DUMP")) {                    /* debugging aid: the raw vector of this flush */
+      FILE *df = fopen(getenv("HTKAMD_SHIM_DUMP"), "ab");
+      if (df) { fwrite(v, sizeof(double), lay.total, df); fclose(df); }
+   }
    for (h = 0; h < z->H; h++) {
       const long n = (long)z->hmmOf[h]->hook + (long)llround(v[lay.nEgs + h]);
       z->hmmOf[h]->hook = (void *)n;

@@ -73,15 +73,27 @@ def test_reference_herest_front_end_runs_its_e_step_on_the_gpu(native, tmp_path)
                 r"average log prob per frame = -5\.900196e\+01", r"total frames seen\s+= 1\.811000e\+03"):
         assert re.search(pat, ref_log) and re.search(pat, r.stdout), (pat, r.stdout[-800:])
     assert r.stdout.count("Utterance prob per frame") == 7             # one FBFile per training file, served by the library
-    ref = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm2_expected")).packed()
+    def by_model(mmf):
+        """name -> (means, variances, gconsts, transition matrix) of a model, whatever order the file defined things in"""
+        pk, out = mmf.packed(), {}
+        for name, h in mmf.logical.items():
+            st = pk["hmmState"][pk["hmmStateOff"][h]:pk["hmmStateOff"][h + 1]]
+            g = np.concatenate([pk["compGauss"][pk["stateCompOff"][x]:pk["stateCompOff"][x + 1]] for x in st])
+            t = pk["hmmTrans"][h]
+            out[name] = (pk["mean"][g], pk["var"][g], pk["gconst"][g], pk["transP"][pk["transOff"][t]:pk["transOff"][t + 1]])
+        return out
+
+    ref = by_model(native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm2_expected")))
     # the front-end saves its set the way it loaded it: one file per model, or everything in `newMacros` (SaveHMMSet HModel.c:4979)
     if (tmp_path / "newMacros").exists():
-        got = native.Mmf(files=[str(tmp_path / "newMacros")], hmm_list=os.path.join(DEMO, "bcplist")).packed()
+        got = by_model(native.Mmf(files=[str(tmp_path / "newMacros")], hmm_list=os.path.join(DEMO, "bcplist")))
     else:
-        got = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=str(tmp_path)).packed()
-    sigma = np.sqrt(ref["var"])
-    assert (np.abs(got["mean"] - ref["mean"]) <= 1e-4 * np.maximum(np.abs(ref["mean"]), sigma) + 1e-6).all()
-    assert np.allclose(got["var"], ref["var"], rtol=1e-4, atol=1e-7)
-    assert np.allclose(got["gconst"], ref["gconst"], rtol=1e-5)
+        got = by_model(native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=str(tmp_path)))
     lin = lambda t: np.where(t > -0.5e10, np.exp(t.astype(np.float64)), 0.0)
-    assert np.allclose(lin(got["transP"]), lin(ref["transP"]), rtol=1e-4, atol=1e-7)
+    assert sorted(ref) == sorted(got) and len(ref) == 5
+    for name, (rm, rv, rg, rt) in ref.items():
+        gm, gv, gg, gt = got[name]
+        assert (np.abs(gm - rm) <= 1e-4 * np.maximum(np.abs(rm), np.sqrt(rv)) + 1e-6).all(), name
+        assert np.allclose(gv, rv, rtol=1e-4, atol=1e-7), name
+        assert np.allclose(gg, rg, rtol=1e-5), name
+        assert np.allclose(lin(gt), lin(rt), rtol=1e-4, atol=1e-7), name
