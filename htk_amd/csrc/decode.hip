@@ -573,7 +573,7 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
          sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
          sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
          sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)((char *)dTasks + sizeof(ScoreTask) * tasks.size());
-         sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab;
+         sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
          if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);   // exact: the decoded path is the reference's; matrix-core modes: tolerance class
       }

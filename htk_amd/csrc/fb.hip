@@ -519,8 +519,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
-   sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab;
-   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
+   sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
+   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16 | HTKAMD_SCORE_SOUTP)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
    const bool fastLadd = (cfg->scoreMode & HTKAMD_SCORE_FASTLADD) != 0;
 
    FbArgs fa;

@@ -30,7 +30,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) float cfloat;    // constant address space -> s_load
 typedef const __attribute__((address_space(4))) int cint;
 
-template <int D>
+// SOUTP = true: the mixture sum as SOutP forms it (HModel.c:5538-5552) -- bx and px are LogDouble there: the weighted component
+// likelihood wt + px is a DOUBLE sum and the running log-sum stays double, rounded to float once at the return -- instead of
+// ShStrP's / cSOutP's float after every step.  The two differ in the last bit of ~7 % of scores; tools that call
+// OutP / POutP / SOutP directly (HRest, HInit, HVite's direct scoring) see the SOUTP form.
+template <int D, bool SOUTP>
 __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
 {
    __shared__ double tab[LADD_TAB_DOUBLES];
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
             acc0 = -0.5f * sum.x; acc1 = -0.5f * sum.y;
          } else {
             acc0 = (float)LZERO; acc1 = (float)LZERO;
+            double dacc0 = LZERO, dacc1 = LZERO;
             for (int c = c0; c < c1; c++) {
                const float wt = compLogWt[c];
                if (wt > (float)LMINMIX) {       // wave-uniform branch
@@ -92,11 +97,18 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
                      xm = xm * iv;
                      sum = sum + xm;
                   }
-                  const v2f y = wt + (-0.5f * sum);
-                  acc0 = ladd_tab_f(acc0, y.x, mle, tab);
-                  acc1 = ladd_tab_f(acc1, y.y, mle, tab);
+                  if constexpr (SOUTP) {
+                     const v2f px = -0.5f * sum;
+                     dacc0 = ladd_tab(dacc0, (double)wt + (double)px.x, mle, tab);
+                     dacc1 = ladd_tab(dacc1, (double)wt + (double)px.y, mle, tab);
+                  } else {
+                     const v2f y = wt + (-0.5f * sum);
+                     acc0 = ladd_tab_f(acc0, y.x, mle, tab);
+                     acc1 = ladd_tab_f(acc1, y.y, mle, tab);
+                  }
                }
             }
+            if constexpr (SOUTP) { acc0 = (float)dacc0; acc1 = (float)dacc1; }
          }
          float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo;
          if (lane < tk.nFrames) o[lane] = acc0;
@@ -106,6 +118,9 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
 }
 
 // Any vector size: features are re-read from global memory per dimension (L1-resident rows).
+// DIAGC = true: DOutP's form (HModel.c:5347-5358), xmm*xmm/var with the float division, for sets that were not put through
+// ConvDiagC (HRest, HInit and every other direct caller of OutP score DIAGC sets as they were loaded).
+template <bool SOUTP, bool DIAGC>
 __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
 {
    __shared__ double tab[LADD_TAB_DOUBLES];
@@ -128,40 +143,58 @@ __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
             const int s = a.slotState[tk.slot0 + k];
             const int c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
             float acc = (float)LZERO;
+            double dacc = LZERO;
             for (int c = c0; c < c1; c++) {
                const float wt = a.compLogWt[c];
                if (c1 - c0 > 1 && !(wt > (float)LMINMIX)) continue;
                const float *P = a.gparam + (size_t)a.compGauss[c] * a.PS;
                float sum = P[2 * D];
+               if constexpr (DIAGC) {
+                  const float *V = a.var + (size_t)a.compGauss[c] * D;
+                  for (int i = 0; i < D; i++) {
+                     float xmm = row[i] - P[2 * i];
+                     sum += xmm * xmm / V[i];
+                  }
+               } else
                for (int i = 0; i < D; i++) {
                   float xmm = row[i] - P[2 * i];
                   sum += xmm * xmm * P[2 * i + 1];
                }
                float mixp = -0.5f * sum;
                if (c1 - c0 == 1) acc = mixp;
+               else if constexpr (SOUTP) dacc = ladd_tab(dacc, (double)wt + (double)mixp, a.minLogExp, tab);
                else {
                   float y = wt + mixp;
                   acc = ladd_tab_f(acc, y, a.minLogExp, tab);
                }
             }
+            if (SOUTP && c1 - c0 > 1) acc = (float)dacc;
             if (live) a.out[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + t] = acc;
          }
       }
    }
 }
 
-int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
+int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, bool soutp, bool diagc)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
    int blocks = (a.nTasks + 3) / 4;
    if (blocks > 256 * 5) blocks = 256 * 5;      // persistent: up to 5 four-wave blocks per CU (VGPR-limited)
    dim3 grid(blocks), block(256);
+   if (soutp || diagc) {                         // the HRest / HInit / direct-OutP forms: not a hot path, one kernel for every size
+      if (diagc && !a.var) { htkamd_set_error("score_exact: DIAGC form without the variance table"); return HTKAMD_EINVAL; }
+      if (soutp && diagc) hipExtLaunchKernelGGL((k_score_exact_anyD<true, true>), grid, block, 0, stream, evStart, evStop, 0, a);
+      else if (soutp) hipExtLaunchKernelGGL((k_score_exact_anyD<true, false>), grid, block, 0, stream, evStart, evStop, 0, a);
+      else hipExtLaunchKernelGGL((k_score_exact_anyD<false, true>), grid, block, 0, stream, evStart, evStop, 0, a);
+      HIPCHECK(hipGetLastError());
+      return HTKAMD_OK;
+   }
    switch (m->D) {
-   case 39: hipExtLaunchKernelGGL((k_score_exact<39>), grid, block, 0, stream, evStart, evStop, 0, a); break;
-   case 26: hipExtLaunchKernelGGL((k_score_exact<26>), grid, block, 0, stream, evStart, evStop, 0, a); break;
-   case 13: hipExtLaunchKernelGGL((k_score_exact<13>), grid, block, 0, stream, evStart, evStop, 0, a); break;
-   default: hipExtLaunchKernelGGL(k_score_exact_anyD, grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 39: hipExtLaunchKernelGGL((k_score_exact<39, false>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 26: hipExtLaunchKernelGGL((k_score_exact<26, false>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 13: hipExtLaunchKernelGGL((k_score_exact<13, false>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   default: hipExtLaunchKernelGGL((k_score_exact_anyD<false, false>), grid, block, 0, stream, evStart, evStop, 0, a); break;
    }
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
@@ -179,7 +212,7 @@ extern "C" int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const 
 extern "C" int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                                       float *dOut, int ldo, int scoreMode, void *stream)
 {
-   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA && scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
+   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA && scoreMode != HTKAMD_SCORE_BF16 && (scoreMode & ~(HTKAMD_SCORE_SOUTP | HTKAMD_SCORE_DIAGC))) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
    return outp_block(m, dX, T, dStates, ns, dOut, ldo, scoreMode, stream);
 }
 
@@ -251,6 +284,8 @@ static int outp_block(htkamd_model *m, const float *dX, int T, const int *dState
    a.gparam = m->d_gparam; a.PS = m->PS; a.D = m->D; a.minLogExp = m->minLogExp;
    a.laddTab = m->d_laddTab; a.taskCounter = (int *)(sl.d + sizeof(ScoreTask) * (size_t)nTasks);
    a.mfmaTab = m->d_mfmaTab; a.stateTileOff = m->d_stateTileOff; a.bf16Tab = m->d_bf16Tab;
+   if (mode & HTKAMD_SCORE_DIAGC) { int rcv = htkamd_model_device_tables(m); if (rcv) return rcv; }
+   a.var = m->d_var;
    const int rc = htkamd_launch_score(mode, m, a, s);
    HIPCHECK(hipEventRecord(sl.ev, s));
    sl.busy = true;

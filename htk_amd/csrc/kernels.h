@@ -32,11 +32,12 @@ struct ScoreArgs {
    const float *mfmaTab;      // MFMA path only
    const int *stateTileOff;
    const void *bf16Tab;       // bf16 x 3 path only
+   const float *var;          // DIAGC form only: variances [G*D]
 };
 
 // evStart/evStop (may be NULL): updated with the dispatch's own start and stop time (hipExtLaunchKernel), i.e. without the time
 // the kernel waits for the machine when another stream is using it
-int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
+int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, bool soutp = false, bool diagc = false);
 int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 // the scoring kernel of a score mode (HTKAMD_SCORE_* bits: BF16 before MFMA before exact)
@@ -44,7 +45,7 @@ static inline int htkamd_launch_score(int mode, const htkamd_model *m, const Sco
 {
    if (mode & HTKAMD_SCORE_BF16) return htkamd_launch_score_bf16(m, a, s, e0, e1);
    if (mode & HTKAMD_SCORE_MFMA) return htkamd_launch_score_mfma(m, a, s, e0, e1);
-   return htkamd_launch_score_exact(m, a, s, e0, e1);
+   return htkamd_launch_score_exact(m, a, s, e0, e1, (mode & HTKAMD_SCORE_SOUTP) != 0, (mode & HTKAMD_SCORE_DIAGC) != 0);
 }
 
 // ---- forward-backward ----

@@ -225,6 +225,13 @@ int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dState
  * matter at fp32 accuracy summed in fp32 (gmm_bf16.hip): the tolerance class of HTKAMD_SCORE_MFMA at ~2.5x its speed (vector sizes up
  * to 48; HTKAMD_EMODEL beyond).  Takes precedence over HTKAMD_SCORE_MFMA when both bits are set. */
 #define HTKAMD_SCORE_BF16  4
+/* Exact arithmetic with SOutP's rounding (HModel.c:5538-5552: the mixture log-sum kept in double, one rounding to float at the end)
+ * instead of ShStrP's / cSOutP's float after every component: what OutP / POutP / SOutP return to a direct caller (HRest, HInit).
+ * Bit-identical to the reference's SOutP. */
+#define HTKAMD_SCORE_SOUTP 8
+/* htkamd_outp_block_mode only, may be or-ed with HTKAMD_SCORE_SOUTP: DOutP's form for DIAGC sets (HModel.c:5347: xmm*xmm/var, the float
+ * division) -- what MOutP dispatches to when the set has not been through ConvDiagC, as in HRest / HInit.  Bit-identical to DOutP. */
+#define HTKAMD_SCORE_DIAGC 16
 #define HTKAMD_SCORE_FAST  (HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)
 #define HTKAMD_SCORE_FASTEST (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_FASTLADD)
 int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,

@@ -168,6 +168,60 @@ float orc_soutp(const orc_model *m, int s, const float *x)
    return bx;
 }
 
+/* HModel.c:5347-5358 DOutP: the DIAGC form, xmm*xmm/var with the float division (sets that did not go through ConvDiagC) */
+float orc_doutp(const float *x, int D, const float *mean, const float *var, float gconst)
+{
+   int i;
+   float sum, xmm;
+   sum = gconst;
+   for (i = 0; i < D; i++) {
+      xmm = x[i] - mean[i];
+      sum += xmm * xmm / var[i];
+   }
+   return -0.5 * sum;
+}
+
+/* SOutP over a whole block in either covariance form: out[t*ns + k]; var == NULL takes the model's 1/variance (IDOutP) */
+void orc_soutp_block(const orc_model *m, const float *var, const float *X, int T, const int *states, int ns, float *out)
+{
+   int t, k, c, g;
+   for (t = 0; t < T; t++)
+      for (k = 0; k < ns; k++) {
+         const int s = states[k], c0 = m->stateCompOff[s], c1 = m->stateCompOff[s + 1];
+         const float *x = X + (size_t)t * m->D;
+         double bx = ORC_LZERO, px;
+         for (c = c0; c < c1; c++) {
+            const float wt = m->compLogWt[c];
+            if (c1 - c0 > 1 && !(wt > ORC_LMINMIX)) continue;
+            g = m->compGauss[c];
+            px = var ? orc_doutp(x, m->D, m->mean + (size_t)g * m->D, var + (size_t)g * m->D, m->gconst[g])
+                     : orc_idoutp(x, m->D, m->mean + (size_t)g * m->D, m->ivar + (size_t)g * m->D, m->gconst[g]);
+            if (c1 - c0 == 1) bx = px; else bx = orc_ladd(bx, wt + px);
+         }
+         out[(size_t)t * ns + k] = bx;
+      }
+}
+
+/* ShStrP's rounding with DOutP's covariance form (HTKAMD_SCORE_DIAGC alone) */
+void orc_score_block_diagc(const orc_model *m, const float *var, const float *X, int T, const int *states, int ns, float *out)
+{
+   int t, k, c, g;
+   for (t = 0; t < T; t++)
+      for (k = 0; k < ns; k++) {
+         const int s = states[k], c0 = m->stateCompOff[s], c1 = m->stateCompOff[s + 1];
+         const float *x = X + (size_t)t * m->D;
+         float xx = ORC_LZERO, mixp;
+         for (c = c0; c < c1; c++) {
+            const float wt = m->compLogWt[c];
+            if (c1 - c0 > 1 && !(wt > ORC_LMINMIX)) continue;
+            g = m->compGauss[c];
+            mixp = orc_doutp(x, m->D, m->mean + (size_t)g * m->D, var + (size_t)g * m->D, m->gconst[g]);
+            if (c1 - c0 == 1) xx = mixp; else xx = orc_ladd(xx, wt + mixp);
+         }
+         out[(size_t)t * ns + k] = xx;
+      }
+}
+
 void orc_score_block(const orc_model *m, const float *X, int T, const int *states, int ns, float *out)
 {
    int t, k;

@@ -97,6 +97,9 @@ float orc_idoutp(const float *x, int D, const float *mean, const float *ivar, fl
 /* ShStrP (HFB.c:898) == cSOutP (HRec.c:438) arithmetic: returns state log-lik, fills mixp[0..M-1]
    (LZERO for skipped components) when mixp != NULL */
 float orc_state_outp(const orc_model *m, int s, const float *x, float *mixp);
+float orc_doutp(const float *x, int D, const float *mean, const float *var, float gconst);    /* HModel.c:5347 */
+void  orc_soutp_block(const orc_model *m, const float *var, const float *X, int T, const int *states, int ns, float *out);
+void  orc_score_block_diagc(const orc_model *m, const float *var, const float *X, int T, const int *states, int ns, float *out);
 /* SOutP arithmetic (HModel.c:5503): double accumulation, one float rounding */
 float orc_soutp(const orc_model *m, int s, const float *x);
 /* dense block: out[t*ns + k] = orc_state_outp(states[k], X[t]) */

@@ -141,6 +141,19 @@ class Model:
         x = np.ascontiguousarray(x, np.float32)
         return lib().orc_soutp(C.byref(self.c), C.c_int(s), _p(x))
 
+    def soutp_block(self, X: np.ndarray, states: np.ndarray, diagc: bool = False) -> np.ndarray:
+        """SOutP's rounding (double log-sum, one float at the end); diagc: DOutP's xmm*xmm/var form"""
+        X = np.ascontiguousarray(X, np.float32); states = np.ascontiguousarray(states, np.int32)
+        out = np.empty((X.shape[0], len(states)), np.float32)
+        lib().orc_soutp_block(C.byref(self.c), _p(self.var) if diagc else None, _p(X), C.c_int(X.shape[0]), _p(states), C.c_int(len(states)), _p(out))
+        return out
+
+    def score_block_diagc(self, X: np.ndarray, states: np.ndarray) -> np.ndarray:
+        X = np.ascontiguousarray(X, np.float32); states = np.ascontiguousarray(states, np.int32)
+        out = np.empty((X.shape[0], len(states)), np.float32)
+        lib().orc_score_block_diagc(C.byref(self.c), _p(self.var), _p(X), C.c_int(X.shape[0]), _p(states), C.c_int(len(states)), _p(out))
+        return out
+
     def score_block(self, X: np.ndarray, states: np.ndarray) -> np.ndarray:
         X = np.ascontiguousarray(X, np.float32); states = np.ascontiguousarray(states, np.int32)
         out = np.empty((X.shape[0], len(states)), np.float32)

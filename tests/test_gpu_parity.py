@@ -58,6 +58,29 @@ def test_outp_block_other_sizes(native, oracle, D, M):
     assert np.array_equal(gm.outp_block(X[:1], states), om.score_block(X[:1], states))
 
 
+@pytest.mark.parametrize("D,M", [(39, 16), (26, 3), (13, 1), (20, 5)])
+def test_outp_block_soutp_and_diagc_forms_bit_exact(native, oracle, D, M):
+    """The forms a direct caller of OutP / POutP / SOutP / MOutP sees (HRest, HInit): SOutP's rounding (HModel.c:5538-5552: double
+    log-sum, one float at the end) and DOutP's xmm*xmm/var for sets that were not put through ConvDiagC (HModel.c:5347) -- every float
+    identical to the oracle's restatement, and the SOutP form does differ from ShStrP's in a few per cent of the mixture scores."""
+    from htk_amd import synth, capi
+    s = synth.generate(25, M, 10, 1, 200, 70 + D + M, D=D)
+    pk = s.packed()
+    gm, om = native.Model(pk), oracle.Model(pk)
+    X = s.feats[0]
+    states = np.arange(25, dtype=np.int32)
+    base = gm.outp_block(X, states, mode=0)
+    so = gm.outp_block(X, states, mode=capi.SCORE_SOUTP)
+    assert np.array_equal(so, om.soutp_block(X, states))
+    assert np.array_equal(gm.outp_block(X, states, mode=capi.SCORE_SOUTP | capi.SCORE_DIAGC), om.soutp_block(X, states, diagc=True))
+    assert np.array_equal(gm.outp_block(X, states, mode=capi.SCORE_DIAGC), om.score_block_diagc(X, states))
+    if M > 1:
+        frac = float((so != base).mean())
+        assert 0.0 < frac < 0.3, frac
+    else:
+        assert np.array_equal(so, base)
+
+
 def test_outp_large_block_statistics(native, oracle):
     """BASELINE config-2 shape (1k states x 8 mix, 2 x 500 frames x all states = 1M scores): bit-exact on a sample of rows,
     and every score finite and negative."""

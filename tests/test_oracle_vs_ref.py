@@ -100,3 +100,28 @@ def test_randomised_sweep_against_the_reference_binaries():
         pytest.skip("reference binaries not built (oracle/_ref)")
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_oracle_vs_ref.py"), "12", "2024"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "ref_outp")), reason="oracle/_ref/ref_outp not built")
+@pytest.mark.parametrize("seed,M,D", [(301, 4, 13), (302, 1, 26), (303, 16, 39)])
+def test_soutp_and_doutp_forms_equal_the_reference_outp(oracle, seed, M, D):
+    """What a direct caller of OutP gets (HModel.c:5503-5600), from the reference itself through oracle/ref_outp.c: the set as loaded
+    (DIAGC variances -> DOutP's division, linear weights -> MixLogWeight on the fly, SOutP's double log-sum) and after
+    ConvDiagC + ConvLogWt (IDOutP).  The oracle's orc_soutp_block must give the same floats, bit for bit, in both forms."""
+    from htk_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        s = synth.generate(24, M, 12, 1, 60, seed, D=D, outdir=d)
+        pk = s.packed()
+        om = oracle.Model(pk)
+        scp = open(os.path.join(d, "train.scp")).read().split()
+        H = int(pk["numPhys"])
+        states = np.asarray(pk["hmmState"], np.int32)                      # models in list order, 3 emitting states each
+        assert len(states) == 3 * H
+        X = s.feats[0]
+        for flag, diagc in (("", True), ("-c", False)):
+            out = os.path.join(d, "outp%s.bin" % flag)
+            r = subprocess.run("%s/ref_outp %s -C config -H hmm0/MMF hmmlist %s %s" % (REFDIR, flag, scp[0], out), shell=True, cwd=d, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            ref = np.fromfile(out, np.float32).reshape(X.shape[0], 3 * H)
+            got = om.soutp_block(X, states, diagc=diagc)
+            assert np.array_equal(got, ref), (flag, float(np.abs(got - ref).max()))
