@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libhtk_amd.so")
-HIP_SRCS = ["csrc/model.hip", "csrc/gmm_exact.hip", "csrc/gmm_mfma.hip", "csrc/gmm_bf16.hip", "csrc/fb_kernels.hip", "csrc/fb_wave.hip", "csrc/fb_state.hip", "csrc/fb.hip", "csrc/viterbi.hip", "csrc/decode.hip", "csrc/mfcc.hip", "csrc/update.hip"]
+HIP_SRCS = ["csrc/model.hip", "csrc/gmm_exact.hip", "csrc/gmm_mfma.hip", "csrc/gmm_bf16.hip", "csrc/fb_kernels.hip", "csrc/fb_wave.hip", "csrc/fb_state.hip", "csrc/fb.hip", "csrc/viterbi.hip", "csrc/decode.hip", "csrc/mfcc.hip", "csrc/update.hip", "csrc/comm.hip"]
 C_SRCS = ["host/prep.c", "host/update.c", "host/fbank.c", "host/accio.c", "host/parmfile.c", "host/mmf.c", "host/labio.c", "host/net.c"]
 HEADERS = ["csrc/internal.h", "csrc/kernels.h", "csrc/hipcheck.h", "csrc/ladd.h", "csrc/wavegrp.h", "../include/htk_amd.h"]
 ARCH = "gfx950"
@@ -54,11 +54,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if pr.wait() != 0:
             raise RuntimeError("build failed: " + " ".join(cmd))
     if force or procs or _newer(LIB, objs):
-        cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"]
+        cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_tools(verbose)
     return LIB
+
+
+TOOLS = ["herest", "hvite"]
+
+
+def build_tools(verbose: bool = False) -> None:
+    """The command-line drivers (tools/*.c): plain C hosts over include/htk_amd.h, linked against the library in-tree."""
+    root = os.path.dirname(HERE)
+    bindir = os.path.join(root, "tools", "bin")
+    os.makedirs(bindir, exist_ok=True)
+    for t in TOOLS:
+        src = os.path.join(root, "tools", t + ".c")
+        if not os.path.exists(src):
+            continue
+        exe = os.path.join(bindir, t)
+        if not _newer(exe, [src, os.path.join(root, "tools", "cli_common.h"), os.path.join(root, "include", "htk_amd.h"), LIB]):
+            continue
+        cmd = ["gcc", "-O2", "-std=gnu11", "-Wall", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "tools"), src, "-o", exe,
+               "-L" + HERE, "-lhtk_amd", "-Wl,-rpath,$ORIGIN/../../htk_amd", "-lm"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
 
 
 if __name__ == "__main__":

@@ -15,7 +15,26 @@
 
 #define HTK_PI 3.14159265358979
 
-static float mel_of(int k, float fres) { return 1127 * log(1 + (k - 1) * fres); }
+/* mel value of FFT bin k (1-based): Mel(k, fres) HSigP.c:443 */
+static float bin_mel(int k, float fres) { return 1127 * log(1 + (k - 1) * fres); }
+static float hz_mel(float hz) { return 1127 * log(1 + hz / 700.0); }
+
+/* The reference generates its FFT and Realft twiddles by walking round the unit circle in double:
+      w_0 = 1,  w_{n+1} = w_n + w_n * ((cos t - 1) + i sin t),   cos t - 1 = -2 sin^2(t/2)
+   (HSigP.c:332-349, :371-386).  Emits steps first .. first+count-1 of that walk as (re, im) pairs, with the same double operations
+   in the same order, so that the tabulated values are the ones the reference multiplies with. */
+static void unit_walk(double theta, int first, int count, double *out)
+{
+   const double h = sin(0.5 * theta), dRe = -2.0 * h * h, dIm = sin(theta);
+   double re = 1.0, im = 0.0;
+   int n;
+   for (n = 0; n < first + count; n++) {
+      const double re0 = re;
+      if (n >= first) { out[2 * (n - first)] = re; out[2 * (n - first) + 1] = im; }
+      re = re * dRe - im * dIm + re;
+      im = im * dRe + re0 * dIm + im;
+   }
+}
 
 int htkamd_mfcc_num_frames(const htkamd_mfcc_config *c, int nSamples)
 {
@@ -38,9 +57,8 @@ void htkamd_mfcc_tables_free(struct htkamd_mfcc_tables *t)
 
 int htkamd_mfcc_tables_build(const htkamd_mfcc_config *c, struct htkamd_mfcc_tables *t)
 {
-   int fftN = 2, Nby2, maxChan, k, chan, i, j, b;
-   float fres, mlo, mhi, ms, *cf;
-   short *loChan;
+   int fftN = 2, half, nEdge, k, i, j, b;
+   float fres, melLo, melHi, *edge;
    memset(t, 0, sizeof(*t));
    t->frSize = (int)(c->winDur / c->sampPeriod);
    t->frRate = (int)(c->frPeriod / c->sampPeriod);
@@ -50,51 +68,48 @@ int htkamd_mfcc_tables_build(const htkamd_mfcc_config *c, struct htkamd_mfcc_tab
    }
    while (t->frSize > fftN) fftN *= 2;
    if (fftN < 8 || fftN > 4096) { htkamd_set_error("mfcc: FFT size %d outside 8..4096", fftN); return HTKAMD_EINVAL; }
-   t->fftN = fftN; Nby2 = fftN / 2; maxChan = c->numChans + 1;
+   t->fftN = fftN; half = fftN / 2;
+   /* ---- mel filterbank (InitFBank HSigP.c:471-555 supplies the numbers; the tables are this file's own form).
+      Band of interest: FFT bins klo..khi, mel range melLo..melHi, optionally narrowed by LOFREQ / HIFREQ. */
    fres = 1.0E7 / ((long)c->sampPeriod * fftN * 700.0);
-   t->klo = 2; t->khi = Nby2;
-   mlo = 0; mhi = mel_of(Nby2 + 1, fres);
+   t->klo = 2; t->khi = half;
+   melLo = 0; melHi = bin_mel(half + 1, fres);
    if (c->loFreq >= 0.0) {
-      mlo = 1127 * log(1 + c->loFreq / 700.0);
+      melLo = hz_mel(c->loFreq);
       t->klo = (int)((c->loFreq * (long)c->sampPeriod * 1.0e-7 * fftN) + 2.5);
       if (t->klo < 2) t->klo = 2;
    }
    if (c->hiFreq >= 0.0) {
-      mhi = 1127 * log(1 + c->hiFreq / 700.0);
+      melHi = hz_mel(c->hiFreq);
       t->khi = (int)((c->hiFreq * (long)c->sampPeriod * 1.0e-7 * fftN) + 0.5);
-      if (t->khi > Nby2) t->khi = Nby2;
+      if (t->khi > half) t->khi = half;
    }
-   cf = (float *)malloc(sizeof(float) * (size_t)(maxChan + 2));
-   ms = mhi - mlo;
-   for (chan = 1; chan <= maxChan; chan++) cf[chan] = ((float)chan / (float)maxChan) * ms + mlo;
-   loChan = (short *)malloc(sizeof(short) * (size_t)(Nby2 + 2));
-   for (k = 1, chan = 1; k <= Nby2; k++) {
-      const float melk = mel_of(k, fres);
-      if (k < t->klo || k > t->khi) loChan[k] = -1;
-      else {
-         while (cf[chan] < melk && chan <= maxChan) ++chan;
-         loChan[k] = (short)(chan - 1);
-      }
-   }
-   t->loWt = (float *)calloc((size_t)Nby2 + 2, sizeof(float));
-   for (k = 1; k <= Nby2; k++) {
-      chan = loChan[k];
-      if (k < t->klo || k > t->khi) t->loWt[k] = 0.0;
-      else if (chan > 0) t->loWt[k] = ((cf[chan + 1] - mel_of(k, fres)) / (cf[chan + 1] - cf[chan]));
-      else t->loWt[k] = (cf[1] - mel_of(k, fres)) / (cf[1] - mlo);
-   }
-   /* Wave2FBank adds, for k = klo..khi in order, loWt*ek to bin loChan[k] and ek-loWt*ek to bin loChan[k]+1.
-      loChan is non-decreasing in k, so bin b receives first the (ek - t1) terms of the k with loChan == b-1 and
-      then the t1 terms of the k with loChan == b: two contiguous k ranges per bin. */
+   /* numChans triangular filters share numChans+2 equally spaced mel edges: edge[0] = melLo, edge[e] = e/(numChans+1) of the span */
+   nEdge = c->numChans + 1;
+   edge = (float *)malloc(sizeof(float) * (size_t)(nEdge + 2));
+   edge[0] = melLo;
+   for (b = 1; b <= nEdge; b++) edge[b] = ((float)b / (float)nEdge) * (melHi - melLo) + melLo;
+   edge[nEdge + 1] = edge[nEdge] + 1.0f;                /* guard: a top bin whose centre rounds above HIFREQ feeds no filter */
+   /* An FFT bin k between edge[lo] and edge[lo+1] feeds filter lo with weight loWt[k] = (edge[lo+1] - mel)/(edge[lo+1] - edge[lo]) and
+      filter lo+1 with the rest (Wave2FBank HSigP.c:558-604 adds loWt*ek to bin lo and ek - loWt*ek to bin lo+1, for k ascending).
+      lo never decreases with k, so filter b receives, in this order, the "rest" terms of the bins with lo == b-1 and then the
+      weighted terms of the bins with lo == b: two contiguous k ranges per filter, [binA0,binA1] and [binB0,binB1]. */
+   t->loWt = (float *)calloc((size_t)half + 2, sizeof(float));
    t->binA0 = (int *)calloc((size_t)4 * (c->numChans + 2), sizeof(int));
    t->binA1 = t->binA0 + (c->numChans + 2); t->binB0 = t->binA1 + (c->numChans + 2); t->binB1 = t->binB0 + (c->numChans + 2);
    for (b = 1; b <= c->numChans; b++) { t->binA0[b] = 1; t->binA1[b] = 0; t->binB0[b] = 1; t->binB1[b] = 0; }
-   for (k = t->klo; k <= t->khi; k++) {
-      const int bin = loChan[k];
-      if (bin > 0) { if (t->binB1[bin] < t->binB0[bin]) t->binB0[bin] = k; t->binB1[bin] = k; }
-      if (bin < c->numChans) { if (t->binA1[bin + 1] < t->binA0[bin + 1]) t->binA0[bin + 1] = k; t->binA1[bin + 1] = k; }
+   {
+      int lo = 0;                                        /* edges 1..lo lie below the current bin's mel value */
+      for (k = 1; k <= half; k++) {
+         const float mel = bin_mel(k, fres);
+         if (k < t->klo || k > t->khi) continue;        /* outside the band: weight 0, feeds nothing */
+         while (lo < nEdge && edge[lo + 1] < mel) lo++;
+         t->loWt[k] = (edge[lo + 1] - mel) / (edge[lo + 1] - edge[lo]);
+         if (lo >= 1 && lo <= c->numChans) { if (t->binB1[lo] < t->binB0[lo]) t->binB0[lo] = k; t->binB1[lo] = k; }
+         if (lo < c->numChans) { if (t->binA1[lo + 1] < t->binA0[lo + 1]) t->binA0[lo + 1] = k; t->binA1[lo + 1] = k; }
+      }
    }
-   free(cf); free(loChan);
+   free(edge);
    t->ham = (float *)calloc((size_t)t->frSize + 1, sizeof(float));
    { const float a = HTK_TPI / (t->frSize - 1); for (i = 1; i <= t->frSize; i++) t->ham[i] = 0.54 - 0.46 * cos(a * (i - 1)); }
    t->cepWin = (float *)calloc((size_t)c->numCeps + 1, sizeof(float));
@@ -112,38 +127,18 @@ int htkamd_mfcc_tables_build(const htkamd_mfcc_config *c, struct htkamd_mfcc_tab
          for (k = 1; k <= c->numChans; k++) t->dct[(size_t)j * (c->numChans + 1) + k] = cos(x * (k - 0.5));
       }
    }
-   /* complex FFT of nn = fftN/2 points: stage with half-size h uses twiddles (wr, wi)[0..h-1] */
+   /* complex FFT of nn = fftN/2 points: the stage that combines blocks of `limit/2` points uses steps 0..limit/2-1 of the walk with
+      angle 2 pi/limit; Realft's post-pass (i = 2..nn/2) steps 1.. of the walk with angle pi/nn */
    {
       const int nn = fftN / 2;
       int limit, off = 0, bits = 0;
       t->tw = (double *)calloc((size_t)2 * nn, sizeof(double));
       for (limit = 2; limit < fftN; limit *= 2) {
-         const double theta = HTK_TPI / limit, x = sin(0.5 * theta);
-         const double wpr = -2.0 * x * x, wpi = sin(theta);
-         double wr = 1.0, wi = 0.0, wx;
-         int ii;
-         for (ii = 1; ii <= limit / 2; ii++) {
-            t->tw[2 * (off + ii - 1)] = wr; t->tw[2 * (off + ii - 1) + 1] = wi;
-            wx = wr;
-            wr = wr * wpr - wi * wpi + wr;
-            wi = wi * wpr + wx * wpi + wi;
-         }
+         unit_walk(HTK_TPI / limit, 0, limit / 2, t->tw + 2 * off);
          off += limit / 2;
       }
-      /* Realft post-pass: (yr, yi) for i = 2..n2 */
-      {
-         const int n = fftN / 2, n2 = n / 2;
-         const double theta = HTK_PI / n, x = sin(0.5 * theta);
-         const double yr2 = -2.0 * x * x, yi2 = sin(theta);
-         double yr = 1.0 + yr2, yi = yi2, yr0;
-         t->rtw = (double *)calloc((size_t)2 * (n2 + 2), sizeof(double));
-         for (i = 2; i <= n2; i++) {
-            t->rtw[2 * i] = yr; t->rtw[2 * i + 1] = yi;
-            yr0 = yr;
-            yr = yr * yr2 - yi * yi2 + yr;
-            yi = yi * yr2 + yr0 * yi2 + yi;
-         }
-      }
+      t->rtw = (double *)calloc((size_t)2 * (nn / 2 + 2), sizeof(double));
+      if (nn / 2 >= 2) unit_walk(HTK_PI / nn, 1, nn / 2 - 1, t->rtw + 4);
       /* bit reversal of the complex index (the swap loop of HSigP.c:319-331) */
       while ((1 << bits) < nn) bits++;
       t->brev = (short *)calloc((size_t)nn, sizeof(short));

@@ -261,6 +261,20 @@ int  htkamd_accs_device_vector(htkamd_accs *a, double **dVec, size_t *n);      /
 int  htkamd_accs_download(htkamd_accs *a, double *hostVec /*[layout.total]*/, void *stream);
 int  htkamd_accs_upload_add(htkamd_accs *a, const double *hostVec, void *stream); /* LoadAccs: adds */
 
+/* The exchange step of a multi-GPU pass from C: sum all-reduce of the accumulator vector over RCCL (xGMI inside a node), one process
+ * per GPU.  Replaces the dump / load round trip of HERest's parallel mode (DumpAccs HTrain.c:1453 per `-p k` process, LoadAccs
+ * HTrain.c:1625 + sum in the `-p 0` process, HERest.c:514-550); afterwards every rank holds the same sums and runs the same update.
+ *   comm_unique_id : rank 0 obtains the 128-byte rendezvous id and passes it to the other ranks (file, socket, environment ...)
+ *   comm_init      : every rank, same id; nRanks == 1 needs neither RCCL nor an id
+ *   accs_allreduce : in place, asynchronous on `stream`
+ * RCCL is bound at run time (librccl.so.1); HTKAMD_ENODEV if it cannot be found when nRanks > 1. */
+typedef struct htkamd_comm htkamd_comm;
+int  htkamd_comm_unique_id(void *id128);
+int  htkamd_comm_init(htkamd_comm **out, int nRanks, int rank, const void *id128);
+void htkamd_comm_destroy(htkamd_comm *c);
+int  htkamd_comm_ranks(const htkamd_comm *c);
+int  htkamd_accs_allreduce(htkamd_accs *a, htkamd_comm *c, void *stream);
+
 /* HTK parameter files: header + big-endian float rows, _C compression and _K checksum on input
  * (ReadHTKHeader HWave.c:1408, OpenParmChannel HParm.c:3561, GetParm :3464, UpdateCRCC :3357).  *data is malloc'd
  * (release with htkamd_free); *kind comes back without the _C/_K bits. */

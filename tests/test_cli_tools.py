@@ -1,0 +1,157 @@
+"""The command-line drivers tools/herest.c and tools/hvite.c (plain C over include/htk_amd.h, built by htk_amd.build into tools/bin/):
+the programs a user of the reference's HERest / HVite switches to, with the reference's switches.
+CPU: they build, refuse to run without a device (no fallback) and reject unknown switches.  GPU: HTKDemo's re-estimation pass and its
+recognition step through the CLIs against the reference's logs / models / label files; HERest's parallel mode (-p N dumps, -p 0 merge);
+word-level alignment and HVite's output formats against the committed HVite files."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tools", "bin")
+DEMO = os.path.join(os.path.dirname(__file__), "golden", "demo")
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "decode")
+
+
+@pytest.fixture(scope="module")
+def tools(native):
+    from htk_amd import build as nbuild
+    nbuild.build_tools()
+    for t in ("herest", "hvite"):
+        assert os.path.exists(os.path.join(BIN, t)), t
+    return BIN
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, **kw)
+
+
+def demo_train_files():
+    return sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+
+
+def herest_demo_cmd(tools, conf, out, extra=()):
+    return [os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", conf, "-u", "tmvw", "-d", os.path.join(DEMO, "hmm1"), "-M", out,
+            "-L", os.path.join(DEMO, "labels"), "-t", "2000.0"] + list(extra) + [os.path.join(DEMO, "bcplist")]
+
+
+def test_tools_refuse_to_run_without_a_device_and_check_their_switches(tools, tmp_path):
+    import torch
+    conf = tmp_path / "c"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    r = run([os.path.join(tools, "herest"), "-Q", "x", os.path.join(DEMO, "bcplist"), "f.mfc"])
+    assert r.returncode != 0 and "unknown switch -Q" in r.stderr
+    r = run([os.path.join(tools, "hvite"), os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist"), "f.mfc"])
+    assert r.returncode != 0 and "either -w net or -a" in r.stderr
+    if not torch.cuda.is_available():
+        r = run(herest_demo_cmd(tools, str(conf), str(tmp_path)) + demo_train_files())
+        assert r.returncode != 0 and "no HIP device" in r.stderr
+        r = run([os.path.join(tools, "hvite"), "-w", os.path.join(DEMO, "monLattice"), os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist"), "f.mfc"])
+        assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+def _same_models(out_dir, ref_dir, tol=2e-4):
+    for name in "SCVNL":
+        ours = open(os.path.join(out_dir, name)).read().split()
+        theirs = open(os.path.join(ref_dir, name)).read().split()
+        assert len(ours) == len(theirs), name
+        for x, y in zip(ours, theirs):
+            if x != y:
+                assert abs(float(x) - float(y)) <= tol * max(abs(float(y)), 1e-3), (name, x, y)
+
+
+@pytest.mark.gpu
+def test_herest_cli_runs_the_demo_pass(tools, tmp_path):
+    conf = tmp_path / "herest.conf"; conf.write_text("# HTKDemo/toolconfs/herest.conf\nTARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "hmm2"; out.mkdir()
+    scp = tmp_path / "train.scp"; scp.write_text("\n".join(demo_train_files()[2:]) + "\n")
+    r = run(herest_demo_cmd(tools, str(conf), str(out), ["-S", str(scp)]) + demo_train_files()[:2])
+    assert r.returncode == 0, r.stderr
+    log = open(os.path.join(DEMO, "herest_pass1.log")).read()
+    for line in ("Pruning-On[2000.0]", "Total 27 floored variance elements in 15 different mixes",
+                 "Reestimation complete - average log prob per frame = -5.900196e+01", "     - total frames seen          = 1.811000e+03"):
+        assert line in log and line in r.stdout, (line, r.stdout[-600:])
+    assert r.stdout.count("Utterance prob per frame") == 7
+    _same_models(str(out), os.path.join(DEMO, "hmm2_expected"))
+
+
+@pytest.mark.gpu
+def test_herest_cli_parallel_mode_dump_and_merge(tools, tmp_path):
+    """HERest -p 1 / -p 2 over two halves of the data, then -p 0 over the two HERn.acc files: the merged re-estimation equals the
+    single-process one (HERest.c:502-557), and the dump files are the reference's byte layout (tests/test_accio.py reads them)."""
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    files = demo_train_files()
+    accdir = tmp_path / "acc"; accdir.mkdir()
+    for k, part in ((1, files[:4]), (2, files[4:])):
+        r = run(herest_demo_cmd(tools, str(conf), str(accdir), ["-p", str(k)]) + part)
+        assert r.returncode == 0 and (accdir / ("HER%d.acc" % k)).exists(), r.stderr
+    out = tmp_path / "hmm2"; out.mkdir()
+    r = run(herest_demo_cmd(tools, str(conf), str(out), ["-p", "0"]) + [str(accdir / "HER1.acc"), str(accdir / "HER2.acc")])
+    assert r.returncode == 0, r.stderr
+    assert "average log prob per frame = -5.900196e+01" in r.stdout and "Total 27 floored variance elements in 15 different mixes" in r.stdout
+    _same_models(str(out), os.path.join(DEMO, "hmm2_expected"))
+
+
+@pytest.mark.gpu
+def test_hvite_cli_recognises_the_demo_sets(tools, tmp_path):
+    expected = json.load(open(os.path.join(DEMO, "hvite_expected.json")))
+    for part in ("test", "train"):
+        names = sorted(expected[part])
+        out = tmp_path / part; out.mkdir()
+        conf = tmp_path / "hvite.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+        r = run([os.path.join(tools, "hvite"), "-C", str(conf), "-d", os.path.join(DEMO, "hmm_final"), "-w", os.path.join(DEMO, "monLattice"), "-l", str(out),
+                 "-t", "300.0", "-p", "5.0", "-s", "0.0", os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] +
+                [os.path.join(DEMO, part, u + ".mfc") for u in names])
+        assert r.returncode == 0, r.stderr
+        for u in names:
+            assert (out / (u + ".rec")).read_text().splitlines() == expected[part][u], (part, u)
+
+
+def _write_case_files(native, case, tmp_path):
+    from htk_amd import synth
+    src = os.path.join(GOLD, case)
+    z = np.load(os.path.join(src, "feats.npz"))
+    files = []
+    for u in range(len(z.files)):
+        fn = str(tmp_path / ("u%d.mfc" % u))
+        synth.write_htk_param(fn, z["u%d" % u], kind=9)
+        files.append(fn)
+    return src, files
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fn", ["loop__-f_-m.mlf", "loop__-m_-o_N.mlf", "loop__-o_ST.mlf", "wint__-m_-o_SWX.mlf", "wint__-f_-m_-o_X.mlf", "loop__-f.mlf"])
+def test_hvite_cli_output_formats_equal_the_reference_mlf(native, tools, tmp_path, fn):
+    """-m / -f / -o through the CLI, written with -i: whole master label files equal to the reference HVite's, byte for byte."""
+    case, optstr = fn[:-4].split("__")
+    opts = optstr.replace("_", " ").split()
+    src, files = _write_case_files(native, case, tmp_path)
+    out = tmp_path / "out.mlf"
+    r = run([os.path.join(tools, "hvite"), "-H", os.path.join(src, "MMF"), "-w", os.path.join(src, "net.slf"), "-i", str(out), "-l", "*", "-t", "250.0"] + opts +
+            [os.path.join(src, "dict"), os.path.join(src, "hmmlist")] + files)
+    assert r.returncode == 0, r.stderr
+    assert out.read_text() == open(os.path.join(GOLD, "outfmt", fn)).read()
+
+
+@pytest.mark.gpu
+def test_hvite_cli_word_level_alignment(native, tools, tmp_path):
+    """hvite -a [-b w] [-m] from word-level label files (DoAlignment HVite.c:830) against the reference's label files."""
+    src, files = _write_case_files(native, "bigram", tmp_path)
+    d = os.path.join(GOLD, "align")
+    z = np.load(os.path.join(d, "feats.npz"))
+    from htk_amd import synth
+    files = []
+    for u in range(len(z.files)):
+        fn = str(tmp_path / ("a%d.mfc" % u)); synth.write_htk_param(fn, z["u%d" % u], kind=9); files.append(fn)
+    words = json.load(open(os.path.join(d, "words.json")))
+    for u, ws in enumerate(words):
+        (tmp_path / ("a%d.lab" % u)).write_text("\n".join(ws) + "\n")
+    expected = json.load(open(os.path.join(d, "expected.json")))
+    for opts, per in expected.items():
+        out = tmp_path / ("o" + str(abs(hash(opts)))); out.mkdir()
+        r = run([os.path.join(tools, "hvite"), "-a", "-H", os.path.join(src, "MMF"), "-l", str(out)] + opts.split() + [os.path.join(src, "dict"), os.path.join(src, "hmmlist")] + files)
+        assert r.returncode == 0, (opts, r.stderr)
+        for u in range(len(words)):
+            assert (out / ("a%d.rec" % u)).read_text().splitlines() == per["u%d" % u], (opts, u)

@@ -1,0 +1,239 @@
+/* herest.c -- embedded Baum-Welch re-estimation on the MI355X: the command-line program a user of the reference's HERest switches to.
+ *
+ *   herest [options] hmmList dataFiles...
+ *
+ * Options (the subset of HTKBook ref.tex "HERest" that SURVEY.md 8(b) lists; same letters, same meaning, same defaults, HERest.c:292-500):
+ *   -C cf          configuration file (TARGETKIND, DELTAWINDOW, ACCWINDOW, THIRDWINDOW, V1COMPAT, SIMPLEDIFFS)
+ *   -S scp         script file: further data files (extended file names logical=physical[s,e] are accepted, the segment is ignored)
+ *   -H mmf         load a master macro file (repeatable)          -d dir / -x ext   directory / extension of single-model files
+ *   -M dir         directory for the re-estimated models          -B                save them in binary
+ *   -L dir / -X ext  directory / extension of the label files (default: beside the data, .lab)      -I mlf   master label file
+ *   -t f [i l]     beam pruning threshold [increment limit]       -c f              mixture pruning threshold (MINFORPROB, default 10)
+ *   -u tmvw        parameters to update (default tmvw)            -m N              minimum examples per model (3)
+ *   -v f           variance floor (0)                             -w f              mixture weight floor as a multiple of MINMIX (0)
+ *   -p N           parallel mode: N > 0 accumulates this shard and writes <-M dir>/HERN.acc; N = 0 takes the data arguments as accumulator
+ *                  files, sums them and re-estimates (HERest.c:502-557)
+ *   -s file        write the state occupation statistics file     -T N              trace (1: progress lines)
+ * Beyond the reference:
+ *   --score m      arithmetic: exact (default: alpha/beta/scores bit-identical to the reference), fast (fp32 matrix-core scores +
+ *                  fp32-transcendental LAdd), fastest (bf16 x 3 matrix-core scores + that LAdd); the latter two are tolerance class (1e-4)
+ *   --batch N      utterances per device batch (default 4096)
+ *   --ranks R --rank r --rccl-id file   one process per GPU: every rank takes the data files r, r+R, r+2R, ..., the accumulators are summed
+ *                  over RCCL (htkamd_accs_allreduce) and every rank re-estimates; rank 0 writes the models.  `file` carries the
+ *                  rendezvous id from rank 0 to the others.
+ * Output on stdout follows HERest -T 1: "Pruning-On[..]", a line per skipped file, "Total N floored variance elements ...",
+ * "Reestimation complete - average log prob per frame = ...".
+ */
+#include <unistd.h>
+#include "cli_common.h"
+
+typedef struct { char *logical; int phys; } modelref;
+
+static int uflags_parse(const char *s)
+{
+   int f = 0;
+   for (; *s; s++)
+      switch (*s) {
+      case 't': f |= HTKAMD_UPTRANS; break; case 'm': f |= HTKAMD_UPMEANS; break; case 'v': f |= HTKAMD_UPVARS; break; case 'w': f |= HTKAMD_UPMIXES; break;
+      default: DIE("-u: unknown update flag %c (t m v w)", *s);
+      }
+   return f;
+}
+
+int main(int argc, char **argv)
+{
+   args a = {argc, 1, argv};
+   config cfg; memset(&cfg, 0, sizeof(cfg));
+   strlist mmfs = {0}, files = {0};
+   const char *hmmDir = NULL, *hmmExt = NULL, *outDir = NULL, *labDir = NULL, *labExt = "lab", *mlfPath = NULL, *statsFile = NULL, *rcclIdFile = NULL;
+   double pruneInit = HTKAMD_NOPRUNE, pruneInc = 0.0, pruneLim = HTKAMD_NOPRUNE;
+   float minFrwdP = 10.0f, minVar = 0.0f, mixFloor = 0.0f;
+   int uFlags = HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES | HTKAMD_UPTRANS, minEgs = 3, parMode = -1, trace = 0, binary = 0;
+   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0;
+   const char *sw;
+
+   while (a.at < a.argc && (a.argv[a.at][0] == '-') && (is_switch(a.argv[a.at]))) {
+      if (!strncmp(a.argv[a.at], "--", 2)) {
+         const char *lo = a.argv[a.at++] + 2;
+         if (!strcmp(lo, "score")) {
+            const char *m = str_arg(&a, "-score");
+            scoreMode = !strcmp(m, "exact") ? HTKAMD_SCORE_EXACT : !strcmp(m, "fast") ? HTKAMD_SCORE_FAST : !strcmp(m, "fastest") ? HTKAMD_SCORE_FASTEST : -1;
+            if (scoreMode < 0) DIE("--score: exact | fast | fastest");
+         } else if (!strcmp(lo, "batch")) batchN = atoi(str_arg(&a, "-batch"));
+         else if (!strcmp(lo, "ranks")) nRanks = atoi(str_arg(&a, "-ranks"));
+         else if (!strcmp(lo, "rank")) rank = atoi(str_arg(&a, "-rank"));
+         else if (!strcmp(lo, "rccl-id")) rcclIdFile = str_arg(&a, "-rccl-id");
+         else DIE("unknown option --%s", lo);
+         continue;
+      }
+      sw = next_switch(&a);
+      switch (sw[0]) {
+      case 'C': cfg_read(&cfg, str_arg(&a, sw)); break;
+      case 'S': {
+         htkamd_scp *scp; CHECK(htkamd_scp_read(str_arg(&a, sw), &scp));
+         for (int i = 0; i < htkamd_scp_count(scp); i++) sl_add(&files, htkamd_scp_physical(scp, i));
+         htkamd_scp_free(scp);
+         break;
+      }
+      case 'H': sl_add(&mmfs, str_arg(&a, sw)); break;
+      case 'd': hmmDir = str_arg(&a, sw); break;
+      case 'x': hmmExt = str_arg(&a, sw); break;
+      case 'M': outDir = str_arg(&a, sw); break;
+      case 'B': binary = 1; break;
+      case 'L': labDir = str_arg(&a, sw); break;
+      case 'X': labExt = str_arg(&a, sw); break;
+      case 'I': mlfPath = str_arg(&a, sw); break;
+      case 't':
+         pruneInit = flt_arg(&a, sw);
+         if (has_num_arg(&a)) { pruneInc = flt_arg(&a, sw); pruneLim = flt_arg(&a, sw); } else { pruneInc = 0.0; pruneLim = pruneInit; }
+         break;
+      case 'c': minFrwdP = (float)flt_arg(&a, sw); break;
+      case 'u': uFlags = uflags_parse(str_arg(&a, sw)); break;
+      case 'm': minEgs = atoi(str_arg(&a, sw)); break;
+      case 'v': minVar = (float)flt_arg(&a, sw); break;
+      case 'w': mixFloor = (float)(1.0e-5 * flt_arg(&a, sw)); break;          /* MINMIX * f (HERest.c:425) */
+      case 'p': parMode = atoi(str_arg(&a, sw)); break;
+      case 's': statsFile = str_arg(&a, sw); break;
+      case 'T': trace = atoi(str_arg(&a, sw)); break;
+      default: DIE("herest: unknown switch -%s", sw);
+      }
+   }
+   if (a.at >= a.argc) DIE("herest: file name of the HMM list expected");
+   const char *hmmList = a.argv[a.at++];
+   while (a.at < a.argc) sl_add(&files, a.argv[a.at++]);
+   if (files.n == 0) DIE("herest: no data files");
+   if (nRanks < 1 || rank < 0 || rank >= nRanks) DIE("herest: --rank must be in 0..ranks-1");
+   if (nRanks > 1 && !rcclIdFile) DIE("herest: --ranks needs --rccl-id <file>");
+
+   if (htkamd_device_count() <= 0) DIE("herest: no HIP device (the MI355X path has no CPU fallback)");
+   CHECK(htkamd_set_device(nRanks > 1 ? rank % htkamd_device_count() : 0));
+
+   /* LoadHMMSet */
+   htkamd_mmf *mmf; CHECK(htkamd_mmf_create(&mmf));
+   for (int i = 0; i < mmfs.n; i++) CHECK(htkamd_mmf_read(mmf, mmfs.v[i], NULL));
+   CHECK(htkamd_mmf_finish(mmf, hmmList, hmmDir, hmmExt));
+   const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
+   const int D = d->vecSize, H = d->numPhys;
+   htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   htkamd_accs *accs; CHECK(htkamd_accs_create(model, &accs));
+   htkamd_accs_layout lay; CHECK(htkamd_accs_get_layout(accs, &lay));
+   double *vec = (double *)calloc(lay.total, sizeof(double));
+   const char **physNames = (const char **)malloc(sizeof(char *) * (size_t)H);
+   for (int h = 0; h < H; h++) physNames[h] = htkamd_mmf_phys_name(mmf, h);
+   const char *tk = cfg_get(&cfg, "TARGETKIND");
+   const int targetKind = kind_parse(tk ? tk : htkamd_mmf_parm_kind(mmf));
+   if (trace & 1) {
+      printf("HERest  ML Updating: %s%s%s%s\n\n", (uFlags & HTKAMD_UPTRANS) ? "Transitions " : "", (uFlags & HTKAMD_UPMEANS) ? "Means " : "",
+             (uFlags & HTKAMD_UPVARS) ? "Variances " : "", (uFlags & HTKAMD_UPMIXES) ? "MixWeights " : "");
+      printf("%d Logical/%d Physical Models Loaded, VecSize=%d\n", htkamd_mmf_num_logical(mmf), H, D);
+   }
+   if (pruneInit < HTKAMD_NOPRUNE) {
+      if (pruneInc != 0.0) printf("Pruning-On[%.1f %.1f %.1f]\n", pruneInit, pruneInc, pruneLim); else printf("Pruning-On[%.1f]\n", pruneInit);
+   } else printf("Pruning-Off\n");
+
+   if (parMode == 0) {
+      /* the data arguments are accumulator files: LoadAccs adds every dump (HTrain.c:1625) */
+      for (int i = 0; i < files.n; i++) CHECK(htkamd_accs_load_file(d, vec, physNames, uFlags, files.v[i]));
+      CHECK(htkamd_accs_upload_add(accs, vec, NULL));
+   } else {
+      htkamd_mlf *mlf = NULL;
+      if (mlfPath) CHECK(htkamd_mlf_read(mlfPath, &mlf));
+      htkamd_comm *comm = NULL;
+      if (nRanks > 1) {
+         unsigned char id[128];
+         if (rank == 0) {
+            CHECK(htkamd_comm_unique_id(id));
+            char tmp[1024]; snprintf(tmp, sizeof(tmp), "%s.tmp", rcclIdFile);
+            FILE *f = fopen(tmp, "wb"); if (!f || fwrite(id, 1, 128, f) != 128) DIE("cannot write %s", tmp);
+            fclose(f); rename(tmp, rcclIdFile);
+         } else {
+            FILE *f = NULL;
+            for (int tries = 0; tries < 6000 && !(f = fopen(rcclIdFile, "rb")); tries++) usleep(10000);
+            if (!f || fread(id, 1, 128, f) != 128) DIE("cannot read the RCCL id from %s", rcclIdFile);
+            fclose(f);
+         }
+         CHECK(htkamd_comm_init(&comm, nRanks, rank, id));
+      }
+      /* this rank's shard: files rank, rank + R, ... (HERest -p semantics with the script file split round-robin) */
+      strlist mine = {0};
+      for (int i = rank; i < files.n; i += nRanks) sl_add(&mine, files.v[i]);
+      htkamd_fb *fb; CHECK(htkamd_fb_create(model, &fb));
+      htkamd_fb_config fc; memset(&fc, 0, sizeof(fc));
+      fc.pruneInit = pruneInit; fc.pruneInc = pruneInc; fc.pruneLim = pruneLim; fc.minFrwdP = minFrwdP; fc.uFlags = uFlags; fc.scoreMode = scoreMode;
+      CHECK(htkamd_accs_zero(accs, NULL));
+      for (int first = 0; first < mine.n; first += batchN) {
+         const int count = (mine.n - first < batchN) ? mine.n - first : batchN;
+         obs_batch ob; memset(&ob, 0, sizeof(ob));
+         load_observations(&mine, first, count, targetKind, &cfg, &ob);
+         if (ob.cols != D) DIE("observations have %d components, the models %d", ob.cols, D);
+         int *labOff = (int *)calloc((size_t)count + 1, sizeof(int)), *labs = NULL, capLab = 0;
+         for (int u = 0; u < count; u++) {
+            char lab[2048];
+            make_fn(mine.v[first + u], labDir, labExt, lab, sizeof(lab));
+            htkamd_labels *L = NULL; const htkamd_labels *Lc = NULL;
+            if (mlf) { Lc = htkamd_mlf_find(mlf, lab); if (!Lc) DIE("%s: no entry in the master label file %s", lab, mlfPath); }
+            else { CHECK(htkamd_labels_read(lab, &L)); Lc = L; }
+            const int n = htkamd_labels_count(Lc);
+            if (n == 0) fprintf(stderr, "WARNING [-7325] LoadUtterance: No labels in file %s\n", lab);
+            if (labOff[u] + n > capLab) { capLab = (labOff[u] + n) * 2 + 64; labs = (int *)realloc(labs, sizeof(int) * (size_t)capLab); }
+            for (int i = 0; i < n; i++) {
+               const int h = htkamd_mmf_find_logical(mmf, htkamd_labels_name(Lc, i));
+               if (h < 0) DIE("[7321] CreateInsts: Unknown label %s in %s", htkamd_labels_name(Lc, i), lab);
+               labs[labOff[u] + i] = h;
+            }
+            labOff[u + 1] = labOff[u] + n;
+            if (L) htkamd_labels_free(L);
+         }
+         htkamd_batch_desc b = {count, ob.dX, ob.frameOff, labOff, labs};
+         CHECK(htkamd_fb_prepare(fb, &b, NULL));
+         CHECK(htkamd_fb_execute(fb, &fc, accs, NULL));
+         double *pr = (double *)malloc(sizeof(double) * (size_t)count); int *st = (int *)malloc(sizeof(int) * (size_t)count);
+         CHECK(htkamd_fb_results(fb, pr, st, NULL));
+         for (int u = 0; u < count; u++) {
+            if (trace & 1) printf(" Processing Data: %s\n", mine.v[first + u]);
+            if (st[u] == HTKAMD_UTT_OK) { if (trace & 1) printf(" Utterance prob per frame = %e\n", pr[u] / (ob.frameOff[u + 1] - ob.frameOff[u])); }
+            else if (st[u] == HTKAMD_UTT_SKIPPED) fprintf(stderr, "WARNING [-7324] StepBack: File %s - bad data or over pruning\n", mine.v[first + u]);
+            else DIE("[%d] forward-backward failed on %s", -st[u], mine.v[first + u]);
+         }
+         free(pr); free(st); free(labOff); free(labs);
+         free_observations(&ob);
+      }
+      htkamd_fb_destroy(fb);
+      if (comm) { CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL)); htkamd_comm_destroy(comm); }
+      CHECK(htkamd_accs_download(accs, vec, NULL));
+      if (mlf) htkamd_mlf_free(mlf);
+   }
+
+   if (parMode > 0) {
+      char fn[2048];
+      snprintf(fn, sizeof(fn), "%s/HER%d.acc", outDir ? outDir : ".", parMode);
+      CHECK(htkamd_accs_dump_file(d, vec, physNames, uFlags, fn));
+      if (trace & 1) printf("Accumulators dumped to %s\n", fn);
+      return 0;
+   }
+   if (statsFile) CHECK(htkamd_stats_write_file(d, vec, physNames, statsFile));
+
+   /* UpdateModels on the device, then SaveHMMSet (every rank computes the same models; rank 0 writes them) */
+   htkamd_update_config uc; memset(&uc, 0, sizeof(uc));
+   uc.minEgs = minEgs; uc.minVar = minVar; uc.mixWeightFloor = mixFloor; uc.uFlags = uFlags; uc.varFloor = htkamd_mmf_var_floor(mmf);
+   uc.singleProcess = (parMode == -1);
+   htkamd_update_stats us;
+   CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
+   if (us.nSkippedHmm > 0) fprintf(stderr, "WARNING [-2331] UpdateModels: %d models had fewer than %d examples and were copied\n", us.nSkippedHmm, minEgs);
+   if (rank == 0) {
+      float *mean = (float *)malloc(sizeof(float) * (size_t)d->numGauss * D), *var = (float *)malloc(sizeof(float) * (size_t)d->numGauss * D);
+      float *gc = (float *)malloc(sizeof(float) * (size_t)d->numGauss), *wt = (float *)malloc(sizeof(float) * (size_t)d->numComp);
+      float *tp = (float *)malloc(sizeof(float) * (size_t)d->transOff[d->numTrans]);
+      CHECK(htkamd_model_get_params(model, mean, var, gc, wt, tp));
+      char one[2048]; const char *oneFile = NULL;
+      if (mmfs.n > 0) { make_fn(mmfs.v[0], outDir ? outDir : ".", NULL, one, sizeof(one)); oneFile = one; }
+      if (binary) CHECK(htkamd_mmf_write_binary(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
+      else CHECK(htkamd_mmf_write(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
+      if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
+      if (trace & 1) printf("Saving hmm's to %s %s\n", oneFile ? "MMF" : "dir", oneFile ? oneFile : (outDir ? outDir : "Current"));
+      printf("Reestimation complete - average log prob per frame = %e\n", vec[lay.totalPr] / vec[lay.totalT]);
+      printf("     - total frames seen          = %e\n", vec[lay.totalT]);
+   }
+   htkamd_accs_destroy(accs); htkamd_model_destroy(model); htkamd_mmf_destroy(mmf);
+   return 0;
+}

@@ -1,0 +1,222 @@
+/* hvite.c -- Viterbi recognition and forced alignment on the MI355X: the command-line program a user of the reference's HVite switches to.
+ *
+ *   hvite [options] -w net.slf dict hmmList dataFiles...          recognition over a word network
+ *   hvite [options] -a [-b sil] dict hmmList dataFiles...         alignment of each file's word-level transcription
+ *
+ * Options (the subset of HTKBook ref.tex "HVite" that SURVEY.md 8(b) lists; same letters, meaning and defaults, HVite.c:227-420):
+ *   -C cf        configuration file (TARGETKIND, DELTAWINDOW, ACCWINDOW, THIRDWINDOW, V1COMPAT, SIMPLEDIFFS)
+ *   -S scp       script file with further data files            -H mmf / -d dir / -x ext   model sources
+ *   -w net       recognition network (SLF word lattice)         -a            align against the label files instead
+ *   -b word      alignment: boundary word at both ends          -L dir / -X ext / -I mlf   transcriptions to align (default .lab)
+ *   -i mlf       write one master label file                    -l dir / -y ext            or one label file per input (default .rec)
+ *   -m           model-level labels                             -f            state-level labels (implies model level as auxiliary)
+ *   -o chars     output format S W T N X C M (HVite -o)
+ *   -t f         general beam (0 = off)                         -v f          word-end beam
+ *   -s f         grammar scale (1.0)    -p f   word insertion penalty (0.0)    -r f   pronunciation scale (1.0)
+ *   -T N         trace (1: one line per file)
+ * Beyond the reference:  --score exact|fast|fastest (default exact: paths and scores are the reference's bit for bit),  --batch N.
+ * Every file's labels are "start end name score [aux ...]" in 100 ns units as TranscriptionFromLattice / FormatTranscription
+ * (HRec.c:2176,2368) produce them; a file in which no token survives gets no entry and a "No tokens survived" line on stderr.
+ */
+#include "cli_common.h"
+
+static int out_flags(const char *s)
+{
+   int f = 0;
+   for (; *s; s++)
+      switch (*s) {
+      case 'S': f |= HTKAMD_OUT_NOSCORES; break; case 'W': f |= HTKAMD_OUT_NOWORDS; break; case 'T': f |= HTKAMD_OUT_NOTIMES; break;
+      case 'N': f |= HTKAMD_OUT_NORMSCORES; break; case 'X': f |= HTKAMD_OUT_TRISTRIP; break; case 'C': f |= HTKAMD_OUT_CENTRE; break;
+      case 'M': f |= HTKAMD_OUT_NOMODELS; break;
+      default: DIE("-o: unknown format character %c (S W T N X C M)", *s);
+      }
+   return f;
+}
+
+/* labels of one decoded utterance -> transcription, at word / model / state level */
+static void emit(htkamd_trans *tr, const htkamd_net *net, const htkamd_mmf *mmf, htkamd_viterbi *vit, const float *dX, int D, int frame0, int T,
+                 int nW, const int *wPron, const int *wStart, const int *wEnd, const float *wScore, const float *wLm,
+                 double period, int models, int states, float lmScale, float wordPen, float alignBeam)
+{
+   if (!models && !states) {
+      for (int w = 0; w < nW; w++) {
+         const char *sym = htkamd_net_out_sym(net, wPron[w]);
+         if (!sym || !sym[0]) continue;                        /* words without output symbol leave no label (HRec.c:2342-2356) */
+         CHECK(htkamd_trans_add(tr, wStart[w] * period, wEnd[w] * period, sym, wScore[w], NULL, 0, NULL, 0));
+      }
+      return;
+   }
+   /* the model chain of the recognised pronunciations, aligned against the same frames: for a fixed word sequence the LM terms are
+      constants, so the best alignment of the chain is the decoder's path (include/htk_amd.h, htkamd_decoder_run) */
+   int nQ = 0, cap = 0, *chain = NULL, *wordOfQ = NULL;
+   for (int w = 0; w < nW; w++) {
+      int tmp[256];
+      const int n = htkamd_net_pron_models(net, wPron[w], tmp, 256);
+      if (n > 256) DIE("pronunciation with %d models", n);
+      if (nQ + n > cap) { cap = (nQ + n) * 2 + 64; chain = (int *)realloc(chain, sizeof(int) * (size_t)cap); wordOfQ = (int *)realloc(wordOfQ, sizeof(int) * (size_t)cap); }
+      for (int k = 0; k < n; k++) { chain[nQ] = tmp[k]; wordOfQ[nQ] = (k == 0) ? w : -1; nQ++; }
+   }
+   if (nQ == 0) { free(chain); free(wordOfQ); return; }
+   int frameOff[2] = {0, T}, labOff[2] = {0, nQ};
+   htkamd_batch_desc b = {1, dX + (size_t)frame0 * D, frameOff, labOff, chain};
+   CHECK(htkamd_viterbi_align(vit, &b, alignBeam, NULL));
+   size_t nSeg, nMod; CHECK(htkamd_viterbi_sizes(vit, &nSeg, &nMod));
+   int *segS = (int *)malloc(sizeof(int) * nSeg), *segE = (int *)malloc(sizeof(int) * nSeg), *modS = (int *)malloc(sizeof(int) * nMod), *modE = (int *)malloc(sizeof(int) * nMod), st;
+   double *segSc = (double *)malloc(sizeof(double) * nSeg), *modSc = (double *)malloc(sizeof(double) * nMod), tot;
+   CHECK(htkamd_viterbi_results(vit, segS, segE, segSc, modS, modE, modSc, &tot, &st, NULL));
+   const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
+   size_t k = 0;
+   for (int q = 0; q < nQ; q++) {
+      const int h = chain[q], ns = d->hmmStateOff[h + 1] - d->hmmStateOff[h], w = wordOfQ[q];
+      const char *mname = htkamd_mmf_phys_name(mmf, h);
+      const char *wname = (w >= 0) ? htkamd_net_word_name(net, wPron[w]) : NULL;     /* -m / -f label the first model of a word with the word's NAME */
+      /* LArcTotLMLike (HNet.h:252): lmlike*lmscale + wdpenalty, in float then double as the reference evaluates it */
+      const float waux = (w >= 0) ? (float)((double)(float)(wLm[w] * lmScale) + (double)wordPen) : 0.0f;
+      if (!states) CHECK(htkamd_trans_add(tr, modS[q] * period, modE[q] * period, mname, (float)modSc[q], wname, wname ? waux : 0.0f, NULL, 0));
+      int first = 1;
+      for (int j = 0; j < ns; j++, k++) {
+         if (!states || segS[k] < 0) continue;
+         char sname[600];
+         if (models) {
+            snprintf(sname, sizeof(sname), "s%d", j + 2);
+            CHECK(htkamd_trans_add(tr, segS[k] * period, segE[k] * period, sname, (float)segSc[k], first ? mname : NULL, first ? (float)modSc[q] : 0.0f,
+                                   first ? wname : NULL, (first && wname) ? waux : 0.0f));
+         } else {
+            snprintf(sname, sizeof(sname), "%s[%d]", mname, j + 2);
+            CHECK(htkamd_trans_add(tr, segS[k] * period, segE[k] * period, sname, (float)segSc[k], first ? wname : NULL, (first && wname) ? waux : 0.0f, NULL, 0));
+         }
+         first = 0;
+      }
+   }
+   free(segS); free(segE); free(modS); free(modE); free(segSc); free(modSc); free(chain); free(wordOfQ);
+}
+
+int main(int argc, char **argv)
+{
+   args a = {argc, 1, argv};
+   config cfg; memset(&cfg, 0, sizeof(cfg));
+   strlist mmfs = {0}, files = {0};
+   const char *hmmDir = NULL, *hmmExt = NULL, *netPath = NULL, *labDir = NULL, *labExt = "lab", *mlfIn = NULL, *mlfOut = NULL, *outDir = NULL, *outExt = "rec", *boundary = NULL;
+   float genBeam = 0.0f, wordBeam = 0.0f, lmScale = 1.0f, wordPen = 0.0f, prScale = 1.0f;
+   int align = 0, models = 0, states = 0, oflags = 0, trace = 0, scoreMode = HTKAMD_SCORE_EXACT, batchN = 1024;
+   const char *sw;
+
+   while (a.at < a.argc && is_switch(a.argv[a.at])) {
+      if (!strncmp(a.argv[a.at], "--", 2)) {
+         const char *lo = a.argv[a.at++] + 2;
+         if (!strcmp(lo, "score")) {
+            const char *m = str_arg(&a, "-score");
+            scoreMode = !strcmp(m, "exact") ? HTKAMD_SCORE_EXACT : !strcmp(m, "fast") ? HTKAMD_SCORE_MFMA : !strcmp(m, "fastest") ? HTKAMD_SCORE_BF16 : -1;
+            if (scoreMode < 0) DIE("--score: exact | fast | fastest");
+         } else if (!strcmp(lo, "batch")) batchN = atoi(str_arg(&a, "-batch"));
+         else DIE("unknown option --%s", lo);
+         continue;
+      }
+      sw = next_switch(&a);
+      switch (sw[0]) {
+      case 'C': cfg_read(&cfg, str_arg(&a, sw)); break;
+      case 'S': {
+         htkamd_scp *scp; CHECK(htkamd_scp_read(str_arg(&a, sw), &scp));
+         for (int i = 0; i < htkamd_scp_count(scp); i++) sl_add(&files, htkamd_scp_physical(scp, i));
+         htkamd_scp_free(scp);
+         break;
+      }
+      case 'H': sl_add(&mmfs, str_arg(&a, sw)); break;
+      case 'd': hmmDir = str_arg(&a, sw); break;
+      case 'x': hmmExt = str_arg(&a, sw); break;
+      case 'w': netPath = str_arg(&a, sw); break;
+      case 'a': align = 1; break;
+      case 'b': boundary = str_arg(&a, sw); break;
+      case 'L': labDir = str_arg(&a, sw); break;
+      case 'X': labExt = str_arg(&a, sw); break;
+      case 'I': mlfIn = str_arg(&a, sw); break;
+      case 'i': mlfOut = str_arg(&a, sw); break;
+      case 'l': outDir = str_arg(&a, sw); break;
+      case 'y': outExt = str_arg(&a, sw); break;
+      case 'm': models = 1; break;
+      case 'f': states = 1; break;
+      case 'o': oflags = out_flags(str_arg(&a, sw)); break;
+      case 't': genBeam = (float)flt_arg(&a, sw); break;
+      case 'v': wordBeam = (float)flt_arg(&a, sw); break;
+      case 's': lmScale = (float)flt_arg(&a, sw); break;
+      case 'p': wordPen = (float)flt_arg(&a, sw); break;
+      case 'r': prScale = (float)flt_arg(&a, sw); break;
+      case 'T': trace = atoi(str_arg(&a, sw)); break;
+      default: DIE("hvite: unknown switch -%s", sw);
+      }
+   }
+   if (a.at + 2 > a.argc) DIE("hvite: dictionary and HMM list expected");
+   const char *dictPath = a.argv[a.at++], *hmmList = a.argv[a.at++];
+   while (a.at < a.argc) sl_add(&files, a.argv[a.at++]);
+   if (files.n == 0) DIE("hvite: no data files");
+   if (!align && !netPath) DIE("hvite: either -w net or -a");
+   if (htkamd_device_count() <= 0) DIE("hvite: no HIP device (the MI355X path has no CPU fallback)");
+
+   htkamd_mmf *mmf; CHECK(htkamd_mmf_create(&mmf));
+   for (int i = 0; i < mmfs.n; i++) CHECK(htkamd_mmf_read(mmf, mmfs.v[i], NULL));
+   CHECK(htkamd_mmf_finish(mmf, hmmList, hmmDir, hmmExt));
+   const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
+   const int D = d->vecSize;
+   htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   htkamd_viterbi *vit; CHECK(htkamd_viterbi_create(model, &vit));
+   const char *tk = cfg_get(&cfg, "TARGETKIND");
+   const int targetKind = kind_parse(tk ? tk : htkamd_mmf_parm_kind(mmf));
+   htkamd_net *net = NULL; htkamd_decoder *dec = NULL;
+   if (!align) { CHECK(htkamd_net_build(netPath, dictPath, mmf, &net)); CHECK(htkamd_decoder_create(model, htkamd_net_get(net), lmScale, &dec)); }
+   htkamd_mlf *mlf = NULL; if (mlfIn) CHECK(htkamd_mlf_read(mlfIn, &mlf));
+   htkamd_mlf_out *mout = NULL; if (mlfOut) CHECK(htkamd_mlf_out_open(mlfOut, &mout));
+   htkamd_decode_config dc; memset(&dc, 0, sizeof(dc));
+   dc.genBeam = genBeam > 0 ? genBeam : 1.0e10f; dc.wordBeam = wordBeam > 0 ? wordBeam : 1.0e10f;
+   dc.lmScale = lmScale; dc.wordPen = wordPen; dc.prScale = prScale; dc.scoreMode = scoreMode;
+   const int maxWords = 4096;
+
+   for (int first = 0; first < files.n; first += (align ? 1 : batchN)) {
+      const int count = align ? 1 : ((files.n - first < batchN) ? files.n - first : batchN);
+      obs_batch ob; memset(&ob, 0, sizeof(ob));
+      load_observations(&files, first, count, targetKind, &cfg, &ob);
+      if (ob.cols != D) DIE("observations have %d components, the models %d", ob.cols, D);
+      htkamd_net *unet = net; htkamd_decoder *udec = dec;
+      if (align) {                                              /* DoAlignment (HVite.c:830): the network of this file's transcription */
+         char lab[2048];
+         make_fn(files.v[first], labDir, labExt, lab, sizeof(lab));
+         htkamd_labels *L = NULL; const htkamd_labels *Lc = NULL;
+         if (mlf) { Lc = htkamd_mlf_find(mlf, lab); if (!Lc) DIE("%s: no entry in the master label file %s", lab, mlfIn); }
+         else { CHECK(htkamd_labels_read(lab, &L)); Lc = L; }
+         const int n = htkamd_labels_count(Lc);
+         const char **words = (const char **)malloc(sizeof(char *) * (size_t)(n ? n : 1));
+         for (int i = 0; i < n; i++) words[i] = htkamd_labels_name(Lc, i);
+         CHECK(htkamd_net_build_words(words, n, boundary, dictPath, mmf, &unet));
+         CHECK(htkamd_decoder_create(model, htkamd_net_get(unet), lmScale, &udec));
+         free(words);
+         if (L) htkamd_labels_free(L);
+      }
+      int *nWords = (int *)malloc(sizeof(int) * (size_t)count), *wPron = (int *)malloc(sizeof(int) * (size_t)count * maxWords);
+      int *wStart = (int *)malloc(sizeof(int) * (size_t)count * maxWords), *wEnd = (int *)malloc(sizeof(int) * (size_t)count * maxWords);
+      float *wScore = (float *)malloc(sizeof(float) * (size_t)count * maxWords), *wLm = (float *)malloc(sizeof(float) * (size_t)count * maxWords);
+      double *total = (double *)malloc(sizeof(double) * (size_t)count);
+      CHECK(htkamd_decoder_run(udec, &dc, ob.dX, ob.frameOff, count, maxWords, nWords, wPron, wStart, wEnd, wScore, wLm, total, NULL));
+      for (int u = 0; u < count; u++) {
+         const char *fn = files.v[first + u];
+         const int T = ob.frameOff[u + 1] - ob.frameOff[u];
+         if (nWords[u] < 0) { fprintf(stderr, "No tokens survived to final node of network: %s\n", fn); continue; }
+         htkamd_trans *tr; CHECK(htkamd_trans_create((models ? 1 : 0) + (states ? 1 : 0), &tr));
+         emit(tr, unet, mmf, vit, ob.dX, D, ob.frameOff[u], T, nWords[u], wPron + (size_t)u * maxWords, wStart + (size_t)u * maxWords, wEnd + (size_t)u * maxWords,
+              wScore + (size_t)u * maxWords, wLm + (size_t)u * maxWords, (double)ob.period, models, states, lmScale, wordPen, dc.genBeam);
+         CHECK(htkamd_trans_format(tr, (double)ob.period, states, models, oflags));
+         char out[2048];
+         make_fn(fn, outDir, outExt, out, sizeof(out));
+         if (mout) CHECK(htkamd_mlf_out_add(mout, out, tr)); else CHECK(htkamd_trans_write(tr, out));
+         htkamd_trans_free(tr);
+         if (trace & 1) printf("File: %s\n==  [%d frames] %.4f [Ac=%.1f]\n", fn, T, total[u] / T, total[u]);
+      }
+      free(nWords); free(wPron); free(wStart); free(wEnd); free(wScore); free(wLm); free(total);
+      if (align) { htkamd_decoder_destroy(udec); htkamd_net_destroy(unet); }
+      free_observations(&ob);
+   }
+   if (mout) htkamd_mlf_out_close(mout);
+   if (mlf) htkamd_mlf_free(mlf);
+   if (dec) htkamd_decoder_destroy(dec);
+   if (net) htkamd_net_destroy(net);
+   htkamd_viterbi_destroy(vit); htkamd_model_destroy(model); htkamd_mmf_destroy(mmf);
+   return 0;
+}
