@@ -76,7 +76,7 @@ struct DecArgs {
    int *pathPrev; double *pathLike; float *pathLm;
    float genBeam, wordBeam, lmScale, wordPen, prScale;
    int maxWords;
-   int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm; double *total;
+   int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm, *wordAc; double *wordLike; double *total; float *finalLm;
 };
 
 __device__ __forceinline__ Tok null_tok() { Tok t; t.like = LZERO; t.lm = 0.0f; t.path = -1; return t; }
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
       const Tok fin = ex[N.final];
       const int fp = fin.path;
       int nW = 0;
-      a.total[u] = LZERO;
+      a.total[u] = LZERO; a.finalLm[u] = 0.0f;
       if (fp >= 0) {
-         a.total[u] = fin.like;
+         a.total[u] = fin.like; a.finalLm[u] = fin.lm;
          for (int p = fp; p >= 0; p = a.pathPrev[ud.path0 + p]) nW++;
          if (nW > a.maxWords) nW = -3;
          else {
@@ -336,6 +336,8 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                a.wordStart[ud.out0 + w] = (prev >= 0) ? prev / N.nWordNodes : 0;
                a.wordScore[ud.out0 + w] = sc;
                a.wordLm[ud.out0 + w] = plm;
+               a.wordAc[ud.out0 + w] = aclike;
+               a.wordLike[ud.out0 + w] = a.pathLike[ud.path0 + p];
                p = prev;
             }
          }
@@ -514,6 +516,20 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
                                   int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
                                   double *total, void *stream)
 {
+   htkamd_decode_out o;
+   memset(&o, 0, sizeof(o));
+   o.nWords = nWords; o.wordPron = wordPron; o.wordStart = wordStart; o.wordEnd = wordEnd; o.wordScore = wordScore; o.wordLm = wordLm; o.total = total;
+   return htkamd_decoder_run_out(d, cfg, dX, frameOff, nUtt, maxWords, &o, stream);
+}
+
+extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
+                                      int maxWords, const htkamd_decode_out *out, void *stream)
+{
+   if (!out) { htkamd_set_error("decoder_run: bad argument"); return HTKAMD_EINVAL; }
+   int *nWords = out->nWords, *wordPron = out->wordPron, *wordStart = out->wordStart, *wordEnd = out->wordEnd;
+   float *wordScore = out->wordScore, *wordLm = out->wordLm, *wordAc = out->wordAc;
+   double *total = out->total, *wordLike = out->wordLike;
+   float *finalLm = out->finalLm;
    if (!d || !cfg || !frameOff || nUtt < 0 || maxWords < 1 || !nWords || !wordPron || !wordStart || !wordEnd || !wordScore || !total) {
       htkamd_set_error("decoder_run: bad argument"); return HTKAMD_EINVAL;
    }
@@ -552,14 +568,15 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
          score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += (size_t)(ud.T + 1) * N.nWordNodes;
       }
       void *dScore = nullptr, *dTok = nullptr, *dEx = nullptr, *dImax = nullptr;
-      void *dPPrev = nullptr, *dPLike = nullptr, *dPLm = nullptr, *dUtt = nullptr, *dTasks = nullptr, *dOutI = nullptr, *dOutF = nullptr, *dTot = nullptr;
+      void *dPPrev = nullptr, *dPLike = nullptr, *dPLm = nullptr, *dUtt = nullptr, *dTasks = nullptr, *dOutI = nullptr, *dOutF = nullptr, *dTot = nullptr, *dOutD = nullptr;
       int rc = HTKAMD_OK;
       auto A = [&](void **p, size_t n) { if (rc) return; hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) { htkamd_set_error("decoder_run: hipMalloc(%zu): %s", n, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; } };
       A(&dScore, score * 4); A(&dTok, tok * sizeof(Tok)); A(&dEx, node * sizeof(Tok)); A(&dImax, node * 8);
       A(&dPPrev, path * 4); A(&dPLike, path * 8); A(&dPLm, path * 4);
       A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
-      A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * (size_t)nu * maxWords * 2); A(&dTot, sizeof(double) * nu);
-      std::vector<int> hI; std::vector<float> hF; std::vector<double> hT;
+      A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * ((size_t)nu * maxWords * 3 + nu)); A(&dTot, sizeof(double) * nu);
+      A(&dOutD, sizeof(double) * (size_t)nu * maxWords);
+      std::vector<int> hI; std::vector<float> hF; std::vector<double> hT, hD;
       if (!rc) {
          hipError_t e;
          if ((e = hipMemcpyAsync(dUtt, utt.data(), sizeof(DecUtt) * nu, hipMemcpyHostToDevice, s)) != hipSuccess ||
@@ -586,28 +603,33 @@ extern "C" int htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config 
          a.maxWords = maxWords;
          int *oi = (int *)dOutI;
          a.nWords = oi; a.wordPron = oi + nu; a.wordStart = a.wordPron + (size_t)nu * maxWords; a.wordEnd = a.wordStart + (size_t)nu * maxWords;
-         a.wordScore = (float *)dOutF; a.wordLm = (float *)dOutF + (size_t)nu * maxWords; a.total = (double *)dTot;
+         a.wordScore = (float *)dOutF; a.wordLm = (float *)dOutF + (size_t)nu * maxWords; a.wordAc = (float *)dOutF + (size_t)nu * maxWords * 2; a.finalLm = (float *)dOutF + (size_t)nu * maxWords * 3; a.total = (double *)dTot;
+         a.wordLike = (double *)dOutD;
          hipLaunchKernelGGL(k_decode, dim3(nu), dim3(DEC_THREADS), 0, s, a);
          hipError_t e = hipGetLastError();
          if (e != hipSuccess) { htkamd_set_error("decoder_run: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       }
       if (!rc) {
-         hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords * 2); hT.resize(nu);
+         hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords * 3 + nu); hT.resize(nu); hD.resize((size_t)nu * maxWords);
          hipError_t e;
          if ((e = hipMemcpyAsync(hI.data(), dOutI, sizeof(int) * hI.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
              (e = hipMemcpyAsync(hF.data(), dOutF, sizeof(float) * hF.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
              (e = hipMemcpyAsync(hT.data(), dTot, sizeof(double) * nu, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+             (e = hipMemcpyAsync(hD.data(), dOutD, sizeof(double) * hD.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
              (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       } else (void)hipStreamSynchronize(s);
-      for (void *p : {dScore, dTok, dEx, dImax, dPPrev, dPLike, dPLm, dUtt, dTasks, dOutI, dOutF, dTot}) (void)hipFree(p);
+      for (void *p : {dScore, dTok, dEx, dImax, dPPrev, dPLike, dPLm, dUtt, dTasks, dOutI, dOutF, dTot, dOutD}) (void)hipFree(p);
       if (rc) return rc;
       for (int k = 0; k < nu; k++) {
          nWords[u0 + k] = hI[k]; total[u0 + k] = hT[k];
+         if (finalLm) finalLm[u0 + k] = hF[(size_t)nu * maxWords * 3 + k];
          const size_t o = (size_t)(u0 + k) * maxWords, si = (size_t)k * maxWords;
          for (int w = 0; w < maxWords; w++) {
             wordPron[o + w] = hI[nu + si + w]; wordStart[o + w] = hI[nu + (size_t)nu * maxWords + si + w];
             wordEnd[o + w] = hI[nu + (size_t)nu * maxWords * 2 + si + w]; wordScore[o + w] = hF[si + w];
             if (wordLm) wordLm[o + w] = hF[(size_t)nu * maxWords + si + w];
+            if (wordAc) wordAc[o + w] = hF[(size_t)nu * maxWords * 2 + si + w];
+            if (wordLike) wordLike[o + w] = hD[si + w];
          }
       }
       u0 = u1;

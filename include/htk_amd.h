@@ -477,6 +477,18 @@ int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, cons
                         int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
                         double *total, void *stream);
 
+/* The same with every per-word quantity of the 1-best path that CompleteRecognition's lattice carries (LatFromPaths HRec.c:1512):
+   wordAc = LArc.aclike (acoustic log likelihood of the word's segment, float), wordLike = Path.like (the token's likelihood at the
+   word end, double).  Any of wordLm / wordAc / wordLike may be NULL. */
+typedef struct {
+   int *nWords, *wordPron, *wordStart, *wordEnd;
+   float *wordScore, *wordLm, *wordAc;
+   double *wordLike, *total;
+   float *finalLm;             /* [nUtt] LM log probability the final token collected after the last word end (may be NULL) */
+} htkamd_decode_out;
+int  htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
+                            int maxWords, const htkamd_decode_out *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Waveform -> MFCC(+_0/_E)(+_D)(+_A)(+_Z) on the device: replaces what OpenBuffer (HParm.h, HParm.c:4357)
  * does for a waveform source with maxObs == 0 (whole file converted into a table):

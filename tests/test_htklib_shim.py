@@ -97,3 +97,55 @@ def test_reference_herest_front_end_runs_its_e_step_on_the_gpu(native, tmp_path)
         assert np.allclose(gv, rv, rtol=1e-4, atol=1e-7), name
         assert np.allclose(gg, rg, rtol=1e-5), name
         assert np.allclose(lin(gt), lin(rt), rtol=1e-4, atol=1e-7), name
+
+
+# ---------------------------------------------------------------------------------------------------------------- HVite
+HVITE = os.path.join(ROOT, "oracle", "_ref", "HVite_amd")
+needs_hvite = pytest.mark.skipif(not os.path.exists(HVITE), reason="oracle/_ref/HVite_amd not built (needs /root/reference: make -C oracle)")
+
+
+def _hvite_cmd(out_dir, conf, part, names):
+    return [HVITE, "-C", conf, "-d", os.path.join(DEMO, "hmm_final"), "-w", os.path.join(DEMO, "monLattice"), "-l", out_dir, "-t", "300.0", "-p", "5.0",
+            "-s", "0.0", os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + [os.path.join(DEMO, part, u + ".mfc") for u in names]
+
+
+@needs_hvite
+def test_hvite_link_routes_the_recogniser_entry_points_through_the_shim(tmp_path):
+    nm = subprocess.run(["nm", HVITE], capture_output=True, text=True, check=True).stdout
+    defined = {l.split()[-1] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] in "Tt"}
+    for s in ["__wrap_StartRecognition", "__wrap_ProcessObservation", "__wrap_CompleteRecognition", "__wrap_InitPSetInfo", "__wrap_InitVRecInfo",
+              "StartRecognition", "TranscriptionFromLattice", "FormatTranscription", "ExpandWordNet", "ReadLattice", "OpenBuffer", "FBFile"]:
+        assert s in defined, s
+    obj = os.path.join(ROOT, "oracle", "_ref", "obj", "htklib_hrec_shim.o")
+    und = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout.split()
+    assert "htkamd_decoder_run_out" in und and "NewLattice" in und and "__real_InitPSetInfo" in und
+    import torch
+    if not torch.cuda.is_available():
+        import json
+        conf = tmp_path / "c"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+        names = sorted(json.load(open(os.path.join(DEMO, "hvite_expected.json")))["test"])
+        r = subprocess.run(_hvite_cmd(str(tmp_path), str(conf), "test", names), capture_output=True, text=True)
+        out = r.stdout + r.stderr
+        assert r.returncode != 0 and "7399" in out and "no HIP device" in out, out[-600:]
+
+
+@pytest.mark.gpu
+@needs_hvite
+def test_reference_hvite_front_end_recognises_on_the_gpu(tmp_path):
+    """The reference's HVite.c, its HNet network expansion, HParm buffers and label writer unchanged; StartRecognition /
+    ProcessObservation / CompleteRecognition served by the library: every .rec file of HTKDemo's test and training sets equals the
+    one the reference's own HVite wrote."""
+    import json
+    expected = json.load(open(os.path.join(DEMO, "hvite_expected.json")))
+    conf = tmp_path / "c"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    n = 0
+    for part in ("test", "train"):
+        names = sorted(expected[part])
+        out = tmp_path / part; out.mkdir()
+        r = subprocess.run(_hvite_cmd(str(out), str(conf), part, names), capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+        for u in names:
+            got = (out / (u + ".rec")).read_text().splitlines()
+            assert got == expected[part][u], (part, u, got[:3], expected[part][u][:3])
+            n += len(got)
+    assert n == 292

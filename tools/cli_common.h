@@ -154,6 +154,6 @@ static int is_switch(const char *s) { return s[0] == '-' && s[1] && !isdigit((un
 static const char *next_switch(args *a) { return (a->at < a->argc && is_switch(a->argv[a->at])) ? a->argv[a->at++] + 1 : NULL; }
 static const char *str_arg(args *a, const char *sw) { if (a->at >= a->argc) DIE("-%s: value expected", sw); return a->argv[a->at++]; }
 static double flt_arg(args *a, const char *sw) { return atof(str_arg(a, sw)); }
-static int has_num_arg(const args *a) { return a->at < a->argc && !is_switch(a->argv[a->at]) && (isdigit((unsigned char)a->argv[a->at][0]) || a->argv[a->at][0] == '.' || a->argv[a->at][0] == '-'); }
+static __attribute__((unused)) int has_num_arg(const args *a) { return a->at < a->argc && !is_switch(a->argv[a->at]) && (isdigit((unsigned char)a->argv[a->at][0]) || a->argv[a->at][0] == '.' || a->argv[a->at][0] == '-'); }
 
 #endif
