@@ -1,0 +1,51 @@
+"""Condense the rocprofv3 output of tools/prof_r02.sh into the small files profiles/ keeps:
+   <tag>_kernel_stats.csv (copied), <tag>_traffic.json (FETCH_SIZE / WRITE_SIZE KB per launch of every kernel of the timed pass),
+   <tag>_sq.json (SQ counters per launch).     python tools/prof_summarise.py gpurun_out/<tag> <tag>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join("profiles", "%s_kernel_stats.csv" % tag))
+
+
+def per_kernel(counter_dir, names):
+    acc = {}
+    for f in glob.glob(os.path.join(counter_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+            if not k.startswith("k_"):
+                continue
+            if r["Counter_Name"] in names:
+                d = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [])
+                d.append(float(r["Counter_Value"]))
+    return acc
+
+
+traffic = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, v in per_kernel(os.path.join(out, "pmc_" + c), {c}).items():
+        vals = v[c]
+        # the bench issues the initial-model pass, the timed iteration and the stand-alone latency passes: report the per-launch mean
+        traffic.setdefault(k, {})[c + "_KB"] = sum(vals) / len(vals)
+        traffic[k]["launches"] = len(vals)
+try:
+    cfg = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])["config"]
+except Exception:  # noqa: BLE001
+    cfg = {}
+json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`, counters' KB per launch, "
+                       "uncorrected (MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of 16 B/lane streaming reads; narrower loads uncalibrated)",
+           "workload": {k: cfg.get(k) for k in ("states", "mix", "utts_per_gpu", "frames", "chunks")}, "kernels": traffic},
+          open(os.path.join("profiles", "%s_traffic.json" % tag), "w"), indent=1)
+sq = {}
+names = {"SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"}
+for k, v in per_kernel(os.path.join(out, "pmc_SQ"), names).items():
+    sq[k] = {c: sum(x) / len(x) for c, x in v.items()}
+json.dump({"_comment": "SQ counters per launch (mean over the launches of `bench.py --steps 1 --warmup 0`)", "kernels": sq},
+          open(os.path.join("profiles", "%s_sq.json" % tag), "w"), indent=1)
+print(json.dumps(traffic, indent=1)[:1500])
