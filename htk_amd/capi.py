@@ -799,7 +799,7 @@ class Net:
 
 class DecodeConfig(C.Structure):
     _fields_ = [("genBeam", C.c_float), ("wordBeam", C.c_float), ("lmScale", C.c_float), ("wordPen", C.c_float), ("prScale", C.c_float),
-                ("scoreMode", C.c_int)]
+                ("scoreMode", C.c_int), ("maxActive", C.c_int)]
 
 
 class Decoder:
@@ -810,7 +810,7 @@ class Decoder:
         self.model, self.net, self.lmScale = model, net, float(lmScale)
         check(lib().htkamd_decoder_create(model.h, C.byref(net.desc), C.c_float(lmScale), C.byref(self.h)), "decoder_create")
 
-    def run(self, feats, genBeam=1.0e10, wordBeam=1.0e10, lmScale=None, wordPen=0.0, prScale=1.0, maxWords=1024, scoreMode=0):
+    def run(self, feats, genBeam=1.0e10, wordBeam=1.0e10, lmScale=None, wordPen=0.0, prScale=1.0, maxWords=1024, scoreMode=0, maxActive=0):
         """feats: list of [T, D] arrays.  Returns per utterance (list of (pron, startFrame, endFrame, score) or None, total)."""
         lmScale = self.lmScale if lmScale is None else float(lmScale)
         if lmScale != self.lmScale:
@@ -822,7 +822,7 @@ class Decoder:
         nW = np.zeros(max(nU, 1), np.int32); tot = np.zeros(max(nU, 1), np.float64)
         wp = np.zeros(max(nU, 1) * maxWords, np.int32); ws = np.zeros_like(wp); we = np.zeros_like(wp); sc = np.zeros(max(nU, 1) * maxWords, np.float32)
         lm = np.zeros_like(sc)
-        cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale, scoreMode)
+        cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale, scoreMode, int(maxActive))
         check(lib().htkamd_decoder_run(self.h, C.byref(cfg), dX.ptr, _p(frameOff), C.c_int(nU), C.c_int(maxWords), _p(nW), _p(wp), _p(ws), _p(we),
                                        _p(sc), _p(lm), _p(tot), None), "decoder_run")
         self.last_lm = [[float(lm[u * maxWords + i]) for i in range(max(int(nW[u]), 0))] for u in range(nU)]

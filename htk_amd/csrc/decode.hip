@@ -75,6 +75,7 @@ struct DecArgs {
    Tok *ex; double *imax;              // [sum nNodes] exit tokens, instance maxima
    int *pathPrev; double *pathLike; float *pathLm;
    float genBeam, wordBeam, lmScale, wordPen, prScale;
+   int maxActive;                      // HVite -u: maximum number of model instances kept per frame (0 = off)
    int maxWords;
    int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm, *wordAc; double *wordLike; double *total; float *finalLm;
 };
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
    __shared__ int redk[DEC_THREADS / 64];
    __shared__ float thr[2];
    __shared__ float ltp[DEC_LDS_TP];
+   __shared__ int uhist[256];
+   __shared__ unsigned int usel[4];            // -u: [0] attached instances, [1] key prefix, [2] rank still to skip, [3] scratch
    const int u = blockIdx.x, tid = threadIdx.x;
    if (u >= a.nUtt) return;
    const DecUtt ud = a.utt[u];
@@ -139,6 +142,58 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
    __syncthreads();
 
    for (int t = 0; t <= T; t++) {
+      if (t >= 1 && a.maxActive > 0) {
+         // ---- maximum-model pruning (ProcessObservation HRec.c:1966-1985): when more than maxActive instances are attached, those
+         // whose max (a float, NetInst.max) lies below the (maxActive+1)-th largest are detached before pass 1.  An instance is
+         // attached when its max reached the previous frame's threshold (imax carries the pass-1 maximum raised by any token that
+         // entered in pass 2; word / null nodes hold the token they were given).  Selection: radix select on the float keys.
+         const float gTp = thr[0];
+         if (tid == 0) usel[0] = 0;
+         __syncthreads();
+         int cnt = 0;
+         for (int n = tid; n < N.nNodes; n += DEC_THREADS) { const double v = imax[n]; if (v >= gTp && v > LSMALL) cnt++; }
+         if (cnt) atomicAdd(&usel[0], (unsigned)cnt);
+         __syncthreads();
+         const int nact = (int)usel[0];
+         if (nact > a.maxActive) {
+            if (tid == 0) { usel[1] = 0; usel[2] = (unsigned)a.maxActive; }
+            unsigned int mask = 0;
+            for (int pass = 0; pass < 4; pass++) {
+               const int shift = 24 - 8 * pass;
+               for (int i = tid; i < 256; i += DEC_THREADS) uhist[i] = 0;
+               __syncthreads();
+               const unsigned int prefix = usel[1];
+               for (int n = tid; n < N.nNodes; n += DEC_THREADS) {
+                  const double v = imax[n];
+                  if (!(v >= gTp && v > LSMALL)) continue;
+                  unsigned int k = __float_as_uint((float)v);
+                  k ^= (k >> 31) ? 0xFFFFFFFFu : 0x80000000u;          // ascending order of the floats
+                  if ((k & mask) == prefix) atomicAdd(&uhist[(k >> shift) & 255], 1);
+               }
+               __syncthreads();
+               if (tid == 0) {
+                  unsigned int skip = usel[2], cum = 0; int b = 255;
+                  for (; b > 0; b--) { if (cum + (unsigned)uhist[b] > skip) break; cum += (unsigned)uhist[b]; }
+                  usel[1] = prefix | ((unsigned)b << shift); usel[2] = skip - cum;
+               }
+               mask |= 255u << shift;
+               __syncthreads();
+            }
+            unsigned int kk = usel[1];
+            kk ^= (kk >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+            const float uth = __uint_as_float(kk);
+            if (uth > (float)LSMALL)
+               for (int n = tid; n < N.nNodes; n += DEC_THREADS) {
+                  const double v = imax[n];
+                  if (!(v >= gTp && v > LSMALL) || !(v < (double)uth)) continue;
+                  imax[n] = LZERO; ex[n] = null_tok();                 // DetachInst: every token of the instance goes, the entry token too
+                  const int4 ni = N.nodeInfo[n];
+                  const int nt = ((ni.x & 15) == HTKAMD_NODE_HMM) ? ((ni.x >> 4) & 255) - 1 : 1;
+                  for (int i = 0; i < nt; i++) tok[ni.y + i] = null_tok();
+               }
+            __syncthreads();
+         }
+      }
       if (t >= 1) {
          const float gT = thr[0];                         // threshold of the previous frame
          double myGen = LZERO, myWord = LZERO;
@@ -213,7 +268,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             } else if (detached) {
                for (int i = 1; i < NS; i++) tok[t0 + i - 1] = null_tok();
             }
-            ex[n] = exT; imax[n] = mx;
+            ex[n] = exT; imax[n] = (double)(float)mx;         // inst->max is a LogFloat (HRec.c:138)
          }
          const double genMax = block_max(myGen, red);
          const double wordMax = block_max(myWord, red2);
@@ -240,13 +295,18 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                const int NS = (ni.x >> 4) & 255;
                tok[ni.y] = st;
                e = ex[n];
-               const double m2 = (st.like > imax[n]) ? st.like : imax[n];
-               if (t >= 1 && m2 < gT) e = null_tok();
-               else if (st.like > LSMALL) {
-                  const double c = st.like + tpBase[ni.z + (NS - 1)];
-                  if (c > e.like) { e = st; e.like = c; }
+               const double m2 = (st.like > imax[n]) ? (double)(float)st.like : imax[n];      // SetEntryState raises the instance's max
+               if (t >= 1 && m2 < gT) { e = null_tok(); imax[n] = LZERO; }
+               else {
+                  imax[n] = m2;
+                  if (st.like > LSMALL) {
+                     const double c = st.like + tpBase[ni.z + (NS - 1)];
+                     if (c > e.like) { e = st; e.like = c; }
+                  }
                }
-            } else if (st.like > LSMALL) {
+            } else if (!(st.like > LSMALL)) imax[n] = LZERO;
+            else {
+               imax[n] = (double)(float)st.like;
                e = st;
                if (kind == HTKAMD_NODE_WORD) {             // StepWord2
                   e.like += a.wordPen;
@@ -279,6 +339,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                if (redk[bw] == 0x7fffffff) b = null_tok();
                if (t == 0 && n == N.initial) { b.like = 0.0; b.lm = 0.0f; b.path = -1; }
                Tok e = null_tok();
+               imax[n] = (b.like > LSMALL) ? (double)(float)b.like : LZERO;
                if (b.like > LSMALL) {
                   e = b;
                   if (N.kind[n] == HTKAMD_NODE_WORD) {
@@ -301,7 +362,9 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             const int4 ni = N.nodeInfo[n];
             if ((ni.x >> 12) & 1) continue;                // tee models got theirs in the level phase
             int ak;
-            tok[ni.y] = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            const Tok en = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            tok[ni.y] = en;
+            if (en.like > imax[n]) imax[n] = (double)(float)en.like;      // SetEntryState: the entering token raises the instance's max
          }
          __syncthreads();
       }
@@ -599,7 +662,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
          a.tok = (Tok *)dTok; a.ex = (Tok *)dEx; a.imax = (double *)dImax;
          a.pathPrev = (int *)dPPrev; a.pathLike = (double *)dPLike; a.pathLm = (float *)dPLm;
-         a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
+         a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale; a.maxActive = cfg->maxActive;
          a.maxWords = maxWords;
          int *oi = (int *)dOutI;
          a.nWords = oi; a.wordPron = oi + nu; a.wordStart = a.wordPron + (size_t)nu * maxWords; a.wordEnd = a.wordStart + (size_t)nu * maxWords;

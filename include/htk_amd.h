@@ -469,6 +469,7 @@ typedef struct {
    float genBeam, wordBeam, lmScale, wordPen, prScale;
    int   scoreMode;   /* HTKAMD_SCORE_EXACT (0): scores, token likelihoods and therefore paths are the reference's bit for bit;
                          HTKAMD_SCORE_MFMA: matrix-core scores (1e-4 class) -- same words unless two paths tie within that */
+   int   maxActive;   /* HVite -u: maximum-model pruning (ProcessObservation HRec.c:1966-1985); 0 = off */
 } htkamd_decode_config;
 typedef struct htkamd_decoder htkamd_decoder;
 int  htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *net, float lmScale, htkamd_decoder **out);

@@ -161,6 +161,11 @@ int orc_decode(const orc_model *m, const float *X, int T,
                const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
                float genBeam, float wordBeam, float lmScale, float wordPen, float prScale,
                int maxWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *totalLike);
+int orc_decode_u(const orc_model *m, const float *X, int T,
+               int nNodes, const int *kind, const int *model, const float *pronProb,
+               const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
+               float genBeam, float wordBeam, float lmScale, float wordPen, float prScale, int maxActive,
+               int maxWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *totalLike);
 int orc_viterbi_align(const orc_model *m, const float *X, int T, const int *labs, int Q, float genBeam,
                       int maxSeg, int *segQ, int *segState, int *segStart, int *segEnd, double *segScore,
                       int *modStart, int *modEnd, double *modScore, double *totalLike);

@@ -22,6 +22,7 @@
  * Ties between tokens of exactly equal likelihood are resolved by list order in the reference and by node order here.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "htk_oracle.h"
@@ -74,10 +75,24 @@ static int is_wd0_link(const dnet *d, int dst)
    return 0;
 }
 
+static int cmp_desc(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return (x < y) - (x > y); }
+
 int orc_decode(const orc_model *m, const float *X, int T,
                int nNodes, const int *kind, const int *model, const float *pronProb,
                const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
                float genBeam, float wordBeam, float lmScale, float wordPen, float prScale,
+               int maxWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *totalLike)
+{
+   return orc_decode_u(m, X, T, nNodes, kind, model, pronProb, linkOff, linkDest, linkLike, initial, final, genBeam, wordBeam, lmScale, wordPen, prScale,
+                       0, maxWords, wordPron, wordStart, wordEnd, wordScore, totalLike);
+}
+
+/* the same with HVite -u: maximum-model pruning (ProcessObservation HRec.c:1966-1985) -- before pass 1 of a frame, when more than
+   maxActive instances are attached, the instances whose max lies below the (maxActive+1)-th largest max (as floats) are detached */
+int orc_decode_u(const orc_model *m, const float *X, int T,
+               int nNodes, const int *kind, const int *model, const float *pronProb,
+               const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
+               float genBeam, float wordBeam, float lmScale, float wordPen, float prScale, int maxActive,
                int maxWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, double *totalLike)
 {
    dnet d; memset(&d, 0, sizeof(d));
@@ -129,6 +144,8 @@ int orc_decode(const orc_model *m, const float *X, int T,
 
    tok_t *tk = (tok_t *)malloc(sizeof(tok_t) * (size_t)nTok), *ex = (tok_t *)malloc(sizeof(tok_t) * (size_t)nNodes), *nw = (tok_t *)malloc(sizeof(tok_t) * (size_t)(maxN + 1));
    double *imax = (double *)malloc(sizeof(double) * (size_t)nNodes);
+   char *att = (char *)calloc((size_t)nNodes, 1);             /* the node has an instance (AttachInst / DetachInst) */
+   float *qsa = (float *)malloc(sizeof(float) * (size_t)(nNodes + 1));
    int capP = 1024, nP = 0;
    path_t *pth = (path_t *)malloc(sizeof(path_t) * (size_t)capP);
    float genThresh = (float)ORC_LSMALL, wordThresh = (float)ORC_LSMALL;
@@ -136,10 +153,11 @@ int orc_decode(const orc_model *m, const float *X, int T,
    int *sct = (int *)calloc((size_t)m->S, sizeof(int));
    for (i = 0; i < nTok; i++) tk[i] = NULLTOK;
    for (n = 0; n < nNodes; n++) { ex[n] = NULLTOK; imax[n] = ORC_LZERO; }
-   tk[d.tok0[initial]].like = 0.0; tk[d.tok0[initial]].lm = 0.0f; tk[d.tok0[initial]].path = -1; imax[initial] = 0.0;
+   tk[d.tok0[initial]].like = 0.0; tk[d.tok0[initial]].lm = 0.0f; tk[d.tok0[initial]].path = -1; imax[initial] = 0.0; att[initial] = 1;
    tok_t finalTok = NULLTOK;
 
-#define ENTER(dst, src) do { tok_t *r_ = &tk[d.tok0[dst]]; if ((src).like > r_->like) *r_ = (src); if (r_->like > imax[dst]) imax[dst] = r_->like; } while (0)
+#define ENTER(dst, src) do { tok_t *r_ = &tk[d.tok0[dst]]; if (!att[dst]) { att[dst] = 1; imax[dst] = ORC_LZERO; } \
+      if ((src).like > r_->like) *r_ = (src); if (r_->like > imax[dst]) imax[dst] = (float)r_->like; } while (0)   /* NetInst.max is a LogFloat (HRec.c:138) */
 #define SEND(n_, tok_) do { if ((tok_).like > genThresh) for (int k_ = linkOff[n_]; k_ < linkOff[(n_) + 1]; k_++) { \
       tok_t x_ = (tok_); const float lm_ = linkLike[k_]; x_.like = (tok_).like + lm_ * lmScale; x_.lm = (tok_).lm + lm_; \
       if (x_.like > genThresh) ENTER(linkDest[k_], x_); } } while (0)
@@ -147,6 +165,20 @@ int orc_decode(const orc_model *m, const float *X, int T,
    for (t = 0; t <= T; t++) {
       if (t >= 1) {
          double genMax = ORC_LZERO, wordMax = ORC_LZERO;
+         if (maxActive > 0) {                                 /* HRec.c:1966-1985 */
+            int nact = 0;
+            for (n = 0; n < nNodes; n++) if (att[n]) qsa[nact++] = (float)imax[n];
+            if (nact > maxActive) {
+               qsort(qsa, (size_t)nact, sizeof(float), cmp_desc);
+               const float thresh = qsa[maxActive];
+               if (thresh > ORC_LSMALL)
+                  for (n = 0; n < nNodes; n++)
+                     if (att[n] && imax[n] < thresh) {
+                        att[n] = 0; imax[n] = ORC_LZERO; ex[n] = NULLTOK;
+                        for (i = d.tok0[n]; i < d.tok0[n + 1]; i++) tk[i] = NULLTOK;
+                     }
+            }
+         }
          for (n = 0; n < nNodes; n++) {
             if (kind[n] != KIND_HMM) { tk[d.tok0[n]] = NULLTOK; ex[n] = NULLTOK; imax[n] = ORC_LZERO; continue; }   /* StepWord1 */
             const int N = d.N[n];
@@ -154,7 +186,7 @@ int orc_decode(const orc_model *m, const float *X, int T,
             double mx = ORC_LZERO;
             int live = 0;
             for (i = 1; i < N; i++) if (s[i].like > ORC_LSMALL) live = 1;
-            if (!live) { ex[n] = NULLTOK; imax[n] = ORC_LZERO; continue; }          /* no instance */
+            if (!live) { ex[n] = NULLTOK; imax[n] = ORC_LZERO; continue; }          /* no instance, or one about to be detached */
             for (j = 2; j < N; j++) {
                int arg = d.seLo[n * (maxN + 1) + j];
                tok_t best = s[arg]; best.like += TPN(&d, n, arg, j);
@@ -172,7 +204,7 @@ int orc_decode(const orc_model *m, const float *X, int T,
             }
             s[1] = NULLTOK;
             for (j = 2; j < N; j++) s[j] = nw[j];
-            imax[n] = mx;
+            imax[n] = (float)mx;                              /* inst->max = max.like: a LogFloat */
             if (mx > genMax) genMax = mx;
             {
                int arg = d.seLo[n * (maxN + 1) + N];
@@ -195,7 +227,7 @@ int orc_decode(const orc_model *m, const float *X, int T,
             if (kind[n] != KIND_HMM) continue;
             if (imax[n] < genThresh) {                        /* DetachInst: every token of the instance is dropped */
                for (i = 1; i < d.N[n]; i++) tk[d.tok0[n] + i - 1] = NULLTOK;
-               ex[n] = NULLTOK;
+               ex[n] = NULLTOK; att[n] = 0;
             }
          }
          for (n = 0; n < nNodes; n++) if (kind[n] == KIND_HMM && !d.tee[n]) SEND(n, ex[n]);
@@ -205,14 +237,14 @@ int orc_decode(const orc_model *m, const float *X, int T,
          n = order[i];
          tok_t *st = &tk[d.tok0[n]];
          if (kind[n] == KIND_HMM) {                           /* tee model: StepHMM2 */
-            if (t >= 1 && imax[n] < genThresh) continue;
+            if (t >= 1 && imax[n] < genThresh) { att[n] = 0; continue; }
             const double c = st->like + TPN(&d, n, 1, d.N[n]);
             if (st->like > ORC_LSMALL && c > ex[n].like) { ex[n] = *st; ex[n].like = c; }
             SEND(n, ex[n]);
             continue;
          }
-         if (!(st->like > ORC_LSMALL)) continue;
-         if (imax[n] < genThresh) { *st = NULLTOK; continue; }
+         if (!(st->like > ORC_LSMALL)) { att[n] = 0; continue; }      /* an instance left over from the previous frame is detached here */
+         if (imax[n] < genThresh) { *st = NULLTOK; att[n] = 0; continue; }
          tok_t e = *st;
          if (kind[n] == KIND_WORD) {                          /* StepWord2 */
             e.like += wordPen;
@@ -254,7 +286,7 @@ int orc_decode(const orc_model *m, const float *X, int T,
          rc = nW;
       }
    }
-   free(tk); free(ex); free(nw); free(imax); free(pth); free(scv); free(sct);
+   free(tk); free(ex); free(nw); free(imax); free(pth); free(scv); free(sct); free(att); free(qsa);
 done0:
    free(indeg); free(order); free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi);
    return rc;

@@ -299,7 +299,7 @@ def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
     return out
 
 
-def decode(model: "Model", X: np.ndarray, net: dict, genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0, maxWords=4096):
+def decode(model: "Model", X: np.ndarray, net: dict, genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0, maxWords=4096, maxActive=0):
     """HRec 1-best decoding over a flat network (dict with the fields of htkamd_net_desc).
     Returns (list of (pron, startFrame, endFrame, score), totalLike) or (None, LZERO)."""
     X = np.ascontiguousarray(X, np.float32)
@@ -308,9 +308,9 @@ def decode(model: "Model", X: np.ndarray, net: dict, genBeam=1.0e10, wordBeam=1.
     kind, mdl, pp, lo, ld, ll = i32(net["kind"]), i32(net["model"]), f32(net["pronProb"]), i32(net["linkOff"]), i32(net["linkDest"]), f32(net["linkLike"])
     wp = np.zeros(maxWords, np.int32); ws = np.zeros(maxWords, np.int32); we = np.zeros(maxWords, np.int32); sc = np.zeros(maxWords, np.float32)
     tot = C.c_double(0.0)
-    n = lib().orc_decode(C.byref(model.c), _p(X), C.c_int(X.shape[0]), C.c_int(len(kind)), _p(kind), _p(mdl), _p(pp), _p(lo), _p(ld), _p(ll),
-                         C.c_int(int(net["initial"])), C.c_int(int(net["final"])), C.c_float(genBeam), C.c_float(wordBeam), C.c_float(lmScale),
-                         C.c_float(wordPen), C.c_float(prScale), C.c_int(maxWords), _p(wp), _p(ws), _p(we), _p(sc), C.byref(tot))
+    n = lib().orc_decode_u(C.byref(model.c), _p(X), C.c_int(X.shape[0]), C.c_int(len(kind)), _p(kind), _p(mdl), _p(pp), _p(lo), _p(ld), _p(ll),
+                           C.c_int(int(net["initial"])), C.c_int(int(net["final"])), C.c_float(genBeam), C.c_float(wordBeam), C.c_float(lmScale),
+                           C.c_float(wordPen), C.c_float(prScale), C.c_int(int(maxActive)), C.c_int(maxWords), _p(wp), _p(ws), _p(we), _p(sc), C.byref(tot))
     if n < 0:
         if n == -1:
             return None, tot.value

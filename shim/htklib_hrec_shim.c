@@ -284,7 +284,7 @@ Lattice *__wrap_CompleteRecognition(VRecInfo *vri, HTime frameDur, MemHeap *heap
    if (!(cfg.genBeam > 0) || cfg.genBeam > 1.0e10f) cfg.genBeam = 1.0e10f;
    if (!(cfg.wordBeam > 0) || cfg.wordBeam > 1.0e10f) cfg.wordBeam = 1.0e10f;
    cfg.lmScale = S.scale; cfg.wordPen = S.wordpen; cfg.prScale = S.pscale; cfg.scoreMode = HTKAMD_SCORE_EXACT;
-   if (vri->maxBeam > 0) HError(7399, "CompleteRecognition: maximum-model pruning (-u) is not supported by the shim");
+   cfg.maxActive = vri->maxBeam > 0 ? vri->maxBeam : 0;      /* HVite -u */
    memset(&out, 0, sizeof(out));
    out.nWords = &nW; out.wordPron = wPron; out.wordStart = wStart; out.wordEnd = wEnd; out.wordScore = wScore; out.wordLm = wLm; out.wordAc = wAc;
    out.wordLike = wLike; out.total = &total; out.finalLm = &finalLm;

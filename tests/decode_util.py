@@ -24,9 +24,9 @@ def parse_opts(opts: str) -> dict:
         del t[t.index("-b"):t.index("-b") + 2]
     t = [x for x in t if x != "-m"]
     p = dict(genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0)
-    key = {"-t": "genBeam", "-v": "wordBeam", "-s": "lmScale", "-p": "wordPen", "-r": "prScale"}
+    key = {"-t": "genBeam", "-v": "wordBeam", "-s": "lmScale", "-p": "wordPen", "-r": "prScale", "-u": "maxActive"}
     for i in range(0, len(t), 2):
-        p[key[t[i]]] = float(t[i + 1])
+        p[key[t[i]]] = int(t[i + 1]) if t[i] == "-u" else float(t[i + 1])
     return p
 
 

@@ -102,6 +102,9 @@ def fuzz_decode(rng, it, tmp):
     if p["genBeam"] < 1e9: opts += ["-t", "%.2f" % p["genBeam"]]
     if p["wordBeam"] < 1e9: opts += ["-v", "%.2f" % p["wordBeam"]]
     opts += ["-s", "%.2f" % p["lmScale"], "-p", "%.2f" % p["wordPen"], "-r", "%.2f" % p["prScale"]]
+    if rng.random() < 0.35:                                      # maximum-model pruning (HRec.c:1966-1985)
+        p["maxActive"] = int(rng.integers(2, 25))
+        opts += ["-u", str(p["maxActive"])]
     mlf = os.path.join(d, "out.mlf")
     r = subprocess.run([os.path.join(REF, "HVite"), "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-S", os.path.join(d, "scp"), "-i", mlf,
                         "-w", os.path.join(d, "net.slf")] + opts + [os.path.join(d, "dict"), os.path.join(d, "hmmlist")], capture_output=True, text=True)

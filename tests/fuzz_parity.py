@@ -179,6 +179,8 @@ def fuzz_decode(rng, it, tmp):
     net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
     p = dict(genBeam=float(rng.choice([1.0e10, rng.uniform(20, 200)])), wordBeam=float(rng.choice([1.0e10, rng.uniform(10, 100)])),
              lmScale=float(rng.choice([1.0, rng.uniform(0.5, 8)])), wordPen=float(rng.choice([0.0, rng.uniform(-20, 10)])), prScale=float(rng.choice([1.0, rng.uniform(0.5, 3)])))
+    if rng.random() < 0.3:
+        p["maxActive"] = int(rng.integers(2, 30))                     # HVite -u
     model = capi.Model(mmf.packed()); om = pyoracle.Model(mmf.packed())
     res = capi.Decoder(model, net, lmScale=p["lmScale"]).run(s.feats, **p)
     ok = True

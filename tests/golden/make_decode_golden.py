@@ -132,7 +132,7 @@ def main():
             alt = prons[w]
             ph += alt[int(rng.integers(0, len(alt)))]
         feats.append(sample(pk, ph, rng))
-    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -s 5.0 -p -10.0", "-t 60.0 -v 30.0 -s 2.0 -p 3.0 -r 2.0", "-m -t 250.0 -s 5.0 -p -10.0", "-t 250.0 -r 2.25", "-v 25.0 -r 1.37"], 9, "")
+    run_hvite(d, feats, ["-t 250.0", "-t 250.0 -s 5.0 -p -10.0", "-t 60.0 -v 30.0 -s 2.0 -p 3.0 -r 2.0", "-m -t 250.0 -s 5.0 -p -10.0", "-t 250.0 -r 2.25", "-v 25.0 -r 1.37", "-u 6 -t 250.0", "-u 3 -s 2.0"], 9, "")
     # ---------------------------------------------------------------- tee
     d = os.path.join(OUT, "tee"); os.makedirs(d, exist_ok=True)
     pk2, tnames, _, _ = synth.make_topo_set(seed=33, D=13, NU=1)
@@ -155,7 +155,7 @@ def main():
                     continue                                                    # pause skipped
                 ph.append(idx[p])
         feats.append(sample(pk2, ph, rng, frames_per_state=3))
-    run_hvite(d, feats, ["-t 250.0", "-t 40.0", "-v 20.0 -p -19.0", "-t 250.0 -v 40.0 -r 2.0", "-v 20.0 -p -21.0"], 9, "")
+    run_hvite(d, feats, ["-t 250.0", "-t 40.0", "-v 20.0 -p -19.0", "-t 250.0 -v 40.0 -r 2.0", "-v 20.0 -p -21.0", "-u 5", "-u 9 -t 250.0 -v 40.0"], 9, "")
     # ---------------------------------------------------------------- wint: word-internal triphones
     d = os.path.join(OUT, "wint"); os.makedirs(d, exist_ok=True)
     synth.write_mmf(os.path.join(d, "MMF"), s, kind="USER")

@@ -11,7 +11,7 @@
  *   -i mlf       write one master label file                    -l dir / -y ext            or one label file per input (default .rec)
  *   -m           model-level labels                             -f            state-level labels (implies model level as auxiliary)
  *   -o chars     output format S W T N X C M (HVite -o)
- *   -t f         general beam (0 = off)                         -v f          word-end beam
+ *   -t f         general beam (0 = off)                         -v f          word-end beam           -u N   maximum active models (0 = off)
  *   -s f         grammar scale (1.0)    -p f   word insertion penalty (0.0)    -r f   pronunciation scale (1.0)
  *   -T N         trace (1: one line per file)
  * Beyond the reference:  --score exact|fast|fastest (default exact: paths and scores are the reference's bit for bit),  --batch N.
@@ -98,7 +98,7 @@ int main(int argc, char **argv)
    strlist mmfs = {0}, files = {0};
    const char *hmmDir = NULL, *hmmExt = NULL, *netPath = NULL, *labDir = NULL, *labExt = "lab", *mlfIn = NULL, *mlfOut = NULL, *outDir = NULL, *outExt = "rec", *boundary = NULL;
    float genBeam = 0.0f, wordBeam = 0.0f, lmScale = 1.0f, wordPen = 0.0f, prScale = 1.0f;
-   int align = 0, models = 0, states = 0, oflags = 0, trace = 0, scoreMode = HTKAMD_SCORE_EXACT, batchN = 1024;
+   int align = 0, models = 0, states = 0, oflags = 0, trace = 0, scoreMode = HTKAMD_SCORE_EXACT, batchN = 1024, maxActive = 0;
    const char *sw;
 
    while (a.at < a.argc && is_switch(a.argv[a.at])) {
@@ -141,6 +141,7 @@ int main(int argc, char **argv)
       case 's': lmScale = (float)flt_arg(&a, sw); break;
       case 'p': wordPen = (float)flt_arg(&a, sw); break;
       case 'r': prScale = (float)flt_arg(&a, sw); break;
+      case 'u': maxActive = atoi(str_arg(&a, sw)); break;
       case 'T': trace = atoi(str_arg(&a, sw)); break;
       default: DIE("hvite: unknown switch -%s", sw);
       }
@@ -167,7 +168,7 @@ int main(int argc, char **argv)
    htkamd_mlf_out *mout = NULL; if (mlfOut) CHECK(htkamd_mlf_out_open(mlfOut, &mout));
    htkamd_decode_config dc; memset(&dc, 0, sizeof(dc));
    dc.genBeam = genBeam > 0 ? genBeam : 1.0e10f; dc.wordBeam = wordBeam > 0 ? wordBeam : 1.0e10f;
-   dc.lmScale = lmScale; dc.wordPen = wordPen; dc.prScale = prScale; dc.scoreMode = scoreMode;
+   dc.lmScale = lmScale; dc.wordPen = wordPen; dc.prScale = prScale; dc.scoreMode = scoreMode; dc.maxActive = maxActive;
    const int maxWords = 4096;
 
    for (int first = 0; first < files.n; first += (align ? 1 : batchN)) {

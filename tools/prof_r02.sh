@@ -15,5 +15,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $out/pmc_SQ -o $tag --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 1 --warmup 0 > $out/bench_pmc_SQ.json 2> $out/rocprof_SQ.log
 python3 bench.py > $out/bench.json 2> $out/bench.err
-python3 tools/prof_summarise.py $out $tag
+# summaries: run `python tools/prof_summarise.py gpurun_out/<tag> <tag>` in the repository afterwards (profiles/ on the box is not copied back)
 tail -c 600 $out/bench.json
