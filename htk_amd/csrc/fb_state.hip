@@ -28,7 +28,7 @@
 #include "wavegrp.h"
 
 #define EXPFLOOR (-100.0)
-#define SPAD 4                        // padding lanes on both sides of the exchange arrays (offsets reach -3..+3)
+#define SPAD 8                        // padding lanes on both sides of the exchange arrays (offsets reach -5..+5)
 
 typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -99,14 +99,37 @@ struct ObsRow {
 #define BETA_S(t) (a.betaW[ud.betaW0 + (size_t)((t) - 1) * L + gl])
 #define BETA_E(t) (a.betaW[ud.betaW0 + (size_t)T * L + (size_t)((t) - 1) * L + gl])
 
+// Transitions of the models on either side of this lane's model, read straight from the batch tables: a lane derives its model's
+// entry value (alpha: the exit value of the model before it) and exit value (beta: the entry value of the model after it) from the
+// neighbour model's published state values itself, so a step needs ONE exchange instead of a second round trip through the lanes
+// that own those values.
+__device__ __forceinline__ void load_neighbours(float aExitPrev[3], float aEntryNext[3], const FbArgs &a, const UttDesc &ud, const StateRegs &s, bool valid)
+{
+#pragma unroll
+   for (int k = 0; k < 3; k++) { aExitPrev[k] = (float)LZERO; aEntryNext[k] = (float)LZERO; }
+   if (!valid) return;
+   if (s.q > 1) {
+      const int mi = s.mi - 1, N = a.mN[mi];
+      const float *tp = a.transP + a.mTp[mi];
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (N - 1 - k >= 2) aExitPrev[k] = tp[(N - 1 - k - 1) * N + (N - 1)];
+   }
+   if (s.q < ud.Q) {
+      const int mi = s.mi + 1, N = a.mN[mi];
+      const float *tp = a.transP + a.mTp[mi];
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (2 + k <= N - 1) aEntryNext[k] = tp[2 + k - 1];
+   }
+}
+
 // ------------------------------------------------------------------------------------ K2s: beta
 template <int W, bool FAST>
 __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
 {
-   constexpr int L = 64 * W;
+   constexpr int L = 64 * W, LP = L + 2 * SPAD;
    __shared__ double ltab[FAST ? 1 : LADD_TAB_DOUBLES];
-   __shared__ double xb[4][L + 2 * SPAD];              // 0: beta_j(t+1)  1: entry values of t+1  2: beta_j(t)  3: b_j (as double) of t+1 / t
-   __shared__ double xo[L + 2 * SPAD];
+   __shared__ double xbeta[2][LP];                     // beta_j of the column just computed, by step parity
+   __shared__ double xobs[2][LP];                      // b_j of that column
    __shared__ float stage[W][2 * 64 * 4];
    __shared__ unsigned long long gx[2 * W * 4];
    __shared__ float ga1[64 * W];
@@ -127,18 +150,19 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
    const bool valid = gl < nS;
    StateRegs s;
    load_state(s, a, ud, gl, valid);
-   for (int i = gl; i < 2 * SPAD + L; i += L) { xb[0][i] = LZERO; xb[1][i] = LZERO; xb[2][i] = LZERO; xb[3][i] = 0.0; xo[i] = 0.0; }
+   float aExitPrev[3], aEntryNext[3];
+   load_neighbours(aExitPrev, aEntryNext, a, ud, s, valid);
+   for (int i = gl; i < LP; i += L) { xbeta[0][i] = LZERO; xbeta[1][i] = LZERO; xobs[0][i] = 0.0; xobs[1][i] = 0.0; }
    sqOf[gl] = (short)(valid ? s.q : Q + 1);
    if (valid && s.first) flOf[s.q] = (short)gl;
    if (gl == 0) { flOf[Q + 1] = (short)nS; flOf[0] = 0; }
    __syncthreads();
-   Xc<W> X0{xb[0], gl}, X1{xb[1], gl}, X2{xb[2], gl}, XO{xo, gl};
    // which neighbour offsets any state of the utterance uses (wave-uniform: unused ones cost nothing)
    bool useOut[5], useEnt[3];
 #pragma unroll
    for (int d = 0; d < 5; d++) useOut[d] = g.ballot(valid && s.aOut[d] > (float)LSMALL).highest() >= 0;
 #pragma unroll
-   for (int k = 0; k < 3; k++) useEnt[k] = g.ballot(valid && s.first && 2 + k <= s.N - 1).highest() >= 0;
+   for (int k = 0; k < 3; k++) useEnt[k] = g.ballot(valid && ((s.first && s.aEntryOf[k] > (float)LSMALL) || aEntryNext[k] > (float)LSMALL)).highest() >= 0;
    const int q = s.q, N = s.N, j = s.j;
    const int offNext = N - j;                          // lane of the next model's first state = gl + offNext
    const short *tLo = a.taperLo + ud.frame0 - 1, *tHi = a.taperHi + ud.frame0 - 1;   // 1-based t
@@ -149,13 +173,42 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
    const double mle = a.minLogExp;
    const bool pruning = a.pruneInit < HTKAMD_NOPRUNE;
 #define ladd(x, y) ladd_sel<FAST>((x), (y), mle, ltab)
+   // everything a step needs of the column before it, read in ONE pass after the single exchange of a step:
+   //   ySucc/oSucc[d]  beta and score of the own model's states j+d-2        bE   beta_1 of the own model (first lane; also lMax)
+   //   bEn             beta_1 of the NEXT model = this model's exit value of the step to come
+#define BETA_GATHER(par, wantOwn)                                                                                                   \
+   do {                                                                                                                           \
+      const double *xb_ = xbeta[par] + SPAD + gl, *xo_ = xobs[par] + SPAD + gl;                                                    \
+      _Pragma("unroll") for (int d = 0; d < 5; d++) if (useOut[d]) { ySucc[d] = xb_[d - 2]; oSucc[d] = xo_[d - 2]; }              \
+      double x_ = LZERO;                                                                                                          \
+      _Pragma("unroll") for (int k = 0; k < 3; k++)                                                                               \
+         if (useEnt[k]) {                                                                                                         \
+            const double aa = aEntryNext[k], y = xb_[offNext + k];                                                                \
+            if (aa > LSMALL && y > LSMALL) x_ = ladd(x_, aa + xo_[offNext + k] + y);                                              \
+         }                                                                                                                        \
+      bEn = x_;                                                                                                                   \
+      lMax = LZERO;                                                                                                               \
+      if ((wantOwn) && s.first) {                                                                                                 \
+         x_ = LZERO;                                                                                                              \
+         _Pragma("unroll") for (int k = 0; k < 3; k++)                                                                            \
+            if (2 + k <= N - 1) {                                                                                                 \
+               const double aa = s.aEntryOf[k], y = xb_[k];                                                                       \
+               if (y > lMax) lMax = y;                                                                                            \
+               if (aa > LSMALL && y > LSMALL) x_ = ladd(x_, aa + xo_[k] + y);                                                     \
+            }                                                                                                                     \
+         bE = x_;                                                                                                                 \
+      }                                                                                                                           \
+   } while (0)
 
    double thresh = a.pruneInit, pr = LZERO;
    int ok = 0;
    for (;;) {                                            // StepBack retry loop (HFB.c:1332-1361)
       int fail = 0;
-      double bJ = LZERO, bE = LZERO;                     // beta_j(t) of this state; beta_1(q,t) in the model's first lane
-      float obT = 0.f, ob1 = 0.f, obP = 0.f;             // b_j(t), b_j(t+1), b_j(t-1)
+      double bJ = LZERO, bE = LZERO, bEn = LZERO, lMax = LZERO;   // beta_j(t); beta_1(q,t) (first lane); beta_1(q+1,t); max_j beta_j(t)
+      double ySucc[5]; float obT = 0.f, obP = 0.f;
+      double oSucc[5];
+#pragma unroll
+      for (int d = 0; d < 5; d++) { ySucc[d] = LZERO; oSucc[d] = 0.0; }
       // ---- t = T (HFB.c:1175-1198): only the last model can end the utterance (no tee models in this path)
       const int endT = tLo[T];
       {
@@ -174,18 +227,9 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
          double mine = 0.0;
          for (int k = Q; k > q && k > endT; k--) mine += (double)(float)LZERO;
          if (inT) bJ = (double)s.aExit + mine;
-         X2.put(inT ? bJ : LZERO); XO.put((double)obT);
+         xbeta[T & 1][SPAD + gl] = inT ? bJ : LZERO; xobs[T & 1][SPAD + gl] = (double)obT;
          xsync<W>();
-         if (inT && s.first) {
-            double x = LZERO;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-               if (useEnt[k] && 2 + k <= N - 1) {
-                  const double aa = s.aEntryOf[k], y = X2.at(k);
-                  if (aa > LSMALL && y > LSMALL) x = ladd(x, aa + XO.at(k) + y);
-               }
-            bE = x;
-         }
+         BETA_GATHER(T & 1, inT);
          if (inT) { BETA_S(T) = bJ; if (s.first) BETA_E(T) = bE; }
       }
       if (gl == 0) { gLo[T] = (short)endT; gHi[T] = (short)Q; }
@@ -198,51 +242,36 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
          const int taperLoT = nxtLo, taperHiT = nxtHi;
          if (t >= 2) { nxtLo = tLo[t - 1]; nxtHi = tHi[t - 1]; }
          if (t >= 2 && ((t - 2) & 3) == 3) { st.park((t - 2) >> 2); if (((t - 2) >> 2) >= 1) st.load(((t - 2) >> 2) - 1); }
-         const double bJ1 = bJ, bE1 = bE;                // column t+1
          if (stPrev) {                                   // the column finished in the previous iteration goes out now
-            if (stIn) { BETA_S(tPrev) = bJ1; if (s.first) BETA_E(tPrev) = bE1; }
+            if (stIn) { BETA_S(tPrev) = bJ; if (s.first) BETA_E(tPrev) = bE; }
             if (gl == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; }
             stPrev = false;
          }
-         ob1 = obT; obT = obP;
+         obT = obP;
          if (t >= 2) obP = st.get(t - 2);
          const int startq = qHiN;
          const int endq = (qLoN == 1) ? 1 : ((taperLoT >= qLoN) ? taperLoT : qLoN - 1);
          const bool inRange = valid && q >= endq && q <= startq;
          const bool wasIn = q >= qLoN && q <= qHiN;
-         // exchange 1: the previous column
-         X0.put(wasIn && valid ? bJ1 : LZERO); X1.put((s.first && wasIn && valid) ? bE1 : LZERO); XO.put((double)ob1);
-         xsync<W>();
          if (inRange) {
             const bool p1 = (q < Q) && (q + 1 >= qLoN) && (q + 1 <= qHiN);
-            const double ex = p1 ? X1.at(offNext) : LZERO;       // beta_N(q,t) = beta_1(q+1,t+1)
+            const double ex = p1 ? bEn : LZERO;                  // beta_N(q,t) = beta_1(q+1,t+1)
             double x = (double)s.aExit + ex;
             if (wasIn) {
 #pragma unroll
                for (int d = 0; d < 5; d++)
                   if (useOut[d]) {
-                     const double aa = s.aOut[d], y = X0.at(d - 2);
-                     if (aa > LSMALL && y > LSMALL) x = ladd(x, aa + XO.at(d - 2) + y);
+                     const double aa = s.aOut[d], y = ySucc[d];
+                     if (aa > LSMALL && y > LSMALL) x = ladd(x, aa + oSucc[d] + y);
                   }
             }
             bJ = x;
          }
-         // exchange 2: the new column, for the entry states and the beam (its barrier also separates this step's reads of the
-         // first exchange from the next step's writes)
-         X2.put(inRange ? bJ : LZERO); xb[3][SPAD + gl] = (double)obT;
+         // the one exchange of the step: publish the new column (buffers alternate with the step's parity, so the writes of this
+         // step never meet the reads of the step before), gather everything the next step needs of it
+         xbeta[t & 1][SPAD + gl] = inRange ? bJ : LZERO; xobs[t & 1][SPAD + gl] = (double)obT;
          xsync<W>();
-         double lMax = LZERO;
-         if (inRange && s.first) {
-            double x = LZERO;
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-               if (2 + k <= N - 1) {
-                  const double aa = s.aEntryOf[k], y = X2.at(k);
-                  if (y > lMax) lMax = y;
-                  if (aa > LSMALL && y > LSMALL) x = ladd(x, aa + xb[3][SPAD + gl + k] + y);
-               }
-            bE = x;
-         }
+         BETA_GATHER(t & 1, inRange);
          int newHi, newLo;
          if (!pruning) {                                 // only the taper acts (HFB.c:1259-1264)
             newHi = (taperHiT < startq) ? taperHiT : startq;
@@ -276,12 +305,13 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
       }
       thresh += a.pruneInc;
       if (thresh > a.pruneLim || a.pruneInc == 0.0) break;
-      xsync<W>();
+      __syncthreads();
    }
    if (gl == 0) {
       a.pr[u] = ok ? pr : LZERO;
       a.status[u] = ok ? HTKAMD_UTT_OK : HTKAMD_UTT_SKIPPED;
    }
+#undef BETA_GATHER
 #undef ladd
 }
 
@@ -289,10 +319,12 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
 template <int W, bool FAST>
 __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
 {
-   constexpr int L = 64 * W;
+   constexpr int L = 64 * W, LP = L + 2 * SPAD;
    __shared__ double ltab[FAST ? 1 : LADD_TAB_DOUBLES];
    __shared__ double etab[FAST ? 1 : EXP_TAB_N];
-   __shared__ double xb[6][L + 2 * SPAD];              // 0: alpha_j(t-1)  1: exit values of t-1  2: alpha_j(t)  3: alpha+beta of t  4: b+beta of t+1  5: exit sums of t
+   __shared__ double xalpha[2][LP];                    // alpha_j(t) by step parity
+   __shared__ double xsum[2][LP];                      // alpha_j(t) + beta_j(t) inside the beta beam (MaxModelProb)
+   __shared__ double xnext[2][LP];                     // b_j(t+1) + beta_j(t+1) inside the beam of t+1 (transition counts)
    __shared__ float stage[W][2 * 64 * 4];
    __shared__ unsigned long long gx[2 * W * 4];
    __shared__ float ga1[64 * W];
@@ -313,20 +345,22 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
    const bool valid = gl < nS;
    StateRegs s;
    load_state(s, a, ud, gl, valid);
-   for (int i = gl; i < 2 * SPAD + L; i += L) {
+   float aExitPrev[3], aEntryNext[3];
+   load_neighbours(aExitPrev, aEntryNext, a, ud, s, valid);
+   for (int i = gl; i < LP; i += L) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) xb[k][i] = LZERO;
+      for (int k = 0; k < 2; k++) { xalpha[k][i] = LZERO; xsum[k][i] = LZERO; xnext[k][i] = LZERO; }
    }
    sqOf[gl] = (short)(valid ? s.q : Q + 1);
    if (valid && s.first) flOf[s.q] = (short)gl;
    if (gl == 0) { flOf[Q + 1] = (short)nS; flOf[0] = 0; }
    __syncthreads();
-   Xc<W> XA{xb[0], gl}, XX{xb[1], gl}, XN{xb[2], gl}, XS{xb[3], gl}, XY{xb[4], gl}, XE{xb[5], gl};
-   bool useIn[5], useExit[3], useOut[5];
+   bool useIn[5], useExitP[3], useOut[5];
 #pragma unroll
    for (int d = 0; d < 5; d++) { useIn[d] = g.ballot(valid && s.aIn[d] > (float)LSMALL).highest() >= 0; useOut[d] = g.ballot(valid && s.aOut[d] > (float)LSMALL).highest() >= 0; }
 #pragma unroll
-   for (int k = 0; k < 3; k++) useExit[k] = g.ballot(valid && s.last && s.aExitOf[k] > (float)LSMALL).highest() >= 0;
+   for (int k = 0; k < 3; k++) useExitP[k] = g.ballot(valid && (aExitPrev[k] > (float)LSMALL || (s.last && s.aExitOf[k] > (float)LSMALL))).highest() >= 0;
+   const MaskW<W> firsts = g.ballot(valid && s.first);   // loop-invariant: one bit per model, at its first lane
    const int q = s.q, N = s.N, j = s.j;
    const int offNext = N - j, offPrev = -(j - 1);       // first lane of the next model / last lane of the previous model
    const int cHmm = valid ? a.mHmm[s.mi] : 0, cTrans = valid ? a.mTrans[s.mi] : 0, mc0 = valid ? a.mCell0[s.mi] : 0;
@@ -338,6 +372,9 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
    st.lds = stage[wv]; st.lane = lane; st.R = (f4s)(0.f);
    st.row = valid ? a.outp + ud.outp0 + (size_t)gl * T : nullptr;
    double *gam = a.gam + ud.gam0 + gl;
+   // beta_1 of the NEXT model (its first lane's column of betaE): every lane of a model reads the same word
+   const double *bNextE = a.betaW + ud.betaW0 + (size_t)T * L + (gl + offNext);
+   const bool hasNext = valid && q < Q;
    const double mle = a.minLogExp, pr = a.pr[u];
    const double minF = (double)a.minFrwdP;
    const bool wantMix = (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) != 0;
@@ -345,18 +382,19 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
 #define ladd(x, y) ladd_sel<FAST>((x), (y), mle, ltab)
 #define EXPT(x) exp_sel<FAST>((x), etab)
 
-   double aJ = LZERO, aE = LZERO, aX = LZERO;            // alpha_j(t); alpha_1(q,t) (every lane of the model); alpha_N(q,t) (last lane)
+   double aJ = LZERO, aE = LZERO, aEnext = LZERO;        // alpha_j(t); alpha_1(q,t); alpha_1(q,t+1) = exit value of the model before, column t
+   double yIn[5];                                        // alpha of the own model's states j+d-2 in the column before
    double xpre = LZERO;
    double taOut[5], taExit = 0.0, taEntry = 0.0, occJ = 0.0, occE = 0.0;
 #pragma unroll
-   for (int d = 0; d < 5; d++) taOut[d] = 0.0;
+   for (int d = 0; d < 5; d++) { taOut[d] = 0.0; yIn[d] = LZERO; }
    // beta / scores / beams of frames t, t+1 and (in flight) t+2
-   double bT = LZERO, bT1 = LZERO, bT2 = LZERO, eT = LZERO, eT1 = LZERO, eT2 = LZERO;
+   double bT = LZERO, bT1 = LZERO, bT2 = LZERO, eT = LZERO, eT1 = LZERO, eT2 = LZERO, nT1 = LZERO, nT2 = LZERO;   // nT1 = beta_1(q+1,t+1)
    float oT = 0.f, oT1 = 0.f;
    int lo0 = 1, hi0 = 0, lo1 = gLo[1], hi1 = gHi[1], lo2 = (T >= 2) ? gLo[2] : 1, hi2 = (T >= 2) ? gHi[2] : 0, lo3 = 1, hi3 = 0;
    if (valid) {
       bT = BETA_S(1); if (s.first) eT = BETA_E(1);
-      if (T >= 2) { bT1 = BETA_S(2); if (s.first) eT1 = BETA_E(2); }
+      if (T >= 2) { bT1 = BETA_S(2); if (s.first) eT1 = BETA_E(2); if (hasNext) nT1 = bNextE[(size_t)1 * L]; }
    }
    st.load(0); st.park(0);
    if (T > 4) st.load(1);
@@ -364,58 +402,43 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
    int sq = 1, eq = hi1, err = 0;
    double mmpA = LZERO;                                  // MaxModelProb of this model in the column just finished (first lane)
 
-   // ---- t = 1: InitAlpha (HFB.c:616-651): without tee models only the first model starts
-   {
-      double a1 = 0.0;
-      for (int k = 2; k <= q && k <= eq; k++) a1 += (double)(float)LZERO;
-      if (valid && q <= eq) {
-         aE = a1;
-         const double aa = s.aEntry;
-         xpre = aE + aa;
-         aJ = (aa > LSMALL) ? xpre + (double)oT : LZERO;
-      }
-      XN.put((valid && q <= eq) ? aJ : LZERO);
-      xsync<W>();
-      if (valid && q <= eq && s.last) {
-         double x = LZERO;
-#pragma unroll
-         for (int k = 2; k >= 0; k--)
-            if (useExit[k] && N - 1 - k >= 2) {
-               const double aa = s.aExitOf[k];
-               if (aa > LSMALL) x = ladd(x, XN.at(-k) + aa);
-            }
-         aX = x;
-      }
-   }
-
    for (int t = 1; t <= T; t++) {
       // request column t+2
       if (t + 2 <= T) {
          lo3 = gLo[t + 2]; hi3 = gHi[t + 2];
-         if (valid) { bT2 = BETA_S(t + 2); if (s.first) eT2 = BETA_E(t + 2); }
+         if (valid) { bT2 = BETA_S(t + 2); if (s.first) eT2 = BETA_E(t + 2); if (hasNext) nT2 = bNextE[(size_t)(t + 1) * L]; }
       }
-      if (t > 1) {
+      bool in;
+      if (t == 1) {
+         // ---- InitAlpha (HFB.c:616-651): without tee models only the first model starts
+         double a1 = 0.0;
+         for (int k = 2; k <= q && k <= eq; k++) a1 += (double)(float)LZERO;
+         in = valid && q <= eq;
+         if (in) {
+            aE = a1;
+            const double aa = s.aEntry;
+            xpre = aE + aa;
+            aJ = (aa > LSMALL) ? xpre + (double)oT : LZERO;
+         }
+      } else {
          // ---- alpha beam (HFB.c:699-722) from MaxModelProb of column t-1: one bit per model at its first lane
-         const MaskW<W> pruneA = g.ballot(valid && s.first && (pr - mmpA > minF));
-         const MaskW<W> firsts = g.ballot(valid && s.first);
+         const MaskW<W> kept = firsts & ~g.ballot(valid && s.first && (pr - mmpA > minF));
          // first model >= qLo[t-1] that is kept; running past the chain "keeps" (mirrors the reference's scan)
-         const int slane = (firsts & ~pruneA & MaskW<W>::range(flOf[lo0], L - 1)).lowest();
+         const int slane = (kept & MaskW<W>::range(flOf[lo0], L - 1)).lowest();
          int sN = (slane >= 0) ? sqOf[slane] : Q + 1;
          if (sN < 1 || sN > hi1) { err = 1; break; }
          if (sN < lo1) sN = lo1;
          int e = (hi0 < Q) ? hi0 + 1 : hi0;
-         const int elane = (firsts & ~pruneA & MaskW<W>::range(0, flOf[e + 1] - 1)).highest();
+         const int elane = (kept & MaskW<W>::range(0, flOf[e + 1] - 1)).highest();
          e = (elane >= 0) ? sqOf[elane] : 0;
          if (e < 1 || e < sN) { err = 1; break; }
          if (e > hi1) e = hi1;
          sq = sN; eq = e;
-         // ---- alpha column t (HFB.c:729-771)
-         XA.put(valid ? aJ : LZERO); XX.put((valid && s.last) ? aX : LZERO);
-         xsync<W>();
-         const bool in = valid && q >= sq && q <= eq;
-         if (valid && !in) { aJ = LZERO; aE = LZERO; aX = LZERO; }
+         // ---- alpha column t (HFB.c:729-771) from the values gathered after the previous step's exchange
+         in = valid && q >= sq && q <= eq;
+         if (valid && !in) { aJ = LZERO; aE = LZERO; }
          if (in) {
-            const double a1 = (q == 1) ? LZERO : XX.at(offPrev);      // alpha_1(q,t) = alpha_N(q-1,t-1)
+            const double a1 = (q == 1) ? LZERO : aEnext;             // alpha_1(q,t) = alpha_N(q-1,t-1)
             aE = a1;
             double aa = s.aEntry;
             double x = (aa > LSMALL) ? aa + a1 : LZERO;
@@ -423,55 +446,71 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
             for (int d = 0; d < 5; d++)
                if (useIn[d]) {
                   aa = s.aIn[d];
-                  const double y = XA.at(d - 2);
+                  const double y = yIn[d];
                   if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa);
                }
             xpre = x;
             aJ = x + (double)oT;
          }
-         XN.put(in ? aJ : LZERO);
-         xsync<W>();
-         if (in && s.last) {
-            double x = LZERO;
-#pragma unroll
-            for (int k = 2; k >= 0; k--)
-               if (useExit[k] && N - 1 - k >= 2) {
-                  const double aa = s.aExitOf[k], y = XN.at(-k);
-                  if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa);
-               }
-            aX = x;
-         }
       }
       if (gl == 0) { gaLo[t] = (short)sq; gaHi[t] = (short)eq; }
+
+      // ---- the one exchange of the step: alpha_j(t), alpha_j + beta_j (MaxModelProb), b_j + beta_j of t+1 (transition counts)
+      const bool inB = valid && q >= lo1 && q <= hi1;    // in the beta beam of t
+      const bool inBeam = valid && q >= sq && q <= eq;
+      const bool bqt1ok = (t < T) && q >= lo2 && q <= hi2;
+      const int par = t & 1;
+      xalpha[par][SPAD + gl] = in ? aJ : LZERO;
+      xsum[par][SPAD + gl] = inB ? aJ + bT : LZERO;
+      xnext[par][SPAD + gl] = bqt1ok ? (double)oT1 + bT1 : LZERO;
+      xsync<W>();
+      const double *xa = xalpha[par] + SPAD + gl;
+      // own model's states for the next column
+#pragma unroll
+      for (int d = 0; d < 5; d++) if (useIn[d]) yIn[d] = xa[d - 2];
+      // exit value of the model BEFORE this one in column t (HFB.c:762-769 there): alpha_1 of this model in column t+1
+      double aXp = LZERO;
+      if (valid && q > 1) {
+#pragma unroll
+         for (int k = 2; k >= 0; k--)
+            if (useExitP[k]) {
+               const double aa = aExitPrev[k], y = xa[offPrev - k];
+               if (aa > LSMALL && y > LSMALL) aXp = ladd(aXp, y + aa);
+            }
+      }
       if (a.alphaDbg && valid) {
          double *ad = a.alphaDbg + ud.beta0 + (size_t)(t - 1) * nC + mc0;
          ad[j - 1] = aJ;
          if (s.first) ad[0] = aE;
-         if (s.last) ad[N - 1] = aX;
-      }
-
-      // ---- statistics for column t (HFB.c:1790-1806) and MaxModelProb of column t
-      const bool inB = valid && q >= lo1 && q <= hi1;    // in the beta beam of t
-      const bool inBeam = valid && q >= sq && q <= eq;
-      const bool bqt1ok = (t < T) && q >= lo2 && q <= hi2;
-      // beta_N(q,t): 0 for the last model at T, else beta_1(q+1,t+1) where that is in the beam of t+1
-      XX.put((valid && s.first && t < T && q >= lo2 && q <= hi2) ? eT1 : LZERO);      // entry values of t+1 (exchange array 1 is free here)
-      XS.put(inB ? aJ + bT : LZERO);
-      XY.put(bqt1ok ? (double)oT1 + bT1 : LZERO);
-      xsync<W>();
-      double bN = LZERO;
-      if (valid) bN = (t == T) ? ((q == Q) ? 0.0 : LZERO) : ((q < Q) ? XX.at(offNext) : LZERO);
-      // exit sum alpha_N + beta_N of the model (last lane), handed to the next model's first lane
-      XE.put((inB && s.last) ? aX + bN : LZERO);
-      double mm = LZERO;
-      if (valid && s.first && inB) {
-         mm = aE + eT;                                   // i = 1
+         if (s.last) {                                   // debugging aid only: this model's own exit value
+            double x = LZERO;
 #pragma unroll
-         for (int k = 0; k < 3; k++) if (2 + k <= N - 1) { const double v = XS.at(k); if (v > mm) mm = v; }
+            for (int k = 2; k >= 0; k--)
+               if (N - 1 - k >= 2) {
+                  const double aa = s.aExitOf[k], y = xa[-k];
+                  if (aa > LSMALL && (t == 1 || y > LSMALL)) x = ladd(x, y + aa);
+               }
+            ad[N - 1] = x;
+         }
       }
-      xsync<W>();
+      // ---- statistics for column t (HFB.c:1790-1806) and MaxModelProb of column t
+      // beta_N(q,t): 0 for the last model at T, else beta_1(q+1,t+1) where that is in the beam of t+1
+      double bN = LZERO;
+      if (valid) bN = (t == T) ? ((q == Q) ? 0.0 : LZERO) : ((hasNext && q + 1 >= lo2 && q + 1 <= hi2) ? nT1 : LZERO);
       if (valid && s.first) {
-         const double prevExit = (q > 1) ? XE.at(-1) : LZERO;        // HFB.c:662-666
+         double mm = LZERO;
+         if (inB) {
+            mm = aE + eT;                                // i = 1
+            const double *xs = xsum[par] + SPAD + gl;
+#pragma unroll
+            for (int k = 0; k < 3; k++) if (2 + k <= N - 1) { const double v = xs[k]; if (v > mm) mm = v; }
+         }
+         // alpha_N + beta_N of the model before (HFB.c:662-666); its beta_N(t) is this model's beta_1(t+1) inside the beam of t+1
+         double prevExit = LZERO;
+         if (q > 1 && q - 1 >= lo1 && q - 1 <= hi1) {
+            const double bNp = (t == T) ? LZERO : ((q >= lo2 && q <= hi2) ? eT1 : LZERO);
+            prevExit = aXp + bNp;
+         }
          mmpA = (prevExit > mm) ? prevExit : mm;
       }
       if (inBeam) {
@@ -486,10 +525,11 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
             x = aE + (double)s.aEntry + (double)oT + bT - pr;
             if (x > EXPFLOOR) taEntry += EXPT(x);
             if (bqt1ok) {
+               const double *xn = xnext[par] + SPAD + gl;
 #pragma unroll
                for (int d = 0; d < 5; d++)
                   if (useOut[d]) {
-                     x = aJ + (double)s.aOut[d] + XY.at(d - 2) - pr;
+                     x = aJ + (double)s.aOut[d] + xn[d - 2] - pr;
                      if (x > EXPFLOOR) taOut[d] += EXPT(x);
                   }
             }
@@ -512,8 +552,9 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
          }
          gam[(size_t)(t - 1) * nS] = seed;
       }
+      aEnext = aXp;
       // rotate: t -> t+1
-      bT = bT1; bT1 = bT2; eT = eT1; eT1 = eT2;
+      bT = bT1; bT1 = bT2; eT = eT1; eT1 = eT2; nT1 = nT2;
       oT = oT1;
       if (t + 2 <= T) {
          const int f = t + 1;                            // frame index (0-based) of t+2

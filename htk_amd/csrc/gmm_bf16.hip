@@ -245,50 +245,52 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
 // ------------------------------------------------------------------------------------ the A-operand table, built on the device
 struct Bf16TabArgs {
    int D, NC, S;
-   const int *stateCompOff, *stateTileOff, *compGauss;
+   const int *stateCompOff, *stateTileOff, *compGauss, *tileState;
    const float *mean, *ivar, *gconst, *compLogWt;
    unsigned short *tab;        // [tile][ 3*NC*64*8 bf16 | 64*4 f32 ]
 };
 
+// one thread per (tile, chunk, lane): its 8 coefficients in three pieces = three 16-byte stores, consecutive lanes to consecutive
+// words; the 16 threads (chunk 0, lane group 0) of a tile also write their component's accumulator start
 __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
 {
-   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-   if (idx >= nTiles * 16) return;
-   const int t = idx >> 4, rowc = idx & 15;            // component = matrix row
-   int lo = 0, hi = a.S - 1;
-   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.stateTileOff[mid] <= t) lo = mid; else hi = mid - 1; }
-   const int s = lo, c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
-   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
    const int NC = a.NC, D = a.D;
+   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+   if (idx >= nTiles * NC * 64) return;
+   const int t = idx / (NC * 64), r = idx - t * (NC * 64), ch = r >> 6, lane = r & 63, rowc = lane & 15, kg = lane >> 4;
+   const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
    const size_t tileShorts = (size_t)3 * NC * 64 * 8 + 64 * 8;      // the f32 part counted in shorts
    unsigned short *T = a.tab + (size_t)t * tileShorts;
-   float *ciBase = (float *)(T + (size_t)3 * NC * 64 * 8);          // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
    const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
-   const float *mu = nullptr, *iv = nullptr;
-   float ci = -1.0e30f;
    const double L2E = 1.4426950408889634;
-   if (live) {
-      const int g = a.compGauss[c];
-      mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D;
-      double k0 = a.gconst[g];
-      for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
-      ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+   const float *mu = nullptr, *iv = nullptr;
+   if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
+   unsigned short p[3][8];
+#pragma unroll
+   for (int j = 0; j < 8; j++) {
+      const int k = 32 * ch + 8 * kg + j, dim = k >> 1;
+      float v = 0.0f;
+      if (live && dim < D) v = (k & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+      split3(v, p[0][j], p[1][j], p[2][j]);
    }
-   for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
-   for (int ch = 0; ch < NC; ch++)
-      for (int kg = 0; kg < 4; kg++) {
-         const int laneA = kg * 16 + rowc;
-         for (int j = 0; j < 8; j++) {
-            const int k = 32 * ch + 8 * kg + j, dim = k >> 1;
-            float v = 0.0f;
-            if (live && dim < D) v = (k & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
-            unsigned short p1, p2, p3;
-            split3(v, p1, p2, p3);
-            T[((size_t)(0 * NC + ch) * 64 + laneA) * 8 + j] = p1;
-            T[((size_t)(1 * NC + ch) * 64 + laneA) * 8 + j] = p2;
-            T[((size_t)(2 * NC + ch) * 64 + laneA) * 8 + j] = p3;
-         }
+#pragma unroll
+   for (int pc = 0; pc < 3; pc++) {
+      u4 w;
+      w[0] = p[pc][0] | ((unsigned int)p[pc][1] << 16); w[1] = p[pc][2] | ((unsigned int)p[pc][3] << 16);
+      w[2] = p[pc][4] | ((unsigned int)p[pc][5] << 16); w[3] = p[pc][6] | ((unsigned int)p[pc][7] << 16);
+      *(u4 *)(T + ((size_t)(pc * NC + ch) * 64 + lane) * 8) = w;
+   }
+   if (ch == 0 && kg == 0) {
+      float ci = -1.0e30f;
+      if (live) {
+         double k0 = a.gconst[a.compGauss[c]];
+         for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
       }
+      float *ciBase = (float *)(T + (size_t)3 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
+      for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
+   }
 }
 
 int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
@@ -296,9 +298,9 @@ int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
    hipStream_t s = (hipStream_t)stream;
    if (!m->d_bf16Tab) return HTKAMD_OK;
    Bf16TabArgs t;
-   t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss;
+   t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss; t.tileState = m->d_tileState;
    t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_bf16Tab;
-   const int n = m->nTiles * 16;
+   const int n = m->nTiles * m->bf16NC * 64;
    hipLaunchKernelGGL(k_build_bf16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;

@@ -186,6 +186,10 @@ int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStrea
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
    if (!m->d_mfmaTab) { htkamd_set_error("score_mfma: vector size %d not supported by the MFMA path (up to 40)", m->D); return HTKAMD_EMODEL; }
+   if (m->mfmaStale) {                             // parameters were re-estimated on the device since the table was built
+      int rcr = htkamd_model_refresh_mfma_device(const_cast<htkamd_model *>(m), stream);
+      if (rcr) return rcr;
+   }
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
    int blocks = a.nTasks;
    if (blocks > 256 * 4) blocks = 256 * 4;      // persistent blocks (4 per CU at <= 128 VGPRs), one task (128 frames x 16 states) at a time

@@ -75,13 +75,16 @@ struct htkamd_model {
    /* MFMA scoring path (gmm_mfma.hip): A-operand fragments [tile][mfmaNS+4][64], 16 components per tile */
    float *d_mfmaTab;           /* NULL when D has no MFMA kernel */
    int   *d_stateTileOff;      /* [S+1] */
+   int   *d_tileState;         /* [nTiles] tied state of every fragment tile */
    int    mfmaNS, nTiles;
+   int    mfmaStale;           /* the fp32 fragment table is older than the parameters (device update): rebuilt on its next use */
    void  *d_bf16Tab;           /* bf16 x 3 scoring path (gmm_bf16.hip): A-operand pieces per tile; NULL when D > 48 */
    int    bf16NC;              /* K chunks of 32 per piece: ceil(2D/32) */
    double minLogExp;
 };
 
 void htkamd_outp_ring_free(void *ring);                      /* gmm_exact.hip */
+int htkamd_model_refresh_mfma_device(struct htkamd_model *m, void *stream);   /* update.hip */
 int htkamd_model_refresh_bf16_device(struct htkamd_model *m, void *stream);   /* gmm_bf16.hip (stream: hipStream_t) */
 int htkamd_model_device_tables(struct htkamd_model *m);      /* model.hip: uploads d_var etc. once */
 int htkamd_model_sync_host(struct htkamd_model *m);          /* model.hip: device -> host parameter copies when stale */

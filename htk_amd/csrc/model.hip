@@ -102,6 +102,12 @@ static int mfma_refresh(htkamd_model *m)
       for (int s = 0; s < m->S; s++) off[s + 1] = off[s] + (m->h_stateCompOff[s + 1] - m->h_stateCompOff[s] + 15) / 16;
       m->nTiles = off[m->S]; m->mfmaNS = NS;
       int rc = toDevice(&m->d_stateTileOff, off, (size_t)m->S + 1);
+      if (!rc) {
+         int *ts = (int *)malloc(sizeof(int) * (size_t)(m->nTiles ? m->nTiles : 1));
+         for (int s = 0; s < m->S; s++) for (int t = off[s]; t < off[s + 1]; t++) ts[t] = s;
+         rc = toDevice(&m->d_tileState, ts, (size_t)m->nTiles);
+         free(ts);
+      }
       free(off);
       if (rc) return rc;
       m->bf16NC = (2 * D + 31) / 32;
@@ -145,6 +151,7 @@ static int mfma_refresh(htkamd_model *m)
    }
    int rc = toDevice(&m->d_mfmaTab, tab, (size_t)m->nTiles * stride);
    free(tab);
+   m->mfmaStale = 0;
    return rc;
 }
 
@@ -288,7 +295,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
    (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff); (void)hipFree(m->d_mfmaTab); (void)hipFree(m->d_stateTileOff);
-   (void)hipFree(m->d_bf16Tab);
+   (void)hipFree(m->d_bf16Tab); (void)hipFree(m->d_tileState);
    (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);

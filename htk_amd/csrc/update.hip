@@ -10,8 +10,9 @@
 //   k_upd_trans   thread = transition matrix (marked): a_ij = tr/occ -> log
 //   k_upd_state   thread = tied state: [single-process float round trip of the weights]; marked: c_m/occ, MINMIX cut, floor; then the
 //                 log weights the kernels use, and the state's Gaussians whose new weight exceeds MINMIX are marked
-//   k_upd_gauss   thread = Gaussian: [round trip of the variances]; marked: variances (before the means), means, gConst; then
-//                 1/variance and the interleaved (mean, 1/var) row of the exact scoring kernel
+//   k_upd_gauss_elem  thread = (Gaussian, dimension): [round trip of the variance]; marked: variance (from the OLD mean's statistics,
+//                 as UpdateVars runs before UpdateMeans), mean; then 1/variance and the interleaved (mean, 1/var) scoring row
+//   k_upd_gconst  thread = Gaussian: gConst (float sum in dimension order)
 //   k_upd_mfma    thread = (fragment tile, component column): the A-operand table of the matrix-core scoring kernel
 // 80 000 Gaussians x 39 dimensions: ~60 MB read, ~60 MB written, a fraction of a millisecond -- against 52 MB D2H, a single host
 // thread over 80 k Gaussians and ~80 MB H2D on the host path (which stays: htkamd_model_update).
@@ -34,6 +35,7 @@ struct UpdArgs {
    double logTpi;                                           // log(2 pi) as the host's libm gives it
    const float *varFloor;
    unsigned char *qualT, *qualS, *qualG, *anyS, *anyG;      // marked by a qualifying model / used by any model
+   unsigned char *flooredG;                                 // a variance element of the Gaussian was floored
    int *stats;                                              // htkamd_update_stats fields in order + [6] weights above 1.001
 };
 
@@ -118,60 +120,75 @@ __global__ void k_upd_state(UpdArgs a)
    }
 }
 
-__global__ void k_upd_gauss(UpdArgs a)
+// Variances and means, one thread per (Gaussian, dimension): every array is walked in storage order (coalesced), the per-Gaussian
+// quantities (marks, occupancies) are broadcast loads.
+__global__ void k_upd_gauss_elem(UpdArgs a)
 {
-   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-   if (g >= a.G) return;
+   const size_t idx0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
    const int D = a.D;
-   float *var = a.var + (size_t)g * D, *mean = a.mean + (size_t)g * D;
-   if (a.singleProcess && a.anyG[g])                         // ConvDiagC before the pass, ForceDiagC after it
-      for (int k = 0; k < D; k++) {
-         float v = var[k], iv;
-         if (v > 1E+30f) v = 1E+30f;
-         if (v < 1E-30f) v = 1E-30f;
-         iv = 1 / v;
-         if (iv > 1E+30f) iv = 1E+30f;
-         if (iv < 1E-30f) iv = 1E-30f;
-         var[k] = 1 / iv;
-      }
+   const bool live = idx0 < (size_t)a.G * D;
+   const size_t idx = live ? idx0 : 0;
+   const int g = (int)(idx / D), k = (int)(idx - (size_t)g * D);
+   float v = a.var[idx], mu = a.mean[idx];
+   bool floored = false;
+   if (a.singleProcess && a.anyG[g]) {                       // ConvDiagC before the pass, ForceDiagC after it
+      float iv;
+      if (v > 1E+30f) v = 1E+30f;
+      if (v < 1E-30f) v = 1E-30f;
+      iv = 1 / v;
+      if (iv > 1E+30f) iv = 1E+30f;
+      if (iv < 1E-30f) iv = 1E-30f;
+      v = 1 / iv;
+   }
    if (a.qualG[g]) {
       const float muOcc = ACCF(a.lay.muOcc, g);
       if (a.uFlags & HTKAMD_UPVARS) {
          const float occim = ACCF(a.lay.vaOcc, g);
          if (occim > 0.0f) {
             const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0f;
-            int floored = 0;
-            for (int k = 0; k < D; k++) {
-               const float muDiffk = shared ? 0.0f : ACCF(a.lay.mu, (size_t)g * D + k) / muOcc;
-               float x = ACCF(a.lay.va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
-               const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
-               if (x < fl) { x = fl; floored++; }
-               var[k] = x;
-            }
-            if (floored) { atomicAdd(a.stats + 0, floored); atomicAdd(a.stats + 1, 1); }
-         } else atomicAdd(a.stats + 5, 1);
+            const float muDiffk = shared ? 0.0f : ACCF(a.lay.mu, idx) / muOcc;
+            float x = ACCF(a.lay.va, idx) / occim - muDiffk * muDiffk;
+            const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
+            if (x < fl) { x = fl; floored = live; }
+            v = x;
+         } else if (k == 0 && live) atomicAdd(a.stats + 5, 1);
       }
-      if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f)
-         for (int k = 0; k < D; k++) mean[k] += ACCF(a.lay.mu, (size_t)g * D + k) / muOcc;
-      if (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS)) {      // FixDiagGConst
-         float sum = (float)((double)D * a.logTpi);
-         for (int k = 0; k < D; k++) {
-            const float z = ((double)var[k] <= MINLARG) ? (float)LZERO : (float)log((double)var[k]);
-            sum += z;
-         }
-         a.gconst[g] = sum;
-      }
+      if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mu += ACCF(a.lay.mu, idx) / muOcc;
    }
+   {  // floored elements: one atomic per wavefront
+      const unsigned long long fb = __ballot(floored);
+      if (fb && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)fb) - 1)) atomicAdd(a.stats + 0, __popcll(fb));
+      if (floored) a.flooredG[g] = 1;
+   }
+   if (!live) return;
+   a.var[idx] = v; a.mean[idx] = mu;
    // derived tables: ConvDiagC (HUtil.c:413) and the interleaved row of the exact scoring kernel
-   float *iv = a.ivar + (size_t)g * D, *gp = a.gparam + (size_t)g * a.PS;
-   for (int k = 0; k < D; k++) {
-      float v = var[k];
-      if (v > 1E+30f) v = 1E+30f;
-      if (v < 1E-30f) v = 1E-30f;
-      const float r = 1 / v;
-      iv[k] = r; gp[2 * k] = mean[k]; gp[2 * k + 1] = r;
+   float c = v;
+   if (c > 1E+30f) c = 1E+30f;
+   if (c < 1E-30f) c = 1E-30f;
+   const float r = 1 / c;
+   a.ivar[idx] = r;
+   float *gp = a.gparam + (size_t)g * a.PS;
+   gp[2 * k] = mu; gp[2 * k + 1] = r;
+}
+
+// gConst, one thread per Gaussian: the float sum over the dimensions runs in the reference's order (FixDiagGConst HModel.c:5641)
+__global__ void k_upd_gconst(UpdArgs a)
+{
+   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= a.G) return;
+   const int D = a.D;
+   if (a.flooredG[g]) atomicAdd(a.stats + 1, 1);
+   if (a.qualG[g] && (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))) {
+      const float *var = a.var + (size_t)g * D;
+      float sum = (float)((double)D * a.logTpi);
+      for (int k = 0; k < D; k++) {
+         const float z = ((double)var[k] <= MINLARG) ? (float)LZERO : (float)log((double)var[k]);
+         sum += z;
+      }
+      a.gconst[g] = sum;
    }
-   gp[2 * D] = a.gconst[g];
+   a.gparam[(size_t)g * a.PS + 2 * D] = a.gconst[g];
 }
 
 // A-operand fragment table of gmm_mfma.hip; layout and arithmetic as mfma_refresh() in model.hip
@@ -217,8 +234,10 @@ __global__ void k_upd_mfma(MfmaTabArgs a, int nTiles)
       }
 }
 
-int htkamd_model_refresh_mfma_device(htkamd_model *m, hipStream_t s)
+int htkamd_model_refresh_mfma_device(htkamd_model *m, void *stream)
 {
+   hipStream_t s = (hipStream_t)stream;
+   m->mfmaStale = 0;
    if (!m->d_mfmaTab) return HTKAMD_OK;
    MfmaTabArgs t;
    t.D = m->D; t.NS = m->mfmaNS; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss;
@@ -236,7 +255,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    hipStream_t s = (hipStream_t)stream;
    int rc;
    if ((rc = htkamd_model_device_tables(m))) return rc;
-   const size_t nFlag = (size_t)m->nT + 2 * (size_t)m->S + 2 * (size_t)m->G;
+   const size_t nFlag = (size_t)m->nT + 2 * (size_t)m->S + 3 * (size_t)m->G;
    const size_t need = ((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int) + sizeof(float) * (size_t)m->D;
    if (need > m->updScratchCap) {
       if (m->d_updScratch) (void)hipFree(m->d_updScratch);
@@ -256,7 +275,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    a.acc = accs->d_vec; a.lay = accs->lay;
    a.minEgs = cfg->minEgs; a.uFlags = cfg->uFlags; a.singleProcess = cfg->singleProcess; a.rowNormalise = cfg->rowNormalise;
    a.minVar = cfg->minVar; a.mixWeightFloor = cfg->mixWeightFloor; a.logTpi = log(HTK_TPI);
-   a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G;
+   a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G; a.flooredG = a.anyG + m->G;
    a.stats = (int *)(fl + ((nFlag + 63) & ~(size_t)63));
    float *dFloor = (float *)(a.stats + 16);
    a.hasVarFloor = cfg->varFloor != nullptr; a.varFloor = dFloor;
@@ -265,9 +284,15 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    hipLaunchKernelGGL(k_upd_mark, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
    hipLaunchKernelGGL(k_upd_trans, dim3((m->nT + B - 1) / B), dim3(B), 0, s, a);
    hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
-   hipLaunchKernelGGL(k_upd_gauss, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
+   {
+      const size_t nEl = (size_t)m->G * m->D;
+      hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
+   }
+   hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
    HIPCHECK(hipGetLastError());
-   if ((rc = htkamd_model_refresh_mfma_device(m, s)) || (rc = htkamd_model_refresh_bf16_device(m, s))) return rc;
+   // the bf16 x 3 fragment table now; the fp32 one when the fp32 matrix-core kernel is next asked for (htkamd_launch_score_mfma)
+   m->mfmaStale = 1;
+   if ((rc = htkamd_model_refresh_bf16_device(m, s))) return rc;
    m->hostStale = 1;
    // the transition matrices are small and the host needs them (minimum durations for CreateInsts, tee flags for the decoder)
    const size_t nTp = (size_t)m->h_transOff[m->nT];
