@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--phones", type=int, default=6000)
     ap.add_argument("--utts", type=int, default=1250, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --utts utterances on every GPU (the contract's default); strong: --total-utts utterances split over the GPUs")
+    ap.add_argument("--total-utts", type=int, default=10000, help="--scaling strong: utterances of the whole job (BASELINE config[2]: 10k)")
     ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
     ap.add_argument("--score", choices=["exact", "mfma", "fast", "fastest"], default="fastest",
                     help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; fastest = bf16 x 3 matrix-core scores + that LAdd (tolerance class, tests/test_gpu_parity.py)")
@@ -157,6 +160,8 @@ def main():
 
     D = 39
     # same model on every rank (model_seed), a different 1250-utterance shard per rank (seed)
+    if args.scaling == "strong":                             # config[2] as one job: rank r takes utterances r, r+world, ... (HERest -p semantics)
+        args.utts = (args.total_utts - rank + world - 1) // world
     s = synth.generate_fast(args.states, args.mix, args.phones, args.utts, args.frames, seed=1000 + rank, model_seed=3)
     pk = s.packed()
     model = capi.Model(pk)
@@ -317,7 +322,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
