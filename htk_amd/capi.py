@@ -268,12 +268,15 @@ def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, 
 class ForwardBackward:
     """htkamd_fb holder: FBFile (HFB.c:1923) over a batch of utterances."""
 
-    def __init__(self, model: Model, debug: bool = False, force_general: bool = False, no_state_path: bool = False):
+    def __init__(self, model: Model, debug: bool = False, force_general: bool = False, no_state_path: bool = False, stats_list: str = "auto"):
+        """stats_list: how the mixture statistics reach the accumulators -- "auto": record list + per-Gaussian reduction,
+        "tiny": a 128-record list (everything beyond it takes the direct-atomics fallback), "off": direct atomics only."""
         self.model = model
         self.h = C.c_void_p()
         check(lib().htkamd_fb_create(model.h, C.byref(self.h)), "fb_create")
-        if debug or force_general or no_state_path:
-            check(lib().htkamd_fb_set_debug(self.h, (1 if debug else 0) | (2 if force_general else 0) | (4 if no_state_path else 0)), "fb_set_debug")
+        flags = (1 if debug else 0) | (2 if force_general else 0) | (4 if no_state_path else 0) | {"auto": 0, "tiny": 8, "off": 16}[stats_list]
+        if flags:
+            check(lib().htkamd_fb_set_debug(self.h, flags), "fb_set_debug")
         self.nUtt = 0
         self._keep = None
 

@@ -132,6 +132,8 @@ struct htkamd_fb {
    size_t betaWTotal;
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
+   DevBuf d_rec, d_recSorted, d_recCtl;     // statistics records (kernels.h MixRec)
+   int recCapForce;                         // > 0: capacity of the record list (tests: forces the overflow path)
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
    hipEvent_t ev[5], evK[2], evCopy;          // ev: stream intervals; evK: the scoring dispatch's own start/stop
@@ -144,7 +146,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; fb->recCapForce = 0; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) fb->ev[i] = nullptr;
    fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
@@ -169,7 +171,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -189,6 +191,7 @@ extern "C" int htkamd_fb_set_debug(htkamd_fb *fb, int on)
    fb->debug = on & 1;
    fb->forceGeneral = (on & 2) ? 1 : 0;
    fb->noStatePath = (on & 4) ? 1 : 0;
+   fb->recCapForce = (on & 8) ? 128 : ((on & 16) ? -1 : 0);          // 8: a 128-record list (overflow path), 16: no record list (direct atomics)
    return HTKAMD_OK;
 }
 
@@ -580,8 +583,17 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       }
       HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }
-   if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES))
+   if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) {
+      if ((cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS)) && fb->recCapForce >= 0) {
+         // ~4 surviving (frame, component) pairs per frame on a trained system; 16 per frame of room, the rest falls back to atomics
+         const size_t cap = fb->recCapForce > 0 ? (size_t)fb->recCapForce : std::min<size_t>((size_t)16 * fb->totalFrames + 4096, (size_t)1 << 30);
+         if ((rc = fb->d_rec.reserve(sizeof(MixRec) * cap)) || (rc = fb->d_recSorted.reserve(sizeof(MixRec) * cap)) ||
+             (rc = fb->d_recCtl.reserve(sizeof(int) * (3 * ((size_t)m->G + 1) + 1 + (size_t)m->G / 2048 + 2))))
+            return rc;
+         fa.rec = (MixRec *)fb->d_rec.p; fa.recSorted = (MixRec *)fb->d_recSorted.p; fa.recCap = (int)cap; fa.G = m->G; fa.recCtl = (int *)fb->d_recCtl.p;
+      }
       if ((rc = htkamd_launch_mixstats(fa, s))) return rc;
+   }
    HIPCHECK(hipEventRecord(fb->ev[4], s));
    fb->timed = true;
    // the metric's unit count rides along in the accumulator vector so that it is all-reduced with it

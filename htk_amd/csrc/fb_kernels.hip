@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
    const int D = DT > 0 ? DT : a.D;
    const double minF = (double)a.minFrwdP;
    const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   int recBase = -1, recUsed = 0;                        // this wavefront's current block of the record list
    // dense scan of the seed array: 8 x 64 seeds per wave and iteration (8 independent 512-byte loads in flight)
    for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
     double vv[8];
@@ -653,13 +654,40 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
 #pragma unroll
             for (int o = GS / 2; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);      // within the hit's lane group
             if (sub == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
+            // record path: list (Gaussian, frame, posterior) for the per-Gaussian reduction (k_rec_reduce).  A wavefront takes list
+            // space in blocks of 64 records (one atomic on the shared cursor per block, not per hit: a single hot address serialises
+            // in L2); what is left of a block when the next is taken, or at the end, is filled with empty records (g = -1)
+            bool stored = false;
+            if (a.rec) {
+               const unsigned long long pk = __ballot(pass);
+               if (pk) {
+                  const int np = __popcll(pk);
+                  if (recBase < 0 || recUsed + np > 64) {
+                     if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
+                     int base = 0;
+                     if (lane == 0) base = atomicAdd(a.recCtl, 64);
+                     base = __shfl(base, 0);
+                     recBase = (base >= 0 && (long long)base + 64 <= a.recCap) ? base : -1;
+                     recUsed = 0;
+                  }
+                  if (recBase >= 0) {
+                     if (pass) {
+                        MixRec r; r.g = g; r.frame = ud.frame0 + t0; r.L = Lr;
+                        a.rec[recBase + recUsed + __popcll(pk & ((1ull << lane) - 1))] = r;
+                        atomicAdd(a.recCtl + 1 + g, 1);
+                        stored = true;
+                     }
+                     recUsed += np;
+                  }
+               }
+            }
             if (pass) {
-               if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
-               if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+               if (upMu && !stored) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+               if (upVa && !stored) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
                if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
             }
             // first-order statistics of every surviving (hit, component): the whole wave, lane = dimension
-            unsigned long long pm = __ballot(pass);
+            unsigned long long pm = __ballot(pass && !stored);        // what the list had no room for: direct atomics
             while (pm) {
                const int ml = __ffsll((long long)pm) - 1;
                pm &= pm - 1;
@@ -684,6 +712,125 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
          }
       }
     }
+   }
+   if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
+}
+
+// ---- record path of K4: bucket the records by Gaussian (counting sort: counts came with the records), then one wavefront per
+// Gaussian sums its records' first- and second-order terms (lane = dimension) and adds them to the accumulators ONCE.
+#define REC_TILE 2048
+__global__ __launch_bounds__(256) void k_rec_tilesum(int *ctl, int G, int *tileSum)
+{
+   __shared__ int part[4];
+   const int *cnt = ctl + 1;
+   int sum = 0;
+   for (int i = blockIdx.x * REC_TILE + threadIdx.x; i < (blockIdx.x + 1) * REC_TILE && i < G; i += 256) sum += cnt[i];
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+   __syncthreads();
+   if (threadIdx.x == 0) tileSum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// exclusive scan of the counts: every block adds up the tiles before its own (a few dozen), then scans its tile (8 per thread)
+__global__ __launch_bounds__(256) void k_rec_tilescan(int *ctl, int G, const int *tileSum)
+{
+   __shared__ int wsum[4];
+   __shared__ int offSh;
+   const int *cnt = ctl + 1;
+   int *start = ctl + 1 + (G + 1);
+   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   int off = 0;
+   for (int b = tid; b < (int)blockIdx.x; b += 256) off += tileSum[b];
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o);
+   if (lane == 0) wsum[wv] = off;
+   __syncthreads();
+   if (tid == 0) offSh = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+   __syncthreads();
+   off = offSh;
+   __syncthreads();
+   const int i0 = blockIdx.x * REC_TILE + tid * 8;
+   int v[8], mine = 0;
+#pragma unroll
+   for (int k = 0; k < 8; k++) { v[k] = (i0 + k < G) ? cnt[i0 + k] : 0; mine += v[k]; }
+   int inc = mine;                                       // inclusive scan over the wave, then over the four waves
+#pragma unroll
+   for (int o = 1; o < 64; o <<= 1) { const int w = __shfl_up(inc, o); if (lane >= o) inc += w; }
+   if (lane == 63) wsum[wv] = inc;
+   __syncthreads();
+   int run = off + inc - mine;
+   for (int w = 0; w < wv; w++) run += wsum[w];
+#pragma unroll
+   for (int k = 0; k < 8; k++) { if (i0 + k < G) start[i0 + k] = run; run += v[k]; }
+   if (i0 <= G - 1 && G - 1 < i0 + 8) start[G] = run;
+}
+
+__global__ __launch_bounds__(256) void k_rec_scatter(FbArgs a)
+{
+   const int G = a.G;
+   const int *start = a.recCtl + 1 + (G + 1);
+   int *cur = a.recCtl + 1 + 2 * (G + 1);
+   const int n = (a.recCtl[0] >= 0 && a.recCtl[0] < a.recCap) ? a.recCtl[0] : (a.recCap & ~63);
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const MixRec r = a.rec[i];
+      if (r.g < 0) continue;
+      a.recSorted[start[r.g] + atomicAdd(cur + r.g, 1)] = r;
+   }
+}
+
+__global__ __launch_bounds__(256) void k_rec_reduce(FbArgs a)
+{
+   const int G = a.G, D = a.D, lane = threadIdx.x & 63;
+   const int *start = a.recCtl + 1 + (G + 1);
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS;
+   const int nWaves = (gridDim.x * blockDim.x) >> 6;
+   for (int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < G; g += nWaves) {
+      const int r0 = start[g], r1 = start[g + 1];
+      if (r0 == r1) continue;
+      for (int k0 = 0; k0 < D; k0 += 64) {
+         const int k = k0 + lane;
+         const float mean = (k < D) ? a.mean[(size_t)g * D + k] : 0.0f;
+         double sMu = 0.0, sVa = 0.0, sL = 0.0;
+         for (int rb = r0; rb < r1; rb += 64) {
+            const int nb = (r1 - rb < 64) ? r1 - rb : 64;
+            MixRec mine; mine.frame = 0; mine.L = 0.0;
+            if (lane < nb) mine = a.recSorted[rb + lane];
+            sL += mine.L;
+            for (int i = 0; i < nb; i += 4) {                     // four rows in flight
+               float xv[4]; double Lv[4];
+#pragma unroll
+               for (int e = 0; e < 4; e++) {
+                  const int ii = (i + e < nb) ? i + e : nb - 1;
+                  const int fr = __shfl(mine.frame, ii);
+                  Lv[e] = (i + e < nb) ? __shfl(mine.L, ii) : 0.0;
+                  xv[e] = (k < D) ? a.X[(size_t)fr * D + k] : 0.0f;
+               }
+#pragma unroll
+               for (int e = 0; e < 4; e++) {
+                  if (i + e >= nb) break;
+                  const float z = xv[e] - mean;
+                  const double L = Lv[e];
+                  if (upMu && upVa) {                    // HFB.c:1673-1678
+                     const float zl = (float)((double)z * L);
+                     sMu += (double)zl; sVa += (double)(z * zl);
+                  } else if (upMu) sMu += (double)z * L;           // HFB.c:1697-1698
+                  else if (upVa) sVa += (double)(z * z) * L;       // HFB.c:1706-1709
+               }
+            }
+         }
+         if (k < D) {
+            if (upMu && sMu != 0.0) atomicAdd(a.acc + a.lay.mu + (size_t)g * D + k, sMu);
+            if (upVa && sVa != 0.0) atomicAdd(a.acc + a.lay.va + (size_t)g * D + k, sVa);
+         }
+         if (k0 == 0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sL += __shfl_xor(sL, o);
+            if (lane == 0) {
+               if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, sL);
+               if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, sL);
+            }
+         }
+      }
    }
 }
 
@@ -720,6 +867,7 @@ int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s)
    if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
    const dim3 grid((unsigned)blocks), block(256);
    const FbArgs &a = a_in;
+   if (a.rec) HIPCHECK(hipMemsetAsync(a.recCtl, 0, sizeof(int) * (3 * ((size_t)a.G + 1) + 1), s));
 #define MIXSTATS_LAUNCH(GS) \
    switch (a.D) { \
    case 39: hipLaunchKernelGGL((k_mixstats<39, GS>), grid, block, 0, s, a); break; \
@@ -732,5 +880,14 @@ int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s)
    else { MIXSTATS_LAUNCH(64) }
 #undef MIXSTATS_LAUNCH
    HIPCHECK(hipGetLastError());
+   if (a.rec) {
+      const int nTile = (a.G + REC_TILE - 1) / REC_TILE;
+      hipLaunchKernelGGL(k_rec_tilesum, dim3(nTile), dim3(256), 0, s, a.recCtl, a.G, a.recCtl + 1 + 3 * (a.G + 1));
+      hipLaunchKernelGGL(k_rec_tilescan, dim3(nTile), dim3(256), 0, s, a.recCtl, a.G, a.recCtl + 1 + 3 * (a.G + 1));
+      hipLaunchKernelGGL(k_rec_scatter, dim3(2048), dim3(256), 0, s, a);
+      const int gb = (a.G + 3) / 4;
+      hipLaunchKernelGGL(k_rec_reduce, dim3(gb < 16384 ? gb : 16384), dim3(256), 0, s, a);
+      HIPCHECK(hipGetLastError());
+   }
    return HTKAMD_OK;
 }

@@ -67,6 +67,8 @@ struct UttDesc {
                       // beta block = betaS[T][64*W] then betaE[T][64*W]
 };
 
+struct MixRec { int g, frame; double L; };          // posterior L of Gaussian g at row `frame` of the feature table
+
 struct FbArgs {
    const UttDesc *utt;
    int nUtt;
@@ -103,6 +105,11 @@ struct FbArgs {
    size_t gamTotal;                  // doubles in gam for this batch
    const size_t *gamOffByUtt;        // [nUtt+1] = utt[u].gam0 (for the flat-index -> utterance search)
    const int *gamChunkUtt;           // [ceil(gamTotal/512)] utterance holding seed 512*c
+   // statistics kernel, record path: the surviving (frame, Gaussian, posterior) triples are listed, bucketed by Gaussian and summed
+   // per Gaussian (one atomic per accumulator element and batch instead of one per triple); NULL = direct atomics only
+   MixRec *rec, *recSorted;
+   int recCap, G;
+   int *recCtl;                      // [0] number of records asked for (may exceed recCap), then gCnt[G+1], gStart[G+1], gCur[G+1]
 };
 
 int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);

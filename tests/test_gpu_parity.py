@@ -15,13 +15,13 @@ CASES = ["fb_small", "fb_small_prune", "fb_topo", "fb_topo_prune"]
 PATHS = ["state", "wave", "general"]        # lane per chain state (fb_state.hip) | lane per model (fb_wave.hip) | workgroup per utterance
 
 
-def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, scoreMode=0, path=None):
+def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, scoreMode=0, path=None, stats_list="auto"):
     model = native.Model(pk)
     X, frameOff, labOff, labs = batch_arrays(utts)
     dX = native.DevArray(X)
     if path is not None:
         general = path == "general"
-    fb = native.ForwardBackward(model, debug=debug, force_general=general, no_state_path=(path == "wave"))
+    fb = native.ForwardBackward(model, debug=debug, force_general=general, no_state_path=(path == "wave"), stats_list=stats_list)
     acc = native.Accs(model)
     fb.prepare(dX.ptr.value, frameOff, labOff, labs)
     fb.execute(native.fb_config(uFlags=uFlags, scoreMode=scoreMode, **(prune or {})), acc)
@@ -271,6 +271,22 @@ def test_update_flags_subset(native, oracle):
         a = acc.download()
         for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
             acc_close(a[k], getattr(oacc, k), "flags=%d %s" % (flags, k))
+
+
+@pytest.mark.parametrize("stats_list", ["tiny", "off"])
+@pytest.mark.parametrize("flags", [15, 1, 2])
+def test_mixture_statistics_fallback_paths(native, oracle, stats_list, flags):
+    """K4's record list (per-Gaussian reduction) is the default everywhere else; here the list is 128 records long, so that almost
+    everything takes the overflow path, or absent (direct atomics): same accumulators (UpMixParms HFB.c:1426-1721)."""
+    case = load_case("fb_topo")
+    om = oracle.Model(case["pk"])
+    model, fb, acc, pr, st = run_fb(native, case["pk"], case["utts"], uFlags=flags, stats_list=stats_list)
+    oacc = oracle.Accs(om); cfg = oracle.fb_cfg(uFlags=flags)
+    for ut in case["utts"]:
+        oracle.fb_utt(om, cfg, ut["feat"], ut["seq"], oacc)
+    a = acc.download()
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc"):
+        acc_close(a[k], getattr(oacc, k), "%s flags=%d %s" % (stats_list, flags, k))
 
 
 # ----------------------------------------------------------------------------------------- update (host C)
