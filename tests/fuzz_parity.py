@@ -49,6 +49,8 @@ def fuzz_fb(rng, it):
     mode = int(rng.random() < 0.3 and pk["vecSize"] in (13, 26, 39))
     if rng.random() < 0.25:
         mode |= 2                                                   # fast LAdd of the recursions (tolerance class)
+    if rng.random() < 0.3:
+        mode |= 32                                                  # scaled linear recursions on the lane-per-state path (tolerance class)
     model = capi.Model(pk); om = pyoracle.Model(pk)
     utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(seqs, feats)]
     X, frameOff, labOff, labs = batch_arrays(utts)
@@ -75,7 +77,7 @@ def fuzz_fb(rng, it):
                                                                     # accumulated part of the utterance: there is no accumulator state to compare
         if (st[u] == 1) != ok_o:
             bad.append("status u%d gpu %d oracle rc %d" % (u, st[u], rc))
-        elif ok_o and abs(pr[u] - opr) > (1e-6 if mode else 1e-10) * abs(opr) and not (mode & 2 and prune):
+        elif ok_o and abs(pr[u] - opr) > (1e-6 if mode else 1e-10) * abs(opr) and not (mode & 34 and prune):
             # (under a beam the tolerance-class LAdd may prune one model more or less than the reference: pr then moves by the pruned mass)
             bad.append("pr u%d %r vs %r" % (u, pr[u], opr))
     tol = 5e-4 if mode else 1e-4          # MFMA scores: posteriors near the MINFORPROB cut move by a few 1e-4 of small occupancies
