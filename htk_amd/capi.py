@@ -143,6 +143,11 @@ class Model:
         self.nT, self.H = d.numTrans, d.numPhys
         self.maxN = int(np.max(k["transN"]))
 
+    def set_sharing(self, meanShare, varShare):
+        """Tied mean / variance vectors (htkamd_model_set_sharing): arrays [G] of share numbers, -1 = private."""
+        ms = np.ascontiguousarray(meanShare, np.int32); vs = np.ascontiguousarray(varShare, np.int32)
+        check(lib().htkamd_model_set_sharing(self.h, _p(ms), _p(vs)), "model_set_sharing")
+
     def set_params(self, mean=None, var=None, gconst=None, compWeight=None, transP=None):
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
         args = [f32(mean), f32(var), f32(gconst), f32(compWeight), f32(transP)]
@@ -592,6 +597,37 @@ def parm_qualify(stat_list, quals: ParmQuals):
     return dOut, frameOff, cols
 
 
+class ParmStream:
+    """htkamd_parm_stream holder: the qualifier step in HParm's buffer mode (rows in pushes, observations out with qwin rows of delay)."""
+
+    def __init__(self, quals: ParmQuals, max_rows: int):
+        self.h = C.c_void_p()
+        self.q = quals
+        self.max_rows = max_rows
+        check(lib().htkamd_parm_stream_open(C.byref(quals), C.c_int(max_rows), C.byref(self.h)), "parm_stream_open")
+        self.cols = lib().htkamd_parm_quals_cols(C.byref(quals))
+        self.lookahead = lib().htkamd_parm_stream_lookahead(self.h)
+
+    def push(self, rows: np.ndarray, last: bool = False) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, self.q.nStat)
+        dIn = DevArray(rows) if rows.shape[0] else None
+        dOut = DevArray(nbytes=4 * max((rows.shape[0] + self.lookahead) * self.cols, 1))
+        n = C.c_int(0)
+        check(lib().htkamd_parm_stream_push(self.h, dIn.ptr if dIn else None, C.c_int(rows.shape[0]), C.c_int(int(last)), dOut.ptr, C.byref(n), None), "parm_stream_push")
+        return dOut.to_host(np.float32, (max(rows.shape[0] + self.lookahead, 1), self.cols))[:n.value].copy()
+
+    def close(self):
+        if self.h:
+            lib().htkamd_parm_stream_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Mmf:
     """htkamd_mmf holder: LoadHMMSet / SaveHMMSet for text model definitions (htk_amd/host/mmf.c)."""
 
@@ -631,6 +667,13 @@ class Mmf:
                   transN=arr(d.transN, nT, C.c_int), transOff=transOff, transP=arr(d.transP, int(transOff[-1]), C.c_float),
                   hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int))
         return pk
+
+    def sharing(self):
+        """(meanShare, varShare): per Gaussian the number of the ~u / ~v macro its mean / variance is, -1 = private; None if nothing is shared."""
+        G = self.desc.numGauss
+        ms = np.full(max(G, 1), -1, np.int32); vs = np.full(max(G, 1), -1, np.int32)
+        n = lib().htkamd_mmf_sharing(self.h, _p(ms), _p(vs))
+        return (ms[:G], vs[:G]) if n > 0 else None
 
     def mixup(self, target: int, states=None):
         """HHEd's MU command on the loaded set: `target` > 0 components per state (or -target more if negative) for the states

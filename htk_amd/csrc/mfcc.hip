@@ -437,6 +437,92 @@ extern "C" int htkamd_parm_add_qualifiers(const float *dStatic, const int *frame
    return htkamd_parm_qualify(dStatic, frameOff, nUtt, &q, dOut, stream);
 }
 
+// ------------------------------------------------------------------------------------ buffered qualifiers (HParm's buffer mode)
+// FillBufFromChannel (HParm.c:4000-4116) qualifies the rows qst..qen of its buffer as soon as the qwin rows of look-ahead behind
+// qen have arrived (tail = qwin, head = min(qst, qwin) rows of real left context; at the end of the input tail = 0), so that the
+// regression windows of interior rows see real neighbours and only the first / last rows of the UTTERANCE replicate -- i.e. exactly
+// the table-mode values, delivered qwin rows late.  Same here: every push qualifies the window [qst - head, rows seen) as one
+// utterance on the device and hands out its rows qst..qen.
+struct htkamd_parm_stream {
+   htkamd_parm_quals q;
+   int qwin, nSeen, qst, base, cap;        // rows seen so far; next row to hand out; absolute index of dBuf's first row; rows of capacity
+   int done;
+   float *dBuf, *dTmp;
+};
+
+extern "C" int htkamd_parm_stream_open(const htkamd_parm_quals *q, int maxRows, htkamd_parm_stream **out)
+{
+   if (!q || !out || maxRows < 1 || q->nStat <= 0) { htkamd_set_error("parm_stream_open: bad argument"); return HTKAMD_EINVAL; }
+   if (q->nZeroMean > 0) { htkamd_set_error("parm_stream_open: _Z needs the whole utterance (table mode: htkamd_parm_qualify)"); return HTKAMD_EINVAL; }
+   if ((q->hasA && !q->hasD) || (q->hasT && !q->hasA) || (q->hasD && q->delWin < 1) || (q->hasA && q->accWin < 1) || (q->hasT && q->thirdWin < 1) ||
+       q->nullECol >= q->nStat || (q->nullECol >= 0 && !q->hasD)) { htkamd_set_error("parm_stream_open: bad qualifier set"); return HTKAMD_EINVAL; }
+   int nd = 0;
+   if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) { htkamd_set_error("parm_stream_open: no HIP device"); return HTKAMD_ENODEV; }
+   htkamd_parm_stream *s = new htkamd_parm_stream();
+   s->q = *q;
+   s->qwin = (q->hasD ? q->delWin : 0) + (q->hasA ? q->accWin : 0) + (q->hasT ? q->thirdWin : 0);
+   s->nSeen = s->qst = s->base = 0; s->done = 0;
+   s->cap = maxRows + 2 * s->qwin + 1;
+   s->dBuf = s->dTmp = nullptr;
+   const int cols = htkamd_parm_quals_cols(q);
+   if (hipMalloc((void **)&s->dBuf, sizeof(float) * (size_t)s->cap * q->nStat) != hipSuccess ||
+       hipMalloc((void **)&s->dTmp, sizeof(float) * (size_t)s->cap * cols) != hipSuccess) {
+      if (s->dBuf) (void)hipFree(s->dBuf);
+      delete s;
+      htkamd_set_error("parm_stream_open: out of device memory"); return HTKAMD_ENOMEM;
+   }
+   *out = s;
+   return HTKAMD_OK;
+}
+
+extern "C" void htkamd_parm_stream_close(htkamd_parm_stream *s)
+{
+   if (!s) return;
+   if (s->dBuf) (void)hipFree(s->dBuf);
+   if (s->dTmp) (void)hipFree(s->dTmp);
+   delete s;
+}
+
+extern "C" int htkamd_parm_stream_lookahead(const htkamd_parm_stream *s) { return s ? s->qwin : 0; }
+
+extern "C" int htkamd_parm_stream_push(htkamd_parm_stream *s, const float *dStatic, int nRows, int last, float *dOut, int *nOut, void *stream)
+{
+   if (!s || nRows < 0 || !nOut || (nRows > 0 && !dStatic)) { htkamd_set_error("parm_stream_push: bad argument"); return HTKAMD_EINVAL; }
+   *nOut = 0;
+   if (s->done) { htkamd_set_error("parm_stream_push: the stream was closed by a push with last = 1"); return HTKAMD_EINVAL; }
+   hipStream_t st = (hipStream_t)stream;
+   const int nStat = s->q.nStat, cols = htkamd_parm_quals_cols(&s->q);
+   if (s->nSeen - s->base + nRows > s->cap) { htkamd_set_error("parm_stream_push: %d rows exceed the stream's maxRows", nRows); return HTKAMD_EINVAL; }
+   if (nRows > 0) HIPCHECK(hipMemcpyAsync(s->dBuf + (size_t)(s->nSeen - s->base) * nStat, dStatic, sizeof(float) * (size_t)nRows * nStat, hipMemcpyDeviceToDevice, st));
+   s->nSeen += nRows;
+   if (last) s->done = 1;
+   const int qen = last ? s->nSeen - 1 : s->nSeen - s->qwin - 1;
+   if (qen < s->qst) return HTKAMD_OK;
+   if (!dOut) { htkamd_set_error("parm_stream_push: NULL output"); return HTKAMD_EINVAL; }
+   const int head = (s->qst < s->qwin) ? s->qst : s->qwin;
+   const int w0 = s->qst - head;
+   const int frameOff[2] = {0, s->nSeen - w0};
+   int rc = htkamd_parm_qualify(s->dBuf + (size_t)(w0 - s->base) * nStat, frameOff, 1, &s->q, s->dTmp, stream);
+   if (rc) return rc;
+   const int n = qen - s->qst + 1;
+   HIPCHECK(hipMemcpyAsync(dOut, s->dTmp + (size_t)head * cols, sizeof(float) * (size_t)n * cols, hipMemcpyDeviceToDevice, st));
+   *nOut = n;
+   s->qst = qen + 1;
+   // keep qwin rows of left context for the next window
+   const int keep0 = (s->qst - s->qwin > s->base) ? s->qst - s->qwin : s->base;
+   if (keep0 > s->base) {
+      const int nKeep = s->nSeen - keep0;
+      if (nKeep > 0) {           // overlapping ranges: through the scratch table
+         HIPCHECK(hipMemcpyAsync(s->dTmp, s->dBuf + (size_t)(keep0 - s->base) * nStat, sizeof(float) * (size_t)nKeep * nStat, hipMemcpyDeviceToDevice, st));
+         HIPCHECK(hipStreamSynchronize(st));      // dOut was copied out of dTmp above
+         HIPCHECK(hipMemcpyAsync(s->dBuf, s->dTmp, sizeof(float) * (size_t)nKeep * nStat, hipMemcpyDeviceToDevice, st));
+      }
+      s->base = keep0;
+   }
+   HIPCHECK(hipStreamSynchronize(st));
+   return HTKAMD_OK;
+}
+
 // ------------------------------------------------------------------------------------ HCompV: global mean and variance
 // One block per slab of frames, thread = dimension (strided), fp64 partial sums, one atomic per (block, dimension).
 __global__ void k_compv(const float *X, long long nFrames, int D, double *acc)

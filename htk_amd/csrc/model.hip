@@ -1,5 +1,6 @@
 // model.hip -- packed HMM set on the device, accumulator vector, error plumbing.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -299,8 +300,50 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
+   free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize);
    free(m);
 }
+
+// Shared mean / variance vectors: share[g] >= 0 names the vector Gaussian g's mean (variance) is a copy of, -1 = private.
+extern "C" int htkamd_model_set_sharing(htkamd_model *m, const int *meanShare, const int *varShare)
+{
+   if (!m) { htkamd_set_error("model_set_sharing: NULL model"); return HTKAMD_EINVAL; }
+   free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize);
+   m->h_meanLeader = m->h_varLeader = m->h_varGroupSize = nullptr;
+   bool any = false;
+   for (int g = 0; g < m->G; g++) if ((meanShare && meanShare[g] >= 0) || (varShare && varShare[g] >= 0)) any = true;
+   if (!any) return HTKAMD_OK;
+   int rc = htkamd_model_sync_host(m);
+   if (rc) return rc;
+   const int G = m->G, D = m->D;
+   m->h_meanLeader = (int *)malloc(sizeof(int) * (size_t)G);
+   m->h_varLeader = (int *)malloc(sizeof(int) * (size_t)G);
+   m->h_varGroupSize = (int *)calloc((size_t)G, sizeof(int));
+   for (int pass = 0; pass < 2; pass++) {
+      const int *share = pass ? varShare : meanShare;
+      int *leader = pass ? m->h_varLeader : m->h_meanLeader;
+      const float *vec = pass ? m->h_var : m->h_mean;
+      int maxId = -1;
+      for (int g = 0; g < G; g++) if (share && share[g] > maxId) maxId = share[g];
+      std::vector<int> first((size_t)(maxId + 1), -1);
+      for (int g = 0; g < G; g++) {
+         leader[g] = g;
+         if (!share || share[g] < 0) continue;
+         if (first[share[g]] < 0) first[share[g]] = g;
+         leader[g] = first[share[g]];
+         if (memcmp(vec + (size_t)g * D, vec + (size_t)leader[g] * D, sizeof(float) * (size_t)D)) {
+            htkamd_set_error("model_set_sharing: Gaussians %d and %d are declared to share a %s but hold different values", leader[g], g, pass ? "variance" : "mean");
+            free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize);
+            m->h_meanLeader = m->h_varLeader = m->h_varGroupSize = nullptr;
+            return HTKAMD_EINVAL;
+         }
+      }
+   }
+   for (int g = 0; g < G; g++) m->h_varGroupSize[m->h_varLeader[g]]++;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_has_sharing(const htkamd_model *m) { return m && m->h_meanLeader ? 1 : 0; }
 
 extern "C" int htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,
                                        const float *compWeight, const float *transP)

@@ -252,6 +252,11 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
 {
    if (!m || !accs || !cfg) { htkamd_set_error("model_update_device: NULL argument"); return HTKAMD_EINVAL; }
    if (accs->m != m) { htkamd_set_error("model_update_device: accumulators belong to a different model"); return HTKAMD_EINVAL; }
+   if (m->h_meanLeader) {
+      // the order-dependent pooling of tied vectors (UpdateVars / UpdateMeans walk the set; HERest.c:974-1122) lives in the host update
+      htkamd_set_error("model_update_device: the set shares mean / variance vectors (~u ~v): use htkamd_model_update");
+      return HTKAMD_EMODEL;
+   }
    hipStream_t s = (hipStream_t)stream;
    int rc;
    if ((rc = htkamd_model_device_tables(m))) return rc;

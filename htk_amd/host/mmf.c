@@ -8,8 +8,10 @@
  * writer SaveHMMSet (:4979) = SaveMacros (:4342: ~o options, then ~t, ~s, ~h macros in hash-table order) with
  * PutStateInfo (:3053), PutMixPDF (:3029), PutTransMat (:2877: rows renormalised in float) and WriteFloat's " %e".
  * Binary definitions (':' + code byte keywords, big-endian numbers: PutSymbol :2581, Token.binForm :505) are read and
- * written as well, shared mixture pdfs (~m) are kept shared (one Gaussian, several components).  Shared mean/variance vectors
- * (~u ~v inside a mixture), stream weights, durations and transforms are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
+ * written as well, shared mixture pdfs (~m) are kept shared (one Gaussian, several components).  Shared mean / variance vectors
+ * (~u / ~v macros referenced inside a mixture, GetMean :1737 / GetVariance :1770) are read, kept (every Gaussian holds its copy of the
+ * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; stream weights, durations and
+ * transforms are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
  */
 #include <ctype.h>
 #include <math.h>
@@ -33,6 +35,9 @@ struct htkamd_mmf {
    mmf_trans *tr; int nTr, capTr; float *tp; int nTp, capTp;       /* tp: LOG transition values */
    mmf_hmm *hm; int nHm, capHm;
    float *varFloor;                                                 /* ~v "varFloor1" or NULL */
+   /* shared vectors: ~u (means) and ~v (variances) macros; gMeanMac/gVarMac[g] = macro of Gaussian g's mean / variance or -1 */
+   struct { char type; char *name; float *v; } *vm; int nVm, capVm;
+   int *gMeanMac, *gVarMac; int capMac;
    /* logical list */
    char **logName; int *logPhys; int nLog;
    /* desc arrays */
@@ -211,6 +216,42 @@ static int find_gauss(const struct htkamd_mmf *s, const char *name)
    return -1;
 }
 
+static int find_vmacro(const struct htkamd_mmf *s, char type, const char *name)
+{
+   for (int i = 0; i < s->nVm; i++) if (s->vm[i].type == type && !strcmp(s->vm[i].name, name)) return i;
+   return -1;
+}
+static void mac_set(struct htkamd_mmf *s, int g, int meanMac, int varMac)
+{
+   if (g + 1 > s->capMac) {
+      const int nc = (g + 1) * 2 + 16;
+      s->gMeanMac = (int *)realloc(s->gMeanMac, sizeof(int) * (size_t)nc);
+      s->gVarMac = (int *)realloc(s->gVarMac, sizeof(int) * (size_t)nc);
+      for (int i = s->capMac; i < nc; i++) { s->gMeanMac[i] = -1; s->gVarMac[i] = -1; }
+      s->capMac = nc;
+   }
+   s->gMeanMac[g] = meanMac; s->gVarMac[g] = varMac;
+}
+/* "<MEAN> n v.." / "<VARIANCE> n v.." inline, or a reference "~u name" / "~v name" to a macro defined earlier */
+static int parse_shared_vector(struct htkamd_mmf *s, rd *r, int k, char type, const char *key, float *dst, int *mac)
+{
+   int rc;
+   *mac = -1;
+   if (k == T_MACRO && r->tok[0] == type) {
+      char *nm;
+      if ((rc = rd_name(r, &nm))) return rc;
+      const int i = find_vmacro(s, type, nm);
+      if (i < 0) { rc = fail(r, type == 'u' ? "undefined ~u macro" : "undefined ~v macro"); free(nm); return rc; }
+      free(nm);
+      memcpy(dst, s->vm[i].v, sizeof(float) * (size_t)s->vecSize);
+      *mac = i;
+      return HTKAMD_OK;
+   }
+   if (k == T_MACRO) return fail(r, "unexpected macro inside a mixture");
+   if (k != T_KEY || strcmp(r->tok, key)) return fail(r, type == 'u' ? "<MEAN> expected" : "<VARIANCE> expected (DIAGC only)");
+   return parse_vector(s, r, dst);
+}
+
 static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
 {
    int rc, k = rd_next(r);
@@ -223,9 +264,7 @@ static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
       *gOut = g;
       return HTKAMD_OK;
    }
-   if (k == T_MACRO) return fail(r, "shared vector macros (~u ~v) inside a mixture are not supported");
    if (k == T_KEY && !strcmp(r->tok, "RCLASS")) { int x; if ((rc = rd_int(r, &x))) return rc; k = rd_next(r); }
-   if (k != T_KEY || strcmp(r->tok, "MEAN")) return fail(r, "<MEAN> expected");
    if (s->vecSize == 0) return fail(r, "<VECSIZE> must precede the first mean");
    GROW(s->gconst, s->nG, s->capG, 1, float);
    { const int cap = s->capG;
@@ -233,11 +272,11 @@ static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
      s->var = (float *)realloc(s->var, sizeof(float) * (size_t)cap * s->vecSize);
      s->hasG = (unsigned char *)realloc(s->hasG, (size_t)cap); }
    const int g = s->nG;
-   if ((rc = parse_vector(s, r, s->mean + (size_t)g * s->vecSize))) return rc;
+   int meanMac, varMac;
+   if ((rc = parse_shared_vector(s, r, k, 'u', "MEAN", s->mean + (size_t)g * s->vecSize, &meanMac))) return rc;
    k = rd_next(r);
-   if (k == T_MACRO) return fail(r, "shared variance macros (~v) inside a mixture are not supported");
-   if (k != T_KEY || strcmp(r->tok, "VARIANCE")) return fail(r, "<VARIANCE> expected (DIAGC only)");
-   if ((rc = parse_vector(s, r, s->var + (size_t)g * s->vecSize))) return rc;
+   if ((rc = parse_shared_vector(s, r, k, 'v', "VARIANCE", s->var + (size_t)g * s->vecSize, &varMac))) return rc;
+   if (meanMac >= 0 || varMac >= 0) mac_set(s, g, meanMac, varMac);
    s->hasG[g] = 0; s->gconst[g] = 0.0f;
    k = rd_next(r);
    if (k == T_KEY && !strcmp(r->tok, "GCONST")) { if ((rc = rd_float(r, s->gconst + g))) return rc; s->hasG[g] = 1; }
@@ -438,13 +477,21 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
          if (find_gauss(s, name) >= 0) { rc = fail(&r, "~m macro defined twice"); free(name); break; }
          if ((rc = parse_mixpdf(s, &r, &g))) { free(name); break; }
          gname_set(s, g, name);
-      } else if (type == 'v') {
-         if (rd_next(&r) != T_KEY || strcmp(r.tok, "VARIANCE")) { rc = fail(&r, "<VARIANCE> expected"); free(name); break; }
-         if (s->vecSize == 0) { rc = fail(&r, "<VECSIZE> must precede ~v"); free(name); break; }
+      } else if (type == 'v' || type == 'u') {
+         const char *key = (type == 'v') ? "VARIANCE" : "MEAN";
+         if (rd_next(&r) != T_KEY || strcmp(r.tok, key)) { rc = fail(&r, type == 'v' ? "<VARIANCE> expected" : "<MEAN> expected"); free(name); break; }
+         if (s->vecSize == 0) { rc = fail(&r, "<VECSIZE> must precede ~u / ~v"); free(name); break; }
+         if (find_vmacro(s, type, name) >= 0) { rc = fail(&r, "~u / ~v macro defined twice"); free(name); break; }
          float *v = (float *)malloc(sizeof(float) * (size_t)s->vecSize);
          if ((rc = parse_vector(s, &r, v))) { free(v); free(name); break; }
-         if (!strncmp(name, "varFloor", 8)) { free(s->varFloor); s->varFloor = v; } else free(v);
-         free(name);
+         if (type == 'v' && !strncmp(name, "varFloor", 8)) {          /* the variance floor macro of HCompV -f: a ~v nobody references */
+            free(s->varFloor);
+            s->varFloor = (float *)malloc(sizeof(float) * (size_t)s->vecSize);
+            memcpy(s->varFloor, v, sizeof(float) * (size_t)s->vecSize);
+         }
+         GROW(s->vm, s->nVm, s->capVm, 1, __typeof__(*s->vm));
+         s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v;
+         s->nVm++;
       } else { rc = fail(&r, "unsupported macro type"); free(name); break; }
    }
    fclose(r.f);
@@ -534,6 +581,21 @@ int htkamd_mmf_logical_phys(const struct htkamd_mmf *s, int i) { return (s && i 
 const char *htkamd_mmf_phys_name(const struct htkamd_mmf *s, int h) { return (s && h >= 0 && h < s->nHm) ? s->hm[h].name : NULL; }
 const char *htkamd_mmf_parm_kind(const struct htkamd_mmf *s) { return s ? s->kind : NULL; }
 const float *htkamd_mmf_var_floor(const struct htkamd_mmf *s) { return s ? s->varFloor : NULL; }
+
+/* Sharing of mean / variance vectors between Gaussians (~u / ~v macros): share[g] = a number that Gaussians with the same vector
+ * have in common, -1 for a private vector.  Returns the number of Gaussians that share something (0: nothing to honour). */
+int htkamd_mmf_sharing(const struct htkamd_mmf *s, int *meanShare, int *varShare)
+{
+   int n = 0;
+   if (!s) return 0;
+   for (int g = 0; g < s->nG; g++) {
+      const int mu = (g < s->capMac) ? s->gMeanMac[g] : -1, va = (g < s->capMac) ? s->gVarMac[g] : -1;
+      if (meanShare) meanShare[g] = mu;
+      if (varShare) varShare[g] = va;
+      if (mu >= 0 || va >= 0) n++;
+   }
+   return n;
+}
 int htkamd_mmf_find_logical(const struct htkamd_mmf *s, const char *name)
 {
    if (!s || !name) return -1;
@@ -552,6 +614,8 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
    free(s->gName);
    free(s->st); free(s->wt); free(s->cg); free(s->mean); free(s->var); free(s->gconst); free(s->hasG); free(s->tr); free(s->tp); free(s->hm);
    free(s->varFloor); free(s->logName); free(s->logPhys);
+   for (int i = 0; i < s->nVm; i++) { free(s->vm[i].name); free(s->vm[i].v); }
+   free(s->vm); free(s->gMeanMac); free(s->gVarMac);
    free(s->stateCompOff); free(s->transN); free(s->transOff); free(s->hmmTrans); free(s->hmmStateOff); free(s->hmmState);
    free(s);
 }
@@ -590,19 +654,25 @@ static void put_vec(FILE *f, const char *key, int code, const float *v, int n)
    for (int i = 0; i < n; i++) put_float(f, v[i]);
    put_nl(f);
 }
+/* PutMixPDF's body (HModel.c:3029): mean and variance inline or as references to their ~u / ~v macros */
+static void put_gauss(const struct htkamd_mmf *s, FILE *f, int g, const float *mean, const float *var, const float *gconst)
+{
+   const int D = s->vecSize;
+   const int mu = (g < s->capMac) ? s->gMeanMac[g] : -1, va = (g < s->capMac) ? s->gVarMac[g] : -1;
+   if (mu >= 0) put_name(f, 'u', s->vm[mu].name); else put_vec(f, "MEAN", 20, mean + (size_t)g * D, D);
+   if (va >= 0) put_name(f, 'v', s->vm[va].name); else put_vec(f, "VARIANCE", 21, var + (size_t)g * D, D);
+   if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
+}
 static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *mean, const float *var, const float *gconst, const float *wt)
 {
    const mmf_state *st = &s->st[si];
-   const int D = s->vecSize;
    if (st->nMix > 1) { put_sym(f, "NUMMIXES", 3); put_short(f, st->nMix); put_nl(f); }
    for (int m = 0; m < st->nMix; m++) {
       const int c = st->comp0 + m, g = s->cg[c];
       if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */
       if (st->nMix > 1) { put_sym(f, "MIXTURE", 17); put_short(f, m + 1); put_float(f, wt[c]); put_nl(f); }
       if (g < s->capGN && s->gName[g]) { put_name(f, 'm', s->gName[g]); continue; }     /* PutMixPDF: macro reference */
-      put_vec(f, "MEAN", 20, mean + (size_t)g * D, D);
-      put_vec(f, "VARIANCE", 21, var + (size_t)g * D, D);
-      if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
+      put_gauss(s, f, g, mean, var, gconst);
    }
 }
 static void put_trans(FILE *f, const float *logp, int N)
@@ -684,9 +754,26 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
       char **names = (char **)malloc(sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + 1));
       int *idx = (int *)malloc(sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + 1));
       int *ord = (int *)malloc(sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + 1));
+      /* atomic macros, one pass over the hash table (SaveMacros :4351-4380): ~u, ~v and ~t interleaved in its order; a shared
+         vector is written with the current value of the first Gaussian that uses it */
+      names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
+      ord = (int *)realloc(ord, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
+      for (int i = 0; i < s->nVm; i++) { names[nN] = s->vm[i].name; idx[nN++] = -1 - i; }
       for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { names[nN] = s->tr[t].name; idx[nN++] = t; }
       macro_order(names, nN, ord);
-      for (int k = 0; k < nN; k++) { const int t = idx[ord[k]]; put_name(f, 't', s->tr[t].name); put_trans(f, transP + s->tr[t].off, s->tr[t].N); }
+      for (int k = 0; k < nN; k++) {
+         const int t = idx[ord[k]];
+         if (t >= 0) { put_name(f, 't', s->tr[t].name); put_trans(f, transP + s->tr[t].off, s->tr[t].N); continue; }
+         const int i = -1 - t;
+         const float *v = s->vm[i].v;
+         for (int g = 0; g < s->nG && g < s->capMac; g++) {
+            if (s->vm[i].type == 'u' && s->gMeanMac[g] == i) { v = mean + (size_t)g * s->vecSize; break; }
+            if (s->vm[i].type == 'v' && s->gVarMac[g] == i) { v = var + (size_t)g * s->vecSize; break; }
+         }
+         put_name(f, s->vm[i].type, s->vm[i].name);
+         if (s->vm[i].type == 'u') put_vec(f, "MEAN", 20, v, s->vecSize); else put_vec(f, "VARIANCE", 21, v, s->vecSize);
+      }
       nN = 0;                                                  /* ~m macros come after the atomic ones, before the states */
       names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
       idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
@@ -696,9 +783,7 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
       for (int k = 0; k < nN; k++) {
          const int g = idx[ord[k]];
          put_name(f, 'm', s->gName[g]);
-         put_vec(f, "MEAN", 20, mean + (size_t)g * s->vecSize, s->vecSize);
-         put_vec(f, "VARIANCE", 21, var + (size_t)g * s->vecSize, s->vecSize);
-         if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
+         put_gauss(s, f, g, mean, var, gconst);
       }
       nN = 0;
       for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { names[nN] = s->st[i].name; idx[nN++] = i; }
@@ -716,6 +801,7 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
    for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { htkamd_set_error("mmf_write: a set with ~s macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { htkamd_set_error("mmf_write: a set with ~t macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g]) { htkamd_set_error("mmf_write: a set with ~m macros must be written to one file"); return HTKAMD_EINVAL; }
+   if (s->nVm > (s->varFloor ? 1 : 0)) { htkamd_set_error("mmf_write: a set with ~u / ~v macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int h = 0; h < s->nHm; h++) {
       char path[1400];
       snprintf(path, sizeof(path), "%s/%s", dir, s->hm[h].name);

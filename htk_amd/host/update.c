@@ -10,6 +10,10 @@
  *   FixGConsts    HModel.c:5688-5714
  *   MLUpdateModels HERest.c:1262-1321 models with fewer than minEgs examples are left alone; a shared
  *                 structure (tied state, Gaussian, transP) is updated by the first model that qualifies.
+ * Tied mean / variance vectors (~u / ~v; htkamd_model_set_sharing): the reference hangs ONE MuAcc / VaAcc on a shared vector, so the
+ * statistics of its users are pooled (here: summed into the group's first Gaussian before the update), the vector is updated by the
+ * first mixture that reaches it, a variance with several users gets no mean-shift correction (`shared`, HERest.c:1080), and a private
+ * variance whose tied mean was already moved by an earlier model gets none either (its MuAcc hook is gone by then).
  * singleProcess mirrors parMode == -1 (HERest.c:1336-1339): the set went through ConvDiagC/ConvLogWt before
  * the pass, so parameters that are not re-estimated come back through ForceDiagC/ConvExpWt float round trips.
  */
@@ -31,6 +35,26 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
    doneS = (unsigned char *)calloc((size_t)m->S, 1);
    doneMu = (unsigned char *)calloc((size_t)m->G, 1);
    doneVa = (unsigned char *)calloc((size_t)m->G, 1);
+   const int *mL = m->h_meanLeader, *vL = m->h_varLeader;
+   double *pool = NULL;
+   if (mL) {                                            /* one accumulator per shared vector */
+      int g;
+      pool = (double *)malloc(sizeof(double) * lay->total);
+      memcpy(pool, acc, sizeof(double) * lay->total);
+      for (g = 0; g < m->G; g++) {
+         if (mL[g] != g) {
+            for (k = 0; k < D; k++) pool[lay->mu + (size_t)mL[g] * D + k] += acc[lay->mu + (size_t)g * D + k];
+            pool[lay->muOcc + mL[g]] += acc[lay->muOcc + g];
+         }
+         if (vL[g] != g) {
+            for (k = 0; k < D; k++) pool[lay->va + (size_t)vL[g] * D + k] += acc[lay->va + (size_t)g * D + k];
+            pool[lay->vaOcc + vL[g]] += acc[lay->vaOcc + g];
+         }
+      }
+      acc = pool;
+   }
+#define ML(g) (mL ? mL[g] : (g))
+#define VL(g) (vL ? vL[g] : (g))
 #define ACCF(off, idx) ((float)acc[(off) + (size_t)(idx)])
    if (cfg->singleProcess) {
       /* the conversions walk the set with an HMM scan: a state macro that no model uses keeps its values */
@@ -115,15 +139,15 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             const int s = hs[j];
             for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
                if (wgt[c] > MINMIX) {
-                  const int g = m->h_compGauss[c];
+                  const int g0 = m->h_compGauss[c], g = VL(g0), gm = ML(g0);
                   if (!doneVa[g]) {
                      const float occim = ACCF(lay->vaOcc, g);
                      int mixFloored = 0;
                      if (occim > 0.0) {
-                        const float muOcc = ACCF(lay->muOcc, g);
-                        const int shared = ((cfg->uFlags & HTKAMD_UPMEANS) == 0 || doneMu[g] || muOcc <= 0.0);
+                        const float muOcc = ACCF(lay->muOcc, gm);
+                        const int shared = ((cfg->uFlags & HTKAMD_UPMEANS) == 0 || doneMu[gm] || muOcc <= 0.0 || (vL && m->h_varGroupSize[g] > 1));
                         for (k = 0; k < D; k++) {
-                           const float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)g * D + k) / muOcc;
+                           const float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)gm * D + k) / muOcc;
                            float x = ACCF(lay->va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
                            const float fl = cfg->varFloor ? cfg->varFloor[k] : cfg->minVar;
                            if (x < fl) { x = fl; st->nFloorVar++; mixFloored = 1; }
@@ -140,7 +164,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             const int s = hs[j];
             for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
                if (wgt[c] > MINMIX) {
-                  const int g = m->h_compGauss[c];
+                  const int g = ML(m->h_compGauss[c]);
                   if (!doneMu[g]) {
                      const float occim = ACCF(lay->muOcc, g);
                      if (occim > 0.0)
@@ -155,11 +179,21 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
                if (wgt[c] > MINMIX) {
                   const int g = m->h_compGauss[c];
-                  htkamd_host_fix_diag_gconst(D, var + (size_t)g * D, gconst + g);
+                  htkamd_host_fix_diag_gconst(D, var + (size_t)VL(g) * D, gconst + g);
                }
          }
    }
 #undef ACCF
+   if (mL) {                                            /* every user of a shared vector sees its new value */
+      int g;
+      for (g = 0; g < m->G; g++) {
+         if (mL[g] != g) memcpy(mean + (size_t)g * D, mean + (size_t)mL[g] * D, sizeof(float) * (size_t)D);
+         if (vL[g] != g) memcpy(var + (size_t)g * D, var + (size_t)vL[g] * D, sizeof(float) * (size_t)D);
+      }
+   }
+#undef ML
+#undef VL
+   free(pool);
    free(doneT); free(doneS); free(doneMu); free(doneVa);
    if (st->nWeightAboveOne > 0) {
       htkamd_set_error("update_models: %d mixture weights above 1.001 (HERest: HError 2393): corrupt accumulators?", st->nWeightAboveOne);

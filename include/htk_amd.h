@@ -90,6 +90,13 @@ typedef struct {
 typedef struct htkamd_model htkamd_model;
 
 int  htkamd_model_create(const htkamd_model_desc *desc, htkamd_model **out);
+/* Tied mean / variance vectors (~u / ~v macros: SVector with nUse > 1, HModel.c:1737-1790).  meanShare[g] / varShare[g] >= 0 name the
+ * vector Gaussian g's mean / variance is a copy of (-1 = private; either array may be NULL); htkamd_mmf_sharing gives them for a set
+ * read from files.  Scoring and the statistics are per Gaussian as always; htkamd_model_update pools the statistics of the sharers
+ * as the reference's hooks on the shared vector do (one MuAcc / VaAcc per vector; a tied variance gets no mean-shift correction,
+ * HERest.c:1080) and keeps the copies equal.  htkamd_model_update_device refuses such a set (HTKAMD_EMODEL). */
+int  htkamd_model_set_sharing(htkamd_model *m, const int *meanShare /*[G]*/, const int *varShare /*[G]*/);
+int  htkamd_model_has_sharing(const htkamd_model *m);
 void htkamd_model_destroy(htkamd_model *m);
 /* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */
 int  htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,
@@ -133,6 +140,7 @@ int  htkamd_mmf_find_logical(const htkamd_mmf *s, const char *name);     /* phys
 const char *htkamd_mmf_phys_name(const htkamd_mmf *s, int h);
 const char *htkamd_mmf_parm_kind(const htkamd_mmf *s);                   /* e.g. "MFCC_E_D" */
 const float *htkamd_mmf_var_floor(const htkamd_mmf *s);                  /* ~v "varFloor1" [vecSize] or NULL */
+int  htkamd_mmf_sharing(const htkamd_mmf *s, int *meanShare /*[numGauss]*/, int *varShare /*[numGauss]*/);   /* ~u / ~v macros; returns the number of Gaussians sharing a vector */
 int  htkamd_mmf_write(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
                       const float *transP, const char *oneFile, const char *dir);
 /* the same in HTK's binary form (SaveHMMSet with binary = TRUE, HERest/HHEd -B); htkamd_mmf_read takes either form */
@@ -544,6 +552,17 @@ typedef struct {
 } htkamd_parm_quals;
 int  htkamd_parm_quals_cols(const htkamd_parm_quals *q);
 int  htkamd_parm_qualify(const float *dStatic, const int *frameOff, int nUtt, const htkamd_parm_quals *q, float *dOut, void *stream);
+/* The same qualifiers in HParm's BUFFER mode (OpenBuffer / ReadAsBuffer, HParm.c:4000-4116 FillBufFromChannel; HVite.c:664 opens its
+   input this way): static rows arrive in pushes, an observation is handed out as soon as the qwin = DELTAWINDOW + ACCWINDOW
+   (+ THIRDWINDOW) rows of look-ahead its regression windows need have arrived; the last push (last = 1) flushes the remaining rows
+   with the end-of-utterance replication.  The rows handed out are bit-identical to htkamd_parm_qualify over the whole utterance.
+   _Z is refused (it needs the whole utterance: table mode), as HParm refuses ENORMALISE on a live buffer (HParm.c:4096).
+     open : maxRows = the largest push;   push : dStatic [nRows x nStat] on the device, dOut receives *nOut <= nRows + qwin rows. */
+typedef struct htkamd_parm_stream htkamd_parm_stream;
+int  htkamd_parm_stream_open(const htkamd_parm_quals *q, int maxRows, htkamd_parm_stream **out);
+int  htkamd_parm_stream_push(htkamd_parm_stream *s, const float *dStatic, int nRows, int last, float *dOut, int *nOut, void *stream);
+int  htkamd_parm_stream_lookahead(const htkamd_parm_stream *s);
+void htkamd_parm_stream_close(htkamd_parm_stream *s);
 /* HCompV's global statistics over a device table of frames: replaces AccVar / CalcCovs (HTKTools/HCompV.c:392-411, :261-291) --
    mean and diagonal variance of all frames, variance floored at minVar (HCompV -v, default 0).  The reference sums in float in
    file order; this sums in fp64 (order-free), so the results agree to the reference's own rounding (~1e-6 relative at a few

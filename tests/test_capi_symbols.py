@@ -46,6 +46,18 @@ def test_fails_loudly_without_a_device(native):
     assert "no HIP device" in str(e.value)
 
 
+def test_parm_stream_argument_checks(native):
+    """Buffer-mode qualifiers: _Z is refused (needs the whole utterance), and without a device the open fails loudly."""
+    q = native.parm_quals_from_kind("MFCC_E_D_A_Z", 13)
+    with pytest.raises(native.HtkAmdError) as e:
+        native.ParmStream(q, 16)
+    assert "_Z" in str(e.value)
+    if native.lib().htkamd_device_count() == 0:
+        with pytest.raises(native.HtkAmdError) as e:
+            native.ParmStream(native.parm_quals_from_kind("MFCC_E_D_A", 13), 16)
+        assert "no HIP device" in str(e.value)
+
+
 def test_bad_arguments_are_rejected(native):
     L = native.lib()
     assert L.htkamd_model_create(None, None) == -1

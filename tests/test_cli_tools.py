@@ -94,6 +94,40 @@ def test_herest_cli_parallel_mode_dump_and_merge(tools, tmp_path):
     _same_models(str(out), os.path.join(DEMO, "hmm2_expected"))
 
 
+def _mmf_numbers(path):
+    """All tokens of an MMF; numbers as floats, everything else as text."""
+    out = []
+    for t in open(path).read().split():
+        try:
+            out.append(float(t))
+        except ValueError:
+            out.append(t)
+    return out
+
+
+@pytest.mark.gpu
+def test_herest_cli_tied_mean_and_variance_vectors(tools, tmp_path):
+    """A set with ~u / ~v macros (HHEd TI on means and variances, tests/golden/make_tied_golden.py) through one pass: the statistics of
+    the users of a vector are pooled, a tied variance gets no mean-shift term, every user keeps the shared value (UpdateVars /
+    UpdateMeans HERest.c:974-1122) -- the MMF equals the one the reference's HERest wrote, macros included."""
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "next"; out.mkdir()
+    tied = os.path.join(DEMO, "hmm_tied")
+    r = run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(tied, "newMacros"), "-M", str(out),
+             "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0, r.stderr
+    for line in open(os.path.join(tied, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-400:])
+    ours, theirs = _mmf_numbers(str(out / "newMacros")), _mmf_numbers(os.path.join(tied, "after_herest"))
+    assert len(ours) == len(theirs)
+    for x, y in zip(ours, theirs):
+        if isinstance(y, float):
+            assert isinstance(x, float) and abs(x - y) <= 2e-4 * max(abs(y), 1e-3), (x, y)
+        else:
+            assert x == y
+    assert open(str(out / "newMacros")).read().count('~v "vCL"') == 5 and open(str(out / "newMacros")).read().count('~u "uSV"') == 3
+
+
 @pytest.mark.gpu
 def test_hvite_cli_recognises_the_demo_sets(tools, tmp_path):
     expected = json.load(open(os.path.join(DEMO, "hvite_expected.json")))

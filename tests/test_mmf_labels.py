@@ -196,3 +196,28 @@ def test_label_writer_columns_and_flags(native, tmp_path):
     assert (tmp_path / "o.mlf").read_text() == '#!MLF!#\n"*/x.rec"\np1\np2\n\'"odd\'\n.\n'
     back = native.Mlf(str(tmp_path / "o.mlf")).find("dir/x.rec")
     assert [l[0] for l in back] == ["p1", "p2", '"odd']
+
+
+def test_mmf_shared_mean_and_variance_macros(native, tmp_path):
+    """~u / ~v macros (GetMean / GetVariance HModel.c:1737-1790, SaveMacros :4342): the set HHEd tied (tests/golden/make_tied_golden.py)
+    reads with every user of a vector holding its values and naming its macro, and is written back byte for byte."""
+    d = os.path.join(GOLD, "demo")
+    src = os.path.join(d, "hmm_tied", "newMacros")
+    m = native.Mmf(files=[src], hmm_list=os.path.join(d, "bcplist"))
+    q = m.packed()
+    ms, vs = m.sharing()
+    assert (ms >= 0).sum() == 2 and (vs >= 0).sum() == 4 + 3              # uSV: 2 means; vCL: 4 variances, vN: 3
+    for share, vec in ((ms, q["mean"]), (vs, q["var"])):
+        for k in set(share[share >= 0]):
+            rows = vec[share == k]
+            assert len(rows) > 1 and (rows == rows[0]).all()
+    params = dict(mean=q["mean"], var=q["var"], gconst=q["gconst"], compWeight=q["compWeight"], transP=q["transP"])
+    out = tmp_path / "tied.mmf"
+    m.write(params, one_file=str(out))
+    assert out.read_bytes() == open(src, "rb").read()
+    # an unknown macro is an error, not a silent private copy
+    bad = tmp_path / "bad.mmf"
+    bad.write_text(open(src).read().replace('~u "uSV"\n<MEAN>', '~u "other"\n<MEAN>', 1))
+    with pytest.raises(native.HtkAmdError) as e:
+        native.Mmf(files=[str(bad)], hmm_list=os.path.join(d, "bcplist"))
+    assert "undefined ~u macro" in str(e.value)

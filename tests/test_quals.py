@@ -116,3 +116,26 @@ def test_device_qualify_rejects(native):
                 capi.ParmQuals(13, 14, 1, 0, 0, 2, 2, 2, -1, 0, 0)):    # more zero-mean columns than statics
         with pytest.raises(capi.HtkAmdError):
             capi.parm_qualify(x, bad)
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,kw", [("MFCC_E_D_A", {}), ("MFCC_E_D_A_T", dict(delWin=3, accWin=2, thirdWin=1)), ("MFCC_0_D_N", dict(delWin=2)), ("MFCC_E_D", dict(simpleDiffs=True))])
+def test_parm_stream_equals_table_mode(native, oracle, kind, kw):
+    """HParm's buffer mode (FillBufFromChannel HParm.c:4000-4116): rows pushed in ragged chunks come out, qwin rows late, with exactly the
+    values of the table-mode qualifier step over the whole utterance (and of the oracle), incl. utterances shorter than the windows."""
+    rng = np.random.default_rng(11)
+    for T in (1, 2, 5, 37, 211):
+        X = rng.normal(size=(T, 13)).astype(np.float32)
+        q = native.parm_quals_from_kind(kind, 13, **kw)
+        d, frameOff, cols = native.parm_qualify([X], q)
+        table = d.to_host(np.float32, (T, cols))
+        st = native.ParmStream(q, 32)
+        out, pos = [], 0
+        while pos < T:
+            n = int(rng.integers(0, 33))
+            n = min(n, T - pos)
+            out.append(st.push(X[pos:pos + n], last=(pos + n == T)))
+            pos += n
+            if pos < T:
+                assert sum(len(o) for o in out) == max(pos - st.lookahead, 0)
+        got = np.concatenate(out)
+        assert got.shape == table.shape and np.array_equal(got, table), (kind, T)
+        st.close()

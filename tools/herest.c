@@ -115,6 +115,11 @@ int main(int argc, char **argv)
    const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
    const int D = d->vecSize, H = d->numPhys;
    htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   {  /* tied mean / variance vectors (~u ~v macros) */
+      int *ms = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1)), *vs = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1));
+      if (htkamd_mmf_sharing(mmf, ms, vs) > 0) CHECK(htkamd_model_set_sharing(model, ms, vs));
+      free(ms); free(vs);
+   }
    htkamd_accs *accs; CHECK(htkamd_accs_create(model, &accs));
    htkamd_accs_layout lay; CHECK(htkamd_accs_get_layout(accs, &lay));
    double *vec = (double *)calloc(lay.total, sizeof(double));
@@ -204,6 +209,8 @@ int main(int argc, char **argv)
       if (mlf) htkamd_mlf_free(mlf);
    }
 
+   if (htkamd_model_has_sharing(model) && parMode >= 0)
+      DIE("tied mean / variance vectors (~u ~v) are not supported in the accumulator files of parallel mode (-p)");
    if (parMode > 0) {
       char fn[2048];
       snprintf(fn, sizeof(fn), "%s/HER%d.acc", outDir ? outDir : ".", parMode);
@@ -218,7 +225,9 @@ int main(int argc, char **argv)
    uc.minEgs = minEgs; uc.minVar = minVar; uc.mixWeightFloor = mixFloor; uc.uFlags = uFlags; uc.varFloor = htkamd_mmf_var_floor(mmf);
    uc.singleProcess = (parMode == -1);
    htkamd_update_stats us;
-   CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
+   if (htkamd_model_has_sharing(model)) {
+      CHECK(htkamd_model_update(model, accs, vec, &uc, &us));         /* pooled statistics of the tied vectors: host update */
+   } else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
    if (us.nSkippedHmm > 0) fprintf(stderr, "WARNING [-2331] UpdateModels: %d models had fewer than %d examples and were copied\n", us.nSkippedHmm, minEgs);
    if (rank == 0) {
       float *mean = (float *)malloc(sizeof(float) * (size_t)d->numGauss * D), *var = (float *)malloc(sizeof(float) * (size_t)d->numGauss * D);
