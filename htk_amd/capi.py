@@ -796,6 +796,9 @@ class Mlf:
             pass
 
 
+NET_ALLOWXWRDEXP, NET_FORCECXTEXP, NET_FORCELEFTBI, NET_FORCERIGHTBI = 1, 2, 4, 8
+
+
 class NetDesc(C.Structure):
     _fields_ = [("nNodes", C.c_int), ("nLinks", C.c_int), ("nProns", C.c_int), ("initial", C.c_int), ("final", C.c_int),
                 ("kind", C.c_void_p), ("model", C.c_void_p), ("pronProb", C.c_void_p),
@@ -805,14 +808,16 @@ class NetDesc(C.Structure):
 class Net:
     """htkamd_net holder: SLF word network + dictionary expanded over a model set (htk_amd/host/net.c)."""
 
-    def __init__(self, slf: str | None, dictionary: str, mmf: "Mmf", words=None, boundary: str | None = None):
-        """slf: word lattice file; or slf=None and words=[...]: the alignment network of HVite -a for that transcription."""
+    def __init__(self, slf: str | None, dictionary: str, mmf: "Mmf", words=None, boundary: str | None = None, flags: int = 0):
+        """slf: word lattice file; or slf=None and words=[...]: the alignment network of HVite -a for that transcription.
+        flags: NET_ALLOWXWRDEXP | NET_FORCECXTEXP | ... (HNet's configuration switches; cross-word context expansion)."""
         L = lib()
+        self._mmf = mmf                                    # a cross-word network names models through the set it was built on
         L.htkamd_net_get.restype = C.POINTER(NetDesc)
         L.htkamd_net_out_sym.restype = C.c_char_p
         self.h = C.c_void_p()
         if slf is not None:
-            check(L.htkamd_net_build(slf.encode(), dictionary.encode(), mmf.h, C.byref(self.h)), "net_build")
+            check(L.htkamd_net_build_ex(slf.encode(), dictionary.encode(), mmf.h, C.c_int(flags), C.byref(self.h)), "net_build")
         else:
             arr = (C.c_char_p * len(words))(*[w.encode() for w in words])
             check(L.htkamd_net_build_words(arr, C.c_int(len(words)), boundary.encode() if boundary else None, dictionary.encode(),
@@ -821,11 +826,27 @@ class Net:
         self.out_syms = [L.htkamd_net_out_sym(self.h, C.c_int(k)).decode() for k in range(self.desc.nProns)]
         L.htkamd_net_word_name.restype = C.c_char_p
         self.word_names = [L.htkamd_net_word_name(self.h, C.c_int(k)).decode() for k in range(self.desc.nProns)]
+        self.xwrd = bool(L.htkamd_net_is_xwrd(self.h))
         self.pron_models = []
         buf = (C.c_int * 256)()
         for k in range(self.desc.nProns):
             n = L.htkamd_net_pron_models(self.h, C.c_int(k), buf, C.c_int(256))
             self.pron_models.append([int(buf[i]) for i in range(min(n, 256))])
+
+    def seq_models(self, prons):
+        """Physical models of a recognised pronunciation sequence, word by word (cross-word contexts applied between neighbours)."""
+        L = lib()
+        buf = (C.c_int * 256)()
+        real = [k for k in prons]
+        out = []
+        for i, k in enumerate(real):
+            prev = next((real[j] for j in range(i - 1, -1, -1) if self.pron_models[real[j]]), -1)
+            nxt = next((real[j] for j in range(i + 1, len(real)) if self.pron_models[real[j]]), -1)
+            n = L.htkamd_net_seq_models(self.h, C.c_int(k), C.c_int(prev), C.c_int(nxt), buf, C.c_int(256))
+            if n < 0:
+                raise HtkAmdError("net_seq_models: " + L.htkamd_last_error().decode())
+            out.append([int(buf[j]) for j in range(min(n, 256))])
+        return out
 
     def arrays(self) -> dict:
         d = self.desc

@@ -10,7 +10,9 @@
  * all final ones (AddInitialFinal :2180).  Node kinds: HMM (emits, unless its model is a tee model: a_1N > LSMALL),
  * WORD (word end of a real pronunciation: adds the word penalty and pron prob, starts a path record), NULL (passes tokens).
  * When the dictionary is written in phones that are not all model names, pronunciations are expanded word-internally into
- * context-dependent models (resolve_models below).  Sub-lattices, tags and cross-word context expansion are out of this row's scope.
+ * context-dependent models (resolve_models below).  With ALLOWXWRDEXP (htkamd_net_build_ex) the expansion is CROSS-WORD (xc > 0 in
+ * ExpandWordNet: CreateX1Model :2773, CreateXEModels :3141, ProcessCrossWordLinks :2559, SetNullContexts :2514) -- expand_xwrd below.
+ * Sub-lattices and tags are out of this row's scope.
  */
 #include <ctype.h>
 #include <math.h>
@@ -27,6 +29,12 @@ struct htkamd_net {
    float *pronProb, *linkLike;
    char **wordName; int nWordNames;
    dpron *pron; int nPron;
+   /* cross-word expansion: the contexts and what is needed to name the models of a pronunciation between two neighbours */
+   int xwrd, flags;
+   const struct htkamd_mmf *hmms;             /* must outlive the network when xwrd != 0 */
+   char **cxName; int nCx;                    /* context c (1-based) = cxName[c-1] */
+   char **depName; int nDep;                  /* base names that have context-dependent models */
+   int sLeft, sRight;
 };
 
 static char *rd_word(char **pp)
@@ -70,13 +78,60 @@ static void set_add(strset *s, const char *x)
 }
 static void set_free(strset *s) { for (int i = 0; i < s->n; i++) free(s->v[i]); free(s->v); }
 
-static int resolve_models(dpron *pr, int nPr, const struct htkamd_mmf *hmms, const char *dictPath)
+/* HMMSetCxtInfo (DefineContexts HNet.c:1892): the phones that appear as somebody's left / right context, the base names that have
+ * context-dependent models, and whether any model carries a left / a right context at all */
+typedef struct { strset cxs, dep; int sLeft, sRight; } hci_t;
+static void hci_define(hci_t *h, const struct htkamd_mmf *hmms)
+{
+   char buf[1600], base[512];
+   const int nLog = htkamd_mmf_num_logical(hmms);
+   memset(h, 0, sizeof(*h));
+   for (int i = 0; i < nLog; i++) {
+      const char *nm = htkamd_mmf_logical_name(hmms, i);
+      const char *mi = strchr(nm, '-'), *pl = strchr(nm, '+');
+      if (mi) { snprintf(buf, sizeof(buf), "%.*s", (int)(mi - nm), nm); set_add(&h->cxs, buf); h->sLeft = 1; }
+      if (pl) { set_add(&h->cxs, pl + 1); h->sRight = 1; }
+      if (mi || pl) { tri_strip(nm, base, sizeof(base)); set_add(&h->dep, base); }
+   }
+}
+static void hci_free(hci_t *h) { set_free(&h->cxs); set_free(&h->dep); }
+/* GetHCIContext (HNet.c:1817) with cross-word contexts on: 1-based context number of a phone, -1 = context free */
+static int hci_context(const strset *cxs, const char *phone)
+{
+   char base[512];
+   tri_strip(phone, base, sizeof(base));
+   for (int i = 0; i < cxs->n; i++) if (!strcmp(cxs->v[i], base)) return i + 1;
+   return -1;
+}
+/* FindModel (HNet.c:2052): the model for `name` between the contexts lc and rc (1-based numbers, <= 0: none); -1 if there is none */
+static int find_model_ctx(const struct htkamd_mmf *hmms, const strset *cxs, const strset *dep, int sLeft, int sRight, int flags,
+                          int lc, const char *name, int rc, char *tried, size_t nTried)
+{
+   char buf[1600];
+   const int forceCxt = (flags & HTKAMD_NET_FORCECXTEXP) != 0, forceL = (flags & HTKAMD_NET_FORCELEFTBI) != 0, forceR = (flags & HTKAMD_NET_FORCERIGHTBI) != 0;
+   const int ci = !set_has(dep, name);                      /* IsHCIContextInd: only the bare model exists */
+   if ((lc <= 0 && rc <= 0) || ci) snprintf(buf, sizeof(buf), "%s", name);
+   else if ((lc <= 0 || forceR || !sLeft) && rc > 0 && !forceL) snprintf(buf, sizeof(buf), "%s+%s", name, cxs->v[rc - 1]);
+   else if ((rc <= 0 || forceL || !sRight) && lc > 0 && !forceR) snprintf(buf, sizeof(buf), "%s-%s", cxs->v[lc - 1], name);
+   else if (!forceL && !forceR) snprintf(buf, sizeof(buf), "%s-%s+%s", cxs->v[lc - 1], name, cxs->v[rc - 1]);
+   else snprintf(buf, sizeof(buf), "%s", name);
+   int h = htkamd_mmf_find_logical(hmms, buf);
+   if (h < 0 && (((lc <= 0 && rc <= 0) || !forceCxt) || (lc <= 0 || !forceL) || (rc <= 0 || !forceR)))
+      h = htkamd_mmf_find_logical(hmms, name);              /* "then try the name itself" */
+   if (tried) snprintf(tried, nTried, "%s", buf);
+   return h;
+}
+
+/* *xwrd (may be NULL) comes back 1 when the network has to be expanded with cross-word contexts (ExpandWordNet HNet.c:3458-3478) */
+static int resolve_models(dpron *pr, int nPr, const struct htkamd_mmf *hmms, const char *dictPath, int flags, int *xwrd)
 {
    int closed = 1;
+   const int force = (flags & (HTKAMD_NET_FORCECXTEXP | HTKAMD_NET_FORCELEFTBI | HTKAMD_NET_FORCERIGHTBI)) != 0;
+   if (xwrd) *xwrd = 0;
    for (int k = 0; k < nPr && closed; k++)
       for (int q = 0; q < pr[k].nPhones; q++)
          if (htkamd_mmf_find_logical(hmms, pr[k].phoneName[q]) < 0) { closed = 0; break; }
-   if (closed) {
+   if (closed && !force) {
       for (int k = 0; k < nPr; k++)
          for (int q = 0; q < pr[k].nPhones; q++) pr[k].phone[q] = htkamd_mmf_find_logical(hmms, pr[k].phoneName[q]);
       return HTKAMD_OK;
@@ -93,7 +148,8 @@ static int resolve_models(dpron *pr, int nPr, const struct htkamd_mmf *hmms, con
       if (pl) { set_add(&cxs, pl + 1); sRight = 1; }
       if (mi || pl) { tri_strip(nm, base, sizeof(base)); set_add(&dep, base); }
    }
-   int rc = HTKAMD_OK;
+   int rc = HTKAMD_OK, internal = 1;
+   const int allowX = (flags & HTKAMD_NET_ALLOWXWRDEXP) != 0 && cxs.n > 0;
    for (int k = 0; k < nPr && !rc; k++) {
       dpron *d = &pr[k];
       for (int q = 0; q < d->nPhones && !rc; q++) {
@@ -112,15 +168,18 @@ static int resolve_models(dpron *pr, int nPr, const struct htkamd_mmf *hmms, con
          else snprintf(buf, sizeof(buf), "%s-%s+%s", lcs, nm, rcs);
          int h = htkamd_mmf_find_logical(hmms, buf);
          if (h < 0) h = htkamd_mmf_find_logical(hmms, nm);      /* "then try the name itself" */
-         if (h < 0) { htkamd_set_error("%s: word %s: no model %s (nor %s) in the model set", dictPath, d->word, buf, nm); rc = HTKAMD_EMODEL; }
+         if (h < 0 && allowX) internal = 0;                     /* InternalDict (HNet.c:2142) fails: cross-word models are needed */
+         else if (h < 0) { htkamd_set_error("%s: word %s: no model %s (nor %s) in the model set", dictPath, d->word, buf, nm); rc = HTKAMD_EMODEL; }
          d->phone[q] = h;
       }
    }
+   if (!rc && allowX && (force || !internal) && xwrd) *xwrd = 1;
+   else if (!rc && !internal) { htkamd_set_error("%s: the dictionary needs cross-word models", dictPath); rc = HTKAMD_EMODEL; }
    set_free(&cxs); set_free(&dep);
    return rc;
 }
 
-static int read_dict(const char *path, const struct htkamd_mmf *hmms, dpron **out, int *nOut)
+static int read_dict(const char *path, const struct htkamd_mmf *hmms, int flags, int *xwrd, dpron **out, int *nOut)
 {
    FILE *f = fopen(path, "r");
    if (!f) { htkamd_set_error("net_build: cannot open dictionary %s", path); return HTKAMD_EIO; }
@@ -163,7 +222,7 @@ static int read_dict(const char *path, const struct htkamd_mmf *hmms, dpron **ou
    }
    fclose(f);
    *out = pr; *nOut = n;
-   return resolve_models(pr, n, hmms, path);
+   return resolve_models(pr, n, hmms, path, flags, xwrd);
 }
 
 typedef struct { char *word; int var; } lnode;
@@ -251,23 +310,33 @@ void htkamd_net_destroy(struct htkamd_net *n)
       free(n->pron[i].phoneName); free(n->pron[i].word); free(n->pron[i].outSym); free(n->pron[i].phone);
    }
    free(n->pron);
+   for (int i = 0; i < n->nCx; i++) free(n->cxName[i]);
+   for (int i = 0; i < n->nDep; i++) free(n->depName[i]);
+   free(n->cxName); free(n->depName);
    free(n);
 }
 
 typedef struct { int from, to; float like; } tlink;
 
-static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, const htkamd_model_desc *md, struct htkamd_net **out);
+typedef struct { const struct htkamd_mmf *hmms; int flags; } xwrd_t;
+static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, const htkamd_model_desc *md, const xwrd_t *xw, struct htkamd_net **out);
 
-int htkamd_net_build(const char *slfPath, const char *dictPath, const struct htkamd_mmf *hmms, struct htkamd_net **out)
+int htkamd_net_build_ex(const char *slfPath, const char *dictPath, const struct htkamd_mmf *hmms, int flags, struct htkamd_net **out)
 {
    if (!slfPath || !dictPath || !hmms || !out) { htkamd_set_error("net_build: NULL argument"); return HTKAMD_EINVAL; }
    const htkamd_model_desc *md = htkamd_mmf_desc(hmms);
    if (!md) { htkamd_set_error("net_build: model set not finished"); return HTKAMD_EINVAL; }
-   dpron *pr = NULL; int nPr = 0, rc;
-   if ((rc = read_dict(dictPath, hmms, &pr, &nPr))) return rc;
+   dpron *pr = NULL; int nPr = 0, rc, xwrd = 0;
+   if ((rc = read_dict(dictPath, hmms, flags, &xwrd, &pr, &nPr))) return rc;
    lnode *ln = NULL; larc *la = NULL; int NN = 0, NA = 0;
    if ((rc = read_slf(slfPath, &ln, &NN, &la, &NA))) return rc;
-   return expand_lattice(ln, NN, la, NA, pr, nPr, slfPath, dictPath, md, out);
+   xwrd_t xw; xw.hmms = hmms; xw.flags = flags;
+   return expand_lattice(ln, NN, la, NA, pr, nPr, slfPath, dictPath, md, xwrd ? &xw : NULL, out);
+}
+
+int htkamd_net_build(const char *slfPath, const char *dictPath, const struct htkamd_mmf *hmms, struct htkamd_net **out)
+{
+   return htkamd_net_build_ex(slfPath, dictPath, hmms, 0, out);
 }
 
 /* The alignment network of HVite -a (DoAlignment HVite.c:830): LatticeFromLabels (HNet.c:1516) makes the word-level transcription a
@@ -279,7 +348,7 @@ int htkamd_net_build_words(const char *const *words, int nWords, const char *bou
    if (!words || nWords <= 0 || !dictPath || !hmms || !out) { htkamd_set_error("net_build_words: bad argument"); return HTKAMD_EINVAL; }
    if (!htkamd_mmf_desc(hmms)) { htkamd_set_error("net_build_words: model set not finished"); return HTKAMD_EINVAL; }
    dpron *pr = NULL; int nPr = 0, rc;
-   if ((rc = read_dict(dictPath, hmms, &pr, &nPr))) return rc;
+   if ((rc = read_dict(dictPath, hmms, 0, NULL, &pr, &nPr))) return rc;
    const int NN = nWords + (boundary ? 2 : 0), NA = NN - 1;
    lnode *ln = (lnode *)calloc((size_t)NN, sizeof(lnode));
    larc *la = (larc *)calloc((size_t)(NA ? NA : 1), sizeof(larc));
@@ -288,10 +357,10 @@ int htkamd_net_build_words(const char *const *words, int nWords, const char *bou
       ln[i].word = strdup(w ? w : "!NULL");
       if (i > 0) { la[i - 1].s = i - 1; la[i - 1].e = i; la[i - 1].l = 0.0f; }
    }
-   return expand_lattice(ln, NN, la, NA, pr, nPr, "(transcription)", dictPath, htkamd_mmf_desc(hmms), out);
+   return expand_lattice(ln, NN, la, NA, pr, nPr, "(transcription)", dictPath, htkamd_mmf_desc(hmms), NULL, out);
 }
 
-static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, const htkamd_model_desc *md, struct htkamd_net **out)
+static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nPr, const char *slfPath, const char *dictPath, const htkamd_model_desc *md, const xwrd_t *xw, struct htkamd_net **out)
 {
    int rc;
 
@@ -311,6 +380,243 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
 
    NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1);                     /* node 0: net->initial */
    NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1);                     /* node 1: net->final   */
+   if (xw) {
+      /* ---------------- cross-word context expansion (ExpandWordNet with xc > 0) ----------------
+       * Every pronunciation instance gets one ENTRY per left context that can reach it (the last context phone of a preceding word,
+       * seen through null words; 0 at the start of the lattice) and one word-end node per right context that can follow it (the first
+       * context phone of a following word; 0 at the end): first model = FindModel(lc, phone, .), last model = FindModel(., phone, rc),
+       * a one-phone word the full (lc, rc) cross-bar (CreateX1Model); context-free phones at either end of a pronunciation (sp, sil
+       * where nobody uses it as a context) keep their own model and pass the context on; null words are copied per (lc, rc) pair
+       * (ProcessCrossWordLinks).  A word-end node (fc, rc) links only to successors whose first context is rc, entering them at lc = fc,
+       * with the arc's LM score.  Models that map to one physical HMM are not merged here (the reference shares them); the paths and
+       * their scores are the same. */
+      hci_t hc; hci_define(&hc, xw->hmms);
+      const int nc = hc.cxs.n, XC = nc + 1;
+      int *iLn = NULL, *iPr = NULL, *iP = NULL, *iQ = NULL, *iFc = NULL, *iIc = NULL; int capX = 0;
+      unsigned char *LC = (unsigned char *)calloc((size_t)NN * XC, 1), *RC = (unsigned char *)calloc((size_t)NN * XC, 1);
+      unsigned char *through = (unsigned char *)calloc((size_t)NN, 1), *hasPredX = (unsigned char *)calloc((size_t)NN, 1), *hasFollX = (unsigned char *)calloc((size_t)NN, 1);
+      int *entryOf = NULL, *wendOf = NULL, *crossOf = NULL, *nullOf = NULL, *thruPron = NULL;
+      char tried[1600];
+      rc = HTKAMD_OK;
+      /* pronunciation instances (same selection and order as the word-internal form below) */
+      for (int i = 0; i < NN && !rc; i++) {
+         firstOf[i] = nInst; cntOf[i] = 0;
+         const int isNull = !strcmp(ln[i].word, "!NULL");
+         int sel[256], nSel = 0, found = 0;
+         for (int k = 0; k < nPr && !isNull; k++) {
+            if (strcmp(pr[k].word, ln[i].word)) continue;
+            found++;
+            if (ln[i].var > 0 && found != ln[i].var) continue;
+            int dup = 0;
+            for (int z = 0; z < nSel && !dup; z++) {
+               const dpron *o = &pr[sel[z]];
+               if (o->nPhones != pr[k].nPhones || o->prob != pr[k].prob) continue;
+               int q = 0;
+               while (q < o->nPhones && !strcmp(o->phoneName[q], pr[k].phoneName[q])) q++;
+               dup = (q == o->nPhones);
+            }
+            if (dup) continue;
+            if (nSel >= 256) { htkamd_set_error("net_build: word %s has more than 256 pronunciations", ln[i].word); rc = HTKAMD_EMODEL; break; }
+            sel[nSel++] = k;
+         }
+         if (!isNull && nSel == 0 && !rc) { htkamd_set_error("net_build: word %s of %s is not in the dictionary %s", ln[i].word, slfPath, dictPath); rc = HTKAMD_EMODEL; }
+         if (isNull) { through[i] = 1; continue; }
+         for (int z = nSel - 1; z >= 0 && !rc; z--) {
+            const int k = sel[z];
+            if (nInst + 1 > capX) {
+               capX = capX * 2 + 1024;
+               iLn = (int *)realloc(iLn, sizeof(int) * (size_t)capX); iPr = (int *)realloc(iPr, sizeof(int) * (size_t)capX); iP = (int *)realloc(iP, sizeof(int) * (size_t)capX);
+               iQ = (int *)realloc(iQ, sizeof(int) * (size_t)capX); iFc = (int *)realloc(iFc, sizeof(int) * (size_t)capX); iIc = (int *)realloc(iIc, sizeof(int) * (size_t)capX);
+            }
+            iLn[nInst] = i; iPr[nInst] = k; iP[nInst] = iQ[nInst] = -1; iFc[nInst] = iIc[nInst] = -1;
+            if (pr[k].nPhones == 0) through[i] = 1;            /* a word without phones passes the contexts on like !NULL */
+            for (int q = 0; q < pr[k].nPhones; q++) {
+               const int c = hci_context(&hc.cxs, pr[k].phoneName[q]);
+               if (c < 0) continue;
+               if (iP[nInst] < 0) { iP[nInst] = q; iIc[nInst] = c; }
+               iQ[nInst] = q; iFc[nInst] = c;
+            }
+            if (pr[k].nPhones > 0 && iP[nInst] < 0) {           /* NewPronHolder HNet.c:2278 */
+               htkamd_set_error("net_build: every word must define some context: no phone of %s is a context of the model set", pr[k].word);
+               rc = HTKAMD_EMODEL;
+            }
+            nInst++; cntOf[i]++;
+         }
+      }
+      /* left / right context sets of the lattice nodes, through null words (SetNullContexts) */
+      for (int j = 0; j < NA; j++) { hasPredX[la[j].e] = 1; hasFollX[la[j].s] = 1; }
+      for (int i = 0; i < NN; i++) { if (!hasPredX[i]) LC[(size_t)i * XC] = 1; if (!hasFollX[i]) RC[(size_t)i * XC] = 1; }
+      for (int changed = 1; changed && !rc;) {
+         changed = 0;
+         for (int j = 0; j < NA; j++) {
+            const int a = la[j].s, b = la[j].e;
+            for (int x = firstOf[a]; x < firstOf[a] + cntOf[a]; x++)
+               if (iFc[x] >= 0 && !LC[(size_t)b * XC + iFc[x]]) { LC[(size_t)b * XC + iFc[x]] = 1; changed = 1; }
+            for (int x = firstOf[b]; x < firstOf[b] + cntOf[b]; x++)
+               if (iIc[x] >= 0 && !RC[(size_t)a * XC + iIc[x]]) { RC[(size_t)a * XC + iIc[x]] = 1; changed = 1; }
+            if (through[a]) for (int c = 0; c < XC; c++) if (LC[(size_t)a * XC + c] && !LC[(size_t)b * XC + c]) { LC[(size_t)b * XC + c] = 1; changed = 1; }
+            if (through[b]) for (int c = 0; c < XC; c++) if (RC[(size_t)b * XC + c] && !RC[(size_t)a * XC + c]) { RC[(size_t)a * XC + c] = 1; changed = 1; }
+         }
+      }
+      entryOf = (int *)malloc(sizeof(int) * ((size_t)nInst * XC + 1)); wendOf = (int *)malloc(sizeof(int) * ((size_t)nInst * XC + 1));
+      crossOf = (int *)malloc(sizeof(int) * ((size_t)nInst + 1));          /* one-phone words without leading context-free phones: base of the (lc, rc) cross-bar */
+      nullOf = (int *)malloc(sizeof(int) * ((size_t)NN + 1));               /* typed copies of a through node: nullOf[i] + lc*XC + rc in nullTab */
+      thruPron = (int *)malloc(sizeof(int) * ((size_t)NN + 1));
+      int *nullTab = NULL, nNullTab = 0;
+      for (size_t z = 0; z < (size_t)nInst * XC; z++) { entryOf[z] = -1; wendOf[z] = -1; }
+      int *crossTab = NULL, nCrossTab = 0;
+#define XMODEL(dst, lc_, k_, q_, rc_) do { (dst) = find_model_ctx(xw->hmms, &hc.cxs, &hc.dep, hc.sLeft, hc.sRight, xw->flags, (lc_), pr[k_].phoneName[q_], (rc_), tried, sizeof(tried)); \
+         if ((dst) < 0) { htkamd_set_error("net_build: word %s: cannot find hmm %s (GetHCIModel HNet.c:2167)", pr[k_].word, tried); rc = HTKAMD_EMODEL; } } while (0)
+      for (int x = 0; x < nInst && !rc; x++) {
+         const int i = iLn[x], k = iPr[x], n = pr[k].nPhones, p = iP[x], q = iQ[x];
+         crossOf[x] = -1;
+         if (n == 0) continue;
+         /* contexts inside the word for phone j: the nearest context phones on either side (FindLContext / FindRContext) */
+#define LCI(j_, dflt) ({ int c_ = (dflt); for (int z_ = (j_) - 1; z_ >= 0; z_--) { const int t_ = hci_context(&hc.cxs, pr[k].phoneName[z_]); if (t_ >= 0) { c_ = t_; break; } } c_; })
+#define RCI(j_, dflt) ({ int c_ = (dflt); for (int z_ = (j_) + 1; z_ < n; z_++) { const int t_ = hci_context(&hc.cxs, pr[k].phoneName[z_]); if (t_ >= 0) { c_ = t_; break; } } c_; })
+         /* trailing part per right context: [last context phone (multi-phone words)] -> context-free phones -> word end */
+         int tailHead[XC];
+         for (int r = 0; r < XC && !rc; r++) {
+            tailHead[r] = -1;
+            if (!RC[(size_t)i * XC + r]) continue;
+            int prev = -1, h;
+            if (p != q) {
+               XMODEL(h, LCI(q, 0), k, q, r); if (rc) break;
+               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1); prev = nN - 1; tailHead[r] = prev;
+            }
+            for (int z = q + 1; z < n && !rc; z++) {
+               XMODEL(h, 0, k, z, 0); if (rc) break;
+               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
+               if (prev >= 0) NEWLINK(prev, nN - 1, 0.0f); else tailHead[r] = nN - 1;
+               prev = nN - 1;
+            }
+            if (rc) break;
+            NEWNODE(HTKAMD_NODE_WORD, k, pr[k].prob, k);
+            if (prev >= 0) NEWLINK(prev, nN - 1, 0.0f); else tailHead[r] = nN - 1;
+            wendOf[(size_t)x * XC + r] = nN - 1;
+         }
+         if (rc) break;
+         /* word-internal part between the first and the last context phone (CreateWIModels) */
+         int midHead = -1, midTail = -1;
+         for (int j = p + 1; j < q && !rc; j++) {
+            int h; XMODEL(h, LCI(j, 0), k, j, RCI(j, 0)); if (rc) break;
+            NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
+            if (midTail >= 0) NEWLINK(midTail, nN - 1, 0.0f); else midHead = nN - 1;
+            midTail = nN - 1;
+         }
+         if (rc) break;
+         if (midTail >= 0) for (int r = 0; r < XC; r++) if (tailHead[r] >= 0) NEWLINK(midTail, tailHead[r], 0.0f);
+         /* leading part per left context */
+         if (p == q && p == 0) { crossOf[x] = nCrossTab; crossTab = (int *)realloc(crossTab, sizeof(int) * (size_t)(nCrossTab + XC * XC)); for (int z = 0; z < XC * XC; z++) crossTab[nCrossTab + z] = -1; nCrossTab += XC * XC; }
+         for (int l = 0; l < XC && !rc; l++) {
+            if (!LC[(size_t)i * XC + l]) continue;
+            int firstCd[XC], nFirst = 0, h;                     /* the node(s) of the first context phone for this left context */
+            if (p != q) {
+               XMODEL(h, l, k, p, RCI(p, 0)); if (rc) break;
+               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
+               firstCd[nFirst++] = nN - 1;
+               if (midHead >= 0) NEWLINK(nN - 1, midHead, 0.0f);
+               else for (int r = 0; r < XC; r++) if (tailHead[r] >= 0) NEWLINK(nN - 1, tailHead[r], 0.0f);      /* two context phones: cross-bar */
+            } else {
+               for (int r = 0; r < XC && !rc; r++) {
+                  if (tailHead[r] < 0) continue;
+                  XMODEL(h, l, k, p, r); if (rc) break;
+                  NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
+                  NEWLINK(nN - 1, tailHead[r], 0.0f);
+                  firstCd[nFirst++] = nN - 1;
+                  if (crossOf[x] >= 0) crossTab[crossOf[x] + l * XC + r] = nN - 1;
+               }
+               if (rc) break;
+            }
+            int head = -1;
+            for (int z = p - 1; z >= 0 && !rc; z--) {          /* context-free phones before the first context phone */
+               XMODEL(h, 0, k, z, 0); if (rc) break;
+               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
+               if (head >= 0) NEWLINK(nN - 1, head, 0.0f); else for (int f = 0; f < nFirst; f++) NEWLINK(nN - 1, firstCd[f], 0.0f);
+               head = nN - 1;
+            }
+            if (rc) break;
+            if (head < 0 && p == q && set_has(&hc.dep, pr[k].phoneName[p])) {
+               /* a one-phone word whose phone has context-dependent models: the reference enters its cross-bar row through a NULL word
+                  node, "single collating point for all r contexts" (CreateX1Model HNet.c:2878, :2993) -- a word-type node, so the
+                  word-end beam is applied to the tokens that enter the word there */
+               NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1);
+               for (int f = 0; f < nFirst; f++) NEWLINK(nN - 1, firstCd[f], 0.0f);
+               head = nN - 1;
+            }
+            entryOf[(size_t)x * XC + l] = (head >= 0) ? head : ((p != q) ? firstCd[0] : -2);       /* -2: enter through the cross-bar row */
+         }
+#undef LCI
+#undef RCI
+      }
+      /* typed copies of the null words and of the words without phones: one per (lc, rc) pair that can pass */
+      for (int i = 0; i < NN && !rc; i++) {
+         nullOf[i] = -1; thruPron[i] = -1;
+         if (!through[i]) continue;
+         for (int x = firstOf[i]; x < firstOf[i] + cntOf[i]; x++) if (pr[iPr[x]].nPhones == 0) thruPron[i] = iPr[x];
+         nullOf[i] = nNullTab;
+         nullTab = (int *)realloc(nullTab, sizeof(int) * (size_t)(nNullTab + XC * XC));
+         for (int l = 0; l < XC; l++)
+            for (int r = 0; r < XC; r++) {
+               int id = -1;
+               if (LC[(size_t)i * XC + l] && RC[(size_t)i * XC + r]) {
+                  if (thruPron[i] >= 0) NEWNODE(HTKAMD_NODE_WORD, thruPron[i], pr[thruPron[i]].prob, thruPron[i]);
+                  else NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1);
+                  id = nN - 1;
+               }
+               nullTab[nNullTab + l * XC + r] = id;
+            }
+         nNullTab += XC * XC;
+      }
+      /* links: out of a word end (instance x, right context r) or a typed null copy (l, r) into everything that follows with first context r */
+#define LINK_INTO(from_, b_, l_, r_, like_) do { \
+         for (int y_ = firstOf[b_]; y_ < firstOf[b_] + cntOf[b_]; y_++) { \
+            if (pr[iPr[y_]].nPhones == 0 || iIc[y_] != (r_)) continue; \
+            const int e_ = entryOf[(size_t)y_ * XC + (l_)]; \
+            if (e_ >= 0) NEWLINK((from_), e_, (like_)); \
+            else if (e_ == -2) { for (int r2_ = 0; r2_ < XC; r2_++) { const int c_ = crossTab[crossOf[y_] + (l_) * XC + r2_]; if (c_ >= 0) NEWLINK((from_), c_, (like_)); } } \
+         } \
+         if (through[b_]) { const int t_ = nullTab[nullOf[b_] + (l_) * XC + (r_)]; if (t_ >= 0) NEWLINK((from_), t_, (like_)); } \
+      } while (0)
+      int nInit = 0, nFin = 0;
+      for (int j = 0; j < NA && !rc; j++) {
+         const int a = la[j].s, b = la[j].e;
+         for (int x = firstOf[a]; x < firstOf[a] + cntOf[a]; x++) {
+            if (pr[iPr[x]].nPhones == 0) continue;
+            for (int r = 0; r < XC; r++) { const int w = wendOf[(size_t)x * XC + r]; if (w >= 0) LINK_INTO(w, b, iFc[x], r, la[j].l); }
+         }
+         if (through[a])
+            for (int l = 0; l < XC; l++)
+               for (int r = 0; r < XC; r++) { const int t = nullTab[nullOf[a] + l * XC + r]; if (t >= 0) LINK_INTO(t, b, l, r, la[j].l); }
+      }
+      for (int i = 0; i < NN && !rc; i++) {
+         if (!hasPredX[i]) {                                    /* AddInitialFinal: the initial node enters with no left context */
+            for (int x = firstOf[i]; x < firstOf[i] + cntOf[i]; x++) {
+               if (pr[iPr[x]].nPhones == 0) continue;
+               const int e = entryOf[(size_t)x * XC];
+               if (e >= 0) { NEWLINK(0, e, 0.0f); nInit++; }
+               else if (e == -2) for (int r = 0; r < XC; r++) { const int c = crossTab[crossOf[x] + r]; if (c >= 0) { NEWLINK(0, c, 0.0f); nInit++; } }
+            }
+            if (through[i]) for (int r = 0; r < XC; r++) { const int t = nullTab[nullOf[i] + r]; if (t >= 0) { NEWLINK(0, t, 0.0f); nInit++; } }
+         }
+         if (!hasFollX[i]) {
+            for (int x = firstOf[i]; x < firstOf[i] + cntOf[i]; x++) { const int w = (pr[iPr[x]].nPhones == 0) ? -1 : wendOf[(size_t)x * XC]; if (w >= 0) { NEWLINK(w, 1, 0.0f); nFin++; } }
+            if (through[i]) for (int l = 0; l < XC; l++) { const int t = nullTab[nullOf[i] + l * XC]; if (t >= 0) { NEWLINK(t, 1, 0.0f); nFin++; } }
+         }
+      }
+#undef LINK_INTO
+#undef XMODEL
+      if (!rc && (!nInit || !nFin)) { htkamd_set_error("net_build: %s has no initial or no final node", slfPath); rc = HTKAMD_EMODEL; }
+      if (!rc) {
+         net->xwrd = 1; net->flags = xw->flags; net->hmms = xw->hmms; net->sLeft = hc.sLeft; net->sRight = hc.sRight;
+         net->cxName = hc.cxs.v; net->nCx = hc.cxs.n; net->depName = hc.dep.v; net->nDep = hc.dep.n;
+         memset(&hc, 0, sizeof(hc));
+      }
+      hci_free(&hc);
+      free(iLn); free(iPr); free(iP); free(iQ); free(iFc); free(iIc); free(LC); free(RC); free(through); free(hasPredX); free(hasFollX);
+      free(entryOf); free(wendOf); free(crossOf); free(nullOf); free(thruPron); free(nullTab); free(crossTab);
+      if (rc) goto done;
+   } else {
    for (int i = 0; i < NN; i++) {
       firstOf[i] = nInst; cntOf[i] = 0;
       const int isNull = !strcmp(ln[i].word, "!NULL");
@@ -379,6 +685,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
       free(hasPred); free(hasFoll);
       if (!nInit || !nFin) { htkamd_set_error("net_build: %s has no initial or no final node", slfPath); rc = HTKAMD_EMODEL; goto done; }
    }
+   }
    /* CSR by source node (stable: creation order within a node) */
    net->linkOff = (int *)calloc((size_t)nN + 1, sizeof(int));
    net->linkDest = (int *)malloc(sizeof(int) * (size_t)(nL ? nL : 1));
@@ -434,6 +741,34 @@ int htkamd_net_pron_models(const struct htkamd_net *n, int k, int *models, int m
    if (!n || k < 0 || k >= n->nPron) return -1;
    for (int q = 0; q < n->pron[k].nPhones && q < max; q++) models[q] = n->pron[k].phone[q];
    return n->pron[k].nPhones;
+}
+
+int htkamd_net_is_xwrd(const struct htkamd_net *n) { return n ? n->xwrd : 0; }
+
+/* models of pronunciation k between two neighbours (cross-word networks: the first / last context phone sees the neighbour's) */
+int htkamd_net_seq_models(const struct htkamd_net *n, int k, int prevPron, int nextPron, int *models, int max)
+{
+   if (!n || k < 0 || k >= n->nPron) return -1;
+   if (!n->xwrd) return htkamd_net_pron_models(n, k, models, max);
+   const dpron *d = &n->pron[k];
+   strset cxs, dep; cxs.v = n->cxName; cxs.n = cxs.cap = n->nCx; dep.v = n->depName; dep.n = dep.cap = n->nDep;
+   int lcX = 0, rcX = 0, p = -1, q = -1;
+   if (prevPron >= 0 && prevPron < n->nPron) for (int z = 0; z < n->pron[prevPron].nPhones; z++) { const int c = hci_context(&cxs, n->pron[prevPron].phoneName[z]); if (c >= 0) lcX = c; }
+   if (nextPron >= 0 && nextPron < n->nPron) for (int z = n->pron[nextPron].nPhones - 1; z >= 0; z--) { const int c = hci_context(&cxs, n->pron[nextPron].phoneName[z]); if (c >= 0) rcX = c; }
+   for (int z = 0; z < d->nPhones; z++) if (hci_context(&cxs, d->phoneName[z]) >= 0) { if (p < 0) p = z; q = z; }
+   for (int j = 0; j < d->nPhones; j++) {
+      int lc = 0, rc = 0;
+      if (j >= p && j <= q) {
+         lc = lcX; rc = rcX;
+         for (int z = j - 1; z >= 0; z--) { const int c = hci_context(&cxs, d->phoneName[z]); if (c >= 0) { lc = c; break; } }
+         for (int z = j + 1; z < d->nPhones; z++) { const int c = hci_context(&cxs, d->phoneName[z]); if (c >= 0) { rc = c; break; } }
+         if (j > p && j < q && hci_context(&cxs, d->phoneName[j]) < 0) { /* context-free phone inside the word: its own model */ }
+      }
+      const int h = find_model_ctx(n->hmms, &cxs, &dep, n->sLeft, n->sRight, n->flags, lc, d->phoneName[j], rc, NULL, 0);
+      if (h < 0) { htkamd_set_error("net_seq_models: no model for phone %s of %s in this context", d->phoneName[j], d->word); return -1; }
+      if (j < max) models[j] = h;
+   }
+   return d->nPhones;
 }
 
 /* the dictionary word a pronunciation belongs to (HVite -m/-f label the first model of a word with the word's NAME) */

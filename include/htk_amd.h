@@ -453,6 +453,23 @@ typedef struct {
 } htkamd_net_desc;
 typedef struct htkamd_net htkamd_net;
 int  htkamd_net_build(const char *slfPath, const char *dictPath, const htkamd_mmf *hmms, htkamd_net **out);
+/* The same with HNet's configuration switches (HNet.c:122-127; HVite reads them from its -C file):
+ *   ALLOWXWRDEXP   contexts may cross word boundaries: when the model set defines contexts and the dictionary cannot be built from
+ *                  word-internal models alone (or one of the FORCE switches is set) the network is expanded with CROSS-WORD contexts
+ *                  (ExpandWordNet HNet.c:3438 with xc > 0): a word's first model depends on the last context phone of the word before,
+ *                  its last model on the first context phone of the word after; context-free phones (sp) and null words pass contexts on
+ *   FORCECXTEXP    expand contexts even when every dictionary phone is a model name      FORCELEFTBI / FORCERIGHTBI   biphone names only
+ * flags = 0 is htkamd_net_build.  With cross-word expansion `hmms` must stay alive as long as the network (htkamd_net_seq_models). */
+#define HTKAMD_NET_ALLOWXWRDEXP 1
+#define HTKAMD_NET_FORCECXTEXP  2
+#define HTKAMD_NET_FORCELEFTBI  4
+#define HTKAMD_NET_FORCERIGHTBI 8
+int  htkamd_net_build_ex(const char *slfPath, const char *dictPath, const htkamd_mmf *hmms, int flags, htkamd_net **out);
+int  htkamd_net_is_xwrd(const htkamd_net *n);
+/* Physical models of pronunciation `pron` when it stands between the pronunciations prevPron and nextPron (-1: utterance boundary;
+ * pronunciations without phones are transparent, so pass the nearest one that has phones): what HVite -m labels for a recognised
+ * word sequence.  Without cross-word expansion this is htkamd_net_pron_models.  Returns the number of models (may exceed `max`). */
+int  htkamd_net_seq_models(const htkamd_net *n, int pron, int prevPron, int nextPron, int *models, int max);
 /* Alignment network of HVite -a from a word-level transcription: LatticeFromLabels (HNet.c:1516: one node per label, the boundary
    word of HVite -b at both ends when non-NULL) + the same expansion; decoding it with htkamd_decoder_* is HVite -a (DoAlignment
    HVite.c:830), word- or model-level (-m) labels. */

@@ -45,7 +45,17 @@ def fuzz_decode(rng, it, tmp):
         names = ["p%d" % i for i in range(NP)]
     wint = tee is None and rng.random() < 0.35                 # word-internal context expansion over a triphone-style logical list
     phones4, ctx = ["a", "b", "c", "d"], None
-    if wint:
+    xwrd = wint and rng.random() < 0.5                          # cross-word context expansion (FORCECXTEXP = T, ALLOWXWRDEXP = T)
+    if xwrd:
+        ctx = phones4 + ["sil"]                                  # every word must define some context: sil is one, sp is context free
+        with open(os.path.join(d, "hmmlist"), "w") as f:
+            f.write("\n".join(names) + "\n")
+            for x in phones4:
+                for l_ in [None] + ctx:
+                    for r_ in [None] + ctx:
+                        f.write("%s%s%s %s\n" % ("%s-" % l_ if l_ else "", x, "+%s" % r_ if r_ else "", names[int(rng.integers(0, NP))]))
+            f.write("sil %s\nsp %s\n" % (names[int(rng.integers(0, NP))], names[int(rng.integers(0, NP))]))
+    elif wint:
         ctx = phones4 + (["sp"] if rng.random() < 0.5 else [])   # sp may or may not be somebody's context
         with open(os.path.join(d, "hmmlist"), "w") as f:
             f.write("\n".join(names) + "\n")
@@ -63,7 +73,14 @@ def fuzz_decode(rng, it, tmp):
     with open(os.path.join(d, "dict"), "w") as f:
         for w in range(V):
             for v in range(int(rng.integers(1, 3))):
-                if wint:
+                if xwrd:
+                    ph = [phones4[int(k)] for k in rng.integers(0, 4, size=int(rng.integers(1, 5)))]        # one-phone words: the (lc, rc) cross-bar
+                    if len(ph) > 2 and rng.random() < 0.15:
+                        ph.insert(int(rng.integers(1, len(ph))), "sp")                                      # a context-free phone inside the word
+                    ph = (["sp"] if rng.random() < 0.1 else []) + ph + (["sp"] if rng.random() < 0.6 else [])
+                    if w == 0:
+                        ph = ["sil"]
+                elif wint:
                     ph = [phones4[int(k)] for k in rng.integers(0, 4, size=int(rng.integers(2, 5)))] + (["sp"] if rng.random() < 0.6 else [])
                     if w == 0:
                         ph = ["sil"]
@@ -97,12 +114,13 @@ def fuzz_decode(rng, it, tmp):
         synth.write_htk_param(fn, X, kind=9)
         scp.append(fn)
     open(os.path.join(d, "scp"), "w").write("\n".join(scp) + "\n")
-    open(os.path.join(d, "config"), "w").write("")
+    open(os.path.join(d, "config"), "w").write("FORCECXTEXP = T\nALLOWXWRDEXP = T\n" if xwrd else "")
     opts = []
     if p["genBeam"] < 1e9: opts += ["-t", "%.2f" % p["genBeam"]]
     if p["wordBeam"] < 1e9: opts += ["-v", "%.2f" % p["wordBeam"]]
     opts += ["-s", "%.2f" % p["lmScale"], "-p", "%.2f" % p["wordPen"], "-r", "%.2f" % p["prScale"]]
-    if rng.random() < 0.35:                                      # maximum-model pruning (HRec.c:1966-1985)
+    if rng.random() < 0.35 and not xwrd:                         # maximum-model pruning (HRec.c:1966-1985); counts instances: not for the cross-word
+                                                                 # networks, where the reference shares nodes between contexts that net.c keeps apart
         p["maxActive"] = int(rng.integers(2, 25))
         opts += ["-u", str(p["maxActive"])]
     mlf = os.path.join(d, "out.mlf")
@@ -119,7 +137,8 @@ def fuzz_decode(rng, it, tmp):
             elif cur is not None:
                 ref[cur].append(line)
     mmf = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
-    net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
+    net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf, flags=(capi.NET_ALLOWXWRDEXP | capi.NET_FORCECXTEXP) if xwrd else 0)
+    assert net.xwrd == xwrd
     om = pyoracle.Model(mmf.packed())
     ok = True
     for u, X in enumerate(s.feats):

@@ -170,6 +170,29 @@ def test_hvite_cli_output_formats_equal_the_reference_mlf(native, tools, tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["net", "loop"])
+def test_hvite_cli_cross_word_expansion(native, tools, tmp_path, which):
+    """hvite -C config with FORCECXTEXP = T, ALLOWXWRDEXP = T: the network is expanded with cross-word contexts (ExpandWordNet HNet.c:3438,
+    xc > 0); word-level and model-level (-m: triphones named by the neighbouring words) label files equal the reference HVite's."""
+    from htk_amd import synth
+    src = os.path.join(GOLD, "xwrd")
+    z = np.load(os.path.join(src, "feats_%s.npz" % which))
+    files = []
+    for u in range(len(z.files)):
+        fn = str(tmp_path / ("u%d.mfc" % u))
+        synth.write_htk_param(fn, z["u%d" % u], kind=9)
+        files.append(fn)
+    expected = json.load(open(os.path.join(src, "expected_%s.json" % which)))
+    for opts, per in expected.items():
+        out = tmp_path / ("out_" + opts.replace(" ", "_")); out.mkdir()
+        r = run([os.path.join(tools, "hvite"), "-C", os.path.join(src, "config"), "-H", os.path.join(src, "MMF"), "-w", os.path.join(src, which + ".slf"), "-l", str(out)] + opts.split() +
+                [os.path.join(src, "dict"), os.path.join(src, "hmmlist")] + files)
+        assert r.returncode == 0, r.stderr
+        for u in range(len(files)):
+            assert (out / ("u%d.rec" % u)).read_text().splitlines() == per["u%d" % u], (which, opts, u)
+
+
+@pytest.mark.gpu
 def test_hvite_cli_word_level_alignment(native, tools, tmp_path):
     """hvite -a [-b w] [-m] from word-level label files (DoAlignment HVite.c:830) against the reference's label files."""
     src, files = _write_case_files(native, "bigram", tmp_path)

@@ -10,7 +10,7 @@ from decode_util import format_words, load_decode_case, parse_opts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint", "ties"])
+@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint", "ties", "xwrd:net", "xwrd:loop"])
 def test_decoder_reproduces_hvite_label_files(native, oracle, case):
     mmf, net, feats, expected = load_decode_case(native, case)
     model = native.Model(mmf.packed())
@@ -132,7 +132,7 @@ def test_decoder_edge_cases(native, oracle):
     assert tight[0][0] == ow                                          # whatever the reference semantics give (None or a path)
 
 
-@pytest.mark.parametrize("case", ["loop", "bigram", "wint"])
+@pytest.mark.parametrize("case", ["loop", "bigram", "wint", "xwrd:net", "xwrd:loop"])
 def test_model_level_labels_of_recognition(native, case):
     """HVite -m with -w: model-level labels of the recognised words = decoder (words, LM scores) + forced alignment of the
     recognised pronunciations' model chain; compared line by line with the reference's output."""
@@ -147,12 +147,13 @@ def test_model_level_labels_of_recognition(native, case):
         p = parse_opts(opts)
         dec = native.Decoder(model, net, lmScale=p["lmScale"])
         res = dec.run(feats, **p)
-        chains = [np.array([m for w in words for m in net.pron_models[w[0]]], np.int32) for words, _ in res]
+        seqm = [net.seq_models([w[0] for w in words]) if net.xwrd else [net.pron_models[w[0]] for w in words] for words, _ in res]
+        chains = [np.array([m for wm in sm for m in wm], np.int32) for sm in seqm]
         X, frameOff, labOff, labs = batch_arrays([dict(seq=c, feat=f) for c, f in zip(chains, feats)])
         dX = native.DevArray(X)
         al = native.Viterbi(model).align(dX.ptr.value, frameOff, labOff, labs, genBeam=p["genBeam"])
         for u, (words, total) in enumerate(res):
-            got = format_model_labels(words, dec.last_lm[u], al[u], net.pron_models, mmf.phys_names, net.word_names, p["lmScale"], p["wordPen"])
+            got = format_model_labels(words, dec.last_lm[u], al[u], net.pron_models, mmf.phys_names, net.word_names, p["lmScale"], p["wordPen"], seq_models=seqm[u])
             assert got == per["u%d" % u], (case, opts, u)
             n += len(got)
     assert n > 10

@@ -10,7 +10,7 @@ import pytest
 from decode_util import GOLD, format_words, load_decode_case, parse_opts
 
 
-@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint", "ties"])
+@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint", "ties", "xwrd:net", "xwrd:loop"])
 def test_oracle_decode_reproduces_hvite(native, oracle, case):
     mmf, net, feats, expected = load_decode_case(native, case)
     om = oracle.Model(mmf.packed())

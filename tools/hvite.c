@@ -50,8 +50,11 @@ static void emit(htkamd_trans *tr, const htkamd_net *net, const htkamd_mmf *mmf,
       constants, so the best alignment of the chain is the decoder's path (include/htk_amd.h, htkamd_decoder_run) */
    int nQ = 0, cap = 0, *chain = NULL, *wordOfQ = NULL;
    for (int w = 0; w < nW; w++) {
-      int tmp[256];
-      const int n = htkamd_net_pron_models(net, wPron[w], tmp, 256);
+      int tmp[256], prev = -1, next = -1;                      /* neighbours with phones: cross-word networks name a word's edge models by them */
+      for (int z = w - 1; z >= 0 && prev < 0; z--) if (htkamd_net_pron_models(net, wPron[z], tmp, 0) > 0) prev = wPron[z];
+      for (int z = w + 1; z < nW && next < 0; z++) if (htkamd_net_pron_models(net, wPron[z], tmp, 0) > 0) next = wPron[z];
+      const int n = htkamd_net_seq_models(net, wPron[w], prev, next, tmp, 256);
+      if (n < 0) DIE("%s", htkamd_last_error());
       if (n > 256) DIE("pronunciation with %d models", n);
       if (nQ + n > cap) { cap = (nQ + n) * 2 + 64; chain = (int *)realloc(chain, sizeof(int) * (size_t)cap); wordOfQ = (int *)realloc(wordOfQ, sizeof(int) * (size_t)cap); }
       for (int k = 0; k < n; k++) { chain[nQ] = tmp[k]; wordOfQ[nQ] = (k == 0) ? w : -1; nQ++; }
@@ -163,7 +166,9 @@ int main(int argc, char **argv)
    const char *tk = cfg_get(&cfg, "TARGETKIND");
    const int targetKind = kind_parse(tk ? tk : htkamd_mmf_parm_kind(mmf));
    htkamd_net *net = NULL; htkamd_decoder *dec = NULL;
-   if (!align) { CHECK(htkamd_net_build(netPath, dictPath, mmf, &net)); CHECK(htkamd_decoder_create(model, htkamd_net_get(net), lmScale, &dec)); }
+   const int netFlags = (cfg_bool(&cfg, "ALLOWXWRDEXP", 0) ? HTKAMD_NET_ALLOWXWRDEXP : 0) | (cfg_bool(&cfg, "FORCECXTEXP", 0) ? HTKAMD_NET_FORCECXTEXP : 0) |
+                        (cfg_bool(&cfg, "FORCELEFTBI", 0) ? HTKAMD_NET_FORCELEFTBI : 0) | (cfg_bool(&cfg, "FORCERIGHTBI", 0) ? HTKAMD_NET_FORCERIGHTBI : 0);     /* HNet.c:122-127 */
+   if (!align) { CHECK(htkamd_net_build_ex(netPath, dictPath, mmf, netFlags, &net)); CHECK(htkamd_decoder_create(model, htkamd_net_get(net), lmScale, &dec)); }
    htkamd_mlf *mlf = NULL; if (mlfIn) CHECK(htkamd_mlf_read(mlfIn, &mlf));
    htkamd_mlf_out *mout = NULL; if (mlfOut) CHECK(htkamd_mlf_out_open(mlfOut, &mout));
    htkamd_decode_config dc; memset(&dc, 0, sizeof(dc));
