@@ -869,6 +869,48 @@ class DecodeConfig(C.Structure):
                 ("scoreMode", C.c_int), ("maxActive", C.c_int)]
 
 
+class LatticeOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("nNodes", "nArcs", "nodeFrame", "nodePron", "nodeNet", "nodeLike", "arcStart", "arcEnd", "arcAc", "arcLm", "arcPr",
+                                          "arcScore", "total")]
+
+
+class Lattice(C.Structure):
+    _fields_ = [("nNodes", C.c_int), ("nArcs", C.c_int), ("nodeFrame", C.c_void_p), ("nodePron", C.c_void_p), ("nodeLike", C.c_void_p),
+                ("arcStart", C.c_void_p), ("arcEnd", C.c_void_p), ("arcAc", C.c_void_p), ("arcLm", C.c_void_p), ("arcPr", C.c_void_p),
+                ("lmScale", C.c_float), ("wordPen", C.c_float), ("prScale", C.c_float), ("frameDur", C.c_double)]
+
+
+def _lattice_struct(lat: dict, frame_dur=0.01):
+    keep = [np.ascontiguousarray(lat[k], dt) for k, dt in (("nodeFrame", np.int32), ("nodePron", np.int32), ("nodeLike", np.float64), ("arcStart", np.int32),
+                                                          ("arcEnd", np.int32), ("arcAc", np.float32), ("arcLm", np.float32), ("arcPr", np.float32))]
+    st = Lattice(len(keep[0]), len(keep[3]), *[_p(x) for x in keep], lat["lmScale"], lat["wordPen"], lat["prScale"], frame_dur)
+    return st, keep
+
+
+def lattice_write(lat: dict, net: "Net", path: str, utterance=None, lm_name=None, vocab_name=None, fmt=0, frame_dur=0.01):
+    """htkamd_lattice_write: the SLF file WriteLattice gives for the lattice (fmt: HTKAMD_LAT_* bits, 0 = t v a l)."""
+    st, keep = _lattice_struct(lat, frame_dur)
+    enc = lambda x: x.encode() if x is not None else None
+    check(lib().htkamd_lattice_write(C.byref(st), net.h, path.encode(), enc(utterance), enc(lm_name), enc(vocab_name), C.c_int(fmt or 0x78)), "lattice_write")
+
+
+def lattice_nbest(lat: dict, net: "Net", N: int, frame_dur=0.01, max_len=4096):
+    """htkamd_lattice_nbest: up to N alternatives, each a list of (pron, startFrame, endFrame, score) for its arcs."""
+    st, keep = _lattice_struct(lat, frame_dur)
+    nAlt = C.c_int(0); altLen = np.zeros(N, np.int32); arcs = np.zeros(N * max_len, np.int32)
+    check(lib().htkamd_lattice_nbest(C.byref(st), net.h, C.c_int(N), C.c_int(max_len), C.byref(nAlt), _p(altLen), _p(arcs)), "lattice_nbest")
+    L = lib(); L.htkamd_lattice_arc_score.restype = C.c_float
+    out = []
+    for i in range(nAlt.value):
+        alt = []
+        for j in range(int(altLen[i])):
+            a_ = int(arcs[i * max_len + j])
+            alt.append((int(lat["nodePron"][lat["arcEnd"][a_]]), int(lat["nodeFrame"][lat["arcStart"][a_]]), int(lat["nodeFrame"][lat["arcEnd"][a_]]),
+                        float(L.htkamd_lattice_arc_score(C.byref(st), C.c_int(a_)))))
+        out.append(alt)
+    return out
+
+
 class Decoder:
     """htkamd_decoder holder: HVite -w (1-best word labels) for a batch of utterances on the device."""
 
@@ -901,6 +943,36 @@ class Decoder:
                 o = u * maxWords
                 out.append(([(int(wp[o + i]), int(ws[o + i]), int(we[o + i]), float(sc[o + i])) for i in range(nW[u])], float(tot[u])))
         return out
+
+    def run_lattice(self, feats, nToks, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=None, wordPen=0.0, prScale=1.0, maxNodes=20000, maxArcs=80000, scoreMode=0):
+        """HVite -n nToks: per utterance the lattice as a dict of arrays (oracle.decode_nbest's fields + nodePron), or None."""
+        lmScale = self.lmScale if lmScale is None else float(lmScale)
+        if lmScale != self.lmScale:
+            raise HtkAmdError("Decoder.run_lattice: the LM scale is fixed at creation (LikeToWord look-ahead)")
+        nU = len(feats)
+        X = np.ascontiguousarray(np.concatenate(feats) if nU else np.zeros((0, self.model.D)), np.float32)
+        frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int32)
+        dX = DevArray(X) if X.size else DevArray(nbytes=4)
+        n1 = max(nU, 1)
+        nn = np.zeros(n1, np.int32); na = np.zeros(n1, np.int32); tot = np.zeros(n1, np.float64)
+        nF = np.zeros(n1 * maxNodes, np.int32); nP = np.zeros_like(nF); nNet = np.zeros_like(nF); nL = np.zeros(n1 * maxNodes, np.float64)
+        aS = np.zeros(n1 * maxArcs, np.int32); aE = np.zeros_like(aS); aAc = np.zeros(n1 * maxArcs, np.float32); aLm = np.zeros_like(aAc); aPr = np.zeros_like(aAc)
+        aSc = np.zeros(n1 * maxArcs, np.float64)
+        out = LatticeOut(_p(nn), _p(na), _p(nF), _p(nP), _p(nNet), _p(nL), _p(aS), _p(aE), _p(aAc), _p(aLm), _p(aPr), _p(aSc), _p(tot))
+        cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale, scoreMode, 0)
+        check(lib().htkamd_decoder_run_lattice(self.h, C.byref(cfg), C.c_int(nToks), C.c_float(genBeam if nBeam is None else nBeam), dX.ptr, _p(frameOff), C.c_int(nU),
+                                               C.c_int(maxNodes), C.c_int(maxArcs), C.byref(out), None), "decoder_run_lattice")
+        res = []
+        for u in range(nU):
+            if nn[u] == -1:
+                res.append(None); continue
+            if nn[u] < 0:
+                raise HtkAmdError("decoder_run_lattice: the lattice of utterance %d does not fit (%d)" % (u, nn[u]))
+            n, a_, o, q = int(nn[u]), int(na[u]), u * maxNodes, u * maxArcs
+            res.append(dict(nodeFrame=nF[o:o + n].copy(), nodePron=nP[o:o + n].copy(), nodeNet=nNet[o:o + n].copy(), nodeLike=nL[o:o + n].copy(),
+                            arcStart=aS[q:q + a_].copy(), arcEnd=aE[q:q + a_].copy(), arcAc=aAc[q:q + a_].copy(), arcLm=aLm[q:q + a_].copy(), arcPr=aPr[q:q + a_].copy(),
+                            arcScore=aSc[q:q + a_].copy(), total=float(tot[u]), lmScale=lmScale, wordPen=float(wordPen), prScale=float(prScale)))
+        return res
 
     def __del__(self):
         try:

@@ -1,0 +1,65 @@
+// decode.h -- what the network decoder's kernels (decode.hip: 1-best; decode_n.hip: N-best token sets + lattice) and their host code share.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "internal.h"
+
+#define DEC_THREADS 1024
+#define DEC_MAXN 8              /* states per model incl. entry/exit */
+#define DEC_WIDE 96             /* fan-in from which a node is reduced by the whole workgroup */
+
+struct DecNet {
+   int nNodes, nHmm, nLevels, nWordNodes, initial, final, nTok, nTpFloats;
+   const int *kind, *model;            // [nNodes]
+   const float *pronProb;              // [nNodes]
+   const int *predOff, *predSrc;       // reverse CSR; bit 31 of predSrc: the predecessor is a word/null node
+   const float *predLike;
+   const int4 *nodeInfo;               // [nNodes] {kind | N << 4 | tee << 12, first token, offset of transP, offset into hmmState}
+   const int *tok0;                    // [nNodes] first token (state 1) of the node
+   const int *hmmNodes;                // [nHmm] model nodes (tee or not)
+   const int *nodeN, *nodeTp, *nodeSt; // [nNodes] HMM: numStates, offset of transP, offset into hmmState
+   const unsigned char *nodeTee;       // [nNodes]
+   const float *wdlk;                  // [nNodes]
+   const int *wordIdx;                 // [nNodes] dense index of WORD nodes (path table column) or -1
+   const int *wordNode;                // [nWordNodes] inverse of wordIdx
+   const int *levelOff, *levelNodes;   // zero-time nodes by level: narrow ones first, then wide ones
+   const int *levelWide;               // [nLevels] index in levelNodes where the wide nodes of the level start
+   const float *transP;
+   const int *hmmState;
+   const int *stateSlot;               // [S] row of the tied state in the score block, -1 if unused
+};
+
+struct DecUtt {
+   int T, frame0, status, pad;
+   size_t score0;      // floats: score[score0 + slot*T + (t-1)]
+   size_t tok0;        // token arrays base
+   size_t node0;       // exit-token / instance-max arrays base
+   size_t path0;       // path table base: (t*nWordNodes + w)
+   size_t out0;        // word output base
+};
+
+struct __attribute__((aligned(16))) Tok { double like; float lm; int path; };   // one 16-byte load/store per token
+
+struct DecArgs {
+   DecNet net;
+   const DecUtt *utt; int nUtt;
+   const float *score;
+   Tok *tok;                           // [sum nTok]   state tokens
+   Tok *ex; double *imax;              // [sum nNodes] exit tokens, instance maxima
+   int *pathPrev; double *pathLike; float *pathLm;
+   float genBeam, wordBeam, lmScale, wordPen, prScale;
+   int maxActive;                      // HVite -u: maximum number of model instances kept per frame (0 = off)
+   int maxWords;
+   int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm, *wordAc; double *wordLike; double *total; float *finalLm;
+};
+
+
+struct htkamd_decoder {
+   htkamd_model *m;
+   DecNet net;                         // device pointers
+   std::vector<void *> owned;
+   std::vector<int> usedStates;        // tied states of the network in slot order
+   std::vector<int> hostModel;         // [nNodes] htkamd_net_desc.model (WORD nodes: the pronunciation)
+   int *d_usedStates;
+   int maxWidthNodes;
+};

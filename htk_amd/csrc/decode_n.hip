@@ -1,0 +1,513 @@
+// decode_n.hip -- K7n: N-best token passing and lattice generation over a recognition network (HVite -n N [-z ext]).
+//
+// Reference semantics (HRec.c with nToks > 1; oracle/orc_decode_n.c is the restatement this kernel is tested against):
+//   TokenSet :100 = the state's best token + up to N-1 RelTokens (float likelihood relative to it, lm, path), sorted, distinct in the
+//   word-end node their path ends in; TokSetMerge :279 wherever the 1-best code takes a maximum (StepHMM1 :642, StepHMM2 :790,
+//   SetEntryState :1303) with the cut nThresh = genMax - nBeam (:2002); StepWord2 :1046 opens a Path record for the best token and a
+//   NxtPath per alternative; CompleteRecognition :2054 -> CreateLattice :1679: MarkPaths numbers the reachable Path records depth
+//   first, LatFromPaths :1512 makes every Path / NxtPath an arc (aclike, lmlike, prlike).
+//
+// Mapping: decode.hip's (one 1024-thread workgroup per utterance, every node PULLS from its predecessors in the order the reference's
+// senders are stepped, emitting models in registers, zero-time nodes level by level), with token SETS where it has tokens:
+//   * a set is a 128-byte record in global memory (L2-resident per utterance); a thread merges into a register-resident copy with the
+//     reference's algorithm operand for operand -- the relative likelihoods are floats re-based at every merge, so the order of the
+//     merges is the reference's order and the arcs come out with the reference's values;
+//   * the state sets of the emitting models are double-buffered per frame (state j of the new column reads several states of the old);
+//   * nodes with a large fan-in (loop / back-off null nodes): every thread merges a CONTIGUOUS run of predecessors in order into a
+//     partial set in LDS, thread 0 merges the non-empty partial sets in run order -- the sets are the reference's, the re-basing of
+//     the relative likelihoods is associated differently (last-bit differences of alternatives' scores are possible there);
+//   * Path records: the dense [frame][word node] table of decode.hip plus N-1 alternative slots per entry;
+//   * the lattice is built on the device by one thread (depth-first over the table with an explicit stack) and only its nodes and
+//     arcs go back to the host.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+#include "decode.h"
+
+#define NT 8                        /* capacity of a token set (HVite -n up to 8) */
+
+struct __attribute__((aligned(16))) TSet {
+   double like; float lm; int path;    // the best token
+   int n, pad;
+   float rl[NT], rlm[NT]; int rp[NT];  // relative tokens; [0] mirrors the best (like 0)
+};
+
+struct NArgs {
+   DecNet net;
+   const DecUtt *utt; int nUtt;
+   const float *score;
+   TSet *tokA, *tokB;                  // [sum nTok] state sets, double-buffered
+   TSet *ex; double *imax;             // [sum nNodes]
+   int *pathPrev; double *pathLike; float *pathLm;             // [sum (T+1)*nWordNodes]
+   int *altN, *altPrev; double *altLike; float *altLm;         // alternatives: altN[path], others [path*(NT-1) + k]
+   int *mark;                                                  // [paths] MarkPaths' usage numbers
+   int *stack;                                                 // [nUtt * 2*maxLatNodes] depth-first stack
+   float genBeam, wordBeam, nBeam, lmScale, wordPen, prScale;
+   int nToks;
+   int maxLatNodes, maxLatArcs;
+   size_t *pathBase;                   // unused
+   int *latN;                          // [nUtt*2] nodes, arcs (or -1 / -3)
+   int *nodeFrame, *nodeNet;           // [nUtt*maxLatNodes]
+   double *nodeLike;
+   int *arcStart, *arcEnd; float *arcAc, *arcLm, *arcPr; double *arcScore;     // [nUtt*maxLatArcs]
+   double *total;
+};
+
+__device__ __forceinline__ void ts_null(TSet &s) { s.like = LZERO; s.lm = 0.0f; s.path = -1; s.n = 1; s.pad = 0; s.rl[0] = 0.0f; s.rlm[0] = 0.0f; s.rp[0] = -1; }
+__device__ __forceinline__ int key_of(int path, int nWordNodes) { return path < 0 ? -1 : path % nWordNodes; }
+
+// TokSetMerge (HRec.c:279): token (cLike, cLm, cPath) with the relative tokens of `src` merged into `res`
+__device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TSet &src, float nThresh, int nToks, int nW)
+{
+   float tl[NT], tlm[NT]; int tp[NT]; int tn; double tLike;
+   if (cLike >= res.like) {
+      if (!(cLike > nThresh)) return;
+      if (res.like > nThresh) {                            // exchange
+         tLike = res.like; tn = res.n;
+         for (int k = 0; k < res.n; k++) { tl[k] = res.rl[k]; tlm[k] = res.rlm[k]; tp[k] = res.rp[k]; }
+         res.like = cLike; res.lm = cLm; res.path = cPath; res.n = src.n;
+         for (int k = 0; k < src.n; k++) { res.rl[k] = src.rl[k]; res.rlm[k] = src.rlm[k]; res.rp[k] = src.rp[k]; }
+      } else {
+         res.like = cLike; res.lm = cLm; res.path = cPath; res.n = src.n;
+         for (int k = 0; k < src.n; k++) { res.rl[k] = src.rl[k]; res.rlm[k] = src.rlm[k]; res.rp[k] = src.rp[k]; }
+         return;
+      }
+   } else {
+      if (!(cLike > nThresh)) return;
+      tLike = cLike; tn = src.n;
+      for (int k = 0; k < src.n; k++) { tl[k] = src.rl[k]; tlm[k] = src.rlm[k]; tp[k] = src.rp[k]; }
+   }
+   const float diff = (float)(res.like - tLike);
+   const float limit = (float)((double)nThresh - tLike);
+   for (int i = 0; i < tn; i++) {
+      if (tl[i] < limit) break;
+      const int key = key_of(tp[i], nW);
+      const float like = tl[i] - diff;
+      int mch = -1;
+      for (int k = 0; k < res.n; k++) if (key_of(res.rp[k], nW) == key) { mch = k; break; }
+      if (mch < 0) {
+         if (res.n < nToks) { mch = res.n++; res.rl[mch] = (float)LZERO; res.rlm[mch] = 0.0f; res.rp[mch] = -1; }
+         else mch = res.n - 1;
+      }
+      if (like > res.rl[mch]) {
+         for (mch--; mch >= 0 && like > res.rl[mch]; mch--) { res.rl[mch + 1] = res.rl[mch]; res.rlm[mch + 1] = res.rlm[mch]; res.rp[mch + 1] = res.rp[mch]; }
+         mch++;
+         res.rp[mch] = tp[i]; res.rlm[mch] = tlm[i]; res.rl[mch] = like;
+      }
+   }
+}
+
+// predecessors k0..k1 (step 1) of a node merged in order into `res` (SetEntryState over StepInst2's sends)
+__device__ void pull_sets(const NArgs &a, const TSet *ex, int k0, int k1, float gT, float wT, float nT, TSet &res)
+{
+   for (int k = k0; k < k1; k++) {
+      const int ps = a.net.predSrc[k];
+      const float lm = a.net.predLike[k];
+      const TSet &e = ex[ps & 0x7fffffff];
+      if (!(e.like > gT)) continue;
+      if (ps < 0 && e.like < wT) continue;
+      const double c = e.like + lm * a.lmScale;
+      if (!(c > gT)) continue;
+      TSet x = e;
+      for (int q = 0; q < x.n; q++) x.rlm[q] = e.rlm[q] + lm;
+      ts_merge(res, c, e.lm + lm, e.path, x, nT, a.nToks, a.net.nWordNodes);
+   }
+}
+
+__device__ __forceinline__ double block_max_n(double v, double *red)
+{
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = (w > v) ? w : v; }
+   const int wv = threadIdx.x >> 6;
+   __syncthreads();
+   if ((threadIdx.x & 63) == 0) red[wv] = v;
+   __syncthreads();
+   double r = red[0];
+   for (int i = 1; i < DEC_THREADS / 64; i++) r = (red[i] > r) ? red[i] : r;
+   return r;
+}
+
+// StepWord2 for the token set `st` that entered word node n at frame t: the Path record and the exit set
+__device__ void word_exit(const NArgs &a, const DecUtt &ud, int n, int t, const TSet &st, TSet &e)
+{
+   const DecNet &N = a.net;
+   e = st;
+   e.like += a.wordPen;
+   e.like += N.pronProb[n] * a.prScale;
+   const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
+   a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
+   a.altN[ud.path0 + pid] = st.n - 1;
+   for (int k = 1; k < st.n; k++) {
+      const size_t z = (ud.path0 + pid) * (NT - 1) + (k - 1);
+      a.altLike[z] = e.like + st.rl[k]; a.altLm[z] = st.rlm[k]; a.altPrev[z] = st.rp[k];
+   }
+   e.path = (int)pid; e.lm = 0.0f;
+   e.n = 1; e.rl[0] = 0.0f; e.rlm[0] = 0.0f; e.rp[0] = e.path;
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
+{
+   __shared__ double red[DEC_THREADS / 64];
+   __shared__ double red2[DEC_THREADS / 64];
+   __shared__ float thr[3];
+   extern __shared__ unsigned char dynLds[];           // partial sets of a wide node: DEC_THREADS x TSet
+   TSet *part = (TSet *)dynLds;
+   const int u = blockIdx.x, tid = threadIdx.x;
+   if (u >= a.nUtt) return;
+   const DecUtt ud = a.utt[u];
+   const DecNet &N = a.net;
+   const int T = ud.T, nW = N.nWordNodes;
+   TSet *cur = a.tokA + ud.tok0, *nxt = a.tokB + ud.tok0, *ex = a.ex + ud.node0;
+   double *imax = a.imax + ud.node0;
+   const float *tpBase = N.transP;
+
+   { TSet z; ts_null(z);
+     for (int i = tid; i < N.nTok; i += DEC_THREADS) { cur[i] = z; nxt[i] = z; }
+     for (int i = tid; i < N.nNodes; i += DEC_THREADS) { ex[i] = z; imax[i] = LZERO; } }
+   for (size_t i = tid; i < (size_t)(T + 1) * nW; i += DEC_THREADS) a.mark[ud.path0 + i] = 0;
+   if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; thr[2] = (float)LSMALL; }
+   __syncthreads();
+
+   for (int t = 0; t <= T; t++) {
+      if (t >= 1) {
+         const float gT = thr[0], nT = thr[2];             // thresholds of the previous frame
+         double myGen = LZERO, myWord = LZERO;
+         for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
+            const int n = N.hmmNodes[hk];
+            const int4 ni = N.nodeInfo[n];
+            const int NS = (ni.x >> 4) & 255, t0 = ni.y;
+            const float *tp = tpBase + ni.z;
+            const bool detached = imax[n] < gT;
+            bool live = false;
+            for (int i = 1; i < NS; i++) {
+               if (i > 1 && detached) { TSet z; ts_null(z); cur[t0 + i - 1] = z; }
+               if (cur[t0 + i - 1].like > LSMALL) live = true;
+            }
+            TSet exS; ts_null(exS);
+            double mx = LZERO;
+            if (live) {
+               for (int j = 2; j < NS; j++) {
+                  int lo = 1, hi = NS - 1;
+                  while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
+                  while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
+                  if (lo > hi) { lo = 1; hi = NS - 1; }
+                  TSet res = cur[t0 + lo - 1];
+                  res.like += tp[(lo - 1) * NS + (j - 1)];
+                  for (int i = lo + 1; i <= hi; i++) {
+                     const TSet &si = cur[t0 + i - 1];
+                     ts_merge(res, si.like + tp[(i - 1) * NS + (j - 1)], si.lm, si.path, si, nT, a.nToks, nW);
+                  }
+                  if (res.like > gT) {
+                     const int st = N.hmmState[ni.w + (j - 2)];
+                     res.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
+                     if (res.like > mx) mx = res.like;
+                  } else ts_null(res);
+                  nxt[t0 + j - 1] = res;
+               }
+               { TSet z; ts_null(z); nxt[t0] = z; }          // entry consumed
+               {
+                  int lo = 2, hi = NS - 1;
+                  while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
+                  while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
+                  if (lo > hi) { lo = 2; hi = NS - 1; }
+                  TSet res = nxt[t0 + lo - 1];
+                  res.like += tp[(lo - 1) * NS + (NS - 1)];
+                  for (int i = lo + 1; i <= hi; i++) {
+                     const TSet &si = nxt[t0 + i - 1];
+                     ts_merge(res, si.like + tp[(i - 1) * NS + (NS - 1)], si.lm, si.path, si, nT, a.nToks, nW);
+                  }
+                  if (res.like > LSMALL) {
+                     exS = res;
+                     const double w = res.like + N.wdlk[n];
+                     if (w > myWord) myWord = w;
+                  }
+               }
+               if (mx > myGen) myGen = mx;
+            } else {
+               TSet z; ts_null(z);
+               for (int i = 1; i < NS; i++) nxt[t0 + i - 1] = z;
+            }
+            ex[n] = exS; imax[n] = (double)(float)mx;
+         }
+         const double genMax = block_max_n(myGen, red);
+         const double wordMax = block_max_n(myWord, red2);
+         if (tid == 0) {
+            float w = (float)(wordMax - a.wordBeam); if (w < (float)LSMALL) w = (float)LSMALL;
+            float g = (float)(genMax - a.genBeam); if (g < (float)LSMALL) g = (float)LSMALL;
+            float nn = (float)(genMax - a.nBeam); if (nn < (float)(LSMALL / 2)) nn = (float)(LSMALL / 2);
+            thr[0] = g; thr[1] = w; thr[2] = nn;
+         }
+         __syncthreads();
+         { TSet *sw = cur; cur = nxt; nxt = sw; }            // the new column is the current one from here on
+      }
+      const float gT = thr[0], wT = thr[1], nT = thr[2];
+      for (int L = 0; L < N.nLevels; L++) {
+         const int l0 = N.levelOff[L], lw = N.levelWide[L], l1 = N.levelOff[L + 1];
+         for (int k = l0 + tid; k < lw; k += DEC_THREADS) {
+            const int n = N.levelNodes[k];
+            const int4 ni = N.nodeInfo[n];
+            const int kind = ni.x & 15;
+            TSet st; ts_null(st);
+            pull_sets(a, ex, N.predOff[n], N.predOff[n + 1], gT, wT, nT, st);
+            if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; st.n = 1; st.rl[0] = 0.0f; st.rlm[0] = 0.0f; st.rp[0] = -1; }
+            TSet e; ts_null(e);
+            if (kind == HTKAMD_NODE_HMM) {                  // tee model: StepHMM2
+               const int NS = (ni.x >> 4) & 255;
+               cur[ni.y] = st;
+               e = ex[n];
+               const double m2 = (st.like > imax[n]) ? (double)(float)st.like : imax[n];
+               if (t >= 1 && m2 < gT) { ts_null(e); imax[n] = LZERO; }
+               else {
+                  imax[n] = m2;
+                  if (st.like > LSMALL) ts_merge(e, st.like + tpBase[ni.z + (NS - 1)], st.lm, st.path, st, nT, a.nToks, nW);
+               }
+            } else if (!(st.like > LSMALL)) imax[n] = LZERO;
+            else {
+               imax[n] = (double)(float)st.like;
+               if (kind == HTKAMD_NODE_WORD) word_exit(a, ud, n, t, st, e);
+               else e = st;
+            }
+            ex[n] = e;
+         }
+         for (int k = lw; k < l1; k++) {                   // wide fan-in: contiguous runs per thread, then thread 0 in run order
+            const int n = N.levelNodes[k];
+            const int p0 = N.predOff[n], p1 = N.predOff[n + 1];
+            const int per = (p1 - p0 + DEC_THREADS - 1) / DEC_THREADS;
+            TSet mine; ts_null(mine);
+            const int b0 = p0 + tid * per, b1 = (b0 + per < p1) ? b0 + per : p1;
+            if (b0 < p1) pull_sets(a, ex, b0, b1, gT, wT, nT, mine);
+            part[tid] = mine;
+            __syncthreads();
+            if (tid == 0) {
+               TSet st; ts_null(st);
+               for (int q = 0; q < DEC_THREADS; q++) {
+                  const TSet &pq = part[q];
+                  if (!(pq.like > LSMALL)) continue;
+                  ts_merge(st, pq.like, pq.lm, pq.path, pq, nT, a.nToks, nW);
+               }
+               if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; st.n = 1; st.rl[0] = 0.0f; st.rlm[0] = 0.0f; st.rp[0] = -1; }
+               TSet e; ts_null(e);
+               imax[n] = (st.like > LSMALL) ? (double)(float)st.like : LZERO;
+               if (st.like > LSMALL) {
+                  if (N.kind[n] == HTKAMD_NODE_WORD) word_exit(a, ud, n, t, st, e);
+                  else e = st;
+               }
+               ex[n] = e;
+            }
+            __syncthreads();
+         }
+         __syncthreads();
+      }
+      if (t < T) {
+         for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
+            const int n = N.hmmNodes[hk];
+            const int4 ni = N.nodeInfo[n];
+            if ((ni.x >> 12) & 1) continue;
+            TSet en; ts_null(en);
+            pull_sets(a, ex, N.predOff[n], N.predOff[n + 1], gT, wT, nT, en);
+            cur[ni.y] = en;
+            if (en.like > imax[n]) imax[n] = (double)(float)en.like;
+         }
+         __syncthreads();
+      }
+   }
+
+   // ---- CompleteRecognition -> CreateLattice: MarkPaths depth first, then one arc per Path / NxtPath (LatFromPaths)
+   if (tid == 0) {
+      const TSet fin = ex[N.final];
+      a.total[u] = LZERO;
+      int *latN = a.latN + 2 * u;
+      latN[0] = -1; latN[1] = 0;
+      if (fin.path >= 0) {
+         a.total[u] = fin.like;
+         const size_t nb = (size_t)u * a.maxLatNodes, ab = (size_t)u * a.maxLatArcs;
+         int *stk = a.stack + (size_t)u * 2 * a.maxLatNodes;
+         int nn = 1, nl = 0, sp = 0;
+         bool overflow = false;
+         // the root (a Path that is not in the table): node 1; children = fin.path, then fin.rp[1..]
+         nn = 2; nl = 1;
+         a.nodeFrame[nb + 0] = 0; a.nodeNet[nb + 0] = -1; a.nodeLike[nb + 0] = 0.0;
+         a.nodeFrame[nb + 1] = T; a.nodeNet[nb + 1] = -2; a.nodeLike[nb + 1] = fin.like;
+         // visit(p): number it, push it; children are looked at in order prev, alt 0, alt 1, ...
+#define VISIT(p_) do { const int pp_ = (p_); if (pp_ >= 0 && a.mark[ud.path0 + pp_] == 0) { \
+            if (nn >= a.maxLatNodes) overflow = true; else { a.mark[ud.path0 + pp_] = nn; \
+               a.nodeFrame[nb + nn] = pp_ / nW; a.nodeNet[nb + nn] = N.wordNode[pp_ % nW]; a.nodeLike[nb + nn] = a.pathLike[ud.path0 + pp_]; nn++; nl++; \
+               stk[2 * sp] = pp_; stk[2 * sp + 1] = 0; sp++; } } } while (0)
+         for (int c = 0; c < fin.n && !overflow; c++) {
+            if (c > 0) nl++;
+            VISIT(c == 0 ? fin.path : fin.rp[c]);
+            while (sp > 0 && !overflow) {
+               const int p = stk[2 * (sp - 1)];
+               const int ch = stk[2 * (sp - 1) + 1]++;
+               const int nAlt = a.altN[ud.path0 + p];
+               if (ch == 0) VISIT(a.pathPrev[ud.path0 + p]);
+               else if (ch - 1 < nAlt) { nl++; VISIT(a.altPrev[(ud.path0 + p) * (NT - 1) + (ch - 1)]); }
+               else sp--;
+            }
+         }
+#undef VISIT
+         if (overflow || nl > a.maxLatArcs) { latN[0] = -3; }
+         else {
+            int ln = 0;
+            // arcs of the root
+            for (int c = 0; c < fin.n; c++) {
+               const int prev = (c == 0) ? fin.path : fin.rp[c];
+               const double plike = (c == 0) ? fin.like : fin.like + fin.rl[c];
+               const float plm = (c == 0) ? fin.lm : fin.rlm[c];
+               const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
+               a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = 1;
+               a.arcAc[ab + ln] = (float)(plike - prlk - plm * a.lmScale - 0.0); a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = 0.0f; a.arcScore[ab + ln] = plike;
+               ln++;
+            }
+            for (int i = 2; i < nn; i++) {
+               const int p = a.nodeFrame[nb + i] * nW + N.wordIdx[a.nodeNet[nb + i]];
+               const int node = a.nodeNet[nb + i];
+               const int nAlt = a.altN[ud.path0 + p];
+               for (int c = 0; c <= nAlt; c++) {
+                  const size_t z = (ud.path0 + p) * (NT - 1) + (c - 1);
+                  const int prev = (c == 0) ? a.pathPrev[ud.path0 + p] : a.altPrev[z];
+                  const double plike = (c == 0) ? a.pathLike[ud.path0 + p] : a.altLike[z];
+                  const float plm = (c == 0) ? a.pathLm[ud.path0 + p] : a.altLm[z];
+                  const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
+                  const double wp = a.wordPen;
+                  float ac = (float)(plike - prlk - plm * a.lmScale - wp);
+                  const float pr = N.pronProb[node];
+                  ac -= pr * a.prScale;
+                  a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = i;
+                  a.arcAc[ab + ln] = ac; a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = pr; a.arcScore[ab + ln] = plike;
+                  ln++;
+               }
+            }
+            latN[0] = nn; latN[1] = ln;
+         }
+      }
+   }
+}
+
+// ------------------------------------------------------------------------------------ host side
+extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, const float *dX, const int *frameOff, int nUtt,
+                                          int maxLatNodes, int maxLatArcs, const htkamd_lattice_out *out, void *stream)
+{
+   if (!d || !cfg || !frameOff || nUtt < 0 || !out || !out->nNodes || !out->nArcs || maxLatNodes < 2 || maxLatArcs < 1) { htkamd_set_error("decoder_run_lattice: bad argument"); return HTKAMD_EINVAL; }
+   if (nToks < 2 || nToks > NT) { htkamd_set_error("decoder_run_lattice: nToks = %d (2..%d tokens per state)", nToks, NT); return HTKAMD_EINVAL; }
+   if (cfg->maxActive > 0) { htkamd_set_error("decoder_run_lattice: maximum-model pruning (-u) is not supported with token sets"); return HTKAMD_EINVAL; }
+   if (nUtt == 0) return HTKAMD_OK;
+   hipStream_t s = (hipStream_t)stream;
+   htkamd_model *m = d->m;
+   const DecNet &N = d->net;
+   const int ns = (int)d->usedStates.size();
+   const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
+   int u0 = 0;
+   while (u0 < nUtt) {
+      size_t bytes = 0; int u1 = u0;
+      while (u1 < nUtt) {
+         const size_t T = (size_t)(frameOff[u1 + 1] - frameOff[u1]);
+         const size_t b = (size_t)ns * T * 4 + (size_t)N.nTok * 2 * sizeof(TSet) + (size_t)N.nNodes * (sizeof(TSet) + 8) + (T + 1) * (size_t)N.nWordNodes * (24 + 16 * (NT - 1));
+         if (u1 > u0 && bytes + b > ((size_t)24 << 30)) break;
+         bytes += b; u1++;
+      }
+      const int nu = u1 - u0;
+      std::vector<DecUtt> utt(nu);
+      std::vector<ScoreTask> tasks;
+      size_t score = 0, tok = 0, node = 0, path = 0;
+      for (int k = 0; k < nu; k++) {
+         DecUtt &ud = utt[k];
+         ud.T = frameOff[u0 + k + 1] - frameOff[u0 + k]; ud.frame0 = frameOff[u0 + k]; ud.status = HTKAMD_UTT_OK; ud.pad = 0;
+         ud.score0 = score; ud.tok0 = tok; ud.node0 = node; ud.path0 = path; ud.out0 = 0;
+         for (int ti = 0; ti * FR < ud.T; ti++)
+            for (int ch = 0; ch * SL < ns; ch++) {
+               ScoreTask tk;
+               tk.frame0 = ud.frame0 + ti * FR; tk.nFrames = std::min(FR, ud.T - ti * FR);
+               tk.slot0 = ch * SL; tk.nSlots = std::min(SL, ns - ch * SL); tk.outSlot0 = ch * SL; tk.ldo = ud.T;
+               tk.outBase = ud.score0 + (size_t)ti * FR;
+               tasks.push_back(tk);
+            }
+         score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += (size_t)(ud.T + 1) * N.nWordNodes;
+      }
+      std::vector<void *> bufs;
+      int rc = HTKAMD_OK;
+      auto A = [&](size_t n) -> void * { void *p = nullptr; if (rc) return p; hipError_t e = hipMalloc(&p, n ? n : 1);
+                                          if (e != hipSuccess) { htkamd_set_error("decoder_run_lattice: hipMalloc(%zu): %s", n, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; return (void *)nullptr; }
+                                          bufs.push_back(p); return p; };
+      NArgs a; memset(&a, 0, sizeof(a));
+      void *dScore = A(score * 4);
+      a.tokA = (TSet *)A(tok * sizeof(TSet)); a.tokB = (TSet *)A(tok * sizeof(TSet)); a.ex = (TSet *)A(node * sizeof(TSet)); a.imax = (double *)A(node * 8);
+      a.pathPrev = (int *)A(path * 4); a.pathLike = (double *)A(path * 8); a.pathLm = (float *)A(path * 4);
+      a.altN = (int *)A(path * 4); a.altPrev = (int *)A(path * 4 * (NT - 1)); a.altLike = (double *)A(path * 8 * (NT - 1)); a.altLm = (float *)A(path * 4 * (NT - 1));
+      a.mark = (int *)A(path * 4); a.stack = (int *)A(sizeof(int) * (size_t)nu * 2 * maxLatNodes);
+      void *dUtt = A(sizeof(DecUtt) * nu), *dTasks = A(sizeof(ScoreTask) * tasks.size() + sizeof(int));
+      a.latN = (int *)A(sizeof(int) * 2 * nu);
+      a.nodeFrame = (int *)A(sizeof(int) * (size_t)nu * maxLatNodes); a.nodeNet = (int *)A(sizeof(int) * (size_t)nu * maxLatNodes); a.nodeLike = (double *)A(8 * (size_t)nu * maxLatNodes);
+      a.arcStart = (int *)A(sizeof(int) * (size_t)nu * maxLatArcs); a.arcEnd = (int *)A(sizeof(int) * (size_t)nu * maxLatArcs);
+      a.arcAc = (float *)A(4 * (size_t)nu * maxLatArcs); a.arcLm = (float *)A(4 * (size_t)nu * maxLatArcs); a.arcPr = (float *)A(4 * (size_t)nu * maxLatArcs);
+      a.arcScore = (double *)A(8 * (size_t)nu * maxLatArcs); a.total = (double *)A(8 * (size_t)nu);
+      if (!rc) {
+         hipError_t e;
+         if ((e = hipMemcpyAsync(dUtt, utt.data(), sizeof(DecUtt) * nu, hipMemcpyHostToDevice, s)) != hipSuccess ||
+             (e = hipMemcpyAsync(dTasks, tasks.data(), sizeof(ScoreTask) * tasks.size(), hipMemcpyHostToDevice, s)) != hipSuccess) {
+            htkamd_set_error("decoder_run_lattice: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP;
+         }
+      }
+      if (!rc) {
+         ScoreArgs sa;
+         sa.tasks = (const ScoreTask *)dTasks; sa.nTasks = (int)tasks.size(); sa.X = dX; sa.slotState = d->d_usedStates; sa.out = (float *)dScore;
+         sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
+         sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
+         sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)((char *)dTasks + sizeof(ScoreTask) * tasks.size());
+         sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
+         if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run_lattice: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
+         else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);
+      }
+      if (!rc) {
+         a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
+         a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.nBeam = nBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
+         a.nToks = nToks; a.maxLatNodes = maxLatNodes; a.maxLatArcs = maxLatArcs;
+         const size_t lds = sizeof(TSet) * DEC_THREADS;
+         hipError_t e = hipFuncSetAttribute((const void *)k_decode_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e == hipSuccess) { hipLaunchKernelGGL(k_decode_n, dim3(nu), dim3(DEC_THREADS), lds, s, a); e = hipGetLastError(); }
+         if (e != hipSuccess) { htkamd_set_error("decoder_run_lattice: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+      }
+      std::vector<int> hN(2 * nu), hNF, hNN, hAS, hAE; std::vector<double> hNL, hSc, hT(nu); std::vector<float> hAc, hLm, hPr;
+      if (!rc) {
+         hNF.resize((size_t)nu * maxLatNodes); hNN.resize(hNF.size()); hNL.resize(hNF.size());
+         hAS.resize((size_t)nu * maxLatArcs); hAE.resize(hAS.size()); hAc.resize(hAS.size()); hLm.resize(hAS.size()); hPr.resize(hAS.size()); hSc.resize(hAS.size());
+         hipError_t e;
+#define D2H(h, dptr) ((e = hipMemcpyAsync((h).data(), (dptr), sizeof((h)[0]) * (h).size(), hipMemcpyDeviceToHost, s)) != hipSuccess)
+         if (D2H(hN, a.latN) || D2H(hNF, a.nodeFrame) || D2H(hNN, a.nodeNet) || D2H(hNL, a.nodeLike) || D2H(hAS, a.arcStart) || D2H(hAE, a.arcEnd) ||
+             D2H(hAc, a.arcAc) || D2H(hLm, a.arcLm) || D2H(hPr, a.arcPr) || D2H(hSc, a.arcScore) || D2H(hT, a.total) ||
+             (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run_lattice: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+#undef D2H
+      } else (void)hipStreamSynchronize(s);
+      for (void *p : bufs) (void)hipFree(p);
+      if (rc) return rc;
+      for (int k = 0; k < nu; k++) {
+         const int uu = u0 + k;
+         out->nNodes[uu] = hN[2 * k]; out->nArcs[uu] = hN[2 * k + 1];
+         if (out->total) out->total[uu] = hT[k];
+         const int nn = hN[2 * k] > 0 ? hN[2 * k] : 0, na = hN[2 * k] > 0 ? hN[2 * k + 1] : 0;
+         for (int i = 0; i < nn; i++) {
+            const size_t o = (size_t)uu * maxLatNodes + i, si = (size_t)k * maxLatNodes + i;
+            if (out->nodeFrame) out->nodeFrame[o] = hNF[si];
+            if (out->nodeNet) out->nodeNet[o] = hNN[si];
+            if (out->nodePron) out->nodePron[o] = hNN[si] >= 0 ? d->hostModel[hNN[si]] : -1;
+            if (out->nodeLike) out->nodeLike[o] = hNL[si];
+         }
+         for (int i = 0; i < na; i++) {
+            const size_t o = (size_t)uu * maxLatArcs + i, si = (size_t)k * maxLatArcs + i;
+            if (out->arcStart) out->arcStart[o] = hAS[si];
+            if (out->arcEnd) out->arcEnd[o] = hAE[si];
+            if (out->arcAc) out->arcAc[o] = hAc[si];
+            if (out->arcLm) out->arcLm[o] = hLm[si];
+            if (out->arcPr) out->arcPr[o] = hPr[si];
+            if (out->arcScore) out->arcScore[o] = hSc[si];
+         }
+      }
+      u0 = u1;
+   }
+   return HTKAMD_OK;
+}

@@ -226,7 +226,7 @@ long htkamd_scp_end(const struct htkamd_scp *s, int i) { return (s && i >= 0 && 
 #include <math.h>
 
 typedef struct { double start, end; char *name; float score; char *aux[2]; float auxScore[2]; } trans_lab;
-struct htkamd_trans { int n, cap, maxAux; trans_lab *lab; };
+struct htkamd_trans { int n, cap, maxAux; trans_lab *lab; struct htkamd_trans *next; };     /* next: the next alternative (label list) */
 
 int htkamd_trans_create(int maxAux, struct htkamd_trans **out)
 {
@@ -239,9 +239,22 @@ int htkamd_trans_create(int maxAux, struct htkamd_trans **out)
 
 void htkamd_trans_free(struct htkamd_trans *t)
 {
-   if (!t) return;
-   for (int i = 0; i < t->n; i++) { free(t->lab[i].name); free(t->lab[i].aux[0]); free(t->lab[i].aux[1]); }
-   free(t->lab); free(t);
+   while (t) {
+      struct htkamd_trans *nx = t->next;
+      for (int i = 0; i < t->n; i++) { free(t->lab[i].name); free(t->lab[i].aux[0]); free(t->lab[i].aux[1]); }
+      free(t->lab); free(t);
+      t = nx;
+   }
+}
+
+/* N-best output: `alt` becomes the last alternative of `t` (a Transcription with several label lists, AddLabelList HLabel.c;
+   written one after the other with a line of "///" between them, SaveHTKLabels :1522).  `t` owns it from here on. */
+int htkamd_trans_append_alternative(struct htkamd_trans *t, struct htkamd_trans *alt)
+{
+   if (!t || !alt || t == alt) { htkamd_set_error("trans_append_alternative: bad argument"); return HTKAMD_EINVAL; }
+   while (t->next) t = t->next;
+   t->next = alt;
+   return HTKAMD_OK;
 }
 
 /* start / end in 100 ns units (-1 = absent); aux1 / aux2 may be NULL */
@@ -268,6 +281,7 @@ static void tri_strip_inplace(char *s)                       /* TriStrip (HLabel
 int htkamd_trans_format(struct htkamd_trans *t, double frameDur, int states, int models, int flags)
 {
    if (!t || frameDur <= 0) { htkamd_set_error("trans_format: bad argument"); return HTKAMD_EINVAL; }
+   if (t->next) { const int rc = htkamd_trans_format(t->next, frameDur, states, models, flags); if (rc) return rc; }
    if (flags & HTKAMD_OUT_NOSCORES)
       for (int i = 0; i < t->n; i++) { t->lab[i].score = 0.0f; t->lab[i].auxScore[0] = t->lab[i].auxScore[1] = 0.0f; }
    if (flags & HTKAMD_OUT_TRISTRIP)
@@ -321,7 +335,12 @@ static void write_name(FILE *f, const char *s)               /* WriteString with
    if (q) fputc(q, f);
 }
 
+static void trans_print_one(FILE *f, const struct htkamd_trans *t);
 static void trans_print(FILE *f, const struct htkamd_trans *t)
+{
+   for (; t; t = t->next) { trans_print_one(f, t); if (t->next) fprintf(f, "///\n"); }
+}
+static void trans_print_one(FILE *f, const struct htkamd_trans *t)
 {
    int has[3] = {0, 0, 0};
    for (int i = 0; i < t->n; i++) {

@@ -771,5 +771,14 @@ int htkamd_net_seq_models(const struct htkamd_net *n, int k, int prevPron, int n
    return d->nPhones;
 }
 
+/* number of pronunciation k among the pronunciations of its word, 1-based, in dictionary order (Pron.pnum: the v= field of lattices) */
+int htkamd_net_pron_num(const struct htkamd_net *n, int k)
+{
+   if (!n || k < 0 || k >= n->nPron) return 0;
+   int v = 1;
+   for (int i = 0; i < k; i++) if (!strcmp(n->pron[i].word, n->pron[k].word)) v++;
+   return v;
+}
+
 /* the dictionary word a pronunciation belongs to (HVite -m/-f label the first model of a word with the word's NAME) */
 const char *htkamd_net_word_name(const struct htkamd_net *n, int k) { return (n && k >= 0 && k < n->nPron) ? n->pron[k].word : NULL; }

@@ -176,6 +176,7 @@ void htkamd_trans_free(htkamd_trans *t);
 int  htkamd_trans_add(htkamd_trans *t, double start, double end, const char *name, float score,
                       const char *aux1, float aux1Score, const char *aux2, float aux2Score);
 int  htkamd_trans_format(htkamd_trans *t, double frameDur, int states, int models, int flags);
+int  htkamd_trans_append_alternative(htkamd_trans *t, htkamd_trans *alt);   /* N-best: further label lists, written after a line of "///"; t owns alt */
 int  htkamd_trans_write(const htkamd_trans *t, const char *path);
 int  htkamd_mlf_out_open(const char *path, htkamd_mlf_out **out);
 int  htkamd_mlf_out_add(htkamd_mlf_out *o, const char *labFile, const htkamd_trans *t);
@@ -504,6 +505,53 @@ typedef struct {
 } htkamd_decode_config;
 typedef struct htkamd_decoder htkamd_decoder;
 int  htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *net, float lmScale, htkamd_decoder **out);
+/* N-best token passing and lattice generation (HVite -n N [-z ext]; HRec.c with nToks > 1: TokSetMerge :279, StepWord2's NxtPath
+ * chains :1046, CreateLattice :1679 / LatFromPaths :1512).  Every state keeps its best token and up to nToks-1 alternatives that
+ * differ in the word they came from; the lattice of an utterance = the word ends reachable from the final token set:
+ *   node 0 = start, node 1 = end (both !NULL, nodePron -1), the others word ends {frame, pronunciation, likelihood of the Path};
+ *   arc = one way into a word end: aclike, lmlike (unscaled LM log probability), prlike (log pronunciation probability).
+ * nToks: 2..8;  nBeam: alternatives more than this below the frame's best token are dropped (HVite uses its -t value);
+ * cfg->maxActive must be 0.  Outputs per utterance u at [u*maxLatNodes + i] / [u*maxLatArcs + j]; nNodes[u] = -1: no token reached
+ * the end, -3: the lattice did not fit.  Pointers other than nNodes / nArcs may be NULL. */
+typedef struct {
+   int *nNodes, *nArcs;
+   int *nodeFrame, *nodePron, *nodeNet;
+   double *nodeLike;
+   int *arcStart, *arcEnd;
+   float *arcAc, *arcLm, *arcPr;
+   double *arcScore;
+   double *total;
+} htkamd_lattice_out;
+int  htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, const float *dX, const int *frameOff, int nUtt,
+                                int maxLatNodes, int maxLatArcs, const htkamd_lattice_out *out, void *stream);
+/* One utterance's lattice for the host-side functions below (pointers into the arrays above). */
+typedef struct {
+   int nNodes, nArcs;
+   const int *nodeFrame, *nodePron;
+   const double *nodeLike;
+   const int *arcStart, *arcEnd;
+   const float *arcAc, *arcLm, *arcPr;
+   float lmScale, wordPen, prScale;     /* of the recognition run (header fields, LArcTotLike) */
+   double frameDur;                     /* seconds per frame */
+} htkamd_lattice;
+/* WriteLattice (HNet.c:631): the SLF text file, byte for byte the reference's for the supported fields.  format = HVite -q letters as
+ * bits; 0 = HTKAMD_LAT_DEFAULT (t v a l).  utterance / lmName / vocabName: header lines (NULL = left out). */
+#define HTKAMD_LAT_ALABS  0x0001
+#define HTKAMD_LAT_LBIN   0x0002
+#define HTKAMD_LAT_TIMES  0x0008
+#define HTKAMD_LAT_PRON   0x0010
+#define HTKAMD_LAT_ACLIKE 0x0020
+#define HTKAMD_LAT_LMLIKE 0x0040
+#define HTKAMD_LAT_ALIGN  0x0080
+#define HTKAMD_LAT_PRLIKE 0x0400
+#define HTKAMD_LAT_DEFAULT (HTKAMD_LAT_TIMES | HTKAMD_LAT_PRON | HTKAMD_LAT_ACLIKE | HTKAMD_LAT_LMLIKE)
+int  htkamd_lattice_write(const htkamd_lattice *lat, const htkamd_net *net, const char *path, const char *utterance, const char *lmName,
+                          const char *vocabName, int format);
+/* TranscriptionFromLattice (HRec.c:2176) with N > 1: the N most likely paths with distinct word sequences, best first.  Alternative i has
+ * altLen[i] arcs altArcs[i*maxLen + 0..], start to end, the closing arc into the end node left out. */
+int  htkamd_lattice_nbest(const htkamd_lattice *lat, const htkamd_net *net, int N, int maxLen, int *nAlt, int *altLen, int *altArcs);
+float htkamd_lattice_arc_score(const htkamd_lattice *lat, int arc);      /* LArcTotLike (HNet.h:257): the score a label of that word carries */
+int  htkamd_net_pron_num(const htkamd_net *n, int pron);                  /* v= : number of the pronunciation within its word, from 1 */
 void htkamd_decoder_destroy(htkamd_decoder *d);
 int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
                         int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,

@@ -154,6 +154,16 @@ int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int has
 /* ---- Viterbi forced alignment of a chain of physical models (HRec token passing, 1-best; orc_viterbi.c) ----
    Returns the number of state segments (time order) or -1 when no token survives.  Frames are 0-based,
    [segStart, segEnd).  segScore = like(next Align record) - like(this one) (LatFromPaths HRec.c:1512). */
+/* N-best token passing + lattice (orc_decode_n.c; HVite -n nToks): the lattice CreateLattice builds from the final token set.
+   Node 0 = start, node 1 = end (no word); latNodeNet = network node of the word end (-1 start, -2 end).  Returns 0, -1 if no token
+   reached the final node, -3 if the lattice does not fit. */
+int orc_decode_nbest(const orc_model *m, const float *X, int T,
+                     int nNodes, const int *kind, const int *model, const float *pronProb,
+                     const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
+                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks,
+                     int maxLatNodes, int maxLatArcs, int *latNodeNet, int *latNodeFrame, double *latNodeLike,
+                     int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
+                     int *nLatNodes, int *nLatArcs, double *totalLike);
 /* 1-best decoding over a flat recognition network (orc_decode.c): returns the number of words, -1 if no token reached
    the final node, -3 if maxWords is too small, -4 if the zero-time nodes form a loop.  Frames are 0-based boundaries. */
 int orc_decode(const orc_model *m, const float *X, int T,

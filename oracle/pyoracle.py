@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(BUILD, "libhtk_oracle.so")
-SRCS = ["htk_oracle.c", "orc_viterbi.c", "orc_mfcc.c", "orc_decode.c"]
+SRCS = ["htk_oracle.c", "orc_viterbi.c", "orc_mfcc.c", "orc_decode.c", "orc_decode_n.c"]
 
 LZERO = -1.0e10
 LSMALL = -0.5e10
@@ -297,6 +297,32 @@ def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
     if T > 0:
         lib().orc_mfcc(_p(wav), C.c_int(len(wav)), C.byref(cfg), _p(out))
     return out
+
+
+def decode_nbest(model: "Model", X: np.ndarray, net: dict, nToks: int, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=1.0, wordPen=0.0, prScale=1.0,
+                 maxNodes=20000, maxArcs=80000):
+    """HRec with nToks > 1 (HVite -n): the lattice of CreateLattice as a dict of arrays, or None when no token reached the final node.
+    nBeam defaults to genBeam (HVite.c:546)."""
+    X = np.ascontiguousarray(X, np.float32)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    kind, mdl, pp, lo, ld, ll = i32(net["kind"]), i32(net["model"]), f32(net["pronProb"]), i32(net["linkOff"]), i32(net["linkDest"]), f32(net["linkLike"])
+    nn = C.c_int(0); na = C.c_int(0); tot = C.c_double(0.0)
+    nNet = np.zeros(maxNodes, np.int32); nFr = np.zeros(maxNodes, np.int32); nLk = np.zeros(maxNodes, np.float64)
+    aS = np.zeros(maxArcs, np.int32); aE = np.zeros(maxArcs, np.int32); aAc = np.zeros(maxArcs, np.float32); aLm = np.zeros(maxArcs, np.float32)
+    aPr = np.zeros(maxArcs, np.float32); aSc = np.zeros(maxArcs, np.float64)
+    rc = lib().orc_decode_nbest(C.byref(model.c), _p(X), C.c_int(X.shape[0]), C.c_int(len(kind)), _p(kind), _p(mdl), _p(pp), _p(lo), _p(ld), _p(ll),
+                                C.c_int(int(net["initial"])), C.c_int(int(net["final"])), C.c_float(genBeam), C.c_float(wordBeam),
+                                C.c_float(genBeam if nBeam is None else nBeam), C.c_float(lmScale), C.c_float(wordPen), C.c_float(prScale), C.c_int(nToks),
+                                C.c_int(maxNodes), C.c_int(maxArcs), _p(nNet), _p(nFr), _p(nLk), _p(aS), _p(aE), _p(aAc), _p(aLm), _p(aPr), _p(aSc),
+                                C.byref(nn), C.byref(na), C.byref(tot))
+    if rc == -1:
+        return None
+    if rc < 0:
+        raise RuntimeError("orc_decode_nbest failed (%d)" % rc)
+    n, a = nn.value, na.value
+    return dict(nodeNet=nNet[:n].copy(), nodeFrame=nFr[:n].copy(), nodeLike=nLk[:n].copy(), arcStart=aS[:a].copy(), arcEnd=aE[:a].copy(),
+                arcAc=aAc[:a].copy(), arcLm=aLm[:a].copy(), arcPr=aPr[:a].copy(), arcScore=aSc[:a].copy(), total=tot.value)
 
 
 def decode(model: "Model", X: np.ndarray, net: dict, genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0, maxWords=4096, maxActive=0):

@@ -193,6 +193,41 @@ def test_hvite_cli_cross_word_expansion(native, tools, tmp_path, which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", json.load(open(os.path.join(GOLD, "nbest", "index.json"))))
+def test_hvite_cli_nbest_and_lattices(native, tools, tmp_path, tag):
+    """hvite -n i [N] [-z lat]: the lattice files and the N-best label files (alternatives separated by "///") of the reference's HVite,
+    byte for byte (WriteLattice HNet.c:631, TranscriptionFromLattice HRec.c:2176).  Run inside a directory with the reference run's
+    relative file names, so that the header lines of the lattices agree as well."""
+    from htk_amd import synth
+    meta = json.load(open(os.path.join(GOLD, "nbest", tag, "nbest.json")))
+    src = os.path.join(GOLD, meta["case"])
+    for fn in ("MMF", "dict", "hmmlist", meta["slf"] + ".slf"):
+        os.symlink(os.path.join(src, fn), str(tmp_path / fn))
+    cfg = []
+    if os.path.exists(os.path.join(src, "config")):
+        os.symlink(os.path.join(src, "config"), str(tmp_path / "config")); cfg = ["-C", "config"]
+    (tmp_path / "nbtmp").mkdir()
+    z = np.load(os.path.join(src, meta["feats"] + ".npz"))
+    files = []
+    for u in range(len(z.files)):
+        synth.write_htk_param(str(tmp_path / "nbtmp" / ("u%d.mfc" % u)), z["u%d" % u], kind=9)
+        files.append("nbtmp/u%d.mfc" % u)
+    base = [os.path.join(tools, "hvite")] + cfg + ["-H", "MMF", "-w", meta["slf"] + ".slf"] + meta["opts"].split()
+    r = run(base + ["-l", "nbtmp", "-n", str(meta["nToks"]), "1", "-z", "lat", "dict", "hmmlist"] + files, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    for u in range(len(files)):
+        assert (tmp_path / "nbtmp" / ("u%d.lat" % u)).read_text() == open(os.path.join(GOLD, "nbest", tag, "u%d.lat" % u)).read(), (tag, u)
+        assert (tmp_path / "nbtmp" / ("u%d.rec" % u)).read_text().splitlines() == meta["nbest"]["u%d" % u][0]
+    r = run(base + ["-i", "nb.mlf", "-n", str(meta["nToks"]), str(meta["nTrans"]), "dict", "hmmlist"] + files, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    want = ["#!MLF!#"]
+    for u in range(len(files)):
+        want.append('"nbtmp/u%d.rec"' % u)
+        want += "\n///\n".join("\n".join(a) for a in meta["nbest"]["u%d" % u]).split("\n") + ["."]
+    assert (tmp_path / "nb.mlf").read_text().splitlines() == want
+
+
+@pytest.mark.gpu
 def test_hvite_cli_word_level_alignment(native, tools, tmp_path):
     """hvite -a [-b w] [-m] from word-level label files (DoAlignment HVite.c:830) against the reference's label files."""
     src, files = _write_case_files(native, "bigram", tmp_path)

@@ -1,0 +1,90 @@
+"""N-best recognition and lattice output (HVite -n N [M] -z lat) against the reference's files (tests/golden/make_nbest_golden.py):
+CPU   the oracle's token-set decoder (oracle/orc_decode_n.c) through the product's host code -- htkamd_lattice_write must give the SLF
+      file HVite wrote, byte for byte, and htkamd_lattice_nbest its alternative transcriptions, line for line;
+GPU   the token-set kernel (htk_amd/csrc/decode_n.hip) must give the oracle's lattice: same nodes, same arcs, same float scores."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from decode_util import GOLD, load_decode_case, parse_opts
+
+NB = os.path.join(GOLD, "nbest")
+TAGS = json.load(open(os.path.join(NB, "index.json")))
+
+
+def _case(native, tag):
+    meta = json.load(open(os.path.join(NB, tag, "nbest.json")))
+    name = meta["case"] + (":" + meta["slf"] if meta["slf"] != "net" else "")
+    mmf, net, feats, _ = load_decode_case(native, name)
+    p = parse_opts(meta["opts"])
+    return meta, mmf, net, feats, p
+
+
+def _with_prons(lat, net):
+    a = net.arrays()
+    lat = dict(lat)
+    lat["nodePron"] = np.array([a["model"][n] if n >= 0 else -1 for n in lat["nodeNet"]], np.int32)
+    return lat
+
+
+def _labels(alt, net, frame_dur=100000):
+    return ["%d %d %s %f" % (s * frame_dur, e * frame_dur, net.out_syms[w], np.float32(sc)) for w, s, e, sc in alt if w >= 0 and net.out_syms[w] != ""]
+
+
+def _check_files(native, lat, net, meta, tag, u, tmp_path):
+    out = str(tmp_path / ("u%d.lat" % u))
+    native.lattice_write(lat, net, out, utterance="nbtmp/u%d.mfc" % u, lm_name=meta["slf"] + ".slf", vocab_name="dict")
+    assert open(out).read() == open(os.path.join(NB, tag, "u%d.lat" % u)).read(), (tag, u)
+    alts = native.lattice_nbest(lat, net, meta["nTrans"])
+    assert [_labels(a, net) for a in alts] == meta["nbest"]["u%d" % u], (tag, u)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_token_sets_and_host_lattice_code_equal_hvite(native, oracle, tag, tmp_path):
+    meta, mmf, net, feats, p = _case(native, tag)
+    om = oracle.Model(mmf.packed())
+    n = 0
+    for u, X in enumerate(feats):
+        lat = oracle.decode_nbest(om, X, net.arrays(), meta["nToks"], **p)
+        assert lat is not None
+        lat = _with_prons(lat, net)
+        lat.update(lmScale=p["lmScale"], wordPen=p["wordPen"], prScale=p["prScale"])
+        _check_files(native, lat, net, meta, tag, u, tmp_path)
+        n += len(lat["arcStart"])
+    assert n > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_token_set_kernel_equals_oracle_and_hvite(native, oracle, tag, tmp_path):
+    meta, mmf, net, feats, p = _case(native, tag)
+    model = native.Model(mmf.packed())
+    om = oracle.Model(mmf.packed())
+    dec = native.Decoder(model, net, lmScale=p["lmScale"])
+    lats = dec.run_lattice(feats, meta["nToks"], **p)
+    for u, X in enumerate(feats):
+        ref = oracle.decode_nbest(om, X, net.arrays(), meta["nToks"], **p)
+        got = lats[u]
+        assert got is not None and ref is not None
+        assert got["total"] == ref["total"]
+        for k in ("nodeFrame", "nodeNet", "nodeLike"):
+            assert np.array_equal(got[k], ref[k]), (tag, u, k)
+        arcs = lambda l: sorted(zip(l["arcStart"].tolist(), l["arcEnd"].tolist(), l["arcAc"].tolist(), l["arcLm"].tolist(), l["arcPr"].tolist(), l["arcScore"].tolist()))
+        assert arcs(got) == arcs(ref), (tag, u)                     # the order in which the arcs are listed is not part of the lattice
+        _check_files(native, got, net, meta, tag, u, tmp_path)
+
+
+@pytest.mark.gpu
+def test_token_set_kernel_edge_cases(native):
+    mmf, net, feats, _ = load_decode_case(native, "bigram")
+    model = native.Model(mmf.packed())
+    dec = native.Decoder(model, net)
+    assert dec.run_lattice([], 3) == []
+    res = dec.run_lattice([feats[0], feats[0][:1]], 3, genBeam=250.0)
+    assert res[0] is not None and res[1] is None                     # one frame cannot reach the end of the network
+    with pytest.raises(native.HtkAmdError):
+        dec.run_lattice([feats[0]], 9)                               # at most 8 tokens per state
+    with pytest.raises(native.HtkAmdError):
+        dec.run_lattice([feats[0]], 3, genBeam=250.0, maxNodes=4)    # a lattice that does not fit is an error, not a truncated file

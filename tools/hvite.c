@@ -102,6 +102,8 @@ int main(int argc, char **argv)
    const char *hmmDir = NULL, *hmmExt = NULL, *netPath = NULL, *labDir = NULL, *labExt = "lab", *mlfIn = NULL, *mlfOut = NULL, *outDir = NULL, *outExt = "rec", *boundary = NULL;
    float genBeam = 0.0f, wordBeam = 0.0f, lmScale = 1.0f, wordPen = 0.0f, prScale = 1.0f;
    int align = 0, models = 0, states = 0, oflags = 0, trace = 0, scoreMode = HTKAMD_SCORE_EXACT, batchN = 1024, maxActive = 0;
+   int nToks = 0, nTrans = 1, latFmt = 0;
+   const char *latExt = NULL;
    const char *sw;
 
    while (a.at < a.argc && is_switch(a.argv[a.at])) {
@@ -145,6 +147,19 @@ int main(int argc, char **argv)
       case 'p': wordPen = (float)flt_arg(&a, sw); break;
       case 'r': prScale = (float)flt_arg(&a, sw); break;
       case 'u': maxActive = atoi(str_arg(&a, sw)); break;
+      case 'n':                                              /* -n i [N]: i tokens per state, N-best transcriptions (HVite.c:287-291) */
+         nToks = atoi(str_arg(&a, sw));
+         if (a.at < a.argc && isdigit((unsigned char)a.argv[a.at][0]) && a.at + 2 < a.argc) nTrans = atoi(a.argv[a.at++]);
+         break;
+      case 'z': latExt = str_arg(&a, sw); break;
+      case 'q':
+         for (const char *c = str_arg(&a, sw); *c; c++)
+            switch (*c) {
+            case 't': latFmt |= HTKAMD_LAT_TIMES; break; case 'v': latFmt |= HTKAMD_LAT_PRON; break; case 'a': latFmt |= HTKAMD_LAT_ACLIKE; break;
+            case 'l': latFmt |= HTKAMD_LAT_LMLIKE; break; case 'r': latFmt |= HTKAMD_LAT_PRLIKE; break;
+            default: DIE("hvite -q: only t v a l r are supported");
+            }
+         break;
       case 'T': trace = atoi(str_arg(&a, sw)); break;
       default: DIE("hvite: unknown switch -%s", sw);
       }
@@ -154,6 +169,9 @@ int main(int argc, char **argv)
    while (a.at < a.argc) sl_add(&files, a.argv[a.at++]);
    if (files.n == 0) DIE("hvite: no data files");
    if (!align && !netPath) DIE("hvite: either -w net or -a");
+   if (nToks == 1 || nToks > 8) DIE("hvite -n: 2..8 tokens per state");
+   if (nToks > 1 && (models || states || align)) DIE("hvite: alignment using multiple tokens is not supported");       /* HVite.c:448 */
+   if (latExt && nToks < 2) DIE("hvite -z: lattices need -n i with i > 1");
    if (htkamd_device_count() <= 0) DIE("hvite: no HIP device (the MI355X path has no CPU fallback)");
 
    htkamd_mmf *mmf; CHECK(htkamd_mmf_create(&mmf));
@@ -195,6 +213,61 @@ int main(int argc, char **argv)
          CHECK(htkamd_decoder_create(model, htkamd_net_get(unet), lmScale, &udec));
          free(words);
          if (L) htkamd_labels_free(L);
+      }
+      if (nToks > 1) {
+         /* ---- N-best: token sets on the device, lattice per file, then WriteLattice / the N most likely transcriptions on the host */
+         const int maxN = 65536, maxA = 262144;
+         const int per = (count < 32) ? count : 32;                    /* lattices of 32 files at a time */
+         for (int b0 = 0; b0 < count; b0 += per) {
+            const int nb = (count - b0 < per) ? count - b0 : per;
+            int *nN = (int *)calloc((size_t)nb, sizeof(int)), *nA = (int *)calloc((size_t)nb, sizeof(int));
+            int *nodeFrame = (int *)malloc(sizeof(int) * (size_t)nb * maxN), *nodePron = (int *)malloc(sizeof(int) * (size_t)nb * maxN);
+            double *nodeLike = (double *)malloc(sizeof(double) * (size_t)nb * maxN);
+            int *aS = (int *)malloc(sizeof(int) * (size_t)nb * maxA), *aE = (int *)malloc(sizeof(int) * (size_t)nb * maxA);
+            float *aAc = (float *)malloc(sizeof(float) * (size_t)nb * maxA), *aLm = (float *)malloc(sizeof(float) * (size_t)nb * maxA), *aPr = (float *)malloc(sizeof(float) * (size_t)nb * maxA);
+            htkamd_lattice_out lo; memset(&lo, 0, sizeof(lo));
+            lo.nNodes = nN; lo.nArcs = nA; lo.nodeFrame = nodeFrame; lo.nodePron = nodePron; lo.nodeLike = nodeLike; lo.arcStart = aS; lo.arcEnd = aE; lo.arcAc = aAc; lo.arcLm = aLm; lo.arcPr = aPr;
+            int *fo = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
+            for (int u = 0; u <= nb; u++) fo[u] = ob.frameOff[b0 + u] - ob.frameOff[b0];
+            CHECK(htkamd_decoder_run_lattice(dec, &dc, nToks, dc.genBeam, ob.dX + (size_t)ob.frameOff[b0] * ob.cols, fo, nb, maxN, maxA, &lo, NULL));   /* nBeam = genBeam (HVite.c:546) */
+            for (int u = 0; u < nb; u++) {
+               const char *fn = files.v[first + b0 + u];
+               if (nN[u] == -1) { fprintf(stderr, "No tokens survived to final node of network: %s\n", fn); continue; }
+               if (nN[u] < 0) DIE("the lattice of %s does not fit (%d nodes / %d arcs of room)", fn, maxN, maxA);
+               htkamd_lattice lat; memset(&lat, 0, sizeof(lat));
+               lat.nNodes = nN[u]; lat.nArcs = nA[u]; lat.nodeFrame = nodeFrame + (size_t)u * maxN; lat.nodePron = nodePron + (size_t)u * maxN; lat.nodeLike = nodeLike + (size_t)u * maxN;
+               lat.arcStart = aS + (size_t)u * maxA; lat.arcEnd = aE + (size_t)u * maxA; lat.arcAc = aAc + (size_t)u * maxA; lat.arcLm = aLm + (size_t)u * maxA; lat.arcPr = aPr + (size_t)u * maxA;
+               lat.lmScale = lmScale; lat.wordPen = wordPen; lat.prScale = prScale; lat.frameDur = (double)ob.period * 1.0e-7;
+               char out[2048];
+               if (latExt) { make_fn(fn, outDir, latExt, out, sizeof(out)); CHECK(htkamd_lattice_write(&lat, net, out, fn, netPath, dictPath, latFmt ? latFmt : HTKAMD_LAT_DEFAULT)); }
+               /* "only output 1-best transcription if generating lattices" (HVite.c:797) */
+               const int want = (nTrans > 1 && latExt) ? 1 : nTrans;
+               int nAlt = 0, *altLen = (int *)malloc(sizeof(int) * (size_t)want), *altArcs = (int *)malloc(sizeof(int) * (size_t)want * maxWords);
+               CHECK(htkamd_lattice_nbest(&lat, net, want, maxWords, &nAlt, altLen, altArcs));
+               htkamd_trans *head = NULL;
+               for (int i = 0; i < nAlt; i++) {
+                  htkamd_trans *tr; CHECK(htkamd_trans_create(0, &tr));
+                  for (int j = 0; j < altLen[i]; j++) {
+                     const int arc = altArcs[(size_t)i * maxWords + j], pron = lat.nodePron[lat.arcEnd[arc]];
+                     const char *sym = pron >= 0 ? htkamd_net_out_sym(net, pron) : NULL;
+                     if (!sym || !sym[0]) continue;
+                     CHECK(htkamd_trans_add(tr, (double)lat.nodeFrame[lat.arcStart[arc]] * ob.period, (double)lat.nodeFrame[lat.arcEnd[arc]] * ob.period, sym,
+                                            htkamd_lattice_arc_score(&lat, arc), NULL, 0, NULL, 0));
+                  }
+                  if (!head) head = tr; else CHECK(htkamd_trans_append_alternative(head, tr));
+               }
+               if (head) {
+                  CHECK(htkamd_trans_format(head, (double)ob.period, 0, 0, oflags));
+                  make_fn(fn, outDir, outExt, out, sizeof(out));
+                  if (mout) CHECK(htkamd_mlf_out_add(mout, out, head)); else CHECK(htkamd_trans_write(head, out));
+                  htkamd_trans_free(head);
+               }
+               free(altLen); free(altArcs);
+            }
+            free(nN); free(nA); free(nodeFrame); free(nodePron); free(nodeLike); free(aS); free(aE); free(aAc); free(aLm); free(aPr); free(fo);
+         }
+         free_observations(&ob);
+         continue;
       }
       int *nWords = (int *)malloc(sizeof(int) * (size_t)count), *wPron = (int *)malloc(sizeof(int) * (size_t)count * maxWords);
       int *wStart = (int *)malloc(sizeof(int) * (size_t)count * maxWords), *wEnd = (int *)malloc(sizeof(int) * (size_t)count * maxWords);
