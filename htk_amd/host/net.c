@@ -464,7 +464,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
       thruPron = (int *)malloc(sizeof(int) * ((size_t)NN + 1));
       int *nullTab = NULL, nNullTab = 0;
       for (size_t z = 0; z < (size_t)nInst * XC; z++) { entryOf[z] = -1; wendOf[z] = -1; }
-      int *crossTab = NULL, nCrossTab = 0;
+      int *crossTab = NULL;                                 /* (entry code -2, a cross-bar row entered directly, is no longer produced) */
 #define XMODEL(dst, lc_, k_, q_, rc_) do { (dst) = find_model_ctx(xw->hmms, &hc.cxs, &hc.dep, hc.sLeft, hc.sRight, xw->flags, (lc_), pr[k_].phoneName[q_], (rc_), tried, sizeof(tried)); \
          if ((dst) < 0) { htkamd_set_error("net_build: word %s: cannot find hmm %s (GetHCIModel HNet.c:2167)", pr[k_].word, tried); rc = HTKAMD_EMODEL; } } while (0)
       for (int x = 0; x < nInst && !rc; x++) {
@@ -474,78 +474,122 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
          /* contexts inside the word for phone j: the nearest context phones on either side (FindLContext / FindRContext) */
 #define LCI(j_, dflt) ({ int c_ = (dflt); for (int z_ = (j_) - 1; z_ >= 0; z_--) { const int t_ = hci_context(&hc.cxs, pr[k].phoneName[z_]); if (t_ >= 0) { c_ = t_; break; } } c_; })
 #define RCI(j_, dflt) ({ int c_ = (dflt); for (int z_ = (j_) + 1; z_ < n; z_++) { const int t_ = hci_context(&hc.cxs, pr[k].phoneName[z_]); if (t_ >= 0) { c_ = t_; break; } } c_; })
-         /* trailing part per right context: [last context phone (multi-phone words)] -> context-free phones -> word end */
-         int tailHead[XC];
-         for (int r = 0; r < XC && !rc; r++) {
-            tailHead[r] = -1;
-            if (!RC[(size_t)i * XC + r]) continue;
-            int prev = -1, h;
-            if (p != q) {
-               XMODEL(h, LCI(q, 0), k, q, r); if (rc) break;
-               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1); prev = nN - 1; tailHead[r] = prev;
+         /* ---- the reference's sharing rules, so that token sets (N-best: alternatives are told apart by the word-end NODE they came
+          * through) and instance counts (-u) see the same nodes:
+          *   word ends   one per right context, ONE for all of them when the last context phone does not depend on its right context
+          *               (fci, IsRContextInd HNet.c:2101; ProcessCrossWordLinks :2654);
+          *   last models one per distinct physical HMM among the right contexts, each followed by its own copies of the trailing
+          *               context-free phones, linked to the word ends of the contexts that chose it (CreateXEModels :3152-3200);
+          *   first models one per distinct physical HMM among the left contexts, each preceded by its own copies of the leading
+          *               context-free phones (:3219-3271);
+          *   one context phone (CreateX1Model :2773): a context-independent phone is a single model for every (lc, rc); otherwise every
+          *               left context has its own row -- a collating NULL word node (or its copy of the leading context-free phones),
+          *               then one model per distinct physical HMM among the right contexts; without any left-context models in the
+          *               set (!sLeft) there is a single row. */
+         int fci;
+         {
+            const int lcInt = (p == q) ? -1 : LCI(q, -1);
+            if (lcInt < 0) fci = !set_has(&hc.dep, pr[k].phoneName[q]);
+            else {
+               int first = -2; fci = 1;
+               for (int j = 1; j < nc && fci; j++) {             /* sic: the reference's loop stops short of the last context */
+                  const int h = find_model_ctx(xw->hmms, &hc.cxs, &hc.dep, hc.sLeft, hc.sRight, xw->flags, lcInt, pr[k].phoneName[q], j, NULL, 0);
+                  if (first == -2 || first < 0) first = h; else if (h != first) fci = 0;
+               }
             }
-            for (int z = q + 1; z < n && !rc; z++) {
-               XMODEL(h, 0, k, z, 0); if (rc) break;
-               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
-               if (prev >= 0) NEWLINK(prev, nN - 1, 0.0f); else tailHead[r] = nN - 1;
-               prev = nN - 1;
+         }
+         /* word-end nodes */
+         int weSingle = -1;
+         for (int r = 0; r < XC; r++) {
+            if (!RC[(size_t)i * XC + r]) continue;
+            if (fci && weSingle >= 0) { wendOf[(size_t)x * XC + r] = weSingle; continue; }
+            NEWNODE(HTKAMD_NODE_WORD, k, pr[k].prob, k);
+            wendOf[(size_t)x * XC + r] = nN - 1;
+            if (fci) weSingle = nN - 1;
+         }
+         /* a model for the last context phone + copies of the trailing context-free phones; returns the head, *last the node that links to the word end */
+#define END_CHAIN(head_, last_, lc_, rc_) do { int h_; XMODEL(h_, (lc_), k, q, (rc_)); if (rc) break; \
+            NEWNODE(HTKAMD_NODE_HMM, h_, 0.0f, -1); (head_) = (last_) = nN - 1; \
+            for (int z_ = q + 1; z_ < n && !rc; z_++) { int hz_; XMODEL(hz_, 0, k, z_, 0); if (rc) break; NEWNODE(HTKAMD_NODE_HMM, hz_, 0.0f, -1); NEWLINK((last_), nN - 1, 0.0f); (last_) = nN - 1; } } while (0)
+         int endHmm[XC], endHead[XC], endLast[XC], nEnd = 0;       /* distinct last models of the current row */
+#define LINK_ONCE(from_, to_) do { int dup_ = 0; for (int z_ = linkMark; z_ < nL; z_++) if (tl[z_].from == (from_) && tl[z_].to == (to_)) dup_ = 1; if (!dup_) NEWLINK((from_), (to_), 0.0f); } while (0)
+         const int linkMark = nL;
+         if (p != q) {
+            /* CreateXEModels */
+            for (int r = 0; r < XC && !rc; r++) {
+               if (!RC[(size_t)i * XC + r]) continue;
+               int h; XMODEL(h, LCI(q, 0), k, q, r); if (rc) break;
+               int e = -1;
+               for (int z = 0; z < nEnd; z++) if (endHmm[z] == h) e = z;
+               if (e < 0) { e = nEnd++; endHmm[e] = h; END_CHAIN(endHead[e], endLast[e], LCI(q, 0), r); if (rc) break; }
+               LINK_ONCE(endLast[e], wendOf[(size_t)x * XC + r]);
+               if (fci) break;                                     /* "only need to do this once" */
             }
             if (rc) break;
-            NEWNODE(HTKAMD_NODE_WORD, k, pr[k].prob, k);
-            if (prev >= 0) NEWLINK(prev, nN - 1, 0.0f); else tailHead[r] = nN - 1;
-            wendOf[(size_t)x * XC + r] = nN - 1;
-         }
-         if (rc) break;
-         /* word-internal part between the first and the last context phone (CreateWIModels) */
-         int midHead = -1, midTail = -1;
-         for (int j = p + 1; j < q && !rc; j++) {
-            int h; XMODEL(h, LCI(j, 0), k, j, RCI(j, 0)); if (rc) break;
-            NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
-            if (midTail >= 0) NEWLINK(midTail, nN - 1, 0.0f); else midHead = nN - 1;
-            midTail = nN - 1;
-         }
-         if (rc) break;
-         if (midTail >= 0) for (int r = 0; r < XC; r++) if (tailHead[r] >= 0) NEWLINK(midTail, tailHead[r], 0.0f);
-         /* leading part per left context */
-         if (p == q && p == 0) { crossOf[x] = nCrossTab; crossTab = (int *)realloc(crossTab, sizeof(int) * (size_t)(nCrossTab + XC * XC)); for (int z = 0; z < XC * XC; z++) crossTab[nCrossTab + z] = -1; nCrossTab += XC * XC; }
-         for (int l = 0; l < XC && !rc; l++) {
-            if (!LC[(size_t)i * XC + l]) continue;
-            int firstCd[XC], nFirst = 0, h;                     /* the node(s) of the first context phone for this left context */
-            if (p != q) {
-               XMODEL(h, l, k, p, RCI(p, 0)); if (rc) break;
+            int midHead = -1, midTail = -1;
+            for (int j = p + 1; j < q && !rc; j++) {
+               int h; XMODEL(h, LCI(j, 0), k, j, RCI(j, 0)); if (rc) break;
                NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
-               firstCd[nFirst++] = nN - 1;
-               if (midHead >= 0) NEWLINK(nN - 1, midHead, 0.0f);
-               else for (int r = 0; r < XC; r++) if (tailHead[r] >= 0) NEWLINK(nN - 1, tailHead[r], 0.0f);      /* two context phones: cross-bar */
-            } else {
-               for (int r = 0; r < XC && !rc; r++) {
-                  if (tailHead[r] < 0) continue;
-                  XMODEL(h, l, k, p, r); if (rc) break;
+               if (midTail >= 0) NEWLINK(midTail, nN - 1, 0.0f); else midHead = nN - 1;
+               midTail = nN - 1;
+            }
+            if (rc) break;
+            if (midTail >= 0) for (int z = 0; z < nEnd; z++) NEWLINK(midTail, endHead[z], 0.0f);
+            int stHmm[XC], stHead[XC], nSt = 0;
+            for (int l = 0; l < XC && !rc; l++) {
+               if (!LC[(size_t)i * XC + l]) continue;
+               int h; XMODEL(h, l, k, p, RCI(p, 0)); if (rc) break;
+               int e = -1;
+               for (int z = 0; z < nSt; z++) if (stHmm[z] == h) e = z;
+               if (e < 0) {
+                  e = nSt++; stHmm[e] = h;
                   NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
-                  NEWLINK(nN - 1, tailHead[r], 0.0f);
-                  firstCd[nFirst++] = nN - 1;
-                  if (crossOf[x] >= 0) crossTab[crossOf[x] + l * XC + r] = nN - 1;
+                  int head = nN - 1;
+                  if (midHead >= 0) NEWLINK(head, midHead, 0.0f); else for (int z = 0; z < nEnd; z++) NEWLINK(head, endHead[z], 0.0f);
+                  for (int z = p - 1; z >= 0 && !rc; z--) { int hz; XMODEL(hz, 0, k, z, 0); if (rc) break; NEWNODE(HTKAMD_NODE_HMM, hz, 0.0f, -1); NEWLINK(nN - 1, head, 0.0f); head = nN - 1; }
+                  stHead[e] = head;
+               }
+               entryOf[(size_t)x * XC + l] = stHead[e];
+            }
+         } else if (!set_has(&hc.dep, pr[k].phoneName[p])) {
+            /* CreateX1Model, context-independent phone: one model for everybody */
+            int head = -1, last = -1;
+            END_CHAIN(head, last, 0, 0); if (rc) break;
+            for (int r = 0; r < XC; r++) if (RC[(size_t)i * XC + r]) LINK_ONCE(last, wendOf[(size_t)x * XC + r]);
+            for (int z = p - 1; z >= 0 && !rc; z--) { int hz; XMODEL(hz, 0, k, z, 0); if (rc) break; NEWNODE(HTKAMD_NODE_HMM, hz, 0.0f, -1); NEWLINK(nN - 1, head, 0.0f); head = nN - 1; }
+            for (int l = 0; l < XC; l++) if (LC[(size_t)i * XC + l]) entryOf[(size_t)x * XC + l] = head;
+         } else {
+            /* CreateX1Model: rows of the (lc, rc) cross-bar */
+            int rowHead = -1;
+            for (int l = 0; l < XC && !rc; l++) {
+               if (!LC[(size_t)i * XC + l]) continue;
+               if (!hc.sLeft && rowHead >= 0) { entryOf[(size_t)x * XC + l] = rowHead; continue; }      /* one row for all left contexts */
+               /* the collating point: a NULL word node, or the row's copy of the leading context-free phones */
+               int head, link;
+               if (p == 0) { NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1); head = link = nN - 1; }
+               else {
+                  int hz; XMODEL(hz, 0, k, 0, 0); if (rc) break;
+                  NEWNODE(HTKAMD_NODE_HMM, hz, 0.0f, -1); head = link = nN - 1;
+                  for (int z = 1; z < p && !rc; z++) { XMODEL(hz, 0, k, z, 0); if (rc) break; NEWNODE(HTKAMD_NODE_HMM, hz, 0.0f, -1); NEWLINK(link, nN - 1, 0.0f); link = nN - 1; }
+                  if (rc) break;
+               }
+               nEnd = 0;
+               for (int r = 0; r < XC && !rc; r++) {
+                  if (!RC[(size_t)i * XC + r]) continue;
+                  int h; XMODEL(h, hc.sLeft ? l : 0, k, q, r); if (rc) break;
+                  int e = -1;
+                  for (int z = 0; z < nEnd; z++) if (endHmm[z] == h) e = z;
+                  if (e < 0) { e = nEnd++; endHmm[e] = h; END_CHAIN(endHead[e], endLast[e], hc.sLeft ? l : 0, r); if (rc) break; NEWLINK(link, endHead[e], 0.0f); }
+                  LINK_ONCE(endLast[e], wendOf[(size_t)x * XC + r]);
                }
                if (rc) break;
+               entryOf[(size_t)x * XC + l] = head;
+               rowHead = head;
             }
-            int head = -1;
-            for (int z = p - 1; z >= 0 && !rc; z--) {          /* context-free phones before the first context phone */
-               XMODEL(h, 0, k, z, 0); if (rc) break;
-               NEWNODE(HTKAMD_NODE_HMM, h, 0.0f, -1);
-               if (head >= 0) NEWLINK(nN - 1, head, 0.0f); else for (int f = 0; f < nFirst; f++) NEWLINK(nN - 1, firstCd[f], 0.0f);
-               head = nN - 1;
-            }
-            if (rc) break;
-            if (head < 0 && p == q && set_has(&hc.dep, pr[k].phoneName[p])) {
-               /* a one-phone word whose phone has context-dependent models: the reference enters its cross-bar row through a NULL word
-                  node, "single collating point for all r contexts" (CreateX1Model HNet.c:2878, :2993) -- a word-type node, so the
-                  word-end beam is applied to the tokens that enter the word there */
-               NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1);
-               for (int f = 0; f < nFirst; f++) NEWLINK(nN - 1, firstCd[f], 0.0f);
-               head = nN - 1;
-            }
-            entryOf[(size_t)x * XC + l] = (head >= 0) ? head : ((p != q) ? firstCd[0] : -2);       /* -2: enter through the cross-bar row */
          }
+#undef END_CHAIN
+#undef LINK_ONCE
+         if (rc) break;
 #undef LCI
 #undef RCI
       }

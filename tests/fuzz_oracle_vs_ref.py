@@ -30,6 +30,42 @@ from decode_util import format_words  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
+def _lat_same(a, b):
+    """Two SLF files: identical, or the same lattice up to the float noise of relative tokens.  (A relative token's likelihood is a
+    float re-based at every TokSetMerge, HRec.c:361-364: the order in which tokens arrive at a node -- HRec's instance-list order, the
+    oracle's node order -- moves its last bits.  That shows as the last printed digit of an ALTERNATIVE's acoustic score, and it decides
+    between two alternatives whose likelihoods agree to ~1e-4 (the same models under two segmentations), so that a handful of arcs --
+    and the nodes only they lead to -- may differ.)  Accepted: >= 99 % of the arcs (as start word/time, end word/time, l=) in common."""
+    if a == b:
+        return True
+    import collections
+    def arcs(txt):
+        nodes, out = {}, collections.Counter()
+        for line in txt.splitlines():
+            f = dict(kv.split("=", 1) for kv in line.split() if "=" in kv)
+            if line.startswith("I="):
+                nodes[f["I"]] = (f.get("t"), f.get("W"), f.get("v"))
+            elif line.startswith("J="):
+                out[(nodes[f["S"]], nodes[f["E"]], f.get("l"))] += 1
+        return out
+    x, y = arcs(a), arcs(b)
+    diff = sum(((x - y) + (y - x)).values())
+    return diff <= max(4, sum(x.values()) // 100)
+
+
+def _labels_same(got, want):
+    if want is None or len(got) != len(want):
+        return False
+    for g, w in zip(got, want):
+        if len(g) != len(w):
+            return False
+        for x, y in zip(g, w):
+            fx, fy = x.split(), y.split()
+            if fx[:3] != fy[:3] or abs(float(fx[3]) - float(fy[3])) > 2e-3:
+                return False
+    return True
+
+
 def fuzz_decode(rng, it, tmp):
     d = os.path.join(tmp, "d%d" % it); os.makedirs(d, exist_ok=True)
     tee = None
@@ -149,6 +185,49 @@ def fuzz_decode(rng, it, tmp):
             # "No tokens survived" utterances: the reference writes no entry
             ok = False
             print("DECODE it %d u%d params %s rc %d\n  oracle %s\n  HVite  %s" % (it, u, p, r.returncode, got, want))
+    if ok and "maxActive" not in p and not xwrd and rng.random() < 0.4:
+        # (not on the cross-word cases: their logical models are tied at random to a handful of physical ones, so that word ends of one
+        #  word in different contexts carry EXACTLY equal likelihoods; which of them a full token set keeps is decided by arrival order --
+        #  HRec's instance list against the oracle's node order, the tie limitation DESIGN.md describes; tests/golden/decode/nbest has a
+        #  cross-word case that is free of such ties and equal byte for byte)
+        # ---- N-best: HVite -n k 1 -z lat (lattice files) and -n k m (alternative transcriptions) against the oracle's token sets put
+        # through the product's host code (htkamd_lattice_write / htkamd_lattice_nbest); run inside d with relative names so that the
+        # header lines of the lattices agree
+        k, mtr = int(rng.integers(2, 7)), int(rng.integers(2, 5))
+        rel = [os.path.basename(f) for f in scp]
+        open(os.path.join(d, "scp_rel"), "w").write("\n".join(rel) + "\n")
+        base = [os.path.join(REF, "HVite"), "-C", "config", "-H", "MMF", "-S", "scp_rel", "-w", "net.slf"] + opts
+        subprocess.run(base + ["-l", ".", "-n", str(k), "1", "-z", "lat", "dict", "hmmlist"], cwd=d, capture_output=True, text=True)
+        subprocess.run(base + ["-i", "nb.mlf", "-n", str(k), str(mtr), "dict", "hmmlist"], cwd=d, capture_output=True, text=True)
+        nb, cur = {}, None
+        if os.path.exists(os.path.join(d, "nb.mlf")):
+            for line in open(os.path.join(d, "nb.mlf")).read().splitlines()[1:]:
+                if line.startswith('"'):
+                    cur = os.path.basename(line.strip('"')).replace(".rec", ""); nb[cur] = [[]]
+                elif line == ".":
+                    cur = None
+                elif line == "///":
+                    nb[cur].append([])
+                elif cur is not None:
+                    nb[cur][-1].append(line)
+        arr = net.arrays()
+        for u, X in enumerate(s.feats):
+            lat = pyoracle.decode_nbest(om, X, arr, k, **p)
+            ref_lat = os.path.join(d, "u%d.lat" % u)
+            if lat is None:
+                if os.path.exists(ref_lat):
+                    ok = False; print("NBEST it %d u%d: oracle has no lattice, HVite wrote one" % (it, u))
+                continue
+            lat["nodePron"] = np.array([arr["model"][n] if n >= 0 else -1 for n in lat["nodeNet"]], np.int32)
+            lat.update(lmScale=p["lmScale"], wordPen=p["wordPen"], prScale=p["prScale"])
+            mine = os.path.join(d, "u%d.mylat" % u)
+            capi.lattice_write(lat, net, mine, utterance=rel[u], lm_name="net.slf", vocab_name="dict")
+            if not os.path.exists(ref_lat) or not _lat_same(open(mine).read(), open(ref_lat).read()):
+                ok = False; print("NBEST it %d u%d k=%d params %s: lattice files differ (%s)" % (it, u, k, p, d))
+            alts = capi.lattice_nbest(lat, net, mtr)
+            got = [["%d %d %s %f" % (st_ * 100000, en_ * 100000, net.out_syms[w], np.float32(sc)) for w, st_, en_, sc in a if w >= 0 and net.out_syms[w] != ""] for a in alts]
+            if open(mine).read() == open(ref_lat).read() and not _labels_same(got, nb.get("u%d" % u)):
+                ok = False; print("NBEST it %d u%d k=%d m=%d params %s:\n  oracle %s\n  HVite  %s" % (it, u, k, mtr, p, got, nb.get("u%d" % u)))
     if not ok and os.environ.get("FUZZ_KEEP"):
         import json, shutil
         json.dump(p, open(os.path.join(d, "params.json"), "w"))

@@ -199,6 +199,19 @@ def fuzz_decode(rng, it, tmp):
         if words_g != ow or (ow is not None and total != ot):
             ok = False
             print("DECODE it %d u%d params %s\n  gpu    %s\n  oracle %s" % (it, u, p, words_g, ow))
+    if "maxActive" not in p and rng.random() < 0.4:                   # token sets (HVite -n k): the kernel's lattice == the oracle's
+        k = int(rng.integers(2, 9))
+        lats = capi.Decoder(model, net, lmScale=p["lmScale"]).run_lattice(s.feats, k, **p)
+        for u, got in enumerate(lats):
+            ref = pyoracle.decode_nbest(om, s.feats[u], net.arrays(), k, **p)
+            same = (got is None) == (ref is None)
+            if same and got is not None:
+                arcs = lambda l: sorted(zip(l["arcStart"].tolist(), l["arcEnd"].tolist(), l["arcAc"].tolist(), l["arcLm"].tolist(), l["arcPr"].tolist(), l["arcScore"].tolist()))
+                same = got["total"] == ref["total"] and all(np.array_equal(got[f], ref[f]) for f in ("nodeFrame", "nodeNet", "nodeLike")) and arcs(got) == arcs(ref)
+            if not same:
+                ok = False
+                print("NBEST it %d u%d k=%d params %s: kernel %s, oracle %s" % (it, u, k, p, None if got is None else (len(got["nodeFrame"]), len(got["arcStart"])),
+                                                                             None if ref is None else (len(ref["nodeFrame"]), len(ref["arcStart"]))))
     return ok
 
 

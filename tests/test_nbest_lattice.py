@@ -88,3 +88,44 @@ def test_token_set_kernel_edge_cases(native):
         dec.run_lattice([feats[0]], 9)                               # at most 8 tokens per state
     with pytest.raises(native.HtkAmdError):
         dec.run_lattice([feats[0]], 3, genBeam=250.0, maxNodes=4)    # a lattice that does not fit is an error, not a truncated file
+
+
+@pytest.mark.gpu
+def test_token_set_kernel_wide_fan_in(native, oracle, tmp_path):
+    """A 400-word loop: the loop's null node has 400 predecessors, which the kernel merges as contiguous runs per thread and then run by
+    run (decode_n.hip); the oracle merges them one after the other.  Same nodes, same arcs; the relative likelihoods of alternatives are
+    floats re-based in another association, so their acoustic scores are compared to 1e-3."""
+    from htk_amd import synth
+    s = synth.generate(150, 4, 400, 3, 70, 17, D=13)
+    d = tmp_path
+    synth.write_mmf(str(d / "MMF"), s, kind="USER")
+    names = ["p%d" % i for i in range(400)]
+    (d / "hmmlist").write_text("\n".join(names) + "\n")
+    (d / "dict").write_text("".join("%s %s\n" % (n, n) for n in names))
+    V = len(names)
+    with open(d / "net.slf", "w") as f:
+        f.write("VERSION=1.0\nN=%d L=%d\n" % (V + 4, 2 * V + 3))
+        f.write("I=0 W=!NULL\nI=1 W=!NULL\n")
+        for i, n in enumerate(names):
+            f.write("I=%d W=%s\n" % (2 + i, n))
+        f.write("I=%d W=!NULL\nI=%d W=!NULL\n" % (V + 2, V + 3))
+        j = 0
+        f.write("J=%d S=0 E=1 l=0.00\n" % j); j += 1
+        f.write("J=%d S=%d E=1 l=0.00\n" % (j, V + 2)); j += 1
+        for i in range(V):
+            f.write("J=%d S=1 E=%d l=%.2f\n" % (j, 2 + i, np.log(1.0 / V))); j += 1
+            f.write("J=%d S=%d E=%d l=0.00\n" % (j, 2 + i, V + 2)); j += 1
+        f.write("J=%d S=%d E=%d l=0.00\n" % (j, V + 2, V + 3))
+    mmf = native.Mmf(files=[str(d / "MMF")], hmm_list=str(d / "hmmlist"))
+    net = native.Net(str(d / "net.slf"), str(d / "dict"), mmf)
+    model = native.Model(mmf.packed()); om = oracle.Model(mmf.packed())
+    lats = native.Decoder(model, net).run_lattice(s.feats, 3, genBeam=150.0)
+    for u, got in enumerate(lats):
+        ref = oracle.decode_nbest(om, s.feats[u], net.arrays(), 3, genBeam=150.0)
+        assert got is not None and ref is not None and got["total"] == ref["total"]
+        key = lambda l: sorted(zip(l["nodeFrame"][l["arcStart"]].tolist(), l["nodeNet"][l["arcStart"]].tolist(), l["nodeFrame"][l["arcEnd"]].tolist(),
+                                   l["nodeNet"][l["arcEnd"]].tolist(), l["arcLm"].tolist(), l["arcAc"].tolist()))
+        g, r = key(got), key(ref)
+        assert len(g) == len(r) and len(g) > 50
+        assert [x[:5] for x in g] == [x[:5] for x in r]
+        assert np.allclose([x[5] for x in g], [x[5] for x in r], atol=1e-3)
