@@ -6,8 +6,8 @@
  * -Wl,--wrap=InitVRecInfo  sends those five calls here and leaves everything else of HTKLib -- including HRec.o's own
  * TranscriptionFromLattice / FormatTranscription, HNet's network expansion, HParm's buffers -- as it is:
  *   InitPSetInfo        remembers the HMMSet (the rest is the reference's)
- *   InitVRecInfo        remembers nToks / models / states (the rest is the reference's); N-best and model/state-level alignment are
- *                       refused here (HError 7399) -- tools/hvite covers them
+ *   InitVRecInfo        remembers nToks / models / states (the rest is the reference's); model/state-level alignment is refused here
+ *                       (HError 7399) -- tools/hvite covers it; nToks > 1 (HVite -n) runs the token-set kernel (htkamd_decoder_run_lattice)
  *   StartRecognition    Network (NetNode graph, HNet.h) -> htkamd_net_desc, model set -> htkamd_model, decoder (cached per network)
  *   ProcessObservation  appends the frame to a host table
  *   CompleteRecognition uploads the table, runs the batch-of-one decoder (htkamd_decoder_run_out) and builds the Lattice exactly as
@@ -15,7 +15,7 @@
  *                       the utterance, nodes 2.. = word ends from the last word back; arcs carry aclike / lmlike / prlike / score.
  * Token likelihoods, times and scores are the reference's bit for bit (htkamd decoder contract), so the label files are HVite's.
  *
- * Restrictions (HError 7399): one stream, diagonal covariances, no input transform, nToks == 1, word-level output, no tagged
+ * Restrictions (HError 7399): one stream, diagonal covariances, no input transform, at most 8 tokens per state, word-level output, no tagged
  * null nodes (sub-lattice tags).  Built only where the reference's headers are (oracle/Makefile, target _ref/HVite_amd).
  */
 #include <stdio.h>
@@ -231,7 +231,7 @@ VRecInfo *__real_InitVRecInfo(PSetInfo *psi, int nToks, Boolean models, Boolean 
 VRecInfo *__wrap_InitVRecInfo(PSetInfo *psi, int nToks, Boolean models, Boolean states)
 {
    S.nToks = nToks; S.models = models; S.states = states;
-   if (nToks > 1) HError(7399, "InitVRecInfo: N-best token sets (-n) are not served by the MI355X recogniser shim");
+   if (nToks > 8) HError(7399, "InitVRecInfo: at most 8 tokens per state (-n) on the MI355X recogniser");
    if (models || states) HError(7399, "InitVRecInfo: model / state level output (-m -f) is not served by the shim (tools/hvite does it)");
    return __real_InitVRecInfo(psi, nToks, models, states);
 }
@@ -285,6 +285,46 @@ Lattice *__wrap_CompleteRecognition(VRecInfo *vri, HTime frameDur, MemHeap *heap
    if (!(cfg.wordBeam > 0) || cfg.wordBeam > 1.0e10f) cfg.wordBeam = 1.0e10f;
    cfg.lmScale = S.scale; cfg.wordPen = S.wordpen; cfg.prScale = S.pscale; cfg.scoreMode = HTKAMD_SCORE_EXACT;
    cfg.maxActive = vri->maxBeam > 0 ? vri->maxBeam : 0;      /* HVite -u */
+   if (S.nToks > 1) {
+      /* ---- N-best (HVite -n): token sets on the device, then the Lattice CreateLattice would have built (HRec.c:1679): node i / arc j
+         of htkamd_decoder_run_lattice become lnodes[i] / larcs[j] (node 0 = start, node 1 = end); the reference's own WriteLattice and
+         TranscriptionFromLattice take it from there */
+      const int maxN = 65536, maxA = 262144;
+      int nn = 0, na = 0, i;
+      int *nodeFrame = (int *)malloc(sizeof(int) * maxN), *nodePron = (int *)malloc(sizeof(int) * maxN), *aS = (int *)malloc(sizeof(int) * maxA), *aE = (int *)malloc(sizeof(int) * maxA);
+      double *nodeLike = (double *)malloc(sizeof(double) * maxN), *aSc = (double *)malloc(sizeof(double) * maxA);
+      float *aAc = (float *)malloc(sizeof(float) * maxA), *aLm = (float *)malloc(sizeof(float) * maxA), *aPr = (float *)malloc(sizeof(float) * maxA);
+      htkamd_lattice_out lo;
+      float nBeam = vri->nBeam;
+      if (!(nBeam > 0) || nBeam > 1.0e10f) nBeam = 1.0e10f;
+      memset(&lo, 0, sizeof(lo));
+      lo.nNodes = &nn; lo.nArcs = &na; lo.nodeFrame = nodeFrame; lo.nodePron = nodePron; lo.nodeLike = nodeLike;
+      lo.arcStart = aS; lo.arcEnd = aE; lo.arcAc = aAc; lo.arcLm = aLm; lo.arcPr = aPr; lo.arcScore = aSc; lo.total = &total;
+      if (cfg.maxActive > 0) HError(7399, "CompleteRecognition: -u together with -n is not served by the MI355X recogniser");
+      amd_check(htkamd_decoder_run_lattice(S.dec, &cfg, S.nToks, nBeam, (const float *)dX, frameOff, 1, maxN, maxA, &lo, NULL), "htkamd_decoder_run_lattice");
+      amd_check(htkamd_dev_free(dX), "htkamd_dev_free");
+      if (nn == -3) HError(7399, "CompleteRecognition: the lattice has more than %d nodes / %d arcs", maxN, maxA);
+      if (nn > 0) {
+         vri->noTokenSurvived = FALSE;
+         lat = NewLattice(heap, nn, na);
+         lat->voc = S.net->vocab;
+         lat->lmscale = S.scale; lat->wdpenalty = S.wordpen; lat->prscale = S.pscale; lat->framedur = frameDur;
+         for (i = 0; i < nn; i++) {
+            LNode *ln = lat->lnodes + i;
+            ln->time = nodeFrame[i] * frameDur; ln->tag = NULL; ln->score = nodeLike[i];
+            if (nodePron[i] >= 0) { NetNode *wn = S.wordNode[nodePron[i]]; ln->word = wn->info.pron->word; ln->tag = wn->tag; ln->v = wn->info.pron->pnum; }
+            else { ln->word = NULL; ln->v = (i == 0) ? -1 : 0; }
+         }
+         for (i = 0; i < na; i++) {
+            LArc *la = lat->larcs + i;
+            la->start = lat->lnodes + aS[i]; la->end = lat->lnodes + aE[i];
+            la->aclike = aAc[i]; la->lmlike = aLm[i]; la->prlike = aPr[i]; la->score = aSc[i];
+            la->farc = la->start->foll; la->parc = la->end->pred; la->start->foll = la->end->pred = la;
+         }
+      }
+      free(nodeFrame); free(nodePron); free(aS); free(aE); free(nodeLike); free(aSc); free(aAc); free(aLm); free(aPr);
+      goto done;
+   }
    memset(&out, 0, sizeof(out));
    out.nWords = &nW; out.wordPron = wPron; out.wordStart = wStart; out.wordEnd = wEnd; out.wordScore = wScore; out.wordLm = wLm; out.wordAc = wAc;
    out.wordLike = wLike; out.total = &total; out.finalLm = &finalLm;
