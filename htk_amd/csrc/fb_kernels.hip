@@ -555,7 +555,7 @@ __global__ void k_alpha(FbArgs a)
 // DT > 0: vector size known at compile time (all parameter loads of a component are issued together);
 // DT == 0: any size.
 template <int DT, int GS>
-__global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
+__global__ __launch_bounds__(256, 4) void k_mixstats(FbArgs a)
 {
    // GS lanes per hit (GS >= max mixture count, a power of two): 64/GS hits are worked on side by side, lane%GS = component
    constexpr int HPS = 64 / GS;
@@ -602,14 +602,16 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
          // utterance of this entry: advance from the chunk's first utterance (seeds are laid out utterance by utterance)
          int u = cu;
          while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
-         const UttDesc ud = a.utt[u];
+         const UttDesc *up = a.utt + u;                      // only four fields of the descriptor are needed
+         const size_t udGam0 = up->gam0;
+         const int udSlots = up->nSlots, udSlot0 = up->slot0, udFrame0 = up->frame0;
          const bool ok = have && a.status[u] == HTKAMD_UTT_OK;
-         const size_t rel = hidx - ud.gam0;
-         const int nSl = ud.nSlots > 0 ? ud.nSlots : 1;
+         const size_t rel = hidx - udGam0;
+         const int nSl = udSlots > 0 ? udSlots : 1;
          const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
-         const int s = ok ? a.slotState[ud.slot0 + slot] : 0;
+         const int s = ok ? a.slotState[udSlot0 + slot] : 0;
          const int c0 = a.stateCompOff[s], M = ok ? a.stateCompOff[s + 1] - c0 : 0;
-         const float *xrow = a.X + (size_t)(ud.frame0 + (ok ? t0 : 0)) * D;
+         const float *xrow = a.X + (size_t)(udFrame0 + (ok ? t0 : 0)) * D;
          // per-component posterior (lane%GS = component): x = initx + logw + prob (HFB.c:1581-1606)
          int Mmax = M;
 #pragma unroll
@@ -628,15 +630,27 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
                      const float *P = a.gparam + (size_t)g * a.PS;
                      float sum = P[2 * D];
                      if (DT > 0) {
-                        const float2 *P2 = (const float2 *)P;         // (mean, ivar) pairs, 8-byte aligned rows
-                        float2 pv[DT > 0 ? DT : 1];
-                        float xv[DT > 0 ? DT : 1];
+                        // (mean, ivar) pairs, two per 16-byte load (rows are PS = 4k floats long and 16-byte aligned): a lane reads its
+                        // own 320-byte row, so every load instruction touches one cache line per lane -- half as many instructions, half
+                        // as many L1 tag look-ups as with 8-byte loads (the kernel was bound by those: ~620 line touches per hit)
+                        const float4 *P4 = (const float4 *)P;
+                        // in batches of 4 loads (8 dimensions): the kernel is a chain of dependent loads per hit, hidden only by other
+                        // wavefronts -- 180 VGPRs (all 39 pairs in flight) left room for 2 per SIMD
+                        constexpr int NQ = (DT + 1) / 2;
+#pragma unroll 1
+                        for (int q0 = 0; q0 < NQ; q0 += 4) {
+                           float4 pv[4]; float xv[8];
 #pragma unroll
-                        for (int i = 0; i < DT; i++) { pv[i] = P2[i]; xv[i] = xrow[i]; }
+                           for (int i = 0; i < 4; i++) if (q0 + i < NQ) pv[i] = P4[q0 + i];
 #pragma unroll
-                        for (int i = 0; i < DT; i++) {
-                           const float xmm = xv[i] - pv[i].x;
-                           sum += xmm * xmm * pv[i].y;
+                           for (int i = 0; i < 8; i++) if (2 * q0 + i < DT) xv[i] = xrow[2 * q0 + i];
+#pragma unroll
+                           for (int i = 0; i < 8; i++)
+                              if (2 * q0 + i < DT) {
+                                 const float mu = (i & 1) ? pv[i >> 1].z : pv[i >> 1].x, iv = (i & 1) ? pv[i >> 1].w : pv[i >> 1].y;
+                                 const float xmm = xv[i] - mu;
+                                 sum += xmm * xmm * iv;
+                              }
                         }
                      } else {
                         for (int i = 0; i < D; i++) {
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(256) void k_mixstats(FbArgs a)
                   }
                   if (recBase >= 0) {
                      if (pass) {
-                        MixRec r; r.g = g; r.frame = ud.frame0 + t0; r.L = Lr;
+                        MixRec r; r.g = g; r.frame = udFrame0 + t0; r.L = Lr;
                         a.rec[recBase + recUsed + __popcll(pk & ((1ull << lane) - 1))] = r;
                         atomicAdd(a.recCtl + 1 + g, 1);
                         stored = true;
