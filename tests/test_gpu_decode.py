@@ -103,6 +103,32 @@ def test_decoder_config3_size_matches_reference(native, tmp_path):
         assert format_words(words, net.out_syms) == exp["u%05d" % u], u
 
 
+def test_decoder_config3_size_bigram_network_matches_reference(native, tmp_path):
+    """BASELINE config[3] as it is worded -- 5000 tied states x 16 mixtures and a BIGRAM network: 6000 words, five explicit successors
+    per word plus a back-off null node that reaches every word (18 000 word/model nodes, 42 000 arcs, fan-in 6000 at the back-off
+    node), -t 250 -s 5 -p -10.  Expected label lines: the reference's HVite on the same seeded set
+    (tests/golden/make_config3_golden.py -> tests/golden/decode/config3/expected_bigram.json)."""
+    import json
+    import sys
+    from htk_amd import synth
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_config3_golden import V, write_bigram
+    exp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "decode", "config3", "expected_bigram.json")))["-t 250.0 -s 5.0 -p -10.0"]
+    s = synth.generate(5000, 16, V, 2, 500, 3)
+    names = ["p%d" % i for i in range(V)]
+    d = tmp_path
+    synth.write_mmf(str(d / "MMF"), s)
+    (d / "hmmlist").write_text("\n".join(names) + "\n")
+    (d / "dict").write_text("".join("%s %s\n" % (n, n) for n in names))
+    write_bigram(str(d / "net.slf"), names)
+    mmf = native.Mmf(files=[str(d / "MMF")], hmm_list=str(d / "hmmlist"))
+    net = native.Net(str(d / "net.slf"), str(d / "dict"), mmf)
+    model = native.Model(mmf.packed())
+    res = native.Decoder(model, net, lmScale=5.0).run(s.feats, genBeam=250.0, lmScale=5.0, wordPen=-10.0)
+    for u, (words, total) in enumerate(res):
+        assert format_words(words, net.out_syms) == exp["u%05d" % u], u
+
+
 def test_decoder_edge_cases(native, oracle):
     """Empty batch, an utterance with no frames, a word budget that is too small, and a beam so tight that the path dies:
     the statuses follow CompleteRecognition (no token in the final node -> nothing to output)."""
