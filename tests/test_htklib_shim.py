@@ -203,3 +203,49 @@ def test_reference_hvite_front_end_nbest_and_lattices_on_the_gpu(tmp_path, tag):
         if g != w:                                           # scores of alternatives: the same float noise, 6 printed decimals
             fg, fw = g.split(), w.split()
             assert fg[:3] == fw[:3] and abs(float(fg[3]) - float(fw[3])) < 1e-3, (g, w)
+
+
+# ---- HDecode's block scorer (HTKLVRec/HLVModel.h:OutPBlock, HLVRec-outP.c:OutPBlock_HMod) served by the library ------------------
+OUTPBLOCK = os.path.join(ROOT, "oracle", "_ref", "ref_outpblock")
+needs_outpblock = pytest.mark.skipif(not os.path.exists(OUTPBLOCK), reason="oracle/_ref/ref_outpblock not built (needs /root/reference)")
+
+
+def _outpblock_cmd(conv, block, ac, conf=None):
+    data = sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))[0]
+    return [OUTPBLOCK] + (["-C", conf] if conf else []) + (["-c"] if conv else []) + ["-d", os.path.join(DEMO, "hmm1"), os.path.join(DEMO, "bcplist"), data, str(block), str(ac)]
+
+
+@needs_outpblock
+def test_block_scorer_shim_exports_hdecodes_two_entry_points():
+    obj = os.path.join(ROOT, "oracle", "_ref", "obj", "hlvmodel_outp_shim.o")
+    nm = subprocess.run(["nm", obj], capture_output=True, text=True, check=True).stdout
+    defined = {l.split()[-1] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] == "T"}
+    assert {"OutPBlock", "OutPBlock_HMod"} <= defined
+    und = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout.split()
+    assert "htkamd_outp_block_mode" in und and "htkamd_model_create" in und
+    header = open(os.path.join(ROOT, "include", "htk_amd.h")).read()
+    for u in und:
+        if u.startswith("htkamd_"):
+            assert re.search(r"\b%s\s*\(" % u, header), u
+
+
+@needs_outpblock
+def test_block_scorer_shim_without_a_device_stops_with_enodev():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    r = subprocess.run(_outpblock_cmd(False, 4, 1.0), capture_output=True, text=True)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and "no HIP device" in out and "HTKAMD_ENODEV" in out, out[-600:]
+
+
+@pytest.mark.gpu
+@needs_outpblock
+@pytest.mark.parametrize("conv,block,ac", [(False, 4, 1.0), (True, 4, 1.0), (True, 7, 0.5), (False, 1, 1.0 / 13)])
+def test_block_scorer_shim_equals_the_references_outp_bit_for_bit(conv, block, ac, tmp_path):
+    conf = tmp_path / "c.conf"
+    conf.write_text("TARGETKIND = MFCC_E_D\n")
+    r = subprocess.run(_outpblock_cmd(conv, block, ac, str(conf)), capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-800:]
+    m = re.search(r"scores (\d+) mismatches (\d+) maxdiff (\S+)", r.stdout)
+    assert m and int(m.group(1)) > 1000 and int(m.group(2)) == 0, r.stdout
