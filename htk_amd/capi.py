@@ -19,6 +19,7 @@ LSMALL = -0.5e10
 NOPRUNE = 1.0e20
 UPMEANS, UPVARS, UPTRANS, UPMIXES = 1, 2, 4, 8
 UPALL = 15
+UPMAP = 32
 UTT_OK, UTT_SKIPPED, UTT_ETEE, UTT_EALPHA = 1, 0, -7332, -7390
 
 
@@ -55,11 +56,11 @@ class FbConfig(C.Structure):
 
 class UpdateConfig(C.Structure):
     _fields_ = [("minEgs", C.c_int), ("minVar", C.c_float), ("mixWeightFloor", C.c_float), ("uFlags", C.c_int),
-                ("singleProcess", C.c_int), ("varFloor", C.POINTER(C.c_float)), ("rowNormalise", C.c_int)]
+                ("singleProcess", C.c_int), ("varFloor", C.POINTER(C.c_float)), ("rowNormalise", C.c_int), ("mapTau", C.c_float), ("mapMinObs", C.c_float)]
 
 
 class UpdateStats(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("nFloorVar", "nFloorVarMix", "nSkippedHmm", "nNoTransOut", "nNoMixUse", "nNoVarUse", "nWeightAboveOne")]
+    _fields_ = [(n, C.c_int) for n in ("nFloorVar", "nFloorVarMix", "nSkippedHmm", "nNoTransOut", "nNoMixUse", "nNoVarUse", "nWeightAboveOne", "nMapObserved")]
 
 
 class BatchDesc(C.Structure):
@@ -160,15 +161,16 @@ class Model:
         return dict(ivar=ivar, gconst=gc, compLogWt=lw, minDur=md)
 
     def update(self, accs: "Accs", vec: np.ndarray, minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False, varFloor=None,
-               rowNormalise=False):
-        """UpdateModels (HERest.c:1326) from a host copy of the (summed) accumulator vector.  varFloor: the ~v "varFloor1" vector."""
+               rowNormalise=False, mapTau=20.0, mapMinObs=0.0):
+        """UpdateModels (HERest.c:1326) from a host copy of the (summed) accumulator vector.  varFloor: the ~v "varFloor1" vector.
+        uFlags with UPMAP: MAPUpdateModels (HMap.c:413) with prior weight mapTau."""
         vec = np.ascontiguousarray(vec, np.float64)
         vf = None
         if varFloor is not None:
             vf = np.ascontiguousarray(varFloor, np.float32)
             assert vf.shape == (self.D,)
         cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess),
-                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise))
+                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise), mapTau, mapMinObs)
         st = UpdateStats()
         check(lib().htkamd_model_update(self.h, accs.h, _p(vec), C.byref(cfg), C.byref(st)), "model_update")
         return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
@@ -181,7 +183,7 @@ class Model:
             vf = np.ascontiguousarray(varFloor, np.float32)
             assert vf.shape == (self.D,)
         cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess),
-                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise))
+                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise), 0.0, 0.0)
         st = UpdateStats()
         check(lib().htkamd_model_update_device(self.h, accs.h, C.byref(cfg), C.byref(st), _stream(stream)), "model_update_device")
         return {n: getattr(st, n) for n, _ in UpdateStats._fields_}

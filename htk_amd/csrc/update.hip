@@ -257,6 +257,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
       htkamd_set_error("model_update_device: the set shares mean / variance vectors (~u ~v): use htkamd_model_update");
       return HTKAMD_EMODEL;
    }
+   if (cfg->uFlags & HTKAMD_UPMAP) { htkamd_set_error("model_update_device: MAP re-estimation (HTKAMD_UPMAP) is done by htkamd_model_update"); return HTKAMD_EMODEL; }
    hipStream_t s = (hipStream_t)stream;
    int rc;
    if ((rc = htkamd_model_device_tables(m))) return rc;

@@ -14,6 +14,10 @@
  * statistics of its users are pooled (here: summed into the group's first Gaussian before the update), the vector is updated by the
  * first mixture that reaches it, a variance with several users gets no mean-shift correction (`shared`, HERest.c:1080), and a private
  * variance whose tied mean was already moved by an earlier model gets none either (its MuAcc hook is gone by then).
+ * MAP (HTKAMD_UPMAP, HERest -u p...): MAPUpdateModels HMap.c:413-460 from the same accumulators --
+ *   UpdateWeights HMap.c:205-276   (max(0, w*vSize*tau - 1) + c_m) / (sum of those + occ), no MINMIX zeroing, forced renormalisation
+ *   UpdateVars    HMap.c:314-377   (tau*var + va - muDiff) / (tau + occ), muDiff = 2 dmu mu - dmu^2 occ, dmu = mu / (tau + occ)
+ *   UpdateMeans   HMap.c:279-311   (mean*tau + (mu + mean*occ)) / (tau + occ)
  * singleProcess mirrors parMode == -1 (HERest.c:1336-1339): the set went through ConvDiagC/ConvLogWt before
  * the pass, so parameters that are not re-estimated come back through ForceDiagC/ConvExpWt float round trips.
  */
@@ -31,6 +35,9 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
    float *mean = m->h_mean, *var = m->h_var, *gconst = m->h_gconst, *wgt = m->h_compWeight, *transP = m->h_transP;
    if (!m || !lay || !acc || !cfg || !st) { htkamd_set_error("update_models: NULL argument"); return HTKAMD_EINVAL; }
    memset(st, 0, sizeof(*st));
+   const int map = (cfg->uFlags & HTKAMD_UPMAP) != 0;
+   const float mapTau = cfg->mapTau;
+   if (map && (cfg->uFlags & HTKAMD_UPTRANS)) { htkamd_set_error("update_models: no MAP update of transition probabilities (HMap.c:434, HError 999)"); return HTKAMD_EINVAL; }
    doneT = (unsigned char *)calloc((size_t)m->nT, 1);
    doneS = (unsigned char *)calloc((size_t)m->S, 1);
    doneMu = (unsigned char *)calloc((size_t)m->G, 1);
@@ -111,7 +118,38 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             const int s = hs[j], c0 = m->h_stateCompOff[s], M = m->h_stateCompOff[s + 1] - c0;
             const float occi = ACCF(lay->wtOcc, s);
             if (doneS[s]) continue;
-            if (occi > 0) {
+            if (occi > 0 && map) {                        /* HMap.c:227-268 */
+               float denom = 0, x;
+               for (k = 0; k < M; k++) {
+                  float tmp = wgt[c0 + k] * D * mapTau - 1;
+                  if (tmp < 0) tmp = 0;
+                  denom += tmp;
+               }
+               for (k = 0; k < M; k++) {
+                  float tmp = wgt[c0 + k] * D * mapTau - 1;
+                  if (tmp < 0) tmp = 0;
+                  x = (tmp + ACCF(lay->wt, c0 + k)) / (denom + occi);
+                  if (x > 1.001) st->nWeightAboveOne++;
+                  if (x > 1.0) x = 1.0;
+                  wgt[c0 + k] = x;
+               }
+               if (cfg->mixWeightFloor > 0.0) {
+                  float sum = 0.0, fsum = 0.0, scale;
+                  const float floor = cfg->mixWeightFloor;
+                  for (k = 0; k < M; k++) {
+                     if (wgt[c0 + k] > floor) sum += wgt[c0 + k];
+                     else { fsum += floor; wgt[c0 + k] = floor; }
+                  }
+                  if (fsum != 0.0 && sum != 0.0) {
+                     scale = (1.0 - fsum) / sum;
+                     for (k = 0; k < M; k++)
+                        if (wgt[c0 + k] > floor) wgt[c0 + k] *= scale;
+                  }
+               }
+               x = 0;                                    /* "Force a normalisation becomes of weird zeroing" */
+               for (k = 0; k < M; k++) x += wgt[c0 + k];
+               for (k = 0; k < M; k++) wgt[c0 + k] /= x;
+            } else if (occi > 0) {
                for (k = 0; k < M; k++) {
                   float x = ACCF(lay->wt, c0 + k) / occi;
                   if (x > 1.001) st->nWeightAboveOne++;          /* fatal HError 2393 in the reference (HERest.c:926) */
@@ -131,7 +169,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                         if (wgt[c0 + k] > floor) wgt[c0 + k] *= scale;
                   }
                }
-            } else st->nNoMixUse++;
+            } else if (!map) st->nNoMixUse++;
             doneS[s] = 1;
          }
       if (cfg->uFlags & HTKAMD_UPVARS)
@@ -147,13 +185,21 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                         const float muOcc = ACCF(lay->muOcc, gm);
                         const int shared = ((cfg->uFlags & HTKAMD_UPMEANS) == 0 || doneMu[gm] || muOcc <= 0.0 || (vL && m->h_varGroupSize[g] > 1));
                         for (k = 0; k < D; k++) {
-                           const float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)gm * D + k) / muOcc;
+                           float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)gm * D + k) / muOcc;
                            float x = ACCF(lay->va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
+                           if (map) {                    /* HMap.c:350-356 */
+                              if (shared) muDiffk = 0.0;
+                              else {
+                                 const float muk = ACCF(lay->mu, (size_t)gm * D + k), dmu = muk / (mapTau + occim);
+                                 muDiffk = 2 * dmu * muk - dmu * dmu * occim;
+                              }
+                              x = (mapTau * var[(size_t)g * D + k] + ACCF(lay->va, (size_t)g * D + k) - muDiffk) / (mapTau + occim);
+                           }
                            const float fl = cfg->varFloor ? cfg->varFloor[k] : cfg->minVar;
                            if (x < fl) { x = fl; st->nFloorVar++; mixFloored = 1; }
                            var[(size_t)g * D + k] = x;
                         }
-                     } else st->nNoVarUse++;
+                     } else if (!map) st->nNoVarUse++;
                      if (mixFloored) st->nFloorVarMix++;
                      doneVa[g] = 1;
                   }
@@ -167,7 +213,13 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                   const int g = ML(m->h_compGauss[c]);
                   if (!doneMu[g]) {
                      const float occim = ACCF(lay->muOcc, g);
-                     if (occim > 0.0)
+                     if (occim > 0.0 && map) {             /* HMap.c:301-304 */
+                        if (occim > cfg->mapMinObs) st->nMapObserved++;
+                        for (k = 0; k < D; k++) {
+                           float *mk = mean + (size_t)g * D + k;
+                           *mk = (*mk * mapTau + (ACCF(lay->mu, (size_t)g * D + k) + *mk * occim)) / (mapTau + occim);
+                        }
+                     } else if (occim > 0.0)
                         for (k = 0; k < D; k++) mean[(size_t)g * D + k] += ACCF(lay->mu, (size_t)g * D + k) / occim;
                      doneMu[g] = 1;
                   }

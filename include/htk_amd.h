@@ -42,6 +42,7 @@ extern "C" {
 #define HTKAMD_UPVARS   2
 #define HTKAMD_UPTRANS  4
 #define HTKAMD_UPMIXES  8
+#define HTKAMD_UPMAP    32   /* HERest -u p: MAP instead of ML re-estimation of means / variances / weights (HMap.c:413 MAPUpdateModels) */
 
 int         htkamd_version(void);
 const char *htkamd_last_error(void);
@@ -318,7 +319,8 @@ int htkamd_stats_write_file(const htkamd_model_desc *d, const double *hostVec, c
  * Model update after a pass: UpdateModels (HERest.c:1326) -> MLUpdateModels (HERest.c:1262) with
  * UpdateTrans :795, UpdateWeights :897 (+FloorMixes :819), UpdateVars :1045, UpdateMeans :974 and
  * FixGConsts (HModel.c:5688).  Runs on the host (milliseconds, as in the reference) from a host copy of
- * the summed accumulator vector, then refreshes the device tables.
+ * the summed accumulator vector, then refreshes the device tables.  With HTKAMD_UPMAP in uFlags: MAPUpdateModels (HMap.c:413)
+ * with its UpdateWeights :205, UpdateVars :314, UpdateMeans :279 -- host update only.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
    int   minEgs;            /* HERest -m, default 3 (HERest.c:96)                                  */
@@ -330,6 +332,11 @@ typedef struct {
                                macro exists it replaces minVar); NULL = minVar everywhere                */
    int   rowNormalise;      /* 1 = transition rows renormalised by their sum, as the isolated-unit trainer does
                                (RestTransP HRest.c:1015); 0 = HERest's UpdateTrans                       */
+   float mapTau;            /* HTKAMD_UPMAP only: HMAP: MAPTAU, the weight of the prior (HMap.c:82, default there 20.0).  With UPMAP the
+                               other fields mean what HMap's own configuration means: minEgs = HMAP: MINEGS (default 0), minVar = HMAP:
+                               MINVAR (default 0.0), mixWeightFloor = MINMIX * HMAP: MIXWEIGHTFLOOR; HTKAMD_UPTRANS is refused
+                               (HError 999 "No support for MAP updating transition probabilities", HMap.c:434)   */
+   float mapMinObs;         /* HMAP: MINOBS: a mean counts as observed in stats.nMapObserved above this occupation          */
 } htkamd_update_config;
 typedef struct {
    int nFloorVar, nFloorVarMix;      /* "Total %d floored variance elements in %d different mixes"  */
@@ -337,6 +344,7 @@ typedef struct {
    int nNoTransOut, nNoMixUse, nNoVarUse;   /* warnings -2326 / -2330                                */
    int nWeightAboveOne;              /* re-estimated mixture weights above 1.001: fatal HError 2393 in UpdateWeights (HERest.c:926);
                                         the update is carried out (weights clamped to 1) and the call returns HTKAMD_EMODEL */
+   int nMapObserved;                 /* HTKAMD_UPMAP: "Observed components (means) %d of ..." (HMap.c:452)                    */
 } htkamd_update_stats;
 int htkamd_model_update(htkamd_model *m, const htkamd_accs *accs, const double *hostVec,
                         const htkamd_update_config *cfg, htkamd_update_stats *stats);

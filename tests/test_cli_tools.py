@@ -129,6 +129,38 @@ def test_herest_cli_tied_mean_and_variance_vectors(tools, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags,conf", [("pmvw", "HMAP: MAPTAU = 6.0\nHMAP: MINVAR = 0.02\nHMAP: MIXWEIGHTFLOOR = 2.0\nHMAP: TRACE = 1\n"), ("pm", "HMAP: TRACE = 1\n")])
+def test_herest_cli_map_reestimation(tools, tmp_path, flags, conf):
+    """HERest -u p...: MAPUpdateModels (HMap.c:413) from the pass's accumulators -- prior-weighted means, variances with the mean-shift
+    term of HMap.c:350-356, weights from max(0, w*vSize*tau - 1) counts, HMap's own configuration (MAPTAU, MINVAR, MIXWEIGHTFLOOR) --
+    against the MMF and the trace lines of the reference's HERest (tests/golden/make_map_golden.py)."""
+    cf = tmp_path / "herest.conf"; cf.write_text("TARGETKIND = MFCC_E_D\n" + conf)
+    out = tmp_path / "next"; out.mkdir()
+    gold = os.path.join(DEMO, "hmm_map")
+    r = run([os.path.join(tools, "herest"), "-T", "1", "-C", str(cf), "-u", flags, "-H", os.path.join(DEMO, "hmm_mixup", "newMacros"), "-M", str(out),
+             "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0, r.stderr
+    for line in open(os.path.join(gold, "herest_%s.log" % flags)).read().splitlines():
+        assert line.strip() in r.stdout, (line, r.stdout[-600:])
+    ours, theirs = _mmf_numbers(str(out / "newMacros")), _mmf_numbers(os.path.join(gold, "after_" + flags))
+    assert len(ours) == len(theirs)
+    for x, y in zip(ours, theirs):
+        if isinstance(y, float):
+            assert isinstance(x, float) and abs(x - y) <= 2e-4 * max(abs(y), 1e-3), (x, y)
+        else:
+            assert x == y
+
+
+@pytest.mark.gpu
+def test_herest_cli_map_refuses_transitions(tools, tmp_path):
+    cf = tmp_path / "herest.conf"; cf.write_text("TARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "next"; out.mkdir()
+    r = run([os.path.join(tools, "herest"), "-C", str(cf), "-u", "ptm", "-H", os.path.join(DEMO, "hmm_mixup", "newMacros"), "-M", str(out),
+             "-L", os.path.join(DEMO, "labels"), os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode != 0 and "no MAP update of transition probabilities" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
 def test_hvite_cli_recognises_the_demo_sets(tools, tmp_path):
     expected = json.load(open(os.path.join(DEMO, "hvite_expected.json")))
     for part in ("test", "train"):

@@ -25,7 +25,7 @@ static void sl_add(strlist *l, const char *s)
 }
 
 /* ---- configuration file: NAME = value lines, optional MODULE: prefix, # comments (ReadConfigFile HShell.c:392) ---- */
-typedef struct { strlist key, val; } config;
+typedef struct { strlist key, val, mod; } config;
 static void cfg_read(config *c, const char *path)
 {
    FILE *f = fopen(path, "r");
@@ -39,17 +39,27 @@ static void cfg_read(config *c, const char *path)
       *eq = 0;
       k = p; while (isspace((unsigned char)*k)) k++;
       e = k + strlen(k); while (e > k && isspace((unsigned char)e[-1])) *--e = 0;
-      { char *colon = strrchr(k, ':'); if (colon) k = colon + 1; }          /* HPARM: TARGETKIND -> TARGETKIND */
+      char *modname = (char *)"";
+      { char *colon = strrchr(k, ':'); if (colon) { *colon = 0; modname = k; k = colon + 1; while (isspace((unsigned char)*k)) k++; } }   /* HPARM: TARGETKIND -> TARGETKIND */
+      for (char *q = modname; *q; q++) *q = (char)toupper((unsigned char)*q);
+      { char *e2 = modname + strlen(modname); while (e2 > modname && isspace((unsigned char)e2[-1])) *--e2 = 0; }
       v = eq + 1; while (isspace((unsigned char)*v)) v++;
       e = v + strlen(v); while (e > v && isspace((unsigned char)e[-1])) *--e = 0;
       for (char *q = k; *q; q++) *q = (char)toupper((unsigned char)*q);
-      sl_add(&c->key, k); sl_add(&c->val, v);
+      sl_add(&c->key, k); sl_add(&c->val, v); sl_add(&c->mod, modname);
    }
    fclose(f);
 }
 static const char *cfg_get(const config *c, const char *key)
 {
    for (int i = c->key.n - 1; i >= 0; i--) if (!strcmp(c->key.v[i], key)) return c->val.v[i];
+   return NULL;
+}
+/* a module's own parameter: `MODULE: NAME = v` or an unqualified `NAME = v` (GetConfig(name, incGlob = TRUE) HShell.c:601) */
+__attribute__((unused)) static const char *cfg_get_mod(const config *c, const char *module, const char *key)
+{
+   for (int i = c->key.n - 1; i >= 0; i--)
+      if (!strcmp(c->key.v[i], key) && (c->mod.v[i][0] == 0 || !strcmp(c->mod.v[i], module))) return c->val.v[i];
    return NULL;
 }
 static int cfg_int(const config *c, const char *key, int dflt) { const char *v = cfg_get(c, key); return v ? atoi(v) : dflt; }

@@ -35,7 +35,8 @@ static int uflags_parse(const char *s)
    for (; *s; s++)
       switch (*s) {
       case 't': f |= HTKAMD_UPTRANS; break; case 'm': f |= HTKAMD_UPMEANS; break; case 'v': f |= HTKAMD_UPVARS; break; case 'w': f |= HTKAMD_UPMIXES; break;
-      default: DIE("-u: unknown update flag %c (t m v w)", *s);
+      case 'p': f |= HTKAMD_UPMAP; break;
+      default: DIE("-u: unknown update flag %c (t m v w p)", *s);
       }
    return f;
 }
@@ -128,7 +129,7 @@ int main(int argc, char **argv)
    const char *tk = cfg_get(&cfg, "TARGETKIND");
    const int targetKind = kind_parse(tk ? tk : htkamd_mmf_parm_kind(mmf));
    if (trace & 1) {
-      printf("HERest  ML Updating: %s%s%s%s\n\n", (uFlags & HTKAMD_UPTRANS) ? "Transitions " : "", (uFlags & HTKAMD_UPMEANS) ? "Means " : "",
+      printf("HERest  %s Updating: %s%s%s%s\n\n", (uFlags & HTKAMD_UPMAP) ? "MAP" : "ML", (uFlags & HTKAMD_UPTRANS) ? "Transitions " : "", (uFlags & HTKAMD_UPMEANS) ? "Means " : "",
              (uFlags & HTKAMD_UPVARS) ? "Variances " : "", (uFlags & HTKAMD_UPMIXES) ? "MixWeights " : "");
       printf("%d Logical/%d Physical Models Loaded, VecSize=%d\n", htkamd_mmf_num_logical(mmf), H, D);
    }
@@ -225,7 +226,25 @@ int main(int argc, char **argv)
    uc.minEgs = minEgs; uc.minVar = minVar; uc.mixWeightFloor = mixFloor; uc.uFlags = uFlags; uc.varFloor = htkamd_mmf_var_floor(mmf);
    uc.singleProcess = (parMode == -1);
    htkamd_update_stats us;
-   if (htkamd_model_has_sharing(model)) {
+   if (uFlags & HTKAMD_UPMAP) {
+      /* MAPUpdateModels reads HMap's own configuration, not HERest's switches (InitMap HMap.c:88-104) */
+      const char *v;
+      uc.minEgs = (v = cfg_get_mod(&cfg, "HMAP", "MINEGS")) ? atoi(v) : 0;
+      uc.minVar = (v = cfg_get_mod(&cfg, "HMAP", "MINVAR")) ? (float)atof(v) : 0.0f;
+      uc.mixWeightFloor = (v = cfg_get_mod(&cfg, "HMAP", "MIXWEIGHTFLOOR")) ? (float)(1.0e-5 * atof(v)) : 0.0f;
+      uc.mapTau = (v = cfg_get_mod(&cfg, "HMAP", "MAPTAU")) ? (float)atof(v) : 20.0f;
+      uc.mapMinObs = (v = cfg_get_mod(&cfg, "HMAP", "MINOBS")) ? (float)atof(v) : 0.0f;
+      CHECK(htkamd_model_update(model, accs, vec, &uc, &us));
+      if ((v = cfg_get_mod(&cfg, "HMAP", "TRACE")) && (atoi(v) & 1)) {
+         int totM = 0;
+         { int *ms = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1)), *vs = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1));
+           const int shared = htkamd_mmf_sharing(mmf, ms, vs);
+           for (int g = 0; g < d->numGauss; g++) if (shared <= 0 || ms[g] == g) totM++;        /* TotMixInSet: distinct mean vectors */
+           free(ms); free(vs); }
+         printf("Observed components (means) %d of %d: %.2f\n", us.nMapObserved, totM, 100 * (float)us.nMapObserved / (float)totM);
+         if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
+      }
+   } else if (htkamd_model_has_sharing(model)) {
       CHECK(htkamd_model_update(model, accs, vec, &uc, &us));         /* pooled statistics of the tied vectors: host update */
    } else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
    if (us.nSkippedHmm > 0) fprintf(stderr, "WARNING [-2331] UpdateModels: %d models had fewer than %d examples and were copied\n", us.nSkippedHmm, minEgs);
@@ -238,7 +257,7 @@ int main(int argc, char **argv)
       if (mmfs.n > 0) { make_fn(mmfs.v[0], outDir ? outDir : ".", NULL, one, sizeof(one)); oneFile = one; }
       if (binary) CHECK(htkamd_mmf_write_binary(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
       else CHECK(htkamd_mmf_write(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
-      if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
+      if (us.nFloorVar > 0 && !(uFlags & HTKAMD_UPMAP)) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
       if (trace & 1) printf("Saving hmm's to %s %s\n", oneFile ? "MMF" : "dir", oneFile ? oneFile : (outDir ? outDir : "Current"));
       printf("Reestimation complete - average log prob per frame = %e\n", vec[lay.totalPr] / vec[lay.totalT]);
       printf("     - total frames seen          = %e\n", vec[lay.totalT]);
