@@ -348,13 +348,13 @@ class Viterbi:
         check(lib().htkamd_viterbi_create(model.h, C.byref(self.h)), "viterbi_create")
         self._keep = None
 
-    def align(self, dX_ptr: int, frameOff, labOff, labs, genBeam: float = 1.0e10, stream=None):
+    def align(self, dX_ptr: int, frameOff, labOff, labs, genBeam: float = 1.0e10, stream=None, scoreMode: int = 0):
         frameOff = np.ascontiguousarray(frameOff, np.int32); labOff = np.ascontiguousarray(labOff, np.int32)
         labs = np.ascontiguousarray(labs, np.int32)
         self._keep = (frameOff, labOff, labs)
         nUtt = len(frameOff) - 1
         b = BatchDesc(nUtt, C.c_void_p(dX_ptr), _p(frameOff), _p(labOff), _p(labs))
-        check(lib().htkamd_viterbi_align(self.h, C.byref(b), C.c_float(genBeam), _stream(stream)), "viterbi_align")
+        check(lib().htkamd_viterbi_align_mode(self.h, C.byref(b), C.c_float(genBeam), C.c_int(scoreMode), _stream(stream)), "viterbi_align")
         ns = C.c_size_t(); nm = C.c_size_t()
         check(lib().htkamd_viterbi_sizes(self.h, C.byref(ns), C.byref(nm)), "viterbi_sizes")
         r = dict(segStart=np.empty(ns.value, np.int32), segEnd=np.empty(ns.value, np.int32), segScore=np.empty(ns.value, np.float64),

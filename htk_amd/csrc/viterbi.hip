@@ -513,6 +513,12 @@ template <typename T> static int vupload(VBuf &b, const std::vector<T> &v, hipSt
 
 extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *b, float genBeam, void *stream)
 {
+   return htkamd_viterbi_align_mode(v, b, genBeam, HTKAMD_SCORE_EXACT, stream);
+}
+
+extern "C" int htkamd_viterbi_align_mode(htkamd_viterbi *v, const htkamd_batch_desc *b, float genBeam, int scoreMode, void *stream)
+{
+   if (scoreMode & ~(HTKAMD_SCORE_SOUTP | HTKAMD_SCORE_DIAGC)) { htkamd_set_error("viterbi_align: score mode %d (0, HTKAMD_SCORE_SOUTP, HTKAMD_SCORE_DIAGC)", scoreMode); return HTKAMD_EINVAL; }
    if (!v || !b || b->nUtt < 0 || (b->nUtt > 0 && (!b->dX || !b->frameOff || !b->labOff || !b->labs))) {
       htkamd_set_error("viterbi_align: bad argument"); return HTKAMD_EINVAL;
    }
@@ -585,7 +591,9 @@ extern "C" int htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)v->d_counter.p;
-   if ((rc = htkamd_launch_score_exact(m, sa, s))) return rc;
+   if (scoreMode & HTKAMD_SCORE_DIAGC) { if ((rc = htkamd_model_device_tables((htkamd_model *)m))) return rc; }
+   sa.var = m->d_var;
+   if ((rc = htkamd_launch_score_exact(m, sa, s, nullptr, nullptr, (scoreMode & HTKAMD_SCORE_SOUTP) != 0, (scoreMode & HTKAMD_SCORE_DIAGC) != 0))) return rc;
 
    VitArgs va;
    va.utt = (const VitUtt *)v->d_utt.p; va.nUtt = U;

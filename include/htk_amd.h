@@ -437,6 +437,10 @@ typedef struct htkamd_viterbi htkamd_viterbi;
 int  htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out);
 void htkamd_viterbi_destroy(htkamd_viterbi *v);
 int  htkamd_viterbi_align(htkamd_viterbi *v, const htkamd_batch_desc *batch, float genBeam, void *stream);
+/* The same with the state scores in another arithmetic of the EXACT family: HTKAMD_SCORE_SOUTP (SOutP's double accumulation with one
+ * float rounding, HModel.c:5538) and / or HTKAMD_SCORE_DIAGC (DOutP's division by the variance, HModel.c:5347) -- what HInit's
+ * ViterbiAlign (HInit.c:792, OutP on a set that has not been through ConvDiagC) computes.  0 = htkamd_viterbi_align. */
+int  htkamd_viterbi_align_mode(htkamd_viterbi *v, const htkamd_batch_desc *batch, float genBeam, int scoreMode, void *stream);
 int  htkamd_viterbi_sizes(const htkamd_viterbi *v, size_t *nSeg /* sum of chain states */, size_t *nMod /* sum of models */);
 int  htkamd_viterbi_results(htkamd_viterbi *v, int *segStart, int *segEnd, double *segScore,
                             int *modStart, int *modEnd, double *modScore,

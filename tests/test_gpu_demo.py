@@ -207,6 +207,51 @@ def test_hinit_viterbi_training(native, oracle, name):
     assert np.allclose(lin(p["transP"][q0["transOff"][t]:q0["transOff"][t] + N * N]), lin(rq["transP"][rq["transOff"][rt]:rq["transOff"][rt] + N * N]), rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", list("SCVNL"))
+def test_hinit_mixture_training(native, oracle, name):
+    """HInit on prototypes with 2 / 3 / 2 mixture components per state (tests/golden/make_hinit_mix_golden.py): uniform segmentation +
+    FlatCluster (HTrain.c:763), Viterbi alignment and best-component choice on the device, hard-assignment re-estimation -- pass by pass
+    against the reference's trace and the model it wrote (weights, means, variances, transitions)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from examples.hinit_model import hinit
+    gold = os.path.join(DEMO, "hinit_mix")
+    mmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(gold, "proto"))
+    files = sorted(f for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    tables, labels = [], []
+    for f in files:
+        X, _, _ = native.parm_read(os.path.join(DEMO, "train", f))
+        tables.append(oracle.parm_qualify(X, hasD=True))
+        labels.append(native.labels_read(os.path.join(DEMO, "labels", f.replace(".mfc", ".lab"))))
+    pk, model, hist, converged = hinit(native, mmf, name, tables, labels, max_iter=10)
+    lines = [l for l in open(os.path.join(gold, "hinit.log")) if l.startswith("HInit %s:" % name)]
+    ref = [float(re.search(r"Average LogP = *(-?[\d.]+)", l).group(1)) for l in lines if "Average LogP" in l]
+    assert len(hist) == len(ref), (hist, ref)
+    for p, rp in zip(hist, ref):
+        assert abs(p - rp) <= 1e-6 * abs(rp), (name, hist, ref)
+    assert converged == any("converged" in l for l in lines)
+    rmmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(gold, "hmm0"))
+    rq, p = rmmf.packed(), model.get_params()
+    q0 = mmf.packed()
+    h, rh = mmf.logical[name], rmmf.logical[name]
+    nmix = []
+    for s, rs in zip(q0["hmmState"][q0["hmmStateOff"][h]:q0["hmmStateOff"][h + 1]], rq["hmmState"][rq["hmmStateOff"][rh]:rq["hmmStateOff"][rh + 1]]):
+        c0, c1, r0, r1 = int(q0["stateCompOff"][s]), int(q0["stateCompOff"][s + 1]), int(rq["stateCompOff"][rs]), int(rq["stateCompOff"][rs + 1])
+        assert c1 - c0 == r1 - r0
+        nmix.append(c1 - c0)
+        for c, rc in zip(range(c0, c1), range(r0, r1)):
+            g, rg = int(q0["compGauss"][c]), int(rq["compGauss"][rc])
+            sigma = np.sqrt(rq["var"][rg])
+            assert abs(p["compWeight"][c] - rq["compWeight"][rc]) <= 1e-5
+            assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-4 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-6).all()
+            assert np.allclose(p["var"][g], rq["var"][rg], rtol=1e-4, atol=1e-7)
+    assert nmix == [2, 3, 2]
+    t, rt = int(q0["hmmTrans"][h]), int(rq["hmmTrans"][rh])
+    N = int(q0["transN"][t])
+    lin = lambda v: np.where(v > -0.5e10, np.exp(v.astype(np.float64)), 0.0)
+    assert np.allclose(lin(p["transP"][q0["transOff"][t]:q0["transOff"][t] + N * N]), lin(rq["transP"][rq["transOff"][rt]:rq["transOff"][rt] + N * N]), rtol=1e-4, atol=1e-7)
+
+
 def test_htkdemo_training_chain_from_prototypes(native, oracle, tmp_path):
     """The whole training side of HTKDemo's monPlainM1S1 on the device, each stage fed by the previous one's OUTPUT FILES:
     prototypes -> HInit (Viterbi training per model) -> HRest (Baum-Welch per model) -> one embedded HERest pass; the result
