@@ -499,16 +499,19 @@ def hmm_scan_order(names) -> np.ndarray:
     return order
 
 
-def accs_dump_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UPALL):
+def accs_dump_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UPALL, sharing=None):
+    """sharing: (meanShare, varShare) of Mmf.sharing() for a set with ~u / ~v vectors."""
     d, keep = _desc_from_packed(pk)
     vec = np.ascontiguousarray(vec, np.float64)
-    check(lib().htkamd_accs_dump_file(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), path.encode()), "accs_dump_file")
+    ms, vs = (None, None) if sharing is None else (np.ascontiguousarray(sharing[0], np.int32), np.ascontiguousarray(sharing[1], np.int32))
+    check(lib().htkamd_accs_dump_file_shared(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), _p(ms), _p(vs), path.encode()), "accs_dump_file")
 
 
-def accs_load_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UPALL):
+def accs_load_file(pk: dict, vec: np.ndarray, names, path: str, uFlags: int = UPALL, sharing=None):
     d, keep = _desc_from_packed(pk)
     assert vec.dtype == np.float64 and vec.flags.c_contiguous
-    check(lib().htkamd_accs_load_file(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), path.encode()), "accs_load_file")
+    ms, vs = (None, None) if sharing is None else (np.ascontiguousarray(sharing[0], np.int32), np.ascontiguousarray(sharing[1], np.int32))
+    check(lib().htkamd_accs_load_file_shared(C.byref(d), _p(vec), _names_array(names), C.c_int(uFlags), _p(ms), _p(vs), path.encode()), "accs_load_file")
 
 
 def stats_write_file(pk: dict, vec: np.ndarray, names, path: str):
@@ -946,8 +949,8 @@ class Decoder:
                 out.append(([(int(wp[o + i]), int(ws[o + i]), int(we[o + i]), float(sc[o + i])) for i in range(nW[u])], float(tot[u])))
         return out
 
-    def run_lattice(self, feats, nToks, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=None, wordPen=0.0, prScale=1.0, maxNodes=20000, maxArcs=80000, scoreMode=0):
-        """HVite -n nToks: per utterance the lattice as a dict of arrays (oracle.decode_nbest's fields + nodePron), or None."""
+    def run_lattice(self, feats, nToks, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=None, wordPen=0.0, prScale=1.0, maxNodes=20000, maxArcs=80000, scoreMode=0, maxActive=0):
+        """HVite -n nToks [-u maxActive]: per utterance the lattice as a dict of arrays (oracle.decode_nbest's fields + nodePron), or None."""
         lmScale = self.lmScale if lmScale is None else float(lmScale)
         if lmScale != self.lmScale:
             raise HtkAmdError("Decoder.run_lattice: the LM scale is fixed at creation (LikeToWord look-ahead)")
@@ -961,7 +964,7 @@ class Decoder:
         aS = np.zeros(n1 * maxArcs, np.int32); aE = np.zeros_like(aS); aAc = np.zeros(n1 * maxArcs, np.float32); aLm = np.zeros_like(aAc); aPr = np.zeros_like(aAc)
         aSc = np.zeros(n1 * maxArcs, np.float64)
         out = LatticeOut(_p(nn), _p(na), _p(nF), _p(nP), _p(nNet), _p(nL), _p(aS), _p(aE), _p(aAc), _p(aLm), _p(aPr), _p(aSc), _p(tot))
-        cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale, scoreMode, 0)
+        cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale, scoreMode, int(maxActive))
         check(lib().htkamd_decoder_run_lattice(self.h, C.byref(cfg), C.c_int(nToks), C.c_float(genBeam if nBeam is None else nBeam), dX.ptr, _p(frameOff), C.c_int(nU),
                                                C.c_int(maxNodes), C.c_int(maxArcs), C.byref(out), None), "decoder_run_lattice")
         res = []

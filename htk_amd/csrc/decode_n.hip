@@ -48,7 +48,7 @@ struct NArgs {
    int *mark;                                                  // [paths] MarkPaths' usage numbers
    int *stack;                                                 // [nUtt * 2*maxLatNodes] depth-first stack
    float genBeam, wordBeam, nBeam, lmScale, wordPen, prScale;
-   int nToks;
+   int nToks, maxActive;
    int maxLatNodes, maxLatArcs;
    size_t *pathBase;                   // unused
    int *latN;                          // [nUtt*2] nodes, arcs (or -1 / -3)
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
    __shared__ double red[DEC_THREADS / 64];
    __shared__ double red2[DEC_THREADS / 64];
    __shared__ float thr[3];
+   __shared__ unsigned int usel[3], uhist[256];
    extern __shared__ unsigned char dynLds[];           // partial sets of a wide node: DEC_THREADS x TSet
    TSet *part = (TSet *)dynLds;
    const int u = blockIdx.x, tid = threadIdx.x;
@@ -174,6 +175,57 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
    __syncthreads();
 
    for (int t = 0; t <= T; t++) {
+      if (t >= 1 && a.maxActive > 0) {
+         // ---- maximum-model pruning (ProcessObservation HRec.c:1966-1985), as in decode.hip: when more than maxActive instances are
+         // attached, those whose max (a float) lies below the (maxActive+1)-th largest lose every token set before pass 1
+         const float gTp = thr[0];
+         if (tid == 0) usel[0] = 0;
+         __syncthreads();
+         int cnt = 0;
+         for (int n = tid; n < N.nNodes; n += DEC_THREADS) { const double v = imax[n]; if (v >= gTp && v > LSMALL) cnt++; }
+         if (cnt) atomicAdd(&usel[0], (unsigned)cnt);
+         __syncthreads();
+         const int nact = (int)usel[0];
+         if (nact > a.maxActive) {
+            if (tid == 0) { usel[1] = 0; usel[2] = (unsigned)a.maxActive; }
+            unsigned int mask = 0;
+            for (int pass = 0; pass < 4; pass++) {
+               const int shift = 24 - 8 * pass;
+               for (int i = tid; i < 256; i += DEC_THREADS) uhist[i] = 0;
+               __syncthreads();
+               const unsigned int prefix = usel[1];
+               for (int n = tid; n < N.nNodes; n += DEC_THREADS) {
+                  const double v = imax[n];
+                  if (!(v >= gTp && v > LSMALL)) continue;
+                  unsigned int k = __float_as_uint((float)v);
+                  k ^= (k >> 31) ? 0xFFFFFFFFu : 0x80000000u;          // ascending order of the floats
+                  if ((k & mask) == prefix) atomicAdd(&uhist[(k >> shift) & 255], 1);
+               }
+               __syncthreads();
+               if (tid == 0) {
+                  unsigned int skip = usel[2], cum = 0; int b = 255;
+                  for (; b > 0; b--) { if (cum + (unsigned)uhist[b] > skip) break; cum += (unsigned)uhist[b]; }
+                  usel[1] = prefix | ((unsigned)b << shift); usel[2] = skip - cum;
+               }
+               mask |= 255u << shift;
+               __syncthreads();
+            }
+            unsigned int kk = usel[1];
+            kk ^= (kk >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+            const float uth = __uint_as_float(kk);
+            if (uth > (float)LSMALL)
+               for (int n = tid; n < N.nNodes; n += DEC_THREADS) {
+                  const double v = imax[n];
+                  if (!(v >= gTp && v > LSMALL) || !(v < (double)uth)) continue;
+                  TSet z; ts_null(z);
+                  imax[n] = LZERO; ex[n] = z;
+                  const int4 ni = N.nodeInfo[n];
+                  const int nt = ((ni.x & 15) == HTKAMD_NODE_HMM) ? ((ni.x >> 4) & 255) - 1 : 1;
+                  for (int i = 0; i < nt; i++) cur[ni.y + i] = z;
+               }
+            __syncthreads();
+         }
+      }
       if (t >= 1) {
          const float gT = thr[0], nT = thr[2];             // thresholds of the previous frame
          double myGen = LZERO, myWord = LZERO;
@@ -395,7 +447,6 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
 {
    if (!d || !cfg || !frameOff || nUtt < 0 || !out || !out->nNodes || !out->nArcs || maxLatNodes < 2 || maxLatArcs < 1) { htkamd_set_error("decoder_run_lattice: bad argument"); return HTKAMD_EINVAL; }
    if (nToks < 2 || nToks > NT) { htkamd_set_error("decoder_run_lattice: nToks = %d (2..%d tokens per state)", nToks, NT); return HTKAMD_EINVAL; }
-   if (cfg->maxActive > 0) { htkamd_set_error("decoder_run_lattice: maximum-model pruning (-u) is not supported with token sets"); return HTKAMD_EINVAL; }
    if (nUtt == 0) return HTKAMD_OK;
    hipStream_t s = (hipStream_t)stream;
    htkamd_model *m = d->m;
@@ -466,7 +517,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
       if (!rc) {
          a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
          a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.nBeam = nBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
-         a.nToks = nToks; a.maxLatNodes = maxLatNodes; a.maxLatArcs = maxLatArcs;
+         a.nToks = nToks; a.maxActive = cfg->maxActive > 0 ? cfg->maxActive : 0; a.maxLatNodes = maxLatNodes; a.maxLatArcs = maxLatArcs;
          const size_t lds = sizeof(TSet) * DEC_THREADS;
          hipError_t e = hipFuncSetAttribute((const void *)k_decode_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e == hipSuccess) { hipLaunchKernelGGL(k_decode_n, dim3(nu), dim3(DEC_THREADS), lds, s, a); e = hipGetLastError(); }

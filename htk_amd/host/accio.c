@@ -5,7 +5,10 @@
  * File layout (binary, big-endian, HShell.c:1638): per physical HMM in HMM-scan order -- quoted name + newline,
  * int32 example count, for every not-yet-seen state WtAcc {c[M], occ} followed by, per not-yet-seen Gaussian,
  * MuAcc {mu[D], occ} and VaAcc {var[D], occ}; for a not-yet-seen transition matrix TrAcc {tran[N][N], occ[N]};
- * int32 marker 123456.  The scan order is the order of the 'h' macros in the set's hash table (HUtil.c:265-295
+ * int32 marker 123456.  A mean or variance vector shared by several Gaussians (~u / ~v macros) carries ONE MuAcc / VaAcc in the
+ * reference and is dumped where the scan first meets it (IsSeenV on the vector, HTrain.c:1484-1493): the writer puts the sum over the
+ * sharers there, the reader adds the file's record to the vector's first sharer (htkamd_model_update pools the sharers anyway).
+ * The scan order is the order of the 'h' macros in the set's hash table (HUtil.c:265-295
  * GoNextHMM over mtab; HModel.c:3314 Hash, :3384 head insertion): ascending hash bucket, later definitions first.
  */
 #include <stdio.h>
@@ -83,9 +86,11 @@ static int get_be32(FILE *f, void *p)
 
 /* walks the file structure once; `wr` != 0 writes vec -> file, else adds file -> vec */
 static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_accs_layout *lay, double *vec,
-                    const char *const *names, int uFlags, const char *path)
+                    const char *const *names, int uFlags, const char *path, const int *meanShare, const int *varShare)
 {
    const int D = d->vecSize;
+   unsigned char *seenMu = (unsigned char *)calloc((size_t)d->numGauss + 1, 1), *seenVa = (unsigned char *)calloc((size_t)d->numGauss + 1, 1);
+   double *pool = NULL;                         /* writer, shared vectors: statistics summed into the first sharer */
    unsigned char *seenS = (unsigned char *)calloc((size_t)d->numStates, 1);
    unsigned char *seenG = (unsigned char *)calloc((size_t)d->numGauss, 1);
    unsigned char *seenT = (unsigned char *)calloc((size_t)d->numTrans, 1);
@@ -95,6 +100,35 @@ static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_ac
    float x;
    for (t = 0; t < d->numTrans; t++) occOff[t + 1] = occOff[t] + d->transN[t];
    htkamd_hmm_scan_order(names, d->numPhys, order);
+   /* vector ids -> the first Gaussian that uses the vector */
+   int *mLead = NULL, *vLead = NULL;
+   for (t = 0; t < 2; t++) {
+      const int *share = t ? varShare : meanShare;
+      int g, mx = -1, *lead, *first;
+      if (!share) continue;
+      lead = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1));
+      for (g = 0; g < d->numGauss; g++) if (share[g] > mx) mx = share[g];
+      first = (int *)malloc(sizeof(int) * (size_t)(mx + 2));
+      for (g = 0; g <= mx; g++) first[g] = -1;
+      for (g = 0; g < d->numGauss; g++) {
+         lead[g] = g;
+         if (share[g] >= 0) { if (first[share[g]] < 0) first[share[g]] = g; lead[g] = first[share[g]]; }
+      }
+      free(first);
+      if (t) vLead = lead; else mLead = lead;
+   }
+#define MLD(g) (mLead ? mLead[g] : (g))
+#define VLD(g) (vLead ? vLead[g] : (g))
+   if (wr && (mLead || vLead)) {
+      int g;
+      pool = (double *)malloc(sizeof(double) * lay->total);
+      memcpy(pool, vec, sizeof(double) * lay->total);
+      for (g = 0; g < d->numGauss; g++) {
+         if (MLD(g) != g) { for (i = 0; i < D; i++) pool[lay->mu + (size_t)MLD(g) * D + i] += vec[lay->mu + (size_t)g * D + i]; pool[lay->muOcc + MLD(g)] += vec[lay->muOcc + g]; }
+         if (VLD(g) != g) { for (i = 0; i < D; i++) pool[lay->va + (size_t)VLD(g) * D + i] += vec[lay->va + (size_t)g * D + i]; pool[lay->vaOcc + VLD(g)] += vec[lay->vaOcc + g]; }
+      }
+      vec = pool;
+   }
 #define IO(off)  do { if (wr) put_f(f, vec[off]); else { if (!get_be32(f, &x)) { rc = HTKAMD_EINVAL; goto bad; } vec[off] += (double)x; } } while (0)
    for (k = 0; k < d->numPhys; k++) {
       const int h = order[k], ti = d->hmmTrans[h], N = d->transN[ti];
@@ -123,11 +157,11 @@ static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_ac
          for (c = d->stateCompOff[s]; c < d->stateCompOff[s + 1]; c++) IO(lay->wt + c);
          IO(lay->wtOcc + s);
          for (c = d->stateCompOff[s]; c < d->stateCompOff[s + 1]; c++) {
-            const int g = d->compGauss[c];
-            if (seenG[g]) continue;
+            const int g = d->compGauss[c], gm = MLD(g), gv = VLD(g);
+            if (seenG[g]) continue;              /* a shared mixture pdf (~m) */
             seenG[g] = 1;
-            if (uFlags & HTKAMD_UPMEANS) { for (i = 0; i < D; i++) IO(lay->mu + (size_t)g * D + i); IO(lay->muOcc + g); }
-            if (uFlags & HTKAMD_UPVARS) { for (i = 0; i < D; i++) IO(lay->va + (size_t)g * D + i); IO(lay->vaOcc + g); }
+            if ((uFlags & HTKAMD_UPMEANS) && !seenMu[gm]) { seenMu[gm] = 1; for (i = 0; i < D; i++) IO(lay->mu + (size_t)gm * D + i); IO(lay->muOcc + gm); }
+            if ((uFlags & HTKAMD_UPVARS) && !seenVa[gv]) { seenVa[gv] = 1; for (i = 0; i < D; i++) IO(lay->va + (size_t)gv * D + i); IO(lay->vaOcc + gv); }
          }
       }
       if (!seenT[ti]) {
@@ -146,12 +180,19 @@ bad:
 bad2:
 done:
 #undef IO
+#undef MLD
+#undef VLD
+   free(pool); free(seenMu); free(seenVa); free(mLead); free(vLead);
    free(seenS); free(seenG); free(seenT); free(order); free(occOff);
    return rc;
 }
 
 /* DumpAccs + HERest's trailer: write the host vector as HER<n>.acc */
 int htkamd_accs_dump_file(const htkamd_model_desc *d, const double *vec, const char *const *names, int uFlags, const char *path)
+{
+   return htkamd_accs_dump_file_shared(d, vec, names, uFlags, NULL, NULL, path);
+}
+int htkamd_accs_dump_file_shared(const htkamd_model_desc *d, const double *vec, const char *const *names, int uFlags, const int *meanShare, const int *varShare, const char *path)
 {
    htkamd_accs_layout lay;
    FILE *f;
@@ -160,13 +201,17 @@ int htkamd_accs_dump_file(const htkamd_model_desc *d, const double *vec, const c
    htkamd_accs_layout_from_desc(d, &lay);
    f = fopen(path, "wb");
    if (!f) { htkamd_set_error("accs_dump_file: cannot open %s", path); return HTKAMD_EINVAL; }
-   rc = acc_walk(f, 1, d, &lay, (double *)vec, names, uFlags, path);
+   rc = acc_walk(f, 1, d, &lay, (double *)vec, names, uFlags, path, meanShare, varShare);
    fclose(f);
    return rc;
 }
 
 /* LoadAccs + trailer: ADD the file to the host vector */
 int htkamd_accs_load_file(const htkamd_model_desc *d, double *vec, const char *const *names, int uFlags, const char *path)
+{
+   return htkamd_accs_load_file_shared(d, vec, names, uFlags, NULL, NULL, path);
+}
+int htkamd_accs_load_file_shared(const htkamd_model_desc *d, double *vec, const char *const *names, int uFlags, const int *meanShare, const int *varShare, const char *path)
 {
    htkamd_accs_layout lay;
    FILE *f;
@@ -175,7 +220,7 @@ int htkamd_accs_load_file(const htkamd_model_desc *d, double *vec, const char *c
    htkamd_accs_layout_from_desc(d, &lay);
    f = fopen(path, "rb");
    if (!f) { htkamd_set_error("accs_load_file: cannot open %s", path); return HTKAMD_EINVAL; }
-   rc = acc_walk(f, 0, d, &lay, vec, names, uFlags, path);
+   rc = acc_walk(f, 0, d, &lay, vec, names, uFlags, path, meanShare, varShare);
    if (rc == HTKAMD_OK && fgetc(f) != EOF) { htkamd_set_error("accs_load_file: %s: trailing bytes", path); rc = HTKAMD_EINVAL; }
    fclose(f);
    return rc;

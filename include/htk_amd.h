@@ -311,6 +311,13 @@ int htkamd_accs_layout_from_desc(const htkamd_model_desc *d, htkamd_accs_layout 
 int htkamd_hmm_scan_order(const char *const *names, int H, int *order);
 int htkamd_accs_dump_file(const htkamd_model_desc *d, const double *hostVec, const char *const *names, int uFlags, const char *path);
 int htkamd_accs_load_file(const htkamd_model_desc *d, double *hostVec, const char *const *names, int uFlags, const char *path);
+/* The same for a set with tied mean / variance vectors (meanShare / varShare as in htkamd_model_set_sharing, either may be NULL): a
+ * shared vector has ONE MuAcc / VaAcc record in the file, where the scan first meets it (HTrain.c:1484-1493).  The writer puts the sum
+ * over the sharers there; the reader adds the record to the vector's first sharer, which is all htkamd_model_update needs. */
+int htkamd_accs_dump_file_shared(const htkamd_model_desc *d, const double *hostVec, const char *const *names, int uFlags,
+                                 const int *meanShare, const int *varShare, const char *path);
+int htkamd_accs_load_file_shared(const htkamd_model_desc *d, double *hostVec, const char *const *names, int uFlags,
+                                 const int *meanShare, const int *varShare, const char *path);
 /* HERest -s file: per physical HMM (scan order) its index, quoted name, example count and the occupation of each emitting
  * state -- StatReport / PrintStats (HERest.c:708-747), the input of HHEd's RO / TB / TC commands. */
 int htkamd_stats_write_file(const htkamd_model_desc *d, const double *hostVec, const char *const *names, const char *path);

@@ -160,7 +160,7 @@ int orc_parm_qualify(const float *stat, int T, int nStat, int nZeroMean, int has
 int orc_decode_nbest(const orc_model *m, const float *X, int T,
                      int nNodes, const int *kind, const int *model, const float *pronProb,
                      const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
-                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks,
+                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks, int maxActive,
                      int maxLatNodes, int maxLatArcs, int *latNodeNet, int *latNodeFrame, double *latNodeLike,
                      int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
                      int *nLatNodes, int *nLatArcs, double *totalLike);

@@ -130,10 +130,12 @@ static void tokset_merge(dnet *d, tset_t *res, const tok_t *cmp, const tset_t *s
    for (i = 0; i < nw; i++) d->aux[nodes[i]] = 0;
 }
 
+static int cmp_desc_n(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return (x < y) - (x > y); }
+
 int orc_decode_nbest(const orc_model *m, const float *X, int T,
                      int nNodes, const int *kind, const int *model, const float *pronProb,
                      const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
-                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks,
+                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks, int maxActive,
                      int maxLatNodes, int maxLatArcs, int *latNodeNet, int *latNodeFrame, double *latNodeLike,
                      int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
                      int *nLatNodes, int *nLatArcs, double *totalLike)
@@ -191,6 +193,7 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
 
    tset_t *tk = (tset_t *)malloc(sizeof(tset_t) * (size_t)nTok), *ex = (tset_t *)malloc(sizeof(tset_t) * (size_t)nNodes), *nw = (tset_t *)malloc(sizeof(tset_t) * (size_t)(maxN + 1));
    double *imax = (double *)malloc(sizeof(double) * (size_t)nNodes);
+   float *qsa = (float *)malloc(sizeof(float) * (size_t)(nNodes + 1));
    char *att = (char *)calloc((size_t)nNodes, 1);
    float genThresh = (float)ORC_LSMALL, wordThresh = (float)ORC_LSMALL;
    float *scv = (float *)malloc(sizeof(float) * (size_t)m->S);
@@ -215,6 +218,20 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
    for (t = 0; t <= T; t++) {
       if (t >= 1) {
          double genMax = ORC_LZERO, wordMax = ORC_LZERO;
+         if (maxActive > 0) {                                 /* maximum-model pruning, HRec.c:1966-1985, as in orc_decode.c */
+            int nact = 0;
+            for (n = 0; n < nNodes; n++) if (att[n]) qsa[nact++] = (float)imax[n];
+            if (nact > maxActive) {
+               qsort(qsa, (size_t)nact, sizeof(float), cmp_desc_n);
+               const float thresh = qsa[maxActive];
+               if (thresh > ORC_LSMALL)
+                  for (n = 0; n < nNodes; n++)
+                     if (att[n] && imax[n] < thresh) {
+                        att[n] = 0; imax[n] = ORC_LZERO; set_null(&ex[n]);
+                        for (i = d.tok0[n]; i < d.tok0[n + 1]; i++) set_null(&tk[i]);
+                     }
+            }
+         }
          for (n = 0; n < nNodes; n++) {
             if (kind[n] != KIND_HMM) { set_null(&tk[d.tok0[n]]); set_null(&ex[n]); imax[n] = ORC_LZERO; continue; }   /* StepWord1 */
             const int N = d.N[n];
@@ -371,7 +388,7 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
          rc = 0;
       }
    }
-   free(tk); free(ex); free(nw); free(imax); free(scv); free(sct); free(att);
+   free(tk); free(ex); free(nw); free(imax); free(qsa); free(scv); free(sct); free(att);
 done0:
    free(indeg); free(order); free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi); free(d.aux); free(d.pth); free(d.nxt);
    return rc;

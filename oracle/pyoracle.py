@@ -300,7 +300,7 @@ def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
 
 
 def decode_nbest(model: "Model", X: np.ndarray, net: dict, nToks: int, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=1.0, wordPen=0.0, prScale=1.0,
-                 maxNodes=20000, maxArcs=80000):
+                 maxNodes=20000, maxArcs=80000, maxActive=0):
     """HRec with nToks > 1 (HVite -n): the lattice of CreateLattice as a dict of arrays, or None when no token reached the final node.
     nBeam defaults to genBeam (HVite.c:546)."""
     X = np.ascontiguousarray(X, np.float32)
@@ -313,7 +313,7 @@ def decode_nbest(model: "Model", X: np.ndarray, net: dict, nToks: int, genBeam=1
     aPr = np.zeros(maxArcs, np.float32); aSc = np.zeros(maxArcs, np.float64)
     rc = lib().orc_decode_nbest(C.byref(model.c), _p(X), C.c_int(X.shape[0]), C.c_int(len(kind)), _p(kind), _p(mdl), _p(pp), _p(lo), _p(ld), _p(ll),
                                 C.c_int(int(net["initial"])), C.c_int(int(net["final"])), C.c_float(genBeam), C.c_float(wordBeam),
-                                C.c_float(genBeam if nBeam is None else nBeam), C.c_float(lmScale), C.c_float(wordPen), C.c_float(prScale), C.c_int(nToks),
+                                C.c_float(genBeam if nBeam is None else nBeam), C.c_float(lmScale), C.c_float(wordPen), C.c_float(prScale), C.c_int(nToks), C.c_int(maxActive),
                                 C.c_int(maxNodes), C.c_int(maxArcs), _p(nNet), _p(nFr), _p(nLk), _p(aS), _p(aE), _p(aAc), _p(aLm), _p(aPr), _p(aSc),
                                 C.byref(nn), C.byref(na), C.byref(tot))
     if rc == -1:

@@ -300,7 +300,6 @@ Lattice *__wrap_CompleteRecognition(VRecInfo *vri, HTime frameDur, MemHeap *heap
       memset(&lo, 0, sizeof(lo));
       lo.nNodes = &nn; lo.nArcs = &na; lo.nodeFrame = nodeFrame; lo.nodePron = nodePron; lo.nodeLike = nodeLike;
       lo.arcStart = aS; lo.arcEnd = aE; lo.arcAc = aAc; lo.arcLm = aLm; lo.arcPr = aPr; lo.arcScore = aSc; lo.total = &total;
-      if (cfg.maxActive > 0) HError(7399, "CompleteRecognition: -u together with -n is not served by the MI355X recogniser");
       amd_check(htkamd_decoder_run_lattice(S.dec, &cfg, S.nToks, nBeam, (const float *)dX, frameOff, 1, maxN, maxA, &lo, NULL), "htkamd_decoder_run_lattice");
       amd_check(htkamd_dev_free(dX), "htkamd_dev_free");
       if (nn == -3) HError(7399, "CompleteRecognition: the lattice has more than %d nodes / %d arcs", maxN, maxA);

@@ -20,7 +20,8 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 DEC = os.path.join(HERE, "decode")
 # case, lattice, features, tokens, transcriptions, other switches
 CASES = [("bigram", "net", "feats", 4, 3, "-t 250.0"), ("bigram", "net", "feats", 2, 2, "-t 250.0 -s 2.0 -p -5.0 -r 1.5"), ("loop", "net", "feats", 3, 3, "-t 250.0"),
-         ("tee", "net", "feats", 3, 2, "-t 250.0"), ("xwrd", "loop", "feats_loop", 4, 3, "-t 250.0")]
+         ("tee", "net", "feats", 3, 2, "-t 250.0"), ("xwrd", "loop", "feats_loop", 4, 3, "-t 250.0"),
+         ("bigram", "net", "feats", 3, 2, "-t 250.0 -u 6"), ("loop", "net", "feats", 3, 3, "-t 250.0 -u 5"), ("tee", "net", "feats", 4, 2, "-t 250.0 -u 4")]   # -u: maximum-model pruning with token sets
 
 
 def main():

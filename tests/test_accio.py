@@ -84,3 +84,37 @@ def test_reference_herest_p0_accepts_our_file(native, oracle):
                                shell=True, cwd=d, capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
         assert open(os.path.join(d, "outA", "MMF")).read() == open(os.path.join(d, "outB", "MMF")).read()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "HERest")), reason="oracle/_ref not built")
+def test_tied_vectors_in_accumulator_files(native):
+    """A set with ~u / ~v vectors (tests/golden/demo/hmm_tied): the reference's `HERest -p 1` dump has ONE MuAcc / VaAcc per shared vector.
+    Our loader reads it (records land on the vector's first sharer), our writer reproduces the file byte for byte, and the reference's
+    `HERest -p 0` builds the same model from our file as from its own."""
+    DEMO = os.path.join(os.path.dirname(__file__), "golden", "demo")
+    tied = os.path.join(DEMO, "hmm_tied", "newMacros")
+    files = sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    mmf = native.Mmf(files=[tied], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk, sharing = mmf.packed(), mmf.sharing()
+    assert sharing is not None
+    names = list(mmf.phys_names)
+    with tempfile.TemporaryDirectory() as d:
+        conf = os.path.join(d, "cfg"); open(conf, "w").write("TARGETKIND = MFCC_E_D\n")
+        os.makedirs(os.path.join(d, "acc")); os.makedirs(os.path.join(d, "a")); os.makedirs(os.path.join(d, "b"))
+        base = [os.path.join(REFDIR, "HERest"), "-C", conf, "-w", "3", "-v", "0.05", "-u", "tmvw", "-H", tied, "-L", os.path.join(DEMO, "labels"), "-t", "2000.0"]
+        r = subprocess.run(base + ["-M", os.path.join(d, "acc"), "-p", "1", os.path.join(DEMO, "bcplist")] + files, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ref_acc = os.path.join(d, "acc", "HER1.acc")
+        lay = native.accs_layout(pk)
+        v = np.zeros(lay.total, np.float64)
+        native.accs_load_file(pk, v, names, ref_acc, sharing=sharing)
+        with pytest.raises(native.HtkAmdError):
+            native.accs_load_file(pk, np.zeros(lay.total, np.float64), names, ref_acc)         # without the sharing the records do not line up
+        ours = os.path.join(d, "HER2.acc")
+        native.accs_dump_file(pk, v, names, ours, sharing=sharing)
+        assert open(ours, "rb").read() == open(ref_acc, "rb").read()
+        for acc, out in ((ref_acc, "a"), (ours, "b")):
+            r = subprocess.run(base + ["-M", os.path.join(d, out), "-p", "0", os.path.join(DEMO, "bcplist"), acc], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+        assert open(os.path.join(d, "a", "newMacros")).read() == open(os.path.join(d, "b", "newMacros")).read()
+        assert open(os.path.join(d, "a", "newMacros")).read() == open(os.path.join(DEMO, "hmm_tied", "after_herest")).read()

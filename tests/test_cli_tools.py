@@ -129,6 +129,31 @@ def test_herest_cli_tied_mean_and_variance_vectors(tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_herest_cli_parallel_mode_with_tied_vectors(tools, tmp_path):
+    """-p 1 / -p 2 / -p 0 on the set with ~u / ~v vectors: a shared vector has one record per dump (HTrain.c:1484-1493; byte layout
+    checked against the reference in tests/test_accio.py); the merged update equals the reference's single-process pass."""
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    tied = os.path.join(DEMO, "hmm_tied")
+    files = demo_train_files()
+    accdir = tmp_path / "acc"; accdir.mkdir()
+    base = [os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(tied, "newMacros"),
+            "-L", os.path.join(DEMO, "labels"), "-t", "2000.0"]
+    for k, part in ((1, files[:3]), (2, files[3:])):
+        r = run(base + ["-M", str(accdir), "-p", str(k), os.path.join(DEMO, "bcplist")] + part)
+        assert r.returncode == 0 and (accdir / ("HER%d.acc" % k)).exists(), r.stderr
+    out = tmp_path / "next"; out.mkdir()
+    r = run(base + ["-M", str(out), "-p", "0", os.path.join(DEMO, "bcplist"), str(accdir / "HER1.acc"), str(accdir / "HER2.acc")])
+    assert r.returncode == 0, r.stderr
+    ours, theirs = _mmf_numbers(str(out / "newMacros")), _mmf_numbers(os.path.join(tied, "after_herest"))
+    assert len(ours) == len(theirs)
+    for x, y in zip(ours, theirs):
+        if isinstance(y, float):
+            assert isinstance(x, float) and abs(x - y) <= 2e-4 * max(abs(y), 1e-3), (x, y)
+        else:
+            assert x == y
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags,conf", [("pmvw", "HMAP: MAPTAU = 6.0\nHMAP: MINVAR = 0.02\nHMAP: MIXWEIGHTFLOOR = 2.0\nHMAP: TRACE = 1\n"), ("pm", "HMAP: TRACE = 1\n")])
 def test_herest_cli_map_reestimation(tools, tmp_path, flags, conf):
     """HERest -u p...: MAPUpdateModels (HMap.c:413) from the pass's accumulators -- prior-weighted means, variances with the mean-shift

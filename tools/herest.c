@@ -116,10 +116,11 @@ int main(int argc, char **argv)
    const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
    const int D = d->vecSize, H = d->numPhys;
    htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   int *shareMu = NULL, *shareVa = NULL;
    {  /* tied mean / variance vectors (~u ~v macros) */
       int *ms = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1)), *vs = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1));
-      if (htkamd_mmf_sharing(mmf, ms, vs) > 0) CHECK(htkamd_model_set_sharing(model, ms, vs));
-      free(ms); free(vs);
+      if (htkamd_mmf_sharing(mmf, ms, vs) > 0) { CHECK(htkamd_model_set_sharing(model, ms, vs)); shareMu = ms; shareVa = vs; }
+      else { free(ms); free(vs); }
    }
    htkamd_accs *accs; CHECK(htkamd_accs_create(model, &accs));
    htkamd_accs_layout lay; CHECK(htkamd_accs_get_layout(accs, &lay));
@@ -139,7 +140,7 @@ int main(int argc, char **argv)
 
    if (parMode == 0) {
       /* the data arguments are accumulator files: LoadAccs adds every dump (HTrain.c:1625) */
-      for (int i = 0; i < files.n; i++) CHECK(htkamd_accs_load_file(d, vec, physNames, uFlags, files.v[i]));
+      for (int i = 0; i < files.n; i++) CHECK(htkamd_accs_load_file_shared(d, vec, physNames, uFlags, shareMu, shareVa, files.v[i]));
       CHECK(htkamd_accs_upload_add(accs, vec, NULL));
    } else {
       htkamd_mlf *mlf = NULL;
@@ -210,12 +211,10 @@ int main(int argc, char **argv)
       if (mlf) htkamd_mlf_free(mlf);
    }
 
-   if (htkamd_model_has_sharing(model) && parMode >= 0)
-      DIE("tied mean / variance vectors (~u ~v) are not supported in the accumulator files of parallel mode (-p)");
    if (parMode > 0) {
       char fn[2048];
       snprintf(fn, sizeof(fn), "%s/HER%d.acc", outDir ? outDir : ".", parMode);
-      CHECK(htkamd_accs_dump_file(d, vec, physNames, uFlags, fn));
+      CHECK(htkamd_accs_dump_file_shared(d, vec, physNames, uFlags, shareMu, shareVa, fn));
       if (trace & 1) printf("Accumulators dumped to %s\n", fn);
       return 0;
    }
