@@ -39,7 +39,7 @@ struct htkamd_mmf {
    struct { char type; char *name; float *v; } *vm; int nVm, capVm;
    int *gMeanMac, *gVarMac; int capMac;
    /* logical list */
-   char **logName; int *logPhys; int nLog;
+   char **logName; int *logPhys; int nLog; int *logSorted;        /* logSorted: list positions in name order (stable) */
    /* desc arrays */
    htkamd_model_desc d; int *stateCompOff, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
    int finished, nFiles;
@@ -49,7 +49,7 @@ struct htkamd_mmf {
 typedef struct { FILE *f; const char *path; int line; int pushed; char tok[256]; int kind; int bin; } rd;   /* bin: the last keyword was a binary symbol, so its numbers are binary too (Token.binForm, HModel.c:505,570) */
 enum { T_EOF, T_MACRO, T_KEY, T_WORD };
 
-static int rd_getc(rd *r) { int c = fgetc(r->f); if (c == '\n') r->line++; return c; }
+static int rd_getc(rd *r) { int c = getc_unlocked(r->f); if (c == '\n') r->line++; return c; }    /* one reader per FILE: no lock per character */
 static void rd_ungetc(rd *r, int c) { if (c == EOF) return; if (c == '\n') r->line--; ungetc(c, r->f); }
 
 static int rd_next(rd *r)
@@ -110,7 +110,7 @@ static int rd_int(rd *r, int *v)
 {
    char *e;
    if (r->bin && !r->pushed) {                       /* ReadShort, big-endian (HShell.c:1545) */
-      const int hi = fgetc(r->f), lo = fgetc(r->f);
+      const int hi = getc_unlocked(r->f), lo = getc_unlocked(r->f);
       if (lo == EOF) return fail(r, "unexpected end of binary data");
       *v = (short)((hi << 8) | lo);
       return HTKAMD_OK;
@@ -119,17 +119,56 @@ static int rd_int(rd *r, int *v)
    *v = (int)strtol(r->tok, &e, 10);
    return *e ? fail(r, "integer expected") : HTKAMD_OK;
 }
+/* Decimal text -> the correctly rounded float without strtof for the numbers model files are made of ([-]d.dddddde[+-]dd, up to 15
+   digits): digits as an integer m < 2^53, then m * 10^k or m / 10^k with k <= 22 -- both operands exact doubles, so the double is
+   correctly rounded (Clinger's fast path) -- and the double rounded to float.  The second rounding can only go wrong when the double
+   lies within its own rounding error of the midpoint of two floats: those (and everything unusual) are left to strtof.  Returns 1 if
+   *v was set. */
+static int fast_float(const char *s, float *v)
+{
+   static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+   unsigned long long m = 0;
+   int neg = 0, nd = 0, frac = 0, e10 = 0, seen = 0;
+   if (*s == '-') { neg = 1; s++; } else if (*s == '+') s++;
+   for (; *s >= '0' && *s <= '9'; s++) { seen = 1; if (nd < 15) { m = m * 10 + (unsigned)(*s - '0'); if (m) nd++; } else return 0; }
+   if (*s == '.') for (s++; *s >= '0' && *s <= '9'; s++) { seen = 1; if (nd < 15) { m = m * 10 + (unsigned)(*s - '0'); if (m) nd++; frac++; } else return 0; }
+   if (!seen) return 0;
+   if (*s == 'e' || *s == 'E') {
+      int es = 1, ev = 0, ed = 0;
+      s++;
+      if (*s == '-') { es = -1; s++; } else if (*s == '+') s++;
+      for (; *s >= '0' && *s <= '9'; s++) { ev = ev * 10 + (*s - '0'); if (++ed > 4) return 0; }
+      if (!ed) return 0;
+      e10 = es * ev;
+   }
+   if (*s) return 0;
+   e10 -= frac;
+   if (m == 0) { *v = neg ? -0.0f : 0.0f; return 1; }
+   if (e10 < -22 || e10 > 22) return 0;
+   const double d = (e10 < 0) ? (double)m / p10[-e10] : (double)m * p10[e10];
+   unsigned long long u;
+   memcpy(&u, &d, 8);
+   const unsigned int low = (unsigned int)(u & 0x1FFFFFFFu);            /* the 29 mantissa bits a float does not keep */
+   if (low >= 0x0FFFFFFEu && low <= 0x10000002u) return 0;               /* at a float midpoint to within the double's own error */
+   const float f = (float)d;
+   if (!(f > 1.0e-30f || f < -1.0e-30f) || f > 1.0e30f || f < -1.0e30f) return 0;   /* near the float range's ends: strtof */
+   *v = neg ? -f : f;
+   return 1;
+}
 static int rd_float(rd *r, float *v)
 {
    char *e;
    if (r->bin && !r->pushed) {                       /* ReadFloat, big-endian IEEE (HShell.c:1600) */
       unsigned char b[4];
-      if (fread(b, 1, 4, r->f) != 4) return fail(r, "unexpected end of binary data");
+      const int c0 = getc_unlocked(r->f), c1 = getc_unlocked(r->f), c2 = getc_unlocked(r->f), c3 = getc_unlocked(r->f);
+      if (c3 == EOF) return fail(r, "unexpected end of binary data");
+      b[0] = (unsigned char)c0; b[1] = (unsigned char)c1; b[2] = (unsigned char)c2; b[3] = (unsigned char)c3;
       const unsigned int u = ((unsigned int)b[0] << 24) | ((unsigned int)b[1] << 16) | ((unsigned int)b[2] << 8) | b[3];
       memcpy(v, &u, 4);
       return HTKAMD_OK;
    }
    if (rd_next(r) != T_WORD) return fail(r, "number expected");
+   if (fast_float(r->tok, v)) return HTKAMD_OK;
    *v = strtof(r->tok, &e);                         /* fscanf("%e") into a float, HShell.c ReadFloat */
    return *e ? fail(r, "number expected") : HTKAMD_OK;
 }
@@ -433,6 +472,12 @@ static char *base_name(const char *path)
    return n;
 }
 
+static char **g_sortNames;
+static int cmp_log_name(const void *a, const void *b)
+{
+   const int x = *(const int *)a, y = *(const int *)b, c = strcmp(g_sortNames[x], g_sortNames[y]);
+   return c ? c : (x > y) - (x < y);
+}
 int htkamd_mmf_create(struct htkamd_mmf **out)
 {
    if (!out) { htkamd_set_error("mmf_create: NULL"); return HTKAMD_EINVAL; }
@@ -448,6 +493,7 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
    rd r; memset(&r, 0, sizeof(r));
    r.f = fopen(path, "rb"); r.path = path; r.line = 1;
    if (!r.f) { htkamd_set_error("mmf_read: cannot open %s", path); return HTKAMD_EIO; }
+   setvbuf(r.f, NULL, _IOFBF, 1 << 20);
    int rc = HTKAMD_OK;
    for (;;) {
       int k = rd_next(&r);
@@ -570,6 +616,12 @@ int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir
    d->gconst = anyG ? s->gconst : NULL;
    d->transN = s->transN; d->transOff = s->transOff; d->transP = s->tp;
    d->hmmTrans = s->hmmTrans; d->hmmStateOff = s->hmmStateOff; d->hmmState = s->hmmState;
+   {  /* name index for htkamd_mmf_find_logical */
+      g_sortNames = s->logName;
+      s->logSorted = (int *)malloc(sizeof(int) * (size_t)(s->nLog ? s->nLog : 1));
+      for (int i = 0; i < s->nLog; i++) s->logSorted[i] = i;
+      qsort(s->logSorted, (size_t)s->nLog, sizeof(int), cmp_log_name);
+   }
    s->finished = 1;
    return HTKAMD_OK;
 }
@@ -599,6 +651,14 @@ int htkamd_mmf_sharing(const struct htkamd_mmf *s, int *meanShare, int *varShare
 int htkamd_mmf_find_logical(const struct htkamd_mmf *s, const char *name)
 {
    if (!s || !name) return -1;
+   if (s->logSorted) {                                /* binary search over the names (first of equal names = first in list order) */
+      int lo = 0, hi = s->nLog - 1, hit = -1;
+      while (lo <= hi) {
+         const int mid = (lo + hi) / 2, c = strcmp(s->logName[s->logSorted[mid]], name);
+         if (c == 0) { hit = mid; hi = mid - 1; } else if (c < 0) lo = mid + 1; else hi = mid - 1;
+      }
+      return hit < 0 ? -1 : s->logPhys[s->logSorted[hit]];
+   }
    for (int i = 0; i < s->nLog; i++) if (!strcmp(s->logName[i], name)) return s->logPhys[i];
    return -1;
 }
@@ -610,6 +670,7 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
    for (int i = 0; i < s->nTr; i++) free(s->tr[i].name);
    for (int i = 0; i < s->nHm; i++) { free(s->hm[i].name); free(s->hm[i].state); }
    for (int i = 0; i < s->nLog; i++) free(s->logName[i]);
+   free(s->logSorted);
    for (int g = 0; g < s->capGN; g++) free(s->gName[g]);
    free(s->gName);
    free(s->st); free(s->wt); free(s->cg); free(s->mean); free(s->var); free(s->gconst); free(s->hasG); free(s->tr); free(s->tp); free(s->hm);
@@ -624,10 +685,73 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
 static int g_bin;                                  /* writer mode: text or binary (SaveHMMSet's `binary`), set by htkamd_mmf_write* */
 static void put_sym(FILE *f, const char *name, int code) { if (g_bin) { fputc(':', f); fputc(code, f); } else fprintf(f, "<%s>", name); }
 static void put_short(FILE *f, int v) { if (g_bin) { fputc((v >> 8) & 255, f); fputc(v & 255, f); } else fprintf(f, " %d", v); }
+/* printf("%e") of a float without printf: the float is m * 2^e2 exactly (m < 2^24), so the seven digits are the integer nearest to
+   m * 2^e2 * 10^(6-k) (ties to even, as the C library rounds), k = the decimal exponent -- exact in 128-bit integers for every normal
+   float.  Writes "d.dddddde+XX" to out (at least 16 bytes), returns the length, or 0 for what is left to fprintf (zero, denormals,
+   infinities, NaN). */
+static int format_e(float v, char *out)
+{
+   static const unsigned long long p5[28] = {1ULL, 5ULL, 25ULL, 125ULL, 625ULL, 3125ULL, 15625ULL, 78125ULL, 390625ULL, 1953125ULL, 9765625ULL, 48828125ULL, 244140625ULL,
+      1220703125ULL, 6103515625ULL, 30517578125ULL, 152587890625ULL, 762939453125ULL, 3814697265625ULL, 19073486328125ULL, 95367431640625ULL, 476837158203125ULL,
+      2384185791015625ULL, 11920928955078125ULL, 59604644775390625ULL, 298023223876953125ULL, 1490116119384765625ULL, 7450580596923828125ULL};
+   unsigned int u; memcpy(&u, &v, 4);
+   const int neg = (int)(u >> 31), be = (int)((u >> 23) & 255);
+   if (be == 0 || be == 255) return 0;
+   const unsigned long long m = (u & 0x7FFFFFu) | 0x800000u;
+   const int e2 = be - 150;                                         /* v = m * 2^e2 */
+   int k = (int)(((be - 127) * 1233) >> 12);                        /* floor(log10) to within one: 1233/4096 ~ log10(2) */
+   unsigned long long N = 0;
+   for (int tries = 0; tries < 3; tries++) {
+      const int p = 6 - k;
+      unsigned __int128 num, den = 1;
+      int sh;                                                        /* value = num * 2^sh / den */
+      if (p >= 0) { if (p > 27) { if (p > 54) return 0; num = (unsigned __int128)m * p5[27] * p5[p - 27]; } else num = (unsigned __int128)m * p5[p]; sh = e2 + p; }
+      else { const int q = -p; if (q > 40) return 0; num = m; den = (q > 27) ? (unsigned __int128)p5[27] * p5[q - 27] : p5[q]; sh = e2 - q; }
+      unsigned __int128 quo, rem, half;
+      if (sh >= 0) {
+         if (sh > 100) return 0;
+         num <<= sh;
+         quo = num / den; rem = num % den; half = den;               /* compare 2 rem with den */
+         const unsigned __int128 r2 = rem * 2;
+         if (r2 > half || (r2 == half && (quo & 1))) quo++;
+      } else {
+         const int s = -sh;                                          /* num / (den * 2^s), den == 1 whenever p >= 0 */
+         if (den != 1) { if (s > 40) return 0; den <<= s; quo = num / den; rem = num % den; const unsigned __int128 r2 = rem * 2; if (r2 > den || (r2 == den && (quo & 1))) quo++; }
+         else if (s >= 128) quo = 0;
+         else {
+            quo = num >> s; rem = num & ((((unsigned __int128)1) << s) - 1); half = ((unsigned __int128)1) << (s - 1);
+            if (rem > half || (rem == half && (quo & 1))) quo++;
+         }
+      }
+      if (quo >= 10000000u) { if (quo == 10000000u && tries == 2) { N = 1000000u; k++; break; } k++; continue; }
+      if (quo < 1000000u) { k--; continue; }
+      N = (unsigned long long)quo;
+      break;
+   }
+   if (N < 1000000u || N >= 10000000u) return 0;
+   int n = 0;
+   if (neg) out[n++] = '-';
+   char d[8];
+   for (int i = 6; i >= 0; i--) { d[i] = (char)('0' + N % 10); N /= 10; }
+   out[n++] = d[0]; out[n++] = '.';
+   for (int i = 1; i < 7; i++) out[n++] = d[i];
+   out[n++] = 'e';
+   int ke = k;
+   if (ke < 0) { out[n++] = '-'; ke = -ke; } else out[n++] = '+';
+   if (ke >= 100) return 0;
+   out[n++] = (char)('0' + ke / 10); out[n++] = (char)('0' + ke % 10);
+   out[n] = 0;
+   return n;
+}
 static void put_float(FILE *f, float v)
 {
-   if (g_bin) { unsigned int u; memcpy(&u, &v, 4); fputc(u >> 24, f); fputc((u >> 16) & 255, f); fputc((u >> 8) & 255, f); fputc(u & 255, f); }
-   else fprintf(f, " %e", v);
+   if (g_bin) { unsigned int u; memcpy(&u, &v, 4); putc_unlocked((int)(u >> 24), f); putc_unlocked((int)((u >> 16) & 255), f); putc_unlocked((int)((u >> 8) & 255), f); putc_unlocked((int)(u & 255), f); }
+   else {
+      char b[24];
+      const int n = format_e(v, b + 1);
+      if (n) { b[0] = ' '; fwrite_unlocked(b, 1, (size_t)n + 1, f); }
+      else fprintf(f, " %e", v);
+   }
 }
 static void put_nl(FILE *f) { if (!g_bin) fputc('\n', f); }
 static void put_name(FILE *f, char type, const char *name)
@@ -748,6 +872,7 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
    if (!s || !s->finished || !mean || !var || !compWeight || !transP) { htkamd_set_error("mmf_write: bad argument"); return HTKAMD_EINVAL; }
    if (oneFile) {
       FILE *f = fopen(oneFile, "wb");
+      if (f) setvbuf(f, NULL, _IOFBF, 1 << 20);
       if (!f) { htkamd_set_error("mmf_write: cannot create %s", oneFile); return HTKAMD_EIO; }
       put_options(s, f);
       int nN = 0;

@@ -776,3 +776,34 @@ def test_viterbi_long_chains_every_kernel_class(native, oracle, beam, topo):
     got = _align(native, pk, sq, ft, beam=beam)
     _check_vs_oracle(oracle, oracle.Model(pk), got, sq, ft, beam)
     assert sum(g["status"] == 1 for g in got) >= 6
+
+
+@pytest.mark.parametrize("mode", [0, 6], ids=["exact", "fastest"])
+def test_run_to_run_reproducibility(native, mode):
+    """The statistics are summed with fp64 atomics, so their LAST bits depend on the order in which wavefronts arrive; everything computed
+    per utterance (log-probabilities, beams, trellis) does not.  Two passes over one batch: `pr` bit-identical, accumulators equal to
+    1e-12 relative (the summation-order noise of an fp64 sum; the reference's float accumulators carry 1e-7), counters identical."""
+    from htk_amd import synth
+    s = synth.generate(40, 4, 30, 12, 120, 4242, D=39)
+    model = native.Model(s.packed())
+    X = np.concatenate(s.feats)
+    frameOff = np.concatenate([[0], np.cumsum([f.shape[0] for f in s.feats])]).astype(np.int32)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)
+    labs = np.concatenate(s.seqs).astype(np.int32)
+    dX = native.DevArray(X)
+    runs = []
+    for k in range(3):
+        fb = native.ForwardBackward(model); acc = native.Accs(model)
+        fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+        fb.execute(native.fb_config(uFlags=15, scoreMode=mode, pruneInit=250.0, pruneInc=150.0, pruneLim=1000.0), acc)
+        pr, st = fb.results()
+        runs.append((np.array(pr), np.array(st), acc.download()["vec"].copy()))
+    for pr, st, vec in runs[1:]:
+        assert np.array_equal(pr, runs[0][0]) and np.array_equal(st, runs[0][1])
+        ref = runs[0][2]
+        scale = np.maximum(np.abs(ref), 1e-6)
+        assert (np.abs(vec - ref) <= 1e-12 * scale + 1e-14).all(), float(np.max(np.abs(vec - ref) / scale))
+        lay = native.accs_layout(s.packed())
+        for k in ("nEgs", "totalT", "nUttDone", "nUttSkipped", "nEval"):
+            o = getattr(lay, k)
+            assert vec[o] == ref[o]

@@ -221,3 +221,56 @@ def test_mmf_shared_mean_and_variance_macros(native, tmp_path):
     with pytest.raises(native.HtkAmdError) as e:
         native.Mmf(files=[str(bad)], hmm_list=os.path.join(d, "bcplist"))
     assert "undefined ~u macro" in str(e.value)
+
+
+def test_mmf_numbers_are_read_as_strtof_reads_them(native, tmp_path):
+    """The reader's own decimal -> float path (Clinger fast path through an exact double, strtof for everything near a rounding boundary,
+    host/mmf.c fast_float) gives the float fscanf("%e") gives: ordinary %e numbers, 9-digit renderings of random bit patterns, midpoints
+    of two floats written out in full, tiny, huge and odd spellings."""
+    rng = np.random.default_rng(12)
+    texts = ["%e" % x for x in rng.normal(0, 30, 400)] + ["%.9e" % x for x in rng.standard_normal(300).astype(np.float32)]
+    bits = rng.integers(0x00800000, 0x7F000000, 400, dtype=np.uint64).astype(np.uint32)
+    texts += ["%.8e" % x for x in bits.view(np.float32)]
+    texts += ["16777217", "16777219", "1.00000005960464477539", "1.0000001788139343", "0.1", "-0.0", "1e-40", "3.4e38", "1e22", "1e23", "123456789012345678",
+              ".5", "5.", "+2.5E+3", "1.17549435e-38", "7.00649232e-46", "0.000001", "4.9999997e-1"]
+    D = len(texts)
+    path = tmp_path / "m"
+    path.write_text('~o <VecSize> %d <USER> <StreamInfo> 1 %d\n~h "a"\n<BeginHMM> <NumStates> 3 <State> 2 <Mean> %d\n%s\n<Variance> %d\n%s\n<TransP> 3\n0 1 0\n0 0.5 0.5\n0 0 0\n<EndHMM>\n'
+                    % (D, D, D, " ".join(texts), D, " ".join(["1.0"] * D)))
+    lst = tmp_path / "l"; lst.write_text("a\n")
+    mmf = native.Mmf(files=[str(path)], hmm_list=str(lst))
+    got = mmf.packed()["mean"].reshape(-1)
+    want = np.array([np.float32(t) for t in texts], np.float32)              # numpy parses with strtod + one rounding... checked below
+    import ctypes
+    libc = ctypes.CDLL(None); libc.strtof.restype = ctypes.c_float; libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    want = np.array([libc.strtof(t.encode(), None) for t in texts], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), [(t, g, w) for t, g, w in zip(texts, got, want) if g != w or np.signbit(g) != np.signbit(w)][:5]
+
+
+def test_mmf_numbers_are_written_as_printf_writes_them(native, tmp_path):
+    """The writer's own "%e" (exact 128-bit integer arithmetic on m * 2^e * 10^p with ties to even, host/mmf.c format_e) against the C
+    library's: random values, random bit patterns over the whole float range, round-up-to-the-next-power cases, denormals and zero (fprintf)."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.normal(0, 20, 300).astype(np.float32), rng.integers(0x00000001, 0x7F7FFFFF, 500, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                           np.array([9.9999995, 9.9999999e9, 0.99999994, 1.0, 0.0, 1e-45, 1.1754942e-38, 3.4028235e38, 123456.7, 9.5367431640625e-7], np.float32)])
+    vals[::7] *= -1
+    D = len(vals)
+    path = tmp_path / "m"
+    path.write_text('~o <VecSize> %d <USER> <StreamInfo> 1 %d\n~h "a"\n<BeginHMM> <NumStates> 3 <State> 2 <Mean> %d\n%s\n<Variance> %d\n%s\n<TransP> 3\n0 1 0\n0 0.5 0.5\n0 0 0\n<EndHMM>\n'
+                    % (D, D, D, " ".join(["0.0"] * D), D, " ".join(["1.0"] * D)))
+    lst = tmp_path / "l"; lst.write_text("a\n")
+    mmf = native.Mmf(files=[str(path)], hmm_list=str(lst))
+    pk = mmf.packed()
+    out = tmp_path / "out"
+    mmf.write(dict(mean=vals.reshape(1, D), var=pk["var"], gconst=None, compWeight=pk["compWeight"], transP=pk["transP"]), one_file=str(out))
+    toks = out.read_text().split()
+    i = toks.index("<MEAN>")
+    got = toks[i + 2:i + 2 + D]
+    libc = ctypes.CDLL(None)
+    want = []
+    for v in vals:
+        b = ctypes.create_string_buffer(64)
+        libc.snprintf(b, 64, b"%e", ctypes.c_double(float(v)))
+        want.append(b.value.decode())
+    assert got == want, [(g, w) for g, w in zip(got, want) if g != w][:5]

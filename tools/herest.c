@@ -29,6 +29,13 @@
 
 typedef struct { char *logical; int phys; } modelref;
 
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+/* -T 4: wall-clock seconds per phase of the run, on stdout at the end */
+static double g_t[8]; static const char *const g_tn[8] = {"load model set", "create device model", "read data + labels", "prepare", "execute + results", "update", "save model set", "other"};
+#define TIC double tic_ = now_s()
+#define TOC(k) do { const double n_ = now_s(); g_t[k] += n_ - tic_; tic_ = n_; } while (0)
+
 static int uflags_parse(const char *s)
 {
    int f = 0;
@@ -110,12 +117,15 @@ int main(int argc, char **argv)
    CHECK(htkamd_set_device(nRanks > 1 ? rank % htkamd_device_count() : 0));
 
    /* LoadHMMSet */
+   TIC;
    htkamd_mmf *mmf; CHECK(htkamd_mmf_create(&mmf));
    for (int i = 0; i < mmfs.n; i++) CHECK(htkamd_mmf_read(mmf, mmfs.v[i], NULL));
    CHECK(htkamd_mmf_finish(mmf, hmmList, hmmDir, hmmExt));
    const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
    const int D = d->vecSize, H = d->numPhys;
+   TOC(0);
    htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   TOC(1);
    int *shareMu = NULL, *shareVa = NULL;
    {  /* tied mean / variance vectors (~u ~v macros) */
       int *ms = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1)), *vs = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1));
@@ -171,6 +181,7 @@ int main(int argc, char **argv)
       for (int first = 0; first < mine.n; first += batchN) {
          const int count = (mine.n - first < batchN) ? mine.n - first : batchN;
          obs_batch ob; memset(&ob, 0, sizeof(ob));
+         tic_ = now_s();
          load_observations(&mine, first, count, targetKind, &cfg, &ob);
          if (ob.cols != D) DIE("observations have %d components, the models %d", ob.cols, D);
          int *labOff = (int *)calloc((size_t)count + 1, sizeof(int)), *labs = NULL, capLab = 0;
@@ -192,10 +203,13 @@ int main(int argc, char **argv)
             if (L) htkamd_labels_free(L);
          }
          htkamd_batch_desc b = {count, ob.dX, ob.frameOff, labOff, labs};
+         TOC(2);
          CHECK(htkamd_fb_prepare(fb, &b, NULL));
+         TOC(3);
          CHECK(htkamd_fb_execute(fb, &fc, accs, NULL));
          double *pr = (double *)malloc(sizeof(double) * (size_t)count); int *st = (int *)malloc(sizeof(int) * (size_t)count);
          CHECK(htkamd_fb_results(fb, pr, st, NULL));
+         TOC(4);
          for (int u = 0; u < count; u++) {
             if (trace & 1) printf(" Processing Data: %s\n", mine.v[first + u]);
             if (st[u] == HTKAMD_UTT_OK) { if (trace & 1) printf(" Utterance prob per frame = %e\n", pr[u] / (ob.frameOff[u + 1] - ob.frameOff[u])); }
@@ -221,6 +235,7 @@ int main(int argc, char **argv)
    if (statsFile) CHECK(htkamd_stats_write_file(d, vec, physNames, statsFile));
 
    /* UpdateModels on the device, then SaveHMMSet (every rank computes the same models; rank 0 writes them) */
+   tic_ = now_s();
    htkamd_update_config uc; memset(&uc, 0, sizeof(uc));
    uc.minEgs = minEgs; uc.minVar = minVar; uc.mixWeightFloor = mixFloor; uc.uFlags = uFlags; uc.varFloor = htkamd_mmf_var_floor(mmf);
    uc.singleProcess = (parMode == -1);
@@ -246,6 +261,7 @@ int main(int argc, char **argv)
    } else if (htkamd_model_has_sharing(model)) {
       CHECK(htkamd_model_update(model, accs, vec, &uc, &us));         /* pooled statistics of the tied vectors: host update */
    } else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
+   TOC(5);
    if (us.nSkippedHmm > 0) fprintf(stderr, "WARNING [-2331] UpdateModels: %d models had fewer than %d examples and were copied\n", us.nSkippedHmm, minEgs);
    if (rank == 0) {
       float *mean = (float *)malloc(sizeof(float) * (size_t)d->numGauss * D), *var = (float *)malloc(sizeof(float) * (size_t)d->numGauss * D);
@@ -256,11 +272,13 @@ int main(int argc, char **argv)
       if (mmfs.n > 0) { make_fn(mmfs.v[0], outDir ? outDir : ".", NULL, one, sizeof(one)); oneFile = one; }
       if (binary) CHECK(htkamd_mmf_write_binary(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
       else CHECK(htkamd_mmf_write(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
+      TOC(6);
       if (us.nFloorVar > 0 && !(uFlags & HTKAMD_UPMAP)) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
       if (trace & 1) printf("Saving hmm's to %s %s\n", oneFile ? "MMF" : "dir", oneFile ? oneFile : (outDir ? outDir : "Current"));
       printf("Reestimation complete - average log prob per frame = %e\n", vec[lay.totalPr] / vec[lay.totalT]);
       printf("     - total frames seen          = %e\n", vec[lay.totalT]);
    }
+   if (trace & 4) for (int k = 0; k < 7; k++) printf("Timing: %-22s %8.3f s\n", g_tn[k], g_t[k]);
    htkamd_accs_destroy(accs); htkamd_model_destroy(model); htkamd_mmf_destroy(mmf);
    return 0;
 }
