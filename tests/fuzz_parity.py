@@ -258,14 +258,77 @@ def fuzz_quals(rng, it):
     return ok
 
 
+def fuzz_herest_cli(rng, it, tmp):
+    """tools/bin/herest against the reference's HERest binary (oracle/_ref, present on the GPU box with the tree) on random sets: one pass,
+    ML (-u tmvw, random -v / -w / -m) or MAP (-u pmvw / pmv / pm with a random HMAP: MAPTAU, MINVAR, MIXWEIGHTFLOOR), every number of the
+    two MMFs to 2e-4 relative (the files carry 7 digits; means relative to max(|mean|, sigma))."""
+    import subprocess
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "HERest"); exe = os.path.join(ROOT, "tools", "bin", "herest")
+    if not (os.path.exists(ref_exe) and os.path.exists(exe)):
+        return True
+    d = os.path.join(tmp, "h%d" % it); os.makedirs(os.path.join(d, "ours")); os.makedirs(os.path.join(d, "ref"))
+    s = synth.generate(int(rng.integers(10, 30)), int(rng.integers(1, 4)), int(rng.integers(5, 12)), int(rng.integers(8, 16)),
+                       int(rng.integers(60, 140)), int(rng.integers(1, 10**6)), D=13)
+    pk = s.packed()
+    names = ["p%d" % i for i in range(pk["numPhys"])]
+    synth.write_mmf_packed(os.path.join(d, "MMF"), pk, names)
+    open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+    scp = []
+    for u, (X, q) in enumerate(zip(s.feats, s.seqs)):
+        fn = os.path.join(d, "u%d.mfc" % u)
+        synth.write_htk_param(fn, X, kind=9); scp.append(fn)
+        open(os.path.join(d, "u%d.lab" % u), "w").write("\n".join(names[int(h)] for h in q) + "\n")
+    conf = ""
+    if rng.random() < 0.5:
+        flags = str(rng.choice(["pmvw", "pmv", "pm", "pmw"]))
+        conf = "HMAP: MAPTAU = %g\nHMAP: MINVAR = %g\n" % (float(rng.choice([0.5, 4.0, 20.0, 60.0])), float(rng.choice([0.0, 0.02, 0.3])))
+        if rng.random() < 0.5:
+            conf += "HMAP: MIXWEIGHTFLOOR = %g\n" % float(rng.choice([1.0, 3.0]))
+        opts = ["-u", flags]
+    else:
+        opts = ["-u", str(rng.choice(["tmvw", "mv", "tw", "tmv"])), "-v", "%g" % float(rng.choice([0.0, 0.05, 0.5])), "-w", "%g" % float(rng.choice([0.0, 2.0])),
+                "-m", "%d" % int(rng.choice([1, 3]))]
+    if rng.random() < 0.4:
+        opts += ["-t", "%g" % float(rng.choice([150.0, 400.0]))]
+    open(os.path.join(d, "config"), "w").write(conf)
+    out = []
+    for e, sub in ((ref_exe, "ref"), (exe, "ours")):
+        r = subprocess.run([e, "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-M", os.path.join(d, sub), "-L", d] + opts + [os.path.join(d, "hmmlist")] + scp,
+                           capture_output=True, text=True)
+        out.append(r)
+    if out[0].returncode != 0 or out[1].returncode != 0:
+        if out[0].returncode != 0 and out[1].returncode != 0:
+            return True                                              # both refuse (e.g. a model without enough examples made the pass fail)
+        print("HEREST it %d opts %s conf %r: rc ref %d ours %d\n  %s\n  %s" % (it, opts, conf, out[0].returncode, out[1].returncode, out[0].stdout[-200:], (out[1].stdout + out[1].stderr)[-200:]))
+        return False
+    a = capi.Mmf(files=[os.path.join(d, "ours", "MMF")], hmm_list=os.path.join(d, "hmmlist")).packed()
+    b = capi.Mmf(files=[os.path.join(d, "ref", "MMF")], hmm_list=os.path.join(d, "hmmlist")).packed()
+    ok = a["numComp"] == b["numComp"] and a["numGauss"] == b["numGauss"]
+    if ok:
+        sig = np.sqrt(np.maximum(b["var"], 1e-12))
+        em = np.max(np.abs(a["mean"] - b["mean"]) / np.maximum(np.abs(b["mean"]), sig))
+        ev = np.max(np.abs(a["var"] - b["var"]) / np.maximum(np.abs(b["var"]), 1e-6))
+        ew = np.max(np.abs(a["compWeight"] - b["compWeight"]))
+        lin = lambda v: np.where(np.asarray(v) > -0.5e10, np.exp(np.asarray(v, np.float64)), 0.0)
+        et = np.max(np.abs(lin(a["transP"]) - lin(b["transP"])))
+        ok = em <= 2e-4 and ev <= 2e-4 and ew <= 2e-5 and et <= 2e-5
+        if not ok:
+            print("HEREST it %d opts %s conf %r: mean %.3g var %.3g weight %.3g trans %.3g" % (it, opts, conf, em, ev, ew, et))
+    else:
+        print("HEREST it %d opts %s: different structure" % (it, opts))
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    return ok
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     tmp = tempfile.mkdtemp()
-    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0], quals=[0, 0])
+    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0], quals=[0, 0], herest=[0, 0])
     for it in range(n):
         for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp)),
-                         ("mfcc", lambda: fuzz_mfcc(rng, it)), ("quals", lambda: fuzz_quals(rng, it))):
+                         ("mfcc", lambda: fuzz_mfcc(rng, it)), ("quals", lambda: fuzz_quals(rng, it)), ("herest", lambda: fuzz_herest_cli(rng, it, tmp))):
             try:
                 ok = fn()
             except Exception as e:  # noqa: BLE001
