@@ -5,6 +5,7 @@ recognition step through the CLIs against the reference's logs / models / label 
 word-level alignment and HVite's output formats against the committed HVite files."""
 import json
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -304,3 +305,44 @@ def test_hvite_cli_word_level_alignment(native, tools, tmp_path):
         assert r.returncode == 0, (opts, r.stderr)
         for u in range(len(words)):
             assert (out / ("a%d.rec" % u)).read_text().splitlines() == per["u%d" % u], (opts, u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,src", [("WAV", "test.wav"), ("HTK", "test.htk")])
+def test_cli_tools_code_waveform_sources_on_the_device(native, tools, tmp_path, fmt, src):
+    """BASELINE config[4] through the drivers: SOURCEFORMAT = WAV (or SOURCEKIND = WAVEFORM on an HTK waveform file) + TARGETKIND =
+    MFCC_0_D_A makes herest / hvite code the waveform on the device (htkamd_mfcc_compute + the qualifier step) instead of reading a
+    parameter file.  One pass and one alignment over the golden waveform give the log probability / the label file that the same tools
+    give on the MFCC_0_D_A file the reference's HCopy coded from it (tests/golden/wave; >99.9 % of its values bit-equal, rest 1 ulp)."""
+    from htk_amd import synth
+    W = os.path.join(os.path.dirname(__file__), "golden", "wave")
+    s = synth.generate(12, 2, 4, 1, 98, 31, D=39)
+    pk = s.packed()
+    names = ["p%d" % i for i in range(pk["numPhys"])]
+    synth.write_mmf_packed(str(tmp_path / "MMF"), pk, names, kind="MFCC_0_D_A")
+    (tmp_path / "hmmlist").write_text("\n".join(names) + "\n")
+    front = "SOURCERATE = 625\nWINDOWSIZE = 250000.0\nTARGETRATE = 100000.0\nNUMCHANS = 26\nNUMCEPS = 12\nCEPLIFTER = 22\nPREEMCOEF = 0.97\nUSEHAMMING = T\nENORMALISE = F\n"
+    (tmp_path / "wav.conf").write_text("SOURCEFORMAT = %s\n%sTARGETKIND = MFCC_0_D_A\n" % (fmt, front) + ("SOURCEKIND = WAVEFORM\n" if fmt == "HTK" else ""))
+    (tmp_path / "mfc.conf").write_text("TARGETKIND = MFCC_0_D_A\n")
+    lab = "\n".join(["p0", "p1", "p2", "p3", "p1"]) + "\n"
+    outs = {}
+    for tag, conf, data in (("wav", "wav.conf", os.path.join(W, src)), ("mfc", "mfc.conf", os.path.join(W, "test_MFCC_0_D_A.mfc"))):
+        d = tmp_path / tag; d.mkdir()
+        base = os.path.splitext(os.path.basename(data))[0]
+        (d / (base + ".lab")).write_text(lab)
+        r = run([os.path.join(tools, "herest"), "-C", str(tmp_path / conf), "-H", str(tmp_path / "MMF"), "-M", str(d), "-L", str(d), "-m", "1", "-v", "0.01", str(tmp_path / "hmmlist"), data])
+        assert r.returncode == 0, r.stdout + r.stderr
+        lp = float(re.search(r"average log prob per frame = (\S+)", r.stdout).group(1))
+        (tmp_path / (tag + ".dict")).write_text("".join("%s %s\n" % (n, n) for n in names))
+        r2 = run([os.path.join(tools, "hvite"), "-C", str(tmp_path / conf), "-H", str(tmp_path / "MMF"), "-a", "-m", "-L", str(d), "-l", str(d), "-y", "rec",
+                  str(tmp_path / (tag + ".dict")), str(tmp_path / "hmmlist"), data])
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+        outs[tag] = (lp, (d / (base + ".rec")).read_text().split())
+    assert abs(outs["wav"][0] - outs["mfc"][0]) <= 2e-6 * abs(outs["mfc"][0])
+    a, b = outs["wav"][1], outs["mfc"][1]
+    assert len(a) == len(b) and len(a) >= 15
+    for x, y in zip(a, b):
+        try:
+            assert abs(float(x) - float(y)) <= 1e-3 * max(1.0, abs(float(y))), (x, y)
+        except ValueError:
+            assert x == y

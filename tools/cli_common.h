@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include "htk_amd.h"
 
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "ERROR [%d] %s: %s\n", rc_, #call, htkamd_last_error()); exit(1); } } while (0)
@@ -113,11 +114,65 @@ typedef struct {
    float *dX;                  /* device [frameOff[nUtt] * cols] */
 } obs_batch;
 
+static double cfg_flt(const config *c, const char *key, double dflt) { const char *v = cfg_get(c, key); return v ? atof(v) : dflt; }
+
+/* Waveform sources (SOURCEFORMAT = WAV, or SOURCEKIND = WAVEFORM with HTK waveform files): the files of the batch are coded on the
+   device as OpenBuffer does for a waveform file (htkamd_mfcc_compute: statics + _0 / _E with HParm's configuration variables and
+   their defaults, HParm.c:337-367); the differentials, _Z and _N of TARGETKIND follow in load_observations as for parameter files.
+   Returns the parameter kind of the table (MFCC + _0 / _E). */
+static int code_waveforms(const strlist *files, int first, int count, int targetKind, const config *cfg, obs_batch *ob, float **dStatOut, int *nStatOut)
+{
+   const char *sfmt = cfg_get(cfg, "SOURCEFORMAT");
+   const int fmt = (sfmt && !strcasecmp(sfmt, "WAV")) ? HTKAMD_WAVE_WAV : HTKAMD_WAVE_HTK;
+   if (targetKind < 0 || (targetKind & 077) != 6) DIE("waveform sources are coded as MFCC: TARGETKIND = MFCC[_0][_E][_D][_A][_T][_Z][_N] expected");
+   short *all = NULL; size_t cap = 0;
+   int *sampOff = (int *)calloc((size_t)count + 1, sizeof(int));
+   double period = cfg_flt(cfg, "SOURCERATE", 0.0);
+   for (int u = 0; u < count; u++) {
+      short *x; long n; double per;
+      CHECK(htkamd_wave_read(files->v[first + u], fmt, &x, &n, &per));
+      if (period <= 0.0) period = per;                               /* SOURCERATE, when set, replaces the header's value (HParm.c:3940) */
+      const size_t need = (size_t)sampOff[u] + (size_t)n;
+      if (need > cap) { cap = need * 2 + 4096; all = (short *)realloc(all, sizeof(short) * cap); }
+      memcpy(all + sampOff[u], x, sizeof(short) * (size_t)n);
+      sampOff[u + 1] = sampOff[u] + (int)n;
+      htkamd_free(x);
+   }
+   htkamd_mfcc_config mc; memset(&mc, 0, sizeof(mc));
+   mc.sampPeriod = period; mc.winDur = cfg_flt(cfg, "WINDOWSIZE", 256000.0); mc.frPeriod = cfg_flt(cfg, "TARGETRATE", 100000.0);
+   mc.numChans = cfg_int(cfg, "NUMCHANS", 20); mc.numCeps = cfg_int(cfg, "NUMCEPS", 12); mc.cepLifter = cfg_int(cfg, "CEPLIFTER", 22);
+   mc.preEmph = (float)cfg_flt(cfg, "PREEMCOEF", 0.97); mc.useHam = cfg_bool(cfg, "USEHAMMING", 1); mc.usePower = cfg_bool(cfg, "USEPOWER", 0);
+   mc.zMeanSource = cfg_bool(cfg, "ZMEANSOURCE", 0); mc.rawEnergy = cfg_bool(cfg, "RAWENERGY", 1); mc.eNormalise = cfg_bool(cfg, "ENORMALISE", 1);
+   mc.loFreq = (float)cfg_flt(cfg, "LOFREQ", -1.0); mc.hiFreq = (float)cfg_flt(cfg, "HIFREQ", -1.0); mc.cepScale = (float)cfg_flt(cfg, "CEPSCALE", 1.0);
+   mc.silFloor = (float)cfg_flt(cfg, "SILFLOOR", 50.0); mc.eScale = (float)cfg_flt(cfg, "ESCALE", 0.1);
+   mc.hasC0 = (targetKind & PK_HASZEROC) != 0; mc.hasE = (targetKind & PK_HASENERGY) != 0;
+   mc.delWin = 2; mc.accWin = 2;
+   htkamd_mfcc *fe; CHECK(htkamd_mfcc_create(&mc, &fe));
+   int F = 0;
+   for (int u = 0; u < count; u++) F += htkamd_mfcc_num_frames(&mc, sampOff[u + 1] - sampOff[u]);
+   const int cols = htkamd_mfcc_num_cols(&mc);
+   short *dWav; float *dStat;
+   CHECK(htkamd_dev_malloc((void **)&dWav, sizeof(short) * (size_t)(sampOff[count] ? sampOff[count] : 1)));
+   CHECK(htkamd_memcpy_h2d(dWav, all, sizeof(short) * (size_t)sampOff[count], NULL));
+   CHECK(htkamd_dev_malloc((void **)&dStat, sizeof(float) * (size_t)(F ? F : 1) * cols));
+   CHECK(htkamd_mfcc_compute(fe, dWav, sampOff, count, ob->frameOff, dStat, NULL));
+   CHECK(htkamd_stream_sync(NULL));
+   CHECK(htkamd_dev_free(dWav)); htkamd_mfcc_destroy(fe); free(all); free(sampOff);
+   ob->period = (int)(mc.frPeriod + 0.5);
+   *dStatOut = dStat; *nStatOut = cols;
+   return 6 | (mc.hasC0 ? PK_HASZEROC : 0) | (mc.hasE ? PK_HASENERGY : 0);
+}
+
 static void load_observations(const strlist *files, int first, int count, int targetKind, const config *cfg, obs_batch *ob)
 {
    float *stat = NULL; size_t cap = 0;
    int nStat = 0, fileKind = -1;
+   float *dStat = NULL;
    ob->nUtt = count; ob->frameOff = (int *)calloc((size_t)count + 1, sizeof(int)); ob->period = 100000;
+   const char *sfmtL = cfg_get(cfg, "SOURCEFORMAT"), *skindL = cfg_get(cfg, "SOURCEKIND");
+   const int waveform = (sfmtL && !strcasecmp(sfmtL, "WAV")) || (skindL && !strcasecmp(skindL, "WAVEFORM"));
+   if (waveform) fileKind = code_waveforms(files, first, count, targetKind, cfg, ob, &dStat, &nStat);
+   else
    for (int u = 0; u < count; u++) {
       float *x; int T, cols, pk, per;
       CHECK(htkamd_parm_read(files->v[first + u], &x, &T, &cols, &per, &pk));
@@ -135,10 +190,11 @@ static void load_observations(const strlist *files, int first, int count, int ta
    if (lost & ~PK_HASNULLE) DIE("TARGETKIND drops qualifiers the files have (0%o)", lost);
    if (add & (PK_HASENERGY | PK_HASZEROC)) DIE("TARGETKIND asks for _E / _0, which cannot be derived from parameter files");
    const int F = ob->frameOff[count];
-   float *dStat;
-   CHECK(htkamd_dev_malloc((void **)&dStat, sizeof(float) * (size_t)(F ? F : 1) * nStat));
-   CHECK(htkamd_memcpy_h2d(dStat, stat, sizeof(float) * (size_t)F * nStat, NULL));
-   free(stat);
+   if (!waveform) {
+      CHECK(htkamd_dev_malloc((void **)&dStat, sizeof(float) * (size_t)(F ? F : 1) * nStat));
+      CHECK(htkamd_memcpy_h2d(dStat, stat, sizeof(float) * (size_t)F * nStat, NULL));
+      free(stat);
+   }
    if (add == 0) { ob->dX = dStat; ob->cols = nStat; return; }
    if (fileKind & (PK_HASDELTA | PK_HASACCS | PK_HASTHIRD)) DIE("files already carry differentials: further qualifiers cannot be appended");
    htkamd_parm_quals q; memset(&q, 0, sizeof(q));
