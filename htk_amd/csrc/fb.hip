@@ -90,7 +90,7 @@ struct PrepPool {
 struct PrepChunk {
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
    std::vector<short> cQ, cI, thrCell, sQ;
-   std::vector<ScoreTask> tasks;
+   std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
    std::vector<int> evLo, evHi, slotModel;
    size_t outp = 0, beta = 0, gam = 0;
    long long frameStates = 0;
@@ -99,7 +99,7 @@ struct PrepChunk {
    void reset()                                          // keeps the vectors' capacity from batch to batch
    {
       mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear();
-      cQ.clear(); cI.clear(); thrCell.clear(); sQ.clear(); tasks.clear();
+      cQ.clear(); cI.clear(); thrCell.clear(); sQ.clear(); tasks.clear(); tasksW.clear();
       outp = beta = gam = 0; frameStates = 0; nCellsMax = QMax = TMax = 1; nThrMax = 64; rc = HTKAMD_OK; err[0] = 0;
    }
 };
@@ -115,7 +115,7 @@ struct htkamd_fb {
    std::vector<UttDesc> utt;
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
    std::vector<short> cQ, cI, taperLo, taperHi, thrCell, sQ;
-   std::vector<ScoreTask> tasks;
+   std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
    std::vector<size_t> gamOff;
    std::vector<int> gamChunkUtt;
    size_t outpTotal, betaTotal, gamTotal;
@@ -124,7 +124,7 @@ struct htkamd_fb {
    const float *dX;
    // device
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
-   DevBuf d_tasks, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
+   DevBuf d_tasks, d_tasksW, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
    DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
@@ -171,7 +171,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
 {
    if (!fb) return;
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
-                    &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_gamOff,
+                    &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
                     &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_lin};
    for (DevBuf *b : all) b->release();
@@ -309,8 +309,14 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
             const int s0 = C.mSlot0[d.q0 + q - 1], n = C.mN[d.q0 + q - 1] - 2;
             for (int j = 0; j < n; j++) slotModel[s0 + j] = q;
          }
-         for (int k0 = 0; k0 < nSlots; k0 += SCORE_TASK_SLOTS) {
-            const int k1 = (k0 + SCORE_TASK_SLOTS < nSlots) ? k0 + SCORE_TASK_SLOTS : nSlots;
+         // two partitions of the same rectangle set: the matrix-core kernels build their B operand (the task's 128 frames, split into
+         // bf16 pieces) once per task, so they get four times as many states per task (measured: 1.32 -> 1.21 ms at the bench workload;
+         // the exact kernel is 10 % slower on the wide tasks)
+         for (int wide = 0; wide < 2; wide++) {
+         const int GS = wide ? SCORE_TASK_SLOTS_WIDE : SCORE_TASK_SLOTS;
+         std::vector<ScoreTask> &dst = wide ? C.tasksW : C.tasks;
+         for (int k0 = 0; k0 < nSlots; k0 += GS) {
+            const int k1 = (k0 + GS < nSlots) ? k0 + GS : nSlots;
             const int qa = slotModel[k0], qb = slotModel[k1 - 1];
             int tmin = 1, tmax = T;
             while (tmin <= T && evHi[tmin] < qa) tmin++;
@@ -323,8 +329,9 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
                tk.nSlots = k1 - k0;
                tk.outSlot0 = k0; tk.ldo = T;
                tk.outBase = d.outp0 + (size_t)t0;
-               C.tasks.push_back(tk);
+               dst.push_back(tk);
             }
+         }
          }
       }
    return HTKAMD_OK;
@@ -382,7 +389,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    for (int k = 0; k < nW; k++) if (chunks[k].rc) { htkamd_set_error("%s", chunks[k].err); return chunks[k].rc; }
    // concatenate the shares, rebasing their offsets
    fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
-   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->thrCell.clear(); fb->sQ.clear();
+   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->tasksW.clear(); fb->thrCell.clear(); fb->sQ.clear();
    fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1; fb->frameStates = 0;
    int nThrMax = 64;
    size_t outp = 0, beta = 0, gam = 0;
@@ -396,9 +403,10 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          fb->gamOff[u] = d.gam0;
       }
       for (ScoreTask &tk : C.tasks) { tk.slot0 += bSlot; tk.outBase += outp; }
+      for (ScoreTask &tk : C.tasksW) { tk.slot0 += bSlot; tk.outBase += outp; }
       auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
       app(fb->mN, C.mN); app(fb->mTp, C.mTp); app(fb->mCell0, C.mCell0); app(fb->mSlot0, C.mSlot0); app(fb->mDms, C.mDms); app(fb->mHmm, C.mHmm);
-      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->sQ, C.sQ); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks);
+      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->sQ, C.sQ); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks); app(fb->tasksW, C.tasksW);
       outp += C.outp; beta += C.beta; gam += C.gam;
       fb->frameStates += C.frameStates;
       if (C.nCellsMax > fb->nCellsMax) fb->nCellsMax = C.nCellsMax;
@@ -460,7 +468,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_slotState, fb->slotState.data(), sizeof(int) * fb->slotState.size(), 0}, {&fb->d_cQ, fb->cQ.data(), sizeof(short) * fb->cQ.size(), 0},
          {&fb->d_thrCell, fb->thrCell.data(), sizeof(short) * fb->thrCell.size(), 0}, {&fb->d_cI, fb->cI.data(), sizeof(short) * fb->cI.size(), 0},
          {&fb->d_taperLo, fb->taperLo.data(), sizeof(short) * fb->taperLo.size(), 0}, {&fb->d_taperHi, fb->taperHi.data(), sizeof(short) * fb->taperHi.size(), 0},
-         {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
+         {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_tasksW, fb->tasksW.data(), sizeof(ScoreTask) * fb->tasksW.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
          {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0},
          {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0}};
       size_t total = 0;
@@ -519,7 +527,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    }
 
    ScoreArgs sa;
-   sa.tasks = (const ScoreTask *)fb->d_tasks.p; sa.nTasks = (int)fb->tasks.size(); sa.X = fb->dX;
+   const bool wideTasks = (cfg->scoreMode & (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_MFMA)) != 0;
+   sa.tasks = (const ScoreTask *)(wideTasks ? fb->d_tasksW.p : fb->d_tasks.p); sa.nTasks = (int)(wideTasks ? fb->tasksW.size() : fb->tasks.size()); sa.X = fb->dX;
    sa.slotState = (const int *)fb->d_slotState.p; sa.out = (float *)fb->d_outp.p;
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;

@@ -6,6 +6,7 @@
 
 #define SCORE_TILE_FRAMES 128   /* 64 lanes x 2 frames per lane */
 #define SCORE_TASK_SLOTS  16    /* chain states scored per task */
+#define SCORE_TASK_SLOTS_WIDE 64 /* the same for the matrix-core kernels in forward-backward (fb.hip) */
 
 struct ScoreTask {
    int frame0;        // first row of the tile in X
