@@ -30,6 +30,12 @@
 #include "fb_state.h"
 
 // ------------------------------------------------------------------------------------ K2s: beta
+// Tolerance-class kernels (FAST): a term whose transition or predecessor is log-zero needs no test -- ladd_fast adds exp2(-1.4e10) = 0
+// to a live value and keeps a dead one below LSMALL, exp_fast of anything below the floor is 0 -- so the lane-divergent branches of the
+// exact form (an exec-mask save / branch / restore each: ~200 scalar instructions per step) are not compiled in.
+#define LADD_TERM(x, cond, v) do { if constexpr (FAST) x = ladd_fast((x), (v)); else if (cond) x = ladd((x), (v)); } while (0)
+#define EXP_TERM(acc, x) do { if constexpr (FAST) acc += exp_fast(x); else if ((x) > EXPFLOOR) acc += EXPT(x); } while (0)
+
 template <int W, bool FAST>
 __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
 {
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
       _Pragma("unroll") for (int k = 0; k < 3; k++)                                                                               \
          if (useEnt[k]) {                                                                                                         \
             const double aa = aEntryNext[k], y = xb_[offNext + k];                                                                \
-            if (aa > LSMALL && y > LSMALL) x_ = ladd(x_, aa + xo_[offNext + k] + y);                                              \
+            LADD_TERM(x_, aa > LSMALL && y > LSMALL, aa + xo_[offNext + k] + y);                                                   \
          }                                                                                                                        \
       bEn = x_;                                                                                                                   \
       lMax = LZERO;                                                                                                               \
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
             if (2 + k <= N - 1) {                                                                                                 \
                const double aa = s.aEntryOf[k], y = xb_[k];                                                                       \
                if (y > lMax) lMax = y;                                                                                            \
-               if (aa > LSMALL && y > LSMALL) x_ = ladd(x_, aa + xo_[k] + y);                                                     \
+               LADD_TERM(x_, aa > LSMALL && y > LSMALL, aa + xo_[k] + y);                                                          \
             }                                                                                                                     \
          bE = x_;                                                                                                                 \
       }                                                                                                                           \
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
                for (int d = 0; d < 5; d++)
                   if (useOut[d]) {
                      const double aa = s.aOut[d], y = ySucc[d];
-                     if (aa > LSMALL && y > LSMALL) x = ladd(x, aa + oSucc[d] + y);
+                     LADD_TERM(x, aa > LSMALL && y > LSMALL, aa + oSucc[d] + y);
                   }
             }
             bJ = x;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
                if (useIn[d]) {
                   aa = s.aIn[d];
                   const double y = yIn[d];
-                  if (aa > LSMALL && y > LSMALL) x = ladd(x, y + aa);
+                  LADD_TERM(x, aa > LSMALL && y > LSMALL, y + aa);
                }
             xpre = x;
             aJ = x + (double)oT;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
          for (int k = 2; k >= 0; k--)
             if (useExitP[k]) {
                const double aa = aExitPrev[k], y = xa[offPrev - k];
-               if (aa > LSMALL && y > LSMALL) aXp = ladd(aXp, y + aa);
+               LADD_TERM(aXp, aa > LSMALL && y > LSMALL, y + aa);
             }
       }
       if (a.alphaDbg && valid) {
@@ -430,18 +436,18 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
          }
          if (wantTrans) {
             x = aE + (double)s.aEntry + (double)oT + bT - pr;
-            if (x > EXPFLOOR) taEntry += EXPT(x);
+            EXP_TERM(taEntry, x);
             if (bqt1ok) {
                const double *xn = xnext[par] + SPAD + gl;
 #pragma unroll
                for (int d = 0; d < 5; d++)
                   if (useOut[d]) {
                      x = aJ + (double)s.aOut[d] + xn[d - 2] - pr;
-                     if (x > EXPFLOOR) taOut[d] += EXPT(x);
+                     EXP_TERM(taOut[d], x);
                   }
             }
             x = aJ + (double)s.aExit + bN - pr;
-            if (x > EXPFLOOR) taExit += EXPT(x);
+            EXP_TERM(taExit, x);
          }
       }
       if (valid) {
