@@ -50,6 +50,9 @@ __global__ __launch_bounds__(64 * W) void k_beta_s(FbArgs a)
    __shared__ short flOf[L + 2];                       // first lane of model q (1-based; [Q+1] = number of chain states)
    if constexpr (!FAST) ladd_table_to_lds(ltab, a.laddTab);
    const int gl = threadIdx.x, lane = gl & 63, wv = gl >> 6;
+   // the padding on both sides of the exchange arrays is read by the edge lanes (their transitions there are log-zero): log-zero values,
+   // so that the FAST form's untested terms stay dead whatever the LDS held before
+   if (gl < 2 * SPAD) { const int p_ = (gl < SPAD) ? gl : L + gl; xbeta[0][p_] = LZERO; xbeta[1][p_] = LZERO; xobs[0][p_] = 0.0; xobs[1][p_] = 0.0; }
    const int li = blockIdx.x;
    if (li >= a.nList) return;
    const int u = a.uttList[li];
@@ -245,6 +248,10 @@ __global__ __launch_bounds__(64 * W) void k_alpha_s(FbArgs a)
    __shared__ short flOf[L + 2];
    if constexpr (!FAST) { ladd_table_to_lds(ltab, a.laddTab); exp_table_to_lds(etab); }
    const int gl = threadIdx.x, lane = gl & 63, wv = gl >> 6;
+   if (gl < 2 * SPAD) {                                // padding of the exchange arrays: log-zero (see k_beta_s)
+      const int p_ = (gl < SPAD) ? gl : L + gl;
+      xalpha[0][p_] = LZERO; xalpha[1][p_] = LZERO; xsum[0][p_] = LZERO; xsum[1][p_] = LZERO; xnext[0][p_] = LZERO; xnext[1][p_] = LZERO;
+   }
    const int li = blockIdx.x;
    if (li >= a.nList) return;
    const int u = a.uttList[li];
