@@ -303,7 +303,7 @@ def main():
         kname = {"exact": "k_score_exact<39>", "fastest": "k_score_bf16<3>", "linear": "k_score_bf16<3>"}.get(args.score, "k_score_mfma<20>")
         traffic = None                                       # HBM-side bytes per launch from the committed PMC pass, same workload only
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02d_traffic.json")))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02e_traffic.json")))
             w = tj["workload"]
             if (w["states"], w["mix"], w["utts_per_gpu"], w["frames"], w.get("chunks", 1)) == (args.states, args.mix, args.utts, args.frames, NCH):
                 k = tj["kernels"][kname]
