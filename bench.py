@@ -347,6 +347,12 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_unit": flop_unit, "units_per_launch": units_local / NCH, "launches_per_step": NCH},
         }
+        if args.score in ("fastest", "linear"):
+            # what the matrix pipe executes for it: six bf16 piece products over K = 2D padded to a multiple of 32, per component
+            kpad = ((2 * D + 31) // 32) * 32
+            exe = units_local * args.mix * kpad * 2 * 6 / k1 / 1e12 if k1 > 0 else 0.0
+            out["roofline"]["executed"] = {"pipe": "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces", "achieved": exe, "peak": 2500.0, "unit": "TFLOP/s",
+                                           "frac": exe / 2500.0, "note": "`achieved` above counts the fp32 algorithm's flops (the unit's definition) against the fp32 matrix peak"}
         if ktimes_solo[0] > 0:
             ach = units_local * flop_unit / float(ktimes_solo[0]) / 1e12
             out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha_stats": ktimes_solo[2] * 1e3, "mix_stats": ktimes_solo[3] * 1e3}

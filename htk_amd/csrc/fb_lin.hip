@@ -467,8 +467,14 @@ __global__ __launch_bounds__(64 * W) void k_alpha_l(FbArgs a)
          for (int w = 1; w < W; w++) X_ = max(X_, xe[par][w]);
          XA = (X_ > NOEXP / 2) ? X_ : 0;
       }
-      const double kappa = exp2_split((SA + lf0.sb - pr) * LOG2E);
-      const double tau = (t < T) ? ldexp(kappa, -lf1.xb) : kappa;      // at T: beta_N of the last model is 1 and SB(T) = 0
+      // kappa = 2^kE * kM and tau = 2^tE * kM: max_j alpha_j * max_j beta_j may exceed pr by far more than a double's range (the two maxima
+      // sit in different states), so the factors are applied as mantissa and exponent -- KAP(v) = v * kappa without ever forming kappa
+      const double zK = (SA + lf0.sb - pr) * LOG2E, zKi = rint(zK);
+      const double kM = (double)__builtin_amdgcn_exp2f((float)(zK - zKi));
+      const int kE = (zKi > 4000.0) ? 4000 : ((zKi < -4000.0) ? -4000 : (int)zKi);
+      const int tE = (t < T) ? kE - lf1.xb : kE;                       // at T: beta_N of the last model is 1 and SB(T) = 0
+#define KAP(v) ldexp((v) * kM, kE)
+#define TAU(v) ldexp((v) * kM, tE)
       const double *xa = xalpha[par] + SPAD + gl;
 #pragma unroll
       for (int d = 0; d < 5; d++) if (useIn[d]) yIn[d] = xa[d - 2];
@@ -492,7 +498,6 @@ __global__ __launch_bounds__(64 * W) void k_alpha_l(FbArgs a)
       // ---- statistics for column t (HFB.c:1790-1806) and MaxModelProb of column t
       double bN = 0.0;
       if (valid) bN = (t == T) ? ((q == Q) ? 1.0 : 0.0) : ((hasNext && q + 1 >= lo2 && q + 1 <= hi2) ? nT1 : 0.0);
-      const double aJk = aJ * kappa;
       if (valid && s.first) {
          double mm = 0.0;
          if (inB) {
@@ -500,37 +505,36 @@ __global__ __launch_bounds__(64 * W) void k_alpha_l(FbArgs a)
             const double *xs = xsum[par] + SPAD + gl;
 #pragma unroll
             for (int k = 0; k < 3; k++) if (2 + k <= N - 1) { const double v = xs[k]; if (v > mm) mm = v; }
-            mm *= kappa;
+            mm = KAP(mm);
          }
          double prevExit = 0.0;
          if (q > 1 && q - 1 >= lo1 && q - 1 <= hi1) {
             const double bNp = (t == T) ? 0.0 : ((q >= lo2 && q <= hi2) ? eT1 : 0.0);
-            prevExit = aXp * bNp * tau;
+            prevExit = TAU(aXp * bNp);
          }
          const double mmp = (prevExit > mm) ? prevExit : mm;
          mmDrop = mmp < eMinF;                           // pr - MaxModelProb > minFrwdP
       }
       if (inBeam) {
-         occJ += aJk * bT;
-         if (s.first) occE += aEh * eT * kappa;
+         occJ += KAP(aJ * bT);
+         if (s.first) occE += KAP(aEh * eT);
          if (wantTrans) {
-            taEntry += aEh * pT * kappa;
+            taEntry += KAP(aEh * pT * lEntry);
             if (bqt1ok) {
                const double *xn = xnext[par] + SPAD + gl;
-               const double aJt = aJ * tau;
 #pragma unroll
-               for (int d = 0; d < 5; d++) if (useOut[d]) taOut[d] += aJt * xn[d - 2];
+               for (int d = 0; d < 5; d++) if (useOut[d]) taOut[d] += TAU(aJ * xn[d - 2] * lOut[d]);
             }
-            taExit += aJ * bN * tau;
+            taExit += TAU(aJ * bN * lExit);
          }
       }
       if (valid) {
          // UpMixParms seed (HFB.c:1479-1489,1573-1606)
          double seed = LZERO;
          if (inBeam && wantMix) {
-            const double gamma = aJk * bT;
+            const double gamma = KAP(aJ * bT);
             if (oneMix) { if (gamma > eMinF) seed = log_split(gamma); }
-            else if (gamma > eMinF2) seed = log_split(uPre * bT * kappa) - (double)lf0.omax;
+            else if (gamma > eMinF2) seed = log_split(KAP(uPre * bT)) - (double)lf0.omax;
          }
          gam[(size_t)(t - 1) * nS] = seed;
       }
@@ -545,16 +549,17 @@ __global__ __launch_bounds__(64 * W) void k_alpha_l(FbArgs a)
       }
       lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = lo3; hi2 = hi3;
       lf0 = lf1; lf1 = lf2;
+#undef KAP
+#undef TAU
    }
 
    if (err) {
       if (gl == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
       return;
    }
-   // ---- flush: the sums carry everything but the transition probability itself
-#pragma unroll
-   for (int d = 0; d < 5; d++) taOut[d] *= lOut[d];
-   taExit *= lExit; taEntry *= lEntry;
+   // ---- flush
+   // (the transition probabilities are inside the sums: where a transition does not exist the rest of the term is not bounded by pr --
+   //  nothing leaves that way -- and may be beyond a double's range; 0 * inf would be NaN)
    if (wantTrans) {
       const int t0 = __shfl(cTrans, 0);
       const bool uniform = __all(!valid || cTrans == t0);

@@ -307,7 +307,9 @@ def fuzz_herest_cli(rng, it, tmp):
     if ok:
         sig = np.sqrt(np.maximum(b["var"], 1e-12))
         em = np.max(np.abs(a["mean"] - b["mean"]) / np.maximum(np.abs(b["mean"]), sig))
-        ev = np.max(np.abs(a["var"] - b["var"]) / np.maximum(np.abs(b["var"]), 1e-6))
+        # (a variance that comes out near zero is the difference of two large float sums in the reference: compared on the scale of
+        #  the variances the data were drawn with, 0.5 .. 2)
+        ev = np.max(np.abs(a["var"] - b["var"]) / np.maximum(np.abs(b["var"]), 5e-2))
         ew = np.max(np.abs(a["compWeight"] - b["compWeight"]))
         lin = lambda v: np.where(np.asarray(v) > -0.5e10, np.exp(np.asarray(v, np.float64)), 0.0)
         et = np.max(np.abs(lin(a["transP"]) - lin(b["transP"])))

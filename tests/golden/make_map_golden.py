@@ -13,7 +13,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 DEMO = os.path.join(ROOT, "tests", "golden", "demo")
 RUNS = {"pmvw": "TARGETKIND = MFCC_E_D\nHMAP: MAPTAU = 6.0\nHMAP: MINVAR = 0.02\nHMAP: MIXWEIGHTFLOOR = 2.0\nHMAP: TRACE = 1\n",
-        "pm": "TARGETKIND = MFCC_E_D\nHMAP: TRACE = 1\n"}
+        "pm": "TARGETKIND = MFCC_E_D\nHMAP: TRACE = 1\n",
+        "tied_pmv": "TARGETKIND = MFCC_E_D\nHMAP: MAPTAU = 3.0\nHMAP: TRACE = 1\n"}          # the set with ~u / ~v vectors (hmm_tied/newMacros)
 
 if __name__ == "__main__":
     out = os.path.join(DEMO, "hmm_map")
@@ -23,7 +24,8 @@ if __name__ == "__main__":
             cfg = os.path.join(d, "cfg")
             open(cfg, "w").write(conf)
             os.makedirs(os.path.join(d, "next"))
-            log = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "HERest"), "-C", cfg, "-u", flags, "-H", os.path.join(DEMO, "hmm_mixup", "newMacros"),
+            src = os.path.join(DEMO, "hmm_tied" if flags.startswith("tied_") else "hmm_mixup", "newMacros")
+            log = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "HERest"), "-C", cfg, "-u", flags.replace("tied_", ""), "-H", src,
                                   "-M", os.path.join(d, "next"), "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", "-T", "1", os.path.join(DEMO, "bcplist")] +
                                  sorted(glob.glob(os.path.join(DEMO, "train", "tr*.mfc"))), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
             shutil.copy(os.path.join(d, "next", "newMacros"), os.path.join(out, "after_" + flags))

@@ -155,7 +155,8 @@ def test_herest_cli_parallel_mode_with_tied_vectors(tools, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags,conf", [("pmvw", "HMAP: MAPTAU = 6.0\nHMAP: MINVAR = 0.02\nHMAP: MIXWEIGHTFLOOR = 2.0\nHMAP: TRACE = 1\n"), ("pm", "HMAP: TRACE = 1\n")])
+@pytest.mark.parametrize("flags,conf", [("pmvw", "HMAP: MAPTAU = 6.0\nHMAP: MINVAR = 0.02\nHMAP: MIXWEIGHTFLOOR = 2.0\nHMAP: TRACE = 1\n"), ("pm", "HMAP: TRACE = 1\n"),
+                                        ("tied_pmv", "HMAP: MAPTAU = 3.0\nHMAP: TRACE = 1\n")])
 def test_herest_cli_map_reestimation(tools, tmp_path, flags, conf):
     """HERest -u p...: MAPUpdateModels (HMap.c:413) from the pass's accumulators -- prior-weighted means, variances with the mean-shift
     term of HMap.c:350-356, weights from max(0, w*vSize*tau - 1) counts, HMap's own configuration (MAPTAU, MINVAR, MIXWEIGHTFLOOR) --
@@ -163,7 +164,8 @@ def test_herest_cli_map_reestimation(tools, tmp_path, flags, conf):
     cf = tmp_path / "herest.conf"; cf.write_text("TARGETKIND = MFCC_E_D\n" + conf)
     out = tmp_path / "next"; out.mkdir()
     gold = os.path.join(DEMO, "hmm_map")
-    r = run([os.path.join(tools, "herest"), "-T", "1", "-C", str(cf), "-u", flags, "-H", os.path.join(DEMO, "hmm_mixup", "newMacros"), "-M", str(out),
+    src = os.path.join(DEMO, "hmm_tied" if flags.startswith("tied_") else "hmm_mixup", "newMacros")       # tied_: the set with ~u / ~v vectors
+    r = run([os.path.join(tools, "herest"), "-T", "1", "-C", str(cf), "-u", flags.replace("tied_", ""), "-H", src, "-M", str(out),
              "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + demo_train_files())
     assert r.returncode == 0, r.stderr
     for line in open(os.path.join(gold, "herest_%s.log" % flags)).read().splitlines():

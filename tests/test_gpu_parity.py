@@ -690,6 +690,30 @@ def test_beta_beam_bottom_model_above_tapered_top(native, oracle, general):
     assert rc == 1 and st[0] == 1 and abs(pr[0] - opr) <= 1e-10 * abs(opr)
 
 
+def test_linear_mode_scale_product_beyond_double_range(native, oracle):
+    """A case the randomised sweep found (tests/fuzz_parity.py 6000 20261003, iteration 4396): a tight beam on 8-model utterances where
+    max_j alpha_j(t) * max_j beta_j(t) exceeds the utterance probability by more than a double's range (the maxima sit in different
+    states).  The scaled-linear kernels (HTKAMD_SCORE_LINEAR, fb_lin.hip) formed that factor -- inf -- before multiplying it with the
+    tiny scaled values; it is applied as mantissa and exponent now.  Statistics finite and equal to the logarithmic path's."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz", "linear_overflow_case.npz"))
+    pk = {k[3:]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("pk_")}
+    if pk["gconst"].size == 0:
+        pk["gconst"] = None
+    for k in ("vecSize", "numStates", "numComp", "numGauss", "numTrans", "numPhys"):
+        pk[k] = int(pk[k])
+    utts = [dict(seq=z["seq%d" % u], feat=z["feat%d" % u]) for u in range(int(z["nUtt"]))]
+    prune = dict(pruneInit=float(z["prune"][0]), pruneInc=float(z["prune"][1]), pruneLim=float(z["prune"][2]), minFrwdP=float(z["minFrwdP"]))
+    res = {}
+    for mode in (2, 32):
+        model, fb, acc, pr, st = run_fb(native, pk, utts, prune, scoreMode=mode)
+        assert (np.asarray(st) == 1).all()
+        res[mode] = (np.asarray(pr), acc.download())
+    assert np.allclose(res[32][0], res[2][0], rtol=1e-9)
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+        assert np.isfinite(res[32][1][k]).all(), k
+        acc_close(res[32][1][k], res[2][1][k], k)
+
+
 # ----------------------------------------------------------------------------------------- long chains: 2 / 4 wavefronts per utterance
 def _concat_chains(rng, seqs, feats, targets):
     """Utterances with chains of about `targets` models: whole utterances of the pool strung together (labels and frames)."""

@@ -253,7 +253,11 @@ int main(int argc, char **argv)
          int totM = 0;
          { int *ms = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1)), *vs = (int *)malloc(sizeof(int) * (size_t)(d->numGauss + 1));
            const int shared = htkamd_mmf_sharing(mmf, ms, vs);
-           for (int g = 0; g < d->numGauss; g++) if (shared <= 0 || ms[g] == g) totM++;        /* TotMixInSet: distinct mean vectors */
+           for (int g = 0; g < d->numGauss; g++) {                                             /* TotMixInSet: distinct mean vectors */
+              int seen = 0;
+              if (shared > 0 && ms[g] >= 0) for (int k = 0; k < g; k++) if (ms[k] == ms[g]) { seen = 1; break; }   /* ms: number of the ~u macro, -1 = private */
+              if (!seen) totM++;
+           }
            free(ms); free(vs); }
          printf("Observed components (means) %d of %d: %.2f\n", us.nMapObserved, totM, 100 * (float)us.nMapObserved / (float)totM);
          if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
