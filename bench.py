@@ -128,8 +128,8 @@ def main():
                     help="weak: --utts utterances on every GPU (the contract's default); strong: --total-utts utterances split over the GPUs")
     ap.add_argument("--total-utts", type=int, default=10000, help="--scaling strong: utterances of the whole job (BASELINE config[2]: 10k)")
     ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
-    ap.add_argument("--score", choices=["exact", "mfma", "fast", "fastest", "linear"], default="fastest",
-                    help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; fastest = bf16 x 3 matrix-core scores + that LAdd; linear = bf16 x 3 scores + scaled linear-domain recursions (tolerance class, tests/test_gpu_parity.py)")
+    ap.add_argument("--score", choices=["exact", "mfma", "fast", "fastest"], default="fastest",
+                    help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; fastest = bf16 x 3 matrix-core scores + that LAdd")
     ap.add_argument("--two-streams", type=int, default=1, help="run the chunks of an iteration on two alternating streams (1) or on one stream (0)")
     ap.add_argument("--chunks", type=int, default=1, help="sub-batches an iteration's shard is cut into (alternating over two streams, one accumulator vector)")
     ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
@@ -166,7 +166,7 @@ def main():
     pk = s.packed()
     model = capi.Model(pk)
     accs = capi.Accs(model)
-    cfg = capi.fb_config(scoreMode={"exact": 0, "mfma": 1, "fast": 3, "fastest": 6, "linear": 38}[args.score])                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
+    cfg = capi.fb_config(scoreMode={"exact": 0, "mfma": 1, "fast": 3, "fastest": 6}[args.score])                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
 
     if args.ragged:                                      # not the headline workload: utterance lengths spread over [frames/2, frames], chains
         rr = np.random.default_rng(77 + rank)            # spread likewise (one model per 12 frames), in random order within the batch
@@ -300,7 +300,7 @@ def main():
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
-        kname = {"exact": "k_score_exact<39>", "fastest": "k_score_bf16<3>", "linear": "k_score_bf16<3>"}.get(args.score, "k_score_mfma<20>")
+        kname = {"exact": "k_score_exact<39>", "fastest": "k_score_bf16<3>"}.get(args.score, "k_score_mfma<20>")
         traffic = None                                       # HBM-side bytes per launch from the committed PMC pass, same workload only
         try:
             tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02e_traffic.json")))
@@ -347,7 +347,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_unit": flop_unit, "units_per_launch": units_local / NCH, "launches_per_step": NCH},
         }
-        if args.score in ("fastest", "linear"):
+        if args.score == "fastest":
             # what the matrix pipe executes for it: six bf16 piece products over K = 2D padded to a multiple of 32, per component
             kpad = ((2 * D + 31) // 32) * 32
             exe = units_local * args.mix * kpad * 2 * 6 / k1 / 1e12 if k1 > 0 else 0.0

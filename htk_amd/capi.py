@@ -28,7 +28,7 @@ def _stream(s):
     return None if s is None else (s if isinstance(s, C.c_void_p) else C.c_void_p(int(s)))
 
 
-SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC, SCORE_LINEAR = 0, 1, 2, 4, 8, 16, 32
+SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC = 0, 1, 2, 4, 8, 16
 
 
 class HtkAmdError(RuntimeError):

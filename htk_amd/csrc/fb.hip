@@ -132,8 +132,6 @@ struct htkamd_fb {
    size_t betaWTotal;
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
-   DevBuf d_lin;                            // LinFrame per frame (scaled-linear recursions)
-   bool lastLinear;                         // the state-path utterances of the last execute ran in the linear domain
    DevBuf d_rec, d_recSorted, d_recCtl;     // statistics records (kernels.h MixRec)
    int recCapForce;                         // > 0: capacity of the record list (tests: forces the overflow path)
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
@@ -148,7 +146,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; fb->recCapForce = 0; fb->lastLinear = false; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; fb->recCapForce = 0; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) fb->ev[i] = nullptr;
    fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
@@ -173,7 +171,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_lin};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -534,7 +532,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
-   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16 | HTKAMD_SCORE_SOUTP | HTKAMD_SCORE_LINEAR)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
+   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16 | HTKAMD_SCORE_SOUTP)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
    const bool fastLadd = (cfg->scoreMode & HTKAMD_SCORE_FASTLADD) != 0;
 
    FbArgs fa;
@@ -579,12 +577,6 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 5 * 64)))) return rc;
    fa.betaW = (double *)fb->d_betaW.p;
    static const int clsW[4] = {1, 2, 4, 8};
-   const bool linear = (cfg->scoreMode & HTKAMD_SCORE_LINEAR) != 0 && fb->clsOff[9] > fb->clsOff[5];
-   fb->lastLinear = linear;
-   if (linear) {
-      if ((rc = fb->d_lin.reserve(sizeof(LinFrame) * (size_t)(fb->totalFrames ? fb->totalFrames : 1)))) return rc;
-      fa.lin = (LinFrame *)fb->d_lin.p;
-   }
    // the longest chains first: their recursions are the critical path of the pass
    for (int pass = 0; pass < 2; pass++) {
       FbArgs fc = fa;
@@ -596,8 +588,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       }
       for (int c = 3; c >= 0; c--) {
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[5 + c]; fc.nList = fb->clsOff[6 + c] - fb->clsOff[5 + c];
-         if (linear) { if ((rc = pass == 0 ? htkamd_launch_beta_l(fc, clsW[c], s) : htkamd_launch_alpha_l(fc, clsW[c], s))) return rc; }
-         else if ((rc = pass == 0 ? htkamd_launch_beta_s(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_s(fc, clsW[c], fastLadd, s))) return rc;
+         if ((rc = pass == 0 ? htkamd_launch_beta_s(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_s(fc, clsW[c], fastLadd, s))) return rc;
       }
       HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }
@@ -678,16 +669,6 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
          const size_t Lw = (size_t)64 * d.W;             // model's first lane); the exit state's value is the next model's entry value one frame on
          std::vector<double> bs((size_t)T * 2 * Lw);
          HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + d.betaW0, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));
-         if (fb->lastLinear) {                           // scaled linear columns (fb_lin.hip) -> logarithms
-            std::vector<LinFrame> lf(T);
-            HIPCHECK(hipMemcpy(lf.data(), (LinFrame *)fb->d_lin.p + d.frame0, sizeof(LinFrame) * T, hipMemcpyDeviceToHost));
-            for (int t = 0; t < T; t++)
-               for (size_t l = 0; l < Lw; l++) {
-                  double &v = bs[(size_t)t * Lw + l], &e = bs[(size_t)T * Lw + (size_t)t * Lw + l];
-                  v = (v > 0.0) ? log(v) + lf[t].sb : LZERO;
-                  e = (e > 0.0) ? log(e) + lf[t].sb + (double)lf[t].omax : LZERO;
-               }
-         }
          const int *mSl = fb->mSlot0.data() + d.q0;
          for (int t = 0; t < T; t++)
             for (int q = 1; q <= Q; q++) {

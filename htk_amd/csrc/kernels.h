@@ -68,8 +68,6 @@ struct UttDesc {
                       // beta block = betaS[T][64*W] then betaE[T][64*W]
 };
 
-struct LinFrame { double sb; float omax; int xb; };   // scaled-linear recursions (fb_lin.hip): scale of beta's column, score normaliser, largest exponent
-
 struct MixRec { int g, frame; double L; };          // posterior L of Gaussian g at row `frame` of the feature table
 
 struct FbArgs {
@@ -112,7 +110,6 @@ struct FbArgs {
    // per Gaussian (one atomic per accumulator element and batch instead of one per triple); NULL = direct atomics only
    MixRec *rec, *recSorted;
    int recCap, G;
-   LinFrame *lin;                    // [frame0 + t - 1], written by k_beta_l, read by k_alpha_l
    int *recCtl;                      // [0] number of records asked for (may exceed recCap), then gCnt[G+1], gStart[G+1], gCur[G+1]
 };
 
@@ -123,9 +120,6 @@ int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s);
 // state-per-lane fast path (fb_state.hip): chains of <= 512 emitting states, models of <= 5 states, no tee models
 int htkamd_launch_beta_s(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_alpha_s(const FbArgs &a, int W, bool fast, hipStream_t s);
-// scaled linear domain (fb_lin.hip), same utterances as the state-per-lane path
-int htkamd_launch_beta_l(const FbArgs &a, int W, hipStream_t s);
-int htkamd_launch_alpha_l(const FbArgs &a, int W, hipStream_t s);
 int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_alpha_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 

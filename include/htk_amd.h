@@ -242,12 +242,6 @@ int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dState
 /* htkamd_outp_block_mode only, may be or-ed with HTKAMD_SCORE_SOUTP: DOutP's form for DIAGC sets (HModel.c:5347: xmm*xmm/var, the float
  * division) -- what MOutP dispatches to when the set has not been through ConvDiagC, as in HRest / HInit.  Bit-identical to DOutP. */
 #define HTKAMD_SCORE_DIAGC 16
-/* Forward-backward only: alpha and beta as probabilities divided by a per-frame scale instead of logarithms (fb_lin.hip): the sums of
- * the recursions become fp64 multiply-adds, the statistics products with two per-frame constants; tolerance class (utterance
- * log-probabilities ~1e-9 relative, accumulators inside the 1e-4 bar).  Applies to utterances on the lane-per-state kernels (no tee
- * models, models of at most 5 states, at most 512 emitting chain states); the others run as HTKAMD_SCORE_FASTLADD says.  Measured
- * slower than HTKAMD_SCORE_FASTLADD on MI355X (fb_lin.hip header): an alternative, not part of HTKAMD_SCORE_FASTEST. */
-#define HTKAMD_SCORE_LINEAR 32
 #define HTKAMD_SCORE_FAST  (HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)
 #define HTKAMD_SCORE_FASTEST (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_FASTLADD)
 int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
