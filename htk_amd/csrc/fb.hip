@@ -311,7 +311,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
          // bf16 pieces) once per task, so they get four times as many states per task (measured: 1.32 -> 1.21 ms at the bench workload;
          // the exact kernel is 10 % slower on the wide tasks)
          for (int wide = 0; wide < 2; wide++) {
-         const int GS = wide ? SCORE_TASK_SLOTS_WIDE : SCORE_TASK_SLOTS;
+         const int GS = wide ? SCORE_TASK_SLOTS_WIDE : SCORE_TASK_SLOTS_EXACT;
          std::vector<ScoreTask> &dst = wide ? C.tasksW : C.tasks;
          for (int k0 = 0; k0 < nSlots; k0 += GS) {
             const int k1 = (k0 + GS < nSlots) ? k0 + GS : nSlots;

@@ -7,6 +7,8 @@
 #define SCORE_TILE_FRAMES 128   /* 64 lanes x 2 frames per lane */
 #define SCORE_TASK_SLOTS  16    /* chain states scored per task */
 #define SCORE_TASK_SLOTS_WIDE 64 /* the same for the matrix-core kernels in forward-backward (fb.hip) */
+#define SCORE_TASK_SLOTS_EXACT 8 /* and for the exact kernel there: one wave per task, features in registers, so small tasks balance best
+                                    (5.28 / 5.19 / 5.11 ms at 16 / 12 / 8 on the bench workload) */
 
 struct ScoreTask {
    int frame0;        // first row of the tile in X
