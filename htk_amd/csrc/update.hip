@@ -127,8 +127,8 @@ __global__ void k_upd_gauss_elem(UpdArgs a)
    const size_t idx0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
    const int D = a.D;
    const bool live = idx0 < (size_t)a.G * D;
-   const size_t idx = live ? idx0 : 0;
-   const int g = (int)(idx / D), k = (int)(idx - (size_t)g * D);
+   const unsigned int idx = live ? (unsigned int)idx0 : 0u;          // G * D < 2^31 (checked by the launcher): 32-bit index arithmetic
+   const int g = (int)(idx / (unsigned int)D), k = (int)(idx - (unsigned int)g * (unsigned int)D);
    float v = a.var[idx], mu = a.mean[idx];
    bool floored = false;
    if (a.singleProcess && a.anyG[g]) {                       // ConvDiagC before the pass, ForceDiagC after it
@@ -292,6 +292,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
    {
       const size_t nEl = (size_t)m->G * m->D;
+      if (nEl >= ((size_t)1 << 31)) { htkamd_set_error("model_update_device: %zu mean / variance elements (the element kernel indexes with 32 bits)", nEl); return HTKAMD_EMODEL; }
       hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
    }
    hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
