@@ -53,7 +53,7 @@ def main():
                          "write_s": round(time.perf_counter() - t0, 2)}
         exe = os.path.join(ROOT, "tools", "bin", "herest")
         cmd = [exe, "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMF"), "-S", os.path.join(d, "scp"), "-I", os.path.join(d, "labels.mlf"),
-               "-M", os.path.join(d, "next"), "-v", "0.01", "-T", "4", "--score", a.score, os.path.join(d, "hmmlist")]
+               "-M", os.path.join(d, "next"), "-v", "0.01", "-T", "16384", "--score", a.score, os.path.join(d, "hmmlist")]
         runs = []
         for k in range(3):                                            # first run also pays the page-cache fill and the GPU context; all are reported
             t0 = time.perf_counter()

@@ -31,7 +31,7 @@ typedef struct { char *logical; int phys; } modelref;
 
 #include <time.h>
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-/* -T 4: wall-clock seconds per phase of the run, on stdout at the end */
+/* -T 16384 (octal 040000, a bit HERest.c does not use: its T_TOP / T_MAP / T_UPD are 1 / 2 / 4): wall-clock seconds per phase of the run, on stdout at the end */
 static double g_t[8]; static const char *const g_tn[8] = {"load model set", "create device model", "read data + labels", "prepare", "execute + results", "update", "save model set", "other"};
 #define TIC double tic_ = now_s()
 #define TOC(k) do { const double n_ = now_s(); g_t[k] += n_ - tic_; tic_ = n_; } while (0)
@@ -282,7 +282,7 @@ int main(int argc, char **argv)
       printf("Reestimation complete - average log prob per frame = %e\n", vec[lay.totalPr] / vec[lay.totalT]);
       printf("     - total frames seen          = %e\n", vec[lay.totalT]);
    }
-   if (trace & 4) for (int k = 0; k < 7; k++) printf("Timing: %-22s %8.3f s\n", g_tn[k], g_t[k]);
+   if (trace & 040000) for (int k = 0; k < 7; k++) printf("Timing: %-22s %8.3f s\n", g_tn[k], g_t[k]);
    htkamd_accs_destroy(accs); htkamd_model_destroy(model); htkamd_mmf_destroy(mmf);
    return 0;
 }
