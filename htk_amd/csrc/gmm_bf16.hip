@@ -13,10 +13,21 @@
 // 6 x 16 = 96 cycles instead of 8 x 32 = 256, and the mixture's log-sum-exp (v_exp_f32 / v_log_f32 / row swaps) issues beside them.
 // Tolerance class like K1m (|score - reference| <= 1e-3, typically 1e-5): the Viterbi path and the C ABI default stay on gmm_exact.hip.
 //
-// Layout.  K is cut into NC chunks of 32 (NC = ceil(2D/32): 3 at D = 39, dimensions beyond D are zero).  Lane l of a wave holds, per
+// Accuracy (round 3).  The matrix unit rounds its fp32 accumulator after every instruction, at the accumulator's magnitude.  With the
+// expanded form's constant -0.5 sum mu^2 ivar (~ -230 in base-2 units at D = 39) as the accumulator's start, all 18 instructions of a
+// tile rounded at ulp(256) = 3e-5: |score error| up to 2e-4, re-estimated variances up to 1.8e-4 off the reference's at the headline
+// size -- over north_star's 1e-4.  So (a) every K chunk carries COMPLETE squares: the dimensions are dealt out to the chunks (dpc =
+// ceil(D/NC) <= 15 per chunk) and k = 30 of a chunk holds, against a constant 1 in B, the chunk's share -0.5 sum_{d in chunk} mu_d^2
+// ivar_d, so that a chunk's product is -0.5 sum ivar (x - mu)^2 over its dimensions and the accumulator moves monotonically from
+// zero to -0.5 sum ivar (x - mu)^2; (b) the accumulator STARTS AT ZERO: the fifteen correction products (everything but a1 z1) come
+// first and stay below ~2, where a rounding is 1e-7, then the three leading products, and log w - 0.5 gConst (~ -55) is added once at
+// the end by the vector unit.  Same matrix instruction count; measured at the headline size: see DESIGN.md §2.
+//
+// Layout.  K is cut into NC chunks of 32 (NC = ceil(D/15): 3 at D = 39); chunk c covers the dimensions dpc*c .. dpc*c + dpc - 1 as
+// (x^2, x) pairs at k = 2i, 2i+1, then zeros, the constant at k = 30.  Lane l of a wave holds, per
 // chunk c, the 8 consecutive k = 32c + 8(l>>4) + j of its matrix row / column (cdna_hip_programming.md "A/B operand lane maps"):
-//   A (Gaussians = rows, l&15): host/device-built table, per tile of 16 components: [piece 3][chunk NC][lane 64][8 bf16], then the
-//       accumulator start cinit as [lane 64][4 f32] in the C layout (row = 4(l>>4) + r, col = l&15: rows only matter).
+//   A (Gaussians = rows, l&15): device-built table, per tile of 16 components: [piece 3][chunk NC][lane 64][8 bf16], then the
+//       accumulator start (log w - 0.5 gConst) log2(e) as [lane 64][4 f32] in the C layout (row = 4(l>>4) + r, col = l&15: rows only matter).
 //   B (frames = columns, l&15): built once per task from the feature rows: 4 consecutive dimensions per lane and chunk, squared and
 //       plain, split into the three pieces (3 x NC x 4 VGPRs per 16-frame column tile).
 // Task structure, LDS staging of the table (one copy per workgroup, a tile ahead), log-sum-exp and stores are K1m's.
@@ -87,6 +98,7 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
    const int col = lane & 15, kg = lane >> 4;
    const int D = a.D;
+   const int dpc = (D + NC - 1) / NC;                  // dimensions per K chunk (<= 15)
    cint *slotState = (cint *)a.slotState;
    cint *stateTileOff = (cint *)a.stateTileOff;
    const u4 *tab = (const u4 *)a.bf16Tab;
@@ -118,16 +130,18 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
          const float *row = a.X + (size_t)(tk.frame0 + f) * D;
 #pragma unroll
          for (int c = 0; c < NC; c++) {
-            const int d0 = 16 * c + 4 * kg;           // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
+            const int d0 = dpc * c + 4 * kg;          // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
             unsigned short p[3][8];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                int dim = d0 + i;
-               const bool pad = dim >= D;
+               const bool pad = 4 * kg + i >= dpc || dim >= D;
                if (pad) dim = D - 1;
                float v = row[dim];
                if (pad) v = 0.0f;
-               split3(v * v, p[0][2 * i], p[1][2 * i], p[2][2 * i]);
+               float v2 = v * v;
+               if (i == 3 && kg == 3) v2 = 1.0f;       // k = 30: the constant that meets the chunk's -0.5 sum mu^2 ivar
+               split3(v2, p[0][2 * i], p[1][2 * i], p[2][2 * i]);
                split3(v, p[0][2 * i + 1], p[1][2 * i + 1], p[2][2 * i + 1]);
             }
 #pragma unroll
@@ -166,8 +180,9 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
                const f4 ci = __builtin_bit_cast(f4, wbuf[buf][3 * NC * 64 + lane]);
                f4 Cx[B16_COL_TILES];
 #pragma unroll
-               for (int ft = 0; ft < B16_COL_TILES; ft++) Cx[ft] = ci;
-               // smallest products first: (a2 z2, a1 z3, a3 z1), then (a1 z2, a2 z1), then a1 z1
+               for (int ft = 0; ft < B16_COL_TILES; ft++) Cx[ft] = (f4)(0.0f);
+               // from zero, smallest first: (a2 z2, a1 z3, a3 z1), then (a1 z2, a2 z1) -- all below ~2 --, then the leading products
+               // a1 z1, complete squares per chunk; the accumulator start is added last, by the vector unit
 #pragma unroll
                for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
                // log-sum-exp over the tile's 16 rows: 4 in this lane, the rest in lanes ^16, ^32, ^48 (base-2 logs, as K1m)
 #pragma unroll
                for (int ft = 0; ft < B16_COL_TILES; ft++) {
-                  const f4 y = Cx[ft];
+                  const f4 y = Cx[ft] + ci;
                   float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
                   mx = rows_max_b(mx);
                   float sm = (EXP2(y[0] - mx) + EXP2(y[1] - mx)) + (EXP2(y[2] - mx) + EXP2(y[3] - mx));
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
 int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
-   if (!m->d_bf16Tab) { htkamd_set_error("score_bf16: vector size %d not supported by the matrix-core paths (up to 48)", m->D); return HTKAMD_EMODEL; }
+   if (!m->d_bf16Tab) { htkamd_set_error("score_bf16: vector size %d not supported by the bf16 matrix-core path (up to 45)", m->D); return HTKAMD_EMODEL; }
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
    int blocks = a.nTasks;
    if (blocks > 256 * 3) blocks = 256 * 3;      // persistent blocks, one task (128 frames x 16 states) at a time
@@ -266,12 +281,18 @@ __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
    const double L2E = 1.4426950408889634;
    const float *mu = nullptr, *iv = nullptr;
    if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
+   const int dpc = (D + NC - 1) / NC, dlo = dpc * ch, dhi = (dlo + dpc < D) ? dlo + dpc : D;     // this chunk's dimensions
    unsigned short p[3][8];
 #pragma unroll
    for (int j = 0; j < 8; j++) {
-      const int k = 32 * ch + 8 * kg + j, dim = k >> 1;
+      const int kk = 8 * kg + j, dim = dlo + (kk >> 1);
       float v = 0.0f;
-      if (live && dim < D) v = (k & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+      if (live && dim < dhi) v = (kk & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+      if (live && kk == 30) {                               // against B's constant 1: -0.5 sum mu^2 ivar over the chunk
+         double q = 0.0;
+         for (int i = dlo; i < dhi; i++) q += (double)mu[i] * mu[i] * iv[i];
+         v = (float)(-0.5 * q * L2E);
+      }
       split3(v, p[0][j], p[1][j], p[2][j]);
    }
 #pragma unroll
@@ -284,8 +305,7 @@ __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
    if (ch == 0 && kg == 0) {
       float ci = -1.0e30f;
       if (live) {
-         double k0 = a.gconst[a.compGauss[c]];
-         for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+         const double k0 = a.gconst[a.compGauss[c]];
          ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
       }
       float *ciBase = (float *)(T + (size_t)3 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4

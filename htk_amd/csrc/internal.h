@@ -78,8 +78,8 @@ struct htkamd_model {
    int   *d_tileState;         /* [nTiles] tied state of every fragment tile */
    int    mfmaNS, nTiles;
    int    mfmaStale;           /* the fp32 fragment table is older than the parameters (device update): rebuilt on its next use */
-   void  *d_bf16Tab;           /* bf16 x 3 scoring path (gmm_bf16.hip): A-operand pieces per tile; NULL when D > 48 */
-   int    bf16NC;              /* K chunks of 32 per piece: ceil(2D/32) */
+   void  *d_bf16Tab;           /* bf16 x 3 scoring path (gmm_bf16.hip): A-operand pieces per tile; NULL when D > 45 */
+   int    bf16NC;              /* K chunks of 32 per piece: ceil(D/15) */
    /* shared mean / variance vectors (~u / ~v macros; htkamd_model_set_sharing): first Gaussian of the group a Gaussian's mean / variance
       belongs to (itself when private), members of its variance group; NULL = no sharing in the set */
    int   *h_meanLeader, *h_varLeader, *h_varGroupSize;

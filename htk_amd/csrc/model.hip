@@ -111,8 +111,8 @@ static int mfma_refresh(htkamd_model *m)
       }
       free(off);
       if (rc) return rc;
-      m->bf16NC = (2 * D + 31) / 32;
-      HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
+      m->bf16NC = (D + 14) / 15;                      // 15 dimensions as (x^2, x) pairs + the chunk's constant per K chunk of 32 (gmm_bf16.hip)
+      if (m->bf16NC <= 3) HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
    }
    {  // bf16 x 3 path: its table is built on the device from the tables just uploaded
       int rcb = htkamd_model_refresh_bf16_device(m, nullptr);

@@ -182,11 +182,23 @@ def generate(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39,
     return s
 
 
-def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39, model_seed: int | None = None) -> SynthSet:
+def round_to_mmf_precision_bulk(a: np.ndarray) -> np.ndarray:
+    """round_to_mmf_precision for millions of values: one format call, one parse."""
+    flat = np.asarray(a, np.float32).reshape(-1)
+    out = np.empty(flat.size, np.float32)
+    for i in range(0, flat.size, 1 << 20):
+        blk = flat[i:i + (1 << 20)]
+        out[i:i + blk.size] = np.array((("%e " * blk.size) % tuple(blk.tolist())).split(), dtype=np.float64).astype(np.float32)
+    return out.reshape(np.shape(a))
+
+
+def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39, model_seed: int | None = None, mmf_round: bool = False) -> SynthSet:
     """Vectorised variant for large workloads (bench.py): same model distribution and utterance structure as
     generate() (Q = T//12 models per utterance, equal thirds per state, frames drawn from the aligned state's
     GMM) but bulk random draws, no files and no MMF-precision round trip.  `model_seed` fixes the model
-    independently of the utterance seed so that every rank of a sharded run holds the same HMM set."""
+    independently of the utterance seed so that every rank of a sharded run holds the same HMM set.
+    `mmf_round`: the set returned holds the parameters a text MMF of it carries ('%e'), as generate() does (the frames are drawn
+    from the unrounded ones either way, so the data do not depend on the switch)."""
     mrng = np.random.default_rng(seed if model_seed is None else model_seed)
     means = mrng.normal(0, 3, size=(NS, M, D)).astype(np.float32)
     var = mrng.uniform(0.5, 2.0, size=(NS, M, D)).astype(np.float32)
@@ -217,6 +229,8 @@ def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int =
         X = means[states, ms] + rng.standard_normal((T, D), dtype=np.float32) * sd[states, ms]
         s.seqs.append(seqs[u].astype(np.int32))
         s.feats.append(X.astype(np.float32))
+    if mmf_round:
+        s.means = round_to_mmf_precision_bulk(means); s.var = round_to_mmf_precision_bulk(var); s.w = round_to_mmf_precision_bulk(w)
     return s
 
 
