@@ -49,7 +49,7 @@ def cpu_baseline(s, pk, budget_s: float):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return n, dt, np.array(prs)
+    return n, dt, np.array(prs), acc
 
 
 def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
@@ -359,12 +359,33 @@ def main():
             out["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}
         if args.cpu_seconds > 0 and world == 1:               # the CPU leg runs at N = 1 only
             per_utt = units_local / max(len(s.feats), 1)
-            n, cdt, opr = cpu_baseline(s, pk, args.cpu_seconds)
+            n, cdt, opr, oacc = cpu_baseline(s, pk, args.cpu_seconds)
             # the checker: the oracle's utterance log-probabilities for the same utterances under the same (initial) model
             tol = 1e-10 if args.score == "exact" else 1e-6
             worst = float(np.max(np.abs(pr_init[:n] - opr) / np.abs(opr))) if n else 0.0
             assert worst <= tol, "bench: utterance log-probabilities differ from the oracle: max relative %.3g over %d utterances" % (worst, n)
+            # ... and its accumulators: the same utterances alone through the HIP path in the bench's mode, under the initial model.
+            # Counts within 1e-4 * max(|ref|, 1e-3); first- and second-order sums (kept about the current mean: entries near zero are
+            # cancellations) within 1e-4 * max(|ref|, the Gaussian's occupancy).
+            m0 = capi.Model(pk); fbc = capi.ForwardBackward(m0); accc = capi.Accs(m0)
+            fo_c = frame_off_all[:n + 1].astype(np.int32)
+            lo_c = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs[:n]])]).astype(np.int32)
+            fbc.prepare(dX.data_ptr(), fo_c, lo_c, np.concatenate(s.seqs[:n]).astype(np.int32), sptr)
+            fbc.execute(cfg, accc, sptr); fbc.results(sptr)
+            ac = accc.download()
+            worst_acc = {}
+            for k_ in ("muOcc", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+                ref_ = np.asarray(getattr(oacc, k_), np.float64).reshape(-1)
+                worst_acc[k_] = float(np.max(np.abs(np.asarray(ac[k_], np.float64).reshape(-1) - ref_) / np.maximum(np.abs(ref_), 1e-3)))
+            occ_ = np.maximum(np.asarray(oacc.muOcc, np.float64), 1e-3)[:, None]
+            for k_ in ("mu", "va"):
+                ref_ = np.asarray(getattr(oacc, k_), np.float64).reshape(occ_.shape[0], -1)
+                worst_acc[k_] = float(np.max(np.abs(np.asarray(ac[k_], np.float64).reshape(ref_.shape) - ref_) / np.maximum(np.abs(ref_), occ_)))
+            assert np.array_equal(np.asarray(ac["nEgs"]).astype(np.int64), np.asarray(oacc.nEgs).astype(np.int64)), "bench: example counts differ from the oracle"
+            assert max(worst_acc.values()) <= 1e-4, "bench: accumulators differ from the oracle: %r" % worst_acc
+            del fbc, accc, m0
             out["oracle_check"] = {"utterances": n, "max_rel_diff_logprob": worst, "tolerance": tol,
+                                   "accumulators_max_rel_diff": worst_acc, "accumulators_tolerance": 1e-4,
                                    "avg_logprob_per_frame_oracle": float(np.sum(opr) / sum(s.feats[u].shape[0] for u in range(n))),
                                    "avg_logprob_per_frame_hip": float(np.sum(pr_init[:n]) / sum(s.feats[u].shape[0] for u in range(n)))}
             port = {"value": n * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",

@@ -66,7 +66,7 @@ __device__ __forceinline__ float rows_sum(float v)
 template <int NS>
 __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
 {
-   constexpr int TW = (NS + 4) * 64;                  // floats per fragment tile
+   constexpr int TW = (NS + 8) * 64;                  // floats per fragment tile: NS K-steps, the accumulators' start, the closing constant
    constexpr int PT = (TW + 255) / 256;               // floats staged per thread
    __shared__ float wbuf[2][TW];
    __shared__ int taskSh;
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
                   if (j * 256 + tid < TW) stg[j] = W[j * 256 + tid];
             }
             if (active) {
-            float w[NS + 4];
+            float w[NS + 8];
 #pragma unroll
-            for (int s = 0; s < NS + 4; s++) w[s] = wbuf[buf][s * 64 + lane];
+            for (int s = 0; s < NS + 8; s++) w[s] = wbuf[buf][s * 64 + lane];
             f4 Cx[MFMA_COL_TILES];
 #pragma unroll
             for (int ft = 0; ft < MFMA_COL_TILES; ft++) Cx[ft] = (f4){w[NS], w[NS + 1], w[NS + 2], w[NS + 3]};
@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256, 4) void k_score_mfma(ScoreArgs a)
             // log-sum-exp over the tile's 16 rows: 4 in this lane, the rest in lanes ^16, ^32, ^48
 #pragma unroll
             for (int ft = 0; ft < MFMA_COL_TILES; ft++) {
-               const f4 y = Cx[ft];
+               // the matrix unit rounds the accumulator at its own magnitude after every instruction: it starts at HALF of the expanded
+               // form's constant -0.5 sum mu^2 ivar (~ -116 at D = 39) and passes through zero on its way up; the other half and
+               // log w - 0.5 gConst are added here, once (starting at the whole constant, ~ -290, cost a factor 3 in accuracy)
+               const f4 y = Cx[ft] + (f4){w[NS + 4], w[NS + 5], w[NS + 6], w[NS + 7]};
                // the table is scaled by log2(e): y is a base-2 logarithm, so v_exp_f32 / v_log_f32 apply without a multiply
                float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
                mx = rows_max(mx);

@@ -88,8 +88,8 @@ template <typename T> static int toDevice(T **dst, const T *src, size_t n)
 // A-operand fragment table of the MFMA scoring kernel (layout: gmm_mfma.hip).  Column j of tile t of state s is
 // component stateCompOff[s] + 16*(t - stateTileOff[s]) + j; K index 4*step + kq carries dimension 2*step + (kq>>1),
 // as the x^2 coefficient -0.5*ivar for even kq and the x coefficient mean*ivar for odd kq; rows mfmaNS..mfmaNS+3 are
-// the accumulator start (log weight - 0.5*(gConst + sum mean^2*ivar)) in the C-operand layout.  Unused components
-// start at -1e30 (drop out of the sum).
+// the accumulator start -0.25*sum mean^2*ivar and rows mfmaNS+4..mfmaNS+7 the closing constant log weight - 0.5*gConst -
+// 0.25*sum mean^2*ivar, both in the C-operand layout.  Unused components close at -1e30 (drop out of the sum).
 static int mfma_refresh(htkamd_model *m)
 {
    const int D = m->D;
@@ -120,7 +120,7 @@ static int mfma_refresh(htkamd_model *m)
       HIPCHECK(hipStreamSynchronize(nullptr));
    }
    if (D > 40) return HTKAMD_OK;
-   const size_t stride = (size_t)(NS + 4) * 64;
+   const size_t stride = (size_t)(NS + 8) * 64;
    float *tab = (float *)calloc((size_t)m->nTiles * stride, sizeof(float));
    size_t t = 0;
    for (int s = 0; s < m->S; s++) {
@@ -131,15 +131,17 @@ static int mfma_refresh(htkamd_model *m)
             const int c = cb + col;
             const bool live = c < c1 && (c1 - c0 == 1 || m->h_compLogWt[c] > (float)LMINMIX);
             // accumulator start of row `col`: lane (kq = col/4, any column) register col%4, i.e. table row NS + col%4
-            float *ciRow = T + (size_t)(NS + (col & 3)) * 64 + (col >> 2) * 16;
-            if (!live) { for (int j = 0; j < 16; j++) ciRow[j] = -1.0e30f; continue; }
+            float *ciRow = T + (size_t)(NS + (col & 3)) * 64 + (col >> 2) * 16, *endRow = ciRow + 4 * 64;
+            if (!live) { for (int j = 0; j < 16; j++) { ciRow[j] = 0.0f; endRow[j] = -1.0e30f; } continue; }
             const int g = m->h_compGauss[c];
             const float *mu = m->h_mean + (size_t)g * D, *iv = m->h_ivar + (size_t)g * D;
-            double k0 = m->h_gconst[g];
-            for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+            double q = 0.0;
+            for (int i = 0; i < D; i++) q += (double)mu[i] * mu[i] * iv[i];
             const double L2E = 1.4426950408889634;           // table in base-2 logarithms (gmm_mfma.hip)
-            const float ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)m->h_compLogWt[c]) - 0.5 * k0) * L2E);
-            for (int j = 0; j < 16; j++) ciRow[j] = ci;
+            // the accumulators start at half of -0.5 sum mu^2 ivar; the rest is added after the contraction (gmm_mfma.hip)
+            const float ci = (float)(-0.25 * q * L2E);
+            const float ce = (float)(((c1 - c0 == 1 ? 0.0 : (double)m->h_compLogWt[c]) - 0.5 * (double)m->h_gconst[g] - 0.25 * q) * L2E);
+            for (int j = 0; j < 16; j++) { ciRow[j] = ci; endRow[j] = ce; }
             for (int st = 0; st < NS; st++)
                for (int kq = 0; kq < 4; kq++) {
                   const int dim = 2 * st + (kq >> 1);

@@ -210,21 +210,22 @@ __global__ void k_upd_mfma(MfmaTabArgs a, int nTiles)
    const int s = lo, c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
    const int c = c0 + 16 * (t - a.stateTileOff[s]) + col;
    const int NS = a.NS, D = a.D;
-   float *T = a.tab + (size_t)t * (NS + 4) * 64;
-   float *ciRow = T + (size_t)(NS + (col & 3)) * 64 + (col >> 2) * 16;
+   float *T = a.tab + (size_t)t * (NS + 8) * 64;
+   float *ciRow = T + (size_t)(NS + (col & 3)) * 64 + (col >> 2) * 16, *endRow = ciRow + 4 * 64;
    const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
    if (!live) {
-      for (int j = 0; j < 16; j++) ciRow[j] = -1.0e30f;
+      for (int j = 0; j < 16; j++) { ciRow[j] = 0.0f; endRow[j] = -1.0e30f; }
       for (int st = 0; st < NS; st++) for (int kq = 0; kq < 4; kq++) T[(size_t)st * 64 + kq * 16 + col] = 0.0f;
       return;
    }
    const int g = a.compGauss[c];
    const float *mu = a.mean + (size_t)g * D, *iv = a.ivar + (size_t)g * D;
-   double k0 = a.gconst[g];
-   for (int i = 0; i < D; i++) k0 += (double)mu[i] * mu[i] * iv[i];
+   double q = 0.0;
+   for (int i = 0; i < D; i++) q += (double)mu[i] * mu[i] * iv[i];
    const double L2E = 1.4426950408889634;
-   const float ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
-   for (int j = 0; j < 16; j++) ciRow[j] = ci;
+   const float ci = (float)(-0.25 * q * L2E);          // start and closing constant as in model.hip
+   const float ce = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * (double)a.gconst[g] - 0.25 * q) * L2E);
+   for (int j = 0; j < 16; j++) { ciRow[j] = ci; endRow[j] = ce; }
    for (int st = 0; st < NS; st++)
       for (int kq = 0; kq < 4; kq++) {
          const int dim = 2 * st + (kq >> 1);
