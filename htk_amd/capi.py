@@ -275,13 +275,13 @@ def fb_config(pruneInit=NOPRUNE, pruneInc=0.0, pruneLim=NOPRUNE, minFrwdP=10.0, 
 class ForwardBackward:
     """htkamd_fb holder: FBFile (HFB.c:1923) over a batch of utterances."""
 
-    def __init__(self, model: Model, debug: bool = False, force_general: bool = False, no_state_path: bool = False, stats_list: str = "auto"):
+    def __init__(self, model: Model, debug: bool = False, force_general: bool = False, no_state_path: bool = False, stats_list: str = "auto", no_lr_path: bool = False):
         """stats_list: how the mixture statistics reach the accumulators -- "auto": record list + per-Gaussian reduction,
         "tiny": a 128-record list (everything beyond it takes the direct-atomics fallback), "off": direct atomics only."""
         self.model = model
         self.h = C.c_void_p()
         check(lib().htkamd_fb_create(model.h, C.byref(self.h)), "fb_create")
-        flags = (1 if debug else 0) | (2 if force_general else 0) | (4 if no_state_path else 0) | {"auto": 0, "tiny": 8, "off": 16}[stats_list]
+        flags = (1 if debug else 0) | (2 if force_general else 0) | (4 if no_state_path else 0) | {"auto": 0, "tiny": 8, "off": 16}[stats_list] | (32 if no_lr_path else 0)
         if flags:
             check(lib().htkamd_fb_set_debug(self.h, flags), "fb_set_debug")
         self.nUtt = 0

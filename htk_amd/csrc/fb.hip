@@ -110,6 +110,7 @@ struct htkamd_fb {
    int debug;
    int forceGeneral;            // test aid: use the workgroup-per-utterance kernels even when the wave path applies
    int noStatePath;             // test aid: keep utterances off the state-per-lane kernels (fb_state.hip)
+   int noLrPath;                // test aid: keep left-to-right chains off their own kernels (fb_lr.hip): they run on fb_state.hip's
    int topoVersion;             // the model's topology version the batch tables were built against
    // host tables of the prepared batch
    std::vector<UttDesc> utt;
@@ -126,10 +127,11 @@ struct htkamd_fb {
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_tasksW, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
-   DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8
+   DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8 | left-to-right W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
-   int clsOff[10];                          // class c occupies uttList[clsOff[c] .. clsOff[c+1])
-   size_t betaWTotal;
+   int clsOff[14];                          // class c occupies uttList[clsOff[c] .. clsOff[c+1])
+   size_t betaWTotal, alphaWTotal;
+   DevBuf d_alphaW, d_qBeam, d_aBeam, d_trPart, d_hits, d_hitCtl;   // left-to-right path (fb_lr.hip)
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
    DevBuf d_rec, d_recSorted, d_recCtl;     // statistics records (kernels.h MixRec)
@@ -146,7 +148,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (!m || !out) { htkamd_set_error("fb_create: NULL argument"); return HTKAMD_EINVAL; }
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
-   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->noStatePath = 0; fb->recCapForce = 0; for (int c = 0; c < 10; c++) fb->clsOff[c] = 0;
+   fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->alphaWTotal = 0; fb->noStatePath = 0; fb->noLrPath = 0; fb->recCapForce = 0; for (int c = 0; c < 14; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 5; i++) fb->ev[i] = nullptr;
    fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
@@ -171,7 +173,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -192,6 +194,7 @@ extern "C" int htkamd_fb_set_debug(htkamd_fb *fb, int on)
    fb->forceGeneral = (on & 2) ? 1 : 0;
    fb->noStatePath = (on & 4) ? 1 : 0;
    fb->recCapForce = (on & 8) ? 128 : ((on & 16) ? -1 : 0);          // 8: a 128-record list (overflow path), 16: no record list (direct atomics)
+   fb->noLrPath = (on & 32) ? 1 : 0;
    return HTKAMD_OK;
 }
 
@@ -426,8 +429,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    fb->blockDim = nThrMax;
    {  // classes: chains of <= 64 / 128 / 256 models of <= 5 states go to the wave kernels with 1 / 2 / 4 wavefronts, the rest to
       // the general workgroup-per-utterance kernels
-      std::vector<int> cls[9];
-      size_t bw = 0;
+      std::vector<int> cls[13];
+      size_t bw = 0, aw = 0;
       for (int u = 0; u < U; u++) {
          UttDesc &d = fb->utt[u];
          // a lane per chain state (fb_state.hip) where the chain has no tee model and at most 512 emitting states; else a lane per model
@@ -436,20 +439,27 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          for (int q = 0; q < d.Q && noTee; q++) if (fb->mDms[d.q0 + q] == 0) noTee = false;
          const bool small = fb->m->maxN <= 5 && !fb->forceGeneral;
          int W = 0, kind = 0;
-         if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) { kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8; }
+         if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) {
+            kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8;
+            // every model left-to-right without skips: the kernels of fb_lr.hip (no statistics in the alpha chain, no entry-state columns)
+            bool lr = !fb->noLrPath;
+            for (int q = 0; q < d.Q && lr; q++) if (fb->m->h_transLR[fb->mTrans[d.q0 + q]] != 1) lr = false;
+            if (lr) kind = 2;
+         }
          else if (small) W = d.Q <= 64 ? 1 : d.Q <= 128 ? 2 : d.Q <= 256 ? 4 : d.Q <= 512 ? 8 : 0;
-         d.W = W; d.pad = kind; d.betaW0 = bw;
-         bw += kind ? (size_t)d.T * 2 * 64 * W : (size_t)d.T * 5 * 64 * W;
+         d.W = W; d.pad = kind; d.betaW0 = bw; d.alphaW0 = aw; d.QP = (d.Q + 7) & ~7; d.pad2 = 0;
+         bw += kind == 2 ? (size_t)d.T * 64 * W : kind ? (size_t)d.T * 2 * 64 * W : (size_t)d.T * 5 * 64 * W;
+         if (kind == 2) aw += (size_t)d.T * (64 * W + d.QP);
          const int wc = W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : W == 8 ? 3 : 4;
-         cls[(kind && W) ? 5 + wc : wc].push_back(u);
+         cls[(kind == 2 && W) ? 9 + wc : (kind && W) ? 5 + wc : wc].push_back(u);
       }
-      fb->betaWTotal = bw;
+      fb->betaWTotal = bw; fb->alphaWTotal = aw;
       // within a class the longest utterances are dispatched first (their recursions are the critical path when the batch is larger
       // than the wavefront slots of the machine)
-      for (int c = 0; c < 9; c++)
+      for (int c = 0; c < 13; c++)
          std::stable_sort(cls[c].begin(), cls[c].end(), [&](int x, int y) { return fb->utt[x].T > fb->utt[y].T; });
       fb->uttList.clear(); fb->clsOff[0] = 0;
-      for (int c = 0; c < 9; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
+      for (int c = 0; c < 13; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
       if (fb->uttList.empty()) fb->uttList.push_back(0);
    }
 
@@ -497,7 +507,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * ((beta && !wavePathPrep) ? beta : 1))) ||
-       (rc = fb->d_gam.reserve(sizeof(double) * (gam ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
+       (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
        (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))))
       return rc;
    if (fb->debug && (rc = fb->d_alpha.reserve(sizeof(double) * (beta ? beta : 1)))) return rc;
@@ -576,6 +586,18 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    if (nGeneral > 0 && ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
    if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 5 * 64)))) return rc;
    fa.betaW = (double *)fb->d_betaW.p;
+   const int nLr = fb->clsOff[13] - fb->clsOff[9];
+   size_t rows = 0;
+   if (nLr > 0) {
+      for (int c = 0; c < 4; c++) rows += (size_t)(fb->clsOff[10 + c] - fb->clsOff[9 + c]) * htkamd_stats_lr_chunks(fb->TMax) * (1 << c);
+      const size_t nfr = fb->totalFrames ? fb->totalFrames : 1;
+      if ((rc = fb->d_alphaW.reserve(sizeof(double) * (fb->alphaWTotal + 64))) || (rc = fb->d_qBeam.reserve(sizeof(int) * (nfr + 2))) ||
+          (rc = fb->d_aBeam.reserve(sizeof(int) * (nfr + 2))) || (rc = fb->d_trPart.reserve(sizeof(double) * htkamd_stats_lr_row_doubles() * (rows + 256))) ||
+          (rc = fb->d_hits.reserve(sizeof(MixHit) * (rows * htkamd_stats_lr_region_cap() + 64))) || (rc = fb->d_hitCtl.reserve(sizeof(int) * (rows + 1))))
+         return rc;
+      fa.alphaW = (double *)fb->d_alphaW.p; fa.qBeam = (int *)fb->d_qBeam.p; fa.aBeam = (int *)fb->d_aBeam.p; fa.trPart = (double *)fb->d_trPart.p;
+      fa.hits = (MixHit *)fb->d_hits.p; fa.hitCtl = (int *)fb->d_hitCtl.p; fa.nHitRegions = (int)rows; fa.hitRegionCap = htkamd_stats_lr_region_cap();
+   }
    static const int clsW[4] = {1, 2, 4, 8};
    // the longest chains first: their recursions are the critical path of the pass
    for (int pass = 0; pass < 2; pass++) {
@@ -590,6 +612,14 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[5 + c]; fc.nList = fb->clsOff[6 + c] - fb->clsOff[5 + c];
          if ((rc = pass == 0 ? htkamd_launch_beta_s(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_s(fc, clsW[c], fastLadd, s))) return rc;
       }
+      size_t rowOff = 0;
+      for (int c = 3; c >= 0; c--) {
+         fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[9 + c]; fc.nList = fb->clsOff[10 + c] - fb->clsOff[9 + c];
+         fc.trPart = fa.trPart ? fa.trPart + rowOff * htkamd_stats_lr_row_doubles() : nullptr;
+         fc.hits = fa.hits ? fa.hits + rowOff * htkamd_stats_lr_region_cap() : nullptr; fc.hitCtl = fa.hitCtl ? fa.hitCtl + rowOff : nullptr;
+         rowOff += (size_t)fc.nList * htkamd_stats_lr_chunks(fb->TMax) * clsW[c];
+         if ((rc = pass == 0 ? htkamd_launch_beta_lr(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_lr(fc, clsW[c], fastLadd, s))) return rc;
+      }
       HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }
    if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) {
@@ -601,7 +631,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
             return rc;
          fa.rec = (MixRec *)fb->d_rec.p; fa.recSorted = (MixRec *)fb->d_recSorted.p; fa.recCap = (int)cap; fa.G = m->G; fa.recCtl = (int *)fb->d_recCtl.p;
       }
-      if ((rc = htkamd_launch_mixstats(fa, s))) return rc;
+      // the dense seed array serves the utterances off the left-to-right path; those on it list their pairs (k_stats_lr -> k_mixhits)
+      if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
    }
    HIPCHECK(hipEventRecord(fb->ev[4], s));
    fb->timed = true;
@@ -665,7 +696,32 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
    const size_t n = (size_t)T * Q * maxN;
    if (beta) {
       std::vector<double> b((size_t)T * nC);
-      if (d.W > 0 && d.pad == 1) {                       // state-per-lane path: betaS[T][L] (emitting states) + betaE[T][L] (entry state at the
+      if (d.W > 0 && d.pad == 2) {                       // left-to-right path: betaS[T][L] only; the entry state's value is a_12 + b_2 + beta_2
+         const size_t Lw = (size_t)64 * d.W;             // (SetBeta with one entry transition), the exit state's the next model's entry value one frame on
+         std::vector<double> bs((size_t)T * Lw);
+         HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + d.betaW0, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));
+         std::vector<float> o((size_t)T * nS);
+         HIPCHECK(hipMemcpy(o.data(), (float *)fb->d_outp.p + d.outp0, sizeof(float) * o.size(), hipMemcpyDeviceToHost));
+         const int *mSl = fb->mSlot0.data() + d.q0, *mTp = fb->mTp.data() + d.q0;
+         auto entry = [&](int t, int q) {                // beta_1(q, t) (t 0-based)
+            const int l0 = mSl[q - 1];
+            const double aa = fb->m->h_transP[mTp[q - 1] + 1], y = bs[(size_t)t * Lw + l0];
+            if (!(aa > LSMALL && y > LSMALL)) return (double)LZERO;
+            const double v = aa + (double)o[(size_t)l0 * T + t] + y;
+            return v < LSMALL ? (double)LZERO : v;
+         };
+         for (int t = 0; t < T; t++)
+            for (int q = 1; q <= Q; q++) {
+               const int Nq = mN[q - 1], l0 = mSl[q - 1];
+               double *cell = &b[(size_t)t * nC + mC[q - 1]];
+               cell[0] = (q >= lo[t] && q <= hi[t]) ? entry(t, q) : LZERO;
+               for (int i = 2; i < Nq; i++) cell[i - 1] = bs[(size_t)t * Lw + l0 + i - 2];
+               double bN = LZERO;
+               if (t == T - 1) bN = (q == Q) ? 0.0 : LZERO;
+               else if (q < Q && q + 1 >= lo[t + 1] && q + 1 <= hi[t + 1]) bN = entry(t + 1, q + 1);
+               cell[Nq - 1] = bN;
+            }
+      } else if (d.W > 0 && d.pad == 1) {                // state-per-lane path: betaS[T][L] (emitting states) + betaE[T][L] (entry state at the
          const size_t Lw = (size_t)64 * d.W;             // model's first lane); the exit state's value is the next model's entry value one frame on
          std::vector<double> bs((size_t)T * 2 * Lw);
          HIPCHECK(hipMemcpy(bs.data(), (double *)fb->d_betaW.p + d.betaW0, sizeof(double) * bs.size(), hipMemcpyDeviceToHost));

@@ -554,20 +554,147 @@ __global__ void k_alpha(FbArgs a)
 // ------------------------------------------------------------------------------------ K4: mixture statistics
 // DT > 0: vector size known at compile time (all parameter loads of a component are issued together);
 // DT == 0: any size.
+//
+// mix_hit: UpMixParms (HFB.c:1573-1721) for up to 64/GS surviving (frame, state) pairs side by side -- GS lanes per pair (GS >= the
+// largest mixture count, a power of two), lane % GS = component.  Per lane group: `ok`, the tied state `st`, the row of the frame in
+// the feature table and the pair's seed (the state's log occupation without the component's own score, or with it for single
+// Gaussians).  Called by every lane of the wavefront; recBase / recUsed: the wavefront's block of the record list.
+template <int DT, int GS>
+__device__ __forceinline__ void mix_hit(const FbArgs &a, const bool ok, const int st, const int frameRow, const double seed, int &recBase, int &recUsed)
+{
+   const int lane = threadIdx.x & 63, sub = lane % GS;
+   const int D = DT > 0 ? DT : a.D;
+   const double minF = (double)a.minFrwdP;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   const int s = ok ? st : 0;
+   const int c0 = a.stateCompOff[s], M = ok ? a.stateCompOff[s + 1] - c0 : 0;
+   const float *xrow = a.X + (size_t)(ok ? frameRow : 0) * D;
+   // per-component posterior (lane%GS = component): x = initx + logw + prob (HFB.c:1581-1606)
+   int Mmax = M;
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(Mmax, o); Mmax = w > Mmax ? w : Mmax; }
+   for (int mb = 0; mb < Mmax; mb += GS) {
+      const int m = mb + sub;
+      bool pass = false;
+      double Lr = 0.0;
+      int g = 0;
+      if (m < M) {
+         g = a.compGauss[c0 + m];
+         if (M == 1 || a.maxM == 1) { pass = true; Lr = exp(seed); }
+         else {
+            const float wt = a.compLogWt[c0 + m];
+            if (wt > (float)LMINMIX) {
+               const float *P = a.gparam + (size_t)g * a.PS;
+               float sum = P[2 * D];
+               if (DT > 0) {
+                  // (mean, ivar) pairs, two per 16-byte load (rows are PS = 4k floats long and 16-byte aligned): a lane reads its
+                  // own 320-byte row, so every load instruction touches one cache line per lane -- half as many instructions, half
+                  // as many L1 tag look-ups as with 8-byte loads (the kernel was bound by those: ~620 line touches per hit)
+                  const float4 *P4 = (const float4 *)P;
+                  // in batches of 4 loads (8 dimensions): the kernel is a chain of dependent loads per hit, hidden only by other
+                  // wavefronts -- 180 VGPRs (all 39 pairs in flight) left room for 2 per SIMD
+                  constexpr int NQ = (DT + 1) / 2;
+#pragma unroll 1
+                  for (int q0 = 0; q0 < NQ; q0 += 4) {
+                     float4 pv[4]; float xv[8];
+#pragma unroll
+                     for (int i = 0; i < 4; i++) if (q0 + i < NQ) pv[i] = P4[q0 + i];
+#pragma unroll
+                     for (int i = 0; i < 8; i++) if (2 * q0 + i < DT) xv[i] = xrow[2 * q0 + i];
+#pragma unroll
+                     for (int i = 0; i < 8; i++)
+                        if (2 * q0 + i < DT) {
+                           const float mu = (i & 1) ? pv[i >> 1].z : pv[i >> 1].x, iv = (i & 1) ? pv[i >> 1].w : pv[i >> 1].y;
+                           const float xmm = xv[i] - mu;
+                           sum += xmm * xmm * iv;
+                        }
+                  }
+               } else {
+                  for (int i = 0; i < D; i++) {
+                     const float xmm = xrow[i] - P[2 * i];
+                     sum += xmm * xmm * P[2 * i + 1];
+                  }
+               }
+               const float prob = -0.5f * sum;
+               const double x = (seed + (double)wt) + (double)prob;
+               if (-x < minF) { pass = true; Lr = exp(x); }
+            }
+         }
+      }
+      double sumLr = pass ? Lr : 0.0;
+#pragma unroll
+      for (int o = GS / 2; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);      // within the hit's lane group
+      if (sub == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
+      // record path: list (Gaussian, frame, posterior) for the per-Gaussian reduction (k_rec_reduce).  A wavefront takes list
+      // space in blocks of 64 records (one atomic on the shared cursor per block, not per hit: a single hot address serialises
+      // in L2); what is left of a block when the next is taken, or at the end, is filled with empty records (g = -1)
+      bool stored = false;
+      if (a.rec) {
+         const unsigned long long pk = __ballot(pass);
+         if (pk) {
+            const int np = __popcll(pk);
+            if (recBase < 0 || recUsed + np > 64) {
+               if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
+               int base = 0;
+               if (lane == 0) base = atomicAdd(a.recCtl, 64);
+               base = __shfl(base, 0);
+               recBase = (base >= 0 && (long long)base + 64 <= a.recCap) ? base : -1;
+               recUsed = 0;
+            }
+            if (recBase >= 0) {
+               if (pass) {
+                  MixRec r; r.g = g; r.frame = frameRow; r.L = Lr;
+                  a.rec[recBase + recUsed + __popcll(pk & ((1ull << lane) - 1))] = r;
+                  atomicAdd(a.recCtl + 1 + g, 1);
+                  stored = true;
+               }
+               recUsed += np;
+            }
+         }
+      }
+      if (pass) {
+         if (upMu && !stored) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+         if (upVa && !stored) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+         if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+      }
+      // first-order statistics of every surviving (hit, component): the whole wave, lane = dimension
+      unsigned long long pm = __ballot(pass && !stored);        // what the list had no room for: direct atomics
+      while (pm) {
+         const int ml = __ffsll((long long)pm) - 1;
+         pm &= pm - 1;
+         const double L = __shfl(Lr, ml);
+         const int gg = __shfl(g, ml);
+         const unsigned long long xp = (unsigned long long)xrow;
+         const float *xr = (const float *)(((unsigned long long)__shfl((int)(xp >> 32), ml) << 32) | (unsigned int)__shfl((int)(xp & 0xffffffffu), ml));
+         const float *mean = a.mean + (size_t)gg * D;
+         for (int k = lane; k < D; k += 64) {
+            const float z = xr[k] - mean[k];
+            if (upMu && upVa) {                    // HFB.c:1673-1678
+               const float zl = (float)((double)z * L);
+               atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+               atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
+            } else if (upMu) {                     // HFB.c:1697-1698
+               atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
+            } else if (upVa) {                     // HFB.c:1706-1709
+               atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
+            }
+         }
+      }
+   }
+}
+
+// k_mixstats: the pairs come from the DENSE seed array gam[u][t][slot] the alpha kernels of fb_state.hip / fb_wave.hip / this file write
+// (log-zero where the MINFORPROB prune lets nothing through: ~98 % of it)
 template <int DT, int GS>
 __global__ __launch_bounds__(256, 4) void k_mixstats(FbArgs a)
 {
-   // GS lanes per hit (GS >= max mixture count, a power of two): 64/GS hits are worked on side by side, lane%GS = component
    constexpr int HPS = 64 / GS;
    __shared__ unsigned short hitIdx[4][512];
    __shared__ double hitSeed[4][512];
    const int lane = threadIdx.x & 63;
-   const int grp = lane / GS, sub = lane % GS;
+   const int grp = lane / GS;
    const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
    const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-   const int D = DT > 0 ? DT : a.D;
-   const double minF = (double)a.minFrwdP;
-   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
    int recBase = -1, recUsed = 0;                        // this wavefront's current block of the record list
    // dense scan of the seed array: 8 x 64 seeds per wave and iteration (8 independent 512-byte loads in flight)
    for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
@@ -593,139 +720,56 @@ __global__ __launch_bounds__(256, 4) void k_mixstats(FbArgs a)
        }
        count += __popcll(hm);
     }
-    {
-      for (int i0 = 0; i0 < count; i0 += HPS) {
-         const int src = (i0 + grp < count) ? i0 + grp : -1;
-         const bool have = src >= 0;
-         const size_t hidx = base0 + (have ? hIdx[src] : 0);
-         const double seed = have ? hSeed[src] : LZERO;
-         // utterance of this entry: advance from the chunk's first utterance (seeds are laid out utterance by utterance)
-         int u = cu;
-         while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
-         const UttDesc *up = a.utt + u;                      // only four fields of the descriptor are needed
-         const size_t udGam0 = up->gam0;
-         const int udSlots = up->nSlots, udSlot0 = up->slot0, udFrame0 = up->frame0;
-         const bool ok = have && a.status[u] == HTKAMD_UTT_OK;
-         const size_t rel = hidx - udGam0;
-         const int nSl = udSlots > 0 ? udSlots : 1;
-         const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
-         const int s = ok ? a.slotState[udSlot0 + slot] : 0;
-         const int c0 = a.stateCompOff[s], M = ok ? a.stateCompOff[s + 1] - c0 : 0;
-         const float *xrow = a.X + (size_t)(udFrame0 + (ok ? t0 : 0)) * D;
-         // per-component posterior (lane%GS = component): x = initx + logw + prob (HFB.c:1581-1606)
-         int Mmax = M;
-#pragma unroll
-         for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(Mmax, o); Mmax = w > Mmax ? w : Mmax; }
-         for (int mb = 0; mb < Mmax; mb += GS) {
-            const int m = mb + sub;
-            bool pass = false;
-            double Lr = 0.0;
-            int g = 0;
-            if (m < M) {
-               g = a.compGauss[c0 + m];
-               if (M == 1 || a.maxM == 1) { pass = true; Lr = exp(seed); }
-               else {
-                  const float wt = a.compLogWt[c0 + m];
-                  if (wt > (float)LMINMIX) {
-                     const float *P = a.gparam + (size_t)g * a.PS;
-                     float sum = P[2 * D];
-                     if (DT > 0) {
-                        // (mean, ivar) pairs, two per 16-byte load (rows are PS = 4k floats long and 16-byte aligned): a lane reads its
-                        // own 320-byte row, so every load instruction touches one cache line per lane -- half as many instructions, half
-                        // as many L1 tag look-ups as with 8-byte loads (the kernel was bound by those: ~620 line touches per hit)
-                        const float4 *P4 = (const float4 *)P;
-                        // in batches of 4 loads (8 dimensions): the kernel is a chain of dependent loads per hit, hidden only by other
-                        // wavefronts -- 180 VGPRs (all 39 pairs in flight) left room for 2 per SIMD
-                        constexpr int NQ = (DT + 1) / 2;
-#pragma unroll 1
-                        for (int q0 = 0; q0 < NQ; q0 += 4) {
-                           float4 pv[4]; float xv[8];
-#pragma unroll
-                           for (int i = 0; i < 4; i++) if (q0 + i < NQ) pv[i] = P4[q0 + i];
-#pragma unroll
-                           for (int i = 0; i < 8; i++) if (2 * q0 + i < DT) xv[i] = xrow[2 * q0 + i];
-#pragma unroll
-                           for (int i = 0; i < 8; i++)
-                              if (2 * q0 + i < DT) {
-                                 const float mu = (i & 1) ? pv[i >> 1].z : pv[i >> 1].x, iv = (i & 1) ? pv[i >> 1].w : pv[i >> 1].y;
-                                 const float xmm = xv[i] - mu;
-                                 sum += xmm * xmm * iv;
-                              }
-                        }
-                     } else {
-                        for (int i = 0; i < D; i++) {
-                           const float xmm = xrow[i] - P[2 * i];
-                           sum += xmm * xmm * P[2 * i + 1];
-                        }
-                     }
-                     const float prob = -0.5f * sum;
-                     const double x = (seed + (double)wt) + (double)prob;
-                     if (-x < minF) { pass = true; Lr = exp(x); }
-                  }
-               }
-            }
-            double sumLr = pass ? Lr : 0.0;
-#pragma unroll
-            for (int o = GS / 2; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);      // within the hit's lane group
-            if (sub == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
-            // record path: list (Gaussian, frame, posterior) for the per-Gaussian reduction (k_rec_reduce).  A wavefront takes list
-            // space in blocks of 64 records (one atomic on the shared cursor per block, not per hit: a single hot address serialises
-            // in L2); what is left of a block when the next is taken, or at the end, is filled with empty records (g = -1)
-            bool stored = false;
-            if (a.rec) {
-               const unsigned long long pk = __ballot(pass);
-               if (pk) {
-                  const int np = __popcll(pk);
-                  if (recBase < 0 || recUsed + np > 64) {
-                     if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
-                     int base = 0;
-                     if (lane == 0) base = atomicAdd(a.recCtl, 64);
-                     base = __shfl(base, 0);
-                     recBase = (base >= 0 && (long long)base + 64 <= a.recCap) ? base : -1;
-                     recUsed = 0;
-                  }
-                  if (recBase >= 0) {
-                     if (pass) {
-                        MixRec r; r.g = g; r.frame = udFrame0 + t0; r.L = Lr;
-                        a.rec[recBase + recUsed + __popcll(pk & ((1ull << lane) - 1))] = r;
-                        atomicAdd(a.recCtl + 1 + g, 1);
-                        stored = true;
-                     }
-                     recUsed += np;
-                  }
-               }
-            }
-            if (pass) {
-               if (upMu && !stored) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
-               if (upVa && !stored) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
-               if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
-            }
-            // first-order statistics of every surviving (hit, component): the whole wave, lane = dimension
-            unsigned long long pm = __ballot(pass && !stored);        // what the list had no room for: direct atomics
-            while (pm) {
-               const int ml = __ffsll((long long)pm) - 1;
-               pm &= pm - 1;
-               const double L = __shfl(Lr, ml);
-               const int gg = __shfl(g, ml);
-               const unsigned long long xp = (unsigned long long)xrow;
-               const float *xr = (const float *)(((unsigned long long)__shfl((int)(xp >> 32), ml) << 32) | (unsigned int)__shfl((int)(xp & 0xffffffffu), ml));
-               const float *mean = a.mean + (size_t)gg * D;
-               for (int k = lane; k < D; k += 64) {
-                  const float z = xr[k] - mean[k];
-                  if (upMu && upVa) {                    // HFB.c:1673-1678
-                     const float zl = (float)((double)z * L);
-                     atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
-                     atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
-                  } else if (upMu) {                     // HFB.c:1697-1698
-                     atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
-                  } else if (upVa) {                     // HFB.c:1706-1709
-                     atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
-                  }
-               }
-            }
+    for (int i0 = 0; i0 < count; i0 += HPS) {
+       const int src = (i0 + grp < count) ? i0 + grp : -1;
+       const bool have = src >= 0;
+       const size_t hidx = base0 + (have ? hIdx[src] : 0);
+       const double seed = have ? hSeed[src] : LZERO;
+       // utterance of this entry: advance from the chunk's first utterance (seeds are laid out utterance by utterance)
+       int u = cu;
+       while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
+       const UttDesc *up = a.utt + u;                      // only four fields of the descriptor are needed
+       const size_t udGam0 = up->gam0;
+       const int udSlots = up->nSlots, udSlot0 = up->slot0, udFrame0 = up->frame0;
+       // utterances of the left-to-right path have no seeds here (their statistics kernel lists the pairs itself: k_mixhits)
+       const bool ok = have && a.status[u] == HTKAMD_UTT_OK && up->pad != 2;
+       const size_t rel = hidx - udGam0;
+       const int nSl = udSlots > 0 ? udSlots : 1;
+       const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
+       mix_hit<DT, GS>(a, ok, ok ? a.slotState[udSlot0 + slot] : 0, udFrame0 + (ok ? t0 : 0), seed, recBase, recUsed);
+    }
+   }
+   if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
+}
+
+// k_mixhits: the pairs come as LISTS (fb_lr.hip: every wavefront of k_stats_lr owns a region of the list -- room for all its (frame,
+// state) pairs, so nothing can overflow and no cursor is shared -- and leaves the number of 16-byte records it wrote in hitCtl):
+// ~20 MB instead of the 0.5 GB seed array written and read back at the bench workload
+template <int DT, int GS>
+__global__ __launch_bounds__(256, 4) void k_mixhits(FbArgs a)
+{
+   constexpr int HPS = 64 / GS;
+   __shared__ int hitSt[4][64], hitFrame[4][64];
+   __shared__ double hitSeed[4][64];
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   const int grp = lane / GS;
+   const int nWaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+   const int waveId = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+   int recBase = -1, recUsed = 0;
+   volatile int *hSt = hitSt[wv], *hFr = hitFrame[wv];
+   volatile double *hSeed = hitSeed[wv];
+   for (int b = waveId; b < a.nHitRegions; b += nWaves) {
+      const int cnt = a.hitCtl[b];
+      const MixHit *reg = a.hits + (size_t)b * a.hitRegionCap;
+      for (int c0 = 0; c0 < cnt; c0 += 64) {
+         const int n = (cnt - c0 < 64) ? cnt - c0 : 64;
+         if (lane < n) { const MixHit h = reg[c0 + lane]; hSt[lane] = h.st; hFr[lane] = h.frame; hSeed[lane] = h.seed; }
+         for (int i0 = 0; i0 < n; i0 += HPS) {
+            const int src = (i0 + grp < n) ? i0 + grp : -1;
+            const bool have = src >= 0;
+            mix_hit<DT, GS>(a, have, have ? hSt[src] : 0, have ? hFr[src] : 0, have ? hSeed[src] : LZERO, recBase, recUsed);
          }
       }
-    }
    }
    if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
 }
@@ -873,26 +917,35 @@ int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s
    return HTKAMD_OK;
 }
 
-int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s)
+// statistics of the surviving pairs: from the dense seed array (gamTotal seeds; the utterances off the left-to-right path) and / or from
+// the hit list of k_stats_lr (a.hits: nHitsMax > 0), then the per-Gaussian reduction of the records both of them listed
+int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool listed)
 {
-   if (a_in.gamTotal == 0) return HTKAMD_OK;
-   size_t waves = (a_in.gamTotal + 511) / 512;
-   size_t blocks = (waves + 3) / 4;
-   if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
-   const dim3 grid((unsigned)blocks), block(256);
+   if (!dense && !listed) return HTKAMD_OK;
    const FbArgs &a = a_in;
    if (a.rec) HIPCHECK(hipMemsetAsync(a.recCtl, 0, sizeof(int) * (3 * ((size_t)a.G + 1) + 1), s));
-#define MIXSTATS_LAUNCH(GS) \
+#define MIX_LAUNCH(K, GS) \
    switch (a.D) { \
-   case 39: hipLaunchKernelGGL((k_mixstats<39, GS>), grid, block, 0, s, a); break; \
-   case 26: hipLaunchKernelGGL((k_mixstats<26, GS>), grid, block, 0, s, a); break; \
-   case 13: hipLaunchKernelGGL((k_mixstats<13, GS>), grid, block, 0, s, a); break; \
-   default: hipLaunchKernelGGL((k_mixstats<0, GS>), grid, block, 0, s, a); break; \
+   case 39: hipLaunchKernelGGL((K<39, GS>), grid, block, 0, s, a); break; \
+   case 26: hipLaunchKernelGGL((K<26, GS>), grid, block, 0, s, a); break; \
+   case 13: hipLaunchKernelGGL((K<13, GS>), grid, block, 0, s, a); break; \
+   default: hipLaunchKernelGGL((K<0, GS>), grid, block, 0, s, a); break; \
    }
-   if (a.maxM <= 16) { MIXSTATS_LAUNCH(16) }
-   else if (a.maxM <= 32) { MIXSTATS_LAUNCH(32) }
-   else { MIXSTATS_LAUNCH(64) }
-#undef MIXSTATS_LAUNCH
+#define MIX_LAUNCH_GS(K) \
+   if (a.maxM <= 16) { MIX_LAUNCH(K, 16) } else if (a.maxM <= 32) { MIX_LAUNCH(K, 32) } else { MIX_LAUNCH(K, 64) }
+   if (dense && a.gamTotal > 0) {
+      size_t waves = (a.gamTotal + 511) / 512;
+      size_t blocks = (waves + 3) / 4;
+      if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
+      const dim3 grid((unsigned)blocks), block(256);
+      MIX_LAUNCH_GS(k_mixstats)
+   }
+   if (listed) {
+      const dim3 grid(4096), block(256);          // grid-stride over the blocks of the list (its length is on the device)
+      MIX_LAUNCH_GS(k_mixhits)
+   }
+#undef MIX_LAUNCH_GS
+#undef MIX_LAUNCH
    HIPCHECK(hipGetLastError());
    if (a.rec) {
       const int nTile = (a.G + REC_TILE - 1) / REC_TILE;

@@ -26,6 +26,7 @@ void   htkamd_host_fix_diag_gconst(int D, const float *var, float *gconst);   /*
 void   htkamd_host_conv_diagc(size_t n, const float *var, float *ivar);        /* HUtil.c:413  */
 float  htkamd_host_mix_log_weight(float w);                                    /* HModel.c:5288 */
 int    htkamd_host_min_dur(int N, const float *tp);                            /* HFB.c:106    */
+int    htkamd_host_trans_is_lr(int N, const float *tp);                        /* left-to-right, no skips (fb_lr.hip) */
 double htkamd_host_min_log_exp(void);                                          /* HMath.c:1680 */
 
 /* device LAdd table: 4 intervals per unit of d over [minLogExp, 0] = [-23.03, 0], degree-10 Taylor rows (8 KB) */
@@ -58,6 +59,8 @@ struct htkamd_model {
    /* host copies */
    int   *h_stateCompOff, *h_compGauss, *h_transN, *h_transOff, *h_hmmTrans, *h_hmmStateOff, *h_hmmState, *h_minDur;
    int   *h_trOccOff;          /* [nT+1] prefix sum of transN */
+   unsigned char *h_transLR;   /* [nT] the matrix is left-to-right without skips: a_1j only for j = 2, a_ij only for j = i, i+1, a_iN only from N-1
+                                  (kept with h_minDur; a change bumps topoVersion) */
    float *h_mean, *h_var, *h_ivar, *h_gconst, *h_compWeight, *h_compLogWt, *h_transP;
    /* device copies */
    float *d_gparam;            /* [G*PS]: (mean[i], ivar[i]) pairs, 8-byte aligned, then gconst at [2*D] */

@@ -67,10 +67,14 @@ struct UttDesc {
    size_t betaW0;     // doubles: wave path's beta block of this utterance, betaW[betaW0 + ((t-1)*5 + i-1)*64*W + model-1]
    int W, pad;        // wavefronts working on the utterance (1, 2, 4 or 8); 0 = general kernels.  pad = 0: a lane per MODEL (fb_wave.hip,
                       // chain of <= 64*W models); pad = 1: a lane per chain STATE (fb_state.hip, <= 64*W emitting states, no tee models),
-                      // beta block = betaS[T][64*W] then betaE[T][64*W]
+                      // beta block = betaS[T][64*W] then betaE[T][64*W]; pad = 2: the same for left-to-right chains (fb_lr.hip), beta block =
+                      // betaS[T][64*W], alpha block (alphaW0) = alphaS[T][64*W] then alphaE[T][QP]
+   size_t alphaW0;    // doubles: the utterance's block in alphaW (pad = 2)
+   int QP, pad2;      // Q rounded up to a multiple of 8
 };
 
 struct MixRec { int g, frame; double L; };          // posterior L of Gaussian g at row `frame` of the feature table
+struct MixHit { int st, frame; double seed; };      // a (frame, state) pair the MINFORPROB prune lets through: tied state, row of the feature table, seed
 
 struct FbArgs {
    const UttDesc *utt;
@@ -92,6 +96,9 @@ struct FbArgs {
    float *outp;
    double *beta, *gam, *alphaDbg;    // alphaDbg: NULL unless debugging, layout as beta
    double *betaW;                    // wave path: beta per utterance as [t-1][state 0..4][64*W lanes] from UttDesc::betaW0 (coalesced per state)
+   double *alphaW;                   // left-to-right path (fb_lr.hip): the alpha columns, UttDesc::alphaW0
+   int *qBeam, *aBeam;               // left-to-right path: per frame lo | hi << 16 of the beta / alpha beam
+   double *trPart;                   // left-to-right path: partial transition counts, a row per (utterance, chunk of frames, wavefront)
    double *pr;                       // [nUtt]
    int *status;                      // [nUtt]
    // model tables for the statistics kernel
@@ -113,16 +120,26 @@ struct FbArgs {
    MixRec *rec, *recSorted;
    int recCap, G;
    int *recCtl;                      // [0] number of records asked for (may exceed recCap), then gCnt[G+1], gStart[G+1], gCur[G+1]
+   // left-to-right path: the surviving (frame, state) pairs as a list (k_stats_lr -> k_mixhits) instead of the dense seed array
+   MixHit *hits;                     // region r (one per wavefront of k_stats_lr, numbered like the rows of trPart): hits[r * hitRegionCap ...]
+   int *hitCtl;                      // [r] records in region r
+   int nHitRegions, hitRegionCap;
 };
 
 int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
-int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s);
+int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s, bool dense, bool listed);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
 // state-per-lane fast path (fb_state.hip): chains of <= 512 emitting states, models of <= 5 states, no tee models
 int htkamd_launch_beta_s(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_alpha_s(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s);
+// left-to-right chains (fb_lr.hip): state-per-lane recursions without statistics + frame-parallel statistics
+int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
+int htkamd_launch_alpha_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
+int htkamd_stats_lr_chunks(int TMax);
+size_t htkamd_stats_lr_row_doubles(void);
+int htkamd_stats_lr_region_cap(void);
 int htkamd_launch_alpha_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 
 #endif

@@ -169,6 +169,8 @@ static int model_refresh(htkamd_model *m, bool derive = true)
    for (int t = 0; t < m->nT; t++) {
       const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
       if (md != m->h_minDur[t]) { m->h_minDur[t] = md; m->topoVersion++; }
+      const unsigned char lr = (unsigned char)htkamd_host_trans_is_lr(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+      if (lr != m->h_transLR[t]) { m->h_transLR[t] = lr; m->topoVersion++; }
    }
    float *gp = (float *)calloc((size_t)m->G * PS, sizeof(float));
    for (int g = 0; g < m->G; g++) {
@@ -243,6 +245,8 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
    m->h_hmmState = dupHost(d->hmmState, (size_t)d->hmmStateOff[m->H]);
    m->h_minDur = dupHost((const int *)nullptr, (size_t)m->nT);
    for (int t = 0; t < m->nT; t++) m->h_minDur[t] = -1;
+   m->h_transLR = (unsigned char *)malloc((size_t)(m->nT ? m->nT : 1));
+   for (int t = 0; t < m->nT; t++) m->h_transLR[t] = 2;          // unknown: model_refresh sets it
    m->h_trOccOff = dupHost((const int *)nullptr, (size_t)m->nT + 1);
    m->h_gconst = dupHost(d->gconst, (size_t)m->G);
    if (!d->gconst)                                   // CheckMix: gConst fixed at load (HModel.c:206-208)
@@ -293,7 +297,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
 {
    if (!m) return;
    free(m->h_stateCompOff); free(m->h_compGauss); free(m->h_transN); free(m->h_transOff); free(m->h_hmmTrans);
-   free(m->h_hmmStateOff); free(m->h_hmmState); free(m->h_minDur); free(m->h_trOccOff);
+   free(m->h_hmmStateOff); free(m->h_hmmState); free(m->h_minDur); free(m->h_transLR); free(m->h_trOccOff);
    free(m->h_mean); free(m->h_var); free(m->h_ivar); free(m->h_gconst); free(m->h_compWeight); free(m->h_compLogWt); free(m->h_transP);
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);

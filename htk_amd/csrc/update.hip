@@ -311,6 +311,8 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    for (int t = 0; t < m->nT; t++) {
       const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
       if (md != m->h_minDur[t]) { m->h_minDur[t] = md; m->topoVersion++; }
+      const unsigned char lr = (unsigned char)htkamd_host_trans_is_lr(m->h_transN[t], m->h_transP + m->h_transOff[t]);
+      if (lr != m->h_transLR[t]) { m->h_transLR[t] = lr; m->topoVersion++; }
    }
    if (stats) {
       stats->nFloorVar = hst[0]; stats->nFloorVarMix = hst[1]; stats->nSkippedHmm = hst[2];

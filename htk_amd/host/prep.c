@@ -132,3 +132,18 @@ void htkamd_host_build_ladd_table(double *tab)
       }
    }
 }
+
+/* Left-to-right without skips (fb_lr.hip): the entry state reaches state 2 only, emitting state i reaches i and i+1 only, the exit
+   state is reached from state N-1 only; no tee transition.  Transitions inside the pattern may be log-zero. */
+int htkamd_host_trans_is_lr(int N, const float *tp)
+{
+   if (N < 3 || N > 5) return 0;
+   for (int j = 3; j <= N; j++) if (tp[j - 1] > (float)LSMALL) return 0;                   /* a_1j, j > 2 (j = N: tee) */
+   for (int i = 2; i <= N - 1; i++)
+      for (int j = 2; j <= N; j++) {
+         const int ok = (j == i) || (j == i + 1);                                           /* i+1 == N for the last emitting state */
+         if (!ok && tp[(i - 1) * N + (j - 1)] > (float)LSMALL) return 0;
+      }
+   return 1;
+}
+

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 CASES = ["fb_small", "fb_small_prune", "fb_topo", "fb_topo_prune"]
 
 
-PATHS = ["state", "wave", "general"]        # lane per chain state (fb_state.hip) | lane per model (fb_wave.hip) | workgroup per utterance
+PATHS = ["lr", "state", "wave", "general"]  # left-to-right chains on fb_lr.hip where the set allows (else as "state") | lane per chain state (fb_state.hip) | lane per model (fb_wave.hip) | workgroup per utterance
 
 
 def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, scoreMode=0, path=None, stats_list="auto"):
@@ -21,7 +21,7 @@ def run_fb(native, pk, utts, prune=None, debug=True, general=False, uFlags=15, s
     dX = native.DevArray(X)
     if path is not None:
         general = path == "general"
-    fb = native.ForwardBackward(model, debug=debug, force_general=general, no_state_path=(path == "wave"), stats_list=stats_list)
+    fb = native.ForwardBackward(model, debug=debug, force_general=general, no_state_path=(path == "wave"), stats_list=stats_list, no_lr_path=(path == "state"))
     acc = native.Accs(model)
     fb.prepare(dX.ptr.value, frameOff, labOff, labs)
     fb.execute(native.fb_config(uFlags=uFlags, scoreMode=scoreMode, **(prune or {})), acc)
