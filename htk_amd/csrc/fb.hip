@@ -689,6 +689,11 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
    HIPCHECK(hipMemcpy(hi.data(), (short *)fb->d_qHi.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
    HIPCHECK(hipMemcpy(alo.data(), (short *)fb->d_aLo.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
    HIPCHECK(hipMemcpy(ahi.data(), (short *)fb->d_aHi.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
+   if (d.W > 0 && d.pad == 2) {                          // left-to-right path: the alpha beam comes as the first lanes of its first and last model
+      std::vector<int> ab(T);
+      HIPCHECK(hipMemcpy(ab.data(), (int *)fb->d_aBeam.p + d.frame0, sizeof(int) * T, hipMemcpyDeviceToHost));
+      for (int t = 0; t < T; t++) { alo[t] = fb->sQ[d.slot0 + (ab[t] & 0xffff)]; ahi[t] = fb->sQ[d.slot0 + ((ab[t] >> 16) & 0xffff)]; }
+   }
    for (int t = 0; t < T; t++) {
       if (qLo) qLo[t] = lo[t]; if (qHi) qHi[t] = hi[t]; if (aLo) aLo[t] = alo[t]; if (aHi) aHi[t] = ahi[t];
    }

@@ -253,17 +253,20 @@ __global__ __launch_bounds__(64 * W) void k_beta_lr(FbArgs a)
 }
 
 // ------------------------------------------------------------------------------------ K3r: alpha (the chain only)
+// ONE workgroup barrier per step.  The alpha beam of column t (HFB.c:699-722) is decided by MaxModelProb of column t-1, one bit per
+// model -- a ballot over the workgroup's wavefronts, i.e. an exchange of its own.  Here the ballot word of a wavefront travels with the
+// column exchange of the SAME step: every lane computes its alpha_j(t) before the beam is known, publishes it unmasked together with
+// the ballot, and after the barrier everybody derives the beam, masks its own value and masks what it reads of its neighbour (a lane
+// knows the first lane of its neighbour's model, which is what the beam is expressed in).
 template <int W, bool FAST>
 __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
 {
    constexpr int L = 64 * W, LP = L + 2 * SPAD;
    __shared__ double ltab[FAST ? 1 : LADD_TAB_DOUBLES];
-   __shared__ double xalpha[2][LP];                    // alpha_j(t) by step parity
+   __shared__ double xalpha[2][LP];                    // alpha_j(t) by step parity (unmasked for t >= 2)
    __shared__ double xsum[2][LP];                      // alpha_j(t) + beta_j(t) inside the beta beam (MaxModelProb)
+   __shared__ unsigned long long bslot[2][8];          // the wavefronts' ballot words, by step parity
    __shared__ float stage[W][2 * 64 * 4];
-   __shared__ unsigned long long gx[2 * W * 4];
-   __shared__ float ga1[64 * W];
-   __shared__ short sqOf[L];
    __shared__ short flOf[L + 2];
    if constexpr (!FAST) ladd_table_to_lds(ltab, a.laddTab);
    const int gl = threadIdx.x, lane = gl & 63, wv = gl >> 6;
@@ -275,7 +278,6 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
       if (gl == 0) atomicAdd(a.acc + a.lay.nUttSkipped, 1.0);
       return;
    }
-   Grp<W> g; g.x = gx; g.a1 = ga1; g.wave = wv; g.lane = lane; g.ph = 0;
    const int T = ud.T, Q = ud.Q, nS = ud.nSlots, nC = ud.nCells;
    const bool valid = gl < nS;
    LrRegs s;
@@ -284,31 +286,42 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
 #pragma unroll
       for (int k = 0; k < 2; k++) { xalpha[k][i] = LZERO; xsum[k][i] = LZERO; }
    }
-   sqOf[gl] = (short)(valid ? s.q : Q + 1);
    if (valid && s.first) flOf[s.q] = (short)gl;
    if (gl == 0) { flOf[Q + 1] = (short)nS; flOf[0] = 0; }
+   {  // one bit per model, at its first lane (loop-invariant)
+      const unsigned long long b = __ballot(valid && s.first);
+      if (lane == 0) bslot[0][wv] = b;
+   }
    __syncthreads();
-   const MaskW<W> firsts = g.ballot(valid && s.first);   // loop-invariant: one bit per model, at its first lane
+   MaskW<W> firsts;
+#pragma unroll
+   for (int k = 0; k < W; k++) firsts.w[k] = bslot[0][k];
+   __syncthreads();
    const int q = s.q, N = s.N, j = s.j;
    const int cHmm = valid ? a.mHmm[s.mi] : 0, mc0 = valid ? a.mCell0[s.mi] : 0;
    cint_lr *qBeam = (cint_lr *)(a.qBeam + ud.frame0 - 1);     // final beta beams, 1-based t, written by the beta launch before this one
-   short *gaLo = a.aLo + ud.frame0 - 1, *gaHi = a.aHi + ud.frame0 - 1;
-   int *gaBeam = a.aBeam + ud.frame0 - 1;
+   int *gaBeam = a.aBeam + ud.frame0 - 1;                      // alpha beams as FIRST LANES: first lane of model sq | first lane of model eq << 16
    ObsRow st;
    st.lds = stage[wv]; st.lane = lane; st.R = (f4s)(0.f);
    st.row = valid ? a.outp + ud.outp0 + (size_t)gl * T : nullptr;
    const double mle = a.minLogExp, pr = a.pr[u];
    const double minF = (double)a.minFrwdP;
    const float aA = s.first ? s.aEntry : s.aPrev;        // the transition into the state from the lane before it / from the entry state
+   const int myFirst = gl - (j - 2);                     // first lane of the own model
+   // first lane of the model of the lane before this one (what its membership of the beam is decided by)
+   int prevFirst = myFirst;
+   if (valid && s.first && q > 1) prevFirst = flOf[q - 1];
 #define ladd(x, y) ladd_sel<FAST>((x), (y), mle, ltab)
 
    double aJ = LZERO, aE = LZERO, aEnext = LZERO;        // alpha_j(t); alpha_1(q,t); alpha_1(q,t+1) = exit value of the model before, column t
-   double yPrev = LZERO;                                 // alpha of the lane before this one in the column before
+   double yPrev = LZERO;                                 // alpha of the lane before this one in the column before (log-zero outside that column's beam)
    double xpre = LZERO;
    double bT = LZERO, bT1 = LZERO, bT2 = LZERO;          // beta of frames t, t+1 and (in flight) t+2
    float oT = 0.f, oT1 = 0.f;
    int w1 = qBeam[1], w2 = (T >= 2) ? qBeam[2] : 1, w3 = 1;
    int lo0 = 1, hi0 = 0, lo1 = w1 & 0xffff, hi1 = w1 >> 16, lo2 = w2 & 0xffff, hi2 = (T >= 2) ? (w2 >> 16) : 0;
+   double *pS = valid ? &ALPHA_S(1) : nullptr;           // this lane's place in the stored columns, advanced by L per step
+   double *pE = (valid && s.first) ? &ALPHA_E(1, q) : nullptr;
    if (valid) {
       bT = BETA_S(1);
       if (T >= 2) bT1 = BETA_S(2);
@@ -316,19 +329,24 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    st.load(0); st.park(0);
    if (T > 4) st.load(1);
    oT = st.get(0); if (T >= 2) oT1 = st.get(1);
-   int eq = hi1, err = 0;
+   int err = 0;
    double mmpA = LZERO;                                  // MaxModelProb of this model in the column just finished (first lane)
-   const int myFirst = gl - (j - 2);                     // first lane of the own model
-   int fLo0 = 0, fLo1 = flOf[lo1], fHi1 = flOf[hi1 > 0 ? hi1 : 1], fE0 = 0, slNow = 0, elNow = 0;
+   int fLo0 = 0, fLo1 = flOf[lo1], fHi1 = flOf[hi1 > 0 ? hi1 : 1], fE0 = 0;
+   double eT = LZERO, eT1 = LZERO;                       // entry-state beta of the own model in columns t, t+1 (first lane)
+   if (valid && s.first) { eT = entry_beta<FAST>(s.aEntry, (double)oT, bT); if (T >= 2) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1); }
 
    for (int t = 1; t <= T; t++) {
       if (t + 2 <= T) {                                  // request column t+2
          w3 = qBeam[t + 2];
          if (valid) bT2 = BETA_S(t + 2);
       }
+      const int par = t & 1;
+      const bool inB = valid && q >= lo1 && q <= hi1;    // in the beta beam of t
       bool in;
+      int sl = 0, el = 0;
       if (t == 1) {
          // ---- InitAlpha (HFB.c:616-651): without tee models only the first model starts
+         const int eq = hi1;
          double a1 = 0.0;
          for (int k = 2; k <= q && k <= eq; k++) a1 += (double)(float)LZERO;
          in = valid && q <= eq;
@@ -338,55 +356,56 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
             xpre = aE + aa;
             aJ = (aa > LSMALL) ? xpre + (double)oT : LZERO;
          }
+         sl = 0; el = fHi1;
+         xalpha[par][SPAD + gl] = in ? aJ : LZERO;
+         xsum[par][SPAD + gl] = inB ? aJ + bT : LZERO;
+         xsync<W>();
+         yPrev = xalpha[par][SPAD + gl - 1];
       } else {
-         // ---- alpha beam (HFB.c:699-722) from MaxModelProb of column t-1: one bit per model at its first lane.  The reference's
-         // comparisons of model numbers are made on the models' first lanes (F(x) = flOf[x] is increasing in x): the bounds F(lo), F(hi)
-         // of the beta beams involved were looked up a step ahead, so that nothing here waits for LDS after the ballot.
-         const MaskW<W> kept = firsts & ~g.ballot(valid && s.first && (pr - mmpA > minF));
+         // ---- this wavefront's word of the ballot on MaxModelProb of column t-1
+         const unsigned long long bal = __ballot(valid && s.first && (pr - mmpA > minF));
+         if constexpr (W > 1) { if (lane == 0) bslot[par][wv] = bal; }
+         // ---- alpha column t (HFB.c:729-771) as if the state were in the beam: entry term (first lane) or the state before (other
+         // lanes), then the state itself
+         const double a1 = (q == 1) ? LZERO : aEnext;                // alpha_1(q,t) = alpha_N(q-1,t-1)
+         double x;
+         if constexpr (FAST) {
+            const double tA = (s.first ? a1 : yPrev) + (double)aA;
+            x = ladd_fast(tA, aJ + (double)s.aSelf);
+         } else {
+            x = s.first ? (((double)s.aEntry > LSMALL) ? (double)s.aEntry + a1 : LZERO) : LZERO;
+            if (!s.first && (double)s.aPrev > LSMALL && yPrev > LSMALL) x = ladd(x, yPrev + (double)s.aPrev);
+            if ((double)s.aSelf > LSMALL && aJ > LSMALL) x = ladd(x, aJ + (double)s.aSelf);
+         }
+         const double aJn = x + (double)oT;
+         xalpha[par][SPAD + gl] = aJn;
+         xsum[par][SPAD + gl] = inB ? aJn + bT : LZERO;
+         xsync<W>();
+         // ---- alpha beam (HFB.c:699-722): the reference's comparisons of model numbers are made on the models' first lanes (F(x) =
+         // flOf[x] is increasing in x); the bounds F(lo), F(hi) of the beta beams involved were looked up a step ahead
+         MaskW<W> kept;
+         if constexpr (W == 1) kept.w[0] = firsts.w[0] & ~bal;
+         else {
+#pragma unroll
+            for (int k = 0; k < W; k++) kept.w[k] = firsts.w[k] & ~bslot[par][k];
+         }
          const int slane = (kept & MaskW<W>::range(fLo0, L - 1)).lowest();             // first model >= qLo[t-1] that is kept
          if (slane < 0 || slane > fHi1) { err = 1; break; }                            // sq > qHi[t]
-         const int sl = (slane < fLo1) ? fLo1 : slane;                                 // start-point below the beta beam: pulled back
+         sl = (slane < fLo1) ? fLo1 : slane;                                           // start-point below the beta beam: pulled back
          const int elane = (kept & MaskW<W>::range(0, fE0 - 1)).highest();             // last kept model <= min(qHi[t-1] + 1, Q)
          if (elane < 0 || elane < sl) { err = 1; break; }
-         const int el = (elane > fHi1) ? fHi1 : elane;
-         slNow = sl; elNow = el;
-         // ---- alpha column t (HFB.c:729-771): entry term (first lane) or the state before (other lanes), then the state itself
+         el = (elane > fHi1) ? fHi1 : elane;
          in = valid && myFirst >= sl && myFirst <= el;
-         if (valid && !in) { aJ = LZERO; aE = LZERO; }
-         if (in) {
-            const double a1 = (q == 1) ? LZERO : aEnext;             // alpha_1(q,t) = alpha_N(q-1,t-1)
-            aE = a1;
-            double x;
-            if constexpr (FAST) {
-               const double tA = (s.first ? a1 : yPrev) + (double)aA;
-               x = ladd_fast(tA, aJ + (double)s.aSelf);
-            } else {
-               x = s.first ? (((double)s.aEntry > LSMALL) ? (double)s.aEntry + a1 : LZERO) : LZERO;
-               if (!s.first && (double)s.aPrev > LSMALL && yPrev > LSMALL) x = ladd(x, yPrev + (double)s.aPrev);
-               if ((double)s.aSelf > LSMALL && aJ > LSMALL) x = ladd(x, aJ + (double)s.aSelf);
-            }
-            xpre = x;
-            aJ = x + (double)oT;
-         }
+         aJ = in ? aJn : LZERO; aE = in ? a1 : LZERO; xpre = x;
+         const bool inPrev = prevFirst >= sl && prevFirst <= el;
+         const double yp = xalpha[par][SPAD + gl - 1];
+         yPrev = inPrev ? yp : LZERO;
       }
-      // the beam as model numbers, for the statistics kernel and the callers: the models whose first lanes bound it know their numbers
-      if (t == 1) { if (gl == 0) { gaLo[1] = 1; gaHi[1] = (short)eq; gaBeam[1] = 1 | (eq << 16); } }
-      else {
-         if (gl == slNow) { gaLo[t] = (short)q; ((short *)(gaBeam + t))[0] = (short)q; }
-         if (gl == elNow) { gaHi[t] = (short)q; ((short *)(gaBeam + t))[1] = (short)q; }
-      }
-
-      // ---- the one exchange of the step: alpha_j(t), alpha_j + beta_j (MaxModelProb)
-      const bool inB = valid && q >= lo1 && q <= hi1;    // in the beta beam of t
-      const int par = t & 1;
-      xalpha[par][SPAD + gl] = in ? aJ : LZERO;
-      xsum[par][SPAD + gl] = inB ? aJ + bT : LZERO;
+      if (gl == 0) gaBeam[t] = sl | (el << 16);
       if (valid) {
-         ALPHA_S(t) = xpre;
-         if (s.first) ALPHA_E(t, q) = aE;
+         *pS = xpre; pS += L;
+         if (s.first) { *pE = aE; pE += ud.QP; }
       }
-      xsync<W>();
-      yPrev = xalpha[par][SPAD + gl - 1];
       // exit value of the model BEFORE this one in column t (HFB.c:762-769 there): alpha_1 of this model in column t+1
       double aXp;
       if constexpr (FAST) aXp = yPrev + (double)s.aExitPrev;
@@ -404,15 +423,17 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
       if (valid && s.first) {
          double mm = LZERO;
          if (inB) {
-            mm = aE + entry_beta<FAST>(s.aEntry, (double)oT, bT);          // i = 1
+            // (outside the alpha beam every term is a log-zero plus something: the model is not kept, whatever the sum)
+            mm = aE + eT;                                // i = 1
             const double *xs = xsum[par] + SPAD + gl;
 #pragma unroll
             for (int k = 0; k < 3; k++) if (2 + k <= N - 1) { const double v = xs[k]; if (v > mm) mm = v; }
+            if (!in) mm = LZERO;                         // the published sums were not masked by the alpha beam
          }
          // alpha_N + beta_N of the model before; its beta_N(t) is this model's beta_1(t+1) inside the beam of t+1
          double prevExit = LZERO;
          if (q > 1 && q - 1 >= lo1 && q - 1 <= hi1) {
-            const double bNp = (t == T) ? LZERO : ((q >= lo2 && q <= hi2) ? entry_beta<FAST>(s.aEntry, (double)oT1, bT1) : LZERO);
+            const double bNp = (t == T) ? LZERO : ((q >= lo2 && q <= hi2) ? eT1 : LZERO);
             prevExit = aXp + bNp;
          }
          mmpA = (prevExit > mm) ? prevExit : mm;
@@ -426,6 +447,8 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
          if ((f & 3) == 0) { st.park(f >> 2); if (4 * ((f >> 2) + 1) < T) st.load((f >> 2) + 1); }
          oT1 = st.get(f);
       }
+      eT = eT1;
+      if (valid && s.first && t + 2 <= T) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1);
       lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = (t + 2 <= T) ? (w3 >> 16) : 0;
       // first lanes of the models that bound the next step's beam decisions (hi1 may be 0 past the last frame: the step is not taken)
       fLo0 = fLo1;
@@ -478,6 +501,7 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
    LrRegs s;
    load_lr(s, a, ud, gl, valid);
    const int q = s.q;
+   const int myFirst = gl - (s.j - 2);
    // scores: the lane's own row, frames t0 .. min(T, t1+1)
    {
       const int nf = ((t1 + 1 < T) ? t1 + 1 : T) - t0 + 1;
@@ -531,8 +555,8 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
       for (int k = 0; k < 4; k++) {
       const int t = tb + k;
       if (t > t1) break;
-      const int sq = wav[k] & 0xffff, eq = wav[k] >> 16, lo2 = wbv[k] & 0xffff, hi2 = (t < T) ? (wbv[k] >> 16) : 0;
-      const bool inBeam = valid && q >= sq && q <= eq;
+      const int sl = wav[k] & 0xffff, el = wav[k] >> 16, lo2 = wbv[k] & 0xffff, hi2 = (t < T) ? (wbv[k] >> 16) : 0;
+      const bool inBeam = valid && myFirst >= sl && myFirst <= el;          // the alpha beam comes as the first lanes of its first and last model
       const bool bqt1ok = (t < T) && q >= lo2 && q <= hi2;
       const double xp = xpv[k], aE = aEv[k], bT = bv[k], bT1 = bv[k + 1], bN1 = bnv[k];
       const double oT = (double)orow[t - t0], oT1 = (double)orow[t - t0 + 1], oN1 = (double)orow[OS + t - t0 + 1];
