@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
 FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                                    # HBM3E, MI355X_MICROARCH.md
+PROFILE_TRAFFIC = "r03_traffic.json"                     # profiles/: PMC passes of this round's kernels (tools/prof_r03.sh)
 
 
 def cpu_baseline(s, pk, budget_s: float):
@@ -101,8 +103,27 @@ def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def cgroup_cpu_quota():
+    """CPUs the container's cgroup grants (cpu.max of cgroup v2, cfs quota of v1), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def host_cores() -> int:
-    """Cores this process may use (the reference is run as that many -p workers, capped at the physical core count)."""
+    """Cores this process may use: the affinity mask, capped at the physical core count and at the cgroup's CPU quota (the reference is
+    run as that many -p workers)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         import psutil
@@ -111,6 +132,9 @@ def host_cores() -> int:
             n = min(n, ph)
     except Exception:  # noqa: BLE001
         pass
+    q = cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q)))
     return max(1, n)
 
 
@@ -135,6 +159,7 @@ def main():
     ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the reference CPU baseline (0 = one per physical host core)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--dump-model", default=None, help="rank 0 writes the model of the last iteration (npz: mean, var, compWeight, transP) -- the multi-GPU tests compare it over rank counts")
     args = ap.parse_args()
 
     import torch
@@ -160,9 +185,12 @@ def main():
 
     D = 39
     # same model on every rank (model_seed), a different 1250-utterance shard per rank (seed)
-    if args.scaling == "strong":                             # config[2] as one job: rank r takes utterances r, r+world, ... (HERest -p semantics)
-        args.utts = (args.total_utts - rank + world - 1) // world
-    s = synth.generate_fast(args.states, args.mix, args.phones, args.utts, args.frames, seed=1000 + rank, model_seed=3)
+    if args.scaling == "strong":                             # config[2] as ONE job: rank r takes utterances r, r+world, ... of it (HERest -p semantics)
+        ids = range(rank, args.total_utts, world)
+        args.utts = len(ids)
+        s = synth.generate_fast(args.states, args.mix, args.phones, 0, args.frames, seed=1000, model_seed=3, utt_ids=ids)
+    else:
+        s = synth.generate_fast(args.states, args.mix, args.phones, args.utts, args.frames, seed=1000 + rank, model_seed=3)
     pk = s.packed()
     model = capi.Model(pk)
     accs = capi.Accs(model)
@@ -264,13 +292,13 @@ def main():
 
     for i in range(args.warmup):
         em_iteration(False)
-    ktimes = np.zeros(4)
+    ktimes = np.zeros(5)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         pr, st, st_upd, kk = em_iteration(True)
         for ch in chunks:
-            ktimes += np.array(ch["fbs"][kk].kernel_times())                    # per kernel: summed over the iteration's chunks
+            ktimes += np.array(ch["fbs"][kk].kernel_times5())                   # per kernel: summed over the iteration's chunks
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -292,7 +320,7 @@ def main():
         torch.cuda.synchronize(); tl = time.perf_counter()
         acc1.zero(sptr); fb1.prepare(dX.data_ptr(), frameOff, labOff, labs, sptr); fb1.execute(cfg, acc1, sptr); fb1.results(sptr)
         lat.append(time.perf_counter() - tl)
-    ktimes_solo = np.array(fb1.kernel_times())
+    ktimes_solo = np.array(fb1.kernel_times5())
     torch.cuda.synchronize()
     units_total = float(a["nEval"]) if world > 1 else float(units_local)
     utts_total = float(a["nUttDone"])
@@ -301,18 +329,33 @@ def main():
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
         kname = {"exact": "k_score_exact<39>", "fastest": "k_score_bf16<3>"}.get(args.score, "k_score_mfma<20>")
-        traffic = None                                       # HBM-side bytes per launch from the committed PMC pass, same workload only
+        # HBM-side bytes per launch of every kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/prof_r03.sh),
+        # same workload only
+        traffic_of = {}
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02e_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)))
             w = tj["workload"]
             if (w["states"], w["mix"], w["utts_per_gpu"], w["frames"], w.get("chunks", 1)) == (args.states, args.mix, args.utts, args.frames, NCH):
-                k = tj["kernels"][kname]
-                traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+                for kn, k in tj["kernels"].items():
+                    traffic_of[kn.split("<")[0]] = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
         except (OSError, KeyError, ValueError):
-            traffic = None
-        # the scoring kernel's launches of one iteration (one per chunk): algorithmic flops of the iteration / summed dispatch time
+            traffic_of = {}
+        # Per kernel of the pass (its launches of one iteration, one per chunk: algorithmic work of the iteration / summed duration).
+        # Scoring: SURVEY §8(d)'s M (4D + 8) flop per frame-state against the fp32 matrix peak.  Recursions: §8(d)'s 36 bytes per
+        # in-beam frame-state against HBM -- the score read and the beta column written in the beta pass (12), the beta column read and the
+        # alpha column written in the alpha pass (16), the alpha column read back by the frame-parallel statistics (8).
         k1 = float(ktimes[0])
         achieved = units_local * flop_unit / k1 / 1e12 if k1 > 0 else 0.0
+        per_kernel = {"score": {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                                "ms": k1 * 1e3, "traffic": traffic_of.get(kname.split("<")[0]), "flop_per_unit": flop_unit}}
+        for key_, ki, kn, bytes_unit in (("beta", 1, "k_beta_lr", 12), ("alpha", 2, "k_alpha_lr", 16), ("stats", 3, "k_stats_lr", 8)):
+            tk = float(ktimes[ki])
+            ach = units_local * bytes_unit / tk / 1e9 if tk > 0 else 0.0
+            per_kernel[key_] = {"kernel": kn, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "ms": tk * 1e3, "traffic": traffic_of.get(kn), "bytes_per_unit": bytes_unit}
+        per_kernel["mix"] = {"kernel": "k_mixhits + k_rec_*", "ms": float(ktimes[4]) * 1e3, "traffic": traffic_of.get("k_mixhits"),
+                             "note": "UpMixParms on the ~2 % of (frame, state) pairs the MINFORPROB prune lets through: no algorithmic unit in SURVEY §8(d)"}
+        dom = max(("score", "beta", "alpha", "stats"), key=lambda k_: per_kernel[k_]["ms"])
         out = {
             "metric": "herest_gmm_frame_state_loglik_per_sec",
             "value": value,
@@ -340,23 +383,25 @@ def main():
             "avg_logprob_per_frame": float(a_init["totalPr"] / a_init["totalT"]) if a_init["totalT"] else None,
             "avg_logprob_per_frame_last_iteration": float(a["totalPr"] / a["totalT"]) if a["totalT"] else None,
             "update_stats_last_iteration": st_upd,
-            "kernel_ms": {"score": k1 * 1e3, "beta": ktimes[1] * 1e3, "alpha_stats": ktimes[2] * 1e3, "mix_stats": ktimes[3] * 1e3},
+            "kernel_ms": {"score": k1 * 1e3, "beta": ktimes[1] * 1e3, "alpha": ktimes[2] * 1e3, "stats": ktimes[3] * 1e3, "mix_stats": ktimes[4] * 1e3},
             "score_mode": args.score,
             "streams": len(lanes),
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "flop_per_unit": flop_unit, "units_per_launch": units_local / NCH, "launches_per_step": NCH},
+            # the kernel with the largest total time in the timed iterations
+            "roofline": dict(per_kernel[dom], units_per_launch=units_local / NCH, launches_per_step=NCH),
+            "roofline_kernels": per_kernel,
         }
         if args.score == "fastest":
-            # what the matrix pipe executes for it: six bf16 piece products over K = 2D padded to a multiple of 32, per component
-            kpad = ((2 * D + 31) // 32) * 32
+            # what the matrix pipe executes for it: six bf16 piece products over three K chunks of 32 (13 dimensions as (x^2, x) pairs + the
+            # chunk's constant, padded), per component
+            kpad = ((D + 14) // 15) * 32
             exe = units_local * args.mix * kpad * 2 * 6 / k1 / 1e12 if k1 > 0 else 0.0
-            out["roofline"]["executed"] = {"pipe": "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces", "achieved": exe, "peak": 2500.0, "unit": "TFLOP/s",
-                                           "frac": exe / 2500.0, "note": "`achieved` above counts the fp32 algorithm's flops (the unit's definition) against the fp32 matrix peak"}
+            ex = {"pipe": "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces", "achieved": exe, "peak": 2500.0, "unit": "TFLOP/s",
+                  "frac": exe / 2500.0, "note": "`achieved` of the scoring kernel counts the fp32 algorithm's flops (the unit's definition) against the fp32 matrix peak"}
+            per_kernel["score"]["executed"] = ex
+            if dom == "score":
+                out["roofline"]["executed"] = ex
         if ktimes_solo[0] > 0:
-            ach = units_local * flop_unit / float(ktimes_solo[0]) / 1e12
-            out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha_stats": ktimes_solo[2] * 1e3, "mix_stats": ktimes_solo[3] * 1e3}
-            out["roofline_isolated"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS}
+            out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha": ktimes_solo[2] * 1e3, "stats": ktimes_solo[3] * 1e3, "mix_stats": ktimes_solo[4] * 1e3}
         if args.cpu_seconds > 0 and world == 1:               # the CPU leg runs at N = 1 only
             per_utt = units_local / max(len(s.feats), 1)
             n, cdt, opr, oacc = cpu_baseline(s, pk, args.cpu_seconds)
@@ -393,16 +438,26 @@ def main():
                     "sample": "%d utterances of the same shard through oracle/htk_oracle.c (scalar C restatement of "
                               "HFB/HModel, bit-exact vs the reference), %.1f s on one host core" % (n, cdt)}
             cores = host_cores() if args.cpu_workers <= 0 else args.cpu_workers
-            ref = cpu_baseline_reference(s, pk, 60, workers=cores)
+            n_ref = 150                                        # utterances per process and round: ~3 s of HERest per process in the first round, ~6 s in the second
+            ref = cpu_baseline_reference(s, pk, n_ref, workers=cores)
+            ref1 = cpu_baseline_reference(s, pk, 60, workers=1) if cores > 1 else ref
             if ref is not None:
                 out["cpu_baseline"] = {"value": ref[0] * per_utt / ref[1], "unit": "frame-state log-lik/s", "cores": ref[2], "kind": "reference",
                                        "utterances_per_sec": ref[0] / ref[1],
-                                       "sample": "the reference's own HERest (oracle/_ref) as %d parallel `-p k` processes, one per host core, %d utterances of the "
-                                                 "same shard each; model loading differenced out (round over 2n minus round over n utterances per process)" % (ref[2], 60)}
+                                       "sample": "the reference's own HERest (oracle/_ref) as %d parallel `-p k` processes, one per host core (affinity mask, physical cores, "
+                                                 "cgroup quota: %s), %d utterances of the same shard each; model loading differenced out (round over 2n minus round over n "
+                                                 "utterances per process)" % (ref[2], cgroup_cpu_quota(), n_ref)}
+                if ref1 is not None:
+                    one = ref1[0] * per_utt / ref1[1]
+                    out["cpu_baseline"]["one_core"] = {"value": one, "utterances_per_sec": ref1[0] / ref1[1], "sample": "one HERest process, 60 utterances, same differencing"}
+                    out["cpu_baseline"]["parallel_efficiency"] = (ref[0] * per_utt / ref[1]) / (one * ref[2]) if one > 0 else None
                 out["cpu_baseline_port"] = port
             else:
                 out["cpu_baseline"] = port
         print(json.dumps(out))
+    if args.dump_model and rank == 0:
+        p_ = model.get_params()
+        np.savez(args.dump_model, mean=p_["mean"], var=p_["var"], compWeight=p_["compWeight"], transP=p_["transP"], totalPr=a["totalPr"], nUttDone=a["nUttDone"])
     if world > 1:
         dist.destroy_process_group()
 

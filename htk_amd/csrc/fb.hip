@@ -138,7 +138,7 @@ struct htkamd_fb {
    int recCapForce;                         // > 0: capacity of the record list (tests: forces the overflow path)
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
-   hipEvent_t ev[5], evK[2], evCopy;          // ev: stream intervals; evK: the scoring dispatch's own start/stop
+   hipEvent_t ev[6], evK[2], evCopy;          // ev: stream intervals (score | beta | alpha | left-to-right statistics | mixture statistics); evK: the scoring dispatch's own start/stop
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending, scored;
 };
@@ -150,12 +150,12 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    htkamd_fb *fb = new htkamd_fb();
    fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->alphaWTotal = 0; fb->noStatePath = 0; fb->noLrPath = 0; fb->recCapForce = 0; for (int c = 0; c < 14; c++) fb->clsOff[c] = 0;
    fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
-   for (int i = 0; i < 5; i++) fb->ev[i] = nullptr;
+   for (int i = 0; i < 6; i++) fb->ev[i] = nullptr;
    fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
    fb->evValid = true;                                   // destroy releases whatever has been created (null handles are skipped)
    auto fail = [&](const char *what, hipError_t e) { htkamd_set_error("fb_create: %s: %s", what, hipGetErrorString(e)); htkamd_fb_destroy(fb); return HTKAMD_EHIP; };
    hipError_t e;
-   for (int i = 0; i < 5; i++) if ((e = hipEventCreate(&fb->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+   for (int i = 0; i < 6; i++) if ((e = hipEventCreate(&fb->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
    if ((e = hipEventCreate(&fb->evK[0])) != hipSuccess || (e = hipEventCreate(&fb->evK[1])) != hipSuccess) return fail("hipEventCreate", e);
    if ((e = hipEventCreateWithFlags(&fb->evCopy, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
    if ((e = hipStreamCreateWithFlags(&fb->resStream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
@@ -178,7 +178,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
    if (fb->evValid) {
-      for (int i = 0; i < 5; i++) if (fb->ev[i]) (void)hipEventDestroy(fb->ev[i]);
+      for (int i = 0; i < 6; i++) if (fb->ev[i]) (void)hipEventDestroy(fb->ev[i]);
       if (fb->evCopy) (void)hipEventDestroy(fb->evCopy);
       if (fb->evK[0]) (void)hipEventDestroy(fb->evK[0]);
       if (fb->evK[1]) (void)hipEventDestroy(fb->evK[1]);
@@ -612,15 +612,23 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[5 + c]; fc.nList = fb->clsOff[6 + c] - fb->clsOff[5 + c];
          if ((rc = pass == 0 ? htkamd_launch_beta_s(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_s(fc, clsW[c], fastLadd, s))) return rc;
       }
+      for (int c = 3; c >= 0; c--) {
+         fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[9 + c]; fc.nList = fb->clsOff[10 + c] - fb->clsOff[9 + c];
+         if ((rc = pass == 0 ? htkamd_launch_beta_lr(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_lr(fc, clsW[c], fastLadd, s))) return rc;
+      }
+      HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
+   }
+   {  // left-to-right path: occupation / transition counts and the list of surviving (frame, state) pairs from the stored columns
+      FbArgs fc = fa;
       size_t rowOff = 0;
       for (int c = 3; c >= 0; c--) {
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[9 + c]; fc.nList = fb->clsOff[10 + c] - fb->clsOff[9 + c];
          fc.trPart = fa.trPart ? fa.trPart + rowOff * htkamd_stats_lr_row_doubles() : nullptr;
          fc.hits = fa.hits ? fa.hits + rowOff * htkamd_stats_lr_region_cap() : nullptr; fc.hitCtl = fa.hitCtl ? fa.hitCtl + rowOff : nullptr;
          rowOff += (size_t)fc.nList * htkamd_stats_lr_chunks(fb->TMax) * clsW[c];
-         if ((rc = pass == 0 ? htkamd_launch_beta_lr(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_lr(fc, clsW[c], fastLadd, s))) return rc;
+         if ((rc = htkamd_launch_stats_lr(fc, clsW[c], fastLadd, s))) return rc;
       }
-      HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
+      HIPCHECK(hipEventRecord(fb->ev[4], s));
    }
    if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) {
       if ((cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS)) && fb->recCapForce >= 0) {
@@ -634,7 +642,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       // the dense seed array serves the utterances off the left-to-right path; those on it list their pairs (k_stats_lr -> k_mixhits)
       if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
    }
-   HIPCHECK(hipEventRecord(fb->ev[4], s));
+   HIPCHECK(hipEventRecord(fb->ev[5], s));
    fb->timed = true;
    // the metric's unit count rides along in the accumulator vector so that it is all-reduced with it
    return HTKAMD_OK;
@@ -647,7 +655,7 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    if (fb->nUtt == 0) return HTKAMD_OK;
    if (fb->timed) {
       // wait for THIS batch's last kernel only (work queued on the stream afterwards, e.g. the next batch, keeps running)
-      HIPCHECK(hipEventSynchronize(fb->ev[4]));
+      HIPCHECK(hipEventSynchronize(fb->ev[5]));
       if (pr) HIPCHECK(hipMemcpyAsync(pr, fb->d_pr.p, sizeof(double) * fb->nUtt, hipMemcpyDeviceToHost, fb->resStream));
       if (status) HIPCHECK(hipMemcpyAsync(status, fb->d_status.p, sizeof(int) * fb->nUtt, hipMemcpyDeviceToHost, fb->resStream));
       HIPCHECK(hipStreamSynchronize(fb->resStream));
@@ -659,18 +667,29 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    return HTKAMD_OK;
 }
 
-extern "C" int htkamd_fb_kernel_times(htkamd_fb *fb, double out[4])
+// out[0..4]: scoring (the dispatch's own start -> stop), beta, alpha, the left-to-right path's frame-parallel statistics, mixture
+// statistics -- the last four as intervals between stream events around the launches
+extern "C" int htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5])
 {
    if (!fb || !out) { htkamd_set_error("fb_kernel_times: NULL"); return HTKAMD_EINVAL; }
    if (!fb->timed) { htkamd_set_error("fb_kernel_times: nothing executed yet"); return HTKAMD_EINVAL; }
-   HIPCHECK(hipEventSynchronize(fb->ev[4]));
-   for (int i = 0; i < 4; i++) {
+   HIPCHECK(hipEventSynchronize(fb->ev[5]));
+   for (int i = 0; i < 5; i++) {
       float ms = 0.f;
-      // scoring: the dispatch's own start -> stop; the others: interval between stream events around the launch
       if (i == 0 && fb->scored) HIPCHECK(hipEventElapsedTime(&ms, fb->evK[0], fb->evK[1]));
       else HIPCHECK(hipEventElapsedTime(&ms, fb->ev[i], fb->ev[i + 1]));
       out[i] = (double)ms * 1e-3;
    }
+   return HTKAMD_OK;
+}
+
+// the four intervals of round 1/2: scoring, beta, alpha + occupation statistics, mixture statistics
+extern "C" int htkamd_fb_kernel_times(htkamd_fb *fb, double out[4])
+{
+   double t[5];
+   const int rc = htkamd_fb_kernel_times5(fb, t);
+   if (rc) return rc;
+   out[0] = t[0]; out[1] = t[1]; out[2] = t[2] + t[3]; out[3] = t[4];
    return HTKAMD_OK;
 }
 

@@ -720,12 +720,19 @@ template <bool FAST> static void launch_beta_lr(const FbArgs &a, int W, hipStrea
    else if (W == 4) hipLaunchKernelGGL((k_beta_lr<4, FAST>), dim3(a.nList), dim3(256), 0, s, a);
    else hipLaunchKernelGGL((k_beta_lr<8, FAST>), dim3(a.nList), dim3(512), 0, s, a);
 }
-template <bool FAST> static void launch_alpha_lr(const FbArgs &a, int W, int nChunks, hipStream_t s)
+template <bool FAST> static void launch_alpha_lr(const FbArgs &a, int W, hipStream_t s)
 {
-   if (W == 1) { hipLaunchKernelGGL((k_alpha_lr<1, FAST>), dim3(a.nList), dim3(64), 0, s, a); hipLaunchKernelGGL((k_stats_lr<1, FAST>), dim3(a.nList, nChunks), dim3(64), 0, s, a); }
-   else if (W == 2) { hipLaunchKernelGGL((k_alpha_lr<2, FAST>), dim3(a.nList), dim3(128), 0, s, a); hipLaunchKernelGGL((k_stats_lr<2, FAST>), dim3(a.nList, nChunks), dim3(128), 0, s, a); }
-   else if (W == 4) { hipLaunchKernelGGL((k_alpha_lr<4, FAST>), dim3(a.nList), dim3(256), 0, s, a); hipLaunchKernelGGL((k_stats_lr<4, FAST>), dim3(a.nList, nChunks), dim3(256), 0, s, a); }
-   else { hipLaunchKernelGGL((k_alpha_lr<8, FAST>), dim3(a.nList), dim3(512), 0, s, a); hipLaunchKernelGGL((k_stats_lr<8, FAST>), dim3(a.nList, nChunks), dim3(512), 0, s, a); }
+   if (W == 1) hipLaunchKernelGGL((k_alpha_lr<1, FAST>), dim3(a.nList), dim3(64), 0, s, a);
+   else if (W == 2) hipLaunchKernelGGL((k_alpha_lr<2, FAST>), dim3(a.nList), dim3(128), 0, s, a);
+   else if (W == 4) hipLaunchKernelGGL((k_alpha_lr<4, FAST>), dim3(a.nList), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL((k_alpha_lr<8, FAST>), dim3(a.nList), dim3(512), 0, s, a);
+}
+template <bool FAST> static void launch_stats_lr(const FbArgs &a, int W, int nChunks, hipStream_t s)
+{
+   if (W == 1) hipLaunchKernelGGL((k_stats_lr<1, FAST>), dim3(a.nList, nChunks), dim3(64), 0, s, a);
+   else if (W == 2) hipLaunchKernelGGL((k_stats_lr<2, FAST>), dim3(a.nList, nChunks), dim3(128), 0, s, a);
+   else if (W == 4) hipLaunchKernelGGL((k_stats_lr<4, FAST>), dim3(a.nList, nChunks), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL((k_stats_lr<8, FAST>), dim3(a.nList, nChunks), dim3(512), 0, s, a);
 }
 
 int htkamd_stats_lr_chunks(int TMax) { return (TMax + STATS_FC - 1) / STATS_FC; }
@@ -740,13 +747,21 @@ int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
    return HTKAMD_OK;
 }
 
-// alpha chain, then the frame-parallel statistics of the same utterances and the reduction of their partial rows (a.trPart: room for
-// nList * chunks * W rows)
 int htkamd_launch_alpha_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
+   if (fast) launch_alpha_lr<true>(a, W, s); else launch_alpha_lr<false>(a, W, s);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+// the frame-parallel statistics of the utterances whose alpha columns are stored, and the reduction of their partial rows (a.trPart,
+// a.hits, a.hitCtl: room for nList * chunks * W rows / regions)
+int htkamd_launch_stats_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
+{
+   if (a.nList <= 0) return HTKAMD_OK;
    const int nChunks = htkamd_stats_lr_chunks(a.TMax);
-   if (fast) launch_alpha_lr<true>(a, W, nChunks, s); else launch_alpha_lr<false>(a, W, nChunks, s);
+   if (fast) launch_stats_lr<true>(a, W, nChunks, s); else launch_stats_lr<false>(a, W, nChunks, s);
    const int nRows = a.nList * nChunks * W;
    hipLaunchKernelGGL(k_trans_reduce, dim3((nRows + 255) / 256), dim3(256), 0, s, a, nRows);
    HIPCHECK(hipGetLastError());

@@ -137,6 +137,7 @@ int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 // left-to-right chains (fb_lr.hip): state-per-lane recursions without statistics + frame-parallel statistics
 int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_alpha_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
+int htkamd_launch_stats_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_stats_lr_chunks(int TMax);
 size_t htkamd_stats_lr_row_doubles(void);
 int htkamd_stats_lr_region_cap(void);

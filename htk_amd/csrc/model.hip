@@ -297,7 +297,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
 {
    if (!m) return;
    free(m->h_stateCompOff); free(m->h_compGauss); free(m->h_transN); free(m->h_transOff); free(m->h_hmmTrans);
-   free(m->h_hmmStateOff); free(m->h_hmmState); free(m->h_minDur); free(m->h_transLR); free(m->h_trOccOff);
+   free(m->h_hmmStateOff); free(m->h_hmmState); free(m->h_minDur); free(m->h_transLR); free(m->h_trOccOff); free(m->h_scanOrder);
    free(m->h_mean); free(m->h_var); free(m->h_ivar); free(m->h_gconst); free(m->h_compWeight); free(m->h_compLogWt); free(m->h_transP);
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
@@ -311,6 +311,22 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
 }
 
 // Shared mean / variance vectors: share[g] >= 0 names the vector Gaussian g's mean (variance) is a copy of, -1 = private.
+extern "C" int htkamd_model_set_scan_order(htkamd_model *m, const int *order)
+{
+   if (!m) { htkamd_set_error("model_set_scan_order: NULL"); return HTKAMD_EINVAL; }
+   free(m->h_scanOrder); m->h_scanOrder = nullptr;
+   if (!order) return HTKAMD_OK;
+   unsigned char *seen = (unsigned char *)calloc((size_t)(m->H ? m->H : 1), 1);
+   for (int k = 0; k < m->H; k++) {
+      if (order[k] < 0 || order[k] >= m->H || seen[order[k]]) { free(seen); htkamd_set_error("model_set_scan_order: not a permutation of the %d physical models", m->H); return HTKAMD_EINVAL; }
+      seen[order[k]] = 1;
+   }
+   free(seen);
+   m->h_scanOrder = (int *)malloc(sizeof(int) * (size_t)(m->H ? m->H : 1));
+   memcpy(m->h_scanOrder, order, sizeof(int) * (size_t)m->H);
+   return HTKAMD_OK;
+}
+
 extern "C" int htkamd_model_set_sharing(htkamd_model *m, const int *meanShare, const int *varShare)
 {
    if (!m) { htkamd_set_error("model_set_sharing: NULL model"); return HTKAMD_EINVAL; }

@@ -20,8 +20,8 @@
 #include <string.h>
 #include "../csrc/internal.h"
 
-typedef struct { char *name; int nMix; int comp0; int inlineOwner; } mmf_state;   /* name NULL = un-named (inline) */
-typedef struct { char *name; int N; int off; } mmf_trans;
+typedef struct { char *name; int nMix; int comp0; int inlineOwner; int src; } mmf_state;   /* name NULL = un-named (inline); src: index of the file it came from */
+typedef struct { char *name; int N; int off; int src; } mmf_trans;
 typedef struct { char *name; int N; int *state; int trans; int src; } mmf_hmm;     /* src: index of the file it came from */
 
 struct htkamd_mmf {
@@ -31,12 +31,12 @@ struct htkamd_mmf {
    mmf_state *st; int nSt, capSt;
    float *wt; int *cg; int nComp, capComp;
    float *mean, *var, *gconst; unsigned char *hasG; int nG, capG;
-   char **gName; int capGN;                                         /* ~m macro name of Gaussian g or NULL */
+   char **gName; int *gSrc; int capGN;                              /* ~m macro name of Gaussian g or NULL, and the file it was defined in */
    mmf_trans *tr; int nTr, capTr; float *tp; int nTp, capTp;       /* tp: LOG transition values */
    mmf_hmm *hm; int nHm, capHm;
    float *varFloor;                                                 /* ~v "varFloor1" or NULL */
    /* shared vectors: ~u (means) and ~v (variances) macros; gMeanMac/gVarMac[g] = macro of Gaussian g's mean / variance or -1 */
-   struct { char type; char *name; float *v; } *vm; int nVm, capVm;
+   struct { char type; char *name; float *v; int src; } *vm; int nVm, capVm;
    int *gMeanMac, *gVarMac; int capMac;
    /* logical list */
    char **logName; int *logPhys; int nLog; int *logSorted;        /* logSorted: list positions in name order (stable) */
@@ -244,10 +244,11 @@ static void gname_set(struct htkamd_mmf *s, int g, char *name)
    if (g + 1 > s->capGN) {
       const int nc = (g + 1) * 2 + 16;
       s->gName = (char **)realloc(s->gName, sizeof(char *) * (size_t)nc);
-      for (int i = s->capGN; i < nc; i++) s->gName[i] = NULL;
+      s->gSrc = (int *)realloc(s->gSrc, sizeof(int) * (size_t)nc);
+      for (int i = s->capGN; i < nc; i++) { s->gName[i] = NULL; s->gSrc[i] = 0; }
       s->capGN = nc;
    }
-   s->gName[g] = name;
+   s->gName[g] = name; s->gSrc[g] = s->nFiles;
 }
 static int find_gauss(const struct htkamd_mmf *s, const char *name)
 {
@@ -369,7 +370,7 @@ static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
       }
    s->nComp += M;
    mmf_state *st = &s->st[s->nSt];
-   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1;
+   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1; st->src = s->nFiles;
    *sOut = s->nSt++;
    return HTKAMD_OK;
 }
@@ -403,7 +404,7 @@ static int parse_transp_body(struct htkamd_mmf *s, rd *r, char *name, int *tOut)
       s->tp[s->nTp + i] = (x <= MINLARG) ? (float)LZERO : (float)log((double)x);     /* GetTransMat, HModel.c:1965-1975 */
    }
    mmf_trans *t = &s->tr[s->nTr];
-   t->name = name; t->N = N; t->off = s->nTp;
+   t->name = name; t->N = N; t->off = s->nTp; t->src = s->nFiles;
    s->nTp += N * N;
    *tOut = s->nTr++;
    return HTKAMD_OK;
@@ -536,7 +537,7 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
             memcpy(s->varFloor, v, sizeof(float) * (size_t)s->vecSize);
          }
          GROW(s->vm, s->nVm, s->capVm, 1, __typeof__(*s->vm));
-         s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v;
+         s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v; s->vm[s->nVm].src = s->nFiles;
          s->nVm++;
       } else { rc = fail(&r, "unsupported macro type"); free(name); break; }
    }
@@ -866,11 +867,12 @@ int htkamd_mmf_write_binary(const struct htkamd_mmf *s, const float *mean, const
    return rc;
 }
 
-static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
-                     const float *transP, const char *oneFile, const char *dir)
+/* The macros that came from file `src` (all of them: src < 0) into one file, in SaveHMMSet's order (HModel.c:4342-4470). */
+static int write_macros(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                        const float *transP, const char *oneFile, int src)
 {
-   if (!s || !s->finished || !mean || !var || !compWeight || !transP) { htkamd_set_error("mmf_write: bad argument"); return HTKAMD_EINVAL; }
-   if (oneFile) {
+#define SRC(x) (src < 0 || (x) == src)
+   {
       FILE *f = fopen(oneFile, "wb");
       if (f) setvbuf(f, NULL, _IOFBF, 1 << 20);
       if (!f) { htkamd_set_error("mmf_write: cannot create %s", oneFile); return HTKAMD_EIO; }
@@ -884,8 +886,8 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
       names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
       idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
       ord = (int *)realloc(ord, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
-      for (int i = 0; i < s->nVm; i++) { names[nN] = s->vm[i].name; idx[nN++] = -1 - i; }
-      for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { names[nN] = s->tr[t].name; idx[nN++] = t; }
+      for (int i = 0; i < s->nVm; i++) if (SRC(s->vm[i].src)) { names[nN] = s->vm[i].name; idx[nN++] = -1 - i; }
+      for (int t = 0; t < s->nTr; t++) if (s->tr[t].name && SRC(s->tr[t].src)) { names[nN] = s->tr[t].name; idx[nN++] = t; }
       macro_order(names, nN, ord);
       for (int k = 0; k < nN; k++) {
          const int t = idx[ord[k]];
@@ -903,7 +905,7 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
       names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
       idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
       ord = (int *)realloc(ord, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
-      for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g]) { names[nN] = s->gName[g]; idx[nN++] = g; }
+      for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g] && SRC(s->gSrc[g])) { names[nN] = s->gName[g]; idx[nN++] = g; }
       macro_order(names, nN, ord);
       for (int k = 0; k < nN; k++) {
          const int g = idx[ord[k]];
@@ -911,17 +913,25 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
          put_gauss(s, f, g, mean, var, gconst);
       }
       nN = 0;
-      for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { names[nN] = s->st[i].name; idx[nN++] = i; }
+      for (int i = 0; i < s->nSt; i++) if (s->st[i].name && SRC(s->st[i].src)) { names[nN] = s->st[i].name; idx[nN++] = i; }
       macro_order(names, nN, ord);
       for (int k = 0; k < nN; k++) { const int i = idx[ord[k]]; put_name(f, 's', s->st[i].name); put_state(s, f, i, mean, var, gconst, compWeight); }
       nN = 0;
-      for (int h = 0; h < s->nHm; h++) { names[nN] = s->hm[h].name; idx[nN++] = h; }
+      for (int h = 0; h < s->nHm; h++) if (SRC(s->hm[h].src)) { names[nN] = s->hm[h].name; idx[nN++] = h; }
       macro_order(names, nN, ord);
       for (int k = 0; k < nN; k++) put_hmm(s, f, idx[ord[k]], 1, mean, var, gconst, compWeight, transP);
       free(names); free(idx); free(ord);
       if (fclose(f)) { htkamd_set_error("mmf_write: write error on %s", oneFile); return HTKAMD_EIO; }
       return HTKAMD_OK;
    }
+#undef SRC
+}
+
+static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                     const float *transP, const char *oneFile, const char *dir)
+{
+   if (!s || !s->finished || !mean || !var || !compWeight || !transP) { htkamd_set_error("mmf_write: bad argument"); return HTKAMD_EINVAL; }
+   if (oneFile) return write_macros(s, mean, var, gconst, compWeight, transP, oneFile, -1);
    if (!dir) { htkamd_set_error("mmf_write: neither file nor directory given"); return HTKAMD_EINVAL; }
    for (int i = 0; i < s->nSt; i++) if (s->st[i].name) { htkamd_set_error("mmf_write: a set with ~s macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { htkamd_set_error("mmf_write: a set with ~t macros must be written to one file"); return HTKAMD_EINVAL; }
@@ -937,6 +947,28 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
       if (fclose(f)) { htkamd_set_error("mmf_write: write error on %s", path); return HTKAMD_EIO; }
    }
    return HTKAMD_OK;
+}
+
+/* SaveHMMSet for a set loaded from SEVERAL master files (HERest -H macros -H hmmdefs -M dir): every macro goes back to the file it
+   was loaded from (HModel.c:4388-4470: SaveMacros per MMF), so that the next iteration finds dir/macros and dir/hmmdefs again.
+   masterOut[k] = where the k-th file read goes (k = order of the htkamd_mmf_read calls); models that came from files of their own
+   beyond those (a -d directory) go to dir/<name>. */
+int htkamd_mmf_write_sources(const struct htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                             const float *transP, const char *const *masterOut, int nMaster, const char *dir, int binary)
+{
+   if (!s || !s->finished || !mean || !var || !compWeight || !transP || nMaster < 0 || (nMaster > 0 && !masterOut)) { htkamd_set_error("mmf_write_sources: bad argument"); return HTKAMD_EINVAL; }
+   int rc = HTKAMD_OK;
+   g_bin = binary ? 1 : 0;
+   for (int k = 0; k < nMaster && !rc; k++) rc = write_macros(s, mean, var, gconst, compWeight, transP, masterOut[k], k);
+   for (int h = 0; h < s->nHm && !rc; h++) {
+      if (s->hm[h].src < nMaster) continue;
+      char path[1400];
+      if (!dir) { htkamd_set_error("mmf_write_sources: model %s came from a file of its own and no directory is given", s->hm[h].name); rc = HTKAMD_EINVAL; break; }
+      snprintf(path, sizeof(path), "%s/%s", dir, s->hm[h].name);
+      rc = write_macros(s, mean, var, gconst, compWeight, transP, path, s->hm[h].src);
+   }
+   g_bin = 0;
+   return rc;
 }
 
 /* HCompV's variance floor macro file (PutVFloor, HCompV.c:359-389): one stream. */

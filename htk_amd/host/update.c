@@ -88,7 +88,12 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
          if (usedS[s0]) for (c = m->h_stateCompOff[s0]; c < m->h_stateCompOff[s0 + 1]; c++) wgt[c] = exp(htkamd_host_mix_log_weight(wgt[c]));
       free(usedS); free(usedG);
    }
-   for (h = 0; h < m->H; h++) {
+   /* UpdateModels walks the set with an HMM scan (HERest.c:1262-1321: NewHMMScan / GoNextHMM, the hash order of the physical models'
+      names).  For private parameters the order is immaterial; for a mean shared by Gaussians of several models it decides whose variance
+      carries the mean-shift term (the first mixture to reach the shared mean: `shared` below).  h_scanOrder (htkamd_model_set_scan_order)
+      is that order; without it the models are taken as defined. */
+   for (int hh = 0; hh < m->H; hh++) {
+      h = m->h_scanOrder ? m->h_scanOrder[hh] : hh;
       const int n = (int)llround(acc[lay->nEgs + h]), ti = m->h_hmmTrans[h], N = m->h_transN[ti];
       const int *hs = m->h_hmmState + m->h_hmmStateOff[h];
       if (n < cfg->minEgs) st->nSkippedHmm++;

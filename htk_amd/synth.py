@@ -192,13 +192,16 @@ def round_to_mmf_precision_bulk(a: np.ndarray) -> np.ndarray:
     return out.reshape(np.shape(a))
 
 
-def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39, model_seed: int | None = None, mmf_round: bool = False) -> SynthSet:
+def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int = 39, model_seed: int | None = None, mmf_round: bool = False,
+                  utt_ids=None) -> SynthSet:
     """Vectorised variant for large workloads (bench.py): same model distribution and utterance structure as
     generate() (Q = T//12 models per utterance, equal thirds per state, frames drawn from the aligned state's
     GMM) but bulk random draws, no files and no MMF-precision round trip.  `model_seed` fixes the model
     independently of the utterance seed so that every rank of a sharded run holds the same HMM set.
     `mmf_round`: the set returned holds the parameters a text MMF of it carries ('%e'), as generate() does (the frames are drawn
-    from the unrounded ones either way, so the data do not depend on the switch)."""
+    from the unrounded ones either way, so the data do not depend on the switch).
+    `utt_ids`: generate exactly these utterances of the job `seed` (NU is ignored): utterance u has its own random stream, so that
+    any split of a job over ranks yields the same utterances (bench.py --scaling strong: rank r of R takes r, r+R, ...)."""
     mrng = np.random.default_rng(seed if model_seed is None else model_seed)
     means = mrng.normal(0, 3, size=(NS, M, D)).astype(np.float32)
     var = mrng.uniform(0.5, 2.0, size=(NS, M, D)).astype(np.float32)
@@ -221,8 +224,18 @@ def generate_fast(NS: int, M: int, NP: int, NU: int, T: int, seed: int, D: int =
             qpos += [q] * nj
             spos += [j] * nj
     qpos = np.array(qpos); spos = np.array(spos)
-    seqs = rng.integers(0, NP, size=(NU, Q))
     sd = np.sqrt(var)
+    if utt_ids is not None:
+        for u in utt_ids:
+            ru = np.random.default_rng([seed, 2, int(u)])
+            seq = ru.integers(0, NP, size=Q)
+            states = st[seq[qpos], spos]
+            ms = ru.integers(0, M, size=T)
+            X = means[states, ms] + ru.standard_normal((T, D), dtype=np.float32) * sd[states, ms]
+            s.seqs.append(seq.astype(np.int32))
+            s.feats.append(X.astype(np.float32))
+        NU = 0
+    seqs = rng.integers(0, NP, size=(NU, Q))
     for u in range(NU):
         states = st[seqs[u][qpos], spos]                      # [T]
         ms = rng.integers(0, M, size=T)

@@ -97,6 +97,10 @@ int  htkamd_model_create(const htkamd_model_desc *desc, htkamd_model **out);
  * as the reference's hooks on the shared vector do (one MuAcc / VaAcc per vector; a tied variance gets no mean-shift correction,
  * HERest.c:1080) and keeps the copies equal.  htkamd_model_update_device refuses such a set (HTKAMD_EMODEL). */
 int  htkamd_model_set_sharing(htkamd_model *m, const int *meanShare /*[G]*/, const int *varShare /*[G]*/);
+/* The order in which UpdateModels (HERest.c:1262-1321) visits the physical models: the reference's HMM scan, i.e. htkamd_hmm_scan_order of
+   their names.  It matters only for sets with mean vectors shared across models (which Gaussian's variance takes the mean-shift term);
+   NULL (the default) = definition order. */
+int  htkamd_model_set_scan_order(htkamd_model *m, const int *order /*[numPhys]*/);
 int  htkamd_model_has_sharing(const htkamd_model *m);
 void htkamd_model_destroy(htkamd_model *m);
 /* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */
@@ -147,6 +151,11 @@ int  htkamd_mmf_write(const htkamd_mmf *s, const float *mean, const float *var, 
 /* the same in HTK's binary form (SaveHMMSet with binary = TRUE, HERest/HHEd -B); htkamd_mmf_read takes either form */
 int  htkamd_mmf_write_binary(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
                              const float *transP, const char *oneFile, const char *dir);
+/* SaveHMMSet for a set loaded from several master files (HERest -H macros -H hmmdefs): every macro goes back to the file it was loaded
+   from (HModel.c:4388-4470).  masterOut[k] = path for the k-th file read (order of the htkamd_mmf_read calls); models read from files of
+   their own beyond those go to dir/<name>. */
+int  htkamd_mmf_write_sources(const htkamd_mmf *s, const float *mean, const float *var, const float *gconst, const float *compWeight,
+                              const float *transP, const char *const *masterOut, int nMaster, const char *dir, int binary);
 
 /* Script files (-S scp): white-space separated or quoted words (ScriptWord HShell.c:661), each a data file name or an extended
  * file name logical=physical[start,end] (RegisterExtFileName HShell.c:86: frames start..end of `physical`, known as `logical`). */
@@ -418,6 +427,8 @@ int  htkamd_fb_get_trellis(htkamd_fb *fb, int utt, double *beta, double *alpha, 
    out[0]=scoring (the dispatch's own start -> stop, hipExtLaunchKernel: what a kernel trace reports even when other streams share
    the device) out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics (intervals between stream events). Synchronises. */
 int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
+/* the same with the alpha pass and the left-to-right path's frame-parallel statistics apart: scoring, beta, alpha, statistics, mixture statistics */
+int  htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5]);
 
 /* ------------------------------------------------------------------------------------------
  * Viterbi forced alignment of a batch (HVite -a): replaces, per utterance, the frame loop of

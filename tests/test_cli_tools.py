@@ -121,11 +121,11 @@ def _mmf_close(ours, theirs, tol=1e-4):
             i += 2 + n
         else:
             i += 1
-    in_mean, left = False, 0
+    in_mean, left, pos = False, 0, 0
     for idx, (x, y) in enumerate(zip(ours, theirs)):
         if not isinstance(y, float):
             assert x == y, (idx, x, y)
-            in_mean, left = (y == "<MEAN>"), -1
+            in_mean, left = (y == "<MEAN>"), (-1 if y in ("<MEAN>", "<VARIANCE>") else 0)
             continue
         assert isinstance(x, float), (idx, x, y)
         if left == -1:                                        # the vector's length
@@ -156,6 +156,40 @@ def test_herest_cli_tied_mean_and_variance_vectors(tools, tmp_path):
     ours, theirs = _mmf_numbers(str(out / "newMacros")), _mmf_numbers(os.path.join(tied, "after_herest"))
     _mmf_close(ours, theirs)
     assert open(str(out / "newMacros")).read().count('~v "vCL"') == 5 and open(str(out / "newMacros")).read().count('~u "uSV"') == 3
+
+
+@pytest.mark.gpu
+def test_herest_cli_mean_tied_across_models_follows_the_scan_order(tools, tmp_path):
+    """Means tied across two models with private variances (tests/golden/make_tied2_golden.py), in a set whose HMM scan order (C L N S V)
+    differs from the order of definition (S C V N L): the variance of the first mixture to reach the shared mean IN SCAN ORDER carries the
+    mean-shift term (UpdateVars, HERest.c:1045-1122) -- the MMF equals the reference's."""
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "next"; out.mkdir()
+    tied = os.path.join(DEMO, "hmm_tied2")
+    r = run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(tied, "newMacros"), "-M", str(out),
+             "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0, r.stderr
+    for line in open(os.path.join(tied, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-400:])
+    _mmf_close(_mmf_numbers(str(out / "newMacros")), _mmf_numbers(os.path.join(tied, "after_herest")))
+
+
+@pytest.mark.gpu
+def test_herest_cli_several_master_files_round_trip(tools, tmp_path):
+    """The usual iteration `-H dir/macros -H dir/hmmdefs -M next`: the re-estimated macros go back to next/macros and next/hmmdefs as the
+    reference's SaveHMMSet writes them (tests/golden/make_multimmf_golden.py: herest_macros / herest_hmmdefs from its HERest), and the
+    next iteration starts from those two files."""
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    multi = os.path.join(DEMO, "hmm_multi")
+    out = tmp_path / "next"; out.mkdir()
+    base = [os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-L", os.path.join(DEMO, "labels"), "-t", "2000.0"]
+    r = run(base + ["-H", os.path.join(multi, "macros"), "-H", os.path.join(multi, "hmmdefs"), "-M", str(out), os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0, r.stderr
+    for name in ("macros", "hmmdefs"):
+        _mmf_close(_mmf_numbers(str(out / name)), _mmf_numbers(os.path.join(multi, "herest_" + name)))
+    out2 = tmp_path / "next2"; out2.mkdir()
+    r = run(base + ["-H", str(out / "macros"), "-H", str(out / "hmmdefs"), "-M", str(out2), os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0 and (out2 / "macros").exists() and (out2 / "hmmdefs").exists(), r.stderr
 
 
 @pytest.mark.gpu

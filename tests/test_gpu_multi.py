@@ -1,0 +1,110 @@
+"""The multi-GPU leg on real devices: utterance shards over one process per GPU, ONE exchange -- the RCCL sum of the accumulator
+vector (HERest -p r / -p 0: HERest.c:514-557; DumpAccs / LoadAccs HTrain.c:1453-1505,1625-1687) -- then the same update on every rank.
+
+Needs >= 2 GPUs on the box (skipped otherwise: the round's 1-GPU boxes cannot run it; the CPU suite covers the sharding / merge logic
+with gloo, tests/test_dist_gloo.py, and tests/test_gpu_rccl.py the RCCL call with one rank).
+  * bench.py through torch.distributed (backend nccl = RCCL), --scaling strong over 2 ranks: the merged model equals the 1-rank model
+  * tools/bin/herest --ranks 2 (C -> htkamd_comm_init -> htkamd_accs_allreduce -> RCCL, no Python between the ranks): rank 0's models
+    equal the single-process run's
+  * the rendezvous of tools/herest does not take a stale id file and does not hang on a missing rank (one GPU is enough for that)"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import test_cli_tools as cli
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU
+
+
+def _env():
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e["MASTER_ADDR"] = "127.0.0.1"
+    return e
+
+
+def _bench(n, out, port, total=256):
+    args = ["--gpus", str(n), "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
+            "--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--dump-model", out]
+    if n == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_bench_two_ranks_rccl_equals_one_rank(tmp_path):
+    if _ngpu() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    o1 = _bench(1, str(tmp_path / "m1.npz"), 29611)
+    o2 = _bench(2, str(tmp_path / "m2.npz"), 29612)
+    l1, l2 = json.loads(o1.strip().splitlines()[-1]), json.loads(o2.strip().splitlines()[-1])
+    assert l2["n_gpus"] == 2 and l1["utterances_ok"] == l2["utterances_ok"] == 256
+    a, b = np.load(str(tmp_path / "m1.npz")), np.load(str(tmp_path / "m2.npz"))
+    assert a["nUttDone"] == b["nUttDone"] == 256
+    assert abs(float(a["totalPr"]) - float(b["totalPr"])) <= 1e-9 * abs(float(a["totalPr"]))
+    for k in ("mean", "var", "compWeight", "transP"):
+        # two EM iterations on fp64 sums whose order differs (atomics, ring): float parameters equal to a few ulp
+        assert np.allclose(a[k], b[k], rtol=2e-6, atol=1e-7), k
+
+
+def test_herest_cli_two_ranks_rccl_equals_one_process(native, tmp_path):
+    if _ngpu() < 2:
+        pytest.skip("needs two GPUs")
+    tools = os.path.join(ROOT, "tools", "bin")
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    one = tmp_path / "one"; one.mkdir()
+    r = cli.run(cli.herest_demo_cmd(tools, str(conf), str(one)) + cli.demo_train_files())
+    assert r.returncode == 0, r.stderr
+    outs = [tmp_path / "r0", tmp_path / "r1"]
+    idf = str(tmp_path / "rccl.id")
+    open(idf, "wb").write(b"stale" * 40)                       # a file a previous run left behind must not be taken for this run's id
+    procs = []
+    for k in (1, 0):                                           # rank 1 first: it has to wait for rank 0's id
+        outs[k].mkdir()
+        cmd = cli.herest_demo_cmd(tools, str(conf), str(outs[k]), ["--ranks", "2", "--rank", str(k), "--rccl-id", idf, "--rccl-nonce", "4242", "--rccl-timeout", "120"]) + cli.demo_train_files()
+        procs.append(subprocess.Popen(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        time.sleep(0.5)
+    res = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [x[1][-800:] for x in res]
+    assert not os.path.exists(idf)                             # rank 0 removes it at exit
+    for name in "SCVNL":
+        x, y = cli._mmf_numbers(str(outs[0] / name)), cli._mmf_numbers(str(one / name))
+        cli._mmf_close(x, y, tol=2e-6)
+    log = open(os.path.join(cli.DEMO, "herest_pass1.log")).read()
+    assert "average log prob per frame = -5.900196e+01" in log and "-5.900196e+01" in res[1][0]
+
+
+def test_herest_cli_rendezvous_is_bounded(native, tmp_path):
+    """A rank whose partner never comes exits non-zero within the timeout; a stale id file of another run is not used."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    tools = os.path.join(ROOT, "tools", "bin")
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "o"; out.mkdir()
+    idf = str(tmp_path / "rccl.id")
+    open(idf, "wb").write((99).to_bytes(8, "little") + b"\0" * 128)          # well-formed, but another run's nonce
+    t0 = time.time()
+    r = cli.run(cli.herest_demo_cmd(tools, str(conf), str(out), ["--ranks", "2", "--rank", "1", "--rccl-id", idf, "--rccl-nonce", "7", "--rccl-timeout", "3"]) + cli.demo_train_files())
+    assert r.returncode != 0 and "no RCCL id of this run" in r.stderr and time.time() - t0 < 60
+    # rank 0 alone: writes its id, then ncclCommInitRank waits for rank 1 -- until the alarm
+    t0 = time.time()
+    r = cli.run(cli.herest_demo_cmd(tools, str(conf), str(out), ["--ranks", "2", "--rank", "0", "--rccl-id", idf, "--rccl-nonce", "7", "--rccl-timeout", "5"]) + cli.demo_train_files())
+    assert r.returncode == 3 and "did not meet" in r.stderr and time.time() - t0 < 90
+    assert not os.path.exists(idf)

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEMO = os.path.join(GOLD, "demo")
 
 
 def _gconst(native, var):
@@ -274,3 +275,23 @@ def test_mmf_numbers_are_written_as_printf_writes_them(native, tmp_path):
         libc.snprintf(b, 64, b"%e", ctypes.c_double(float(v)))
         want.append(b.value.decode())
     assert got == want, [(g, w) for g, w in zip(got, want) if g != w][:5]
+
+
+def test_set_from_several_master_files_is_saved_file_by_file(native, tmp_path):
+    """`-H macros -H hmmdefs` (tests/golden/make_multimmf_golden.py): SaveHMMSet writes every macro back to the master file it was loaded
+    from (HModel.c:4388-4470) -- both files equal the ones the reference's HHEd wrote, byte for byte; a model set saved that way loads
+    again to the same description."""
+    import filecmp
+    D = os.path.join(DEMO, "hmm_multi")
+    m = native.Mmf([os.path.join(D, "macros"), os.path.join(D, "hmmdefs")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = m.packed()
+    outs = [str(tmp_path / "macros"), str(tmp_path / "hmmdefs")]
+    m.write_sources(pk, outs, out_dir=str(tmp_path))
+    assert filecmp.cmp(outs[0], os.path.join(D, "hhed_macros"), shallow=False)
+    assert filecmp.cmp(outs[1], os.path.join(D, "hhed_hmmdefs"), shallow=False)
+    again = native.Mmf(outs, hmm_list=os.path.join(DEMO, "bcplist")).packed()
+    for k in ("mean", "var", "compWeight", "transP", "hmmState", "stateCompOff"):
+        assert np.array_equal(again[k], pk[k]), k
+    one = native.Mmf([os.path.join(DEMO, "hmm_tied", "newMacros")], hmm_list=os.path.join(DEMO, "bcplist")).packed()
+    assert np.array_equal(one["mean"], pk["mean"]) and np.array_equal(one["var"], pk["var"])
+

@@ -20,10 +20,13 @@
  *   --batch N      utterances per device batch (default 4096)
  *   --ranks R --rank r --rccl-id file   one process per GPU: every rank takes the data files r, r+R, r+2R, ..., the accumulators are summed
  *                  over RCCL (htkamd_accs_allreduce) and every rank re-estimates; rank 0 writes the models.  `file` carries the
- *                  rendezvous id from rank 0 to the others.
+ *                  rendezvous id from rank 0 to the others, tagged with the run's nonce (--rccl-nonce N; default: the launcher's process
+ *                  id, which the ranks of one run share); rank 0 removes the file before writing and at exit.  --rccl-timeout S (120):
+ *                  a rank that cannot meet the others within S seconds -- at the rendezvous or in the all-reduce -- exits with status 3.
  * Output on stdout follows HERest -T 1: "Pruning-On[..]", a line per skipped file, "Total N floored variance elements ...",
  * "Reestimation complete - average log prob per frame = ...".
  */
+#include <signal.h>
 #include <unistd.h>
 #include "cli_common.h"
 
@@ -48,6 +51,18 @@ static int uflags_parse(const char *s)
    return f;
 }
 
+static const char *g_rcclIdFile = NULL;
+static int g_rank = 0;
+static void remove_id_file(void) { if (g_rcclIdFile) unlink(g_rcclIdFile); }
+static void rendezvous_timeout(int sig)
+{
+   (void)sig;
+   static const char msg[] = "ERROR herest: the ranks did not meet within --rccl-timeout seconds (a rank missing or dead)\n";
+   if (write(2, msg, sizeof(msg) - 1) < 0) { }
+   if (g_rank == 0 && g_rcclIdFile) unlink(g_rcclIdFile);
+   _exit(3);
+}
+
 int main(int argc, char **argv)
 {
    args a = {argc, 1, argv};
@@ -57,7 +72,8 @@ int main(int argc, char **argv)
    double pruneInit = HTKAMD_NOPRUNE, pruneInc = 0.0, pruneLim = HTKAMD_NOPRUNE;
    float minFrwdP = 10.0f, minVar = 0.0f, mixFloor = 0.0f;
    int uFlags = HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES | HTKAMD_UPTRANS, minEgs = 3, parMode = -1, trace = 0, binary = 0;
-   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0;
+   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120;
+   unsigned long long rcclNonce = (unsigned long long)getppid();      /* the ranks of one run are children of one launcher; --rccl-nonce overrides */
    const char *sw;
 
    while (a.at < a.argc && (a.argv[a.at][0] == '-') && (is_switch(a.argv[a.at]))) {
@@ -71,6 +87,8 @@ int main(int argc, char **argv)
          else if (!strcmp(lo, "ranks")) nRanks = atoi(str_arg(&a, "-ranks"));
          else if (!strcmp(lo, "rank")) rank = atoi(str_arg(&a, "-rank"));
          else if (!strcmp(lo, "rccl-id")) rcclIdFile = str_arg(&a, "-rccl-id");
+         else if (!strcmp(lo, "rccl-nonce")) rcclNonce = strtoull(str_arg(&a, "-rccl-nonce"), NULL, 0);
+         else if (!strcmp(lo, "rccl-timeout")) rcclTimeout = atoi(str_arg(&a, "-rccl-timeout"));
          else DIE("unknown option --%s", lo);
          continue;
       }
@@ -132,6 +150,14 @@ int main(int argc, char **argv)
       if (htkamd_mmf_sharing(mmf, ms, vs) > 0) { CHECK(htkamd_model_set_sharing(model, ms, vs)); shareMu = ms; shareVa = vs; }
       else { free(ms); free(vs); }
    }
+   {  /* the update visits the models in the reference's scan order (it decides which user of a shared mean takes the mean-shift term) */
+      const char **nm = (const char **)malloc(sizeof(char *) * (size_t)(d->numPhys + 1));
+      int *order = (int *)malloc(sizeof(int) * (size_t)(d->numPhys + 1));
+      for (int h = 0; h < d->numPhys; h++) nm[h] = htkamd_mmf_phys_name(mmf, h);
+      CHECK(htkamd_hmm_scan_order(nm, d->numPhys, order));
+      CHECK(htkamd_model_set_scan_order(model, order));
+      free(nm); free(order);
+   }
    htkamd_accs *accs; CHECK(htkamd_accs_create(model, &accs));
    htkamd_accs_layout lay; CHECK(htkamd_accs_get_layout(accs, &lay));
    double *vec = (double *)calloc(lay.total, sizeof(double));
@@ -157,19 +183,32 @@ int main(int argc, char **argv)
       if (mlfPath) CHECK(htkamd_mlf_read(mlfPath, &mlf));
       htkamd_comm *comm = NULL;
       if (nRanks > 1) {
+         /* Rendezvous through a file: [8-byte nonce of the run][128-byte RCCL id].  Rank 0 removes whatever a previous run left under
+            the name before it writes (and again when it exits); the other ranks take a file only if it carries this run's nonce, so a
+            stale id is waited out, not used.  Every wait is bounded: a rank that cannot meet the others within --rccl-timeout seconds
+            (here, or in the all-reduce below when a rank has died on an error) exits non-zero instead of hanging. */
          unsigned char id[128];
          if (rank == 0) {
+            unlink(rcclIdFile);
             CHECK(htkamd_comm_unique_id(id));
             char tmp[1024]; snprintf(tmp, sizeof(tmp), "%s.tmp", rcclIdFile);
-            FILE *f = fopen(tmp, "wb"); if (!f || fwrite(id, 1, 128, f) != 128) DIE("cannot write %s", tmp);
+            FILE *f = fopen(tmp, "wb");
+            if (!f || fwrite(&rcclNonce, 1, 8, f) != 8 || fwrite(id, 1, 128, f) != 128) DIE("cannot write %s", tmp);
             fclose(f); rename(tmp, rcclIdFile);
+            g_rcclIdFile = rcclIdFile; atexit(remove_id_file);
          } else {
-            FILE *f = NULL;
-            for (int tries = 0; tries < 6000 && !(f = fopen(rcclIdFile, "rb")); tries++) usleep(10000);
-            if (!f || fread(id, 1, 128, f) != 128) DIE("cannot read the RCCL id from %s", rcclIdFile);
-            fclose(f);
+            int got = 0;
+            for (int tries = 0; tries < rcclTimeout * 100 && !got; tries++) {
+               FILE *f = fopen(rcclIdFile, "rb");
+               unsigned long long n = 0;
+               if (f) { got = fread(&n, 1, 8, f) == 8 && n == rcclNonce && fread(id, 1, 128, f) == 128; fclose(f); }
+               if (!got) usleep(10000);
+            }
+            if (!got) DIE("rank %d: no RCCL id of this run (nonce %llu) in %s after %d s", rank, rcclNonce, rcclIdFile, rcclTimeout);
          }
+         g_rank = rank; signal(SIGALRM, rendezvous_timeout); alarm((unsigned)rcclTimeout);
          CHECK(htkamd_comm_init(&comm, nRanks, rank, id));
+         alarm(0);
       }
       /* this rank's shard: files rank, rank + R, ... (HERest -p semantics with the script file split round-robin) */
       strlist mine = {0};
@@ -220,7 +259,12 @@ int main(int argc, char **argv)
          free_observations(&ob);
       }
       htkamd_fb_destroy(fb);
-      if (comm) { CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL)); htkamd_comm_destroy(comm); }
+      if (comm) {
+         alarm((unsigned)rcclTimeout);                      /* a rank that died before this point would leave the others in the collective for ever */
+         CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL));
+         alarm(0);
+         htkamd_comm_destroy(comm);
+      }
       CHECK(htkamd_accs_download(accs, vec, NULL));
       if (mlf) htkamd_mlf_free(mlf);
    }
@@ -274,7 +318,16 @@ int main(int argc, char **argv)
       CHECK(htkamd_model_get_params(model, mean, var, gc, wt, tp));
       char one[2048]; const char *oneFile = NULL;
       if (mmfs.n > 0) { make_fn(mmfs.v[0], outDir ? outDir : ".", NULL, one, sizeof(one)); oneFile = one; }
-      if (binary) CHECK(htkamd_mmf_write_binary(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
+      if (mmfs.n > 1) {
+         /* several master files (-H macros -H hmmdefs): every macro back to the file it came from, as SaveHMMSet does, so that the
+            next iteration's -H dir/macros -H dir/hmmdefs finds them */
+         char **outs = (char **)malloc(sizeof(char *) * (size_t)mmfs.n);
+         for (int k = 0; k < mmfs.n; k++) { outs[k] = (char *)malloc(2048); make_fn(mmfs.v[k], outDir ? outDir : ".", NULL, outs[k], 2048); }
+         CHECK(htkamd_mmf_write_sources(mmf, mean, var, gc, wt, tp, (const char *const *)outs, mmfs.n, outDir ? outDir : ".", binary));
+         for (int k = 0; k < mmfs.n; k++) free(outs[k]);
+         free(outs);
+      }
+      else if (binary) CHECK(htkamd_mmf_write_binary(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
       else CHECK(htkamd_mmf_write(mmf, mean, var, gc, wt, tp, oneFile, oneFile ? NULL : (outDir ? outDir : ".")));
       TOC(6);
       if (us.nFloorVar > 0 && !(uFlags & HTKAMD_UPMAP)) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);

@@ -48,4 +48,15 @@ for k, v in per_kernel(os.path.join(out, "pmc_SQ"), names).items():
     sq[k] = {c: sum(x) / len(x) for c, x in v.items()}
 json.dump({"_comment": "SQ counters per launch (mean over the launches of `bench.py --steps 1 --warmup 0`)", "kernels": sq},
           open(os.path.join("profiles", "%s_sq.json" % tag), "w"), indent=1)
+mf = {}
+mnames = {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_MFMA"}
+for k, v in per_kernel(os.path.join(out, "pmc_MFMA"), mnames).items():
+    mf[k] = {c: sum(x) / len(x) for c, x in v.items()}
+    if mf[k].get("SQ_BUSY_CU_CYCLES"):
+        # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD (4 per CU) against SQ_BUSY_CU_CYCLES per CU (MI355X_MICROARCH.md)
+        mf[k]["mfma_busy_frac"] = mf[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * mf[k]["SQ_BUSY_CU_CYCLES"])
+if mf:
+    json.dump({"_comment": "matrix-pipe counters per launch (mean over the launches of `bench.py --steps 1 --warmup 0`); mfma_busy_frac = "
+                           "SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)", "kernels": mf},
+              open(os.path.join("profiles", "%s_mfma.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:1500])
