@@ -209,15 +209,6 @@ class Model:
         out = dO.to_host(np.float32, (ns, T))
         return np.ascontiguousarray(out.T)
 
-    def write_sources(self, params: dict, master_out, out_dir=None, binary=False):
-        """SaveHMMSet for a set loaded from several master files: master_out[k] = path for the k-th file read (htkamd_mmf_write_sources)."""
-        g = params.get("gconst")
-        arr = (C.c_char_p * len(master_out))(*[str(x).encode() for x in master_out])
-        check(lib().htkamd_mmf_write_sources(self.h, _p(np.ascontiguousarray(params["mean"], np.float32)), _p(np.ascontiguousarray(params["var"], np.float32)),
-                                             _p(np.ascontiguousarray(g, np.float32)) if g is not None else None,
-                                             _p(np.ascontiguousarray(params["compWeight"], np.float32)), _p(np.ascontiguousarray(params["transP"], np.float32)),
-                                             arr, C.c_int(len(master_out)), out_dir.encode() if out_dir else None, C.c_int(1 if binary else 0)), "mmf_write_sources")
-
     def close(self):
         if self.h:
             lib().htkamd_model_destroy(self.h)
@@ -710,6 +701,15 @@ class Mmf:
                                      _p(np.ascontiguousarray(g, np.float32)) if g is not None else None,
                                      _p(np.ascontiguousarray(params["compWeight"], np.float32)), _p(np.ascontiguousarray(params["transP"], np.float32)),
                                      one_file.encode() if one_file else None, out_dir.encode() if out_dir else None), "mmf_write")
+
+    def write_sources(self, params: dict, master_out, out_dir=None, binary=False):
+        """SaveHMMSet for a set loaded from several master files: master_out[k] = path for the k-th file read (htkamd_mmf_write_sources)."""
+        g = params.get("gconst")
+        arr = (C.c_char_p * len(master_out))(*[str(x).encode() for x in master_out])
+        check(lib().htkamd_mmf_write_sources(self.h, _p(np.ascontiguousarray(params["mean"], np.float32)), _p(np.ascontiguousarray(params["var"], np.float32)),
+                                             _p(np.ascontiguousarray(g, np.float32)) if g is not None else None,
+                                             _p(np.ascontiguousarray(params["compWeight"], np.float32)), _p(np.ascontiguousarray(params["transP"], np.float32)),
+                                             arr, C.c_int(len(master_out)), out_dir.encode() if out_dir else None, C.c_int(1 if binary else 0)), "mmf_write_sources")
 
     def close(self):
         if self.h:
