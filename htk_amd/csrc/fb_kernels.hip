@@ -559,6 +559,76 @@ __global__ void k_alpha(FbArgs a)
 // largest mixture count, a power of two), lane % GS = component.  Per lane group: `ok`, the tied state `st`, the row of the frame in
 // the feature table and the pair's seed (the state's log occupation without the component's own score, or with it for single
 // Gaussians).  Called by every lane of the wavefront; recBase / recUsed: the wavefront's block of the record list.
+// what follows the posterior of a lane's component (pass, Lr; g = its Gaussian, c0 + m its component, s the tied state): weight counts,
+// the record list of the per-Gaussian reduction, direct atomics for what the list has no room for
+template <int GS>
+__device__ __forceinline__ void mix_post(const FbArgs &a, const int s, const int c0, const int m, const int g, const bool pass, const double Lr,
+                                         const int frameRow, const float *xrow, int &recBase, int &recUsed)
+{
+   const int lane = threadIdx.x & 63, sub = lane % GS;
+   const int D = a.D;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   double sumLr = pass ? Lr : 0.0;
+#pragma unroll
+   for (int o = GS / 2; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);      // within the hit's lane group
+   if (sub == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
+   // record path: list (Gaussian, frame, posterior) for the per-Gaussian reduction (k_rec_reduce).  A wavefront takes list
+   // space in blocks of 64 records (one atomic on the shared cursor per block, not per hit: a single hot address serialises
+   // in L2); what is left of a block when the next is taken, or at the end, is filled with empty records (g = -1)
+   bool stored = false;
+   if (a.rec) {
+      const unsigned long long pk = __ballot(pass);
+      if (pk) {
+         const int np = __popcll(pk);
+         if (recBase < 0 || recUsed + np > 64) {
+            if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.recCtl, 64);
+            base = __shfl(base, 0);
+            recBase = (base >= 0 && (long long)base + 64 <= a.recCap) ? base : -1;
+            recUsed = 0;
+         }
+         if (recBase >= 0) {
+            if (pass) {
+               MixRec r; r.g = g; r.frame = frameRow; r.L = Lr;
+               a.rec[recBase + recUsed + __popcll(pk & ((1ull << lane) - 1))] = r;
+               atomicAdd(a.recCtl + 1 + g, 1);
+               stored = true;
+            }
+            recUsed += np;
+         }
+      }
+   }
+   if (pass) {
+      if (upMu && !stored) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+      if (upVa && !stored) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+      if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+   }
+   // first-order statistics of every surviving (hit, component): the whole wave, lane = dimension
+   unsigned long long pm = __ballot(pass && !stored);        // what the list had no room for: direct atomics
+   while (pm) {
+      const int ml = __ffsll((long long)pm) - 1;
+      pm &= pm - 1;
+      const double L = __shfl(Lr, ml);
+      const int gg = __shfl(g, ml);
+      const unsigned long long xp = (unsigned long long)xrow;
+      const float *xr = (const float *)(((unsigned long long)__shfl((int)(xp >> 32), ml) << 32) | (unsigned int)__shfl((int)(xp & 0xffffffffu), ml));
+      const float *mean = a.mean + (size_t)gg * D;
+      for (int k = lane; k < D; k += 64) {
+         const float z = xr[k] - mean[k];
+         if (upMu && upVa) {                    // HFB.c:1673-1678
+            const float zl = (float)((double)z * L);
+            atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+            atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
+         } else if (upMu) {                     // HFB.c:1697-1698
+            atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
+         } else if (upVa) {                     // HFB.c:1706-1709
+            atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
+         }
+      }
+   }
+}
+
 template <int DT, int GS>
 __device__ __forceinline__ void mix_hit(const FbArgs &a, const bool ok, const int st, const int frameRow, const double seed, int &recBase, int &recUsed)
 {
@@ -621,65 +691,7 @@ __device__ __forceinline__ void mix_hit(const FbArgs &a, const bool ok, const in
             }
          }
       }
-      double sumLr = pass ? Lr : 0.0;
-#pragma unroll
-      for (int o = GS / 2; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);      // within the hit's lane group
-      if (sub == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + s, sumLr);
-      // record path: list (Gaussian, frame, posterior) for the per-Gaussian reduction (k_rec_reduce).  A wavefront takes list
-      // space in blocks of 64 records (one atomic on the shared cursor per block, not per hit: a single hot address serialises
-      // in L2); what is left of a block when the next is taken, or at the end, is filled with empty records (g = -1)
-      bool stored = false;
-      if (a.rec) {
-         const unsigned long long pk = __ballot(pass);
-         if (pk) {
-            const int np = __popcll(pk);
-            if (recBase < 0 || recUsed + np > 64) {
-               if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
-               int base = 0;
-               if (lane == 0) base = atomicAdd(a.recCtl, 64);
-               base = __shfl(base, 0);
-               recBase = (base >= 0 && (long long)base + 64 <= a.recCap) ? base : -1;
-               recUsed = 0;
-            }
-            if (recBase >= 0) {
-               if (pass) {
-                  MixRec r; r.g = g; r.frame = frameRow; r.L = Lr;
-                  a.rec[recBase + recUsed + __popcll(pk & ((1ull << lane) - 1))] = r;
-                  atomicAdd(a.recCtl + 1 + g, 1);
-                  stored = true;
-               }
-               recUsed += np;
-            }
-         }
-      }
-      if (pass) {
-         if (upMu && !stored) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
-         if (upVa && !stored) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
-         if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
-      }
-      // first-order statistics of every surviving (hit, component): the whole wave, lane = dimension
-      unsigned long long pm = __ballot(pass && !stored);        // what the list had no room for: direct atomics
-      while (pm) {
-         const int ml = __ffsll((long long)pm) - 1;
-         pm &= pm - 1;
-         const double L = __shfl(Lr, ml);
-         const int gg = __shfl(g, ml);
-         const unsigned long long xp = (unsigned long long)xrow;
-         const float *xr = (const float *)(((unsigned long long)__shfl((int)(xp >> 32), ml) << 32) | (unsigned int)__shfl((int)(xp & 0xffffffffu), ml));
-         const float *mean = a.mean + (size_t)gg * D;
-         for (int k = lane; k < D; k += 64) {
-            const float z = xr[k] - mean[k];
-            if (upMu && upVa) {                    // HFB.c:1673-1678
-               const float zl = (float)((double)z * L);
-               atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
-               atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
-            } else if (upMu) {                     // HFB.c:1697-1698
-               atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
-            } else if (upVa) {                     // HFB.c:1706-1709
-               atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
-            }
-         }
-      }
+      mix_post<GS>(a, s, c0, m, g, pass, Lr, frameRow, xrow, recBase, recUsed);
    }
 }
 
@@ -746,28 +758,95 @@ __global__ __launch_bounds__(256, 4) void k_mixstats(FbArgs a)
 // state) pairs, so nothing can overflow and no cursor is shared -- and leaves the number of 16-byte records it wrote in hitCtl):
 // ~20 MB instead of the 0.5 GB seed array written and read back at the bench workload
 template <int DT, int GS>
-__global__ __launch_bounds__(256, 4) void k_mixhits(FbArgs a)
+__global__ __launch_bounds__(256, 3) void k_mixhits(FbArgs a)
 {
    constexpr int HPS = 64 / GS;
    __shared__ int hitSt[4][64], hitFrame[4][64];
    __shared__ double hitSeed[4][64];
+   __shared__ unsigned long long hitKey[4][64];
    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-   const int grp = lane / GS;
+   const int grp = lane / GS, sub = lane % GS;
    const int nWaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
    const int waveId = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
    int recBase = -1, recUsed = 0;
    volatile int *hSt = hitSt[wv], *hFr = hitFrame[wv];
    volatile double *hSeed = hitSeed[wv];
+   volatile unsigned long long *hKey = hitKey[wv];
    for (int b = waveId; b < a.nHitRegions; b += nWaves) {
       const int cnt = a.hitCtl[b];
       const MixHit *reg = a.hits + (size_t)b * a.hitRegionCap;
-      for (int c0 = 0; c0 < cnt; c0 += 64) {
-         const int n = (cnt - c0 < 64) ? cnt - c0 : 64;
-         if (lane < n) { const MixHit h = reg[c0 + lane]; hSt[lane] = h.st; hFr[lane] = h.frame; hSeed[lane] = h.seed; }
-         for (int i0 = 0; i0 < n; i0 += HPS) {
-            const int src = (i0 + grp < n) ? i0 + grp : -1;
-            const bool have = src >= 0;
-            mix_hit<DT, GS>(a, have, have ? hSt[src] : 0, have ? hFr[src] : 0, have ? hSeed[src] : LZERO, recBase, recUsed);
+      for (int c0r = 0; c0r < cnt; c0r += 64) {
+         const int n = (cnt - c0r < 64) ? cnt - c0r : 64;
+         if constexpr (DT > 0) {
+            // The pairs of a region are a few states over a run of frames.  Sorted by state, a lane group meets the same state several
+            // times in a row and keeps its component's (mean, 1/variance) row IN REGISTERS across them: the posterior evaluation read
+            // 16 x 320 bytes of parameters per pair (6 GB from L2 / the Infinity Cache per pass at the bench workload), now once per run.
+            MixHit h; h.st = 0; h.frame = 0; h.seed = LZERO;
+            if (lane < n) h = reg[c0r + lane];
+            const unsigned long long key = ((unsigned long long)(unsigned int)h.st << 32) | (unsigned int)h.frame;
+            hKey[lane] = (lane < n) ? key : ~0ull;
+            int rank = 0;
+            for (int jx = 0; jx < n; jx++) { const unsigned long long kj = hKey[jx]; rank += (kj < key || (kj == key && jx < lane)) ? 1 : 0; }
+            if (lane < n) { hSt[rank] = h.st; hFr[rank] = h.frame; hSeed[rank] = h.seed; }
+            const int per = (n + HPS - 1) / HPS;
+            const int i0g = grp * per, i1g = (i0g + per < n) ? i0g + per : n;
+            constexpr int NQ = (DT + 1) / 2;
+            float4 pm[NQ];
+            float gcst = 0.0f, wt = 0.0f;
+            int stPrev = -1, c0 = 0, M = 0, g = 0;
+            const double minF = (double)a.minFrwdP;
+            for (int it = 0; it < per; it++) {
+               const int idx = i0g + it;
+               const bool have = idx < i1g;
+               const int st = have ? hSt[idx] : 0, frameRow = have ? hFr[idx] : 0;
+               const double seed = have ? hSeed[idx] : LZERO;
+               if (have && st != stPrev) {
+                  stPrev = st;
+                  c0 = a.stateCompOff[st]; M = a.stateCompOff[st + 1] - c0;
+                  if (sub < M) {
+                     g = a.compGauss[c0 + sub];
+                     wt = a.compLogWt[c0 + sub];
+                     const float4 *P4 = (const float4 *)(a.gparam + (size_t)g * a.PS);
+#pragma unroll
+                     for (int q = 0; q < NQ; q++) pm[q] = P4[q];
+                     gcst = a.gparam[(size_t)g * a.PS + 2 * DT];
+                  }
+               }
+               const float *xrow = a.X + (size_t)frameRow * DT;
+               bool pass = false;
+               double Lr = 0.0;
+               if (have && sub < M) {
+                  if (M == 1 || a.maxM == 1) { pass = true; Lr = exp(seed); }
+                  else if (wt > (float)LMINMIX) {
+                     float sum = gcst;
+#pragma unroll
+                     for (int q0 = 0; q0 < NQ; q0 += 4) {
+                        float xv[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) if (2 * q0 + i < DT) xv[i] = xrow[2 * q0 + i];
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                           if (2 * q0 + i < DT) {
+                              const float4 pv = pm[q0 + (i >> 1)];
+                              const float mu = (i & 1) ? pv.z : pv.x, iv = (i & 1) ? pv.w : pv.y;
+                              const float xmm = xv[i] - mu;
+                              sum += xmm * xmm * iv;
+                           }
+                     }
+                     const float prob = -0.5f * sum;
+                     const double x = (seed + (double)wt) + (double)prob;
+                     if (-x < minF) { pass = true; Lr = exp(x); }
+                  }
+               }
+               mix_post<GS>(a, st, c0, sub, g, pass, Lr, frameRow, xrow, recBase, recUsed);
+            }
+         } else {
+            if (lane < n) { const MixHit h = reg[c0r + lane]; hSt[lane] = h.st; hFr[lane] = h.frame; hSeed[lane] = h.seed; }
+            for (int i0 = 0; i0 < n; i0 += HPS) {
+               const int src = (i0 + grp < n) ? i0 + grp : -1;
+               const bool have = src >= 0;
+               mix_hit<DT, GS>(a, have, have ? hSt[src] : 0, have ? hFr[src] : 0, have ? hSeed[src] : LZERO, recBase, recUsed);
+            }
          }
       }
    }

@@ -109,19 +109,21 @@ def _mmf_numbers(path):
 def _mmf_close(ours, theirs, tol=1e-4):
     """Token-by-token comparison of two text MMFs (tokens from _mmf_numbers): names and keywords equal, numbers within `tol` of the
     reference's -- relative for variances, weights, transition probabilities and gConsts, and relative to max(|mean|, sigma_i) for the
-    elements of a mean vector (a mean near zero has no scale of its own), with sigma_i the smallest standard deviation
-    the reference's file holds for vector element i."""
+    elements of a mean vector (a mean near zero has no scale of its own).  sigma_i comes from the variance vector that
+    follows the mean in the file (the same mixture component); a mean without one (a ~u macro, a component with a ~v reference) takes
+    the median over the file's variance vectors at element i."""
     assert len(ours) == len(theirs)
-    vmin, i = {}, 0
-    while i < len(theirs):                                   # smallest variance per vector position
+    cols, i = {}, 0
+    while i < len(theirs):
         if theirs[i] == "<VARIANCE>":
             n = int(theirs[i + 1])
             for k in range(n):
-                vmin[k] = min(vmin.get(k, np.inf), theirs[i + 2 + k])
+                cols.setdefault(k, []).append(theirs[i + 2 + k])
             i += 2 + n
         else:
             i += 1
-    in_mean, left, pos = False, 0, 0
+    vmed = {k: float(np.median(v)) for k, v in cols.items()}
+    in_mean, left, pos, own = False, 0, 0, None
     for idx, (x, y) in enumerate(zip(ours, theirs)):
         if not isinstance(y, float):
             assert x == y, (idx, x, y)
@@ -131,10 +133,12 @@ def _mmf_close(ours, theirs, tol=1e-4):
         if left == -1:                                        # the vector's length
             assert x == y
             left = int(y); pos = 0
+            j = idx + 1 + left                                # the variance vector of the same component, if it follows
+            own = theirs[j + 2:j + 2 + left] if in_mean and j + 1 < len(theirs) and theirs[j] == "<VARIANCE>" else None
             continue
         scale = max(abs(y), 1e-3)
         if in_mean and left > 0:
-            scale = max(abs(y), float(np.sqrt(vmin.get(pos, 0.0))))
+            scale = max(abs(y), float(np.sqrt(own[pos] if own is not None else vmed.get(pos, 0.0))))
         if left > 0:
             left -= 1; pos += 1
         assert abs(x - y) <= tol * scale, (idx, x, y, scale)
