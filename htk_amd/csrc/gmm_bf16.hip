@@ -99,8 +99,6 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
    const int col = lane & 15, kg = lane >> 4;
    const int D = a.D;
    const int dpc = (D + NC - 1) / NC;                  // dimensions per K chunk (<= 15)
-   cint *slotState = (cint *)a.slotState;
-   cint *stateTileOff = (cint *)a.stateTileOff;
    const u4 *tab = (const u4 *)a.bf16Tab;
 
    for (;;) {
@@ -112,7 +110,11 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
       const int fw = 32 * wv;                         // this wave's first frame in the tile
       const bool active = fw < tk.nFrames;
 
-      int tile = stateTileOff[slotState[tk.slot0]];
+      // first tile and tile count of every state of the task, one per lane (tasks hold at most 64 states): the tile loop below reads them
+      // with v_readlane instead of chains of dependent scalar loads (two per state, each a round trip to the scalar cache or L2)
+      int tFirstV = 0, tEndV = 0;
+      if (lane < tk.nSlots) { const int stl = a.slotState[tk.slot0 + lane]; tFirstV = a.stateTileOff[stl]; tEndV = a.stateTileOff[stl + 1]; }
+      int tile = __builtin_amdgcn_readlane(tFirstV, 0);
       {
          const u4 *W = tab + (size_t)tile * TW4;
 #pragma unroll
@@ -157,9 +159,8 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
 
       int buf = 0;
       for (int k = 0; k < tk.nSlots; k++) {
-         const int st = slotState[tk.slot0 + k];
-         const int t1 = stateTileOff[st + 1];
-         const int nextFirst = (k + 1 < tk.nSlots) ? stateTileOff[slotState[tk.slot0 + k + 1]] : -1;
+         const int t1 = __builtin_amdgcn_readlane(tEndV, k);
+         const int nextFirst = (k + 1 < tk.nSlots) ? __builtin_amdgcn_readlane(tFirstV, (k + 1) & 63) : -1;
          float rM[B16_COL_TILES], rS[B16_COL_TILES];
          bool first = true;
          for (;;) {
