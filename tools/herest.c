@@ -18,6 +18,9 @@
  *   --score m      arithmetic: exact (default: alpha/beta/scores bit-identical to the reference), fast (fp32 matrix-core scores +
  *                  fp32-transcendental LAdd), fastest (bf16 x 3 matrix-core scores + that LAdd); the latter two are tolerance class (1e-4)
  *   --batch N      utterances per device batch (default 4096)
+ *   --iterations K  K Baum-Welch iterations in one process: features, transcriptions and batch tables stay on the device, the model is
+ *                  re-estimated where it is (htkamd_model_update_device) and only the last iteration's set is written to -M (HTK's recipe runs
+ *                  one HERest process per iteration: load 88 MB, save 88 MB around 5 ms of device work)
  *   --ranks R --rank r --rccl-id file   one process per GPU: every rank takes the data files r, r+R, r+2R, ..., the accumulators are summed
  *                  over RCCL (htkamd_accs_allreduce) and every rank re-estimates; rank 0 writes the models.  `file` carries the
  *                  rendezvous id from rank 0 to the others, tagged with the run's nonce (--rccl-nonce N; default: the launcher's process
@@ -72,7 +75,7 @@ int main(int argc, char **argv)
    double pruneInit = HTKAMD_NOPRUNE, pruneInc = 0.0, pruneLim = HTKAMD_NOPRUNE;
    float minFrwdP = 10.0f, minVar = 0.0f, mixFloor = 0.0f;
    int uFlags = HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES | HTKAMD_UPTRANS, minEgs = 3, parMode = -1, trace = 0, binary = 0;
-   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120;
+   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1;
    unsigned long long rcclNonce = (unsigned long long)getppid();      /* the ranks of one run are children of one launcher; --rccl-nonce overrides */
    const char *sw;
 
@@ -86,6 +89,7 @@ int main(int argc, char **argv)
          } else if (!strcmp(lo, "batch")) batchN = atoi(str_arg(&a, "-batch"));
          else if (!strcmp(lo, "ranks")) nRanks = atoi(str_arg(&a, "-ranks"));
          else if (!strcmp(lo, "rank")) rank = atoi(str_arg(&a, "-rank"));
+         else if (!strcmp(lo, "iterations")) nIter = atoi(str_arg(&a, "-iterations"));
          else if (!strcmp(lo, "rccl-id")) rcclIdFile = str_arg(&a, "-rccl-id");
          else if (!strcmp(lo, "rccl-nonce")) rcclNonce = strtoull(str_arg(&a, "-rccl-nonce"), NULL, 0);
          else if (!strcmp(lo, "rccl-timeout")) rcclTimeout = atoi(str_arg(&a, "-rccl-timeout"));
@@ -130,6 +134,8 @@ int main(int argc, char **argv)
    if (files.n == 0) DIE("herest: no data files");
    if (nRanks < 1 || rank < 0 || rank >= nRanks) DIE("herest: --rank must be in 0..ranks-1");
    if (nRanks > 1 && !rcclIdFile) DIE("herest: --ranks needs --rccl-id <file>");
+   if (nIter < 1) DIE("herest: --iterations must be at least 1");
+   if (nIter > 1 && parMode >= 0) DIE("herest: --iterations goes with the single-process form (or --ranks), not with -p");
 
    if (htkamd_device_count() <= 0) DIE("herest: no HIP device (the MI355X path has no CPU fallback)");
    CHECK(htkamd_set_device(nRanks > 1 ? rank % htkamd_device_count() : 0));
@@ -213,58 +219,94 @@ int main(int argc, char **argv)
       /* this rank's shard: files rank, rank + R, ... (HERest -p semantics with the script file split round-robin) */
       strlist mine = {0};
       for (int i = rank; i < files.n; i += nRanks) sl_add(&mine, files.v[i]);
-      htkamd_fb *fb; CHECK(htkamd_fb_create(model, &fb));
       htkamd_fb_config fc; memset(&fc, 0, sizeof(fc));
       fc.pruneInit = pruneInit; fc.pruneInc = pruneInc; fc.pruneLim = pruneLim; fc.minFrwdP = minFrwdP; fc.uFlags = uFlags; fc.scoreMode = scoreMode;
-      CHECK(htkamd_accs_zero(accs, NULL));
-      for (int first = 0; first < mine.n; first += batchN) {
-         const int count = (mine.n - first < batchN) ? mine.n - first : batchN;
-         obs_batch ob; memset(&ob, 0, sizeof(ob));
-         tic_ = now_s();
-         load_observations(&mine, first, count, targetKind, &cfg, &ob);
-         if (ob.cols != D) DIE("observations have %d components, the models %d", ob.cols, D);
-         int *labOff = (int *)calloc((size_t)count + 1, sizeof(int)), *labs = NULL, capLab = 0;
-         for (int u = 0; u < count; u++) {
-            char lab[2048];
-            make_fn(mine.v[first + u], labDir, labExt, lab, sizeof(lab));
-            htkamd_labels *L = NULL; const htkamd_labels *Lc = NULL;
-            if (mlf) { Lc = htkamd_mlf_find(mlf, lab); if (!Lc) DIE("%s: no entry in the master label file %s", lab, mlfPath); }
-            else { CHECK(htkamd_labels_read(lab, &L)); Lc = L; }
-            const int n = htkamd_labels_count(Lc);
-            if (n == 0) fprintf(stderr, "WARNING [-7325] LoadUtterance: No labels in file %s\n", lab);
-            if (labOff[u] + n > capLab) { capLab = (labOff[u] + n) * 2 + 64; labs = (int *)realloc(labs, sizeof(int) * (size_t)capLab); }
-            for (int i = 0; i < n; i++) {
-               const int h = htkamd_mmf_find_logical(mmf, htkamd_labels_name(Lc, i));
-               if (h < 0) DIE("[7321] CreateInsts: Unknown label %s in %s", htkamd_labels_name(Lc, i), lab);
-               labs[labOff[u] + i] = h;
+      /* The shard in batches.  With --iterations K > 1 everything a batch needs stays where the first iteration put it -- features in HBM,
+         transcriptions as model indices, the batch tables of CreateInsts / SetBeamTaper in their context -- and the model never leaves
+         the device between iterations: iteration 2.. cost the pass and the update, not the files. */
+      typedef struct { obs_batch ob; int *labOff, *labs; int count, first; htkamd_fb *fb; } dev_batch;
+      const int nBatch = (mine.n + batchN - 1) / batchN;
+      dev_batch *bt = (dev_batch *)calloc((size_t)(nBatch ? nBatch : 1), sizeof(dev_batch));
+      for (int it = 1; it <= nIter; it++) {
+         CHECK(htkamd_accs_zero(accs, NULL));
+         for (int bi = 0; bi <= nBatch; bi++) {
+            if (bi < nBatch) {
+               dev_batch *B = &bt[bi];
+               tic_ = now_s();
+               if (it == 1) {
+                  B->first = bi * batchN; B->count = (mine.n - B->first < batchN) ? mine.n - B->first : batchN;
+                  load_observations(&mine, B->first, B->count, targetKind, &cfg, &B->ob);
+                  if (B->ob.cols != D) DIE("observations have %d components, the models %d", B->ob.cols, D);
+                  int capLab = 0;
+                  B->labOff = (int *)calloc((size_t)B->count + 1, sizeof(int));
+                  for (int u = 0; u < B->count; u++) {
+                     char lab[2048];
+                     make_fn(mine.v[B->first + u], labDir, labExt, lab, sizeof(lab));
+                     htkamd_labels *L = NULL; const htkamd_labels *Lc = NULL;
+                     if (mlf) { Lc = htkamd_mlf_find(mlf, lab); if (!Lc) DIE("%s: no entry in the master label file %s", lab, mlfPath); }
+                     else { CHECK(htkamd_labels_read(lab, &L)); Lc = L; }
+                     const int n = htkamd_labels_count(Lc);
+                     if (n == 0) fprintf(stderr, "WARNING [-7325] LoadUtterance: No labels in file %s\n", lab);
+                     if (B->labOff[u] + n > capLab) { capLab = (B->labOff[u] + n) * 2 + 64; B->labs = (int *)realloc(B->labs, sizeof(int) * (size_t)capLab); }
+                     for (int i = 0; i < n; i++) {
+                        const int h = htkamd_mmf_find_logical(mmf, htkamd_labels_name(Lc, i));
+                        if (h < 0) DIE("[7321] CreateInsts: Unknown label %s in %s", htkamd_labels_name(Lc, i), lab);
+                        B->labs[B->labOff[u] + i] = h;
+                     }
+                     B->labOff[u + 1] = B->labOff[u] + n;
+                     if (L) htkamd_labels_free(L);
+                  }
+                  CHECK(htkamd_fb_create(model, &B->fb));
+               }
+               TOC(2);
+               if (it == 1 || !htkamd_fb_prepared_current(B->fb)) {           /* the update changed a minimum duration: tables again */
+                  htkamd_batch_desc b = {B->count, B->ob.dX, B->ob.frameOff, B->labOff, B->labs};
+                  CHECK(htkamd_fb_prepare(B->fb, &b, NULL));
+               }
+               TOC(3);
+               CHECK(htkamd_fb_execute(B->fb, &fc, accs, NULL));            /* asynchronous: the next batch's files are read while this one runs */
             }
-            labOff[u + 1] = labOff[u] + n;
-            if (L) htkamd_labels_free(L);
+            if (bi > 0) {                                                     /* results of the batch before */
+               dev_batch *B = &bt[bi - 1];
+               double *pr = (double *)malloc(sizeof(double) * (size_t)B->count); int *st = (int *)malloc(sizeof(int) * (size_t)B->count);
+               tic_ = now_s();
+               CHECK(htkamd_fb_results(B->fb, pr, st, NULL));
+               TOC(4);
+               for (int u = 0; u < B->count; u++) {
+                  if (trace & 1) printf(" Processing Data: %s\n", mine.v[B->first + u]);
+                  if (st[u] == HTKAMD_UTT_OK) { if (trace & 1) printf(" Utterance prob per frame = %e\n", pr[u] / (B->ob.frameOff[u + 1] - B->ob.frameOff[u])); }
+                  else if (st[u] == HTKAMD_UTT_SKIPPED) fprintf(stderr, "WARNING [-7324] StepBack: File %s - bad data or over pruning\n", mine.v[B->first + u]);
+                  else DIE("[%d] forward-backward failed on %s", -st[u], mine.v[B->first + u]);
+               }
+               free(pr); free(st);
+               if (nIter == 1) { free(B->labOff); free(B->labs); free_observations(&B->ob); htkamd_fb_destroy(B->fb); B->fb = NULL; }
+            }
          }
-         htkamd_batch_desc b = {count, ob.dX, ob.frameOff, labOff, labs};
-         TOC(2);
-         CHECK(htkamd_fb_prepare(fb, &b, NULL));
-         TOC(3);
-         CHECK(htkamd_fb_execute(fb, &fc, accs, NULL));
-         double *pr = (double *)malloc(sizeof(double) * (size_t)count); int *st = (int *)malloc(sizeof(int) * (size_t)count);
-         CHECK(htkamd_fb_results(fb, pr, st, NULL));
-         TOC(4);
-         for (int u = 0; u < count; u++) {
-            if (trace & 1) printf(" Processing Data: %s\n", mine.v[first + u]);
-            if (st[u] == HTKAMD_UTT_OK) { if (trace & 1) printf(" Utterance prob per frame = %e\n", pr[u] / (ob.frameOff[u + 1] - ob.frameOff[u])); }
-            else if (st[u] == HTKAMD_UTT_SKIPPED) fprintf(stderr, "WARNING [-7324] StepBack: File %s - bad data or over pruning\n", mine.v[first + u]);
-            else DIE("[%d] forward-backward failed on %s", -st[u], mine.v[first + u]);
+         if (comm) {
+            alarm((unsigned)rcclTimeout);                   /* a rank that died before this point would leave the others in the collective for ever */
+            CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL));
+            alarm(0);
          }
-         free(pr); free(st); free(labOff); free(labs);
-         free_observations(&ob);
+         if (it < nIter) {
+            /* an intermediate iteration: UpdateModels where the model is, HERest's summary lines, nothing written */
+            tic_ = now_s();
+            CHECK(htkamd_accs_download(accs, vec, NULL));
+            htkamd_update_config uc; memset(&uc, 0, sizeof(uc));
+            uc.minEgs = minEgs; uc.minVar = minVar; uc.mixWeightFloor = mixFloor; uc.uFlags = uFlags; uc.varFloor = htkamd_mmf_var_floor(mmf); uc.singleProcess = (parMode == -1);   /* every iteration as a HERest process of its own would make it */
+            htkamd_update_stats us;
+            if (uFlags & HTKAMD_UPMAP) DIE("herest: --iterations with -u p (MAP) is not supported: one HERest pass per prior");
+            if (htkamd_model_has_sharing(model)) CHECK(htkamd_model_update(model, accs, vec, &uc, &us));
+            else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
+            TOC(5);
+            if (rank == 0) {
+               if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
+               printf("Iteration %d of %d complete - average log prob per frame = %e\n", it, nIter, vec[lay.totalPr] / vec[lay.totalT]);
+            }
+         }
       }
-      htkamd_fb_destroy(fb);
-      if (comm) {
-         alarm((unsigned)rcclTimeout);                      /* a rank that died before this point would leave the others in the collective for ever */
-         CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL));
-         alarm(0);
-         htkamd_comm_destroy(comm);
-      }
+      for (int bi = 0; bi < nBatch; bi++) if (bt[bi].fb) { free(bt[bi].labOff); free(bt[bi].labs); free_observations(&bt[bi].ob); htkamd_fb_destroy(bt[bi].fb); }
+      free(bt);
+      if (comm) htkamd_comm_destroy(comm);
       CHECK(htkamd_accs_download(accs, vec, NULL));
       if (mlf) htkamd_mlf_free(mlf);
    }
