@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--states", type=int, default=5000); ap.add_argument("--mix", type=int, default=16); ap.add_argument("--phones", type=int, default=6000)
     ap.add_argument("--utts", type=int, default=1250); ap.add_argument("--frames", type=int, default=500); ap.add_argument("--ref-utts", type=int, default=40)
     ap.add_argument("--score", default="fastest")
+    ap.add_argument("--iterations", type=int, default=4, help="also time K iterations in one process (tools/bin/herest --iterations K) against K chained processes")
     a = ap.parse_args()
     s = synth.generate_fast(a.states, a.mix, a.phones, a.utts, a.frames, seed=1000, model_seed=3)
     pk = s.packed()
@@ -83,6 +84,31 @@ def main():
             if r.returncode == 0:
                 out["binary_mmf"] = {"wall_s": runs, "mmf_MB": round(os.path.getsize(os.path.join(d, "bin0", "MMF")) / 1e6, 1),
                                      "phases_s": {" ".join(l.split()[1:-2]): float(l.split()[-2]) for l in r.stdout.splitlines() if l.startswith("Timing:")}}
+        # K Baum-Welch iterations: one process with --iterations K (everything stays on the device, one set written) against K processes
+        # chained through binary model files (HTK's recipe: one HERest run per iteration)
+        K = a.iterations
+        if K > 1:
+            os.makedirs(os.path.join(d, "itK"))
+            ck = [c for c in cmd]
+            ck[ck.index("-M") + 1] = os.path.join(d, "itK")
+            runs = []
+            for k in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run(ck[:-1] + ["-B", "--iterations", str(K), ck[-1]], capture_output=True, text=True)
+                runs.append(round(time.perf_counter() - t0, 3))
+            if r.returncode == 0:
+                t0 = time.perf_counter()
+                srcm = os.path.join(d, "MMF")
+                for k in range(K):
+                    os.makedirs(os.path.join(d, "ch%d" % k))
+                    cc = [c for c in cmd]
+                    cc[cc.index("-H") + 1] = srcm; cc[cc.index("-M") + 1] = os.path.join(d, "ch%d" % k)
+                    rc = subprocess.run(cc[:-1] + ["-B", cc[-1]], capture_output=True, text=True)
+                    srcm = os.path.join(d, "ch%d" % k, "MMF")
+                chain = round(time.perf_counter() - t0, 3)
+                out["iterations"] = {"K": K, "one_process_wall_s": runs, "chain_of_K_processes_wall_s": chain,
+                                     "phases_s": {" ".join(l.split()[1:-2]): float(l.split()[-2]) for l in r.stdout.splitlines() if l.startswith("Timing:")},
+                                     "log": [l.strip() for l in r.stdout.splitlines() if "average log prob" in l]}
         ref = os.path.join(ROOT, "oracle", "_ref", "HERest")
         if os.path.exists(ref) and a.ref_utts > 0:
             tt = []
