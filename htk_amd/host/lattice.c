@@ -43,12 +43,17 @@ static void put_word(FILE *f, const char *s)          /* "W=%-19s " with ReWrite
    fprintf(f, "W=%-19s ", buf);
 }
 
-float htkamd_lattice_arc_score(const htkamd_lattice *lat, int arc)
+/* LArcTotLike (HNet.h:257): the three scaled likelihoods summed in float, the word penalty added in DOUBLE (the macro's `? 0.0 :
+   wdpenalty` makes the last operand a double) -- TranscriptionFromLattice accumulates that double in its backward scores and in the
+   A* search (HRec.c:2176-2290); only the label's score is a float */
+static double arc_total_like(const htkamd_lattice *lat, int arc)
 {
    const int pron = lat->nodePron[lat->arcEnd[arc]];
    const float ac = lat->arcAc[arc] * 1.0f, lm = lat->arcLm[arc] * lat->lmScale, pr = lat->arcPr[arc] * lat->prScale;
-   return (float)((double)((ac + lm) + pr) + (pron < 0 ? 0.0 : (double)lat->wordPen));
+   return (double)((ac + lm) + pr) + (pron < 0 ? 0.0 : (double)lat->wordPen);
 }
+
+float htkamd_lattice_arc_score(const htkamd_lattice *lat, int arc) { return (float)arc_total_like(lat, arc); }
 
 int htkamd_lattice_write(const htkamd_lattice *lat, const struct htkamd_net *net, const char *path, const char *utterance, const char *lmName,
                          const char *vocabName, int format)
@@ -142,7 +147,7 @@ int htkamd_lattice_nbest(const htkamd_lattice *lat, const struct htkamd_net *net
    for (int i = nn - 1; i > 0; i--) {
       const int ln = order[i];
       for (int a = pred[ln]; a >= 0; a = parc[a]) {
-         const double sc = score[ln] + (double)htkamd_lattice_arc_score(lat, a);
+         const double sc = score[ln] + arc_total_like(lat, a);
          if (sc > score[lat->arcStart[a]]) score[lat->arcStart[a]] = sc;
       }
    }
@@ -158,7 +163,7 @@ int htkamd_lattice_nbest(const htkamd_lattice *lat, const struct htkamd_net *net
       if (pred[i] >= 0) continue;
       if (score[i] < LSMALL) { htkamd_set_error("lattice_nbest: no route through the lattice"); rc = HTKAMD_EMODEL; break; }
       for (int a = foll[i]; a >= 0; a = farc[a]) {
-         const double like = (double)htkamd_lattice_arc_score(lat, a), sc = like + score[lat->arcEnd[a]];
+         const double like = arc_total_like(lat, a), sc = like + score[lat->arcEnd[a]];
          if (sc < LSMALL) continue;
          PUSH(sc, like, lat->arcEnd[a], a, -1);
       }
@@ -169,7 +174,7 @@ int htkamd_lattice_nbest(const htkamd_lattice *lat, const struct htkamd_net *net
       e[e[best].link].knil = e[best].knil; e[e[best].knil].link = e[best].link;
       if (foll[e[best].lnode] >= 0) {
          for (int a = foll[e[best].lnode]; a >= 0; a = farc[a]) {
-            const double like = e[best].like + (double)htkamd_lattice_arc_score(lat, a), sc = like + score[lat->arcEnd[a]];
+            const double like = e[best].like + arc_total_like(lat, a), sc = like + score[lat->arcEnd[a]];
             if (sc < LSMALL) continue;
             PUSH(sc, like, lat->arcEnd[a], a, best);
          }
