@@ -241,7 +241,9 @@ def main():
         ch["fbs"][k].prepare(ch["x_ptr"], ch["frameOff"], ch["labOff"], ch["labs"], sp)
         ch["ready"][k] = True
 
-    def em_iteration(timed: bool):
+    def em_iteration(timed: bool, parts=None):
+        """One EM iteration.  `parts` (an array of four) asks for the wall-clock split pass | all-reduce | update | results: that costs three
+        extra stream synchronisations, so it is taken in a few iterations AFTER the timed region, never inside it."""
         k = it_no[0] & 1
         it_no[0] += 1
         t = [time.perf_counter()]
@@ -261,19 +263,19 @@ def main():
             prep(ch, k ^ 1, lanes[c % len(lanes)].cuda_stream)
         for c in range(NCH):
             stream.wait_event(ev_chunk[c])
-        if timed:
+        if parts is not None:
             stream.synchronize(); t.append(time.perf_counter())
         if world > 1:
             herest.all_reduce_accumulators(acc_t)                              # the iteration's one exchange: RCCL sum over xGMI
-        if timed:
+        if parts is not None:
             stream.synchronize(); t.append(time.perf_counter())
         st_upd = model.update_device(accs, stream=sptr, **upd)                   # synchronises the stream
-        if timed:
+        if parts is not None:
             t.append(time.perf_counter())
         prs, sts = zip(*[ch["fbs"][k].results(sptr) for ch in chunks])
-        if timed:
+        if parts is not None:
             t.append(time.perf_counter())
-            t_parts[:] += np.diff(t)
+            parts[:] += np.diff(t)
         return np.concatenate(prs), np.concatenate(sts), st_upd, k
 
     def sync_all():
@@ -306,8 +308,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ktimes /= max(args.steps, 1)
-    t_parts /= max(args.steps, 1)
     a = accs.download()                                                        # the last iteration's summed statistics
+    for i in range(3):                                                         # the split of an iteration's wall clock, outside the timed region
+        em_iteration(False, parts=t_parts)
+    t_parts /= 3.0
 
     # one un-chunked pass ALONE (outside the timed region): the kernels' own durations, the latency of a single pass
     fb1 = capi.ForwardBackward(model)
@@ -378,6 +382,8 @@ def main():
             "utterances_ok": utts_total,
             "em_iteration_ms": dt / args.steps * 1e3,
             "batch_tables_rebuilt_in_iteration": n_reprepared[0],
+            # split of an iteration's wall clock, from three iterations AFTER the timed region run with a stream synchronisation after every
+            # part (the timed iterations carry none but the one the model update needs: their sum is above ms_per_step)
             "em_iteration_parts_ms": {"pass": t_parts[0] * 1e3, "allreduce": t_parts[1] * 1e3, "update_and_refresh": t_parts[2] * 1e3, "results": t_parts[3] * 1e3},
             "pass_latency_ms": float(np.median(lat)) * 1e3,
             "avg_logprob_per_frame": float(a_init["totalPr"] / a_init["totalT"]) if a_init["totalT"] else None,

@@ -332,6 +332,9 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    int err = 0;
    double mmpA = LZERO;                                  // MaxModelProb of this model in the column just finished (first lane)
    int fLo0 = 0, fLo1 = flOf[lo1], fHi1 = flOf[hi1 > 0 ? hi1 : 1], fE0 = 0;
+   // the two range masks of the beam decision, kept while their bounds stay (the beta beam's bounds move every few frames only)
+   MaskW<W> mLo = MaskW<W>::range(0, L - 1), mE = MaskW<W>::range(0, -1);
+   int mLoOf = 0, mEOf = 0, lo1Of = lo1, hi1Of = hi1, e0Of = -1;
    double eT = LZERO, eT1 = LZERO;                       // entry-state beta of the own model in columns t, t+1 (first lane)
    if (valid && s.first) { eT = entry_beta<FAST>(s.aEntry, (double)oT, bT); if (T >= 2) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1); }
 
@@ -389,10 +392,12 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
 #pragma unroll
             for (int k = 0; k < W; k++) kept.w[k] = firsts.w[k] & ~bslot[par][k];
          }
-         const int slane = (kept & MaskW<W>::range(fLo0, L - 1)).lowest();             // first model >= qLo[t-1] that is kept
+         if (fLo0 != mLoOf) { mLo = MaskW<W>::range(fLo0, L - 1); mLoOf = fLo0; }
+         if (fE0 != mEOf) { mE = MaskW<W>::range(0, fE0 - 1); mEOf = fE0; }
+         const int slane = (kept & mLo).lowest();                                      // first model >= qLo[t-1] that is kept
          if (slane < 0 || slane > fHi1) { err = 1; break; }                            // sq > qHi[t]
          sl = (slane < fLo1) ? fLo1 : slane;                                           // start-point below the beta beam: pulled back
-         const int elane = (kept & MaskW<W>::range(0, fE0 - 1)).highest();             // last kept model <= min(qHi[t-1] + 1, Q)
+         const int elane = (kept & mE).highest();                                      // last kept model <= min(qHi[t-1] + 1, Q)
          if (elane < 0 || elane < sl) { err = 1; break; }
          el = (elane > fHi1) ? fHi1 : elane;
          in = valid && myFirst >= sl && myFirst <= el;
@@ -452,7 +457,9 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
       lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = (t + 2 <= T) ? (w3 >> 16) : 0;
       // first lanes of the models that bound the next step's beam decisions (hi1 may be 0 past the last frame: the step is not taken)
       fLo0 = fLo1;
-      fLo1 = flOf[lo1]; fHi1 = flOf[hi1 > 0 ? hi1 : 1]; fE0 = flOf[((hi0 < Q) ? hi0 + 1 : hi0) + 1];
+      if (lo1 != lo1Of) { fLo1 = flOf[lo1]; lo1Of = lo1; }
+      if (hi1 != hi1Of) { fHi1 = flOf[hi1 > 0 ? hi1 : 1]; hi1Of = hi1; }
+      { const int e0 = ((hi0 < Q) ? hi0 + 1 : hi0) + 1; if (e0 != e0Of) { fE0 = flOf[e0]; e0Of = e0; } }
    }
 
    if (err) {

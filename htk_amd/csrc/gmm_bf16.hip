@@ -87,12 +87,16 @@ __device__ __host__ __forceinline__ void split3(float x, unsigned short &p1, uns
    p3 = bf16_bits(r2);
 }
 
+#ifndef B16_WPB
+#define B16_WPB 4                                       // wavefronts per workgroup: 4 x 32 frames = a whole 128-frame task; 2: the task in two halves
+#endif
 template <int NC>
-__global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
+__global__ __launch_bounds__(64 * B16_WPB, 12 / B16_WPB) void k_score_bf16(ScoreArgs a)
 {
+   constexpr int NT = 64 * B16_WPB, HALVES = 4 / B16_WPB;
    constexpr int TWB = 3 * NC * 64 * 16 + 64 * 16;     // bytes per fragment tile
    constexpr int TW4 = TWB / 16;                       // 16-byte words per tile
-   constexpr int PT = (TW4 + 255) / 256;               // words staged per thread
+   constexpr int PT = (TW4 + NT - 1) / NT;             // words staged per thread
    __shared__ u4 wbuf[2][TW4];
    __shared__ int taskSh;
    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -104,10 +108,11 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
    for (;;) {
       if (tid == 0) taskSh = atomicAdd(a.taskCounter, 1);
       __syncthreads();
-      const int task = __builtin_amdgcn_readfirstlane(taskSh);
+      const int vtask = __builtin_amdgcn_readfirstlane(taskSh);
+      const int task = vtask / HALVES;
       if (task >= a.nTasks) break;
       const ScoreTask tk = a.tasks[task];
-      const int fw = 32 * wv;                         // this wave's first frame in the tile
+      const int fw = 32 * wv + (128 / HALVES) * (vtask % HALVES);      // this wave's first frame in the tile
       const bool active = fw < tk.nFrames;
 
       // first tile and tile count of every state of the task, one per lane (tasks hold at most 64 states): the tile loop below reads them
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
          const u4 *W = tab + (size_t)tile * TW4;
 #pragma unroll
          for (int j = 0; j < PT; j++)
-            if (j * 256 + tid < TW4) wbuf[0][j * 256 + tid] = W[j * 256 + tid];
+            if (j * NT + tid < TW4) wbuf[0][j * NT + tid] = W[j * NT + tid];
       }
 
       // B operand: this lane's frame (col) of each column tile, the 8 k of lane group kg in every chunk, in three bf16 pieces
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
                const u4 *W = tab + (size_t)nextTile * TW4;
 #pragma unroll
                for (int j = 0; j < PT; j++)
-                  if (j * 256 + tid < TW4) stg[j] = W[j * 256 + tid];
+                  if (j * NT + tid < TW4) stg[j] = W[j * NT + tid];
             }
             if (active) {
                bf8 wa[3][NC];
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void k_score_bf16(ScoreArgs a)
             if (nextTile >= 0) {
 #pragma unroll
                for (int j = 0; j < PT; j++)
-                  if (j * 256 + tid < TW4) wbuf[buf ^ 1][j * 256 + tid] = stg[j];
+                  if (j * NT + tid < TW4) wbuf[buf ^ 1][j * NT + tid] = stg[j];
             }
             __syncthreads();
             buf ^= 1;
@@ -245,9 +250,9 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
    if (a.nTasks <= 0) return HTKAMD_OK;
    if (!m->d_bf16Tab) { htkamd_set_error("score_bf16: vector size %d not supported by the bf16 matrix-core path (up to 45)", m->D); return HTKAMD_EMODEL; }
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
-   int blocks = a.nTasks;
-   if (blocks > 256 * 3) blocks = 256 * 3;      // persistent blocks, one task (128 frames x 16 states) at a time
-   dim3 grid(blocks), block(256);
+   int blocks = a.nTasks * (4 / B16_WPB);
+   if (blocks > 256 * (12 / B16_WPB)) blocks = 256 * (12 / B16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) or half-task at a time
+   dim3 grid(blocks), block(64 * B16_WPB);
    switch (m->bf16NC) {
    case 3: hipExtLaunchKernelGGL((k_score_bf16<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
    case 2: hipExtLaunchKernelGGL((k_score_bf16<2>), grid, block, 0, stream, evStart, evStop, 0, a); break;
