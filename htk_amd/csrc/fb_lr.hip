@@ -490,6 +490,11 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
    constexpr int L = 64 * W, FC = STATS_FC, OS = FC + 3;
    __shared__ double etab[FAST ? 1 : EXP_TAB_N];
    __shared__ float otile[(L + 1) * OS];                 // scores of frames t0 .. t1+1, one row per lane (+ one row of zeros after the last)
+   // the surviving pairs of a wavefront wait here and go out in whole lines at the end (a global store per frame made the next frame wait
+   // for it: the compiler drains vmcnt before it reuses the store's registers -- 0.33 ms of the kernel's 0.59)
+   constexpr int HB = 128;
+   __shared__ int hbSt[W][HB], hbFr[W][HB];
+   __shared__ double hbSeed[W][HB];
    if constexpr (!FAST) exp_table_to_lds(etab);
    const int gl = threadIdx.x, lane = gl & 63, wv = gl >> 6;
    const int li = blockIdx.x, ch = blockIdx.y;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
    int cM = 0, sidx = 0;
    if (valid) { sidx = a.slotState[ud.slot0 + gl]; cM = a.stateCompOff[sidx + 1] - a.stateCompOff[sidx]; }
    MixHit *hreg = a.hits + region * (size_t)(STATS_FC * 64);
-   int hc = 0;                                           // records in this wavefront's region of the hit list
+   int hc = 0, hb = 0;                                   // records in this wavefront's region of the hit list / waiting in its LDS buffer
    const bool single = (a.maxM == 1);
    const bool hasNext = valid && q < Q;
    const bool nbValid = gl + 1 < nS;                     // the lane next door holds a state
@@ -572,7 +577,11 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
       // nothing (below e^-100) for all but the few states along the alignment: the exponentials run only where it is not, and not at all
       // in a wavefront none of whose states is occupied in this frame.
       const double xo = aJ + bT - pr;
+#ifdef STATS_EXP_NOOCC
+      const bool occd = false;
+#else
       const bool occd = inBeam && xo > EXPFLOOR;
+#endif
       if (__any(occd)) {
       if (occd) {
          // SetOcct + UpTranParms for state j, and for the entry state at the model's first lane
@@ -612,15 +621,26 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
                if (ub > -minF - 0.01) seed = initx;
             }
          }
+#ifdef STATS_EXP_NOHIT
+         const bool hit = false;
+#else
          const bool hit = seed > LSMALL;
+#endif
          const unsigned long long hm = __ballot(hit);
          if (hm) {
-            if (hit) { MixHit h; h.st = sidx; h.frame = ud.frame0 + t - 1; h.seed = seed; hreg[hc + __popcll(hm & ((1ull << lane) - 1))] = h; }
-            hc += __popcll(hm);
+            const int np = __popcll(hm);
+            if (hb + np > HB) {                          // the buffer is full: out with it
+               for (int i = lane; i < hb; i += 64) { MixHit h; h.st = hbSt[wv][i]; h.frame = hbFr[wv][i]; h.seed = hbSeed[wv][i]; hreg[hc + i] = h; }
+               hc += hb; hb = 0;
+            }
+            if (hit) { const int pos = hb + __popcll(hm & ((1ull << lane) - 1)); hbSt[wv][pos] = sidx; hbFr[wv][pos] = ud.frame0 + t - 1; hbSeed[wv][pos] = seed; }
+            hb += np;
          }
       }
       }
    }
+   for (int i = lane; i < hb; i += 64) { MixHit h; h.st = hbSt[wv][i]; h.frame = hbFr[wv][i]; h.seed = hbSeed[wv][i]; hreg[hc + i] = h; }
+   hc += hb;
    if (lane == 0) a.hitCtl[region] = hc;
 
    // ---- this workgroup's counts.  One transition matrix for the whole chain (a tied-transition system): a row of partial sums per
