@@ -285,10 +285,13 @@ def main():
         torch.cuda.synchronize()
 
     # the pass with the INITIAL model, outside the timed region: its log-probabilities are checked against the oracle below
-    accs.zero(sptr)
-    for ch in chunks:
-        prep(ch, 0, sptr); ch["fbs"][0].execute(cfg, accs, sptr)
-    pr_init = np.concatenate([ch["fbs"][0].results(sptr)[0] for ch in chunks])
+    # (run through BOTH batch contexts of every chunk: a context allocates its device workspace at its first pass, and that must not fall
+    # into the timed region whatever --warmup is)
+    for k0 in (1, 0):
+        accs.zero(sptr)
+        for ch in chunks:
+            prep(ch, k0, sptr); ch["fbs"][k0].execute(cfg, accs, sptr)
+        pr_init = np.concatenate([ch["fbs"][k0].results(sptr)[0] for ch in chunks])
     a_init = accs.download()
     units_local = sum(ch["fbs"][0].frame_states() for ch in chunks)           # (frame, chain state) evaluations of this rank's shard
 
