@@ -103,6 +103,77 @@ def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=32):
+    """The path's other two consumers, at the same set, outside the timed region (reported, never `value`):
+    HVite -a forced alignment (K5) of the shard's first utterances -- checked against the oracle's token likelihood on one of them --
+    and HVite -w decoding (K7) over a word loop of the set's 6 000 one-model words with -t 250 (BASELINE config[3])."""
+    import tempfile
+    from htk_amd import capi
+    from oracle import pyoracle as po
+    out = {}
+    model = capi.Model(pk)
+    n_align = min(n_align, len(s.feats))
+    fo = frame_off_all[:n_align + 1].astype(np.int32)
+    lo = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs[:n_align]])]).astype(np.int32)
+    lb = np.concatenate(s.seqs[:n_align]).astype(np.int32)
+    vit = capi.Viterbi(model)
+    got = vit.align(dX.data_ptr(), fo, lo, lb)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        got = vit.align(dX.data_ptr(), fo, lo, lb)
+    dt = (time.perf_counter() - t0) / 3
+    ref = po.viterbi_align(po.Model(pk), s.feats[0], s.seqs[0])
+    assert ref is not None and got[0]["status"] == 1 and got[0]["total"] == ref["total"], "bench: alignment differs from the oracle"
+    out["hvite_alignment"] = {"utterances": n_align, "ms": dt * 1e3, "utterances_per_sec": n_align / dt, "frames_per_sec": float(fo[-1]) / dt,
+                              "oracle_check": "token likelihood of utterance 0 bit-identical", "arithmetic": "exact (K1 + K5)"}
+    # decoding: the network builder wants names and topologies only -- a stand-in model file with the set's 6 000 models over one state
+    V = int(pk["numPhys"])
+    d = tempfile.mkdtemp(prefix="bench_dec_")
+    try:
+        names = ["p%d" % i for i in range(V)]
+        Dv = int(pk["vecSize"])
+        with open(os.path.join(d, "MMF"), "w") as f:
+            f.write("~o\n<STREAMINFO> 1 %d\n<VECSIZE> %d<NULLD><USER><DIAGC>\n" % (Dv, Dv))
+            f.write('~t "T0"\n<TRANSP> 5\n 0 1 0 0 0\n 0 0.6 0.4 0 0\n 0 0 0.6 0.4 0\n 0 0 0 0.7 0.3\n 0 0 0 0 0\n')
+            f.write('~s "S0"\n<MEAN> %d\n%s\n<VARIANCE> %d\n%s\n' % (Dv, " 0" * Dv, Dv, " 1" * Dv))
+            for n_ in names:
+                f.write('~h "%s"\n<BEGINHMM>\n<NUMSTATES> 5\n<STATE> 2\n~s "S0"\n<STATE> 3\n~s "S0"\n<STATE> 4\n~s "S0"\n~t "T0"\n<ENDHMM>\n' % n_)
+        open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
+        open(os.path.join(d, "dict"), "w").write("".join("%s %s\n" % (n_, n_) for n_ in names))
+        with open(os.path.join(d, "net.slf"), "w") as f:                       # the word loop HBuild writes
+            f.write("VERSION=1.0\nN=%d L=%d\nI=0 W=!NULL\nI=1 W=!NULL\n" % (V + 4, 2 * V + 3))
+            for i, n_ in enumerate(names):
+                f.write("I=%d W=%s\n" % (2 + i, n_))
+            f.write("I=%d W=!NULL\nI=%d W=!NULL\n" % (V + 2, V + 3))
+            j = 0
+            f.write("J=%d S=0 E=1 l=0.00\n" % j); j += 1
+            f.write("J=%d S=%d E=1 l=0.00\n" % (j, V + 2)); j += 1
+            for i in range(V):
+                f.write("J=%d S=1 E=%d l=%.2f\n" % (j, 2 + i, np.log(1.0 / V))); j += 1
+                f.write("J=%d S=%d E=%d l=0.00\n" % (j, 2 + i, V + 2)); j += 1
+            f.write("J=%d S=%d E=%d l=0.00\n" % (j, V + 2, V + 3))
+        mmf = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
+        net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
+        dec = capi.Decoder(model, net)
+        feats = s.feats[:n_decode]
+        res = dec.run(feats, genBeam=250.0)
+        t0 = time.perf_counter()
+        res = dec.run(feats, genBeam=250.0)
+        dt = time.perf_counter() - t0
+        hit = tot = 0
+        for (w, _), q in zip(res, s.seqs[:n_decode]):
+            rec = [] if w is None else [net.out_syms[p_] for p_, _, _, _ in w]
+            ref_ = ["p%d" % k for k in q]
+            tot += len(ref_); hit += sum(1 for x, y in zip(rec, ref_) if x == y) if len(rec) == len(ref_) else 0
+        out["hvite_decoding"] = {"utterances": len(feats), "ms": dt * 1e3, "utterances_per_sec": len(feats) / dt, "frames_per_sec": sum(f.shape[0] for f in feats) / dt,
+                                 "network": "word loop over %d one-model words, -t 250 (BASELINE config[3])" % V, "words_correct": "%d/%d" % (hit, tot),
+                                 "arithmetic": "exact (K1 dense + K7)"}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def cgroup_cpu_quota():
     """CPUs the container's cgroup grants (cpu.max of cgroup v2, cfs quota of v1), or None when unlimited / unknown."""
     try:
@@ -159,6 +230,7 @@ def main():
     ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the reference CPU baseline (0 = one per physical host core)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="1: also time forced alignment and network decoding at the same set after the timed region (N = 1 only; reported as other_paths)")
     ap.add_argument("--dump-model", default=None, help="rank 0 writes the model of the last iteration (npz: mean, var, compWeight, transP) -- the multi-GPU tests compare it over rank counts")
     args = ap.parse_args()
 
@@ -463,6 +535,11 @@ def main():
                 out["cpu_baseline_port"] = port
             else:
                 out["cpu_baseline"] = port
+        if args.extras and world == 1:
+            try:
+                out["other_paths"] = other_paths(s, pk, dX, frame_off_all)
+            except Exception as e:  # noqa: BLE001  (reported beside the line, never instead of it)
+                out["other_paths"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
     if args.dump_model and rank == 0:
         p_ = model.get_params()

@@ -36,7 +36,7 @@ def _env():
 
 def _bench(n, out, port, total=256):
     args = ["--gpus", str(n), "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
-            "--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--dump-model", out]
+            "--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--extras", "0", "--dump-model", out]
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
