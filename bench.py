@@ -302,6 +302,7 @@ def main():
         chunks.append(dict(fbs=[capi.ForwardBackward(model), capi.ForwardBackward(model)], ready=[False, False], frameOff=fo, labOff=lo, labs=lb,
                            x_ptr=dX.data_ptr() + int(frame_off_all[u0]) * D * 4, n=u1 - u0))
     lanes = [torch.cuda.Stream() for _ in range(min(2, NCH))] if (args.two_streams and NCH > 1) else [stream]
+    copy_stream = torch.cuda.Stream()
     ev_chunk = [torch.cuda.Event() for _ in range(NCH)]
     ev_zero = torch.cuda.Event()
     upd = dict(minEgs=3, minVar=args.min_var)                                   # HERest -m 3 (default), -v
@@ -331,8 +332,8 @@ def main():
                 n_reprepared[0] += int(timed)
             ch["fbs"][k].execute(cfg, accs, ln.cuda_stream)
             ev_chunk[c].record(ln)
-        for c, ch in enumerate(chunks):                                        # the kernels are running: next iteration's tables
-            prep(ch, k ^ 1, lanes[c % len(lanes)].cuda_stream)
+        for c, ch in enumerate(chunks):                                        # the kernels are running: next iteration's tables, uploaded on a
+            prep(ch, k ^ 1, copy_stream.cuda_stream)                           # stream of their own (htkamd_fb_execute waits for the copy's event)
         for c in range(NCH):
             stream.wait_event(ev_chunk[c])
         if parts is not None:

@@ -577,6 +577,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
                            2 * r8(nc * mn * 4) + 4 * r8(qm * 4) + 2 * r8(tm * 2);
 
    int rc;
+   // the batch tables may have been uploaded on another stream (htkamd_fb_prepare's): the kernels wait for that copy, not the host
+   if (fb->copyPending) HIPCHECK(hipStreamWaitEvent(s, fb->evCopy, 0));
    HIPCHECK(hipEventRecord(fb->ev[0], s));
    if ((rc = htkamd_launch_score(cfg->scoreMode, m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
    fb->scored = sa.nTasks > 0;
