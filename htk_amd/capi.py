@@ -149,6 +149,12 @@ class Model:
         ms = np.ascontiguousarray(meanShare, np.int32); vs = np.ascontiguousarray(varShare, np.int32)
         check(lib().htkamd_model_set_sharing(self.h, _p(ms), _p(vs)), "model_set_sharing")
 
+    def set_scan_order(self, order):
+        """The order in which UpdateModels visits the physical models (htkamd_model_set_scan_order; hmm_scan_order() gives HTK's)."""
+        o = np.ascontiguousarray(order, np.int32)
+        assert o.shape == (self.H,)
+        check(lib().htkamd_model_set_scan_order(self.h, _p(o)), "model_set_scan_order")
+
     def set_params(self, mean=None, var=None, gconst=None, compWeight=None, transP=None):
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
         args = [f32(mean), f32(var), f32(gconst), f32(compWeight), f32(transP)]

@@ -86,6 +86,8 @@ struct htkamd_model {
    /* shared mean / variance vectors (~u / ~v macros; htkamd_model_set_sharing): first Gaussian of the group a Gaussian's mean / variance
       belongs to (itself when private), members of its variance group; NULL = no sharing in the set */
    int   *h_meanLeader, *h_varLeader, *h_varGroupSize;
+   int   *d_shareTab;                 /* meanLeader[G] varLeader[G] varGroupSize[G] muMemOff[G+1] vaMemOff[G+1] muMem[] vaMem[] (update.hip) */
+   int    shareMuMem, shareVaMem;     /* lengths of the two member lists */
    int   *h_scanOrder;         /* [H] the reference's HMM scan order of the physical models (htkamd_model_set_scan_order), or NULL */
    double minLogExp;
 };

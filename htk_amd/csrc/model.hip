@@ -306,7 +306,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
-   free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize);
+   free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize); (void)hipFree(m->d_shareTab);
    free(m);
 }
 
@@ -332,6 +332,7 @@ extern "C" int htkamd_model_set_sharing(htkamd_model *m, const int *meanShare, c
    if (!m) { htkamd_set_error("model_set_sharing: NULL model"); return HTKAMD_EINVAL; }
    free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize);
    m->h_meanLeader = m->h_varLeader = m->h_varGroupSize = nullptr;
+   if (m->d_shareTab) { (void)hipFree(m->d_shareTab); m->d_shareTab = nullptr; }
    bool any = false;
    for (int g = 0; g < m->G; g++) if ((meanShare && meanShare[g] >= 0) || (varShare && varShare[g] >= 0)) any = true;
    if (!any) return HTKAMD_OK;
@@ -362,6 +363,31 @@ extern "C" int htkamd_model_set_sharing(htkamd_model *m, const int *meanShare, c
       }
    }
    for (int g = 0; g < G; g++) m->h_varGroupSize[m->h_varLeader[g]]++;
+   // the device update's copy: leaders, group sizes and, per leader, the other members of its group in ascending order (the order
+   // in which htkamd_update_models pools their statistics)
+   {
+      std::vector<int> tab((size_t)3 * G + 2 * ((size_t)G + 1));
+      memcpy(tab.data(), m->h_meanLeader, sizeof(int) * (size_t)G);
+      memcpy(tab.data() + G, m->h_varLeader, sizeof(int) * (size_t)G);
+      memcpy(tab.data() + 2 * (size_t)G, m->h_varGroupSize, sizeof(int) * (size_t)G);
+      std::vector<int> mem[2];
+      for (int pass = 0; pass < 2; pass++) {
+         const int *leader = pass ? m->h_varLeader : m->h_meanLeader;
+         int *off = tab.data() + 3 * (size_t)G + (size_t)pass * (G + 1);
+         std::vector<int> cnt((size_t)G + 1, 0);
+         for (int g = 0; g < G; g++) if (leader[g] != g) cnt[leader[g] + 1]++;
+         off[0] = 0;
+         for (int g = 0; g < G; g++) off[g + 1] = off[g] + cnt[g + 1];
+         mem[pass].resize((size_t)off[G] + 1);
+         std::vector<int> fill(off, off + G);
+         for (int g = 0; g < G; g++) if (leader[g] != g) mem[pass][fill[leader[g]]++] = g;
+         (pass ? m->shareVaMem : m->shareMuMem) = off[G];
+      }
+      tab.insert(tab.end(), mem[0].begin(), mem[0].begin() + m->shareMuMem);
+      tab.insert(tab.end(), mem[1].begin(), mem[1].begin() + m->shareVaMem);
+      HIPCHECK(hipMalloc(&m->d_shareTab, sizeof(int) * tab.size()));
+      HIPCHECK(hipMemcpy(m->d_shareTab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+   }
    return HTKAMD_OK;
 }
 

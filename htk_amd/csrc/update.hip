@@ -37,6 +37,10 @@ struct UpdArgs {
    unsigned char *qualT, *qualS, *qualG, *anyS, *anyG;      // marked by a qualifying model / used by any model
    unsigned char *flooredG;                                 // a variance element of the Gaussian was floored
    int *stats;                                              // htkamd_update_stats fields in order + [6] weights above 1.001
+   // sets with tied mean / variance vectors (~u ~v; htkamd_model_set_sharing), else tied == 0
+   int tied;
+   const int *meanLeader, *varLeader, *varGroupSize, *muMemOff, *vaMemOff, *muMem, *vaMem, *scanPos;
+   int *firstMu, *firstVa;                                  // scan position of the first qualifying model whose mixture reaches the vector
 };
 
 #define ACCF(off, idx) ((float)a.acc[(off) + (size_t)(idx)])
@@ -118,6 +122,90 @@ __global__ void k_upd_state(UpdArgs a)
       if (a.anyS[s]) a.anyG[g] = 1;
       if (a.qualS[s] && (double)wgt[k] > MINMIX) a.qualG[g] = 1;
    }
+}
+
+// Tied vectors.  The reference hangs ONE accumulator on a shared vector and lets the first mixture that reaches it (models in scan
+// order; in a model all variances, then all means: HERest.c:1262-1321) update it; a variance loses its mean-shift term when its mean
+// was moved by an EARLIER model (HERest.c:1080 `shared`).  "First" is a minimum over scan positions, which needs no order:
+__global__ void k_upd_first(UpdArgs a)
+{
+   const int h = blockIdx.x * blockDim.x + threadIdx.x;
+   if (h >= a.H) return;
+   const long long n = llround(a.acc[a.lay.nEgs + h]);
+   if (!(n >= a.minEgs && n > 0)) return;
+   const int pos = a.scanPos ? a.scanPos[h] : h;
+   const int *hs = a.hmmState + a.hmmStateOff[h];
+   const int ns = a.hmmStateOff[h + 1] - a.hmmStateOff[h];
+   for (int j = 0; j < ns; j++)
+      for (int c = a.stateCompOff[hs[j]]; c < a.stateCompOff[hs[j] + 1]; c++)
+         if ((double)a.compWeight[c] > MINMIX) {
+            const int g = a.compGauss[c];
+            atomicMin(a.firstMu + a.meanLeader[g], pos);
+            atomicMin(a.firstVa + a.varLeader[g], pos);
+         }
+}
+
+// the group's statistic: the leader's plus its members' in ascending order, as htkamd_update_models pools them (fp64)
+__device__ __forceinline__ double pooled(const double *acc, size_t off, int leader, int stride, int k, const int *memOff, const int *mem)
+{
+   double v = acc[off + (size_t)leader * stride + k];
+   for (int i = memOff[leader]; i < memOff[leader + 1]; i++) v += acc[off + (size_t)mem[i] * stride + k];
+   return v;
+}
+
+// Every member of a group computes the group's new vector from the pooled statistics and its OWN (equal) copy of the old one, so no
+// copy pass is needed and no thread reads a slot another one writes; the counts are taken by the leader's threads.
+__global__ void k_upd_gauss_elem_tied(UpdArgs a)
+{
+   const size_t idx0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   const int D = a.D;
+   const bool live = idx0 < (size_t)a.G * D;
+   const unsigned int idx = live ? (unsigned int)idx0 : 0u;
+   const int g = (int)(idx / (unsigned int)D), k = (int)(idx - (unsigned int)g * (unsigned int)D);
+   const int gv = a.varLeader[g], gm = a.meanLeader[g];
+   float v = a.var[idx], mu = a.mean[idx];
+   bool floored = false;
+   if (a.singleProcess && a.anyG[gv]) {
+      float iv;
+      if (v > 1E+30f) v = 1E+30f;
+      if (v < 1E-30f) v = 1E-30f;
+      iv = 1 / v;
+      if (iv > 1E+30f) iv = 1E+30f;
+      if (iv < 1E-30f) iv = 1E-30f;
+      v = 1 / iv;
+   }
+   const int posVa = a.firstVa[gv], posMu = a.firstMu[gm];
+   if ((a.uFlags & HTKAMD_UPVARS) && posVa != 0x7f7f7f7f) {
+      const float occim = (float)pooled(a.acc, a.lay.vaOcc, gv, 1, 0, a.vaMemOff, a.vaMem);
+      if (occim > 0.0f) {
+         // the mean of the mixture that reached this variance first: for a private variance its own Gaussian's
+         const float muOcc = (float)pooled(a.acc, a.lay.muOcc, gm, 1, 0, a.muMemOff, a.muMem);
+         const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || posMu < posVa || muOcc <= 0.0f || a.varGroupSize[gv] > 1;
+         const float muDiffk = shared ? 0.0f : (float)pooled(a.acc, a.lay.mu, gm, D, k, a.muMemOff, a.muMem) / muOcc;
+         float x = (float)pooled(a.acc, a.lay.va, gv, D, k, a.vaMemOff, a.vaMem) / occim - muDiffk * muDiffk;
+         const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
+         if (x < fl) { x = fl; floored = live && g == gv; }
+         v = x;
+      } else if (k == 0 && live && g == gv) atomicAdd(a.stats + 5, 1);
+   }
+   if ((a.uFlags & HTKAMD_UPMEANS) && posMu != 0x7f7f7f7f) {
+      const float muOcc = (float)pooled(a.acc, a.lay.muOcc, gm, 1, 0, a.muMemOff, a.muMem);
+      if (muOcc > 0.0f) mu += (float)pooled(a.acc, a.lay.mu, gm, D, k, a.muMemOff, a.muMem) / muOcc;
+   }
+   {
+      const unsigned long long fb = __ballot(floored);
+      if (fb && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)fb) - 1)) atomicAdd(a.stats + 0, __popcll(fb));
+      if (floored) a.flooredG[g] = 1;
+   }
+   if (!live) return;
+   a.var[idx] = v; a.mean[idx] = mu;
+   float c = v;
+   if (c > 1E+30f) c = 1E+30f;
+   if (c < 1E-30f) c = 1E-30f;
+   const float r = 1 / c;
+   a.ivar[idx] = r;
+   float *gp = a.gparam + (size_t)g * a.PS;
+   gp[2 * k] = mu; gp[2 * k + 1] = r;
 }
 
 // Variances and means, one thread per (Gaussian, dimension): every array is walked in storage order (coalesced), the per-Gaussian
@@ -253,17 +341,14 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
 {
    if (!m || !accs || !cfg) { htkamd_set_error("model_update_device: NULL argument"); return HTKAMD_EINVAL; }
    if (accs->m != m) { htkamd_set_error("model_update_device: accumulators belong to a different model"); return HTKAMD_EINVAL; }
-   if (m->h_meanLeader) {
-      // the order-dependent pooling of tied vectors (UpdateVars / UpdateMeans walk the set; HERest.c:974-1122) lives in the host update
-      htkamd_set_error("model_update_device: the set shares mean / variance vectors (~u ~v): use htkamd_model_update");
-      return HTKAMD_EMODEL;
-   }
    if (cfg->uFlags & HTKAMD_UPMAP) { htkamd_set_error("model_update_device: MAP re-estimation (HTKAMD_UPMAP) is done by htkamd_model_update"); return HTKAMD_EMODEL; }
    hipStream_t s = (hipStream_t)stream;
    int rc;
    if ((rc = htkamd_model_device_tables(m))) return rc;
    const size_t nFlag = (size_t)m->nT + 2 * (size_t)m->S + 3 * (size_t)m->G;
-   const size_t need = ((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int) + sizeof(float) * (size_t)m->D;
+   const bool tied = m->h_meanLeader != nullptr;
+   const size_t nTiedInts = tied ? 2 * (size_t)m->G + (size_t)m->H : 0;           // firstMu[G] firstVa[G] scanPos[H]
+   const size_t need = ((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int) + sizeof(float) * (size_t)m->D + sizeof(int) * nTiedInts;
    if (need > m->updScratchCap) {
       if (m->d_updScratch) (void)hipFree(m->d_updScratch);
       m->d_updScratch = nullptr; m->updScratchCap = 0;
@@ -287,6 +372,21 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    float *dFloor = (float *)(a.stats + 16);
    a.hasVarFloor = cfg->varFloor != nullptr; a.varFloor = dFloor;
    if (cfg->varFloor) HIPCHECK(hipMemcpyAsync(dFloor, cfg->varFloor, sizeof(float) * (size_t)m->D, hipMemcpyHostToDevice, s));
+   int *scanPosHost = nullptr;
+   if (tied) {
+      const int G = m->G;
+      a.tied = 1;
+      a.meanLeader = m->d_shareTab; a.varLeader = a.meanLeader + G; a.varGroupSize = a.varLeader + G;
+      a.muMemOff = a.varGroupSize + G; a.vaMemOff = a.muMemOff + G + 1; a.muMem = a.vaMemOff + G + 1; a.vaMem = a.muMem + m->shareMuMem;
+      a.firstMu = (int *)(dFloor + m->D); a.firstVa = a.firstMu + G;
+      HIPCHECK(hipMemsetAsync(a.firstMu, 0x7f, sizeof(int) * 2 * (size_t)G, s));         // 0x7f7f7f7f: "no model yet" below
+      if (m->h_scanOrder) {
+         scanPosHost = (int *)malloc(sizeof(int) * (size_t)m->H);
+         for (int k = 0; k < m->H; k++) scanPosHost[m->h_scanOrder[k]] = k;
+         HIPCHECK(hipMemcpyAsync(a.firstVa + G, scanPosHost, sizeof(int) * (size_t)m->H, hipMemcpyHostToDevice, s));
+         a.scanPos = a.firstVa + G;
+      }
+   }
    const int B = 128;
    hipLaunchKernelGGL(k_upd_mark, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
    hipLaunchKernelGGL(k_upd_trans, dim3((m->nT + B - 1) / B), dim3(B), 0, s, a);
@@ -294,7 +394,11 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    {
       const size_t nEl = (size_t)m->G * m->D;
       if (nEl >= ((size_t)1 << 31)) { htkamd_set_error("model_update_device: %zu mean / variance elements (the element kernel indexes with 32 bits)", nEl); return HTKAMD_EMODEL; }
-      hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
+      if (tied) {
+         hipLaunchKernelGGL(k_upd_first, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
+         hipLaunchKernelGGL(k_upd_gauss_elem_tied, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
+      } else
+         hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
    }
    hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
    HIPCHECK(hipGetLastError());
@@ -308,6 +412,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    HIPCHECK(hipMemcpyAsync(m->h_transP, m->d_transP, sizeof(float) * nTp, hipMemcpyDeviceToHost, s));
    HIPCHECK(hipMemcpyAsync(hst, a.stats, sizeof(hst), hipMemcpyDeviceToHost, s));
    HIPCHECK(hipStreamSynchronize(s));
+   free(scanPosHost);
    for (int t = 0; t < m->nT; t++) {
       const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
       if (md != m->h_minDur[t]) { m->h_minDur[t] = md; m->topoVersion++; }

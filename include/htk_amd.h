@@ -95,7 +95,8 @@ int  htkamd_model_create(const htkamd_model_desc *desc, htkamd_model **out);
  * vector Gaussian g's mean / variance is a copy of (-1 = private; either array may be NULL); htkamd_mmf_sharing gives them for a set
  * read from files.  Scoring and the statistics are per Gaussian as always; htkamd_model_update pools the statistics of the sharers
  * as the reference's hooks on the shared vector do (one MuAcc / VaAcc per vector; a tied variance gets no mean-shift correction,
- * HERest.c:1080) and keeps the copies equal.  htkamd_model_update_device refuses such a set (HTKAMD_EMODEL). */
+ * HERest.c:1080) and keeps the copies equal; htkamd_model_update_device does the same where the accumulators lie (the "first mixture
+ * to reach the vector" of the reference's scan as a minimum over scan positions). */
 int  htkamd_model_set_sharing(htkamd_model *m, const int *meanShare /*[G]*/, const int *varShare /*[G]*/);
 /* The order in which UpdateModels (HERest.c:1262-1321) visits the physical models: the reference's HMM scan, i.e. htkamd_hmm_scan_order of
    their names.  It matters only for sets with mean vectors shared across models (which Gaussian's variance takes the mean-shift term);

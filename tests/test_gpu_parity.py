@@ -369,6 +369,65 @@ def test_device_update_equals_host_update(native, name, variant):
     assert np.allclose(res[0], res[1], rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize("variant", ["plain", "single", "floors", "means_only"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_device_update_with_tied_vectors_equals_host_update(native, seed, variant):
+    """Sets with tied mean / variance vectors (~u ~v): htkamd_model_update_device pools the statistics of a group and decides "whose
+    variance keeps the mean-shift term" by minimum scan position (update.hip: k_upd_first) -- against the host update, which walks the
+    models in scan order as UpdateModels does (HERest.c:974-1122, 1262-1321; pinned to the reference's MMFs by tests/test_cli_tools.py).
+    Random groups across states and models, a random scan order, models below minEgs."""
+    from htk_amd import synth, capi
+    rng = np.random.default_rng(seed)
+    s = synth.generate(40, 3, 30, 20, 90, 11 + seed)
+    pk = dict(s.packed())
+    G, D = int(pk["numGauss"]), int(pk["vecSize"])
+    mean, var = np.array(pk["mean"], np.float32).reshape(G, D), np.array(pk["var"], np.float32).reshape(G, D)
+    ms, vs = np.full(G, -1, np.int32), np.full(G, -1, np.int32)
+    for share, vec in ((ms, mean), (vs, var)):
+        perm = rng.permutation(G)
+        pos, gid = 0, 0
+        while pos < G // 2:
+            n = int(rng.integers(2, 5))
+            grp = perm[pos:pos + n]; pos += n
+            share[grp] = gid; gid += 1
+            vec[grp] = vec[grp.min()]
+    pk["mean"], pk["var"] = mean.reshape(np.shape(pk["mean"])), var.reshape(np.shape(pk["var"]))
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    kw = dict(plain=dict(minEgs=2), single=dict(minEgs=1, singleProcess=True), floors=dict(minEgs=1, minVar=0.6, mixWeightFloor=2e-5 * 3),
+              means_only=dict(minEgs=1, uFlags=capi.UPMEANS | capi.UPMIXES))[variant]
+    models, order = [], None
+    for _ in range(2):
+        m = native.Model(pk); m.set_sharing(ms, vs)
+        if order is None:
+            order = rng.permutation(m.H).astype(np.int32)
+        m.set_scan_order(order)
+        models.append(m)
+    mh, md = models
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = native.DevArray(X)
+    fb, acc = native.ForwardBackward(mh), native.Accs(mh)
+    fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+    fb.execute(native.fb_config(), acc)
+    a = acc.download()
+    sh = mh.update(acc, a["vec"], **kw)
+    accd = native.Accs(md); accd.upload_add(a["vec"])
+    sd = md.update_device(accd, **kw)
+    assert sh == sd, (sh, sd)
+    ph, pd = mh.get_params(), md.get_params()
+    for k in ("mean", "var", "gconst", "compWeight", "transP"):
+        x, y = ph[k].reshape(-1), pd[k].reshape(-1)
+        ne = x != y
+        assert ne.sum() <= max(3, 1e-5 * x.size), (k, int(ne.sum()), np.abs(x - y).max())
+        assert np.allclose(x[ne], y[ne], rtol=2.5e-7, atol=0), k
+    # every user of a vector holds the group's value
+    for share, k in ((ms, "mean"), (vs, "var")):
+        v = pd[k].reshape(G, D)
+        for gid in range(int(share.max()) + 1):
+            grp = np.nonzero(share == gid)[0]
+            assert (v[grp] == v[grp[0]]).all()
+    assert (pd["mean"] != np.asarray(pk["mean"]).reshape(pd["mean"].shape)).any()
+
+
 def test_em_iterations_increase_likelihood(native):
     """Three Baum-Welch iterations through prepare/execute/update: the total log-likelihood must not decrease."""
     from htk_amd import synth

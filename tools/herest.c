@@ -295,8 +295,7 @@ int main(int argc, char **argv)
             uc.minEgs = minEgs; uc.minVar = minVar; uc.mixWeightFloor = mixFloor; uc.uFlags = uFlags; uc.varFloor = htkamd_mmf_var_floor(mmf); uc.singleProcess = (parMode == -1);   /* every iteration as a HERest process of its own would make it */
             htkamd_update_stats us;
             if (uFlags & HTKAMD_UPMAP) DIE("herest: --iterations with -u p (MAP) is not supported: one HERest pass per prior");
-            if (htkamd_model_has_sharing(model)) CHECK(htkamd_model_update(model, accs, vec, &uc, &us));
-            else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
+            CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
             TOC(5);
             if (rank == 0) {
                if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
@@ -348,9 +347,7 @@ int main(int argc, char **argv)
          printf("Observed components (means) %d of %d: %.2f\n", us.nMapObserved, totM, 100 * (float)us.nMapObserved / (float)totM);
          if (us.nFloorVar > 0) printf("Total %d floored variance elements in %d different mixes\n", us.nFloorVar, us.nFloorVarMix);
       }
-   } else if (htkamd_model_has_sharing(model)) {
-      CHECK(htkamd_model_update(model, accs, vec, &uc, &us));         /* pooled statistics of the tied vectors: host update */
-   } else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));
+   } else CHECK(htkamd_model_update_device(model, accs, &uc, &us, NULL));      /* tied ~u ~v vectors included (pooled statistics, update.hip) */
    TOC(5);
    if (us.nSkippedHmm > 0) fprintf(stderr, "WARNING [-2331] UpdateModels: %d models had fewer than %d examples and were copied\n", us.nSkippedHmm, minEgs);
    if (rank == 0) {
