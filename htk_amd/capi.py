@@ -41,7 +41,8 @@ class ModelDesc(C.Structure):
                 ("stateCompOff", C.c_void_p), ("compWeight", C.c_void_p), ("compGauss", C.c_void_p),
                 ("mean", C.c_void_p), ("var", C.c_void_p), ("gconst", C.c_void_p),
                 ("transN", C.c_void_p), ("transOff", C.c_void_p), ("transP", C.c_void_p),
-                ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p)]
+                ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p),
+                ("numStreams", C.c_int), ("dimStream", C.c_void_p)]
 
 
 class AccsLayout(C.Structure):
@@ -132,12 +133,15 @@ class Model:
         self._keep = dict(stateCompOff=i32(pk["stateCompOff"]), compWeight=f32(pk["compWeight"]), compGauss=i32(pk["compGauss"]),
                           mean=f32(pk["mean"]), var=f32(pk["var"]), gconst=f32(pk.get("gconst")),
                           transN=i32(pk["transN"]), transOff=i32(pk["transOff"]), transP=f32(pk["transP"]),
-                          hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]))
+                          hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]),
+                          dimStream=i32(pk["dimStream"]) if pk.get("dimStream") is not None else None)
         k = self._keep
+        self.NS = int(pk.get("numStreams", 1) or 1)
         d = ModelDesc(int(pk["vecSize"]), int(pk["numStates"]), int(pk["numComp"]), int(pk["numGauss"]),
                       int(pk["numTrans"]), int(pk["numPhys"]),
                       _p(k["stateCompOff"]), _p(k["compWeight"]), _p(k["compGauss"]), _p(k["mean"]), _p(k["var"]), _p(k["gconst"]),
-                      _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]))
+                      _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]),
+                      self.NS, _p(k["dimStream"]))
         self.h = C.c_void_p()
         check(lib().htkamd_model_create(C.byref(d), C.byref(self.h)), "model_create")
         self.D, self.S, self.C, self.G = d.vecSize, d.numStates, d.numComp, d.numGauss
@@ -258,7 +262,7 @@ class Accs:
         GD = m.G * m.D
         return dict(vec=v, mu=v[L.mu:L.mu + GD].reshape(m.G, m.D), muOcc=v[L.muOcc:L.muOcc + m.G],
                     va=v[L.va:L.va + GD].reshape(m.G, m.D), vaOcc=v[L.vaOcc:L.vaOcc + m.G],
-                    wt=v[L.wt:L.wt + m.C], wtOcc=v[L.wtOcc:L.wtOcc + m.S], tr=v[L.tr:L.trOcc], trOcc=v[L.trOcc:L.nEgs],
+                    wt=v[L.wt:L.wt + m.C], wtOcc=v[L.wtOcc:L.tr], tr=v[L.tr:L.trOcc], trOcc=v[L.trOcc:L.nEgs],
                     nEgs=v[L.nEgs:L.nEgs + m.H], totalPr=v[L.totalPr], totalT=v[L.totalT], nUttDone=v[L.nUttDone],
                     nUttSkipped=v[L.nUttSkipped], nEval=v[L.nEval])
 
@@ -486,10 +490,12 @@ def _desc_from_packed(pk: dict):
     k = dict(stateCompOff=i32(pk["stateCompOff"]), compWeight=f32(pk["compWeight"]), compGauss=i32(pk["compGauss"]),
              mean=f32(pk["mean"]), var=f32(pk["var"]), gconst=f32(pk.get("gconst")),
              transN=i32(pk["transN"]), transOff=i32(pk["transOff"]), transP=f32(pk["transP"]),
-             hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]))
+             hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]),
+             dimStream=i32(pk["dimStream"]) if pk.get("dimStream") is not None else None)
     d = ModelDesc(int(pk["vecSize"]), int(pk["numStates"]), int(pk["numComp"]), int(pk["numGauss"]), int(pk["numTrans"]), int(pk["numPhys"]),
                   _p(k["stateCompOff"]), _p(k["compWeight"]), _p(k["compGauss"]), _p(k["mean"]), _p(k["var"]), _p(k["gconst"]),
-                  _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]))
+                  _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]),
+                  int(pk.get("numStreams", 1) or 1), _p(k["dimStream"]))
     return d, k
 
 
@@ -677,12 +683,13 @@ class Mmf:
         S, Cn, G, nT, H, D = d.numStates, d.numComp, d.numGauss, d.numTrans, d.numPhys, d.vecSize
         transOff = arr(d.transOff, nT + 1, C.c_int); hmmStateOff = arr(d.hmmStateOff, H + 1, C.c_int)
         pk = dict(vecSize=D, numStates=S, numComp=Cn, numGauss=G, numTrans=nT, numPhys=H,
-                  stateCompOff=arr(d.stateCompOff, S + 1, C.c_int), compWeight=arr(d.compWeight, Cn, C.c_float),
+                  stateCompOff=arr(d.stateCompOff, S * max(d.numStreams, 1) + 1, C.c_int), compWeight=arr(d.compWeight, Cn, C.c_float),
                   compGauss=arr(d.compGauss, Cn, C.c_int), mean=arr(d.mean, G * D, C.c_float).reshape(G, D),
                   var=arr(d.var, G * D, C.c_float).reshape(G, D),
                   gconst=arr(d.gconst, G, C.c_float) if d.gconst else None,
                   transN=arr(d.transN, nT, C.c_int), transOff=transOff, transP=arr(d.transP, int(transOff[-1]), C.c_float),
-                  hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int))
+                  hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int),
+                  numStreams=max(d.numStreams, 1), dimStream=arr(d.dimStream, D, C.c_int) if d.numStreams > 1 else None)
         return pk
 
     def sharing(self):

@@ -412,6 +412,7 @@ static float like_to_word(const htkamd_net_desc *nd, const htkamd_model *m, cons
 extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd, float lmScale, htkamd_decoder **out)
 {
    if (!m || !nd || !out) { htkamd_set_error("decoder_create: NULL argument"); return HTKAMD_EINVAL; }
+   if (m->NSt > 1) { htkamd_set_error("decoder_create: multi-stream sets are served by the forward-backward pass only (the decoder's stream-weighted OutP, HModel.c:5523, is not built)"); return HTKAMD_EMODEL; }
    const int nN = nd->nNodes;
    std::vector<int> kind(nd->kind, nd->kind + nN), model(nd->model, nd->model + nN), tok0(nN), nodeN(nN, 2), nodeTp(nN, 0), nodeSt(nN, 0), wordIdx(nN, -1), hmmNodes;
    std::vector<float> pron(nd->pronProb, nd->pronProb + nN), wdlk(nN, (float)LZERO);

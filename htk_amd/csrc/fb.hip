@@ -89,6 +89,7 @@ struct PrepPool {
 // One worker's share of a batch: the tables of a contiguous range of utterances with offsets relative to the share.
 struct PrepChunk {
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
+   std::vector<int> slotStateU;               // several streams: the (state, stream) element of every chain state, per utterance NSt blocks of nSlots
    std::vector<short> cQ, cI, thrCell, sQ;
    std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
    std::vector<int> evLo, evHi, slotModel;
@@ -98,7 +99,7 @@ struct PrepChunk {
    char err[256] = "";
    void reset()                                          // keeps the vectors' capacity from batch to batch
    {
-      mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear();
+      mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear(); slotStateU.clear();
       cQ.clear(); cI.clear(); thrCell.clear(); sQ.clear(); tasks.clear(); tasksW.clear();
       outp = beta = gam = 0; frameStates = 0; nCellsMax = QMax = TMax = 1; nThrMax = 64; rc = HTKAMD_OK; err[0] = 0;
    }
@@ -114,7 +115,7 @@ struct htkamd_fb {
    int topoVersion;             // the model's topology version the batch tables were built against
    // host tables of the prepared batch
    std::vector<UttDesc> utt;
-   std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
+   std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState, slotStateU;
    std::vector<short> cQ, cI, taperLo, taperHi, thrCell, sQ;
    std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
    std::vector<size_t> gamOff;
@@ -127,6 +128,7 @@ struct htkamd_fb {
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_tasksW, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
+   DevBuf d_slotStateU, d_outpU;            // several streams: element of every (stream, chain state), and their scores: stream k of utterance u at outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
    DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8 | left-to-right W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
    int clsOff[14];                          // class c occupies uttList[clsOff[c] .. clsOff[c+1])
@@ -173,7 +175,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -228,7 +230,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
          C.mN.push_back(N); C.mTp.push_back(m->h_transOff[ti]); C.mCell0.push_back(nCells); C.mSlot0.push_back(nSlots);
          C.mDms.push_back(dm); C.mHmm.push_back(h); C.mTrans.push_back(ti);
          for (int i = 1; i <= N; i++) { C.cQ.push_back((short)q); C.cI.push_back((short)i); }
-         for (int j = 2; j < N; j++) { C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]); C.sQ.push_back((short)q); }
+         for (int j = 2; j < N; j++) { C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2) * m->NSt]); C.sQ.push_back((short)q); }      // several streams: the state's first element
          nCells += N; nSlots += N - 2; qt += dm;
          if (q > 1 && dm == 0 && prevDm == 0) d.status = HTKAMD_UTT_ETEE;      // successive tee models (HFB.c:557)
          prevDm = dm;
@@ -236,6 +238,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
       if (C.mDms[d.q0] == 0 || C.mDms[d.q0 + Q - 1] == 0) d.status = HTKAMD_UTT_ETEE;   // HFB.c:564
       if (d.status == HTKAMD_UTT_OK && qt > T) d.status = HTKAMD_UTT_SKIPPED;                 // HFB.c:1339
       d.nCells = nCells; d.nSlots = nSlots;
+      if (m->NSt > 1) for (int ks = 0; ks < m->NSt; ks++) for (int k = 0; k < nSlots; k++) C.slotStateU.push_back(C.slotState[d.slot0 + k] + ks);
       {  // thread map: entry cells | emitting cells | exit cells, each group padded to a multiple of 64
          d.thr0 = (int)C.thrCell.size();
          for (int role = 0; role < 3; role++) {
@@ -313,9 +316,13 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
          // two partitions of the same rectangle set: the matrix-core kernels build their B operand (the task's 128 frames, split into
          // bf16 pieces) once per task, so they get four times as many states per task (measured: 1.32 -> 1.21 ms at the bench workload;
          // the exact kernel is 10 % slower on the wide tasks)
+         // several streams: every stream of a chain state is a row of its own in the score block (NSt blocks of nSlots rows per
+         // utterance, k_combine_streams sums them into the state's row of outp)
+         const int NSt = m->NSt;
          for (int wide = 0; wide < 2; wide++) {
          const int GS = wide ? SCORE_TASK_SLOTS_WIDE : SCORE_TASK_SLOTS_EXACT;
          std::vector<ScoreTask> &dst = wide ? C.tasksW : C.tasks;
+         for (int ks = 0; ks < NSt; ks++)
          for (int k0 = 0; k0 < nSlots; k0 += GS) {
             const int k1 = (k0 + GS < nSlots) ? k0 + GS : nSlots;
             const int qa = slotModel[k0], qb = slotModel[k1 - 1];
@@ -326,10 +333,10 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
                ScoreTask tk;
                tk.frame0 = d.frame0 + t0;
                tk.nFrames = (tmax - t0 < SCORE_TILE_FRAMES) ? tmax - t0 : SCORE_TILE_FRAMES;
-               tk.slot0 = d.slot0 + k0;
+               tk.slot0 = d.slot0 * NSt + ks * nSlots + k0;
                tk.nSlots = k1 - k0;
-               tk.outSlot0 = k0; tk.ldo = T;
-               tk.outBase = d.outp0 + (size_t)t0;
+               tk.outSlot0 = ks * nSlots + k0; tk.ldo = T;
+               tk.outBase = d.outp0 * NSt + (size_t)t0;
                dst.push_back(tk);
             }
          }
@@ -390,7 +397,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    for (int k = 0; k < nW; k++) if (chunks[k].rc) { htkamd_set_error("%s", chunks[k].err); return chunks[k].rc; }
    // concatenate the shares, rebasing their offsets
    fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
-   fb->slotState.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->tasksW.clear(); fb->thrCell.clear(); fb->sQ.clear();
+   fb->slotState.clear(); fb->slotStateU.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->tasksW.clear(); fb->thrCell.clear(); fb->sQ.clear();
    fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1; fb->frameStates = 0;
    int nThrMax = 64;
    size_t outp = 0, beta = 0, gam = 0;
@@ -403,11 +410,12 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          d.q0 += bQ; d.cell0 += bCell; d.slot0 += bSlot; d.thr0 += bThr; d.outp0 += outp; d.beta0 += beta; d.gam0 += gam;
          fb->gamOff[u] = d.gam0;
       }
-      for (ScoreTask &tk : C.tasks) { tk.slot0 += bSlot; tk.outBase += outp; }
-      for (ScoreTask &tk : C.tasksW) { tk.slot0 += bSlot; tk.outBase += outp; }
+      const int NSt = fb->m->NSt;
+      for (ScoreTask &tk : C.tasks) { tk.slot0 += bSlot * NSt; tk.outBase += outp * NSt; }
+      for (ScoreTask &tk : C.tasksW) { tk.slot0 += bSlot * NSt; tk.outBase += outp * NSt; }
       auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
       app(fb->mN, C.mN); app(fb->mTp, C.mTp); app(fb->mCell0, C.mCell0); app(fb->mSlot0, C.mSlot0); app(fb->mDms, C.mDms); app(fb->mHmm, C.mHmm);
-      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->sQ, C.sQ); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks); app(fb->tasksW, C.tasksW);
+      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->slotStateU, C.slotStateU); app(fb->sQ, C.sQ); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks); app(fb->tasksW, C.tasksW);
       outp += C.outp; beta += C.beta; gam += C.gam;
       fb->frameStates += C.frameStates;
       if (C.nCellsMax > fb->nCellsMax) fb->nCellsMax = C.nCellsMax;
@@ -442,7 +450,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) {
             kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8;
             // every model left-to-right without skips: the kernels of fb_lr.hip (no statistics in the alpha chain, no entry-state columns)
-            bool lr = !fb->noLrPath;
+            bool lr = !fb->noLrPath && fb->m->NSt == 1;      // several streams: the dense seed array feeds k_mixstats_ms
             for (int q = 0; q < d.Q && lr; q++) if (fb->m->h_transLR[fb->mTrans[d.q0 + q]] != 1) lr = false;
             if (lr) kind = 2;
          }
@@ -478,7 +486,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_taperLo, fb->taperLo.data(), sizeof(short) * fb->taperLo.size(), 0}, {&fb->d_taperHi, fb->taperHi.data(), sizeof(short) * fb->taperHi.size(), 0},
          {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_tasksW, fb->tasksW.data(), sizeof(ScoreTask) * fb->tasksW.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
          {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0},
-         {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0}};
+         {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0},
+         {&fb->d_slotStateU, fb->slotStateU.data(), sizeof(int) * fb->slotStateU.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -508,7 +517,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * ((beta && !wavePathPrep) ? beta : 1))) ||
        (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
-       (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))))
+       (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))) ||
+       (fb->m->NSt > 1 && (rc = fb->d_outpU.reserve(sizeof(float) * (outp * fb->m->NSt + 16)))))
       return rc;
    if (fb->debug && (rc = fb->d_alpha.reserve(sizeof(double) * (beta ? beta : 1)))) return rc;
    lap("reserve");
@@ -538,6 +548,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    const bool wideTasks = (cfg->scoreMode & (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_MFMA)) != 0;
    sa.tasks = (const ScoreTask *)(wideTasks ? fb->d_tasksW.p : fb->d_tasks.p); sa.nTasks = (int)(wideTasks ? fb->tasksW.size() : fb->tasks.size()); sa.X = fb->dX;
    sa.slotState = (const int *)fb->d_slotState.p; sa.out = (float *)fb->d_outp.p;
+   if (m->NSt > 1) { sa.slotState = (const int *)fb->d_slotStateU.p; sa.out = (float *)fb->d_outpU.p; }      // per (stream, chain state)
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
@@ -559,6 +570,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.beta = (double *)fb->d_beta.p; fa.gam = (double *)fb->d_gam.p; fa.alphaDbg = fb->debug ? (double *)fb->d_alpha.p : nullptr;
    fa.pr = (double *)fb->d_pr.p; fa.status = (int *)fb->d_status.p;
    fa.stateCompOff = m->d_stateCompOff; fa.compGauss = m->d_compGauss;
+   fa.NSt = m->NSt; fa.outpU = (const float *)fb->d_outpU.p; fa.dimStream = m->d_dimStream;
    fa.transOff = (const int *)fb->d_transOff.p; fa.trOccOff = (const int *)fb->d_trOccOff.p;
    fa.compLogWt = m->d_compLogWt; fa.gparam = m->d_gparam; fa.mean = m->d_mean; fa.laddTab = m->d_laddTab;
    fa.PS = m->PS; fa.D = m->D; fa.maxN = m->maxN; fa.maxM = m->maxM;
@@ -582,6 +594,13 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    HIPCHECK(hipEventRecord(fb->ev[0], s));
    if ((rc = htkamd_launch_score(cfg->scoreMode, m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
    fb->scored = sa.nTasks > 0;
+   if (m->NSt > 1) {
+      // Setotprob for S > 1 (HFB.c:1057-1066): the state's log probability is the float sum of its streams' in stream order.  The
+      // recursions then see a state with "two components" whatever its streams hold (they only ask whether it is a single Gaussian,
+      // for the seed they leave to the mixture statistics)
+      if ((rc = htkamd_launch_combine_streams(fa, s))) return rc;
+      if (m->maxM > 1) fa.stateCompOff = m->d_msCompOff;
+   }
    HIPCHECK(hipEventRecord(fb->ev[1], s));
    const int nGeneral = fb->clsOff[5] - fb->clsOff[4];
    fb->lastWave = nGeneral == 0;
@@ -642,7 +661,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          fa.rec = (MixRec *)fb->d_rec.p; fa.recSorted = (MixRec *)fb->d_recSorted.p; fa.recCap = (int)cap; fa.G = m->G; fa.recCtl = (int *)fb->d_recCtl.p;
       }
       // the dense seed array serves the utterances off the left-to-right path; those on it list their pairs (k_stats_lr -> k_mixhits)
-      if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
+      if (m->NSt > 1) { fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr; if ((rc = htkamd_launch_mixstats_ms(fa, s))) return rc; }
+      else if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
    }
    HIPCHECK(hipEventRecord(fb->ev[5], s));
    fb->timed = true;

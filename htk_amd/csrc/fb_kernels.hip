@@ -1037,3 +1037,145 @@ int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool l
    }
    return HTKAMD_OK;
 }
+
+// ---- several streams (HFB.c:1026-1066 Setotprob with S > 1, :1499-1602 UpMixParms' stream loop) -------------------------------
+// The scoring kernels leave one row per (stream, chain state) in outpU; the state's log probability is their float sum in stream
+// order (`sum += outprobj[s][0]`, :1057).  The reference then REPLACES every stream's value by "the sum of the other streams",
+// sum - x_s in float (:1062-1064), which is what UpMixParms adds to a component's log posterior (:1611).  (Its second visit to a
+// tied state at the same frame reads those replaced values back and halves their sum, :1059 -- equal to the first visit's value for
+// S = 3 up to float rounding, and a different number for any other S: a defect this path does not reproduce; oracle/ does.)
+__global__ __launch_bounds__(256) void k_combine_streams(FbArgs a)
+{
+   const UttDesc *up = a.utt + blockIdx.x;
+   const size_t n = (size_t)up->T * up->nSlots;
+   const float *src = a.outpU + up->outp0 * a.NSt;
+   float *dst = a.outp + up->outp0;
+   for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.y * blockDim.x) {
+      float sum = 0.0f;
+      for (int k = 0; k < a.NSt; k++) sum += src[(size_t)k * n + i];
+      dst[i] = sum;
+   }
+}
+
+int htkamd_launch_combine_streams(const FbArgs &a, hipStream_t s)
+{
+   if (a.nUtt <= 0) return HTKAMD_OK;
+   hipLaunchKernelGGL(k_combine_streams, dim3((unsigned)a.nUtt, 16), dim3(256), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+// UpMixParms for S > 1: the surviving (frame, chain state) pairs of the dense seed array, a wavefront per pair, lane = component for
+// the posteriors and lane = dimension for the first- and second-order sums (only the dimensions of the component's stream).
+// seed = initx (the state's log occupation without its own output probability) when some stream of the set has several components,
+// else log alpha + log beta - pr.
+__global__ __launch_bounds__(256) void k_mixstats_ms(FbArgs a)
+{
+   __shared__ unsigned short hitIdx[4][512];
+   __shared__ double hitSeed[4][512];
+   const int lane = threadIdx.x & 63;
+   const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+   const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const int D = a.D, NSt = a.NSt;
+   const double minF = (double)a.minFrwdP;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
+      volatile unsigned short *hIdx = hitIdx[threadIdx.x >> 6];
+      volatile double *hSeed = hitSeed[threadIdx.x >> 6];
+      int count = 0;
+      for (int r = 0; r < 8; r++) {
+         const size_t idx = base0 + (size_t)r * 64 + lane;
+         const double v = (idx < a.gamTotal) ? a.gam[idx] : LZERO;
+         const unsigned long long hm = __ballot(v > LSMALL);
+         if (v > LSMALL) {
+            const int pos = count + __popcll(hm & ((1ull << lane) - 1));
+            hIdx[pos] = (unsigned short)(r * 64 + lane); hSeed[pos] = v;
+         }
+         count += __popcll(hm);
+      }
+      int u = a.gamChunkUtt[base0 >> 9];
+      for (int i = 0; i < count; i++) {
+         const size_t hidx = base0 + hIdx[i];
+         const double seed = hSeed[i];
+         while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
+         const UttDesc *up = a.utt + u;
+         if (a.status[u] != HTKAMD_UTT_OK) continue;
+         const int nSl = up->nSlots, T = up->T;
+         const size_t rel = hidx - up->gam0;
+         const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
+         const int e0 = a.slotState[up->slot0 + slot];
+         const float *xrow = a.X + (size_t)(up->frame0 + t0) * D;
+         const float oS = a.outp[up->outp0 + (size_t)slot * T + t0];
+         for (int ks = 0; ks < NSt; ks++) {
+            const int e = e0 + ks, c0 = a.stateCompOff[e], M = a.stateCompOff[e + 1] - c0;
+            const float oK = a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
+            const float others = oS - oK;                              // outprob[s][0] after Setotprob (HFB.c:1064)
+            for (int mb = 0; mb < M; mb += 64) {
+               const int m = mb + lane;
+               bool pass = false;
+               double Lr = 0.0;
+               int g = 0;
+               if (m < M) {
+                  const float wt = a.compLogWt[c0 + m];
+                  g = a.compGauss[c0 + m];
+                  if (wt > (float)LMINMIX) {
+                     double x;
+                     if (M == 1) x = (a.maxM == 1) ? seed : seed + (double)oS;        // !mmix: log alpha + log beta - pr (HFB.c:1584)
+                     else {
+                        const float *P = a.gparam + (size_t)g * a.PS;
+                        float sum = P[2 * D];
+                        for (int k = 0; k < D; k++) {
+                           const float xmm = xrow[k] - P[2 * k];
+                           sum += xmm * xmm * P[2 * k + 1];
+                        }
+                        const float prob = -0.5f * sum;
+                        x = seed + (double)wt;
+                        x += (double)prob;
+                        x += (double)others;                                            // "adjust for parallel streams" (HFB.c:1611)
+                     }
+                     if (-x < minF) { pass = true; Lr = exp(x); }
+                  }
+               }
+               double sumLr = pass ? Lr : 0.0;
+#pragma unroll
+               for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
+               if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + e, sumLr);
+               if (pass) {
+                  if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+                  if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+                  if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+               }
+               unsigned long long pm = __ballot(pass);
+               while (pm) {
+                  const int ml = __ffsll((long long)pm) - 1;
+                  pm &= pm - 1;
+                  const double L = __shfl(Lr, ml);
+                  const int gg = __shfl(g, ml);
+                  const float *mean = a.mean + (size_t)gg * D;
+                  for (int k = lane; k < D; k += 64) {
+                     if (a.dimStream[k] != ks) continue;
+                     const float z = xrow[k] - mean[k];
+                     if (upMu && upVa) {                    // HFB.c:1673-1678
+                        const float zl = (float)((double)z * L);
+                        atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+                        atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
+                     } else if (upMu) atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
+                     else if (upVa) atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
+                  }
+               }
+            }
+         }
+      }
+   }
+}
+
+int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s)
+{
+   if (a.gamTotal == 0) return HTKAMD_OK;
+   size_t waves = (a.gamTotal + 511) / 512;
+   size_t blocks = (waves + 3) / 4;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_mixstats_ms, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}

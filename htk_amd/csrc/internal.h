@@ -26,6 +26,8 @@ void   htkamd_host_fix_diag_gconst(int D, const float *var, float *gconst);   /*
 void   htkamd_host_conv_diagc(size_t n, const float *var, float *ivar);        /* HUtil.c:413  */
 float  htkamd_host_mix_log_weight(float w);                                    /* HModel.c:5288 */
 int    htkamd_host_min_dur(int N, const float *tp);                            /* HFB.c:106    */
+int    htkamd_host_stream_dims(const char *kind, int vecSize, int S, const int *width, int *dimStream, char *why, size_t whyLen);   /* HParm.c:3094,2843 */
+void   htkamd_host_fix_diag_gconst_ms(int D, const float *var, const int *dimStream, int stream, float *gconst);
 int    htkamd_host_trans_is_lr(int N, const float *tp);                        /* left-to-right, no skips (fb_lr.hip) */
 double htkamd_host_min_log_exp(void);                                          /* HMath.c:1680 */
 
@@ -88,6 +90,12 @@ struct htkamd_model {
    int   *h_meanLeader, *h_varLeader, *h_varGroupSize;
    int   *d_shareTab;                 /* meanLeader[G] varLeader[G] varGroupSize[G] muMemOff[G+1] vaMemOff[G+1] muMem[] vaMem[] (update.hip) */
    int    shareMuMem, shareVaMem;     /* lengths of the two member lists */
+   /* several streams (htkamd_model_desc::numStreams > 1): S counts (state, stream) ELEMENTS, element = tied state * NSt + stream, and
+      h_hmmState lists the NSt elements of every emitting state; a Gaussian is an undivided row whose dimensions outside its stream
+      carry mean 0, 1/variance 0 */
+   int    NSt;                 /* streams (1: none of the following is allocated) */
+   int   *h_dimStream, *h_gaussStream, *d_dimStream, *d_gaussStream;   /* [D] stream of a dimension, [G] stream of a Gaussian */
+   int   *d_msCompOff;         /* [S+1] = 2e: what the recursion kernels read as "components of the chain state" (they only ask == 1) */
    int   *h_scanOrder;         /* [H] the reference's HMM scan order of the physical models (htkamd_model_set_scan_order), or NULL */
    double minLogExp;
 };

@@ -121,6 +121,10 @@ struct FbArgs {
    int recCap, G;
    int *recCtl;                      // [0] number of records asked for (may exceed recCap), then gCnt[G+1], gStart[G+1], gCur[G+1]
    // left-to-right path: the surviving (frame, state) pairs as a list (k_stats_lr -> k_mixhits) instead of the dense seed array
+   // several streams (model NSt > 1): scores per (stream, chain state) and the map dimension -> stream
+   int NSt;
+   const float *outpU;               // stream k of utterance u: outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
+   const int *dimStream;
    MixHit *hits;                     // region r (one per wavefront of k_stats_lr, numbered like the rows of trPart): hits[r * hitRegionCap ...]
    int *hitCtl;                      // [r] records in region r
    int nHitRegions, hitRegionCap;
@@ -129,6 +133,9 @@ struct FbArgs {
 int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s, bool dense, bool listed);
+// several streams: outp = sum over streams of outpU; UpMixParms per stream from the dense seed array
+int htkamd_launch_combine_streams(const FbArgs &a, hipStream_t s);
+int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
 // state-per-lane fast path (fb_state.hip): chains of <= 512 emitting states, models of <= 5 states, no tee models
 int htkamd_launch_beta_s(const FbArgs &a, int W, bool fast, hipStream_t s);

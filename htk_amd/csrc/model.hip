@@ -164,6 +164,9 @@ static int model_refresh(htkamd_model *m, bool derive = true)
    const int D = m->D, PS = m->PS;
    if (derive) {
       htkamd_host_conv_diagc((size_t)m->G * D, m->h_var, m->h_ivar);
+      if (m->NSt > 1)                                    // a dimension outside the Gaussian's stream takes no part in its score
+         for (int g = 0; g < m->G; g++)
+            for (int k = 0; k < D; k++) if (m->h_dimStream[k] != m->h_gaussStream[g]) m->h_ivar[(size_t)g * D + k] = 0.0f;
       for (int c = 0; c < m->C; c++) m->h_compLogWt[c] = htkamd_host_mix_log_weight(m->h_compWeight[c]);
    }
    for (int t = 0; t < m->nT; t++) {
@@ -227,7 +230,10 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
       htkamd_set_error("model_create: empty model"); return HTKAMD_EINVAL;
    }
    htkamd_model *m = (htkamd_model *)calloc(1, sizeof(htkamd_model));
-   m->D = d->vecSize; m->S = d->numStates; m->C = d->numComp; m->G = d->numGauss; m->nT = d->numTrans; m->H = d->numPhys;
+   const int NSt = d->numStreams > 1 ? d->numStreams : 1;
+   if (NSt > 1 && !d->dimStream) { free(m); htkamd_set_error("model_create: numStreams = %d without dimStream", NSt); return HTKAMD_EINVAL; }
+   m->NSt = NSt;
+   m->D = d->vecSize; m->S = d->numStates * NSt; m->C = d->numComp; m->G = d->numGauss; m->nT = d->numTrans; m->H = d->numPhys;
    m->PS = ((2 * m->D + 1) + 3) & ~3;
    m->minLogExp = htkamd_host_min_log_exp();
    m->h_stateCompOff = dupHost(d->stateCompOff, (size_t)m->S + 1);
@@ -243,6 +249,24 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
    m->h_hmmTrans = dupHost(d->hmmTrans, (size_t)m->H);
    m->h_hmmStateOff = dupHost(d->hmmStateOff, (size_t)m->H + 1);
    m->h_hmmState = dupHost(d->hmmState, (size_t)d->hmmStateOff[m->H]);
+   if (NSt > 1) {                                        // every emitting state becomes its NSt elements
+      const int n = d->hmmStateOff[m->H];
+      free(m->h_hmmState);
+      m->h_hmmState = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1) * NSt);
+      for (int i = 0; i < n; i++) for (int k = 0; k < NSt; k++) m->h_hmmState[(size_t)i * NSt + k] = d->hmmState[i] * NSt + k;
+      for (int h = 0; h <= m->H; h++) m->h_hmmStateOff[h] = d->hmmStateOff[h] * NSt;
+      m->h_dimStream = dupHost(d->dimStream, (size_t)m->D);
+      m->h_gaussStream = (int *)malloc(sizeof(int) * (size_t)m->G);
+      for (int g = 0; g < m->G; g++) m->h_gaussStream[g] = -1;
+      for (int k = 0; k < m->D; k++) if (d->dimStream[k] < 0 || d->dimStream[k] >= NSt) { htkamd_set_error("model_create: dimStream[%d] = %d", k, d->dimStream[k]); htkamd_model_destroy(m); return HTKAMD_EINVAL; }
+      for (int e = 0; e < m->S; e++)
+         for (int c = d->stateCompOff[e]; c < d->stateCompOff[e + 1]; c++) {
+            const int g = d->compGauss[c];
+            if (m->h_gaussStream[g] >= 0 && m->h_gaussStream[g] != e % NSt) { htkamd_set_error("model_create: Gaussian %d is used by streams %d and %d", g, m->h_gaussStream[g] + 1, e % NSt + 1); htkamd_model_destroy(m); return HTKAMD_EINVAL; }
+            m->h_gaussStream[g] = e % NSt;
+         }
+      for (int g = 0; g < m->G; g++) if (m->h_gaussStream[g] < 0) m->h_gaussStream[g] = 0;
+   }
    m->h_minDur = dupHost((const int *)nullptr, (size_t)m->nT);
    for (int t = 0; t < m->nT; t++) m->h_minDur[t] = -1;
    m->h_transLR = (unsigned char *)malloc((size_t)(m->nT ? m->nT : 1));
@@ -250,7 +274,7 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
    m->h_trOccOff = dupHost((const int *)nullptr, (size_t)m->nT + 1);
    m->h_gconst = dupHost(d->gconst, (size_t)m->G);
    if (!d->gconst)                                   // CheckMix: gConst fixed at load (HModel.c:206-208)
-      for (int g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst(m->D, m->h_var + (size_t)g * m->D, m->h_gconst + g);
+      for (int g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst_ms(m->D, m->h_var + (size_t)g * m->D, m->h_dimStream, m->h_gaussStream ? m->h_gaussStream[g] : 0, m->h_gconst + g);
    m->maxN = 0; m->maxM = 1; m->h_trOccOff[0] = 0;
    for (int t = 0; t < m->nT; t++) {
       if (m->h_transN[t] > m->maxN) m->maxN = m->h_transN[t];
@@ -267,9 +291,9 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
    }
    for (int h = 0; h < m->H; h++) {
       int N = m->h_transN[m->h_hmmTrans[h]];
-      if (m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h] != N - 2) {
+      if (m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h] != (N - 2) * NSt) {
          htkamd_set_error("model_create: HMM %d has %d emitting states but its transP has %d states", h,
-                          m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h], N);
+                          (m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h]) / NSt, N);
          htkamd_model_destroy(m); return HTKAMD_EINVAL;
       }
    }
@@ -280,6 +304,12 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
        (rc = toDevice(&m->d_transOff, m->h_transOff, (size_t)m->nT + 1)) ||
        (rc = model_refresh(m))) {
       htkamd_model_destroy(m); return rc;
+   }
+   if (NSt > 1) {
+      std::vector<int> two((size_t)m->S + 1);
+      for (int e = 0; e <= m->S; e++) two[e] = 2 * e;
+      if ((rc = toDevice(&m->d_dimStream, m->h_dimStream, (size_t)m->D)) || (rc = toDevice(&m->d_gaussStream, m->h_gaussStream, (size_t)m->G)) ||
+          (rc = toDevice(&m->d_msCompOff, two.data(), (size_t)m->S + 1))) { htkamd_model_destroy(m); return rc; }
    }
    {
       const int n = htkamd_host_ladd_table_size();
@@ -307,6 +337,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
    free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize); (void)hipFree(m->d_shareTab);
+   free(m->h_dimStream); free(m->h_gaussStream); (void)hipFree(m->d_dimStream); (void)hipFree(m->d_gaussStream); (void)hipFree(m->d_msCompOff);
    free(m);
 }
 
@@ -402,7 +433,7 @@ extern "C" int htkamd_model_set_params(htkamd_model *m, const float *mean, const
    if (var) memcpy(m->h_var, var, sizeof(float) * (size_t)m->G * m->D);
    if (gconst) memcpy(m->h_gconst, gconst, sizeof(float) * (size_t)m->G);
    else if (var)
-      for (int g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst(m->D, m->h_var + (size_t)g * m->D, m->h_gconst + g);
+      for (int g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst_ms(m->D, m->h_var + (size_t)g * m->D, m->h_dimStream, m->h_gaussStream ? m->h_gaussStream[g] : 0, m->h_gconst + g);
    if (compWeight) memcpy(m->h_compWeight, compWeight, sizeof(float) * (size_t)m->C);
    if (transP) memcpy(m->h_transP, transP, sizeof(float) * (size_t)m->h_transOff[m->nT]);
    return model_refresh(m);

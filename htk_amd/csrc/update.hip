@@ -41,7 +41,10 @@ struct UpdArgs {
    int tied;
    const int *meanLeader, *varLeader, *varGroupSize, *muMemOff, *vaMemOff, *muMem, *vaMem, *scanPos;
    int *firstMu, *firstVa;                                  // scan position of the first qualifying model whose mixture reaches the vector
+   const int *dimStream, *gaussStream;                      // several streams: stream of a dimension / of a Gaussian (NULL: one stream)
 };
+// a dimension outside the Gaussian's stream: never re-estimated, 1/variance 0 (internal.h)
+#define OUTSIDE(g, k) (a.dimStream != nullptr && a.dimStream[k] != a.gaussStream[g])
 
 #define ACCF(off, idx) ((float)a.acc[(off) + (size_t)(idx)])
 
@@ -165,7 +168,8 @@ __global__ void k_upd_gauss_elem_tied(UpdArgs a)
    const int gv = a.varLeader[g], gm = a.meanLeader[g];
    float v = a.var[idx], mu = a.mean[idx];
    bool floored = false;
-   if (a.singleProcess && a.anyG[gv]) {
+   const bool outside = OUTSIDE(g, k);
+   if (a.singleProcess && a.anyG[gv] && !outside) {
       float iv;
       if (v > 1E+30f) v = 1E+30f;
       if (v < 1E-30f) v = 1E-30f;
@@ -175,7 +179,7 @@ __global__ void k_upd_gauss_elem_tied(UpdArgs a)
       v = 1 / iv;
    }
    const int posVa = a.firstVa[gv], posMu = a.firstMu[gm];
-   if ((a.uFlags & HTKAMD_UPVARS) && posVa != 0x7f7f7f7f) {
+   if ((a.uFlags & HTKAMD_UPVARS) && posVa != 0x7f7f7f7f && !outside) {
       const float occim = (float)pooled(a.acc, a.lay.vaOcc, gv, 1, 0, a.vaMemOff, a.vaMem);
       if (occim > 0.0f) {
          // the mean of the mixture that reached this variance first: for a private variance its own Gaussian's
@@ -188,7 +192,7 @@ __global__ void k_upd_gauss_elem_tied(UpdArgs a)
          v = x;
       } else if (k == 0 && live && g == gv) atomicAdd(a.stats + 5, 1);
    }
-   if ((a.uFlags & HTKAMD_UPMEANS) && posMu != 0x7f7f7f7f) {
+   if ((a.uFlags & HTKAMD_UPMEANS) && posMu != 0x7f7f7f7f && !outside) {
       const float muOcc = (float)pooled(a.acc, a.lay.muOcc, gm, 1, 0, a.muMemOff, a.muMem);
       if (muOcc > 0.0f) mu += (float)pooled(a.acc, a.lay.mu, gm, D, k, a.muMemOff, a.muMem) / muOcc;
    }
@@ -202,7 +206,7 @@ __global__ void k_upd_gauss_elem_tied(UpdArgs a)
    float c = v;
    if (c > 1E+30f) c = 1E+30f;
    if (c < 1E-30f) c = 1E-30f;
-   const float r = 1 / c;
+   const float r = outside ? 0.0f : 1 / c;
    a.ivar[idx] = r;
    float *gp = a.gparam + (size_t)g * a.PS;
    gp[2 * k] = mu; gp[2 * k + 1] = r;
@@ -219,7 +223,8 @@ __global__ void k_upd_gauss_elem(UpdArgs a)
    const int g = (int)(idx / (unsigned int)D), k = (int)(idx - (unsigned int)g * (unsigned int)D);
    float v = a.var[idx], mu = a.mean[idx];
    bool floored = false;
-   if (a.singleProcess && a.anyG[g]) {                       // ConvDiagC before the pass, ForceDiagC after it
+   const bool outside = OUTSIDE(g, k);
+   if (a.singleProcess && a.anyG[g] && !outside) {           // ConvDiagC before the pass, ForceDiagC after it
       float iv;
       if (v > 1E+30f) v = 1E+30f;
       if (v < 1E-30f) v = 1E-30f;
@@ -228,7 +233,7 @@ __global__ void k_upd_gauss_elem(UpdArgs a)
       if (iv < 1E-30f) iv = 1E-30f;
       v = 1 / iv;
    }
-   if (a.qualG[g]) {
+   if (a.qualG[g] && !outside) {
       const float muOcc = ACCF(a.lay.muOcc, g);
       if (a.uFlags & HTKAMD_UPVARS) {
          const float occim = ACCF(a.lay.vaOcc, g);
@@ -254,7 +259,7 @@ __global__ void k_upd_gauss_elem(UpdArgs a)
    float c = v;
    if (c > 1E+30f) c = 1E+30f;
    if (c < 1E-30f) c = 1E-30f;
-   const float r = 1 / c;
+   const float r = outside ? 0.0f : 1 / c;
    a.ivar[idx] = r;
    float *gp = a.gparam + (size_t)g * a.PS;
    gp[2 * k] = mu; gp[2 * k + 1] = r;
@@ -269,8 +274,11 @@ __global__ void k_upd_gconst(UpdArgs a)
    if (a.flooredG[g]) atomicAdd(a.stats + 1, 1);
    if (a.qualG[g] && (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))) {
       const float *var = a.var + (size_t)g * D;
-      float sum = (float)((double)D * a.logTpi);
+      int n = D;
+      if (a.dimStream) { n = 0; for (int k = 0; k < D; k++) if (!OUTSIDE(g, k)) n++; }
+      float sum = (float)((double)n * a.logTpi);
       for (int k = 0; k < D; k++) {
+         if (OUTSIDE(g, k)) continue;
          const float z = ((double)var[k] <= MINLARG) ? (float)LZERO : (float)log((double)var[k]);
          sum += z;
       }
@@ -365,6 +373,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    a.mean = m->d_mean; a.var = m->d_var; a.gconst = m->d_gconst; a.compWeight = m->d_compWeight; a.transP = m->d_transP;
    a.ivar = m->d_ivar; a.gparam = m->d_gparam; a.compLogWt = m->d_compLogWt;
    a.acc = accs->d_vec; a.lay = accs->lay;
+   a.dimStream = m->NSt > 1 ? m->d_dimStream : nullptr; a.gaussStream = m->NSt > 1 ? m->d_gaussStream : nullptr;
    a.minEgs = cfg->minEgs; a.uFlags = cfg->uFlags; a.singleProcess = cfg->singleProcess; a.rowNormalise = cfg->rowNormalise;
    a.minVar = cfg->minVar; a.mixWeightFloor = cfg->mixWeightFloor; a.logTpi = log(HTK_TPI);
    a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G; a.flooredG = a.anyG + m->G;

@@ -486,6 +486,7 @@ struct htkamd_viterbi {
 extern "C" int htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out)
 {
    if (!m || !out) { htkamd_set_error("viterbi_create: NULL argument"); return HTKAMD_EINVAL; }
+   if (m->NSt > 1) { htkamd_set_error("viterbi_create: multi-stream sets are served by the forward-backward pass only"); return HTKAMD_EMODEL; }
    if (m->maxN > VG_MAXN) { htkamd_set_error("viterbi_create: models with %d states; this path handles up to %d", m->maxN, VG_MAXN); return HTKAMD_EMODEL; }
    htkamd_viterbi *v = new htkamd_viterbi();
    v->m = m; v->nUtt = 0; v->segTotal = v->modTotal = 0;

@@ -59,7 +59,7 @@ int htkamd_accs_layout_from_desc(const htkamd_model_desc *d, htkamd_accs_layout 
    lay->va = o; o += GD;
    lay->vaOcc = o; o += d->numGauss;
    lay->wt = o; o += d->numComp;
-   lay->wtOcc = o; o += d->numStates;
+   lay->wtOcc = o; o += (size_t)d->numStates * (d->numStreams > 1 ? d->numStreams : 1);      /* one WtAcc per (state, stream) */
    lay->tr = o; o += d->transOff[d->numTrans];
    lay->trOcc = o; o += sumN;
    lay->nEgs = o; o += d->numPhys;
@@ -88,7 +88,7 @@ static int get_be32(FILE *f, void *p)
 static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_accs_layout *lay, double *vec,
                     const char *const *names, int uFlags, const char *path, const int *meanShare, const int *varShare)
 {
-   const int D = d->vecSize;
+   const int D = d->vecSize, NS = d->numStreams > 1 ? d->numStreams : 1;
    unsigned char *seenMu = (unsigned char *)calloc((size_t)d->numGauss + 1, 1), *seenVa = (unsigned char *)calloc((size_t)d->numGauss + 1, 1);
    double *pool = NULL;                         /* writer, shared vectors: statistics summed into the first sharer */
    unsigned char *seenS = (unsigned char *)calloc((size_t)d->numStates, 1);
@@ -152,16 +152,22 @@ static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_ac
       }
       for (j = 0; j < N - 2; j++) {
          const int s = d->hmmState[d->hmmStateOff[h] + j];
+         int ks;
          if (seenS[s]) continue;
          seenS[s] = 1;
-         for (c = d->stateCompOff[s]; c < d->stateCompOff[s + 1]; c++) IO(lay->wt + c);
-         IO(lay->wtOcc + s);
-         for (c = d->stateCompOff[s]; c < d->stateCompOff[s + 1]; c++) {
-            const int g = d->compGauss[c], gm = MLD(g), gv = VLD(g);
-            if (seenG[g]) continue;              /* a shared mixture pdf (~m) */
-            seenG[g] = 1;
-            if ((uFlags & HTKAMD_UPMEANS) && !seenMu[gm]) { seenMu[gm] = 1; for (i = 0; i < D; i++) IO(lay->mu + (size_t)gm * D + i); IO(lay->muOcc + gm); }
-            if ((uFlags & HTKAMD_UPVARS) && !seenVa[gv]) { seenVa[gv] = 1; for (i = 0; i < D; i++) IO(lay->va + (size_t)gv * D + i); IO(lay->vaOcc + gv); }
+         for (ks = 0; ks < NS; ks++) {           /* GoNextStream inside GoNextState: the stream's WtAcc, then its Gaussians (vectors of the stream's width) */
+            const int e = s * NS + ks;
+            for (c = d->stateCompOff[e]; c < d->stateCompOff[e + 1]; c++) IO(lay->wt + c);
+            IO(lay->wtOcc + e);
+            for (c = d->stateCompOff[e]; c < d->stateCompOff[e + 1]; c++) {
+               const int g = d->compGauss[c], gm = MLD(g), gv = VLD(g);
+               if (seenG[g]) continue;              /* a shared mixture pdf (~m) */
+               seenG[g] = 1;
+#define INS(i) (NS == 1 || d->dimStream[i] == ks)
+               if ((uFlags & HTKAMD_UPMEANS) && !seenMu[gm]) { seenMu[gm] = 1; for (i = 0; i < D; i++) if (INS(i)) IO(lay->mu + (size_t)gm * D + i); IO(lay->muOcc + gm); }
+               if ((uFlags & HTKAMD_UPVARS) && !seenVa[gv]) { seenVa[gv] = 1; for (i = 0; i < D; i++) if (INS(i)) IO(lay->va + (size_t)gv * D + i); IO(lay->vaOcc + gv); }
+#undef INS
+            }
          }
       }
       if (!seenT[ti]) {

@@ -1,7 +1,8 @@
 /* mmf.c -- HTK model definition files (text MMF / one-HMM-per-file) <-> the flat htkamd_model_desc.
  *
- * Replaces, for the model kinds the hot path supports (one stream, diagonal covariance, continuous densities,
- * PLAINHS/SHAREDHS): LoadHMMSet (HModel.c:3809) = MakeHMMSet (:3580, the HMM list "logical [physical]") +
+ * Replaces, for the model kinds the hot path supports (diagonal covariance, continuous densities, PLAINHS/SHAREDHS; one stream,
+ * or several -- <STREAMINFO> S, <NUMMIXES> per stream, <SWEIGHTS>, <STREAM> s, ~v varFloorN: every vector of a stream is held at the
+ * stream's dimensions of an undivided row, htkamd_host_stream_dims --): LoadHMMSet (HModel.c:3809) = MakeHMMSet (:3580, the HMM list "logical [physical]") +
  * LoadAllMacros / LoadMacroFiles (:3721) + the -d directory search; the grammar of GetOptions (:1649),
  * GetMean/GetVariance/GetTransMat (:1737-1990: transitions become log values, <= MINLARG -> LZERO), GetMixPDF (:2140),
  * GetStateInfo (:2350: a missing <MIXTURE> index is a pruned component of weight 0), GetHMMDef (:2490); and the
@@ -10,7 +11,7 @@
  * Binary definitions (':' + code byte keywords, big-endian numbers: PutSymbol :2581, Token.binForm :505) are read and
  * written as well, shared mixture pdfs (~m) are kept shared (one Gaussian, several components).  Shared mean / variance vectors
  * (~u / ~v macros referenced inside a mixture, GetMean :1737 / GetVariance :1770) are read, kept (every Gaussian holds its copy of the
- * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; stream weights, durations and
+ * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; ~w / ~m / ~u / ~v macros inside multi-stream sets, durations and
  * transforms are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
  */
 #include <ctype.h>
@@ -20,12 +21,14 @@
 #include <string.h>
 #include "../csrc/internal.h"
 
-typedef struct { char *name; int nMix; int comp0; int inlineOwner; int src; } mmf_state;   /* name NULL = un-named (inline); src: index of the file it came from */
+typedef struct { char *name; int nMix; int comp0; int inlineOwner; int src; int *sMix; float *sw; } mmf_state;   /* name NULL = un-named (inline); src: index of the file it came from;
+   several streams: nMix = all components of the state, sMix[s] those of stream s (consecutive from comp0), sw = <SWEIGHTS> or NULL */
 typedef struct { char *name; int N; int off; int src; } mmf_trans;
 typedef struct { char *name; int N; int *state; int trans; int src; } mmf_hmm;     /* src: index of the file it came from */
 
 struct htkamd_mmf {
    int vecSize, streamWidth, hasOpts;
+   int nStreams, swidth[8], *dimStream, curStream;                  /* several streams (<STREAMINFO> S w1..wS): dimension -> stream over the undivided vector */
    char kind[64], cov[16], dur[16], setId[128];
    /* pools */
    mmf_state *st; int nSt, capSt;
@@ -36,12 +39,13 @@ struct htkamd_mmf {
    mmf_hmm *hm; int nHm, capHm;
    float *varFloor;                                                 /* ~v "varFloor1" or NULL */
    /* shared vectors: ~u (means) and ~v (variances) macros; gMeanMac/gVarMac[g] = macro of Gaussian g's mean / variance or -1 */
-   struct { char type; char *name; float *v; int src; } *vm; int nVm, capVm;
+   struct { char type; char *name; float *v; int src; int stream; } *vm; int nVm, capVm;      /* stream: of a varFloorN macro of a multi-stream set, else -1 */
    int *gMeanMac, *gVarMac; int capMac;
    /* logical list */
    char **logName; int *logPhys; int nLog; int *logSorted;        /* logSorted: list positions in name order (stable) */
    /* desc arrays */
    htkamd_model_desc d; int *stateCompOff, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
+   int *gStr;                                                       /* stream of Gaussian g */
    int finished, nFiles;
 };
 
@@ -202,10 +206,15 @@ static int parse_options(struct htkamd_mmf *s, rd *r)
       if (!strcmp(t, "STREAMINFO")) {
          int S, w;
          if ((rc = rd_int(r, &S))) return rc;
-         if (S != 1) return fail(r, "multi-stream models are not supported");
-         if ((rc = rd_int(r, &w))) return rc;
-         if (s->streamWidth && s->streamWidth != w) return fail(r, "inconsistent stream width");
-         s->streamWidth = w;
+         if (S < 1 || S > 7) return fail(r, "<STREAMINFO>: 1..7 streams");
+         if (s->nStreams && s->nStreams != S) return fail(r, "inconsistent number of streams");
+         for (int i = 0; i < S; i++) {
+            if ((rc = rd_int(r, &w))) return rc;
+            if (s->nStreams && s->swidth[i] != w) return fail(r, "inconsistent stream width");
+            s->swidth[i] = w;
+         }
+         s->nStreams = S;
+         if (S == 1) s->streamWidth = s->swidth[0];
       } else if (!strcmp(t, "VECSIZE")) {
          int v;
          if ((rc = rd_int(r, &v))) return rc;
@@ -229,15 +238,44 @@ static int parse_options(struct htkamd_mmf *s, rd *r)
    }
 }
 
-static int parse_vector(struct htkamd_mmf *s, rd *r, float *dst)
+/* several streams: the map dimension -> stream, once the kind and the widths are known */
+static int need_stream_dims(struct htkamd_mmf *s, rd *r)
+{
+   char why[160];
+   if (s->dimStream) return HTKAMD_OK;
+   if (s->vecSize == 0) return fail(r, "<VECSIZE> must precede the first vector");
+   s->dimStream = (int *)malloc(sizeof(int) * (size_t)s->vecSize);
+   if (htkamd_host_stream_dims(s->kind, s->vecSize, s->nStreams, s->swidth, s->dimStream, why, sizeof(why))) {
+      free(s->dimStream); s->dimStream = NULL;
+      htkamd_set_error("%s:%d: <STREAMINFO>: %s", r->path, r->line, why);
+      return HTKAMD_EMODEL;
+   }
+   return HTKAMD_OK;
+}
+
+/* A vector of the whole observation, or (several streams) of stream `stream`: its values go to the stream's dimensions of the
+   undivided row dst, the other dimensions are set to `fill` (0 for means; +infinity for variances: such a dimension contributes
+   x*x/inf = 0 and 1/variance = 0 to every score). */
+static int parse_vector_ms(struct htkamd_mmf *s, rd *r, float *dst, int stream, float fill)
 {
    int n, rc;
    if ((rc = rd_int(r, &n))) return rc;
+   if (s->nStreams > 1) {
+      if ((rc = need_stream_dims(s, r))) return rc;
+      if (stream < 0 || stream >= s->nStreams) return fail(r, "vector outside a stream");
+      if (n != s->swidth[stream]) return fail(r, "vector size differs from the stream's width");
+      for (int i = 0; i < s->vecSize; i++) {
+         if (s->dimStream[i] != stream) { dst[i] = fill; continue; }
+         if ((rc = rd_float(r, dst + i))) return rc;
+      }
+      return HTKAMD_OK;
+   }
    if (s->vecSize == 0) s->vecSize = n;
    if (n != s->vecSize) return fail(r, "vector size differs from <VECSIZE>");
    for (int i = 0; i < n; i++) if ((rc = rd_float(r, dst + i))) return rc;
    return HTKAMD_OK;
 }
+static int parse_vector(struct htkamd_mmf *s, rd *r, float *dst) { return parse_vector_ms(s, r, dst, s->curStream, 0.0f); }
 
 static void gname_set(struct htkamd_mmf *s, int g, char *name)
 {
@@ -279,6 +317,7 @@ static int parse_shared_vector(struct htkamd_mmf *s, rd *r, int k, char type, co
    *mac = -1;
    if (k == T_MACRO && r->tok[0] == type) {
       char *nm;
+      if (s->nStreams > 1) return fail(r, "~u / ~v macros in a multi-stream set are not supported");
       if ((rc = rd_name(r, &nm))) return rc;
       const int i = find_vmacro(s, type, nm);
       if (i < 0) { rc = fail(r, type == 'u' ? "undefined ~u macro" : "undefined ~v macro"); free(nm); return rc; }
@@ -289,7 +328,7 @@ static int parse_shared_vector(struct htkamd_mmf *s, rd *r, int k, char type, co
    }
    if (k == T_MACRO) return fail(r, "unexpected macro inside a mixture");
    if (k != T_KEY || strcmp(r->tok, key)) return fail(r, type == 'u' ? "<MEAN> expected" : "<VARIANCE> expected (DIAGC only)");
-   return parse_vector(s, r, dst);
+   return parse_vector_ms(s, r, dst, s->curStream, type == 'u' ? 0.0f : INFINITY);
 }
 
 static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
@@ -297,6 +336,7 @@ static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
    int rc, k = rd_next(r);
    if (k == T_MACRO && r->tok[0] == 'm') {               /* reference to a shared mixture pdf */
       char *nm;
+      if (s->nStreams > 1) return fail(r, "~m macros in a multi-stream set are not supported");
       if ((rc = rd_name(r, &nm))) return rc;
       const int g = find_gauss(s, nm);
       if (g < 0) { rc = fail(r, "undefined ~m macro"); free(nm); return rc; }
@@ -326,51 +366,86 @@ static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
    return HTKAMD_OK;
 }
 
-/* state body after "~s name" or "<STATE> i": returns the new state index */
+/* state body after "~s name" or "<STATE> i": returns the new state index (GetStateInfo HModel.c:1924, GetStream :1850) */
 static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
 {
-   int rc, M = 1, k = rd_next(r);
-   if (k == T_KEY && !strcmp(r->tok, "NUMMIXES")) { if ((rc = rd_int(r, &M))) return rc; k = rd_next(r); }
-   if (k == T_KEY && !strcmp(r->tok, "SWEIGHTS")) return fail(r, "stream weights are not supported");
-   if (k == T_KEY && !strcmp(r->tok, "STREAM")) { int x; if ((rc = rd_int(r, &x))) return rc; if (x != 1) return fail(r, "multi-stream"); k = rd_next(r); }
-   if (M < 1) return fail(r, "bad <NUMMIXES>");
+   const int S = s->nStreams > 1 ? s->nStreams : 1;
+   int rc, M = 0, k = rd_next(r), nMixS[8], off[9], seen[8] = {0};
+   float *sw = NULL;
+   for (int i = 0; i < S; i++) nMixS[i] = 1;
+   if (k == T_KEY && !strcmp(r->tok, "NUMMIXES")) { for (int i = 0; i < S; i++) if ((rc = rd_int(r, &nMixS[i]))) return rc; k = rd_next(r); }
+   off[0] = 0;
+   for (int i = 0; i < S; i++) { if (nMixS[i] < 1) return fail(r, "bad <NUMMIXES>"); off[i + 1] = off[i] + nMixS[i]; }
+   M = off[S];
+   if (k == T_MACRO && r->tok[0] == 'w') return fail(r, "~w stream weight macros are not supported");
+   if (k == T_KEY && !strcmp(r->tok, "SWEIGHTS")) {
+      int n;
+      if ((rc = rd_int(r, &n))) return rc;
+      if (n != S) return fail(r, "incorrect number of stream weights");
+      sw = (float *)malloc(sizeof(float) * (size_t)S);
+      for (int i = 0; i < S; i++) if ((rc = rd_float(r, sw + i))) { free(sw); return rc; }
+      k = rd_next(r);
+   }
    GROW(s->st, s->nSt, s->capSt, 1, mmf_state);
    GROW(s->wt, s->nComp, s->capComp, M, float);
    s->cg = (int *)realloc(s->cg, sizeof(int) * (size_t)s->capComp);
    const int c0 = s->nComp;
    for (int m = 0; m < M; m++) { s->wt[c0 + m] = 0.0f; s->cg[c0 + m] = -1; }
-   if (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
-      while (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
-         int m; float w;
-         if ((rc = rd_int(r, &m)) || (rc = rd_float(r, &w))) return rc;
-         if (m < 1 || m > M) return fail(r, "mixture index out of range");
-         if (s->cg[c0 + m - 1] >= 0) return fail(r, "mixture defined twice");
-         s->wt[c0 + m - 1] = w;
-         if ((rc = parse_mixpdf(s, r, &s->cg[c0 + m - 1]))) return rc;
+   for (;;) {
+      int stream = 0;
+      if (k == T_KEY && !strcmp(r->tok, "STREAM")) {
+         int x;
+         if ((rc = rd_int(r, &x))) { free(sw); return rc; }
+         if (x < 1 || x > S) { free(sw); return fail(r, "stream index out of range"); }
+         stream = x - 1;
          k = rd_next(r);
       }
-      rd_push(r);
-   } else {
-      if (M != 1) return fail(r, "<MIXTURE> expected");
-      rd_push(r);
-      s->wt[c0] = 1.0f;
-      if ((rc = parse_mixpdf(s, r, &s->cg[c0]))) return rc;
-   }
-   /* pruned components (no <MIXTURE> entry): weight 0 with an empty Gaussian (GetStateInfo gives them EmptyMixPDF) */
-   for (int m = 0; m < M; m++)
-      if (s->cg[c0 + m] < 0) {
-         GROW(s->gconst, s->nG, s->capG, 1, float);
-         { const int cap = s->capG;
-           s->mean = (float *)realloc(s->mean, sizeof(float) * (size_t)cap * s->vecSize);
-           s->var = (float *)realloc(s->var, sizeof(float) * (size_t)cap * s->vecSize);
-           s->hasG = (unsigned char *)realloc(s->hasG, (size_t)cap); }
-         for (int i = 0; i < s->vecSize; i++) { s->mean[(size_t)s->nG * s->vecSize + i] = 0.0f; s->var[(size_t)s->nG * s->vecSize + i] = 1.0f; }
-         s->gconst[s->nG] = 0.0f; s->hasG[s->nG] = 0;
-         s->cg[c0 + m] = s->nG++;
+      if (seen[stream]) { free(sw); return fail(r, "stream defined twice"); }
+      seen[stream] = 1;
+      s->curStream = stream;
+      const int cs = c0 + off[stream], Ms = nMixS[stream];
+      if (k == T_KEY && (!strcmp(r->tok, "TMIX") || !strcmp(r->tok, "DPROB"))) { free(sw); return fail(r, "tied-mixture / discrete streams are not supported"); }
+      if (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
+         while (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
+            int m; float w;
+            if ((rc = rd_int(r, &m)) || (rc = rd_float(r, &w))) { free(sw); return rc; }
+            if (m < 1 || m > Ms) { free(sw); return fail(r, "mixture index out of range"); }
+            if (s->cg[cs + m - 1] >= 0) { free(sw); return fail(r, "mixture defined twice"); }
+            s->wt[cs + m - 1] = w;
+            if ((rc = parse_mixpdf(s, r, &s->cg[cs + m - 1]))) { free(sw); return rc; }
+            k = rd_next(r);
+         }
+         rd_push(r);
+      } else {
+         if (Ms != 1) { free(sw); return fail(r, "<MIXTURE> expected"); }
+         rd_push(r);
+         s->wt[cs] = 1.0f;
+         if ((rc = parse_mixpdf(s, r, &s->cg[cs]))) { free(sw); return rc; }
       }
+      /* pruned components (no <MIXTURE> entry): weight 0 with an empty Gaussian (GetStream gives them EmptyMixPDF) */
+      for (int m = 0; m < Ms; m++)
+         if (s->cg[cs + m] < 0) {
+            GROW(s->gconst, s->nG, s->capG, 1, float);
+            { const int cap = s->capG;
+              s->mean = (float *)realloc(s->mean, sizeof(float) * (size_t)cap * s->vecSize);
+              s->var = (float *)realloc(s->var, sizeof(float) * (size_t)cap * s->vecSize);
+              s->hasG = (unsigned char *)realloc(s->hasG, (size_t)cap); }
+            for (int i = 0; i < s->vecSize; i++) {
+               s->mean[(size_t)s->nG * s->vecSize + i] = 0.0f;
+               s->var[(size_t)s->nG * s->vecSize + i] = (S > 1 && s->dimStream && s->dimStream[i] != stream) ? INFINITY : 1.0f;
+            }
+            s->gconst[s->nG] = 0.0f; s->hasG[s->nG] = 0;
+            s->cg[cs + m] = s->nG++;
+         }
+      k = rd_next(r);
+      if (!(k == T_KEY && !strcmp(r->tok, "STREAM"))) { rd_push(r); break; }
+   }
+   s->curStream = 0;
+   for (int i = 0; i < S; i++) if (!seen[i]) { free(sw); return fail(r, "a stream of the state is not defined"); }
    s->nComp += M;
    mmf_state *st = &s->st[s->nSt];
-   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1; st->src = s->nFiles;
+   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1; st->src = s->nFiles; st->sMix = NULL; st->sw = sw;
+   if (S > 1) { st->sMix = (int *)malloc(sizeof(int) * (size_t)S); memcpy(st->sMix, nMixS, sizeof(int) * (size_t)S); }
    *sOut = s->nSt++;
    return HTKAMD_OK;
 }
@@ -530,14 +605,26 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
          if (s->vecSize == 0) { rc = fail(&r, "<VECSIZE> must precede ~u / ~v"); free(name); break; }
          if (find_vmacro(s, type, name) >= 0) { rc = fail(&r, "~u / ~v macro defined twice"); free(name); break; }
          float *v = (float *)malloc(sizeof(float) * (size_t)s->vecSize);
-         if ((rc = parse_vector(s, &r, v))) { free(v); free(name); break; }
+         int vstream = -1;
+         if (s->nStreams > 1) {                                        /* only the variance floors, one macro per stream: varFloor1..varFloorS */
+            if (!(type == 'v' && !strncmp(name, "varFloor", 8) && name[8] >= '1' && name[8] <= '0' + s->nStreams && !name[9])) {
+               rc = fail(&r, "~u / ~v macros in a multi-stream set are not supported (but ~v varFloorN)"); free(v); free(name); break;
+            }
+            vstream = name[8] - '1';
+         }
+         if ((rc = parse_vector_ms(s, &r, v, vstream < 0 ? 0 : vstream, 0.0f))) { free(v); free(name); break; }
          if (type == 'v' && !strncmp(name, "varFloor", 8)) {          /* the variance floor macro of HCompV -f: a ~v nobody references */
-            free(s->varFloor);
-            s->varFloor = (float *)malloc(sizeof(float) * (size_t)s->vecSize);
-            memcpy(s->varFloor, v, sizeof(float) * (size_t)s->vecSize);
+            if (vstream < 0) {
+               free(s->varFloor);
+               s->varFloor = (float *)malloc(sizeof(float) * (size_t)s->vecSize);
+               memcpy(s->varFloor, v, sizeof(float) * (size_t)s->vecSize);
+            } else {
+               if (!s->varFloor) s->varFloor = (float *)calloc((size_t)s->vecSize, sizeof(float));
+               for (int i = 0; i < s->vecSize; i++) if (s->dimStream[i] == vstream) s->varFloor[i] = v[i];
+            }
          }
          GROW(s->vm, s->nVm, s->capVm, 1, __typeof__(*s->vm));
-         s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v; s->vm[s->nVm].src = s->nFiles;
+         s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v; s->vm[s->nVm].src = s->nFiles; s->vm[s->nVm].stream = vstream;
          s->nVm++;
       } else { rc = fail(&r, "unsupported macro type"); free(name); break; }
    }
@@ -588,10 +675,21 @@ int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir
    if (s->cov[0] == 0) snprintf(s->cov, sizeof(s->cov), "DIAGC");
    if (s->dur[0] == 0) snprintf(s->dur, sizeof(s->dur), "NULLD");
    if (s->streamWidth == 0) s->streamWidth = s->vecSize;
-   /* flat description */
-   s->stateCompOff = (int *)malloc(sizeof(int) * ((size_t)s->nSt + 1));
-   for (int i = 0; i < s->nSt; i++) s->stateCompOff[i] = s->st[i].comp0;
-   s->stateCompOff[s->nSt] = s->nComp;
+   const int NS = s->nStreams > 1 ? s->nStreams : 1;
+   if (NS > 1 && !s->dimStream) { htkamd_set_error("mmf_finish: a multi-stream set without a single Gaussian"); return HTKAMD_EMODEL; }
+   /* flat description: one entry per (state, stream) */
+   s->stateCompOff = (int *)malloc(sizeof(int) * ((size_t)s->nSt * NS + 1));
+   s->gStr = (int *)calloc((size_t)(s->nG ? s->nG : 1), sizeof(int));
+   for (int i = 0; i < s->nSt; i++) {
+      int c = s->st[i].comp0;
+      for (int k = 0; k < NS; k++) {
+         s->stateCompOff[(size_t)i * NS + k] = c;
+         const int n = NS > 1 ? s->st[i].sMix[k] : s->st[i].nMix;
+         for (int m = 0; m < n; m++) s->gStr[s->cg[c + m]] = k;
+         c += n;
+      }
+   }
+   s->stateCompOff[(size_t)s->nSt * NS] = s->nComp;
    s->transN = (int *)malloc(sizeof(int) * (size_t)s->nTr);
    s->transOff = (int *)malloc(sizeof(int) * ((size_t)s->nTr + 1));
    for (int t = 0; t < s->nTr; t++) { s->transN[t] = s->tr[t].N; s->transOff[t] = s->tr[t].off; }
@@ -610,13 +708,14 @@ int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir
    int anyG = 0, allG = 1;
    for (int g = 0; g < s->nG; g++) { if (s->hasG[g]) anyG = 1; else allG = 0; }
    if (anyG && !allG)                                 /* CheckMix: missing gConst computed at load (HModel.c:206-208) */
-      for (int g = 0; g < s->nG; g++) if (!s->hasG[g]) htkamd_host_fix_diag_gconst(s->vecSize, s->var + (size_t)g * s->vecSize, s->gconst + g);
+      for (int g = 0; g < s->nG; g++) if (!s->hasG[g]) htkamd_host_fix_diag_gconst_ms(s->vecSize, s->var + (size_t)g * s->vecSize, NS > 1 ? s->dimStream : NULL, s->gStr[g], s->gconst + g);
    htkamd_model_desc *d = &s->d;
    d->vecSize = s->vecSize; d->numStates = s->nSt; d->numComp = s->nComp; d->numGauss = s->nG; d->numTrans = s->nTr; d->numPhys = s->nHm;
    d->stateCompOff = s->stateCompOff; d->compWeight = s->wt; d->compGauss = s->cg; d->mean = s->mean; d->var = s->var;
    d->gconst = anyG ? s->gconst : NULL;
    d->transN = s->transN; d->transOff = s->transOff; d->transP = s->tp;
    d->hmmTrans = s->hmmTrans; d->hmmStateOff = s->hmmStateOff; d->hmmState = s->hmmState;
+   d->numStreams = NS; d->dimStream = NS > 1 ? s->dimStream : NULL;
    {  /* name index for htkamd_mmf_find_logical */
       g_sortNames = s->logName;
       s->logSorted = (int *)malloc(sizeof(int) * (size_t)(s->nLog ? s->nLog : 1));
@@ -667,7 +766,8 @@ int htkamd_mmf_find_logical(const struct htkamd_mmf *s, const char *name)
 void htkamd_mmf_destroy(struct htkamd_mmf *s)
 {
    if (!s) return;
-   for (int i = 0; i < s->nSt; i++) free(s->st[i].name);
+   for (int i = 0; i < s->nSt; i++) { free(s->st[i].name); free(s->st[i].sMix); free(s->st[i].sw); }
+   free(s->dimStream); free(s->gStr);
    for (int i = 0; i < s->nTr; i++) free(s->tr[i].name);
    for (int i = 0; i < s->nHm; i++) { free(s->hm[i].name); free(s->hm[i].state); }
    for (int i = 0; i < s->nLog; i++) free(s->logName[i]);
@@ -767,7 +867,10 @@ static void put_options(const struct htkamd_mmf *s, FILE *f)
 {
    fprintf(f, "~o\n");
    if (s->setId[0]) { put_sym(f, "HMMSETID", 119); fprintf(f, " %s\n", s->setId); }
-   put_sym(f, "STREAMINFO", 5); put_short(f, 1); put_short(f, s->streamWidth); put_nl(f);
+   put_sym(f, "STREAMINFO", 5);
+   if (s->nStreams > 1) { put_short(f, s->nStreams); for (int i = 0; i < s->nStreams; i++) put_short(f, s->swidth[i]); }
+   else { put_short(f, 1); put_short(f, s->streamWidth); }
+   put_nl(f);
    put_sym(f, "VECSIZE", 6); put_short(f, s->vecSize);
    put_sym(f, s->dur, 7);                                            /* NULLD */
    fprintf(f, "<%s><%s>", s->kind[0] ? s->kind : "USER", s->cov);      /* parameter and covariance kinds are text even in binary files */
@@ -779,25 +882,46 @@ static void put_vec(FILE *f, const char *key, int code, const float *v, int n)
    for (int i = 0; i < n; i++) put_float(f, v[i]);
    put_nl(f);
 }
+/* the vector of one stream out of an undivided row (stream < 0 or one stream: the row itself) */
+static void put_vec_ms(const struct htkamd_mmf *s, FILE *f, const char *key, int code, const float *v, int stream)
+{
+   if (s->nStreams <= 1 || stream < 0) { put_vec(f, key, code, v, s->vecSize); return; }
+   put_sym(f, key, code); put_short(f, s->swidth[stream]); put_nl(f);
+   for (int i = 0; i < s->vecSize; i++) if (s->dimStream[i] == stream) put_float(f, v[i]);
+   put_nl(f);
+}
 /* PutMixPDF's body (HModel.c:3029): mean and variance inline or as references to their ~u / ~v macros */
 static void put_gauss(const struct htkamd_mmf *s, FILE *f, int g, const float *mean, const float *var, const float *gconst)
 {
    const int D = s->vecSize;
    const int mu = (g < s->capMac) ? s->gMeanMac[g] : -1, va = (g < s->capMac) ? s->gVarMac[g] : -1;
-   if (mu >= 0) put_name(f, 'u', s->vm[mu].name); else put_vec(f, "MEAN", 20, mean + (size_t)g * D, D);
-   if (va >= 0) put_name(f, 'v', s->vm[va].name); else put_vec(f, "VARIANCE", 21, var + (size_t)g * D, D);
+   if (mu >= 0) put_name(f, 'u', s->vm[mu].name); else put_vec_ms(s, f, "MEAN", 20, mean + (size_t)g * D, s->nStreams > 1 ? s->gStr[g] : -1);
+   if (va >= 0) put_name(f, 'v', s->vm[va].name); else put_vec_ms(s, f, "VARIANCE", 21, var + (size_t)g * D, s->nStreams > 1 ? s->gStr[g] : -1);
    if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
 }
 static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *mean, const float *var, const float *gconst, const float *wt)
 {
    const mmf_state *st = &s->st[si];
-   if (st->nMix > 1) { put_sym(f, "NUMMIXES", 3); put_short(f, st->nMix); put_nl(f); }
-   for (int m = 0; m < st->nMix; m++) {
-      const int c = st->comp0 + m, g = s->cg[c];
-      if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */
-      if (st->nMix > 1) { put_sym(f, "MIXTURE", 17); put_short(f, m + 1); put_float(f, wt[c]); put_nl(f); }
-      if (g < s->capGN && s->gName[g]) { put_name(f, 'm', s->gName[g]); continue; }     /* PutMixPDF: macro reference */
-      put_gauss(s, f, g, mean, var, gconst);
+   const int NS = s->nStreams > 1 ? s->nStreams : 1;
+   int needNM = 0, c0 = st->comp0;
+   for (int k = 0; k < NS; k++) if ((NS > 1 ? st->sMix[k] : st->nMix) > 1) needNM = 1;
+   if (needNM) { put_sym(f, "NUMMIXES", 3); for (int k = 0; k < NS; k++) put_short(f, NS > 1 ? st->sMix[k] : st->nMix); put_nl(f); }
+   if (NS > 1) {                                                       /* GetStateInfo gives a multi-stream state weights of 1 when it has none (:1994) */
+      put_sym(f, "SWEIGHTS", 19); put_short(f, NS); put_nl(f);
+      for (int k = 0; k < NS; k++) put_float(f, st->sw ? st->sw[k] : 1.0f);
+      put_nl(f);
+   }
+   for (int k = 0; k < NS; k++) {
+      const int M = NS > 1 ? st->sMix[k] : st->nMix;
+      if (NS > 1) { put_sym(f, "STREAM", 18); put_short(f, k + 1); put_nl(f); }
+      for (int m = 0; m < M; m++) {
+         const int c = c0 + m, g = s->cg[c];
+         if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */
+         if (M > 1) { put_sym(f, "MIXTURE", 17); put_short(f, m + 1); put_float(f, wt[c]); put_nl(f); }
+         if (g < s->capGN && s->gName[g]) { put_name(f, 'm', s->gName[g]); continue; }     /* PutMixPDF: macro reference */
+         put_gauss(s, f, g, mean, var, gconst);
+      }
+      c0 += M;
    }
 }
 static void put_trans(FILE *f, const float *logp, int N)
@@ -899,7 +1023,7 @@ static int write_macros(const struct htkamd_mmf *s, const float *mean, const flo
             if (s->vm[i].type == 'v' && s->gVarMac[g] == i) { v = var + (size_t)g * s->vecSize; break; }
          }
          put_name(f, s->vm[i].type, s->vm[i].name);
-         if (s->vm[i].type == 'u') put_vec(f, "MEAN", 20, v, s->vecSize); else put_vec(f, "VARIANCE", 21, v, s->vecSize);
+         if (s->vm[i].type == 'u') put_vec_ms(s, f, "MEAN", 20, v, s->vm[i].stream); else put_vec_ms(s, f, "VARIANCE", 21, v, s->vm[i].stream);
       }
       nN = 0;                                                  /* ~m macros come after the atomic ones, before the states */
       names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nG + 1));
@@ -1047,6 +1171,7 @@ static void mix_split(struct htkamd_mmf *s, mix_elem *me, int m, mix_elem *secon
 int htkamd_mmf_mixup(struct htkamd_mmf *s, int target, const unsigned char *stateSel)
 {
    if (!s || !s->finished || target == 0) { htkamd_set_error("mmf_mixup: bad argument (set not finished, or target 0)"); return HTKAMD_EINVAL; }
+   if (s->nStreams > 1) { htkamd_set_error("mmf_mixup: multi-stream sets are not supported"); return HTKAMD_EMODEL; }
    const int D = s->vecSize;
    for (int g = 0; g < s->nG; g++) { htkamd_host_fix_diag_gconst(D, s->var + (size_t)g * D, s->gconst + g); s->hasG[g] = 1; }   /* FixAllGConsts */
    double sum = 0.0, sumsq = 0.0; int count = 0;

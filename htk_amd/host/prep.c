@@ -9,7 +9,9 @@
  * Compile without FMA contraction so that float results equal the reference's SSE2 arithmetic.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../csrc/internal.h"
 
 double htkamd_host_min_log_exp(void)
@@ -147,3 +149,79 @@ int htkamd_host_trans_is_lr(int N, const float *tp)
    return 1;
 }
 
+
+/* ---- several streams --------------------------------------------------------------------------------------------------
+ * A multi-stream set splits the observation vector into S stream vectors: SetStreamWidths (HParm.c:3094-3168: the standard split of
+ * the parameter kind, `eSep` = the energy terms form the last stream) and ExtractObservation (HParm.c:2843-2895: where each element of
+ * the table row goes).  Here the split is a map dimension -> stream over the undivided row (dimStream), each stream's elements in
+ * ascending order -- the order ExtractObservation fills a stream vector in, so sums over a stream's dimensions run in the reference's
+ * order.  kind: the target kind as text ("MFCC_E_D"); width[s]: <STREAMINFO>.  Returns 0, or -1 (no such split: message in `why`). */
+int htkamd_host_stream_dims(const char *kind, int vecSize, int S, const int *width, int *dimStream, char *why, size_t whyLen)
+{
+   int hasE = 0, has0 = 0, hasN = 0, hasD = 0, hasA = 0, hasT = 0, s, k, tot = 0;
+   const char *p = kind ? strchr(kind, '_') : NULL;
+   if (S < 1 || S > 7) { snprintf(why, whyLen, "%d streams (1..7 supported)", S); return -1; }
+   for (s = 0; s < S; s++) { if (width[s] < 1) { snprintf(why, whyLen, "stream %d has width %d", s + 1, width[s]); return -1; } tot += width[s]; }
+   if (tot != vecSize) { snprintf(why, whyLen, "stream widths sum to %d, vector size is %d", tot, vecSize); return -1; }
+   for (; p && *p; p++) {
+      if (*p != '_') continue;
+      switch (p[1]) { case 'E': hasE = 1; break; case '0': has0 = 1; break; case 'N': hasN = 1; break; case 'D': hasD = 1; break; case 'A': hasA = 1; break; case 'T': hasT = 1; break; default: break; }
+   }
+   if (S == 1) { for (k = 0; k < vecSize; k++) dimStream[k] = 0; return 0; }
+   if (hasN) { snprintf(why, whyLen, "several streams with the _N qualifier are not supported"); return -1; }
+   /* the standard split, if there is one (SetStreamWidths) */
+   {
+      const int nBlocks = 1 + hasD + (hasD && hasA) + (hasD && hasA && hasT);
+      const int en = (hasE || has0) ? 1 : 0;                            /* NumEnergy counts one term per block */
+      const int neObs = en ? nBlocks : 0;
+      int sw[8] = {0}, ok = 1, eSep = 0;
+      if ((hasE && has0) || vecSize % nBlocks) ok = 0;
+      const int blk = vecSize / nBlocks, stat = blk - en;
+      if (ok) switch (S) {
+         case 2:
+            if (en) { sw[1] = neObs; sw[0] = vecSize - neObs; eSep = 1; }
+            else if (!hasA && hasD) { sw[1] = blk; sw[0] = vecSize - blk; }
+            else ok = 0;
+            break;
+         case 3:
+            if (hasA) { sw[1] = blk; sw[2] = blk; sw[0] = vecSize - 2 * blk; }
+            else if (hasD && en) { sw[0] = sw[1] = stat; sw[2] = neObs; eSep = 1; }
+            else ok = 0;
+            break;
+         case 4:
+            if (hasA && en) { sw[0] = sw[1] = sw[2] = stat; sw[3] = neObs; eSep = 1; }
+            else ok = 0;
+            break;
+         default: ok = 0; break;
+      }
+      if (ok) for (s = 0; s < S; s++) if (sw[s] != width[s]) { eSep = 0; break; }
+      if (eSep) {
+         /* the row is nBlocks blocks of (stat coefficients, energy): ExtractObservation :2855-2877 */
+         for (k = 0; k < vecSize; k++) {
+            const int b = k / blk, i = k % blk;
+            if (i == blk - 1) dimStream[k] = S - 1;
+            else dimStream[k] = (S == 2) ? 0 : b;
+         }
+         return 0;
+      }
+   }
+   /* any other split: the streams are consecutive pieces of the row (ExtractObservation :2883-2893) */
+   for (s = 0, k = 0; s < S; s++) { int j; for (j = 0; j < width[s]; j++) dimStream[k++] = s; }
+   return 0;
+}
+
+/* FixDiagGConst (HModel.c:5641) for the Gaussian of one stream held in an undivided row: n log(2 pi) + sum of log variances over the
+   stream's dimensions in ascending order.  dimStream == NULL: every dimension. */
+void htkamd_host_fix_diag_gconst_ms(int D, const float *var, const int *dimStream, int stream, float *gconst)
+{
+   int i, n = 0;
+   float sum;
+   for (i = 0; i < D; i++) if (!dimStream || dimStream[i] == stream) n++;
+   sum = n * log(HTK_TPI);
+   for (i = 0; i < D; i++)
+      if (!dimStream || dimStream[i] == stream) {
+         float z = (var[i] <= MINLARG) ? LZERO : log(var[i]);
+         sum += z;
+      }
+   *gconst = sum;
+}

@@ -37,6 +37,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
    memset(st, 0, sizeof(*st));
    const int map = (cfg->uFlags & HTKAMD_UPMAP) != 0;
    const float mapTau = cfg->mapTau;
+   if (map && m->NSt > 1) { htkamd_set_error("update_models: MAP re-estimation of a multi-stream set is not supported"); return HTKAMD_EMODEL; }
    if (map && (cfg->uFlags & HTKAMD_UPTRANS)) { htkamd_set_error("update_models: no MAP update of transition probabilities (HMap.c:434, HError 999)"); return HTKAMD_EINVAL; }
    doneT = (unsigned char *)calloc((size_t)m->nT, 1);
    doneS = (unsigned char *)calloc((size_t)m->S, 1);
@@ -60,6 +61,8 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
       }
       acc = pool;
    }
+/* several streams: a Gaussian lives on the dimensions of its stream, the rest of its row is never touched */
+#define OUTSIDE(g, k) (m->NSt > 1 && m->h_dimStream[k] != m->h_gaussStream[g])
 #define ML(g) (mL ? mL[g] : (g))
 #define VL(g) (vL ? vL[g] : (g))
 #define ACCF(off, idx) ((float)acc[(off) + (size_t)(idx)])
@@ -76,6 +79,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
          if (!usedG[g]) continue;
          for (z = (size_t)g * D; z < (size_t)(g + 1) * D; z++) {
             float v = var[z], iv;
+            if (OUTSIDE(g, (int)(z - (size_t)g * D))) continue;
             if (v > 1E+30) v = 1E+30;
             if (v < 1E-30) v = 1E-30;
             iv = 1 / v;
@@ -96,6 +100,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
       h = m->h_scanOrder ? m->h_scanOrder[hh] : hh;
       const int n = (int)llround(acc[lay->nEgs + h]), ti = m->h_hmmTrans[h], N = m->h_transN[ti];
       const int *hs = m->h_hmmState + m->h_hmmStateOff[h];
+      const int nHs = m->h_hmmStateOff[h + 1] - m->h_hmmStateOff[h];          /* N - 2 states, or their (state, stream) elements */
       if (n < cfg->minEgs) st->nSkippedHmm++;
       if (!(n >= cfg->minEgs && n > 0)) continue;
       if ((cfg->uFlags & HTKAMD_UPTRANS) && !doneT[ti]) {
@@ -119,7 +124,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
          doneT[ti] = 1;
       }
       if (maxM > 1 && (cfg->uFlags & HTKAMD_UPMIXES))
-         for (j = 0; j < N - 2; j++) {
+         for (j = 0; j < nHs; j++) {
             const int s = hs[j], c0 = m->h_stateCompOff[s], M = m->h_stateCompOff[s + 1] - c0;
             const float occi = ACCF(lay->wtOcc, s);
             if (doneS[s]) continue;
@@ -178,7 +183,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             doneS[s] = 1;
          }
       if (cfg->uFlags & HTKAMD_UPVARS)
-         for (j = 0; j < N - 2; j++) {
+         for (j = 0; j < nHs; j++) {
             const int s = hs[j];
             for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
                if (wgt[c] > MINMIX) {
@@ -190,6 +195,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                         const float muOcc = ACCF(lay->muOcc, gm);
                         const int shared = ((cfg->uFlags & HTKAMD_UPMEANS) == 0 || doneMu[gm] || muOcc <= 0.0 || (vL && m->h_varGroupSize[g] > 1));
                         for (k = 0; k < D; k++) {
+                           if (OUTSIDE(g, k)) continue;
                            float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)gm * D + k) / muOcc;
                            float x = ACCF(lay->va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
                            if (map) {                    /* HMap.c:350-356 */
@@ -211,7 +217,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                }
          }
       if (cfg->uFlags & HTKAMD_UPMEANS)
-         for (j = 0; j < N - 2; j++) {
+         for (j = 0; j < nHs; j++) {
             const int s = hs[j];
             for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
                if (wgt[c] > MINMIX) {
@@ -225,18 +231,18 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
                            *mk = (*mk * mapTau + (ACCF(lay->mu, (size_t)g * D + k) + *mk * occim)) / (mapTau + occim);
                         }
                      } else if (occim > 0.0)
-                        for (k = 0; k < D; k++) mean[(size_t)g * D + k] += ACCF(lay->mu, (size_t)g * D + k) / occim;
+                        for (k = 0; k < D; k++) { if (OUTSIDE(g, k)) continue; mean[(size_t)g * D + k] += ACCF(lay->mu, (size_t)g * D + k) / occim; }
                      doneMu[g] = 1;
                   }
                }
          }
       if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))
-         for (j = 0; j < N - 2; j++) {
+         for (j = 0; j < nHs; j++) {
             const int s = hs[j];
             for (c = m->h_stateCompOff[s]; c < m->h_stateCompOff[s + 1]; c++)
                if (wgt[c] > MINMIX) {
                   const int g = m->h_compGauss[c];
-                  htkamd_host_fix_diag_gconst(D, var + (size_t)VL(g) * D, gconst + g);
+                  htkamd_host_fix_diag_gconst_ms(D, var + (size_t)VL(g) * D, m->h_dimStream, m->h_gaussStream ? m->h_gaussStream[g] : 0, gconst + g);
                }
          }
    }
@@ -249,6 +255,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
       }
    }
 #undef ML
+#undef OUTSIDE
 #undef VL
    free(pool);
    free(doneT); free(doneS); free(doneMu); free(doneVa);

@@ -86,6 +86,13 @@ typedef struct {
    const int   *hmmTrans;     /* [H] tIdx of each physical HMM                        */
    const int   *hmmStateOff;  /* [H+1]                                                */
    const int   *hmmState;     /* tied-state index of the emitting states 2..N-1       */
+   /* Several streams (hset->swidth[0] > 1; HModel.h StreamElem, HParm.c:3094 SetStreamWidths).  numStreams 0 or 1: one stream, the
+      fields above as described.  numStreams = NS > 1: stateCompOff has numStates*NS + 1 entries, the components of stream k of state
+      s are stateCompOff[s*NS + k] .. [s*NS + k + 1); a Gaussian belongs to one stream and is held in an UNDIVIDED row of vecSize
+      elements: its values at the dimensions d with dimStream[d] == its stream, mean 0 and variance +infinity elsewhere (such a
+      dimension contributes nothing to a score and is never re-estimated); the feature rows stay undivided as well. */
+   int numStreams;
+   const int   *dimStream;    /* [D] stream (0-based) of each dimension, NULL for one stream (htkamd_mmf computes it from the kind) */
 } htkamd_model_desc;
 
 typedef struct htkamd_model htkamd_model;

@@ -44,6 +44,20 @@ void orc_fix_diag_gconst(int D, const float *var, float *gconst_out)
    *gconst_out = sum;
 }
 
+void orc_fix_diag_gconst_ms(int D, const float *var, const int *dimStream, int stream, float *gconst_out)
+{
+   float sum, z;
+   int i, n = 0;
+   for (i = 0; i < D; i++) if (!dimStream || dimStream[i] == stream) n++;
+   sum = n * log(ORC_TPI);                 /* vSize = the stream's width */
+   for (i = 0; i < D; i++) {
+      if (dimStream && dimStream[i] != stream) continue;
+      z = (var[i] <= ORC_MINLARG) ? ORC_LZERO : log(var[i]);
+      sum += z;
+   }
+   *gconst_out = sum;
+}
+
 /* HUtil.c:413-437 ConvDiagC(convData=TRUE): clamp to [MINVAR,MAXVAR] then 1/v in float */
 void orc_conv_diagc(int n, const float *var, float *ivar_out)
 {
@@ -140,6 +154,47 @@ float orc_state_outp(const orc_model *m, int s, const float *x, float *mixp_out)
          mixp = orc_idoutp(x, m->D, m->mean + (size_t)g * m->D, m->ivar + (size_t)g * m->D, m->gconst[g]);
          mixp += det;
          xx = orc_ladd(xx, wt + mixp);   /* float add, double LAdd, float store */
+         if (mixp_out) mixp_out[k] = mixp;
+      }
+   }
+   return xx;
+}
+
+/* IDOutP over the dimensions of one stream of the undivided row (the stream vector ot.fv[s] in ascending order) */
+static float idoutp_ms(const float *x, int D, const float *mean, const float *ivar, float gconst, const int *dimStream, int stream)
+{
+   int i;
+   float sum, xmm;
+   sum = gconst;
+   for (i = 0; i < D; i++) {
+      if (dimStream[i] != stream) continue;
+      xmm = x[i] - mean[i];
+      sum += xmm * xmm * ivar[i];
+   }
+   return -0.5 * sum;
+}
+
+/* ShStrP (HFB.c:898-988) for one stream element of a multi-stream state */
+float orc_elem_outp(const orc_model *m, int e, const float *x, float *mixp_out)
+{
+   int c0 = m->stateCompOff[e], c1 = m->stateCompOff[e + 1], M = c1 - c0, k, g, str = e % m->NSt;
+   float xx, mixp, wt, det = 0.0f;
+   if (M == 1) {
+      g = m->compGauss[c0];
+      xx = idoutp_ms(x, m->D, m->mean + (size_t)g * m->D, m->ivar + (size_t)g * m->D, m->gconst[g], m->dimStream, str);
+      xx += det;
+      if (mixp_out) mixp_out[0] = xx;
+      return xx;
+   }
+   xx = ORC_LZERO;
+   for (k = 0; k < M; k++) {
+      if (mixp_out) mixp_out[k] = ORC_LZERO;
+      wt = m->compLogWt[c0 + k];
+      if (wt > ORC_LMINMIX) {
+         g = m->compGauss[c0 + k];
+         mixp = idoutp_ms(x, m->D, m->mean + (size_t)g * m->D, m->ivar + (size_t)g * m->D, m->gconst[g], m->dimStream, str);
+         mixp += det;
+         xx = orc_ladd(xx, wt + mixp);
          if (mixp_out) mixp_out[k] = mixp;
       }
    }
@@ -252,7 +307,30 @@ typedef struct {
    double *alphat, *alphat1; /* [(Q+2)*(maxN+1)] */
    float *occt;       /* [maxN+1] */
    long long nEval;
+   /* several streams: otprob[t][q][j][s], s = 1..S -- pointers to the stream's probability vector ([0] = the stream's log
+      probability, [1..M] per component), which a tied state met again at the same frame SHARES with its first visit (ShStrP's
+      wa->prob, HFB.c:911-912) */
+   int NSt;
+   float **sv;        /* [(T+1)*nSlots*NSt] */
+   int *lastT;        /* [S*NSt] wa->time */
+   float **lastVec;   /* [S*NSt] wa->prob */
+   float **blocks; int nBlocks, capBlocks; size_t blockUsed;
 } fbws;
+
+#define SV_(t,q,j) (((size_t)(t) * w->nSlots + w->slotOff[q] + ((j) - 2)) * w->NSt)
+#define ORC_ARENA 65536
+static float *sv_alloc(fbws *w, int n)
+{
+   float *p;
+   if (w->nBlocks == 0 || w->blockUsed + (size_t)n > ORC_ARENA) {
+      if (w->nBlocks == w->capBlocks) { w->capBlocks = w->capBlocks * 2 + 16; w->blocks = (float **)realloc(w->blocks, sizeof(float *) * (size_t)w->capBlocks); }
+      w->blocks[w->nBlocks++] = (float *)malloc(sizeof(float) * (n > ORC_ARENA ? (size_t)n : ORC_ARENA));
+      w->blockUsed = 0;
+   }
+   p = w->blocks[w->nBlocks - 1] + w->blockUsed;
+   w->blockUsed += (size_t)n;
+   return p;
+}
 
 #define A_(q,i)   ((size_t)(q) * (w->maxN + 1) + (i))
 #define B_(t,q,i) (((size_t)(t) * (w->Q + 2) + (q)) * (w->maxN + 1) + (i))
@@ -298,6 +376,29 @@ static void set_otprob(fbws *w, int t, int qHi, int qLo)
          for (j = 2; j < w->N[q]; j++) {
             int s = m->hmmState[m->hmmStateOff[h] + (j - 2)];
             float *o = w->outp + O_(t, q, j);
+            if (w->NSt > 1) {                     /* HFB.c:1026-1066, PLAINHS / SHAREDHS with S > 1 */
+               float **sv = w->sv + SV_(t, q, j), sum = 0.0;
+               int ks, seenState = 0;
+               for (ks = 0; ks < w->NSt; ks++) {
+                  const int e = s * w->NSt + ks, M = m->stateCompOff[e + 1] - m->stateCompOff[e];
+                  seenState = (!m->msIntended && w->lastT[e] == t);      /* :1044, overwritten stream by stream: the LAST stream's decides */
+                  if (seenState) sv[ks] = w->lastVec[e];                  /* ShStrP :911-912 */
+                  else {
+                     float *v = sv_alloc(w, M == 1 ? 1 : M + 1);          /* NewOtprobVec :883 */
+                     v[0] = orc_elem_outp(m, e, w->X + (size_t)(t - 1) * m->D, M == 1 ? NULL : v + 1);
+                     w->lastT[e] = t; w->lastVec[e] = v;
+                     sv[ks] = v;
+                  }
+                  sum += sv[ks][0];
+               }
+               if (seenState) o[0] = sum / 2;                             /* :1059 */
+               else {
+                  o[0] = sum;
+                  for (ks = 0; ks < w->NSt; ks++) sv[ks][0] = sum - sv[ks][0];      /* :1062-1064: in the SHARED vector */
+               }
+               w->nEval++;
+               continue;
+            }
             o[0] = orc_state_outp(m, s, w->X + (size_t)(t - 1) * m->D, o + 1);
             w->nEval++;
          }
@@ -583,7 +684,7 @@ static void up_mix_parms(fbws *w, orc_accs *acc, int t, int q, const double *aqt
 
    for (j = 2; j < N; j++) {
       int s = m->hmmState[m->hmmStateOff[h] + (j - 2)];
-      int c0 = m->stateCompOff[s];
+      int c0 = m->stateCompOff[w->NSt > 1 ? s * w->NSt : s];
       const float *outprob = w->outp + O_(t, q, j);
       const float *ot = w->X + (size_t)(t - 1) * D;
       if (w->maxM > 1) {                          /* fbInfo->maxM: maximum over the whole set */
@@ -595,6 +696,63 @@ static void up_mix_parms(fbws *w, orc_accs *acc, int t, int q, const double *aqt
                   initx = orc_ladd(initx, aqt1[i] + a);
             }
          initx += bqt[j] - pr;
+      }
+      if (w->NSt > 1) {                           /* the stream loop of UpMixParms (HFB.c:1499-1721) */
+         int ks;
+         for (ks = 0; ks < w->NSt; ks++) {
+            const int e = s * w->NSt + ks;
+            const float *op = w->sv[SV_(t, q, j) + ks];
+            c0 = m->stateCompOff[e];
+            M = m->stateCompOff[e + 1] - c0;
+            steSumLr = 0.0;
+            for (mx = 1; mx <= M; mx++) {
+               int c = c0 + mx - 1, g = m->compGauss[c];
+               wght = m->compLogWt[c];
+               if (wght > ORC_LMINMIX) {
+                  if (M == 1) x = aqt[j] + bqt[j] - pr;
+                  else {
+                     c_jm = wght;
+                     x = initx + c_jm;
+                     prob = op[mx];
+                     x += prob;
+                     x += op[0];                  /* adjust for parallel streams :1611 */
+                  }
+                  if (-x < w->cfg->minFrwdP) {
+                     const float *mean = m->mean + (size_t)g * D;
+                     Lr = exp(x);
+                     steSumLr += Lr;
+                     if ((uF & ORC_UPMEANS) && (uF & ORC_UPVARS)) {
+                        float *mu_jm = acc->mu + (size_t)g * D, *var = acc->va + (size_t)g * D;
+                        acc->muOcc[g] += Lr;
+                        acc->vaOcc[g] += Lr;
+                        for (k = 0; k < D; k++) {
+                           if (m->dimStream[k] != ks) continue;
+                           zmean = ot[k] - mean[k];
+                           zmeanlr = zmean * Lr;
+                           mu_jm[k] += zmeanlr;
+                           var[k] += zmean * zmeanlr;
+                        }
+                     } else if (uF & ORC_UPMEANS) {
+                        float *mu_jm = acc->mu + (size_t)g * D;
+                        acc->muOcc[g] += Lr;
+                        for (k = 0; k < D; k++) if (m->dimStream[k] == ks) mu_jm[k] += (ot[k] - mean[k]) * Lr;
+                     } else if (uF & ORC_UPVARS) {
+                        float *var = acc->va + (size_t)g * D;
+                        acc->vaOcc[g] += Lr;
+                        for (k = 0; k < D; k++) {
+                           if (m->dimStream[k] != ks) continue;
+                           zmean = ot[k] - mean[k];
+                           var[k] += zmean * zmean * Lr;
+                        }
+                     }
+                     if (uF & ORC_UPMIXES)
+                        acc->wt[c] += Lr;
+                  }
+               }
+            }
+            acc->wtOcc[e] += steSumLr;
+         }
+         continue;
       }
       M = m->stateCompOff[s + 1] - c0;
       steSumLr = 0.0;
@@ -663,7 +821,8 @@ int orc_fb_utt(const orc_model *m, const orc_fbcfg *cfg, const float *X, int T,
    w->qLo = (short *)calloc(T + 2, sizeof(short));
    w->qHi = (short *)calloc(T + 2, sizeof(short));
    w->maxM = 1;
-   for (i = 0; i < m->S; i++) {           /* MaxMixInSet (HFB.c:261) is a property of the whole set */
+   w->NSt = m->NSt > 1 ? m->NSt : 1;
+   for (i = 0; i < m->S * w->NSt; i++) {  /* MaxMixInSet (HFB.c:261) is a property of the whole set */
       int M = m->stateCompOff[i + 1] - m->stateCompOff[i];
       if (M > w->maxM) w->maxM = M;
    }
@@ -693,12 +852,18 @@ int orc_fb_utt(const orc_model *m, const orc_fbcfg *cfg, const float *X, int T,
    w->alphat = (double *)malloc((size_t)(Q + 2) * (w->maxN + 1) * sizeof(double));
    w->alphat1 = (double *)malloc((size_t)(Q + 2) * (w->maxN + 1) * sizeof(double));
    w->occt = (float *)malloc((w->maxN + 1) * sizeof(float));
+   if (w->NSt > 1) {
+      w->sv = (float **)calloc((size_t)(T + 1) * w->nSlots * w->NSt, sizeof(float *));
+      w->lastT = (int *)malloc(sizeof(int) * (size_t)m->S * w->NSt);
+      w->lastVec = (float **)calloc((size_t)m->S * w->NSt, sizeof(float *));
+   }
 
    /* StepBack HFB.c:1321-1366 */
    w->pruneThresh = cfg->pruneInit;
    for (;;) {
       memset(w->bpres, 0, (size_t)(T + 2) * (Q + 2));
       memset(w->opres, 0, (size_t)(T + 2) * (Q + 2));
+      if (w->NSt > 1) for (i = 0; i < m->S * w->NSt; i++) w->lastT[i] = -1;     /* a new pass re-creates otprob; ResetHMMPreComps / ResetHMMWtAccs (HFB.c:559-562) */
       set_beam_taper(w);
       lbeta = set_beta(w);
       if (lbeta > ORC_LSMALL) break;
@@ -765,6 +930,9 @@ int orc_fb_utt(const orc_model *m, const orc_fbcfg *cfg, const float *X, int T,
 done:
    free(w->beta); free(w->bpres); free(w->outp); free(w->opres);
    free(w->alphat); free(w->alphat1); free(w->occt);
+   free(w->sv); free(w->lastT); free(w->lastVec);
+   for (i = 0; i < w->nBlocks; i++) free(w->blocks[i]);
+   free(w->blocks);
 done0:
    free(w->N); free((void *)w->tp); free(w->qDms); free(w->slotOff); free(w->qLo); free(w->qHi);
    return rc;

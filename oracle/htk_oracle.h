@@ -53,6 +53,14 @@ typedef struct {
    const int   *hmmTrans;     /* [H]                                       */
    const int   *hmmStateOff;  /* [H+1]                                     */
    const int   *hmmState;     /* tied-state index of emitting states 2..N-1*/
+   /* several streams (hset->swidth[0] = NSt > 1; 0 or 1: one stream).  stateCompOff then has S*NSt + 1 entries -- the components of
+      stream k of state s are [s*NSt + k] .. [s*NSt + k + 1) -- and a Gaussian is held in an undivided row of D elements of which
+      only the dimensions d with dimStream[d] == its stream are read: a stream vector is those elements in ascending order
+      (ExtractObservation HParm.c:2843).  wtOcc accumulators: [S*NSt]. */
+   int NSt;
+   const int   *dimStream;    /* [D] */
+   int msIntended;            /* 0: Setotprob as the reference has it, with its second-visit branch (HFB.c:1044,1059); 1: every visit
+                                 computes the first visit's values (what that branch equals for S = 3 only) */
 } orc_model;
 
 typedef struct {              /* float accumulators exactly as HTrain.h:211-232 */
@@ -88,6 +96,7 @@ double orc_ladd(double x, double y);
 
 /* ---- model preparation ---- */
 void  orc_fix_diag_gconst(int D, const float *var, float *gconst_out);      /* HModel.c:5641 */
+void  orc_fix_diag_gconst_ms(int D, const float *var, const int *dimStream, int stream, float *gconst_out);   /* the same over one stream's dimensions */
 void  orc_conv_diagc(int n, const float *var, float *ivar_out);              /* HUtil.c:413   */
 float orc_mix_log_weight(float w);                                           /* HModel.c:5288 */
 int   orc_min_dur(int N, const float *transP);                               /* HFB.c:106     */
@@ -97,6 +106,8 @@ float orc_idoutp(const float *x, int D, const float *mean, const float *ivar, fl
 /* ShStrP (HFB.c:898) == cSOutP (HRec.c:438) arithmetic: returns state log-lik, fills mixp[0..M-1]
    (LZERO for skipped components) when mixp != NULL */
 float orc_state_outp(const orc_model *m, int s, const float *x, float *mixp);
+/* the same for stream element e = state*NSt + stream of a multi-stream set (x: the undivided row) */
+float orc_elem_outp(const orc_model *m, int e, const float *x, float *mixp);
 float orc_doutp(const float *x, int D, const float *mean, const float *var, float gconst);    /* HModel.c:5347 */
 void  orc_soutp_block(const orc_model *m, const float *var, const float *X, int T, const int *states, int ns, float *out);
 void  orc_score_block_diagc(const orc_model *m, const float *var, const float *X, int T, const int *states, int ns, float *out);

@@ -63,7 +63,8 @@ class CModel(C.Structure):
                 ("stateCompOff", C.c_void_p), ("compLogWt", C.c_void_p), ("compGauss", C.c_void_p),
                 ("mean", C.c_void_p), ("ivar", C.c_void_p), ("gconst", C.c_void_p),
                 ("transN", C.c_void_p), ("transOff", C.c_void_p), ("transP", C.c_void_p),
-                ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p)]
+                ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p),
+                ("NSt", C.c_int), ("dimStream", C.c_void_p), ("msIntended", C.c_int)]
 
 
 class CAccs(C.Structure):
@@ -94,9 +95,13 @@ class Model:
     """Packed model (same field names as include/htk_amd.h) prepared the way HERest/HVite prepare an HMMSet:
     FixDiagGConst if no gconst (HModel.c:206-208), ConvDiagC (HUtil.c:413), ConvLogWt (HUtil.c:474)."""
 
-    def __init__(self, pk: dict):
+    def __init__(self, pk: dict, ms_intended: bool = False):
         L = lib()
         self.pk = pk
+        # several streams (pk["numStreams"] > 1): stateCompOff per (state, stream), Gaussians in undivided rows (htk_oracle.h)
+        self.NSt = int(pk.get("numStreams", 1) or 1)
+        self.dimStream = np.ascontiguousarray(pk["dimStream"], np.int32) if self.NSt > 1 else None
+        self.ms_intended = bool(ms_intended)
         self.D = int(pk["vecSize"]); self.S = int(pk["numStates"]); self.C = int(pk["numComp"])
         self.G = int(pk["numGauss"]); self.nT = int(pk["numTrans"]); self.H = int(pk["numPhys"])
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -108,8 +113,12 @@ class Model:
         self.hmmTrans = i32(pk["hmmTrans"]); self.hmmStateOff = i32(pk["hmmStateOff"]); self.hmmState = i32(pk["hmmState"])
         if pk.get("gconst") is None:
             self.gconst = np.empty(self.G, np.float32)
+            gs = np.zeros(self.G, np.int32)
+            if self.NSt > 1:
+                for e in range(self.S * self.NSt):
+                    gs[self.compGauss[self.stateCompOff[e]:self.stateCompOff[e + 1]]] = e % self.NSt
             for g in range(self.G):
-                L.orc_fix_diag_gconst(C.c_int(self.D), _p(self.var[g]), C.c_void_p(self.gconst.ctypes.data + 4 * g))
+                L.orc_fix_diag_gconst_ms(C.c_int(self.D), _p(self.var[g]), _p(self.dimStream), C.c_int(int(gs[g])), C.c_void_p(self.gconst.ctypes.data + 4 * g))
         else:
             self.gconst = f32(pk["gconst"]).copy()
         self.refresh()
@@ -124,7 +133,8 @@ class Model:
                         _p(self.stateCompOff), _p(self.compLogWt), _p(self.compGauss),
                         _p(self.mean), _p(self.ivar), _p(self.gconst),
                         _p(self.transN), _p(self.transOff), _p(self.transP),
-                        _p(self.hmmTrans), _p(self.hmmStateOff), _p(self.hmmState))
+                        _p(self.hmmTrans), _p(self.hmmStateOff), _p(self.hmmState),
+                        self.NSt, _p(self.dimStream), int(self.ms_intended))
 
     @property
     def maxN(self):
@@ -166,7 +176,7 @@ class Accs:
         self.m = m
         self.mu = np.zeros((m.G, m.D), np.float32); self.muOcc = np.zeros(m.G, np.float32)
         self.va = np.zeros((m.G, m.D), np.float32); self.vaOcc = np.zeros(m.G, np.float32)
-        self.wt = np.zeros(m.C, np.float32); self.wtOcc = np.zeros(m.S, np.float32)
+        self.wt = np.zeros(m.C, np.float32); self.wtOcc = np.zeros(m.S * getattr(m, "NSt", 1), np.float32)
         self.tr = np.zeros(int(m.transOff[-1]), np.float32); self.trOcc = np.zeros(int(m.transN.sum()), np.float32)
         self.nEgs = np.zeros(m.H, np.int32)
         self.c = CAccs(*[_p(getattr(self, n)) for n in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs")])

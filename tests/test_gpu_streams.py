@@ -1,0 +1,166 @@
+"""Multi-stream forward-backward on the device (HFB.c:1026-1066 Setotprob with S > 1, :1499-1602 UpMixParms' stream
+loop): a row of scores per (stream, chain state), their float sum as the state's log probability (k_combine_streams), per-stream
+posteriors with "the other streams" added (k_mixstats_ms), one WtAcc per (state, stream), Gaussians re-estimated on their stream's
+dimensions only.
+
+Against what:
+  * S = 3 demo set: the reference's own accumulators (`HERest -p 1`) and re-estimated MMF (tests/golden/make_streams_golden.py).  The
+    reference meets a tied state a second time at a frame through `sum/2` of replaced values (HFB.c:1059), which for S = 3 is the same
+    number as the first visit up to float rounding -- so its accumulators are matched like every other set's (1e-4 against float sums), not bit for bit.
+  * any S: oracle/htk_oracle.c with `ms_intended` (every visit computes the first visit's values); the oracle WITHOUT it is pinned to
+    the reference float for float in tests/test_streams.py, S = 2 with the reference's defect included.
+  * random multi-stream sets: S = 2, 3, 4, streams with one and with several components, all kernels paths."""
+import os
+
+import numpy as np
+import pytest
+
+import streams_util as su
+import test_cli_tools as cli
+from util import batch_arrays, acc_close
+
+pytestmark = pytest.mark.gpu
+DEMO = su.DEMO
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(native, pk, utts, path=None, mode=0, prune=None, uFlags=15):
+    model = native.Model(pk)
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = native.DevArray(X)
+    fb = native.ForwardBackward(model, debug=True, force_general=(path == "general"), no_state_path=(path == "wave"))
+    acc = native.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+    fb.execute(native.fb_config(uFlags=uFlags, scoreMode=mode, **(prune or {})), acc)
+    pr, st = fb.results()
+    return model, fb, acc, pr, st
+
+
+def _oracle_accs(oracle, pk, utts, prune=None, uFlags=15, intended=True):
+    om = oracle.Model(pk, ms_intended=intended)
+    acc = oracle.Accs(om)
+    prs = []
+    for u in utts:
+        rc, pr, _ = oracle.fb_utt(om, oracle.fb_cfg(uFlags=uFlags, **(prune or {})), u["feat"], u["seq"], acc)
+        prs.append(pr if rc == 1 else np.nan)
+    return om, acc, np.array(prs)
+
+
+def _close_stat(got, ref, occ, sigma2, k, rtol, what):
+    """First- / second-order sums about the OLD mean: sum L (x - mu) and sum L (x - mu)^2 are sums of terms of size L sigma and L sigma^2
+    that largely cancel in the first case, so their natural scale is occ sigma (occ sigma^2), not the net value."""
+    s2 = np.where(np.isfinite(sigma2), sigma2, 0.0)
+    scale = np.maximum(np.abs(ref), occ[:, None] * (np.sqrt(s2) if k == "mu" else s2))
+    err = np.abs(got - ref)
+    bad = err > rtol * np.maximum(scale, 1e-3)
+    assert not bad.any(), "%s %s: %d outside tolerance, worst %g of scale %g" % (what, k, int(bad.sum()), err[bad].max(), scale[bad][np.argmax(err[bad])])
+
+
+def _compare(a, ref, rtol, what, var):
+    """ref: dict of arrays (oracle accumulators or the reference's file)"""
+    G = var.shape[0]
+    for k in ("mu", "va"):
+        r = np.asarray(ref[k], np.float64).reshape(G, -1)
+        _close_stat(a[k].reshape(r.shape), r, np.asarray(ref[k + "Occ"], np.float64), var.astype(np.float64), k, rtol, what)
+    for k in ("muOcc", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+        acc_close(a[k], np.asarray(ref[k], np.float64), "%s %s" % (what, k), rtol=rtol, floor=1e-3)
+
+
+def _odict(oacc):
+    return {k: getattr(oacc, k) for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc")}
+
+
+@pytest.mark.parametrize("path", ["state", "wave", "general"])
+@pytest.mark.parametrize("S", [3, 2])
+def test_demo_stream_sets_against_oracle_and_reference(native, oracle, S, path):
+    d = os.path.join(DEMO, "hmm_streams%d" % S)
+    mmf = native.Mmf(files=[os.path.join(d, "newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    utts = su.demo_utterances(native, oracle, mmf)
+    prune = dict(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0)
+    model, fb, acc, pr, st = _run(native, pk, utts, path=path, prune=prune)
+    assert (st == 1).all()
+    a = acc.download()
+    om, oacc, opr = _oracle_accs(oracle, pk, utts, prune=dict(pruneInit=2000.0))
+    assert np.allclose(pr, opr, rtol=1e-9, atol=0)
+    _compare(a, _odict(oacc), 1e-4, "S=%d %s vs oracle" % (S, path), pk["var"])        # float accumulators on the oracle side (as in the reference), fp64 sums here
+    # the dimensions outside a Gaussian's stream collect nothing
+    gs = np.zeros(pk["numGauss"], np.int32)
+    for e in range(pk["numStates"] * S):
+        gs[pk["compGauss"][pk["stateCompOff"][e]:pk["stateCompOff"][e + 1]]] = e % S
+    outside = pk["dimStream"][None, :] != gs[:, None]
+    assert (a["mu"].reshape(outside.shape)[outside] == 0).all() and (a["va"].reshape(outside.shape)[outside] == 0).all()
+    if S == 3:
+        # the reference itself: accumulators of `HERest -p 1`, its summary line
+        lay = native.accs_layout(pk)
+        v = np.zeros(lay.total, np.float64)
+        native.accs_load_file(pk, v, list(mmf.phys_names), os.path.join(d, "HER1.acc"))
+        _compare(a, {k: v[getattr(lay, k):getattr(lay, k) + a[k].size] for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc")}, 1e-4,
+                 "S=3 %s vs the reference's accumulators" % path, pk["var"])
+        assert "average log prob per frame = %e" % (a["totalPr"] / a["totalT"]) in open(os.path.join(d, "herest.log")).read()
+
+
+@pytest.mark.parametrize("device_update", [False, True])
+def test_demo_three_streams_reestimated_model_equals_the_reference(native, oracle, tmp_path, device_update):
+    d = os.path.join(DEMO, "hmm_streams3")
+    mmf = native.Mmf(files=[os.path.join(d, "newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    utts = su.demo_utterances(native, oracle, mmf)
+    model, fb, acc, pr, st = _run(native, pk, utts, prune=dict(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0))
+    kw = dict(minEgs=3, minVar=0.05, mixWeightFloor=3 * 1.0e-5)
+    stats = model.update_device(acc, **kw) if device_update else model.update(acc, acc.download()["vec"], **kw)
+    assert "Total %d floored variance elements in %d different mixes" % (stats["nFloorVar"], stats["nFloorVarMix"]) in open(os.path.join(d, "herest.log")).read()
+    p = model.get_params()
+    out = str(tmp_path / "newMacros")
+    mmf.write(p, one_file=out)
+    cli._mmf_close(cli._mmf_numbers(out), cli._mmf_numbers(os.path.join(d, "after_herest")))
+    # the structure of the file is the reference's: same keywords in the same order
+    kw_of = lambda path: [t for t in open(path).read().split() if t.startswith("<") or t.startswith("~")]
+    assert kw_of(out) == kw_of(os.path.join(d, "after_herest"))
+
+
+def test_herest_cli_three_streams(native, tmp_path):
+    tools = os.path.join(ROOT, "tools", "bin")
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "next"; out.mkdir()
+    d = os.path.join(DEMO, "hmm_streams3")
+    r = cli.run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d, "newMacros"), "-M", str(out),
+                 "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
+    assert r.returncode == 0, r.stderr
+    for line in open(os.path.join(d, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-400:])
+    cli._mmf_close(cli._mmf_numbers(str(out / "newMacros")), cli._mmf_numbers(os.path.join(d, "after_herest")))
+    # parallel mode: the accumulator file of this run is the reference's to the float
+    acc = tmp_path / "acc"; acc.mkdir()
+    r = cli.run([os.path.join(tools, "herest"), "-p", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d, "newMacros"), "-M", str(acc),
+                 "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(str(acc / "HER1.acc")) == os.path.getsize(os.path.join(d, "HER1.acc"))
+
+
+@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("widths,single,seed", [((10, 10), (), 1), ((8, 8, 4), (2,), 2), ((6, 6, 6, 2), (), 3), ((12, 8), (0, 1), 4), ((5, 15), (1,), 5)])
+def test_random_stream_sets(native, oracle, widths, single, seed, mode):
+    """Random sets on random transcriptions; `single`: streams with one Gaussian (their posterior is the state's occupation, HFB.c:1584);
+    (0, 1) of two streams = a set without any mixture (maxM == 1: the seed is log alpha + log beta - pr)."""
+    from htk_amd import synth
+    rng = np.random.default_rng(seed)
+    s = synth.generate(12, 1, 10, 6, 60, 40 + seed, D=sum(widths))
+    pk = su.make_multistream(s.packed(), list(widths), rng, max_mix=4, single=single)
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    om, oacc, opr = _oracle_accs(oracle, pk, utts)
+    ok = ~np.isnan(opr)
+    assert ok.sum() >= len(utts) // 2
+    for path in ("state", "wave", "general"):
+        model, fb, acc, pr, st = _run(native, pk, utts, path=path, mode=mode)
+        assert ((st == 1) == ok).all()
+        rt = 1e-9 if mode == 0 else 2e-5
+        assert np.allclose(pr[ok], opr[ok], rtol=rt, atol=0), (path, np.abs(pr[ok] / opr[ok] - 1).max())
+        _compare(acc.download(), _odict(oacc), 1e-4, "%s mode %d %s" % (widths, mode, path), pk["var"])
+
+
+def test_streams_are_refused_where_they_are_not_served(native):
+    mmf = native.Mmf(files=[os.path.join(DEMO, "hmm_streams3", "newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    model = native.Model(mmf.packed())
+    with pytest.raises(native.HtkAmdError, match="multi-stream"):
+        native.Viterbi(model)
