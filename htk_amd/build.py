@@ -23,6 +23,8 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["-fno-honor-nans"]}
 if os.environ.get("HTKAMD_LR_DEFS"):               # experiment switches of fb_lr.hip, e.g. HTKAMD_LR_DEFS="-DSTATS_EXP_NOOCC"
     EXTRA_FLAGS["csrc/fb_lr.hip"] = os.environ["HTKAMD_LR_DEFS"].split()
+if os.environ.get("HTKAMD_B16_CT"):              # experiment switch: column tiles per wavefront of the bf16 scoring kernel (gmm_bf16.hip: B16_COL_TILES)
+    EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_COL_TILES=" + os.environ["HTKAMD_B16_CT"]]
 if os.environ.get("HTKAMD_B16_WPB"):             # experiment switch: wavefronts per workgroup of the bf16 scoring kernel (gmm_bf16.hip: B16_WPB)
     EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_WPB=" + os.environ["HTKAMD_B16_WPB"]]
 

@@ -45,7 +45,9 @@ typedef const __attribute__((address_space(4))) int cint;
 
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 #define LOG2(x) __builtin_amdgcn_logf(x)
-#define B16_COL_TILES 2
+#ifndef B16_COL_TILES
+#define B16_COL_TILES 2                                 // 16-frame column tiles per wavefront: 2 (four wavefronts per 128-frame task) or 4 (two)
+#endif
 
 __device__ __forceinline__ float rows_max_b(float v)
 {
@@ -88,12 +90,12 @@ __device__ __host__ __forceinline__ void split3(float x, unsigned short &p1, uns
 }
 
 #ifndef B16_WPB
-#define B16_WPB 4                                       // wavefronts per workgroup: 4 x 32 frames = a whole 128-frame task; 2: the task in two halves
+#define B16_WPB (8 / B16_COL_TILES)                     // wavefronts per workgroup: together a whole 128-frame task (B16_WPB smaller: the task in parts)
 #endif
 template <int NC>
-__global__ __launch_bounds__(64 * B16_WPB, 12 / B16_WPB) void k_score_bf16(ScoreArgs a)
+__global__ __launch_bounds__(64 * B16_WPB, B16_COL_TILES > 2 ? 2 : 3) void k_score_bf16(ScoreArgs a)      // second figure: wavefronts per SIMD the register budget is cut for
 {
-   constexpr int NT = 64 * B16_WPB, HALVES = 4 / B16_WPB;
+   constexpr int NT = 64 * B16_WPB, FPW = 16 * B16_COL_TILES, HALVES = 128 / (FPW * B16_WPB);
    constexpr int TWB = 3 * NC * 64 * 16 + 64 * 16;     // bytes per fragment tile
    constexpr int TW4 = TWB / 16;                       // 16-byte words per tile
    constexpr int PT = (TW4 + NT - 1) / NT;             // words staged per thread
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64 * B16_WPB, 12 / B16_WPB) void k_score_bf16(Score
       const int task = vtask / HALVES;
       if (task >= a.nTasks) break;
       const ScoreTask tk = a.tasks[task];
-      const int fw = 32 * wv + (128 / HALVES) * (vtask % HALVES);      // this wave's first frame in the tile
+      const int fw = FPW * wv + (128 / HALVES) * (vtask % HALVES);      // this wave's first frame in the tile
       const bool active = fw < tk.nFrames;
 
       // first tile and tile count of every state of the task, one per lane (tasks hold at most 64 states): the tile loop below reads them
@@ -237,10 +239,14 @@ __global__ __launch_bounds__(64 * B16_WPB, 12 / B16_WPB) void k_score_bf16(Score
             if (tile >= t1) break;
          }
          tile = nextFirst;
-         const float r0 = (rM[0] + LOG2(rS[0])) * 0.69314718055994531f, r1 = (rM[1] + LOG2(rS[1])) * 0.69314718055994531f;
-         const float res = (kg == 1) ? r1 : r0;
+         float res = 0.0f;
+#pragma unroll
+         for (int ft = 0; ft < B16_COL_TILES; ft++) {
+            const float r = (rM[ft] + LOG2(rS[ft])) * 0.69314718055994531f;
+            if (kg == ft) res = r;
+         }
          float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + fw;
-         if (active && lane < 32 && fw + lane < tk.nFrames) o[lane] = res;
+         if (active && lane < FPW && fw + lane < tk.nFrames) o[lane] = res;
       }
    }
 }
@@ -250,8 +256,9 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
    if (a.nTasks <= 0) return HTKAMD_OK;
    if (!m->d_bf16Tab) { htkamd_set_error("score_bf16: vector size %d not supported by the bf16 matrix-core path (up to 45)", m->D); return HTKAMD_EMODEL; }
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
-   int blocks = a.nTasks * (4 / B16_WPB);
-   if (blocks > 256 * (12 / B16_WPB)) blocks = 256 * (12 / B16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) or half-task at a time
+   const int parts = 128 / (16 * B16_COL_TILES * B16_WPB);
+   int blocks = a.nTasks * parts;
+   if (blocks > 256 * ((B16_COL_TILES > 2 ? 8 : 12) / B16_WPB)) blocks = 256 * ((B16_COL_TILES > 2 ? 8 : 12) / B16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) or half-task at a time
    dim3 grid(blocks), block(64 * B16_WPB);
    switch (m->bf16NC) {
    case 3: hipExtLaunchKernelGGL((k_score_bf16<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
