@@ -128,6 +128,7 @@ struct htkamd_fb {
    DevBuf d_utt, d_mN, d_mTp, d_mCell0, d_mSlot0, d_mDms, d_mHmm, d_mTrans, d_slotState, d_cQ, d_cI, d_taperLo, d_taperHi;
    DevBuf d_tasks, d_tasksW, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
+   DevBuf d_tmE, d_tmMaxP;                  // tied mixtures: the pool's per-frame table (kernels.h FbArgs::tmE)
    DevBuf d_slotStateU, d_outpU;            // several streams: element of every (stream, chain state), and their scores: stream k of utterance u at outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
    DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8 | left-to-right W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
@@ -175,7 +176,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    delete fb->pool; delete fb->chunks;
@@ -450,7 +451,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) {
             kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8;
             // every model left-to-right without skips: the kernels of fb_lr.hip (no statistics in the alpha chain, no entry-state columns)
-            bool lr = !fb->noLrPath && fb->m->NSt == 1;      // several streams: the dense seed array feeds k_mixstats_ms
+            bool lr = !fb->noLrPath && fb->m->NSt == 1 && !fb->m->tiedMix;      // several streams: the dense seed array feeds k_mixstats_ms
             for (int q = 0; q < d.Q && lr; q++) if (fb->m->h_transLR[fb->mTrans[d.q0 + q]] != 1) lr = false;
             if (lr) kind = 2;
          }
@@ -518,7 +519,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
        (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * ((beta && !wavePathPrep) ? beta : 1))) ||
        (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
        (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))) ||
-       (fb->m->NSt > 1 && (rc = fb->d_outpU.reserve(sizeof(float) * (outp * fb->m->NSt + 16)))))
+       (fb->m->NSt > 1 && (rc = fb->d_outpU.reserve(sizeof(float) * (outp * fb->m->NSt + 16)))) ||
+       (fb->m->tiedMix && ((rc = fb->d_tmE.reserve(sizeof(float) * (nf * fb->m->tmPool + 16))) || (rc = fb->d_tmMaxP.reserve(sizeof(float) * (nf * fb->m->NSt + 16))))))
       return rc;
    if (fb->debug && (rc = fb->d_alpha.reserve(sizeof(double) * (beta ? beta : 1)))) return rc;
    lap("reserve");
@@ -592,15 +594,24 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    // the batch tables may have been uploaded on another stream (htkamd_fb_prepare's): the kernels wait for that copy, not the host
    if (fb->copyPending) HIPCHECK(hipStreamWaitEvent(s, fb->evCopy, 0));
    HIPCHECK(hipEventRecord(fb->ev[0], s));
+   if (m->tiedMix) {
+      // hsKind TIEDHS: the pool once per frame, then every state's weighted sum of it (no other arithmetic mode exists for it)
+      fa.tmE = (float *)fb->d_tmE.p; fa.tmMaxP = (float *)fb->d_tmMaxP.p; fa.tmPoolOff = m->d_tmPoolOff; fa.tmPool = m->tmPool; fa.totalFrames = fb->totalFrames;
+      fa.tmTasks = (const ScoreTask *)fb->d_tasks.p; fa.tmNTasks = (int)fb->tasks.size(); fa.tmSlotState = sa.slotState; fa.tmOut = sa.out;
+      fa.compWeight = m->d_compWeight; fa.var = m->d_var;
+      if ((rc = htkamd_launch_tm_score(fa, s))) return rc;
+      fb->scored = false;
+   } else {
    if ((rc = htkamd_launch_score(cfg->scoreMode, m, sa, s, fb->evK[0], fb->evK[1]))) return rc;
    fb->scored = sa.nTasks > 0;
+   }
    if (m->NSt > 1) {
       // Setotprob for S > 1 (HFB.c:1057-1066): the state's log probability is the float sum of its streams' in stream order.  The
       // recursions then see a state with "two components" whatever its streams hold (they only ask whether it is a single Gaussian,
       // for the seed they leave to the mixture statistics)
       if ((rc = htkamd_launch_combine_streams(fa, s))) return rc;
       if (m->maxM > 1) fa.stateCompOff = m->d_msCompOff;
-   }
+   } else if (m->tiedMix) fa.stateCompOff = m->d_msCompOff;
    HIPCHECK(hipEventRecord(fb->ev[1], s));
    const int nGeneral = fb->clsOff[5] - fb->clsOff[4];
    fb->lastWave = nGeneral == 0;
@@ -661,7 +672,8 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          fa.rec = (MixRec *)fb->d_rec.p; fa.recSorted = (MixRec *)fb->d_recSorted.p; fa.recCap = (int)cap; fa.G = m->G; fa.recCtl = (int *)fb->d_recCtl.p;
       }
       // the dense seed array serves the utterances off the left-to-right path; those on it list their pairs (k_stats_lr -> k_mixhits)
-      if (m->NSt > 1) { fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr; if ((rc = htkamd_launch_mixstats_ms(fa, s))) return rc; }
+      if (m->tiedMix) { fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr; if ((rc = htkamd_launch_mixstats_tm(fa, s))) return rc; }
+      else if (m->NSt > 1) { fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr; if ((rc = htkamd_launch_mixstats_ms(fa, s))) return rc; }
       else if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
    }
    HIPCHECK(hipEventRecord(fb->ev[5], s));

@@ -1179,3 +1179,183 @@ int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s)
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }
+
+// ---- tied mixtures (hsKind TIEDHS) ------------------------------------------------------------------------------------------
+// PrecomputeTMix (HModel.c:5308-5346, called with tmThresh = minFrwdP and topM = 0 from HFB.c:1011,1781): per frame and stream the log
+// probability of every pool Gaussian (MOutP -> DOutP: the set keeps its variances), their maximum, and for those within tmThresh of
+// it exp(p - max); the others are out (marked -1 here: the reference stops at the first of them in its sorted list).
+// One workgroup per (frame, stream), thread = pool Gaussian.
+__global__ __launch_bounds__(256) void k_tm_pool(FbArgs a)
+{
+   __shared__ float red[256];
+   const int row = blockIdx.x, ks = blockIdx.y, D = a.D;
+   const int p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
+   const int c0 = a.stateCompOff[ks];                         // the pool of stream ks, as state 0 lists it
+   const float *x = a.X + (size_t)row * D;
+   float mx = (float)LZERO;
+   for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      const int g = a.compGauss[c0 + m];
+      const float *mean = a.mean + (size_t)g * D, *var = a.var + (size_t)g * D;
+      float sum = a.gparam[(size_t)g * a.PS + 2 * D];           // gConst
+      for (int k = 0; k < D; k++) {
+         if (a.dimStream && a.dimStream[k] != ks) continue;
+         const float xmm = x[k] - mean[k];
+         sum += xmm * xmm / var[k];
+      }
+      const float p = -0.5f * sum;
+      a.tmE[(size_t)row * a.tmPool + p0 + m] = p;
+      mx = p > mx ? p : mx;
+   }
+   red[threadIdx.x] = mx;
+   __syncthreads();
+   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+   const float maxP = red[0];
+   const float minP = maxP - a.minFrwdP;
+   if (threadIdx.x == 0) a.tmMaxP[(size_t)row * a.NSt + ks] = maxP;
+   for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      float *e = a.tmE + (size_t)row * a.tmPool + p0 + m;
+      const float p = *e;
+      if (p < minP) *e = -1.0f;
+      else { const float dp = p - maxP; *e = ((double)dp < MINEARG) ? 0.0f : (float)exp((double)dp); }
+   }
+}
+
+// SOutP, TIEDHS (HModel.c:5555-5566): sum over the kept pool entries of (scaled probability x weight), float products summed in
+// double, log + maximum.  (The reference adds them in the order of its sorted list; the order here is the pool's: the double sum can
+// differ in its last bit.)  One workgroup per scoring task, thread = frame of the tile.
+__global__ __launch_bounds__(SCORE_TILE_FRAMES) void k_tm_state(FbArgs a)
+{
+   for (int task = blockIdx.x; task < a.tmNTasks; task += gridDim.x) {
+      const ScoreTask tk = a.tmTasks[task];
+      const int f = threadIdx.x;
+      if (f >= tk.nFrames) continue;
+      const size_t row = (size_t)tk.frame0 + f;
+      for (int k = 0; k < tk.nSlots; k++) {
+         const int e = a.tmSlotState[tk.slot0 + k], ks = e % a.NSt;
+         const int c0 = a.stateCompOff[e], p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
+         const float *E = a.tmE + row * a.tmPool + p0, *w = a.compWeight + c0;
+         double sum = 0.0;
+         for (int m = 0; m < M; m++) {
+            const float ev = E[m];
+            if (ev >= 0.0f) sum += (double)(ev * w[m]);
+         }
+         const float xs = (sum >= MINLARG) ? (float)(log(sum) + (double)a.tmMaxP[row * a.NSt + ks]) : (float)LZERO;
+         a.tmOut[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + f] = xs;
+      }
+   }
+}
+
+int htkamd_launch_tm_score(const FbArgs &a, hipStream_t s)
+{
+   if (a.totalFrames <= 0 || a.tmNTasks <= 0) return HTKAMD_OK;
+   hipLaunchKernelGGL(k_tm_pool, dim3((unsigned)a.totalFrames, (unsigned)a.NSt), dim3(256), 0, s, a);
+   hipLaunchKernelGGL(k_tm_state, dim3((unsigned)(a.tmNTasks < 65535 ? a.tmNTasks : 65535)), dim3(SCORE_TILE_FRAMES), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+// UpMixParms, TIEDHS (HFB.c:1503-1507, 1559-1563, 1590-1612): the kept pool entries of the frame; a component's log probability is
+// log(scaled probability) + maximum, as the reference recovers it from the table PrecomputeTMix left
+__global__ __launch_bounds__(256) void k_mixstats_tm(FbArgs a)
+{
+   __shared__ unsigned short hitIdx[4][512];
+   __shared__ double hitSeed[4][512];
+   const int lane = threadIdx.x & 63;
+   const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+   const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const int D = a.D, NSt = a.NSt;
+   const double minF = (double)a.minFrwdP;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
+      volatile unsigned short *hIdx = hitIdx[threadIdx.x >> 6];
+      volatile double *hSeed = hitSeed[threadIdx.x >> 6];
+      int count = 0;
+      for (int r = 0; r < 8; r++) {
+         const size_t idx = base0 + (size_t)r * 64 + lane;
+         const double v = (idx < a.gamTotal) ? a.gam[idx] : LZERO;
+         const unsigned long long hm = __ballot(v > LSMALL);
+         if (v > LSMALL) {
+            const int pos = count + __popcll(hm & ((1ull << lane) - 1));
+            hIdx[pos] = (unsigned short)(r * 64 + lane); hSeed[pos] = v;
+         }
+         count += __popcll(hm);
+      }
+      int u = a.gamChunkUtt[base0 >> 9];
+      for (int i = 0; i < count; i++) {
+         const size_t hidx = base0 + hIdx[i];
+         const double seed = hSeed[i];
+         while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
+         const UttDesc *up = a.utt + u;
+         if (a.status[u] != HTKAMD_UTT_OK) continue;
+         const int nSl = up->nSlots, T = up->T;
+         const size_t rel = hidx - up->gam0;
+         const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
+         const int e0 = a.slotState[up->slot0 + slot];
+         const size_t row = (size_t)up->frame0 + t0;
+         const float *xrow = a.X + row * D;
+         const float oS = a.outp[up->outp0 + (size_t)slot * T + t0];
+         for (int ks = 0; ks < NSt; ks++) {
+            const int e = e0 + ks, c0 = a.stateCompOff[e], p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
+            const float maxP = a.tmMaxP[row * NSt + ks];
+            float others = 0.0f;
+            if (NSt > 1) others = oS - a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
+            for (int mb = 0; mb < M; mb += 64) {
+               const int m = mb + lane;
+               bool pass = false;
+               double Lr = 0.0;
+               int g = 0;
+               if (m < M) {
+                  const float ev = a.tmE[row * a.tmPool + p0 + m];
+                  const float wt = a.compLogWt[c0 + m];
+                  g = a.compGauss[c0 + m];
+                  if (ev >= 0.0f && wt > (float)LMINMIX) {
+                     const float prob = ((double)ev >= MINLARG) ? (float)(log((double)ev) + (double)maxP) : (float)LZERO;
+                     double x = seed + (double)wt;
+                     x += (double)prob;
+                     if (NSt > 1) x += (double)others;
+                     if (-x < minF) { pass = true; Lr = exp(x); }
+                  }
+               }
+               double sumLr = pass ? Lr : 0.0;
+#pragma unroll
+               for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
+               if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + e, sumLr);
+               if (pass) {
+                  if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+                  if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+                  if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+               }
+               unsigned long long pm = __ballot(pass);
+               while (pm) {
+                  const int ml = __ffsll((long long)pm) - 1;
+                  pm &= pm - 1;
+                  const double L = __shfl(Lr, ml);
+                  const int gg = __shfl(g, ml);
+                  const float *mean = a.mean + (size_t)gg * D;
+                  for (int k = lane; k < D; k += 64) {
+                     if (a.dimStream && a.dimStream[k] != ks) continue;
+                     const float z = xrow[k] - mean[k];
+                     if (upMu && upVa) {
+                        const float zl = (float)((double)z * L);
+                        atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+                        atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
+                     } else if (upMu) atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
+                     else if (upVa) atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
+                  }
+               }
+            }
+         }
+      }
+   }
+}
+
+int htkamd_launch_mixstats_tm(const FbArgs &a, hipStream_t s)
+{
+   if (a.gamTotal == 0) return HTKAMD_OK;
+   size_t waves = (a.gamTotal + 511) / 512;
+   size_t blocks = (waves + 3) / 4;
+   if (blocks > 8192) blocks = 8192;
+   hipLaunchKernelGGL(k_mixstats_tm, dim3((unsigned)blocks), dim3(256), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}

@@ -125,6 +125,14 @@ struct FbArgs {
    int NSt;
    const float *outpU;               // stream k of utterance u: outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
    const int *dimStream;
+   // tied mixtures (model tiedMix): per frame of the batch the pool's scaled probabilities (-1 = pruned by PrecomputeTMix) and their
+   // maximum per stream; the pool-to-state kernel's task list and rows
+   float *tmE;                       // [totalFrames][tmPool]
+   float *tmMaxP;                    // [totalFrames][NSt]
+   const int *tmPoolOff;             // [NSt + 1]
+   int tmPool, totalFrames;
+   const ScoreTask *tmTasks; int tmNTasks; const int *tmSlotState; float *tmOut;
+   const float *compWeight, *var;    // linear weights, variances
    MixHit *hits;                     // region r (one per wavefront of k_stats_lr, numbered like the rows of trPart): hits[r * hitRegionCap ...]
    int *hitCtl;                      // [r] records in region r
    int nHitRegions, hitRegionCap;
@@ -136,6 +144,9 @@ int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s, bool dense, bool list
 // several streams: outp = sum over streams of outpU; UpMixParms per stream from the dense seed array
 int htkamd_launch_combine_streams(const FbArgs &a, hipStream_t s);
 int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s);
+// tied mixtures: PrecomputeTMix for every frame, SOutP for every (row, frame) of the task list, UpMixParms' TIEDHS branch
+int htkamd_launch_tm_score(const FbArgs &a, hipStream_t s);
+int htkamd_launch_mixstats_tm(const FbArgs &a, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
 // state-per-lane fast path (fb_state.hip): chains of <= 512 emitting states, models of <= 5 states, no tee models
 int htkamd_launch_beta_s(const FbArgs &a, int W, bool fast, hipStream_t s);

@@ -305,10 +305,24 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
        (rc = model_refresh(m))) {
       htkamd_model_destroy(m); return rc;
    }
-   if (NSt > 1) {
+   if (d->hsKind == HTKAMD_HS_TIED) {
+      m->tiedMix = 1;
+      m->h_tmPoolOff = (int *)calloc((size_t)NSt + 1, sizeof(int));
+      for (int k = 0; k < NSt; k++) m->h_tmPoolOff[k + 1] = m->h_tmPoolOff[k] + (m->h_stateCompOff[k + 1] - m->h_stateCompOff[k]);
+      m->tmPool = m->h_tmPoolOff[NSt];
+      for (int e = 0; e < m->S; e++) {
+         const int k = e % NSt, c0 = m->h_stateCompOff[e], M = m->h_stateCompOff[e + 1] - c0, p0 = m->h_stateCompOff[k];
+         bool same = M == m->h_stateCompOff[k + 1] - p0;
+         for (int i = 0; same && i < M; i++) same = m->h_compGauss[c0 + i] == m->h_compGauss[p0 + i];
+         if (!same) { htkamd_set_error("model_create: tied-mixture set: stream %d of state %d does not list its stream's pool", k + 1, e / NSt); htkamd_model_destroy(m); return HTKAMD_EINVAL; }
+         if (M < 2) { htkamd_set_error("model_create: tied-mixture set: a pool of one Gaussian"); htkamd_model_destroy(m); return HTKAMD_EINVAL; }
+      }
+      if ((rc = toDevice(&m->d_tmPoolOff, m->h_tmPoolOff, (size_t)NSt + 1)) || (rc = htkamd_model_device_tables(m))) { htkamd_model_destroy(m); return rc; }
+   }
+   if (NSt > 1 || m->tiedMix) {
       std::vector<int> two((size_t)m->S + 1);
       for (int e = 0; e <= m->S; e++) two[e] = 2 * e;
-      if ((rc = toDevice(&m->d_dimStream, m->h_dimStream, (size_t)m->D)) || (rc = toDevice(&m->d_gaussStream, m->h_gaussStream, (size_t)m->G)) ||
+      if ((NSt > 1 && ((rc = toDevice(&m->d_dimStream, m->h_dimStream, (size_t)m->D)) || (rc = toDevice(&m->d_gaussStream, m->h_gaussStream, (size_t)m->G)))) ||
           (rc = toDevice(&m->d_msCompOff, two.data(), (size_t)m->S + 1))) { htkamd_model_destroy(m); return rc; }
    }
    {
@@ -337,6 +351,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
    free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize); (void)hipFree(m->d_shareTab);
+   free(m->h_tmPoolOff); (void)hipFree(m->d_tmPoolOff);
    free(m->h_dimStream); free(m->h_gaussStream); (void)hipFree(m->d_dimStream); (void)hipFree(m->d_gaussStream); (void)hipFree(m->d_msCompOff);
    free(m);
 }

@@ -374,7 +374,7 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    a.ivar = m->d_ivar; a.gparam = m->d_gparam; a.compLogWt = m->d_compLogWt;
    a.acc = accs->d_vec; a.lay = accs->lay;
    a.dimStream = m->NSt > 1 ? m->d_dimStream : nullptr; a.gaussStream = m->NSt > 1 ? m->d_gaussStream : nullptr;
-   a.minEgs = cfg->minEgs; a.uFlags = cfg->uFlags; a.singleProcess = cfg->singleProcess; a.rowNormalise = cfg->rowNormalise;
+   a.minEgs = cfg->minEgs; a.uFlags = cfg->uFlags; a.singleProcess = m->tiedMix ? 0 : cfg->singleProcess; a.rowNormalise = cfg->rowNormalise;
    a.minVar = cfg->minVar; a.mixWeightFloor = cfg->mixWeightFloor; a.logTpi = log(HTK_TPI);
    a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G; a.flooredG = a.anyG + m->G;
    a.stats = (int *)(fl + ((nFlag + 63) & ~(size_t)63));
@@ -400,6 +400,9 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    hipLaunchKernelGGL(k_upd_mark, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
    hipLaunchKernelGGL(k_upd_trans, dim3((m->nT + B - 1) / B), dim3(B), 0, s, a);
    hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
+   // a tied-mixture set's pool is re-estimated once per set, whatever the models' example counts and the components' weights
+   // (MLUpdateModels HERest.c:1272-1279: UpdateTMVars / UpdateTMMeans / FixAllGConsts)
+   if (m->tiedMix) HIPCHECK(hipMemsetAsync(a.qualG, 1, (size_t)m->G, s));
    {
       const size_t nEl = (size_t)m->G * m->D;
       if (nEl >= ((size_t)1 << 31)) { htkamd_set_error("model_update_device: %zu mean / variance elements (the element kernel indexes with 32 bits)", nEl); return HTKAMD_EMODEL; }

@@ -159,6 +159,7 @@ static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_ac
             const int e = s * NS + ks;
             for (c = d->stateCompOff[e]; c < d->stateCompOff[e + 1]; c++) IO(lay->wt + c);
             IO(lay->wtOcc + e);
+            if (d->hsKind == HTKAMD_HS_TIED) continue;   /* tied mixtures: the pool's MuAcc / VaAcc follow the last model (below) */
             for (c = d->stateCompOff[e]; c < d->stateCompOff[e + 1]; c++) {
                const int g = d->compGauss[c], gm = MLD(g), gv = VLD(g);
                if (seenG[g]) continue;              /* a shared mixture pdf (~m) */
@@ -177,6 +178,18 @@ static int acc_walk(FILE *f, int wr, const htkamd_model_desc *d, const htkamd_ac
       }
       if (wr) put_i(f, 123456);
       else { int mark; if (!get_be32(f, &mark) || mark != 123456) { htkamd_set_error("accs_load_file: %s: marker missing after \"%s\"", path, names[h]); rc = HTKAMD_EINVAL; goto bad2; } }
+   }
+   if (d->hsKind == HTKAMD_HS_TIED) {           /* DumpAccs / LoadAccs, TIEDHS tail (HTrain.c:1493-1501,1675-1684): MuAcc then VaAcc of every pool
+                                                   Gaussian, stream by stream, whatever the update flags say */
+      int ks;
+      for (ks = 0; ks < NS; ks++)
+         for (c = d->stateCompOff[ks]; c < d->stateCompOff[ks + 1]; c++) {      /* the pool as state 0 lists it */
+            const int g = d->compGauss[c];
+            for (i = 0; i < D; i++) if (NS == 1 || d->dimStream[i] == ks) IO(lay->mu + (size_t)g * D + i);
+            IO(lay->muOcc + g);
+            for (i = 0; i < D; i++) if (NS == 1 || d->dimStream[i] == ks) IO(lay->va + (size_t)g * D + i);
+            IO(lay->vaOcc + g);
+         }
    }
    if (wr) { put_f(f, vec[lay->totalPr]); put_i(f, (int)(vec[lay->totalT] + 0.5)); }
    else { int tt; if (!get_be32(f, &x) || !get_be32(f, &tt)) { rc = HTKAMD_EINVAL; goto bad; } vec[lay->totalPr] += (double)x; vec[lay->totalT] += tt; }

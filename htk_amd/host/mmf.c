@@ -46,6 +46,9 @@ struct htkamd_mmf {
    /* desc arrays */
    htkamd_model_desc d; int *stateCompOff, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
    int *gStr;                                                       /* stream of Gaussian g */
+   int tiedMix;                                                     /* hsKind TIEDHS: <TMIX> streams (GetStream HModel.c:1878-1892) */
+   char *tmName[8]; int tmM[8];                                     /* per stream: generic ~m macro name and pool size (tmRecs[s].mixId / nMix) */
+   int *gPend; int capPend, lastVecN;                                         /* a ~m macro of a multi-stream set read before its stream is known: its width, values at [0..width) of the row */
    int finished, nFiles;
 };
 
@@ -231,7 +234,7 @@ static int parse_options(struct htkamd_mmf *s, rd *r)
          if (s->kind[0] && strcmp(s->kind, t)) return fail(r, "inconsistent parameter kind");
          snprintf(s->kind, sizeof(s->kind), "%.63s", t);
       } else if (!strcmp(t, "PROJSIZE") || !strcmp(t, "INPUTXFORM") || !strcmp(t, "PARENTXFORM") || !strcmp(t, "MSDINFO") ||
-                 !strcmp(t, "DISCRETE") || !strcmp(t, "TMIX") || !strcmp(t, "DPROB")) {
+                 !strcmp(t, "DISCRETE") || !strcmp(t, "DPROB")) {
          return fail(r, "unsupported global option");
       } else { rd_push(r); return HTKAMD_OK; }      /* structural keyword: the caller's business */
       s->hasOpts = 1;
@@ -260,6 +263,13 @@ static int parse_vector_ms(struct htkamd_mmf *s, rd *r, float *dst, int stream, 
 {
    int n, rc;
    if ((rc = rd_int(r, &n))) return rc;
+   if (s->nStreams > 1 && stream == -1) {               /* a ~m macro defined outside any state: its stream is known when it is first used */
+      if (s->vecSize == 0) return fail(r, "<VECSIZE> must precede the first vector");
+      if (n < 1 || n > s->vecSize) return fail(r, "vector size");
+      for (int i = 0; i < s->vecSize; i++) { if (i >= n) { dst[i] = fill; continue; } if ((rc = rd_float(r, dst + i))) return rc; }
+      s->lastVecN = n;
+      return HTKAMD_OK;
+   }
    if (s->nStreams > 1) {
       if ((rc = need_stream_dims(s, r))) return rc;
       if (stream < 0 || stream >= s->nStreams) return fail(r, "vector outside a stream");
@@ -331,16 +341,50 @@ static int parse_shared_vector(struct htkamd_mmf *s, rd *r, int k, char type, co
    return parse_vector_ms(s, r, dst, s->curStream, type == 'u' ? 0.0f : INFINITY);
 }
 
+static void pend_set(struct htkamd_mmf *s, int g, int v)
+{
+   if (g + 1 > s->capPend) {
+      const int nc = (g + 1) * 2 + 16;
+      s->gPend = (int *)realloc(s->gPend, sizeof(int) * (size_t)nc);
+      for (int i = s->capPend; i < nc; i++) s->gPend[i] = 0;
+      s->capPend = nc;
+   }
+   s->gPend[g] = v;
+}
+/* A ~m macro of a multi-stream set is used by stream `stream`: its vectors move to that stream's dimensions of the undivided row (first
+   use), or it must have been used by the same stream before. */
+static int resolve_stream(struct htkamd_mmf *s, rd *r, int g, int stream)
+{
+   if (s->nStreams <= 1) return HTKAMD_OK;
+   const int pend = (g < s->capPend) ? s->gPend[g] : 0;
+   if (pend < 0) return (-pend - 1 == stream) ? HTKAMD_OK : fail(r, "a ~m macro is used by two streams");
+   if (pend == 0) return fail(r, "a ~m macro defined inside a stream cannot be shared here");
+   int rc;
+   if ((rc = need_stream_dims(s, r))) return rc;
+   if (pend != s->swidth[stream]) return fail(r, "~m macro: vector size differs from the stream's width");
+   const int D = s->vecSize;
+   float *tmp = (float *)malloc(sizeof(float) * (size_t)pend);
+   for (int pass = 0; pass < 2; pass++) {
+      float *row = (pass ? s->var : s->mean) + (size_t)g * D;
+      memcpy(tmp, row, sizeof(float) * (size_t)pend);
+      int j = 0;
+      for (int i = 0; i < D; i++) row[i] = (s->dimStream[i] == stream) ? tmp[j++] : (pass ? INFINITY : 0.0f);
+   }
+   free(tmp);
+   pend_set(s, g, -(stream + 1));
+   return HTKAMD_OK;
+}
+
 static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
 {
    int rc, k = rd_next(r);
    if (k == T_MACRO && r->tok[0] == 'm') {               /* reference to a shared mixture pdf */
       char *nm;
-      if (s->nStreams > 1) return fail(r, "~m macros in a multi-stream set are not supported");
       if ((rc = rd_name(r, &nm))) return rc;
       const int g = find_gauss(s, nm);
       if (g < 0) { rc = fail(r, "undefined ~m macro"); free(nm); return rc; }
       free(nm);
+      if ((rc = resolve_stream(s, r, g, s->curStream))) return rc;
       *gOut = g;
       return HTKAMD_OK;
    }
@@ -404,7 +448,44 @@ static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
       seen[stream] = 1;
       s->curStream = stream;
       const int cs = c0 + off[stream], Ms = nMixS[stream];
-      if (k == T_KEY && (!strcmp(r->tok, "TMIX") || !strcmp(r->tok, "DPROB"))) { free(sw); return fail(r, "tied-mixture / discrete streams are not supported"); }
+      if (k == T_KEY && !strcmp(r->tok, "DPROB")) { free(sw); return fail(r, "discrete streams are not supported"); }
+      if (k == T_KEY && !strcmp(r->tok, "TMIX")) {
+         /* GetTiedMixtures (HModel.c:991): the generic macro name; the pool is ~m "name1" .. "nameM"; then the compact weights */
+         if (rd_next(r) != T_WORD) { free(sw); return fail(r, "tied mix macro name expected"); }
+         if (!s->tmName[stream]) {
+            s->tmName[stream] = strdup(r->tok); s->tmM[stream] = Ms;
+         } else if (strcmp(s->tmName[stream], r->tok)) { free(sw); return fail(r, "bad generic ~m macro name in <TMIX>"); }
+         else if (s->tmM[stream] != Ms) { free(sw); return fail(r, "inconsistent number of mixtures in <TMIX>"); }
+         s->tiedMix = 1;
+         for (int m = 0; m < Ms; m++) {
+            char nm[320];
+            snprintf(nm, sizeof(nm), "%s%d", s->tmName[stream], m + 1);
+            const int g = find_gauss(s, nm);
+            if (g < 0) { free(sw); return fail(r, "unknown tied mix macro (~m name<m>)"); }
+            if ((rc = resolve_stream(s, r, g, stream))) { free(sw); return rc; }
+            s->cg[cs + m] = g;
+         }
+         {  /* GetTiedWeights (HModel.c:882): a weight may be followed by *n (text) or come as weight - 2 with a count byte (binary) */
+            float wv = 0.0f; int rep = 0;
+            for (int m = 0; m < Ms; m++) {
+               if (rep > 0) --rep;
+               else if (r->bin) {
+                  if ((rc = rd_float(r, &wv))) { free(sw); return rc; }
+                  if (wv < 0.0f) { const int cnt = getc_unlocked(r->f); if (cnt == EOF) { free(sw); return fail(r, "repeat count expected"); } rep = cnt - 1; wv = wv + 2.0f; }
+               } else {
+                  if (rd_next(r) != T_WORD) { free(sw); return fail(r, "tied weight expected"); }
+                  char *star = strchr(r->tok, '*'), *e;
+                  if (star) { *star = 0; rep = (int)strtol(star + 1, &e, 10) - 1; if (*e || rep < 0) { free(sw); return fail(r, "repeat count expected"); } }
+                  if (!fast_float(r->tok, &wv)) { wv = strtof(r->tok, &e); if (*e) { free(sw); return fail(r, "tied weight expected"); } }
+               }
+               s->wt[cs + m] = wv;
+            }
+         }
+         k = rd_next(r);
+         if (!(k == T_KEY && !strcmp(r->tok, "STREAM"))) { rd_push(r); break; }
+         continue;
+      }
+      if (s->tiedMix) { free(sw); return fail(r, "a tied-mixture set (<TMIX>) cannot hold ordinary mixtures"); }
       if (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
          while (k == T_KEY && !strcmp(r->tok, "MIXTURE")) {
             int m; float w;
@@ -597,7 +678,11 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
       } else if (type == 'm') {
          int g;
          if (find_gauss(s, name) >= 0) { rc = fail(&r, "~m macro defined twice"); free(name); break; }
-         if ((rc = parse_mixpdf(s, &r, &g))) { free(name); break; }
+         if (s->nStreams > 1) s->curStream = -1;           /* stream not known yet: resolve_stream */
+         rc = parse_mixpdf(s, &r, &g);
+         s->curStream = 0;
+         if (rc) { free(name); break; }
+         if (s->nStreams > 1) pend_set(s, g, s->lastVecN);
          gname_set(s, g, name);
       } else if (type == 'v' || type == 'u') {
          const char *key = (type == 'v') ? "VARIANCE" : "MEAN";
@@ -690,6 +775,23 @@ int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir
       }
    }
    s->stateCompOff[(size_t)s->nSt * NS] = s->nComp;
+   if (NS > 1)                                         /* a ~m macro nobody used: the first stream of its width */
+      for (int g = 0; g < s->nG && g < s->capPend; g++)
+         if (s->gPend[g] > 0) {
+            int k, hit = -1;
+            for (k = 0; k < NS; k++) if (s->swidth[k] == s->gPend[g]) { hit = k; break; }
+            if (hit < 0) { htkamd_set_error("mmf_finish: a ~m macro of width %d fits no stream", s->gPend[g]); return HTKAMD_EMODEL; }
+            const int D = s->vecSize, n = s->gPend[g];
+            float *tmp = (float *)malloc(sizeof(float) * (size_t)n);
+            for (int pass = 0; pass < 2; pass++) {
+               float *row = (pass ? s->var : s->mean) + (size_t)g * D;
+               memcpy(tmp, row, sizeof(float) * (size_t)n);
+               int j = 0;
+               for (int i = 0; i < D; i++) row[i] = (s->dimStream[i] == hit) ? tmp[j++] : (pass ? INFINITY : 0.0f);
+            }
+            free(tmp);
+            s->gPend[g] = -(hit + 1); s->gStr[g] = hit;
+         }
    s->transN = (int *)malloc(sizeof(int) * (size_t)s->nTr);
    s->transOff = (int *)malloc(sizeof(int) * ((size_t)s->nTr + 1));
    for (int t = 0; t < s->nTr; t++) { s->transN[t] = s->tr[t].N; s->transOff[t] = s->tr[t].off; }
@@ -716,6 +818,7 @@ int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir
    d->transN = s->transN; d->transOff = s->transOff; d->transP = s->tp;
    d->hmmTrans = s->hmmTrans; d->hmmStateOff = s->hmmStateOff; d->hmmState = s->hmmState;
    d->numStreams = NS; d->dimStream = NS > 1 ? s->dimStream : NULL;
+   d->hsKind = s->tiedMix ? HTKAMD_HS_TIED : HTKAMD_HS_PLAIN;
    {  /* name index for htkamd_mmf_find_logical */
       g_sortNames = s->logName;
       s->logSorted = (int *)malloc(sizeof(int) * (size_t)(s->nLog ? s->nLog : 1));
@@ -767,7 +870,8 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
 {
    if (!s) return;
    for (int i = 0; i < s->nSt; i++) { free(s->st[i].name); free(s->st[i].sMix); free(s->st[i].sw); }
-   free(s->dimStream); free(s->gStr);
+   free(s->dimStream); free(s->gStr); free(s->gPend);
+   for (int i = 0; i < 8; i++) free(s->tmName[i]);
    for (int i = 0; i < s->nTr; i++) free(s->tr[i].name);
    for (int i = 0; i < s->nHm; i++) { free(s->hm[i].name); free(s->hm[i].state); }
    for (int i = 0; i < s->nLog; i++) free(s->logName[i]);
@@ -914,6 +1018,27 @@ static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *
    for (int k = 0; k < NS; k++) {
       const int M = NS > 1 ? st->sMix[k] : st->nMix;
       if (NS > 1) { put_sym(f, "STREAM", 18); put_short(f, k + 1); put_nl(f); }
+      if (s->tiedMix) {                                                   /* PutTiedMixtures / PutTiedWeights (HModel.c:2706,2620): runs of up to 256 equal weights */
+         put_sym(f, "TMIX", 16);
+         fprintf(f, " \"");
+         for (const char *p = s->tmName[k]; *p; p++) { if (*p == '"' || *p == '\\') fputc('\\', f); fputc(*p, f); }
+         fprintf(f, "\"");
+         put_nl(f);
+         for (int m = 0; m < M; ) {
+            int run = 1;
+            while (m + run < M && wt[c0 + m + run] == wt[c0 + m] && run < 256) run++;
+            if (g_bin) {
+               if (run > 1) { put_float(f, wt[c0 + m] - 2.0f); fputc(run, f); } else put_float(f, wt[c0 + m]);
+            } else {
+               put_float(f, wt[c0 + m]);
+               if (run > 1) fprintf(f, "*%d", run);
+            }
+            m += run;
+         }
+         put_nl(f);
+         c0 += M;
+         continue;
+      }
       for (int m = 0; m < M; m++) {
          const int c = c0 + m, g = s->cg[c];
          if (!(wt[c] > (float)MINMIX)) continue;                       /* PutStateInfo :3094 */

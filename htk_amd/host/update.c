@@ -66,7 +66,41 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
 #define ML(g) (mL ? mL[g] : (g))
 #define VL(g) (vL ? vL[g] : (g))
 #define ACCF(off, idx) ((float)acc[(off) + (size_t)(idx)])
-   if (cfg->singleProcess) {
+   if (m->tiedMix) {
+      /* hsKind TIEDHS (MLUpdateModels HERest.c:1272-1279): the pool is re-estimated ONCE per set, before the models are visited and
+         whatever their example counts -- UpdateTMVars (:1124-1195), UpdateTMMeans (:1014-1042), FixAllGConsts; a pool Gaussian has no
+         weight to test, its variance carries the mean-shift term whenever its mean has statistics */
+      int ks, g;
+      if (map) { htkamd_set_error("update_models: MAP re-estimation of a tied-mixture set is not supported"); free(doneT); free(doneS); free(doneMu); free(doneVa); free(pool); return HTKAMD_EMODEL; }
+      if (cfg->uFlags & HTKAMD_UPVARS)
+         for (ks = 0; ks < m->NSt; ks++)
+            for (c = m->h_stateCompOff[ks]; c < m->h_stateCompOff[ks + 1]; c++) {
+               g = m->h_compGauss[c];
+               const float occim = ACCF(lay->vaOcc, g), muOcc = ACCF(lay->muOcc, g);
+               int mixFloored = 0;
+               if (!(occim > 0.0)) continue;
+               const int shared = ((cfg->uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0);
+               for (k = 0; k < D; k++) {
+                  if (OUTSIDE(g, k)) continue;
+                  const float muDiffk = shared ? 0.0 : ACCF(lay->mu, (size_t)g * D + k) / muOcc;
+                  float x = ACCF(lay->va, (size_t)g * D + k) / occim - muDiffk * muDiffk;
+                  const float fl = cfg->varFloor ? cfg->varFloor[k] : cfg->minVar;
+                  if (x < fl) { x = fl; st->nFloorVar++; mixFloored = 1; }
+                  var[(size_t)g * D + k] = x;
+               }
+               if (mixFloored) st->nFloorVarMix++;
+            }
+      if (cfg->uFlags & HTKAMD_UPMEANS)
+         for (ks = 0; ks < m->NSt; ks++)
+            for (c = m->h_stateCompOff[ks]; c < m->h_stateCompOff[ks + 1]; c++) {
+               g = m->h_compGauss[c];
+               const float occim = ACCF(lay->muOcc, g);
+               if (occim > 0.0) for (k = 0; k < D; k++) { if (OUTSIDE(g, k)) continue; mean[(size_t)g * D + k] += ACCF(lay->mu, (size_t)g * D + k) / occim; }
+            }
+      if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))
+         for (g = 0; g < m->G; g++) htkamd_host_fix_diag_gconst_ms(D, var + (size_t)g * D, m->h_dimStream, m->h_gaussStream ? m->h_gaussStream[g] : 0, gconst + g);
+   }
+   if (cfg->singleProcess && !m->tiedMix) {             /* ConvDiagC / ConvLogWt leave a TIEDHS set alone (HUtil.c:419,478) */
       /* the conversions walk the set with an HMM scan: a state macro that no model uses keeps its values */
       unsigned char *usedS = (unsigned char *)calloc((size_t)m->S, 1), *usedG = (unsigned char *)calloc((size_t)m->G, 1);
       size_t z;
@@ -182,6 +216,7 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
             } else if (!map) st->nNoMixUse++;
             doneS[s] = 1;
          }
+      if (m->tiedMix) continue;                          /* the pool was done above */
       if (cfg->uFlags & HTKAMD_UPVARS)
          for (j = 0; j < nHs; j++) {
             const int s = hs[j];

@@ -93,7 +93,13 @@ typedef struct {
       dimension contributes nothing to a score and is never re-estimated); the feature rows stay undivided as well. */
    int numStreams;
    const int   *dimStream;    /* [D] stream (0-based) of each dimension, NULL for one stream (htkamd_mmf computes it from the kind) */
+   /* HTKAMD_HS_TIED: a tied-mixture set (hsKind TIEDHS, <TMIX>): every (state, stream) lists the SAME pool of Gaussians of its stream
+      (compGauss equal across states) with its own weights; output probabilities and statistics go through the pool's top-M arithmetic
+      (PrecomputeTMix HModel.c:5308, SOutP :5555, UpMixParms HFB.c:1524-1600), the pool is re-estimated once per set (HERest.c:1272). */
+   int hsKind;
 } htkamd_model_desc;
+#define HTKAMD_HS_PLAIN 0
+#define HTKAMD_HS_TIED  1
 
 typedef struct htkamd_model htkamd_model;
 

@@ -315,6 +315,8 @@ typedef struct {
    int *lastT;        /* [S*NSt] wa->time */
    float **lastVec;   /* [S*NSt] wa->prob */
    float **blocks; int nBlocks, capBlocks; size_t blockUsed;
+   /* tied mixtures: tmRecs[s] of the current frame -- probs (index, prob) sorted by prob, topM, maxP (HModel.h TMixRec) */
+   int tmCap; int *tmIndex; float *tmProb; int *tmTopM; float *tmMaxP; int *tmOff;
 } fbws;
 
 #define SV_(t,q,j) (((size_t)(t) * w->nSlots + w->slotOff[q] + ((j) - 2)) * w->NSt)
@@ -364,11 +366,68 @@ static void set_beam_taper(fbws *w)
    }
 }
 
+typedef struct { int index; float prob; } tmprob;
+static int cmp_tm(const void *a, const void *b)      /* CmpTM HModel.c:5298 */
+{
+   if (((const tmprob *)b)->prob < ((const tmprob *)a)->prob) return -1;
+   if (((const tmprob *)b)->prob > ((const tmprob *)a)->prob) return +1;
+   return 0;
+}
+/* PrecomputeTMix (HModel.c:5308-5346) with topM == 0: the pool's log probabilities at frame t, sorted, those within tmThresh of the
+   best scaled by it and kept */
+static void precompute_tmix(fbws *w, int t)
+{
+   const orc_model *m = w->m;
+   const float *x = w->X + (size_t)(t - 1) * m->D;
+   const float tmThresh = w->cfg->minFrwdP;
+   int s, k;
+   for (s = 0; s < w->NSt; s++) {
+      const int c0 = m->stateCompOff[s], M = m->stateCompOff[s + 1] - c0;      /* the pool of stream s, as state 0 lists it */
+      tmprob *pr = (tmprob *)malloc(sizeof(tmprob) * (size_t)M);
+      float maxP = ORC_LZERO, minP, p;
+      int mm;
+      for (mm = 0; mm < M; mm++) {
+         const int g = m->compGauss[c0 + mm];
+         float sum = m->gconst[g], xmm;
+         for (k = 0; k < m->D; k++) {             /* MOutP -> DOutP (HModel.c:5347) on the stream's vector */
+            if (m->dimStream && m->dimStream[k] != s) continue;
+            xmm = x[k] - m->mean[(size_t)g * m->D + k];
+            sum += xmm * xmm / m->var[(size_t)g * m->D + k];
+         }
+         p = -0.5 * sum;
+         if (p > maxP) maxP = p;
+         pr[mm].prob = p; pr[mm].index = mm;
+      }
+      qsort(pr, (size_t)M, sizeof(tmprob), cmp_tm);
+      minP = maxP - tmThresh;
+      for (mm = 0; mm < M; mm++) {
+         if (pr[mm].prob < minP) break;
+         p = pr[mm].prob - maxP;
+         pr[mm].prob = (p < ORC_MINEARG) ? 0.0 : exp(p);
+      }
+      w->tmTopM[s] = mm; w->tmMaxP[s] = maxP;
+      for (mm = 0; mm < M; mm++) { w->tmIndex[w->tmOff[s] + mm] = pr[mm].index; w->tmProb[w->tmOff[s] + mm] = pr[mm].prob; }
+      free(pr);
+   }
+}
+/* SOutP, TIEDHS (HModel.c:5555-5566) for element e = state*NSt + stream */
+static float tm_soutp(const fbws *w, int e)
+{
+   const orc_model *m = w->m;
+   const int s = e % w->NSt, c0 = m->stateCompOff[e];
+   double sum = 0.0;
+   int mx;
+   for (mx = 0; mx < w->tmTopM[s]; mx++)
+      sum += w->tmProb[w->tmOff[s] + mx] * m->compWeight[c0 + w->tmIndex[w->tmOff[s] + mx]];
+   return (sum >= ORC_MINLARG) ? log(sum) + w->tmMaxP[s] : ORC_LZERO;
+}
+
 /* HFB.c:991-1080 Setotprob for PLAINHS/SHAREDHS, S==1: evaluates models qLo-1(if >1)..qHi */
 static void set_otprob(fbws *w, int t, int qHi, int qLo)
 {
    int q, j;
    const orc_model *m = w->m;
+   if (m->tiedMix) precompute_tmix(w, t);        /* HFB.c:1010 */
    if (qLo > 1) --qLo;
    for (q = qHi; q >= qLo; q--) {
       if (!w->opres[BP_(t, q)]) {
@@ -376,6 +435,17 @@ static void set_otprob(fbws *w, int t, int qHi, int qLo)
          for (j = 2; j < w->N[q]; j++) {
             int s = m->hmmState[m->hmmStateOff[h] + (j - 2)];
             float *o = w->outp + O_(t, q, j);
+            if (m->tiedMix) {                     /* HFB.c:1030-1040: SOutP per stream into fresh one-element vectors */
+               if (w->NSt > 1) {
+                  float **sv = w->sv + SV_(t, q, j), sum = 0.0;
+                  int ks;
+                  for (ks = 0; ks < w->NSt; ks++) { sv[ks] = sv_alloc(w, 1); sv[ks][0] = tm_soutp(w, s * w->NSt + ks); sum += sv[ks][0]; }
+                  o[0] = sum;
+                  for (ks = 0; ks < w->NSt; ks++) sv[ks][0] = sum - sv[ks][0];
+               } else o[0] = tm_soutp(w, s);
+               w->nEval++;
+               continue;
+            }
             if (w->NSt > 1) {                     /* HFB.c:1026-1066, PLAINHS / SHAREDHS with S > 1 */
                float **sv = w->sv + SV_(t, q, j), sum = 0.0;
                int ks, seenState = 0;
@@ -697,6 +767,61 @@ static void up_mix_parms(fbws *w, orc_accs *acc, int t, int q, const double *aqt
             }
          initx += bqt[j] - pr;
       }
+      if (m->tiedMix) {                           /* UpMixParms, TIEDHS: the non-pruned components of the pool (HFB.c:1503-1507,1559-1563,1597-1600) */
+         int ks;
+         for (ks = 0; ks < w->NSt; ks++) {
+            const int e = s * w->NSt + ks;
+            const float others = (w->NSt > 1) ? w->sv[SV_(t, q, j) + ks][0] : 0.0f;
+            c0 = m->stateCompOff[e];
+            steSumLr = 0.0;
+            for (mx = 0; mx < w->tmTopM[ks]; mx++) {
+               const int mi = w->tmIndex[w->tmOff[ks] + mx], c = c0 + mi, g = m->compGauss[c];
+               float tmp;
+               wght = orc_mix_log_weight(m->compWeight[c]);
+               if (wght > ORC_LMINMIX) {
+                  c_jm = wght;
+                  x = initx + c_jm;
+                  tmp = w->tmProb[w->tmOff[ks] + mx];
+                  prob = (tmp >= ORC_MINLARG) ? log(tmp) + w->tmMaxP[ks] : ORC_LZERO;
+                  x += prob;
+                  if (w->NSt > 1) x += others;
+                  if (-x < w->cfg->minFrwdP) {
+                     const float *mean = m->mean + (size_t)g * D;
+                     Lr = exp(x);
+                     steSumLr += Lr;
+                     if ((uF & ORC_UPMEANS) && (uF & ORC_UPVARS)) {
+                        float *mu_jm = acc->mu + (size_t)g * D, *var = acc->va + (size_t)g * D;
+                        acc->muOcc[g] += Lr;
+                        acc->vaOcc[g] += Lr;
+                        for (k = 0; k < D; k++) {
+                           if (m->dimStream && m->dimStream[k] != ks) continue;
+                           zmean = ot[k] - mean[k];
+                           zmeanlr = zmean * Lr;
+                           mu_jm[k] += zmeanlr;
+                           var[k] += zmean * zmeanlr;
+                        }
+                     } else if (uF & ORC_UPMEANS) {
+                        float *mu_jm = acc->mu + (size_t)g * D;
+                        acc->muOcc[g] += Lr;
+                        for (k = 0; k < D; k++) if (!m->dimStream || m->dimStream[k] == ks) mu_jm[k] += (ot[k] - mean[k]) * Lr;
+                     } else if (uF & ORC_UPVARS) {
+                        float *var = acc->va + (size_t)g * D;
+                        acc->vaOcc[g] += Lr;
+                        for (k = 0; k < D; k++) {
+                           if (m->dimStream && m->dimStream[k] != ks) continue;
+                           zmean = ot[k] - mean[k];
+                           var[k] += zmean * zmean * Lr;
+                        }
+                     }
+                     if (uF & ORC_UPMIXES)
+                        acc->wt[c] += Lr;
+                  }
+               }
+            }
+            acc->wtOcc[e] += steSumLr;
+         }
+         continue;
+      }
       if (w->NSt > 1) {                           /* the stream loop of UpMixParms (HFB.c:1499-1721) */
          int ks;
          for (ks = 0; ks < w->NSt; ks++) {
@@ -852,6 +977,13 @@ int orc_fb_utt(const orc_model *m, const orc_fbcfg *cfg, const float *X, int T,
    w->alphat = (double *)malloc((size_t)(Q + 2) * (w->maxN + 1) * sizeof(double));
    w->alphat1 = (double *)malloc((size_t)(Q + 2) * (w->maxN + 1) * sizeof(double));
    w->occt = (float *)malloc((w->maxN + 1) * sizeof(float));
+   if (m->tiedMix) {
+      int tot = 0, ks;
+      w->tmOff = (int *)calloc((size_t)w->NSt + 1, sizeof(int));
+      for (ks = 0; ks < w->NSt; ks++) { w->tmOff[ks] = tot; tot += m->stateCompOff[ks + 1] - m->stateCompOff[ks]; }
+      w->tmIndex = (int *)malloc(sizeof(int) * (size_t)tot); w->tmProb = (float *)malloc(sizeof(float) * (size_t)tot);
+      w->tmTopM = (int *)calloc((size_t)w->NSt, sizeof(int)); w->tmMaxP = (float *)calloc((size_t)w->NSt, sizeof(float));
+   }
    if (w->NSt > 1) {
       w->sv = (float **)calloc((size_t)(T + 1) * w->nSlots * w->NSt, sizeof(float *));
       w->lastT = (int *)malloc(sizeof(int) * (size_t)m->S * w->NSt);
@@ -899,6 +1031,7 @@ int orc_fb_utt(const orc_model *m, const orc_fbcfg *cfg, const float *X, int T,
    for (q = 1; q <= Q; q++)
       acc->nEgs[labs[q - 1]] += 1;
    for (t = 1; t <= T; t++) {
+      if (m->tiedMix) precompute_tmix(w, t);     /* StepForward HFB.c:1780 */
       if (t > 1) {
          int e = step_alpha(w, t, &start, &end, pr);
          if (e != 0) { rc = e; goto done; }
@@ -931,6 +1064,7 @@ done:
    free(w->beta); free(w->bpres); free(w->outp); free(w->opres);
    free(w->alphat); free(w->alphat1); free(w->occt);
    free(w->sv); free(w->lastT); free(w->lastVec);
+   free(w->tmOff); free(w->tmIndex); free(w->tmProb); free(w->tmTopM); free(w->tmMaxP);
    for (i = 0; i < w->nBlocks; i++) free(w->blocks[i]);
    free(w->blocks);
 done0:

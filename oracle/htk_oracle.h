@@ -59,6 +59,12 @@ typedef struct {
       (ExtractObservation HParm.c:2843).  wtOcc accumulators: [S*NSt]. */
    int NSt;
    const int   *dimStream;    /* [D] */
+   /* tied-mixture sets (hsKind TIEDHS, <TMIX>): every (state, stream) lists the pool of its stream (compGauss equal across states);
+      the arithmetic is PrecomputeTMix / SOutP's (HModel.c:5308,5555) and UpMixParms' TIEDHS branches (HFB.c:1524-1600): it needs the
+      LINEAR weights (tpdf) and the VARIANCES (the set stays DIAGC: ConvDiagC / ConvLogWt skip it, HUtil.c:419,478) */
+   int tiedMix;
+   const float *compWeight;   /* [C] linear weights */
+   const float *var;          /* [G*D] variances */
    int msIntended;            /* 0: Setotprob as the reference has it, with its second-visit branch (HFB.c:1044,1059); 1: every visit
                                  computes the first visit's values (what that branch equals for S = 3 only) */
 } orc_model;

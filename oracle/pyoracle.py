@@ -64,7 +64,7 @@ class CModel(C.Structure):
                 ("mean", C.c_void_p), ("ivar", C.c_void_p), ("gconst", C.c_void_p),
                 ("transN", C.c_void_p), ("transOff", C.c_void_p), ("transP", C.c_void_p),
                 ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p),
-                ("NSt", C.c_int), ("dimStream", C.c_void_p), ("msIntended", C.c_int)]
+                ("NSt", C.c_int), ("dimStream", C.c_void_p), ("tiedMix", C.c_int), ("compWeight", C.c_void_p), ("var", C.c_void_p), ("msIntended", C.c_int)]
 
 
 class CAccs(C.Structure):
@@ -102,6 +102,7 @@ class Model:
         self.NSt = int(pk.get("numStreams", 1) or 1)
         self.dimStream = np.ascontiguousarray(pk["dimStream"], np.int32) if self.NSt > 1 else None
         self.ms_intended = bool(ms_intended)
+        self.tiedMix = int(pk.get("hsKind", 0) or 0) == 1
         self.D = int(pk["vecSize"]); self.S = int(pk["numStates"]); self.C = int(pk["numComp"])
         self.G = int(pk["numGauss"]); self.nT = int(pk["numTrans"]); self.H = int(pk["numPhys"])
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -134,7 +135,7 @@ class Model:
                         _p(self.mean), _p(self.ivar), _p(self.gconst),
                         _p(self.transN), _p(self.transOff), _p(self.transP),
                         _p(self.hmmTrans), _p(self.hmmStateOff), _p(self.hmmState),
-                        self.NSt, _p(self.dimStream), int(self.ms_intended))
+                        self.NSt, _p(self.dimStream), int(self.tiedMix), _p(self.compWeight), _p(self.var), int(self.ms_intended))
 
     @property
     def maxN(self):

@@ -179,6 +179,23 @@ def test_herest_cli_mean_tied_across_models_follows_the_scan_order(tools, tmp_pa
 
 
 @pytest.mark.gpu
+def test_herest_cli_tied_mixture_pool_in_shared_form(tools, tmp_path):
+    """The tied-mixture pool WITHOUT `HK TIEDHS` (tests/golden/make_tmix_golden.py: ~m macros inside ordinary mixtures, hsKind SHAREDHS).
+    The reference's HERest mistreats such a set: ConvLogWt (HUtil.c:474-485) walks the mixtures with GoNextMix(noSkip = FALSE), which skips
+    a shared pdf after its first visit, so only the FIRST state's weights become logarithms and every other state's linear weights are
+    then read as log weights -- -59.47 per frame on this data.  This library scores the mixtures as written (-61.00, the value the
+    reference's own TIEDHS arithmetic gives to within its pruning, tiedhs.log); the test pins that number and that the run works."""
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    out = tmp_path / "next"; out.mkdir()
+    tm = os.path.join(DEMO, "hmm_tmix")
+    r = run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(tm, "newMacros"), "-M", str(out),
+             "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0, r.stderr
+    assert "average log prob per frame = -6.09970" in r.stdout and "-5.946912e+01" in open(os.path.join(tm, "herest.log")).read()
+    assert open(str(out / "newMacros")).read().count('~m "MIX_') == 8 + 15 * 8
+
+
+@pytest.mark.gpu
 def test_herest_cli_several_master_files_round_trip(tools, tmp_path):
     """The usual iteration `-H dir/macros -H dir/hmmdefs -M next`: the re-estimated macros go back to next/macros and next/hmmdefs as the
     reference's SaveHMMSet writes them (tests/golden/make_multimmf_golden.py: herest_macros / herest_hmmdefs from its HERest), and the

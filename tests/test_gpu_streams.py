@@ -159,6 +159,60 @@ def test_random_stream_sets(native, oracle, widths, single, seed, mode):
         _compare(acc.download(), _odict(oacc), 1e-4, "%s mode %d %s" % (widths, mode, path), pk["var"])
 
 
+TMIX = os.path.join(DEMO, "hmm_tmix")
+
+
+@pytest.mark.parametrize("path", ["state", "wave", "general"])
+@pytest.mark.parametrize("kind", ["tiedhs", "tiedhs3"])
+def test_tied_mixture_sets_against_oracle_and_reference(native, oracle, kind, path):
+    """hsKind TIEDHS on the device (k_tm_pool / k_tm_state / k_mixstats_tm): utterance log probabilities and accumulators against the
+    oracle (itself equal to the reference's accumulator file float for float: tests/test_streams.py) and against that file."""
+    mmf = native.Mmf(files=[os.path.join(TMIX, kind + "_newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    utts = su.demo_utterances(native, oracle, mmf)
+    model, fb, acc, pr, st = _run(native, pk, utts, path=path, prune=dict(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0))
+    assert (st == 1).all()
+    a = acc.download()
+    om, oacc, opr = _oracle_accs(oracle, pk, utts, prune=dict(pruneInit=2000.0), intended=False)
+    assert np.allclose(pr, opr, rtol=1e-7, atol=0), np.abs(pr / opr - 1).max()          # float scores: a last bit of the double sum's order
+    var = np.where(np.isfinite(pk["var"]), pk["var"], 0.0)
+    _compare(a, _odict(oacc), 1e-4, "%s %s vs oracle" % (kind, path), var)
+    lay = native.accs_layout(pk)
+    v = np.zeros(lay.total, np.float64)
+    native.accs_load_file(pk, v, list(mmf.phys_names), os.path.join(TMIX, kind + "_HER1.acc"))
+    _compare(a, {k: v[getattr(lay, k):getattr(lay, k) + a[k].size] for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc")}, 1e-4,
+             "%s %s vs the reference's accumulators" % (kind, path), var)
+    assert "average log prob per frame = %e" % (a["totalPr"] / a["totalT"]) in open(os.path.join(TMIX, kind + ".log")).read()
+
+
+@pytest.mark.parametrize("device_update", [False, True])
+@pytest.mark.parametrize("kind", ["tiedhs", "tiedhs3"])
+def test_tied_mixture_reestimated_model_equals_the_reference(native, oracle, tmp_path, kind, device_update):
+    mmf = native.Mmf(files=[os.path.join(TMIX, kind + "_newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    utts = su.demo_utterances(native, oracle, mmf)
+    model, fb, acc, pr, st = _run(native, pk, utts, prune=dict(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0))
+    kw = dict(minEgs=3, minVar=0.05, mixWeightFloor=3 * 1.0e-5)
+    stats = model.update_device(acc, **kw) if device_update else model.update(acc, acc.download()["vec"], **kw)
+    assert "Total %d floored variance elements in %d different mixes" % (stats["nFloorVar"], stats["nFloorVarMix"]) in open(os.path.join(TMIX, kind + ".log")).read()
+    out = str(tmp_path / "newMacros")
+    mmf.write(model.get_params(), one_file=out)
+    cli._mmf_close(cli._mmf_numbers(out), cli._mmf_numbers(os.path.join(TMIX, kind + "_after_herest")))
+
+
+def test_herest_cli_tied_mixtures(native, tmp_path):
+    tools = os.path.join(ROOT, "tools", "bin")
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    for kind in ("tiedhs", "tiedhs3"):
+        out = tmp_path / kind; out.mkdir()
+        r = cli.run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(TMIX, kind + "_newMacros"),
+                     "-M", str(out), "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
+        assert r.returncode == 0, r.stderr
+        for line in open(os.path.join(TMIX, kind + ".log")).read().splitlines():
+            assert line in r.stdout, (line, r.stdout[-400:])
+        cli._mmf_close(cli._mmf_numbers(str(out / (kind + "_newMacros"))), cli._mmf_numbers(os.path.join(TMIX, kind + "_after_herest")))
+
+
 def test_streams_are_refused_where_they_are_not_served(native):
     mmf = native.Mmf(files=[os.path.join(DEMO, "hmm_streams3", "newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
     model = native.Model(mmf.packed())

@@ -98,3 +98,56 @@ def test_oracle_streams_equal_the_reference_accumulators(native, oracle, S):
         acc2 = oracle.Accs(om2)
         tot2 = sum(oracle.fb_utt(om2, oracle.fb_cfg(pruneInit=2000.0), u["feat"], u["seq"], acc2)[1] for u in su.demo_utterances(native, oracle, mmf))
         assert abs(tot2 / T - (-59.08)) < 0.01 and abs(tot / T - (-33.645)) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------ tied mixtures (hsKind TIEDHS)
+TMIX = os.path.join(DEMO, "hmm_tmix")
+
+
+@pytest.mark.parametrize("kind", ["tiedhs", "tiedhs3"])
+def test_tmix_mmf_round_trips(native, tmp_path, kind):
+    src = os.path.join(TMIX, kind + "_newMacros")
+    mmf = native.Mmf(files=[src], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    S = 3 if kind == "tiedhs3" else 1
+    assert pk["hsKind"] == 1 and pk["numStreams"] == S and pk["numGauss"] == (10 if S == 3 else 8)
+    # every (state, stream) lists its stream's pool
+    sco, cg = pk["stateCompOff"], pk["compGauss"]
+    for e in range(15 * S):
+        assert np.array_equal(cg[sco[e]:sco[e + 1]], cg[sco[e % S]:sco[e % S + 1]])
+    out = str(tmp_path / "newMacros")
+    mmf.write(pk, one_file=out)
+    assert open(out).read() == open(src).read()                      # <TMIX> "name" and the run-length weights as PutTiedWeights writes them
+    outb = str(tmp_path / "bin")
+    mmf.write(pk, one_file=outb, binary=True)
+    p2 = native.Mmf(files=[outb], hmm_list=os.path.join(DEMO, "bcplist")).packed()
+    assert np.array_equal(pk["mean"], p2["mean"]) and np.array_equal(pk["compGauss"], p2["compGauss"])
+    assert np.allclose(pk["compWeight"], p2["compWeight"], rtol=0, atol=2e-7)     # binary runs are stored as weight - 2 (HModel.c:2602): lossy by design
+
+
+@pytest.mark.parametrize("kind", ["tiedhs", "tiedhs3"])
+def test_oracle_tied_mixtures_equal_the_reference_accumulators(native, oracle, kind):
+    """PrecomputeTMix / SOutP / UpMixParms' TIEDHS branches as restated in oracle/htk_oracle.c against the reference's `HERest -p 1`
+    accumulator file: every float, the summary line, and our reader / writer of the file (pool records after the last model)."""
+    mmf = native.Mmf(files=[os.path.join(TMIX, kind + "_newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    om = oracle.Model(pk)
+    acc = oracle.Accs(om)
+    tot, T = 0.0, 0
+    for u in su.demo_utterances(native, oracle, mmf):
+        rc, pr, _ = oracle.fb_utt(om, oracle.fb_cfg(pruneInit=2000.0), u["feat"], u["seq"], acc)
+        assert rc == 1
+        tot += pr; T += len(u["feat"])
+    assert "average log prob per frame = %e" % (tot / T) in open(os.path.join(TMIX, kind + ".log")).read()
+    lay = native.accs_layout(pk)
+    v = np.zeros(lay.total, np.float64)
+    ref = os.path.join(TMIX, kind + "_HER1.acc")
+    native.accs_load_file(pk, v, list(mmf.phys_names), ref)
+    for k, a in (("mu", acc.mu.reshape(-1)), ("muOcc", acc.muOcc), ("va", acc.va.reshape(-1)), ("vaOcc", acc.vaOcc), ("wt", acc.wt), ("wtOcc", acc.wtOcc),
+                 ("tr", acc.tr), ("trOcc", acc.trOcc)):
+        o = getattr(lay, k)
+        assert np.array_equal(a.astype(np.float32), v[o:o + a.size].astype(np.float32)), k
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        native.accs_dump_file(pk, v, list(mmf.phys_names), os.path.join(td, "HER1.acc"))
+        assert open(os.path.join(td, "HER1.acc"), "rb").read() == open(ref, "rb").read()
