@@ -42,7 +42,7 @@ class ModelDesc(C.Structure):
                 ("mean", C.c_void_p), ("var", C.c_void_p), ("gconst", C.c_void_p),
                 ("transN", C.c_void_p), ("transOff", C.c_void_p), ("transP", C.c_void_p),
                 ("hmmTrans", C.c_void_p), ("hmmStateOff", C.c_void_p), ("hmmState", C.c_void_p),
-                ("numStreams", C.c_int), ("dimStream", C.c_void_p), ("hsKind", C.c_int)]
+                ("numStreams", C.c_int), ("dimStream", C.c_void_p), ("hsKind", C.c_int), ("streamWeight", C.c_void_p)]
 
 
 class AccsLayout(C.Structure):
@@ -134,14 +134,15 @@ class Model:
                           mean=f32(pk["mean"]), var=f32(pk["var"]), gconst=f32(pk.get("gconst")),
                           transN=i32(pk["transN"]), transOff=i32(pk["transOff"]), transP=f32(pk["transP"]),
                           hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]),
-                          dimStream=i32(pk["dimStream"]) if pk.get("dimStream") is not None else None)
+                          dimStream=i32(pk["dimStream"]) if pk.get("dimStream") is not None else None,
+                          streamWeight=f32(pk.get("streamWeight")))
         k = self._keep
         self.NS = int(pk.get("numStreams", 1) or 1)
         d = ModelDesc(int(pk["vecSize"]), int(pk["numStates"]), int(pk["numComp"]), int(pk["numGauss"]),
                       int(pk["numTrans"]), int(pk["numPhys"]),
                       _p(k["stateCompOff"]), _p(k["compWeight"]), _p(k["compGauss"]), _p(k["mean"]), _p(k["var"]), _p(k["gconst"]),
                       _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]),
-                      self.NS, _p(k["dimStream"]), int(pk.get("hsKind", 0) or 0))
+                      self.NS, _p(k["dimStream"]), int(pk.get("hsKind", 0) or 0), _p(k["streamWeight"]))
         self.h = C.c_void_p()
         check(lib().htkamd_model_create(C.byref(d), C.byref(self.h)), "model_create")
         self.D, self.S, self.C, self.G = d.vecSize, d.numStates, d.numComp, d.numGauss
@@ -491,11 +492,11 @@ def _desc_from_packed(pk: dict):
              mean=f32(pk["mean"]), var=f32(pk["var"]), gconst=f32(pk.get("gconst")),
              transN=i32(pk["transN"]), transOff=i32(pk["transOff"]), transP=f32(pk["transP"]),
              hmmTrans=i32(pk["hmmTrans"]), hmmStateOff=i32(pk["hmmStateOff"]), hmmState=i32(pk["hmmState"]),
-             dimStream=i32(pk["dimStream"]) if pk.get("dimStream") is not None else None)
+             dimStream=i32(pk["dimStream"]) if pk.get("dimStream") is not None else None, streamWeight=f32(pk.get("streamWeight")))
     d = ModelDesc(int(pk["vecSize"]), int(pk["numStates"]), int(pk["numComp"]), int(pk["numGauss"]), int(pk["numTrans"]), int(pk["numPhys"]),
                   _p(k["stateCompOff"]), _p(k["compWeight"]), _p(k["compGauss"]), _p(k["mean"]), _p(k["var"]), _p(k["gconst"]),
                   _p(k["transN"]), _p(k["transOff"]), _p(k["transP"]), _p(k["hmmTrans"]), _p(k["hmmStateOff"]), _p(k["hmmState"]),
-                  int(pk.get("numStreams", 1) or 1), _p(k["dimStream"]), int(pk.get("hsKind", 0) or 0))
+                  int(pk.get("numStreams", 1) or 1), _p(k["dimStream"]), int(pk.get("hsKind", 0) or 0), _p(k["streamWeight"]))
     return d, k
 
 
@@ -689,7 +690,8 @@ class Mmf:
                   gconst=arr(d.gconst, G, C.c_float) if d.gconst else None,
                   transN=arr(d.transN, nT, C.c_int), transOff=transOff, transP=arr(d.transP, int(transOff[-1]), C.c_float),
                   hmmTrans=arr(d.hmmTrans, H, C.c_int), hmmStateOff=hmmStateOff, hmmState=arr(d.hmmState, int(hmmStateOff[-1]), C.c_int),
-                  numStreams=max(d.numStreams, 1), dimStream=arr(d.dimStream, D, C.c_int) if d.numStreams > 1 else None, hsKind=int(d.hsKind))
+                  numStreams=max(d.numStreams, 1), dimStream=arr(d.dimStream, D, C.c_int) if d.numStreams > 1 else None, hsKind=int(d.hsKind),
+                  streamWeight=arr(d.streamWeight, S * d.numStreams, C.c_float) if (d.numStreams > 1 and d.streamWeight) else None)
         return pk
 
     def sharing(self):

@@ -140,9 +140,12 @@ __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
          if (!live) t = tk.nFrames - 1;
          const float *row = a.X + (size_t)(tk.frame0 + t) * D;
          for (int k = 0; k < tk.nSlots; k++) {
-            const int s = a.slotState[tk.slot0 + k];
+            const int s0 = a.slotState[tk.slot0 + k];
+            float total = 0.0f, acc = (float)LZERO;
+            for (int ks = 0; ks < (a.NSt > 1 ? a.NSt : 1); ks++) {
+            const int s = s0 + ks;
             const int c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
-            float acc = (float)LZERO;
+            acc = (float)LZERO;
             double dacc = LZERO;
             for (int c = c0; c < c1; c++) {
                const float wt = a.compLogWt[c];
@@ -169,6 +172,9 @@ __global__ __launch_bounds__(256) void k_score_exact_anyD(ScoreArgs a)
                }
             }
             if (SOUTP && c1 - c0 > 1) acc = (float)dacc;
+            if (a.NSt > 1) { const float wx = a.streamWt[s] * acc; total = total + wx; }     // cPOutP / POutP: float product, float sum
+            }
+            if (a.NSt > 1) acc = total;
             if (live) a.out[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + t] = acc;
          }
       }
@@ -182,6 +188,12 @@ int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStre
    int blocks = (a.nTasks + 3) / 4;
    if (blocks > 256 * 5) blocks = 256 * 5;      // persistent: up to 5 four-wave blocks per CU (VGPR-limited)
    dim3 grid(blocks), block(256);
+   if (a.NSt > 1 && !a.streamWt) { htkamd_set_error("score_exact: several streams without stream weights"); return HTKAMD_EINVAL; }
+   if (a.NSt > 1 && !soutp && !diagc) {          // stream-weighted state probabilities (HVite on a multi-stream set): the general kernel
+      hipExtLaunchKernelGGL((k_score_exact_anyD<false, false>), grid, block, 0, stream, evStart, evStop, 0, a);
+      HIPCHECK(hipGetLastError());
+      return HTKAMD_OK;
+   }
    if (soutp || diagc) {                         // the HRest / HInit / direct-OutP forms: not a hot path, one kernel for every size
       if (diagc && !a.var) { htkamd_set_error("score_exact: DIAGC form without the variance table"); return HTKAMD_EINVAL; }
       if (soutp && diagc) hipExtLaunchKernelGGL((k_score_exact_anyD<true, true>), grid, block, 0, stream, evStart, evStop, 0, a);

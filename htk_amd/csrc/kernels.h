@@ -36,6 +36,11 @@ struct ScoreArgs {
    const int *stateTileOff;
    const void *bf16Tab;       // bf16 x 3 path only
    const float *var;          // DIAGC form only: variances [G*D]
+   // several streams, HRec's state output probability (cPOutP HRec.c:510-548: outp += w[s] * cSOutP(s), float): a slot names the state's
+   // first (state, stream) element, the kernel scores its NSt elements and writes their weighted sum.  NSt <= 1 (what forward-backward
+   // passes, whose rows ARE elements): a slot is scored as it stands.
+   int NSt = 1;
+   const float *streamWt = nullptr;   // [elements]
 };
 
 // evStart/evStop (may be NULL): updated with the dispatch's own start and stop time (hipExtLaunchKernel), i.e. without the time

@@ -266,6 +266,8 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
             m->h_gaussStream[g] = e % NSt;
          }
       for (int g = 0; g < m->G; g++) if (m->h_gaussStream[g] < 0) m->h_gaussStream[g] = 0;
+      m->h_streamWt = (float *)malloc(sizeof(float) * (size_t)m->S);
+      for (int e = 0; e < m->S; e++) m->h_streamWt[e] = d->streamWeight ? d->streamWeight[e] : 1.0f;
    }
    m->h_minDur = dupHost((const int *)nullptr, (size_t)m->nT);
    for (int t = 0; t < m->nT; t++) m->h_minDur[t] = -1;
@@ -322,7 +324,8 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
    if (NSt > 1 || m->tiedMix) {
       std::vector<int> two((size_t)m->S + 1);
       for (int e = 0; e <= m->S; e++) two[e] = 2 * e;
-      if ((NSt > 1 && ((rc = toDevice(&m->d_dimStream, m->h_dimStream, (size_t)m->D)) || (rc = toDevice(&m->d_gaussStream, m->h_gaussStream, (size_t)m->G)))) ||
+      if ((NSt > 1 && ((rc = toDevice(&m->d_dimStream, m->h_dimStream, (size_t)m->D)) || (rc = toDevice(&m->d_gaussStream, m->h_gaussStream, (size_t)m->G)) ||
+                       (rc = toDevice(&m->d_streamWt, m->h_streamWt, (size_t)m->S)))) ||
           (rc = toDevice(&m->d_msCompOff, two.data(), (size_t)m->S + 1))) { htkamd_model_destroy(m); return rc; }
    }
    {
@@ -351,7 +354,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
    free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize); (void)hipFree(m->d_shareTab);
-   free(m->h_tmPoolOff); (void)hipFree(m->d_tmPoolOff);
+   free(m->h_tmPoolOff); (void)hipFree(m->d_tmPoolOff); free(m->h_streamWt); (void)hipFree(m->d_streamWt);
    free(m->h_dimStream); free(m->h_gaussStream); (void)hipFree(m->d_dimStream); (void)hipFree(m->d_gaussStream); (void)hipFree(m->d_msCompOff);
    free(m);
 }

@@ -46,6 +46,7 @@ struct htkamd_mmf {
    /* desc arrays */
    htkamd_model_desc d; int *stateCompOff, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
    int *gStr;                                                       /* stream of Gaussian g */
+   float *swAll;                                                    /* [nSt*NS] stream weights for the desc */
    int tiedMix;                                                     /* hsKind TIEDHS: <TMIX> streams (GetStream HModel.c:1878-1892) */
    char *tmName[8]; int tmM[8];                                     /* per stream: generic ~m macro name and pool size (tmRecs[s].mixId / nMix) */
    int *gPend; int capPend, lastVecN;                                         /* a ~m macro of a multi-stream set read before its stream is known: its width, values at [0..width) of the row */
@@ -819,6 +820,12 @@ int htkamd_mmf_finish(struct htkamd_mmf *s, const char *hmmList, const char *dir
    d->hmmTrans = s->hmmTrans; d->hmmStateOff = s->hmmStateOff; d->hmmState = s->hmmState;
    d->numStreams = NS; d->dimStream = NS > 1 ? s->dimStream : NULL;
    d->hsKind = s->tiedMix ? HTKAMD_HS_TIED : HTKAMD_HS_PLAIN;
+   d->streamWeight = NULL;
+   if (NS > 1) {
+      s->swAll = (float *)malloc(sizeof(float) * (size_t)s->nSt * NS);
+      for (int i = 0; i < s->nSt; i++) for (int k = 0; k < NS; k++) s->swAll[(size_t)i * NS + k] = s->st[i].sw ? s->st[i].sw[k] : 1.0f;
+      d->streamWeight = s->swAll;
+   }
    {  /* name index for htkamd_mmf_find_logical */
       g_sortNames = s->logName;
       s->logSorted = (int *)malloc(sizeof(int) * (size_t)(s->nLog ? s->nLog : 1));
@@ -870,7 +877,7 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
 {
    if (!s) return;
    for (int i = 0; i < s->nSt; i++) { free(s->st[i].name); free(s->st[i].sMix); free(s->st[i].sw); }
-   free(s->dimStream); free(s->gStr); free(s->gPend);
+   free(s->dimStream); free(s->gStr); free(s->gPend); free(s->swAll);
    for (int i = 0; i < 8; i++) free(s->tmName[i]);
    for (int i = 0; i < s->nTr; i++) free(s->tr[i].name);
    for (int i = 0; i < s->nHm; i++) { free(s->hm[i].name); free(s->hm[i].state); }

@@ -97,6 +97,8 @@ typedef struct {
       (compGauss equal across states) with its own weights; output probabilities and statistics go through the pool's top-M arithmetic
       (PrecomputeTMix HModel.c:5308, SOutP :5555, UpMixParms HFB.c:1524-1600), the pool is re-estimated once per set (HERest.c:1272). */
    int hsKind;
+   const float *streamWeight; /* [numStates*NS] <SWEIGHTS> of every state, NULL = all 1 (GetStateInfo HModel.c:1994).  Used by the aligner and
+                                 the decoder (OutP = sum_s w_s SOutP_s, HModel.c:5570-5583 / HRec.c:510-548); HFB ignores them (HFB.c:1057) */
 } htkamd_model_desc;
 #define HTKAMD_HS_PLAIN 0
 #define HTKAMD_HS_TIED  1
