@@ -412,7 +412,7 @@ static float like_to_word(const htkamd_net_desc *nd, const htkamd_model *m, cons
 extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd, float lmScale, htkamd_decoder **out)
 {
    if (!m || !nd || !out) { htkamd_set_error("decoder_create: NULL argument"); return HTKAMD_EINVAL; }
-   if (m->NSt > 1) { htkamd_set_error("decoder_create: multi-stream sets are served by the forward-backward pass only (the decoder's stream-weighted OutP, HModel.c:5523, is not built)"); return HTKAMD_EMODEL; }
+   if (m->tiedMix) { htkamd_set_error("decoder_create: tied-mixture sets are served by the forward-backward pass only"); return HTKAMD_EMODEL; }
    const int nN = nd->nNodes;
    std::vector<int> kind(nd->kind, nd->kind + nN), model(nd->model, nd->model + nN), tok0(nN), nodeN(nN, 2), nodeTp(nN, 0), nodeSt(nN, 0), wordIdx(nN, -1), hmmNodes;
    std::vector<float> pron(nd->pronProb, nd->pronProb + nN), wdlk(nN, (float)LZERO);
@@ -428,12 +428,12 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
          if (h < 0 || h >= m->H) { htkamd_set_error("decoder_create: node %d names model %d of %d", n, h, m->H); delete d; return HTKAMD_EINVAL; }
          const int ti = m->h_hmmTrans[h], NS = m->h_transN[ti];
          if (NS > DEC_MAXN) { htkamd_set_error("decoder_create: model with %d states (max %d)", NS, DEC_MAXN); delete d; return HTKAMD_EMODEL; }
-         nodeN[n] = NS; nodeTp[n] = m->h_transOff[ti]; nodeSt[n] = m->h_hmmStateOff[h];
+         nodeN[n] = NS; nodeTp[n] = m->h_transOff[ti]; nodeSt[n] = m->h_hmmStateOff[h] / m->NSt;      // several streams: the table below lists a state's FIRST element only
          tee[n] = m->h_transP[m->h_transOff[ti] + (NS - 1)] > (float)LSMALL;
          nTok += NS - 1;
          hmmNodes.push_back(n);
          for (int j = 0; j < NS - 2; j++) {
-            const int s = m->h_hmmState[m->h_hmmStateOff[h] + j];
+            const int s = m->h_hmmState[m->h_hmmStateOff[h] + j * m->NSt];
             if (stateSlot[s] < 0) { stateSlot[s] = (int)d->usedStates.size(); d->usedStates.push_back(s); }
          }
       } else {
@@ -509,7 +509,8 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
        (rc = upv(d, levelWide, &N.levelWide)) || (rc = upv(d, stateSlot, &N.stateSlot)) || (rc = upv(d, wordNode, &N.wordNode)) ||
        (rc = upv(d, nodeInfo, &N.nodeInfo))) { htkamd_decoder_destroy(d); return rc; }
    {
-      std::vector<int> hs(m->h_hmmState, m->h_hmmState + m->h_hmmStateOff[m->H]);
+      std::vector<int> hs((size_t)(m->h_hmmStateOff[m->H] / m->NSt));
+      for (size_t i = 0; i < hs.size(); i++) hs[i] = m->h_hmmState[i * m->NSt];      // a state's first (state, stream) element: the scorer sums its streams (ScoreArgs::NSt)
       if ((rc = upv(d, hs, &N.hmmState))) { htkamd_decoder_destroy(d); return rc; }
       const int *us = nullptr;
       if ((rc = upv(d, d->usedStates, &us))) { htkamd_decoder_destroy(d); return rc; }
@@ -599,7 +600,9 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
          sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)((char *)dTasks + sizeof(ScoreTask) * tasks.size());
          sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
-         if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
+         sa.NSt = m->NSt; sa.streamWt = m->d_streamWt;
+         if (m->NSt > 1 && cfg->scoreMode != HTKAMD_SCORE_EXACT) { htkamd_set_error("decoder_run: multi-stream sets are scored in the exact mode only"); rc = HTKAMD_EINVAL; }
+         else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);   // exact: the decoded path is the reference's; matrix-core modes: tolerance class
       }
       if (!rc) {

@@ -511,7 +511,9 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
          sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)((char *)dTasks + sizeof(ScoreTask) * tasks.size());
          sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
-         if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run_lattice: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
+         sa.NSt = m->NSt; sa.streamWt = m->d_streamWt;
+         if (m->NSt > 1 && cfg->scoreMode != HTKAMD_SCORE_EXACT) { htkamd_set_error("decoder_run_lattice: multi-stream sets are scored in the exact mode only"); rc = HTKAMD_EINVAL; }
+         else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run_lattice: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);
       }
       if (!rc) {

@@ -486,7 +486,7 @@ struct htkamd_viterbi {
 extern "C" int htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out)
 {
    if (!m || !out) { htkamd_set_error("viterbi_create: NULL argument"); return HTKAMD_EINVAL; }
-   if (m->NSt > 1) { htkamd_set_error("viterbi_create: multi-stream sets are served by the forward-backward pass only"); return HTKAMD_EMODEL; }
+   if (m->tiedMix) { htkamd_set_error("viterbi_create: tied-mixture sets are served by the forward-backward pass only"); return HTKAMD_EMODEL; }
    if (m->maxN > VG_MAXN) { htkamd_set_error("viterbi_create: models with %d states; this path handles up to %d", m->maxN, VG_MAXN); return HTKAMD_EMODEL; }
    htkamd_viterbi *v = new htkamd_viterbi();
    v->m = m; v->nUtt = 0; v->segTotal = v->modTotal = 0;
@@ -553,7 +553,7 @@ extern "C" int htkamd_viterbi_align_mode(htkamd_viterbi *v, const htkamd_batch_d
          if (h < 0 || h >= m->H) { htkamd_set_error("viterbi_align: utterance %d label %d: HMM index %d out of range", u, q, h); return HTKAMD_EINVAL; }
          const int ti = m->h_hmmTrans[h], N = m->h_transN[ti];
          v->mN.push_back(N); v->mTp.push_back(m->h_transOff[ti]); v->mSlot0.push_back(nSlots);
-         for (int j = 2; j < N; j++) v->slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2)]);
+         for (int j = 2; j < N; j++) v->slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2) * m->NSt]);      // several streams: the state's first element (ScoreArgs::NSt)
          nSlots += N - 2;
       }
       d.nSlots = nSlots;
@@ -594,6 +594,7 @@ extern "C" int htkamd_viterbi_align_mode(htkamd_viterbi *v, const htkamd_batch_d
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)v->d_counter.p;
    if (scoreMode & HTKAMD_SCORE_DIAGC) { if ((rc = htkamd_model_device_tables((htkamd_model *)m))) return rc; }
    sa.var = m->d_var;
+   sa.NSt = m->NSt; sa.streamWt = m->d_streamWt;
    if ((rc = htkamd_launch_score_exact(m, sa, s, nullptr, nullptr, (scoreMode & HTKAMD_SCORE_SOUTP) != 0, (scoreMode & HTKAMD_SCORE_DIAGC) != 0))) return rc;
 
    VitArgs va;

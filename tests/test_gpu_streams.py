@@ -213,8 +213,30 @@ def test_herest_cli_tied_mixtures(native, tmp_path):
         cli._mmf_close(cli._mmf_numbers(str(out / (kind + "_newMacros"))), cli._mmf_numbers(os.path.join(TMIX, kind + "_after_herest")))
 
 
-def test_streams_are_refused_where_they_are_not_served(native):
-    mmf = native.Mmf(files=[os.path.join(DEMO, "hmm_streams3", "newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+@pytest.mark.parametrize("name", ["after_herest", "sw_after_herest"])
+def test_hvite_cli_on_a_three_stream_set(native, tmp_path, name):
+    """Recognition and forced alignment of a multi-stream set: state output probability = sum over streams of w_s x (the stream's mixture
+    log likelihood) (cPOutP HRec.c:510-548), here with <SWEIGHTS> 1 1 1 and 1 0.5 2 -- the label files of the reference's HVite, line for
+    line (tests/golden/make_streams_hvite_golden.py)."""
+    import json
+    tools = os.path.join(ROOT, "tools", "bin")
+    d3 = os.path.join(DEMO, "hmm_streams3")
+    exp = json.load(open(os.path.join(d3, "hvite_expected.json")))[name]
+    conf = tmp_path / "hvite.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    path = lambda u: os.path.join(DEMO, "test" if u.startswith("te") else "train", u + ".mfc")
+    for what, opts in (("rec", ["-w", os.path.join(DEMO, "monLattice"), "-t", "300.0", "-p", "5.0", "-s", "0.0", "-m", "-f"]),
+                       ("align", ["-a", "-m", "-f", "-L", os.path.join(DEMO, "labels"), "-t", "300.0"])):
+        out = tmp_path / what; out.mkdir()
+        names = sorted(exp[what])
+        r = cli.run([os.path.join(tools, "hvite"), "-C", str(conf), "-H", os.path.join(d3, name), "-l", str(out)] + opts +
+                    [os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + [path(u) for u in names])
+        assert r.returncode == 0, r.stderr
+        for u in names:
+            assert (out / (u + ".rec")).read_text().splitlines() == exp[what][u], (what, u)
+
+
+def test_tied_mixtures_are_refused_where_they_are_not_served(native):
+    mmf = native.Mmf(files=[os.path.join(TMIX, "tiedhs_newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
     model = native.Model(mmf.packed())
-    with pytest.raises(native.HtkAmdError, match="multi-stream"):
+    with pytest.raises(native.HtkAmdError, match="tied-mixture"):
         native.Viterbi(model)
