@@ -102,6 +102,10 @@ typedef struct {
 } htkamd_model_desc;
 #define HTKAMD_HS_PLAIN 0
 #define HTKAMD_HS_TIED  1
+/* dimStream for a parameter kind given as text ("MFCC_E_D") and the stream widths of <STREAMINFO>: the split SetStreamWidths /
+   ExtractObservation make (HParm.c:3094,2843 -- the standard splits take the energy terms out into the last stream, any other split is
+   consecutive pieces).  Returns 0, or -1 with the reason in `why`. */
+int htkamd_host_stream_dims(const char *kind, int vecSize, int S, const int *width, int *dimStream /*[vecSize]*/, char *why, size_t whyLen);
 
 typedef struct htkamd_model htkamd_model;
 

@@ -15,7 +15,7 @@
  * afterwards: every consumer (MLUpdateModels HERest.c:1262, DumpAccs HTrain.c:1453, StatReport HERest.c:708) starts with
  * NewHMMScan, so the link line wraps that one symbol (-Wl,--wrap=NewHMMScan) and __wrap_NewHMMScan below flushes first.
  *
- * Restrictions (HError 7399, as the library's own): one stream, diagonal covariances, PLAINHS/SHAREDHS, no input transform, no
+ * Restrictions (HError 7399, as the library's own): diagonal covariances, PLAINHS/SHAREDHS (one stream or several), no input transform, no
  * two-model re-estimation, no single-pass retraining (two data files).  FBFile is called per file by the front-end and is served
  * as a batch of one; the batched entry points of htk_amd.h are the fast path (tools/herest.c).
  */
@@ -53,8 +53,9 @@ typedef struct {
    HMMSet *hset;
    int packed;                         /* tables below are valid */
    int D, S, C, G, nT, H;
+   int NSt, *dimStream, *gaussStream;  /* data streams (hset->swidth[0]); dimension -> stream of the undivided row; stream of Gaussian g (1-based g) */
    HLink *hmmOf;                       /* [H] */
-   StreamElem **steOf;                 /* [S] stream element of tied state s */
+   StreamElem **steOf;                 /* [S] FIRST stream element of tied state s (its streams follow it) */
    MixPDF **mixOf;                     /* [G] */
    HLink *transOwner;                  /* [nT] a model that owns matrix t */
    int *stateCompOff, *compGauss, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState;
@@ -192,8 +193,7 @@ void InitialiseForBack(FBInfo *fbInfo, MemHeap *x, HMMSet *hset, UPDSet uset,
       if (prune.pruneInc != 0.0) printf("Pruning-On[%.1f %.1f %.1f]\n", prune.pruneInit, prune.pruneInc, prune.pruneLim);
       else printf("Pruning-On[%.1f]\n", prune.pruneInit);
    } else printf("Pruning-Off\n");
-   if (hset->swidth[0] != 1) HError(7399, "InitialiseForBack: %d data streams (the MI355X module takes one)", hset->swidth[0]);
-   if (hset->hsKind != PLAINHS && hset->hsKind != SHAREDHS) HError(7399, "InitialiseForBack: tied-mixture and discrete systems are not supported");
+   if (hset->hsKind != PLAINHS && hset->hsKind != SHAREDHS) HError(7399, "InitialiseForBack: tied-mixture and discrete systems are not supported by this module (tools/herest serves <TMIX> sets)");
    memset(&g_set, 0, sizeof(g_set));
    g_set.hset = hset; g_set.uFlags = uset;
 }
@@ -284,7 +284,18 @@ static void pack_set(ShimSet *z)
       z->steOf = (StreamElem **)calloc((size_t)capS + 1, sizeof(StreamElem *));
       z->mixOf = (MixPDF **)calloc((size_t)capG + 1, sizeof(MixPDF *));
       z->transOwner = (HLink *)calloc((size_t)capT + 1, sizeof(HLink));
+      z->gaussStream = (int *)calloc((size_t)capG + 1, sizeof(int));
       z->S = z->G = z->nT = 0;
+      z->NSt = hset->swidth[0];
+      z->D = hset->vecSize;
+      z->dimStream = (int *)calloc((size_t)z->D, sizeof(int));
+      if (z->NSt > 1) {                                   /* where ExtractObservation puts each element of the row (HParm.c:2843) */
+         char kind[64], why[160];
+         int w[SMAX];
+         for (s = 1; s <= z->NSt; s++) w[s - 1] = hset->swidth[s];
+         ParmKind2Str(hset->pkind, kind);
+         if (htkamd_host_stream_dims(kind, z->D, z->NSt, w, z->dimStream, why, sizeof(why))) HError(7399, "FBFile: stream widths: %s", why);
+      }
       h = 0;
       NewHMMScan(hset, &hss);
       do {
@@ -303,29 +314,31 @@ static void pack_set(ShimSet *z)
             if (map_get(z, si) >= 0) continue;
             if (z->S + 1 > capS) { capS *= 2; z->steOf = (StreamElem **)realloc(z->steOf, sizeof(StreamElem *) * ((size_t)capS + 1)); }
             map_put(z, si, z->S); z->steOf[++z->S] = ste;
-            for (k = 1; k <= ste->nMix; k++) {
-               MixPDF *mp = ste->spdf.cpdf[k].mpdf;
+            for (s = 0; s < z->NSt; s++)
+            for (k = 1; k <= ste[s].nMix; k++) {
+               MixPDF *mp = ste[s].spdf.cpdf[k].mpdf;
                if (map_get(z, mp) >= 0) continue;
-               if (z->G + 1 > capG) { capG *= 2; z->mixOf = (MixPDF **)realloc(z->mixOf, sizeof(MixPDF *) * ((size_t)capG + 1)); }
-               map_put(z, mp, z->G); z->mixOf[++z->G] = mp;
+               if (z->G + 1 > capG) { capG *= 2; z->mixOf = (MixPDF **)realloc(z->mixOf, sizeof(MixPDF *) * ((size_t)capG + 1)); z->gaussStream = (int *)realloc(z->gaussStream, sizeof(int) * ((size_t)capG + 1)); }
+               map_put(z, mp, z->G); z->mixOf[++z->G] = mp; z->gaussStream[z->G] = s;
             }
          }
          h++;
       } while (GoNextHMM(&hss));
       EndHMMScan(&hss);
    }
-   z->D = hset->vecSize;
    if (h != z->H) HError(7399, "FBFile: %d physical models scanned, %d expected", h, z->H);
-   z->stateCompOff = (int *)calloc((size_t)z->S + 1, sizeof(int));
-   for (s = 1; s <= z->S; s++) z->stateCompOff[s] = z->stateCompOff[s - 1] + z->steOf[s]->nMix;
-   z->C = z->stateCompOff[z->S];
+   /* one entry per (state, stream): element e = (s - 1) * NSt + stream */
+   z->stateCompOff = (int *)calloc((size_t)z->S * z->NSt + 1, sizeof(int));
+   for (s = 1; s <= z->S; s++) for (k = 0; k < z->NSt; k++) { const int e = (s - 1) * z->NSt + k; z->stateCompOff[e + 1] = z->stateCompOff[e] + z->steOf[s][k].nMix; }
+   z->C = z->stateCompOff[z->S * z->NSt];
    z->compGauss = (int *)calloc((size_t)z->C, sizeof(int));
    weight = (float *)calloc((size_t)z->C, sizeof(float)); logwt = (float *)calloc((size_t)z->C, sizeof(float));
    for (s = 1; s <= z->S; s++)
-      for (k = 1; k <= z->steOf[s]->nMix; k++) {
-         MixtureElem *me = z->steOf[s]->spdf.cpdf + k;
+      for (i = 0; i < z->NSt; i++)
+      for (k = 1; k <= z->steOf[s][i].nMix; k++) {
+         MixtureElem *me = z->steOf[s][i].spdf.cpdf + k;
          MixPDF *mp = me->mpdf;
-         c = z->stateCompOff[s - 1] + k - 1;
+         c = z->stateCompOff[(s - 1) * z->NSt + i] + k - 1;
          if (mp->ckind != DIAGC && mp->ckind != INVDIAGC) HError(7399, "FBFile: only diagonal covariances are supported by the MI355X module");
          z->compGauss[c] = map_get(z, mp);
          /* the front-end has already run ConvLogWt when the first file arrives (HERest.c:640): keep BOTH forms exact */
@@ -336,11 +349,15 @@ static void pack_set(ShimSet *z)
    ivar = (float *)calloc((size_t)z->G * z->D, sizeof(float)); gconst = (float *)calloc((size_t)z->G, sizeof(float));
    for (g = 1; g <= z->G; g++) {
       MixPDF *mp = z->mixOf[g];
+      int kk = 0;                                          /* index in the stream's own vector */
       for (k = 1; k <= z->D; k++) {
-         const float v = mp->cov.var[k];
-         mean[(size_t)(g - 1) * z->D + k - 1] = mp->mean[k];
-         if (mp->ckind == INVDIAGC) { ivar[(size_t)(g - 1) * z->D + k - 1] = v; var[(size_t)(g - 1) * z->D + k - 1] = 1 / v; }
-         else { float c2 = v; if (c2 > 1E+30) c2 = 1E+30; if (c2 < 1E-30) c2 = 1E-30; var[(size_t)(g - 1) * z->D + k - 1] = v; ivar[(size_t)(g - 1) * z->D + k - 1] = 1 / c2; }
+         const size_t at = (size_t)(g - 1) * z->D + k - 1;
+         if (z->NSt > 1 && z->dimStream[k - 1] != z->gaussStream[g]) { mean[at] = 0.0f; var[at] = INFINITY; ivar[at] = 0.0f; continue; }   /* include/htk_amd.h: undivided rows */
+         kk++;
+         const float v = mp->cov.var[kk];
+         mean[at] = mp->mean[kk];
+         if (mp->ckind == INVDIAGC) { ivar[at] = v; var[at] = 1 / v; }
+         else { float c2 = v; if (c2 > 1E+30) c2 = 1E+30; if (c2 < 1E-30) c2 = 1E-30; var[at] = v; ivar[at] = 1 / c2; }
       }
       gconst[g - 1] = mp->gConst;
    }
@@ -365,6 +382,7 @@ static void pack_set(ShimSet *z)
    d.vecSize = z->D; d.numStates = z->S; d.numComp = z->C; d.numGauss = z->G; d.numTrans = z->nT; d.numPhys = z->H;
    d.stateCompOff = z->stateCompOff; d.compWeight = weight; d.compGauss = z->compGauss; d.mean = mean; d.var = var; d.gconst = gconst;
    d.transN = z->transN; d.transOff = z->transOff; d.transP = transP; d.hmmTrans = z->hmmTrans; d.hmmStateOff = z->hmmStateOff; d.hmmState = z->hmmState;
+   d.numStreams = z->NSt; d.dimStream = z->NSt > 1 ? z->dimStream : NULL;
    amd_check(htkamd_model_create(&d, &z->model), "htkamd_model_create");
    /* the tables the kernels read are the front-end's own numbers, bit for bit: 1/variance from ConvDiagC, log weights from ConvLogWt */
    amd_check(htkamd_model_set_prepared(z->model, ivar, gconst, logwt), "htkamd_model_set_prepared");
@@ -408,22 +426,26 @@ static void flush_to_hooks(ShimSet *z)
          ta->occ[i] += (float)v[lay.trOcc + occOff + i - 1];
       }
    }
-   for (s = 1; s <= z->S; s++) {
-      WtAcc *wa = (WtAcc *)z->steOf[s]->hook;
-      if (wa == NULL) continue;
-      for (k = 1; k <= z->steOf[s]->nMix; k++) wa->c[k] += (float)v[lay.wt + z->stateCompOff[s - 1] + k - 1];
-      wa->occ += (float)v[lay.wtOcc + s - 1];
-   }
+   for (s = 1; s <= z->S; s++)
+      for (i = 0; i < z->NSt; i++) {
+         const int e = (s - 1) * z->NSt + i;
+         WtAcc *wa = (WtAcc *)z->steOf[s][i].hook;
+         if (wa == NULL) continue;
+         for (k = 1; k <= z->steOf[s][i].nMix; k++) wa->c[k] += (float)v[lay.wt + z->stateCompOff[e] + k - 1];
+         wa->occ += (float)v[lay.wtOcc + e];
+      }
    for (g = 1; g <= z->G; g++) {
       MixPDF *mp = z->mixOf[g];
       MuAcc *ma = (z->uFlags & UPMEANS) ? (MuAcc *)GetHook(mp->mean) : NULL;
       VaAcc *va = (z->uFlags & UPVARS) ? (VaAcc *)GetHook(mp->cov.var) : NULL;
       if (ma != NULL) {
-         for (k = 1; k <= z->D; k++) ma->mu[k] += (float)v[lay.mu + (size_t)(g - 1) * z->D + k - 1];
+         int kk = 0;
+         for (k = 1; k <= z->D; k++) if (z->NSt == 1 || z->dimStream[k - 1] == z->gaussStream[g]) ma->mu[++kk] += (float)v[lay.mu + (size_t)(g - 1) * z->D + k - 1];
          ma->occ += (float)v[lay.muOcc + g - 1];
       }
       if (va != NULL) {
-         for (k = 1; k <= z->D; k++) va->cov.var[k] += (float)v[lay.va + (size_t)(g - 1) * z->D + k - 1];
+         int kk = 0;
+         for (k = 1; k <= z->D; k++) if (z->NSt == 1 || z->dimStream[k - 1] == z->gaussStream[g]) va->cov.var[++kk] += (float)v[lay.va + (size_t)(g - 1) * z->D + k - 1];
          va->occ += (float)v[lay.vaOcc + g - 1];
       }
    }
@@ -465,7 +487,11 @@ Boolean FBFile(FBInfo *fbInfo, UttInfo *utt, char *datafn)
    if ((size_t)utt->T * z->D > z->hXcap) { free(z->hX); z->hXcap = (size_t)utt->T * z->D * 2; z->hX = (float *)malloc(sizeof(float) * z->hXcap); }
    for (t = 0; t < utt->T; t++) {
       ReadAsTable(utt->pbuf, t, &utt->ot);
-      for (k = 1; k <= z->D; k++) z->hX[(size_t)t * z->D + k - 1] = utt->ot.fv[1][k];
+      if (z->NSt == 1) for (k = 1; k <= z->D; k++) z->hX[(size_t)t * z->D + k - 1] = utt->ot.fv[1][k];
+      else {                                              /* the undivided row back from the stream vectors */
+         int at[SMAX] = {0};
+         for (k = 0; k < z->D; k++) { const int st = z->dimStream[k]; z->hX[(size_t)t * z->D + k] = utt->ot.fv[st + 1][++at[st]]; }
+      }
    }
    if (sizeof(float) * (size_t)utt->T * z->D > z->dXcap) {
       if (z->dX) amd_check(htkamd_dev_free(z->dX), "htkamd_dev_free");

@@ -76,6 +76,7 @@ static struct {
    HMMSet *hset;
    int nToks, models, states;
    htkamd_model *model; pmap hmmIdx;           /* HLink -> physical index */
+   int NSt, *dimStream;                        /* data streams; dimension -> stream of the undivided feature row (several streams) */
    Network *net; htkamd_decoder *dec;          /* decoder of the network last started */
    NetNode **wordNode; int nWordNode;          /* WORD node table: htkamd "pronunciation" index -> NetNode */
    float scale, wordpen, pscale;
@@ -93,8 +94,19 @@ static void pack_model(void)
    htkamd_model_desc d;
    float *weight, *logwt, *mean, *var, *ivar, *gconst, *transP;
    int *stateCompOff, *compGauss, *transN, *transOff, *hmmTrans, *hmmStateOff, *hmmState, C;
+   int *gStr = NULL, ks;
+   float *sweight = NULL;
+   const int NSt = hset->swidth[0];
 
-   if (hset->swidth[0] != 1) HError(7399, "StartRecognition: %d data streams (the MI355X recogniser takes one)", hset->swidth[0]);
+   S.NSt = NSt; S.D = hset->vecSize;
+   free(S.dimStream); S.dimStream = (int *)calloc((size_t)S.D, sizeof(int));
+   if (NSt > 1) {                                          /* where ExtractObservation puts each element of the row (HParm.c:2843) */
+      char kind[64], why[160];
+      int w[SMAX];
+      for (s = 1; s <= NSt; s++) w[s - 1] = hset->swidth[s];
+      ParmKind2Str(hset->pkind, kind);
+      if (htkamd_host_stream_dims(kind, S.D, NSt, w, S.dimStream, why, sizeof(why))) HError(7399, "StartRecognition: stream widths: %s", why);
+   }
    if (hset->hsKind != PLAINHS && hset->hsKind != SHAREDHS) HError(7399, "StartRecognition: tied-mixture and discrete systems are not supported");
    if (hset->xf != NULL) HError(7399, "StartRecognition: input transforms are not supported");
    NewHMMScan(hset, &hss);
@@ -111,25 +123,28 @@ static void pack_model(void)
          if (pm_get(&sm, si) >= 0) continue;
          if (nS + 1 > capS) { capS = capS * 2 + 256; ste = (StreamElem **)realloc(ste, sizeof(StreamElem *) * (size_t)capS); }
          pm_put(&sm, si, nS); ste[nS++] = si->pdf + 1;
-         for (k = 1; k <= si->pdf[1].nMix; k++) {
-            MixPDF *mp = si->pdf[1].spdf.cpdf[k].mpdf;
+         sweight = (float *)realloc(sweight, sizeof(float) * (size_t)nS * NSt);
+         for (ks = 0; ks < NSt; ks++) sweight[(size_t)(nS - 1) * NSt + ks] = si->weights ? si->weights[ks + 1] : 1.0f;
+         for (ks = 1; ks <= NSt; ks++)
+         for (k = 1; k <= si->pdf[ks].nMix; k++) {
+            MixPDF *mp = si->pdf[ks].spdf.cpdf[k].mpdf;
             if (pm_get(&gm, mp) >= 0) continue;
-            if (nG + 1 > capG) { capG = capG * 2 + 1024; mix = (MixPDF **)realloc(mix, sizeof(MixPDF *) * (size_t)capG); }
-            pm_put(&gm, mp, nG); mix[nG++] = mp;
+            if (nG + 1 > capG) { capG = capG * 2 + 1024; mix = (MixPDF **)realloc(mix, sizeof(MixPDF *) * (size_t)capG); gStr = (int *)realloc(gStr, sizeof(int) * (size_t)capG); }
+            pm_put(&gm, mp, nG); gStr[nG] = ks - 1; mix[nG++] = mp;
          }
       }
       h++;
    } while (GoNextHMM(&hss));
    EndHMMScan(&hss);
-   S.D = hset->vecSize;
-   stateCompOff = (int *)calloc((size_t)nS + 1, sizeof(int));
-   for (s = 0; s < nS; s++) stateCompOff[s + 1] = stateCompOff[s] + ste[s]->nMix;
-   C = stateCompOff[nS];
+   stateCompOff = (int *)calloc((size_t)nS * NSt + 1, sizeof(int));           /* one entry per (state, stream) */
+   for (s = 0; s < nS; s++) for (ks = 0; ks < NSt; ks++) stateCompOff[s * NSt + ks + 1] = stateCompOff[s * NSt + ks] + ste[s][ks].nMix;
+   C = stateCompOff[nS * NSt];
    compGauss = (int *)calloc((size_t)C, sizeof(int)); weight = (float *)calloc((size_t)C, sizeof(float)); logwt = (float *)calloc((size_t)C, sizeof(float));
    for (s = 0; s < nS; s++)
-      for (k = 1; k <= ste[s]->nMix; k++) {
-         MixtureElem *me = ste[s]->spdf.cpdf + k;
-         c = stateCompOff[s] + k - 1;
+      for (ks = 0; ks < NSt; ks++)
+      for (k = 1; k <= ste[s][ks].nMix; k++) {
+         MixtureElem *me = ste[s][ks].spdf.cpdf + k;
+         c = stateCompOff[s * NSt + ks] + k - 1;
          if (me->mpdf->ckind != DIAGC && me->mpdf->ckind != INVDIAGC) HError(7399, "StartRecognition: only diagonal covariances are supported");
          compGauss[c] = pm_get(&gm, me->mpdf);
          if (hset->logWt) { logwt[c] = me->weight; weight[c] = (me->weight <= LMINMIX) ? 0.0f : (float)exp((double)me->weight); }
@@ -138,11 +153,15 @@ static void pack_model(void)
    mean = (float *)calloc((size_t)nG * S.D, sizeof(float)); var = (float *)calloc((size_t)nG * S.D, sizeof(float));
    ivar = (float *)calloc((size_t)nG * S.D, sizeof(float)); gconst = (float *)calloc((size_t)nG, sizeof(float));
    for (g = 0; g < nG; g++) {
+      int kk = 0;                                          /* index in the stream's own vector */
       for (k = 1; k <= S.D; k++) {
-         const float v = mix[g]->cov.var[k];
-         mean[(size_t)g * S.D + k - 1] = mix[g]->mean[k];
-         if (mix[g]->ckind == INVDIAGC) { ivar[(size_t)g * S.D + k - 1] = v; var[(size_t)g * S.D + k - 1] = 1 / v; }
-         else { float c2 = v; if (c2 > 1E+30) c2 = 1E+30; if (c2 < 1E-30) c2 = 1E-30; var[(size_t)g * S.D + k - 1] = v; ivar[(size_t)g * S.D + k - 1] = 1 / c2; }
+         const size_t at = (size_t)g * S.D + k - 1;
+         if (NSt > 1 && S.dimStream[k - 1] != gStr[g]) { mean[at] = 0.0f; var[at] = INFINITY; ivar[at] = 0.0f; continue; }      /* include/htk_amd.h: undivided rows */
+         kk++;
+         const float v = mix[g]->cov.var[kk];
+         mean[at] = mix[g]->mean[kk];
+         if (mix[g]->ckind == INVDIAGC) { ivar[at] = v; var[at] = 1 / v; }
+         else { float c2 = v; if (c2 > 1E+30) c2 = 1E+30; if (c2 < 1E-30) c2 = 1E-30; var[at] = v; ivar[at] = 1 / c2; }
       }
       gconst[g] = mix[g]->gConst;
    }
@@ -162,10 +181,11 @@ static void pack_model(void)
    d.vecSize = S.D; d.numStates = nS; d.numComp = C; d.numGauss = nG; d.numTrans = nT; d.numPhys = H;
    d.stateCompOff = stateCompOff; d.compWeight = weight; d.compGauss = compGauss; d.mean = mean; d.var = var; d.gconst = gconst;
    d.transN = transN; d.transOff = transOff; d.transP = transP; d.hmmTrans = hmmTrans; d.hmmStateOff = hmmStateOff; d.hmmState = hmmState;
+   d.numStreams = NSt; d.dimStream = NSt > 1 ? S.dimStream : NULL; d.streamWeight = NSt > 1 ? sweight : NULL;
    amd_check(htkamd_model_create(&d, &S.model), "htkamd_model_create");
    amd_check(htkamd_model_set_prepared(S.model, ivar, gconst, logwt), "htkamd_model_set_prepared");   /* HVite ran ConvDiagC (HVite.c:503) */
    free(weight); free(logwt); free(mean); free(var); free(ivar); free(gconst); free(transP); free(stateCompOff); free(compGauss);
-   free(transN); free(transOff); free(hmmTrans); free(hmmStateOff); free(hmmState); free(hmmOf); free(ste); free(mix); free(towner);
+   free(transN); free(transOff); free(hmmTrans); free(hmmStateOff); free(hmmState); free(hmmOf); free(ste); free(mix); free(towner); free(gStr); free(sweight);
    pm_free(&sm); pm_free(&gm); pm_free(&tm);
 }
 
@@ -256,7 +276,11 @@ void __wrap_ProcessObservation(VRecInfo *vri, Observation *obs, int id, AdaptXFo
    (void)id;
    if (xform != NULL) HError(7399, "ProcessObservation: input transforms are not supported");
    if (S.nX + (size_t)S.D > S.capX) { S.capX = (S.capX + (size_t)S.D) * 2 + 4096; S.X = (float *)realloc(S.X, sizeof(float) * S.capX); }
-   for (k = 1; k <= S.D; k++) S.X[S.nX++] = obs->fv[1][k];
+   if (S.NSt <= 1) for (k = 1; k <= S.D; k++) S.X[S.nX++] = obs->fv[1][k];
+   else {                                                  /* the undivided row back from the stream vectors */
+      int at[SMAX] = {0};
+      for (k = 0; k < S.D; k++) { const int st = S.dimStream[k]; S.X[S.nX++] = obs->fv[st + 1][++at[st]]; }
+   }
    vri->frame++;
 }
 

@@ -3,7 +3,7 @@
 (cPOutP HRec.c:510-548 / POutP HModel.c:5570-5583: outp += w[s] * SOutP_s, float).  The demo's 3-stream set after one pass of HERest
 (tests/golden/demo/hmm_streams3/after_herest), once as it is (weights 1) and once with <SWEIGHTS> 1.0 0.5 2.0 in every state, through
 the reference's HVite:
-    rec    recognition of the test and training files with the demo's loop lattice (-t 300.0 -p 5.0 -s 0.0), with -m -f
+    rec    recognition of the test and training files with the demo's loop lattice (-t 300.0 -p 5.0 -s 0.0), with -m -f; recw: without
     align  forced alignment of the training files (-a -m -f) from their label files
     tests/golden/demo/hmm_streams3/hvite_expected.json, sw_after_herest (the re-weighted set)
     python tests/golden/make_streams_hvite_golden.py"""
@@ -30,6 +30,7 @@ if __name__ == "__main__":
         for name in ("after_herest", "sw_after_herest"):
             per = {}
             for what, files, opts in (("rec", test + train, ["-w", os.path.join(DEMO, "monLattice"), "-t", "300.0", "-p", "5.0", "-s", "0.0", "-m", "-f"]),
+                                      ("recw", test + train, ["-w", os.path.join(DEMO, "monLattice"), "-t", "300.0", "-p", "5.0", "-s", "0.0"]),
                                       ("align", train, ["-a", "-m", "-f", "-L", os.path.join(DEMO, "labels"), "-t", "300.0"])):
                 od = os.path.join(d, name + "_" + what); os.makedirs(od)
                 subprocess.run([os.path.join(REF, "HVite"), "-C", cfg, "-H", os.path.join(d3, name), "-l", od] + opts + [os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + files,

@@ -99,6 +99,25 @@ def test_reference_herest_front_end_runs_its_e_step_on_the_gpu(native, tmp_path)
         assert np.allclose(lin(gt), lin(rt), rtol=1e-4, atol=1e-7), name
 
 
+@pytest.mark.gpu
+@needs_exe
+def test_reference_herest_front_end_on_a_three_stream_set(native, tmp_path):
+    """The reference's HERest.o over the shim on a multi-stream set (tests/golden/demo/hmm_streams3): the shim packs every StreamElem,
+    hands the library undivided rows, and adds the statistics back per stream; the front-end's own UpdateModels then writes the model the
+    reference's HERest writes."""
+    import test_cli_tools as cli
+    d3 = os.path.join(DEMO, "hmm_streams3")
+    conf = tmp_path / "herest.conf"
+    conf.write_text("TARGETKIND = MFCC_E_D\n")
+    files = sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    r = subprocess.run([EXE, "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d3, "newMacros"), "-M", str(tmp_path),
+                        "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + files, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    for line in open(os.path.join(d3, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-600:])
+    cli._mmf_close(cli._mmf_numbers(str(tmp_path / "newMacros")), cli._mmf_numbers(os.path.join(d3, "after_herest")))
+
+
 # ---------------------------------------------------------------------------------------------------------------- HVite
 HVITE = os.path.join(ROOT, "oracle", "_ref", "HVite_amd")
 needs_hvite = pytest.mark.skipif(not os.path.exists(HVITE), reason="oracle/_ref/HVite_amd not built (needs /root/reference: make -C oracle)")
@@ -149,6 +168,27 @@ def test_reference_hvite_front_end_recognises_on_the_gpu(tmp_path):
             assert got == expected[part][u], (part, u, got[:3], expected[part][u][:3])
             n += len(got)
     assert n == 292
+
+
+@pytest.mark.gpu
+@needs_hvite
+@pytest.mark.parametrize("name", ["after_herest", "sw_after_herest"])
+def test_reference_hvite_front_end_on_a_three_stream_set(tmp_path, name):
+    """The reference's HVite.o over the recogniser shim on a multi-stream set, stream weights 1 1 1 and 1 0.5 2: the label files of the
+    reference's own HVite (tests/golden/make_streams_hvite_golden.py), word-level recognition."""
+    import json
+    d3 = os.path.join(DEMO, "hmm_streams3")
+    exp = json.load(open(os.path.join(d3, "hvite_expected.json")))[name]
+    conf = tmp_path / "hvite.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    path = lambda u: os.path.join(DEMO, "test" if u.startswith("te") else "train", u + ".mfc")
+    for what, opts in (("recw", ["-w", os.path.join(DEMO, "monLattice"), "-t", "300.0", "-p", "5.0", "-s", "0.0"]),):       # word level: what this shim serves
+        out = tmp_path / what; out.mkdir()
+        names = sorted(exp[what])
+        r = subprocess.run([HVITE, "-C", str(conf), "-H", os.path.join(d3, name), "-l", str(out)] + opts + [os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] +
+                           [path(u) for u in names], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+        for u in names:
+            assert (out / (u + ".rec")).read_text().splitlines() == exp[what][u], (what, u)
 
 
 @pytest.mark.gpu
