@@ -416,6 +416,38 @@ def test_hvite_cli_word_level_alignment(native, tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hvite_cli_alignment_beam_retries_and_numeric_arguments(native, tools, tmp_path):
+    """`-t f i l` (HVite.c:308-322): alignment retries a file with beams f, f+i, .. while no token reaches the final node (DoAlignment
+    :900-913) -- against the reference's HVite run beside it; and the optional numbers of -t / -n are taken only when the WHOLE next argument
+    is a number (NextArg() == INTARG / FLOATARG), so a dictionary called `3dict` stays a dictionary."""
+    import shutil
+    ref = os.path.join(ROOT, "oracle", "_ref", "HVite")
+    conf = tmp_path / "hvite.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    files = demo_train_files()
+    base = ["-C", str(conf), "-d", os.path.join(DEMO, "hmm_final"), "-a", "-m", "-L", os.path.join(DEMO, "labels")]
+    for beam in (["-t", "15.0", "20.0", "200.0"], ["-t", "15.0", "20.0", "40.0"], ["-t", "150.0"]):
+        ours = tmp_path / ("o" + "_".join(beam[1:])); ours.mkdir()
+        r = run([os.path.join(tools, "hvite")] + base + beam + ["-l", str(ours), os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + files)
+        assert r.returncode == 0, r.stderr
+        if not os.path.exists(ref):
+            continue
+        theirs = tmp_path / ("r" + "_".join(beam[1:])); theirs.mkdir()
+        rr = subprocess.run([ref] + base + beam + ["-l", str(theirs), os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + files, capture_output=True, text=True)
+        assert rr.returncode == 0, rr.stdout + rr.stderr
+        got, exp = sorted(os.listdir(str(ours))), sorted(os.listdir(str(theirs)))
+        assert got == exp and (len(exp) == len(files) or beam[-1] == "40.0"), (beam, got, exp)
+        for f in exp:
+            assert (ours / f).read_text() == (theirs / f).read_text(), (beam, f)
+    # a dictionary whose name starts with a digit, right after -n 2 and after -t 300.0
+    shutil.copy(os.path.join(DEMO, "bcpvocab"), str(tmp_path / "3dict"))
+    out = tmp_path / "n"; out.mkdir()
+    r = run([os.path.join(tools, "hvite"), "-C", str(conf), "-d", os.path.join(DEMO, "hmm_final"), "-w", os.path.join(DEMO, "monLattice"), "-l", str(out), "-t", "300.0", "-n", "2",
+             str(tmp_path / "3dict").replace(str(tmp_path), "."), os.path.join(DEMO, "bcplist")] + [os.path.join(DEMO, "test", "te1.mfc")], cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert (out / "te1.rec").exists()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fmt,src", [("WAV", "test.wav"), ("HTK", "test.htk")])
 def test_cli_tools_code_waveform_sources_on_the_device(native, tools, tmp_path, fmt, src):
     """BASELINE config[4] through the drivers: SOURCEFORMAT = WAV (or SOURCEKIND = WAVEFORM on an HTK waveform file) + TARGETKIND =

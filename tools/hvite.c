@@ -94,6 +94,29 @@ static void emit(htkamd_trans *tr, const htkamd_net *net, const htkamd_mmf *mmf,
    free(segS); free(segE); free(modS); free(modE); free(segSc); free(modSc); free(chain); free(wordOfQ);
 }
 
+/* HShell's argument classes (NextArg, HShell.c:1158-1200): an argument is a number when the whole of it parses as one; *isInt: no
+   fraction, no exponent */
+static int is_number(const char *s, int *isInt)
+{
+   const char *p = s;
+   int digits = 0, frac = 0;
+   if (*p == '+' || *p == '-') p++;
+   while (isdigit((unsigned char)*p)) { p++; digits++; }
+   if (*p == '.') { frac = 1; p++; while (isdigit((unsigned char)*p)) { p++; digits++; } }
+   if (!digits) return 0;
+   if (*p == 'e' || *p == 'E') {
+      const char *q = p + 1;
+      int ed = 0;
+      if (*q == '+' || *q == '-') q++;
+      while (isdigit((unsigned char)*q)) { q++; ed++; }
+      if (!ed) return 0;
+      frac = 1; p = q;
+   }
+   if (*p) return 0;
+   if (isInt) *isInt = !frac;
+   return 1;
+}
+
 int main(int argc, char **argv)
 {
    args a = {argc, 1, argv};
@@ -101,6 +124,7 @@ int main(int argc, char **argv)
    strlist mmfs = {0}, files = {0};
    const char *hmmDir = NULL, *hmmExt = NULL, *netPath = NULL, *labDir = NULL, *labExt = "lab", *mlfIn = NULL, *mlfOut = NULL, *outDir = NULL, *outExt = "rec", *boundary = NULL;
    float genBeam = 0.0f, wordBeam = 0.0f, lmScale = 1.0f, wordPen = 0.0f, prScale = 1.0f;
+   float genBeamInc = 0.0f, genBeamLim = 0.0f;             /* -t f [i l]: alignment retries a file with wider beams (HVite.c:308-322, 900-913) */
    int align = 0, models = 0, states = 0, oflags = 0, trace = 0, scoreMode = HTKAMD_SCORE_EXACT, batchN = 1024, maxActive = 0;
    int nToks = 0, nTrans = 1, latFmt = 0;
    const char *latExt = NULL;
@@ -141,7 +165,16 @@ int main(int argc, char **argv)
       case 'm': models = 1; break;
       case 'f': states = 1; break;
       case 'o': oflags = out_flags(str_arg(&a, sw)); break;
-      case 't': genBeam = (float)flt_arg(&a, sw); break;
+      case 't':                                             /* -t f [i l] (HVite.c:308-322): the two further values only when the next argument IS a number */
+         genBeam = (float)flt_arg(&a, sw);
+         genBeamInc = 0.0f; genBeamLim = genBeam;
+         if (a.at < a.argc && is_number(a.argv[a.at], NULL)) {
+            genBeamInc = (float)flt_arg(&a, sw);
+            if (!(a.at < a.argc && is_number(a.argv[a.at], NULL))) DIE("hvite -t: f [i l] -- the limit is missing");
+            genBeamLim = (float)flt_arg(&a, sw);
+            if (genBeamLim < genBeam + genBeamInc) { genBeamLim = genBeam; genBeamInc = 0.0f; }
+         }
+         break;
       case 'v': wordBeam = (float)flt_arg(&a, sw); break;
       case 's': lmScale = (float)flt_arg(&a, sw); break;
       case 'p': wordPen = (float)flt_arg(&a, sw); break;
@@ -149,7 +182,8 @@ int main(int argc, char **argv)
       case 'u': maxActive = atoi(str_arg(&a, sw)); break;
       case 'n':                                              /* -n i [N]: i tokens per state, N-best transcriptions (HVite.c:287-291) */
          nToks = atoi(str_arg(&a, sw));
-         if (a.at < a.argc && isdigit((unsigned char)a.argv[a.at][0]) && a.at + 2 < a.argc) nTrans = atoi(a.argv[a.at++]);
+         { int isInt = 0;                                   /* NextArg() == INTARG (HVite.c:289): the WHOLE argument is an integer */
+           if (a.at < a.argc && is_number(a.argv[a.at], &isInt) && isInt) nTrans = atoi(a.argv[a.at++]); }
          break;
       case 'z': latExt = str_arg(&a, sw); break;
       case 'q':
@@ -274,13 +308,25 @@ int main(int argc, char **argv)
       float *wScore = (float *)malloc(sizeof(float) * (size_t)count * maxWords), *wLm = (float *)malloc(sizeof(float) * (size_t)count * maxWords);
       double *total = (double *)malloc(sizeof(double) * (size_t)count);
       CHECK(htkamd_decoder_run(udec, &dc, ob.dX, ob.frameOff, count, maxWords, nWords, wPron, wStart, wEnd, wScore, wLm, total, NULL));
+      float usedBeam = dc.genBeam;
+      if (align && genBeamInc > 0.0f) {                       /* DoAlignment's retries (HVite.c:900-913): wider beams while nothing reaches the final node */
+         htkamd_decode_config dr = dc;
+         float cur = dc.genBeam + genBeamInc;
+         while (nWords[0] < 0 && cur <= genBeamLim - genBeamInc) {
+            if (trace & 1) printf("No tokens survived to final node of network at beam %.1f\n", cur - genBeamInc);
+            dr.genBeam = usedBeam = cur;
+            CHECK(htkamd_decoder_run(udec, &dr, ob.dX, ob.frameOff, count, maxWords, nWords, wPron, wStart, wEnd, wScore, wLm, total, NULL));
+            cur += genBeamInc;
+         }
+         if (nWords[0] < 0) { dr.genBeam = usedBeam = cur; CHECK(htkamd_decoder_run(udec, &dr, ob.dX, ob.frameOff, count, maxWords, nWords, wPron, wStart, wEnd, wScore, wLm, total, NULL)); }
+      }
       for (int u = 0; u < count; u++) {
          const char *fn = files.v[first + u];
          const int T = ob.frameOff[u + 1] - ob.frameOff[u];
          if (nWords[u] < 0) { fprintf(stderr, "No tokens survived to final node of network: %s\n", fn); continue; }
          htkamd_trans *tr; CHECK(htkamd_trans_create((models ? 1 : 0) + (states ? 1 : 0), &tr));
          emit(tr, unet, mmf, vit, ob.dX, D, ob.frameOff[u], T, nWords[u], wPron + (size_t)u * maxWords, wStart + (size_t)u * maxWords, wEnd + (size_t)u * maxWords,
-              wScore + (size_t)u * maxWords, wLm + (size_t)u * maxWords, (double)ob.period, models, states, lmScale, wordPen, dc.genBeam);
+              wScore + (size_t)u * maxWords, wLm + (size_t)u * maxWords, (double)ob.period, models, states, lmScale, wordPen, usedBeam);
          CHECK(htkamd_trans_format(tr, (double)ob.period, states, models, oflags));
          char out[2048];
          make_fn(fn, outDir, outExt, out, sizeof(out));
