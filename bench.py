@@ -373,10 +373,53 @@ def main():
     ktimes = np.zeros(5)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        pr, st, st_upd, kk = em_iteration(True)
+    # The timed iterations, host side pipelined: the update is queued in two halves (htkamd_model_update_device_begin / _end) and the NEXT
+    # iteration's pass is queued behind its kernels before the host waits for the few bytes the update sends back (transition matrices for
+    # the minimum durations, counters) -- the launches of an iteration are issued while the previous one still runs.  Same device work in
+    # the same order as em_iteration(); should an update change a minimum duration, the pass queued on the old batch tables is repeated.
+    def launch_pass(k, timed):
+        accs.zero(sptr)
+        ev_zero.record(stream)
+        for c, ch in enumerate(chunks):
+            ln = lanes[c % len(lanes)]
+            ln.wait_event(ev_zero)
+            if not (ch["ready"][k] and ch["fbs"][k].prepared_current()):
+                prep(ch, k, ln.cuda_stream)
+                n_reprepared[0] += int(timed)
+            ch["fbs"][k].execute(cfg, accs, ln.cuda_stream)
+            ev_chunk[c].record(ln)
+        for c in range(NCH):
+            stream.wait_event(ev_chunk[c])
+
+    def collect(k):
+        prs, sts = zip(*[ch["fbs"][k].results(sptr) for ch in chunks])
+        kt = np.zeros(5)
         for ch in chunks:
-            ktimes += np.array(ch["fbs"][kk].kernel_times5())                   # per kernel: summed over the iteration's chunks
+            kt += np.array(ch["fbs"][k].kernel_times5())                       # per kernel: summed over the iteration's chunks
+        return np.concatenate(prs), np.concatenate(sts), kt
+
+    pending, prev_k = False, None
+    for i in range(args.steps):
+        kk = it_no[0] & 1
+        it_no[0] += 1
+        launch_pass(kk, True)
+        if pending:
+            st_upd = model.update_device_end()
+            if not all(ch["fbs"][kk].prepared_current() for ch in chunks):      # a minimum duration changed under the pass just queued
+                stream.synchronize()
+                launch_pass(kk, True)
+            pr, st, kt = collect(prev_k)
+            ktimes += kt
+        for ch in chunks:                                                      # next iteration's tables, on a stream of their own
+            prep(ch, kk ^ 1, copy_stream.cuda_stream)
+        if world > 1:
+            herest.all_reduce_accumulators(acc_t)
+        model.update_device_begin(accs, stream=sptr, **upd)
+        pending, prev_k = True, kk
+    if pending:
+        st_upd = model.update_device_end()
+        pr, st, kt = collect(prev_k)
+        ktimes += kt
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:

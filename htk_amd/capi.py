@@ -199,6 +199,23 @@ class Model:
         check(lib().htkamd_model_update_device(self.h, accs.h, C.byref(cfg), C.byref(st), _stream(stream)), "model_update_device")
         return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
 
+    def update_device_begin(self, accs: "Accs", minEgs=3, minVar=0.0, mixWeightFloor=0.0, uFlags=UPALL, singleProcess=False, varFloor=None,
+                            rowNormalise=False, stream=None):
+        """First half of update_device: every launch and the copy of what the host needs, no wait (htkamd_model_update_device_begin)."""
+        vf = None
+        if varFloor is not None:
+            vf = np.ascontiguousarray(varFloor, np.float32)
+            assert vf.shape == (self.D,)
+        cfg = UpdateConfig(minEgs, minVar, mixWeightFloor, uFlags, int(singleProcess),
+                           vf.ctypes.data_as(C.POINTER(C.c_float)) if vf is not None else None, int(rowNormalise), 0.0, 0.0)
+        check(lib().htkamd_model_update_device_begin(self.h, accs.h, C.byref(cfg), _stream(stream)), "model_update_device_begin")
+
+    def update_device_end(self):
+        """Second half: waits for the update's copy only and returns the counters (htkamd_model_update_device_end)."""
+        st = UpdateStats()
+        check(lib().htkamd_model_update_device_end(self.h, C.byref(st)), "model_update_device_end")
+        return {n: getattr(st, n) for n, _ in UpdateStats._fields_}
+
     def get_params(self) -> dict:
         k = self._keep
         out = dict(mean=np.empty((self.G, self.D), np.float32), var=np.empty((self.G, self.D), np.float32),

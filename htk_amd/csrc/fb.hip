@@ -141,6 +141,7 @@ struct htkamd_fb {
    int recCapForce;                         // > 0: capacity of the record list (tests: forces the overflow path)
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
+   void *h_res; size_t h_resCap;            // pinned staging copy of the results (one D2H transfer per htkamd_fb_results)
    hipEvent_t ev[6], evK[2], evCopy;          // ev: stream intervals (score | beta | alpha | left-to-right statistics | mixture statistics); evK: the scoring dispatch's own start/stop
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending, scored;
@@ -152,7 +153,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
    fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->alphaWTotal = 0; fb->noStatePath = 0; fb->noLrPath = 0; fb->recCapForce = 0; for (int c = 0; c < 14; c++) fb->clsOff[c] = 0;
-   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
+   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->h_res = nullptr; fb->h_resCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 6; i++) fb->ev[i] = nullptr;
    fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
    fb->evValid = true;                                   // destroy releases whatever has been created (null handles are skipped)
@@ -179,6 +180,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
                     &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
+   if (fb->h_res) (void)hipHostFree(fb->h_res);
    delete fb->pool; delete fb->chunks;
    if (fb->evValid) {
       for (int i = 0; i < 6; i++) if (fb->ev[i]) (void)hipEventDestroy(fb->ev[i]);
@@ -494,6 +496,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       if (total == 0) total = 256;
       if (total > fb->h_arenaCap) {
          if (fb->h_arena) (void)hipHostFree(fb->h_arena);
+   if (fb->h_res) (void)hipHostFree(fb->h_res);
          fb->h_arena = nullptr; fb->h_arenaCap = 0;
          const size_t want = total + total / 4;
          HIPCHECK(hipHostMalloc(&fb->h_arena, want, hipHostMallocDefault));
@@ -517,8 +520,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * ((beta && !wavePathPrep) ? beta : 1))) ||
-       (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve(sizeof(double) * (U ? U : 1))) ||
-       (rc = fb->d_status.reserve(sizeof(int) * (U ? U : 1))) ||
+       (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve((sizeof(double) + sizeof(int)) * (size_t)(U ? U : 1))) ||      /* log probabilities, then the status words: ONE copy brings both back */
        (fb->m->NSt > 1 && (rc = fb->d_outpU.reserve(sizeof(float) * (outp * fb->m->NSt + 16)))) ||
        (fb->m->tiedMix && ((rc = fb->d_tmE.reserve(sizeof(float) * (nf * fb->m->tmPool + 16))) || (rc = fb->d_tmMaxP.reserve(sizeof(float) * (nf * fb->m->NSt + 16))))))
       return rc;
@@ -570,7 +572,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.qLo = (short *)fb->d_qLo.p; fa.qHi = (short *)fb->d_qHi.p; fa.aLo = (short *)fb->d_aLo.p; fa.aHi = (short *)fb->d_aHi.p;
    fa.X = fb->dX; fa.transP = m->d_transP; fa.outp = (float *)fb->d_outp.p;
    fa.beta = (double *)fb->d_beta.p; fa.gam = (double *)fb->d_gam.p; fa.alphaDbg = fb->debug ? (double *)fb->d_alpha.p : nullptr;
-   fa.pr = (double *)fb->d_pr.p; fa.status = (int *)fb->d_status.p;
+   fa.pr = (double *)fb->d_pr.p; fa.status = (int *)((double *)fb->d_pr.p + fb->nUtt);
    fa.stateCompOff = m->d_stateCompOff; fa.compGauss = m->d_compGauss;
    fa.NSt = m->NSt; fa.outpU = (const float *)fb->d_outpU.p; fa.dimStream = m->d_dimStream;
    fa.transOff = (const int *)fb->d_transOff.p; fa.trOccOff = (const int *)fb->d_trOccOff.p;
@@ -687,17 +689,25 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    if (!fb) { htkamd_set_error("fb_results: NULL"); return HTKAMD_EINVAL; }
    hipStream_t s = (hipStream_t)stream;
    if (fb->nUtt == 0) return HTKAMD_OK;
+   // log probabilities and status words lie in one device buffer and come back in one copy through a pinned staging buffer
+   const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt;
+   if (bytes > fb->h_resCap) {
+      if (fb->h_res) (void)hipHostFree(fb->h_res);
+      fb->h_res = nullptr; fb->h_resCap = 0;
+      HIPCHECK(hipHostMalloc(&fb->h_res, bytes + bytes / 4, hipHostMallocDefault));
+      fb->h_resCap = bytes + bytes / 4;
+   }
    if (fb->timed) {
       // wait for THIS batch's last kernel only (work queued on the stream afterwards, e.g. the next batch, keeps running)
       HIPCHECK(hipEventSynchronize(fb->ev[5]));
-      if (pr) HIPCHECK(hipMemcpyAsync(pr, fb->d_pr.p, sizeof(double) * fb->nUtt, hipMemcpyDeviceToHost, fb->resStream));
-      if (status) HIPCHECK(hipMemcpyAsync(status, fb->d_status.p, sizeof(int) * fb->nUtt, hipMemcpyDeviceToHost, fb->resStream));
+      HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, fb->resStream));
       HIPCHECK(hipStreamSynchronize(fb->resStream));
-      return HTKAMD_OK;
+   } else {
+      HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
    }
-   if (pr) HIPCHECK(hipMemcpyAsync(pr, fb->d_pr.p, sizeof(double) * fb->nUtt, hipMemcpyDeviceToHost, s));
-   if (status) HIPCHECK(hipMemcpyAsync(status, fb->d_status.p, sizeof(int) * fb->nUtt, hipMemcpyDeviceToHost, s));
-   HIPCHECK(hipStreamSynchronize(s));
+   if (pr) memcpy(pr, fb->h_res, sizeof(double) * (size_t)fb->nUtt);
+   if (status) memcpy(status, (const char *)fb->h_res + sizeof(double) * (size_t)fb->nUtt, sizeof(int) * (size_t)fb->nUtt);
    return HTKAMD_OK;
 }
 

@@ -73,6 +73,8 @@ struct htkamd_model {
    float *d_var, *d_compWeight;
    int   *d_trOccOff, *d_hmmTrans, *d_hmmStateOff, *d_hmmState;
    void  *d_updScratch; size_t updScratchCap;
+   void  *evUpd; int updPending;  /* htkamd_model_update_device_begin .. _end: the event behind the update's copy */
+   void  *h_updPin;            /* pinned: transition matrices + the 16 counters of a device update, one D2H copy */
    int    topoVersion;         /* bumped whenever a minimum duration (hence tee-ness) of a transition matrix changes: batch tables
                                   prepared before that (htkamd_fb_prepare) no longer describe the model */
    void  *obRing;              /* task-table ring of htkamd_outp_block (gmm_exact.hip) */

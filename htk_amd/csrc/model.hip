@@ -191,6 +191,7 @@ static int model_refresh(htkamd_model *m, bool derive = true)
    if ((rc = toDevice(&m->d_ivar, m->h_ivar, (size_t)m->G * D))) return rc;
    if ((rc = toDevice(&m->d_gconst, m->h_gconst, (size_t)m->G))) return rc;
    if ((rc = toDevice(&m->d_compLogWt, m->h_compLogWt, (size_t)m->C))) return rc;
+   if (!m->d_transP) HIPCHECK(hipMalloc((void **)&m->d_transP, sizeof(float) * ((size_t)m->h_transOff[m->nT] + 16)));      // + the device update's 16 counters: one copy brings both back (update.hip)
    if ((rc = toDevice(&m->d_transP, m->h_transP, (size_t)m->h_transOff[m->nT]))) return rc;
    if (m->d_var && ((rc = toDevice(&m->d_var, m->h_var, (size_t)m->G * D)) || (rc = toDevice(&m->d_compWeight, m->h_compWeight, (size_t)m->C)))) return rc;
    return mfma_refresh(m);
@@ -354,6 +355,8 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);
    free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize); (void)hipFree(m->d_shareTab);
+   if (m->h_updPin) (void)hipHostFree(m->h_updPin);
+   if (m->evUpd) (void)hipEventDestroy((hipEvent_t)m->evUpd);
    free(m->h_tmPoolOff); (void)hipFree(m->d_tmPoolOff); free(m->h_streamWt); (void)hipFree(m->d_streamWt);
    free(m->h_dimStream); free(m->h_gaussStream); (void)hipFree(m->d_dimStream); (void)hipFree(m->d_gaussStream); (void)hipFree(m->d_msCompOff);
    free(m);

@@ -331,6 +331,12 @@ __global__ void k_upd_mfma(MfmaTabArgs a, int nTiles)
       }
 }
 
+// the update's counters behind the transition matrices, so that one copy brings both to the host
+__global__ void k_upd_export(const int *stats, int *dst)
+{
+   if (threadIdx.x < 16) dst[threadIdx.x] = stats[threadIdx.x];
+}
+
 int htkamd_model_refresh_mfma_device(htkamd_model *m, void *stream)
 {
    hipStream_t s = (hipStream_t)stream;
@@ -345,7 +351,10 @@ int htkamd_model_refresh_mfma_device(htkamd_model *m, void *stream)
    return HTKAMD_OK;
 }
 
-extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, htkamd_update_stats *stats, void *stream)
+// The update in two halves, so that a host loop can queue the next pass behind the update's kernels BEFORE it waits for the few bytes the update
+// sends back (transition matrices for the minimum durations, counters): begin = every launch + the copy, recorded in an event; end = wait for
+// that event (not for the stream) and fold the copy into the host tables.  htkamd_model_update_device = begin + end.
+extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, void *stream)
 {
    if (!m || !accs || !cfg) { htkamd_set_error("model_update_device: NULL argument"); return HTKAMD_EINVAL; }
    if (accs->m != m) { htkamd_set_error("model_update_device: accumulators belong to a different model"); return HTKAMD_EINVAL; }
@@ -420,11 +429,25 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    m->hostStale = 1;
    // the transition matrices are small and the host needs them (minimum durations for CreateInsts, tee flags for the decoder)
    const size_t nTp = (size_t)m->h_transOff[m->nT];
-   int hst[16];
-   HIPCHECK(hipMemcpyAsync(m->h_transP, m->d_transP, sizeof(float) * nTp, hipMemcpyDeviceToHost, s));
-   HIPCHECK(hipMemcpyAsync(hst, a.stats, sizeof(hst), hipMemcpyDeviceToHost, s));
-   HIPCHECK(hipStreamSynchronize(s));
+   if (!m->h_updPin) HIPCHECK(hipHostMalloc(&m->h_updPin, sizeof(float) * (nTp + 16), hipHostMallocDefault));
+   if (!m->evUpd) { hipEvent_t e; HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->evUpd = (void *)e; }
+   hipLaunchKernelGGL(k_upd_export, dim3(1), dim3(64), 0, s, a.stats, (int *)(m->d_transP + nTp));
+   HIPCHECK(hipMemcpyAsync(m->h_updPin, m->d_transP, sizeof(float) * (nTp + 16), hipMemcpyDeviceToHost, s));
+   HIPCHECK(hipEventRecord((hipEvent_t)m->evUpd, s));
    free(scanPosHost);
+   m->updPending = 1;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_update_device_end(htkamd_model *m, htkamd_update_stats *stats)
+{
+   if (!m || !m->updPending) { htkamd_set_error("model_update_device_end: no update in flight"); return HTKAMD_EINVAL; }
+   m->updPending = 0;
+   HIPCHECK(hipEventSynchronize((hipEvent_t)m->evUpd));
+   const size_t nTp = (size_t)m->h_transOff[m->nT];
+   int hst[16];
+   memcpy(m->h_transP, m->h_updPin, sizeof(float) * nTp);
+   memcpy(hst, (const float *)m->h_updPin + nTp, sizeof(hst));
    for (int t = 0; t < m->nT; t++) {
       const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
       if (md != m->h_minDur[t]) { m->h_minDur[t] = md; m->topoVersion++; }
@@ -437,4 +460,10 @@ extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, co
    }
    if (hst[6] > 0) { htkamd_set_error("model_update_device: %d mixture weights above 1.001 (HERest: HError 2393)", hst[6]); return HTKAMD_EMODEL; }
    return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, htkamd_update_stats *stats, void *stream)
+{
+   const int rc = htkamd_model_update_device_begin(m, accs, cfg, stream);
+   return rc ? rc : htkamd_model_update_device_end(m, stats);
 }

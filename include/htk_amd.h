@@ -383,6 +383,13 @@ int htkamd_model_update(htkamd_model *m, const htkamd_accs *accs, const double *
    read -- 1/variance, the interleaved scoring rows, log weights, the matrix-core fragment table -- is rebuilt in place.
    Arithmetic as htkamd_model_update; `stats` may be NULL.  Synchronises `stream` before returning. */
 int htkamd_model_update_device(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, htkamd_update_stats *stats, void *stream);
+/* The same in two halves for a host loop that wants the next pass queued behind the update's kernels before it waits: _begin launches
+   everything and the copy of the transition matrices + counters and returns; _end waits for that copy only (an event, not the stream) and
+   folds it into the host tables.  Between the two the host tables are the OLD ones: a pass queued in between runs on the new parameters
+   (stream order) with batch tables prepared for the old minimum durations -- after _end, htkamd_fb_prepared_current tells whether that
+   pass has to be repeated (a minimum duration changed: rare).  One update in flight per model. */
+int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *accs, const htkamd_update_config *cfg, void *stream);
+int htkamd_model_update_device_end(htkamd_model *m, htkamd_update_stats *stats);
 /* Current parameters (DIAGC variances, linear weights, log transitions); any pointer may be NULL. */
 int htkamd_model_get_params(htkamd_model *m, float *mean, float *var, float *gconst, float *compWeight, float *transP);
 
