@@ -221,10 +221,13 @@ __global__ void k_upd_gauss_elem(UpdArgs a)
    const bool live = idx0 < (size_t)a.G * D;
    const unsigned int idx = live ? (unsigned int)idx0 : 0u;          // G * D < 2^31 (checked by the launcher): 32-bit index arithmetic
    const int g = (int)(idx / (unsigned int)D), k = (int)(idx - (unsigned int)g * (unsigned int)D);
+   // every load of the thread issued before the first use: the kernel is one round trip to memory deep, not four
    float v = a.var[idx], mu = a.mean[idx];
+   const double dMu = a.acc[a.lay.mu + idx], dVa = a.acc[a.lay.va + idx], dMuOcc = a.acc[a.lay.muOcc + g], dVaOcc = a.acc[a.lay.vaOcc + g];
+   const unsigned char qual = a.qualG[g], any = a.anyG[g];
    bool floored = false;
    const bool outside = OUTSIDE(g, k);
-   if (a.singleProcess && a.anyG[g] && !outside) {           // ConvDiagC before the pass, ForceDiagC after it
+   if (a.singleProcess && any && !outside) {                 // ConvDiagC before the pass, ForceDiagC after it
       float iv;
       if (v > 1E+30f) v = 1E+30f;
       if (v < 1E-30f) v = 1E-30f;
@@ -233,20 +236,20 @@ __global__ void k_upd_gauss_elem(UpdArgs a)
       if (iv < 1E-30f) iv = 1E-30f;
       v = 1 / iv;
    }
-   if (a.qualG[g] && !outside) {
-      const float muOcc = ACCF(a.lay.muOcc, g);
+   if (qual && !outside) {
+      const float muOcc = (float)dMuOcc;
       if (a.uFlags & HTKAMD_UPVARS) {
-         const float occim = ACCF(a.lay.vaOcc, g);
+         const float occim = (float)dVaOcc;
          if (occim > 0.0f) {
             const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0f;
-            const float muDiffk = shared ? 0.0f : ACCF(a.lay.mu, idx) / muOcc;
-            float x = ACCF(a.lay.va, idx) / occim - muDiffk * muDiffk;
+            const float muDiffk = shared ? 0.0f : (float)dMu / muOcc;
+            float x = (float)dVa / occim - muDiffk * muDiffk;
             const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
             if (x < fl) { x = fl; floored = live; }
             v = x;
          } else if (k == 0 && live) atomicAdd(a.stats + 5, 1);
       }
-      if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mu += ACCF(a.lay.mu, idx) / muOcc;
+      if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mu += (float)dMu / muOcc;
    }
    {  // floored elements: one atomic per wavefront
       const unsigned long long fb = __ballot(floored);

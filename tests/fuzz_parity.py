@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HIP path against the oracle (run on the GPU box; not part of the test-suite because of its
 run time): forward-backward (pr, beams, accumulators) with random topologies / pruning / ragged batches, forced alignment
-with random beams, network decoding over random word networks.   python tests/fuzz_parity.py [iterations] [seed]"""
+with random beams, network decoding over random word networks; multi-stream and tied-mixture sets.   python tests/fuzz_parity.py [iterations] [seed]"""
 import os
 import sys
 import tempfile
@@ -91,6 +91,98 @@ def fuzz_fb(rng, it):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)             # keep the case for a closer look
         pickle.dump(dict(pk=pk, utts=utts, prune=prune, extra=extra, general=general, mode=mode, bad=bad),
                     open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_fb_%d.pkl" % it), "wb"))
+    return not bad
+
+
+def _random_widths(rng, D):
+    S = int(rng.integers(2, 5))
+    cuts = sorted(rng.choice(np.arange(1, D), size=S - 1, replace=False).tolist())
+    return [b - a for a, b in zip([0] + cuts, cuts + [D])]
+
+
+def _as_tied_mixture(pk, rng):
+    """every (state, stream) lists its stream's pool (the components of state 0) with weights of its own"""
+    NS, S = int(pk.get("numStreams", 1) or 1), int(pk["numStates"])
+    sco, cg = np.asarray(pk["stateCompOff"]), np.asarray(pk["compGauss"])
+    pools = [cg[sco[k]:sco[k + 1]] for k in range(NS)]
+    pools = [p if len(p) > 1 else np.concatenate([p, cg[sco[NS + k]:sco[NS + k] + 1]]) for k, p in enumerate(pools)]      # a pool holds >= 2 Gaussians
+    off, wt, ncg = [0], [], []
+    for s_ in range(S):
+        for k in range(NS):
+            w = rng.random(len(pools[k])).astype(np.float32) + 0.05
+            if rng.random() < 0.3:
+                w[int(rng.integers(0, len(w)))] = 0.0                    # a pruned entry
+            w /= w.sum()
+            wt += list(w); ncg += list(pools[k]); off.append(len(wt))
+    out = dict(pk)
+    used = np.unique(np.concatenate(pools))
+    remap = -np.ones(int(pk["numGauss"]), np.int64); remap[used] = np.arange(len(used))
+    out.update(hsKind=1, stateCompOff=np.array(off, np.int32), compWeight=np.array(wt, np.float32), compGauss=remap[np.array(ncg)].astype(np.int32),
+               mean=np.asarray(pk["mean"]).reshape(int(pk["numGauss"]), -1)[used], var=np.asarray(pk["var"]).reshape(int(pk["numGauss"]), -1)[used],
+               gconst=None, numComp=len(wt), numGauss=len(used))
+    return out
+
+
+def fuzz_streams(rng, it):
+    """Multi-stream and tied-mixture sets against the oracle: random stream widths, streams of one and of several
+    components, tied-mixture pools, every recursion path, pruning, update flags."""
+    import streams_util as su
+    D = int(rng.choice([8, 13, 20, 26]))
+    if rng.random() < 0.5:
+        pk, names, seqs, feats = synth.make_topo_set(seed=int(rng.integers(1, 10**6)), D=D, NU=int(rng.integers(2, 6)))
+    else:
+        s = synth.generate(int(rng.integers(8, 30)), 1, int(rng.integers(6, 20)), int(rng.integers(2, 6)), int(rng.integers(30, 120)), int(rng.integers(1, 10**6)), D=D)
+        pk, seqs, feats = s.packed(), s.seqs, s.feats
+    kind = rng.choice(["ms", "ms", "tm1", "tmS"])
+    if kind != "tm1":
+        widths = _random_widths(rng, D)
+        single = tuple(k for k in range(len(widths)) if rng.random() < 0.3)
+        pk = su.make_multistream(pk, widths, rng, max_mix=int(rng.integers(1, 6)), single=single)
+    else:
+        pk = dict(pk)
+    if kind.startswith("tm"):
+        if kind == "tm1":                                            # one stream: give the states mixtures first
+            pk = su.make_multistream(pk, [D], rng, max_mix=int(rng.integers(2, 7)))
+            pk["numStreams"] = 1; pk["dimStream"] = None
+            pk["var"] = np.where(np.isfinite(pk["var"]), pk["var"], 1.0)
+        pk = _as_tied_mixture(pk, rng)
+    prune = {}
+    if rng.random() < 0.4:
+        prune = dict(pruneInit=float(rng.uniform(30, 200)), pruneInc=0.0, pruneLim=0.0); prune["pruneLim"] = prune["pruneInit"]
+    extra = {}
+    if rng.random() < 0.3:
+        extra["minFrwdP"] = float(rng.choice([5.0, 20.0]))
+    if rng.random() < 0.3:
+        extra["uFlags"] = int(rng.integers(1, 16))
+    path = rng.choice(["state", "wave", "general"])
+    model = capi.Model(pk); om = pyoracle.Model(pk, ms_intended=True)
+    utts = [dict(seq=np.asarray(q, np.int32), feat=x[: max(3, len(x) - int(rng.integers(0, 6)))]) for q, x in zip(seqs, feats)]
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = capi.DevArray(X)
+    fb = capi.ForwardBackward(model, debug=False, force_general=(path == "general"), no_state_path=(path == "wave"))
+    acc = capi.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+    fb.execute(capi.fb_config(**prune, **extra), acc)
+    pr, st = fb.results()
+    a = acc.download()
+    oacc = pyoracle.Accs(om)
+    bad, aborted = [], False
+    for u, ut in enumerate(utts):
+        rc, opr, _ = pyoracle.fb_utt(om, pyoracle.fb_cfg(**prune, **extra), ut["feat"], ut["seq"], oacc)
+        aborted |= rc == -7390
+        if (st[u] == 1) != (rc == 1):
+            bad.append("status u%d gpu %d oracle rc %d" % (u, st[u], rc))
+        elif rc == 1 and abs(pr[u] - opr) > 1e-7 * abs(opr):
+            bad.append("pr u%d %r vs %r" % (u, pr[u], opr))
+    for k in ("muOcc", "vaOcc", "wtOcc", "trOcc", "tr", "wt"):
+        e = 0.0 if aborted else rel(a[k], getattr(oacc, k))
+        if e > 1e-4:
+            bad.append("%s rel %.3g" % (k, e))
+    if bad:
+        print("STREAMS it %d kind=%s path=%s prune=%s extra=%s: %s" % (it, kind, path, prune, extra, "; ".join(bad)))
+        import pickle
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        pickle.dump(dict(pk=pk, utts=utts, prune=prune, extra=extra, path=str(path), bad=bad), open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_streams_%d.pkl" % it), "wb"))
     return not bad
 
 
@@ -327,9 +419,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     tmp = tempfile.mkdtemp()
-    res = dict(fb=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0], quals=[0, 0], herest=[0, 0])
+    res = dict(fb=[0, 0], streams=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0], quals=[0, 0], herest=[0, 0])
     for it in range(n):
-        for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp)),
+        for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("streams", lambda: fuzz_streams(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp)),
                          ("mfcc", lambda: fuzz_mfcc(rng, it)), ("quals", lambda: fuzz_quals(rng, it)), ("herest", lambda: fuzz_herest_cli(rng, it, tmp))):
             try:
                 ok = fn()
