@@ -37,6 +37,7 @@ struct UpdArgs {
    unsigned char *qualT, *qualS, *qualG, *anyS, *anyG;      // marked by a qualifying model / used by any model
    unsigned char *flooredG;                                 // a variance element of the Gaussian was floored
    int *stats;                                              // htkamd_update_stats fields in order + [6] weights above 1.001
+   float *logVar;                                           // [G*D] log of the new variances (k_upd_gauss_elem) for k_upd_gconst's sum; NULL: tied sets
    // sets with tied mean / variance vectors (~u ~v; htkamd_model_set_sharing), else tied == 0
    int tied;
    const int *meanLeader, *varLeader, *varGroupSize, *muMemOff, *vaMemOff, *muMem, *vaMem, *scanPos;
@@ -214,75 +215,126 @@ __global__ void k_upd_gauss_elem_tied(UpdArgs a)
 
 // Variances and means, one thread per (Gaussian, dimension): every array is walked in storage order (coalesced), the per-Gaussian
 // quantities (marks, occupancies) are broadcast loads.
-__global__ void k_upd_gauss_elem(UpdArgs a)
+__global__ __launch_bounds__(256) void k_upd_gauss_elem(UpdArgs a)
 {
-   const size_t idx0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+   // four consecutive elements per thread: the parameter arrays move as 16-byte words (the kernel was ~1 TB/s of 4- and 8-byte accesses)
+   const unsigned int nEl = (unsigned int)a.G * (unsigned int)a.D;      // < 2^31 (checked by the launcher)
+   const unsigned int i0 = ((unsigned int)blockIdx.x * blockDim.x + threadIdx.x) * 4u;
    const int D = a.D;
-   const bool live = idx0 < (size_t)a.G * D;
-   const unsigned int idx = live ? (unsigned int)idx0 : 0u;          // G * D < 2^31 (checked by the launcher): 32-bit index arithmetic
-   const int g = (int)(idx / (unsigned int)D), k = (int)(idx - (unsigned int)g * (unsigned int)D);
-   // every load of the thread issued before the first use: the kernel is one round trip to memory deep, not four
-   float v = a.var[idx], mu = a.mean[idx];
-   const double dMu = a.acc[a.lay.mu + idx], dVa = a.acc[a.lay.va + idx], dMuOcc = a.acc[a.lay.muOcc + g], dVaOcc = a.acc[a.lay.vaOcc + g];
-   const unsigned char qual = a.qualG[g], any = a.anyG[g];
-   bool floored = false;
-   const bool outside = OUTSIDE(g, k);
-   if (a.singleProcess && any && !outside) {                 // ConvDiagC before the pass, ForceDiagC after it
-      float iv;
-      if (v > 1E+30f) v = 1E+30f;
-      if (v < 1E-30f) v = 1E-30f;
-      iv = 1 / v;
-      if (iv > 1E+30f) iv = 1E+30f;
-      if (iv < 1E-30f) iv = 1E-30f;
-      v = 1 / iv;
+   const bool any4 = i0 < nEl;
+   const bool full = i0 + 3u < nEl;
+   float v[4], mu[4], r[4];
+   double dMu[4], dVa[4];
+   int g[4], k[4];
+   bool live[4], floored[4];
+   if (full) {
+      const float4 v4 = *(const float4 *)(a.var + i0), m4 = *(const float4 *)(a.mean + i0);
+      v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w; mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
    }
-   if (qual && !outside) {
-      const float muOcc = (float)dMuOcc;
-      if (a.uFlags & HTKAMD_UPVARS) {
-         const float occim = (float)dVaOcc;
-         if (occim > 0.0f) {
-            const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0f;
-            const float muDiffk = shared ? 0.0f : (float)dMu / muOcc;
-            float x = (float)dVa / occim - muDiffk * muDiffk;
-            const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
-            if (x < fl) { x = fl; floored = live; }
-            v = x;
-         } else if (k == 0 && live) atomicAdd(a.stats + 5, 1);
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      const unsigned int idx = (i0 + j < nEl) ? i0 + j : 0u;
+      live[j] = i0 + j < nEl;
+      g[j] = (int)(idx / (unsigned int)D); k[j] = (int)(idx - (unsigned int)g[j] * (unsigned int)D);
+      if (!full) { v[j] = a.var[idx]; mu[j] = a.mean[idx]; }
+      dMu[j] = a.acc[a.lay.mu + idx]; dVa[j] = a.acc[a.lay.va + idx];
+      floored[j] = false;
+   }
+   // per-Gaussian quantities: the four elements lie in one Gaussian or in two
+   const double oMu0 = a.acc[a.lay.muOcc + g[0]], oVa0 = a.acc[a.lay.vaOcc + g[0]], oMu3 = a.acc[a.lay.muOcc + g[3]], oVa3 = a.acc[a.lay.vaOcc + g[3]];
+   const unsigned char q0 = a.qualG[g[0]], q3 = a.qualG[g[3]], an0 = a.anyG[g[0]], an3 = a.anyG[g[3]];
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      const bool lo = g[j] == g[0];                           // D >= 4 is not assumed: a third Gaussian in between is read on its own
+      const bool hi = g[j] == g[3];
+      const double dMuOcc = lo ? oMu0 : hi ? oMu3 : a.acc[a.lay.muOcc + g[j]], dVaOcc = lo ? oVa0 : hi ? oVa3 : a.acc[a.lay.vaOcc + g[j]];
+      const unsigned char qual = lo ? q0 : hi ? q3 : a.qualG[g[j]], any = lo ? an0 : hi ? an3 : a.anyG[g[j]];
+      const bool outside = OUTSIDE(g[j], k[j]);
+      float vv = v[j], mm = mu[j];
+      if (a.singleProcess && any && !outside) {              // ConvDiagC before the pass, ForceDiagC after it
+         float iv;
+         if (vv > 1E+30f) vv = 1E+30f;
+         if (vv < 1E-30f) vv = 1E-30f;
+         iv = 1 / vv;
+         if (iv > 1E+30f) iv = 1E+30f;
+         if (iv < 1E-30f) iv = 1E-30f;
+         vv = 1 / iv;
       }
-      if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mu += (float)dMu / muOcc;
+      if (qual && !outside) {
+         const float muOcc = (float)dMuOcc;
+         if (a.uFlags & HTKAMD_UPVARS) {
+            const float occim = (float)dVaOcc;
+            if (occim > 0.0f) {
+               const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0f;
+               const float muDiffk = shared ? 0.0f : (float)dMu[j] / muOcc;
+               float x = (float)dVa[j] / occim - muDiffk * muDiffk;
+               const float fl = a.hasVarFloor ? a.varFloor[k[j]] : a.minVar;
+               if (x < fl) { x = fl; floored[j] = live[j]; }
+               vv = x;
+            } else if (k[j] == 0 && live[j]) atomicAdd(a.stats + 5, 1);
+         }
+         if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mm += (float)dMu[j] / muOcc;
+      }
+      v[j] = vv; mu[j] = mm;
+      // derived tables: ConvDiagC (HUtil.c:413) and the interleaved row of the exact scoring kernel
+      float c = vv;
+      if (c > 1E+30f) c = 1E+30f;
+      if (c < 1E-30f) c = 1E-30f;
+      r[j] = outside ? 0.0f : 1 / c;
    }
    {  // floored elements: one atomic per wavefront
-      const unsigned long long fb = __ballot(floored);
-      if (fb && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)fb) - 1)) atomicAdd(a.stats + 0, __popcll(fb));
-      if (floored) a.flooredG[g] = 1;
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { cnt += __popcll(__ballot(floored[j])); if (floored[j]) a.flooredG[g[j]] = 1; }
+      if (cnt && (threadIdx.x & 63) == 0) atomicAdd(a.stats + 0, cnt);
    }
-   if (!live) return;
-   a.var[idx] = v; a.mean[idx] = mu;
-   // derived tables: ConvDiagC (HUtil.c:413) and the interleaved row of the exact scoring kernel
-   float c = v;
-   if (c > 1E+30f) c = 1E+30f;
-   if (c < 1E-30f) c = 1E-30f;
-   const float r = outside ? 0.0f : 1 / c;
-   a.ivar[idx] = r;
-   float *gp = a.gparam + (size_t)g * a.PS;
-   gp[2 * k] = mu; gp[2 * k + 1] = r;
+   if (!any4) return;
+   // the terms of gConst (FixDiagGConst HModel.c:5641: log evaluated in double, rounded to float) where this kernel has ALU time to spare
+   float z[4];
+#pragma unroll
+   for (int j = 0; j < 4; j++) z[j] = ((double)v[j] <= MINLARG) ? (float)LZERO : (float)log((double)v[j]);
+   if (full) {
+      *(float4 *)(a.var + i0) = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4 *)(a.mean + i0) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+      *(float4 *)(a.ivar + i0) = make_float4(r[0], r[1], r[2], r[3]);
+      *(float4 *)(a.logVar + i0) = make_float4(z[0], z[1], z[2], z[3]);
+   }
+#pragma unroll
+   for (int j = 0; j < 4; j++) {
+      if (!live[j]) continue;
+      if (!full) { a.var[i0 + j] = v[j]; a.mean[i0 + j] = mu[j]; a.ivar[i0 + j] = r[j]; a.logVar[i0 + j] = z[j]; }
+      *(float2 *)(a.gparam + (size_t)g[j] * a.PS + 2 * k[j]) = make_float2(mu[j], r[j]);
+   }
 }
 
 // gConst, one thread per Gaussian: the float sum over the dimensions runs in the reference's order (FixDiagGConst HModel.c:5641)
-__global__ void k_upd_gconst(UpdArgs a)
+__global__ __launch_bounds__(128) void k_upd_gconst(UpdArgs a)
 {
-   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-   if (g >= a.G) return;
+   // the block's rows of log variances through LDS: read in storage order, summed by one thread per Gaussian in the reference's order
+   extern __shared__ float lvRows[];                        // [128][D] when a.logVar is there
+   const int g0 = blockIdx.x * blockDim.x, g = g0 + threadIdx.x;
    const int D = a.D;
-   if (a.flooredG[g]) atomicAdd(a.stats + 1, 1);
+   if (a.logVar) {
+      const int nG = (a.G - g0 < (int)blockDim.x) ? a.G - g0 : (int)blockDim.x;
+      const float *src = a.logVar + (size_t)g0 * D;
+      for (int i = threadIdx.x; i < nG * D; i += blockDim.x) lvRows[i] = src[i];
+      __syncthreads();
+   }
+   if (g >= a.G) return;
+   int flooredCnt = a.flooredG[g] ? 1 : 0;
+   {  // one atomic per wavefront
+      const unsigned long long fb = __ballot(flooredCnt != 0);
+      if (fb && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)fb) - 1)) atomicAdd(a.stats + 1, __popcll(fb));
+   }
    if (a.qualG[g] && (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))) {
       const float *var = a.var + (size_t)g * D;
       int n = D;
       if (a.dimStream) { n = 0; for (int k = 0; k < D; k++) if (!OUTSIDE(g, k)) n++; }
       float sum = (float)((double)n * a.logTpi);
+      const float *lv = a.logVar ? lvRows + (size_t)threadIdx.x * D : nullptr;
       for (int k = 0; k < D; k++) {
          if (OUTSIDE(g, k)) continue;
-         const float z = ((double)var[k] <= MINLARG) ? (float)LZERO : (float)log((double)var[k]);
+         const float z = lv ? lv[k] : (((double)var[k] <= MINLARG) ? (float)LZERO : (float)log((double)var[k]));
          sum += z;
       }
       a.gconst[g] = sum;
@@ -368,7 +420,9 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
    const size_t nFlag = (size_t)m->nT + 2 * (size_t)m->S + 3 * (size_t)m->G;
    const bool tied = m->h_meanLeader != nullptr;
    const size_t nTiedInts = tied ? 2 * (size_t)m->G + (size_t)m->H : 0;           // firstMu[G] firstVa[G] scanPos[H]
-   const size_t need = ((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int) + sizeof(float) * (size_t)m->D + sizeof(int) * nTiedInts;
+   const size_t nLog = tied ? 0 : (((size_t)m->G * m->D + 3) & ~(size_t)3);            // k_upd_gauss_elem's log variances (16-byte aligned block at the end)
+   const size_t headBytes = (((nFlag + 63) & ~(size_t)63) + 16 * sizeof(int) + sizeof(float) * (size_t)m->D + sizeof(int) * nTiedInts + 255) & ~(size_t)255;
+   const size_t need = headBytes + sizeof(float) * nLog;
    if (need > m->updScratchCap) {
       if (m->d_updScratch) (void)hipFree(m->d_updScratch);
       m->d_updScratch = nullptr; m->updScratchCap = 0;
@@ -390,6 +444,7 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
    a.minVar = cfg->minVar; a.mixWeightFloor = cfg->mixWeightFloor; a.logTpi = log(HTK_TPI);
    a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G; a.flooredG = a.anyG + m->G;
    a.stats = (int *)(fl + ((nFlag + 63) & ~(size_t)63));
+   a.logVar = tied ? nullptr : (float *)(fl + headBytes);
    float *dFloor = (float *)(a.stats + 16);
    a.hasVarFloor = cfg->varFloor != nullptr; a.varFloor = dFloor;
    if (cfg->varFloor) HIPCHECK(hipMemcpyAsync(dFloor, cfg->varFloor, sizeof(float) * (size_t)m->D, hipMemcpyHostToDevice, s));
@@ -422,9 +477,13 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
          hipLaunchKernelGGL(k_upd_first, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
          hipLaunchKernelGGL(k_upd_gauss_elem_tied, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
       } else
-         hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
+         hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 1023) / 1024)), dim3(256), 0, s, a);
    }
-   hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), 0, s, a);
+   {
+      UpdArgs ag = a;
+      if (sizeof(float) * (size_t)B * m->D > 48 * 1024) ag.logVar = nullptr;          // rows too long for the LDS staging: the kernel takes the logs itself
+      hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), ag.logVar ? sizeof(float) * (size_t)B * m->D : 0, s, ag);
+   }
    HIPCHECK(hipGetLastError());
    // the bf16 x 3 fragment table now; the fp32 one when the fp32 matrix-core kernel is next asked for (htkamd_launch_score_mfma)
    m->mfmaStale = 1;
