@@ -496,7 +496,6 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       if (total == 0) total = 256;
       if (total > fb->h_arenaCap) {
          if (fb->h_arena) (void)hipHostFree(fb->h_arena);
-   if (fb->h_res) (void)hipHostFree(fb->h_res);
          fb->h_arena = nullptr; fb->h_arenaCap = 0;
          const size_t want = total + total / 4;
          HIPCHECK(hipHostMalloc(&fb->h_arena, want, hipHostMallocDefault));

@@ -265,7 +265,8 @@ int htkamd_stats_write_file(const htkamd_model_desc *d, const double *vec, const
       for (const char *p = names[h]; *p && n < 1000; p++) { if (*p == '"' || *p == '\\') buf[n++] = '\\'; buf[n++] = *p; }
       buf[n++] = '"'; buf[n] = 0;
       fprintf(f, "%4d %14s %4d ", k + 1, buf, (int)(vec[lay.nEgs + h] + 0.5));
-      for (int j = 0; j < N - 2; j++) fprintf(f, " %10f", (float)vec[lay.wtOcc + d->hmmState[d->hmmStateOff[h] + j]]);
+      const int NS = d->numStreams > 1 ? d->numStreams : 1;
+      for (int j = 0; j < N - 2; j++) fprintf(f, " %10f", (float)vec[lay.wtOcc + (size_t)d->hmmState[d->hmmStateOff[h] + j] * NS]);      /* the first stream's WtAcc (PrintStats HERest.c:690) */
       fprintf(f, "\n");
    }
    free(order);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Multi-stream sets (<STREAMINFO> S > 1) through the reference: its HHEd splits the demo's 3-mixture monophones into streams
 (SS 3 -> 12 | 12 | 2 with the energy terms as the last stream; SS 2 -> 13 | 13), its HERest makes one embedded pass.
-    tests/golden/demo/hmm_streams3/  newMacros (the set), after_herest (re-estimated), HER1.acc (`-p 1` accumulators), herest.log
+    tests/golden/demo/hmm_streams3/  newMacros (the set), after_herest (re-estimated), HER1.acc (`-p 1` accumulators), herest.log, stats (`-s`)
     tests/golden/demo/hmm_streams2/  newMacros, HER1.acc, herest.log
 S = 3 is the one stream count for which HFB.c's Setotprob is consistent: on meeting a tied state for the second time at a frame it
 takes `sum/2` of the streams' REPLACED values (HFB.c:1044,1059-1064) = (S-1)/2 times the state's log probability.  The S = 2 fixture
@@ -29,7 +29,8 @@ if __name__ == "__main__":
             base = [os.path.join(REF, "HERest"), "-C", cfg, "-w", "3", "-v", "0.05", "-u", "tmvw", "-H", os.path.join(out, "newMacros"),
                     "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", "-T", "1"]
             os.makedirs(os.path.join(d, "next")); os.makedirs(os.path.join(d, "acc"))
-            log = subprocess.run(base + ["-M", os.path.join(d, "next"), os.path.join(DEMO, "bcplist")] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+            log = subprocess.run(base + ["-s", os.path.join(d, "stats"), "-M", os.path.join(d, "next"), os.path.join(DEMO, "bcplist")] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+            shutil.copy(os.path.join(d, "stats"), os.path.join(out, "stats"))
             subprocess.run(base + ["-M", os.path.join(d, "acc"), "-p", "1", os.path.join(DEMO, "bcplist")] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True)
             if S == 3:
                 shutil.copy(os.path.join(d, "next", "newMacros"), os.path.join(out, "after_herest"))

@@ -125,11 +125,16 @@ def test_herest_cli_three_streams(native, tmp_path):
     out = tmp_path / "next"; out.mkdir()
     d = os.path.join(DEMO, "hmm_streams3")
     r = cli.run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d, "newMacros"), "-M", str(out),
-                 "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
+                 "-s", str(tmp_path / "stats"), "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
     assert r.returncode == 0, r.stderr
     for line in open(os.path.join(d, "herest.log")).read().splitlines():
         assert line in r.stdout, (line, r.stdout[-400:])
     cli._mmf_close(cli._mmf_numbers(str(out / "newMacros")), cli._mmf_numbers(os.path.join(d, "after_herest")))
+    # the occupation statistics file: the first stream's WtAcc per state (PrintStats HERest.c:680-695)
+    ours, theirs = (tmp_path / "stats").read_text().split(), open(os.path.join(d, "stats")).read().split()
+    assert len(ours) == len(theirs)
+    for x, y in zip(ours, theirs):
+        assert x == y or abs(float(x) - float(y)) <= 1e-4 * max(abs(float(y)), 1.0), (x, y)
     # parallel mode: the accumulator file of this run is the reference's to the float
     acc = tmp_path / "acc"; acc.mkdir()
     r = cli.run([os.path.join(tools, "herest"), "-p", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d, "newMacros"), "-M", str(acc),
