@@ -387,6 +387,7 @@ def main():
                 prep(ch, k, ln.cuda_stream)
                 n_reprepared[0] += int(timed)
             ch["fbs"][k].execute(cfg, accs, ln.cuda_stream)
+            ch["fbs"][k].results_begin(ln.cuda_stream)                          # the results' copy in stream order behind the pass
             ev_chunk[c].record(ln)
         for c in range(NCH):
             stream.wait_event(ev_chunk[c])
@@ -399,23 +400,32 @@ def main():
         return np.concatenate(prs), np.concatenate(sts), kt
 
     pending, prev_k = False, None
+    host_trace = os.environ.get("BENCH_HOST_TRACE")
     for i in range(args.steps):
         kk = it_no[0] & 1
         it_no[0] += 1
+        th = [time.perf_counter()]
         launch_pass(kk, True)
+        th.append(time.perf_counter())
         if pending:
             st_upd = model.update_device_end()
+            th.append(time.perf_counter())
             if not all(ch["fbs"][kk].prepared_current() for ch in chunks):      # a minimum duration changed under the pass just queued
                 stream.synchronize()
                 launch_pass(kk, True)
             pr, st, kt = collect(prev_k)
             ktimes += kt
-        for ch in chunks:                                                      # next iteration's tables, on a stream of their own
-            prep(ch, kk ^ 1, copy_stream.cuda_stream)
+            th.append(time.perf_counter())
         if world > 1:
             herest.all_reduce_accumulators(acc_t)
         model.update_device_begin(accs, stream=sptr, **upd)
         pending, prev_k = True, kk
+        th.append(time.perf_counter())
+        for ch in chunks:                                                      # next iteration's tables while this one runs: the other context (its pass
+            prep(ch, kk ^ 1, copy_stream.cuda_stream)                          # is over: update_device_end waited for it), uploaded on a stream of their own
+        th.append(time.perf_counter())
+        if host_trace and rank == 0:
+            print("host it %d:" % i, " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(th, th[1:])), file=sys.stderr)
     if pending:
         st_upd = model.update_device_end()
         pr, st, kt = collect(prev_k)

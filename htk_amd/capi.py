@@ -326,6 +326,10 @@ class ForwardBackward:
     def execute(self, cfg: FbConfig, accs: Accs, stream=None):
         check(lib().htkamd_fb_execute(self.h, C.byref(cfg), accs.h, _stream(stream)), "fb_execute")
 
+    def results_begin(self, stream=None):
+        """Queue the copy of the results behind the pass on its stream (htkamd_fb_results_begin); results() then only waits for it."""
+        check(lib().htkamd_fb_results_begin(self.h, _stream(stream)), "fb_results_begin")
+
     def results(self, stream=None):
         pr = np.empty(self.nUtt, np.float64); st = np.empty(self.nUtt, np.int32)
         check(lib().htkamd_fb_results(self.h, _p(pr), _p(st), _stream(stream)), "fb_results")

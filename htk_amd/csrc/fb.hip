@@ -142,6 +142,7 @@ struct htkamd_fb {
    PrepPool *pool; std::vector<PrepChunk> *chunks;   // host workers and their reusable share buffers
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
    void *h_res; size_t h_resCap;            // pinned staging copy of the results (one D2H transfer per htkamd_fb_results)
+   hipEvent_t evRes; bool resPending;       // htkamd_fb_results_begin: the event behind the queued copy
    hipEvent_t ev[6], evK[2], evCopy;          // ev: stream intervals (score | beta | alpha | left-to-right statistics | mixture statistics); evK: the scoring dispatch's own start/stop
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending, scored;
@@ -153,7 +154,7 @@ extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
    if (m->maxM > 4096) { htkamd_set_error("fb_create: %d mixture components per state not supported", m->maxM); return HTKAMD_EMODEL; }
    htkamd_fb *fb = new htkamd_fb();
    fb->m = m; fb->nUtt = 0; fb->debug = 0; fb->forceGeneral = 0; fb->evValid = false; fb->timed = false; fb->copyPending = false; fb->scored = false; fb->lastWave = false; fb->betaWTotal = 0; fb->alphaWTotal = 0; fb->noStatePath = 0; fb->noLrPath = 0; fb->recCapForce = 0; for (int c = 0; c < 14; c++) fb->clsOff[c] = 0;
-   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->h_res = nullptr; fb->h_resCap = 0; fb->pool = nullptr; fb->chunks = nullptr;
+   fb->outpTotal = fb->betaTotal = fb->gamTotal = 0; fb->frameStates = 0; fb->dX = nullptr; fb->h_arena = nullptr; fb->h_arenaCap = 0; fb->h_res = nullptr; fb->h_resCap = 0; fb->evRes = nullptr; fb->resPending = false; fb->pool = nullptr; fb->chunks = nullptr;
    for (int i = 0; i < 6; i++) fb->ev[i] = nullptr;
    fb->evK[0] = fb->evK[1] = fb->evCopy = nullptr; fb->resStream = nullptr;
    fb->evValid = true;                                   // destroy releases whatever has been created (null handles are skipped)
@@ -185,6 +186,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    if (fb->evValid) {
       for (int i = 0; i < 6; i++) if (fb->ev[i]) (void)hipEventDestroy(fb->ev[i]);
       if (fb->evCopy) (void)hipEventDestroy(fb->evCopy);
+      if (fb->evRes) (void)hipEventDestroy(fb->evRes);
       if (fb->evK[0]) (void)hipEventDestroy(fb->evK[0]);
       if (fb->evK[1]) (void)hipEventDestroy(fb->evK[1]);
       if (fb->resStream) (void)hipStreamDestroy(fb->resStream);
@@ -683,6 +685,35 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    return HTKAMD_OK;
 }
 
+static int res_staging(htkamd_fb *fb, size_t bytes)
+{
+   if (bytes > fb->h_resCap) {
+      if (fb->h_res) (void)hipHostFree(fb->h_res);
+      fb->h_res = nullptr; fb->h_resCap = 0;
+      HIPCHECK(hipHostMalloc(&fb->h_res, bytes + bytes / 4, hipHostMallocDefault));
+      fb->h_resCap = bytes + bytes / 4;
+   }
+   return HTKAMD_OK;
+}
+
+// The copy of the results queued on `stream` (the stream of htkamd_fb_execute: it then follows the pass's last kernel in stream order and
+// needs no scheduling of its own) and recorded in an event; htkamd_fb_results afterwards only waits for that event.  For host loops that
+// queue the next pass before they look at this one's results.
+extern "C" int htkamd_fb_results_begin(htkamd_fb *fb, void *stream)
+{
+   if (!fb) { htkamd_set_error("fb_results_begin: NULL"); return HTKAMD_EINVAL; }
+   if (fb->nUtt == 0) return HTKAMD_OK;
+   hipStream_t s = (hipStream_t)stream;
+   const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt;
+   int rc = res_staging(fb, bytes);
+   if (rc) return rc;
+   if (!fb->evRes) HIPCHECK(hipEventCreateWithFlags(&fb->evRes, hipEventDisableTiming));
+   HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, s));
+   HIPCHECK(hipEventRecord(fb->evRes, s));
+   fb->resPending = true;
+   return HTKAMD_OK;
+}
+
 extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *stream)
 {
    if (!fb) { htkamd_set_error("fb_results: NULL"); return HTKAMD_EINVAL; }
@@ -690,20 +721,21 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    if (fb->nUtt == 0) return HTKAMD_OK;
    // log probabilities and status words lie in one device buffer and come back in one copy through a pinned staging buffer
    const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt;
-   if (bytes > fb->h_resCap) {
-      if (fb->h_res) (void)hipHostFree(fb->h_res);
-      fb->h_res = nullptr; fb->h_resCap = 0;
-      HIPCHECK(hipHostMalloc(&fb->h_res, bytes + bytes / 4, hipHostMallocDefault));
-      fb->h_resCap = bytes + bytes / 4;
-   }
-   if (fb->timed) {
-      // wait for THIS batch's last kernel only (work queued on the stream afterwards, e.g. the next batch, keeps running)
-      HIPCHECK(hipEventSynchronize(fb->ev[5]));
-      HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, fb->resStream));
-      HIPCHECK(hipStreamSynchronize(fb->resStream));
+   if (fb->resPending) {                                    // htkamd_fb_results_begin queued the copy behind the pass
+      fb->resPending = false;
+      HIPCHECK(hipEventSynchronize(fb->evRes));
    } else {
-      HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
+      int rc = res_staging(fb, bytes);
+      if (rc) return rc;
+      if (fb->timed) {
+         // wait for THIS batch's last kernel only (work queued on the stream afterwards, e.g. the next batch, keeps running)
+         HIPCHECK(hipEventSynchronize(fb->ev[5]));
+         HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, fb->resStream));
+         HIPCHECK(hipStreamSynchronize(fb->resStream));
+      } else {
+         HIPCHECK(hipMemcpyAsync(fb->h_res, fb->d_pr.p, bytes, hipMemcpyDeviceToHost, s));
+         HIPCHECK(hipStreamSynchronize(s));
+      }
    }
    if (pr) memcpy(pr, fb->h_res, sizeof(double) * (size_t)fb->nUtt);
    if (status) memcpy(status, (const char *)fb->h_res + sizeof(double) * (size_t)fb->nUtt, sizeof(int) * (size_t)fb->nUtt);

@@ -443,6 +443,9 @@ int  htkamd_fb_prepared_current(const htkamd_fb *fb);
 int  htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream);
 /* Waits for the stream and copies per-utterance log-probabilities (utt->pr) and status. */
 int  htkamd_fb_results(htkamd_fb *fb, double *pr /*[nUtt]*/, int *status /*[nUtt]*/, void *stream);
+/* For host loops that queue the next pass before they read this one's results: the copy of the results queued on `stream` (the stream
+   htkamd_fb_execute ran on) right behind the pass; htkamd_fb_results then only waits for that copy. */
+int  htkamd_fb_results_begin(htkamd_fb *fb, void *stream);
 /* Number of (frame, chain-state) output-probability evaluations the reference would perform
    for the prepared batch without pruning (Setotprob visits) -- the unit of the throughput metric. */
 long long htkamd_fb_frame_states(const htkamd_fb *fb);
