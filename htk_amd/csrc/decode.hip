@@ -412,7 +412,6 @@ static float like_to_word(const htkamd_net_desc *nd, const htkamd_model *m, cons
 extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd, float lmScale, htkamd_decoder **out)
 {
    if (!m || !nd || !out) { htkamd_set_error("decoder_create: NULL argument"); return HTKAMD_EINVAL; }
-   if (m->tiedMix) { htkamd_set_error("decoder_create: tied-mixture sets are served by the forward-backward pass only"); return HTKAMD_EMODEL; }
    const int nN = nd->nNodes;
    std::vector<int> kind(nd->kind, nd->kind + nN), model(nd->model, nd->model + nN), tok0(nN), nodeN(nN, 2), nodeTp(nN, 0), nodeSt(nN, 0), wordIdx(nN, -1), hmmNodes;
    std::vector<float> pron(nd->pronProb, nd->pronProb + nN), wdlk(nN, (float)LZERO);
@@ -602,6 +601,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
          sa.NSt = m->NSt; sa.streamWt = m->d_streamWt;
          if (m->NSt > 1 && cfg->scoreMode != HTKAMD_SCORE_EXACT) { htkamd_set_error("decoder_run: multi-stream sets are scored in the exact mode only"); rc = HTKAMD_EINVAL; }
+         else if (m->tiedMix) rc = htkamd_tm_score_block(m, sa, frameOff[u1], m->tmBeam, s);
          else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);   // exact: the decoded path is the reference's; matrix-core modes: tolerance class
       }

@@ -513,6 +513,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
          sa.NSt = m->NSt; sa.streamWt = m->d_streamWt;
          if (m->NSt > 1 && cfg->scoreMode != HTKAMD_SCORE_EXACT) { htkamd_set_error("decoder_run_lattice: multi-stream sets are scored in the exact mode only"); rc = HTKAMD_EINVAL; }
+         else if (m->tiedMix) rc = htkamd_tm_score_block(m, sa, frameOff[u1], m->tmBeam, s);
          else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run_lattice: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);
       }

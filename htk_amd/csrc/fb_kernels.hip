@@ -19,6 +19,7 @@
 // with whole waves, recomputing the per-component likelihoods only for the ~2% of (frame,state)
 // pairs that survive the prune.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <cstdlib>
 #include "internal.h"
 #include "hipcheck.h"
@@ -1231,16 +1232,21 @@ __global__ __launch_bounds__(SCORE_TILE_FRAMES) void k_tm_state(FbArgs a)
       if (f >= tk.nFrames) continue;
       const size_t row = (size_t)tk.frame0 + f;
       for (int k = 0; k < tk.nSlots; k++) {
-         const int e = a.tmSlotState[tk.slot0 + k], ks = e % a.NSt;
-         const int c0 = a.stateCompOff[e], p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
-         const float *E = a.tmE + row * a.tmPool + p0, *w = a.compWeight + c0;
-         double sum = 0.0;
-         for (int m = 0; m < M; m++) {
-            const float ev = E[m];
-            if (ev >= 0.0f) sum += (double)(ev * w[m]);
+         const int e0 = a.tmSlotState[tk.slot0 + k];
+         float total = 0.0f, xs = 0.0f;
+         for (int kk = 0; kk < (a.tmCombine ? a.NSt : 1); kk++) {
+            const int e = e0 + kk, ks = e % a.NSt;
+            const int c0 = a.stateCompOff[e], p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
+            const float *E = a.tmE + row * a.tmPool + p0, *w = a.compWeight + c0;
+            double sum = 0.0;
+            for (int m = 0; m < M; m++) {
+               const float ev = E[m];
+               if (ev >= 0.0f) sum += (double)(ev * w[m]);
+            }
+            xs = (sum >= MINLARG) ? (float)(log(sum) + (double)a.tmMaxP[row * a.NSt + ks]) : (float)LZERO;
+            if (a.tmCombine && a.NSt > 1) { const float wx = a.streamWt[e] * xs; total = total + wx; }      // cPOutP: float product, float sum
          }
-         const float xs = (sum >= MINLARG) ? (float)(log(sum) + (double)a.tmMaxP[row * a.NSt + ks]) : (float)LZERO;
-         a.tmOut[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + f] = xs;
+         a.tmOut[tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + f] = (a.tmCombine && a.NSt > 1) ? total : xs;
       }
    }
 }
@@ -1252,6 +1258,27 @@ int htkamd_launch_tm_score(const FbArgs &a, hipStream_t s)
    hipLaunchKernelGGL(k_tm_state, dim3((unsigned)(a.tmNTasks < 65535 ? a.tmNTasks : 65535)), dim3(SCORE_TILE_FRAMES), 0, s, a);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
+}
+
+int htkamd_tm_score_block(const htkamd_model *m, const ScoreArgs &sa, int nRows, float tmBeam, hipStream_t s)
+{
+   if (nRows <= 0 || sa.nTasks <= 0) return HTKAMD_OK;
+   FbArgs a;
+   memset(&a, 0, sizeof(a));
+   float *tmE = nullptr, *tmMaxP = nullptr;
+   HIPCHECK(hipMalloc((void **)&tmE, sizeof(float) * ((size_t)nRows * m->tmPool + 16)));
+   hipError_t e = hipMalloc((void **)&tmMaxP, sizeof(float) * ((size_t)nRows * m->NSt + 16));
+   if (e != hipSuccess) { (void)hipFree(tmE); htkamd_set_error("tm_score_block: hipMalloc: %s", hipGetErrorString(e)); return HTKAMD_ENOMEM; }
+   a.X = sa.X; a.D = m->D; a.PS = m->PS; a.gparam = m->d_gparam; a.mean = m->d_mean; a.var = m->d_var; a.compGauss = m->d_compGauss; a.stateCompOff = m->d_stateCompOff;
+   a.dimStream = m->d_dimStream; a.NSt = m->NSt; a.tmE = tmE; a.tmMaxP = tmMaxP; a.tmPoolOff = m->d_tmPoolOff; a.tmPool = m->tmPool; a.totalFrames = nRows;
+   a.minFrwdP = tmBeam;                                   // PrecomputeTMix's tmThresh: HVite -c (HVite.c:115,255), HRec.c:1987
+   a.tmTasks = sa.tasks; a.tmNTasks = sa.nTasks; a.tmSlotState = sa.slotState; a.tmOut = sa.out; a.compWeight = m->d_compWeight;
+   a.tmCombine = 1; a.streamWt = m->d_streamWt;
+   int rc = htkamd_launch_tm_score(a, s);
+   hipError_t e2 = hipStreamSynchronize(s);
+   (void)hipFree(tmE); (void)hipFree(tmMaxP);
+   if (!rc && e2 != hipSuccess) { htkamd_set_error("tm_score_block: %s", hipGetErrorString(e2)); rc = HTKAMD_EHIP; }
+   return rc;
 }
 
 // UpMixParms, TIEDHS (HFB.c:1503-1507, 1559-1563, 1590-1612): the kept pool entries of the frame; a component's log probability is

@@ -99,6 +99,7 @@ struct htkamd_model {
    int   *h_dimStream, *h_gaussStream, *d_dimStream, *d_gaussStream;   /* [D] stream of a dimension, [G] stream of a Gaussian */
    /* tied mixtures (htkamd_model_desc::hsKind == HTKAMD_HS_TIED): the pool of stream k is what element k (state 0) lists */
    int    tiedMix, tmPool;     /* tmPool: Gaussians in all pools together */
+   float  tmBeam;              /* aligner / decoders: PrecomputeTMix's threshold (HVite -c, default 10.0; htkamd_model_set_tm_beam) */
    int   *h_tmPoolOff, *d_tmPoolOff;   /* [NSt+1] first pool entry of a stream in the per-frame pool table (fb.hip tmE) */
    float *h_streamWt, *d_streamWt;    /* [S] stream weight of every element (1 unless <SWEIGHTS>) */
    int   *d_msCompOff;         /* [S+1] = 2e: what the recursion kernels read as "components of the chain state" (they only ask == 1) */

@@ -138,6 +138,8 @@ struct FbArgs {
    int tmPool, totalFrames;
    const ScoreTask *tmTasks; int tmNTasks; const int *tmSlotState; float *tmOut;
    const float *compWeight, *var;    // linear weights, variances
+   int tmCombine;                    // HVite side: a row is a STATE (its first element), scored as sum_s w_s SOutP_s (cPOutP HRec.c:540); 0: a row is an element
+   const float *streamWt;            // [elements], with tmCombine
    MixHit *hits;                     // region r (one per wavefront of k_stats_lr, numbered like the rows of trPart): hits[r * hitRegionCap ...]
    int *hitCtl;                      // [r] records in region r
    int nHitRegions, hitRegionCap;
@@ -152,6 +154,8 @@ int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s);
 // tied mixtures: PrecomputeTMix for every frame, SOutP for every (row, frame) of the task list, UpMixParms' TIEDHS branch
 int htkamd_launch_tm_score(const FbArgs &a, hipStream_t s);
 int htkamd_launch_mixstats_tm(const FbArgs &a, hipStream_t s);
+// aligner / decoders on a tied-mixture set: the score block of `sa` (rows = states) filled by PrecomputeTMix(tmBeam) + SOutP over the first nRows feature rows
+int htkamd_tm_score_block(const htkamd_model *m, const ScoreArgs &sa, int nRows, float tmBeam, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
 // state-per-lane fast path (fb_state.hip): chains of <= 512 emitting states, models of <= 5 states, no tee models
 int htkamd_launch_beta_s(const FbArgs &a, int W, bool fast, hipStream_t s);

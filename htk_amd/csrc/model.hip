@@ -309,7 +309,7 @@ extern "C" int htkamd_model_create(const htkamd_model_desc *d, htkamd_model **ou
       htkamd_model_destroy(m); return rc;
    }
    if (d->hsKind == HTKAMD_HS_TIED) {
-      m->tiedMix = 1;
+      m->tiedMix = 1; m->tmBeam = 10.0f;
       m->h_tmPoolOff = (int *)calloc((size_t)NSt + 1, sizeof(int));
       for (int k = 0; k < NSt; k++) m->h_tmPoolOff[k + 1] = m->h_tmPoolOff[k] + (m->h_stateCompOff[k + 1] - m->h_stateCompOff[k]);
       m->tmPool = m->h_tmPoolOff[NSt];
@@ -440,6 +440,13 @@ extern "C" int htkamd_model_set_sharing(htkamd_model *m, const int *meanShare, c
       HIPCHECK(hipMalloc(&m->d_shareTab, sizeof(int) * tab.size()));
       HIPCHECK(hipMemcpy(m->d_shareTab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
    }
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_set_tm_beam(htkamd_model *m, float tmBeam)
+{
+   if (!m || !(tmBeam >= 0.0f)) { htkamd_set_error("model_set_tm_beam: bad argument"); return HTKAMD_EINVAL; }
+   m->tmBeam = tmBeam;
    return HTKAMD_OK;
 }
 

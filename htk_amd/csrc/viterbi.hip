@@ -486,7 +486,6 @@ struct htkamd_viterbi {
 extern "C" int htkamd_viterbi_create(htkamd_model *m, htkamd_viterbi **out)
 {
    if (!m || !out) { htkamd_set_error("viterbi_create: NULL argument"); return HTKAMD_EINVAL; }
-   if (m->tiedMix) { htkamd_set_error("viterbi_create: tied-mixture sets are served by the forward-backward pass only"); return HTKAMD_EMODEL; }
    if (m->maxN > VG_MAXN) { htkamd_set_error("viterbi_create: models with %d states; this path handles up to %d", m->maxN, VG_MAXN); return HTKAMD_EMODEL; }
    htkamd_viterbi *v = new htkamd_viterbi();
    v->m = m; v->nUtt = 0; v->segTotal = v->modTotal = 0;
@@ -595,6 +594,9 @@ extern "C" int htkamd_viterbi_align_mode(htkamd_viterbi *v, const htkamd_batch_d
    if (scoreMode & HTKAMD_SCORE_DIAGC) { if ((rc = htkamd_model_device_tables((htkamd_model *)m))) return rc; }
    sa.var = m->d_var;
    sa.NSt = m->NSt; sa.streamWt = m->d_streamWt;
+   if (m->tiedMix) {                                      // hsKind TIEDHS: PrecomputeTMix(tmBeam) per frame + SOutP's pool sum (HRec.c:1987, 493-503)
+      if ((rc = htkamd_tm_score_block(m, sa, b->frameOff[U], m->tmBeam, s))) return rc;
+   } else
    if ((rc = htkamd_launch_score_exact(m, sa, s, nullptr, nullptr, (scoreMode & HTKAMD_SCORE_SOUTP) != 0, (scoreMode & HTKAMD_SCORE_DIAGC) != 0))) return rc;
 
    VitArgs va;

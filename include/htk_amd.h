@@ -122,6 +122,9 @@ int  htkamd_model_set_sharing(htkamd_model *m, const int *meanShare /*[G]*/, con
    NULL (the default) = definition order. */
 int  htkamd_model_set_scan_order(htkamd_model *m, const int *order /*[numPhys]*/);
 int  htkamd_model_has_sharing(const htkamd_model *m);
+/* Tied-mixture sets in the aligner and the decoders: the pruning threshold of the pool (HVite -c f, tmBeam HVite.c:115: pool entries more
+   than f below the frame's best are left out of every state's sum; default 10.0).  Forward-backward uses its own (minFrwdP, HFB.c:1011). */
+int  htkamd_model_set_tm_beam(htkamd_model *m, float tmBeam);
 void htkamd_model_destroy(htkamd_model *m);
 /* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */
 int  htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,

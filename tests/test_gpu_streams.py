@@ -240,8 +240,23 @@ def test_hvite_cli_on_a_three_stream_set(native, tmp_path, name):
             assert (out / (u + ".rec")).read_text().splitlines() == exp[what][u], (what, u)
 
 
-def test_tied_mixtures_are_refused_where_they_are_not_served(native):
-    mmf = native.Mmf(files=[os.path.join(TMIX, "tiedhs_newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
-    model = native.Model(mmf.packed())
-    with pytest.raises(native.HtkAmdError, match="tied-mixture"):
-        native.Viterbi(model)
+@pytest.mark.parametrize("name", ["tiedhs_after_herest", "tiedhs3_after_herest"])
+def test_hvite_cli_on_tied_mixture_sets(native, tmp_path, name):
+    """Recognition and forced alignment of <TMIX> sets, one stream and three: per frame PrecomputeTMix with HVite's -c threshold
+    (HRec.c:1987), per state SOutP's sum over the kept pool entries, stream-weighted (cPOutP) -- the label files of the reference's
+    HVite line for line (tests/golden/make_tmix_hvite_golden.py), with the default threshold and with -c 3.0."""
+    import json
+    tools = os.path.join(ROOT, "tools", "bin")
+    exp = json.load(open(os.path.join(TMIX, "hvite_expected.json")))[name]
+    conf = tmp_path / "hvite.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    path = lambda u: os.path.join(DEMO, "test" if u.startswith("te") else "train", u + ".mfc")
+    for what, opts in (("rec", ["-w", os.path.join(DEMO, "monLattice"), "-t", "300.0", "-p", "5.0", "-s", "0.0", "-m", "-f"]),
+                       ("rec_c3", ["-w", os.path.join(DEMO, "monLattice"), "-t", "300.0", "-p", "5.0", "-s", "0.0", "-c", "3.0"]),
+                       ("align", ["-a", "-m", "-f", "-L", os.path.join(DEMO, "labels"), "-t", "300.0"])):
+        out = tmp_path / what; out.mkdir()
+        names = sorted(exp[what])
+        r = cli.run([os.path.join(tools, "hvite"), "-C", str(conf), "-H", os.path.join(TMIX, name), "-l", str(out)] + opts +
+                    [os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + [path(u) for u in names])
+        assert r.returncode == 0, r.stderr
+        for u in names:
+            assert (out / (u + ".rec")).read_text().splitlines() == exp[what][u], (what, u)

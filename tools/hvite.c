@@ -124,7 +124,7 @@ int main(int argc, char **argv)
    strlist mmfs = {0}, files = {0};
    const char *hmmDir = NULL, *hmmExt = NULL, *netPath = NULL, *labDir = NULL, *labExt = "lab", *mlfIn = NULL, *mlfOut = NULL, *outDir = NULL, *outExt = "rec", *boundary = NULL;
    float genBeam = 0.0f, wordBeam = 0.0f, lmScale = 1.0f, wordPen = 0.0f, prScale = 1.0f;
-   float genBeamInc = 0.0f, genBeamLim = 0.0f;             /* -t f [i l]: alignment retries a file with wider beams (HVite.c:308-322, 900-913) */
+   float genBeamInc = 0.0f, genBeamLim = 0.0f, tmBeam = 10.0f;             /* -t f [i l]: alignment retries a file with wider beams (HVite.c:308-322, 900-913) */
    int align = 0, models = 0, states = 0, oflags = 0, trace = 0, scoreMode = HTKAMD_SCORE_EXACT, batchN = 1024, maxActive = 0;
    int nToks = 0, nTrans = 1, latFmt = 0;
    const char *latExt = NULL;
@@ -175,6 +175,7 @@ int main(int argc, char **argv)
             if (genBeamLim < genBeam + genBeamInc) { genBeamLim = genBeam; genBeamInc = 0.0f; }
          }
          break;
+      case 'c': tmBeam = (float)flt_arg(&a, sw); break;     /* tied mixture pruning threshold (HVite.c:255) */
       case 'v': wordBeam = (float)flt_arg(&a, sw); break;
       case 's': lmScale = (float)flt_arg(&a, sw); break;
       case 'p': wordPen = (float)flt_arg(&a, sw); break;
@@ -214,6 +215,7 @@ int main(int argc, char **argv)
    const htkamd_model_desc *d = htkamd_mmf_desc(mmf);
    const int D = d->vecSize;
    htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   if (d->hsKind == HTKAMD_HS_TIED) CHECK(htkamd_model_set_tm_beam(model, tmBeam));
    htkamd_viterbi *vit; CHECK(htkamd_viterbi_create(model, &vit));
    const char *tk = cfg_get(&cfg, "TARGETKIND");
    const int targetKind = kind_parse(tk ? tk : htkamd_mmf_parm_kind(mmf));
