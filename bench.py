@@ -103,7 +103,7 @@ def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=32):
+def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # the decoder runs a workgroup per utterance: a machine of 256 CUs wants that many
     """The path's other two consumers, at the same set, outside the timed region (reported, never `value`):
     HVite -a forced alignment (K5) of the shard's first utterances -- checked against the oracle's token likelihood on one of them --
     and HVite -w decoding (K7) over a word loop of the set's 6 000 one-model words with -t 250 (BASELINE config[3])."""
