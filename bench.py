@@ -248,12 +248,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    # test aid (tests/test_gpu_multi.py on a one-GPU box): every rank on device 0 and the exchange through gloo -- RCCL refuses two ranks
+    # on one device; the loop around the collective is the same
+    one_device = os.environ.get("HTKAMD_BENCH_ONE_DEVICE_GLOO") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     capi.check(capi.lib().htkamd_set_device(local_rank), "set_device")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     D = 39
     # same model on every rank (model_seed), a different 1250-utterance shard per rank (seed)

@@ -34,7 +34,7 @@ def _env():
     return e
 
 
-def _bench(n, out, port, total=256):
+def _bench(n, out, port, total=256, env=None):
     args = ["--gpus", str(n), "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
             "--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--extras", "0", "--dump-model", out]
     if n == 1:
@@ -42,9 +42,28 @@ def _bench(n, out, port, total=256):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.join(ROOT, "bench.py")] + args
-    r = subprocess.run(cmd, cwd=ROOT, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(_env(), **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stdout
+
+
+def test_bench_two_ranks_on_one_device_over_gloo_equal_one_rank(tmp_path):
+    """The loop of bench.py with two ranks -- sharding by utterance id, the pipelined host loop around the ONE collective of an iteration,
+    the update on every rank -- on a one-GPU box: both ranks on device 0, the exchange through gloo (HTKAMD_BENCH_ONE_DEVICE_GLOO: RCCL
+    refuses two ranks on one device; with two devices the test above runs the same over RCCL).  The merged model equals the 1-rank model."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    o1 = _bench(1, str(tmp_path / "m1.npz"), 29621)
+    o2 = _bench(2, str(tmp_path / "m2.npz"), 29622, env={"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"})
+    l1, l2 = json.loads(o1.strip().splitlines()[-1]), json.loads(o2.strip().splitlines()[-1])
+    assert l2["n_gpus"] == 2 and l1["utterances_ok"] == l2["utterances_ok"] == 256
+    a, b = np.load(str(tmp_path / "m1.npz")), np.load(str(tmp_path / "m2.npz"))
+    assert a["nUttDone"] == b["nUttDone"] == 256
+    assert abs(float(a["totalPr"]) - float(b["totalPr"])) <= 1e-9 * abs(float(a["totalPr"]))
+    for k in ("mean", "var", "compWeight", "transP"):
+        assert np.allclose(a[k], b[k], rtol=2e-6, atol=1e-7), k
 
 
 def test_bench_two_ranks_rccl_equals_one_rank(tmp_path):
