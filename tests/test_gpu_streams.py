@@ -260,3 +260,24 @@ def test_hvite_cli_on_tied_mixture_sets(native, tmp_path, name):
         assert r.returncode == 0, r.stderr
         for u in names:
             assert (out / (u + ".rec")).read_text().splitlines() == exp[what][u], (what, u)
+
+
+def test_hvite_cli_nbest_on_stream_and_tied_mixture_sets(native, tmp_path):
+    """N-best decoding (token sets, -n 3 2) of a three-stream tied-mixture set and of a three-stream set with stream weights 1 0.5 2: the
+    label files of the reference's HVite run beside ours (oracle/_ref travels to the GPU box), byte for byte."""
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref", "HVite")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/HVite is not on this box")
+    conf = tmp_path / "hvite.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    files = [os.path.join(DEMO, "test", "te1.mfc"), os.path.join(DEMO, "test", "te2.mfc"), os.path.join(DEMO, "train", "tr3.mfc")]
+    for k, mset in enumerate([os.path.join(TMIX, "tiedhs3_after_herest"), os.path.join(DEMO, "hmm_streams3", "sw_after_herest")]):
+        outs = []
+        for who, exe in (("ours", os.path.join(ROOT, "tools", "bin", "hvite")), ("ref", ref)):
+            out = tmp_path / ("%s%d" % (who, k)); out.mkdir(); outs.append(out)
+            r = subprocess.run([exe, "-C", str(conf), "-H", mset, "-w", os.path.join(DEMO, "monLattice"), "-l", str(out), "-t", "300.0", "-p", "5.0", "-s", "0.0",
+                                "-n", "3", "2", os.path.join(DEMO, "bcpvocab"), os.path.join(DEMO, "bcplist")] + files, capture_output=True, text=True)
+            assert r.returncode == 0, (who, r.stdout[-400:], r.stderr[-400:])
+        for f in ("te1.rec", "te2.rec", "tr3.rec"):
+            assert (outs[0] / f).read_text() == (outs[1] / f).read_text(), (mset, f)
+            assert "///" in (outs[0] / f).read_text()
