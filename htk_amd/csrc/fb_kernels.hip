@@ -636,7 +636,6 @@ __device__ __forceinline__ void mix_hit(const FbArgs &a, const bool ok, const in
    const int lane = threadIdx.x & 63, sub = lane % GS;
    const int D = DT > 0 ? DT : a.D;
    const double minF = (double)a.minFrwdP;
-   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
    const int s = ok ? st : 0;
    const int c0 = a.stateCompOff[s], M = ok ? a.stateCompOff[s + 1] - c0 : 0;
    const float *xrow = a.X + (size_t)(ok ? frameRow : 0) * D;

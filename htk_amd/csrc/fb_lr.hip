@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    double bT = LZERO, bT1 = LZERO, bT2 = LZERO;          // beta of frames t, t+1 and (in flight) t+2
    float oT = 0.f, oT1 = 0.f;
    int w1 = qBeam[1], w2 = (T >= 2) ? qBeam[2] : 1, w3 = 1;
-   int lo0 = 1, hi0 = 0, lo1 = w1 & 0xffff, hi1 = w1 >> 16, lo2 = w2 & 0xffff, hi2 = (T >= 2) ? (w2 >> 16) : 0;
+   int hi0 = 0, lo1 = w1 & 0xffff, hi1 = w1 >> 16, lo2 = w2 & 0xffff, hi2 = (T >= 2) ? (w2 >> 16) : 0;
    double *pS = valid ? &ALPHA_S(1) : nullptr;           // this lane's place in the stored columns, advanced by L per step
    double *pE = (valid && s.first) ? &ALPHA_E(1, q) : nullptr;
    if (valid) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
       }
       eT = eT1;
       if (valid && s.first && t + 2 <= T) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1);
-      lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = (t + 2 <= T) ? (w3 >> 16) : 0;
+      hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = (t + 2 <= T) ? (w3 >> 16) : 0;
       // first lanes of the models that bound the next step's beam decisions (hi1 may be 0 past the last frame: the step is not taken)
       fLo0 = fLo1;
       if (lo1 != lo1Of) { fLo1 = flOf[lo1]; lo1Of = lo1; }

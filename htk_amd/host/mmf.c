@@ -286,7 +286,6 @@ static int parse_vector_ms(struct htkamd_mmf *s, rd *r, float *dst, int stream, 
    for (int i = 0; i < n; i++) if ((rc = rd_float(r, dst + i))) return rc;
    return HTKAMD_OK;
 }
-static int parse_vector(struct htkamd_mmf *s, rd *r, float *dst) { return parse_vector_ms(s, r, dst, s->curStream, 0.0f); }
 
 static void gname_set(struct htkamd_mmf *s, int g, char *name)
 {
