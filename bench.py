@@ -223,8 +223,8 @@ def main():
                     help="weak: --utts utterances on every GPU (the contract's default); strong: --total-utts utterances split over the GPUs")
     ap.add_argument("--total-utts", type=int, default=10000, help="--scaling strong: utterances of the whole job (BASELINE config[2]: 10k)")
     ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
-    ap.add_argument("--score", choices=["exact", "mfma", "fast", "fastest"], default="fastest",
-                    help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; fastest = bf16 x 3 matrix-core scores + that LAdd")
+    ap.add_argument("--score", choices=["exact", "mfma", "fast", "bf16", "fastest"], default="fastest",
+                    help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; bf16 = bf16 x 3 matrix-core scores + that LAdd; fastest = fp16 x 2 matrix-core scores + that LAdd")
     ap.add_argument("--two-streams", type=int, default=1, help="run the chunks of an iteration on two alternating streams (1) or on one stream (0)")
     ap.add_argument("--chunks", type=int, default=1, help="sub-batches an iteration's shard is cut into (alternating over two streams, one accumulator vector)")
     ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
@@ -274,7 +274,7 @@ def main():
     pk = s.packed()
     model = capi.Model(pk)
     accs = capi.Accs(model)
-    cfg = capi.fb_config(scoreMode={"exact": 0, "mfma": 1, "fast": 3, "fastest": 6}[args.score])                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
+    cfg = capi.fb_config(scoreMode={"exact": 0, "mfma": 1, "fast": 3, "bf16": 6, "fastest": 34}[args.score])                               # HERest defaults: pruning off, MINFORPROB 10, -u tmvw
 
     if args.ragged:                                      # not the headline workload: utterance lengths spread over [frames/2, frames], chains
         rr = np.random.default_rng(77 + rank)            # spread likewise (one model per 12 frames), in random order within the batch
@@ -469,7 +469,7 @@ def main():
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
-        kname = {"exact": "k_score_exact<39>", "fastest": "k_score_bf16<3>"}.get(args.score, "k_score_mfma<20>")
+        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16<3>", "fastest": "k_score_f16<3>"}.get(args.score, "k_score_mfma<20>")
         # HBM-side bytes per launch of every kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/prof_r03.sh),
         # same workload only
         traffic_of = {}
@@ -533,12 +533,14 @@ def main():
             "roofline": dict(per_kernel[dom], units_per_launch=units_local / NCH, launches_per_step=NCH),
             "roofline_kernels": per_kernel,
         }
-        if args.score == "fastest":
-            # what the matrix pipe executes for it: six bf16 piece products over three K chunks of 32 (13 dimensions as (x^2, x) pairs + the
-            # chunk's constant, padded), per component
+        if args.score in ("fastest", "bf16"):
+            # what the matrix pipe executes for it: three fp16 (six bf16) piece products over three K chunks of 32 (13 dimensions as
+            # (x^2, x) pairs + the chunk's constant, padded), per component
             kpad = ((D + 14) // 15) * 32
-            exe = units_local * args.mix * kpad * 2 * 6 / k1 / 1e12 if k1 > 0 else 0.0
-            ex = {"pipe": "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces", "achieved": exe, "peak": 2500.0, "unit": "TFLOP/s",
+            nprod = 3 if args.score == "fastest" else 6
+            exe = units_local * args.mix * kpad * 2 * nprod / k1 / 1e12 if k1 > 0 else 0.0
+            ex = {"pipe": "v_mfma_f32_16x16x32_f16, operands split in two fp16 pieces" if args.score == "fastest" else "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces",
+                  "achieved": exe, "peak": 2500.0, "unit": "TFLOP/s",
                   "frac": exe / 2500.0, "note": "`achieved` of the scoring kernel counts the fp32 algorithm's flops (the unit's definition) against the fp32 matrix peak"}
             per_kernel["score"]["executed"] = ex
             if dom == "score":

@@ -15,16 +15,19 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libhtk_amd.so")
-HIP_SRCS = ["csrc/model.hip", "csrc/gmm_exact.hip", "csrc/gmm_mfma.hip", "csrc/gmm_bf16.hip", "csrc/fb_kernels.hip", "csrc/fb_wave.hip", "csrc/fb_state.hip", "csrc/fb_lr.hip", "csrc/fb.hip", "csrc/viterbi.hip", "csrc/decode.hip", "csrc/decode_n.hip", "csrc/mfcc.hip", "csrc/update.hip", "csrc/comm.hip"]
+HIP_SRCS = ["csrc/model.hip", "csrc/gmm_exact.hip", "csrc/gmm_mfma.hip", "csrc/gmm_bf16.hip", "csrc/gmm_f16.hip", "csrc/fb_kernels.hip", "csrc/fb_wave.hip", "csrc/fb_state.hip", "csrc/fb_lr.hip", "csrc/fb.hip", "csrc/viterbi.hip", "csrc/decode.hip", "csrc/decode_n.hip", "csrc/mfcc.hip", "csrc/update.hip", "csrc/comm.hip"]
 C_SRCS = ["host/prep.c", "host/update.c", "host/fbank.c", "host/accio.c", "host/parmfile.c", "host/mmf.c", "host/labio.c", "host/net.c", "host/lattice.c"]
 HEADERS = ["csrc/internal.h", "csrc/kernels.h", "csrc/hipcheck.h", "csrc/ladd.h", "csrc/wavegrp.h", "csrc/fb_state.h", "csrc/decode.h", "../include/htk_amd.h"]
 ARCH = "gfx950"
 # the tolerance-class scoring kernel never sees NaNs: lets v_max_f32 go without the IEEE canonicalisation of its operands
-EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["-fno-honor-nans"], "csrc/gmm_f16.hip": ["-fno-honor-nans"]}
 if os.environ.get("HTKAMD_LR_DEFS"):               # experiment switches of fb_lr.hip, e.g. HTKAMD_LR_DEFS="-DSTATS_EXP_NOOCC"
     EXTRA_FLAGS["csrc/fb_lr.hip"] = os.environ["HTKAMD_LR_DEFS"].split()
 if os.environ.get("HTKAMD_B16_CT"):              # experiment switch: column tiles per wavefront of the bf16 scoring kernel (gmm_bf16.hip: B16_COL_TILES)
     EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_COL_TILES=" + os.environ["HTKAMD_B16_CT"]]
+if os.environ.get("HTKAMD_B16_TF"):              # experiment switch: frames per task of the bf16 scoring kernel in forward-backward (kernels.h: B16_TASK_FRAMES)
+    EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_TASK_FRAMES=" + os.environ["HTKAMD_B16_TF"]]
+    EXTRA_FLAGS["csrc/fb.hip"] = ["-DB16_TASK_FRAMES=" + os.environ["HTKAMD_B16_TF"]]
 if os.environ.get("HTKAMD_B16_WPB"):             # experiment switch: wavefronts per workgroup of the bf16 scoring kernel (gmm_bf16.hip: B16_WPB)
     EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_WPB=" + os.environ["HTKAMD_B16_WPB"]]
 

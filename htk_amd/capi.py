@@ -28,11 +28,12 @@ def _stream(s):
     return None if s is None else (s if isinstance(s, C.c_void_p) else C.c_void_p(int(s)))
 
 
-SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC = 0, 1, 2, 4, 8, 16
+SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC, SCORE_F16 = 0, 1, 2, 4, 8, 16, 32
+ERANGE = -7
 
 
 class HtkAmdError(RuntimeError):
-    pass
+    rc = 0
 
 
 class ModelDesc(C.Structure):
@@ -87,7 +88,9 @@ def lib():
 
 def check(rc: int, what: str = ""):
     if rc != 0:
-        raise HtkAmdError("%s failed (%d): %s" % (what, rc, lib().htkamd_last_error().decode()))
+        e = HtkAmdError("%s failed (%d): %s" % (what, rc, lib().htkamd_last_error().decode()))
+        e.rc = rc
+        raise e
 
 
 def _p(a):
@@ -234,6 +237,8 @@ class Model:
         dX, dS = DevArray(X), DevArray(states)
         dO = DevArray(nbytes=4 * T * ns)
         check(lib().htkamd_outp_block_mode(self.h, dX.ptr, C.c_int(T), dS.ptr, C.c_int(ns), dO.ptr, C.c_int(T), C.c_int(mode), None), "outp_block")
+        if mode & SCORE_F16:
+            check(lib().htkamd_model_f16_check(self.h, None), "model_f16_check")      # HTKAMD_ERANGE: repeat with SCORE_BF16
         out = dO.to_host(np.float32, (ns, T))
         return np.ascontiguousarray(out.T)
 

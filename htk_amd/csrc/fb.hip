@@ -143,6 +143,7 @@ struct htkamd_fb {
    void *h_arena; size_t h_arenaCap;        // pinned staging copy of the batch tables (one H2D transfer per prepare)
    void *h_res; size_t h_resCap;            // pinned staging copy of the results (one D2H transfer per htkamd_fb_results)
    hipEvent_t evRes; bool resPending;       // htkamd_fb_results_begin: the event behind the queued copy
+   bool f16Pass = false;                    // the last pass scored on the fp16 path: its range flag lies behind the status words
    hipEvent_t ev[6], evK[2], evCopy;          // ev: stream intervals (score | beta | alpha | left-to-right statistics | mixture statistics); evK: the scoring dispatch's own start/stop
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending, scored;
@@ -334,10 +335,11 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
             int tmin = 1, tmax = T;
             while (tmin <= T && evHi[tmin] < qa) tmin++;
             while (tmax >= 1 && evLo[tmax] > qb) tmax--;
-            for (int t0 = tmin - 1; t0 < tmax; t0 += SCORE_TILE_FRAMES) {
+            const int TF = wide ? B16_TASK_FRAMES : SCORE_TILE_FRAMES;
+            for (int t0 = tmin - 1; t0 < tmax; t0 += TF) {
                ScoreTask tk;
                tk.frame0 = d.frame0 + t0;
-               tk.nFrames = (tmax - t0 < SCORE_TILE_FRAMES) ? tmax - t0 : SCORE_TILE_FRAMES;
+               tk.nFrames = (tmax - t0 < TF) ? tmax - t0 : TF;
                tk.slot0 = d.slot0 * NSt + ks * nSlots + k0;
                tk.nSlots = k1 - k0;
                tk.outSlot0 = ks * nSlots + k0; tk.ldo = T;
@@ -521,7 +523,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    if ((rc = fb->d_qLo.reserve(sizeof(short) * nf)) || (rc = fb->d_qHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_aLo.reserve(sizeof(short) * nf)) || (rc = fb->d_aHi.reserve(sizeof(short) * nf)) ||
        (rc = fb->d_outp.reserve(sizeof(float) * (outp + 16))) || (rc = fb->d_beta.reserve(sizeof(double) * ((beta && !wavePathPrep) ? beta : 1))) ||
-       (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve((sizeof(double) + sizeof(int)) * (size_t)(U ? U : 1))) ||      /* log probabilities, then the status words: ONE copy brings both back */
+       (rc = fb->d_gam.reserve(sizeof(double) * ((gam && fb->clsOff[9] > 0) ? gam : 1))) || (rc = fb->d_pr.reserve((sizeof(double) + sizeof(int)) * (size_t)(U ? U : 1) + 2 * sizeof(int))) ||      /* log probabilities, then the status words, then the fp16 scoring path's task counter and range flag: ONE copy brings all back */
        (fb->m->NSt > 1 && (rc = fb->d_outpU.reserve(sizeof(float) * (outp * fb->m->NSt + 16)))) ||
        (fb->m->tiedMix && ((rc = fb->d_tmE.reserve(sizeof(float) * (nf * fb->m->tmPool + 16))) || (rc = fb->d_tmMaxP.reserve(sizeof(float) * (nf * fb->m->NSt + 16))))))
       return rc;
@@ -550,7 +552,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    }
 
    ScoreArgs sa;
-   const bool wideTasks = (cfg->scoreMode & (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_MFMA)) != 0;
+   const bool wideTasks = (cfg->scoreMode & (HTKAMD_SCORE_F16 | HTKAMD_SCORE_BF16 | HTKAMD_SCORE_MFMA)) != 0;
    sa.tasks = (const ScoreTask *)(wideTasks ? fb->d_tasksW.p : fb->d_tasks.p); sa.nTasks = (int)(wideTasks ? fb->tasksW.size() : fb->tasks.size()); sa.X = fb->dX;
    sa.slotState = (const int *)fb->d_slotState.p; sa.out = (float *)fb->d_outp.p;
    if (m->NSt > 1) { sa.slotState = (const int *)fb->d_slotStateU.p; sa.out = (float *)fb->d_outpU.p; }      // per (stream, chain state)
@@ -558,7 +560,12 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
-   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16 | HTKAMD_SCORE_SOUTP)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
+   fb->f16Pass = (cfg->scoreMode & HTKAMD_SCORE_F16) != 0 && !m->tiedMix;
+   if (fb->f16Pass) {      // the pass's own range flag, behind the status words (zeroed with the task counter before it, by the launcher)
+      sa.taskCounter = (int *)((char *)fb->d_pr.p + (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt);
+      sa.rangeFlag = sa.taskCounter + 1;
+   }
+   if (cfg->scoreMode & ~(HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD | HTKAMD_SCORE_BF16 | HTKAMD_SCORE_F16 | HTKAMD_SCORE_SOUTP)) { htkamd_set_error("fb_execute: unknown score mode %d", cfg->scoreMode); return HTKAMD_EINVAL; }
    const bool fastLadd = (cfg->scoreMode & HTKAMD_SCORE_FASTLADD) != 0;
 
    FbArgs fa;
@@ -704,7 +711,7 @@ extern "C" int htkamd_fb_results_begin(htkamd_fb *fb, void *stream)
    if (!fb) { htkamd_set_error("fb_results_begin: NULL"); return HTKAMD_EINVAL; }
    if (fb->nUtt == 0) return HTKAMD_OK;
    hipStream_t s = (hipStream_t)stream;
-   const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt;
+   const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt + 2 * sizeof(int);
    int rc = res_staging(fb, bytes);
    if (rc) return rc;
    if (!fb->evRes) HIPCHECK(hipEventCreateWithFlags(&fb->evRes, hipEventDisableTiming));
@@ -720,7 +727,7 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    hipStream_t s = (hipStream_t)stream;
    if (fb->nUtt == 0) return HTKAMD_OK;
    // log probabilities and status words lie in one device buffer and come back in one copy through a pinned staging buffer
-   const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt;
+   const size_t bytes = (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt + 2 * sizeof(int);
    if (fb->resPending) {                                    // htkamd_fb_results_begin queued the copy behind the pass
       fb->resPending = false;
       HIPCHECK(hipEventSynchronize(fb->evRes));
@@ -739,6 +746,15 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    }
    if (pr) memcpy(pr, fb->h_res, sizeof(double) * (size_t)fb->nUtt);
    if (status) memcpy(status, (const char *)fb->h_res + sizeof(double) * (size_t)fb->nUtt, sizeof(int) * (size_t)fb->nUtt);
+   if (fb->f16Pass) {
+      int flag;
+      memcpy(&flag, (const char *)fb->h_res + (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt + sizeof(int), sizeof(int));
+      if (flag) {
+         htkamd_set_error("fb_results: the fp16 scoring path met %s%s%s outside its range: nothing of this pass can be used (accumulators included) -- repeat it with HTKAMD_SCORE_BF16",
+                          (flag & HTKAMD_F16_EMODEL) ? "a model coefficient" : "", (flag & HTKAMD_F16_EMODEL) && (flag & HTKAMD_F16_EFEAT) ? " and " : "", (flag & HTKAMD_F16_EFEAT) ? "a feature value" : "");
+         return HTKAMD_ERANGE;
+      }
+   }
    return HTKAMD_OK;
 }
 

@@ -95,7 +95,7 @@ __device__ __host__ __forceinline__ void split3(float x, unsigned short &p1, uns
 template <int NC>
 __global__ __launch_bounds__(64 * B16_WPB, B16_COL_TILES > 2 ? 2 : 3) void k_score_bf16(ScoreArgs a)      // second figure: wavefronts per SIMD the register budget is cut for
 {
-   constexpr int NT = 64 * B16_WPB, FPW = 16 * B16_COL_TILES, HALVES = 128 / (FPW * B16_WPB);
+   constexpr int NT = 64 * B16_WPB, FPW = 16 * B16_COL_TILES, HALVES = B16_TASK_FRAMES / (FPW * B16_WPB);
    constexpr int TWB = 3 * NC * 64 * 16 + 64 * 16;     // bytes per fragment tile
    constexpr int TW4 = TWB / 16;                       // 16-byte words per tile
    constexpr int PT = (TW4 + NT - 1) / NT;             // words staged per thread
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * B16_WPB, B16_COL_TILES > 2 ? 2 : 3) void k_sco
       const int task = vtask / HALVES;
       if (task >= a.nTasks) break;
       const ScoreTask tk = a.tasks[task];
-      const int fw = FPW * wv + (128 / HALVES) * (vtask % HALVES);      // this wave's first frame in the tile
+      const int fw = FPW * wv + (B16_TASK_FRAMES / HALVES) * (vtask % HALVES);      // this wave's first frame in the tile
       const bool active = fw < tk.nFrames;
 
       // first tile and tile count of every state of the task, one per lane (tasks hold at most 64 states): the tile loop below reads them
@@ -255,8 +255,13 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
    if (!m->d_bf16Tab) { htkamd_set_error("score_bf16: vector size %d not supported by the bf16 matrix-core path (up to 45)", m->D); return HTKAMD_EMODEL; }
+   if (m->bf16Stale) {                               // parameters were re-estimated on the device since the table was built (and this path was not in use then)
+      int rc = htkamd_model_refresh_bf16_device((htkamd_model *)m, (void *)stream);
+      if (rc) return rc;
+   }
+   ((htkamd_model *)m)->fastUse |= HTKAMD_SCORE_BF16;
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
-   const int parts = 128 / (16 * B16_COL_TILES * B16_WPB);
+   const int parts = B16_TASK_FRAMES / (16 * B16_COL_TILES * B16_WPB);
    int blocks = a.nTasks * parts;
    if (blocks > 256 * ((B16_COL_TILES > 2 ? 8 : 12) / B16_WPB)) blocks = 256 * ((B16_COL_TILES > 2 ? 8 : 12) / B16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) or half-task at a time
    dim3 grid(blocks), block(64 * B16_WPB);
@@ -336,5 +341,6 @@ int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
    const int n = m->nTiles * m->bf16NC * 64;
    hipLaunchKernelGGL(k_build_bf16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    HIPCHECK(hipGetLastError());
+   m->bf16Stale = 0;
    return HTKAMD_OK;
 }

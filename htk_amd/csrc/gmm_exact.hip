@@ -224,7 +224,7 @@ extern "C" int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const 
 extern "C" int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                                       float *dOut, int ldo, int scoreMode, void *stream)
 {
-   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA && scoreMode != HTKAMD_SCORE_BF16 && (scoreMode & ~(HTKAMD_SCORE_SOUTP | HTKAMD_SCORE_DIAGC))) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
+   if (scoreMode != HTKAMD_SCORE_EXACT && scoreMode != HTKAMD_SCORE_MFMA && scoreMode != HTKAMD_SCORE_BF16 && scoreMode != HTKAMD_SCORE_F16 && (scoreMode & ~(HTKAMD_SCORE_SOUTP | HTKAMD_SCORE_DIAGC))) { htkamd_set_error("outp_block: unknown score mode %d", scoreMode); return HTKAMD_EINVAL; }
    return outp_block(m, dX, T, dStates, ns, dOut, ldo, scoreMode, stream);
 }
 

@@ -1,0 +1,428 @@
+// gmm_f16.hip -- K1h: GMM state log-likelihoods on the FP16 matrix pipe with two-way operand splitting.
+//
+// Same quantity, the same expanded form and the same task / tile / log-sum-exp structure as gmm_bf16.hip (K1b):
+//     log2( w_m N(x; mu_m, var_m) ) = cinit_m + sum_k a_mk z_k ,   z = (x_0^2, x_0, x_1^2, x_1, ...)
+// K1b splits both operands into THREE bf16 pieces (8 significant bits each) and needs six piece products per K chunk for fp32 accuracy.
+// An fp16 carries 11 significant bits, so TWO pieces reach fp32's 24 (round to nearest: |a - a1| <= 2^-11 |a|, and the second piece
+// takes 11 bits of the remainder: |a - a1 - a2| <= 2^-22 |a|, 2^-24.6 rms -- fp32's own rounding is 2^-24) and THREE products do:
+//     a z  =  a1 z1 + (a1 z2 + a2 z1)  +  O(2^-22 |a z|)
+// on v_mfma_f32_16x16x32_f16, which runs at the bf16 instruction's rate: half of K1b's matrix instructions, two thirds of its operand
+// registers (4 waves per SIMD instead of 3), LDS reads and table bytes.  What fp16 lacks is RANGE (6e-5 .. 65504), so
+//   * every k carries a power-of-two scale s_k: the table holds a_k s_k, the frames' side z_k / s_k (exact).  s_k puts the largest
+//     |a_k| over the Gaussians and the largest |z_k| the model lets expect (|x| <= |mu| + 8 sigma) at the same height, the square root
+//     of their product: (k_f16_range, k_f16_scale, on the device with every table refresh);
+//   * the second pieces are carried at 2^11 times their value, a2' = (a - a1) 2^11 -- as large as a1, never subnormal where a1 is not --
+//     and their products go to an accumulator of their own, added as Cc 2^-11 at the end.  The leading products a1 z1 (complete
+//     squares per chunk, as in K1b) have the main accumulator to themselves: three roundings at its magnitude instead of eighteen;
+//   * a scaled value beyond 65504 -- a feature far outside anything the model describes, or a model whose coefficients span more than
+//     the format -- raises a flag (ScoreArgs::rangeFlag) instead of a silent infinity: htkamd_fb_results / htkamd_outp_block_mode
+//     return HTKAMD_ERANGE and the caller repeats the pass with HTKAMD_SCORE_BF16, whose pieces have fp32's exponent.
+// Measured (bench workload, exp/score_cmp.py): |score - exact| rms 3.4e-5, max 2.1e-4 against K1b's 3.2e-5 / 1.8e-4 (the final rounding
+// to float at |score| ~ 100..500 dominates both); 0.85 ms against K1b's 1.24 ms.
+//
+// Layout.  K chunks as K1b (NC = ceil(D/15) chunks of 32: 15 dimensions as (x^2, x) pairs, the chunk's -0.5 sum mu^2 ivar at k = 30
+// against a constant).  Table per tile of 16 components: [piece 2][chunk NC][lane 64][8 f16], then (log w - 0.5 gConst) log2(e) as
+// [lane 64][4 f32] in the accumulator's layout.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include "internal.h"
+#include "hipcheck.h"
+#include "kernels.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) int cint;
+
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#define LOG2(x) __builtin_amdgcn_logf(x)
+#ifndef F16_COL_TILES
+#define F16_COL_TILES 2                                 // 16-frame column tiles per wavefront: 2 (four wavefronts per 128-frame task) or 4 (two)
+#endif
+
+__device__ __forceinline__ float rows_max_b(float v)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum_b(float v)
+{
+   auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+   auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// x = p1 + 2^-11 p2 + O(2^-22 |x|) (rms 2^-24.6), both pieces fp16 (round to nearest even), the difference exact in fp32
+#define F16_CORR 2048.0f
+__device__ __forceinline__ void split2(float x, _Float16 &p1, _Float16 &p2)
+{
+   p1 = (_Float16)x;
+   p2 = (_Float16)((x - (float)p1) * F16_CORR);
+}
+__device__ __forceinline__ unsigned int pack2(_Float16 a, _Float16 b)
+{
+   h2 v; v[0] = a; v[1] = b;
+   return __builtin_bit_cast(unsigned int, v);
+}
+
+// the model's control block (htkamd_model::d_f16Ctl): float scale[96] of every k (table side), float inverse[96] (frames' side),
+// unsigned range[192] (bits of max |a_k|, then of the expected max |z_k|), int flag (HTKAMD_F16_* bits of the last table build), the
+// model's sticky flag, and at F16_CTL_MQ a row of k_f16_range's
+#define F16_CTL_RANGE 192
+#define F16_CTL_FLAG  384
+#define F16_CTL_STICKY 511     /* the model's sticky range flag */
+#define F16_CTL_MQ    400      /* float bits [48]: per dimension the largest 0.5 mu^2 ivar log2(e) (k_f16_range -> k_f16_scale) */
+#define F16_MAX 65504.0f
+
+#ifndef F16_EU
+#define F16_EU (F16_COL_TILES > 2 ? 2 : 4)
+#endif
+#ifndef F16_WPB
+#define F16_WPB (8 / F16_COL_TILES)                     // wavefronts per workgroup: together a whole 128-frame task (F16_WPB smaller: the task in parts)
+#endif
+template <int NC>
+__global__ __launch_bounds__(64 * F16_WPB, F16_EU) void k_score_f16(ScoreArgs a)      // second figure: wavefronts per SIMD the register budget is cut for
+{
+   constexpr int NT = 64 * F16_WPB, FPW = 16 * F16_COL_TILES, HALVES = B16_TASK_FRAMES / (FPW * F16_WPB);
+   constexpr int TWB = 2 * NC * 64 * 16 + 64 * 16;     // bytes per fragment tile
+   constexpr int TW4 = TWB / 16;                       // 16-byte words per tile
+   constexpr int PT = (TW4 + NT - 1) / NT;             // words staged per thread
+   __shared__ u4 wbuf[2][TW4];
+   __shared__ int taskSh;
+   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   const int col = lane & 15, kg = lane >> 4;
+   const int D = a.D;
+   const int dpc = (D + NC - 1) / NC;                  // dimensions per K chunk (<= 15)
+   const u4 *tab = (const u4 *)a.f16Tab;
+   if (blockIdx.x == 0 && tid == 0 && a.f16Ctl[F16_CTL_FLAG]) atomicOr(a.rangeFlag, a.f16Ctl[F16_CTL_FLAG]);      // what the table build found
+
+   for (;;) {
+      if (tid == 0) taskSh = atomicAdd(a.taskCounter, 1);
+      __syncthreads();
+      const int vtask = __builtin_amdgcn_readfirstlane(taskSh);
+      const int task = vtask / HALVES;
+      if (task >= a.nTasks) break;
+      const ScoreTask tk = a.tasks[task];
+      const int fw = FPW * wv + (B16_TASK_FRAMES / HALVES) * (vtask % HALVES);      // this wave's first frame in the tile
+      const bool active = fw < tk.nFrames;
+
+      // first tile and tile count of every state of the task, one per lane (tasks hold at most 64 states): the tile loop below reads them
+      // with v_readlane instead of chains of dependent scalar loads (two per state, each a round trip to the scalar cache or L2)
+      int tFirstV = 0, tEndV = 0;
+      if (lane < tk.nSlots) { const int stl = a.slotState[tk.slot0 + lane]; tFirstV = a.stateTileOff[stl]; tEndV = a.stateTileOff[stl + 1]; }
+      int tile = __builtin_amdgcn_readlane(tFirstV, 0);
+      {
+         const u4 *W = tab + (size_t)tile * TW4;
+#pragma unroll
+         for (int j = 0; j < PT; j++)
+            if (j * NT + tid < TW4) wbuf[0][j * NT + tid] = W[j * NT + tid];
+      }
+
+      // B operand: this lane's frame (col) of each column tile, the 8 k of lane group kg in every chunk, scaled, in two fp16 pieces
+      h8 zb[F16_COL_TILES][2][NC];
+      if (active) {
+         const float *zs = (const float *)a.f16Ctl + 96;      // 1 / scale of every k
+         bool over = false;
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+         float is[8];
+#pragma unroll
+         for (int j = 0; j < 8; j++) is[j] = zs[c * 32 + 8 * kg + j];
+#pragma unroll
+      for (int ft = 0; ft < F16_COL_TILES; ft++) {
+         int f = fw + ft * 16 + col;
+         if (f > tk.nFrames - 1) f = tk.nFrames - 1;
+         const float *row = a.X + (size_t)(tk.frame0 + f) * D;
+            const int d0 = dpc * c + 4 * kg;          // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
+            _Float16 p[2][8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+               int dim = d0 + i;
+               const bool pad = 4 * kg + i >= dpc || dim >= D;
+               if (pad) dim = D - 1;
+               float v = row[dim];
+               if (pad) v = 0.0f;
+               float v2 = v * v;
+               if (i == 3 && kg == 3) v2 = 1.0f;       // k = 30: the constant that meets the chunk's -0.5 sum mu^2 ivar
+               v2 *= is[2 * i]; v *= is[2 * i + 1];
+               over = over || !(v2 <= F16_MAX) || !(fabsf(v) <= F16_MAX);
+               split2(v2, p[0][2 * i], p[1][2 * i]);
+               split2(v, p[0][2 * i + 1], p[1][2 * i + 1]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+               u4 w;
+               w[0] = pack2(p[s][0], p[s][1]); w[1] = pack2(p[s][2], p[s][3]);
+               w[2] = pack2(p[s][4], p[s][5]); w[3] = pack2(p[s][6], p[s][7]);
+               zb[ft][s][c] = __builtin_bit_cast(h8, w);
+            }
+         }
+      }
+         if (over) atomicOr(a.rangeFlag, HTKAMD_F16_EFEAT);
+      }
+      __syncthreads();
+
+      int buf = 0;
+      for (int k = 0; k < tk.nSlots; k++) {
+         const int t1 = __builtin_amdgcn_readlane(tEndV, k);
+         const int nextFirst = (k + 1 < tk.nSlots) ? __builtin_amdgcn_readlane(tFirstV, (k + 1) & 63) : -1;
+         float rM[F16_COL_TILES], rS[F16_COL_TILES];
+         bool first = true;
+         for (;;) {
+            const int nextTile = (tile + 1 < t1) ? tile + 1 : nextFirst;
+            u4 stg[PT];
+            if (nextTile >= 0) {
+               const u4 *W = tab + (size_t)nextTile * TW4;
+#pragma unroll
+               for (int j = 0; j < PT; j++)
+                  if (j * NT + tid < TW4) stg[j] = W[j * NT + tid];
+            }
+            if (active) {
+               h8 wa[2][NC];
+#pragma unroll
+               for (int s = 0; s < 2; s++)
+#pragma unroll
+                  for (int c = 0; c < NC; c++) wa[s][c] = __builtin_bit_cast(h8, wbuf[buf][(s * NC + c) * 64 + lane]);
+               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][2 * NC * 64 + lane]);
+               f4 Cx[F16_COL_TILES], Cc[F16_COL_TILES];
+#pragma unroll
+               for (int ft = 0; ft < F16_COL_TILES; ft++) { Cx[ft] = (f4)(0.0f); Cc[ft] = (f4)(0.0f); }
+               // corrections (a2 z1 + a1 z2, both carried at 2^11 times their value) in an accumulator of their own, the leading products
+               // a1 z1 -- complete squares per chunk -- in the other
+#pragma unroll
+               for (int c = 0; c < NC; c++)
+#pragma unroll
+                  for (int ft = 0; ft < F16_COL_TILES; ft++) {
+                     Cc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1][c], zb[ft][0][c], Cc[ft], 0, 0, 0);
+                     Cx[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][c], zb[ft][0][c], Cx[ft], 0, 0, 0);
+                     Cc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][c], zb[ft][1][c], Cc[ft], 0, 0, 0);
+                  }
+               // log-sum-exp over the tile's 16 rows: 4 in this lane, the rest in lanes ^16, ^32, ^48 (base-2 logs, as K1m)
+#pragma unroll
+               for (int ft = 0; ft < F16_COL_TILES; ft++) {
+                  const f4 y = (Cx[ft] + Cc[ft] * (1.0f / F16_CORR)) + ci;
+                  float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                  mx = rows_max_b(mx);
+                  float sm = (EXP2(y[0] - mx) + EXP2(y[1] - mx)) + (EXP2(y[2] - mx) + EXP2(y[3] - mx));
+                  sm = rows_sum_b(sm);
+                  if (first) { rM[ft] = mx; rS[ft] = sm; }
+                  else {
+                     const float M2 = fmaxf(rM[ft], mx);
+                     rS[ft] = rS[ft] * EXP2(rM[ft] - M2) + sm * EXP2(mx - M2);
+                     rM[ft] = M2;
+                  }
+               }
+               first = false;
+            }
+            if (nextTile >= 0) {
+#pragma unroll
+               for (int j = 0; j < PT; j++)
+                  if (j * NT + tid < TW4) wbuf[buf ^ 1][j * NT + tid] = stg[j];
+            }
+            __syncthreads();
+            buf ^= 1;
+            tile++;
+            if (tile >= t1) break;
+         }
+         tile = nextFirst;
+         float res = 0.0f;
+#pragma unroll
+         for (int ft = 0; ft < F16_COL_TILES; ft++) {
+            const float r = (rM[ft] + LOG2(rS[ft])) * 0.69314718055994531f;
+            if (kg == ft) res = r;
+         }
+         float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + k) * tk.ldo + fw;
+         if (active && lane < FPW && fw + lane < tk.nFrames) o[lane] = res;
+      }
+   }
+}
+
+int htkamd_launch_score_f16(const htkamd_model *m, const ScoreArgs &a0, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
+{
+   if (a0.nTasks <= 0) return HTKAMD_OK;
+   if (!m->d_f16Tab) { htkamd_set_error("score_f16: vector size %d not supported by the fp16 matrix-core path (up to 45)", m->D); return HTKAMD_EMODEL; }
+   if (m->f16Stale) {                                // parameters were re-estimated on the device since the table was built (and this path was not in use then)
+      int rc = htkamd_model_refresh_f16_device((htkamd_model *)m, (void *)stream);
+      if (rc) return rc;
+   }
+   ((htkamd_model *)m)->fastUse |= HTKAMD_SCORE_F16;
+   ScoreArgs a = a0;
+   a.f16Tab = m->d_f16Tab; a.f16Ctl = (const int *)m->d_f16Ctl;
+   if (!a.rangeFlag) a.rangeFlag = (int *)m->d_f16Ctl + F16_CTL_STICKY;      // the model's sticky flag
+   HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int) * (a.rangeFlag == a.taskCounter + 1 ? 2 : 1), stream));      // a pass's own flag lies behind its counter
+   const int parts = B16_TASK_FRAMES / (16 * F16_COL_TILES * F16_WPB);
+   int blocks = a.nTasks * parts;
+   if (blocks > 256 * ((4 * F16_EU) / F16_WPB)) blocks = 256 * ((4 * F16_EU) / F16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) at a time
+   dim3 grid(blocks), block(64 * F16_WPB);
+   switch (m->bf16NC) {
+   case 3: hipExtLaunchKernelGGL((k_score_f16<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 2: hipExtLaunchKernelGGL((k_score_f16<2>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   case 1: hipExtLaunchKernelGGL((k_score_f16<1>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+   default: htkamd_set_error("score_f16: no kernel for %d K-chunks", m->bf16NC); return HTKAMD_EMODEL;
+   }
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------ the A-operand table, built on the device
+struct F16TabArgs {
+   int D, NC, S, G;
+   const int *stateCompOff, *stateTileOff, *compGauss, *tileState;
+   const float *mean, *ivar, *gconst, *compLogWt;
+   unsigned short *tab;        // [tile][ 2*NC*64*8 f16 | 64*4 f32 ]
+   float *ctl;                 // the model's control block
+};
+
+// ranges: per k the largest |coefficient| over the Gaussians and an estimate of the largest |z| (|x| <= |mu| + 8 sigma).  A block reads
+// R = 256 / D whole rows at a time, thread t always dimension t % D: its running maxima stay in registers, the block's go through LDS
+// to the control block with one atomic each.  The chunks' constants -0.5 sum mu^2 ivar are bounded by the sum of the dimensions' maxima.
+#define F16_RANGE_BLOCKS 512
+__global__ __launch_bounds__(256) void k_f16_range(F16TabArgs a)
+{
+   __shared__ unsigned int sm[5 * 48];              // [aq | al | zq | zl | mu^2 ivar][D <= 45]
+   const int D = a.D, tid = threadIdx.x, R = 256 / D;
+   const float L2E = 1.4426950408889634f;
+   for (int i = tid; i < 5 * 48; i += 256) sm[i] = 0u;
+   __syncthreads();
+   const int d = tid % D;
+   float aq = 0.0f, al = 0.0f, zq = 0.0f, zl = 0.0f, mq = 0.0f;
+   if (tid < R * D)
+      for (size_t g0 = (size_t)blockIdx.x * R; g0 < (size_t)a.G; g0 += (size_t)gridDim.x * R) {
+         const size_t idx = g0 * D + tid;
+         if (idx >= (size_t)a.G * D) break;
+         const float m = a.mean[idx], v = a.ivar[idx];
+         const float xm = fabsf(m) + 8.0f * (v > 0.0f ? rsqrtf(v) : 0.0f);
+         aq = fmaxf(aq, 0.5f * v * L2E); al = fmaxf(al, fabsf(m * v * L2E)); zq = fmaxf(zq, xm * xm); zl = fmaxf(zl, xm); mq = fmaxf(mq, 0.5f * m * m * v * L2E);
+      }
+   atomicMax(&sm[d], __float_as_uint(aq)); atomicMax(&sm[48 + d], __float_as_uint(al));
+   atomicMax(&sm[96 + d], __float_as_uint(zq)); atomicMax(&sm[144 + d], __float_as_uint(zl)); atomicMax(&sm[192 + d], __float_as_uint(mq));
+   __syncthreads();
+   unsigned int *rng = (unsigned int *)a.ctl + F16_CTL_RANGE;
+   if (tid < D) {
+      const int dpc = (D + a.NC - 1) / a.NC, ch = tid / dpc, k = ch * 32 + 2 * (tid - ch * dpc);
+      atomicMax(&rng[k], sm[tid]); atomicMax(&rng[k + 1], sm[48 + tid]);
+      atomicMax(&rng[96 + k], sm[96 + tid]); atomicMax(&rng[96 + k + 1], sm[144 + tid]);
+      atomicMax(&rng[F16_CTL_MQ - F16_CTL_RANGE + tid], sm[192 + tid]);
+   }
+}
+
+// scale of k: a power of two that puts the largest scaled coefficient and the largest scaled z at the same height
+__global__ void k_f16_scale(float *ctl, int D, int NC)
+{
+   const int k = threadIdx.x;
+   if (k >= 96) return;
+   const unsigned int *rng = (const unsigned int *)ctl + F16_CTL_RANGE;
+   float *scl = ctl;
+   float am = __uint_as_float(rng[k]), zm = __uint_as_float(rng[96 + k]);
+   if ((k & 31) == 30 && (k >> 5) < NC) {            // the chunk's constant: at most the sum of its dimensions' largest 0.5 mu^2 ivar, against 1
+      const int dpc = (D + NC - 1) / NC, dlo = dpc * (k >> 5), dhi = (dlo + dpc < D) ? dlo + dpc : D;
+      am = 0.0f;
+      for (int d = dlo; d < dhi; d++) am += __uint_as_float(rng[F16_CTL_MQ - F16_CTL_RANGE + d]);
+      zm = 1.0f;
+   }
+   float e = 0.0f;
+   if (am > 0.0f && zm > 0.0f) e = rintf(0.5f * (log2f(zm) - log2f(am)));
+   scl[k] = exp2f(e);
+   scl[96 + k] = exp2f(-e);
+}
+
+// one thread per (tile, chunk, lane): its 8 coefficients in two pieces = two 16-byte stores, consecutive lanes to consecutive
+// words; the 16 threads (chunk 0, lane group 0) of a tile also write their component's accumulator start
+__global__ void k_build_f16tab(F16TabArgs a, int nTiles)
+{
+   const int NC = a.NC, D = a.D;
+   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+   if (idx >= nTiles * NC * 64) return;
+   const int t = idx / (NC * 64), r = idx - t * (NC * 64), ch = r >> 6, lane = r & 63, rowc = lane & 15, kg = lane >> 4;
+   const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
+   const size_t tileShorts = (size_t)2 * NC * 64 * 8 + 64 * 8;      // the f32 part counted in shorts
+   unsigned short *T = a.tab + (size_t)t * tileShorts;
+   const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
+   const double L2E = 1.4426950408889634;
+   const float *mu = nullptr, *iv = nullptr;
+   if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
+   const int dpc = (D + NC - 1) / NC, dlo = dpc * ch, dhi = (dlo + dpc < D) ? dlo + dpc : D;     // this chunk's dimensions
+   _Float16 p[2][8];
+   bool over = false;
+#pragma unroll
+   for (int j = 0; j < 8; j++) {
+      const int kk = 8 * kg + j, dim = dlo + (kk >> 1);
+      float v = 0.0f;
+      if (live && dim < dhi) v = (kk & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+      if (live && kk == 30) {                               // against B's constant 1: -0.5 sum mu^2 ivar over the chunk
+         double q = 0.0;
+         for (int i = dlo; i < dhi; i++) q += (double)mu[i] * mu[i] * iv[i];
+         v = (float)(-0.5 * q * L2E);
+      }
+      v *= a.ctl[ch * 32 + kk];
+      if (!(fabsf(v) <= F16_MAX)) over = true;
+      split2(v, p[0][j], p[1][j]);
+   }
+#pragma unroll
+   for (int pc = 0; pc < 2; pc++) {
+      u4 w;
+      w[0] = pack2(p[pc][0], p[pc][1]); w[1] = pack2(p[pc][2], p[pc][3]);
+      w[2] = pack2(p[pc][4], p[pc][5]); w[3] = pack2(p[pc][6], p[pc][7]);
+      *(u4 *)(T + ((size_t)(pc * NC + ch) * 64 + lane) * 8) = w;
+   }
+   if (over) atomicOr((int *)a.ctl + F16_CTL_FLAG, HTKAMD_F16_EMODEL);
+   if (ch == 0 && kg == 0) {
+      float ci = -1.0e30f;
+      if (live) {
+         const double k0 = a.gconst[a.compGauss[c]];
+         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+      }
+      float *ciBase = (float *)(T + (size_t)2 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
+      for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
+   }
+}
+
+int htkamd_model_refresh_f16_device(htkamd_model *m, void *stream)
+{
+   hipStream_t s = (hipStream_t)stream;
+   if (!m->d_f16Tab) return HTKAMD_OK;
+   F16TabArgs t;
+   t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.G = m->G; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss; t.tileState = m->d_tileState;
+   t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_f16Tab; t.ctl = m->d_f16Ctl;
+   HIPCHECK(hipMemsetAsync(m->d_f16Ctl + F16_CTL_RANGE, 0, sizeof(int) * (F16_CTL_MQ + 48 - F16_CTL_RANGE), s));      // ranges, the table's flag, k_f16_range's row; the sticky flag stays
+   hipLaunchKernelGGL(k_f16_range, dim3(F16_RANGE_BLOCKS), dim3(256), 0, s, t);
+   hipLaunchKernelGGL(k_f16_scale, dim3(1), dim3(128), 0, s, m->d_f16Ctl, m->D, m->bf16NC);
+   const int n = m->nTiles * m->bf16NC * 64;
+   hipLaunchKernelGGL(k_build_f16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   HIPCHECK(hipGetLastError());
+   m->f16Stale = 0;
+   return HTKAMD_OK;
+}
+
+// the model's sticky range flag (set by launches that have no flag of their own to raise: htkamd_outp_block_mode), read and cleared
+int htkamd_model_f16_flag(htkamd_model *m, void *stream, int *flag)
+{
+   hipStream_t s = (hipStream_t)stream;
+   *flag = 0;
+   if (!m->d_f16Ctl) return HTKAMD_OK;
+   int *p = (int *)m->d_f16Ctl + F16_CTL_STICKY;
+   HIPCHECK(hipMemcpyAsync(flag, p, sizeof(int), hipMemcpyDeviceToHost, s));
+   HIPCHECK(hipStreamSynchronize(s));
+   if (*flag) HIPCHECK(hipMemsetAsync(p, 0, sizeof(int), s));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_model_f16_check(htkamd_model *m, void *stream)
+{
+   if (!m) { htkamd_set_error("model_f16_check: NULL"); return HTKAMD_EINVAL; }
+   int flag = 0;
+   const int rc = htkamd_model_f16_flag(m, stream, &flag);
+   if (rc) return rc;
+   if (flag) {
+      htkamd_set_error("model_f16_check: the fp16 scoring path met %s%s%s outside its range since the last check: repeat those calls with HTKAMD_SCORE_BF16",
+                       (flag & HTKAMD_F16_EMODEL) ? "a model coefficient" : "", (flag & HTKAMD_F16_EMODEL) && (flag & HTKAMD_F16_EFEAT) ? " and " : "", (flag & HTKAMD_F16_EFEAT) ? "a feature value" : "");
+      return HTKAMD_ERANGE;
+   }
+   return HTKAMD_OK;
+}

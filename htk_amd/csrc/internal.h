@@ -87,6 +87,10 @@ struct htkamd_model {
    int    mfmaStale;           /* the fp32 fragment table is older than the parameters (device update): rebuilt on its next use */
    void  *d_bf16Tab;           /* bf16 x 3 scoring path (gmm_bf16.hip): A-operand pieces per tile; NULL when D > 45 */
    int    bf16NC;              /* K chunks of 32 per piece: ceil(D/15) */
+   void  *d_f16Tab;            /* fp16 x 2 scoring path (gmm_f16.hip): A-operand pieces per tile, K chunks as the bf16 path; NULL when D > 45 */
+   float *d_f16Ctl;            /* its control block: scale[96], 1/scale[96], range[192], flag of the last table build, sticky range flag */
+   int    bf16Stale, f16Stale; /* the table is older than the parameters (a device update while the path was not in use): rebuilt on its next use */
+   int    fastUse;             /* HTKAMD_SCORE_BF16 / _F16 bits: the paths that have scored with this model (their tables follow every device update) */
    /* shared mean / variance vectors (~u / ~v macros; htkamd_model_set_sharing): first Gaussian of the group a Gaussian's mean / variance
       belongs to (itself when private), members of its variance group; NULL = no sharing in the set */
    int   *h_meanLeader, *h_varLeader, *h_varGroupSize;
@@ -110,6 +114,11 @@ struct htkamd_model {
 void htkamd_outp_ring_free(void *ring);                      /* gmm_exact.hip */
 int htkamd_model_refresh_mfma_device(struct htkamd_model *m, void *stream);   /* update.hip */
 int htkamd_model_refresh_bf16_device(struct htkamd_model *m, void *stream);   /* gmm_bf16.hip (stream: hipStream_t) */
+int htkamd_model_refresh_f16_device(struct htkamd_model *m, void *stream);    /* gmm_f16.hip */
+int htkamd_model_f16_flag(struct htkamd_model *m, void *stream, int *flag);   /* gmm_f16.hip: the sticky range flag, read and cleared */
+/* range flag of the fp16 path (ScoreArgs::rangeFlag) */
+#define HTKAMD_F16_EMODEL 1    /* a scaled coefficient of the model exceeds fp16's range */
+#define HTKAMD_F16_EFEAT  2    /* a scaled feature value (x or x^2) exceeds fp16's range */
 int htkamd_model_device_tables(struct htkamd_model *m);      /* model.hip: uploads d_var etc. once */
 int htkamd_model_sync_host(struct htkamd_model *m);          /* model.hip: device -> host parameter copies when stale */
 int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, const double *acc,

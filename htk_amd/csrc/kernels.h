@@ -5,6 +5,9 @@
 #include "internal.h"
 
 #define SCORE_TILE_FRAMES 128   /* 64 lanes x 2 frames per lane */
+#ifndef B16_TASK_FRAMES
+#define B16_TASK_FRAMES 128     /* frames per task of the bf16 matrix-core kernel in forward-backward (experiment switch HTKAMD_B16_TF) */
+#endif
 #define SCORE_TASK_SLOTS  16    /* chain states scored per task */
 #define SCORE_TASK_SLOTS_WIDE 64 /* the same for the matrix-core kernels in forward-backward (fb.hip) */
 #define SCORE_TASK_SLOTS_EXACT 8 /* and for the exact kernel there: one wave per task, features in registers, so small tasks balance best
@@ -35,6 +38,9 @@ struct ScoreArgs {
    const float *mfmaTab;      // MFMA path only
    const int *stateTileOff;
    const void *bf16Tab;       // bf16 x 3 path only
+   const void *f16Tab = nullptr;       // fp16 x 2 path only (set by its launcher): the table, the model's control block
+   const int *f16Ctl = nullptr;
+   int *rangeFlag = nullptr;           // fp16 x 2 path: where HTKAMD_F16_* bits are raised (NULL: the model's sticky flag)
    const float *var;          // DIAGC form only: variances [G*D]
    // several streams, HRec's state output probability (cPOutP HRec.c:510-548: outp += w[s] * cSOutP(s), float): a slot names the state's
    // first (state, stream) element, the kernel scores its NSt elements and writes their weighted sum.  NSt <= 1 (what forward-backward
@@ -48,9 +54,11 @@ struct ScoreArgs {
 int htkamd_launch_score_exact(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr, bool soutp = false, bool diagc = false);
 int htkamd_launch_score_mfma(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
-// the scoring kernel of a score mode (HTKAMD_SCORE_* bits: BF16 before MFMA before exact)
+int htkamd_launch_score_f16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
+// the scoring kernel of a score mode (HTKAMD_SCORE_* bits: F16 before BF16 before MFMA before exact)
 static inline int htkamd_launch_score(int mode, const htkamd_model *m, const ScoreArgs &a, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
+   if (mode & HTKAMD_SCORE_F16) return htkamd_launch_score_f16(m, a, s, e0, e1);
    if (mode & HTKAMD_SCORE_BF16) return htkamd_launch_score_bf16(m, a, s, e0, e1);
    if (mode & HTKAMD_SCORE_MFMA) return htkamd_launch_score_mfma(m, a, s, e0, e1);
    return htkamd_launch_score_exact(m, a, s, e0, e1, (mode & HTKAMD_SCORE_SOUTP) != 0, (mode & HTKAMD_SCORE_DIAGC) != 0);

@@ -112,10 +112,16 @@ static int mfma_refresh(htkamd_model *m)
       free(off);
       if (rc) return rc;
       m->bf16NC = (D + 14) / 15;                      // 15 dimensions as (x^2, x) pairs + the chunk's constant per K chunk of 32 (gmm_bf16.hip)
-      if (m->bf16NC <= 3) HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
+      if (m->bf16NC <= 3) {
+         HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
+         HIPCHECK(hipMalloc(&m->d_f16Tab, (size_t)m->nTiles * ((size_t)2 * m->bf16NC * 64 * 16 + 64 * 16)));
+         HIPCHECK(hipMalloc(&m->d_f16Ctl, sizeof(float) * 512));
+         HIPCHECK(hipMemset(m->d_f16Ctl, 0, sizeof(float) * 512));
+      }
    }
-   {  // bf16 x 3 path: its table is built on the device from the tables just uploaded
+   {  // bf16 x 3 and fp16 x 2 paths: their tables are built on the device from the tables just uploaded
       int rcb = htkamd_model_refresh_bf16_device(m, nullptr);
+      if (!rcb) rcb = htkamd_model_refresh_f16_device(m, nullptr);
       if (rcb) return rcb;
       HIPCHECK(hipStreamSynchronize(nullptr));
    }
@@ -350,7 +356,7 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    (void)hipFree(m->d_gparam); (void)hipFree(m->d_laddTab); (void)hipFree(m->d_mean); (void)hipFree(m->d_ivar); (void)hipFree(m->d_gconst);
    (void)hipFree(m->d_compLogWt); (void)hipFree(m->d_transP); (void)hipFree(m->d_stateCompOff); (void)hipFree(m->d_compGauss);
    (void)hipFree(m->d_transN); (void)hipFree(m->d_transOff); (void)hipFree(m->d_mfmaTab); (void)hipFree(m->d_stateTileOff);
-   (void)hipFree(m->d_bf16Tab); (void)hipFree(m->d_tileState);
+   (void)hipFree(m->d_bf16Tab); (void)hipFree(m->d_f16Tab); (void)hipFree(m->d_f16Ctl); (void)hipFree(m->d_tileState);
    (void)hipFree(m->d_var); (void)hipFree(m->d_compWeight); (void)hipFree(m->d_trOccOff); (void)hipFree(m->d_hmmTrans);
    (void)hipFree(m->d_hmmStateOff); (void)hipFree(m->d_hmmState); (void)hipFree(m->d_updScratch);
    htkamd_outp_ring_free(m->obRing);

@@ -485,9 +485,11 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
       hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), ag.logVar ? sizeof(float) * (size_t)B * m->D : 0, s, ag);
    }
    HIPCHECK(hipGetLastError());
-   // the bf16 x 3 fragment table now; the fp32 one when the fp32 matrix-core kernel is next asked for (htkamd_launch_score_mfma)
-   m->mfmaStale = 1;
-   if ((rc = htkamd_model_refresh_bf16_device(m, s))) return rc;
+   // the fragment tables of the matrix-core paths that have been scoring with this model now (bf16 x 3, fp16 x 2), the others when
+   // they are next asked for (htkamd_launch_score_mfma / _bf16 / _f16)
+   m->mfmaStale = 1; m->bf16Stale = 1; m->f16Stale = 1;
+   if ((m->fastUse & HTKAMD_SCORE_BF16) && (rc = htkamd_model_refresh_bf16_device(m, s))) return rc;
+   if ((m->fastUse & HTKAMD_SCORE_F16) && (rc = htkamd_model_refresh_f16_device(m, s))) return rc;
    m->hostStale = 1;
    // the transition matrices are small and the host needs them (minimum durations for CreateInsts, tee flags for the decoder)
    const size_t nTp = (size_t)m->h_transOff[m->nT];

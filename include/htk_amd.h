@@ -31,6 +31,8 @@ extern "C" {
 #define HTKAMD_EHIP     (-4)   /* HIP runtime error, see htkamd_last_error() */
 #define HTKAMD_EMODEL   (-5)   /* model violates a restriction of this path (streams>1, non-diagonal cov...) */
 #define HTKAMD_EIO      (-6)   /* file cannot be opened / read / written */
+#define HTKAMD_ERANGE   (-7)   /* HTKAMD_SCORE_F16 only: a feature value or a model coefficient does not fit the fp16 scoring path's range;
+                                  nothing of the pass can be used -- repeat it with HTKAMD_SCORE_BF16 (same tolerance class, fp32's exponent) */
 
 /* HTK's log-arithmetic constants (HMath.h:42-45, HModel.h:52-53, HFB.h:31) */
 #define HTKAMD_LZERO    (-1.0E10)
@@ -274,10 +276,22 @@ int htkamd_outp_block(htkamd_model *m, const float *dX, int T, const int *dState
 /* htkamd_outp_block_mode only, may be or-ed with HTKAMD_SCORE_SOUTP: DOutP's form for DIAGC sets (HModel.c:5347: xmm*xmm/var, the float
  * division) -- what MOutP dispatches to when the set has not been through ConvDiagC, as in HRest / HInit.  Bit-identical to DOutP. */
 #define HTKAMD_SCORE_DIAGC 16
+/* The expanded form on the FP16 matrix pipe, both operands split into TWO fp16 pieces (11 + 11 significant bits and the signs: fp32's 24)
+ * and the three piece products that matter summed in fp32 (gmm_f16.hip): half the matrix instructions of HTKAMD_SCORE_BF16 for the same
+ * tolerance class (measured |score - exact| rms 3.4e-5 against 3.2e-5), ~1.45x its speed.  fp16's range is bridged by a power-of-two
+ * scale per term, chosen from the model on the device; a feature value far outside anything the model describes (or a model whose
+ * coefficients span more than the format) is DETECTED, not computed wrongly: htkamd_fb_results / htkamd_outp_block_mode return
+ * HTKAMD_ERANGE and the pass is to be repeated with HTKAMD_SCORE_BF16.  Forward-backward and htkamd_outp_block_mode (vector sizes up
+ * to 45); takes precedence over HTKAMD_SCORE_BF16 and HTKAMD_SCORE_MFMA. */
+#define HTKAMD_SCORE_F16   32
 #define HTKAMD_SCORE_FAST  (HTKAMD_SCORE_MFMA | HTKAMD_SCORE_FASTLADD)
-#define HTKAMD_SCORE_FASTEST (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_FASTLADD)
+#define HTKAMD_SCORE_FASTEST (HTKAMD_SCORE_F16 | HTKAMD_SCORE_FASTLADD)
 int htkamd_outp_block_mode(htkamd_model *m, const float *dX, int T, const int *dStates, int ns,
                            float *dOut, int ldo, int scoreMode, void *stream);
+/* HTKAMD_SCORE_F16 through htkamd_outp_block_mode: the calls are asynchronous, so the range flag they raise is the model's.  This waits
+ * for the stream and returns HTKAMD_ERANGE if a call since the last check raised it (and clears it): the scores of those calls are to
+ * be recomputed with HTKAMD_SCORE_BF16.  (Forward-backward passes carry their own flag: htkamd_fb_results.) */
+int htkamd_model_f16_check(htkamd_model *m, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Baum-Welch accumulators: MuAcc / VaAcc / WtAcc / TrAcc of HTrain.h:211-232 plus the

@@ -24,7 +24,7 @@ import c3_herest as c3
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(0, "exact"), (6, "fastest")]
+MODES = [(0, "exact"), (6, "bf16x3fast"), (34, "fastest")]
 
 
 def _hip_model(native, s, pk, mode):

@@ -97,7 +97,7 @@ def test_outp_large_block_statistics(native, oracle):
 
 
 # ----------------------------------------------------------------------------------------- scoring on the matrix cores (K1m)
-@pytest.mark.parametrize("mode", [1, 4], ids=["f32mfma", "bf16x3"])
+@pytest.mark.parametrize("mode", [1, 4, 32], ids=["f32mfma", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("D,M", [(39, 16), (39, 20), (39, 5), (26, 2), (13, 1), (13, 33), (36, 8), (20, 3), (7, 2), (40, 4), (45, 3), (16, 6), (17, 2)])
 def test_outp_block_mfma_tolerance(native, oracle, D, M, mode):
     """HTKAMD_SCORE_MFMA: expanded-form fp32 GEMM + float log-sum-exp.  Tolerance class: |score - reference| <= 1e-3
@@ -122,6 +122,48 @@ def test_outp_block_mfma_tolerance(native, oracle, D, M, mode):
         assert np.abs(g1 - ref[:T]).max() <= 1e-3
 
 
+def test_f16_path_detects_what_it_cannot_represent(native, oracle):
+    """HTKAMD_SCORE_F16 scales every term by a power of two chosen from the model; a feature value far outside anything the model
+    describes (here 3e4 in one dimension of one frame: x^2 = 9e8, scaled beyond 65504) must raise HTKAMD_ERANGE -- from
+    htkamd_model_f16_check for block scoring, from htkamd_fb_results for a forward-backward pass -- and never come out as a wrong
+    score; the same data through HTKAMD_SCORE_BF16 is within tolerance, and ordinary data afterwards passes again."""
+    from htk_amd import synth
+    s = synth.generate(25, 4, 10, 3, 60, 77, D=39)
+    pk = s.packed()
+    gm, om = native.Model(pk), oracle.Model(pk)
+    states = np.arange(25, dtype=np.int32)
+    X = s.feats[0].copy()
+    ok = gm.outp_block(X, states, mode=32)
+    assert np.abs(ok - om.score_block(X, states)).max() <= 1e-3
+    Xb = X.copy(); Xb[17, 5] = 3.0e4
+    with pytest.raises(native.HtkAmdError) as ei:
+        gm.outp_block(Xb, states, mode=32)
+    assert ei.value.rc == native.ERANGE and "feature" in str(ei.value)
+    ref = om.score_block(Xb, states)
+    got = gm.outp_block(Xb, states, mode=4)
+    assert np.abs(got - ref)[np.arange(len(Xb)) != 17].max() <= 1e-3
+    assert np.allclose(got[17], ref[17], rtol=1e-5)
+    assert np.abs(gm.outp_block(X, states, mode=32) - om.score_block(X, states)).max() <= 1e-3      # the flag was cleared
+    # forward-backward: the pass's own flag
+    feats = [f.copy() for f in s.feats]
+    feats[1][3, 0] = -5.0e4
+    fb = native.ForwardBackward(gm); acc = native.Accs(gm)
+    Xall = np.concatenate(feats)
+    frameOff = np.concatenate([[0], np.cumsum([len(f) for f in feats])]).astype(np.int32)
+    labOff = np.concatenate([[0], np.cumsum([len(q) for q in s.seqs])]).astype(np.int32)
+    labs = np.concatenate(s.seqs).astype(np.int32)
+    dX = native.DevArray(Xall)
+    for mode, bad in ((34, True), (6, False)):
+        acc.zero(None); fb.prepare(dX.ptr.value, frameOff, labOff, labs, None); fb.execute(native.fb_config(scoreMode=mode), acc, None)
+        if bad:
+            with pytest.raises(native.HtkAmdError) as ei:
+                fb.results(None)
+            assert ei.value.rc == native.ERANGE
+        else:
+            pr, st = fb.results(None)
+            assert (st == 1).all()
+
+
 def test_outp_block_mfma_rejects_other_sizes(native):
     from htk_amd import synth
     s = synth.generate(5, 2, 4, 1, 20, 5, D=45)
@@ -132,7 +174,7 @@ def test_outp_block_mfma_rejects_other_sizes(native):
         gm.outp_block(s.feats[0], np.arange(5, dtype=np.int32), mode=7)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 6], ids=["mfma", "fastladd", "fast", "bf16x3", "fastest"])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 6, 32, 34], ids=["mfma", "fastladd", "fast", "bf16x3", "bf16x3fast", "f16x2", "fastest"])
 @pytest.mark.parametrize("name", ["fb_small", "fb_topo", "fb_small_prune", "fb_topo_prune"])
 def test_mfma_forward_backward_within_tolerance(native, name, mode):
     """HERest through the tolerance-class kernels (matrix-core scores and / or the fp32-transcendental LAdd of the recursions):
@@ -479,7 +521,7 @@ def test_config2_properties(native):
     assert a["nEval"] == fb.frame_states() == 64 * 47220
 
 
-@pytest.mark.parametrize("mode", [0, 3, 6], ids=["exact", "fast", "fastest"])
+@pytest.mark.parametrize("mode", [0, 3, 6, 34], ids=["exact", "fast", "bf16x3fast", "fastest"])
 def test_config3_headline_size(native, oracle, mode):
     """The configuration bench.py measures (BASELINE config[2] per GPU: 5k tied states x 16 mix, D = 39, 500-frame utterances of 41
     models), 64 utterances, in the exact mode and in the mode the bench runs (matrix-core scores + fast LAdd): utterance
@@ -832,7 +874,7 @@ def test_viterbi_long_chains_every_kernel_class(native, oracle, beam, topo):
     assert sum(g["status"] == 1 for g in got) >= 6
 
 
-@pytest.mark.parametrize("mode", [0, 6], ids=["exact", "fastest"])
+@pytest.mark.parametrize("mode", [0, 6, 34], ids=["exact", "bf16x3fast", "fastest"])
 def test_run_to_run_reproducibility(native, mode):
     """The statistics are summed with fp64 atomics, so their LAST bits depend on the order in which wavefronts arrive; everything computed
     per utterance (log-probabilities, beams, trellis) does not.  Two passes over one batch: `pr` bit-identical, accumulators equal to

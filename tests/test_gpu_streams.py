@@ -143,7 +143,7 @@ def test_herest_cli_three_streams(native, tmp_path):
     assert os.path.getsize(str(acc / "HER1.acc")) == os.path.getsize(os.path.join(d, "HER1.acc"))
 
 
-@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("mode", [0, 6, 34])
 @pytest.mark.parametrize("widths,single,seed", [((10, 10), (), 1), ((8, 8, 4), (2,), 2), ((6, 6, 6, 2), (), 3), ((12, 8), (0, 1), 4), ((5, 15), (1,), 5)])
 def test_random_stream_sets(native, oracle, widths, single, seed, mode):
     """Random sets on random transcriptions; `single`: streams with one Gaussian (their posterior is the state's occupation, HFB.c:1584);

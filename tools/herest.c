@@ -224,16 +224,20 @@ int main(int argc, char **argv)
       /* The shard in batches.  With --iterations K > 1 everything a batch needs stays where the first iteration put it -- features in HBM,
          transcriptions as model indices, the batch tables of CreateInsts / SetBeamTaper in their context -- and the model never leaves
          the device between iterations: iteration 2.. cost the pass and the update, not the files. */
-      typedef struct { obs_batch ob; int *labOff, *labs; int count, first; htkamd_fb *fb; } dev_batch;
+      typedef struct { obs_batch ob; int *labOff, *labs; int count, first, prepared; htkamd_fb *fb; } dev_batch;
       const int nBatch = (mine.n + batchN - 1) / batchN;
       dev_batch *bt = (dev_batch *)calloc((size_t)(nBatch ? nBatch : 1), sizeof(dev_batch));
       for (int it = 1; it <= nIter; it++) {
+         int again;
+         do {                                          /* twice only when the fp16 scoring path reports data outside its range */
+         again = 0;
          CHECK(htkamd_accs_zero(accs, NULL));
-         for (int bi = 0; bi <= nBatch; bi++) {
+         const int keep = nIter > 1 || (fc.scoreMode & HTKAMD_SCORE_F16);      /* the batches stay until the iteration stands */
+         for (int bi = 0; bi <= nBatch && !again; bi++) {
             if (bi < nBatch) {
                dev_batch *B = &bt[bi];
                tic_ = now_s();
-               if (it == 1) {
+               if (!B->fb) {
                   B->first = bi * batchN; B->count = (mine.n - B->first < batchN) ? mine.n - B->first : batchN;
                   load_observations(&mine, B->first, B->count, targetKind, &cfg, &B->ob);
                   if (B->ob.cols != D) DIE("observations have %d components, the models %d", B->ob.cols, D);
@@ -259,7 +263,8 @@ int main(int argc, char **argv)
                   CHECK(htkamd_fb_create(model, &B->fb));
                }
                TOC(2);
-               if (it == 1 || !htkamd_fb_prepared_current(B->fb)) {           /* the update changed a minimum duration: tables again */
+               if (!B->prepared || !htkamd_fb_prepared_current(B->fb)) {      /* the update changed a minimum duration: tables again */
+                  B->prepared = 1;
                   htkamd_batch_desc b = {B->count, B->ob.dX, B->ob.frameOff, B->labOff, B->labs};
                   CHECK(htkamd_fb_prepare(B->fb, &b, NULL));
                }
@@ -270,7 +275,17 @@ int main(int argc, char **argv)
                dev_batch *B = &bt[bi - 1];
                double *pr = (double *)malloc(sizeof(double) * (size_t)B->count); int *st = (int *)malloc(sizeof(int) * (size_t)B->count);
                tic_ = now_s();
-               CHECK(htkamd_fb_results(B->fb, pr, st, NULL));
+               const int rcr = htkamd_fb_results(B->fb, pr, st, NULL);
+               if (rcr == HTKAMD_ERANGE && (fc.scoreMode & HTKAMD_SCORE_F16)) {
+                  /* a value the fp16 x 2 scores cannot hold: the whole iteration again on the bf16 x 3 path (same tolerance class, fp32's range) */
+                  fprintf(stderr, "WARNING: %s\n  herest: repeating the iteration with the bf16 x 3 scoring path\n", htkamd_last_error());
+                  fc.scoreMode = (fc.scoreMode & ~HTKAMD_SCORE_F16) | HTKAMD_SCORE_BF16;
+                  CHECK(htkamd_stream_sync(NULL));
+                  free(pr); free(st);
+                  again = 1;
+                  break;
+               }
+               CHECK(rcr);
                TOC(4);
                for (int u = 0; u < B->count; u++) {
                   if (trace & 1) printf(" Processing Data: %s\n", mine.v[B->first + u]);
@@ -279,9 +294,10 @@ int main(int argc, char **argv)
                   else DIE("[%d] forward-backward failed on %s", -st[u], mine.v[B->first + u]);
                }
                free(pr); free(st);
-               if (nIter == 1) { free(B->labOff); free(B->labs); free_observations(&B->ob); htkamd_fb_destroy(B->fb); B->fb = NULL; }
+               if (!keep) { free(B->labOff); free(B->labs); free_observations(&B->ob); htkamd_fb_destroy(B->fb); B->fb = NULL; B->labOff = NULL; B->labs = NULL; B->prepared = 0; }
             }
          }
+         } while (again);
          if (comm) {
             alarm((unsigned)rcclTimeout);                   /* a rank that died before this point would leave the others in the collective for ever */
             CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL));
