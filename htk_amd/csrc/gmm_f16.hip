@@ -242,6 +242,215 @@ __global__ __launch_bounds__(64 * F16_WPB, F16_EU) void k_score_f16(ScoreArgs a)
    }
 }
 
+// ------------------------------------------------------------------------------------ the same on 32 x 32 blocks, states in pairs
+// For sets whose states all fit one tile (<= 16 components: htkamd_model::f16Wide).  v_mfma_f32_32x32x16_f16 leaves a lane the rows
+// 8b + 4(lane >> 5) + r (b, r = 0..3) of column lane & 31: with the components of state A dealt to the rows whose bit 2 is clear and
+// those of state B to the others, lanes 0..31 hold ALL 16 components of state A for their frame and lanes 32..63 those of state B.
+// The mixture's log-sum-exp then needs no exchange between lanes (the 16 x 16 form pays four row swaps per column tile), its maximum
+// and sum are trees of packed operations within the lane, and every lane ends with one result to store: ~60 vector instructions per
+// pair of states where the 16 x 16 form issues ~200, for the same 18 x 32 matrix cycles.
+//   Table per tile: [k-step 2 NC][piece 2][k-half 2][component 16][8 f16], then (log w - 0.5 gConst) log2(e) [16 f32]; a k-step is 16 k,
+//   chunk c = k-steps 2c, 2c + 1.  In LDS a pair is [k-step][piece][lane 64][8 f16] with lane = 32 k-half + 8 (comp >> 2) + 4 h + (comp & 3),
+//   then the two states' constants.
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef F16W_DIAG
+#define F16W_DIAG 0
+#endif
+#ifdef F16W_STAMP            /* experiment builds only (exp/score_exp.py): cycles per phase and wavefront */
+__device__ unsigned long long g_dbg[4096 * 16];
+#define STAMP_DECL unsigned long long t_ = __builtin_amdgcn_s_memtime(), t0_ = t_, acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - t_; t_ = n_; } while (0)
+#define STAMP_COUNT(i, n) acc_[i] += (n)
+#define STAMP_FLUSH do { if (lane == 0) { const int w_ = (blockIdx.x * 4 + wv) & 4095; acc_[6] = __builtin_amdgcn_s_memtime() - t0_; for (int i_ = 0; i_ < 10; i_++) g_dbg[w_ * 16 + i_] += acc_[i_]; } } while (0)
+extern "C" void htkamd_dbg_zero(void) { void *p; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg)); (void)hipMemset(p, 0, sizeof(unsigned long long) * 4096 * 16); }
+extern "C" void htkamd_dbg_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 4096 * 16); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_COUNT(i, n)
+#define STAMP_FLUSH
+#endif
+#ifndef F16W_EU
+#define F16W_EU 3
+#endif
+#ifndef F16W_AHEAD
+#define F16W_AHEAD 1
+#endif
+template <int NC>
+__global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
+{
+   static_assert(B16_TASK_FRAMES == 128, "four wavefronts x 32 frames");
+   constexpr int KS = 2 * NC;                          // k-steps of 16
+   constexpr int TW4 = KS * 2 * 32 + 4;                // 16-byte words per tile in the table
+   constexpr int PW4 = KS * 2 * 64 + 8;                // ... per pair in LDS
+   constexpr int PT = (TW4 + 127) / 128;               // words staged per thread (a half workgroup per tile)
+   __shared__ u4 wbuf[2][PW4];
+   __shared__ float xbuf[128 * 15 * NC];               // the task's 128 feature rows (D <= 15 NC), as they lie in memory
+   __shared__ float zsSh[32 * NC];                     // 1 / scale of every k
+   __shared__ int taskSh;
+   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   const int fcol = lane & 31, kh = lane >> 5;
+   const int D = a.D;
+   const int dpc = (D + NC - 1) / NC;                  // dimensions per K chunk (<= 15)
+   const u4 *tab = (const u4 *)a.f16Tab;
+   if (blockIdx.x == 0 && tid == 0 && a.f16Ctl[F16_CTL_FLAG]) atomicOr(a.rangeFlag, a.f16Ctl[F16_CTL_FLAG]);      // what the table build found
+   if (tid < 32 * NC) zsSh[tid] = ((const float *)a.f16Ctl)[96 + tid];
+   // staging: wavefronts 0, 1 bring the first state's tile, 2, 3 the second's; word w of a tile goes to the lane that multiplies it
+   const int hsel = __builtin_amdgcn_readfirstlane(wv >> 1), t7 = tid & 127;
+   int dst[PT];
+#pragma unroll
+   for (int j = 0; j < PT; j++) {
+      const int w = t7 + 128 * j;
+      const int comp = w & 15;
+      dst[j] = (w < KS * 64) ? (w >> 5) * 64 + ((w >> 4) & 1) * 32 + 8 * (comp >> 2) + 4 * hsel + (comp & 3) : KS * 128 + hsel * 4 + (w - KS * 64);
+   }
+   const int fw = 32 * wv;                             // this wave's first frame in the task's tile
+   STAMP_DECL;
+
+   for (;;) {
+      if (tid == 0) taskSh = atomicAdd(a.taskCounter, 1);
+      __syncthreads();
+      const int task = __builtin_amdgcn_readfirstlane(taskSh);
+      if (task >= a.nTasks) break;
+      const ScoreTask tk = a.tasks[task];
+      const bool active = fw < tk.nFrames;
+      const int nPairs = (tk.nSlots + 1) >> 1;
+      STAMP(0);
+      // the task's feature rows: one contiguous block, read in order by the whole workgroup
+      {
+         const float *xs = a.X + (size_t)tk.frame0 * D;
+         for (int i = tid; i < tk.nFrames * D; i += 256) xbuf[i] = xs[i];
+      }
+      // the tile of every state of the task, one per lane (tasks hold at most 64 states); one tile per state: the tile's number is the state's
+      int tileV = 0;
+      if (lane < tk.nSlots) tileV = a.slotState[tk.slot0 + lane];
+      auto pair_tile = [&](int j) { const int k = 2 * j + hsel; return __builtin_amdgcn_readlane(tileV, (k < tk.nSlots ? k : tk.nSlots - 1) & 63); };
+      {
+         const u4 *W = tab + (size_t)pair_tile(0) * TW4;
+#pragma unroll
+         for (int j = 0; j < PT; j++)
+            if (t7 + 128 * j < TW4) wbuf[0][dst[j]] = W[t7 + 128 * j];
+      }
+      STAMP(1);
+      __syncthreads();
+      STAMP(3);
+
+      // B operand from the rows in LDS: this lane's frame, the 8 k of its k-half in every k-step, scaled, in two fp16 pieces
+      h8 zb[KS][2];
+      if (active) {
+         bool over = false;
+         int f = fw + fcol;
+         if (f > tk.nFrames - 1) f = tk.nFrames - 1;
+         const float *row = xbuf + f * D;
+#pragma unroll
+         for (int ks = 0; ks < KS; ks++) {
+            const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * kh;      // chunk; first of this lane's four dimensions within it
+            _Float16 p[2][8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+               int dim = dpc * c + i0 + i;
+               const bool pad = i0 + i >= dpc || dim >= D;
+               if (pad) dim = D - 1;
+               float v = row[dim];
+               if (pad) v = 0.0f;
+               float v2 = v * v;
+               if ((ks & 1) && kh == 1 && i == 3) v2 = 1.0f;      // k = 30 of the chunk: the constant that meets -0.5 sum mu^2 ivar
+               v2 *= zsSh[c * 32 + 2 * (i0 + i)]; v *= zsSh[c * 32 + 2 * (i0 + i) + 1];
+               over = over || !(v2 <= F16_MAX) || !(fabsf(v) <= F16_MAX);
+               split2(v2, p[0][2 * i], p[1][2 * i]);
+               split2(v, p[0][2 * i + 1], p[1][2 * i + 1]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+               u4 w;
+               w[0] = pack2(p[s][0], p[s][1]); w[1] = pack2(p[s][2], p[s][3]);
+               w[2] = pack2(p[s][4], p[s][5]); w[3] = pack2(p[s][6], p[s][7]);
+               zb[ks][s] = __builtin_bit_cast(h8, w);
+            }
+         }
+         if (over) atomicOr(a.rangeFlag, HTKAMD_F16_EFEAT);
+      }
+      STAMP(0); STAMP_COUNT(8, 1);
+
+      int buf = 0;
+      float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + kh) * tk.ldo + fw + fcol;      // this lane's state (kh of the pair) and frame
+      const size_t oStep = 2 * (size_t)tk.ldo;
+      for (int j = 0; j < nPairs; j++) {
+         u4 stg[PT];
+         const bool more = j + 1 < nPairs;
+         if (more) {
+            const u4 *W = tab + (size_t)pair_tile(j + 1) * TW4;
+#pragma unroll
+            for (int q = 0; q < PT; q++)
+               if (t7 + 128 * q < TW4) stg[q] = W[t7 + 128 * q];
+         }
+         STAMP(1); STAMP_COUNT(7, 1);
+         if (active) {
+            STAMP_COUNT(9, 1);
+            f16v Cx, Cc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }
+            // corrections (a2 z1 + a1 z2, carried at 2^11 times their value) and leading products a1 z1 in accumulators of their own
+            // (the table's fragments a k-step ahead of the matrix instructions that take them: F16W_AHEAD)
+            h8 wa[KS][2];
+#pragma unroll
+            for (int ks = 0; ks < F16W_AHEAD && ks < KS; ks++) {
+               wa[ks][0] = __builtin_bit_cast(h8, wbuf[buf][(ks * 2 + 0) * 64 + lane]);
+               wa[ks][1] = __builtin_bit_cast(h8, wbuf[buf][(ks * 2 + 1) * 64 + lane]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+               if (ks + F16W_AHEAD < KS) {
+                  wa[ks + F16W_AHEAD][0] = __builtin_bit_cast(h8, wbuf[buf][((ks + F16W_AHEAD) * 2 + 0) * 64 + lane]);
+                  wa[ks + F16W_AHEAD][1] = __builtin_bit_cast(h8, wbuf[buf][((ks + F16W_AHEAD) * 2 + 1) * 64 + lane]);
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
+               Cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
+            }
+            // this lane's state: its 16 components in registers 4b + r
+            float y[16];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 128 + kh * 4 + b]);
+#pragma unroll
+               for (int r = 0; r < 4; r++) y[4 * b + r] = __builtin_fmaf(Cc[4 * b + r], 1.0f / F16_CORR, Cx[4 * b + r]) + ci[r];
+            }
+            float m8[8], m4[4];
+#pragma unroll
+            for (int r = 0; r < 8; r++) m8[r] = fmaxf(y[r], y[r + 8]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]);
+            const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) e[r] = EXP2(y[r] - mx);
+#pragma unroll
+            for (int r = 0; r < 8; r++) e[r] += e[r + 8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) e[r] += e[r + 4];
+            const float sm = (e[0] + e[1]) + (e[2] + e[3]);
+            const float res = (mx + LOG2(sm)) * 0.69314718055994531f;
+            if (fw + fcol < tk.nFrames && 2 * j + kh < tk.nSlots) *o = res;
+            o += oStep;
+         }
+         STAMP(2);
+         if (more) {
+#pragma unroll
+            for (int q = 0; q < PT; q++)
+               if (t7 + 128 * q < TW4) wbuf[buf ^ 1][dst[q]] = stg[q];
+         }
+         STAMP(4);
+         __syncthreads();
+         STAMP(5);
+         buf ^= 1;
+      }
+   }
+   STAMP_FLUSH;
+}
+
 int htkamd_launch_score_f16(const htkamd_model *m, const ScoreArgs &a0, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
 {
    if (a0.nTasks <= 0) return HTKAMD_OK;
@@ -255,6 +464,19 @@ int htkamd_launch_score_f16(const htkamd_model *m, const ScoreArgs &a0, hipStrea
    a.f16Tab = m->d_f16Tab; a.f16Ctl = (const int *)m->d_f16Ctl;
    if (!a.rangeFlag) a.rangeFlag = (int *)m->d_f16Ctl + F16_CTL_STICKY;      // the model's sticky flag
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int) * (a.rangeFlag == a.taskCounter + 1 ? 2 : 1), stream));      // a pass's own flag lies behind its counter
+   if (m->f16Wide) {                                 // every state in one tile: 32 x 32 blocks, states in pairs
+      int blocks = a.nTasks;
+      if (blocks > 256 * F16W_EU) blocks = 256 * F16W_EU;
+      dim3 grid(blocks), block(256);
+      switch (m->bf16NC) {
+      case 3: hipExtLaunchKernelGGL((k_score_f16w<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      case 2: hipExtLaunchKernelGGL((k_score_f16w<2>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      case 1: hipExtLaunchKernelGGL((k_score_f16w<1>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      default: htkamd_set_error("score_f16: no kernel for %d K-chunks", m->bf16NC); return HTKAMD_EMODEL;
+      }
+      HIPCHECK(hipGetLastError());
+      return HTKAMD_OK;
+   }
    const int parts = B16_TASK_FRAMES / (16 * F16_COL_TILES * F16_WPB);
    int blocks = a.nTasks * parts;
    if (blocks > 256 * ((4 * F16_EU) / F16_WPB)) blocks = 256 * ((4 * F16_EU) / F16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) at a time
@@ -383,6 +605,56 @@ __global__ void k_build_f16tab(F16TabArgs a, int nTiles)
    }
 }
 
+// the 32 x 32 form's table: one thread per (tile, k-step, k-half, component): its 8 coefficients in two pieces = two 16-byte stores
+__global__ void k_build_f16tab_w(F16TabArgs a, int nTiles)
+{
+   const int NC = a.NC, D = a.D, KS = 2 * NC;
+   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+   if (idx >= nTiles * KS * 32) return;
+   const int t = idx / (KS * 32), r = idx - t * (KS * 32), ks = r >> 5, kh = (r >> 4) & 1, rowc = r & 15, ch = ks >> 1;
+   const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
+   const size_t tileShorts = ((size_t)KS * 2 * 32 + 4) * 8;
+   unsigned short *T = a.tab + (size_t)t * tileShorts;
+   const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
+   const double L2E = 1.4426950408889634;
+   const float *mu = nullptr, *iv = nullptr;
+   if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
+   const int dpc = (D + NC - 1) / NC, dlo = dpc * ch, dhi = (dlo + dpc < D) ? dlo + dpc : D;     // this chunk's dimensions
+   _Float16 p[2][8];
+   bool over = false;
+#pragma unroll
+   for (int j = 0; j < 8; j++) {
+      const int kk = 16 * (ks & 1) + 8 * kh + j, dim = dlo + (kk >> 1);
+      float v = 0.0f;
+      if (live && dim < dhi) v = (kk & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+      if (live && kk == 30) {                               // against B's constant 1: -0.5 sum mu^2 ivar over the chunk
+         double q = 0.0;
+         for (int i = dlo; i < dhi; i++) q += (double)mu[i] * mu[i] * iv[i];
+         v = (float)(-0.5 * q * L2E);
+      }
+      v *= a.ctl[ch * 32 + kk];
+      if (!(fabsf(v) <= F16_MAX)) over = true;
+      split2(v, p[0][j], p[1][j]);
+   }
+#pragma unroll
+   for (int pc = 0; pc < 2; pc++) {
+      u4 w;
+      w[0] = pack2(p[pc][0], p[pc][1]); w[1] = pack2(p[pc][2], p[pc][3]);
+      w[2] = pack2(p[pc][4], p[pc][5]); w[3] = pack2(p[pc][6], p[pc][7]);
+      *(u4 *)(T + ((size_t)(ks * 2 + pc) * 32 + kh * 16 + rowc) * 8) = w;
+   }
+   if (over) atomicOr((int *)a.ctl + F16_CTL_FLAG, HTKAMD_F16_EMODEL);
+   if (ks == 0 && kh == 0) {
+      float ci = -1.0e30f;
+      if (live) {
+         const double k0 = a.gconst[a.compGauss[c]];
+         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+      }
+      ((float *)(T + (size_t)KS * 2 * 32 * 8))[rowc] = ci;
+   }
+}
+
 int htkamd_model_refresh_f16_device(htkamd_model *m, void *stream)
 {
    hipStream_t s = (hipStream_t)stream;
@@ -393,8 +665,13 @@ int htkamd_model_refresh_f16_device(htkamd_model *m, void *stream)
    HIPCHECK(hipMemsetAsync(m->d_f16Ctl + F16_CTL_RANGE, 0, sizeof(int) * (F16_CTL_MQ + 48 - F16_CTL_RANGE), s));      // ranges, the table's flag, k_f16_range's row; the sticky flag stays
    hipLaunchKernelGGL(k_f16_range, dim3(F16_RANGE_BLOCKS), dim3(256), 0, s, t);
    hipLaunchKernelGGL(k_f16_scale, dim3(1), dim3(128), 0, s, m->d_f16Ctl, m->D, m->bf16NC);
-   const int n = m->nTiles * m->bf16NC * 64;
-   hipLaunchKernelGGL(k_build_f16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   if (m->f16Wide) {
+      const int n = m->nTiles * m->bf16NC * 64;      // 2 NC k-steps x 32 threads per tile
+      hipLaunchKernelGGL(k_build_f16tab_w, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   } else {
+      const int n = m->nTiles * m->bf16NC * 64;
+      hipLaunchKernelGGL(k_build_f16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   }
    HIPCHECK(hipGetLastError());
    m->f16Stale = 0;
    return HTKAMD_OK;

@@ -114,6 +114,7 @@ static int mfma_refresh(htkamd_model *m)
       m->bf16NC = (D + 14) / 15;                      // 15 dimensions as (x^2, x) pairs + the chunk's constant per K chunk of 32 (gmm_bf16.hip)
       if (m->bf16NC <= 3) {
          HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
+         m->f16Wide = m->nTiles == m->S && !getenv("HTKAMD_F16_NARROW");      // (the switch: tests of the 16 x 16 form on such sets)
          HIPCHECK(hipMalloc(&m->d_f16Tab, (size_t)m->nTiles * ((size_t)2 * m->bf16NC * 64 * 16 + 64 * 16)));
          HIPCHECK(hipMalloc(&m->d_f16Ctl, sizeof(float) * 512));
          HIPCHECK(hipMemset(m->d_f16Ctl, 0, sizeof(float) * 512));
