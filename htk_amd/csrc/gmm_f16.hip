@@ -128,27 +128,29 @@ __global__ __launch_bounds__(64 * F16_WPB, F16_EU) void k_score_f16(ScoreArgs a)
       if (active) {
          const float *zs = (const float *)a.f16Ctl + 96;      // 1 / scale of every k
          bool over = false;
+         int kgL = kg, colL = col;
+         asm volatile("" : "+v"(kgL), "+v"(colL));      // (the indices below are cheap to recompute per task: hoisted out of the task loop they are spilled)
 #pragma unroll
       for (int c = 0; c < NC; c++) {
          float is[8];
 #pragma unroll
-         for (int j = 0; j < 8; j++) is[j] = zs[c * 32 + 8 * kg + j];
+         for (int j = 0; j < 8; j++) is[j] = zs[c * 32 + 8 * kgL + j];
 #pragma unroll
       for (int ft = 0; ft < F16_COL_TILES; ft++) {
-         int f = fw + ft * 16 + col;
+         int f = fw + ft * 16 + colL;
          if (f > tk.nFrames - 1) f = tk.nFrames - 1;
          const float *row = a.X + (size_t)(tk.frame0 + f) * D;
-            const int d0 = dpc * c + 4 * kg;          // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
+            const int d0 = dpc * c + 4 * kgL;          // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
             _Float16 p[2][8];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                int dim = d0 + i;
-               const bool pad = 4 * kg + i >= dpc || dim >= D;
+               const bool pad = 4 * kgL + i >= dpc || dim >= D;
                if (pad) dim = D - 1;
                float v = row[dim];
                if (pad) v = 0.0f;
                float v2 = v * v;
-               if (i == 3 && kg == 3) v2 = 1.0f;       // k = 30: the constant that meets the chunk's -0.5 sum mu^2 ivar
+               if (i == 3 && kgL == 3) v2 = 1.0f;       // k = 30: the constant that meets the chunk's -0.5 sum mu^2 ivar
                v2 *= is[2 * i]; v *= is[2 * i + 1];
                over = over || !(v2 <= F16_MAX) || !(fabsf(v) <= F16_MAX);
                split2(v2, p[0][2 * i], p[1][2 * i]);
@@ -271,6 +273,12 @@ extern "C" void htkamd_dbg_read(void *dst) { (void)hipDeviceSynchronize(); (void
 #define STAMP_COUNT(i, n)
 #define STAMP_FLUSH
 #endif
+#ifndef F16W_PIPE
+#define F16W_PIPE 1
+#endif
+#ifndef F16W_VPM
+#define F16W_VPM 4
+#endif
 #ifndef F16W_EU
 #define F16W_EU 3
 #endif
@@ -340,12 +348,13 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
       h8 zb[KS][2];
       if (active) {
          bool over = false;
-         int f = fw + fcol;
+         int khL = kh, f = fw + fcol;
+         asm volatile("" : "+v"(khL), "+v"(f));         // (the indices below are cheap to recompute per task: hoisted out of the task loop they are spilled)
          if (f > tk.nFrames - 1) f = tk.nFrames - 1;
          const float *row = xbuf + f * D;
 #pragma unroll
          for (int ks = 0; ks < KS; ks++) {
-            const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * kh;      // chunk; first of this lane's four dimensions within it
+            const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * khL;      // chunk; first of this lane's four dimensions within it
             _Float16 p[2][8];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
                float v = row[dim];
                if (pad) v = 0.0f;
                float v2 = v * v;
-               if ((ks & 1) && kh == 1 && i == 3) v2 = 1.0f;      // k = 30 of the chunk: the constant that meets -0.5 sum mu^2 ivar
+               if ((ks & 1) && khL == 1 && i == 3) v2 = 1.0f;      // k = 30 of the chunk: the constant that meets -0.5 sum mu^2 ivar
                v2 *= zsSh[c * 32 + 2 * (i0 + i)]; v *= zsSh[c * 32 + 2 * (i0 + i) + 1];
                over = over || !(v2 <= F16_MAX) || !(fabsf(v) <= F16_MAX);
                split2(v2, p[0][2 * i], p[1][2 * i]);
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
                w[2] = pack2(p[s][4], p[s][5]); w[3] = pack2(p[s][6], p[s][7]);
                zb[ks][s] = __builtin_bit_cast(h8, w);
             }
+            __builtin_amdgcn_sched_barrier(0);               // one k-step's values in flight at a time: the registers are wanted for zb
          }
          if (over) atomicOr(a.rangeFlag, HTKAMD_F16_EFEAT);
       }
@@ -376,6 +386,11 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
       int buf = 0;
       float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + kh) * tk.ldo + fw + fcol;      // this lane's state (kh of the pair) and frame
       const size_t oStep = 2 * (size_t)tk.ldo;
+#if F16W_PIPE
+      float yP[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) yP[r] = 0.0f;
+#endif
       for (int j = 0; j < nPairs; j++) {
          u4 stg[PT];
          const bool more = j + 1 < nPairs;
@@ -388,27 +403,65 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
          STAMP(1); STAMP_COUNT(7, 1);
          if (active) {
             STAMP_COUNT(9, 1);
+#if F16W_PIPE
+            // The log-sum-exp of the pair BEFORE this one (its 16 values per lane were left in yP) in 18 slices, one behind each of this
+            // pair's matrix instructions and fenced there: ~4 vector instructions fit in the shadow of a 32-cycle matrix instruction.
+            float m8[8], m4[4], m2[2], mx = 0.0f, e[16], sm = 0.0f, lg = 0.0f, resP = 0.0f;
+            auto lse_slice = [&](int sl) {
+               if (sl < 2) { for (int r = 4 * sl; r < 4 * sl + 4; r++) m8[r] = fmaxf(yP[r], yP[r + 8]); }
+               else if (sl == 2) { for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]); }
+               else if (sl == 3) { m2[0] = fmaxf(m4[0], m4[1]); m2[1] = fmaxf(m4[2], m4[3]); mx = fmaxf(m2[0], m2[1]); }
+               else if (sl < 12) { for (int r = 2 * (sl - 4); r < 2 * (sl - 4) + 2; r++) e[r] = EXP2(yP[r] - mx); }
+               else if (sl < 14) { for (int r = 4 * (sl - 12); r < 4 * (sl - 12) + 4; r++) e[r] += e[r + 8]; }
+               else if (sl == 14) { for (int r = 0; r < 4; r++) e[r] += e[r + 4]; }
+               else if (sl == 15) { sm = (e[0] + e[1]) + (e[2] + e[3]); }
+               else if (sl == 16) { lg = LOG2(sm); }
+               else { resP = (mx + lg) * 0.69314718055994531f; }
+            };
             f16v Cx, Cc;
 #pragma unroll
             for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }
-            // corrections (a2 z1 + a1 z2, carried at 2^11 times their value) and leading products a1 z1 in accumulators of their own
-            // (the table's fragments a k-step ahead of the matrix instructions that take them: F16W_AHEAD)
             h8 wa[KS][2];
-#pragma unroll
-            for (int ks = 0; ks < F16W_AHEAD && ks < KS; ks++) {
-               wa[ks][0] = __builtin_bit_cast(h8, wbuf[buf][(ks * 2 + 0) * 64 + lane]);
-               wa[ks][1] = __builtin_bit_cast(h8, wbuf[buf][(ks * 2 + 1) * 64 + lane]);
-            }
+            wa[0][0] = __builtin_bit_cast(h8, wbuf[buf][0 * 64 + lane]);
+            wa[0][1] = __builtin_bit_cast(h8, wbuf[buf][1 * 64 + lane]);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
-               if (ks + F16W_AHEAD < KS) {
-                  wa[ks + F16W_AHEAD][0] = __builtin_bit_cast(h8, wbuf[buf][((ks + F16W_AHEAD) * 2 + 0) * 64 + lane]);
-                  wa[ks + F16W_AHEAD][1] = __builtin_bit_cast(h8, wbuf[buf][((ks + F16W_AHEAD) * 2 + 1) * 64 + lane]);
+               if (ks + 1 < KS) {
+                  wa[ks + 1][0] = __builtin_bit_cast(h8, wbuf[buf][((ks + 1) * 2 + 0) * 64 + lane]);
+                  wa[ks + 1][1] = __builtin_bit_cast(h8, wbuf[buf][((ks + 1) * 2 + 1) * 64 + lane]);
                }
                __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
+               if (3 * ks + 0 < 18) lse_slice(3 * ks + 0);
+               __builtin_amdgcn_sched_barrier(0);
                Cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
+               if (3 * ks + 1 < 18) lse_slice(3 * ks + 1);
+               __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
+               if (3 * ks + 2 < 18) lse_slice(3 * ks + 2);
+               __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
+            asm volatile("" : "+v"(resP));                       // (computed HERE, not inside the branch of its store)
+            if (j > 0 && fw + fcol < tk.nFrames) *o = resP;      // (the pair before always has both its states)
+            if (j > 0) o += oStep;
+            // this pair's 16 components per lane, registers 4b + r: left for the next round
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 128 + kh * 4 + b]);
+#pragma unroll
+               for (int r = 0; r < 4; r++) yP[4 * b + r] = __builtin_fmaf(Cc[4 * b + r], 1.0f / F16_CORR, Cx[4 * b + r]) + ci[r];
+            }
+#else
+            f16v Cx, Cc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+               const h8 wa0 = __builtin_bit_cast(h8, wbuf[buf][(ks * 2 + 0) * 64 + lane]), wa1 = __builtin_bit_cast(h8, wbuf[buf][(ks * 2 + 1) * 64 + lane]);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa1, zb[ks][0], Cc, 0, 0, 0);
+               Cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, zb[ks][0], Cx, 0, 0, 0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa0, zb[ks][1], Cc, 0, 0, 0);
             }
             // this lane's state: its 16 components in registers 4b + r
             float y[16];
@@ -435,6 +488,7 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
             const float res = (mx + LOG2(sm)) * 0.69314718055994531f;
             if (fw + fcol < tk.nFrames && 2 * j + kh < tk.nSlots) *o = res;
             o += oStep;
+#endif
          }
          STAMP(2);
          if (more) {
@@ -447,6 +501,25 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
          STAMP(5);
          buf ^= 1;
       }
+#if F16W_PIPE
+      if (active) {                                    // the last pair's log-sum-exp
+         float m8[8], m4[4];
+#pragma unroll
+         for (int r = 0; r < 8; r++) m8[r] = fmaxf(yP[r], yP[r + 8]);
+#pragma unroll
+         for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]);
+         const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+         float e[16];
+#pragma unroll
+         for (int r = 0; r < 16; r++) e[r] = EXP2(yP[r] - mx);
+#pragma unroll
+         for (int r = 0; r < 8; r++) e[r] += e[r + 8];
+#pragma unroll
+         for (int r = 0; r < 4; r++) e[r] += e[r + 4];
+         const float sm = (e[0] + e[1]) + (e[2] + e[3]);
+         if (fw + fcol < tk.nFrames && 2 * (nPairs - 1) + kh < tk.nSlots) *o = (mx + LOG2(sm)) * 0.69314718055994531f;
+      }
+#endif
    }
    STAMP_FLUSH;
 }

@@ -50,7 +50,7 @@ def fuzz_fb(rng, it):
     if rng.random() < 0.25:
         mode |= 2                                                   # fast LAdd of the recursions (tolerance class)
     if rng.random() < 0.3 and (mode & 1):                           # (this draw once selected the removed scaled-linear mode)
-        mode = (mode & ~1) | 4                                      # bf16 x 3 matrix-core scores instead of the fp32 ones (bench.py's default with |2)
+        mode = (mode & ~1) | (4 if it % 2 else 32)                  # bf16 x 3 / fp16 x 2 matrix-core scores instead of the fp32 ones (the latter with |2: bench.py's default)
     model = capi.Model(pk); om = pyoracle.Model(pk)
     utts = [dict(seq=np.asarray(q, np.int32), feat=x) for q, x in zip(seqs, feats)]
     X, frameOff, labOff, labs = batch_arrays(utts)
