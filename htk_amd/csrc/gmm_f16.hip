@@ -626,17 +626,25 @@ __global__ void k_f16_scale(float *ctl, int D, int NC)
    scl[96 + k] = exp2f(-e);
 }
 
-// one thread per (tile, chunk, lane): its 8 coefficients in two pieces = two 16-byte stores, consecutive lanes to consecutive
-// words; the 16 threads (chunk 0, lane group 0) of a tile also write their component's accumulator start
+// The table of a tile: every coefficient in two pieces, and the components' accumulator starts.
+//   What two fp16 pieces leave of a coefficient, rho_k = a_k s_k - a1 - a2 2^-11 (|rho| <= 2^-22 |a s|), is the same in every frame: an
+// error of the score that does not average out along a path (measured on the bench set: 6e-6 rms per Gaussian over its own frames,
+// worst 2e-5 -- occupancies off by several 1e-5).  Its EXPECTATION under the Gaussian itself, sum_k rho_k E[z_k] / s_k with
+// E[x^2] = mu^2 + sigma^2, E[x] = mu, E[1] = 1, is a constant of the component and goes into its accumulator start (fp32, added by the
+// vector unit): what is left has mean zero over the Gaussian's own frames (3e-7 rms, worst 1e-6 in the same measurement), and the
+// chunk constants' share is removed exactly.
+template <bool WIDE>
 __global__ void k_build_f16tab(F16TabArgs a, int nTiles)
 {
+   // a workgroup per tile, a thread per (chunk, group of 8 k, component): 64 NC threads, consecutive components in consecutive threads
+   // (their 16-byte stores are adjacent); the 4 NC partial sums of a component's correction meet in LDS and are added in a fixed order
+   __shared__ double part[16][12];
    const int NC = a.NC, D = a.D;
-   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-   if (idx >= nTiles * NC * 64) return;
-   const int t = idx / (NC * 64), r = idx - t * (NC * 64), ch = r >> 6, lane = r & 63, rowc = lane & 15, kg = lane >> 4;
+   const int t = blockIdx.x, r = threadIdx.x, ch = r >> 6, kg = (r >> 4) & 3, rowc = r & 15;
    const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
    const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
-   const size_t tileShorts = (size_t)2 * NC * 64 * 8 + 64 * 8;      // the f32 part counted in shorts
+   // WIDE: [k-step 2 NC][piece 2][k-half 2][component 16][8 f16] then 16 f32; else [piece 2][chunk NC][lane 64][8 f16] then [lane 64][4 f32]
+   const size_t tileShorts = WIDE ? ((size_t)NC * 2 * 2 * 32 + 4) * 8 : (size_t)2 * NC * 64 * 8 + 64 * 8;
    unsigned short *T = a.tab + (size_t)t * tileShorts;
    const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
    const double L2E = 1.4426950408889634;
@@ -645,86 +653,53 @@ __global__ void k_build_f16tab(F16TabArgs a, int nTiles)
    const int dpc = (D + NC - 1) / NC, dlo = dpc * ch, dhi = (dlo + dpc < D) ? dlo + dpc : D;     // this chunk's dimensions
    _Float16 p[2][8];
    bool over = false;
+   double bias = 0.0;
 #pragma unroll
    for (int j = 0; j < 8; j++) {
       const int kk = 8 * kg + j, dim = dlo + (kk >> 1);
       float v = 0.0f;
-      if (live && dim < dhi) v = (kk & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
+      double ez = 0.0;                                       // E[z_k] under the Gaussian
+      if (live && dim < dhi && kk < 30) {
+         const double m = mu[dim], w = iv[dim];
+         v = (kk & 1) ? (float)(m * w * L2E) : (float)(-0.5 * w * L2E);
+         ez = (kk & 1) ? m : ((w > 0.0) ? m * m + 1.0 / w : 0.0);      // (1/variance 0: a dimension outside the Gaussian's stream, coefficient 0)
+      }
       if (live && kk == 30) {                               // against B's constant 1: -0.5 sum mu^2 ivar over the chunk
          double q = 0.0;
          for (int i = dlo; i < dhi; i++) q += (double)mu[i] * mu[i] * iv[i];
-         v = (float)(-0.5 * q * L2E);
+         v = (float)(-0.5 * q * L2E); ez = 1.0;
       }
-      v *= a.ctl[ch * 32 + kk];
+      const float sc = a.ctl[ch * 32 + kk];
+      v *= sc;
       if (!(fabsf(v) <= F16_MAX)) over = true;
       split2(v, p[0][j], p[1][j]);
+      bias += ((double)v - (double)(float)p[0][j] - (double)(float)p[1][j] * (1.0 / F16_CORR)) * ez / (double)sc;
    }
 #pragma unroll
    for (int pc = 0; pc < 2; pc++) {
       u4 w;
       w[0] = pack2(p[pc][0], p[pc][1]); w[1] = pack2(p[pc][2], p[pc][3]);
       w[2] = pack2(p[pc][4], p[pc][5]); w[3] = pack2(p[pc][6], p[pc][7]);
-      *(u4 *)(T + ((size_t)(pc * NC + ch) * 64 + lane) * 8) = w;
+      // k = 32 ch + 8 kg + j: WIDE k-step 2 ch + (kg >> 1), k-half kg & 1; else lane 16 kg + component of chunk ch
+      const size_t word = WIDE ? (size_t)((2 * ch + (kg >> 1)) * 2 + pc) * 32 + (kg & 1) * 16 + rowc : (size_t)(pc * NC + ch) * 64 + 16 * kg + rowc;
+      *(u4 *)(T + word * 8) = w;
    }
    if (over) atomicOr((int *)a.ctl + F16_CTL_FLAG, HTKAMD_F16_EMODEL);
+   part[rowc][ch * 4 + kg] = bias;
+   __syncthreads();
    if (ch == 0 && kg == 0) {
       float ci = -1.0e30f;
       if (live) {
+         double bsum = 0.0;
+         for (int i = 0; i < 4 * NC; i++) bsum += part[rowc][i];
          const double k0 = a.gconst[a.compGauss[c]];
-         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E + bsum);
       }
-      float *ciBase = (float *)(T + (size_t)2 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
-      for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
-   }
-}
-
-// the 32 x 32 form's table: one thread per (tile, k-step, k-half, component): its 8 coefficients in two pieces = two 16-byte stores
-__global__ void k_build_f16tab_w(F16TabArgs a, int nTiles)
-{
-   const int NC = a.NC, D = a.D, KS = 2 * NC;
-   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-   if (idx >= nTiles * KS * 32) return;
-   const int t = idx / (KS * 32), r = idx - t * (KS * 32), ks = r >> 5, kh = (r >> 4) & 1, rowc = r & 15, ch = ks >> 1;
-   const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
-   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
-   const size_t tileShorts = ((size_t)KS * 2 * 32 + 4) * 8;
-   unsigned short *T = a.tab + (size_t)t * tileShorts;
-   const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
-   const double L2E = 1.4426950408889634;
-   const float *mu = nullptr, *iv = nullptr;
-   if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
-   const int dpc = (D + NC - 1) / NC, dlo = dpc * ch, dhi = (dlo + dpc < D) ? dlo + dpc : D;     // this chunk's dimensions
-   _Float16 p[2][8];
-   bool over = false;
-#pragma unroll
-   for (int j = 0; j < 8; j++) {
-      const int kk = 16 * (ks & 1) + 8 * kh + j, dim = dlo + (kk >> 1);
-      float v = 0.0f;
-      if (live && dim < dhi) v = (kk & 1) ? (float)((double)mu[dim] * iv[dim] * L2E) : (float)(-0.5 * (double)iv[dim] * L2E);
-      if (live && kk == 30) {                               // against B's constant 1: -0.5 sum mu^2 ivar over the chunk
-         double q = 0.0;
-         for (int i = dlo; i < dhi; i++) q += (double)mu[i] * mu[i] * iv[i];
-         v = (float)(-0.5 * q * L2E);
+      if (WIDE) ((float *)(T + (size_t)NC * 2 * 2 * 32 * 8))[rowc] = ci;
+      else {
+         float *ciBase = (float *)(T + (size_t)2 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
+         for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
       }
-      v *= a.ctl[ch * 32 + kk];
-      if (!(fabsf(v) <= F16_MAX)) over = true;
-      split2(v, p[0][j], p[1][j]);
-   }
-#pragma unroll
-   for (int pc = 0; pc < 2; pc++) {
-      u4 w;
-      w[0] = pack2(p[pc][0], p[pc][1]); w[1] = pack2(p[pc][2], p[pc][3]);
-      w[2] = pack2(p[pc][4], p[pc][5]); w[3] = pack2(p[pc][6], p[pc][7]);
-      *(u4 *)(T + ((size_t)(ks * 2 + pc) * 32 + kh * 16 + rowc) * 8) = w;
-   }
-   if (over) atomicOr((int *)a.ctl + F16_CTL_FLAG, HTKAMD_F16_EMODEL);
-   if (ks == 0 && kh == 0) {
-      float ci = -1.0e30f;
-      if (live) {
-         const double k0 = a.gconst[a.compGauss[c]];
-         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
-      }
-      ((float *)(T + (size_t)KS * 2 * 32 * 8))[rowc] = ci;
    }
 }
 
@@ -738,12 +713,9 @@ int htkamd_model_refresh_f16_device(htkamd_model *m, void *stream)
    HIPCHECK(hipMemsetAsync(m->d_f16Ctl + F16_CTL_RANGE, 0, sizeof(int) * (F16_CTL_MQ + 48 - F16_CTL_RANGE), s));      // ranges, the table's flag, k_f16_range's row; the sticky flag stays
    hipLaunchKernelGGL(k_f16_range, dim3(F16_RANGE_BLOCKS), dim3(256), 0, s, t);
    hipLaunchKernelGGL(k_f16_scale, dim3(1), dim3(128), 0, s, m->d_f16Ctl, m->D, m->bf16NC);
-   if (m->f16Wide) {
-      const int n = m->nTiles * m->bf16NC * 64;      // 2 NC k-steps x 32 threads per tile
-      hipLaunchKernelGGL(k_build_f16tab_w, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
-   } else {
-      const int n = m->nTiles * m->bf16NC * 64;
-      hipLaunchKernelGGL(k_build_f16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   if (m->nTiles > 0) {
+      if (m->f16Wide) hipLaunchKernelGGL(k_build_f16tab<true>, dim3(m->nTiles), dim3(64 * m->bf16NC), 0, s, t, m->nTiles);
+      else hipLaunchKernelGGL(k_build_f16tab<false>, dim3(m->nTiles), dim3(64 * m->bf16NC), 0, s, t, m->nTiles);
    }
    HIPCHECK(hipGetLastError());
    m->f16Stale = 0;

@@ -15,6 +15,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
    rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o $tag --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 1 --warmup 0 > $out/bench_pmc_$c.json 2> $out/rocprof_$c.log
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d $out/pmc_SQ -o $tag --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 1 --warmup 0 > $out/bench_pmc_SQ.json 2> $out/rocprof_SQ.log
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA --kernel-trace -d $out/pmc_MFMA -o $tag --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 1 --warmup 0 > $out/bench_pmc_MFMA.json 2> $out/rocprof_MFMA.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA --kernel-trace -d $out/pmc_MFMA -o $tag --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 1 --warmup 0 > $out/bench_pmc_MFMA.json 2> $out/rocprof_MFMA.log
 python3 bench.py > $out/bench.json 2> $out/bench.err
 tail -c 600 $out/bench.json

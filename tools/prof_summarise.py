@@ -49,7 +49,7 @@ for k, v in per_kernel(os.path.join(out, "pmc_SQ"), names).items():
 json.dump({"_comment": "SQ counters per launch (mean over the launches of `bench.py --steps 1 --warmup 0`)", "kernels": sq},
           open(os.path.join("profiles", "%s_sq.json" % tag), "w"), indent=1)
 mf = {}
-mnames = {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_MFMA"}
+mnames = {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA"}
 for k, v in per_kernel(os.path.join(out, "pmc_MFMA"), mnames).items():
     mf[k] = {c: sum(x) / len(x) for c, x in v.items()}
     if mf[k].get("SQ_BUSY_CU_CYCLES"):
