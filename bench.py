@@ -469,7 +469,7 @@ def main():
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
-        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16<3>", "fastest": "k_score_f16<3>"}.get(args.score, "k_score_mfma<20>")
+        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16<3>", "fastest": "k_score_f16w<3>"}.get(args.score, "k_score_mfma<20>")
         # HBM-side bytes per launch of every kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/prof_r03.sh),
         # same workload only
         traffic_of = {}
@@ -539,7 +539,7 @@ def main():
             kpad = ((D + 14) // 15) * 32
             nprod = 3 if args.score == "fastest" else 6
             exe = units_local * args.mix * kpad * 2 * nprod / k1 / 1e12 if k1 > 0 else 0.0
-            ex = {"pipe": "v_mfma_f32_16x16x32_f16, operands split in two fp16 pieces" if args.score == "fastest" else "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces",
+            ex = {"pipe": "v_mfma_f32_32x32x16_f16, operands split in two fp16 pieces" if args.score == "fastest" else "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces",
                   "achieved": exe, "peak": 2500.0, "unit": "TFLOP/s",
                   "frac": exe / 2500.0, "note": "`achieved` of the scoring kernel counts the fp32 algorithm's flops (the unit's definition) against the fp32 matrix peak"}
             per_kernel["score"]["executed"] = ex
