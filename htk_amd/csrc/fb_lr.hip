@@ -25,6 +25,7 @@
 //   alphaW[alphaW0 + T L + (t-1) QP + q-1]               alpha_1(q,t), the entry-state value of model q
 //   qBeam / aBeam [frame0 + t-1]                         lo | hi << 16 of the beta and alpha beams (one scalar load per frame)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "internal.h"
 #include "hipcheck.h"
 #include "kernels.h"
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64 * W) void k_beta_lr(FbArgs a)
    int *gBeam = a.qBeam + ud.frame0 - 1;
    ObsRow st;
    st.lds = stage[wv]; st.lane = lane; st.R = (f4s)(0.f);
-   st.row = valid ? a.outp + ud.outp0 + (size_t)gl * T : nullptr;
+   st.row = a.outp + ud.outp0 + (size_t)(valid ? gl : 0) * T;      // (lanes past the chain read the first state's row: no lane-divergent loads)
    const double mle = a.minLogExp;
    const bool pruning = a.pruneInit < HTKAMD_NOPRUNE;
 #define ladd(x, y) ladd_sel<FAST>((x), (y), mle, ltab)
@@ -136,12 +137,12 @@ __global__ __launch_bounds__(64 * W) void k_beta_lr(FbArgs a)
       const int endT = tLo[T];
       {
          const int bl = (T - 1) >> 2;
-         st.load(bl); st.park(bl);
-         if (bl >= 1) st.load(bl - 1);
-         obT = st.get(T - 1);
+         st.load_all(bl); st.park(bl);
+         if (bl >= 1) st.load_all(bl - 1);
+         obT = st.get_all(T - 1);
          if (T >= 2) {
-            if (((T - 2) & 3) == 3) { st.park((T - 2) >> 2); if (((T - 2) >> 2) >= 1) st.load(((T - 2) >> 2) - 1); }
-            obP = st.get(T - 2);
+            if (((T - 2) & 3) == 3) { st.park((T - 2) >> 2); if (((T - 2) >> 2) >= 1) st.load_all(((T - 2) >> 2) - 1); }
+            obP = st.get_all(T - 2);
          }
       }
       const bool inT = valid && q >= endT;
@@ -164,27 +165,29 @@ __global__ __launch_bounds__(64 * W) void k_beta_lr(FbArgs a)
       for (int t = T - 1; t >= 1; t--) {
          const int taperLoT = nxtLo, taperHiT = nxtHi;
          if (t >= 2) { nxtLo = tLo[t - 1]; nxtHi = tHi[t - 1]; }
-         if (t >= 2 && ((t - 2) & 3) == 3) { st.park((t - 2) >> 2); if (((t - 2) >> 2) >= 1) st.load(((t - 2) >> 2) - 1); }
+         if (t >= 2 && ((t - 2) & 3) == 3) { st.park((t - 2) >> 2); if (((t - 2) >> 2) >= 1) st.load_all(((t - 2) >> 2) - 1); }
          if (stPrev) {                                   // the column finished in the previous iteration goes out now
             if (stIn) BETA_S(tPrev) = bJ;
             if (gl == 0) { gLo[tPrev] = (short)loPrev; gHi[tPrev] = (short)hiPrev; gBeam[tPrev] = loPrev | (hiPrev << 16); }
             stPrev = false;
          }
          obT = obP;
-         if (t >= 2) obP = st.get(t - 2);
+         if (t >= 2) obP = st.get_all(t - 2);
          const int startq = qHiN;
          const int endq = (qLoN == 1) ? 1 : ((taperLoT >= qLoN) ? taperLoT : qLoN - 1);
          const bool inRange = valid && q >= endq && q <= startq;
          const bool wasIn = q >= qLoN && q <= qHiN;
-         if (inRange) {
+         if constexpr (FAST) {                          // (every lane, selects instead of a lane-divergent branch)
             const bool p1 = (q < Q) && (q + 1 >= qLoN) && (q + 1 <= qHiN);
-            if constexpr (FAST) {
-               // the lane next door: the next state of the model, or (last lane) the exit state = the entry state of the next model
-               const double nb = s.last ? ((double)s.aExit + (p1 ? (double)s.aEntryNext + oN + yN : LZERO))
-                                        : (wasIn ? (double)s.aNext + oN + yN : LZERO);
-               const double self = wasIn ? (double)s.aSelf + obL + bJ : LZERO;
-               bJ = ladd_fast(nb, self);
-            } else {
+            // the lane next door: the next state of the model, or (last lane) the exit state = the entry state of the next model
+            const double nb = s.last ? ((double)s.aExit + (p1 ? (double)s.aEntryNext + oN + yN : LZERO))
+                                     : (wasIn ? (double)s.aNext + oN + yN : LZERO);
+            const double self = wasIn ? (double)s.aSelf + obL + bJ : LZERO;
+            const double bn = ladd_fast(nb, self);
+            bJ = inRange ? bn : bJ;
+         } else if (inRange) {
+            const bool p1 = (q < Q) && (q + 1 >= qLoN) && (q + 1 <= qHiN);
+            {
                double ex = LZERO;                                   // beta_N(q,t) = beta_1(q+1,t+1)
                if (s.last && p1) ex = entry_beta<false>(s.aEntryNext, oN, yN);
                double x = (double)s.aExit + ex;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    int *gaBeam = a.aBeam + ud.frame0 - 1;                      // alpha beams as FIRST LANES: first lane of model sq | first lane of model eq << 16
    ObsRow st;
    st.lds = stage[wv]; st.lane = lane; st.R = (f4s)(0.f);
-   st.row = valid ? a.outp + ud.outp0 + (size_t)gl * T : nullptr;
+   st.row = a.outp + ud.outp0 + (size_t)(valid ? gl : 0) * T;      // (lanes past the chain read the first state's row: no lane-divergent loads)
    const double mle = a.minLogExp, pr = a.pr[u];
    const double minF = (double)a.minFrwdP;
    const float aA = s.first ? s.aEntry : s.aPrev;        // the transition into the state from the lane before it / from the entry state
@@ -320,15 +323,15 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    float oT = 0.f, oT1 = 0.f;
    int w1 = qBeam[1], w2 = (T >= 2) ? qBeam[2] : 1, w3 = 1;
    int hi0 = 0, lo1 = w1 & 0xffff, hi1 = w1 >> 16, lo2 = w2 & 0xffff, hi2 = (T >= 2) ? (w2 >> 16) : 0;
-   double *pS = valid ? &ALPHA_S(1) : nullptr;           // this lane's place in the stored columns, advanced by L per step
+   double *pS = &ALPHA_S(1);                             // this lane's place in the stored columns, advanced by L per step (every lane of the workgroup has one)
    double *pE = (valid && s.first) ? &ALPHA_E(1, q) : nullptr;
-   if (valid) {
+   {
       bT = BETA_S(1);
       if (T >= 2) bT1 = BETA_S(2);
    }
-   st.load(0); st.park(0);
-   if (T > 4) st.load(1);
-   oT = st.get(0); if (T >= 2) oT1 = st.get(1);
+   st.load_all(0); st.park(0);
+   if (T > 4) st.load_all(1);
+   oT = st.get_all(0); if (T >= 2) oT1 = st.get_all(1);
    int err = 0;
    double mmpA = LZERO;                                  // MaxModelProb of this model in the column just finished (first lane)
    int fLo0 = 0, fLo1 = flOf[lo1], fHi1 = flOf[hi1 > 0 ? hi1 : 1], fE0 = 0;
@@ -338,16 +341,18 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    double eT = LZERO, eT1 = LZERO;                       // entry-state beta of the own model in columns t, t+1 (first lane)
    if (valid && s.first) { eT = entry_beta<FAST>(s.aEntry, (double)oT, bT); if (T >= 2) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1); }
 
-   for (int t = 1; t <= T; t++) {
-      if (t + 2 <= T) {                                  // request column t+2
+   // (column 1 -- InitAlpha -- is a call of its own: the loop body carries no branch on t and no copies of the state it does not touch)
+   auto step = [&](const int t, auto first_) -> bool {
+      constexpr bool FIRST = decltype(first_)::value;
+      if (t + 2 <= T) {                                  // request column t+2 (lanes past the chain read their own unused places: no divergence)
          w3 = qBeam[t + 2];
-         if (valid) bT2 = BETA_S(t + 2);
+         bT2 = BETA_S(t + 2);
       }
       const int par = t & 1;
       const bool inB = valid && q >= lo1 && q <= hi1;    // in the beta beam of t
       bool in;
       int sl = 0, el = 0;
-      if (t == 1) {
+      if constexpr (FIRST) {
          // ---- InitAlpha (HFB.c:616-651): without tee models only the first model starts
          const int eq = hi1;
          double a1 = 0.0;
@@ -395,10 +400,10 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
          if (fLo0 != mLoOf) { mLo = MaskW<W>::range(fLo0, L - 1); mLoOf = fLo0; }
          if (fE0 != mEOf) { mE = MaskW<W>::range(0, fE0 - 1); mEOf = fE0; }
          const int slane = (kept & mLo).lowest();                                      // first model >= qLo[t-1] that is kept
-         if (slane < 0 || slane > fHi1) { err = 1; break; }                            // sq > qHi[t]
+         if (slane < 0 || slane > fHi1) { err = 1; return false; }                            // sq > qHi[t]
          sl = (slane < fLo1) ? fLo1 : slane;                                           // start-point below the beta beam: pulled back
          const int elane = (kept & mE).highest();                                      // last kept model <= min(qHi[t-1] + 1, Q)
-         if (elane < 0 || elane < sl) { err = 1; break; }
+         if (elane < 0 || elane < sl) { err = 1; return false; }
          el = (elane > fHi1) ? fHi1 : elane;
          in = valid && myFirst >= sl && myFirst <= el;
          aJ = in ? aJn : LZERO; aE = in ? a1 : LZERO; xpre = x;
@@ -407,10 +412,8 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
          yPrev = inPrev ? yp : LZERO;
       }
       if (gl == 0) gaBeam[t] = sl | (el << 16);
-      if (valid) {
-         *pS = xpre; pS += L;
-         if (s.first) { *pE = aE; pE += ud.QP; }
-      }
+      *pS = xpre; pS += L;
+      if (valid && s.first) { *pE = aE; pE += ud.QP; }
       // exit value of the model BEFORE this one in column t (HFB.c:762-769 there): alpha_1 of this model in column t+1
       double aXp;
       if constexpr (FAST) aXp = yPrev + (double)s.aExitPrev;
@@ -425,22 +428,16 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
          }
       }
       // ---- MaxModelProb of column t (HFB.c:655-683), at the model's first lane
-      if (valid && s.first) {
-         double mm = LZERO;
-         if (inB) {
-            // (outside the alpha beam every term is a log-zero plus something: the model is not kept, whatever the sum)
-            mm = aE + eT;                                // i = 1
-            const double *xs = xsum[par] + SPAD + gl;
+      {  // (every lane computes it, selects instead of branches; the ballot of the next step asks the models' first lanes only)
+         // (outside the alpha beam every term is a log-zero plus something: the model is not kept, whatever the sum)
+         double mm = aE + eT;                            // i = 1
+         const double *xs = xsum[par] + SPAD + gl;
 #pragma unroll
-            for (int k = 0; k < 3; k++) if (2 + k <= N - 1) { const double v = xs[k]; if (v > mm) mm = v; }
-            if (!in) mm = LZERO;                         // the published sums were not masked by the alpha beam
-         }
+         for (int k = 0; k < 3; k++) { const double v = xs[k]; mm = (2 + k <= N - 1 && v > mm) ? v : mm; }
+         mm = (inB && in) ? mm : LZERO;                  // the published sums were not masked by the alpha beam
          // alpha_N + beta_N of the model before; its beta_N(t) is this model's beta_1(t+1) inside the beam of t+1
-         double prevExit = LZERO;
-         if (q > 1 && q - 1 >= lo1 && q - 1 <= hi1) {
-            const double bNp = (t == T) ? LZERO : ((q >= lo2 && q <= hi2) ? eT1 : LZERO);
-            prevExit = aXp + bNp;
-         }
+         const double bNp = (t != T && q >= lo2 && q <= hi2) ? eT1 : LZERO;
+         const double prevExit = (q > 1 && q - 1 >= lo1 && q - 1 <= hi1) ? aXp + bNp : LZERO;
          mmpA = (prevExit > mm) ? prevExit : mm;
       }
       aEnext = aXp;
@@ -449,18 +446,21 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
       oT = oT1;
       if (t + 2 <= T) {
          const int f = t + 1;                            // frame index (0-based) of t+2
-         if ((f & 3) == 0) { st.park(f >> 2); if (4 * ((f >> 2) + 1) < T) st.load((f >> 2) + 1); }
-         oT1 = st.get(f);
+         if ((f & 3) == 0) { st.park(f >> 2); if (4 * ((f >> 2) + 1) < T) st.load_all((f >> 2) + 1); }
+         oT1 = st.get_all(f);
       }
       eT = eT1;
-      if (valid && s.first && t + 2 <= T) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1);
+      if (t + 2 <= T) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1);      // (meaningful at the models' first lanes)
       hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = (t + 2 <= T) ? (w3 >> 16) : 0;
       // first lanes of the models that bound the next step's beam decisions (hi1 may be 0 past the last frame: the step is not taken)
       fLo0 = fLo1;
       if (lo1 != lo1Of) { fLo1 = flOf[lo1]; lo1Of = lo1; }
       if (hi1 != hi1Of) { fHi1 = flOf[hi1 > 0 ? hi1 : 1]; hi1Of = hi1; }
       { const int e0 = ((hi0 < Q) ? hi0 + 1 : hi0) + 1; if (e0 != e0Of) { fE0 = flOf[e0]; e0Of = e0; } }
-   }
+      return true;
+   };
+   if (T >= 1 && step(1, std::true_type{}))
+      for (int t = 2; t <= T; t++) if (!step(t, std::false_type{})) break;
 
    if (err) {
       if (gl == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }

@@ -73,6 +73,9 @@ struct ObsRow {
    __device__ __forceinline__ void load(int blk) { if (row) R = *(const f4s *)(row + 4 * blk); }
    __device__ __forceinline__ void park(int blk) { *(f4s *)(lds + ((((blk & 1) * 64) + lane) << 2)) = R; }
    __device__ __forceinline__ float get(int f) const { return row ? lds[(((((f >> 2) & 1) * 64) + lane) << 2) + (f & 3)] : 0.0f; }
+   // the same for callers that give EVERY lane a row (lanes past the chain: any row of the block): no lane-divergent branch
+   __device__ __forceinline__ void load_all(int blk) { R = *(const f4s *)(row + 4 * blk); }
+   __device__ __forceinline__ float get_all(int f) const { return lds[(((((f >> 2) & 1) * 64) + lane) << 2) + (f & 3)]; }
 };
 
 #define BETA_S(t) (a.betaW[ud.betaW0 + (size_t)((t) - 1) * L + gl])
