@@ -322,6 +322,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    double bT = LZERO, bT1 = LZERO, bT2 = LZERO;          // beta of frames t, t+1 and (in flight) t+2
    float oT = 0.f, oT1 = 0.f;
    int w1 = qBeam[1], w2 = (T >= 2) ? qBeam[2] : 1, w3 = 1;
+   int wq1 = w1, wq2 = w2, wSame = -1;                  // the words of columns t, t+1; their common value while the window t .. t+2 is uniform
    int hi0 = 0, lo1 = w1 & 0xffff, hi1 = w1 >> 16, lo2 = w2 & 0xffff, hi2 = (T >= 2) ? (w2 >> 16) : 0;
    double *pS = &ALPHA_S(1);                             // this lane's place in the stored columns, advanced by L per step (every lane of the workgroup has one)
    double *pE = (valid && s.first) ? &ALPHA_E(1, q) : nullptr;
@@ -342,9 +343,11 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
    if (valid && s.first) { eT = entry_beta<FAST>(s.aEntry, (double)oT, bT); if (T >= 2) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1); }
 
    // (column 1 -- InitAlpha -- is a call of its own: the loop body carries no branch on t and no copies of the state it does not touch)
-   auto step = [&](const int t, auto first_) -> bool {
-      constexpr bool FIRST = decltype(first_)::value;
-      if (t + 2 <= T) {                                  // request column t+2 (lanes past the chain read their own unused places: no divergence)
+   // (... and so are the last two columns: in the loop between, column t + 2 exists without asking)
+   auto step = [&](const int t, auto first_, auto inner_) -> bool {
+      constexpr bool FIRST = decltype(first_)::value, INNER = decltype(inner_)::value;
+      const bool has2 = INNER || t + 2 <= T, isLast = !INNER && t == T;
+      if (has2) {                                        // request column t+2 (lanes past the chain read their own unused places: no divergence)
          w3 = qBeam[t + 2];
          bT2 = BETA_S(t + 2);
       }
@@ -397,8 +400,6 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
 #pragma unroll
             for (int k = 0; k < W; k++) kept.w[k] = firsts.w[k] & ~bslot[par][k];
          }
-         if (fLo0 != mLoOf) { mLo = MaskW<W>::range(fLo0, L - 1); mLoOf = fLo0; }
-         if (fE0 != mEOf) { mE = MaskW<W>::range(0, fE0 - 1); mEOf = fE0; }
          const int slane = (kept & mLo).lowest();                                      // first model >= qLo[t-1] that is kept
          if (slane < 0 || slane > fHi1) { err = 1; return false; }                            // sq > qHi[t]
          sl = (slane < fLo1) ? fLo1 : slane;                                           // start-point below the beta beam: pulled back
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
          for (int k = 0; k < 3; k++) { const double v = xs[k]; mm = (2 + k <= N - 1 && v > mm) ? v : mm; }
          mm = (inB && in) ? mm : LZERO;                  // the published sums were not masked by the alpha beam
          // alpha_N + beta_N of the model before; its beta_N(t) is this model's beta_1(t+1) inside the beam of t+1
-         const double bNp = (t != T && q >= lo2 && q <= hi2) ? eT1 : LZERO;
+         const double bNp = (!isLast && q >= lo2 && q <= hi2) ? eT1 : LZERO;
          const double prevExit = (q > 1 && q - 1 >= lo1 && q - 1 <= hi1) ? aXp + bNp : LZERO;
          mmpA = (prevExit > mm) ? prevExit : mm;
       }
@@ -444,23 +445,34 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
       // rotate: t -> t+1
       bT = bT1; bT1 = bT2;
       oT = oT1;
-      if (t + 2 <= T) {
+      if (has2) {
          const int f = t + 1;                            // frame index (0-based) of t+2
          if ((f & 3) == 0) { st.park(f >> 2); if (4 * ((f >> 2) + 1) < T) st.load_all((f >> 2) + 1); }
          oT1 = st.get_all(f);
       }
       eT = eT1;
-      if (t + 2 <= T) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1);      // (meaningful at the models' first lanes)
-      hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = (t + 2 <= T) ? (w3 >> 16) : 0;
-      // first lanes of the models that bound the next step's beam decisions (hi1 may be 0 past the last frame: the step is not taken)
-      fLo0 = fLo1;
-      if (lo1 != lo1Of) { fLo1 = flOf[lo1]; lo1Of = lo1; }
-      if (hi1 != hi1Of) { fHi1 = flOf[hi1 > 0 ? hi1 : 1]; hi1Of = hi1; }
-      { const int e0 = ((hi0 < Q) ? hi0 + 1 : hi0) + 1; if (e0 != e0Of) { fE0 = flOf[e0]; e0Of = e0; } }
+      if (has2) eT1 = entry_beta<FAST>(s.aEntry, (double)oT1, bT1);      // (meaningful at the models' first lanes)
+      // The beta beam's words of columns t, t+1, t+2 decide everything below, and without pruning they stay the same for hundreds of
+      // columns: while the word coming in equals the one all three had (wSame), nothing moves and the step skips the lot.
+      if (!INNER || w3 != wSame) {
+         hi0 = hi1; lo1 = lo2; hi1 = hi2; lo2 = w3 & 0xffff; hi2 = has2 ? (w3 >> 16) : 0;
+         // first lanes of the models that bound the next step's beam decisions (hi1 may be 0 past the last frame: the step is not taken)
+         fLo0 = fLo1;
+         if (lo1 != lo1Of) { fLo1 = flOf[lo1]; lo1Of = lo1; }
+         if (hi1 != hi1Of) { fHi1 = flOf[hi1 > 0 ? hi1 : 1]; hi1Of = hi1; }
+         { const int e0 = ((hi0 < Q) ? hi0 + 1 : hi0) + 1; if (e0 != e0Of) { fE0 = flOf[e0]; e0Of = e0; } }
+         if (fLo0 != mLoOf) { mLo = MaskW<W>::range(fLo0, L - 1); mLoOf = fLo0; }
+         if (fE0 != mEOf) { mE = MaskW<W>::range(0, fE0 - 1); mEOf = fE0; }
+         wSame = (has2 && wq1 == wq2 && wq2 == w3) ? w3 : -1;
+         wq1 = wq2; wq2 = w3;
+      }
       return true;
    };
-   if (T >= 1 && step(1, std::true_type{}))
-      for (int t = 2; t <= T; t++) if (!step(t, std::false_type{})) break;
+   if (T >= 1 && step(1, std::true_type{}, std::false_type{})) {
+      int t = 2;
+      for (; t + 2 <= T; t++) if (!step(t, std::false_type{}, std::true_type{})) { t = T + 1; break; }
+      for (; t <= T; t++) if (!step(t, std::false_type{}, std::false_type{})) break;
+   }
 
    if (err) {
       if (gl == 0) { a.status[u] = HTKAMD_UTT_EALPHA; atomicAdd(a.acc + a.lay.nUttSkipped, 1.0); }
