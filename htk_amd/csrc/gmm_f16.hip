@@ -256,9 +256,6 @@ __global__ __launch_bounds__(64 * F16_WPB, F16_EU) void k_score_f16(ScoreArgs a)
 //   then the two states' constants.
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
-#ifndef F16W_DIAG
-#define F16W_DIAG 0
-#endif
 #ifdef F16W_STAMP            /* experiment builds only (tools/ubench/score_exp.py): cycles per phase and wavefront */
 __device__ unsigned long long g_dbg[4096 * 16];
 #define STAMP_DECL unsigned long long t_ = __builtin_amdgcn_s_memtime(), t0_ = t_, acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
@@ -276,14 +273,8 @@ extern "C" void htkamd_dbg_read(void *dst) { (void)hipDeviceSynchronize(); (void
 #ifndef F16W_PIPE
 #define F16W_PIPE 1
 #endif
-#ifndef F16W_VPM
-#define F16W_VPM 4
-#endif
 #ifndef F16W_EU
 #define F16W_EU 3
-#endif
-#ifndef F16W_AHEAD
-#define F16W_AHEAD 1
 #endif
 template <int NC>
 __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
