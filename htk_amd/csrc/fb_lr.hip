@@ -492,7 +492,9 @@ __global__ __launch_bounds__(64 * W) void k_alpha_lr(FbArgs a)
 // Workgroup = (utterance, chunk of STATS_FC frames), lane = chain state as above.  Per frame and lane: SetOcct (HFB.c:399-418),
 // UpTranParms (HFB.c:1390-1410) and the UpMixParms seed (HFB.c:1479-1489,1573-1606) from the stored alpha column, beta column and
 // scores; frames are independent, the loads of the frames of a chunk are all in flight together.
+#ifndef STATS_FC
 #define STATS_FC 32
+#endif
 #define TR_ROW 16
 #define EXP_TERM(acc, x) do { if constexpr (FAST) acc += exp_fast(x); else if ((x) > EXPFLOOR) acc += exp_tab((x), etab); } while (0)
 
