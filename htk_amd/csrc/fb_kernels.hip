@@ -754,6 +754,14 @@ __global__ __launch_bounds__(256, 4) void k_mixstats(FbArgs a)
    if (recBase >= 0 && recUsed + lane < 64) a.rec[recBase + recUsed + lane].g = -1;
 }
 
+// a wave-uniform double held in scalar registers (the compiler keeps a converted kernel argument in a vector pair otherwise)
+__device__ __forceinline__ double uniform_f64(double v)
+{
+   const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b), hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // k_mixhits: the pairs come as LISTS (fb_lr.hip: every wavefront of k_stats_lr owns a region of the list -- room for all its (frame,
 // state) pairs, so nothing can overflow and no cursor is shared -- and leaves the number of 16-byte records it wrote in hitCtl):
 // ~20 MB instead of the 0.5 GB seed array written and read back at the bench workload
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(256, 3) void k_mixhits(FbArgs a)
             float4 pm[NQ];
             float gcst = 0.0f, wt = 0.0f;
             int stPrev = -1, c0 = 0, M = 0, g = 0;
-            const double minF = (double)a.minFrwdP;
+            const double minF = uniform_f64((double)a.minFrwdP);      // (in scalar registers: as a vector pair it was SPILLED and reloaded -- with a full vmcnt wait -- in every iteration below)
             for (int it = 0; it < per; it++) {
                const int idx = i0g + it;
                const bool have = idx < i1g;
