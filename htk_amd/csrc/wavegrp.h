@@ -18,7 +18,15 @@ __device__ __forceinline__ unsigned long long lane_range(int lo, int hi)
 // ---- the W wavefronts of one utterance as one group of 64*W "lanes" (group lane gl = 64*wave + lane holds model gl+1)
 template <int W> struct MaskW {                 // one bit per group lane
    unsigned long long w[W];
-   __device__ __forceinline__ bool bit(int i) const { return W == 1 ? ((w[0] >> i) & 1ull) != 0 : ((w[(i >> 6) & (W - 1)] >> (i & 63)) & 1ull) != 0; }
+   // (the word by selects: indexed by a run-time value the words went to scratch memory, a store and a load per step of the pruning beta pass)
+   __device__ __forceinline__ bool bit(int i) const
+   {
+      const int kw = (i >> 6) & (W - 1);
+      unsigned long long v = 0;
+#pragma unroll
+      for (int k = 0; k < W; k++) v |= w[k] & (0ull - (unsigned long long)(kw == k));      // (masks, not selects: a chain of selects is folded back into an indexed load)
+      return ((v >> (i & 63)) & 1ull) != 0;
+   }
    __device__ __forceinline__ int highest() const
    {
 #pragma unroll
@@ -31,8 +39,20 @@ template <int W> struct MaskW {                 // one bit per group lane
       for (int k = 0; k < W; k++) if (w[k]) return 64 * k + lowest_set(w[k]);
       return -1;
    }
-   __device__ __forceinline__ MaskW operator&(const MaskW &o) const { MaskW r; for (int k = 0; k < W; k++) r.w[k] = w[k] & o.w[k]; return r; }
-   __device__ __forceinline__ MaskW operator~() const { MaskW r; for (int k = 0; k < W; k++) r.w[k] = ~w[k]; return r; }
+   __device__ __forceinline__ MaskW operator&(const MaskW &o) const
+   {
+      MaskW r;
+#pragma unroll
+      for (int k = 0; k < W; k++) r.w[k] = w[k] & o.w[k];
+      return r;
+   }
+   __device__ __forceinline__ MaskW operator~() const
+   {
+      MaskW r;
+#pragma unroll
+      for (int k = 0; k < W; k++) r.w[k] = ~w[k];
+      return r;
+   }
    static __device__ __forceinline__ MaskW range(int lo, int hi)          // group lanes [lo..hi], 0-based inclusive
    {
       MaskW r;
