@@ -131,25 +131,27 @@ __global__ __launch_bounds__(64 * B16_WPB, B16_COL_TILES > 2 ? 2 : 3) void k_sco
 
       // B operand: this lane's frame (col) of each column tile, the 8 k of lane group kg in every chunk, in three bf16 pieces
       bf8 zb[B16_COL_TILES][3][NC];
-      if (active)
+      if (active) {
+      int kgL = kg, colL = col;
+      asm volatile("" : "+v"(kgL), "+v"(colL));         // (the indices below are cheap to recompute per task: hoisted out of the task loop they are spilled)
 #pragma unroll
       for (int ft = 0; ft < B16_COL_TILES; ft++) {
-         int f = fw + ft * 16 + col;
+         int f = fw + ft * 16 + colL;
          if (f > tk.nFrames - 1) f = tk.nFrames - 1;
          const float *row = a.X + (size_t)(tk.frame0 + f) * D;
 #pragma unroll
          for (int c = 0; c < NC; c++) {
-            const int d0 = dpc * c + 4 * kg;          // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
+            const int d0 = dpc * c + 4 * kgL;         // dimensions d0..d0+3 -> k = 32c + 8kg + (0..7) = (x^2, x) pairs
             unsigned short p[3][8];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                int dim = d0 + i;
-               const bool pad = 4 * kg + i >= dpc || dim >= D;
+               const bool pad = 4 * kgL + i >= dpc || dim >= D;
                if (pad) dim = D - 1;
                float v = row[dim];
                if (pad) v = 0.0f;
                float v2 = v * v;
-               if (i == 3 && kg == 3) v2 = 1.0f;       // k = 30: the constant that meets the chunk's -0.5 sum mu^2 ivar
+               if (i == 3 && kgL == 3) v2 = 1.0f;      // k = 30: the constant that meets the chunk's -0.5 sum mu^2 ivar
                split3(v2, p[0][2 * i], p[1][2 * i], p[2][2 * i]);
                split3(v, p[0][2 * i + 1], p[1][2 * i + 1], p[2][2 * i + 1]);
             }
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(64 * B16_WPB, B16_COL_TILES > 2 ? 2 : 3) void k_sco
                zb[ft][s][c] = __builtin_bit_cast(bf8, w);
             }
          }
+      }
       }
       __syncthreads();
 
