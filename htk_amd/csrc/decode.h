@@ -62,4 +62,8 @@ struct htkamd_decoder {
    std::vector<int> hostModel;         // [nNodes] htkamd_net_desc.model (WORD nodes: the pronunciation)
    int *d_usedStates;
    int maxWidthNodes;
+   // workspace of htkamd_decoder_run, kept between calls and grown when a batch needs more (the score block and the path tables are
+   // gigabytes at 256 utterances: allocating and freeing them per call cost 5 - 500 ms of a 130 ms call)
+   void *ws[16];
+   size_t wsCap[16];
 };

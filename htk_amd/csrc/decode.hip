@@ -377,6 +377,7 @@ extern "C" void htkamd_decoder_destroy(htkamd_decoder *d)
 {
    if (!d) return;
    for (void *p : d->owned) (void)hipFree(p);
+   for (void *p : d->ws) if (p) (void)hipFree(p);
    delete d;
 }
 
@@ -578,7 +579,20 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
       void *dScore = nullptr, *dTok = nullptr, *dEx = nullptr, *dImax = nullptr;
       void *dPPrev = nullptr, *dPLike = nullptr, *dPLm = nullptr, *dUtt = nullptr, *dTasks = nullptr, *dOutI = nullptr, *dOutF = nullptr, *dTot = nullptr, *dOutD = nullptr;
       int rc = HTKAMD_OK;
-      auto A = [&](void **p, size_t n) { if (rc) return; hipError_t e = hipMalloc(p, n ? n : 1); if (e != hipSuccess) { htkamd_set_error("decoder_run: hipMalloc(%zu): %s", n, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; } };
+      int wsi = 0;
+      auto A = [&](void **p, size_t n) {                 // the decoder's own buffers, grown (not shrunk) as batches ask
+         const int i = wsi++;
+         if (rc) return;
+         if (n < 1) n = 1;
+         if (d->wsCap[i] < n) {
+            if (d->ws[i]) { (void)hipStreamSynchronize(s); (void)hipFree(d->ws[i]); d->ws[i] = nullptr; d->wsCap[i] = 0; }
+            const size_t want = n + n / 8;
+            hipError_t e = hipMalloc(&d->ws[i], want);
+            if (e != hipSuccess) { htkamd_set_error("decoder_run: hipMalloc(%zu): %s", want, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; d->ws[i] = nullptr; return; }
+            d->wsCap[i] = want;
+         }
+         *p = d->ws[i];
+      };
       A(&dScore, score * 4); A(&dTok, tok * sizeof(Tok)); A(&dEx, node * sizeof(Tok)); A(&dImax, node * 8);
       A(&dPPrev, path * 4); A(&dPLike, path * 8); A(&dPLm, path * 4);
       A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
@@ -629,7 +643,6 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
              (e = hipMemcpyAsync(hD.data(), dOutD, sizeof(double) * hD.size(), hipMemcpyDeviceToHost, s)) != hipSuccess ||
              (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       } else (void)hipStreamSynchronize(s);
-      for (void *p : {dScore, dTok, dEx, dImax, dPPrev, dPLike, dPLm, dUtt, dTasks, dOutI, dOutF, dTot, dOutD}) (void)hipFree(p);
       if (rc) return rc;
       for (int k = 0; k < nu; k++) {
          nWords[u0 + k] = hI[k]; total[u0 + k] = hT[k];
