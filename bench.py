@@ -382,6 +382,8 @@ def main():
     for i in range(args.warmup):
         em_iteration(False)
     ktimes = np.zeros(5)
+    import gc
+    gc.collect(); gc.disable()                               # (no collector pause inside the few milliseconds that are timed; on again behind them)
     sync_all()
     t0 = time.perf_counter()
     # The timed iterations, host side pipelined: the update is queued in two halves (htkamd_model_update_device_begin / _end) and the NEXT
@@ -443,6 +445,7 @@ def main():
         ktimes += kt
     sync_all()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
