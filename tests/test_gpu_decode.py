@@ -66,6 +66,11 @@ def test_decoder_larger_loop_matches_oracle(native, oracle, tmp_path):
     # an impossible utterance (shorter than any path through the network) reports "no token survived"
     short = native.Decoder(model, net).run([s.feats[0][:2]], genBeam=120.0)
     assert short[0][0] is None
+    # one decoder over batches of different sizes: its workspace is kept between calls and grown when a batch needs more
+    dec = native.Decoder(model, net)
+    for sel in ([0], [0, 1, 2, 3, 4, 5], [2], [5, 4, 3]):
+        got = dec.run([feats[u] for u in sel], genBeam=120.0)
+        assert [(w, t) for w, t in got] == [res[u] for u in sel], sel
 
 
 def test_decoder_config3_size_matches_reference(native, tmp_path):
