@@ -66,4 +66,6 @@ struct htkamd_decoder {
    // gigabytes at 256 utterances: allocating and freeing them per call cost 5 - 500 ms of a 130 ms call)
    void *ws[16];
    size_t wsCap[16];
+   void *wsN[32];                      // ... and of htkamd_decoder_run_lattice
+   size_t wsNCap[32];
 };

@@ -378,6 +378,7 @@ extern "C" void htkamd_decoder_destroy(htkamd_decoder *d)
    if (!d) return;
    for (void *p : d->owned) (void)hipFree(p);
    for (void *p : d->ws) if (p) (void)hipFree(p);
+   for (void *p : d->wsN) if (p) (void)hipFree(p);
    delete d;
 }
 

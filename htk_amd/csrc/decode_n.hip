@@ -480,11 +480,20 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
             }
          score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += (size_t)(ud.T + 1) * N.nWordNodes;
       }
-      std::vector<void *> bufs;
-      int rc = HTKAMD_OK;
-      auto A = [&](size_t n) -> void * { void *p = nullptr; if (rc) return p; hipError_t e = hipMalloc(&p, n ? n : 1);
-                                          if (e != hipSuccess) { htkamd_set_error("decoder_run_lattice: hipMalloc(%zu): %s", n, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; return (void *)nullptr; }
-                                          bufs.push_back(p); return p; };
+      int rc = HTKAMD_OK, wsi = 0;
+      auto A = [&](size_t n) -> void * {                 // the decoder's own buffers, kept between calls and grown as batches ask (decode.hip)
+         const int i = wsi++;
+         if (rc) return nullptr;
+         if (n < 1) n = 1;
+         if (d->wsNCap[i] < n) {
+            if (d->wsN[i]) { (void)hipStreamSynchronize(s); (void)hipFree(d->wsN[i]); d->wsN[i] = nullptr; d->wsNCap[i] = 0; }
+            const size_t want = n + n / 8;
+            hipError_t e = hipMalloc(&d->wsN[i], want);
+            if (e != hipSuccess) { htkamd_set_error("decoder_run_lattice: hipMalloc(%zu): %s", want, hipGetErrorString(e)); rc = HTKAMD_ENOMEM; d->wsN[i] = nullptr; return nullptr; }
+            d->wsNCap[i] = want;
+         }
+         return d->wsN[i];
+      };
       NArgs a; memset(&a, 0, sizeof(a));
       void *dScore = A(score * 4);
       a.tokA = (TSet *)A(tok * sizeof(TSet)); a.tokB = (TSet *)A(tok * sizeof(TSet)); a.ex = (TSet *)A(node * sizeof(TSet)); a.imax = (double *)A(node * 8);
@@ -537,7 +546,6 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
              (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run_lattice: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
 #undef D2H
       } else (void)hipStreamSynchronize(s);
-      for (void *p : bufs) (void)hipFree(p);
       if (rc) return rc;
       for (int k = 0; k < nu; k++) {
          const int uu = u0 + k;
