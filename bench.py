@@ -44,14 +44,16 @@ def cpu_baseline(s, pk, budget_s: float):
     acc = po.Accs(om)
     cfg = po.fb_cfg()
     n, t0, prs = 0, time.perf_counter(), []
-    while n < len(s.feats):
-        rc, pr, _ = po.fb_utt(om, cfg, s.feats[n], s.seqs[n], acc)
+    n_timed, dt = 0, 0.0
+    while n < len(s.feats):                                  # the rate is taken over the first budget_s seconds; the CHECK wants the whole shard
+        rc, pr, _ = po.fb_utt(om, cfg, s.feats[n], s.seqs[n], acc)   # (a sample whose size follows the host's speed made the check's worst entry a lottery)
         prs.append(pr)
         n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return n, dt, np.array(prs), acc
+        if n_timed == 0 and time.perf_counter() - t0 > budget_s:
+            n_timed, dt = n, time.perf_counter() - t0
+    if n_timed == 0:
+        n_timed, dt = n, time.perf_counter() - t0
+    return n, dt, np.array(prs), acc, n_timed
 
 
 def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
@@ -555,7 +557,7 @@ def main():
             out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha": ktimes_solo[2] * 1e3, "stats": ktimes_solo[3] * 1e3, "mix_stats": ktimes_solo[4] * 1e3}
         if args.cpu_seconds > 0 and world == 1:               # the CPU leg runs at N = 1 only
             per_utt = units_local / max(len(s.feats), 1)
-            n, cdt, opr, oacc = cpu_baseline(s, pk, args.cpu_seconds)
+            n, cdt, opr, oacc, n_timed = cpu_baseline(s, pk, args.cpu_seconds)
             # the checker: the oracle's utterance log-probabilities for the same utterances under the same (initial) model
             tol = 1e-10 if args.score == "exact" else 1e-6
             worst = float(np.max(np.abs(pr_init[:n] - opr) / np.abs(opr))) if n else 0.0
@@ -595,10 +597,11 @@ def main():
                                    "accumulators_max_rel_diff": worst_acc, "accumulators_tolerance": 1e-4,
                                    "avg_logprob_per_frame_oracle": float(np.sum(opr) / sum(s.feats[u].shape[0] for u in range(n))),
                                    "avg_logprob_per_frame_hip": float(np.sum(pr_init[:n]) / sum(s.feats[u].shape[0] for u in range(n)))}
-            port = {"value": n * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",
-                    "utterances_per_sec": n / cdt,
+            port = {"value": n_timed * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",
+                    "utterances_per_sec": n_timed / cdt,
                     "sample": "%d utterances of the same shard through oracle/htk_oracle.c (scalar C restatement of "
-                              "HFB/HModel, bit-exact vs the reference), %.1f s on one host core" % (n, cdt)}
+                              "HFB/HModel, bit-exact vs the reference), %.1f s on one host core (the oracle then goes on, untimed, "
+                              "through the rest of the shard: the check in `oracle_check` covers all %d)" % (n_timed, cdt, n)}
             cores = host_cores() if args.cpu_workers <= 0 else args.cpu_workers
             n_ref = 150                                        # utterances per process and round: ~3 s of HERest per process in the first round, ~6 s in the second
             ref = cpu_baseline_reference(s, pk, n_ref, workers=cores)
