@@ -214,6 +214,36 @@ def test_herest_cli_several_master_files_round_trip(tools, tmp_path):
 
 
 @pytest.mark.gpu
+def test_herest_cli_repeats_an_iteration_the_fp16_scores_cannot_hold(tools, tmp_path):
+    """--score fastest (fp16 x 2 scores) on data with one value far outside anything the models describe (3e4 in one coefficient of one
+    frame): the pass reports HTKAMD_ERANGE, the tool says so and repeats the iteration with the bf16 x 3 scores -- the models it writes
+    are the ones --score bf16 writes, byte for byte."""
+    import shutil
+    from htk_amd import capi
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    data = tmp_path / "data"; data.mkdir()
+    files = []
+    for i, f in enumerate(demo_train_files()):
+        dst = str(data / os.path.basename(f))
+        if i == 1:
+            X, per, kind = capi.parm_read(f)
+            X[7, 2] = 3.0e4
+            capi.parm_write(dst, X, per, kind)
+        else:
+            shutil.copy(f, dst)
+        files.append(dst)
+    outs = {}
+    for mode in ("fastest", "bf16"):
+        out = tmp_path / mode; out.mkdir()
+        r = run(herest_demo_cmd(tools, str(conf), str(out), ["--score", mode, "--batch", "3"]) + files)
+        assert r.returncode == 0, r.stderr
+        assert ("repeating the iteration with the bf16 x 3 scoring path" in r.stderr) == (mode == "fastest"), r.stderr[-800:]
+        outs[mode] = {n: open(os.path.join(str(out), n), "rb").read() for n in "SCVNL"}
+        assert r.stdout.count("Reestimation complete") == 1
+    assert outs["fastest"] == outs["bf16"]
+
+
+@pytest.mark.gpu
 def test_herest_cli_iterations_in_one_process_equal_a_chain_of_runs(tools, tmp_path):
     """--iterations 3 (features, transcriptions, batch tables and the model stay on the device; only the last set is written) against
     three HERest-style runs chained through binary model files: the same models (the second and third iteration of the chain start

@@ -16,7 +16,9 @@
  *   -s file        write the state occupation statistics file     -T N              trace (1: progress lines)
  * Beyond the reference:
  *   --score m      arithmetic: exact (default: alpha/beta/scores bit-identical to the reference), fast (fp32 matrix-core scores +
- *                  fp32-transcendental LAdd), fastest (bf16 x 3 matrix-core scores + that LAdd); the latter two are tolerance class (1e-4)
+ *                  fp32-transcendental LAdd), bf16 (bf16 x 3 matrix-core scores + that LAdd), fastest (fp16 x 2 matrix-core scores + that
+ *                  LAdd; an iteration whose data or model does not fit fp16's range -- HTKAMD_ERANGE -- is repeated as bf16, with a
+ *                  warning); all but exact are tolerance class (1e-4)
  *   --batch N      utterances per device batch (default 4096)
  *   --iterations K  K Baum-Welch iterations in one process: features, transcriptions and batch tables stay on the device, the model is
  *                  re-estimated where it is (htkamd_model_update_device) and only the last iteration's set is written to -M (HTK's recipe runs
@@ -84,8 +86,9 @@ int main(int argc, char **argv)
          const char *lo = a.argv[a.at++] + 2;
          if (!strcmp(lo, "score")) {
             const char *m = str_arg(&a, "-score");
-            scoreMode = !strcmp(m, "exact") ? HTKAMD_SCORE_EXACT : !strcmp(m, "fast") ? HTKAMD_SCORE_FAST : !strcmp(m, "fastest") ? HTKAMD_SCORE_FASTEST : -1;
-            if (scoreMode < 0) DIE("--score: exact | fast | fastest");
+            scoreMode = !strcmp(m, "exact") ? HTKAMD_SCORE_EXACT : !strcmp(m, "fast") ? HTKAMD_SCORE_FAST : !strcmp(m, "fastest") ? HTKAMD_SCORE_FASTEST :
+                        !strcmp(m, "bf16") ? (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_FASTLADD) : -1;
+            if (scoreMode < 0) DIE("--score: exact | fast | bf16 | fastest");
          } else if (!strcmp(lo, "batch")) batchN = atoi(str_arg(&a, "-batch"));
          else if (!strcmp(lo, "ranks")) nRanks = atoi(str_arg(&a, "-ranks"));
          else if (!strcmp(lo, "rank")) rank = atoi(str_arg(&a, "-rank"));
