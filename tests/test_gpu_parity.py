@@ -144,6 +144,13 @@ def test_f16_path_detects_what_it_cannot_represent(native, oracle):
     assert np.abs(got - ref)[np.arange(len(Xb)) != 17].max() <= 1e-3
     assert np.allclose(got[17], ref[17], rtol=1e-5)
     assert np.abs(gm.outp_block(X, states, mode=32) - om.score_block(X, states)).max() <= 1e-3      # the flag was cleared
+    # a model whose coefficients span more than the format (one variance of 1e-10 among ordinary ones): flagged when the table is built
+    pk2 = dict(pk); pk2["var"] = pk["var"].copy(); pk2["var"][3, 4] = 1.0e-10
+    gm2 = native.Model(pk2)
+    with pytest.raises(native.HtkAmdError) as ei:
+        gm2.outp_block(X, states, mode=32)
+    assert ei.value.rc == native.ERANGE and "model coefficient" in str(ei.value)
+    assert np.isfinite(gm2.outp_block(X, states, mode=4)).all()
     # forward-backward: the pass's own flag
     feats = [f.copy() for f in s.feats]
     feats[1][3, 0] = -5.0e4
