@@ -280,6 +280,10 @@ class Accs:
         assert vec.size == self.lay.total
         check(lib().htkamd_accs_upload_add(self.h, _p(vec), None), "accs_upload_add")
 
+    def wire_round(self, stream=None):
+        """One rank's share of the fp32-on-the-wire exchange (htkamd_accs_allreduce_wire, HTKAMD_WIRE_F32): the statistics rounded to float once."""
+        check(lib().htkamd_accs_wire_round(self.h, _stream(stream)), "accs_wire_round")
+
     def split(self, v: np.ndarray) -> dict:
         m, L = self.model, self.lay
         GD = m.G * m.D

@@ -40,7 +40,7 @@ static int rccl_bind()
    return HTKAMD_OK;
 }
 
-struct htkamd_comm { rcclComm c; int nRanks, rank; };
+struct htkamd_comm { rcclComm c; int nRanks, rank; float *d_wire; size_t wireCap; int *d_flag; };
 
 #define RCCLCHECK(call) do { const int r_ = (call); if (r_ != 0) { htkamd_set_error("%s -> %s", #call, g_rccl.err ? g_rccl.err(r_) : "RCCL error"); return HTKAMD_EHIP; } } while (0)
 
@@ -76,6 +76,8 @@ extern "C" void htkamd_comm_destroy(htkamd_comm *c)
 {
    if (!c) return;
    if (c->c && g_rccl.destroy) (void)g_rccl.destroy(c->c);
+   if (c->d_wire) (void)hipFree(c->d_wire);
+   if (c->d_flag) (void)hipFree(c->d_flag);
    free(c);
 }
 
@@ -87,5 +89,68 @@ extern "C" int htkamd_accs_allreduce(htkamd_accs *a, htkamd_comm *c, void *strea
    if (!a || !c) { htkamd_set_error("accs_allreduce: NULL argument"); return HTKAMD_EINVAL; }
    if (c->nRanks == 1) return HTKAMD_OK;
    RCCLCHECK(g_rccl.allReduce(a->d_vec, a->d_vec, a->lay.total, 8 /* ncclFloat64 */, 0 /* ncclSum */, c->c, (hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+// The same exchange with the statistics on the wire as fp32 (HTKAMD_WIRE_F32): every rank rounds its fp64 partial sums to float ONCE,
+// the ring adds floats, the result goes back into the fp64 vector.  Half the bytes of the fp64 exchange (SURVEY §8(e) prices the
+// payload as 25.9 MB of floats); still tighter than the reference, whose accumulators ARE floats summed utterance by utterance
+// (HTrain.c:1625-1687 adds float dumps).  The counters behind the statistics -- nEgs, totalPr, totalT, utterance and evaluation
+// counts: integers beyond 2^24 and a sum of ~1e8 -- stay fp64 in a second, small all-reduce.
+__global__ void k_wire_pack(const double *__restrict__ v, float *__restrict__ w, size_t n)
+{
+   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) w[i] = (float)v[i];
+}
+__global__ void k_wire_unpack(const float *__restrict__ w, double *__restrict__ v, size_t n)
+{
+   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v[i] = (double)w[i];
+}
+
+extern "C" int htkamd_accs_wire_round(htkamd_accs *a, void *stream)
+{
+   // what HTKAMD_WIRE_F32 does to ONE rank's vector before the sum (for tests that emulate the exchange without RCCL)
+   if (!a) { htkamd_set_error("accs_wire_round: NULL argument"); return HTKAMD_EINVAL; }
+   const size_t bulk = a->lay.nEgs;
+   float *w = nullptr;
+   HIPCHECK(hipMalloc(&w, sizeof(float) * bulk));
+   k_wire_pack<<<1024, 256, 0, (hipStream_t)stream>>>(a->d_vec, w, bulk);
+   k_wire_unpack<<<1024, 256, 0, (hipStream_t)stream>>>(w, a->d_vec, bulk);
+   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+   HIPCHECK(hipFree(w));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_accs_allreduce_wire(htkamd_accs *a, htkamd_comm *c, int wire, void *stream)
+{
+   if (wire == HTKAMD_WIRE_F64) return htkamd_accs_allreduce(a, c, stream);
+   if (!a || !c || wire != HTKAMD_WIRE_F32) { htkamd_set_error("accs_allreduce_wire: bad argument"); return HTKAMD_EINVAL; }
+   if (c->nRanks == 1) return HTKAMD_OK;
+   const size_t bulk = a->lay.nEgs, tail = a->lay.total - bulk;
+   if (c->wireCap < bulk) {
+      if (c->d_wire) HIPCHECK(hipFree(c->d_wire));
+      c->d_wire = nullptr; c->wireCap = 0;
+      HIPCHECK(hipMalloc(&c->d_wire, sizeof(float) * bulk));
+      c->wireCap = bulk;
+   }
+   hipStream_t st = (hipStream_t)stream;
+   k_wire_pack<<<1024, 256, 0, st>>>(a->d_vec, c->d_wire, bulk);
+   RCCLCHECK(g_rccl.allReduce(c->d_wire, c->d_wire, bulk, 7 /* ncclFloat32 */, 0 /* ncclSum */, c->c, st));
+   RCCLCHECK(g_rccl.allReduce(a->d_vec + bulk, a->d_vec + bulk, tail, 8 /* ncclFloat64 */, 0, c->c, st));
+   k_wire_unpack<<<1024, 256, 0, st>>>(c->d_wire, a->d_vec, bulk);
+   return HTKAMD_OK;
+}
+
+// max over the ranks of one int, synchronous: the ranks agree on a decision every one of them must take alike (tools/herest.c: the
+// fp16 -> bf16 fallback of an iteration, so that no two ranks add statistics of different arithmetic)
+extern "C" int htkamd_comm_agree_max(htkamd_comm *c, int *value, void *stream)
+{
+   if (!c || !value) { htkamd_set_error("comm_agree_max: NULL argument"); return HTKAMD_EINVAL; }
+   if (c->nRanks == 1) return HTKAMD_OK;
+   if (!c->d_flag) HIPCHECK(hipMalloc(&c->d_flag, sizeof(int)));
+   hipStream_t st = (hipStream_t)stream;
+   HIPCHECK(hipMemcpyAsync(c->d_flag, value, sizeof(int), hipMemcpyHostToDevice, st));
+   RCCLCHECK(g_rccl.allReduce(c->d_flag, c->d_flag, 1, 2 /* ncclInt32 */, 2 /* ncclMax */, c->c, st));
+   HIPCHECK(hipMemcpyAsync(value, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPCHECK(hipStreamSynchronize(st));
    return HTKAMD_OK;
 }

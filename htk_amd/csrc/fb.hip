@@ -560,7 +560,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
-   fb->f16Pass = (cfg->scoreMode & HTKAMD_SCORE_F16) != 0 && !m->tiedMix;
+   fb->f16Pass = (cfg->scoreMode & HTKAMD_SCORE_F16) != 0 && !m->tiedMix && sa.nTasks > 0;      // no tasks, no launch: nothing zeroes or raises the flag
    if (fb->f16Pass) {      // the pass's own range flag, behind the status words (zeroed with the task counter before it, by the launcher)
       sa.taskCounter = (int *)((char *)fb->d_pr.p + (sizeof(double) + sizeof(int)) * (size_t)fb->nUtt);
       sa.rangeFlag = sa.taskCounter + 1;

@@ -42,11 +42,28 @@ def pack_vector(lay: dict, acc, total_pr: float, total_t: int, n_done: int, n_sk
     return v
 
 
-def all_reduce_accumulators(vec_tensor) -> None:
-    """The one exchange step of a pass: sum the accumulator vectors of all ranks in place."""
+def all_reduce_accumulators(vec_tensor, wire: str = "f64", bulk: int | None = None, staging=None) -> None:
+    """The one exchange step of a pass: sum the accumulator vectors of all ranks in place.
+
+    wire = "f32" (htkamd_accs_allreduce_wire / HTKAMD_WIRE_F32 in the C ABI): the statistics -- the first `bulk` = layout.nEgs entries --
+    travel as floats: every rank rounds its fp64 partial sums once, the ring adds floats, the sums return to the fp64 vector; the
+    counters behind them (nEgs, totalPr, totalT, ...) stay fp64 in a second, small all-reduce.  Half the bytes of the fp64 exchange and
+    still tighter than the reference, which merges float dumps (LoadAccs, HTrain.c:1625-1687).  `staging`: a float32 tensor of `bulk`
+    entries to reuse."""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    if wire == "f64":
         dist.all_reduce(vec_tensor, op=dist.ReduceOp.SUM)
+        return
+    assert wire == "f32" and bulk is not None and 0 < bulk <= vec_tensor.numel()
+    w = staging if staging is not None else torch.empty(bulk, dtype=torch.float32, device=vec_tensor.device)
+    w.copy_(vec_tensor[:bulk])
+    dist.all_reduce(w, op=dist.ReduceOp.SUM)
+    if bulk < vec_tensor.numel():
+        dist.all_reduce(vec_tensor[bulk:], op=dist.ReduceOp.SUM)
+    vec_tensor[:bulk].copy_(w)
 
 
 def device_vector_as_tensor(accs, device_index: int):

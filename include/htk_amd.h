@@ -330,6 +330,16 @@ int  htkamd_comm_init(htkamd_comm **out, int nRanks, int rank, const void *id128
 void htkamd_comm_destroy(htkamd_comm *c);
 int  htkamd_comm_ranks(const htkamd_comm *c);
 int  htkamd_accs_allreduce(htkamd_accs *a, htkamd_comm *c, void *stream);
+/* The exchange with fp32 on the wire (half the bytes: SURVEY §8(e)'s 25.9 MB): every rank rounds its fp64 partial statistics to float
+ * once, RCCL sums floats, the sums return to the fp64 vector; nEgs / totalPr / totalT / the counters stay fp64 (a second, small
+ * all-reduce).  The reference's merge adds float dumps (LoadAccs HTrain.c:1625-1687): this is tighter.  accs_wire_round applies the
+ * rounding alone (one rank's share of it, for emulating the exchange in tests); comm_agree_max = max over the ranks of one int,
+ * synchronous -- a decision all ranks must take alike (the fp16 -> bf16 fallback of an iteration). */
+#define HTKAMD_WIRE_F64 0
+#define HTKAMD_WIRE_F32 1
+int  htkamd_accs_allreduce_wire(htkamd_accs *a, htkamd_comm *c, int wire, void *stream);
+int  htkamd_accs_wire_round(htkamd_accs *a, void *stream);
+int  htkamd_comm_agree_max(htkamd_comm *c, int *value, void *stream);
 
 /* HTK parameter files: header + big-endian float rows, _C compression and _K checksum on input
  * (ReadHTKHeader HWave.c:1408, OpenParmChannel HParm.c:3561, GetParm :3464, UpdateCRCC :3357).  *data is malloc'd

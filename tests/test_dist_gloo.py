@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wire="f64", nutt=9):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     from oracle import pyoracle as po
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    s = synth.generate(30, 3, 20, 9, 90, 55)
+    s = synth.generate(30, 3, 20, nutt, 90, 55)
     pk = s.packed()
     m = po.Model(pk)
     lay = herest.layout_from_packed(pk)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
             tot_pr += pr; tot_t += s.feats[u].shape[0]; done += 1
     vec = herest.pack_vector(lay, acc, tot_pr, tot_t, done)
     t = torch.from_numpy(vec)
-    herest.all_reduce_accumulators(t)                      # dist.all_reduce(SUM) on the flat fp64 vector
+    herest.all_reduce_accumulators(t, wire=wire, bulk=lay["nEgs"])      # dist.all_reduce(SUM) on the flat vector (fp64, or floats on the wire)
     q.put((rank, t.numpy().copy(), list(mine)))
     dist.destroy_process_group()
 
@@ -74,6 +74,50 @@ def test_two_rank_allreduce_equals_single_process():
     assert np.allclose(v0, ref, rtol=2e-5, atol=1e-5)
     assert v0[lay["nUttDone"]] == 9 and v0[lay["totalT"]] == tot_t
     assert np.array_equal(v0[lay["nEgs"]:lay["nEgs"] + 20], acc.nEgs.astype(np.float64))
+
+
+def test_eight_rank_fp32_wire_equals_single_process():
+    """bench.py --wire f32 / htkamd_accs_allreduce_wire(HTKAMD_WIRE_F32): eight ranks, every rank's fp64 statistics rounded to float once,
+    floats summed, counters in fp64 -- against the single process's sums: within float rounding of the partial sums (a few 1e-7), far
+    inside the 1e-4 the re-estimated parameters are held to; the counters exactly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    NU = 24
+    ps = [ctx.Process(target=_worker, args=(r, 8, port, q, "f32", NU)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    v0 = res[0][1]
+    for _, v, _ in res[1:]:
+        assert np.array_equal(v0, v)                        # every rank holds the same sum
+    sys.path.insert(0, ROOT)
+    from htk_amd import herest, synth
+    from oracle import pyoracle as po
+    s = synth.generate(30, 3, 20, NU, 90, 55)
+    pk = s.packed(); m = po.Model(pk); lay = herest.layout_from_packed(pk)
+    # the same partial sums in fp64, added in fp64: what the float wire is held against
+    ref = np.zeros(lay["total"])
+    for r in range(8):
+        acc = po.Accs(m); cfg = po.fb_cfg()
+        tot_pr, tot_t, done = 0.0, 0, 0
+        for u in herest.shard_indices(NU, r, 8):
+            rc, pr, _ = po.fb_utt(m, cfg, s.feats[u], s.seqs[u], acc)
+            if rc == 1:
+                tot_pr += pr; tot_t += s.feats[u].shape[0]; done += 1
+        ref += herest.pack_vector(lay, acc, tot_pr, tot_t, done)
+    bulk = lay["nEgs"]
+    ipr = lay["totalPr"] - bulk                             # nEgs, totalT, counters: integers in fp64, exact; totalPr: an fp64 sum in ring order
+    assert np.array_equal(np.delete(v0[bulk:], ipr), np.delete(ref[bulk:], ipr))
+    assert abs(v0[lay["totalPr"]] - ref[lay["totalPr"]]) <= 1e-12 * abs(ref[lay["totalPr"]])
+    assert v0[lay["nUttDone"]] == NU
+    scale = np.maximum(np.abs(ref[:bulk]), 1.0)
+    assert np.max(np.abs(v0[:bulk] - ref[:bulk]) / scale) <= 1e-6
+    assert np.all(v0[:bulk] == v0[:bulk].astype(np.float32))  # what came back are floats
 
 
 def test_shards_are_balanced_and_disjoint():

@@ -77,7 +77,7 @@ int main(int argc, char **argv)
    double pruneInit = HTKAMD_NOPRUNE, pruneInc = 0.0, pruneLim = HTKAMD_NOPRUNE;
    float minFrwdP = 10.0f, minVar = 0.0f, mixFloor = 0.0f;
    int uFlags = HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES | HTKAMD_UPTRANS, minEgs = 3, parMode = -1, trace = 0, binary = 0;
-   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1;
+   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1, wire = HTKAMD_WIRE_F64;
    unsigned long long rcclNonce = (unsigned long long)getppid();      /* the ranks of one run are children of one launcher; --rccl-nonce overrides */
    const char *sw;
 
@@ -96,6 +96,11 @@ int main(int argc, char **argv)
          else if (!strcmp(lo, "rccl-id")) rcclIdFile = str_arg(&a, "-rccl-id");
          else if (!strcmp(lo, "rccl-nonce")) rcclNonce = strtoull(str_arg(&a, "-rccl-nonce"), NULL, 0);
          else if (!strcmp(lo, "rccl-timeout")) rcclTimeout = atoi(str_arg(&a, "-rccl-timeout"));
+         else if (!strcmp(lo, "wire")) {
+            const char *m = str_arg(&a, "-wire");
+            wire = !strcmp(m, "f32") ? HTKAMD_WIRE_F32 : !strcmp(m, "f64") ? HTKAMD_WIRE_F64 : -1;
+            if (wire < 0) DIE("--wire: f32 | f64");
+         }
          else DIE("unknown option --%s", lo);
          continue;
       }
@@ -230,12 +235,19 @@ int main(int argc, char **argv)
       typedef struct { obs_batch ob; int *labOff, *labs; int count, first, prepared; htkamd_fb *fb; } dev_batch;
       const int nBatch = (mine.n + batchN - 1) / batchN;
       dev_batch *bt = (dev_batch *)calloc((size_t)(nBatch ? nBatch : 1), sizeof(dev_batch));
+      int settled = 0;                                 /* the ranks have agreed on the bf16 fallback */
       for (int it = 1; it <= nIter; it++) {
          int again;
+         const double itStart = now_s();
+         /* bound of a wait in a collective: --rccl-timeout on top of twice what this rank's own pass has taken so far (the shards are even;
+            a rank repeating its iteration as bf16 takes twice as long): a healthy job with long passes is not mistaken for a dead rank */
+#define COLL_ALARM() alarm((unsigned)rcclTimeout + (unsigned)(2.0 * (now_s() - itStart)) + 1u)
          do {                                          /* twice only when the fp16 scoring path reports data outside its range */
          again = 0;
          CHECK(htkamd_accs_zero(accs, NULL));
-         const int keep = nIter > 1 || (fc.scoreMode & HTKAMD_SCORE_F16);      /* the batches stay until the iteration stands */
+         /* Batches stay resident only across --iterations: a single pass streams them in bounded memory in every scoring mode.  Should
+            the fp16 range check trip (rare), the iteration starts over as bf16 and the batches already released are read again. */
+         const int keep = nIter > 1;
          for (int bi = 0; bi <= nBatch && !again; bi++) {
             if (bi < nBatch) {
                dev_batch *B = &bt[bi];
@@ -300,10 +312,27 @@ int main(int argc, char **argv)
                if (!keep) { free(B->labOff); free(B->labs); free_observations(&B->ob); htkamd_fb_destroy(B->fb); B->fb = NULL; B->labOff = NULL; B->labs = NULL; B->prepared = 0; }
             }
          }
+         if (comm && !again && (scoreMode & HTKAMD_SCORE_F16) && !settled) {
+            /* the ranks take the fp16 -> bf16 decision alike: no sum of statistics of two arithmetics.  One call per iteration on every
+               rank until a fallback is agreed (a rank that fell back repeats its iteration FIRST and says so here; the others repeat
+               theirs after this call, without a second one), none afterwards: the counts of collectives stay equal. */
+            int fell = !(fc.scoreMode & HTKAMD_SCORE_F16);
+            COLL_ALARM();
+            CHECK(htkamd_comm_agree_max(comm, &fell, NULL));
+            alarm(0);
+            if (fell) {
+               settled = 1;
+               if (fc.scoreMode & HTKAMD_SCORE_F16) {
+                  fprintf(stderr, "WARNING: herest rank %d: another rank's data does not fit the fp16 scores' range: repeating the iteration with the bf16 x 3 scoring path\n", rank);
+                  fc.scoreMode = (fc.scoreMode & ~HTKAMD_SCORE_F16) | HTKAMD_SCORE_BF16;
+                  again = 1;
+               }
+            }
+         }
          } while (again);
          if (comm) {
-            alarm((unsigned)rcclTimeout);                   /* a rank that died before this point would leave the others in the collective for ever */
-            CHECK(htkamd_accs_allreduce(accs, comm, NULL)); CHECK(htkamd_stream_sync(NULL));
+            COLL_ALARM();                                   /* a rank that died before this point would leave the others in the collective for ever */
+            CHECK(htkamd_accs_allreduce_wire(accs, comm, wire, NULL)); CHECK(htkamd_stream_sync(NULL));
             alarm(0);
          }
          if (it < nIter) {
