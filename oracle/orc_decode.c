@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "htk_oracle.h"
+#include "orc_ilist.h"
 
 typedef struct { double like; float lm; int path; } tok_t;
 typedef struct { int prev, node, frame; double like; float lm; } path_t;
@@ -124,17 +125,21 @@ int orc_decode_u(const orc_model *m, const float *X, int T,
          d.seLo[n * (maxN + 1) + j] = mn; d.seHi[n * (maxN + 1) + j] = mx;
       }
    }
-   /* zero-time topological order (Kahn over links whose destination is a zero-time node) */
-   int *indeg = (int *)calloc((size_t)nNodes, sizeof(int)), *order = (int *)malloc(sizeof(int) * (size_t)nNodes), nOrd = 0;
-   for (n = 0; n < nNodes; n++)
-      if (zero_time(&d, n))
-         for (int k = linkOff[n]; k < linkOff[n + 1]; k++) if (zero_time(&d, linkDest[k])) indeg[linkDest[k]]++;
-   for (n = 0; n < nNodes; n++) if (zero_time(&d, n) && indeg[n] == 0) order[nOrd++] = n;
-   for (i = 0; i < nOrd; i++) {
-      n = order[i];
-      for (int k = linkOff[n]; k < linkOff[n + 1]; k++) { const int dst = linkDest[k]; if (zero_time(&d, dst) && --indeg[dst] == 0) order[nOrd++] = dst; }
+   /* a zero-time loop is refused (ExpandWordNet would have refused the lattice): Kahn over links whose destination is a zero-time node */
+   {
+      int *indeg = (int *)calloc((size_t)nNodes, sizeof(int)), *order = (int *)malloc(sizeof(int) * (size_t)nNodes), nOrd = 0, nz = 0;
+      for (n = 0; n < nNodes; n++)
+         if (zero_time(&d, n))
+            for (int k = linkOff[n]; k < linkOff[n + 1]; k++) if (zero_time(&d, linkDest[k])) indeg[linkDest[k]]++;
+      for (n = 0; n < nNodes; n++) if (zero_time(&d, n) && indeg[n] == 0) order[nOrd++] = n;
+      for (i = 0; i < nOrd; i++) {
+         n = order[i];
+         for (int k = linkOff[n]; k < linkOff[n + 1]; k++) { const int dst = linkDest[k]; if (zero_time(&d, dst) && --indeg[dst] == 0) order[nOrd++] = dst; }
+      }
+      for (n = 0; n < nNodes; n++) if (zero_time(&d, n)) nz++;
+      free(indeg); free(order);
+      if (nz != nOrd) { rc = -4; goto done0; }
    }
-   { int nz = 0; for (n = 0; n < nNodes; n++) if (zero_time(&d, n)) nz++; if (nz != nOrd) { rc = -4; goto done0; } }   /* zero-time loop */
    for (n = 0; n < nNodes; n++) {
       int wd0 = 0;
       if (kind[n] == KIND_HMM)
@@ -144,7 +149,6 @@ int orc_decode_u(const orc_model *m, const float *X, int T,
 
    tok_t *tk = (tok_t *)malloc(sizeof(tok_t) * (size_t)nTok), *ex = (tok_t *)malloc(sizeof(tok_t) * (size_t)nNodes), *nw = (tok_t *)malloc(sizeof(tok_t) * (size_t)(maxN + 1));
    double *imax = (double *)malloc(sizeof(double) * (size_t)nNodes);
-   char *att = (char *)calloc((size_t)nNodes, 1);             /* the node has an instance (AttachInst / DetachInst) */
    float *qsa = (float *)malloc(sizeof(float) * (size_t)(nNodes + 1));
    int capP = 1024, nP = 0;
    path_t *pth = (path_t *)malloc(sizeof(path_t) * (size_t)capP);
@@ -153,113 +157,116 @@ int orc_decode_u(const orc_model *m, const float *X, int T,
    int *sct = (int *)calloc((size_t)m->S, sizeof(int));
    for (i = 0; i < nTok; i++) tk[i] = NULLTOK;
    for (n = 0; n < nNodes; n++) { ex[n] = NULLTOK; imax[n] = ORC_LZERO; }
-   tk[d.tok0[initial]].like = 0.0; tk[d.tok0[initial]].lm = 0.0f; tk[d.tok0[initial]].path = -1; imax[initial] = 0.0; att[initial] = 1;
    tok_t finalTok = NULLTOK;
 
-#define ENTER(dst, src) do { tok_t *r_ = &tk[d.tok0[dst]]; if (!att[dst]) { att[dst] = 1; imax[dst] = ORC_LZERO; } \
-      if ((src).like > r_->like) *r_ = (src); if (r_->like > imax[dst]) imax[dst] = (float)r_->like; } while (0)   /* NetInst.max is a LogFloat (HRec.c:138) */
-#define SEND(n_, tok_) do { if ((tok_).like > genThresh) for (int k_ = linkOff[n_]; k_ < linkOff[(n_) + 1]; k_++) { \
-      tok_t x_ = (tok_); const float lm_ = linkLike[k_]; x_.like = (tok_).like + lm_ * lmScale; x_.lm = (tok_).lm + lm_; \
-      if (x_.like > genThresh) ENTER(linkDest[k_], x_); } } while (0)
+   /* The instance list (HRec.c:1123-1270), restated with the node as the instance (a node has at most one): a doubly linked list
+      between two sentinels in which AttachInst appends, MoveToRecent re-appends and DetachInst unlinks; pass 2 walks it from the head
+      while it changes.  Its ORDER decides which of two exactly equal tokens reaches a node first (SetEntryState keeps the first: strict >). */
+   orc_ilist L;
+   L.nNodes = nNodes; L.linkOff = linkOff; L.linkDest = linkDest;
+   L.link = (int *)malloc(sizeof(int) * (size_t)(nNodes + 2)); L.knil = (int *)malloc(sizeof(int) * (size_t)(nNodes + 2));
+   L.att = (char *)calloc((size_t)nNodes, 1); L.ooo = (char *)calloc((size_t)nNodes, 1); L.tr0 = (char *)calloc((size_t)nNodes, 1);
+   for (n = 0; n < nNodes; n++) L.tr0[n] = (char)zero_time(&d, n);
+   L.link[nNodes] = nNodes + 1; L.knil[nNodes + 1] = nNodes; L.link[nNodes + 1] = -1; L.knil[nNodes] = -1; L.nxtInst = -1;
+   const int HEAD = nNodes, TAIL = nNodes + 1;
 
-   for (t = 0; t <= T; t++) {
-      if (t >= 1) {
-         double genMax = ORC_LZERO, wordMax = ORC_LZERO;
-         if (maxActive > 0) {                                 /* HRec.c:1966-1985 */
-            int nact = 0;
-            for (n = 0; n < nNodes; n++) if (att[n]) qsa[nact++] = (float)imax[n];
-            if (nact > maxActive) {
-               qsort(qsa, (size_t)nact, sizeof(float), cmp_desc);
-               const float thresh = qsa[maxActive];
-               if (thresh > ORC_LSMALL)
-                  for (n = 0; n < nNodes; n++)
-                     if (att[n] && imax[n] < thresh) {
-                        att[n] = 0; imax[n] = ORC_LZERO; ex[n] = NULLTOK;
-                        for (i = d.tok0[n]; i < d.tok0[n + 1]; i++) tk[i] = NULLTOK;
-                     }
+#define ATTACH(n_) do { const int a_ = (n_); for (int i_ = d.tok0[a_]; i_ < d.tok0[a_ + 1]; i_++) tk[i_] = NULLTOK; ex[a_] = NULLTOK; imax[a_] = ORC_LZERO; \
+      orc_ilist_attach(&L, a_); } while (0)
+#define DETACH(n_) do { const int a_ = (n_); for (int i_ = d.tok0[a_]; i_ < d.tok0[a_ + 1]; i_++) tk[i_] = NULLTOK; ex[a_] = NULLTOK; imax[a_] = ORC_LZERO; \
+      orc_ilist_detach(&L, a_); } while (0)
+   /* SetEntryState (HRec.c:1303): the first of equal tokens stays; NetInst.max is a LogFloat (HRec.c:138) */
+#define ENTER(dst, src) do { const int e_ = (dst); if (!L.att[e_]) ATTACH(e_); tok_t *r_ = &tk[d.tok0[e_]]; \
+      if ((src).like > r_->like) *r_ = (src); if (r_->like > imax[e_]) imax[e_] = (float)r_->like; } while (0)
+
+   /* StepInst2 (HRec.c:1360) -- may run twice on a node in one frame (a node moved behind a new predecessor is stepped again) */
+#define STEP_INST2(n_) do { const int s_ = (n_); tok_t *st_ = &tk[d.tok0[s_]]; \
+      if (kind[s_] == KIND_WORD) {                           /* StepWord2 (HRec.c:1046): a Path record per call */ \
+         tok_t e_ = *st_; e_.like += wordPen; e_.like += pronProb[s_] * prScale; \
+         if (nP + 1 > capP) { capP *= 2; pth = (path_t *)realloc(pth, sizeof(path_t) * (size_t)capP); } \
+         pth[nP].prev = st_->path; pth[nP].node = s_; pth[nP].frame = t; pth[nP].like = e_.like; pth[nP].lm = e_.lm; \
+         e_.path = nP++; e_.lm = 0.0f; ex[s_] = e_; \
+      } else if (kind[s_] == KIND_NULL) ex[s_] = *st_; \
+      else if (d.tee[s_]) {                                  /* StepHMM2 (HRec.c:790) */ \
+         const double c_ = st_->like + TPN(&d, s_, 1, d.N[s_]); \
+         if (c_ > ex[s_].like) { ex[s_] = *st_; ex[s_].like = c_; } \
+      } \
+      tok_t tok_ = ex[s_]; \
+      if (kind[s_] != KIND_HMM && tok_.like < wordThresh) tok_ = NULLTOK; \
+      if (tok_.like > genThresh) for (int k_ = linkOff[s_]; k_ < linkOff[s_ + 1]; k_++) { \
+         tok_t x_ = tok_; const float lm_ = linkLike[k_]; x_.like = tok_.like + lm_ * lmScale; x_.lm = tok_.lm + lm_; \
+         if (x_.like > genThresh) ENTER(linkDest[k_], x_); } } while (0)
+#define PASS2() do { int cur_, next_; for (cur_ = L.link[HEAD]; cur_ != TAIL; cur_ = next_) { \
+         if (imax[cur_] < genThresh) { next_ = L.link[cur_]; DETACH(cur_); } \
+         else { L.nxtInst = cur_; STEP_INST2(cur_); next_ = L.link[L.nxtInst]; } } } while (0)
+
+   /* StartRecognition (HRec.c:1884): the initial node's instance with a token of likelihood 0, thresholds at LSMALL, one pass 2 */
+   t = 0;
+   ATTACH(initial);
+   tk[d.tok0[initial]].like = 0.0; tk[d.tok0[initial]].lm = 0.0f; tk[d.tok0[initial]].path = -1; imax[initial] = 0.0;
+   PASS2();
+   if (T == 0) finalTok = L.att[final] ? ex[final] : NULLTOK;
+
+   for (t = 1; t <= T; t++) {
+      double genMax = ORC_LZERO, wordMax = ORC_LZERO;
+      if (maxActive > 0) {                                    /* HRec.c:1966-1985 */
+         int nact = 0;
+         for (n = L.link[HEAD]; n != TAIL; n = L.link[n]) qsa[nact++] = (float)imax[n];
+         if (nact > maxActive) {
+            qsort(qsa, (size_t)nact, sizeof(float), cmp_desc);
+            const float thresh = qsa[maxActive];
+            if (thresh > ORC_LSMALL) {
+               int nx;
+               for (n = L.link[HEAD]; n != TAIL; n = nx) { nx = L.link[n]; if (imax[n] < thresh) DETACH(n); }
             }
          }
-         for (n = 0; n < nNodes; n++) {
-            if (kind[n] != KIND_HMM) { tk[d.tok0[n]] = NULLTOK; ex[n] = NULLTOK; imax[n] = ORC_LZERO; continue; }   /* StepWord1 */
-            const int N = d.N[n];
-            tok_t *s = tk + d.tok0[n] - 1;                    /* s[1..N-1] */
-            double mx = ORC_LZERO;
-            int live = 0;
-            for (i = 1; i < N; i++) if (s[i].like > ORC_LSMALL) live = 1;
-            if (!live) { ex[n] = NULLTOK; imax[n] = ORC_LZERO; continue; }          /* no instance, or one about to be detached */
-            for (j = 2; j < N; j++) {
-               int arg = d.seLo[n * (maxN + 1) + j];
-               tok_t best = s[arg]; best.like += TPN(&d, n, arg, j);
-               for (i = arg + 1; i <= d.seHi[n * (maxN + 1) + j]; i++) {
-                  const double c = s[i].like + TPN(&d, n, i, j);
-                  if (c > best.like) { best = s[i]; best.like = c; }
-               }
-               if (best.like > genThresh) {
-                  const int st = m->hmmState[m->hmmStateOff[model[n]] + (j - 2)];
-                  if (sct[st] != t) { scv[st] = orc_state_outp(m, st, X + (size_t)(t - 1) * m->D, NULL); sct[st] = t; }
-                  best.like += scv[st];
-                  nw[j] = best;
-                  if (best.like > mx) mx = best.like;
-               } else nw[j] = NULLTOK;
-            }
-            s[1] = NULLTOK;
-            for (j = 2; j < N; j++) s[j] = nw[j];
-            imax[n] = (float)mx;                              /* inst->max = max.like: a LogFloat */
-            if (mx > genMax) genMax = mx;
-            {
-               int arg = d.seLo[n * (maxN + 1) + N];
-               tok_t best = s[arg]; best.like += TPN(&d, n, arg, N);
-               for (i = arg + 1; i <= d.seHi[n * (maxN + 1) + N]; i++) {
-                  const double c = s[i].like + TPN(&d, n, i, N);
-                  if (c > best.like) { best = s[i]; best.like = c; }
-               }
-               if (best.like > ORC_LSMALL) {
-                  ex[n] = best;
-                  const double w = best.like + d.wdlk[n];
-                  if (w > wordMax) wordMax = w;
-               } else ex[n] = NULLTOK;
-            }
-         }
-         wordThresh = (float)(wordMax - wordBeam); if (wordThresh < ORC_LSMALL) wordThresh = (float)ORC_LSMALL;
-         genThresh = (float)(genMax - genBeam); if (genThresh < ORC_LSMALL) genThresh = (float)ORC_LSMALL;
-         /* pass 2a: detach / propagate the emitting models' exit tokens */
-         for (n = 0; n < nNodes; n++) {
-            if (kind[n] != KIND_HMM) continue;
-            if (imax[n] < genThresh) {                        /* DetachInst: every token of the instance is dropped */
-               for (i = 1; i < d.N[n]; i++) tk[d.tok0[n] + i - 1] = NULLTOK;
-               ex[n] = NULLTOK; att[n] = 0;
-            }
-         }
-         for (n = 0; n < nNodes; n++) if (kind[n] == KIND_HMM && !d.tee[n]) SEND(n, ex[n]);
       }
-      /* pass 2b: zero-time nodes in topological order (at t = 0 this is StartRecognition's propagation) */
-      for (i = 0; i < nOrd; i++) {
-         n = order[i];
-         tok_t *st = &tk[d.tok0[n]];
-         if (kind[n] == KIND_HMM) {                           /* tee model: StepHMM2 */
-            if (t >= 1 && imax[n] < genThresh) { att[n] = 0; continue; }
-            const double c = st->like + TPN(&d, n, 1, d.N[n]);
-            if (st->like > ORC_LSMALL && c > ex[n].like) { ex[n] = *st; ex[n].like = c; }
-            SEND(n, ex[n]);
-            continue;
+      /* pass 1 (StepInst1 on every instance; its order decides nothing: the beams' tops are maxima) */
+      for (n = L.link[HEAD]; n != TAIL; n = L.link[n]) {
+         if (kind[n] != KIND_HMM) { tk[d.tok0[n]] = NULLTOK; ex[n] = NULLTOK; imax[n] = ORC_LZERO; continue; }   /* StepWord1 */
+         const int N = d.N[n];
+         tok_t *s = tk + d.tok0[n] - 1;                       /* s[1..N-1] */
+         double mx = ORC_LZERO;
+         for (j = 2; j < N; j++) {
+            int arg = d.seLo[n * (maxN + 1) + j];
+            tok_t best = s[arg]; best.like += TPN(&d, n, arg, j);
+            for (i = arg + 1; i <= d.seHi[n * (maxN + 1) + j]; i++) {
+               const double c = s[i].like + TPN(&d, n, i, j);
+               if (c > best.like) { best = s[i]; best.like = c; }
+            }
+            if (best.like > genThresh) {
+               const int st = m->hmmState[m->hmmStateOff[model[n]] + (j - 2)];
+               if (sct[st] != t) { scv[st] = orc_state_outp(m, st, X + (size_t)(t - 1) * m->D, NULL); sct[st] = t; }
+               best.like += scv[st];
+               nw[j] = best;
+               if (best.like > mx) mx = best.like;
+            } else nw[j] = NULLTOK;
          }
-         if (!(st->like > ORC_LSMALL)) { att[n] = 0; continue; }      /* an instance left over from the previous frame is detached here */
-         if (imax[n] < genThresh) { *st = NULLTOK; att[n] = 0; continue; }
-         tok_t e = *st;
-         if (kind[n] == KIND_WORD) {                          /* StepWord2 */
-            e.like += wordPen;
-            e.like += pronProb[n] * prScale;
-            if (nP + 1 > capP) { capP *= 2; pth = (path_t *)realloc(pth, sizeof(path_t) * (size_t)capP); }
-            pth[nP].prev = st->path; pth[nP].node = n; pth[nP].frame = t; pth[nP].like = e.like; pth[nP].lm = e.lm;
-            e.path = nP++; e.lm = 0.0f;
+         s[1] = NULLTOK;
+         for (j = 2; j < N; j++) s[j] = nw[j];
+         imax[n] = (float)mx;                                 /* inst->max = max.like: a LogFloat */
+         if (mx > genMax) genMax = mx;
+         {
+            int arg = d.seLo[n * (maxN + 1) + N];
+            tok_t best = s[arg]; best.like += TPN(&d, n, arg, N);
+            for (i = arg + 1; i <= d.seHi[n * (maxN + 1) + N]; i++) {
+               const double c = s[i].like + TPN(&d, n, i, N);
+               if (c > best.like) { best = s[i]; best.like = c; }
+            }
+            if (best.like > ORC_LSMALL) {
+               ex[n] = best;
+               const double w = best.like + d.wdlk[n];
+               if (w > wordMax) wordMax = w;
+            } else ex[n] = NULLTOK;
          }
-         ex[n] = e;
-         if (e.like < wordThresh) e = NULLTOK;
-         SEND(n, e);
       }
-      if (t == T) finalTok = ex[final];
-      if (t == 0) { tk[d.tok0[initial]] = NULLTOK; ex[initial] = NULLTOK; }
+      wordThresh = (float)(wordMax - wordBeam); if (wordThresh < ORC_LSMALL) wordThresh = (float)ORC_LSMALL;
+      genThresh = (float)(genMax - genBeam); if (genThresh < ORC_LSMALL) genThresh = (float)ORC_LSMALL;
+      /* pass 2 (HRec.c:2011-2021): the list from its head -- an instance under the beam is detached, the others are stepped; what a step
+         attaches or moves lies behind the cursor and is reached in the same walk */
+      PASS2();
+      if (t == T) finalTok = L.att[final] ? ex[final] : NULLTOK;
    }
+   free(L.link); free(L.knil); free(L.att); free(L.ooo); free(L.tr0);
 
    *totalLike = ORC_LZERO;
    rc = -1;
@@ -286,8 +293,8 @@ int orc_decode_u(const orc_model *m, const float *X, int T,
          rc = nW;
       }
    }
-   free(tk); free(ex); free(nw); free(imax); free(pth); free(scv); free(sct); free(att); free(qsa);
+   free(tk); free(ex); free(nw); free(imax); free(pth); free(scv); free(sct); free(qsa);
 done0:
-   free(indeg); free(order); free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi);
+   free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi);
    return rc;
 }

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "htk_oracle.h"
+#include "orc_ilist.h"
 
 #define MAXTOK 16
 typedef struct { double like; float lm; int path; } tok_t;
@@ -174,16 +175,20 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
          d.seLo[n * (maxN + 1) + j] = mn; d.seHi[n * (maxN + 1) + j] = mx;
       }
    }
-   int *indeg = (int *)calloc((size_t)nNodes, sizeof(int)), *order = (int *)malloc(sizeof(int) * (size_t)nNodes), nOrd = 0;
-   for (n = 0; n < nNodes; n++)
-      if (zero_time(&d, n))
-         for (k = linkOff[n]; k < linkOff[n + 1]; k++) if (zero_time(&d, linkDest[k])) indeg[linkDest[k]]++;
-   for (n = 0; n < nNodes; n++) if (zero_time(&d, n) && indeg[n] == 0) order[nOrd++] = n;
-   for (i = 0; i < nOrd; i++) {
-      n = order[i];
-      for (k = linkOff[n]; k < linkOff[n + 1]; k++) { const int dst = linkDest[k]; if (zero_time(&d, dst) && --indeg[dst] == 0) order[nOrd++] = dst; }
+   {  /* a zero-time loop is refused, as in orc_decode.c */
+      int *indeg = (int *)calloc((size_t)nNodes, sizeof(int)), *order = (int *)malloc(sizeof(int) * (size_t)nNodes), nOrd = 0, nz = 0;
+      for (n = 0; n < nNodes; n++)
+         if (zero_time(&d, n))
+            for (k = linkOff[n]; k < linkOff[n + 1]; k++) if (zero_time(&d, linkDest[k])) indeg[linkDest[k]]++;
+      for (n = 0; n < nNodes; n++) if (zero_time(&d, n) && indeg[n] == 0) order[nOrd++] = n;
+      for (i = 0; i < nOrd; i++) {
+         n = order[i];
+         for (k = linkOff[n]; k < linkOff[n + 1]; k++) { const int dst = linkDest[k]; if (zero_time(&d, dst) && --indeg[dst] == 0) order[nOrd++] = dst; }
+      }
+      for (n = 0; n < nNodes; n++) if (zero_time(&d, n)) nz++;
+      free(indeg); free(order);
+      if (nz != nOrd) { rc = -4; goto done0; }
    }
-   { int nz = 0; for (n = 0; n < nNodes; n++) if (zero_time(&d, n)) nz++; if (nz != nOrd) { rc = -4; goto done0; } }
    for (n = 0; n < nNodes; n++) {
       int wd0 = 0;
       if (kind[n] == KIND_HMM)
@@ -194,52 +199,56 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
    tset_t *tk = (tset_t *)malloc(sizeof(tset_t) * (size_t)nTok), *ex = (tset_t *)malloc(sizeof(tset_t) * (size_t)nNodes), *nw = (tset_t *)malloc(sizeof(tset_t) * (size_t)(maxN + 1));
    double *imax = (double *)malloc(sizeof(double) * (size_t)nNodes);
    float *qsa = (float *)malloc(sizeof(float) * (size_t)(nNodes + 1));
-   char *att = (char *)calloc((size_t)nNodes, 1);
    float genThresh = (float)ORC_LSMALL, wordThresh = (float)ORC_LSMALL;
    float *scv = (float *)malloc(sizeof(float) * (size_t)m->S);
    int *sct = (int *)calloc((size_t)m->S, sizeof(int));
-   for (i = 0; i < nTok; i++) { set_null(&tk[i]); tk[i].set[0].like = 0.0f; tk[i].set[0].lm = 0.0f; tk[i].set[0].path = -1; }
-   for (n = 0; n < nNodes; n++) { set_null(&ex[n]); ex[n].set[0].like = 0.0f; ex[n].set[0].lm = 0.0f; ex[n].set[0].path = -1; imax[n] = ORC_LZERO; }
-   {
-      tset_t *s0 = &tk[d.tok0[initial]];
-      s0->tok.like = 0.0; s0->tok.lm = 0.0f; s0->tok.path = -1; s0->n = 1;
-      s0->set[0].like = 0.0f; s0->set[0].lm = 0.0f; s0->set[0].path = -1;
-      imax[initial] = 0.0; att[initial] = 1;
-   }
+   static const rtok_t RMAX = { 0.0f, 0.0f, -1 };
+   for (i = 0; i < nTok; i++) { set_null(&tk[i]); tk[i].set[0] = RMAX; }
+   for (n = 0; n < nNodes; n++) { set_null(&ex[n]); ex[n].set[0] = RMAX; imax[n] = ORC_LZERO; }
    tset_t finalSet; set_null(&finalSet);
 
-#define ENTER(dst, srcset) do { tset_t *r_ = &tk[d.tok0[dst]]; if (!att[dst]) { att[dst] = 1; imax[dst] = ORC_LZERO; } \
-      tokset_merge(&d, r_, &(srcset).tok, &(srcset)); if (r_->tok.like > imax[dst]) imax[dst] = (float)r_->tok.like; } while (0)
-#define SEND(n_, es_, tk_) do { if ((tk_).like > genThresh) for (int k_ = linkOff[n_]; k_ < linkOff[(n_) + 1]; k_++) { \
-      tset_t x_; const float lm_ = linkLike[k_]; x_.tok = (tk_); x_.tok.like = (tk_).like + lm_ * lmScale; x_.tok.lm = (tk_).lm + lm_; x_.n = (es_).n; \
-      for (int q_ = 0; q_ < x_.n; q_++) { x_.set[q_] = (es_).set[q_]; x_.set[q_].lm = (es_).set[q_].lm + lm_; } \
-      if (x_.tok.like > genThresh) ENTER(linkDest[k_], x_); } } while (0)
+   /* the instance list in the reference's order (orc_ilist.h): in N-best mode it decides more than ties -- every TokSetMerge re-bases
+      its relative tokens as floats (HRec.c:361-364), so the order in which the senders of a node are stepped is in the last bit of
+      every alternative's likelihood */
+   orc_ilist L;
+   L.nNodes = nNodes; L.linkOff = linkOff; L.linkDest = linkDest;
+   L.link = (int *)malloc(sizeof(int) * (size_t)(nNodes + 2)); L.knil = (int *)malloc(sizeof(int) * (size_t)(nNodes + 2));
+   L.att = (char *)calloc((size_t)nNodes, 1); L.ooo = (char *)calloc((size_t)nNodes, 1); L.tr0 = (char *)calloc((size_t)nNodes, 1);
+   for (n = 0; n < nNodes; n++) L.tr0[n] = (char)zero_time(&d, n);
+   L.link[nNodes] = nNodes + 1; L.knil[nNodes + 1] = nNodes; L.link[nNodes + 1] = -1; L.knil[nNodes] = -1; L.nxtInst = -1;
+   const int HEAD = nNodes, TAIL = nNodes + 1;
+
+   /* AttachInst (HRec.c:1200): every set empty with one relative token rmax; DetachInst (:1270) */
+#define ATTACH(n_) do { const int a_ = (n_); for (int i_ = d.tok0[a_]; i_ < d.tok0[a_ + 1]; i_++) { set_null(&tk[i_]); tk[i_].set[0] = RMAX; } \
+      set_null(&ex[a_]); ex[a_].set[0] = RMAX; imax[a_] = ORC_LZERO; orc_ilist_attach(&L, a_); } while (0)
+#define DETACH(n_) do { const int a_ = (n_); for (int i_ = d.tok0[a_]; i_ < d.tok0[a_ + 1]; i_++) set_null(&tk[i_]); \
+      set_null(&ex[a_]); imax[a_] = ORC_LZERO; orc_ilist_detach(&L, a_); } while (0)
+#define ENTER(dst, srcset) do { const int e_ = (dst); if (!L.att[e_]) ATTACH(e_); tset_t *r_ = &tk[d.tok0[e_]]; \
+      tokset_merge(&d, r_, &(srcset).tok, &(srcset)); if (r_->tok.like > imax[e_]) imax[e_] = (float)r_->tok.like; } while (0)
 
    for (t = 0; t <= T; t++) {
-      if (t >= 1) {
+      if (t == 0) {                                           /* StartRecognition (HRec.c:1884) */
+         ATTACH(initial);
+         tset_t *s0 = &tk[d.tok0[initial]];
+         s0->tok.like = 0.0; s0->tok.lm = 0.0f; s0->tok.path = -1; s0->n = 1;
+         imax[initial] = 0.0;
+      } else {
          double genMax = ORC_LZERO, wordMax = ORC_LZERO;
          if (maxActive > 0) {                                 /* maximum-model pruning, HRec.c:1966-1985, as in orc_decode.c */
-            int nact = 0;
-            for (n = 0; n < nNodes; n++) if (att[n]) qsa[nact++] = (float)imax[n];
+            int nact = 0, nx;
+            for (n = L.link[HEAD]; n != TAIL; n = L.link[n]) qsa[nact++] = (float)imax[n];
             if (nact > maxActive) {
                qsort(qsa, (size_t)nact, sizeof(float), cmp_desc_n);
                const float thresh = qsa[maxActive];
                if (thresh > ORC_LSMALL)
-                  for (n = 0; n < nNodes; n++)
-                     if (att[n] && imax[n] < thresh) {
-                        att[n] = 0; imax[n] = ORC_LZERO; set_null(&ex[n]);
-                        for (i = d.tok0[n]; i < d.tok0[n + 1]; i++) set_null(&tk[i]);
-                     }
+                  for (n = L.link[HEAD]; n != TAIL; n = nx) { nx = L.link[n]; if (imax[n] < thresh) DETACH(n); }
             }
          }
-         for (n = 0; n < nNodes; n++) {
+         for (n = L.link[HEAD]; n != TAIL; n = L.link[n]) {    /* pass 1 */
             if (kind[n] != KIND_HMM) { set_null(&tk[d.tok0[n]]); set_null(&ex[n]); imax[n] = ORC_LZERO; continue; }   /* StepWord1 */
             const int N = d.N[n];
             tset_t *s = tk + d.tok0[n] - 1;                   /* s[1..N-1] */
             double mx = ORC_LZERO;
-            int live = 0;
-            for (i = 1; i < N; i++) if (s[i].tok.like > ORC_LSMALL) live = 1;
-            if (!live) { set_null(&ex[n]); imax[n] = ORC_LZERO; continue; }
             for (j = 2; j < N; j++) {
                int a0 = d.seLo[n * (maxN + 1) + j];
                tset_t res = s[a0];
@@ -254,7 +263,7 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                   res.tok.like += scv[st];
                   nw[j] = res;
                   if (res.tok.like > mx) mx = res.tok.like;
-               } else set_null(&nw[j]);
+               } else { nw[j] = res; set_null(&nw[j]); }
             }
             set_null(&s[1]);
             for (j = 2; j < N; j++) s[j] = nw[j];
@@ -272,57 +281,54 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                   ex[n] = res;
                   const double w = res.tok.like + d.wdlk[n];
                   if (w > wordMax) wordMax = w;
-               } else set_null(&ex[n]);
+               } else { ex[n] = res; set_null(&ex[n]); }
             }
          }
          wordThresh = (float)(wordMax - wordBeam); if (wordThresh < ORC_LSMALL) wordThresh = (float)ORC_LSMALL;
          genThresh = (float)(genMax - genBeam); if (genThresh < ORC_LSMALL) genThresh = (float)ORC_LSMALL;
          d.nThresh = (float)(genMax - nBeam); if (d.nThresh < ORC_LSMALL / 2) d.nThresh = (float)(ORC_LSMALL / 2);
-         for (n = 0; n < nNodes; n++) {
-            if (kind[n] != KIND_HMM) continue;
-            if (imax[n] < genThresh) {
-               for (i = 1; i < d.N[n]; i++) set_null(&tk[d.tok0[n] + i - 1]);
-               set_null(&ex[n]); att[n] = 0;
-            }
-         }
-         for (n = 0; n < nNodes; n++) if (kind[n] == KIND_HMM && !d.tee[n]) SEND(n, ex[n], ex[n].tok);
       }
-      for (i = 0; i < nOrd; i++) {
-         n = order[i];
+      /* pass 2 (HRec.c:2011-2021; at t = 0 StartRecognition's): the list from its head while it changes */
+      int cur, next;
+      for (cur = L.link[HEAD]; cur != TAIL; cur = next) {
+         if (imax[cur] < genThresh) { next = L.link[cur]; DETACH(cur); continue; }
+         L.nxtInst = cur;
+         n = cur;
          tset_t *st = &tk[d.tok0[n]];
-         if (kind[n] == KIND_HMM) {                           /* tee model: StepHMM2 */
-            if (t >= 1 && imax[n] < genThresh) { att[n] = 0; continue; }
-            tok_t c = st->tok; c.like += TPN(&d, n, 1, d.N[n]);
-            if (st->tok.like > ORC_LSMALL) tokset_merge(&d, &ex[n], &c, st);
-            SEND(n, ex[n], ex[n].tok);
-            continue;
-         }
-         if (!(st->tok.like > ORC_LSMALL)) { att[n] = 0; continue; }
-         if (imax[n] < genThresh) { set_null(st); att[n] = 0; continue; }
-         tset_t e = *st;
-         if (kind[n] == KIND_WORD) {                          /* StepWord2 */
-            e.tok.like += wordPen;
-            e.tok.like += pronProb[n] * prScale;
+         if (kind[n] == KIND_WORD) {                          /* StepWord2 (HRec.c:1046): a Path record, one NxtPath per alternative, per call */
+            tok_t e = st->tok;
+            e.like += wordPen;
+            e.like += pronProb[n] * prScale;
             if (d.nP + 1 > d.capP) { d.capP *= 2; d.pth = (path_t *)realloc(d.pth, sizeof(path_t) * (size_t)d.capP); }
             path_t *np = &d.pth[d.nP];
-            np->prev = st->tok.path; np->node = n; np->frame = t; np->like = e.tok.like; np->lm = e.tok.lm; np->usage = 0;
+            np->prev = st->tok.path; np->node = n; np->frame = t; np->like = e.like; np->lm = e.lm; np->usage = 0;
             np->chain0 = d.nX; np->nChain = 0;
             for (k = 1; k < st->n; k++) {
                if (d.nX + 1 > d.capX) { d.capX *= 2; d.nxt = (nxt_t *)realloc(d.nxt, sizeof(nxt_t) * (size_t)d.capX); }
                d.nxt[d.nX].like = np->like + st->set[k].like; d.nxt[d.nX].lm = st->set[k].lm; d.nxt[d.nX].prev = st->set[k].path;
                d.nX++; np->nChain++;
             }
-            e.tok.path = d.nP++; e.tok.lm = 0.0f;
-            e.n = 1; e.set[0].like = 0.0f; e.set[0].lm = 0.0f; e.set[0].path = e.tok.path;
+            e.path = d.nP++; e.lm = 0.0f;
+            ex[n].tok = e; ex[n].n = 1; ex[n].set[0].path = e.path;        /* set[0].like / .lm stay what AttachInst made them (rmax) */
+         } else if (kind[n] == KIND_NULL) ex[n] = *st;
+         else if (d.tee[n]) {                                 /* StepHMM2 (HRec.c:790) */
+            tok_t c = st->tok; c.like += TPN(&d, n, 1, d.N[n]);
+            tokset_merge(&d, &ex[n], &c, st);
          }
-         ex[n] = e;
-         tok_t out = e.tok;
-         if (out.like < wordThresh) out = NULLTOK;
-         SEND(n, e, out);
+         tok_t tok = ex[n].tok;
+         if (kind[n] != KIND_HMM && tok.like < wordThresh) tok = NULLTOK;
+         if (tok.like > genThresh)
+            for (k = linkOff[n]; k < linkOff[n + 1]; k++) {
+               tset_t x; const float lm = linkLike[k];
+               x.tok = ex[n].tok; x.tok.like = tok.like + lm * lmScale; x.tok.lm = tok.lm + lm; x.n = ex[n].n;
+               for (int q = 0; q < x.n; q++) { x.set[q] = ex[n].set[q]; x.set[q].lm = ex[n].set[q].lm + lm; }
+               if (x.tok.like > genThresh) ENTER(linkDest[k], x);
+            }
+         next = L.link[L.nxtInst];
       }
-      if (t == T) finalSet = ex[final];
-      if (t == 0) { set_null(&tk[d.tok0[initial]]); set_null(&ex[initial]); }
+      if (t == T) { if (L.att[final]) finalSet = ex[final]; else set_null(&finalSet); }
    }
+   free(L.link); free(L.knil); free(L.att); free(L.ooo); free(L.tr0);
 
    *totalLike = ORC_LZERO; *nLatNodes = 0; *nLatArcs = 0;
    rc = -1;
@@ -388,8 +394,8 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
          rc = 0;
       }
    }
-   free(tk); free(ex); free(nw); free(imax); free(qsa); free(scv); free(sct); free(att);
+   free(tk); free(ex); free(nw); free(imax); free(qsa); free(scv); free(sct);
 done0:
-   free(indeg); free(order); free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi); free(d.aux); free(d.pth); free(d.nxt);
+   free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi); free(d.aux); free(d.pth); free(d.nxt);
    return rc;
 }

@@ -24,7 +24,7 @@ NOPRUNE = 1.0e20
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
-    deps = srcs + [os.path.join(HERE, "htk_oracle.h")]
+    deps = srcs + [os.path.join(HERE, "htk_oracle.h"), os.path.join(HERE, "orc_ilist.h")]
     if (not force) and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     os.makedirs(BUILD, exist_ok=True)

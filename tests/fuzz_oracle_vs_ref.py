@@ -30,15 +30,18 @@ from decode_util import format_words  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def _lat_same(a, b):
-    """Two SLF files: identical, or the same lattice up to the float noise of relative tokens.  (A relative token's likelihood is a
-    float re-based at every TokSetMerge, HRec.c:361-364: the order in which tokens arrive at a node -- HRec's instance-list order, the
-    oracle's node order -- moves its last bits.  That shows as the last printed digit of an ALTERNATIVE's acoustic score, and it decides
-    between two alternatives whose likelihoods agree to ~1e-4 (the same models under two segmentations), so that a handful of arcs --
-    and the nodes only they lead to -- may differ; so do EXACT ties between two segmentations of the same model sequence (tee models,
-    homophones), which the reference resolves by arrival order.)  Accepted: >= 95 % of the arcs (as start word/time, end word/time, l=) in common."""
+def _lat_same(a, b, xwrd=False):
+    """Two SLF files: identical, byte for byte.  (Until round 4 this accepted "the same lattice up to the float noise of relative tokens":
+    a relative token's likelihood is a float re-based at every TokSetMerge, HRec.c:361-364, so the order in which tokens arrive at a node
+    is in its last bits -- and the oracle pulled in node order.  It walks HRec's instance list now, oracle/orc_ilist.h.)
+    One family keeps the old allowance: CROSS-WORD networks.  net.c's expansion gives the reference's models, links and label files, but
+    not its node count (141 against the reference's 136 on a typical case: it keeps a few collating null nodes apart that ExpandWordNet
+    shares), so the merges at those nodes are associated differently: the last printed digit / the sign of a zero of an ALTERNATIVE's
+    acoustic score on about one such case in twenty.  There: >= 95 % of the arcs (start word/time, end word/time, l=) in common."""
     if a == b:
         return True
+    if not xwrd:
+        return False
     import collections
     def arcs(txt):
         nodes, out = {}, collections.Counter()
@@ -55,16 +58,7 @@ def _lat_same(a, b):
 
 
 def _labels_same(got, want):
-    if want is None or len(got) != len(want):
-        return False
-    for g, w in zip(got, want):
-        if len(g) != len(w):
-            return False
-        for x, y in zip(g, w):
-            fx, fy = x.split(), y.split()
-            if fx[:3] != fy[:3] or abs(float(fx[3]) - float(fy[3])) > 2e-3:
-                return False
-    return True
+    return want is not None and got == want
 
 
 def fuzz_decode(rng, it, tmp):
@@ -186,11 +180,7 @@ def fuzz_decode(rng, it, tmp):
             # "No tokens survived" utterances: the reference writes no entry
             ok = False
             print("DECODE it %d u%d params %s rc %d\n  oracle %s\n  HVite  %s" % (it, u, p, r.returncode, got, want))
-    if ok and not xwrd and rng.random() < 0.4:
-        # (not on the cross-word cases: their logical models are tied at random to a handful of physical ones, so that word ends of one
-        #  word in different contexts carry EXACTLY equal likelihoods; which of them a full token set keeps is decided by arrival order --
-        #  HRec's instance list against the oracle's node order, the tie limitation DESIGN.md describes; tests/golden/decode/nbest has a
-        #  cross-word case that is free of such ties and equal byte for byte)
+    if ok and rng.random() < 0.4:
         # ---- N-best: HVite -n k 1 -z lat (lattice files) and -n k m (alternative transcriptions) against the oracle's token sets put
         # through the product's host code (htkamd_lattice_write / htkamd_lattice_nbest); run inside d with relative names so that the
         # header lines of the lattices agree
@@ -223,7 +213,7 @@ def fuzz_decode(rng, it, tmp):
             lat.update(lmScale=p["lmScale"], wordPen=p["wordPen"], prScale=p["prScale"])
             mine = os.path.join(d, "u%d.mylat" % u)
             capi.lattice_write(lat, net, mine, utterance=rel[u], lm_name="net.slf", vocab_name="dict")
-            if not os.path.exists(ref_lat) or not _lat_same(open(mine).read(), open(ref_lat).read()):
+            if not os.path.exists(ref_lat) or not _lat_same(open(mine).read(), open(ref_lat).read(), xwrd):
                 ok = False; print("NBEST it %d u%d k=%d params %s: lattice files differ (%s)" % (it, u, k, p, d))
             alts = capi.lattice_nbest(lat, net, mtr)
             got = [["%d %d %s %f" % (st_ * 100000, en_ * 100000, net.out_syms[w], np.float32(sc)) for w, st_, en_, sc in a if w >= 0 and net.out_syms[w] != ""] for a in alts]

@@ -45,8 +45,8 @@ def _env():
     return e
 
 
-def _bench(n, out, port, total=256, env=None):
-    args = ["--gpus", str(n), "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
+def _bench(n, out, port, total=256, env=None, wire="f64"):
+    args = ["--gpus", str(n), "--wire", wire, "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
             "--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--extras", "0", "--dump-model", out]
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
@@ -73,6 +73,17 @@ def test_bench_two_ranks_on_one_device_over_gloo_equal_one_rank(tmp_path):
     assert abs(float(a["totalPr"]) - float(b["totalPr"])) <= 1e-9 * abs(float(a["totalPr"]))
     for k in ("mean", "var", "compWeight", "transP"):
         assert np.allclose(a[k], b[k], rtol=2e-6, atol=1e-7), k
+    # the same with floats on the wire (bench.py's default for N > 1): every rank's partial sums rounded to float once -- the model of
+    # the first iteration moves by float rounding, the second iteration's log probability with it
+    o3 = _bench(2, str(tmp_path / "m3.npz"), 29623, env={"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"}, wire="f32")
+    l3 = json.loads(o3.strip().splitlines()[-1])
+    c = np.load(str(tmp_path / "m3.npz"))
+    assert l3["utterances_ok"] == 256 and "f32 on the wire" in l3["config"]["parallelism"]
+    assert abs(float(a["totalPr"]) - float(c["totalPr"])) <= 1e-7 * abs(float(a["totalPr"]))
+    for k in ("mean", "compWeight", "transP"):
+        assert np.allclose(a[k], c[k], rtol=2e-5, atol=2e-6), k
+    # a variance is a difference of two sums: held to its second moment about the old mean, as everywhere (tests/c3_herest.py)
+    assert np.all(np.abs(a["var"].astype(np.float64) - c["var"]) <= 2e-5 * (np.abs(a["var"]) + 1.0)), "var"
 
 
 def test_bench_two_ranks_rccl_equals_one_rank(tmp_path):
