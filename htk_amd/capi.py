@@ -30,6 +30,7 @@ def _stream(s):
 
 SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC, SCORE_F16 = 0, 1, 2, 4, 8, 16, 32
 ERANGE = -7
+ORDER_AUTO, ORDER_FAST, ORDER_EXACT = 0, 1, 2
 
 
 class HtkAmdError(RuntimeError):
@@ -983,6 +984,13 @@ class Decoder:
         self.h = C.c_void_p()
         self.model, self.net, self.lmScale = model, net, float(lmScale)
         check(lib().htkamd_decoder_create(model.h, C.byref(net.desc), C.c_float(lmScale), C.byref(self.h)), "decoder_create")
+
+    def set_order(self, mode: int):
+        """htkamd_decoder_set_order: ORDER_AUTO (exact-tie utterances again in HRec's instance order), ORDER_FAST, ORDER_EXACT."""
+        check(lib().htkamd_decoder_set_order(self.h, C.c_int(mode)), "decoder_set_order")
+
+    def last_tied(self) -> int:
+        return int(lib().htkamd_decoder_last_tied(self.h))
 
     def run(self, feats, genBeam=1.0e10, wordBeam=1.0e10, lmScale=None, wordPen=0.0, prScale=1.0, maxWords=1024, scoreMode=0, maxActive=0):
         """feats: list of [T, D] arrays.  Returns per utterance (list of (pron, startFrame, endFrame, score) or None, total)."""

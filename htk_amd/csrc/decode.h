@@ -27,10 +27,16 @@ struct DecNet {
    const float *transP;
    const int *hmmState;
    const int *stateSlot;               // [S] row of the tied state in the score block, -1 if unused
+   // forward CSR in the network's own link order (the tr0 links first, ExpandWordNet HNet.c:3632-3645): the exact-order kernels
+   // (decode_ord.hip) PUSH along it as HRec does
+   const int *linkOff, *linkDest;      // [nNodes + 1], [nLinks]
+   const float *linkLike;
+   const int *nTr0;                    // [nNodes] number of leading links whose destination is a zero-time node (word end, null node, tee model)
+   const unsigned char *dupDest;       // [nNodes] two links of the node share a destination
 };
 
 struct DecUtt {
-   int T, frame0, status, pad;
+   int T, frame0, status, idx;         // idx: the utterance's number in the batch (its slot in the per-utterance outputs)
    size_t score0;      // floats: score[score0 + slot*T + (t-1)]
    size_t tok0;        // token arrays base
    size_t node0;       // exit-token / instance-max arrays base
@@ -51,7 +57,18 @@ struct DecArgs {
    int maxActive;                      // HVite -u: maximum number of model instances kept per frame (0 = off)
    int maxWords;
    int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm, *wordAc; double *wordLike; double *total; float *finalLm;
+   int *tieFlag;                       // [nUtt] k_decode: two tokens of exactly equal likelihood and different histories met at a node (see decode_ord.hip)
 };
+
+// Exact-order decoding (decode_ord.hip): the utterances k_decode flagged, or every utterance of an N-best run.
+struct OrdArgs {
+   DecArgs d;                          // utt = the selected utterances' descriptors (idx = slot in the outputs)
+   int *seq; int seqCap;               // [nSel * 2 * seqCap] the instance list as an array (two buffers per utterance)
+   int *pos; unsigned char *ooo;       // [sum nNodes] (at DecUtt.node0) position of the node's instance in seq (-1: none); NetInst.ooo
+   int *pathNode, *pathFrame;          // [paths] (at DecUtt.path0) Path records are allocated one by one here
+   int pathExtra;                      // records per utterance beyond (T + 1) * nWordNodes
+};
+int htkamd_launch_decode_ord(const OrdArgs &a, int nSel, hipStream_t s);
 
 
 struct htkamd_decoder {
@@ -64,8 +81,10 @@ struct htkamd_decoder {
    int maxWidthNodes;
    // workspace of htkamd_decoder_run, kept between calls and grown when a batch needs more (the score block and the path tables are
    // gigabytes at 256 utterances: allocating and freeing them per call cost 5 - 500 ms of a 130 ms call)
-   void *ws[16];
-   size_t wsCap[16];
+   void *ws[32];
+   size_t wsCap[32];
+   int orderMode;                      // HTKAMD_ORDER_AUTO / _FAST / _EXACT (htkamd_decoder_set_order)
+   int lastTied;                       // utterances of the last run that went through the exact-order kernel
    void *wsN[32];                      // ... and of htkamd_decoder_run_lattice
    size_t wsNCap[32];
 };

@@ -35,11 +35,14 @@
 
 __device__ __forceinline__ Tok null_tok() { Tok t; t.like = LZERO; t.lm = 0.0f; t.path = -1; return t; }
 
-// entry token of node n: best over predecessors (SetEntryState over StepInst2's sends), first maximum wins
-__device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k0, int k1, int kstep, float gT, float wT, int *argk)
+// entry token of node n: best over predecessors (SetEntryState over StepInst2's sends), first maximum wins.
+// *tie is set when a second token of EXACTLY the winner's likelihood and another history (path or LM share) was met: which of the two
+// the reference keeps depends on the order of its instance list (decode_ord.hip decodes such utterances again, in that order).
+__device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k0, int k1, int kstep, float gT, float wT, int *argk, bool *tie)
 {
    Tok best = null_tok();
    int arg = 0x7fffffff;
+   bool tb = false;
    for (int k = k0; k < k1; k += kstep) {
       const int ps = a.net.predSrc[k];
       const float lm = a.net.predLike[k];
@@ -48,9 +51,11 @@ __device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k
       if (ps < 0 && e.like < wT) continue;                            // word-end beam on word/null tokens
       const double c = e.like + lm * a.lmScale;
       if (!(c > gT)) continue;
-      if (c > best.like) { best.like = c; best.lm = e.lm + lm; best.path = e.path; arg = k; }
+      if (c > best.like) { best.like = c; best.lm = e.lm + lm; best.path = e.path; arg = k; tb = false; }
+      else if (c == best.like && (e.path != best.path || e.lm + lm != best.lm)) tb = true;
    }
    *argk = arg;
+   if (tb) *tie = true;
    return best;
 }
 
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
    const bool tpInLds = N.nTpFloats <= DEC_LDS_TP;
    if (tpInLds) for (int i = tid; i < N.nTpFloats; i += DEC_THREADS) ltp[i] = N.transP[i];
    const float *tpBase = tpInLds ? ltp : N.transP;
+   bool tie = false;                           // this thread met two equally likely tokens with different histories (pull_range)
 
    for (int i = tid; i < N.nTok; i += DEC_THREADS) tok[i] = null_tok();
    for (int i = tid; i < N.nNodes; i += DEC_THREADS) { ex[i] = null_tok(); imax[i] = LZERO; }
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             const int4 ni = N.nodeInfo[n];
             const int kind = ni.x & 15;
             int ak;
-            Tok st = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            Tok st = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie);
             if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; }
             Tok e = null_tok();
             if (kind == HTKAMD_NODE_HMM) {                 // tee model: StepHMM2
@@ -274,12 +280,13 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
          for (int k = lw; k < l1; k++) {                  // wide fan-in: the whole workgroup reduces one node
             const int n = N.levelNodes[k];
             int ak;
-            Tok st = pull_range(a, ex, N.predOff[n] + tid, N.predOff[n + 1], DEC_THREADS, gT, wT, &ak);
+            Tok st = pull_range(a, ex, N.predOff[n] + tid, N.predOff[n + 1], DEC_THREADS, gT, wT, &ak, &tie);
             // argmax over the workgroup: larger like, then smaller predecessor position
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                const double ol = __shfl_xor(st.like, o); const int ok = __shfl_xor(ak, o);
                const float olm = __shfl_xor(st.lm, o); const int op = __shfl_xor(st.path, o);
+               if (ol == st.like && ok != 0x7fffffff && ak != 0x7fffffff && (op != st.path || olm != st.lm)) tie = true;
                if (ol > st.like || (ol == st.like && ok < ak)) { st.like = ol; st.lm = olm; st.path = op; ak = ok; }
             }
             __syncthreads();
@@ -287,7 +294,10 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             __syncthreads();
             if (tid == 0) {
                int bw = 0;
-               for (int i = 1; i < DEC_THREADS / 64; i++) if (red[i] > red[bw] || (red[i] == red[bw] && redk[i] < redk[bw])) bw = i;
+               for (int i = 1; i < DEC_THREADS / 64; i++) {
+                  if (red[i] == red[bw] && redk[i] != 0x7fffffff && redk[bw] != 0x7fffffff && red2[i] != red2[bw]) tie = true;   // (lm, path) packed in red2
+                  if (red[i] > red[bw] || (red[i] == red[bw] && redk[i] < redk[bw])) bw = i;
+               }
                Tok b; b.like = red[bw]; b.lm = __int_as_float(__double2hiint(red2[bw])); b.path = __double2loint(red2[bw]);
                if (redk[bw] == 0x7fffffff) b = null_tok();
                if (t == 0 && n == N.initial) { b.like = 0.0; b.lm = 0.0f; b.path = -1; }
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             const int4 ni = N.nodeInfo[n];
             if ((ni.x >> 12) & 1) continue;                // tee models got theirs in the level phase
             int ak;
-            const Tok en = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak);
+            const Tok en = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie);
             tok[ni.y] = en;
             if (en.like > imax[n]) imax[n] = (double)(float)en.like;      // SetEntryState: the entering token raises the instance's max
          }
@@ -323,6 +333,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
       }
    }
 
+   if (tie) a.tieFlag[u] = 1;                  // (zeroed by the host before the launch)
    // ---- CompleteRecognition + LatFromPaths + TranscriptionFromLattice for the 1-best chain
    if (tid == 0) {
       const Tok fin = ex[N.final];
@@ -372,6 +383,14 @@ template <typename T> static int upv(htkamd_decoder *d, const std::vector<T> &v,
    *out = p;
    return HTKAMD_OK;
 }
+
+extern "C" int htkamd_decoder_set_order(htkamd_decoder *d, int mode)
+{
+   if (!d || mode < HTKAMD_ORDER_AUTO || mode > HTKAMD_ORDER_EXACT) { htkamd_set_error("decoder_set_order: bad argument"); return HTKAMD_EINVAL; }
+   d->orderMode = mode;
+   return HTKAMD_OK;
+}
+extern "C" int htkamd_decoder_last_tied(const htkamd_decoder *d) { return d ? d->lastTied : 0; }
 
 extern "C" void htkamd_decoder_destroy(htkamd_decoder *d)
 {
@@ -517,6 +536,22 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       if ((rc = upv(d, d->usedStates, &us))) { htkamd_decoder_destroy(d); return rc; }
       d->d_usedStates = (int *)us;
    }
+   {
+      // the network's own link order for the exact-order kernels (decode_ord.hip)
+      std::vector<int> lo(nd->linkOff, nd->linkOff + nN + 1), ld(nd->linkDest, nd->linkDest + nd->nLinks), nTr0(nN, 0);
+      std::vector<float> ll(nd->linkLike, nd->linkLike + nd->nLinks);
+      std::vector<unsigned char> dup(nN, 0);
+      for (int n = 0; n < nN; n++) {
+         int c = 0;
+         for (int k = lo[n]; k < lo[n + 1] && zt(ld[k]); k++) c++;
+         nTr0[n] = c;
+         std::vector<int> ds(ld.begin() + lo[n], ld.begin() + lo[n + 1]);
+         std::sort(ds.begin(), ds.end());
+         dup[n] = std::adjacent_find(ds.begin(), ds.end()) != ds.end();
+      }
+      if ((rc = upv(d, lo, &N.linkOff)) || (rc = upv(d, ld, &N.linkDest)) || (rc = upv(d, ll, &N.linkLike)) || (rc = upv(d, nTr0, &N.nTr0)) ||
+          (rc = upv(d, dup, &N.dupDest))) { htkamd_decoder_destroy(d); return rc; }
+   }
    N.transP = m->d_transP;
    *out = d;
    return HTKAMD_OK;
@@ -549,6 +584,9 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
    const DecNet &N = d->net;
    const int ns = (int)d->usedStates.size();
    const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
+   int orderMode = d->orderMode;
+   if (const char *ev = getenv("HTKAMD_DECODE_ORDER")) orderMode = !strcmp(ev, "fast") ? HTKAMD_ORDER_FAST : !strcmp(ev, "exact") ? HTKAMD_ORDER_EXACT : HTKAMD_ORDER_AUTO;
+   d->lastTied = 0;
    // chunk the batch so that the per-utterance work space (scores, tokens, path table) stays under ~24 GB
    int u0 = 0;
    while (u0 < nUtt) {
@@ -565,7 +603,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
       size_t score = 0, tok = 0, node = 0, path = 0;
       for (int k = 0; k < nu; k++) {
          DecUtt &ud = utt[k];
-         ud.T = frameOff[u0 + k + 1] - frameOff[u0 + k]; ud.frame0 = frameOff[u0 + k]; ud.status = HTKAMD_UTT_OK; ud.pad = 0;
+         ud.T = frameOff[u0 + k + 1] - frameOff[u0 + k]; ud.frame0 = frameOff[u0 + k]; ud.status = HTKAMD_UTT_OK; ud.idx = k;
          ud.score0 = score; ud.tok0 = tok; ud.node0 = node; ud.path0 = path; ud.out0 = (size_t)k * maxWords;
          for (int ti = 0; ti * FR < ud.T; ti++)
             for (int ch = 0; ch * SL < ns; ch++) {
@@ -599,6 +637,8 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
       A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
       A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * ((size_t)nu * maxWords * 3 + nu)); A(&dTot, sizeof(double) * nu);
       A(&dOutD, sizeof(double) * (size_t)nu * maxWords);
+      void *dTie = nullptr;
+      A(&dTie, sizeof(int) * nu);
       std::vector<int> hI; std::vector<float> hF; std::vector<double> hT, hD;
       if (!rc) {
          hipError_t e;
@@ -620,8 +660,9 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);   // exact: the decoded path is the reference's; matrix-core modes: tolerance class
       }
+      DecArgs a;
+      memset(&a, 0, sizeof(a));
       if (!rc) {
-         DecArgs a;
          a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
          a.tok = (Tok *)dTok; a.ex = (Tok *)dEx; a.imax = (double *)dImax;
          a.pathPrev = (int *)dPPrev; a.pathLike = (double *)dPLike; a.pathLm = (float *)dPLm;
@@ -631,9 +672,53 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          a.nWords = oi; a.wordPron = oi + nu; a.wordStart = a.wordPron + (size_t)nu * maxWords; a.wordEnd = a.wordStart + (size_t)nu * maxWords;
          a.wordScore = (float *)dOutF; a.wordLm = (float *)dOutF + (size_t)nu * maxWords; a.wordAc = (float *)dOutF + (size_t)nu * maxWords * 2; a.finalLm = (float *)dOutF + (size_t)nu * maxWords * 3; a.total = (double *)dTot;
          a.wordLike = (double *)dOutD;
+         a.tieFlag = (int *)dTie;
+         (void)hipMemsetAsync(dTie, 0, sizeof(int) * nu, s);
          hipLaunchKernelGGL(k_decode, dim3(nu), dim3(DEC_THREADS), 0, s, a);
          hipError_t e = hipGetLastError();
          if (e != hipSuccess) { htkamd_set_error("decoder_run: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+      }
+      if (!rc && orderMode != HTKAMD_ORDER_FAST) {
+         // the utterances in which two equally likely tokens with different histories met (or all of them: HTKAMD_ORDER_EXACT) once more,
+         // in the order of HRec's instance list (decode_ord.hip); their results replace k_decode's
+         std::vector<int> flags(nu, 1);
+         if (orderMode == HTKAMD_ORDER_AUTO) {
+            hipError_t e;
+            if ((e = hipMemcpyAsync(flags.data(), dTie, sizeof(int) * nu, hipMemcpyDeviceToHost, s)) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) {
+               htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP;
+            }
+         }
+         std::vector<DecUtt> sel;
+         size_t opath = 0;
+         const int pathExtra = 64;
+         for (int k = 0; k < nu && !rc; k++)
+            if (flags[k]) {
+               DecUtt ud = utt[k];
+               ud.path0 = opath;
+               opath += 3 * ((size_t)(ud.T + 1) * N.nWordNodes) + pathExtra;      // StepWord2 "may be repeated" (HRec.c:1046): room for every word node thrice per frame
+               sel.push_back(ud);
+            }
+         if (!rc && !sel.empty()) {
+            const int nSel = (int)sel.size();
+            const int seqCap = 8 * N.nNodes + 1024;          // appends of one frame's pass 2 (attaches + moves) on top of the live instances
+            void *dSel = nullptr, *dSeq = nullptr, *dPos = nullptr, *dOoo = nullptr, *oPrev = nullptr, *oLike = nullptr, *oLm = nullptr, *oNode = nullptr, *oFrame = nullptr;
+            A(&dSel, sizeof(DecUtt) * nSel); A(&dSeq, sizeof(int) * (size_t)nSel * 2 * seqCap); A(&dPos, sizeof(int) * node); A(&dOoo, node);
+            A(&oPrev, opath * 4); A(&oLike, opath * 8); A(&oLm, opath * 4); A(&oNode, opath * 4); A(&oFrame, opath * 4);
+            if (!rc) {
+               hipError_t e = hipMemcpyAsync(dSel, sel.data(), sizeof(DecUtt) * nSel, hipMemcpyHostToDevice, s);
+               if (e != hipSuccess) { htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+            }
+            if (!rc) {
+               OrdArgs oa;
+               oa.d = a; oa.d.utt = (const DecUtt *)dSel; oa.d.nUtt = nSel;
+               oa.d.pathPrev = (int *)oPrev; oa.d.pathLike = (double *)oLike; oa.d.pathLm = (float *)oLm;
+               oa.seq = (int *)dSeq; oa.seqCap = seqCap; oa.pos = (int *)dPos; oa.ooo = (unsigned char *)dOoo;
+               oa.pathNode = (int *)oNode; oa.pathFrame = (int *)oFrame; oa.pathExtra = pathExtra;
+               // (the path capacity the kernel assumes per utterance is 3 (T + 1) nWordNodes + pathExtra: see opath above)
+               rc = htkamd_launch_decode_ord(oa, nSel, s);
+            }
+            d->lastTied += nSel;
+         }
       }
       if (!rc) {
          hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords * 3 + nu); hT.resize(nu); hD.resize((size_t)nu * maxWords);

@@ -468,7 +468,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
       size_t score = 0, tok = 0, node = 0, path = 0;
       for (int k = 0; k < nu; k++) {
          DecUtt &ud = utt[k];
-         ud.T = frameOff[u0 + k + 1] - frameOff[u0 + k]; ud.frame0 = frameOff[u0 + k]; ud.status = HTKAMD_UTT_OK; ud.pad = 0;
+         ud.T = frameOff[u0 + k + 1] - frameOff[u0 + k]; ud.frame0 = frameOff[u0 + k]; ud.status = HTKAMD_UTT_OK; ud.idx = k;
          ud.score0 = score; ud.tok0 = tok; ud.node0 = node; ud.path0 = path; ud.out0 = 0;
          for (int ti = 0; ti * FR < ud.T; ti++)
             for (int ch = 0; ch * SL < ns; ch++) {

@@ -634,6 +634,19 @@ int  htkamd_lattice_nbest(const htkamd_lattice *lat, const htkamd_net *net, int 
 float htkamd_lattice_arc_score(const htkamd_lattice *lat, int arc);      /* LArcTotLike (HNet.h:257): the score a label of that word carries */
 int  htkamd_net_pron_num(const htkamd_net *n, int pron);                  /* v= : number of the pronunciation within its word, from 1 */
 void htkamd_decoder_destroy(htkamd_decoder *d);
+/* The order in which equally likely tokens reach a node.  SetEntryState (HRec.c:1303) keeps the FIRST of two tokens of exactly equal
+ * likelihood, and "first" is a matter of HRec's instance list, which AttachInst / MoveToRecent / ReOrderList / DetachInst
+ * (HRec.c:1123-1301) re-order as the utterance goes.  The batch kernel pulls in a static order and NOTES when two such tokens with
+ * different histories meet; HTKAMD_ORDER_AUTO (default) then decodes that utterance again with the list itself kept and walked on the
+ * device (exact: HVite's choice among homophones of equal score, at a fraction of the batch kernel's speed); _FAST keeps the static
+ * order's answer (same likelihoods, possibly the other of two equally scored words); _EXACT sends every utterance through the list
+ * kernel.  The environment variable HTKAMD_DECODE_ORDER = auto | fast | exact overrides.  decoder_last_tied: how many utterances of the
+ * last htkamd_decoder_run took the list kernel.  N-best runs (htkamd_decoder_run_lattice) always use the list. */
+#define HTKAMD_ORDER_AUTO  0
+#define HTKAMD_ORDER_FAST  1
+#define HTKAMD_ORDER_EXACT 2
+int  htkamd_decoder_set_order(htkamd_decoder *d, int mode);
+int  htkamd_decoder_last_tied(const htkamd_decoder *d);
 int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
                         int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
                         double *total, void *stream);

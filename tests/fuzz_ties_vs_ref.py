@@ -3,7 +3,10 @@ several words, with and without a closing tee model, different pronunciation pro
 log-probability values, so that different word sequences reach a node with EXACTLY the same likelihood -- sums of the same float
 terms in another order are exact in double.  What survives such a tie in the reference is decided by the order of its instance
 list (SetEntryState HRec.c:1303 keeps the first arrival); the oracle must make the same choice.
-   python tests/fuzz_ties_vs_ref.py [iterations] [seed]"""
+   python tests/fuzz_ties_vs_ref.py [iterations] [seed] [--device]
+With --device (a GPU box; oracle/_ref travels there) the HIP decoder is held against HVite on the same cases as well, in its default mode
+(batch kernel; utterances in which it met an exact tie once more in the list's order, decode_ord.hip) and with every utterance through the
+list kernel."""
 import os
 import subprocess
 import sys
@@ -86,10 +89,13 @@ def run_hvite(d, feats, opts):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    device = "--device" in sys.argv
+    argv = [a for a in sys.argv if a != "--device"]
+    n = int(argv[1]) if len(argv) > 1 else 50
+    rng = np.random.default_rng(int(argv[2]) if len(argv) > 2 else 1)
     tmp = tempfile.mkdtemp()
     bad = 0; tot = 0
+    dbad = 0; dtied = 0
     for it in range(n):
         d = os.path.join(tmp, "t%d" % it); os.makedirs(d)
         feats, p, opts = tie_case(rng, d)
@@ -97,6 +103,19 @@ def main():
         mmf = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
         net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
         om = pyoracle.Model(mmf.packed())
+        if device:
+            dec = capi.Decoder(capi.Model(mmf.packed()), net, lmScale=p["lmScale"])
+            for mode in (capi.ORDER_AUTO, capi.ORDER_EXACT):
+                dec.set_order(mode)
+                res = dec.run(feats, **p)
+                if mode == capi.ORDER_AUTO:
+                    dtied += dec.last_tied()
+                for u, (w, _) in enumerate(res):
+                    got = None if w is None else format_words(w, net.out_syms)
+                    want = ref.get("u%d" % u)
+                    if got != want and not (got is None and want is None):
+                        dbad += 1
+                        print("TIE-DEVICE it %d u%d mode %d %s\n  device %s\n  HVite  %s" % (it, u, mode, opts, got, want))
         for u, X in enumerate(feats):
             ow, ot = pyoracle.decode(om, X, net.arrays(), **p)
             got = None if ow is None else format_words(ow, net.out_syms)
@@ -111,7 +130,9 @@ def main():
                     np.savez(os.path.join(d, "feats.npz"), **{"u%d" % k: x for k, x in enumerate(feats)})
                     shutil.copytree(d, os.path.join(os.environ["FUZZ_KEEP"], "tie_%d" % it), dirs_exist_ok=True)
     print("utterances equal to HVite: %d/%d" % (tot - bad, tot))
-    sys.exit(1 if bad else 0)
+    if device:
+        print("device: %d differences from HVite over %d utterances x 2 modes; %d utterances took the list kernel in the default mode" % (dbad, tot, dtied))
+    sys.exit(1 if (bad or dbad) else 0)
 
 
 if __name__ == "__main__":
