@@ -85,6 +85,6 @@ struct htkamd_decoder {
    size_t wsCap[32];
    int orderMode;                      // HTKAMD_ORDER_AUTO / _FAST / _EXACT (htkamd_decoder_set_order)
    int lastTied;                       // utterances of the last run that went through the exact-order kernel
-   void *wsN[32];                      // ... and of htkamd_decoder_run_lattice
-   size_t wsNCap[32];
+   void *wsN[48];                      // ... and of htkamd_decoder_run_lattice
+   size_t wsNCap[48];
 };

@@ -28,6 +28,7 @@
 #include "hipcheck.h"
 #include "kernels.h"
 #include "decode.h"
+#include "decode_ord.h"
 
 #define NT 8                        /* capacity of a token set (HVite -n up to 8) */
 
@@ -47,6 +48,9 @@ struct NArgs {
    int *altN, *altPrev; double *altLike; float *altLm;         // alternatives: altN[path], others [path*(NT-1) + k]
    int *mark;                                                  // [paths] MarkPaths' usage numbers
    int *stack;                                                 // [nUtt * 2*maxLatNodes] depth-first stack
+   int *nodePath;                                              // [nUtt * maxLatNodes] the Path record of a lattice node
+   // k_decode_ord_n: the instance list (decode_ord.h) and Path records allocated one by one
+   int *seq; int seqCap; int *pos; unsigned char *ooo; int *pathNode, *pathFrame; int pathExtra;
    float genBeam, wordBeam, nBeam, lmScale, wordPen, prScale;
    int nToks, maxActive;
    int maxLatNodes, maxLatArcs;
@@ -59,10 +63,15 @@ struct NArgs {
 };
 
 __device__ __forceinline__ void ts_null(TSet &s) { s.like = LZERO; s.lm = 0.0f; s.path = -1; s.n = 1; s.pad = 0; s.rl[0] = 0.0f; s.rlm[0] = 0.0f; s.rp[0] = -1; }
-__device__ __forceinline__ int key_of(int path, int nWordNodes) { return path < 0 ? -1 : path % nWordNodes; }
+// the word-end node a path ends in (TokSetMerge compares path->node): the dense table's column, or -- Path records allocated one by one
+// (k_decode_ord_n) -- the record's node
+struct KeyOf {
+   const int *pathNode; int nW;
+   __device__ __forceinline__ int operator()(int path) const { return path < 0 ? -1 : (pathNode ? pathNode[path] : path % nW); }
+};
 
 // TokSetMerge (HRec.c:279): token (cLike, cLm, cPath) with the relative tokens of `src` merged into `res`
-__device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TSet &src, float nThresh, int nToks, int nW)
+__device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TSet &src, float nThresh, int nToks, const KeyOf key_of)
 {
    float tl[NT], tlm[NT]; int tp[NT]; int tn; double tLike;
    if (cLike >= res.like) {
@@ -86,10 +95,10 @@ __device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TS
    const float limit = (float)((double)nThresh - tLike);
    for (int i = 0; i < tn; i++) {
       if (tl[i] < limit) break;
-      const int key = key_of(tp[i], nW);
+      const int key = key_of(tp[i]);
       const float like = tl[i] - diff;
       int mch = -1;
-      for (int k = 0; k < res.n; k++) if (key_of(res.rp[k], nW) == key) { mch = k; break; }
+      for (int k = 0; k < res.n; k++) if (key_of(res.rp[k]) == key) { mch = k; break; }
       if (mch < 0) {
          if (res.n < nToks) { mch = res.n++; res.rl[mch] = (float)LZERO; res.rlm[mch] = 0.0f; res.rp[mch] = -1; }
          else mch = res.n - 1;
@@ -115,7 +124,7 @@ __device__ void pull_sets(const NArgs &a, const TSet *ex, int k0, int k1, float 
       if (!(c > gT)) continue;
       TSet x = e;
       for (int q = 0; q < x.n; q++) x.rlm[q] = e.rlm[q] + lm;
-      ts_merge(res, c, e.lm + lm, e.path, x, nT, a.nToks, a.net.nWordNodes);
+      ts_merge(res, c, e.lm + lm, e.path, x, nT, a.nToks, KeyOf{nullptr, a.net.nWordNodes});
    }
 }
 
@@ -148,6 +157,85 @@ __device__ void word_exit(const NArgs &a, const DecUtt &ud, int n, int t, const 
    }
    e.path = (int)pid; e.lm = 0.0f;
    e.n = 1; e.rl[0] = 0.0f; e.rlm[0] = 0.0f; e.rp[0] = e.path;
+}
+
+// CompleteRecognition (HRec.c:2054) -> CreateLattice (:1679): MarkPaths (:1664) numbers the Path records reachable from the final token
+// set depth first, LatFromPaths (:1512) makes every Path / NxtPath an arc.  By ONE thread.  Where a Path record lies: the dense
+// [frame][word node] table of k_decode_n, or records allocated one by one with their frame and node beside them (k_decode_ord_n).
+struct PathView {
+   const int *pathFrame, *pathNode; int nW; const int *wordNode;
+   __device__ __forceinline__ int frame(int p) const { return pathFrame ? pathFrame[p] : p / nW; }
+   __device__ __forceinline__ int node(int p) const { return pathNode ? pathNode[p] : wordNode[p % nW]; }
+};
+
+__device__ void build_lattice(const NArgs &a, const DecUtt &ud, int u, const TSet &fin, const PathView pv)
+{
+   const DecNet &N = a.net;
+   const int T = ud.T;
+   a.total[u] = LZERO;
+   int *latN = a.latN + 2 * u;
+   latN[0] = -1; latN[1] = 0;
+   if (fin.path < 0) return;
+   a.total[u] = fin.like;
+   const size_t nb = (size_t)u * a.maxLatNodes, ab = (size_t)u * a.maxLatArcs;
+   int *stk = a.stack + (size_t)u * 2 * a.maxLatNodes;
+   int *nodePath = a.nodePath + nb;
+   int nn = 1, nl = 0, sp = 0;
+   bool overflow = false;
+   // the root (a Path that is not in the table): node 1; children = fin.path, then fin.rp[1..]
+   nn = 2; nl = 1;
+   a.nodeFrame[nb + 0] = 0; a.nodeNet[nb + 0] = -1; a.nodeLike[nb + 0] = 0.0;
+   a.nodeFrame[nb + 1] = T; a.nodeNet[nb + 1] = -2; a.nodeLike[nb + 1] = fin.like;
+   // visit(p): number it, push it; children are looked at in order prev, alt 0, alt 1, ...
+#define VISIT(p_) do { const int pp_ = (p_); if (pp_ >= 0 && a.mark[ud.path0 + pp_] == 0) { \
+      if (nn >= a.maxLatNodes) overflow = true; else { a.mark[ud.path0 + pp_] = nn; nodePath[nn] = pp_; \
+         a.nodeFrame[nb + nn] = pv.frame(pp_); a.nodeNet[nb + nn] = pv.node(pp_); a.nodeLike[nb + nn] = a.pathLike[ud.path0 + pp_]; nn++; nl++; \
+         stk[2 * sp] = pp_; stk[2 * sp + 1] = 0; sp++; } } } while (0)
+   for (int c = 0; c < fin.n && !overflow; c++) {
+      if (c > 0) nl++;
+      VISIT(c == 0 ? fin.path : fin.rp[c]);
+      while (sp > 0 && !overflow) {
+         const int p = stk[2 * (sp - 1)];
+         const int ch = stk[2 * (sp - 1) + 1]++;
+         const int nAlt = a.altN[ud.path0 + p];
+         if (ch == 0) VISIT(a.pathPrev[ud.path0 + p]);
+         else if (ch - 1 < nAlt) { nl++; VISIT(a.altPrev[(ud.path0 + p) * (NT - 1) + (ch - 1)]); }
+         else sp--;
+      }
+   }
+#undef VISIT
+   if (overflow || nl > a.maxLatArcs) { latN[0] = -3; return; }
+   int ln = 0;
+   // arcs of the root
+   for (int c = 0; c < fin.n; c++) {
+      const int prev = (c == 0) ? fin.path : fin.rp[c];
+      const double plike = (c == 0) ? fin.like : fin.like + fin.rl[c];
+      const float plm = (c == 0) ? fin.lm : fin.rlm[c];
+      const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
+      a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = 1;
+      a.arcAc[ab + ln] = (float)(plike - prlk - plm * a.lmScale - 0.0); a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = 0.0f; a.arcScore[ab + ln] = plike;
+      ln++;
+   }
+   for (int i = 2; i < nn; i++) {
+      const int p = nodePath[i];
+      const int node = a.nodeNet[nb + i];
+      const int nAlt = a.altN[ud.path0 + p];
+      for (int c = 0; c <= nAlt; c++) {
+         const size_t z = (ud.path0 + p) * (NT - 1) + (c - 1);
+         const int prev = (c == 0) ? a.pathPrev[ud.path0 + p] : a.altPrev[z];
+         const double plike = (c == 0) ? a.pathLike[ud.path0 + p] : a.altLike[z];
+         const float plm = (c == 0) ? a.pathLm[ud.path0 + p] : a.altLm[z];
+         const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
+         const double wp = a.wordPen;
+         float ac = (float)(plike - prlk - plm * a.lmScale - wp);
+         const float pr = N.pronProb[node];
+         ac -= pr * a.prScale;
+         a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = i;
+         a.arcAc[ab + ln] = ac; a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = pr; a.arcScore[ab + ln] = plike;
+         ln++;
+      }
+   }
+   latN[0] = nn; latN[1] = ln;
 }
 
 __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
@@ -252,7 +340,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
                   res.like += tp[(lo - 1) * NS + (j - 1)];
                   for (int i = lo + 1; i <= hi; i++) {
                      const TSet &si = cur[t0 + i - 1];
-                     ts_merge(res, si.like + tp[(i - 1) * NS + (j - 1)], si.lm, si.path, si, nT, a.nToks, nW);
+                     ts_merge(res, si.like + tp[(i - 1) * NS + (j - 1)], si.lm, si.path, si, nT, a.nToks, KeyOf{nullptr, nW});
                   }
                   if (res.like > gT) {
                      const int st = N.hmmState[ni.w + (j - 2)];
@@ -271,7 +359,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
                   res.like += tp[(lo - 1) * NS + (NS - 1)];
                   for (int i = lo + 1; i <= hi; i++) {
                      const TSet &si = nxt[t0 + i - 1];
-                     ts_merge(res, si.like + tp[(i - 1) * NS + (NS - 1)], si.lm, si.path, si, nT, a.nToks, nW);
+                     ts_merge(res, si.like + tp[(i - 1) * NS + (NS - 1)], si.lm, si.path, si, nT, a.nToks, KeyOf{nullptr, nW});
                   }
                   if (res.like > LSMALL) {
                      exS = res;
@@ -316,7 +404,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
                if (t >= 1 && m2 < gT) { ts_null(e); imax[n] = LZERO; }
                else {
                   imax[n] = m2;
-                  if (st.like > LSMALL) ts_merge(e, st.like + tpBase[ni.z + (NS - 1)], st.lm, st.path, st, nT, a.nToks, nW);
+                  if (st.like > LSMALL) ts_merge(e, st.like + tpBase[ni.z + (NS - 1)], st.lm, st.path, st, nT, a.nToks, KeyOf{nullptr, nW});
                }
             } else if (!(st.like > LSMALL)) imax[n] = LZERO;
             else {
@@ -340,7 +428,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
                for (int q = 0; q < DEC_THREADS; q++) {
                   const TSet &pq = part[q];
                   if (!(pq.like > LSMALL)) continue;
-                  ts_merge(st, pq.like, pq.lm, pq.path, pq, nT, a.nToks, nW);
+                  ts_merge(st, pq.like, pq.lm, pq.path, pq, nT, a.nToks, KeyOf{nullptr, nW});
                }
                if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; st.n = 1; st.rl[0] = 0.0f; st.rlm[0] = 0.0f; st.rp[0] = -1; }
                TSet e; ts_null(e);
@@ -369,74 +457,326 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
       }
    }
 
-   // ---- CompleteRecognition -> CreateLattice: MarkPaths depth first, then one arc per Path / NxtPath (LatFromPaths)
-   if (tid == 0) {
-      const TSet fin = ex[N.final];
-      a.total[u] = LZERO;
-      int *latN = a.latN + 2 * u;
-      latN[0] = -1; latN[1] = 0;
-      if (fin.path >= 0) {
-         a.total[u] = fin.like;
-         const size_t nb = (size_t)u * a.maxLatNodes, ab = (size_t)u * a.maxLatArcs;
-         int *stk = a.stack + (size_t)u * 2 * a.maxLatNodes;
-         int nn = 1, nl = 0, sp = 0;
-         bool overflow = false;
-         // the root (a Path that is not in the table): node 1; children = fin.path, then fin.rp[1..]
-         nn = 2; nl = 1;
-         a.nodeFrame[nb + 0] = 0; a.nodeNet[nb + 0] = -1; a.nodeLike[nb + 0] = 0.0;
-         a.nodeFrame[nb + 1] = T; a.nodeNet[nb + 1] = -2; a.nodeLike[nb + 1] = fin.like;
-         // visit(p): number it, push it; children are looked at in order prev, alt 0, alt 1, ...
-#define VISIT(p_) do { const int pp_ = (p_); if (pp_ >= 0 && a.mark[ud.path0 + pp_] == 0) { \
-            if (nn >= a.maxLatNodes) overflow = true; else { a.mark[ud.path0 + pp_] = nn; \
-               a.nodeFrame[nb + nn] = pp_ / nW; a.nodeNet[nb + nn] = N.wordNode[pp_ % nW]; a.nodeLike[nb + nn] = a.pathLike[ud.path0 + pp_]; nn++; nl++; \
-               stk[2 * sp] = pp_; stk[2 * sp + 1] = 0; sp++; } } } while (0)
-         for (int c = 0; c < fin.n && !overflow; c++) {
-            if (c > 0) nl++;
-            VISIT(c == 0 ? fin.path : fin.rp[c]);
-            while (sp > 0 && !overflow) {
-               const int p = stk[2 * (sp - 1)];
-               const int ch = stk[2 * (sp - 1) + 1]++;
-               const int nAlt = a.altN[ud.path0 + p];
-               if (ch == 0) VISIT(a.pathPrev[ud.path0 + p]);
-               else if (ch - 1 < nAlt) { nl++; VISIT(a.altPrev[(ud.path0 + p) * (NT - 1) + (ch - 1)]); }
-               else sp--;
+   // ---- CompleteRecognition -> CreateLattice
+   if (tid == 0) build_lattice(a, ud, u, ex[N.final], PathView{nullptr, nullptr, nW, N.wordNode});
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_decode_ord_n -- N-best token passing in the order of HRec's instance list (decode_ord.hip has the design; this is its token-set
+// form).  In N-best mode the list's order decides more than exact ties: every TokSetMerge re-bases its relative tokens as floats
+// (HRec.c:361-364), so the order in which a node's senders are stepped is in the last bit of every alternative's likelihood -- and in
+// which of two alternatives of nearly equal likelihood survives.  The run therefore always walks the list.  Pass 1 = k_decode_n's
+// StepHMM1 over the list's instances; pass 2 = the walk of k_decode_ord with token sets pushed along the links in link order, each
+// merge by one lane on the set in global memory; StepWord2 allocates its Path record (+ NxtPaths) per call.
+__device__ void word_exit_ord(const NArgs &a, const DecUtt &ud, int n, int t, const TSet &st, TSet &e, int pid, int *pathNode, int *pathFrame)
+{
+   const DecNet &N = a.net;
+   e = st;
+   e.like += a.wordPen;
+   e.like += N.pronProb[n] * a.prScale;
+   a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
+   pathNode[pid] = n; pathFrame[pid] = t;
+   a.altN[ud.path0 + pid] = st.n - 1;
+   for (int k = 1; k < st.n; k++) {
+      const size_t z = (ud.path0 + pid) * (NT - 1) + (k - 1);
+      a.altLike[z] = e.like + st.rl[k]; a.altLm[z] = st.rlm[k]; a.altPrev[z] = st.rp[k];
+   }
+   e.path = pid; e.lm = 0.0f;
+   e.n = 1; e.rp[0] = e.path;                            // rl[0] / rlm[0] stay what the exit set held (AttachInst's rmax: 0, 0)
+}
+
+__global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
+{
+   __shared__ double red[ORD_THREADS / 64];
+   __shared__ double red2[ORD_THREADS / 64];
+   __shared__ float thr[3];
+   __shared__ unsigned int usel[3], uhist[256];
+   __shared__ int scan[ORD_THREADS / 64 + 1];
+   __shared__ OrdShared sh;
+   const int sel = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   if (sel >= a.nUtt) return;
+   const DecUtt ud = a.utt[sel];
+   const DecNet &N = a.net;
+   const int T = ud.T, u = ud.idx;
+   TSet *cur = a.tokA + ud.tok0, *nxt = a.tokB + ud.tok0, *ex = a.ex + ud.node0;
+   volatile double *imax = a.imax + ud.node0;
+   volatile int *pos = a.pos + ud.node0;
+   volatile unsigned char *ooo = a.ooo + ud.node0;
+   int *seqA = a.seq + (size_t)sel * 2 * a.seqCap, *seqB = seqA + a.seqCap;
+   const size_t pathCap = 3 * ((size_t)(T + 1) * N.nWordNodes) + (size_t)a.pathExtra;
+   int *pathNode = a.pathNode + ud.path0, *pathFrame = a.pathFrame + ud.path0;
+   const float *tpBase = N.transP;
+   const KeyOf ko{pathNode, 0};
+
+   { TSet z; ts_null(z);
+     for (int i = tid; i < N.nTok; i += ORD_THREADS) { cur[i] = z; nxt[i] = z; }
+     for (int i = tid; i < N.nNodes; i += ORD_THREADS) { ex[i] = z; imax[i] = LZERO; pos[i] = -1; ooo[i] = 0; } }
+   for (size_t i = tid; i < pathCap; i += ORD_THREADS) a.mark[ud.path0 + i] = 0;
+   if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; thr[2] = (float)LSMALL; sh.tail = 0; sh.nPath = 0; sh.status = 0; sh.base = 0; sh.cn = 0; }
+   __syncthreads();
+   OrdCtx c;
+   c.N = &N; c.seq = seqA; c.pos = pos; c.ooo = ooo; c.imax = imax; c.seqCap = a.seqCap; c.sh = &sh;
+   if (tid == 0) {                                          // StartRecognition (HRec.c:1884)
+      o_attach(c, N.initial);
+      TSet &s0 = cur[N.nodeInfo[N.initial].y];
+      s0.like = 0.0; s0.lm = 0.0f; s0.path = -1; s0.n = 1;
+      imax[N.initial] = 0.0;
+   }
+   __threadfence_block();
+   __syncthreads();
+
+   for (int t = 0; t <= T; t++) {
+      if (t >= 1) {
+         if (a.maxActive > 0 && sh.tail > a.maxActive) {    // maximum-model pruning (HRec.c:1966-1985), as in k_decode_ord
+            int cnt = 0;
+            if (tid == 0) usel[0] = 0;
+            __syncthreads();
+            for (int i = tid; i < sh.tail; i += ORD_THREADS) if (c.seq[i] >= 0) cnt++;
+            if (cnt) atomicAdd(&usel[0], (unsigned)cnt);
+            __syncthreads();
+            if ((int)usel[0] > a.maxActive) {
+               if (tid == 0) { usel[1] = 0; usel[2] = (unsigned)a.maxActive; }
+               unsigned int mask = 0;
+               for (int pass = 0; pass < 4; pass++) {
+                  const int shift = 24 - 8 * pass;
+                  for (int i = tid; i < 256; i += ORD_THREADS) uhist[i] = 0;
+                  __syncthreads();
+                  const unsigned int prefix = usel[1];
+                  for (int i = tid; i < sh.tail; i += ORD_THREADS) {
+                     const int n = c.seq[i];
+                     if (n < 0) continue;
+                     unsigned int k = __float_as_uint((float)imax[n]);
+                     k ^= (k >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+                     if ((k & mask) == prefix) atomicAdd(&uhist[(k >> shift) & 255], 1);
+                  }
+                  __syncthreads();
+                  if (tid == 0) {
+                     unsigned int skip = usel[2], cum = 0; int b = 255;
+                     for (; b > 0; b--) { if (cum + (unsigned)uhist[b] > skip) break; cum += (unsigned)uhist[b]; }
+                     usel[1] = prefix | ((unsigned)b << shift); usel[2] = skip - cum;
+                  }
+                  mask |= 255u << shift;
+                  __syncthreads();
+               }
+               unsigned int kk = usel[1];
+               kk ^= (kk >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+               const float uth = __uint_as_float(kk);
+               if (uth > (float)LSMALL)
+                  for (int i = tid; i < sh.tail; i += ORD_THREADS) {
+                     const int n = c.seq[i];
+                     if (n < 0 || !((float)imax[n] < uth)) continue;
+                     TSet z; ts_null(z);
+                     c.seq[i] = -1; pos[n] = -1; imax[n] = LZERO; ex[n] = z;
+                     const int4 ni = N.nodeInfo[n];
+                     const int nt = ((ni.x & 15) == HTKAMD_NODE_HMM) ? ((ni.x >> 4) & 255) - 1 : 1;
+                     for (int q = 0; q < nt; q++) { cur[ni.y + q] = z; nxt[ni.y + q] = z; }
+                  }
             }
+            __syncthreads();
          }
-#undef VISIT
-         if (overflow || nl > a.maxLatArcs) { latN[0] = -3; }
-         else {
-            int ln = 0;
-            // arcs of the root
-            for (int c = 0; c < fin.n; c++) {
-               const int prev = (c == 0) ? fin.path : fin.rp[c];
-               const double plike = (c == 0) ? fin.like : fin.like + fin.rl[c];
-               const float plm = (c == 0) ? fin.lm : fin.rlm[c];
-               const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
-               a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = 1;
-               a.arcAc[ab + ln] = (float)(plike - prlk - plm * a.lmScale - 0.0); a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = 0.0f; a.arcScore[ab + ln] = plike;
-               ln++;
+         {  // the blanks out of the list
+            int *src = (int *)c.seq, *dst = (src == seqA) ? seqB : seqA;
+            const int tl = sh.tail;
+            int outBase = 0;
+            for (int b0 = 0; b0 < tl; b0 += ORD_THREADS) {
+               const int i = b0 + tid;
+               const int n = (i < tl) ? src[i] : -1;
+               const unsigned long long m = __ballot(n >= 0);
+               if (lane == 0) scan[wv] = __popcll(m);
+               __syncthreads();
+               int off = outBase;
+               for (int w = 0; w < wv; w++) off += scan[w];
+               int tot = 0;
+               for (int w = 0; w < ORD_THREADS / 64; w++) tot += scan[w];
+               if (n >= 0) { const int o = off + __popcll(m & ((1ull << lane) - 1ull)); dst[o] = n; pos[n] = o; }
+               outBase += tot;
+               __syncthreads();
             }
-            for (int i = 2; i < nn; i++) {
-               const int p = a.nodeFrame[nb + i] * nW + N.wordIdx[a.nodeNet[nb + i]];
-               const int node = a.nodeNet[nb + i];
-               const int nAlt = a.altN[ud.path0 + p];
-               for (int c = 0; c <= nAlt; c++) {
-                  const size_t z = (ud.path0 + p) * (NT - 1) + (c - 1);
-                  const int prev = (c == 0) ? a.pathPrev[ud.path0 + p] : a.altPrev[z];
-                  const double plike = (c == 0) ? a.pathLike[ud.path0 + p] : a.altLike[z];
-                  const float plm = (c == 0) ? a.pathLm[ud.path0 + p] : a.altLm[z];
-                  const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
-                  const double wp = a.wordPen;
-                  float ac = (float)(plike - prlk - plm * a.lmScale - wp);
-                  const float pr = N.pronProb[node];
-                  ac -= pr * a.prScale;
-                  a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = i;
-                  a.arcAc[ab + ln] = ac; a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = pr; a.arcScore[ab + ln] = plike;
-                  ln++;
+            c.seq = dst;
+            if (tid == 0) sh.tail = outBase;
+            __syncthreads();
+         }
+         // ---- pass 1 over the list's instances (k_decode_n's StepHMM1; StepWord1 for the rest)
+         const float gT = thr[0], nT = thr[2];
+         double myGen = LZERO, myWord = LZERO;
+         const int nLive = sh.tail;
+         for (int li = tid; li < nLive; li += ORD_THREADS) {
+            const int n = c.seq[li];
+            const int4 ni = N.nodeInfo[n];
+            const int NS = (ni.x >> 4) & 255, t0 = ni.y;
+            if ((ni.x & 15) != HTKAMD_NODE_HMM) {             // StepWord1 (HRec.c:1038): the sets' relative tokens stay as they are
+               TSet z = cur[t0]; z.like = LZERO; z.lm = 0.0f; z.path = -1; z.n = 1; nxt[t0] = z;
+               TSet ze = ex[n]; ze.like = LZERO; ze.lm = 0.0f; ze.path = -1; ze.n = 1; ex[n] = ze;
+               imax[n] = LZERO;
+               continue;
+            }
+            const float *tp = tpBase + ni.z;
+            TSet exS; ts_null(exS);
+            double mx = LZERO;
+            for (int j = 2; j < NS; j++) {
+               int lo = 1, hi = NS - 1;
+               while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
+               while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
+               if (lo > hi) { lo = 1; hi = NS - 1; }
+               TSet res = cur[t0 + lo - 1];
+               res.like += tp[(lo - 1) * NS + (j - 1)];
+               for (int i = lo + 1; i <= hi; i++) {
+                  const TSet &si = cur[t0 + i - 1];
+                  ts_merge(res, si.like + tp[(i - 1) * NS + (j - 1)], si.lm, si.path, si, nT, a.nToks, ko);
+               }
+               if (res.like > gT) {
+                  const int st = N.hmmState[ni.w + (j - 2)];
+                  res.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
+                  if (res.like > mx) mx = res.like;
+               } else { res.like = LZERO; res.lm = 0.0f; res.path = -1; res.n = 1; }
+               nxt[t0 + j - 1] = res;
+            }
+            { TSet z = cur[t0]; z.like = LZERO; z.lm = 0.0f; z.path = -1; z.n = 1; nxt[t0] = z; }          // entry consumed
+            {
+               int lo = 2, hi = NS - 1;
+               while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
+               while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
+               if (lo > hi) { lo = 2; hi = NS - 1; }
+               TSet res = nxt[t0 + lo - 1];
+               res.like += tp[(lo - 1) * NS + (NS - 1)];
+               for (int i = lo + 1; i <= hi; i++) {
+                  const TSet &si = nxt[t0 + i - 1];
+                  ts_merge(res, si.like + tp[(i - 1) * NS + (NS - 1)], si.lm, si.path, si, nT, a.nToks, ko);
+               }
+               if (res.like > LSMALL) {
+                  exS = res;
+                  const double w = res.like + N.wdlk[n];
+                  if (w > myWord) myWord = w;
+               } else { exS = res; exS.like = LZERO; exS.lm = 0.0f; exS.path = -1; exS.n = 1; }
+            }
+            if (mx > myGen) myGen = mx;
+            ex[n] = exS; imax[n] = (double)(float)mx;
+         }
+         const double genMax = o_block_max(myGen, red);
+         const double wordMax = o_block_max(myWord, red2);
+         if (tid == 0) {
+            float w = (float)(wordMax - a.wordBeam); if (w < (float)LSMALL) w = (float)LSMALL;
+            float g = (float)(genMax - a.genBeam); if (g < (float)LSMALL) g = (float)LSMALL;
+            float nn = (float)(genMax - a.nBeam); if (nn < (float)(LSMALL / 2)) nn = (float)(LSMALL / 2);
+            thr[0] = g; thr[1] = w; thr[2] = nn;
+         }
+         __threadfence_block();
+         __syncthreads();
+         { TSet *sw = cur; cur = nxt; nxt = sw; }            // the new column is the current one from here on
+      }
+      // ---- pass 2: wavefront 0 walks the list while it changes
+      if (wv == 0) {
+         const float gT = thr[0], wT = thr[1], nT = thr[2];
+         volatile OrdShared *vs = &sh;
+         int idx = 0;
+         while (idx < vs->tail && vs->status == 0) {
+            const int tl = vs->tail;
+            const int cn = (tl - idx < 64) ? tl - idx : 64;
+            {
+               const int n = (lane < cn) ? c.seq[idx + lane] : -1;
+               vs->chunkNode[lane] = n;
+               vs->chunkMax[lane] = (n >= 0) ? (float)imax[n] : 0.0f;
+               if (lane == 0) { vs->base = idx; vs->cn = cn; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < cn && vs->status == 0; i++) {
+               const int n = vs->chunkNode[i];
+               if (n < 0) continue;
+               const float nmax = vs->chunkMax[i];
+               const int4 ni = N.nodeInfo[n];
+               const int kind = ni.x & 15, NS = (ni.x >> 4) & 255, t0 = ni.y;
+               if (nmax < gT) {                               // DetachInst
+                  if (lane == 0) { TSet z; ts_null(z); o_blank(c, n); pos[n] = -1; imax[n] = LZERO; ex[n] = z; }
+                  const int nt = (kind == HTKAMD_NODE_HMM) ? NS - 1 : 1;
+                  if (lane < nt) { TSet z; ts_null(z); cur[t0 + lane] = z; nxt[t0 + lane] = z; }
+                  __threadfence_block();
+                  continue;
+               }
+               // StepInst2 (HRec.c:1360); lane 0 makes the exit set, then every lane reads it
+               if (lane == 0) {
+                  if (kind == HTKAMD_NODE_WORD) {
+                     const int pid = vs->nPath;
+                     if ((size_t)pid >= pathCap) vs->status = -4;
+                     else {
+                        TSet e = ex[n];
+                        const TSet st = cur[t0];
+                        const float r0 = e.rl[0], m0 = e.rlm[0];
+                        word_exit_ord(a, ud, n, t, st, e, pid, pathNode, pathFrame);
+                        e.rl[0] = r0; e.rlm[0] = m0;
+                        vs->nPath = pid + 1;
+                        ex[n] = e;
+                     }
+                  } else if (kind == HTKAMD_NODE_NULL) ex[n] = cur[t0];
+                  else if ((ni.x >> 12) & 1) {              // tee model: StepHMM2 (HRec.c:790)
+                     const TSet st = cur[t0];
+                     TSet e = ex[n];
+                     ts_merge(e, st.like + tpBase[ni.z + (NS - 1)], st.lm, st.path, st, nT, a.nToks, ko);
+                     ex[n] = e;
+                  }
+               }
+               __threadfence_block();
+               if (vs->status != 0) break;
+               const TSet e = ex[n];
+               double tkLike = e.like; float tkLm = e.lm;
+               if (kind != HTKAMD_NODE_HMM && tkLike < wT) tkLike = LZERO;
+               if (tkLike > gT) {
+                  const int k0 = N.linkOff[n], k1 = N.linkOff[n + 1];
+                  const bool dup = N.dupDest[n] != 0;
+                  for (int kb = k0; kb < k1; kb += 64) {
+                     const int k = kb + lane;
+                     const bool act = k < k1;
+                     const int d = act ? N.linkDest[k] : 0;
+                     const float lm = act ? N.linkLike[k] : 0.0f;
+                     const double xl = tkLike + lm * a.lmScale;
+                     const bool pass = act && xl > gT;
+                     unsigned long long need = __ballot(pass && pos[d] < 0);
+                     while (need) {
+                        const int j = __ffsll((long long)need) - 1;
+                        need &= need - 1;
+                        const int dj = __shfl(d, j);
+                        if (lane == 0 && pos[dj] < 0) o_attach(c, dj);
+                        __threadfence_block();
+                     }
+                     if (vs->status != 0) break;
+                     unsigned long long todo = __ballot(pass);
+                     if (!dup) todo = pass ? (1ull << lane) : 0ull;
+                     while (todo) {
+                        const int j = dup ? __ffsll((long long)todo) - 1 : lane;
+                        todo = dup ? (todo & (todo - 1)) : 0ull;
+                        if (lane == j) {                      // SetEntryState (HRec.c:1303): TokSetMerge into the destination's entry set
+                           const int td = N.nodeInfo[d].y;
+                           TSet x = e;
+                           for (int q = 0; q < x.n; q++) x.rlm[q] = e.rlm[q] + lm;
+                           TSet res = cur[td];
+                           ts_merge(res, xl, tkLm + lm, e.path, x, nT, a.nToks, ko);
+                           cur[td] = res;
+                           const double m0 = imax[d];
+                           if (res.like > m0) {
+                              const float nm = (float)res.like;
+                              imax[d] = (double)nm;
+                              const int pd = pos[d];
+                              if (pd >= vs->base && pd < vs->base + vs->cn) vs->chunkMax[pd - vs->base] = nm;
+                           }
+                        }
+                        if (dup) __threadfence_block();
+                     }
+                     __threadfence_block();
+                  }
                }
             }
-            latN[0] = nn; latN[1] = ln;
+            idx += cn;
          }
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (sh.status != 0) break;
+   }
+   if (tid == 0) {
+      if (sh.status != 0) { a.total[u] = LZERO; a.latN[2 * u] = sh.status == -4 ? -3 : sh.status; a.latN[2 * u + 1] = 0; }
+      else {
+         TSet fin; ts_null(fin);
+         if (pos[N.final] >= 0) fin = ex[N.final];
+         build_lattice(a, ud, u, fin, PathView{pathFrame, pathNode, N.nWordNodes, N.wordNode});
       }
    }
 }
@@ -453,12 +793,21 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
    const DecNet &N = d->net;
    const int ns = (int)d->usedStates.size();
    const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
+   // the list kernel (k_decode_ord_n) unless the static order was asked for: in N-best mode the order of the merges is in every
+   // alternative's likelihood, so "exact" is the default here, not a fallback
+   int orderMode = d->orderMode;
+   if (const char *ev = getenv("HTKAMD_DECODE_ORDER")) orderMode = !strcmp(ev, "fast") ? HTKAMD_ORDER_FAST : !strcmp(ev, "exact") ? HTKAMD_ORDER_EXACT : HTKAMD_ORDER_AUTO;
+   const bool listOrder = orderMode != HTKAMD_ORDER_FAST;
+   const size_t pathMul = listOrder ? 3 : 1, pathExtra = listOrder ? 64 : 0;       // StepWord2 "may be repeated" (HRec.c:1046)
+   const int seqCap = 8 * N.nNodes + 1024;
+   d->lastTied = 0;
    int u0 = 0;
    while (u0 < nUtt) {
       size_t bytes = 0; int u1 = u0;
       while (u1 < nUtt) {
          const size_t T = (size_t)(frameOff[u1 + 1] - frameOff[u1]);
-         const size_t b = (size_t)ns * T * 4 + (size_t)N.nTok * 2 * sizeof(TSet) + (size_t)N.nNodes * (sizeof(TSet) + 8) + (T + 1) * (size_t)N.nWordNodes * (24 + 16 * (NT - 1));
+         const size_t b = (size_t)ns * T * 4 + (size_t)N.nTok * 2 * sizeof(TSet) + (size_t)N.nNodes * (sizeof(TSet) + 8) + (pathMul * (T + 1) * (size_t)N.nWordNodes + pathExtra) * (24 + 16 * (NT - 1) + 8) +
+                          (listOrder ? (size_t)seqCap * 8 : 0);
          if (u1 > u0 && bytes + b > ((size_t)24 << 30)) break;
          bytes += b; u1++;
       }
@@ -478,7 +827,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
                tk.outBase = ud.score0 + (size_t)ti * FR;
                tasks.push_back(tk);
             }
-         score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += (size_t)(ud.T + 1) * N.nWordNodes;
+         score += (size_t)ns * ud.T; tok += (size_t)N.nTok; node += (size_t)N.nNodes; path += pathMul * ((size_t)(ud.T + 1) * N.nWordNodes) + pathExtra;
       }
       int rc = HTKAMD_OK, wsi = 0;
       auto A = [&](size_t n) -> void * {                 // the decoder's own buffers, kept between calls and grown as batches ask (decode.hip)
@@ -499,13 +848,17 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
       a.tokA = (TSet *)A(tok * sizeof(TSet)); a.tokB = (TSet *)A(tok * sizeof(TSet)); a.ex = (TSet *)A(node * sizeof(TSet)); a.imax = (double *)A(node * 8);
       a.pathPrev = (int *)A(path * 4); a.pathLike = (double *)A(path * 8); a.pathLm = (float *)A(path * 4);
       a.altN = (int *)A(path * 4); a.altPrev = (int *)A(path * 4 * (NT - 1)); a.altLike = (double *)A(path * 8 * (NT - 1)); a.altLm = (float *)A(path * 4 * (NT - 1));
-      a.mark = (int *)A(path * 4); a.stack = (int *)A(sizeof(int) * (size_t)nu * 2 * maxLatNodes);
+      a.mark = (int *)A(path * 4); a.stack = (int *)A(sizeof(int) * (size_t)nu * 2 * maxLatNodes); a.nodePath = (int *)A(sizeof(int) * (size_t)nu * maxLatNodes);
       void *dUtt = A(sizeof(DecUtt) * nu), *dTasks = A(sizeof(ScoreTask) * tasks.size() + sizeof(int));
       a.latN = (int *)A(sizeof(int) * 2 * nu);
       a.nodeFrame = (int *)A(sizeof(int) * (size_t)nu * maxLatNodes); a.nodeNet = (int *)A(sizeof(int) * (size_t)nu * maxLatNodes); a.nodeLike = (double *)A(8 * (size_t)nu * maxLatNodes);
       a.arcStart = (int *)A(sizeof(int) * (size_t)nu * maxLatArcs); a.arcEnd = (int *)A(sizeof(int) * (size_t)nu * maxLatArcs);
       a.arcAc = (float *)A(4 * (size_t)nu * maxLatArcs); a.arcLm = (float *)A(4 * (size_t)nu * maxLatArcs); a.arcPr = (float *)A(4 * (size_t)nu * maxLatArcs);
       a.arcScore = (double *)A(8 * (size_t)nu * maxLatArcs); a.total = (double *)A(8 * (size_t)nu);
+      if (listOrder) {
+         a.seq = (int *)A(sizeof(int) * (size_t)nu * 2 * seqCap); a.seqCap = seqCap; a.pos = (int *)A(sizeof(int) * node); a.ooo = (unsigned char *)A(node);
+         a.pathNode = (int *)A(path * 4); a.pathFrame = (int *)A(path * 4); a.pathExtra = (int)pathExtra;
+      }
       if (!rc) {
          hipError_t e;
          if ((e = hipMemcpyAsync(dUtt, utt.data(), sizeof(DecUtt) * nu, hipMemcpyHostToDevice, s)) != hipSuccess ||
@@ -531,8 +884,12 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.nBeam = nBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
          a.nToks = nToks; a.maxActive = cfg->maxActive > 0 ? cfg->maxActive : 0; a.maxLatNodes = maxLatNodes; a.maxLatArcs = maxLatArcs;
          const size_t lds = sizeof(TSet) * DEC_THREADS;
-         hipError_t e = hipFuncSetAttribute((const void *)k_decode_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-         if (e == hipSuccess) { hipLaunchKernelGGL(k_decode_n, dim3(nu), dim3(DEC_THREADS), lds, s, a); e = hipGetLastError(); }
+         hipError_t e = hipSuccess;
+         if (listOrder) { hipLaunchKernelGGL(k_decode_ord_n, dim3(nu), dim3(ORD_THREADS), 0, s, a); e = hipGetLastError(); d->lastTied += nu; }
+         else {
+            e = hipFuncSetAttribute((const void *)k_decode_n, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) { hipLaunchKernelGGL(k_decode_n, dim3(nu), dim3(DEC_THREADS), lds, s, a); e = hipGetLastError(); }
+         }
          if (e != hipSuccess) { htkamd_set_error("decoder_run_lattice: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       }
       std::vector<int> hN(2 * nu), hNF, hNN, hAS, hAE; std::vector<double> hNL, hSc, hT(nu); std::vector<float> hAc, hLm, hPr;
