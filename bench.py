@@ -229,8 +229,11 @@ def main():
                     help="weak: --utts utterances on every GPU (the contract's default); strong: --total-utts utterances split over the GPUs")
     ap.add_argument("--total-utts", type=int, default=10000, help="--scaling strong: utterances of the whole job (BASELINE config[2]: 10k)")
     ap.add_argument("--ragged", type=int, default=0, help="1: utterance lengths uniform in [frames/2, frames] (a look at mixed batches; the headline run uses 0)")
-    ap.add_argument("--score", choices=["exact", "mfma", "fast", "bf16", "fastest"], default="fastest",
-                    help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; bf16 = bf16 x 3 matrix-core scores + that LAdd; fastest = fp16 x 2 matrix-core scores + that LAdd")
+    ap.add_argument("--score", choices=["exact", "mfma", "fast", "bf16", "fastest"], default="bf16",
+                    help="arithmetic: exact = bit-identical to the reference; mfma = fp32 matrix-core scores; fast = mfma + fp32-transcendental LAdd in the recursions; "
+                         "bf16 (default: every asserted parity figure at half the 1e-4 bar or better) = bf16 x 3 matrix-core scores + that LAdd; "
+                         "fastest = fp16 x 2 matrix-core scores + that LAdd (the parity figures reach 0.6 - 1.0 of the bar depending on the sample)")
+    ap.add_argument("--also-fastest", type=int, default=1, help="1: after the measurement (N = 1, --score bf16) the same timed iterations once more with the fp16 x 2 scores, reported as `fastest_mode` beside the line, never as `value`")
     ap.add_argument("--two-streams", type=int, default=1, help="run the chunks of an iteration on two alternating streams (1) or on one stream (0)")
     ap.add_argument("--chunks", type=int, default=1, help="sub-batches an iteration's shard is cut into (alternating over two streams, one accumulator vector)")
     ap.add_argument("--min-var", type=float, default=0.01, help="HERest -v: variance floor of the update (the shard has ~8 frames per Gaussian)")
@@ -544,13 +547,36 @@ def main():
         lat.append(time.perf_counter() - tl)
     ktimes_solo = np.array(fb1.kernel_times5())
     torch.cuda.synchronize()
+    # the same timed iterations once more on the fp16 x 2 scores (from the initial model again): reported beside the line, never `value`
+    fastest_side = None
+    if args.also_fastest and world == 1 and args.score == "bf16":
+        keep_mode = cfg.scoreMode
+        try:
+            model.set_params(mean=pk["mean"], var=pk["var"], compWeight=pk["compWeight"], transP=pk["transP"])
+            for ch in chunks:
+                ch["ready"] = [False, False]
+            cfg.scoreMode = 34
+            range_hit[0] = False
+            dt_f, kt_f, _ = measure()
+            kt_f = kt_f / max(args.steps, 1)
+            if not range_hit[0]:
+                fastest_side = {"score_mode": "fastest (fp16 x 2 split operands, k_score_f16w)", "ms_per_step": dt_f / args.steps * 1e3,
+                                "value": float(units_local) * args.steps / dt_f, "kernel_ms_score": float(kt_f[0]) * 1e3,
+                                "note": "parity of this mode: tests/test_gpu_headline_parity.py -- accumulator deviations 0.6 - 1.0 of the 1e-4 bar depending on the sample, "
+                                        "against <= 0.5 for the bf16 x 3 scores the line is measured with"}
+            else:
+                fastest_side = {"score_mode": "fastest", "error": "the fp16 range check tripped (HTKAMD_ERANGE)"}
+        except capi.HtkAmdError as e:
+            fastest_side = {"score_mode": "fastest", "error": str(e)[:200]}
+        cfg.scoreMode = keep_mode
+        torch.cuda.synchronize()
     units_total = float(a["nEval"]) if world > 1 else float(units_local)
     utts_total = float(a["nUttDone"])
     value = units_total * args.steps / dt
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
-        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16<3>", "fastest": "k_score_f16w<3>"}.get(args.score, "k_score_mfma<20>")
+        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16w<3>", "fastest": "k_score_f16w<3>"}.get(args.score, "k_score_mfma<20>")
         # HBM-side bytes per launch of every kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/prof_r03.sh),
         # same workload only
         traffic_of = {}
@@ -590,7 +616,7 @@ def main():
             exe = units_local * args.mix * kpad * 2 * nprod / k1 / 1e12 if k1 > 0 else 0.0
             sc.update({"achieved": exe, "peak": F16_PEAK_TFLOPS, "frac": exe / F16_PEAK_TFLOPS, "flop_per_unit": args.mix * kpad * 2 * nprod,
                        "pipe": "v_mfma_f32_32x32x16_f16, operands split in two fp16 pieces, fp32 accumulate" if args.score == "fastest"
-                               else "v_mfma_f32_16x16x32_bf16, operands split in three bf16 pieces, fp32 accumulate"})
+                               else "v_mfma_f32_32x32x16_bf16, operands split in three bf16 pieces, fp32 accumulate"})
         elif args.score == "exact":
             sc["pipe"] = "packed fp32 VALU (the reference's four roundings per dimension, no FMA)"
         else:
@@ -636,6 +662,8 @@ def main():
             "roofline": dict(per_kernel[dom], units_per_launch=units_local / NCH, launches_per_step=NCH),
             "roofline_kernels": per_kernel,
         }
+        if fastest_side is not None:
+            out["fastest_mode"] = fastest_side
         if ktimes_solo[0] > 0:
             out["kernel_ms_isolated"] = {"score": ktimes_solo[0] * 1e3, "beta": ktimes_solo[1] * 1e3, "alpha": ktimes_solo[2] * 1e3, "stats": ktimes_solo[3] * 1e3, "mix_stats": ktimes_solo[4] * 1e3}
         if args.cpu_seconds > 0 and world == 1:               # the CPU leg runs at N = 1 only

@@ -254,6 +254,204 @@ __global__ __launch_bounds__(64 * B16_WPB, B16_COL_TILES > 2 ? 2 : 3) void k_sco
    }
 }
 
+// ------------------------------------------------------------------------------------ the 32 x 32 form (round 4)
+// K1bw `k_score_bf16w`: K1h's shape (gmm_f16.hip, k_score_f16w) under K1b's arithmetic.  Sets whose states all have <= 16 components
+// (one tile per state: the headline set).  v_mfma_f32_32x32x16_bf16 on PAIRS of states -- the components of state A on the accumulator
+// rows whose bit 2 is clear, those of state B on the others -- so that a lane ends with all 16 components of ONE state for ITS frame:
+// the mixture's log-sum-exp is a tree inside the lane (no row swaps), cut into slices that issue behind the next pair's matrix
+// instructions; the task's 128 feature rows come through LDS as one contiguous block.  Three bf16 pieces per operand, six products:
+//     Cx += a1 z1                                      (16-bit products: the matrix unit adds them without dropping a bit)
+//     Cc += a2 z2 + a1 z3 + a3 z1 + a1 z2 + a2 z1      (everything below 2^-8 of the leading term: an accumulator that stays small)
+//     y   = (Cx + Cc) + (log w - 0.5 gConst) log2(e)   (by the vector unit, last)
+// with K1b's complete squares per K chunk.  36 matrix instructions of 32 cycles per pair against K1h's 18: twice the matrix time under
+// the same vector, LDS and staging work -- which therefore hides better (K1b, the 16 x 16 form: 1.22 ms; this: see DESIGN.md §4).
+//   Table per tile: [k-step 2 NC][piece 3][k-half 2][component 16][8 bf16], then (log w - 0.5 gConst) log2(e) [16 f32].  In LDS a pair
+//   is [k-step][piece][lane 64][8 bf16] with lane = 32 k-half + 8 (comp >> 2) + 4 h + (comp & 3), then the two states' constants.
+typedef float f16v __attribute__((ext_vector_type(16)));
+#ifndef B16W_EU
+#define B16W_EU 2
+#endif
+template <int NC>
+__global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
+{
+   static_assert(B16_TASK_FRAMES == 128, "four wavefronts x 32 frames");
+   constexpr int KS = 2 * NC;                          // k-steps of 16
+   constexpr int TW4 = KS * 3 * 32 + 4;                // 16-byte words per tile in the table
+   constexpr int PW4 = KS * 3 * 64 + 8;                // ... per pair in LDS
+   constexpr int PT = (TW4 + 127) / 128;               // words staged per thread (a half workgroup per tile)
+   __shared__ u4 wbuf[2][PW4];
+   __shared__ float xbuf[128 * 15 * NC];               // the task's 128 feature rows (D <= 15 NC), as they lie in memory
+   __shared__ int taskSh;
+   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+   const int fcol = lane & 31, kh = lane >> 5;
+   const int D = a.D;
+   const int dpc = (D + NC - 1) / NC;                  // dimensions per K chunk (<= 15)
+   const u4 *tab = (const u4 *)a.bf16Tab;
+   // staging: wavefronts 0, 1 bring the first state's tile, 2, 3 the second's; word w of a tile goes to the lane that multiplies it
+   const int hsel = __builtin_amdgcn_readfirstlane(wv >> 1), t7 = tid & 127;
+   int dst[PT];
+#pragma unroll
+   for (int j = 0; j < PT; j++) {
+      const int w = t7 + 128 * j;
+      const int comp = w & 15;
+      dst[j] = (w < KS * 96) ? (w >> 5) * 64 + ((w >> 4) & 1) * 32 + 8 * (comp >> 2) + 4 * hsel + (comp & 3) : KS * 192 + hsel * 4 + (w - KS * 96);
+   }
+   const int fw = 32 * wv;                             // this wave's first frame in the task's tile
+
+   for (;;) {
+      if (tid == 0) taskSh = atomicAdd(a.taskCounter, 1);
+      __syncthreads();
+      const int task = __builtin_amdgcn_readfirstlane(taskSh);
+      if (task >= a.nTasks) break;
+      const ScoreTask tk = a.tasks[task];
+      const bool active = fw < tk.nFrames;
+      const int nPairs = (tk.nSlots + 1) >> 1;
+      {
+         const float *xs = a.X + (size_t)tk.frame0 * D;
+         for (int i = tid; i < tk.nFrames * D; i += 256) xbuf[i] = xs[i];
+      }
+      int tileV = 0;
+      if (lane < tk.nSlots) tileV = a.slotState[tk.slot0 + lane];
+      auto pair_tile = [&](int j) { const int k = 2 * j + hsel; return __builtin_amdgcn_readlane(tileV, (k < tk.nSlots ? k : tk.nSlots - 1) & 63); };
+      {
+         const u4 *W = tab + (size_t)pair_tile(0) * TW4;
+#pragma unroll
+         for (int j = 0; j < PT; j++)
+            if (t7 + 128 * j < TW4) wbuf[0][dst[j]] = W[t7 + 128 * j];
+      }
+      __syncthreads();
+
+      // B operand from the rows in LDS: this lane's frame, the 8 k of its k-half in every k-step, in three bf16 pieces
+      bf8 zb[KS][3];
+      if (active) {
+         int khL = kh, f = fw + fcol;
+         asm volatile("" : "+v"(khL), "+v"(f));         // (cheap to recompute per task: hoisted out of the task loop they are spilled)
+         if (f > tk.nFrames - 1) f = tk.nFrames - 1;
+         const float *row = xbuf + f * D;
+#pragma unroll
+         for (int ks = 0; ks < KS; ks++) {
+            const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * khL;      // chunk; first of this lane's four dimensions within it
+            unsigned short p[3][8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+               int dim = dpc * c + i0 + i;
+               const bool pad = i0 + i >= dpc || dim >= D;
+               if (pad) dim = D - 1;
+               float v = row[dim];
+               if (pad) v = 0.0f;
+               float v2 = v * v;
+               if ((ks & 1) && khL == 1 && i == 3) v2 = 1.0f;      // k = 30 of the chunk: the constant that meets -0.5 sum mu^2 ivar
+               split3(v2, p[0][2 * i], p[1][2 * i], p[2][2 * i]);
+               split3(v, p[0][2 * i + 1], p[1][2 * i + 1], p[2][2 * i + 1]);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+               u4 w;
+               w[0] = p[s][0] | ((unsigned int)p[s][1] << 16); w[1] = p[s][2] | ((unsigned int)p[s][3] << 16);
+               w[2] = p[s][4] | ((unsigned int)p[s][5] << 16); w[3] = p[s][6] | ((unsigned int)p[s][7] << 16);
+               zb[ks][s] = __builtin_bit_cast(bf8, w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      }
+
+      int buf = 0;
+      float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + kh) * tk.ldo + fw + fcol;      // this lane's state (kh of the pair) and frame
+      const size_t oStep = 2 * (size_t)tk.ldo;
+      float yP[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) yP[r] = 0.0f;
+      for (int j = 0; j < nPairs; j++) {
+         u4 stg[PT];
+         const bool more = j + 1 < nPairs;
+         if (more) {
+            const u4 *W = tab + (size_t)pair_tile(j + 1) * TW4;
+#pragma unroll
+            for (int q = 0; q < PT; q++)
+               if (t7 + 128 * q < TW4) stg[q] = W[t7 + 128 * q];
+         }
+         if (active) {
+            // the log-sum-exp of the pair BEFORE this one (left in yP) in 18 slices, one behind every second matrix instruction of this pair
+            float m8[8], m4[4], m2[2], mx = 0.0f, e[16], sm = 0.0f, lg = 0.0f, resP = 0.0f;
+            auto lse_slice = [&](int sl) {
+               if (sl < 2) { for (int r = 4 * sl; r < 4 * sl + 4; r++) m8[r] = fmaxf(yP[r], yP[r + 8]); }
+               else if (sl == 2) { for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]); }
+               else if (sl == 3) { m2[0] = fmaxf(m4[0], m4[1]); m2[1] = fmaxf(m4[2], m4[3]); mx = fmaxf(m2[0], m2[1]); }
+               else if (sl < 12) { for (int r = 2 * (sl - 4); r < 2 * (sl - 4) + 2; r++) e[r] = EXP2(yP[r] - mx); }
+               else if (sl < 14) { for (int r = 4 * (sl - 12); r < 4 * (sl - 12) + 4; r++) e[r] += e[r + 8]; }
+               else if (sl == 14) { for (int r = 0; r < 4; r++) e[r] += e[r + 4]; }
+               else if (sl == 15) { sm = (e[0] + e[1]) + (e[2] + e[3]); }
+               else if (sl == 16) { lg = LOG2(sm); }
+               else { resP = (mx + lg) * 0.69314718055994531f; }
+            };
+            f16v Cx, Cc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }
+            bf8 wa[KS][3];
+#pragma unroll
+            for (int s = 0; s < 3; s++) wa[0][s] = __builtin_bit_cast(bf8, wbuf[buf][(0 * 3 + s) * 64 + lane]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+               if (ks + 1 < KS) {
+#pragma unroll
+                  for (int s = 0; s < 3; s++) wa[ks + 1][s] = __builtin_bit_cast(bf8, wbuf[buf][((ks + 1) * 3 + s) * 64 + lane]);
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][1], Cc, 0, 0, 0);
+               if (3 * ks + 0 < 18) lse_slice(3 * ks + 0);
+               __builtin_amdgcn_sched_barrier(0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][2], Cc, 0, 0, 0);
+               __builtin_amdgcn_sched_barrier(0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][2], zb[ks][0], Cc, 0, 0, 0);
+               if (3 * ks + 1 < 18) lse_slice(3 * ks + 1);
+               __builtin_amdgcn_sched_barrier(0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
+               __builtin_amdgcn_sched_barrier(0);
+               Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
+               if (3 * ks + 2 < 18) lse_slice(3 * ks + 2);
+               __builtin_amdgcn_sched_barrier(0);
+               Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
+               __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
+            asm volatile("" : "+v"(resP));
+            if (j > 0 && fw + fcol < tk.nFrames) *o = resP;      // (the pair before always has both its states)
+            if (j > 0) o += oStep;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
+#pragma unroll
+               for (int r = 0; r < 4; r++) yP[4 * b + r] = (Cx[4 * b + r] + Cc[4 * b + r]) + ci[r];
+            }
+         }
+         if (more) {
+#pragma unroll
+            for (int q = 0; q < PT; q++)
+               if (t7 + 128 * q < TW4) wbuf[buf ^ 1][dst[q]] = stg[q];
+         }
+         __syncthreads();
+         buf ^= 1;
+      }
+      if (active) {                                    // the last pair's log-sum-exp
+         float m8[8], m4[4];
+#pragma unroll
+         for (int r = 0; r < 8; r++) m8[r] = fmaxf(yP[r], yP[r + 8]);
+#pragma unroll
+         for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]);
+         const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+         float e[16];
+#pragma unroll
+         for (int r = 0; r < 16; r++) e[r] = EXP2(yP[r] - mx);
+#pragma unroll
+         for (int r = 0; r < 8; r++) e[r] += e[r + 8];
+#pragma unroll
+         for (int r = 0; r < 4; r++) e[r] += e[r + 4];
+         const float sm = (e[0] + e[1]) + (e[2] + e[3]);
+         if (fw + fcol < tk.nFrames && 2 * (nPairs - 1) + kh < tk.nSlots) *o = (mx + LOG2(sm)) * 0.69314718055994531f;
+      }
+   }
+}
+
 int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
 {
    if (a.nTasks <= 0) return HTKAMD_OK;
@@ -264,6 +462,19 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
    }
    ((htkamd_model *)m)->fastUse |= HTKAMD_SCORE_BF16;
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
+   if (m->f16Wide) {                                 // every state in one tile: 32 x 32 blocks, states in pairs (the table is in that layout)
+      int blocks = a.nTasks;
+      if (blocks > 256 * B16W_EU) blocks = 256 * B16W_EU;
+      dim3 grid(blocks), block(256);
+      switch (m->bf16NC) {
+      case 3: hipExtLaunchKernelGGL((k_score_bf16w<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      case 2: hipExtLaunchKernelGGL((k_score_bf16w<2>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      case 1: hipExtLaunchKernelGGL((k_score_bf16w<1>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      default: htkamd_set_error("score_bf16: no kernel for %d K-chunks", m->bf16NC); return HTKAMD_EMODEL;
+      }
+      HIPCHECK(hipGetLastError());
+      return HTKAMD_OK;
+   }
    const int parts = B16_TASK_FRAMES / (16 * B16_COL_TILES * B16_WPB);
    int blocks = a.nTasks * parts;
    if (blocks > 256 * ((B16_COL_TILES > 2 ? 8 : 12) / B16_WPB)) blocks = 256 * ((B16_COL_TILES > 2 ? 8 : 12) / B16_WPB);      // persistent blocks, one task (128 frames x up to 64 states) or half-task at a time
@@ -288,6 +499,7 @@ struct Bf16TabArgs {
 
 // one thread per (tile, chunk, lane): its 8 coefficients in three pieces = three 16-byte stores, consecutive lanes to consecutive
 // words; the 16 threads (chunk 0, lane group 0) of a tile also write their component's accumulator start
+template <bool WIDE>
 __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
 {
    const int NC = a.NC, D = a.D;
@@ -296,7 +508,8 @@ __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
    const int t = idx / (NC * 64), r = idx - t * (NC * 64), ch = r >> 6, lane = r & 63, rowc = lane & 15, kg = lane >> 4;
    const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
    const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
-   const size_t tileShorts = (size_t)3 * NC * 64 * 8 + 64 * 8;      // the f32 part counted in shorts
+   // WIDE: [k-step 2 NC][piece 3][k-half 2][component 16][8 bf16] then 16 f32; else [piece 3][chunk NC][lane 64][8 bf16] then [lane 64][4 f32]
+   const size_t tileShorts = WIDE ? ((size_t)NC * 2 * 3 * 32 + 4) * 8 : (size_t)3 * NC * 64 * 8 + 64 * 8;      // the f32 part counted in shorts
    unsigned short *T = a.tab + (size_t)t * tileShorts;
    const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
    const double L2E = 1.4426950408889634;
@@ -321,7 +534,9 @@ __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
       u4 w;
       w[0] = p[pc][0] | ((unsigned int)p[pc][1] << 16); w[1] = p[pc][2] | ((unsigned int)p[pc][3] << 16);
       w[2] = p[pc][4] | ((unsigned int)p[pc][5] << 16); w[3] = p[pc][6] | ((unsigned int)p[pc][7] << 16);
-      *(u4 *)(T + ((size_t)(pc * NC + ch) * 64 + lane) * 8) = w;
+      // k = 32 ch + 8 kg + j: WIDE k-step 2 ch + (kg >> 1), k-half kg & 1
+      const size_t word = WIDE ? (size_t)((2 * ch + (kg >> 1)) * 3 + pc) * 32 + (kg & 1) * 16 + rowc : (size_t)(pc * NC + ch) * 64 + lane;
+      *(u4 *)(T + word * 8) = w;
    }
    if (ch == 0 && kg == 0) {
       float ci = -1.0e30f;
@@ -329,8 +544,11 @@ __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
          const double k0 = a.gconst[a.compGauss[c]];
          ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
       }
-      float *ciBase = (float *)(T + (size_t)3 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
-      for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
+      if (WIDE) ((float *)(T + (size_t)NC * 2 * 3 * 32 * 8))[rowc] = ci;
+      else {
+         float *ciBase = (float *)(T + (size_t)3 * NC * 64 * 8);       // [lane][4]: row 4(l>>4)+r lives in lanes with l>>4 == row/4, register row%4
+         for (int j = 0; j < 16; j++) ciBase[((rowc >> 2) * 16 + j) * 4 + (rowc & 3)] = ci;
+      }
    }
 }
 
@@ -342,7 +560,8 @@ int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
    t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss; t.tileState = m->d_tileState;
    t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_bf16Tab;
    const int n = m->nTiles * m->bf16NC * 64;
-   hipLaunchKernelGGL(k_build_bf16tab, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   if (m->f16Wide) hipLaunchKernelGGL(k_build_bf16tab<true>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   else hipLaunchKernelGGL(k_build_bf16tab<false>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    HIPCHECK(hipGetLastError());
    m->bf16Stale = 0;
    return HTKAMD_OK;
