@@ -571,12 +571,19 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
             if (valid) {
                xpv[k] = ALPHA_S(t);
                if (s.first) aEv[k] = ALPHA_E(t, q);
-               if (t < T && nbValid) bnv[k] = a.betaW[ud.betaW0 + (size_t)t * L + gl + 1];
+               // beta_{j+1}(t+1): the lane next door's own bv[k + 1] -- taken from it below (a lane shift); only a wavefront's last lane,
+               // whose neighbour sits in the next wavefront, reads it from memory (round 3: every lane did -- the column was read twice)
+               if (lane == 63 && t < T && nbValid) bnv[k] = a.betaW[ud.betaW0 + (size_t)t * L + gl + 1];
             }
          }
       }
 #pragma unroll
       for (int k = 0; k < 5; k++) { const int t = tb + k; bv[k] = (valid && t <= T && t <= t1 + 1) ? BETA_S(t) : LZERO; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+         const double nb = __shfl_down(bv[k + 1], 1);      // (an invalid or out-of-range neighbour holds LZERO there, as the load gave)
+         if (lane != 63) bnv[k] = (tb + k <= t1) ? nb : LZERO;
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
       const int t = tb + k;

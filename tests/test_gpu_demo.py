@@ -252,11 +252,13 @@ def test_hinit_mixture_training(native, oracle, name):
     assert np.allclose(lin(p["transP"][q0["transOff"][t]:q0["transOff"][t] + N * N]), lin(rq["transP"][rq["transOff"][rt]:rq["transOff"][rt] + N * N]), rtol=1e-4, atol=1e-7)
 
 
+CHAIN_BAR = 1e-4
+
+
 def test_htkdemo_training_chain_from_prototypes(native, oracle, tmp_path):
     """The whole training side of HTKDemo's monPlainM1S1 on the device, each stage fed by the previous one's OUTPUT FILES:
     prototypes -> HInit (Viterbi training per model) -> HRest (Baum-Welch per model) -> one embedded HERest pass; the result
-    against the models the reference's own chain wrote (hmm2_expected).  The stages' own parity is tested above at 1e-4; the
-    chain's differences add up, so the bar here is 1e-3."""
+    against the models the reference's own chain wrote (hmm2_expected), at north_star's 1e-4 like every stage on its own above."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
     from examples.hinit_model import hinit
@@ -298,13 +300,16 @@ def test_htkdemo_training_chain_from_prototypes(native, oracle, tmp_path):
     model.update(acc, a["vec"], minEgs=3, minVar=0.05, mixWeightFloor=3 * 1.0e-5)
     rmmf = native.Mmf(hmm_list=os.path.join(DEMO, "bcplist"), hmm_dir=os.path.join(DEMO, "hmm2_expected"))
     rq, pk, p = rmmf.packed(), mmf.packed(), model.get_params()
+    worst_m = worst_v = 0.0
     for name in "SCVNL":
         h, rh = mmf.logical[name], rmmf.logical[name]
         for s, rs in zip(pk["hmmState"][pk["hmmStateOff"][h]:pk["hmmStateOff"][h + 1]], rq["hmmState"][rq["hmmStateOff"][rh]:rq["hmmStateOff"][rh + 1]]):
             g, rg = int(pk["compGauss"][pk["stateCompOff"][s]]), int(rq["compGauss"][rq["stateCompOff"][rs]])
             sigma = np.sqrt(rq["var"][rg])
-            assert (np.abs(p["mean"][g] - rq["mean"][rg]) <= 1e-3 * np.maximum(np.abs(rq["mean"][rg]), sigma) + 1e-5).all(), name
-            assert np.allclose(p["var"][g], rq["var"][rg], rtol=2e-3, atol=1e-6), name
+            worst_m = max(worst_m, float(np.max(np.abs(p["mean"][g] - rq["mean"][rg]) / np.maximum(np.abs(rq["mean"][rg]), sigma))))
+            worst_v = max(worst_v, float(np.max(np.abs(p["var"][g] - rq["var"][rg]) / rq["var"][rg])))
+    print("chain: worst mean deviation %.3g (of max(|mean|, sigma)), worst variance deviation %.3g" % (worst_m, worst_v))
+    assert worst_m <= CHAIN_BAR and worst_v <= CHAIN_BAR, (worst_m, worst_v)
 
 
 def test_htkdemo_recognition_matches_reference_label_files(native):
