@@ -547,6 +547,7 @@ def main():
         lat.append(time.perf_counter() - tl)
     ktimes_solo = np.array(fb1.kernel_times5())
     torch.cuda.synchronize()
+    p_dump = model.get_params() if (args.dump_model and rank == 0) else None      # the model of the MEASURED iterations (the side run below moves it)
     # the same timed iterations once more on the fp16 x 2 scores (from the initial model again): reported beside the line, never `value`
     fastest_side = None
     if args.also_fastest and world == 1 and args.score == "bf16":
@@ -741,7 +742,7 @@ def main():
                 out["other_paths"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
     if args.dump_model and rank == 0:
-        p_ = model.get_params()
+        p_ = p_dump
         np.savez(args.dump_model, mean=p_["mean"], var=p_["var"], compWeight=p_["compWeight"], transP=p_["transP"], totalPr=a["totalPr"], nUttDone=a["nUttDone"])
     if world > 1:
         dist.destroy_process_group()
