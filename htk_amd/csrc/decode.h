@@ -24,6 +24,7 @@ struct DecNet {
    const int *wordNode;                // [nWordNodes] inverse of wordIdx
    const int *levelOff, *levelNodes;   // zero-time nodes by level: narrow ones first, then wide ones
    const int *levelWide;               // [nLevels] index in levelNodes where the wide nodes of the level start
+   const int *levelOffAll, *levelNodesAll, *levelWideAll;   // the same with the nodes k_decode<NPT > 0> steps from registers (regFused) left in
    const float *transP;
    const int *hmmState;
    const int *stateSlot;               // [S] row of the tied state in the score block, -1 if unused
@@ -33,7 +34,15 @@ struct DecNet {
    const float *linkLike;
    const int *nTr0;                    // [nNodes] number of leading links whose destination is a zero-time node (word end, null node, tee model)
    const unsigned char *dupDest;       // [nNodes] two links of the node share a destination
+   // k_decode<NPT > 0>: hmmNodes[0 .. nReg) are plain models of at most three emitting states whose tokens live in registers
+   int nReg;
+   const int *regFused;                // [nReg] the word / null node whose only predecessor is this model (stepped by its owner), or -1
+   const float *regFusedLike;          // [nReg] LM log probability of that link
+   const unsigned char *regNoEx;       // [nReg] nobody pulls this model's exit token from memory
+   const int4 *regRecA, *regRecB; const float2 *regRecF;      // [nReg] the same and the model's constants packed: {node, kind | N << 4, transP offset, fused node}, {score slots of states 2..4, regNoEx}, {wdlk, fused link's LM}
 };
+#define DEC_REG_THREADS 512
+#define DEC_REG_MAXNPT 12
 
 struct DecUtt {
    int T, frame0, status, idx;         // idx: the utterance's number in the batch (its slot in the per-utterance outputs)
@@ -49,7 +58,7 @@ struct __attribute__((aligned(16))) Tok { double like; float lm; int path; };   
 struct DecArgs {
    DecNet net;
    const DecUtt *utt; int nUtt;
-   const float *score;
+   const float *score; int ns;         // frame-major since round 4: score[score0 + (t-1)*ns + slot] (k_score_transpose), ns = tied states of the network
    Tok *tok;                           // [sum nTok]   state tokens
    Tok *ex; double *imax;              // [sum nNodes] exit tokens, instance maxima
    int *pathPrev; double *pathLike; float *pathLm;
@@ -69,6 +78,9 @@ struct OrdArgs {
    int pathExtra;                      // records per utterance beyond (T + 1) * nWordNodes
 };
 int htkamd_launch_decode_ord(const OrdArgs &a, int nSel, hipStream_t s);
+// K1 writes a score block state-major (a state's frames are a lane's stores); the token loops read a COLUMN per frame: one 128-byte line per
+// state and frame -- 640 KB per utterance and frame on the 5k-state set.  Transposed once (tiles through LDS), a frame's column is 20 KB.
+int htkamd_launch_score_transpose(const float *in, float *out, const DecUtt *dUtt, int nUtt, int maxT, int ns, hipStream_t s);
 
 
 struct htkamd_decoder {

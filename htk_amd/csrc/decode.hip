@@ -59,6 +59,7 @@ __device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k
    return best;
 }
 
+template <int NTHR>
 __device__ __forceinline__ double block_max(double v, double *red)
 {
 #pragma unroll
@@ -68,17 +69,100 @@ __device__ __forceinline__ double block_max(double v, double *red)
    if ((threadIdx.x & 63) == 0) red[wv] = v;
    __syncthreads();
    double r = red[0];
-   for (int i = 1; i < DEC_THREADS / 64; i++) r = (red[i] > r) ? red[i] : r;
+   for (int i = 1; i < NTHR / 64; i++) r = (red[i] > r) ? red[i] : r;
    return r;
 }
 
 #define DEC_LDS_TP 4096            /* floats of transition matrices cached in LDS (all of them, else global memory) */
 
-__global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
+// StepHMM1 (HRec.c:642) on one model instance: s[1 .. NS-1] = the state tokens on entry (s[1] the entry token) and the new ones on
+// return (s[1] null: the entry is consumed); exT = the exit token, mx = the instance's maximum, wordTop raised by exit + LikeToWord.
+template <int MX, bool SLOTS = false>
+__device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, const int4 ni, const float *tp, Tok (&s)[MX], const float gT, const int t,
+                                          const float wdlk, Tok &exT, double &mx, double &wordTop, const int sl2 = 0, const int sl3 = 0, const int sl4 = 0)
 {
-   __shared__ double red[DEC_THREADS / 64];
-   __shared__ double red2[DEC_THREADS / 64];
-   __shared__ int redk[DEC_THREADS / 64];
+   const DecNet &N = a.net;
+   const int NS = (ni.x >> 4) & 255;
+   Tok nw[MX];
+#pragma unroll
+   for (int j = 2; j < MX; j++) {
+      nw[j] = null_tok();
+      if (j < NS) {
+         // CreateSEIndex (HRec.c:1403): predecessor range with a transition, first maximum wins
+         int lo = 1, hi = NS - 1;
+         while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
+         while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
+         if (lo > hi) { lo = 1; hi = NS - 1; }
+         Tok best = s[1]; double bl = LZERO;
+#pragma unroll
+         for (int i = 1; i < MX; i++)
+            if (i >= lo && i <= hi) {
+               const double c = s[i].like + tp[(i - 1) * NS + (j - 1)];
+               if (i == lo || c > bl) { best = s[i]; bl = c; }
+            }
+         best.like = bl;
+         if (best.like > gT) {
+            int slot;
+            if constexpr (SLOTS) slot = (j == 2) ? sl2 : (j == 3) ? sl3 : sl4;      // (the register-resident models carry their score slots)
+            else slot = N.stateSlot[N.hmmState[ni.w + (j - 2)]];
+            best.like += a.score[ud.score0 + (size_t)(t - 1) * a.ns + slot];
+            nw[j] = best;
+            if (best.like > mx) mx = best.like;
+         }
+      }
+   }
+   {
+      int lo = 2, hi = NS - 1;
+      while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
+      while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
+      if (lo > hi) { lo = 2; hi = NS - 1; }
+      Tok best = nw[2]; double bl = LZERO;
+#pragma unroll
+      for (int i = 2; i < MX; i++)
+         if (i >= lo && i <= hi) {
+            const double c = nw[i].like + tp[(i - 1) * NS + (NS - 1)];
+            if (i == lo || c > bl) { best = nw[i]; bl = c; }
+         }
+      best.like = bl;
+      if (best.like > LSMALL) {
+         exT = best;
+         const double w = best.like + wdlk;
+         if (w > wordTop) wordTop = w;
+      }
+   }
+   s[1] = null_tok();                                      // entry consumed
+#pragma unroll
+   for (int j = 2; j < MX; j++) if (j < NS) s[j] = nw[j];
+}
+
+// StepWord2 (HRec.c:1046) for the token `st` that entered word node n at frame t: the Path record, the exit token
+__device__ __forceinline__ Tok word_step2(const DecArgs &a, const DecUtt &ud, const int n, const int t, const Tok st)
+{
+   const DecNet &N = a.net;
+   Tok e = st;
+   e.like += a.wordPen;
+   e.like += N.pronProb[n] * a.prScale;
+   const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
+   a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
+   e.path = (int)pid; e.lm = 0.0f;
+   return e;
+}
+
+// k_decode<NPT, NTHR>.  NPT = 0, NTHR = 1024: every token in global memory (any network).  NPT > 0 (round 4): the first NPT * NTHR model
+// nodes of N.hmmNodes -- plain models of at most three emitting states, the host put them first (DecNet::nReg) -- keep their state
+// tokens, their entry token and, between pass 1 and pass 2, their exit token in REGISTERS of the thread that owns them for the whole
+// utterance (node hmmNodes[tid + k NTHR] is thread tid's k-th: 16 VGPRs per node); a word / null node whose ONLY predecessor is such a
+// model is stepped by that thread from the register (DecNet::regFused), and a model all of whose successors are stepped that way never
+// writes its exit token to memory.  Round 3 moved 2.2 MB per utterance and frame on the 6 000-word loop -- 277 GB per launch of 256
+// utterances, 563 MB of live state against 256 MB of Infinity Cache; what is left in memory here: exit tokens of the word nodes, instance
+// maxima, Path records, the score column.
+#define DEC_MAXR 5                 /* states of a register-resident model incl. entry / exit */
+template <int NPT, int NTHR, bool HASG>       // HASG: model nodes outside the registers exist (tee models, more than three emitting states, overflow)
+__global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
+{
+   __shared__ double red[NTHR / 64];
+   __shared__ double red2[NTHR / 64];
+   __shared__ int redk[NTHR / 64];
    __shared__ float thr[2];
    __shared__ float ltp[DEC_LDS_TP];
    __shared__ int uhist[256];
@@ -91,12 +175,28 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
    Tok *tok = a.tok + ud.tok0, *ex = a.ex + ud.node0;
    double *imax = a.imax + ud.node0;
    const bool tpInLds = N.nTpFloats <= DEC_LDS_TP;
-   if (tpInLds) for (int i = tid; i < N.nTpFloats; i += DEC_THREADS) ltp[i] = N.transP[i];
+   if (tpInLds) for (int i = tid; i < N.nTpFloats; i += NTHR) ltp[i] = N.transP[i];
    const float *tpBase = tpInLds ? ltp : N.transP;
    bool tie = false;                           // this thread met two equally likely tokens with different histories (pull_range)
+   const int nReg = (NPT > 0) ? N.nReg : 0;    // model nodes hmmNodes[0 .. nReg) live in registers
+   // this thread's register-resident models: rs[k][0 ..] = the tokens of states 2 .. ; the entry token (the exit token between the
+   // passes) of its k-th model waits in LDS, xs[k NTHR + tid] (registers for it too made the compiler spill at 12 models per thread)
+   extern __shared__ Tok xs[];
+   Tok rs[NPT > 0 ? NPT : 1][DEC_MAXR - 2];
+   float *rmaxL = (float *)(xs + (size_t)(NPT > 0 ? NPT : 0) * NTHR);      // NetInst.max of the register-resident models (a LogFloat), [k NTHR + tid], behind xs
+#define rmax(k_) rmaxL[(k_) * NTHR + tid]
+   if constexpr (NPT > 0) {
+#pragma unroll
+      for (int k = 0; k < NPT; k++) {
+         xs[k * NTHR + tid] = null_tok();
+         rmax(k) = (float)LZERO;
+#pragma unroll
+         for (int i = 0; i < DEC_MAXR - 2; i++) rs[k][i] = null_tok();
+      }
+   }
 
-   for (int i = tid; i < N.nTok; i += DEC_THREADS) tok[i] = null_tok();
-   for (int i = tid; i < N.nNodes; i += DEC_THREADS) { ex[i] = null_tok(); imax[i] = LZERO; }
+   for (int i = tid; i < N.nTok; i += NTHR) tok[i] = null_tok();
+   for (int i = tid; i < N.nNodes; i += NTHR) { ex[i] = null_tok(); imax[i] = LZERO; }
    if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; }
    __syncthreads();
 
@@ -110,7 +210,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
          if (tid == 0) usel[0] = 0;
          __syncthreads();
          int cnt = 0;
-         for (int n = tid; n < N.nNodes; n += DEC_THREADS) { const double v = imax[n]; if (v >= gTp && v > LSMALL) cnt++; }
+         for (int n = tid; n < N.nNodes; n += NTHR) { const double v = imax[n]; if (v >= gTp && v > LSMALL) cnt++; }
          if (cnt) atomicAdd(&usel[0], (unsigned)cnt);
          __syncthreads();
          const int nact = (int)usel[0];
@@ -119,10 +219,10 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             unsigned int mask = 0;
             for (int pass = 0; pass < 4; pass++) {
                const int shift = 24 - 8 * pass;
-               for (int i = tid; i < 256; i += DEC_THREADS) uhist[i] = 0;
+               for (int i = tid; i < 256; i += NTHR) uhist[i] = 0;
                __syncthreads();
                const unsigned int prefix = usel[1];
-               for (int n = tid; n < N.nNodes; n += DEC_THREADS) {
+               for (int n = tid; n < N.nNodes; n += NTHR) {
                   const double v = imax[n];
                   if (!(v >= gTp && v > LSMALL)) continue;
                   unsigned int k = __float_as_uint((float)v);
@@ -141,8 +241,24 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             unsigned int kk = usel[1];
             kk ^= (kk >> 31) ? 0x80000000u : 0xFFFFFFFFu;
             const float uth = __uint_as_float(kk);
-            if (uth > (float)LSMALL)
-               for (int n = tid; n < N.nNodes; n += DEC_THREADS) {
+            if (uth > (float)LSMALL) {
+               if constexpr (NPT > 0) {                                // the tokens that live in registers: their owners drop them (before imax changes)
+#pragma unroll
+                  for (int k = 0; k < NPT; k++) {
+                     const int hk = tid + k * NTHR;
+                     if (hk < nReg) {
+                        const double v = imax[N.hmmNodes[hk]];
+                        if (v >= gTp && v > LSMALL && v < (double)uth) {
+                           xs[k * NTHR + tid] = null_tok();
+                           rmax(k) = (float)LZERO;
+#pragma unroll
+                           for (int i = 0; i < DEC_MAXR - 2; i++) rs[k][i] = null_tok();
+                        }
+                     }
+                  }
+                  __syncthreads();
+               }
+               for (int n = tid; n < N.nNodes; n += NTHR) {
                   const double v = imax[n];
                   if (!(v >= gTp && v > LSMALL) || !(v < (double)uth)) continue;
                   imax[n] = LZERO; ex[n] = null_tok();                 // DetachInst: every token of the instance goes, the entry token too
@@ -150,20 +266,62 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                   const int nt = ((ni.x & 15) == HTKAMD_NODE_HMM) ? ((ni.x >> 4) & 255) - 1 : 1;
                   for (int i = 0; i < nt; i++) tok[ni.y + i] = null_tok();
                }
+            }
             __syncthreads();
          }
       }
       if (t >= 1) {
          const float gT = thr[0];                         // threshold of the previous frame
          double myGen = LZERO, myWord = LZERO;
-         for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
+         if constexpr (NPT > 0) {
+#pragma unroll
+            for (int k = 0; k < NPT; k++) {
+               const int hk = tid + k * NTHR;
+               if (hk < nReg) {
+                  const int4 ra = N.regRecA[hk];          // {node, kind | N << 4, offset of transP, fused node}: one coalesced load, nothing dependent behind it
+                  const int4 rb = N.regRecB[hk];          // {score slots of states 2, 3, 4, nobody pulls the exit token}
+                  const int n = ra.x;
+                  const int4 ni = make_int4(ra.y, 0, ra.z, 0);
+                  const int NS = (ni.x >> 4) & 255;
+                  Tok s[DEC_MAXR];
+                  const bool detached = rmax(k) < gT;     // DetachInst of the previous frame's pass 2
+                  bool live = false;
+                  s[0] = null_tok();
+#pragma unroll
+                  for (int i = 1; i < DEC_MAXR; i++) {
+                     s[i] = null_tok();
+                     if (i < NS && (i == 1 || !detached)) s[i] = (i == 1) ? xs[k * NTHR + tid] : rs[k][i - 2];
+                  }
+#pragma unroll
+                  for (int i = 1; i < DEC_MAXR; i++) if (i < NS && s[i].like > LSMALL) live = true;
+                  Tok exT = null_tok();
+                  double mx = LZERO;
+                  if (live) {
+                     hmm_step1<DEC_MAXR, true>(a, ud, ni, tpBase + ni.z, s, gT, t, N.regRecF[hk].x, exT, mx, myWord, rb.x, rb.y, rb.z);
+                     if (mx > myGen) myGen = mx;
+                  } else {
+#pragma unroll
+                     for (int i = 1; i < DEC_MAXR; i++) s[i] = null_tok();
+                  }
+#pragma unroll
+                  for (int i = 2; i < DEC_MAXR; i++) rs[k][i - 2] = s[i];
+                  xs[k * NTHR + tid] = exT;                // the exit token, until pass 2 has used it
+                  if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four models at a time: all twelve interleaved, their temporaries spill)
+                  if (!rb.w) ex[n] = exT;                  // (somebody pulls it from memory)
+                  rmax(k) = (float)mx;                     // inst->max is a LogFloat (HRec.c:138); in memory only where -u wants to see it
+                  if (a.maxActive > 0) imax[n] = (double)(float)mx;
+               }
+            }
+         }
+         if constexpr (HASG)
+         for (int hk = nReg + tid; hk < N.nHmm; hk += NTHR) {
             const int n = N.hmmNodes[hk];
             const int4 ni = N.nodeInfo[n];
             const int NS = (ni.x >> 4) & 255, t0 = ni.y;
-            const float *tp = tpBase + ni.z;
             Tok s[DEC_MAXN];
             const bool detached = imax[n] < gT;           // DetachInst of the previous frame's pass 2
             bool live = false;
+            s[0] = null_tok();
 #pragma unroll
             for (int i = 1; i < DEC_MAXN; i++) {
                s[i] = null_tok();
@@ -175,62 +333,17 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             Tok exT = null_tok();
             double mx = LZERO;
             if (live) {
-               Tok nw[DEC_MAXN];
+               hmm_step1<DEC_MAXN>(a, ud, ni, tpBase + ni.z, s, gT, t, N.wdlk[n], exT, mx, myWord);
 #pragma unroll
-               for (int j = 2; j < DEC_MAXN; j++) {
-                  nw[j] = null_tok();
-                  if (j < NS) {
-                     // CreateSEIndex (HRec.c:1403): predecessor range with a transition, first maximum wins
-                     int lo = 1, hi = NS - 1;
-                     while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
-                     while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
-                     if (lo > hi) { lo = 1; hi = NS - 1; }
-                     Tok best = s[1]; double bl = LZERO;
-#pragma unroll
-                     for (int i = 1; i < DEC_MAXN; i++)
-                        if (i >= lo && i <= hi) {
-                           const double c = s[i].like + tp[(i - 1) * NS + (j - 1)];
-                           if (i == lo || c > bl) { best = s[i]; bl = c; }
-                        }
-                     best.like = bl;
-                     if (best.like > gT) {
-                        const int st = N.hmmState[ni.w + (j - 2)];
-                        best.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
-                        nw[j] = best;
-                        if (best.like > mx) mx = best.like;
-                     }
-                  }
-               }
-               {
-                  int lo = 2, hi = NS - 1;
-                  while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
-                  while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
-                  if (lo > hi) { lo = 2; hi = NS - 1; }
-                  Tok best = nw[2]; double bl = LZERO;
-#pragma unroll
-                  for (int i = 2; i < DEC_MAXN; i++)
-                     if (i >= lo && i <= hi) {
-                        const double c = nw[i].like + tp[(i - 1) * NS + (NS - 1)];
-                        if (i == lo || c > bl) { best = nw[i]; bl = c; }
-                     }
-                  best.like = bl;
-                  if (best.like > LSMALL) {
-                     exT = best;
-                     const double w = best.like + N.wdlk[n];
-                     if (w > myWord) myWord = w;
-                  }
-               }
-               tok[t0] = null_tok();                        // entry consumed
-#pragma unroll
-               for (int j = 2; j < DEC_MAXN; j++) if (j < NS) tok[t0 + j - 1] = nw[j];
+               for (int j = 1; j < DEC_MAXN; j++) if (j < NS) tok[t0 + j - 1] = s[j];
                if (mx > myGen) myGen = mx;
             } else if (detached) {
                for (int i = 1; i < NS; i++) tok[t0 + i - 1] = null_tok();
             }
             ex[n] = exT; imax[n] = (double)(float)mx;         // inst->max is a LogFloat (HRec.c:138)
          }
-         const double genMax = block_max(myGen, red);
-         const double wordMax = block_max(myWord, red2);
+         const double genMax = block_max<NTHR>(myGen, red);
+         const double wordMax = block_max<NTHR>(myWord, red2);
          if (tid == 0) {
             float w = (float)(wordMax - a.wordBeam); if (w < (float)LSMALL) w = (float)LSMALL;
             float g = (float)(genMax - a.genBeam); if (g < (float)LSMALL) g = (float)LSMALL;
@@ -240,9 +353,35 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
       }
       // ---- zero-time nodes, level by level (at t = 0: StartRecognition's propagation of the initial token)
       const float gT = thr[0], wT = thr[1];
+      if constexpr (NPT > 0) {
+         // word / null nodes with ONE predecessor, a register-resident model: stepped by its owner from the exit token in the register
+         if (t >= 1) {
+#pragma unroll
+            for (int k = 0; k < NPT; k++) {
+               const int hk = tid + k * NTHR;
+               if (hk < nReg) {
+                  const int n = N.regRecA[hk].w;
+                  if (n >= 0) {
+                     const Tok e0 = xs[k * NTHR + tid];
+                     const float lm = N.regRecF[hk].y;
+                     Tok st = null_tok();
+                     if (e0.like > gT) {                   // pull_range over the one predecessor (a model: no word-end beam on its token)
+                        const double c = e0.like + lm * a.lmScale;
+                        if (c > gT) { st.like = c; st.lm = e0.lm + lm; st.path = e0.path; }
+                     }
+                     Tok e = null_tok();
+                     if (st.like > LSMALL) e = (N.kind[n] == HTKAMD_NODE_WORD) ? word_step2(a, ud, n, t, st) : st;
+                     if (a.maxActive > 0) imax[n] = (st.like > LSMALL) ? (double)(float)st.like : LZERO;      // (a word / null node's max is read by -u only)
+                     ex[n] = e;
+                  }
+               }
+               if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+         }
+      }
       for (int L = 0; L < N.nLevels; L++) {
          const int l0 = N.levelOff[L], lw = N.levelWide[L], l1 = N.levelOff[L + 1];
-         for (int k = l0 + tid; k < lw; k += DEC_THREADS) {
+         for (int k = l0 + tid; k < lw; k += NTHR) {
             const int n = N.levelNodes[k];
             const int4 ni = N.nodeInfo[n];
             const int kind = ni.x & 15;
@@ -266,21 +405,14 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             } else if (!(st.like > LSMALL)) imax[n] = LZERO;
             else {
                imax[n] = (double)(float)st.like;
-               e = st;
-               if (kind == HTKAMD_NODE_WORD) {             // StepWord2
-                  e.like += a.wordPen;
-                  e.like += N.pronProb[n] * a.prScale;
-                  const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
-                  a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
-                  e.path = (int)pid; e.lm = 0.0f;
-               }
+               e = (kind == HTKAMD_NODE_WORD) ? word_step2(a, ud, n, t, st) : st;
             }
             ex[n] = e;
          }
          for (int k = lw; k < l1; k++) {                  // wide fan-in: the whole workgroup reduces one node
             const int n = N.levelNodes[k];
             int ak;
-            Tok st = pull_range(a, ex, N.predOff[n] + tid, N.predOff[n + 1], DEC_THREADS, gT, wT, &ak, &tie);
+            Tok st = pull_range(a, ex, N.predOff[n] + tid, N.predOff[n + 1], NTHR, gT, wT, &ak, &tie);
             // argmax over the workgroup: larger like, then smaller predecessor position
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -294,7 +426,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
             __syncthreads();
             if (tid == 0) {
                int bw = 0;
-               for (int i = 1; i < DEC_THREADS / 64; i++) {
+               for (int i = 1; i < NTHR / 64; i++) {
                   if (red[i] == red[bw] && redk[i] != 0x7fffffff && redk[bw] != 0x7fffffff && red2[i] != red2[bw]) tie = true;   // (lm, path) packed in red2
                   if (red[i] > red[bw] || (red[i] == red[bw] && redk[i] < redk[bw])) bw = i;
                }
@@ -303,16 +435,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
                if (t == 0 && n == N.initial) { b.like = 0.0; b.lm = 0.0f; b.path = -1; }
                Tok e = null_tok();
                imax[n] = (b.like > LSMALL) ? (double)(float)b.like : LZERO;
-               if (b.like > LSMALL) {
-                  e = b;
-                  if (N.kind[n] == HTKAMD_NODE_WORD) {
-                     e.like += a.wordPen;
-                     e.like += N.pronProb[n] * a.prScale;
-                     const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
-                     a.pathPrev[ud.path0 + pid] = b.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
-                     e.path = (int)pid; e.lm = 0.0f;
-                  }
-               }
+               if (b.like > LSMALL) e = (N.kind[n] == HTKAMD_NODE_WORD) ? word_step2(a, ud, n, t, b) : b;
                ex[n] = e;
             }
          }
@@ -320,7 +443,25 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
       }
       // ---- entry tokens of the emitting models for the next frame (SetEntryState from this frame's exits)
       if (t < T) {
-         for (int hk = tid; hk < N.nHmm; hk += DEC_THREADS) {
+         if constexpr (NPT > 0) {
+#pragma unroll
+            for (int k = 0; k < NPT; k++) {
+               const int hk = tid + k * NTHR;
+               if (hk < nReg) {
+                  const int n = N.regRecA[hk].x;
+                  int ak;
+                  const Tok en = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie);
+                  xs[k * NTHR + tid] = en;
+                  if (en.like > (double)rmax(k)) {
+                     rmax(k) = (float)en.like;
+                     if (a.maxActive > 0) imax[n] = (double)(float)en.like;
+                  }
+               }
+               if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+         }
+         if constexpr (HASG)
+         for (int hk = nReg + tid; hk < N.nHmm; hk += NTHR) {
             const int n = N.hmmNodes[hk];
             const int4 ni = N.nodeInfo[n];
             if ((ni.x >> 12) & 1) continue;                // tee models got theirs in the level phase
@@ -371,6 +512,34 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode(DecArgs a)
       } else nW = -1;
       a.nWords[u] = nW;
    }
+}
+
+// state-major score block -> frame-major, per utterance: 32 x 32 tiles through LDS (both sides in whole lines)
+__global__ __launch_bounds__(256) void k_score_transpose(const float *__restrict__ in, float *__restrict__ out, const DecUtt *utt, int ns)
+{
+   __shared__ float tile[32][33];
+   const DecUtt ud = utt[blockIdx.z];
+   const int T = ud.T, f0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
+   if (f0 >= T) return;
+   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+   for (int r = ty; r < 32; r += 8) {
+      const int sl = s0 + r, f = f0 + tx;
+      tile[r][tx] = (sl < ns && f < T) ? in[ud.score0 + (size_t)sl * T + f] : 0.0f;
+   }
+   __syncthreads();
+   for (int r = ty; r < 32; r += 8) {
+      const int f = f0 + r, sl = s0 + tx;
+      if (f < T && sl < ns) out[ud.score0 + (size_t)f * ns + sl] = tile[tx][r];
+   }
+}
+
+int htkamd_launch_score_transpose(const float *in, float *out, const DecUtt *dUtt, int nUtt, int maxT, int ns, hipStream_t s)
+{
+   if (nUtt <= 0 || maxT <= 0 || ns <= 0) return HTKAMD_OK;
+   hipLaunchKernelGGL(k_score_transpose, dim3((maxT + 31) / 32, (ns + 31) / 32, nUtt), dim3(256), 0, s, in, out, dUtt, ns);
+   hipError_t e = hipGetLastError();
+   if (e != hipSuccess) { htkamd_set_error("score_transpose: launch: %s", hipGetErrorString(e)); return HTKAMD_EHIP; }
+   return HTKAMD_OK;
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -500,10 +669,39 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       for (int n = 0; n < nN; n++) if (!zt(n)) send(n);
       for (int n : queue) send(n);
    }
+   // Register-resident models (k_decode<NPT > 0>): plain models of at most three emitting states come first in hmmNodes, up to what
+   // DEC_REG_MAXNPT per thread hold; a word / null node of level 0 with ONE predecessor, such a model, is stepped by that model's owner.
+   std::vector<int> regFused, fusedOf(nN, -1);
+   std::vector<int4> regRecA, regRecB;
+   std::vector<float2> regRecF;
+   std::vector<float> regFusedLike;
+   std::vector<unsigned char> regNoEx, isFused(nN, 0);
+   int nReg = 0;
+   if (!getenv("HTKAMD_DECODE_NOREG")) {
+      std::vector<int> reg, rest;
+      for (int n : hmmNodes) ((!tee[n] && nodeN[n] <= 5 && (int)reg.size() < DEC_REG_MAXNPT * DEC_REG_THREADS) ? reg : rest).push_back(n);
+      nReg = (int)reg.size();
+      hmmNodes = reg; hmmNodes.insert(hmmNodes.end(), rest.begin(), rest.end());
+      std::vector<int> slotOf(nN, -1);
+      for (int k = 0; k < nReg; k++) slotOf[reg[k]] = k;
+      regFused.assign(nReg, -1); regFusedLike.assign(nReg, 0.0f); regNoEx.assign(nReg, 0);
+      for (int w = 0; w < nN; w++) {
+         if (kind[w] == HTKAMD_NODE_HMM || w == nd->initial || level[w] != 0 || predOff[w + 1] - predOff[w] != 1) continue;
+         const int pnode = predSrc[predOff[w]] & 0x7fffffff;
+         const int k = slotOf[pnode];
+         if (k < 0 || regFused[k] >= 0) continue;
+         regFused[k] = w; regFusedLike[k] = predLike[predOff[w]]; isFused[w] = 1;
+      }
+      for (int k = 0; k < nReg; k++) {
+         const int n = reg[k];
+         regNoEx[k] = regFused[k] >= 0 && nd->linkOff[n + 1] - nd->linkOff[n] == 1;
+      }
+      regRecA.resize(nReg); regRecB.resize(nReg); regRecF.resize(nReg);
+   }
    std::vector<int> levelOff(nLevels + 1, 0), levelWide(nLevels, 0), levelNodes;
    for (int L = 0; L < nLevels; L++) {
       levelOff[L] = (int)levelNodes.size();
-      for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] < DEC_WIDE) levelNodes.push_back(n);
+      for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] < DEC_WIDE && !isFused[n]) levelNodes.push_back(n);
       levelWide[L] = (int)levelNodes.size();
       for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] >= DEC_WIDE) {
          if (kind[n] == HTKAMD_NODE_HMM) { htkamd_set_error("decoder_create: tee model with %d predecessors", predOff[n + 1] - predOff[n]); delete d; return HTKAMD_EMODEL; }
@@ -511,22 +709,42 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       }
    }
    levelOff[nLevels] = (int)levelNodes.size();
+   // ... and the same lists with every zero-time node in them, for the kernels that keep no tokens in registers (k_decode_n)
+   std::vector<int> levelOffA(nLevels + 1, 0), levelWideA(nLevels, 0), levelNodesA;
+   for (int L = 0; L < nLevels; L++) {
+      levelOffA[L] = (int)levelNodesA.size();
+      for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] < DEC_WIDE) levelNodesA.push_back(n);
+      levelWideA[L] = (int)levelNodesA.size();
+      for (int n = 0; n < nN; n++) if (zt(n) && level[n] == L && predOff[n + 1] - predOff[n] >= DEC_WIDE) levelNodesA.push_back(n);
+   }
+   levelOffA[nLevels] = (int)levelNodesA.size();
    for (int n = 0; n < nN; n++) {
       bool wd0 = false;
       if (kind[n] == HTKAMD_NODE_HMM) for (int k = nd->linkOff[n]; k < nd->linkOff[n + 1]; k++) if (is_wd0_link(nd, tee, nd->linkDest[k])) wd0 = true;   // n_wd0 (HNet.c:3626-3631)
       if (wd0) wdlk[n] = like_to_word(nd, m, tee, n, lmScale);
    }
+   for (int k = 0; k < nReg; k++) {
+      const int n = hmmNodes[k], h = model[n];
+      int sl[3] = {0, 0, 0};
+      for (int j = 0; j < nodeN[n] - 2 && j < 3; j++) sl[j] = stateSlot[m->h_hmmState[m->h_hmmStateOff[h] + j * m->NSt]];
+      regRecA[k] = make_int4(n, kind[n] | (nodeN[n] << 4), nodeTp[n], regFused[k]);
+      regRecB[k] = make_int4(sl[0], sl[1], sl[2], (int)regNoEx[k]);
+      regRecF[k] = make_float2(wdlk[n], regFusedLike[k]);
+   }
    std::vector<int4> nodeInfo(nN);
    for (int n = 0; n < nN; n++) nodeInfo[n] = make_int4(kind[n] | (nodeN[n] << 4) | ((int)tee[n] << 12), tok0[n], nodeTp[n], nodeSt[n]);
    DecNet &N = d->net;
    memset(&N, 0, sizeof(N));
+   int rc0 = HTKAMD_OK;
+   N.nReg = nReg;
+   if (nReg > 0 && ((rc0 = upv(d, regFused, &N.regFused)) || (rc0 = upv(d, regFusedLike, &N.regFusedLike)) || (rc0 = upv(d, regNoEx, &N.regNoEx)) || (rc0 = upv(d, regRecA, &N.regRecA)) || (rc0 = upv(d, regRecB, &N.regRecB)) || (rc0 = upv(d, regRecF, &N.regRecF)))) { htkamd_decoder_destroy(d); return rc0; }
    N.nNodes = nN; N.nHmm = (int)hmmNodes.size(); N.nLevels = nLevels; N.nWordNodes = nW > 0 ? nW : 1; N.initial = nd->initial; N.final = nd->final; N.nTok = nTok; N.nTpFloats = m->h_transOff[m->nT];
    int rc;
    if ((rc = upv(d, kind, &N.kind)) || (rc = upv(d, model, &N.model)) || (rc = upv(d, pron, &N.pronProb)) || (rc = upv(d, predOff, &N.predOff)) ||
        (rc = upv(d, predSrc, &N.predSrc)) || (rc = upv(d, predLike, &N.predLike)) || (rc = upv(d, tok0, &N.tok0)) || (rc = upv(d, hmmNodes, &N.hmmNodes)) ||
        (rc = upv(d, nodeN, &N.nodeN)) || (rc = upv(d, nodeTp, &N.nodeTp)) || (rc = upv(d, nodeSt, &N.nodeSt)) || (rc = upv(d, tee, &N.nodeTee)) ||
        (rc = upv(d, wdlk, &N.wdlk)) || (rc = upv(d, wordIdx, &N.wordIdx)) || (rc = upv(d, levelOff, &N.levelOff)) || (rc = upv(d, levelNodes, &N.levelNodes)) ||
-       (rc = upv(d, levelWide, &N.levelWide)) || (rc = upv(d, stateSlot, &N.stateSlot)) || (rc = upv(d, wordNode, &N.wordNode)) ||
+       (rc = upv(d, levelWide, &N.levelWide)) || (rc = upv(d, levelOffA, &N.levelOffAll)) || (rc = upv(d, levelNodesA, &N.levelNodesAll)) || (rc = upv(d, levelWideA, &N.levelWideAll)) || (rc = upv(d, stateSlot, &N.stateSlot)) || (rc = upv(d, wordNode, &N.wordNode)) ||
        (rc = upv(d, nodeInfo, &N.nodeInfo))) { htkamd_decoder_destroy(d); return rc; }
    {
       std::vector<int> hs((size_t)(m->h_hmmStateOff[m->H] / m->NSt));
@@ -593,7 +811,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
       size_t bytes = 0; int u1 = u0;
       while (u1 < nUtt) {
          const size_t T = (size_t)(frameOff[u1 + 1] - frameOff[u1]);
-         const size_t b = (size_t)ns * T * 4 + (size_t)N.nTok * 16 + (size_t)N.nNodes * 24 + (T + 1) * (size_t)N.nWordNodes * 16;
+         const size_t b = (size_t)ns * T * 8 + (size_t)N.nTok * 16 + (size_t)N.nNodes * 24 + (T + 1) * (size_t)N.nWordNodes * 16;
          if (u1 > u0 && bytes + b > ((size_t)24 << 30)) break;
          bytes += b; u1++;
       }
@@ -632,7 +850,8 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          }
          *p = d->ws[i];
       };
-      A(&dScore, score * 4); A(&dTok, tok * sizeof(Tok)); A(&dEx, node * sizeof(Tok)); A(&dImax, node * 8);
+      void *dScoreT = nullptr;
+      A(&dScore, score * 4); A(&dScoreT, score * 4); A(&dTok, tok * sizeof(Tok)); A(&dEx, node * sizeof(Tok)); A(&dImax, node * 8);
       A(&dPPrev, path * 4); A(&dPLike, path * 8); A(&dPLm, path * 4);
       A(&dUtt, sizeof(DecUtt) * nu); A(&dTasks, sizeof(ScoreTask) * tasks.size() + sizeof(int));
       A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * ((size_t)nu * maxWords * 3 + nu)); A(&dTot, sizeof(double) * nu);
@@ -660,10 +879,15 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);   // exact: the decoded path is the reference's; matrix-core modes: tolerance class
       }
+      if (!rc) {
+         int maxT = 0;
+         for (int k = 0; k < nu; k++) maxT = std::max(maxT, utt[k].T);
+         rc = htkamd_launch_score_transpose((const float *)dScore, (float *)dScoreT, (const DecUtt *)dUtt, nu, maxT, ns, s);
+      }
       DecArgs a;
       memset(&a, 0, sizeof(a));
       if (!rc) {
-         a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
+         a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScoreT; a.ns = ns;
          a.tok = (Tok *)dTok; a.ex = (Tok *)dEx; a.imax = (double *)dImax;
          a.pathPrev = (int *)dPPrev; a.pathLike = (double *)dPLike; a.pathLm = (float *)dPLm;
          a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale; a.maxActive = cfg->maxActive;
@@ -674,7 +898,20 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          a.wordLike = (double *)dOutD;
          a.tieFlag = (int *)dTie;
          (void)hipMemsetAsync(dTie, 0, sizeof(int) * nu, s);
-         hipLaunchKernelGGL(k_decode, dim3(nu), dim3(DEC_THREADS), 0, s, a);
+         // tokens of the plain models in registers where the network has such models (DecNet::nReg), NPT of them per thread
+         const int npt = (N.nReg + DEC_REG_THREADS - 1) / DEC_REG_THREADS;
+#define DEC_LAUNCH_REG(NPT_) do { const size_t lds_ = (sizeof(Tok) + sizeof(float)) * (size_t)(NPT_) * DEC_REG_THREADS; \
+            if (hasG) { (void)hipFuncSetAttribute((const void *)k_decode<NPT_, DEC_REG_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+                        hipLaunchKernelGGL((k_decode<NPT_, DEC_REG_THREADS, true>), dim3(nu), dim3(DEC_REG_THREADS), lds_, s, a); } \
+            else { (void)hipFuncSetAttribute((const void *)k_decode<NPT_, DEC_REG_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+                   hipLaunchKernelGGL((k_decode<NPT_, DEC_REG_THREADS, false>), dim3(nu), dim3(DEC_REG_THREADS), lds_, s, a); } } while (0)
+         const bool hasG = N.nReg < N.nHmm;
+         if (npt == 0) hipLaunchKernelGGL((k_decode<0, DEC_THREADS, true>), dim3(nu), dim3(DEC_THREADS), 0, s, a);
+         else if (npt <= 2) DEC_LAUNCH_REG(2);
+         else if (npt <= 4) DEC_LAUNCH_REG(4);
+         else if (npt <= 8) DEC_LAUNCH_REG(8);
+         else DEC_LAUNCH_REG(DEC_REG_MAXNPT);
+#undef DEC_LAUNCH_REG
          hipError_t e = hipGetLastError();
          if (e != hipSuccess) { htkamd_set_error("decoder_run: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       }

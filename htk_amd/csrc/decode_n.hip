@@ -41,7 +41,7 @@ struct __attribute__((aligned(16))) TSet {
 struct NArgs {
    DecNet net;
    const DecUtt *utt; int nUtt;
-   const float *score;
+   const float *score; int ns;         // frame-major: score[score0 + (t-1)*ns + slot]
    TSet *tokA, *tokB;                  // [sum nTok] state sets, double-buffered
    TSet *ex; double *imax;             // [sum nNodes]
    int *pathPrev; double *pathLike; float *pathLm;             // [sum (T+1)*nWordNodes]
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
                   }
                   if (res.like > gT) {
                      const int st = N.hmmState[ni.w + (j - 2)];
-                     res.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
+                     res.like += a.score[ud.score0 + (size_t)(t - 1) * a.ns + N.stateSlot[st]];
                      if (res.like > mx) mx = res.like;
                   } else ts_null(res);
                   nxt[t0 + j - 1] = res;
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
       }
       const float gT = thr[0], wT = thr[1], nT = thr[2];
       for (int L = 0; L < N.nLevels; L++) {
-         const int l0 = N.levelOff[L], lw = N.levelWide[L], l1 = N.levelOff[L + 1];
+         const int l0 = N.levelOffAll[L], lw = N.levelWideAll[L], l1 = N.levelOffAll[L + 1];
          for (int k = l0 + tid; k < lw; k += DEC_THREADS) {
-            const int n = N.levelNodes[k];
+            const int n = N.levelNodesAll[k];
             const int4 ni = N.nodeInfo[n];
             const int kind = ni.x & 15;
             TSet st; ts_null(st);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
             ex[n] = e;
          }
          for (int k = lw; k < l1; k++) {                   // wide fan-in: contiguous runs per thread, then thread 0 in run order
-            const int n = N.levelNodes[k];
+            const int n = N.levelNodesAll[k];
             const int p0 = N.predOff[n], p1 = N.predOff[n + 1];
             const int per = (p1 - p0 + DEC_THREADS - 1) / DEC_THREADS;
             TSet mine; ts_null(mine);
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
                }
                if (res.like > gT) {
                   const int st = N.hmmState[ni.w + (j - 2)];
-                  res.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
+                  res.like += a.score[ud.score0 + (size_t)(t - 1) * a.ns + N.stateSlot[st]];
                   if (res.like > mx) mx = res.like;
                } else { res.like = LZERO; res.lm = 0.0f; res.path = -1; res.n = 1; }
                nxt[t0 + j - 1] = res;
@@ -806,7 +806,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
       size_t bytes = 0; int u1 = u0;
       while (u1 < nUtt) {
          const size_t T = (size_t)(frameOff[u1 + 1] - frameOff[u1]);
-         const size_t b = (size_t)ns * T * 4 + (size_t)N.nTok * 2 * sizeof(TSet) + (size_t)N.nNodes * (sizeof(TSet) + 8) + (pathMul * (T + 1) * (size_t)N.nWordNodes + pathExtra) * (24 + 16 * (NT - 1) + 8) +
+         const size_t b = (size_t)ns * T * 8 + (size_t)N.nTok * 2 * sizeof(TSet) + (size_t)N.nNodes * (sizeof(TSet) + 8) + (pathMul * (T + 1) * (size_t)N.nWordNodes + pathExtra) * (24 + 16 * (NT - 1) + 8) +
                           (listOrder ? (size_t)seqCap * 8 : 0);
          if (u1 > u0 && bytes + b > ((size_t)24 << 30)) break;
          bytes += b; u1++;
@@ -844,7 +844,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          return d->wsN[i];
       };
       NArgs a; memset(&a, 0, sizeof(a));
-      void *dScore = A(score * 4);
+      void *dScore = A(score * 4), *dScoreT = A(score * 4);
       a.tokA = (TSet *)A(tok * sizeof(TSet)); a.tokB = (TSet *)A(tok * sizeof(TSet)); a.ex = (TSet *)A(node * sizeof(TSet)); a.imax = (double *)A(node * 8);
       a.pathPrev = (int *)A(path * 4); a.pathLike = (double *)A(path * 8); a.pathLm = (float *)A(path * 4);
       a.altN = (int *)A(path * 4); a.altPrev = (int *)A(path * 4 * (NT - 1)); a.altLike = (double *)A(path * 8 * (NT - 1)); a.altLm = (float *)A(path * 4 * (NT - 1));
@@ -880,7 +880,12 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);
       }
       if (!rc) {
-         a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScore;
+         int maxT = 0;
+         for (int k = 0; k < nu; k++) maxT = std::max(maxT, utt[k].T);
+         rc = htkamd_launch_score_transpose((const float *)dScore, (float *)dScoreT, (const DecUtt *)dUtt, nu, maxT, ns, s);
+      }
+      if (!rc) {
+         a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScoreT; a.ns = ns;
          a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.nBeam = nBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
          a.nToks = nToks; a.maxActive = cfg->maxActive > 0 ? cfg->maxActive : 0; a.maxLatNodes = maxLatNodes; a.maxLatArcs = maxLatArcs;
          const size_t lds = sizeof(TSet) * DEC_THREADS;

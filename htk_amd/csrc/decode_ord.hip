@@ -184,7 +184,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord(OrdArgs oa)
                      best.like = bl;
                      if (best.like > gT) {
                         const int st = N.hmmState[ni.w + (j - 2)];
-                        best.like += a.score[ud.score0 + (size_t)N.stateSlot[st] * T + (t - 1)];
+                        best.like += a.score[ud.score0 + (size_t)(t - 1) * a.ns + N.stateSlot[st]];
                         nw[j] = best;
                         if (best.like > mx) mx = best.like;
                      }

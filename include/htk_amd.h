@@ -92,7 +92,18 @@ typedef struct {
       fields above as described.  numStreams = NS > 1: stateCompOff has numStates*NS + 1 entries, the components of stream k of state
       s are stateCompOff[s*NS + k] .. [s*NS + k + 1); a Gaussian belongs to one stream and is held in an UNDIVIDED row of vecSize
       elements: its values at the dimensions d with dimStream[d] == its stream, mean 0 and variance +infinity elsewhere (such a
-      dimension contributes nothing to a score and is never re-estimated); the feature rows stay undivided as well. */
+      dimension contributes nothing to a score and is never re-estimated); the feature rows stay undivided as well.
+      WHERE THIS LIBRARY DELIBERATELY DIFFERS FROM THE REFERENCE'S HERest (both differences are defects of the reference; the oracle
+      restates them bit for bit, oracle/htk_oracle.c, and DESIGN.md §4b / §4c measures them):
+        * NS != 3: when a tied state is met a second time in one frame (by another chain state), Setotprob sums the cached stream
+          vectors it has already overwritten with "the sum of the others" and halves the result (HFB.c:1044-1064) -- the first visit's
+          value for NS = 3 only; for NS = 2 every repeated state gets HALF its log probability (the reference reports -33.6 per frame
+          on the demo set split 13 | 13 where the sum of the streams' log probabilities gives -59.1).  This library computes the
+          first visit's value at every visit: equal to HERest for NS = 1 and NS = 3, NOT for NS = 2 or NS >= 4 on sets with repeated
+          tied states.
+        * SHAREDHS sets whose mixtures share pdfs (~m macros without HHEd's TIEDHS conversion): ConvLogWt converts the weights of the
+          FIRST state that uses a shared pdf only (HUtil.c:474-485), the others are read as log weights; this library converts
+          every weight once. */
    int numStreams;
    const int   *dimStream;    /* [D] stream (0-based) of each dimension, NULL for one stream (htkamd_mmf computes it from the kind) */
    /* HTKAMD_HS_TIED: a tied-mixture set (hsKind TIEDHS, <TMIX>): every (state, stream) lists the SAME pool of Gaussians of its stream
