@@ -171,9 +171,25 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # th
             rec = [] if w is None else [net.out_syms[p_] for p_, _, _, _ in w]
             ref_ = ["p%d" % k for k in q]
             tot += len(ref_); hit += sum(1 for x, y in zip(rec, ref_) if x == y) if len(rec) == len(ref_) else 0
-        out["hvite_decoding"] = {"utterances": len(feats), "ms": dt * 1e3, "utterances_per_sec": len(feats) / dt, "frames_per_sec": sum(f.shape[0] for f in feats) / dt,
+        frames_ = sum(f.shape[0] for f in feats)
+        sc_ms, tok_ms = dec.last_times()                                         # device events of the last run
+        S_ = int(pk["numStates"]); M_ = int(np.max(np.diff(pk["stateCompOff"])))
+        # the token kernel against HBM: per (utterance, frame) the score column (4 B per tied state), every word end's exit token written and
+        # read once (2 x 16 B) and its Path record (16 B) -- what stays in memory with the models' tokens on chip
+        dec_bytes = frames_ * (4.0 * S_ + 48.0 * V)
+        ach = dec_bytes / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
+        # the dense scores against the fp32 vector peak the exact kernel is bounded by (no FMA: half of it at best)
+        sc_flop = float(frames_) * S_ * FLOP_PER_FRAME_STATE(M_, Dv)
+        sc_ach = sc_flop / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0
+        out["hvite_decoding"] = {"utterances": len(feats), "ms": dt * 1e3, "utterances_per_sec": len(feats) / dt, "frames_per_sec": frames_ / dt,
                                  "network": "word loop over %d one-model words, -t 250 (BASELINE config[3])" % V, "words_correct": "%d/%d" % (hit, tot),
-                                 "arithmetic": "exact (K1 dense + K7)"}
+                                 "arithmetic": "exact (K1 dense + K7)", "exact_order_utterances": dec.last_tied(),
+                                 "roofline": {"kernel": "k_decode (token passing)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                              "ms": tok_ms, "bytes_per_unit": 4.0 * S_ + 48.0 * V, "unit_is": "(utterance, frame)", "units_per_launch": frames_,
+                                              "traffic": None, "note": "counter bytes: profiles/ (k_decode FETCH_SIZE + WRITE_SIZE)"},
+                                 "score_roofline": {"kernel": "k_score_exact (every tied state, every frame) + k_score_transpose", "bound": "mfma", "achieved": sc_ach,
+                                                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sc_ach / FP32_PEAK_TFLOPS, "ms": sc_ms,
+                                                    "note": "packed fp32 VALU, the reference's four roundings per dimension: half the fp32 peak at best"}}
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)

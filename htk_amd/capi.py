@@ -992,6 +992,12 @@ class Decoder:
     def last_tied(self) -> int:
         return int(lib().htkamd_decoder_last_tied(self.h))
 
+    def last_times(self):
+        """(scoring ms, token-kernel ms) of the last run, by device events."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(lib().htkamd_decoder_last_times(self.h, C.byref(a), C.byref(b)), "decoder_last_times")
+        return a.value, b.value
+
     def run(self, feats, genBeam=1.0e10, wordBeam=1.0e10, lmScale=None, wordPen=0.0, prScale=1.0, maxWords=1024, scoreMode=0, maxActive=0):
         """feats: list of [T, D] arrays.  Returns per utterance (list of (pron, startFrame, endFrame, score) or None, total)."""
         lmScale = self.lmScale if lmScale is None else float(lmScale)

@@ -97,6 +97,8 @@ struct htkamd_decoder {
    size_t wsCap[32];
    int orderMode;                      // HTKAMD_ORDER_AUTO / _FAST / _EXACT (htkamd_decoder_set_order)
    int lastTied;                       // utterances of the last run that went through the exact-order kernel
+   hipEvent_t ev[4];                   // around the scoring kernels and around the token kernel of the last chunk of a run
+   float lastScoreMs, lastTokenMs;
    void *wsN[48];                      // ... and of htkamd_decoder_run_lattice
    size_t wsNCap[48];
 };

@@ -560,11 +560,19 @@ extern "C" int htkamd_decoder_set_order(htkamd_decoder *d, int mode)
    return HTKAMD_OK;
 }
 extern "C" int htkamd_decoder_last_tied(const htkamd_decoder *d) { return d ? d->lastTied : 0; }
+extern "C" int htkamd_decoder_last_times(const htkamd_decoder *d, double *scoreMs, double *tokenMs)
+{
+   if (!d) { htkamd_set_error("decoder_last_times: NULL"); return HTKAMD_EINVAL; }
+   if (scoreMs) *scoreMs = d->lastScoreMs;
+   if (tokenMs) *tokenMs = d->lastTokenMs;
+   return HTKAMD_OK;
+}
 
 extern "C" void htkamd_decoder_destroy(htkamd_decoder *d)
 {
    if (!d) return;
    for (void *p : d->owned) (void)hipFree(p);
+   for (hipEvent_t e : d->ev) if (e) (void)hipEventDestroy(e);
    for (void *p : d->ws) if (p) (void)hipFree(p);
    for (void *p : d->wsN) if (p) (void)hipFree(p);
    delete d;
@@ -802,6 +810,8 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
    const DecNet &N = d->net;
    const int ns = (int)d->usedStates.size();
    const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
+   if (!d->ev[0]) for (int i = 0; i < 4; i++) HIPCHECK(hipEventCreate(&d->ev[i]));
+   d->lastScoreMs = d->lastTokenMs = 0.0f;
    int orderMode = d->orderMode;
    if (const char *ev = getenv("HTKAMD_DECODE_ORDER")) orderMode = !strcmp(ev, "fast") ? HTKAMD_ORDER_FAST : !strcmp(ev, "exact") ? HTKAMD_ORDER_EXACT : HTKAMD_ORDER_AUTO;
    d->lastTied = 0;
@@ -866,6 +876,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
             htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP;
          }
       }
+      if (!rc) (void)hipEventRecord(d->ev[0], s);
       if (!rc) {
          ScoreArgs sa;
          sa.tasks = (const ScoreTask *)dTasks; sa.nTasks = (int)tasks.size(); sa.X = dX; sa.slotState = d->d_usedStates; sa.out = (float *)dScore;
@@ -884,6 +895,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          for (int k = 0; k < nu; k++) maxT = std::max(maxT, utt[k].T);
          rc = htkamd_launch_score_transpose((const float *)dScore, (float *)dScoreT, (const DecUtt *)dUtt, nu, maxT, ns, s);
       }
+      if (!rc) { (void)hipEventRecord(d->ev[1], s); (void)hipEventRecord(d->ev[2], s); }
       DecArgs a;
       memset(&a, 0, sizeof(a));
       if (!rc) {
@@ -914,6 +926,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
 #undef DEC_LAUNCH_REG
          hipError_t e = hipGetLastError();
          if (e != hipSuccess) { htkamd_set_error("decoder_run: launch: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
+         (void)hipEventRecord(d->ev[3], s);
       }
       if (!rc && orderMode != HTKAMD_ORDER_FAST) {
          // the utterances in which two equally likely tokens with different histories met (or all of them: HTKAMD_ORDER_EXACT) once more,
@@ -967,6 +980,9 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
              (e = hipStreamSynchronize(s)) != hipSuccess) { htkamd_set_error("decoder_run: %s", hipGetErrorString(e)); rc = HTKAMD_EHIP; }
       } else (void)hipStreamSynchronize(s);
       if (rc) return rc;
+      { float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, d->ev[0], d->ev[1]) == hipSuccess) d->lastScoreMs += ms;
+        if (hipEventElapsedTime(&ms, d->ev[2], d->ev[3]) == hipSuccess) d->lastTokenMs += ms; }
       for (int k = 0; k < nu; k++) {
          nWords[u0 + k] = hI[k]; total[u0 + k] = hT[k];
          if (finalLm) finalLm[u0 + k] = hF[(size_t)nu * maxWords * 3 + k];

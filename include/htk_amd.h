@@ -658,6 +658,8 @@ void htkamd_decoder_destroy(htkamd_decoder *d);
 #define HTKAMD_ORDER_EXACT 2
 int  htkamd_decoder_set_order(htkamd_decoder *d, int mode);
 int  htkamd_decoder_last_tied(const htkamd_decoder *d);
+/* Device time of the last htkamd_decoder_run: the scoring kernels (K1 + the score block's transposition) and the token kernel(s), milliseconds. */
+int  htkamd_decoder_last_times(const htkamd_decoder *d, double *scoreMs, double *tokenMs);
 int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
                         int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
                         double *total, void *stream);

@@ -181,6 +181,16 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                      int maxLatNodes, int maxLatArcs, int *latNodeNet, int *latNodeFrame, double *latNodeLike,
                      int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
                      int *nLatNodes, int *nLatArcs, double *totalLike);
+/* ... with alignment records (HVite -n with -m: alignMode & 1 / -f: & 2): arc j's lAlign = [arcAlignOff[j], arcAlignOff[j+1]) of alState /
+   alNode (network node of the model) / alDur (frames) / alLike (LatFromPaths HRec.c:1582-1656, -DPHNALG) */
+int orc_decode_nbest_align(const orc_model *m, const float *X, int T,
+                     int nNodes, const int *kind, const int *model, const float *pronProb,
+                     const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
+                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks, int maxActive, int alignMode,
+                     int maxLatNodes, int maxLatArcs, int *latNodeNet, int *latNodeFrame, double *latNodeLike,
+                     int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
+                     int *nLatNodes, int *nLatArcs, double *totalLike,
+                     int maxAlign, int *arcAlignOff, int *alState, int *alNode, int *alDur, float *alLike);
 /* 1-best decoding over a flat recognition network (orc_decode.c): returns the number of words, -1 if no token reached
    the final node, -3 if maxWords is too small, -4 if the zero-time nodes form a loop.  Frames are 0-based boundaries. */
 int orc_decode(const orc_model *m, const float *X, int T,

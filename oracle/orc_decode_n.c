@@ -20,13 +20,14 @@
 #include "orc_ilist.h"
 
 #define MAXTOK 16
-typedef struct { double like; float lm; int path; } tok_t;
-typedef struct { float like, lm; int path; } rtok_t;
+typedef struct { double like; float lm; int path; int align; } tok_t;             /* align: Token.align (HRec.h), an index into dnet.al, -1 = NULL */
+typedef struct { float like, lm; int path; int align; } rtok_t;                   /* RelToken.align exists with -DPHNALG (HTKLib/Makefile.in:45) */
+typedef struct { int node, state, frame, prev; double like; } align_t;            /* Align (HRec.c:150-164) */
 typedef struct { tok_t tok; int n; rtok_t set[MAXTOK]; } tset_t;
-typedef struct { int prev, node, frame; double like; float lm; int chain0, nChain; int usage; } path_t;
-typedef struct { int prev; double like; float lm; } nxt_t;
+typedef struct { int prev, node, frame; double like; float lm; int chain0, nChain; int usage; int align; } path_t;
+typedef struct { int prev; double like; float lm; int align; } nxt_t;
 
-static const tok_t NULLTOK = { ORC_LZERO, 0.0f, -1 };
+static const tok_t NULLTOK = { ORC_LZERO, 0.0f, -1, -1 };
 
 #define KIND_HMM 0
 #define KIND_WORD 1
@@ -42,7 +43,19 @@ typedef struct {
    path_t *pth; int nP, capP;
    nxt_t *nxt; int nX, capX;
    int *aux;                       /* per network node: NetNode.aux of TokSetMerge */
+   /* alignment records (HVite -m / -f together with -n: pri->models / pri->states) */
+   int models, states;
+   align_t *al; int nAl, capAl;
 } dnet;
+
+/* NewNRefAlign (HRec.c:598-622) */
+static int new_align(dnet *d, int node, int state, double like, int frame, int prev)
+{
+   if (d->nAl + 1 > d->capAl) { d->capAl = d->capAl ? d->capAl * 2 : 4096; d->al = (align_t *)realloc(d->al, sizeof(align_t) * (size_t)d->capAl); }
+   align_t *a = &d->al[d->nAl];
+   a->node = node; a->state = state; a->like = like; a->frame = frame; a->prev = prev;
+   return d->nAl++;
+}
 
 #define TPN(d,n,i,j) ((d)->tp[n][((i)-1)*(d)->N[n] + ((j)-1)])
 
@@ -119,13 +132,13 @@ static void tokset_merge(dnet *d, tset_t *res, const tok_t *cmp, const tset_t *s
          for (k = aux - 1; k < res->n; k++)
             if (word_node_of(d, res->set[k].path) == node) { mch = k; break; }
       if (mch < 0) {
-         if (res->n < d->nToks) { mch = res->n++; res->set[mch].like = (float)ORC_LZERO; res->set[mch].lm = 0.0f; res->set[mch].path = -1; }
+         if (res->n < d->nToks) { mch = res->n++; res->set[mch].like = (float)ORC_LZERO; res->set[mch].lm = 0.0f; res->set[mch].path = -1; res->set[mch].align = -1; }
          else mch = res->n - 1;
       }
       if (like > res->set[mch].like) {
          for (mch--; mch >= 0 && like > res->set[mch].like; mch--) res->set[mch + 1] = res->set[mch];
          mch++;
-         res->set[mch].path = cur->path; res->set[mch].lm = cur->lm; res->set[mch].like = like;
+         res->set[mch].path = cur->path; res->set[mch].lm = cur->lm; res->set[mch].align = cur->align; res->set[mch].like = like;
       }
    }
    for (i = 0; i < nw; i++) d->aux[nodes[i]] = 0;
@@ -141,7 +154,26 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                      int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
                      int *nLatNodes, int *nLatArcs, double *totalLike)
 {
+   return orc_decode_nbest_align(m, X, T, nNodes, kind, model, pronProb, linkOff, linkDest, linkLike, initial, final, genBeam, wordBeam, nBeam, lmScale, wordPen, prScale,
+                                 nToks, maxActive, 0, maxLatNodes, maxLatArcs, latNodeNet, latNodeFrame, latNodeLike, latArcStart, latArcEnd, latArcAc, latArcLm, latArcPr,
+                                 latArcScore, nLatNodes, nLatArcs, totalLike, 0, NULL, NULL, NULL, NULL, NULL);
+}
+
+/* The same with alignment records (HVite -n together with -m: alignMode & 1, pri->models; -f: alignMode & 2, pri->states).  Every lattice
+   arc then carries LatFromPaths' lAlign (HRec.c:1582-1656): arc j's records are [arcAlignOff[j], arcAlignOff[j+1]) of alState (the state,
+   -1 for a model record) / alNode (network node of the model) / alDur (frames) / alLike (as the reference computes it, float).  -3 also
+   when maxAlign records do not hold them. */
+int orc_decode_nbest_align(const orc_model *m, const float *X, int T,
+                     int nNodes, const int *kind, const int *model, const float *pronProb,
+                     const int *linkOff, const int *linkDest, const float *linkLike, int initial, int final,
+                     float genBeam, float wordBeam, float nBeam, float lmScale, float wordPen, float prScale, int nToks, int maxActive, int alignMode,
+                     int maxLatNodes, int maxLatArcs, int *latNodeNet, int *latNodeFrame, double *latNodeLike,
+                     int *latArcStart, int *latArcEnd, float *latArcAc, float *latArcLm, float *latArcPr, double *latArcScore,
+                     int *nLatNodes, int *nLatArcs, double *totalLike,
+                     int maxAlign, int *arcAlignOff, int *alState, int *alNode, int *alDur, float *alLike)
+{
    dnet d; memset(&d, 0, sizeof(d));
+   d.models = (alignMode & 1) != 0; d.states = (alignMode & 2) != 0;
    if (nToks < 2 || nToks > MAXTOK) return -5;
    d.m = m; d.nNodes = nNodes; d.kind = kind; d.model = model; d.pronProb = pronProb; d.linkOff = linkOff; d.linkDest = linkDest; d.linkLike = linkLike;
    d.nToks = nToks; d.nThresh = (float)ORC_LSMALL;
@@ -202,7 +234,7 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
    float genThresh = (float)ORC_LSMALL, wordThresh = (float)ORC_LSMALL;
    float *scv = (float *)malloc(sizeof(float) * (size_t)m->S);
    int *sct = (int *)calloc((size_t)m->S, sizeof(int));
-   static const rtok_t RMAX = { 0.0f, 0.0f, -1 };
+   static const rtok_t RMAX = { 0.0f, 0.0f, -1, -1 };
    for (i = 0; i < nTok; i++) { set_null(&tk[i]); tk[i].set[0] = RMAX; }
    for (n = 0; n < nNodes; n++) { set_null(&ex[n]); ex[n].set[0] = RMAX; imax[n] = ORC_LZERO; }
    tset_t finalSet; set_null(&finalSet);
@@ -261,6 +293,16 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                   const int st = m->hmmState[m->hmmStateOff[model[n]] + (j - 2)];
                   if (sct[st] != t) { scv[st] = orc_state_outp(m, st, X + (size_t)(t - 1) * m->D, NULL); sct[st] = t; }
                   res.tok.like += scv[st];
+                  if (d.states) {                              /* HRec.c:680-704 (with -DPHNALG): a record where a token enters state j */
+                     const double alk = res.tok.like - scv[st] - res.tok.lm * lmScale;
+                     if (res.tok.align < 0 || d.al[res.tok.align].state != j || d.al[res.tok.align].node != n) {
+                        res.tok.align = new_align(&d, n, j, alk, t - 1, res.tok.align);
+                        res.set[0].align = res.tok.align;
+                     }
+                     for (int q = 1; q < res.n; q++)
+                        if (res.set[q].align < 0 || d.al[res.set[q].align].state != j || d.al[res.set[q].align].node != n)
+                           res.set[q].align = new_align(&d, n, j, alk, t - 1, res.set[q].align);      /* (the BEST token's likelihood: what the reference writes) */
+                  }
                   nw[j] = res;
                   if (res.tok.like > mx) mx = res.tok.like;
                } else { nw[j] = res; set_null(&nw[j]); }
@@ -278,9 +320,15 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                   tokset_merge(&d, &res, &c, &s[i]);
                }
                if (res.tok.like > ORC_LSMALL) {
-                  ex[n] = res;
                   const double w = res.tok.like + d.wdlk[n];
                   if (w > wordMax) wordMax = w;
+                  if (!d.tee[n] && d.models) {                 /* HRec.c:762-776: the model's exit record, one per token of the set */
+                     const double alk = res.tok.like - res.tok.lm * lmScale;
+                     res.tok.align = new_align(&d, n, -1, alk, t, res.tok.align);
+                     res.set[0].align = res.tok.align;
+                     for (int q = 1; q < res.n; q++) res.set[q].align = new_align(&d, n, -1, alk, t, res.set[q].align);
+                  }
+                  ex[n] = res;
                } else { ex[n] = res; set_null(&ex[n]); }
             }
          }
@@ -302,18 +350,27 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
             if (d.nP + 1 > d.capP) { d.capP *= 2; d.pth = (path_t *)realloc(d.pth, sizeof(path_t) * (size_t)d.capP); }
             path_t *np = &d.pth[d.nP];
             np->prev = st->tok.path; np->node = n; np->frame = t; np->like = e.like; np->lm = e.lm; np->usage = 0;
+            np->align = e.align;
             np->chain0 = d.nX; np->nChain = 0;
             for (k = 1; k < st->n; k++) {
                if (d.nX + 1 > d.capX) { d.capX *= 2; d.nxt = (nxt_t *)realloc(d.nxt, sizeof(nxt_t) * (size_t)d.capX); }
                d.nxt[d.nX].like = np->like + st->set[k].like; d.nxt[d.nX].lm = st->set[k].lm; d.nxt[d.nX].prev = st->set[k].path;
+               d.nxt[d.nX].align = st->set[k].align;
                d.nX++; np->nChain++;
             }
-            e.path = d.nP++; e.lm = 0.0f;
+            e.path = d.nP++; e.lm = 0.0f; e.align = -1;
             ex[n].tok = e; ex[n].n = 1; ex[n].set[0].path = e.path;        /* set[0].like / .lm stay what AttachInst made them (rmax) */
          } else if (kind[n] == KIND_NULL) ex[n] = *st;
          else if (d.tee[n]) {                                 /* StepHMM2 (HRec.c:790) */
             tok_t c = st->tok; c.like += TPN(&d, n, 1, d.N[n]);
             tokset_merge(&d, &ex[n], &c, st);
+            if (d.models) {                                  /* HRec.c:817-832 */
+               tset_t *r = &ex[n];
+               const double alk = r->tok.like - r->tok.lm * lmScale;
+               r->tok.align = new_align(&d, n, -1, alk, t, r->tok.align);
+               r->set[0].align = r->tok.align;
+               for (int q = 1; q < r->n; q++) r->set[q].align = new_align(&d, n, -1, alk, t, r->set[q].align);
+            }
          }
          tok_t tok = ex[n].tok;
          if (kind[n] != KIND_HMM && tok.like < wordThresh) tok = NULLTOK;
@@ -338,10 +395,12 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
       if (d.nP + 1 > d.capP) { d.capP += 8; d.pth = (path_t *)realloc(d.pth, sizeof(path_t) * (size_t)d.capP); }
       path_t *root = &d.pth[d.nP];
       root->prev = finalSet.tok.path; root->node = -2; root->frame = T; root->like = finalSet.tok.like; root->lm = finalSet.tok.lm; root->usage = 0;
+      root->align = finalSet.tok.align;
       root->chain0 = d.nX; root->nChain = 0;
       for (k = 1; k < finalSet.n; k++) {
          if (d.nX + 1 > d.capX) { d.capX *= 2; d.nxt = (nxt_t *)realloc(d.nxt, sizeof(nxt_t) * (size_t)d.capX); }
          d.nxt[d.nX].like = finalSet.tok.like + finalSet.set[k].like; d.nxt[d.nX].lm = finalSet.set[k].lm; d.nxt[d.nX].prev = finalSet.set[k].path;
+         d.nxt[d.nX].align = finalSet.set[k].align;
          d.nX++; root->nChain++;
       }
       const int rootIdx = d.nP++;
@@ -369,7 +428,7 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
       free(stack); free(child);
       if (nn > maxLatNodes || nl > maxLatArcs) rc = -3;
       else {
-         int ln = 0;
+         int ln = 0, nAlOut = 0, alOverflow = 0;
          latNodeNet[0] = -1; latNodeFrame[0] = 0; latNodeLike[0] = 0.0;
          for (int p = 0; p < d.nP; p++) {
             const path_t *pp = &d.pth[p];
@@ -387,15 +446,59 @@ int orc_decode_nbest(const orc_model *m, const float *X, int T,
                if (pp->node >= 0) { ac -= pronProb[pp->node] * prScale; pr = pronProb[pp->node]; }
                latArcStart[ln] = (prev >= 0) ? -d.pth[prev].usage : 0; latArcEnd[ln] = ne;
                latArcAc[ln] = ac; latArcLm[ln] = plm; latArcPr[ln] = pr; latArcScore[ln] = plike;
+               if (arcAlignOff) {
+                  /* lAlign of this arc (HRec.c:1582-1656 with -DPHNALG): the arc's own chain of records, latest first; a state record's
+                     likelihood is the running difference, a model record closes the model BEHIND it (the one met before, i.e. later) */
+                  arcAlignOff[ln] = nAlOut;
+                  const int a0 = (c == 0) ? pp->align : d.nxt[pp->chain0 + c - 1].align;
+                  if (a0 >= 0) {
+                     int cnt = 0, al;
+                     for (al = a0; al >= 0; al = d.al[al].prev) cnt++;
+                     if (nAlOut + cnt > maxAlign) { alOverflow = 1; }
+                     else {
+                        int i = cnt, frame = pp->frame, prr = -1, labpr = -1;
+                        double like = plike - plm * lmScale - wp;
+                        const int base = nAlOut;
+                        for (al = a0; al >= 0; al = d.al[al].prev) {
+                           const align_t *A = &d.al[al];
+                           int durF, labNode;
+                           if (A->state < 0) {
+                              if (prr < 0) { prr = al; labpr = A->node; continue; }
+                              durF = d.al[prr].frame - A->frame;
+                              like = d.al[prr].like - A->like;
+                              prr = al;
+                              labNode = labpr; labpr = A->node;
+                           } else {
+                              labNode = A->node;
+                              durF = frame - A->frame;
+                              like = like - A->like;
+                              frame = A->frame;
+                           }
+                           i--;
+                           alState[base + i] = A->state; alNode[base + i] = labNode; alDur[base + i] = durF; alLike[base + i] = (float)like;
+                           like = A->like;
+                        }
+                        if (prr >= 0) {
+                           int durF;
+                           if (prev >= 0) { durF = d.al[prr].frame - d.pth[prev].frame; like = d.al[prr].like - d.pth[prev].like; }
+                           else { durF = d.al[prr].frame; like = d.al[prr].like; }
+                           i--;
+                           alState[base + i] = -1; alNode[base + i] = labpr; alDur[base + i] = durF; alLike[base + i] = (float)like;
+                        }
+                        nAlOut += cnt;
+                     }
+                  }
+               }
                ln++;
             }
          }
+         if (arcAlignOff) arcAlignOff[ln] = nAlOut;
          *nLatNodes = nn; *nLatArcs = ln;
-         rc = 0;
+         rc = alOverflow ? -3 : 0;
       }
    }
    free(tk); free(ex); free(nw); free(imax); free(qsa); free(scv); free(sct);
 done0:
-   free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi); free(d.aux); free(d.pth); free(d.nxt);
+   free(d.N); free(d.tok0); free(d.tee); free(d.tp); free(d.wdlk); free(d.seLo); free(d.seHi); free(d.aux); free(d.pth); free(d.nxt); free(d.al);
    return rc;
 }

@@ -311,9 +311,12 @@ def mfcc(wav: np.ndarray, cfg: CMfccCfg) -> np.ndarray:
 
 
 def decode_nbest(model: "Model", X: np.ndarray, net: dict, nToks: int, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=1.0, wordPen=0.0, prScale=1.0,
-                 maxNodes=20000, maxArcs=80000, maxActive=0):
+                 maxNodes=20000, maxArcs=80000, maxActive=0, align=0, maxAlign=400000):
     """HRec with nToks > 1 (HVite -n): the lattice of CreateLattice as a dict of arrays, or None when no token reached the final node.
-    nBeam defaults to genBeam (HVite.c:546)."""
+    nBeam defaults to genBeam (HVite.c:546).  align: 1 = model records (HVite -m), 2 = state records (-f), 3 = both: the lattice then has
+    arcAlignOff / alState / alNode / alDur (frames) / alLike -- LatFromPaths' lAlign per arc."""
+    if align:
+        return _decode_nbest_align(model, X, net, nToks, genBeam, wordBeam, nBeam, lmScale, wordPen, prScale, maxNodes, maxArcs, maxActive, align, maxAlign)
     X = np.ascontiguousarray(X, np.float32)
     i32 = lambda a: np.ascontiguousarray(a, np.int32)
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
@@ -334,6 +337,32 @@ def decode_nbest(model: "Model", X: np.ndarray, net: dict, nToks: int, genBeam=1
     n, a = nn.value, na.value
     return dict(nodeNet=nNet[:n].copy(), nodeFrame=nFr[:n].copy(), nodeLike=nLk[:n].copy(), arcStart=aS[:a].copy(), arcEnd=aE[:a].copy(),
                 arcAc=aAc[:a].copy(), arcLm=aLm[:a].copy(), arcPr=aPr[:a].copy(), arcScore=aSc[:a].copy(), total=tot.value)
+
+
+def _decode_nbest_align(model, X, net, nToks, genBeam, wordBeam, nBeam, lmScale, wordPen, prScale, maxNodes, maxArcs, maxActive, align, maxAlign):
+    X = np.ascontiguousarray(X, np.float32)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    kind, mdl, pp, lo, ld, ll = i32(net["kind"]), i32(net["model"]), f32(net["pronProb"]), i32(net["linkOff"]), i32(net["linkDest"]), f32(net["linkLike"])
+    nn = C.c_int(0); na = C.c_int(0); tot = C.c_double(0.0)
+    nNet = np.zeros(maxNodes, np.int32); nFr = np.zeros(maxNodes, np.int32); nLk = np.zeros(maxNodes, np.float64)
+    aS = np.zeros(maxArcs, np.int32); aE = np.zeros(maxArcs, np.int32); aAc = np.zeros(maxArcs, np.float32); aLm = np.zeros(maxArcs, np.float32)
+    aPr = np.zeros(maxArcs, np.float32); aSc = np.zeros(maxArcs, np.float64)
+    aOff = np.zeros(maxArcs + 1, np.int32); alS = np.zeros(maxAlign, np.int32); alN = np.zeros(maxAlign, np.int32); alD = np.zeros(maxAlign, np.int32); alL = np.zeros(maxAlign, np.float32)
+    rc = lib().orc_decode_nbest_align(C.byref(model.c), _p(X), C.c_int(X.shape[0]), C.c_int(len(kind)), _p(kind), _p(mdl), _p(pp), _p(lo), _p(ld), _p(ll),
+                                      C.c_int(int(net["initial"])), C.c_int(int(net["final"])), C.c_float(genBeam), C.c_float(wordBeam),
+                                      C.c_float(genBeam if nBeam is None else nBeam), C.c_float(lmScale), C.c_float(wordPen), C.c_float(prScale), C.c_int(nToks), C.c_int(maxActive),
+                                      C.c_int(int(align)), C.c_int(maxNodes), C.c_int(maxArcs), _p(nNet), _p(nFr), _p(nLk), _p(aS), _p(aE), _p(aAc), _p(aLm), _p(aPr), _p(aSc),
+                                      C.byref(nn), C.byref(na), C.byref(tot), C.c_int(maxAlign), _p(aOff), _p(alS), _p(alN), _p(alD), _p(alL))
+    if rc == -1:
+        return None
+    if rc < 0:
+        raise RuntimeError("orc_decode_nbest_align failed (%d)" % rc)
+    n, a = nn.value, na.value
+    k = int(aOff[a])
+    return dict(nodeNet=nNet[:n].copy(), nodeFrame=nFr[:n].copy(), nodeLike=nLk[:n].copy(), arcStart=aS[:a].copy(), arcEnd=aE[:a].copy(),
+                arcAc=aAc[:a].copy(), arcLm=aLm[:a].copy(), arcPr=aPr[:a].copy(), arcScore=aSc[:a].copy(), total=tot.value,
+                arcAlignOff=aOff[:a + 1].copy(), alState=alS[:k].copy(), alNode=alN[:k].copy(), alDur=alD[:k].copy(), alLike=alL[:k].copy())
 
 
 def decode(model: "Model", X: np.ndarray, net: dict, genBeam=1.0e10, wordBeam=1.0e10, lmScale=1.0, wordPen=0.0, prScale=1.0, maxWords=4096, maxActive=0):
