@@ -940,6 +940,14 @@ class LatticeOut(C.Structure):
                                           "arcScore", "total")]
 
 
+class LatticeAlignOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("arcAlignOff", "alState", "alModel", "alDur", "alLike")]
+
+
+class LatticeAlign(C.Structure):
+    _fields_ = [("arcAlignOff", C.c_void_p), ("alState", C.c_void_p), ("alModel", C.c_void_p), ("alDur", C.c_void_p), ("alLike", C.c_void_p), ("models", C.c_int)]
+
+
 class Lattice(C.Structure):
     _fields_ = [("nNodes", C.c_int), ("nArcs", C.c_int), ("nodeFrame", C.c_void_p), ("nodePron", C.c_void_p), ("nodeLike", C.c_void_p),
                 ("arcStart", C.c_void_p), ("arcEnd", C.c_void_p), ("arcAc", C.c_void_p), ("arcLm", C.c_void_p), ("arcPr", C.c_void_p),
@@ -953,10 +961,16 @@ def _lattice_struct(lat: dict, frame_dur=0.01):
     return st, keep
 
 
-def lattice_write(lat: dict, net: "Net", path: str, utterance=None, lm_name=None, vocab_name=None, fmt=0, frame_dur=0.01):
-    """htkamd_lattice_write: the SLF file WriteLattice gives for the lattice (fmt: HTKAMD_LAT_* bits, 0 = t v a l)."""
+def lattice_write(lat: dict, net: "Net", path: str, utterance=None, lm_name=None, vocab_name=None, fmt=0, frame_dur=0.01, mmf: "Mmf" = None):
+    """htkamd_lattice_write: the SLF file WriteLattice gives for the lattice (fmt: HTKAMD_LAT_* bits, 0 = t v a l; with alignment records in
+    `lat` -- Decoder.run_lattice(align=...) -- and the model set `mmf` for the names: 0 = HVite's default t v a l d with durations and likelihoods)."""
     st, keep = _lattice_struct(lat, frame_dur)
     enc = lambda x: x.encode() if x is not None else None
+    if "arcAlignOff" in lat and mmf is not None:
+        ka = [np.ascontiguousarray(lat[k], dt) for k, dt in (("arcAlignOff", np.int32), ("alState", np.int32), ("alModel", np.int32), ("alDur", np.int32), ("alLike", np.float32))]
+        al = LatticeAlign(*[_p(x) for x in ka], 1 if lat.get("alignModels") else 0)
+        check(lib().htkamd_lattice_write_align(C.byref(st), C.byref(al), mmf.h, net.h, path.encode(), enc(utterance), enc(lm_name), enc(vocab_name), C.c_int(fmt or 0x3f8)), "lattice_write_align")
+        return
     check(lib().htkamd_lattice_write(C.byref(st), net.h, path.encode(), enc(utterance), enc(lm_name), enc(vocab_name), C.c_int(fmt or 0x78)), "lattice_write")
 
 
@@ -974,6 +988,31 @@ def lattice_nbest(lat: dict, net: "Net", N: int, frame_dur=0.01, max_len=4096):
             alt.append((int(lat["nodePron"][lat["arcEnd"][a_]]), int(lat["nodeFrame"][lat["arcStart"][a_]]), int(lat["nodeFrame"][lat["arcEnd"][a_]]),
                         float(L.htkamd_lattice_arc_score(C.byref(st), C.c_int(a_)))))
         out.append(alt)
+    return out
+
+
+def lattice_nbest_align(lat: dict, net: "Net", mmf: "Mmf", N: int, states=False, models=True, frame_dur=0.01, max_len=4096, flags=""):
+    """The N most likely alternatives as the label lines HVite -n N M -m / -f writes: htkamd_lattice_nbest for the arcs,
+    htkamd_lattice_align_trans for the labels of the arcs' alignment records, htkamd_trans_format (-o) and the label writer."""
+    import tempfile
+    st, keep = _lattice_struct(lat, frame_dur)
+    ka = [np.ascontiguousarray(lat[k], dt) for k, dt in (("arcAlignOff", np.int32), ("alState", np.int32), ("alModel", np.int32), ("alDur", np.int32), ("alLike", np.float32))]
+    al = LatticeAlign(*[_p(x) for x in ka], 1 if lat.get("alignModels") else 0)
+    nAlt = C.c_int(0); altLen = np.zeros(N, np.int32); arcs = np.zeros(N * max_len, np.int32)
+    check(lib().htkamd_lattice_nbest(C.byref(st), net.h, C.c_int(N), C.c_int(max_len), C.byref(nAlt), _p(altLen), _p(arcs)), "lattice_nbest")
+    out = []
+    L = lib()
+    for i in range(nAlt.value):
+        tr = C.c_void_p()
+        a_i = np.ascontiguousarray(arcs[i * max_len:i * max_len + int(altLen[i])], np.int32)
+        check(L.htkamd_lattice_align_trans(C.byref(st), C.byref(al), mmf.h, net.h, _p(a_i), C.c_int(len(a_i)), C.byref(tr)), "lattice_align_trans")
+        if not tr.value:
+            out.append(None); continue
+        check(L.htkamd_trans_format(tr, C.c_double(frame_dur * 1.0e7), C.c_int(int(states)), C.c_int(int(models)), C.c_int(sum(OUT_FLAGS[c] for c in flags))), "trans_format")
+        with tempfile.NamedTemporaryFile("r", suffix=".rec") as f:
+            check(L.htkamd_trans_write(tr, f.name.encode()), "trans_write")
+            out.append(open(f.name).read().splitlines())
+        L.htkamd_trans_free(tr)
     return out
 
 
@@ -1023,7 +1062,8 @@ class Decoder:
                 out.append(([(int(wp[o + i]), int(ws[o + i]), int(we[o + i]), float(sc[o + i])) for i in range(nW[u])], float(tot[u])))
         return out
 
-    def run_lattice(self, feats, nToks, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=None, wordPen=0.0, prScale=1.0, maxNodes=20000, maxArcs=80000, scoreMode=0, maxActive=0):
+    def run_lattice(self, feats, nToks, genBeam=1.0e10, wordBeam=1.0e10, nBeam=None, lmScale=None, wordPen=0.0, prScale=1.0, maxNodes=20000, maxArcs=80000, scoreMode=0, maxActive=0,
+                    align=0, maxAlign=400000):
         """HVite -n nToks [-u maxActive]: per utterance the lattice as a dict of arrays (oracle.decode_nbest's fields + nodePron), or None."""
         lmScale = self.lmScale if lmScale is None else float(lmScale)
         if lmScale != self.lmScale:
@@ -1039,8 +1079,16 @@ class Decoder:
         aSc = np.zeros(n1 * maxArcs, np.float64)
         out = LatticeOut(_p(nn), _p(na), _p(nF), _p(nP), _p(nNet), _p(nL), _p(aS), _p(aE), _p(aAc), _p(aLm), _p(aPr), _p(aSc), _p(tot))
         cfg = DecodeConfig(genBeam, wordBeam, lmScale, wordPen, prScale, scoreMode, int(maxActive))
-        check(lib().htkamd_decoder_run_lattice(self.h, C.byref(cfg), C.c_int(nToks), C.c_float(genBeam if nBeam is None else nBeam), dX.ptr, _p(frameOff), C.c_int(nU),
-                                               C.c_int(maxNodes), C.c_int(maxArcs), C.byref(out), None), "decoder_run_lattice")
+        if align:                                            # HVite -n with -m (1) / -f (2): lAlign of every arc
+            aOff = np.zeros(n1 * (maxArcs + 1), np.int32); alS = np.zeros(n1 * maxAlign, np.int32); alM = np.zeros_like(alS); alD = np.zeros_like(alS)
+            alL = np.zeros(n1 * maxAlign, np.float32)
+            alo = LatticeAlignOut(_p(aOff), _p(alS), _p(alM), _p(alD), _p(alL))
+            check(lib().htkamd_decoder_run_lattice_align(self.h, C.byref(cfg), C.c_int(nToks), C.c_float(genBeam if nBeam is None else nBeam), C.c_int(int(align)), dX.ptr,
+                                                         _p(frameOff), C.c_int(nU), C.c_int(maxNodes), C.c_int(maxArcs), C.c_int(maxAlign), C.byref(out), C.byref(alo), None),
+                  "decoder_run_lattice_align")
+        else:
+            check(lib().htkamd_decoder_run_lattice(self.h, C.byref(cfg), C.c_int(nToks), C.c_float(genBeam if nBeam is None else nBeam), dX.ptr, _p(frameOff), C.c_int(nU),
+                                                   C.c_int(maxNodes), C.c_int(maxArcs), C.byref(out), None), "decoder_run_lattice")
         res = []
         for u in range(nU):
             if nn[u] == -1:
@@ -1051,6 +1099,10 @@ class Decoder:
             res.append(dict(nodeFrame=nF[o:o + n].copy(), nodePron=nP[o:o + n].copy(), nodeNet=nNet[o:o + n].copy(), nodeLike=nL[o:o + n].copy(),
                             arcStart=aS[q:q + a_].copy(), arcEnd=aE[q:q + a_].copy(), arcAc=aAc[q:q + a_].copy(), arcLm=aLm[q:q + a_].copy(), arcPr=aPr[q:q + a_].copy(),
                             arcScore=aSc[q:q + a_].copy(), total=float(tot[u]), lmScale=lmScale, wordPen=float(wordPen), prScale=float(prScale)))
+            if align:
+                off = aOff[u * (maxArcs + 1):u * (maxArcs + 1) + a_ + 1].copy(); k = int(off[-1]); b = u * maxAlign
+                res[-1].update(arcAlignOff=off, alState=alS[b:b + k].copy(), alModel=alM[b:b + k].copy(), alDur=alD[b:b + k].copy(), alLike=alL[b:b + k].copy(),
+                               alignModels=bool(align & 1))
         return res
 
     def __del__(self):

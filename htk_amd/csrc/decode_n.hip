@@ -34,9 +34,11 @@
 
 struct __attribute__((aligned(16))) TSet {
    double like; float lm; int path;    // the best token
-   int n, pad;
+   int n, align;                       // align: Token.align (an index into the utterance's Align records, -1 = NULL; k_decode_ord_n with -m / -f)
    float rl[NT], rlm[NT]; int rp[NT];  // relative tokens; [0] mirrors the best (like 0)
+   int ra[NT];                         // RelToken.align (-DPHNALG)
 };
+struct __attribute__((aligned(8))) AlignRec { int node, state, frame, prev; double like; };      // Align (HRec.c:150-164)
 
 struct NArgs {
    DecNet net;
@@ -51,6 +53,10 @@ struct NArgs {
    int *nodePath;                                              // [nUtt * maxLatNodes] the Path record of a lattice node
    // k_decode_ord_n: the instance list (decode_ord.h) and Path records allocated one by one
    int *seq; int seqCap; int *pos; unsigned char *ooo; int *pathNode, *pathFrame; int pathExtra;
+   // ... and alignment records (HVite -n with -m: alignMode & 1 = pri->models, -f: & 2 = pri->states)
+   int alignMode; AlignRec *al; int alCap; int *alCount;          // [nUtt * alCap] records, [nUtt] records made
+   int *pathAlign, *altAlign;                                     // Path.align [paths], NxtPath.align [paths * (NT-1)]
+   int maxAlign; int *arcAlignOff, *alState, *alNode, *alDur; float *alLike;      // lAlign of the arcs: [nUtt * (maxLatArcs + 1)], [nUtt * maxAlign]
    float genBeam, wordBeam, nBeam, lmScale, wordPen, prScale;
    int nToks, maxActive;
    int maxLatNodes, maxLatArcs;
@@ -62,7 +68,7 @@ struct NArgs {
    double *total;
 };
 
-__device__ __forceinline__ void ts_null(TSet &s) { s.like = LZERO; s.lm = 0.0f; s.path = -1; s.n = 1; s.pad = 0; s.rl[0] = 0.0f; s.rlm[0] = 0.0f; s.rp[0] = -1; }
+__device__ __forceinline__ void ts_null(TSet &s) { s.like = LZERO; s.lm = 0.0f; s.path = -1; s.n = 1; s.align = -1; s.rl[0] = 0.0f; s.rlm[0] = 0.0f; s.rp[0] = -1; s.ra[0] = -1; }
 // the word-end node a path ends in (TokSetMerge compares path->node): the dense table's column, or -- Path records allocated one by one
 // (k_decode_ord_n) -- the record's node
 struct KeyOf {
@@ -71,25 +77,25 @@ struct KeyOf {
 };
 
 // TokSetMerge (HRec.c:279): token (cLike, cLm, cPath) with the relative tokens of `src` merged into `res`
-__device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TSet &src, float nThresh, int nToks, const KeyOf key_of)
+__device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TSet &src, float nThresh, int nToks, const KeyOf key_of, const int cAlign = -1)
 {
-   float tl[NT], tlm[NT]; int tp[NT]; int tn; double tLike;
+   float tl[NT], tlm[NT]; int tp[NT], ta[NT]; int tn; double tLike;
    if (cLike >= res.like) {
       if (!(cLike > nThresh)) return;
       if (res.like > nThresh) {                            // exchange
          tLike = res.like; tn = res.n;
-         for (int k = 0; k < res.n; k++) { tl[k] = res.rl[k]; tlm[k] = res.rlm[k]; tp[k] = res.rp[k]; }
-         res.like = cLike; res.lm = cLm; res.path = cPath; res.n = src.n;
-         for (int k = 0; k < src.n; k++) { res.rl[k] = src.rl[k]; res.rlm[k] = src.rlm[k]; res.rp[k] = src.rp[k]; }
+         for (int k = 0; k < res.n; k++) { tl[k] = res.rl[k]; tlm[k] = res.rlm[k]; tp[k] = res.rp[k]; ta[k] = res.ra[k]; }
+         res.like = cLike; res.lm = cLm; res.path = cPath; res.align = cAlign; res.n = src.n;
+         for (int k = 0; k < src.n; k++) { res.rl[k] = src.rl[k]; res.rlm[k] = src.rlm[k]; res.rp[k] = src.rp[k]; res.ra[k] = src.ra[k]; }
       } else {
-         res.like = cLike; res.lm = cLm; res.path = cPath; res.n = src.n;
-         for (int k = 0; k < src.n; k++) { res.rl[k] = src.rl[k]; res.rlm[k] = src.rlm[k]; res.rp[k] = src.rp[k]; }
+         res.like = cLike; res.lm = cLm; res.path = cPath; res.align = cAlign; res.n = src.n;
+         for (int k = 0; k < src.n; k++) { res.rl[k] = src.rl[k]; res.rlm[k] = src.rlm[k]; res.rp[k] = src.rp[k]; res.ra[k] = src.ra[k]; }
          return;
       }
    } else {
       if (!(cLike > nThresh)) return;
       tLike = cLike; tn = src.n;
-      for (int k = 0; k < src.n; k++) { tl[k] = src.rl[k]; tlm[k] = src.rlm[k]; tp[k] = src.rp[k]; }
+      for (int k = 0; k < src.n; k++) { tl[k] = src.rl[k]; tlm[k] = src.rlm[k]; tp[k] = src.rp[k]; ta[k] = src.ra[k]; }
    }
    const float diff = (float)(res.like - tLike);
    const float limit = (float)((double)nThresh - tLike);
@@ -100,13 +106,13 @@ __device__ void ts_merge(TSet &res, double cLike, float cLm, int cPath, const TS
       int mch = -1;
       for (int k = 0; k < res.n; k++) if (key_of(res.rp[k]) == key) { mch = k; break; }
       if (mch < 0) {
-         if (res.n < nToks) { mch = res.n++; res.rl[mch] = (float)LZERO; res.rlm[mch] = 0.0f; res.rp[mch] = -1; }
+         if (res.n < nToks) { mch = res.n++; res.rl[mch] = (float)LZERO; res.rlm[mch] = 0.0f; res.rp[mch] = -1; res.ra[mch] = -1; }
          else mch = res.n - 1;
       }
       if (like > res.rl[mch]) {
-         for (mch--; mch >= 0 && like > res.rl[mch]; mch--) { res.rl[mch + 1] = res.rl[mch]; res.rlm[mch + 1] = res.rlm[mch]; res.rp[mch + 1] = res.rp[mch]; }
+         for (mch--; mch >= 0 && like > res.rl[mch]; mch--) { res.rl[mch + 1] = res.rl[mch]; res.rlm[mch + 1] = res.rlm[mch]; res.rp[mch + 1] = res.rp[mch]; res.ra[mch + 1] = res.ra[mch]; }
          mch++;
-         res.rp[mch] = tp[i]; res.rlm[mch] = tlm[i]; res.rl[mch] = like;
+         res.rp[mch] = tp[i]; res.rlm[mch] = tlm[i]; res.ra[mch] = ta[i]; res.rl[mch] = like;
       }
    }
 }
@@ -159,6 +165,46 @@ __device__ void word_exit(const NArgs &a, const DecUtt &ud, int n, int t, const 
    e.n = 1; e.rl[0] = 0.0f; e.rlm[0] = 0.0f; e.rp[0] = e.path;
 }
 
+// lAlign of one arc (LatFromPaths HRec.c:1582-1656 with -DPHNALG): the arc's chain of records, latest first; a state record's likelihood
+// is the running difference, a model record closes the model met before it.  Returns the number of records, -1 if they do not fit.
+__device__ int emit_lalign(const NArgs &a, int sel, size_t outBase, int at, int a0, int pathFrame, double plike, float plm, double wp, int prevFrame, double prevLike, bool hasPrev)
+{
+   const AlignRec *AL = a.al + (size_t)sel * a.alCap;
+   int cnt = 0;
+   for (int al = a0; al >= 0; al = AL[al].prev) cnt++;
+   if (cnt == 0) return 0;
+   if (at + cnt > a.maxAlign) return -1;
+   int i = cnt, frame = pathFrame, prr = -1, labpr = -1;
+   double like = plike - plm * a.lmScale - wp;
+   for (int al = a0; al >= 0; al = AL[al].prev) {
+      const AlignRec A = AL[al];
+      int durF, labNode;
+      if (A.state < 0) {
+         if (prr < 0) { prr = al; labpr = A.node; continue; }
+         durF = AL[prr].frame - A.frame;
+         like = AL[prr].like - A.like;
+         prr = al;
+         labNode = labpr; labpr = A.node;
+      } else {
+         labNode = A.node;
+         durF = frame - A.frame;
+         like = like - A.like;
+         frame = A.frame;
+      }
+      i--;
+      a.alState[outBase + at + i] = A.state; a.alNode[outBase + at + i] = labNode; a.alDur[outBase + at + i] = durF; a.alLike[outBase + at + i] = (float)like;
+      like = A.like;
+   }
+   if (prr >= 0) {
+      int durF;
+      if (hasPrev) { durF = AL[prr].frame - prevFrame; like = AL[prr].like - prevLike; }
+      else { durF = AL[prr].frame; like = AL[prr].like; }
+      i--;
+      a.alState[outBase + at + i] = -1; a.alNode[outBase + at + i] = labpr; a.alDur[outBase + at + i] = durF; a.alLike[outBase + at + i] = (float)like;
+   }
+   return cnt;
+}
+
 // CompleteRecognition (HRec.c:2054) -> CreateLattice (:1679): MarkPaths (:1664) numbers the Path records reachable from the final token
 // set depth first, LatFromPaths (:1512) makes every Path / NxtPath an arc.  By ONE thread.  Where a Path record lies: the dense
 // [frame][word node] table of k_decode_n, or records allocated one by one with their frame and node beside them (k_decode_ord_n).
@@ -168,7 +214,7 @@ struct PathView {
    __device__ __forceinline__ int node(int p) const { return pathNode ? pathNode[p] : wordNode[p % nW]; }
 };
 
-__device__ void build_lattice(const NArgs &a, const DecUtt &ud, int u, const TSet &fin, const PathView pv)
+__device__ void build_lattice(const NArgs &a, const DecUtt &ud, int u, const TSet &fin, const PathView pv, const int sel = 0)
 {
    const DecNet &N = a.net;
    const int T = ud.T;
@@ -205,7 +251,8 @@ __device__ void build_lattice(const NArgs &a, const DecUtt &ud, int u, const TSe
    }
 #undef VISIT
    if (overflow || nl > a.maxLatArcs) { latN[0] = -3; return; }
-   int ln = 0;
+   int ln = 0, nAl = 0;
+   const size_t aob = (size_t)u * (a.maxLatArcs + 1), alb = (size_t)u * a.maxAlign;
    // arcs of the root
    for (int c = 0; c < fin.n; c++) {
       const int prev = (c == 0) ? fin.path : fin.rp[c];
@@ -214,6 +261,12 @@ __device__ void build_lattice(const NArgs &a, const DecUtt &ud, int u, const TSe
       const double prlk = (prev >= 0) ? a.pathLike[ud.path0 + prev] : 0.0;
       a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = 1;
       a.arcAc[ab + ln] = (float)(plike - prlk - plm * a.lmScale - 0.0); a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = 0.0f; a.arcScore[ab + ln] = plike;
+      if (a.alignMode) {
+         a.arcAlignOff[aob + ln] = nAl;
+         const int r = emit_lalign(a, sel, alb, nAl, (c == 0) ? fin.align : fin.ra[c], T, plike, plm, 0.0, (prev >= 0) ? pv.frame(prev) : 0, prlk, prev >= 0);
+         if (r < 0) { latN[0] = -3; return; }
+         nAl += r;
+      }
       ln++;
    }
    for (int i = 2; i < nn; i++) {
@@ -232,9 +285,16 @@ __device__ void build_lattice(const NArgs &a, const DecUtt &ud, int u, const TSe
          ac -= pr * a.prScale;
          a.arcStart[ab + ln] = (prev >= 0) ? a.mark[ud.path0 + prev] : 0; a.arcEnd[ab + ln] = i;
          a.arcAc[ab + ln] = ac; a.arcLm[ab + ln] = plm; a.arcPr[ab + ln] = pr; a.arcScore[ab + ln] = plike;
+         if (a.alignMode) {
+            a.arcAlignOff[aob + ln] = nAl;
+            const int r = emit_lalign(a, sel, alb, nAl, (c == 0) ? a.pathAlign[ud.path0 + p] : a.altAlign[z], pv.frame(p), plike, plm, wp, (prev >= 0) ? pv.frame(prev) : 0, prlk, prev >= 0);
+            if (r < 0) { latN[0] = -3; return; }
+            nAl += r;
+         }
          ln++;
       }
    }
+   if (a.alignMode) a.arcAlignOff[aob + ln] = nAl;
    latN[0] = nn; latN[1] = ln;
 }
 
@@ -468,6 +528,16 @@ __global__ __launch_bounds__(DEC_THREADS) void k_decode_n(NArgs a)
 // which of two alternatives of nearly equal likelihood survives.  The run therefore always walks the list.  Pass 1 = k_decode_n's
 // StepHMM1 over the list's instances; pass 2 = the walk of k_decode_ord with token sets pushed along the links in link order, each
 // merge by one lane on the set in global memory; StepWord2 allocates its Path record (+ NxtPaths) per call.
+// NewNRefAlign (HRec.c:598-622): records are allocated one by one per utterance (any thread; their numbers are not part of any result)
+__device__ __forceinline__ int new_align(const NArgs &a, int sel, int node, int state, double like, int frame, int prev)
+{
+   const int i = atomicAdd(&a.alCount[sel], 1);
+   if (i >= a.alCap) return -1;                          // (counted: the utterance ends as "did not fit")
+   AlignRec r; r.node = node; r.state = state; r.frame = frame; r.prev = prev; r.like = like;
+   a.al[(size_t)sel * a.alCap + i] = r;
+   return i;
+}
+
 __device__ void word_exit_ord(const NArgs &a, const DecUtt &ud, int n, int t, const TSet &st, TSet &e, int pid, int *pathNode, int *pathFrame)
 {
    const DecNet &N = a.net;
@@ -477,12 +547,14 @@ __device__ void word_exit_ord(const NArgs &a, const DecUtt &ud, int n, int t, co
    a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
    pathNode[pid] = n; pathFrame[pid] = t;
    a.altN[ud.path0 + pid] = st.n - 1;
+   if (a.alignMode) a.pathAlign[ud.path0 + pid] = st.align;
    for (int k = 1; k < st.n; k++) {
       const size_t z = (ud.path0 + pid) * (NT - 1) + (k - 1);
       a.altLike[z] = e.like + st.rl[k]; a.altLm[z] = st.rlm[k]; a.altPrev[z] = st.rp[k];
+      if (a.alignMode) a.altAlign[z] = st.ra[k];
    }
-   e.path = pid; e.lm = 0.0f;
-   e.n = 1; e.rp[0] = e.path;                            // rl[0] / rlm[0] stay what the exit set held (AttachInst's rmax: 0, 0)
+   e.path = pid; e.lm = 0.0f; e.align = -1;
+   e.n = 1; e.rp[0] = e.path;                            // rl[0] / rlm[0] / ra[0] stay what the exit set held (AttachInst's rmax: 0, 0, NULL)
 }
 
 __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
@@ -512,7 +584,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
      for (int i = tid; i < N.nTok; i += ORD_THREADS) { cur[i] = z; nxt[i] = z; }
      for (int i = tid; i < N.nNodes; i += ORD_THREADS) { ex[i] = z; imax[i] = LZERO; pos[i] = -1; ooo[i] = 0; } }
    for (size_t i = tid; i < pathCap; i += ORD_THREADS) a.mark[ud.path0 + i] = 0;
-   if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; thr[2] = (float)LSMALL; sh.tail = 0; sh.nPath = 0; sh.status = 0; sh.base = 0; sh.cn = 0; }
+   if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; thr[2] = (float)LSMALL; sh.tail = 0; sh.nPath = 0; sh.status = 0; sh.base = 0; sh.cn = 0; if (a.alignMode) a.alCount[sel] = 0; }
    __syncthreads();
    OrdCtx c;
    c.N = &N; c.seq = seqA; c.pos = pos; c.ooo = ooo; c.imax = imax; c.seqCap = a.seqCap; c.sh = &sh;
@@ -605,8 +677,8 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
             const int4 ni = N.nodeInfo[n];
             const int NS = (ni.x >> 4) & 255, t0 = ni.y;
             if ((ni.x & 15) != HTKAMD_NODE_HMM) {             // StepWord1 (HRec.c:1038): the sets' relative tokens stay as they are
-               TSet z = cur[t0]; z.like = LZERO; z.lm = 0.0f; z.path = -1; z.n = 1; nxt[t0] = z;
-               TSet ze = ex[n]; ze.like = LZERO; ze.lm = 0.0f; ze.path = -1; ze.n = 1; ex[n] = ze;
+               TSet z = cur[t0]; z.like = LZERO; z.lm = 0.0f; z.path = -1; z.align = -1; z.n = 1; nxt[t0] = z;
+               TSet ze = ex[n]; ze.like = LZERO; ze.lm = 0.0f; ze.path = -1; ze.align = -1; ze.n = 1; ex[n] = ze;
                imax[n] = LZERO;
                continue;
             }
@@ -622,16 +694,24 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
                res.like += tp[(lo - 1) * NS + (j - 1)];
                for (int i = lo + 1; i <= hi; i++) {
                   const TSet &si = cur[t0 + i - 1];
-                  ts_merge(res, si.like + tp[(i - 1) * NS + (j - 1)], si.lm, si.path, si, nT, a.nToks, ko);
+                  ts_merge(res, si.like + tp[(i - 1) * NS + (j - 1)], si.lm, si.path, si, nT, a.nToks, ko, si.align);
                }
                if (res.like > gT) {
                   const int st = N.hmmState[ni.w + (j - 2)];
-                  res.like += a.score[ud.score0 + (size_t)(t - 1) * a.ns + N.stateSlot[st]];
+                  const float outp = a.score[ud.score0 + (size_t)(t - 1) * a.ns + N.stateSlot[st]];
+                  res.like += outp;
                   if (res.like > mx) mx = res.like;
-               } else { res.like = LZERO; res.lm = 0.0f; res.path = -1; res.n = 1; }
+                  if (a.alignMode & 2) {                       // pri->states (HRec.c:680-704, -DPHNALG): a record where a token enters state j
+                     const double alk = res.like - outp - res.lm * a.lmScale;
+                     const AlignRec *AL = a.al + (size_t)sel * a.alCap;
+                     if (res.align < 0 || AL[res.align].state != j || AL[res.align].node != n) { res.align = new_align(a, sel, n, j, alk, t - 1, res.align); res.ra[0] = res.align; }
+                     for (int q = 1; q < res.n; q++)
+                        if (res.ra[q] < 0 || AL[res.ra[q]].state != j || AL[res.ra[q]].node != n) res.ra[q] = new_align(a, sel, n, j, alk, t - 1, res.ra[q]);
+                  }
+               } else { res.like = LZERO; res.lm = 0.0f; res.path = -1; res.align = -1; res.n = 1; }
                nxt[t0 + j - 1] = res;
             }
-            { TSet z = cur[t0]; z.like = LZERO; z.lm = 0.0f; z.path = -1; z.n = 1; nxt[t0] = z; }          // entry consumed
+            { TSet z = cur[t0]; z.like = LZERO; z.lm = 0.0f; z.path = -1; z.align = -1; z.n = 1; nxt[t0] = z; }          // entry consumed
             {
                int lo = 2, hi = NS - 1;
                while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
@@ -641,13 +721,18 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
                res.like += tp[(lo - 1) * NS + (NS - 1)];
                for (int i = lo + 1; i <= hi; i++) {
                   const TSet &si = nxt[t0 + i - 1];
-                  ts_merge(res, si.like + tp[(i - 1) * NS + (NS - 1)], si.lm, si.path, si, nT, a.nToks, ko);
+                  ts_merge(res, si.like + tp[(i - 1) * NS + (NS - 1)], si.lm, si.path, si, nT, a.nToks, ko, si.align);
                }
                if (res.like > LSMALL) {
-                  exS = res;
                   const double w = res.like + N.wdlk[n];
                   if (w > myWord) myWord = w;
-               } else { exS = res; exS.like = LZERO; exS.lm = 0.0f; exS.path = -1; exS.n = 1; }
+                  if ((a.alignMode & 1) && !((ni.x >> 12) & 1)) {      // pri->models, not a tee model (HRec.c:762-776): the model's exit record per token
+                     const double alk = res.like - res.lm * a.lmScale;
+                     res.align = new_align(a, sel, n, -1, alk, t, res.align); res.ra[0] = res.align;
+                     for (int q = 1; q < res.n; q++) res.ra[q] = new_align(a, sel, n, -1, alk, t, res.ra[q]);
+                  }
+                  exS = res;
+               } else { exS = res; exS.like = LZERO; exS.lm = 0.0f; exS.path = -1; exS.align = -1; exS.n = 1; }
             }
             if (mx > myGen) myGen = mx;
             ex[n] = exS; imax[n] = (double)(float)mx;
@@ -700,9 +785,9 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
                      else {
                         TSet e = ex[n];
                         const TSet st = cur[t0];
-                        const float r0 = e.rl[0], m0 = e.rlm[0];
+                        const float r0 = e.rl[0], m0 = e.rlm[0]; const int a0 = e.ra[0];
                         word_exit_ord(a, ud, n, t, st, e, pid, pathNode, pathFrame);
-                        e.rl[0] = r0; e.rlm[0] = m0;
+                        e.rl[0] = r0; e.rlm[0] = m0; e.ra[0] = a0;
                         vs->nPath = pid + 1;
                         ex[n] = e;
                      }
@@ -710,7 +795,12 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
                   else if ((ni.x >> 12) & 1) {              // tee model: StepHMM2 (HRec.c:790)
                      const TSet st = cur[t0];
                      TSet e = ex[n];
-                     ts_merge(e, st.like + tpBase[ni.z + (NS - 1)], st.lm, st.path, st, nT, a.nToks, ko);
+                     ts_merge(e, st.like + tpBase[ni.z + (NS - 1)], st.lm, st.path, st, nT, a.nToks, ko, st.align);
+                     if (a.alignMode & 1) {                   // HRec.c:817-832
+                        const double alk = e.like - e.lm * a.lmScale;
+                        e.align = new_align(a, sel, n, -1, alk, t, e.align); e.ra[0] = e.align;
+                        for (int q = 1; q < e.n; q++) e.ra[q] = new_align(a, sel, n, -1, alk, t, e.ra[q]);
+                     }
                      ex[n] = e;
                   }
                }
@@ -748,7 +838,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
                            TSet x = e;
                            for (int q = 0; q < x.n; q++) x.rlm[q] = e.rlm[q] + lm;
                            TSet res = cur[td];
-                           ts_merge(res, xl, tkLm + lm, e.path, x, nT, a.nToks, ko);
+                           ts_merge(res, xl, tkLm + lm, e.path, x, nT, a.nToks, ko, e.align);
                            cur[td] = res;
                            const double m0 = imax[d];
                            if (res.like > m0) {
@@ -772,18 +862,38 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord_n(NArgs a)
       if (sh.status != 0) break;
    }
    if (tid == 0) {
+      if (a.alignMode && a.alCount[sel] > a.alCap) sh.status = -4;                 // more alignment records than there was room for
       if (sh.status != 0) { a.total[u] = LZERO; a.latN[2 * u] = sh.status == -4 ? -3 : sh.status; a.latN[2 * u + 1] = 0; }
       else {
          TSet fin; ts_null(fin);
          if (pos[N.final] >= 0) fin = ex[N.final];
-         build_lattice(a, ud, u, fin, PathView{pathFrame, pathNode, N.nWordNodes, N.wordNode});
+         build_lattice(a, ud, u, fin, PathView{pathFrame, pathNode, N.nWordNodes, N.wordNode}, sel);
       }
    }
 }
 
 // ------------------------------------------------------------------------------------ host side
+static int run_lattice_impl(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, const float *dX, const int *frameOff, int nUtt,
+                            int maxLatNodes, int maxLatArcs, const htkamd_lattice_out *out, int alignMode, int maxAlign, const htkamd_lattice_align_out *alOut, void *stream);
+
 extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, const float *dX, const int *frameOff, int nUtt,
                                           int maxLatNodes, int maxLatArcs, const htkamd_lattice_out *out, void *stream)
+{
+   return run_lattice_impl(d, cfg, nToks, nBeam, dX, frameOff, nUtt, maxLatNodes, maxLatArcs, out, 0, 0, nullptr, stream);
+}
+
+extern "C" int htkamd_decoder_run_lattice_align(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, int alignMode, const float *dX, const int *frameOff,
+                                                int nUtt, int maxLatNodes, int maxLatArcs, int maxAlign, const htkamd_lattice_out *out, const htkamd_lattice_align_out *alOut,
+                                                void *stream)
+{
+   if (alignMode < 0 || alignMode > 3 || (alignMode && (maxAlign < 1 || !alOut || !alOut->arcAlignOff || !alOut->alState || !alOut->alModel || !alOut->alDur || !alOut->alLike))) {
+      htkamd_set_error("decoder_run_lattice_align: bad argument"); return HTKAMD_EINVAL;
+   }
+   return run_lattice_impl(d, cfg, nToks, nBeam, dX, frameOff, nUtt, maxLatNodes, maxLatArcs, out, alignMode, maxAlign, alOut, stream);
+}
+
+static int run_lattice_impl(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, const float *dX, const int *frameOff, int nUtt,
+                            int maxLatNodes, int maxLatArcs, const htkamd_lattice_out *out, int alignMode, int maxAlign, const htkamd_lattice_align_out *alOut, void *stream)
 {
    if (!d || !cfg || !frameOff || nUtt < 0 || !out || !out->nNodes || !out->nArcs || maxLatNodes < 2 || maxLatArcs < 1) { htkamd_set_error("decoder_run_lattice: bad argument"); return HTKAMD_EINVAL; }
    if (nToks < 2 || nToks > NT) { htkamd_set_error("decoder_run_lattice: nToks = %d (2..%d tokens per state)", nToks, NT); return HTKAMD_EINVAL; }
@@ -797,6 +907,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
    // alternative's likelihood, so "exact" is the default here, not a fallback
    int orderMode = d->orderMode;
    if (const char *ev = getenv("HTKAMD_DECODE_ORDER")) orderMode = !strcmp(ev, "fast") ? HTKAMD_ORDER_FAST : !strcmp(ev, "exact") ? HTKAMD_ORDER_EXACT : HTKAMD_ORDER_AUTO;
+   if (alignMode && orderMode == HTKAMD_ORDER_FAST) { htkamd_set_error("decoder_run_lattice_align: alignment records need the list kernel (not HTKAMD_ORDER_FAST)"); return HTKAMD_EINVAL; }
    const bool listOrder = orderMode != HTKAMD_ORDER_FAST;
    const size_t pathMul = listOrder ? 3 : 1, pathExtra = listOrder ? 64 : 0;       // StepWord2 "may be repeated" (HRec.c:1046)
    const int seqCap = 8 * N.nNodes + 1024;
@@ -859,6 +970,20 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          a.seq = (int *)A(sizeof(int) * (size_t)nu * 2 * seqCap); a.seqCap = seqCap; a.pos = (int *)A(sizeof(int) * node); a.ooo = (unsigned char *)A(node);
          a.pathNode = (int *)A(path * 4); a.pathFrame = (int *)A(path * 4); a.pathExtra = (int)pathExtra;
       }
+      int maxT = 0;
+      for (int k = 0; k < nu; k++) maxT = std::max(maxT, utt[k].T);
+      if (alignMode) {
+         // Align records: one per token of a set where it enters a state (-f) and where it leaves a model (-m), never freed within an
+         // utterance (the reference collects garbage; here the utterance must fit): frames x model nodes x tokens x (states + 1), capped
+         size_t cap = (size_t)(maxT + 1) * (size_t)N.nHmm * (size_t)nToks * (size_t)((alignMode & 2 ? 3 : 0) + (alignMode & 1 ? 1 : 0));
+         if (cap > ((size_t)1 << 27)) cap = (size_t)1 << 27;
+         if (cap * (size_t)nu * sizeof(AlignRec) > ((size_t)16 << 30)) cap = ((size_t)16 << 30) / ((size_t)nu * sizeof(AlignRec));
+         a.alignMode = alignMode; a.alCap = (int)cap; a.al = (AlignRec *)A(sizeof(AlignRec) * cap * nu); a.alCount = (int *)A(sizeof(int) * nu);
+         a.pathAlign = (int *)A(path * 4); a.altAlign = (int *)A(path * 4 * (NT - 1));
+         a.maxAlign = maxAlign; a.arcAlignOff = (int *)A(sizeof(int) * (size_t)nu * (maxLatArcs + 1));
+         a.alState = (int *)A(sizeof(int) * (size_t)nu * maxAlign); a.alNode = (int *)A(sizeof(int) * (size_t)nu * maxAlign); a.alDur = (int *)A(sizeof(int) * (size_t)nu * maxAlign);
+         a.alLike = (float *)A(sizeof(float) * (size_t)nu * maxAlign);
+      }
       if (!rc) {
          hipError_t e;
          if ((e = hipMemcpyAsync(dUtt, utt.data(), sizeof(DecUtt) * nu, hipMemcpyHostToDevice, s)) != hipSuccess ||
@@ -879,11 +1004,7 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
          else if (cfg->scoreMode != HTKAMD_SCORE_EXACT && cfg->scoreMode != HTKAMD_SCORE_MFMA && cfg->scoreMode != HTKAMD_SCORE_BF16) { htkamd_set_error("decoder_run_lattice: unknown score mode %d", cfg->scoreMode); rc = HTKAMD_EINVAL; }
          else rc = htkamd_launch_score(cfg->scoreMode, m, sa, s);
       }
-      if (!rc) {
-         int maxT = 0;
-         for (int k = 0; k < nu; k++) maxT = std::max(maxT, utt[k].T);
-         rc = htkamd_launch_score_transpose((const float *)dScore, (float *)dScoreT, (const DecUtt *)dUtt, nu, maxT, ns, s);
-      }
+      if (!rc) rc = htkamd_launch_score_transpose((const float *)dScore, (float *)dScoreT, (const DecUtt *)dUtt, nu, maxT, ns, s);
       if (!rc) {
          a.net = N; a.utt = (const DecUtt *)dUtt; a.nUtt = nu; a.score = (const float *)dScoreT; a.ns = ns;
          a.genBeam = cfg->genBeam; a.wordBeam = cfg->wordBeam; a.nBeam = nBeam; a.lmScale = cfg->lmScale; a.wordPen = cfg->wordPen; a.prScale = cfg->prScale;
@@ -909,6 +1030,25 @@ extern "C" int htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode
 #undef D2H
       } else (void)hipStreamSynchronize(s);
       if (rc) return rc;
+      if (alignMode) {
+         std::vector<int> hOff((size_t)nu * (maxLatArcs + 1)), hSt((size_t)nu * maxAlign), hNd(hSt.size()), hDu(hSt.size()); std::vector<float> hLk(hSt.size());
+         hipError_t e;
+         if ((e = hipMemcpy(hOff.data(), a.arcAlignOff, sizeof(int) * hOff.size(), hipMemcpyDeviceToHost)) != hipSuccess ||
+             (e = hipMemcpy(hSt.data(), a.alState, sizeof(int) * hSt.size(), hipMemcpyDeviceToHost)) != hipSuccess ||
+             (e = hipMemcpy(hNd.data(), a.alNode, sizeof(int) * hNd.size(), hipMemcpyDeviceToHost)) != hipSuccess ||
+             (e = hipMemcpy(hDu.data(), a.alDur, sizeof(int) * hDu.size(), hipMemcpyDeviceToHost)) != hipSuccess ||
+             (e = hipMemcpy(hLk.data(), a.alLike, sizeof(float) * hLk.size(), hipMemcpyDeviceToHost)) != hipSuccess) { htkamd_set_error("decoder_run_lattice_align: %s", hipGetErrorString(e)); return HTKAMD_EHIP; }
+         for (int k = 0; k < nu; k++) {
+            const int uu = u0 + k;
+            const int na = hN[2 * k] > 0 ? hN[2 * k + 1] : 0;
+            for (int i = 0; i <= na; i++) alOut->arcAlignOff[(size_t)uu * (maxLatArcs + 1) + i] = hOff[(size_t)k * (maxLatArcs + 1) + i];
+            const int nr = na > 0 ? hOff[(size_t)k * (maxLatArcs + 1) + na] : 0;
+            for (int i = 0; i < nr; i++) {
+               const size_t o = (size_t)uu * maxAlign + i, si = (size_t)k * maxAlign + i;
+               alOut->alState[o] = hSt[si]; alOut->alModel[o] = d->hostModel[hNd[si]]; alOut->alDur[o] = hDu[si]; alOut->alLike[o] = hLk[si];
+            }
+         }
+      }
       for (int k = 0; k < nu; k++) {
          const int uu = u0 + k;
          out->nNodes[uu] = hN[2 * k]; out->nArcs[uu] = hN[2 * k + 1];

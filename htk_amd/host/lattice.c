@@ -6,7 +6,7 @@
  *                          backward pass, then A* over partial paths ordered by like + completion, hypotheses with the word sequence
  *                          of an earlier answer dropped (WordMatch :2166);
  *   htkamd_lattice_arc_score   LArcTotLike (HNet.h:257), the label score.
- * Alignment records inside arcs (-q d/m/n with -m/-f) are not produced by the token-set kernel and not written.
+ * Alignment records inside arcs (HVite -n with -m / -f): htkamd_lattice_write_align, OutputAlign (HNet.c:503-516).
  */
 #include <math.h>
 #include <stdio.h>
@@ -58,8 +58,15 @@ float htkamd_lattice_arc_score(const htkamd_lattice *lat, int arc) { return (flo
 int htkamd_lattice_write(const htkamd_lattice *lat, const struct htkamd_net *net, const char *path, const char *utterance, const char *lmName,
                          const char *vocabName, int format)
 {
-   if (!lat || !net || !path || lat->nNodes < 2 || lat->nArcs < 1) { htkamd_set_error("lattice_write: bad argument"); return HTKAMD_EINVAL; }
-   if (format & (HTKAMD_LAT_ALIGN | HTKAMD_LAT_LBIN | HTKAMD_LAT_ALABS)) { htkamd_set_error("lattice_write: -q A / B / d are not supported"); return HTKAMD_EINVAL; }
+   if (format & HTKAMD_LAT_ALIGN) { htkamd_set_error("lattice_write: -q d wants the alignment records (htkamd_lattice_write_align)"); return HTKAMD_EINVAL; }
+   return htkamd_lattice_write_align(lat, NULL, NULL, net, path, utterance, lmName, vocabName, format);
+}
+
+int htkamd_lattice_write_align(const htkamd_lattice *lat, const htkamd_lattice_align *al, const struct htkamd_mmf *hmms, const struct htkamd_net *net, const char *path,
+                               const char *utterance, const char *lmName, const char *vocabName, int format)
+{
+   if (!lat || !net || !path || lat->nNodes < 2 || lat->nArcs < 1 || (al && !hmms)) { htkamd_set_error("lattice_write: bad argument"); return HTKAMD_EINVAL; }
+   if (format & (HTKAMD_LAT_LBIN | HTKAMD_LAT_ALABS)) { htkamd_set_error("lattice_write: -q A / B are not supported"); return HTKAMD_EINVAL; }
    FILE *f = fopen(path, "w");
    if (!f) { htkamd_set_error("lattice_write: cannot create %s", path); return HTKAMD_EIO; }
    fprintf(f, "VERSION=1.0\n");
@@ -94,11 +101,70 @@ int htkamd_lattice_write(const htkamd_lattice *lat, const struct htkamd_net *net
       if (format & HTKAMD_LAT_ACLIKE) fprintf(f, "a=%-9.2f ", lat->arcAc[a]);
       if (format & HTKAMD_LAT_LMLIKE) fprintf(f, "l=%-7.3f ", lat->arcLm[a]);
       if (format & HTKAMD_LAT_PRLIKE) fprintf(f, "r=%-6.2f ", lat->arcPr[a]);
+      if (al && (format & HTKAMD_LAT_ALIGN) && al->arcAlignOff[a + 1] > al->arcAlignOff[a]) {      /* OutputAlign (HNet.c:503-516) */
+         fprintf(f, "d=:");
+         for (int q = al->arcAlignOff[a]; q < al->arcAlignOff[a + 1]; q++) {
+            const char *mn = htkamd_mmf_phys_name(hmms, al->alModel[q]);
+            if (al->alState[q] < 0) fprintf(f, "%s", mn ? mn : "?");
+            else if (al->models) fprintf(f, "s%d", al->alState[q]);
+            else fprintf(f, "%s[%d]", mn ? mn : "?", al->alState[q]);
+            if (format & HTKAMD_LAT_ALDUR) fprintf(f, ",%.2f", (float)(al->alDur[q] * lat->frameDur));
+            if (format & HTKAMD_LAT_ALLIKE) fprintf(f, ",%.2f", al->alLike[q]);
+            fprintf(f, ":");
+         }
+      }
       fprintf(f, "\n");
    }
    free(order); free(rorder);
    g_lat = NULL; g_rank = NULL;
    if (fclose(f)) { htkamd_set_error("lattice_write: write error on %s", path); return HTKAMD_EIO; }
+   return HTKAMD_OK;
+}
+
+/* TranscriptionFromLattice's label list for ONE alternative whose arcs carry alignment records (HRec.c:2284-2338): a label per model
+   record (-m) or per state record (-f, the model then an auxiliary label of its first state), the WORD as the last auxiliary label of the
+   arc's first label, scores = the records' likelihoods, times accumulated from the arc's start in the records' float durations. */
+int htkamd_lattice_align_trans(const htkamd_lattice *lat, const htkamd_lattice_align *al, const struct htkamd_mmf *hmms, const struct htkamd_net *net,
+                               const int *arcs, int nArcs, htkamd_trans **out)
+{
+   if (!lat || !al || !hmms || !net || !arcs || nArcs < 0 || !out) { htkamd_set_error("lattice_align_trans: bad argument"); return HTKAMD_EINVAL; }
+   int states = 0, models = 0;
+   for (int i = 0; i < nArcs; i++) {
+      const int a = arcs[i];
+      if (lat->nodePron[lat->arcEnd[a]] < 0) continue;                      /* !NULL */
+      if (al->arcAlignOff[a + 1] == al->arcAlignOff[a]) { *out = NULL; return HTKAMD_OK; }      /* an arc without records: word labels (the caller's) */
+      for (int q = al->arcAlignOff[a]; q < al->arcAlignOff[a + 1]; q++) { if (al->alState[q] < 0) models = 1; else if (al->alState[q] > 0) states = 1; }
+   }
+   const int nAux = states + models;
+   if (nAux == 0) { *out = NULL; return HTKAMD_OK; }
+   htkamd_trans *tr;
+   int rc = htkamd_trans_create(nAux, &tr);
+   if (rc) return rc;
+   for (int i = 0; i < nArcs; i++) {
+      const int a = arcs[i], pron = lat->nodePron[lat->arcEnd[a]];
+      if (pron < 0) continue;
+      const char *word = htkamd_net_word_name(net, pron), *model = NULL;
+      const float lmf = lat->arcLm[a] * lat->lmScale;                      /* LArcTotLMLike (HNet.h:252) */
+      float lm = (float)((double)lmf + (double)lat->wordPen), modlk = 0.0f;
+      double start = (lat->nodeFrame[lat->arcStart[a]] * lat->frameDur) * 1.0E7;
+      for (int q = al->arcAlignOff[a]; q < al->arcAlignOff[a + 1]; q++) {
+         const char *mn = htkamd_mmf_phys_name(hmms, al->alModel[q]);
+         char buf[300];
+         const char *label;
+         if (al->alState[q] < 0) label = mn;
+         else { if (al->models) snprintf(buf, sizeof(buf), "s%d", al->alState[q]); else snprintf(buf, sizeof(buf), "%s[%d]", mn ? mn : "?", al->alState[q]); label = buf; }
+         if (al->alState[q] < 0 && states) { model = label; modlk = al->alLike[q]; continue; }
+         const float dur = (float)(al->alDur[q] * lat->frameDur);
+         const double end = start + dur * 1.0E7;
+         const char *a1 = NULL, *a2 = NULL; float s1 = 0.0f, s2 = 0.0f;
+         if (models && states) { a1 = model; s1 = modlk; model = NULL; modlk = 0.0f; a2 = word; s2 = lm; }
+         else { a1 = word; s1 = lm; }
+         rc = htkamd_trans_add(tr, start, end, label, al->alLike[q], a1, s1, a2, s2);
+         if (rc) { htkamd_trans_free(tr); return rc; }
+         start = end; word = NULL; lm = 0.0f;
+      }
+   }
+   *out = tr;
    return HTKAMD_OK;
 }
 

@@ -616,6 +616,20 @@ typedef struct {
 } htkamd_lattice_out;
 int  htkamd_decoder_run_lattice(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, const float *dX, const int *frameOff, int nUtt,
                                 int maxLatNodes, int maxLatArcs, const htkamd_lattice_out *out, void *stream);
+/* The same with alignment records inside the arcs (HVite -n together with -m: alignMode & 1, model records / -f: alignMode & 2, state
+ * records; LatFromPaths' lAlign, HRec.c:1582-1656, as the reference built with -DPHNALG -- HTKLib/Makefile.in:45 -- writes it: the records
+ * of a relative token carry the BEST token's likelihoods, so an alternative's alignment likelihoods need not add up to its arc's).  Arc j
+ * of utterance u owns records [arcAlignOff[u*(maxLatArcs+1) + j], .. + j + 1) of alState (-1: a model record) / alModel (physical model)
+ * / alDur (frames) / alLike at u*maxAlign + i.  Alignment records are kept for the whole utterance on the device (frames x models x
+ * tokens of them): meant for rescoring-size networks.  nNodes[u] = -3 also when they (or maxAlign) do not fit. */
+typedef struct {
+   int *arcAlignOff;
+   int *alState, *alModel, *alDur;
+   float *alLike;
+} htkamd_lattice_align_out;
+int  htkamd_decoder_run_lattice_align(htkamd_decoder *d, const htkamd_decode_config *cfg, int nToks, float nBeam, int alignMode, const float *dX, const int *frameOff,
+                                      int nUtt, int maxLatNodes, int maxLatArcs, int maxAlign, const htkamd_lattice_out *out, const htkamd_lattice_align_out *alOut,
+                                      void *stream);
 /* One utterance's lattice for the host-side functions below (pointers into the arrays above). */
 typedef struct {
    int nNodes, nArcs;
@@ -639,6 +653,26 @@ typedef struct {
 #define HTKAMD_LAT_DEFAULT (HTKAMD_LAT_TIMES | HTKAMD_LAT_PRON | HTKAMD_LAT_ACLIKE | HTKAMD_LAT_LMLIKE)
 int  htkamd_lattice_write(const htkamd_lattice *lat, const htkamd_net *net, const char *path, const char *utterance, const char *lmName,
                           const char *vocabName, int format);
+/* ... with the arcs' alignment records (htkamd_decoder_run_lattice_align) as WriteLattice's OutputAlign writes them (HNet.c:503-516):
+ * `d=:label[,duration][,likelihood]: ...` per arc that has records -- label = the physical model's name for a model record, "s<j>" for a
+ * state record when model records were made too (models != 0), "<model>[<j>]" otherwise; format bits HTKAMD_LAT_ALIGN / _ALDUR / _ALLIKE
+ * (HVite's default -q is all of t v a l d with durations and likelihoods: HTKAMD_LAT_DEFAULT_ALIGN). */
+typedef struct {
+   const int *arcAlignOff;              /* [nArcs + 1] */
+   const int *alState, *alModel, *alDur;
+   const float *alLike;
+   int models;
+} htkamd_lattice_align;
+#define HTKAMD_LAT_ALDUR  0x0100
+#define HTKAMD_LAT_ALLIKE 0x0200
+#define HTKAMD_LAT_DEFAULT_ALIGN 0x03f8
+int  htkamd_lattice_write_align(const htkamd_lattice *lat, const htkamd_lattice_align *al, const htkamd_mmf *hmms, const htkamd_net *net, const char *path,
+                                const char *utterance, const char *lmName, const char *vocabName, int format);
+/* TranscriptionFromLattice's label list for ONE alternative (arcs from htkamd_lattice_nbest) whose arcs carry alignment records
+ * (HRec.c:2284-2338): model labels (-m), state labels (-f; with -m too the model rides as their first auxiliary label), the word as the last
+ * auxiliary label of an arc's first label.  *out = NULL when an arc of the alternative has no records (word labels are then the caller's). */
+int  htkamd_lattice_align_trans(const htkamd_lattice *lat, const htkamd_lattice_align *al, const htkamd_mmf *hmms, const htkamd_net *net,
+                                const int *arcs, int nArcs, htkamd_trans **out);
 /* TranscriptionFromLattice (HRec.c:2176) with N > 1: the N most likely paths with distinct word sequences, best first.  Alternative i has
  * altLen[i] arcs altArcs[i*maxLen + 0..], start to end, the closing arc into the end node left out. */
 int  htkamd_lattice_nbest(const htkamd_lattice *lat, const htkamd_net *net, int N, int maxLen, int *nAlt, int *altLen, int *altArcs);

@@ -21,7 +21,9 @@ DEC = os.path.join(HERE, "decode")
 # case, lattice, features, tokens, transcriptions, other switches
 CASES = [("bigram", "net", "feats", 4, 3, "-t 250.0"), ("bigram", "net", "feats", 2, 2, "-t 250.0 -s 2.0 -p -5.0 -r 1.5"), ("loop", "net", "feats", 3, 3, "-t 250.0"),
          ("tee", "net", "feats", 3, 2, "-t 250.0"), ("xwrd", "loop", "feats_loop", 4, 3, "-t 250.0"),
-         ("bigram", "net", "feats", 3, 2, "-t 250.0 -u 6"), ("loop", "net", "feats", 3, 3, "-t 250.0 -u 5"), ("tee", "net", "feats", 4, 2, "-t 250.0 -u 4")]   # -u: maximum-model pruning with token sets
+         ("bigram", "net", "feats", 3, 2, "-t 250.0 -u 6"), ("loop", "net", "feats", 3, 3, "-t 250.0 -u 5"), ("tee", "net", "feats", 4, 2, "-t 250.0 -u 4"),   # -u: maximum-model pruning with token sets
+         # -m / -f together with -n (the reference is built with -DPHNALG): alignment records inside the lattice arcs (d=), model / state level alternatives
+         ("loop", "net", "feats", 3, 3, "-t 250.0 -m"), ("bigram", "net", "feats", 4, 2, "-t 250.0 -f"), ("tee", "net", "feats", 3, 2, "-t 250.0 -m -f"), ("wint", "net", "feats", 3, 2, "-t 250.0 -m")]
 
 
 def main():

@@ -18,7 +18,9 @@ def _case(native, tag):
     meta = json.load(open(os.path.join(NB, tag, "nbest.json")))
     name = meta["case"] + (":" + meta["slf"] if meta["slf"] != "net" else "")
     mmf, net, feats, _ = load_decode_case(native, name)
-    p = parse_opts(meta["opts"])
+    t = meta["opts"].split()
+    meta["align"] = (1 if "-m" in t else 0) | (2 if "-f" in t else 0)      # -m / -f with -n: alignment records inside the arcs (HRec.c:1582-1656)
+    p = parse_opts(" ".join(x for x in t if x not in ("-m", "-f")))
     return meta, mmf, net, feats, p
 
 
@@ -33,10 +35,15 @@ def _labels(alt, net, frame_dur=100000):
     return ["%d %d %s %f" % (s * frame_dur, e * frame_dur, net.out_syms[w], np.float32(sc)) for w, s, e, sc in alt if w >= 0 and net.out_syms[w] != ""]
 
 
-def _check_files(native, lat, net, meta, tag, u, tmp_path):
+def _check_files(native, lat, net, meta, tag, u, tmp_path, mmf=None):
     out = str(tmp_path / ("u%d.lat" % u))
-    native.lattice_write(lat, net, out, utterance="nbtmp/u%d.mfc" % u, lm_name=meta["slf"] + ".slf", vocab_name="dict")
+    native.lattice_write(lat, net, out, utterance="nbtmp/u%d.mfc" % u, lm_name=meta["slf"] + ".slf", vocab_name="dict", mmf=mmf if meta["align"] else None)
     assert open(out).read() == open(os.path.join(NB, tag, "u%d.lat" % u)).read(), (tag, u)
+    if meta["align"]:
+        # model / state level alternatives: TranscriptionFromLattice over the arcs' records, HVite's -o formatting, the label file's lines
+        alts = native.lattice_nbest_align(lat, net, mmf, meta["nTrans"], states=bool(meta["align"] & 2), models=bool(meta["align"] & 1))
+        assert alts == meta["nbest"]["u%d" % u], (tag, u)
+        return
     alts = native.lattice_nbest(lat, net, meta["nTrans"])
     assert [_labels(a, net) for a in alts] == meta["nbest"]["u%d" % u], (tag, u)
 
@@ -47,11 +54,13 @@ def test_oracle_token_sets_and_host_lattice_code_equal_hvite(native, oracle, tag
     om = oracle.Model(mmf.packed())
     n = 0
     for u, X in enumerate(feats):
-        lat = oracle.decode_nbest(om, X, net.arrays(), meta["nToks"], **p)
+        lat = oracle.decode_nbest(om, X, net.arrays(), meta["nToks"], align=meta["align"], **p)
         assert lat is not None
         lat = _with_prons(lat, net)
         lat.update(lmScale=p["lmScale"], wordPen=p["wordPen"], prScale=p["prScale"])
-        _check_files(native, lat, net, meta, tag, u, tmp_path)
+        if meta["align"]:
+            lat["alModel"] = np.array([net.arrays()["model"][n] for n in lat["alNode"]], np.int32); lat["alignModels"] = bool(meta["align"] & 1)
+        _check_files(native, lat, net, meta, tag, u, tmp_path, mmf)
         n += len(lat["arcStart"])
     assert n > 20
 
@@ -63,9 +72,9 @@ def test_token_set_kernel_equals_oracle_and_hvite(native, oracle, tag, tmp_path)
     model = native.Model(mmf.packed())
     om = oracle.Model(mmf.packed())
     dec = native.Decoder(model, net, lmScale=p["lmScale"])
-    lats = dec.run_lattice(feats, meta["nToks"], **p)
+    lats = dec.run_lattice(feats, meta["nToks"], align=meta["align"], **p)
     for u, X in enumerate(feats):
-        ref = oracle.decode_nbest(om, X, net.arrays(), meta["nToks"], **p)
+        ref = oracle.decode_nbest(om, X, net.arrays(), meta["nToks"], align=meta["align"], **p)
         got = lats[u]
         assert got is not None and ref is not None
         assert got["total"] == ref["total"]
@@ -73,7 +82,17 @@ def test_token_set_kernel_equals_oracle_and_hvite(native, oracle, tag, tmp_path)
             assert np.array_equal(got[k], ref[k]), (tag, u, k)
         arcs = lambda l: sorted(zip(l["arcStart"].tolist(), l["arcEnd"].tolist(), l["arcAc"].tolist(), l["arcLm"].tolist(), l["arcPr"].tolist(), l["arcScore"].tolist()))
         assert arcs(got) == arcs(ref), (tag, u)                     # the order in which the arcs are listed is not part of the lattice
-        _check_files(native, got, net, meta, tag, u, tmp_path)
+        if meta["align"]:                                           # every arc's records: the oracle's, value for value
+            am = net.arrays()["model"]
+            def recs(l, model_of):
+                out = []
+                for j in range(len(l["arcStart"])):
+                    a0, a1 = int(l["arcAlignOff"][j]), int(l["arcAlignOff"][j + 1])
+                    out.append((int(l["arcStart"][j]), int(l["arcEnd"][j]), float(l["arcScore"][j]),
+                                tuple((int(l["alState"][q]), int(model_of(l, q)), int(l["alDur"][q]), float(l["alLike"][q])) for q in range(a0, a1))))
+                return sorted(out)
+            assert recs(got, lambda l, q: l["alModel"][q]) == recs(ref, lambda l, q: am[l["alNode"][q]]), (tag, u)
+        _check_files(native, got, net, meta, tag, u, tmp_path, mmf)
 
 
 @pytest.mark.gpu

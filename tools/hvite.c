@@ -205,7 +205,7 @@ int main(int argc, char **argv)
    if (files.n == 0) DIE("hvite: no data files");
    if (!align && !netPath) DIE("hvite: either -w net or -a");
    if (nToks == 1 || nToks > 8) DIE("hvite -n: 2..8 tokens per state");
-   if (nToks > 1 && (models || states || align)) DIE("hvite: alignment using multiple tokens is not supported");       /* HVite.c:448 */
+   if (nToks > 1 && align) DIE("hvite: alignment using multiple tokens is not supported");       /* HVite.c:448 (-m / -f with -n: as the reference built with -DPHNALG, alignment records inside the lattice arcs) */
    if (latExt && nToks < 2) DIE("hvite -z: lattices need -n i with i > 1");
    if (htkamd_device_count() <= 0) DIE("hvite: no HIP device (the MI355X path has no CPU fallback)");
 
@@ -265,6 +265,14 @@ int main(int argc, char **argv)
             lo.nNodes = nN; lo.nArcs = nA; lo.nodeFrame = nodeFrame; lo.nodePron = nodePron; lo.nodeLike = nodeLike; lo.arcStart = aS; lo.arcEnd = aE; lo.arcAc = aAc; lo.arcLm = aLm; lo.arcPr = aPr;
             int *fo = (int *)malloc(sizeof(int) * (size_t)(nb + 1));
             for (int u = 0; u <= nb; u++) fo[u] = ob.frameOff[b0 + u] - ob.frameOff[b0];
+            /* -m / -f together with -n: alignment records inside the arcs (LatFromPaths' lAlign) */
+            const int alMode = (models ? 1 : 0) | (states ? 2 : 0), maxAl = alMode ? 4 * maxA : 0;
+            htkamd_lattice_align_out ao; memset(&ao, 0, sizeof(ao));
+            if (alMode) {
+               ao.arcAlignOff = (int *)malloc(sizeof(int) * (size_t)nb * (maxA + 1)); ao.alState = (int *)malloc(sizeof(int) * (size_t)nb * maxAl);
+               ao.alModel = (int *)malloc(sizeof(int) * (size_t)nb * maxAl); ao.alDur = (int *)malloc(sizeof(int) * (size_t)nb * maxAl); ao.alLike = (float *)malloc(sizeof(float) * (size_t)nb * maxAl);
+               CHECK(htkamd_decoder_run_lattice_align(dec, &dc, nToks, dc.genBeam, alMode, ob.dX + (size_t)ob.frameOff[b0] * ob.cols, fo, nb, maxN, maxA, maxAl, &lo, &ao, NULL));
+            } else
             CHECK(htkamd_decoder_run_lattice(dec, &dc, nToks, dc.genBeam, ob.dX + (size_t)ob.frameOff[b0] * ob.cols, fo, nb, maxN, maxA, &lo, NULL));   /* nBeam = genBeam (HVite.c:546) */
             for (int u = 0; u < nb; u++) {
                const char *fn = files.v[first + b0 + u];
@@ -275,14 +283,26 @@ int main(int argc, char **argv)
                lat.arcStart = aS + (size_t)u * maxA; lat.arcEnd = aE + (size_t)u * maxA; lat.arcAc = aAc + (size_t)u * maxA; lat.arcLm = aLm + (size_t)u * maxA; lat.arcPr = aPr + (size_t)u * maxA;
                lat.lmScale = lmScale; lat.wordPen = wordPen; lat.prScale = prScale; lat.frameDur = (double)ob.period * 1.0e-7;
                char out[2048];
-               if (latExt) { make_fn(fn, outDir, latExt, out, sizeof(out)); CHECK(htkamd_lattice_write(&lat, net, out, fn, netPath, dictPath, latFmt ? latFmt : HTKAMD_LAT_DEFAULT)); }
+               htkamd_lattice_align la; memset(&la, 0, sizeof(la));
+               if (alMode) {
+                  la.arcAlignOff = ao.arcAlignOff + (size_t)u * (maxA + 1); la.alState = ao.alState + (size_t)u * maxAl; la.alModel = ao.alModel + (size_t)u * maxAl;
+                  la.alDur = ao.alDur + (size_t)u * maxAl; la.alLike = ao.alLike + (size_t)u * maxAl; la.models = models;
+               }
+               if (latExt) {
+                  make_fn(fn, outDir, latExt, out, sizeof(out));
+                  if (alMode) CHECK(htkamd_lattice_write_align(&lat, &la, mmf, net, out, fn, netPath, dictPath, latFmt ? latFmt : HTKAMD_LAT_DEFAULT_ALIGN));
+                  else CHECK(htkamd_lattice_write(&lat, net, out, fn, netPath, dictPath, latFmt ? latFmt : HTKAMD_LAT_DEFAULT));
+               }
                /* "only output 1-best transcription if generating lattices" (HVite.c:797) */
                const int want = (nTrans > 1 && latExt) ? 1 : nTrans;
                int nAlt = 0, *altLen = (int *)malloc(sizeof(int) * (size_t)want), *altArcs = (int *)malloc(sizeof(int) * (size_t)want * maxWords);
                CHECK(htkamd_lattice_nbest(&lat, net, want, maxWords, &nAlt, altLen, altArcs));
                htkamd_trans *head = NULL;
                for (int i = 0; i < nAlt; i++) {
-                  htkamd_trans *tr; CHECK(htkamd_trans_create(0, &tr));
+                  htkamd_trans *tr = NULL;
+                  if (alMode) CHECK(htkamd_lattice_align_trans(&lat, &la, mmf, net, altArcs + (size_t)i * maxWords, altLen[i], &tr));      /* model / state labels from the arcs' records */
+                  if (tr) { if (!head) head = tr; else CHECK(htkamd_trans_append_alternative(head, tr)); continue; }
+                  CHECK(htkamd_trans_create(0, &tr));
                   for (int j = 0; j < altLen[i]; j++) {
                      const int arc = altArcs[(size_t)i * maxWords + j], pron = lat.nodePron[lat.arcEnd[arc]];
                      const char *sym = pron >= 0 ? htkamd_net_out_sym(net, pron) : NULL;
@@ -293,7 +313,7 @@ int main(int argc, char **argv)
                   if (!head) head = tr; else CHECK(htkamd_trans_append_alternative(head, tr));
                }
                if (head) {
-                  CHECK(htkamd_trans_format(head, (double)ob.period, 0, 0, oflags));
+                  CHECK(htkamd_trans_format(head, (double)ob.period, alMode ? states : 0, alMode ? models : 0, oflags));
                   make_fn(fn, outDir, outExt, out, sizeof(out));
                   if (mout) CHECK(htkamd_mlf_out_add(mout, out, head)); else CHECK(htkamd_trans_write(head, out));
                   htkamd_trans_free(head);
@@ -301,6 +321,7 @@ int main(int argc, char **argv)
                free(altLen); free(altArcs);
             }
             free(nN); free(nA); free(nodeFrame); free(nodePron); free(nodeLike); free(aS); free(aE); free(aAc); free(aLm); free(aPr); free(fo);
+            free(ao.arcAlignOff); free(ao.alState); free(ao.alModel); free(ao.alDur); free(ao.alLike);
          }
          free_observations(&ob);
          continue;
