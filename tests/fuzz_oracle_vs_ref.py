@@ -187,7 +187,10 @@ def fuzz_decode(rng, it, tmp):
         k, mtr = int(rng.integers(2, 7)), int(rng.integers(2, 5))
         rel = [os.path.basename(f) for f in scp]
         open(os.path.join(d, "scp_rel"), "w").write("\n".join(rel) + "\n")
-        base = [os.path.join(REF, "HVite"), "-C", "config", "-H", "MMF", "-S", "scp_rel", "-w", "net.slf"] + opts
+        # a third of the cases with -m / -f: alignment records inside the arcs (LatFromPaths' lAlign, the reference built with -DPHNALG)
+        al_mode = int(rng.integers(1, 4)) if rng.random() < 0.33 else 0
+        al_opts = (["-m"] if al_mode & 1 else []) + (["-f"] if al_mode & 2 else [])
+        base = [os.path.join(REF, "HVite"), "-C", "config", "-H", "MMF", "-S", "scp_rel", "-w", "net.slf"] + opts + al_opts
         subprocess.run(base + ["-l", ".", "-n", str(k), "1", "-z", "lat", "dict", "hmmlist"], cwd=d, capture_output=True, text=True)
         subprocess.run(base + ["-i", "nb.mlf", "-n", str(k), str(mtr), "dict", "hmmlist"], cwd=d, capture_output=True, text=True)
         nb, cur = {}, None
@@ -203,7 +206,7 @@ def fuzz_decode(rng, it, tmp):
                     nb[cur][-1].append(line)
         arr = net.arrays()
         for u, X in enumerate(s.feats):
-            lat = pyoracle.decode_nbest(om, X, arr, k, **p)
+            lat = pyoracle.decode_nbest(om, X, arr, k, align=al_mode, **p)
             ref_lat = os.path.join(d, "u%d.lat" % u)
             if lat is None:
                 if os.path.exists(ref_lat):
@@ -212,11 +215,16 @@ def fuzz_decode(rng, it, tmp):
             lat["nodePron"] = np.array([arr["model"][n] if n >= 0 else -1 for n in lat["nodeNet"]], np.int32)
             lat.update(lmScale=p["lmScale"], wordPen=p["wordPen"], prScale=p["prScale"])
             mine = os.path.join(d, "u%d.mylat" % u)
-            capi.lattice_write(lat, net, mine, utterance=rel[u], lm_name="net.slf", vocab_name="dict")
+            if al_mode:
+                lat["alModel"] = np.array([arr["model"][n] for n in lat["alNode"]], np.int32); lat["alignModels"] = bool(al_mode & 1)
+            capi.lattice_write(lat, net, mine, utterance=rel[u], lm_name="net.slf", vocab_name="dict", mmf=mmf if al_mode else None)
             if not os.path.exists(ref_lat) or not _lat_same(open(mine).read(), open(ref_lat).read(), xwrd):
                 ok = False; print("NBEST it %d u%d k=%d params %s: lattice files differ (%s)" % (it, u, k, p, d))
-            alts = capi.lattice_nbest(lat, net, mtr)
-            got = [["%d %d %s %f" % (st_ * 100000, en_ * 100000, net.out_syms[w], np.float32(sc)) for w, st_, en_, sc in a if w >= 0 and net.out_syms[w] != ""] for a in alts]
+            if al_mode:
+                got = capi.lattice_nbest_align(lat, net, mmf, mtr, states=bool(al_mode & 2), models=bool(al_mode & 1))
+            else:
+                alts = capi.lattice_nbest(lat, net, mtr)
+                got = [["%d %d %s %f" % (st_ * 100000, en_ * 100000, net.out_syms[w], np.float32(sc)) for w, st_, en_, sc in a if w >= 0 and net.out_syms[w] != ""] for a in alts]
             if open(mine).read() == open(ref_lat).read() and not _labels_same(got, nb.get("u%d" % u)):
                 ok = False; print("NBEST it %d u%d k=%d m=%d params %s:\n  oracle %s\n  HVite  %s" % (it, u, k, mtr, p, got, nb.get("u%d" % u)))
     if not ok and os.environ.get("FUZZ_KEEP"):
