@@ -293,13 +293,21 @@ def fuzz_decode(rng, it, tmp):
             print("DECODE it %d u%d params %s\n  gpu    %s\n  oracle %s" % (it, u, p, words_g, ow))
     if rng.random() < 0.4:                   # token sets (HVite -n k): the kernel's lattice == the oracle's
         k = int(rng.integers(2, 9))
-        lats = capi.Decoder(model, net, lmScale=p["lmScale"]).run_lattice(s.feats, k, **p)
+        al = int(rng.integers(1, 4)) if rng.random() < 0.35 else 0            # -m / -f with -n: alignment records inside the arcs
+        lats = capi.Decoder(model, net, lmScale=p["lmScale"]).run_lattice(s.feats, k, align=al, **p)
+        am = net.arrays()["model"]
         for u, got in enumerate(lats):
-            ref = pyoracle.decode_nbest(om, s.feats[u], net.arrays(), k, **p)
+            ref = pyoracle.decode_nbest(om, s.feats[u], net.arrays(), k, align=al, **p)
             same = (got is None) == (ref is None)
             if same and got is not None:
                 arcs = lambda l: sorted(zip(l["arcStart"].tolist(), l["arcEnd"].tolist(), l["arcAc"].tolist(), l["arcLm"].tolist(), l["arcPr"].tolist(), l["arcScore"].tolist()))
                 same = got["total"] == ref["total"] and all(np.array_equal(got[f], ref[f]) for f in ("nodeFrame", "nodeNet", "nodeLike")) and arcs(got) == arcs(ref)
+                if same and al:
+                    def recs(l, mo):
+                        return sorted((int(l["arcStart"][j]), int(l["arcEnd"][j]), float(l["arcScore"][j]),
+                                       tuple((int(l["alState"][q]), int(mo(l, q)), int(l["alDur"][q]), float(l["alLike"][q])) for q in range(int(l["arcAlignOff"][j]), int(l["arcAlignOff"][j + 1]))))
+                                      for j in range(len(l["arcStart"])))
+                    same = recs(got, lambda l, q: l["alModel"][q]) == recs(ref, lambda l, q: am[l["alNode"][q]])
             if not same:
                 ok = False
                 print("NBEST it %d u%d k=%d params %s: kernel %s, oracle %s" % (it, u, k, p, None if got is None else (len(got["nodeFrame"]), len(got["arcStart"])),
