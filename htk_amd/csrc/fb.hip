@@ -457,7 +457,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) {
             kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8;
             // every model left-to-right without skips: the kernels of fb_lr.hip (no statistics in the alpha chain, no entry-state columns)
-            bool lr = !fb->noLrPath && fb->m->NSt == 1 && !fb->m->tiedMix;      // several streams: the dense seed array feeds k_mixstats_ms
+            bool lr = !fb->noLrPath;      // (several streams / tied mixtures too since round 4: their pairs go to the list with the chain state's slot, k_mixhits_streams)
             for (int q = 0; q < d.Q && lr; q++) if (fb->m->h_transLR[fb->mTrans[d.q0 + q]] != 1) lr = false;
             if (lr) kind = 2;
          }
@@ -639,6 +639,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          return rc;
       fa.alphaW = (double *)fb->d_alphaW.p; fa.qBeam = (int *)fb->d_qBeam.p; fa.aBeam = (int *)fb->d_aBeam.p; fa.trPart = (double *)fb->d_trPart.p;
       fa.hits = (MixHit *)fb->d_hits.p; fa.hitCtl = (int *)fb->d_hitCtl.p; fa.nHitRegions = (int)rows; fa.hitRegionCap = htkamd_stats_lr_region_cap();
+      fa.hitSlots = (m->NSt > 1 || m->tiedMix) ? 1 : 0;
    }
    static const int clsW[4] = {1, 2, 4, 8};
    // the longest chains first: their recursions are the critical path of the pass
@@ -682,8 +683,15 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          fa.rec = (MixRec *)fb->d_rec.p; fa.recSorted = (MixRec *)fb->d_recSorted.p; fa.recCap = (int)cap; fa.G = m->G; fa.recCtl = (int *)fb->d_recCtl.p;
       }
       // the dense seed array serves the utterances off the left-to-right path; those on it list their pairs (k_stats_lr -> k_mixhits)
-      if (m->tiedMix) { fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr; if ((rc = htkamd_launch_mixstats_tm(fa, s))) return rc; }
-      else if (m->NSt > 1) { fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr; if ((rc = htkamd_launch_mixstats_ms(fa, s))) return rc; }
+      if (m->tiedMix) {
+         fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr;
+         if (fb->nUtt > nLr && (rc = htkamd_launch_mixstats_tm(fa, s))) return rc;
+         if (nLr > 0 && (rc = htkamd_launch_mixhits_streams(fa, true, s))) return rc;
+      } else if (m->NSt > 1) {
+         fa.stateCompOff = m->d_stateCompOff; fa.rec = nullptr;
+         if (fb->nUtt > nLr && (rc = htkamd_launch_mixstats_ms(fa, s))) return rc;
+         if (nLr > 0 && (rc = htkamd_launch_mixhits_streams(fa, false, s))) return rc;
+      }
       else if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
    }
    HIPCHECK(hipEventRecord(fb->ev[5], s));

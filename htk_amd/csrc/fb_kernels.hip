@@ -1077,6 +1077,77 @@ int htkamd_launch_combine_streams(const FbArgs &a, hipStream_t s)
 // the posteriors and lane = dimension for the first- and second-order sums (only the dimensions of the component's stream).
 // seed = initx (the state's log occupation without its own output probability) when some stream of the set has several components,
 // else log alpha + log beta - pr.
+// one surviving (frame, chain state) pair of a multi-stream set: every stream's components, posteriors and sums (by ONE wavefront)
+__device__ void ms_pair(const FbArgs &a, const UttDesc *up, const int t0, const int slot, const double seed, const int lane)
+{
+   const int D = a.D, NSt = a.NSt;
+   const double minF = (double)a.minFrwdP;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   const int nSl = up->nSlots, T = up->T;
+   const int e0 = a.slotState[up->slot0 + slot];
+   const float *xrow = a.X + (size_t)(up->frame0 + t0) * D;
+   const float oS = a.outp[up->outp0 + (size_t)slot * T + t0];
+   for (int ks = 0; ks < NSt; ks++) {
+      const int e = e0 + ks, c0 = a.stateCompOff[e], M = a.stateCompOff[e + 1] - c0;
+      const float oK = a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
+      const float others = oS - oK;                              // outprob[s][0] after Setotprob (HFB.c:1064)
+      for (int mb = 0; mb < M; mb += 64) {
+         const int m = mb + lane;
+         bool pass = false;
+         double Lr = 0.0;
+         int g = 0;
+         if (m < M) {
+            const float wt = a.compLogWt[c0 + m];
+            g = a.compGauss[c0 + m];
+            if (wt > (float)LMINMIX) {
+               double x;
+               if (M == 1) x = (a.maxM == 1) ? seed : seed + (double)oS;        // !mmix: log alpha + log beta - pr (HFB.c:1584)
+               else {
+                  const float *P = a.gparam + (size_t)g * a.PS;
+                  float sum = P[2 * D];
+                  for (int k = 0; k < D; k++) {
+                     const float xmm = xrow[k] - P[2 * k];
+                     sum += xmm * xmm * P[2 * k + 1];
+                  }
+                  const float prob = -0.5f * sum;
+                  x = seed + (double)wt;
+                  x += (double)prob;
+                  x += (double)others;                                            // "adjust for parallel streams" (HFB.c:1611)
+               }
+               if (-x < minF) { pass = true; Lr = exp(x); }
+            }
+         }
+         double sumLr = pass ? Lr : 0.0;
+#pragma unroll
+         for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
+         if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + e, sumLr);
+         if (pass) {
+            if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+            if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+            if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+         }
+         unsigned long long pm = __ballot(pass);
+         while (pm) {
+            const int ml = __ffsll((long long)pm) - 1;
+            pm &= pm - 1;
+            const double L = __shfl(Lr, ml);
+            const int gg = __shfl(g, ml);
+            const float *mean = a.mean + (size_t)gg * D;
+            for (int k = lane; k < D; k += 64) {
+               if (a.dimStream[k] != ks) continue;
+               const float z = xrow[k] - mean[k];
+               if (upMu && upVa) {                    // HFB.c:1673-1678
+                  const float zl = (float)((double)z * L);
+                  atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+                  atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
+               } else if (upMu) atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
+               else if (upVa) atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
+            }
+         }
+      }
+   }
+}
+
 __global__ __launch_bounds__(256) void k_mixstats_ms(FbArgs a)
 {
    __shared__ unsigned short hitIdx[4][512];
@@ -1107,74 +1178,50 @@ __global__ __launch_bounds__(256) void k_mixstats_ms(FbArgs a)
          const double seed = hSeed[i];
          while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
          const UttDesc *up = a.utt + u;
-         if (a.status[u] != HTKAMD_UTT_OK) continue;
-         const int nSl = up->nSlots, T = up->T;
+         if (a.status[u] != HTKAMD_UTT_OK || up->pad == 2) continue;      // (an utterance of the left-to-right path has no seeds here: its pairs are listed)
+         const int nSl_ = up->nSlots;
          const size_t rel = hidx - up->gam0;
-         const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
-         const int e0 = a.slotState[up->slot0 + slot];
-         const float *xrow = a.X + (size_t)(up->frame0 + t0) * D;
-         const float oS = a.outp[up->outp0 + (size_t)slot * T + t0];
-         for (int ks = 0; ks < NSt; ks++) {
-            const int e = e0 + ks, c0 = a.stateCompOff[e], M = a.stateCompOff[e + 1] - c0;
-            const float oK = a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
-            const float others = oS - oK;                              // outprob[s][0] after Setotprob (HFB.c:1064)
-            for (int mb = 0; mb < M; mb += 64) {
-               const int m = mb + lane;
-               bool pass = false;
-               double Lr = 0.0;
-               int g = 0;
-               if (m < M) {
-                  const float wt = a.compLogWt[c0 + m];
-                  g = a.compGauss[c0 + m];
-                  if (wt > (float)LMINMIX) {
-                     double x;
-                     if (M == 1) x = (a.maxM == 1) ? seed : seed + (double)oS;        // !mmix: log alpha + log beta - pr (HFB.c:1584)
-                     else {
-                        const float *P = a.gparam + (size_t)g * a.PS;
-                        float sum = P[2 * D];
-                        for (int k = 0; k < D; k++) {
-                           const float xmm = xrow[k] - P[2 * k];
-                           sum += xmm * xmm * P[2 * k + 1];
-                        }
-                        const float prob = -0.5f * sum;
-                        x = seed + (double)wt;
-                        x += (double)prob;
-                        x += (double)others;                                            // "adjust for parallel streams" (HFB.c:1611)
-                     }
-                     if (-x < minF) { pass = true; Lr = exp(x); }
-                  }
-               }
-               double sumLr = pass ? Lr : 0.0;
-#pragma unroll
-               for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
-               if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + e, sumLr);
-               if (pass) {
-                  if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
-                  if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
-                  if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
-               }
-               unsigned long long pm = __ballot(pass);
-               while (pm) {
-                  const int ml = __ffsll((long long)pm) - 1;
-                  pm &= pm - 1;
-                  const double L = __shfl(Lr, ml);
-                  const int gg = __shfl(g, ml);
-                  const float *mean = a.mean + (size_t)gg * D;
-                  for (int k = lane; k < D; k += 64) {
-                     if (a.dimStream[k] != ks) continue;
-                     const float z = xrow[k] - mean[k];
-                     if (upMu && upVa) {                    // HFB.c:1673-1678
-                        const float zl = (float)((double)z * L);
-                        atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
-                        atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
-                     } else if (upMu) atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
-                     else if (upVa) atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
-                  }
-               }
-            }
-         }
+         ms_pair(a, up, (int)(rel / nSl_), (int)(rel % nSl_), seed, lane);
       }
    }
+}
+
+__device__ void tm_pair(const FbArgs &a, const UttDesc *up, const int t0, const int slot, const double seed, const int lane);
+// The same from the LISTS of k_stats_lr (left-to-right chains, round 4): a wavefront per region, a pair after the other.  A record of
+// these sets carries the pair's GLOBAL slot (FbArgs::hitSlots) -- the statistics want the chain state's own stream scores -- and the
+// utterance is found from it (the slots of a batch ascend with the utterances).
+template <bool TIED>
+__global__ __launch_bounds__(256) void k_mixhits_streams(FbArgs a)
+{
+   const int lane = threadIdx.x & 63;
+   const int nWaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+   const int waveId = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+   for (int b = waveId; b < a.nHitRegions; b += nWaves) {
+      const int cnt = a.hitCtl[b];
+      const MixHit *reg = a.hits + (size_t)b * a.hitRegionCap;
+      int u = 0;
+      for (int i = 0; i < cnt; i++) {
+         const MixHit h = reg[i];
+         if (i == 0 || h.st < a.utt[u].slot0 || h.st >= a.utt[u].slot0 + a.utt[u].nSlots) {      // (a region lies within one utterance: searched once)
+            int lo = 0, hi = a.nUtt - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.utt[mid].slot0 <= h.st) lo = mid; else hi = mid - 1; }
+            u = lo;
+         }
+         const UttDesc *up = a.utt + u;
+         if (a.status[u] != HTKAMD_UTT_OK) continue;
+         if (TIED) tm_pair(a, up, h.frame - up->frame0, h.st - up->slot0, h.seed, lane);
+         else ms_pair(a, up, h.frame - up->frame0, h.st - up->slot0, h.seed, lane);
+      }
+   }
+}
+
+int htkamd_launch_mixhits_streams(const FbArgs &a, bool tied, hipStream_t s)
+{
+   if (a.nHitRegions <= 0) return HTKAMD_OK;
+   if (tied) hipLaunchKernelGGL(k_mixhits_streams<true>, dim3(4096), dim3(256), 0, s, a);
+   else hipLaunchKernelGGL(k_mixhits_streams<false>, dim3(4096), dim3(256), 0, s, a);
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
 }
 
 int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s)
@@ -1290,6 +1337,70 @@ int htkamd_tm_score_block(const htkamd_model *m, const ScoreArgs &sa, int nRows,
 
 // UpMixParms, TIEDHS (HFB.c:1503-1507, 1559-1563, 1590-1612): the kept pool entries of the frame; a component's log probability is
 // log(scaled probability) + maximum, as the reference recovers it from the table PrecomputeTMix left
+// one surviving (frame, chain state) pair of a tied-mixture set: the kept pool entries of every stream (by ONE wavefront)
+__device__ void tm_pair(const FbArgs &a, const UttDesc *up, const int t0, const int slot, const double seed, const int lane)
+{
+   const int D = a.D, NSt = a.NSt;
+   const double minF = (double)a.minFrwdP;
+   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
+   const int nSl = up->nSlots, T = up->T;
+   const int e0 = a.slotState[up->slot0 + slot];
+   const size_t row = (size_t)up->frame0 + t0;
+   const float *xrow = a.X + row * D;
+   const float oS = a.outp[up->outp0 + (size_t)slot * T + t0];
+   for (int ks = 0; ks < NSt; ks++) {
+      const int e = e0 + ks, c0 = a.stateCompOff[e], p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
+      const float maxP = a.tmMaxP[row * NSt + ks];
+      float others = 0.0f;
+      if (NSt > 1) others = oS - a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
+      for (int mb = 0; mb < M; mb += 64) {
+         const int m = mb + lane;
+         bool pass = false;
+         double Lr = 0.0;
+         int g = 0;
+         if (m < M) {
+            const float ev = a.tmE[row * a.tmPool + p0 + m];
+            const float wt = a.compLogWt[c0 + m];
+            g = a.compGauss[c0 + m];
+            if (ev >= 0.0f && wt > (float)LMINMIX) {
+               const float prob = ((double)ev >= MINLARG) ? (float)(log((double)ev) + (double)maxP) : (float)LZERO;
+               double x = seed + (double)wt;
+               x += (double)prob;
+               if (NSt > 1) x += (double)others;
+               if (-x < minF) { pass = true; Lr = exp(x); }
+            }
+         }
+         double sumLr = pass ? Lr : 0.0;
+#pragma unroll
+         for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
+         if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + e, sumLr);
+         if (pass) {
+            if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
+            if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
+            if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
+         }
+         unsigned long long pm = __ballot(pass);
+         while (pm) {
+            const int ml = __ffsll((long long)pm) - 1;
+            pm &= pm - 1;
+            const double L = __shfl(Lr, ml);
+            const int gg = __shfl(g, ml);
+            const float *mean = a.mean + (size_t)gg * D;
+            for (int k = lane; k < D; k += 64) {
+               if (a.dimStream && a.dimStream[k] != ks) continue;
+               const float z = xrow[k] - mean[k];
+               if (upMu && upVa) {
+                  const float zl = (float)((double)z * L);
+                  atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
+                  atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
+               } else if (upMu) atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
+               else if (upVa) atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
+            }
+         }
+      }
+   }
+}
+
 __global__ __launch_bounds__(256) void k_mixstats_tm(FbArgs a)
 {
    __shared__ unsigned short hitIdx[4][512];
@@ -1320,65 +1431,10 @@ __global__ __launch_bounds__(256) void k_mixstats_tm(FbArgs a)
          const double seed = hSeed[i];
          while (u + 1 < a.nUtt && a.gamOffByUtt[u + 1] <= hidx) u++;
          const UttDesc *up = a.utt + u;
-         if (a.status[u] != HTKAMD_UTT_OK) continue;
-         const int nSl = up->nSlots, T = up->T;
+         if (a.status[u] != HTKAMD_UTT_OK || up->pad == 2) continue;      // (an utterance of the left-to-right path has no seeds here: its pairs are listed)
+         const int nSl_ = up->nSlots;
          const size_t rel = hidx - up->gam0;
-         const int t0 = (int)(rel / nSl), slot = (int)(rel % nSl);
-         const int e0 = a.slotState[up->slot0 + slot];
-         const size_t row = (size_t)up->frame0 + t0;
-         const float *xrow = a.X + row * D;
-         const float oS = a.outp[up->outp0 + (size_t)slot * T + t0];
-         for (int ks = 0; ks < NSt; ks++) {
-            const int e = e0 + ks, c0 = a.stateCompOff[e], p0 = a.tmPoolOff[ks], M = a.tmPoolOff[ks + 1] - p0;
-            const float maxP = a.tmMaxP[row * NSt + ks];
-            float others = 0.0f;
-            if (NSt > 1) others = oS - a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
-            for (int mb = 0; mb < M; mb += 64) {
-               const int m = mb + lane;
-               bool pass = false;
-               double Lr = 0.0;
-               int g = 0;
-               if (m < M) {
-                  const float ev = a.tmE[row * a.tmPool + p0 + m];
-                  const float wt = a.compLogWt[c0 + m];
-                  g = a.compGauss[c0 + m];
-                  if (ev >= 0.0f && wt > (float)LMINMIX) {
-                     const float prob = ((double)ev >= MINLARG) ? (float)(log((double)ev) + (double)maxP) : (float)LZERO;
-                     double x = seed + (double)wt;
-                     x += (double)prob;
-                     if (NSt > 1) x += (double)others;
-                     if (-x < minF) { pass = true; Lr = exp(x); }
-                  }
-               }
-               double sumLr = pass ? Lr : 0.0;
-#pragma unroll
-               for (int o = 32; o > 0; o >>= 1) sumLr += __shfl_xor(sumLr, o);
-               if (lane == 0 && sumLr != 0.0) atomicAdd(a.acc + a.lay.wtOcc + e, sumLr);
-               if (pass) {
-                  if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, Lr);
-                  if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, Lr);
-                  if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + m, Lr);
-               }
-               unsigned long long pm = __ballot(pass);
-               while (pm) {
-                  const int ml = __ffsll((long long)pm) - 1;
-                  pm &= pm - 1;
-                  const double L = __shfl(Lr, ml);
-                  const int gg = __shfl(g, ml);
-                  const float *mean = a.mean + (size_t)gg * D;
-                  for (int k = lane; k < D; k += 64) {
-                     if (a.dimStream && a.dimStream[k] != ks) continue;
-                     const float z = xrow[k] - mean[k];
-                     if (upMu && upVa) {
-                        const float zl = (float)((double)z * L);
-                        atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)zl);
-                        atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * zl));
-                     } else if (upMu) atomicAdd(a.acc + a.lay.mu + (size_t)gg * D + k, (double)z * L);
-                     else if (upVa) atomicAdd(a.acc + a.lay.va + (size_t)gg * D + k, (double)(z * z) * L);
-                  }
-               }
-            }
-         }
+         tm_pair(a, up, (int)(rel / nSl_), (int)(rel % nSl_), seed, lane);
       }
    }
 }

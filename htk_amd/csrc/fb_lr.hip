@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * W) void k_stats_lr(FbArgs a)
                for (int i = lane; i < hb; i += 64) { MixHit h; h.st = hbSt[wv][i]; h.frame = hbFr[wv][i]; h.seed = hbSeed[wv][i]; hreg[hc + i] = h; }
                hc += hb; hb = 0;
             }
-            if (hit) { const int pos = hb + __popcll(hm & ((1ull << lane) - 1)); hbSt[wv][pos] = sidx; hbFr[wv][pos] = ud.frame0 + t - 1; hbSeed[wv][pos] = seed; }
+            if (hit) { const int pos = hb + __popcll(hm & ((1ull << lane) - 1)); hbSt[wv][pos] = a.hitSlots ? ud.slot0 + gl : sidx; hbFr[wv][pos] = ud.frame0 + t - 1; hbSeed[wv][pos] = seed; }
             hb += np;
          }
       }

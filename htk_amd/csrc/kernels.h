@@ -149,6 +149,7 @@ struct FbArgs {
    int tmCombine;                    // HVite side: a row is a STATE (its first element), scored as sum_s w_s SOutP_s (cPOutP HRec.c:540); 0: a row is an element
    const float *streamWt;            // [elements], with tmCombine
    MixHit *hits;                     // region r (one per wavefront of k_stats_lr, numbered like the rows of trPart): hits[r * hitRegionCap ...]
+   int hitSlots;                     // multi-stream / tied-mixture sets: MixHit::st is the pair's global SLOT (slot0 of its utterance + chain state), not its tied state
    int *hitCtl;                      // [r] records in region r
    int nHitRegions, hitRegionCap;
 };
@@ -162,6 +163,7 @@ int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s);
 // tied mixtures: PrecomputeTMix for every frame, SOutP for every (row, frame) of the task list, UpMixParms' TIEDHS branch
 int htkamd_launch_tm_score(const FbArgs &a, hipStream_t s);
 int htkamd_launch_mixstats_tm(const FbArgs &a, hipStream_t s);
+int htkamd_launch_mixhits_streams(const FbArgs &a, bool tied, hipStream_t s);      // the same two from the lists of the left-to-right path
 // aligner / decoders on a tied-mixture set: the score block of `sa` (rows = states) filled by PrecomputeTMix(tmBeam) + SOutP over the first nRows feature rows
 int htkamd_tm_score_block(const htkamd_model *m, const ScoreArgs &sa, int nRows, float tmBeam, hipStream_t s);
 // wave-per-utterance fast path (fb_wave.hip): chains of <= 64 models with <= 5 states each
