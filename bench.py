@@ -546,6 +546,7 @@ def main():
         assert not any_rank(range_hit[0])
     ktimes /= max(args.steps, 1)
     a = accs.download()                                                        # the last iteration's summed statistics
+    p_dump = model.get_params() if (args.dump_model and rank == 0) else None      # the model of the MEASURED iterations (the split iterations and the side run below move it)
     for i in range(3):                                                         # the split of an iteration's wall clock, outside the timed region
         em_iteration(False, parts=t_parts)
     t_parts /= 3.0
@@ -563,7 +564,6 @@ def main():
         lat.append(time.perf_counter() - tl)
     ktimes_solo = np.array(fb1.kernel_times5())
     torch.cuda.synchronize()
-    p_dump = model.get_params() if (args.dump_model and rank == 0) else None      # the model of the MEASURED iterations (the side run below moves it)
     # the same timed iterations once more on the fp16 x 2 scores (from the initial model again): reported beside the line, never `value`
     fastest_side = None
     if args.also_fastest and world == 1 and args.score == "bf16":
@@ -759,7 +759,9 @@ def main():
         print(json.dumps(out))
     if args.dump_model and rank == 0:
         p_ = p_dump
-        np.savez(args.dump_model, mean=p_["mean"], var=p_["var"], compWeight=p_["compWeight"], transP=p_["transP"], totalPr=a["totalPr"], nUttDone=a["nUttDone"])
+        np.savez(args.dump_model, mean=p_["mean"], var=p_["var"], compWeight=p_["compWeight"], transP=p_["transP"], totalPr=a["totalPr"], nUttDone=a["nUttDone"],
+                 accVec=a["vec"], accBulk=int(accs.lay.nEgs),
+                 accLay=np.array([int(getattr(accs.lay, n)) for n in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc", "nEgs")]))
     if world > 1:
         dist.destroy_process_group()
 

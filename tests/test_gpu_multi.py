@@ -45,9 +45,9 @@ def _env():
     return e
 
 
-def _bench(n, out, port, total=256, env=None, wire="f64"):
+def _bench(n, out, port, total=256, env=None, wire="f64", steps=2):
     args = ["--gpus", str(n), "--wire", wire, "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
-            "--steps", "2", "--warmup", "0", "--cpu-seconds", "0", "--extras", "0", "--dump-model", out]
+            "--steps", str(steps), "--warmup", "0", "--cpu-seconds", "0", "--extras", "0", "--dump-model", out]
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
@@ -73,17 +73,34 @@ def test_bench_two_ranks_on_one_device_over_gloo_equal_one_rank(tmp_path):
     assert abs(float(a["totalPr"]) - float(b["totalPr"])) <= 1e-9 * abs(float(a["totalPr"]))
     for k in ("mean", "var", "compWeight", "transP"):
         assert np.allclose(a[k], b[k], rtol=2e-6, atol=1e-7), k
-    # the same with floats on the wire (bench.py's default for N > 1): every rank's partial sums rounded to float once -- the model of
-    # the first iteration moves by float rounding, the second iteration's log probability with it
-    o3 = _bench(2, str(tmp_path / "m3.npz"), 29623, env={"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"}, wire="f32")
+    # the same with floats on the wire (bench.py's default for N > 1; what HERest -p itself exchanges: DumpAccs writes floats,
+    # HTrain.c:1453-1505).  ONE iteration: every rank's partial sums rounded to float once -- the model moves by float rounding
+    # (measured on MI355X: weights 2.4e-7, means 1.2e-7 absolute, variances 5.9e-6 of themselves: a variance is a difference of sums)
+    _bench(2, str(tmp_path / "m2s1.npz"), 29624, env={"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"}, steps=1)
+    o3 = _bench(2, str(tmp_path / "m3s1.npz"), 29623, env={"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"}, wire="f32", steps=1)
     l3 = json.loads(o3.strip().splitlines()[-1])
-    c = np.load(str(tmp_path / "m3.npz"))
     assert l3["utterances_ok"] == 256 and "f32 on the wire" in l3["config"]["parallelism"]
+    lin = lambda v: np.where(v > -0.5e10, np.exp(v.astype(np.float64)), 0.0)          # transition LOG probabilities
+
+    def moved(x, y):
+        sig = np.sqrt(x["var"].astype(np.float64))
+        return dict(mean=float((np.abs(x["mean"].astype(np.float64) - y["mean"]) / np.maximum(np.abs(x["mean"]), sig)).max()),
+                    var=float((np.abs(x["var"].astype(np.float64) - y["var"]) / (np.abs(x["var"]) + 1.0)).max()),
+                    compWeight=float((np.abs(x["compWeight"].astype(np.float64) - y["compWeight"]) / np.maximum(np.abs(x["compWeight"]), 1e-2)).max()),
+                    transP=float(np.abs(lin(x["transP"]) - lin(y["transP"])).max()))
+    b1, c1 = np.load(str(tmp_path / "m2s1.npz")), np.load(str(tmp_path / "m3s1.npz"))
+    assert float(b1["totalPr"]) == float(c1["totalPr"])                           # the first pass ran on the same model; its sum travels as fp64
+    m1 = moved(b1, c1)
+    print("f32 wire, one iteration:", m1)
+    assert m1["mean"] <= 5e-6 and m1["var"] <= 5e-6 and m1["compWeight"] <= 2e-6 and m1["transP"] <= 1e-6, m1
+    # ... and a SECOND iteration on that model: its statistics see the first one's rounding through the state alignments (measured:
+    # weights 6.4e-5 of themselves, means 4.5e-6 absolute) -- a property of EM on this data, not of the exchange, held below the 1e-4 bar
+    _bench(2, str(tmp_path / "m3.npz"), 29625, env={"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"}, wire="f32")
+    c = np.load(str(tmp_path / "m3.npz"))
     assert abs(float(a["totalPr"]) - float(c["totalPr"])) <= 1e-7 * abs(float(a["totalPr"]))
-    for k in ("mean", "compWeight", "transP"):
-        assert np.allclose(a[k], c[k], rtol=2e-5, atol=2e-6), k
-    # a variance is a difference of two sums: held to its second moment about the old mean, as everywhere (tests/c3_herest.py)
-    assert np.all(np.abs(a["var"].astype(np.float64) - c["var"]) <= 2e-5 * (np.abs(a["var"]) + 1.0)), "var"
+    m2 = moved(a, c)
+    print("f32 wire, two iterations:", m2)
+    assert m2["mean"] <= 1e-4 and m2["var"] <= 1e-4 and m2["compWeight"] <= 3e-4 and m2["transP"] <= 1e-5, m2
 
 
 def test_bench_two_ranks_rccl_equals_one_rank(tmp_path):
