@@ -458,6 +458,31 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
             if (through[b]) for (int c = 0; c < XC; c++) if (RC[(size_t)b * XC + c] && !RC[(size_t)a * XC + c]) { RC[(size_t)a * XC + c] = 1; changed = 1; }
          }
       }
+      /* What ProcessCrossWordLinks (HNet.c:2559-2680) makes of the arcs, node by node, as the reference does it:
+       *   - a word's END nodes are typed (lc, rc): lc is the word's last context, but 0 on an arc INTO A NULL NODE WITHOUT FOLLOWERS
+       *     (:2611) -- such a word has one more end node, `wendFin`, beside those of its other right contexts (NR: the right contexts
+       *     its other arcs ask for); the model of right context 0 links to whichever of the two the LAST arc asked for (zeroSrc);
+       *   - a null node without followers is ONE node for every context (InitPronHolders :2436-2449, type n_word);
+       *   - a null node without predecessors links into every word from its copy (0, 0), whatever the word's first context (:2640),
+       *     and only that copy hangs on net->initial (AddInitialFinal :2208);
+       *   - otherwise a null node has the copies (lc, rc) its arcs ask for: rc = first context of a following word, or the rcs it
+       *     shares with a following null node. */
+      int *outOff = (int *)calloc((size_t)NN + 2, sizeof(int)), *outArc = (int *)malloc(sizeof(int) * ((size_t)NA + 1));
+      for (int j = 0; j < NA; j++) outOff[la[j].s + 1]++;
+      for (int i = 0; i < NN; i++) outOff[i + 1] += outOff[i];
+      { int *fill = (int *)calloc((size_t)NN + 1, sizeof(int)); for (int j = 0; j < NA; j++) outArc[outOff[la[j].s] + fill[la[j].s]++] = j; free(fill); }
+      unsigned char *NR = (unsigned char *)calloc((size_t)NN * XC, 1), *NF = (unsigned char *)calloc((size_t)NN, 1), *zeroSrc = (unsigned char *)calloc((size_t)NN, 1);
+#define FINAL_NULL(b_) (through[b_] && !hasFollX[b_])
+      for (int i = 0; i < NN; i++) {
+         if (!hasFollX[i]) { NR[(size_t)i * XC] = 1; zeroSrc[i] = 1; }
+         for (int z = outOff[i]; z < outOff[i + 1]; z++) {
+            const int b = la[outArc[z]].e;
+            if (FINAL_NULL(b)) { NF[i] = 1; zeroSrc[i] = 2; }
+            else if (through[b]) for (int r = 0; r < XC; r++) if (RC[(size_t)b * XC + r]) { NR[(size_t)i * XC + r] = 1; if (r == 0) zeroSrc[i] = 1; }
+            for (int y = firstOf[b]; y < firstOf[b] + cntOf[b]; y++) if (pr[iPr[y]].nPhones > 0 && iIc[y] >= 0) NR[(size_t)i * XC + iIc[y]] = 1;
+         }
+      }
+      int *wendFin = (int *)malloc(sizeof(int) * ((size_t)nInst + 1));
       entryOf = (int *)malloc(sizeof(int) * ((size_t)nInst * XC + 1)); wendOf = (int *)malloc(sizeof(int) * ((size_t)nInst * XC + 1));
       crossOf = (int *)malloc(sizeof(int) * ((size_t)nInst + 1));          /* one-phone words without leading context-free phones: base of the (lc, rc) cross-bar */
       nullOf = (int *)malloc(sizeof(int) * ((size_t)NN + 1));               /* typed copies of a through node: nullOf[i] + lc*XC + rc in nullTab */
@@ -501,12 +526,16 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
          /* word-end nodes */
          int weSingle = -1;
          for (int r = 0; r < XC; r++) {
-            if (!RC[(size_t)i * XC + r]) continue;
+            if (!NR[(size_t)i * XC + r]) continue;
             if (fci && weSingle >= 0) { wendOf[(size_t)x * XC + r] = weSingle; continue; }
             NEWNODE(HTKAMD_NODE_WORD, k, pr[k].prob, k);
             wendOf[(size_t)x * XC + r] = nN - 1;
             if (fci) weSingle = nN - 1;
          }
+         wendFin[x] = -1;
+         if (NF[i]) { NEWNODE(HTKAMD_NODE_WORD, k, pr[k].prob, k); wendFin[x] = nN - 1; }
+         /* pInst->rc[r]: the word node the model of right context r links to */
+#define RCNODE(r_) (((r_) == 0 && zeroSrc[i] == 2) ? wendFin[x] : wendOf[(size_t)x * XC + (r_)])
          /* a model for the last context phone + copies of the trailing context-free phones; returns the head, *last the node that links to the word end */
 #define END_CHAIN(head_, last_, lc_, rc_) do { int h_; XMODEL(h_, (lc_), k, q, (rc_)); if (rc) break; \
             NEWNODE(HTKAMD_NODE_HMM, h_, 0.0f, -1); (head_) = (last_) = nN - 1; \
@@ -522,7 +551,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
                int e = -1;
                for (int z = 0; z < nEnd; z++) if (endHmm[z] == h) e = z;
                if (e < 0) { e = nEnd++; endHmm[e] = h; END_CHAIN(endHead[e], endLast[e], LCI(q, 0), r); if (rc) break; }
-               LINK_ONCE(endLast[e], wendOf[(size_t)x * XC + r]);
+               if (RCNODE(r) >= 0) LINK_ONCE(endLast[e], RCNODE(r));
                if (fci) break;                                     /* "only need to do this once" */
             }
             if (rc) break;
@@ -555,7 +584,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
             /* CreateX1Model, context-independent phone: one model for everybody */
             int head = -1, last = -1;
             END_CHAIN(head, last, 0, 0); if (rc) break;
-            for (int r = 0; r < XC; r++) if (RC[(size_t)i * XC + r]) LINK_ONCE(last, wendOf[(size_t)x * XC + r]);
+            for (int r = 0; r < XC; r++) if (RC[(size_t)i * XC + r] && RCNODE(r) >= 0) LINK_ONCE(last, RCNODE(r));
             for (int z = p - 1; z >= 0 && !rc; z--) { int hz; XMODEL(hz, 0, k, z, 0); if (rc) break; NEWNODE(HTKAMD_NODE_HMM, hz, 0.0f, -1); NEWLINK(nN - 1, head, 0.0f); head = nN - 1; }
             for (int l = 0; l < XC; l++) if (LC[(size_t)i * XC + l]) entryOf[(size_t)x * XC + l] = head;
          } else {
@@ -580,7 +609,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
                   int e = -1;
                   for (int z = 0; z < nEnd; z++) if (endHmm[z] == h) e = z;
                   if (e < 0) { e = nEnd++; endHmm[e] = h; END_CHAIN(endHead[e], endLast[e], hc.sLeft ? l : 0, r); if (rc) break; NEWLINK(link, endHead[e], 0.0f); }
-                  LINK_ONCE(endLast[e], wendOf[(size_t)x * XC + r]);
+                  if (RCNODE(r) >= 0) LINK_ONCE(endLast[e], RCNODE(r));
                }
                if (rc) break;
                entryOf[(size_t)x * XC + l] = head;
@@ -589,6 +618,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
          }
 #undef END_CHAIN
 #undef LINK_ONCE
+#undef RCNODE
          if (rc) break;
 #undef LCI
 #undef RCI
@@ -600,38 +630,65 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
          for (int x = firstOf[i]; x < firstOf[i] + cntOf[i]; x++) if (pr[iPr[x]].nPhones == 0) thruPron[i] = iPr[x];
          nullOf[i] = nNullTab;
          nullTab = (int *)realloc(nullTab, sizeof(int) * (size_t)(nNullTab + XC * XC));
-         for (int l = 0; l < XC; l++)
-            for (int r = 0; r < XC; r++) {
-               int id = -1;
-               if (LC[(size_t)i * XC + l] && RC[(size_t)i * XC + r]) {
-                  if (thruPron[i] >= 0) NEWNODE(HTKAMD_NODE_WORD, thruPron[i], pr[thruPron[i]].prob, thruPron[i]);
-                  else NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1);
-                  id = nN - 1;
+#define NEW_THROUGH() do { if (thruPron[i] >= 0) NEWNODE(HTKAMD_NODE_WORD, thruPron[i], pr[thruPron[i]].prob, thruPron[i]); else NEWNODE(HTKAMD_NODE_NULL, -1, 0.0f, -1); } while (0)
+         for (int z = 0; z < XC * XC; z++) nullTab[nNullTab + z] = -1;
+         if (!hasFollX[i]) {                                    /* one node for every context */
+            NEW_THROUGH();
+            for (int l = 0; l < XC; l++) nullTab[nNullTab + l * XC] = nN - 1;
+         } else {
+            unsigned char *need = (unsigned char *)calloc((size_t)XC * XC, 1);
+            for (int z = outOff[i]; z < outOff[i + 1]; z++) {
+               const int b = la[outArc[z]].e;
+               for (int l = 0; l < XC; l++) {
+                  if (!LC[(size_t)i * XC + l]) continue;
+                  if (through[b]) for (int r = 0; r < XC; r++) if (RC[(size_t)i * XC + r] && RC[(size_t)b * XC + r] && LC[(size_t)b * XC + l]) need[l * XC + r] = 1;
+                  for (int y = firstOf[b]; y < firstOf[b] + cntOf[b]; y++)
+                     if (pr[iPr[y]].nPhones > 0 && iIc[y] >= 0) need[l * XC + (hasPredX[i] ? iIc[y] : 0)] = 1;
                }
-               nullTab[nNullTab + l * XC + r] = id;
             }
+            for (int l = 0; l < XC; l++)
+               for (int r = 0; r < XC; r++)
+                  if (need[l * XC + r]) { NEW_THROUGH(); nullTab[nNullTab + l * XC + r] = nN - 1; }
+            free(need);
+         }
+#undef NEW_THROUGH
          nNullTab += XC * XC;
       }
       /* links: out of a word end (instance x, right context r) or a typed null copy (l, r) into everything that follows with first context r */
-#define LINK_INTO(from_, b_, l_, r_, like_) do { \
+#define LINK_INTO(from_, b_, l_, r_, like_, anyIc_, intoFinal_) do { \
          for (int y_ = firstOf[b_]; y_ < firstOf[b_] + cntOf[b_]; y_++) { \
-            if (pr[iPr[y_]].nPhones == 0 || iIc[y_] != (r_)) continue; \
+            if (pr[iPr[y_]].nPhones == 0 || (!(anyIc_) && iIc[y_] != (r_))) continue; \
             const int e_ = entryOf[(size_t)y_ * XC + (l_)]; \
             if (e_ >= 0) NEWLINK((from_), e_, (like_)); \
             else if (e_ == -2) { for (int r2_ = 0; r2_ < XC; r2_++) { const int c_ = crossTab[crossOf[y_] + (l_) * XC + r2_]; if (c_ >= 0) NEWLINK((from_), c_, (like_)); } } \
          } \
-         if (through[b_]) { const int t_ = nullTab[nullOf[b_] + (l_) * XC + (r_)]; if (t_ >= 0) NEWLINK((from_), t_, (like_)); } \
+         if (through[b_] && ((intoFinal_) || hasFollX[b_])) { const int t_ = nullTab[nullOf[b_] + (l_) * XC + (r_)]; if (t_ >= 0) NEWLINK((from_), t_, (like_)); } \
       } while (0)
       int nInit = 0, nFin = 0;
       for (int j = 0; j < NA && !rc; j++) {
          const int a = la[j].s, b = la[j].e;
          for (int x = firstOf[a]; x < firstOf[a] + cntOf[a]; x++) {
             if (pr[iPr[x]].nPhones == 0) continue;
-            for (int r = 0; r < XC; r++) { const int w = wendOf[(size_t)x * XC + r]; if (w >= 0) LINK_INTO(w, b, iFc[x], r, la[j].l); }
+            if (FINAL_NULL(b)) { if (wendFin[x] >= 0) NEWLINK(wendFin[x], nullTab[nullOf[b]], la[j].l); }
+            for (int r = 0; r < XC; r++) {
+               const int w = wendOf[(size_t)x * XC + r];
+               if (w < 0) continue;
+               LINK_INTO(w, b, iFc[x], r, la[j].l, 0, 0);
+            }
          }
-         if (through[a])
+         if (through[a] && hasFollX[a]) {
+            const int init = !hasPredX[a];
             for (int l = 0; l < XC; l++)
-               for (int r = 0; r < XC; r++) { const int t = nullTab[nullOf[a] + l * XC + r]; if (t >= 0) LINK_INTO(t, b, l, r, la[j].l); }
+               for (int r = 0; r < XC; r++) {
+                  const int t = nullTab[nullOf[a] + l * XC + r];
+                  if (t < 0) continue;
+                  if (init && r != 0) {                           /* copies (0, r) of an initial null node: into following null nodes only */
+                     if (through[b]) { const int t2 = nullTab[nullOf[b] + l * XC + r]; if (t2 >= 0) NEWLINK(t, t2, la[j].l); }
+                     continue;
+                  }
+                  LINK_INTO(t, b, l, r, la[j].l, init, 1);
+               }
+         }
       }
       for (int i = 0; i < NN && !rc; i++) {
          if (!hasPredX[i]) {                                    /* AddInitialFinal: the initial node enters with no left context */
@@ -641,14 +698,15 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
                if (e >= 0) { NEWLINK(0, e, 0.0f); nInit++; }
                else if (e == -2) for (int r = 0; r < XC; r++) { const int c = crossTab[crossOf[x] + r]; if (c >= 0) { NEWLINK(0, c, 0.0f); nInit++; } }
             }
-            if (through[i]) for (int r = 0; r < XC; r++) { const int t = nullTab[nullOf[i] + r]; if (t >= 0) { NEWLINK(0, t, 0.0f); nInit++; } }
+            if (through[i]) { const int t = nullTab[nullOf[i]]; if (t >= 0) { NEWLINK(0, t, 0.0f); nInit++; } }      /* FindWordNode(.., n_word): the copy (0, 0) */
          }
          if (!hasFollX[i]) {
             for (int x = firstOf[i]; x < firstOf[i] + cntOf[i]; x++) { const int w = (pr[iPr[x]].nPhones == 0) ? -1 : wendOf[(size_t)x * XC]; if (w >= 0) { NEWLINK(w, 1, 0.0f); nFin++; } }
-            if (through[i]) for (int l = 0; l < XC; l++) { const int t = nullTab[nullOf[i] + l * XC]; if (t >= 0) { NEWLINK(t, 1, 0.0f); nFin++; } }
+            if (through[i]) { const int t = nullTab[nullOf[i]]; if (t >= 0) { NEWLINK(t, 1, 0.0f); nFin++; } }
          }
       }
 #undef LINK_INTO
+#undef FINAL_NULL
 #undef XMODEL
       if (!rc && (!nInit || !nFin)) { htkamd_set_error("net_build: %s has no initial or no final node", slfPath); rc = HTKAMD_EMODEL; }
       if (!rc) {
@@ -659,6 +717,7 @@ static int expand_lattice(lnode *ln, int NN, larc *la, int NA, dpron *pr, int nP
       hci_free(&hc);
       free(iLn); free(iPr); free(iP); free(iQ); free(iFc); free(iIc); free(LC); free(RC); free(through); free(hasPredX); free(hasFollX);
       free(entryOf); free(wendOf); free(crossOf); free(nullOf); free(thruPron); free(nullTab); free(crossTab);
+      free(outOff); free(outArc); free(NR); free(NF); free(zeroSrc); free(wendFin);
       if (rc) goto done;
    } else {
    for (int i = 0; i < NN; i++) {
