@@ -30,6 +30,7 @@ def _stream(s):
 
 SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC, SCORE_F16 = 0, 1, 2, 4, 8, 16, 32
 ERANGE = -7
+COMPAT_STREAM_REVISIT = 1
 ORDER_AUTO, ORDER_FAST, ORDER_EXACT = 0, 1, 2
 
 
@@ -157,6 +158,10 @@ class Model:
         """Tied mean / variance vectors (htkamd_model_set_sharing): arrays [G] of share numbers, -1 = private."""
         ms = np.ascontiguousarray(meanShare, np.int32); vs = np.ascontiguousarray(varShare, np.int32)
         check(lib().htkamd_model_set_sharing(self.h, _p(ms), _p(vs)), "model_set_sharing")
+
+    def set_compat(self, flags: int):
+        """The reference's own arithmetic where the library computes something else (htkamd_model_set_compat; COMPAT_STREAM_REVISIT)."""
+        check(lib().htkamd_model_set_compat(self.h, C.c_int(int(flags))), "model_set_compat")
 
     def set_scan_order(self, order):
         """The order in which UpdateModels visits the physical models (htkamd_model_set_scan_order; hmm_scan_order() gives HTK's)."""

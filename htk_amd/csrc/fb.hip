@@ -129,6 +129,7 @@ struct htkamd_fb {
    DevBuf d_tasks, d_tasksW, d_gamOff, d_qLo, d_qHi, d_aLo, d_aHi, d_outp, d_beta, d_gam, d_alpha, d_pr, d_status;
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
    DevBuf d_tmE, d_tmMaxP;                  // tied mixtures: the pool's per-frame table (kernels.h FbArgs::tmE)
+   std::vector<int> nextSame; DevBuf d_nextSame;   // HTKAMD_COMPAT_STREAM_REVISIT (kernels.h FbArgs::nextSame)
    DevBuf d_slotStateU, d_outpU;            // several streams: element of every (stream, chain state), and their scores: stream k of utterance u at outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
    DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8 | left-to-right W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
@@ -148,6 +149,9 @@ struct htkamd_fb {
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending, scored;
 };
+
+// the reference's second-visit arithmetic is asked for AND can be reached with this set (htkamd_model_set_compat)
+static bool compat_revisit(const htkamd_model *m) { return (m->compat & HTKAMD_COMPAT_STREAM_REVISIT) && m->NSt > 1 && m->NSt != 3 && !m->tiedMix; }
 
 extern "C" int htkamd_fb_create(htkamd_model *m, htkamd_fb **out)
 {
@@ -260,7 +264,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
       }
       // chains of up to 512 models of up to 5 states run on 1..8 wavefronts (fb_wave.hip); the others on the general kernels: one
       // thread per model state, everything of a frame in LDS
-      const bool waveOk = fb->m->maxN <= 5 && !fb->forceGeneral && Q <= 512;
+      const bool waveOk = fb->m->maxN <= 5 && !fb->forceGeneral && !compat_revisit(fb->m) && Q <= 512;
       if (!waveOk) {
          if (Q > 32000 || d.nThr > 1024) {
             snprintf(C.err, sizeof(C.err), "fb_prepare: utterance %d has %d models / %d model states; the device path handles chains of up to 512 models of "
@@ -452,7 +456,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          // (fb_wave.hip, chains of up to 512 models); else the general workgroup-per-utterance kernels
          bool noTee = d.status == HTKAMD_UTT_OK || d.status == HTKAMD_UTT_SKIPPED;
          for (int q = 0; q < d.Q && noTee; q++) if (fb->mDms[d.q0 + q] == 0) noTee = false;
-         const bool small = fb->m->maxN <= 5 && !fb->forceGeneral;
+         const bool small = fb->m->maxN <= 5 && !fb->forceGeneral && !compat_revisit(fb->m);
          int W = 0, kind = 0;
          if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) {
             kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8;
@@ -478,6 +482,28 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       if (fb->uttList.empty()) fb->uttList.push_back(0);
    }
 
+   fb->nextSame.clear();
+   if (compat_revisit(fb->m)) {
+      // per utterance: the chain states of one tied state sorted by (model ascending, state descending); a state's successor in that
+      // list is the one Setotprob visited last before it among those that can be in the same call (it walks the models right to left,
+      // a model's states left to right: HFB.c:1015-1024)
+      fb->nextSame.assign(fb->slotState.size(), -1);
+      std::vector<int> ord;
+      for (int u = 0; u < U; u++) {
+         const UttDesc &d = fb->utt[u];
+         ord.resize(d.nSlots);
+         for (int k = 0; k < d.nSlots; k++) ord[k] = k;
+         std::sort(ord.begin(), ord.end(), [&](int x, int y) {
+            const int ex = fb->slotState[d.slot0 + x], ey = fb->slotState[d.slot0 + y];
+            if (ex != ey) return ex < ey;
+            const int qx = fb->sQ[d.slot0 + x], qy = fb->sQ[d.slot0 + y];
+            if (qx != qy) return qx < qy;
+            return x > y;                                    // same model: slots ascend with the state
+         });
+         for (int k = 0; k + 1 < d.nSlots; k++)
+            if (fb->slotState[d.slot0 + ord[k]] == fb->slotState[d.slot0 + ord[k + 1]]) fb->nextSame[d.slot0 + ord[k]] = ord[k + 1];
+      }
+   }
    lap("merge");
    int rc;
    {
@@ -494,7 +520,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_tasks, fb->tasks.data(), sizeof(ScoreTask) * fb->tasks.size(), 0}, {&fb->d_tasksW, fb->tasksW.data(), sizeof(ScoreTask) * fb->tasksW.size(), 0}, {&fb->d_gamOff, fb->gamOff.data(), sizeof(size_t) * fb->gamOff.size(), 0},
          {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0},
          {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0},
-         {&fb->d_slotStateU, fb->slotStateU.data(), sizeof(int) * fb->slotStateU.size(), 0}};
+         {&fb->d_slotStateU, fb->slotStateU.data(), sizeof(int) * fb->slotStateU.size(), 0},
+         {&fb->d_nextSame, fb->nextSame.data(), sizeof(int) * fb->nextSame.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -583,6 +610,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    fa.pr = (double *)fb->d_pr.p; fa.status = (int *)((double *)fb->d_pr.p + fb->nUtt);
    fa.stateCompOff = m->d_stateCompOff; fa.compGauss = m->d_compGauss;
    fa.NSt = m->NSt; fa.outpU = (const float *)fb->d_outpU.p; fa.dimStream = m->d_dimStream;
+   fa.compatRevisit = compat_revisit(m) && !fb->nextSame.empty(); fa.nextSame = (const int *)fb->d_nextSame.p;
    fa.transOff = (const int *)fb->d_transOff.p; fa.trOccOff = (const int *)fb->d_trOccOff.p;
    fa.compLogWt = m->d_compLogWt; fa.gparam = m->d_gparam; fa.mean = m->d_mean; fa.laddTab = m->d_laddTab;
    fa.PS = m->PS; fa.D = m->D; fa.maxN = m->maxN; fa.maxM = m->maxM;

@@ -101,6 +101,30 @@ __global__ void k_beta(FbArgs a)
    const double mle = a.minLogExp;
    const bool pruning = a.pruneInit < HTKAMD_NOPRUNE;
 
+   // HTKAMD_COMPAT_STREAM_REVISIT -- Setotprob(t, hiQ, loQ) for S > 1 as the reference computes it (HFB.c:1015-1066): it walks the models
+   // hiQ .. loQ - 1 and a model's states 2 .. N - 1; a tied state it has met before IN THIS CALL gets the float sum of the streams'
+   // replaced values (sum - x_s), halved (:1059), the others the sum of the streams.  Every retry of StepBack starts afresh (:559-562),
+   // so the state's row is rewritten for every model the call covers.
+   const int mySlot = (live && cm.i > 1 && cm.i < cm.N) ? cm.ms0 + cm.i - 2 : -1;
+   auto setotprob_revisit = [&](int t, int hiQ, int loQ) {
+      if (loQ > 1) --loQ;
+      if (mySlot >= 0 && cm.q >= loQ && cm.q <= hiQ) {
+         const int nx = a.nextSame[ud.slot0 + mySlot];
+         const bool seen = nx >= 0 && (int)a.sQ[ud.slot0 + nx] <= hiQ;
+         const float *pu = a.outpU + ud.outp0 * a.NSt + (size_t)mySlot * T + (t - 1);
+         const size_t strideK = (size_t)ud.nSlots * T;
+         float sum = 0.0f;
+         for (int k = 0; k < a.NSt; k++) sum += pu[k * strideK];
+         if (seen) {
+            float s2 = 0.0f;
+            for (int k = 0; k < a.NSt; k++) s2 += sum - pu[k * strideK];
+            sum = s2 / 2;
+         }
+         ((float *)outp)[(size_t)mySlot * T + (t - 1)] = sum;
+      }
+      __syncthreads();
+   };
+
    double thresh = a.pruneInit, pr = LZERO;
    int ok = 0;
    for (;;) {                                            // StepBack retry loop (HFB.c:1332-1361)
@@ -108,6 +132,7 @@ __global__ void k_beta(FbArgs a)
       int fail = 0;
       // ---- t = T (HFB.c:1175-1198)
       int endq = tLo[T];
+      if (a.compatRevisit) setotprob_revisit(T, Q, endq);
       if (tid == 0) {
          double e = 0.0;
          for (int q = Q; q >= endq; q--) {
@@ -139,6 +164,7 @@ __global__ void k_beta(FbArgs a)
          endq = (qLoN == 1) ? 1 : ((tLo[t] >= qLoN) ? tLo[t] : qLoN - 1);
          while (endq > 1 && mDm[endq - 1] == 0) endq--;
          { double *tmp = colC; colC = colN; colN = tmp; }
+         if (a.compatRevisit) setotprob_revisit(t, startq, endq);
          const bool inRange = live && cm.q >= endq && cm.q <= startq;
          if (inRange && cm.i > 1) {
             const int q = cm.q;
@@ -1090,7 +1116,12 @@ __device__ void ms_pair(const FbArgs &a, const UttDesc *up, const int t0, const 
    for (int ks = 0; ks < NSt; ks++) {
       const int e = e0 + ks, c0 = a.stateCompOff[e], M = a.stateCompOff[e + 1] - c0;
       const float oK = a.outpU[up->outp0 * NSt + ((size_t)ks * nSl + slot) * T + t0];
-      const float others = oS - oK;                              // outprob[s][0] after Setotprob (HFB.c:1064)
+      float sumS = oS;
+      if (a.compatRevisit) {                                     // (the state's row may hold a second visit's value: the shared vectors keep the first visit's)
+         sumS = 0.0f;
+         for (int k2 = 0; k2 < NSt; k2++) sumS += a.outpU[up->outp0 * NSt + ((size_t)k2 * nSl + slot) * T + t0];
+      }
+      const float others = sumS - oK;                            // outprob[s][0] after Setotprob (HFB.c:1064)
       for (int mb = 0; mb < M; mb += 64) {
          const int m = mb + lane;
          bool pass = false;

@@ -91,6 +91,7 @@ struct htkamd_model {
    int    f16Wide;             /* every state fits one tile (<= 16 components): the 32 x 32 form of the kernel and its table layout */
    float *d_f16Ctl;            /* its control block: scale[96], 1/scale[96], range[192], flag of the last table build, sticky range flag */
    int    bf16Stale, f16Stale; /* the table is older than the parameters (a device update while the path was not in use): rebuilt on its next use */
+   int    compat;              /* HTKAMD_COMPAT_* bits (htkamd_model_set_compat) */
    int    fastUse;             /* HTKAMD_SCORE_BF16 / _F16 bits: the paths that have scored with this model (their tables follow every device update) */
    /* shared mean / variance vectors (~u / ~v macros; htkamd_model_set_sharing): first Gaussian of the group a Gaussian's mean / variance
       belongs to (itself when private), members of its variance group; NULL = no sharing in the set */

@@ -137,6 +137,10 @@ struct FbArgs {
    // several streams (model NSt > 1): scores per (stream, chain state) and the map dimension -> stream
    int NSt;
    const float *outpU;               // stream k of utterance u: outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
+   // HTKAMD_COMPAT_STREAM_REVISIT (k_beta): the next chain state of the same tied state in Setotprob's visiting order seen backwards --
+   // same model and an earlier state, else the nearest model further right -- as a slot of the utterance, -1 = none
+   int compatRevisit;
+   const int *nextSame;              // [slot0 + slot]
    const int *dimStream;
    // tied mixtures (model tiedMix): per frame of the batch the pool's scaled probabilities (-1 = pruned by PrecomputeTMix) and their
    // maximum per stream; the pool-to-state kernel's task list and rows

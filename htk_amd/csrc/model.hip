@@ -457,6 +457,13 @@ extern "C" int htkamd_model_set_tm_beam(htkamd_model *m, float tmBeam)
    return HTKAMD_OK;
 }
 
+extern "C" int htkamd_model_set_compat(htkamd_model *m, int flags)
+{
+   if (!m || (flags & ~HTKAMD_COMPAT_STREAM_REVISIT)) { htkamd_set_error("model_set_compat: unknown flags %d", flags); return HTKAMD_EINVAL; }
+   m->compat = flags;
+   return HTKAMD_OK;
+}
+
 extern "C" int htkamd_model_has_sharing(const htkamd_model *m) { return m && m->h_meanLeader ? 1 : 0; }
 
 extern "C" int htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,

@@ -100,7 +100,7 @@ typedef struct {
           value for NS = 3 only; for NS = 2 every repeated state gets HALF its log probability (the reference reports -33.6 per frame
           on the demo set split 13 | 13 where the sum of the streams' log probabilities gives -59.1).  This library computes the
           first visit's value at every visit: equal to HERest for NS = 1 and NS = 3, NOT for NS = 2 or NS >= 4 on sets with repeated
-          tied states.
+          tied states -- unless htkamd_model_set_compat(HTKAMD_COMPAT_STREAM_REVISIT) asks for the reference's value.
         * SHAREDHS sets whose mixtures share pdfs (~m macros without HHEd's TIEDHS conversion): ConvLogWt converts the weights of the
           FIRST state that uses a shared pdf only (HUtil.c:474-485), the others are read as log weights; this library converts
           every weight once. */
@@ -138,6 +138,16 @@ int  htkamd_model_has_sharing(const htkamd_model *m);
 /* Tied-mixture sets in the aligner and the decoders: the pruning threshold of the pool (HVite -c f, tmBeam HVite.c:115: pool entries more
    than f below the frame's best are left out of every state's sum; default 10.0).  Forward-backward uses its own (minFrwdP, HFB.c:1011). */
 int  htkamd_model_set_tm_beam(htkamd_model *m, float tmBeam);
+/* The reference's own arithmetic where this library deliberately computes something else (htkamd_model_desc, "WHERE THIS LIBRARY
+   DELIBERATELY DIFFERS").  HTKAMD_COMPAT_STREAM_REVISIT: forward-backward on PLAINHS / SHAREDHS sets with NS != 3 streams gives a chain
+   state whose tied state was met before in the same Setotprob call -- by a model further right in the beam, or an earlier state of the
+   same model -- the value HFB.c:1059 gives it: the float sum of the streams' "sum of the others", halved, i.e. (NS - 1) / 2 times the
+   state's log probability.  The recursions, occupation and transition counts see that value, the mixture statistics the first visit's
+   "sum of the others", as in the reference (HFB.c:1062-1064,1611).  Batches then run on the general workgroup-per-utterance kernels
+   (call before htkamd_fb_prepare).  No effect on sets with one or three streams or on tied-mixture sets (the reference's defect is not
+   reached there).  The second difference (weights of shared pdfs, HUtil.c:474) has no switch. */
+#define HTKAMD_COMPAT_STREAM_REVISIT 1
+int  htkamd_model_set_compat(htkamd_model *m, int flags);
 void htkamd_model_destroy(htkamd_model *m);
 /* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */
 int  htkamd_model_set_params(htkamd_model *m, const float *mean, const float *var, const float *gconst,

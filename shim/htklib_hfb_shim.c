@@ -386,6 +386,8 @@ static void pack_set(ShimSet *z)
    amd_check(htkamd_model_create(&d, &z->model), "htkamd_model_create");
    /* the tables the kernels read are the front-end's own numbers, bit for bit: 1/variance from ConvDiagC, log weights from ConvLogWt */
    amd_check(htkamd_model_set_prepared(z->model, ivar, gconst, logwt), "htkamd_model_set_prepared");
+   /* under the reference's own HERest.o the numbers are the reference's: Setotprob's second visit of a tied state as HFB.c:1059 has it */
+   amd_check(htkamd_model_set_compat(z->model, HTKAMD_COMPAT_STREAM_REVISIT), "htkamd_model_set_compat");
    amd_check(htkamd_accs_create(z->model, &z->accs), "htkamd_accs_create");
    amd_check(htkamd_fb_create(z->model, &z->fb), "htkamd_fb_create");
    free(weight); free(logwt); free(mean); free(var); free(ivar); free(gconst); free(transP);

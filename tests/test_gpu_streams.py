@@ -24,8 +24,10 @@ DEMO = su.DEMO
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(native, pk, utts, path=None, mode=0, prune=None, uFlags=15):
+def _run(native, pk, utts, path=None, mode=0, prune=None, uFlags=15, compat=0):
     model = native.Model(pk)
+    if compat:
+        model.set_compat(compat)
     X, frameOff, labOff, labs = batch_arrays(utts)
     dX = native.DevArray(X)
     fb = native.ForwardBackward(model, debug=True, force_general=(path == "general"), no_state_path=(path == "wave"))
@@ -100,6 +102,53 @@ def test_demo_stream_sets_against_oracle_and_reference(native, oracle, S, path):
         assert "average log prob per frame = %e" % (a["totalPr"] / a["totalT"]) in open(os.path.join(d, "herest.log")).read()
 
 
+@pytest.mark.parametrize("path", ["state", "general"])
+def test_demo_two_streams_with_the_reference_s_second_visit_arithmetic(native, oracle, path):
+    """htkamd_model_set_compat(HTKAMD_COMPAT_STREAM_REVISIT): a tied state met again in one Setotprob call gets the halved sum of the
+    streams' replaced values (HFB.c:1059) -- for two streams HALF its log probability.  Against the oracle WITHOUT `ms_intended` (pinned
+    to the reference float for float, tests/test_streams.py) and against the reference's own `HERest -p 1` accumulators and summary line
+    (-33.6 per frame where the sum of the streams gives -59.1)."""
+    d = os.path.join(DEMO, "hmm_streams2")
+    mmf = native.Mmf(files=[os.path.join(d, "newMacros")], hmm_list=os.path.join(DEMO, "bcplist"))
+    pk = mmf.packed()
+    utts = su.demo_utterances(native, oracle, mmf)
+    prune = dict(pruneInit=2000.0, pruneInc=0.0, pruneLim=2000.0)
+    model, fb, acc, pr, st = _run(native, pk, utts, path=path, prune=prune, compat=native.COMPAT_STREAM_REVISIT)
+    assert (st == 1).all()
+    a = acc.download()
+    om, oacc, opr = _oracle_accs(oracle, pk, utts, prune=dict(pruneInit=2000.0), intended=False)
+    assert np.allclose(pr, opr, rtol=1e-9, atol=0)
+    _compare(a, _odict(oacc), 1e-4, "S=2 compat %s vs oracle" % path, pk["var"])
+    lay = native.accs_layout(pk)
+    v = np.zeros(lay.total, np.float64)
+    native.accs_load_file(pk, v, list(mmf.phys_names), os.path.join(d, "HER1.acc"))
+    _compare(a, {k: v[getattr(lay, k):getattr(lay, k) + a[k].size] for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc")}, 1e-4,
+             "S=2 compat %s vs the reference's accumulators" % path, pk["var"])
+    assert "average log prob per frame = %e" % (a["totalPr"] / a["totalT"]) in open(os.path.join(d, "herest.log")).read()
+    # and without the switch the same set gives the sum of the streams (what the test above holds against `ms_intended`)
+    _, _, acc0, pr0, _ = _run(native, pk, utts, path=path, prune=prune)
+    assert pr0.sum() < pr.sum() - 1000.0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_stream_sets_with_the_reference_s_second_visit_arithmetic(native, oracle, seed):
+    """The same on random sets of two and four streams with repeated models in the transcriptions (every utterance meets tied states
+    again), beams that prune, and a retry of StepBack (pruneInc): against the oracle without `ms_intended`."""
+    from htk_amd import synth
+    rng = np.random.default_rng(seed)
+    widths = (10, 10) if seed % 2 else (6, 6, 6, 2)
+    s = synth.generate(12, 1, 5, 6, 60, 40 + seed, D=sum(widths))          # five models: every transcription repeats some
+    pk = su.make_multistream(s.packed(), list(widths), rng, max_mix=4, single=())
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    prune = dict(pruneInit=float(rng.choice([60.0, 150.0, 2000.0])), pruneInc=50.0, pruneLim=2000.0)
+    model, fb, acc, pr, st = _run(native, pk, utts, prune=prune, compat=native.COMPAT_STREAM_REVISIT)
+    om, oacc, opr = _oracle_accs(oracle, pk, utts, prune=prune, intended=False)
+    ok = st == 1
+    assert (ok == np.isfinite(opr)).all() and ok.any()
+    assert np.allclose(pr[ok], opr[ok], rtol=1e-9, atol=0)
+    _compare(acc.download(), _odict(oacc), 1e-4, "compat, %d streams" % len(widths), pk["var"])
+
+
 @pytest.mark.parametrize("device_update", [False, True])
 def test_demo_three_streams_reestimated_model_equals_the_reference(native, oracle, tmp_path, device_update):
     d = os.path.join(DEMO, "hmm_streams3")
@@ -141,6 +190,29 @@ def test_herest_cli_three_streams(native, tmp_path):
                  "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
     assert r.returncode == 0, r.stderr
     assert os.path.getsize(str(acc / "HER1.acc")) == os.path.getsize(os.path.join(d, "HER1.acc"))
+
+
+def test_herest_cli_two_streams_compat(native, tmp_path):
+    """tools/bin/herest --compat on the demo set split 13 | 13: the reference HERest's summary lines, statistics file and re-estimated
+    MMF -- the numbers its second-visit arithmetic gives (-33.6 per frame); without the switch the sum of the streams (-59.1)."""
+    tools = os.path.join(ROOT, "tools", "bin")
+    conf = tmp_path / "herest.conf"; conf.write_text("TARGETKIND = MFCC_E_D\n")
+    d = os.path.join(DEMO, "hmm_streams2")
+    def run(extra, out):
+        out.mkdir()
+        return cli.run([os.path.join(tools, "herest"), "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d, "newMacros"), "-M", str(out),
+                        "-s", str(out / "stats"), "-L", os.path.join(DEMO, "labels"), "-t", "2000.0"] + extra + [os.path.join(DEMO, "bcplist")] + cli.demo_train_files())
+    r = run(["--compat"], tmp_path / "c")
+    assert r.returncode == 0, r.stderr
+    for line in open(os.path.join(d, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-400:])
+    cli._mmf_close(cli._mmf_numbers(str(tmp_path / "c" / "newMacros")), cli._mmf_numbers(os.path.join(d, "after_herest")))
+    ours, theirs = (tmp_path / "c" / "stats").read_text().split(), open(os.path.join(d, "stats")).read().split()
+    assert len(ours) == len(theirs)
+    for x, y in zip(ours, theirs):
+        assert x == y or abs(float(x) - float(y)) <= 1e-4 * max(abs(float(y)), 1.0), (x, y)
+    r0 = run([], tmp_path / "p")
+    assert r0.returncode == 0 and "average log prob per frame = -5.9" in r0.stdout, r0.stdout[-300:]
 
 
 @pytest.mark.parametrize("mode", [0, 6, 34])

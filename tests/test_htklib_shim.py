@@ -48,9 +48,8 @@ def test_link_resolves_and_hfb_comes_from_the_shim():
 
 
 @needs_exe
-def test_without_a_device_the_front_end_stops_with_enodev(tmp_path):
-    import torch
-    if torch.cuda.is_available():
+def test_without_a_device_the_front_end_stops_with_enodev(native, tmp_path):
+    if native.lib().htkamd_device_count() > 0:              # (asked of the library itself: torch, asked after it, has answered "none" on a GPU box)
         pytest.skip("a GPU is visible")
     conf = tmp_path / "herest.conf"
     conf.write_text("TARGETKIND = MFCC_E_D\n")
@@ -116,6 +115,25 @@ def test_reference_herest_front_end_on_a_three_stream_set(native, tmp_path):
     for line in open(os.path.join(d3, "herest.log")).read().splitlines():
         assert line in r.stdout, (line, r.stdout[-600:])
     cli._mmf_close(cli._mmf_numbers(str(tmp_path / "newMacros")), cli._mmf_numbers(os.path.join(d3, "after_herest")))
+
+
+@pytest.mark.gpu
+@needs_exe
+def test_reference_herest_front_end_on_a_two_stream_set(native, tmp_path):
+    """... and on the set split into TWO streams, where the reference's Setotprob gives a tied state met again half its log probability
+    (HFB.c:1059): under the reference's own HERest.o the shim asks the library for that arithmetic (htkamd_model_set_compat), so the
+    drop-in writes the reference's summary lines and model there too."""
+    import test_cli_tools as cli
+    d2 = os.path.join(DEMO, "hmm_streams2")
+    conf = tmp_path / "herest.conf"
+    conf.write_text("TARGETKIND = MFCC_E_D\n")
+    files = sorted(os.path.join(DEMO, "train", f) for f in os.listdir(os.path.join(DEMO, "train")) if f.endswith(".mfc"))
+    r = subprocess.run([EXE, "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(d2, "newMacros"), "-M", str(tmp_path),
+                        "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + files, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    for line in open(os.path.join(d2, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-600:])
+    cli._mmf_close(cli._mmf_numbers(str(tmp_path / "newMacros")), cli._mmf_numbers(os.path.join(d2, "after_herest")))
 
 
 # ---------------------------------------------------------------------------------------------------------------- HVite
@@ -270,9 +288,8 @@ def test_block_scorer_shim_exports_hdecodes_two_entry_points():
 
 
 @needs_outpblock
-def test_block_scorer_shim_without_a_device_stops_with_enodev():
-    import torch
-    if torch.cuda.is_available():
+def test_block_scorer_shim_without_a_device_stops_with_enodev(native):
+    if native.lib().htkamd_device_count() > 0:
         pytest.skip("a GPU is visible")
     r = subprocess.run(_outpblock_cmd(False, 4, 1.0), capture_output=True, text=True)
     out = r.stdout + r.stderr

@@ -77,7 +77,7 @@ int main(int argc, char **argv)
    double pruneInit = HTKAMD_NOPRUNE, pruneInc = 0.0, pruneLim = HTKAMD_NOPRUNE;
    float minFrwdP = 10.0f, minVar = 0.0f, mixFloor = 0.0f;
    int uFlags = HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES | HTKAMD_UPTRANS, minEgs = 3, parMode = -1, trace = 0, binary = 0;
-   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1, wire = HTKAMD_WIRE_F64;
+   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1, wire = HTKAMD_WIRE_F64, compat = 0;
    unsigned long long rcclNonce = (unsigned long long)getppid();      /* the ranks of one run are children of one launcher; --rccl-nonce overrides */
    const char *sw;
 
@@ -101,6 +101,7 @@ int main(int argc, char **argv)
             wire = !strcmp(m, "f32") ? HTKAMD_WIRE_F32 : !strcmp(m, "f64") ? HTKAMD_WIRE_F64 : -1;
             if (wire < 0) DIE("--wire: f32 | f64");
          }
+         else if (!strcmp(lo, "compat")) compat = HTKAMD_COMPAT_STREAM_REVISIT;      /* HERest's own numbers on sets of 2 or 4+ streams (HFB.c:1059) */
          else DIE("unknown option --%s", lo);
          continue;
       }
@@ -157,6 +158,7 @@ int main(int argc, char **argv)
    const int D = d->vecSize, H = d->numPhys;
    TOC(0);
    htkamd_model *model; CHECK(htkamd_model_create(d, &model));
+   if (compat) CHECK(htkamd_model_set_compat(model, compat));
    TOC(1);
    int *shareMu = NULL, *shareVa = NULL;
    {  /* tied mean / variance vectors (~u ~v macros) */
