@@ -34,7 +34,7 @@ FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
 FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
 F16_PEAK_TFLOPS = 2500.0                                 # dense f16 / bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                                    # HBM3E, MI355X_MICROARCH.md
-PROFILE_TRAFFIC = "r04a_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
+PROFILE_TRAFFIC = "r04b_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
 
 
 def cpu_baseline(s, pk, budget_s: float):
@@ -186,7 +186,7 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # th
                                  "arithmetic": "exact (K1 dense + K7)", "exact_order_utterances": dec.last_tied(),
                                  "roofline": {"kernel": "k_decode (token passing)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                               "ms": tok_ms, "bytes_per_unit": 4.0 * S_ + 48.0 * V, "unit_is": "(utterance, frame)", "units_per_launch": frames_,
-                                              "traffic": None, "note": "counter bytes: profiles/ (k_decode FETCH_SIZE + WRITE_SIZE)"},
+                                              "traffic": None, "note": "traffic: counter bytes per launch from profiles/ (k_decode FETCH_SIZE + WRITE_SIZE), filled in when the committed PMC passes are of this workload"},
                                  "score_roofline": {"kernel": "k_score_exact (every tied state, every frame) + k_score_transpose", "bound": "mfma", "achieved": sc_ach,
                                                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sc_ach / FP32_PEAK_TFLOPS, "ms": sc_ms,
                                                     "note": "packed fp32 VALU, the reference's four roundings per dimension: half the fp32 peak at best"}}
@@ -754,6 +754,8 @@ def main():
         if args.extras and world == 1:
             try:
                 out["other_paths"] = other_paths(s, pk, dX, frame_off_all)
+                if "k_decode" in traffic_of and "hvite_decoding" in out["other_paths"]:          # counter bytes of the token kernel, per launch (same PMC passes)
+                    out["other_paths"]["hvite_decoding"]["roofline"]["traffic"] = traffic_of["k_decode"]
             except Exception as e:  # noqa: BLE001  (reported beside the line, never instead of it)
                 out["other_paths"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
