@@ -31,6 +31,7 @@ def _stream(s):
 SCORE_EXACT, SCORE_MFMA, SCORE_FASTLADD, SCORE_BF16, SCORE_SOUTP, SCORE_DIAGC, SCORE_F16 = 0, 1, 2, 4, 8, 16, 32
 ERANGE = -7
 COMPAT_STREAM_REVISIT = 1
+COMPAT_SHARED_LOGWT = 2
 ORDER_AUTO, ORDER_FAST, ORDER_EXACT = 0, 1, 2
 
 

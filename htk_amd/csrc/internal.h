@@ -92,6 +92,7 @@ struct htkamd_model {
    float *d_f16Ctl;            /* its control block: scale[96], 1/scale[96], range[192], flag of the last table build, sticky range flag */
    int    bf16Stale, f16Stale; /* the table is older than the parameters (a device update while the path was not in use): rebuilt on its next use */
    int    compat;              /* HTKAMD_COMPAT_* bits (htkamd_model_set_compat) */
+   unsigned char *h_rawLogWt, *d_rawLogWt;   /* [C] HTKAMD_COMPAT_SHARED_LOGWT: the component's weight is read as a LOG weight as it stands (ConvLogWt skipped it), or NULL */
    int    fastUse;             /* HTKAMD_SCORE_BF16 / _F16 bits: the paths that have scored with this model (their tables follow every device update) */
    /* shared mean / variance vectors (~u / ~v macros; htkamd_model_set_sharing): first Gaussian of the group a Gaussian's mean / variance
       belongs to (itself when private), members of its variance group; NULL = no sharing in the set */

@@ -174,7 +174,8 @@ static int model_refresh(htkamd_model *m, bool derive = true)
       if (m->NSt > 1)                                    // a dimension outside the Gaussian's stream takes no part in its score
          for (int g = 0; g < m->G; g++)
             for (int k = 0; k < D; k++) if (m->h_dimStream[k] != m->h_gaussStream[g]) m->h_ivar[(size_t)g * D + k] = 0.0f;
-      for (int c = 0; c < m->C; c++) m->h_compLogWt[c] = htkamd_host_mix_log_weight(m->h_compWeight[c]);
+      for (int c = 0; c < m->C; c++)
+         m->h_compLogWt[c] = (m->h_rawLogWt && m->h_rawLogWt[c]) ? m->h_compWeight[c] : htkamd_host_mix_log_weight(m->h_compWeight[c]);
    }
    for (int t = 0; t < m->nT; t++) {
       const int md = htkamd_host_min_dur(m->h_transN[t], m->h_transP + m->h_transOff[t]);
@@ -364,11 +365,13 @@ extern "C" void htkamd_model_destroy(htkamd_model *m)
    free(m->h_meanLeader); free(m->h_varLeader); free(m->h_varGroupSize); (void)hipFree(m->d_shareTab);
    if (m->h_updPin) (void)hipHostFree(m->h_updPin);
    if (m->evUpd) (void)hipEventDestroy((hipEvent_t)m->evUpd);
+   free(m->h_rawLogWt); (void)hipFree(m->d_rawLogWt);
    free(m->h_tmPoolOff); (void)hipFree(m->d_tmPoolOff); free(m->h_streamWt); (void)hipFree(m->d_streamWt);
    free(m->h_dimStream); free(m->h_gaussStream); (void)hipFree(m->d_dimStream); (void)hipFree(m->d_gaussStream); (void)hipFree(m->d_msCompOff);
    free(m);
 }
 
+static int compat_raw_logwt(htkamd_model *m);
 // Shared mean / variance vectors: share[g] >= 0 names the vector Gaussian g's mean (variance) is a copy of, -1 = private.
 extern "C" int htkamd_model_set_scan_order(htkamd_model *m, const int *order)
 {
@@ -383,6 +386,12 @@ extern "C" int htkamd_model_set_scan_order(htkamd_model *m, const int *order)
    free(seen);
    m->h_scanOrder = (int *)malloc(sizeof(int) * (size_t)(m->H ? m->H : 1));
    memcpy(m->h_scanOrder, order, sizeof(int) * (size_t)m->H);
+   if (m->compat & HTKAMD_COMPAT_SHARED_LOGWT) {           // which state is the FIRST user of a shared pdf depends on the order
+      int rc = compat_raw_logwt(m);
+      if (rc) return rc;
+      if ((rc = model_refresh(m))) return rc;
+      m->bf16Stale = 1; m->f16Stale = 1;
+   }
    return HTKAMD_OK;
 }
 
@@ -457,10 +466,50 @@ extern "C" int htkamd_model_set_tm_beam(htkamd_model *m, float tmBeam)
    return HTKAMD_OK;
 }
 
+// HTKAMD_COMPAT_SHARED_LOGWT: ConvLogWt (HUtil.c:474-485) walks the set with GoNextMix(noSkip = FALSE), which passes over a mixture
+// component whose pdf it has met before (HUtil.c:371-394: IsSeen(mp->nUse)) -- the WEIGHT of that component stays linear and is read as
+// a log weight from then on (MixLogWeight returns it as it stands once hset->logWt is set, HModel.c:5290).  The walk: models in HMM scan
+// order, a model's states 2 .. N - 1 (a state met before is skipped whole), streams, components.
+static int compat_raw_logwt(htkamd_model *m)
+{
+   free(m->h_rawLogWt); m->h_rawLogWt = nullptr;
+   if (m->d_rawLogWt) { (void)hipFree(m->d_rawLogWt); m->d_rawLogWt = nullptr; }
+   if (!(m->compat & HTKAMD_COMPAT_SHARED_LOGWT) || m->tiedMix) return HTKAMD_OK;
+   unsigned char *raw = (unsigned char *)calloc((size_t)(m->C ? m->C : 1), 1);
+   const int NSt = m->NSt > 1 ? m->NSt : 1;
+   unsigned char *seenS = (unsigned char *)calloc((size_t)(m->S ? m->S : 1) * NSt, 1), *seenG = (unsigned char *)calloc((size_t)(m->G ? m->G : 1), 1);
+   int any = 0;
+   for (int hh = 0; hh < m->H; hh++) {
+      const int h = m->h_scanOrder ? m->h_scanOrder[hh] : hh;
+      for (int j = m->h_hmmStateOff[h]; j < m->h_hmmStateOff[h + 1]; j++) {
+         const int e = m->h_hmmState[j];                    // a (state, stream) element: the list holds a state's streams one after the other
+         if (seenS[e]) continue;                            // (a state met before is skipped whole: its elements with it)
+         seenS[e] = 1;
+         for (int c = m->h_stateCompOff[e]; c < m->h_stateCompOff[e + 1]; c++) {
+            const int g = m->h_compGauss[c];
+            if (seenG[g]) { raw[c] = 1; any = 1; } else seenG[g] = 1;
+         }
+      }
+   }
+   free(seenS); free(seenG);
+   if (!any) { free(raw); return HTKAMD_OK; }             // no pdf is shared: nothing differs
+   m->h_rawLogWt = raw;
+   HIPCHECK(hipMalloc((void **)&m->d_rawLogWt, (size_t)m->C));
+   HIPCHECK(hipMemcpy(m->d_rawLogWt, raw, (size_t)m->C, hipMemcpyHostToDevice));
+   return HTKAMD_OK;
+}
+
 extern "C" int htkamd_model_set_compat(htkamd_model *m, int flags)
 {
-   if (!m || (flags & ~HTKAMD_COMPAT_STREAM_REVISIT)) { htkamd_set_error("model_set_compat: unknown flags %d", flags); return HTKAMD_EINVAL; }
+   if (!m || (flags & ~(HTKAMD_COMPAT_STREAM_REVISIT | HTKAMD_COMPAT_SHARED_LOGWT))) { htkamd_set_error("model_set_compat: unknown flags %d", flags); return HTKAMD_EINVAL; }
+   const bool wtChange = ((m->compat ^ flags) & HTKAMD_COMPAT_SHARED_LOGWT) != 0;
    m->compat = flags;
+   if (wtChange) {
+      int rc = compat_raw_logwt(m);
+      if (rc) return rc;
+      if ((rc = model_refresh(m))) return rc;
+      m->bf16Stale = 1; m->f16Stale = 1;
+   }
    return HTKAMD_OK;
 }
 

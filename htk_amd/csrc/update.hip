@@ -28,6 +28,7 @@ struct UpdArgs {
    const int *stateCompOff, *compGauss, *transN, *transOff, *trOccOff, *hmmTrans, *hmmStateOff, *hmmState;
    float *mean, *var, *gconst, *compWeight, *transP;        // parameters (DIAGC variances, linear weights, log transitions)
    float *ivar, *gparam, *compLogWt;                        // derived tables
+   const unsigned char *rawLogWt;                           // HTKAMD_COMPAT_SHARED_LOGWT: components whose weight ConvLogWt skipped (internal.h), or NULL
    const double *acc;
    htkamd_accs_layout lay;
    int minEgs, uFlags, singleProcess, rowNormalise, hasVarFloor;
@@ -96,7 +97,7 @@ __global__ void k_upd_state(UpdArgs a)
    const int c0 = a.stateCompOff[s], M = a.stateCompOff[s + 1] - c0;
    float *wgt = a.compWeight + c0;
    if (a.singleProcess && a.anyS[s])                         // ConvLogWt before the pass, ConvExpWt after it (HERest.c:1336-1339)
-      for (int k = 0; k < M; k++) wgt[k] = (float)exp((double)mix_log_weight(wgt[k]));
+      for (int k = 0; k < M; k++) if (!(a.rawLogWt && a.rawLogWt[c0 + k])) wgt[k] = (float)exp((double)mix_log_weight(wgt[k]));
    if (a.qualS[s] && a.maxM > 1 && (a.uFlags & HTKAMD_UPMIXES)) {
       const float occi = ACCF(a.lay.wtOcc, s);
       if (occi > 0.0f) {
@@ -121,7 +122,7 @@ __global__ void k_upd_state(UpdArgs a)
       } else atomicAdd(a.stats + 4, 1);
    }
    for (int k = 0; k < M; k++) {
-      a.compLogWt[c0 + k] = mix_log_weight(wgt[k]);
+      a.compLogWt[c0 + k] = (a.rawLogWt && a.rawLogWt[c0 + k]) ? wgt[k] : mix_log_weight(wgt[k]);
       const int g = a.compGauss[c0 + k];
       if (a.anyS[s]) a.anyG[g] = 1;
       if (a.qualS[s] && (double)wgt[k] > MINMIX) a.qualG[g] = 1;
@@ -437,7 +438,7 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
    a.stateCompOff = m->d_stateCompOff; a.compGauss = m->d_compGauss; a.transN = m->d_transN; a.transOff = m->d_transOff;
    a.trOccOff = m->d_trOccOff; a.hmmTrans = m->d_hmmTrans; a.hmmStateOff = m->d_hmmStateOff; a.hmmState = m->d_hmmState;
    a.mean = m->d_mean; a.var = m->d_var; a.gconst = m->d_gconst; a.compWeight = m->d_compWeight; a.transP = m->d_transP;
-   a.ivar = m->d_ivar; a.gparam = m->d_gparam; a.compLogWt = m->d_compLogWt;
+   a.ivar = m->d_ivar; a.gparam = m->d_gparam; a.compLogWt = m->d_compLogWt; a.rawLogWt = m->d_rawLogWt;
    a.acc = accs->d_vec; a.lay = accs->lay;
    a.dimStream = m->NSt > 1 ? m->d_dimStream : nullptr; a.gaussStream = m->NSt > 1 ? m->d_gaussStream : nullptr;
    a.minEgs = cfg->minEgs; a.uFlags = cfg->uFlags; a.singleProcess = m->tiedMix ? 0 : cfg->singleProcess; a.rowNormalise = cfg->rowNormalise;

@@ -123,7 +123,8 @@ int htkamd_update_models(struct htkamd_model *m, const htkamd_accs_layout *lay, 
          }
       }
       for (s0 = 0; s0 < m->S; s0++)
-         if (usedS[s0]) for (c = m->h_stateCompOff[s0]; c < m->h_stateCompOff[s0 + 1]; c++) wgt[c] = exp(htkamd_host_mix_log_weight(wgt[c]));
+         if (usedS[s0]) for (c = m->h_stateCompOff[s0]; c < m->h_stateCompOff[s0 + 1]; c++)
+            if (!(m->h_rawLogWt && m->h_rawLogWt[c])) wgt[c] = exp(htkamd_host_mix_log_weight(wgt[c]));      /* (a weight ConvLogWt skipped, ConvExpWt skips too) */
       free(usedS); free(usedG);
    }
    /* UpdateModels walks the set with an HMM scan (HERest.c:1262-1321: NewHMMScan / GoNextHMM, the hash order of the physical models'

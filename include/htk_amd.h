@@ -103,7 +103,7 @@ typedef struct {
           tied states -- unless htkamd_model_set_compat(HTKAMD_COMPAT_STREAM_REVISIT) asks for the reference's value.
         * SHAREDHS sets whose mixtures share pdfs (~m macros without HHEd's TIEDHS conversion): ConvLogWt converts the weights of the
           FIRST state that uses a shared pdf only (HUtil.c:474-485), the others are read as log weights; this library converts
-          every weight once. */
+          every weight once -- unless htkamd_model_set_compat(HTKAMD_COMPAT_SHARED_LOGWT) asks for the reference's reading. */
    int numStreams;
    const int   *dimStream;    /* [D] stream (0-based) of each dimension, NULL for one stream (htkamd_mmf computes it from the kind) */
    /* HTKAMD_HS_TIED: a tied-mixture set (hsKind TIEDHS, <TMIX>): every (state, stream) lists the SAME pool of Gaussians of its stream
@@ -145,8 +145,13 @@ int  htkamd_model_set_tm_beam(htkamd_model *m, float tmBeam);
    state's log probability.  The recursions, occupation and transition counts see that value, the mixture statistics the first visit's
    "sum of the others", as in the reference (HFB.c:1062-1064,1611).  Batches then run on the general workgroup-per-utterance kernels
    (call before htkamd_fb_prepare).  No effect on sets with one or three streams or on tied-mixture sets (the reference's defect is not
-   reached there).  The second difference (weights of shared pdfs, HUtil.c:474) has no switch. */
+   reached there).
+   HTKAMD_COMPAT_SHARED_LOGWT: PLAINHS / SHAREDHS sets whose mixtures share pdfs (~m macros): ConvLogWt passes over a component whose pdf
+   it has met before (GoNextMix, HUtil.c:371-394,474-485), so only the first state's weight of a shared pdf becomes a logarithm and the
+   others are read as log weights as they stand.  "First" is in HMM scan order (htkamd_model_set_scan_order; either call order works).
+   The scoring tables (and every refresh of them after an update) then hold the linear weight where the reference reads it as a log. */
 #define HTKAMD_COMPAT_STREAM_REVISIT 1
+#define HTKAMD_COMPAT_SHARED_LOGWT   2
 int  htkamd_model_set_compat(htkamd_model *m, int flags);
 void htkamd_model_destroy(htkamd_model *m);
 /* Replace the parameters after a re-estimation pass (same topology). Any pointer may be NULL = unchanged. */

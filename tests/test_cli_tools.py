@@ -193,6 +193,14 @@ def test_herest_cli_tied_mixture_pool_in_shared_form(tools, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "average log prob per frame = -6.09970" in r.stdout and "-5.946912e+01" in open(os.path.join(tm, "herest.log")).read()
     assert open(str(out / "newMacros")).read().count('~m "MIX_') == 8 + 15 * 8
+    # ... and with --compat (HTKAMD_COMPAT_SHARED_LOGWT) the reference's reading of those weights: its summary lines and the model it wrote
+    out2 = tmp_path / "compat"; out2.mkdir()
+    r = run([os.path.join(tools, "herest"), "--compat", "-T", "1", "-w", "3", "-v", "0.05", "-C", str(conf), "-u", "tmvw", "-H", os.path.join(tm, "newMacros"), "-M", str(out2),
+             "-L", os.path.join(DEMO, "labels"), "-t", "2000.0", os.path.join(DEMO, "bcplist")] + demo_train_files())
+    assert r.returncode == 0, r.stderr
+    for line in open(os.path.join(tm, "herest.log")).read().splitlines():
+        assert line in r.stdout, (line, r.stdout[-400:])
+    _mmf_close(_mmf_numbers(str(out2 / "newMacros")), _mmf_numbers(os.path.join(tm, "after_herest")))
 
 
 @pytest.mark.gpu

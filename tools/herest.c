@@ -101,7 +101,7 @@ int main(int argc, char **argv)
             wire = !strcmp(m, "f32") ? HTKAMD_WIRE_F32 : !strcmp(m, "f64") ? HTKAMD_WIRE_F64 : -1;
             if (wire < 0) DIE("--wire: f32 | f64");
          }
-         else if (!strcmp(lo, "compat")) compat = HTKAMD_COMPAT_STREAM_REVISIT;      /* HERest's own numbers on sets of 2 or 4+ streams (HFB.c:1059) */
+         else if (!strcmp(lo, "compat")) compat = HTKAMD_COMPAT_STREAM_REVISIT | HTKAMD_COMPAT_SHARED_LOGWT;      /* HERest's own numbers on sets of 2 or 4+ streams (HFB.c:1059) and on sets with shared pdfs (HUtil.c:474) */
          else DIE("unknown option --%s", lo);
          continue;
       }
