@@ -526,8 +526,10 @@ __global__ void k_alpha(FbArgs a)
                   double initx = xpre;
                   initx += bi - pr;
                   // every component's x = initx + logw + prob is <= initx + b_j(t) (+ float rounding)
+                  // (HTKAMD_COMPAT_STREAM_REVISIT: the row may hold a second visit's value, (NS - 1) / 2 times the state's log probability --
+                  //  below it for four streams and more, so no bound: k_mixstats_ms weighs every component of the pair itself)
                   const double ub = initx + (double)oT[c];
-                  if (ub > -minF - 0.01) seed = initx;
+                  if (ub > -minF - 0.01 || a.compatRevisit) seed = initx;
                }
             }
          }

@@ -155,7 +155,14 @@ def fuzz_streams(rng, it):
     if rng.random() < 0.3:
         extra["uFlags"] = int(rng.integers(1, 16))
     path = rng.choice(["state", "wave", "general"])
-    model = capi.Model(pk); om = pyoracle.Model(pk, ms_intended=True)
+    # a third of the plain multi-stream cases with the reference's own second-visit arithmetic (htkamd_model_set_compat): against the oracle
+    # WITHOUT ms_intended, retries of StepBack included
+    compat = kind == "ms" and rng.random() < 0.33
+    if compat and prune and rng.random() < 0.5:
+        prune["pruneInc"] = float(rng.uniform(20, 80)); prune["pruneLim"] = prune["pruneInit"] + 4 * prune["pruneInc"]
+    model = capi.Model(pk); om = pyoracle.Model(pk, ms_intended=not compat)
+    if compat:
+        model.set_compat(capi.COMPAT_STREAM_REVISIT)
     utts = [dict(seq=np.asarray(q, np.int32), feat=x[: max(3, len(x) - int(rng.integers(0, 6)))]) for q, x in zip(seqs, feats)]
     X, frameOff, labOff, labs = batch_arrays(utts)
     dX = capi.DevArray(X)
@@ -179,7 +186,7 @@ def fuzz_streams(rng, it):
         if e > 1e-4:
             bad.append("%s rel %.3g" % (k, e))
     if bad:
-        print("STREAMS it %d kind=%s path=%s prune=%s extra=%s: %s" % (it, kind, path, prune, extra, "; ".join(bad)))
+        print("STREAMS it %d kind=%s path=%s compat=%s prune=%s extra=%s: %s" % (it, kind, path, compat, prune, extra, "; ".join(bad)))
         import pickle
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         pickle.dump(dict(pk=pk, utts=utts, prune=prune, extra=extra, path=str(path), bad=bad), open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_streams_%d.pkl" % it), "wb"))

@@ -130,10 +130,12 @@ def test_demo_two_streams_with_the_reference_s_second_visit_arithmetic(native, o
     assert pr0.sum() < pr.sum() - 1000.0
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+@pytest.mark.parametrize("seed", list(range(11, 27)))
 def test_random_stream_sets_with_the_reference_s_second_visit_arithmetic(native, oracle, seed):
     """The same on random sets of two and four streams with repeated models in the transcriptions (every utterance meets tied states
-    again), beams that prune, and a retry of StepBack (pruneInc): against the oracle without `ms_intended`."""
+    again), beams that prune, and a retry of StepBack (pruneInc): against the oracle without `ms_intended`.  (Four streams: the second
+    visit's value, 1.5 times the log probability, lies BELOW it -- it is no upper bound for a component's posterior; the sweep of
+    tests/fuzz_parity.py found the alpha kernel pruning mixture seeds with it.)"""
     from htk_amd import synth
     rng = np.random.default_rng(seed)
     widths = (10, 10) if seed % 2 else (6, 6, 6, 2)
