@@ -34,7 +34,7 @@ FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
 FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
 F16_PEAK_TFLOPS = 2500.0                                 # dense f16 / bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                                    # HBM3E, MI355X_MICROARCH.md
-PROFILE_TRAFFIC = "r04b_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
+PROFILE_TRAFFIC = "r04c_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
 
 
 def cpu_baseline(s, pk, budget_s: float):
@@ -593,7 +593,7 @@ def main():
 
     if rank == 0:
         flop_unit = FLOP_PER_FRAME_STATE(args.mix, D)
-        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16w<3>", "fastest": "k_score_f16w<3>"}.get(args.score, "k_score_mfma<20>")
+        kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16w<5>" if 31 <= D <= 39 and args.mix <= 16 else "k_score_bf16w", "fastest": "k_score_f16w<3>"}.get(args.score, "k_score_mfma<20>")
         # HBM-side bytes per launch of every kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/prof_r03.sh),
         # same workload only
         traffic_of = {}
@@ -630,6 +630,8 @@ def main():
             # (x^2, x) pairs + the chunk's constant, padded), per component
             kpad = ((D + 14) // 15) * 32
             nprod = 3 if args.score == "fastest" else 6
+            if args.score == "bf16" and 31 <= D <= 39 and args.mix <= 16 and not os.environ.get("HTKAMD_BF16_CHUNKED"):
+                kpad = 80                                   # k_score_bf16w<5>: the 2 D + 2 terms in five k-steps of 16 (gmm_bf16.hip, the dense layout)
             exe = units_local * args.mix * kpad * 2 * nprod / k1 / 1e12 if k1 > 0 else 0.0
             sc.update({"achieved": exe, "peak": F16_PEAK_TFLOPS, "frac": exe / F16_PEAK_TFLOPS, "flop_per_unit": args.mix * kpad * 2 * nprod,
                        "pipe": "v_mfma_f32_32x32x16_f16, operands split in two fp16 pieces, fp32 accumulate" if args.score == "fastest"

@@ -28,6 +28,8 @@ if os.environ.get("HTKAMD_B16_CT"):              # experiment switch: column til
 if os.environ.get("HTKAMD_B16_TF"):              # experiment switch: frames per task of the bf16 scoring kernel in forward-backward (kernels.h: B16_TASK_FRAMES)
     EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_TASK_FRAMES=" + os.environ["HTKAMD_B16_TF"]]
     EXTRA_FLAGS["csrc/fb.hip"] = ["-DB16_TASK_FRAMES=" + os.environ["HTKAMD_B16_TF"]]
+if os.environ.get("HTKAMD_B16_DEFS"):            # experiment switches of gmm_bf16.hip, e.g. HTKAMD_B16_DEFS="-DB16W_EU5=3"
+    EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + os.environ["HTKAMD_B16_DEFS"].split()
 if os.environ.get("HTKAMD_B16_WPB"):             # experiment switch: wavefronts per workgroup of the bf16 scoring kernel (gmm_bf16.hip: B16_WPB)
     EXTRA_FLAGS["csrc/gmm_bf16.hip"] = EXTRA_FLAGS["csrc/gmm_bf16.hip"] + ["-DB16_WPB=" + os.environ["HTKAMD_B16_WPB"]]
 

@@ -271,31 +271,52 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #ifndef B16W_EU
 #define B16W_EU 2
 #endif
-template <int NC>
-__global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
+// KS k-steps of 16.  Even KS: NC = KS / 2 chunks of 32 as described above.  KS = 5, the DENSE layout for 31 <= D <= 39 (39: the usual
+// MFCC_E_D_A, whose 2 D + 2 = 80 terms fill five k-steps exactly where three chunks take six -- a sixth of the matrix instructions,
+// table words and LDS traffic less): two blocks of dimensions, D0 = ceil(D / 2) and D - D0, each as (x^2, x) pairs followed by its
+// constant -0.5 sum mu^2 ivar (k = 2 D0 and k = 2 D + 1); k-steps cut across the pairs, which the products do not mind.  The accumulator
+// still moves from zero through complete squares; between the constants up to 20 dimensions are open instead of 8 (measured: DESIGN §4).
+__device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)      // kind 0: x^2, 1: x, 2: first constant, 3: second constant, -1: padding
+{
+   const int D0 = (D + 1) >> 1;
+   const bool second = k > 2 * D0;                     // (selects, no branches: the kernel runs this per lane)
+   const int kk = second ? k - 2 * D0 - 1 : k;
+   dim = (second ? D0 : 0) + (kk >> 1);
+   kind = kk & 1;
+   if (k == 2 * D0) kind = 2;
+   if (k == 2 * D + 1) kind = 3;
+   if (k > 2 * D + 1) kind = -1;
+   if (kind >= 2 || kind < 0 || dim >= D) dim = 0;
+}
+
+// workgroups per CU by registers and LDS: six k-steps 180 registers / 60 KB -> 2; five 168 / 51 KB -> 3 (measured against 2: DESIGN §4); four 152 / 40 KB -> 3; two 111 / 20 KB -> 4
+#ifndef B16W_EU5
+#define B16W_EU5 3
+#endif
+constexpr int b16w_eu(int KS) { return KS >= 6 ? B16W_EU : KS == 5 ? B16W_EU5 : KS == 4 ? 3 : 4; }
+template <int KS>
+__global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
 {
    static_assert(B16_TASK_FRAMES == 128, "four wavefronts x 32 frames");
-   constexpr int KS = 2 * NC;                          // k-steps of 16
+   constexpr bool DENSE = (KS & 1) != 0;
+   constexpr int NC = (KS + 1) / 2;
    constexpr int TW4 = KS * 3 * 32 + 4;                // 16-byte words per tile in the table
    constexpr int PW4 = KS * 3 * 64 + 8;                // ... per pair in LDS
-   constexpr int PT = (TW4 + 127) / 128;               // words staged per thread (a half workgroup per tile)
    __shared__ u4 wbuf[2][PW4];
-   __shared__ float xbuf[128 * 15 * NC];               // the task's 128 feature rows (D <= 15 NC), as they lie in memory
+   __shared__ float xbuf[128 * (DENSE ? 8 * KS : 15 * NC)];      // the task's 128 feature rows (D <= 15 NC; dense: 2 D + 2 <= 16 KS), as they lie in memory
    __shared__ int taskSh;
    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
    const int fcol = lane & 31, kh = lane >> 5;
    const int D = a.D;
    const int dpc = (D + NC - 1) / NC;                  // dimensions per K chunk (<= 15)
    const u4 *tab = (const u4 *)a.bf16Tab;
-   // staging: wavefronts 0, 1 bring the first state's tile, 2, 3 the second's; word w of a tile goes to the lane that multiplies it
-   const int hsel = __builtin_amdgcn_readfirstlane(wv >> 1), t7 = tid & 127;
-   int dst[PT];
-#pragma unroll
-   for (int j = 0; j < PT; j++) {
-      const int w = t7 + 128 * j;
-      const int comp = w & 15;
-      dst[j] = (w < KS * 96) ? (w >> 5) * 64 + ((w >> 4) & 1) * 32 + 8 * (comp >> 2) + 4 * hsel + (comp & 3) : KS * 192 + hsel * 4 + (w - KS * 96);
-   }
+   // staging by LDS-DMA (global_load_lds_dwordx4: no registers, no LDS store instructions): a row (k-step, piece) of a PAIR is 64 x 16 bytes
+   // in LDS, one wave-instruction; the destination is wave-uniform base + 16 lane, so the interleave of the two states' tiles is made on
+   // the SOURCE side -- LDS lane l' = 32 k-half + 8 (comp >> 2) + 4 h + (comp & 3) takes word (row 32 + 16 k-half + comp) of tile h.
+   // Wavefront w brings rows w, w + 4, ...; the last one also the two states' constants (8 words).
+   const int hL = (lane >> 2) & 1;
+   const int srcOff = (lane >> 5) * 16 + ((lane >> 3) & 3) * 4 + (lane & 3);
+#define GLDS16(src_, dst_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_), (__attribute__((address_space(3))) void *)(dst_), 16, 0, 0)
    const int fw = 32 * wv;                             // this wave's first frame in the task's tile
 
    for (;;) {
@@ -312,13 +333,20 @@ __global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
       }
       int tileV = 0;
       if (lane < tk.nSlots) tileV = a.slotState[tk.slot0 + lane];
-      auto pair_tile = [&](int j) { const int k = 2 * j + hsel; return __builtin_amdgcn_readlane(tileV, (k < tk.nSlots ? k : tk.nSlots - 1) & 63); };
-      {
-         const u4 *W = tab + (size_t)pair_tile(0) * TW4;
+      auto pair_tile = [&](int j, int h) { const int k = 2 * j + h; return __builtin_amdgcn_readlane(tileV, (k < tk.nSlots ? k : tk.nSlots - 1) & 63); };
+      auto stage_pair = [&](int j, int bufi) {
+         const int tA = pair_tile(j, 0), tB = pair_tile(j, 1);
+         // (a uniform base and ONE 32-bit offset per lane: the table is < 4 GB -- 64-bit lane addresses were spilled)
+         const unsigned int off = ((unsigned int)(hL ? tB : tA) * TW4 + srcOff) * 16u;
 #pragma unroll
-         for (int j = 0; j < PT; j++)
-            if (t7 + 128 * j < TW4) wbuf[0][dst[j]] = W[t7 + 128 * j];
-      }
+         for (int r0 = 0; r0 < KS * 3; r0 += 4) {
+            const int r = __builtin_amdgcn_readfirstlane(r0 + wv);
+            if (r < KS * 3) GLDS16((const char *)tab + (off + (unsigned int)r * 512u), &wbuf[bufi][r * 64]);
+         }
+         if (wv == 3 && lane < 8) GLDS16((const char *)tab + (((unsigned int)((lane >> 2) ? tB : tA) * TW4 + KS * 96 + (lane & 3)) * 16u), &wbuf[bufi][KS * 192]);
+      };
+      stage_pair(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 
       // B operand from the rows in LDS: this lane's frame, the 8 k of its k-half in every k-step, in three bf16 pieces
@@ -330,8 +358,18 @@ __global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
          const float *row = xbuf + f * D;
 #pragma unroll
          for (int ks = 0; ks < KS; ks++) {
-            const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * khL;      // chunk; first of this lane's four dimensions within it
             unsigned short p[3][8];
+            if constexpr (DENSE) {
+#pragma unroll
+               for (int i = 0; i < 8; i++) {                        // this lane's eight k of the k-step, one by one
+                  int dim, kind;
+                  dense_slot(16 * ks + 8 * khL + i, D, dim, kind);
+                  const float x = row[dim];
+                  const float v = kind == 0 ? x * x : kind == 1 ? x : kind >= 2 ? 1.0f : 0.0f;
+                  split3(v, p[0][i], p[1][i], p[2][i]);
+               }
+            } else {
+            const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * khL;      // chunk; first of this lane's four dimensions within it
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                int dim = dpc * c + i0 + i;
@@ -343,6 +381,7 @@ __global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
                if ((ks & 1) && khL == 1 && i == 3) v2 = 1.0f;      // k = 30 of the chunk: the constant that meets -0.5 sum mu^2 ivar
                split3(v2, p[0][2 * i], p[1][2 * i], p[2][2 * i]);
                split3(v, p[0][2 * i + 1], p[1][2 * i + 1], p[2][2 * i + 1]);
+            }
             }
 #pragma unroll
             for (int s = 0; s < 3; s++) {
@@ -361,26 +400,28 @@ __global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
       float yP[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) yP[r] = 0.0f;
+      float resQ = 0.0f;                                // the result of the pair before the last one: stored at the top of the next round, so
+      bool haveQ = false;                               // that the store is long done where the round's staging is waited for (vmcnt counts both)
       for (int j = 0; j < nPairs; j++) {
-         u4 stg[PT];
          const bool more = j + 1 < nPairs;
-         if (more) {
-            const u4 *W = tab + (size_t)pair_tile(j + 1) * TW4;
-#pragma unroll
-            for (int q = 0; q < PT; q++)
-               if (t7 + 128 * q < TW4) stg[q] = W[t7 + 128 * q];
-         }
+         if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
+         if (more) stage_pair(j + 1, buf ^ 1);
          if (active) {
             // the log-sum-exp of the pair BEFORE this one (left in yP) in 18 slices, one behind every second matrix instruction of this pair
-            float m8[8], m4[4], m2[2], mx = 0.0f, e[16], sm = 0.0f, lg = 0.0f, resP = 0.0f;
+            // (the sum's tree is ((e_k + e_k+8) + (e_k+4 + e_k+12)) for k = 0 .. 3, then (E0 + E1) + (E2 + E3): the exponentials are taken in
+            //  that order and added as they come -- four partial sums alive instead of sixteen terms)
+            float m8[8], m4[4], m2[2], mx = 0.0f, E[4], pA = 0.0f, sm = 0.0f, lg = 0.0f, resP = 0.0f;
             auto lse_slice = [&](int sl) {
                if (sl < 2) { for (int r = 4 * sl; r < 4 * sl + 4; r++) m8[r] = fmaxf(yP[r], yP[r + 8]); }
                else if (sl == 2) { for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]); }
                else if (sl == 3) { m2[0] = fmaxf(m4[0], m4[1]); m2[1] = fmaxf(m4[2], m4[3]); mx = fmaxf(m2[0], m2[1]); }
-               else if (sl < 12) { for (int r = 2 * (sl - 4); r < 2 * (sl - 4) + 2; r++) e[r] = EXP2(yP[r] - mx); }
-               else if (sl < 14) { for (int r = 4 * (sl - 12); r < 4 * (sl - 12) + 4; r++) e[r] += e[r + 8]; }
-               else if (sl == 14) { for (int r = 0; r < 4; r++) e[r] += e[r + 4]; }
-               else if (sl == 15) { sm = (e[0] + e[1]) + (e[2] + e[3]); }
+               else if (sl < 12) {
+                  const int k = (sl - 4) >> 1;
+                  if (((sl - 4) & 1) == 0) pA = EXP2(yP[k] - mx) + EXP2(yP[k + 8] - mx);
+                  else E[k] = pA + (EXP2(yP[k + 4] - mx) + EXP2(yP[k + 12] - mx));
+               }
+               else if (sl < 15) { }
+               else if (sl == 15) { sm = (E[0] + E[1]) + (E[2] + E[3]); }
                else if (sl == 16) { lg = LOG2(sm); }
                else { resP = (mx + lg) * 0.69314718055994531f; }
             };
@@ -415,8 +456,7 @@ __global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
             }
             for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
             asm volatile("" : "+v"(resP));
-            if (j > 0 && fw + fcol < tk.nFrames) *o = resP;      // (the pair before always has both its states)
-            if (j > 0) o += oStep;
+            resQ = resP; haveQ = j > 0;                  // (the pair before always has both its states)
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
@@ -424,14 +464,11 @@ __global__ __launch_bounds__(256, B16W_EU) void k_score_bf16w(ScoreArgs a)
                for (int r = 0; r < 4; r++) yP[4 * b + r] = (Cx[4 * b + r] + Cc[4 * b + r]) + ci[r];
             }
          }
-         if (more) {
-#pragma unroll
-            for (int q = 0; q < PT; q++)
-               if (t7 + 128 * q < TW4) wbuf[buf ^ 1][dst[q]] = stg[q];
-         }
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next pair's rows have landed (issued a whole round ago)
          __syncthreads();
          buf ^= 1;
       }
+      if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
       if (active) {                                    // the last pair's log-sum-exp
          float m8[8], m4[4];
 #pragma unroll
@@ -462,16 +499,21 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
    }
    ((htkamd_model *)m)->fastUse |= HTKAMD_SCORE_BF16;
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
+   if (m->f16Wide && (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16) >= ((size_t)1 << 32)) {
+      htkamd_set_error("score_bf16: a table of %d tiles is beyond the kernel's 32-bit staging offsets", m->nTiles); return HTKAMD_EMODEL;
+   }
    if (m->f16Wide) {                                 // every state in one tile: 32 x 32 blocks, states in pairs (the table is in that layout)
-      int blocks = a.nTasks;
-      if (blocks > 256 * B16W_EU) blocks = 256 * B16W_EU;
-      dim3 grid(blocks), block(256);
+      dim3 block(256);
+#define W_LAUNCH(KS_) do { const int b_ = a.nTasks < 256 * b16w_eu(KS_) ? a.nTasks : 256 * b16w_eu(KS_); \
+                           hipExtLaunchKernelGGL((k_score_bf16w<KS_>), dim3(b_), block, 0, stream, evStart, evStop, 0, a); } while (0)
+      if (m->bf16Dense) { W_LAUNCH(5); HIPCHECK(hipGetLastError()); return HTKAMD_OK; }
       switch (m->bf16NC) {
-      case 3: hipExtLaunchKernelGGL((k_score_bf16w<3>), grid, block, 0, stream, evStart, evStop, 0, a); break;
-      case 2: hipExtLaunchKernelGGL((k_score_bf16w<2>), grid, block, 0, stream, evStart, evStop, 0, a); break;
-      case 1: hipExtLaunchKernelGGL((k_score_bf16w<1>), grid, block, 0, stream, evStart, evStop, 0, a); break;
+      case 3: W_LAUNCH(6); break;
+      case 2: W_LAUNCH(4); break;
+      case 1: W_LAUNCH(2); break;
       default: htkamd_set_error("score_bf16: no kernel for %d K-chunks", m->bf16NC); return HTKAMD_EMODEL;
       }
+#undef W_LAUNCH
       HIPCHECK(hipGetLastError());
       return HTKAMD_OK;
    }
@@ -552,6 +594,54 @@ __global__ void k_build_bf16tab(Bf16TabArgs a, int nTiles)
    }
 }
 
+// the DENSE layout's table (k_score_bf16w<5>): one thread per (tile, k-step, k-half, component): its 8 coefficients in three pieces
+__global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
+{
+   const int D = a.D;
+   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+   if (idx >= nTiles * KS * 32) return;
+   const int t = idx / (KS * 32), r = idx - t * (KS * 32), ks = r >> 5, khf = (r >> 4) & 1, rowc = r & 15;
+   const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+   const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
+   const size_t tileShorts = ((size_t)KS * 3 * 32 + 4) * 8;
+   unsigned short *T = a.tab + (size_t)t * tileShorts;
+   const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
+   const double L2E = 1.4426950408889634;
+   const float *mu = nullptr, *iv = nullptr;
+   if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
+   const int D0 = (D + 1) >> 1;
+   unsigned short p[3][8];
+#pragma unroll
+   for (int j = 0; j < 8; j++) {
+      int dim, kind;
+      dense_slot(16 * ks + 8 * khf + j, D, dim, kind);
+      float v = 0.0f;
+      if (live && kind == 0) v = (float)(-0.5 * (double)iv[dim] * L2E);
+      else if (live && kind == 1) v = (float)((double)mu[dim] * iv[dim] * L2E);
+      else if (live && kind >= 2) {                         // against B's constant 1: -0.5 sum mu^2 ivar over the block
+         double q = 0.0;
+         for (int i = (kind == 2 ? 0 : D0); i < (kind == 2 ? D0 : D); i++) q += (double)mu[i] * mu[i] * iv[i];
+         v = (float)(-0.5 * q * L2E);
+      }
+      split3(v, p[0][j], p[1][j], p[2][j]);
+   }
+#pragma unroll
+   for (int pc = 0; pc < 3; pc++) {
+      u4 w;
+      w[0] = p[pc][0] | ((unsigned int)p[pc][1] << 16); w[1] = p[pc][2] | ((unsigned int)p[pc][3] << 16);
+      w[2] = p[pc][4] | ((unsigned int)p[pc][5] << 16); w[3] = p[pc][6] | ((unsigned int)p[pc][7] << 16);
+      *(u4 *)(T + ((size_t)(ks * 3 + pc) * 32 + khf * 16 + rowc) * 8) = w;
+   }
+   if (ks == 0 && khf == 0) {
+      float ci = -1.0e30f;
+      if (live) {
+         const double k0 = a.gconst[a.compGauss[c]];
+         ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
+      }
+      ((float *)(T + (size_t)KS * 3 * 32 * 8))[rowc] = ci;
+   }
+}
+
 int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
 {
    hipStream_t s = (hipStream_t)stream;
@@ -560,7 +650,8 @@ int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
    t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss; t.tileState = m->d_tileState;
    t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_bf16Tab;
    const int n = m->nTiles * m->bf16NC * 64;
-   if (m->f16Wide) hipLaunchKernelGGL(k_build_bf16tab<true>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
+   if (m->f16Wide && m->bf16Dense) hipLaunchKernelGGL(k_build_bf16tab_dense, dim3((m->nTiles * 5 * 32 + 255) / 256), dim3(256), 0, s, t, m->nTiles, 5);
+   else if (m->f16Wide) hipLaunchKernelGGL(k_build_bf16tab<true>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    else hipLaunchKernelGGL(k_build_bf16tab<false>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    HIPCHECK(hipGetLastError());
    m->bf16Stale = 0;

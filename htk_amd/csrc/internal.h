@@ -87,6 +87,7 @@ struct htkamd_model {
    int    mfmaStale;           /* the fp32 fragment table is older than the parameters (device update): rebuilt on its next use */
    void  *d_bf16Tab;           /* bf16 x 3 scoring path (gmm_bf16.hip): A-operand pieces per tile; NULL when D > 45 */
    int    bf16NC;              /* K chunks of 32 per piece: ceil(D/15) */
+   int    bf16Dense;           /* the 32 x 32 bf16 kernel's five-k-step layout (31 <= D <= 39, every state in one tile): gmm_bf16.hip, k_score_bf16w<5> */
    void  *d_f16Tab;            /* fp16 x 2 scoring path (gmm_f16.hip): A-operand pieces per tile, K chunks as the bf16 path; NULL when D > 45 */
    int    f16Wide;             /* every state fits one tile (<= 16 components): the 32 x 32 form of the kernel and its table layout */
    float *d_f16Ctl;            /* its control block: scale[96], 1/scale[96], range[192], flag of the last table build, sticky range flag */

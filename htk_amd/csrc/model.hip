@@ -115,6 +115,7 @@ static int mfma_refresh(htkamd_model *m)
       if (m->bf16NC <= 3) {
          HIPCHECK(hipMalloc(&m->d_bf16Tab, (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16)));
          m->f16Wide = m->nTiles == m->S && !getenv("HTKAMD_F16_NARROW");      // (the switch: tests of the 16 x 16 form on such sets)
+         m->bf16Dense = m->f16Wide && D >= 31 && D <= 39 && !getenv("HTKAMD_BF16_CHUNKED");      // (the switch: the six-k-step layout on such sets, for comparisons)
          HIPCHECK(hipMalloc(&m->d_f16Tab, (size_t)m->nTiles * ((size_t)2 * m->bf16NC * 64 * 16 + 64 * 16)));
          HIPCHECK(hipMalloc(&m->d_f16Ctl, sizeof(float) * 512));
          HIPCHECK(hipMemset(m->d_f16Ctl, 0, sizeof(float) * 512));
