@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
          if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
          if (more) stage_pair(j + 1, buf ^ 1);
          if (active) {
-            // the log-sum-exp of the pair BEFORE this one (left in yP) in 18 slices, one behind every second matrix instruction of this pair
+            // the log-sum-exp of the pair BEFORE this one (left in yP) in 18 slices, written between the matrix instructions of this pair (the
+            // compiler places them: pinning every slice with sched_barrier cost 16 registers and 1 % at three workgroups per CU)
             // (the sum's tree is ((e_k + e_k+8) + (e_k+4 + e_k+12)) for k = 0 .. 3, then (E0 + E1) + (E2 + E3): the exponentials are taken in
             //  that order and added as they come -- four partial sums alive instead of sixteen terms)
             float m8[8], m4[4], m2[2], mx = 0.0f, E[4], pA = 0.0f, sm = 0.0f, lg = 0.0f, resP = 0.0f;
@@ -437,22 +438,15 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
 #pragma unroll
                   for (int s = 0; s < 3; s++) wa[ks + 1][s] = __builtin_bit_cast(bf8, wbuf[buf][((ks + 1) * 3 + s) * 64 + lane]);
                }
-               __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][1], Cc, 0, 0, 0);
                if (3 * ks + 0 < 18) lse_slice(3 * ks + 0);
-               __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][2], Cc, 0, 0, 0);
-               __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][2], zb[ks][0], Cc, 0, 0, 0);
                if (3 * ks + 1 < 18) lse_slice(3 * ks + 1);
-               __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
-               __builtin_amdgcn_sched_barrier(0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
                if (3 * ks + 2 < 18) lse_slice(3 * ks + 2);
-               __builtin_amdgcn_sched_barrier(0);
                Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
-               __builtin_amdgcn_sched_barrier(0);
             }
             for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
             asm volatile("" : "+v"(resP));
