@@ -407,32 +407,49 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    lap("workers");
    for (int k = 0; k < nW; k++) if (chunks[k].rc) { htkamd_set_error("%s", chunks[k].err); return chunks[k].rc; }
    // concatenate the shares, rebasing their offsets
-   fb->mN.clear(); fb->mTp.clear(); fb->mCell0.clear(); fb->mSlot0.clear(); fb->mDms.clear(); fb->mHmm.clear(); fb->mTrans.clear();
-   fb->slotState.clear(); fb->slotStateU.clear(); fb->cQ.clear(); fb->cI.clear(); fb->tasks.clear(); fb->tasksW.clear(); fb->thrCell.clear(); fb->sQ.clear();
+   // (the tables are NOT cleared first: resize() of an emptied vector writes zeros over every element the workers are about to fill)
    fb->nCellsMax = 1; fb->QMax = 1; fb->TMax = 1; fb->frameStates = 0;
    int nThrMax = 64;
    size_t outp = 0, beta = 0, gam = 0;
-   for (int k = 0; k < nW; k++) {
-      PrepChunk &C = chunks[k];
-      const int u0 = (int)((long long)U * k / nW), u1 = (int)((long long)U * (k + 1) / nW);
-      const int bQ = (int)fb->mN.size(), bCell = (int)fb->cQ.size(), bSlot = (int)fb->slotState.size(), bThr = (int)fb->thrCell.size();
-      for (int u = u0; u < u1; u++) {
-         UttDesc &d = fb->utt[u];
-         d.q0 += bQ; d.cell0 += bCell; d.slot0 += bSlot; d.thr0 += bThr; d.outp0 += outp; d.beta0 += beta; d.gam0 += gam;
-         fb->gamOff[u] = d.gam0;
+   {
+      // where every share's part begins in the batch's tables, then every worker rebases and copies its own share (the copies were a
+      // third of the call, one thread's)
+      struct Base { size_t q, cell, slot, slotU, thr, tasks, tasksW, outp, beta, gam; };
+      std::vector<Base> base((size_t)nW + 1);
+      Base z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < nW; k++) {
+         const PrepChunk &C = chunks[k];
+         base[k] = z;
+         z.q += C.mN.size(); z.cell += C.cQ.size(); z.slot += C.slotState.size(); z.slotU += C.slotStateU.size(); z.thr += C.thrCell.size();
+         z.tasks += C.tasks.size(); z.tasksW += C.tasksW.size(); z.outp += C.outp; z.beta += C.beta; z.gam += C.gam;
+         fb->frameStates += C.frameStates;
+         if (C.nCellsMax > fb->nCellsMax) fb->nCellsMax = C.nCellsMax;
+         if (C.QMax > fb->QMax) fb->QMax = C.QMax;
+         if (C.TMax > fb->TMax) fb->TMax = C.TMax;
+         if (C.nThrMax > nThrMax) nThrMax = C.nThrMax;
       }
+      base[nW] = z;
+      outp = z.outp; beta = z.beta; gam = z.gam;
+      fb->mN.resize(z.q); fb->mTp.resize(z.q); fb->mCell0.resize(z.q); fb->mSlot0.resize(z.q); fb->mDms.resize(z.q); fb->mHmm.resize(z.q); fb->mTrans.resize(z.q);
+      fb->slotState.resize(z.slot); fb->sQ.resize(z.slot); fb->slotStateU.resize(z.slotU); fb->cQ.resize(z.cell); fb->cI.resize(z.cell); fb->thrCell.resize(z.thr);
+      fb->tasks.resize(z.tasks); fb->tasksW.resize(z.tasksW);
       const int NSt = fb->m->NSt;
-      for (ScoreTask &tk : C.tasks) { tk.slot0 += bSlot * NSt; tk.outBase += outp * NSt; }
-      for (ScoreTask &tk : C.tasksW) { tk.slot0 += bSlot * NSt; tk.outBase += outp * NSt; }
-      auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
-      app(fb->mN, C.mN); app(fb->mTp, C.mTp); app(fb->mCell0, C.mCell0); app(fb->mSlot0, C.mSlot0); app(fb->mDms, C.mDms); app(fb->mHmm, C.mHmm);
-      app(fb->mTrans, C.mTrans); app(fb->slotState, C.slotState); app(fb->slotStateU, C.slotStateU); app(fb->sQ, C.sQ); app(fb->cQ, C.cQ); app(fb->cI, C.cI); app(fb->thrCell, C.thrCell); app(fb->tasks, C.tasks); app(fb->tasksW, C.tasksW);
-      outp += C.outp; beta += C.beta; gam += C.gam;
-      fb->frameStates += C.frameStates;
-      if (C.nCellsMax > fb->nCellsMax) fb->nCellsMax = C.nCellsMax;
-      if (C.QMax > fb->QMax) fb->QMax = C.QMax;
-      if (C.TMax > fb->TMax) fb->TMax = C.TMax;
-      if (C.nThrMax > nThrMax) nThrMax = C.nThrMax;
+      fb->pool->run(nW, [&](int k) {
+         PrepChunk &C = chunks[k];
+         const Base &B = base[k];
+         const int u0 = (int)((long long)U * k / nW), u1 = (int)((long long)U * (k + 1) / nW);
+         for (int u = u0; u < u1; u++) {
+            UttDesc &d = fb->utt[u];
+            d.q0 += (int)B.q; d.cell0 += (int)B.cell; d.slot0 += (int)B.slot; d.thr0 += (int)B.thr; d.outp0 += B.outp; d.beta0 += B.beta; d.gam0 += B.gam;
+            fb->gamOff[u] = d.gam0;
+         }
+         for (ScoreTask &tk : C.tasks) { tk.slot0 += (int)B.slot * NSt; tk.outBase += B.outp * NSt; }
+         for (ScoreTask &tk : C.tasksW) { tk.slot0 += (int)B.slot * NSt; tk.outBase += B.outp * NSt; }
+         auto put = [](auto &dst, size_t at, const auto &src) { if (!src.empty()) memcpy(dst.data() + at, src.data(), sizeof(src[0]) * src.size()); };
+         put(fb->mN, B.q, C.mN); put(fb->mTp, B.q, C.mTp); put(fb->mCell0, B.q, C.mCell0); put(fb->mSlot0, B.q, C.mSlot0); put(fb->mDms, B.q, C.mDms); put(fb->mHmm, B.q, C.mHmm);
+         put(fb->mTrans, B.q, C.mTrans); put(fb->slotState, B.slot, C.slotState); put(fb->sQ, B.slot, C.sQ); put(fb->slotStateU, B.slotU, C.slotStateU);
+         put(fb->cQ, B.cell, C.cQ); put(fb->cI, B.cell, C.cI); put(fb->thrCell, B.thr, C.thrCell); put(fb->tasks, B.tasks, C.tasks); put(fb->tasksW, B.tasksW, C.tasksW);
+      });
    }
    fb->gamOff[U] = gam;
    {  // utterance of every 512th seed (k_mixstats' scan chunks)
@@ -535,9 +552,16 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       if (fb->copyPending) { HIPCHECK(hipEventSynchronize(fb->evCopy)); fb->copyPending = false; }   // previous batch still in flight
       for (Part &q : parts) q.dst->release();
       if ((rc = fb->d_arena.reserve(total))) return rc;
-      for (Part &q : parts) {
-         if (q.bytes) memcpy((char *)fb->h_arena + q.off, q.src, q.bytes);
-         q.dst->set_view((char *)fb->d_arena.p + q.off);
+      {  // the staging copy by the workers too: parts cut into 256 KB pieces
+         struct Piece { char *dst; const char *src; size_t n; };
+         std::vector<Piece> pieces;
+         for (Part &q : parts) {
+            for (size_t o = 0; o < q.bytes; o += (size_t)256 << 10)
+               pieces.push_back({(char *)fb->h_arena + q.off + o, (const char *)q.src + o, (q.bytes - o < ((size_t)256 << 10)) ? q.bytes - o : ((size_t)256 << 10)});
+            q.dst->set_view((char *)fb->d_arena.p + q.off);
+         }
+         const int nP = (int)pieces.size(), nT = nW < 8 ? nW : 8;
+         fb->pool->run(nT, [&](int k) { for (int i = k; i < nP; i += nT) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n); });
       }
       HIPCHECK(hipMemcpyAsync(fb->d_arena.p, fb->h_arena, total, hipMemcpyHostToDevice, s));
       HIPCHECK(hipEventRecord(fb->evCopy, s));
