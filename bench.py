@@ -601,8 +601,13 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)))
             w = tj["workload"]
             if (w["states"], w["mix"], w["utts_per_gpu"], w["frames"], w.get("chunks", 1)) == (args.states, args.mix, args.utts, args.frames, NCH):
+                # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE tallies a 16-byte-per-lane streaming read at HALF its bytes -- doubled for the
+                # kernels whose reads are of that width (the matrix-core scoring kernels' table tiles); WRITE_SIZE is exact for 16-byte
+                # stores and float atomics; other widths (the recursions' 8-byte columns, 4-byte scores) are uncalibrated and left as counted
                 for kn, k in tj["kernels"].items():
-                    traffic_of[kn.split("<")[0]] = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+                    base = kn.split("<")[0]
+                    corr = 2.0 if base in ("k_score_bf16w", "k_score_f16w", "k_score_bf16", "k_score_f16") else 1.0
+                    traffic_of[base] = (corr * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
         except (OSError, KeyError, ValueError):
             traffic_of = {}
         # Per kernel of the pass (its launches of one iteration, one per chunk: algorithmic work of the iteration / summed duration).
@@ -678,7 +683,10 @@ def main():
             "score_mode": args.score,
             "streams": len(lanes),
             # the kernel with the largest total time in the timed iterations
-            "roofline": dict(per_kernel[dom], units_per_launch=units_local / NCH, launches_per_step=NCH),
+            "roofline": dict(per_kernel[dom], units_per_launch=units_local / NCH, launches_per_step=NCH,
+                             traffic_source="profiles/%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bytes per launch; FETCH_SIZE doubled for this "
+                                            "kernel's 16-byte-per-lane reads (MI355X_MICROARCH.md: gfx950 tallies them at half)" % PROFILE_TRAFFIC
+                             if dom == "score" and args.score in ("bf16", "fastest") else "profiles/%s: FETCH_SIZE + WRITE_SIZE per launch as counted (8- and 4-byte accesses: uncalibrated on gfx950)" % PROFILE_TRAFFIC),
             "roofline_kernels": per_kernel,
         }
         if fastest_side is not None:

@@ -39,7 +39,7 @@ try:
 except Exception:  # noqa: BLE001
     cfg = {}
 json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`, counters' KB per launch, "
-                       "uncorrected (MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of 16 B/lane streaming reads; narrower loads uncalibrated)",
+                       "as counted -- bench.py doubles FETCH_SIZE for the kernels whose reads are 16 bytes per lane (MI355X_MICROARCH.md: gfx950 tallies those at half; narrower loads uncalibrated)",
            "workload": {k: cfg.get(k) for k in ("states", "mix", "utts_per_gpu", "frames", "chunks")}, "kernels": traffic},
           open(os.path.join("profiles", "%s_traffic.json" % tag), "w"), indent=1)
 sq = {}
