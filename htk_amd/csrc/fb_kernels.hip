@@ -1188,9 +1188,6 @@ __global__ __launch_bounds__(256) void k_mixstats_ms(FbArgs a)
    const int lane = threadIdx.x & 63;
    const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
    const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-   const int D = a.D, NSt = a.NSt;
-   const double minF = (double)a.minFrwdP;
-   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
    for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
       volatile unsigned short *hIdx = hitIdx[threadIdx.x >> 6];
       volatile double *hSeed = hitSeed[threadIdx.x >> 6];
@@ -1441,9 +1438,6 @@ __global__ __launch_bounds__(256) void k_mixstats_tm(FbArgs a)
    const int lane = threadIdx.x & 63;
    const size_t nWaves = ((size_t)gridDim.x * blockDim.x) >> 6;
    const size_t waveId = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-   const int D = a.D, NSt = a.NSt;
-   const double minF = (double)a.minFrwdP;
-   const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS, upWt = a.uFlags & HTKAMD_UPMIXES;
    for (size_t base0 = waveId * 512; base0 < a.gamTotal; base0 += nWaves * 512) {
       volatile unsigned short *hIdx = hitIdx[threadIdx.x >> 6];
       volatile double *hSeed = hitSeed[threadIdx.x >> 6];
