@@ -34,7 +34,7 @@ FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
 FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
 F16_PEAK_TFLOPS = 2500.0                                 # dense f16 / bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                                    # HBM3E, MI355X_MICROARCH.md
-PROFILE_TRAFFIC = "r04c_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
+PROFILE_TRAFFIC = "r04d_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
 
 
 def cpu_baseline(s, pk, budget_s: float):
