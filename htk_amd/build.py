@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libhtk_amd.so")
 HIP_SRCS = ["csrc/model.hip", "csrc/gmm_exact.hip", "csrc/gmm_mfma.hip", "csrc/gmm_bf16.hip", "csrc/gmm_f16.hip", "csrc/fb_kernels.hip", "csrc/fb_wave.hip", "csrc/fb_state.hip", "csrc/fb_lr.hip", "csrc/fb.hip", "csrc/viterbi.hip", "csrc/decode.hip", "csrc/decode_n.hip", "csrc/decode_ord.hip", "csrc/mfcc.hip", "csrc/update.hip", "csrc/comm.hip"]
 C_SRCS = ["host/prep.c", "host/update.c", "host/fbank.c", "host/accio.c", "host/parmfile.c", "host/mmf.c", "host/labio.c", "host/net.c", "host/lattice.c"]
-HEADERS = ["csrc/internal.h", "csrc/kernels.h", "csrc/hipcheck.h", "csrc/ladd.h", "csrc/wavegrp.h", "csrc/fb_state.h", "csrc/decode.h", "csrc/decode_ord.h", "../include/htk_amd.h"]
+HEADERS = ["csrc/fb_lr_lean.inc", "csrc/internal.h", "csrc/kernels.h", "csrc/hipcheck.h", "csrc/ladd.h", "csrc/wavegrp.h", "csrc/fb_state.h", "csrc/decode.h", "csrc/decode_ord.h", "../include/htk_amd.h"]
 ARCH = "gfx950"
 # the tolerance-class scoring kernel never sees NaNs: lets v_max_f32 go without the IEEE canonicalisation of its operands
 EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["-fno-honor-nans"], "csrc/gmm_f16.hip": ["-fno-honor-nans"]}

@@ -117,6 +117,7 @@ struct htkamd_fb {
    std::vector<UttDesc> utt;
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState, slotStateU;
    std::vector<short> cQ, cI, taperLo, taperHi, thrCell, sQ;
+   std::vector<int> qBeamNP;    // per frame: the beta beam of the un-pruned pass, lo | hi << 16 (what SetBeta leaves in qLo / qHi when only the taper acts)
    std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
    std::vector<size_t> gamOff;
    std::vector<int> gamChunkUtt;
@@ -136,6 +137,9 @@ struct htkamd_fb {
    int clsOff[14];                          // class c occupies uttList[clsOff[c] .. clsOff[c+1])
    size_t betaWTotal, alphaWTotal;
    DevBuf d_alphaW, d_qBeam, d_aBeam, d_trPart, d_hits, d_hitCtl;   // left-to-right path (fb_lr.hip)
+   DevBuf d_sink;                            // FbArgs::sink
+   DevBuf d_qBeamNP, d_laneRec;              // ... the host's un-pruned beta beams (a view into the arena); a record per chain state for the sparse statistics
+   const int *qBeamLast = nullptr;           // the beta beam words the last pass's left-to-right kernels read (d_qBeam or d_qBeamNP)
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
    DevBuf d_rec, d_recSorted, d_recCtl;     // statistics records (kernels.h MixRec)
@@ -183,7 +187,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_laneRec, &fb->d_sink};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    if (fb->h_res) (void)hipHostFree(fb->h_res);
@@ -299,6 +303,8 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
       {
          const long long before = C.frameStates;
          int qHiN = Q, qLoN = lo[T];
+         int *npw = fb->qBeamNP.data() + d.frame0 - 1;                      // 1-based t
+         npw[T] = qLoN | (qHiN << 16);
          const int *msl = C.mSlot0.data() + d.q0 - 1;
          auto slotsIn = [&](int a, int z) { return (z < Q ? msl[z + 1] : nSlots) - msl[a]; };
          evLo[T] = qLoN > 1 ? qLoN - 1 : 1; evHi[T] = Q;
@@ -310,6 +316,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
             evLo[t] = endq > 1 ? endq - 1 : 1; evHi[t] = startq;
             C.frameStates += slotsIn(evLo[t], startq);
             qHiN = (hi[t] < startq) ? hi[t] : startq; qLoN = endq;
+            npw[t] = qLoN | (qHiN << 16);
          }
          d.nEval = (int)(C.frameStates - before);
       }
@@ -384,6 +391,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    fb->utt.assign(U, UttDesc());
    fb->totalFrames = U ? b->frameOff[U] : 0;
    fb->taperLo.assign(fb->totalFrames, 0); fb->taperHi.assign(fb->totalFrames, 0);
+   fb->qBeamNP.assign((size_t)fb->totalFrames + 1, 1);
    fb->gamOff.assign(U + 1, 0);
    if (!fb->pool) {
       int hw = (int)std::thread::hardware_concurrency();
@@ -538,7 +546,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_gamChunkUtt, fb->gamChunkUtt.data(), sizeof(int) * fb->gamChunkUtt.size(), 0},
          {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0},
          {&fb->d_slotStateU, fb->slotStateU.data(), sizeof(int) * fb->slotStateU.size(), 0},
-         {&fb->d_nextSame, fb->nextSame.data(), sizeof(int) * fb->nextSame.size(), 0}};
+         {&fb->d_nextSame, fb->nextSame.data(), sizeof(int) * fb->nextSame.size(), 0},
+         {&fb->d_qBeamNP, fb->qBeamNP.data(), sizeof(int) * fb->qBeamNP.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -678,13 +687,15 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    const int nGeneral = fb->clsOff[5] - fb->clsOff[4];
    fb->lastWave = nGeneral == 0;
    if (nGeneral > 0 && ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
-   if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 5 * 64)))) return rc;
+   if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 8 * 512)))) return rc;      /* (the lean alpha kernel requests up to three columns past an utterance's last: never used, but inside the buffer) */
    fa.betaW = (double *)fb->d_betaW.p;
    const int nLr = fb->clsOff[13] - fb->clsOff[9];
    size_t rows = 0;
    if (nLr > 0) {
       for (int c = 0; c < 4; c++) rows += (size_t)(fb->clsOff[10 + c] - fb->clsOff[9 + c]) * htkamd_stats_lr_chunks(fb->TMax) * (1 << c);
       const size_t nfr = fb->totalFrames ? fb->totalFrames : 1;
+      if ((rc = fb->d_laneRec.reserve(sizeof(LaneRec) * (fb->slotState.size() + 1))) || (rc = fb->d_sink.reserve(256))) return rc;
+      fa.laneRec = (LaneRec *)fb->d_laneRec.p; fa.sink = (double *)fb->d_sink.p;
       if ((rc = fb->d_alphaW.reserve(sizeof(double) * (fb->alphaWTotal + 64))) || (rc = fb->d_qBeam.reserve(sizeof(int) * (nfr + 2))) ||
           (rc = fb->d_aBeam.reserve(sizeof(int) * (nfr + 2))) || (rc = fb->d_trPart.reserve(sizeof(double) * htkamd_stats_lr_row_doubles() * (rows + 256))) ||
           (rc = fb->d_hits.reserve(sizeof(MixHit) * (rows * htkamd_stats_lr_region_cap() + 64))) || (rc = fb->d_hitCtl.reserve(sizeof(int) * (rows + 1))))
@@ -692,6 +703,12 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       fa.alphaW = (double *)fb->d_alphaW.p; fa.qBeam = (int *)fb->d_qBeam.p; fa.aBeam = (int *)fb->d_aBeam.p; fa.trPart = (double *)fb->d_trPart.p;
       fa.hits = (MixHit *)fb->d_hits.p; fa.hitCtl = (int *)fb->d_hitCtl.p; fa.nHitRegions = (int)rows; fa.hitRegionCap = htkamd_stats_lr_region_cap();
       fa.hitSlots = (m->NSt > 1 || m->tiedMix) ? 1 : 0;
+      // without a pruning beam the beta beams are the taper's, made on the host with the batch tables: the lean beta kernel reads them,
+      // and so do the alpha and statistics kernels behind it (fb_lr_lean.inc)
+      fa.qBeamNP = (const int *)fb->d_qBeamNP.p;
+      if (htkamd_beta_lr_is_lean(fa, fastLadd)) fa.qBeam = (int *)fb->d_qBeamNP.p;
+      fb->qBeamLast = fa.qBeam;
+      { const char *e = getenv("HTKAMD_LR_EXP"); fa.lrExp = e ? atoi(e) : 0; }
    }
    static const int clsW[4] = {1, 2, 4, 8};
    // the longest chains first: their recursions are the critical path of the pass
@@ -859,7 +876,12 @@ extern "C" int htkamd_fb_get_trellis(htkamd_fb *fb, int u, double *beta, double 
    HIPCHECK(hipMemcpy(hi.data(), (short *)fb->d_qHi.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
    HIPCHECK(hipMemcpy(alo.data(), (short *)fb->d_aLo.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
    HIPCHECK(hipMemcpy(ahi.data(), (short *)fb->d_aHi.p + d.frame0, sizeof(short) * T, hipMemcpyDeviceToHost));
-   if (d.W > 0 && d.pad == 2) {                          // left-to-right path: the alpha beam comes as the first lanes of its first and last model
+   if (d.W > 0 && d.pad == 2 && fb->qBeamLast) {         // left-to-right path: the beta beams as words (the lean beta kernel writes no qLo / qHi)
+      std::vector<int> qb(T);
+      HIPCHECK(hipMemcpy(qb.data(), fb->qBeamLast + d.frame0, sizeof(int) * T, hipMemcpyDeviceToHost));
+      for (int t = 0; t < T; t++) { lo[t] = (short)(qb[t] & 0xffff); hi[t] = (short)((qb[t] >> 16) & 0xffff); }
+   }
+   if (d.W > 0 && d.pad == 2) {                          // left-to-right path: the alpha beam comes as lanes of its first and last model
       std::vector<int> ab(T);
       HIPCHECK(hipMemcpy(ab.data(), (int *)fb->d_aBeam.p + d.frame0, sizeof(int) * T, hipMemcpyDeviceToHost));
       for (int t = 0; t < T; t++) { alo[t] = fb->sQ[d.slot0 + (ab[t] & 0xffff)]; ahi[t] = fb->sQ[d.slot0 + ((ab[t] >> 16) & 0xffff)]; }

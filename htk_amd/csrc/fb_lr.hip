@@ -67,6 +67,18 @@ __device__ __forceinline__ void load_lr(LrRegs &s, const FbArgs &a, const UttDes
    if (s.last && s.q < ud.Q) s.aEntryNext = a.transP[a.mTp[s.mi + 1] + 1];
 }
 
+// what the sparse statistics kernel (k_stats_sp) needs of a chain state, left by the beta kernels in the batch's record table
+__device__ __forceinline__ void store_lane_rec(const FbArgs &a, const UttDesc &ud, int gl, bool valid, const LrRegs &s)
+{
+   if (!valid || !a.laneRec) return;
+   LaneRec r;
+   r.aSelf = s.aSelf; r.aOut = s.last ? s.aExit : s.aNext; r.aEntry = s.aEntry; r.aEntryNext = s.aEntryNext;
+   r.q = (short)s.q; r.j = (short)s.j; r.N = (short)s.N; r.pad = 0;
+   r.sidx = a.slotState[ud.slot0 + gl];
+   r.cM = a.stateCompOff[r.sidx + 1] - a.stateCompOff[r.sidx];
+   a.laneRec[ud.slot0 + gl] = r;
+}
+
 // LAdd(LZERO, v) of the reference (HMath.c:1576): v itself unless it is below LSMALL
 __device__ __forceinline__ double from_zero(double v) { return (v < LSMALL) ? LZERO : v; }
 
@@ -108,6 +120,7 @@ __global__ __launch_bounds__(64 * W) void k_beta_lr(FbArgs a)
    const bool valid = gl < nS;
    LrRegs s;
    load_lr(s, a, ud, gl, valid);
+   store_lane_rec(a, ud, gl, valid, s);
    for (int i = gl; i < LP; i += L) { xbeta[0][i] = LZERO; xbeta[1][i] = LZERO; xobs[0][i] = 0.0; xobs[1][i] = 0.0; }
    sqOf[gl] = (short)(valid ? s.q : Q + 1);
    if (valid && s.first) flOf[s.q] = (short)gl;
@@ -761,6 +774,8 @@ __global__ __launch_bounds__(256) void k_trans_reduce(FbArgs a, int nRows)
    if (tid == 0) add_row(tb, sh[16]);
 }
 
+#include "fb_lr_lean.inc"
+
 template <bool FAST> static void launch_beta_lr(const FbArgs &a, int W, hipStream_t s)
 {
    if (W == 1) hipLaunchKernelGGL((k_beta_lr<1, FAST>), dim3(a.nList), dim3(64), 0, s, a);
@@ -787,9 +802,37 @@ int htkamd_stats_lr_chunks(int TMax) { return (TMax + STATS_FC - 1) / STATS_FC; 
 int htkamd_stats_lr_region_cap(void) { return STATS_FC * 64; }
 size_t htkamd_stats_lr_row_doubles(void) { return TR_ROW; }
 
+// experiment / fallback switch: HTKAMD_LR_LEAN=0 keeps the round-4 kernels (bit 0: beta, bit 1: alpha, bit 2: statistics, bit 3: one
+// wavefront with two states per lane for chains of 65 .. 128 states; default 15)
+static int lr_lean_mask()
+{
+   static const int m = [] { const char *e = getenv("HTKAMD_LR_LEAN"); return e ? atoi(e) : 15; }();
+   return m;
+}
+#define LAUNCH_W(K, ...) \
+   do { \
+      if (W == 1) hipLaunchKernelGGL((K<1, ##__VA_ARGS__>), grid, dim3(64), 0, s, a); \
+      else if (W == 2) hipLaunchKernelGGL((K<2, ##__VA_ARGS__>), grid, dim3(128), 0, s, a); \
+      else if (W == 4) hipLaunchKernelGGL((K<4, ##__VA_ARGS__>), grid, dim3(256), 0, s, a); \
+      else hipLaunchKernelGGL((K<8, ##__VA_ARGS__>), grid, dim3(512), 0, s, a); \
+   } while (0)
+
+// no pruning beam and the fp32-transcendental class: the lean kernels (fb_lr_lean.inc)
+bool htkamd_beta_lr_is_lean(const FbArgs &a, bool fast) { return fast && a.qBeamNP && !(a.pruneInit < HTKAMD_NOPRUNE) && (lr_lean_mask() & 1); }
+
 int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
+   if (htkamd_beta_lr_is_lean(a, fast)) {
+      const dim3 grid(a.nList);
+      if (W == 2 && (lr_lean_mask() & 8)) hipLaunchKernelGGL(k_beta_np2, grid, dim3(64), 0, s, a);      // one wavefront, two states per lane
+      else if (W == 1) hipLaunchKernelGGL((k_beta_np<1>), grid, dim3(64), 0, s, a);
+      else if (W == 2) hipLaunchKernelGGL((k_beta_np<2>), grid, dim3(128), 0, s, a);
+      else if (W == 4) hipLaunchKernelGGL((k_beta_np<4>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_beta_np<8>), grid, dim3(512), 0, s, a);
+      HIPCHECK(hipGetLastError());
+      return HTKAMD_OK;
+   }
    if (fast) launch_beta_lr<true>(a, W, s); else launch_beta_lr<false>(a, W, s);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
@@ -798,6 +841,15 @@ int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
 int htkamd_launch_alpha_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
+   if (fast && (lr_lean_mask() & 2)) {
+      const dim3 grid(a.nList);
+      if (W == 2 && (lr_lean_mask() & 8)) {
+         if (a.alphaDbg) hipLaunchKernelGGL(k_alpha_f2<true>, grid, dim3(64), 0, s, a); else hipLaunchKernelGGL(k_alpha_f2<false>, grid, dim3(64), 0, s, a);
+      }
+      else if (a.alphaDbg) LAUNCH_W(k_alpha_f, true); else LAUNCH_W(k_alpha_f, false);
+      HIPCHECK(hipGetLastError());
+      return HTKAMD_OK;
+   }
    if (fast) launch_alpha_lr<true>(a, W, s); else launch_alpha_lr<false>(a, W, s);
    HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
@@ -809,7 +861,11 @@ int htkamd_launch_stats_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
    const int nChunks = htkamd_stats_lr_chunks(a.TMax);
-   if (fast) launch_stats_lr<true>(a, W, nChunks, s); else launch_stats_lr<false>(a, W, nChunks, s);
+   if (a.laneRec && (lr_lean_mask() & 4)) {
+      const dim3 grid(a.nList, nChunks);
+      if (fast) LAUNCH_W(k_stats_sp, true); else LAUNCH_W(k_stats_sp, false);
+   }
+   else if (fast) launch_stats_lr<true>(a, W, nChunks, s); else launch_stats_lr<false>(a, W, nChunks, s);
    const int nRows = a.nList * nChunks * W;
    hipLaunchKernelGGL(k_trans_reduce, dim3((nRows + 255) / 256), dim3(256), 0, s, a, nRows);
    HIPCHECK(hipGetLastError());

@@ -86,6 +86,8 @@ struct UttDesc {
    int QP, pad2;      // Q rounded up to a multiple of 8
 };
 
+// what the statistics of a (frame, chain state) pair need of the state (left-to-right path: written by the beta kernels, a record per slot)
+struct LaneRec { float aSelf, aOut, aEntry, aEntryNext; short q, j, N, pad; int sidx, cM; };
 struct MixRec { int g, frame; double L; };          // posterior L of Gaussian g at row `frame` of the feature table
 struct MixHit { int st, frame; double seed; };      // a (frame, state) pair the MINFORPROB prune lets through: tied state, row of the feature table, seed
 
@@ -156,6 +158,10 @@ struct FbArgs {
    int hitSlots;                     // multi-stream / tied-mixture sets: MixHit::st is the pair's global SLOT (slot0 of its utterance + chain state), not its tied state
    int *hitCtl;                      // [r] records in region r
    int nHitRegions, hitRegionCap;
+   LaneRec *laneRec;                 // left-to-right path: [slot0 + lane], written by the beta kernels
+   const int *qBeamNP;               // left-to-right path: the beta beams of the un-pruned pass (host: SetBeamTaper alone decides them), lo | hi << 16 per frame
+   double *sink;                     // 64 bytes nobody reads: where the lanes outside a beam "store" (one cache line instead of a branch around the store)
+   int lrExp;                        // ablation bits of an -DLR_EXP_BUILD=1 build (tools/lr_exp.py); 0 otherwise
 };
 
 int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
@@ -177,6 +183,7 @@ int htkamd_launch_alpha_s(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_beta_w(const FbArgs &a, int W, bool fast, hipStream_t s);
 // left-to-right chains (fb_lr.hip): state-per-lane recursions without statistics + frame-parallel statistics
 int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
+bool htkamd_beta_lr_is_lean(const FbArgs &a, bool fast);      // the pass's beta kernel reads the host's un-pruned beams (FbArgs::qBeamNP) instead of writing FbArgs::qBeam
 int htkamd_launch_alpha_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_stats_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_stats_lr_chunks(int TMax);
