@@ -138,6 +138,7 @@ struct htkamd_fb {
    size_t betaWTotal, alphaWTotal;
    DevBuf d_alphaW, d_qBeam, d_aBeam, d_trPart, d_hits, d_hitCtl;   // left-to-right path (fb_lr.hip)
    DevBuf d_sink;                            // FbArgs::sink
+   DevBuf d_stCnt, d_stBucket;               // FbArgs::stCnt, stBucket (k_mixstate)
    DevBuf d_qBeamNP, d_laneRec;              // ... the host's un-pruned beta beams (a view into the arena); a record per chain state for the sparse statistics
    const int *qBeamLast = nullptr;           // the beta beam words the last pass's left-to-right kernels read (d_qBeam or d_qBeamNP)
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
@@ -187,7 +188,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_laneRec, &fb->d_sink};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_laneRec, &fb->d_sink, &fb->d_stCnt, &fb->d_stBucket};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    if (fb->h_res) (void)hipHostFree(fb->h_res);
@@ -709,6 +710,19 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       if (htkamd_beta_lr_is_lean(fa, fastLadd)) fa.qBeam = (int *)fb->d_qBeamNP.p;
       fb->qBeamLast = fa.qBeam;
       { const char *e = getenv("HTKAMD_LR_EXP"); fa.lrExp = e ? atoi(e) : 0; }
+      fa.fastMath = fastLadd ? 1 : 0;
+      // mixture statistics bucketed by tied state (k_mixstate): the default list mode, one stream, the sparse statistics kernel counting
+      static const bool noMixState = getenv("HTKAMD_NO_MIXSTATE") != nullptr;
+      if (!noMixState && fb->recCapForce == 0 && !fa.hitSlots && m->maxM <= 16 && (m->D == 39 || m->D == 26 || m->D == 13) && htkamd_stats_lr_is_sparse(fa) &&
+          (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES))) {
+         // room per state: eight times an even share of 2 pairs per frame, a power of two in [64, 65536], the lot within 1 GB
+         size_t cap = 64;
+         while (cap < 65536 && cap * (size_t)m->S < (size_t)16 * fb->totalFrames) cap <<= 1;
+         while (cap > 64 && cap * (size_t)m->S * sizeof(HitS) > ((size_t)1 << 30)) cap >>= 1;
+         if ((rc = fb->d_stCnt.reserve(sizeof(int) * ((size_t)m->S + 1))) || (rc = fb->d_stBucket.reserve(sizeof(HitS) * cap * (size_t)m->S))) return rc;
+         fa.stCnt = (int *)fb->d_stCnt.p; fa.nTiedStates = m->S; fa.stBucket = (HitS *)fb->d_stBucket.p; fa.stCap = (int)cap;
+         HIPCHECK(hipMemsetAsync(fa.stCnt, 0, sizeof(int) * ((size_t)m->S + 1), s));
+      }
    }
    static const int clsW[4] = {1, 2, 4, 8};
    // the longest chains first: their recursions are the critical path of the pass

@@ -804,6 +804,7 @@ __global__ __launch_bounds__(256, 3) void k_mixhits(FbArgs a)
    const int grp = lane / GS, sub = lane % GS;
    const int nWaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
    const int waveId = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+   if (a.stCnt && a.stBucket && !a.hitSlots && a.stCnt[a.nTiedStates] == 0) return;      // every pair found room in its state's bucket (k_mixstate)
    int recBase = -1, recUsed = 0;
    volatile int *hSt = hitSt[wv], *hFr = hitFrame[wv];
    volatile double *hSeed = hitSeed[wv];
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(256, 3) void k_mixhits(FbArgs a)
 __global__ __launch_bounds__(256) void k_rec_tilesum(int *ctl, int G, int *tileSum)
 {
    __shared__ int part[4];
+   if (ctl[0] == 0) return;                              // no record was listed (k_mixstate took every pair): the four kernels have nothing to do
    const int *cnt = ctl + 1;
    int sum = 0;
    for (int i = blockIdx.x * REC_TILE + threadIdx.x; i < (blockIdx.x + 1) * REC_TILE && i < G; i += 256) sum += cnt[i];
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(256) void k_rec_tilescan(int *ctl, int G, const int
 {
    __shared__ int wsum[4];
    __shared__ int offSh;
+   if (ctl[0] == 0) return;
    const int *cnt = ctl + 1;
    int *start = ctl + 1 + (G + 1);
    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -941,6 +944,7 @@ __global__ __launch_bounds__(256) void k_rec_tilescan(int *ctl, int G, const int
 __global__ __launch_bounds__(256) void k_rec_scatter(FbArgs a)
 {
    const int G = a.G;
+   if (a.recCtl[0] == 0) return;
    const int *start = a.recCtl + 1 + (G + 1);
    int *cur = a.recCtl + 1 + 2 * (G + 1);
    const int n = (a.recCtl[0] >= 0 && a.recCtl[0] < a.recCap) ? a.recCtl[0] : (a.recCap & ~63);
@@ -954,6 +958,7 @@ __global__ __launch_bounds__(256) void k_rec_scatter(FbArgs a)
 __global__ __launch_bounds__(256) void k_rec_reduce(FbArgs a)
 {
    const int G = a.G, D = a.D, lane = threadIdx.x & 63;
+   if (a.recCtl[0] == 0) return;
    const int *start = a.recCtl + 1 + (G + 1);
    const bool upMu = a.uFlags & HTKAMD_UPMEANS, upVa = a.uFlags & HTKAMD_UPVARS;
    const int nWaves = (gridDim.x * blockDim.x) >> 6;
@@ -1007,6 +1012,189 @@ __global__ __launch_bounds__(256) void k_rec_reduce(FbArgs a)
    }
 }
 
+// ---- K4s (round 5): mixture statistics bucketed by TIED STATE (left-to-right path, one stream, <= 16 components per state).
+// The list kernel above meets a state for ~4 frames in a row (a state lasts that long on the alignment), so it reloads the state's 16
+// parameter rows every few pairs -- a chain of three dependent loads each time -- and hands every posterior to a record list that four
+// more kernels bucket by Gaussian.  Bucketed by state first (k_stats_sp counts the pairs per state, k_hit_scan / k_hit_scatter make
+// the list), ONE wavefront takes ALL pairs of a state: parameters in registers once, the frames' rows through LDS 64 at a time, the
+// posteriors of a chunk in LDS, and then the same wavefront with lane = dimension sums mean / variance statistics of the state's
+// Gaussians in registers -- one atomic per accumulator element and state at the end, no record list.  UpMixParms HFB.c:1573-1721.
+#ifndef LR_EXP_BUILD
+#define LR_EXP_BUILD 0
+#endif
+#define MS_EXP(bit) (LR_EXP_BUILD && (a.lrExp & (bit)))      // ablations of a diagnostic build (tools/lr_exp.py): 256 no sums, 512 fp32 exp, 1024 no rows, 2048 no distances
+template <int DT, int MODE>      // MODE: 3 means and variances (HFB.c:1673-1678), 1 means only (:1697), 2 variances only (:1706), 0 weights only
+__global__ __launch_bounds__(64, 3) void k_mixstate(FbArgs a)
+{
+#ifndef MS_CHUNK
+#define MS_CHUNK 32
+#endif
+   constexpr int GS = 16, HPS = 64 / GS, NQ = (DT + 1) / 2, XS = (DT + 3) & ~3;      // XS: floats per row in LDS (16-byte multiple)
+   constexpr int CH = MS_CHUNK;                          // pairs per chunk: 14 KB of LDS at 32 (11 workgroups per CU), 24 KB at 64 (6)
+   __shared__ float xs[CH * XS];
+   __shared__ double Lt[CH][GS];
+   __shared__ double hSeed[CH];
+   const int st = blockIdx.x, lane = threadIdx.x, grp = lane / GS, sub = lane % GS;
+   const int nst = a.stCnt[st] < a.stCap ? a.stCnt[st] : a.stCap;
+   if (nst <= 0) return;
+   const HitS *bucket = a.stBucket + (size_t)st * a.stCap;
+   const int r0 = 0, r1 = nst;
+   const int c0 = a.stateCompOff[st], M = a.stateCompOff[st + 1] - c0;
+   const bool single = (M == 1 || a.maxM == 1);
+   constexpr bool upMu = (MODE & 1) != 0, upVa = (MODE & 2) != 0;
+   const bool upWt = a.uFlags & HTKAMD_UPMIXES;
+   // the state's parameters as pl[dimension pair][component] = (mean d, mean d+1, 1/variance d, 1/variance d+1): the four lane groups of a
+   // wavefront work on the same state, so a read is 16 consecutive 16-byte words broadcast to all groups, and two dimensions go through
+   // one packed subtract and two packed multiplies (in registers -- 80 of them -- the kernel ran one wavefront per SIMD)
+   __shared__ float4 pl[NQ][GS];
+   int g = 0;
+   float wt = 0.0f, gcst = 0.0f;
+   if (sub < M) {
+      g = a.compGauss[c0 + sub];
+      wt = a.compLogWt[c0 + sub];
+      gcst = a.gparam[(size_t)g * a.PS + 2 * DT];
+      if (grp == 0) {
+         const float4 *P4 = (const float4 *)(a.gparam + (size_t)g * a.PS);
+#pragma unroll
+         for (int q = 0; q < NQ; q++) { const float4 pv = P4[q]; pl[q][sub] = make_float4(pv.x, pv.z, pv.y, pv.w); }
+      }
+   }
+   // second view of the wavefront: lane = dimension; the means of the state's Gaussians at that dimension
+   float meanR[GS];
+#pragma unroll
+   for (int m = 0; m < GS; m++) meanR[m] = (m < M && lane < DT) ? a.mean[(size_t)a.compGauss[c0 + m] * DT + lane] : 0.0f;
+   double sMu[GS], sVa[GS];
+#pragma unroll
+   for (int m = 0; m < GS; m++) { sMu[m] = 0.0; sVa[m] = 0.0; }
+   double wtAcc = 0.0;                                   // posteriors of the lane's component over the pairs of its lane group
+   const double minF = uniform_f64((double)a.minFrwdP);
+
+   for (int base = r0; base < r1; base += CH) {
+      const int n = (r1 - base < CH) ? r1 - base : CH;
+      __syncthreads();
+      int hfr = 0;
+      if (lane < n) { const HitS h = bucket[base + lane]; hfr = h.frame; hSeed[lane] = h.seed; }
+      // the frames' rows by LDS-DMA, a row per load instruction (its DT lanes read 4 DT contiguous bytes -- a lane fetching the row of its OWN
+      // pair touched 64 cache lines per instruction and cost the kernel 0.19 ms): no registers in between, every row of the chunk in flight
+      if (lane < DT) {
+         for (int r = 0; r < n; r++) {
+            const int fr = MS_EXP(1024) ? 0 : __builtin_amdgcn_readlane(hfr, r);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.X + (size_t)fr * DT + lane),
+                                             (__attribute__((address_space(3))) void *)(xs + r * XS), 4, 0, 0);
+         }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // ---- the posteriors of the chunk: lane group = pair, lane in the group = component (HFB.c:1581-1606)
+      for (int it = 0; it * HPS < n; it++) {
+         const int h = it * HPS + grp;
+         const bool have = h < n;
+         bool pass = false;
+         double Lr = 0.0;
+         if (have && sub < M) {
+            const double seed = hSeed[h];
+            if (single) { pass = true; Lr = exp(seed); }
+            else if (wt > (float)LMINMIX) {
+               typedef float v2f __attribute__((ext_vector_type(2)));
+               const v2f *xr = (const v2f *)(xs + h * XS);
+               float sum = gcst;
+               if (!MS_EXP(2048))
+#pragma unroll
+               for (int q = 0; q < NQ; q++) {                // the reference's sum, a dimension after the other (HModel.c:5420-5431); the products two at a time
+                  const float4 pv = pl[q][sub];
+                  const v2f xv = xr[q];
+                  v2f mu; mu[0] = pv.x; mu[1] = pv.y;
+                  v2f iv; iv[0] = pv.z; iv[1] = pv.w;
+                  const v2f xmm = xv - mu;
+                  const v2f tt = xmm * xmm * iv;
+                  sum += tt[0];
+                  if (2 * q + 1 < DT) sum += tt[1];
+               }
+               const float prob = MS_EXP(2048) ? -1.0e30f : -0.5f * sum;
+               const double x = (seed + (double)wt) + (double)prob;
+               if (-x < minF) { pass = true; Lr = a.fastMath ? (double)__builtin_amdgcn_exp2f((float)x * 1.44269504088896341f) : exp(x); }
+            }
+         }
+         if (have) Lt[h][sub] = pass ? Lr : 0.0;
+         wtAcc += pass ? Lr : 0.0;
+      }
+      __syncthreads();
+      // ---- first- and second-order sums of the chunk: lane = dimension, a Gaussian after the other, the pairs it survived in (HFB.c:1673-1709)
+      if ((upMu || upVa) && !MS_EXP(256)) {
+#pragma unroll
+         for (int m = 0; m < GS; m++) {
+            if (m < M) {
+               const double Lmine = (lane < n) ? Lt[lane][m] : 0.0;
+               unsigned long long bm = __ballot(Lmine != 0.0);
+               // (the running sums of THIS Gaussian as two scalars around the loop, and no branch inside it: updated as elements of the
+               // arrays under control flow, every pair cost a copy of all 32 accumulator registers)
+               double mu = sMu[m], va = sVa[m];
+               const float mean = meanR[m];
+               while (bm) {                                  // four pairs' operands requested together; an empty slot adds zeros
+                  double Lv[4]; float xv[4];
+#pragma unroll
+                  for (int i = 0; i < 4; i++) {
+                     const bool live = bm != 0;
+                     const int h = live ? (int)__builtin_ctzll(bm) : 0;
+                     bm &= bm - 1;
+                     Lv[i] = live ? Lt[h][m] : 0.0;
+                     xv[i] = xs[h * XS + (lane < DT ? lane : 0)];
+                  }
+#pragma unroll
+                  for (int i = 0; i < 4; i++) {
+                     const double L = Lv[i];
+                     const float z = xv[i] - mean;
+                     if constexpr (upMu && upVa) { const float zl = (float)((double)z * L); mu += (double)zl; va += (double)(z * zl); }
+                     else if constexpr (upMu) mu += (double)z * L;
+                     else va += (double)(z * z) * L;
+                  }
+               }
+               sMu[m] = mu; sVa[m] = va;
+            }
+         }
+      }
+   }
+   // ---- out: one atomic per accumulator element of the state's Gaussians, component, and the state
+#pragma unroll
+   for (int m = 0; m < GS; m++) {
+      if (m < M && lane < DT) {
+         const int gm = a.compGauss[c0 + m];
+         if (upMu && sMu[m] != 0.0) atomicAdd(a.acc + a.lay.mu + (size_t)gm * DT + lane, sMu[m]);
+         if (upVa && sVa[m] != 0.0) atomicAdd(a.acc + a.lay.va + (size_t)gm * DT + lane, sVa[m]);
+      }
+   }
+   double w = wtAcc;
+   w += __shfl_xor(w, 16); w += __shfl_xor(w, 32);       // the four lane groups' shares of the component
+   if (grp == 0 && sub < M && w != 0.0) {
+      if (upWt) atomicAdd(a.acc + a.lay.wt + c0 + sub, w);
+      if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, w);
+      if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, w);
+   }
+   double so = (sub < M) ? w : 0.0;
+#pragma unroll
+   for (int o = GS / 2; o > 0; o >>= 1) so += __shfl_xor(so, o);
+   if (lane == 0 && so != 0.0) atomicAdd(a.acc + a.lay.wtOcc + st, so);
+}
+
+// the pass's surviving pairs by tied state (the buckets k_stats_sp filled): a wavefront per state
+bool htkamd_mixstate_applies(const FbArgs &a) { return a.stCnt && a.stBucket && !a.hitSlots && a.maxM <= 16 && (a.D == 39 || a.D == 26 || a.D == 13); }
+static int launch_mixstate(const FbArgs &a, hipStream_t s)
+{
+   const int S = a.nTiedStates;
+   const int mode = ((a.uFlags & HTKAMD_UPMEANS) ? 1 : 0) | ((a.uFlags & HTKAMD_UPVARS) ? 2 : 0);
+#define MS_LAUNCH(DT_) \
+   do { \
+      if (mode == 3) hipLaunchKernelGGL((k_mixstate<DT_, 3>), dim3(S), dim3(64), 0, s, a); \
+      else if (mode == 1) hipLaunchKernelGGL((k_mixstate<DT_, 1>), dim3(S), dim3(64), 0, s, a); \
+      else if (mode == 2) hipLaunchKernelGGL((k_mixstate<DT_, 2>), dim3(S), dim3(64), 0, s, a); \
+      else hipLaunchKernelGGL((k_mixstate<DT_, 0>), dim3(S), dim3(64), 0, s, a); \
+   } while (0)
+   if (a.D == 39) MS_LAUNCH(39); else if (a.D == 26) MS_LAUNCH(26); else MS_LAUNCH(13);
+#undef MS_LAUNCH
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
 static int set_lds_limit(const void *fn, size_t lds)
 {
    if (lds > 64 * 1024)      // dynamic LDS beyond 64 KiB must be allowed explicitly (160 KiB per CU on gfx950)
@@ -1056,6 +1244,8 @@ int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool l
       MIX_LAUNCH_GS(k_mixstats)
    }
    if (listed) {
+      // (bucketed by state where that applies: k_mixstate; the list then only holds what the buckets had no room for)
+      if (htkamd_mixstate_applies(a)) { const int rc = launch_mixstate(a, s); if (rc) return rc; }
       const dim3 grid(4096), block(256);          // grid-stride over the blocks of the list (its length is on the device)
       MIX_LAUNCH_GS(k_mixhits)
    }

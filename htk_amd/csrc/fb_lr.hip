@@ -817,6 +817,7 @@ static int lr_lean_mask()
       else hipLaunchKernelGGL((K<8, ##__VA_ARGS__>), grid, dim3(512), 0, s, a); \
    } while (0)
 
+bool htkamd_stats_lr_is_sparse(const FbArgs &a) { return a.laneRec && (lr_lean_mask() & 4); }
 // no pruning beam and the fp32-transcendental class: the lean kernels (fb_lr_lean.inc)
 bool htkamd_beta_lr_is_lean(const FbArgs &a, bool fast) { return fast && a.qBeamNP && !(a.pruneInit < HTKAMD_NOPRUNE) && (lr_lean_mask() & 1); }
 
@@ -861,7 +862,7 @@ int htkamd_launch_stats_lr(const FbArgs &a, int W, bool fast, hipStream_t s)
 {
    if (a.nList <= 0) return HTKAMD_OK;
    const int nChunks = htkamd_stats_lr_chunks(a.TMax);
-   if (a.laneRec && (lr_lean_mask() & 4)) {
+   if (htkamd_stats_lr_is_sparse(a)) {
       const dim3 grid(a.nList, nChunks);
       if (fast) LAUNCH_W(k_stats_sp, true); else LAUNCH_W(k_stats_sp, false);
    }

@@ -88,6 +88,7 @@ struct UttDesc {
 
 // what the statistics of a (frame, chain state) pair need of the state (left-to-right path: written by the beta kernels, a record per slot)
 struct LaneRec { float aSelf, aOut, aEntry, aEntryNext; short q, j, N, pad; int sidx, cM; };
+struct HitS { int frame, pad; double seed; };      // a surviving (frame, state) pair in the list bucketed by tied state (k_mixstate): the state is the bucket
 struct MixRec { int g, frame; double L; };          // posterior L of Gaussian g at row `frame` of the feature table
 struct MixHit { int st, frame; double seed; };      // a (frame, state) pair the MINFORPROB prune lets through: tied state, row of the feature table, seed
 
@@ -160,6 +161,10 @@ struct FbArgs {
    int nHitRegions, hitRegionCap;
    LaneRec *laneRec;                 // left-to-right path: [slot0 + lane], written by the beta kernels
    const int *qBeamNP;               // left-to-right path: the beta beams of the un-pruned pass (host: SetBeamTaper alone decides them), lo | hi << 16 per frame
+   // mixture statistics bucketed by tied state (k_mixstate; sets of one stream with <= 16 components per state): k_stats_sp drops a surviving
+   // pair into its state's bucket (stCnt[st] counts, stBucket[st * stCap ...]); what a bucket has no room for goes to the list of k_mixhits
+   int *stCnt; int nTiedStates; HitS *stBucket; int stCap;      // stCnt[nTiedStates] = pairs turned away by a full bucket (0: the list kernels have nothing to do)
+   int fastMath;                     // the pass runs in the fp32-transcendental class (HTKAMD_SCORE_FASTLADD): posteriors by v_exp_f32
    double *sink;                     // 64 bytes nobody reads: where the lanes outside a beam "store" (one cache line instead of a branch around the store)
    int lrExp;                        // ablation bits of an -DLR_EXP_BUILD=1 build (tools/lr_exp.py); 0 otherwise
 };
@@ -186,6 +191,7 @@ int htkamd_launch_beta_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
 bool htkamd_beta_lr_is_lean(const FbArgs &a, bool fast);      // the pass's beta kernel reads the host's un-pruned beams (FbArgs::qBeamNP) instead of writing FbArgs::qBeam
 int htkamd_launch_alpha_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
 int htkamd_launch_stats_lr(const FbArgs &a, int W, bool fast, hipStream_t s);
+bool htkamd_stats_lr_is_sparse(const FbArgs &a);             // k_stats_sp takes the pass's statistics (it counts the surviving pairs per tied state)
 int htkamd_stats_lr_chunks(int TMax);
 size_t htkamd_stats_lr_row_doubles(void);
 int htkamd_stats_lr_region_cap(void);
