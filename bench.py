@@ -34,7 +34,7 @@ FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
 FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
 F16_PEAK_TFLOPS = 2500.0                                 # dense f16 / bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                                    # HBM3E, MI355X_MICROARCH.md
-PROFILE_TRAFFIC = "r04d_traffic.json"                    # profiles/: PMC passes of this round's kernels (tools/prof_r04.sh)
+PROFILE_TRAFFIC = "r05_traffic.json"                     # profiles/: PMC passes of this round's kernels (tools/prof_r05.sh)
 
 
 def cpu_baseline(s, pk, budget_s: float):
@@ -106,12 +106,12 @@ def cpu_baseline_reference(s, pk, n_utt: int, workers: int = 1):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # the decoder runs a workgroup per utterance: a machine of 256 CUs wants that many
+def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256, cpu_utts=2):       # the decoder runs a workgroup per utterance: a machine of 256 CUs wants that many
     """The path's other two consumers, at the same set, outside the timed region (reported, never `value`):
     HVite -a forced alignment (K5) of the shard's first utterances -- checked against the oracle's token likelihood on one of them --
     and HVite -w decoding (K7) over a word loop of the set's 6 000 one-model words with -t 250 (BASELINE config[3])."""
     import tempfile
-    from htk_amd import capi
+    from htk_amd import capi, synth
     from oracle import pyoracle as po
     out = {}
     model = capi.Model(pk)
@@ -144,27 +144,19 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # th
                 f.write('~h "%s"\n<BEGINHMM>\n<NUMSTATES> 5\n<STATE> 2\n~s "S0"\n<STATE> 3\n~s "S0"\n<STATE> 4\n~s "S0"\n~t "T0"\n<ENDHMM>\n' % n_)
         open(os.path.join(d, "hmmlist"), "w").write("\n".join(names) + "\n")
         open(os.path.join(d, "dict"), "w").write("".join("%s %s\n" % (n_, n_) for n_ in names))
-        with open(os.path.join(d, "net.slf"), "w") as f:                       # the word loop HBuild writes
-            f.write("VERSION=1.0\nN=%d L=%d\nI=0 W=!NULL\nI=1 W=!NULL\n" % (V + 4, 2 * V + 3))
-            for i, n_ in enumerate(names):
-                f.write("I=%d W=%s\n" % (2 + i, n_))
-            f.write("I=%d W=!NULL\nI=%d W=!NULL\n" % (V + 2, V + 3))
-            j = 0
-            f.write("J=%d S=0 E=1 l=0.00\n" % j); j += 1
-            f.write("J=%d S=%d E=1 l=0.00\n" % (j, V + 2)); j += 1
-            for i in range(V):
-                f.write("J=%d S=1 E=%d l=%.2f\n" % (j, 2 + i, np.log(1.0 / V))); j += 1
-                f.write("J=%d S=%d E=%d l=0.00\n" % (j, 2 + i, V + 2)); j += 1
-            f.write("J=%d S=%d E=%d l=0.00\n" % (j, V + 2, V + 3))
+        # BASELINE config[3] as it is worded: a back-off BIGRAM network over the 6 000 words (ProcessBoBiGram's shape, HBuild.c:368-461: five
+        # explicit successors per word + the back-off node that reaches every word), HVite -t 250 -s 5 -p -10
+        n_arcs = synth.write_bigram_slf(os.path.join(d, "net.slf"), names)
         mmf = capi.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
         net = capi.Net(os.path.join(d, "net.slf"), os.path.join(d, "dict"), mmf)
-        dec = capi.Decoder(model, net)
+        dec = capi.Decoder(model, net, lmScale=5.0)
         feats = s.feats[:n_decode]
-        res = dec.run(feats, genBeam=250.0)
+        kw = dict(genBeam=250.0, lmScale=5.0, wordPen=-10.0)
+        res = dec.run(feats, **kw)
         dt = 1e30
         for _ in range(3):                                  # the fastest of three: the leg runs after the CPU baseline, on a device whose clocks have gone idle
             t0 = time.perf_counter()
-            res = dec.run(feats, genBeam=250.0)
+            res = dec.run(feats, **kw)
             dt = min(dt, time.perf_counter() - t0)
         hit = tot = 0
         for (w, _), q in zip(res, s.seqs[:n_decode]):
@@ -182,7 +174,8 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # th
         sc_flop = float(frames_) * S_ * FLOP_PER_FRAME_STATE(M_, Dv)
         sc_ach = sc_flop / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0
         out["hvite_decoding"] = {"utterances": len(feats), "ms": dt * 1e3, "utterances_per_sec": len(feats) / dt, "frames_per_sec": frames_ / dt,
-                                 "network": "word loop over %d one-model words, -t 250 (BASELINE config[3])" % V, "words_correct": "%d/%d" % (hit, tot),
+                                 "network": "back-off bigram over %d one-model words (%d arcs, fan-in %d at the back-off node), -t 250 -s 5 -p -10 (BASELINE config[3])" % (V, n_arcs, V),
+                                 "words_correct": "%d/%d" % (hit, tot),
                                  "arithmetic": "exact (K1 dense + K7)", "exact_order_utterances": dec.last_tied(),
                                  "roofline": {"kernel": "k_decode (token passing)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                               "ms": tok_ms, "bytes_per_unit": 4.0 * S_ + 48.0 * V, "unit_is": "(utterance, frame)", "units_per_launch": frames_,
@@ -190,10 +183,128 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256):       # th
                                  "score_roofline": {"kernel": "k_score_exact (every tied state, every frame) + k_score_transpose", "bound": "mfma", "achieved": sc_ach,
                                                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sc_ach / FP32_PEAK_TFLOPS, "ms": sc_ms,
                                                     "note": "packed fp32 VALU, the reference's four roundings per dimension: half the fp32 peak at best"}}
+        # the reference's HVite beside it (oracle/_ref/HVite, one core): the same network, dictionary and utterances from files; the 25 MB model
+        # set's loading and the network expansion cancel in the difference of a run over n and a run over 2 n utterances
+        exe = os.path.join(ROOT, "oracle", "_ref", "HVite")
+        if cpu_utts > 0 and os.path.exists(exe):
+            import subprocess
+            synth.write_mmf_packed(os.path.join(d, "MMFfull"), pk, names)
+            open(os.path.join(d, "config"), "w").close()
+            for u in range(2 * cpu_utts):
+                synth.write_htk_param(os.path.join(d, "u%05d.mfc" % u), s.feats[u], kind=9)
+            tt = []
+            for n_ in (cpu_utts, 2 * cpu_utts):
+                scp = os.path.join(d, "scp%d" % n_)
+                open(scp, "w").write("\n".join(os.path.join(d, "u%05d.mfc" % u) for u in range(n_)) + "\n")
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "-C", os.path.join(d, "config"), "-H", os.path.join(d, "MMFfull"), "-S", scp, "-i", os.path.join(d, "rec%d.mlf" % n_), "-w", os.path.join(d, "net.slf"),
+                                    "-t", "250.0", "-s", "5.0", "-p", "-10.0", os.path.join(d, "dict"), os.path.join(d, "hmmlist")], stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+                tt.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    tt = None
+                    break
+            if tt and tt[1] > tt[0]:
+                per = (tt[1] - tt[0]) / cpu_utts
+                out["hvite_decoding"]["cpu_baseline"] = {"value": 1.0 / per, "unit": "utterances/s", "cores": 1, "kind": "reference",
+                                                         "sample": "the reference's HVite (oracle/_ref) on %d and %d of the same utterances, same network; per-utterance time from the difference (%.2f s), fixed cost %.1f s" % (cpu_utts, 2 * cpu_utts, per, tt[0] - per * cpu_utts),
+                                                         "frames_per_sec": 500.0 / per}
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
     return out
+
+
+def mfcc_leg(pk, n_utt=2000, cpu_files=40):
+    """BASELINE config[4]: raw 16 kHz waveforms -> on-device HSigP / HParm MFCC_0_D_A (512-point FFT, 26 channels, 12 cepstra + C0, deltas and
+    accelerations: 39 columns) -> GMM state scores of the frames, everything resident on the device; the reference's HCopy beside it on one
+    host core (files on disk, the difference of a run over n and one over 2 n files).  Reported under other_paths, never `value`."""
+    import ctypes as C
+    import tempfile
+    import torch
+    from htk_amd import capi, synth
+    rng = np.random.default_rng(7)
+    n = 48000                                               # 3 s
+    t = np.arange(n) / 16000.0
+    base = (3000 * np.sin(2 * np.pi * 440 * t) + 2000 * np.sin(2 * np.pi * 1800 * t)).astype(np.float32)
+    distinct = [(base + rng.normal(0, 500, n)).astype(np.int16) for _ in range(8)]
+    waves = [distinct[i % 8] for i in range(n_utt)]
+    cfg = capi.mfcc_config("MFCC_0_D_A")
+    fe = capi.Mfcc(cfg)
+    sampOff = np.concatenate([[0], np.cumsum([len(w) for w in waves])]).astype(np.int32)
+    allw = np.concatenate(waves)
+    per_utt = capi.lib().htkamd_mfcc_num_frames(C.byref(cfg), C.c_int(n))
+    frames = per_utt * n_utt
+    dW = capi.DevArray(allw)
+    dO = capi.DevArray(nbytes=4 * frames * fe.cols)
+    frameOff = np.zeros(n_utt + 1, np.int32)
+    dt = 1e30
+    for _ in range(4):
+        t0 = time.perf_counter()
+        capi.check(capi.lib().htkamd_mfcc_compute(fe.h, dW.ptr, sampOff.ctypes.data_as(C.c_void_p), C.c_int(n_utt), frameOff.ctypes.data_as(C.c_void_p), dO.ptr, None), "mfcc_compute")
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
+    out = {"utterances": n_utt, "seconds_of_audio": 3.0 * n_utt, "frames": int(frames), "ms": dt * 1e3, "frames_per_sec": frames / dt, "pcm_GB_per_sec": allw.nbytes / dt / 1e9,
+           "x_real_time": 3.0 * n_utt / dt, "config": "16 kHz, 25 ms / 10 ms, 512-point FFT, 26 channels, 12 cepstra + C0, _D_A (39 columns)",
+           # SURVEY §8(d): 800 bytes in / 52 out per static frame; here also the 39-column rows of the qualifier kernels (written once, read by the regressions)
+           "roofline": {"kernel": "k_mfcc_frames + energy / regression kernels (host-timed call, waveforms and features resident)", "bound": "hbm",
+                        "achieved": (allw.nbytes + 4.0 * frames * fe.cols) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (allw.nbytes + 4.0 * frames * fe.cols) / dt / 1e9 / HBM_PEAK_GBS,
+                        "note": "bandwidth-trivial by construction (an LDS-resident FFT per frame): the figure of merit is frames/s"}}
+    # ... -> GMM scoring: the frames against the first 1 024 tied states of the headline set's shape (D = 39), bf16 x 3 matrix-core scores, on the device
+    if int(pk["vecSize"]) == fe.cols:
+        model = capi.Model(pk)
+        ns = min(1024, int(pk["numStates"]))
+        dS = capi.DevArray(np.arange(ns, dtype=np.int32))
+        dY = capi.DevArray(nbytes=4 * frames * ns)
+        ds = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            capi.check(capi.lib().htkamd_outp_block_mode(model.h, dO.ptr, C.c_int(frames), dS.ptr, C.c_int(ns), dY.ptr, C.c_int(frames), C.c_int(capi.SCORE_BF16), None), "outp_block")
+            torch.cuda.synchronize()
+            ds = min(ds, time.perf_counter() - t0)
+        M_ = int(np.max(np.diff(pk["stateCompOff"])))
+        out["scoring"] = {"states": ns, "ms": ds * 1e3, "frame_state_loglik_per_sec": frames * ns / ds,
+                          "algorithmic_TFLOPs": frames * ns * FLOP_PER_FRAME_STATE(M_, fe.cols) / ds / 1e12,
+                          "wav_to_scores_ms": (dt + ds) * 1e3}
+    exe = os.path.join(ROOT, "oracle", "_ref", "HCopy")
+    if cpu_files > 0 and os.path.exists(exe):
+        import subprocess
+        d = tempfile.mkdtemp(prefix="bench_mfcc_")
+        try:
+            open(os.path.join(d, "config"), "w").write("SOURCEFORMAT = WAV\nSOURCERATE = 625\nTARGETKIND = MFCC_0_D_A\nTARGETRATE = 100000\nWINDOWSIZE = 250000\n"
+                                                       "NUMCHANS = 26\nNUMCEPS = 12\nCEPLIFTER = 22\nPREEMCOEF = 0.97\nUSEHAMMING = T\nENORMALISE = T\n")
+            for u in range(2 * cpu_files):
+                synth.write_wav(os.path.join(d, "w%04d.wav" % u), distinct[u % 8])
+            tt = []
+            for n_ in (cpu_files, 2 * cpu_files):
+                scp = os.path.join(d, "scp%d" % n_)
+                open(scp, "w").write("".join("%s %s\n" % (os.path.join(d, "w%04d.wav" % u), os.path.join(d, "w%04d.mfc" % u)) for u in range(n_)))
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "-C", os.path.join(d, "config"), "-S", scp], stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+                tt.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    tt = None
+                    break
+            if tt and tt[1] > tt[0]:
+                per = (tt[1] - tt[0]) / cpu_files
+                out["cpu_baseline"] = {"value": per_utt / per, "unit": "frames/s", "cores": 1, "kind": "reference",
+                                       "sample": "the reference's HCopy (oracle/_ref) on %d and %d of the same 3 s waveforms as WAV files; per-file time from the difference" % (cpu_files, 2 * cpu_files)}
+        finally:
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def subprocess_leg(argv, timeout_s, pick):
+    """A leg that is a run of its own (another process, after this one's timed region): its last JSON line, reduced by `pick`."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        if r.returncode != 0:
+            return {"error": (r.stdout[-200:] + r.stderr[-300:])}
+        return pick(json.loads(r.stdout.strip().splitlines()[-1]))
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def cgroup_cpu_quota():
@@ -596,7 +707,7 @@ def main():
         kname = {"exact": "k_score_exact<39>", "bf16": "k_score_bf16w<5>" if 31 <= D <= 39 and args.mix <= 16 else "k_score_bf16w", "fastest": "k_score_f16w<3>"}.get(args.score, "k_score_mfma<20>")
         # HBM-side bytes per launch of every kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs: tools/prof_r03.sh),
         # same workload only
-        traffic_of = {}
+        traffic_of, traffic_upper = {}, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)))
             w = tj["workload"]
@@ -606,10 +717,11 @@ def main():
                 # stores and float atomics; other widths (the recursions' 8-byte columns, 4-byte scores) are uncalibrated and left as counted
                 for kn, k in tj["kernels"].items():
                     base = kn.split("<")[0]
-                    corr = 2.0 if base in ("k_score_bf16w", "k_score_f16w", "k_score_bf16", "k_score_f16") else 1.0
-                    traffic_of[base] = (corr * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+                    traffic_of[base] = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0              # as counted
+                    if base in ("k_score_bf16w", "k_score_f16w", "k_score_bf16", "k_score_f16"):     # an UPPER bound: every fetched byte taken as a 16-byte-per-lane read
+                        traffic_upper[base] = (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
         except (OSError, KeyError, ValueError):
-            traffic_of = {}
+            traffic_of, traffic_upper = {}, {}
         # Per kernel of the pass (its launches of one iteration, one per chunk: algorithmic work of the iteration / summed duration).
         # Scoring: SURVEY §8(d)'s M (4D + 8) flop per frame-state against the fp32 matrix peak.  Recursions: §8(d)'s 36 bytes per
         # in-beam frame-state against HBM -- the score read and the beta column written in the beta pass (12), the beta column read and the
@@ -618,13 +730,27 @@ def main():
         achieved = units_local * flop_unit / k1 / 1e12 if k1 > 0 else 0.0
         per_kernel = {"score": {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                                 "ms": k1 * 1e3, "traffic": traffic_of.get(kname.split("<")[0]), "flop_per_unit": flop_unit}}
-        for key_, ki, kn, bytes_unit in (("beta", 1, "k_beta_lr", 12), ("alpha", 2, "k_alpha_lr", 16), ("stats", 3, "k_stats_lr", 8)):
+        lean = os.environ.get("HTKAMD_LR_LEAN", "15") != "0"
+        for key_, ki, kn, bytes_unit in (("beta", 1, "k_beta_np2" if lean else "k_beta_lr", 12), ("alpha", 2, "k_alpha_f2" if lean else "k_alpha_lr", 16),
+                                         ("stats", 3, "k_stats_sp" if lean else "k_stats_lr", 8)):
             tk = float(ktimes[ki])
             ach = units_local * bytes_unit / tk / 1e9 if tk > 0 else 0.0
             per_kernel[key_] = {"kernel": kn, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                 "ms": tk * 1e3, "traffic": traffic_of.get(kn), "bytes_per_unit": bytes_unit}
-        per_kernel["mix"] = {"kernel": "k_mixhits + k_rec_*", "ms": float(ktimes[4]) * 1e3, "traffic": traffic_of.get("k_mixhits"),
-                             "note": "UpMixParms on the ~2 % of (frame, state) pairs the MINFORPROB prune lets through: no algorithmic unit in SURVEY §8(d)"}
+        # mixture statistics: SURVEY §8(d)'s accumulation row -- 2 D FMAs and 2 x 2 D x 4 bytes of accumulator read-modify-write per retained
+        # (frame, state, component) triple (624 bytes at D = 39); the triples are counted on the device (htkamd_fb_mix_counts)
+        pairs_ = triples_ = 0
+        for ch in chunks:                                   # the last pass of every sub-batch (either context: the same utterances under nearly the same model)
+            p_c, t_c = max(ch["fbs"][0].mix_counts(), ch["fbs"][1].mix_counts())
+            pairs_ += p_c; triples_ += t_c
+        tmix = float(ktimes[4])
+        per_kernel["mix"] = {"kernel": "k_mixstate (+ k_mixhits / k_rec_* for what its buckets turn away)", "bound": "hbm", "ms": tmix * 1e3,
+                             "traffic": traffic_of.get("k_mixstate"), "bytes_per_unit": 16 * D, "unit_is": "(frame, state, component) triple past the MINFORPROB prune",
+                             "units_per_launch": triples_, "pairs_per_launch": pairs_}
+        if triples_ > 0 and tmix > 0:
+            am = triples_ * 16.0 * D / tmix / 1e9
+            per_kernel["mix"].update({"achieved": am, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": am / HBM_PEAK_GBS,
+                                      "note": "the accumulator traffic of §8(d)'s row never reaches memory here: a state's sums stay in registers until one atomic per element"})
         # The scoring kernel's `frac` is EXECUTED flops over the dense peak of the pipe it runs on (<= 1 by construction); SURVEY §8(d)'s
         # algorithmic count (the fp32 algorithm's M (4D + 8) flop per frame-state) stays beside it under `algorithmic`.
         sc = per_kernel["score"]
@@ -638,7 +764,11 @@ def main():
             if args.score == "bf16" and 31 <= D <= 39 and args.mix <= 16 and not os.environ.get("HTKAMD_BF16_CHUNKED"):
                 kpad = 80                                   # k_score_bf16w<5>: the 2 D + 2 terms in five k-steps of 16 (gmm_bf16.hip, the dense layout)
             exe = units_local * args.mix * kpad * 2 * nprod / k1 / 1e12 if k1 > 0 else 0.0
-            sc.update({"achieved": exe, "peak": F16_PEAK_TFLOPS, "frac": exe / F16_PEAK_TFLOPS, "flop_per_unit": args.mix * kpad * 2 * nprod,
+            # `frac` as SURVEY §8(d) defines it: ALGORITHMIC flops over the dense peak of the pipe the kernel runs on; what the pipe executes
+            # (the split operands' piece products, padding included) beside it as executed_frac
+            sc.update({"achieved": achieved, "peak": F16_PEAK_TFLOPS, "frac": achieved / F16_PEAK_TFLOPS, "flop_per_unit": flop_unit,
+                       "executed": {"achieved": exe, "unit": "TFLOP/s", "flop_per_unit": args.mix * kpad * 2 * nprod}, "executed_frac": exe / F16_PEAK_TFLOPS,
+                       "traffic_upper_bound": traffic_upper.get(kname.split("<")[0]),
                        "pipe": "v_mfma_f32_32x32x16_f16, operands split in two fp16 pieces, fp32 accumulate" if args.score == "fastest"
                                else "v_mfma_f32_32x32x16_bf16, operands split in three bf16 pieces, fp32 accumulate"})
         elif args.score == "exact":
@@ -684,8 +814,9 @@ def main():
             "streams": len(lanes),
             # the kernel with the largest total time in the timed iterations
             "roofline": dict(per_kernel[dom], units_per_launch=units_local / NCH, launches_per_step=NCH,
-                             traffic_source="profiles/%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bytes per launch; FETCH_SIZE doubled for this "
-                                            "kernel's 16-byte-per-lane reads (MI355X_MICROARCH.md: gfx950 tallies them at half)" % PROFILE_TRAFFIC
+                             traffic_source="profiles/%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bytes per launch as counted; "
+                                            "traffic_upper_bound: FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies 16-byte-per-lane streaming reads at half; "
+                                            "this kernel's table tiles are such reads, its feature rows and task words are not)" % PROFILE_TRAFFIC
                              if dom == "score" and args.score in ("bf16", "fastest") else "profiles/%s: FETCH_SIZE + WRITE_SIZE per launch as counted (8- and 4-byte accesses: uncalibrated on gfx950)" % PROFILE_TRAFFIC),
             "roofline_kernels": per_kernel,
         }
@@ -763,9 +894,20 @@ def main():
                 out["cpu_baseline"] = port
         if args.extras and world == 1:
             try:
-                out["other_paths"] = other_paths(s, pk, dX, frame_off_all)
+                out["other_paths"] = other_paths(s, pk, dX, frame_off_all, cpu_utts=2 if args.cpu_seconds > 0 else 0)
                 if "k_decode" in traffic_of and "hvite_decoding" in out["other_paths"]:          # counter bytes of the token kernel, per launch (same PMC passes)
                     out["other_paths"]["hvite_decoding"]["roofline"]["traffic"] = traffic_of["k_decode"]
+                try:
+                    out["other_paths"]["mfcc"] = mfcc_leg(pk, cpu_files=40 if args.cpu_seconds > 0 else 0)
+                except Exception as e:  # noqa: BLE001
+                    out["other_paths"]["mfcc"] = {"error": repr(e)[:300]}
+                if args.extras >= 1 and args.cpu_seconds > 0:
+                    # BASELINE config[2] as ONE job on ONE GPU (10 000 utterances in eight sub-batches): the denominator of the 8-GPU speed-up
+                    out["other_paths"]["strong_1gpu"] = subprocess_leg(
+                        ["bench.py", "--gpus", "1", "--scaling", "strong", "--chunks", "8", "--cpu-seconds", "0", "--extras", "0", "--also-fastest", "0", "--steps", "5", "--warmup", "2"], 900,
+                        lambda j: {k_: j.get(k_) for k_ in ("value", "unit", "ms_per_step", "herest_utterances_per_sec", "utterances_ok", "config", "kernel_ms")})
+                    # the link-compatible boundary: the reference's unchanged HERest.o over the HFB shim, files per second (tools/shim_latency.py)
+                    out["other_paths"]["boundary"] = subprocess_leg(["tools/shim_latency.py", "200"], 600, lambda j: j)
             except Exception as e:  # noqa: BLE001  (reported beside the line, never instead of it)
                 out["other_paths"] = {"error": repr(e)[:300]}
         print(json.dumps(out))

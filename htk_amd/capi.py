@@ -368,6 +368,12 @@ class ForwardBackward:
         check(lib().htkamd_fb_kernel_times5(self.h, t), "fb_kernel_times5")
         return list(t)
 
+    def mix_counts(self):
+        """(pairs, triples) of the last pass's mixture statistics, -1 where uncounted (htkamd_fb_mix_counts)"""
+        t = (C.c_longlong * 2)()
+        check(lib().htkamd_fb_mix_counts(self.h, t), "fb_mix_counts")
+        return int(t[0]), int(t[1])
+
     def trellis(self, u: int, want_alpha: bool = True):
         T = C.c_int(); Q = C.c_int(); mN = C.c_int()
         check(lib().htkamd_fb_get_trellis(self.h, C.c_int(u), None, None, None, None, None, None, None,

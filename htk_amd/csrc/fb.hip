@@ -117,6 +117,7 @@ struct htkamd_fb {
    std::vector<UttDesc> utt;
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState, slotStateU;
    std::vector<short> cQ, cI, taperLo, taperHi, thrCell, sQ;
+   std::vector<int> wqStart;    // tasksW in eight queues by utterance % 8 (ScoreArgs::qStart): first task of every queue, then the total
    std::vector<int> qBeamNP;    // per frame: the beta beam of the un-pruned pass, lo | hi << 16 (what SetBeta leaves in qLo / qHi when only the taper acts)
    std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
    std::vector<size_t> gamOff;
@@ -137,9 +138,11 @@ struct htkamd_fb {
    int clsOff[14];                          // class c occupies uttList[clsOff[c] .. clsOff[c+1])
    size_t betaWTotal, alphaWTotal;
    DevBuf d_alphaW, d_qBeam, d_aBeam, d_trPart, d_hits, d_hitCtl;   // left-to-right path (fb_lr.hip)
+   DevBuf d_wqStart;                         // ScoreArgs::qStart
    DevBuf d_sink;                            // FbArgs::sink
    DevBuf d_stCnt, d_stBucket;               // FbArgs::stCnt, stBucket (k_mixstate)
    DevBuf d_qBeamNP, d_laneRec;              // ... the host's un-pruned beta beams (a view into the arena); a record per chain state for the sparse statistics
+   bool mixStateLast = false;                // the last pass ran k_mixstate (its counters are behind d_stCnt)
    const int *qBeamLast = nullptr;           // the beta beam words the last pass's left-to-right kernels read (d_qBeam or d_qBeamNP)
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
@@ -188,7 +191,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_laneRec, &fb->d_sink, &fb->d_stCnt, &fb->d_stBucket};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_laneRec, &fb->d_sink, &fb->d_stCnt, &fb->d_stBucket, &fb->d_wqStart};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    if (fb->h_res) (void)hipHostFree(fb->h_res);
@@ -461,6 +464,22 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       });
    }
    fb->gamOff[U] = gam;
+   {  // the wide tasks in eight queues, utterance u in queue u % 8 (the tasks lie in utterance order: one walk finds their utterances)
+      std::vector<ScoreTask> q[8];
+      int u = 0;
+      for (const ScoreTask &tk : fb->tasksW) {
+         while (u + 1 < U && tk.frame0 >= b->frameOff[u + 1]) u++;
+         q[u & 7].push_back(tk);
+      }
+      fb->wqStart.assign(9, 0);
+      size_t at = 0;
+      for (int k = 0; k < 8; k++) {
+         fb->wqStart[k] = (int)at;
+         if (!q[k].empty()) memcpy(fb->tasksW.data() + at, q[k].data(), sizeof(ScoreTask) * q[k].size());
+         at += q[k].size();
+      }
+      fb->wqStart[8] = (int)at;
+   }
    {  // utterance of every 512th seed (k_mixstats' scan chunks)
       const size_t nChunk = (gam + 511) / 512;
       fb->gamChunkUtt.assign(nChunk ? nChunk : 1, 0);
@@ -548,7 +567,8 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0},
          {&fb->d_slotStateU, fb->slotStateU.data(), sizeof(int) * fb->slotStateU.size(), 0},
          {&fb->d_nextSame, fb->nextSame.data(), sizeof(int) * fb->nextSame.size(), 0},
-         {&fb->d_qBeamNP, fb->qBeamNP.data(), sizeof(int) * fb->qBeamNP.size(), 0}};
+         {&fb->d_qBeamNP, fb->qBeamNP.data(), sizeof(int) * fb->qBeamNP.size(), 0},
+         {&fb->d_wqStart, fb->wqStart.data(), sizeof(int) * fb->wqStart.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
       if (total == 0) total = 256;
@@ -620,6 +640,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.stateCompOff = m->d_stateCompOff; sa.compGauss = m->d_compGauss; sa.compLogWt = m->d_compLogWt;
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
+   if (wideTasks && m->NSt == 1 && fb->wqStart.size() == 9 && !getenv("HTKAMD_NO_XCDQ")) { sa.qStart = (const int *)fb->d_wqStart.p; sa.qCounters = (int *)fb->d_counter.p + 8; }
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
    fb->f16Pass = (cfg->scoreMode & HTKAMD_SCORE_F16) != 0 && !m->tiedMix && sa.nTasks > 0;      // no tasks, no launch: nothing zeroes or raises the flag
    if (fb->f16Pass) {      // the pass's own range flag, behind the status words (zeroed with the task counter before it, by the launcher)
@@ -709,6 +730,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       fa.qBeamNP = (const int *)fb->d_qBeamNP.p;
       if (htkamd_beta_lr_is_lean(fa, fastLadd)) fa.qBeam = (int *)fb->d_qBeamNP.p;
       fb->qBeamLast = fa.qBeam;
+      fb->mixStateLast = false;
       { const char *e = getenv("HTKAMD_LR_EXP"); fa.lrExp = e ? atoi(e) : 0; }
       fa.fastMath = fastLadd ? 1 : 0;
       // mixture statistics bucketed by tied state (k_mixstate): the default list mode, one stream, the sparse statistics kernel counting
@@ -719,9 +741,10 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          size_t cap = 64;
          while (cap < 65536 && cap * (size_t)m->S < (size_t)16 * fb->totalFrames) cap <<= 1;
          while (cap > 64 && cap * (size_t)m->S * sizeof(HitS) > ((size_t)1 << 30)) cap >>= 1;
-         if ((rc = fb->d_stCnt.reserve(sizeof(int) * ((size_t)m->S + 1))) || (rc = fb->d_stBucket.reserve(sizeof(HitS) * cap * (size_t)m->S))) return rc;
+         if ((rc = fb->d_stCnt.reserve(sizeof(int) * ((size_t)m->S + 4))) || (rc = fb->d_stBucket.reserve(sizeof(HitS) * cap * (size_t)m->S))) return rc;
+         fb->mixStateLast = true;
          fa.stCnt = (int *)fb->d_stCnt.p; fa.nTiedStates = m->S; fa.stBucket = (HitS *)fb->d_stBucket.p; fa.stCap = (int)cap;
-         HIPCHECK(hipMemsetAsync(fa.stCnt, 0, sizeof(int) * ((size_t)m->S + 1), s));
+         HIPCHECK(hipMemsetAsync(fa.stCnt, 0, sizeof(int) * ((size_t)m->S + 4), s));      /* counts, then: pairs turned away, pairs, triples */
       }
    }
    static const int clsW[4] = {1, 2, 4, 8};
@@ -862,6 +885,21 @@ extern "C" int htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5])
       else HIPCHECK(hipEventElapsedTime(&ms, fb->ev[i], fb->ev[i + 1]));
       out[i] = (double)ms * 1e-3;
    }
+   return HTKAMD_OK;
+}
+
+// out[0]: (frame, state) pairs the MINFORPROB prune let through in the last pass, out[1]: (frame, state, component) triples whose
+// statistics were accumulated -- the units of the mixture-statistics kernel's roofline (2 D FMAs and 624 bytes of
+// accumulator traffic per triple at D = 39).  Counted by k_mixstate; -1 where the pass ran on the list kernels alone.
+extern "C" int htkamd_fb_mix_counts(htkamd_fb *fb, long long out[2])
+{
+   if (!fb || !out) { htkamd_set_error("fb_mix_counts: NULL"); return HTKAMD_EINVAL; }
+   out[0] = out[1] = -1;
+   if (!fb->timed || !fb->mixStateLast || !fb->d_stCnt.p) return HTKAMD_OK;
+   HIPCHECK(hipEventSynchronize(fb->ev[5]));
+   int c[3] = {0, 0, 0};
+   HIPCHECK(hipMemcpy(c, (int *)fb->d_stCnt.p + fb->m->S, sizeof(c), hipMemcpyDeviceToHost));
+   out[0] = c[1]; out[1] = c[2];
    return HTKAMD_OK;
 }
 

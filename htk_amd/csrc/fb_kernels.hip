@@ -1067,6 +1067,7 @@ __global__ __launch_bounds__(64, 3) void k_mixstate(FbArgs a)
 #pragma unroll
    for (int m = 0; m < GS; m++) { sMu[m] = 0.0; sVa[m] = 0.0; }
    double wtAcc = 0.0;                                   // posteriors of the lane's component over the pairs of its lane group
+   int nTriples = 0;                                     // (frame, state, component) triples that passed, this lane's share
    const double minF = uniform_f64((double)a.minFrwdP);
 
    for (int base = r0; base < r1; base += CH) {
@@ -1117,6 +1118,7 @@ __global__ __launch_bounds__(64, 3) void k_mixstate(FbArgs a)
          }
          if (have) Lt[h][sub] = pass ? Lr : 0.0;
          wtAcc += pass ? Lr : 0.0;
+         nTriples += pass ? 1 : 0;
       }
       __syncthreads();
       // ---- first- and second-order sums of the chunk: lane = dimension, a Gaussian after the other, the pairs it survived in (HFB.c:1673-1709)
@@ -1170,6 +1172,9 @@ __global__ __launch_bounds__(64, 3) void k_mixstate(FbArgs a)
       if (upMu) atomicAdd(a.acc + a.lay.muOcc + g, w);
       if (upVa) atomicAdd(a.acc + a.lay.vaOcc + g, w);
    }
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) nTriples += __shfl_xor(nTriples, o);
+   if (lane == 0) { atomicAdd(a.stCnt + a.nTiedStates + 1, nst); atomicAdd(a.stCnt + a.nTiedStates + 2, nTriples); }
    double so = (sub < M) ? w : 0.0;
 #pragma unroll
    for (int o = GS / 2; o > 0; o >>= 1) so += __shfl_xor(so, o);

@@ -319,8 +319,22 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
 #define GLDS16(src_, dst_) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_), (__attribute__((address_space(3))) void *)(dst_), 16, 0, 0)
    const int fw = 32 * wv;                             // this wave's first frame in the task's tile
 
+   // eight task queues, one per XCD (ScoreArgs::qStart): a workgroup pulls from the queue of the XCD it runs on (HW_REG_XCC_ID) and moves on
+   // round the others when that one is empty -- the frame tiles of a state chunk then meet their 64 table tiles in ONE L2
+   int myQ = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);
    for (;;) {
-      if (tid == 0) taskSh = atomicAdd(a.taskCounter, 1);
+      if (tid == 0) {
+         int t_;
+         if (a.qStart) {
+            t_ = 0x7fffffff;
+            for (int k = 0; k < 8; k++) {
+               const int tk_ = atomicAdd(a.qCounters + myQ, 1);
+               if (tk_ < a.qStart[myQ + 1] - a.qStart[myQ]) { t_ = a.qStart[myQ] + tk_; break; }
+               myQ = (myQ + 1) & 7;
+            }
+         } else t_ = atomicAdd(a.taskCounter, 1);
+         taskSh = t_;
+      }
       __syncthreads();
       const int task = __builtin_amdgcn_readfirstlane(taskSh);
       if (task >= a.nTasks) break;
@@ -493,6 +507,7 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
    }
    ((htkamd_model *)m)->fastUse |= HTKAMD_SCORE_BF16;
    HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
+   if (a.qCounters) HIPCHECK(hipMemsetAsync(a.qCounters, 0, 8 * sizeof(int), stream));
    if (m->f16Wide && (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16) >= ((size_t)1 << 32)) {
       htkamd_set_error("score_bf16: a table of %d tiles is beyond the kernel's 32-bit staging offsets", m->nTiles); return HTKAMD_EMODEL;
    }

@@ -47,6 +47,10 @@ struct ScoreArgs {
    // passes, whose rows ARE elements): a slot is scored as it stands.
    int NSt = 1;
    const float *streamWt = nullptr;   // [elements]
+   // k_score_bf16w: the task list cut into eight queues, one per XCD (tasks of utterance u in queue u % 8, so that the frame tiles of a
+   // state chunk -- which stream the same 64 table tiles -- are pulled by workgroups behind the same L2); qStart[9], qCounters[8]; NULL: one queue
+   const int *qStart = nullptr;
+   int *qCounters = nullptr;
 };
 
 // evStart/evStop (may be NULL): updated with the dispatch's own start and stop time (hipExtLaunchKernel), i.e. without the time

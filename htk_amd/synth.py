@@ -351,3 +351,38 @@ def make_topo_set(seed: int = 21, D: int = 13, NU: int = 5, outdir: str | None =
                     f.write("\n".join(TOPO_NAMES[h] for h in seqs[u]) + "\n")
                 scp.write(fn + "\n")
     return pk, list(TOPO_NAMES), seqs, feats
+
+
+def write_bigram_slf(path: str, names, seed: int = 7, n_succ: int = 5):
+    """A back-off bigram word network over `names` in SLF form, the shape ProcessBoBiGram gives (HTKTools/HBuild.c:368-461): every word has
+    `n_succ` explicit successors with bigram scores and an arc to the back-off !NULL node, which reaches every word with its unigram score.
+    Nodes: 0 start (!NULL), 1 back-off (!NULL), 2..V+1 words, V+2 end (!NULL).  (Same draw order as tests/golden/make_config3_golden.py.)"""
+    V = len(names)
+    rng = np.random.default_rng(seed)
+    uni = rng.dirichlet(np.ones(V) * 2.0)
+    arcs = [(0, 1, 0.0)]
+    for w in range(V):
+        arcs.append((1, 2 + w, float(np.log(uni[w]))))
+        succ = rng.choice(V, size=n_succ, replace=False)
+        p = rng.dirichlet(np.ones(n_succ + 1))
+        for k, s_ in enumerate(succ):
+            arcs.append((2 + w, 2 + int(s_), float(np.log(0.8 * p[k]))))
+        arcs.append((2 + w, 1, float(np.log(0.8 * p[n_succ]))))        # back-off weight
+        arcs.append((2 + w, V + 2, float(np.log(0.2))))
+    with open(path, "w") as f:
+        f.write("VERSION=1.0\nN=%d L=%d\nI=0 W=!NULL\nI=1 W=!NULL\n" % (V + 3, len(arcs)))
+        for i, n in enumerate(names):
+            f.write("I=%d W=%s\n" % (2 + i, n))
+        f.write("I=%d W=!NULL\n" % (V + 2))
+        for j, (a, b, l) in enumerate(arcs):
+            f.write("J=%d S=%d E=%d l=%.3f\n" % (j, a, b, l))
+    return len(arcs)
+
+
+def write_wav(path: str, pcm: np.ndarray, rate: int = 16000):
+    """16-bit mono RIFF/WAVE file (what SOURCEFORMAT = WAV reads, HWave.c:1393)."""
+    import struct
+    pcm = np.ascontiguousarray(pcm, "<i2")
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, 2 * rate, 2, 16) + b"data" + struct.pack("<I", pcm.nbytes))
+        f.write(pcm.tobytes())

@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 output of tools/prof_r02.sh into the small files profiles/ keeps:
+"""Condense the rocprofv3 output of tools/prof_r05.sh into the small files profiles/ keeps:
    <tag>_kernel_stats.csv (copied), <tag>_traffic.json (FETCH_SIZE / WRITE_SIZE KB per launch of every kernel of the timed pass),
    <tag>_sq.json (SQ counters per launch).     python tools/prof_summarise.py gpurun_out/<tag> <tag>"""
 import csv
@@ -39,7 +39,8 @@ try:
 except Exception:  # noqa: BLE001
     cfg = {}
 json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`, counters' KB per launch, "
-                       "as counted -- bench.py doubles FETCH_SIZE for the kernels whose reads are 16 bytes per lane (MI355X_MICROARCH.md: gfx950 tallies those at half; narrower loads uncalibrated)",
+                       "as counted -- bench.py reports them as counted and, for the scoring kernels, an upper bound with FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 tallies "
+                       "16-byte-per-lane streaming reads at half; narrower loads uncalibrated)",
            "workload": {k: cfg.get(k) for k in ("states", "mix", "utts_per_gpu", "frames", "chunks")}, "kernels": traffic},
           open(os.path.join("profiles", "%s_traffic.json" % tag), "w"), indent=1)
 sq = {}
@@ -59,4 +60,13 @@ if mf:
     json.dump({"_comment": "matrix-pipe counters per launch (mean over the launches of `bench.py --steps 1 --warmup 0`); mfma_busy_frac = "
                            "SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)", "kernels": mf},
               open(os.path.join("profiles", "%s_mfma.json" % tag), "w"), indent=1)
+tcc = {}
+for k, v in per_kernel(os.path.join(out, "pmc_TCC"), {"TCC_HIT_sum", "TCC_MISS_sum"}).items():
+    tcc[k] = {c: sum(x) / len(x) for c, x in v.items()}
+    h, m_ = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
+    if h + m_ > 0:
+        tcc[k]["l2_hit_rate"] = h / (h + m_)
+if tcc:
+    json.dump({"_comment": "L2 (TCC) hits and misses per launch, summed over the XCDs (mean over the launches of `bench.py --steps 1 --warmup 0`)", "kernels": tcc},
+              open(os.path.join("profiles", "%s_tcc.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:1500])
