@@ -797,6 +797,7 @@ def main():
                                    "%d x %d-frame utterances per GPU (BASELINE config[2]: 10k utterances sharded 8-way)" % (args.states, args.mix, args.utts, args.frames),
                        "states": args.states, "mix": args.mix, "utts_per_gpu": args.utts, "frames": args.frames, "chunks": NCH,
                        "update": "HERest -m 3 -v %g, on the device" % args.min_var,
+                       "wire": (args.wire if world > 1 else None),      # (the C library's htkamd_accs_allreduce defaults to fp64; tools/herest --wire f32 is this exchange)
                        "parallelism": "utterance shards, 1 all-reduce of %d accumulators per iteration (%s on the wire)" % (vec_n, args.wire if world > 1 else "no exchange at N = 1")},
             "herest_utterances_per_sec": utts_total * args.steps / dt,
             "utterances_ok": utts_total,
@@ -847,9 +848,17 @@ def main():
             occ_ = np.maximum(np.asarray(oacc.muOcc, np.float64), 1e-3)[:, None]
             few_ = occ_[:, 0] < 3.0                              # Gaussians the sample gives fewer than three frames
             worst_few = {}
+            pure_ = {}                                           # entries beyond 1e-4 of THEIR OWN value (no floor, no scale): counts, of how many
+            for k_ in ("muOcc", "wt", "wtOcc", "tr", "trOcc"):
+                ref_ = np.asarray(getattr(oacc, k_), np.float64).reshape(-1); got_ = np.asarray(ac[k_], np.float64).reshape(-1)
+                nz_ = np.abs(ref_) > 0
+                pure_[k_] = {"n": int(nz_.sum()), "n_above_1e4": int((np.abs(got_ - ref_)[nz_] > 1e-4 * np.abs(ref_)[nz_]).sum())}
             for k_ in ("mu", "va"):
                 ref_ = np.asarray(getattr(oacc, k_), np.float64).reshape(occ_.shape[0], -1)
                 rel_ = np.abs(np.asarray(ac[k_], np.float64).reshape(ref_.shape) - ref_) / np.maximum(np.abs(ref_), occ_)
+                nz_ = np.abs(ref_) > 0
+                pure_[k_] = {"n": int(nz_.sum()), "n_above_1e4": int((np.abs(np.asarray(ac[k_], np.float64).reshape(ref_.shape) - ref_)[nz_] > 1e-4 * np.abs(ref_)[nz_]).sum()),
+                             "note": "sums about the current mean: an entry near zero is a cancellation, its own value no scale for it"}
                 worst_acc[k_] = float(np.max(rel_[~few_])) if (~few_).any() else 0.0
                 worst_few[k_] = float(np.max(rel_[few_])) if few_.any() else 0.0
                 if os.environ.get("BENCH_ACC_DETAIL"):
@@ -868,6 +877,7 @@ def main():
             del fbc, accc, m0
             out["oracle_check"] = {"utterances": n, "max_rel_diff_logprob": worst, "tolerance": tol,
                                    "accumulators_max_rel_diff": worst_acc, "accumulators_tolerance": 1e-4,
+                                   "accumulators_pure_relative_1e4": pure_,
                                    "avg_logprob_per_frame_oracle": float(np.sum(opr) / sum(s.feats[u].shape[0] for u in range(n))),
                                    "avg_logprob_per_frame_hip": float(np.sum(pr_init[:n]) / sum(s.feats[u].shape[0] for u in range(n)))}
             port = {"value": n_timed * per_utt / cdt, "unit": "frame-state log-lik/s", "cores": 1, "kind": "port",

@@ -114,7 +114,9 @@ extern "C" int htkamd_accs_wire_round(htkamd_accs *a, void *stream)
    float *w = nullptr;
    HIPCHECK(hipMalloc(&w, sizeof(float) * bulk));
    k_wire_pack<<<1024, 256, 0, (hipStream_t)stream>>>(a->d_vec, w, bulk);
+   HIPCHECK(hipGetLastError());
    k_wire_unpack<<<1024, 256, 0, (hipStream_t)stream>>>(w, a->d_vec, bulk);
+   HIPCHECK(hipGetLastError());
    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
    HIPCHECK(hipFree(w));
    return HTKAMD_OK;
@@ -134,9 +136,11 @@ extern "C" int htkamd_accs_allreduce_wire(htkamd_accs *a, htkamd_comm *c, int wi
    }
    hipStream_t st = (hipStream_t)stream;
    k_wire_pack<<<1024, 256, 0, st>>>(a->d_vec, c->d_wire, bulk);
+   HIPCHECK(hipGetLastError());                          // (a pack that did not launch would let RCCL sum an uninitialised buffer into the statistics)
    RCCLCHECK(g_rccl.allReduce(c->d_wire, c->d_wire, bulk, 7 /* ncclFloat32 */, 0 /* ncclSum */, c->c, st));
    RCCLCHECK(g_rccl.allReduce(a->d_vec + bulk, a->d_vec + bulk, tail, 8 /* ncclFloat64 */, 0, c->c, st));
    k_wire_unpack<<<1024, 256, 0, st>>>(c->d_wire, a->d_vec, bulk);
+   HIPCHECK(hipGetLastError());
    return HTKAMD_OK;
 }
 

@@ -76,6 +76,8 @@ struct OrdArgs {
    int *pos; unsigned char *ooo;       // [sum nNodes] (at DecUtt.node0) position of the node's instance in seq (-1: none); NetInst.ooo
    int *pathNode, *pathFrame;          // [paths] (at DecUtt.path0) Path records are allocated one by one here
    int pathExtra;                      // records per utterance beyond (T + 1) * nWordNodes
+   int keepFast;                       // the outputs hold k_decode's result of the same utterance (HTKAMD_ORDER_AUTO): a walk that runs out of one of its
+                                       // fixed capacities (-4 path records, -5 list appends of a frame, -6 nesting of zero-time nodes) leaves it standing
 };
 int htkamd_launch_decode_ord(const OrdArgs &a, int nSel, hipStream_t s);
 // K1 writes a score block state-major (a state's frames are a lane's stores); the token loops read a COLUMN per frame: one 128-byte line per

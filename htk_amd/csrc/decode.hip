@@ -964,6 +964,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
                oa.d.pathPrev = (int *)oPrev; oa.d.pathLike = (double *)oLike; oa.d.pathLm = (float *)oLm;
                oa.seq = (int *)dSeq; oa.seqCap = seqCap; oa.pos = (int *)dPos; oa.ooo = (unsigned char *)dOoo;
                oa.pathNode = (int *)oNode; oa.pathFrame = (int *)oFrame; oa.pathExtra = pathExtra;
+               oa.keepFast = orderMode == HTKAMD_ORDER_AUTO ? 1 : 0;
                // (the path capacity the kernel assumes per utterance is 3 (T + 1) nWordNodes + pathExtra: see opath above)
                rc = htkamd_launch_decode_ord(oa, nSel, s);
             }

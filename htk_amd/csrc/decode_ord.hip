@@ -338,6 +338,9 @@ __global__ __launch_bounds__(ORD_THREADS) void k_decode_ord(OrdArgs oa)
    // ---- CompleteRecognition (HRec.c:2054) + LatFromPaths (:1512) + TranscriptionFromLattice (:2176) for the 1-best chain
    if (tid == 0) {
       int nW = 0;
+      // (a capacity of the LIST walk is no reason to lose an answer the batch kernel has already given -- a tie-free order is
+      // one valid order of HRec's; the status codes -4 / -5 / -6 then never reach the caller in the default mode)
+      if (sh.status != 0 && oa.keepFast && a.nWords[u] >= 0) return;
       a.total[u] = LZERO; a.finalLm[u] = 0.0f;
       if (sh.status != 0) nW = sh.status;
       else {

@@ -57,6 +57,29 @@ extern "C" int htkamd_memcpy_h2d(void *dDst, const void *hSrc, size_t bytes, voi
    return HTKAMD_OK;
 }
 
+// host memory the device can read directly (page-locked): a copy from it is a plain DMA, and htkamd_memcpy_h2d_async need not wait for it --
+// the copy is ordered before whatever follows on the same stream; the buffer may be refilled once that work has been waited for
+extern "C" int htkamd_host_malloc(void **hptr, size_t bytes)
+{
+   if (!hptr) { htkamd_set_error("host_malloc: NULL"); return HTKAMD_EINVAL; }
+   hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+   if (e != hipSuccess) { htkamd_set_error("host_malloc(%zu): %s", bytes, hipGetErrorString(e)); return (e == hipErrorOutOfMemory) ? HTKAMD_ENOMEM : HTKAMD_EHIP; }
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_host_free(void *hptr)
+{
+   if (hptr) HIPCHECK(hipHostFree(hptr));
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_memcpy_h2d_async(void *dDst, const void *hSrc, size_t bytes, void *stream)
+{
+   if (bytes == 0) return HTKAMD_OK;
+   HIPCHECK(hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
 extern "C" int htkamd_memcpy_d2h(void *hDst, const void *dSrc, size_t bytes, void *stream)
 {
    if (bytes == 0) return HTKAMD_OK;

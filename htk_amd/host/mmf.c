@@ -11,7 +11,7 @@
  * Binary definitions (':' + code byte keywords, big-endian numbers: PutSymbol :2581, Token.binForm :505) are read and
  * written as well, shared mixture pdfs (~m) are kept shared (one Gaussian, several components).  Shared mean / variance vectors
  * (~u / ~v macros referenced inside a mixture, GetMean :1737 / GetVariance :1770) are read, kept (every Gaussian holds its copy of the
- * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; ~w / ~m / ~u / ~v macros inside multi-stream sets, durations and
+ * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; ~m / ~u / ~v macros inside multi-stream sets, durations and
  * transforms are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
  */
 #include <ctype.h>
@@ -41,6 +41,9 @@ struct htkamd_mmf {
    /* shared vectors: ~u (means) and ~v (variances) macros; gMeanMac/gVarMac[g] = macro of Gaussian g's mean / variance or -1 */
    struct { char type; char *name; float *v; int src; int stream; } *vm; int nVm, capVm;      /* stream: of a varFloorN macro of a multi-stream set, else -1 */
    int *gMeanMac, *gVarMac; int capMac;
+   /* ~w stream-weight macros (GetSWeights HModel.c:1621): nStreams numbers under a name; a state that names one takes a copy (the set is written
+      back with <SWEIGHTS> in the states) */
+   struct { char *name; float w[8]; } *wm; int nWm, capWm;
    /* logical list */
    char **logName; int *logPhys; int nLog; int *logSorted;        /* logSorted: list positions in name order (stable) */
    /* desc arrays */
@@ -421,8 +424,18 @@ static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
    off[0] = 0;
    for (int i = 0; i < S; i++) { if (nMixS[i] < 1) return fail(r, "bad <NUMMIXES>"); off[i + 1] = off[i] + nMixS[i]; }
    M = off[S];
-   if (k == T_MACRO && r->tok[0] == 'w') return fail(r, "~w stream weight macros are not supported");
-   if (k == T_KEY && !strcmp(r->tok, "SWEIGHTS")) {
+   if (k == T_MACRO && r->tok[0] == 'w') {               /* a reference to a ~w macro where <SWEIGHTS> would stand (GetStateInfo HModel.c:1966) */
+      char *nm;
+      if ((rc = rd_name(r, &nm))) return rc;
+      int i = -1;
+      for (int q = 0; q < s->nWm; q++) if (!strcmp(s->wm[q].name, nm)) { i = q; break; }
+      free(nm);
+      if (i < 0) return fail(r, "undefined ~w macro");
+      sw = (float *)malloc(sizeof(float) * (size_t)S);
+      memcpy(sw, s->wm[i].w, sizeof(float) * (size_t)S);
+      k = rd_next(r);
+   }
+   else if (k == T_KEY && !strcmp(r->tok, "SWEIGHTS")) {
       int n;
       if ((rc = rd_int(r, &n))) return rc;
       if (n != S) return fail(r, "incorrect number of stream weights");
@@ -585,7 +598,11 @@ static int parse_hmm(struct htkamd_mmf *s, rd *r, char *name)
          if ((rc = rd_int(r, &i))) goto bad;
          if (i < 2 || i > N - 1) { rc = fail(r, "state index out of range"); goto bad; }
          k = rd_next(r);
-         if (k == T_MACRO) {
+         if (k == T_MACRO && r->tok[0] == 'w') {         /* an inline state that opens with its ~w stream weights */
+            rd_push(r);
+            if ((rc = parse_state_body(s, r, NULL, &states[i - 1]))) goto bad;
+            s->st[states[i - 1]].inlineOwner = s->nHm;
+         } else if (k == T_MACRO) {
             if (r->tok[0] != 's') { rc = fail(r, "~s expected"); goto bad; }
             char *nm;
             if ((rc = rd_name(r, &nm))) goto bad;
@@ -711,6 +728,20 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
          GROW(s->vm, s->nVm, s->capVm, 1, __typeof__(*s->vm));
          s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v; s->vm[s->nVm].src = s->nFiles; s->vm[s->nVm].stream = vstream;
          s->nVm++;
+      } else if (type == 'w') {                              /* ~w "name" <SWEIGHTS> S w1 .. wS */
+         int n = 0;
+         const int S = s->nStreams > 1 ? s->nStreams : 1;
+         if (rd_next(&r) != T_KEY || strcmp(r.tok, "SWEIGHTS")) { rc = fail(&r, "<SWEIGHTS> expected"); free(name); break; }
+         if ((rc = rd_int(&r, &n))) { free(name); break; }
+         if (n != S) { rc = fail(&r, "incorrect number of stream weights"); free(name); break; }
+         int dup = 0;
+         for (int q = 0; q < s->nWm; q++) if (!strcmp(s->wm[q].name, name)) dup = 1;
+         if (dup) { rc = fail(&r, "~w macro defined twice"); free(name); break; }
+         GROW(s->wm, s->nWm, s->capWm, 1, __typeof__(*s->wm));
+         for (int i = 0; i < S && !rc; i++) rc = rd_float(&r, &s->wm[s->nWm].w[i]);
+         if (rc) { free(name); break; }
+         s->wm[s->nWm].name = name;
+         s->nWm++;
       } else { rc = fail(&r, "unsupported macro type"); free(name); break; }
    }
    fclose(r.f);
@@ -887,6 +918,8 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
    free(s->st); free(s->wt); free(s->cg); free(s->mean); free(s->var); free(s->gconst); free(s->hasG); free(s->tr); free(s->tp); free(s->hm);
    free(s->varFloor); free(s->logName); free(s->logPhys);
    for (int i = 0; i < s->nVm; i++) { free(s->vm[i].name); free(s->vm[i].v); }
+   for (int i = 0; i < s->nWm; i++) free(s->wm[i].name);
+   free(s->wm);
    free(s->vm); free(s->gMeanMac); free(s->gVarMac);
    free(s->stateCompOff); free(s->transN); free(s->transOff); free(s->hmmTrans); free(s->hmmStateOff); free(s->hmmState);
    free(s);

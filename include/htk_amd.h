@@ -55,6 +55,11 @@ int         htkamd_set_device(int ordinal);
 int htkamd_dev_malloc(void **dptr, size_t bytes);
 int htkamd_dev_free(void *dptr);
 int htkamd_memcpy_h2d(void *dDst, const void *hSrc, size_t bytes, void *stream);   /* synchronous on return */
+/* page-locked host memory and a copy from it that does not wait: ordered before the work queued behind it on `stream`; refill the buffer only
+   after that work has been waited for (the HFB shim stages an utterance's observations this way: shim/htklib_hfb_shim.c, FBFile HFB.c:1923) */
+int htkamd_host_malloc(void **hptr, size_t bytes);
+int htkamd_host_free(void *hptr);
+int htkamd_memcpy_h2d_async(void *dDst, const void *hSrc, size_t bytes, void *stream);
 int htkamd_memcpy_d2h(void *hDst, const void *dSrc, size_t bytes, void *stream);   /* synchronous on return */
 int htkamd_stream_sync(void *stream);
 
@@ -598,7 +603,9 @@ const char *htkamd_net_word_name(const htkamd_net *n, int pron);
  * ProcessObservation / CompleteRecognition (HRec.h:150-190) with nToks = 1 and TranscriptionFromLattice (HRec.c:2176)
  * for the word-level 1-best labels.  genBeam / wordBeam = HVite -t / -v (1e10 = off), lmScale -s, wordPen -p, prScale -r.
  * LikeToWord look-ahead (HRec.c:1172) depends on the LM scale, hence lmScale at creation.
- * Results per utterance u: nWords[u] (-1: no token reached the end of the network, -3: more than maxWords words), and for
+ * Results per utterance u: nWords[u] (-1: no token reached the end of the network, -3: more than maxWords words; from the walk of HRec's
+ * instance list -- HTKAMD_ORDER_EXACT and N-best runs only, in the default HTKAMD_ORDER_AUTO mode such an utterance keeps the batch kernel's
+ * answer --: -4 out of Path records, -5 more list appends in one frame than 8 nNodes + 1024, -6 zero-time nodes nested deeper than 64), and for
  * word w < nWords[u] at [u*maxWords + w]: pronunciation index (htkamd_net_out_sym), frames [start, end), score = LArcTotLike
  * (acoustic + scaled LM + scaled pron prob + word penalty, HNet.h:257), wordLm (may be NULL) = the arc's LM log probability
  * (LArc.lmlike: what HVite -m/-f print, scaled and with the word penalty, as the word's auxiliary score); total[u] = likelihood

@@ -65,7 +65,9 @@ typedef struct {
    htkamd_accs *accs;
    htkamd_fb *fb;
    void *dX; size_t dXcap;
-   float *hX; size_t hXcap;
+   float *hX; size_t hXcap;            /* page-locked staging of an utterance's observations */
+   int *labs; size_t labsCap;
+   int exactLadd;                      /* HTKAMD_SHIM_EXACT=1: the table-driven log-add in the recursions (default: fp32 transcendentals) */
    int dirty;                          /* statistics on the device not yet added to the hooks */
    UPDSet uFlags;
 } ShimSet;
@@ -388,6 +390,7 @@ static void pack_set(ShimSet *z)
    amd_check(htkamd_model_set_prepared(z->model, ivar, gconst, logwt), "htkamd_model_set_prepared");
    /* under the reference's own HERest.o the numbers are the reference's: Setotprob's second visit of a tied state as HFB.c:1059 has it */
    amd_check(htkamd_model_set_compat(z->model, HTKAMD_COMPAT_STREAM_REVISIT), "htkamd_model_set_compat");
+   { const char *e = getenv("HTKAMD_SHIM_EXACT"); z->exactLadd = (e != NULL && e[0] == '1'); }
    amd_check(htkamd_accs_create(z->model, &z->accs), "htkamd_accs_create");
    amd_check(htkamd_fb_create(z->model, &z->fb), "htkamd_fb_create");
    free(weight); free(logwt); free(mean); free(var); free(ivar); free(gconst); free(transP);
@@ -477,7 +480,8 @@ Boolean FBFile(FBInfo *fbInfo, UttInfo *utt, char *datafn)
    if (fbInfo->al_hset != z->hset) HError(7399, "FBFile: model set differs from the one given to InitialiseForBack");
    if (!z->packed) pack_set(z);
    /* CreateInsts (HFB.c:508): label sequence -> physical models */
-   labs = (int *)malloc(sizeof(int) * (size_t)(utt->Q > 0 ? utt->Q : 1));
+   if ((size_t)utt->Q + 1 > z->labsCap) { free(z->labs); z->labsCap = 2 * (size_t)utt->Q + 64; z->labs = (int *)malloc(sizeof(int) * z->labsCap); }
+   labs = z->labs;
    for (q = 1; q <= utt->Q; q++) {
       MLink ml;
       lab = GetLabN(utt->tr->head, q);
@@ -486,7 +490,11 @@ Boolean FBFile(FBInfo *fbInfo, UttInfo *utt, char *datafn)
       if (labs[q - 1] < 0) HError(7321, "CreateInsts: label %s has no physical model in the packed set", lab->labid->name);
    }
    /* observations o_1..o_T as one row-major matrix */
-   if ((size_t)utt->T * z->D > z->hXcap) { free(z->hX); z->hXcap = (size_t)utt->T * z->D * 2; z->hX = (float *)malloc(sizeof(float) * z->hXcap); }
+   if ((size_t)utt->T * z->D > z->hXcap) {               /* page-locked: the copy below is a DMA that nobody waits for */
+      if (z->hX) amd_check(htkamd_host_free(z->hX), "htkamd_host_free");
+      z->hXcap = (size_t)utt->T * z->D * 2;
+      amd_check(htkamd_host_malloc((void **)&z->hX, sizeof(float) * z->hXcap), "htkamd_host_malloc");
+   }
    for (t = 0; t < utt->T; t++) {
       ReadAsTable(utt->pbuf, t, &utt->ot);
       if (z->NSt == 1) for (k = 1; k <= z->D; k++) z->hX[(size_t)t * z->D + k - 1] = utt->ot.fv[1][k];
@@ -500,11 +508,15 @@ Boolean FBFile(FBInfo *fbInfo, UttInfo *utt, char *datafn)
       z->dXcap = sizeof(float) * (size_t)utt->T * z->D * 2;
       amd_check(htkamd_dev_malloc(&z->dX, z->dXcap), "htkamd_dev_malloc");
    }
-   amd_check(htkamd_memcpy_h2d(z->dX, z->hX, sizeof(float) * (size_t)utt->T * z->D, NULL), "htkamd_memcpy_h2d");
+   amd_check(htkamd_memcpy_h2d_async(z->dX, z->hX, sizeof(float) * (size_t)utt->T * z->D, NULL), "htkamd_memcpy_h2d_async");      /* (htkamd_fb_results below waits for the pass behind it) */
    frameOff[0] = 0; frameOff[1] = utt->T; labOff[0] = 0; labOff[1] = utt->Q;
    b.nUtt = 1; b.dX = (const float *)z->dX; b.frameOff = frameOff; b.labOff = labOff; b.labs = labs;
    cfg.pruneInit = prune.pruneInit; cfg.pruneInc = prune.pruneInc; cfg.pruneLim = prune.pruneLim;
-   cfg.minFrwdP = prune.minFrwdP; cfg.uFlags = 0; cfg.scoreMode = HTKAMD_SCORE_EXACT;
+   /* One utterance per call: the call's time is the LATENCY of one utterance's recursions, T dependent steps each.  The state scores stay exact
+      (SCORE_EXACT: IDOutP's arithmetic); the recursions take their log-adds from the fp32 transcendental unit (FASTLADD: the lean kernels of
+      fb_lr_lean.inc, ~0.55 us per step against ~1.1) -- within 1e-4 on every re-estimated parameter (tests/test_htklib_shim.py); HTKAMD_SHIM_EXACT=1
+      in the environment asks for the table-driven log-add, bit-compatible with the reference's alpha / beta */
+   cfg.minFrwdP = prune.minFrwdP; cfg.uFlags = 0; cfg.scoreMode = z->exactLadd ? HTKAMD_SCORE_EXACT : (HTKAMD_SCORE_EXACT | HTKAMD_SCORE_FASTLADD);
    if (fbInfo->uFlags & UPMEANS) cfg.uFlags |= HTKAMD_UPMEANS;
    if (fbInfo->uFlags & UPVARS) cfg.uFlags |= HTKAMD_UPVARS;
    if (fbInfo->uFlags & UPTRANS) cfg.uFlags |= HTKAMD_UPTRANS;
@@ -512,7 +524,6 @@ Boolean FBFile(FBInfo *fbInfo, UttInfo *utt, char *datafn)
    amd_check(htkamd_fb_prepare(z->fb, &b, NULL), "htkamd_fb_prepare");
    amd_check(htkamd_fb_execute(z->fb, &cfg, z->accs, NULL), "htkamd_fb_execute");
    amd_check(htkamd_fb_results(z->fb, &pr, &status, NULL), "htkamd_fb_results");
-   free(labs);
    z->dirty = 1;
    if (status == HTKAMD_UTT_ETEE) HError(7332, "CreateInsts: Cannot have successive Tee models or Tee models at start or end of transcription");
    if (status == HTKAMD_UTT_EALPHA) HError(7390, "StepAlpha: Alpha prune failed");

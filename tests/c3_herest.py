@@ -125,22 +125,33 @@ def compare(got: dict, ref1: dict, ref8: dict, occ: np.ndarray, min_occ: float =
     carries 1e-4 is the second moment about that mean, var + (mean_new - mean_old)^2: with `init_mean` that is the scale (it equals
     the variance itself but for a Gaussian whose mean moved by more than its width -- 7 of the headline set's 2.9 M entries then sit
     between 1e-4 and 1.8e-4 of their own value in the tolerance-class mode, one does in the reference's own 1-vs-8 difference).
-    `n_above_1e4` always counts against the variance itself.  Returns counts and worst ratios; the caller asserts."""
+    `n_above_1e4` always counts against the variance itself.  Returns counts and worst ratios; the caller asserts.
+    Groups: `mean` / `var` = the Gaussians of at least `min_occ` frames of occupancy; `mean_low_occ` / `var_low_occ` = the others that exist in
+    the reference's model (until round 5 they were left out)."""
     r = {}
-    sel = occ >= min_occ
+    # A component HERest's update turned off (its new weight fell to zero: MINMIX, HERest.c:1014-1057) is no longer IN the reference's model --
+    # PutMixPDF writes no <MIXTURE> for it, and a reader finds default values in its place: it is compared through `weight.zeros_equal` only.
+    # Every other entry is held to the bar, in two groups: the Gaussians of at least `min_occ` frames, and (round 5) the rest.
+    exists = ref1["compWeight"].astype(np.float64) > 0 if ref1["compWeight"].shape[0] == occ.shape[0] else np.ones(occ.shape[0], bool)
+    sel = exists & (occ >= min_occ)
+    low = exists & ~(occ >= min_occ)
     s1 = np.sqrt(np.abs(ref1["var"].astype(np.float64)))
     vscale = np.abs(ref1["var"].astype(np.float64))
     if init_mean is not None:
         vscale = vscale + (ref1["mean"].astype(np.float64) - np.asarray(init_mean, np.float64)) ** 2
     for k, scale in (("mean", np.maximum(np.abs(ref1["mean"].astype(np.float64)), s1)), ("var", vscale)):
-        e = np.abs(got[k].astype(np.float64) - ref1[k])[sel]
-        self_ = np.abs(ref8[k].astype(np.float64) - ref1[k])[sel]
-        sc = scale[sel]
-        own = np.abs(ref1[k].astype(np.float64))[sel] if k == "var" else sc
-        r[k] = dict(n=int(e.size), worst_rel=float((e / own).max()), n_above_1e4=int((e > 1e-4 * own).sum()),
-                    n_self_above_1e4=int((self_ > 1e-4 * own).sum()), self_worst_rel=float((self_ / own).max()),
-                    n_fail=int((e > np.maximum(1e-4 * sc, 2.0 * self_)).sum()),
-                    p9999_rel=float(np.quantile(e / sc, 0.9999)), self_p9999_rel=float(np.quantile(self_ / sc, 0.9999)))
+        for tag, pick in ((k, sel), (k + "_low_occ", low)):
+            if not pick.any():
+                continue
+            e = np.abs(got[k].astype(np.float64) - ref1[k])[pick]
+            self_ = np.abs(ref8[k].astype(np.float64) - ref1[k])[pick]
+            sc = scale[pick]
+            own = np.abs(ref1[k].astype(np.float64))[pick] if k == "var" else sc
+            r[tag] = dict(n=int(e.size), worst_rel=float((e / own).max()), n_above_1e4=int((e > 1e-4 * own).sum()),
+                          n_self_above_1e4=int((self_ > 1e-4 * own).sum()), self_worst_rel=float((self_ / own).max()),
+                          n_above_1e4_not_self=int(((e > 1e-4 * own) & ~(self_ > 1e-4 * own)).sum()),
+                          n_fail=int((e > np.maximum(1e-4 * sc, 2.0 * self_)).sum()), worst_rel_scaled=float((e / sc).max()),
+                          p9999_rel=float(np.quantile(e / sc, 0.9999)), self_p9999_rel=float(np.quantile(self_ / sc, 0.9999)))
     w, w1, w8 = got["compWeight"].astype(np.float64), ref1["compWeight"].astype(np.float64), ref8["compWeight"].astype(np.float64)
     e, self_ = np.abs(w - w1), np.abs(w8 - w1)
     pos = w1 > 0

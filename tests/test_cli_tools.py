@@ -7,6 +7,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -524,3 +525,25 @@ def test_cli_tools_code_waveform_sources_on_the_device(native, tools, tmp_path, 
             assert abs(float(x) - float(y)) <= 1e-3 * max(1.0, abs(float(y))), (x, y)
         except ValueError:
             assert x == y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,src", [("WAV", "test.wav"), ("HTK", "test.htk")])
+def test_wav_sources_align_and_decode_match_reference_hvite(native, tools, tmp_path, fmt, src):
+    """north_star's "bit-exact Viterbi alignments" FROM A WAVEFORM SOURCE: tools/bin/hvite codes the waveform on the device (k_mfcc_*, the
+    qualifier kernels) and aligns (-a -m -f: model and state level) / recognises over a word loop (-w) -- the label files must be the bytes
+    the reference's HVite writes from the same waveform with its own HParm / HSigP front end.  Expected lines: committed
+    (tests/golden/make_wav_labels_golden.py -> tests/golden/wave/expected_wav_labels.json); where oracle/_ref/HVite is on the box it is run
+    beside as well.  The set is fitted to the file (tests/golden/wave/fitted.mmf), so the boundaries are decided by the data."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_wav_labels_golden as g
+    exp = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wave", "expected_wav_labels.json")))
+    wav = os.path.join(os.path.dirname(__file__), "golden", "wave", src)
+    d = str(tmp_path)
+    g.write_case(d, fmt)
+    ref = os.path.join(ROOT, "oracle", "_ref", "HVite")
+    for mode in ("align", "loop"):
+        ours = g.run_tool(os.path.join(tools, "hvite"), d, wav, mode)
+        assert ours == exp["%s/%s" % (fmt, mode)], (fmt, mode, ours)
+        if os.path.exists(ref):
+            assert ours == g.run_tool(ref, d, wav, mode), (fmt, mode)

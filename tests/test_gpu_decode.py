@@ -368,3 +368,37 @@ def test_list_order_kernel_reproduces_hvite_label_files(native, case):
             want = per.get("u%d" % u)
             got = None if words is None else format_words(words, net.out_syms)
             assert got == want, (case, opts, u)
+
+
+def test_list_walk_out_of_capacity_keeps_the_batch_kernels_answer(native, tmp_path):
+    """in the default mode an utterance with an exact tie is decoded again by the list kernel; when that walk runs out of one
+    of its fixed capacities (here: a chain of 70 !NULL nodes in front of the final node, deeper than the 64 zero-time nodes ReOrderList's
+    explicit stack holds: status -6) the batch kernel's valid result stays instead of turning into a failure."""
+    import json
+    from decode_util import GOLD
+    d = os.path.join(GOLD, "ties2", "tie_122")
+    lines = open(os.path.join(d, "net.slf")).read().splitlines()
+    nodes = [l for l in lines if l.startswith("I=")]
+    arcs = [l for l in lines if l.startswith("J=")]
+    n0 = len(nodes)
+    final = n0 - 1                                           # the lattice's last node is its end
+    # the old end node stays (a !NULL), 70 more follow it in a row
+    extra = ["I=%d W=!NULL" % (n0 + k) for k in range(70)]
+    xarcs = ["J=%d S=%d E=%d l=0.00" % (len(arcs) + k, final if k == 0 else n0 + k - 1, n0 + k) for k in range(70)]
+    slf = tmp_path / "net.slf"
+    slf.write_text("VERSION=1.0\nN=%d L=%d\n" % (n0 + 70, len(arcs) + 70) + "\n".join(nodes + extra + arcs + xarcs) + "\n")
+    mmf = native.Mmf(files=[os.path.join(d, "MMF")], hmm_list=os.path.join(d, "hmmlist"))
+    net = native.Net(str(slf), os.path.join(d, "dict"), mmf)
+    z = np.load(os.path.join(d, "feats.npz"))
+    feats = [z["u%d" % u] for u in range(len(z.files))]
+    expected = json.load(open(os.path.join(d, "expected.json")))
+    p = parse_opts(next(iter(expected)))
+    model = native.Model(mmf.packed())
+    dec = native.Decoder(model, net, lmScale=p["lmScale"])
+    dec.set_order(native.ORDER_FAST)
+    fast = dec.run(feats, **p)
+    assert all(w is not None and len(w) > 0 for w, _ in fast)
+    dec.set_order(native.ORDER_AUTO)
+    auto = dec.run(feats, **p)
+    assert dec.last_tied() >= 1                               # the tie was seen and the list kernel tried
+    assert auto == fast

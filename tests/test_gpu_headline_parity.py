@@ -59,8 +59,9 @@ def _run(native, mode):
 
 def _assert_report(r, what):
     msg = "%s: %s" % (what, json.dumps(r))
-    for k in ("mean", "var", "weight"):
-        assert r[k]["n_fail"] == 0, msg
+    for k in ("mean", "var", "weight", "mean_low_occ", "var_low_occ"):
+        if k in r:
+            assert r[k]["n_fail"] == 0, msg
     assert r["trans"]["worst_rel"] <= 1e-4 and r["trans"]["zeros_equal"], msg
 
 
@@ -120,6 +121,11 @@ def test_headline_model_vs_reference_live(native, mode, name):
     _assert_report(r, "all %d Gaussians, mode %s" % (G, name))
     # against the variances' own values: a handful of the 2.9 M, none beyond 2e-4 (the reference's own 1-vs-8 difference has one at 1.3e-4)
     assert r["var"]["n_above_1e4"] <= 10 and r["var"]["worst_rel"] <= 2e-4 and r["mean"]["n_above_1e4"] == 0
+    # ... and (round 5) the 193 089 entries of the Gaussians with fewer than two frames, every one that exists in the reference's model: means
+    # all inside 1e-4; variances -- a difference of two sums over one or two frames -- inside 1e-4 of the second moment the accumulators carry
+    # (n_fail, above), and against their own value: exact mode none above 1e-4, bf16 x 3 six (worst 2.1e-4), fp16 x 2 three (1.7e-4)
+    assert r["mean_low_occ"]["n_above_1e4"] == 0 and r["mean_low_occ"]["n"] > 150000
+    assert r["var_low_occ"]["n_above_1e4"] <= (0 if mode == 0 else 10) and r["var_low_occ"]["worst_rel"] <= (1e-6 if mode == 0 else 3e-4)
     # the accumulators themselves: occupancies and weight counts of the whole set
     assert np.allclose(a["muOcc"], occ, rtol=1e-4, atol=1e-4)
 

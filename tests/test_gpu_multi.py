@@ -162,3 +162,32 @@ def test_herest_cli_rendezvous_is_bounded(native, tmp_path):
     r = cli.run(cli.herest_demo_cmd(tools, str(conf), str(out), ["--ranks", "2", "--rank", "0", "--rccl-id", idf, "--rccl-nonce", "7", "--rccl-timeout", "5"]) + cli.demo_train_files())
     assert r.returncode == 3 and "did not meet" in r.stderr and time.time() - t0 < 90
     assert not os.path.exists(idf)
+
+
+def test_bench_self_launch_eight_ranks_on_one_device(tmp_path):
+    """`python bench.py --gpus 8` exactly as the driver's scaling run starts it -- no WORLD_SIZE in the environment, bench.py launches its
+    own eight ranks under torch.distributed.run (port from the environment, MASTER_ADDR 127.0.0.1), every rank reads RANK / LOCAL_RANK /
+    WORLD_SIZE, rank 0 alone prints the JSON line -- on a one-GPU box: all ranks on device 0, the exchange through gloo
+    (HTKAMD_BENCH_ONE_DEVICE_GLOO).  What a first 8-GPU run could die of before it reaches RCCL -- plumbing -- is covered here; the
+    merged model equals the one-rank model of the same job."""
+    import json
+    assert _ngpu() >= 1, "a `-m gpu` test on a box without a device"
+    args = ["--wire", "f32", "--scaling", "strong", "--total-utts", "256", "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
+            "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--extras", "0"]
+    env = dict(_env(), HTKAMD_BENCH_ONE_DEVICE_GLOO="1", MASTER_PORT="29631")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dump-model", str(tmp_path / "m8.npz")] + args, cwd=ROOT, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    lines = [l for l in r8.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r8.stdout[-1500:]                  # rank 0 only
+    l8 = json.loads(lines[0])
+    assert l8["n_gpus"] == 8 and l8["utterances_ok"] == 256 and l8["scaling"] == "strong" and l8["value"] > 0
+    _bench(1, str(tmp_path / "m1.npz"), 29632, wire="f32", steps=1)
+    a, b = np.load(str(tmp_path / "m1.npz")), np.load(str(tmp_path / "m8.npz"))
+    assert a["nUttDone"] == b["nUttDone"] == 256
+    assert abs(float(a["totalPr"]) - float(b["totalPr"])) <= 1e-9 * abs(float(a["totalPr"]))
+    sig = np.sqrt(a["var"].astype(np.float64))
+    assert (np.abs(a["mean"].astype(np.float64) - b["mean"]) <= 2e-5 * np.maximum(np.abs(a["mean"]), sig)).all()
+    assert np.allclose(a["var"], b["var"], rtol=2e-5, atol=1e-6) and np.allclose(a["compWeight"], b["compWeight"], rtol=2e-5, atol=1e-7)

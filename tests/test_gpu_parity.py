@@ -679,8 +679,7 @@ def _test_wave(n=48000, seed=7):
                                      ("MFCC_0_D_A", dict(loFreq=300.0, hiFreq=3400.0, numChans=20, numCeps=10, usePower=True))])
 def test_mfcc_matches_reference_front_end(native, oracle, kind, kw):
     """WAV -> MFCC on the device vs the oracle (bit-equal to the reference's HCopy, tests/test_oracle_golden.py).
-    Tolerance class: 1e-4 relative with an absolute floor of 1e-3; observed: bit-equal except where the
-    device's double log() rounds differently."""
+    Bit for bit: the kernels keep the reference's operation order and its double-precision detours (FFT twiddles tabulated on the host)."""
     waves = [_test_wave(48000, 7), _test_wave(12345, 8), _test_wave(400, 9), _test_wave(399, 10)]     # ragged, 1 frame, 0 frames
     got, frameOff = native.Mfcc(native.mfcc_config(kind, **kw)).compute_host(waves)
     ocfg = oracle.mfcc_cfg(kind, **kw)
@@ -689,8 +688,8 @@ def test_mfcc_matches_reference_front_end(native, oracle, kind, kw):
     assert refs[2].shape[0] == 1 and refs[3].shape[0] == 0
     ref = np.concatenate(refs)
     assert got.shape == ref.shape
-    assert np.allclose(got, ref, rtol=1e-4, atol=1e-3)
-    assert (got == ref).mean() > 0.999
+    # (round 5: measured over 1.3 M floats of these configurations and longer waveforms, tools/mfcc_diag.py -- not one differs)
+    assert np.array_equal(got, ref)
 
 
 def test_mfcc_known_answer_config5(native):

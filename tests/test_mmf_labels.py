@@ -295,3 +295,20 @@ def test_set_from_several_master_files_is_saved_file_by_file(native, tmp_path):
     one = native.Mmf([os.path.join(DEMO, "hmm_tied", "newMacros")], hmm_list=os.path.join(DEMO, "bcplist")).packed()
     assert np.array_equal(one["mean"], pk["mean"]) and np.array_equal(one["var"], pk["var"])
 
+
+def test_mmf_stream_weight_macros(native, tmp_path):
+    """~w "name" <SWEIGHTS> S w1..wS and its use in a state where <SWEIGHTS> would stand (GetSWeights HModel.c:1621, GetStateInfo :1966):
+    the set reads as the one with the weights written out in the states."""
+    head = "~o <STREAMINFO> 2 1 1 <VECSIZE> 2 <NULLD><USER><DIAGC>\n"
+    tr = '~t "T"\n<TRANSP> 3\n0 1 0\n0 0.5 0.5\n0 0 0\n'
+    body = "<STREAM> 1\n<MEAN> 1\n 0.5\n<VARIANCE> 1\n 1.5\n<STREAM> 2\n<MEAN> 1\n -0.25\n<VARIANCE> 1\n 2.0\n"
+    with_macro = head + '~w "sw" <SWEIGHTS> 2 1.0 0.5\n' + tr + '~h "a"\n<BEGINHMM>\n<NUMSTATES> 3\n<STATE> 2\n~w "sw"\n' + body + '~t "T"\n<ENDHMM>\n'
+    inline = head + tr + '~h "a"\n<BEGINHMM>\n<NUMSTATES> 3\n<STATE> 2\n<SWEIGHTS> 2 1.0 0.5\n' + body + '~t "T"\n<ENDHMM>\n'
+    (tmp_path / "m").write_text(with_macro); (tmp_path / "i").write_text(inline)
+    a, b = native.Mmf(files=[str(tmp_path / "m")]).packed(), native.Mmf(files=[str(tmp_path / "i")]).packed()
+    assert np.array_equal(a["streamWeight"], b["streamWeight"]) and list(a["streamWeight"]) == [1.0, 0.5]
+    for k in ("mean", "var", "compWeight", "transP"):
+        assert np.array_equal(a[k], b[k]), k
+    (tmp_path / "u").write_text(head + tr + '~h "a"\n<BEGINHMM>\n<NUMSTATES> 3\n<STATE> 2\n~w "nope"\n' + body + '~t "T"\n<ENDHMM>\n')
+    with pytest.raises(native.HtkAmdError):
+        native.Mmf(files=[str(tmp_path / "u")])
