@@ -651,6 +651,83 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
    }
 }
 
+// The same table through LDS (round 5): a workgroup takes TB tiles; their 16 TB rows of means and inverse variances arrive in storage order
+// (a row is D consecutive floats; k_build_bf16tab_dense read them 8 scattered floats per lane, 32 lines per load), the two constants of a
+// row are summed once (by one thread each, in the order of the sum above) instead of by each of the threads whose slots hold them, and the
+// slots are cut from LDS.  Same arithmetic per value: the tables are identical.
+#define BT_TILES 4
+__global__ __launch_bounds__(256) void k_build_bf16tab_dense_lds(Bf16TabArgs a, int nTiles, int KS)
+{
+   extern __shared__ float btRows[];                         // [BT_TILES*16][2][D] (mu, ivar), then [BT_TILES*16][2] constants (float), then [BT_TILES*16] live flags
+   const int D = a.D, D0 = (D + 1) >> 1;
+   const int t0 = blockIdx.x * BT_TILES;
+   const int nT = (nTiles - t0 < BT_TILES) ? nTiles - t0 : BT_TILES;
+   const int nR = nT * 16;
+   float *qc = btRows + (size_t)BT_TILES * 16 * 2 * D;
+   int *gOf = (int *)(qc + BT_TILES * 16 * 2);               // the row's Gaussian, -1: not live
+   int *cOf = gOf + BT_TILES * 16;
+   const double L2E = 1.4426950408889634;
+   if ((int)threadIdx.x < nR) {
+      const int t = t0 + (threadIdx.x >> 4), rowc = threadIdx.x & 15;
+      const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
+      const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
+      const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
+      gOf[threadIdx.x] = live ? a.compGauss[c] : -1;
+      cOf[threadIdx.x] = (c1 - c0 == 1) ? -1 - c : c;         // single-component states carry no weight
+   }
+   __syncthreads();
+   for (int i = threadIdx.x; i < nR * D; i += blockDim.x) {
+      const int r = i / D, d = i - r * D, g = gOf[r];
+      float mu = 0.0f, iv = 0.0f;
+      if (g >= 0) { mu = a.mean[(size_t)g * D + d]; iv = a.ivar[(size_t)g * D + d]; }
+      btRows[(size_t)(2 * r) * D + d] = mu; btRows[(size_t)(2 * r + 1) * D + d] = iv;
+   }
+   __syncthreads();
+   if ((int)threadIdx.x < 2 * nR) {
+      const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+      const float *mu = btRows + (size_t)(2 * r) * D, *iv = mu + D;
+      double q = 0.0;
+      for (int i = (h ? D0 : 0); i < (h ? D : D0); i++) q += (double)mu[i] * mu[i] * iv[i];
+      qc[threadIdx.x] = (float)(-0.5 * q * L2E);
+   }
+   __syncthreads();
+   const size_t tileShorts = ((size_t)KS * 3 * 32 + 4) * 8;
+   for (int w = threadIdx.x; w < nT * KS * 32; w += blockDim.x) {
+      const int tl = w / (KS * 32), r = w - tl * (KS * 32), ks = r >> 5, khf = (r >> 4) & 1, rowc = r & 15;
+      const int row = tl * 16 + rowc;
+      const bool live = gOf[row] >= 0;
+      const float *mu = btRows + (size_t)(2 * row) * D, *iv = mu + D;
+      unsigned short *T = a.tab + (size_t)(t0 + tl) * tileShorts;
+      unsigned short p[3][8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         int dim, kind;
+         dense_slot(16 * ks + 8 * khf + j, D, dim, kind);
+         float v = 0.0f;
+         if (live && kind == 0) v = (float)(-0.5 * (double)iv[dim] * L2E);
+         else if (live && kind == 1) v = (float)((double)mu[dim] * iv[dim] * L2E);
+         else if (live && kind >= 2) v = qc[2 * row + (kind - 2)];
+         split3(v, p[0][j], p[1][j], p[2][j]);
+      }
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) {
+         u4 wv;
+         wv[0] = p[pc][0] | ((unsigned int)p[pc][1] << 16); wv[1] = p[pc][2] | ((unsigned int)p[pc][3] << 16);
+         wv[2] = p[pc][4] | ((unsigned int)p[pc][5] << 16); wv[3] = p[pc][6] | ((unsigned int)p[pc][7] << 16);
+         *(u4 *)(T + ((size_t)(ks * 3 + pc) * 32 + khf * 16 + rowc) * 8) = wv;
+      }
+      if (ks == 0 && khf == 0) {
+         float ci = -1.0e30f;
+         if (live) {
+            const double k0 = a.gconst[gOf[row]];
+            const int cc = cOf[row];
+            ci = (float)(((cc < 0 ? 0.0 : (double)a.compLogWt[cc]) - 0.5 * k0) * L2E);
+         }
+         ((float *)(T + (size_t)KS * 3 * 32 * 8))[rowc] = ci;
+      }
+   }
+}
+
 int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
 {
    hipStream_t s = (hipStream_t)stream;
@@ -659,7 +736,10 @@ int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
    t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss; t.tileState = m->d_tileState;
    t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_bf16Tab;
    const int n = m->nTiles * m->bf16NC * 64;
-   if (m->f16Wide && m->bf16Dense) hipLaunchKernelGGL(k_build_bf16tab_dense, dim3((m->nTiles * 5 * 32 + 255) / 256), dim3(256), 0, s, t, m->nTiles, 5);
+   const size_t ldsDense = sizeof(float) * ((size_t)BT_TILES * 16 * 2 * m->D + BT_TILES * 16 * 2) + sizeof(int) * BT_TILES * 16 * 2;
+   if (m->f16Wide && m->bf16Dense && ldsDense <= 60 * 1024 && !getenv("HTKAMD_TAB_GATHER"))
+      hipLaunchKernelGGL(k_build_bf16tab_dense_lds, dim3((m->nTiles + BT_TILES - 1) / BT_TILES), dim3(256), ldsDense, s, t, m->nTiles, 5);
+   else if (m->f16Wide && m->bf16Dense) hipLaunchKernelGGL(k_build_bf16tab_dense, dim3((m->nTiles * 5 * 32 + 255) / 256), dim3(256), 0, s, t, m->nTiles, 5);
    else if (m->f16Wide) hipLaunchKernelGGL(k_build_bf16tab<true>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    else hipLaunchKernelGGL(k_build_bf16tab<false>, dim3((n + 255) / 256), dim3(256), 0, s, t, m->nTiles);
    HIPCHECK(hipGetLastError());

@@ -64,9 +64,8 @@ __global__ void k_upd_mark(UpdArgs a)
    for (int j = 0; j < ns; j++) a.qualS[hs[j]] = 1;
 }
 
-__global__ void k_upd_trans(UpdArgs a)
+__device__ __forceinline__ void upd_trans_one(const UpdArgs &a, const int ti)
 {
-   const int ti = blockIdx.x * blockDim.x + threadIdx.x;
    if (ti >= a.nT || !a.qualT[ti] || !(a.uFlags & HTKAMD_UPTRANS)) return;
    const int N = a.transN[ti];
    float *tp = a.transP + a.transOff[ti];
@@ -87,6 +86,8 @@ __global__ void k_upd_trans(UpdArgs a)
       } else atomicAdd(a.stats + 3, 1);
    }
 }
+
+__global__ void k_upd_trans(UpdArgs a) { upd_trans_one(a, blockIdx.x * blockDim.x + threadIdx.x); }
 
 __device__ __forceinline__ float mix_log_weight(float w) { return ((double)w < MINMIX) ? (float)LZERO : (float)log((double)w); }
 
@@ -127,6 +128,51 @@ __global__ void k_upd_state(UpdArgs a)
       if (a.anyS[s]) a.anyG[g] = 1;
       if (a.qualS[s] && (double)wgt[k] > MINMIX) a.qualG[g] = 1;
    }
+}
+
+// The same with one thread per mixture component, GW (a power of two >= the largest mixture) lanes to a state: the double exp() / log() of
+// the conversions run side by side; the two float sums of FloorMixes are taken by every lane over the group's weights in the reference's
+// order.  5 000 threads of k_upd_state were 23 us of latency at 5k x 16.
+template <int GW>
+__global__ __launch_bounds__(256) void k_upd_state_w(UpdArgs a, const int nbState)
+{
+   if ((int)blockIdx.x >= nbState) { upd_trans_one(a, (blockIdx.x - nbState) * blockDim.x + threadIdx.x); return; }      // the transitions ride along
+   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+   const int s = tid / GW, k = tid % GW;
+   const bool sIn = s < a.S;
+   const int sc = sIn ? s : 0;
+   const int c0 = a.stateCompOff[sc], M = a.stateCompOff[sc + 1] - c0;
+   const bool in = sIn && k < M;
+   const int c = in ? c0 + k : c0;
+   const bool raw = a.rawLogWt && a.rawLogWt[c];
+   const unsigned char anyS = a.anyS[sc], qualS = a.qualS[sc];
+   float w = a.compWeight[c];
+   if (a.singleProcess && anyS && !raw) w = (float)exp((double)mix_log_weight(w));
+   if (qualS && a.maxM > 1 && (a.uFlags & HTKAMD_UPMIXES)) {
+      const float occi = ACCF(a.lay.wtOcc, sc);
+      if (occi > 0.0f) {
+         float x = ACCF(a.lay.wt, c) / occi;
+         if (in && (double)x > 1.001) atomicAdd(a.stats + 6, 1);
+         if (x > 1.0f) x = 1.0f;
+         w = ((double)x > MINMIX) ? x : 0.0f;
+         if (a.mixWeightFloor > 0.0f) {                      // FloorMixes
+            const float floor = a.mixWeightFloor;
+            float sum = 0.0f, fsum = 0.0f;
+            for (int j = 0; j < GW; j++) {
+               const float wj = __shfl(w, j, GW);
+               if (j < M) { if (wj > floor) sum += wj; else fsum += floor; }
+            }
+            if (!(w > floor)) w = floor;
+            else if (fsum != 0.0f && sum != 0.0f) w *= (float)((1.0 - (double)fsum) / (double)sum);
+         }
+      } else if (sIn && k == 0) atomicAdd(a.stats + 4, 1);
+   }
+   if (!in) return;
+   a.compWeight[c] = w;
+   a.compLogWt[c] = raw ? w : mix_log_weight(w);
+   const int g = a.compGauss[c];
+   if (anyS) a.anyG[g] = 1;
+   if (qualS && (double)w > MINMIX) a.qualG[g] = 1;
 }
 
 // Tied vectors.  The reference hangs ONE accumulator on a shared vector and lets the first mixture that reaches it (models in scan
@@ -308,6 +354,159 @@ __global__ __launch_bounds__(256) void k_upd_gauss_elem(UpdArgs a)
    }
 }
 
+// Variances, means AND gConst in one pass (round 5): a workgroup owns UPD_GPB whole Gaussians -- their elements as 16-byte words in storage
+// order (coalesced, as k_upd_gauss_elem), the logs of the new variances into LDS, then one thread per Gaussian sums its row in the
+// reference's order (FixDiagGConst HModel.c:5641) and closes the Gaussian's row of the scoring table.  Saves the separate gConst launch
+// and the write + read of the log-variance array (25 MB at 5k x 16).  Sets without shared vectors and with G D divisible by 4.
+#define UPD_GPB 64
+template <int NIT>                                         // 16-byte words per thread: ceil(UPD_GPB D / 1024)
+__global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
+{
+   // [UPD_GPB][PS] the block's rows of the exact kernel's table (mean, inverse variance interleaved; gConst; padding), [UPD_GPB][D] log
+   // variances, [UPD_GPB] floored flags.  The table rows leave as whole 16-byte words: written pair by pair from the element loop they were
+   // 8-byte stores 32 bytes apart, and the kernel's HBM writes were twice its data (WRITE_SIZE, profiles/README.md r05b).
+   extern __shared__ float updLds[];
+   const int D = a.D, PS = a.PS;
+   const int g0 = blockIdx.x * UPD_GPB;
+   const int nG = (a.G - g0 < UPD_GPB) ? a.G - g0 : UPD_GPB;
+   float *gpRows = updLds, *lvRows = updLds + (size_t)UPD_GPB * PS;
+   int *flRow = (int *)(lvRows + (size_t)UPD_GPB * D);
+   for (int i = threadIdx.x; i < UPD_GPB; i += blockDim.x) flRow[i] = 0;
+   for (int i = threadIdx.x; i < nG; i += blockDim.x)
+      for (int k = 2 * D + 1; k < PS; k++) gpRows[i * PS + k] = 0.0f;                       // (the padding of a row is zeros: gparam_refresh, model.hip)
+   __syncthreads();
+   const unsigned int e0 = (unsigned int)g0 * (unsigned int)D, nEl = (unsigned int)nG * (unsigned int)D;      // the block's elements: e0 .. e0 + nEl
+   const bool accPairs = ((a.lay.mu | a.lay.va) & 1) == 0 && (((size_t)a.acc & 15) == 0);   // the statistics as 16-byte words
+   int nFloored = 0;
+   // every load of the thread first: the block's waves all start together and there is one round of blocks, so a wave that loads, computes
+   // and stores word by word leaves the memory system idle while the chip takes its logarithms (74 us against 58 with the loads up front)
+   float4 vAll[NIT], mAll[NIT];
+   double dMuAll[NIT][4], dVaAll[NIT][4];
+#pragma unroll
+   for (int it = 0; it < NIT; it++) {
+      const unsigned int c = (threadIdx.x + it * 256u) * 4u, i0 = e0 + c;
+      vAll[it] = mAll[it] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+      for (int j = 0; j < 4; j++) dMuAll[it][j] = dVaAll[it][j] = 0.0;
+      if (c + 3u < nEl) {
+         vAll[it] = *(const float4 *)(a.var + i0); mAll[it] = *(const float4 *)(a.mean + i0);
+         if (accPairs) {
+            const double2 m0 = *(const double2 *)(a.acc + a.lay.mu + i0), m1 = *(const double2 *)(a.acc + a.lay.mu + i0 + 2);
+            const double2 q0 = *(const double2 *)(a.acc + a.lay.va + i0), q1 = *(const double2 *)(a.acc + a.lay.va + i0 + 2);
+            dMuAll[it][0] = m0.x; dMuAll[it][1] = m0.y; dMuAll[it][2] = m1.x; dMuAll[it][3] = m1.y;
+            dVaAll[it][0] = q0.x; dVaAll[it][1] = q0.y; dVaAll[it][2] = q1.x; dVaAll[it][3] = q1.y;
+         } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { dMuAll[it][j] = a.acc[a.lay.mu + i0 + j]; dVaAll[it][j] = a.acc[a.lay.va + i0 + j]; }
+         }
+      } else if (c < nEl) {                                  // the set's last word, cut short
+         float tv[4] = {1.0f, 1.0f, 1.0f, 1.0f}, tm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+         for (int j = 0; j < 4; j++)
+            if (c + j < nEl) { tv[j] = a.var[i0 + j]; tm[j] = a.mean[i0 + j]; dMuAll[it][j] = a.acc[a.lay.mu + i0 + j]; dVaAll[it][j] = a.acc[a.lay.va + i0 + j]; }
+         vAll[it] = make_float4(tv[0], tv[1], tv[2], tv[3]); mAll[it] = make_float4(tm[0], tm[1], tm[2], tm[3]);
+      }
+   }
+#pragma unroll
+   for (int it = 0; it < NIT; it++) {
+      const unsigned int c = (threadIdx.x + it * 256u) * 4u;
+      if (c >= nEl) break;
+      const unsigned int i0 = e0 + c;                       // a multiple of 4 (UPD_GPB D is)
+      const bool full = c + 3u < nEl;
+      float v[4] = {vAll[it].x, vAll[it].y, vAll[it].z, vAll[it].w}, mu[4] = {mAll[it].x, mAll[it].y, mAll[it].z, mAll[it].w}, r[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+         const bool live = c + j < nEl;
+         const unsigned int cl = live ? c + j : 0u;
+         const unsigned int idx = e0 + cl;
+         const int gl = (int)(cl / (unsigned int)D), k = (int)(cl - (unsigned int)gl * (unsigned int)D), g = g0 + gl;
+         const double dMu = dMuAll[it][j], dVa = dVaAll[it][j];
+         const double dMuOcc = a.acc[a.lay.muOcc + g], dVaOcc = a.acc[a.lay.vaOcc + g];
+         const unsigned char qual = a.qualG[g], any = a.anyG[g];
+         const bool outside = OUTSIDE(g, k);
+         float vv = v[j], mm = mu[j];
+         bool floored = false;
+         if (a.singleProcess && any && !outside) {              // ConvDiagC before the pass, ForceDiagC after it
+            float iv;
+            if (vv > 1E+30f) vv = 1E+30f;
+            if (vv < 1E-30f) vv = 1E-30f;
+            iv = 1 / vv;
+            if (iv > 1E+30f) iv = 1E+30f;
+            if (iv < 1E-30f) iv = 1E-30f;
+            vv = 1 / iv;
+         }
+         if (qual && !outside) {
+            const float muOcc = (float)dMuOcc;
+            if (a.uFlags & HTKAMD_UPVARS) {
+               const float occim = (float)dVaOcc;
+               if (occim > 0.0f) {
+                  const bool shared = (a.uFlags & HTKAMD_UPMEANS) == 0 || muOcc <= 0.0f;
+                  const float muDiffk = shared ? 0.0f : (float)dMu / muOcc;
+                  float x = (float)dVa / occim - muDiffk * muDiffk;
+                  const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
+                  if (x < fl) { x = fl; floored = live; }
+                  vv = x;
+               } else if (k == 0 && live) atomicAdd(a.stats + 5, 1);
+            }
+            if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mm += (float)dMu / muOcc;
+         }
+         v[j] = vv; mu[j] = mm;
+         float cc = vv;
+         if (cc > 1E+30f) cc = 1E+30f;
+         if (cc < 1E-30f) cc = 1E-30f;
+         r[j] = outside ? 0.0f : 1 / cc;
+         const float z = ((double)vv <= MINLARG) ? (float)LZERO : (float)log((double)vv);
+         if (floored) { nFloored++; flRow[gl] = 1; }
+         if (live) {
+            lvRows[cl] = z;
+            if (!full) { a.var[idx] = vv; a.mean[idx] = mm; a.ivar[idx] = r[j]; }
+            *(float2 *)(gpRows + (size_t)gl * PS + 2 * k) = make_float2(mm, r[j]);
+         }
+      }
+      if (full) {
+         *(float4 *)(a.var + i0) = make_float4(v[0], v[1], v[2], v[3]);
+         *(float4 *)(a.mean + i0) = make_float4(mu[0], mu[1], mu[2], mu[3]);
+         *(float4 *)(a.ivar + i0) = make_float4(r[0], r[1], r[2], r[3]);
+      }
+   }
+   {  // floored elements: one atomic per wavefront
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) nFloored += __shfl_xor(nFloored, o);
+      if (nFloored && (threadIdx.x & 63) == 0) atomicAdd(a.stats + 0, nFloored);
+   }
+   __syncthreads();
+   // ---- gConst of the block's Gaussians, one thread each
+   const int t = threadIdx.x;
+   bool fl = false;
+   if (t < nG) {
+      const int g = g0 + t;
+      fl = flRow[t] != 0;
+      if (fl) a.flooredG[g] = 1;
+      float gc = a.gconst[g];
+      if (a.qualG[g] && (a.uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS))) {
+         int n = D;
+         if (a.dimStream) { n = 0; for (int k = 0; k < D; k++) if (!OUTSIDE(g, k)) n++; }
+         float sum = (float)((double)n * a.logTpi);
+         const float *lv = lvRows + (size_t)t * D;
+         for (int k = 0; k < D; k++) {
+            if (OUTSIDE(g, k)) continue;
+            sum += lv[k];
+         }
+         a.gconst[g] = gc = sum;
+      }
+      gpRows[(size_t)t * PS + 2 * D] = gc;
+   }
+   if (t < 64) {                                             // (the threads of the Gaussians are wavefront 0: UPD_GPB = 64)
+      const unsigned long long fb = __ballot(fl);
+      if (fb && t == 0) atomicAdd(a.stats + 1, __popcll(fb));
+   }
+   __syncthreads();
+   // ---- the rows of the exact kernel's table, in storage order
+   float4 *dst = (float4 *)(a.gparam + (size_t)g0 * PS);     // (PS is a multiple of 4 and the table 16-byte aligned)
+   const float4 *src = (const float4 *)gpRows;
+   for (int i = threadIdx.x; i < nG * (PS >> 2); i += blockDim.x) dst[i] = src[i];
+}
+
 // gConst, one thread per Gaussian: the float sum over the dimensions runs in the reference's order (FixDiagGConst HModel.c:5641)
 __global__ __launch_bounds__(128) void k_upd_gconst(UpdArgs a)
 {
@@ -466,21 +665,42 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
    }
    const int B = 128;
    hipLaunchKernelGGL(k_upd_mark, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
-   hipLaunchKernelGGL(k_upd_trans, dim3((m->nT + B - 1) / B), dim3(B), 0, s, a);
-   hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
+   {  // weights and the marks of the Gaussians, one thread per component; the transition matrices in the launch's last blocks
+      const int gw = m->maxM <= 4 ? 4 : m->maxM <= 16 ? 16 : m->maxM <= 64 ? 64 : 0;
+      const unsigned nb = gw ? (unsigned)(((size_t)m->S * gw + 255) / 256) : 0, nbT = (unsigned)((m->nT + 255) / 256);
+      if (gw == 4) hipLaunchKernelGGL(k_upd_state_w<4>, dim3(nb + nbT), dim3(256), 0, s, a, (int)nb);
+      else if (gw == 16) hipLaunchKernelGGL(k_upd_state_w<16>, dim3(nb + nbT), dim3(256), 0, s, a, (int)nb);
+      else if (gw == 64) hipLaunchKernelGGL(k_upd_state_w<64>, dim3(nb + nbT), dim3(256), 0, s, a, (int)nb);
+      else {
+         hipLaunchKernelGGL(k_upd_trans, dim3((m->nT + B - 1) / B), dim3(B), 0, s, a);
+         hipLaunchKernelGGL(k_upd_state, dim3((m->S + B - 1) / B), dim3(B), 0, s, a);
+      }
+   }
    // a tied-mixture set's pool is re-estimated once per set, whatever the models' example counts and the components' weights
    // (MLUpdateModels HERest.c:1272-1279: UpdateTMVars / UpdateTMMeans / FixAllGConsts)
    if (m->tiedMix) HIPCHECK(hipMemsetAsync(a.qualG, 1, (size_t)m->G, s));
+   bool fusedG = false;
    {
       const size_t nEl = (size_t)m->G * m->D;
+      const size_t ldsFused = sizeof(float) * (size_t)UPD_GPB * (m->D + m->PS) + sizeof(int) * UPD_GPB;
       if (nEl >= ((size_t)1 << 31)) { htkamd_set_error("model_update_device: %zu mean / variance elements (the element kernel indexes with 32 bits)", nEl); return HTKAMD_EMODEL; }
       if (tied) {
          hipLaunchKernelGGL(k_upd_first, dim3((m->H + B - 1) / B), dim3(B), 0, s, a);
          hipLaunchKernelGGL(k_upd_gauss_elem_tied, dim3((unsigned)((nEl + 255) / 256)), dim3(256), 0, s, a);
+      } else if (!m->tiedMix && ldsFused <= 60 * 1024 && (m->PS & 3) == 0 && m->D <= 64 && !getenv("HTKAMD_UPD_UNFUSED")) {
+         // elements and gConst in one kernel
+         const dim3 gr((unsigned)((m->G + UPD_GPB - 1) / UPD_GPB));
+         switch ((UPD_GPB * m->D + 1023) / 1024) {
+         case 1: hipLaunchKernelGGL(k_upd_gauss_fused<1>, gr, dim3(256), ldsFused, s, a); break;
+         case 2: hipLaunchKernelGGL(k_upd_gauss_fused<2>, gr, dim3(256), ldsFused, s, a); break;
+         case 3: hipLaunchKernelGGL(k_upd_gauss_fused<3>, gr, dim3(256), ldsFused, s, a); break;
+         default: hipLaunchKernelGGL(k_upd_gauss_fused<4>, gr, dim3(256), ldsFused, s, a); break;
+         }
+         fusedG = true;
       } else
          hipLaunchKernelGGL(k_upd_gauss_elem, dim3((unsigned)((nEl + 1023) / 1024)), dim3(256), 0, s, a);
    }
-   {
+   if (!fusedG) {
       UpdArgs ag = a;
       if (sizeof(float) * (size_t)B * m->D > 48 * 1024) ag.logVar = nullptr;          // rows too long for the LDS staging: the kernel takes the logs itself
       hipLaunchKernelGGL(k_upd_gconst, dim3((m->G + B - 1) / B), dim3(B), ag.logVar ? sizeof(float) * (size_t)B * m->D : 0, s, ag);
