@@ -741,10 +741,10 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          size_t cap = 64;
          while (cap < 65536 && cap * (size_t)m->S < (size_t)16 * fb->totalFrames) cap <<= 1;
          while (cap > 64 && cap * (size_t)m->S * sizeof(HitS) > ((size_t)1 << 30)) cap >>= 1;
-         if ((rc = fb->d_stCnt.reserve(sizeof(int) * ((size_t)m->S + 4))) || (rc = fb->d_stBucket.reserve(sizeof(HitS) * cap * (size_t)m->S))) return rc;
+         if ((rc = fb->d_stCnt.reserve(sizeof(int) * (3 * (size_t)m->S + 4))) || (rc = fb->d_stBucket.reserve(sizeof(HitS) * cap * (size_t)m->S))) return rc;
          fb->mixStateLast = true;
          fa.stCnt = (int *)fb->d_stCnt.p; fa.nTiedStates = m->S; fa.stBucket = (HitS *)fb->d_stBucket.p; fa.stCap = (int)cap;
-         HIPCHECK(hipMemsetAsync(fa.stCnt, 0, sizeof(int) * ((size_t)m->S + 4), s));      /* counts, then: pairs turned away, pairs, triples */
+         HIPCHECK(hipMemsetAsync(fa.stCnt, 0, sizeof(int) * (3 * (size_t)m->S + 4), s));  /* counts; pairs turned away (+3 spare); then per state: pairs, triples */
       }
    }
    static const int clsW[4] = {1, 2, 4, 8};
@@ -897,9 +897,14 @@ extern "C" int htkamd_fb_mix_counts(htkamd_fb *fb, long long out[2])
    out[0] = out[1] = -1;
    if (!fb->timed || !fb->mixStateLast || !fb->d_stCnt.p) return HTKAMD_OK;
    HIPCHECK(hipEventSynchronize(fb->ev[5]));
-   int c[3] = {0, 0, 0};
-   HIPCHECK(hipMemcpy(c, (int *)fb->d_stCnt.p + fb->m->S, sizeof(c), hipMemcpyDeviceToHost));
-   out[0] = c[1]; out[1] = c[2];
+   const size_t S = (size_t)fb->m->S;
+   int *c = (int *)malloc(sizeof(int) * 2 * S);
+   if (!c) { htkamd_set_error("fb_mix_counts: out of memory"); return HTKAMD_ENOMEM; }
+   const hipError_t e = hipMemcpy(c, (int *)fb->d_stCnt.p + S + 4, sizeof(int) * 2 * S, hipMemcpyDeviceToHost);
+   if (e != hipSuccess) { free(c); HIPCHECK(e); }
+   out[0] = out[1] = 0;
+   for (size_t i = 0; i < S; i++) { out[0] += c[2 * i]; out[1] += c[2 * i + 1]; }
+   free(c);
    return HTKAMD_OK;
 }
 

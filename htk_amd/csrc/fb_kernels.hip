@@ -1174,7 +1174,8 @@ __global__ __launch_bounds__(64, 3) void k_mixstate(FbArgs a)
    }
 #pragma unroll
    for (int o = 32; o > 0; o >>= 1) nTriples += __shfl_xor(nTriples, o);
-   if (lane == 0) { atomicAdd(a.stCnt + a.nTiedStates + 1, nst); atomicAdd(a.stCnt + a.nTiedStates + 2, nTriples); }
+   // the state's counts in its own two cells (htkamd_fb_mix_counts sums them): 10 000 updates of two shared cells were 10 us of the kernel's tail
+   if (lane == 0) { a.stCnt[a.nTiedStates + 4 + 2 * st] = nst; a.stCnt[a.nTiedStates + 5 + 2 * st] = nTriples; }
    double so = (sub < M) ? w : 0.0;
 #pragma unroll
    for (int o = GS / 2; o > 0; o >>= 1) so += __shfl_xor(so, o);

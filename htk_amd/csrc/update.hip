@@ -38,6 +38,7 @@ struct UpdArgs {
    unsigned char *qualT, *qualS, *qualG, *anyS, *anyG;      // marked by a qualifying model / used by any model
    unsigned char *flooredG;                                 // a variance element of the Gaussian was floored
    int *stats;                                              // htkamd_update_stats fields in order + [6] weights above 1.001
+   int *blkStats;                                           // k_upd_gauss_fused: [blocks][3] counters of the blocks (in logVar's place)
    float *logVar;                                           // [G*D] log of the new variances (k_upd_gauss_elem) for k_upd_gconst's sum; NULL: tied sets
    // sets with tied mean / variance vectors (~u ~v; htkamd_model_set_sharing), else tied == 0
    int tied;
@@ -371,6 +372,10 @@ __global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
    const int nG = (a.G - g0 < UPD_GPB) ? a.G - g0 : UPD_GPB;
    float *gpRows = updLds, *lvRows = updLds + (size_t)UPD_GPB * PS;
    int *flRow = (int *)(lvRows + (size_t)UPD_GPB * D);
+   // the block's counters (floored elements, floored Gaussians, Gaussians without variance statistics): summed by k_upd_export.  One atomic
+   // per wavefront on the set's counter was 5 000 updates of one address, 7 ns each: 35 of the kernel's 76 us
+   __shared__ int blkCnt[4];
+   if (threadIdx.x < 4) blkCnt[threadIdx.x] = 0;
    for (int i = threadIdx.x; i < UPD_GPB; i += blockDim.x) flRow[i] = 0;
    for (int i = threadIdx.x; i < nG; i += blockDim.x)
       for (int k = 2 * D + 1; k < PS; k++) gpRows[i * PS + k] = 0.0f;                       // (the padding of a row is zeros: gparam_refresh, model.hip)
@@ -378,12 +383,10 @@ __global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
    const unsigned int e0 = (unsigned int)g0 * (unsigned int)D, nEl = (unsigned int)nG * (unsigned int)D;      // the block's elements: e0 .. e0 + nEl
    const bool accPairs = ((a.lay.mu | a.lay.va) & 1) == 0 && (((size_t)a.acc & 15) == 0);   // the statistics as 16-byte words
    int nFloored = 0;
-   // every load of the thread first: the block's waves all start together and there is one round of blocks, so a wave that loads, computes
-   // and stores word by word leaves the memory system idle while the chip takes its logarithms (74 us against 58 with the loads up front)
+   // (UPD_HOIST=1: every load of the thread before the first element is worked on -- measured slower, 48 us against 39)
    float4 vAll[NIT], mAll[NIT];
    double dMuAll[NIT][4], dVaAll[NIT][4];
-#pragma unroll
-   for (int it = 0; it < NIT; it++) {
+   auto load_it = [&](const int it) {
       const unsigned int c = (threadIdx.x + it * 256u) * 4u, i0 = e0 + c;
       vAll[it] = mAll[it] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
@@ -406,11 +409,21 @@ __global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
             if (c + j < nEl) { tv[j] = a.var[i0 + j]; tm[j] = a.mean[i0 + j]; dMuAll[it][j] = a.acc[a.lay.mu + i0 + j]; dVaAll[it][j] = a.acc[a.lay.va + i0 + j]; }
          vAll[it] = make_float4(tv[0], tv[1], tv[2], tv[3]); mAll[it] = make_float4(tm[0], tm[1], tm[2], tm[3]);
       }
-   }
+   };
+#ifndef UPD_HOIST
+#define UPD_HOIST 0
+#endif
+#if UPD_HOIST
+#pragma unroll
+   for (int it = 0; it < NIT; it++) load_it(it);
+#endif
 #pragma unroll
    for (int it = 0; it < NIT; it++) {
       const unsigned int c = (threadIdx.x + it * 256u) * 4u;
       if (c >= nEl) break;
+#if !UPD_HOIST
+      load_it(it);
+#endif
       const unsigned int i0 = e0 + c;                       // a multiple of 4 (UPD_GPB D is)
       const bool full = c + 3u < nEl;
       float v[4] = {vAll[it].x, vAll[it].y, vAll[it].z, vAll[it].w}, mu[4] = {mAll[it].x, mAll[it].y, mAll[it].z, mAll[it].w}, r[4];
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
                   const float fl = a.hasVarFloor ? a.varFloor[k] : a.minVar;
                   if (x < fl) { x = fl; floored = live; }
                   vv = x;
-               } else if (k == 0 && live) atomicAdd(a.stats + 5, 1);
+               } else if (k == 0 && live) atomicAdd(blkCnt + 2, 1);
             }
             if ((a.uFlags & HTKAMD_UPMEANS) && muOcc > 0.0f) mm += (float)dMu / muOcc;
          }
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
    {  // floored elements: one atomic per wavefront
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) nFloored += __shfl_xor(nFloored, o);
-      if (nFloored && (threadIdx.x & 63) == 0) atomicAdd(a.stats + 0, nFloored);
+      if (nFloored && (threadIdx.x & 63) == 0) atomicAdd(blkCnt + 0, nFloored);
    }
    __syncthreads();
    // ---- gConst of the block's Gaussians, one thread each
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(256) void k_upd_gauss_fused(UpdArgs a)
    }
    if (t < 64) {                                             // (the threads of the Gaussians are wavefront 0: UPD_GPB = 64)
       const unsigned long long fb = __ballot(fl);
-      if (fb && t == 0) atomicAdd(a.stats + 1, __popcll(fb));
+      if (t == 0) { a.blkStats[3 * blockIdx.x + 0] = blkCnt[0]; a.blkStats[3 * blockIdx.x + 1] = __popcll(fb); a.blkStats[3 * blockIdx.x + 2] = blkCnt[2]; }
    }
    __syncthreads();
    // ---- the rows of the exact kernel's table, in storage order
@@ -587,9 +600,13 @@ __global__ void k_upd_mfma(MfmaTabArgs a, int nTiles)
 }
 
 // the update's counters behind the transition matrices, so that one copy brings both to the host
-__global__ void k_upd_export(const int *stats, int *dst)
+__global__ void k_upd_export(const int *stats, int *dst, const int *blkStats, int nBlk)
 {
-   if (threadIdx.x < 16) dst[threadIdx.x] = stats[threadIdx.x];
+   int c0 = 0, c1 = 0, c2 = 0;                               // the fused kernel's per-block counters: stats[0], [1], [5]
+   for (int i = threadIdx.x; i < nBlk; i += 64) { c0 += blkStats[3 * i]; c1 += blkStats[3 * i + 1]; c2 += blkStats[3 * i + 2]; }
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+   if (threadIdx.x < 16) dst[threadIdx.x] = stats[threadIdx.x] + (threadIdx.x == 0 ? c0 : threadIdx.x == 1 ? c1 : threadIdx.x == 5 ? c2 : 0);
 }
 
 int htkamd_model_refresh_mfma_device(htkamd_model *m, void *stream)
@@ -645,6 +662,7 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
    a.qualT = fl; a.qualS = a.qualT + m->nT; a.anyS = a.qualS + m->S; a.qualG = a.anyS + m->S; a.anyG = a.qualG + m->G; a.flooredG = a.anyG + m->G;
    a.stats = (int *)(fl + ((nFlag + 63) & ~(size_t)63));
    a.logVar = tied ? nullptr : (float *)(fl + headBytes);
+   a.blkStats = (int *)a.logVar;                             // (3 ints per 64 Gaussians in the place of D floats per Gaussian)
    float *dFloor = (float *)(a.stats + 16);
    a.hasVarFloor = cfg->varFloor != nullptr; a.varFloor = dFloor;
    if (cfg->varFloor) HIPCHECK(hipMemcpyAsync(dFloor, cfg->varFloor, sizeof(float) * (size_t)m->D, hipMemcpyHostToDevice, s));
@@ -716,7 +734,7 @@ extern "C" int htkamd_model_update_device_begin(htkamd_model *m, htkamd_accs *ac
    const size_t nTp = (size_t)m->h_transOff[m->nT];
    if (!m->h_updPin) HIPCHECK(hipHostMalloc(&m->h_updPin, sizeof(float) * (nTp + 16), hipHostMallocDefault));
    if (!m->evUpd) { hipEvent_t e; HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->evUpd = (void *)e; }
-   hipLaunchKernelGGL(k_upd_export, dim3(1), dim3(64), 0, s, a.stats, (int *)(m->d_transP + nTp));
+   hipLaunchKernelGGL(k_upd_export, dim3(1), dim3(64), 0, s, a.stats, (int *)(m->d_transP + nTp), a.blkStats, fusedG ? (int)((m->G + UPD_GPB - 1) / UPD_GPB) : 0);
    HIPCHECK(hipMemcpyAsync(m->h_updPin, m->d_transP, sizeof(float) * (nTp + 16), hipMemcpyDeviceToHost, s));
    HIPCHECK(hipEventRecord((hipEvent_t)m->evUpd, s));
    free(scanPosHost);
