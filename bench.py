@@ -177,6 +177,7 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256, cpu_utts=2)
                                  "network": "back-off bigram over %d one-model words (%d arcs, fan-in %d at the back-off node), -t 250 -s 5 -p -10 (BASELINE config[3])" % (V, n_arcs, V),
                                  "words_correct": "%d/%d" % (hit, tot),
                                  "arithmetic": "exact (K1 dense + K7)", "exact_order_utterances": dec.last_tied(),
+                                 "model_instance_steps": dict(zip(("live", "dead"), dec.last_live())),
                                  "roofline": {"kernel": "k_decode (token passing)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                               "ms": tok_ms, "bytes_per_unit": 4.0 * S_ + 48.0 * V, "unit_is": "(utterance, frame)", "units_per_launch": frames_,
                                               "traffic": None, "note": "traffic: counter bytes per launch from profiles/ (k_decode FETCH_SIZE + WRITE_SIZE), filled in when the committed PMC passes are of this workload"},

@@ -24,6 +24,8 @@ EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["
 if os.environ.get("HTKAMD_LR_DEFS"):               # experiment switches of fb_lr.hip, e.g. HTKAMD_LR_DEFS="-DSTATS_EXP_NOOCC"
     EXTRA_FLAGS["csrc/fb_lr.hip"] = os.environ["HTKAMD_LR_DEFS"].split()
     EXTRA_FLAGS["csrc/fb_kernels.hip"] = os.environ["HTKAMD_LR_DEFS"].split()
+if os.environ.get("HTKAMD_DEC_DEFS"):              # ... and decode.hip (-DDEC_CLK: phase stamps)
+    EXTRA_FLAGS["csrc/decode.hip"] = os.environ["HTKAMD_DEC_DEFS"].split()
 if os.environ.get("HTKAMD_UPD_DEFS"):              # the same for update.hip / gmm_bf16.hip (tools/r05_updvar.sh)
     EXTRA_FLAGS["csrc/update.hip"] = os.environ["HTKAMD_UPD_DEFS"].split()
 if os.environ.get("HTKAMD_B16_CT"):              # experiment switch: column tiles per wavefront of the bf16 scoring kernel (gmm_bf16.hip: B16_COL_TILES)

@@ -1049,6 +1049,12 @@ class Decoder:
         check(lib().htkamd_decoder_last_times(self.h, C.byref(a), C.byref(b)), "decoder_last_times")
         return a.value, b.value
 
+    def last_live(self):
+        """(model-instance steps with a live token, without) of the last run's token kernel: htkamd_decoder_last_live."""
+        out = (C.c_longlong * 2)()
+        check(lib().htkamd_decoder_last_live(self.h, out), "decoder_last_live")
+        return int(out[0]), int(out[1])
+
     def run(self, feats, genBeam=1.0e10, wordBeam=1.0e10, lmScale=None, wordPen=0.0, prScale=1.0, maxWords=1024, scoreMode=0, maxActive=0):
         """feats: list of [T, D] arrays.  Returns per utterance (list of (pron, startFrame, endFrame, score) or None, total)."""
         lmScale = self.lmScale if lmScale is None else float(lmScale)

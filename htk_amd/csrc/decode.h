@@ -39,10 +39,23 @@ struct DecNet {
    const int *regFused;                // [nReg] the word / null node whose only predecessor is this model (stepped by its owner), or -1
    const float *regFusedLike;          // [nReg] LM log probability of that link
    const unsigned char *regNoEx;       // [nReg] nobody pulls this model's exit token from memory
+   // k_decode<.., EXL>: the exit tokens the register-resident models pull are kept in LDS beside memory -- a WORD node's as its likelihood alone
+   // (its lm is 0 and its path is frame * nWordNodes + wordIdx: StepWord2 HRec.c:1046), a null node's whole
+   const int *zl;                      // [nNodes] -1, or bit 30 | wordIdx (WORD node), or the null node's slot in the LDS table
+   int nNullLds;                       // null nodes with a slot (<= DEC_NULL_LDS)
+   const int2 *predRecL;               // [links] predRec with x = bit 31 | bit 30 | wordIdx for a WORD predecessor, bit 31 | bit 29 | slot for a null node with a slot
+   const int *regFusedZl;              // [nReg] zl of the model's fused node (-1: none / no slot)
+   const int4 *regFusedRec;            // [nReg] {fused node or -1, its zl, bits of its pronProb, its wordIdx or -1}: StepWord2 without four dependent loads
+   const int2 *regPred;                // [nReg] the model's range in predRecReg / predRecRegL: the entry pull's range without the two loads behind the node's number
+   const int2 *predRecReg, *predRecRegL;   // the register-resident models' lists of predRec / predRecL, in the models' order
+   const int2 *predRec;                // [links] {predSrc, bits of predLike}: one load per predecessor
    const int4 *regRecA, *regRecB; const float2 *regRecF;      // [nReg] the same and the model's constants packed: {node, kind | N << 4, transP offset, fused node}, {score slots of states 2..4, regNoEx}, {wdlk, fused link's LM}
 };
-#define DEC_REG_THREADS 512
-#define DEC_REG_MAXNPT 12
+// 1024 threads x 6 models: four wavefronts per SIMD hide one another's memory latencies; 512 x 12 (round 4: no register spills to speak of,
+// two wavefronts per SIMD) took 50 ms where this takes 41 on the 6 000-word bigram network, 768 x 8 42 (tools/r05_decvar.sh)
+#define DEC_REG_THREADS 1024
+#define DEC_REG_MAXNPT 6
+#define DEC_NULL_LDS 64             /* null nodes whose tokens k_decode<.., EXL> keeps in LDS */
 
 struct DecUtt {
    int T, frame0, status, idx;         // idx: the utterance's number in the batch (its slot in the per-utterance outputs)
@@ -66,6 +79,7 @@ struct DecArgs {
    int maxActive;                      // HVite -u: maximum number of model instances kept per frame (0 = off)
    int maxWords;
    int *nWords, *wordPron, *wordStart, *wordEnd; float *wordScore, *wordLm, *wordAc; double *wordLike; double *total; float *finalLm;
+   unsigned long long *liveCnt;        // [nUtt][2] k_decode<NPT > 0>: register-resident model instances stepped with a live token / with none (htkamd_decoder_last_live)
    int *tieFlag;                       // [nUtt] k_decode: two tokens of exactly equal likelihood and different histories met at a node (see decode_ord.hip)
 };
 
@@ -101,6 +115,7 @@ struct htkamd_decoder {
    int lastTied;                       // utterances of the last run that went through the exact-order kernel
    hipEvent_t ev[4];                   // around the scoring kernels and around the token kernel of the last chunk of a run
    float lastScoreMs, lastTokenMs;
+   long long lastLive[2];              // model-instance steps of the last run's register kernel: with a live token, without
    void *wsN[48];                      // ... and of htkamd_decoder_run_lattice
    size_t wsNCap[48];
 };

@@ -38,25 +38,61 @@ __device__ __forceinline__ Tok null_tok() { Tok t; t.like = LZERO; t.lm = 0.0f; 
 // entry token of node n: best over predecessors (SetEntryState over StepInst2's sends), first maximum wins.
 // *tie is set when a second token of EXACTLY the winner's likelihood and another history (path or LM share) was met: which of the two
 // the reference keeps depends on the order of its instance list (decode_ord.hip decodes such utterances again, in that order).
-__device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k0, int k1, int kstep, float gT, float wT, int *argk, bool *tie)
+struct PullAcc { Tok best; int arg; bool tb; };
+__device__ __forceinline__ PullAcc pull_start() { PullAcc p; p.best = null_tok(); p.arg = 0x7fffffff; p.tb = false; return p; }
+// one predecessor: its exit token e, the link (ps: node | bit 31 for a word / null predecessor; lm), its position k in the list
+__device__ __forceinline__ void pull_fold(PullAcc &p, const DecArgs &a, const Tok e, const int ps, const float lm, const int k, const float gT, const float wT)
 {
-   Tok best = null_tok();
-   int arg = 0x7fffffff;
-   bool tb = false;
-   for (int k = k0; k < k1; k += kstep) {
-      const int ps = a.net.predSrc[k];
-      const float lm = a.net.predLike[k];
-      const Tok e = ex[ps & 0x7fffffff];
-      if (!(e.like > gT)) continue;
-      if (ps < 0 && e.like < wT) continue;                            // word-end beam on word/null tokens
-      const double c = e.like + lm * a.lmScale;
-      if (!(c > gT)) continue;
-      if (c > best.like) { best.like = c; best.lm = e.lm + lm; best.path = e.path; arg = k; tb = false; }
-      else if (c == best.like && (e.path != best.path || e.lm + lm != best.lm)) tb = true;
+   if (!(e.like > gT)) return;
+   if (ps < 0 && e.like < wT) return;                                  // word-end beam on word/null tokens
+   const double c = e.like + lm * a.lmScale;
+   if (!(c > gT)) return;
+   if (c > p.best.like) { p.best.like = c; p.best.lm = e.lm + lm; p.best.path = e.path; p.arg = k; p.tb = false; }
+   else if (c == p.best.like && (e.path != p.best.path || e.lm + lm != p.best.lm)) p.tb = true;
+}
+// The list is walked four predecessors at a time: their link words first, then their tokens, then the comparisons in list order.  One by
+// one, each token's load waited for its link's load and the next link for the comparison before it: two memory latencies per predecessor,
+// 68 % of k_decode's cycles on the 6 000-word bigram network (tools/dec_diag.py with -DDEC_CLK).
+// EXL: predecessors with a copy in LDS (DecNet::zl) are taken from there: wl the WORD nodes' likelihoods, nullL the null nodes' tokens, tNW = frame * nWordNodes
+template <bool EXL = false>
+__device__ __forceinline__ Tok pull_range(const DecArgs &a, const Tok *ex, int k0, int k1, int kstep, float gT, float wT, int *argk, bool *tie,
+                                          const double *wl = nullptr, const Tok *nullL = nullptr, const int tNW = 0)
+{
+   PullAcc p = pull_start();
+   for (int k = k0; k < k1; k += 4 * kstep) {
+      int2 r[4]; Tok e[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int kk = k + i * kstep; r[i] = (EXL ? a.net.predRecL : a.net.predRec)[kk < k1 ? kk : k0]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+         const int x = r[i].x;
+         if (EXL && (x & 0x40000000)) {
+            const int wi = x & 0x1fffffff;
+            const double l = wl[wi];
+            e[i].like = l; e[i].lm = 0.0f; e[i].path = (l > LSMALL) ? tNW + wi : -1;
+         } else if (EXL && (x & 0x20000000)) e[i] = nullL[x & 0x1fffffff];
+         else e[i] = ex[x & 0x1fffffff];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int kk = k + i * kstep; if (kk < k1) pull_fold(p, a, e[i], r[i].x, __int_as_float(r[i].y), kk, gT, wT); }
    }
-   *argk = arg;
-   if (tb) *tie = true;
-   return best;
+   *argk = p.arg;
+   if (p.tb) *tie = true;
+   return p.best;
+}
+
+// the two beam tops in one pass over the workgroup
+template <int NTHR>
+__device__ __forceinline__ void block_max2(double &v, double &w, double *red, double *red2)
+{
+#pragma unroll
+   for (int o = 32; o > 0; o >>= 1) { const double x = __shfl_xor(v, o), y = __shfl_xor(w, o); v = (x > v) ? x : v; w = (y > w) ? y : w; }
+   const int wv = threadIdx.x >> 6;
+   __syncthreads();
+   if ((threadIdx.x & 63) == 0) { red[wv] = v; red2[wv] = w; }
+   __syncthreads();
+   v = red[0]; w = red2[0];
+   for (int i = 1; i < NTHR / 64; i++) { v = (red[i] > v) ? red[i] : v; w = (red2[i] > w) ? red2[i] : w; }
 }
 
 template <int NTHR>
@@ -105,7 +141,7 @@ __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, co
             int slot;
             if constexpr (SLOTS) slot = (j == 2) ? sl2 : (j == 3) ? sl3 : sl4;      // (the register-resident models carry their score slots)
             else slot = N.stateSlot[N.hmmState[ni.w + (j - 2)]];
-            best.like += a.score[ud.score0 + (size_t)(t - 1) * a.ns + slot];
+            best.like += __builtin_nontemporal_load(a.score + ud.score0 + (size_t)(t - 1) * a.ns + slot);      // (a frame's column is read once)
             nw[j] = best;
             if (best.like > mx) mx = best.like;
          }
@@ -143,7 +179,8 @@ __device__ __forceinline__ Tok word_step2(const DecArgs &a, const DecUtt &ud, co
    e.like += a.wordPen;
    e.like += N.pronProb[n] * a.prScale;
    const size_t pid = (size_t)t * N.nWordNodes + N.wordIdx[n];
-   a.pathPrev[ud.path0 + pid] = st.path; a.pathLike[ud.path0 + pid] = e.like; a.pathLm[ud.path0 + pid] = e.lm;
+   __builtin_nontemporal_store(st.path, a.pathPrev + ud.path0 + pid); __builtin_nontemporal_store(e.like, a.pathLike + ud.path0 + pid);
+   __builtin_nontemporal_store(e.lm, a.pathLm + ud.path0 + pid);
    e.path = (int)pid; e.lm = 0.0f;
    return e;
 }
@@ -157,14 +194,15 @@ __device__ __forceinline__ Tok word_step2(const DecArgs &a, const DecUtt &ud, co
 // utterances, 563 MB of live state against 256 MB of Infinity Cache; what is left in memory here: exit tokens of the word nodes, instance
 // maxima, Path records, the score column.
 #define DEC_MAXR 5                 /* states of a register-resident model incl. entry / exit */
-template <int NPT, int NTHR, bool HASG>       // HASG: model nodes outside the registers exist (tee models, more than three emitting states, overflow)
+template <int NPT, int NTHR, bool HASG, bool EXL = false>       // HASG: model nodes outside the registers exist (tee models, more than three emitting states, overflow); EXL: see DecNet::zl
 __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
 {
    __shared__ double red[NTHR / 64];
    __shared__ double red2[NTHR / 64];
    __shared__ int redk[NTHR / 64];
    __shared__ float thr[2];
-   __shared__ float ltp[DEC_LDS_TP];
+   __shared__ float ltpS[EXL ? 1 : DEC_LDS_TP];    // (EXL: the matrices behind the dynamic block, as many floats as there are)
+   __shared__ Tok nullL[EXL ? DEC_NULL_LDS : 1];
    __shared__ int uhist[256];
    __shared__ unsigned int usel[4];            // -u: [0] attached instances, [1] key prefix, [2] rank still to skip, [3] scratch
    const int u = blockIdx.x, tid = threadIdx.x;
@@ -174,17 +212,41 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
    const int T = ud.T;
    Tok *tok = a.tok + ud.tok0, *ex = a.ex + ud.node0;
    double *imax = a.imax + ud.node0;
-   const bool tpInLds = N.nTpFloats <= DEC_LDS_TP;
+   extern __shared__ Tok xs[];
+   // dynamic LDS: xs [NPT NTHR] tokens | EXL: wl [nWordNodes] doubles, ltp [nTpFloats] floats | else: rmaxL [NPT NTHR] floats
+   double *wl = (double *)(xs + (size_t)(NPT > 0 ? NPT : 0) * NTHR);
+   float *ltp = EXL ? (float *)(wl + N.nWordNodes) : ltpS;
+   const bool tpInLds = EXL || N.nTpFloats <= DEC_LDS_TP;     // (EXL is launched only when they fit)
    if (tpInLds) for (int i = tid; i < N.nTpFloats; i += NTHR) ltp[i] = N.transP[i];
+   if constexpr (EXL) {
+      for (int i = tid; i < N.nWordNodes; i += NTHR) wl[i] = LZERO;
+      for (int i = tid; i < DEC_NULL_LDS; i += NTHR) nullL[i] = null_tok();
+   }
+   // the LDS copy of a zero-time node's exit token (every store to ex[] of such a node comes through here)
+   // (a node with a slot is read from LDS by every pull of this kernel: its token stays out of memory -- 96 KB per utterance and frame on
+   // the 6 000-word network, which with the Path records pushed the network's tables out of the L2 every frame)
+   auto put_ex = [&](const int n, const Tok e, const int zl) {
+      if constexpr (EXL) {
+         if (zl >= 0) { if (zl & 0x40000000) wl[zl & 0x3fffffff] = e.like; else nullL[zl] = e; return; }
+      }
+      ex[n] = e;
+   };
    const float *tpBase = tpInLds ? ltp : N.transP;
    bool tie = false;                           // this thread met two equally likely tokens with different histories (pull_range)
+   unsigned int nLive = 0, nDead = 0;          // this thread's register-resident model steps with / without a live token
+#ifdef DEC_CLK                                 // cycle stamps of thread 0 at the phase boundaries (tools/dec_diag.py): prune | models | beam tops | fused words | levels | entries
+   unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, c0 = 0;
+#define DEC_STAMP(i_) do { const unsigned long long c_ = __builtin_readcyclecounter(); clk[i_] += c_ - c0; c0 = c_; } while (0)
+#else
+#define DEC_STAMP(i_) do { } while (0)
+#endif
    const int nReg = (NPT > 0) ? N.nReg : 0;    // model nodes hmmNodes[0 .. nReg) live in registers
    // this thread's register-resident models: rs[k][0 ..] = the tokens of states 2 .. ; the entry token (the exit token between the
    // passes) of its k-th model waits in LDS, xs[k NTHR + tid] (registers for it too made the compiler spill at 12 models per thread)
-   extern __shared__ Tok xs[];
    Tok rs[NPT > 0 ? NPT : 1][DEC_MAXR - 2];
    float *rmaxL = (float *)(xs + (size_t)(NPT > 0 ? NPT : 0) * NTHR);      // NetInst.max of the register-resident models (a LogFloat), [k NTHR + tid], behind xs
-#define rmax(k_) rmaxL[(k_) * NTHR + tid]
+   float rmaxR[(EXL && NPT > 0) ? NPT : 1];                                // ... in registers where LDS holds the word ends instead
+#define rmax(k_) (*(EXL ? &rmaxR[k_] : &rmaxL[(k_) * NTHR + tid]))
    if constexpr (NPT > 0) {
 #pragma unroll
       for (int k = 0; k < NPT; k++) {
@@ -200,6 +262,9 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
    if (tid == 0) { thr[0] = (float)LSMALL; thr[1] = (float)LSMALL; }
    __syncthreads();
 
+#ifdef DEC_CLK
+   c0 = __builtin_readcyclecounter();
+#endif
    for (int t = 0; t <= T; t++) {
       if (t >= 1 && a.maxActive > 0) {
          // ---- maximum-model pruning (ProcessObservation HRec.c:1966-1985): when more than maxActive instances are attached, those
@@ -261,7 +326,7 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                for (int n = tid; n < N.nNodes; n += NTHR) {
                   const double v = imax[n];
                   if (!(v >= gTp && v > LSMALL) || !(v < (double)uth)) continue;
-                  imax[n] = LZERO; ex[n] = null_tok();                 // DetachInst: every token of the instance goes, the entry token too
+                  imax[n] = LZERO; put_ex(n, null_tok(), EXL ? N.zl[n] : -1);      // DetachInst: every token of the instance goes, the entry token too
                   const int4 ni = N.nodeInfo[n];
                   const int nt = ((ni.x & 15) == HTKAMD_NODE_HMM) ? ((ni.x >> 4) & 255) - 1 : 1;
                   for (int i = 0; i < nt; i++) tok[ni.y + i] = null_tok();
@@ -270,6 +335,7 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
             __syncthreads();
          }
       }
+      DEC_STAMP(0);
       if (t >= 1) {
          const float gT = thr[0];                         // threshold of the previous frame
          double myGen = LZERO, myWord = LZERO;
@@ -299,7 +365,9 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                   if (live) {
                      hmm_step1<DEC_MAXR, true>(a, ud, ni, tpBase + ni.z, s, gT, t, N.regRecF[hk].x, exT, mx, myWord, rb.x, rb.y, rb.z);
                      if (mx > myGen) myGen = mx;
+                     nLive++;
                   } else {
+                     nDead++;
 #pragma unroll
                      for (int i = 1; i < DEC_MAXR; i++) s[i] = null_tok();
                   }
@@ -342,8 +410,9 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
             }
             ex[n] = exT; imax[n] = (double)(float)mx;         // inst->max is a LogFloat (HRec.c:138)
          }
-         const double genMax = block_max<NTHR>(myGen, red);
-         const double wordMax = block_max<NTHR>(myWord, red2);
+         DEC_STAMP(1);
+         double genMax = myGen, wordMax = myWord;
+         block_max2<NTHR>(genMax, wordMax, red, red2);
          if (tid == 0) {
             float w = (float)(wordMax - a.wordBeam); if (w < (float)LSMALL) w = (float)LSMALL;
             float g = (float)(genMax - a.genBeam); if (g < (float)LSMALL) g = (float)LSMALL;
@@ -351,6 +420,7 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
          }
          __syncthreads();
       }
+      DEC_STAMP(2);
       // ---- zero-time nodes, level by level (at t = 0: StartRecognition's propagation of the initial token)
       const float gT = thr[0], wT = thr[1];
       if constexpr (NPT > 0) {
@@ -360,7 +430,8 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
             for (int k = 0; k < NPT; k++) {
                const int hk = tid + k * NTHR;
                if (hk < nReg) {
-                  const int n = N.regRecA[hk].w;
+                  const int4 fr = N.regFusedRec[hk];      // {fused node, its LDS slot (DecNet::zl), bits of its pronunciation probability, its column in the Path table or -1: a null node}
+                  const int n = fr.x;
                   if (n >= 0) {
                      const Tok e0 = xs[k * NTHR + tid];
                      const float lm = N.regRecF[hk].y;
@@ -370,15 +441,27 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                         if (c > gT) { st.like = c; st.lm = e0.lm + lm; st.path = e0.path; }
                      }
                      Tok e = null_tok();
-                     if (st.like > LSMALL) e = (N.kind[n] == HTKAMD_NODE_WORD) ? word_step2(a, ud, n, t, st) : st;
+                     if (st.like > LSMALL) {
+                        e = st;
+                        if (fr.w >= 0) {                      // StepWord2 (word_step2 with the node's constants from the record)
+                           e.like += a.wordPen;
+                           e.like += __int_as_float(fr.z) * a.prScale;
+                           const size_t pid = (size_t)t * N.nWordNodes + fr.w;
+                           // (written once, read by the final walk only: past the L2's retention)
+                           __builtin_nontemporal_store(st.path, a.pathPrev + ud.path0 + pid); __builtin_nontemporal_store(e.like, a.pathLike + ud.path0 + pid);
+                           __builtin_nontemporal_store(e.lm, a.pathLm + ud.path0 + pid);
+                           e.path = (int)pid; e.lm = 0.0f;
+                        }
+                     }
                      if (a.maxActive > 0) imax[n] = (st.like > LSMALL) ? (double)(float)st.like : LZERO;      // (a word / null node's max is read by -u only)
-                     ex[n] = e;
+                     put_ex(n, e, EXL ? fr.y : -1);
                   }
                }
                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
          }
       }
+      DEC_STAMP(3);
       for (int L = 0; L < N.nLevels; L++) {
          const int l0 = N.levelOff[L], lw = N.levelWide[L], l1 = N.levelOff[L + 1];
          for (int k = l0 + tid; k < lw; k += NTHR) {
@@ -386,7 +469,7 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
             const int4 ni = N.nodeInfo[n];
             const int kind = ni.x & 15;
             int ak;
-            Tok st = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie);
+            Tok st = pull_range<EXL>(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie, wl, nullL, t * N.nWordNodes);
             if (t == 0 && n == N.initial) { st.like = 0.0; st.lm = 0.0f; st.path = -1; }
             Tok e = null_tok();
             if (kind == HTKAMD_NODE_HMM) {                 // tee model: StepHMM2
@@ -407,12 +490,12 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                imax[n] = (double)(float)st.like;
                e = (kind == HTKAMD_NODE_WORD) ? word_step2(a, ud, n, t, st) : st;
             }
-            ex[n] = e;
+            put_ex(n, e, (EXL && kind != HTKAMD_NODE_HMM) ? N.zl[n] : -1);
          }
          for (int k = lw; k < l1; k++) {                  // wide fan-in: the whole workgroup reduces one node
             const int n = N.levelNodes[k];
             int ak;
-            Tok st = pull_range(a, ex, N.predOff[n] + tid, N.predOff[n + 1], NTHR, gT, wT, &ak, &tie);
+            Tok st = pull_range<EXL>(a, ex, N.predOff[n] + tid, N.predOff[n + 1], NTHR, gT, wT, &ak, &tie, wl, nullL, t * N.nWordNodes);
             // argmax over the workgroup: larger like, then smaller predecessor position
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -436,28 +519,77 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                Tok e = null_tok();
                imax[n] = (b.like > LSMALL) ? (double)(float)b.like : LZERO;
                if (b.like > LSMALL) e = (N.kind[n] == HTKAMD_NODE_WORD) ? word_step2(a, ud, n, t, b) : b;
-               ex[n] = e;
+               put_ex(n, e, EXL ? N.zl[n] : -1);
             }
          }
          __syncthreads();
       }
+      DEC_STAMP(4);
       // ---- entry tokens of the emitting models for the next frame (SetEntryState from this frame's exits)
       if (t < T) {
          if constexpr (NPT > 0) {
+            // four models in step, two predecessors of each per round: eight link words, then eight tokens in flight (see pull_range)
+            constexpr int GM = (NPT % 4 == 0) ? 4 : 2;
 #pragma unroll
-            for (int k = 0; k < NPT; k++) {
-               const int hk = tid + k * NTHR;
-               if (hk < nReg) {
-                  const int n = N.regRecA[hk].x;
-                  int ak;
-                  const Tok en = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie);
-                  xs[k * NTHR + tid] = en;
-                  if (en.like > (double)rmax(k)) {
-                     rmax(k) = (float)en.like;
-                     if (a.maxActive > 0) imax[n] = (double)(float)en.like;
+            for (int k4 = 0; k4 < NPT; k4 += GM) {
+               int2 pr[GM]; PullAcc pa[GM];
+               int nmax = 0;
+#pragma unroll
+               for (int j = 0; j < GM; j++) {
+                  const int hk = tid + (k4 + j) * NTHR;
+                  pr[j] = (hk < nReg) ? N.regPred[hk] : make_int2(0, 0);
+                  pa[j] = pull_start();
+                  nmax = (pr[j].y - pr[j].x > nmax) ? pr[j].y - pr[j].x : nmax;
+               }
+               for (int i = 0; i < nmax; i += 2) {
+                  int2 r[GM][2];
+#pragma unroll
+                  for (int j = 0; j < GM; j++)
+#pragma unroll
+                     for (int ii = 0; ii < 2; ii++) { const int kk = pr[j].x + i + ii; r[j][ii] = (EXL ? N.predRecRegL : N.predRecReg)[kk < pr[j].y ? kk : 0]; }
+                  if constexpr (EXL) {
+                     // the tokens come from LDS: taken and compared one by one (eight of them held at once spilled registers)
+#pragma unroll
+                     for (int j = 0; j < GM; j++)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ii++) {
+                           const int kk = pr[j].x + i + ii, x = r[j][ii].x;
+                           if (kk >= pr[j].y) continue;
+                           Tok e;
+                           if (x & 0x40000000) {              // a WORD node: its likelihood from LDS, the rest of its token follows from the frame
+                              const int wi = x & 0x1fffffff;
+                              const double l = wl[wi];
+                              e.like = l; e.lm = 0.0f; e.path = (l > LSMALL) ? t * N.nWordNodes + wi : -1;
+                           } else if (x & 0x20000000) e = nullL[x & 0x1fffffff];
+                           else e = ex[x & 0x1fffffff];
+                           pull_fold(pa[j], a, e, x, __int_as_float(r[j][ii].y), kk, gT, wT);
+                        }
+                  } else {
+                     Tok e[GM][2];
+#pragma unroll
+                     for (int j = 0; j < GM; j++)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ii++) e[j][ii] = ex[r[j][ii].x & 0x1fffffff];
+#pragma unroll
+                     for (int j = 0; j < GM; j++)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ii++) { const int kk = pr[j].x + i + ii; if (kk < pr[j].y) pull_fold(pa[j], a, e[j][ii], r[j][ii].x, __int_as_float(r[j][ii].y), kk, gT, wT); }
                   }
                }
-               if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+               for (int j = 0; j < GM; j++) {
+                  const int k = k4 + j, hk = tid + k * NTHR;
+                  if (hk < nReg) {
+                     if (pa[j].tb) tie = true;
+                     const Tok en = pa[j].best;
+                     xs[k * NTHR + tid] = en;
+                     if (en.like > (double)rmax(k)) {
+                        rmax(k) = (float)en.like;
+                        if (a.maxActive > 0) imax[N.regRecA[hk].x] = (double)(float)en.like;
+                     }
+                  }
+               }
+               __builtin_amdgcn_sched_barrier(0);
             }
          }
          if constexpr (HASG)
@@ -466,18 +598,35 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
             const int4 ni = N.nodeInfo[n];
             if ((ni.x >> 12) & 1) continue;                // tee models got theirs in the level phase
             int ak;
-            const Tok en = pull_range(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie);
+            const Tok en = pull_range<EXL>(a, ex, N.predOff[n], N.predOff[n + 1], 1, gT, wT, &ak, &tie, wl, nullL, t * N.nWordNodes);
             tok[ni.y] = en;
             if (en.like > imax[n]) imax[n] = (double)(float)en.like;      // SetEntryState: the entering token raises the instance's max
          }
          __syncthreads();
       }
+      DEC_STAMP(5);
    }
 
+#ifdef DEC_CLK
+   if (tid == 0 && a.liveCnt) for (int i = 0; i < 6; i++) atomicAdd(a.liveCnt + 2 * a.nUtt + i, clk[i]);
+#endif
    if (tie) a.tieFlag[u] = 1;                  // (zeroed by the host before the launch)
+   if (NPT > 0 && a.liveCnt) {
+      unsigned long long l = nLive, dd = nDead;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); dd += __shfl_xor(dd, o); }
+      if ((tid & 63) == 0) { atomicAdd(a.liveCnt + 2 * u, l); atomicAdd(a.liveCnt + 2 * u + 1, dd); }
+   }
    // ---- CompleteRecognition + LatFromPaths + TranscriptionFromLattice for the 1-best chain
    if (tid == 0) {
-      const Tok fin = ex[N.final];
+      Tok fin = ex[N.final];
+      if constexpr (EXL) {
+         const int zf = N.zl[N.final];
+         if (zf >= 0) {
+            if (zf & 0x40000000) { const double l = wl[zf & 0x3fffffff]; fin.like = l; fin.lm = 0.0f; fin.path = (l > LSMALL) ? T * N.nWordNodes + (zf & 0x3fffffff) : -1; }
+            else fin = nullL[zf];
+         }
+      }
       const int fp = fin.path;
       int nW = 0;
       a.total[u] = LZERO; a.finalLm[u] = 0.0f;
@@ -565,6 +714,13 @@ extern "C" int htkamd_decoder_last_times(const htkamd_decoder *d, double *scoreM
    if (!d) { htkamd_set_error("decoder_last_times: NULL"); return HTKAMD_EINVAL; }
    if (scoreMs) *scoreMs = d->lastScoreMs;
    if (tokenMs) *tokenMs = d->lastTokenMs;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_decoder_last_live(const htkamd_decoder *d, long long out[2])
+{
+   if (!d || !out) { htkamd_set_error("decoder_last_live: NULL"); return HTKAMD_EINVAL; }
+   out[0] = d->lastLive[0]; out[1] = d->lastLive[1];
    return HTKAMD_OK;
 }
 
@@ -689,6 +845,10 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       std::vector<int> reg, rest;
       for (int n : hmmNodes) ((!tee[n] && nodeN[n] <= 5 && (int)reg.size() < DEC_REG_MAXNPT * DEC_REG_THREADS) ? reg : rest).push_back(n);
       nReg = (int)reg.size();
+      // most predecessors first: the entry pulls of a wavefront run until its longest list is done (two predecessors a round), so lists of one
+      // length belong together -- thread t's k-th model is reg[t + k NTHR], the 1 024 longest lists are everybody's first model, and so on
+      // (6 000-word bigram network: 20 rounds a frame in storage order, 11 sorted)
+      std::stable_sort(reg.begin(), reg.end(), [&](int x, int y) { return predOff[x + 1] - predOff[x] > predOff[y + 1] - predOff[y]; });
       hmmNodes = reg; hmmNodes.insert(hmmNodes.end(), rest.begin(), rest.end());
       std::vector<int> slotOf(nN, -1);
       for (int k = 0; k < nReg; k++) slotOf[reg[k]] = k;
@@ -717,6 +877,8 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       }
    }
    levelOff[nLevels] = (int)levelNodes.size();
+   if (getenv("HTKAMD_DECODE_VERBOSE"))
+      for (int L = 0; L < nLevels; L++) fprintf(stderr, "decoder_create: level %d: %d narrow + %d wide zero-time nodes (register models %d, fused nodes %d)\n", L, levelWide[L] - levelOff[L], levelOff[L + 1] - levelWide[L], nReg, (int)std::count(isFused.begin(), isFused.end(), 1));
    // ... and the same lists with every zero-time node in them, for the kernels that keep no tokens in registers (k_decode_n)
    std::vector<int> levelOffA(nLevels + 1, 0), levelWideA(nLevels, 0), levelNodesA;
    for (int L = 0; L < nLevels; L++) {
@@ -745,6 +907,41 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
    memset(&N, 0, sizeof(N));
    int rc0 = HTKAMD_OK;
    N.nReg = nReg;
+   std::vector<int2> regPred(nReg), predRec(predSrc.size() ? predSrc.size() : 1, make_int2(0, 0));
+   for (size_t k = 0; k < predSrc.size(); k++) { int b; memcpy(&b, &predLike[k], 4); predRec[k] = make_int2(predSrc[k], b); }
+   // LDS slots of the zero-time nodes the register-resident models pull from (k_decode<.., EXL>)
+   std::vector<int> zl(nN, -1), regFusedZl(nReg > 0 ? nReg : 1, -1);
+   std::vector<int2> predRecL(predRec);
+   int nNullLds = 0;
+   for (int k = 0; k < nReg; k++)
+      for (int q = predOff[hmmNodes[k]]; q < predOff[hmmNodes[k] + 1]; q++) {
+         const int src = predSrc[q] & 0x7fffffff;
+         if (kind[src] == HTKAMD_NODE_WORD) zl[src] = 0x40000000 | wordIdx[src];
+         else if (kind[src] != HTKAMD_NODE_HMM && zl[src] < 0 && nNullLds < DEC_NULL_LDS) zl[src] = nNullLds++;
+      }
+   for (size_t q = 0; q < predSrc.size(); q++) {
+      const int src = predSrc[q] & 0x7fffffff;
+      if (zl[src] >= 0) predRecL[q].x = (int)0x80000000 | ((zl[src] & 0x40000000) ? zl[src] : (0x20000000 | zl[src]));
+   }
+   // the register-resident models' lists once more, in the models' order (neighbouring lanes read neighbouring records), both forms: regPred indexes these
+   std::vector<int2> predRecReg, predRecRegL;
+   for (int k = 0; k < nReg; k++) {
+      const int n = hmmNodes[k];
+      regPred[k] = make_int2((int)predRecReg.size(), (int)predRecReg.size() + predOff[n + 1] - predOff[n]);
+      for (int q = predOff[n]; q < predOff[n + 1]; q++) { predRecReg.push_back(predRec[q]); predRecRegL.push_back(predRecL[q]); }
+   }
+   if (predRecReg.empty()) { predRecReg.push_back(make_int2(0, 0)); predRecRegL.push_back(make_int2(0, 0)); }
+   std::vector<int4> regFusedRec(nReg > 0 ? nReg : 1, make_int4(-1, -1, 0, -1));
+   for (int k = 0; k < nReg; k++)
+      if (regFused[k] >= 0) {
+         const int w = regFused[k];
+         int pb; memcpy(&pb, &pron[w], 4);
+         regFusedZl[k] = zl[w];
+         regFusedRec[k] = make_int4(w, zl[w], pb, kind[w] == HTKAMD_NODE_WORD ? wordIdx[w] : -1);
+      }
+   N.nNullLds = nNullLds;
+   if ((rc0 = upv(d, predRec, &N.predRec)) || (rc0 = upv(d, predRecL, &N.predRecL)) || (rc0 = upv(d, zl, &N.zl)) || (rc0 = upv(d, regFusedZl, &N.regFusedZl)) || (rc0 = upv(d, regFusedRec, &N.regFusedRec)) || (rc0 = upv(d, predRecReg, &N.predRecReg)) || (rc0 = upv(d, predRecRegL, &N.predRecRegL)) ||
+       (nReg > 0 && (rc0 = upv(d, regPred, &N.regPred)))) { htkamd_decoder_destroy(d); return rc0; }
    if (nReg > 0 && ((rc0 = upv(d, regFused, &N.regFused)) || (rc0 = upv(d, regFusedLike, &N.regFusedLike)) || (rc0 = upv(d, regNoEx, &N.regNoEx)) || (rc0 = upv(d, regRecA, &N.regRecA)) || (rc0 = upv(d, regRecB, &N.regRecB)) || (rc0 = upv(d, regRecF, &N.regRecF)))) { htkamd_decoder_destroy(d); return rc0; }
    N.nNodes = nN; N.nHmm = (int)hmmNodes.size(); N.nLevels = nLevels; N.nWordNodes = nW > 0 ? nW : 1; N.initial = nd->initial; N.final = nd->final; N.nTok = nTok; N.nTpFloats = m->h_transOff[m->nT];
    int rc;
@@ -812,6 +1009,7 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
    const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
    if (!d->ev[0]) for (int i = 0; i < 4; i++) HIPCHECK(hipEventCreate(&d->ev[i]));
    d->lastScoreMs = d->lastTokenMs = 0.0f;
+   d->lastLive[0] = d->lastLive[1] = 0;
    int orderMode = d->orderMode;
    if (const char *ev = getenv("HTKAMD_DECODE_ORDER")) orderMode = !strcmp(ev, "fast") ? HTKAMD_ORDER_FAST : !strcmp(ev, "exact") ? HTKAMD_ORDER_EXACT : HTKAMD_ORDER_AUTO;
    d->lastTied = 0;
@@ -867,7 +1065,8 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
       A(&dOutI, sizeof(int) * ((size_t)nu * maxWords * 3 + nu)); A(&dOutF, sizeof(float) * ((size_t)nu * maxWords * 3 + nu)); A(&dTot, sizeof(double) * nu);
       A(&dOutD, sizeof(double) * (size_t)nu * maxWords);
       void *dTie = nullptr;
-      A(&dTie, sizeof(int) * nu);
+      const size_t tieBytes = (sizeof(int) * nu + 7) & ~(size_t)7;
+      A(&dTie, tieBytes + sizeof(unsigned long long) * (2 * (size_t)nu + 8));
       std::vector<int> hI; std::vector<float> hF; std::vector<double> hT, hD;
       if (!rc) {
          hipError_t e;
@@ -909,19 +1108,24 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
          a.wordScore = (float *)dOutF; a.wordLm = (float *)dOutF + (size_t)nu * maxWords; a.wordAc = (float *)dOutF + (size_t)nu * maxWords * 2; a.finalLm = (float *)dOutF + (size_t)nu * maxWords * 3; a.total = (double *)dTot;
          a.wordLike = (double *)dOutD;
          a.tieFlag = (int *)dTie;
-         (void)hipMemsetAsync(dTie, 0, sizeof(int) * nu, s);
+         a.liveCnt = (unsigned long long *)((char *)dTie + tieBytes);
+         (void)hipMemsetAsync(dTie, 0, tieBytes + sizeof(unsigned long long) * (2 * (size_t)nu + 8), s);
          // tokens of the plain models in registers where the network has such models (DecNet::nReg), NPT of them per thread
          const int npt = (N.nReg + DEC_REG_THREADS - 1) / DEC_REG_THREADS;
-#define DEC_LAUNCH_REG(NPT_) do { const size_t lds_ = (sizeof(Tok) + sizeof(float)) * (size_t)(NPT_) * DEC_REG_THREADS; \
-            if (hasG) { (void)hipFuncSetAttribute((const void *)k_decode<NPT_, DEC_REG_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
-                        hipLaunchKernelGGL((k_decode<NPT_, DEC_REG_THREADS, true>), dim3(nu), dim3(DEC_REG_THREADS), lds_, s, a); } \
-            else { (void)hipFuncSetAttribute((const void *)k_decode<NPT_, DEC_REG_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
-                   hipLaunchKernelGGL((k_decode<NPT_, DEC_REG_THREADS, false>), dim3(nu), dim3(DEC_REG_THREADS), lds_, s, a); } } while (0)
          const bool hasG = N.nReg < N.nHmm;
+         // ... and the exit tokens they pull in LDS where xs, the word ends' likelihoods and the transition matrices fit beside the static 3 KB
+#define DEC_LAUNCH_REG(NPT_) do { \
+            const size_t ldsX_ = sizeof(Tok) * (size_t)(NPT_) * DEC_REG_THREADS + sizeof(double) * (size_t)N.nWordNodes + sizeof(float) * (size_t)N.nTpFloats; \
+            const bool exl_ = ldsX_ + 3072 <= 160 * 1024 && !getenv("HTKAMD_DECODE_NOEXL"); \
+            const size_t lds_ = exl_ ? ldsX_ : (sizeof(Tok) + sizeof(float)) * (size_t)(NPT_) * DEC_REG_THREADS; \
+            const void *fn_ = exl_ ? (hasG ? (const void *)k_decode<NPT_, DEC_REG_THREADS, true, true> : (const void *)k_decode<NPT_, DEC_REG_THREADS, false, true>) \
+                                   : (hasG ? (const void *)k_decode<NPT_, DEC_REG_THREADS, true, false> : (const void *)k_decode<NPT_, DEC_REG_THREADS, false, false>); \
+            (void)hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+            void *args_[] = {(void *)&a}; \
+            (void)hipLaunchKernel(fn_, dim3(nu), dim3(DEC_REG_THREADS), args_, lds_, s); } while (0)
          if (npt == 0) hipLaunchKernelGGL((k_decode<0, DEC_THREADS, true>), dim3(nu), dim3(DEC_THREADS), 0, s, a);
          else if (npt <= 2) DEC_LAUNCH_REG(2);
          else if (npt <= 4) DEC_LAUNCH_REG(4);
-         else if (npt <= 8) DEC_LAUNCH_REG(8);
          else DEC_LAUNCH_REG(DEC_REG_MAXNPT);
 #undef DEC_LAUNCH_REG
          hipError_t e = hipGetLastError();
@@ -971,6 +1175,8 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
             d->lastTied += nSel;
          }
       }
+      std::vector<unsigned long long> hLive(2 * (size_t)nu + 8, 0);
+      if (!rc) (void)hipMemcpyAsync(hLive.data(), (char *)dTie + tieBytes, sizeof(unsigned long long) * hLive.size(), hipMemcpyDeviceToHost, s);
       if (!rc) {
          hI.resize((size_t)nu * maxWords * 3 + nu); hF.resize((size_t)nu * maxWords * 3 + nu); hT.resize(nu); hD.resize((size_t)nu * maxWords);
          hipError_t e;
@@ -984,6 +1190,11 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
       { float ms = 0.0f;
         if (hipEventElapsedTime(&ms, d->ev[0], d->ev[1]) == hipSuccess) d->lastScoreMs += ms;
         if (hipEventElapsedTime(&ms, d->ev[2], d->ev[3]) == hipSuccess) d->lastTokenMs += ms; }
+      for (int k = 0; k < nu; k++) { d->lastLive[0] += (long long)hLive[2 * k]; d->lastLive[1] += (long long)hLive[2 * k + 1]; }
+#ifdef DEC_CLK
+      fprintf(stderr, "k_decode phase cycles (sum over %d utterances): prune %llu | models %llu | beam tops %llu | fused words %llu | levels %llu | entries %llu\n", nu,
+              hLive[2 * (size_t)nu], hLive[2 * (size_t)nu + 1], hLive[2 * (size_t)nu + 2], hLive[2 * (size_t)nu + 3], hLive[2 * (size_t)nu + 4], hLive[2 * (size_t)nu + 5]);
+#endif
       for (int k = 0; k < nu; k++) {
          nWords[u0 + k] = hI[k]; total[u0 + k] = hT[k];
          if (finalLm) finalLm[u0 + k] = hF[(size_t)nu * maxWords * 3 + k];

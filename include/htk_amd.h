@@ -719,6 +719,10 @@ int  htkamd_decoder_set_order(htkamd_decoder *d, int mode);
 int  htkamd_decoder_last_tied(const htkamd_decoder *d);
 /* Device time of the last htkamd_decoder_run: the scoring kernels (K1 + the score block's transposition) and the token kernel(s), milliseconds. */
 int  htkamd_decoder_last_times(const htkamd_decoder *d, double *scoreMs, double *tokenMs);
+/* Model-instance steps of the last htkamd_decoder_run's token kernel (the register-resident models of the network): out[0] with a live
+ * token (StepHMM1 ran: HRec.c:642), out[1] with none (the instance would not be in HRec's list: DetachInst HRec.c:1330).  out[0] 3 states
+ * is what demand-driven scoring (HRec.c:438-551) would evaluate against the dense block's tied states x frames. */
+int  htkamd_decoder_last_live(const htkamd_decoder *d, long long out[2]);
 int  htkamd_decoder_run(htkamd_decoder *d, const htkamd_decode_config *cfg, const float *dX, const int *frameOff, int nUtt,
                         int maxWords, int *nWords, int *wordPron, int *wordStart, int *wordEnd, float *wordScore, float *wordLm,
                         double *total, void *stream);
