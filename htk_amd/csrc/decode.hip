@@ -115,7 +115,7 @@ __device__ __forceinline__ double block_max(double v, double *red)
 // return (s[1] null: the entry is consumed); exT = the exit token, mx = the instance's maximum, wordTop raised by exit + LikeToWord.
 template <int MX, bool SLOTS = false>
 __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, const int4 ni, const float *tp, Tok (&s)[MX], const float gT, const int t,
-                                          const float wdlk, Tok &exT, double &mx, double &wordTop, const int sl2 = 0, const int sl3 = 0, const int sl4 = 0)
+                                          const float wdlk, Tok &exT, double &mx, double &wordTop, const int sl2 = 0, const int sl3 = 0, const int sl4 = 0, const int se = 0)
 {
    const DecNet &N = a.net;
    const int NS = (ni.x >> 4) & 255;
@@ -126,9 +126,12 @@ __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, co
       if (j < NS) {
          // CreateSEIndex (HRec.c:1403): predecessor range with a transition, first maximum wins
          int lo = 1, hi = NS - 1;
-         while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
-         while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
-         if (lo > hi) { lo = 1; hi = NS - 1; }
+         if constexpr (SLOTS) { lo = (se >> (6 * (j - 2))) & 7; hi = (se >> (6 * (j - 2) + 3)) & 7; }      // (the ranges of the register-resident models come with their records)
+         else {
+            while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
+            while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
+            if (lo > hi) { lo = 1; hi = NS - 1; }
+         }
          Tok best = s[1]; double bl = LZERO;
 #pragma unroll
          for (int i = 1; i < MX; i++)
@@ -149,9 +152,12 @@ __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, co
    }
    {
       int lo = 2, hi = NS - 1;
-      while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
-      while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
-      if (lo > hi) { lo = 2; hi = NS - 1; }
+      if constexpr (SLOTS) { lo = (se >> 18) & 7; hi = (se >> 21) & 7; }
+      else {
+         while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
+         while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
+         if (lo > hi) { lo = 2; hi = NS - 1; }
+      }
       Tok best = nw[2]; double bl = LZERO;
 #pragma unroll
       for (int i = 2; i < MX; i++)
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                   Tok exT = null_tok();
                   double mx = LZERO;
                   if (live) {
-                     hmm_step1<DEC_MAXR, true>(a, ud, ni, tpBase + ni.z, s, gT, t, N.regRecF[hk].x, exT, mx, myWord, rb.x, rb.y, rb.z);
+                     hmm_step1<DEC_MAXR, true>(a, ud, ni, tpBase + ni.z, s, gT, t, N.regRecF[hk].x, exT, mx, myWord, rb.x, rb.y, rb.z, rb.w >> 1);
                      if (mx > myGen) myGen = mx;
                      nLive++;
                   } else {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
                   for (int i = 2; i < DEC_MAXR; i++) rs[k][i - 2] = s[i];
                   xs[k * NTHR + tid] = exT;                // the exit token, until pass 2 has used it
                   if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four models at a time: all twelve interleaved, their temporaries spill)
-                  if (!rb.w) ex[n] = exT;                  // (somebody pulls it from memory)
+                  if (!(rb.w & 1)) ex[n] = exT;            // (somebody pulls it from memory)
                   rmax(k) = (float)mx;                     // inst->max is a LogFloat (HRec.c:138); in memory only where -u wants to see it
                   if (a.maxActive > 0) imax[n] = (double)(float)mx;
                }
@@ -898,7 +904,27 @@ extern "C" int htkamd_decoder_create(htkamd_model *m, const htkamd_net_desc *nd,
       int sl[3] = {0, 0, 0};
       for (int j = 0; j < nodeN[n] - 2 && j < 3; j++) sl[j] = stateSlot[m->h_hmmState[m->h_hmmStateOff[h] + j * m->NSt]];
       regRecA[k] = make_int4(n, kind[n] | (nodeN[n] << 4), nodeTp[n], regFused[k]);
-      regRecB[k] = make_int4(sl[0], sl[1], sl[2], (int)regNoEx[k]);
+      // CreateSEIndex's ranges of the model's states 2 .. 4 and of its exit state, (lo, hi) in three bits each (hmm_step1<.., SLOTS>)
+      int se = 0;
+      {
+         const int NS = nodeN[n];
+         const float *tp = m->h_transP + nodeTp[n];
+         for (int j = 2; j <= 4; j++) {
+            int lo = 1, hi = NS - 1;
+            if (j < NS) {
+               while (lo < NS && !(tp[(lo - 1) * NS + (j - 1)] > LSMALL)) lo++;
+               while (hi > 1 && !(tp[(hi - 1) * NS + (j - 1)] > LSMALL)) hi--;
+               if (lo > hi) { lo = 1; hi = NS - 1; }
+            }
+            se |= (lo & 7) << (6 * (j - 2)) | (hi & 7) << (6 * (j - 2) + 3);
+         }
+         int lo = 2, hi = NS - 1;
+         while (lo < NS && !(tp[(lo - 1) * NS + (NS - 1)] > LSMALL)) lo++;
+         while (hi > 1 && !(tp[(hi - 1) * NS + (NS - 1)] > LSMALL)) hi--;
+         if (lo > hi) { lo = 2; hi = NS - 1; }
+         se |= (lo & 7) << 18 | (hi & 7) << 21;
+      }
+      regRecB[k] = make_int4(sl[0], sl[1], sl[2], (int)regNoEx[k] | (se << 1));
       regRecF[k] = make_float2(wdlk[n], regFusedLike[k]);
    }
    std::vector<int4> nodeInfo(nN);

@@ -276,17 +276,22 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // table words and LDS traffic less): two blocks of dimensions, D0 = ceil(D / 2) and D - D0, each as (x^2, x) pairs followed by its
 // constant -0.5 sum mu^2 ivar (k = 2 D0 and k = 2 D + 1); k-steps cut across the pairs, which the products do not mind.  The accumulator
 // still moves from zero through complete squares; between the constants up to 20 dimensions are open instead of 8 (measured: DESIGN §4).
+// Round 5: the constants sit side by side in ONE pair slot behind the first block, k = 2 D0 and 2 D0 + 1 with D0 = floor(D / 2): every other
+// slot is the (x^2, x) pair of a dimension at an even k, which lets the kernel build its operand pair by pair -- one packed conversion per
+// piece (v_cvt_pk_bf16_f32) and a dimension number that is the pair's number less one behind the constants.  The per-slot arithmetic of the
+// first layout (selects on the slot's kind and block) was 1 700 vector instructions per task and wavefront against 890 in the pairs' loop,
+// on the issue port the matrix instructions share (profiles/README.md r05b).  Open dimensions between the constants: 20 at most, as before
+// (the second block's constant comes before its dimensions instead of after them).
+__device__ __host__ __forceinline__ int dense_D0(int D) { return D >> 1; }
 __device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)      // kind 0: x^2, 1: x, 2: first constant, 3: second constant, -1: padding
 {
-   const int D0 = (D + 1) >> 1;
-   const bool second = k > 2 * D0;                     // (selects, no branches: the kernel runs this per lane)
-   const int kk = second ? k - 2 * D0 - 1 : k;
-   dim = (second ? D0 : 0) + (kk >> 1);
-   kind = kk & 1;
-   if (k == 2 * D0) kind = 2;
-   if (k == 2 * D + 1) kind = 3;
-   if (k > 2 * D + 1) kind = -1;
-   if (kind >= 2 || kind < 0 || dim >= D) dim = 0;
+   const int D0 = dense_D0(D);
+   const int j = k >> 1;                               // the pair
+   dim = j - (j > D0 ? 1 : 0);
+   kind = k & 1;
+   if (j == D0) kind = 2 + (k & 1);
+   if (dim >= D && j != D0) kind = -1;
+   if (kind >= 2 || kind < 0) dim = 0;
 }
 
 // workgroups per CU by registers and LDS: six k-steps 180 registers / 60 KB -> 2; five 168 / 51 KB -> 3 (measured against 2: DESIGN §4); four 152 / 40 KB -> 3; two 111 / 20 KB -> 4
@@ -294,9 +299,18 @@ __device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)   
 #define B16W_EU5 3
 #endif
 constexpr int b16w_eu(int KS) { return KS >= 6 ? B16W_EU : KS == 5 ? B16W_EU5 : KS == 4 ? 3 : 4; }
+#ifdef B16_CLK                                          // cycle stamps of thread 0 of every workgroup, summed: task fetch | rows + first pair landed | operand built | pairs' loop
+__device__ unsigned long long g_b16clk[8];
+#define B16_STAMP(i_) do { if (tid == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); clkAcc[i_] += c_ - clk0; clk0 = c_; } } while (0)
+#else
+#define B16_STAMP(i_) do { } while (0)
+#endif
 template <int KS>
 __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
 {
+#ifdef B16_CLK
+   unsigned long long clkAcc[5] = {0, 0, 0, 0, 0}, clk0 = __builtin_readcyclecounter();
+#endif
    static_assert(B16_TASK_FRAMES == 128, "four wavefronts x 32 frames");
    constexpr bool DENSE = (KS & 1) != 0;
    constexpr int NC = (KS + 1) / 2;
@@ -339,6 +353,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
       const int task = __builtin_amdgcn_readfirstlane(taskSh);
       if (task >= a.nTasks) break;
       const ScoreTask tk = a.tasks[task];
+      B16_STAMP(0);
       const bool active = fw < tk.nFrames;
       const int nPairs = (tk.nSlots + 1) >> 1;
       {
@@ -362,6 +377,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
       stage_pair(0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      B16_STAMP(1);
 
       // B operand from the rows in LDS: this lane's frame, the 8 k of its k-half in every k-step, in three bf16 pieces
       bf8 zb[KS][3];
@@ -374,14 +390,33 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
          for (int ks = 0; ks < KS; ks++) {
             unsigned short p[3][8];
             if constexpr (DENSE) {
+               // this lane's four pairs of the k-step: pair j = 8 ks + 4 k-half + q holds dimension j (before the constants' pair D0), the two
+               // constants, or dimension j - 1; a pair's two values are split together (dense_slot is the same map, slot by slot)
+               const int D0 = dense_D0(D), jb = 8 * ks + 4 * khL;
+               typedef float v2f_ __attribute__((ext_vector_type(2)));
+               typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
+               unsigned int w3[3][4];
 #pragma unroll
-               for (int i = 0; i < 8; i++) {                        // this lane's eight k of the k-step, one by one
-                  int dim, kind;
-                  dense_slot(16 * ks + 8 * khL + i, D, dim, kind);
-                  const float x = row[dim];
-                  const float v = kind == 0 ? x * x : kind == 1 ? x : kind >= 2 ? 1.0f : 0.0f;
-                  split3(v, p[0][i], p[1][i], p[2][i]);
+               for (int q = 0; q < 4; q++) {
+                  const int j = jb + q;
+                  const int dim = j - (j > D0 ? 1 : 0);
+                  float x = row[dim];                              // (past the row's end for a padding pair: inside xbuf, and not used)
+                  x = (j == D0) ? 1.0f : (dim >= D ? 0.0f : x);
+                  v2f_ v = {x * x, x};
+#pragma unroll
+                  for (int s = 0; s < 3; s++) {
+                     const unsigned int u = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf2_));
+                     w3[s][q] = u;
+                     if (s < 2) v = v - (v2f_){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+                  }
                }
+#pragma unroll
+               for (int s = 0; s < 3; s++) {
+                  u4 w; w[0] = w3[s][0]; w[1] = w3[s][1]; w[2] = w3[s][2]; w[3] = w3[s][3];
+                  zb[ks][s] = __builtin_bit_cast(bf8, w);
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               continue;
             } else {
             const int c = ks >> 1, i0 = 8 * (ks & 1) + 4 * khL;      // chunk; first of this lane's four dimensions within it
 #pragma unroll
@@ -408,6 +443,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
          }
       }
 
+      B16_STAMP(2);
       int buf = 0;
       float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + kh) * tk.ldo + fw + fcol;      // this lane's state (kh of the pair) and frame
       const size_t oStep = 2 * (size_t)tk.ldo;
@@ -425,15 +461,23 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             // compiler places them: pinning every slice with sched_barrier cost 16 registers and 1 % at three workgroups per CU)
             // (the sum's tree is ((e_k + e_k+8) + (e_k+4 + e_k+12)) for k = 0 .. 3, then (E0 + E1) + (E2 + E3): the exponentials are taken in
             //  that order and added as they come -- four partial sums alive instead of sixteen terms)
-            float m8[8], m4[4], m2[2], mx = 0.0f, E[4], pA = 0.0f, sm = 0.0f, lg = 0.0f, resP = 0.0f;
+            // (round 5: the matrix instructions share the vector ALU's issue port -- 4.9 vector instructions per matrix instruction, 16 of them
+            //  transcendental, left the matrix pipe 58 % busy.  Now: maxima three at a time, differences and sums as packed pairs, the
+            //  accumulators start from the constant 0 / from the tile's constants as they come out of LDS instead of 32 moves and 16 additions)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            float m6[6], m2[2], mx = 0.0f, E[4], sm = 0.0f, lg = 0.0f, resP = 0.0f;
+            v2f nmx = {0.0f, 0.0f}, pAB = {0.0f, 0.0f};
             auto lse_slice = [&](int sl) {
-               if (sl < 2) { for (int r = 4 * sl; r < 4 * sl + 4; r++) m8[r] = fmaxf(yP[r], yP[r + 8]); }
-               else if (sl == 2) { for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]); }
-               else if (sl == 3) { m2[0] = fmaxf(m4[0], m4[1]); m2[1] = fmaxf(m4[2], m4[3]); mx = fmaxf(m2[0], m2[1]); }
+               if (sl == 0) { for (int r = 0; r < 3; r++) m6[r] = fmaxf(fmaxf(yP[3 * r], yP[3 * r + 1]), yP[3 * r + 2]); }
+               else if (sl == 1) { for (int r = 3; r < 5; r++) m6[r] = fmaxf(fmaxf(yP[3 * r], yP[3 * r + 1]), yP[3 * r + 2]); m6[5] = yP[15]; }
+               else if (sl == 2) { m2[0] = fmaxf(fmaxf(m6[0], m6[1]), m6[2]); m2[1] = fmaxf(fmaxf(m6[3], m6[4]), m6[5]); }
+               else if (sl == 3) { mx = fmaxf(m2[0], m2[1]); nmx = (v2f){-mx, -mx}; }
                else if (sl < 12) {
                   const int k = (sl - 4) >> 1;
-                  if (((sl - 4) & 1) == 0) pA = EXP2(yP[k] - mx) + EXP2(yP[k + 8] - mx);
-                  else E[k] = pA + (EXP2(yP[k + 4] - mx) + EXP2(yP[k + 12] - mx));
+                  if (((sl - 4) & 1) == 0) {
+                     const v2f d0 = (v2f){yP[k], yP[k + 4]} + nmx, d1 = (v2f){yP[k + 8], yP[k + 12]} + nmx;
+                     pAB = (v2f){EXP2(d0.x), EXP2(d0.y)} + (v2f){EXP2(d1.x), EXP2(d1.y)};      // (e_k + e_k+8, e_k+4 + e_k+12)
+                  } else E[k] = pAB.x + pAB.y;
                }
                else if (sl < 15) { }
                else if (sl == 15) { sm = (E[0] + E[1]) + (E[2] + E[3]); }
@@ -441,8 +485,15 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
                else { resP = (mx + lg) * 0.69314718055994531f; }
             };
             f16v Cx, Cc;
+            {  // the cross terms are added to the tile's constants (row 4 b + r of this lane's k-half: word kh 4 + b, component r)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }
+               for (int b = 0; b < 4; b++) {
+                  const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
+#pragma unroll
+                  for (int r = 0; r < 4; r++) Cc[4 * b + r] = ci[r];
+               }
+            }
+            const f16v zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             bf8 wa[KS][3];
 #pragma unroll
             for (int s = 0; s < 3; s++) wa[0][s] = __builtin_bit_cast(bf8, wbuf[buf][(0 * 3 + s) * 64 + lane]);
@@ -460,22 +511,26 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
                if (3 * ks + 2 < 18) lse_slice(3 * ks + 2);
-               Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
+               if (ks == 0) Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], zero16, 0, 0, 0);
+               else Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
             }
             for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
             asm volatile("" : "+v"(resP));
             resQ = resP; haveQ = j > 0;                  // (the pair before always has both its states)
+            {
+               typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
-#pragma unroll
-               for (int r = 0; r < 4; r++) yP[4 * b + r] = (Cx[4 * b + r] + Cc[4 * b + r]) + ci[r];
+               for (int r = 0; r < 16; r += 2) { const v2f y = (v2f){Cx[r], Cx[r + 1]} + (v2f){Cc[r], Cc[r + 1]}; yP[r] = y.x; yP[r + 1] = y.y; }
             }
          }
          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next pair's rows have landed (issued a whole round ago)
          __syncthreads();
          buf ^= 1;
       }
+      B16_STAMP(3);
+#ifdef B16_CLK
+      if (tid == 0) clkAcc[4] += (unsigned long long)nPairs;
+#endif
       if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
       if (active) {                                    // the last pair's log-sum-exp
          float m8[8], m4[4];
@@ -495,6 +550,9 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
          if (fw + fcol < tk.nFrames && 2 * (nPairs - 1) + kh < tk.nSlots) *o = (mx + LOG2(sm)) * 0.69314718055994531f;
       }
    }
+#ifdef B16_CLK
+   if (tid == 0) { for (int i = 0; i < 5; i++) atomicAdd(&g_b16clk[i], clkAcc[i]); atomicAdd(&g_b16clk[5], 1ull); }
+#endif
 }
 
 int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop)
@@ -515,7 +573,15 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
       dim3 block(256);
 #define W_LAUNCH(KS_) do { const int b_ = a.nTasks < 256 * b16w_eu(KS_) ? a.nTasks : 256 * b16w_eu(KS_); \
                            hipExtLaunchKernelGGL((k_score_bf16w<KS_>), dim3(b_), block, 0, stream, evStart, evStop, 0, a); } while (0)
-      if (m->bf16Dense) { W_LAUNCH(5); HIPCHECK(hipGetLastError()); return HTKAMD_OK; }
+      if (m->bf16Dense) {
+         W_LAUNCH(5); HIPCHECK(hipGetLastError());
+#ifdef B16_CLK
+         {  unsigned long long h[8]; static int nth = 0;
+            HIPCHECK(hipStreamSynchronize(stream)); HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_b16clk), sizeof(h)));
+            if (++nth % 8 == 0) fprintf(stderr, "k_score_bf16w<5> cycles summed over %llu workgroups (cumulative): fetch %llu | landed %llu | operand %llu | pairs %llu ; pairs %llu, tasks %d\n", h[5], h[0], h[1], h[2], h[3], h[4], a.nTasks); }
+#endif
+         return HTKAMD_OK;
+      }
       switch (m->bf16NC) {
       case 3: W_LAUNCH(6); break;
       case 2: W_LAUNCH(4); break;
@@ -618,7 +684,7 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
    const double L2E = 1.4426950408889634;
    const float *mu = nullptr, *iv = nullptr;
    if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
-   const int D0 = (D + 1) >> 1;
+   const int D0 = dense_D0(D);
    unsigned short p[3][8];
 #pragma unroll
    for (int j = 0; j < 8; j++) {
@@ -659,7 +725,7 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
 __global__ __launch_bounds__(256) void k_build_bf16tab_dense_lds(Bf16TabArgs a, int nTiles, int KS)
 {
    extern __shared__ float btRows[];                         // [BT_TILES*16][2][D] (mu, ivar), then [BT_TILES*16][2] constants (float), then [BT_TILES*16] live flags
-   const int D = a.D, D0 = (D + 1) >> 1;
+   const int D = a.D, D0 = dense_D0(D);
    const int t0 = blockIdx.x * BT_TILES;
    const int nT = (nTiles - t0 < BT_TILES) ? nTiles - t0 : BT_TILES;
    const int nR = nT * 16;
