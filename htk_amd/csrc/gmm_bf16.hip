@@ -299,6 +299,9 @@ __device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)   
 #define B16W_EU5 3
 #endif
 constexpr int b16w_eu(int KS) { return KS >= 6 ? B16W_EU : KS == 5 ? B16W_EU5 : KS == 4 ? 3 : 4; }
+#ifndef B16_ABL
+#define B16_ABL 0                                       /* diagnostic builds: 1 no barrier per pair, 2 no log-sum-exp, 4 one fragment load per pair, 8 no staging */
+#endif
 #ifdef B16_CLK                                          // cycle stamps of thread 0 of every workgroup, summed: task fetch | rows + first pair landed | operand built | pairs' loop
 __device__ unsigned long long g_b16clk[8];
 #define B16_STAMP(i_) do { if (tid == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); clkAcc[i_] += c_ - clk0; clk0 = c_; } } while (0)
@@ -455,45 +458,47 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
       for (int j = 0; j < nPairs; j++) {
          const bool more = j + 1 < nPairs;
          if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
-         if (more) stage_pair(j + 1, buf ^ 1);
+         if (more && !(B16_ABL & 8)) stage_pair(j + 1, buf ^ 1);
          if (active) {
             // the log-sum-exp of the pair BEFORE this one (left in yP) in 18 slices, written between the matrix instructions of this pair (the
             // compiler places them: pinning every slice with sched_barrier cost 16 registers and 1 % at three workgroups per CU)
             // (the sum's tree is ((e_k + e_k+8) + (e_k+4 + e_k+12)) for k = 0 .. 3, then (E0 + E1) + (E2 + E3): the exponentials are taken in
             //  that order and added as they come -- four partial sums alive instead of sixteen terms)
             // (round 5: the matrix instructions share the vector ALU's issue port -- 4.9 vector instructions per matrix instruction, 16 of them
-            //  transcendental, left the matrix pipe 58 % busy.  Now: maxima three at a time, differences and sums as packed pairs, the
-            //  accumulators start from the constant 0 / from the tile's constants as they come out of LDS instead of 32 moves and 16 additions)
+            //  transcendental, left the matrix pipe 58 % busy; diagnostic builds (B16_ABL): without this log-sum-exp the kernel takes 0.77 ms,
+            //  its floor with nothing but the matrix instructions 0.76, with it 0.93.  Maxima three at a time, differences and sums as packed pairs)
             typedef float v2f __attribute__((ext_vector_type(2)));
-            float m6[6], m2[2], mx = 0.0f, E[4], sm = 0.0f, lg = 0.0f, resP = 0.0f;
-            v2f nmx = {0.0f, 0.0f}, pAB = {0.0f, 0.0f};
+            float m6[6], m2[2], mx = 0.0f, sm = 0.0f, lg = 0.0f, resP = 0.0f;
+            v2f nmx = {0.0f, 0.0f}, eA = {0.0f, 0.0f}, sA = {0.0f, 0.0f}, sB = {0.0f, 0.0f}, E01 = {0.0f, 0.0f}, E23 = {0.0f, 0.0f};
+            // the exponentials of components (2 i, 2 i + 1) -- neighbours in the registers, so that the packed instructions need no moves
+            auto exp_pair = [&](int i) { const v2f d = (v2f){yP[2 * i], yP[2 * i + 1]} + nmx; return (v2f){EXP2(d.x), EXP2(d.y)}; };
             auto lse_slice = [&](int sl) {
+#if (B16_ABL & 2)
+               if (sl == 17) resP = yP[0] + yP[5];
+               return;
+#endif
                if (sl == 0) { for (int r = 0; r < 3; r++) m6[r] = fmaxf(fmaxf(yP[3 * r], yP[3 * r + 1]), yP[3 * r + 2]); }
                else if (sl == 1) { for (int r = 3; r < 5; r++) m6[r] = fmaxf(fmaxf(yP[3 * r], yP[3 * r + 1]), yP[3 * r + 2]); m6[5] = yP[15]; }
                else if (sl == 2) { m2[0] = fmaxf(fmaxf(m6[0], m6[1]), m6[2]); m2[1] = fmaxf(fmaxf(m6[3], m6[4]), m6[5]); }
                else if (sl == 3) { mx = fmaxf(m2[0], m2[1]); nmx = (v2f){-mx, -mx}; }
-               else if (sl < 12) {
-                  const int k = (sl - 4) >> 1;
-                  if (((sl - 4) & 1) == 0) {
-                     const v2f d0 = (v2f){yP[k], yP[k + 4]} + nmx, d1 = (v2f){yP[k + 8], yP[k + 12]} + nmx;
-                     pAB = (v2f){EXP2(d0.x), EXP2(d0.y)} + (v2f){EXP2(d1.x), EXP2(d1.y)};      // (e_k + e_k+8, e_k+4 + e_k+12)
-                  } else E[k] = pAB.x + pAB.y;
-               }
+               // the sum's tree, as at the task's last pair below: s_k = e_k + e_k+8, E_k = s_k + s_k+4 (k = 0 .. 3), (E0 + E1) + (E2 + E3) --
+               // two components at a time: (s0,s1) = (e0,e1) + (e8,e9); (s4,s5) likewise; (E0,E1) = (s0,s1) + (s4,s5); then components 2, 3
+               else if (sl == 4) eA = exp_pair(0);
+               else if (sl == 5) sA = eA + exp_pair(4);
+               else if (sl == 6) eA = exp_pair(2);
+               else if (sl == 7) { sB = eA + exp_pair(6); E01 = sA + sB; }
+               else if (sl == 8) eA = exp_pair(1);
+               else if (sl == 9) sA = eA + exp_pair(5);
+               else if (sl == 10) eA = exp_pair(3);
+               else if (sl == 11) { sB = eA + exp_pair(7); E23 = sA + sB; }
                else if (sl < 15) { }
-               else if (sl == 15) { sm = (E[0] + E[1]) + (E[2] + E[3]); }
+               else if (sl == 15) { sm = (E01.x + E01.y) + (E23.x + E23.y); }
                else if (sl == 16) { lg = LOG2(sm); }
                else { resP = (mx + lg) * 0.69314718055994531f; }
             };
             f16v Cx, Cc;
-            {  // the cross terms are added to the tile's constants (row 4 b + r of this lane's k-half: word kh 4 + b, component r)
 #pragma unroll
-               for (int b = 0; b < 4; b++) {
-                  const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
-#pragma unroll
-                  for (int r = 0; r < 4; r++) Cc[4 * b + r] = ci[r];
-               }
-            }
-            const f16v zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }      // (no instructions: the first product of each takes the constant 0)
             bf8 wa[KS][3];
 #pragma unroll
             for (int s = 0; s < 3; s++) wa[0][s] = __builtin_bit_cast(bf8, wbuf[buf][(0 * 3 + s) * 64 + lane]);
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             for (int ks = 0; ks < KS; ks++) {
                if (ks + 1 < KS) {
 #pragma unroll
-                  for (int s = 0; s < 3; s++) wa[ks + 1][s] = __builtin_bit_cast(bf8, wbuf[buf][((ks + 1) * 3 + s) * 64 + lane]);
+                  for (int s = 0; s < 3; s++) wa[ks + 1][s] = (B16_ABL & 4) ? wa[0][s] : __builtin_bit_cast(bf8, wbuf[buf][((ks + 1) * 3 + s) * 64 + lane]);
                }
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][1], Cc, 0, 0, 0);
                if (3 * ks + 0 < 18) lse_slice(3 * ks + 0);
@@ -511,20 +516,22 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
                if (3 * ks + 2 < 18) lse_slice(3 * ks + 2);
-               if (ks == 0) Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], zero16, 0, 0, 0);
-               else Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
+               Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
             }
             for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
             asm volatile("" : "+v"(resP));
             resQ = resP; haveQ = j > 0;                  // (the pair before always has both its states)
-            {
-               typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-               for (int r = 0; r < 16; r += 2) { const v2f y = (v2f){Cx[r], Cx[r + 1]} + (v2f){Cc[r], Cc[r + 1]}; yP[r] = y.x; yP[r + 1] = y.y; }
+            for (int b = 0; b < 4; b++) {
+               const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
+#pragma unroll
+               for (int r = 0; r < 4; r++) yP[4 * b + r] = (Cx[4 * b + r] + Cc[4 * b + r]) + ci[r];
             }
          }
+#if !(B16_ABL & 1)
          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next pair's rows have landed (issued a whole round ago)
          __syncthreads();
+#endif
          buf ^= 1;
       }
       B16_STAMP(3);
