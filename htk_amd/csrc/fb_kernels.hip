@@ -1023,8 +1023,11 @@ __global__ __launch_bounds__(256) void k_rec_reduce(FbArgs a)
 #define LR_EXP_BUILD 0
 #endif
 #define MS_EXP(bit) (LR_EXP_BUILD && (a.lrExp & (bit)))      // ablations of a diagnostic build (tools/lr_exp.py): 256 no sums, 512 fp32 exp, 1024 no rows, 2048 no distances
+#ifndef MS_EU
+#define MS_EU 8                  /* the launch bound's second figure: 1, 2, 4, 5, 6, 8 give the same 155-register kernel at 0.28-0.29 ms, 3 a 151-register one at 0.33 (tools/r05_var.sh) */
+#endif
 template <int DT, int MODE>      // MODE: 3 means and variances (HFB.c:1673-1678), 1 means only (:1697), 2 variances only (:1706), 0 weights only
-__global__ __launch_bounds__(64, 3) void k_mixstate(FbArgs a)
+__global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
 {
 #ifndef MS_CHUNK
 #define MS_CHUNK 32
