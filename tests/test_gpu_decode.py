@@ -402,3 +402,24 @@ def test_list_walk_out_of_capacity_keeps_the_batch_kernels_answer(native, tmp_pa
     auto = dec.run(feats, **p)
     assert dec.last_tied() >= 1                               # the tie was seen and the list kernel tried
     assert auto == fast
+
+
+@pytest.mark.parametrize("case", ["loop", "bigram", "tee", "wint", "ties", "xwrd:net"])
+def test_token_kernel_variants_agree(native, case, monkeypatch):
+    """The register kernel with the word ends' tokens in LDS (the default where they fit), the same with every exit token in memory
+    (HTKAMD_DECODE_NOEXL) and the kernel with no tokens in registers at all (HTKAMD_DECODE_NOREG, read when the decoder is created):
+    the same words, boundaries, scores and total likelihoods to the last bit, with and without -u (maxActive)."""
+    mmf, net, feats, expected = load_decode_case(native, case)
+    model = native.Model(mmf.packed())
+    for opts in list(expected)[:2]:
+        if "-m" in opts.split():
+            continue
+        p = parse_opts(opts)
+        for extra in ({}, {"maxActive": 12}):
+            kw = dict(p, **extra)
+            monkeypatch.delenv("HTKAMD_DECODE_NOEXL", raising=False); monkeypatch.delenv("HTKAMD_DECODE_NOREG", raising=False)
+            ref = native.Decoder(model, net, lmScale=p["lmScale"]).run(feats, **kw)
+            monkeypatch.setenv("HTKAMD_DECODE_NOEXL", "1")
+            assert native.Decoder(model, net, lmScale=p["lmScale"]).run(feats, **kw) == ref, (case, opts, extra, "NOEXL")
+            monkeypatch.setenv("HTKAMD_DECODE_NOREG", "1")
+            assert native.Decoder(model, net, lmScale=p["lmScale"]).run(feats, **kw) == ref, (case, opts, extra, "NOREG")
