@@ -120,6 +120,40 @@ __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, co
    const DecNet &N = a.net;
    const int NS = (ni.x >> 4) & 255;
    Tok nw[MX];
+   if constexpr (SLOTS && MX == 5) {
+      // The usual model -- three emitting states, no skips: ranges (1,2) (2,3) (3,4), exit (4,4) -- when every live lane of the wavefront has
+      // it: the same comparisons as below for those ranges, without the twelve guarded (state, predecessor) combinations of the general form
+      constexpr int SE_LTR5 = 1 | (2 << 3) | (2 << 6) | (3 << 9) | (3 << 12) | (4 << 15) | (4 << 18) | (4 << 21);
+      if (__builtin_amdgcn_ballot_w64(!(NS == 5 && se == SE_LTR5)) == 0ull) {
+         const float t12 = tp[1], t22 = tp[6], t23 = tp[7], t33 = tp[12], t34 = tp[13], t44 = tp[18], t45 = tp[19];
+         const float tIn[3] = {t12, t23, t34}, tSelf[3] = {t22, t33, t44};
+         const int slj[3] = {sl2, sl3, sl4};
+#pragma unroll
+         for (int j = 2; j < 5; j++) {
+            nw[j] = null_tok();
+            const double c1 = s[j - 1].like + tIn[j - 2], c2 = s[j].like + tSelf[j - 2];
+            Tok best = s[j - 1]; double bl = c1;
+            if (c2 > bl) { best = s[j]; bl = c2; }
+            best.like = bl;
+            if (best.like > gT) {
+               best.like += __builtin_nontemporal_load(a.score + ud.score0 + (size_t)(t - 1) * a.ns + slj[j - 2]);
+               nw[j] = best;
+               if (best.like > mx) mx = best.like;
+            }
+         }
+         Tok best = nw[4];
+         best.like = nw[4].like + t45;
+         if (best.like > LSMALL) {
+            exT = best;
+            const double w = best.like + wdlk;
+            if (w > wordTop) wordTop = w;
+         }
+         s[1] = null_tok();
+#pragma unroll
+         for (int j = 2; j < 5; j++) s[j] = nw[j];
+         return;
+      }
+   }
 #pragma unroll
    for (int j = 2; j < MX; j++) {
       nw[j] = null_tok();
