@@ -362,6 +362,10 @@ class ForwardBackward:
         check(lib().htkamd_fb_kernel_times(self.h, t), "fb_kernel_times")
         return list(t)
 
+    def set_event_mode(self, mode: int):
+        """htkamd_fb_set_event_mode: 0 events between all kernels (default), 1 the scoring dispatch's own only (the other intervals read -1)."""
+        check(lib().htkamd_fb_set_event_mode(self.h, C.c_int(mode)), "fb_set_event_mode")
+
     def kernel_times5(self):
         """seconds: scoring, beta, alpha, left-to-right statistics, mixture statistics (htkamd_fb_kernel_times5)"""
         t = (C.c_double * 5)()

@@ -156,6 +156,7 @@ struct htkamd_fb {
    hipEvent_t ev[6], evK[2], evCopy;          // ev: stream intervals (score | beta | alpha | left-to-right statistics | mixture statistics); evK: the scoring dispatch's own start/stop
    hipStream_t resStream;                   // non-blocking stream for fb_results (does not wait for later launches)
    bool evValid, timed, copyPending, scored;
+   int evMode = 0, evModeLast = 0;           // htkamd_fb_set_event_mode; the mode of the last htkamd_fb_execute
 };
 
 // the reference's second-visit arithmetic is asked for AND can be reached with this set (htkamd_model_set_compat)
@@ -686,6 +687,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    int rc;
    // the batch tables may have been uploaded on another stream (htkamd_fb_prepare's): the kernels wait for that copy, not the host
    if (fb->copyPending) HIPCHECK(hipStreamWaitEvent(s, fb->evCopy, 0));
+   const bool noEv = fb->evMode == 1;      // htkamd_fb_set_event_mode: only the scoring dispatch's own start / stop (no stream events between the kernels)
    HIPCHECK(hipEventRecord(fb->ev[0], s));
    if (m->tiedMix) {
       // hsKind TIEDHS: the pool once per frame, then every state's weighted sum of it (no other arithmetic mode exists for it)
@@ -705,7 +707,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       if ((rc = htkamd_launch_combine_streams(fa, s))) return rc;
       if (m->maxM > 1) fa.stateCompOff = m->d_msCompOff;
    } else if (m->tiedMix) fa.stateCompOff = m->d_msCompOff;
-   HIPCHECK(hipEventRecord(fb->ev[1], s));
+   if (!noEv) HIPCHECK(hipEventRecord(fb->ev[1], s));
    const int nGeneral = fb->clsOff[5] - fb->clsOff[4];
    fb->lastWave = nGeneral == 0;
    if (nGeneral > 0 && ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
@@ -765,7 +767,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          fc.uttList = (const int *)fb->d_uttList.p + fb->clsOff[9 + c]; fc.nList = fb->clsOff[10 + c] - fb->clsOff[9 + c];
          if ((rc = pass == 0 ? htkamd_launch_beta_lr(fc, clsW[c], fastLadd, s) : htkamd_launch_alpha_lr(fc, clsW[c], fastLadd, s))) return rc;
       }
-      HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
+      if (!noEv) HIPCHECK(hipEventRecord(fb->ev[2 + pass], s));
    }
    {  // left-to-right path: occupation / transition counts and the list of surviving (frame, state) pairs from the stored columns
       FbArgs fc = fa;
@@ -777,7 +779,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          rowOff += (size_t)fc.nList * htkamd_stats_lr_chunks(fb->TMax) * clsW[c];
          if ((rc = htkamd_launch_stats_lr(fc, clsW[c], fastLadd, s))) return rc;
       }
-      HIPCHECK(hipEventRecord(fb->ev[4], s));
+      if (!noEv) HIPCHECK(hipEventRecord(fb->ev[4], s));
    }
    if (cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES)) {
       if ((cfg->uFlags & (HTKAMD_UPMEANS | HTKAMD_UPVARS)) && fb->recCapForce >= 0) {
@@ -801,7 +803,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
       else if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
    }
    HIPCHECK(hipEventRecord(fb->ev[5], s));
-   fb->timed = true;
+   fb->timed = true; fb->evModeLast = noEv ? 1 : 0;
    // the metric's unit count rides along in the accumulator vector so that it is all-reduced with it
    return HTKAMD_OK;
 }
@@ -872,6 +874,16 @@ extern "C" int htkamd_fb_results(htkamd_fb *fb, double *pr, int *status, void *s
    return HTKAMD_OK;
 }
 
+// The events htkamd_fb_execute records for htkamd_fb_kernel_times*: 0 (default) the scoring dispatch's own start / stop and five stream
+// events between the kernels (each a barrier packet: ~5 us of idle queue apiece, 20-40 us of a 2 ms pass); 1 the scoring dispatch's only --
+// htkamd_fb_kernel_times5 then reports -1 for the other four intervals.
+extern "C" int htkamd_fb_set_event_mode(htkamd_fb *fb, int mode)
+{
+   if (!fb || mode < 0 || mode > 1) { htkamd_set_error("fb_set_event_mode: bad argument"); return HTKAMD_EINVAL; }
+   fb->evMode = mode;
+   return HTKAMD_OK;
+}
+
 // out[0..4]: scoring (the dispatch's own start -> stop), beta, alpha, the left-to-right path's frame-parallel statistics, mixture
 // statistics -- the last four as intervals between stream events around the launches
 extern "C" int htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5])
@@ -882,6 +894,7 @@ extern "C" int htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5])
    for (int i = 0; i < 5; i++) {
       float ms = 0.f;
       if (i == 0 && fb->scored) HIPCHECK(hipEventElapsedTime(&ms, fb->evK[0], fb->evK[1]));
+      else if (fb->evModeLast == 1) { out[i] = -1.0; continue; }                  // not measured in this pass
       else HIPCHECK(hipEventElapsedTime(&ms, fb->ev[i], fb->ev[i + 1]));
       out[i] = (double)ms * 1e-3;
    }

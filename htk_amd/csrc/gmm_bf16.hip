@@ -571,8 +571,11 @@ int htkamd_launch_score_bf16(const htkamd_model *m, const ScoreArgs &a, hipStrea
       if (rc) return rc;
    }
    ((htkamd_model *)m)->fastUse |= HTKAMD_SCORE_BF16;
-   HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
-   if (a.qCounters) HIPCHECK(hipMemsetAsync(a.qCounters, 0, 8 * sizeof(int), stream));
+   if (a.qCounters == a.taskCounter + 8) HIPCHECK(hipMemsetAsync(a.taskCounter, 0, 16 * sizeof(int), stream));      // the counter and the eight queues' behind it: one fill
+   else {
+      HIPCHECK(hipMemsetAsync(a.taskCounter, 0, sizeof(int), stream));
+      if (a.qCounters) HIPCHECK(hipMemsetAsync(a.qCounters, 0, 8 * sizeof(int), stream));
+   }
    if (m->f16Wide && (size_t)m->nTiles * ((size_t)3 * m->bf16NC * 64 * 16 + 64 * 16) >= ((size_t)1 << 32)) {
       htkamd_set_error("score_bf16: a table of %d tiles is beyond the kernel's 32-bit staging offsets", m->nTiles); return HTKAMD_EMODEL;
    }

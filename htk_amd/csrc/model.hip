@@ -621,9 +621,12 @@ extern "C" int htkamd_accs_create(htkamd_model *m, htkamd_accs **out)
    a->lay.nEgs = o; o += m->H;
    a->lay.totalPr = o++; a->lay.totalT = o++; a->lay.nUttDone = o++; a->lay.nUttSkipped = o++; a->lay.nEval = o++;
    a->lay.total = o;
-   hipError_t e = hipMalloc((void **)&a->d_vec, sizeof(double) * o);
+   // (room to the next 256 bytes behind the vector: htkamd_accs_zero clears whole 256-byte blocks -- a size that is not such a multiple is
+   //  filled by two kernels, bulk and tail, 4 us apart in every EM iteration)
+   const size_t oPad = (o + 31) & ~(size_t)31;
+   hipError_t e = hipMalloc((void **)&a->d_vec, sizeof(double) * oPad);
    if (e != hipSuccess) { htkamd_set_error("accs_create: hipMalloc(%zu doubles): %s", o, hipGetErrorString(e)); free(a); return HTKAMD_ENOMEM; }
-   e = hipMemset(a->d_vec, 0, sizeof(double) * o);
+   e = hipMemset(a->d_vec, 0, sizeof(double) * oPad);
    if (e != hipSuccess) { htkamd_set_error("accs_create: hipMemset: %s", hipGetErrorString(e)); (void)hipFree(a->d_vec); free(a); return HTKAMD_EHIP; }
    *out = a;
    return HTKAMD_OK;
@@ -639,7 +642,7 @@ extern "C" void htkamd_accs_destroy(htkamd_accs *a)
 extern "C" int htkamd_accs_zero(htkamd_accs *a, void *stream)
 {
    if (!a) { htkamd_set_error("accs_zero: NULL"); return HTKAMD_EINVAL; }
-   HIPCHECK(hipMemsetAsync(a->d_vec, 0, sizeof(double) * a->lay.total, (hipStream_t)stream));
+   HIPCHECK(hipMemsetAsync(a->d_vec, 0, sizeof(double) * ((a->lay.total + 31) & ~(size_t)31), (hipStream_t)stream));
    return HTKAMD_OK;
 }
 

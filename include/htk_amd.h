@@ -517,6 +517,9 @@ int  htkamd_fb_get_trellis(htkamd_fb *fb, int utt, double *beta, double *alpha, 
 int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
 /* the same with the alpha pass and the left-to-right path's frame-parallel statistics apart: scoring, beta, alpha, statistics, mixture statistics */
 int  htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5]);
+/* Which events htkamd_fb_execute records for the two calls above: 0 (default) the scoring dispatch's own start / stop plus stream events between
+   the kernels (each a barrier packet: 20 - 40 us of a 2 ms pass in all); 1 the scoring dispatch's only -- the other intervals then read -1. */
+int  htkamd_fb_set_event_mode(htkamd_fb *fb, int mode);
 /* the last pass's mixture statistics in units (UpMixParms HFB.c:1573-1721): out[0] (frame, state) pairs past the MINFORPROB prune, out[1] (frame,
    state, component) triples accumulated; -1 where the pass did not count them (sets of several streams, states of more than 16 components) */
 int  htkamd_fb_mix_counts(htkamd_fb *fb, long long out[2]);
