@@ -103,8 +103,14 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
                      dacc1 = ladd_tab(dacc1, (double)wt + (double)px.y, mle, tab);
                   } else {
                      const v2f y = wt + (-0.5f * sum);
+#ifdef EX_ABL_NOLADD
+                     acc0 = fmaxf(acc0, y.x); acc1 = fmaxf(acc1, y.y);
+#elif defined(EX_LADD_TWICE)
                      acc0 = ladd_tab_f(acc0, y.x, mle, tab);
                      acc1 = ladd_tab_f(acc1, y.y, mle, tab);
+#else
+                     ladd_tab_f2(acc0, y.x, acc1, y.y, mle, tab);
+#endif
                   }
                }
             }

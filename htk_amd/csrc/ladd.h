@@ -91,6 +91,9 @@ __device__ __forceinline__ double exp_tab(const double x, const double *etab)
 __device__ __forceinline__ float ladd_tab_f(const float xf, const float yf, const double minLogExp, const double *tab)
 {
    const float hi = fmaxf(xf, yf), lo = fminf(xf, yf);
+   // (the float difference first: it is the double one to 2^-24 of its size, so below -23.03 the reference's cut-off, minLogExp = -23.0259,
+   //  holds for certain and no double is formed)
+   if (lo - hi < -23.03f) return (hi < (float)LSMALL) ? (float)LZERO : hi;
    const double d = (double)lo - (double)hi;
    if (d < minLogExp) return (hi < (float)LSMALL) ? (float)LZERO : hi;
    if (d < -16.0 && hi <= -16.0f) return hi;
@@ -101,6 +104,36 @@ __device__ __forceinline__ float ladd_tab_f(const float xf, const float yf, cons
 #pragma unroll
    for (int j = LADD_DEG - 1; j >= 0; j--) f = fma(f, r, row[j]);
    return (float)((double)hi + f);
+}
+
+// Two independent LAdds of a lane (k_score_exact: its two frames) with ONE evaluation of the table row where that is enough.  A lane
+// needs the row for a term in one case in ten, but some lane of the 64 nearly always does, so two calls of ladd_tab_f run the eleven
+// double FMAs twice per Gaussian with a handful of lanes enabled: here the lanes that need it for either term evaluate it once (for the
+// first such term), and the few that need it for both go round again.  Results identical to ladd_tab_f term by term.
+__device__ __forceinline__ void ladd_tab_f2(float &a0, const float y0, float &a1, const float y1, const double minLogExp, const double *tab)
+{
+   const float hi0 = fmaxf(a0, y0), lo0 = fminf(a0, y0), hi1 = fmaxf(a1, y1), lo1 = fminf(a1, y1);
+   const float keep0 = (hi0 < (float)LSMALL) ? (float)LZERO : hi0, keep1 = (hi1 < (float)LSMALL) ? (float)LZERO : hi1;
+   const double d0 = (double)lo0 - (double)hi0, d1 = (double)lo1 - (double)hi1;
+   // row wanted: past the float pre-test, the reference's cut-off and the exact shortcut of ladd_tab_f
+   bool n0 = !(lo0 - hi0 < -23.03f) && !(d0 < minLogExp) && !(d0 < -16.0 && hi0 <= -16.0f);
+   bool n1 = !(lo1 - hi1 < -23.03f) && !(d1 < minLogExp) && !(d1 < -16.0 && hi1 <= -16.0f);
+   // what a term without the row comes to: the cut-off's value, or hi (the shortcut)
+   float r0 = (lo0 - hi0 < -23.03f || d0 < minLogExp) ? keep0 : hi0, r1 = (lo1 - hi1 < -23.03f || d1 < minLogExp) ? keep1 : hi1;
+   while (n0 || n1) {                                      // (at most two rounds)
+      const bool first = n0;
+      const double d = first ? d0 : d1;
+      const float hi = first ? hi0 : hi1;
+      const int k = (int)(-d * (double)LADD_INV_H);
+      const double r = d + ((double)k + 0.5) * (1.0 / (double)LADD_INV_H);
+      const double *row = tab + k * LADD_ROW;
+      double f = row[LADD_DEG];
+#pragma unroll
+      for (int j = LADD_DEG - 1; j >= 0; j--) f = fma(f, r, row[j]);
+      const float v = (float)((double)hi + f);
+      if (first) { r0 = v; n0 = false; } else { r1 = v; n1 = false; }
+   }
+   a0 = r0; a1 = r1;
 }
 
 // Tolerance-class forms for the HERest recursions (scoreMode bit HTKAMD_SCORE_FASTLADD): the increment log(1+exp(d)) and the
