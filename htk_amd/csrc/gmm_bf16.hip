@@ -299,6 +299,14 @@ __device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)   
 #define B16W_EU5 3
 #endif
 constexpr int b16w_eu(int KS) { return KS >= 6 ? B16W_EU : KS == 5 ? B16W_EU5 : KS == 4 ? 3 : 4; }
+#ifndef B16_PRIO_LEVEL
+#define B16_PRIO_LEVEL 1
+#endif
+#ifndef B16_PRIO
+#define B16_PRIO 1                                      /* 1: the pairs' loop at a raised wavefront priority, the operand build at the normal one: a workgroup in its products goes
+                                                           before one that is building (-3 %: 0.94 -> 0.91 ms; levels 1 - 3 alike).  Experiments: 2 the log-sum-exp behind the products at a
+                                                           lowered priority (0 %), 3 the priority dropped around every slice of it (as 1) */
+#endif
 #ifndef B16_ABL
 #define B16_ABL 0                                       /* diagnostic builds: 1 no barrier per pair, 2 no log-sum-exp, 4 one fragment load per pair, 8 no staging */
 #endif
@@ -382,6 +390,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
       __syncthreads();
       B16_STAMP(1);
 
+      if (B16_PRIO) __builtin_amdgcn_s_setprio(0);
       // B operand from the rows in LDS: this lane's frame, the 8 k of its k-half in every k-step, in three bf16 pieces
       bf8 zb[KS][3];
       if (active) {
@@ -502,6 +511,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             bf8 wa[KS][3];
 #pragma unroll
             for (int s = 0; s < 3; s++) wa[0][s] = __builtin_bit_cast(bf8, wbuf[buf][(0 * 3 + s) * 64 + lane]);
+            if (B16_PRIO) __builtin_amdgcn_s_setprio(B16_PRIO == 2 ? 2 : B16_PRIO_LEVEL);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                if (ks + 1 < KS) {
@@ -509,15 +519,17 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
                   for (int s = 0; s < 3; s++) wa[ks + 1][s] = (B16_ABL & 4) ? wa[0][s] : __builtin_bit_cast(bf8, wbuf[buf][((ks + 1) * 3 + s) * 64 + lane]);
                }
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][1], Cc, 0, 0, 0);
-               if (3 * ks + 0 < 18) lse_slice(3 * ks + 0);
+               if (B16_PRIO != 2 && 3 * ks + 0 < 18) { if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(0); lse_slice(3 * ks + 0); if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(B16_PRIO_LEVEL); }
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][2], Cc, 0, 0, 0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][2], zb[ks][0], Cc, 0, 0, 0);
-               if (3 * ks + 1 < 18) lse_slice(3 * ks + 1);
+               if (B16_PRIO != 2 && 3 * ks + 1 < 18) { if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(0); lse_slice(3 * ks + 1); if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(B16_PRIO_LEVEL); }
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][0], Cc, 0, 0, 0);
-               if (3 * ks + 2 < 18) lse_slice(3 * ks + 2);
+               if (B16_PRIO != 2 && 3 * ks + 2 < 18) { if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(0); lse_slice(3 * ks + 2); if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(B16_PRIO_LEVEL); }
                Cx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][0], Cx, 0, 0, 0);
             }
+            if (B16_PRIO == 2) { __builtin_amdgcn_s_setprio(0); for (int sl = 0; sl < 18; sl++) lse_slice(sl); }
+            else
             for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
             asm volatile("" : "+v"(resP));
             resQ = resP; haveQ = j > 0;                  // (the pair before always has both its states)
