@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
       __syncthreads();
       STAMP(3);
 
+      __builtin_amdgcn_s_setprio(0);                      // (the pairs' loop below runs at a raised priority: gmm_bf16.hip, B16_PRIO)
       // B operand from the rows in LDS: this lane's frame, the 8 k of its k-half in every k-step, scaled, in two fp16 pieces
       h8 zb[KS][2];
       if (active) {
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(256, F16W_EU) void k_score_f16w(ScoreArgs a)
 #pragma unroll
       for (int r = 0; r < 16; r++) yP[r] = 0.0f;
 #endif
+      __builtin_amdgcn_s_setprio(1);
       for (int j = 0; j < nPairs; j++) {
          u4 stg[PT];
          const bool more = j + 1 < nPairs;
