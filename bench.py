@@ -943,9 +943,10 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     out["other_paths"]["mfcc"] = {"error": repr(e)[:300]}
                 if args.extras >= 1 and args.cpu_seconds > 0:
-                    # BASELINE config[2] as ONE job on ONE GPU (10 000 utterances in eight sub-batches): the denominator of the 8-GPU speed-up
+                    # BASELINE config[2] as ONE job on ONE GPU (10 000 utterances in one batch: the fastest way one GPU does it -- eight sub-batches
+                    # on two streams take 17.5 ms for this 14.7): the denominator of the 8-GPU speed-up
                     out["other_paths"]["strong_1gpu"] = subprocess_leg(
-                        ["bench.py", "--gpus", "1", "--scaling", "strong", "--chunks", "8", "--cpu-seconds", "0", "--extras", "0", "--also-fastest", "0", "--steps", "5", "--warmup", "2"], 900,
+                        ["bench.py", "--gpus", "1", "--scaling", "strong", "--chunks", "1", "--cpu-seconds", "0", "--extras", "0", "--also-fastest", "0", "--steps", "10", "--warmup", "2"], 900,
                         lambda j: {k_: j.get(k_) for k_ in ("value", "unit", "ms_per_step", "herest_utterances_per_sec", "utterances_ok", "config", "kernel_ms")})
                     # the link-compatible boundary: the reference's unchanged HERest.o over the HFB shim, files per second (tools/shim_latency.py)
                     out["other_paths"]["boundary"] = subprocess_leg(["tools/shim_latency.py", "200"], 600, lambda j: j)
