@@ -20,10 +20,11 @@ C_SRCS = ["host/prep.c", "host/update.c", "host/fbank.c", "host/accio.c", "host/
 HEADERS = ["csrc/fb_lr_lean.inc", "csrc/internal.h", "csrc/kernels.h", "csrc/hipcheck.h", "csrc/ladd.h", "csrc/wavegrp.h", "csrc/fb_state.h", "csrc/decode.h", "csrc/decode_ord.h", "../include/htk_amd.h"]
 ARCH = "gfx950"
 # the tolerance-class scoring kernel never sees NaNs: lets v_max_f32 go without the IEEE canonicalisation of its operands
-EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["-fno-honor-nans"], "csrc/gmm_f16.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"csrc/gmm_mfma.hip": ["-fno-honor-nans"], "csrc/gmm_bf16.hip": ["-fno-honor-nans"], "csrc/gmm_f16.hip": ["-fno-honor-nans"],
+               "csrc/fb_kernels.hip": ["-Wno-pass-failed"]}      # (k_mixstate asks for an occupancy it knows it cannot have: MS_EU in fb_kernels.hip)
 if os.environ.get("HTKAMD_LR_DEFS"):               # experiment switches of fb_lr.hip, e.g. HTKAMD_LR_DEFS="-DSTATS_EXP_NOOCC"
     EXTRA_FLAGS["csrc/fb_lr.hip"] = os.environ["HTKAMD_LR_DEFS"].split()
-    EXTRA_FLAGS["csrc/fb_kernels.hip"] = os.environ["HTKAMD_LR_DEFS"].split()
+    EXTRA_FLAGS["csrc/fb_kernels.hip"] = EXTRA_FLAGS["csrc/fb_kernels.hip"] + os.environ["HTKAMD_LR_DEFS"].split()
 if os.environ.get("HTKAMD_DEC_DEFS"):              # ... and decode.hip (-DDEC_CLK: phase stamps)
     EXTRA_FLAGS["csrc/decode.hip"] = os.environ["HTKAMD_DEC_DEFS"].split()
 if os.environ.get("HTKAMD_EX_DEFS"):               # ... and gmm_exact.hip
