@@ -1064,8 +1064,10 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
    }
    // second view of the wavefront: lane = dimension; the means of the state's Gaussians at that dimension
    float meanR[GS];
+   // (the Gaussians' numbers by ONE load, a lane each: read one by one they were sixteen scalar loads, each waited for before its mean's load)
+   const int gOfLane = (lane < M) ? a.compGauss[c0 + lane] : 0;
 #pragma unroll
-   for (int m = 0; m < GS; m++) meanR[m] = (m < M && lane < DT) ? a.mean[(size_t)a.compGauss[c0 + m] * DT + lane] : 0.0f;
+   for (int m = 0; m < GS; m++) { const int gm_ = __builtin_amdgcn_readlane(gOfLane, m); meanR[m] = (m < M && lane < DT) ? a.mean[(size_t)gm_ * DT + lane] : 0.0f; }
    double sMu[GS], sVa[GS];
 #pragma unroll
    for (int m = 0; m < GS; m++) { sMu[m] = 0.0; sVa[m] = 0.0; }
@@ -1126,11 +1128,20 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
       __syncthreads();
       // ---- first- and second-order sums of the chunk: lane = dimension, a Gaussian after the other, the pairs it survived in (HFB.c:1673-1709)
       if ((upMu || upVa) && !MS_EXP(256)) {
+         // (the sixteen ballots first, four LDS reads in flight at a time: read Gaussian by Gaussian, every one was waited for on its own)
+         unsigned long long bmAll[GS];
+#pragma unroll
+         for (int m4 = 0; m4 < GS; m4 += 4) {
+            double Lq[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) Lq[i] = (lane < n) ? Lt[lane][m4 + i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) bmAll[m4 + i] = __ballot(Lq[i] != 0.0);
+         }
 #pragma unroll
          for (int m = 0; m < GS; m++) {
             if (m < M) {
-               const double Lmine = (lane < n) ? Lt[lane][m] : 0.0;
-               unsigned long long bm = __ballot(Lmine != 0.0);
+               unsigned long long bm = bmAll[m];
                // (the running sums of THIS Gaussian as two scalars around the loop, and no branch inside it: updated as elements of the
                // arrays under control flow, every pair cost a copy of all 32 accumulator registers)
                double mu = sMu[m], va = sVa[m];
