@@ -240,6 +240,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
       d.status = HTKAMD_UTT_OK; d.nEval = 0;
       d.outp0 = C.outp; d.beta0 = C.beta; d.gam0 = C.gam;
       
+      d.pad2 = 3;                                   // bit 0: no tee model in the chain, bit 1: every model left-to-right without skips (read and cleared by htkamd_fb_prepare's class loop)
       if (T <= 0 || Q <= 0) { d.status = HTKAMD_UTT_SKIPPED; d.nCells = d.nSlots = 0; d.thr0 = (int)C.thrCell.size(); d.nThr = 0; return HTKAMD_OK; }
       int nCells = 0, nSlots = 0, qt = 0, prevDm = 1;
       for (int q = 1; q <= Q; q++) {
@@ -251,6 +252,8 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
          for (int i = 1; i <= N; i++) { C.cQ.push_back((short)q); C.cI.push_back((short)i); }
          for (int j = 2; j < N; j++) { C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2) * m->NSt]); C.sQ.push_back((short)q); }      // several streams: the state's first element
          nCells += N; nSlots += N - 2; qt += dm;
+         if (dm == 0) d.pad2 &= ~1;
+         if (m->h_transLR[ti] != 1) d.pad2 &= ~2;
          if (q > 1 && dm == 0 && prevDm == 0) d.status = HTKAMD_UTT_ETEE;      // successive tee models (HFB.c:557)
          prevDm = dm;
       }
@@ -465,6 +468,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       });
    }
    fb->gamOff[U] = gam;
+   lap("merge:copy");
    {  // the wide tasks in eight queues, utterance u in queue u % 8 (the tasks lie in utterance order: one walk finds their utterances)
       std::vector<ScoreTask> q[8];
       int u = 0;
@@ -481,15 +485,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       }
       fb->wqStart[8] = (int)at;
    }
-   {  // utterance of every 512th seed (k_mixstats' scan chunks)
-      const size_t nChunk = (gam + 511) / 512;
-      fb->gamChunkUtt.assign(nChunk ? nChunk : 1, 0);
-      int u = 0;
-      for (size_t c = 0; c < nChunk; c++) {
-         while (u + 1 < U && fb->gamOff[u + 1] <= c * 512) u++;
-         fb->gamChunkUtt[c] = u;
-      }
-   }
+   lap("merge:queues");
    fb->outpTotal = outp; fb->betaTotal = beta; fb->gamTotal = gam;
    fb->blockDim = nThrMax;
    {  // classes: chains of <= 64 / 128 / 256 models of <= 5 states go to the wave kernels with 1 / 2 / 4 wavefronts, the rest to
@@ -500,15 +496,13 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          UttDesc &d = fb->utt[u];
          // a lane per chain state (fb_state.hip) where the chain has no tee model and at most 512 emitting states; else a lane per model
          // (fb_wave.hip, chains of up to 512 models); else the general workgroup-per-utterance kernels
-         bool noTee = d.status == HTKAMD_UTT_OK || d.status == HTKAMD_UTT_SKIPPED;
-         for (int q = 0; q < d.Q && noTee; q++) if (fb->mDms[d.q0 + q] == 0) noTee = false;
+         const bool noTee = (d.status == HTKAMD_UTT_OK || d.status == HTKAMD_UTT_SKIPPED) && (d.pad2 & 1);      // (the models were looked at by the workers)
          const bool small = fb->m->maxN <= 5 && !fb->forceGeneral && !compat_revisit(fb->m);
          int W = 0, kind = 0;
          if (small && !fb->noStatePath && noTee && d.nSlots >= 1 && d.nSlots <= 512) {
             kind = 1; W = d.nSlots <= 64 ? 1 : d.nSlots <= 128 ? 2 : d.nSlots <= 256 ? 4 : 8;
             // every model left-to-right without skips: the kernels of fb_lr.hip (no statistics in the alpha chain, no entry-state columns)
-            bool lr = !fb->noLrPath;      // (several streams / tied mixtures too since round 4: their pairs go to the list with the chain state's slot, k_mixhits_streams)
-            for (int q = 0; q < d.Q && lr; q++) if (fb->m->h_transLR[fb->mTrans[d.q0 + q]] != 1) lr = false;
+            const bool lr = !fb->noLrPath && (d.pad2 & 2);      // (several streams / tied mixtures too since round 4: their pairs go to the list with the chain state's slot, k_mixhits_streams)
             if (lr) kind = 2;
          }
          else if (small) W = d.Q <= 64 ? 1 : d.Q <= 128 ? 2 : d.Q <= 256 ? 4 : d.Q <= 512 ? 8 : 0;
@@ -527,7 +521,19 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       for (int c = 0; c < 13; c++) { fb->uttList.insert(fb->uttList.end(), cls[c].begin(), cls[c].end()); fb->clsOff[c + 1] = (int)fb->uttList.size(); }
       if (fb->uttList.empty()) fb->uttList.push_back(0);
    }
+   {  // utterance of every 512th seed (the scan chunks of k_mixstats and its several-stream / tied-mixture forms: the utterances that are
+      // NOT on the left-to-right path -- a batch without such utterances does not build or upload the table, 115 000 entries at the bench's)
+      const bool anyGeneral = fb->clsOff[9] > 0;
+      const size_t nChunk = anyGeneral ? (gam + 511) / 512 : 0;
+      fb->gamChunkUtt.assign(nChunk ? nChunk : 1, 0);
+      int u = 0;
+      for (size_t c = 0; c < nChunk; c++) {
+         while (u + 1 < U && fb->gamOff[u + 1] <= c * 512) u++;
+         fb->gamChunkUtt[c] = u;
+      }
+   }
 
+   lap("merge:classes");
    fb->nextSame.clear();
    if (compat_revisit(fb->m)) {
       // per utterance: the chain states of one tied state sorted by (model ascending, state descending); a state's successor in that
