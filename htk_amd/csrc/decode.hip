@@ -110,6 +110,12 @@ __device__ __forceinline__ double block_max(double v, double *red)
 }
 
 #define DEC_LDS_TP 4096            /* floats of transition matrices cached in LDS (all of them, else global memory) */
+#ifdef DEC_NEED                    /* diagnostic build: distinct tied states whose score a live token asked for, per frame (tools/dec_diag.py) */
+__shared__ unsigned int needB[256];            // (up to 8 192 score slots)
+#define DEC_NEED_MARK(slot_) atomicOr(&needB[((slot_) >> 5) & 255], 1u << ((slot_) & 31))
+#else
+#define DEC_NEED_MARK(slot_) do { } while (0)
+#endif
 
 // StepHMM1 (HRec.c:642) on one model instance: s[1 .. NS-1] = the state tokens on entry (s[1] the entry token) and the new ones on
 // return (s[1] null: the entry is consumed); exT = the exit token, mx = the instance's maximum, wordTop raised by exit + LikeToWord.
@@ -137,6 +143,7 @@ __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, co
             best.like = bl;
             if (best.like > gT) {
                best.like += __builtin_nontemporal_load(a.score + ud.score0 + (size_t)(t - 1) * a.ns + slj[j - 2]);
+               DEC_NEED_MARK(slj[j - 2]);
                nw[j] = best;
                if (best.like > mx) mx = best.like;
             }
@@ -179,6 +186,7 @@ __device__ __forceinline__ void hmm_step1(const DecArgs &a, const DecUtt &ud, co
             if constexpr (SLOTS) slot = (j == 2) ? sl2 : (j == 3) ? sl3 : sl4;      // (the register-resident models carry their score slots)
             else slot = N.stateSlot[N.hmmState[ni.w + (j - 2)]];
             best.like += __builtin_nontemporal_load(a.score + ud.score0 + (size_t)(t - 1) * a.ns + slot);      // (a frame's column is read once)
+            DEC_NEED_MARK(slot);
             nw[j] = best;
             if (best.like > mx) mx = best.like;
          }
@@ -243,6 +251,9 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
    __shared__ float thr[2];
    __shared__ float ltpS[EXL ? 1 : DEC_LDS_TP];    // (EXL: the matrices behind the dynamic block, as many floats as there are)
    __shared__ Tok nullL[EXL ? DEC_NULL_LDS : 1];
+#ifdef DEC_NEED
+   unsigned long long needSum = 0;
+#endif
    __shared__ int uhist[256];
    __shared__ unsigned int usel[4];            // -u: [0] attached instances, [1] key prefix, [2] rank still to skip, [3] scratch
    const int u = blockIdx.x, tid = threadIdx.x;
@@ -376,6 +387,10 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
          }
       }
       DEC_STAMP(0);
+#ifdef DEC_NEED
+      if (tid < 256) needB[tid] = 0;
+      __syncthreads();
+#endif
       if (t >= 1) {
          const float gT = thr[0];                         // threshold of the previous frame
          double myGen = LZERO, myWord = LZERO;
@@ -460,6 +475,16 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
          }
          __syncthreads();
       }
+#ifdef DEC_NEED
+      __syncthreads();
+      if (t >= 1 && tid < 64) {
+         unsigned int c = 0;
+         for (int i = tid; i < 256; i += 64) c += __popc(needB[i]);
+#pragma unroll
+         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+         needSum += c;
+      }
+#endif
       DEC_STAMP(2);
       // ---- zero-time nodes, level by level (at t = 0: StartRecognition's propagation of the initial token)
       const float gT = thr[0], wT = thr[1];
@@ -649,6 +674,9 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
 
 #ifdef DEC_CLK
    if (tid == 0 && a.liveCnt) for (int i = 0; i < 6; i++) atomicAdd(a.liveCnt + 2 * a.nUtt + i, clk[i]);
+#endif
+#ifdef DEC_NEED
+   if (tid == 0 && a.liveCnt) atomicAdd(a.liveCnt + 2 * a.nUtt + 6, needSum);
 #endif
    if (tie) a.tieFlag[u] = 1;                  // (zeroed by the host before the launch)
    if (NPT > 0 && a.liveCnt) {
@@ -1251,6 +1279,9 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
         if (hipEventElapsedTime(&ms, d->ev[0], d->ev[1]) == hipSuccess) d->lastScoreMs += ms;
         if (hipEventElapsedTime(&ms, d->ev[2], d->ev[3]) == hipSuccess) d->lastTokenMs += ms; }
       for (int k = 0; k < nu; k++) { d->lastLive[0] += (long long)hLive[2 * k]; d->lastLive[1] += (long long)hLive[2 * k + 1]; }
+#ifdef DEC_NEED
+      fprintf(stderr, "k_decode: %llu (frame, tied state) scores asked for by live tokens, of %d x %lld in the dense block\n", hLive[2 * (size_t)nu + 6], ns, (long long)(score / (ns ? ns : 1)));
+#endif
 #ifdef DEC_CLK
       fprintf(stderr, "k_decode phase cycles (sum over %d utterances): prune %llu | models %llu | beam tops %llu | fused words %llu | levels %llu | entries %llu\n", nu,
               hLive[2 * (size_t)nu], hLive[2 * (size_t)nu + 1], hLive[2 * (size_t)nu + 2], hLive[2 * (size_t)nu + 3], hLive[2 * (size_t)nu + 4], hLive[2 * (size_t)nu + 5]);
