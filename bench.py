@@ -805,6 +805,14 @@ def main():
             sc["pipe"] = "packed fp32 VALU (the reference's four roundings per dimension, no FMA)"
         else:
             sc["pipe"] = "v_mfma_f32_16x16x4_f32"
+        # the matrix-core work of a pass, counted by the host from the task list (htkamd_fb_score_work): blocks of (32 frames of a wavefront, pair of
+        # chain states) the kernel issues its products for, what it issued before Setotprob's per-state frame ranges reached it, what the units need
+        sw = np.sum([ch["fbs"][0].score_work() for ch in chunks], axis=0)
+        mi_blk = {"bf16": 30 if (31 <= D <= 39 and args.mix <= 16 and not os.environ.get("HTKAMD_BF16_CHUNKED")) else 36, "fastest": 15}.get(args.score)
+        score_work = {"unit": "(wavefront of 32 frames, pair of chain states) blocks per pass", "issued": int(sw[0]), "issued_without_frame_ranges": int(sw[1]),
+                      "needed": int(sw[2]), "needed_over_issued": float(sw[2]) / max(float(sw[0]), 1.0),
+                      "frame_ranges_in_kernel": not os.environ.get("HTKAMD_NO_TAPER_SKIP"),
+                      "matrix_instructions_per_block": mi_blk, "mfma_issued": int(sw[0]) * mi_blk if mi_blk else None, "mfma_needed": int(sw[2]) * mi_blk if mi_blk else None}
         dom = max(("score", "beta", "alpha", "stats"), key=lambda k_: per_kernel[k_]["ms"])
         out = {
             "metric": "herest_gmm_frame_state_loglik_per_sec",
@@ -842,6 +850,7 @@ def main():
             "update_stats_last_iteration": st_upd,
             "kernel_ms": {"score": k1 * 1e3, "beta": ktimes[1] * 1e3, "alpha": ktimes[2] * 1e3, "stats": ktimes[3] * 1e3, "mix_stats": ktimes[4] * 1e3},
             "kernel_ms_source": kernel_ms_source,
+            "score_work": score_work,
             "score_mode": args.score,
             "streams": len(lanes),
             # the kernel with the largest total time in the timed iterations

@@ -83,6 +83,7 @@ def lib():
             raise HtkAmdError("%s is missing: run `python -m htk_amd.build` (hipcc --offload-arch=gfx950)" % LIBPATH)
         L = C.CDLL(LIBPATH)
         L.htkamd_last_error.restype = C.c_char_p
+        L.htkamd_fb_score_work.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.htkamd_fb_frame_states.restype = C.c_longlong
         L.htkamd_fb_frame_states.argtypes = [C.c_void_p]
         _lib = L
@@ -377,6 +378,12 @@ class ForwardBackward:
         t = (C.c_longlong * 2)()
         check(lib().htkamd_fb_mix_counts(self.h, t), "fb_mix_counts")
         return int(t[0]), int(t[1])
+
+    def score_work(self):
+        """(issued, issued without the per-state frame ranges, needed) in (wavefront, pair) units of the pair kernels (htkamd_fb_score_work)"""
+        t = (C.c_longlong * 3)()
+        check(lib().htkamd_fb_score_work(self.h, t), "fb_score_work")
+        return int(t[0]), int(t[1]), int(t[2])
 
     def trellis(self, u: int, want_alpha: bool = True):
         T = C.c_int(); Q = C.c_int(); mN = C.c_int()

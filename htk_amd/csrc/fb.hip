@@ -89,6 +89,7 @@ struct PrepPool {
 // One worker's share of a batch: the tables of a contiguous range of utterances with offsets relative to the share.
 struct PrepChunk {
    std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState;
+   std::vector<int> slotRange;                // per chain state [first row, last row] of X that Setotprob of the un-pruned pass evaluates (ScoreArgs::slotRange)
    std::vector<int> slotStateU;               // several streams: the (state, stream) element of every chain state, per utterance NSt blocks of nSlots
    std::vector<short> cQ, cI, thrCell, sQ;
    std::vector<ScoreTask> tasks, tasksW;      // scoring tasks in groups of SCORE_TASK_SLOTS chain states (exact kernel) and of SCORE_TASK_SLOTS_WIDE (matrix-core kernels)
@@ -99,7 +100,7 @@ struct PrepChunk {
    char err[256] = "";
    void reset()                                          // keeps the vectors' capacity from batch to batch
    {
-      mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear(); slotStateU.clear();
+      mN.clear(); mTp.clear(); mCell0.clear(); mSlot0.clear(); mDms.clear(); mHmm.clear(); mTrans.clear(); slotState.clear(); slotStateU.clear(); slotRange.clear();
       cQ.clear(); cI.clear(); thrCell.clear(); sQ.clear(); tasks.clear(); tasksW.clear();
       outp = beta = gam = 0; frameStates = 0; nCellsMax = QMax = TMax = 1; nThrMax = 64; rc = HTKAMD_OK; err[0] = 0;
    }
@@ -115,7 +116,7 @@ struct htkamd_fb {
    int topoVersion;             // the model's topology version the batch tables were built against
    // host tables of the prepared batch
    std::vector<UttDesc> utt;
-   std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState, slotStateU;
+   std::vector<int> mN, mTp, mCell0, mSlot0, mDms, mHmm, mTrans, slotState, slotStateU, slotRange;
    std::vector<short> cQ, cI, taperLo, taperHi, thrCell, sQ;
    std::vector<int> wqStart;    // tasksW in eight queues by utterance % 8 (ScoreArgs::qStart): first task of every queue, then the total
    std::vector<int> qBeamNP;    // per frame: the beta beam of the un-pruned pass, lo | hi << 16 (what SetBeta leaves in qLo / qHi when only the taper acts)
@@ -132,6 +133,7 @@ struct htkamd_fb {
    DevBuf d_betaW;                          // wave path's beta blocks (UttDesc::betaW0)
    DevBuf d_tmE, d_tmMaxP;                  // tied mixtures: the pool's per-frame table (kernels.h FbArgs::tmE)
    std::vector<int> nextSame; DevBuf d_nextSame;   // HTKAMD_COMPAT_STREAM_REVISIT (kernels.h FbArgs::nextSame)
+   DevBuf d_slotRange;
    DevBuf d_slotStateU, d_outpU;            // several streams: element of every (stream, chain state), and their scores: stream k of utterance u at outpU[NSt*outp0 + (k*nSlots + slot)*T + t-1]
    DevBuf d_uttList, d_sQ;                  // utterance numbers grouped by class: lane-per-model W = 1 | 2 | 4 | 8 | general | lane-per-state W = 1 | 2 | 4 | 8 | left-to-right W = 1 | 2 | 4 | 8
    std::vector<int> uttList;
@@ -192,7 +194,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    DevBuf *all[] = {&fb->d_utt, &fb->d_mN, &fb->d_mTp, &fb->d_mCell0, &fb->d_mSlot0, &fb->d_mDms, &fb->d_mHmm, &fb->d_mTrans,
                     &fb->d_slotState, &fb->d_cQ, &fb->d_cI, &fb->d_taperLo, &fb->d_taperHi, &fb->d_tasks, &fb->d_tasksW, &fb->d_gamOff,
                     &fb->d_qLo, &fb->d_qHi, &fb->d_aLo, &fb->d_aHi, &fb->d_outp, &fb->d_beta, &fb->d_gam, &fb->d_alpha,
-                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_laneRec, &fb->d_sink, &fb->d_stCnt, &fb->d_stBucket, &fb->d_wqStart};
+                    &fb->d_pr, &fb->d_status, &fb->d_betaW, &fb->d_uttList, &fb->d_sQ, &fb->d_transOff, &fb->d_trOccOff, &fb->d_counter, &fb->d_thrCell, &fb->d_arena, &fb->d_gamChunkUtt, &fb->d_rec, &fb->d_recSorted, &fb->d_recCtl, &fb->d_alphaW, &fb->d_qBeam, &fb->d_aBeam, &fb->d_trPart, &fb->d_hits, &fb->d_hitCtl, &fb->d_slotStateU, &fb->d_outpU, &fb->d_tmE, &fb->d_tmMaxP, &fb->d_qBeamNP, &fb->d_slotRange, &fb->d_laneRec, &fb->d_sink, &fb->d_stCnt, &fb->d_stBucket, &fb->d_wqStart};
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    if (fb->h_res) (void)hipHostFree(fb->h_res);
@@ -250,7 +252,7 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
          C.mN.push_back(N); C.mTp.push_back(m->h_transOff[ti]); C.mCell0.push_back(nCells); C.mSlot0.push_back(nSlots);
          C.mDms.push_back(dm); C.mHmm.push_back(h); C.mTrans.push_back(ti);
          for (int i = 1; i <= N; i++) { C.cQ.push_back((short)q); C.cI.push_back((short)i); }
-         for (int j = 2; j < N; j++) { C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2) * m->NSt]); C.sQ.push_back((short)q); }      // several streams: the state's first element
+         for (int j = 2; j < N; j++) { C.slotState.push_back(m->h_hmmState[m->h_hmmStateOff[h] + (j - 2) * m->NSt]); C.sQ.push_back((short)q); C.slotRange.push_back(0); C.slotRange.push_back(-1); }      // several streams: the state's first element
          nCells += N; nSlots += N - 2; qt += dm;
          if (dm == 0) d.pad2 &= ~1;
          if (m->h_transLR[ti] != 1) d.pad2 &= ~2;
@@ -327,6 +329,21 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
             npw[t] = qLoN | (qHiN << 16);
          }
          d.nEval = (int)(C.frameStates - before);
+      }
+      {  // per chain state the frames in which its model lies inside [evLo, evHi] (both rise with t): first t with evHi[t] >= q .. last t with evLo[t] <= q
+         int *rng = C.slotRange.data() + 2 * (size_t)d.slot0;
+         int t = 1;
+         for (int q = 1; q <= Q; q++) {
+            while (t <= T && evHi[t] < q) t++;
+            const int s0 = C.mSlot0[d.q0 + q - 1], n = C.mN[d.q0 + q - 1] - 2;
+            for (int j = 0; j < n; j++) rng[2 * (s0 + j)] = d.frame0 + t - 1;
+         }
+         t = T;
+         for (int q = Q; q >= 1; q--) {
+            while (t >= 1 && evLo[t] > q) t--;
+            const int s0 = C.mSlot0[d.q0 + q - 1], n = C.mN[d.q0 + q - 1] - 2;
+            for (int j = 0; j < n; j++) rng[2 * (s0 + j) + 1] = d.frame0 + t - 1;
+         }
       }
       // scoring tasks: chunks of chain states x tiles of the frames in which the chunk can be in the beam
       {
@@ -449,7 +466,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
       base[nW] = z;
       outp = z.outp; beta = z.beta; gam = z.gam;
       fb->mN.resize(z.q); fb->mTp.resize(z.q); fb->mCell0.resize(z.q); fb->mSlot0.resize(z.q); fb->mDms.resize(z.q); fb->mHmm.resize(z.q); fb->mTrans.resize(z.q);
-      fb->slotState.resize(z.slot); fb->sQ.resize(z.slot); fb->slotStateU.resize(z.slotU); fb->cQ.resize(z.cell); fb->cI.resize(z.cell); fb->thrCell.resize(z.thr);
+      fb->slotState.resize(z.slot); fb->slotRange.resize(2 * z.slot); fb->sQ.resize(z.slot); fb->slotStateU.resize(z.slotU); fb->cQ.resize(z.cell); fb->cI.resize(z.cell); fb->thrCell.resize(z.thr);
       fb->tasks.resize(z.tasks); fb->tasksW.resize(z.tasksW);
       const int NSt = fb->m->NSt;
       fb->pool->run(nW, [&](int k) {
@@ -465,7 +482,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          for (ScoreTask &tk : C.tasksW) { tk.slot0 += (int)B.slot * NSt; tk.outBase += B.outp * NSt; }
          auto put = [](auto &dst, size_t at, const auto &src) { if (!src.empty()) memcpy(dst.data() + at, src.data(), sizeof(src[0]) * src.size()); };
          put(fb->mN, B.q, C.mN); put(fb->mTp, B.q, C.mTp); put(fb->mCell0, B.q, C.mCell0); put(fb->mSlot0, B.q, C.mSlot0); put(fb->mDms, B.q, C.mDms); put(fb->mHmm, B.q, C.mHmm);
-         put(fb->mTrans, B.q, C.mTrans); put(fb->slotState, B.slot, C.slotState); put(fb->sQ, B.slot, C.sQ); put(fb->slotStateU, B.slotU, C.slotStateU);
+         put(fb->mTrans, B.q, C.mTrans); put(fb->slotState, B.slot, C.slotState); put(fb->slotRange, 2 * B.slot, C.slotRange); put(fb->sQ, B.slot, C.sQ); put(fb->slotStateU, B.slotU, C.slotStateU);
          put(fb->cQ, B.cell, C.cQ); put(fb->cI, B.cell, C.cI); put(fb->thrCell, B.thr, C.thrCell); put(fb->tasks, B.tasks, C.tasks); put(fb->tasksW, B.tasksW, C.tasksW);
       });
    }
@@ -576,7 +593,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
          {&fb->d_uttList, fb->uttList.data(), sizeof(int) * fb->uttList.size(), 0}, {&fb->d_sQ, fb->sQ.data(), sizeof(short) * fb->sQ.size(), 0},
          {&fb->d_slotStateU, fb->slotStateU.data(), sizeof(int) * fb->slotStateU.size(), 0},
          {&fb->d_nextSame, fb->nextSame.data(), sizeof(int) * fb->nextSame.size(), 0},
-         {&fb->d_qBeamNP, fb->qBeamNP.data(), sizeof(int) * fb->qBeamNP.size(), 0},
+         {&fb->d_qBeamNP, fb->qBeamNP.data(), sizeof(int) * fb->qBeamNP.size(), 0}, {&fb->d_slotRange, fb->slotRange.data(), sizeof(int) * fb->slotRange.size(), 0},
          {&fb->d_wqStart, fb->wqStart.data(), sizeof(int) * fb->wqStart.size(), 0}};
       size_t total = 0;
       for (Part &q : parts) { q.off = total; total += (q.bytes + 255) & ~(size_t)255; }
@@ -627,6 +644,29 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
 
 extern "C" long long htkamd_fb_frame_states(const htkamd_fb *fb) { return fb ? fb->frameStates : 0; }
 
+extern "C" int htkamd_fb_score_work(const htkamd_fb *fb, long long out[3])
+{
+   if (!fb || !out) { htkamd_set_error("fb_score_work: NULL argument"); return HTKAMD_EINVAL; }
+   long long skip = 0, all = 0;
+   const bool ranges = fb->m->NSt == 1 && fb->slotRange.size() == 2 * fb->slotState.size();
+   for (const ScoreTask &tk : fb->tasksW) {
+      const int nPairs = (tk.nSlots + 1) >> 1;
+      for (int w = 0; w < B16_TASK_FRAMES / 32; w++) {
+         if (32 * w >= tk.nFrames) break;
+         all += nPairs;
+         if (!ranges) { skip += nPairs; continue; }
+         const int r0 = tk.frame0 + 32 * w, r1 = r0 + 31;
+         for (int j = 0; j < nPairs; j++) {
+            const int k0 = tk.slot0 + 2 * j, k1 = (2 * j + 1 < tk.nSlots) ? k0 + 1 : k0;
+            const int lo = std::min(fb->slotRange[2 * k0], fb->slotRange[2 * k1]), hi = std::max(fb->slotRange[2 * k0 + 1], fb->slotRange[2 * k1 + 1]);
+            if (lo <= r1 && hi >= r0) skip++;
+         }
+      }
+   }
+   out[0] = skip; out[1] = all; out[2] = (fb->frameStates + 63) / 64;
+   return HTKAMD_OK;
+}
+
 extern "C" int htkamd_fb_prepared_current(const htkamd_fb *fb) { return fb && fb->topoVersion == fb->m->topoVersion; }
 
 extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream)
@@ -650,6 +690,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
    if (wideTasks && m->NSt == 1 && fb->wqStart.size() == 9 && !getenv("HTKAMD_NO_XCDQ")) { sa.qStart = (const int *)fb->d_wqStart.p; sa.qCounters = (int *)fb->d_counter.p + 8; }
+   if (wideTasks && m->NSt == 1 && !getenv("HTKAMD_NO_TAPER_SKIP")) sa.slotRange = (const int *)fb->d_slotRange.p;      // (the switch: for A/B measurements)
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
    fb->f16Pass = (cfg->scoreMode & HTKAMD_SCORE_F16) != 0 && !m->tiedMix && sa.nTasks > 0;      // no tasks, no launch: nothing zeroes or raises the flag
    if (fb->f16Pass) {      // the pass's own range flag, behind the status words (zeroed with the task counter before it, by the launcher)

@@ -282,7 +282,18 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // first layout (selects on the slot's kind and block) was 1 700 vector instructions per task and wavefront against 890 in the pairs' loop,
 // on the issue port the matrix instructions share (profiles/README.md r05b).  Open dimensions between the constants: 20 at most, as before
 // (the second block's constant comes before its dimensions instead of after them).
-__device__ __host__ __forceinline__ int dense_D0(int D) { return D >> 1; }
+// Round 6: WHERE the accumulator of the leading products walks.  With both constants in the middle (pair floor(D / 2), round 5) it climbs
+// to +1/2 sum_{d < 19} mu^2 ivar (~ +110 in base-2 units on the headline set), drops to ~ -100 and climbs back: four of its five roundings
+// happen at ulp(64) = 7.6e-6, and the matrix unit cuts every product at the accumulator's last bit.  B16_LAYOUT 2: the accumulator STARTS at
+// the share of the first 16 dimensions (the pairs of the first two k-steps), I = -1/2 sum_{d < 16} mu^2 ivar, read from the tile beside
+// log w - 1/2 gConst; the constants' pair sits at pair PC = floor(4 D / 5) (the fourth k-step) and holds the shares of dimensions 16 .. PC - 1
+// and PC .. D - 1.  The walk is then  I -> ~I/2 -> -Q16 (complete squares) -> ~+I/2 -> ~-I/2 -> -Q : never beyond half of what it was.
+// B16_LAYOUT 0 keeps round 5's placement (no start value, constants at pair floor(D / 2)) for comparisons.
+#ifndef B16_LAYOUT
+#define B16_LAYOUT 2
+#endif
+__device__ __host__ __forceinline__ int dense_D0(int D) { return B16_LAYOUT == 2 ? (4 * D) / 5 : D >> 1; }      // the constants' pair
+__device__ __host__ __forceinline__ int dense_NI(int D) { return B16_LAYOUT == 2 ? 16 : 0; }                   // dimensions whose share the accumulator starts from
 __device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)      // kind 0: x^2, 1: x, 2: first constant, 3: second constant, -1: padding
 {
    const int D0 = dense_D0(D);
@@ -292,6 +303,14 @@ __device__ __forceinline__ void dense_slot(int k, int D, int &dim, int &kind)   
    if (j == D0) kind = 2 + (k & 1);
    if (dim >= D && j != D0) kind = -1;
    if (kind >= 2 || kind < 0) dim = 0;
+}
+// the dimensions a constant stands for: which = 0 the accumulator's start, 1 / 2 the first / second constant of the pair
+__device__ __forceinline__ void dense_const_range(int which, int D, int &lo, int &hi)
+{
+   const int NI = dense_NI(D), D0 = dense_D0(D);
+   lo = which == 0 ? 0 : which == 1 ? NI : D0;
+   hi = which == 0 ? NI : which == 1 ? D0 : D;
+   if (hi < lo) hi = lo;
 }
 
 // workgroups per CU by registers and LDS: six k-steps 180 registers / 60 KB -> 2; five 168 / 51 KB -> 3 (measured against 2: DESIGN §4); four 152 / 40 KB -> 3; two 111 / 20 KB -> 4
@@ -325,8 +344,9 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
    static_assert(B16_TASK_FRAMES == 128, "four wavefronts x 32 frames");
    constexpr bool DENSE = (KS & 1) != 0;
    constexpr int NC = (KS + 1) / 2;
-   constexpr int TW4 = KS * 3 * 32 + 4;                // 16-byte words per tile in the table
-   constexpr int PW4 = KS * 3 * 64 + 8;                // ... per pair in LDS
+   constexpr int CW = DENSE ? 8 : 4;                   // 16-byte words of per-component constants in a tile: log w - 0.5 gConst; dense: then the accumulator's start
+   constexpr int TW4 = KS * 3 * 32 + CW;               // 16-byte words per tile in the table
+   constexpr int PW4 = KS * 3 * 64 + 2 * CW;           // ... per pair in LDS
    __shared__ u4 wbuf[2][PW4];
    __shared__ float xbuf[128 * (DENSE ? 8 * KS : 15 * NC)];      // the task's 128 feature rows (D <= 15 NC; dense: 2 D + 2 <= 16 KS), as they lie in memory
    __shared__ int taskSh;
@@ -383,7 +403,9 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             const int r = __builtin_amdgcn_readfirstlane(r0 + wv);
             if (r < KS * 3) GLDS16((const char *)tab + (off + (unsigned int)r * 512u), &wbuf[bufi][r * 64]);
          }
-         if (wv == 3 && lane < 8) GLDS16((const char *)tab + (((unsigned int)((lane >> 2) ? tB : tA) * TW4 + KS * 96 + (lane & 3)) * 16u), &wbuf[bufi][KS * 192]);
+         // the two states' constants: LDS words [A's four | B's four], dense: then [A's start values | B's]
+         if (wv == 3 && lane < 2 * CW)
+            GLDS16((const char *)tab + (((unsigned int)(((lane >> 2) & 1) ? tB : tA) * TW4 + KS * 96 + (lane >> 3) * 4 + (lane & 3)) * 16u), &wbuf[bufi][KS * 192]);
       };
       stage_pair(0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,18 +479,52 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
 
       B16_STAMP(2);
       int buf = 0;
-      float *o = a.out + tk.outBase + (size_t)(tk.outSlot0 + kh) * tk.ldo + fw + fcol;      // this lane's state (kh of the pair) and frame
+      float *oPrev = a.out + tk.outBase + (size_t)(tk.outSlot0 + kh) * tk.ldo + fw + fcol;      // this lane's state (kh of the pair) and frame: the pair BEFORE the round's
       const size_t oStep = 2 * (size_t)tk.ldo;
+      oPrev -= oStep;
+      float *oQ = oPrev;
       float yP[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) yP[r] = 0.0f;
       float resQ = 0.0f;                                // the result of the pair before the last one: stored at the top of the next round, so
       bool haveQ = false;                               // that the store is long done where the round's staging is waited for (vmcnt counts both)
+      bool prevAct = false;                             // the pair before this round's was computed: its sums are in yP
+      // the last pair's log-sum-exp and that of a pair behind which this wavefront sits a round out: the same maxima, the same tree of sums as the slices
+      auto lse_full = [&]() {
+         float m8[8], m4[4];
+#pragma unroll
+         for (int r = 0; r < 8; r++) m8[r] = fmaxf(yP[r], yP[r + 8]);
+#pragma unroll
+         for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]);
+         const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+         float e[16];
+#pragma unroll
+         for (int r = 0; r < 16; r++) e[r] = EXP2(yP[r] - mx);
+#pragma unroll
+         for (int r = 0; r < 8; r++) e[r] += e[r + 8];
+#pragma unroll
+         for (int r = 0; r < 4; r++) e[r] += e[r + 4];
+         const float sm = (e[0] + e[1]) + (e[2] + e[3]);
+         return (mx + LOG2(sm)) * 0.69314718055994531f;
+      };
+      // Setotprob's ranges per chain state (HFB.c:1014 with 1177 / 1215; ScoreArgs::slotRange): a wavefront whose 32 frames lie outside the
+      // ranges of BOTH states of a pair leaves the pair's products, log-sum-exp and store out -- it stages, and waits at the barrier
+      int rLoV = 0x7fffffff, rHiV = -1;
+      if (a.slotRange && lane < tk.nSlots) { const int2 rr = ((const int2 *)a.slotRange)[tk.slot0 + lane]; rLoV = rr.x; rHiV = rr.y; }
+      const int wRow0 = tk.frame0 + fw, wRow1 = wRow0 + 31;
       for (int j = 0; j < nPairs; j++) {
          const bool more = j + 1 < nPairs;
-         if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
+         bool actJ = active;
+         if (a.slotRange) {
+            const int lo0 = __builtin_amdgcn_readlane(rLoV, (2 * j) & 63), lo1 = __builtin_amdgcn_readlane(rLoV, (2 * j + 1) & 63);
+            const int hi0 = __builtin_amdgcn_readlane(rHiV, (2 * j) & 63), hi1 = __builtin_amdgcn_readlane(rHiV, (2 * j + 1) & 63);
+            actJ = active && (lo0 < lo1 ? lo0 : lo1) <= wRow1 && (hi0 > hi1 ? hi0 : hi1) >= wRow0;
+         }
+         if (haveQ) { if (fw + fcol < tk.nFrames) *oQ = resQ; haveQ = false; }
          if (more && !(B16_ABL & 8)) stage_pair(j + 1, buf ^ 1);
-         if (active) {
+         if (!actJ) {
+            if (prevAct) { resQ = lse_full(); oQ = oPrev; haveQ = true; }
+         } else {
             // the log-sum-exp of the pair BEFORE this one (left in yP) in 18 slices, written between the matrix instructions of this pair (the
             // compiler places them: pinning every slice with sched_barrier cost 16 registers and 1 % at three workgroups per CU)
             // (the sum's tree is ((e_k + e_k+8) + (e_k+4 + e_k+12)) for k = 0 .. 3, then (E0 + E1) + (E2 + E3): the exponentials are taken in
@@ -508,6 +564,14 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             f16v Cx, Cc;
 #pragma unroll
             for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }      // (no instructions: the first product of each takes the constant 0)
+            if constexpr (DENSE && B16_LAYOUT == 2) {                        // the leading products start from the share of the first 16 dimensions (dense_NI)
+#pragma unroll
+               for (int b = 0; b < 4; b++) {
+                  const f4 c0 = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + 8 + kh * 4 + b]);
+#pragma unroll
+                  for (int r = 0; r < 4; r++) Cx[4 * b + r] = c0[r];
+               }
+            }
             bf8 wa[KS][3];
 #pragma unroll
             for (int s = 0; s < 3; s++) wa[0][s] = __builtin_bit_cast(bf8, wbuf[buf][(0 * 3 + s) * 64 + lane]);
@@ -532,7 +596,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             else
             for (int sl = 3 * KS; sl < 18; sl++) lse_slice(sl);      // (fewer than 6 k-steps: the rest of the slices)
             asm volatile("" : "+v"(resP));
-            resQ = resP; haveQ = j > 0;                  // (the pair before always has both its states)
+            resQ = resP; oQ = oPrev; haveQ = prevAct;    // (the pair before always has both its states)
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                const f4 ci = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + kh * 4 + b]);
@@ -540,6 +604,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
                for (int r = 0; r < 4; r++) yP[4 * b + r] = (Cx[4 * b + r] + Cc[4 * b + r]) + ci[r];
             }
          }
+         prevAct = actJ; oPrev += oStep;
 #if !(B16_ABL & 1)
          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next pair's rows have landed (issued a whole round ago)
          __syncthreads();
@@ -550,23 +615,10 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
 #ifdef B16_CLK
       if (tid == 0) clkAcc[4] += (unsigned long long)nPairs;
 #endif
-      if (active && haveQ) { if (fw + fcol < tk.nFrames) *o = resQ; o += oStep; }
-      if (active) {                                    // the last pair's log-sum-exp
-         float m8[8], m4[4];
-#pragma unroll
-         for (int r = 0; r < 8; r++) m8[r] = fmaxf(yP[r], yP[r + 8]);
-#pragma unroll
-         for (int r = 0; r < 4; r++) m4[r] = fmaxf(m8[r], m8[r + 4]);
-         const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-         float e[16];
-#pragma unroll
-         for (int r = 0; r < 16; r++) e[r] = EXP2(yP[r] - mx);
-#pragma unroll
-         for (int r = 0; r < 8; r++) e[r] += e[r + 8];
-#pragma unroll
-         for (int r = 0; r < 4; r++) e[r] += e[r + 4];
-         const float sm = (e[0] + e[1]) + (e[2] + e[3]);
-         if (fw + fcol < tk.nFrames && 2 * (nPairs - 1) + kh < tk.nSlots) *o = (mx + LOG2(sm)) * 0.69314718055994531f;
+      if (haveQ) { if (fw + fcol < tk.nFrames) *oQ = resQ; }
+      if (prevAct) {                                   // the last pair's log-sum-exp
+         const float res = lse_full();
+         if (fw + fcol < tk.nFrames && 2 * (nPairs - 1) + kh < tk.nSlots) *oPrev = res;
       }
    }
 #ifdef B16_CLK
@@ -700,13 +752,18 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
    const int t = idx / (KS * 32), r = idx - t * (KS * 32), ks = r >> 5, khf = (r >> 4) & 1, rowc = r & 15;
    const int s = a.tileState[t], c0 = a.stateCompOff[s], c1 = a.stateCompOff[s + 1];
    const int c = c0 + 16 * (t - a.stateTileOff[s]) + rowc;
-   const size_t tileShorts = ((size_t)KS * 3 * 32 + 4) * 8;
+   const size_t tileShorts = ((size_t)KS * 3 * 32 + 8) * 8;
    unsigned short *T = a.tab + (size_t)t * tileShorts;
    const bool live = c < c1 && (c1 - c0 == 1 || a.compLogWt[c] > (float)LMINMIX);
    const double L2E = 1.4426950408889634;
    const float *mu = nullptr, *iv = nullptr;
    if (live) { const int g = a.compGauss[c]; mu = a.mean + (size_t)g * D; iv = a.ivar + (size_t)g * D; }
-   const int D0 = dense_D0(D);
+   auto share = [&](int which) {                           // -0.5 sum mu^2 ivar over the dimensions constant `which` stands for (dense_const_range)
+      int lo, hi; dense_const_range(which, D, lo, hi);
+      double q = 0.0;
+      for (int i = lo; i < hi; i++) q += (double)mu[i] * mu[i] * iv[i];
+      return (float)(-0.5 * q * L2E);
+   };
    unsigned short p[3][8];
 #pragma unroll
    for (int j = 0; j < 8; j++) {
@@ -715,11 +772,7 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
       float v = 0.0f;
       if (live && kind == 0) v = (float)(-0.5 * (double)iv[dim] * L2E);
       else if (live && kind == 1) v = (float)((double)mu[dim] * iv[dim] * L2E);
-      else if (live && kind >= 2) {                         // against B's constant 1: -0.5 sum mu^2 ivar over the block
-         double q = 0.0;
-         for (int i = (kind == 2 ? 0 : D0); i < (kind == 2 ? D0 : D); i++) q += (double)mu[i] * mu[i] * iv[i];
-         v = (float)(-0.5 * q * L2E);
-      }
+      else if (live && kind >= 2) v = share(kind - 1);      // against B's constant 1
       split3(v, p[0][j], p[1][j], p[2][j]);
    }
 #pragma unroll
@@ -736,6 +789,7 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
          ci = (float)(((c1 - c0 == 1 ? 0.0 : (double)a.compLogWt[c]) - 0.5 * k0) * L2E);
       }
       ((float *)(T + (size_t)KS * 3 * 32 * 8))[rowc] = ci;
+      ((float *)(T + (size_t)KS * 3 * 32 * 8))[16 + rowc] = live ? share(0) : 0.0f;      // the accumulator's start
    }
 }
 
@@ -746,13 +800,13 @@ __global__ void k_build_bf16tab_dense(Bf16TabArgs a, int nTiles, int KS)
 #define BT_TILES 4
 __global__ __launch_bounds__(256) void k_build_bf16tab_dense_lds(Bf16TabArgs a, int nTiles, int KS)
 {
-   extern __shared__ float btRows[];                         // [BT_TILES*16][2][D] (mu, ivar), then [BT_TILES*16][2] constants (float), then [BT_TILES*16] live flags
-   const int D = a.D, D0 = dense_D0(D);
+   extern __shared__ float btRows[];                         // [BT_TILES*16][2][D] (mu, ivar), then [BT_TILES*16][3] constants (float: start, first, second), then [BT_TILES*16] live flags
+   const int D = a.D;
    const int t0 = blockIdx.x * BT_TILES;
    const int nT = (nTiles - t0 < BT_TILES) ? nTiles - t0 : BT_TILES;
    const int nR = nT * 16;
    float *qc = btRows + (size_t)BT_TILES * 16 * 2 * D;
-   int *gOf = (int *)(qc + BT_TILES * 16 * 2);               // the row's Gaussian, -1: not live
+   int *gOf = (int *)(qc + BT_TILES * 16 * 3);               // the row's Gaussian, -1: not live
    int *cOf = gOf + BT_TILES * 16;
    const double L2E = 1.4426950408889634;
    if ((int)threadIdx.x < nR) {
@@ -771,15 +825,16 @@ __global__ __launch_bounds__(256) void k_build_bf16tab_dense_lds(Bf16TabArgs a, 
       btRows[(size_t)(2 * r) * D + d] = mu; btRows[(size_t)(2 * r + 1) * D + d] = iv;
    }
    __syncthreads();
-   if ((int)threadIdx.x < 2 * nR) {
-      const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+   if ((int)threadIdx.x < 3 * nR) {
+      const int r = threadIdx.x / 3, h = threadIdx.x - 3 * r;
       const float *mu = btRows + (size_t)(2 * r) * D, *iv = mu + D;
+      int lo, hi; dense_const_range(h, D, lo, hi);
       double q = 0.0;
-      for (int i = (h ? D0 : 0); i < (h ? D : D0); i++) q += (double)mu[i] * mu[i] * iv[i];
+      for (int i = lo; i < hi; i++) q += (double)mu[i] * mu[i] * iv[i];
       qc[threadIdx.x] = (float)(-0.5 * q * L2E);
    }
    __syncthreads();
-   const size_t tileShorts = ((size_t)KS * 3 * 32 + 4) * 8;
+   const size_t tileShorts = ((size_t)KS * 3 * 32 + 8) * 8;
    for (int w = threadIdx.x; w < nT * KS * 32; w += blockDim.x) {
       const int tl = w / (KS * 32), r = w - tl * (KS * 32), ks = r >> 5, khf = (r >> 4) & 1, rowc = r & 15;
       const int row = tl * 16 + rowc;
@@ -794,7 +849,7 @@ __global__ __launch_bounds__(256) void k_build_bf16tab_dense_lds(Bf16TabArgs a, 
          float v = 0.0f;
          if (live && kind == 0) v = (float)(-0.5 * (double)iv[dim] * L2E);
          else if (live && kind == 1) v = (float)((double)mu[dim] * iv[dim] * L2E);
-         else if (live && kind >= 2) v = qc[2 * row + (kind - 2)];
+         else if (live && kind >= 2) v = qc[3 * row + (kind - 1)];
          split3(v, p[0][j], p[1][j], p[2][j]);
       }
 #pragma unroll
@@ -812,6 +867,7 @@ __global__ __launch_bounds__(256) void k_build_bf16tab_dense_lds(Bf16TabArgs a, 
             ci = (float)(((cc < 0 ? 0.0 : (double)a.compLogWt[cc]) - 0.5 * k0) * L2E);
          }
          ((float *)(T + (size_t)KS * 3 * 32 * 8))[rowc] = ci;
+         ((float *)(T + (size_t)KS * 3 * 32 * 8))[16 + rowc] = live ? qc[3 * row] : 0.0f;      // the accumulator's start
       }
    }
 }
@@ -824,7 +880,7 @@ int htkamd_model_refresh_bf16_device(htkamd_model *m, void *stream)
    t.D = m->D; t.NC = m->bf16NC; t.S = m->S; t.stateCompOff = m->d_stateCompOff; t.stateTileOff = m->d_stateTileOff; t.compGauss = m->d_compGauss; t.tileState = m->d_tileState;
    t.mean = m->d_mean; t.ivar = m->d_ivar; t.gconst = m->d_gconst; t.compLogWt = m->d_compLogWt; t.tab = (unsigned short *)m->d_bf16Tab;
    const int n = m->nTiles * m->bf16NC * 64;
-   const size_t ldsDense = sizeof(float) * ((size_t)BT_TILES * 16 * 2 * m->D + BT_TILES * 16 * 2) + sizeof(int) * BT_TILES * 16 * 2;
+   const size_t ldsDense = sizeof(float) * ((size_t)BT_TILES * 16 * 2 * m->D + BT_TILES * 16 * 3) + sizeof(int) * BT_TILES * 16 * 2;
    if (m->f16Wide && m->bf16Dense && ldsDense <= 60 * 1024 && !getenv("HTKAMD_TAB_GATHER"))
       hipLaunchKernelGGL(k_build_bf16tab_dense_lds, dim3((m->nTiles + BT_TILES - 1) / BT_TILES), dim3(256), ldsDense, s, t, m->nTiles, 5);
    else if (m->f16Wide && m->bf16Dense) hipLaunchKernelGGL(k_build_bf16tab_dense, dim3((m->nTiles * 5 * 32 + 255) / 256), dim3(256), 0, s, t, m->nTiles, 5);

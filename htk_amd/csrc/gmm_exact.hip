@@ -88,6 +88,22 @@ __global__ __launch_bounds__(256) void k_score_exact(ScoreArgs a)
                const float wt = compLogWt[c];
                if (wt > (float)LMINMIX) {       // wave-uniform branch
                   cfloat *P = (cfloat *)(a.gparam + (size_t)compGauss[c] * a.PS);
+#ifdef EX_TRUTH                                         /* diagnostic build: float64 arithmetic on the same fp32 parameters -- what a scorer without rounding error
+                                                           would hand the recursions (tools/r06_parvar.sh: the floor of the tolerance class against the reference's floats) */
+                  {
+                     double s0 = P[2 * D], s1 = P[2 * D];
+#pragma unroll
+                     for (int i = 0; i < D; i++) {
+                        const double mu = P[2 * i], iv = P[2 * i + 1];
+                        const double d0 = (double)x[i].x - mu, d1 = (double)x[i].y - mu;
+                        s0 += d0 * d0 * iv; s1 += d1 * d1 * iv;
+                     }
+                     dacc0 = ladd_tab(dacc0, (double)wt - 0.5 * s0, mle, tab);
+                     dacc1 = ladd_tab(dacc1, (double)wt - 0.5 * s1, mle, tab);
+                     acc0 = (float)dacc0; acc1 = (float)dacc1;
+                     continue;
+                  }
+#endif
                   v2f sum = {P[2 * D], P[2 * D]};
 #pragma unroll
                   for (int i = 0; i < D; i++) {

@@ -51,6 +51,9 @@ struct ScoreArgs {
    // state chunk -- which stream the same 64 table tiles -- are pulled by workgroups behind the same L2); qStart[9], qCounters[8]; NULL: one queue
    const int *qStart = nullptr;
    int *qCounters = nullptr;
+   // forward-backward, k_score_bf16w / k_score_f16w: per entry of slotState the first and the last row of X in which Setotprob of the un-pruned
+   // pass evaluates the chain state (HFB.c:1014, 1177, 1215) -- [2] ints per slot; NULL (block scoring, decoders): every frame of a task
+   const int *slotRange = nullptr;
 };
 
 // evStart/evStop (may be NULL): updated with the dispatch's own start and stop time (hipExtLaunchKernel), i.e. without the time

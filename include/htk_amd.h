@@ -523,6 +523,11 @@ int  htkamd_fb_set_event_mode(htkamd_fb *fb, int mode);
 /* the last pass's mixture statistics in units (UpMixParms HFB.c:1573-1721): out[0] (frame, state) pairs past the MINFORPROB prune, out[1] (frame,
    state, component) triples accumulated; -1 where the pass did not count them (sets of several streams, states of more than 16 components) */
 int  htkamd_fb_mix_counts(htkamd_fb *fb, long long out[2]);
+/* the prepared batch's work on the matrix cores, counted on the host from its task list (the 32 x 32 x 16 pair kernels, one state per
+   16-component tile): out[0] matrix instructions (per operand-piece product and k-step 1; multiply by the kernel's 6 x 5 or 3 x 5) a pass
+   issues per (wavefront, pair of states) it does not sit out, out[1] the same with every wavefront of a task working on every pair (before the
+   per-state frame ranges of Setotprob, HFB.c:1014, reached the kernel), out[2] what the (frame, chain state) evaluations need: units / 64 */
+int  htkamd_fb_score_work(const htkamd_fb *fb, long long out[3]);
 
 /* ------------------------------------------------------------------------------------------
  * Viterbi forced alignment of a batch (HVite -a): replaces, per utterance, the frame loop of

@@ -217,6 +217,45 @@ def test_mfma_forward_backward_within_tolerance(native, name, mode):
     assert np.allclose(p["compWeight"], np.asarray(upd["compWeight"], np.float64), rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("mode", [6, 34], ids=["bf16x3fast", "fastest"])
+def test_scoring_sits_out_what_setotprob_never_evaluates(native, oracle, mode, monkeypatch):
+    """The pair kernels leave out, wavefront by wavefront, the (32 frames, pair of chain states) blocks that lie outside Setotprob's ranges
+    of the un-pruned pass (HFB.c:1014 with 1177 / 1215: model q at frame t only for qLo-1 <= q <= qHi).  Nothing that the recursions read
+    may change: log-probabilities and every beta / alpha the reference holds are bit-equal with and without the skip, the accumulators equal
+    to the order of the atomics, and the log-probabilities are the oracle's."""
+    from htk_amd import synth
+    from util import batch_arrays
+    s = synth.generate(60, 4, 45, 5, 420, 77)                      # 35 models = 105 chain states: two chunks of states, four tiles of frames, a taper that cuts through both
+    s.feats[3] = s.feats[3][:300]; s.seqs[3] = s.seqs[3][:25]      # ragged
+    pk = s.packed()
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    runs = {}
+    for skip in (False, True):
+        if skip:
+            monkeypatch.delenv("HTKAMD_NO_TAPER_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("HTKAMD_NO_TAPER_SKIP", "1")
+        model, fb, acc, pr, st = run_fb(native, pk, utts, scoreMode=mode)
+        assert (st == 1).all()
+        runs[skip] = (pr, [fb.trellis(u) for u in range(len(utts))], acc.download(), fb.score_work())
+    (pr0, tr0, a0, w0), (pr1, tr1, a1, w1) = runs[False], runs[True]
+    assert np.array_equal(pr0, pr1)
+    for g0, g1 in zip(tr0, tr1):
+        for k in ("beta", "alpha"):
+            assert np.array_equal(np.isnan(g0[k]), np.isnan(g1[k])) and np.array_equal(g0[k][~np.isnan(g0[k])], g1[k][~np.isnan(g1[k])]), k
+        for k in ("qLo", "qHi", "aLo", "aHi"):
+            assert np.array_equal(g0[k], g1[k])
+    for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+        assert np.allclose(a0[k], a1[k], rtol=1e-11, atol=1e-13), k
+    issued, everything, needed = w1
+    assert needed <= issued < everything and w0[:2] == (issued, everything), (w0, w1)      # (the count is the batch's, not the switch's)
+    om, oacc, ocfg = oracle.Model(pk), None, oracle.fb_cfg()
+    oacc = oracle.Accs(om)
+    for u, ut in enumerate(utts):
+        rc, opr, _ = oracle.fb_utt(om, ocfg, ut["feat"], ut["seq"], oacc)
+        assert rc == 1 and abs(opr - pr1[u]) <= 1e-6 * abs(opr)
+
+
 # ----------------------------------------------------------------------------------------- forward-backward
 @pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", CASES)
