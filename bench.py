@@ -370,6 +370,9 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the reference CPU baseline (0 = one per physical host core)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="1: also time forced alignment and network decoding at the same set after the timed region (N = 1 only; reported as other_paths)")
+    ap.add_argument("--exchange-slices", type=int, default=4,
+                    help="N > 1 only: the accumulator exchange of an iteration in this many parts by tied state -- a part travels (on a stream of its own) while the next "
+                         "range of states' mixture statistics is still being summed (htkamd_fb_execute_begin / _mix); 1: one all-reduce behind the pass")
     ap.add_argument("--wire", choices=["f32", "f64"], default="f32",
                     help="N > 1: the accumulator statistics on the wire as fp32 (every rank rounds its fp64 partial sums once; counters stay fp64) or fp64")
     ap.add_argument("--dump-model", default=None, help="rank 0 writes the model of the last iteration (npz: mean, var, compWeight, transP) -- the multi-GPU tests compare it over rank counts")
@@ -447,6 +450,49 @@ def main():
     wire_buf = torch.empty(wire_bulk, dtype=torch.float32, device=acc_t.device) if (world > 1 and args.wire == "f32") else None
     def exchange():
         herest.all_reduce_accumulators(acc_t, wire=args.wire, bulk=wire_bulk, staging=wire_buf)
+    # The same exchange in parts (--exchange-slices): tied states [S i / n, S (i + 1) / n) own a range each of mu / muOcc / va / vaOcc / wt /
+    # wtOcc (htkamd_accs_state_ranges); the last part also carries what no state owns (tr, trOcc) and the fp64 counters.  Part i is packed,
+    # summed and unpacked on `comm_stream` as soon as the mixture statistics of its states are done, while part i + 1's are being summed.
+    n_slices = max(1, args.exchange_slices) if (world > 1 and max(1, args.chunks) == 1) else 1
+    part_ranges, part_pos, part_states = [], [], []
+    if n_slices > 1:
+        try:
+            S_ = int(pk["numStates"]); pos_ = 0
+            for i_ in range(n_slices):
+                s0_, s1_ = S_ * i_ // n_slices, S_ * (i_ + 1) // n_slices
+                rg_ = accs.state_ranges(s0_, s1_, with_rest=(i_ == n_slices - 1))
+                part_states.append((s0_, s1_)); part_ranges.append(rg_); part_pos.append(pos_)
+                pos_ += (sum(l_ for _, l_ in rg_) + 63) & ~63
+            assert pos_ <= wire_bulk + 64 * n_slices
+        except capi.HtkAmdError:                           # a set whose Gaussians are not in state order: the vector travels whole
+            n_slices = 1
+    comm_stream = torch.cuda.Stream() if n_slices > 1 else None
+    ev_part = [torch.cuda.Event() for _ in range(n_slices)] if n_slices > 1 else []
+    part_buf = (torch.empty(wire_bulk + 64 * n_slices, dtype=torch.float32 if args.wire == "f32" else torch.float64, device=acc_t.device) if n_slices > 1 else None)
+
+    def pass_with_exchange(fb, ln):
+        """The pass on stream `ln`; with --exchange-slices the exchange too, part by part behind the ranges of states.  True: the accumulators are summed
+        over the ranks when the work queued here is done (`stream` waits for it); False: the caller exchanges them."""
+        if n_slices <= 1:
+            fb.execute(cfg, accs, ln.cuda_stream)
+            return False
+        if not fb.execute_begin(cfg, accs, ln.cuda_stream):
+            return False                                   # a pass of another kind: complete, nothing deferred
+        wcode = 1 if args.wire == "f32" else 0
+        for i_, (s0_, s1_) in enumerate(part_states):
+            fb.execute_mix(s0_, s1_, ln.cuda_stream)
+            ev_part[i_].record(ln)
+            comm_stream.wait_event(ev_part[i_])
+            with torch.cuda.stream(comm_stream):
+                n_ = sum(l_ for _, l_ in part_ranges[i_])
+                buf_ = part_buf[part_pos[i_]:part_pos[i_] + n_]
+                accs.pack_ranges(part_ranges[i_], wcode, buf_.data_ptr(), comm_stream.cuda_stream)
+                dist.all_reduce(buf_, op=dist.ReduceOp.SUM)
+                accs.unpack_ranges(part_ranges[i_], wcode, buf_.data_ptr(), comm_stream.cuda_stream)
+                if i_ == n_slices - 1:
+                    dist.all_reduce(acc_t[wire_bulk:], op=dist.ReduceOp.SUM)      # nEgs, totalPr, totalT, the counters: fp64
+        ln.wait_stream(comm_stream)
+        return True
     # A step is one EM ITERATION of HERest over the rank's shard, nothing left out and nothing carried over from the step before:
     #   ZeroAccs -> [CreateInsts/SetBeamTaper on the host, K1 scoring, K2 beta, K3 alpha + occupation/transition counts, K4 mixture
     #   statistics] -> all-reduce(sum) of the accumulator vector over the ranks -> UpdateModels + rebuild of every scoring table on the
@@ -498,7 +544,7 @@ def main():
             if not (ch["ready"][k] and ch["fbs"][k].prepared_current()):
                 prep(ch, k, ln.cuda_stream)
                 n_reprepared[0] += int(timed)
-            ch["fbs"][k].execute(cfg, accs, ln.cuda_stream)
+            exchanged = pass_with_exchange(ch["fbs"][k], ln)
             ev_chunk[c].record(ln)
         for c, ch in enumerate(chunks):                                        # the kernels are running: next iteration's tables, uploaded on a
             prep(ch, k ^ 1, copy_stream.cuda_stream)                           # stream of their own (htkamd_fb_execute waits for the copy's event)
@@ -506,7 +552,7 @@ def main():
             stream.wait_event(ev_chunk[c])
         if parts is not None:
             stream.synchronize(); t.append(time.perf_counter())
-        if world > 1:
+        if world > 1 and not exchanged:
             exchange()                              # the iteration's one exchange: RCCL sum over xGMI
         if parts is not None:
             stream.synchronize(); t.append(time.perf_counter())
@@ -580,11 +626,12 @@ def main():
             if not (ch["ready"][k] and ch["fbs"][k].prepared_current()):
                 prep(ch, k, ln.cuda_stream)
                 n_reprepared[0] += int(timed)
-            ch["fbs"][k].execute(cfg, accs, ln.cuda_stream)
+            exchanged = pass_with_exchange(ch["fbs"][k], ln)
             ch["fbs"][k].results_begin(ln.cuda_stream)                          # the results' copy in stream order behind the pass
             ev_chunk[c].record(ln)
         for c in range(NCH):
             stream.wait_event(ev_chunk[c])
+        return exchanged
 
     def collect(k):
         try:
@@ -622,18 +669,18 @@ def main():
             kk = it_no[0] & 1
             it_no[0] += 1
             th = [time.perf_counter()]
-            launch_pass(kk, True)
+            exchanged = launch_pass(kk, True)
             th.append(time.perf_counter())
             if pending:
                 st_upd = model.update_device_end()
                 th.append(time.perf_counter())
                 if not all(ch["fbs"][kk].prepared_current() for ch in chunks):      # a minimum duration changed under the pass just queued
                     stream.synchronize()
-                    launch_pass(kk, True)
+                    exchanged = launch_pass(kk, True)
                 pr, st, kt = collect(prev_k)
                 ktimes += kt
                 th.append(time.perf_counter())
-            if world > 1:
+            if world > 1 and not exchanged:
                 exchange()
             model.update_device_begin(accs, stream=sptr, **upd)
             pending, prev_k = True, kk
@@ -811,8 +858,9 @@ def main():
         mi_blk = {"bf16": 30 if (31 <= D <= 39 and args.mix <= 16 and not os.environ.get("HTKAMD_BF16_CHUNKED")) else 36, "fastest": 15}.get(args.score)
         score_work = {"unit": "(wavefront of 32 frames, pair of chain states) blocks per pass", "issued": int(sw[0]), "issued_without_frame_ranges": int(sw[1]),
                       "needed": int(sw[2]), "needed_over_issued": float(sw[2]) / max(float(sw[0]), 1.0),
-                      "frame_ranges_in_kernel": not os.environ.get("HTKAMD_NO_TAPER_SKIP"),
-                      "matrix_instructions_per_block": mi_blk, "mfma_issued": int(sw[0]) * mi_blk if mi_blk else None, "mfma_needed": int(sw[2]) * mi_blk if mi_blk else None}
+                      "frame_ranges_in_kernel": args.score == "bf16" and not os.environ.get("HTKAMD_NO_TAPER_SKIP"),      # (k_score_f16w works on every block of its tasks: the skip cost it 7 %)
+                      "matrix_instructions_per_block": mi_blk, "mfma_issued": int(sw[0 if args.score == "bf16" else 1]) * mi_blk if mi_blk else None,
+                      "mfma_needed": int(sw[2]) * mi_blk if mi_blk else None}
         dom = max(("score", "beta", "alpha", "stats"), key=lambda k_: per_kernel[k_]["ms"])
         out = {
             "metric": "herest_gmm_frame_state_loglik_per_sec",
@@ -835,6 +883,7 @@ def main():
                                    "%d x %d-frame utterances per GPU (BASELINE config[2]: 10k utterances sharded 8-way)" % (args.states, args.mix, args.utts, args.frames),
                        "states": args.states, "mix": args.mix, "utts_per_gpu": args.utts, "frames": args.frames, "chunks": NCH,
                        "update": "HERest -m 3 -v %g, on the device" % args.min_var,
+                       "exchange_slices": (n_slices if world > 1 else None),      # parts the exchange travels in, each behind its range of states (1: one all-reduce behind the pass)
                        "wire": (args.wire if world > 1 else None),      # (the C library's htkamd_accs_allreduce defaults to fp64; tools/herest --wire f32 is this exchange)
                        "parallelism": "utterance shards, 1 all-reduce of %d accumulators per iteration (%s on the wire)" % (vec_n, args.wire if world > 1 else "no exchange at N = 1")},
             "herest_utterances_per_sec": utts_total * args.steps / dt,

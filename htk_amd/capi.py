@@ -292,6 +292,24 @@ class Accs:
         """One rank's share of the fp32-on-the-wire exchange (htkamd_accs_allreduce_wire, HTKAMD_WIRE_F32): the statistics rounded to float once."""
         check(lib().htkamd_accs_wire_round(self.h, _stream(stream)), "accs_wire_round")
 
+    def state_ranges(self, state0: int, state1: int, with_rest: bool = False):
+        """htkamd_accs_state_ranges: [(offset, length)] of the vector's ranges that belong to tied states [state0, state1) (+ tr / trOcc with with_rest)"""
+        off = (C.c_size_t * 7)(); ln = (C.c_size_t * 7)(); n = C.c_int(0)
+        check(lib().htkamd_accs_state_ranges(self.h, C.c_int(state0), C.c_int(state1), C.c_int(int(with_rest)), off, ln, C.byref(n)), "accs_state_ranges")
+        return [(int(off[k]), int(ln[k])) for k in range(n.value)]
+
+    def _ranges(self, fn, ranges, wire, ptr, stream):
+        n = len(ranges)
+        off = (C.c_size_t * max(n, 1))(*[r[0] for r in ranges]); ln = (C.c_size_t * max(n, 1))(*[r[1] for r in ranges])
+        check(fn(self.h, C.c_int(n), off, ln, C.c_int(wire), C.c_void_p(ptr), _stream(stream)), "accs ranges")
+
+    def pack_ranges(self, ranges, wire: int, dst_ptr: int, stream=None):
+        """htkamd_accs_pack_ranges: the ranges one behind the other into device memory at dst_ptr, as floats (wire = 1) or doubles (0)"""
+        self._ranges(lib().htkamd_accs_pack_ranges, ranges, wire, dst_ptr, stream)
+
+    def unpack_ranges(self, ranges, wire: int, src_ptr: int, stream=None):
+        self._ranges(lib().htkamd_accs_unpack_ranges, ranges, wire, src_ptr, stream)
+
     def split(self, v: np.ndarray) -> dict:
         m, L = self.model, self.lay
         GD = m.G * m.D
@@ -342,6 +360,16 @@ class ForwardBackward:
 
     def execute(self, cfg: FbConfig, accs: Accs, stream=None):
         check(lib().htkamd_fb_execute(self.h, C.byref(cfg), accs.h, _stream(stream)), "fb_execute")
+
+    def execute_begin(self, cfg: FbConfig, accs: Accs, stream=None) -> bool:
+        """htkamd_fb_execute_begin: the pass but for the state-bucketed mixture statistics; True when those wait for execute_mix."""
+        d = C.c_int(0)
+        check(lib().htkamd_fb_execute_begin(self.h, C.byref(cfg), accs.h, _stream(stream), C.byref(d)), "fb_execute_begin")
+        return bool(d.value)
+
+    def execute_mix(self, state0: int, state1: int, stream=None):
+        """htkamd_fb_execute_mix: the mixture statistics of tied states [state0, state1)."""
+        check(lib().htkamd_fb_execute_mix(self.h, C.c_int(state0), C.c_int(state1), _stream(stream)), "fb_execute_mix")
 
     def results_begin(self, stream=None):
         """Queue the copy of the results behind the pass on its stream (htkamd_fb_results_begin); results() then only waits for it."""

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include "internal.h"
 #include "hipcheck.h"
 
@@ -40,7 +41,7 @@ static int rccl_bind()
    return HTKAMD_OK;
 }
 
-struct htkamd_comm { rcclComm c; int nRanks, rank; float *d_wire; size_t wireCap; int *d_flag; };
+struct htkamd_comm { rcclComm c; int nRanks, rank; float *d_wire; size_t wireCap, wireUsed; int *d_flag; };
 
 #define RCCLCHECK(call) do { const int r_ = (call); if (r_ != 0) { htkamd_set_error("%s -> %s", #call, g_rccl.err ? g_rccl.err(r_) : "RCCL error"); return HTKAMD_EHIP; } } while (0)
 
@@ -141,6 +142,101 @@ extern "C" int htkamd_accs_allreduce_wire(htkamd_accs *a, htkamd_comm *c, int wi
    RCCLCHECK(g_rccl.allReduce(a->d_vec + bulk, a->d_vec + bulk, tail, 8 /* ncclFloat64 */, 0, c->c, st));
    k_wire_unpack<<<1024, 256, 0, st>>>(c->d_wire, a->d_vec, bulk);
    HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+// ---- the exchange in parts (htkamd_fb_execute_begin / _mix): ranges of the vector by tied state
+extern "C" int htkamd_accs_state_ranges(htkamd_accs *a, int state0, int state1, int withRest, size_t off[7], size_t len[7], int *n)
+{
+   if (!a || !off || !len || !n) { htkamd_set_error("accs_state_ranges: NULL argument"); return HTKAMD_EINVAL; }
+   const htkamd_model *m = a->m;
+   if (state0 < 0 || state1 > m->S || state0 > state1) { htkamd_set_error("accs_state_ranges: states [%d, %d) outside the set's %d", state0, state1, m->S); return HTKAMD_EINVAL; }
+   if (a->stateOrder == 0) {
+      a->stateOrder = (m->G == m->C && m->NSt <= 1 && !m->tiedMix) ? 1 : -1;
+      for (int c = 0; c < m->C && a->stateOrder == 1; c++) if (m->h_compGauss[c] != c) a->stateOrder = -1;
+   }
+   if (a->stateOrder < 0) { htkamd_set_error("accs_state_ranges: the set's components do not own their Gaussians in state order (shared pdfs, several streams or tied mixtures): exchange the vector whole"); return HTKAMD_EMODEL; }
+   const size_t g0 = (size_t)m->h_stateCompOff[state0], g1 = (size_t)m->h_stateCompOff[state1], D = (size_t)m->D;
+   int k = 0;
+   auto put = [&](size_t o, size_t l) { if (l) { off[k] = o; len[k] = l; k++; } };
+   put(a->lay.mu + g0 * D, (g1 - g0) * D); put(a->lay.muOcc + g0, g1 - g0);
+   put(a->lay.va + g0 * D, (g1 - g0) * D); put(a->lay.vaOcc + g0, g1 - g0);
+   put(a->lay.wt + g0, g1 - g0); put(a->lay.wtOcc + (size_t)state0, (size_t)(state1 - state0));
+   if (withRest) put(a->lay.tr, a->lay.nEgs - a->lay.tr);                      // tr, trOcc: up to the counters
+   *n = k;
+   return HTKAMD_OK;
+}
+
+struct RangeSet { size_t off[7], len[7], start[8]; int n; };
+template <typename W, bool PACK>
+__global__ void k_ranges(double *__restrict__ v, W *__restrict__ w, RangeSet r)
+{
+   const size_t total = r.start[r.n];
+   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      int k = 0;
+      while (k + 1 < r.n && i >= r.start[k + 1]) k++;
+      const size_t j = r.off[k] + (i - r.start[k]);
+      if (PACK) w[i] = (W)v[j]; else v[j] = (double)w[i];
+   }
+}
+
+static int ranges_launch(htkamd_accs *a, int n, const size_t *off, const size_t *len, int wire, void *buf, hipStream_t st, bool pack, size_t *totalOut)
+{
+   if (!a || n < 0 || n > 7 || (n && (!off || !len)) || (wire != HTKAMD_WIRE_F32 && wire != HTKAMD_WIRE_F64)) { htkamd_set_error("accs ranges: bad argument"); return HTKAMD_EINVAL; }
+   RangeSet r; r.n = n; r.start[0] = 0;
+   for (int k = 0; k < n; k++) {
+      if (off[k] + len[k] > a->lay.total) { htkamd_set_error("accs ranges: range %d beyond the vector", k); return HTKAMD_EINVAL; }
+      r.off[k] = off[k]; r.len[k] = len[k]; r.start[k + 1] = r.start[k] + len[k];
+   }
+   if (totalOut) *totalOut = r.start[n];
+   if (r.start[n] == 0) return HTKAMD_OK;
+   if (!buf) { htkamd_set_error("accs ranges: NULL buffer"); return HTKAMD_EINVAL; }
+   const unsigned blocks = (unsigned)std::min<size_t>((r.start[n] + 255) / 256, 2048);
+   if (wire == HTKAMD_WIRE_F32) { if (pack) k_ranges<float, true><<<blocks, 256, 0, st>>>(a->d_vec, (float *)buf, r); else k_ranges<float, false><<<blocks, 256, 0, st>>>(a->d_vec, (float *)buf, r); }
+   else { if (pack) k_ranges<double, true><<<blocks, 256, 0, st>>>(a->d_vec, (double *)buf, r); else k_ranges<double, false><<<blocks, 256, 0, st>>>(a->d_vec, (double *)buf, r); }
+   HIPCHECK(hipGetLastError());
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_accs_pack_ranges(htkamd_accs *a, int n, const size_t *off, const size_t *len, int wire, void *dst, void *stream)
+{
+   return ranges_launch(a, n, off, len, wire, dst, (hipStream_t)stream, true, nullptr);
+}
+
+extern "C" int htkamd_accs_unpack_ranges(htkamd_accs *a, int n, const size_t *off, const size_t *len, int wire, const void *src, void *stream)
+{
+   return ranges_launch(a, n, off, len, wire, (void *)src, (hipStream_t)stream, false, nullptr);
+}
+
+extern "C" int htkamd_accs_allreduce_states(htkamd_accs *a, htkamd_comm *c, int wire, int state0, int state1, int withRest, void *stream)
+{
+   if (!a || !c) { htkamd_set_error("accs_allreduce_states: NULL argument"); return HTKAMD_EINVAL; }
+   if (c->nRanks == 1) return HTKAMD_OK;
+   size_t off[7], len[7], total = 0;
+   int n = 0;
+   int rc = htkamd_accs_state_ranges(a, state0, state1, withRest, off, len, &n);
+   if (rc) return rc;
+   for (int k = 0; k < n; k++) total += len[k];
+   hipStream_t st = (hipStream_t)stream;
+   // the part's room in the wire buffer: parts of one iteration lie one behind the other (a part may still be on its way when the next is packed
+   // on another stream); a call with withRest closes the iteration
+   const size_t need = a->lay.nEgs * (wire == HTKAMD_WIRE_F64 ? 2 : 1);             // in floats
+   if (c->wireCap < need) {
+      if (c->d_wire) HIPCHECK(hipFree(c->d_wire));
+      c->d_wire = nullptr; c->wireCap = 0; c->wireUsed = 0;
+      HIPCHECK(hipMalloc(&c->d_wire, sizeof(float) * need));
+      c->wireCap = need;
+   }
+   const size_t words = total * (wire == HTKAMD_WIRE_F64 ? 2 : 1);
+   if (c->wireUsed + words > c->wireCap) c->wireUsed = 0;
+   void *buf = c->d_wire + c->wireUsed;
+   c->wireUsed = withRest ? 0 : c->wireUsed + ((words + 63) & ~(size_t)63);
+   if (total) {
+      if ((rc = ranges_launch(a, n, off, len, wire, buf, st, true, nullptr))) return rc;
+      RCCLCHECK(g_rccl.allReduce(buf, buf, total, wire == HTKAMD_WIRE_F64 ? 8 : 7, 0 /* ncclSum */, c->c, st));
+      if ((rc = ranges_launch(a, n, off, len, wire, buf, st, false, nullptr))) return rc;
+   }
+   if (withRest) RCCLCHECK(g_rccl.allReduce(a->d_vec + a->lay.nEgs, a->d_vec + a->lay.nEgs, a->lay.total - a->lay.nEgs, 8 /* ncclFloat64 */, 0, c->c, st));
    return HTKAMD_OK;
 }
 

@@ -145,6 +145,8 @@ struct htkamd_fb {
    DevBuf d_stCnt, d_stBucket;               // FbArgs::stCnt, stBucket (k_mixstate)
    DevBuf d_qBeamNP, d_laneRec;              // ... the host's un-pruned beta beams (a view into the arena); a record per chain state for the sparse statistics
    bool mixStateLast = false;                // the last pass ran k_mixstate (its counters are behind d_stCnt)
+   bool mixDeferred = false;                 // htkamd_fb_execute_begin left the state-bucketed statistics to htkamd_fb_execute_mix
+   FbArgs *faMix = nullptr;                  // ... with these arguments
    const int *qBeamLast = nullptr;           // the beta beam words the last pass's left-to-right kernels read (d_qBeam or d_qBeamNP)
    bool lastWave;                           // (kept for the tests' introspection) the last execute used no general kernel
    DevBuf d_transOff, d_trOccOff, d_counter, d_thrCell, d_arena, d_gamChunkUtt;
@@ -198,7 +200,7 @@ extern "C" void htkamd_fb_destroy(htkamd_fb *fb)
    for (DevBuf *b : all) b->release();
    if (fb->h_arena) (void)hipHostFree(fb->h_arena);
    if (fb->h_res) (void)hipHostFree(fb->h_res);
-   delete fb->pool; delete fb->chunks;
+   delete fb->pool; delete fb->chunks; delete fb->faMix;
    if (fb->evValid) {
       for (int i = 0; i < 6; i++) if (fb->ev[i]) (void)hipEventDestroy(fb->ev[i]);
       if (fb->evCopy) (void)hipEventDestroy(fb->evCopy);
@@ -669,9 +671,41 @@ extern "C" int htkamd_fb_score_work(const htkamd_fb *fb, long long out[3])
 
 extern "C" int htkamd_fb_prepared_current(const htkamd_fb *fb) { return fb && fb->topoVersion == fb->m->topoVersion; }
 
+static int fb_execute_impl(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream, bool defer);
+
 extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream)
 {
+   return fb_execute_impl(fb, cfg, accs, stream, false);
+}
+
+// The pass in two phases, for hosts that send a range of states' statistics on their way while the next range is still being summed (the
+// accumulator exchange of a multi-GPU HERest: HERest.c:514-557 dumps and merges whole files behind the pass).  _begin runs everything but
+// the state-bucketed mixture statistics and says whether such statistics are waiting (*deferred; 0: the pass was of another kind and is
+// complete); _mix then takes tied states [state0, state1) -- every state once per pass, in any order.  Behind _mix of a range the
+// accumulators of its states' Gaussians, components and the states' own counts are final on this rank (htkamd_accs_state_ranges);
+// everything no state owns -- transitions, counters -- is final behind _begin.
+extern "C" int htkamd_fb_execute_begin(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream, int *deferred)
+{
+   if (deferred) *deferred = 0;
+   const int rc = fb_execute_impl(fb, cfg, accs, stream, true);
+   if (rc == HTKAMD_OK && deferred && fb && fb->nUtt > 0) *deferred = fb->mixDeferred ? 1 : 0;
+   return rc;
+}
+
+extern "C" int htkamd_fb_execute_mix(htkamd_fb *fb, int state0, int state1, void *stream)
+{
+   if (!fb) { htkamd_set_error("fb_execute_mix: NULL"); return HTKAMD_EINVAL; }
+   if (fb->nUtt == 0 || !fb->mixDeferred) return HTKAMD_OK;
+   const int rc = htkamd_launch_mixstate_range(*fb->faMix, state0, state1, (hipStream_t)stream);
+   if (rc) return rc;
+   HIPCHECK(hipEventRecord(fb->ev[5], (hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+static int fb_execute_impl(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream, bool defer)
+{
    if (!fb || !cfg || !accs) { htkamd_set_error("fb_execute: NULL argument"); return HTKAMD_EINVAL; }
+   fb->mixDeferred = false;
    if (accs->m != fb->m) { htkamd_set_error("fb_execute: accumulators belong to a different model"); return HTKAMD_EINVAL; }
    if (fb->nUtt == 0) return HTKAMD_OK;
    const htkamd_model *m = fb->m;
@@ -690,7 +724,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
    sa.gparam = m->d_gparam; sa.PS = m->PS; sa.D = m->D; sa.minLogExp = m->minLogExp;
    sa.laddTab = m->d_laddTab; sa.taskCounter = (int *)fb->d_counter.p;
    if (wideTasks && m->NSt == 1 && fb->wqStart.size() == 9 && !getenv("HTKAMD_NO_XCDQ")) { sa.qStart = (const int *)fb->d_wqStart.p; sa.qCounters = (int *)fb->d_counter.p + 8; }
-   if (wideTasks && m->NSt == 1 && !getenv("HTKAMD_NO_TAPER_SKIP")) sa.slotRange = (const int *)fb->d_slotRange.p;      // (the switch: for A/B measurements)
+   if ((cfg->scoreMode & HTKAMD_SCORE_BF16) && !(cfg->scoreMode & HTKAMD_SCORE_F16) && m->NSt == 1 && !getenv("HTKAMD_NO_TAPER_SKIP")) sa.slotRange = (const int *)fb->d_slotRange.p;      // (the switch: for A/B measurements)
    sa.mfmaTab = m->d_mfmaTab; sa.stateTileOff = m->d_stateTileOff; sa.bf16Tab = m->d_bf16Tab; sa.var = m->d_var;
    fb->f16Pass = (cfg->scoreMode & HTKAMD_SCORE_F16) != 0 && !m->tiedMix && sa.nTasks > 0;      // no tasks, no launch: nothing zeroes or raises the flag
    if (fb->f16Pass) {      // the pass's own range flag, behind the status words (zeroed with the task counter before it, by the launcher)
@@ -792,6 +826,7 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          size_t cap = 64;
          while (cap < 65536 && cap * (size_t)m->S < (size_t)16 * fb->totalFrames) cap <<= 1;
          while (cap > 64 && cap * (size_t)m->S * sizeof(HitS) > ((size_t)1 << 30)) cap >>= 1;
+         { const char *e = getenv("HTKAMD_ST_CAP"); if (e && atoi(e) > 0) cap = (size_t)atoi(e); }      // test aid: tiny buckets, so that most pairs take the list kernel behind them
          if ((rc = fb->d_stCnt.reserve(sizeof(int) * (3 * (size_t)m->S + 4))) || (rc = fb->d_stBucket.reserve(sizeof(HitS) * cap * (size_t)m->S))) return rc;
          fb->mixStateLast = true;
          fa.stCnt = (int *)fb->d_stCnt.p; fa.nTiedStates = m->S; fa.stBucket = (HitS *)fb->d_stBucket.p; fa.stCap = (int)cap;
@@ -849,7 +884,15 @@ extern "C" int htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htk
          if (fb->nUtt > nLr && (rc = htkamd_launch_mixstats_ms(fa, s))) return rc;
          if (nLr > 0 && (rc = htkamd_launch_mixhits_streams(fa, false, s))) return rc;
       }
-      else if ((rc = htkamd_launch_mixstats(fa, s, fb->nUtt > nLr, nLr > 0))) return rc;
+      else {
+         const bool dense = fb->nUtt > nLr && fa.gamTotal > 0, listed = nLr > 0;
+         if ((rc = htkamd_launch_mixstats(fa, s, dense, listed, defer))) return rc;
+         if (defer && listed && !dense && htkamd_mixstate_applies(fa)) {
+            if (!fb->faMix) fb->faMix = new FbArgs();
+            *fb->faMix = fa;
+            fb->mixDeferred = true;
+         }
+      }
    }
    HIPCHECK(hipEventRecord(fb->ev[5], s));
    fb->timed = true; fb->evModeLast = noEv ? 1 : 0;

@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
    __shared__ float xs[CH * XS];
    __shared__ double Lt[CH][GS];
    __shared__ double hSeed[CH];
-   const int st = blockIdx.x, lane = threadIdx.x, grp = lane / GS, sub = lane % GS;
+   const int st = a.stBase + blockIdx.x, lane = threadIdx.x, grp = lane / GS, sub = lane % GS;
    const int nst = a.stCnt[st] < a.stCap ? a.stCnt[st] : a.stCap;
    if (nst <= 0) return;
    const HitS *bucket = a.stBucket + (size_t)st * a.stCap;
@@ -1082,12 +1082,13 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
       if (lane < n) { const HitS h = bucket[base + lane]; hfr = h.frame; hSeed[lane] = h.seed; }
       // the frames' rows by LDS-DMA, a row per load instruction (its DT lanes read 4 DT contiguous bytes -- a lane fetching the row of its OWN
       // pair touched 64 cache lines per instruction and cost the kernel 0.19 ms): no registers in between, every row of the chunk in flight
-      if (lane < DT) {
-         for (int r = 0; r < n; r++) {
-            const int fr = MS_EXP(1024) ? 0 : __builtin_amdgcn_readlane(hfr, r);
+      // (the frame numbers are taken with every lane switched on -- lane r of `hfr` is read for r < n <= 32, and at D = 13 / 26 some of those
+      //  lanes are outside the loads' `lane < DT` -- only the load itself is predicated)
+      for (int r = 0; r < n; r++) {
+         const int fr = MS_EXP(1024) ? 0 : __builtin_amdgcn_readlane(hfr, r);
+         if (lane < DT)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.X + (size_t)fr * DT + lane),
                                              (__attribute__((address_space(3))) void *)(xs + r * XS), 4, 0, 0);
-         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1198,9 +1199,13 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
 
 // the pass's surviving pairs by tied state (the buckets k_stats_sp filled): a wavefront per state
 bool htkamd_mixstate_applies(const FbArgs &a) { return a.stCnt && a.stBucket && !a.hitSlots && a.maxM <= 16 && (a.D == 39 || a.D == 26 || a.D == 13); }
-static int launch_mixstate(const FbArgs &a, hipStream_t s)
+int htkamd_launch_mixstate_range(const FbArgs &a_in, int st0, int st1, hipStream_t s)
 {
-   const int S = a.nTiedStates;
+   if (st0 < 0 || st1 > a_in.nTiedStates || st0 > st1) { htkamd_set_error("mixture statistics: state range [%d, %d) outside the set's %d", st0, st1, a_in.nTiedStates); return HTKAMD_EINVAL; }
+   if (st0 == st1) return HTKAMD_OK;
+   FbArgs a = a_in;
+   a.stBase = st0;
+   const int S = st1 - st0;
    const int mode = ((a.uFlags & HTKAMD_UPMEANS) ? 1 : 0) | ((a.uFlags & HTKAMD_UPVARS) ? 2 : 0);
 #define MS_LAUNCH(DT_) \
    do { \
@@ -1242,10 +1247,17 @@ int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s
 
 // statistics of the surviving pairs: from the dense seed array (gamTotal seeds; the utterances off the left-to-right path) and / or from
 // the hit list of k_stats_lr (a.hits: nHitsMax > 0), then the per-Gaussian reduction of the records both of them listed
-int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool listed)
+int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool listed, bool deferState)
 {
    if (!dense && !listed) return HTKAMD_OK;
-   const FbArgs &a = a_in;
+   FbArgs a = a_in;
+   dense = dense && a.gamTotal > 0;
+   // bucketed by state and nothing from the dense seed array: the list holds only what a full bucket turned away -- rarely anything -- and is
+   // taken by ONE launch of the list kernel with direct atomics, which leaves at once when the counter of such pairs is zero (round 5: the
+   // record path's five launches ran empty in every pass, 24 us of nothing), in front of the states so that what it adds is in place when a
+   // range of states is called final
+   const bool stateOnly = listed && !dense && htkamd_mixstate_applies(a);
+   if (stateOnly) a.rec = nullptr;
    if (a.rec) HIPCHECK(hipMemsetAsync(a.recCtl, 0, sizeof(int) * (3 * ((size_t)a.G + 1) + 1), s));
 #define MIX_LAUNCH(K, GS) \
    switch (a.D) { \
@@ -1256,7 +1268,7 @@ int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool l
    }
 #define MIX_LAUNCH_GS(K) \
    if (a.maxM <= 16) { MIX_LAUNCH(K, 16) } else if (a.maxM <= 32) { MIX_LAUNCH(K, 32) } else { MIX_LAUNCH(K, 64) }
-   if (dense && a.gamTotal > 0) {
+   if (dense) {
       size_t waves = (a.gamTotal + 511) / 512;
       size_t blocks = (waves + 3) / 4;
       if (blocks > 8192) blocks = 8192;          // grid-stride beyond 32 waves per CU
@@ -1265,9 +1277,15 @@ int htkamd_launch_mixstats(const FbArgs &a_in, hipStream_t s, bool dense, bool l
    }
    if (listed) {
       // (bucketed by state where that applies: k_mixstate; the list then only holds what the buckets had no room for)
-      if (htkamd_mixstate_applies(a)) { const int rc = launch_mixstate(a, s); if (rc) return rc; }
-      const dim3 grid(4096), block(256);          // grid-stride over the blocks of the list (its length is on the device)
-      MIX_LAUNCH_GS(k_mixhits)
+      const dim3 grid(stateOnly ? 512 : 4096), block(256);          // grid-stride over the blocks of the list (its length is on the device)
+      if (stateOnly) {
+         MIX_LAUNCH_GS(k_mixhits)
+         HIPCHECK(hipGetLastError());
+         if (!deferState) { const int rc = htkamd_launch_mixstate_range(a_in, 0, a_in.nTiedStates, s); if (rc) return rc; }
+      } else {
+         if (htkamd_mixstate_applies(a)) { const int rc = htkamd_launch_mixstate_range(a, 0, a.nTiedStates, s); if (rc) return rc; }
+         MIX_LAUNCH_GS(k_mixhits)
+      }
    }
 #undef MIX_LAUNCH_GS
 #undef MIX_LAUNCH

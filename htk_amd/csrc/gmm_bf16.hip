@@ -564,14 +564,20 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
             f16v Cx, Cc;
 #pragma unroll
             for (int r = 0; r < 16; r++) { Cx[r] = 0.0f; Cc[r] = 0.0f; }      // (no instructions: the first product of each takes the constant 0)
-            if constexpr (DENSE && B16_LAYOUT == 2) {                        // the leading products start from the share of the first 16 dimensions (dense_NI)
+            auto cx_start = [&]() {
+               if constexpr (DENSE && B16_LAYOUT == 2) {                     // the leading products start from the share of the first 16 dimensions (dense_NI)
 #pragma unroll
-               for (int b = 0; b < 4; b++) {
-                  const f4 c0 = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + 8 + kh * 4 + b]);
+                  for (int b = 0; b < 4; b++) {
+                     const f4 c0 = __builtin_bit_cast(f4, wbuf[buf][KS * 192 + 8 + kh * 4 + b]);
 #pragma unroll
-                  for (int r = 0; r < 4; r++) Cx[4 * b + r] = c0[r];
+                     for (int r = 0; r < 4; r++) Cx[4 * b + r] = c0[r];
+                  }
                }
-            }
+            };
+#ifndef B16_INIT_LATE
+#define B16_INIT_LATE 1                                 /* the start values are read behind the round's first products (their product is the sixth) */
+#endif
+            if (!B16_INIT_LATE) cx_start();
             bf8 wa[KS][3];
 #pragma unroll
             for (int s = 0; s < 3; s++) wa[0][s] = __builtin_bit_cast(bf8, wbuf[buf][(0 * 3 + s) * 64 + lane]);
@@ -585,6 +591,7 @@ __global__ __launch_bounds__(256, b16w_eu(KS)) void k_score_bf16w(ScoreArgs a)
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][1], zb[ks][1], Cc, 0, 0, 0);
                if (B16_PRIO != 2 && 3 * ks + 0 < 18) { if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(0); lse_slice(3 * ks + 0); if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(B16_PRIO_LEVEL); }
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][2], Cc, 0, 0, 0);
+               if (B16_INIT_LATE && ks == 0) cx_start();
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][2], zb[ks][0], Cc, 0, 0, 0);
                if (B16_PRIO != 2 && 3 * ks + 1 < 18) { if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(0); lse_slice(3 * ks + 1); if (B16_PRIO == 3) __builtin_amdgcn_s_setprio(B16_PRIO_LEVEL); }
                Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][0], zb[ks][1], Cc, 0, 0, 0);

@@ -132,6 +132,7 @@ struct htkamd_accs {
    struct htkamd_model *m;
    htkamd_accs_layout lay;
    double *d_vec;
+   int stateOrder;             /* htkamd_accs_state_ranges: 0 not looked at yet, 1 compGauss[c] == c throughout (a state's Gaussians are a range of the vector), -1 not so */
 };
 
 #ifdef __cplusplus

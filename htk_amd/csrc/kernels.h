@@ -170,6 +170,7 @@ struct FbArgs {
    const int *qBeamNP;               // left-to-right path: the beta beams of the un-pruned pass (host: SetBeamTaper alone decides them), lo | hi << 16 per frame
    // mixture statistics bucketed by tied state (k_mixstate; sets of one stream with <= 16 components per state): k_stats_sp drops a surviving
    // pair into its state's bucket (stCnt[st] counts, stBucket[st * stCap ...]); what a bucket has no room for goes to the list of k_mixhits
+   int stBase;                                                   // k_mixstate: first tied state of the launch (htkamd_fb_execute_mix takes the states in ranges)
    int *stCnt; int nTiedStates; HitS *stBucket; int stCap;      // stCnt[nTiedStates] = pairs turned away by a full bucket (0: the list kernels have nothing to do)
    int fastMath;                     // the pass runs in the fp32-transcendental class (HTKAMD_SCORE_FASTLADD): posteriors by v_exp_f32
    double *sink;                     // 64 bytes nobody reads: where the lanes outside a beam "store" (one cache line instead of a branch around the store)
@@ -178,7 +179,11 @@ struct FbArgs {
 
 int htkamd_launch_beta(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
 int htkamd_launch_alpha(const FbArgs &a, int blockDim, size_t lds, hipStream_t s);
-int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s, bool dense, bool listed);
+// deferState: where the state-bucketed kernel applies, only what its buckets turned away is taken now (by the list kernel, direct atomics);
+// the states themselves wait for htkamd_launch_mixstate_range (htkamd_fb_execute_mix)
+int htkamd_launch_mixstats(const FbArgs &a, hipStream_t s, bool dense, bool listed, bool deferState = false);
+bool htkamd_mixstate_applies(const FbArgs &a);
+int htkamd_launch_mixstate_range(const FbArgs &a, int st0, int st1, hipStream_t s);
 // several streams: outp = sum over streams of outpU; UpMixParms per stream from the dense seed array
 int htkamd_launch_combine_streams(const FbArgs &a, hipStream_t s);
 int htkamd_launch_mixstats_ms(const FbArgs &a, hipStream_t s);

@@ -371,6 +371,25 @@ int  htkamd_accs_allreduce(htkamd_accs *a, htkamd_comm *c, void *stream);
 int  htkamd_accs_allreduce_wire(htkamd_accs *a, htkamd_comm *c, int wire, void *stream);
 int  htkamd_accs_wire_round(htkamd_accs *a, void *stream);
 int  htkamd_comm_agree_max(htkamd_comm *c, int *value, void *stream);
+/* The exchange in parts, behind a pass in two phases (htkamd_fb_execute_begin / _mix): the statistics of tied states [state0, state1) travel
+ * while the next range of states is still being summed.  One logical exchange per iteration (what `HERest -p 0 HER*.acc` merges,
+ * HERest.c:514-557, HTrain.c:1625-1687), cut along the accumulator vector.
+ *   htkamd_accs_state_ranges   the ranges of the vector that belong to those states -- mu, muOcc, va, vaOcc of their Gaussians, wt of their
+ *                              components, wtOcc -- and with `withRest` what no state owns and the whole-vector exchange sends as
+ *                              statistics (tr, trOcc): up to 7 ranges in off[] / len[] (doubles), their number in *n.  Needs a set whose
+ *                              components own their Gaussians in state order (compGauss[c] == c: no shared pdfs); else HTKAMD_EMODEL,
+ *                              and the caller exchanges the vector whole.
+ *   htkamd_accs_pack_ranges    the ranges, one behind the other, into `dst` as floats (HTKAMD_WIRE_F32) or doubles; _unpack_ranges back.
+ *                              For hosts with a collective of their own (bench.py: torch.distributed).
+ *   htkamd_accs_allreduce_states   pack, sum over the ranks (RCCL), unpack -- all on `stream`; `withRest` adds tr / trOcc to the part and
+ *                              sums the counters behind them (nEgs ... nEval) in fp64 as htkamd_accs_allreduce_wire does.  Calls with
+ *                              withRest = 1 once per iteration, and every state once, leave every rank with the vector the whole
+ *                              exchange would have left (bit for bit on the fp64 wire, for any ring order on the fp32 wire: the same
+ *                              values are rounded and summed). */
+int  htkamd_accs_state_ranges(htkamd_accs *a, int state0, int state1, int withRest, size_t off[7], size_t len[7], int *n);
+int  htkamd_accs_pack_ranges(htkamd_accs *a, int n, const size_t *off, const size_t *len, int wire, void *dst, void *stream);
+int  htkamd_accs_unpack_ranges(htkamd_accs *a, int n, const size_t *off, const size_t *len, int wire, const void *src, void *stream);
+int  htkamd_accs_allreduce_states(htkamd_accs *a, htkamd_comm *c, int wire, int state0, int state1, int withRest, void *stream);
 
 /* HTK parameter files: header + big-endian float rows, _C compression and _K checksum on input
  * (ReadHTKHeader HWave.c:1408, OpenParmChannel HParm.c:3561, GetParm :3464, UpdateCRCC :3357).  *data is malloc'd
@@ -500,6 +519,13 @@ int  htkamd_fb_prepared_current(const htkamd_fb *fb);
 /* Device part: scores, beta pass, alpha pass + statistics into `accs`. Asynchronous on `stream`. */
 int  htkamd_fb_execute(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream);
 /* Waits for the stream and copies per-utterance log-probabilities (utt->pr) and status. */
+/* The pass in two phases (multi-GPU hosts: a range of states' statistics is exchanged while the next is being summed).  _begin: everything
+   but the state-bucketed mixture statistics (UpMixParms HFB.c:1426 for the left-to-right path's surviving pairs); *deferred = 1 when those
+   wait for _mix, 0 when the pass was of another kind and is complete.  _mix: the statistics of tied states [state0, state1); every state
+   once per pass, any order.  Behind _mix the ranges htkamd_accs_state_ranges names for those states are final on this rank; what no state
+   owns is final behind _begin.  htkamd_fb_execute = _begin + _mix(0, numStates). */
+int  htkamd_fb_execute_begin(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_accs *accs, void *stream, int *deferred);
+int  htkamd_fb_execute_mix(htkamd_fb *fb, int state0, int state1, void *stream);
 int  htkamd_fb_results(htkamd_fb *fb, double *pr /*[nUtt]*/, int *status /*[nUtt]*/, void *stream);
 /* For host loops that queue the next pass before they read this one's results: the copy of the results queued on `stream` (the stream
    htkamd_fb_execute ran on) right behind the pass; htkamd_fb_results then only waits for that copy. */

@@ -11,8 +11,8 @@ The bar per entry: |got - ref| <= 1e-4 * scale, scale = |ref| for weights / tran
 (SURVEY.md §8c), and for variances the second moment about the previous mean, var + (mean_new - mean_old)^2 -- the quantity HERest's
 accumulators hold (tests/c3_herest.py: compare); widened only where the reference's OWN 1-process-vs-8-way difference at that entry is
 larger than half of it (one variance in 2.9 M on this workload: tests/golden/c3_herest.npz `whole_set_self`).  Against the variances'
-own values: exact mode 1 entry of 2.9 M above 1e-4 (the very entry the reference does not reproduce itself), tolerance-class mode 7,
-worst 1.74e-4 -- asserted as such below."""
+own values: exact mode 1 entry of 2.9 M above 1e-4 (the very entry the reference does not reproduce itself), bf16 x 3 scores 3, fp16 x 2
+scores 7, a float64 scorer 6 -- asserted at observed + 1 below (RAW_BARS)."""
 import json
 import os
 import tempfile
@@ -25,6 +25,14 @@ import c3_herest as c3
 pytestmark = pytest.mark.gpu
 
 MODES = [(0, "exact"), (6, "bf16x3fast"), (34, "fastest")]
+# variances beyond 1e-4 of their own value, whole set: (count, worst) for the Gaussians of two frames or more, (count, worst) for the others --
+# observed in round 6 (profiles/r06_headline_parity_*.json: exact 1 / 1.31e-4, 0; bf16 x 3 3 / 1.41e-4, 5 / 1.70e-4; fp16 x 2 7 / 1.46e-4, 3 / 1.70e-4) + 1 entry, + ~0.1e-4
+RAW_BARS = {"exact": (1, 1.4e-4, 0, 1e-6), "bf16x3fast": (4, 1.5e-4, 6, 1.8e-4), "fastest": (8, 1.6e-4, 4, 1.8e-4)}
+
+
+def msg_raw(r):
+    return "var: %d above 1e-4 of their own value (worst %.3g); under two frames: %d (worst %.3g)" % (
+        r["var"]["n_above_1e4"], r["var"]["worst_rel"], r["var_low_occ"]["n_above_1e4"], r["var_low_occ"]["worst_rel"])
 
 
 def _hip_model(native, s, pk, mode):
@@ -119,13 +127,17 @@ def test_headline_model_vs_reference_live(native, mode, name):
     os.makedirs(os.path.join(c3.ROOT, "gpurun_out"), exist_ok=True)
     json.dump(r, open(os.path.join(c3.ROOT, "gpurun_out", "headline_parity_%s.json" % name), "w"))
     _assert_report(r, "all %d Gaussians, mode %s" % (G, name))
-    # against the variances' own values: a handful of the 2.9 M, none beyond 2e-4 (the reference's own 1-vs-8 difference has one at 1.3e-4)
-    assert r["var"]["n_above_1e4"] <= 10 and r["var"]["worst_rel"] <= 2e-4 and r["mean"]["n_above_1e4"] == 0
-    # ... and (round 5) the 193 089 entries of the Gaussians with fewer than two frames, every one that exists in the reference's model: means
-    # all inside 1e-4; variances -- a difference of two sums over one or two frames -- inside 1e-4 of the second moment the accumulators carry
-    # (n_fail, above), and against their own value: exact mode none above 1e-4, bf16 x 3 six (worst 2.1e-4), fp16 x 2 three (1.7e-4)
+    # Against the variances' OWN values (no second-moment scale): the counts and worst ratios observed on MI355X in round 6, plus one entry /
+    # a tenth -- RAW_BARS below.  What they can be: the reference's float arithmetic is itself 2.1e-5 rms away from exact arithmetic per
+    # score, and a scorer WITHOUT rounding error (a diagnostic build that scores in float64, tools/r06_parvar.sh `truth`) has 6 entries
+    # above 1e-4 (worst 1.81e-4) and 6 among the Gaussians under two frames (2.12e-4): only the bit-identical exact mode can have fewer
+    # than a handful, and a tolerance-class mode that counts 3 is inside that scatter, not better than it.
+    n_max, worst_max, n_low_max, worst_low_max = RAW_BARS[name]
+    assert r["var"]["n_above_1e4"] <= n_max and r["var"]["worst_rel"] <= worst_max and r["mean"]["n_above_1e4"] == 0, msg_raw(r)
+    # ... and the 193 089 entries of the Gaussians with fewer than two frames, every one that exists in the reference's model: means all inside
+    # 1e-4; variances -- a difference of two sums over one or two frames -- inside 1e-4 of the second moment the accumulators carry (n_fail, above)
     assert r["mean_low_occ"]["n_above_1e4"] == 0 and r["mean_low_occ"]["n"] > 150000
-    assert r["var_low_occ"]["n_above_1e4"] <= (0 if mode == 0 else 10) and r["var_low_occ"]["worst_rel"] <= (1e-6 if mode == 0 else 3e-4)
+    assert r["var_low_occ"]["n_above_1e4"] <= n_low_max and r["var_low_occ"]["worst_rel"] <= worst_low_max, msg_raw(r)
     # the accumulators themselves: occupancies and weight counts of the whole set
     assert np.allclose(a["muOcc"], occ, rtol=1e-4, atol=1e-4)
 

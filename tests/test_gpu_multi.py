@@ -45,9 +45,11 @@ def _env():
     return e
 
 
-def _bench(n, out, port, total=256, env=None, wire="f64", steps=2):
+def _bench(n, out, port, total=256, env=None, wire="f64", steps=2, slices=None):
     args = ["--gpus", str(n), "--wire", wire, "--scaling", "strong", "--total-utts", str(total), "--states", "600", "--mix", "4", "--phones", "300", "--frames", "200",
             "--steps", str(steps), "--warmup", "0", "--cpu-seconds", "0", "--extras", "0", "--dump-model", out]
+    if slices is not None:
+        args += ["--exchange-slices", str(slices)]
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
@@ -101,6 +103,29 @@ def test_bench_two_ranks_on_one_device_over_gloo_equal_one_rank(tmp_path):
     m2 = moved(a, c)
     print("f32 wire, two iterations:", m2)
     assert m2["mean"] <= 1e-4 and m2["var"] <= 1e-4 and m2["compWeight"] <= 3e-4 and m2["transP"] <= 1e-5, m2
+
+
+@pytest.mark.parametrize("wire", ["f64", "f32"])
+def test_exchange_in_parts_equals_the_whole_exchange(tmp_path, wire):
+    """bench.py --exchange-slices: the accumulators travel in four parts by tied state, each as soon as its states' mixture statistics are summed
+    (htkamd_fb_execute_begin / _mix, htkamd_accs_state_ranges / _pack_ranges), against ONE all-reduce behind the pass.  Two ranks: a sum of
+    two is the same in either order, so the merged model of two EM iterations is the same float for float -- on the fp64 wire and on the fp32
+    wire (the same values are rounded once and added).  Eight ranks in parts: test_bench_self_launch_eight_ranks_on_one_device."""
+    import json
+    assert _ngpu() >= 1, "a `-m gpu` test on a box without a device"
+    env = {"HTKAMD_BENCH_ONE_DEVICE_GLOO": "1"}
+    o1 = _bench(2, str(tmp_path / "whole.npz"), 29641 + (wire == "f32"), env=env, wire=wire, slices=1)
+    o4 = _bench(2, str(tmp_path / "parts.npz"), 29643 + (wire == "f32"), env=env, wire=wire, slices=4)
+    l1, l4 = json.loads(o1.strip().splitlines()[-1]), json.loads(o4.strip().splitlines()[-1])
+    assert l1["config"]["exchange_slices"] == 1 and l4["config"]["exchange_slices"] == 4 and l1["utterances_ok"] == l4["utterances_ok"] == 256
+    a, b = np.load(str(tmp_path / "whole.npz")), np.load(str(tmp_path / "parts.npz"))
+    assert a["nUttDone"] == b["nUttDone"] == 256
+    # the transition and occupation counts are sums of atomics whose order differs from run to run (fp64: 1e-16), the mixture statistics
+    # one wavefront's sums per state: means, variances and weights come out bit-equal unless such a count sits on a float's rounding edge
+    assert abs(float(a["totalPr"]) - float(b["totalPr"])) <= 1e-12 * abs(float(a["totalPr"]))
+    for k in ("mean", "var", "compWeight", "transP"):
+        assert np.allclose(a[k], b[k], rtol=3e-7, atol=1e-9), k
+        assert (a[k] != b[k]).mean() < 1e-3, k
 
 
 def test_bench_two_ranks_rccl_equals_one_rank(tmp_path):

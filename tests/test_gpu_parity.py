@@ -209,15 +209,20 @@ def test_mfma_forward_backward_within_tolerance(native, name, mode):
     ok = ~np.isnan(ref_mean)
     sigma = np.sqrt(np.where(ok, np.abs(ref_var), 1.0))
     assert (np.abs(p["mean"] - ref_mean)[ok] <= 1e-4 * np.maximum(np.abs(ref_mean), sigma)[ok] + 1e-6).all()
-    # a Gaussian whose occupancy is essentially one frame has var = sum(g*(x-mu)^2)/occ - (mu_new-mu)^2 ~ 0 by cancellation:
-    # its relative error is unbounded for ANY change of the scores, so the variance bar applies from two frames up
-    well = ok & (np.asarray(ref["muOcc"])[:, None] >= 2.0)
+    # Two groups, both held to 1e-4 (as tests/c3_herest.py: compare does at the headline size): the Gaussians of two frames of occupancy or more
+    # against the variance's own value; the others -- var = sum(g (x - mu)^2) / occ - (mu_new - mu)^2 is a difference of two sums over one or
+    # two frames -- against the second moment about the previous mean, var + (mu_new - mu_old)^2, the quantity the accumulators carry
+    # (HFB.c:1671-1678).  No entry is left out.
+    low = ok & ~(np.asarray(ref["muOcc"])[:, None] >= 2.0)
+    well = ok & ~low
     assert well.sum() > 0.3 * ok.sum()
     assert np.allclose(p["var"][well], ref_var[well], rtol=1e-4, atol=1e-6)
+    moment = np.abs(ref_var) + (ref_mean - np.asarray(case["pk"]["mean"], np.float64)) ** 2
+    assert (np.abs(p["var"] - ref_var)[low] <= 1e-4 * moment[low] + 1e-6).all(), float((np.abs(p["var"] - ref_var)[low] / moment[low]).max())
     assert np.allclose(p["compWeight"], np.asarray(upd["compWeight"], np.float64), rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("mode", [6, 34], ids=["bf16x3fast", "fastest"])
+@pytest.mark.parametrize("mode", [6, 4], ids=["bf16x3fast", "bf16x3"])
 def test_scoring_sits_out_what_setotprob_never_evaluates(native, oracle, mode, monkeypatch):
     """The pair kernels leave out, wavefront by wavefront, the (32 frames, pair of chain states) blocks that lie outside Setotprob's ranges
     of the un-pruned pass (HFB.c:1014 with 1177 / 1215: model q at frame t only for qLo-1 <= q <= qHi).  Nothing that the recursions read
@@ -254,6 +259,82 @@ def test_scoring_sits_out_what_setotprob_never_evaluates(native, oracle, mode, m
     for u, ut in enumerate(utts):
         rc, opr, _ = oracle.fb_utt(om, ocfg, ut["feat"], ut["seq"], oacc)
         assert rc == 1 and abs(opr - pr1[u]) <= 1e-6 * abs(opr)
+
+
+def test_pass_in_two_phases_and_exchange_ranges(native, oracle, monkeypatch):
+    """htkamd_fb_execute_begin / _mix (the multi-GPU hosts' form of the pass: a range of states' statistics travels while the next is summed):
+    the states in three uneven ranges, last first, leave the accumulators of htkamd_fb_execute; htkamd_accs_state_ranges cuts the statistics'
+    part of the vector into disjoint ranges that cover it; pack / unpack move them unchanged (fp64) or rounded to float once (fp32).
+    With two-pair buckets (HTKAMD_ST_CAP) nearly every pair goes through the list kernel in front of the states: same sums, the oracle's."""
+    from htk_amd import synth
+    s = synth.generate(50, 4, 40, 6, 200, 91)
+    pk = s.packed()
+    utts = [dict(seq=q, feat=x) for q, x in zip(s.seqs, s.feats)]
+    from util import batch_arrays
+    model = native.Model(pk)
+    X, frameOff, labOff, labs = batch_arrays(utts)
+    dX = native.DevArray(X)                                        # (kept alive: the passes below run on this prepared batch)
+    fb, acc = native.ForwardBackward(model), native.Accs(model)
+    fb.prepare(dX.ptr.value, frameOff, labOff, labs)
+    cfg = native.fb_config(scoreMode=6)
+    fb.execute(cfg, acc)
+    pr, st = fb.results()
+    assert (st == 1).all()
+    whole = acc.download()
+    cuts = [(31, 50), (0, 7), (7, 31)]
+    for cap in (None, "2"):
+        if cap:
+            monkeypatch.setenv("HTKAMD_ST_CAP", cap)
+        acc2 = native.Accs(model)
+        assert fb.execute_begin(cfg, acc2)
+        part = acc2.download()
+        assert np.array_equal(part["tr"], whole["tr"]) or np.allclose(part["tr"], whole["tr"], rtol=1e-12)      # what no state owns is there behind _begin
+        if not cap:
+            assert not part["mu"].any()                                                                          # ... and nothing of the states yet
+        for s0, s1 in cuts:
+            fb.execute_mix(s0, s1)
+        pr2, st2 = fb.results()
+        assert np.array_equal(pr2, pr)
+        got = acc2.download()
+        # (the list kernel takes exp() where the state kernel of the fast class takes v_exp_f32: posteriors equal to 1e-7)
+        for k in ("mu", "muOcc", "va", "vaOcc", "wt", "wtOcc", "tr", "trOcc"):
+            assert np.allclose(got[k], whole[k], rtol=2e-6 if cap else 1e-11, atol=1e-6 if cap else 1e-12), (cap, k)
+        monkeypatch.delenv("HTKAMD_ST_CAP", raising=False)
+    om = oracle.Model(pk); oacc = oracle.Accs(om); ocfg = oracle.fb_cfg()
+    for ut in utts:
+        oracle.fb_utt(om, ocfg, ut["feat"], ut["seq"], oacc)
+    for k in ("muOcc", "vaOcc", "wt", "wtOcc"):
+        acc_close(got[k], getattr(oacc, k), "tiny buckets / %s" % k)
+    occ = np.maximum(np.asarray(oacc.muOcc, np.float64), 1e-3)[:, None]
+    for k in ("mu", "va"):                                             # sums about the current mean: an entry near zero is a cancellation, the Gaussian's occupancy its scale (bench.py's rule)
+        ref = np.asarray(getattr(oacc, k), np.float64).reshape(occ.shape[0], -1)
+        assert (np.abs(np.asarray(got[k]).reshape(ref.shape) - ref) <= 1e-4 * np.maximum(np.abs(ref), occ)).all(), k
+    # the ranges: disjoint, and together the statistics' part of the vector (everything in front of nEgs)
+    L = acc.lay
+    seen = np.zeros(L.total, np.int32)
+    for i, (s0, s1) in enumerate(cuts):
+        for off, ln in acc.state_ranges(s0, s1, with_rest=(i == 2)):
+            seen[off:off + ln] += 1
+    assert (seen[:L.nEgs] == 1).all() and not seen[L.nEgs:].any()
+    # pack / unpack
+    v0 = acc.download()["vec"].copy()
+    rg = acc.state_ranges(7, 31, with_rest=True)
+    n = sum(l for _, l in rg)
+    for wire, dt in ((0, np.float64), (1, np.float32)):
+        buf = native.DevArray(np.zeros(n, dt))
+        acc.pack_ranges(rg, wire, buf.ptr.value)
+        flat = buf.to_host(dt, (n,))
+        assert np.array_equal(flat, np.concatenate([v0[off:off + ln] for off, ln in rg]).astype(dt))
+        acc.zero(None)
+        acc.unpack_ranges(rg, wire, buf.ptr.value)
+        v1 = acc.download()["vec"]
+        want = np.zeros_like(v0)
+        for off, ln in rg:
+            want[off:off + ln] = v0[off:off + ln].astype(dt).astype(np.float64)
+        assert np.array_equal(v1, want)
+        acc.zero(None); acc.upload_add(v0)
+    with pytest.raises(native.HtkAmdError):
+        acc.state_ranges(5, 51)
 
 
 # ----------------------------------------------------------------------------------------- forward-backward

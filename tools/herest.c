@@ -28,6 +28,8 @@
  *                  rendezvous id from rank 0 to the others, tagged with the run's nonce (--rccl-nonce N; default: the launcher's process
  *                  id, which the ranks of one run share); rank 0 removes the file before writing and at exit.  --rccl-timeout S (120):
  *                  a rank that cannot meet the others within S seconds -- at the rendezvous or in the all-reduce -- exits with status 3.
+ *                  --wire f32 | f64: the statistics on the wire as floats (default: what HERest's own accumulator dumps carry, HTrain.c:1453-1505,
+ *                  and what bench.py's multi-GPU line is measured with; every rank rounds its fp64 partial sums once, counters stay fp64) or as doubles.
  * Output on stdout follows HERest -T 1: "Pruning-On[..]", a line per skipped file, "Total N floored variance elements ...",
  * "Reestimation complete - average log prob per frame = ...".
  */
@@ -77,7 +79,7 @@ int main(int argc, char **argv)
    double pruneInit = HTKAMD_NOPRUNE, pruneInc = 0.0, pruneLim = HTKAMD_NOPRUNE;
    float minFrwdP = 10.0f, minVar = 0.0f, mixFloor = 0.0f;
    int uFlags = HTKAMD_UPMEANS | HTKAMD_UPVARS | HTKAMD_UPMIXES | HTKAMD_UPTRANS, minEgs = 3, parMode = -1, trace = 0, binary = 0;
-   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1, wire = HTKAMD_WIRE_F64, compat = 0;
+   int scoreMode = HTKAMD_SCORE_EXACT, batchN = 4096, nRanks = 1, rank = 0, rcclTimeout = 120, nIter = 1, wire = HTKAMD_WIRE_F32, compat = 0;
    unsigned long long rcclNonce = (unsigned long long)getppid();      /* the ranks of one run are children of one launcher; --rccl-nonce overrides */
    const char *sw;
 
