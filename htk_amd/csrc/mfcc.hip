@@ -101,8 +101,33 @@ __global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
    __syncthreads();
    // ---- complex FFT, radix-2 DIT (HSigP.c:332-349): stage with half-size h, twiddles tabulated
    {
-      int twOff = 0;
-      for (int h = 1; h < nn; h *= 2) {
+      // Stages in PAIRS (round 6): a lane takes the four elements base + {0, h, 2h, 3h} through the stages of half-size h and 2h in registers --
+      // the same butterflies on the same floats (every result is rounded to float where the reference stores it), so the output is unchanged
+      // bit for bit, with half the passes through LDS and half the barriers.  Twiddles of the stage of half-size h start at h - 1 in the table.
+      auto bfly = [](float &ar, float &ai, float &br, float &bi, const double wr, const double wi) {
+         const double xre = wr * (double)br - wi * (double)bi;
+         const double xri = wr * (double)bi + wi * (double)br;
+         const float nbr = (float)((double)ar - xre), nbi = (float)((double)ai - xri);
+         const float nar = (float)((double)ar + xre), nai = (float)((double)ai + xri);
+         ar = nar; ai = nai; br = nbr; bi = nbi;
+      };
+      int h = 1, lg = 0;
+      for (; 4 * h <= nn; h *= 4, lg += 2) {
+         for (int g = lane; g < nn / 4; g += 64) {
+            const int pos = g & (h - 1), base = ((g >> lg) << (lg + 2)) + pos;
+            float2 e0 = *(const float2 *)(xs + 2 * base), e1 = *(const float2 *)(xs + 2 * (base + h));
+            float2 e2 = *(const float2 *)(xs + 2 * (base + 2 * h)), e3 = *(const float2 *)(xs + 2 * (base + 3 * h));
+            const double2 t1 = *(const double2 *)(a.tw + 2 * (h - 1 + pos));
+            const double2 t2 = *(const double2 *)(a.tw + 2 * (2 * h - 1 + pos)), t3 = *(const double2 *)(a.tw + 2 * (2 * h - 1 + pos + h));
+            bfly(e0.x, e0.y, e1.x, e1.y, t1.x, t1.y); bfly(e2.x, e2.y, e3.x, e3.y, t1.x, t1.y);
+            bfly(e0.x, e0.y, e2.x, e2.y, t2.x, t2.y); bfly(e1.x, e1.y, e3.x, e3.y, t3.x, t3.y);
+            *(float2 *)(xs + 2 * base) = e0; *(float2 *)(xs + 2 * (base + h)) = e1;
+            *(float2 *)(xs + 2 * (base + 2 * h)) = e2; *(float2 *)(xs + 2 * (base + 3 * h)) = e3;
+         }
+         __syncthreads();
+      }
+      int twOff = h - 1;
+      for (; h < nn; h *= 2) {                           // (an odd number of stages: the last one alone)
          for (int b = lane; b < nn / 2; b += 64) {
             const int grp = b / h, pos = b % h;
             const int ia = grp * 2 * h + pos, ib = ia + h;

@@ -100,6 +100,33 @@ def test_reference_herest_front_end_runs_its_e_step_on_the_gpu(native, tmp_path)
 
 @pytest.mark.gpu
 @needs_exe
+def test_shim_default_is_the_references_arithmetic_and_fast_is_opt_in(native, tmp_path):
+    """Under the reference's own HERest.o the shim's default is exact scores + the table-driven log-add: every "Utterance prob per frame" line
+    HERest -T 1 prints (%e: seven digits of a double that is the reference's bit for bit) equals the line the reference's own binary prints.
+    HTKAMD_SHIM_FAST=1 is the opt-in tolerance class: the same lines within 1e-6 relative."""
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "HERest")
+    if not os.path.exists(ref_exe):
+        pytest.skip("oracle/_ref/HERest is not on this box")
+    conf = tmp_path / "herest.conf"
+    conf.write_text("TARGETKIND = MFCC_E_D\n")
+    lines = {}
+    for tag, exe, env in (("ref", ref_exe, {}), ("shim", EXE, {}), ("fast", EXE, {"HTKAMD_SHIM_FAST": "1"})):
+        out = tmp_path / tag
+        out.mkdir()
+        cmd = _demo_cmd(str(out), str(conf))
+        cmd[0] = exe
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+        lines[tag] = [l.strip() for l in r.stdout.splitlines() if "Utterance prob per frame" in l]
+        assert len(lines[tag]) == 7, r.stdout[-800:]
+    assert lines["shim"] == lines["ref"]
+    for a, b in zip(lines["fast"], lines["ref"]):
+        x, y = float(a.split("=")[1]), float(b.split("=")[1])
+        assert abs(x - y) <= 1e-6 * abs(y), (a, b)
+
+
+@pytest.mark.gpu
+@needs_exe
 def test_reference_herest_front_end_on_a_three_stream_set(native, tmp_path):
     """The reference's HERest.o over the shim on a multi-stream set (tests/golden/demo/hmm_streams3): the shim packs every StreamElem,
     hands the library undivided rows, and adds the statistics back per stream; the front-end's own UpdateModels then writes the model the
