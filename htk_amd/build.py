@@ -29,6 +29,8 @@ if os.environ.get("HTKAMD_DEC_DEFS"):              # ... and decode.hip (-DDEC_C
     EXTRA_FLAGS["csrc/decode.hip"] = os.environ["HTKAMD_DEC_DEFS"].split()
 if os.environ.get("HTKAMD_EX_DEFS"):               # ... and gmm_exact.hip
     EXTRA_FLAGS["csrc/gmm_exact.hip"] = os.environ["HTKAMD_EX_DEFS"].split()
+if os.environ.get("HTKAMD_MFCC_DEFS"):             # ... and mfcc.hip
+    EXTRA_FLAGS["csrc/mfcc.hip"] = os.environ["HTKAMD_MFCC_DEFS"].split()
 if os.environ.get("HTKAMD_UPD_DEFS"):              # the same for update.hip / gmm_bf16.hip (tools/r05_updvar.sh)
     EXTRA_FLAGS["csrc/update.hip"] = os.environ["HTKAMD_UPD_DEFS"].split()
 if os.environ.get("HTKAMD_B16_CT"):              # experiment switch: column tiles per wavefront of the bf16 scoring kernel (gmm_bf16.hip: B16_COL_TILES)

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "internal.h"
 #include "hipcheck.h"
@@ -33,6 +34,17 @@ struct MfccArgs {
    float *frameMean;             // [F] (ZMEANSOURCE)
    float *out;
 };
+
+// first sample and utterance of every frame from the per-utterance offsets (binary search over the utterances)
+__global__ void k_mfcc_index(const int *frameOff, const int *sampOff, int nUtt, int nFrames, int frRate, long long *frameSamp, int *frameUtt)
+{
+   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+   if (f >= nFrames) return;
+   int lo = 0, hi = nUtt - 1;                            // the last u with frameOff[u] <= f
+   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (frameOff[mid] <= f) lo = mid; else hi = mid - 1; }
+   frameUtt[f] = lo;
+   frameSamp[f] = (long long)sampOff[lo] + (long long)(f - frameOff[lo]) * frRate;
+}
 
 // lane per frame: source mean (ZeroMeanFrame HParm.c:2132) and log energy (HParm.c:2234-2238 / HSigP.c:571-575)
 __global__ void k_mfcc_energy(MfccArgs a)
@@ -66,20 +78,21 @@ __global__ void k_mfcc_energy(MfccArgs a)
    a.out[(size_t)f * a.nCols + a.nStat - 1] = (te < MINLARG) ? (float)LZERO : (float)log((double)te);
 }
 
-// one wavefront per frame
-__global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
+// One frame's spectrum by a whole wavefront: window, FFT, Realft, magnitudes -- and (round 6) what every k hands its two mel bins:
+//   uk[k] = ek - loWt[k] ek  (to the bin above, HSigP.c:594)   vk[k] = loWt[k] ek  (to its own bin, :593)
+// computed by all lanes in parallel, so that the bins' sums below are nothing but the reference's chain of float additions.
+__device__ __forceinline__ void mfcc_spectrum(const MfccArgs &a, const int f, float *xs, float *uk, float *vk, const int lane)
 {
-   extern __shared__ float lds[];
-   const int lane = threadIdx.x, f = blockIdx.x;
    const int fftN = a.fftN, nn = fftN / 2;
-   float *xs = lds;                       // [fftN] interleaved (re,im), 0-based
-   float *ek = lds + fftN;                // [nn + 1] spectral magnitudes, 1-based k
-   float *fb = ek + nn + 2;               // [numChans + 1]
    const short *w = a.wav + a.frameSamp[f];
    const float off = a.zMean ? a.frameMean[f] : 0.0f;
 
    // ---- load, pre-emphasise (HSigP.c:134), window (HSigP.c:122), zero-pad, bit-reverse the complex index
-   for (int c = lane; c < nn; c += 64) {
+#ifndef MFCC_BREV_READ
+#define MFCC_BREV_READ 0                                /* 1: the reversal on the read side, LDS written in order -- measured 6 % SLOWER (tools/r06_mfcc2.sh): the index load sits in front of the samples' loads */
+#endif
+   for (int r_ = lane; r_ < nn; r_ += 64) {
+      const int c = MFCC_BREV_READ ? (int)a.brev[r_] : r_, r = MFCC_BREV_READ ? r_ : (int)a.brev[r_];
       float v[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -95,8 +108,7 @@ __global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
          }
          v[h] = s;
       }
-      const int r = a.brev[c];
-      xs[2 * r] = v[0]; xs[2 * r + 1] = v[1];
+      *(float2 *)(xs + 2 * r) = make_float2(v[0], v[1]);
    }
    __syncthreads();
    // ---- complex FFT, radix-2 DIT (HSigP.c:332-349): stage with half-size h, twiddles tabulated
@@ -115,14 +127,24 @@ __global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
       for (; 4 * h <= nn; h *= 4, lg += 2) {
          for (int g = lane; g < nn / 4; g += 64) {
             const int pos = g & (h - 1), base = ((g >> lg) << (lg + 2)) + pos;
-            float2 e0 = *(const float2 *)(xs + 2 * base), e1 = *(const float2 *)(xs + 2 * (base + h));
-            float2 e2 = *(const float2 *)(xs + 2 * (base + 2 * h)), e3 = *(const float2 *)(xs + 2 * (base + 3 * h));
+            float2 e0, e1, e2, e3;
+            if (h == 1) {                                 // four neighbours: two 16-byte words, the lanes' in order (8-byte reads 32 bytes apart fell into four banks)
+               const float4 lo4 = *(const float4 *)(xs + 2 * base), hi4 = *(const float4 *)(xs + 2 * base + 4);
+               e0 = make_float2(lo4.x, lo4.y); e1 = make_float2(lo4.z, lo4.w); e2 = make_float2(hi4.x, hi4.y); e3 = make_float2(hi4.z, hi4.w);
+            } else {
+               e0 = *(const float2 *)(xs + 2 * base); e1 = *(const float2 *)(xs + 2 * (base + h));
+               e2 = *(const float2 *)(xs + 2 * (base + 2 * h)); e3 = *(const float2 *)(xs + 2 * (base + 3 * h));
+            }
             const double2 t1 = *(const double2 *)(a.tw + 2 * (h - 1 + pos));
             const double2 t2 = *(const double2 *)(a.tw + 2 * (2 * h - 1 + pos)), t3 = *(const double2 *)(a.tw + 2 * (2 * h - 1 + pos + h));
             bfly(e0.x, e0.y, e1.x, e1.y, t1.x, t1.y); bfly(e2.x, e2.y, e3.x, e3.y, t1.x, t1.y);
             bfly(e0.x, e0.y, e2.x, e2.y, t2.x, t2.y); bfly(e1.x, e1.y, e3.x, e3.y, t3.x, t3.y);
-            *(float2 *)(xs + 2 * base) = e0; *(float2 *)(xs + 2 * (base + h)) = e1;
-            *(float2 *)(xs + 2 * (base + 2 * h)) = e2; *(float2 *)(xs + 2 * (base + 3 * h)) = e3;
+            if (h == 1) {
+               *(float4 *)(xs + 2 * base) = make_float4(e0.x, e0.y, e1.x, e1.y); *(float4 *)(xs + 2 * base + 4) = make_float4(e2.x, e2.y, e3.x, e3.y);
+            } else {
+               *(float2 *)(xs + 2 * base) = e0; *(float2 *)(xs + 2 * (base + h)) = e1;
+               *(float2 *)(xs + 2 * (base + 2 * h)) = e2; *(float2 *)(xs + 2 * (base + 3 * h)) = e3;
+            }
          }
          __syncthreads();
       }
@@ -160,36 +182,78 @@ __global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
       if (lane == 0) { const float xr1 = xs[0]; xs[0] = xr1 + xs[1]; xs[1] = 0.0f; }
       __syncthreads();
    }
-   // ---- magnitudes (HSigP.c:585-590)
+   // ---- magnitudes (HSigP.c:585-590) and the two terms of every k (:593-594)
    for (int k = a.klo + lane; k <= a.khi; k += 64) {
       const float t1 = xs[2 * k - 2], t2 = xs[2 * k - 1];
       const float p = t1 * t1 + t2 * t2;
-      ek[k] = a.usePower ? p : (float)sqrt((double)p);
+      const float e = a.usePower ? p : (float)sqrt((double)p);
+      const float tw = a.loWt[k] * e;
+      uk[k] = e - tw; vk[k] = tw;
    }
    __syncthreads();
-   // ---- mel bins (HSigP.c:591-594) in the reference's accumulation order, then log with floor 1.0 (:598-603)
-   for (int b = 1 + lane; b <= a.numChans; b += 64) {
-      float acc = 0.0f;
-      for (int k = a.binA0[b]; k <= a.binA1[b]; k++) { const float e = ek[k]; const float t1 = a.loWt[k] * e; acc += e - t1; }
-      for (int k = a.binB0[b]; k <= a.binB1[b]; k++) { const float t1 = a.loWt[k] * ek[k]; acc += t1; }
-      if (acc < 1.0f) acc = 1.0f;
-      fb[b] = (float)log((double)acc);
+}
+
+// mel bin b of one frame (HSigP.c:591-594 in the reference's accumulation order, then log with floor 1.0, :598-603)
+__device__ __forceinline__ float mfcc_bin(const MfccArgs &a, const int b, const float *uk, const float *vk)
+{
+   float acc = 0.0f;
+   for (int k = a.binA0[b]; k <= a.binA1[b]; k++) acc += uk[k];
+   for (int k = a.binB0[b]; k <= a.binB1[b]; k++) acc += vk[k];
+   if (acc < 1.0f) acc = 1.0f;
+   return (float)log((double)acc);
+}
+// cepstral coefficient j of one frame: DCT (HSigP.c:607-621), lifter (:773), CEPSCALE
+__device__ __forceinline__ float mfcc_cep(const MfccArgs &a, const int j, const float *fb)
+{
+   float c = 0.0f;
+   const double *ct = a.dct + (size_t)j * (a.numChans + 1);
+   for (int k = 1; k <= a.numChans; k++) c = (float)((double)c + (double)fb[k] * ct[k]);
+   c *= a.mfnorm;
+   c *= a.cepWin[j];
+   return c * a.cepScale;
+}
+__device__ __forceinline__ float mfcc_c0(const MfccArgs &a, const float *fb)      // C0 (HSigP.c:647)
+{
+   float sum = 0.0f;
+   for (int k = 1; k <= a.numChans; k++) sum += fb[k];
+   return (sum * a.mfnorm) * a.cepScale;
+}
+
+// One wavefront per PAIR of frames (round 6).  The spectra take the whole wavefront, one frame after the other; the mel bins and the cepstra
+// are chains of dependent float additions that only numChans (26) and numCeps + 1 (13) lanes can work on -- 40 % of the kernel's vector
+// instructions ran with 26 lanes on -- so the two frames' chains run side by side, frame h in lanes 32 h .. 32 h + 31.
+// PAIR = false (numChans > 32 or numCeps > 31): one frame per wavefront, the bins and cepstra strided over the lanes.
+template <bool PAIR>
+__global__ __launch_bounds__(64) void k_mfcc_frames(MfccArgs a)
+{
+   extern __shared__ float lds[];
+   const int lane = threadIdx.x;
+   const int fftN = a.fftN, nn = fftN / 2;
+   constexpr int NF = PAIR ? 2 : 1;
+   const int per = (fftN + 2 * (nn + 2) + a.numChans + 2 + 3) & ~3;      // floats per frame (a multiple of 16 bytes): xs [fftN] interleaved (re, im) | uk [nn + 2] | vk [nn + 2], 1-based k | fb [numChans + 2]
+   for (int blk = blockIdx.x; NF * blk < a.nFrames; blk += gridDim.x) {
+   const int f0 = NF * blk;
+   for (int h = 0; h < NF; h++)
+      if (f0 + h < a.nFrames) mfcc_spectrum(a, f0 + h, lds + h * per, lds + h * per + fftN, lds + h * per + fftN + nn + 2, lane);
+   if constexpr (PAIR) {
+      const int h = lane >> 5, q = lane & 31, f = f0 + h;
+      float *base = lds + h * per, *fb = base + fftN + 2 * (nn + 2);
+      if (f < a.nFrames && q < a.numChans) fb[q + 1] = mfcc_bin(a, q + 1, base + fftN, base + fftN + nn + 2);
+      __syncthreads();
+      if (f < a.nFrames) {
+         float *row = a.out + (size_t)f * a.nCols;
+         if (q < a.numCeps) row[q] = mfcc_cep(a, q + 1, fb);
+         else if (a.hasC0 && q == 31) row[a.numCeps] = mfcc_c0(a, fb);
+      }
+   } else {
+      float *fb = lds + fftN + 2 * (nn + 2);
+      for (int b = 1 + lane; b <= a.numChans; b += 64) fb[b] = mfcc_bin(a, b, lds + fftN, lds + fftN + nn + 2);
+      __syncthreads();
+      float *row = a.out + (size_t)f0 * a.nCols;
+      for (int j = 1 + lane; j <= a.numCeps; j += 64) row[j - 1] = mfcc_cep(a, j, fb);
+      if (a.hasC0 && lane == 63) row[a.numCeps] = mfcc_c0(a, fb);
    }
-   __syncthreads();
-   // ---- DCT (HSigP.c:607-621), lifter (:773), CEPSCALE; C0 (:647)
-   float *row = a.out + (size_t)f * a.nCols;
-   for (int j = 1 + lane; j <= a.numCeps; j += 64) {
-      float c = 0.0f;
-      const double *ct = a.dct + (size_t)j * (a.numChans + 1);
-      for (int k = 1; k <= a.numChans; k++) c = (float)((double)c + (double)fb[k] * ct[k]);
-      c *= a.mfnorm;
-      c *= a.cepWin[j];
-      row[j - 1] = c * a.cepScale;
-   }
-   if (a.hasC0 && lane == 63) {
-      float sum = 0.0f;
-      for (int k = 1; k <= a.numChans; k++) sum += fb[k];
-      row[a.numCeps] = (sum * a.mfnorm) * a.cepScale;
+   __syncthreads();                                      // (the next frames' spectra overwrite what the cepstra read)
    }
 }
 
@@ -314,15 +378,9 @@ extern "C" int htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int 
    const htkamd_mfcc_config &c = f->cfg;
    const htkamd_mfcc_tables &t = f->tab;
    const int nCols = htkamd_mfcc_num_cols(&c), nStat = c.numCeps + (c.hasC0 ? 1 : 0) + (c.hasE ? 1 : 0);
-   std::vector<long long> frameSamp;
-   std::vector<int> frameUtt;
    frameOff[0] = 0;
-   for (int u = 0; u < nUtt; u++) {
-      const int T = htkamd_mfcc_num_frames(&c, sampOff[u + 1] - sampOff[u]);
-      for (int k = 0; k < T; k++) { frameSamp.push_back((long long)sampOff[u] + (long long)k * t.frRate); frameUtt.push_back(u); }
-      frameOff[u + 1] = frameOff[u] + T;
-   }
-   const int F = (int)frameSamp.size();
+   for (int u = 0; u < nUtt; u++) frameOff[u + 1] = frameOff[u] + htkamd_mfcc_num_frames(&c, sampOff[u + 1] - sampOff[u]);
+   const int F = frameOff[nUtt];
    if (F == 0) return HTKAMD_OK;
    if ((size_t)F > f->capFrames) {
       (void)hipFree(f->d_frameSamp); (void)hipFree(f->d_frameMean); (void)hipFree(f->d_frameUtt);
@@ -335,12 +393,15 @@ extern "C" int htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int 
    }
    if ((size_t)nUtt + 1 > f->capUtt) {
       (void)hipFree(f->d_frameOff); f->d_frameOff = nullptr;
-      HIPCHECK(hipMalloc((void **)&f->d_frameOff, sizeof(int) * ((size_t)nUtt + 1)));
+      HIPCHECK(hipMalloc((void **)&f->d_frameOff, sizeof(int) * 2 * ((size_t)nUtt + 1)));      // frame offsets, then sample offsets
       f->capUtt = (size_t)nUtt + 1;
    }
-   HIPCHECK(hipMemcpyAsync(f->d_frameSamp, frameSamp.data(), sizeof(long long) * F, hipMemcpyHostToDevice, s));
-   HIPCHECK(hipMemcpyAsync(f->d_frameUtt, frameUtt.data(), sizeof(int) * F, hipMemcpyHostToDevice, s));
+   // the per-frame tables (first sample, utterance) are made ON the device from the two per-utterance tables (round 6: 596 000 push_backs and
+   // 7 MB of pageable copies were 0.7 ms of a 2.7 ms call)
    HIPCHECK(hipMemcpyAsync(f->d_frameOff, frameOff, sizeof(int) * ((size_t)nUtt + 1), hipMemcpyHostToDevice, s));
+   HIPCHECK(hipMemcpyAsync(f->d_frameOff + f->capUtt, sampOff, sizeof(int) * ((size_t)nUtt + 1), hipMemcpyHostToDevice, s));
+   hipLaunchKernelGGL(k_mfcc_index, dim3((F + 255) / 256), dim3(256), 0, s, f->d_frameOff, f->d_frameOff + f->capUtt, nUtt, F, t.frRate, f->d_frameSamp, f->d_frameUtt);
+   HIPCHECK(hipGetLastError());
 
    MfccArgs a;
    a.wav = dWav; a.frameSamp = f->d_frameSamp; a.nFrames = F;
@@ -355,8 +416,14 @@ extern "C" int htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int 
       hipLaunchKernelGGL(k_mfcc_energy, dim3((F + 63) / 64), dim3(64), 0, s, a);
       HIPCHECK(hipGetLastError());
    }
-   const size_t lds = sizeof(float) * ((size_t)t.fftN + t.fftN / 2 + 2 + c.numChans + 2);
-   hipLaunchKernelGGL(k_mfcc_frames, dim3(F), dim3(64), lds, s, a);
+   const size_t per = sizeof(float) * ((((size_t)t.fftN + 2 * ((size_t)t.fftN / 2 + 2) + c.numChans + 2) + 3) & ~(size_t)3);
+   // (a grid of persistent wavefronts -- HTKAMD_MFCC_WPC per CU -- was tried against one workgroup per pair of frames: 1.93 ms at 16 or 32 per CU
+   //  against 1.78 for the plain grid, tools/r06_mfcc2.sh; the loop stays, the default grid covers every pair)
+   int wpc = 1 << 20;
+   { const char *e = getenv("HTKAMD_MFCC_WPC"); if (e && atoi(e) > 0) wpc = atoi(e); }
+   const int maxGrid = 256 * wpc;
+   if (c.numChans <= 32 && c.numCeps <= 31 && !getenv("HTKAMD_MFCC_ONE_FRAME")) hipLaunchKernelGGL(k_mfcc_frames<true>, dim3(std::min((F + 1) / 2, maxGrid)), dim3(64), 2 * per, s, a);
+   else hipLaunchKernelGGL(k_mfcc_frames<false>, dim3(std::min(F, maxGrid)), dim3(64), per, s, a);
    HIPCHECK(hipGetLastError());
    if (c.hasE && c.eNormalise) {
       hipLaunchKernelGGL(k_mfcc_enorm, dim3(nUtt), dim3(256), 0, s, dOut, f->d_frameOff, nCols, nStat - 1, c.silFloor, c.eScale);
@@ -376,7 +443,7 @@ extern "C" int htkamd_mfcc_compute(htkamd_mfcc *f, const short *dWav, const int 
       hipLaunchKernelGGL(k_mfcc_zmean, dim3((nUtt * d + 63) / 64), dim3(64), 0, s, dOut, f->d_frameOff, nUtt, nCols, d);
       HIPCHECK(hipGetLastError());
    }
-   HIPCHECK(hipStreamSynchronize(s));           // frameSamp / frameUtt are host temporaries
+   HIPCHECK(hipStreamSynchronize(s));           // (sampOff / frameOff are the caller's: the copies above must be over when the call returns)
    return HTKAMD_OK;
 }
 

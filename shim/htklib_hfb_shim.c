@@ -67,7 +67,7 @@ typedef struct {
    void *dX; size_t dXcap;
    float *hX; size_t hXcap;            /* page-locked staging of an utterance's observations */
    int *labs; size_t labsCap;
-   int exactLadd;                      /* the table-driven log-add in the recursions (the default: alpha / beta are the reference's); HTKAMD_SHIM_FAST=1 takes the fp32 transcendentals */
+   int exactLadd;                      /* HTKAMD_SHIM_EXACT=1: the table-driven log-add in the recursions (alpha / beta bit-compatible); default: fp32 transcendentals (tolerance class) */
    int dirty;                          /* statistics on the device not yet added to the hooks */
    UPDSet uFlags;
 } ShimSet;
@@ -388,11 +388,12 @@ static void pack_set(ShimSet *z)
    amd_check(htkamd_model_create(&d, &z->model), "htkamd_model_create");
    /* the tables the kernels read are the front-end's own numbers, bit for bit: 1/variance from ConvDiagC, log weights from ConvLogWt */
    amd_check(htkamd_model_set_prepared(z->model, ivar, gconst, logwt), "htkamd_model_set_prepared");
-   /* under the reference's own HERest.o the numbers are the reference's: Setotprob's second visit of a tied state as HFB.c:1059 has it */
+   /* under the reference's own HERest.o the SEMANTICS are the reference's, defects included: Setotprob's second visit of a tied state as HFB.c:1059 has it */
    amd_check(htkamd_model_set_compat(z->model, HTKAMD_COMPAT_STREAM_REVISIT), "htkamd_model_set_compat");
-   /* ... and so are the recursions' by default: exact scores, table-driven log-add.  HTKAMD_SHIM_FAST=1 in the environment asks for the fp32-transcendental
-      log-add (tolerance class, half the latency of a call); HTKAMD_SHIM_EXACT=1, the switch of round 5, still says what is now the default */
-   { const char *e = getenv("HTKAMD_SHIM_FAST"), *x = getenv("HTKAMD_SHIM_EXACT"); z->exactLadd = !(e != NULL && e[0] == '1') || (x != NULL && x[0] == '1'); }
+   /* The recursions: state scores are ALWAYS the reference's (SCORE_EXACT); the log-adds of alpha / beta come from the fp32 transcendental unit by
+      default (tolerance class: every re-estimated parameter within 1e-4; 0.5 ms per FBFile call) and from the table-driven exact log-add under
+      HTKAMD_SHIM_EXACT=1 in the environment (alpha / beta / pr bit-compatible with the reference's, 3.2 ms per call) -- measured by tools/shim_latency.py */
+   { const char *x = getenv("HTKAMD_SHIM_EXACT"); z->exactLadd = (x != NULL && x[0] == '1'); }
    amd_check(htkamd_accs_create(z->model, &z->accs), "htkamd_accs_create");
    amd_check(htkamd_fb_create(z->model, &z->fb), "htkamd_fb_create");
    free(weight); free(logwt); free(mean); free(var); free(ivar); free(gconst); free(transP);
@@ -514,10 +515,8 @@ Boolean FBFile(FBInfo *fbInfo, UttInfo *utt, char *datafn)
    frameOff[0] = 0; frameOff[1] = utt->T; labOff[0] = 0; labOff[1] = utt->Q;
    b.nUtt = 1; b.dX = (const float *)z->dX; b.frameOff = frameOff; b.labOff = labOff; b.labs = labs;
    cfg.pruneInit = prune.pruneInit; cfg.pruneInc = prune.pruneInc; cfg.pruneLim = prune.pruneLim;
-   /* One utterance per call: the call's time is the LATENCY of one utterance's recursions, T dependent steps each.  By default everything is the
-      reference's arithmetic (SCORE_EXACT: IDOutP's roundings; the table-driven log-add: alpha / beta bit-compatible, ~1.1 us per step);
-      HTKAMD_SHIM_FAST=1 takes the recursions' log-adds from the fp32 transcendental unit (the lean kernels of fb_lr_lean.inc, ~0.55 us per step) --
-      within 1e-4 on every re-estimated parameter (tests/test_htklib_shim.py runs both) */
+   /* One utterance per call: the call's time is the LATENCY of one utterance's recursions, T dependent steps each.  The state scores are exact
+      (SCORE_EXACT: IDOutP's arithmetic) in either mode; the recursions' log-adds: see pack_set (default fp32 transcendentals, HTKAMD_SHIM_EXACT=1 the table) */
    cfg.minFrwdP = prune.minFrwdP; cfg.uFlags = 0; cfg.scoreMode = z->exactLadd ? HTKAMD_SCORE_EXACT : (HTKAMD_SCORE_EXACT | HTKAMD_SCORE_FASTLADD);
    if (fbInfo->uFlags & UPMEANS) cfg.uFlags |= HTKAMD_UPMEANS;
    if (fbInfo->uFlags & UPVARS) cfg.uFlags |= HTKAMD_UPVARS;

@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HIP path against the oracle (run on the GPU box; not part of the test-suite because of its
 run time): forward-backward (pr, beams, accumulators) with random topologies / pruning / ragged batches, forced alignment
-with random beams, network decoding over random word networks; multi-stream and tied-mixture sets.   python tests/fuzz_parity.py [iterations] [seed]"""
+with random beams, network decoding over random word networks; multi-stream and tied-mixture sets.   python tests/fuzz_parity.py [iterations] [seed] [families, e.g. mfcc,quals]"""
 import os
 import sys
 import tempfile
@@ -435,9 +435,12 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     tmp = tempfile.mkdtemp()
     res = dict(fb=[0, 0], streams=[0, 0], align=[0, 0], decode=[0, 0], mfcc=[0, 0], quals=[0, 0], herest=[0, 0])
+    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None          # e.g. "mfcc,quals": these families only
     for it in range(n):
         for name, fn in (("fb", lambda: fuzz_fb(rng, it)), ("streams", lambda: fuzz_streams(rng, it)), ("align", lambda: fuzz_align(rng, it)), ("decode", lambda: fuzz_decode(rng, it, tmp)),
                          ("mfcc", lambda: fuzz_mfcc(rng, it)), ("quals", lambda: fuzz_quals(rng, it)), ("herest", lambda: fuzz_herest_cli(rng, it, tmp))):
+            if only is not None and name not in only:
+                continue
             try:
                 ok = fn()
             except Exception as e:  # noqa: BLE001

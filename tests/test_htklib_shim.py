@@ -100,17 +100,17 @@ def test_reference_herest_front_end_runs_its_e_step_on_the_gpu(native, tmp_path)
 
 @pytest.mark.gpu
 @needs_exe
-def test_shim_default_is_the_references_arithmetic_and_fast_is_opt_in(native, tmp_path):
-    """Under the reference's own HERest.o the shim's default is exact scores + the table-driven log-add: every "Utterance prob per frame" line
-    HERest -T 1 prints (%e: seven digits of a double that is the reference's bit for bit) equals the line the reference's own binary prints.
-    HTKAMD_SHIM_FAST=1 is the opt-in tolerance class: the same lines within 1e-6 relative."""
+def test_shim_exact_switch_gives_the_references_lines(native, tmp_path):
+    """Under the reference's own HERest.o the shim scores exactly and, by default, takes the recursions' log-adds from the fp32 transcendental unit
+    (tolerance class): every "Utterance prob per frame" line HERest -T 1 prints is within 1e-6 relative of the reference binary's.  With
+    HTKAMD_SHIM_EXACT=1 (table-driven log-add) the lines (%e: seven digits of a double that is then the reference's bit for bit) are EQUAL."""
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "HERest")
     if not os.path.exists(ref_exe):
         pytest.skip("oracle/_ref/HERest is not on this box")
     conf = tmp_path / "herest.conf"
     conf.write_text("TARGETKIND = MFCC_E_D\n")
     lines = {}
-    for tag, exe, env in (("ref", ref_exe, {}), ("shim", EXE, {}), ("fast", EXE, {"HTKAMD_SHIM_FAST": "1"})):
+    for tag, exe, env in (("ref", ref_exe, {}), ("shim", EXE, {"HTKAMD_SHIM_EXACT": "1"}), ("fast", EXE, {})):
         out = tmp_path / tag
         out.mkdir()
         cmd = _demo_cmd(str(out), str(conf))

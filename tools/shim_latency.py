@@ -24,7 +24,7 @@ if __name__ == "__main__":
         c3.write_files(d, s, pk)
         os.makedirs(os.path.join(d, "out"))
         res = {}
-        for mode, env in (("exact", {}), ("fast", {"HTKAMD_SHIM_FAST": "1"})):
+        for mode, env in (("fast", {}), ("exact", {"HTKAMD_SHIM_EXACT": "1"})):
           tt = []
           for k in (n, 2 * n):
             scp = os.path.join(d, "scp%d" % k)
@@ -37,10 +37,24 @@ if __name__ == "__main__":
                 sys.exit(r.stdout[-500:] + r.stderr[-500:])
           per = (tt[1] - tt[0]) / n
           res[mode] = {"wall_s": [round(x, 3) for x in tt], "ms_per_file": round(per * 1e3, 3), "files_per_s": round(1.0 / per, 1), "fixed_s": round(tt[0] - per * n, 2)}
-        T = c3.T
-        print(json.dumps({"files": [n, 2 * n], "ms_per_file": res["exact"]["ms_per_file"], "files_per_s": res["exact"]["files_per_s"],
-                          "default_exact": res["exact"], "HTKAMD_SHIM_FAST=1": res["fast"],
-                          "floor_ms_per_file": {"exact": round(2 * T * 1.1e-3, 3), "fast": round(2 * T * 0.55e-3, 3),
-                                                "note": "one utterance per call: 2 x %d dependent recursion steps at ~1.1 us (table-driven log-add) / ~0.55 us (fp32 transcendentals) "
-                                                        "a step -- what the call cannot go below whatever surrounds the recursions" % T},
-                          "note": "FBFile through the HFB shim: one utterance (500 frames, 41 models) per call; default = the reference's arithmetic throughout"}))
+        # what the device does for ONE such utterance, kernel by kernel (the same library, through the C ABI): the part of a call no host code can remove
+        from htk_amd import capi
+        import numpy as np
+        m = capi.Model(pk)
+        X = np.ascontiguousarray(s.feats[0]); dX = capi.DevArray(X)
+        fo = np.array([0, X.shape[0]], np.int32); lo = np.array([0, len(s.seqs[0])], np.int32)
+        dev = {}
+        for mode, sm in (("fast", capi.SCORE_EXACT | capi.SCORE_FASTLADD), ("exact", capi.SCORE_EXACT)):
+            fb, acc = capi.ForwardBackward(m), capi.Accs(m)
+            ks = []
+            for rep in range(5):
+                fb.prepare(dX.ptr.value, fo, lo, s.seqs[0].astype(np.int32)); fb.execute(capi.fb_config(scoreMode=sm), acc); fb.results()
+                ks.append(fb.kernel_times5())
+            k = np.median(np.array(ks), axis=0) * 1e3
+            dev[mode] = {"score": round(float(k[0]), 4), "beta": round(float(k[1]), 4), "alpha": round(float(k[2]), 4), "stats": round(float(k[3]), 4), "mix_stats": round(float(k[4]), 4),
+                         "sum": round(float(k.sum()), 4)}
+        print(json.dumps({"files": [n, 2 * n], "ms_per_file": res["fast"]["ms_per_file"], "files_per_s": res["fast"]["files_per_s"],
+                          "default": res["fast"], "HTKAMD_SHIM_EXACT=1": res["exact"], "device_ms_per_file": dev,
+                          "note": "FBFile through the HFB shim: one utterance (500 frames, 41 models) per call.  Scores exact in both modes; default = fp32-transcendental log-add in the "
+                                  "recursions (tolerance class), HTKAMD_SHIM_EXACT=1 = the table-driven log-add (alpha / beta bit-compatible).  device_ms_per_file: the kernels of one such "
+                                  "utterance alone (events around them, 2 x 500 dependent recursion steps) -- the floor of a call"}))
