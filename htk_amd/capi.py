@@ -83,7 +83,6 @@ def lib():
             raise HtkAmdError("%s is missing: run `python -m htk_amd.build` (hipcc --offload-arch=gfx950)" % LIBPATH)
         L = C.CDLL(LIBPATH)
         L.htkamd_last_error.restype = C.c_char_p
-        L.htkamd_fb_score_work.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.htkamd_fb_frame_states.restype = C.c_longlong
         L.htkamd_fb_frame_states.argtypes = [C.c_void_p]
         _lib = L

@@ -34,6 +34,20 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         # the bench issues the initial-model pass, the timed iteration and the stand-alone latency passes: report the per-launch mean
         traffic.setdefault(k, {})[c + "_KB"] = sum(vals) / len(vals)
         traffic[k]["launches"] = len(vals)
+# the other_paths legs' kernels, profiled on their own (tools/prof_r06.sh step 7, tools/r06_pmc_cmd.sh): k_decode joins the traffic table, both keep their counters
+legs = {}
+for leg in ("dec", "mfcc"):
+    p = os.path.join(out, leg, "summary.json")
+    if os.path.exists(p):
+        legs[leg] = json.load(open(p))
+        d = legs[leg]
+        if leg == "dec" and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            traffic["k_decode"] = {"FETCH_SIZE_KB": d["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": d["WRITE_SIZE"]["mean_per_launch"], "launches": d["FETCH_SIZE"]["n"],
+                                   "workload": "tools/dec_diag.py 256: 256 x 500 frames on the 6 000-word back-off bigram network (bench.py other_paths.hvite_decoding)"}
+if legs:
+    json.dump({"_comment": "counters of the other_paths legs' dominant kernels, each leg run on its own (tools/r06_pmc_cmd.sh): per-launch means; k_mfcc_frames: 2 000 x 3 s = 596 000 frames "
+                           "(tools/mfcc_bench.py), k_decode: 256 x 500 frames on the bigram network (tools/dec_diag.py)", "legs": legs},
+              open(os.path.join("profiles", "%s_legs.json" % tag), "w"), indent=1)
 try:
     cfg = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])["config"]
 except Exception:  # noqa: BLE001
