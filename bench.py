@@ -34,7 +34,8 @@ FLOP_PER_FRAME_STATE = lambda M, D: M * (4 * D + 8)
 FP32_PEAK_TFLOPS = 157.3                                 # MI355X dense FP32 (vector = matrix), MI355X_MICROARCH.md
 F16_PEAK_TFLOPS = 2500.0                                 # dense f16 / bf16 matrix peak (no sparsity), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                                    # HBM3E, MI355X_MICROARCH.md
-PROFILE_TRAFFIC = "r05_traffic.json"                     # profiles/: PMC passes of this round's kernels (tools/prof_r05.sh)
+PROFILE_TRAFFIC = "r06_traffic.json"                     # profiles/: PMC passes of this round's kernels (tools/prof_r06.sh)
+PROFILE_LEGS = "r06_legs.json"                           # ... and of the other_paths legs' kernels, each leg profiled on its own
 
 
 def cpu_baseline(s, pk, budget_s: float):
@@ -248,10 +249,27 @@ def mfcc_leg(pk, n_utt=2000, cpu_files=40):
     out = {"utterances": n_utt, "seconds_of_audio": 3.0 * n_utt, "frames": int(frames), "ms": dt * 1e3, "frames_per_sec": frames / dt, "pcm_GB_per_sec": allw.nbytes / dt / 1e9,
            "x_real_time": 3.0 * n_utt / dt, "config": "16 kHz, 25 ms / 10 ms, 512-point FFT, 26 channels, 12 cepstra + C0, _D_A (39 columns)",
            # 800 bytes in / 52 out per static frame; here also the 39-column rows of the qualifier kernels (written once, read by the regressions)
-           "roofline": {"kernel": "k_mfcc_frames + energy / regression kernels (host-timed call, waveforms and features resident)", "bound": "hbm",
-                        "achieved": (allw.nbytes + 4.0 * frames * fe.cols) / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": (allw.nbytes + 4.0 * frames * fe.cols) / dt / 1e9 / HBM_PEAK_GBS,
-                        "note": "bandwidth-trivial by construction (an LDS-resident FFT per frame): the figure of merit is frames/s"}}
+           "hbm_GB_per_sec": (allw.nbytes + 4.0 * frames * fe.cols) / dt / 1e9}
+    # What bounds the leg: not memory (800 bytes in, 156 out per frame: 0.01 of HBM) -- the frame kernel issues ~1 000 vector instructions and keeps the
+    # LDS pipe busy for ~600 cycles per frame, bank conflicts included.  Both from the committed counters of this workload (profiles/r06_legs.json:
+    # SQ_INSTS_VALU, SQ_ACTIVE_INST_LDS + SQ_LDS_BANK_CONFLICT per launch of k_mfcc_frames), priced against the call's time measured here:
+    # vector issue = 1 024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; LDS = one pipe per CU.
+    try:
+        lg = json.load(open(os.path.join(ROOT, "profiles", PROFILE_LEGS)))["legs"]["mfcc"]
+        valu, lds_cyc = lg["SQ_INSTS_VALU"]["mean_per_launch"], lg["SQ_ACTIVE_INST_LDS"]["mean_per_launch"] + lg["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"]
+        peak_issue = 1024 * 2.4e9 / 4.0
+        scale = frames / 596000.0                           # the counters are of the 596 000-frame run
+        out["roofline"] = {"kernel": "k_mfcc_frames (two frames per wavefront; + the regression kernels in the host-timed call)", "bound": "vector issue",
+                           "achieved": valu * scale / dt / 1e9, "peak": peak_issue / 1e9, "unit": "G wave-instructions/s", "frac": valu * scale / dt / peak_issue,
+                           "vector_instructions_per_frame": valu / 596000.0,
+                           "lds": {"busy_cycles_per_frame": lds_cyc / 596000.0, "bank_conflict_share": lg["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / lds_cyc,
+                                   "frac_of_lds_pipe": lds_cyc * scale / dt / (256 * 2.4e9)},
+                           "kernel_us_in_the_profiled_run": lg.get("duration_us", {}).get("median"),
+                           "note": "counters: profiles/%s (rocprofv3 --pmc, tools/r06_pmc_cmd.sh); time: this run's call.  HBM: %.3f of peak -- not the bound" % (
+                               PROFILE_LEGS, (allw.nbytes + 4.0 * frames * fe.cols) / dt / 1e9 / HBM_PEAK_GBS)}
+    except (OSError, KeyError, ValueError):
+        out["roofline"] = {"kernel": "k_mfcc_frames", "bound": "vector issue", "achieved": None, "peak": 1024 * 2.4 / 4.0, "unit": "G wave-instructions/s", "frac": None,
+                           "note": "no committed counters of this workload (profiles/%s)" % PROFILE_LEGS}
     # ... -> GMM scoring: the frames against the first 1 024 tied states of the headline set's shape (D = 39), bf16 x 3 matrix-core scores, on the device
     if int(pk["vecSize"]) == fe.cols:
         model = capi.Model(pk)
@@ -825,9 +843,15 @@ def main():
                              "traffic": traffic_of.get("k_mixstate"), "bytes_per_unit": 16 * D, "unit_is": "(frame, state, component) triple past the MINFORPROB prune",
                              "units_per_launch": triples_, "pairs_per_launch": pairs_}
         if triples_ > 0 and tmix > 0:
+            # `frac` is what the memory system really moved (counter bytes of the committed PMC passes) over the HBM peak; SURVEY §8(d)'s row -- 624 bytes of
+            # accumulator read-modify-write per triple -- is kept beside it as an ALGORITHMIC figure: those bytes never reach memory here (a state's sums
+            # stay in registers until one atomic per element), so it is no utilisation of anything.  The kernel is bound by latency (its ablations: DESIGN §4)
             am = triples_ * 16.0 * D / tmix / 1e9
-            per_kernel["mix"].update({"achieved": am, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": am / HBM_PEAK_GBS,
-                                      "note": "the accumulator traffic of §8(d)'s row never reaches memory here: a state's sums stay in registers until one atomic per element"})
+            tr_ = traffic_of.get("k_mixstate")
+            per_kernel["mix"].update({"bound": "latency (dependent phases per 32-pair chunk, one atomic per accumulator element and state)",
+                                      "achieved": (tr_ / tmix / 1e9) if tr_ else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (tr_ / tmix / 1e9 / HBM_PEAK_GBS) if tr_ else None,
+                                      "algorithmic": {"achieved": am, "unit": "GB/s", "over_hbm_peak": am / HBM_PEAK_GBS,
+                                                      "note": "SURVEY §8(d)'s accumulation row; not a bandwidth the kernel draws"}})
         # The scoring kernel's `frac` is EXECUTED flops over the dense peak of the pipe it runs on (<= 1 by construction); SURVEY §8(d)'s
         # algorithmic count (the fp32 algorithm's M (4D + 8) flop per frame-state) stays beside it under `algorithmic`.
         sc = per_kernel["score"]

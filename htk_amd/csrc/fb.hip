@@ -293,7 +293,12 @@ static int prep_utterance(htkamd_fb *fb, const htkamd_batch_desc *b, int u, Prep
       }
       if (T > C.TMax) C.TMax = T;
       C.outp += (size_t)T * nSlots; C.beta += (size_t)T * nCells; C.gam += (size_t)T * nSlots;
-      if (d.status != HTKAMD_UTT_OK) return HTKAMD_OK;
+      if (d.status != HTKAMD_UTT_OK) {
+         // (the per-frame tables are filled only when the batch's size changes: an utterance that stops here must not keep the words of another
+         //  batch's utterance at its frames -- htkamd_fb_get_trellis reads qBeamNP for the left-to-right class)
+         for (int t = 0; t < T; t++) { fb->taperLo[d.frame0 + t] = 0; fb->taperHi[d.frame0 + t] = 0; fb->qBeamNP[d.frame0 + t] = 1; }
+         return HTKAMD_OK;
+      }
       // SetBeamTaper
       short *lo = fb->taperLo.data() + d.frame0 - 1, *hi = fb->taperHi.data() + d.frame0 - 1;
       const int *dms = C.mDms.data() + d.q0 - 1;                         // 1-based q
@@ -794,7 +799,7 @@ static int fb_execute_impl(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_ac
    const int nGeneral = fb->clsOff[5] - fb->clsOff[4];
    fb->lastWave = nGeneral == 0;
    if (nGeneral > 0 && ldsAlpha > 160 * 1024) { htkamd_set_error("fb_execute: %zu bytes of LDS needed (max model size %zu states)", ldsAlpha, mn); return HTKAMD_EMODEL; }
-   if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 8 * 512)))) return rc;      /* (the lean alpha kernel requests up to three columns past an utterance's last: never used, but inside the buffer) */
+   if ((rc = fb->d_betaW.reserve(sizeof(double) * (fb->betaWTotal + 8 * 512)))) return rc;      /* (the lean alpha kernels request whole blocks of eight columns: up to seven columns of 64 W <= 512 values past an utterance's last -- never used, but inside the buffer) */
    fa.betaW = (double *)fb->d_betaW.p;
    const int nLr = fb->clsOff[13] - fb->clsOff[9];
    size_t rows = 0;
@@ -1019,7 +1024,8 @@ extern "C" int htkamd_fb_kernel_times(htkamd_fb *fb, double out[4])
    double t[5];
    const int rc = htkamd_fb_kernel_times5(fb, t);
    if (rc) return rc;
-   out[0] = t[0]; out[1] = t[1]; out[2] = t[2] + t[3]; out[3] = t[4];
+   // (-1: an interval the pass did not measure, htkamd_fb_set_event_mode(fb, 1) -- it stays -1 here, a sum with one is -1 too)
+   out[0] = t[0]; out[1] = t[1]; out[2] = (t[2] < 0.0 || t[3] < 0.0) ? -1.0 : t[2] + t[3]; out[3] = t[4];
    return HTKAMD_OK;
 }
 

@@ -93,6 +93,9 @@ __device__ __forceinline__ float ladd_tab_f(const float xf, const float yf, cons
    const float hi = fmaxf(xf, yf), lo = fminf(xf, yf);
    // (the float difference first: it is the double one to 2^-24 of its size, so below -23.03 the reference's cut-off, minLogExp = -23.0259,
    //  holds for certain and no double is formed)
+   // (the pre-test is valid only while the cut-off it anticipates is not below it: minLogExp = -log(-LZERO) = -23.0259 in every model this library makes,
+   //  htkamd_host_min_log_exp; a build with another LZERO has to move the literal)
+   static_assert(LZERO == -1.0E10, "ladd_tab_f: the float pre-test -23.03 assumes minLogExp = -log(1e10) = -23.0259");
    if (lo - hi < -23.03f) return (hi < (float)LSMALL) ? (float)LZERO : hi;
    const double d = (double)lo - (double)hi;
    if (d < minLogExp) return (hi < (float)LSMALL) ? (float)LZERO : hi;

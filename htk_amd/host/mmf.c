@@ -11,7 +11,8 @@
  * Binary definitions (':' + code byte keywords, big-endian numbers: PutSymbol :2581, Token.binForm :505) are read and
  * written as well, shared mixture pdfs (~m) are kept shared (one Gaussian, several components).  Shared mean / variance vectors
  * (~u / ~v macros referenced inside a mixture, GetMean :1737 / GetVariance :1770) are read, kept (every Gaussian holds its copy of the
- * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; ~m / ~u / ~v macros inside multi-stream sets, durations and
+ * values plus the number of the macro it shares: htkamd_mmf_sharing) and written back as macros; duration vectors (<DURATION>, ~d macros; the set's <POISSOND> / <GAMMAD> / <GEND> kind) are carried and written
+ * back (round 6); ~u / ~v macros inside multi-stream sets and
  * transforms are rejected with HTKAMD_EMODEL: they do not occur on the path's configurations.
  */
 #include <ctype.h>
@@ -21,10 +22,10 @@
 #include <string.h>
 #include "../csrc/internal.h"
 
-typedef struct { char *name; int nMix; int comp0; int inlineOwner; int src; int *sMix; float *sw; } mmf_state;   /* name NULL = un-named (inline); src: index of the file it came from;
-   several streams: nMix = all components of the state, sMix[s] those of stream s (consecutive from comp0), sw = <SWEIGHTS> or NULL */
+typedef struct { char *name; int nMix; int comp0; int inlineOwner; int src; int *sMix; float *sw; int dur; } mmf_state;   /* name NULL = un-named (inline); src: index of the file it came from;
+   several streams: nMix = all components of the state, sMix[s] those of stream s (consecutive from comp0), sw = <SWEIGHTS> or NULL; dur: its duration vector (dm[]) or -1 */
 typedef struct { char *name; int N; int off; int src; } mmf_trans;
-typedef struct { char *name; int N; int *state; int trans; int src; } mmf_hmm;     /* src: index of the file it came from */
+typedef struct { char *name; int N; int *state; int trans; int src; int dur; } mmf_hmm;     /* src: index of the file it came from; dur: the model's duration vector (dm[]) or -1 */
 
 struct htkamd_mmf {
    int vecSize, streamWidth, hasOpts;
@@ -44,6 +45,9 @@ struct htkamd_mmf {
    /* ~w stream-weight macros (GetSWeights HModel.c:1621): nStreams numbers under a name; a state that names one takes a copy (the set is written
       back with <SWEIGHTS> in the states) */
    struct { char *name; float w[8]; } *wm; int nWm, capWm;
+   /* duration vectors (GetDuration HModel.c:1580, PutDuration :2840): <DURATION> n v1..vn behind a state's streams or a model's transition matrix, inline or as
+      a ~d macro.  Nothing on the path reads them (HERest / HVite neither): they are carried and written back where they stood */
+   struct { char *name; int n; float *v; int src; } *dm; int nDm, capDm;
    /* logical list */
    char **logName; int *logPhys; int nLog; int *logSorted;        /* logSorted: list positions in name order (stable) */
    /* desc arrays */
@@ -230,8 +234,10 @@ static int parse_options(struct htkamd_mmf *s, rd *r)
       } else if (!strcmp(t, "HMMSETID")) {
          if (rd_next(r) != T_WORD) return fail(r, "set id expected");
          snprintf(s->setId, sizeof(s->setId), "%.127s", r->tok);
-      } else if (!strcmp(t, "NULLD")) snprintf(s->dur, sizeof(s->dur), "%.15s", t);
-      else if (!strcmp(t, "POISSOND") || !strcmp(t, "GAMMAD") || !strcmp(t, "GEND")) return fail(r, "duration models are not supported");
+      } else if (!strcmp(t, "NULLD") || !strcmp(t, "POISSOND") || !strcmp(t, "GAMMAD") || !strcmp(t, "GEND") || !strcmp(t, "RELD")) {
+         if (s->dur[0] && strcmp(s->dur, t)) return fail(r, "inconsistent duration kind");
+         snprintf(s->dur, sizeof(s->dur), "%.15s", t);                        /* (carried: no tool on the path evaluates a duration model) */
+      }
       else if (!strcmp(t, "DIAGC")) snprintf(s->cov, sizeof(s->cov), "%.15s", t);
       else if (!strcmp(t, "FULLC") || !strcmp(t, "XFORMC") || !strcmp(t, "LLTC") || !strcmp(t, "INVDIAGC")) return fail(r, "only DIAGC covariances are supported");
       else if (is_parm_kind(t)) {
@@ -414,6 +420,38 @@ static int parse_mixpdf(struct htkamd_mmf *s, rd *r, int *gOut)
 }
 
 /* state body after "~s name" or "<STATE> i": returns the new state index (GetStateInfo HModel.c:1924, GetStream :1850) */
+/* <DURATION> n v1 .. vn (the keyword has been read) -> a new entry of dm[] */
+static int parse_duration_body(struct htkamd_mmf *s, rd *r, char *name, int *dOut)
+{
+   int n, rc;
+   if ((rc = rd_int(r, &n))) return rc;
+   if (n < 1 || n > 4096) return fail(r, "bad size of a duration vector");
+   float *v = (float *)malloc(sizeof(float) * (size_t)n);
+   for (int i = 0; i < n; i++) if ((rc = rd_float(r, v + i))) { free(v); return rc; }
+   GROW(s->dm, s->nDm, s->capDm, 1, __typeof__(*s->dm));
+   s->dm[s->nDm].name = name; s->dm[s->nDm].n = n; s->dm[s->nDm].v = v; s->dm[s->nDm].src = s->nFiles;
+   *dOut = s->nDm++;
+   return HTKAMD_OK;
+}
+/* where a duration may stand (behind a state's streams, behind a model's transition matrix): <DURATION> ..., a ~d reference, or nothing (*dOut = -1, token pushed back) */
+static int parse_duration_opt(struct htkamd_mmf *s, rd *r, int *dOut)
+{
+   const int k = rd_next(r);
+   *dOut = -1;
+   if (k == T_KEY && !strcmp(r->tok, "DURATION")) return parse_duration_body(s, r, NULL, dOut);
+   if (k == T_MACRO && r->tok[0] == 'd') {
+      char *nm;
+      int rc;
+      if ((rc = rd_name(r, &nm))) return rc;
+      for (int q = 0; q < s->nDm; q++) if (s->dm[q].name && !strcmp(s->dm[q].name, nm)) *dOut = q;
+      free(nm);
+      if (*dOut < 0) return fail(r, "undefined ~d macro");
+      return HTKAMD_OK;
+   }
+   rd_push(r);
+   return HTKAMD_OK;
+}
+
 static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
 {
    const int S = s->nStreams > 1 ? s->nStreams : 1;
@@ -537,8 +575,10 @@ static int parse_state_body(struct htkamd_mmf *s, rd *r, char *name, int *sOut)
    s->curStream = 0;
    for (int i = 0; i < S; i++) if (!seen[i]) { free(sw); return fail(r, "a stream of the state is not defined"); }
    s->nComp += M;
+   int dur = -1;
+   if ((rc = parse_duration_opt(s, r, &dur))) { free(sw); return rc; }      /* GetStateInfo HModel.c:1985 */
    mmf_state *st = &s->st[s->nSt];
-   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1; st->src = s->nFiles; st->sMix = NULL; st->sw = sw;
+   st->name = name; st->nMix = M; st->comp0 = c0; st->inlineOwner = -1; st->src = s->nFiles; st->sMix = NULL; st->sw = sw; st->dur = dur;
    if (S > 1) { st->sMix = (int *)malloc(sizeof(int) * (size_t)S); memcpy(st->sMix, nMixS, sizeof(int) * (size_t)S); }
    *sOut = s->nSt++;
    return HTKAMD_OK;
@@ -590,9 +630,14 @@ static int parse_hmm(struct htkamd_mmf *s, rd *r, char *name)
    if (N < 3) { free(name); return fail(r, "<NUMSTATES> < 3"); }
    int *states = (int *)malloc(sizeof(int) * (size_t)N);
    for (int i = 0; i < N; i++) states[i] = -1;
-   int trans = -1;
+   int trans = -1, hdur = -1;
    for (;;) {
       k = rd_next(r);
+      if (trans >= 0 && ((k == T_KEY && !strcmp(r->tok, "DURATION")) || (k == T_MACRO && r->tok[0] == 'd'))) {      /* GetHMMDef HModel.c:2136: behind the transition matrix */
+         rd_push(r);
+         if ((rc = parse_duration_opt(s, r, &hdur))) goto bad;
+         continue;
+      }
       if (k == T_KEY && !strcmp(r->tok, "STATE")) {
          int i;
          if ((rc = rd_int(r, &i))) goto bad;
@@ -630,7 +675,7 @@ static int parse_hmm(struct htkamd_mmf *s, rd *r, char *name)
    for (int i = 1; i < N - 1; i++) if (states[i] < 0) { rc = fail(r, "missing <STATE>"); goto bad; }
    GROW(s->hm, s->nHm, s->capHm, 1, mmf_hmm);
    mmf_hmm *h = &s->hm[s->nHm++];
-   h->name = name; h->N = N; h->state = states; h->trans = trans; h->src = s->nFiles;
+   h->name = name; h->N = N; h->state = states; h->trans = trans; h->src = s->nFiles; h->dur = hdur;
    return HTKAMD_OK;
 bad:
    free(states); free(name);
@@ -728,6 +773,12 @@ int htkamd_mmf_read(struct htkamd_mmf *s, const char *path, const char *defName)
          GROW(s->vm, s->nVm, s->capVm, 1, __typeof__(*s->vm));
          s->vm[s->nVm].type = type; s->vm[s->nVm].name = name; s->vm[s->nVm].v = v; s->vm[s->nVm].src = s->nFiles; s->vm[s->nVm].stream = vstream;
          s->nVm++;
+      } else if (type == 'd') {                              /* ~d "name" <DURATION> n v1 .. vn */
+         int di, dup = 0;
+         for (int q = 0; q < s->nDm; q++) if (s->dm[q].name && !strcmp(s->dm[q].name, name)) dup = 1;
+         if (dup) { rc = fail(&r, "~d macro defined twice"); free(name); break; }
+         if (rd_next(&r) != T_KEY || strcmp(r.tok, "DURATION")) { rc = fail(&r, "<DURATION> expected"); free(name); break; }
+         if ((rc = parse_duration_body(s, &r, name, &di))) { free(name); break; }
       } else if (type == 'w') {                              /* ~w "name" <SWEIGHTS> S w1 .. wS */
          int n = 0;
          const int S = s->nStreams > 1 ? s->nStreams : 1;
@@ -920,6 +971,8 @@ void htkamd_mmf_destroy(struct htkamd_mmf *s)
    for (int i = 0; i < s->nVm; i++) { free(s->vm[i].name); free(s->vm[i].v); }
    for (int i = 0; i < s->nWm; i++) free(s->wm[i].name);
    free(s->wm);
+   for (int i = 0; i < s->nDm; i++) { free(s->dm[i].name); free(s->dm[i].v); }
+   free(s->dm);
    free(s->vm); free(s->gMeanMac); free(s->gVarMac);
    free(s->stateCompOff); free(s->transN); free(s->transOff); free(s->hmmTrans); free(s->hmmStateOff); free(s->hmmState);
    free(s);
@@ -1015,7 +1068,7 @@ static void put_options(const struct htkamd_mmf *s, FILE *f)
    else { put_short(f, 1); put_short(f, s->streamWidth); }
    put_nl(f);
    put_sym(f, "VECSIZE", 6); put_short(f, s->vecSize);
-   put_sym(f, s->dur, 7);                                            /* NULLD */
+   put_sym(f, s->dur, !strcmp(s->dur, "POISSOND") ? 8 : !strcmp(s->dur, "GAMMAD") ? 9 : !strcmp(s->dur, "RELD") ? 10 : !strcmp(s->dur, "GEND") ? 11 : 7);      /* NULLD unless the set says otherwise */
    fprintf(f, "<%s><%s>", s->kind[0] ? s->kind : "USER", s->cov);      /* parameter and covariance kinds are text even in binary files */
    put_nl(f);
 }
@@ -1042,6 +1095,7 @@ static void put_gauss(const struct htkamd_mmf *s, FILE *f, int g, const float *m
    if (va >= 0) put_name(f, 'v', s->vm[va].name); else put_vec_ms(s, f, "VARIANCE", 21, var + (size_t)g * D, s->nStreams > 1 ? s->gStr[g] : -1);
    if (gconst) { put_sym(f, "GCONST", 24); put_float(f, gconst[g]); put_nl(f); }
 }
+static void put_dur(const struct htkamd_mmf *s, FILE *f, int d, int define);
 static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *mean, const float *var, const float *gconst, const float *wt)
 {
    const mmf_state *st = &s->st[si];
@@ -1087,6 +1141,15 @@ static void put_state(const struct htkamd_mmf *s, FILE *f, int si, const float *
       }
       c0 += M;
    }
+   put_dur(s, f, st->dur, 0);
+}
+static void put_dur(const struct htkamd_mmf *s, FILE *f, int d, int define)      /* PutDuration HModel.c:2840: a named vector is a reference but where it is defined */
+{
+   if (d < 0) return;
+   if (s->dm[d].name && !define) { put_name(f, 'd', s->dm[d].name); return; }
+   put_sym(f, "DURATION", 25); put_short(f, s->dm[d].n); put_nl(f);
+   for (int i = 0; i < s->dm[d].n; i++) put_float(f, s->dm[d].v[i]);
+   put_nl(f);
 }
 static void put_trans(FILE *f, const float *logp, int N)
 {
@@ -1117,6 +1180,7 @@ static void put_hmm(const struct htkamd_mmf *s, FILE *f, int h, int withHdr, con
    }
    if (s->tr[hm->trans].name) put_name(f, 't', s->tr[hm->trans].name);
    else put_trans(f, tp + s->tr[hm->trans].off, hm->N);
+   put_dur(s, f, hm->dur, 0);
    put_sym(f, "ENDHMM", 2); put_nl(f);
 }
 
@@ -1174,11 +1238,17 @@ static int write_macros(const struct htkamd_mmf *s, const float *mean, const flo
       names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
       idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
       ord = (int *)realloc(ord, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + 1));
+      names = (char **)realloc(names, sizeof(char *) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + s->nDm + 1));
+      idx = (int *)realloc(idx, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + s->nDm + 1));
+      ord = (int *)realloc(ord, sizeof(int) * (size_t)(s->nSt + s->nTr + s->nHm + s->nVm + s->nDm + 1));
+      const int DUR0 = 1 << 29;                                /* idx >= DUR0: duration macro idx - DUR0 (~d is an atomic macro too, SaveMacros :4375) */
       for (int i = 0; i < s->nVm; i++) if (SRC(s->vm[i].src)) { names[nN] = s->vm[i].name; idx[nN++] = -1 - i; }
       for (int t = 0; t < s->nTr; t++) if (s->tr[t].name && SRC(s->tr[t].src)) { names[nN] = s->tr[t].name; idx[nN++] = t; }
+      for (int q = 0; q < s->nDm; q++) if (s->dm[q].name && SRC(s->dm[q].src)) { names[nN] = s->dm[q].name; idx[nN++] = DUR0 + q; }
       macro_order(names, nN, ord);
       for (int k = 0; k < nN; k++) {
          const int t = idx[ord[k]];
+         if (t >= DUR0) { put_name(f, 'd', s->dm[t - DUR0].name); put_dur(s, f, t - DUR0, 1); continue; }
          if (t >= 0) { put_name(f, 't', s->tr[t].name); put_trans(f, transP + s->tr[t].off, s->tr[t].N); continue; }
          const int i = -1 - t;
          const float *v = s->vm[i].v;
@@ -1225,6 +1295,7 @@ static int mmf_write(const struct htkamd_mmf *s, const float *mean, const float 
    for (int t = 0; t < s->nTr; t++) if (s->tr[t].name) { htkamd_set_error("mmf_write: a set with ~t macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int g = 0; g < s->nG && g < s->capGN; g++) if (s->gName[g]) { htkamd_set_error("mmf_write: a set with ~m macros must be written to one file"); return HTKAMD_EINVAL; }
    if (s->nVm > (s->varFloor ? 1 : 0)) { htkamd_set_error("mmf_write: a set with ~u / ~v macros must be written to one file"); return HTKAMD_EINVAL; }
+   for (int q = 0; q < s->nDm; q++) if (s->dm[q].name) { htkamd_set_error("mmf_write: a set with ~d macros must be written to one file"); return HTKAMD_EINVAL; }
    for (int h = 0; h < s->nHm; h++) {
       char path[1400];
       snprintf(path, sizeof(path), "%s/%s", dir, s->hm[h].name);

@@ -539,7 +539,8 @@ int  htkamd_fb_get_trellis(htkamd_fb *fb, int utt, double *beta, double *alpha, 
                            int *qLo, int *qHi, int *aLo, int *aHi, int *T, int *Q, int *maxN, void *stream);
 /* Seconds spent in the kernels of the last execute, measured with HIP events on `stream`:
    out[0]=scoring (the dispatch's own start -> stop, hipExtLaunchKernel: what a kernel trace reports even when other streams share
-   the device) out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics (intervals between stream events). Synchronises. */
+   the device) out[1]=beta out[2]=alpha+occ/trans out[3]=mixture statistics (intervals between stream events). Synchronises.
+   An interval the pass did not measure (htkamd_fb_set_event_mode(fb, 1)) reads -1, and so does a sum with one. */
 int  htkamd_fb_kernel_times(htkamd_fb *fb, double out[4]);
 /* the same with the alpha pass and the left-to-right path's frame-parallel statistics apart: scoring, beta, alpha, statistics, mixture statistics */
 int  htkamd_fb_kernel_times5(htkamd_fb *fb, double out[5]);

@@ -121,6 +121,35 @@ def test_mmf_binary_form(native, tmp_path):
     assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "syn_resaved_bin.mmf"), "rb").read()
 
 
+def test_mmf_duration_vectors_are_carried(native, tmp_path):
+    """<DURATION> vectors and ~d macros (GetDuration HModel.c:1580; no tool on the path evaluates them): a hand-written set with a <GAMMAD> kind, a ~d macro
+    named by a state and by a model, an inline vector in a state and in a model is written back -- text and binary -- byte for byte as the reference's
+    HHEd re-saves it (tests/golden/make_duration_golden.py), and the binary form reads to the same set."""
+    lst = os.path.join(GOLD, "mmf", "dur_list")
+    m = native.Mmf(files=[os.path.join(GOLD, "mmf", "dur_in.mmf")], hmm_list=lst)
+    q = m.packed()
+    assert q["numStates"] == 3 and q["numGauss"] == 4 and m.phys_names == ["a", "b"]
+    params = dict(mean=q["mean"], var=q["var"], gconst=_gconst(native, q["var"]), compWeight=q["compWeight"], transP=q["transP"])
+    out = tmp_path / "out.mmf"
+    m.write(params, one_file=str(out))
+    assert out.read_bytes() == open(os.path.join(GOLD, "mmf", "dur_resaved.mmf"), "rb").read()
+    mb = native.Mmf(files=[os.path.join(GOLD, "mmf", "dur_resaved_bin.mmf")], hmm_list=lst)
+    qb = mb.packed()
+    for k in ("mean", "var", "compWeight", "hmmState", "stateCompOff"):
+        assert np.array_equal(q[k], qb[k]), k
+    outb = tmp_path / "out.bin"
+    mb.write(dict(mean=qb["mean"], var=qb["var"], gconst=qb["gconst"], compWeight=qb["compWeight"], transP=qb["transP"]), one_file=str(outb), binary=True)
+    assert outb.read_bytes() == open(os.path.join(GOLD, "mmf", "dur_resaved_bin.mmf"), "rb").read()
+    # a set with a ~d macro cannot go to one file per model; an undefined macro is an error with the file's line
+    with pytest.raises(native.HtkAmdError):
+        m.write(params, out_dir=str(tmp_path))
+    bad = tmp_path / "bad.mmf"
+    bad.write_text(open(os.path.join(GOLD, "mmf", "dur_in.mmf")).read().replace('~d "durA"\n<ENDHMM>', '~d "nope"\n<ENDHMM>'))
+    with pytest.raises(native.HtkAmdError) as ei:
+        native.Mmf(files=[str(bad)], hmm_list=lst)
+    assert "undefined ~d macro" in str(ei.value)
+
+
 def test_mmf_shared_mixture_macros(native, tmp_path):
     """~m macros (HHEd TI on mixture components): the shared pdf is ONE Gaussian referenced by several components, and the
     set is written back exactly as the reference wrote it."""
