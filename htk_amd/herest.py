@@ -66,6 +66,43 @@ def all_reduce_accumulators(vec_tensor, wire: str = "f64", bulk: int | None = No
     vec_tensor[:bulk].copy_(w)
 
 
+def state_ranges(pk: dict, lay: dict, state0: int, state1: int, with_rest: bool = False):
+    """[(offset, length)] of the accumulator vector's ranges that belong to tied states [state0, state1): mu, muOcc, va, vaOcc of their Gaussians, wt of their components,
+    wtOcc -- and with `with_rest` what no state owns and travels as statistics (tr, trOcc).  The host mirror of htkamd_accs_state_ranges (csrc/comm.hip): sets whose
+    components own their Gaussians in state order only (compGauss[c] == c)."""
+    cg = np.asarray(pk["compGauss"])
+    if int(pk["numGauss"]) != int(pk["numComp"]) or not np.array_equal(cg, np.arange(cg.size)) or int(pk.get("numStreams", 1) or 1) > 1:
+        raise ValueError("the set's components do not own their Gaussians in state order: exchange the vector whole")
+    off = np.asarray(pk["stateCompOff"])
+    g0, g1, D = int(off[state0]), int(off[state1]), int(pk["vecSize"])
+    out = [(lay["mu"] + g0 * D, (g1 - g0) * D), (lay["muOcc"] + g0, g1 - g0), (lay["va"] + g0 * D, (g1 - g0) * D), (lay["vaOcc"] + g0, g1 - g0),
+           (lay["wt"] + g0, g1 - g0), (lay["wtOcc"] + state0, state1 - state0)]
+    if with_rest:
+        out.append((lay["tr"], lay["nEgs"] - lay["tr"]))
+    return [(o, n) for o, n in out if n > 0]
+
+
+def all_reduce_accumulators_in_parts(vec_tensor, pk: dict, lay: dict, n_parts: int, wire: str = "f32") -> None:
+    """The exchange of all_reduce_accumulators cut into `n_parts` by tied state (bench.py --exchange-slices; on the device the parts are packed by
+    htkamd_accs_pack_ranges and travel while the next range of states is still being summed): part i = the ranges of states [S i / n, S (i + 1) / n), the last part with
+    tr / trOcc and the fp64 counters behind them.  Leaves the vector the whole exchange leaves."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    S = int(pk["numStates"])
+    dt = torch.float32 if wire == "f32" else torch.float64
+    for i in range(n_parts):
+        rg = state_ranges(pk, lay, S * i // n_parts, S * (i + 1) // n_parts, with_rest=(i == n_parts - 1))
+        w = torch.cat([vec_tensor[o:o + n] for o, n in rg]).to(dt)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        at = 0
+        for o, n in rg:
+            vec_tensor[o:o + n] = w[at:at + n].to(vec_tensor.dtype); at += n
+    if lay["nEgs"] < vec_tensor.numel():
+        dist.all_reduce(vec_tensor[lay["nEgs"]:], op=dist.ReduceOp.SUM)
+
+
 def device_vector_as_tensor(accs, device_index: int):
     """Zero-copy torch view of an htkamd_accs device vector (for the collective)."""
     import torch

@@ -63,7 +63,15 @@ def fuzz_fb(rng, it):
         extra["minFrwdP"] = float(rng.choice([3.0, 5.0, 20.0, 40.0]))
     if rng.random() < 0.3:
         extra["uFlags"] = int(rng.integers(1, 16))
-    fb.execute(capi.fb_config(scoreMode=mode, **prune, **extra), acc)
+    if rng.random() < 0.35:                                            # the pass in two phases, the states in random ranges in random order (htkamd_fb_execute_begin / _mix)
+        if fb.execute_begin(capi.fb_config(scoreMode=mode, **prune, **extra), acc):
+            S_ = int(pk["numStates"])
+            cuts = sorted(set([0, S_] + [int(x) for x in rng.integers(0, S_ + 1, size=int(rng.integers(0, 4)))]))
+            parts = list(zip(cuts[:-1], cuts[1:]))
+            for k_ in rng.permutation(len(parts)):
+                fb.execute_mix(parts[k_][0], parts[k_][1])
+    else:
+        fb.execute(capi.fb_config(scoreMode=mode, **prune, **extra), acc)
     pr, st = fb.results()
     a = acc.download()
     oacc = pyoracle.Accs(om)

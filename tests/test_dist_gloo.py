@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, wire="f64", nutt=9):
+def _worker(rank, world, port, q, wire="f64", nutt=9, parts=0):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -38,7 +38,10 @@ def _worker(rank, world, port, q, wire="f64", nutt=9):
             tot_pr += pr; tot_t += s.feats[u].shape[0]; done += 1
     vec = herest.pack_vector(lay, acc, tot_pr, tot_t, done)
     t = torch.from_numpy(vec)
-    herest.all_reduce_accumulators(t, wire=wire, bulk=lay["nEgs"])      # dist.all_reduce(SUM) on the flat vector (fp64, or floats on the wire)
+    if parts:
+        herest.all_reduce_accumulators_in_parts(t, pk, lay, parts, wire=wire)      # the same exchange in `parts` parts by tied state (bench.py --exchange-slices)
+    else:
+        herest.all_reduce_accumulators(t, wire=wire, bulk=lay["nEgs"])      # dist.all_reduce(SUM) on the flat vector (fp64, or floats on the wire)
     q.put((rank, t.numpy().copy(), list(mine)))
     dist.destroy_process_group()
 
@@ -118,6 +121,39 @@ def test_eight_rank_fp32_wire_equals_single_process():
     scale = np.maximum(np.abs(ref[:bulk]), 1.0)
     assert np.max(np.abs(v0[:bulk] - ref[:bulk]) / scale) <= 1e-6
     assert np.all(v0[:bulk] == v0[:bulk].astype(np.float32))  # what came back are floats
+
+
+@pytest.mark.parametrize("wire", ["f64", "f32"])
+def test_exchange_in_parts_equals_the_whole_exchange_two_ranks(wire):
+    """bench.py --exchange-slices on the host side: the accumulator vector travels in four parts by tied state (herest.state_ranges, the mirror of
+    htkamd_accs_state_ranges) -- every rank ends with the vector ONE all-reduce leaves, bit for bit on either wire (two ranks: a sum of two is the same in either order);
+    the parts are disjoint and cover the statistics' part of the vector."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from htk_amd import herest, synth
+    ctx = mp.get_context("spawn")
+    out = {}
+    for parts in (0, 4):
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_worker, args=(r, 2, port, q, wire, 9, parts)) for r in range(2)]
+        for p in ps:
+            p.start()
+        res = sorted([q.get(timeout=120) for _ in ps], key=lambda x: x[0])
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        assert np.array_equal(res[0][1], res[1][1])
+        out[parts] = res[0][1]
+    assert np.array_equal(out[0], out[4])
+    pk = synth.generate(30, 3, 20, 1, 20, 55).packed()
+    lay = herest.layout_from_packed(pk)
+    seen = np.zeros(lay["total"], np.int32)
+    S = int(pk["numStates"])
+    for i in range(4):
+        for o, n in herest.state_ranges(pk, lay, S * i // 4, S * (i + 1) // 4, with_rest=(i == 3)):
+            seen[o:o + n] += 1
+    assert (seen[:lay["nEgs"]] == 1).all() and not seen[lay["nEgs"]:].any()
 
 
 def test_shards_are_balanced_and_disjoint():

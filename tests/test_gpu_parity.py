@@ -316,6 +316,10 @@ def test_pass_in_two_phases_and_exchange_ranges(native, oracle, monkeypatch):
         for off, ln in acc.state_ranges(s0, s1, with_rest=(i == 2)):
             seen[off:off + ln] += 1
     assert (seen[:L.nEgs] == 1).all() and not seen[L.nEgs:].any()
+    from htk_amd import herest                                             # the host mirror the CPU (gloo) tests use names the same ranges
+    hl = herest.layout_from_packed(pk)
+    for i, (s0, s1) in enumerate(cuts):
+        assert herest.state_ranges(pk, hl, s0, s1, with_rest=(i == 2)) == acc.state_ranges(s0, s1, with_rest=(i == 2))
     # pack / unpack
     v0 = acc.download()["vec"].copy()
     rg = acc.state_ranges(7, 31, with_rest=True)
