@@ -387,8 +387,8 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
          }
       }
       DEC_STAMP(0);
-#ifdef DEC_NEED
-      if (tid < 256) needB[tid] = 0;
+#ifdef DEC_NEED                                         /* -DDEC_NEED=1: per frame; -DDEC_NEED=16: the union over blocks of 16 frames (what ANY block-wise scheme has to score at least) */
+      if ((t - 1) % (DEC_NEED + 0 > 0 ? DEC_NEED + 0 : 1) == 0 || t < 1) { if (tid < 256) needB[tid] = 0; }
       __syncthreads();
 #endif
       if (t >= 1) {
@@ -477,12 +477,13 @@ __global__ __launch_bounds__(NTHR) void k_decode(DecArgs a)
       }
 #ifdef DEC_NEED
       __syncthreads();
-      if (t >= 1 && tid < 64) {
+      if (t >= 1 && tid < 64 && (t % (DEC_NEED + 0 > 0 ? DEC_NEED + 0 : 1) == 0 || t == ud.T)) {      /* at the end of a block: its distinct states x its frames */
          unsigned int c = 0;
          for (int i = tid; i < 256; i += 64) c += __popc(needB[i]);
 #pragma unroll
          for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-         needSum += c;
+         const int blk = (DEC_NEED + 0 > 0 ? DEC_NEED + 0 : 1);
+         needSum += (unsigned long long)c * (unsigned long long)(t % blk == 0 ? blk : t % blk);
       }
 #endif
       DEC_STAMP(2);
