@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_rec_reduce(FbArgs a)
 #ifndef LR_EXP_BUILD
 #define LR_EXP_BUILD 0
 #endif
-#define MS_EXP(bit) (LR_EXP_BUILD && (a.lrExp & (bit)))      // ablations of a diagnostic build (tools/lr_exp.py): 256 no sums, 512 fp32 exp, 1024 no rows, 2048 no distances
+#define MS_EXP(bit) (LR_EXP_BUILD && (a.lrExp & (bit)))      // ablations of a diagnostic build (tools/lr_exp.py): 256 no sums, 512 fp32 exp, 1024 no rows, 2048 no distances, 8192 no atomics
 #ifndef MS_EU
 #define MS_EU 8                  /* the launch bound's second figure: 1, 2, 4, 5, 6, 8 give the same 155-register kernel at 0.28-0.29 ms, 3 a 151-register one at 0.33 (tools/r05_var.sh) */
 #endif
@@ -1032,6 +1032,12 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
 #ifndef MS_CHUNK
 #define MS_CHUNK 32
 #endif
+#ifndef MS_CAP
+#define MS_CAP 128               /* pairs per part of a state: 64 / 96 / 128 / 256 give 0.255 / 0.237 / 0.239 / 0.242 ms against 0.285 for whole states (tools/r05_var.sh) */
+#endif
+#ifndef MS_PARTS
+#define MS_PARTS 4
+#endif
    constexpr int GS = 16, HPS = 64 / GS, NQ = (DT + 1) / 2, XS = (DT + 3) & ~3;      // XS: floats per row in LDS (16-byte multiple)
    constexpr int CH = MS_CHUNK;                          // pairs per chunk: 14 KB of LDS at 32 (11 workgroups per CU), 24 KB at 64 (6)
    __shared__ float xs[CH * XS];
@@ -1039,9 +1045,13 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
    __shared__ double hSeed[CH];
    const int st = a.stBase + blockIdx.x, lane = threadIdx.x, grp = lane / GS, sub = lane % GS;
    const int nst = a.stCnt[st] < a.stCap ? a.stCnt[st] : a.stCap;
-   if (nst <= 0) return;
+   // A state's pairs in PARTS of MS_CAP, a wavefront each (blockIdx.y; the last part takes what is left).  Round 6: the kernel's time was its LONGEST
+   // wavefront's -- 435 pairs = 14 chunks on the headline set where the mean is 125 = 4.4 chunks (a tied state is used by 1 + Poisson(2.6) models) --
+   // 284 us for 133 us worth of work per slot.  A part has its own sums and its own atomics (7 282 parts instead of 5 000 wavefronts at 128).
+   const int part = blockIdx.y;
+   const int r0 = part * MS_CAP, r1 = (part == (int)gridDim.y - 1 || r0 + MS_CAP > nst) ? nst : r0 + MS_CAP;
+   if (r0 >= nst) return;
    const HitS *bucket = a.stBucket + (size_t)st * a.stCap;
-   const int r0 = 0, r1 = nst;
    const int c0 = a.stateCompOff[st], M = a.stateCompOff[st + 1] - c0;
    const bool single = (M == 1 || a.maxM == 1);
    constexpr bool upMu = (MODE & 1) != 0, upVa = (MODE & 2) != 0;
@@ -1084,6 +1094,8 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
       // pair touched 64 cache lines per instruction and cost the kernel 0.19 ms): no registers in between, every row of the chunk in flight
       // (the frame numbers are taken with every lane switched on -- lane r of `hfr` is read for r < n <= 32, and at D = 13 / 26 some of those
       //  lanes are outside the loads' `lane < DT` -- only the load itself is predicated)
+      // (round 6: the next chunk's rows requested while this chunk is worked on -- two halves of `xs`, the entries a chunk further ahead -- measured:
+      //  0.235 ms at 16 pairs per chunk against 0.239 without at 32; the second half's LDS costs the occupancy what the overlap gains.  Not kept.)
       for (int r = 0; r < n; r++) {
          const int fr = MS_EXP(1024) ? 0 : __builtin_amdgcn_readlane(hfr, r);
          if (lane < DT)
@@ -1172,6 +1184,7 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
       }
    }
    // ---- out: one atomic per accumulator element of the state's Gaussians, component, and the state
+   if (MS_EXP(8192)) return;                             // (diagnostic: without the atomics)
 #pragma unroll
    for (int m = 0; m < GS; m++) {
       if (m < M && lane < DT) {
@@ -1190,7 +1203,7 @@ __global__ __launch_bounds__(64, MS_EU) void k_mixstate(FbArgs a)
 #pragma unroll
    for (int o = 32; o > 0; o >>= 1) nTriples += __shfl_xor(nTriples, o);
    // the state's counts in its own two cells (htkamd_fb_mix_counts sums them): 10 000 updates of two shared cells were 10 us of the kernel's tail
-   if (lane == 0) { a.stCnt[a.nTiedStates + 4 + 2 * st] = nst; a.stCnt[a.nTiedStates + 5 + 2 * st] = nTriples; }
+   if (lane == 0) { if (part == 0) a.stCnt[a.nTiedStates + 4 + 2 * st] = nst; atomicAdd(a.stCnt + a.nTiedStates + 5 + 2 * st, nTriples); }      // (zeroed with the buckets' counters before the pass)
    double so = (sub < M) ? w : 0.0;
 #pragma unroll
    for (int o = GS / 2; o > 0; o >>= 1) so += __shfl_xor(so, o);
@@ -1209,10 +1222,10 @@ int htkamd_launch_mixstate_range(const FbArgs &a_in, int st0, int st1, hipStream
    const int mode = ((a.uFlags & HTKAMD_UPMEANS) ? 1 : 0) | ((a.uFlags & HTKAMD_UPVARS) ? 2 : 0);
 #define MS_LAUNCH(DT_) \
    do { \
-      if (mode == 3) hipLaunchKernelGGL((k_mixstate<DT_, 3>), dim3(S), dim3(64), 0, s, a); \
-      else if (mode == 1) hipLaunchKernelGGL((k_mixstate<DT_, 1>), dim3(S), dim3(64), 0, s, a); \
-      else if (mode == 2) hipLaunchKernelGGL((k_mixstate<DT_, 2>), dim3(S), dim3(64), 0, s, a); \
-      else hipLaunchKernelGGL((k_mixstate<DT_, 0>), dim3(S), dim3(64), 0, s, a); \
+      if (mode == 3) hipLaunchKernelGGL((k_mixstate<DT_, 3>), dim3(S, MS_PARTS), dim3(64), 0, s, a); \
+      else if (mode == 1) hipLaunchKernelGGL((k_mixstate<DT_, 1>), dim3(S, MS_PARTS), dim3(64), 0, s, a); \
+      else if (mode == 2) hipLaunchKernelGGL((k_mixstate<DT_, 2>), dim3(S, MS_PARTS), dim3(64), 0, s, a); \
+      else hipLaunchKernelGGL((k_mixstate<DT_, 0>), dim3(S, MS_PARTS), dim3(64), 0, s, a); \
    } while (0)
    if (a.D == 39) MS_LAUNCH(39); else if (a.D == 26) MS_LAUNCH(26); else MS_LAUNCH(13);
 #undef MS_LAUNCH
