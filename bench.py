@@ -982,11 +982,12 @@ def main():
             # occupancy in the sample (a sum over one or two frames carries the posterior noise of those frames undiminished; reported
             # below as `sums_of_gaussians_under_3_frames`, unasserted: the whole job gives every Gaussian 8x the shard's frames)
             assert max(worst_acc.values()) <= 1e-4, "bench: accumulators differ from the oracle: %r (Gaussians under three frames: %r)" % (worst_acc, worst_few)
-            # ... and those sums themselves against a bound of their own: 2e-4 of max(|ref|, occupancy) -- one or two frames' posteriors do not
-            # average out, so the entry-wise worst case over ~11 000 such Gaussians sits above the 1e-4 of the others (observed 6e-5 .. 1e-4);
-            # a real regression of the scores shows here first and fails the run
-            assert max(worst_few.values()) <= 2e-4, "bench: sums of the Gaussians under three frames differ from the oracle: %r" % (worst_few,)
-            worst_acc["sums_of_gaussians_under_3_frames"] = dict(worst_few, gaussians=int(few_.sum()), asserted_at=2e-4)
+            # ... and those sums themselves -- one or two frames' posteriors do not average out -- at 1e-4 too in the mode the line is measured with (bf16 x 3 scores:
+            # observed 5.2e-5 over the ~11 000 such Gaussians of the shard; the exact mode far below); the fp16 x 2 scores of `--score fastest` have been seen
+            # at 6e-5 .. 1e-4 there and keep 2e-4.  A real regression of the scores shows here first and fails the run
+            bar_few = 2e-4 if (cfg.scoreMode & capi.SCORE_F16) else 1e-4
+            assert max(worst_few.values()) <= bar_few, "bench: sums of the Gaussians under three frames differ from the oracle: %r" % (worst_few,)
+            worst_acc["sums_of_gaussians_under_3_frames"] = dict(worst_few, gaussians=int(few_.sum()), asserted_at=bar_few)
             del fbc, accc, m0
             out["oracle_check"] = {"utterances": n, "max_rel_diff_logprob": worst, "tolerance": tol,
                                    "accumulators_max_rel_diff": worst_acc, "accumulators_tolerance": 1e-4,

@@ -3,8 +3,8 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?}"
 tag=${1:-r06c}
-bash tools/r05_decvar.sh "-DDEC_NEED=1" "-DDEC_NEED=4" "-DDEC_NEED=16" 2>&1 | grep -v "^$" | tail -12
-touch htk_amd/csrc/decode.hip; python3 -m htk_amd.build > /dev/null 2>&1
+# (the decoder's block-wise demand: bash tools/r05_decvar.sh "-DDEC_NEED=1" "-DDEC_NEED=4" "-DDEC_NEED=16" -- measured once, docs/history.md)
+
 python -m pytest tests/test_htklib_shim.py tests/test_gpu_parity.py tests/test_gpu_multi.py -x -q -m gpu -k "shim or two_phases or sits_out or exchange_in_parts" 2>&1 | tail -3
 python tests/fuzz_parity.py 400 20261104 fb,streams 2>&1 | tail -2
 bash tools/prof_r06.sh "$tag" 2>&1 | tail -2
