@@ -94,6 +94,33 @@ extern "C" int htkamd_stream_sync(void *stream)
    return HTKAMD_OK;
 }
 
+extern "C" int htkamd_stream_create(void **stream)
+{
+   if (!stream) { htkamd_set_error("stream_create: NULL"); return HTKAMD_EINVAL; }
+   hipStream_t s;
+   HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+   *stream = (void *)s;
+   return HTKAMD_OK;
+}
+
+extern "C" int htkamd_stream_destroy(void *stream)
+{
+   if (stream) HIPCHECK(hipStreamDestroy((hipStream_t)stream));
+   return HTKAMD_OK;
+}
+
+// what is queued on `waiter` from here on starts behind what has been queued on `signaller` so far
+extern "C" int htkamd_stream_wait(void *waiter, void *signaller)
+{
+   hipEvent_t ev;
+   HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+   hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+   if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+   (void)hipEventDestroy(ev);                            // (released when the record has completed)
+   if (e != hipSuccess) { htkamd_set_error("stream_wait: %s", hipGetErrorString(e)); return HTKAMD_EHIP; }
+   return HTKAMD_OK;
+}
+
 template <typename T> static T *dupHost(const T *src, size_t n)
 {
    T *p = (T *)malloc(sizeof(T) * (n ? n : 1));

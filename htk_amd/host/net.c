@@ -258,7 +258,7 @@ static int read_slf(const char *path, lnode **nodes, int *nn, larc **arcs, int *
       const char *p = line;
       while (isspace((unsigned char)*p)) p++;
       if (*p == '#' || !*p) continue;
-      if (!strncmp(p, "SUBLAT", 6)) { fclose(f); free(ln); free(la); htkamd_set_error("%s: a multi-level lattice (SUBLAT) must be expanded before a network is made of it (the reference says the same: InitPronHolders HNet.c:2358, "Expand lattice before making network"; HBuild -x expands)", path); return HTKAMD_EMODEL; }
+      if (!strncmp(p, "SUBLAT", 6)) { fclose(f); free(ln); free(la); htkamd_set_error("%s: a multi-level lattice (SUBLAT) must be expanded before a network is made of it (the reference says the same: InitPronHolders HNet.c:2358, 'Expand lattice before making network'; HBuild -x expands)", path); return HTKAMD_EMODEL; }
       if (N < 0) {
          if (field(p, "N", v, sizeof(v)) || field(p, "NODES", v, sizeof(v))) {
             N = atoi(v);

@@ -62,6 +62,11 @@ int htkamd_host_free(void *hptr);
 int htkamd_memcpy_h2d_async(void *dDst, const void *hSrc, size_t bytes, void *stream);
 int htkamd_memcpy_d2h(void *hDst, const void *dSrc, size_t bytes, void *stream);   /* synchronous on return */
 int htkamd_stream_sync(void *stream);
+/* streams for hosts without HIP headers (C drivers of the exchange in parts): a stream of one's own, and "the work queued on `waiter` from
+   here on starts behind what has been queued on `signaller` so far" (an event recorded on the one, waited for by the other; NULL = the default stream) */
+int htkamd_stream_create(void **stream);
+int htkamd_stream_destroy(void *stream);
+int htkamd_stream_wait(void *waiter, void *signaller);
 
 /* ------------------------------------------------------------------------------------------
  * Packed HMM set.  Flat restatement of HMMSet / HMMDef / StateInfo / StreamElem / MixPDF

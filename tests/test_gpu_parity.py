@@ -320,13 +320,18 @@ def test_pass_in_two_phases_and_exchange_ranges(native, oracle, monkeypatch):
     hl = herest.layout_from_packed(pk)
     for i, (s0, s1) in enumerate(cuts):
         assert herest.state_ranges(pk, hl, s0, s1, with_rest=(i == 2)) == acc.state_ranges(s0, s1, with_rest=(i == 2))
-    # pack / unpack
+    # pack / unpack, on a stream of the library's making ordered behind the default stream (htkamd_stream_create / _wait: what a C host of the exchange in parts uses)
+    import ctypes as C
+    cs = C.c_void_p()
+    native.check(native.lib().htkamd_stream_create(C.byref(cs)), "stream_create")
+    native.check(native.lib().htkamd_stream_wait(cs, None), "stream_wait")
     v0 = acc.download()["vec"].copy()
     rg = acc.state_ranges(7, 31, with_rest=True)
     n = sum(l for _, l in rg)
     for wire, dt in ((0, np.float64), (1, np.float32)):
         buf = native.DevArray(np.zeros(n, dt))
-        acc.pack_ranges(rg, wire, buf.ptr.value)
+        acc.pack_ranges(rg, wire, buf.ptr.value, stream=cs.value)
+        native.check(native.lib().htkamd_stream_wait(None, cs), "stream_wait")
         flat = buf.to_host(dt, (n,))
         assert np.array_equal(flat, np.concatenate([v0[off:off + ln] for off, ln in rg]).astype(dt))
         acc.zero(None)
@@ -337,6 +342,7 @@ def test_pass_in_two_phases_and_exchange_ranges(native, oracle, monkeypatch):
             want[off:off + ln] = v0[off:off + ln].astype(dt).astype(np.float64)
         assert np.array_equal(v1, want)
         acc.zero(None); acc.upload_add(v0)
+    native.check(native.lib().htkamd_stream_destroy(cs), "stream_destroy")
     with pytest.raises(native.HtkAmdError):
         acc.state_ranges(5, 51)
 
