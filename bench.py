@@ -159,6 +159,23 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256, cpu_utts=2)
             t0 = time.perf_counter()
             res = dec.run(feats, **kw)
             dt = min(dt, time.perf_counter() - t0)
+        # ... and the same decoding with the bf16 x 3 matrix-core scores (tolerance class; HVite's output is held to the exact scores above): how many
+        # utterances come out with the same words and boundaries, what the leg then takes
+        tol_side = None
+        try:
+            res_t = dec.run(feats, scoreMode=capi.SCORE_BF16, **kw)
+            dt_t = 1e30
+            for _ in range(2):
+                t0 = time.perf_counter()
+                res_t = dec.run(feats, scoreMode=capi.SCORE_BF16, **kw)
+                dt_t = min(dt_t, time.perf_counter() - t0)
+            sc_t, tok_t = dec.last_times()
+            same = sum(1 for (wa, _), (wb, _) in zip(res, res_t) if (wa is None) == (wb is None) and (wa is None or [x[:3] for x in wa] == [x[:3] for x in wb]))
+            tol_side = {"arithmetic": "bf16 x 3 matrix-core scores (k_score_bf16w) + K7", "ms": dt_t * 1e3, "utterances_per_sec": len(feats) / dt_t, "score_ms": sc_t, "token_ms": tok_t,
+                        "utterances_with_the_exact_runs_words_and_boundaries": "%d/%d" % (same, len(feats))}
+            res = dec.run(feats, **kw)                      # (the exact run again: what follows reads its times and counts)
+        except capi.HtkAmdError as e:
+            tol_side = {"error": str(e)[:200]}
         hit = tot = 0
         for (w, _), q in zip(res, s.seqs[:n_decode]):
             rec = [] if w is None else [net.out_syms[p_] for p_, _, _, _ in w]
@@ -178,7 +195,7 @@ def other_paths(s, pk, dX, frame_off_all, n_align=256, n_decode=256, cpu_utts=2)
         out["hvite_decoding"] = {"utterances": len(feats), "ms": dt * 1e3, "utterances_per_sec": len(feats) / dt, "frames_per_sec": frames_ / dt,
                                  "network": "back-off bigram over %d one-model words (%d arcs, fan-in %d at the back-off node), -t 250 -s 5 -p -10 (BASELINE config[3])" % (V, n_arcs, V),
                                  "words_correct": "%d/%d" % (hit, tot),
-                                 "arithmetic": "exact (K1 dense + K7)", "exact_order_utterances": dec.last_tied(),
+                                 "arithmetic": "exact (K1 dense + K7)", "exact_order_utterances": dec.last_tied(), "tolerance_class_scores": tol_side,
                                  "model_instance_steps": dict(zip(("live", "dead"), dec.last_live())),
                                  "roofline": {"kernel": "k_decode (token passing)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                               "ms": tok_ms, "bytes_per_unit": 4.0 * S_ + 16.0 * V, "unit_is": "(utterance, frame)", "units_per_launch": frames_,

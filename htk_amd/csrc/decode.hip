@@ -1095,7 +1095,8 @@ extern "C" int htkamd_decoder_run_out(htkamd_decoder *d, const htkamd_decode_con
    htkamd_model *m = d->m;
    const DecNet &N = d->net;
    const int ns = (int)d->usedStates.size();
-   const int FR = SCORE_TILE_FRAMES, SL = SCORE_TASK_SLOTS;
+   // (the matrix-core kernels build their frames' operand once per task: four times as many states per task for them, as in forward-backward)
+   const int FR = SCORE_TILE_FRAMES, SL = (cfg->scoreMode & (HTKAMD_SCORE_BF16 | HTKAMD_SCORE_MFMA)) ? SCORE_TASK_SLOTS_WIDE : SCORE_TASK_SLOTS;
    if (!d->ev[0]) for (int i = 0; i < 4; i++) HIPCHECK(hipEventCreate(&d->ev[i]));
    d->lastScoreMs = d->lastTokenMs = 0.0f;
    d->lastLive[0] = d->lastLive[1] = 0;

@@ -13,3 +13,4 @@ dX = torch.from_numpy(X).cuda()
 out = bench.other_paths(s, pk, dX, fo, n_align=8, n_decode=n, cpu_utts=0)
 d = out["hvite_decoding"]
 print(json.dumps({k: d[k] for k in ("utterances", "ms", "words_correct", "exact_order_utterances", "model_instance_steps")}), d["roofline"]["ms"], d["score_roofline"]["ms"])
+print("tolerance-class scores:", json.dumps(d.get("tolerance_class_scores")))
