@@ -420,6 +420,7 @@ extern "C" int htkamd_fb_prepare(htkamd_fb *fb, const htkamd_batch_desc *b, void
    auto lap = [&](const char *what) { if (!timing) return; auto t = std::chrono::steady_clock::now();
       fprintf(stderr, "  prepare %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp0).count()); tp0 = t; };
    fb->nUtt = U; fb->dX = b->dX; fb->topoVersion = fb->m->topoVersion;
+   fb->mixDeferred = false;                              // (statistics left waiting by htkamd_fb_execute_begin belong to the batch before)
    fb->utt.assign(U, UttDesc());
    fb->totalFrames = U ? b->frameOff[U] : 0;
    // (filled only when the batch's size changes: the workers write every frame of every utterance that a kernel will look at -- utterances that
