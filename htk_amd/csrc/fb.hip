@@ -839,6 +839,10 @@ static int fb_execute_impl(htkamd_fb *fb, const htkamd_fb_config *cfg, htkamd_ac
          HIPCHECK(hipMemsetAsync(fa.stCnt, 0, sizeof(int) * (3 * (size_t)m->S + 4), s));  /* counts; pairs turned away (+3 spare); then per state: pairs, triples */
       }
    }
+   {  // diagnostic (tools/r06_hosttrace.sh): n more tiny fills in the pass -- what ONE more dispatch costs an iteration on the box at hand
+      static const int extra = [] { const char *e = getenv("HTKAMD_EXTRA_FILLS"); return e ? atoi(e) : 0; }();
+      for (int i = 0; i < extra; i++) HIPCHECK(hipMemsetAsync(fb->d_counter.p, 0, 4, s));
+   }
    static const int clsW[4] = {1, 2, 4, 8};
    // the longest chains first: their recursions are the critical path of the pass
    for (int pass = 0; pass < 2; pass++) {

@@ -7,3 +7,4 @@ grep "host it" gpurun_out/hosttrace.err | tail -30 | awk '{a+=$4; b+=$5; c+=$6; 
 grep "prepare workers" gpurun_out/hosttrace.err | tail -20 | awk '{a+=$3; n++} END {printf "prepare workers %.3f ms\n", a/n}'
 grep "prepare stage" gpurun_out/hosttrace.err | tail -20 | awk '{a+=$3; n++} END {printf "prepare stage+copy %.3f ms\n", a/n}'
 python3 -c "import json; d=json.loads(open('gpurun_out/hosttrace.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'], d['kernel_ms'])"
+for n in 0 8 0 8; do HTKAMD_EXTRA_FILLS=$n python3 bench.py --cpu-seconds 0 --extras 0 --also-fastest 0 --steps 100 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('extra fills $n: ms_per_step', round(d['ms_per_step'],4))"; done
